@@ -1,0 +1,77 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY.  CPU restatement of the jolt-atlas
+ * ONNXProof::prove hot path (sumcheck rounds, EQ tables, lookup evaluation loops,
+ * HyperKZG MSMs).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load liboracle.so.  PARITY UNPINNED against a reference run — see
+ * bn254.h for what pins it instead. */
+#ifndef ORACLE_H
+#define ORACLE_H
+#include "bn254.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- BLAKE2b-256 + Blake2bTranscript (joltworks/src/transcripts/blake2b.rs) ---- */
+typedef struct {
+    uint8_t  state[32];
+    uint32_t n_rounds;
+    uint8_t *history;      /* optional state-history recorder (blake2b.rs:17-25) */
+    size_t   history_cap;  /* in 32-byte entries */
+    size_t   history_len;
+} orc_transcript;
+
+void orc_blake2b256(const uint8_t *in, size_t len, uint8_t out[32]);
+void orc_transcript_new(orc_transcript *t, const char *label);
+void orc_transcript_record(orc_transcript *t, uint8_t *buf, size_t cap);
+void orc_transcript_append_message(orc_transcript *t, const char *msg);
+void orc_transcript_append_bytes(orc_transcript *t, const uint8_t *b, size_t n);
+void orc_transcript_append_u64(orc_transcript *t, uint64_t x);
+void orc_transcript_append_scalar(orc_transcript *t, const fr_t *a);
+void orc_transcript_append_scalars(orc_transcript *t, const fr_t *a, size_t n);
+void orc_transcript_challenge_bytes32(orc_transcript *t, uint8_t out[32]);
+u128 orc_transcript_challenge_u128(orc_transcript *t);
+void orc_transcript_challenge_scalar(orc_transcript *t, fr_t *o);
+void orc_transcript_challenge_optimized(orc_transcript *t, u128 *raw, fr_t *o);
+
+/* ---- polynomials (joltworks/src/poly) ---- */
+enum { ORC_HIGH_TO_LOW = 0, ORC_LOW_TO_HIGH = 1 };  /* BindingOrder, multilinear_polynomial.rs:69-73 */
+
+void orc_eq_evals(const fr_t *r, size_t n, const fr_t *scaling, fr_t *out); /* eq_poly.rs:92-101 */
+void orc_bind(fr_t *z, size_t len, const fr_t *r, int order);               /* dense_mlpoly.rs:84-89 */
+void orc_bind_i32(const int32_t *z, size_t len, const fr_t *r, int order, fr_t *out); /* compact_polynomial.rs:272-353 */
+void orc_evaluate(const fr_t *z, size_t n_vars, const fr_t *r, fr_t *out);  /* dense_mlpoly.rs:265-305 */
+void orc_i32_to_fr(const int32_t *z, size_t len, fr_t *out);
+
+/* UniPoly (joltworks/src/poly/unipoly.rs). coeffs buffers hold >= n entries. */
+size_t orc_unipoly_from_evals_and_hint(const fr_t *hint, const fr_t *evals, size_t n_evals, fr_t *coeffs);
+void   orc_unipoly_eval(const fr_t *coeffs, size_t n, const fr_t *x, fr_t *out);
+size_t orc_unipoly_compress(const fr_t *coeffs, size_t n, fr_t *out);
+void   orc_compressed_eval_from_hint(const fr_t *cc, size_t n, const fr_t *hint, const fr_t *x, fr_t *out);
+void   orc_transcript_append_compressed(orc_transcript *t, const fr_t *cc, size_t n);
+
+/* ---- sumcheck (joltworks/src/subprotocols/sumcheck.rs:565-599) with the einsum
+ * dot-product instance (jolt-atlas-core/src/onnx_proof/ops/einsum/dot.rs:290-375).
+ * schedule: 0 none (deg 2), 1 High{a=log_eq,b=low_bits}, 2 Low{a=log_k,b=log_b}.
+ * left/right/eq are consumed (bound in place).  proof_coeffs receives, per round,
+ * `degree` compressed coefficients (c0, c2[, c3]); challenges the raw u128 draws.
+ * final_claims = left(r), right(r), eq(r)|1.  Returns 0 on success. */
+int orc_sumcheck_dot_prove(fr_t *left, fr_t *right, fr_t *eq, size_t n_vars, int schedule,
+                           size_t sched_a, size_t sched_b, const fr_t *input_claim,
+                           orc_transcript *t, fr_t *proof_coeffs, u128 *challenges,
+                           fr_t *final_claims);
+/* same instance but operands given as i32 (CompactPolynomial first round) */
+int orc_sumcheck_dot_prove_i32(const int32_t *left, const int32_t *right, size_t n_vars,
+                               const fr_t *input_claim, orc_transcript *t, fr_t *proof_coeffs,
+                               u128 *challenges, fr_t *final_claims);
+/* SumcheckInstanceProof::verify (sumcheck.rs:653-686): returns 0 ok, fills e and r. */
+int orc_sumcheck_verify(const fr_t *proof_coeffs, size_t n_rounds, size_t degree,
+                        const fr_t *claim, orc_transcript *t, fr_t *e_out, u128 *challenges);
+
+void orc_dot_claim(const fr_t *l, const fr_t *r, const fr_t *eq, size_t len, int schedule,
+                   size_t sched_a, size_t sched_b, fr_t *out);
+int  orc_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

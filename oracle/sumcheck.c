@@ -1,0 +1,297 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY (see bn254.h header note; parity unpinned).
+ * CPU restatement of the sumcheck hot loop.  Reference (under /root/reference):
+ *   joltworks/src/poly/eq_poly.rs:149-167,225-252          EQ tables
+ *   joltworks/src/poly/dense_mlpoly.rs:84-141,209-305      bind / evaluate
+ *   joltworks/src/poly/compact_polynomial.rs:272-353       small-scalar first bind
+ *   joltworks/src/poly/multilinear_polynomial.rs:873-905   sumcheck_evals
+ *   joltworks/src/poly/unipoly.rs:55-133,219-245,307-318,502-558
+ *   joltworks/src/subprotocols/sumcheck.rs:565-599,653-686 driver / verifier
+ *   jolt-atlas-core/src/onnx_proof/ops/einsum/dot.rs:290-375   dot-product instance
+ * Rayon's chunked map-reduce is mirrored with OpenMP; all reductions are over exact
+ * field elements so the association order cannot change a result. */
+#include "oracle.h"
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------ EQ */
+void orc_eq_evals(const fr_t *r, size_t n, const fr_t *scaling, fr_t *out) {
+    /* evals_parallel (eq_poly.rs:225-252): iterate r reversed, doubling; r[0] = MSB */
+    if (scaling) out[0] = *scaling; else fr_one(&out[0]);
+    size_t size = 1;
+    for (size_t k = n; k-- > 0;) {
+        const fr_t rk = r[k];
+#pragma omp parallel for schedule(static) if (size >= 4096)
+        for (size_t i = 0; i < size; i++) {
+            fr_t y; fr_mul(&out[i], &rk, &y);
+            out[i + size] = y;
+            fr_sub(&out[i], &y, &out[i]);
+        }
+        size *= 2;
+    }
+}
+
+/* ------------------------------------------------------------------ bind */
+void orc_bind(fr_t *z, size_t len, const fr_t *r, int order) {
+    size_t n = len / 2;
+    if (order == ORC_HIGH_TO_LOW) {
+        /* bound_poly_var_top (dense_mlpoly.rs:91-101): a += r*(b-a) in place */
+#pragma omp parallel for schedule(static) if (n >= 4096)
+        for (size_t i = 0; i < n; i++) {
+            fr_t m; fr_sub(&z[i + n], &z[i], &m);
+            fr_mul(&m, r, &m);
+            fr_add(&z[i], &m, &z[i]);
+        }
+    } else {
+        /* bound_poly_var_bot_01_optimized (dense_mlpoly.rs:219-239) writes a new
+         * vector; in place is safe serially, so compute into scratch when parallel. */
+        fr_t *tmp = (fr_t *)malloc(n * sizeof(fr_t));
+#pragma omp parallel for schedule(static) if (n >= 512)
+        for (size_t i = 0; i < n; i++) {
+            fr_t m; fr_sub(&z[2 * i + 1], &z[2 * i], &m);
+            fr_mul(&m, r, &m);
+            fr_add(&z[2 * i], &m, &tmp[i]);
+        }
+        memcpy(z, tmp, n * sizeof(fr_t));
+        free(tmp);
+    }
+}
+
+void orc_i32_to_fr(const int32_t *z, size_t len, fr_t *out) {
+#pragma omp parallel for schedule(static) if (len >= 4096)
+    for (size_t i = 0; i < len; i++) fr_from_i64(z[i], &out[i]);
+}
+
+void orc_bind_i32(const int32_t *z, size_t len, const fr_t *r, int order, fr_t *out) {
+    /* CompactPolynomial::bind_parallel, unbound branch (compact_polynomial.rs:305-350):
+     * a (+|-) r*|b-a| with diff_mul_field = r.mul_u64(abs_diff) (small_scalar.rs:184-186) */
+    size_t n = len / 2;
+#pragma omp parallel for schedule(static) if (n >= 4096)
+    for (size_t i = 0; i < n; i++) {
+        int32_t a = order == ORC_HIGH_TO_LOW ? z[i] : z[2 * i];
+        int32_t b = order == ORC_HIGH_TO_LOW ? z[i + n] : z[2 * i + 1];
+        fr_t fa; fr_from_i64(a, &fa);
+        if (a == b) { out[i] = fa; continue; }
+        uint64_t d = a < b ? (uint64_t)((int64_t)b - a) : (uint64_t)((int64_t)a - b);
+        fr_t fd, m; fr_from_u64(d, &fd); fr_mul(r, &fd, &m);
+        if (a < b) fr_add(&fa, &m, &out[i]); else fr_sub(&fa, &m, &out[i]);
+    }
+}
+
+void orc_evaluate(const fr_t *z, size_t n_vars, const fr_t *r, fr_t *out) {
+    /* DensePolynomial::evaluate (dense_mlpoly.rs:265-305): split-eq double sum */
+    size_t m = n_vars / 2;
+    size_t n1 = (size_t)1 << m, n2 = (size_t)1 << (n_vars - m);
+    fr_t *eq1 = (fr_t *)malloc(n1 * sizeof(fr_t)), *eq2 = (fr_t *)malloc(n2 * sizeof(fr_t));
+    orc_eq_evals(r, m, 0, eq1);          /* r2 = r[..m]  -> eq_one (outer) */
+    orc_eq_evals(r + m, n_vars - m, 0, eq2);
+    fr_t acc; fr_zero(&acc);
+    for (size_t x1 = 0; x1 < n1; x1++) {
+        fr_t part; fr_zero(&part);
+        for (size_t x2 = 0; x2 < n2; x2++) {
+            fr_t t; fr_mul(&eq2[x2], &z[x1 * n2 + x2], &t); fr_add(&part, &t, &part);
+        }
+        fr_mul(&eq1[x1], &part, &part); fr_add(&acc, &part, &acc);
+    }
+    *out = acc; free(eq1); free(eq2);
+}
+
+/* ------------------------------------------------------------------ UniPoly */
+static void fr_small(uint64_t v, fr_t *o) { fr_from_u64(v, o); }
+
+size_t orc_unipoly_from_evals_and_hint(const fr_t *hint, const fr_t *evals, size_t n_evals, fr_t *c) {
+    /* unipoly.rs:91-98 then from_evals_degree2 / degree3 (:66-89): fixed length, no trim */
+    fr_t e0 = evals[0], e1; fr_sub(hint, &e0, &e1);
+    fr_t two, two_inv; fr_small(2, &two); fr_inv(&two, &two_inv);
+    if (n_evals == 2) {
+        fr_t e2 = evals[1], t;
+        c[0] = e0;
+        fr_sub(&e0, &e1, &t); fr_sub(&t, &e1, &t); fr_add(&t, &e2, &t); fr_mul(&t, &two_inv, &c[2]);
+        fr_sub(&e1, &e0, &t); fr_sub(&t, &c[2], &c[1]);
+        return 3;
+    }
+    fr_t e2 = evals[1], e3 = evals[2], t, u, three, six, six_inv;
+    fr_small(3, &three); fr_small(6, &six); fr_inv(&six, &six_inv);
+    c[0] = e0;
+    fr_sub(&e1, &e2, &u); fr_mul(&u, &three, &u);
+    fr_sub(&e3, &e0, &t); fr_add(&t, &u, &t); fr_mul(&t, &six_inv, &c[3]);
+    fr_sub(&e0, &e1, &t); fr_sub(&t, &e1, &t); fr_add(&t, &e2, &t); fr_mul(&t, &two_inv, &t);
+    fr_sub(&t, &c[3], &t); fr_sub(&t, &c[3], &t); fr_sub(&t, &c[3], &c[2]);
+    fr_sub(&e1, &e0, &t); fr_sub(&t, &c[2], &t); fr_sub(&t, &c[3], &c[1]);
+    return 4;
+}
+
+void orc_unipoly_eval(const fr_t *c, size_t n, const fr_t *x, fr_t *out) {
+    /* eval_with_coeffs (unipoly.rs:229-245) */
+    fr_t ev = c[0], pw = *x;
+    for (size_t i = 1; i < n; i++) {
+        fr_t t; fr_mul(&pw, &c[i], &t); fr_add(&ev, &t, &ev);
+        fr_mul(&pw, x, &pw);
+    }
+    *out = ev;
+}
+
+size_t orc_unipoly_compress(const fr_t *c, size_t n, fr_t *out) { /* unipoly.rs:307-318 */
+    if (n < 2) { if (n) out[0] = c[0]; return n; }
+    out[0] = c[0];
+    for (size_t i = 2; i < n; i++) out[i - 1] = c[i];
+    return n - 1;
+}
+
+void orc_compressed_eval_from_hint(const fr_t *cc, size_t n, const fr_t *hint, const fr_t *x, fr_t *out) {
+    /* unipoly.rs:519-533 */
+    fr_t lin; fr_sub(hint, &cc[0], &lin); fr_sub(&lin, &cc[0], &lin);
+    for (size_t i = 1; i < n; i++) fr_sub(&lin, &cc[i], &lin);
+    fr_t rp = *x, sum, t;
+    fr_mul(x, &lin, &t); fr_add(&cc[0], &t, &sum);
+    for (size_t i = 1; i < n; i++) {
+        fr_mul(&rp, x, &rp);
+        fr_mul(&cc[i], &rp, &t); fr_add(&sum, &t, &sum);
+    }
+    *out = sum;
+}
+
+void orc_transcript_append_compressed(orc_transcript *t, const fr_t *cc, size_t n) { /* unipoly.rs:550-558 */
+    orc_transcript_append_message(t, "UniPoly_begin");
+    for (size_t i = 0; i < n; i++) orc_transcript_append_scalar(t, &cc[i]);
+    orc_transcript_append_message(t, "UniPoly_end");
+}
+
+/* ------------------------------------------------------------------ dot instance */
+static inline void evals3(const fr_t *z, size_t i, size_t half, fr_t e[3], int deg) {
+    /* sumcheck_evals HighToLow: values at 0, 2, 3 */
+    e[0] = z[i];
+    fr_t m, v = z[i + half]; fr_sub(&v, &e[0], &m);
+    for (int k = 1; k < deg; k++) { fr_add(&v, &m, &v); e[k] = v; }
+}
+
+typedef struct { size_t round, half; int schedule; size_t a, b; const fr_t *eq; fr_t eq_bound; size_t eq_len; } dot_ctx;
+
+static void dot_message(const fr_t *L, const fr_t *R, const dot_ctx *cx, fr_t out[3]) {
+    const int deg = cx->schedule == 0 ? 2 : 3;
+    const size_t half = cx->half;
+    int nt = 1;
+#ifdef _OPENMP
+    nt = half >= 2048 ? omp_get_max_threads() : 1;
+#endif
+    fr_t *part = (fr_t *)calloc((size_t)nt * 3, sizeof(fr_t));
+#pragma omp parallel num_threads(nt)
+    {
+        int tid = 0;
+#ifdef _OPENMP
+        tid = omp_get_thread_num();
+#endif
+        fr_t acc[3]; fr_zero(&acc[0]); fr_zero(&acc[1]); fr_zero(&acc[2]);
+#pragma omp for schedule(static)
+        for (size_t i = 0; i < half; i++) {
+            fr_t l[3], r[3], q[3], t;
+            evals3(L, i, half, l, deg); evals3(R, i, half, r, deg);
+            if (cx->schedule == 1) {
+                if (cx->round < cx->a) evals3(cx->eq, i >> cx->b, cx->eq_len / 2, q, 3);
+                else q[0] = q[1] = q[2] = cx->eq_bound;
+            } else if (cx->schedule == 2) {
+                if (cx->round < cx->a) q[0] = q[1] = q[2] = cx->eq[i & (((size_t)1 << cx->b) - 1)];
+                else evals3(cx->eq, i, cx->eq_len / 2, q, 3);
+            }
+            for (int k = 0; k < deg; k++) {
+                fr_mul(&l[k], &r[k], &t);
+                if (cx->schedule) fr_mul(&t, &q[k], &t);
+                fr_add(&acc[k], &t, &acc[k]);
+            }
+        }
+        part[3 * tid] = acc[0]; part[3 * tid + 1] = acc[1]; part[3 * tid + 2] = acc[2];
+    }
+    fr_zero(&out[0]); fr_zero(&out[1]); fr_zero(&out[2]);
+    for (int t = 0; t < nt; t++)
+        for (int k = 0; k < 3; k++) fr_add(&out[k], &part[3 * t + k], &out[k]);
+    free(part);
+}
+
+void orc_dot_claim(const fr_t *l, const fr_t *r, const fr_t *eq, size_t len, int schedule,
+                   size_t a, size_t b, fr_t *out) {
+    fr_t acc; fr_zero(&acc);
+    for (size_t i = 0; i < len; i++) {
+        fr_t t; fr_mul(&l[i], &r[i], &t);
+        if (schedule == 1) fr_mul(&t, &eq[i >> b], &t);
+        if (schedule == 2) fr_mul(&t, &eq[i & (((size_t)1 << b) - 1)], &t);
+        fr_add(&acc, &t, &acc);
+    }
+    (void)a; *out = acc;
+}
+
+int orc_sumcheck_dot_prove(fr_t *left, fr_t *right, fr_t *eq, size_t n_vars, int schedule,
+                           size_t sa, size_t sb, const fr_t *input_claim, orc_transcript *t,
+                           fr_t *proof, u128 *challenges, fr_t *final_claims) {
+    const size_t deg = schedule == 0 ? 2 : 3;
+    size_t len = (size_t)1 << n_vars;
+    dot_ctx cx; memset(&cx, 0, sizeof cx);
+    cx.schedule = schedule; cx.a = sa; cx.b = sb; cx.eq = eq;
+    cx.eq_len = schedule == 1 ? ((size_t)1 << sa) : schedule == 2 ? ((size_t)1 << sb) : 0;
+    if (schedule == 1 && sa == 0) cx.eq_bound = eq[0];
+    orc_transcript_append_scalar(t, input_claim);            /* sumcheck.rs:573-574 */
+    fr_t prev = *input_claim;
+    for (size_t rnd = 0; rnd < n_vars; rnd++) {
+        fr_t ev[3], coeffs[4], cc[3], r;
+        cx.round = rnd; cx.half = len / 2;
+        dot_message(left, right, &cx, ev);                   /* dot.rs:290-350 */
+        size_t nc = orc_unipoly_from_evals_and_hint(&prev, ev, deg, coeffs);
+        size_t ncc = orc_unipoly_compress(coeffs, nc, cc);   /* sumcheck.rs:581 */
+        orc_transcript_append_compressed(t, cc, ncc);
+        u128 raw; orc_transcript_challenge_optimized(t, &raw, &r);  /* :583 */
+        challenges[rnd] = raw;
+        orc_unipoly_eval(coeffs, nc, &r, &prev);             /* :587 */
+        orc_bind(left, len, &r, ORC_HIGH_TO_LOW);            /* dot.rs:352-375 */
+        orc_bind(right, len, &r, ORC_HIGH_TO_LOW);
+        if (schedule == 1 && rnd < sa) {
+            orc_bind(eq, cx.eq_len, &r, ORC_HIGH_TO_LOW); cx.eq_len /= 2;
+            if (rnd == sa - 1) cx.eq_bound = eq[0];
+        } else if (schedule == 2 && rnd >= sa) {
+            orc_bind(eq, cx.eq_len, &r, ORC_HIGH_TO_LOW); cx.eq_len /= 2;
+        }
+        len /= 2;
+        for (size_t k = 0; k < ncc; k++) proof[rnd * deg + k] = cc[k];
+    }
+    final_claims[0] = left[0]; final_claims[1] = right[0];
+    if (schedule == 1) final_claims[2] = cx.eq_bound;
+    else if (schedule == 2) final_claims[2] = eq[0];
+    else fr_one(&final_claims[2]);
+    return 0;
+}
+
+int orc_sumcheck_dot_prove_i32(const int32_t *left, const int32_t *right, size_t n_vars,
+                               const fr_t *input_claim, orc_transcript *t, fr_t *proof,
+                               u128 *challenges, fr_t *final_claims) {
+    /* I32Scalars operands: sumcheck_evals go through get_bound_coeff -> to_field
+     * (multilinear_polynomial.rs:242-319), first bind is CompactPolynomial's. Values are
+     * those of the dense instance on the converted operands. */
+    size_t len = (size_t)1 << n_vars;
+    fr_t *L = (fr_t *)malloc(len * sizeof(fr_t)), *R = (fr_t *)malloc(len * sizeof(fr_t));
+    orc_i32_to_fr(left, len, L); orc_i32_to_fr(right, len, R);
+    int rc = orc_sumcheck_dot_prove(L, R, 0, n_vars, 0, 0, 0, input_claim, t, proof, challenges, final_claims);
+    free(L); free(R);
+    return rc;
+}
+
+int orc_sumcheck_verify(const fr_t *proof, size_t n_rounds, size_t degree, const fr_t *claim,
+                        orc_transcript *t, fr_t *e_out, u128 *challenges) {
+    fr_t e = *claim;
+    for (size_t i = 0; i < n_rounds; i++) {
+        const fr_t *cc = &proof[i * degree];
+        orc_transcript_append_compressed(t, cc, degree);
+        fr_t r; u128 raw; orc_transcript_challenge_optimized(t, &raw, &r);
+        if (challenges) challenges[i] = raw;
+        orc_compressed_eval_from_hint(cc, degree, &e, &r, &e);
+    }
+    *e_out = e;
+    return 0;
+}
