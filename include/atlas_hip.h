@@ -1,0 +1,134 @@
+/* atlas_hip.h — C-ABI of libatlas_hip.so, the MI355X (gfx950) backend for the
+ * jolt-atlas `ONNXProof::prove` hot path.
+ *
+ * Every entry point is what a Rust `extern "C"` block on the reference side would bind
+ * (see INTEGRATION.md); each one cites the reference interface it replaces, as
+ * path:line under the jolt-atlas tree.  Plain pointers and sizes only.  All functions
+ * return 0 on success and a negative ATLAS_E* code on failure (the Rust shim maps
+ * non-zero to the panic / ProofVerifyError::InternalError the reference raises today,
+ * joltworks/src/poly/commitment/hyperkzg/commitment_scheme.rs:58-63,118).  No function
+ * falls back to the CPU: without a usable HIP device every call fails with
+ * ATLAS_ENODEV.
+ *
+ * Value types are the reference's memory images:
+ *   atlas_fr_t   = ark_bn254::Fr   : 4 x u64 LE limbs of the Montgomery residue
+ *                                    (joltworks/src/field/ark.rs:16-29)
+ *   atlas_u128_t = the u128 drawn by Transcript::challenge_u128; the field value is
+ *                  MontU128Challenge::from(it) (field/challenge/mont_ark_u128.rs:51-62)
+ *   atlas_transcript_t = Blake2bTranscript {state, n_rounds} (transcripts/blake2b.rs:12-16)
+ */
+#ifndef ATLAS_HIP_H
+#define ATLAS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ATLAS_OK        0
+#define ATLAS_ENODEV   (-1)   /* no HIP device / runtime error (see atlas_last_error) */
+#define ATLAS_EINVAL   (-2)   /* bad argument (length not a power of two, null, ...) */
+#define ATLAS_ENOMEM   (-3)
+#define ATLAS_ESTATE   (-4)   /* handle used in the wrong state */
+
+typedef struct { uint64_t l[4]; } atlas_fr_t;
+typedef struct { uint64_t lo, hi; } atlas_u128_t;
+typedef struct { uint8_t state[32]; uint32_t n_rounds; uint32_t pad_[3]; } atlas_transcript_t;
+
+/* BindingOrder (joltworks/src/poly/multilinear_polynomial.rs:69-73) */
+#define ATLAS_HIGH_TO_LOW 0
+#define ATLAS_LOW_TO_HIGH 1
+
+/* EqSchedule (jolt-atlas-core/src/onnx_proof/ops/einsum/dot.rs:70-95) */
+#define ATLAS_EQ_NONE 0   /* degree-2 dot product                       */
+#define ATLAS_EQ_HIGH 1   /* High { log_eq = a, low_bits = b }          */
+#define ATLAS_EQ_LOW  2   /* Low  { log_k  = a, log_b    = b }          */
+
+/* ---- runtime ------------------------------------------------------------------ */
+int  atlas_init(int device_ordinal);            /* hipSetDevice + stream; idempotent */
+int  atlas_shutdown(void);
+const char *atlas_last_error(void);
+int  atlas_device_count(void);
+int  atlas_sync(void);                           /* drain the library stream */
+/* Field value of a challenge: 0 = limbs [0,0,lo,hi] are the Montgomery residue (default,
+ * the `mul_hi_bigint_u128` reading), 1 = canonical integer c<<128. */
+int  atlas_set_challenge_mode(int mode);
+int  atlas_get_challenge_mode(void);
+
+/* ---- transcript (host side; joltworks/src/transcripts/transcript.rs:6-28,
+ *      blake2b.rs:81-238) ---------------------------------------------------------- */
+int atlas_transcript_new(atlas_transcript_t *t, const uint8_t *label, size_t label_len);
+int atlas_transcript_append_message(atlas_transcript_t *t, const uint8_t *msg, size_t len);
+int atlas_transcript_append_bytes(atlas_transcript_t *t, const uint8_t *bytes, size_t len);
+int atlas_transcript_append_u64(atlas_transcript_t *t, uint64_t x);
+int atlas_transcript_append_scalar(atlas_transcript_t *t, const atlas_fr_t *s);
+int atlas_transcript_append_scalars(atlas_transcript_t *t, const atlas_fr_t *s, size_t n);
+int atlas_transcript_challenge_u128(atlas_transcript_t *t, atlas_u128_t *out);
+int atlas_transcript_challenge_scalar(atlas_transcript_t *t, atlas_fr_t *out);
+int atlas_challenge_to_fr(const atlas_u128_t *c, atlas_fr_t *out);  /* Into<Fr> for MontU128Challenge */
+
+/* ---- device polynomials (MultilinearPolynomial<F>, multilinear_polynomial.rs:22-35) -- */
+typedef struct atlas_poly *atlas_poly_t;          /* opaque; owns HBM */
+/* LargeScalars: copy `len` Fr (power of two) host -> HBM */
+int atlas_poly_upload_fr(const atlas_fr_t *host, size_t len, atlas_poly_t *out);
+/* I32Scalars (CompactPolynomial<i32>, compact_polynomial.rs:20-40): 4 B/coeff in HBM,
+ * promoted to Fr by the first bind */
+int atlas_poly_upload_i32(const int32_t *host, size_t len, atlas_poly_t *out);
+/* wrap memory that is already resident (device pointer), no copy, not owned */
+int atlas_poly_wrap_device_fr(void *dptr, size_t len, atlas_poly_t *out);
+int atlas_poly_len(atlas_poly_t p, size_t *len);   /* current (bound) length */
+int atlas_poly_download(atlas_poly_t p, atlas_fr_t *host, size_t cap);  /* current coeffs */
+int atlas_poly_clone(atlas_poly_t p, atlas_poly_t *out);
+int atlas_poly_free(atlas_poly_t p);
+/* PolynomialBinding::bind_parallel (multilinear_polynomial.rs:657-667;
+ * dense_mlpoly.rs:84-89; compact_polynomial.rs:272-353) */
+int atlas_poly_bind(atlas_poly_t p, const atlas_u128_t *r, int order);
+/* PolynomialBinding::final_claim (len must be 1) */
+int atlas_poly_final_claim(atlas_poly_t p, atlas_fr_t *out);
+
+/* ---- sumcheck: EinsumDotProver behind SumcheckInstanceProver
+ *      (joltworks/src/subprotocols/sumcheck_prover.rs:10-68;
+ *       jolt-atlas-core/src/onnx_proof/ops/einsum/dot.rs:255-375) ---------------------- */
+typedef struct atlas_dot_prover *atlas_dot_prover_t;
+/* Takes ownership of left/right/eq (they are consumed by binding, like the reference's
+ * `left`, `right`, `eq` fields).  eq may be NULL iff schedule == ATLAS_EQ_NONE. */
+int atlas_dot_prover_new(atlas_poly_t left, atlas_poly_t right, atlas_poly_t eq, int schedule,
+                         size_t sched_a, size_t sched_b, atlas_dot_prover_t *out);
+int atlas_dot_prover_free(atlas_dot_prover_t p);
+/* compute_message(round, previous_claim) -> UniPoly coefficients c0..c_deg (deg+1 Fr),
+ * dot.rs:290-350 + UniPoly::from_evals_and_hint */
+int atlas_dot_compute_message(atlas_dot_prover_t p, size_t round, const atlas_fr_t *previous_claim,
+                              atlas_fr_t *coeffs_out, size_t *n_coeffs);
+/* ingest_challenge(r_j, round), dot.rs:352-375 */
+int atlas_dot_ingest_challenge(atlas_dot_prover_t p, const atlas_u128_t *r_j, size_t round);
+/* left/right/eq final_claim()s read by cache_openings, dot.rs:377-400 */
+int atlas_dot_final_claims(atlas_dot_prover_t p, atlas_fr_t out[3]);
+
+/* Sumcheck::prove for that instance with the transcript resident on the device
+ * (joltworks/src/subprotocols/sumcheck.rs:565-599): the whole round loop runs as a chain
+ * of launches without a host round-trip.  transcript is read and updated.
+ *   compressed_polys : n_rounds * degree Fr, row i = coeffs_except_linear_term of round i
+ *   challenges       : n_rounds raw u128 draws (r_sumcheck before masking)
+ *   final_claims     : left(r), right(r), eq(r) (or 1)
+ * Consumes the prover's polynomials. */
+int atlas_sumcheck_prove_dot(atlas_dot_prover_t p, const atlas_fr_t *input_claim,
+                             atlas_transcript_t *transcript, atlas_fr_t *compressed_polys,
+                             atlas_u128_t *challenges, atlas_fr_t final_claims[3]);
+
+/* ---- measurement: HIP-event time of the launches issued by the last
+ *      atlas_sumcheck_prove_dot / atlas_msm_* call, on the library stream ------------- */
+typedef struct {
+    double total_ms;          /* first launch -> last launch complete */
+    double pass_ms;           /* sum over the data passes (eval + fused bind/eval) */
+    double fs_ms;             /* sum over transcript (fs) launches + tail */
+    uint64_t pass_bytes;      /* algorithmic bytes moved by the data passes */
+    uint32_t n_pass, n_fs;
+} atlas_timing_t;
+int atlas_set_timing(int enabled);   /* per-launch events; off by default */
+int atlas_last_timing(atlas_timing_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

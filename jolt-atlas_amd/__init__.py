@@ -1,0 +1,257 @@
+"""jolt-atlas_amd — Python plumbing over libatlas_hip.so (the C-ABI in include/atlas_hip.h).
+
+This is test/bench plumbing, not the product: the product is the shared library, which a
+Rust `extern "C"` block binds directly.  The classes mirror the
+reference's names so the parity tests read like the reference's own:
+
+  Blake2bTranscript      joltworks/src/transcripts/blake2b.rs
+  MultilinearPolynomial  joltworks/src/poly/multilinear_polynomial.rs:22-35
+  EinsumDotProver        jolt-atlas-core/src/onnx_proof/ops/einsum/dot.rs:255-375
+  Sumcheck.prove         joltworks/src/subprotocols/sumcheck.rs:565-599
+
+There is no CPU fallback: importing works anywhere (so the symbol table can be checked),
+but every compute call raises AtlasError when the HIP device or the library is missing.
+Fr values are numpy uint64 arrays (..., 4): the ark_bn254::Fr Montgomery limb image.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libatlas_hip.so")
+
+HIGH_TO_LOW, LOW_TO_HIGH = 0, 1
+EQ_NONE, EQ_HIGH, EQ_LOW = 0, 1, 2
+
+
+class AtlasError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise AtlasError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+u64p = C.POINTER(C.c_uint64)
+
+
+class U128(C.Structure):
+    _fields_ = [("lo", C.c_uint64), ("hi", C.c_uint64)]
+
+
+class TranscriptState(C.Structure):
+    _fields_ = [("state", C.c_uint8 * 32), ("n_rounds", C.c_uint32), ("pad_", C.c_uint32 * 3)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("total_ms", C.c_double), ("pass_ms", C.c_double), ("fs_ms", C.c_double),
+                ("pass_bytes", C.c_uint64), ("n_pass", C.c_uint32), ("n_fs", C.c_uint32)]
+
+
+lib.atlas_last_error.restype = C.c_char_p
+for _name in ("atlas_poly_upload_fr", "atlas_poly_upload_i32", "atlas_poly_wrap_device_fr", "atlas_poly_len",
+              "atlas_poly_download", "atlas_poly_clone", "atlas_poly_free", "atlas_poly_bind",
+              "atlas_poly_final_claim", "atlas_dot_prover_new", "atlas_dot_prover_free",
+              "atlas_dot_compute_message", "atlas_dot_ingest_challenge", "atlas_dot_final_claims",
+              "atlas_sumcheck_prove_dot"):
+    getattr(lib, _name).restype = C.c_int
+
+
+def _check(rc):
+    if rc != 0:
+        raise AtlasError(f"atlas error {rc}: {lib.atlas_last_error().decode()}")
+
+
+def _fr(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    assert a.shape[-1] == 4
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(u64p)
+
+
+def init(device=0):
+    _check(lib.atlas_init(C.c_int(device)))
+
+
+def device_count():
+    return lib.atlas_device_count()
+
+
+def set_challenge_mode(mode):
+    _check(lib.atlas_set_challenge_mode(C.c_int(mode)))
+
+
+def set_timing(on):
+    _check(lib.atlas_set_timing(C.c_int(1 if on else 0)))
+
+
+def last_timing():
+    t = Timing()
+    _check(lib.atlas_last_timing(C.byref(t)))
+    return t
+
+
+def sync():
+    _check(lib.atlas_sync())
+
+
+def challenge_to_fr(c128):
+    out = np.zeros(4, dtype=np.uint64)
+    u = U128(c128 & ((1 << 64) - 1), c128 >> 64)
+    _check(lib.atlas_challenge_to_fr(C.byref(u), _p(out)))
+    return out
+
+
+class Blake2bTranscript:
+    """Host-side transcript (Transcript trait, transcripts/transcript.rs:6-28)."""
+
+    def __init__(self, label: bytes):
+        self.t = TranscriptState()
+        _check(lib.atlas_transcript_new(C.byref(self.t), label, C.c_size_t(len(label))))
+
+    @property
+    def state(self):
+        return bytes(self.t.state)
+
+    @property
+    def n_rounds(self):
+        return self.t.n_rounds
+
+    def append_message(self, msg: bytes):
+        _check(lib.atlas_transcript_append_message(C.byref(self.t), msg, C.c_size_t(len(msg))))
+
+    def append_bytes(self, b: bytes):
+        _check(lib.atlas_transcript_append_bytes(C.byref(self.t), b, C.c_size_t(len(b))))
+
+    def append_u64(self, x):
+        _check(lib.atlas_transcript_append_u64(C.byref(self.t), C.c_uint64(x)))
+
+    def append_scalar(self, fr):
+        fr = _fr(fr)
+        _check(lib.atlas_transcript_append_scalar(C.byref(self.t), _p(fr)))
+
+    def append_scalars(self, frs):
+        frs = _fr(frs)
+        _check(lib.atlas_transcript_append_scalars(C.byref(self.t), _p(frs), C.c_size_t(len(frs))))
+
+    def challenge_u128(self):
+        u = U128()
+        _check(lib.atlas_transcript_challenge_u128(C.byref(self.t), C.byref(u)))
+        return u.lo | (u.hi << 64)
+
+    def challenge_scalar(self):
+        out = np.zeros(4, dtype=np.uint64)
+        _check(lib.atlas_transcript_challenge_scalar(C.byref(self.t), _p(out)))
+        return out
+
+
+class MultilinearPolynomial:
+    """Device-resident MLE: LargeScalars (Fr) or I32Scalars."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def from_fr(cls, arr):
+        arr = _fr(arr)
+        h = C.c_void_p()
+        _check(lib.atlas_poly_upload_fr(_p(arr), C.c_size_t(arr.shape[0]), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_i32(cls, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.int32)
+        h = C.c_void_p()
+        _check(lib.atlas_poly_upload_i32(arr.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(arr.shape[0]),
+                                         C.byref(h)))
+        return cls(h)
+
+    def len(self):
+        n = C.c_size_t()
+        _check(lib.atlas_poly_len(self.h, C.byref(n)))
+        return n.value
+
+    def clone(self):
+        h = C.c_void_p()
+        _check(lib.atlas_poly_clone(self.h, C.byref(h)))
+        return MultilinearPolynomial(h)
+
+    def to_host(self):
+        n = self.len()
+        out = np.zeros((n, 4), dtype=np.uint64)
+        _check(lib.atlas_poly_download(self.h, _p(out), C.c_size_t(n)))
+        return out
+
+    def bind_parallel(self, r_u128, order):
+        u = U128(r_u128 & ((1 << 64) - 1), r_u128 >> 64)
+        _check(lib.atlas_poly_bind(self.h, C.byref(u), C.c_int(order)))
+
+    def final_claim(self):
+        out = np.zeros(4, dtype=np.uint64)
+        _check(lib.atlas_poly_final_claim(self.h, _p(out)))
+        return out
+
+    def free(self):
+        if self.h:
+            lib.atlas_poly_free(self.h)
+            self.h = None
+
+
+class EinsumDotProver:
+    """SumcheckInstanceProver for the einsum contraction (dot.rs:255-375)."""
+
+    def __init__(self, left, right, eq=None, schedule=EQ_NONE, a=0, b=0):
+        h = C.c_void_p()
+        _check(lib.atlas_dot_prover_new(left.h, right.h, eq.h if eq is not None else None, C.c_int(schedule),
+                                        C.c_size_t(a), C.c_size_t(b), C.byref(h)))
+        left.h = right.h = None  # ownership moved
+        if eq is not None:
+            eq.h = None
+        self.h = h
+        self.deg = 2 if schedule == EQ_NONE else 3
+
+    def compute_message(self, rnd, previous_claim):
+        out = np.zeros((4, 4), dtype=np.uint64)
+        n = C.c_size_t()
+        pc = _fr(previous_claim)
+        _check(lib.atlas_dot_compute_message(self.h, C.c_size_t(rnd), _p(pc), _p(out), C.byref(n)))
+        return out[:n.value]
+
+    def ingest_challenge(self, r_u128, rnd):
+        u = U128(r_u128 & ((1 << 64) - 1), r_u128 >> 64)
+        _check(lib.atlas_dot_ingest_challenge(self.h, C.byref(u), C.c_size_t(rnd)))
+
+    def final_claims(self):
+        out = np.zeros((3, 4), dtype=np.uint64)
+        _check(lib.atlas_dot_final_claims(self.h, _p(out)))
+        return out
+
+    def free(self):
+        if self.h:
+            lib.atlas_dot_prover_free(self.h)
+            self.h = None
+
+
+class Sumcheck:
+    @staticmethod
+    def prove(prover: EinsumDotProver, input_claim, transcript: Blake2bTranscript, n_rounds):
+        """Sumcheck::prove with the transcript resident on the device.
+        Returns (compressed_polys (n_rounds, deg, 4), challenges [u128], final_claims (3,4))."""
+        deg = prover.deg
+        proof = np.zeros((max(n_rounds, 1) * deg, 4), dtype=np.uint64)
+        ch = np.zeros(2 * max(n_rounds, 1), dtype=np.uint64)
+        fin = np.zeros((3, 4), dtype=np.uint64)
+        ic = _fr(input_claim)
+        _check(lib.atlas_sumcheck_prove_dot(prover.h, _p(ic), C.byref(transcript.t), _p(proof), _p(ch), _p(fin)))
+        chal = [int(ch[2 * i]) | (int(ch[2 * i + 1]) << 64) for i in range(n_rounds)]
+        return proof[:n_rounds * deg].reshape(n_rounds, deg, 4), chal, fin

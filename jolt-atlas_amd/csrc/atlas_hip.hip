@@ -1,0 +1,713 @@
+// libatlas_hip.so — runtime, device polynomials, sumcheck driver and the C-ABI
+// (include/atlas_hip.h).  Host logic mirrors the reference's prover-side interfaces:
+//   SumcheckInstanceProver for EinsumDotProver  jolt-atlas-core/src/onnx_proof/ops/einsum/dot.rs:255-375
+//   Sumcheck::prove                              joltworks/src/subprotocols/sumcheck.rs:565-599
+//   PolynomialBinding                            joltworks/src/poly/multilinear_polynomial.rs:657-667
+// The product path never touches oracle/ and has no CPU fallback: every entry point
+// fails with ATLAS_ENODEV when the HIP device is not usable.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/atlas_hip.h"
+#include "host_field.hpp"
+#include "sumcheck_kernels.hip.h"
+
+using namespace atlas;
+namespace H = atlas_host;
+
+// ------------------------------------------------------------------ runtime state
+namespace {
+
+struct Runtime {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    int challenge_mode = 0;
+    bool timing = false;
+    atlas_timing_t last_timing{};
+    std::string err;
+    Fr* d_partials = nullptr;      // SC_MAX_BLOCKS * 3 Fr
+    ScCtx* d_ctx = nullptr;
+    Fr* d_proof = nullptr;         // up to 64 rounds * 3
+    uint64_t* d_chal = nullptr;    // up to 64 rounds * 2
+    Fr* d_finals = nullptr;        // 3 (+3 scratch for reduced evals)
+    void* h_pinned = nullptr;      // pinned staging for small D2H/H2D
+    std::mutex mu;
+};
+Runtime g;
+
+constexpr size_t MAX_ROUNDS = 64;
+constexpr size_t PINNED_BYTES = 1 << 16;
+
+int fail(int code, const char* what, hipError_t e = hipSuccess) {
+    g.err = what;
+    if (e != hipSuccess) { g.err += ": "; g.err += hipGetErrorString(e); }
+    return code;
+}
+#define HIP_TRY(x)                                                   \
+    do {                                                             \
+        hipError_t e_ = (x);                                         \
+        if (e_ != hipSuccess) return fail(ATLAS_ENODEV, #x, e_);     \
+    } while (0)
+#define NEED_INIT()                                                            \
+    do {                                                                       \
+        if (!g.ready) {                                                        \
+            int rc_ = atlas_init(g.device < 0 ? 0 : g.device);                 \
+            if (rc_) return rc_;                                               \
+        }                                                                      \
+    } while (0)
+
+ScConsts make_consts() {
+    ScConsts K;
+    const uint32_t two_inv[8] = {0x1ffffffeu, 0x783c14d8u, 0x0c8d1eddu, 0xaf982f6fu,
+                                 0xfcfd4f45u, 0x8f5f7492u, 0x3d9cbfacu, 0x1f37631au};
+    const uint32_t six_inv[8] = {0x0aaaaaaau, 0x7d695c48u, 0xaed9b4f4u, 0x3a880fcfu,
+                                 0xa9a9c517u, 0xda7526dbu, 0x69deea8eu, 0x0a67cbb3u};
+    const uint32_t k32[8] = {0x15b8b9dau, 0x93e78865u, 0xb05ea154u, 0x16df2426u,
+                             0x302ab839u, 0x1271b743u, 0xec6c226eu, 0x06bc037eu};
+    const uint32_t k64[8] = {0x7c5fb586u, 0xb4c6edf9u, 0xbfeb93beu, 0x708c8d50u,
+                             0x04f7e0efu, 0x9ffd1de4u, 0x9a392866u, 0x215b02acu};
+    for (int i = 0; i < 8; i++) {
+        K.two_inv.v[i] = two_inv[i]; K.six_inv.v[i] = six_inv[i];
+        K.k32.v[i] = k32[i]; K.k64.v[i] = k64[i];
+    }
+    const uint64_t b[4] = {0x5f796c6f50696e55ULL, 0x0000006e69676562ULL, 0, 0};  // "UniPoly_begin"
+    const uint64_t e[4] = {0x5f796c6f50696e55ULL, 0x0000000000646e65ULL, 0, 0};  // "UniPoly_end"
+    for (int i = 0; i < 4; i++) { K.lbl_begin[i] = b[i]; K.lbl_end[i] = e[i]; }
+    return K;
+}
+
+inline int grid_for(size_t work) {
+    size_t b = (work + SC_THREADS - 1) / SC_THREADS;
+    if (b < 1) b = 1;
+    if (b > (size_t)SC_MAX_BLOCKS) b = SC_MAX_BLOCKS;
+    return (int)b;
+}
+
+inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
+inline unsigned ilog2(size_t x) { unsigned n = 0; while (x > 1) { x >>= 1; n++; } return n; }
+
+// ---- timing: hip events on the library stream around each launch --------------------
+struct Timer {
+    std::vector<hipEvent_t> ev;     // pairs (start, stop)
+    std::vector<int> kind;          // 0 = data pass, 1 = fs/tail
+    std::vector<uint64_t> bytes;
+    void begin(int k, uint64_t b) {
+        if (!g.timing) return;
+        hipEvent_t a, c; hipEventCreate(&a); hipEventCreate(&c);
+        hipEventRecord(a, g.stream); ev.push_back(a); ev.push_back(c); kind.push_back(k); bytes.push_back(b);
+    }
+    void end() { if (g.timing) hipEventRecord(ev.back(), g.stream); }
+    void collect() {
+        atlas_timing_t t{};
+        if (g.timing && !ev.empty()) {
+            hipEventSynchronize(ev.back());
+            float ms = 0;
+            for (size_t i = 0; i < kind.size(); i++) {
+                hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+                if (kind[i] == 0) { t.pass_ms += ms; t.pass_bytes += bytes[i]; t.n_pass++; }
+                else { t.fs_ms += ms; t.n_fs++; }
+            }
+            hipEventElapsedTime(&ms, ev.front(), ev.back());
+            t.total_ms = ms;
+            for (auto e : ev) hipEventDestroy(e);
+        }
+        g.last_timing = t;
+        ev.clear(); kind.clear(); bytes.clear();
+    }
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------ handles
+struct atlas_poly {
+    void* d = nullptr;       // current coefficients: Fr if !is_i32, int32 if is_i32
+    size_t len = 0;          // current length
+    size_t cap_bytes = 0;
+    bool is_i32 = false;
+    bool owned = true;
+};
+
+struct atlas_dot_prover {
+    atlas_poly_t left = nullptr, right = nullptr, eq = nullptr;
+    int schedule = 0;
+    size_t a = 0, b = 0;
+    size_t n_rounds = 0;
+    bool consumed = false;
+};
+
+// ------------------------------------------------------------------ runtime API
+extern "C" {
+
+int atlas_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int atlas_init(int device_ordinal) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (g.ready && g.device == device_ordinal) return ATLAS_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return fail(ATLAS_ENODEV, "no HIP device available", e);
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(ATLAS_EINVAL, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device_ordinal));
+    if (!g.stream) HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(&g.d_partials, sizeof(Fr) * SC_MAX_BLOCKS * 3));
+    HIP_TRY(hipMalloc(&g.d_ctx, sizeof(ScCtx)));
+    HIP_TRY(hipMalloc(&g.d_proof, sizeof(Fr) * MAX_ROUNDS * 3));
+    HIP_TRY(hipMalloc(&g.d_chal, sizeof(uint64_t) * MAX_ROUNDS * 2));
+    HIP_TRY(hipMalloc(&g.d_finals, sizeof(Fr) * 8));
+    HIP_TRY(hipHostMalloc(&g.h_pinned, PINNED_BYTES, hipHostMallocDefault));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dot_tail<2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (sizeof(Fr) << SC_TAIL_LOG)));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dot_tail<3>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (sizeof(Fr) << SC_TAIL_LOG)));
+    g.device = device_ordinal;
+    g.ready = true;
+    return ATLAS_OK;
+}
+
+int atlas_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!g.ready) return ATLAS_OK;
+    hipStreamSynchronize(g.stream);
+    hipFree(g.d_partials); hipFree(g.d_ctx); hipFree(g.d_proof); hipFree(g.d_chal); hipFree(g.d_finals);
+    hipHostFree(g.h_pinned);
+    hipStreamDestroy(g.stream);
+    g.ready = false; g.stream = nullptr; g.d_partials = nullptr; g.d_ctx = nullptr; g.d_proof = nullptr;
+    g.d_chal = nullptr; g.d_finals = nullptr; g.h_pinned = nullptr;
+    return ATLAS_OK;
+}
+
+const char* atlas_last_error(void) { return g.err.c_str(); }
+
+int atlas_sync(void) {
+    NEED_INIT();
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return ATLAS_OK;
+}
+
+int atlas_set_challenge_mode(int mode) {
+    if (mode != 0 && mode != 1) return fail(ATLAS_EINVAL, "challenge mode must be 0 or 1");
+    g.challenge_mode = mode;
+    return ATLAS_OK;
+}
+int atlas_get_challenge_mode(void) { return g.challenge_mode; }
+
+int atlas_set_timing(int enabled) { g.timing = enabled != 0; return ATLAS_OK; }
+int atlas_last_timing(atlas_timing_t* out) {
+    if (!out) return fail(ATLAS_EINVAL, "null out");
+    *out = g.last_timing;
+    return ATLAS_OK;
+}
+
+// ------------------------------------------------------------------ transcript API
+static_assert(sizeof(atlas_transcript_t) == sizeof(H::Transcript), "transcript image");
+static_assert(sizeof(atlas_transcript_t) == sizeof(DevTranscript), "transcript image (device)");
+static_assert(sizeof(atlas_fr_t) == sizeof(Fr), "Fr image");
+
+int atlas_transcript_new(atlas_transcript_t* t, const uint8_t* label, size_t n) {
+    if (!t || !label || n > 32) return fail(ATLAS_EINVAL, "transcript_new: label must be <= 32 bytes");
+    H::tr_new(*reinterpret_cast<H::Transcript*>(t), label, n);
+    return ATLAS_OK;
+}
+int atlas_transcript_append_message(atlas_transcript_t* t, const uint8_t* msg, size_t n) {
+    if (!t || !msg || n > 32) return fail(ATLAS_EINVAL, "append_message: msg must be <= 32 bytes");
+    H::tr_append_message(*reinterpret_cast<H::Transcript*>(t), msg, n);
+    return ATLAS_OK;
+}
+int atlas_transcript_append_bytes(atlas_transcript_t* t, const uint8_t* b, size_t n) {
+    if (!t || (!b && n)) return fail(ATLAS_EINVAL, "append_bytes");
+    H::tr_append_bytes(*reinterpret_cast<H::Transcript*>(t), b, n);
+    return ATLAS_OK;
+}
+int atlas_transcript_append_u64(atlas_transcript_t* t, uint64_t x) {
+    if (!t) return fail(ATLAS_EINVAL, "append_u64");
+    H::tr_append_u64(*reinterpret_cast<H::Transcript*>(t), x);
+    return ATLAS_OK;
+}
+int atlas_transcript_append_scalar(atlas_transcript_t* t, const atlas_fr_t* s) {
+    if (!t || !s) return fail(ATLAS_EINVAL, "append_scalar");
+    H::tr_append_scalar(*reinterpret_cast<H::Transcript*>(t), *reinterpret_cast<const H::Fr*>(s));
+    return ATLAS_OK;
+}
+int atlas_transcript_append_scalars(atlas_transcript_t* t, const atlas_fr_t* s, size_t n) {
+    if (!t || (!s && n)) return fail(ATLAS_EINVAL, "append_scalars");
+    H::tr_append_scalars(*reinterpret_cast<H::Transcript*>(t), reinterpret_cast<const H::Fr*>(s), n);
+    return ATLAS_OK;
+}
+int atlas_transcript_challenge_u128(atlas_transcript_t* t, atlas_u128_t* out) {
+    if (!t || !out) return fail(ATLAS_EINVAL, "challenge_u128");
+    H::tr_challenge_u128(*reinterpret_cast<H::Transcript*>(t), out->lo, out->hi);
+    return ATLAS_OK;
+}
+int atlas_transcript_challenge_scalar(atlas_transcript_t* t, atlas_fr_t* out) {
+    if (!t || !out) return fail(ATLAS_EINVAL, "challenge_scalar");
+    H::Fr f = H::tr_challenge_scalar(*reinterpret_cast<H::Transcript*>(t));
+    std::memcpy(out, &f, 32);
+    return ATLAS_OK;
+}
+int atlas_challenge_to_fr(const atlas_u128_t* c, atlas_fr_t* out) {
+    if (!c || !out) return fail(ATLAS_EINVAL, "challenge_to_fr");
+    H::Fr f = H::challenge_to_fr(c->lo, c->hi, g.challenge_mode);
+    std::memcpy(out, &f, 32);
+    return ATLAS_OK;
+}
+
+// ------------------------------------------------------------------ polynomial API
+static int poly_alloc(size_t bytes, bool is_i32, size_t len, atlas_poly_t* out) {
+    atlas_poly* p = new atlas_poly();
+    hipError_t e = hipMalloc(&p->d, bytes ? bytes : 32);
+    if (e != hipSuccess) { delete p; return fail(ATLAS_ENOMEM, "hipMalloc(poly)", e); }
+    p->len = len; p->cap_bytes = bytes; p->is_i32 = is_i32; p->owned = true;
+    *out = p;
+    return ATLAS_OK;
+}
+
+int atlas_poly_upload_fr(const atlas_fr_t* host, size_t len, atlas_poly_t* out) {
+    NEED_INIT();
+    if (!host || !out || !is_pow2(len)) return fail(ATLAS_EINVAL, "poly_upload_fr: len must be a power of two");
+    int rc = poly_alloc(len * sizeof(Fr), false, len, out);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync((*out)->d, host, len * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return ATLAS_OK;
+}
+
+int atlas_poly_upload_i32(const int32_t* host, size_t len, atlas_poly_t* out) {
+    NEED_INIT();
+    if (!host || !out || !is_pow2(len)) return fail(ATLAS_EINVAL, "poly_upload_i32: len must be a power of two");
+    int rc = poly_alloc(len * sizeof(int32_t), true, len, out);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync((*out)->d, host, len * sizeof(int32_t), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return ATLAS_OK;
+}
+
+int atlas_poly_wrap_device_fr(void* dptr, size_t len, atlas_poly_t* out) {
+    NEED_INIT();
+    if (!dptr || !out || !is_pow2(len)) return fail(ATLAS_EINVAL, "poly_wrap_device_fr");
+    atlas_poly* p = new atlas_poly();
+    p->d = dptr; p->len = len; p->cap_bytes = len * sizeof(Fr); p->is_i32 = false; p->owned = false;
+    *out = p;
+    return ATLAS_OK;
+}
+
+int atlas_poly_len(atlas_poly_t p, size_t* len) {
+    if (!p || !len) return fail(ATLAS_EINVAL, "poly_len");
+    *len = p->len;
+    return ATLAS_OK;
+}
+
+// i32 -> Fr promotion without binding (to_field over the whole vector)
+__global__ __launch_bounds__(SC_THREADS) void k_i32_to_fr(const int32_t* in, Fr* out, size_t n, ScConsts K) {
+    for (size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * SC_THREADS)
+        fe_store(out + i, fr_from_i32(in[i], K.k32));
+}
+
+int atlas_poly_download(atlas_poly_t p, atlas_fr_t* host, size_t cap) {
+    NEED_INIT();
+    if (!p || !host || cap < p->len) return fail(ATLAS_EINVAL, "poly_download: buffer too small");
+    if (p->is_i32) {
+        Fr* tmp = nullptr;
+        HIP_TRY(hipMalloc(&tmp, p->len * sizeof(Fr)));
+        k_i32_to_fr<<<grid_for(p->len), SC_THREADS, 0, g.stream>>>((const int32_t*)p->d, tmp, p->len, make_consts());
+        hipError_t e = hipMemcpyAsync(host, tmp, p->len * sizeof(Fr), hipMemcpyDeviceToHost, g.stream);
+        hipStreamSynchronize(g.stream);
+        hipFree(tmp);
+        if (e != hipSuccess) return fail(ATLAS_ENODEV, "poly_download", e);
+        return ATLAS_OK;
+    }
+    HIP_TRY(hipMemcpyAsync(host, p->d, p->len * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return ATLAS_OK;
+}
+
+int atlas_poly_clone(atlas_poly_t p, atlas_poly_t* out) {
+    NEED_INIT();
+    if (!p || !out) return fail(ATLAS_EINVAL, "poly_clone");
+    size_t bytes = p->len * (p->is_i32 ? sizeof(int32_t) : sizeof(Fr));
+    int rc = poly_alloc(bytes, p->is_i32, p->len, out);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync((*out)->d, p->d, bytes, hipMemcpyDeviceToDevice, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return ATLAS_OK;
+}
+
+int atlas_poly_free(atlas_poly_t p) {
+    if (!p) return ATLAS_OK;
+    if (p->owned && p->d) hipFree(p->d);
+    delete p;
+    return ATLAS_OK;
+}
+
+// first bind of an I32Scalars polynomial into a fresh Fr buffer (either order)
+__global__ __launch_bounds__(SC_THREADS) void k_bind_i32(const int32_t* z, Fr* out, size_t half, int order,
+                                                         Fr r_s64, ScConsts K) {
+    for (size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x; i < half; i += (size_t)gridDim.x * SC_THREADS) {
+        int32_t a = order == ATLAS_HIGH_TO_LOW ? z[i] : z[2 * i];
+        int32_t b = order == ATLAS_HIGH_TO_LOW ? z[i + half] : z[2 * i + 1];
+        fe_store(out + i, bind_pair_i32(a, b, nullptr, K, r_s64));
+    }
+}
+
+__global__ __launch_bounds__(SC_THREADS) void k_bind_hi_val(Fr* z, size_t half, Fr r, int r_hi_only) {
+    for (size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x; i < half; i += (size_t)gridDim.x * SC_THREADS) {
+        Fr a = fe_load(z + i), b = fe_load(z + i + half);
+        fe_store(z + i, bind_pair(a, b, r, r_hi_only != 0));
+    }
+}
+
+__global__ __launch_bounds__(SC_THREADS) void k_bind_lo_val(const Fr* z, Fr* out, size_t half, Fr r, int r_hi_only) {
+    for (size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x; i < half; i += (size_t)gridDim.x * SC_THREADS) {
+        Fr a = fe_load(z + 2 * i), b = fe_load(z + 2 * i + 1);
+        fe_store(out + i, bind_pair(a, b, r, r_hi_only != 0));
+    }
+}
+
+static Fr host_to_dev(const H::Fr& f) { Fr o; std::memcpy(o.v, f.l, 32); return o; }
+
+// bind on the library stream, no sync
+static int poly_bind_async(atlas_poly* p, const atlas_u128_t* rc128, int order) {
+    if (p->len < 2) return fail(ATLAS_ESTATE, "bind: polynomial is fully bound");
+    const size_t half = p->len / 2;
+    H::Fr rh = H::challenge_to_fr(rc128->lo, rc128->hi, g.challenge_mode);
+    const int hi_only = g.challenge_mode == 0;
+    if (p->is_i32) {
+        static const uint64_t two64[4] = {0, 1, 0, 0};
+        static const H::Fr k64 = H::from_canonical(two64);
+        H::Fr rs = H::mul(rh, k64);
+        Fr* out = nullptr;
+        hipError_t e = hipMalloc(&out, half * sizeof(Fr));
+        if (e != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(bind_i32)", e);
+        k_bind_i32<<<grid_for(half), SC_THREADS, 0, g.stream>>>((const int32_t*)p->d, out, half, order,
+                                                               host_to_dev(rs), make_consts());
+        if (p->owned) { hipStreamSynchronize(g.stream); hipFree(p->d); }
+        p->d = out; p->is_i32 = false; p->owned = true; p->cap_bytes = half * sizeof(Fr);
+    } else if (order == ATLAS_HIGH_TO_LOW) {
+        k_bind_hi_val<<<grid_for(half), SC_THREADS, 0, g.stream>>>((Fr*)p->d, half, host_to_dev(rh), hi_only);
+    } else {
+        Fr* out = nullptr;
+        hipError_t e = hipMalloc(&out, half * sizeof(Fr));
+        if (e != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(bind_lo)", e);
+        k_bind_lo_val<<<grid_for(half), SC_THREADS, 0, g.stream>>>((const Fr*)p->d, out, half, host_to_dev(rh), hi_only);
+        // keep the caller's buffer: copy back in place (stream-ordered), drop the scratch
+        hipMemcpyAsync(p->d, out, half * sizeof(Fr), hipMemcpyDeviceToDevice, g.stream);
+        hipStreamSynchronize(g.stream);
+        hipFree(out);
+    }
+    p->len = half;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ATLAS_ENODEV, "bind launch", e);
+    return ATLAS_OK;
+}
+
+int atlas_poly_bind(atlas_poly_t p, const atlas_u128_t* r, int order) {
+    NEED_INIT();
+    if (!p || !r || (order != ATLAS_HIGH_TO_LOW && order != ATLAS_LOW_TO_HIGH)) return fail(ATLAS_EINVAL, "poly_bind");
+    int rc = poly_bind_async(p, r, order);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return ATLAS_OK;
+}
+
+int atlas_poly_final_claim(atlas_poly_t p, atlas_fr_t* out) {
+    NEED_INIT();
+    if (!p || !out) return fail(ATLAS_EINVAL, "final_claim");
+    if (p->len != 1) return fail(ATLAS_ESTATE, "final_claim: polynomial not fully bound");
+    return atlas_poly_download(p, out, 1);
+}
+
+// ------------------------------------------------------------------ dot prover
+static EqView eq_view_for_round(const atlas_dot_prover* P, size_t round, const Fr* eq_ptr, size_t eq_len) {
+    EqView v; v.p = eq_ptr; v.mode = EQ_NONE; v.shift = 0; v.mask = 0; v.half = 0;
+    if (P->schedule == ATLAS_EQ_HIGH) {
+        if (round < P->a) { v.mode = EQ_PAIR; v.shift = (uint32_t)P->b; v.half = (uint32_t)(eq_len / 2); }
+        else { v.mode = EQ_IDX; v.mask = 0; }
+    } else if (P->schedule == ATLAS_EQ_LOW) {
+        if (round < P->a) { v.mode = EQ_IDX; v.mask = (uint32_t)((1ull << P->b) - 1); }
+        else { v.mode = EQ_PAIR; v.shift = 0; v.half = (uint32_t)(eq_len / 2); }
+    }
+    return v;
+}
+
+int atlas_dot_prover_new(atlas_poly_t left, atlas_poly_t right, atlas_poly_t eq, int schedule, size_t a, size_t b,
+                         atlas_dot_prover_t* out) {
+    NEED_INIT();
+    if (!left || !right || !out) return fail(ATLAS_EINVAL, "dot_prover_new: null operand");
+    if (left->len != right->len || !is_pow2(left->len)) return fail(ATLAS_EINVAL, "dot_prover_new: operand lengths");
+    if (left->is_i32 != right->is_i32) return fail(ATLAS_EINVAL, "dot_prover_new: mixed operand types");
+    const size_t n = ilog2(left->len);
+    if (n > MAX_ROUNDS) return fail(ATLAS_EINVAL, "dot_prover_new: too many rounds");
+    if (schedule == ATLAS_EQ_NONE) {
+        if (eq) return fail(ATLAS_EINVAL, "dot_prover_new: eq given with EqSchedule::None");
+    } else if (schedule == ATLAS_EQ_HIGH || schedule == ATLAS_EQ_LOW) {
+        if (!eq || eq->is_i32) return fail(ATLAS_EINVAL, "dot_prover_new: eq table required (Fr)");
+        if (a + b != n) return fail(ATLAS_EINVAL, "dot_prover_new: schedule bits != num_rounds");
+        size_t want = schedule == ATLAS_EQ_HIGH ? ((size_t)1 << a) : ((size_t)1 << b);
+        if (eq->len != want) return fail(ATLAS_EINVAL, "dot_prover_new: eq table length");
+        if (left->is_i32) return fail(ATLAS_EINVAL, "dot_prover_new: i32 operands only with EqSchedule::None");
+    } else {
+        return fail(ATLAS_EINVAL, "dot_prover_new: unknown schedule");
+    }
+    atlas_dot_prover* P = new atlas_dot_prover();
+    P->left = left; P->right = right; P->eq = eq; P->schedule = schedule; P->a = a; P->b = b; P->n_rounds = n;
+    *out = P;
+    return ATLAS_OK;
+}
+
+int atlas_dot_prover_free(atlas_dot_prover_t P) {
+    if (!P) return ATLAS_OK;
+    atlas_poly_free(P->left); atlas_poly_free(P->right); atlas_poly_free(P->eq);
+    delete P;
+    return ATLAS_OK;
+}
+
+}  // extern "C"
+
+// sum of per-workgroup partials -> DEG Fr at out[0..DEG)
+template <int DEG>
+__global__ __launch_bounds__(SC_THREADS) void k_reduce_partials(const Fr* partials, int n_partials, Fr* out) {
+    __shared__ Fr red[SC_THREADS / 64][DEG];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    Fr acc[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) acc[k] = fe_zero();
+    for (int b = threadIdx.x; b < n_partials; b += SC_THREADS)
+#pragma unroll
+        for (int k = 0; k < DEG; k++) acc[k] = fr_add(acc[k], fe_load(partials + (size_t)b * DEG + k));
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        Fr s = fr_wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < DEG) {
+        Fr s = red[0][threadIdx.x];
+        for (int w = 1; w < SC_THREADS / 64; w++) s = fr_add(s, red[w][threadIdx.x]);
+        fe_store(out + threadIdx.x, s);
+    }
+}
+
+template <int DEG>
+static void launch_eval(const atlas_dot_prover* P, const EqView& eq, size_t half, int grid) {
+    const ScConsts K = make_consts();
+    if (P->left->is_i32)
+        k_dot_eval<DEG, int32_t><<<grid, SC_THREADS, 0, g.stream>>>((const int32_t*)P->left->d, (const int32_t*)P->right->d,
+                                                                 eq, half, g.d_partials, K);
+    else
+        k_dot_eval<DEG, Fr><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, eq, half,
+                                                            g.d_partials, K);
+}
+
+extern "C" {
+
+int atlas_dot_compute_message(atlas_dot_prover_t P, size_t round, const atlas_fr_t* previous_claim,
+                              atlas_fr_t* coeffs_out, size_t* n_coeffs) {
+    NEED_INIT();
+    if (!P || !previous_claim || !coeffs_out || !n_coeffs) return fail(ATLAS_EINVAL, "compute_message");
+    if (P->consumed) return fail(ATLAS_ESTATE, "compute_message: prover already consumed");
+    if (round >= P->n_rounds || P->left->len != ((size_t)1 << (P->n_rounds - round)))
+        return fail(ATLAS_ESTATE, "compute_message: round out of order");
+    const int deg = P->schedule == ATLAS_EQ_NONE ? 2 : 3;
+    const size_t half = P->left->len / 2;
+    const int grid = grid_for(half);
+    EqView eq = eq_view_for_round(P, round, P->eq ? (const Fr*)P->eq->d : nullptr, P->eq ? P->eq->len : 0);
+    if (deg == 2) { launch_eval<2>(P, eq, half, grid); k_reduce_partials<2><<<1, SC_THREADS, 0, g.stream>>>(g.d_partials, grid, g.d_finals + 3); }
+    else { launch_eval<3>(P, eq, half, grid); k_reduce_partials<3><<<1, SC_THREADS, 0, g.stream>>>(g.d_partials, grid, g.d_finals + 3); }
+    H::Fr ev[3];
+    HIP_TRY(hipMemcpyAsync(g.h_pinned, g.d_finals + 3, deg * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    std::memcpy(ev, g.h_pinned, deg * sizeof(Fr));
+    H::Fr c[4];
+    int nc = H::unipoly_from_evals_and_hint(*reinterpret_cast<const H::Fr*>(previous_claim), ev, deg, c);
+    std::memcpy(coeffs_out, c, nc * sizeof(H::Fr));
+    *n_coeffs = (size_t)nc;
+    return ATLAS_OK;
+}
+
+int atlas_dot_ingest_challenge(atlas_dot_prover_t P, const atlas_u128_t* r_j, size_t round) {
+    NEED_INIT();
+    if (!P || !r_j) return fail(ATLAS_EINVAL, "ingest_challenge");
+    if (P->consumed) return fail(ATLAS_ESTATE, "ingest_challenge: prover already consumed");
+    if (round >= P->n_rounds || P->left->len != ((size_t)1 << (P->n_rounds - round)))
+        return fail(ATLAS_ESTATE, "ingest_challenge: round out of order");
+    int rc = poly_bind_async(P->left, r_j, ATLAS_HIGH_TO_LOW);
+    if (!rc) rc = poly_bind_async(P->right, r_j, ATLAS_HIGH_TO_LOW);
+    if (!rc && P->schedule == ATLAS_EQ_HIGH && round < P->a) rc = poly_bind_async(P->eq, r_j, ATLAS_HIGH_TO_LOW);
+    if (!rc && P->schedule == ATLAS_EQ_LOW && round >= P->a) rc = poly_bind_async(P->eq, r_j, ATLAS_HIGH_TO_LOW);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return ATLAS_OK;
+}
+
+int atlas_dot_final_claims(atlas_dot_prover_t P, atlas_fr_t out[3]) {
+    NEED_INIT();
+    if (!P || !out) return fail(ATLAS_EINVAL, "final_claims");
+    if (P->consumed) return fail(ATLAS_ESTATE, "final_claims: prover consumed by atlas_sumcheck_prove_dot");
+    if (P->left->len != 1) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
+    int rc = atlas_poly_download(P->left, &out[0], 1);
+    if (!rc) rc = atlas_poly_download(P->right, &out[1], 1);
+    if (rc) return rc;
+    if (P->eq) {
+        if (P->eq->len != 1) return fail(ATLAS_ESTATE, "final_claims: eq not fully bound");
+        return atlas_poly_download(P->eq, &out[2], 1);
+    }
+    H::Fr one = H::one();
+    std::memcpy(&out[2], &one, 32);
+    return ATLAS_OK;
+}
+
+}  // extern "C"
+
+// ---- whole-instance prove: the round loop as a launch chain, transcript on device ----
+template <int DEG>
+static int prove_dot_impl(atlas_dot_prover* P, const atlas_fr_t* input_claim, atlas_transcript_t* transcript,
+                          atlas_fr_t* compressed_polys, atlas_u128_t* challenges, atlas_fr_t final_claims[3]) {
+    const ScConsts K = make_consts();
+    const size_t n = P->n_rounds;
+    const int mode = g.challenge_mode;
+    const int hi_only = mode == 0;
+    Timer tm;
+
+    // control block: transcript + running claim
+    ScCtx* hctx = reinterpret_cast<ScCtx*>(g.h_pinned);
+    std::memset(hctx, 0, sizeof(ScCtx));
+    std::memcpy(&hctx->tr, transcript, sizeof(DevTranscript));
+    std::memcpy(&hctx->claim, input_claim, sizeof(Fr));
+    HIP_TRY(hipMemcpyAsync(g.d_ctx, hctx, sizeof(ScCtx), hipMemcpyHostToDevice, g.stream));
+
+    size_t len = P->left->len;
+    size_t eq_len = P->eq ? P->eq->len : 0;
+    Fr* eqp = P->eq ? (Fr*)P->eq->d : nullptr;
+    size_t rounds_done = 0;       // messages emitted so far
+    int pending = 0;              // challenge of round rounds_done-1 not yet bound
+    const size_t esz = P->left->is_i32 ? sizeof(int32_t) : sizeof(Fr);
+
+    if (n > (size_t)SC_TAIL_LOG) {
+        // round 0 message over the untouched operands
+        {
+            const size_t half = len / 2;
+            const int grid = grid_for(half);
+            EqView eq = eq_view_for_round(P, 0, eqp, eq_len);
+            tm.begin(0, 2 * len * esz);
+            launch_eval<DEG>(P, eq, half, grid);
+            tm.end();
+            tm.begin(1, 0);
+            k_fs_round<DEG><<<1, SC_THREADS, 0, g.stream>>>(g.d_ctx, g.d_partials, grid, g.d_proof, g.d_chal, K, 1, mode);
+            tm.end();
+            rounds_done = 1; pending = 1;
+        }
+        // fused passes: bind r_j, emit message j+1, while the operands exceed the tail size
+        while (len > ((size_t)1 << SC_TAIL_LOG)) {
+            const size_t j = rounds_done - 1;          // challenge index being bound
+            const size_t q = len / 4;
+            const int grid = grid_for(q);
+            bool fuse_eq = false;
+            if (P->schedule == ATLAS_EQ_HIGH && j < P->a) {
+                tm.begin(0, (eq_len + eq_len / 2) * sizeof(Fr));
+                k_bind_hi<<<grid_for(eq_len / 2), SC_THREADS, 0, g.stream>>>(eqp, eq_len / 2, &g.d_ctx->r, hi_only);
+                tm.end();
+                eq_len /= 2;
+            } else if (P->schedule == ATLAS_EQ_LOW && j >= P->a) {
+                fuse_eq = true;
+            }
+            EqView eq = eq_view_for_round(P, j + 1, eqp, fuse_eq ? eq_len / 2 : eq_len);
+            uint64_t bytes = 2 * len * esz + 2 * (len / 2) * sizeof(Fr);
+            if (fuse_eq) bytes += (eq_len + eq_len / 2) * sizeof(Fr);
+            tm.begin(0, bytes);
+            if (P->left->is_i32) {
+                Fr *Ld = nullptr, *Rd = nullptr;
+                HIP_TRY(hipMalloc(&Ld, (len / 2) * sizeof(Fr)));
+                HIP_TRY(hipMalloc(&Rd, (len / 2) * sizeof(Fr)));
+                k_dot_bind_eval<DEG, int32_t, false><<<grid, SC_THREADS, 0, g.stream>>>(
+                    (const int32_t*)P->left->d, (const int32_t*)P->right->d, Ld, Rd, nullptr, eq, q, g.d_ctx,
+                    g.d_partials, K, hi_only);
+                tm.end();
+                HIP_TRY(hipStreamSynchronize(g.stream));
+                if (P->left->owned) (void)hipFree(P->left->d);
+                if (P->right->owned) (void)hipFree(P->right->d);
+                P->left->d = Ld; P->left->is_i32 = false; P->left->owned = true;
+                P->right->d = Rd; P->right->is_i32 = false; P->right->owned = true;
+            } else if (fuse_eq) {
+                k_dot_bind_eval<DEG, Fr, true><<<grid, SC_THREADS, 0, g.stream>>>(
+                    (const Fr*)P->left->d, (const Fr*)P->right->d, (Fr*)P->left->d, (Fr*)P->right->d, eqp, eq, q,
+                    g.d_ctx, g.d_partials, K, hi_only);
+                tm.end();
+                eq_len /= 2;
+            } else {
+                k_dot_bind_eval<DEG, Fr, false><<<grid, SC_THREADS, 0, g.stream>>>(
+                    (const Fr*)P->left->d, (const Fr*)P->right->d, (Fr*)P->left->d, (Fr*)P->right->d, nullptr, eq, q,
+                    g.d_ctx, g.d_partials, K, hi_only);
+                tm.end();
+            }
+            len /= 2;
+            tm.begin(1, 0);
+            k_fs_round<DEG><<<1, SC_THREADS, 0, g.stream>>>(g.d_ctx, g.d_partials, grid, g.d_proof + rounds_done * DEG,
+                                                          g.d_chal + 2 * rounds_done, K, 0, mode);
+            tm.end();
+            rounds_done += 1;
+        }
+    }
+
+    // tail: all remaining rounds in one launch
+    {
+        TailArgs A;
+        A.L = P->left->d; A.R = P->right->d; A.eq = eqp;
+        A.len = (uint32_t)len; A.eq_len = (uint32_t)eq_len;
+        A.src_i32 = P->left->is_i32 ? 1 : 0;
+        A.sched = P->schedule; A.a = (uint32_t)P->a; A.b = (uint32_t)P->b;
+        A.round0 = (uint32_t)rounds_done; A.n_rounds = (uint32_t)n;
+        A.first = rounds_done == 0 ? 1 : 0;
+        A.pending_bind = pending;
+        A.challenge_mode = mode;
+        tm.begin(1, 0);
+        k_dot_tail<DEG><<<1, SC_THREADS, 3 * (sizeof(Fr) << SC_TAIL_LOG), g.stream>>>(A, g.d_ctx, g.d_proof, g.d_chal,
+                                                                                     g.d_finals, K);
+        tm.end();
+    }
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail(ATLAS_ENODEV, "sumcheck launch", le);
+
+    // results: one D2H each, stream ordered
+    uint8_t* hp = reinterpret_cast<uint8_t*>(g.h_pinned);
+    const size_t proof_bytes = n * DEG * sizeof(Fr), chal_bytes = n * 2 * sizeof(uint64_t);
+    HIP_TRY(hipMemcpyAsync(hp, g.d_proof, proof_bytes ? proof_bytes : 32, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync(hp + 8192, g.d_chal, chal_bytes ? chal_bytes : 16, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync(hp + 12288, g.d_finals, 3 * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync(hp + 16384, g.d_ctx, sizeof(ScCtx), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    std::memcpy(compressed_polys, hp, proof_bytes);
+    std::memcpy(challenges, hp + 8192, chal_bytes);
+    std::memcpy(final_claims, hp + 12288, 3 * sizeof(Fr));
+    std::memcpy(transcript, hp + 16384, sizeof(DevTranscript));
+    tm.collect();
+    P->consumed = true;
+    P->left->len = 1; P->right->len = 1;
+    if (P->eq) P->eq->len = 1;
+    return ATLAS_OK;
+}
+
+extern "C" {
+
+int atlas_sumcheck_prove_dot(atlas_dot_prover_t P, const atlas_fr_t* input_claim, atlas_transcript_t* transcript,
+                             atlas_fr_t* compressed_polys, atlas_u128_t* challenges, atlas_fr_t final_claims[3]) {
+    NEED_INIT();
+    if (!P || !input_claim || !transcript || !compressed_polys || !challenges || !final_claims)
+        return fail(ATLAS_EINVAL, "sumcheck_prove_dot: null argument");
+    if (P->consumed) return fail(ATLAS_ESTATE, "sumcheck_prove_dot: prover already consumed");
+    if (P->left->len != ((size_t)1 << P->n_rounds)) return fail(ATLAS_ESTATE, "sumcheck_prove_dot: rounds already run");
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (P->schedule == ATLAS_EQ_NONE) return prove_dot_impl<2>(P, input_claim, transcript, compressed_polys, challenges, final_claims);
+    return prove_dot_impl<3>(P, input_claim, transcript, compressed_polys, challenges, final_claims);
+}
+
+}  // extern "C"
