@@ -96,6 +96,10 @@ typedef struct atlas_dot_prover *atlas_dot_prover_t;
 int atlas_dot_prover_new(atlas_poly_t left, atlas_poly_t right, atlas_poly_t eq, int schedule,
                          size_t sched_a, size_t sched_b, atlas_dot_prover_t *out);
 int atlas_dot_prover_free(atlas_dot_prover_t p);
+/* input_claim(): sum_h L(h) R(h) [EQ(h)] over the unbound operands.  The reference reads
+ * it from the opening accumulator (dot.rs:204-207 -> fused_rebase::fused_input_claim);
+ * synthetic instances have no accumulator, so the device computes it. */
+int atlas_dot_input_claim(atlas_dot_prover_t p, atlas_fr_t *out);
 /* compute_message(round, previous_claim) -> UniPoly coefficients c0..c_deg (deg+1 Fr),
  * dot.rs:290-350 + UniPoly::from_evals_and_hint */
 int atlas_dot_compute_message(atlas_dot_prover_t p, size_t round, const atlas_fr_t *previous_claim,

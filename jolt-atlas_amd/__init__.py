@@ -59,7 +59,7 @@ lib.atlas_last_error.restype = C.c_char_p
 for _name in ("atlas_poly_upload_fr", "atlas_poly_upload_i32", "atlas_poly_wrap_device_fr", "atlas_poly_len",
               "atlas_poly_download", "atlas_poly_clone", "atlas_poly_free", "atlas_poly_bind",
               "atlas_poly_final_claim", "atlas_dot_prover_new", "atlas_dot_prover_free",
-              "atlas_dot_compute_message", "atlas_dot_ingest_challenge", "atlas_dot_final_claims",
+              "atlas_dot_compute_message", "atlas_dot_input_claim", "atlas_dot_ingest_challenge", "atlas_dot_final_claims",
               "atlas_sumcheck_prove_dot"):
     getattr(lib, _name).restype = C.c_int
 
@@ -220,6 +220,11 @@ class EinsumDotProver:
         self.h = h
         self.deg = 2 if schedule == EQ_NONE else 3
 
+    def input_claim(self):
+        out = np.zeros(4, dtype=np.uint64)
+        _check(lib.atlas_dot_input_claim(self.h, _p(out)))
+        return out
+
     def compute_message(self, rnd, previous_claim):
         out = np.zeros((4, 4), dtype=np.uint64)
         n = C.c_size_t()
@@ -255,3 +260,27 @@ class Sumcheck:
         _check(lib.atlas_sumcheck_prove_dot(prover.h, _p(ic), C.byref(transcript.t), _p(proof), _p(ch), _p(fin)))
         chal = [int(ch[2 * i]) | (int(ch[2 * i + 1]) << 64) for i in range(n_rounds)]
         return proof[:n_rounds * deg].reshape(n_rounds, deg, 4), chal, fin
+
+
+_FR_MOD = np.array([0x43e1f593f0000001, 0x2833e84879b97091, 0xb85045b68181585d, 0x30644e72e131a029], dtype=np.uint64)
+
+
+def random_fr(n, seed):
+    """n uniform Fr as Montgomery limbs: draw 4 x u64, clear the top two bits, rejection-
+    sample < r (SURVEY §8d input recipe; PCG64 stands in for ChaCha20 — these are inputs,
+    not protocol outputs).  Any residue < r is a valid Montgomery image."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+    out[:, 3] &= np.uint64((1 << 62) - 1)
+    while True:
+        ge = np.zeros(n, dtype=bool)
+        und = np.ones(n, dtype=bool)
+        for k in (3, 2, 1, 0):
+            ge |= und & (out[:, k] > _FR_MOD[k])
+            und &= out[:, k] == _FR_MOD[k]
+        bad = np.nonzero(ge | und)[0]
+        if bad.size == 0:
+            return out
+        new = rng.integers(0, 1 << 64, size=(bad.size, 4), dtype=np.uint64)
+        new[:, 3] &= np.uint64((1 << 62) - 1)
+        out[bad] = new

@@ -534,6 +534,27 @@ int atlas_dot_compute_message(atlas_dot_prover_t P, size_t round, const atlas_fr
     return ATLAS_OK;
 }
 
+int atlas_dot_input_claim(atlas_dot_prover_t P, atlas_fr_t* out) {
+    NEED_INIT();
+    if (!P || !out) return fail(ATLAS_EINVAL, "input_claim");
+    if (P->consumed || P->left->len != ((size_t)1 << P->n_rounds)) return fail(ATLAS_ESTATE, "input_claim: instance already bound");
+    const size_t len = P->left->len;
+    const int grid = grid_for(len);
+    EqView eq; eq.p = P->eq ? (const Fr*)P->eq->d : nullptr; eq.mode = EQ_NONE; eq.shift = 0; eq.mask = 0; eq.half = 0;
+    if (P->schedule == ATLAS_EQ_HIGH) { eq.mode = EQ_PAIR; eq.shift = (uint32_t)P->b; }
+    if (P->schedule == ATLAS_EQ_LOW) { eq.mode = EQ_IDX; eq.mask = (uint32_t)((1ull << P->b) - 1); }
+    const ScConsts K = make_consts();
+    if (P->left->is_i32)
+        k_dot_claim<int32_t><<<grid, SC_THREADS, 0, g.stream>>>((const int32_t*)P->left->d, (const int32_t*)P->right->d, eq, len, g.d_partials, K);
+    else
+        k_dot_claim<Fr><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, eq, len, g.d_partials, K);
+    k_reduce_partials<1><<<1, SC_THREADS, 0, g.stream>>>(g.d_partials, grid, g.d_finals + 3);
+    HIP_TRY(hipMemcpyAsync(g.h_pinned, g.d_finals + 3, sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    std::memcpy(out, g.h_pinned, sizeof(Fr));
+    return ATLAS_OK;
+}
+
 int atlas_dot_ingest_challenge(atlas_dot_prover_t P, const atlas_u128_t* r_j, size_t round) {
     NEED_INIT();
     if (!P || !r_j) return fail(ATLAS_EINVAL, "ingest_challenge");

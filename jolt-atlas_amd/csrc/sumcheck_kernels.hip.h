@@ -193,6 +193,23 @@ __global__ __launch_bounds__(SC_THREADS) void k_dot_eval(const T* __restrict__ L
     block_reduce_store<DEG>(acc, partials);
 }
 
+// input claim of the instance, sum_h L(h) R(h) [EQ(h)] over the whole cube (what the
+// reference reads from the opening accumulator, dot.rs:204-207; needed for synthetic inputs)
+template <class T>
+__global__ __launch_bounds__(SC_THREADS) void k_dot_claim(const T* __restrict__ L, const T* __restrict__ R,
+                                                          EqView eq, size_t len, Fr* partials, ScConsts K) {
+    Fr acc[1];
+    acc[0] = fe_zero();
+    for (size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x; i < len;
+         i += (size_t)gridDim.x * SC_THREADS) {
+        Fr t = fr_mul(Src<T>::get(L, i, K), Src<T>::get(R, i, K));
+        if (eq.mode == EQ_IDX) t = fr_mul(t, fe_load(eq.p + (i & eq.mask)));
+        else if (eq.mode == EQ_PAIR) t = fr_mul(t, fe_load(eq.p + (i >> eq.shift)));
+        acc[0] = fr_add(acc[0], t);
+    }
+    block_reduce_store<1>(acc, partials);
+}
+
 // ---- fused pass: ingest_challenge(r_j) + compute_message(round j+1) --------------------
 // len = current length (>= 4); q = len/4. Fr operands are bound in place; i32 operands
 // are read from Lsrc/Rsrc and the bound Fr written to Ldst/Rdst (len/2 entries).

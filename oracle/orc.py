@@ -115,12 +115,17 @@ def dot_claim(L, R, eq=None, schedule=0, a=0, b=0):
     return out
 
 
-def sumcheck_dot_prove(L, R, claim, t, eq=None, schedule=0, a=0, b=0):
-    """Consumes copies of L/R/eq. Returns (proof (rounds,deg,4), challenges [u128], finals (3,4))."""
+def sumcheck_dot_prove(L, R, claim, t, eq=None, schedule=0, a=0, b=0, consume=False):
+    """Binds copies of L/R/eq (or the arrays themselves when consume=True, like the
+    reference). Returns (proof (rounds,deg,4), challenges [u128], finals (3,4))."""
     n_vars = (len(L)).bit_length() - 1
     deg = 2 if schedule == 0 else 3
-    L = np.ascontiguousarray(L).copy(); R = np.ascontiguousarray(R).copy()
-    eqc = None if eq is None else np.ascontiguousarray(eq).copy()
+    if consume:
+        assert L.flags.c_contiguous and R.flags.c_contiguous
+        eqc = eq
+    else:
+        L = np.ascontiguousarray(L).copy(); R = np.ascontiguousarray(R).copy()
+        eqc = None if eq is None else np.ascontiguousarray(eq).copy()
     proof = fr_array(n_vars * deg)
     ch = np.zeros(2 * n_vars, dtype=np.uint64)
     fin = fr_array(3)

@@ -129,3 +129,35 @@ def test_host_transcript_matches_oracle(atlas):
     s = t.challenge_scalar(); so = orc.fr_array(1); orc.lib.orc_transcript_challenge_scalar(C.byref(o), orc._p(so))
     assert np.array_equal(s, so[0])
     assert t.state == o.state_bytes() and t.n_rounds == o.n_rounds
+
+
+@pytest.mark.parametrize("n,sched,a,b", [(9, 0, 0, 0), (13, 0, 0, 0), (13, 1, 5, 8), (13, 2, 5, 8)])
+def test_input_claim(atlas, n, sched, a, b):
+    from oracle import orc
+    A = atlas
+    L = orc.random_fr(1 << n, 21 + n); R = orc.random_fr(1 << n, 22 + n)
+    eq = None
+    if sched:
+        eq = orc.eq_evals(orc.random_fr(a if sched == 1 else b, 23 + n))
+    prover = A.EinsumDotProver(A.MultilinearPolynomial.from_fr(L), A.MultilinearPolynomial.from_fr(R),
+                               A.MultilinearPolynomial.from_fr(eq) if eq is not None else None, sched, a, b)
+    assert np.array_equal(prover.input_claim(), orc.dot_claim(L, R, eq, sched, a, b)[0])
+    prover.free()
+
+
+def test_random_fr_generators_agree(atlas):
+    from oracle import orc
+    assert np.array_equal(atlas.random_fr(1000, 77), orc.random_fr(1000, 77))
+
+
+def test_errors_are_loud(atlas):
+    A = atlas
+    with pytest.raises(A.AtlasError):
+        A.MultilinearPolynomial.from_fr(np.zeros((3, 4), dtype=np.uint64))      # not a power of two
+    p = A.MultilinearPolynomial.from_fr(np.zeros((4, 4), dtype=np.uint64))
+    q = A.MultilinearPolynomial.from_fr(np.zeros((8, 4), dtype=np.uint64))
+    with pytest.raises(A.AtlasError):
+        A.EinsumDotProver(p, q)                                                 # length mismatch
+    with pytest.raises(A.AtlasError):
+        p.final_claim()                                                         # not fully bound
+    p.free(); q.free()
