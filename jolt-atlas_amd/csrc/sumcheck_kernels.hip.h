@@ -287,11 +287,34 @@ __global__ __launch_bounds__(SC_THREADS) void k_bind_lo(const Fr* z, Fr* out, si
     }
 }
 
-// ---- the serial spine of one round (one lane): sumcheck.rs:579-588 ----------------------
+// ---- the serial spine of one round (one wavefront, VALU): sumcheck.rs:579-588 ------------
+// Every lane holds the same field values; the transcript state is spread over each quad.
+__device__ __forceinline__ Fr fr_half(const Fr& a) {      // a/2: (a + (a odd ? p : 0)) >> 1
+    uint32_t t[8];
+    const uint32_t odd = a.v[0] & 1u;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (uint64_t)a.v[i] + (odd ? FrParams::p(i) : 0u);
+        t[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    Fr o;
+#pragma unroll
+    for (int i = 0; i < 7; i++) o.v[i] = (t[i] >> 1) | (t[i + 1] << 31);
+    o.v[7] = (t[7] >> 1) | ((uint32_t)c << 31);
+    return o;
+}
+
+struct FsScratch {           // LDS used by the wave-cooperative transcript
+    WaveTranscriptLds wt;
+};
+
 template <int DEG>
-__device__ inline void fs_round_serial(RegTranscript& T, const Fr ev[DEG], Fr& claim, Fr& r_out,
-                                       Fr& r_s64_out, Fr* proof_row, uint64_t* chal_row,
-                                       const ScConsts& K, int challenge_mode) {
+__device__ __forceinline__ void fs_round_wave(WaveTranscript& T, FsScratch* S, const WaveBlakeSched& W,
+                                              uint32_t lane, const Fr ev[DEG], Fr& claim, Fr& r_out,
+                                              Fr* proof_row, uint64_t* chal_row, const ScConsts& K,
+                                              int challenge_mode) {
     // UniPoly::from_evals_and_hint (unipoly.rs:91-98) -> degree2/degree3 closed forms (:66-89)
     Fr c[DEG + 1];
     const Fr e0 = ev[0];
@@ -299,53 +322,58 @@ __device__ inline void fs_round_serial(RegTranscript& T, const Fr ev[DEG], Fr& c
     const Fr e2 = ev[1];
     c[0] = e0;
     if constexpr (DEG == 2) {
-        Fr t = fr_add(fr_sub(fr_sub(e0, e1), e1), e2);
-        c[2] = fr_mul(t, K.two_inv);
+        c[2] = fr_half(fr_add(fr_sub(fr_sub(e0, e1), e1), e2));
         c[1] = fr_sub(fr_sub(e1, e0), c[2]);
     } else {
         const Fr e3 = ev[2];
         Fr u = fr_sub(e1, e2);
         u = fr_add(fr_dbl(u), u);
         c[3] = fr_mul(fr_add(fr_sub(e3, e0), u), K.six_inv);
-        Fr t = fr_mul(fr_add(fr_sub(fr_sub(e0, e1), e1), e2), K.two_inv);
+        Fr t = fr_half(fr_add(fr_sub(fr_sub(e0, e1), e1), e2));
         c[2] = fr_sub(fr_sub(fr_sub(t, c[3]), c[3]), c[3]);
         c[1] = fr_sub(fr_sub(fr_sub(e1, e0), c[2]), c[3]);
     }
-    // compress (drop the linear term) + append_to_transcript (unipoly.rs:307-318,550-558)
-    tr_append_label(T, K.lbl_begin);
-    tr_append_scalar(T, c[0]);
-    fe_store(proof_row + 0, c[0]);
+    // canonical forms for the transcript (independent of the hash chain: overlaps with it)
+    Fr canon[DEG];
+    canon[0] = fe_from_mont<FrParams>(c[0]);
 #pragma unroll
-    for (int k = 2; k <= DEG; k++) {
-        tr_append_scalar(T, c[k]);
-        fe_store(proof_row + k - 1, c[k]);
-    }
-    tr_append_label(T, K.lbl_end);
+    for (int k = 2; k <= DEG; k++) canon[k - 1] = fe_from_mont<FrParams>(c[k]);
+    // compress (drop the linear term) + append_to_transcript (unipoly.rs:307-318,550-558)
+    wt_append_label(T, &S->wt, W, lane, K.lbl_begin);
+#pragma unroll
+    for (int k = 0; k < DEG; k++) wt_append_canonical(T, &S->wt, W, lane, canon[k]);
+    wt_append_label(T, &S->wt, W, lane, K.lbl_end);
     // challenge_scalar_optimized (blake2b.rs:233-238)
     uint64_t lo, hi;
-    tr_challenge_u128(T, lo, hi);
-    chal_row[0] = lo; chal_row[1] = hi;
+    wt_challenge_u128(T, &S->wt, W, lane, lo, hi);
     const Fr r = challenge_to_mont(lo, hi, challenge_mode);
     // previous_claim = poly.evaluate(r_j) (unipoly.rs:229-245)
     Fr ev_r = c[0], pw = r;
 #pragma unroll
     for (int k = 1; k <= DEG; k++) {
-        ev_r = fr_add(ev_r, fr_mul(pw, c[k]));
-        if (k < DEG) pw = fr_mul(pw, r);
+        // only r itself has the four zero low limbs; its powers are full-width
+        ev_r = fr_add(ev_r, (k == 1 && challenge_mode == 0) ? fr_mul_hi(c[k], pw) : fr_mul(pw, c[k]));
+        if (k < DEG) pw = challenge_mode == 0 ? fr_mul_hi(pw, r) : fr_mul(pw, r);
     }
     claim = ev_r;
     r_out = r;
-    r_s64_out = fr_mul(r, K.k64);   // Montgomery(r * 2^64)
+    if (lane == 0) {
+        fe_store(proof_row + 0, c[0]);
+#pragma unroll
+        for (int k = 2; k <= DEG; k++) fe_store(proof_row + k - 1, c[k]);
+        chal_row[0] = lo; chal_row[1] = hi;
+    }
 }
 
-// fold the per-workgroup partials, then run the serial spine. One workgroup.
+// fold the per-workgroup partials, then run the serial spine on wavefront 0.
 // first != 0: Sumcheck::prove's `transcript.append_scalar(&input_claim)` (sumcheck.rs:573-574)
 template <int DEG>
 __global__ __launch_bounds__(SC_THREADS) void k_fs_round(ScCtx* cx, const Fr* partials, int n_partials,
                                                          Fr* proof_row, uint64_t* chal_row, ScConsts K,
                                                          int first, int challenge_mode) {
     __shared__ Fr red[SC_THREADS / 64][DEG];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ FsScratch fs;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     Fr acc[DEG];
 #pragma unroll
     for (int k = 0; k < DEG; k++) acc[k] = fe_zero();
@@ -358,24 +386,29 @@ __global__ __launch_bounds__(SC_THREADS) void k_fs_round(ScCtx* cx, const Fr* pa
         Fr s = fr_wave_sum(acc[k]);
         if (lane == 0) red[wave][k] = s;
     }
+    if (wave == 0) wt_init_lds(&fs.wt, lane);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        Fr ev[DEG];
+    if (wave != 0) return;
+    const uint32_t vz = vgpr_zero();
+    const WaveBlakeSched W = wave_blake_sched(lane & 3);
+    Fr ev[DEG];
 #pragma unroll
-        for (int k = 0; k < DEG; k++) {
-            Fr s = red[0][k];
-            for (int w = 1; w < SC_THREADS / 64; w++) s = fr_add(s, red[w][k]);
-            ev[k] = s;
-        }
-        RegTranscript T = tr_load(&cx->tr);
-        Fr claim = fe_load(&cx->claim);
-        if (first) tr_append_scalar(T, claim);
-        Fr r, r_s64;
-        fs_round_serial<DEG>(T, ev, claim, r, r_s64, proof_row, chal_row, K, challenge_mode);
-        tr_store(&cx->tr, T);
+    for (int k = 0; k < DEG; k++) {
+        const Fr* rp = &red[0][0] + vz;
+        Fr s = rp[k];
+        for (int w = 1; w < SC_THREADS / 64; w++) s = fr_add(s, rp[w * DEG + k]);
+        ev[k] = s;
+    }
+    WaveTranscript T = wt_load(&cx->tr, lane, vz);
+    Fr claim = fe_load(&cx->claim + vz);
+    if (first) wt_append_canonical(T, &fs.wt, W, lane, fe_from_mont<FrParams>(claim));
+    Fr r;
+    fs_round_wave<DEG>(T, &fs, W, lane, ev, claim, r, proof_row, chal_row, K, challenge_mode);
+    wt_store(&cx->tr, T, lane);
+    if (lane == 0) {
         fe_store(&cx->claim, claim);
         fe_store(&cx->r, r);
-        fe_store(&cx->r_s64, r_s64);
+        fe_store(&cx->r_s64, fr_mul(r, K.k64));   // Montgomery(r * 2^64) for small-scalar binds
     }
 }
 
@@ -404,8 +437,8 @@ __global__ __launch_bounds__(SC_THREADS) void k_dot_tail(TailArgs A, ScCtx* cx, 
     Fr* sE = sR + (1u << SC_TAIL_LOG);
     __shared__ Fr red[SC_THREADS / 64][DEG];
     __shared__ Fr s_r;
-    __shared__ Fr s_eq_bound;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ FsScratch fs;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool hi_only = A.challenge_mode == 0;
 
     uint32_t len = A.len, eq_len = A.eq_len;
@@ -421,12 +454,18 @@ __global__ __launch_bounds__(SC_THREADS) void k_dot_tail(TailArgs A, ScCtx* cx, 
     for (uint32_t i = tid; i < eq_len; i += SC_THREADS) sE[i] = fe_load(A.eq + i);
     __syncthreads();
 
-    RegTranscript T;
+    // wavefront 0 carries the transcript and the running claim (same values in every lane)
+    WaveTranscript T;
+    WaveBlakeSched W;
     Fr claim;
-    if (tid == 0) {
-        T = tr_load(&cx->tr);
-        claim = fe_load(&cx->claim);
-        if (A.first) tr_append_scalar(T, claim);
+    uint32_t vz = 0;
+    if (wave == 0) {
+        vz = vgpr_zero();
+        W = wave_blake_sched(lane & 3);
+        wt_init_lds(&fs.wt, lane);
+        T = wt_load(&cx->tr, lane, vz);
+        claim = fe_load(&cx->claim + vz);
+        if (A.first) wt_append_canonical(T, &fs.wt, W, lane, fe_from_mont<FrParams>(claim));
     }
 
     // a challenge produced by the last fs launch that the big-pass chain did not apply
@@ -481,26 +520,27 @@ __global__ __launch_bounds__(SC_THREADS) void k_dot_tail(TailArgs A, ScCtx* cx, 
             if (lane == 0) red[wave][k] = s;
         }
         __syncthreads();
-        if (tid == 0) {
+        if (wave == 0) {
             Fr ev[DEG];
+            const Fr* rp = &red[0][0] + vz;
 #pragma unroll
             for (int k = 0; k < DEG; k++) {
-                Fr s = red[0][k];
-                for (int w = 1; w < SC_THREADS / 64; w++) s = fr_add(s, red[w][k]);
+                Fr s = rp[k];
+                for (int w = 1; w < SC_THREADS / 64; w++) s = fr_add(s, rp[w * DEG + k]);
                 ev[k] = s;
             }
-            Fr r, r_s64;
-            fs_round_serial<DEG>(T, ev, claim, r, r_s64, proof + (size_t)round * DEG, chal + 2 * (size_t)round,
-                                 K, A.challenge_mode);
-            s_r = r;
+            Fr r;
+            fs_round_wave<DEG>(T, &fs, W, lane, ev, claim, r, proof + (size_t)round * DEG,
+                               chal + 2 * (size_t)round, K, A.challenge_mode);
+            if (lane == 0) s_r = r;
         }
         __syncthreads();
         pending = 1;
         round += 1;
     }
 
+    if (wave == 0) wt_store(&cx->tr, T, lane);
     if (tid == 0) {
-        tr_store(&cx->tr, T);
         fe_store(&cx->claim, claim);
         fe_store(&cx->r, s_r);
         // final_claim()s cached by cache_openings (dot.rs:377-400)
@@ -508,7 +548,6 @@ __global__ __launch_bounds__(SC_THREADS) void k_dot_tail(TailArgs A, ScCtx* cx, 
         fe_store(finals + 1, sR[0]);
         fe_store(finals + 2, A.sched ? sE[0] : fr_one());
     }
-    (void)s_eq_bound;
 }
 
 }  // namespace atlas
