@@ -120,6 +120,36 @@ int atlas_sumcheck_prove_dot(atlas_dot_prover_t p, const atlas_fr_t *input_claim
                              atlas_transcript_t *transcript, atlas_fr_t *compressed_polys,
                              atlas_u128_t *challenges, atlas_fr_t final_claims[3]);
 
+/* ---- SRS + multi-scalar multiplication: the arithmetic behind the CommitmentScheme
+ *      plug-in (joltworks/src/poly/commitment/commitment_scheme.rs:11-131) for HyperKZG --- */
+typedef struct { uint64_t l[4]; } atlas_fq_t;            /* ark_bn254::Fq, Montgomery limbs */
+/* ark_bn254::G1Affine image: x, y, infinity flag (72 bytes with padding) */
+typedef struct { atlas_fq_t x, y; uint64_t infinity; } atlas_g1_affine_t;
+typedef struct atlas_srs *atlas_srs_t;                   /* KZGProverKey::g1_powers resident in HBM */
+/* Upload `n` affine bases.  `stride_bytes` = distance between consecutive points in the
+ * caller's slice (72 for &[ark_bn254::G1Affine]; 64 for packed x,y); x at +0, y at +32,
+ * infinity flag byte at +64 when the stride allows.  (SRS / KZGProverKey, kzg.rs:18-143;
+ * done once, reused for every commit/open.) */
+int atlas_srs_upload(const void *bases, size_t n, size_t stride_bytes, atlas_srs_t *out);
+/* SRS::setup (kzg.rs:26-93) for a caller-supplied trapdoor: bases[i] = tau^(i+1) * G1,
+ * G1 = (1,2) — the reference's power layout (starts at beta^1).  Test/bench SRS. */
+int atlas_srs_generate(const atlas_fr_t *tau, size_t n, atlas_srs_t *out);
+int atlas_srs_len(atlas_srs_t s, size_t *len);
+int atlas_srs_download(atlas_srs_t s, size_t offset, size_t n, atlas_g1_affine_t *out);
+int atlas_srs_free(atlas_srs_t s);
+/* VariableBaseMSM::msm / msm_field_elements over bases[offset .. offset+n)
+ * (joltworks/src/msm/mod.rs:27-38,184-190; replaces the arkworks Pippenger call).
+ * Fails with ATLAS_EINVAL ("KeyLengthError") when the SRS slice is shorter than n. */
+int atlas_msm_fr(atlas_srs_t srs, size_t offset, const atlas_fr_t *scalars, size_t n,
+                 atlas_g1_affine_t *out);
+/* same, scalars = a device-resident LargeScalars polynomial: UnivariateKZG::
+ * commit_as_univariate (kzg.rs:285-298) without a host copy */
+int atlas_msm_poly(atlas_srs_t srs, size_t offset, atlas_poly_t poly, atlas_g1_affine_t *out);
+/* sum of bases[indices[i]] — HyperKZG::commit_one_hot (hyperkzg/mod.rs:520-554): the caller
+ * passes the flat indices k*T + t of the non-zero coefficients; replaces
+ * jolt_optimizations::batch_g1_additions_multi */
+int atlas_g1_sum_indexed(atlas_srs_t srs, const uint32_t *indices, size_t n, atlas_g1_affine_t *out);
+
 /* ---- measurement: HIP-event time of the launches issued by the last
  *      atlas_sumcheck_prove_dot / atlas_msm_* call, on the library stream ------------- */
 typedef struct {

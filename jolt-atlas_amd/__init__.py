@@ -284,3 +284,70 @@ def random_fr(n, seed):
         new = rng.integers(0, 1 << 64, size=(bad.size, 4), dtype=np.uint64)
         new[:, 3] &= np.uint64((1 << 62) - 1)
         out[bad] = new
+
+
+# ---------------------------------------------------------------- SRS / MSM (HyperKZG)
+G1_DTYPE = np.dtype([("x", np.uint64, (4,)), ("y", np.uint64, (4,)), ("infinity", np.uint64)])  # 72 bytes
+
+for _name in ("atlas_srs_upload", "atlas_srs_generate", "atlas_srs_len", "atlas_srs_download", "atlas_srs_free",
+              "atlas_msm_fr", "atlas_msm_poly", "atlas_g1_sum_indexed"):
+    getattr(lib, _name).restype = C.c_int
+
+
+class SRS:
+    """KZGProverKey::g1_powers resident in HBM (hyperkzg/kzg.rs:107-143)."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def upload(cls, bases):
+        """bases: numpy array of G1_DTYPE (the 72-byte arkworks G1Affine image)."""
+        bases = np.ascontiguousarray(bases, dtype=G1_DTYPE)
+        h = C.c_void_p()
+        _check(lib.atlas_srs_upload(bases.ctypes.data_as(C.c_void_p), C.c_size_t(len(bases)), C.c_size_t(72),
+                                    C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def generate(cls, tau_fr, n):
+        """bases[i] = tau^(i+1) * G (SRS::setup with a caller-supplied trapdoor)."""
+        tau_fr = _fr(tau_fr)
+        h = C.c_void_p()
+        _check(lib.atlas_srs_generate(_p(tau_fr), C.c_size_t(n), C.byref(h)))
+        return cls(h)
+
+    def len(self):
+        n = C.c_size_t()
+        _check(lib.atlas_srs_len(self.h, C.byref(n)))
+        return n.value
+
+    def download(self, offset=0, n=None):
+        n = self.len() - offset if n is None else n
+        out = np.zeros(n, dtype=G1_DTYPE)
+        _check(lib.atlas_srs_download(self.h, C.c_size_t(offset), C.c_size_t(n), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def msm(self, scalars, offset=0):
+        """VariableBaseMSM::msm: scalars = (n,4) Fr array or a device MultilinearPolynomial."""
+        out = np.zeros(1, dtype=G1_DTYPE)
+        if isinstance(scalars, MultilinearPolynomial):
+            _check(lib.atlas_msm_poly(self.h, C.c_size_t(offset), scalars.h, out.ctypes.data_as(C.c_void_p)))
+        else:
+            s = _fr(scalars).reshape(-1, 4)
+            _check(lib.atlas_msm_fr(self.h, C.c_size_t(offset), _p(s), C.c_size_t(s.shape[0]),
+                                    out.ctypes.data_as(C.c_void_p)))
+        return out[0]
+
+    def sum_indexed(self, indices):
+        """HyperKZG::commit_one_hot: sum of bases[k*T + t] over the non-zero coefficients."""
+        idx = np.ascontiguousarray(indices, dtype=np.uint32)
+        out = np.zeros(1, dtype=G1_DTYPE)
+        _check(lib.atlas_g1_sum_indexed(self.h, idx.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_size_t(len(idx)),
+                                        out.ctypes.data_as(C.c_void_p)))
+        return out[0]
+
+    def free(self):
+        if self.h:
+            lib.atlas_srs_free(self.h)
+            self.h = None

@@ -16,52 +16,27 @@
 
 #include "../../include/atlas_hip.h"
 #include "host_field.hpp"
+#include "runtime.hpp"
 #include "sumcheck_kernels.hip.h"
 
 using namespace atlas;
 namespace H = atlas_host;
 
 // ------------------------------------------------------------------ runtime state
-namespace {
-
-struct Runtime {
-    bool ready = false;
-    int device = -1;
-    hipStream_t stream = nullptr;
-    int challenge_mode = 0;
-    bool timing = false;
-    atlas_timing_t last_timing{};
-    std::string err;
-    Fr* d_partials = nullptr;      // SC_MAX_BLOCKS * 3 Fr
-    ScCtx* d_ctx = nullptr;
-    Fr* d_proof = nullptr;         // up to 64 rounds * 3
-    uint64_t* d_chal = nullptr;    // up to 64 rounds * 2
-    Fr* d_finals = nullptr;        // 3 (+3 scratch for reduced evals)
-    void* h_pinned = nullptr;      // pinned staging for small D2H/H2D
-    std::mutex mu;
-};
+namespace atlas_rt {
 Runtime g;
-
-constexpr size_t MAX_ROUNDS = 64;
-constexpr size_t PINNED_BYTES = 1 << 16;
-
-int fail(int code, const char* what, hipError_t e = hipSuccess) {
+int fail(int code, const char* what, hipError_t e) {
     g.err = what;
     if (e != hipSuccess) { g.err += ": "; g.err += hipGetErrorString(e); }
     return code;
 }
-#define HIP_TRY(x)                                                   \
-    do {                                                             \
-        hipError_t e_ = (x);                                         \
-        if (e_ != hipSuccess) return fail(ATLAS_ENODEV, #x, e_);     \
-    } while (0)
-#define NEED_INIT()                                                            \
-    do {                                                                       \
-        if (!g.ready) {                                                        \
-            int rc_ = atlas_init(g.device < 0 ? 0 : g.device);                 \
-            if (rc_) return rc_;                                               \
-        }                                                                      \
-    } while (0)
+}  // namespace atlas_rt
+using atlas_rt::fail;
+using atlas_rt::g;
+using atlas_rt::MAX_ROUNDS;
+using atlas_rt::PINNED_BYTES;
+
+namespace {
 
 ScConsts make_consts() {
     ScConsts K;

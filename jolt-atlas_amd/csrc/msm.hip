@@ -1,0 +1,279 @@
+// SRS handle, multi-scalar multiplication and one-hot commitment: host side + C-ABI.
+// Mirrors (paths under the jolt-atlas tree):
+//   SRS / KZGProverKey                 joltworks/src/poly/commitment/hyperkzg/kzg.rs:18-143
+//   VariableBaseMSM::{msm, msm_field_elements}   joltworks/src/msm/mod.rs:27-190
+//   UnivariateKZG::commit_as_univariate          kzg.rs:285-298
+//   HyperKZG::commit_one_hot                     hyperkzg/mod.rs:520-554
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "../../include/atlas_hip.h"
+#include "host_curve.hpp"
+#include "host_field.hpp"
+#include "msm_kernels.hip.h"
+#include "runtime.hpp"
+
+using namespace atlas;
+namespace H = atlas_host;
+using atlas_rt::fail;
+using atlas_rt::g;
+
+struct atlas_srs {
+    G1Affine* d = nullptr;
+    size_t len = 0;
+};
+
+struct atlas_poly {   // same definition as in atlas_hip.hip
+    void* d = nullptr;
+    size_t len = 0;
+    size_t cap_bytes = 0;
+    bool is_i32 = false;
+    bool owned = true;
+};
+
+namespace {
+
+// grow-only device workspace shared by MSM calls (serialised by g.mu)
+struct Workspace {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return ATLAS_OK;
+        if (p) hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(msm workspace)", e);
+        cap = bytes;
+        return ATLAS_OK;
+    }
+};
+Workspace ws;
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+MsmShape pick_shape(size_t n) {
+    MsmShape S;
+    // window width by problem size: bucket folding costs ~2 * n_windows * 2^(c-1) additions
+    S.c = n >= (1u << 18) ? 16 : n >= (1u << 13) ? 12 : n >= (1u << 8) ? 8 : 6;
+    S.n_windows = (255 + S.c - 1) / S.c;
+    S.bpw = 1u << (S.c - 1);
+    return S;
+}
+
+inline int grid_for(size_t work, int cap = 4096) {
+    size_t b = (work + MSM_THREADS - 1) / MSM_THREADS;
+    if (b < 1) b = 1;
+    if (b > (size_t)cap) b = cap;
+    return (int)b;
+}
+
+void to_out(const H::G1Aff& a, atlas_g1_affine_t* out) {
+    std::memcpy(out->x.l, a.x.l, 32);
+    std::memcpy(out->y.l, a.y.l, 32);
+    out->infinity = (H::q_is_zero(a.x) && H::q_is_zero(a.y)) ? 1 : 0;
+}
+
+// core: scalars are Montgomery Fr already on the device
+int msm_device(const G1Affine* bases, const Fr* d_scalars, size_t n, atlas_g1_affine_t* out) {
+    if (n == 0) { H::G1Aff z{H::q_zero(), H::q_zero()}; to_out(z, out); return ATLAS_OK; }
+    const MsmShape S = pick_shape(n);
+    const uint32_t TB = S.n_windows * S.bpw;
+    const uint32_t chunk = S.bpw < (uint32_t)MSM_CHUNK ? S.bpw : (uint32_t)MSM_CHUNK;
+    const uint32_t n_chunks = TB / chunk;
+    const uint32_t chunks_per_window = S.bpw / chunk;
+
+    // workspace carve-up
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_canon = carve(n * sizeof(Fr));
+    const size_t o_counts = carve((size_t)(TB + 1) * 4);
+    const size_t o_offsets = carve((size_t)(TB + 1) * 4);
+    const size_t o_cursor = carve((size_t)(TB + 1) * 4);
+    const size_t o_sorted = carve(n * (size_t)S.n_windows * 4);
+    const size_t o_buckets = carve((size_t)TB * sizeof(G1Xyzz));
+    const size_t o_chunks = carve((size_t)n_chunks * sizeof(G1Xyzz));
+    const size_t o_wsum = carve((size_t)S.n_windows * sizeof(G1Xyzz));
+    int rc = ws.ensure(off);
+    if (rc) return rc;
+    unsigned char* W = (unsigned char*)ws.p;
+    Fr* canon = (Fr*)(W + o_canon);
+    uint32_t* counts = (uint32_t*)(W + o_counts);
+    uint32_t* offsets = (uint32_t*)(W + o_offsets);
+    uint32_t* cursor = (uint32_t*)(W + o_cursor);
+    uint32_t* sorted = (uint32_t*)(W + o_sorted);
+    G1Xyzz* buckets = (G1Xyzz*)(W + o_buckets);
+    G1Xyzz* chunks = (G1Xyzz*)(W + o_chunks);
+    G1Xyzz* wsum = (G1Xyzz*)(W + o_wsum);
+
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+    if (g.timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2); hipEventCreate(&e3); hipEventRecord(e0, g.stream); }
+
+    HIP_TRY(hipMemsetAsync(counts, 0, (size_t)(TB + 1) * 4, g.stream));
+    k_msm_canon<<<grid_for(n), MSM_THREADS, 0, g.stream>>>(d_scalars, canon, n);
+    k_msm_hist<<<grid_for(n), MSM_THREADS, 0, g.stream>>>(canon, n, S, counts);
+    k_exclusive_scan<<<1, 1024, 0, g.stream>>>(counts, TB, offsets, cursor);
+    k_msm_scatter<<<grid_for(n), MSM_THREADS, 0, g.stream>>>(canon, n, S, cursor, sorted);
+    if (g.timing) hipEventRecord(e1, g.stream);
+    k_msm_accumulate<<<(TB + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, g.stream>>>(bases, sorted, offsets, TB, buckets);
+    if (g.timing) hipEventRecord(e2, g.stream);
+    k_msm_fold_chunks<<<(n_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, g.stream>>>(buckets, S, chunk, n_chunks, chunks);
+    k_g1_group_sum<<<S.n_windows, MSM_THREADS, 0, g.stream>>>(chunks, chunks_per_window, wsum);
+    if (g.timing) hipEventRecord(e3, g.stream);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail(ATLAS_ENODEV, "msm launch", le);
+
+    std::vector<H::G1X> hw(S.n_windows);
+    HIP_TRY(hipMemcpyAsync(hw.data(), wsum, S.n_windows * sizeof(G1Xyzz), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    // Horner over the windows: acc = 2^c * acc + W_w
+    H::G1X acc = hw[S.n_windows - 1];
+    for (int w = (int)S.n_windows - 2; w >= 0; w--) {
+        for (uint32_t k = 0; k < S.c; k++) acc = H::gx_dbl(acc);
+        acc = H::gx_add(acc, hw[w]);
+    }
+    to_out(H::gx_to_aff(acc), out);
+
+    if (g.timing) {
+        float a = 0, b = 0, c = 0;
+        hipEventElapsedTime(&a, e0, e1); hipEventElapsedTime(&b, e1, e2); hipEventElapsedTime(&c, e2, e3);
+        atlas_timing_t t{};
+        t.total_ms = a + b + c; t.pass_ms = b; t.fs_ms = a + c;
+        t.pass_bytes = (uint64_t)n * (sizeof(G1Affine) + sizeof(Fr));
+        t.n_pass = 1; t.n_fs = S.c;   // n_fs carries the window width for the caller
+        g.last_timing = t;
+        hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2); hipEventDestroy(e3);
+    }
+    return ATLAS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+static_assert(sizeof(atlas_g1_affine_t) == 72, "arkworks G1Affine image");
+
+int atlas_srs_upload(const void* bases, size_t n, size_t stride_bytes, atlas_srs_t* out) {
+    NEED_INIT();
+    if (!bases || !out || n == 0 || stride_bytes < 64) return fail(ATLAS_EINVAL, "srs_upload");
+    std::vector<G1Affine> tmp(n);
+    const unsigned char* p = (const unsigned char*)bases;
+    for (size_t i = 0; i < n; i++) {
+        std::memcpy(&tmp[i], p + i * stride_bytes, 64);
+        if (stride_bytes >= 65 && p[i * stride_bytes + 64]) std::memset(&tmp[i], 0, 64);   // infinity flag
+    }
+    atlas_srs* s = new atlas_srs();
+    hipError_t e = hipMalloc(&s->d, n * sizeof(G1Affine));
+    if (e != hipSuccess) { delete s; return fail(ATLAS_ENOMEM, "hipMalloc(srs)", e); }
+    s->len = n;
+    HIP_TRY(hipMemcpyAsync(s->d, tmp.data(), n * sizeof(G1Affine), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    *out = s;
+    return ATLAS_OK;
+}
+
+int atlas_srs_generate(const atlas_fr_t* tau, size_t n, atlas_srs_t* out) {
+    NEED_INIT();
+    if (!tau || !out || n == 0) return fail(ATLAS_EINVAL, "srs_generate");
+    std::lock_guard<std::mutex> lk(g.mu);
+    // tau^(2^j), j < 64 ; 2^j * G, j < 254 (host, O(1) work)
+    std::vector<H::Fr> tp(64);
+    std::memcpy(&tp[0], tau, 32);
+    for (int j = 1; j < 64; j++) tp[j] = H::mul(tp[j - 1], tp[j - 1]);
+    std::vector<H::G1Aff> dt(254);
+    H::G1X cur = H::gx_from_aff(H::G1Aff{H::q_from_u64(1), H::q_from_u64(2)});
+    for (int j = 0; j < 254; j++) { dt[j] = H::gx_to_aff(cur); cur = H::gx_dbl(cur); }
+    Fr* d_tp = nullptr; G1Affine* d_dt = nullptr;
+    HIP_TRY(hipMalloc(&d_tp, 64 * sizeof(Fr)));
+    HIP_TRY(hipMalloc(&d_dt, 254 * sizeof(G1Affine)));
+    HIP_TRY(hipMemcpyAsync(d_tp, tp.data(), 64 * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(d_dt, dt.data(), 254 * sizeof(G1Affine), hipMemcpyHostToDevice, g.stream));
+    atlas_srs* s = new atlas_srs();
+    hipError_t e = hipMalloc(&s->d, n * sizeof(G1Affine));
+    if (e != hipSuccess) { delete s; hipFree(d_tp); hipFree(d_dt); return fail(ATLAS_ENOMEM, "hipMalloc(srs)", e); }
+    s->len = n;
+    k_srs_generate<<<grid_for(n, 8192), MSM_THREADS, 0, g.stream>>>(d_tp, d_dt, n, s->d);
+    hipError_t se = hipStreamSynchronize(g.stream);
+    hipFree(d_tp); hipFree(d_dt);
+    if (se != hipSuccess) { hipFree(s->d); delete s; return fail(ATLAS_ENODEV, "srs_generate", se); }
+    *out = s;
+    return ATLAS_OK;
+}
+
+int atlas_srs_len(atlas_srs_t s, size_t* len) {
+    if (!s || !len) return fail(ATLAS_EINVAL, "srs_len");
+    *len = s->len;
+    return ATLAS_OK;
+}
+
+int atlas_srs_download(atlas_srs_t s, size_t offset, size_t n, atlas_g1_affine_t* out) {
+    NEED_INIT();
+    if (!s || !out || offset + n > s->len) return fail(ATLAS_EINVAL, "srs_download: range");
+    std::vector<G1Affine> tmp(n);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), s->d + offset, n * sizeof(G1Affine), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    for (size_t i = 0; i < n; i++) {
+        H::G1Aff a; std::memcpy(&a, &tmp[i], 64);
+        to_out(a, &out[i]);
+    }
+    return ATLAS_OK;
+}
+
+int atlas_srs_free(atlas_srs_t s) {
+    if (!s) return ATLAS_OK;
+    if (s->d) hipFree(s->d);
+    delete s;
+    return ATLAS_OK;
+}
+
+int atlas_msm_fr(atlas_srs_t srs, size_t offset, const atlas_fr_t* scalars, size_t n, atlas_g1_affine_t* out) {
+    NEED_INIT();
+    if (!srs || !out || (!scalars && n)) return fail(ATLAS_EINVAL, "msm_fr: null argument");
+    if (offset + n > srs->len)   // ProofVerifyError::KeyLengthError (msm/mod.rs:35-37)
+        return fail(ATLAS_EINVAL, "msm_fr: KeyLengthError (bases shorter than scalars)");
+    std::lock_guard<std::mutex> lk(g.mu);
+    Fr* d_s = nullptr;
+    if (n) {
+        HIP_TRY(hipMalloc(&d_s, n * sizeof(Fr)));
+        HIP_TRY(hipMemcpyAsync(d_s, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    }
+    int rc = msm_device(srs->d + offset, d_s, n, out);
+    if (d_s) hipFree(d_s);
+    return rc;
+}
+
+int atlas_msm_poly(atlas_srs_t srs, size_t offset, atlas_poly_t poly, atlas_g1_affine_t* out) {
+    NEED_INIT();
+    if (!srs || !poly || !out) return fail(ATLAS_EINVAL, "msm_poly: null argument");
+    if (poly->is_i32) return fail(ATLAS_EINVAL, "msm_poly: I32Scalars not supported yet (use LargeScalars)");
+    if (offset + poly->len > srs->len) return fail(ATLAS_EINVAL, "msm_poly: KeyLengthError (bases shorter than scalars)");
+    std::lock_guard<std::mutex> lk(g.mu);
+    return msm_device(srs->d + offset, (const Fr*)poly->d, poly->len, out);
+}
+
+int atlas_g1_sum_indexed(atlas_srs_t srs, const uint32_t* indices, size_t n, atlas_g1_affine_t* out) {
+    NEED_INIT();
+    if (!srs || !out || (!indices && n)) return fail(ATLAS_EINVAL, "g1_sum_indexed: null argument");
+    for (size_t i = 0; i < n; i++)
+        if (indices[i] >= srs->len) return fail(ATLAS_EINVAL, "g1_sum_indexed: KeyLengthError (index beyond the SRS)");
+    if (n == 0) { H::G1Aff z{H::q_zero(), H::q_zero()}; to_out(z, out); return ATLAS_OK; }
+    std::lock_guard<std::mutex> lk(g.mu);
+    const int grid = grid_for(n, 1024);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_idx = carve(n * 4), o_part = carve((size_t)grid * sizeof(G1Xyzz)), o_one = carve(sizeof(G1Xyzz));
+    int rc = ws.ensure(off);
+    if (rc) return rc;
+    unsigned char* W = (unsigned char*)ws.p;
+    HIP_TRY(hipMemcpyAsync(W + o_idx, indices, n * 4, hipMemcpyHostToDevice, g.stream));
+    k_g1_sum_indexed<<<grid, MSM_THREADS, 0, g.stream>>>(srs->d, (const uint32_t*)(W + o_idx), n, (G1Xyzz*)(W + o_part));
+    k_g1_group_sum<<<1, MSM_THREADS, 0, g.stream>>>((const G1Xyzz*)(W + o_part), (uint32_t)grid, (G1Xyzz*)(W + o_one));
+    H::G1X r;
+    HIP_TRY(hipMemcpyAsync(&r, W + o_one, sizeof(G1Xyzz), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    to_out(H::gx_to_aff(r), out);
+    return ATLAS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,206 @@
+// Pippenger (bucket method) multi-scalar multiplication on gfx950.
+//
+// Device replacement for the arkworks call behind VariableBaseMSM::msm
+// (joltworks/src/msm/mod.rs:27-181, called from UnivariateKZG::commit_* kzg.rs:195-298 and
+// HyperKZG::open hyperkzg/mod.rs:400-447), and for jolt_optimizations::batch_g1_additions_multi
+// behind HyperKZG::commit_one_hot (hyperkzg/mod.rs:520-554).
+//
+// Layout: bases are 64-byte affine points (x, y Montgomery Fq) resident in HBM (the SRS is
+// uploaded once and reused across proofs); scalars are the 32-byte Montgomery Fr image.
+// Signed c-bit windows; every (scalar, window) digit becomes one 4-byte entry
+// (index | sign<<31) that a counting sort (histogram -> exclusive scan -> scatter) groups
+// by bucket; one thread per bucket then streams its entries with mixed XYZZ additions;
+// buckets are folded by the running-sum method in chunks; the last O(windows) doublings and
+// the one inversion to affine run on the host.
+#pragma once
+#include "curve.hip.h"
+
+namespace atlas {
+
+constexpr int MSM_THREADS = 256;
+constexpr int MSM_CHUNK = 32;          // buckets folded by one thread in the reduce step
+
+struct MsmShape {
+    uint32_t c;          // window bits (<= 16)
+    uint32_t n_windows;  // ceil(255 / c)
+    uint32_t bpw;        // buckets per window = 2^(c-1)
+};
+
+// Montgomery Fr -> canonical integer limbs
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_canon(const Fr* __restrict__ s, Fr* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * MSM_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * MSM_THREADS)
+        fe_store(out + i, fe_from_mont<FrParams>(fe_load(s + i)));
+}
+
+// c-bit field of a 256-bit little-endian integer starting at bit `lo`
+__device__ __forceinline__ uint32_t bits_at(const uint32_t k[8], uint32_t lo, uint32_t c) {
+    const uint32_t w = lo >> 5, sh = lo & 31;
+    uint64_t v = k[w];
+    if (w + 1 < 8) v |= (uint64_t)k[w + 1] << 32;
+    return (uint32_t)(v >> sh) & ((1u << c) - 1u);
+}
+
+// Walk the signed digits of one scalar; F(window, bucket_in_window, negative)
+template <class F>
+__device__ __forceinline__ void for_each_digit(const Fr& k, const MsmShape S, F&& f) {
+    uint32_t carry = 0;
+    const uint32_t half = 1u << (S.c - 1);
+    for (uint32_t w = 0; w < S.n_windows; w++) {
+        const uint32_t lo = w * S.c;
+        uint32_t d = (lo < 256 ? bits_at(k.v, lo, S.c) : 0u) + carry;
+        carry = 0;
+        if (d > half) { d = (1u << S.c) - d; carry = 1; if (d) f(w, d - 1, true); }
+        else if (d) f(w, d - 1, false);
+    }
+}
+
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_hist(const Fr* __restrict__ canon, size_t n, MsmShape S,
+                                                          uint32_t* counts) {
+    for (size_t i = (size_t)blockIdx.x * MSM_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * MSM_THREADS) {
+        const Fr k = fe_load(canon + i);
+        for_each_digit(k, S, [&](uint32_t w, uint32_t b, bool) { atomicAdd(&counts[w * S.bpw + b], 1u); });
+    }
+}
+
+// exclusive scan of `n` counts into offsets[0..n] (offsets[n] = total) and a copy in cursor.
+// One workgroup of 1024 threads; n <= 1024 * per_thread.
+__global__ __launch_bounds__(1024) void k_exclusive_scan(const uint32_t* __restrict__ counts, uint32_t n,
+                                                         uint32_t* offsets, uint32_t* cursor) {
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t lo = t * per, hi = min(lo + per, n);
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; i++) s += counts[i];
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {      // Hillis-Steele inclusive scan
+        uint32_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = t ? part[t - 1] : 0;
+    for (uint32_t i = lo; i < hi; i++) {
+        offsets[i] = run; cursor[i] = run;
+        run += counts[i];
+    }
+    if (t == 1023) offsets[n] = part[1023];
+}
+
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_scatter(const Fr* __restrict__ canon, size_t n, MsmShape S,
+                                                             uint32_t* cursor, uint32_t* __restrict__ sorted) {
+    for (size_t i = (size_t)blockIdx.x * MSM_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * MSM_THREADS) {
+        const Fr k = fe_load(canon + i);
+        for_each_digit(k, S, [&](uint32_t w, uint32_t b, bool neg) {
+            const uint32_t pos = atomicAdd(&cursor[w * S.bpw + b], 1u);
+            sorted[pos] = (uint32_t)i | (neg ? 0x80000000u : 0u);
+        });
+    }
+}
+
+// one thread per bucket: stream its sorted entries with mixed additions
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_accumulate(const G1Affine* __restrict__ bases,
+                                                                const uint32_t* __restrict__ sorted,
+                                                                const uint32_t* __restrict__ offsets,
+                                                                uint32_t n_buckets, G1Xyzz* __restrict__ buckets) {
+    const uint32_t b = blockIdx.x * MSM_THREADS + threadIdx.x;
+    if (b >= n_buckets) return;
+    const uint32_t lo = offsets[b], hi = offsets[b + 1];
+    G1Xyzz acc = g1_inf();
+    for (uint32_t j = lo; j < hi; j++) {
+        const uint32_t v = sorted[j];
+        const G1Affine p = g1_aff_load(bases + (v & 0x7fffffffu));
+        if (g1_aff_is_inf(p)) continue;
+        acc = g1_madd(acc, p, (v >> 31) != 0);
+    }
+    g1_store(buckets + b, acc);
+}
+
+// small * P by double-and-add
+__device__ inline G1Xyzz g1_mul_small(const G1Xyzz& p, uint32_t s) {
+    G1Xyzz acc = g1_inf();
+    for (int i = 31 - __clz((int)(s | 1u)); i >= 0; i--) {
+        acc = g1_dbl(acc);
+        if ((s >> i) & 1u) acc = g1_add(acc, p);
+    }
+    return s ? acc : g1_inf();
+}
+
+// fold MSM_CHUNK buckets: sum_{k in chunk} (k+1) * B_k, k = index within the window
+// (bucket k holds digit magnitude k+1).  One thread per chunk.
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_fold_chunks(const G1Xyzz* __restrict__ buckets, MsmShape S,
+                                                                 uint32_t chunk, uint32_t n_chunks_total,
+                                                                 G1Xyzz* __restrict__ out) {
+    const uint32_t t = blockIdx.x * MSM_THREADS + threadIdx.x;
+    if (t >= n_chunks_total) return;
+    const uint32_t chunks_per_window = S.bpw / chunk;
+    const uint32_t w = t / chunks_per_window, j = t % chunks_per_window;
+    const G1Xyzz* base = buckets + (size_t)w * S.bpw + (size_t)j * chunk;
+    G1Xyzz run = g1_inf(), acc = g1_inf();
+    for (int k = (int)chunk - 1; k >= 0; k--) {
+        run = g1_add(run, g1_load(base + k));
+        acc = g1_add(acc, run);
+    }
+    // acc = sum (k_local + 1) B ; add (j*chunk) * run for the chunk's offset
+    acc = g1_add(acc, g1_mul_small(run, j * chunk));
+    g1_store(out + t, acc);
+}
+
+// sum groups of `per_group` points: one workgroup per group, tree in LDS
+__global__ __launch_bounds__(MSM_THREADS) void k_g1_group_sum(const G1Xyzz* __restrict__ pts, uint32_t per_group,
+                                                              G1Xyzz* __restrict__ out) {
+    __shared__ G1Xyzz sm[MSM_THREADS];
+    const G1Xyzz* base = pts + (size_t)blockIdx.x * per_group;
+    G1Xyzz acc = g1_inf();
+    for (uint32_t i = threadIdx.x; i < per_group; i += MSM_THREADS) acc = g1_add(acc, g1_load(base + i));
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t d = MSM_THREADS / 2; d >= 1; d >>= 1) {
+        if (threadIdx.x < d) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + d]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) g1_store(out + blockIdx.x, sm[0]);
+}
+
+// one-hot commit: sum of bases[idx[i]] — each thread folds a strided slice, then the
+// workgroup tree; one partial per workgroup (hyperkzg/mod.rs:520-554: T additions)
+__global__ __launch_bounds__(MSM_THREADS) void k_g1_sum_indexed(const G1Affine* __restrict__ bases,
+                                                                const uint32_t* __restrict__ idx, size_t n,
+                                                                G1Xyzz* __restrict__ out) {
+    __shared__ G1Xyzz sm[MSM_THREADS];
+    G1Xyzz acc = g1_inf();
+    for (size_t i = (size_t)blockIdx.x * MSM_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * MSM_THREADS) {
+        const G1Affine p = g1_aff_load(bases + idx[i]);
+        if (!g1_aff_is_inf(p)) acc = g1_madd(acc, p, false);
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t d = MSM_THREADS / 2; d >= 1; d >>= 1) {
+        if (threadIdx.x < d) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + d]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) g1_store(out + blockIdx.x, sm[0]);
+}
+
+// SRS generation (SRS::setup, hyperkzg/kzg.rs:26-93): out[i] = tau^(i+1) * G.
+// tau_pow2[j] = tau^(2^j) (Montgomery Fr), dbl_table[j] = 2^j * G (affine).
+__global__ __launch_bounds__(MSM_THREADS) void k_srs_generate(const Fr* __restrict__ tau_pow2,
+                                                              const G1Affine* __restrict__ dbl_table, size_t n,
+                                                              G1Affine* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * MSM_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * MSM_THREADS) {
+        uint64_t e = (uint64_t)i + 1;
+        Fr s = fr_one();
+        for (int j = 0; e; j++, e >>= 1)
+            if (e & 1) s = fr_mul(s, fe_load(tau_pow2 + j));
+        const Fr k = fe_from_mont<FrParams>(s);
+        G1Xyzz acc = g1_inf();
+        for (int b = 0; b < 254; b++)
+            if ((k.v[b >> 5] >> (b & 31)) & 1u) acc = g1_madd(acc, g1_aff_load(dbl_table + b), false);
+        const G1Affine a = g1_to_aff(acc);
+        fe_store(&out[i].x, a.x);
+        fe_store(&out[i].y, a.y);
+    }
+}
+
+}  // namespace atlas

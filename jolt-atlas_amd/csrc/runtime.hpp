@@ -1,0 +1,53 @@
+// Shared runtime state of libatlas_hip.so (one HIP stream, scratch buffers, last error).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+
+#include "../../include/atlas_hip.h"
+
+namespace atlas {
+struct Fe;
+struct ScCtx;
+}  // namespace atlas
+
+namespace atlas_rt {
+
+struct Runtime {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    int challenge_mode = 0;
+    bool timing = false;
+    atlas_timing_t last_timing{};
+    std::string err;
+    atlas::Fe* d_partials = nullptr;   // SC_MAX_BLOCKS * 3 Fr
+    atlas::ScCtx* d_ctx = nullptr;
+    atlas::Fe* d_proof = nullptr;      // up to 64 rounds * 3
+    uint64_t* d_chal = nullptr;        // up to 64 rounds * 2
+    atlas::Fe* d_finals = nullptr;     // 3 (+ scratch for reduced evals)
+    void* h_pinned = nullptr;          // pinned staging for small D2H/H2D
+    std::mutex mu;
+};
+extern Runtime g;
+
+constexpr size_t MAX_ROUNDS = 64;
+constexpr size_t PINNED_BYTES = 1 << 16;
+
+int fail(int code, const char* what, hipError_t e = hipSuccess);
+
+}  // namespace atlas_rt
+
+#define HIP_TRY(x)                                                             \
+    do {                                                                       \
+        hipError_t e_ = (x);                                                   \
+        if (e_ != hipSuccess) return atlas_rt::fail(ATLAS_ENODEV, #x, e_);     \
+    } while (0)
+#define NEED_INIT()                                                            \
+    do {                                                                       \
+        if (!atlas_rt::g.ready) {                                              \
+            int rc_ = atlas_init(atlas_rt::g.device < 0 ? 0 : atlas_rt::g.device); \
+            if (rc_) return rc_;                                               \
+        }                                                                      \
+    } while (0)

@@ -1,0 +1,191 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY (see bn254.h header note; parity unpinned).
+ * BN254 G1 (y^2 = x^3 + 3 over Fq) and multi-scalar multiplication.
+ *
+ * The reference calls arkworks for all of this (EXTERNAL, un-vendored):
+ *   VariableBaseMSM::msm            joltworks/src/msm/mod.rs:27-181  -> ark_ec Pippenger
+ *   batch_g1_additions_multi        joltworks/src/poly/commitment/hyperkzg/mod.rs:551,593
+ * A group element has a unique affine representative, so any correct algorithm yields the
+ * same (x, y) bytes; this file restates the published algorithms (Jacobian formulas
+ * add-2007-bl / dbl-2009-l, bucket-method MSM with arkworks' window heuristic). */
+#include "oracle.h"
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define Q (&ORC_FQ)
+
+static void fq_set_u64(uint64_t v, fq_t *o) { uint64_t c[4] = {v, 0, 0, 0}; fp_from_canonical(Q, c, o); }
+
+void g1_jac_set_inf(g1_jac_t *p) { memset(p, 0, sizeof *p); memcpy(p->x.l, Q->r, 32); memcpy(p->y.l, Q->r, 32); }
+int  g1_jac_is_inf(const g1_jac_t *p) { return fp_is_zero(&p->z); }
+
+void g1_generator(g1_aff_t *g) { fq_set_u64(1, &g->x); fq_set_u64(2, &g->y); g->inf = 0; }
+
+int g1_aff_on_curve(const g1_aff_t *p) {
+    if (p->inf) return 1;
+    fq_t y2, x3, b;
+    fp_sqr(Q, &p->y, &y2); fp_sqr(Q, &p->x, &x3); fp_mul(Q, &x3, &p->x, &x3);
+    fq_set_u64(3, &b); fp_add(Q, &x3, &b, &x3);
+    return fp_eq(&y2, &x3);
+}
+
+void g1_jac_from_aff(const g1_aff_t *a, g1_jac_t *o) {
+    if (a->inf) { g1_jac_set_inf(o); return; }
+    o->x = a->x; o->y = a->y; memcpy(o->z.l, Q->r, 32);
+}
+
+void g1_jac_dbl(const g1_jac_t *p, g1_jac_t *o) {       /* dbl-2009-l (a = 0) */
+    if (g1_jac_is_inf(p)) { *o = *p; return; }
+    fq_t A, B, C, D, E, F, t, X3, Y3, Z3;
+    fp_sqr(Q, &p->x, &A); fp_sqr(Q, &p->y, &B); fp_sqr(Q, &B, &C);
+    fp_add(Q, &p->x, &B, &t); fp_sqr(Q, &t, &t); fp_sub(Q, &t, &A, &t); fp_sub(Q, &t, &C, &t);
+    fp_add(Q, &t, &t, &D);
+    fp_add(Q, &A, &A, &E); fp_add(Q, &E, &A, &E);
+    fp_sqr(Q, &E, &F);
+    fp_sub(Q, &F, &D, &X3); fp_sub(Q, &X3, &D, &X3);
+    fp_sub(Q, &D, &X3, &t); fp_mul(Q, &E, &t, &Y3);
+    fp_add(Q, &C, &C, &t); fp_add(Q, &t, &t, &t); fp_add(Q, &t, &t, &t);
+    fp_sub(Q, &Y3, &t, &Y3);
+    fp_mul(Q, &p->y, &p->z, &Z3); fp_add(Q, &Z3, &Z3, &Z3);
+    o->x = X3; o->y = Y3; o->z = Z3;
+}
+
+void g1_jac_add(const g1_jac_t *p, const g1_jac_t *q, g1_jac_t *o) {   /* add-2007-bl */
+    if (g1_jac_is_inf(p)) { *o = *q; return; }
+    if (g1_jac_is_inf(q)) { *o = *p; return; }
+    fq_t Z1Z1, Z2Z2, U1, U2, S1, S2, H, I, J, r, V, t, X3, Y3, Z3;
+    fp_sqr(Q, &p->z, &Z1Z1); fp_sqr(Q, &q->z, &Z2Z2);
+    fp_mul(Q, &p->x, &Z2Z2, &U1); fp_mul(Q, &q->x, &Z1Z1, &U2);
+    fp_mul(Q, &p->y, &q->z, &S1); fp_mul(Q, &S1, &Z2Z2, &S1);
+    fp_mul(Q, &q->y, &p->z, &S2); fp_mul(Q, &S2, &Z1Z1, &S2);
+    if (fp_eq(&U1, &U2)) {
+        if (fp_eq(&S1, &S2)) { g1_jac_dbl(p, o); return; }
+        g1_jac_set_inf(o); return;
+    }
+    fp_sub(Q, &U2, &U1, &H);
+    fp_add(Q, &H, &H, &I); fp_sqr(Q, &I, &I);
+    fp_mul(Q, &H, &I, &J);
+    fp_sub(Q, &S2, &S1, &r); fp_add(Q, &r, &r, &r);
+    fp_mul(Q, &U1, &I, &V);
+    fp_sqr(Q, &r, &X3); fp_sub(Q, &X3, &J, &X3); fp_sub(Q, &X3, &V, &X3); fp_sub(Q, &X3, &V, &X3);
+    fp_sub(Q, &V, &X3, &t); fp_mul(Q, &r, &t, &Y3);
+    fp_mul(Q, &S1, &J, &t); fp_add(Q, &t, &t, &t); fp_sub(Q, &Y3, &t, &Y3);
+    fp_add(Q, &p->z, &q->z, &Z3); fp_sqr(Q, &Z3, &Z3); fp_sub(Q, &Z3, &Z1Z1, &Z3); fp_sub(Q, &Z3, &Z2Z2, &Z3);
+    fp_mul(Q, &Z3, &H, &Z3);
+    o->x = X3; o->y = Y3; o->z = Z3;
+}
+
+void g1_jac_add_aff(const g1_jac_t *p, const g1_aff_t *q, g1_jac_t *o) {
+    g1_jac_t qq; g1_jac_from_aff(q, &qq);
+    g1_jac_add(p, &qq, o);
+}
+
+void g1_jac_neg(const g1_jac_t *p, g1_jac_t *o) { *o = *p; fp_neg(Q, &p->y, &o->y); }
+
+void g1_jac_to_aff(const g1_jac_t *p, g1_aff_t *o) {
+    if (g1_jac_is_inf(p)) { memset(o, 0, sizeof *o); o->inf = 1; return; }
+    fq_t zi, zi2, zi3;
+    fp_inv(Q, &p->z, &zi); fp_sqr(Q, &zi, &zi2); fp_mul(Q, &zi2, &zi, &zi3);
+    fp_mul(Q, &p->x, &zi2, &o->x); fp_mul(Q, &p->y, &zi3, &o->y); o->inf = 0;
+}
+
+/* scalar given as canonical 4x64 integer */
+void g1_mul_canonical(const g1_aff_t *p, const uint64_t k[4], g1_jac_t *o) {
+    g1_jac_t acc; g1_jac_set_inf(&acc);
+    for (int i = 255; i >= 0; i--) {
+        g1_jac_dbl(&acc, &acc);
+        if ((k[i >> 6] >> (i & 63)) & 1) g1_jac_add_aff(&acc, p, &acc);
+    }
+    *o = acc;
+}
+
+void g1_mul_fr(const g1_aff_t *p, const fr_t *s, g1_aff_t *o) {
+    uint64_t k[4]; fp_to_canonical(&ORC_FR, s, k);
+    g1_jac_t r; g1_mul_canonical(p, k, &r); g1_jac_to_aff(&r, o);
+}
+
+/* naive MSM: sum_i s_i * P_i by double-and-add (small sizes; the ground truth) */
+void orc_msm_naive(const g1_aff_t *bases, const fr_t *scalars, size_t n, g1_aff_t *out) {
+    g1_jac_t acc; g1_jac_set_inf(&acc);
+    for (size_t i = 0; i < n; i++) {
+        uint64_t k[4]; fp_to_canonical(&ORC_FR, &scalars[i], k);
+        g1_jac_t t; g1_mul_canonical(&bases[i], k, &t);
+        g1_jac_add(&acc, &t, &acc);
+    }
+    g1_jac_to_aff(&acc, out);
+}
+
+/* bucket-method MSM (what arkworks' VariableBaseMSM::msm does): unsigned c-bit windows,
+ * c = ln(n) + 2 for n >= 32 else 3 (ark-ec variable_base/mod.rs heuristic), windows in
+ * parallel (Rayon there, OpenMP here), running-sum bucket reduction, Horner over windows. */
+void orc_msm_pippenger(const g1_aff_t *bases, const fr_t *scalars, size_t n, g1_aff_t *out) {
+    if (n == 0) { memset(out, 0, sizeof *out); out->inf = 1; return; }
+    unsigned c = n < 32 ? 3 : (unsigned)(log((double)n) * 69.0 / 100.0) + 2;   /* ln_without_floats */
+    const unsigned nbits = 254;
+    const unsigned nwin = (nbits + c - 1) / c;
+    uint64_t *canon = (uint64_t *)malloc(n * 32);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) fp_to_canonical(&ORC_FR, &scalars[i], canon + 4 * i);
+    g1_jac_t *wsum = (g1_jac_t *)malloc(nwin * sizeof(g1_jac_t));
+#pragma omp parallel for schedule(dynamic, 1)
+    for (unsigned w = 0; w < nwin; w++) {
+        const size_t nb = ((size_t)1 << c) - 1;
+        g1_jac_t *bk = (g1_jac_t *)malloc(nb * sizeof(g1_jac_t));
+        for (size_t b = 0; b < nb; b++) g1_jac_set_inf(&bk[b]);
+        const unsigned lo = w * c;
+        for (size_t i = 0; i < n; i++) {
+            const uint64_t *k = canon + 4 * i;
+            uint64_t d = k[lo >> 6] >> (lo & 63);
+            if ((lo & 63) + c > 64 && (lo >> 6) < 3) d |= k[(lo >> 6) + 1] << (64 - (lo & 63));
+            d &= ((uint64_t)1 << c) - 1;
+            if (d) g1_jac_add_aff(&bk[d - 1], &bases[i], &bk[d - 1]);
+        }
+        g1_jac_t run, res; g1_jac_set_inf(&run); g1_jac_set_inf(&res);
+        for (size_t b = nb; b-- > 0;) { g1_jac_add(&run, &bk[b], &run); g1_jac_add(&res, &run, &res); }
+        wsum[w] = res;
+        free(bk);
+    }
+    g1_jac_t acc = wsum[nwin - 1];
+    for (unsigned w = nwin - 1; w-- > 0;) {
+        for (unsigned k = 0; k < c; k++) g1_jac_dbl(&acc, &acc);
+        g1_jac_add(&acc, &wsum[w], &acc);
+    }
+    g1_jac_to_aff(&acc, out);
+    free(wsum); free(canon);
+}
+
+/* one-hot commit: sum of bases[idx[i]] (pure additions) — HyperKZG::commit_one_hot,
+ * hyperkzg/mod.rs:520-554 */
+void orc_g1_sum_indexed(const g1_aff_t *bases, const uint64_t *idx, size_t n, g1_aff_t *out) {
+    g1_jac_t acc; g1_jac_set_inf(&acc);
+    for (size_t i = 0; i < n; i++) g1_jac_add_aff(&acc, &bases[idx[i]], &acc);
+    g1_jac_to_aff(&acc, out);
+}
+
+/* SRS of this build: bases[i] = tau^(i+1) * G, G = (1, 2)  — the reference's
+ * layout (powers start at beta^1, kzg.rs:47-53) with tau supplied by the caller.
+ * Computed incrementally by scalar multiplication of the previous point (exact). */
+void orc_srs_powers(const fr_t *tau, size_t n, g1_aff_t *out) {
+    g1_aff_t g; g1_generator(&g);
+    fr_t pw = *tau;
+    /* independent scalar muls: out[i] = tau^(i+1) * G */
+    fr_t *pws = (fr_t *)malloc(n * sizeof(fr_t));
+    for (size_t i = 0; i < n; i++) { pws[i] = pw; fr_mul(&pw, tau, &pw); }
+#pragma omp parallel for schedule(dynamic, 64)
+    for (size_t i = 0; i < n; i++) g1_mul_fr(&g, &pws[i], &out[i]);
+    free(pws);
+}
+
+/* UniPoly::eval_as_univariate for LargeScalars (joltworks/src/poly/unipoly.rs:247-259):
+ * sum_i f[i] * r^i, serial power accumulation as in the reference. */
+void orc_eval_as_univariate(const fr_t *f, size_t n, const fr_t *r, fr_t *out) {
+    fr_t ev = f[0], pw = *r;
+    for (size_t i = 1; i < n; i++) {
+        fr_t t; fr_mul(&pw, &f[i], &t); fr_add(&ev, &t, &ev);
+        fr_mul(&pw, r, &pw);
+    }
+    *out = ev;
+}

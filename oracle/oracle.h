@@ -71,6 +71,28 @@ void orc_dot_claim(const fr_t *l, const fr_t *r, const fr_t *eq, size_t len, int
                    size_t sched_a, size_t sched_b, fr_t *out);
 int  orc_num_threads(void);
 
+/* ---- BN254 G1 + MSM (arkworks, EXTERNAL to the reference tree; call sites
+ *      joltworks/src/msm/mod.rs:27-181, hyperkzg/mod.rs:520-596, kzg.rs:195-298) ---- */
+typedef struct { fq_t x, y; uint64_t inf; } g1_aff_t;   /* 72 bytes: the arkworks G1Affine image */
+typedef struct { fq_t x, y, z; } g1_jac_t;
+void g1_generator(g1_aff_t *g);
+int  g1_aff_on_curve(const g1_aff_t *p);
+void g1_jac_set_inf(g1_jac_t *p);
+int  g1_jac_is_inf(const g1_jac_t *p);
+void g1_jac_from_aff(const g1_aff_t *a, g1_jac_t *o);
+void g1_jac_dbl(const g1_jac_t *p, g1_jac_t *o);
+void g1_jac_add(const g1_jac_t *p, const g1_jac_t *q, g1_jac_t *o);
+void g1_jac_add_aff(const g1_jac_t *p, const g1_aff_t *q, g1_jac_t *o);
+void g1_jac_neg(const g1_jac_t *p, g1_jac_t *o);
+void g1_jac_to_aff(const g1_jac_t *p, g1_aff_t *o);
+void g1_mul_canonical(const g1_aff_t *p, const uint64_t k[4], g1_jac_t *o);
+void g1_mul_fr(const g1_aff_t *p, const fr_t *s, g1_aff_t *o);
+void orc_msm_naive(const g1_aff_t *bases, const fr_t *scalars, size_t n, g1_aff_t *out);
+void orc_msm_pippenger(const g1_aff_t *bases, const fr_t *scalars, size_t n, g1_aff_t *out);
+void orc_g1_sum_indexed(const g1_aff_t *bases, const uint64_t *idx, size_t n, g1_aff_t *out);
+void orc_srs_powers(const fr_t *tau, size_t n, g1_aff_t *out);
+void orc_eval_as_univariate(const fr_t *f, size_t n, const fr_t *r, fr_t *out);   /* unipoly.rs:247-259 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -178,6 +178,65 @@ def challenge_to_fr(c128):
     return out
 
 
+G1_DTYPE = np.dtype([("x", np.uint64, (4,)), ("y", np.uint64, (4,)), ("infinity", np.uint64)])  # g1_aff_t
+
+
+def srs_powers(tau_fr, n):
+    """bases[i] = tau^(i+1) * G as a G1_DTYPE array (orc_srs_powers)."""
+    out = np.zeros(n, dtype=G1_DTYPE)
+    t = np.ascontiguousarray(tau_fr, dtype=np.uint64).reshape(1, 4)
+    lib.orc_srs_powers(_p(t), C.c_size_t(n), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def msm(bases, scalars, naive=False):
+    bases = np.ascontiguousarray(bases, dtype=G1_DTYPE)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros(1, dtype=G1_DTYPE)
+    fn = lib.orc_msm_naive if naive else lib.orc_msm_pippenger
+    fn(bases.ctypes.data_as(C.c_void_p), _p(scalars), C.c_size_t(len(scalars)), out.ctypes.data_as(C.c_void_p))
+    return out[0]
+
+
+def g1_mul_generator(k_fr):
+    """k * G for a Montgomery Fr scalar."""
+    g = np.zeros(1, dtype=G1_DTYPE)
+    lib.g1_generator(g.ctypes.data_as(C.c_void_p))
+    out = np.zeros(1, dtype=G1_DTYPE)
+    k = np.ascontiguousarray(k_fr, dtype=np.uint64).reshape(1, 4)
+    lib.g1_mul_fr(g.ctypes.data_as(C.c_void_p), _p(k), out.ctypes.data_as(C.c_void_p))
+    return out[0]
+
+
+def g1_sum_indexed(bases, idx):
+    bases = np.ascontiguousarray(bases, dtype=G1_DTYPE)
+    idx = np.ascontiguousarray(idx, dtype=np.uint64)
+    out = np.zeros(1, dtype=G1_DTYPE)
+    lib.orc_g1_sum_indexed(bases.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(u64p), C.c_size_t(len(idx)),
+                           out.ctypes.data_as(C.c_void_p))
+    return out[0]
+
+
+def g1_eq(a, b):
+    if int(a["infinity"]) or int(b["infinity"]):
+        return bool(int(a["infinity"])) == bool(int(b["infinity"]))
+    return np.array_equal(a["x"], b["x"]) and np.array_equal(a["y"], b["y"])
+
+
+def fr_mul_arr(a, b):
+    out = fr_array(1)
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(1, 4); b = np.ascontiguousarray(b, dtype=np.uint64).reshape(1, 4)
+    lib.fr_mul(_p(a), _p(b), _p(out))
+    return out[0]
+
+
+def fr_add_arr(a, b):
+    out = fr_array(1)
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(1, 4); b = np.ascontiguousarray(b, dtype=np.uint64).reshape(1, 4)
+    lib.fr_add(_p(a), _p(b), _p(out))
+    return out[0]
+
+
 def serialize_proof(proof):
     """ark CanonicalSerialize bytes of SumcheckInstanceProof."""
     n_rounds, deg = proof.shape[0], proof.shape[1]
