@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n-vars", type=int, default=N_VARS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-msm", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -200,6 +201,31 @@ def main():
                      "bytes_per_step": int(tm.pass_bytes), "pass_ms": tm.pass_ms, "fs_ms": tm.fs_ms,
                      "instrumented_total_ms": tm.total_ms},
     }
+    # second leg: the HyperKZG MSM of the same size (2^n_vars points, full-width scalars),
+    # reported beside the sumcheck line; bases = tau^(i+1) G resident in HBM.
+    if not args.no_msm:
+        for p, q in sets:
+            p.free(); q.free()
+        tau = A.random_fr(1, 0x51250001)[0]
+        srs = A.SRS.generate(tau, 1 << n_vars)
+        scal = A.MultilinearPolynomial.from_fr(A.random_fr(1 << n_vars, 0x5CA1A5 + n_vars + 7919 * rank))
+        msm_steps = max(1, min(args.steps, 5))
+        pts = {}
+
+        def msm_step(i):
+            pts[i] = srs.msm(scal)
+
+        dt_m = timed_steps(msm_step, msm_steps, 1, sync, barrier, allreduce_max)
+        assert all(np.array_equal(pts[i]["x"], pts[0]["x"]) for i in pts), "non-deterministic MSM"
+        A.set_timing(True)
+        srs.msm(scal)
+        tmm = A.last_timing()
+        A.set_timing(False)
+        out["msm"] = {"points": 1 << n_vars, "scalar_bits": 254, "window_bits": int(tmm.n_fs),
+                      "ms_per_msm": dt_m * 1e3 / msm_steps, "points_per_s": world * (1 << n_vars) * msm_steps / dt_m,
+                      "steps": msm_steps, "bucket_accumulate_ms": tmm.pass_ms, "sort_and_fold_ms": tmm.fs_ms,
+                      "compulsory_GBps": tmm.pass_bytes / (tmm.total_ms * 1e-3) / 1e9 if tmm.total_ms > 0 else 0.0,
+                      "compulsory_bytes": int(tmm.pass_bytes)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n_vars)
     if rank == 0:

@@ -149,6 +149,9 @@ int atlas_msm_poly(atlas_srs_t srs, size_t offset, atlas_poly_t poly, atlas_g1_a
  * passes the flat indices k*T + t of the non-zero coefficients; replaces
  * jolt_optimizations::batch_g1_additions_multi */
 int atlas_g1_sum_indexed(atlas_srs_t srs, const uint32_t *indices, size_t n, atlas_g1_affine_t *out);
+/* Transcript::append_point / append_points (blake2b.rs:166-195), host side */
+int atlas_transcript_append_point(atlas_transcript_t *t, const atlas_g1_affine_t *p);
+int atlas_transcript_append_points(atlas_transcript_t *t, const atlas_g1_affine_t *p, size_t n);
 
 /* ---- measurement: HIP-event time of the launches issued by the last
  *      atlas_sumcheck_prove_dot / atlas_msm_* call, on the library stream ------------- */

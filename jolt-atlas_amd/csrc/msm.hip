@@ -150,9 +150,38 @@ int msm_device(const G1Affine* bases, const Fr* d_scalars, size_t n, atlas_g1_af
 
 }  // namespace
 
+// Transcript::append_point (blake2b.rs:166-187) on the host transcript
+static void host_append_point(H::Transcript& T, const atlas_g1_affine_t* p) {
+    uint8_t buf[64];
+    if (p->infinity) { std::memset(buf, 0, 64); H::tr_append_bytes(T, buf, 64); return; }
+    H::Fq x, y, one{{1, 0, 0, 0}};
+    std::memcpy(x.l, p->x.l, 32); std::memcpy(y.l, p->y.l, 32);
+    H::Fq cx = H::q_mul(x, one), cy = H::q_mul(y, one);       // canonical integers
+    for (int i = 0; i < 32; i++) {
+        buf[31 - i] = (uint8_t)(cx.l[i >> 3] >> (8 * (i & 7)));
+        buf[63 - i] = (uint8_t)(cy.l[i >> 3] >> (8 * (i & 7)));
+    }
+    H::tr_append_bytes(T, buf, 64);
+}
+
 extern "C" {
 
 static_assert(sizeof(atlas_g1_affine_t) == 72, "arkworks G1Affine image");
+
+int atlas_transcript_append_point(atlas_transcript_t* t, const atlas_g1_affine_t* p) {
+    if (!t || !p) return fail(ATLAS_EINVAL, "append_point");
+    host_append_point(*reinterpret_cast<H::Transcript*>(t), p);
+    return ATLAS_OK;
+}
+
+int atlas_transcript_append_points(atlas_transcript_t* t, const atlas_g1_affine_t* p, size_t n) {
+    if (!t || (!p && n)) return fail(ATLAS_EINVAL, "append_points");
+    H::Transcript& T = *reinterpret_cast<H::Transcript*>(t);
+    H::tr_append_message(T, "begin_append_vector");
+    for (size_t i = 0; i < n; i++) host_append_point(T, &p[i]);
+    H::tr_append_message(T, "end_append_vector");
+    return ATLAS_OK;
+}
 
 int atlas_srs_upload(const void* bases, size_t n, size_t stride_bytes, atlas_srs_t* out) {
     NEED_INIT();

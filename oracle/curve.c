@@ -189,3 +189,22 @@ void orc_eval_as_univariate(const fr_t *f, size_t n, const fr_t *r, fr_t *out) {
     }
     *out = ev;
 }
+
+/* Transcript::append_point / append_points (joltworks/src/transcripts/blake2b.rs:166-195):
+ * identity -> 64 zero bytes; else one hash over x_be32 || y_be32 (affine, canonical). */
+void orc_transcript_append_point(orc_transcript *t, const g1_aff_t *p) {
+    uint8_t buf[64];
+    if (p->inf) { memset(buf, 0, 64); orc_transcript_append_bytes(t, buf, 64); return; }
+    uint64_t c[4];
+    fp_to_canonical(Q, &p->x, c);
+    for (int i = 0; i < 32; i++) buf[31 - i] = (uint8_t)(c[i >> 3] >> (8 * (i & 7)));
+    fp_to_canonical(Q, &p->y, c);
+    for (int i = 0; i < 32; i++) buf[63 - i] = (uint8_t)(c[i >> 3] >> (8 * (i & 7)));
+    orc_transcript_append_bytes(t, buf, 64);
+}
+
+void orc_transcript_append_points(orc_transcript *t, const g1_aff_t *p, size_t n) {
+    orc_transcript_append_message(t, "begin_append_vector");
+    for (size_t i = 0; i < n; i++) orc_transcript_append_point(t, &p[i]);
+    orc_transcript_append_message(t, "end_append_vector");
+}

@@ -91,6 +91,8 @@ void orc_msm_naive(const g1_aff_t *bases, const fr_t *scalars, size_t n, g1_aff_
 void orc_msm_pippenger(const g1_aff_t *bases, const fr_t *scalars, size_t n, g1_aff_t *out);
 void orc_g1_sum_indexed(const g1_aff_t *bases, const uint64_t *idx, size_t n, g1_aff_t *out);
 void orc_srs_powers(const fr_t *tau, size_t n, g1_aff_t *out);
+void orc_transcript_append_point(orc_transcript *t, const g1_aff_t *p);   /* blake2b.rs:166-187 */
+void orc_transcript_append_points(orc_transcript *t, const g1_aff_t *p, size_t n);
 void orc_eval_as_univariate(const fr_t *f, size_t n, const fr_t *r, fr_t *out);   /* unipoly.rs:247-259 */
 
 #ifdef __cplusplus
