@@ -149,6 +149,16 @@ int atlas_msm_poly(atlas_srs_t srs, size_t offset, atlas_poly_t poly, atlas_g1_a
  * passes the flat indices k*T + t of the non-zero coefficients; replaces
  * jolt_optimizations::batch_g1_additions_multi */
 int atlas_g1_sum_indexed(atlas_srs_t srs, const uint32_t *indices, size_t n, atlas_g1_affine_t *out);
+/* HyperKZG::open (joltworks/src/poly/commitment/hyperkzg/mod.rs:400-447, the body of
+ * CommitmentScheme::prove, commitment_scheme.rs:93-108): ell-1 folds, their commitments,
+ * the 3*ell univariate evaluations, the batched witness polynomials and their 3
+ * commitments, with the transcript interaction of the reference.  `poly` = LargeScalars of
+ * length 2^ell (not consumed); `point` = the ell opening-point challenges (raw u128).
+ *   com : ell-1 points    w : 3 points    v : 3*ell Fr, v[i*ell + j] = Pi_j(u_i)
+ * (HyperKZGProof { com, w, v }, hyperkzg/mod.rs:168-173). */
+int atlas_hyperkzg_open(atlas_srs_t srs, atlas_poly_t poly, const atlas_u128_t *point, size_t ell,
+                        atlas_transcript_t *transcript, atlas_g1_affine_t *com, atlas_g1_affine_t *w,
+                        atlas_fr_t *v);
 /* Transcript::append_point / append_points (blake2b.rs:166-195), host side */
 int atlas_transcript_append_point(atlas_transcript_t *t, const atlas_g1_affine_t *p);
 int atlas_transcript_append_points(atlas_transcript_t *t, const atlas_g1_affine_t *p, size_t n);

@@ -351,3 +351,25 @@ class SRS:
         if self.h:
             lib.atlas_srs_free(self.h)
             self.h = None
+
+
+class HyperKZG:
+    """CommitmentScheme arithmetic for HyperKZG (commitment_scheme.rs:11-131)."""
+
+    @staticmethod
+    def commit(srs: SRS, poly: MultilinearPolynomial):
+        """HyperKZG::commit for a dense polynomial = commit_as_univariate (kzg.rs:285-298)."""
+        return srs.msm(poly)
+
+    @staticmethod
+    def open(srs: SRS, poly: MultilinearPolynomial, point_u128, transcript: Blake2bTranscript):
+        """HyperKZG::open. Returns (com (ell-1,), w (3,), v (3, ell, 4))."""
+        ell = len(point_u128)
+        pts = (U128 * ell)(*[U128(c & ((1 << 64) - 1), c >> 64) for c in point_u128])
+        com = np.zeros(max(ell - 1, 1), dtype=G1_DTYPE)
+        w = np.zeros(3, dtype=G1_DTYPE)
+        v = np.zeros((3 * ell, 4), dtype=np.uint64)
+        lib.atlas_hyperkzg_open.restype = C.c_int
+        _check(lib.atlas_hyperkzg_open(srs.h, poly.h, pts, C.c_size_t(ell), C.byref(transcript.t),
+                                       com.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), _p(v)))
+        return com[:ell - 1], w, v.reshape(3, ell, 4)

@@ -12,6 +12,7 @@
 #include "../../include/atlas_hip.h"
 #include "host_curve.hpp"
 #include "host_field.hpp"
+#include "hyperkzg_kernels.hip.h"
 #include "msm_kernels.hip.h"
 #include "runtime.hpp"
 
@@ -302,6 +303,111 @@ int atlas_g1_sum_indexed(atlas_srs_t srs, const uint32_t* indices, size_t n, atl
     HIP_TRY(hipMemcpyAsync(&r, W + o_one, sizeof(G1Xyzz), hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
     to_out(H::gx_to_aff(r), out);
+    return ATLAS_OK;
+}
+
+// ------------------------------------------------------------------ HyperKZG::open
+// hyperkzg/mod.rs:400-447 + kzg_open_batch :231-280.  poly is not consumed.
+//   com : ell-1 commitments to the folded polynomials Pi_1..Pi_{ell-1}
+//   w   : 3 witness commitments,  v : 3*ell evaluations, v[i*ell + j] = Pi_j(u_i)
+int atlas_hyperkzg_open(atlas_srs_t srs, atlas_poly_t poly, const atlas_u128_t* point, size_t ell,
+                        atlas_transcript_t* transcript, atlas_g1_affine_t* com, atlas_g1_affine_t* w, atlas_fr_t* v) {
+    NEED_INIT();
+    if (!srs || !poly || !point || !transcript || !w || !v || ell == 0 || ell > 30 || (!com && ell > 1))
+        return fail(ATLAS_EINVAL, "hyperkzg_open: bad argument");
+    const size_t n = (size_t)1 << ell;
+    if (poly->is_i32 || poly->len != n) return fail(ATLAS_EINVAL, "hyperkzg_open: poly must be LargeScalars of length 2^ell");
+    if (srs->len < n) return fail(ATLAS_EINVAL, "hyperkzg_open: KeyLengthError (SRS shorter than the polynomial)");
+    std::lock_guard<std::mutex> lk(g.mu);
+    H::Transcript& T = *reinterpret_cast<H::Transcript*>(transcript);
+    const int mode = g.challenge_mode;
+
+    // one buffer for Pi_0..Pi_{ell-1} (2n - 2 coefficients), B, and the three h_k
+    Fr *polys = nullptr, *B = nullptr, *h = nullptr, *scr = nullptr;
+    const size_t n_blocks = (n + HK_BLOCK - 1) / HK_BLOCK;
+    HIP_TRY(hipMalloc(&polys, 2 * n * sizeof(Fr)));
+    HIP_TRY(hipMalloc(&B, n * sizeof(Fr)));
+    HIP_TRY(hipMalloc(&h, 3 * n * sizeof(Fr)));
+    // scratch: xincl 3*(n_blocks*256) | blocktot 3*n_blocks | G 3*n_blocks | total 3 | pw16 3*257 | q ell
+    const size_t xs = n_blocks * HK_THREADS;
+    const size_t scr_elems = 3 * xs + 6 * n_blocks + 3 + 3 * 257 + ell;
+    HIP_TRY(hipMalloc(&scr, scr_elems * sizeof(Fr)));
+    Fr* xincl = scr; Fr* blocktot = xincl + 3 * xs; Fr* G = blocktot + 3 * n_blocks; Fr* total = G + 3 * n_blocks;
+    Fr* pw16 = total + 3; Fr* dq = pw16 + 3 * 257;
+    auto cleanup = [&]() { hipFree(polys); hipFree(B); hipFree(h); hipFree(scr); };
+
+    // Phase 1: folds (LowToHigh, variable point[ell-i-1])
+    HIP_TRY(hipMemcpyAsync(polys, poly->d, n * sizeof(Fr), hipMemcpyDeviceToDevice, g.stream));
+    {
+        size_t off = 0, len = n;
+        for (size_t i = 0; i + 1 < ell; i++) {
+            H::Fr x = H::challenge_to_fr(point[ell - i - 1].lo, point[ell - i - 1].hi, mode);
+            Fr xd; std::memcpy(xd.v, x.l, 32);
+            k_hk_fold<<<grid_for(len / 2, 2048), HK_THREADS, 0, g.stream>>>(polys + off, polys + off + len, len / 2, xd, mode == 0);
+            off += len; len >>= 1;
+        }
+    }
+    // commitments to Pi_1.. (commit_variable_batch, kzg.rs:227-243)
+    {
+        size_t off = n, len = n >> 1;
+        for (size_t i = 1; i < ell; i++) {
+            int rc = msm_device(srs->d, polys + off, len, &com[i - 1]);
+            if (rc) { cleanup(); return rc; }
+            off += len; len >>= 1;
+        }
+    }
+    // Phase 2: transcript, r, u = [r, -r, r^2]
+    H::tr_append_message(T, "begin_append_vector");
+    for (size_t i = 0; i + 1 < ell; i++) host_append_point(T, &com[i]);
+    H::tr_append_message(T, "end_append_vector");
+    const H::Fr r = H::tr_challenge_scalar(T);
+    const H::Fr u[3] = {r, H::neg(r), H::mul(r, r)};
+    HkPowers P;
+    std::vector<H::Fr> hpw16(3 * 257);
+    for (int k = 0; k < 3; k++) {
+        H::Fr c = u[k];
+        for (int b = 0; b < 32; b++) { std::memcpy(P.p2[k][b].v, c.l, 32); c = H::mul(c, c); }
+        H::Fr u16; std::memcpy(u16.l, P.p2[k][4].v, 32);
+        H::Fr acc = H::one();
+        for (int j = 0; j <= 256; j++) { hpw16[k * 257 + j] = acc; acc = H::mul(acc, u16); }
+    }
+    HIP_TRY(hipMemcpyAsync(pw16, hpw16.data(), 3 * 257 * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    // Phase 3a: v[i][j] = Pi_j(u_i)
+    std::vector<H::Fr> hv(3 * ell);
+    {
+        size_t off = 0, len = n;
+        for (size_t j = 0; j < ell; j++) {
+            const size_t nb = (len + HK_BLOCK - 1) / HK_BLOCK;
+            k_hk_scan_blocks<<<(unsigned)nb, HK_THREADS, 0, g.stream>>>(polys + off, len, P, nullptr, 0, blocktot, nb);
+            k_hk_scan_grid<<<1, HK_THREADS, 0, g.stream>>>(blocktot, nb, P, G, total);
+            HIP_TRY(hipMemcpyAsync(g.h_pinned, total, 3 * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+            HIP_TRY(hipStreamSynchronize(g.stream));
+            for (int k = 0; k < 3; k++) std::memcpy(&hv[k * ell + j], (unsigned char*)g.h_pinned + k * sizeof(Fr), sizeof(Fr));
+            off += len; len >>= 1;
+        }
+    }
+    std::memcpy(v, hv.data(), 3 * ell * sizeof(Fr));
+    H::tr_append_scalars(T, hv.data(), 3 * ell);
+    // q powers (challenge_scalar_powers, blake2b.rs:224-231), B = sum q^j Pi_j
+    std::vector<H::Fr> q(ell);
+    { H::Fr q1 = H::tr_challenge_scalar(T); q[0] = H::one(); for (size_t j = 1; j < ell; j++) q[j] = H::mul(q[j - 1], q1); }
+    HIP_TRY(hipMemcpyAsync(dq, q.data(), ell * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    k_hk_lincomb<<<grid_for(n, 2048), HK_THREADS, 0, g.stream>>>(polys, n, (uint32_t)ell, dq, B);
+    // Phase 3b: witness polynomials h_k = B / (x - u_k) and their commitments
+    k_hk_scan_blocks<<<(unsigned)n_blocks, HK_THREADS, 0, g.stream>>>(B, n, P, xincl, xs, blocktot, n_blocks);
+    k_hk_scan_grid<<<1, HK_THREADS, 0, g.stream>>>(blocktot, n_blocks, P, G, total);
+    k_hk_witness<<<(unsigned)n_blocks, HK_THREADS, 0, g.stream>>>(B, n, P, xincl, xs, G, n_blocks, pw16, h, n);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { cleanup(); return fail(ATLAS_ENODEV, "hyperkzg launch", le); }
+    for (int k = 0; k < 3; k++) {
+        int rc = msm_device(srs->d, h + (size_t)k * n, n, &w[k]);
+        if (rc) { cleanup(); return rc; }
+    }
+    H::tr_append_message(T, "begin_append_vector");
+    for (int k = 0; k < 3; k++) host_append_point(T, &w[k]);
+    H::tr_append_message(T, "end_append_vector");
+    (void)H::tr_challenge_scalar(T);      // d_0: keeps the transcript in step with the verifier (:276-277)
+    cleanup();
     return ATLAS_OK;
 }
 

@@ -208,3 +208,94 @@ void orc_transcript_append_points(orc_transcript *t, const g1_aff_t *p, size_t n
     for (size_t i = 0; i < n; i++) orc_transcript_append_point(t, &p[i]);
     orc_transcript_append_message(t, "end_append_vector");
 }
+
+/* ---------------------------------------------------------------- HyperKZG
+ * HyperKZG::open (joltworks/src/poly/commitment/hyperkzg/mod.rs:400-447), kzg_open_batch
+ * (:231-280), compute_witness_polynomial (:213-229), DensePolynomial::linear_combination
+ * (dense_mlpoly.rs:444-499).  srs[i] = g1_powers[i].  point = the ell MontU128Challenge
+ * values as Fr.  Outputs: com[ell-1], w[3], v[3*ell] (v[i*ell + j] = f_j(u_i)). */
+int orc_hyperkzg_open(const g1_aff_t *srs, const fr_t *poly, size_t ell, const fr_t *point,
+                      orc_transcript *t, g1_aff_t *com, g1_aff_t *w, fr_t *v) {
+    const size_t n = (size_t)1 << ell;
+    /* Phase 1: polys[i+1][j] = point[ell-i-1]*(p[2j+1]-p[2j]) + p[2j]   (:413-428) */
+    fr_t **polys = (fr_t **)malloc(ell * sizeof(fr_t *));
+    polys[0] = (fr_t *)malloc(n * sizeof(fr_t)); memcpy(polys[0], poly, n * sizeof(fr_t));
+    for (size_t i = 0; i + 1 < ell; i++) {
+        size_t len = n >> (i + 1);
+        polys[i + 1] = (fr_t *)malloc(len * sizeof(fr_t));
+        for (size_t j = 0; j < len; j++) {
+            fr_t d; fr_sub(&polys[i][2 * j + 1], &polys[i][2 * j], &d);
+            fr_mul(&point[ell - i - 1], &d, &d);
+            fr_add(&d, &polys[i][2 * j], &polys[i + 1][j]);
+        }
+    }
+    for (size_t i = 1; i < ell; i++) orc_msm_pippenger(srs, polys[i], n >> i, &com[i - 1]);   /* :434 */
+    /* Phase 2 (:439-441) */
+    orc_transcript_append_points(t, com, ell - 1);
+    fr_t r, u[3]; orc_transcript_challenge_scalar(t, &r);
+    u[0] = r; fr_neg(&r, &u[1]); fr_mul(&r, &r, &u[2]);
+    /* Phase 3: kzg_open_batch */
+    for (size_t i = 0; i < 3; i++)
+        for (size_t j = 0; j < ell; j++) orc_eval_as_univariate(polys[j], n >> j, &u[i], &v[i * ell + j]);
+    orc_transcript_append_scalars(t, v, 3 * ell);
+    fr_t *q = (fr_t *)malloc(ell * sizeof(fr_t));            /* challenge_scalar_powers (blake2b.rs:224-231) */
+    { fr_t q1; orc_transcript_challenge_scalar(t, &q1); fr_one(&q[0]); for (size_t j = 1; j < ell; j++) fr_mul(&q[j - 1], &q1, &q[j]); }
+    fr_t *B = (fr_t *)calloc(n, sizeof(fr_t));
+    for (size_t j = 0; j < ell; j++)
+        for (size_t i = 0; i < (n >> j); i++) { fr_t m; fr_mul(&polys[j][i], &q[j], &m); fr_add(&B[i], &m, &B[i]); }
+    fr_t *h = (fr_t *)malloc(n * sizeof(fr_t));
+    for (size_t k = 0; k < 3; k++) {
+        fr_zero(&h[n - 1]);
+        for (size_t i = n - 1; i >= 1; i--) { fr_t m; fr_mul(&h[i], &u[k], &m); fr_add(&B[i], &m, &h[i - 1]); }
+        orc_msm_pippenger(srs, h, n, &w[k]);
+    }
+    orc_transcript_append_points(t, w, 3);
+    fr_t d0; orc_transcript_challenge_scalar(t, &d0);
+    for (size_t i = 0; i < ell; i++) free(polys[i]);
+    free(polys); free(q); free(B); free(h);
+    return 0;
+}
+
+/* verify_inner (:451-509) + kzg_verify_batch (:283-366) with the pairing check
+ * e(L, H) == e(R, tau*H) replaced by L == tau*R (known-trapdoor SRS).  Returns 1 = accept. */
+int orc_hyperkzg_verify_trapdoor(const g1_aff_t *srs, const fr_t *tau, const g1_aff_t *C, size_t ell,
+                                 const fr_t *point, const fr_t *y, const g1_aff_t *com, const g1_aff_t *w,
+                                 const fr_t *v, orc_transcript *t) {
+    orc_transcript_append_points(t, com, ell - 1);
+    fr_t r; orc_transcript_challenge_scalar(t, &r);
+    if (fp_is_zero(&r) || C->inf) return 0;
+    fr_t u[3]; u[0] = r; fr_neg(&r, &u[1]); fr_mul(&r, &r, &u[2]);
+    const fr_t *ypos = v, *yneg = v + ell, *Yv = v + 2 * ell;
+    fr_t one, two; fr_one(&one); fr_from_u64(2, &two);
+    for (size_t i = 0; i < ell; i++) {
+        fr_t Ynext = (i + 1 < ell) ? Yv[i + 1] : *y;
+        fr_t lhs, rhs, a, b, x = point[ell - i - 1];
+        fr_mul(&two, &r, &lhs); fr_mul(&lhs, &Ynext, &lhs);
+        fr_sub(&one, &x, &a); fr_mul(&r, &a, &a); fr_add(&ypos[i], &yneg[i], &b); fr_mul(&a, &b, &a);
+        fr_sub(&ypos[i], &yneg[i], &b); fr_mul(&x, &b, &b); fr_add(&a, &b, &rhs);
+        if (!fp_eq(&lhs, &rhs)) return 0;
+    }
+    orc_transcript_append_scalars(t, v, 3 * ell);
+    fr_t *q = (fr_t *)malloc(ell * sizeof(fr_t));
+    { fr_t q1; orc_transcript_challenge_scalar(t, &q1); fr_one(&q[0]); for (size_t j = 1; j < ell; j++) fr_mul(&q[j - 1], &q1, &q[j]); }
+    orc_transcript_append_points(t, w, 3);
+    fr_t d0, d1, mult; orc_transcript_challenge_scalar(t, &d0); fr_mul(&d0, &d0, &d1);
+    fr_add(&one, &d0, &mult); fr_add(&mult, &d1, &mult);
+    fr_t Bu[3];
+    for (int k = 0; k < 3; k++) { fr_zero(&Bu[k]); for (size_t j = 0; j < ell; j++) { fr_t m; fr_mul(&v[k * ell + j], &q[j], &m); fr_add(&Bu[k], &m, &Bu[k]); } }
+    size_t nb = ell + 4;
+    g1_aff_t *bases = (g1_aff_t *)malloc(nb * sizeof(g1_aff_t)); fr_t *sc = (fr_t *)malloc(nb * sizeof(fr_t));
+    bases[0] = *C; for (size_t j = 1; j < ell; j++) bases[j] = com[j - 1];
+    for (size_t j = 0; j < ell; j++) fr_mul(&q[j], &mult, &sc[j]);
+    bases[ell] = w[0]; bases[ell + 1] = w[1]; bases[ell + 2] = w[2]; bases[ell + 3] = srs[0];
+    sc[ell] = u[0]; fr_mul(&u[1], &d0, &sc[ell + 1]); fr_mul(&u[2], &d1, &sc[ell + 2]);
+    { fr_t a, b; fr_mul(&d0, &Bu[1], &a); fr_mul(&d1, &Bu[2], &b); fr_add(&Bu[0], &a, &a); fr_add(&a, &b, &a); fr_neg(&a, &sc[ell + 3]); }
+    g1_aff_t L; orc_msm_naive(bases, sc, nb, &L);
+    g1_aff_t Rb[3] = {w[0], w[1], w[2]}; fr_t Rs[3]; Rs[0] = one; Rs[1] = d0; Rs[2] = d1;
+    g1_aff_t R, tR; orc_msm_naive(Rb, Rs, 3, &R);
+    g1_mul_fr(&R, tau, &tR);
+    free(q); free(bases); free(sc);
+    if (R.inf) return L.inf ? 1 : 0;
+    if (L.inf || tR.inf) return (L.inf && tR.inf) ? 1 : 0;
+    return fp_eq(&L.x, &tR.x) && fp_eq(&L.y, &tR.y);
+}

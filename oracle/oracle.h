@@ -93,6 +93,11 @@ void orc_g1_sum_indexed(const g1_aff_t *bases, const uint64_t *idx, size_t n, g1
 void orc_srs_powers(const fr_t *tau, size_t n, g1_aff_t *out);
 void orc_transcript_append_point(orc_transcript *t, const g1_aff_t *p);   /* blake2b.rs:166-187 */
 void orc_transcript_append_points(orc_transcript *t, const g1_aff_t *p, size_t n);
+int  orc_hyperkzg_open(const g1_aff_t *srs, const fr_t *poly, size_t ell, const fr_t *point,
+                       orc_transcript *t, g1_aff_t *com, g1_aff_t *w, fr_t *v);   /* hyperkzg/mod.rs:400-447 */
+int  orc_hyperkzg_verify_trapdoor(const g1_aff_t *srs, const fr_t *tau, const g1_aff_t *C, size_t ell,
+                                  const fr_t *point, const fr_t *y, const g1_aff_t *com, const g1_aff_t *w,
+                                  const fr_t *v, orc_transcript *t);                /* :451-509, 283-366 */
 void orc_eval_as_univariate(const fr_t *f, size_t n, const fr_t *r, fr_t *out);   /* unipoly.rs:247-259 */
 
 #ifdef __cplusplus

@@ -217,6 +217,45 @@ def g1_sum_indexed(bases, idx):
     return out[0]
 
 
+def challenges_to_fr(c128_list):
+    return np.stack([challenge_to_fr(c)[0] for c in c128_list]) if c128_list else fr_array(0)
+
+
+def hyperkzg_open(srs, poly, point_c128, t):
+    """Returns (com (ell-1,) G1, w (3,) G1, v (3, ell, 4) Fr)."""
+    ell = len(point_c128)
+    srs = np.ascontiguousarray(srs, dtype=G1_DTYPE)
+    poly = np.ascontiguousarray(poly, dtype=np.uint64)
+    pt = np.ascontiguousarray(challenges_to_fr(point_c128))
+    com = np.zeros(max(ell - 1, 1), dtype=G1_DTYPE); w = np.zeros(3, dtype=G1_DTYPE); v = fr_array(3 * ell)
+    lib.orc_hyperkzg_open(srs.ctypes.data_as(C.c_void_p), _p(poly), C.c_size_t(ell), _p(pt), C.byref(t),
+                          com.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), _p(v))
+    return com[:ell - 1], w, v.reshape(3, ell, 4)
+
+
+def hyperkzg_verify_trapdoor(srs, tau_fr, commitment, point_c128, y_fr, com, w, v, t):
+    ell = len(point_c128)
+    srs = np.ascontiguousarray(srs, dtype=G1_DTYPE)
+    pt = np.ascontiguousarray(challenges_to_fr(point_c128))
+    tau = np.ascontiguousarray(tau_fr, dtype=np.uint64).reshape(1, 4)
+    y = np.ascontiguousarray(y_fr, dtype=np.uint64).reshape(1, 4)
+    cm = np.ascontiguousarray(np.array([commitment], dtype=G1_DTYPE))
+    com = np.ascontiguousarray(com, dtype=G1_DTYPE) if len(com) else np.zeros(1, dtype=G1_DTYPE)
+    w = np.ascontiguousarray(w, dtype=G1_DTYPE)
+    v = np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4)
+    lib.orc_hyperkzg_verify_trapdoor.restype = C.c_int
+    return bool(lib.orc_hyperkzg_verify_trapdoor(
+        srs.ctypes.data_as(C.c_void_p), _p(tau), cm.ctypes.data_as(C.c_void_p), C.c_size_t(ell), _p(pt), _p(y),
+        com.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), _p(v), C.byref(t)))
+
+
+def evaluate(poly, point_fr):
+    n = len(point_fr)
+    out = fr_array(1)
+    lib.orc_evaluate(_p(np.ascontiguousarray(poly)), C.c_size_t(n), _p(np.ascontiguousarray(point_fr)), _p(out))
+    return out[0]
+
+
 def g1_eq(a, b):
     if int(a["infinity"]) or int(b["infinity"]):
         return bool(int(a["infinity"])) == bool(int(b["infinity"]))

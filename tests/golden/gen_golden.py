@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from oracle.pymodel import curve as EC            # noqa: E402
 from oracle.pymodel import field as F             # noqa: E402
+from oracle.pymodel import hyperkzg as HK        # noqa: E402
 from oracle.pymodel import poly as P              # noqa: E402
 from oracle.pymodel import sumcheck as S          # noqa: E402
 from oracle.pymodel import transcript as T        # noqa: E402
@@ -116,8 +117,32 @@ def curve_vectors():
             "sum_indexed": {"idx": idx, "point": [hx(acc[0]), hx(acc[1])]}}
 
 
+def hyperkzg_vectors():
+    out = []
+    tau = rnd.randrange(F.FR)
+    for ell in (1, 2, 3, 5):
+        n = 1 << ell
+        srs = EC.srs_powers(tau, n)
+        poly = [rnd.randrange(F.FR) for _ in range(n)]
+        pt = [rnd.getrandbits(128) for _ in range(ell)]
+        C = HK.commit(srs, poly)
+        y = P.evaluate(poly, [F.challenge_to_fr(c) for c in pt])
+        t = T.Blake2bTranscript(b"TestEval")
+        com, w, v = HK.open_(srs, poly, pt, t)
+        tv = T.Blake2bTranscript(b"TestEval")
+        assert HK.verify_trapdoor(srs, tau, C, pt, y, (com, w, v), tv) and tv.state == t.state
+        ser_len = 8 + (ell - 1) * 32 + 8 + 3 * 32 + 8 + 3 * (8 + ell * 32)      # ark compressed sizes
+        out.append({"ell": ell, "tau": hx(tau), "poly": [hx(c) for c in poly], "point_c128": ["%032x" % c for c in pt],
+                    "commitment": [hx(C[0]), hx(C[1])], "eval": hx(y),
+                    "com": [[hx(p[0]), hx(p[1])] for p in com], "w": [[hx(p[0]), hx(p[1])] for p in w],
+                    "v": [[hx(x) for x in row] for row in v], "final_state": t.state.hex(),
+                    "serialized_len": ser_len})
+    assert out[1]["serialized_len"] == 368          # reference: hyperkzg/tests.rs:107-109
+    return out
+
+
 def main():
-    data = {"field": field_vectors(), "transcript": transcript_vectors(), "sumcheck": sumcheck_vectors(),
+    data = {"hyperkzg": hyperkzg_vectors(), "field": field_vectors(), "transcript": transcript_vectors(), "sumcheck": sumcheck_vectors(),
             "eq": eq_vectors(), "curve": curve_vectors()}
     for k, v in data.items():
         with open(os.path.join(OUT, k + ".json"), "w") as f:
