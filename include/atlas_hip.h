@@ -120,6 +120,32 @@ int atlas_sumcheck_prove_dot(atlas_dot_prover_t p, const atlas_fr_t *input_claim
                              atlas_transcript_t *transcript, atlas_fr_t *compressed_polys,
                              atlas_u128_t *challenges, atlas_fr_t final_claims[3]);
 
+/* ---- EQ tables and MLE evaluation ---------------------------------------------------- */
+/* EqPolynomial::evals / evals_with_scaling (joltworks/src/poly/eq_poly.rs:77-101): the 2^n
+ * table { scaling * eq(r, x) }, big-endian index (r[0] = MSB); r as Fr (a challenge is
+ * converted with atlas_challenge_to_fr).  scaling may be NULL (= 1). */
+int atlas_eq_evals(const atlas_fr_t *r, size_t n, const atlas_fr_t *scaling, atlas_poly_t *out);
+/* PolynomialEvaluation::evaluate (multilinear_polynomial.rs:766-862; dense_mlpoly.rs:265-305):
+ * P(r), r[0] = MSB variable; p is not modified */
+int atlas_poly_evaluate(atlas_poly_t p, const atlas_fr_t *r, size_t n, atlas_fr_t *out);
+
+/* ---- sumcheck: MulProver over GruenSplitEqPolynomial (element-wise ops)
+ *      (jolt-atlas-core/src/onnx_proof/ops/mul.rs:125-185;
+ *       joltworks/src/poly/split_eq_poly.rs:86-145,331-429,526-597) ----------------------- */
+typedef struct atlas_mul_prover *atlas_mul_prover_t;
+/* MulProver::initialize: takes ownership of the two operand polynomials (length 2^n);
+ * w = r_node_output as n Fr (big-endian point), bound LowToHigh */
+int atlas_mul_prover_new(atlas_poly_t left, atlas_poly_t right, const atlas_fr_t *w, size_t n,
+                         atlas_mul_prover_t *out);
+int atlas_mul_prover_free(atlas_mul_prover_t p);
+/* sum_x eq(w,x) L(x) R(x) (the node-output opening the reference reads, mul.rs:60-66) */
+int atlas_mul_input_claim(atlas_mul_prover_t p, atlas_fr_t *out);
+/* Sumcheck::prove for that instance, transcript on the device; rows of 3 coefficients
+ * (c0, c2, c3); final_claims = left(r), right(r), eq(w, r) */
+int atlas_sumcheck_prove_mul(atlas_mul_prover_t p, const atlas_fr_t *input_claim,
+                             atlas_transcript_t *transcript, atlas_fr_t *compressed_polys,
+                             atlas_u128_t *challenges, atlas_fr_t final_claims[3]);
+
 /* ---- SRS + multi-scalar multiplication: the arithmetic behind the CommitmentScheme
  *      plug-in (joltworks/src/poly/commitment/commitment_scheme.rs:11-131) for HyperKZG --- */
 typedef struct { uint64_t l[4]; } atlas_fq_t;            /* ark_bn254::Fq, Montgomery limbs */

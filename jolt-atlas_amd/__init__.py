@@ -353,6 +353,63 @@ class SRS:
             self.h = None
 
 
+for _name in ("atlas_eq_evals", "atlas_poly_evaluate", "atlas_mul_prover_new", "atlas_mul_prover_free",
+              "atlas_mul_input_claim", "atlas_sumcheck_prove_mul"):
+    getattr(lib, _name).restype = C.c_int
+
+
+class EqPolynomial:
+    @staticmethod
+    def evals(r_fr, scaling=None):
+        """EqPolynomial::evals(_with_scaling): device table of 2^n entries, r[0] = MSB."""
+        r = _fr(r_fr).reshape(-1, 4)
+        h = C.c_void_p()
+        sc = _fr(scaling) if scaling is not None else None
+        _check(lib.atlas_eq_evals(_p(r) if len(r) else None, C.c_size_t(len(r)), _p(sc) if sc is not None else None,
+                                  C.byref(h)))
+        return MultilinearPolynomial(h)
+
+
+def evaluate(poly: MultilinearPolynomial, r_fr):
+    """PolynomialEvaluation::evaluate at the point r (Fr array, r[0] = MSB)."""
+    r = _fr(r_fr).reshape(-1, 4)
+    out = np.zeros(4, dtype=np.uint64)
+    _check(lib.atlas_poly_evaluate(poly.h, _p(r) if len(r) else None, C.c_size_t(len(r)), _p(out)))
+    return out
+
+
+class MulProver:
+    """SumcheckInstanceProver for element-wise multiplication (ops/mul.rs:125-185)."""
+
+    def __init__(self, left, right, w_fr):
+        w = _fr(w_fr).reshape(-1, 4)
+        h = C.c_void_p()
+        _check(lib.atlas_mul_prover_new(left.h, right.h, _p(w), C.c_size_t(len(w)), C.byref(h)))
+        left.h = right.h = None
+        self.h = h
+        self.n = len(w)
+
+    def input_claim(self):
+        out = np.zeros(4, dtype=np.uint64)
+        _check(lib.atlas_mul_input_claim(self.h, _p(out)))
+        return out
+
+    def prove(self, input_claim, transcript):
+        """Sumcheck::prove. Returns (compressed_polys (n,3,4), challenges, final_claims (3,4))."""
+        n = self.n
+        proof = np.zeros((n * 3, 4), dtype=np.uint64)
+        ch = np.zeros(2 * n, dtype=np.uint64)
+        fin = np.zeros((3, 4), dtype=np.uint64)
+        ic = _fr(input_claim)
+        _check(lib.atlas_sumcheck_prove_mul(self.h, _p(ic), C.byref(transcript.t), _p(proof), _p(ch), _p(fin)))
+        return proof.reshape(n, 3, 4), [int(ch[2 * i]) | (int(ch[2 * i + 1]) << 64) for i in range(n)], fin
+
+    def free(self):
+        if self.h:
+            lib.atlas_mul_prover_free(self.h)
+            self.h = None
+
+
 class HyperKZG:
     """CommitmentScheme arithmetic for HyperKZG (commitment_scheme.rs:11-131)."""
 

@@ -26,14 +26,6 @@ struct atlas_srs {
     size_t len = 0;
 };
 
-struct atlas_poly {   // same definition as in atlas_hip.hip
-    void* d = nullptr;
-    size_t len = 0;
-    size_t cap_bytes = 0;
-    bool is_i32 = false;
-    bool owned = true;
-};
-
 namespace {
 
 // grow-only device workspace shared by MSM calls (serialised by g.mu)

@@ -12,6 +12,15 @@ struct Fe;
 struct ScCtx;
 }  // namespace atlas
 
+// device polynomial handle (MultilinearPolynomial: LargeScalars or I32Scalars)
+struct atlas_poly {
+    void* d = nullptr;       // current coefficients: Fr if !is_i32, int32 if is_i32
+    size_t len = 0;          // current length
+    size_t cap_bytes = 0;
+    bool is_i32 = false;
+    bool owned = true;
+};
+
 namespace atlas_rt {
 
 struct Runtime {

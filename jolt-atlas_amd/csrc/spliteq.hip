@@ -1,0 +1,285 @@
+// EQ tables, MLE evaluation and the Gruen split-eq product sumcheck: host side + C-ABI.
+// Mirrors (paths under the jolt-atlas tree):
+//   EqPolynomial::evals                    joltworks/src/poly/eq_poly.rs:77-101
+//   MultilinearPolynomial::evaluate        joltworks/src/poly/multilinear_polynomial.rs:766-862
+//   MulProver as SumcheckInstanceProver    jolt-atlas-core/src/onnx_proof/ops/mul.rs:125-185
+//   Sumcheck::prove                        joltworks/src/subprotocols/sumcheck.rs:565-599
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "../../include/atlas_hip.h"
+#include "host_field.hpp"
+#include "runtime.hpp"
+#include "sc_consts.hpp"
+#include "spliteq_kernels.hip.h"
+
+using namespace atlas;
+namespace H = atlas_host;
+using atlas_rt::fail;
+using atlas_rt::g;
+using atlas_rt::MAX_ROUNDS;
+
+struct atlas_mul_prover {
+    atlas_poly_t left = nullptr, right = nullptr;
+    size_t n = 0, m = 0;
+    Fr* d_w = nullptr;          // w (n Fr)
+    Fr* d_eout = nullptr;       // prefix tables of w_out = w[0..m): 2^(m+1) - 1 Fr
+    Fr* d_ein = nullptr;        // prefix tables of w_in = w[m..n-1)
+    std::vector<H::Fr> w;
+    H::Fr scalar;               // current_scalar (host copy for the round API)
+    bool consumed = false;
+};
+
+namespace {
+
+inline int grid_for(size_t work) {
+    size_t b = (work + SC_THREADS - 1) / SC_THREADS;
+    if (b < 1) b = 1;
+    if (b > (size_t)SC_MAX_BLOCKS) b = SC_MAX_BLOCKS;
+    return (int)b;
+}
+inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
+inline unsigned ilog2(size_t x) { unsigned n = 0; while (x > 1) { x >>= 1; n++; } return n; }
+Fr to_dev(const H::Fr& f) { Fr o; std::memcpy(o.v, f.l, 32); return o; }
+
+__global__ __launch_bounds__(SC_THREADS) void k_reduce1(const Fr* partials, int n_partials, Fr* out, int width) {
+    __shared__ Fr red[SC_THREADS / 64][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = 0; k < width; k++) {
+        Fr acc = fe_zero();
+        for (int b = threadIdx.x; b < n_partials; b += SC_THREADS) acc = fr_add(acc, fe_load(partials + (size_t)b * width + k));
+        Fr s = fr_wave_sum(acc);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < width) {
+        Fr s = red[0][threadIdx.x];
+        for (int w = 1; w < SC_THREADS / 64; w++) s = fr_add(s, red[w][threadIdx.x]);
+        fe_store(out + threadIdx.x, s);
+    }
+}
+
+// EqPolynomial::evals into a fresh device buffer (2^n Fr)
+int eq_evals_device(const H::Fr* r, size_t n, const H::Fr* scaling, Fr** out) {
+    const size_t len = (size_t)1 << n;
+    Fr* ev = nullptr;
+    hipError_t e = hipMalloc(&ev, len * sizeof(Fr));
+    if (e != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(eq)", e);
+    Fr* d_r = nullptr;
+    HIP_TRY(hipMalloc(&d_r, (n ? n : 1) * sizeof(Fr)));
+    if (n) HIP_TRY(hipMemcpyAsync(d_r, r, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    const uint32_t head = n < 12 ? (uint32_t)n : 12u;
+    k_eq_head<<<1, 1024, 0, g.stream>>>(ev, d_r, (uint32_t)n, head, to_dev(scaling ? *scaling : H::one()));
+    for (size_t p = head; p < n; p++)
+        k_eq_double<<<grid_for((size_t)1 << p), SC_THREADS, 0, g.stream>>>(ev, (size_t)1 << p, to_dev(r[n - 1 - p]));
+    hipError_t le = hipStreamSynchronize(g.stream);
+    hipFree(d_r);
+    if (le != hipSuccess) { hipFree(ev); return fail(ATLAS_ENODEV, "eq_evals", le); }
+    *out = ev;
+    return ATLAS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int atlas_eq_evals(const atlas_fr_t* r, size_t n, const atlas_fr_t* scaling, atlas_poly_t* out) {
+    NEED_INIT();
+    if ((!r && n) || !out || n > 30) return fail(ATLAS_EINVAL, "eq_evals");
+    std::lock_guard<std::mutex> lk(g.mu);
+    Fr* ev = nullptr;
+    int rc = eq_evals_device(reinterpret_cast<const H::Fr*>(r), n, reinterpret_cast<const H::Fr*>(scaling), &ev);
+    if (rc) return rc;
+    atlas_poly* p = new atlas_poly();
+    p->d = ev; p->len = (size_t)1 << n; p->cap_bytes = p->len * sizeof(Fr); p->is_i32 = false; p->owned = true;
+    *out = p;
+    return ATLAS_OK;
+}
+
+int atlas_poly_evaluate(atlas_poly_t p, const atlas_fr_t* r, size_t n, atlas_fr_t* out) {
+    NEED_INIT();
+    if (!p || (!r && n) || !out) return fail(ATLAS_EINVAL, "poly_evaluate");
+    if (p->len != ((size_t)1 << n)) return fail(ATLAS_EINVAL, "poly_evaluate: point length != num_vars");
+    std::lock_guard<std::mutex> lk(g.mu);
+    // DensePolynomial::evaluate: r = (r2 | r1), eq_one = evals(r2) outer, eq_two = evals(r1) inner
+    const size_t m = n / 2;
+    const H::Fr* rr = reinterpret_cast<const H::Fr*>(r);
+    Fr *eq1 = nullptr, *eq2 = nullptr;
+    int rc = eq_evals_device(rr, m, nullptr, &eq1);
+    if (rc) return rc;
+    rc = eq_evals_device(rr + m, n - m, nullptr, &eq2);
+    if (rc) { hipFree(eq1); return rc; }
+    const int grid = grid_for(p->len);
+    const ScConsts K = make_consts();
+    if (p->is_i32)
+        k_mle_evaluate<int32_t><<<grid, SC_THREADS, 0, g.stream>>>((const int32_t*)p->d, p->len, eq1, eq2, (uint32_t)(n - m), g.d_partials, K);
+    else
+        k_mle_evaluate<Fr><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)p->d, p->len, eq1, eq2, (uint32_t)(n - m), g.d_partials, K);
+    k_reduce1<<<1, SC_THREADS, 0, g.stream>>>(g.d_partials, grid, g.d_finals + 3, 1);
+    hipError_t e = hipMemcpyAsync(g.h_pinned, g.d_finals + 3, sizeof(Fr), hipMemcpyDeviceToHost, g.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    hipFree(eq1); hipFree(eq2);
+    if (e != hipSuccess) return fail(ATLAS_ENODEV, "poly_evaluate", e);
+    std::memcpy(out, g.h_pinned, sizeof(Fr));
+    return ATLAS_OK;
+}
+
+// ------------------------------------------------------------------ MulProver
+int atlas_mul_prover_new(atlas_poly_t left, atlas_poly_t right, const atlas_fr_t* w, size_t n, atlas_mul_prover_t* out) {
+    NEED_INIT();
+    if (!left || !right || !w || !out) return fail(ATLAS_EINVAL, "mul_prover_new: null argument");
+    if (left->len != right->len || !is_pow2(left->len) || ilog2(left->len) != n || n == 0 || n > MAX_ROUNDS)
+        return fail(ATLAS_EINVAL, "mul_prover_new: operand length must be 2^n, n >= 1");
+    if (left->is_i32 != right->is_i32) return fail(ATLAS_EINVAL, "mul_prover_new: mixed operand types");
+    if (n / 2 > 12 || n - 1 - n / 2 > 12) return fail(ATLAS_EINVAL, "mul_prover_new: n > 25 not supported");
+    std::lock_guard<std::mutex> lk(g.mu);
+    atlas_mul_prover* P = new atlas_mul_prover();
+    P->left = left; P->right = right; P->n = n; P->m = n / 2;
+    P->w.assign(reinterpret_cast<const H::Fr*>(w), reinterpret_cast<const H::Fr*>(w) + n);
+    P->scalar = H::one();
+    const size_t k_out = P->m, k_in = n - 1 - P->m;
+    HIP_TRY(hipMalloc(&P->d_w, n * sizeof(Fr)));
+    HIP_TRY(hipMalloc(&P->d_eout, (((size_t)2 << k_out)) * sizeof(Fr)));
+    HIP_TRY(hipMalloc(&P->d_ein, (((size_t)2 << k_in)) * sizeof(Fr)));
+    HIP_TRY(hipMemcpyAsync(P->d_w, w, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    // GruenSplitEqPolynomial::new, LowToHigh: w = [w_out | w_in | w_last] (split_eq_poly.rs:97-121)
+    k_eq_cached<<<1, 1024, 0, g.stream>>>(P->d_eout, P->d_w, (uint32_t)k_out);
+    k_eq_cached<<<1, 1024, 0, g.stream>>>(P->d_ein, P->d_w + P->m, (uint32_t)k_in);
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    *out = P;
+    return ATLAS_OK;
+}
+
+int atlas_mul_prover_free(atlas_mul_prover_t P) {
+    if (!P) return ATLAS_OK;
+    atlas_poly_free(P->left); atlas_poly_free(P->right);
+    if (P->d_w) hipFree(P->d_w);
+    if (P->d_eout) hipFree(P->d_eout);
+    if (P->d_ein) hipFree(P->d_ein);
+    delete P;
+    return ATLAS_OK;
+}
+
+static SplitEqView view_for_round(const atlas_mul_prover* P, size_t round) {
+    const size_t n_free = P->n - round - 1;
+    const size_t out_bits = n_free < P->m ? n_free : P->m;
+    const size_t in_bits = n_free - out_bits;
+    SplitEqView E;
+    E.e_out = P->d_eout + (((size_t)1 << out_bits) - 1);
+    E.e_in = P->d_ein + (((size_t)1 << in_bits) - 1);
+    E.in_bits = (uint32_t)in_bits;
+    return E;
+}
+
+// input_claim = sum_x eq(w, x) L(x) R(x)  (the node-output opening in the reference, mul.rs:60-66)
+int atlas_mul_input_claim(atlas_mul_prover_t P, atlas_fr_t* out) {
+    NEED_INIT();
+    if (!P || !out) return fail(ATLAS_EINVAL, "mul_input_claim");
+    if (P->consumed || P->left->len != ((size_t)1 << P->n)) return fail(ATLAS_ESTATE, "mul_input_claim: instance already bound");
+    std::lock_guard<std::mutex> lk(g.mu);
+    // s(0) + s(1) of round 0: eq0*q0 + eq1*q1 with the round-0 sums
+    const ScConsts K = make_consts();
+    const size_t groups = P->left->len / 2;
+    const int grid = grid_for(groups);
+    SplitEqView E = view_for_round(P, 0);
+    if (P->left->is_i32) k_mul_eval<int32_t><<<grid, SC_THREADS, 0, g.stream>>>((const int32_t*)P->left->d, (const int32_t*)P->right->d, E, groups, g.d_partials, K);
+    else k_mul_eval<Fr><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, E, groups, g.d_partials, K);
+    k_reduce1<<<1, SC_THREADS, 0, g.stream>>>(g.d_partials, grid, g.d_finals + 3, 3);
+    HIP_TRY(hipMemcpyAsync(g.h_pinned, g.d_finals + 3, 3 * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    H::Fr s[3]; std::memcpy(s, g.h_pinned, sizeof s);
+    const H::Fr wl = P->w[P->n - 1];
+    H::Fr claim = H::add(H::mul(H::sub(H::one(), wl), s[0]), H::mul(wl, s[1]));
+    std::memcpy(out, &claim, 32);
+    return ATLAS_OK;
+}
+
+// Sumcheck::prove for the Mul instance, transcript resident on the device.
+//   compressed_polys : n * 3 Fr (c0, c2, c3 per round)   challenges : n raw u128
+//   final_claims     : left(r), right(r), eq(w, r)
+int atlas_sumcheck_prove_mul(atlas_mul_prover_t P, const atlas_fr_t* input_claim, atlas_transcript_t* transcript,
+                             atlas_fr_t* compressed_polys, atlas_u128_t* challenges, atlas_fr_t final_claims[3]) {
+    NEED_INIT();
+    if (!P || !input_claim || !transcript || !compressed_polys || !challenges || !final_claims)
+        return fail(ATLAS_EINVAL, "sumcheck_prove_mul: null argument");
+    if (P->consumed || P->left->len != ((size_t)1 << P->n)) return fail(ATLAS_ESTATE, "sumcheck_prove_mul: prover already consumed");
+    std::lock_guard<std::mutex> lk(g.mu);
+    const ScConsts K = make_consts();
+    const size_t n = P->n;
+    const int mode = g.challenge_mode;
+    const int hi_only = mode == 0;
+
+    MulCtx* d_cx = reinterpret_cast<MulCtx*>(g.d_ctx);          // same scratch block (sizeof(MulCtx) <= sizeof(ScCtx))
+    static_assert(sizeof(MulCtx) <= sizeof(ScCtx), "control block size");
+    MulCtx* hcx = reinterpret_cast<MulCtx*>(g.h_pinned);
+    std::memset(hcx, 0, sizeof(MulCtx));
+    std::memcpy(&hcx->tr, transcript, sizeof(DevTranscript));
+    std::memcpy(&hcx->claim, input_claim, sizeof(Fr));
+    H::Fr one = H::one(); std::memcpy(&hcx->scalar, &one, sizeof(Fr));
+    HIP_TRY(hipMemcpyAsync(d_cx, hcx, sizeof(MulCtx), hipMemcpyHostToDevice, g.stream));
+
+    size_t len = P->left->len;
+    size_t rounds_done = 0;
+    int pending = 0;
+    const void *curL = P->left->d, *curR = P->right->d;
+    bool cur_i32 = P->left->is_i32;
+    Fr* pp[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // ping-pong [which][L/R]
+    int which = 0;
+
+    if (n > (size_t)SC_TAIL_LOG) {
+        HIP_TRY(hipMalloc(&pp[0][0], (len / 2) * sizeof(Fr))); HIP_TRY(hipMalloc(&pp[0][1], (len / 2) * sizeof(Fr)));
+        HIP_TRY(hipMalloc(&pp[1][0], (len / 4) * sizeof(Fr))); HIP_TRY(hipMalloc(&pp[1][1], (len / 4) * sizeof(Fr)));
+        {
+            const size_t groups = len / 2;
+            const int grid = grid_for(groups);
+            SplitEqView E = view_for_round(P, 0);
+            if (cur_i32) k_mul_eval<int32_t><<<grid, SC_THREADS, 0, g.stream>>>((const int32_t*)curL, (const int32_t*)curR, E, groups, g.d_partials, K);
+            else k_mul_eval<Fr><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)curL, (const Fr*)curR, E, groups, g.d_partials, K);
+            k_mul_fs_round<<<1, SC_THREADS, 0, g.stream>>>(d_cx, g.d_partials, grid, P->d_w + (n - 1), g.d_proof, g.d_chal, K, 1, mode);
+            rounds_done = 1; pending = 1;
+        }
+        while (len > ((size_t)1 << SC_TAIL_LOG)) {
+            const size_t groups_new = len / 4;
+            const int grid = grid_for(groups_new);
+            SplitEqView E = view_for_round(P, rounds_done);
+            Fr* dL = pp[which][0]; Fr* dR = pp[which][1];
+            if (cur_i32)
+                k_mul_bind_eval<int32_t><<<grid, SC_THREADS, 0, g.stream>>>((const int32_t*)curL, (const int32_t*)curR, dL, dR, E, groups_new, d_cx, g.d_partials, K, hi_only);
+            else
+                k_mul_bind_eval<Fr><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)curL, (const Fr*)curR, dL, dR, E, groups_new, d_cx, g.d_partials, K, hi_only);
+            curL = dL; curR = dR; cur_i32 = false; which ^= 1;
+            len /= 2;
+            k_mul_fs_round<<<1, SC_THREADS, 0, g.stream>>>(d_cx, g.d_partials, grid, P->d_w + (n - 1 - rounds_done),
+                                                        g.d_proof + rounds_done * 3, g.d_chal + 2 * rounds_done, K, 0, mode);
+            rounds_done += 1;
+        }
+    }
+    {
+        MulTailArgs A;
+        A.L = curL; A.R = curR; A.len = (uint32_t)len; A.src_i32 = cur_i32 ? 1 : 0;
+        A.e_out_tabs = P->d_eout; A.e_in_tabs = P->d_ein; A.w = P->d_w;
+        A.n = (uint32_t)n; A.m = (uint32_t)P->m; A.round0 = (uint32_t)rounds_done;
+        A.first = rounds_done == 0 ? 1 : 0; A.pending_bind = pending; A.challenge_mode = mode;
+        k_mul_tail<<<1, SC_THREADS, 3 * (sizeof(Fr) << SC_TAIL_LOG), g.stream>>>(A, d_cx, g.d_proof, g.d_chal, g.d_finals, K);
+    }
+    hipError_t le = hipGetLastError();
+    uint8_t* hp = reinterpret_cast<uint8_t*>(g.h_pinned);
+    const size_t proof_bytes = n * 3 * sizeof(Fr), chal_bytes = n * 2 * sizeof(uint64_t);
+    if (le == hipSuccess) le = hipMemcpyAsync(hp, g.d_proof, proof_bytes, hipMemcpyDeviceToHost, g.stream);
+    if (le == hipSuccess) le = hipMemcpyAsync(hp + 8192, g.d_chal, chal_bytes, hipMemcpyDeviceToHost, g.stream);
+    if (le == hipSuccess) le = hipMemcpyAsync(hp + 12288, g.d_finals, 3 * sizeof(Fr), hipMemcpyDeviceToHost, g.stream);
+    if (le == hipSuccess) le = hipMemcpyAsync(hp + 16384, d_cx, sizeof(MulCtx), hipMemcpyDeviceToHost, g.stream);
+    if (le == hipSuccess) le = hipStreamSynchronize(g.stream);
+    for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) if (pp[a][b]) hipFree(pp[a][b]);
+    if (le != hipSuccess) return fail(ATLAS_ENODEV, "sumcheck_prove_mul", le);
+    std::memcpy(compressed_polys, hp, proof_bytes);
+    std::memcpy(challenges, hp + 8192, chal_bytes);
+    std::memcpy(final_claims, hp + 12288, 3 * sizeof(Fr));
+    std::memcpy(transcript, hp + 16384, sizeof(DevTranscript));
+    P->consumed = true;
+    return ATLAS_OK;
+}
+
+}  // extern "C"

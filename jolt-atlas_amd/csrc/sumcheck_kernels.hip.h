@@ -267,7 +267,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_dot_bind_eval(const T* Lsrc, con
 
 // plain in-place high-to-low bind of one array (EQ tables bound ahead of a fused pass,
 // and the PolynomialBinding::bind_parallel entry point of the C-ABI)
-__global__ __launch_bounds__(SC_THREADS) void k_bind_hi(Fr* z, size_t half, const Fr* r_ptr, int r_hi_only) {
+static __global__ __launch_bounds__(SC_THREADS) void k_bind_hi(Fr* z, size_t half, const Fr* r_ptr, int r_hi_only) {
     const Fr r = fe_load(r_ptr);
     for (size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x; i < half;
          i += (size_t)gridDim.x * SC_THREADS) {
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_bind_hi(Fr* z, size_t half, cons
 }
 
 // low-to-high bind (pairs 2i, 2i+1) into a separate destination (dense_mlpoly.rs:219-239)
-__global__ __launch_bounds__(SC_THREADS) void k_bind_lo(const Fr* z, Fr* out, size_t half, const Fr* r_ptr,
+static __global__ __launch_bounds__(SC_THREADS) void k_bind_lo(const Fr* z, Fr* out, size_t half, const Fr* r_ptr,
                                                         int r_hi_only) {
     const Fr r = fe_load(r_ptr);
     for (size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x; i < half;

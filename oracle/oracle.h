@@ -67,6 +67,10 @@ int orc_sumcheck_dot_prove_i32(const int32_t *left, const int32_t *right, size_t
 int orc_sumcheck_verify(const fr_t *proof_coeffs, size_t n_rounds, size_t degree,
                         const fr_t *claim, orc_transcript *t, fr_t *e_out, u128 *challenges);
 
+/* MulProver over GruenSplitEqPolynomial (mul.rs:125-185; split_eq_poly.rs): proof rows of 3 */
+int  orc_sumcheck_mul_prove(fr_t *left, fr_t *right, const fr_t *w, size_t n, const fr_t *input_claim,
+                            orc_transcript *t, fr_t *proof, u128 *challenges, fr_t *final_claims);
+void orc_mul_claim(const fr_t *l, const fr_t *r, const fr_t *w, size_t n, fr_t *out);
 void orc_dot_claim(const fr_t *l, const fr_t *r, const fr_t *eq, size_t len, int schedule,
                    size_t sched_a, size_t sched_b, fr_t *out);
 int  orc_num_threads(void);

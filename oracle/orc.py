@@ -217,6 +217,24 @@ def g1_sum_indexed(bases, idx):
     return out[0]
 
 
+def mul_claim(L, R, w):
+    out = fr_array(1)
+    w = np.ascontiguousarray(w)
+    lib.orc_mul_claim(_p(np.ascontiguousarray(L)), _p(np.ascontiguousarray(R)), _p(w), C.c_size_t(len(w)), _p(out))
+    return out
+
+
+def sumcheck_mul_prove(L, R, w, claim, t):
+    """MulProver + Sumcheck::prove. Returns (proof (n,3,4), challenges, finals (3,4))."""
+    n = len(w)
+    L = np.ascontiguousarray(L).copy(); R = np.ascontiguousarray(R).copy(); w = np.ascontiguousarray(w)
+    proof = fr_array(3 * n); ch = np.zeros(2 * n, dtype=np.uint64); fin = fr_array(3)
+    lib.orc_sumcheck_mul_prove.restype = C.c_int
+    rc = lib.orc_sumcheck_mul_prove(_p(L), _p(R), _p(w), C.c_size_t(n), _p(claim), C.byref(t), _p(proof), _p(ch), _p(fin))
+    assert rc == 0
+    return proof.reshape(n, 3, 4), _u128_list(ch, n), fin
+
+
 def challenges_to_fr(c128_list):
     return np.stack([challenge_to_fr(c)[0] for c in c128_list]) if c128_list else fr_array(0)
 

@@ -295,3 +295,107 @@ int orc_sumcheck_verify(const fr_t *proof, size_t n_rounds, size_t degree, const
     *e_out = e;
     return 0;
 }
+
+/* ------------------------------------------------------------------ Mul (Gruen split-eq)
+ * MulProver (jolt-atlas-core/src/onnx_proof/ops/mul.rs:125-185) over
+ * GruenSplitEqPolynomial (joltworks/src/poly/split_eq_poly.rs): LowToHigh binding,
+ * w = [w_out | w_in | w_last] (:97-121), prefix tables evals_cached (eq_poly.rs:174-192),
+ * par_fold_out_in (:526-597), gruen_poly_deg_3 with the division by eq(1) (:379-429),
+ * bind (:331-348). */
+static void eq_cached(const fr_t *w, size_t k, fr_t **tabs) {
+    tabs[0] = (fr_t *)malloc(sizeof(fr_t)); fr_one(&tabs[0][0]);
+    for (size_t j = 0; j < k; j++) {
+        size_t sz = (size_t)1 << j;
+        tabs[j + 1] = (fr_t *)malloc(2 * sz * sizeof(fr_t));
+        for (size_t i = 0; i < sz; i++) {
+            fr_mul(&tabs[j][i], &w[j], &tabs[j + 1][2 * i + 1]);
+            fr_sub(&tabs[j][i], &tabs[j + 1][2 * i + 1], &tabs[j + 1][2 * i]);
+        }
+    }
+}
+
+int orc_sumcheck_mul_prove(fr_t *left, fr_t *right, const fr_t *w, size_t n, const fr_t *input_claim,
+                           orc_transcript *t, fr_t *proof, u128 *challenges, fr_t *final_claims) {
+    const size_t m = n / 2;
+    const size_t k_out = m, k_in = n - 1 - m;
+    fr_t **Eout = (fr_t **)malloc((k_out + 1) * sizeof(fr_t *)), **Ein = (fr_t **)malloc((k_in + 1) * sizeof(fr_t *));
+    eq_cached(w, k_out, Eout); eq_cached(w + m, k_in, Ein);
+    size_t out_top = k_out, in_top = k_in;          /* index of the current (last) table */
+    size_t current_index = n;
+    fr_t scalar; fr_one(&scalar);
+    size_t len = (size_t)1 << n;
+    orc_transcript_append_scalar(t, input_claim);
+    fr_t prev = *input_claim;
+    for (size_t rnd = 0; rnd < n; rnd++) {
+        const fr_t *e_out = Eout[out_top], *e_in = Ein[in_top];
+        const size_t out_len = (size_t)1 << out_top, in_len = (size_t)1 << in_top;
+        fr_t qc, qe; fr_zero(&qc); fr_zero(&qe);
+#pragma omp parallel if (out_len * in_len >= 4096)
+        {
+            fr_t pc, pe; fr_zero(&pc); fr_zero(&pe);
+#pragma omp for schedule(static)
+            for (size_t xo = 0; xo < out_len; xo++) {
+                fr_t ic, ie; fr_zero(&ic); fr_zero(&ie);
+                for (size_t xi = 0; xi < in_len; xi++) {
+                    size_t gidx = (xo << in_top) | xi;
+                    fr_t lo0 = left[2 * gidx], loi, ro0 = right[2 * gidx], roi, c0, e;
+                    fr_sub(&left[2 * gidx + 1], &lo0, &loi); fr_sub(&right[2 * gidx + 1], &ro0, &roi);
+                    fr_mul(&lo0, &ro0, &c0); fr_mul(&loi, &roi, &e);
+                    fr_mul(&e_in[xi], &c0, &c0); fr_mul(&e_in[xi], &e, &e);
+                    fr_add(&ic, &c0, &ic); fr_add(&ie, &e, &ie);
+                }
+                fr_mul(&e_out[xo], &ic, &ic); fr_mul(&e_out[xo], &ie, &ie);
+                fr_add(&pc, &ic, &pc); fr_add(&pe, &ie, &pe);
+            }
+#pragma omp critical
+            { fr_add(&qc, &pc, &qc); fr_add(&qe, &pe, &qe); }
+        }
+        /* gruen_poly_deg_3 */
+        fr_t eq1, eq0, eqm, eq2, eq3, c_ev0, c_ev1, q1, q2, q3, e2, inv, evals[4];
+        fr_mul(&scalar, &w[current_index - 1], &eq1); fr_sub(&scalar, &eq1, &eq0);
+        fr_sub(&eq1, &eq0, &eqm); fr_add(&eq1, &eqm, &eq2); fr_add(&eq2, &eqm, &eq3);
+        fr_mul(&eq0, &qc, &c_ev0); fr_sub(&prev, &c_ev0, &c_ev1);
+        fr_inv(&eq1, &inv); fr_mul(&c_ev1, &inv, &q1);
+        fr_add(&qe, &qe, &e2);
+        fr_add(&q1, &q1, &q2); fr_sub(&q2, &qc, &q2); fr_add(&q2, &e2, &q2);
+        fr_add(&q2, &q1, &q3); fr_sub(&q3, &qc, &q3); fr_add(&q3, &e2, &q3); fr_add(&q3, &e2, &q3);
+        evals[0] = c_ev0; evals[1] = c_ev1; fr_mul(&eq2, &q2, &evals[2]); fr_mul(&eq3, &q3, &evals[3]);
+        /* UniPoly::from_evals degree 3: reuse the hint form (hint = e0 + e1) */
+        fr_t hint, ev3[3], coeffs[4], cc[3], r;
+        fr_add(&evals[0], &evals[1], &hint); ev3[0] = evals[0]; ev3[1] = evals[2]; ev3[2] = evals[3];
+        size_t nc = orc_unipoly_from_evals_and_hint(&hint, ev3, 3, coeffs);
+        size_t ncc = orc_unipoly_compress(coeffs, nc, cc);
+        orc_transcript_append_compressed(t, cc, ncc);
+        u128 raw; orc_transcript_challenge_optimized(t, &raw, &r);
+        challenges[rnd] = raw;
+        orc_unipoly_eval(coeffs, nc, &r, &prev);
+        for (size_t k = 0; k < 3; k++) proof[rnd * 3 + k] = cc[k];
+        /* ingest_challenge: eq.bind(r); left/right bind LowToHigh */
+        {
+            fr_t wr, f, one; fr_one(&one);
+            fr_mul(&w[current_index - 1], &r, &wr);
+            fr_sub(&one, &w[current_index - 1], &f); fr_sub(&f, &r, &f); fr_add(&f, &wr, &f); fr_add(&f, &wr, &f);
+            fr_mul(&scalar, &f, &scalar);
+            current_index -= 1;
+            if (n / 2 < current_index && in_top > 0) in_top--;
+            else if (0 < current_index && out_top > 0) out_top--;
+        }
+        orc_bind(left, len, &r, ORC_LOW_TO_HIGH); orc_bind(right, len, &r, ORC_LOW_TO_HIGH);
+        len /= 2;
+    }
+    final_claims[0] = left[0]; final_claims[1] = right[0]; final_claims[2] = scalar;
+    for (size_t j = 0; j <= k_out; j++) free(Eout[j]);
+    for (size_t j = 0; j <= k_in; j++) free(Ein[j]);
+    free(Eout); free(Ein);
+    return 0;
+}
+
+/* sum_x eq(w, x) L(x) R(x) */
+void orc_mul_claim(const fr_t *l, const fr_t *r, const fr_t *w, size_t n, fr_t *out) {
+    size_t len = (size_t)1 << n;
+    fr_t *eq = (fr_t *)malloc(len * sizeof(fr_t));
+    orc_eq_evals(w, n, 0, eq);
+    fr_t acc; fr_zero(&acc);
+    for (size_t i = 0; i < len; i++) { fr_t t; fr_mul(&l[i], &r[i], &t); fr_mul(&t, &eq[i], &t); fr_add(&acc, &t, &acc); }
+    *out = acc; free(eq);
+}
