@@ -19,6 +19,7 @@
 #include "runtime.hpp"
 #include "sumcheck_kernels.hip.h"
 #include "sc_consts.hpp"
+#include "sumcheck_f9_kernels.hip.h"
 
 using namespace atlas;
 namespace H = atlas_host;
@@ -560,15 +561,19 @@ static int prove_dot_impl(atlas_dot_prover* P, const atlas_fr_t* input_claim, at
     size_t rounds_done = 0;       // messages emitted so far
     int pending = 0;              // challenge of round rounds_done-1 not yet bound
     const size_t esz = P->left->is_i32 ? sizeof(int32_t) : sizeof(Fr);
+    // degree-2 / LargeScalars / challenge mode 0: data passes on the 29-bit lazy-limb kernels
+    const bool use_f9 = DEG == 2 && !P->left->is_i32 && mode == 0;
+    auto grid_f9 = [](size_t work) { size_t b = (work + SC_THREADS - 1) / SC_THREADS; return (int)(b < 1 ? 1 : b > 256 ? 256 : b); };
 
     if (n > (size_t)SC_TAIL_LOG) {
         // round 0 message over the untouched operands
         {
             const size_t half = len / 2;
-            const int grid = grid_for(half);
+            const int grid = use_f9 ? grid_f9(half) : grid_for(half);
             EqView eq = eq_view_for_round(P, 0, eqp, eq_len);
             tm.begin(0, 2 * len * esz);
-            launch_eval<DEG>(P, eq, half, grid);
+            if (use_f9) k_dot_eval2_f9<<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, half, g.d_partials);
+            else launch_eval<DEG>(P, eq, half, grid);
             tm.end();
             tm.begin(1, 0);
             k_fs_round<DEG><<<1, SC_THREADS, 0, g.stream>>>(g.d_ctx, g.d_partials, grid, g.d_proof, g.d_chal, K, 1, mode);
@@ -579,7 +584,7 @@ static int prove_dot_impl(atlas_dot_prover* P, const atlas_fr_t* input_claim, at
         while (len > ((size_t)1 << SC_TAIL_LOG)) {
             const size_t j = rounds_done - 1;          // challenge index being bound
             const size_t q = len / 4;
-            const int grid = grid_for(q);
+            const int grid = use_f9 ? grid_f9(q) : grid_for(q);
             bool fuse_eq = false;
             if (P->schedule == ATLAS_EQ_HIGH && j < P->a) {
                 tm.begin(0, (eq_len + eq_len / 2) * sizeof(Fr));
@@ -612,6 +617,13 @@ static int prove_dot_impl(atlas_dot_prover* P, const atlas_fr_t* input_claim, at
                     g.d_ctx, g.d_partials, K, hi_only);
                 tm.end();
                 eq_len /= 2;
+            } else if (use_f9) {
+                // last fused pass hands canonical residues to the LDS tail kernel
+                if (len / 2 <= ((size_t)1 << SC_TAIL_LOG))
+                    k_dot_bind_eval2_f9<true><<<grid, SC_THREADS, 0, g.stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, g.d_ctx, g.d_partials);
+                else
+                    k_dot_bind_eval2_f9<false><<<grid, SC_THREADS, 0, g.stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, g.d_ctx, g.d_partials);
+                tm.end();
             } else {
                 k_dot_bind_eval<DEG, Fr, false><<<grid, SC_THREADS, 0, g.stream>>>(
                     (const Fr*)P->left->d, (const Fr*)P->right->d, (Fr*)P->left->d, (Fr*)P->right->d, nullptr, eq, q,

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_dot_bind_eval(const T* Lsrc, con
     for (int k = 0; k < DEG; k++) acc[k] = fe_zero();
     const Fr r = fe_load(&cx->r);
     Fr r_s64;
-    if constexpr (sizeof(T) == 4) r_s64 = fe_load(&cx->r_s64);
+    if constexpr (sizeof(T) == 4) r_s64 = fr_mul(r, K.k64);   // Montgomery(r * 2^64) for small-scalar binds
     const bool hi = r_hi_only != 0;
     for (size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x; i < q;
          i += (size_t)gridDim.x * SC_THREADS) {
@@ -347,14 +347,12 @@ __device__ __forceinline__ void fs_round_wave(WaveTranscript& T, FsScratch* S, c
     uint64_t lo, hi;
     wt_challenge_u128(T, &S->wt, W, lane, lo, hi);
     const Fr r = challenge_to_mont(lo, hi, challenge_mode);
-    // previous_claim = poly.evaluate(r_j) (unipoly.rs:229-245)
-    Fr ev_r = c[0], pw = r;
+    // previous_claim = poly.evaluate(r_j) (unipoly.rs:229-245), Horner form: every product has
+    // the sparse challenge as one factor (same value, exact arithmetic)
+    Fr ev_r = c[DEG];
 #pragma unroll
-    for (int k = 1; k <= DEG; k++) {
-        // only r itself has the four zero low limbs; its powers are full-width
-        ev_r = fr_add(ev_r, (k == 1 && challenge_mode == 0) ? fr_mul_hi(c[k], pw) : fr_mul(pw, c[k]));
-        if (k < DEG) pw = challenge_mode == 0 ? fr_mul_hi(pw, r) : fr_mul(pw, r);
-    }
+    for (int k = DEG - 1; k >= 0; k--)
+        ev_r = fr_add(challenge_mode == 0 ? fr_mul_hi(ev_r, r) : fr_mul(ev_r, r), c[k]);
     claim = ev_r;
     r_out = r;
     if (lane == 0) {
@@ -408,7 +406,6 @@ __global__ __launch_bounds__(SC_THREADS) void k_fs_round(ScCtx* cx, const Fr* pa
     if (lane == 0) {
         fe_store(&cx->claim, claim);
         fe_store(&cx->r, r);
-        fe_store(&cx->r_s64, fr_mul(r, K.k64));   // Montgomery(r * 2^64) for small-scalar binds
     }
 }
 

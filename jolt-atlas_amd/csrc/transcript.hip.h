@@ -60,15 +60,62 @@ struct WaveTranscript {
     uint32_t n_rounds;
 };
 
-// per-lane byte offsets into the 16-word message block for round r, slot k:
-//   k=0,1 column step  (words sigma[r][2q], sigma[r][2q+1])
-//   k=2,3 diagonal step (words sigma[r][8+2q], sigma[r][9+2q])
+// (kept for call-site compatibility: the message schedule now lives in registers)
 struct WaveBlakeSched {
-    uint32_t off[48];
+    uint32_t unused;
 };
+__device__ __forceinline__ WaveBlakeSched wave_blake_sched(uint32_t) { return WaveBlakeSched{0}; }
 
-__device__ __forceinline__ WaveBlakeSched wave_blake_sched(uint32_t q) {
-    // SIGMA rows packed per quad lane: 16 bits per round = nibbles (2q, 2q+1, 8+2q, 9+2q)
+// 64-bit lanes of the hash as explicit 32-bit halves: keeps every value in free-standing
+// VGPRs (the compiler's u64 ops want aligned register pairs and pay for it in v_mov).
+struct U64 {
+    uint32_t lo, hi;
+};
+__device__ __forceinline__ U64 u64_split(uint64_t x) { return U64{(uint32_t)x, (uint32_t)(x >> 32)}; }
+__device__ __forceinline__ uint64_t u64_join(U64 x) { return ((uint64_t)x.hi << 32) | x.lo; }
+__device__ __forceinline__ U64 u64_add(U64 a, U64 b) {
+    U64 o;
+    asm("v_add_co_u32 %0, vcc, %2, %4\n\tv_addc_co_u32 %1, vcc, %3, %5, vcc"
+        : "=&v"(o.lo), "=v"(o.hi) : "v"(a.lo), "v"(a.hi), "v"(b.lo), "v"(b.hi) : "vcc");
+    return o;
+}
+__device__ __forceinline__ U64 u64_xor(U64 a, U64 b) { return U64{a.lo ^ b.lo, a.hi ^ b.hi}; }
+template <int N>
+__device__ __forceinline__ U64 u64_rotr(U64 x) {
+    if constexpr (N == 32) return U64{x.hi, x.lo};
+    else if constexpr (N < 32) return U64{__builtin_amdgcn_alignbit(x.hi, x.lo, N), __builtin_amdgcn_alignbit(x.lo, x.hi, N)};
+    else return U64{__builtin_amdgcn_alignbit(x.lo, x.hi, N - 32), __builtin_amdgcn_alignbit(x.hi, x.lo, N - 32)};
+}
+template <int CTRL>
+__device__ __forceinline__ U64 u64_quad_perm(U64 x) {
+    return U64{(uint32_t)__builtin_amdgcn_mov_dpp((int)x.lo, CTRL, 0xf, 0xf, true),
+               (uint32_t)__builtin_amdgcn_mov_dpp((int)x.hi, CTRL, 0xf, 0xf, true)};
+}
+__device__ __forceinline__ U64 u64_sel4(uint32_t q, U64 x0, U64 x1, U64 x2, U64 x3) {
+    const bool b0 = q & 1, b1 = q & 2;
+    U64 lo{b0 ? x1.lo : x0.lo, b0 ? x1.hi : x0.hi}, hi{b0 ? x3.lo : x2.lo, b0 ? x3.hi : x2.hi};
+    return U64{b1 ? hi.lo : lo.lo, b1 ? hi.hi : lo.hi};
+}
+
+// G with the message words added only when they can be non-zero (ZX / ZY known at compile time)
+template <bool ZX, bool ZY>
+__device__ __forceinline__ void blake_g(U64& a, U64& b, U64& c, U64& d, U64 x, U64 y) {
+    a = u64_add(a, b); if constexpr (!ZX) a = u64_add(a, x);
+    d = u64_rotr<32>(u64_xor(d, a));
+    c = u64_add(c, d); b = u64_rotr<24>(u64_xor(b, c));
+    a = u64_add(a, b); if constexpr (!ZY) a = u64_add(a, y);
+    d = u64_rotr<16>(u64_xor(d, a));
+    c = u64_add(c, d); b = u64_rotr<63>(u64_xor(b, c));
+}
+
+// One final-block compression from the fixed initial chaining value (every transcript hash
+// is a single block: 64-byte prefix + <= 64-byte payload).  M = the 16 message words, each
+// uniform across the quad, held in registers; words 4-6 and 12-15 are always zero, 8-11 are
+// zero without payload.  The per-lane word of a round is a 4-way select among compile-time
+// known registers (no LDS, no waits on the hash's critical path).
+// Returns, in lane l, digest word (l & 3).
+template <bool PAYLOAD>
+__device__ __forceinline__ uint64_t wave_blake2b_block(const U64 M[16], uint32_t q, uint32_t t_bytes) {
     constexpr uint8_t S[12][16] = {
         {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15},
         {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
@@ -82,87 +129,61 @@ __device__ __forceinline__ WaveBlakeSched wave_blake_sched(uint32_t q) {
         {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
         {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15},
         {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
-    WaveBlakeSched W;
-#pragma unroll
-    for (int r = 0; r < 12; r++) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int base = (k < 2) ? k : 8 + (k - 2);
-            const uint32_t o0 = 8u * S[r][base + 0], o1 = 8u * S[r][base + 2], o2 = 8u * S[r][base + 4],
-                           o3 = 8u * S[r][base + 6];
-            uint32_t lo = (q & 1) ? o1 : o0;
-            uint32_t hi = (q & 1) ? o3 : o2;
-            W.off[r * 4 + k] = (q & 2) ? hi : lo;
-        }
-    }
-    return W;
-}
-
-#define ATLAS_G(a, b, c, d, x, y)                          \
-    do {                                                   \
-        a = a + b + (x); d = rotr64(d ^ a, 32);            \
-        c = c + d;       b = rotr64(b ^ c, 24);            \
-        a = a + b + (y); d = rotr64(d ^ a, 16);            \
-        c = c + d;       b = rotr64(b ^ c, 63);            \
-    } while (0)
-
-// One final-block compression from the fixed initial chaining value (every transcript
-// hash is a single block: 64-byte prefix + <= 64-byte payload).  msg = 16 words in LDS,
-// already written.  Returns, in lane l, digest word (l & 3).
-__device__ __forceinline__ uint64_t wave_blake2b_block(const uint64_t* msg, const WaveBlakeSched& W,
-                                                       uint32_t q, uint64_t t_bytes) {
     const uint64_t iv_lo = sel4(q, 0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL,
                                 0xa54ff53a5f1d36f1ULL);
     const uint64_t iv_hi = sel4(q, 0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL,
                                 0x5be0cd19137e2179ULL);
     const uint64_t h_lo = iv_lo ^ (q == 0 ? 0x01010020ULL : 0ULL);   // digest 32, fanout 1, depth 1
-    uint64_t a = h_lo, b = iv_hi, c = iv_lo;
-    uint64_t d = iv_hi ^ (q == 0 ? t_bytes : 0ULL) ^ (q == 2 ? ~0ULL : 0ULL);
-    const unsigned char* mb = reinterpret_cast<const unsigned char*>(msg);
-#pragma unroll
-    for (int r = 0; r < 12; r++) {
-        uint64_t x = *reinterpret_cast<const uint64_t*>(mb + W.off[r * 4 + 0]);
-        uint64_t y = *reinterpret_cast<const uint64_t*>(mb + W.off[r * 4 + 1]);
-        ATLAS_G(a, b, c, d, x, y);
-        b = quad_perm64<0x39>(b);   // lane i <- lane (i+1)&3
-        c = quad_perm64<0x4E>(c);   // lane i <- lane (i+2)&3
-        d = quad_perm64<0x93>(d);   // lane i <- lane (i+3)&3
-        x = *reinterpret_cast<const uint64_t*>(mb + W.off[r * 4 + 2]);
-        y = *reinterpret_cast<const uint64_t*>(mb + W.off[r * 4 + 3]);
-        ATLAS_G(a, b, c, d, x, y);
-        b = quad_perm64<0x93>(b);
-        c = quad_perm64<0x4E>(c);
-        d = quad_perm64<0x39>(d);
-    }
-    return h_lo ^ a ^ c;
+    U64 a = u64_split(h_lo), b = u64_split(iv_hi), c = u64_split(iv_lo);
+    U64 d = u64_split(iv_hi ^ (q == 0 ? (uint64_t)t_bytes : 0ULL) ^ (q == 2 ? ~0ULL : 0ULL));
+    auto zero_word = [](int w) constexpr { return (w >= 4 && w <= 6) || w >= 12 || (!PAYLOAD && w >= 8); };
+#define ATLAS_WORD(r, k0) u64_sel4(q, M[S[r][k0]], M[S[r][k0 + 2]], M[S[r][k0 + 4]], M[S[r][k0 + 6]])
+#define ATLAS_ZERO(r, k0) (zero_word(S[r][k0]) && zero_word(S[r][k0 + 2]) && zero_word(S[r][k0 + 4]) && zero_word(S[r][k0 + 6]))
+#define ATLAS_ROUND(r)                                                                                   \
+    do {                                                                                                  \
+        blake_g<ATLAS_ZERO(r, 0), ATLAS_ZERO(r, 1)>(a, b, c, d, ATLAS_WORD(r, 0), ATLAS_WORD(r, 1));       \
+        b = u64_quad_perm<0x39>(b); c = u64_quad_perm<0x4E>(c); d = u64_quad_perm<0x93>(d);               \
+        blake_g<ATLAS_ZERO(r, 8), ATLAS_ZERO(r, 9)>(a, b, c, d, ATLAS_WORD(r, 8), ATLAS_WORD(r, 9));       \
+        b = u64_quad_perm<0x93>(b); c = u64_quad_perm<0x4E>(c); d = u64_quad_perm<0x39>(d);               \
+    } while (0)
+    ATLAS_ROUND(0); ATLAS_ROUND(1); ATLAS_ROUND(2); ATLAS_ROUND(3); ATLAS_ROUND(4); ATLAS_ROUND(5);
+    ATLAS_ROUND(6); ATLAS_ROUND(7); ATLAS_ROUND(8); ATLAS_ROUND(9); ATLAS_ROUND(10); ATLAS_ROUND(11);
+#undef ATLAS_ROUND
+#undef ATLAS_ZERO
+#undef ATLAS_WORD
+    return h_lo ^ u64_join(u64_xor(a, c));
 }
-#undef ATLAS_G
 
-// LDS scratch of the wave-cooperative transcript: one 128-byte message block.
+// (kept for call-site compatibility; no LDS is used any more)
 struct WaveTranscriptLds {
-    uint64_t msg[16];
+    uint64_t unused;
 };
-
-// must be called once (by the whole wave) before the first absorb: zero the fixed words
-__device__ __forceinline__ void wt_init_lds(WaveTranscriptLds* S, uint32_t lane) {
-    if (lane < 16) S->msg[lane] = 0;
-}
+__device__ __forceinline__ void wt_init_lds(WaveTranscriptLds*, uint32_t) {}
 
 // state' = BLAKE2b-256(state || 0^28 || n_rounds_be32 || payload) (blake2b.rs:31-37,64-78)
-// pw = payload word for this lane's quad position (0 when has_payload == false)
-__device__ __forceinline__ void wt_absorb(WaveTranscript& T, WaveTranscriptLds* S, const WaveBlakeSched& W,
-                                          uint32_t lane, uint64_t pw, bool has_payload) {
+// pw = payload word for this lane's quad position (ignored when has_payload == false)
+template <bool PAYLOAD>
+__device__ __forceinline__ void wt_absorb_t(WaveTranscript& T, uint32_t lane, uint64_t pw) {
     const uint32_t q = lane & 3;
-    if (lane < 4) {
-        S->msg[lane] = T.sw;
-        S->msg[8 + lane] = pw;
+    U64 M[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) M[i] = U64{0, 0};
+    const U64 sw = u64_split(T.sw);
+    M[0] = u64_quad_perm<0x00>(sw); M[1] = u64_quad_perm<0x55>(sw);      // broadcast lane k of the quad
+    M[2] = u64_quad_perm<0xAA>(sw); M[3] = u64_quad_perm<0xFF>(sw);
+    M[7] = U64{0, __builtin_bswap32(T.n_rounds)};                        // bytes 60..63 big-endian
+    if constexpr (PAYLOAD) {
+        const U64 p = u64_split(pw);
+        M[8] = u64_quad_perm<0x00>(p); M[9] = u64_quad_perm<0x55>(p);
+        M[10] = u64_quad_perm<0xAA>(p); M[11] = u64_quad_perm<0xFF>(p);
     }
-    if (lane == 0) S->msg[7] = (uint64_t)__builtin_bswap32(T.n_rounds) << 32;   // bytes 60..63 BE
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    T.sw = wave_blake2b_block(S->msg, W, q, has_payload ? 96 : 64);
+    T.sw = wave_blake2b_block<PAYLOAD>(M, q, PAYLOAD ? 96u : 64u);
     T.n_rounds += 1;
-    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void wt_absorb(WaveTranscript& T, WaveTranscriptLds*, const WaveBlakeSched&,
+                                          uint32_t lane, uint64_t pw, bool has_payload) {
+    if (has_payload) wt_absorb_t<true>(T, lane, pw);
+    else wt_absorb_t<false>(T, lane, pw);
 }
 
 // append_message with a label packed by the host into 4 LE words (blake2b.rs:109-122)
