@@ -129,6 +129,17 @@ int atlas_eq_evals(const atlas_fr_t *r, size_t n, const atlas_fr_t *scaling, atl
  * P(r), r[0] = MSB variable; p is not modified */
 int atlas_poly_evaluate(atlas_poly_t p, const atlas_fr_t *r, size_t n, atlas_fr_t *out);
 
+/* ---- einsum operand folds: i32 matrix x Fr vector
+ *      (EinsumLayout::fold, jolt-atlas-core/src/onnx_proof/ops/einsum/mk_kn_mn.rs:47-79;
+ *       the operands are Tensor<i32>, row-major, resident in HBM) ------------------------- */
+int atlas_i32_upload(const int32_t *host, size_t n, int32_t **d_out);   /* Tensor<i32> -> HBM */
+int atlas_i32_free(int32_t *d);
+/* out[j] = sum_h M[j*cols + h] * eq[h]   (`right` of mk,kn->mn with M = B (k x n), eq = eq_r_n);
+ * rows must be a power of two; eq = device table of `cols` Fr (atlas_eq_evals) */
+int atlas_fold_i32_rows(const int32_t *d_matrix, size_t rows, size_t cols, atlas_poly_t eq, atlas_poly_t *out);
+/* out[j] = sum_i M[i*cols + j] * eq[i]   (`left` of mk,kn->mn with M = A (m x k), eq = eq_r_m) */
+int atlas_fold_i32_cols(const int32_t *d_matrix, size_t rows, size_t cols, atlas_poly_t eq, atlas_poly_t *out);
+
 /* ---- sumcheck: MulProver over GruenSplitEqPolynomial (element-wise ops)
  *      (jolt-atlas-core/src/onnx_proof/ops/mul.rs:125-185;
  *       joltworks/src/poly/split_eq_poly.rs:86-145,331-429,526-597) ----------------------- */

@@ -410,6 +410,40 @@ class MulProver:
             self.h = None
 
 
+class TensorI32:
+    """A row-major Tensor<i32> resident in HBM (einsum operand)."""
+
+    def __init__(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.int32)
+        self.shape = arr.shape
+        self.d = C.POINTER(C.c_int32)()
+        lib.atlas_i32_upload.restype = C.c_int
+        _check(lib.atlas_i32_upload(arr.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(arr.size), C.byref(self.d)))
+
+    def free(self):
+        if self.d:
+            lib.atlas_i32_free(self.d)
+            self.d = None
+
+
+def fold_rows(t: TensorI32, eq: MultilinearPolynomial):
+    """out[j] = sum_h M[j, h] * eq[h]  (mk_kn_mn.rs:66-73, the `right` fold)."""
+    rows, cols = t.shape
+    h = C.c_void_p()
+    lib.atlas_fold_i32_rows.restype = C.c_int
+    _check(lib.atlas_fold_i32_rows(t.d, C.c_size_t(rows), C.c_size_t(cols), eq.h, C.byref(h)))
+    return MultilinearPolynomial(h)
+
+
+def fold_cols(t: TensorI32, eq: MultilinearPolynomial):
+    """out[j] = sum_i M[i, j] * eq[i]  (mk_kn_mn.rs:57-65, the `left` fold)."""
+    rows, cols = t.shape
+    h = C.c_void_p()
+    lib.atlas_fold_i32_cols.restype = C.c_int
+    _check(lib.atlas_fold_i32_cols(t.d, C.c_size_t(rows), C.c_size_t(cols), eq.h, C.byref(h)))
+    return MultilinearPolynomial(h)
+
+
 class HyperKZG:
     """CommitmentScheme arithmetic for HyperKZG (commitment_scheme.rs:11-131)."""
 
