@@ -140,6 +140,24 @@ int atlas_fold_i32_rows(const int32_t *d_matrix, size_t rows, size_t cols, atlas
 /* out[j] = sum_i M[i*cols + j] * eq[i]   (`left` of mk,kn->mn with M = A (m x k), eq = eq_r_m) */
 int atlas_fold_i32_cols(const int32_t *d_matrix, size_t rows, size_t cols, atlas_poly_t eq, atlas_poly_t *out);
 
+/* ---- Shout lookup argument: prover-side table builds
+ *      (joltworks/src/subprotocols/shout.rs:193-262, 550-598) ---------------------------- */
+/* ReadRafProver::initialize: G[k] = sum_{j : lookup_indices[j] = k} E[j], E = eq_r (device
+ * table of >= T Fr); out = 2^log_K Fr */
+int atlas_shout_read_raf_G(const uint64_t *lookup_indices, size_t T, size_t log_K, atlas_poly_t eq_r,
+                           atlas_poly_t *out);
+/* compute_ra_evals: the same histogram for each of the d = ceil(log_K / log_k_chunk) chunks of
+ * the lookup index (chunk 0 = most significant, config.rs:73-75); out = d * 2^log_k_chunk Fr,
+ * row i = chunk i (shared by the RaVirtual / HammingWeight / Booleanity provers) */
+int atlas_shout_ra_evals(const uint64_t *lookup_indices, size_t T, size_t log_K, size_t log_k_chunk,
+                         atlas_poly_t eq_r_cycle, atlas_poly_t *out);
+/* ReadRafProver as a sumcheck instance: sum_k G[k] (val[k] + gamma int[k]) over the 2^log_K
+ * table, HighToLow, degree 2.  Takes ownership of G; the returned handle is driven with the
+ * atlas_dot_* / atlas_sumcheck_prove_dot entry points (final_claims[0] = G(r), what
+ * cache_openings appends, shout.rs:264-277). */
+int atlas_shout_read_raf_prover_new(atlas_poly_t G, const int32_t *table, size_t log_K,
+                                    const atlas_fr_t *gamma, atlas_dot_prover_t *out);
+
 /* ---- sumcheck: MulProver over GruenSplitEqPolynomial (element-wise ops)
  *      (jolt-atlas-core/src/onnx_proof/ops/mul.rs:125-185;
  *       joltworks/src/poly/split_eq_poly.rs:86-145,331-429,526-597) ----------------------- */

@@ -410,6 +410,43 @@ class MulProver:
             self.h = None
 
 
+class Shout:
+    """Prover-side table builds of the Shout lookup argument (subprotocols/shout.rs)."""
+
+    @staticmethod
+    def read_raf_G(lookup_indices, log_K, eq_r: MultilinearPolynomial):
+        idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)
+        h = C.c_void_p()
+        lib.atlas_shout_read_raf_G.restype = C.c_int
+        _check(lib.atlas_shout_read_raf_G(idx.ctypes.data_as(u64p), C.c_size_t(len(idx)), C.c_size_t(log_K), eq_r.h,
+                                          C.byref(h)))
+        return MultilinearPolynomial(h)
+
+    @staticmethod
+    def ra_evals(lookup_indices, log_K, log_k_chunk, eq_r_cycle: MultilinearPolynomial):
+        idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)
+        h = C.c_void_p()
+        lib.atlas_shout_ra_evals.restype = C.c_int
+        _check(lib.atlas_shout_ra_evals(idx.ctypes.data_as(u64p), C.c_size_t(len(idx)), C.c_size_t(log_K),
+                                        C.c_size_t(log_k_chunk), eq_r_cycle.h, C.byref(h)))
+        return MultilinearPolynomial(h)
+
+    @staticmethod
+    def read_raf_prover(G: MultilinearPolynomial, table, log_K, gamma_fr):
+        """ReadRafProver (shout.rs:184-277) as an EinsumDotProver-shaped handle."""
+        tab = np.ascontiguousarray(table, dtype=np.int32)
+        gm = _fr(gamma_fr)
+        h = C.c_void_p()
+        lib.atlas_shout_read_raf_prover_new.restype = C.c_int
+        _check(lib.atlas_shout_read_raf_prover_new(G.h, tab.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(log_K),
+                                                   _p(gm), C.byref(h)))
+        G.h = None
+        p = EinsumDotProver.__new__(EinsumDotProver)
+        p.h = h
+        p.deg = 2
+        return p
+
+
 class TensorI32:
     """A row-major Tensor<i32> resident in HBM (einsum operand)."""
 

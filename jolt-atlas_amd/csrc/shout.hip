@@ -1,0 +1,189 @@
+// Shout lookup argument, prover-side table builds.
+//
+// Device counterpart of (paths under the jolt-atlas tree):
+//   ReadRafProver::initialize   joltworks/src/subprotocols/shout.rs:193-225
+//        G[k] = sum_{j : idx_j = k} E[j],  E = eq(r_cycle, .)     (weighted histogram)
+//   ReadRafProver::compute_message / ingest_challenge   shout.rs:233-262
+//        sum_k G[k] * (val[k] + gamma * int[k]),  HighToLow, degree 2
+//        = the dot-product instance over (G, W), W = val + gamma * int (both multilinear, so
+//          binding W equals binding val and int separately): reuses the fused dot kernels.
+//   compute_ra_evals            shout.rs:550-598 : the same histogram per 4-bit chunk of the
+//        lookup index (OneHotParams::lookup_index_chunk, config.rs:73-75), d chunks at once.
+//
+// Fr has no atomic add, so the histogram is a counting sort by bucket (u32 atomics: count ->
+// exclusive scan -> scatter of j) followed by one workgroup (or one thread, for large tables)
+// per bucket summing E over its list with the lazy 29-bit-limb adds.  Any summation order
+// gives the same residue.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "../../include/atlas_hip.h"
+#include "f9.hip.h"
+#include "host_field.hpp"
+#include "scan.hip.h"
+#include "runtime.hpp"
+
+using namespace atlas;
+namespace H = atlas_host;
+using atlas_rt::fail;
+using atlas_rt::g;
+
+namespace {
+
+constexpr int SH_THREADS = 256;
+
+struct KeySpec {          // key(j, i) = i * k_chunk + ((idx_j >> shift_i) & (k_chunk - 1)), i < d
+    uint32_t d;
+    uint32_t log_k_chunk;
+};
+
+__device__ __forceinline__ uint32_t key_of(uint64_t idx, uint32_t i, KeySpec S) {
+    const uint32_t shift = S.log_k_chunk * (S.d - 1 - i);
+    const uint32_t chunk = S.log_k_chunk >= 64 ? 0u : (uint32_t)((idx >> shift) & ((1ull << S.log_k_chunk) - 1));
+    return (i << S.log_k_chunk) + chunk;
+}
+
+__global__ __launch_bounds__(SH_THREADS) void k_sh_hist(const uint64_t* __restrict__ idx, size_t T, KeySpec S, uint32_t* counts) {
+    for (size_t j = (size_t)blockIdx.x * SH_THREADS + threadIdx.x; j < T; j += (size_t)gridDim.x * SH_THREADS) {
+        const uint64_t v = idx[j];
+        for (uint32_t i = 0; i < S.d; i++) atomicAdd(&counts[key_of(v, i, S)], 1u);
+    }
+}
+
+__global__ __launch_bounds__(SH_THREADS) void k_sh_scatter(const uint64_t* __restrict__ idx, size_t T, KeySpec S,
+                                                           uint32_t* cursor, uint32_t* __restrict__ sorted) {
+    for (size_t j = (size_t)blockIdx.x * SH_THREADS + threadIdx.x; j < T; j += (size_t)gridDim.x * SH_THREADS) {
+        const uint64_t v = idx[j];
+        for (uint32_t i = 0; i < S.d; i++) sorted[atomicAdd(&cursor[key_of(v, i, S)], 1u)] = (uint32_t)j;
+    }
+}
+
+// one workgroup per bucket
+__global__ __launch_bounds__(SH_THREADS) void k_sh_bucket_sum_wg(const Fe* __restrict__ E, const uint32_t* __restrict__ sorted,
+                                                                 const uint32_t* __restrict__ offsets, Fe* __restrict__ G) {
+    using P9 = Fr9Params;
+    const uint32_t b = blockIdx.x, lo = offsets[b], hi = offsets[b + 1];
+    F9 acc = f9_zero();
+    for (uint32_t t = lo + threadIdx.x; t < hi; t += SH_THREADS) acc = f9_norm_red<P9>(f9_add(acc, f9_load(E + sorted[t])));
+    acc = f9_wave_sum<P9>(acc);
+    __shared__ F9 red[SH_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        F9 s = red[0];
+        for (int w = 1; w < SH_THREADS / 64; w++) s = f9_norm_red<P9>(f9_add(s, red[w]));
+        fe_store(G + b, f9_canon<P9>(s));
+    }
+}
+
+// one thread per bucket (large tables, short lists)
+__global__ __launch_bounds__(SH_THREADS) void k_sh_bucket_sum_thread(const Fe* __restrict__ E, const uint32_t* __restrict__ sorted,
+                                                                     const uint32_t* __restrict__ offsets, uint32_t n_buckets,
+                                                                     Fe* __restrict__ G) {
+    using P9 = Fr9Params;
+    const uint32_t b = blockIdx.x * SH_THREADS + threadIdx.x;
+    if (b >= n_buckets) return;
+    F9 acc = f9_zero();
+    for (uint32_t t = offsets[b]; t < offsets[b + 1]; t++) acc = f9_norm_red<P9>(f9_add(acc, f9_load(E + sorted[t])));
+    fe_store(G + b, f9_canon<P9>(acc));
+}
+
+// W[k] = from_i32(table[k]) + gamma * k   (val + gamma * IdentityPolynomial)
+__global__ __launch_bounds__(SH_THREADS) void k_sh_build_w(const int32_t* __restrict__ table, size_t K, Fe gamma, Fe* __restrict__ W) {
+    for (size_t k = (size_t)blockIdx.x * SH_THREADS + threadIdx.x; k < K; k += (size_t)gridDim.x * SH_THREADS) {
+        const Fe v = fr_from_i64((int64_t)table[k]);
+        const Fe kk = fr_from_i64((int64_t)k);
+        fe_store(W + k, fr_add(v, fr_mul(gamma, kk)));
+    }
+}
+
+inline int grid_for(size_t work) {
+    size_t b = (work + SH_THREADS - 1) / SH_THREADS;
+    return (int)(b < 1 ? 1 : b > 2048 ? 2048 : b);
+}
+
+// weighted histogram: G[key] = sum E[j] over the (j, i) pairs with that key; n_buckets = d * k_chunk
+int histogram(const uint64_t* h_idx, size_t T, KeySpec S, const atlas_poly* E, atlas_poly_t* out) {
+    const uint32_t n_buckets = S.d << S.log_k_chunk;
+    if (E->is_i32 || E->len < T) return fail(ATLAS_EINVAL, "shout: eq table shorter than the index list");
+    if (T >= (1ull << 31) || (uint64_t)T * S.d >= (1ull << 32)) return fail(ATLAS_EINVAL, "shout: too many lookups");
+    uint64_t* d_idx = nullptr; uint32_t *counts = nullptr, *offsets = nullptr, *cursor = nullptr, *sorted = nullptr;
+    Fe* G = nullptr;
+    auto cleanup = [&]() { hipFree(d_idx); hipFree(counts); hipFree(offsets); hipFree(cursor); hipFree(sorted); };
+    HIP_TRY(hipMalloc(&d_idx, (T ? T : 1) * 8));
+    HIP_TRY(hipMalloc(&counts, (size_t)(n_buckets + 1) * 4));
+    HIP_TRY(hipMalloc(&offsets, (size_t)(n_buckets + 1) * 4));
+    HIP_TRY(hipMalloc(&cursor, (size_t)(n_buckets + 1) * 4));
+    HIP_TRY(hipMalloc(&sorted, (T * S.d ? T * S.d : 1) * 4));
+    hipError_t e = hipMalloc(&G, (size_t)n_buckets * sizeof(Fe));
+    if (e != hipSuccess) { cleanup(); return fail(ATLAS_ENOMEM, "hipMalloc(G)", e); }
+    HIP_TRY(hipMemcpyAsync(d_idx, h_idx, T * 8, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemsetAsync(counts, 0, (size_t)(n_buckets + 1) * 4, g.stream));
+    k_sh_hist<<<grid_for(T), SH_THREADS, 0, g.stream>>>(d_idx, T, S, counts);
+    k_exclusive_scan<<<1, 1024, 0, g.stream>>>(counts, n_buckets, offsets, cursor);
+    k_sh_scatter<<<grid_for(T), SH_THREADS, 0, g.stream>>>(d_idx, T, S, cursor, sorted);
+    if (n_buckets <= 8192)
+        k_sh_bucket_sum_wg<<<n_buckets, SH_THREADS, 0, g.stream>>>((const Fe*)E->d, sorted, offsets, G);
+    else
+        k_sh_bucket_sum_thread<<<(n_buckets + SH_THREADS - 1) / SH_THREADS, SH_THREADS, 0, g.stream>>>((const Fe*)E->d, sorted, offsets, n_buckets, G);
+    e = hipStreamSynchronize(g.stream);
+    cleanup();
+    if (e != hipSuccess) { hipFree(G); return fail(ATLAS_ENODEV, "shout histogram", e); }
+    atlas_poly* p = new atlas_poly();
+    p->d = G; p->len = n_buckets; p->cap_bytes = (size_t)n_buckets * sizeof(Fe); p->is_i32 = false; p->owned = true;
+    *out = p;
+    return ATLAS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int atlas_shout_read_raf_G(const uint64_t* lookup_indices, size_t T, size_t log_K, atlas_poly_t eq_r, atlas_poly_t* out) {
+    NEED_INIT();
+    if ((!lookup_indices && T) || !eq_r || !out || log_K > 24) return fail(ATLAS_EINVAL, "shout_read_raf_G");
+    for (size_t j = 0; j < T; j++)
+        if (lookup_indices[j] >> log_K) return fail(ATLAS_EINVAL, "shout_read_raf_G: lookup index outside the table");
+    std::lock_guard<std::mutex> lk(g.mu);
+    return histogram(lookup_indices, T, KeySpec{1u, (uint32_t)log_K}, eq_r, out);
+}
+
+int atlas_shout_ra_evals(const uint64_t* lookup_indices, size_t T, size_t log_K, size_t log_k_chunk, atlas_poly_t eq_r_cycle,
+                         atlas_poly_t* out) {
+    NEED_INIT();
+    if ((!lookup_indices && T) || !eq_r_cycle || !out || log_k_chunk == 0 || log_k_chunk > 16 || log_K == 0 || log_K > 64)
+        return fail(ATLAS_EINVAL, "shout_ra_evals");
+    const uint32_t d = (uint32_t)((log_K + log_k_chunk - 1) / log_k_chunk);     // instruction_d (config.rs:45)
+    std::lock_guard<std::mutex> lk(g.mu);
+    return histogram(lookup_indices, T, KeySpec{d, (uint32_t)log_k_chunk}, eq_r_cycle, out);
+}
+
+int atlas_shout_read_raf_prover_new(atlas_poly_t G, const int32_t* table, size_t log_K, const atlas_fr_t* gamma,
+                                    atlas_dot_prover_t* out) {
+    NEED_INIT();
+    if (!G || !table || !gamma || !out) return fail(ATLAS_EINVAL, "shout_read_raf_prover_new");
+    const size_t K = (size_t)1 << log_K;
+    if (G->is_i32 || G->len != K) return fail(ATLAS_EINVAL, "shout_read_raf_prover_new: G length != table size");
+    int32_t* d_tab = nullptr; Fe* W = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        HIP_TRY(hipMalloc(&d_tab, K * 4));
+        hipError_t e = hipMalloc(&W, K * sizeof(Fe));
+        if (e != hipSuccess) { hipFree(d_tab); return fail(ATLAS_ENOMEM, "hipMalloc(W)", e); }
+        HIP_TRY(hipMemcpyAsync(d_tab, table, K * 4, hipMemcpyHostToDevice, g.stream));
+        Fe gm; std::memcpy(gm.v, gamma, 32);
+        k_sh_build_w<<<grid_for(K), SH_THREADS, 0, g.stream>>>(d_tab, K, gm, W);
+        e = hipStreamSynchronize(g.stream);
+        hipFree(d_tab);
+        if (e != hipSuccess) { hipFree(W); return fail(ATLAS_ENODEV, "shout build W", e); }
+    }
+    atlas_poly* w = new atlas_poly();
+    w->d = W; w->len = K; w->cap_bytes = K * sizeof(Fe); w->is_i32 = false; w->owned = true;
+    int rc = atlas_dot_prover_new(G, w, nullptr, ATLAS_EQ_NONE, 0, 0, out);
+    if (rc) atlas_poly_free(w);
+    return rc;
+}
+
+}  // extern "C"
