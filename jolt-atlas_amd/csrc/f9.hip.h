@@ -153,11 +153,14 @@ __device__ __forceinline__ F9 f9_norm(const F9& a) {
 // carry propagation + one conditional subtraction of 2p: for an input < ~4p the result is
 // normalized and < 2p(1 + 2^-20).  The decision uses a lower estimate of the top limb, so
 // the subtraction never underflows.
-template <class P9>
+template <class P9, int MAXK = 2>
 __device__ __forceinline__ F9 f9_norm_red(const F9& a) {
-    // k = how many times 2p is subtracted (0, 1 or 2): any input < 6p comes out < 2p(1+2^-20)
+    // k = how many times 2p is subtracted (0..MAXK): any input < (2 MAXK + 2) p comes out
+    // < 2p(1+2^-20).  floor(2jp / 2^232) <= j TOP2P + j, so top_est > j TOP2P + j  =>  value > 2jp.
     const uint32_t top_est = a.l[8] + (a.l[7] >> 29);
-    const uint32_t k = top_est > 2 * P9::TOP2P + 2 ? 2u : (top_est > P9::TOP2P + 1 ? 1u : 0u);
+    uint32_t k = 0;
+#pragma unroll
+    for (uint32_t j = 1; j <= (uint32_t)MAXK; j++) k = top_est > j * P9::TOP2P + j ? j : k;
     F9 o;
     int32_t c = 0;
 #pragma unroll

@@ -80,7 +80,9 @@ int msm_device(const G1Affine* bases, const Fr* d_scalars, size_t n, atlas_g1_af
     // workspace carve-up
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    const size_t o_canon = carve(n * sizeof(Fr));
+    const size_t o_digits = carve(n * (size_t)S.n_windows * sizeof(int16_t));
+    const size_t n_scan_blocks = ((size_t)TB + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    const size_t o_bsum = carve((n_scan_blocks + 1) * 4 * 3);
     const size_t o_counts = carve((size_t)(TB + 1) * 4);
     const size_t o_offsets = carve((size_t)(TB + 1) * 4);
     const size_t o_cursor = carve((size_t)(TB + 1) * 4);
@@ -91,7 +93,10 @@ int msm_device(const G1Affine* bases, const Fr* d_scalars, size_t n, atlas_g1_af
     int rc = ws.ensure(off);
     if (rc) return rc;
     unsigned char* W = (unsigned char*)ws.p;
-    Fr* canon = (Fr*)(W + o_canon);
+    int16_t* digits = (int16_t*)(W + o_digits);
+    uint32_t* bsum = (uint32_t*)(W + o_bsum);
+    uint32_t* boff = bsum + (n_scan_blocks + 1);
+    uint32_t* bcur = boff + (n_scan_blocks + 1);
     uint32_t* counts = (uint32_t*)(W + o_counts);
     uint32_t* offsets = (uint32_t*)(W + o_offsets);
     uint32_t* cursor = (uint32_t*)(W + o_cursor);
@@ -104,10 +109,14 @@ int msm_device(const G1Affine* bases, const Fr* d_scalars, size_t n, atlas_g1_af
     if (g.timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2); hipEventCreate(&e3); hipEventRecord(e0, g.stream); }
 
     HIP_TRY(hipMemsetAsync(counts, 0, (size_t)(TB + 1) * 4, g.stream));
-    k_msm_canon<<<grid_for(n), MSM_THREADS, 0, g.stream>>>(d_scalars, canon, n);
-    k_msm_hist<<<grid_for(n), MSM_THREADS, 0, g.stream>>>(canon, n, S, counts);
-    k_exclusive_scan<<<1, 1024, 0, g.stream>>>(counts, TB, offsets, cursor);
-    k_msm_scatter<<<grid_for(n), MSM_THREADS, 0, g.stream>>>(canon, n, S, cursor, sorted);
+    // signed digits once, window-major; histogram of all windows; scan; scatter window by window
+    k_msm_digits<<<grid_for(n), MSM_THREADS, 0, g.stream>>>(d_scalars, n, S, digits);
+    k_msm_hist_w<<<dim3((unsigned)grid_for(n, 256), S.n_windows), MSM_THREADS, 0, g.stream>>>(digits, n, S, counts);
+    k_scan_block_sums<<<(unsigned)n_scan_blocks, 256, 0, g.stream>>>(counts, TB, bsum);
+    k_exclusive_scan<<<1, 1024, 0, g.stream>>>(bsum, (uint32_t)n_scan_blocks, boff, bcur);
+    k_scan_apply<<<(unsigned)n_scan_blocks, 256, 0, g.stream>>>(counts, TB, boff, offsets, cursor, (uint32_t)n_scan_blocks);
+    for (uint32_t w = 0; w < S.n_windows; w++)
+        k_msm_scatter_w<<<grid_for(n, 1024), MSM_THREADS, 0, g.stream>>>(digits + (size_t)w * n, n, cursor + (size_t)w * S.bpw, sorted);
     if (g.timing) hipEventRecord(e1, g.stream);
     k_msm_accumulate<<<(TB + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, g.stream>>>(bases, sorted, offsets, TB, buckets);
     if (g.timing) hipEventRecord(e2, g.stream);

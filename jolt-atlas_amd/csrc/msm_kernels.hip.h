@@ -14,6 +14,7 @@
 // the one inversion to affine run on the host.
 #pragma once
 #include "curve.hip.h"
+#include "curve_f9.hip.h"
 #include "scan.hip.h"
 
 namespace atlas {
@@ -50,7 +51,8 @@ __device__ __forceinline__ void for_each_digit(const Fr& k, const MsmShape S, F&
         const uint32_t lo = w * S.c;
         uint32_t d = (lo < 256 ? bits_at(k.v, lo, S.c) : 0u) + carry;
         carry = 0;
-        if (d > half) { d = (1u << S.c) - d; carry = 1; if (d) f(w, d - 1, true); }
+        // d >= half goes negative: positive digits <= half-1, negative magnitudes <= half (fits int16 at c = 16)
+        if (d >= half) { d = (1u << S.c) - d; carry = 1; if (d) f(w, d - 1, true); }
         else if (d) f(w, d - 1, false);
     }
 }
@@ -64,6 +66,46 @@ __global__ __launch_bounds__(MSM_THREADS) void k_msm_hist(const Fr* __restrict__
 }
 
 // (k_exclusive_scan lives in scan.hip.h)
+
+// ---- window-major digit pipeline -------------------------------------------------------
+// Signed digits are computed once (Montgomery -> canonical -> 16 x int16 per scalar) and stored
+// window-major (digits[w*n + i]), so the histogram / scatter of ONE window touches n*2 bytes
+// of input and a bucket range of 2^(c-1) counters + ~n entries of output: the random part of
+// the counting sort stays inside the 32 MiB of L2 instead of spraying the whole N*W*4 B array.
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_digits(const Fr* __restrict__ s, size_t n, MsmShape S,
+                                                            int16_t* __restrict__ digits) {
+    for (size_t i = (size_t)blockIdx.x * MSM_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * MSM_THREADS) {
+        const Fr k = fe_from_mont<FrParams>(fe_load(s + i));
+        for (uint32_t w = 0; w < S.n_windows; w++) digits[(size_t)w * n + i] = 0;
+        for_each_digit(k, S, [&](uint32_t w, uint32_t b, bool neg) {
+            digits[(size_t)w * n + i] = neg ? (int16_t)(-(int32_t)(b + 1)) : (int16_t)(b + 1);
+        });
+    }
+}
+
+// blockIdx.y = window
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_hist_w(const int16_t* __restrict__ digits, size_t n, MsmShape S,
+                                                            uint32_t* counts) {
+    const uint32_t w = blockIdx.y;
+    const int16_t* dw = digits + (size_t)w * n;
+    uint32_t* cw = counts + (size_t)w * S.bpw;
+    for (size_t i = (size_t)blockIdx.x * MSM_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * MSM_THREADS) {
+        const int32_t d = dw[i];
+        if (d) atomicAdd(&cw[(d < 0 ? -d : d) - 1], 1u);
+    }
+}
+
+// one window per launch
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_scatter_w(const int16_t* __restrict__ dw, size_t n,
+                                                               uint32_t* cursor_w, uint32_t* __restrict__ sorted) {
+    for (size_t i = (size_t)blockIdx.x * MSM_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * MSM_THREADS) {
+        const int32_t d = dw[i];
+        if (d) {
+            const uint32_t pos = atomicAdd(&cursor_w[(d < 0 ? -d : d) - 1], 1u);
+            sorted[pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+        }
+    }
+}
 
 __global__ __launch_bounds__(MSM_THREADS) void k_msm_scatter(const Fr* __restrict__ canon, size_t n, MsmShape S,
                                                              uint32_t* cursor, uint32_t* __restrict__ sorted) {
@@ -84,14 +126,17 @@ __global__ __launch_bounds__(MSM_THREADS) void k_msm_accumulate(const G1Affine* 
     const uint32_t b = blockIdx.x * MSM_THREADS + threadIdx.x;
     if (b >= n_buckets) return;
     const uint32_t lo = offsets[b], hi = offsets[b + 1];
-    G1Xyzz acc = g1_inf();
+    // 29-bit lazy-limb accumulator (curve_f9.hip.h); canonical XYZZ written once per bucket
+    G1Xyzz9 acc;
+    acc.inf = true;
+    acc.x = f9_zero(); acc.y = f9_zero(); acc.zz = f9_zero(); acc.zzz = f9_zero();
     for (uint32_t j = lo; j < hi; j++) {
         const uint32_t v = sorted[j];
         const G1Affine p = g1_aff_load(bases + (v & 0x7fffffffu));
         if (g1_aff_is_inf(p)) continue;
-        acc = g1_madd(acc, p, (v >> 31) != 0);
+        g1_madd_f9(acc, p, (v >> 31) != 0);
     }
-    g1_store(buckets + b, acc);
+    g1_store(buckets + b, g1_from_f9(acc));
 }
 
 // small * P by double-and-add
