@@ -218,6 +218,23 @@ int atlas_hyperkzg_open(atlas_srs_t srs, atlas_poly_t poly, const atlas_u128_t *
 int atlas_transcript_append_point(atlas_transcript_t *t, const atlas_g1_affine_t *p);
 int atlas_transcript_append_points(atlas_transcript_t *t, const atlas_g1_affine_t *p, size_t n);
 
+/* ---- one instance / one MSM sharded over the GPUs of a node (one process per GPU) -------
+ * Rank g of `world` holds the strided shard L_g[k] = L[k*world + g] of each operand (the
+ * HighToLow pairs (i, i + len/2) stay on one rank).  Per round: local partial message ->
+ * all-gather of world*2 Fr (RCCL over xGMI, done by the caller with torch.distributed) ->
+ * the same transcript step on every rank.  Degree-2 LargeScalars instances. */
+int atlas_dot_shard_begin(atlas_dot_prover_t p, const atlas_fr_t *input_claim,
+                          const atlas_transcript_t *transcript);
+int atlas_dot_shard_local_message(atlas_dot_prover_t p, atlas_fr_t *out2);        /* this rank's 2 partial evals */
+int atlas_dot_shard_round(atlas_dot_prover_t p, const atlas_fr_t *gathered, size_t world); /* world*2, rank-major */
+int atlas_dot_shard_local_final(atlas_dot_prover_t p, atlas_fr_t *out2);          /* (L_g, R_g) after the local rounds */
+int atlas_dot_shard_finish(atlas_dot_prover_t p, const atlas_fr_t *gathered_lr, size_t world,
+                           atlas_transcript_t *transcript, atlas_fr_t *compressed_polys,
+                           atlas_u128_t *challenges, atlas_fr_t final_claims[3]);
+int atlas_fr_sum(const atlas_fr_t *v, size_t n, atlas_fr_t *out);                 /* host: sum of per-rank claims */
+/* host: sum of the per-rank partial MSM results of a point-range sharded commitment */
+int atlas_g1_sum_affine(const atlas_g1_affine_t *pts, size_t n, atlas_g1_affine_t *out);
+
 /* ---- measurement: HIP-event time of the launches issued by the last
  *      atlas_sumcheck_prove_dot / atlas_msm_* call, on the library stream ------------- */
 typedef struct {

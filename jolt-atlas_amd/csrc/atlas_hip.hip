@@ -89,6 +89,10 @@ struct atlas_dot_prover {
     size_t a = 0, b = 0;
     size_t n_rounds = 0;
     bool consumed = false;
+    // sharded stepping (atlas_dot_shard_*): messages emitted so far / unapplied challenge
+    size_t shard_rounds_done = 0;
+    bool shard_pending = false;
+    bool shard_active = false;
 };
 
 // ------------------------------------------------------------------ runtime API
@@ -689,6 +693,154 @@ int atlas_sumcheck_prove_dot(atlas_dot_prover_t P, const atlas_fr_t* input_claim
     std::lock_guard<std::mutex> lk(g.mu);
     if (P->schedule == ATLAS_EQ_NONE) return prove_dot_impl<2>(P, input_claim, transcript, compressed_polys, challenges, final_claims);
     return prove_dot_impl<3>(P, input_claim, transcript, compressed_polys, challenges, final_claims);
+}
+
+// ------------------------------------------------------------------ sharded instance (multi-GPU)
+// One sumcheck instance split over `world` ranks, one GPU each.  Rank g holds the
+// strided shard L_g[k] = L[k*world + g] (HighToLow binding pairs i and i + len/2, which have
+// the same residue mod world, so the first n - log2(world) rounds need no data exchange).
+// Per round every rank computes its local partial message, the ranks all-gather world*DEG
+// field elements (RCCL / torch.distributed, done by the caller) and every rank runs the same
+// transcript step on the gathered partials — the challenge is identical everywhere, no
+// broadcast.  After the local rounds each rank holds one coefficient per operand; these are
+// gathered and the last log2(world) rounds run redundantly on every rank.
+// Degree-2 (EqSchedule::None) LargeScalars instances.
+
+int atlas_dot_shard_begin(atlas_dot_prover_t P, const atlas_fr_t* input_claim, const atlas_transcript_t* transcript) {
+    NEED_INIT();
+    if (!P || !input_claim || !transcript) return fail(ATLAS_EINVAL, "dot_shard_begin: null argument");
+    if (P->schedule != ATLAS_EQ_NONE || P->left->is_i32) return fail(ATLAS_EINVAL, "dot_shard_begin: degree-2 LargeScalars instances only");
+    if (P->consumed || P->left->len != ((size_t)1 << P->n_rounds)) return fail(ATLAS_ESTATE, "dot_shard_begin: prover already used");
+    std::lock_guard<std::mutex> lk(g.mu);
+    ScCtx* hctx = reinterpret_cast<ScCtx*>(g.h_pinned);
+    std::memset(hctx, 0, sizeof(ScCtx));
+    std::memcpy(&hctx->tr, transcript, sizeof(DevTranscript));
+    std::memcpy(&hctx->claim, input_claim, sizeof(Fr));
+    HIP_TRY(hipMemcpyAsync(g.d_ctx, hctx, sizeof(ScCtx), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    P->shard_rounds_done = 0; P->shard_pending = false; P->shard_active = true;
+    return ATLAS_OK;
+}
+
+// local partial of the next message: 2 Fr (evals at 0 and 2 over this rank's shard) -> host
+int atlas_dot_shard_local_message(atlas_dot_prover_t P, atlas_fr_t* out2) {
+    NEED_INIT();
+    if (!P || !out2) return fail(ATLAS_EINVAL, "dot_shard_local_message");
+    if (!P->shard_active || P->left->len < 2) return fail(ATLAS_ESTATE, "dot_shard_local_message: no local round left");
+    std::lock_guard<std::mutex> lk(g.mu);
+    const ScConsts K = make_consts();
+    const int hi_only = g.challenge_mode == 0;
+    const bool f9 = g.challenge_mode == 0;
+    const size_t len = P->left->len;
+    int grid;
+    EqView eq; eq.p = nullptr; eq.mode = EQ_NONE; eq.shift = 0; eq.mask = 0; eq.half = 0;
+    if (!P->shard_pending) {          // first message: no bind
+        const size_t half = len / 2;
+        grid = (int)((half + SC_THREADS - 1) / SC_THREADS); if (grid > 256) grid = 256; if (grid < 1) grid = 1;
+        if (f9) k_dot_eval2_f9<<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, half, g.d_partials);
+        else k_dot_eval<2, Fr><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, eq, half, g.d_partials, K);
+    } else {                          // bind the last challenge, evaluate the next message
+        if (len < 4) return fail(ATLAS_ESTATE, "dot_shard_local_message: use atlas_dot_shard_local_final");
+        const size_t q = len / 4;
+        grid = (int)((q + SC_THREADS - 1) / SC_THREADS); if (grid > 256) grid = 256; if (grid < 1) grid = 1;
+        // canonical residues in HBM: the exact kernels may read them later (local_final)
+        if (f9) k_dot_bind_eval2_f9<true><<<grid, SC_THREADS, 0, g.stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, g.d_ctx, g.d_partials);
+        else k_dot_bind_eval<2, Fr, false><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, (Fr*)P->left->d, (Fr*)P->right->d, nullptr, eq, q, g.d_ctx, g.d_partials, K, hi_only);
+        P->left->len = len / 2; P->right->len = len / 2;
+        P->shard_pending = false;
+    }
+    k_reduce_partials<2><<<1, SC_THREADS, 0, g.stream>>>(g.d_partials, grid, g.d_finals + 3);
+    HIP_TRY(hipMemcpyAsync(g.h_pinned, g.d_finals + 3, 2 * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    std::memcpy(out2, g.h_pinned, 2 * sizeof(Fr));
+    return ATLAS_OK;
+}
+
+// transcript step on the gathered partials (world * 2 Fr, rank-major); identical on every rank
+int atlas_dot_shard_round(atlas_dot_prover_t P, const atlas_fr_t* gathered, size_t world) {
+    NEED_INIT();
+    if (!P || !gathered || world == 0 || world > SC_MAX_BLOCKS) return fail(ATLAS_EINVAL, "dot_shard_round");
+    if (!P->shard_active || P->shard_pending) return fail(ATLAS_ESTATE, "dot_shard_round: out of order");
+    std::lock_guard<std::mutex> lk(g.mu);
+    const ScConsts K = make_consts();
+    HIP_TRY(hipMemcpyAsync(g.d_partials, gathered, world * 2 * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    const size_t rd = P->shard_rounds_done;
+    if (rd >= MAX_ROUNDS) return fail(ATLAS_ESTATE, "dot_shard_round: too many rounds");
+    k_fs_round<2><<<1, SC_THREADS, 0, g.stream>>>(g.d_ctx, g.d_partials, (int)world, g.d_proof + rd * 2, g.d_chal + 2 * rd, K,
+                                                 rd == 0 ? 1 : 0, g.challenge_mode);
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    P->shard_rounds_done = rd + 1;
+    P->shard_pending = true;
+    return ATLAS_OK;
+}
+
+// after the last local round: apply the pending challenge to the two remaining coefficients
+// of each operand and return this rank's (L_g, R_g)
+int atlas_dot_shard_local_final(atlas_dot_prover_t P, atlas_fr_t* out2) {
+    NEED_INIT();
+    if (!P || !out2) return fail(ATLAS_EINVAL, "dot_shard_local_final");
+    if (!P->shard_active || !P->shard_pending || P->left->len != 2) return fail(ATLAS_ESTATE, "dot_shard_local_final: local rounds not finished");
+    std::lock_guard<std::mutex> lk(g.mu);
+    const int hi_only = g.challenge_mode == 0;
+    k_bind_hi<<<1, SC_THREADS, 0, g.stream>>>((Fr*)P->left->d, 1, &g.d_ctx->r, hi_only);
+    k_bind_hi<<<1, SC_THREADS, 0, g.stream>>>((Fr*)P->right->d, 1, &g.d_ctx->r, hi_only);
+    HIP_TRY(hipMemcpyAsync(g.h_pinned, P->left->d, sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync((char*)g.h_pinned + sizeof(Fr), P->right->d, sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    std::memcpy(out2, g.h_pinned, 2 * sizeof(Fr));
+    P->left->len = 1; P->right->len = 1; P->shard_pending = false;
+    return ATLAS_OK;
+}
+
+// gathered_lr: world * 2 Fr, rank-major (L_0, R_0, L_1, R_1, ...).  Runs the last log2(world)
+// rounds (same on every rank) and returns the whole proof.
+int atlas_dot_shard_finish(atlas_dot_prover_t P, const atlas_fr_t* gathered_lr, size_t world, atlas_transcript_t* transcript,
+                           atlas_fr_t* compressed_polys, atlas_u128_t* challenges, atlas_fr_t final_claims[3]) {
+    NEED_INIT();
+    if (!P || !gathered_lr || !transcript || !compressed_polys || !challenges || !final_claims || !is_pow2(world) ||
+        world > ((size_t)1 << SC_TAIL_LOG))
+        return fail(ATLAS_EINVAL, "dot_shard_finish");
+    if (!P->shard_active || P->left->len != 1 || P->shard_pending) return fail(ATLAS_ESTATE, "dot_shard_finish: out of order");
+    std::lock_guard<std::mutex> lk(g.mu);
+    const ScConsts K = make_consts();
+    const size_t n_total = P->shard_rounds_done + ilog2(world);
+    if (n_total > MAX_ROUNDS) return fail(ATLAS_EINVAL, "dot_shard_finish: too many rounds");
+    // de-interleave into two device arrays of `world` coefficients
+    std::vector<Fr> hl(world), hr(world);
+    for (size_t i = 0; i < world; i++) { std::memcpy(&hl[i], &gathered_lr[2 * i], sizeof(Fr)); std::memcpy(&hr[i], &gathered_lr[2 * i + 1], sizeof(Fr)); }
+    Fr *dl = nullptr, *dr = nullptr;
+    HIP_TRY(hipMalloc(&dl, world * sizeof(Fr))); HIP_TRY(hipMalloc(&dr, world * sizeof(Fr)));
+    HIP_TRY(hipMemcpyAsync(dl, hl.data(), world * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(dr, hr.data(), world * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    TailArgs A;
+    A.L = dl; A.R = dr; A.eq = nullptr; A.len = (uint32_t)world; A.eq_len = 0; A.src_i32 = 0;
+    A.sched = 0; A.a = 0; A.b = 0; A.round0 = (uint32_t)P->shard_rounds_done; A.n_rounds = (uint32_t)n_total;
+    A.first = 0; A.pending_bind = 0; A.challenge_mode = g.challenge_mode;
+    k_dot_tail<2><<<1, SC_THREADS, 3 * (sizeof(Fr) << SC_TAIL_LOG), g.stream>>>(A, g.d_ctx, g.d_proof, g.d_chal, g.d_finals, K);
+    uint8_t* hp = reinterpret_cast<uint8_t*>(g.h_pinned);
+    const size_t proof_bytes = n_total * 2 * sizeof(Fr), chal_bytes = n_total * 2 * sizeof(uint64_t);
+    hipError_t e = hipMemcpyAsync(hp, g.d_proof, proof_bytes, hipMemcpyDeviceToHost, g.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hp + 8192, g.d_chal, chal_bytes, hipMemcpyDeviceToHost, g.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hp + 12288, g.d_finals, 3 * sizeof(Fr), hipMemcpyDeviceToHost, g.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hp + 16384, g.d_ctx, sizeof(ScCtx), hipMemcpyDeviceToHost, g.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    hipFree(dl); hipFree(dr);
+    if (e != hipSuccess) return fail(ATLAS_ENODEV, "dot_shard_finish", e);
+    std::memcpy(compressed_polys, hp, proof_bytes);
+    std::memcpy(challenges, hp + 8192, chal_bytes);
+    std::memcpy(final_claims, hp + 12288, 3 * sizeof(Fr));
+    std::memcpy(transcript, hp + 16384, sizeof(DevTranscript));
+    P->consumed = true; P->shard_active = false;
+    return ATLAS_OK;
+}
+
+// sum of n field elements on the host (combining per-rank input claims)
+int atlas_fr_sum(const atlas_fr_t* v, size_t n, atlas_fr_t* out) {
+    if ((!v && n) || !out) return fail(ATLAS_EINVAL, "fr_sum");
+    H::Fr acc = H::zero();
+    for (size_t i = 0; i < n; i++) acc = H::add(acc, *reinterpret_cast<const H::Fr*>(&v[i]));
+    std::memcpy(out, &acc, 32);
+    return ATLAS_OK;
 }
 
 }  // extern "C"

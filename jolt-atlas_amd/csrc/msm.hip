@@ -412,4 +412,18 @@ int atlas_hyperkzg_open(atlas_srs_t srs, atlas_poly_t poly, const atlas_u128_t* 
     return ATLAS_OK;
 }
 
+// sum of n affine points on the host: combines the per-rank partial MSMs of a point-range
+// sharded commitment (one 72-byte point per GPU)
+int atlas_g1_sum_affine(const atlas_g1_affine_t* pts, size_t n, atlas_g1_affine_t* out) {
+    if ((!pts && n) || !out) return fail(ATLAS_EINVAL, "g1_sum_affine");
+    H::G1X acc = H::gx_inf();
+    for (size_t i = 0; i < n; i++) {
+        if (pts[i].infinity) continue;
+        H::G1Aff a; std::memcpy(a.x.l, pts[i].x.l, 32); std::memcpy(a.y.l, pts[i].y.l, 32);
+        acc = H::gx_add(acc, H::gx_from_aff(a));
+    }
+    to_out(H::gx_to_aff(acc), out);
+    return ATLAS_OK;
+}
+
 }  // extern "C"
