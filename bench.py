@@ -185,6 +185,15 @@ def main():
     tm = A.last_timing()
     A.set_timing(False)
     achieved = tm.pass_bytes / (tm.pass_ms * 1e-3) / 1e9 if tm.pass_ms > 0 else 0.0
+    # HBM bytes per step of the same data-pass kernels from the committed PMC profile
+    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot run inside this process)
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")))
+        if n_vars == 22:
+            traffic = int(pmc["data_pass_hbm_bytes_per_step"])
+    except Exception:
+        traffic = None
 
     ms_per_step = dt * 1e3 / args.steps
     value = world * field_ops(n_vars) * args.steps / dt
@@ -198,7 +207,7 @@ def main():
                    "n_vars": n_vars, "instances_per_gpu": 1, "parallelism": "independent instance per GPU"},
         "mulmod_per_s": world * MULS_PER_INDEX_ROUND * ((1 << n_vars) - 1) * args.steps / dt,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "k_dot_eval + k_dot_bind_eval (data passes)", "launches": int(tm.n_pass),
                      "bytes_per_step": int(tm.pass_bytes), "pass_ms": tm.pass_ms, "fs_ms": tm.fs_ms,
                      "instrumented_total_ms": tm.total_ms},
