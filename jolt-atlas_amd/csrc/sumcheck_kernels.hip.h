@@ -16,6 +16,7 @@
 // thread -> wavefront (__shfl_xor) -> LDS -> one partial per workgroup; the `fs` workgroup
 // folds the partials and runs the transcript, leaving r_{j+1} in HBM for the next pass.
 #pragma once
+#include "f9.hip.h"
 #include "transcript.hip.h"
 
 namespace atlas {
@@ -306,6 +307,14 @@ __device__ __forceinline__ Fr fr_half(const Fr& a) {      // a/2: (a + (a odd ? 
     return o;
 }
 
+// Montgomery residue -> canonical integer on the 29-bit limbs (exact: see fs_round_wave)
+__device__ __forceinline__ Fr fs_from_mont(const Fr& x) {
+    using P9 = Fr9Params;
+    F9 k = f9_zero();
+    k.l[0] = 32u;
+    return f9_to_fe(f9_mul<P9>(f9_from_fe(x), k));
+}
+
 struct FsScratch {           // LDS used by the wave-cooperative transcript
     WaveTranscriptLds wt;
 };
@@ -333,11 +342,13 @@ __device__ __forceinline__ void fs_round_wave(WaveTranscript& T, FsScratch* S, c
         c[2] = fr_sub(fr_sub(fr_sub(t, c[3]), c[3]), c[3]);
         c[1] = fr_sub(fr_sub(fr_sub(e1, e0), c[2]), c[3]);
     }
-    // canonical forms for the transcript (independent of the hash chain: overlaps with it)
+    // canonical integers for the transcript (independent of the hash chain: overlaps with it).
+    // 29-bit-limb path: x * 32 * 2^-261 = x * 2^-256, a product with a one-limb multiplier (90
+    // multiply-adds instead of the 8x32 reduction); the result is < p for x != 0, 0 for x = 0.
     Fr canon[DEG];
-    canon[0] = fe_from_mont<FrParams>(c[0]);
+    canon[0] = fs_from_mont(c[0]);
 #pragma unroll
-    for (int k = 2; k <= DEG; k++) canon[k - 1] = fe_from_mont<FrParams>(c[k]);
+    for (int k = 2; k <= DEG; k++) canon[k - 1] = fs_from_mont(c[k]);
     // compress (drop the linear term) + append_to_transcript (unipoly.rs:307-318,550-558)
     wt_append_label(T, &S->wt, W, lane, K.lbl_begin);
 #pragma unroll
@@ -349,11 +360,23 @@ __device__ __forceinline__ void fs_round_wave(WaveTranscript& T, FsScratch* S, c
     const Fr r = challenge_to_mont(lo, hi, challenge_mode);
     // previous_claim = poly.evaluate(r_j) (unipoly.rs:229-245), Horner form: every product has
     // the sparse challenge as one factor (same value, exact arithmetic)
-    Fr ev_r = c[DEG];
+    if (challenge_mode == 0) {
+        // 29-bit limbs: r pre-scaled by 32 keeps the products in Montgomery form; the running value
+        // stays < 2.3p and is reduced exactly at the end
+        using P9 = Fr9Params;
+        const F9 r32 = f9_shl5(f9_from_fe(r));
+        F9 acc = f9_from_fe(c[DEG]);
 #pragma unroll
-    for (int k = DEG - 1; k >= 0; k--)
-        ev_r = fr_add(challenge_mode == 0 ? fr_mul_hi(ev_r, r) : fr_mul(ev_r, r), c[k]);
-    claim = ev_r;
+        for (int k = DEG - 1; k >= 0; k--) acc = f9_add(f9_mul<P9, 4>(acc, r32), f9_from_fe(c[k]));
+        Fr ev_r = f9_to_fe(f9_norm(acc));
+        fe_cond_sub_p<FrParams>(ev_r.v); fe_cond_sub_p<FrParams>(ev_r.v); fe_cond_sub_p<FrParams>(ev_r.v);
+        claim = ev_r;
+    } else {
+        Fr ev_r = c[DEG];
+#pragma unroll
+        for (int k = DEG - 1; k >= 0; k--) ev_r = fr_add(fr_mul(ev_r, r), c[k]);
+        claim = ev_r;
+    }
     r_out = r;
     if (lane == 0) {
         fe_store(proof_row + 0, c[0]);
