@@ -174,6 +174,36 @@ int atlas_mul_input_claim(atlas_mul_prover_t p, atlas_fr_t *out);
 int atlas_sumcheck_prove_mul(atlas_mul_prover_t p, const atlas_fr_t *input_claim,
                              atlas_transcript_t *transcript, atlas_fr_t *compressed_polys,
                              atlas_u128_t *challenges, atlas_fr_t final_claims[3]);
+/* The same instance behind the trait's per-round methods (mul.rs:160-185), host-stepped so
+ * that it can take part in a BatchedSumcheck: compute_message -> 4 coefficients of
+ * gruen_poly_deg_3 (split_eq_poly.rs:331-429) interpolated with the claim hint;
+ * ingest_challenge binds both operands LowToHigh and the split-eq scalar. */
+int atlas_mul_compute_message(atlas_mul_prover_t p, size_t round, const atlas_fr_t *previous_claim,
+                              atlas_fr_t *coeffs_out, size_t *n_coeffs);
+int atlas_mul_ingest_challenge(atlas_mul_prover_t p, const atlas_u128_t *r_j, size_t round);
+int atlas_mul_final_claims(atlas_mul_prover_t p, atlas_fr_t out[3]);
+size_t atlas_mul_num_rounds(atlas_mul_prover_t p);   /* SumcheckInstanceProver::num_rounds */
+size_t atlas_dot_num_rounds(atlas_dot_prover_t p);
+int atlas_dot_degree(atlas_dot_prover_t p);          /* SumcheckInstanceProver::degree */
+
+/* ---- BatchedSumcheck::prove (joltworks/src/subprotocols/sumcheck.rs:30-184): several
+ *      instances of differing round counts under one transcript, front-loaded batching ---- */
+typedef struct atlas_batched *atlas_batched_t;
+int atlas_batched_new(atlas_batched_t *out);
+int atlas_batched_free(atlas_batched_t b);           /* does not free the instances */
+/* Vec<&mut dyn SumcheckInstanceProver> entries, in order; input_claim = what
+ * SumcheckInstanceProver::input_claim(accumulator) returns for that instance */
+int atlas_batched_add_dot(atlas_batched_t b, atlas_dot_prover_t p, const atlas_fr_t *input_claim);
+int atlas_batched_add_mul(atlas_batched_t b, atlas_mul_prover_t p, const atlas_fr_t *input_claim);
+/* Runs the protocol: appends the input claims, draws the batching coefficients, then per
+ * round combines the instances' round polynomials, compresses, appends, draws r_j and has
+ * the active instances ingest it.
+ *   compressed : max_rounds rows of 4 Fr; row i holds n_coeffs[i] coefficients
+ *                (coeffs_except_linear_term of the batched round polynomial)
+ *   challenges : max_rounds raw u128 draws
+ * Instances are left fully bound; their final claims are read with *_final_claims. */
+int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t *transcript, atlas_fr_t *compressed,
+                        uint32_t *n_coeffs, atlas_u128_t *challenges, size_t *max_rounds_out);
 
 /* ---- SRS + multi-scalar multiplication: the arithmetic behind the CommitmentScheme
  *      plug-in (joltworks/src/poly/commitment/commitment_scheme.rs:11-131) for HyperKZG --- */

@@ -404,10 +404,59 @@ class MulProver:
         _check(lib.atlas_sumcheck_prove_mul(self.h, _p(ic), C.byref(transcript.t), _p(proof), _p(ch), _p(fin)))
         return proof.reshape(n, 3, 4), [int(ch[2 * i]) | (int(ch[2 * i + 1]) << 64) for i in range(n)], fin
 
+    def compute_message(self, rnd, previous_claim):
+        out = np.zeros((4, 4), dtype=np.uint64)
+        n = C.c_size_t()
+        pc = _fr(previous_claim)
+        _check(lib.atlas_mul_compute_message(self.h, C.c_size_t(rnd), _p(pc), _p(out), C.byref(n)))
+        return out[:n.value]
+
+    def ingest_challenge(self, r_u128, rnd):
+        u = U128(r_u128 & ((1 << 64) - 1), r_u128 >> 64)
+        _check(lib.atlas_mul_ingest_challenge(self.h, C.byref(u), C.c_size_t(rnd)))
+
+    def final_claims(self):
+        out = np.zeros((3, 4), dtype=np.uint64)
+        _check(lib.atlas_mul_final_claims(self.h, _p(out)))
+        return out
+
     def free(self):
         if self.h:
             lib.atlas_mul_prover_free(self.h)
             self.h = None
+
+
+class BatchedSumcheck:
+    """BatchedSumcheck::prove (joltworks/src/subprotocols/sumcheck.rs:30-184)."""
+
+    @staticmethod
+    def prove(instances, input_claims, transcript: Blake2bTranscript):
+        """instances: EinsumDotProver / MulProver objects, in batch order.
+        Returns (rows: list of (k,4) compressed coefficient arrays, challenges [u128])."""
+        b = C.c_void_p()
+        _check(lib.atlas_batched_new(C.byref(b)))
+        try:
+            mx = 0
+            for inst, c in zip(instances, input_claims):
+                ic = _fr(c)
+                if isinstance(inst, MulProver):
+                    _check(lib.atlas_batched_add_mul(b, inst.h, _p(ic)))
+                    lib.atlas_mul_num_rounds.restype = C.c_size_t
+                    mx = max(mx, lib.atlas_mul_num_rounds(inst.h))
+                else:
+                    _check(lib.atlas_batched_add_dot(b, inst.h, _p(ic)))
+                    lib.atlas_dot_num_rounds.restype = C.c_size_t
+                    mx = max(mx, lib.atlas_dot_num_rounds(inst.h))
+            comp = np.zeros((max(mx, 1), 4, 4), dtype=np.uint64)
+            nco = np.zeros(max(mx, 1), dtype=np.uint32)
+            ch = np.zeros(2 * max(mx, 1), dtype=np.uint64)
+            mr = C.c_size_t()
+            _check(lib.atlas_batched_prove(b, C.byref(transcript.t), _p(comp), nco.ctypes.data_as(C.c_void_p), _p(ch),
+                                           C.byref(mr)))
+            rows = [comp[i, :nco[i]].copy() for i in range(mr.value)]
+            return rows, [int(ch[2 * i]) | (int(ch[2 * i + 1]) << 64) for i in range(mr.value)]
+        finally:
+            lib.atlas_batched_free(b)
 
 
 class Shout:

@@ -834,6 +834,9 @@ int atlas_dot_shard_finish(atlas_dot_prover_t P, const atlas_fr_t* gathered_lr, 
     return ATLAS_OK;
 }
 
+size_t atlas_dot_num_rounds(atlas_dot_prover_t P) { return P ? P->n_rounds : 0; }
+int atlas_dot_degree(atlas_dot_prover_t P) { return P ? (P->schedule == ATLAS_EQ_NONE ? 2 : 3) : 0; }
+
 // sum of n field elements on the host (combining per-rank input claims)
 int atlas_fr_sum(const atlas_fr_t* v, size_t n, atlas_fr_t* out) {
     if ((!v && n) || !out) return fail(ATLAS_EINVAL, "fr_sum");

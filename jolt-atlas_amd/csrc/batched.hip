@@ -1,0 +1,168 @@
+// BatchedSumcheck::prove — front-loaded batching of several sumcheck instances
+// (joltworks/src/subprotocols/sumcheck.rs:30-184): host driver over the trait-shaped round
+// API of the device instances (compute_message / ingest_challenge).  The arithmetic per round
+// is O(instances * degree) field operations on the host; all O(2^n) work stays in the
+// instances' kernels.  Restated rules that decide the proof bytes:
+//   * input claims are appended first, then one batching coefficient per instance is drawn with
+//     challenge_vector (full 128-bit scalars, :40-47);
+//   * an instance with fewer rounds contributes the constant polynomial
+//     input_claim * 2^(remaining - rounds - 1) until its first round (:91-104), its running claim
+//     starts at input_claim * 2^(max_rounds - rounds) (:58-66);
+//   * poly * coeff trims trailing zero coefficients (UniPoly::from_coeff, unipoly.rs:39-52,
+//     454-461); the sum keeps the longest length (:401-413); the batched polynomial is
+//     compressed and absorbed like a single instance's (:118-121).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "../../include/atlas_hip.h"
+#include "host_field.hpp"
+#include "runtime.hpp"
+
+namespace H = atlas_host;
+using atlas_rt::fail;
+using atlas_rt::g;
+
+namespace {
+
+struct Instance {
+    int kind;                 // 0 = dot, 1 = mul
+    void* handle;
+    H::Fr input_claim;
+    size_t rounds;
+};
+
+H::Fr mul_pow2(H::Fr x, size_t pow) {      // JoltField::mul_pow_2 (field/mod.rs:274-284): same value, x * 2^pow
+    const H::Fr two = H::from_u64(2);
+    for (size_t i = 0; i < pow; i++) x = H::mul(x, two);
+    return x;
+}
+
+std::vector<H::Fr> trimmed_scale(const std::vector<H::Fr>& p, const H::Fr& c) {   // &UniPoly * F -> from_coeff
+    std::vector<H::Fr> o(p.size());
+    for (size_t i = 0; i < p.size(); i++) o[i] = H::mul(p[i], c);
+    const H::Fr z = H::zero();
+    while (!o.empty() && o.back() == z) o.pop_back();
+    if (o.empty()) o.push_back(z);
+    return o;
+}
+
+H::Fr eval_with_challenge(const std::vector<H::Fr>& c, const H::Fr& r) {           // UniPoly::evaluate (unipoly.rs:229-245)
+    H::Fr ev = c[0], pw = r;
+    for (size_t i = 1; i < c.size(); i++) { ev = H::add(ev, H::mul(pw, c[i])); pw = H::mul(pw, r); }
+    return ev;
+}
+
+}  // namespace
+
+struct atlas_batched {
+    std::vector<Instance> inst;
+};
+
+extern "C" {
+
+int atlas_batched_new(atlas_batched_t* out) {
+    if (!out) return fail(ATLAS_EINVAL, "batched_new");
+    *out = new atlas_batched();
+    return ATLAS_OK;
+}
+
+int atlas_batched_free(atlas_batched_t b) {
+    delete b;          // instances stay owned by the caller
+    return ATLAS_OK;
+}
+
+int atlas_batched_add_dot(atlas_batched_t b, atlas_dot_prover_t p, const atlas_fr_t* input_claim) {
+    if (!b || !p || !input_claim) return fail(ATLAS_EINVAL, "batched_add_dot");
+    Instance I; I.kind = 0; I.handle = p; std::memcpy(&I.input_claim, input_claim, 32); I.rounds = atlas_dot_num_rounds(p);
+    b->inst.push_back(I);
+    return ATLAS_OK;
+}
+
+int atlas_batched_add_mul(atlas_batched_t b, atlas_mul_prover_t p, const atlas_fr_t* input_claim) {
+    if (!b || !p || !input_claim) return fail(ATLAS_EINVAL, "batched_add_mul");
+    Instance I; I.kind = 1; I.handle = p; std::memcpy(&I.input_claim, input_claim, 32); I.rounds = atlas_mul_num_rounds(p);
+    b->inst.push_back(I);
+    return ATLAS_OK;
+}
+
+// BatchedSumcheck::prove.  Outputs, per round i < max_rounds:
+//   n_coeffs[i]                         number of compressed coefficients of round i
+//   compressed[i*4 .. i*4+n_coeffs[i])  coeffs_except_linear_term (at most 4: degree <= 4 batched)
+//   challenges[i]                       raw u128 draw
+// max_rounds_out = number of rounds.  The instances are left fully bound (final claims are
+// read with atlas_dot_final_claims / atlas_mul_final_claims; cache_openings is the caller's).
+int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas_fr_t* compressed, uint32_t* n_coeffs,
+                        atlas_u128_t* challenges, size_t* max_rounds_out) {
+    NEED_INIT();
+    if (!b || !transcript || !compressed || !n_coeffs || !challenges || !max_rounds_out || b->inst.empty())
+        return fail(ATLAS_EINVAL, "batched_prove");
+    H::Transcript& T = *reinterpret_cast<H::Transcript*>(transcript);
+    const size_t n = b->inst.size();
+    size_t max_rounds = 0;
+    for (auto& I : b->inst) max_rounds = I.rounds > max_rounds ? I.rounds : max_rounds;
+    for (auto& I : b->inst) H::tr_append_scalar(T, I.input_claim);                    // :42-45
+    std::vector<H::Fr> coeff(n);
+    for (size_t i = 0; i < n; i++) coeff[i] = H::tr_challenge_scalar(T);               // challenge_vector :47
+    std::vector<H::Fr> claim(n);
+    for (size_t i = 0; i < n; i++) claim[i] = mul_pow2(b->inst[i].input_claim, max_rounds - b->inst[i].rounds);
+
+    for (size_t round = 0; round < max_rounds; round++) {
+        const size_t remaining = max_rounds - round;
+        std::vector<std::vector<H::Fr>> polys(n);
+        for (size_t i = 0; i < n; i++) {
+            Instance& I = b->inst[i];
+            if (remaining > I.rounds) {
+                // constant polynomial, from_coeff (a zero claim stays [0])
+                polys[i] = {mul_pow2(I.input_claim, remaining - I.rounds - 1)};
+            } else {
+                atlas_fr_t c[4]; size_t nc = 0;
+                const size_t local = round - (max_rounds - I.rounds);
+                int rc = I.kind == 0
+                             ? atlas_dot_compute_message((atlas_dot_prover_t)I.handle, local, (const atlas_fr_t*)&claim[i], c, &nc)
+                             : atlas_mul_compute_message((atlas_mul_prover_t)I.handle, local, (const atlas_fr_t*)&claim[i], c, &nc);
+                if (rc) return rc;
+                polys[i].resize(nc);
+                std::memcpy(polys[i].data(), c, nc * 32);
+            }
+        }
+        // batched = sum coeff_i * poly_i, starting from UniPoly::from_coeff(vec![]) = [0]  (:109-116)
+        std::vector<H::Fr> batched = {H::zero()};
+        for (size_t i = 0; i < n; i++) {
+            std::vector<H::Fr> t = trimmed_scale(polys[i], coeff[i]);
+            for (size_t k = 0; k < t.size(); k++) {
+                if (k < batched.size()) batched[k] = H::add(batched[k], t[k]);
+                else batched.push_back(t[k]);
+            }
+        }
+        // compress (unipoly.rs:307-318) + append_to_transcript (:550-558)
+        std::vector<H::Fr> cc;
+        if (batched.size() < 2) cc = batched;
+        else { cc.push_back(batched[0]); for (size_t k = 2; k < batched.size(); k++) cc.push_back(batched[k]); }
+        if (cc.size() > 4) return fail(ATLAS_EINVAL, "batched_prove: degree above 4 not supported");
+        H::tr_append_message(T, "UniPoly_begin");
+        for (auto& x : cc) H::tr_append_scalar(T, x);
+        H::tr_append_message(T, "UniPoly_end");
+        n_coeffs[round] = (uint32_t)cc.size();
+        std::memcpy(&compressed[round * 4], cc.data(), cc.size() * 32);
+        uint64_t lo, hi;
+        H::tr_challenge_u128(T, lo, hi);                                              // challenge_scalar_optimized :119
+        challenges[round].lo = lo; challenges[round].hi = hi;
+        const H::Fr r = H::challenge_to_fr(lo, hi, g.challenge_mode);
+        for (size_t i = 0; i < n; i++) claim[i] = eval_with_challenge(polys[i], r);    // :123-126
+        for (size_t i = 0; i < n; i++) {
+            Instance& I = b->inst[i];
+            if (remaining <= I.rounds) {
+                const size_t local = round - (max_rounds - I.rounds);
+                int rc = I.kind == 0 ? atlas_dot_ingest_challenge((atlas_dot_prover_t)I.handle, &challenges[round], local)
+                                     : atlas_mul_ingest_challenge((atlas_mul_prover_t)I.handle, &challenges[round], local);
+                if (rc) return rc;
+            }
+        }
+    }
+    *max_rounds_out = max_rounds;
+    return ATLAS_OK;
+}
+
+}  // extern "C"

@@ -282,4 +282,66 @@ int atlas_sumcheck_prove_mul(atlas_mul_prover_t P, const atlas_fr_t* input_claim
     return ATLAS_OK;
 }
 
+// ---- trait-shaped round API (the caller owns the loop and the transcript, e.g. inside
+//      BatchedSumcheck::prove): MulProver::compute_message / ingest_challenge, mul.rs:160-185
+int atlas_mul_compute_message(atlas_mul_prover_t P, size_t round, const atlas_fr_t* previous_claim, atlas_fr_t* coeffs_out,
+                              size_t* n_coeffs) {
+    NEED_INIT();
+    if (!P || !previous_claim || !coeffs_out || !n_coeffs) return fail(ATLAS_EINVAL, "mul_compute_message");
+    if (P->consumed || round >= P->n || P->left->len != ((size_t)1 << (P->n - round))) return fail(ATLAS_ESTATE, "mul_compute_message: round out of order");
+    std::lock_guard<std::mutex> lk(g.mu);
+    const ScConsts K = make_consts();
+    const size_t groups = P->left->len / 2;
+    const int grid = grid_for(groups);
+    SplitEqView E = view_for_round(P, round);
+    if (P->left->is_i32) k_mul_eval<int32_t><<<grid, SC_THREADS, 0, g.stream>>>((const int32_t*)P->left->d, (const int32_t*)P->right->d, E, groups, g.d_partials, K);
+    else k_mul_eval<Fr><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, E, groups, g.d_partials, K);
+    k_reduce1<<<1, SC_THREADS, 0, g.stream>>>(g.d_partials, grid, g.d_finals + 3, 3);
+    HIP_TRY(hipMemcpyAsync(g.h_pinned, g.d_finals + 3, 3 * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    H::Fr s[3]; std::memcpy(s, g.h_pinned, sizeof s);
+    // gruen_poly_deg_3 (split_eq_poly.rs:379-429) with q(1) taken from the third running sum
+    const H::Fr w_cur = P->w[P->n - 1 - round];
+    const H::Fr eq1 = H::mul(P->scalar, w_cur), eq0 = H::sub(P->scalar, eq1), eqm = H::sub(eq1, eq0);
+    const H::Fr eq2 = H::add(eq1, eqm), eq3 = H::add(eq2, eqm);
+    const H::Fr q0 = s[0], q1 = s[1], e2 = H::add(s[2], s[2]);
+    const H::Fr q2 = H::add(H::sub(H::add(q1, q1), q0), e2);
+    const H::Fr q3 = H::add(H::add(H::sub(H::add(q2, q1), q0), e2), e2);
+    const H::Fr ev[3] = {H::mul(eq0, q0), H::mul(eq2, q2), H::mul(eq3, q3)};
+    H::Fr c[4];
+    const int nc = H::unipoly_from_evals_and_hint(*reinterpret_cast<const H::Fr*>(previous_claim), ev, 3, c);
+    std::memcpy(coeffs_out, c, nc * sizeof(H::Fr));
+    *n_coeffs = (size_t)nc;
+    return ATLAS_OK;
+}
+
+int atlas_mul_ingest_challenge(atlas_mul_prover_t P, const atlas_u128_t* r_j, size_t round) {
+    NEED_INIT();
+    if (!P || !r_j) return fail(ATLAS_EINVAL, "mul_ingest_challenge");
+    if (P->consumed || round >= P->n || P->left->len != ((size_t)1 << (P->n - round))) return fail(ATLAS_ESTATE, "mul_ingest_challenge: round out of order");
+    int rc = atlas_poly_bind(P->left, r_j, ATLAS_LOW_TO_HIGH);
+    if (!rc) rc = atlas_poly_bind(P->right, r_j, ATLAS_LOW_TO_HIGH);
+    if (rc) return rc;
+    // GruenSplitEqPolynomial::bind: current_scalar *= 1 - w - r + 2 w r (split_eq_poly.rs:336-339)
+    const H::Fr r = H::challenge_to_fr(r_j->lo, r_j->hi, g.challenge_mode);
+    const H::Fr w_cur = P->w[P->n - 1 - round];
+    const H::Fr wr = H::mul(w_cur, r);
+    P->scalar = H::mul(P->scalar, H::add(H::add(H::sub(H::sub(H::one(), w_cur), r), wr), wr));
+    return ATLAS_OK;
+}
+
+int atlas_mul_final_claims(atlas_mul_prover_t P, atlas_fr_t out[3]) {
+    NEED_INIT();
+    if (!P || !out) return fail(ATLAS_EINVAL, "mul_final_claims");
+    if (P->consumed) return fail(ATLAS_ESTATE, "mul_final_claims: prover consumed by atlas_sumcheck_prove_mul");
+    if (P->left->len != 1) return fail(ATLAS_ESTATE, "mul_final_claims: rounds remaining");
+    int rc = atlas_poly_final_claim(P->left, &out[0]);
+    if (!rc) rc = atlas_poly_final_claim(P->right, &out[1]);
+    if (rc) return rc;
+    std::memcpy(&out[2], &P->scalar, 32);
+    return ATLAS_OK;
+}
+
+size_t atlas_mul_num_rounds(atlas_mul_prover_t P) { return P ? P->n : 0; }
+
 }  // extern "C"

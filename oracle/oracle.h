@@ -75,6 +75,22 @@ void orc_dot_claim(const fr_t *l, const fr_t *r, const fr_t *eq, size_t len, int
                    size_t sched_a, size_t sched_b, fr_t *out);
 int  orc_num_threads(void);
 
+/* BatchedSumcheck::prove (sumcheck.rs:30-184).  kind 0 = dot instance (schedule/sa/sb/eq as
+ * above), 1 = Mul instance (w = n_vars Fr).  Operands are bound in place; final_claims as the
+ * single-instance provers.  compressed: rows of 4 Fr, n_coeffs[i] of them valid. */
+typedef struct {
+    int kind; int schedule; size_t n_vars, sa, sb;
+    fr_t *left, *right, *eq; const fr_t *w;
+    fr_t input_claim; fr_t final_claims[3];
+} orc_batched_inst;
+int orc_batched_prove(orc_batched_inst *inst, size_t n_inst, orc_transcript *t, fr_t *compressed,
+                      uint32_t *n_coeffs, u128 *challenges, size_t *max_rounds_out);
+/* BatchedSumcheck::verify (sumcheck.rs:186-262) up to the expected-output check: returns the
+ * final batched claim e and the coefficients; claim_i and rounds_i per instance. */
+int orc_batched_verify(const fr_t *compressed, const uint32_t *n_coeffs, size_t max_rounds, const fr_t *input_claims,
+                       const size_t *rounds, size_t n_inst, orc_transcript *t, fr_t *e_out, fr_t *coeffs_out,
+                       u128 *challenges);
+
 /* ---- BN254 G1 + MSM (arkworks, EXTERNAL to the reference tree; call sites
  *      joltworks/src/msm/mod.rs:27-181, hyperkzg/mod.rs:520-596, kzg.rs:195-298) ---- */
 typedef struct { fq_t x, y; uint64_t inf; } g1_aff_t;   /* 72 bytes: the arkworks G1Affine image */

@@ -1,0 +1,71 @@
+"""ctypes binding of the oracle's BatchedSumcheck restatement (oracle/sumcheck.c, reference
+joltworks/src/subprotocols/sumcheck.rs:30-262).  TEST INFRASTRUCTURE ONLY, like orc.py."""
+import ctypes as C
+
+import numpy as np
+
+from . import orc
+
+FR = C.c_uint64 * 4
+
+
+class Inst(C.Structure):
+    _fields_ = [("kind", C.c_int), ("schedule", C.c_int), ("n_vars", C.c_size_t), ("sa", C.c_size_t), ("sb", C.c_size_t),
+                ("left", C.c_void_p), ("right", C.c_void_p), ("eq", C.c_void_p), ("w", C.c_void_p),
+                ("input_claim", FR), ("final_claims", FR * 3)]
+
+
+def dot_instance(L, R, claim, eq=None, schedule=0, a=0, b=0):
+    return dict(kind=0, L=np.ascontiguousarray(L).copy(), R=np.ascontiguousarray(R).copy(),
+                eq=None if eq is None else np.ascontiguousarray(eq).copy(), schedule=schedule, a=a, b=b,
+                claim=np.ascontiguousarray(claim, dtype=np.uint64).reshape(4), n=int(len(L)).bit_length() - 1)
+
+
+def mul_instance(L, R, w, claim):
+    return dict(kind=1, L=np.ascontiguousarray(L).copy(), R=np.ascontiguousarray(R).copy(), w=np.ascontiguousarray(w).copy(),
+                claim=np.ascontiguousarray(claim, dtype=np.uint64).reshape(4), n=len(w))
+
+
+def batched_prove(instances, t):
+    """Returns (rows: list of (k,4) arrays of compressed coefficients, challenges, finals: list of (3,4))."""
+    n = len(instances)
+    arr = (Inst * n)()
+    for i, d in enumerate(instances):
+        I = arr[i]
+        I.kind = d["kind"]; I.n_vars = d["n"]
+        I.left = d["L"].ctypes.data; I.right = d["R"].ctypes.data
+        if d["kind"] == 0:
+            I.schedule = d["schedule"]; I.sa = d["a"]; I.sb = d["b"]
+            I.eq = d["eq"].ctypes.data if d["eq"] is not None else None
+        else:
+            I.w = d["w"].ctypes.data
+        for k in range(4):
+            I.input_claim[k] = int(d["claim"][k])
+    max_rounds = max(d["n"] for d in instances)
+    comp = orc.fr_array(4 * max_rounds); nco = np.zeros(max_rounds, dtype=np.uint32)
+    ch = np.zeros(2 * max_rounds, dtype=np.uint64); mr = C.c_size_t(0)
+    orc.lib.orc_batched_prove.restype = C.c_int
+    rc = orc.lib.orc_batched_prove(arr, C.c_size_t(n), C.byref(t), orc._p(comp), nco.ctypes.data_as(C.c_void_p),
+                                   orc._p(ch), C.byref(mr))
+    assert rc == 0 and mr.value == max_rounds
+    comp = comp.reshape(max_rounds, 4, 4)
+    rows = [comp[i, :nco[i]].copy() for i in range(max_rounds)]
+    finals = [np.array([[arr[i].final_claims[j][k] for k in range(4)] for j in range(3)], dtype=np.uint64) for i in range(n)]
+    return rows, orc._u128_list(ch, max_rounds), finals
+
+
+def batched_verify(rows, input_claims, rounds, t):
+    """BatchedSumcheck::verify up to the expected-output check. Returns (e (4,), coeffs (n,4), challenges)."""
+    max_rounds = len(rows); n = len(rounds)
+    comp = orc.fr_array(4 * max_rounds).reshape(max_rounds, 4, 4); nco = np.zeros(max_rounds, dtype=np.uint32)
+    for i, r in enumerate(rows):
+        comp[i, :len(r)] = r; nco[i] = len(r)
+    comp = np.ascontiguousarray(comp)
+    claims = np.ascontiguousarray(np.stack([np.asarray(c, dtype=np.uint64).reshape(4) for c in input_claims]))
+    rds = np.asarray(rounds, dtype=np.uint64)
+    e = orc.fr_array(1); co = orc.fr_array(n); ch = np.zeros(2 * max_rounds, dtype=np.uint64)
+    orc.lib.orc_batched_verify.restype = C.c_int
+    rc = orc.lib.orc_batched_verify(orc._p(comp), nco.ctypes.data_as(C.c_void_p), C.c_size_t(max_rounds), orc._p(claims),
+                                    rds.ctypes.data_as(C.c_void_p), C.c_size_t(n), C.byref(t), orc._p(e), orc._p(co), orc._p(ch))
+    assert rc == 0
+    return e.reshape(4), co.reshape(n, 4), orc._u128_list(ch, max_rounds)

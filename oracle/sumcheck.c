@@ -229,42 +229,64 @@ void orc_dot_claim(const fr_t *l, const fr_t *r, const fr_t *eq, size_t len, int
     (void)a; *out = acc;
 }
 
+typedef struct { fr_t *left, *right, *eq; size_t len, sa; dot_ctx cx; } dot_state;
+
+static void dot_init(dot_state *S, fr_t *left, fr_t *right, fr_t *eq, size_t n_vars, int schedule, size_t sa, size_t sb) {
+    S->left = left; S->right = right; S->eq = eq; S->len = (size_t)1 << n_vars; S->sa = sa;
+    memset(&S->cx, 0, sizeof S->cx);
+    S->cx.schedule = schedule; S->cx.a = sa; S->cx.b = sb; S->cx.eq = eq;
+    S->cx.eq_len = schedule == 1 ? ((size_t)1 << sa) : schedule == 2 ? ((size_t)1 << sb) : 0;
+    if (schedule == 1 && sa == 0) S->cx.eq_bound = eq[0];
+}
+
+/* compute_message (dot.rs:290-350) + UniPoly::from_evals_and_hint */
+static size_t dot_round_message(dot_state *S, size_t rnd, const fr_t *prev, fr_t coeffs[4]) {
+    fr_t ev[3];
+    S->cx.round = rnd; S->cx.half = S->len / 2;
+    dot_message(S->left, S->right, &S->cx, ev);
+    return orc_unipoly_from_evals_and_hint(prev, ev, S->cx.schedule == 0 ? 2 : 3, coeffs);
+}
+
+/* ingest_challenge (dot.rs:352-375) */
+static void dot_ingest(dot_state *S, size_t rnd, const fr_t *r) {
+    const int schedule = S->cx.schedule;
+    orc_bind(S->left, S->len, r, ORC_HIGH_TO_LOW);
+    orc_bind(S->right, S->len, r, ORC_HIGH_TO_LOW);
+    if (schedule == 1 && rnd < S->sa) {
+        orc_bind(S->eq, S->cx.eq_len, r, ORC_HIGH_TO_LOW); S->cx.eq_len /= 2;
+        if (rnd == S->sa - 1) S->cx.eq_bound = S->eq[0];
+    } else if (schedule == 2 && rnd >= S->sa) {
+        orc_bind(S->eq, S->cx.eq_len, r, ORC_HIGH_TO_LOW); S->cx.eq_len /= 2;
+    }
+    S->len /= 2;
+}
+
+static void dot_finals(const dot_state *S, fr_t *final_claims) {
+    final_claims[0] = S->left[0]; final_claims[1] = S->right[0];
+    if (S->cx.schedule == 1) final_claims[2] = S->cx.eq_bound;
+    else if (S->cx.schedule == 2) final_claims[2] = S->eq[0];
+    else fr_one(&final_claims[2]);
+}
+
 int orc_sumcheck_dot_prove(fr_t *left, fr_t *right, fr_t *eq, size_t n_vars, int schedule,
                            size_t sa, size_t sb, const fr_t *input_claim, orc_transcript *t,
                            fr_t *proof, u128 *challenges, fr_t *final_claims) {
     const size_t deg = schedule == 0 ? 2 : 3;
-    size_t len = (size_t)1 << n_vars;
-    dot_ctx cx; memset(&cx, 0, sizeof cx);
-    cx.schedule = schedule; cx.a = sa; cx.b = sb; cx.eq = eq;
-    cx.eq_len = schedule == 1 ? ((size_t)1 << sa) : schedule == 2 ? ((size_t)1 << sb) : 0;
-    if (schedule == 1 && sa == 0) cx.eq_bound = eq[0];
+    dot_state S; dot_init(&S, left, right, eq, n_vars, schedule, sa, sb);
     orc_transcript_append_scalar(t, input_claim);            /* sumcheck.rs:573-574 */
     fr_t prev = *input_claim;
     for (size_t rnd = 0; rnd < n_vars; rnd++) {
-        fr_t ev[3], coeffs[4], cc[3], r;
-        cx.round = rnd; cx.half = len / 2;
-        dot_message(left, right, &cx, ev);                   /* dot.rs:290-350 */
-        size_t nc = orc_unipoly_from_evals_and_hint(&prev, ev, deg, coeffs);
+        fr_t coeffs[4], cc[3], r;
+        size_t nc = dot_round_message(&S, rnd, &prev, coeffs);
         size_t ncc = orc_unipoly_compress(coeffs, nc, cc);   /* sumcheck.rs:581 */
         orc_transcript_append_compressed(t, cc, ncc);
         u128 raw; orc_transcript_challenge_optimized(t, &raw, &r);  /* :583 */
         challenges[rnd] = raw;
         orc_unipoly_eval(coeffs, nc, &r, &prev);             /* :587 */
-        orc_bind(left, len, &r, ORC_HIGH_TO_LOW);            /* dot.rs:352-375 */
-        orc_bind(right, len, &r, ORC_HIGH_TO_LOW);
-        if (schedule == 1 && rnd < sa) {
-            orc_bind(eq, cx.eq_len, &r, ORC_HIGH_TO_LOW); cx.eq_len /= 2;
-            if (rnd == sa - 1) cx.eq_bound = eq[0];
-        } else if (schedule == 2 && rnd >= sa) {
-            orc_bind(eq, cx.eq_len, &r, ORC_HIGH_TO_LOW); cx.eq_len /= 2;
-        }
-        len /= 2;
+        dot_ingest(&S, rnd, &r);
         for (size_t k = 0; k < ncc; k++) proof[rnd * deg + k] = cc[k];
     }
-    final_claims[0] = left[0]; final_claims[1] = right[0];
-    if (schedule == 1) final_claims[2] = cx.eq_bound;
-    else if (schedule == 2) final_claims[2] = eq[0];
-    else fr_one(&final_claims[2]);
+    dot_finals(&S, final_claims);
     return 0;
 }
 
@@ -314,79 +336,103 @@ static void eq_cached(const fr_t *w, size_t k, fr_t **tabs) {
     }
 }
 
+typedef struct {
+    fr_t *left, *right; const fr_t *w; size_t n, len, out_top, in_top, k_out, k_in, current_index;
+    fr_t **Eout, **Ein; fr_t scalar;
+} mul_state;
+
+static void mul_init(mul_state *S, fr_t *left, fr_t *right, const fr_t *w, size_t n) {
+    const size_t m = n / 2;
+    S->left = left; S->right = right; S->w = w; S->n = n; S->len = (size_t)1 << n;
+    S->k_out = m; S->k_in = n - 1 - m;
+    S->Eout = (fr_t **)malloc((S->k_out + 1) * sizeof(fr_t *)); S->Ein = (fr_t **)malloc((S->k_in + 1) * sizeof(fr_t *));
+    eq_cached(w, S->k_out, S->Eout); eq_cached(w + m, S->k_in, S->Ein);
+    S->out_top = S->k_out; S->in_top = S->k_in;     /* index of the current (last) table */
+    S->current_index = n;
+    fr_one(&S->scalar);
+}
+
+static void mul_free(mul_state *S) {
+    for (size_t j = 0; j <= S->k_out; j++) free(S->Eout[j]);
+    for (size_t j = 0; j <= S->k_in; j++) free(S->Ein[j]);
+    free(S->Eout); free(S->Ein);
+}
+
+/* compute_message (mul.rs:160-176): 4 coefficients of the round polynomial */
+static size_t mul_message(const mul_state *S, const fr_t *prev, fr_t coeffs[4]) {
+    const fr_t *left = S->left, *right = S->right, *w = S->w;
+    const size_t in_top = S->in_top;
+    const fr_t *e_out = S->Eout[S->out_top], *e_in = S->Ein[in_top];
+    const size_t out_len = (size_t)1 << S->out_top, in_len = (size_t)1 << in_top;
+    fr_t qc, qe; fr_zero(&qc); fr_zero(&qe);
+#pragma omp parallel if (out_len * in_len >= 4096)
+    {
+        fr_t pc, pe; fr_zero(&pc); fr_zero(&pe);
+#pragma omp for schedule(static)
+        for (size_t xo = 0; xo < out_len; xo++) {
+            fr_t ic, ie; fr_zero(&ic); fr_zero(&ie);
+            for (size_t xi = 0; xi < in_len; xi++) {
+                size_t gidx = (xo << in_top) | xi;
+                fr_t lo0 = left[2 * gidx], loi, ro0 = right[2 * gidx], roi, c0, e;
+                fr_sub(&left[2 * gidx + 1], &lo0, &loi); fr_sub(&right[2 * gidx + 1], &ro0, &roi);
+                fr_mul(&lo0, &ro0, &c0); fr_mul(&loi, &roi, &e);
+                fr_mul(&e_in[xi], &c0, &c0); fr_mul(&e_in[xi], &e, &e);
+                fr_add(&ic, &c0, &ic); fr_add(&ie, &e, &ie);
+            }
+            fr_mul(&e_out[xo], &ic, &ic); fr_mul(&e_out[xo], &ie, &ie);
+            fr_add(&pc, &ic, &pc); fr_add(&pe, &ie, &pe);
+        }
+#pragma omp critical
+        { fr_add(&qc, &pc, &qc); fr_add(&qe, &pe, &qe); }
+    }
+    /* gruen_poly_deg_3 */
+    fr_t eq1, eq0, eqm, eq2, eq3, c_ev0, c_ev1, q1, q2, q3, e2, inv, evals[4];
+    fr_mul(&S->scalar, &w[S->current_index - 1], &eq1); fr_sub(&S->scalar, &eq1, &eq0);
+    fr_sub(&eq1, &eq0, &eqm); fr_add(&eq1, &eqm, &eq2); fr_add(&eq2, &eqm, &eq3);
+    fr_mul(&eq0, &qc, &c_ev0); fr_sub(prev, &c_ev0, &c_ev1);
+    fr_inv(&eq1, &inv); fr_mul(&c_ev1, &inv, &q1);
+    fr_add(&qe, &qe, &e2);
+    fr_add(&q1, &q1, &q2); fr_sub(&q2, &qc, &q2); fr_add(&q2, &e2, &q2);
+    fr_add(&q2, &q1, &q3); fr_sub(&q3, &qc, &q3); fr_add(&q3, &e2, &q3); fr_add(&q3, &e2, &q3);
+    evals[0] = c_ev0; evals[1] = c_ev1; fr_mul(&eq2, &q2, &evals[2]); fr_mul(&eq3, &q3, &evals[3]);
+    /* UniPoly::from_evals degree 3: reuse the hint form (hint = e0 + e1) */
+    fr_t hint, ev3[3];
+    fr_add(&evals[0], &evals[1], &hint); ev3[0] = evals[0]; ev3[1] = evals[2]; ev3[2] = evals[3];
+    return orc_unipoly_from_evals_and_hint(&hint, ev3, 3, coeffs);
+}
+
+/* ingest_challenge (mul.rs:178-185): eq.bind(r); left/right bind LowToHigh */
+static void mul_ingest(mul_state *S, const fr_t *r) {
+    const fr_t *w = S->w;
+    fr_t wr, f, one; fr_one(&one);
+    fr_mul(&w[S->current_index - 1], r, &wr);
+    fr_sub(&one, &w[S->current_index - 1], &f); fr_sub(&f, r, &f); fr_add(&f, &wr, &f); fr_add(&f, &wr, &f);
+    fr_mul(&S->scalar, &f, &S->scalar);
+    S->current_index -= 1;
+    if (S->n / 2 < S->current_index && S->in_top > 0) S->in_top--;
+    else if (0 < S->current_index && S->out_top > 0) S->out_top--;
+    orc_bind(S->left, S->len, r, ORC_LOW_TO_HIGH); orc_bind(S->right, S->len, r, ORC_LOW_TO_HIGH);
+    S->len /= 2;
+}
+
 int orc_sumcheck_mul_prove(fr_t *left, fr_t *right, const fr_t *w, size_t n, const fr_t *input_claim,
                            orc_transcript *t, fr_t *proof, u128 *challenges, fr_t *final_claims) {
-    const size_t m = n / 2;
-    const size_t k_out = m, k_in = n - 1 - m;
-    fr_t **Eout = (fr_t **)malloc((k_out + 1) * sizeof(fr_t *)), **Ein = (fr_t **)malloc((k_in + 1) * sizeof(fr_t *));
-    eq_cached(w, k_out, Eout); eq_cached(w + m, k_in, Ein);
-    size_t out_top = k_out, in_top = k_in;          /* index of the current (last) table */
-    size_t current_index = n;
-    fr_t scalar; fr_one(&scalar);
-    size_t len = (size_t)1 << n;
+    mul_state S; mul_init(&S, left, right, w, n);
     orc_transcript_append_scalar(t, input_claim);
     fr_t prev = *input_claim;
     for (size_t rnd = 0; rnd < n; rnd++) {
-        const fr_t *e_out = Eout[out_top], *e_in = Ein[in_top];
-        const size_t out_len = (size_t)1 << out_top, in_len = (size_t)1 << in_top;
-        fr_t qc, qe; fr_zero(&qc); fr_zero(&qe);
-#pragma omp parallel if (out_len * in_len >= 4096)
-        {
-            fr_t pc, pe; fr_zero(&pc); fr_zero(&pe);
-#pragma omp for schedule(static)
-            for (size_t xo = 0; xo < out_len; xo++) {
-                fr_t ic, ie; fr_zero(&ic); fr_zero(&ie);
-                for (size_t xi = 0; xi < in_len; xi++) {
-                    size_t gidx = (xo << in_top) | xi;
-                    fr_t lo0 = left[2 * gidx], loi, ro0 = right[2 * gidx], roi, c0, e;
-                    fr_sub(&left[2 * gidx + 1], &lo0, &loi); fr_sub(&right[2 * gidx + 1], &ro0, &roi);
-                    fr_mul(&lo0, &ro0, &c0); fr_mul(&loi, &roi, &e);
-                    fr_mul(&e_in[xi], &c0, &c0); fr_mul(&e_in[xi], &e, &e);
-                    fr_add(&ic, &c0, &ic); fr_add(&ie, &e, &ie);
-                }
-                fr_mul(&e_out[xo], &ic, &ic); fr_mul(&e_out[xo], &ie, &ie);
-                fr_add(&pc, &ic, &pc); fr_add(&pe, &ie, &pe);
-            }
-#pragma omp critical
-            { fr_add(&qc, &pc, &qc); fr_add(&qe, &pe, &qe); }
-        }
-        /* gruen_poly_deg_3 */
-        fr_t eq1, eq0, eqm, eq2, eq3, c_ev0, c_ev1, q1, q2, q3, e2, inv, evals[4];
-        fr_mul(&scalar, &w[current_index - 1], &eq1); fr_sub(&scalar, &eq1, &eq0);
-        fr_sub(&eq1, &eq0, &eqm); fr_add(&eq1, &eqm, &eq2); fr_add(&eq2, &eqm, &eq3);
-        fr_mul(&eq0, &qc, &c_ev0); fr_sub(&prev, &c_ev0, &c_ev1);
-        fr_inv(&eq1, &inv); fr_mul(&c_ev1, &inv, &q1);
-        fr_add(&qe, &qe, &e2);
-        fr_add(&q1, &q1, &q2); fr_sub(&q2, &qc, &q2); fr_add(&q2, &e2, &q2);
-        fr_add(&q2, &q1, &q3); fr_sub(&q3, &qc, &q3); fr_add(&q3, &e2, &q3); fr_add(&q3, &e2, &q3);
-        evals[0] = c_ev0; evals[1] = c_ev1; fr_mul(&eq2, &q2, &evals[2]); fr_mul(&eq3, &q3, &evals[3]);
-        /* UniPoly::from_evals degree 3: reuse the hint form (hint = e0 + e1) */
-        fr_t hint, ev3[3], coeffs[4], cc[3], r;
-        fr_add(&evals[0], &evals[1], &hint); ev3[0] = evals[0]; ev3[1] = evals[2]; ev3[2] = evals[3];
-        size_t nc = orc_unipoly_from_evals_and_hint(&hint, ev3, 3, coeffs);
+        fr_t coeffs[4], cc[3], r;
+        size_t nc = mul_message(&S, &prev, coeffs);
         size_t ncc = orc_unipoly_compress(coeffs, nc, cc);
         orc_transcript_append_compressed(t, cc, ncc);
         u128 raw; orc_transcript_challenge_optimized(t, &raw, &r);
         challenges[rnd] = raw;
         orc_unipoly_eval(coeffs, nc, &r, &prev);
         for (size_t k = 0; k < 3; k++) proof[rnd * 3 + k] = cc[k];
-        /* ingest_challenge: eq.bind(r); left/right bind LowToHigh */
-        {
-            fr_t wr, f, one; fr_one(&one);
-            fr_mul(&w[current_index - 1], &r, &wr);
-            fr_sub(&one, &w[current_index - 1], &f); fr_sub(&f, &r, &f); fr_add(&f, &wr, &f); fr_add(&f, &wr, &f);
-            fr_mul(&scalar, &f, &scalar);
-            current_index -= 1;
-            if (n / 2 < current_index && in_top > 0) in_top--;
-            else if (0 < current_index && out_top > 0) out_top--;
-        }
-        orc_bind(left, len, &r, ORC_LOW_TO_HIGH); orc_bind(right, len, &r, ORC_LOW_TO_HIGH);
-        len /= 2;
+        mul_ingest(&S, &r);
     }
-    final_claims[0] = left[0]; final_claims[1] = right[0]; final_claims[2] = scalar;
-    for (size_t j = 0; j <= k_out; j++) free(Eout[j]);
-    for (size_t j = 0; j <= k_in; j++) free(Ein[j]);
-    free(Eout); free(Ein);
+    final_claims[0] = left[0]; final_claims[1] = right[0]; final_claims[2] = S.scalar;
+    mul_free(&S);
     return 0;
 }
 
@@ -398,4 +444,106 @@ void orc_mul_claim(const fr_t *l, const fr_t *r, const fr_t *w, size_t n, fr_t *
     fr_t acc; fr_zero(&acc);
     for (size_t i = 0; i < len; i++) { fr_t t; fr_mul(&l[i], &r[i], &t); fr_mul(&t, &eq[i], &t); fr_add(&acc, &t, &acc); }
     *out = acc; free(eq);
+}
+
+/* ------------------------------------------------------------------ BatchedSumcheck::prove
+ * joltworks/src/subprotocols/sumcheck.rs:30-184.  Instances are described by orc_batched_inst
+ * (kind 0 = dot instance, 1 = Mul instance); operand arrays are bound in place. */
+static void fr_mul_pow2(const fr_t *x, size_t pow, fr_t *o) {          /* field/mod.rs:274-284 */
+    fr_t v = *x;
+    for (size_t i = 0; i < pow; i++) fr_add(&v, &v, &v);
+    *o = v;
+}
+
+static int fr_eq(const fr_t *a, const fr_t *b) { return memcmp(a, b, sizeof(fr_t)) == 0; }
+
+static size_t scale_trim(const fr_t *p, size_t n, const fr_t *c, fr_t *o) {   /* &UniPoly * F -> from_coeff (unipoly.rs:39-52,454-461) */
+    for (size_t i = 0; i < n; i++) fr_mul(&p[i], c, &o[i]);
+    fr_t z; fr_zero(&z);
+    while (n > 0 && fr_eq(&o[n - 1], &z)) n--;
+    if (n == 0) { o[0] = z; n = 1; }
+    return n;
+}
+
+int orc_batched_prove(orc_batched_inst *inst, size_t n_inst, orc_transcript *t, fr_t *compressed, uint32_t *n_coeffs,
+                      u128 *challenges, size_t *max_rounds_out) {
+    size_t max_rounds = 0;
+    dot_state *D = (dot_state *)calloc(n_inst, sizeof(dot_state));
+    mul_state *M = (mul_state *)calloc(n_inst, sizeof(mul_state));
+    fr_t *coeff = (fr_t *)malloc(n_inst * sizeof(fr_t)), *claim = (fr_t *)malloc(n_inst * sizeof(fr_t));
+    fr_t (*polys)[4] = (fr_t (*)[4])malloc(n_inst * sizeof(fr_t[4]));
+    size_t *plen = (size_t *)malloc(n_inst * sizeof(size_t));
+    for (size_t i = 0; i < n_inst; i++) {
+        orc_batched_inst *I = &inst[i];
+        if (I->kind == 0) dot_init(&D[i], I->left, I->right, I->eq, I->n_vars, I->schedule, I->sa, I->sb);
+        else mul_init(&M[i], I->left, I->right, I->w, I->n_vars);
+        if (I->n_vars > max_rounds) max_rounds = I->n_vars;
+    }
+    for (size_t i = 0; i < n_inst; i++) orc_transcript_append_scalar(t, &inst[i].input_claim);   /* :42-45 */
+    for (size_t i = 0; i < n_inst; i++) orc_transcript_challenge_scalar(t, &coeff[i]);           /* :47 */
+    for (size_t i = 0; i < n_inst; i++) fr_mul_pow2(&inst[i].input_claim, max_rounds - inst[i].n_vars, &claim[i]);  /* :58-66 */
+    for (size_t round = 0; round < max_rounds; round++) {
+        const size_t remaining = max_rounds - round;
+        for (size_t i = 0; i < n_inst; i++) {
+            const size_t nr = inst[i].n_vars;
+            if (remaining > nr) { fr_mul_pow2(&inst[i].input_claim, remaining - nr - 1, &polys[i][0]); plen[i] = 1; }   /* :91-98 */
+            else {
+                const size_t local = round - (max_rounds - nr);
+                plen[i] = inst[i].kind == 0 ? dot_round_message(&D[i], local, &claim[i], polys[i])
+                                            : mul_message(&M[i], &claim[i], polys[i]);
+            }
+        }
+        fr_t batched[4], tmp[4]; size_t blen = 1; fr_zero(&batched[0]);                            /* :109-116 */
+        for (size_t i = 0; i < n_inst; i++) {
+            size_t tl = scale_trim(polys[i], plen[i], &coeff[i], tmp);
+            for (size_t k = 0; k < tl; k++) {
+                if (k < blen) fr_add(&batched[k], &tmp[k], &batched[k]);
+                else batched[blen++] = tmp[k];
+            }
+        }
+        fr_t cc[4]; size_t ncc = orc_unipoly_compress(batched, blen, cc);
+        orc_transcript_append_compressed(t, cc, ncc);
+        fr_t r; u128 raw; orc_transcript_challenge_optimized(t, &raw, &r);
+        challenges[round] = raw; n_coeffs[round] = (uint32_t)ncc;
+        for (size_t k = 0; k < ncc; k++) compressed[round * 4 + k] = cc[k];
+        for (size_t i = 0; i < n_inst; i++) orc_unipoly_eval(polys[i], plen[i], &r, &claim[i]);    /* :123-126 */
+        for (size_t i = 0; i < n_inst; i++) {
+            const size_t nr = inst[i].n_vars;
+            if (remaining <= nr) {
+                if (inst[i].kind == 0) dot_ingest(&D[i], round - (max_rounds - nr), &r);
+                else mul_ingest(&M[i], &r);
+            }
+        }
+    }
+    for (size_t i = 0; i < n_inst; i++) {
+        if (inst[i].kind == 0) dot_finals(&D[i], inst[i].final_claims);
+        else {
+            inst[i].final_claims[0] = inst[i].left[0]; inst[i].final_claims[1] = inst[i].right[0];
+            inst[i].final_claims[2] = M[i].scalar; mul_free(&M[i]);
+        }
+    }
+    *max_rounds_out = max_rounds;
+    free(D); free(M); free(coeff); free(claim); free(polys); free(plen);
+    return 0;
+}
+
+int orc_batched_verify(const fr_t *compressed, const uint32_t *n_coeffs, size_t max_rounds, const fr_t *input_claims,
+                       const size_t *rounds, size_t n_inst, orc_transcript *t, fr_t *e_out, fr_t *coeffs_out,
+                       u128 *challenges) {
+    for (size_t i = 0; i < n_inst; i++) orc_transcript_append_scalar(t, &input_claims[i]);      /* :205-208 */
+    for (size_t i = 0; i < n_inst; i++) orc_transcript_challenge_scalar(t, &coeffs_out[i]);    /* :210 */
+    fr_t e; fr_zero(&e);
+    for (size_t i = 0; i < n_inst; i++) {                                                       /* :221-229 */
+        fr_t c; fr_mul_pow2(&input_claims[i], max_rounds - rounds[i], &c);
+        fr_mul(&c, &coeffs_out[i], &c); fr_add(&e, &c, &e);
+    }
+    for (size_t i = 0; i < max_rounds; i++) {                                                   /* proof.verify :653-686 */
+        const fr_t *cc = &compressed[i * 4];
+        orc_transcript_append_compressed(t, cc, n_coeffs[i]);
+        fr_t r; u128 raw; orc_transcript_challenge_optimized(t, &raw, &r);
+        if (challenges) challenges[i] = raw;
+        orc_compressed_eval_from_hint(cc, n_coeffs[i], &e, &r, &e);
+    }
+    *e_out = e;
+    return 0;
 }
