@@ -227,9 +227,17 @@ int atlas_srs_free(atlas_srs_t s);
  * Fails with ATLAS_EINVAL ("KeyLengthError") when the SRS slice is shorter than n. */
 int atlas_msm_fr(atlas_srs_t srs, size_t offset, const atlas_fr_t *scalars, size_t n,
                  atlas_g1_affine_t *out);
-/* same, scalars = a device-resident LargeScalars polynomial: UnivariateKZG::
- * commit_as_univariate (kzg.rs:285-298) without a host copy */
+/* same, scalars = a device-resident polynomial: UnivariateKZG::commit_as_univariate
+ * (kzg.rs:285-298) without a host copy; I32Scalars polynomials take the narrow-scalar plan */
 int atlas_msm_poly(atlas_srs_t srs, size_t offset, atlas_poly_t poly, atlas_g1_affine_t *out);
+/* VariableBaseMSM::msm for the narrow MultilinearPolynomial variants (joltworks/src/msm/mod.rs:
+ * 38-181, 193-307: msm_u8 / msm_u16 / msm_u32 / msm_u64 and the sign-split I32 / I64 cases).
+ * scalars = n host integers of the given kind.  The window plan follows the data's bit length;
+ * negative scalars contribute negated digits (same group element as pos-MSM minus neg-MSM). */
+enum { ATLAS_SCALAR_U8 = 0, ATLAS_SCALAR_U16 = 1, ATLAS_SCALAR_U32 = 2, ATLAS_SCALAR_U64 = 3,
+       ATLAS_SCALAR_I32 = 4, ATLAS_SCALAR_I64 = 5 };
+int atlas_msm_small(atlas_srs_t srs, size_t offset, const void *scalars, size_t n, int kind,
+                    atlas_g1_affine_t *out);
 /* sum of bases[indices[i]] — HyperKZG::commit_one_hot (hyperkzg/mod.rs:520-554): the caller
  * passes the flat indices k*T + t of the non-zero coefficients; replaces
  * jolt_optimizations::batch_g1_additions_multi */

@@ -339,6 +339,17 @@ class SRS:
                                     out.ctypes.data_as(C.c_void_p)))
         return out[0]
 
+    _SMALL_KIND = {"uint8": 0, "uint16": 1, "uint32": 2, "uint64": 3, "int32": 4, "int64": 5}
+
+    def msm_small(self, scalars, offset=0):
+        """VariableBaseMSM::msm for the U8/U16/U32/U64/I32/I64Scalars variants (msm/mod.rs:38-181)."""
+        s = np.ascontiguousarray(scalars)
+        kind = self._SMALL_KIND[s.dtype.name]
+        out = np.zeros(1, dtype=G1_DTYPE)
+        _check(lib.atlas_msm_small(self.h, C.c_size_t(offset), s.ctypes.data_as(C.c_void_p), C.c_size_t(s.size),
+                                   C.c_int(kind), out.ctypes.data_as(C.c_void_p)))
+        return out[0]
+
     def sum_indexed(self, indices):
         """HyperKZG::commit_one_hot: sum of bases[k*T + t] over the non-zero coefficients."""
         idx = np.ascontiguousarray(indices, dtype=np.uint32)

@@ -68,10 +68,10 @@ void to_out(const H::G1Aff& a, atlas_g1_affine_t* out) {
     out->infinity = (H::q_is_zero(a.x) && H::q_is_zero(a.y)) ? 1 : 0;
 }
 
-// core: scalars are Montgomery Fr already on the device
-int msm_device(const G1Affine* bases, const Fr* d_scalars, size_t n, atlas_g1_affine_t* out) {
+// core: `launch_digits(digits)` fills the window-major signed digits for shape S
+template <class DigitsFn>
+int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launch_digits, atlas_g1_affine_t* out) {
     if (n == 0) { H::G1Aff z{H::q_zero(), H::q_zero()}; to_out(z, out); return ATLAS_OK; }
-    const MsmShape S = pick_shape(n);
     const uint32_t TB = S.n_windows * S.bpw;
     const uint32_t chunk = S.bpw < (uint32_t)MSM_CHUNK ? S.bpw : (uint32_t)MSM_CHUNK;
     const uint32_t n_chunks = TB / chunk;
@@ -87,6 +87,10 @@ int msm_device(const G1Affine* bases, const Fr* d_scalars, size_t n, atlas_g1_af
     const size_t o_offsets = carve((size_t)(TB + 1) * 4);
     const size_t o_cursor = carve((size_t)(TB + 1) * 4);
     const size_t o_sorted = carve(n * (size_t)S.n_windows * 4);
+    // few buckets (narrow scalars): SEG threads share a bucket, partials summed afterwards
+    uint32_t seg = 1;
+    while (seg < 256 && (size_t)TB * seg < 32768 && (size_t)TB * seg * 64 < n * (size_t)S.n_windows) seg <<= 1;
+    const size_t o_partial = carve(seg > 1 ? (size_t)TB * seg * sizeof(G1Xyzz) : 0);
     const size_t o_buckets = carve((size_t)TB * sizeof(G1Xyzz));
     const size_t o_chunks = carve((size_t)n_chunks * sizeof(G1Xyzz));
     const size_t o_wsum = carve((size_t)S.n_windows * sizeof(G1Xyzz));
@@ -102,6 +106,7 @@ int msm_device(const G1Affine* bases, const Fr* d_scalars, size_t n, atlas_g1_af
     uint32_t* cursor = (uint32_t*)(W + o_cursor);
     uint32_t* sorted = (uint32_t*)(W + o_sorted);
     G1Xyzz* buckets = (G1Xyzz*)(W + o_buckets);
+    G1Xyzz* partial = (G1Xyzz*)(W + o_partial);
     G1Xyzz* chunks = (G1Xyzz*)(W + o_chunks);
     G1Xyzz* wsum = (G1Xyzz*)(W + o_wsum);
 
@@ -110,7 +115,7 @@ int msm_device(const G1Affine* bases, const Fr* d_scalars, size_t n, atlas_g1_af
 
     HIP_TRY(hipMemsetAsync(counts, 0, (size_t)(TB + 1) * 4, g.stream));
     // signed digits once, window-major; histogram of all windows; scan; scatter window by window
-    k_msm_digits<<<grid_for(n), MSM_THREADS, 0, g.stream>>>(d_scalars, n, S, digits);
+    launch_digits(digits);
     k_msm_hist_w<<<dim3((unsigned)grid_for(n, 256), S.n_windows), MSM_THREADS, 0, g.stream>>>(digits, n, S, counts);
     k_scan_block_sums<<<(unsigned)n_scan_blocks, 256, 0, g.stream>>>(counts, TB, bsum);
     k_exclusive_scan<<<1, 1024, 0, g.stream>>>(bsum, (uint32_t)n_scan_blocks, boff, bcur);
@@ -118,7 +123,12 @@ int msm_device(const G1Affine* bases, const Fr* d_scalars, size_t n, atlas_g1_af
     for (uint32_t w = 0; w < S.n_windows; w++)
         k_msm_scatter_w<<<grid_for(n, 1024), MSM_THREADS, 0, g.stream>>>(digits + (size_t)w * n, n, cursor + (size_t)w * S.bpw, sorted);
     if (g.timing) hipEventRecord(e1, g.stream);
-    k_msm_accumulate<<<(TB + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, g.stream>>>(bases, sorted, offsets, TB, buckets);
+    if (seg == 1) {
+        k_msm_accumulate<<<(TB + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, g.stream>>>(bases, sorted, offsets, TB, 1, buckets);
+    } else {
+        k_msm_accumulate<<<(TB * seg + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, g.stream>>>(bases, sorted, offsets, TB, seg, partial);
+        k_g1_seg_sum<<<(TB + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, g.stream>>>(partial, seg, TB, buckets);
+    }
     if (g.timing) hipEventRecord(e2, g.stream);
     k_msm_fold_chunks<<<(n_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, g.stream>>>(buckets, S, chunk, n_chunks, chunks);
     k_g1_group_sum<<<S.n_windows, MSM_THREADS, 0, g.stream>>>(chunks, chunks_per_window, wsum);
@@ -148,6 +158,44 @@ int msm_device(const G1Affine* bases, const Fr* d_scalars, size_t n, atlas_g1_af
         hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2); hipEventDestroy(e3);
     }
     return ATLAS_OK;
+}
+
+// scalars are Montgomery Fr already on the device
+int msm_device(const G1Affine* bases, const Fr* d_scalars, size_t n, atlas_g1_affine_t* out) {
+    const MsmShape S = pick_shape(n);
+    return msm_core(bases, n, S, [&](int16_t* digits) {
+        k_msm_digits<<<grid_for(n), MSM_THREADS, 0, g.stream>>>(d_scalars, n, S, digits);
+    }, out);
+}
+
+// narrow integer scalars (msm_u8 .. msm_u64 and the signed split of I32/I64Scalars,
+// joltworks/src/msm/mod.rs:38-181): the window plan follows the data's actual bit length so
+// the buckets stay balanced, and a negative scalar flips the sign of its digits instead of
+// going through two MSMs.
+template <typename T>
+int msm_small_device(const G1Affine* bases, const T* d_scalars, size_t n, atlas_g1_affine_t* out) {
+    if (n == 0) { H::G1Aff z{H::q_zero(), H::q_zero()}; to_out(z, out); return ATLAS_OK; }
+    int rc = ws.ensure(256);
+    if (rc) return rc;
+    unsigned long long* d_max = (unsigned long long*)ws.p;
+    HIP_TRY(hipMemsetAsync(d_max, 0, 8, g.stream));
+    k_abs_max<T><<<grid_for(n, 1024), MSM_THREADS, 0, g.stream>>>(d_scalars, n, d_max);
+    unsigned long long mx = 0;
+    HIP_TRY(hipMemcpyAsync(&mx, d_max, 8, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    if (mx == 0) { H::G1Aff z{H::q_zero(), H::q_zero()}; to_out(z, out); return ATLAS_OK; }
+    const uint32_t bits = 64 - (uint32_t)__builtin_clzll(mx);
+    // the top window must stay below half after the incoming carry (digits >= half go negative)
+    const uint32_t total = bits + 2;
+    const uint32_t c0 = pick_shape(n).c;
+    MsmShape S;
+    S.n_windows = (total + c0 - 1) / c0;
+    S.c = (total + S.n_windows - 1) / S.n_windows;
+    if (S.c < 2) S.c = 2;
+    S.bpw = 1u << (S.c - 1);
+    return msm_core(bases, n, S, [&](int16_t* digits) {
+        k_msm_digits_small<T><<<grid_for(n), MSM_THREADS, 0, g.stream>>>(d_scalars, n, S, digits);
+    }, out);
 }
 
 }  // namespace
@@ -277,10 +325,38 @@ int atlas_msm_fr(atlas_srs_t srs, size_t offset, const atlas_fr_t* scalars, size
 int atlas_msm_poly(atlas_srs_t srs, size_t offset, atlas_poly_t poly, atlas_g1_affine_t* out) {
     NEED_INIT();
     if (!srs || !poly || !out) return fail(ATLAS_EINVAL, "msm_poly: null argument");
-    if (poly->is_i32) return fail(ATLAS_EINVAL, "msm_poly: I32Scalars not supported yet (use LargeScalars)");
     if (offset + poly->len > srs->len) return fail(ATLAS_EINVAL, "msm_poly: KeyLengthError (bases shorter than scalars)");
     std::lock_guard<std::mutex> lk(g.mu);
+    if (poly->is_i32) return msm_small_device<int32_t>(srs->d + offset, (const int32_t*)poly->d, poly->len, out);   // I32Scalars, msm/mod.rs:88-130
     return msm_device(srs->d + offset, (const Fr*)poly->d, poly->len, out);
+}
+
+// msm over device-resident narrow scalars; kind = ATLAS_SCALAR_* (element type of the
+// MultilinearPolynomial variant, msm/mod.rs:38-181)
+int atlas_msm_small(atlas_srs_t srs, size_t offset, const void* scalars, size_t n, int kind, atlas_g1_affine_t* out) {
+    NEED_INIT();
+    if (!srs || !out || (!scalars && n) || offset + n > srs->len) return fail(ATLAS_EINVAL, "msm_small: KeyLengthError");
+    std::lock_guard<std::mutex> lk(g.mu);
+    static const size_t width[] = {1, 2, 4, 8, 4, 8};
+    if (kind < 0 || kind > ATLAS_SCALAR_I64) return fail(ATLAS_EINVAL, "msm_small: kind");
+    void* d_s = nullptr;
+    if (n) {
+        HIP_TRY(hipMalloc(&d_s, n * width[kind]));
+        hipError_t e = hipMemcpyAsync(d_s, scalars, n * width[kind], hipMemcpyHostToDevice, g.stream);
+        if (e != hipSuccess) { hipFree(d_s); return fail(ATLAS_ENODEV, "msm_small copy", e); }
+    }
+    int rc = ATLAS_EINVAL;
+    const G1Affine* b = srs->d + offset;
+    switch (kind) {
+        case ATLAS_SCALAR_U8: rc = msm_small_device<uint8_t>(b, (const uint8_t*)d_s, n, out); break;
+        case ATLAS_SCALAR_U16: rc = msm_small_device<uint16_t>(b, (const uint16_t*)d_s, n, out); break;
+        case ATLAS_SCALAR_U32: rc = msm_small_device<uint32_t>(b, (const uint32_t*)d_s, n, out); break;
+        case ATLAS_SCALAR_U64: rc = msm_small_device<uint64_t>(b, (const uint64_t*)d_s, n, out); break;
+        case ATLAS_SCALAR_I32: rc = msm_small_device<int32_t>(b, (const int32_t*)d_s, n, out); break;
+        case ATLAS_SCALAR_I64: rc = msm_small_device<int64_t>(b, (const int64_t*)d_s, n, out); break;
+    }
+    if (d_s) hipFree(d_s);
+    return rc;
 }
 
 int atlas_g1_sum_indexed(atlas_srs_t srs, const uint32_t* indices, size_t n, atlas_g1_affine_t* out) {

@@ -13,6 +13,7 @@
 // buckets are folded by the running-sum method in chunks; the last O(windows) doublings and
 // the one inversion to affine run on the host.
 #pragma once
+#include <type_traits>
 #include "curve.hip.h"
 #include "curve_f9.hip.h"
 #include "scan.hip.h"
@@ -122,10 +123,17 @@ __global__ __launch_bounds__(MSM_THREADS) void k_msm_scatter(const Fr* __restric
 __global__ __launch_bounds__(MSM_THREADS) void k_msm_accumulate(const G1Affine* __restrict__ bases,
                                                                 const uint32_t* __restrict__ sorted,
                                                                 const uint32_t* __restrict__ offsets,
-                                                                uint32_t n_buckets, G1Xyzz* __restrict__ buckets) {
-    const uint32_t b = blockIdx.x * MSM_THREADS + threadIdx.x;
+                                                                uint32_t n_buckets, uint32_t seg,
+                                                                G1Xyzz* __restrict__ buckets) {
+    const uint32_t t = blockIdx.x * MSM_THREADS + threadIdx.x;
+    const uint32_t b = t / seg;
     if (b >= n_buckets) return;
-    const uint32_t lo = offsets[b], hi = offsets[b + 1];
+    uint32_t lo = offsets[b], hi = offsets[b + 1];
+    if (seg > 1) {   // this thread's slice of the bucket
+        const uint32_t len = hi - lo, s = t % seg;
+        const uint32_t a = (uint32_t)(((uint64_t)len * s) / seg), e = (uint32_t)(((uint64_t)len * (s + 1)) / seg);
+        hi = lo + e; lo = lo + a;
+    }
     // 29-bit lazy-limb accumulator (curve_f9.hip.h); canonical XYZZ written once per bucket
     G1Xyzz9 acc;
     acc.inf = true;
@@ -136,7 +144,61 @@ __global__ __launch_bounds__(MSM_THREADS) void k_msm_accumulate(const G1Affine* 
         if (g1_aff_is_inf(p)) continue;
         g1_madd_f9(acc, p, (v >> 31) != 0);
     }
-    g1_store(buckets + b, g1_from_f9(acc));
+    g1_store(buckets + t, g1_from_f9(acc));
+}
+
+// buckets[b] = sum of its `seg` partials
+__global__ __launch_bounds__(MSM_THREADS) void k_g1_seg_sum(const G1Xyzz* __restrict__ partial, uint32_t seg,
+                                                            uint32_t n_buckets, G1Xyzz* __restrict__ buckets) {
+    const uint32_t b = blockIdx.x * MSM_THREADS + threadIdx.x;
+    if (b >= n_buckets) return;
+    G1Xyzz acc = g1_load(partial + (size_t)b * seg);
+    for (uint32_t s = 1; s < seg; s++) acc = g1_add(acc, g1_load(partial + (size_t)b * seg + s));
+    g1_store(buckets + b, acc);
+}
+
+// narrow scalars: |s| as a 64-bit magnitude
+template <typename T>
+__device__ __forceinline__ uint64_t small_abs(T v, bool& neg) {
+    if constexpr (std::is_signed<T>::value) {
+        neg = v < 0;
+        const uint64_t u = (uint64_t)(int64_t)v;
+        return neg ? (uint64_t)0 - u : u;
+    } else {
+        neg = false;
+        return (uint64_t)v;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(MSM_THREADS) void k_abs_max(const T* __restrict__ s, size_t n, unsigned long long* out) {
+    unsigned long long m = 0;
+    for (size_t i = (size_t)blockIdx.x * MSM_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * MSM_THREADS) {
+        bool neg;
+        const unsigned long long a = small_abs<T>(s[i], neg);
+        m = a > m ? a : m;
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned long long x = __shfl_xor(m, o);
+        m = x > m ? x : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+template <typename T>
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_digits_small(const T* __restrict__ s, size_t n, MsmShape S,
+                                                                  int16_t* __restrict__ digits) {
+    for (size_t i = (size_t)blockIdx.x * MSM_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * MSM_THREADS) {
+        bool sneg;
+        const uint64_t a = small_abs<T>(s[i], sneg);
+        Fr k;
+        k.v[0] = (uint32_t)a; k.v[1] = (uint32_t)(a >> 32);
+        for (int j = 2; j < 8; j++) k.v[j] = 0;
+        for (uint32_t w = 0; w < S.n_windows; w++) digits[(size_t)w * n + i] = 0;
+        for_each_digit(k, S, [&](uint32_t w, uint32_t b, bool neg) {
+            digits[(size_t)w * n + i] = (neg != sneg) ? (int16_t)(-(int32_t)(b + 1)) : (int16_t)(b + 1);
+        });
+    }
 }
 
 // small * P by double-and-add

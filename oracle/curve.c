@@ -299,3 +299,34 @@ int orc_hyperkzg_verify_trapdoor(const g1_aff_t *srs, const fr_t *tau, const g1_
     if (L.inf || tR.inf) return (L.inf && tR.inf) ? 1 : 0;
     return fp_eq(&L.x, &tR.x) && fp_eq(&L.y, &tR.y);
 }
+
+/* VariableBaseMSM::msm for the narrow MultilinearPolynomial variants (joltworks/src/msm/mod.rs:
+ * 38-181): unsigned kinds go to msm_uN; I32/I64 split into positive and negative magnitudes and
+ * return msm_u64(pos) - msm_u64(neg).  kind: 0 u8, 1 u16, 2 u32, 3 u64, 4 i32, 5 i64. */
+void orc_msm_small(const g1_aff_t *bases, const void *scalars, size_t n, int kind, g1_aff_t *out) {
+    g1_aff_t *pb = (g1_aff_t *)malloc((n + 1) * sizeof(g1_aff_t)), *nb = (g1_aff_t *)malloc((n + 1) * sizeof(g1_aff_t));
+    fr_t *ps = (fr_t *)malloc((n + 1) * sizeof(fr_t)), *ns = (fr_t *)malloc((n + 1) * sizeof(fr_t));
+    size_t np = 0, nn = 0;
+    for (size_t i = 0; i < n; i++) {
+        uint64_t mag = 0; int neg = 0;
+        switch (kind) {
+            case 0: mag = ((const uint8_t *)scalars)[i]; break;
+            case 1: mag = ((const uint16_t *)scalars)[i]; break;
+            case 2: mag = ((const uint32_t *)scalars)[i]; break;
+            case 3: mag = ((const uint64_t *)scalars)[i]; break;
+            case 4: { int32_t v = ((const int32_t *)scalars)[i]; neg = v < 0; mag = neg ? (uint64_t)(-(int64_t)v) : (uint64_t)v; break; }
+            default: { int64_t v = ((const int64_t *)scalars)[i]; neg = v < 0; mag = neg ? (uint64_t)0 - (uint64_t)v : (uint64_t)v; break; }
+        }
+        if (!mag) continue;
+        if (neg) { nb[nn] = bases[i]; fr_from_u64(mag, &ns[nn]); nn++; }
+        else { pb[np] = bases[i]; fr_from_u64(mag, &ps[np]); np++; }
+    }
+    g1_aff_t P, N;
+    orc_msm_pippenger(pb, ps, np, &P);
+    orc_msm_pippenger(nb, ns, nn, &N);
+    g1_jac_t jp, jn, r;
+    g1_jac_from_aff(&P, &jp); g1_jac_from_aff(&N, &jn); g1_jac_neg(&jn, &jn);
+    g1_jac_add(&jp, &jn, &r);
+    g1_jac_to_aff(&r, out);
+    free(pb); free(nb); free(ps); free(ns);
+}

@@ -110,6 +110,8 @@ void g1_mul_fr(const g1_aff_t *p, const fr_t *s, g1_aff_t *o);
 void orc_msm_naive(const g1_aff_t *bases, const fr_t *scalars, size_t n, g1_aff_t *out);
 void orc_msm_pippenger(const g1_aff_t *bases, const fr_t *scalars, size_t n, g1_aff_t *out);
 void orc_g1_sum_indexed(const g1_aff_t *bases, const uint64_t *idx, size_t n, g1_aff_t *out);
+/* msm/mod.rs:38-181 narrow-scalar variants; kind 0 u8, 1 u16, 2 u32, 3 u64, 4 i32, 5 i64 */
+void orc_msm_small(const g1_aff_t *bases, const void *scalars, size_t n, int kind, g1_aff_t *out);
 void orc_srs_powers(const fr_t *tau, size_t n, g1_aff_t *out);
 void orc_transcript_append_point(orc_transcript *t, const g1_aff_t *p);   /* blake2b.rs:166-187 */
 void orc_transcript_append_points(orc_transcript *t, const g1_aff_t *p, size_t n);

@@ -69,3 +69,17 @@ def batched_verify(rows, input_claims, rounds, t):
                                     rds.ctypes.data_as(C.c_void_p), C.c_size_t(n), C.byref(t), orc._p(e), orc._p(co), orc._p(ch))
     assert rc == 0
     return e.reshape(4), co.reshape(n, 4), orc._u128_list(ch, max_rounds)
+
+
+_KIND = {np.dtype(np.uint8): 0, np.dtype(np.uint16): 1, np.dtype(np.uint32): 2, np.dtype(np.uint64): 3,
+         np.dtype(np.int32): 4, np.dtype(np.int64): 5}
+
+
+def msm_small(bases, scalars):
+    """VariableBaseMSM::msm on a narrow-scalar polynomial (msm/mod.rs:38-181)."""
+    bases = np.ascontiguousarray(bases, dtype=orc.G1_DTYPE)
+    scalars = np.ascontiguousarray(scalars)
+    out = np.zeros(1, dtype=orc.G1_DTYPE)
+    orc.lib.orc_msm_small(bases.ctypes.data_as(C.c_void_p), scalars.ctypes.data_as(C.c_void_p), C.c_size_t(len(scalars)),
+                          C.c_int(_KIND[scalars.dtype]), out.ctypes.data_as(C.c_void_p))
+    return out[0]
