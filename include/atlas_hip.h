@@ -205,6 +205,20 @@ int atlas_batched_add_mul(atlas_batched_t b, atlas_mul_prover_t p, const atlas_f
 int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t *transcript, atlas_fr_t *compressed,
                         uint32_t *n_coeffs, atlas_u128_t *challenges, size_t *max_rounds_out);
 
+/* ---- build_materialized_rlc (joltworks/src/poly/rlc_polynomial.rs:13-78): the joint polynomial
+ *      joint[i] = sum_j coeff_j * dense_j[i];  joint[k_j[t] * T_j + t] += coeff_j (one-hot) ---- */
+typedef struct { atlas_poly_t poly; atlas_fr_t coeff; } atlas_rlc_dense_t;   /* LargeScalars / I32Scalars */
+typedef struct {
+    const int32_t *k;     /* OneHotPolynomial::nonzero_indices as i32, negative = None; T entries */
+    size_t T, K;          /* cycles, address space (one_hot_polynomial.rs:21-40) */
+    atlas_fr_t coeff;
+    int k_on_device;      /* non-zero: k is a device pointer */
+} atlas_rlc_onehot_t;
+/* joint length = max(max dense len, max K*T) and must be a power of two (DensePolynomial::new,
+ * dense_mlpoly.rs:33-45).  The inputs are not consumed. */
+int atlas_rlc_build(const atlas_rlc_dense_t *dense, size_t n_dense, const atlas_rlc_onehot_t *onehot,
+                    size_t n_onehot, atlas_poly_t *out);
+
 /* ---- SRS + multi-scalar multiplication: the arithmetic behind the CommitmentScheme
  *      plug-in (joltworks/src/poly/commitment/commitment_scheme.rs:11-131) for HyperKZG --- */
 typedef struct { uint64_t l[4]; } atlas_fq_t;            /* ark_bn254::Fq, Montgomery limbs */

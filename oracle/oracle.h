@@ -110,6 +110,10 @@ void g1_mul_fr(const g1_aff_t *p, const fr_t *s, g1_aff_t *o);
 void orc_msm_naive(const g1_aff_t *bases, const fr_t *scalars, size_t n, g1_aff_t *out);
 void orc_msm_pippenger(const g1_aff_t *bases, const fr_t *scalars, size_t n, g1_aff_t *out);
 void orc_g1_sum_indexed(const g1_aff_t *bases, const uint64_t *idx, size_t n, g1_aff_t *out);
+/* build_materialized_rlc (poly/rlc_polynomial.rs:13-78) */
+void orc_rlc_build(const fr_t *const *dense_fr, const int32_t *const *dense_i32, const size_t *dense_len,
+                   const fr_t *dense_coeff, size_t n_dense, const int32_t *const *oh_k, const size_t *oh_T,
+                   const fr_t *oh_coeff, size_t n_oh, fr_t *joint, size_t joint_len);
 /* msm/mod.rs:38-181 narrow-scalar variants; kind 0 u8, 1 u16, 2 u32, 3 u64, 4 i32, 5 i64 */
 void orc_msm_small(const g1_aff_t *bases, const void *scalars, size_t n, int kind, g1_aff_t *out);
 void orc_srs_powers(const fr_t *tau, size_t n, g1_aff_t *out);

@@ -83,3 +83,31 @@ def msm_small(bases, scalars):
     orc.lib.orc_msm_small(bases.ctypes.data_as(C.c_void_p), scalars.ctypes.data_as(C.c_void_p), C.c_size_t(len(scalars)),
                           C.c_int(_KIND[scalars.dtype]), out.ctypes.data_as(C.c_void_p))
     return out[0]
+
+
+def rlc_build(dense, onehot):
+    """build_materialized_rlc.  dense: list of (array (len,4) Fr | int32 array, coeff (4,));
+    onehot: list of (k int32 array of T entries (negative = None), K, coeff (4,))."""
+    nd, no = len(dense), len(onehot)
+    joint_len = max([len(a) for a, _ in dense] + [K * len(k) for k, K, _ in onehot])
+    keep = []
+    fr_ptrs = (C.c_void_p * max(nd, 1))(); i32_ptrs = (C.c_void_p * max(nd, 1))()
+    lens = (C.c_size_t * max(nd, 1))()
+    dco = orc.fr_array(max(nd, 1))
+    for j, (a, c) in enumerate(dense):
+        a = np.ascontiguousarray(a); keep.append(a)
+        if a.dtype == np.int32:
+            i32_ptrs[j] = a.ctypes.data; fr_ptrs[j] = None
+        else:
+            fr_ptrs[j] = a.ctypes.data; i32_ptrs[j] = None
+        lens[j] = len(a); dco[j] = c
+    k_ptrs = (C.c_void_p * max(no, 1))(); Ts = (C.c_size_t * max(no, 1))()
+    oco = orc.fr_array(max(no, 1))
+    for j, (k, K, c) in enumerate(onehot):
+        k = np.ascontiguousarray(k, dtype=np.int32); keep.append(k)
+        k_ptrs[j] = k.ctypes.data; Ts[j] = len(k); oco[j] = c
+    joint = orc.fr_array(joint_len)
+    orc.lib.orc_rlc_build.restype = None
+    orc.lib.orc_rlc_build(fr_ptrs, i32_ptrs, lens, orc._p(dco), C.c_size_t(nd), k_ptrs, Ts, orc._p(oco), C.c_size_t(no),
+                          orc._p(joint), C.c_size_t(joint_len))
+    return joint
