@@ -1,0 +1,86 @@
+"""ctypes binding of oracle/ra.c (RaVirtual / Booleanity / HammingWeight instances).
+TEST INFRASTRUCTURE ONLY, like orc.py."""
+import ctypes as C
+
+import numpy as np
+
+from . import orc
+
+RA_VIRTUAL, BOOLEANITY, HAMMING = 2, 3, 4
+_STATE_BYTES = 1024          # >= sizeof of any orc_* state struct
+
+
+def _idx_ptrs(H_indices):
+    arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in H_indices]
+    ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    return arrs, ptrs
+
+
+class Instance:
+    def __init__(self, kind, n_rounds):
+        self.kind, self.n_rounds = kind, n_rounds
+        self.st = C.create_string_buffer(_STATE_BYTES)
+        self.keep = []
+
+    def message(self, rnd, claim):
+        out = orc.fr_array(40)
+        orc.lib.orc_ra_inst_message.restype = C.c_size_t
+        n = orc.lib.orc_ra_inst_message(C.c_int(self.kind), self.st, C.c_size_t(rnd), orc._p(np.ascontiguousarray(claim)), orc._p(out))
+        return out[:n]
+
+    def ingest(self, rnd, r_fr):
+        orc.lib.orc_ra_inst_ingest(C.c_int(self.kind), self.st, C.c_size_t(rnd), orc._p(np.ascontiguousarray(r_fr)))
+
+    def prove(self, claim, t, stride=20):
+        n = self.n_rounds
+        comp = orc.fr_array(max(n, 1) * stride); nco = np.zeros(max(n, 1), dtype=np.uint32)
+        ch = np.zeros(2 * max(n, 1), dtype=np.uint64)
+        claim = np.ascontiguousarray(claim, dtype=np.uint64).reshape(1, 4)
+        orc.lib.orc_ra_inst_prove(C.c_int(self.kind), self.st, C.c_size_t(n), orc._p(claim), C.byref(t), orc._p(comp),
+                                  C.c_size_t(stride), nco.ctypes.data_as(C.c_void_p), orc._p(ch))
+        comp = comp.reshape(max(n, 1), stride, 4)
+        return [comp[i, :nco[i]].copy() for i in range(n)], orc._u128_list(ch, n)
+
+
+def ra_virtual(H_indices, log_k, r_address_chunks, r_cycle):
+    """r_address_chunks: (d, log_k, 4) Fr; r_cycle: (log_T, 4) Fr."""
+    d = len(H_indices); log_T = len(r_cycle)
+    I = Instance(RA_VIRTUAL, log_T)
+    arrs, ptrs = _idx_ptrs(H_indices)
+    ch = np.ascontiguousarray(r_address_chunks, dtype=np.uint64); rc = np.ascontiguousarray(r_cycle, dtype=np.uint64)
+    I.keep = [arrs, ptrs, ch, rc]
+    orc.lib.orc_ra_virtual_init(I.st, ptrs, C.c_size_t(d), C.c_size_t(log_k), C.c_size_t(log_T), orc._p(ch), orc._p(rc))
+    return I
+
+
+def booleanity(G, H_indices, log_k, gammas, r_address, r_cycle):
+    d = len(H_indices); log_T = len(r_cycle)
+    I = Instance(BOOLEANITY, log_k + log_T)
+    arrs, ptrs = _idx_ptrs(H_indices)
+    G = np.ascontiguousarray(G, dtype=np.uint64); ga = np.ascontiguousarray(gammas, dtype=np.uint64)
+    ra = np.ascontiguousarray(r_address, dtype=np.uint64); rc = np.ascontiguousarray(r_cycle, dtype=np.uint64)
+    I.keep = [arrs, ptrs, G, ga, ra, rc]
+    orc.lib.orc_booleanity_init(I.st, orc._p(G), ptrs, C.c_size_t(d), C.c_size_t(log_k), C.c_size_t(log_T), orc._p(ga),
+                                orc._p(ra), orc._p(rc))
+    return I
+
+
+def hamming(G, log_k, gamma_powers):
+    G = np.ascontiguousarray(G, dtype=np.uint64); gp = np.ascontiguousarray(gamma_powers, dtype=np.uint64)
+    d = len(gp)
+    I = Instance(HAMMING, log_k)
+    I.keep = [G, gp]
+    orc.lib.orc_hamming_init(I.st, orc._p(G), C.c_size_t(d), C.c_size_t(log_k), orc._p(gp))
+    return I
+
+
+def ra_G(H_indices, log_k, r_cycle):
+    """compute_ra_evals-style G_i[k] = sum_{j: idx_i[j] = k} eq(r_cycle, j) (shout.rs:550-598)."""
+    E = orc.eq_evals(np.ascontiguousarray(r_cycle))
+    K = 1 << log_k
+    out = orc.fr_array(len(H_indices) * K).reshape(len(H_indices), K, 4)
+    for i, idx in enumerate(H_indices):
+        for j, k in enumerate(idx):
+            if k >= 0:
+                out[i, k] = orc.fr_add_arr(out[i, k], E[j])
+    return out

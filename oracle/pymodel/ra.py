@@ -1,0 +1,158 @@
+"""Naive full-table models of the one-hot "ra" sumcheck instances (second, independent restatement
+used to pin oracle/ra.c).  TEST INFRASTRUCTURE ONLY (oracle).
+
+Each model keeps the whole summand as dense tables and produces the round polynomial by
+evaluating it at 0..deg and interpolating — no Gruen split, no prefix tables, no grid tricks — so
+agreement with oracle/ra.c checks those optimisations as restated from
+  subprotocols/ra_virtual.rs:97-145, mles_product_sum.rs:15-131,330-376,
+  subprotocols/booleanity.rs:169-348, subprotocols/hamming_weight.rs:106-148,
+  poly/split_eq_poly.rs, poly/ra_poly.rs, utils/expanding_table.rs.
+Indices: list of ints, negative = None.
+"""
+from .field import FR
+from . import poly as P
+
+L2H = P.LOW_TO_HIGH
+
+
+def interpolate(evals):
+    """coefficients of the polynomial through (0, e0), (1, e1), ... (exact, mod FR)."""
+    n = len(evals)
+    coeffs = [0] * n
+    for i, yi in enumerate(evals):
+        num = [1]
+        den = 1
+        for j in range(n):
+            if j == i:
+                continue
+            num = [(a - j * b) % FR for a, b in zip([0] + num, num + [0])]
+            den = den * (i - j) % FR
+        s = yi * pow(den, -1, FR) % FR
+        for k in range(n):
+            coeffs[k] = (coeffs[k] + s * num[k]) % FR
+    return coeffs
+
+
+def from_coeff(c):
+    c = list(c)
+    while c and c[-1] == 0:
+        c.pop()
+    return c or [0]
+
+
+def _ext(z, i, npts):
+    """values at X = 0..npts-1 of the LowToHigh restriction of table z at pair i."""
+    a, b = z[2 * i], z[2 * i + 1]
+    m = (b - a) % FR
+    return [(a + x * m) % FR for x in range(npts)]
+
+
+class RaVirtualModel:
+    """sum_j eq(r_cycle, j) prod_i ra_i(j), ra_i(j) = eq(chunk_i, idx_i[j])."""
+
+    def __init__(self, H_indices, r_address_chunks, r_cycle):
+        self.d = len(H_indices)
+        self.ra = []
+        for idx, chunk in zip(H_indices, r_address_chunks):
+            F = P.eq_evals(chunk)
+            self.ra.append([0 if k < 0 else F[k] for k in idx])
+        self.eq = P.eq_evals(r_cycle)
+        self._n = len(r_cycle)
+
+    def num_rounds(self):
+        return self._n
+
+    def input_claim(self):
+        acc = 0
+        for j in range(len(self.eq)):
+            t = self.eq[j]
+            for ra in self.ra:
+                t = t * ra[j] % FR
+            acc = (acc + t) % FR
+        return acc
+
+    def compute_message(self, rnd, previous_claim):
+        npts = self.d + 2
+        ev = [0] * npts
+        for i in range(len(self.eq) // 2):
+            cols = [_ext(self.eq, i, npts)] + [_ext(ra, i, npts) for ra in self.ra]
+            for x in range(npts):
+                t = 1
+                for c in cols:
+                    t = t * c[x] % FR
+                ev[x] = (ev[x] + t) % FR
+        assert (ev[0] + ev[1]) % FR == previous_claim % FR
+        return from_coeff(interpolate(ev))
+
+    def ingest_challenge(self, r, rnd):
+        self.eq = P.bind(self.eq, r, L2H)
+        self.ra = [P.bind(ra, r, L2H) for ra in self.ra]
+
+    def finals(self):
+        return [ra[0] for ra in self.ra]
+
+
+class BooleanityModel:
+    """sum_{k,j} eq(r_address,k) eq(r_cycle,j) sum_i gamma_i (ra_i(k,j)^2 - ra_i(k,j)); address
+    variables first (LowToHigh), then cycle variables (LowToHigh)."""
+
+    def __init__(self, H_indices, log_k, gammas, r_address, r_cycle):
+        K = 1 << log_k
+        T = len(H_indices[0])
+        self.log_k = log_k
+        ea, ec = P.eq_evals(r_address), P.eq_evals(r_cycle)
+        self.eq = [ec[j] * ea[k] % FR for j in range(T) for k in range(K)]
+        self.ra = [[1 if idx[j] == k else 0 for j in range(T) for k in range(K)] for idx in H_indices]
+        self.gammas = list(gammas)
+        self._n = log_k + len(r_cycle)
+
+    def num_rounds(self):
+        return self._n
+
+    def compute_message(self, rnd, previous_claim):
+        ev = [0] * 4
+        for i in range(len(self.eq) // 2):
+            e = _ext(self.eq, i, 4)
+            cols = [_ext(ra, i, 4) for ra in self.ra]
+            for x in range(4):
+                s = 0
+                for g, c in zip(self.gammas, cols):
+                    s = (s + g * (c[x] * c[x] - c[x])) % FR
+                ev[x] = (ev[x] + e[x] * s) % FR
+        assert (ev[0] + ev[1]) % FR == previous_claim % FR
+        c = interpolate(ev)
+        return c if rnd < self.log_k else from_coeff(c)     # phase 2 scales by eq_r_r -> from_coeff
+
+    def ingest_challenge(self, r, rnd):
+        self.eq = P.bind(self.eq, r, L2H)
+        self.ra = [P.bind(ra, r, L2H) for ra in self.ra]
+
+    def finals(self):
+        return [ra[0] for ra in self.ra]
+
+
+class HammingModel:
+    """sum_k sum_i gamma_i G_i[k], LowToHigh, degree 1."""
+
+    def __init__(self, G, gamma_powers):
+        self.ra = [list(g) for g in G]
+        self.g = list(gamma_powers)
+        self._n = len(G[0]).bit_length() - 1
+
+    def num_rounds(self):
+        return self._n
+
+    def compute_message(self, rnd, previous_claim):
+        ev = [0, 0]
+        for ra, g in zip(self.ra, self.g):
+            for i in range(len(ra) // 2):
+                ev[0] = (ev[0] + g * ra[2 * i]) % FR
+                ev[1] = (ev[1] + g * ra[2 * i + 1]) % FR
+        assert (ev[0] + ev[1]) % FR == previous_claim % FR
+        return from_coeff([ev[0], (ev[1] - ev[0]) % FR])
+
+    def ingest_challenge(self, r, rnd):
+        self.ra = [P.bind(ra, r, L2H) for ra in self.ra]
+
+    def finals(self):
+        return [ra[0] for ra in self.ra]
