@@ -198,12 +198,52 @@ int atlas_batched_add_mul(atlas_batched_t b, atlas_mul_prover_t p, const atlas_f
 /* Runs the protocol: appends the input claims, draws the batching coefficients, then per
  * round combines the instances' round polynomials, compresses, appends, draws r_j and has
  * the active instances ingest it.
- *   compressed : max_rounds rows of 4 Fr; row i holds n_coeffs[i] coefficients
- *                (coeffs_except_linear_term of the batched round polynomial)
+ *   compressed : max_rounds rows of row_stride Fr; row i holds n_coeffs[i] coefficients
+ *                (coeffs_except_linear_term of the batched round polynomial; row_stride must
+ *                be at least the largest instance degree)
  *   challenges : max_rounds raw u128 draws
  * Instances are left fully bound; their final claims are read with *_final_claims. */
 int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t *transcript, atlas_fr_t *compressed,
-                        uint32_t *n_coeffs, atlas_u128_t *challenges, size_t *max_rounds_out);
+                        size_t row_stride, uint32_t *n_coeffs, atlas_u128_t *challenges,
+                        size_t *max_rounds_out);
+
+/* ---- generic SumcheckInstanceProver handle (joltworks/src/subprotocols/sumcheck_prover.rs:
+ *      10-68): what the constructors below return; host-stepped, so an instance can sit in a
+ *      BatchedSumcheck next to the dot / Mul provers ---------------------------------------- */
+typedef struct atlas_instance *atlas_instance_t;
+size_t atlas_instance_num_rounds(atlas_instance_t i);
+size_t atlas_instance_degree(atlas_instance_t i);
+int atlas_instance_compute_message(atlas_instance_t i, size_t round, const atlas_fr_t *previous_claim,
+                                   atlas_fr_t *coeffs_out, size_t cap, size_t *n_coeffs);
+int atlas_instance_ingest_challenge(atlas_instance_t i, const atlas_u128_t *r_j, size_t round);
+/* the polynomials' final_claim()s in the order cache_openings appends them */
+int atlas_instance_final_claims(atlas_instance_t i, atlas_fr_t *out, size_t cap, size_t *n);
+int atlas_instance_free(atlas_instance_t i);
+/* Sumcheck::prove (sumcheck.rs:565-599) for one instance; rows as atlas_batched_prove */
+int atlas_instance_prove(atlas_instance_t i, const atlas_fr_t *input_claim, atlas_transcript_t *transcript,
+                         atlas_fr_t *compressed, size_t row_stride, uint32_t *n_coeffs,
+                         atlas_u128_t *challenges);
+int atlas_batched_add_instance(atlas_batched_t b, atlas_instance_t i, const atlas_fr_t *input_claim);
+
+/* ---- one-hot "ra" instances of the lookup arguments.  H_indices = d host arrays of T = 2^log_T
+ *      int32 (the reference's Vec<Vec<Option<u8>>> / Option<u16>, negative = None) ----------- */
+/* RaSumcheckProver::gen (subprotocols/ra_virtual.rs:97-125): sum_j eq(r_cycle, j) prod_i ra_i(j),
+ * degree d + 1, log_T rounds LowToHigh.  r_address_chunks = d * log_k_chunk Fr, row i = chunk i
+ * (OneHotParams::compute_r_address_chunks, config.rs:77-100); r_cycle = log_T Fr, big-endian.
+ * final claims: ra_0(r) .. ra_{d-1}(r).  d <= 16. */
+int atlas_ra_virtual_new(const int32_t *const *H_indices, size_t d, size_t log_k_chunk, size_t log_T,
+                         const atlas_fr_t *r_address_chunks, const atlas_fr_t *r_cycle,
+                         atlas_instance_t *out);
+/* BooleanitySumcheckProver::gen (subprotocols/booleanity.rs:169-190): log_k_chunk address rounds
+ * over G (d * 2^log_k_chunk Fr, from atlas_shout_ra_evals) then log_T cycle rounds over the
+ * gathered H_i; degree 3; input claim 0.  gammas = field values of the d batching challenges. */
+int atlas_booleanity_new(const atlas_fr_t *G, const int32_t *const *H_indices, size_t d,
+                         size_t log_k_chunk, size_t log_T, const atlas_fr_t *gammas,
+                         const atlas_fr_t *r_address, const atlas_fr_t *r_cycle, atlas_instance_t *out);
+/* HammingWeightSumcheckProver::gen (subprotocols/hamming_weight.rs:106-116): sum_k sum_i
+ * gamma^i G_i[k], degree 1, log_k_chunk rounds */
+int atlas_hamming_weight_new(const atlas_fr_t *G, size_t d, size_t log_k_chunk,
+                             const atlas_fr_t *gamma_powers, atlas_instance_t *out);
 
 /* ---- build_materialized_rlc (joltworks/src/poly/rlc_polynomial.rs:13-78): the joint polynomial
  *      joint[i] = sum_j coeff_j * dense_j[i];  joint[k_j[t] * T_j + t] += coeff_j (one-hot) ---- */

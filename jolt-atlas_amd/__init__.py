@@ -447,23 +447,27 @@ class BatchedSumcheck:
         b = C.c_void_p()
         _check(lib.atlas_batched_new(C.byref(b)))
         try:
-            mx = 0
+            mx, stride = 0, 4
             for inst, c in zip(instances, input_claims):
                 ic = _fr(c)
                 if isinstance(inst, MulProver):
                     _check(lib.atlas_batched_add_mul(b, inst.h, _p(ic)))
                     lib.atlas_mul_num_rounds.restype = C.c_size_t
                     mx = max(mx, lib.atlas_mul_num_rounds(inst.h))
-                else:
+                elif isinstance(inst, EinsumDotProver):
                     _check(lib.atlas_batched_add_dot(b, inst.h, _p(ic)))
                     lib.atlas_dot_num_rounds.restype = C.c_size_t
                     mx = max(mx, lib.atlas_dot_num_rounds(inst.h))
-            comp = np.zeros((max(mx, 1), 4, 4), dtype=np.uint64)
+                else:   # generic atlas_instance_t wrapper (instances.Instance)
+                    _check(lib.atlas_batched_add_instance(b, inst.h, _p(ic)))
+                    mx = max(mx, inst.num_rounds())
+                    stride = max(stride, inst.degree() + 1)
+            comp = np.zeros((max(mx, 1), stride, 4), dtype=np.uint64)
             nco = np.zeros(max(mx, 1), dtype=np.uint32)
             ch = np.zeros(2 * max(mx, 1), dtype=np.uint64)
             mr = C.c_size_t()
-            _check(lib.atlas_batched_prove(b, C.byref(transcript.t), _p(comp), nco.ctypes.data_as(C.c_void_p), _p(ch),
-                                           C.byref(mr)))
+            _check(lib.atlas_batched_prove(b, C.byref(transcript.t), _p(comp), C.c_size_t(stride),
+                                           nco.ctypes.data_as(C.c_void_p), _p(ch), C.byref(mr)))
             rows = [comp[i, :nco[i]].copy() for i in range(mr.value)]
             return rows, [int(ch[2 * i]) | (int(ch[2 * i + 1]) << 64) for i in range(mr.value)]
         finally:

@@ -18,6 +18,7 @@
 
 #include "../../include/atlas_hip.h"
 #include "host_field.hpp"
+#include "instance.hpp"
 #include "runtime.hpp"
 
 namespace H = atlas_host;
@@ -26,9 +27,40 @@ using atlas_rt::g;
 
 namespace {
 
+// adapters: the dot / Mul provers behind the generic instance interface
+struct DotAdapter : atlas_instance {
+    atlas_dot_prover_t p;
+    explicit DotAdapter(atlas_dot_prover_t p_) : p(p_) {}
+    size_t rounds() const override { return atlas_dot_num_rounds(p); }
+    size_t degree() const override { return (size_t)atlas_dot_degree(p); }
+    int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& c) override {
+        c.resize(4); size_t n = 0;
+        int rc = atlas_dot_compute_message(p, round, (const atlas_fr_t*)&claim, (atlas_fr_t*)c.data(), &n);
+        c.resize(rc ? 0 : n);
+        return rc;
+    }
+    int ingest(const atlas_u128_t& r, size_t round) override { return atlas_dot_ingest_challenge(p, &r, round); }
+    int finals(std::vector<H::Fr>& out) override { out.resize(3); return atlas_dot_final_claims(p, (atlas_fr_t*)out.data()); }
+};
+
+struct MulAdapter : atlas_instance {
+    atlas_mul_prover_t p;
+    explicit MulAdapter(atlas_mul_prover_t p_) : p(p_) {}
+    size_t rounds() const override { return atlas_mul_num_rounds(p); }
+    size_t degree() const override { return 3; }
+    int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& c) override {
+        c.resize(4); size_t n = 0;
+        int rc = atlas_mul_compute_message(p, round, (const atlas_fr_t*)&claim, (atlas_fr_t*)c.data(), &n);
+        c.resize(rc ? 0 : n);
+        return rc;
+    }
+    int ingest(const atlas_u128_t& r, size_t round) override { return atlas_mul_ingest_challenge(p, &r, round); }
+    int finals(std::vector<H::Fr>& out) override { out.resize(3); return atlas_mul_final_claims(p, (atlas_fr_t*)out.data()); }
+};
+
 struct Instance {
-    int kind;                 // 0 = dot, 1 = mul
-    void* handle;
+    atlas_instance* inst;
+    bool owned;               // adapter created here
     H::Fr input_claim;
     size_t rounds;
 };
@@ -58,7 +90,14 @@ H::Fr eval_with_challenge(const std::vector<H::Fr>& c, const H::Fr& r) {        
 
 struct atlas_batched {
     std::vector<Instance> inst;
+    ~atlas_batched() { for (auto& I : inst) if (I.owned) delete I.inst; }
 };
+
+static int add_instance(atlas_batched_t b, atlas_instance* inst, bool owned, const atlas_fr_t* input_claim) {
+    Instance I; I.inst = inst; I.owned = owned; std::memcpy(&I.input_claim, input_claim, 32); I.rounds = inst->rounds();
+    b->inst.push_back(I);
+    return ATLAS_OK;
+}
 
 extern "C" {
 
@@ -75,26 +114,96 @@ int atlas_batched_free(atlas_batched_t b) {
 
 int atlas_batched_add_dot(atlas_batched_t b, atlas_dot_prover_t p, const atlas_fr_t* input_claim) {
     if (!b || !p || !input_claim) return fail(ATLAS_EINVAL, "batched_add_dot");
-    Instance I; I.kind = 0; I.handle = p; std::memcpy(&I.input_claim, input_claim, 32); I.rounds = atlas_dot_num_rounds(p);
-    b->inst.push_back(I);
-    return ATLAS_OK;
+    return add_instance(b, new DotAdapter(p), true, input_claim);
 }
 
 int atlas_batched_add_mul(atlas_batched_t b, atlas_mul_prover_t p, const atlas_fr_t* input_claim) {
     if (!b || !p || !input_claim) return fail(ATLAS_EINVAL, "batched_add_mul");
-    Instance I; I.kind = 1; I.handle = p; std::memcpy(&I.input_claim, input_claim, 32); I.rounds = atlas_mul_num_rounds(p);
-    b->inst.push_back(I);
+    return add_instance(b, new MulAdapter(p), true, input_claim);
+}
+
+int atlas_batched_add_instance(atlas_batched_t b, atlas_instance_t inst, const atlas_fr_t* input_claim) {
+    if (!b || !inst || !input_claim) return fail(ATLAS_EINVAL, "batched_add_instance");
+    return add_instance(b, inst, false, input_claim);
+}
+
+// ---- the generic SumcheckInstanceProver surface
+size_t atlas_instance_num_rounds(atlas_instance_t i) { return i ? i->rounds() : 0; }
+size_t atlas_instance_degree(atlas_instance_t i) { return i ? i->degree() : 0; }
+
+int atlas_instance_compute_message(atlas_instance_t i, size_t round, const atlas_fr_t* previous_claim, atlas_fr_t* coeffs_out,
+                                   size_t cap, size_t* n_coeffs) {
+    NEED_INIT();
+    if (!i || !previous_claim || !coeffs_out || !n_coeffs) return fail(ATLAS_EINVAL, "instance_compute_message");
+    std::vector<H::Fr> c;
+    int rc = i->message(round, *reinterpret_cast<const H::Fr*>(previous_claim), c);
+    if (rc) return rc;
+    if (c.size() > cap) return fail(ATLAS_EINVAL, "instance_compute_message: coefficient buffer too small");
+    std::memcpy(coeffs_out, c.data(), c.size() * 32);
+    *n_coeffs = c.size();
+    return ATLAS_OK;
+}
+
+int atlas_instance_ingest_challenge(atlas_instance_t i, const atlas_u128_t* r_j, size_t round) {
+    NEED_INIT();
+    if (!i || !r_j) return fail(ATLAS_EINVAL, "instance_ingest_challenge");
+    return i->ingest(*r_j, round);
+}
+
+int atlas_instance_final_claims(atlas_instance_t i, atlas_fr_t* out, size_t cap, size_t* n) {
+    NEED_INIT();
+    if (!i || !out || !n) return fail(ATLAS_EINVAL, "instance_final_claims");
+    std::vector<H::Fr> f;
+    int rc = i->finals(f);
+    if (rc) return rc;
+    if (f.size() > cap) return fail(ATLAS_EINVAL, "instance_final_claims: buffer too small");
+    std::memcpy(out, f.data(), f.size() * 32);
+    *n = f.size();
+    return ATLAS_OK;
+}
+
+int atlas_instance_free(atlas_instance_t i) { delete i; return ATLAS_OK; }
+
+// Sumcheck::prove (sumcheck.rs:565-599) over one generic instance, host-stepped
+int atlas_instance_prove(atlas_instance_t inst, const atlas_fr_t* input_claim, atlas_transcript_t* transcript,
+                         atlas_fr_t* compressed, size_t row_stride, uint32_t* n_coeffs, atlas_u128_t* challenges) {
+    NEED_INIT();
+    if (!inst || !input_claim || !transcript || !compressed || !n_coeffs || !challenges) return fail(ATLAS_EINVAL, "instance_prove");
+    H::Transcript& T = *reinterpret_cast<H::Transcript*>(transcript);
+    H::Fr prev = *reinterpret_cast<const H::Fr*>(input_claim);
+    H::tr_append_scalar(T, prev);
+    const size_t n = inst->rounds();
+    std::vector<H::Fr> c;
+    for (size_t round = 0; round < n; round++) {
+        int rc = inst->message(round, prev, c);
+        if (rc) return rc;
+        std::vector<H::Fr> cc;
+        if (c.size() < 2) cc = c;
+        else { cc.push_back(c[0]); for (size_t k = 2; k < c.size(); k++) cc.push_back(c[k]); }
+        if (cc.size() > row_stride) return fail(ATLAS_EINVAL, "instance_prove: row_stride below the degree");
+        H::tr_append_message(T, "UniPoly_begin");
+        for (auto& x : cc) H::tr_append_scalar(T, x);
+        H::tr_append_message(T, "UniPoly_end");
+        n_coeffs[round] = (uint32_t)cc.size();
+        std::memcpy(&compressed[round * row_stride], cc.data(), cc.size() * 32);
+        uint64_t lo, hi;
+        H::tr_challenge_u128(T, lo, hi);
+        challenges[round].lo = lo; challenges[round].hi = hi;
+        prev = eval_with_challenge(c, H::challenge_to_fr(lo, hi, g.challenge_mode));
+        rc = inst->ingest(challenges[round], round);
+        if (rc) return rc;
+    }
     return ATLAS_OK;
 }
 
 // BatchedSumcheck::prove.  Outputs, per round i < max_rounds:
 //   n_coeffs[i]                         number of compressed coefficients of round i
-//   compressed[i*4 .. i*4+n_coeffs[i])  coeffs_except_linear_term (at most 4: degree <= 4 batched)
+//   compressed[i*row_stride ..)         n_coeffs[i] coefficients: coeffs_except_linear_term
 //   challenges[i]                       raw u128 draw
 // max_rounds_out = number of rounds.  The instances are left fully bound (final claims are
 // read with atlas_dot_final_claims / atlas_mul_final_claims; cache_openings is the caller's).
-int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas_fr_t* compressed, uint32_t* n_coeffs,
-                        atlas_u128_t* challenges, size_t* max_rounds_out) {
+int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas_fr_t* compressed, size_t row_stride,
+                        uint32_t* n_coeffs, atlas_u128_t* challenges, size_t* max_rounds_out) {
     NEED_INIT();
     if (!b || !transcript || !compressed || !n_coeffs || !challenges || !max_rounds_out || b->inst.empty())
         return fail(ATLAS_EINVAL, "batched_prove");
@@ -117,14 +226,8 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
                 // constant polynomial, from_coeff (a zero claim stays [0])
                 polys[i] = {mul_pow2(I.input_claim, remaining - I.rounds - 1)};
             } else {
-                atlas_fr_t c[4]; size_t nc = 0;
-                const size_t local = round - (max_rounds - I.rounds);
-                int rc = I.kind == 0
-                             ? atlas_dot_compute_message((atlas_dot_prover_t)I.handle, local, (const atlas_fr_t*)&claim[i], c, &nc)
-                             : atlas_mul_compute_message((atlas_mul_prover_t)I.handle, local, (const atlas_fr_t*)&claim[i], c, &nc);
+                int rc = I.inst->message(round - (max_rounds - I.rounds), claim[i], polys[i]);
                 if (rc) return rc;
-                polys[i].resize(nc);
-                std::memcpy(polys[i].data(), c, nc * 32);
             }
         }
         // batched = sum coeff_i * poly_i, starting from UniPoly::from_coeff(vec![]) = [0]  (:109-116)
@@ -140,12 +243,12 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         std::vector<H::Fr> cc;
         if (batched.size() < 2) cc = batched;
         else { cc.push_back(batched[0]); for (size_t k = 2; k < batched.size(); k++) cc.push_back(batched[k]); }
-        if (cc.size() > 4) return fail(ATLAS_EINVAL, "batched_prove: degree above 4 not supported");
+        if (cc.size() > row_stride) return fail(ATLAS_EINVAL, "batched_prove: row_stride below the batched degree");
         H::tr_append_message(T, "UniPoly_begin");
         for (auto& x : cc) H::tr_append_scalar(T, x);
         H::tr_append_message(T, "UniPoly_end");
         n_coeffs[round] = (uint32_t)cc.size();
-        std::memcpy(&compressed[round * 4], cc.data(), cc.size() * 32);
+        std::memcpy(&compressed[round * row_stride], cc.data(), cc.size() * 32);
         uint64_t lo, hi;
         H::tr_challenge_u128(T, lo, hi);                                              // challenge_scalar_optimized :119
         challenges[round].lo = lo; challenges[round].hi = hi;
@@ -154,9 +257,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         for (size_t i = 0; i < n; i++) {
             Instance& I = b->inst[i];
             if (remaining <= I.rounds) {
-                const size_t local = round - (max_rounds - I.rounds);
-                int rc = I.kind == 0 ? atlas_dot_ingest_challenge((atlas_dot_prover_t)I.handle, &challenges[round], local)
-                                     : atlas_mul_ingest_challenge((atlas_mul_prover_t)I.handle, &challenges[round], local);
+                int rc = I.inst->ingest(challenges[round], round - (max_rounds - I.rounds));
                 if (rc) return rc;
             }
         }

@@ -1,0 +1,133 @@
+// Host-side univariate helpers shared by the host-stepped sumcheck instances: the O(degree)
+// arithmetic that turns device-reduced sums into the round polynomial.  Restates (paths under
+// the jolt-atlas tree, joltworks/src/):
+//   UniPoly::from_coeff            poly/unipoly.rs:39-52
+//   UniPoly::from_evals_toom       poly/unipoly.rs:103-134 (+ utils/gaussian_elimination.rs)
+//   gruen_poly_deg_3               poly/split_eq_poly.rs:379-429
+//   finish_mles_product_sum_from_evals   subprotocols/mles_product_sum.rs:330-376
+//   GruenSplitEqPolynomial::{new,bind} (LowToHigh) poly/split_eq_poly.rs:97-121,331-348
+#pragma once
+#include <cstring>
+#include <vector>
+
+#include "host_field.hpp"
+
+namespace atlas_host {
+
+inline void trim(std::vector<Fr>& c) {
+    const Fr z = zero();
+    while (!c.empty() && c.back() == z) c.pop_back();
+    if (c.empty()) c.push_back(z);
+}
+
+// unique solution of the n x n system m[i][0..n) * c = m[i][n]
+inline std::vector<Fr> gauss_solve(std::vector<std::vector<Fr>>& m) {
+    const size_t n = m.size();
+    const Fr z = zero();
+    for (size_t col = 0; col < n; col++) {
+        size_t piv = col;
+        while (piv < n && m[piv][col] == z) piv++;
+        if (piv != col) std::swap(m[piv], m[col]);
+        const Fr iv = inv(m[col][col]);
+        for (size_t k = 0; k <= n; k++) m[col][k] = mul(m[col][k], iv);
+        for (size_t r = 0; r < n; r++) {
+            if (r == col || m[r][col] == z) continue;
+            const Fr f = m[r][col];
+            for (size_t k = 0; k <= n; k++) m[r][k] = sub(m[r][k], mul(f, m[col][k]));
+        }
+    }
+    std::vector<Fr> c(n);
+    for (size_t i = 0; i < n; i++) c[i] = m[i][n];
+    return c;
+}
+
+// evals on [0, 1, ..., n-2, inf] -> n coefficients
+inline std::vector<Fr> from_evals_toom(const std::vector<Fr>& evals) {
+    const size_t n = evals.size();
+    std::vector<std::vector<Fr>> m(n, std::vector<Fr>(n + 1, zero()));
+    for (size_t i = 0; i + 1 < n; i++) {
+        const Fr x = from_u64(i);
+        m[i][0] = one();
+        for (size_t j = 1; j < n; j++) m[i][j] = mul(m[i][j - 1], x);
+        m[i][n] = evals[i];
+    }
+    m[n - 1][n - 1] = one();
+    m[n - 1][n] = evals[n - 1];
+    return gauss_solve(m);
+}
+
+// LowToHigh GruenSplitEqPolynomial bookkeeping that lives on the host: w, current_scalar, the
+// table tops.  The prefix tables themselves are wherever the instance keeps them.
+struct GseState {
+    std::vector<Fr> w;
+    size_t n = 0, m = 0, k_out = 0, k_in = 0, out_top = 0, in_top = 0, current_index = 0;
+    Fr scalar = one();
+    void init(const Fr* w_, size_t n_) {
+        w.assign(w_, w_ + n_);
+        n = n_; m = n / 2; k_out = m; k_in = n ? n - 1 - m : 0;
+        out_top = k_out; in_top = k_in; current_index = n; scalar = one();
+    }
+    const Fr& w_cur() const { return w[current_index - 1]; }
+    void bind(const Fr& r) {
+        const Fr& wc = w_cur();
+        const Fr wr = mul(wc, r);
+        scalar = mul(scalar, add(add(sub(sub(one(), wc), r), wr), wr));
+        current_index -= 1;
+        if (n / 2 < current_index && in_top > 0) in_top--;
+        else if (0 < current_index && out_top > 0) out_top--;
+    }
+};
+
+// 4 coefficients (fixed length, UniPoly::from_evals of 4 points)
+inline void gruen_deg3(const GseState& S, const Fr& q0, const Fr& qinf, const Fr& claim, Fr coeffs[4]) {
+    const Fr eq1 = mul(S.scalar, S.w_cur()), eq0 = sub(S.scalar, eq1), eqm = sub(eq1, eq0);
+    const Fr eq2 = add(eq1, eqm), eq3 = add(eq2, eqm);
+    const Fr c0 = mul(eq0, q0), c1 = sub(claim, c0);
+    const Fr q1 = mul(c1, inv(eq1));
+    const Fr e2 = add(qinf, qinf);
+    const Fr q2 = add(sub(add(q1, q1), q0), e2);
+    const Fr q3 = add(add(sub(add(q2, q1), q0), e2), e2);
+    const Fr ev[3] = {c0, mul(eq2, q2), mul(eq3, q3)};
+    unipoly_from_evals_and_hint(add(c0, c1), ev, 3, coeffs);
+}
+
+// sum_evals = h on [1, ..., d-1, inf] (already scaled by current_scalar) -> g = eq(X, w_cur) * h
+inline std::vector<Fr> finish_product_sum(const std::vector<Fr>& sum_evals, const Fr& claim, const GseState& S) {
+    const size_t d = sum_evals.size();
+    const Fr r = S.w_cur();
+    const Fr eq0 = sub(one(), r);
+    Fr e0 = sub(claim, mul(r, sum_evals[0]));
+    if (d > 1) e0 = mul(e0, inv(eq0));
+    std::vector<Fr> toom(d + 1);
+    toom[0] = e0;
+    for (size_t k = 0; k < d; k++) toom[k + 1] = sum_evals[k];
+    const std::vector<Fr> tmp = from_evals_toom(toom);
+    const Fr xc = sub(add(r, r), one());
+    std::vector<Fr> c(d + 2, zero());
+    for (size_t i = 0; i < d + 1; i++) {
+        c[i] = add(c[i], mul(tmp[i], eq0));
+        c[i + 1] = add(c[i + 1], mul(tmp[i], xc));
+    }
+    trim(c);
+    return c;
+}
+
+// host prefix tables of w[0..k) (EqPolynomial::evals_cached, eq_poly.rs:174-192)
+inline std::vector<std::vector<Fr>> eq_cached(const Fr* w, size_t k) {
+    std::vector<std::vector<Fr>> t(k + 1);
+    t[0] = {one()};
+    for (size_t j = 0; j < k; j++) {
+        t[j + 1].resize((size_t)2 << j);
+        for (size_t i = 0; i < ((size_t)1 << j); i++) {
+            const Fr hi = mul(t[j][i], w[j]);
+            t[j + 1][2 * i + 1] = hi;
+            t[j + 1][2 * i] = sub(t[j][i], hi);
+        }
+    }
+    return t;
+}
+
+// EqPolynomial::evals, big-endian index (eq_poly.rs:77-101)
+inline std::vector<Fr> eq_evals(const Fr* r, size_t n) { return eq_cached(r, n)[n]; }
+
+}  // namespace atlas_host

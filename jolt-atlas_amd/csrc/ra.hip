@@ -1,0 +1,498 @@
+// The one-hot "ra" sumcheck instances of the lookup arguments, as
+// host-stepped SumcheckInstanceProver objects (instance.hpp) over device-resident polynomials.
+// Device counterparts of (paths under the jolt-atlas tree, joltworks/src/):
+//   RaPolynomial                 poly/ra_poly.rs:21-110      ra(j) = F[idx_j] (0 for None)
+//   RaSumcheckProver             subprotocols/ra_virtual.rs:97-145
+//   compute_mles_product_sum     subprotocols/mles_product_sum.rs:15-131
+//   BooleanitySumcheckProver     subprotocols/booleanity.rs:169-348
+//   HammingWeightSumcheckProver  subprotocols/hamming_weight.rs:106-148
+//
+// Layout: the d polynomials of one instance live in one allocation, row i at i * stride, and are
+// bound LowToHigh out of place between two buffers (T and T/2 coefficients per row).  The
+// reference keeps RaPolynomial as (index, 16-entry table) for the first three binds to save host
+// memory; the MLE it represents is the gathered vector, which is what is materialised here.
+//
+// Work split: everything that is O(T) runs in kernels (gather, product grid, booleanity fold,
+// binds); everything that is O(d * 2^log_k_chunk) or O(degree^3) (phase-1 booleanity, hamming
+// weight, Toom interpolation, Gruen's cubic) is host arithmetic between launches — those
+// tables have 16 (at most 256) entries.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "../../include/atlas_hip.h"
+#include "host_poly.hpp"
+#include "instance.hpp"
+#include "runtime.hpp"
+#include "sc_consts.hpp"
+#include "spliteq_kernels.hip.h"
+
+using namespace atlas;
+namespace H = atlas_host;
+using atlas_rt::fail;
+using atlas_rt::g;
+
+namespace {
+
+constexpr int RA_THREADS = 256;
+constexpr size_t RA_MAX_D = 16;
+
+inline Fr to_dev(const H::Fr& a) { Fr o; std::memcpy(&o, &a, 32); return o; }
+
+// ra_i[j] = idx_i[j] < 0 ? 0 : F_i[idx_i[j]]       (RaPolynomialRound1::get_bound_coeff)
+__global__ __launch_bounds__(RA_THREADS) void k_ra_gather(const int32_t* __restrict__ idx, const Fr* __restrict__ F,
+                                                          uint32_t f_stride, size_t T, Fr* __restrict__ out) {
+    const uint32_t i = blockIdx.y;
+    for (size_t j = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; j < T; j += (size_t)gridDim.x * RA_THREADS) {
+        const int32_t k = idx[(size_t)i * T + j];
+        fe_store(out + (size_t)i * T + j, k < 0 ? fe_zero() : fe_load(F + (size_t)i * f_stride + k));
+    }
+}
+
+// bind every row LowToHigh: dst[i][j] = src[i][2j] + r (src[i][2j+1] - src[i][2j])
+__global__ __launch_bounds__(RA_THREADS) void k_ra_bind(const Fr* __restrict__ src, size_t src_stride, Fr* __restrict__ dst,
+                                                        size_t dst_stride, size_t half, Fr r, int r_hi_only) {
+    const Fr* s = src + (size_t)blockIdx.y * src_stride;
+    Fr* d = dst + (size_t)blockIdx.y * dst_stride;
+    for (size_t j = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; j < half; j += (size_t)gridDim.x * RA_THREADS)
+        fe_store(d + j, bind_pair(fe_load(s + 2 * j), fe_load(s + 2 * j + 1), r, r_hi_only != 0));
+}
+
+__device__ __forceinline__ Fr gse_weight(const SplitEqView& E, size_t gidx) {
+    return fr_mul(fe_load(E.e_out + (gidx >> E.in_bits)), fe_load(E.e_in + (gidx & (((size_t)1 << E.in_bits) - 1))));
+}
+
+// compute_mles_product_sum_evals_generic: per pair index g the product of the D lines
+// p_i(X) = ra_i[2g] + X (ra_i[2g+1] - ra_i[2g]) on the grid [1, ..., D-1, inf], weighted by
+// E_out * E_in.  One g per thread (D running products = 8 D VGPRs), block sums to partials.
+template <int D>
+__global__ __launch_bounds__(RA_THREADS) void k_ra_prod(const Fr* __restrict__ ra, size_t stride, SplitEqView E,
+                                                        size_t n_groups, Fr* __restrict__ partials) {
+    const size_t gidx = (size_t)blockIdx.x * RA_THREADS + threadIdx.x;
+    Fr prod[D];
+    if (gidx < n_groups) {
+        {
+            Fr cur = fe_load(ra + 2 * gidx);
+            const Fr dl = fr_sub(fe_load(ra + 2 * gidx + 1), cur);
+#pragma unroll
+            for (int k = 0; k < D - 1; k++) { cur = fr_add(cur, dl); prod[k] = cur; }
+            prod[D - 1] = dl;
+        }
+#pragma unroll 1
+        for (int i = 1; i < D; i++) {
+            const Fr* row = ra + (size_t)i * stride;
+            Fr cur = fe_load(row + 2 * gidx);
+            const Fr dl = fr_sub(fe_load(row + 2 * gidx + 1), cur);
+#pragma unroll
+            for (int k = 0; k < D - 1; k++) { cur = fr_add(cur, dl); prod[k] = fr_mul(prod[k], cur); }
+            prod[D - 1] = fr_mul(prod[D - 1], dl);
+        }
+        const Fr wgt = gse_weight(E, gidx);
+#pragma unroll
+        for (int k = 0; k < D; k++) prod[k] = fr_mul(prod[k], wgt);
+    } else {
+#pragma unroll
+        for (int k = 0; k < D; k++) prod[k] = fe_zero();
+    }
+    block_reduce_store<D>(prod, partials);
+}
+
+// booleanity phase 2 (booleanity.rs:254-276): per pair index j
+//   c = sum_i gamma_i h0 (h0 - 1),  e = sum_i gamma_i (h1 - h0)^2, folded with E_out * E_in
+__global__ __launch_bounds__(RA_THREADS) void k_bool_fold(const Fr* __restrict__ Hp, size_t stride, uint32_t d,
+                                                          const Fr* __restrict__ gammas, SplitEqView E, size_t n_groups,
+                                                          Fr* __restrict__ partials) {
+    Fr acc[2];
+    acc[0] = fe_zero(); acc[1] = fe_zero();
+    const Fr one = fr_one();
+    for (size_t j = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; j < n_groups; j += (size_t)gridDim.x * RA_THREADS) {
+        Fr c = fe_zero(), e = fe_zero();
+        for (uint32_t i = 0; i < d; i++) {
+            const Fr* row = Hp + (size_t)i * stride;
+            const Fr h0 = fe_load(row + 2 * j), h1 = fe_load(row + 2 * j + 1);
+            const Fr b = fr_sub(h1, h0);
+            const Fr gm = fe_load(gammas + i);
+            c = fr_add(c, fr_mul(fr_mul(gm, h0), fr_sub(h0, one)));
+            e = fr_add(e, fr_mul(fr_mul(gm, b), b));
+        }
+        const Fr wgt = gse_weight(E, j);
+        acc[0] = fr_add(acc[0], fr_mul(wgt, c));
+        acc[1] = fr_add(acc[1], fr_mul(wgt, e));
+    }
+    block_reduce_store<2>(acc, partials);
+}
+
+// out[k] = sum_p partials[p * K + k]; one workgroup per column
+__global__ __launch_bounds__(RA_THREADS) void k_col_reduce(const Fr* __restrict__ partials, uint32_t n_partials, uint32_t K,
+                                                           Fr* __restrict__ out) {
+    __shared__ Fr red[RA_THREADS / 64];
+    const uint32_t k = blockIdx.x;
+    Fr acc = fe_zero();
+    for (uint32_t p = threadIdx.x; p < n_partials; p += RA_THREADS) acc = fr_add(acc, fe_load(partials + (size_t)p * K + k));
+    acc = fr_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Fr s = red[0];
+        for (int w = 1; w < RA_THREADS / 64; w++) s = fr_add(s, red[w]);
+        fe_store(out + k, s);
+    }
+}
+
+// device half of a LowToHigh GruenSplitEqPolynomial: the cached prefix tables
+struct GseDev {
+    H::GseState st;
+    Fr *d_w = nullptr, *d_eout = nullptr, *d_ein = nullptr;
+    int init(const H::Fr* w, size_t n) {
+        st.init(w, n);
+        if (st.k_out > 12 || st.k_in > 12) return fail(ATLAS_EINVAL, "split-eq: more than 25 variables not supported");
+        HIP_TRY(hipMalloc(&d_w, (n ? n : 1) * sizeof(Fr)));
+        HIP_TRY(hipMalloc(&d_eout, ((size_t)2 << st.k_out) * sizeof(Fr)));
+        HIP_TRY(hipMalloc(&d_ein, ((size_t)2 << st.k_in) * sizeof(Fr)));
+        if (n) HIP_TRY(hipMemcpyAsync(d_w, w, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+        k_eq_cached<<<1, 1024, 0, g.stream>>>(d_eout, d_w, (uint32_t)st.k_out);
+        k_eq_cached<<<1, 1024, 0, g.stream>>>(d_ein, d_w + st.m, (uint32_t)st.k_in);
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        return ATLAS_OK;
+    }
+    SplitEqView view() const {
+        SplitEqView E;
+        E.e_out = d_eout + (((size_t)1 << st.out_top) - 1);
+        E.e_in = d_ein + (((size_t)1 << st.in_top) - 1);
+        E.in_bits = (uint32_t)st.in_top;
+        return E;
+    }
+    void release() { if (d_w) hipFree(d_w); if (d_eout) hipFree(d_eout); if (d_ein) hipFree(d_ein); d_w = d_eout = d_ein = nullptr; }
+};
+
+// d rows of one instance, ping-pong bound
+struct RaRows {
+    size_t d = 0, len = 0;
+    Fr* buf[2] = {nullptr, nullptr};
+    size_t stride[2] = {0, 0};
+    int cur = 0;
+    Fr* partials = nullptr;     // ceil(T/2 / RA_THREADS) * max(d, 2) Fr
+    Fr* d_sums = nullptr;       // max(d, 2) Fr
+    size_t K = 0;
+
+    int alloc(size_t d_, size_t T) {
+        d = d_; len = T; K = d > 2 ? d : 2;
+        HIP_TRY(hipMalloc(&buf[0], d * T * sizeof(Fr)));
+        HIP_TRY(hipMalloc(&buf[1], d * (T > 1 ? T / 2 : 1) * sizeof(Fr)));
+        stride[0] = T; stride[1] = T > 1 ? T / 2 : 1;
+        const size_t blocks = (T / 2 + RA_THREADS - 1) / RA_THREADS + 1;
+        HIP_TRY(hipMalloc(&partials, blocks * K * sizeof(Fr)));
+        HIP_TRY(hipMalloc(&d_sums, K * sizeof(Fr)));
+        return ATLAS_OK;
+    }
+    // gather from host index rows (d * T int32) and device tables (d rows of f_stride Fr)
+    int gather(const int32_t* const* H_indices, const Fr* d_tables, uint32_t f_stride) {
+        int32_t* d_idx = nullptr;
+        HIP_TRY(hipMalloc(&d_idx, d * len * sizeof(int32_t)));
+        for (size_t i = 0; i < d; i++) {
+            hipError_t e = hipMemcpyAsync(d_idx + i * len, H_indices[i], len * sizeof(int32_t), hipMemcpyHostToDevice, g.stream);
+            if (e != hipSuccess) { hipFree(d_idx); return fail(ATLAS_ENODEV, "ra indices copy", e); }
+        }
+        size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
+        k_ra_gather<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, g.stream>>>(d_idx, d_tables, f_stride, len, buf[0]);
+        hipError_t e = hipStreamSynchronize(g.stream);
+        hipFree(d_idx);
+        if (e != hipSuccess) return fail(ATLAS_ENODEV, "ra gather", e);
+        cur = 0; stride[0] = len;
+        return ATLAS_OK;
+    }
+    int bind(const atlas_u128_t& r) {
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        const size_t half = len / 2;
+        const int nxt = cur ^ 1;
+        stride[nxt] = half;
+        size_t gb = (half + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096; if (gb < 1) gb = 1;
+        k_ra_bind<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, g.stream>>>(buf[cur], stride[cur], buf[nxt], stride[nxt], half,
+                                                                               to_dev(rf), g.challenge_mode == 0 ? 1 : 0);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(ATLAS_ENODEV, "ra bind", e);
+        cur = nxt; len = half;
+        return ATLAS_OK;
+    }
+    int reduce_to_host(uint32_t n_partials, uint32_t k, H::Fr* out) {
+        k_col_reduce<<<k, RA_THREADS, 0, g.stream>>>(partials, n_partials, k, d_sums);
+        HIP_TRY(hipMemcpyAsync(g.h_pinned, d_sums, k * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        std::memcpy(out, g.h_pinned, k * sizeof(Fr));
+        return ATLAS_OK;
+    }
+    int finals(std::vector<H::Fr>& out) {
+        if (len != 1) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
+        out.resize(d);
+        for (size_t i = 0; i < d; i++)
+            HIP_TRY(hipMemcpyAsync((uint8_t*)g.h_pinned + 32 * i, buf[cur] + i * stride[cur], sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        std::memcpy(out.data(), g.h_pinned, d * sizeof(Fr));
+        return ATLAS_OK;
+    }
+    void release() { for (auto& b : buf) if (b) hipFree(b); if (partials) hipFree(partials); if (d_sums) hipFree(d_sums); buf[0] = buf[1] = partials = d_sums = nullptr; }
+};
+
+template <int D>
+void launch_prod(const RaRows& R, const SplitEqView& E, size_t n_groups, unsigned blocks) {
+    k_ra_prod<D><<<blocks, RA_THREADS, 0, g.stream>>>(R.buf[R.cur], R.stride[R.cur], E, n_groups, R.partials);
+}
+
+// ---------------------------------------------------------------- RaSumcheckProver
+struct RaVirtual : atlas_instance {
+    RaRows rows;
+    GseDev eq;
+    size_t log_T = 0, round_next = 0;
+    ~RaVirtual() override { rows.release(); eq.release(); }
+    size_t rounds() const override { return log_T; }
+    size_t degree() const override { return rows.d + 1; }
+    int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
+        if (round != round_next || round >= log_T) return fail(ATLAS_ESTATE, "ra_virtual: round out of order");
+        std::lock_guard<std::mutex> lk(g.mu);
+        const size_t n_groups = rows.len / 2;
+        const unsigned blocks = (unsigned)((n_groups + RA_THREADS - 1) / RA_THREADS);
+        const SplitEqView E = eq.view();
+        switch (rows.d) {
+#define RA_CASE(D) case D: launch_prod<D>(rows, E, n_groups, blocks); break;
+            RA_CASE(1) RA_CASE(2) RA_CASE(3) RA_CASE(4) RA_CASE(5) RA_CASE(6) RA_CASE(7) RA_CASE(8)
+            RA_CASE(9) RA_CASE(10) RA_CASE(11) RA_CASE(12) RA_CASE(13) RA_CASE(14) RA_CASE(15) RA_CASE(16)
+#undef RA_CASE
+            default: return fail(ATLAS_EINVAL, "ra_virtual: d > 16");
+        }
+        std::vector<H::Fr> sums(rows.d);
+        int rc = rows.reduce_to_host(blocks, (uint32_t)rows.d, sums.data());
+        if (rc) return rc;
+        for (auto& s : sums) s = H::mul(s, eq.st.scalar);            // mles_product_sum.rs:131
+        coeffs = H::finish_product_sum(sums, claim, eq.st);
+        return ATLAS_OK;
+    }
+    int ingest(const atlas_u128_t& r, size_t round) override {
+        if (round != round_next || round >= log_T) return fail(ATLAS_ESTATE, "ra_virtual: round out of order");
+        std::lock_guard<std::mutex> lk(g.mu);
+        int rc = rows.bind(r);
+        if (rc) return rc;
+        eq.st.bind(H::challenge_to_fr(r.lo, r.hi, g.challenge_mode));
+        round_next++;
+        return ATLAS_OK;
+    }
+    int finals(std::vector<H::Fr>& out) override { std::lock_guard<std::mutex> lk(g.mu); return rows.finals(out); }
+};
+
+// upload d host tables of K Fr each
+int upload_tables(const std::vector<std::vector<H::Fr>>& t, size_t K, Fr** out) {
+    Fr* d = nullptr;
+    HIP_TRY(hipMalloc(&d, t.size() * K * sizeof(Fr)));
+    for (size_t i = 0; i < t.size(); i++)
+        HIP_TRY(hipMemcpyAsync(d + i * K, t[i].data(), K * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    *out = d;
+    return ATLAS_OK;
+}
+
+// ---------------------------------------------------------------- BooleanitySumcheckProver
+struct Booleanity : atlas_instance {
+    size_t d = 0, log_k = 0, log_T = 0, round_next = 0;
+    std::vector<std::vector<H::Fr>> G;                 // d x 2^log_k (host: 16 entries each)
+    std::vector<std::vector<int32_t>> H_idx;           // kept until phase 2 starts
+    std::vector<H::Fr> gammas, F;                      // F = ExpandingTable values
+    H::GseState B;
+    std::vector<std::vector<H::Fr>> B_out, B_in;       // host prefix tables of B
+    GseDev D;
+    RaRows rows;
+    Fr* d_gammas = nullptr;
+    H::Fr eq_r_r = H::zero();
+    ~Booleanity() override { rows.release(); D.release(); if (d_gammas) hipFree(d_gammas); }
+    size_t rounds() const override { return log_k + log_T; }
+    size_t degree() const override { return 3; }
+
+    int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
+        if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "booleanity: round out of order");
+        coeffs.assign(4, H::zero());
+        if (round < log_k) {                                         // compute_phase1_message
+            const size_t m = round + 1;
+            const auto& e_out = B_out[B.out_top]; const auto& e_in = B_in[B.in_top];
+            H::Fr q0 = H::zero(), qinf = H::zero();
+            for (size_t xo = 0; xo < e_out.size(); xo++) {
+                H::Fr i0 = H::zero(), i1 = H::zero();
+                for (size_t xi = 0; xi < e_in.size(); xi++) {
+                    const size_t kp = (xo << B.in_top) | xi;
+                    H::Fr c0 = H::zero(), c1 = H::zero();
+                    for (size_t i = 0; i < d; i++) {
+                        H::Fr s0 = H::zero(), s1 = H::zero();
+                        for (size_t k = 0; k < ((size_t)1 << m); k++) {
+                            const H::Fr& Gk = G[i][(kp << m) + k];
+                            const H::Fr& Fk = F[k % ((size_t)1 << (m - 1))];
+                            const H::Fr gf = H::mul(Gk, Fk), ei = H::mul(gf, Fk);
+                            if ((k >> (m - 1)) == 0) s0 = H::add(s0, H::sub(ei, gf));
+                            s1 = H::add(s1, ei);
+                        }
+                        c0 = H::add(c0, H::mul(gammas[i], s0)); c1 = H::add(c1, H::mul(gammas[i], s1));
+                    }
+                    i0 = H::add(i0, H::mul(e_in[xi], c0)); i1 = H::add(i1, H::mul(e_in[xi], c1));
+                }
+                q0 = H::add(q0, H::mul(e_out[xo], i0)); qinf = H::add(qinf, H::mul(e_out[xo], i1));
+            }
+            H::gruen_deg3(B, q0, qinf, claim, coeffs.data());
+            return ATLAS_OK;
+        }
+        std::lock_guard<std::mutex> lk(g.mu);                        // compute_phase2_message
+        const size_t n_groups = rows.len / 2;
+        size_t blocks = (n_groups + RA_THREADS - 1) / RA_THREADS; if (blocks > 2048) blocks = 2048;
+        k_bool_fold<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(rows.buf[rows.cur], rows.stride[rows.cur], (uint32_t)d, d_gammas,
+                                                                  D.view(), n_groups, rows.partials);
+        H::Fr s[2];
+        int rc = rows.reduce_to_host((uint32_t)blocks, 2, s);
+        if (rc) return rc;
+        const H::Fr adj = H::mul(claim, H::inv(eq_r_r));
+        H::gruen_deg3(D.st, s[0], s[1], adj, coeffs.data());
+        for (auto& c : coeffs) c = H::mul(c, eq_r_r);                // gruen_poly * eq_r_r (from_coeff)
+        H::trim(coeffs);
+        return ATLAS_OK;
+    }
+
+    int ingest(const atlas_u128_t& r, size_t round) override {
+        if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "booleanity: round out of order");
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        if (round < log_k) {
+            B.bind(rf);
+            const size_t n = F.size();                               // ExpandingTable::update, LowToHigh
+            F.resize(2 * n);
+            for (size_t x = 0; x < n; x++) { F[n + x] = H::mul(F[x], rf); F[x] = H::sub(F[x], F[n + x]); }
+            if (round == log_k - 1) {
+                std::lock_guard<std::mutex> lk(g.mu);
+                eq_r_r = B.scalar;
+                Fr* d_F = nullptr;
+                HIP_TRY(hipMalloc(&d_F, F.size() * sizeof(Fr)));
+                HIP_TRY(hipMemcpyAsync(d_F, F.data(), F.size() * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+                std::vector<const int32_t*> ptrs(d);
+                for (size_t i = 0; i < d; i++) ptrs[i] = H_idx[i].data();
+                int rc = rows.gather(ptrs.data(), d_F, 0);            // every H_i reads the same table F
+                hipFree(d_F);
+                if (rc) return rc;
+                H_idx.clear(); H_idx.shrink_to_fit(); G.clear();
+            }
+        } else {
+            std::lock_guard<std::mutex> lk(g.mu);
+            D.st.bind(rf);
+            int rc = rows.bind(r);
+            if (rc) return rc;
+        }
+        round_next++;
+        return ATLAS_OK;
+    }
+    int finals(std::vector<H::Fr>& out) override { std::lock_guard<std::mutex> lk(g.mu); return rows.finals(out); }
+};
+
+// ---------------------------------------------------------------- HammingWeightSumcheckProver (host: d x 2^log_k)
+struct HammingWeight : atlas_instance {
+    size_t log_k = 0, round_next = 0;
+    std::vector<std::vector<H::Fr>> ra;
+    std::vector<H::Fr> gamma_powers;
+    size_t rounds() const override { return log_k; }
+    size_t degree() const override { return 1; }
+    int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
+        if (round != round_next || round >= log_k) return fail(ATLAS_ESTATE, "hamming_weight: round out of order");
+        H::Fr e0 = H::zero();
+        for (size_t i = 0; i < ra.size(); i++) {
+            H::Fr s = H::zero();
+            for (size_t k = 0; k < ra[i].size() / 2; k++) s = H::add(s, ra[i][2 * k]);
+            e0 = H::add(e0, H::mul(s, gamma_powers[i]));
+        }
+        const H::Fr e1 = H::sub(claim, e0);
+        coeffs = {e0, H::sub(e1, e0)};                                // from_evals (2 points) -> from_coeff
+        H::trim(coeffs);
+        return ATLAS_OK;
+    }
+    int ingest(const atlas_u128_t& r, size_t round) override {
+        if (round != round_next || round >= log_k) return fail(ATLAS_ESTATE, "hamming_weight: round out of order");
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        for (auto& p : ra) {
+            const size_t half = p.size() / 2;
+            for (size_t k = 0; k < half; k++) p[k] = H::add(p[2 * k], H::mul(rf, H::sub(p[2 * k + 1], p[2 * k])));
+            p.resize(half);
+        }
+        round_next++;
+        return ATLAS_OK;
+    }
+    int finals(std::vector<H::Fr>& out) override {
+        out.clear();
+        for (auto& p : ra) { if (p.size() != 1) return fail(ATLAS_ESTATE, "final_claims: rounds remaining"); out.push_back(p[0]); }
+        return ATLAS_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int atlas_ra_virtual_new(const int32_t* const* H_indices, size_t d, size_t log_k_chunk, size_t log_T,
+                         const atlas_fr_t* r_address_chunks, const atlas_fr_t* r_cycle, atlas_instance_t* out) {
+    NEED_INIT();
+    if (!H_indices || !r_address_chunks || (!r_cycle && log_T) || !out) return fail(ATLAS_EINVAL, "ra_virtual_new: null argument");
+    if (d == 0 || d > RA_MAX_D) return fail(ATLAS_EINVAL, "ra_virtual_new: d must be in 1..16");
+    if (log_k_chunk > 16 || log_T == 0 || log_T > 25) return fail(ATLAS_EINVAL, "ra_virtual_new: log_k_chunk <= 16, 1 <= log_T <= 25");
+    std::lock_guard<std::mutex> lk(g.mu);
+    RaVirtual* P = new RaVirtual();
+    P->log_T = log_T;
+    const size_t K = (size_t)1 << log_k_chunk, T = (size_t)1 << log_T;
+    std::vector<std::vector<H::Fr>> tabs(d);
+    const H::Fr* ch = reinterpret_cast<const H::Fr*>(r_address_chunks);
+    for (size_t i = 0; i < d; i++) tabs[i] = H::eq_evals(ch + i * log_k_chunk, log_k_chunk);   // ra_virtual.rs:113-116
+    Fr* d_tabs = nullptr;
+    int rc = upload_tables(tabs, K, &d_tabs);
+    if (!rc) rc = P->rows.alloc(d, T);
+    if (!rc) rc = P->rows.gather(H_indices, d_tabs, (uint32_t)K);
+    if (d_tabs) hipFree(d_tabs);
+    if (!rc) rc = P->eq.init(reinterpret_cast<const H::Fr*>(r_cycle), log_T);
+    if (rc) { delete P; return rc; }
+    *out = P;
+    return ATLAS_OK;
+}
+
+int atlas_booleanity_new(const atlas_fr_t* G, const int32_t* const* H_indices, size_t d, size_t log_k_chunk, size_t log_T,
+                         const atlas_fr_t* gammas, const atlas_fr_t* r_address, const atlas_fr_t* r_cycle, atlas_instance_t* out) {
+    NEED_INIT();
+    if (!G || !H_indices || !gammas || !r_address || (!r_cycle && log_T) || !out) return fail(ATLAS_EINVAL, "booleanity_new: null argument");
+    if (d == 0 || log_k_chunk == 0 || log_k_chunk > 16 || log_T == 0 || log_T > 25)
+        return fail(ATLAS_EINVAL, "booleanity_new: 1 <= log_k_chunk <= 16, 1 <= log_T <= 25");
+    std::lock_guard<std::mutex> lk(g.mu);
+    Booleanity* P = new Booleanity();
+    P->d = d; P->log_k = log_k_chunk; P->log_T = log_T;
+    const size_t K = (size_t)1 << log_k_chunk, T = (size_t)1 << log_T;
+    const H::Fr* Gh = reinterpret_cast<const H::Fr*>(G);
+    P->G.resize(d); P->H_idx.resize(d);
+    for (size_t i = 0; i < d; i++) { P->G[i].assign(Gh + i * K, Gh + (i + 1) * K); P->H_idx[i].assign(H_indices[i], H_indices[i] + T); }
+    P->gammas.assign(reinterpret_cast<const H::Fr*>(gammas), reinterpret_cast<const H::Fr*>(gammas) + d);
+    P->F = {H::one()};
+    const H::Fr* ra = reinterpret_cast<const H::Fr*>(r_address);
+    P->B.init(ra, log_k_chunk);
+    P->B_out = H::eq_cached(ra, P->B.k_out);
+    P->B_in = H::eq_cached(ra + P->B.m, P->B.k_in);
+    int rc = P->D.init(reinterpret_cast<const H::Fr*>(r_cycle), log_T);
+    if (!rc) rc = P->rows.alloc(d, T);
+    if (!rc) {
+        hipError_t e = hipMalloc(&P->d_gammas, d * sizeof(Fr));
+        if (e == hipSuccess) e = hipMemcpyAsync(P->d_gammas, gammas, d * sizeof(Fr), hipMemcpyHostToDevice, g.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+        if (e != hipSuccess) rc = fail(ATLAS_ENODEV, "booleanity_new: gammas", e);
+    }
+    if (rc) { delete P; return rc; }
+    *out = P;
+    return ATLAS_OK;
+}
+
+int atlas_hamming_weight_new(const atlas_fr_t* G, size_t d, size_t log_k_chunk, const atlas_fr_t* gamma_powers, atlas_instance_t* out) {
+    if (!G || !gamma_powers || !out || d == 0 || log_k_chunk > 20) return fail(ATLAS_EINVAL, "hamming_weight_new");
+    HammingWeight* P = new HammingWeight();
+    P->log_k = log_k_chunk;
+    const size_t K = (size_t)1 << log_k_chunk;
+    const H::Fr* Gh = reinterpret_cast<const H::Fr*>(G);
+    P->ra.resize(d);
+    for (size_t i = 0; i < d; i++) P->ra[i].assign(Gh + i * K, Gh + (i + 1) * K);
+    P->gamma_powers.assign(reinterpret_cast<const H::Fr*>(gamma_powers), reinterpret_cast<const H::Fr*>(gamma_powers) + d);
+    *out = P;
+    return ATLAS_OK;
+}
+
+}  // extern "C"

@@ -26,7 +26,7 @@ namespace atlas {
 
 // ---- EQ tables -----------------------------------------------------------------------
 // One doubling pass of evals_parallel (eq_poly.rs:225-252), in place: y = x*r; x -= y.
-__global__ __launch_bounds__(SC_THREADS) void k_eq_double(Fr* ev, size_t size, Fr r) {
+static __global__ __launch_bounds__(SC_THREADS) void k_eq_double(Fr* ev, size_t size, Fr r) {
     for (size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x; i < size; i += (size_t)gridDim.x * SC_THREADS) {
         Fr x = fe_load(ev + i);
         Fr y = fr_mul(x, r);
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_eq_double(Fr* ev, size_t size, F
 
 // first `levels` doubling passes in one workgroup (tables up to 2^12 entries), same index
 // convention as k_eq_double: pass p uses r[n-1-p]
-__global__ __launch_bounds__(1024) void k_eq_head(Fr* ev, const Fr* r, uint32_t n, uint32_t levels, Fr scale) {
+static __global__ __launch_bounds__(1024) void k_eq_head(Fr* ev, const Fr* r, uint32_t n, uint32_t levels, Fr scale) {
     if (threadIdx.x == 0) fe_store(ev, scale);
     __syncthreads();
     for (uint32_t p = 0; p < levels; p++) {
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(1024) void k_eq_head(Fr* ev, const Fr* r, uint32_t 
 
 // evals_cached (eq_poly.rs:174-192): all prefix tables of w[0..k), table j at offset 2^j-1.
 // One workgroup; k <= 12.
-__global__ __launch_bounds__(1024) void k_eq_cached(Fr* tabs, const Fr* w, uint32_t k) {
+static __global__ __launch_bounds__(1024) void k_eq_cached(Fr* tabs, const Fr* w, uint32_t k) {
     if (threadIdx.x == 0) fe_store(tabs, fr_one());
     __syncthreads();
     for (uint32_t j = 0; j < k; j++) {
@@ -219,7 +219,7 @@ __device__ __forceinline__ void mul_round_wave(WaveTranscript& T, FsScratch* S, 
     }
 }
 
-__global__ __launch_bounds__(SC_THREADS) void k_mul_fs_round(MulCtx* cx, const Fr* partials, int n_partials,
+static __global__ __launch_bounds__(SC_THREADS) void k_mul_fs_round(MulCtx* cx, const Fr* partials, int n_partials,
                                                              const Fr* w_cur_ptr, Fr* proof_row, uint64_t* chal_row,
                                                              ScConsts K, int first, int challenge_mode) {
     __shared__ Fr red[SC_THREADS / 64][3];
@@ -275,7 +275,7 @@ struct MulTailArgs {
     int first, pending_bind, challenge_mode;
 };
 
-__global__ __launch_bounds__(SC_THREADS) void k_mul_tail(MulTailArgs A, MulCtx* cx, Fr* proof, uint64_t* chal,
+static __global__ __launch_bounds__(SC_THREADS) void k_mul_tail(MulTailArgs A, MulCtx* cx, Fr* proof, uint64_t* chal,
                                                          Fr* finals, ScConsts K) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     Fr* bufL[2]; Fr* bufR[2];

@@ -389,7 +389,7 @@ __device__ __forceinline__ void fs_round_wave(WaveTranscript& T, FsScratch* S, c
 // fold the per-workgroup partials, then run the serial spine on wavefront 0.
 // first != 0: Sumcheck::prove's `transcript.append_scalar(&input_claim)` (sumcheck.rs:573-574)
 template <int DEG>
-__global__ __launch_bounds__(SC_THREADS) void k_fs_round(ScCtx* cx, const Fr* partials, int n_partials,
+static __global__ __launch_bounds__(SC_THREADS) void k_fs_round(ScCtx* cx, const Fr* partials, int n_partials,
                                                          Fr* proof_row, uint64_t* chal_row, ScConsts K,
                                                          int first, int challenge_mode) {
     __shared__ Fr red[SC_THREADS / 64][DEG];
@@ -449,7 +449,7 @@ struct TailArgs {
 };
 
 template <int DEG>
-__global__ __launch_bounds__(SC_THREADS) void k_dot_tail(TailArgs A, ScCtx* cx, Fr* proof, uint64_t* chal,
+static __global__ __launch_bounds__(SC_THREADS) void k_dot_tail(TailArgs A, ScCtx* cx, Fr* proof, uint64_t* chal,
                                                          Fr* finals, ScConsts K) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     Fr* sL = reinterpret_cast<Fr*>(smem_raw);

@@ -1,0 +1,87 @@
+"""Generic SumcheckInstanceProver handles (atlas_instance_t) and the one-hot "ra" instances:
+RaSumcheckProver (ra_virtual.rs:97-145), BooleanitySumcheckProver (booleanity.rs:169-348),
+HammingWeightSumcheckProver (hamming_weight.rs:106-148)."""
+import ctypes as C
+
+import numpy as np
+
+from . import U128, _check, _fr, _p, lib
+
+lib.atlas_instance_num_rounds.restype = C.c_size_t
+lib.atlas_instance_degree.restype = C.c_size_t
+
+
+class Instance:
+    def __init__(self, handle, keep=()):
+        self.h = handle
+        self._keep = keep
+
+    def num_rounds(self):
+        return lib.atlas_instance_num_rounds(self.h)
+
+    def degree(self):
+        return lib.atlas_instance_degree(self.h)
+
+    def compute_message(self, rnd, previous_claim):
+        cap = self.degree() + 2
+        out = np.zeros((cap, 4), dtype=np.uint64)
+        n = C.c_size_t()
+        pc = _fr(previous_claim)
+        _check(lib.atlas_instance_compute_message(self.h, C.c_size_t(rnd), _p(pc), _p(out), C.c_size_t(cap), C.byref(n)))
+        return out[:n.value]
+
+    def ingest_challenge(self, r_u128, rnd):
+        u = U128(r_u128 & ((1 << 64) - 1), r_u128 >> 64)
+        _check(lib.atlas_instance_ingest_challenge(self.h, C.byref(u), C.c_size_t(rnd)))
+
+    def final_claims(self):
+        out = np.zeros((64, 4), dtype=np.uint64)
+        n = C.c_size_t()
+        _check(lib.atlas_instance_final_claims(self.h, _p(out), C.c_size_t(64), C.byref(n)))
+        return out[:n.value]
+
+    def prove(self, input_claim, transcript):
+        """Sumcheck::prove. Returns (rows of compressed coefficients, challenges [u128])."""
+        n = self.num_rounds(); stride = self.degree() + 1
+        comp = np.zeros((max(n, 1), stride, 4), dtype=np.uint64)
+        nco = np.zeros(max(n, 1), dtype=np.uint32); ch = np.zeros(2 * max(n, 1), dtype=np.uint64)
+        ic = _fr(input_claim)
+        _check(lib.atlas_instance_prove(self.h, _p(ic), C.byref(transcript.t), _p(comp), C.c_size_t(stride),
+                                        nco.ctypes.data_as(C.c_void_p), _p(ch)))
+        return [comp[i, :nco[i]].copy() for i in range(n)], [int(ch[2 * i]) | (int(ch[2 * i + 1]) << 64) for i in range(n)]
+
+    def free(self):
+        if self.h:
+            lib.atlas_instance_free(self.h)
+            self.h = None
+
+
+def _idx_ptrs(H_indices):
+    arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in H_indices]
+    return arrs, (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+
+
+def ra_virtual(H_indices, log_k_chunk, r_address_chunks, r_cycle):
+    arrs, ptrs = _idx_ptrs(H_indices)
+    ch = np.ascontiguousarray(r_address_chunks, dtype=np.uint64); rc = np.ascontiguousarray(r_cycle, dtype=np.uint64)
+    h = C.c_void_p()
+    _check(lib.atlas_ra_virtual_new(ptrs, C.c_size_t(len(arrs)), C.c_size_t(log_k_chunk), C.c_size_t(len(rc)), _p(ch), _p(rc),
+                                    C.byref(h)))
+    return Instance(h)
+
+
+def booleanity(G, H_indices, log_k_chunk, gammas, r_address, r_cycle):
+    arrs, ptrs = _idx_ptrs(H_indices)
+    G = np.ascontiguousarray(G, dtype=np.uint64); ga = np.ascontiguousarray(gammas, dtype=np.uint64)
+    ra = np.ascontiguousarray(r_address, dtype=np.uint64); rc = np.ascontiguousarray(r_cycle, dtype=np.uint64)
+    h = C.c_void_p()
+    _check(lib.atlas_booleanity_new(_p(G), ptrs, C.c_size_t(len(arrs)), C.c_size_t(log_k_chunk), C.c_size_t(len(rc)), _p(ga),
+                                    _p(ra), _p(rc), C.byref(h)))
+    return Instance(h)
+
+
+def hamming_weight(G, log_k_chunk, gamma_powers):
+    G = np.ascontiguousarray(G, dtype=np.uint64); gp = np.ascontiguousarray(gamma_powers, dtype=np.uint64)
+    h = C.c_void_p()
+    _check(lib.atlas_hamming_weight_new(_p(G), C.c_size_t(len(gp)), C.c_size_t(log_k_chunk), _p(gp), C.byref(h)))
+    return Instance(h)

@@ -77,17 +77,18 @@ int  orc_num_threads(void);
 
 /* BatchedSumcheck::prove (sumcheck.rs:30-184).  kind 0 = dot instance (schedule/sa/sb/eq as
  * above), 1 = Mul instance (w = n_vars Fr).  Operands are bound in place; final_claims as the
- * single-instance provers.  compressed: rows of 4 Fr, n_coeffs[i] of them valid. */
+ * single-instance provers.  compressed: rows of `stride` Fr, n_coeffs[i] of them valid. */
 typedef struct {
     int kind; int schedule; size_t n_vars, sa, sb;
     fr_t *left, *right, *eq; const fr_t *w;
     fr_t input_claim; fr_t final_claims[3];
+    void *state;          /* kinds >= 2 (ra.h ORC_INST_*): initialised instance state, n_vars = rounds */
 } orc_batched_inst;
-int orc_batched_prove(orc_batched_inst *inst, size_t n_inst, orc_transcript *t, fr_t *compressed,
+int orc_batched_prove(orc_batched_inst *inst, size_t n_inst, orc_transcript *t, fr_t *compressed, size_t stride,
                       uint32_t *n_coeffs, u128 *challenges, size_t *max_rounds_out);
 /* BatchedSumcheck::verify (sumcheck.rs:186-262) up to the expected-output check: returns the
  * final batched claim e and the coefficients; claim_i and rounds_i per instance. */
-int orc_batched_verify(const fr_t *compressed, const uint32_t *n_coeffs, size_t max_rounds, const fr_t *input_claims,
+int orc_batched_verify(const fr_t *compressed, size_t stride, const uint32_t *n_coeffs, size_t max_rounds, const fr_t *input_claims,
                        const size_t *rounds, size_t n_inst, orc_transcript *t, fr_t *e_out, fr_t *coeffs_out,
                        u128 *challenges);
 

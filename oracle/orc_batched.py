@@ -7,12 +7,13 @@ import numpy as np
 from . import orc
 
 FR = C.c_uint64 * 4
+STRIDE = 24
 
 
 class Inst(C.Structure):
     _fields_ = [("kind", C.c_int), ("schedule", C.c_int), ("n_vars", C.c_size_t), ("sa", C.c_size_t), ("sb", C.c_size_t),
                 ("left", C.c_void_p), ("right", C.c_void_p), ("eq", C.c_void_p), ("w", C.c_void_p),
-                ("input_claim", FR), ("final_claims", FR * 3)]
+                ("input_claim", FR), ("final_claims", FR * 3), ("state", C.c_void_p)]
 
 
 def dot_instance(L, R, claim, eq=None, schedule=0, a=0, b=0):
@@ -26,6 +27,11 @@ def mul_instance(L, R, w, claim):
                 claim=np.ascontiguousarray(claim, dtype=np.uint64).reshape(4), n=len(w))
 
 
+def ra_instance(inst, claim):
+    """an oracle/ra.c instance (orc_ra.Instance) as a batch member."""
+    return dict(kind=inst.kind, inst=inst, n=inst.n_rounds, claim=np.ascontiguousarray(claim, dtype=np.uint64).reshape(4))
+
+
 def batched_prove(instances, t):
     """Returns (rows: list of (k,4) arrays of compressed coefficients, challenges, finals: list of (3,4))."""
     n = len(instances)
@@ -33,8 +39,13 @@ def batched_prove(instances, t):
     for i, d in enumerate(instances):
         I = arr[i]
         I.kind = d["kind"]; I.n_vars = d["n"]
-        I.left = d["L"].ctypes.data; I.right = d["R"].ctypes.data
-        if d["kind"] == 0:
+        if d["kind"] >= 2:
+            I.state = C.addressof(d["inst"].st)
+        else:
+            I.left = d["L"].ctypes.data; I.right = d["R"].ctypes.data
+        if d["kind"] >= 2:
+            pass
+        elif d["kind"] == 0:
             I.schedule = d["schedule"]; I.sa = d["a"]; I.sb = d["b"]
             I.eq = d["eq"].ctypes.data if d["eq"] is not None else None
         else:
@@ -42,13 +53,13 @@ def batched_prove(instances, t):
         for k in range(4):
             I.input_claim[k] = int(d["claim"][k])
     max_rounds = max(d["n"] for d in instances)
-    comp = orc.fr_array(4 * max_rounds); nco = np.zeros(max_rounds, dtype=np.uint32)
+    comp = orc.fr_array(STRIDE * max_rounds); nco = np.zeros(max_rounds, dtype=np.uint32)
     ch = np.zeros(2 * max_rounds, dtype=np.uint64); mr = C.c_size_t(0)
     orc.lib.orc_batched_prove.restype = C.c_int
-    rc = orc.lib.orc_batched_prove(arr, C.c_size_t(n), C.byref(t), orc._p(comp), nco.ctypes.data_as(C.c_void_p),
-                                   orc._p(ch), C.byref(mr))
+    rc = orc.lib.orc_batched_prove(arr, C.c_size_t(n), C.byref(t), orc._p(comp), C.c_size_t(STRIDE),
+                                   nco.ctypes.data_as(C.c_void_p), orc._p(ch), C.byref(mr))
     assert rc == 0 and mr.value == max_rounds
-    comp = comp.reshape(max_rounds, 4, 4)
+    comp = comp.reshape(max_rounds, STRIDE, 4)
     rows = [comp[i, :nco[i]].copy() for i in range(max_rounds)]
     finals = [np.array([[arr[i].final_claims[j][k] for k in range(4)] for j in range(3)], dtype=np.uint64) for i in range(n)]
     return rows, orc._u128_list(ch, max_rounds), finals
@@ -57,7 +68,7 @@ def batched_prove(instances, t):
 def batched_verify(rows, input_claims, rounds, t):
     """BatchedSumcheck::verify up to the expected-output check. Returns (e (4,), coeffs (n,4), challenges)."""
     max_rounds = len(rows); n = len(rounds)
-    comp = orc.fr_array(4 * max_rounds).reshape(max_rounds, 4, 4); nco = np.zeros(max_rounds, dtype=np.uint32)
+    comp = orc.fr_array(STRIDE * max_rounds).reshape(max_rounds, STRIDE, 4); nco = np.zeros(max_rounds, dtype=np.uint32)
     for i, r in enumerate(rows):
         comp[i, :len(r)] = r; nco[i] = len(r)
     comp = np.ascontiguousarray(comp)
@@ -65,7 +76,7 @@ def batched_verify(rows, input_claims, rounds, t):
     rds = np.asarray(rounds, dtype=np.uint64)
     e = orc.fr_array(1); co = orc.fr_array(n); ch = np.zeros(2 * max_rounds, dtype=np.uint64)
     orc.lib.orc_batched_verify.restype = C.c_int
-    rc = orc.lib.orc_batched_verify(orc._p(comp), nco.ctypes.data_as(C.c_void_p), C.c_size_t(max_rounds), orc._p(claims),
+    rc = orc.lib.orc_batched_verify(orc._p(comp), C.c_size_t(STRIDE), nco.ctypes.data_as(C.c_void_p), C.c_size_t(max_rounds), orc._p(claims),
                                     rds.ctypes.data_as(C.c_void_p), C.c_size_t(n), C.byref(t), orc._p(e), orc._p(co), orc._p(ch))
     assert rc == 0
     return e.reshape(4), co.reshape(n, 4), orc._u128_list(ch, max_rounds)

@@ -10,6 +10,7 @@
  * Rayon's chunked map-reduce is mirrored with OpenMP; all reductions are over exact
  * field elements so the association order cannot change a result. */
 #include "oracle.h"
+#include "ra.h"
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -465,18 +466,20 @@ static size_t scale_trim(const fr_t *p, size_t n, const fr_t *c, fr_t *o) {   /*
     return n;
 }
 
-int orc_batched_prove(orc_batched_inst *inst, size_t n_inst, orc_transcript *t, fr_t *compressed, uint32_t *n_coeffs,
-                      u128 *challenges, size_t *max_rounds_out) {
+#define ORC_BATCH_MAXC 40
+int orc_batched_prove(orc_batched_inst *inst, size_t n_inst, orc_transcript *t, fr_t *compressed, size_t stride,
+                      uint32_t *n_coeffs, u128 *challenges, size_t *max_rounds_out) {
     size_t max_rounds = 0;
     dot_state *D = (dot_state *)calloc(n_inst, sizeof(dot_state));
     mul_state *M = (mul_state *)calloc(n_inst, sizeof(mul_state));
     fr_t *coeff = (fr_t *)malloc(n_inst * sizeof(fr_t)), *claim = (fr_t *)malloc(n_inst * sizeof(fr_t));
-    fr_t (*polys)[4] = (fr_t (*)[4])malloc(n_inst * sizeof(fr_t[4]));
+    fr_t (*polys)[ORC_BATCH_MAXC] = (fr_t (*)[ORC_BATCH_MAXC])malloc(n_inst * sizeof(fr_t[ORC_BATCH_MAXC]));
     size_t *plen = (size_t *)malloc(n_inst * sizeof(size_t));
     for (size_t i = 0; i < n_inst; i++) {
         orc_batched_inst *I = &inst[i];
         if (I->kind == 0) dot_init(&D[i], I->left, I->right, I->eq, I->n_vars, I->schedule, I->sa, I->sb);
-        else mul_init(&M[i], I->left, I->right, I->w, I->n_vars);
+        else if (I->kind == 1) mul_init(&M[i], I->left, I->right, I->w, I->n_vars);
+        /* kinds >= 2: an initialised oracle/ra.c state in I->state, n_vars = its round count */
         if (I->n_vars > max_rounds) max_rounds = I->n_vars;
     }
     for (size_t i = 0; i < n_inst; i++) orc_transcript_append_scalar(t, &inst[i].input_claim);   /* :42-45 */
@@ -490,10 +493,11 @@ int orc_batched_prove(orc_batched_inst *inst, size_t n_inst, orc_transcript *t, 
             else {
                 const size_t local = round - (max_rounds - nr);
                 plen[i] = inst[i].kind == 0 ? dot_round_message(&D[i], local, &claim[i], polys[i])
-                                            : mul_message(&M[i], &claim[i], polys[i]);
+                        : inst[i].kind == 1 ? mul_message(&M[i], &claim[i], polys[i])
+                                            : orc_ra_inst_message(inst[i].kind, inst[i].state, local, &claim[i], polys[i]);
             }
         }
-        fr_t batched[4], tmp[4]; size_t blen = 1; fr_zero(&batched[0]);                            /* :109-116 */
+        fr_t batched[ORC_BATCH_MAXC], tmp[ORC_BATCH_MAXC]; size_t blen = 1; fr_zero(&batched[0]);   /* :109-116 */
         for (size_t i = 0; i < n_inst; i++) {
             size_t tl = scale_trim(polys[i], plen[i], &coeff[i], tmp);
             for (size_t k = 0; k < tl; k++) {
@@ -501,23 +505,25 @@ int orc_batched_prove(orc_batched_inst *inst, size_t n_inst, orc_transcript *t, 
                 else batched[blen++] = tmp[k];
             }
         }
-        fr_t cc[4]; size_t ncc = orc_unipoly_compress(batched, blen, cc);
+        fr_t cc[ORC_BATCH_MAXC]; size_t ncc = orc_unipoly_compress(batched, blen, cc);
         orc_transcript_append_compressed(t, cc, ncc);
         fr_t r; u128 raw; orc_transcript_challenge_optimized(t, &raw, &r);
         challenges[round] = raw; n_coeffs[round] = (uint32_t)ncc;
-        for (size_t k = 0; k < ncc; k++) compressed[round * 4 + k] = cc[k];
+        for (size_t k = 0; k < ncc; k++) compressed[round * stride + k] = cc[k];
         for (size_t i = 0; i < n_inst; i++) orc_unipoly_eval(polys[i], plen[i], &r, &claim[i]);    /* :123-126 */
         for (size_t i = 0; i < n_inst; i++) {
             const size_t nr = inst[i].n_vars;
             if (remaining <= nr) {
-                if (inst[i].kind == 0) dot_ingest(&D[i], round - (max_rounds - nr), &r);
-                else mul_ingest(&M[i], &r);
+                const size_t local = round - (max_rounds - nr);
+                if (inst[i].kind == 0) dot_ingest(&D[i], local, &r);
+                else if (inst[i].kind == 1) mul_ingest(&M[i], &r);
+                else orc_ra_inst_ingest(inst[i].kind, inst[i].state, local, &r);
             }
         }
     }
     for (size_t i = 0; i < n_inst; i++) {
         if (inst[i].kind == 0) dot_finals(&D[i], inst[i].final_claims);
-        else {
+        else if (inst[i].kind == 1) {
             inst[i].final_claims[0] = inst[i].left[0]; inst[i].final_claims[1] = inst[i].right[0];
             inst[i].final_claims[2] = M[i].scalar; mul_free(&M[i]);
         }
@@ -527,7 +533,7 @@ int orc_batched_prove(orc_batched_inst *inst, size_t n_inst, orc_transcript *t, 
     return 0;
 }
 
-int orc_batched_verify(const fr_t *compressed, const uint32_t *n_coeffs, size_t max_rounds, const fr_t *input_claims,
+int orc_batched_verify(const fr_t *compressed, size_t stride, const uint32_t *n_coeffs, size_t max_rounds, const fr_t *input_claims,
                        const size_t *rounds, size_t n_inst, orc_transcript *t, fr_t *e_out, fr_t *coeffs_out,
                        u128 *challenges) {
     for (size_t i = 0; i < n_inst; i++) orc_transcript_append_scalar(t, &input_claims[i]);      /* :205-208 */
@@ -538,7 +544,7 @@ int orc_batched_verify(const fr_t *compressed, const uint32_t *n_coeffs, size_t 
         fr_mul(&c, &coeffs_out[i], &c); fr_add(&e, &c, &e);
     }
     for (size_t i = 0; i < max_rounds; i++) {                                                   /* proof.verify :653-686 */
-        const fr_t *cc = &compressed[i * 4];
+        const fr_t *cc = &compressed[i * stride];
         orc_transcript_append_compressed(t, cc, n_coeffs[i]);
         fr_t r; u128 raw; orc_transcript_challenge_optimized(t, &raw, &r);
         if (challenges) challenges[i] = raw;

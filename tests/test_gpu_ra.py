@@ -1,0 +1,184 @@
+"""GPU parity: RaVirtual / Booleanity / HammingWeight sumcheck instances vs oracle/ra.c, bit exact
+(proof rows, challenges, transcript state, final claims)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _indices(d, T, K, seed, none_frac=0.1):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(d):
+        a = rng.integers(0, K, size=T).astype(np.int32)
+        a[rng.random(T) < none_frac] = -1
+        out.append(a)
+    return out
+
+
+def _rows_equal(a, b):
+    return len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def _ra_claim(orc, H, chunks, r_cycle, log_k):
+    """sum_j eq(r_cycle, j) prod_i F_i[idx_i[j]] with the oracle's field ops."""
+    E = orc.eq_evals(r_cycle)
+    Fs = [orc.eq_evals(c) for c in chunks]
+    acc = orc.fr_array(1)[0]
+    for j in range(len(E)):
+        t = E[j]
+        for F, idx in zip(Fs, H):
+            if idx[j] < 0:
+                t = None
+                break
+            t = orc.fr_mul_arr(t, F[idx[j]])
+        if t is not None:
+            acc = orc.fr_add_arr(acc, t)
+    return acc
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("d,log_k,log_T", [(1, 4, 3), (2, 4, 9), (3, 2, 1), (4, 4, 11), (8, 4, 10), (16, 4, 9), (5, 8, 6)])
+def test_ra_virtual_bit_exact(atlas, d, log_k, log_T, mode):
+    from oracle import orc, orc_ra as OR
+    from jolt_atlas_amd import instances as I
+    A = atlas
+    A.set_challenge_mode(mode); orc.lib.orc_set_challenge_mode(mode)
+    try:
+        T, K = 1 << log_T, 1 << log_k
+        H = _indices(d, T, K, 13 * d + log_T, none_frac=0.02)
+        chunks = orc.random_fr(d * log_k, 5).reshape(d, log_k, 4)
+        r_cycle = orc.random_fr(log_T, 6)
+        claim = _ra_claim(orc, H, chunks, r_cycle, log_k)
+        inst_o = OR.ra_virtual(H, log_k, chunks, r_cycle)
+        t_o = orc.new_transcript(b"ra_virtual")
+        rows_o, ch_o = inst_o.prove(claim, t_o)
+        inst = I.ra_virtual(H, log_k, chunks, r_cycle)
+        assert inst.num_rounds() == log_T and inst.degree() == d + 1
+        t_g = A.Blake2bTranscript(b"ra_virtual")
+        rows_g, ch_g = inst.prove(claim, t_g)
+        assert ch_g == ch_o
+        assert _rows_equal(rows_g, rows_o)
+        assert t_g.state == t_o.state_bytes() and t_g.n_rounds == t_o.n_rounds
+        # final claims: ra_i(r) = MLE of the gathered vector at the (reversed) challenges
+        fin = inst.final_claims()
+        assert len(fin) == d
+        rs = orc.challenges_to_fr(ch_g)[::-1]
+        for i in range(d):
+            F = orc.eq_evals(chunks[i])
+            vec = np.stack([F[k] if k >= 0 else np.zeros(4, dtype=np.uint64) for k in H[i]])
+            assert np.array_equal(fin[i], orc.evaluate(vec, np.ascontiguousarray(rs)))
+        inst.free()
+    finally:
+        A.set_challenge_mode(0); orc.lib.orc_set_challenge_mode(0)
+
+
+@pytest.mark.parametrize("d,log_k,log_T", [(1, 1, 1), (2, 4, 9), (8, 4, 10), (16, 4, 8), (3, 8, 5)])
+def test_booleanity_bit_exact(atlas, d, log_k, log_T):
+    from oracle import orc, orc_ra as OR
+    from jolt_atlas_amd import instances as I
+    A = atlas
+    T, K = 1 << log_T, 1 << log_k
+    H = _indices(d, T, K, 17 * d + log_T)
+    r_address, r_cycle = orc.random_fr(log_k, 7), orc.random_fr(log_T, 8)
+    gammas = orc.random_fr(d, 9)
+    G = OR.ra_G(H, log_k, r_cycle)
+    inst_o = OR.booleanity(G, H, log_k, gammas, r_address, r_cycle)
+    t_o = orc.new_transcript(b"booleanity")
+    zero = orc.fr_array(1)[0]
+    rows_o, ch_o = inst_o.prove(zero, t_o)
+    inst = I.booleanity(G, H, log_k, gammas, r_address, r_cycle)
+    assert inst.num_rounds() == log_k + log_T and inst.degree() == 3
+    t_g = A.Blake2bTranscript(b"booleanity")
+    rows_g, ch_g = inst.prove(zero, t_g)
+    assert ch_g == ch_o
+    assert _rows_equal(rows_g, rows_o)
+    assert t_g.state == t_o.state_bytes()
+    assert len(inst.final_claims()) == d
+    inst.free()
+
+
+@pytest.mark.parametrize("d,log_k", [(1, 1), (8, 4), (16, 4), (2, 8)])
+def test_hamming_weight_bit_exact(atlas, d, log_k):
+    from oracle import orc, orc_ra as OR
+    from jolt_atlas_amd import instances as I
+    A = atlas
+    K = 1 << log_k
+    G = orc.random_fr(d * K, 3).reshape(d, K, 4)
+    gp = orc.random_fr(d, 4)
+    claim = orc.fr_array(1)[0]
+    for i in range(d):
+        s = orc.fr_array(1)[0]
+        for k in range(K):
+            s = orc.fr_add_arr(s, G[i, k])
+        claim = orc.fr_add_arr(claim, orc.fr_mul_arr(s, gp[i]))
+    inst_o = OR.hamming(G, log_k, gp)
+    t_o = orc.new_transcript(b"hamming")
+    rows_o, ch_o = inst_o.prove(claim, t_o)
+    inst = I.hamming_weight(G, log_k, gp)
+    t_g = A.Blake2bTranscript(b"hamming")
+    rows_g, ch_g = inst.prove(claim, t_g)
+    assert ch_g == ch_o and _rows_equal(rows_g, rows_o) and t_g.state == t_o.state_bytes()
+    rs = np.ascontiguousarray(orc.challenges_to_fr(ch_g)[::-1])
+    fin = inst.final_claims()
+    for i in range(d):
+        assert np.array_equal(fin[i], orc.evaluate(G[i], rs))
+    inst.free()
+
+
+def test_round_order_is_enforced(atlas):
+    from oracle import orc
+    from jolt_atlas_amd import instances as I
+    H = _indices(2, 16, 16, 1)
+    inst = I.ra_virtual(H, 4, orc.random_fr(8, 1).reshape(2, 4, 4), orc.random_fr(4, 2))
+    with pytest.raises(atlas.AtlasError):
+        inst.ingest_challenge(5, 1)
+    with pytest.raises(atlas.AtlasError):
+        inst.final_claims()
+    inst.free()
+    with pytest.raises(atlas.AtlasError):
+        I.ra_virtual(_indices(17, 4, 16, 1), 4, orc.random_fr(17 * 4, 1).reshape(17, 4, 4), orc.random_fr(2, 2))
+
+
+@pytest.mark.parametrize("d,log_k,log_T", [(2, 4, 6), (8, 4, 9)])
+def test_batched_lookup_group_bit_exact(atlas, d, log_k, log_T):
+    """BatchedSumcheck over booleanity + hamming weight + ra virtualisation + a Mul and a dot
+    instance of other sizes, vs the oracle's batched driver."""
+    from oracle import orc, orc_ra as OR, orc_batched as OB
+    from jolt_atlas_amd import instances as I
+    A = atlas
+    T, K = 1 << log_T, 1 << log_k
+    H = _indices(d, T, K, 21 * d)
+    chunks = orc.random_fr(d * log_k, 1).reshape(d, log_k, 4)
+    r_cycle, r_address = orc.random_fr(log_T, 2), orc.random_fr(log_k, 3)
+    gammas, gp = orc.random_fr(d, 4), orc.random_fr(d, 5)
+    G = OR.ra_G(H, log_k, r_cycle)
+    ham_claim = orc.fr_array(1)[0]
+    for i in range(d):
+        s = orc.fr_array(1)[0]
+        for k in range(K):
+            s = orc.fr_add_arr(s, G[i, k])
+        ham_claim = orc.fr_add_arr(ham_claim, orc.fr_mul_arr(s, gp[i]))
+    ra_claim = _ra_claim(orc, H, chunks, r_cycle, log_k)
+    zero = orc.fr_array(1)[0]
+    n_mul, n_dot = log_T + 2, 3
+    Lm, Rm, w = orc.random_fr(1 << n_mul, 6), orc.random_fr(1 << n_mul, 7), orc.random_fr(n_mul, 8)
+    Ld, Rd = orc.random_fr(1 << n_dot, 9), orc.random_fr(1 << n_dot, 10)
+    mul_claim, dot_claim = orc.mul_claim(Lm, Rm, w)[0], orc.dot_claim(Ld, Rd)[0]
+    claims = [zero, ham_claim, ra_claim, mul_claim, dot_claim]
+    o = [OB.ra_instance(OR.booleanity(G, H, log_k, gammas, r_address, r_cycle), zero),
+         OB.ra_instance(OR.hamming(G, log_k, gp), ham_claim),
+         OB.ra_instance(OR.ra_virtual(H, log_k, chunks, r_cycle), ra_claim),
+         OB.mul_instance(Lm, Rm, w, mul_claim), OB.dot_instance(Ld, Rd, dot_claim)]
+    t_o = orc.new_transcript(b"lookup_group")
+    rows_o, ch_o, _ = OB.batched_prove(o, t_o)
+    P = A.MultilinearPolynomial.from_fr
+    gi = [I.booleanity(G, H, log_k, gammas, r_address, r_cycle), I.hamming_weight(G, log_k, gp),
+          I.ra_virtual(H, log_k, chunks, r_cycle), A.MulProver(P(Lm), P(Rm), w), A.EinsumDotProver(P(Ld), P(Rd))]
+    t_g = A.Blake2bTranscript(b"lookup_group")
+    rows_g, ch_g = A.BatchedSumcheck.prove(gi, claims, t_g)
+    assert ch_g == ch_o
+    assert _rows_equal(rows_g, rows_o)
+    assert t_g.state == t_o.state_bytes()
+    for x in gi:
+        x.free()

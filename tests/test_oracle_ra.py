@@ -91,3 +91,40 @@ def test_degenerate_all_none_indices_trim_to_zero_polys():
     rows_o, raw_o = inst.prove(orc.from_ints([0])[0], to)
     assert [orc.to_ints(r) for r in rows_o] == rows_p and raw_o == raw_p
     assert all(r == [0] for r in rows_p)
+
+
+def test_batched_mix_of_ra_instances_matches_python_model():
+    """BatchedSumcheck over booleanity + hamming weight + ra virtualisation + a dot instance, the
+    grouping the lookup ops use (sumcheck.rs:30-184)."""
+    from oracle import orc_batched as OB
+    from oracle.pymodel import batched as PB
+    d, log_k, log_T = 2, 2, 3
+    T, K = 1 << log_T, 1 << log_k
+    H = _indices(d, T, K, 99)
+    Hl = [list(map(int, h)) for h in H]
+    chunks = [_rand(log_k, 1), _rand(log_k, 2)]
+    r_cycle, r_address = _rand(log_T, 3), _rand(log_k, 4)
+    gammas, gp = [g >> 130 for g in _rand(d, 5)], _rand(d, 6)
+    Gm = [[0] * K for _ in range(d)]
+    from oracle.pymodel import poly as P
+    E = P.eq_evals(r_cycle)
+    for i in range(d):
+        for j, k in enumerate(Hl[i]):
+            if k >= 0:
+                Gm[i][k] = (Gm[i][k] + E[j]) % F.FR
+    L, R = _rand(16, 7), _rand(16, 8)
+    m_ra = PR.RaVirtualModel(Hl, chunks, r_cycle)
+    models = [PR.BooleanityModel(Hl, log_k, gammas, r_address, r_cycle), PR.HammingModel(Gm, gp), m_ra, PS.DotProver(L, R)]
+    claims = [0, sum(g * sum(row) for g, row in zip(gp, Gm)) % F.FR, m_ra.input_claim(), sum(a * b for a, b in zip(L, R)) % F.FR]
+    tp = Blake2bTranscript(b"mix")
+    rows_p, raw_p, _ = PB.prove(PB.prepare(models), claims, tp)
+    G = np.stack([orc.from_ints(g) for g in Gm])
+    o = [OB.ra_instance(OR.booleanity(G, H, log_k, orc.from_ints(gammas), orc.from_ints(r_address), orc.from_ints(r_cycle)), orc.from_ints([claims[0]])[0]),
+         OB.ra_instance(OR.hamming(G, log_k, orc.from_ints(gp)), orc.from_ints([claims[1]])[0]),
+         OB.ra_instance(OR.ra_virtual(H, log_k, np.stack([orc.from_ints(c) for c in chunks]), orc.from_ints(r_cycle)), orc.from_ints([claims[2]])[0]),
+         OB.dot_instance(orc.from_ints(L), orc.from_ints(R), orc.from_ints([claims[3]])[0])]
+    to = orc.new_transcript(b"mix")
+    rows_o, raw_o, _ = OB.batched_prove(o, to)
+    assert raw_o == raw_p
+    assert [orc.to_ints(r) for r in rows_o] == rows_p
+    assert bytes(to.state) == tp.state
