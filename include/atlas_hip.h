@@ -240,6 +240,21 @@ int atlas_ra_virtual_new(const int32_t *const *H_indices, size_t d, size_t log_k
 int atlas_booleanity_new(const atlas_fr_t *G, const int32_t *const *H_indices, size_t d,
                          size_t log_k_chunk, size_t log_T, const atlas_fr_t *gammas,
                          const atlas_fr_t *r_address, const atlas_fr_t *r_cycle, atlas_instance_t *out);
+/* ---- opening-reduction provers (joltworks/src/subprotocols/opening_reduction.rs), the instances
+ *      ProverOpeningAccumulator::prove_batch_opening_sumcheck batches (poly/opening_proof.rs:447-532).
+ *      Both bind HighToLow over the HighToLow GruenSplitEqPolynomial, degree 2. ------------------ */
+/* DensePolynomialProverOpening (:355-425): sum_j eq(opening_point, j) P(j); takes ownership of poly
+ * (LargeScalars or I32Scalars, length 2^n); final claim = P(r_sumcheck). */
+int atlas_dense_opening_new(atlas_poly_t poly, const atlas_fr_t *opening_point, size_t n,
+                            atlas_instance_t *out);
+/* OneHotPolynomialProverOpening::{new,initialize} (:509-575): sum_{k,j} eq(r_address,k)
+ * eq(r_cycle,j) ra(k,j) for the one-hot polynomial given by nonzero_indices (T = 2^log_T host int32,
+ * negative = None; OneHotPolynomial::nonzero_indices, one_hot_polynomial.rs:21-28), K = 2^log_K.
+ * log_K address rounds then log_T cycle rounds; final claim = H(r). */
+int atlas_onehot_opening_new(const int32_t *nonzero_indices, size_t log_K, size_t log_T,
+                             const atlas_fr_t *r_address, const atlas_fr_t *r_cycle,
+                             atlas_instance_t *out);
+
 /* HammingWeightSumcheckProver::gen (subprotocols/hamming_weight.rs:106-116): sum_k sum_i
  * gamma^i G_i[k], degree 1, log_k_chunk rounds */
 int atlas_hamming_weight_new(const atlas_fr_t *G, size_t d, size_t log_k_chunk,

@@ -131,3 +131,42 @@ inline std::vector<std::vector<Fr>> eq_cached(const Fr* w, size_t k) {
 inline std::vector<Fr> eq_evals(const Fr* r, size_t n) { return eq_cached(r, n)[n]; }
 
 }  // namespace atlas_host
+
+namespace atlas_host {
+
+// HighToLow GruenSplitEqPolynomial bookkeeping (split_eq_poly.rs:121-145, 349-372):
+// w = [w_first | w_in (n/2) | w_out (rest)], current_index counts bound variables.
+struct GseStateH {
+    std::vector<Fr> w;
+    size_t n = 0, k_in = 0, k_out = 0, in_top = 0, out_top = 0, current_index = 0;
+    Fr scalar = one();
+    void init(const Fr* w_, size_t n_) {
+        w.assign(w_, w_ + n_);
+        n = n_;
+        const size_t m = n / 2;
+        k_in = n ? (m < n - 1 ? m : n - 1) : 0;
+        k_out = n ? n - 1 - k_in : 0;
+        in_top = k_in; out_top = k_out; current_index = 0; scalar = one();
+    }
+    const Fr& w_cur() const { return w[current_index]; }
+    void bind(const Fr& r) {
+        const Fr& wc = w_cur();
+        const Fr wr = mul(wc, r);
+        scalar = mul(scalar, add(add(sub(sub(one(), wc), r), wr), wr));
+        current_index += 1;
+        if (current_index <= n / 2 && in_top > 0) in_top--;
+        else if (current_index <= n && out_top > 0) out_top--;
+    }
+};
+
+// gruen_poly_deg_2 (split_eq_poly.rs:379-428): 3 coefficients, fixed length
+inline void gruen_deg2(const Fr& scalar, const Fr& w_cur, const Fr& q0, const Fr& claim, Fr coeffs[3]) {
+    const Fr eq1 = mul(scalar, w_cur), eq0 = sub(scalar, eq1), eqm = sub(eq1, eq0), eq2 = add(eq1, eqm);
+    const Fr c0 = mul(eq0, q0), c1 = sub(claim, c0);
+    const Fr l1 = mul(c1, inv(eq1));
+    const Fr l2 = sub(add(l1, l1), q0);
+    const Fr ev[2] = {c0, mul(eq2, l2)};
+    unipoly_from_evals_and_hint(add(c0, c1), ev, 2, coeffs);
+}
+
+}  // namespace atlas_host

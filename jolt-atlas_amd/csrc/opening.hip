@@ -1,0 +1,341 @@
+// Opening-reduction sumcheck provers as host-stepped instances over device data.
+// Device counterparts of (paths under the jolt-atlas tree, joltworks/src/):
+//   DensePolynomialProverOpening::{compute_message,bind}   subprotocols/opening_reduction.rs:355-425
+//   OneHotPolynomialProverOpening::{initialize,compute_message,bind}          :532-723
+//   GruenSplitEqPolynomial (HighToLow), gruen_poly_deg_2   poly/split_eq_poly.rs:121-145,349-428
+//   EqPolynomial::evals_cached_rev                         poly/eq_poly.rs:193-217
+// The reference shares EqCycleState / EqAddressState / SharedDensePolynomial between openings at the
+// same point so that a table is bound once; every opening here carries its own (identical values).
+//
+// O(T) work is in kernels: the weighted half-sum sum_{j < len/2} E_in[j_hi] E_out[j_lo] P[j], the
+// HighToLow bind, the G histogram over the T indices and the gather H[j] = F[idx_j].  The K-sized
+// address phase (K = 16 .. 256) is host arithmetic between launches.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "../../include/atlas_hip.h"
+#include "host_poly.hpp"
+#include "instance.hpp"
+#include "runtime.hpp"
+#include "sc_consts.hpp"
+#include "spliteq_kernels.hip.h"
+
+using namespace atlas;
+namespace H = atlas_host;
+using atlas_rt::fail;
+using atlas_rt::g;
+
+namespace {
+
+constexpr int OP_THREADS = 256;
+inline Fr to_dev(const H::Fr& a) { Fr o; std::memcpy(&o, &a, 32); return o; }
+
+// evals_cached_rev: table j = eq over the last j entries of r[0..k), stored at offset 2^j - 1;
+// the variable added at step j becomes the top index bit (big-endian within the suffix).
+__global__ __launch_bounds__(1024) void k_eq_cached_rev(Fr* tabs, const Fr* r, uint32_t k) {
+    if (threadIdx.x == 0) fe_store(tabs, fr_one());
+    __syncthreads();
+    for (uint32_t j = 0; j < k; j++) {
+        const Fr rv = fe_load(r + (k - 1 - j));
+        const uint32_t size = 1u << j;
+        const Fr* cur = tabs + (size - 1);
+        Fr* nxt = tabs + (2 * size - 1);
+        for (uint32_t i = threadIdx.x; i < size; i += 1024) {
+            const Fr s = fe_load(cur + i);
+            const Fr hi = fr_mul(s, rv);
+            fe_store(nxt + i + size, hi);
+            fe_store(nxt + i, fr_sub(s, hi));
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// sum_{j < half} E_hi[j >> lo_bits] * E_lo[j & mask] * P[j]
+template <class T>
+__global__ __launch_bounds__(OP_THREADS) void k_open_fold(const T* __restrict__ P, size_t half, SplitEqView E,
+                                                          Fr* __restrict__ partials, ScConsts K) {
+    Fr acc[1];
+    acc[0] = fe_zero();
+    const size_t mask = ((size_t)1 << E.in_bits) - 1;
+    for (size_t j = (size_t)blockIdx.x * OP_THREADS + threadIdx.x; j < half; j += (size_t)gridDim.x * OP_THREADS) {
+        const Fr w = fr_mul(fe_load(E.e_out + (j >> E.in_bits)), fe_load(E.e_in + (j & mask)));
+        acc[0] = fr_add(acc[0], fr_mul(w, Src<T>::get(P, j, K)));
+    }
+    block_reduce_store<1>(acc, partials);
+}
+
+__global__ __launch_bounds__(OP_THREADS) void k_open_reduce(const Fr* __restrict__ partials, uint32_t n, Fr* out) {
+    __shared__ Fr red[OP_THREADS / 64];
+    Fr acc = fe_zero();
+    for (uint32_t p = threadIdx.x; p < n; p += OP_THREADS) acc = fr_add(acc, fe_load(partials + p));
+    acc = fr_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Fr s = red[0];
+        for (int w = 1; w < OP_THREADS / 64; w++) s = fr_add(s, red[w]);
+        fe_store(out, s);
+    }
+}
+
+// HighToLow bind in place: z[i] += r (z[i + half] - z[i])
+__global__ __launch_bounds__(OP_THREADS) void k_open_bind_hi(Fr* z, size_t half, Fr r, int r_hi_only) {
+    for (size_t i = (size_t)blockIdx.x * OP_THREADS + threadIdx.x; i < half; i += (size_t)gridDim.x * OP_THREADS)
+        fe_store(z + i, bind_pair(fe_load(z + i), fe_load(z + i + half), r, r_hi_only != 0));
+}
+
+// G[k] = sum_{j : idx_j = k} E[j]: one workgroup per k (K <= 65536, T * K index reads)
+__global__ __launch_bounds__(OP_THREADS) void k_onehot_G(const int32_t* __restrict__ idx, const Fr* __restrict__ E, size_t T,
+                                                         Fr* __restrict__ G) {
+    __shared__ Fr red[OP_THREADS / 64];
+    const int32_t k = (int32_t)blockIdx.x;
+    Fr acc = fe_zero();
+    for (size_t j = threadIdx.x; j < T; j += OP_THREADS)
+        if (idx[j] == k) acc = fr_add(acc, fe_load(E + j));
+    acc = fr_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Fr s = red[0];
+        for (int w = 1; w < OP_THREADS / 64; w++) s = fr_add(s, red[w]);
+        fe_store(G + k, s);
+    }
+}
+
+__global__ __launch_bounds__(OP_THREADS) void k_onehot_gather(const int32_t* __restrict__ idx, const Fr* __restrict__ F, size_t T,
+                                                              Fr* __restrict__ out) {
+    for (size_t j = (size_t)blockIdx.x * OP_THREADS + threadIdx.x; j < T; j += (size_t)gridDim.x * OP_THREADS) {
+        const int32_t k = idx[j];
+        fe_store(out + j, k < 0 ? fe_zero() : fe_load(F + k));
+    }
+}
+
+inline unsigned grid_for(size_t work, size_t cap = 2048) {
+    size_t b = (work + OP_THREADS - 1) / OP_THREADS;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (unsigned)b;
+}
+
+// device half of the HighToLow split-eq: suffix tables of w_in and w_out
+struct GseDevH {
+    H::GseStateH st;
+    Fr *d_w = nullptr, *d_ein = nullptr, *d_eout = nullptr, *d_part = nullptr, *d_sum = nullptr;
+    int init(const H::Fr* w, size_t n) {
+        st.init(w, n);
+        if (st.k_in > 13 || st.k_out > 13) return fail(ATLAS_EINVAL, "split-eq (HighToLow): more than 26 variables not supported");
+        HIP_TRY(hipMalloc(&d_w, (n ? n : 1) * sizeof(Fr)));
+        HIP_TRY(hipMalloc(&d_ein, ((size_t)2 << st.k_in) * sizeof(Fr)));
+        HIP_TRY(hipMalloc(&d_eout, ((size_t)2 << st.k_out) * sizeof(Fr)));
+        HIP_TRY(hipMalloc(&d_part, 2048 * sizeof(Fr)));
+        HIP_TRY(hipMalloc(&d_sum, sizeof(Fr)));
+        if (n) HIP_TRY(hipMemcpyAsync(d_w, w, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+        k_eq_cached_rev<<<1, 1024, 0, g.stream>>>(d_ein, d_w + (n ? 1 : 0), (uint32_t)st.k_in);
+        k_eq_cached_rev<<<1, 1024, 0, g.stream>>>(d_eout, d_w + (n ? 1 : 0) + st.k_in, (uint32_t)st.k_out);
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        return ATLAS_OK;
+    }
+    SplitEqView view() const {     // high index bits <- w_in suffix, low bits <- w_out suffix
+        SplitEqView E;
+        E.e_out = d_ein + (((size_t)1 << st.in_top) - 1);
+        E.e_in = d_eout + (((size_t)1 << st.out_top) - 1);
+        E.in_bits = (uint32_t)st.out_top;
+        return E;
+    }
+    // q(0) = sum over the lower half of P weighted by the current tables
+    template <class T>
+    int q0(const T* P, size_t half, H::Fr* out) {
+        const unsigned grid = grid_for(half);
+        k_open_fold<T><<<grid, OP_THREADS, 0, g.stream>>>(P, half, view(), d_part, make_consts());
+        k_open_reduce<<<1, OP_THREADS, 0, g.stream>>>(d_part, grid, d_sum);
+        HIP_TRY(hipMemcpyAsync(g.h_pinned, d_sum, sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        std::memcpy(out, g.h_pinned, sizeof(Fr));
+        return ATLAS_OK;
+    }
+    void release() { for (Fr* p : {d_w, d_ein, d_eout, d_part, d_sum}) if (p) hipFree(p); d_w = d_ein = d_eout = d_part = d_sum = nullptr; }
+};
+
+// ---------------------------------------------------------------- DensePolynomialProverOpening
+struct DenseOpening : atlas_instance {
+    atlas_poly_t P = nullptr;
+    GseDevH D;
+    size_t n = 0, round_next = 0;
+    ~DenseOpening() override { if (P) atlas_poly_free(P); D.release(); }
+    size_t rounds() const override { return n; }
+    size_t degree() const override { return 2; }
+    int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
+        if (round != round_next || round >= n) return fail(ATLAS_ESTATE, "dense_opening: round out of order");
+        H::Fr q0;
+        {
+            std::lock_guard<std::mutex> lk(g.mu);
+            const int rc = P->is_i32 ? D.q0<int32_t>((const int32_t*)P->d, P->len / 2, &q0) : D.q0<Fr>((const Fr*)P->d, P->len / 2, &q0);
+            if (rc) return rc;
+        }
+        coeffs.resize(3);
+        H::gruen_deg2(D.st.scalar, D.st.w_cur(), q0, claim, coeffs.data());
+        return ATLAS_OK;
+    }
+    int ingest(const atlas_u128_t& r, size_t round) override {
+        if (round != round_next || round >= n) return fail(ATLAS_ESTATE, "dense_opening: round out of order");
+        int rc = atlas_poly_bind(P, &r, ATLAS_HIGH_TO_LOW);
+        if (rc) return rc;
+        D.st.bind(H::challenge_to_fr(r.lo, r.hi, g.challenge_mode));
+        round_next++;
+        return ATLAS_OK;
+    }
+    int finals(std::vector<H::Fr>& out) override {
+        out.resize(1);
+        return atlas_poly_final_claim(P, (atlas_fr_t*)out.data());
+    }
+};
+
+// ---------------------------------------------------------------- OneHotPolynomialProverOpening
+struct OneHotOpening : atlas_instance {
+    size_t log_K = 0, log_T = 0, round_next = 0;
+    std::vector<H::Fr> B, F, G;          // eq(r_address, .) bound HighToLow; expanding table; histogram
+    int32_t* d_idx = nullptr;
+    Fr* d_H = nullptr;
+    size_t H_len = 0;
+    GseDevH D;
+    ~OneHotOpening() override { if (d_idx) hipFree(d_idx); if (d_H) hipFree(d_H); D.release(); }
+    size_t rounds() const override { return log_K + log_T; }
+    size_t degree() const override { return 2; }
+
+    int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
+        if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "onehot_opening: round out of order");
+        coeffs.assign(3, H::zero());
+        if (round < log_K) {                                         // opening_reduction.rs:583-633
+            const size_t unbound = log_K - round, K = (size_t)1 << log_K, half = B.size() / 2;
+            H::Fr e0 = H::zero(), e2 = H::zero();
+            for (size_t kp = 0; kp < half; kp++) {
+                const H::Fr b0 = B[kp], b2 = H::add(B[kp + half], H::sub(B[kp + half], b0));
+                H::Fr s0 = H::zero(), s2 = H::zero();
+                for (size_t k = kp; k < K; k += half) {
+                    const H::Fr gf = H::mul(G[k], F[k >> unbound]);
+                    if (((k >> (unbound - 1)) & 1) == 0) { s0 = H::add(s0, gf); s2 = H::sub(s2, gf); }
+                    else s2 = H::add(s2, H::add(gf, gf));
+                }
+                e0 = H::add(e0, H::mul(b0, s0)); e2 = H::add(e2, H::mul(b2, s2));
+            }
+            const H::Fr ev[2] = {e0, e2};
+            H::unipoly_from_evals_and_hint(claim, ev, 2, coeffs.data());
+            return ATLAS_OK;
+        }
+        H::Fr q0;                                                    // :634-676
+        {
+            std::lock_guard<std::mutex> lk(g.mu);
+            const int rc = D.q0<Fr>(d_H, H_len / 2, &q0);
+            if (rc) return rc;
+        }
+        const H::Fr eqa = B[0];
+        H::gruen_deg2(D.st.scalar, D.st.w_cur(), q0, H::mul(claim, H::inv(eqa)), coeffs.data());
+        for (auto& c : coeffs) c = H::mul(c, eqa);                   // UniPoly * F -> from_coeff
+        H::trim(coeffs);
+        return ATLAS_OK;
+    }
+
+    int ingest(const atlas_u128_t& r, size_t round) override {      // :679-718
+        if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "onehot_opening: round out of order");
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        if (round < log_K) {
+            const size_t half = B.size() / 2;
+            for (size_t i = 0; i < half; i++) B[i] = H::add(B[i], H::mul(rf, H::sub(B[i + half], B[i])));
+            B.resize(half);
+            std::vector<H::Fr> nf(2 * F.size());                     // ExpandingTable::update, HighToLow
+            for (size_t i = 0; i < F.size(); i++) { nf[2 * i + 1] = H::mul(rf, F[i]); nf[2 * i] = H::sub(F[i], nf[2 * i + 1]); }
+            F.swap(nf);
+            if (round == log_K - 1) {
+                std::lock_guard<std::mutex> lk(g.mu);
+                const size_t T = (size_t)1 << log_T;
+                Fr* d_F = nullptr;
+                HIP_TRY(hipMalloc(&d_F, F.size() * sizeof(Fr)));
+                HIP_TRY(hipMemcpyAsync(d_F, F.data(), F.size() * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+                k_onehot_gather<<<grid_for(T, 4096), OP_THREADS, 0, g.stream>>>(d_idx, d_F, T, d_H);
+                hipError_t e = hipStreamSynchronize(g.stream);
+                hipFree(d_F);
+                if (e != hipSuccess) return fail(ATLAS_ENODEV, "onehot_opening: gather", e);
+                H_len = T;
+                G.clear();
+            }
+        } else {
+            std::lock_guard<std::mutex> lk(g.mu);
+            const size_t half = H_len / 2;
+            k_open_bind_hi<<<grid_for(half, 4096), OP_THREADS, 0, g.stream>>>(d_H, half, to_dev(rf), g.challenge_mode == 0 ? 1 : 0);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return fail(ATLAS_ENODEV, "onehot_opening: bind", e);
+            H_len = half;
+            D.st.bind(rf);
+        }
+        round_next++;
+        return ATLAS_OK;
+    }
+
+    int finals(std::vector<H::Fr>& out) override {
+        if (round_next != rounds()) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
+        std::lock_guard<std::mutex> lk(g.mu);
+        out.resize(1);
+        HIP_TRY(hipMemcpyAsync(g.h_pinned, d_H, sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        std::memcpy(out.data(), g.h_pinned, sizeof(Fr));
+        return ATLAS_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int atlas_dense_opening_new(atlas_poly_t poly, const atlas_fr_t* opening_point, size_t n, atlas_instance_t* out) {
+    NEED_INIT();
+    if (!poly || (!opening_point && n) || !out) return fail(ATLAS_EINVAL, "dense_opening_new: null argument");
+    if (n == 0 || poly->len != ((size_t)1 << n)) return fail(ATLAS_EINVAL, "dense_opening_new: polynomial length != 2^n, n >= 1");
+    std::lock_guard<std::mutex> lk(g.mu);
+    DenseOpening* P = new DenseOpening();
+    P->n = n;
+    int rc = P->D.init(reinterpret_cast<const H::Fr*>(opening_point), n);
+    if (rc) { delete P; return rc; }
+    P->P = poly;                                                     // ownership moves (bound in place)
+    *out = P;
+    return ATLAS_OK;
+}
+
+int atlas_onehot_opening_new(const int32_t* nonzero_indices, size_t log_K, size_t log_T, const atlas_fr_t* r_address,
+                             const atlas_fr_t* r_cycle, atlas_instance_t* out) {
+    NEED_INIT();
+    if (!nonzero_indices || !r_address || !r_cycle || !out) return fail(ATLAS_EINVAL, "onehot_opening_new: null argument");
+    if (log_K == 0 || log_K > 16 || log_T == 0 || log_T > 26) return fail(ATLAS_EINVAL, "onehot_opening_new: 1 <= log_K <= 16, 1 <= log_T <= 26");
+    const size_t K = (size_t)1 << log_K, T = (size_t)1 << log_T;
+    // D.merge() before any bind = EqPolynomial::evals(r_cycle) (scalar 1): device table for the histogram
+    atlas_poly_t E = nullptr;
+    int rc = atlas_eq_evals(r_cycle, log_T, nullptr, &E);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g.mu);
+    OneHotOpening* P = new OneHotOpening();
+    P->log_K = log_K; P->log_T = log_T;
+    P->B = H::eq_evals(reinterpret_cast<const H::Fr*>(r_address), log_K);   // EqAddressState::new
+    P->F = {H::one()};
+    P->G.resize(K);
+    Fr* d_G = nullptr;
+    hipError_t e = hipMalloc(&P->d_idx, T * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&P->d_H, T * sizeof(Fr));
+    if (e == hipSuccess) e = hipMalloc(&d_G, K * sizeof(Fr));
+    if (e == hipSuccess) e = hipMemcpyAsync(P->d_idx, nonzero_indices, T * sizeof(int32_t), hipMemcpyHostToDevice, g.stream);
+    if (e == hipSuccess) {
+        k_onehot_G<<<(unsigned)K, OP_THREADS, 0, g.stream>>>(P->d_idx, (const Fr*)E->d, T, d_G);
+        e = hipMemcpyAsync(P->G.data(), d_G, K * sizeof(Fr), hipMemcpyDeviceToHost, g.stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    if (d_G) hipFree(d_G);
+    if (e != hipSuccess) { delete P; hipFree(E->d); delete E; return fail(ATLAS_ENODEV, "onehot_opening_new", e); }
+    hipFree(E->d); delete E;
+    rc = P->D.init(reinterpret_cast<const H::Fr*>(r_cycle), log_T);
+    if (rc) { delete P; return rc; }
+    *out = P;
+    return ATLAS_OK;
+}
+
+}  // extern "C"

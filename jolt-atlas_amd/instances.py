@@ -85,3 +85,21 @@ def hamming_weight(G, log_k_chunk, gamma_powers):
     h = C.c_void_p()
     _check(lib.atlas_hamming_weight_new(_p(G), C.c_size_t(len(gp)), C.c_size_t(log_k_chunk), _p(gp), C.byref(h)))
     return Instance(h)
+
+
+def dense_opening(poly, opening_point):
+    """DensePolynomialProverOpening over a device polynomial (ownership moves)."""
+    pt = np.ascontiguousarray(opening_point, dtype=np.uint64)
+    h = C.c_void_p()
+    _check(lib.atlas_dense_opening_new(poly.h, _p(pt), C.c_size_t(len(pt)), C.byref(h)))
+    poly.h = None
+    return Instance(h)
+
+
+def onehot_opening(nonzero_indices, log_K, r_address, r_cycle):
+    idx = np.ascontiguousarray(nonzero_indices, dtype=np.int32)
+    ra = np.ascontiguousarray(r_address, dtype=np.uint64); rc = np.ascontiguousarray(r_cycle, dtype=np.uint64)
+    h = C.c_void_p()
+    _check(lib.atlas_onehot_opening_new(idx.ctypes.data_as(C.c_void_p), C.c_size_t(log_K), C.c_size_t(len(rc)), _p(ra), _p(rc),
+                                        C.byref(h)))
+    return Instance(h)

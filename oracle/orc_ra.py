@@ -84,3 +84,24 @@ def ra_G(H_indices, log_k, r_cycle):
             if k >= 0:
                 out[i, k] = orc.fr_add_arr(out[i, k], E[j])
     return out
+
+
+DENSE_OPENING, ONEHOT_OPENING = 5, 6
+
+
+def dense_opening(poly, point):
+    """DensePolynomialProverOpening: poly (2^n, 4) Fr, point (n, 4) Fr."""
+    poly = np.ascontiguousarray(poly, dtype=np.uint64); point = np.ascontiguousarray(point, dtype=np.uint64)
+    I = Instance(DENSE_OPENING, len(point))
+    I.keep = [poly, point]
+    orc.lib.orc_dense_opening_init(I.st, orc._p(poly), C.c_size_t(len(point)), orc._p(point))
+    return I
+
+
+def onehot_opening(idx, log_K, r_address, r_cycle):
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    ra = np.ascontiguousarray(r_address, dtype=np.uint64); rc = np.ascontiguousarray(r_cycle, dtype=np.uint64)
+    I = Instance(ONEHOT_OPENING, log_K + len(rc))
+    I.keep = [idx, ra, rc]
+    orc.lib.orc_onehot_opening_init(I.st, idx.ctypes.data_as(C.c_void_p), C.c_size_t(log_K), C.c_size_t(len(rc)), orc._p(ra), orc._p(rc))
+    return I

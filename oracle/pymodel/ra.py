@@ -156,3 +156,78 @@ class HammingModel:
 
     def finals(self):
         return [ra[0] for ra in self.ra]
+
+
+H2L = P.HIGH_TO_LOW
+
+
+def _ext_h(z, i, npts):
+    """values at X = 0..npts-1 of the HighToLow restriction of table z at index i."""
+    n = len(z) // 2
+    a, b = z[i], z[i + n]
+    m = (b - a) % FR
+    return [(a + x * m) % FR for x in range(npts)]
+
+
+class DenseOpeningModel:
+    """sum_j eq(point, j) P(j), HighToLow, degree 2 (opening_reduction.rs:355-425), naive."""
+
+    def __init__(self, poly, point):
+        self.P = list(poly)
+        self.eq = P.eq_evals(point)
+        self._n = len(point)
+
+    def num_rounds(self):
+        return self._n
+
+    def compute_message(self, rnd, previous_claim):
+        ev = [0, 0, 0]
+        for i in range(len(self.P) // 2):
+            e, p = _ext_h(self.eq, i, 3), _ext_h(self.P, i, 3)
+            for x in range(3):
+                ev[x] = (ev[x] + e[x] * p[x]) % FR
+        assert (ev[0] + ev[1]) % FR == previous_claim % FR
+        return interpolate(ev)                       # UniPoly::from_evals of 3 points: fixed length
+
+    def ingest_challenge(self, r, rnd):
+        self.P = P.bind(self.P, r, H2L)
+        self.eq = P.bind(self.eq, r, H2L)
+
+    def finals(self):
+        return [self.P[0]]
+
+
+class OneHotOpeningModel:
+    """sum_{k,j} eq(r_address,k) eq(r_cycle,j) [idx_j = k]; address variables first, everything
+    HighToLow (opening_reduction.rs:532-723), naive over the K*T table (index k*T + j)."""
+
+    def __init__(self, idx, log_K, r_address, r_cycle):
+        K, T = 1 << log_K, len(idx)
+        self.log_K = log_K
+        ea, ec = P.eq_evals(r_address), P.eq_evals(r_cycle)
+        self.eq = [ea[k] * ec[j] % FR for k in range(K) for j in range(T)]
+        self.ra = [1 if idx[j] == k else 0 for k in range(K) for j in range(T)]
+        self._n = log_K + len(r_cycle)
+
+    def num_rounds(self):
+        return self._n
+
+    def input_claim(self):
+        return sum(e * a for e, a in zip(self.eq, self.ra)) % FR
+
+    def compute_message(self, rnd, previous_claim):
+        ev = [0, 0, 0]
+        for i in range(len(self.eq) // 2):
+            e, p = _ext_h(self.eq, i, 3), _ext_h(self.ra, i, 3)
+            for x in range(3):
+                ev[x] = (ev[x] + e[x] * p[x]) % FR
+        assert (ev[0] + ev[1]) % FR == previous_claim % FR
+        c = interpolate(ev)
+        return c if rnd < self.log_K else from_coeff(c)
+
+    def ingest_challenge(self, r, rnd):
+        self.eq = P.bind(self.eq, r, H2L)
+        self.ra = P.bind(self.ra, r, H2L)
+
+    def finals(self):
+        return [self.ra[0]]

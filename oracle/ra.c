@@ -14,6 +14,7 @@
 #include <string.h>
 #include "oracle.h"
 #include "ra.h"
+#include "opening.h"
 
 /* ------------------------------------------------------------------ small helpers */
 static size_t trim(fr_t *c, size_t n) {                 /* UniPoly::from_coeff (unipoly.rs:39-52) */
@@ -329,6 +330,8 @@ static size_t inst_message(int kind, void *st, size_t round, const fr_t *claim, 
     switch (kind) {
         case ORC_INST_RA_VIRTUAL: return orc_ra_virtual_message((orc_ra_virtual *)st, claim, c);
         case ORC_INST_BOOLEANITY: return orc_booleanity_message((orc_booleanity *)st, round, claim, c);
+        case ORC_INST_DENSE_OPENING: return orc_dense_opening_message((orc_dense_opening *)st, claim, c);
+        case ORC_INST_ONEHOT_OPENING: return orc_onehot_opening_message((orc_onehot_opening *)st, round, claim, c);
         default: return orc_hamming_message((orc_hamming *)st, claim, c);
     }
 }
@@ -336,6 +339,8 @@ static void inst_ingest(int kind, void *st, size_t round, const fr_t *r) {
     switch (kind) {
         case ORC_INST_RA_VIRTUAL: orc_ra_virtual_ingest((orc_ra_virtual *)st, r); break;
         case ORC_INST_BOOLEANITY: orc_booleanity_ingest((orc_booleanity *)st, round, r); break;
+        case ORC_INST_DENSE_OPENING: orc_dense_opening_ingest((orc_dense_opening *)st, r); break;
+        case ORC_INST_ONEHOT_OPENING: orc_onehot_opening_ingest((orc_onehot_opening *)st, round, r); break;
         default: orc_hamming_ingest((orc_hamming *)st, r); break;
     }
 }

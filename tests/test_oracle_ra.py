@@ -128,3 +128,32 @@ def test_batched_mix_of_ra_instances_matches_python_model():
     assert raw_o == raw_p
     assert [orc.to_ints(r) for r in rows_o] == rows_p
     assert bytes(to.state) == tp.state
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7])
+def test_dense_opening_oracle_matches_naive_model(n):
+    poly, point = _rand(1 << n, 31 + n), _rand(n, 32 + n)
+    model = PR.DenseOpeningModel(poly, point)
+    claim = sum(e * p for e, p in zip(model.eq, poly)) % F.FR
+    rows_p, raw_p, tp = _prove_py(model, claim, b"dense_opening")
+    inst = OR.dense_opening(orc.from_ints(poly), orc.from_ints(point))
+    to = orc.new_transcript(b"dense_opening")
+    rows_o, raw_o = inst.prove(orc.from_ints([claim])[0], to)
+    assert raw_o == raw_p
+    assert [orc.to_ints(r) for r in rows_o] == rows_p
+    assert bytes(to.state) == tp.state
+
+
+@pytest.mark.parametrize("log_K,log_T", [(1, 1), (2, 3), (4, 2), (4, 5), (3, 4), (8, 1)])
+def test_onehot_opening_oracle_matches_naive_model(log_K, log_T):
+    idx = _indices(1, 1 << log_T, 1 << log_K, 5 * log_K + log_T)[0]
+    r_address, r_cycle = _rand(log_K, 41), _rand(log_T, 42)
+    model = PR.OneHotOpeningModel(list(map(int, idx)), log_K, r_address, r_cycle)
+    claim = model.input_claim()
+    rows_p, raw_p, tp = _prove_py(model, claim, b"onehot_opening")
+    inst = OR.onehot_opening(idx, log_K, orc.from_ints(r_address), orc.from_ints(r_cycle))
+    to = orc.new_transcript(b"onehot_opening")
+    rows_o, raw_o = inst.prove(orc.from_ints([claim])[0], to)
+    assert raw_o == raw_p
+    assert [orc.to_ints(r) for r in rows_o] == rows_p
+    assert bytes(to.state) == tp.state
