@@ -240,6 +240,16 @@ int atlas_ra_virtual_new(const int32_t *const *H_indices, size_t d, size_t log_k
 int atlas_booleanity_new(const atlas_fr_t *G, const int32_t *const *H_indices, size_t d,
                          size_t log_k_chunk, size_t log_T, const atlas_fr_t *gammas,
                          const atlas_fr_t *r_address, const atlas_fr_t *r_cycle, atlas_instance_t *out);
+/* ---- N-to-1 evaluation reduction: EvalReductionInstance::prove with compute_h and eval_on_l
+ *      (joltworks/src/subprotocols/evaluation_reduction.rs:91-147, 213-249).  points = N rows of n
+ *      Fr (the opening points of one polynomial), claims = N Fr.  h(t) = P(l(t)) is returned as
+ *      trimmed monomial coefficients (at most n (N-1) + 1), appended to the transcript uncompressed,
+ *      then r' = l(x'), v' = h(x') for the drawn x'.  mle is not consumed.  N = 1 is the short path
+ *      (h = [claim], transcript untouched). ------------------------------------------------------ */
+int atlas_eval_reduction_prove(atlas_poly_t mle, const atlas_fr_t *points, const atlas_fr_t *claims,
+                               size_t N, size_t n, atlas_transcript_t *transcript, atlas_fr_t *h_out,
+                               size_t h_cap, size_t *h_len, atlas_fr_t *r_out, atlas_fr_t *claim_out);
+
 /* ---- opening-reduction provers (joltworks/src/subprotocols/opening_reduction.rs), the instances
  *      ProverOpeningAccumulator::prove_batch_opening_sumcheck batches (poly/opening_proof.rs:447-532).
  *      Both bind HighToLow over the HighToLow GruenSplitEqPolynomial, degree 2. ------------------ */

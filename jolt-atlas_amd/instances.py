@@ -103,3 +103,16 @@ def onehot_opening(nonzero_indices, log_K, r_address, r_cycle):
     _check(lib.atlas_onehot_opening_new(idx.ctypes.data_as(C.c_void_p), C.c_size_t(log_K), C.c_size_t(len(rc)), _p(ra), _p(rc),
                                         C.byref(h)))
     return Instance(h)
+
+
+def eval_reduction_prove(mle, points, claims, transcript):
+    """EvalReductionInstance::prove (evaluation_reduction.rs:91-147). points (N, n, 4).
+    Returns (h (len,4), r' (n,4), v' (4,))."""
+    pts = np.ascontiguousarray(points, dtype=np.uint64); cl = np.ascontiguousarray(claims, dtype=np.uint64)
+    N, n = pts.shape[0], pts.shape[1]
+    cap = n * max(N - 1, 1) + 1
+    h = np.zeros((cap, 4), dtype=np.uint64); hl = C.c_size_t()
+    r = np.zeros((max(n, 1), 4), dtype=np.uint64); c = np.zeros(4, dtype=np.uint64)
+    _check(lib.atlas_eval_reduction_prove(mle.h, _p(pts), _p(cl), C.c_size_t(N), C.c_size_t(n), C.byref(transcript.t), _p(h),
+                                          C.c_size_t(cap), C.byref(hl), _p(r), _p(c)))
+    return h[:hl.value].copy(), r[:n].copy(), c

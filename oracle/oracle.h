@@ -111,6 +111,10 @@ void g1_mul_fr(const g1_aff_t *p, const fr_t *s, g1_aff_t *o);
 void orc_msm_naive(const g1_aff_t *bases, const fr_t *scalars, size_t n, g1_aff_t *out);
 void orc_msm_pippenger(const g1_aff_t *bases, const fr_t *scalars, size_t n, g1_aff_t *out);
 void orc_g1_sum_indexed(const g1_aff_t *bases, const uint64_t *idx, size_t n, g1_aff_t *out);
+/* EvalReductionInstance::prove (subprotocols/evaluation_reduction.rs:91-147): points = N rows of n Fr,
+ * h_out capacity n*(N-1)+1; returns h, the reduced point l(x') and claim h(x') */
+int orc_eval_reduction_prove(const fr_t *mle, size_t n, const fr_t *points, const fr_t *claims, size_t N,
+                             orc_transcript *t, fr_t *h_out, size_t *h_len, fr_t *r_out, fr_t *claim_out);
 /* build_materialized_rlc (poly/rlc_polynomial.rs:13-78) */
 void orc_rlc_build(const fr_t *const *dense_fr, const int32_t *const *dense_i32, const size_t *dense_len,
                    const fr_t *dense_coeff, size_t n_dense, const int32_t *const *oh_k, const size_t *oh_T,

@@ -105,3 +105,16 @@ def onehot_opening(idx, log_K, r_address, r_cycle):
     I.keep = [idx, ra, rc]
     orc.lib.orc_onehot_opening_init(I.st, idx.ctypes.data_as(C.c_void_p), C.c_size_t(log_K), C.c_size_t(len(rc)), orc._p(ra), orc._p(rc))
     return I
+
+
+def eval_reduction_prove(mle, points, claims, t):
+    """EvalReductionInstance::prove. points (N, n, 4). Returns (h (len,4), r (n,4), claim (4,))."""
+    mle = np.ascontiguousarray(mle, dtype=np.uint64); pts = np.ascontiguousarray(points, dtype=np.uint64)
+    cl = np.ascontiguousarray(claims, dtype=np.uint64)
+    N, n = pts.shape[0], pts.shape[1]
+    h = orc.fr_array(n * max(N - 1, 1) + 1); hl = C.c_size_t(); r = orc.fr_array(max(n, 1)); c = orc.fr_array(1)
+    orc.lib.orc_eval_reduction_prove.restype = C.c_int
+    rc = orc.lib.orc_eval_reduction_prove(orc._p(mle), C.c_size_t(n), orc._p(pts), orc._p(cl), C.c_size_t(N), C.byref(t),
+                                          orc._p(h), C.byref(hl), orc._p(r), orc._p(c))
+    assert rc == 0
+    return h[:hl.value].copy(), r[:n].copy(), c[0].copy()

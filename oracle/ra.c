@@ -25,7 +25,7 @@ static size_t trim(fr_t *c, size_t n) {                 /* UniPoly::from_coeff (
 }
 
 /* solve the n x n system rows[i][0..n) * c = rows[i][n] (unique solution; any pivoting) */
-static void gauss_solve(fr_t *m, size_t n, fr_t *c) {
+void orc_gauss_solve(fr_t *m, size_t n, fr_t *c) {
     const size_t W = n + 1;
     fr_t z; fr_zero(&z);
     for (size_t col = 0; col < n; col++) {
@@ -56,7 +56,7 @@ void orc_unipoly_from_evals_toom(const fr_t *evals, size_t n, fr_t *coeffs) {
     }
     fr_one(&m[(n - 1) * W + n - 1]);
     m[(n - 1) * W + n] = evals[n - 1];
-    gauss_solve(m, n, coeffs);
+    orc_gauss_solve(m, n, coeffs);
     free(m);
 }
 

@@ -157,3 +157,55 @@ def test_onehot_opening_oracle_matches_naive_model(log_K, log_T):
     assert raw_o == raw_p
     assert [orc.to_ints(r) for r in rows_o] == rows_p
     assert bytes(to.state) == tp.state
+
+
+@pytest.mark.parametrize("n,N", [(1, 2), (3, 2), (4, 3), (3, 4), (2, 5), (5, 3)])
+def test_eval_reduction_oracle_properties(n, N):
+    """h(i) = claim_i, h(t) = P(l(t)) at a random t, degree bound, and the reduced claim P(r') = v'
+    (evaluation_reduction.rs:129-137, 186-204), all checked with the plain-int model."""
+    from oracle.pymodel import poly as P
+    mle = _rand(1 << n, 61 + n)
+    pts = [_rand(n, 70 + j) for j in range(N)]
+    claims = [P.evaluate(mle, p) for p in pts]
+    to = orc.new_transcript(b"eval_reduction")
+    h, r, c = OR.eval_reduction_prove(orc.from_ints(mle), np.stack([orc.from_ints(p) for p in pts]), orc.from_ints(claims), to)
+    hc = orc.to_ints(h)
+    assert len(hc) <= n * (N - 1) + 1 and len(hc) == n * (N - 1) + 1      # generic inputs reach the bound
+    ev = lambda t: sum(cf * pow(t, k, F.FR) for k, cf in enumerate(hc)) % F.FR
+    for i in range(N):
+        assert ev(i) == claims[i]
+    # l(t): per-variable interpolation through (j, pts[j][i])
+    tt = _rand(1, 5)[0]
+    lt = [sum(cf * pow(tt, k, F.FR) for k, cf in enumerate(PR.interpolate([pts[j][i] for j in range(N)]))) % F.FR for i in range(n)]
+    assert ev(tt) == P.evaluate(mle, lt)
+    # transcript + reduced instance
+    tp = Blake2bTranscript(b"eval_reduction")
+    tp.append_message(b"UncompressedUniPoly_begin")
+    for cf in hc:
+        tp.append_scalar(cf)
+    tp.append_message(b"UncompressedUniPoly_end")
+    x = F.challenge_to_fr(tp.challenge_u128())
+    assert bytes(to.state) == tp.state
+    rr = orc.to_ints(r)
+    assert rr == [sum(cf * pow(x, k, F.FR) for k, cf in enumerate(PR.interpolate([pts[j][i] for j in range(N)]))) % F.FR for i in range(n)]
+    assert orc.to_ints(c)[0] == ev(x) == P.evaluate(mle, rr)
+
+
+def test_eval_reduction_structured_inputs_trim():
+    """zero-padded coefficients and points sharing coordinates: h is the trimmed exact polynomial."""
+    from oracle.pymodel import poly as P
+    n, N = 3, 3
+    mle = _rand(3, 1) + [0] * 5
+    base = _rand(n, 2)
+    pts = [list(base), [base[0], _rand(1, 3)[0], base[2]], [base[0], _rand(1, 4)[0], base[2]]]
+    claims = [P.evaluate(mle, p) for p in pts]
+    to = orc.new_transcript(b"eval_reduction")
+    h, r, c = OR.eval_reduction_prove(orc.from_ints(mle), np.stack([orc.from_ints(p) for p in pts]), orc.from_ints(claims), to)
+    hc = orc.to_ints(h)
+    assert hc[-1] != 0 or hc == [0]
+    assert len(hc) <= 1 * (N - 1) + 1          # only variable 1 moves along l
+    assert P.evaluate(mle, orc.to_ints(r)) == orc.to_ints(c)[0]
+    # single opening: short path, no transcript interaction
+    t1 = orc.new_transcript(b"x")
+    h1, r1, c1 = OR.eval_reduction_prove(orc.from_ints(mle), np.stack([orc.from_ints(pts[0])]), orc.from_ints(claims[:1]), t1)
+    assert orc.to_ints(h1) == [claims[0]] and orc.to_ints(r1) == pts[0] and t1.n_rounds == 0
