@@ -89,7 +89,7 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
     const size_t o_sorted = carve(n * (size_t)S.n_windows * 4);
     // few buckets (narrow scalars): SEG threads share a bucket, partials summed afterwards
     uint32_t seg = 1;
-    while (seg < 256 && (size_t)TB * seg < 32768 && (size_t)TB * seg * 64 < n * (size_t)S.n_windows) seg <<= 1;
+    while (seg < 256 && (size_t)TB * seg < 131072 && (size_t)TB * seg * 32 < n * (size_t)S.n_windows) seg <<= 1;
     const size_t o_partial = carve(seg > 1 ? (size_t)TB * seg * sizeof(G1Xyzz) : 0);
     const size_t o_buckets = carve((size_t)TB * sizeof(G1Xyzz));
     const size_t o_chunks = carve((size_t)n_chunks * sizeof(G1Xyzz));
@@ -116,18 +116,24 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
     HIP_TRY(hipMemsetAsync(counts, 0, (size_t)(TB + 1) * 4, g.stream));
     // signed digits once, window-major; histogram of all windows; scan; scatter window by window
     launch_digits(digits);
-    k_msm_hist_w<<<dim3((unsigned)grid_for(n, 256), S.n_windows), MSM_THREADS, 0, g.stream>>>(digits, n, S, counts);
+    const bool lds_sort = S.bpw <= MSM_LDS_BPW;
+    const unsigned n_tiles = (unsigned)((n + MSM_TILE - 1) / MSM_TILE);
+    if (lds_sort) k_msm_hist_lds<<<dim3(n_tiles, S.n_windows), MSM_THREADS, 0, g.stream>>>(digits, n, S, counts);
+    else k_msm_hist_w<<<dim3((unsigned)grid_for(n, 256), S.n_windows), MSM_THREADS, 0, g.stream>>>(digits, n, S, counts);
     k_scan_block_sums<<<(unsigned)n_scan_blocks, 256, 0, g.stream>>>(counts, TB, bsum);
     k_exclusive_scan<<<1, 1024, 0, g.stream>>>(bsum, (uint32_t)n_scan_blocks, boff, bcur);
     k_scan_apply<<<(unsigned)n_scan_blocks, 256, 0, g.stream>>>(counts, TB, boff, offsets, cursor, (uint32_t)n_scan_blocks);
-    for (uint32_t w = 0; w < S.n_windows; w++)
-        k_msm_scatter_w<<<grid_for(n, 1024), MSM_THREADS, 0, g.stream>>>(digits + (size_t)w * n, n, cursor + (size_t)w * S.bpw, sorted);
+    for (uint32_t w = 0; w < S.n_windows; w++) {
+        if (lds_sort) k_msm_scatter_lds<<<n_tiles, MSM_THREADS, 0, g.stream>>>(digits + (size_t)w * n, n, S.bpw, cursor + (size_t)w * S.bpw, sorted);
+        else k_msm_scatter_w<<<grid_for(n, 1024), MSM_THREADS, 0, g.stream>>>(digits + (size_t)w * n, n, cursor + (size_t)w * S.bpw, sorted);
+    }
     if (g.timing) hipEventRecord(e1, g.stream);
     if (seg == 1) {
         k_msm_accumulate<<<(TB + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, g.stream>>>(bases, sorted, offsets, TB, 1, buckets);
     } else {
         k_msm_accumulate<<<(TB * seg + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, g.stream>>>(bases, sorted, offsets, TB, seg, partial);
-        k_g1_seg_sum<<<(TB + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, g.stream>>>(partial, seg, TB, buckets);
+        if (seg >= 8) k_g1_group_sum<<<TB, MSM_THREADS, 0, g.stream>>>(partial, seg, buckets);   // one workgroup per bucket
+        else k_g1_seg_sum<<<(TB + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, g.stream>>>(partial, seg, TB, buckets);
     }
     if (g.timing) hipEventRecord(e2, g.stream);
     k_msm_fold_chunks<<<(n_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, g.stream>>>(buckets, S, chunk, n_chunks, chunks);

@@ -21,7 +21,7 @@
 namespace atlas {
 
 constexpr int MSM_THREADS = 256;
-constexpr int MSM_CHUNK = 32;          // buckets folded by one thread in the reduce step
+constexpr int MSM_CHUNK = 8;           // buckets folded by one thread in the reduce step
 
 struct MsmShape {
     uint32_t c;          // window bits (<= 16)
@@ -93,6 +93,58 @@ __global__ __launch_bounds__(MSM_THREADS) void k_msm_hist_w(const int16_t* __res
     for (size_t i = (size_t)blockIdx.x * MSM_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * MSM_THREADS) {
         const int32_t d = dw[i];
         if (d) atomicAdd(&cw[(d < 0 ? -d : d) - 1], 1u);
+    }
+}
+
+// ---- few-bucket plans (narrow scalars, bpw <= 4096): the global counters of a window would be hit
+// by every element, so counts and ranks are taken in LDS per workgroup tile and only one global
+// atomic per (workgroup, non-empty bucket) remains.
+constexpr uint32_t MSM_LDS_BPW = 4096;
+constexpr uint32_t MSM_TILE = 16384;      // elements per workgroup tile
+
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_hist_lds(const int16_t* __restrict__ digits, size_t n, MsmShape S,
+                                                              uint32_t* counts) {
+    __shared__ uint32_t h[MSM_LDS_BPW];
+    const uint32_t w = blockIdx.y;
+    for (uint32_t b = threadIdx.x; b < S.bpw; b += MSM_THREADS) h[b] = 0;
+    __syncthreads();
+    const int16_t* dw = digits + (size_t)w * n;
+    const size_t t0 = (size_t)blockIdx.x * MSM_TILE, t1 = t0 + MSM_TILE < n ? t0 + MSM_TILE : n;
+    for (size_t i = t0 + threadIdx.x; i < t1; i += MSM_THREADS) {
+        const int32_t d = dw[i];
+        if (d) atomicAdd(&h[(d < 0 ? -d : d) - 1], 1u);
+    }
+    __syncthreads();
+    uint32_t* cw = counts + (size_t)w * S.bpw;
+    for (uint32_t b = threadIdx.x; b < S.bpw; b += MSM_THREADS)
+        if (h[b]) atomicAdd(&cw[b], h[b]);
+}
+
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_scatter_lds(const int16_t* __restrict__ dw, size_t n, uint32_t bpw,
+                                                                 uint32_t* cursor_w, uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t cnt[MSM_LDS_BPW];
+    __shared__ uint32_t base[MSM_LDS_BPW];
+    for (uint32_t b = threadIdx.x; b < bpw; b += MSM_THREADS) cnt[b] = 0;
+    __syncthreads();
+    const size_t t0 = (size_t)blockIdx.x * MSM_TILE, t1 = t0 + MSM_TILE < n ? t0 + MSM_TILE : n;
+    for (size_t i = t0 + threadIdx.x; i < t1; i += MSM_THREADS) {
+        const int32_t d = dw[i];
+        if (d) atomicAdd(&cnt[(d < 0 ? -d : d) - 1], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < bpw; b += MSM_THREADS) {
+        const uint32_t c = cnt[b];
+        base[b] = c ? atomicAdd(&cursor_w[b], c) : 0u;
+        cnt[b] = 0;
+    }
+    __syncthreads();
+    for (size_t i = t0 + threadIdx.x; i < t1; i += MSM_THREADS) {
+        const int32_t d = dw[i];
+        if (d) {
+            const uint32_t b = (uint32_t)((d < 0 ? -d : d) - 1);
+            const uint32_t r = atomicAdd(&cnt[b], 1u);
+            sorted[base[b] + r] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+        }
     }
 }
 

@@ -1,6 +1,6 @@
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import jolt_atlas_amd as A
 A.init(0)
 k, n = 768, 65536

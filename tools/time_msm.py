@@ -1,5 +1,5 @@
 import sys
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 import jolt_atlas_amd as A
 A.init(0)
