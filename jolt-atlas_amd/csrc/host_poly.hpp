@@ -8,6 +8,8 @@
 //   GruenSplitEqPolynomial::{new,bind} (LowToHigh) poly/split_eq_poly.rs:97-121,331-348
 #pragma once
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "host_field.hpp"
@@ -41,19 +43,48 @@ inline std::vector<Fr> gauss_solve(std::vector<std::vector<Fr>>& m) {
     return c;
 }
 
-// evals on [0, 1, ..., n-2, inf] -> n coefficients
-inline std::vector<Fr> from_evals_toom(const std::vector<Fr>& evals) {
-    const size_t n = evals.size();
-    std::vector<std::vector<Fr>> m(n, std::vector<Fr>(n + 1, zero()));
+// evals on [0, 1, ..., n-2, inf] -> n coefficients.  The system matrix depends on n only, so its
+// inverse is computed once per n (Gauss-Jordan on [A | I]) and a call is an n x n matrix-vector
+// product; the solution of a non-singular system does not depend on how it is solved.
+inline const std::vector<std::vector<Fr>>& toom_inverse(size_t n) {
+    static std::mutex mu;
+    static std::map<size_t, std::vector<std::vector<Fr>>> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(n);
+    if (it != cache.end()) return it->second;
+    const Fr z = zero();
+    std::vector<std::vector<Fr>> m(n, std::vector<Fr>(2 * n, z));
     for (size_t i = 0; i + 1 < n; i++) {
         const Fr x = from_u64(i);
         m[i][0] = one();
         for (size_t j = 1; j < n; j++) m[i][j] = mul(m[i][j - 1], x);
-        m[i][n] = evals[i];
     }
     m[n - 1][n - 1] = one();
-    m[n - 1][n] = evals[n - 1];
-    return gauss_solve(m);
+    for (size_t i = 0; i < n; i++) m[i][n + i] = one();
+    for (size_t col = 0; col < n; col++) {
+        size_t piv = col;
+        while (m[piv][col] == z) piv++;
+        if (piv != col) std::swap(m[piv], m[col]);
+        const Fr iv = inv(m[col][col]);
+        for (size_t k = 0; k < 2 * n; k++) m[col][k] = mul(m[col][k], iv);
+        for (size_t r = 0; r < n; r++) {
+            if (r == col || m[r][col] == z) continue;
+            const Fr f = m[r][col];
+            for (size_t k = 0; k < 2 * n; k++) m[r][k] = sub(m[r][k], mul(f, m[col][k]));
+        }
+    }
+    std::vector<std::vector<Fr>> invm(n, std::vector<Fr>(n));
+    for (size_t i = 0; i < n; i++) for (size_t j = 0; j < n; j++) invm[i][j] = m[i][n + j];
+    return cache.emplace(n, std::move(invm)).first->second;
+}
+
+inline std::vector<Fr> from_evals_toom(const std::vector<Fr>& evals) {
+    const size_t n = evals.size();
+    const auto& M = toom_inverse(n);
+    std::vector<Fr> c(n, zero());
+    for (size_t i = 0; i < n; i++)
+        for (size_t j = 0; j < n; j++) c[i] = add(c[i], mul(M[i][j], evals[j]));
+    return c;
 }
 
 // LowToHigh GruenSplitEqPolynomial bookkeeping that lives on the host: w, current_scalar, the

@@ -27,6 +27,7 @@
 #include "runtime.hpp"
 #include "sc_consts.hpp"
 #include "spliteq_kernels.hip.h"
+#include "f9.hip.h"
 
 using namespace atlas;
 namespace H = atlas_host;
@@ -65,37 +66,52 @@ __device__ __forceinline__ Fr gse_weight(const SplitEqView& E, size_t gidx) {
 
 // compute_mles_product_sum_evals_generic: per pair index g the product of the D lines
 // p_i(X) = ra_i[2g] + X (ra_i[2g+1] - ra_i[2g]) on the grid [1, ..., D-1, inf], weighted by
-// E_out * E_in.  One g per thread (D running products = 8 D VGPRs), block sums to partials.
-template <int D>
-__global__ __launch_bounds__(RA_THREADS) void k_ra_prod(const Fr* __restrict__ ra, size_t stride, SplitEqView E,
-                                                        size_t n_groups, Fr* __restrict__ partials) {
+// E_out * E_in.  One g per thread; the KN running products of grid columns [K0, K0 + KN) live in
+// registers as 9 x 29-bit lazy limbs (f9.hip.h), so a launch covers at most 8 columns and D > 8
+// takes two launches (the rows are re-read through L2).  Every f9_mul carries 2^-5 relative to
+// the Montgomery radix: a stored sum is 32^-(D+1) times the true one, undone on the host.
+template <int D, int K0, int KN>
+__global__ __launch_bounds__(RA_THREADS) void k_ra_prod_f9(const Fr* __restrict__ ra, size_t stride, SplitEqView E,
+                                                           size_t n_groups, Fr* __restrict__ partials) {
+    using P9 = Fr9Params;
     const size_t gidx = (size_t)blockIdx.x * RA_THREADS + threadIdx.x;
-    Fr prod[D];
+    F9 prod[KN];
+#pragma unroll
+    for (int k = 0; k < KN; k++) prod[k] = f9_zero();
     if (gidx < n_groups) {
-        {
-            Fr cur = fe_load(ra + 2 * gidx);
-            const Fr dl = fr_sub(fe_load(ra + 2 * gidx + 1), cur);
-#pragma unroll
-            for (int k = 0; k < D - 1; k++) { cur = fr_add(cur, dl); prod[k] = cur; }
-            prod[D - 1] = dl;
-        }
+        const size_t mask = ((size_t)1 << E.in_bits) - 1;
+        const F9 wgt = f9_mul<P9>(f9_load(E.e_out + (gidx >> E.in_bits)), f9_load(E.e_in + (gidx & mask)));
+        // iteration D multiplies the weight in (kept inside the one loop: the running products stay in VGPRs)
 #pragma unroll 1
-        for (int i = 1; i < D; i++) {
-            const Fr* row = ra + (size_t)i * stride;
-            Fr cur = fe_load(row + 2 * gidx);
-            const Fr dl = fr_sub(fe_load(row + 2 * gidx + 1), cur);
+        for (int i = 0; i <= D; i++) {
+            const Fr* row = ra + (size_t)(i < D ? i : 0) * stride + 2 * gidx;
+            const F9 a0 = f9_load(row), a1 = f9_load(row + 1);
+            const F9 dl = f9_norm_red<P9, 2>(f9_sub<P9>(a1, a0));          // a1 - a0 (+4p), < 2.1p
+            F9 cur = a0;
 #pragma unroll
-            for (int k = 0; k < D - 1; k++) { cur = fr_add(cur, dl); prod[k] = fr_mul(prod[k], cur); }
-            prod[D - 1] = fr_mul(prod[D - 1], dl);
+            for (int s = 0; s < K0 + 1; s++) cur = f9_norm_red<P9, 2>(f9_add(cur, dl));   // p_i(K0 + 1)
+#pragma unroll
+            for (int k = 0; k < KN; k++) {
+                const bool inf = (K0 + k == D - 1);                             // column D-1 = X -> inf
+                const F9 val = i == D ? wgt : (inf ? dl : cur);
+                if (!inf) cur = f9_norm_red<P9, 2>(f9_add(cur, dl));
+                prod[k] = i == 0 ? val : f9_mul<P9>(prod[k], val);
+            }
         }
-        const Fr wgt = gse_weight(E, gidx);
-#pragma unroll
-        for (int k = 0; k < D; k++) prod[k] = fr_mul(prod[k], wgt);
-    } else {
-#pragma unroll
-        for (int k = 0; k < D; k++) prod[k] = fe_zero();
     }
-    block_reduce_store<D>(prod, partials);
+    __shared__ F9 red9[RA_THREADS / 64][KN];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < KN; k++) {
+        const F9 sres = f9_wave_sum<P9>(prod[k]);
+        if (lane == 0) red9[wave][k] = sres;
+    }
+    __syncthreads();
+    if (threadIdx.x < KN) {
+        F9 sres = red9[0][threadIdx.x];
+        for (int w = 1; w < RA_THREADS / 64; w++) sres = f9_norm_red<P9>(f9_add(sres, red9[w][threadIdx.x]));
+        fe_store(partials + (size_t)blockIdx.x * D + K0 + threadIdx.x, f9_canon<P9>(sres));
+    }
 }
 
 // booleanity phase 2 (booleanity.rs:254-276): per pair index j
@@ -186,18 +202,22 @@ struct RaRows {
         HIP_TRY(hipMalloc(&d_sums, K * sizeof(Fr)));
         return ATLAS_OK;
     }
-    // gather from host index rows (d * T int32) and device tables (d rows of f_stride Fr)
-    int gather(const int32_t* const* H_indices, const Fr* d_tables, uint32_t f_stride) {
-        int32_t* d_idx = nullptr;
+    // indices: d host rows of T int32 -> one device allocation (kept until the gather)
+    int32_t* d_idx = nullptr;
+    int upload_indices(const int32_t* const* H_indices) {
         HIP_TRY(hipMalloc(&d_idx, d * len * sizeof(int32_t)));
-        for (size_t i = 0; i < d; i++) {
-            hipError_t e = hipMemcpyAsync(d_idx + i * len, H_indices[i], len * sizeof(int32_t), hipMemcpyHostToDevice, g.stream);
-            if (e != hipSuccess) { hipFree(d_idx); return fail(ATLAS_ENODEV, "ra indices copy", e); }
-        }
+        for (size_t i = 0; i < d; i++)
+            HIP_TRY(hipMemcpyAsync(d_idx + i * len, H_indices[i], len * sizeof(int32_t), hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        return ATLAS_OK;
+    }
+    // ra_i[j] = table_i[idx_i[j]] from device tables (d rows of f_stride Fr; f_stride 0 = shared table)
+    int gather(const Fr* d_tables, uint32_t f_stride) {
+        if (!d_idx) return fail(ATLAS_ESTATE, "ra gather: indices not uploaded");
         size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
         k_ra_gather<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, g.stream>>>(d_idx, d_tables, f_stride, len, buf[0]);
         hipError_t e = hipStreamSynchronize(g.stream);
-        hipFree(d_idx);
+        hipFree(d_idx); d_idx = nullptr;
         if (e != hipSuccess) return fail(ATLAS_ENODEV, "ra gather", e);
         cur = 0; stride[0] = len;
         return ATLAS_OK;
@@ -231,12 +251,15 @@ struct RaRows {
         std::memcpy(out.data(), g.h_pinned, d * sizeof(Fr));
         return ATLAS_OK;
     }
-    void release() { for (auto& b : buf) if (b) hipFree(b); if (partials) hipFree(partials); if (d_sums) hipFree(d_sums); buf[0] = buf[1] = partials = d_sums = nullptr; }
+    void release() { for (auto& b : buf) if (b) hipFree(b); if (partials) hipFree(partials); if (d_sums) hipFree(d_sums); if (d_idx) hipFree(d_idx); buf[0] = buf[1] = partials = d_sums = nullptr; d_idx = nullptr; }
 };
 
 template <int D>
 void launch_prod(const RaRows& R, const SplitEqView& E, size_t n_groups, unsigned blocks) {
-    k_ra_prod<D><<<blocks, RA_THREADS, 0, g.stream>>>(R.buf[R.cur], R.stride[R.cur], E, n_groups, R.partials);
+    constexpr int KA = D < 8 ? D : 8;
+    k_ra_prod_f9<D, 0, KA><<<blocks, RA_THREADS, 0, g.stream>>>(R.buf[R.cur], R.stride[R.cur], E, n_groups, R.partials);
+    if constexpr (D > 8)
+        k_ra_prod_f9<D, 8, D - 8><<<blocks, RA_THREADS, 0, g.stream>>>(R.buf[R.cur], R.stride[R.cur], E, n_groups, R.partials);
 }
 
 // ---------------------------------------------------------------- RaSumcheckProver
@@ -263,7 +286,10 @@ struct RaVirtual : atlas_instance {
         std::vector<H::Fr> sums(rows.d);
         int rc = rows.reduce_to_host(blocks, (uint32_t)rows.d, sums.data());
         if (rc) return rc;
-        for (auto& s : sums) s = H::mul(s, eq.st.scalar);            // mles_product_sum.rs:131
+        H::Fr fix = H::one();                                        // 32^(d+1): the 2^-5 per f9_mul
+        for (size_t k = 0; k < rows.d + 1; k++) fix = H::mul(fix, H::from_u64(32));
+        fix = H::mul(fix, eq.st.scalar);                             // mles_product_sum.rs:131
+        for (auto& s : sums) s = H::mul(s, fix);
         coeffs = H::finish_product_sum(sums, claim, eq.st);
         return ATLAS_OK;
     }
@@ -294,7 +320,6 @@ int upload_tables(const std::vector<std::vector<H::Fr>>& t, size_t K, Fr** out) 
 struct Booleanity : atlas_instance {
     size_t d = 0, log_k = 0, log_T = 0, round_next = 0;
     std::vector<std::vector<H::Fr>> G;                 // d x 2^log_k (host: 16 entries each)
-    std::vector<std::vector<int32_t>> H_idx;           // kept until phase 2 starts
     std::vector<H::Fr> gammas, F;                      // F = ExpandingTable values
     H::GseState B;
     std::vector<std::vector<H::Fr>> B_out, B_in;       // host prefix tables of B
@@ -365,12 +390,10 @@ struct Booleanity : atlas_instance {
                 Fr* d_F = nullptr;
                 HIP_TRY(hipMalloc(&d_F, F.size() * sizeof(Fr)));
                 HIP_TRY(hipMemcpyAsync(d_F, F.data(), F.size() * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
-                std::vector<const int32_t*> ptrs(d);
-                for (size_t i = 0; i < d; i++) ptrs[i] = H_idx[i].data();
-                int rc = rows.gather(ptrs.data(), d_F, 0);            // every H_i reads the same table F
+                int rc = rows.gather(d_F, 0);                         // every H_i reads the same table F
                 hipFree(d_F);
                 if (rc) return rc;
-                H_idx.clear(); H_idx.shrink_to_fit(); G.clear();
+                G.clear();
             }
         } else {
             std::lock_guard<std::mutex> lk(g.mu);
@@ -442,7 +465,8 @@ int atlas_ra_virtual_new(const int32_t* const* H_indices, size_t d, size_t log_k
     Fr* d_tabs = nullptr;
     int rc = upload_tables(tabs, K, &d_tabs);
     if (!rc) rc = P->rows.alloc(d, T);
-    if (!rc) rc = P->rows.gather(H_indices, d_tabs, (uint32_t)K);
+    if (!rc) rc = P->rows.upload_indices(H_indices);
+    if (!rc) rc = P->rows.gather(d_tabs, (uint32_t)K);
     if (d_tabs) hipFree(d_tabs);
     if (!rc) rc = P->eq.init(reinterpret_cast<const H::Fr*>(r_cycle), log_T);
     if (rc) { delete P; return rc; }
@@ -461,8 +485,8 @@ int atlas_booleanity_new(const atlas_fr_t* G, const int32_t* const* H_indices, s
     P->d = d; P->log_k = log_k_chunk; P->log_T = log_T;
     const size_t K = (size_t)1 << log_k_chunk, T = (size_t)1 << log_T;
     const H::Fr* Gh = reinterpret_cast<const H::Fr*>(G);
-    P->G.resize(d); P->H_idx.resize(d);
-    for (size_t i = 0; i < d; i++) { P->G[i].assign(Gh + i * K, Gh + (i + 1) * K); P->H_idx[i].assign(H_indices[i], H_indices[i] + T); }
+    P->G.resize(d);
+    for (size_t i = 0; i < d; i++) P->G[i].assign(Gh + i * K, Gh + (i + 1) * K);
     P->gammas.assign(reinterpret_cast<const H::Fr*>(gammas), reinterpret_cast<const H::Fr*>(gammas) + d);
     P->F = {H::one()};
     const H::Fr* ra = reinterpret_cast<const H::Fr*>(r_address);
@@ -471,6 +495,7 @@ int atlas_booleanity_new(const atlas_fr_t* G, const int32_t* const* H_indices, s
     P->B_in = H::eq_cached(ra + P->B.m, P->B.k_in);
     int rc = P->D.init(reinterpret_cast<const H::Fr*>(r_cycle), log_T);
     if (!rc) rc = P->rows.alloc(d, T);
+    if (!rc) rc = P->rows.upload_indices(H_indices);       // resident until the phase-2 gather
     if (!rc) {
         hipError_t e = hipMalloc(&P->d_gammas, d * sizeof(Fr));
         if (e == hipSuccess) e = hipMemcpyAsync(P->d_gammas, gammas, d * sizeof(Fr), hipMemcpyHostToDevice, g.stream);
