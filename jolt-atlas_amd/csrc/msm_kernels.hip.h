@@ -99,7 +99,7 @@ __global__ __launch_bounds__(MSM_THREADS) void k_msm_hist_w(const int16_t* __res
 // ---- few-bucket plans (narrow scalars, bpw <= 4096): the global counters of a window would be hit
 // by every element, so counts and ranks are taken in LDS per workgroup tile and only one global
 // atomic per (workgroup, non-empty bucket) remains.
-constexpr uint32_t MSM_LDS_BPW = 4096;
+constexpr uint32_t MSM_LDS_BPW = 8192;
 constexpr uint32_t MSM_TILE = 16384;      // elements per workgroup tile
 
 __global__ __launch_bounds__(MSM_THREADS) void k_msm_hist_lds(const int16_t* __restrict__ digits, size_t n, MsmShape S,
@@ -197,6 +197,80 @@ __global__ __launch_bounds__(MSM_THREADS) void k_msm_accumulate(const G1Affine* 
         g1_madd_f9(acc, p, (v >> 31) != 0);
     }
     g1_store(buckets + t, g1_from_f9(acc));
+}
+
+// ---- load-balanced accumulation: a bucket is cut into segments of at most MSM_SEG_LEN sorted
+// entries; thread t owns segment t (bucket found by binary search in the segment offsets), so a
+// skewed window (the short top window of a 254-bit scalar, or narrow activations) cannot leave one
+// thread with a million additions.
+constexpr uint32_t MSM_SEG_LEN = 128;
+
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_seg_counts(const uint32_t* __restrict__ offsets, uint32_t n_buckets,
+                                                                uint32_t* __restrict__ segc) {
+    const uint32_t b = blockIdx.x * MSM_THREADS + threadIdx.x;
+    if (b < n_buckets) segc[b] = (offsets[b + 1] - offsets[b] + MSM_SEG_LEN - 1) / MSM_SEG_LEN;
+}
+
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_accumulate_seg(const G1Affine* __restrict__ bases,
+                                                                    const uint32_t* __restrict__ sorted,
+                                                                    const uint32_t* __restrict__ offsets,
+                                                                    const uint32_t* __restrict__ seg_off, uint32_t n_buckets,
+                                                                    G1Xyzz* __restrict__ partial) {
+    const uint32_t t = blockIdx.x * MSM_THREADS + threadIdx.x;
+    if (t >= seg_off[n_buckets]) return;
+    uint32_t lo_b = 0, hi_b = n_buckets;              // largest b with seg_off[b] <= t
+    while (hi_b - lo_b > 1) {
+        const uint32_t mid = (lo_b + hi_b) >> 1;
+        if (seg_off[mid] <= t) lo_b = mid; else hi_b = mid;
+    }
+    const uint32_t b = lo_b;
+    const uint32_t lo = offsets[b] + (t - seg_off[b]) * MSM_SEG_LEN;
+    const uint32_t end = offsets[b + 1];
+    const uint32_t hi = lo + MSM_SEG_LEN < end ? lo + MSM_SEG_LEN : end;
+    G1Xyzz9 acc;
+    acc.inf = true;
+    acc.x = f9_zero(); acc.y = f9_zero(); acc.zz = f9_zero(); acc.zzz = f9_zero();
+    for (uint32_t j = lo; j < hi; j++) {
+        const uint32_t v = sorted[j];
+        const G1Affine p = g1_aff_load(bases + (v & 0x7fffffffu));
+        if (g1_aff_is_inf(p)) continue;
+        g1_madd_f9(acc, p, (v >> 31) != 0);
+    }
+    g1_store(partial + t, g1_from_f9(acc));
+}
+
+// buckets with at most MSM_SMALL_SEGS segments: one thread sums them
+constexpr uint32_t MSM_SMALL_SEGS = 12;
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_bucket_reduce_small(const G1Xyzz* __restrict__ partial,
+                                                                         const uint32_t* __restrict__ seg_off, uint32_t n_buckets,
+                                                                         G1Xyzz* __restrict__ buckets) {
+    const uint32_t b = blockIdx.x * MSM_THREADS + threadIdx.x;
+    if (b >= n_buckets) return;
+    const uint32_t s0 = seg_off[b], cnt = seg_off[b + 1] - s0;
+    if (cnt > MSM_SMALL_SEGS) return;
+    G1Xyzz acc = g1_inf();
+    if (cnt) acc = g1_load(partial + s0);
+    for (uint32_t s = 1; s < cnt; s++) acc = g1_add(acc, g1_load(partial + s0 + s));
+    g1_store(buckets + b, acc);
+}
+
+// the long ones: one workgroup per bucket (workgroups of short buckets leave at once)
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_bucket_reduce_big(const G1Xyzz* __restrict__ partial,
+                                                                       const uint32_t* __restrict__ seg_off,
+                                                                       G1Xyzz* __restrict__ buckets) {
+    __shared__ G1Xyzz sm[MSM_THREADS];
+    const uint32_t b = blockIdx.x;
+    const uint32_t s0 = seg_off[b], cnt = seg_off[b + 1] - s0;
+    if (cnt <= MSM_SMALL_SEGS) return;
+    G1Xyzz acc = g1_inf();
+    for (uint32_t i = threadIdx.x; i < cnt; i += MSM_THREADS) acc = g1_add(acc, g1_load(partial + s0 + i));
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t d = MSM_THREADS / 2; d >= 1; d >>= 1) {
+        if (threadIdx.x < d) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + d]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) g1_store(buckets + b, sm[0]);
 }
 
 // buckets[b] = sum of its `seg` partials
