@@ -7,7 +7,7 @@ import numpy as np
 from . import orc
 
 RA_VIRTUAL, BOOLEANITY, HAMMING = 2, 3, 4
-_STATE_BYTES = 1024          # >= sizeof of any orc_* state struct
+_STATE_BYTES = 16384         # >= sizeof of any orc_* state struct
 
 
 def _idx_ptrs(H_indices):
@@ -118,3 +118,16 @@ def eval_reduction_prove(mle, points, claims, t):
                                           orc._p(h), C.byref(hl), orc._p(r), orc._p(c))
     assert rc == 0
     return h[:hl.value].copy(), r[:n].copy(), c[0].copy()
+
+
+PS_RELU = 7
+
+
+def ps_relu(lookup_indices, N, r_node, gamma):
+    """Unary prefix-suffix read-raf prover with the ReLU table (ps_shout/unary.rs:110-148)."""
+    idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)
+    rn = np.ascontiguousarray(r_node, dtype=np.uint64); g = np.ascontiguousarray(gamma, dtype=np.uint64).reshape(1, 4)
+    I = Instance(PS_RELU, N + len(rn))
+    I.keep = [idx, rn, g]
+    orc.lib.orc_ps_relu_init(I.st, idx.ctypes.data_as(C.c_void_p), C.c_size_t(N), C.c_size_t(len(rn)), orc._p(rn), orc._p(g))
+    return I

@@ -1,0 +1,219 @@
+/* TEST INFRASTRUCTURE ONLY (oracle): prefix-suffix Shout read-raf sumcheck, unary flavour with the
+ * ReLU table, restated from /root/reference/joltworks/src:
+ *   ReadRafSumcheckProver             subprotocols/ps_shout/mod.rs:227-560 (new_inner, init_phase,
+ *                                     init_suffix_polys, prover_msg_read_checking, init_log_t_rounds,
+ *                                     compute_message, ingest_challenge)
+ *   UnaryRafPS / ps_read_raf_prover   subprotocols/ps_shout/unary.rs:45-148
+ *   PrefixSuffixDecomposition         poly/prefix_suffix.rs:237-330 (init_Q, SIGNED), :433-492
+ *   SignedIdentityPoly prefix/suffix  poly/signed_identity_poly.rs:136-209, 379-402
+ *   ReluTable                         lookup_tables/relu.rs:46-60
+ *   NotMsb / WordNoMsb prefixes       lookup_tables/prefixes/not_msb.rs, word_no_msb.rs
+ *   One / WordNoMSB suffixes          lookup_tables/suffixes/one.rs, word_no_msb.rs
+ *   LookupBits::split                 utils/lookup_bits.rs:32-38;  ExpandingTable HighToLow
+ * LOG_K = N = X_LEN (16, 32 or 64), NUM_PHASES = 8, log_m = N / 8. */
+#include <stdlib.h>
+#include <string.h>
+#include "oracle.h"
+#include "ra.h"
+#include "psshout.h"
+
+static void fr_pow2(unsigned k, fr_t *o) { fr_t two; fr_from_u64(2, &two); fr_one(o); for (unsigned i = 0; i < k; i++) fr_mul(o, &two, o); }
+static uint64_t split_prefix(uint64_t k, size_t suffix_len) { return suffix_len >= 64 ? 0 : k >> suffix_len; }
+static uint64_t split_suffix(uint64_t k, size_t suffix_len) { return suffix_len >= 64 ? k : k % ((uint64_t)1 << suffix_len); }
+
+static void init_phase(orc_ps_relu *S, size_t phase) {                      /* mod.rs:269-301 */
+    const size_t log_m = S->log_m, m = S->m, m_mask = m - 1, T = S->T;
+    if (phase != 0)
+        for (size_t t = 0; t < T; t++) {
+            const uint64_t k_bound = split_prefix(S->idx[t], (8 - phase) * log_m) & m_mask;
+            fr_mul(&S->u[t], &S->v[phase - 1][k_bound], &S->u[t]);
+        }
+    const size_t suffix_len = (8 - 1 - phase) * log_m;
+    /* raf_state.init_Q: suffixes [One, Identity], SIGNED accumulation (prefix_suffix.rs:237-330) */
+    for (int s = 0; s < 2; s++) { for (size_t y = 0; y < m; y++) { fr_zero(&S->RQ[s][y]); fr_zero(&S->Q[s][y]); } }
+    for (size_t t = 0; t < T; t++) {
+        const uint64_t y = split_prefix(S->idx[t], suffix_len) & m_mask, sb = split_suffix(S->idx[t], suffix_len);
+        fr_add(&S->RQ[0][y], &S->u[t], &S->RQ[0][y]);                       /* One: t = 1 */
+        if (sb) { fr_t w, x; fr_from_i64((int64_t)sb, &w); fr_mul(&S->u[t], &w, &x); fr_add(&S->RQ[1][y], &x, &S->RQ[1][y]); }
+        /* init_suffix_polys (mod.rs:304-335): suffixes [One, WordNoMSB], t as u32 */
+        fr_add(&S->Q[0][y], &S->u[t], &S->Q[0][y]);
+        const uint32_t tw = (uint32_t)(sb % ((uint64_t)1 << (S->N - 1)));
+        if (tw) { fr_t w, x; fr_from_u64(tw, &w); fr_mul(&S->u[t], &w, &x); fr_add(&S->Q[1][y], &x, &S->Q[1][y]); }
+    }
+    S->Q_len = m;
+    /* raf_state.init_P: SignedIdentity prefix polynomial of this phase (signed_identity_poly.rs:181-209) */
+    {
+        const size_t xlen = S->N, sfx = xlen - log_m * (phase + 1);
+        fr_t bound; if (S->has_sid) bound = S->sid_cp; else fr_zero(&bound);
+        fr_t penalty; fr_pow2((unsigned)xlen, &penalty);
+        for (size_t i = 0; i < m; i++) {
+            /* (i << sfx) % 2^xlen as a field element: i < 2^log_m, sfx + log_m <= xlen */
+            fr_t sh, vi; fr_pow2((unsigned)sfx, &sh); fr_from_u64(i, &vi); fr_mul(&vi, &sh, &vi);
+            if (phase == 0 && sfx + log_m == xlen) { /* % 2^xlen never wraps: i << sfx < 2^xlen */ }
+            fr_add(&bound, &vi, &S->RP[i]);
+            if (phase == 0 && ((i >> (log_m - 1)) & 1)) fr_sub(&S->RP[i], &penalty, &S->RP[i]);   /* sign_correction */
+        }
+        S->RP_len = m;
+    }
+    fr_one(&S->v[phase][0]); S->v_len[phase] = 1;                           /* v[phase].reset(1) */
+}
+
+void orc_ps_relu_init(orc_ps_relu *S, const uint64_t *idx, size_t N, size_t log_T, const fr_t *r_node, const fr_t *gamma) {
+    memset(S, 0, sizeof *S);
+    S->N = N; S->log_T = log_T; S->log_m = N / 8; S->m = (size_t)1 << S->log_m; S->T = (size_t)1 << log_T;
+    S->idx = idx; S->gamma = *gamma;
+    S->u = (fr_t *)malloc(S->T * sizeof(fr_t)); orc_eq_evals(r_node, log_T, 0, S->u);        /* mod.rs:234 */
+    for (int s = 0; s < 2; s++) { S->Q[s] = (fr_t *)malloc(S->m * sizeof(fr_t)); S->RQ[s] = (fr_t *)malloc(S->m * sizeof(fr_t)); }
+    S->RP = (fr_t *)malloc(S->m * sizeof(fr_t));
+    for (int p = 0; p < 8; p++) S->v[p] = (fr_t *)calloc(S->m, sizeof(fr_t));
+    gse_init(&S->eq, r_node, log_T);
+    init_phase(S, 0);
+}
+
+void orc_ps_relu_free(orc_ps_relu *S) {
+    free(S->u); for (int s = 0; s < 2; s++) { free(S->Q[s]); free(S->RQ[s]); } free(S->RP);
+    for (int p = 0; p < 8; p++) free(S->v[p]);
+    if (S->ra) free(S->ra);
+    gse_free(&S->eq);
+}
+
+/* prefix_mle of the two ReLU prefixes (not_msb.rs:12-33, word_no_msb.rs:12-50); bits b of length blen */
+static void prefix_not_msb(const orc_ps_relu *S, const fr_t *r_x, uint32_t c, size_t j, fr_t *o) {
+    fr_t one; fr_one(&one);
+    if (j == 0) { fr_t cc; fr_from_u64(c, &cc); fr_sub(&one, &cc, o); }
+    else if (j == 1) fr_sub(&one, r_x, o);
+    else *o = S->cp_notmsb;
+}
+static void prefix_word_no_msb(const orc_ps_relu *S, const fr_t *r_x, uint32_t c, uint64_t b, size_t blen, size_t j, fr_t *o) {
+    fr_t word; if (S->has_word) word = S->cp_word; else fr_zero(&word);
+    const size_t XLEN = S->N;
+    if (j >= XLEN) { *o = word; return; }
+    const size_t suffix_len = XLEN - j - blen - 1;
+    fr_t w, t, cc; fr_from_u64(c, &cc);
+    if (!r_x && j == 0) {
+    } else if (!r_x) {
+        const size_t x_shift = XLEN - j - 1, y_shift = x_shift - 1;
+        fr_pow2((unsigned)x_shift, &w); fr_mul(&w, &cc, &t); fr_add(&word, &t, &word);
+        const uint64_t msb = (b >> (blen - 1)) & 1; b %= (uint64_t)1 << (blen - 1); blen -= 1;      /* pop_msb */
+        fr_pow2((unsigned)y_shift, &w); fr_from_u64(msb, &t); fr_mul(&w, &t, &t); fr_add(&word, &t, &word);
+    } else {
+        const size_t x_shift = XLEN - j, y_shift = x_shift - 1;
+        fr_t rx; if (j == 1) fr_zero(&rx); else rx = *r_x;
+        fr_pow2((unsigned)x_shift, &w); fr_mul(&w, &rx, &t); fr_add(&word, &t, &word);
+        fr_pow2((unsigned)y_shift, &w); fr_mul(&w, &cc, &t); fr_add(&word, &t, &word);
+    }
+    fr_from_u64(b << suffix_len, &t); fr_add(&word, &t, &word);
+    *o = word;
+}
+
+static void combine(const fr_t *p_notmsb, const fr_t *p_word, const fr_t *s_one, const fr_t *s_relu, fr_t *o) {   /* relu.rs:55-59 */
+    fr_t a, b; fr_mul(p_notmsb, p_word, &a); fr_mul(&a, s_one, &a); fr_mul(p_notmsb, s_relu, &b); fr_add(&a, &b, o);
+}
+
+size_t orc_ps_relu_message(orc_ps_relu *S, size_t round, const fr_t *claim, fr_t *coeffs) {
+    if (round < S->N) {                                                      /* mod.rs:337-352 */
+        const size_t j = round, half = S->Q_len / 2;
+        size_t blen = 0; while (((size_t)1 << blen) < half) blen++;
+        const fr_t *r_x = (j % 2 == 1) ? &S->r[S->n_r - 1] : 0;
+        fr_t e0, e2l, e2h; fr_zero(&e0); fr_zero(&e2l); fr_zero(&e2h);
+        for (size_t i = 0; i < half; i++) {                                  /* prover_msg_read_checking :354-417 */
+            fr_t n0, w0, n2, w2, t;
+            prefix_not_msb(S, r_x, 0, j, &n0); prefix_word_no_msb(S, r_x, 0, i, blen, j, &w0);
+            prefix_not_msb(S, r_x, 2, j, &n2); prefix_word_no_msb(S, r_x, 2, i, blen, j, &w2);
+            combine(&n0, &w0, &S->Q[0][i], &S->Q[1][i], &t); fr_add(&e0, &t, &e0);
+            combine(&n2, &w2, &S->Q[0][i], &S->Q[1][i], &t); fr_add(&e2l, &t, &e2l);
+            combine(&n2, &w2, &S->Q[0][i + half], &S->Q[1][i + half], &t); fr_add(&e2h, &t, &e2h);
+        }
+        fr_t rc0 = e0, rc2; fr_add(&e2h, &e2h, &rc2); fr_sub(&rc2, &e2l, &rc2);
+        /* raf_state.prover_msg (unary.rs:55-79): sum_b identity_ps.sumcheck_evals(b), times gamma */
+        fr_t o0, o2l, o2r; fr_zero(&o0); fr_zero(&o2l); fr_zero(&o2r);
+        for (size_t b = 0; b < half; b++) {
+            /* P[0] = SignedIdentity prefix poly (HighToLow sumcheck evals at 0 and 2), P[1] = None -> (1, 1) */
+            fr_t p0 = S->RP[b], p2, m, t; fr_sub(&S->RP[b + S->RP_len / 2], &p0, &m); fr_add(&S->RP[b + S->RP_len / 2], &m, &p2);
+            fr_mul(&p0, &S->RQ[0][b], &t); fr_add(&o0, &t, &o0);
+            fr_mul(&p2, &S->RQ[0][b], &t); fr_add(&o2l, &t, &o2l);
+            fr_mul(&p2, &S->RQ[0][b + half], &t); fr_add(&o2r, &t, &o2r);
+            fr_add(&o0, &S->RQ[1][b], &o0); fr_add(&o2l, &S->RQ[1][b], &o2l); fr_add(&o2r, &S->RQ[1][b + half], &o2r);
+        }
+        fr_t op2; fr_add(&o2r, &o2r, &op2); fr_sub(&op2, &o2l, &op2);
+        fr_mul(&o0, &S->gamma, &o0); fr_mul(&op2, &S->gamma, &op2);
+        fr_t ev[2]; fr_add(&rc0, &o0, &ev[0]); fr_add(&rc2, &op2, &ev[1]);
+        return orc_unipoly_from_evals_and_hint(claim, ev, 2, coeffs);
+    }
+    /* log T rounds (mod.rs:461-487): eval_at_0 = sum_j E_out E_in ra[2j]; gruen_poly_deg_2 (LowToHigh) */
+    const gse_t *E = &S->eq;
+    const fr_t *e_out = E->Eout[E->out_top], *e_in = E->Ein[E->in_top];
+    const size_t out_len = (size_t)1 << E->out_top, in_len = (size_t)1 << E->in_top;
+    fr_t acc; fr_zero(&acc);
+    for (size_t xo = 0; xo < out_len; xo++) {
+        fr_t inner; fr_zero(&inner);
+        for (size_t xi = 0; xi < in_len; xi++) { const size_t jj = (xo << E->in_top) | xi; fr_t t; fr_mul(&e_in[xi], &S->ra[2 * jj], &t); fr_add(&inner, &t, &inner); }
+        fr_mul(&e_out[xo], &inner, &inner); fr_add(&acc, &inner, &acc);
+    }
+    fr_t vv, q0; fr_add(&S->val, &S->raf_val, &vv); fr_mul(&acc, &vv, &q0);
+    /* gruen_poly_deg_2 (split_eq_poly.rs:379-428), LowToHigh: w[current_index - 1] */
+    fr_t eq1, eq0, eqm, eq2, c0, c1, l1, l2, inv, ev2[2], hint;
+    fr_mul(&E->scalar, &E->w[E->current_index - 1], &eq1); fr_sub(&E->scalar, &eq1, &eq0);
+    fr_sub(&eq1, &eq0, &eqm); fr_add(&eq1, &eqm, &eq2);
+    fr_mul(&eq0, &q0, &c0); fr_sub(claim, &c0, &c1);
+    fr_inv(&eq1, &inv); fr_mul(&c1, &inv, &l1);
+    fr_add(&l1, &l1, &l2); fr_sub(&l2, &q0, &l2);
+    ev2[0] = c0; fr_mul(&eq2, &l2, &ev2[1]); fr_add(&c0, &c1, &hint);
+    return orc_unipoly_from_evals_and_hint(&hint, ev2, 2, coeffs);
+}
+
+static void bind_h2l(fr_t *z, size_t *len, const fr_t *r) { orc_bind(z, *len, r, ORC_HIGH_TO_LOW); *len /= 2; }
+
+void orc_ps_relu_ingest(orc_ps_relu *S, size_t round, const fr_t *r) {      /* mod.rs:490-560 */
+    const size_t log_m = S->log_m, LOG_K = S->N;
+    S->r[S->n_r++] = *r;
+    if (round < LOG_K) {
+        const size_t phase = round / log_m;
+        size_t ql = S->Q_len;
+        for (int s = 0; s < 2; s++) { size_t l = ql; bind_h2l(S->Q[s], &l, r); l = ql; bind_h2l(S->RQ[s], &l, r); }
+        S->Q_len = ql / 2;
+        bind_h2l(S->RP, &S->RP_len, r);                                      /* identity_ps.bind: P and Q HighToLow */
+        {                                                                    /* v[phase].update(r), HighToLow */
+            const size_t n = S->v_len[phase];
+            fr_t *nv = (fr_t *)calloc(S->m, sizeof(fr_t));
+            for (size_t i = 0; i < n; i++) { fr_mul(r, &S->v[phase][i], &nv[2 * i + 1]); fr_sub(&S->v[phase][i], &nv[2 * i + 1], &nv[2 * i]); }
+            free(S->v[phase]); S->v[phase] = nv; S->v_len[phase] = 2 * n;
+        }
+        if (S->n_r % 2 == 0) {                                               /* Prefixes::update_checkpoints, j = round */
+            const fr_t *r_x = &S->r[S->n_r - 2], *r_y = &S->r[S->n_r - 1];
+            const size_t j = round;
+            fr_t one; fr_one(&one);
+            if (j == 1) { fr_sub(&one, r_x, &S->cp_notmsb); S->has_notmsb = 1; }          /* not_msb.rs:35-50 */
+            {                                                                /* word_no_msb.rs:52-70 */
+                fr_t word; if (S->has_word) word = S->cp_word; else fr_zero(&word);
+                const size_t x_shift = LOG_K >= j ? LOG_K - j : 0, y_shift = x_shift ? x_shift - 1 : 0;
+                fr_t rx, w, t; if (j == 1) fr_zero(&rx); else rx = *r_x;
+                fr_pow2((unsigned)x_shift, &w); fr_mul(&w, &rx, &t); fr_add(&word, &t, &word);
+                fr_pow2((unsigned)y_shift, &w); fr_mul(&w, r_y, &t); fr_add(&word, &t, &word);
+                S->cp_word = word; S->has_word = 1;
+            }
+        }
+        if ((round + 1) % log_m == 0) {
+            S->sid_cp = S->RP[0]; S->has_sid = 1;                            /* prefix_registry.update_checkpoints */
+            if (phase != 7) init_phase(S, phase + 1);
+        }
+        if (round + 1 == LOG_K) {
+            /* val = combine(prefix checkpoints, suffix_mle(empty)) : One -> 1, WordNoMSB -> 0 */
+            fr_t one, zero; fr_one(&one); fr_zero(&zero);
+            combine(&S->cp_notmsb, &S->cp_word, &one, &zero, &S->val);
+            fr_mul(&S->gamma, &S->sid_cp, &S->raf_val);                       /* unary.rs:85-88 */
+            S->ra = (fr_t *)malloc(S->T * sizeof(fr_t)); S->ra_len = S->T;    /* init_log_t_rounds :419-446 */
+            for (size_t t = 0; t < S->T; t++) {
+                fr_t p; fr_one(&p);
+                for (size_t ph = 0; ph < 8; ph++) {
+                    const uint64_t kb = split_prefix(S->idx[t], (8 - 1 - ph) * log_m) & (S->m - 1);
+                    fr_mul(&p, &S->v[ph][kb], &p);
+                }
+                S->ra[t] = p;
+            }
+        }
+    } else {
+        orc_bind(S->ra, S->ra_len, r, ORC_LOW_TO_HIGH); S->ra_len /= 2;
+        gse_bind(&S->eq, r);
+    }
+}

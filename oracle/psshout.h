@@ -1,0 +1,24 @@
+/* TEST INFRASTRUCTURE ONLY (oracle): state of the prefix-suffix Shout read-raf prover (psshout.c). */
+#ifndef ORC_PSSHOUT_H
+#define ORC_PSSHOUT_H
+#include "oracle.h"
+#include "ra.h"
+
+enum { ORC_INST_PS_RELU = 7 };
+
+typedef struct {
+    size_t N, log_T, log_m, m, T, Q_len, RP_len, n_r, ra_len;
+    const uint64_t *idx;
+    fr_t gamma, *u, *Q[2], *RQ[2], *RP, *v[8], *ra;
+    size_t v_len[8];
+    fr_t cp_notmsb, cp_word, sid_cp, val, raf_val;
+    int has_notmsb, has_word, has_sid;
+    fr_t r[160];
+    gse_t eq;
+} orc_ps_relu;
+/* lookup indices: T = 2^log_T N-bit values; N = 16, 32 or 64; r_node: log_T Fr (big-endian) */
+void   orc_ps_relu_init(orc_ps_relu *S, const uint64_t *idx, size_t N, size_t log_T, const fr_t *r_node, const fr_t *gamma);
+void   orc_ps_relu_free(orc_ps_relu *S);
+size_t orc_ps_relu_message(orc_ps_relu *S, size_t round, const fr_t *claim, fr_t *coeffs);
+void   orc_ps_relu_ingest(orc_ps_relu *S, size_t round, const fr_t *r);
+#endif

@@ -231,3 +231,79 @@ class OneHotOpeningModel:
 
     def finals(self):
         return [self.ra[0]]
+
+
+class PsReluModel:
+    """Read-raf sumcheck of the ReLU lookup, unary: sum_{k,t} eq(r_node,t) [k = idx_t] (Val(k) + gamma SId(k)),
+    address variables MSB first, then cycle variables LowToHigh (ps_shout/mod.rs, unary.rs).  Closed-form
+    model: no prefix/suffix tables, no checkpoints — each lookup's contribution is evaluated from the
+    multilinear extensions Val~(x) = (1 - x_0) sum_{i>=1} x_i 2^(N-1-i) (relu.rs:30-43) and
+    SId~(x) = sum_i x_i 2^(N-1-i) - x_0 2^N (signed_identity_poly.rs:44-60)."""
+
+    def __init__(self, idx, N, r_node, gamma):
+        self.idx, self.N, self.gamma = list(idx), N, gamma
+        self.u = P.eq_evals(r_node)
+        self.r_addr = []
+        self._n = N + len(r_node)
+        self.eq = None
+
+    def num_rounds(self):
+        return self._n
+
+    def _W(self, x):
+        N = self.N
+        word = sum(x[i] * (1 << (N - 1 - i)) for i in range(1, N)) % FR
+        val = (1 - x[0]) * word % FR
+        sid = (sum(x[i] * (1 << (N - 1 - i)) for i in range(N)) - x[0] * (1 << N)) % FR
+        return (val + self.gamma * sid) % FR
+
+    def input_claim(self):
+        N = self.N
+        acc = 0
+        for t, k in enumerate(self.idx):
+            bits = [(k >> (N - 1 - i)) & 1 for i in range(N)]
+            acc = (acc + self.u[t] * self._W(bits)) % FR
+        return acc
+
+    def compute_message(self, rnd, previous_claim):
+        N = self.N
+        ev = [0, 0, 0]
+        if rnd < N:
+            j = rnd
+            for t, k in enumerate(self.idx):
+                bits = [(k >> (N - 1 - i)) & 1 for i in range(N)]
+                w = self.u[t]
+                for i in range(j):
+                    w = w * (self.r_addr[i] if bits[i] else (1 - self.r_addr[i])) % FR
+                for X in range(3):
+                    e = X if bits[j] else (1 - X)
+                    x = self.r_addr[:j] + [X] + bits[j + 1:]
+                    ev[X] = (ev[X] + w * e * self._W(x)) % FR
+        else:
+            for i in range(len(self.eq) // 2):
+                e, a = _ext(self.eq, i, 3), _ext(self.ra, i, 3)
+                for X in range(3):
+                    ev[X] = (ev[X] + e[X] * a[X] % FR * self.wv) % FR
+        assert (ev[0] + ev[1]) % FR == previous_claim % FR
+        return interpolate(ev)
+
+    def ingest_challenge(self, r, rnd):
+        N = self.N
+        if rnd < N:
+            self.r_addr.append(r)
+            if rnd == N - 1:
+                self.ra = []
+                for k in self.idx:
+                    bits = [(k >> (N - 1 - i)) & 1 for i in range(N)]
+                    w = 1
+                    for i in range(N):
+                        w = w * (self.r_addr[i] if bits[i] else (1 - self.r_addr[i])) % FR
+                    self.ra.append(w)
+                self.eq = list(self.u)
+                self.wv = self._W(self.r_addr)
+        else:
+            self.eq = P.bind(self.eq, r, L2H)
+            self.ra = P.bind(self.ra, r, L2H)
+
+    def finals(self):
+        return [self.ra[0]]

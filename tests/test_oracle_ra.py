@@ -209,3 +209,30 @@ def test_eval_reduction_structured_inputs_trim():
     t1 = orc.new_transcript(b"x")
     h1, r1, c1 = OR.eval_reduction_prove(orc.from_ints(mle), np.stack([orc.from_ints(pts[0])]), orc.from_ints(claims[:1]), t1)
     assert orc.to_ints(h1) == [claims[0]] and orc.to_ints(r1) == pts[0] and t1.n_rounds == 0
+
+
+@pytest.mark.parametrize("N,log_T", [(16, 1), (16, 3), (32, 2), (32, 4)])
+def test_ps_shout_relu_oracle_matches_closed_form_model(N, log_T):
+    """oracle/psshout.c (prefix checkpoints, suffix Q tables, phases, expanding tables, Gruen) against
+    the closed-form model; also pins ReLU's table MLE on boolean points."""
+    T = 1 << log_T
+    rng = np.random.default_rng(N + log_T)
+    idx = [int(x) for x in rng.integers(0, 1 << N, size=T, dtype=np.uint64)]
+    idx[0] = (1 << N) - 1                      # negative value, all ones
+    if T > 2:
+        idx[1] = 0; idx[2] = 1 << (N - 1)      # zero; most negative
+    r_node, gamma = _rand(log_T, 3), _rand(1, 4)[0] >> 130
+    model = PR.PsReluModel(idx, N, r_node, gamma)
+    # ReluTable::materialize_entry vs the MLE on boolean inputs
+    for k in idx:
+        bits = [(k >> (N - 1 - i)) & 1 for i in range(N)]
+        signed = k - (1 << N) if k >> (N - 1) else k
+        assert model._W(bits) == (max(0, signed) + gamma * signed) % F.FR
+    claim = model.input_claim()
+    rows_p, raw_p, tp = _prove_py(model, claim, b"ps_relu")
+    inst = OR.ps_relu(idx, N, orc.from_ints(r_node), orc.from_ints([gamma])[0])
+    to = orc.new_transcript(b"ps_relu")
+    rows_o, raw_o = inst.prove(orc.from_ints([claim])[0], to)
+    assert raw_o == raw_p
+    assert [orc.to_ints(r) for r in rows_o] == rows_p
+    assert bytes(to.state) == tp.state
