@@ -240,6 +240,18 @@ int atlas_ra_virtual_new(const int32_t *const *H_indices, size_t d, size_t log_k
 int atlas_booleanity_new(const atlas_fr_t *G, const int32_t *const *H_indices, size_t d,
                          size_t log_k_chunk, size_t log_T, const atlas_fr_t *gammas,
                          const atlas_fr_t *r_address, const atlas_fr_t *r_cycle, atlas_instance_t *out);
+/* ---- prefix-suffix Shout read-raf sumcheck, unary lookups (joltworks/src/subprotocols/ps_shout/
+ *      mod.rs:227-560, unary.rs:110-148 ps_read_raf_prover) with ReluTable<X_LEN>
+ *      (lookup_tables/relu.rs) and the SignedIdentity RAF term:
+ *        sum_{k,t} eq(r_node_output, t) ra(k, t) (Relu(k) + gamma * SignedIdentity(k)),
+ *      X_LEN address rounds (8 phases of X_LEN/8 bits) then log_T cycle rounds, degree 2.
+ *      lookup_indices = T = 2^log_T values of X_LEN bits (LookupBits); gamma = the challenge_scalar the
+ *      caller drew; input claim = rv_claim + gamma * operand_claim.  Final claim = ra(r).
+ *      X_LEN = 16 or 32 (the reference's WordNoMSB suffix is a u32, exact only up to 32 bits). ---- */
+int atlas_ps_shout_relu_new(const uint64_t *lookup_indices, size_t log_T, size_t xlen,
+                            const atlas_fr_t *r_node_output, const atlas_fr_t *gamma,
+                            atlas_instance_t *out);
+
 /* ---- N-to-1 evaluation reduction: EvalReductionInstance::prove with compute_h and eval_on_l
  *      (joltworks/src/subprotocols/evaluation_reduction.rs:91-147, 213-249).  points = N rows of n
  *      Fr (the opening points of one polynomial), claims = N Fr.  h(t) = P(l(t)) is returned as

@@ -445,6 +445,185 @@ struct HammingWeight : atlas_instance {
     }
 };
 
+// ---------------------------------------------------------------- prefix-suffix Shout read-raf (unary, ReLU)
+// ReadRafSumcheckProver over a unary lookup table (joltworks/src/subprotocols/ps_shout/mod.rs:227-560,
+// unary.rs:45-148) for ReluTable<N> (lookup_tables/relu.rs) with the SignedIdentity RAF term
+// (poly/signed_identity_poly.rs).  N address rounds in 8 phases of log_m = N/8 bits, then log_T cycle
+// rounds (LowToHigh Gruen, degree 2).
+//
+// The summand is  eq(r_node, t) [k = idx_t] (Val(k) + gamma SId(k)).  With the index split as
+// prefix | chunk_p | suffix in phase p, both Val and SId are  A(prefix, chunk) * 1 + B(prefix, chunk) *
+// suffix  (relu.rs:55-59; signed_identity_poly.rs:136-160), so two suffix tables per phase carry the
+// whole O(T) part:   Q1[y] = sum_{t : chunk_p(idx_t) = y} u_t,   Qs[y] = sum ... u_t * suffix_t,
+// u_t = eq(r_node, t) * prod_{q < p} v_q[chunk_q(idx_t)]  (mod.rs:269-335).  They are built by
+// k_ps_q (one workgroup per (bin, slice of T)); the per-round arithmetic over the 2^log_m entries —
+// prefix evaluations, binding Q and the expanding table v_p — is host work.  The reference keeps the
+// WordNoMSB suffix as u32, which is exact for N <= 32; N = 64 is refused here for that reason.
+__global__ __launch_bounds__(RA_THREADS) void k_ps_q(const uint64_t* __restrict__ idx, const Fr* __restrict__ u0,
+                                                     const Fr* __restrict__ prod, size_t T, uint32_t suffix_len, uint32_t m_mask,
+                                                     Fr* __restrict__ partials /* [slices][2 m] */) {
+    __shared__ Fr red[RA_THREADS / 64][2];
+    const uint32_t y = blockIdx.x, slice = blockIdx.y, n_slices = gridDim.y;
+    const size_t per = (T + n_slices - 1) / n_slices, t0 = (size_t)slice * per, t1 = t0 + per < T ? t0 + per : T;
+    Fr a1 = fe_zero(), as = fe_zero();
+    const uint64_t smask = suffix_len >= 64 ? ~0ull : (((uint64_t)1 << suffix_len) - 1);
+    for (size_t t = t0 + threadIdx.x; t < t1; t += RA_THREADS) {
+        const uint64_t k = idx[t];
+        if (((uint32_t)(k >> suffix_len) & m_mask) != y) continue;
+        const Fr u = fr_mul(fe_load(u0 + t), fe_load(prod + t));
+        a1 = fr_add(a1, u);
+        const uint64_t sb = k & smask;
+        if (sb) as = fr_add(as, fr_mul(u, fr_from_i64((int64_t)sb)));
+    }
+    a1 = fr_wave_sum(a1); as = fr_wave_sum(as);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = a1; red[threadIdx.x >> 6][1] = as; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        Fr sres = red[0][threadIdx.x];
+        for (int w = 1; w < RA_THREADS / 64; w++) sres = fr_add(sres, red[w][threadIdx.x]);
+        fe_store(partials + ((size_t)slice * 2 * (m_mask + 1)) + 2 * y + threadIdx.x, sres);
+    }
+}
+
+// prod[t] *= v[chunk(idx_t)]   (u_evals rescale, mod.rs:275-284, and the ra product, :429-441)
+__global__ __launch_bounds__(RA_THREADS) void k_ps_scale(const uint64_t* __restrict__ idx, const Fr* __restrict__ v, size_t T,
+                                                         uint32_t shift, uint32_t m_mask, Fr* __restrict__ prod) {
+    for (size_t t = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; t < T; t += (size_t)gridDim.x * RA_THREADS)
+        fe_store(prod + t, fr_mul(fe_load(prod + t), fe_load(v + ((uint32_t)(idx[t] >> shift) & m_mask))));
+}
+
+__global__ __launch_bounds__(RA_THREADS) void k_ps_fill_one(Fr* p, size_t T) {
+    const Fr one = fr_one();
+    for (size_t t = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; t < T; t += (size_t)gridDim.x * RA_THREADS) fe_store(p + t, one);
+}
+
+// sum_j E_out E_in ra[2 j]   (mod.rs:463-484)
+__global__ __launch_bounds__(RA_THREADS) void k_ps_fold(const Fr* __restrict__ ra, SplitEqView E, size_t n_groups, Fr* __restrict__ partials) {
+    Fr acc[1];
+    acc[0] = fe_zero();
+    for (size_t j = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; j < n_groups; j += (size_t)gridDim.x * RA_THREADS)
+        acc[0] = fr_add(acc[0], fr_mul(gse_weight(E, j), fe_load(ra + 2 * j)));
+    block_reduce_store<1>(acc, partials);
+}
+
+struct PsRelu : atlas_instance {
+    size_t N = 0, log_m = 0, m = 0, log_T = 0, T = 0, round_next = 0;
+    H::Fr gamma;
+    uint64_t* d_idx = nullptr;
+    Fr *d_u0 = nullptr, *d_v = nullptr, *d_qpart = nullptr;
+    RaRows rows;                          // row 0 = running product of the v tables = ra at the end
+    GseDev eq;
+    std::vector<H::Fr> Q1, Qs, v;         // current phase: suffix tables (bound HighToLow) and expanding table
+    std::vector<H::Fr> r_addr;
+    H::Fr word_acc = H::zero(), sid_acc = H::zero(), wv = H::zero();
+    static constexpr unsigned SLICES = 64;
+
+    ~PsRelu() override { for (void* p : {(void*)d_idx, (void*)d_u0, (void*)d_v, (void*)d_qpart}) if (p) hipFree(p); rows.release(); eq.release(); }
+    size_t rounds() const override { return N + log_T; }
+    size_t degree() const override { return 2; }
+
+    static H::Fr pow2(size_t k) { H::Fr o = H::one(); const H::Fr two = H::from_u64(2); for (size_t i = 0; i < k; i++) o = H::mul(o, two); return o; }
+    H::Fr weight(size_t i) const { H::Fr w = pow2(N - 1 - i); return i == 0 ? H::sub(w, pow2(N)) : w; }   // SId coefficient of bit i
+
+    int build_Q(size_t phase) {           // init_phase: Q tables of `phase` from the current products
+        const uint32_t suffix_len = (uint32_t)((8 - 1 - phase) * log_m);
+        k_ps_q<<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), d_qpart);
+        k_col_reduce<<<(unsigned)(2 * m), RA_THREADS, 0, g.stream>>>(d_qpart, SLICES, (uint32_t)(2 * m), d_qpart + (size_t)SLICES * 2 * m);
+        std::vector<H::Fr> q(2 * m);
+        HIP_TRY(hipMemcpyAsync(q.data(), d_qpart + (size_t)SLICES * 2 * m, 2 * m * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        Q1.resize(m); Qs.resize(m);
+        for (size_t y = 0; y < m; y++) { Q1[y] = q[2 * y]; Qs[y] = q[2 * y + 1]; }
+        v.assign(1, H::one());
+        return ATLAS_OK;
+    }
+
+    int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
+        if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "ps_shout: round out of order");
+        coeffs.assign(3, H::zero());
+        if (round < N) {
+            const size_t j = round, p = j / log_m, half = Q1.size() / 2;
+            const size_t suffix_len = N - (p + 1) * log_m;
+            const H::Fr sh = pow2(suffix_len), one = H::one();
+            H::Fr ev[2];
+            for (int ci = 0; ci < 2; ci++) {
+                const H::Fr c = H::from_u64(ci ? 2 : 0);
+                const H::Fr not_msb = j == 0 ? H::sub(one, c) : H::sub(one, r_addr[0]);
+                const H::Fr word_c = j >= 1 ? H::add(word_acc, H::mul(c, pow2(N - 1 - j))) : H::zero();
+                const H::Fr sid_c = H::add(sid_acc, H::mul(c, weight(j)));
+                H::Fr acc = H::zero();
+                for (size_t b = 0; b < half; b++) {
+                    const H::Fr bs = H::mul(H::from_u64(b), sh);
+                    const H::Fr q1 = ci ? H::sub(H::add(Q1[b + half], Q1[b + half]), Q1[b]) : Q1[b];
+                    const H::Fr qs = ci ? H::sub(H::add(Qs[b + half], Qs[b + half]), Qs[b]) : Qs[b];
+                    // Val: not_msb * (word * 1 + suffix);  RAF: gamma * (sid * 1 + suffix)
+                    const H::Fr val = H::mul(not_msb, H::add(H::mul(H::add(word_c, bs), q1), qs));
+                    const H::Fr raf = H::mul(gamma, H::add(H::mul(H::add(sid_c, bs), q1), qs));
+                    acc = H::add(acc, H::add(val, raf));
+                }
+                ev[ci] = acc;
+            }
+            H::unipoly_from_evals_and_hint(claim, ev, 2, coeffs.data());
+            return ATLAS_OK;
+        }
+        std::lock_guard<std::mutex> lk(g.mu);
+        const size_t n_groups = rows.len / 2;
+        size_t blocks = (n_groups + RA_THREADS - 1) / RA_THREADS; if (blocks > 2048) blocks = 2048;
+        k_ps_fold<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(rows.buf[rows.cur], eq.view(), n_groups, rows.partials);
+        H::Fr s;
+        int rc = rows.reduce_to_host((uint32_t)blocks, 1, &s);
+        if (rc) return rc;
+        H::gruen_deg2(eq.st.scalar, eq.st.w_cur(), H::mul(s, wv), claim, coeffs.data());
+        return ATLAS_OK;
+    }
+
+    int ingest(const atlas_u128_t& r, size_t round) override {
+        if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "ps_shout: round out of order");
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        if (round < N) {
+            const size_t j = round, p = j / log_m;
+            const size_t half = Q1.size() / 2;
+            for (size_t i = 0; i < half; i++) {                       // suffix polys bind HighToLow
+                Q1[i] = H::add(Q1[i], H::mul(rf, H::sub(Q1[i + half], Q1[i])));
+                Qs[i] = H::add(Qs[i], H::mul(rf, H::sub(Qs[i + half], Qs[i])));
+            }
+            Q1.resize(half); Qs.resize(half);
+            std::vector<H::Fr> nv(2 * v.size());                      // ExpandingTable::update, HighToLow
+            for (size_t i = 0; i < v.size(); i++) { nv[2 * i + 1] = H::mul(rf, v[i]); nv[2 * i] = H::sub(v[i], nv[2 * i + 1]); }
+            v.swap(nv);
+            if (j >= 1) word_acc = H::add(word_acc, H::mul(rf, pow2(N - 1 - j)));
+            sid_acc = H::add(sid_acc, H::mul(rf, weight(j)));
+            r_addr.push_back(rf);
+            if ((j + 1) % log_m == 0) {                               // phase boundary: fold v_p into the products
+                std::lock_guard<std::mutex> lk(g.mu);
+                HIP_TRY(hipMemcpyAsync(d_v, v.data(), m * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+                size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
+                k_ps_scale<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(d_idx, d_v, T, (uint32_t)((8 - 1 - p) * log_m), (uint32_t)(m - 1), rows.buf[0]);
+                HIP_TRY(hipStreamSynchronize(g.stream));
+                if (p != 7) { int rc = build_Q(p + 1); if (rc) return rc; }
+            }
+            if (j + 1 == N) {
+                // val = Val~(r_address), raf_val = gamma * SId~(r_address)   (mod.rs:523-548)
+                const H::Fr val = H::mul(H::sub(H::one(), r_addr[0]), word_acc);
+                wv = H::add(val, H::mul(gamma, sid_acc));
+                rows.cur = 0; rows.stride[0] = T; rows.len = T;       // the products are ra (init_log_t_rounds)
+            }
+        } else {
+            std::lock_guard<std::mutex> lk(g.mu);
+            int rc = rows.bind(r);
+            if (rc) return rc;
+            eq.st.bind(rf);
+        }
+        round_next++;
+        return ATLAS_OK;
+    }
+    int finals(std::vector<H::Fr>& out) override {
+        if (round_next != rounds()) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
+        std::lock_guard<std::mutex> lk(g.mu);
+        return rows.finals(out);
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -516,6 +695,38 @@ int atlas_hamming_weight_new(const atlas_fr_t* G, size_t d, size_t log_k_chunk, 
     P->ra.resize(d);
     for (size_t i = 0; i < d; i++) P->ra[i].assign(Gh + i * K, Gh + (i + 1) * K);
     P->gamma_powers.assign(reinterpret_cast<const H::Fr*>(gamma_powers), reinterpret_cast<const H::Fr*>(gamma_powers) + d);
+    *out = P;
+    return ATLAS_OK;
+}
+
+int atlas_ps_shout_relu_new(const uint64_t* lookup_indices, size_t log_T, size_t xlen, const atlas_fr_t* r_node_output,
+                            const atlas_fr_t* gamma, atlas_instance_t* out) {
+    NEED_INIT();
+    if (!lookup_indices || !r_node_output || !gamma || !out) return fail(ATLAS_EINVAL, "ps_shout_relu_new: null argument");
+    if (xlen != 16 && xlen != 32) return fail(ATLAS_EINVAL, "ps_shout_relu_new: X_LEN must be 16 or 32 (the reference's WordNoMSB suffix is a u32)");
+    if (log_T == 0 || log_T > 25) return fail(ATLAS_EINVAL, "ps_shout_relu_new: 1 <= log_T <= 25");
+    atlas_poly_t E = nullptr;
+    int rc = atlas_eq_evals(r_node_output, log_T, nullptr, &E);      // u_evals = EqPolynomial::evals(r_node_output), mod.rs:234
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g.mu);
+    PsRelu* P = new PsRelu();
+    P->N = xlen; P->log_m = xlen / 8; P->m = (size_t)1 << P->log_m; P->log_T = log_T; P->T = (size_t)1 << log_T;
+    std::memcpy(&P->gamma, gamma, 32);
+    P->d_u0 = (Fr*)E->d; delete E;                                   // keep the table, drop the handle
+    const size_t T = P->T, m = P->m;
+    hipError_t e = hipMalloc(&P->d_idx, T * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc(&P->d_v, m * sizeof(Fr));
+    if (e == hipSuccess) e = hipMalloc(&P->d_qpart, ((size_t)PsRelu::SLICES + 1) * 2 * m * sizeof(Fr));
+    if (e == hipSuccess) e = hipMemcpyAsync(P->d_idx, lookup_indices, T * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream);
+    if (e != hipSuccess) { delete P; return fail(ATLAS_ENOMEM, "ps_shout_relu_new", e); }
+    rc = P->rows.alloc(1, T);
+    if (!rc) {
+        size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
+        k_ps_fill_one<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(P->rows.buf[0], T);
+        rc = P->eq.init(reinterpret_cast<const H::Fr*>(r_node_output), log_T);
+    }
+    if (!rc) rc = P->build_Q(0);
+    if (rc) { delete P; return rc; }
     *out = P;
     return ATLAS_OK;
 }

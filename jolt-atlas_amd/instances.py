@@ -116,3 +116,13 @@ def eval_reduction_prove(mle, points, claims, transcript):
     _check(lib.atlas_eval_reduction_prove(mle.h, _p(pts), _p(cl), C.c_size_t(N), C.c_size_t(n), C.byref(transcript.t), _p(h),
                                           C.c_size_t(cap), C.byref(hl), _p(r), _p(c)))
     return h[:hl.value].copy(), r[:n].copy(), c
+
+
+def ps_shout_relu(lookup_indices, xlen, r_node_output, gamma):
+    """ps_read_raf_prover for ReluTable<xlen> (ps_shout/unary.rs:110-148)."""
+    idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)
+    rn = np.ascontiguousarray(r_node_output, dtype=np.uint64); g = _fr(gamma)
+    h = C.c_void_p()
+    _check(lib.atlas_ps_shout_relu_new(idx.ctypes.data_as(C.c_void_p), C.c_size_t(len(rn)), C.c_size_t(xlen), _p(rn), _p(g),
+                                       C.byref(h)))
+    return Instance(h)

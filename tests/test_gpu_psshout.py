@@ -1,0 +1,81 @@
+"""GPU parity: prefix-suffix Shout read-raf sumcheck (unary, ReLU table) vs oracle/psshout.c."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _claim(orc, idx, N, r_node, gamma):
+    """rv_claim + gamma * operand_claim = sum_t eq(r_node, t) (relu(x_t) + gamma x_t), x_t signed."""
+    E = orc.eq_evals(r_node)
+    acc = orc.fr_array(1)[0]
+    for t, k in enumerate(idx):
+        k = int(k)
+        x = k - (1 << N) if k >> (N - 1) else k
+        w = orc.fr_array(1)
+        orc.lib.fr_from_i64(x, orc._p(w))
+        rv = orc.from_ints([max(0, x)])[0]
+        term = orc.fr_add_arr(rv, orc.fr_mul_arr(gamma, w[0]))
+        acc = orc.fr_add_arr(acc, orc.fr_mul_arr(E[t], term))
+    return acc
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("N,log_T", [(16, 1), (16, 6), (32, 3), (32, 10), (32, 13)])
+def test_ps_shout_relu_bit_exact(atlas, N, log_T, mode):
+    import ctypes as C
+    from oracle import orc, orc_ra as OR
+    from jolt_atlas_amd import instances as I
+    A = atlas
+    orc.lib.fr_from_i64.argtypes = [C.c_int64, C.c_void_p]
+    A.set_challenge_mode(mode); orc.lib.orc_set_challenge_mode(mode)
+    try:
+        T = 1 << log_T
+        rng = np.random.default_rng(N * 100 + log_T)
+        # activations: mostly small magnitudes of both signs, plus extremes
+        small = rng.integers(-(1 << 14), 1 << 14, size=T, dtype=np.int64)
+        idx = (small & ((1 << N) - 1)).astype(np.uint64)
+        idx[0] = (1 << N) - 1
+        if T > 2:
+            idx[1] = 0; idx[2] = 1 << (N - 1)
+        if T > 4:
+            idx[3] = (1 << (N - 1)) - 1
+        r_node, gamma = orc.random_fr(log_T, 5), orc.random_fr(1, 6)[0]
+        claim = _claim(orc, idx, N, r_node, gamma)
+        t_o = orc.new_transcript(b"ps_relu")
+        rows_o, ch_o = OR.ps_relu(idx, N, r_node, gamma).prove(claim, t_o)
+        inst = I.ps_shout_relu(idx, N, r_node, gamma)
+        assert inst.num_rounds() == N + log_T and inst.degree() == 2
+        t_g = A.Blake2bTranscript(b"ps_relu")
+        rows_g, ch_g = inst.prove(claim, t_g)
+        assert ch_g == ch_o
+        assert len(rows_g) == len(rows_o) and all(np.array_equal(a, b) for a, b in zip(rows_g, rows_o))
+        assert t_g.state == t_o.state_bytes()
+        # final claim: ra(r_address, r_cycle) — MLE over t of eq(r_address, idx_t) at the reversed cycle challenges
+        rs = orc.challenges_to_fr(ch_g)
+        if log_T <= 6:
+            r_addr, r_cyc = rs[:N], rs[N:][::-1]
+            vals = []
+            for k in idx:
+                w = orc.from_ints([1])[0]
+                for i in range(N):
+                    bit = (int(k) >> (N - 1 - i)) & 1
+                    f = r_addr[i] if bit else orc.fr_add_arr(orc.from_ints([1])[0], orc.fr_mul_arr(orc.from_ints([F_MINUS_ONE])[0], r_addr[i]))
+                    w = orc.fr_mul_arr(w, f)
+                vals.append(w)
+            assert np.array_equal(inst.final_claims()[0], orc.evaluate(np.stack(vals), np.ascontiguousarray(r_cyc)))
+        inst.free()
+    finally:
+        A.set_challenge_mode(0); orc.lib.orc_set_challenge_mode(0)
+
+
+F_MINUS_ONE = 21888242871839275222246405745257275088548364400416034343698204186575808495616
+
+
+def test_ps_shout_rejects_unsupported_widths(atlas):
+    from oracle import orc
+    from jolt_atlas_amd import instances as I
+    with pytest.raises(atlas.AtlasError):
+        I.ps_shout_relu(np.zeros(4, dtype=np.uint64), 64, orc.random_fr(2, 1), orc.random_fr(1, 2)[0])
+    with pytest.raises(atlas.AtlasError):
+        I.ps_shout_relu(np.zeros(4, dtype=np.uint64), 8, orc.random_fr(2, 1), orc.random_fr(1, 2)[0])
