@@ -140,6 +140,18 @@ int atlas_fold_i32_rows(const int32_t *d_matrix, size_t rows, size_t cols, atlas
 /* out[j] = sum_i M[i*cols + j] * eq[i]   (`left` of mk,kn->mn with M = A (m x k), eq = eq_r_m) */
 int atlas_fold_i32_cols(const int32_t *d_matrix, size_t rows, size_t cols, atlas_poly_t eq, atlas_poly_t *out);
 
+/* Strided forms covering the batched layouts (ops/einsum/bmk_rhs_mbn.rs:78-110, mbk_rhs_bmn.rs:78-119,
+ * k_nk_n.rs:46-68; transposes of utils/dims.rs:658-690 folded into the output strides):
+ *   rows_batched: out[o0*t0 + o1*t1] = sum_{h<R} M[o0*s0 + o1*s1 + h] * eq[h]   (reduce axis contiguous)
+ *   cols_batched: out[z*tB + j*tC]   = sum_{i<R} M[z*sB + i*sR + j] * eq[i]     (output axis j contiguous)
+ * e.g. bmk,?->mbn: left = cols_batched(B=b, sB=k*m, R=m, sR=k, C=k, tB=1, tC=b); right (kbn) =
+ * rows_batched(n0=k, n1=b, s0=b*n, s1=n, R=n, t0=b, t1=1), (bkn) = rows_batched(n0=b, n1=k, s0=k*n,
+ * s1=n, R=n, t0=1, t1=b).  Output length n0*n1 (B*C) must be a power of two. */
+int atlas_fold_i32_rows_batched(const int32_t *d_matrix, size_t n0, size_t n1, size_t s0, size_t s1, size_t R,
+                                size_t t0, size_t t1, atlas_poly_t eq, atlas_poly_t *out);
+int atlas_fold_i32_cols_batched(const int32_t *d_matrix, size_t B, size_t sB, size_t R, size_t sR, size_t C,
+                                size_t tB, size_t tC, atlas_poly_t eq, atlas_poly_t *out);
+
 /* ---- Shout lookup argument: prover-side table builds
  *      (joltworks/src/subprotocols/shout.rs:193-262, 550-598) ---------------------------- */
 /* ReadRafProver::initialize: G[k] = sum_{j : lookup_indices[j] = k} E[j], E = eq_r (device

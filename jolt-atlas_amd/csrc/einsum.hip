@@ -131,6 +131,50 @@ __global__ __launch_bounds__(FOLD_THREADS) void k_fold_rows(const int32_t* __res
     }
 }
 
+// batched row fold (bmk/mbk/rbmk layouts): out[o0*t0 + o1*t1] = sum_{h < R} M[o0*s0 + o1*s1 + h] * e[h];
+// one workgroup per (o0, o1), lanes stride the contiguous reduce axis
+__global__ __launch_bounds__(FOLD_THREADS) void k_fold_rows_batched(const int32_t* __restrict__ M, const Fe* __restrict__ e,
+                                                                    size_t n1, size_t s0, size_t s1, size_t R, size_t t0, size_t t1,
+                                                                    Fe* __restrict__ out) {
+    using P9 = Fr9Params;
+    const size_t o0 = blockIdx.x / n1, o1 = blockIdx.x % n1;
+    const int32_t* row = M + o0 * s0 + o1 * s1;
+    Cols s; cols_zero(s);
+    int since = 0;
+    for (size_t h = threadIdx.x; h < R; h += FOLD_THREADS) {
+        cols_mad(s, row[h], f9_load(e + h));
+        if (++since == FOLD_NORM_EVERY) { cols_norm(s); since = 0; }
+    }
+    F9 v = f9_wave_sum<P9>(cols_redc(s));
+    __shared__ F9 red[FOLD_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        F9 t = red[0];
+        for (int w = 1; w < FOLD_THREADS / 64; w++) t = f9_norm_red<P9>(f9_add(t, red[w]));
+        fe_store(out + o0 * t0 + o1 * t1, fold_finish(t));
+    }
+}
+
+// batched column fold: out[z*tB + j*tC] = sum_{i < R} M[z*sB + i*sR + j] * e[i]; one thread per (z, j),
+// j contiguous in memory so a wavefront reads 256 B per reduce step
+__global__ __launch_bounds__(FOLD_THREADS) void k_fold_cols_batched(const int32_t* __restrict__ M, const Fe* __restrict__ e,
+                                                                    size_t sB, size_t R, size_t sR, size_t C, size_t tB, size_t tC,
+                                                                    Fe* __restrict__ out) {
+    using P9 = Fr9Params;
+    const size_t j = (size_t)blockIdx.x * FOLD_THREADS + threadIdx.x, z = blockIdx.y;
+    if (j >= C) return;
+    const int32_t* base = M + z * sB + j;
+    Cols s; cols_zero(s);
+    int since = 0;
+    for (size_t i = 0; i < R; i++) {
+        cols_mad(s, base[i * sR], f9_load(e + i));
+        if (++since == FOLD_NORM_EVERY) { cols_norm(s); since = 0; }
+    }
+    fe_store(out + z * tB + j * tC, fold_finish(f9_norm_red<P9>(cols_redc(s))));
+}
+
 // out[j] = sum_i M[i*cols + j] * e[i] : one thread per column j, rows split over blockIdx.y
 // (partial[blockIdx.y][j] as F9-in-Fe; combined by k_fold_cols_finish)
 __global__ __launch_bounds__(FOLD_THREADS) void k_fold_cols(const int32_t* __restrict__ M, const Fe* __restrict__ e,
@@ -208,6 +252,35 @@ int atlas_fold_i32_cols(const int32_t* d_matrix, size_t rows, size_t cols, atlas
     hipError_t e = hipStreamSynchronize(g.stream);
     hipFree(partial);
     if (e != hipSuccess) return fail(ATLAS_ENODEV, "fold_i32_cols", e);
+    return ATLAS_OK;
+}
+
+int atlas_fold_i32_rows_batched(const int32_t* d_matrix, size_t n0, size_t n1, size_t s0, size_t s1, size_t R, size_t t0,
+                                size_t t1, atlas_poly_t eq, atlas_poly_t* out) {
+    NEED_INIT();
+    if (!d_matrix || !eq || !out || n0 == 0 || n1 == 0 || R == 0 || !is_pow2(n0 * n1)) return fail(ATLAS_EINVAL, "fold_i32_rows_batched: n0*n1 must be a power of two");
+    if (eq->is_i32 || eq->len != R) return fail(ATLAS_EINVAL, "fold_i32_rows_batched: eq table length != R");
+    if ((n0 - 1) * t0 + (n1 - 1) * t1 >= n0 * n1) return fail(ATLAS_EINVAL, "fold_i32_rows_batched: output strides leave the n0*n1 range");
+    std::lock_guard<std::mutex> lk(g.mu);
+    int rc = make_poly(n0 * n1, out);
+    if (rc) return rc;
+    k_fold_rows_batched<<<(unsigned)(n0 * n1), FOLD_THREADS, 0, g.stream>>>(d_matrix, (const Fe*)eq->d, n1, s0, s1, R, t0, t1, (Fe*)(*out)->d);
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return ATLAS_OK;
+}
+
+int atlas_fold_i32_cols_batched(const int32_t* d_matrix, size_t B, size_t sB, size_t R, size_t sR, size_t C, size_t tB, size_t tC,
+                                atlas_poly_t eq, atlas_poly_t* out) {
+    NEED_INIT();
+    if (!d_matrix || !eq || !out || B == 0 || C == 0 || R == 0 || !is_pow2(B * C)) return fail(ATLAS_EINVAL, "fold_i32_cols_batched: B*C must be a power of two");
+    if (eq->is_i32 || eq->len != R) return fail(ATLAS_EINVAL, "fold_i32_cols_batched: eq table length != R");
+    if ((B - 1) * tB + (C - 1) * tC >= B * C) return fail(ATLAS_EINVAL, "fold_i32_cols_batched: output strides leave the B*C range");
+    std::lock_guard<std::mutex> lk(g.mu);
+    int rc = make_poly(B * C, out);
+    if (rc) return rc;
+    k_fold_cols_batched<<<dim3((unsigned)((C + FOLD_THREADS - 1) / FOLD_THREADS), (unsigned)B), FOLD_THREADS, 0, g.stream>>>(
+        d_matrix, (const Fe*)eq->d, sB, R, sR, C, tB, tC, (Fe*)(*out)->d);
+    HIP_TRY(hipStreamSynchronize(g.stream));
     return ATLAS_OK;
 }
 

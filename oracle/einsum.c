@@ -3,6 +3,8 @@
  * (jolt-atlas-core/src/onnx_proof/ops/einsum/mk_kn_mn.rs:47-79):
  *   left[j]  = sum_i from_i32(A[i*k + j]) * eq_m[i]
  *   right[j] = sum_h from_i32(B[j*n + h]) * eq_n[h] */
+#include <stdlib.h>
+#include <string.h>
 #include "oracle.h"
 
 void orc_fold_i32_cols(const int32_t *M, size_t rows, size_t cols, const fr_t *eq, fr_t *out) {
@@ -25,4 +27,54 @@ void orc_fold_i32_rows(const int32_t *M, size_t rows, size_t cols, const fr_t *e
         }
         out[j] = acc;
     }
+}
+
+/* Folds of the other einsum layouts, loops as written in the reference
+ * (jolt-atlas-core/src/onnx_proof/ops/einsum/): layout 0 = bmk,bkn->mbn, 1 = bmk,kbn->mbn
+ * (bmk_rhs_mbn.rs:78-110 + transpose_flat_matrix, utils/dims.rs:658-690), 2 = mbk,bnk->bmn,
+ * 3 = mbk,nbk->bmn (mbk_rhs_bmn.rs:78-119), 4 = k,nk->n (k_nk_n.rs:46-68, right only).
+ * left_out / right_out: k*b Fr each (layout 4: right_out k Fr, left_out unused). */
+static void transpose_flat(const fr_t *v, size_t num_rows, size_t num_cols, fr_t *out) {
+    for (size_t j = 0; j < num_cols; j++) for (size_t i = 0; i < num_rows; i++) out[j * num_rows + i] = v[i * num_cols + j];
+}
+
+void orc_einsum_fold_layout(int layout, const int32_t *left, const int32_t *right, size_t b, size_t m, size_t k, size_t n,
+                            const fr_t *eq_r_m, const fr_t *eq_r_n, fr_t *left_out, fr_t *right_out) {
+    fr_t a, t;
+    if (layout == 4) {
+        for (size_t j = 0; j < k; j++) {
+            fr_t acc; fr_zero(&acc);
+            for (size_t h = 0; h < n; h++) { fr_from_i64(right[h * k + j], &a); fr_mul(&a, &eq_r_n[h], &t); fr_add(&acc, &t, &acc); }
+            right_out[j] = acc;
+        }
+        return;
+    }
+    fr_t *lo = (fr_t *)malloc(k * b * sizeof(fr_t)), *ro = (fr_t *)malloc(k * b * sizeof(fr_t));
+    if (layout <= 1) {
+        for (size_t h = 0; h < b; h++) for (size_t j = 0; j < k; j++) {
+            fr_t acc; fr_zero(&acc);
+            for (size_t i = 0; i < m; i++) { fr_from_i64(left[h * (k * m) + i * k + j], &a); fr_mul(&a, &eq_r_m[i], &t); fr_add(&acc, &t, &acc); }
+            lo[h * k + j] = acc;
+        }
+        for (size_t j = 0; j < k; j++) for (size_t h = 0; h < b; h++) {
+            fr_t acc; fr_zero(&acc);
+            for (size_t l = 0; l < n; l++) { fr_from_i64(right[j * (b * n) + h * n + l], &a); fr_mul(&a, &eq_r_n[l], &t); fr_add(&acc, &t, &acc); }
+            ro[j * b + h] = acc;
+        }
+        transpose_flat(lo, b, k, left_out);
+        if (layout == 0) transpose_flat(ro, b, k, right_out); else memcpy(right_out, ro, k * b * sizeof(fr_t));
+    } else {
+        for (size_t h = 0; h < b; h++) for (size_t j = 0; j < k; j++) {
+            fr_t acc; fr_zero(&acc);
+            for (size_t i = 0; i < m; i++) { fr_from_i64(left[i * (k * b) + h * k + j], &a); fr_mul(&a, &eq_r_m[i], &t); fr_add(&acc, &t, &acc); }
+            left_out[h * k + j] = acc;
+            fr_zero(&acc);
+            for (size_t l = 0; l < n; l++) {
+                const size_t idx = layout == 2 ? h * (n * k) + l * k + j : l * (k * b) + h * k + j;
+                fr_from_i64(right[idx], &a); fr_mul(&a, &eq_r_n[l], &t); fr_add(&acc, &t, &acc);
+            }
+            right_out[h * k + j] = acc;
+        }
+    }
+    free(lo); free(ro);
 }
