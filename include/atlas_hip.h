@@ -264,6 +264,12 @@ int atlas_ps_shout_relu_new(const uint64_t *lookup_indices, size_t log_T, size_t
                             const atlas_fr_t *r_node_output, const atlas_fr_t *gamma,
                             atlas_instance_t *out);
 
+/* IdentityRCProver::gen (joltworks/src/subprotocols/identity_range_check.rs:196-420): the range check
+ * sum_{k,t} eq(r_node_output, t) ra(k, t) Identity(k) over log_K address bits in `phases` phases
+ * (IdentityRCProvider::{log_K, phases}), then log_T cycle rounds; degree 2; final claim = ra(r). */
+int atlas_identity_range_check_new(const uint64_t *lookup_indices, size_t log_T, size_t log_K, size_t phases,
+                                   const atlas_fr_t *r_node_output, atlas_instance_t *out);
+
 /* ---- N-to-1 evaluation reduction: EvalReductionInstance::prove with compute_h and eval_on_l
  *      (joltworks/src/subprotocols/evaluation_reduction.rs:91-147, 213-249).  points = N rows of n
  *      Fr (the opening points of one polynomial), claims = N Fr.  h(t) = P(l(t)) is returned as

@@ -507,8 +507,9 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_fold(const Fr* __restrict__ r
 }
 
 struct PsRelu : atlas_instance {
-    size_t N = 0, log_m = 0, m = 0, log_T = 0, T = 0, round_next = 0;
-    H::Fr gamma;
+    size_t N = 0, log_m = 0, m = 0, log_T = 0, T = 0, round_next = 0, phases = 8;   // N = LOG_K
+    int mode = 0;                         // 0 = ReLU + gamma * SignedIdentity (unary read-raf), 1 = Identity (range check)
+    H::Fr gamma = H::zero();
     uint64_t* d_idx = nullptr;
     Fr *d_u0 = nullptr, *d_v = nullptr, *d_qpart = nullptr;
     RaRows rows;                          // row 0 = running product of the v tables = ra at the end
@@ -523,10 +524,10 @@ struct PsRelu : atlas_instance {
     size_t degree() const override { return 2; }
 
     static H::Fr pow2(size_t k) { H::Fr o = H::one(); const H::Fr two = H::from_u64(2); for (size_t i = 0; i < k; i++) o = H::mul(o, two); return o; }
-    H::Fr weight(size_t i) const { H::Fr w = pow2(N - 1 - i); return i == 0 ? H::sub(w, pow2(N)) : w; }   // SId coefficient of bit i
+    H::Fr weight(size_t i) const { H::Fr w = pow2(N - 1 - i); return (i == 0 && mode == 0) ? H::sub(w, pow2(N)) : w; }   // (Signed)Identity coefficient of bit i
 
     int build_Q(size_t phase) {           // init_phase: Q tables of `phase` from the current products
-        const uint32_t suffix_len = (uint32_t)((8 - 1 - phase) * log_m);
+        const uint32_t suffix_len = (uint32_t)((phases - 1 - phase) * log_m);
         k_ps_q<<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), d_qpart);
         k_col_reduce<<<(unsigned)(2 * m), RA_THREADS, 0, g.stream>>>(d_qpart, SLICES, (uint32_t)(2 * m), d_qpart + (size_t)SLICES * 2 * m);
         std::vector<H::Fr> q(2 * m);
@@ -557,9 +558,10 @@ struct PsRelu : atlas_instance {
                     const H::Fr q1 = ci ? H::sub(H::add(Q1[b + half], Q1[b + half]), Q1[b]) : Q1[b];
                     const H::Fr qs = ci ? H::sub(H::add(Qs[b + half], Qs[b + half]), Qs[b]) : Qs[b];
                     // Val: not_msb * (word * 1 + suffix);  RAF: gamma * (sid * 1 + suffix)
+                    const H::Fr idt = H::add(H::mul(H::add(sid_c, bs), q1), qs);          // (Signed)Identity term
+                    if (mode == 1) { acc = H::add(acc, idt); continue; }
                     const H::Fr val = H::mul(not_msb, H::add(H::mul(H::add(word_c, bs), q1), qs));
-                    const H::Fr raf = H::mul(gamma, H::add(H::mul(H::add(sid_c, bs), q1), qs));
-                    acc = H::add(acc, H::add(val, raf));
+                    acc = H::add(acc, H::add(val, H::mul(gamma, idt)));
                 }
                 ev[ci] = acc;
             }
@@ -598,14 +600,14 @@ struct PsRelu : atlas_instance {
                 std::lock_guard<std::mutex> lk(g.mu);
                 HIP_TRY(hipMemcpyAsync(d_v, v.data(), m * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
                 size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
-                k_ps_scale<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(d_idx, d_v, T, (uint32_t)((8 - 1 - p) * log_m), (uint32_t)(m - 1), rows.buf[0]);
+                k_ps_scale<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(d_idx, d_v, T, (uint32_t)((phases - 1 - p) * log_m), (uint32_t)(m - 1), rows.buf[0]);
                 HIP_TRY(hipStreamSynchronize(g.stream));
-                if (p != 7) { int rc = build_Q(p + 1); if (rc) return rc; }
+                if (p != phases - 1) { int rc = build_Q(p + 1); if (rc) return rc; }
             }
             if (j + 1 == N) {
                 // val = Val~(r_address), raf_val = gamma * SId~(r_address)   (mod.rs:523-548)
                 const H::Fr val = H::mul(H::sub(H::one(), r_addr[0]), word_acc);
-                wv = H::add(val, H::mul(gamma, sid_acc));
+                wv = mode == 1 ? sid_acc : H::add(val, H::mul(gamma, sid_acc));            // identity_range_check.rs:377-380
                 rows.cur = 0; rows.stride[0] = T; rows.len = T;       // the products are ra (init_log_t_rounds)
             }
         } else {
@@ -699,26 +701,23 @@ int atlas_hamming_weight_new(const atlas_fr_t* G, size_t d, size_t log_k_chunk, 
     return ATLAS_OK;
 }
 
-int atlas_ps_shout_relu_new(const uint64_t* lookup_indices, size_t log_T, size_t xlen, const atlas_fr_t* r_node_output,
-                            const atlas_fr_t* gamma, atlas_instance_t* out) {
-    NEED_INIT();
-    if (!lookup_indices || !r_node_output || !gamma || !out) return fail(ATLAS_EINVAL, "ps_shout_relu_new: null argument");
-    if (xlen != 16 && xlen != 32) return fail(ATLAS_EINVAL, "ps_shout_relu_new: X_LEN must be 16 or 32 (the reference's WordNoMSB suffix is a u32)");
-    if (log_T == 0 || log_T > 25) return fail(ATLAS_EINVAL, "ps_shout_relu_new: 1 <= log_T <= 25");
+static int ps_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, size_t phases, int mode, const atlas_fr_t* r_node_output,
+                  const atlas_fr_t* gamma, atlas_instance_t* out) {
     atlas_poly_t E = nullptr;
     int rc = atlas_eq_evals(r_node_output, log_T, nullptr, &E);      // u_evals = EqPolynomial::evals(r_node_output), mod.rs:234
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(g.mu);
     PsRelu* P = new PsRelu();
-    P->N = xlen; P->log_m = xlen / 8; P->m = (size_t)1 << P->log_m; P->log_T = log_T; P->T = (size_t)1 << log_T;
-    std::memcpy(&P->gamma, gamma, 32);
+    P->N = log_K; P->phases = phases; P->mode = mode;
+    P->log_m = log_K / phases; P->m = (size_t)1 << P->log_m; P->log_T = log_T; P->T = (size_t)1 << log_T;
+    if (gamma) std::memcpy(&P->gamma, gamma, 32);
     P->d_u0 = (Fr*)E->d; delete E;                                   // keep the table, drop the handle
     const size_t T = P->T, m = P->m;
     hipError_t e = hipMalloc(&P->d_idx, T * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc(&P->d_v, m * sizeof(Fr));
     if (e == hipSuccess) e = hipMalloc(&P->d_qpart, ((size_t)PsRelu::SLICES + 1) * 2 * m * sizeof(Fr));
     if (e == hipSuccess) e = hipMemcpyAsync(P->d_idx, lookup_indices, T * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream);
-    if (e != hipSuccess) { delete P; return fail(ATLAS_ENOMEM, "ps_shout_relu_new", e); }
+    if (e != hipSuccess) { delete P; return fail(ATLAS_ENOMEM, "ps_shout_new", e); }
     rc = P->rows.alloc(1, T);
     if (!rc) {
         size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
@@ -729,6 +728,25 @@ int atlas_ps_shout_relu_new(const uint64_t* lookup_indices, size_t log_T, size_t
     if (rc) { delete P; return rc; }
     *out = P;
     return ATLAS_OK;
+}
+
+int atlas_ps_shout_relu_new(const uint64_t* lookup_indices, size_t log_T, size_t xlen, const atlas_fr_t* r_node_output,
+                            const atlas_fr_t* gamma, atlas_instance_t* out) {
+    NEED_INIT();
+    if (!lookup_indices || !r_node_output || !gamma || !out) return fail(ATLAS_EINVAL, "ps_shout_relu_new: null argument");
+    if (xlen != 16 && xlen != 32) return fail(ATLAS_EINVAL, "ps_shout_relu_new: X_LEN must be 16 or 32 (the reference's WordNoMSB suffix is a u32)");
+    if (log_T == 0 || log_T > 25) return fail(ATLAS_EINVAL, "ps_shout_relu_new: 1 <= log_T <= 25");
+    return ps_new(lookup_indices, log_T, xlen, 8, 0, r_node_output, gamma, out);
+}
+
+int atlas_identity_range_check_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, size_t phases,
+                                   const atlas_fr_t* r_node_output, atlas_instance_t* out) {
+    NEED_INIT();
+    if (!lookup_indices || !r_node_output || !out) return fail(ATLAS_EINVAL, "identity_range_check_new: null argument");
+    if (phases == 0 || log_K == 0 || log_K > 64 || log_K % phases || log_K / phases > 12)
+        return fail(ATLAS_EINVAL, "identity_range_check_new: log_K must be a multiple of phases, chunks of at most 12 bits");
+    if (log_T == 0 || log_T > 25) return fail(ATLAS_EINVAL, "identity_range_check_new: 1 <= log_T <= 25");
+    return ps_new(lookup_indices, log_T, log_K, phases, 1, r_node_output, nullptr, out);
 }
 
 }  // extern "C"

@@ -126,3 +126,13 @@ def ps_shout_relu(lookup_indices, xlen, r_node_output, gamma):
     _check(lib.atlas_ps_shout_relu_new(idx.ctypes.data_as(C.c_void_p), C.c_size_t(len(rn)), C.c_size_t(xlen), _p(rn), _p(g),
                                        C.byref(h)))
     return Instance(h)
+
+
+def identity_range_check(lookup_indices, log_K, phases, r_node_output):
+    """IdentityRCProver::gen (identity_range_check.rs:196-233)."""
+    idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)
+    rn = np.ascontiguousarray(r_node_output, dtype=np.uint64)
+    h = C.c_void_p()
+    _check(lib.atlas_identity_range_check_new(idx.ctypes.data_as(C.c_void_p), C.c_size_t(len(rn)), C.c_size_t(log_K),
+                                              C.c_size_t(phases), _p(rn), C.byref(h)))
+    return Instance(h)

@@ -131,3 +131,15 @@ def ps_relu(lookup_indices, N, r_node, gamma):
     I.keep = [idx, rn, g]
     orc.lib.orc_ps_relu_init(I.st, idx.ctypes.data_as(C.c_void_p), C.c_size_t(N), C.c_size_t(len(rn)), orc._p(rn), orc._p(g))
     return I
+
+
+PS_IDENTITY = 8
+
+
+def ps_identity(lookup_indices, log_K, phases, r_node):
+    """IdentityRCProver (identity_range_check.rs:196-420)."""
+    idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64); rn = np.ascontiguousarray(r_node, dtype=np.uint64)
+    I = Instance(PS_IDENTITY, log_K + len(rn))
+    I.keep = [idx, rn]
+    orc.lib.orc_ps_identity_init(I.st, idx.ctypes.data_as(C.c_void_p), C.c_size_t(log_K), C.c_size_t(phases), C.c_size_t(len(rn)), orc._p(rn))
+    return I

@@ -217,3 +217,119 @@ void orc_ps_relu_ingest(orc_ps_relu *S, size_t round, const fr_t *r) {      /* m
         gse_bind(&S->eq, r);
     }
 }
+
+/* ------------------------------------------------------------------ IdentityRCProver
+ * subprotocols/identity_range_check.rs:196-420 with IdentityPolynomial's prefix-suffix decomposition
+ * (poly/identity_poly.rs:112-165): suffixes [Shift: 2^len(b), Identity: b], prefix polynomial
+ * bound * 2^chunk_len + i, UNSIGNED accumulation (prefix_suffix.rs:237-330). */
+static void idrc_init_phase(orc_ps_identity *S, size_t phase) {
+    const size_t log_m = S->log_m, m = S->m, m_mask = m - 1, T = S->T;
+    if (phase != 0)
+        for (size_t t = 0; t < T; t++) {
+            const uint64_t k_bound = split_prefix(S->idx[t], (S->phases - phase) * log_m) & m_mask;
+            fr_mul(&S->u[t], &S->v[phase - 1][k_bound], &S->u[t]);
+        }
+    const size_t suffix_len = (S->phases - 1 - phase) * log_m;
+    for (int s = 0; s < 2; s++) for (size_t y = 0; y < m; y++) fr_zero(&S->Q[s][y]);
+    fr_t shift; fr_pow2((unsigned)suffix_len, &shift);                       /* ShiftSuffixPolynomial: 1 << b.len() */
+    for (size_t t = 0; t < T; t++) {
+        const uint64_t y = split_prefix(S->idx[t], suffix_len) & m_mask, sb = split_suffix(S->idx[t], suffix_len);
+        fr_t x; fr_mul(&S->u[t], &shift, &x); fr_add(&S->Q[0][y], &x, &S->Q[0][y]);
+        if (sb) { fr_t w; fr_from_u64(sb, &w); fr_mul(&S->u[t], &w, &x); fr_add(&S->Q[1][y], &x, &S->Q[1][y]); }
+    }
+    S->Q_len = m;
+    fr_t bound, sc; if (S->has_cp) bound = S->cp; else fr_zero(&bound);
+    fr_pow2((unsigned)log_m, &sc); fr_mul(&bound, &sc, &bound);              /* bound_value.mul_u128(1 << chunk_len) */
+    for (size_t i = 0; i < m; i++) { fr_t vi; fr_from_u64(i, &vi); fr_add(&bound, &vi, &S->P[i]); }
+    S->P_len = m;
+    fr_one(&S->v[phase][0]); S->v_len[phase] = 1;
+}
+
+void orc_ps_identity_init(orc_ps_identity *S, const uint64_t *idx, size_t log_K, size_t phases, size_t log_T, const fr_t *r_node) {
+    memset(S, 0, sizeof *S);
+    S->log_K = log_K; S->phases = phases; S->log_T = log_T; S->log_m = log_K / phases; S->m = (size_t)1 << S->log_m; S->T = (size_t)1 << log_T;
+    S->idx = idx;
+    S->u = (fr_t *)malloc(S->T * sizeof(fr_t)); orc_eq_evals(r_node, log_T, 0, S->u);
+    for (int s = 0; s < 2; s++) S->Q[s] = (fr_t *)malloc(S->m * sizeof(fr_t));
+    S->P = (fr_t *)malloc(S->m * sizeof(fr_t));
+    for (size_t p = 0; p < phases; p++) S->v[p] = (fr_t *)calloc(S->m, sizeof(fr_t));
+    gse_init(&S->eq, r_node, log_T);
+    idrc_init_phase(S, 0);
+}
+
+void orc_ps_identity_free(orc_ps_identity *S) {
+    free(S->u); free(S->Q[0]); free(S->Q[1]); free(S->P);
+    for (size_t p = 0; p < S->phases; p++) free(S->v[p]);
+    if (S->ra) free(S->ra);
+    gse_free(&S->eq);
+}
+
+size_t orc_ps_identity_message(orc_ps_identity *S, size_t round, const fr_t *claim, fr_t *coeffs) {
+    if (round < S->log_K) {
+        const size_t half = S->Q_len / 2;
+        fr_t o0, o2l, o2r; fr_zero(&o0); fr_zero(&o2l); fr_zero(&o2r);
+        for (size_t b = 0; b < half; b++) {                                  /* identity_ps.sumcheck_evals(b) */
+            fr_t p0 = S->P[b], p2, m, t; fr_sub(&S->P[b + S->P_len / 2], &p0, &m); fr_add(&S->P[b + S->P_len / 2], &m, &p2);
+            fr_mul(&p0, &S->Q[0][b], &t); fr_add(&o0, &t, &o0);
+            fr_mul(&p2, &S->Q[0][b], &t); fr_add(&o2l, &t, &o2l);
+            fr_mul(&p2, &S->Q[0][b + half], &t); fr_add(&o2r, &t, &o2r);
+            fr_add(&o0, &S->Q[1][b], &o0); fr_add(&o2l, &S->Q[1][b], &o2l); fr_add(&o2r, &S->Q[1][b + half], &o2r);
+        }
+        fr_t ev[2]; ev[0] = o0; fr_add(&o2r, &o2r, &ev[1]); fr_sub(&ev[1], &o2l, &ev[1]);
+        return orc_unipoly_from_evals_and_hint(claim, ev, 2, coeffs);
+    }
+    const gse_t *E = &S->eq;
+    const fr_t *e_out = E->Eout[E->out_top], *e_in = E->Ein[E->in_top];
+    const size_t out_len = (size_t)1 << E->out_top, in_len = (size_t)1 << E->in_top;
+    fr_t acc; fr_zero(&acc);
+    for (size_t xo = 0; xo < out_len; xo++) {
+        fr_t inner; fr_zero(&inner);
+        for (size_t xi = 0; xi < in_len; xi++) { const size_t jj = (xo << E->in_top) | xi; fr_t t; fr_mul(&e_in[xi], &S->ra[2 * jj], &t); fr_add(&inner, &t, &inner); }
+        fr_mul(&e_out[xo], &inner, &inner); fr_add(&acc, &inner, &acc);
+    }
+    fr_t q0; fr_mul(&acc, &S->raf_val, &q0);
+    fr_t eq1, eq0, eqm, eq2, c0, c1, l1, l2, inv, ev2[2], hint;
+    fr_mul(&E->scalar, &E->w[E->current_index - 1], &eq1); fr_sub(&E->scalar, &eq1, &eq0);
+    fr_sub(&eq1, &eq0, &eqm); fr_add(&eq1, &eqm, &eq2);
+    fr_mul(&eq0, &q0, &c0); fr_sub(claim, &c0, &c1);
+    fr_inv(&eq1, &inv); fr_mul(&c1, &inv, &l1);
+    fr_add(&l1, &l1, &l2); fr_sub(&l2, &q0, &l2);
+    ev2[0] = c0; fr_mul(&eq2, &l2, &ev2[1]); fr_add(&c0, &c1, &hint);
+    return orc_unipoly_from_evals_and_hint(&hint, ev2, 2, coeffs);
+}
+
+void orc_ps_identity_ingest(orc_ps_identity *S, size_t round, const fr_t *r) {
+    const size_t log_m = S->log_m;
+    if (round < S->log_K) {
+        const size_t phase = round / log_m;
+        size_t ql = S->Q_len;
+        for (int s = 0; s < 2; s++) { size_t l = ql; bind_h2l(S->Q[s], &l, r); }
+        S->Q_len = ql / 2;
+        bind_h2l(S->P, &S->P_len, r);
+        {
+            const size_t n = S->v_len[phase];
+            fr_t *nv = (fr_t *)calloc(S->m, sizeof(fr_t));
+            for (size_t i = 0; i < n; i++) { fr_mul(r, &S->v[phase][i], &nv[2 * i + 1]); fr_sub(&S->v[phase][i], &nv[2 * i + 1], &nv[2 * i]); }
+            free(S->v[phase]); S->v[phase] = nv; S->v_len[phase] = 2 * n;
+        }
+        if ((round + 1) % log_m == 0) {
+            S->cp = S->P[0]; S->has_cp = 1;
+            if (phase != S->phases - 1) idrc_init_phase(S, phase + 1);
+        }
+        if (round + 1 == S->log_K) {
+            S->raf_val = S->cp;
+            S->ra = (fr_t *)malloc(S->T * sizeof(fr_t)); S->ra_len = S->T;
+            for (size_t t = 0; t < S->T; t++) {
+                fr_t p; fr_one(&p);
+                for (size_t ph = 0; ph < S->phases; ph++) {
+                    const uint64_t kb = split_prefix(S->idx[t], (S->phases - 1 - ph) * log_m) & (S->m - 1);
+                    fr_mul(&p, &S->v[ph][kb], &p);
+                }
+                S->ra[t] = p;
+            }
+        }
+    } else {
+        orc_bind(S->ra, S->ra_len, r, ORC_LOW_TO_HIGH); S->ra_len /= 2;
+        gse_bind(&S->eq, r);
+    }
+}

@@ -21,4 +21,19 @@ void   orc_ps_relu_init(orc_ps_relu *S, const uint64_t *idx, size_t N, size_t lo
 void   orc_ps_relu_free(orc_ps_relu *S);
 size_t orc_ps_relu_message(orc_ps_relu *S, size_t round, const fr_t *claim, fr_t *coeffs);
 void   orc_ps_relu_ingest(orc_ps_relu *S, size_t round, const fr_t *r);
+
+enum { ORC_INST_PS_IDENTITY = 8 };
+typedef struct {
+    size_t log_K, phases, log_T, log_m, m, T, Q_len, P_len, ra_len;
+    const uint64_t *idx;
+    fr_t *u, *Q[2], *P, *v[64], *ra;
+    size_t v_len[64];
+    fr_t cp, raf_val; int has_cp;
+    gse_t eq;
+} orc_ps_identity;
+/* IdentityRCProver (subprotocols/identity_range_check.rs:196-420): sum eq(r_node,t) ra(k,t) Id(k) */
+void   orc_ps_identity_init(orc_ps_identity *S, const uint64_t *idx, size_t log_K, size_t phases, size_t log_T, const fr_t *r_node);
+void   orc_ps_identity_free(orc_ps_identity *S);
+size_t orc_ps_identity_message(orc_ps_identity *S, size_t round, const fr_t *claim, fr_t *coeffs);
+void   orc_ps_identity_ingest(orc_ps_identity *S, size_t round, const fr_t *r);
 #endif

@@ -307,3 +307,15 @@ class PsReluModel:
 
     def finals(self):
         return [self.ra[0]]
+
+
+class PsIdentityModel(PsReluModel):
+    """IdentityRC: sum_{k,t} eq(r_node,t) [k = idx_t] Id(k), Id~(x) = sum_i x_i 2^(L-1-i)
+    (identity_range_check.rs:196-420), same closed-form evaluation as PsReluModel."""
+
+    def __init__(self, idx, log_K, r_node):
+        super().__init__(idx, log_K, r_node, 0)
+
+    def _W(self, x):
+        N = self.N
+        return sum(x[i] * (1 << (N - 1 - i)) for i in range(N)) % FR

@@ -79,3 +79,31 @@ def test_ps_shout_rejects_unsupported_widths(atlas):
         I.ps_shout_relu(np.zeros(4, dtype=np.uint64), 64, orc.random_fr(2, 1), orc.random_fr(1, 2)[0])
     with pytest.raises(atlas.AtlasError):
         I.ps_shout_relu(np.zeros(4, dtype=np.uint64), 8, orc.random_fr(2, 1), orc.random_fr(1, 2)[0])
+
+
+@pytest.mark.parametrize("log_K,phases,log_T", [(8, 4, 2), (16, 8, 9), (16, 2, 5), (32, 8, 12), (64, 8, 7), (12, 3, 6)])
+def test_identity_range_check_bit_exact(atlas, log_K, phases, log_T):
+    from oracle import orc, orc_ra as OR
+    from jolt_atlas_amd import instances as I
+    A = atlas
+    T = 1 << log_T
+    rng = np.random.default_rng(log_K * 10 + log_T)
+    hi = (1 << log_K) - 1
+    idx = rng.integers(0, hi, size=T, dtype=np.uint64, endpoint=True)
+    idx[0] = hi; idx[1] = 0
+    r_node = orc.random_fr(log_T, 8)
+    E = orc.eq_evals(r_node)
+    claim = orc.fr_array(1)[0]
+    for t in range(T):
+        claim = orc.fr_add_arr(claim, orc.fr_mul_arr(E[t], orc.from_ints([int(idx[t])])[0]))
+    t_o = orc.new_transcript(b"identity_rc")
+    rows_o, ch_o = OR.ps_identity(idx, log_K, phases, r_node).prove(claim, t_o)
+    inst = I.identity_range_check(idx, log_K, phases, r_node)
+    assert inst.num_rounds() == log_K + log_T
+    t_g = A.Blake2bTranscript(b"identity_rc")
+    rows_g, ch_g = inst.prove(claim, t_g)
+    assert ch_g == ch_o
+    assert len(rows_g) == len(rows_o) and all(np.array_equal(a, b) for a, b in zip(rows_g, rows_o))
+    assert t_g.state == t_o.state_bytes()
+    assert len(inst.final_claims()) == 1
+    inst.free()

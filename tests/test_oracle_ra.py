@@ -236,3 +236,21 @@ def test_ps_shout_relu_oracle_matches_closed_form_model(N, log_T):
     assert raw_o == raw_p
     assert [orc.to_ints(r) for r in rows_o] == rows_p
     assert bytes(to.state) == tp.state
+
+
+@pytest.mark.parametrize("log_K,phases,log_T", [(8, 4, 2), (16, 8, 3), (16, 2, 1), (12, 3, 4), (32, 8, 2)])
+def test_identity_range_check_oracle_matches_closed_form_model(log_K, phases, log_T):
+    T = 1 << log_T
+    rng = np.random.default_rng(log_K + phases + log_T)
+    idx = [int(x) for x in rng.integers(0, 1 << log_K, size=T, dtype=np.uint64)]
+    idx[0] = (1 << log_K) - 1
+    r_node = _rand(log_T, 3)
+    model = PR.PsIdentityModel(idx, log_K, r_node)
+    claim = model.input_claim()
+    rows_p, raw_p, tp = _prove_py(model, claim, b"identity_rc")
+    inst = OR.ps_identity(idx, log_K, phases, orc.from_ints(r_node))
+    to = orc.new_transcript(b"identity_rc")
+    rows_o, raw_o = inst.prove(orc.from_ints([claim])[0], to)
+    assert raw_o == raw_p
+    assert [orc.to_ints(r) for r in rows_o] == rows_p
+    assert bytes(to.state) == tp.state
