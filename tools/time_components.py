@@ -134,6 +134,33 @@ def main():
         return dt
     batched_once()
     out[f"batched_4xdot_2^{a.log_t}_prove_ms"] = 1e3 * float(np.median([batched_once() for _ in range(3)]))
+
+    # ---- prefix-suffix Shout (ReLU, X_LEN = 32) and the identity range check at T = 2^log_t
+    act = (rng.integers(-(1 << 14), 1 << 14, size=Tt, dtype=np.int64) & 0xffffffff).astype(np.uint64)
+    rn = A.random_fr(a.log_t, 21); gm = A.random_fr(1, 22)[0]
+
+    def ps_once():
+        t0 = time.perf_counter()
+        inst = I.ps_shout_relu(act, 32, rn, gm)
+        t1 = time.perf_counter()
+        inst.prove(A.random_fr(1, 1)[0], A.Blake2bTranscript(b"t"))
+        t2 = time.perf_counter()
+        inst.free()
+        return t1 - t0, t2 - t1
+    ps_once()
+    r = [ps_once() for _ in range(3)]
+    out[f"ps_shout_relu32_T2^{a.log_t}_new_ms_incl_h2d"] = 1e3 * float(np.median([x[0] for x in r]))
+    out[f"ps_shout_relu32_T2^{a.log_t}_prove_ms"] = 1e3 * float(np.median([x[1] for x in r]))
+
+    def idrc_once():
+        inst = I.identity_range_check(act & np.uint64(0xffff), 16, 8, rn)
+        t1 = time.perf_counter()
+        inst.prove(A.random_fr(1, 1)[0], A.Blake2bTranscript(b"t"))
+        t2 = time.perf_counter()
+        inst.free()
+        return t2 - t1
+    idrc_once()
+    out[f"identity_rc_logK16_T2^{a.log_t}_prove_ms"] = 1e3 * float(np.median([idrc_once() for _ in range(3)]))
     print(json.dumps(out, indent=1))
     if a.out:
         with open(a.out, "w") as f:
