@@ -264,6 +264,13 @@ int atlas_ps_shout_relu_new(const uint64_t *lookup_indices, size_t log_T, size_t
                             const atlas_fr_t *r_node_output, const atlas_fr_t *gamma,
                             atlas_instance_t *out);
 
+/* The same read-raf prover for the clamp family ClampBoundedTable<X_LEN, BOUND, SYMMETRIC>
+ * (joltworks/src/lookup_tables/clamp.rs:44-121): ClampTable = (X_LEN, 9, true), SaturationTable =
+ * (64, 31, true), ActivationClampTable = (X_LEN, MODEL_SCALE + 3, true), SoftmaxClampTable =
+ * (X_LEN, SOFTMAX_CLAMP_BOUND, false).  X_LEN = 16, 32 or 64; BOUND <= 31. */
+int atlas_ps_shout_clamp_new(const uint64_t *lookup_indices, size_t log_T, size_t xlen, size_t bound,
+                             int symmetric, const atlas_fr_t *r_node_output, const atlas_fr_t *gamma,
+                             atlas_instance_t *out);
 /* IdentityRCProver::gen (joltworks/src/subprotocols/identity_range_check.rs:196-420): the range check
  * sum_{k,t} eq(r_node_output, t) ra(k, t) Identity(k) over log_K address bits in `phases` phases
  * (IdentityRCProvider::{log_K, phases}), then log_T cycle rounds; degree 2; final claim = ra(r). */

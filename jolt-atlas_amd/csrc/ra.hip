@@ -459,29 +459,53 @@ struct HammingWeight : atlas_instance {
 // k_ps_q (one workgroup per (bin, slice of T)); the per-round arithmetic over the 2^log_m entries —
 // prefix evaluations, binding Q and the expanding table v_p — is host work.  The reference keeps the
 // WordNoMSB suffix as u32, which is exact for N <= 32; N = 64 is refused here for that reason.
+// spec of the suffix functions: mode 0/1 -> {1, suffix}; mode 2 (clamp, BOUND) additionally
+// {HAZ_s, HAZ_s * lw_s, HAO_s, HAO_s * lw_s} with HAZ_s / HAO_s = "the suffix bits of significance >= BOUND are
+// all zero / all one" and lw_s = the suffix bits below BOUND (suffixes/higher_all_zero.rs, hzero_mul_lword.rs,
+// hone_mul_lword.rs)
+template <int NQ>
 __global__ __launch_bounds__(RA_THREADS) void k_ps_q(const uint64_t* __restrict__ idx, const Fr* __restrict__ u0,
                                                      const Fr* __restrict__ prod, size_t T, uint32_t suffix_len, uint32_t m_mask,
-                                                     Fr* __restrict__ partials /* [slices][2 m] */) {
-    __shared__ Fr red[RA_THREADS / 64][2];
+                                                     uint32_t bound, Fr* __restrict__ partials /* [slices][NQ m] */) {
+    __shared__ Fr red[RA_THREADS / 64][NQ];
     const uint32_t y = blockIdx.x, slice = blockIdx.y, n_slices = gridDim.y;
     const size_t per = (T + n_slices - 1) / n_slices, t0 = (size_t)slice * per, t1 = t0 + per < T ? t0 + per : T;
-    Fr a1 = fe_zero(), as = fe_zero();
+    Fr acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) acc[q] = fe_zero();
     const uint64_t smask = suffix_len >= 64 ? ~0ull : (((uint64_t)1 << suffix_len) - 1);
     for (size_t t = t0 + threadIdx.x; t < t1; t += RA_THREADS) {
         const uint64_t k = idx[t];
         if (((uint32_t)(k >> suffix_len) & m_mask) != y) continue;
         const Fr u = fr_mul(fe_load(u0 + t), fe_load(prod + t));
-        a1 = fr_add(a1, u);
+        acc[0] = fr_add(acc[0], u);
         const uint64_t sb = k & smask;
-        if (sb) as = fr_add(as, fr_mul(u, fr_from_i64((int64_t)sb)));
+        if (sb) acc[1] = fr_add(acc[1], fr_mul(u, fr_from_i64((int64_t)sb)));
+        if constexpr (NQ == 6) {
+            bool haz = true, hao = true;
+            uint64_t lw = sb;
+            if (suffix_len > bound) {
+                const uint64_t hi = sb >> bound, ones = (((uint64_t)1 << (suffix_len - bound)) - 1);
+                haz = hi == 0; hao = hi == ones;
+                lw = sb & (((uint64_t)1 << bound) - 1);
+            }
+            if (haz || hao) {
+                const Fr ul = lw ? fr_mul(u, fr_from_i64((int64_t)lw)) : fe_zero();
+                if (haz) { acc[2] = fr_add(acc[2], u); acc[3] = fr_add(acc[3], ul); }
+                if (hao) { acc[4] = fr_add(acc[4], u); acc[5] = fr_add(acc[5], ul); }
+            }
+        }
     }
-    a1 = fr_wave_sum(a1); as = fr_wave_sum(as);
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = a1; red[threadIdx.x >> 6][1] = as; }
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const Fr sres = fr_wave_sum(acc[q]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = sres;
+    }
     __syncthreads();
-    if (threadIdx.x < 2) {
+    if (threadIdx.x < NQ) {
         Fr sres = red[0][threadIdx.x];
         for (int w = 1; w < RA_THREADS / 64; w++) sres = fr_add(sres, red[w][threadIdx.x]);
-        fe_store(partials + ((size_t)slice * 2 * (m_mask + 1)) + 2 * y + threadIdx.x, sres);
+        fe_store(partials + ((size_t)slice * NQ * (m_mask + 1)) + NQ * y + threadIdx.x, sres);
     }
 }
 
@@ -508,13 +532,17 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_fold(const Fr* __restrict__ r
 
 struct PsRelu : atlas_instance {
     size_t N = 0, log_m = 0, m = 0, log_T = 0, T = 0, round_next = 0, phases = 8;   // N = LOG_K
-    int mode = 0;                         // 0 = ReLU + gamma * SignedIdentity (unary read-raf), 1 = Identity (range check)
+    int mode = 0;                         // 0 = ReLU + gamma * SignedIdentity (unary read-raf), 1 = Identity (range check), 2 = clamp family
+    size_t bound = 0; bool symmetric = true;   // ClampBoundedTable<N, BOUND, SYMMETRIC> (lookup_tables/clamp.rs)
+    size_t nq() const { return mode == 2 ? 6 : 2; }
     H::Fr gamma = H::zero();
     uint64_t* d_idx = nullptr;
     Fr *d_u0 = nullptr, *d_v = nullptr, *d_qpart = nullptr;
     RaRows rows;                          // row 0 = running product of the v tables = ra at the end
     GseDev eq;
-    std::vector<H::Fr> Q1, Qs, v;         // current phase: suffix tables (bound HighToLow) and expanding table
+    std::vector<std::vector<H::Fr>> Q;    // current phase's suffix tables (bound HighToLow): 0 = One, 1 = suffix, 2..5 clamp
+    std::vector<H::Fr> v;                 // expanding table of the phase
+    H::Fr haz_acc = H::one(), hao_acc = H::one(), lw_acc = H::zero();
     std::vector<H::Fr> r_addr;
     H::Fr word_acc = H::zero(), sid_acc = H::zero(), wv = H::zero();
     static constexpr unsigned SLICES = 64;
@@ -524,17 +552,19 @@ struct PsRelu : atlas_instance {
     size_t degree() const override { return 2; }
 
     static H::Fr pow2(size_t k) { H::Fr o = H::one(); const H::Fr two = H::from_u64(2); for (size_t i = 0; i < k; i++) o = H::mul(o, two); return o; }
-    H::Fr weight(size_t i) const { H::Fr w = pow2(N - 1 - i); return (i == 0 && mode == 0) ? H::sub(w, pow2(N)) : w; }   // (Signed)Identity coefficient of bit i
+    H::Fr weight(size_t i) const { H::Fr w = pow2(N - 1 - i); return (i == 0 && mode != 1) ? H::sub(w, pow2(N)) : w; }   // (Signed)Identity coefficient of bit i
 
     int build_Q(size_t phase) {           // init_phase: Q tables of `phase` from the current products
         const uint32_t suffix_len = (uint32_t)((phases - 1 - phase) * log_m);
-        k_ps_q<<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), d_qpart);
-        k_col_reduce<<<(unsigned)(2 * m), RA_THREADS, 0, g.stream>>>(d_qpart, SLICES, (uint32_t)(2 * m), d_qpart + (size_t)SLICES * 2 * m);
-        std::vector<H::Fr> q(2 * m);
-        HIP_TRY(hipMemcpyAsync(q.data(), d_qpart + (size_t)SLICES * 2 * m, 2 * m * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+        const size_t NQ = nq();
+        if (NQ == 6) k_ps_q<6><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), (uint32_t)bound, d_qpart);
+        else k_ps_q<2><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), 0u, d_qpart);
+        k_col_reduce<<<(unsigned)(NQ * m), RA_THREADS, 0, g.stream>>>(d_qpart, SLICES, (uint32_t)(NQ * m), d_qpart + (size_t)SLICES * NQ * m);
+        std::vector<H::Fr> q(NQ * m);
+        HIP_TRY(hipMemcpyAsync(q.data(), d_qpart + (size_t)SLICES * NQ * m, NQ * m * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
-        Q1.resize(m); Qs.resize(m);
-        for (size_t y = 0; y < m; y++) { Q1[y] = q[2 * y]; Qs[y] = q[2 * y + 1]; }
+        Q.assign(NQ, std::vector<H::Fr>(m));
+        for (size_t y = 0; y < m; y++) for (size_t k = 0; k < NQ; k++) Q[k][y] = q[NQ * y + k];
         v.assign(1, H::one());
         return ATLAS_OK;
     }
@@ -543,24 +573,49 @@ struct PsRelu : atlas_instance {
         if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "ps_shout: round out of order");
         coeffs.assign(3, H::zero());
         if (round < N) {
-            const size_t j = round, p = j / log_m, half = Q1.size() / 2;
+            const size_t j = round, p = j / log_m, half = Q[0].size() / 2;
             const size_t suffix_len = N - (p + 1) * log_m;
+            const size_t blen = log_m - (j % log_m) - 1;              // chunk bits still boolean after variable j
+            const size_t hbits = mode == 2 ? N - bound : 0;           // variables 0..hbits-1 are the clamp's high bits
             const H::Fr sh = pow2(suffix_len), one = H::one();
+            const H::Fr U = mode == 2 ? H::from_u64(((uint64_t)1 << bound) - 1) : H::zero();
+            const H::Fr LC = symmetric ? H::add(H::add(U, U), one) : U;
             H::Fr ev[2];
             for (int ci = 0; ci < 2; ci++) {
                 const H::Fr c = H::from_u64(ci ? 2 : 0);
                 const H::Fr not_msb = j == 0 ? H::sub(one, c) : H::sub(one, r_addr[0]);
                 const H::Fr word_c = j >= 1 ? H::add(word_acc, H::mul(c, pow2(N - 1 - j))) : H::zero();
                 const H::Fr sid_c = H::add(sid_acc, H::mul(c, weight(j)));
+                // clamp prefixes over the bound variables and c
+                const H::Fr msb = j == 0 ? c : (r_addr.empty() ? c : r_addr[0]);
+                const H::Fr haz_c = j < hbits ? H::mul(haz_acc, H::sub(one, c)) : haz_acc;
+                const H::Fr hao_c = j < hbits ? H::mul(hao_acc, c) : hao_acc;
+                const H::Fr lw_c = (mode == 2 && j >= hbits) ? H::add(lw_acc, H::mul(c, pow2(N - 1 - j))) : lw_acc;
                 H::Fr acc = H::zero();
                 for (size_t b = 0; b < half; b++) {
                     const H::Fr bs = H::mul(H::from_u64(b), sh);
-                    const H::Fr q1 = ci ? H::sub(H::add(Q1[b + half], Q1[b + half]), Q1[b]) : Q1[b];
-                    const H::Fr qs = ci ? H::sub(H::add(Qs[b + half], Qs[b + half]), Qs[b]) : Qs[b];
-                    // Val: not_msb * (word * 1 + suffix);  RAF: gamma * (sid * 1 + suffix)
+                    auto qv = [&](size_t k) { return ci ? H::sub(H::add(Q[k][b + half], Q[k][b + half]), Q[k][b]) : Q[k][b]; };
+                    const H::Fr q1 = qv(0), qs = qv(1);
                     const H::Fr idt = H::add(H::mul(H::add(sid_c, bs), q1), qs);          // (Signed)Identity term
                     if (mode == 1) { acc = H::add(acc, idt); continue; }
-                    const H::Fr val = H::mul(not_msb, H::add(H::mul(H::add(word_c, bs), q1), qs));
+                    if (mode == 0) {
+                        const H::Fr val = H::mul(not_msb, H::add(H::mul(H::add(word_c, bs), q1), qs));
+                        acc = H::add(acc, H::add(val, H::mul(gamma, idt)));
+                        continue;
+                    }
+                    // clamp (clamp.rs:84-109): chunk bits of b at variable index j+1+q are high iff that index < hbits
+                    bool z = true, o = true;
+                    uint64_t lwb = 0;
+                    for (size_t q = 0; q < blen; q++) {
+                        const size_t var = j + 1 + q;
+                        const uint64_t bit = (b >> (blen - 1 - q)) & 1;
+                        if (var < hbits) { if (bit) z = false; else o = false; }
+                        else lwb |= bit << (N - 1 - var);
+                    }
+                    H::Fr val = H::mul(H::sub(U, H::mul(msb, LC)), q1);
+                    const H::Fr lw = H::add(lw_c, H::from_u64(lwb));
+                    if (z) val = H::add(val, H::mul(haz_c, H::add(H::mul(H::sub(lw, U), qv(2)), qv(3))));
+                    if (o && symmetric) val = H::add(val, H::mul(hao_c, H::add(H::mul(lw, qv(4)), qv(5))));
                     acc = H::add(acc, H::add(val, H::mul(gamma, idt)));
                 }
                 ev[ci] = acc;
@@ -584,17 +639,20 @@ struct PsRelu : atlas_instance {
         const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
         if (round < N) {
             const size_t j = round, p = j / log_m;
-            const size_t half = Q1.size() / 2;
-            for (size_t i = 0; i < half; i++) {                       // suffix polys bind HighToLow
-                Q1[i] = H::add(Q1[i], H::mul(rf, H::sub(Q1[i + half], Q1[i])));
-                Qs[i] = H::add(Qs[i], H::mul(rf, H::sub(Qs[i + half], Qs[i])));
+            const size_t half = Q[0].size() / 2;
+            for (auto& q : Q) {                                       // suffix polys bind HighToLow
+                for (size_t i = 0; i < half; i++) q[i] = H::add(q[i], H::mul(rf, H::sub(q[i + half], q[i])));
+                q.resize(half);
             }
-            Q1.resize(half); Qs.resize(half);
             std::vector<H::Fr> nv(2 * v.size());                      // ExpandingTable::update, HighToLow
             for (size_t i = 0; i < v.size(); i++) { nv[2 * i + 1] = H::mul(rf, v[i]); nv[2 * i] = H::sub(v[i], nv[2 * i + 1]); }
             v.swap(nv);
             if (j >= 1) word_acc = H::add(word_acc, H::mul(rf, pow2(N - 1 - j)));
             sid_acc = H::add(sid_acc, H::mul(rf, weight(j)));
+            if (mode == 2) {
+                if (j < N - bound) { haz_acc = H::mul(haz_acc, H::sub(H::one(), rf)); hao_acc = H::mul(hao_acc, rf); }
+                else lw_acc = H::add(lw_acc, H::mul(rf, pow2(N - 1 - j)));
+            }
             r_addr.push_back(rf);
             if ((j + 1) % log_m == 0) {                               // phase boundary: fold v_p into the products
                 std::lock_guard<std::mutex> lk(g.mu);
@@ -608,6 +666,13 @@ struct PsRelu : atlas_instance {
                 // val = Val~(r_address), raf_val = gamma * SId~(r_address)   (mod.rs:523-548)
                 const H::Fr val = H::mul(H::sub(H::one(), r_addr[0]), word_acc);
                 wv = mode == 1 ? sid_acc : H::add(val, H::mul(gamma, sid_acc));            // identity_range_check.rs:377-380
+                if (mode == 2) {                                      // ClampBoundedTable::evaluate_mle at r_address
+                    const H::Fr U = H::from_u64(((uint64_t)1 << bound) - 1);
+                    const H::Fr LC = symmetric ? H::add(H::add(U, U), H::one()) : U;
+                    H::Fr cv = H::add(H::sub(U, H::mul(r_addr[0], LC)), H::mul(haz_acc, H::sub(lw_acc, U)));
+                    if (symmetric) cv = H::add(cv, H::mul(hao_acc, lw_acc));
+                    wv = H::add(cv, H::mul(gamma, sid_acc));
+                }
                 rows.cur = 0; rows.stride[0] = T; rows.len = T;       // the products are ra (init_log_t_rounds)
             }
         } else {
@@ -702,20 +767,20 @@ int atlas_hamming_weight_new(const atlas_fr_t* G, size_t d, size_t log_k_chunk, 
 }
 
 static int ps_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, size_t phases, int mode, const atlas_fr_t* r_node_output,
-                  const atlas_fr_t* gamma, atlas_instance_t* out) {
+                  const atlas_fr_t* gamma, atlas_instance_t* out, size_t bound = 0, bool symmetric = true) {
     atlas_poly_t E = nullptr;
     int rc = atlas_eq_evals(r_node_output, log_T, nullptr, &E);      // u_evals = EqPolynomial::evals(r_node_output), mod.rs:234
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(g.mu);
     PsRelu* P = new PsRelu();
-    P->N = log_K; P->phases = phases; P->mode = mode;
+    P->N = log_K; P->phases = phases; P->mode = mode; P->bound = bound; P->symmetric = symmetric;
     P->log_m = log_K / phases; P->m = (size_t)1 << P->log_m; P->log_T = log_T; P->T = (size_t)1 << log_T;
     if (gamma) std::memcpy(&P->gamma, gamma, 32);
     P->d_u0 = (Fr*)E->d; delete E;                                   // keep the table, drop the handle
     const size_t T = P->T, m = P->m;
     hipError_t e = hipMalloc(&P->d_idx, T * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc(&P->d_v, m * sizeof(Fr));
-    if (e == hipSuccess) e = hipMalloc(&P->d_qpart, ((size_t)PsRelu::SLICES + 1) * 2 * m * sizeof(Fr));
+    if (e == hipSuccess) e = hipMalloc(&P->d_qpart, ((size_t)PsRelu::SLICES + 1) * 6 * m * sizeof(Fr));
     if (e == hipSuccess) e = hipMemcpyAsync(P->d_idx, lookup_indices, T * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream);
     if (e != hipSuccess) { delete P; return fail(ATLAS_ENOMEM, "ps_shout_new", e); }
     rc = P->rows.alloc(1, T);
@@ -737,6 +802,16 @@ int atlas_ps_shout_relu_new(const uint64_t* lookup_indices, size_t log_T, size_t
     if (xlen != 16 && xlen != 32) return fail(ATLAS_EINVAL, "ps_shout_relu_new: X_LEN must be 16 or 32 (the reference's WordNoMSB suffix is a u32)");
     if (log_T == 0 || log_T > 25) return fail(ATLAS_EINVAL, "ps_shout_relu_new: 1 <= log_T <= 25");
     return ps_new(lookup_indices, log_T, xlen, 8, 0, r_node_output, gamma, out);
+}
+
+int atlas_ps_shout_clamp_new(const uint64_t* lookup_indices, size_t log_T, size_t xlen, size_t bound, int symmetric,
+                             const atlas_fr_t* r_node_output, const atlas_fr_t* gamma, atlas_instance_t* out) {
+    NEED_INIT();
+    if (!lookup_indices || !r_node_output || !gamma || !out) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: null argument");
+    if (xlen != 16 && xlen != 32 && xlen != 64) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: X_LEN must be 16, 32 or 64");
+    if (bound == 0 || bound + 1 >= xlen || bound > 31) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: 1 <= BOUND <= 31 and BOUND < X_LEN - 1");
+    if (log_T == 0 || log_T > 25) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: 1 <= log_T <= 25");
+    return ps_new(lookup_indices, log_T, xlen, 8, 2, r_node_output, gamma, out, bound, symmetric != 0);
 }
 
 int atlas_identity_range_check_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, size_t phases,

@@ -136,3 +136,13 @@ def identity_range_check(lookup_indices, log_K, phases, r_node_output):
     _check(lib.atlas_identity_range_check_new(idx.ctypes.data_as(C.c_void_p), C.c_size_t(len(rn)), C.c_size_t(log_K),
                                               C.c_size_t(phases), _p(rn), C.byref(h)))
     return Instance(h)
+
+
+def ps_shout_clamp(lookup_indices, xlen, bound, symmetric, r_node_output, gamma):
+    """ps_read_raf_prover for ClampBoundedTable<xlen, bound, symmetric> (lookup_tables/clamp.rs)."""
+    idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)
+    rn = np.ascontiguousarray(r_node_output, dtype=np.uint64); g = _fr(gamma)
+    h = C.c_void_p()
+    _check(lib.atlas_ps_shout_clamp_new(idx.ctypes.data_as(C.c_void_p), C.c_size_t(len(rn)), C.c_size_t(xlen), C.c_size_t(bound),
+                                        C.c_int(1 if symmetric else 0), _p(rn), _p(g), C.byref(h)))
+    return Instance(h)

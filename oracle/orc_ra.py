@@ -143,3 +143,17 @@ def ps_identity(lookup_indices, log_K, phases, r_node):
     I.keep = [idx, rn]
     orc.lib.orc_ps_identity_init(I.st, idx.ctypes.data_as(C.c_void_p), C.c_size_t(log_K), C.c_size_t(phases), C.c_size_t(len(rn)), orc._p(rn))
     return I
+
+
+PS_CLAMP = 9
+
+
+def ps_clamp(lookup_indices, N, bound, symmetric, r_node, gamma):
+    """Unary read-raf prover with ClampBoundedTable<N, bound, symmetric> (lookup_tables/clamp.rs)."""
+    idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)
+    rn = np.ascontiguousarray(r_node, dtype=np.uint64); g = np.ascontiguousarray(gamma, dtype=np.uint64).reshape(1, 4)
+    I = Instance(PS_CLAMP, N + len(rn))
+    I.keep = [idx, rn, g]
+    orc.lib.orc_ps_clamp_init(I.st, idx.ctypes.data_as(C.c_void_p), C.c_size_t(N), C.c_size_t(bound), C.c_int(1 if symmetric else 0),
+                              C.c_size_t(len(rn)), orc._p(rn), orc._p(g))
+    return I

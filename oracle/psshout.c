@@ -333,3 +333,199 @@ void orc_ps_identity_ingest(orc_ps_identity *S, size_t round, const fr_t *r) {
         gse_bind(&S->eq, r);
     }
 }
+
+/* ------------------------------------------------------------------ clamp family (unary read-raf)
+ * ClampBoundedTable<XLEN, BOUND, SYMMETRIC> (lookup_tables/clamp.rs:44-121): suffixes
+ * [HigherAllZero, HZeroMulLWord, HOneMulLWord, One] restated from suffixes/higher_all_zero.rs,
+ * hzero_mul_lword.rs, hone_mul_lword.rs; `combine` as written (clamp.rs:84-109); prefixes
+ * HigherAllZero / HigherAllOne / LowerWord / Msb evaluated as the multilinear extensions they stand for
+ * (clamp.rs:140-195 evaluate_mle gives the same factors); RAF = SignedIdentity as in the ReLU case. */
+static uint32_t suf_haz(uint64_t bits, size_t len, size_t XLEN, size_t BOUND) {
+    const size_t bound_index = XLEN - BOUND - 1, start = XLEN - len;
+    for (size_t pos = 0; pos < len; pos++) if (start + pos <= bound_index && ((bits >> (len - 1 - pos)) & 1)) return 0;
+    return 1;
+}
+static uint32_t suf_hz_lw(uint64_t bits, size_t len, size_t XLEN, size_t BOUND) {
+    const size_t bound_index = XLEN - BOUND - 1, start = XLEN - len;
+    uint32_t lw = 0;
+    for (size_t pos = 0; pos < len; pos++) {
+        const size_t gi = start + pos; const uint32_t bit = (uint32_t)((bits >> (len - 1 - pos)) & 1);
+        if (gi <= bound_index && bit == 1) return 0;
+        if (gi > bound_index) lw += bit << (XLEN - gi - 1);
+    }
+    return lw;
+}
+static uint32_t suf_ho_lw(uint64_t bits, size_t len, size_t XLEN, size_t BOUND) {
+    const size_t bound_index = XLEN - BOUND - 1, start = XLEN - len;
+    uint32_t lw = 0;
+    for (size_t pos = 0; pos < len; pos++) {
+        const size_t gi = start + pos; const uint32_t bit = (uint32_t)((bits >> (len - 1 - pos)) & 1);
+        if (gi <= bound_index && bit == 0) return 0;
+        if (gi > bound_index) lw += bit << (XLEN - gi - 1);
+    }
+    return lw;
+}
+
+static void clamp_init_phase(orc_ps_clamp *S, size_t phase) {
+    const size_t log_m = S->log_m, m = S->m, m_mask = m - 1, T = S->T;
+    if (phase != 0)
+        for (size_t t = 0; t < T; t++) {
+            const uint64_t k_bound = split_prefix(S->idx[t], (8 - phase) * log_m) & m_mask;
+            fr_mul(&S->u[t], &S->v[phase - 1][k_bound], &S->u[t]);
+        }
+    const size_t suffix_len = (8 - 1 - phase) * log_m;
+    for (int s = 0; s < 6; s++) for (size_t y = 0; y < m; y++) fr_zero(&S->Q[s][y]);
+    for (size_t t = 0; t < T; t++) {
+        const uint64_t y = split_prefix(S->idx[t], suffix_len) & m_mask, sb = split_suffix(S->idx[t], suffix_len);
+        const uint32_t tv[4] = {suf_haz(sb, suffix_len, S->N, S->bound), suf_hz_lw(sb, suffix_len, S->N, S->bound),
+                                S->symmetric ? suf_ho_lw(sb, suffix_len, S->N, S->bound) : 1u, 1u};
+        for (int s = 0; s < 4; s++) if (tv[s]) { fr_t w, x; fr_from_u64(tv[s], &w); fr_mul(&S->u[t], &w, &x); fr_add(&S->Q[s][y], &x, &S->Q[s][y]); }
+        fr_add(&S->Q[4][y], &S->u[t], &S->Q[4][y]);                         /* RAF One */
+        if (sb) { fr_t w, x; fr_from_i64((int64_t)sb, &w); fr_mul(&S->u[t], &w, &x); fr_add(&S->Q[5][y], &x, &S->Q[5][y]); }
+    }
+    S->Q_len = m;
+    fr_one(&S->v[phase][0]); S->v_len[phase] = 1;
+}
+
+void orc_ps_clamp_init(orc_ps_clamp *S, const uint64_t *idx, size_t N, size_t bound, int symmetric, size_t log_T,
+                       const fr_t *r_node, const fr_t *gamma) {
+    memset(S, 0, sizeof *S);
+    S->N = N; S->bound = bound; S->symmetric = symmetric; S->log_T = log_T; S->log_m = N / 8; S->m = (size_t)1 << S->log_m; S->T = (size_t)1 << log_T;
+    S->idx = idx; S->gamma = *gamma;
+    S->u = (fr_t *)malloc(S->T * sizeof(fr_t)); orc_eq_evals(r_node, log_T, 0, S->u);
+    for (int s = 0; s < 6; s++) S->Q[s] = (fr_t *)malloc(S->m * sizeof(fr_t));
+    for (int p = 0; p < 8; p++) S->v[p] = (fr_t *)calloc(S->m, sizeof(fr_t));
+    gse_init(&S->eq, r_node, log_T);
+    clamp_init_phase(S, 0);
+}
+
+void orc_ps_clamp_free(orc_ps_clamp *S) {
+    free(S->u); for (int s = 0; s < 6; s++) free(S->Q[s]);
+    for (int p = 0; p < 8; p++) free(S->v[p]);
+    if (S->ra) free(S->ra);
+    gse_free(&S->eq);
+}
+
+/* prefix MLEs at (r_0..r_{j-1}, c, b): x = the first j + 1 + blen variables */
+static void clamp_prefixes(const orc_ps_clamp *S, size_t j, uint32_t c, uint64_t b, size_t blen,
+                           fr_t *haz, fr_t *hao, fr_t *lw, fr_t *msb, fr_t *sid) {
+    const size_t XLEN = S->N, h = XLEN - S->bound;                          /* variables 0..h-1 are the high ones */
+    fr_t one, x; fr_one(&one); fr_one(haz); fr_one(hao); fr_zero(lw); fr_zero(sid);
+    for (size_t i = 0; i < j + 1 + blen; i++) {
+        if (i < j) x = S->r[i];
+        else if (i == j) fr_from_u64(c, &x);
+        else fr_from_u64((b >> (blen - 1 - (i - j - 1))) & 1, &x);
+        if (i == 0) *msb = x;
+        fr_t w, t; fr_pow2((unsigned)(XLEN - 1 - i), &w);
+        if (i < h) { fr_sub(&one, &x, &t); fr_mul(haz, &t, haz); fr_mul(hao, &x, hao); }
+        else { fr_mul(&w, &x, &t); fr_add(lw, &t, lw); }
+        fr_mul(&w, &x, &t); fr_add(sid, &t, sid);
+        if (i == 0) { fr_t pen; fr_pow2((unsigned)XLEN, &pen); fr_mul(&pen, &x, &t); fr_sub(sid, &t, sid); }
+    }
+    if (!S->symmetric) fr_zero(hao);                                         /* ZeroPrefix */
+}
+
+static void clamp_combine(const orc_ps_clamp *S, const fr_t *haz, const fr_t *hao, const fr_t *lw, const fr_t *msb,
+                          const fr_t *s_haz, const fr_t *s_hzlw, const fr_t *s_holw, const fr_t *s_one, fr_t *o) {   /* clamp.rs:84-109 */
+    fr_t cu, lc, one, t, u, acc; fr_one(&one);
+    fr_from_u64(((uint64_t)1 << S->bound) - 1, &cu);
+    if (S->symmetric) { fr_add(&cu, &cu, &lc); fr_add(&lc, &one, &lc); } else lc = cu;
+    fr_mul(s_one, &cu, &acc);
+    fr_mul(msb, s_one, &t); fr_mul(&t, &lc, &t); fr_sub(&acc, &t, &acc);
+    fr_mul(lw, s_one, &t); fr_add(s_hzlw, &t, &t); fr_mul(s_haz, &cu, &u); fr_sub(&t, &u, &t); fr_mul(haz, &t, &t); fr_add(&acc, &t, &acc);
+    fr_mul(lw, s_one, &t); fr_add(s_holw, &t, &t); fr_mul(hao, &t, &t); fr_add(&acc, &t, &acc);
+    *o = acc;
+}
+
+size_t orc_ps_clamp_message(orc_ps_clamp *S, size_t round, const fr_t *claim, fr_t *coeffs) {
+    if (round < S->N) {
+        const size_t j = round, half = S->Q_len / 2;
+        size_t blen = 0; while (((size_t)1 << blen) < half) blen++;
+        fr_t ev[2];
+        for (int ci = 0; ci < 2; ci++) {
+            const uint32_t c = ci ? 2 : 0;
+            fr_t acc; fr_zero(&acc);
+            for (size_t i = 0; i < half; i++) {
+                fr_t haz, hao, lw, msb, sid, q[6], t;
+                clamp_prefixes(S, j, c, i, blen, &haz, &hao, &lw, &msb, &sid);
+                for (int s = 0; s < 6; s++) {
+                    if (ci == 0) q[s] = S->Q[s][i];
+                    else { fr_add(&S->Q[s][i + half], &S->Q[s][i + half], &q[s]); fr_sub(&q[s], &S->Q[s][i], &q[s]); }
+                }
+                clamp_combine(S, &haz, &hao, &lw, &msb, &q[0], &q[1], &q[2], &q[3], &t); fr_add(&acc, &t, &acc);
+                fr_mul(&sid, &q[4], &t); fr_add(&t, &q[5], &t); fr_mul(&t, &S->gamma, &t); fr_add(&acc, &t, &acc);
+            }
+            ev[ci] = acc;
+        }
+        return orc_unipoly_from_evals_and_hint(claim, ev, 2, coeffs);
+    }
+    const gse_t *E = &S->eq;
+    const fr_t *e_out = E->Eout[E->out_top], *e_in = E->Ein[E->in_top];
+    const size_t out_len = (size_t)1 << E->out_top, in_len = (size_t)1 << E->in_top;
+    fr_t acc; fr_zero(&acc);
+    for (size_t xo = 0; xo < out_len; xo++) {
+        fr_t inner; fr_zero(&inner);
+        for (size_t xi = 0; xi < in_len; xi++) { const size_t jj = (xo << E->in_top) | xi; fr_t t; fr_mul(&e_in[xi], &S->ra[2 * jj], &t); fr_add(&inner, &t, &inner); }
+        fr_mul(&e_out[xo], &inner, &inner); fr_add(&acc, &inner, &acc);
+    }
+    fr_t q0; fr_mul(&acc, &S->wv, &q0);
+    fr_t eq1, eq0, eqm, eq2, c0, c1, l1, l2, inv, ev2[2], hint;
+    fr_mul(&E->scalar, &E->w[E->current_index - 1], &eq1); fr_sub(&E->scalar, &eq1, &eq0);
+    fr_sub(&eq1, &eq0, &eqm); fr_add(&eq1, &eqm, &eq2);
+    fr_mul(&eq0, &q0, &c0); fr_sub(claim, &c0, &c1);
+    fr_inv(&eq1, &inv); fr_mul(&c1, &inv, &l1);
+    fr_add(&l1, &l1, &l2); fr_sub(&l2, &q0, &l2);
+    ev2[0] = c0; fr_mul(&eq2, &l2, &ev2[1]); fr_add(&c0, &c1, &hint);
+    return orc_unipoly_from_evals_and_hint(&hint, ev2, 2, coeffs);
+}
+
+void orc_ps_clamp_ingest(orc_ps_clamp *S, size_t round, const fr_t *r) {
+    const size_t log_m = S->log_m, LOG_K = S->N;
+    if (round < LOG_K) {
+        S->r[S->n_r++] = *r;
+        const size_t phase = round / log_m;
+        size_t ql = S->Q_len;
+        for (int s = 0; s < 6; s++) { size_t l = ql; bind_h2l(S->Q[s], &l, r); }
+        S->Q_len = ql / 2;
+        {
+            const size_t n = S->v_len[phase];
+            fr_t *nv = (fr_t *)calloc(S->m, sizeof(fr_t));
+            for (size_t i = 0; i < n; i++) { fr_mul(r, &S->v[phase][i], &nv[2 * i + 1]); fr_sub(&S->v[phase][i], &nv[2 * i + 1], &nv[2 * i]); }
+            free(S->v[phase]); S->v[phase] = nv; S->v_len[phase] = 2 * n;
+        }
+        if ((round + 1) % log_m == 0 && phase != 7) clamp_init_phase(S, phase + 1);
+        if (round + 1 == LOG_K) {
+            /* val = combine(prefixes at r, suffix_mle(empty)): HAZ = 1, HZeroMulLWord = 0, HOneMulLWord = 0 (One for softmax), One = 1 */
+            fr_t haz, hao, lw, msb, sid, one, zero, s3; fr_one(&one); fr_zero(&zero);
+            S->r[S->n_r] = zero;                                             /* placeholder for the c slot */
+            {   /* all N variables bound: evaluate with j = N - 1, c = r_{N-1} handled by a direct loop */
+                const size_t XLEN = S->N, h = XLEN - S->bound;
+                fr_one(&haz); fr_one(&hao); fr_zero(&lw); fr_zero(&sid);
+                for (size_t i = 0; i < XLEN; i++) {
+                    const fr_t x = S->r[i]; fr_t w, t; fr_pow2((unsigned)(XLEN - 1 - i), &w);
+                    if (i == 0) msb = x;
+                    if (i < h) { fr_sub(&one, &x, &t); fr_mul(&haz, &t, &haz); fr_mul(&hao, &x, &hao); }
+                    else { fr_mul(&w, &x, &t); fr_add(&lw, &t, &lw); }
+                    fr_mul(&w, &x, &t); fr_add(&sid, &t, &sid);
+                    if (i == 0) { fr_t pen; fr_pow2((unsigned)XLEN, &pen); fr_mul(&pen, &x, &t); fr_sub(&sid, &t, &sid); }
+                }
+                if (!S->symmetric) fr_zero(&hao);
+            }
+            s3 = S->symmetric ? zero : one;
+            fr_t val; clamp_combine(S, &haz, &hao, &lw, &msb, &one, &zero, &s3, &one, &val);
+            fr_t rv; fr_mul(&S->gamma, &sid, &rv); fr_add(&val, &rv, &S->wv);
+            S->ra = (fr_t *)malloc(S->T * sizeof(fr_t)); S->ra_len = S->T;
+            for (size_t t = 0; t < S->T; t++) {
+                fr_t p; fr_one(&p);
+                for (size_t ph = 0; ph < 8; ph++) {
+                    const uint64_t kb = split_prefix(S->idx[t], (8 - 1 - ph) * log_m) & (S->m - 1);
+                    fr_mul(&p, &S->v[ph][kb], &p);
+                }
+                S->ra[t] = p;
+            }
+        }
+    } else {
+        orc_bind(S->ra, S->ra_len, r, ORC_LOW_TO_HIGH); S->ra_len /= 2;
+        gse_bind(&S->eq, r);
+    }
+}

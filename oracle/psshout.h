@@ -36,4 +36,21 @@ void   orc_ps_identity_init(orc_ps_identity *S, const uint64_t *idx, size_t log_
 void   orc_ps_identity_free(orc_ps_identity *S);
 size_t orc_ps_identity_message(orc_ps_identity *S, size_t round, const fr_t *claim, fr_t *coeffs);
 void   orc_ps_identity_ingest(orc_ps_identity *S, size_t round, const fr_t *r);
+
+enum { ORC_INST_PS_CLAMP = 9 };
+typedef struct {
+    size_t N, bound, log_T, log_m, m, T, Q_len, n_r, ra_len;
+    int symmetric;
+    const uint64_t *idx;
+    fr_t gamma, *u, *Q[6], *v[8], *ra, wv;
+    size_t v_len[8];
+    fr_t r[160];
+    gse_t eq;
+} orc_ps_clamp;
+/* ClampBoundedTable<N, bound, symmetric> read-raf (lookup_tables/clamp.rs), unary, with SignedIdentity RAF */
+void   orc_ps_clamp_init(orc_ps_clamp *S, const uint64_t *idx, size_t N, size_t bound, int symmetric, size_t log_T,
+                         const fr_t *r_node, const fr_t *gamma);
+void   orc_ps_clamp_free(orc_ps_clamp *S);
+size_t orc_ps_clamp_message(orc_ps_clamp *S, size_t round, const fr_t *claim, fr_t *coeffs);
+void   orc_ps_clamp_ingest(orc_ps_clamp *S, size_t round, const fr_t *r);
 #endif

@@ -319,3 +319,28 @@ class PsIdentityModel(PsReluModel):
     def _W(self, x):
         N = self.N
         return sum(x[i] * (1 << (N - 1 - i)) for i in range(N)) % FR
+
+
+class PsClampModel(PsReluModel):
+    """ClampBoundedTable<N, bound, symmetric> read-raf: Val~ as ClampBoundedTable::evaluate_mle
+    (lookup_tables/clamp.rs:140-195) + gamma * SignedIdentity."""
+
+    def __init__(self, idx, N, bound, symmetric, r_node, gamma):
+        super().__init__(idx, N, r_node, gamma)
+        self.bound, self.symmetric = bound, symmetric
+
+    def _W(self, x):
+        N, B = self.N, self.bound
+        h = N - B
+        haz = hao = 1
+        for i in range(h):
+            haz = haz * (1 - x[i]) % FR
+            hao = hao * x[i] % FR
+        if not self.symmetric:
+            hao = 0
+        lw = sum(x[i] * (1 << (N - 1 - i)) for i in range(h, N)) % FR
+        U = (1 << B) - 1
+        LC = 2 * U + 1 if self.symmetric else U
+        val = (U - x[0] * LC + haz * (lw - U) + hao * lw) % FR
+        sid = (sum(x[i] * (1 << (N - 1 - i)) for i in range(N)) - x[0] * (1 << N)) % FR
+        return (val + self.gamma * sid) % FR

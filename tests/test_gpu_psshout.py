@@ -107,3 +107,39 @@ def test_identity_range_check_bit_exact(atlas, log_K, phases, log_T):
     assert t_g.state == t_o.state_bytes()
     assert len(inst.final_claims()) == 1
     inst.free()
+
+
+@pytest.mark.parametrize("N,bound,sym,log_T", [(16, 9, True, 4), (32, 9, True, 10), (32, 17, True, 12), (32, 12, False, 9), (64, 31, True, 8), (16, 5, False, 1)])
+def test_ps_shout_clamp_bit_exact(atlas, N, bound, sym, log_T):
+    """ClampTable / ActivationClampTable / SoftmaxClampTable / SaturationTable shapes."""
+    import ctypes as C
+    from oracle import orc, orc_ra as OR
+    from jolt_atlas_amd import instances as I
+    A = atlas
+    orc.lib.fr_from_i64.argtypes = [C.c_int64, C.c_void_p]
+    T = 1 << log_T
+    rng = np.random.default_rng(N + bound + log_T)
+    vals = rng.integers(-(1 << (bound + 2)), 1 << (bound + 2), size=T, dtype=np.int64)
+    vals[0] = -1; vals[1] = (1 << bound) - 1
+    if T > 4:
+        vals[2] = -(1 << bound); vals[3] = -(1 << (N - 1)) if N < 64 else -(1 << 62); vals[4] = (1 << (N - 2))
+    idx = (vals.astype(np.int64).view(np.uint64) & np.uint64((1 << N) - 1 if N < 64 else 0xffffffffffffffff))
+    r_node, gamma = orc.random_fr(log_T, 5), orc.random_fr(1, 6)[0]
+    E = orc.eq_evals(r_node)
+    claim = orc.fr_array(1)[0]
+    lo = -(1 << bound) if sym else 0
+    for t in range(T):
+        x = int(vals[t])
+        w = orc.fr_array(1); orc.lib.fr_from_i64(x, orc._p(w))
+        rvv = orc.fr_array(1); orc.lib.fr_from_i64(min(max(x, lo), (1 << bound) - 1), orc._p(rvv))
+        claim = orc.fr_add_arr(claim, orc.fr_mul_arr(E[t], orc.fr_add_arr(rvv[0], orc.fr_mul_arr(gamma, w[0]))))
+    t_o = orc.new_transcript(b"ps_clamp")
+    rows_o, ch_o = OR.ps_clamp(idx, N, bound, sym, r_node, gamma).prove(claim, t_o)
+    inst = I.ps_shout_clamp(idx, N, bound, sym, r_node, gamma)
+    assert inst.num_rounds() == N + log_T
+    t_g = A.Blake2bTranscript(b"ps_clamp")
+    rows_g, ch_g = inst.prove(claim, t_g)
+    assert ch_g == ch_o
+    assert len(rows_g) == len(rows_o) and all(np.array_equal(a, b) for a, b in zip(rows_g, rows_o))
+    assert t_g.state == t_o.state_bytes()
+    inst.free()

@@ -254,3 +254,30 @@ def test_identity_range_check_oracle_matches_closed_form_model(log_K, phases, lo
     assert raw_o == raw_p
     assert [orc.to_ints(r) for r in rows_o] == rows_p
     assert bytes(to.state) == tp.state
+
+
+@pytest.mark.parametrize("N,bound,sym,log_T", [(16, 9, True, 2), (16, 5, False, 3), (32, 9, True, 3), (32, 17, True, 2), (32, 12, False, 2), (64, 31, True, 2)])
+def test_ps_shout_clamp_oracle_matches_closed_form_model(N, bound, sym, log_T):
+    T = 1 << log_T
+    rng = np.random.default_rng(N + bound + log_T)
+    vals = [int(v) for v in rng.integers(-(1 << (bound + 2)), 1 << (bound + 2), size=T)]
+    vals[0] = -1; vals[1] = (1 << bound) - 1
+    if T > 2:
+        vals[2] = -(1 << bound); vals[3] = -(1 << (N - 1))
+    idx = [v & ((1 << N) - 1) for v in vals]
+    r_node, gamma = _rand(log_T, 3), _rand(1, 4)[0] >> 130
+    model = PR.PsClampModel(idx, N, bound, sym, r_node, gamma)
+    # materialize_entry (clamp.rs:124-136) vs the MLE on boolean points
+    for v, k in zip(vals, idx):
+        bits = [(k >> (N - 1 - i)) & 1 for i in range(N)]
+        lo = -(1 << bound) if sym else 0
+        want = min(max(v, lo), (1 << bound) - 1)
+        assert model._W(bits) == (want + gamma * v) % F.FR
+    claim = model.input_claim()
+    rows_p, raw_p, tp = _prove_py(model, claim, b"ps_clamp")
+    inst = OR.ps_clamp(idx, N, bound, sym, orc.from_ints(r_node), orc.from_ints([gamma])[0])
+    to = orc.new_transcript(b"ps_clamp")
+    rows_o, raw_o = inst.prove(orc.from_ints([claim])[0], to)
+    assert raw_o == raw_p
+    assert [orc.to_ints(r) for r in rows_o] == rows_p
+    assert bytes(to.state) == tp.state
