@@ -368,6 +368,28 @@ int atlas_g1_sum_indexed(atlas_srs_t srs, const uint32_t *indices, size_t n, atl
 int atlas_hyperkzg_open(atlas_srs_t srs, atlas_poly_t poly, const atlas_u128_t *point, size_t ell,
                         atlas_transcript_t *transcript, atlas_g1_affine_t *com, atlas_g1_affine_t *w,
                         atlas_fr_t *v);
+/* ONNXProof::prove_reduced_openings (jolt-atlas-core/src/onnx_proof/prover.rs:141-176):
+ * prepare_for_sumcheck + prove_batch_opening_sumcheck + finalize_batch_opening_sumcheck
+ * (joltworks/src/poly/opening_proof.rs:447-532, 611-643) + build_materialized_rlc + PCS::prove.
+ * `openings` = the accumulator's sumchecks in BTreeMap<CommittedPoly> order (their claims were
+ * appended to the transcript when they were registered, opening_proof.rs:281, 336).  Outputs: the
+ * batched sumcheck (rows of 3 Fr, n_coeffs, challenges = r_sumcheck, max_rounds), sumcheck_claims
+ * (P_i(r_sumcheck) per opening), and the HyperKZG proof of the joint polynomial at r_sumcheck
+ * (com: max_rounds-1 points, w: 3 points, v: 3*max_rounds Fr).  The polynomials are not consumed. */
+typedef struct {
+    int kind;                 /* 0 = dense (LargeScalars / I32Scalars), 1 = one-hot */
+    atlas_poly_t poly;        /* dense: the committed polynomial, length 2^n */
+    size_t n;                 /* dense: number of variables */
+    const int32_t *k;         /* one-hot: nonzero_indices (T host int32, negative = None) */
+    size_t log_K, log_T;      /* one-hot */
+    const atlas_fr_t *point;  /* dense: n Fr; one-hot: r_address (log_K) followed by r_cycle (log_T) */
+    atlas_fr_t claim;         /* the opening claim P(point) */
+} atlas_opening_t;
+int atlas_prove_reduced_openings(const atlas_opening_t *openings, size_t n_openings, atlas_srs_t srs,
+                                 atlas_transcript_t *transcript, atlas_fr_t *sumcheck_rows, uint32_t *n_coeffs,
+                                 atlas_u128_t *challenges, size_t *max_rounds_out, atlas_fr_t *sumcheck_claims,
+                                 atlas_g1_affine_t *com, atlas_g1_affine_t *w, atlas_fr_t *v);
+
 /* Transcript::append_point / append_points (blake2b.rs:166-195), host side */
 int atlas_transcript_append_point(atlas_transcript_t *t, const atlas_g1_affine_t *p);
 int atlas_transcript_append_points(atlas_transcript_t *t, const atlas_g1_affine_t *p, size_t n);

@@ -1,0 +1,88 @@
+// ONNXProof::prove_reduced_openings (jolt-atlas-core/src/onnx_proof/prover.rs:141-176): the last
+// stage of the prover — the batched opening-reduction sumcheck over every committed polynomial,
+// the claim/gamma exchange of ProverOpeningAccumulator::finalize_batch_opening_sumcheck
+// (joltworks/src/poly/opening_proof.rs:611-643), the joint polynomial of build_materialized_rlc and
+// the HyperKZG opening at r_sumcheck.  Everything here is a composition of entry points that exist
+// on their own; the accumulator's map bookkeeping (a22) stays with the caller, who passes the
+// openings in BTreeMap<CommittedPoly> order.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "../../include/atlas_hip.h"
+#include "host_field.hpp"
+#include "runtime.hpp"
+
+namespace H = atlas_host;
+using atlas_rt::fail;
+
+extern "C" int atlas_prove_reduced_openings(const atlas_opening_t* openings, size_t n_open, atlas_srs_t srs,
+                                            atlas_transcript_t* transcript, atlas_fr_t* sumcheck_rows, uint32_t* n_coeffs,
+                                            atlas_u128_t* challenges, size_t* max_rounds_out, atlas_fr_t* sumcheck_claims,
+                                            atlas_g1_affine_t* com, atlas_g1_affine_t* w, atlas_fr_t* v) {
+    NEED_INIT();
+    if (!openings || n_open == 0 || !srs || !transcript || !sumcheck_rows || !n_coeffs || !challenges || !max_rounds_out ||
+        !sumcheck_claims || !com || !w || !v)
+        return fail(ATLAS_EINVAL, "prove_reduced_openings: null argument");
+    std::vector<atlas_instance_t> inst(n_open, nullptr);
+    atlas_batched_t b = nullptr;
+    atlas_poly_t joint = nullptr;
+    int rc = ATLAS_OK;
+    auto cleanup = [&]() {
+        for (auto i : inst) if (i) atlas_instance_free(i);
+        if (b) atlas_batched_free(b);
+        if (joint) atlas_poly_free(joint);
+    };
+    // prepare_for_sumcheck: one opening-reduction instance per committed polynomial (the dense ones work on a
+    // copy: the joint polynomial needs the originals)
+    for (size_t i = 0; i < n_open && !rc; i++) {
+        const atlas_opening_t& O = openings[i];
+        if (O.kind == 0) {
+            atlas_poly_t c = nullptr;
+            if (!O.poly || !O.point) { rc = fail(ATLAS_EINVAL, "prove_reduced_openings: dense opening without polynomial/point"); break; }
+            rc = atlas_poly_clone(O.poly, &c);
+            if (!rc) { rc = atlas_dense_opening_new(c, O.point, O.n, &inst[i]); if (rc) atlas_poly_free(c); }
+        } else {
+            if (!O.k || !O.point) { rc = fail(ATLAS_EINVAL, "prove_reduced_openings: one-hot opening without indices/point"); break; }
+            rc = atlas_onehot_opening_new(O.k, O.log_K, O.log_T, O.point, O.point + O.log_K, &inst[i]);
+        }
+    }
+    // prove_batch_opening_sumcheck: BatchedSumcheck::prove over the instances (degree 2: rows of 3)
+    if (!rc) rc = atlas_batched_new(&b);
+    for (size_t i = 0; i < n_open && !rc; i++) rc = atlas_batched_add_instance(b, inst[i], &openings[i].claim);
+    if (!rc) rc = atlas_batched_prove(b, transcript, sumcheck_rows, 3, n_coeffs, challenges, max_rounds_out);
+    // cache_openings -> sumcheck_claims (opening_reduction.rs:238-246), then finalize (:611-643)
+    for (size_t i = 0; i < n_open && !rc; i++) {
+        size_t nf = 0;
+        rc = atlas_instance_final_claims(inst[i], &sumcheck_claims[i], 1, &nf);
+    }
+    if (rc) { cleanup(); return rc; }
+    H::Transcript& T = *reinterpret_cast<H::Transcript*>(transcript);
+    H::tr_append_scalars(T, reinterpret_cast<const H::Fr*>(sumcheck_claims), n_open);
+    std::vector<H::Fr> gamma(n_open);                               // challenge_scalar_powers (blake2b.rs:224-231)
+    {
+        const H::Fr q = H::tr_challenge_scalar(T);
+        gamma[0] = H::one();
+        for (size_t i = 1; i < n_open; i++) gamma[i] = H::mul(gamma[i - 1], q);
+    }
+    // build_materialized_rlc(gamma_powers, poly_map)
+    std::vector<atlas_rlc_dense_t> dense;
+    std::vector<atlas_rlc_onehot_t> onehot;
+    for (size_t i = 0; i < n_open; i++) {
+        const atlas_opening_t& O = openings[i];
+        if (O.kind == 0) { atlas_rlc_dense_t d; d.poly = O.poly; std::memcpy(&d.coeff, &gamma[i], 32); dense.push_back(d); }
+        else {
+            atlas_rlc_onehot_t o; o.k = O.k; o.T = (size_t)1 << O.log_T; o.K = (size_t)1 << O.log_K; o.k_on_device = 0;
+            std::memcpy(&o.coeff, &gamma[i], 32); onehot.push_back(o);
+        }
+    }
+    rc = atlas_rlc_build(dense.data(), dense.size(), onehot.data(), onehot.size(), &joint);
+    size_t jlen = 0;
+    if (!rc) atlas_poly_len(joint, &jlen);
+    if (!rc && jlen != ((size_t)1 << *max_rounds_out)) rc = fail(ATLAS_EINVAL, "prove_reduced_openings: joint polynomial length != 2^max_rounds");
+    // PCS::prove(generators, &rlc, &r_sumcheck, None, transcript) = HyperKZG::open
+    if (!rc) rc = atlas_hyperkzg_open(srs, joint, challenges, *max_rounds_out, transcript, com, w, v);
+    cleanup();
+    return rc;
+}

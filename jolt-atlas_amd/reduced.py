@@ -1,0 +1,46 @@
+"""ONNXProof::prove_reduced_openings (jolt-atlas-core/src/onnx_proof/prover.rs:141-176)."""
+import ctypes as C
+
+import numpy as np
+
+from . import G1_DTYPE, U128, _check, _fr, _p, lib
+
+
+class _Opening(C.Structure):
+    _fields_ = [("kind", C.c_int), ("poly", C.c_void_p), ("n", C.c_size_t), ("k", C.c_void_p), ("log_K", C.c_size_t),
+                ("log_T", C.c_size_t), ("point", C.c_void_p), ("claim", C.c_uint64 * 4)]
+
+
+def prove_reduced_openings(openings, srs, transcript):
+    """openings: list of dicts {"poly": MultilinearPolynomial, "point": (n,4), "claim": (4,)} (dense) or
+    {"k": int32 array, "log_K": int, "r_address": (log_K,4), "r_cycle": (log_T,4), "claim": (4,)} (one-hot),
+    in CommittedPoly order.  Returns (rows, challenges, sumcheck_claims, com, w, v)."""
+    n = len(openings)
+    arr = (_Opening * n)()
+    keep = []
+    max_rounds = 0
+    for i, o in enumerate(openings):
+        c = _fr(o["claim"]).reshape(4)
+        for q in range(4):
+            arr[i].claim[q] = int(c[q])
+        if "poly" in o:
+            pt = np.ascontiguousarray(o["point"], dtype=np.uint64); keep.append(pt)
+            arr[i].kind = 0; arr[i].poly = o["poly"].h; arr[i].n = len(pt); arr[i].point = pt.ctypes.data
+            max_rounds = max(max_rounds, len(pt))
+        else:
+            k = np.ascontiguousarray(o["k"], dtype=np.int32)
+            pt = np.ascontiguousarray(np.concatenate([o["r_address"], o["r_cycle"]]), dtype=np.uint64); keep += [k, pt]
+            arr[i].kind = 1; arr[i].k = k.ctypes.data; arr[i].log_K = o["log_K"]; arr[i].log_T = len(o["r_cycle"])
+            arr[i].point = pt.ctypes.data
+            max_rounds = max(max_rounds, o["log_K"] + len(o["r_cycle"]))
+    rows = np.zeros((max_rounds, 3, 4), dtype=np.uint64); nco = np.zeros(max_rounds, dtype=np.uint32)
+    ch = np.zeros(2 * max_rounds, dtype=np.uint64); mr = C.c_size_t()
+    claims = np.zeros((n, 4), dtype=np.uint64)
+    com = np.zeros(max(max_rounds - 1, 1), dtype=G1_DTYPE); w = np.zeros(3, dtype=G1_DTYPE)
+    v = np.zeros((3 * max_rounds, 4), dtype=np.uint64)
+    _check(lib.atlas_prove_reduced_openings(arr, C.c_size_t(n), srs.h, C.byref(transcript.t), _p(rows), nco.ctypes.data_as(C.c_void_p),
+                                            _p(ch), C.byref(mr), _p(claims), com.ctypes.data_as(C.c_void_p),
+                                            w.ctypes.data_as(C.c_void_p), _p(v)))
+    assert mr.value == max_rounds
+    return ([rows[i, :nco[i]].copy() for i in range(max_rounds)], [int(ch[2 * i]) | (int(ch[2 * i + 1]) << 64) for i in range(max_rounds)],
+            claims, com[:max_rounds - 1], w, v.reshape(3, max_rounds, 4))
