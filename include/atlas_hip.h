@@ -271,6 +271,12 @@ int atlas_ps_shout_relu_new(const uint64_t *lookup_indices, size_t log_T, size_t
 int atlas_ps_shout_clamp_new(const uint64_t *lookup_indices, size_t log_T, size_t xlen, size_t bound,
                              int symmetric, const atlas_fr_t *r_node_output, const atlas_fr_t *gamma,
                              atlas_instance_t *out);
+/* The binary flavour (joltworks/src/subprotocols/ps_shout/binary.rs:148-200 ps_read_raf_prover) with
+ * UnsignedLessThanTable<32> (lookup_tables/unsigned_less_than.rs): lookup index = interleave_bits(x, y)
+ * (utils/mod.rs:146-164), 64 address rounds, summand ra * (LT(x,y) + gamma * SignedLeft + gamma^2 *
+ * SignedRight); input claim = rv_claim + gamma * (left_operand_claim + gamma * right_operand_claim). */
+int atlas_ps_shout_ult_new(const uint64_t *lookup_indices, size_t log_T, const atlas_fr_t *r_node_output,
+                           const atlas_fr_t *gamma, atlas_instance_t *out);
 /* IdentityRCProver::gen (joltworks/src/subprotocols/identity_range_check.rs:196-420): the range check
  * sum_{k,t} eq(r_node_output, t) ra(k, t) Identity(k) over log_K address bits in `phases` phases
  * (IdentityRCProvider::{log_K, phases}), then log_T cycle rounds; degree 2; final claim = ra(r). */

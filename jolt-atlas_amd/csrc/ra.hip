@@ -480,6 +480,17 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_q(const uint64_t* __restrict_
         const Fr u = fr_mul(fe_load(u0 + t), fe_load(prod + t));
         acc[0] = fr_add(acc[0], u);
         const uint64_t sb = k & smask;
+        if constexpr (NQ == 4) {      // binary lookups: suffix = interleave(x, y) (utils/mod.rs:105-125 uninterleave_bits)
+            uint64_t xb = (sb >> 1) & 0x5555555555555555ull, yb = sb & 0x5555555555555555ull;
+            xb = (xb | (xb >> 1)) & 0x3333333333333333ull; xb = (xb | (xb >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+            xb = (xb | (xb >> 4)) & 0x00FF00FF00FF00FFull; xb = (xb | (xb >> 8)) & 0x0000FFFF0000FFFFull; xb = (xb | (xb >> 16)) & 0xFFFFFFFFull;
+            yb = (yb | (yb >> 1)) & 0x3333333333333333ull; yb = (yb | (yb >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+            yb = (yb | (yb >> 4)) & 0x00FF00FF00FF00FFull; yb = (yb | (yb >> 8)) & 0x0000FFFF0000FFFFull; yb = (yb | (yb >> 16)) & 0xFFFFFFFFull;
+            if (xb < yb) acc[1] = fr_add(acc[1], u);                              // LessThan suffix
+            if (xb) acc[2] = fr_add(acc[2], fr_mul(u, fr_from_i64((int64_t)xb)));   // left operand of the suffix
+            if (yb) acc[3] = fr_add(acc[3], fr_mul(u, fr_from_i64((int64_t)yb)));   // right operand
+            continue;
+        }
         if (sb) acc[1] = fr_add(acc[1], fr_mul(u, fr_from_i64((int64_t)sb)));
         if constexpr (NQ == 6) {
             bool haz = true, hao = true;
@@ -534,7 +545,7 @@ struct PsRelu : atlas_instance {
     size_t N = 0, log_m = 0, m = 0, log_T = 0, T = 0, round_next = 0, phases = 8;   // N = LOG_K
     int mode = 0;                         // 0 = ReLU + gamma * SignedIdentity (unary read-raf), 1 = Identity (range check), 2 = clamp family
     size_t bound = 0; bool symmetric = true;   // ClampBoundedTable<N, BOUND, SYMMETRIC> (lookup_tables/clamp.rs)
-    size_t nq() const { return mode == 2 ? 6 : 2; }
+    size_t nq() const { return mode == 2 ? 6 : mode == 3 ? 4 : 2; }
     H::Fr gamma = H::zero();
     uint64_t* d_idx = nullptr;
     Fr *d_u0 = nullptr, *d_v = nullptr, *d_qpart = nullptr;
@@ -543,6 +554,7 @@ struct PsRelu : atlas_instance {
     std::vector<std::vector<H::Fr>> Q;    // current phase's suffix tables (bound HighToLow): 0 = One, 1 = suffix, 2..5 clamp
     std::vector<H::Fr> v;                 // expanding table of the phase
     H::Fr haz_acc = H::one(), hao_acc = H::one(), lw_acc = H::zero();
+    H::Fr lt_acc = H::zero(), eq_acc = H::one(), lop_acc = H::zero(), rop_acc = H::zero();   // mode 3 (UnsignedLessThan, binary)
     std::vector<H::Fr> r_addr;
     H::Fr word_acc = H::zero(), sid_acc = H::zero(), wv = H::zero();
     static constexpr unsigned SLICES = 64;
@@ -557,7 +569,8 @@ struct PsRelu : atlas_instance {
     int build_Q(size_t phase) {           // init_phase: Q tables of `phase` from the current products
         const uint32_t suffix_len = (uint32_t)((phases - 1 - phase) * log_m);
         const size_t NQ = nq();
-        if (NQ == 6) k_ps_q<6><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), (uint32_t)bound, d_qpart);
+        if (NQ == 4) k_ps_q<4><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), 0u, d_qpart);
+        else if (NQ == 6) k_ps_q<6><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), (uint32_t)bound, d_qpart);
         else k_ps_q<2><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), 0u, d_qpart);
         k_col_reduce<<<(unsigned)(NQ * m), RA_THREADS, 0, g.stream>>>(d_qpart, SLICES, (uint32_t)(NQ * m), d_qpart + (size_t)SLICES * NQ * m);
         std::vector<H::Fr> q(NQ * m);
@@ -595,6 +608,35 @@ struct PsRelu : atlas_instance {
                 for (size_t b = 0; b < half; b++) {
                     const H::Fr bs = H::mul(H::from_u64(b), sh);
                     auto qv = [&](size_t k) { return ci ? H::sub(H::add(Q[k][b + half], Q[k][b + half]), Q[k][b]) : Q[k][b]; };
+                    if (mode == 3) {     // UnsignedLessThan over interleaved (x, y) pairs + gamma * Left + gamma^2 * Right
+                        H::Fr lt = lt_acc, eq = eq_acc, lo = lop_acc, ro = rop_acc;
+                        auto pair = [&](const H::Fr& x, const H::Fr& y) {              // unsigned_less_than.rs:33-41
+                            lt = H::add(lt, H::mul(eq, H::mul(H::sub(one, x), y)));
+                            eq = H::mul(eq, H::add(H::mul(x, y), H::mul(H::sub(one, x), H::sub(one, y))));
+                        };
+                        auto opw = [&](size_t var) { H::Fr w = pow2(31 - var / 2); return var < 2 ? H::sub(w, pow2(32)) : w; };
+                        size_t q = 0;                                                   // next bit of b (MSB first)
+                        auto bbit = [&](size_t qq) { return H::from_u64((b >> (blen - 1 - qq)) & 1); };
+                        if (j % 2 == 0) {
+                            const H::Fr y = bbit(0); q = 1;
+                            pair(c, y);
+                            lo = H::add(lo, H::mul(c, opw(j))); ro = H::add(ro, H::mul(y, opw(j + 1)));
+                        } else {
+                            pair(r_addr[j - 1], c);
+                            ro = H::add(ro, H::mul(c, opw(j)));
+                        }
+                        for (; q + 1 < blen + 1 && q < blen; q += 2) {
+                            const H::Fr x = bbit(q), y = bbit(q + 1);
+                            pair(x, y);
+                            lo = H::add(lo, H::mul(x, opw(j + 1 + q))); ro = H::add(ro, H::mul(y, opw(j + 2 + q)));
+                        }
+                        const H::Fr g2 = H::mul(gamma, gamma);
+                        H::Fr val = H::add(H::mul(lt, qv(0)), H::mul(eq, qv(1)));
+                        val = H::add(val, H::mul(gamma, H::add(H::mul(lo, qv(0)), qv(2))));
+                        val = H::add(val, H::mul(g2, H::add(H::mul(ro, qv(0)), qv(3))));
+                        acc = H::add(acc, val);
+                        continue;
+                    }
                     const H::Fr q1 = qv(0), qs = qv(1);
                     const H::Fr idt = H::add(H::mul(H::add(sid_c, bs), q1), qs);          // (Signed)Identity term
                     if (mode == 1) { acc = H::add(acc, idt); continue; }
@@ -649,6 +691,16 @@ struct PsRelu : atlas_instance {
             v.swap(nv);
             if (j >= 1) word_acc = H::add(word_acc, H::mul(rf, pow2(N - 1 - j)));
             sid_acc = H::add(sid_acc, H::mul(rf, weight(j)));
+            if (mode == 3) {
+                const H::Fr w = j < 2 ? H::sub(pow2(31 - j / 2), pow2(32)) : pow2(31 - j / 2);
+                if (j % 2 == 0) lop_acc = H::add(lop_acc, H::mul(rf, w));
+                else {
+                    rop_acc = H::add(rop_acc, H::mul(rf, w));
+                    const H::Fr x = r_addr[j - 1], one = H::one();
+                    lt_acc = H::add(lt_acc, H::mul(eq_acc, H::mul(H::sub(one, x), rf)));
+                    eq_acc = H::mul(eq_acc, H::add(H::mul(x, rf), H::mul(H::sub(one, x), H::sub(one, rf))));
+                }
+            }
             if (mode == 2) {
                 if (j < N - bound) { haz_acc = H::mul(haz_acc, H::sub(H::one(), rf)); hao_acc = H::mul(hao_acc, rf); }
                 else lw_acc = H::add(lw_acc, H::mul(rf, pow2(N - 1 - j)));
@@ -666,6 +718,7 @@ struct PsRelu : atlas_instance {
                 // val = Val~(r_address), raf_val = gamma * SId~(r_address)   (mod.rs:523-548)
                 const H::Fr val = H::mul(H::sub(H::one(), r_addr[0]), word_acc);
                 wv = mode == 1 ? sid_acc : H::add(val, H::mul(gamma, sid_acc));            // identity_range_check.rs:377-380
+                if (mode == 3) wv = H::add(lt_acc, H::add(H::mul(gamma, lop_acc), H::mul(H::mul(gamma, gamma), rop_acc)));   // binary.rs:108-116
                 if (mode == 2) {                                      // ClampBoundedTable::evaluate_mle at r_address
                     const H::Fr U = H::from_u64(((uint64_t)1 << bound) - 1);
                     const H::Fr LC = symmetric ? H::add(H::add(U, U), H::one()) : U;
@@ -812,6 +865,14 @@ int atlas_ps_shout_clamp_new(const uint64_t* lookup_indices, size_t log_T, size_
     if (bound == 0 || bound + 1 >= xlen || bound > 31) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: 1 <= BOUND <= 31 and BOUND < X_LEN - 1");
     if (log_T == 0 || log_T > 25) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: 1 <= log_T <= 25");
     return ps_new(lookup_indices, log_T, xlen, 8, 2, r_node_output, gamma, out, bound, symmetric != 0);
+}
+
+int atlas_ps_shout_ult_new(const uint64_t* lookup_indices, size_t log_T, const atlas_fr_t* r_node_output, const atlas_fr_t* gamma,
+                           atlas_instance_t* out) {
+    NEED_INIT();
+    if (!lookup_indices || !r_node_output || !gamma || !out) return fail(ATLAS_EINVAL, "ps_shout_ult_new: null argument");
+    if (log_T == 0 || log_T > 25) return fail(ATLAS_EINVAL, "ps_shout_ult_new: 1 <= log_T <= 25");
+    return ps_new(lookup_indices, log_T, 64, 8, 3, r_node_output, gamma, out);
 }
 
 int atlas_identity_range_check_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, size_t phases,

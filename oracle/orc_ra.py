@@ -157,3 +157,25 @@ def ps_clamp(lookup_indices, N, bound, symmetric, r_node, gamma):
     orc.lib.orc_ps_clamp_init(I.st, idx.ctypes.data_as(C.c_void_p), C.c_size_t(N), C.c_size_t(bound), C.c_int(1 if symmetric else 0),
                               C.c_size_t(len(rn)), orc._p(rn), orc._p(g))
     return I
+
+
+PS_ULT = 10
+
+
+def ps_ult(lookup_indices, r_node, gamma):
+    """Binary read-raf prover with UnsignedLessThanTable<32> (ps_shout/binary.rs:148-200)."""
+    idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)
+    rn = np.ascontiguousarray(r_node, dtype=np.uint64); g = np.ascontiguousarray(gamma, dtype=np.uint64).reshape(1, 4)
+    I = Instance(PS_ULT, 64 + len(rn))
+    I.keep = [idx, rn, g]
+    orc.lib.orc_ps_ult_init(I.st, idx.ctypes.data_as(C.c_void_p), C.c_size_t(len(rn)), orc._p(rn), orc._p(g))
+    return I
+
+
+def interleave(x, y):
+    """interleave_bits (utils/mod.rs:146-164): x on the odd bit positions, y on the even ones."""
+    out = 0
+    for i in range(32):
+        out |= ((int(x) >> i) & 1) << (2 * i + 1)
+        out |= ((int(y) >> i) & 1) << (2 * i)
+    return out

@@ -529,3 +529,149 @@ void orc_ps_clamp_ingest(orc_ps_clamp *S, size_t round, const fr_t *r) {
         gse_bind(&S->eq, r);
     }
 }
+
+/* ------------------------------------------------------------------ binary read-raf: UnsignedLessThanTable<32>
+ * ps_shout/binary.rs:26-200 (LOG_K = 64 interleaved operand bits, RAF = gamma * SignedLeft + gamma^2 * SignedRight),
+ * lookup_tables/unsigned_less_than.rs:16-60 (prefixes [Eq, LessThan], suffixes [One, LessThan], combine),
+ * suffixes/less_than.rs + utils/mod.rs:105-125 (uninterleave_bits), poly/signed_identity_poly.rs:213-250
+ * (SignedOperandPoly::evaluate).  Prefixes are evaluated as the multilinear extensions they stand for. */
+static void uninterleave(uint64_t val, uint32_t *x, uint32_t *y) {           /* utils/mod.rs:105-125 */
+    uint64_t xb = (val >> 1) & 0x5555555555555555ull, yb = val & 0x5555555555555555ull;
+    xb = (xb | (xb >> 1)) & 0x3333333333333333ull; xb = (xb | (xb >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    xb = (xb | (xb >> 4)) & 0x00FF00FF00FF00FFull; xb = (xb | (xb >> 8)) & 0x0000FFFF0000FFFFull; xb = (xb | (xb >> 16)) & 0xFFFFFFFFull;
+    yb = (yb | (yb >> 1)) & 0x3333333333333333ull; yb = (yb | (yb >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    yb = (yb | (yb >> 4)) & 0x00FF00FF00FF00FFull; yb = (yb | (yb >> 8)) & 0x0000FFFF0000FFFFull; yb = (yb | (yb >> 16)) & 0xFFFFFFFFull;
+    *x = (uint32_t)xb; *y = (uint32_t)yb;
+}
+
+static void ult_init_phase(orc_ps_ult *S, size_t phase) {
+    const size_t log_m = 8, m = 256, m_mask = 255, T = S->T;
+    if (phase != 0)
+        for (size_t t = 0; t < T; t++) {
+            const uint64_t k_bound = split_prefix(S->idx[t], (8 - phase) * log_m) & m_mask;
+            fr_mul(&S->u[t], &S->v[phase - 1][k_bound], &S->u[t]);
+        }
+    const size_t suffix_len = (8 - 1 - phase) * log_m;
+    for (int s = 0; s < 4; s++) for (size_t y = 0; y < m; y++) fr_zero(&S->Q[s][y]);
+    for (size_t t = 0; t < T; t++) {
+        const uint64_t y = split_prefix(S->idx[t], suffix_len) & m_mask, sb = split_suffix(S->idx[t], suffix_len);
+        uint32_t sx, sy; uninterleave(sb, &sx, &sy);
+        fr_add(&S->Q[0][y], &S->u[t], &S->Q[0][y]);                         /* One */
+        if (sx < sy) fr_add(&S->Q[1][y], &S->u[t], &S->Q[1][y]);            /* LessThan suffix */
+        if (sx) { fr_t w, x; fr_from_u64(sx, &w); fr_mul(&S->u[t], &w, &x); fr_add(&S->Q[2][y], &x, &S->Q[2][y]); }   /* left operand of the suffix */
+        if (sy) { fr_t w, x; fr_from_u64(sy, &w); fr_mul(&S->u[t], &w, &x); fr_add(&S->Q[3][y], &x, &S->Q[3][y]); }   /* right operand */
+    }
+    S->Q_len = m;
+    fr_one(&S->v[phase][0]); S->v_len[phase] = 1;
+}
+
+void orc_ps_ult_init(orc_ps_ult *S, const uint64_t *idx, size_t log_T, const fr_t *r_node, const fr_t *gamma) {
+    memset(S, 0, sizeof *S);
+    S->log_T = log_T; S->T = (size_t)1 << log_T; S->idx = idx; S->gamma = *gamma;
+    S->u = (fr_t *)malloc(S->T * sizeof(fr_t)); orc_eq_evals(r_node, log_T, 0, S->u);
+    for (int s = 0; s < 4; s++) S->Q[s] = (fr_t *)malloc(256 * sizeof(fr_t));
+    for (int p = 0; p < 8; p++) S->v[p] = (fr_t *)calloc(256, sizeof(fr_t));
+    gse_init(&S->eq, r_node, log_T);
+    ult_init_phase(S, 0);
+}
+
+void orc_ps_ult_free(orc_ps_ult *S) {
+    free(S->u); for (int s = 0; s < 4; s++) free(S->Q[s]);
+    for (int p = 0; p < 8; p++) free(S->v[p]);
+    if (S->ra) free(S->ra);
+    gse_free(&S->eq);
+}
+
+/* LT~, EQ~, SignedLeft~, SignedRight~ over the first nv variables x[0..nv) (nv even) of the 64 */
+static void ult_prefixes(const fr_t *x, size_t nv, fr_t *lt, fr_t *eq, fr_t *lo, fr_t *ro) {
+    fr_t one; fr_one(&one); fr_zero(lt); fr_one(eq); fr_zero(lo); fr_zero(ro);
+    for (size_t i = 0; 2 * i + 1 < nv + 1 && 2 * i < nv; i++) {
+        const fr_t xi = x[2 * i], yi = x[2 * i + 1];
+        fr_t a, b, t, w;
+        fr_sub(&one, &xi, &a); fr_mul(&a, &yi, &t); fr_mul(&t, eq, &t); fr_add(lt, &t, lt);       /* (1-x) y eq */
+        fr_sub(&one, &yi, &b); fr_mul(&a, &b, &a); fr_mul(&xi, &yi, &t); fr_add(&a, &t, &a); fr_mul(eq, &a, eq);
+        fr_pow2((unsigned)(32 - 1 - i), &w);
+        fr_mul(&w, &xi, &t); fr_add(lo, &t, lo); fr_mul(&w, &yi, &t); fr_add(ro, &t, ro);
+        if (i == 0) { fr_t pen; fr_pow2(32, &pen); fr_mul(&pen, &xi, &t); fr_sub(lo, &t, lo); fr_mul(&pen, &yi, &t); fr_sub(ro, &t, ro); }
+    }
+}
+
+size_t orc_ps_ult_message(orc_ps_ult *S, size_t round, const fr_t *claim, fr_t *coeffs) {
+    if (round < 64) {
+        const size_t j = round, half = S->Q_len / 2;
+        size_t blen = 0; while (((size_t)1 << blen) < half) blen++;
+        fr_t g2; fr_mul(&S->gamma, &S->gamma, &g2);
+        fr_t ev[2];
+        for (int ci = 0; ci < 2; ci++) {
+            fr_t acc; fr_zero(&acc);
+            for (size_t i = 0; i < half; i++) {
+                fr_t x[64]; const size_t nv = j + 1 + blen;                  /* a whole number of (x, y) pairs: chunks are 8 bits */
+                for (size_t q = 0; q < nv; q++) {
+                    if (q < j) x[q] = S->r[q];
+                    else if (q == j) fr_from_u64(ci ? 2 : 0, &x[q]);
+                    else fr_from_u64((i >> (blen - 1 - (q - j - 1))) & 1, &x[q]);
+                }
+                fr_t lt, eq, lo, ro, q4[4], t, u;
+                ult_prefixes(x, nv, &lt, &eq, &lo, &ro);
+                for (int s = 0; s < 4; s++) {
+                    if (ci == 0) q4[s] = S->Q[s][i];
+                    else { fr_add(&S->Q[s][i + half], &S->Q[s][i + half], &q4[s]); fr_sub(&q4[s], &S->Q[s][i], &q4[s]); }
+                }
+                fr_mul(&lt, &q4[0], &t); fr_mul(&eq, &q4[1], &u); fr_add(&t, &u, &t); fr_add(&acc, &t, &acc);   /* combine: lt * one + eq * lt_suffix */
+                fr_mul(&lo, &q4[0], &t); fr_add(&t, &q4[2], &t); fr_mul(&t, &S->gamma, &t); fr_add(&acc, &t, &acc);
+                fr_mul(&ro, &q4[0], &t); fr_add(&t, &q4[3], &t); fr_mul(&t, &g2, &t); fr_add(&acc, &t, &acc);
+            }
+            ev[ci] = acc;
+        }
+        return orc_unipoly_from_evals_and_hint(claim, ev, 2, coeffs);
+    }
+    const gse_t *E = &S->eq;
+    const fr_t *e_out = E->Eout[E->out_top], *e_in = E->Ein[E->in_top];
+    const size_t out_len = (size_t)1 << E->out_top, in_len = (size_t)1 << E->in_top;
+    fr_t acc; fr_zero(&acc);
+    for (size_t xo = 0; xo < out_len; xo++) {
+        fr_t inner; fr_zero(&inner);
+        for (size_t xi = 0; xi < in_len; xi++) { const size_t jj = (xo << E->in_top) | xi; fr_t t; fr_mul(&e_in[xi], &S->ra[2 * jj], &t); fr_add(&inner, &t, &inner); }
+        fr_mul(&e_out[xo], &inner, &inner); fr_add(&acc, &inner, &acc);
+    }
+    fr_t q0; fr_mul(&acc, &S->wv, &q0);
+    fr_t eq1, eq0, eqm, eq2, c0, c1, l1, l2, inv, ev2[2], hint;
+    fr_mul(&E->scalar, &E->w[E->current_index - 1], &eq1); fr_sub(&E->scalar, &eq1, &eq0);
+    fr_sub(&eq1, &eq0, &eqm); fr_add(&eq1, &eqm, &eq2);
+    fr_mul(&eq0, &q0, &c0); fr_sub(claim, &c0, &c1);
+    fr_inv(&eq1, &inv); fr_mul(&c1, &inv, &l1);
+    fr_add(&l1, &l1, &l2); fr_sub(&l2, &q0, &l2);
+    ev2[0] = c0; fr_mul(&eq2, &l2, &ev2[1]); fr_add(&c0, &c1, &hint);
+    return orc_unipoly_from_evals_and_hint(&hint, ev2, 2, coeffs);
+}
+
+void orc_ps_ult_ingest(orc_ps_ult *S, size_t round, const fr_t *r) {
+    if (round < 64) {
+        S->r[S->n_r++] = *r;
+        const size_t phase = round / 8;
+        size_t ql = S->Q_len;
+        for (int s = 0; s < 4; s++) { size_t l = ql; bind_h2l(S->Q[s], &l, r); }
+        S->Q_len = ql / 2;
+        {
+            const size_t n = S->v_len[phase];
+            fr_t *nv = (fr_t *)calloc(256, sizeof(fr_t));
+            for (size_t i = 0; i < n; i++) { fr_mul(r, &S->v[phase][i], &nv[2 * i + 1]); fr_sub(&S->v[phase][i], &nv[2 * i + 1], &nv[2 * i]); }
+            free(S->v[phase]); S->v[phase] = nv; S->v_len[phase] = 2 * n;
+        }
+        if ((round + 1) % 8 == 0 && phase != 7) ult_init_phase(S, phase + 1);
+        if (round + 1 == 64) {
+            fr_t lt, eq, lo, ro, t, g2; fr_mul(&S->gamma, &S->gamma, &g2);
+            ult_prefixes(S->r, 64, &lt, &eq, &lo, &ro);                      /* val = lt (LessThan suffix of empty bits = 0) */
+            S->wv = lt; fr_mul(&S->gamma, &lo, &t); fr_add(&S->wv, &t, &S->wv); fr_mul(&g2, &ro, &t); fr_add(&S->wv, &t, &S->wv);
+            S->ra = (fr_t *)malloc(S->T * sizeof(fr_t)); S->ra_len = S->T;
+            for (size_t tt = 0; tt < S->T; tt++) {
+                fr_t p; fr_one(&p);
+                for (size_t ph = 0; ph < 8; ph++) { const uint64_t kb = split_prefix(S->idx[tt], (8 - 1 - ph) * 8) & 255; fr_mul(&p, &S->v[ph][kb], &p); }
+                S->ra[tt] = p;
+            }
+        }
+    } else {
+        orc_bind(S->ra, S->ra_len, r, ORC_LOW_TO_HIGH); S->ra_len /= 2;
+        gse_bind(&S->eq, r);
+    }
+}

@@ -53,4 +53,19 @@ void   orc_ps_clamp_init(orc_ps_clamp *S, const uint64_t *idx, size_t N, size_t 
 void   orc_ps_clamp_free(orc_ps_clamp *S);
 size_t orc_ps_clamp_message(orc_ps_clamp *S, size_t round, const fr_t *claim, fr_t *coeffs);
 void   orc_ps_clamp_ingest(orc_ps_clamp *S, size_t round, const fr_t *r);
+
+enum { ORC_INST_PS_ULT = 10 };
+typedef struct {
+    size_t log_T, T, Q_len, n_r, ra_len;
+    const uint64_t *idx;
+    fr_t gamma, *u, *Q[4], *v[8], *ra, wv;
+    size_t v_len[8];
+    fr_t r[160];
+    gse_t eq;
+} orc_ps_ult;
+/* binary read-raf with UnsignedLessThanTable<32>: lookup index = interleave(x, y), 64 address rounds */
+void   orc_ps_ult_init(orc_ps_ult *S, const uint64_t *idx, size_t log_T, const fr_t *r_node, const fr_t *gamma);
+void   orc_ps_ult_free(orc_ps_ult *S);
+size_t orc_ps_ult_message(orc_ps_ult *S, size_t round, const fr_t *claim, fr_t *coeffs);
+void   orc_ps_ult_ingest(orc_ps_ult *S, size_t round, const fr_t *r);
 #endif

@@ -344,3 +344,23 @@ class PsClampModel(PsReluModel):
         val = (U - x[0] * LC + haz * (lw - U) + hao * lw) % FR
         sid = (sum(x[i] * (1 << (N - 1 - i)) for i in range(N)) - x[0] * (1 << N)) % FR
         return (val + self.gamma * sid) % FR
+
+
+class PsUltModel(PsReluModel):
+    """Binary read-raf with UnsignedLessThanTable<32>: W = LT~ + gamma SignedLeft~ + gamma^2 SignedRight~ over the
+    64 interleaved variables (unsigned_less_than.rs:27-43, signed_identity_poly.rs:226-244)."""
+
+    def __init__(self, idx, r_node, gamma):
+        super().__init__(idx, 64, r_node, gamma)
+
+    def _W(self, v):
+        lt, eq, lo, ro = 0, 1, 0, 0
+        for i in range(32):
+            x, y = v[2 * i], v[2 * i + 1]
+            lt = (lt + (1 - x) * y * eq) % FR
+            eq = eq * (x * y + (1 - x) * (1 - y)) % FR
+            lo = (lo + x * (1 << (31 - i))) % FR
+            ro = (ro + y * (1 << (31 - i))) % FR
+        lo = (lo - v[0] * (1 << 32)) % FR
+        ro = (ro - v[1] * (1 << 32)) % FR
+        return (lt + self.gamma * lo + self.gamma * self.gamma * ro) % FR

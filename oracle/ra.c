@@ -336,6 +336,7 @@ static size_t inst_message(int kind, void *st, size_t round, const fr_t *claim, 
         case ORC_INST_PS_RELU: return orc_ps_relu_message((orc_ps_relu *)st, round, claim, c);
         case ORC_INST_PS_IDENTITY: return orc_ps_identity_message((orc_ps_identity *)st, round, claim, c);
         case ORC_INST_PS_CLAMP: return orc_ps_clamp_message((orc_ps_clamp *)st, round, claim, c);
+        case ORC_INST_PS_ULT: return orc_ps_ult_message((orc_ps_ult *)st, round, claim, c);
         default: return orc_hamming_message((orc_hamming *)st, claim, c);
     }
 }
@@ -348,6 +349,7 @@ static void inst_ingest(int kind, void *st, size_t round, const fr_t *r) {
         case ORC_INST_PS_RELU: orc_ps_relu_ingest((orc_ps_relu *)st, round, r); break;
         case ORC_INST_PS_IDENTITY: orc_ps_identity_ingest((orc_ps_identity *)st, round, r); break;
         case ORC_INST_PS_CLAMP: orc_ps_clamp_ingest((orc_ps_clamp *)st, round, r); break;
+        case ORC_INST_PS_ULT: orc_ps_ult_ingest((orc_ps_ult *)st, round, r); break;
         default: orc_hamming_ingest((orc_hamming *)st, r); break;
     }
 }

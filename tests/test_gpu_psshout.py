@@ -143,3 +143,42 @@ def test_ps_shout_clamp_bit_exact(atlas, N, bound, sym, log_T):
     assert len(rows_g) == len(rows_o) and all(np.array_equal(a, b) for a, b in zip(rows_g, rows_o))
     assert t_g.state == t_o.state_bytes()
     inst.free()
+
+
+@pytest.mark.parametrize("log_T", [1, 5, 10, 13])
+def test_ps_shout_unsigned_less_than_bit_exact(atlas, log_T):
+    import ctypes as C
+    from oracle import orc, orc_ra as OR
+    from jolt_atlas_amd import instances as I
+    A = atlas
+    orc.lib.fr_from_i64.argtypes = [C.c_int64, C.c_void_p]
+    T = 1 << log_T
+    rng = np.random.default_rng(log_T)
+    xs = rng.integers(0, 1 << 32, size=T, dtype=np.uint64)
+    ys = rng.integers(0, 1 << 32, size=T, dtype=np.uint64)
+    near = rng.random(T) < 0.5                       # divisions compare remainders with divisors: close operands
+    ys[near] = xs[near] + rng.integers(-3, 4, size=int(near.sum())).astype(np.int64).astype(np.uint64)
+    ys &= np.uint64(0xffffffff)
+    xs[0], ys[0] = 5, 5
+    xs[1], ys[1] = 0xffffffff, 0
+    idx = np.array([OR.interleave(x, y) for x, y in zip(xs, ys)], dtype=np.uint64)
+    r_node, gamma = orc.random_fr(log_T, 5), orc.random_fr(1, 6)[0]
+    g2 = orc.fr_mul_arr(gamma, gamma)
+    E = orc.eq_evals(r_node)
+    sgn = lambda v: int(v) - (1 << 32) if int(v) >> 31 else int(v)
+    claim = orc.fr_array(1)[0]
+    for t in range(T):
+        a, b = orc.fr_array(1), orc.fr_array(1)
+        orc.lib.fr_from_i64(sgn(xs[t]), orc._p(a)); orc.lib.fr_from_i64(sgn(ys[t]), orc._p(b))
+        term = orc.fr_add_arr(orc.from_ints([int(xs[t] < ys[t])])[0], orc.fr_add_arr(orc.fr_mul_arr(gamma, a[0]), orc.fr_mul_arr(g2, b[0])))
+        claim = orc.fr_add_arr(claim, orc.fr_mul_arr(E[t], term))
+    t_o = orc.new_transcript(b"ps_ult")
+    rows_o, ch_o = OR.ps_ult(idx, r_node, gamma).prove(claim, t_o)
+    inst = I.ps_shout_ult(idx, r_node, gamma)
+    assert inst.num_rounds() == 64 + log_T and inst.degree() == 2
+    t_g = A.Blake2bTranscript(b"ps_ult")
+    rows_g, ch_g = inst.prove(claim, t_g)
+    assert ch_g == ch_o
+    assert len(rows_g) == len(rows_o) and all(np.array_equal(a, b) for a, b in zip(rows_g, rows_o))
+    assert t_g.state == t_o.state_bytes()
+    inst.free()

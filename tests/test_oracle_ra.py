@@ -281,3 +281,32 @@ def test_ps_shout_clamp_oracle_matches_closed_form_model(N, bound, sym, log_T):
     assert raw_o == raw_p
     assert [orc.to_ints(r) for r in rows_o] == rows_p
     assert bytes(to.state) == tp.state
+
+
+@pytest.mark.parametrize("log_T", [1, 3])
+def test_ps_shout_unsigned_less_than_oracle_matches_closed_form_model(log_T):
+    """binary read-raf (ps_shout/binary.rs) with UnsignedLessThanTable<32>: 64 interleaved address bits."""
+    T = 1 << log_T
+    rng = np.random.default_rng(log_T)
+    xs = [int(v) for v in rng.integers(0, 1 << 32, size=T, dtype=np.uint64)]
+    ys = [int(v) for v in rng.integers(0, 1 << 32, size=T, dtype=np.uint64)]
+    xs[0], ys[0] = 5, 5                               # equal operands
+    xs[1], ys[1] = (1 << 32) - 1, 0
+    if T > 2:
+        xs[2], ys[2] = 7, (1 << 31); xs[3], ys[3] = ys[3] & ~0xff, (ys[3] & ~0xff) + 1     # differ only in the low byte
+        xs[3] = ys[3] - 1
+    idx = [OR.interleave(x, y) for x, y in zip(xs, ys)]
+    r_node, gamma = _rand(log_T, 3), _rand(1, 4)[0] >> 130
+    model = PR.PsUltModel(idx, r_node, gamma)
+    sgn = lambda v: v - (1 << 32) if v >> 31 else v
+    for k, x, y in zip(idx, xs, ys):
+        bits = [(k >> (63 - i)) & 1 for i in range(64)]
+        assert model._W(bits) == (int(x < y) + gamma * sgn(x) + gamma * gamma * sgn(y)) % F.FR
+    claim = model.input_claim()
+    rows_p, raw_p, tp = _prove_py(model, claim, b"ps_ult")
+    inst = OR.ps_ult(idx, orc.from_ints(r_node), orc.from_ints([gamma])[0])
+    to = orc.new_transcript(b"ps_ult")
+    rows_o, raw_o = inst.prove(orc.from_ints([claim])[0], to)
+    assert raw_o == raw_p
+    assert [orc.to_ints(r) for r in rows_o] == rows_p
+    assert bytes(to.state) == tp.state
