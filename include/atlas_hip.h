@@ -308,6 +308,14 @@ int atlas_onehot_opening_new(const int32_t *nonzero_indices, size_t log_K, size_
                              const atlas_fr_t *r_address, const atlas_fr_t *r_cycle,
                              atlas_instance_t *out);
 
+/* R one-hot openings that share r_cycle (one EqCycleState in the reference, opening_proof.rs:339-343):
+ * out receives R handles, one per polynomial, usable like any other instance but advancing round by
+ * round together (as inside one BatchedSumcheck); their cycle-phase folds and binds run as one launch
+ * each.  r_addresses = R rows of log_K Fr. */
+int atlas_onehot_opening_group_new(const int32_t *const *nonzero_indices, size_t R, size_t log_K, size_t log_T,
+                                   const atlas_fr_t *r_addresses, const atlas_fr_t *r_cycle,
+                                   atlas_instance_t *out);
+
 /* HammingWeightSumcheckProver::gen (subprotocols/hamming_weight.rs:106-116): sum_k sum_i
  * gamma^i G_i[k], degree 1, log_k_chunk rounds */
 int atlas_hamming_weight_new(const atlas_fr_t *G, size_t d, size_t log_k_chunk,

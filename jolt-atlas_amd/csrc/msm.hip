@@ -72,10 +72,17 @@ void to_out(const H::G1Aff& a, atlas_g1_affine_t* out) {
 }
 
 // core: `launch_digits(digits)` fills the window-major signed digits for shape S
+// Several scalar vectors over the same bases (prefixes of the SRS) share one pipeline: n = total number of scalars
+// in the concatenation, vector k = [offs[k], offs[k] + lens[k]); out[k] = its MSM.  K = 1 is the plain case.
+struct MsmMulti { size_t K; const size_t* lens; const size_t* offs; };
+
 template <class DigitsFn>
-int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launch_digits, atlas_g1_affine_t* out) {
-    if (n == 0) { H::G1Aff z{H::q_zero(), H::q_zero()}; to_out(z, out); return ATLAS_OK; }
-    const uint32_t TB = S.n_windows * S.bpw;
+int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launch_digits, atlas_g1_affine_t* out,
+             const MsmMulti* multi = nullptr) {
+    const size_t K = multi ? multi->K : 1;
+    if (n == 0) { H::G1Aff z{H::q_zero(), H::q_zero()}; for (size_t k = 0; k < K; k++) to_out(z, out + k); return ATLAS_OK; }
+    const uint32_t V = (uint32_t)K * S.n_windows;          // virtual windows
+    const uint32_t TB = V * S.bpw;
     const uint32_t chunk = S.bpw < (uint32_t)MSM_CHUNK ? S.bpw : (uint32_t)MSM_CHUNK;
     const uint32_t n_chunks = TB / chunk;
     const uint32_t chunks_per_window = S.bpw / chunk;
@@ -91,14 +98,17 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
     const size_t o_cursor = carve((size_t)(TB + 1) * 4);
     const size_t o_sorted = carve(n * (size_t)S.n_windows * 4);
     // load-balanced accumulation: segments of <= MSM_SEG_LEN sorted entries (see msm_kernels.hip.h)
-    const size_t s_max = (n * (size_t)S.n_windows) / MSM_SEG_LEN + TB + 1;
+    // segment length: full length for big problems, shorter when there would be fewer than ~2^17 segments
+    uint32_t seg_len = MSM_SEG_LEN;
+    while (seg_len > 8 && (n * (size_t)S.n_windows) / seg_len < ((size_t)1 << 17)) seg_len >>= 1;
+    const size_t s_max = (n * (size_t)S.n_windows) / seg_len + TB + 1;
     const size_t o_segc = carve((size_t)(TB + 1) * 4);
     const size_t o_segoff = carve((size_t)(TB + 1) * 4);
     const size_t o_segcur = carve((size_t)(TB + 1) * 4);
     const size_t o_partial = carve(s_max * sizeof(G1Xyzz));
     const size_t o_buckets = carve((size_t)TB * sizeof(G1Xyzz));
     const size_t o_chunks = carve((size_t)n_chunks * sizeof(G1Xyzz));
-    const size_t o_wsum = carve((size_t)S.n_windows * sizeof(G1Xyzz));
+    const size_t o_wsum = carve((size_t)V * sizeof(G1Xyzz));
     int rc = ws.ensure(off);
     if (rc) return rc;
     unsigned char* W = (unsigned char*)ws.p;
@@ -125,41 +135,59 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
     // signed digits once, window-major; histogram of all windows; scan; scatter window by window
     launch_digits(digits);
     const bool lds_sort = S.bpw <= MSM_LDS_BPW;
-    const unsigned n_tiles = (unsigned)((n + MSM_TILE - 1) / MSM_TILE);
-    if (lds_sort) k_msm_hist_lds<<<dim3(n_tiles, S.n_windows), MSM_THREADS, 0, g.stream>>>(digits, n, S, counts);
+    if (multi && !lds_sort) return fail(ATLAS_EINVAL, "msm: batched vectors need an LDS-sortable window width");
+    std::vector<MsmTile> h_tiles;
+    for (size_t k = 0; k < K; k++) {
+        const size_t o = multi ? multi->offs[k] : 0, len = multi ? multi->lens[k] : n;
+        for (size_t t0 = 0; t0 < len; t0 += MSM_TILE)
+            h_tiles.push_back(MsmTile{(uint32_t)(o + t0), (uint32_t)(o + (t0 + MSM_TILE < len ? t0 + MSM_TILE : len)),
+                                      (uint32_t)(k * S.n_windows * S.bpw), (uint32_t)o});
+    }
+    const unsigned n_tiles = (unsigned)h_tiles.size();
+    MsmTile* d_tiles = nullptr;
+    if (lds_sort) {
+        HIP_TRY(hipMalloc(&d_tiles, h_tiles.size() * sizeof(MsmTile)));
+        HIP_TRY(hipMemcpyAsync(d_tiles, h_tiles.data(), h_tiles.size() * sizeof(MsmTile), hipMemcpyHostToDevice, g.stream));
+    }
+    if (lds_sort) k_msm_hist_lds<<<dim3(n_tiles, S.n_windows), MSM_THREADS, 0, g.stream>>>(digits, n, d_tiles, S, counts);
     else k_msm_hist_w<<<dim3((unsigned)grid_for(n, 256), S.n_windows), MSM_THREADS, 0, g.stream>>>(digits, n, S, counts);
     k_scan_block_sums<<<(unsigned)n_scan_blocks, 256, 0, g.stream>>>(counts, TB, bsum);
     k_exclusive_scan<<<1, 1024, 0, g.stream>>>(bsum, (uint32_t)n_scan_blocks, boff, bcur);
     k_scan_apply<<<(unsigned)n_scan_blocks, 256, 0, g.stream>>>(counts, TB, boff, offsets, cursor, (uint32_t)n_scan_blocks);
-    for (uint32_t w = 0; w < S.n_windows; w++) {
-        if (lds_sort) k_msm_scatter_lds<<<n_tiles, MSM_THREADS, 0, g.stream>>>(digits + (size_t)w * n, n, S.bpw, cursor + (size_t)w * S.bpw, sorted);
-        else k_msm_scatter_w<<<grid_for(n, 1024), MSM_THREADS, 0, g.stream>>>(digits + (size_t)w * n, n, cursor + (size_t)w * S.bpw, sorted);
-    }
+    if (lds_sort) k_msm_scatter_lds<<<dim3(n_tiles, S.n_windows), MSM_THREADS, 0, g.stream>>>(digits, n, d_tiles, S.bpw, cursor, sorted);
+    else
+        for (uint32_t w = 0; w < S.n_windows; w++)
+            k_msm_scatter_w<<<grid_for(n, 1024), MSM_THREADS, 0, g.stream>>>(digits + (size_t)w * n, n, cursor + (size_t)w * S.bpw, sorted);
     if (g.timing) hipEventRecord(e1, g.stream);
-    k_msm_seg_counts<<<(TB + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, g.stream>>>(offsets, TB, segc);
+    k_msm_seg_counts<<<(TB + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, g.stream>>>(offsets, TB, seg_len, segc);
     k_scan_block_sums<<<(unsigned)n_scan_blocks, 256, 0, g.stream>>>(segc, TB, bsum);
     k_exclusive_scan<<<1, 1024, 0, g.stream>>>(bsum, (uint32_t)n_scan_blocks, boff, bcur);
     k_scan_apply<<<(unsigned)n_scan_blocks, 256, 0, g.stream>>>(segc, TB, boff, seg_off, seg_cur, (uint32_t)n_scan_blocks);
-    k_msm_accumulate_seg<<<(unsigned)((s_max + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, g.stream>>>(bases, sorted, offsets, seg_off, TB, partial);
+    k_msm_accumulate_seg<<<(unsigned)((s_max + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, g.stream>>>(bases, sorted, offsets, seg_off, TB, seg_len, partial);
     k_msm_bucket_reduce_small<<<(TB + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, g.stream>>>(partial, seg_off, TB, buckets);
     k_msm_bucket_reduce_big<<<TB, MSM_THREADS, 0, g.stream>>>(partial, seg_off, buckets);
     if (g.timing) hipEventRecord(e2, g.stream);
     k_msm_fold_chunks<<<(n_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, g.stream>>>(buckets, S, chunk, n_chunks, chunks);
-    k_g1_group_sum<<<S.n_windows, MSM_THREADS, 0, g.stream>>>(chunks, chunks_per_window, wsum);
+    k_g1_group_sum<<<V, MSM_THREADS, 0, g.stream>>>(chunks, chunks_per_window, wsum);
     if (g.timing) hipEventRecord(e3, g.stream);
     hipError_t le = hipGetLastError();
-    if (le != hipSuccess) return fail(ATLAS_ENODEV, "msm launch", le);
+    if (le != hipSuccess) { if (d_tiles) hipFree(d_tiles); return fail(ATLAS_ENODEV, "msm launch", le); }
 
-    std::vector<H::G1X> hw(S.n_windows);
-    HIP_TRY(hipMemcpyAsync(hw.data(), wsum, S.n_windows * sizeof(G1Xyzz), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
-    // Horner over the windows: acc = 2^c * acc + W_w
-    H::G1X acc = hw[S.n_windows - 1];
-    for (int w = (int)S.n_windows - 2; w >= 0; w--) {
-        for (uint32_t k = 0; k < S.c; k++) acc = H::gx_dbl(acc);
-        acc = H::gx_add(acc, hw[w]);
+    std::vector<H::G1X> hw(V);
+    hipError_t ce = hipMemcpyAsync(hw.data(), wsum, V * sizeof(G1Xyzz), hipMemcpyDeviceToHost, g.stream);
+    if (ce == hipSuccess) ce = hipStreamSynchronize(g.stream);
+    if (d_tiles) hipFree(d_tiles);
+    if (ce != hipSuccess) return fail(ATLAS_ENODEV, "msm result copy", ce);
+    // Horner over the windows of each vector: acc = 2^c * acc + W_w
+    for (size_t k = 0; k < K; k++) {
+        const H::G1X* hk = hw.data() + k * S.n_windows;
+        H::G1X acc = hk[S.n_windows - 1];
+        for (int w = (int)S.n_windows - 2; w >= 0; w--) {
+            for (uint32_t d = 0; d < S.c; d++) acc = H::gx_dbl(acc);
+            acc = H::gx_add(acc, hk[w]);
+        }
+        to_out(H::gx_to_aff(acc), out + k);
     }
-    to_out(H::gx_to_aff(acc), out);
 
     if (g.timing) {
         float a = 0, b = 0, c = 0;
@@ -180,6 +208,18 @@ int msm_device(const G1Affine* bases, const Fr* d_scalars, size_t n, atlas_g1_af
     return msm_core(bases, n, S, [&](int16_t* digits) {
         k_msm_digits<<<grid_for(n), MSM_THREADS, 0, g.stream>>>(d_scalars, n, S, digits);
     }, out);
+}
+
+// K vectors stored back to back in d_scalars (vector k at offs[k], lens[k] scalars), each against bases[0..lens[k])
+int msm_device_multi(const G1Affine* bases, const Fr* d_scalars, size_t n_tot, size_t K, const size_t* lens, const size_t* offs,
+                     atlas_g1_affine_t* out) {
+    size_t mx = 0;
+    for (size_t k = 0; k < K; k++) mx = lens[k] > mx ? lens[k] : mx;
+    const MsmShape S = pick_shape(mx);
+    const MsmMulti M{K, lens, offs};
+    return msm_core(bases, n_tot, S, [&](int16_t* digits) {
+        k_msm_digits<<<grid_for(n_tot), MSM_THREADS, 0, g.stream>>>(d_scalars, n_tot, S, digits);
+    }, out, &M);
 }
 
 // narrow integer scalars (msm_u8 .. msm_u64 and the signed split of I32/I64Scalars,
@@ -439,13 +479,13 @@ int atlas_hyperkzg_open(atlas_srs_t srs, atlas_poly_t poly, const atlas_u128_t* 
         }
     }
     // commitments to Pi_1.. (commit_variable_batch, kzg.rs:227-243)
-    {
-        size_t off = n, len = n >> 1;
-        for (size_t i = 1; i < ell; i++) {
-            int rc = msm_device(srs->d, polys + off, len, &com[i - 1]);
-            if (rc) { cleanup(); return rc; }
-            off += len; len >>= 1;
-        }
+    // Pi_1 .. Pi_{ell-1} lie back to back after Pi_0: one batched pipeline over all of them (n - 2 scalars)
+    if (ell > 1) {
+        std::vector<size_t> lens(ell - 1), offs(ell - 1);
+        size_t off = 0, len = n >> 1;
+        for (size_t i = 1; i < ell; i++) { lens[i - 1] = len; offs[i - 1] = off; off += len; len >>= 1; }
+        int rc = msm_device_multi(srs->d, polys + n, off, ell - 1, lens.data(), offs.data(), com);
+        if (rc) { cleanup(); return rc; }
     }
     // Phase 2: transcript, r, u = [r, -r, r^2]
     H::tr_append_message(T, "begin_append_vector");
@@ -490,8 +530,9 @@ int atlas_hyperkzg_open(atlas_srs_t srs, atlas_poly_t poly, const atlas_u128_t* 
     k_hk_witness<<<(unsigned)n_blocks, HK_THREADS, 0, g.stream>>>(B, n, P, xincl, xs, G, n_blocks, pw16, h, n);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { cleanup(); return fail(ATLAS_ENODEV, "hyperkzg launch", le); }
-    for (int k = 0; k < 3; k++) {
-        int rc = msm_device(srs->d, h + (size_t)k * n, n, &w[k]);
+    {   // the three witness commitments share the bases: one batched pipeline
+        const size_t lens[3] = {n, n, n}, offs[3] = {0, n, 2 * n};
+        int rc = msm_device_multi(srs->d, h, 3 * n, 3, lens, offs, w);
         if (rc) { cleanup(); return rc; }
     }
     H::tr_append_message(T, "begin_append_vector");

@@ -102,32 +102,44 @@ __global__ __launch_bounds__(MSM_THREADS) void k_msm_hist_w(const int16_t* __res
 constexpr uint32_t MSM_LDS_BPW = 8192;
 constexpr uint32_t MSM_TILE = 16384;      // elements per workgroup tile
 
-__global__ __launch_bounds__(MSM_THREADS) void k_msm_hist_lds(const int16_t* __restrict__ digits, size_t n, MsmShape S,
-                                                              uint32_t* counts) {
+// a tile = at most MSM_TILE consecutive scalars of ONE scalar vector; several vectors over the same bases
+// (the shrinking polynomials of HyperKZG::open) run through one pipeline as extra "virtual windows":
+// vector k, window w owns buckets [bucket_base + w * bpw, +bpw)
+struct MsmTile {
+    uint32_t begin, end;        // range in the concatenated scalar index space
+    uint32_t bucket_base;       // k * n_windows * bpw
+    uint32_t local_off;         // offset of vector k: sorted entries carry (i - local_off), the base index
+};
+
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_hist_lds(const int16_t* __restrict__ digits, size_t n_tot,
+                                                              const MsmTile* __restrict__ tiles, MsmShape S, uint32_t* counts) {
     __shared__ uint32_t h[MSM_LDS_BPW];
     const uint32_t w = blockIdx.y;
+    const MsmTile tl = tiles[blockIdx.x];
     for (uint32_t b = threadIdx.x; b < S.bpw; b += MSM_THREADS) h[b] = 0;
     __syncthreads();
-    const int16_t* dw = digits + (size_t)w * n;
-    const size_t t0 = (size_t)blockIdx.x * MSM_TILE, t1 = t0 + MSM_TILE < n ? t0 + MSM_TILE : n;
-    for (size_t i = t0 + threadIdx.x; i < t1; i += MSM_THREADS) {
+    const int16_t* dw = digits + (size_t)w * n_tot;
+    for (uint32_t i = tl.begin + threadIdx.x; i < tl.end; i += MSM_THREADS) {
         const int32_t d = dw[i];
         if (d) atomicAdd(&h[(d < 0 ? -d : d) - 1], 1u);
     }
     __syncthreads();
-    uint32_t* cw = counts + (size_t)w * S.bpw;
+    uint32_t* cw = counts + tl.bucket_base + (size_t)w * S.bpw;
     for (uint32_t b = threadIdx.x; b < S.bpw; b += MSM_THREADS)
         if (h[b]) atomicAdd(&cw[b], h[b]);
 }
 
-__global__ __launch_bounds__(MSM_THREADS) void k_msm_scatter_lds(const int16_t* __restrict__ dw, size_t n, uint32_t bpw,
-                                                                 uint32_t* cursor_w, uint32_t* __restrict__ sorted) {
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_scatter_lds(const int16_t* __restrict__ digits, size_t n_tot,
+                                                                 const MsmTile* __restrict__ tiles, uint32_t bpw,
+                                                                 uint32_t* cursor, uint32_t* __restrict__ sorted) {
     __shared__ uint32_t cnt[MSM_LDS_BPW];
     __shared__ uint32_t base[MSM_LDS_BPW];
+    const MsmTile tl = tiles[blockIdx.x];
+    const int16_t* dw = digits + (size_t)blockIdx.y * n_tot;          // blockIdx.y = window
+    uint32_t* cursor_w = cursor + tl.bucket_base + (size_t)blockIdx.y * bpw;
     for (uint32_t b = threadIdx.x; b < bpw; b += MSM_THREADS) cnt[b] = 0;
     __syncthreads();
-    const size_t t0 = (size_t)blockIdx.x * MSM_TILE, t1 = t0 + MSM_TILE < n ? t0 + MSM_TILE : n;
-    for (size_t i = t0 + threadIdx.x; i < t1; i += MSM_THREADS) {
+    for (uint32_t i = tl.begin + threadIdx.x; i < tl.end; i += MSM_THREADS) {
         const int32_t d = dw[i];
         if (d) atomicAdd(&cnt[(d < 0 ? -d : d) - 1], 1u);
     }
@@ -138,12 +150,12 @@ __global__ __launch_bounds__(MSM_THREADS) void k_msm_scatter_lds(const int16_t* 
         cnt[b] = 0;
     }
     __syncthreads();
-    for (size_t i = t0 + threadIdx.x; i < t1; i += MSM_THREADS) {
+    for (uint32_t i = tl.begin + threadIdx.x; i < tl.end; i += MSM_THREADS) {
         const int32_t d = dw[i];
         if (d) {
             const uint32_t b = (uint32_t)((d < 0 ? -d : d) - 1);
             const uint32_t r = atomicAdd(&cnt[b], 1u);
-            sorted[base[b] + r] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+            sorted[base[b] + r] = (i - tl.local_off) | (d < 0 ? 0x80000000u : 0u);
         }
     }
 }
@@ -203,19 +215,19 @@ __global__ __launch_bounds__(MSM_THREADS) void k_msm_accumulate(const G1Affine* 
 // entries; thread t owns segment t (bucket found by binary search in the segment offsets), so a
 // skewed window (the short top window of a 254-bit scalar, or narrow activations) cannot leave one
 // thread with a million additions.
-constexpr uint32_t MSM_SEG_LEN = 128;
+constexpr uint32_t MSM_SEG_LEN = 128;     // upper bound; small problems use shorter segments (more threads, shorter chains)
 
 __global__ __launch_bounds__(MSM_THREADS) void k_msm_seg_counts(const uint32_t* __restrict__ offsets, uint32_t n_buckets,
-                                                                uint32_t* __restrict__ segc) {
+                                                                uint32_t seg_len, uint32_t* __restrict__ segc) {
     const uint32_t b = blockIdx.x * MSM_THREADS + threadIdx.x;
-    if (b < n_buckets) segc[b] = (offsets[b + 1] - offsets[b] + MSM_SEG_LEN - 1) / MSM_SEG_LEN;
+    if (b < n_buckets) segc[b] = (offsets[b + 1] - offsets[b] + seg_len - 1) / seg_len;
 }
 
 __global__ __launch_bounds__(MSM_THREADS) void k_msm_accumulate_seg(const G1Affine* __restrict__ bases,
                                                                     const uint32_t* __restrict__ sorted,
                                                                     const uint32_t* __restrict__ offsets,
                                                                     const uint32_t* __restrict__ seg_off, uint32_t n_buckets,
-                                                                    G1Xyzz* __restrict__ partial) {
+                                                                    uint32_t seg_len, G1Xyzz* __restrict__ partial) {
     const uint32_t t = blockIdx.x * MSM_THREADS + threadIdx.x;
     if (t >= seg_off[n_buckets]) return;
     uint32_t lo_b = 0, hi_b = n_buckets;              // largest b with seg_off[b] <= t
@@ -224,9 +236,9 @@ __global__ __launch_bounds__(MSM_THREADS) void k_msm_accumulate_seg(const G1Affi
         if (seg_off[mid] <= t) lo_b = mid; else hi_b = mid;
     }
     const uint32_t b = lo_b;
-    const uint32_t lo = offsets[b] + (t - seg_off[b]) * MSM_SEG_LEN;
+    const uint32_t lo = offsets[b] + (t - seg_off[b]) * seg_len;
     const uint32_t end = offsets[b + 1];
-    const uint32_t hi = lo + MSM_SEG_LEN < end ? lo + MSM_SEG_LEN : end;
+    const uint32_t hi = lo + seg_len < end ? lo + seg_len : end;
     G1Xyzz9 acc;
     acc.inf = true;
     acc.x = f9_zero(); acc.y = f9_zero(); acc.zz = f9_zero(); acc.zzz = f9_zero();

@@ -285,6 +285,187 @@ struct OneHotOpening : atlas_instance {
     }
 };
 
+// ---------------------------------------------------------------- one-hot openings that share r_cycle
+// The reference keeps one EqCycleState per distinct r_cycle and binds it once per round for every
+// opening that refers to it (opening_reduction.rs:686-698, opening_proof.rs:339-343).  Here the rows of
+// such a group also share their launches: one fold, one bind and one reduction per round for all R
+// polynomials (a lookup op registers d = 16 of them at a time), instead of R of each.
+__global__ __launch_bounds__(OP_THREADS) void k_onehot_G_rows(const int32_t* __restrict__ idx, const Fr* __restrict__ E, size_t T,
+                                                              uint32_t K, Fr* __restrict__ G /* [R][K] */) {
+    __shared__ Fr red[OP_THREADS / 64];
+    const int32_t k = (int32_t)blockIdx.x;
+    const size_t row = blockIdx.y;
+    const int32_t* ix = idx + row * T;
+    Fr acc = fe_zero();
+    for (size_t j = threadIdx.x; j < T; j += OP_THREADS)
+        if (ix[j] == k) acc = fr_add(acc, fe_load(E + j));
+    acc = fr_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Fr s = red[0];
+        for (int w = 1; w < OP_THREADS / 64; w++) s = fr_add(s, red[w]);
+        fe_store(G + row * K + k, s);
+    }
+}
+
+__global__ __launch_bounds__(OP_THREADS) void k_open_fold_rows(const Fr* __restrict__ H, size_t stride, size_t half, SplitEqView E,
+                                                               Fr* __restrict__ partials /* [R][gridDim.x] */) {
+    Fr acc[1];
+    acc[0] = fe_zero();
+    const Fr* row = H + (size_t)blockIdx.y * stride;
+    const size_t mask = ((size_t)1 << E.in_bits) - 1;
+    for (size_t j = (size_t)blockIdx.x * OP_THREADS + threadIdx.x; j < half; j += (size_t)gridDim.x * OP_THREADS) {
+        const Fr w = fr_mul(fe_load(E.e_out + (j >> E.in_bits)), fe_load(E.e_in + (j & mask)));
+        acc[0] = fr_add(acc[0], fr_mul(w, fe_load(row + j)));
+    }
+    block_reduce_store<1>(acc, partials + (size_t)blockIdx.y * gridDim.x);
+}
+
+__global__ __launch_bounds__(OP_THREADS) void k_open_reduce_rows(const Fr* __restrict__ partials, uint32_t n, Fr* out) {
+    __shared__ Fr red[OP_THREADS / 64];
+    const Fr* p = partials + (size_t)blockIdx.x * n;
+    Fr acc = fe_zero();
+    for (uint32_t i = threadIdx.x; i < n; i += OP_THREADS) acc = fr_add(acc, fe_load(p + i));
+    acc = fr_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Fr s = red[0];
+        for (int w = 1; w < OP_THREADS / 64; w++) s = fr_add(s, red[w]);
+        fe_store(out + blockIdx.x, s);
+    }
+}
+
+__global__ __launch_bounds__(OP_THREADS) void k_open_bind_hi_rows(Fr* H, size_t stride, size_t half, Fr r, int r_hi_only) {
+    Fr* z = H + (size_t)blockIdx.y * stride;
+    for (size_t i = (size_t)blockIdx.x * OP_THREADS + threadIdx.x; i < half; i += (size_t)gridDim.x * OP_THREADS)
+        fe_store(z + i, bind_pair(fe_load(z + i), fe_load(z + i + half), r, r_hi_only != 0));
+}
+
+struct OneHotGroup {
+    size_t R = 0, log_K = 0, log_T = 0, T = 0, H_len = 0;
+    int32_t* d_idx = nullptr;            // [R][T]
+    Fr *d_H = nullptr, *d_part = nullptr, *d_q0 = nullptr;
+    GseDevH D;
+    std::vector<std::vector<H::Fr>> G;   // [R][K]
+    std::vector<H::Fr> q0;               // cycle round cache: one fold per round for all rows
+    H::Fr q0_scalar = H::one(), q0_w = H::zero();   // the split-eq's scalar and w of that round
+    size_t q0_round = (size_t)-1, bound_rounds = 0;   // cycle rounds whose challenge has been applied
+    size_t refs = 0;
+    ~OneHotGroup() { for (void* p : {(void*)d_idx, (void*)d_H, (void*)d_part, (void*)d_q0}) if (p) hipFree(p); D.release(); }
+
+    int fold_all(size_t cycle_round) {   // H rows at the current length, all rows at once
+        if (q0_round == cycle_round) return ATLAS_OK;
+        if (bound_rounds != cycle_round) return fail(ATLAS_ESTATE, "onehot group: rows of a group must advance round by round together");
+        const size_t half = H_len / 2;
+        const unsigned grid = grid_for(half, 512);
+        k_open_fold_rows<<<dim3(grid, (unsigned)R), OP_THREADS, 0, g.stream>>>(d_H, T, half, D.view(), d_part);
+        k_open_reduce_rows<<<(unsigned)R, OP_THREADS, 0, g.stream>>>(d_part, grid, d_q0);
+        q0.resize(R);
+        HIP_TRY(hipMemcpyAsync(q0.data(), d_q0, R * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        q0_round = cycle_round; q0_scalar = D.st.scalar; q0_w = D.st.w_cur();
+        return ATLAS_OK;
+    }
+    int bind_all(size_t cycle_round, const H::Fr& rf) {   // "if num_variables_bound <= round" (opening_reduction.rs:686-698)
+        if (bound_rounds > cycle_round) return ATLAS_OK;
+        const size_t half = H_len / 2;
+        k_open_bind_hi_rows<<<dim3(grid_for(half, 1024), (unsigned)R), OP_THREADS, 0, g.stream>>>(d_H, T, half, to_dev(rf), g.challenge_mode == 0 ? 1 : 0);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(ATLAS_ENODEV, "onehot group bind", e);
+        H_len = half;
+        D.st.bind(rf);
+        bound_rounds = cycle_round + 1;
+        return ATLAS_OK;
+    }
+};
+
+struct OneHotRow : atlas_instance {
+    OneHotGroup* grp = nullptr;
+    size_t row = 0, round_next = 0;
+    std::vector<H::Fr> B, F;
+    ~OneHotRow() override { if (grp && --grp->refs == 0) delete grp; }
+    size_t rounds() const override { return grp->log_K + grp->log_T; }
+    size_t degree() const override { return 2; }
+
+    int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
+        if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "onehot_opening: round out of order");
+        coeffs.assign(3, H::zero());
+        const size_t log_K = grp->log_K;
+        if (round < log_K) {
+            const std::vector<H::Fr>& G = grp->G[row];
+            const size_t unbound = log_K - round, K = (size_t)1 << log_K, half = B.size() / 2;
+            H::Fr e0 = H::zero(), e2 = H::zero();
+            for (size_t kp = 0; kp < half; kp++) {
+                const H::Fr b0 = B[kp], b2 = H::add(B[kp + half], H::sub(B[kp + half], b0));
+                H::Fr s0 = H::zero(), s2 = H::zero();
+                for (size_t k = kp; k < K; k += half) {
+                    const H::Fr gf = H::mul(G[k], F[k >> unbound]);
+                    if (((k >> (unbound - 1)) & 1) == 0) { s0 = H::add(s0, gf); s2 = H::sub(s2, gf); }
+                    else s2 = H::add(s2, H::add(gf, gf));
+                }
+                e0 = H::add(e0, H::mul(b0, s0)); e2 = H::add(e2, H::mul(b2, s2));
+            }
+            const H::Fr ev[2] = {e0, e2};
+            H::unipoly_from_evals_and_hint(claim, ev, 2, coeffs.data());
+            return ATLAS_OK;
+        }
+        {
+            std::lock_guard<std::mutex> lk(g.mu);
+            const int rc = grp->fold_all(round - log_K);
+            if (rc) return rc;
+        }
+        const H::Fr eqa = B[0];
+        H::gruen_deg2(grp->q0_scalar, grp->q0_w, grp->q0[row], H::mul(claim, H::inv(eqa)), coeffs.data());
+        for (auto& c : coeffs) c = H::mul(c, eqa);
+        H::trim(coeffs);
+        return ATLAS_OK;
+    }
+
+    int ingest(const atlas_u128_t& r, size_t round) override {
+        if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "onehot_opening: round out of order");
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        const size_t log_K = grp->log_K;
+        if (round < log_K) {
+            const size_t half = B.size() / 2;
+            for (size_t i = 0; i < half; i++) B[i] = H::add(B[i], H::mul(rf, H::sub(B[i + half], B[i])));
+            B.resize(half);
+            std::vector<H::Fr> nf(2 * F.size());
+            for (size_t i = 0; i < F.size(); i++) { nf[2 * i + 1] = H::mul(rf, F[i]); nf[2 * i] = H::sub(F[i], nf[2 * i + 1]); }
+            F.swap(nf);
+            if (round == log_K - 1) {                                // this row's H = F[idx]
+                std::lock_guard<std::mutex> lk(g.mu);
+                const size_t T = grp->T;
+                Fr* d_F = nullptr;
+                HIP_TRY(hipMalloc(&d_F, F.size() * sizeof(Fr)));
+                HIP_TRY(hipMemcpyAsync(d_F, F.data(), F.size() * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+                k_onehot_gather<<<grid_for(T, 4096), OP_THREADS, 0, g.stream>>>(grp->d_idx + row * T, d_F, T, grp->d_H + row * T);
+                hipError_t e = hipStreamSynchronize(g.stream);
+                hipFree(d_F);
+                if (e != hipSuccess) return fail(ATLAS_ENODEV, "onehot_opening: gather", e);
+                grp->G[row].clear();
+            }
+        } else {
+            std::lock_guard<std::mutex> lk(g.mu);
+            const int rc = grp->bind_all(round - log_K, rf);
+            if (rc) return rc;
+        }
+        round_next++;
+        return ATLAS_OK;
+    }
+
+    int finals(std::vector<H::Fr>& out) override {
+        if (round_next != rounds()) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
+        std::lock_guard<std::mutex> lk(g.mu);
+        out.resize(1);
+        HIP_TRY(hipMemcpyAsync(g.h_pinned, grp->d_H + row * grp->T, sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        std::memcpy(out.data(), g.h_pinned, sizeof(Fr));
+        return ATLAS_OK;
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -335,6 +516,51 @@ int atlas_onehot_opening_new(const int32_t* nonzero_indices, size_t log_K, size_
     rc = P->D.init(reinterpret_cast<const H::Fr*>(r_cycle), log_T);
     if (rc) { delete P; return rc; }
     *out = P;
+    return ATLAS_OK;
+}
+
+int atlas_onehot_opening_group_new(const int32_t* const* nonzero_indices, size_t R, size_t log_K, size_t log_T,
+                                   const atlas_fr_t* r_addresses, const atlas_fr_t* r_cycle, atlas_instance_t* out) {
+    NEED_INIT();
+    if (!nonzero_indices || !r_addresses || !r_cycle || !out || R == 0) return fail(ATLAS_EINVAL, "onehot_opening_group_new: null argument");
+    if (log_K == 0 || log_K > 16 || log_T == 0 || log_T > 26) return fail(ATLAS_EINVAL, "onehot_opening_group_new: 1 <= log_K <= 16, 1 <= log_T <= 26");
+    const size_t K = (size_t)1 << log_K, T = (size_t)1 << log_T;
+    atlas_poly_t E = nullptr;
+    int rc = atlas_eq_evals(r_cycle, log_T, nullptr, &E);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g.mu);
+    OneHotGroup* Gp = new OneHotGroup();
+    Gp->R = R; Gp->log_K = log_K; Gp->log_T = log_T; Gp->T = T; Gp->H_len = T;
+    Fr* d_G = nullptr;
+    hipError_t e = hipMalloc(&Gp->d_idx, R * T * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&Gp->d_H, R * T * sizeof(Fr));
+    if (e == hipSuccess) e = hipMalloc(&Gp->d_part, R * 512 * sizeof(Fr));
+    if (e == hipSuccess) e = hipMalloc(&Gp->d_q0, R * sizeof(Fr));
+    if (e == hipSuccess) e = hipMalloc(&d_G, R * K * sizeof(Fr));
+    for (size_t r = 0; r < R && e == hipSuccess; r++)
+        e = hipMemcpyAsync(Gp->d_idx + r * T, nonzero_indices[r], T * sizeof(int32_t), hipMemcpyHostToDevice, g.stream);
+    std::vector<H::Fr> hG(R * K);
+    if (e == hipSuccess) {
+        k_onehot_G_rows<<<dim3((unsigned)K, (unsigned)R), OP_THREADS, 0, g.stream>>>(Gp->d_idx, (const Fr*)E->d, T, (uint32_t)K, d_G);
+        e = hipMemcpyAsync(hG.data(), d_G, R * K * sizeof(Fr), hipMemcpyDeviceToHost, g.stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    if (d_G) hipFree(d_G);
+    hipFree(E->d); delete E;
+    if (e != hipSuccess) { delete Gp; return fail(ATLAS_ENODEV, "onehot_opening_group_new", e); }
+    rc = Gp->D.init(reinterpret_cast<const H::Fr*>(r_cycle), log_T);
+    if (rc) { delete Gp; return rc; }
+    Gp->G.resize(R);
+    Gp->refs = R;
+    const H::Fr* ra = reinterpret_cast<const H::Fr*>(r_addresses);
+    for (size_t r = 0; r < R; r++) {
+        Gp->G[r].assign(hG.begin() + r * K, hG.begin() + (r + 1) * K);
+        OneHotRow* P = new OneHotRow();
+        P->grp = Gp; P->row = r;
+        P->B = H::eq_evals(ra + r * log_K, log_K);
+        P->F = {H::one()};
+        out[r] = P;
+    }
     return ATLAS_OK;
 }
 

@@ -36,6 +36,9 @@ extern "C" int atlas_prove_reduced_openings(const atlas_opening_t* openings, siz
     };
     // prepare_for_sumcheck: one opening-reduction instance per committed polynomial (the dense ones work on a
     // copy: the joint polynomial needs the originals)
+    // one-hot openings with the same (log_K, log_T, r_cycle) share their cycle-phase launches (EqCycleState sharing,
+    // opening_proof.rs:339-343)
+    std::vector<char> done(n_open, 0);
     for (size_t i = 0; i < n_open && !rc; i++) {
         const atlas_opening_t& O = openings[i];
         if (O.kind == 0) {
@@ -43,10 +46,26 @@ extern "C" int atlas_prove_reduced_openings(const atlas_opening_t* openings, siz
             if (!O.poly || !O.point) { rc = fail(ATLAS_EINVAL, "prove_reduced_openings: dense opening without polynomial/point"); break; }
             rc = atlas_poly_clone(O.poly, &c);
             if (!rc) { rc = atlas_dense_opening_new(c, O.point, O.n, &inst[i]); if (rc) atlas_poly_free(c); }
-        } else {
-            if (!O.k || !O.point) { rc = fail(ATLAS_EINVAL, "prove_reduced_openings: one-hot opening without indices/point"); break; }
-            rc = atlas_onehot_opening_new(O.k, O.log_K, O.log_T, O.point, O.point + O.log_K, &inst[i]);
+            continue;
         }
+        if (done[i]) continue;
+        if (!O.k || !O.point) { rc = fail(ATLAS_EINVAL, "prove_reduced_openings: one-hot opening without indices/point"); break; }
+        std::vector<size_t> members;
+        for (size_t q = i; q < n_open; q++) {
+            const atlas_opening_t& Q = openings[q];
+            if (Q.kind == 1 && !done[q] && Q.k && Q.point && Q.log_K == O.log_K && Q.log_T == O.log_T &&
+                std::memcmp(Q.point + Q.log_K, O.point + O.log_K, O.log_T * sizeof(atlas_fr_t)) == 0)
+                members.push_back(q);
+        }
+        std::vector<const int32_t*> idx(members.size());
+        std::vector<atlas_fr_t> ra(members.size() * O.log_K);
+        std::vector<atlas_instance_t> rows(members.size(), nullptr);
+        for (size_t q = 0; q < members.size(); q++) {
+            idx[q] = openings[members[q]].k;
+            std::memcpy(&ra[q * O.log_K], openings[members[q]].point, O.log_K * sizeof(atlas_fr_t));
+        }
+        rc = atlas_onehot_opening_group_new(idx.data(), members.size(), O.log_K, O.log_T, ra.data(), O.point + O.log_K, rows.data());
+        for (size_t q = 0; q < members.size() && !rc; q++) { inst[members[q]] = rows[q]; done[members[q]] = 1; }
     }
     // prove_batch_opening_sumcheck: BatchedSumcheck::prove over the instances (degree 2: rows of 3)
     if (!rc) rc = atlas_batched_new(&b);

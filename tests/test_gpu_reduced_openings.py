@@ -21,6 +21,8 @@ def _onehot(T, K, seed):
     dict(dense=[10, 10, 7], onehot=[(4, 6)]),
     dict(dense=[12], onehot=[(4, 8), (4, 8), (4, 5)]),
     dict(dense=[], onehot=[(4, 7), (2, 9)]),
+    dict(dense=[11], onehot=[(4, 7)] * 5, shared_cycle=True),      # a lookup op's d polynomials: one r_cycle, own r_address each
+    dict(dense=[], onehot=[(4, 6), (4, 6), (2, 8), (4, 6)], shared_cycle=True),
 ])
 def test_prove_reduced_openings_bit_exact(atlas, shape):
     from oracle import orc, orc_ra as OR, orc_batched as OB
@@ -40,7 +42,7 @@ def test_prove_reduced_openings_bit_exact(atlas, shape):
         inst_o.append(OB.ra_instance(OR.dense_opening(p, pt), c)); claims.append(c); kinds.append(("d", p))
     for j, (log_K, log_T) in enumerate(shape["onehot"]):
         k = _onehot(1 << log_T, 1 << log_K, 30 + j)
-        ra, rc = orc.random_fr(log_K, 40 + j), orc.random_fr(log_T, 50 + j)
+        ra, rc = orc.random_fr(log_K, 40 + j), orc.random_fr(log_T, 50 + (0 if shape.get("shared_cycle") else j))
         Fa = orc.eq_evals(ra)
         vec = np.stack([Fa[x] if x >= 0 else np.zeros(4, dtype=np.uint64) for x in k])
         c = orc.evaluate(vec, rc)

@@ -161,6 +161,16 @@ def main():
         return t2 - t1
     idrc_once()
     out[f"identity_rc_logK16_T2^{a.log_t}_prove_ms"] = 1e3 * float(np.median([idrc_once() for _ in range(3)]))
+
+    # ---- prove_reduced_openings: 16 one-hot polynomials (K = 16, T = 2^16, one r_cycle) + 1 dense 2^20, SRS 2^20
+    from jolt_atlas_amd import reduced
+    srs20 = A.SRS.generate(A.random_fr(1, 1)[0], 1 << 20)
+    rcy = A.random_fr(16, 31)
+    ops = [dict(poly=A.MultilinearPolynomial.from_fr(A.random_fr(1 << 20, 32)), point=A.random_fr(20, 33), claim=A.random_fr(1, 34)[0])]
+    for q in range(16):
+        ops.append(dict(k=rng.integers(0, 16, size=1 << 16, dtype=np.int32), log_K=4, r_address=A.random_fr(4, 35 + q), r_cycle=rcy,
+                        claim=A.random_fr(1, 60 + q)[0]))
+    out["prove_reduced_openings_16onehot_T2^16_1dense_2^20_ms"] = timed(lambda: reduced.prove_reduced_openings(ops, srs20, A.Blake2bTranscript(b"t")), reps=3)
     print(json.dumps(out, indent=1))
     if a.out:
         with open(a.out, "w") as f:
