@@ -4,7 +4,7 @@
 // The reference builds h(t) = P(l(t)) by folding 2^n univariate polynomials on one thread
 // (O(2^n * n * N) coefficient operations).  Here h is recovered from its values: deg h <= n (N-1),
 // so D + 1 = n (N-1) + 1 multilinear evaluations P(l(0)), ..., P(l(D)) determine it — each one is
-// the split-eq evaluation kernel over the device-resident coefficients (atlas_poly_evaluate), and the
+// a split-eq evaluation over the device-resident coefficients (eight points per pass, k_er_eval), and the
 // O(D^2) Newton interpolation back to monomial coefficients is host arithmetic.  The coefficient
 // vector is the exact polynomial with trailing zeros trimmed, which is what the reference's
 // Add / Mul / from_coeff chain yields (unipoly.rs:415-476).
@@ -16,12 +16,125 @@
 #include "../../include/atlas_hip.h"
 #include "host_poly.hpp"
 #include "runtime.hpp"
+#include "sc_consts.hpp"
+#include "spliteq_kernels.hip.h"
 
+using namespace atlas;
 namespace H = atlas_host;
 using atlas_rt::fail;
 using atlas_rt::g;
 
 namespace {
+
+constexpr int ER_THREADS = 256;
+constexpr int ER_GROUP = 8;        // evaluation points per pass over the coefficients
+
+// eq tables of every evaluation point: blockIdx.x = point, blockIdx.y = half (0: r[0..m) outer, 1: r[m..n) inner);
+// big-endian like EqPolynomial::evals (pass p of the doubling uses the p-th variable from the end)
+__global__ __launch_bounds__(1024) void k_er_tables(const Fr* __restrict__ points, uint32_t n, uint32_t m, Fr* __restrict__ tab1,
+                                                    Fr* __restrict__ tab2) {
+    const uint32_t p = blockIdx.x, half = blockIdx.y;
+    const uint32_t k = half ? n - m : m;
+    const Fr* r = points + (size_t)p * n + (half ? m : 0);
+    Fr* ev = half ? tab2 + ((size_t)p << (n - m)) : tab1 + ((size_t)p << m);
+    if (threadIdx.x == 0) fe_store(ev, fr_one());
+    __syncthreads();
+    for (uint32_t q = 0; q < k; q++) {
+        const uint32_t size = 1u << q;
+        const Fr rq = fe_load(r + (k - 1 - q));
+        for (uint32_t i = threadIdx.x; i < size; i += 1024) {
+            const Fr x = fe_load(ev + i), y = fr_mul(x, rq);
+            fe_store(ev + i + size, y);
+            fe_store(ev + i, fr_sub(x, y));
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// out[t0 + q] += sum_{x_hi} E1_q[x_hi] * sum_{x_lo} E2_q[x_lo] * Z[x_hi, x_lo] for q < G: one pass over Z serves G
+// evaluation points (DensePolynomial::evaluate's split, dense_mlpoly.rs:265-305).  A workgroup takes whole rows.
+template <class T, int G>
+__global__ __launch_bounds__(ER_THREADS) void k_er_eval(const T* __restrict__ Z, uint32_t n, uint32_t m, const Fr* __restrict__ tab1,
+                                                        const Fr* __restrict__ tab2, uint32_t t0, uint32_t n_pts,
+                                                        Fr* __restrict__ partials /* [gridDim.x][G] */, ScConsts K) {
+    __shared__ Fr red[ER_THREADS / 64][G];
+    const uint32_t n2 = n - m;
+    const size_t rows = (size_t)1 << m, cols = (size_t)1 << n2;
+    Fr total = fe_zero();                                     // thread q < G keeps point q's running sum
+    for (size_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        Fr acc[G];
+#pragma unroll
+        for (int q = 0; q < G; q++) acc[q] = fe_zero();
+        for (size_t c = threadIdx.x; c < cols; c += ER_THREADS) {
+            const Fr z = Src<T>::get(Z, (row << n2) | c, K);
+#pragma unroll
+            for (int q = 0; q < G; q++)
+                if (t0 + q < n_pts) acc[q] = fr_add(acc[q], fr_mul(z, fe_load(tab2 + ((size_t)(t0 + q) << n2) + c)));
+        }
+#pragma unroll
+        for (int q = 0; q < G; q++) {
+            const Fr sres = fr_wave_sum(acc[q]);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = sres;
+        }
+        __syncthreads();
+        if (threadIdx.x < G && t0 + threadIdx.x < n_pts) {
+            Fr sres = red[0][threadIdx.x];
+            for (int w = 1; w < ER_THREADS / 64; w++) sres = fr_add(sres, red[w][threadIdx.x]);
+            total = fr_add(total, fr_mul(sres, fe_load(tab1 + ((size_t)(t0 + threadIdx.x) << m) + row)));
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < G) fe_store(partials + (size_t)blockIdx.x * G + threadIdx.x, total);
+}
+
+__global__ __launch_bounds__(ER_THREADS) void k_er_reduce(const Fr* __restrict__ partials, uint32_t n_blocks, uint32_t G, Fr* out) {
+    __shared__ Fr red[ER_THREADS / 64];
+    const uint32_t q = blockIdx.x;
+    Fr acc = fe_zero();
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += ER_THREADS) acc = fr_add(acc, fe_load(partials + (size_t)b * G + q));
+    acc = fr_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Fr sres = red[0];
+        for (int w = 1; w < ER_THREADS / 64; w++) sres = fr_add(sres, red[w]);
+        fe_store(out + q, sres);
+    }
+}
+
+// P(point_t) for all t at once; points = n_pts rows of n Fr (host)
+int evaluate_many(atlas_poly_t mle, const std::vector<H::Fr>& points, size_t n_pts, size_t n, std::vector<H::Fr>& out) {
+    const uint32_t m = (uint32_t)(n / 2), n2 = (uint32_t)(n - m);
+    if (m > 13 || n2 > 13) return fail(ATLAS_EINVAL, "eval_reduction: more than 26 variables not supported");
+    std::lock_guard<std::mutex> lk(g.mu);
+    Fr *d_pts = nullptr, *tab1 = nullptr, *tab2 = nullptr, *part = nullptr, *d_out = nullptr;
+    const size_t rows = (size_t)1 << m;
+    const unsigned grid = (unsigned)(rows < 1024 ? rows : 1024);
+    auto cleanup = [&]() { for (Fr* p : {d_pts, tab1, tab2, part, d_out}) if (p) hipFree(p); };
+    hipError_t e = hipMalloc(&d_pts, (n_pts * n + 1) * sizeof(Fr));
+    if (e == hipSuccess) e = hipMalloc(&tab1, (n_pts << m) * sizeof(Fr));
+    if (e == hipSuccess) e = hipMalloc(&tab2, (n_pts << n2) * sizeof(Fr));
+    if (e == hipSuccess) e = hipMalloc(&part, (size_t)grid * ER_GROUP * sizeof(Fr));
+    if (e == hipSuccess) e = hipMalloc(&d_out, (n_pts + ER_GROUP) * sizeof(Fr));
+    if (e == hipSuccess && n) e = hipMemcpyAsync(d_pts, points.data(), n_pts * n * sizeof(Fr), hipMemcpyHostToDevice, g.stream);
+    if (e != hipSuccess) { cleanup(); return fail(ATLAS_ENOMEM, "eval_reduction workspace", e); }
+    k_er_tables<<<dim3((unsigned)n_pts, 2), 1024, 0, g.stream>>>(d_pts, (uint32_t)n, m, tab1, tab2);
+    const ScConsts K = make_consts();
+    for (size_t t0 = 0; t0 < n_pts; t0 += ER_GROUP) {
+        if (mle->is_i32) k_er_eval<int32_t, ER_GROUP><<<grid, ER_THREADS, 0, g.stream>>>((const int32_t*)mle->d, (uint32_t)n, m, tab1, tab2, (uint32_t)t0, (uint32_t)n_pts, part, K);
+        else k_er_eval<Fr, ER_GROUP><<<grid, ER_THREADS, 0, g.stream>>>((const Fr*)mle->d, (uint32_t)n, m, tab1, tab2, (uint32_t)t0, (uint32_t)n_pts, part, K);
+        k_er_reduce<<<ER_GROUP, ER_THREADS, 0, g.stream>>>(part, grid, ER_GROUP, d_out + t0);
+    }
+    out.resize(n_pts + ER_GROUP);
+    e = hipMemcpyAsync(out.data(), d_out, (n_pts + ER_GROUP) * sizeof(Fr), hipMemcpyDeviceToHost, g.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    cleanup();
+    if (e != hipSuccess) return fail(ATLAS_ENODEV, "eval_reduction", e);
+    out.resize(n_pts);
+    return ATLAS_OK;
+}
 
 // coefficients of the polynomial through (0, e0), ..., (D, eD): Newton forward differences, then
 // expansion of the Newton basis prod_{j<k} (x - j)
@@ -81,12 +194,14 @@ extern "C" int atlas_eval_reduction_prove(atlas_poly_t mle, const atlas_fr_t* po
         for (size_t j = 0; j < N; j++) ev[j] = pts[j * n + i];
         var[i] = interpolate_consecutive(ev);
     }
-    // h on 0..D by multilinear evaluation on the device
-    std::vector<H::Fr> hev(D + 1), lt(n ? n : 1);
+    // h on 0..D by multilinear evaluation on the device: all D + 1 points share the passes over the coefficients
+    std::vector<H::Fr> hev, lpts((D + 1) * n);
     for (size_t t = 0; t <= D; t++) {
         const H::Fr x = H::from_u64(t);
-        for (size_t i = 0; i < n; i++) lt[i] = horner(var[i], x);
-        int rc = atlas_poly_evaluate(mle, (const atlas_fr_t*)lt.data(), n, (atlas_fr_t*)&hev[t]);
+        for (size_t i = 0; i < n; i++) lpts[t * n + i] = horner(var[i], x);
+    }
+    {
+        int rc = evaluate_many(mle, lpts, D + 1, n, hev);
         if (rc) return rc;
     }
     std::vector<H::Fr> h = interpolate_consecutive(hev);
