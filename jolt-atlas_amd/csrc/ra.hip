@@ -114,6 +114,42 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_prod_f9(const Fr* __restrict_
     }
 }
 
+// the same sums with one grid column per thread (blockIdx.y = column): for short instances the chain of D
+// multiplications per column is the latency of the round, so the columns go to different threads
+template <int D>
+__global__ __launch_bounds__(RA_THREADS) void k_ra_prod_f9_col(const Fr* __restrict__ ra, size_t stride, SplitEqView E,
+                                                               size_t n_groups, Fr* __restrict__ partials /* [gridDim.x][D] */) {
+    using P9 = Fr9Params;
+    const size_t gidx = (size_t)blockIdx.x * RA_THREADS + threadIdx.x;
+    const int k = blockIdx.y;
+    F9 prod = f9_zero();
+    if (gidx < n_groups) {
+        const size_t mask = ((size_t)1 << E.in_bits) - 1;
+        prod = f9_mul<P9>(f9_load(E.e_out + (gidx >> E.in_bits)), f9_load(E.e_in + (gidx & mask)));
+#pragma unroll 1
+        for (int i = 0; i < D; i++) {
+            const Fr* row = ra + (size_t)i * stride + 2 * gidx;
+            const F9 a0 = f9_load(row), a1 = f9_load(row + 1);
+            const F9 dl = f9_norm_red<P9, 2>(f9_sub<P9>(a1, a0));
+            F9 val = dl;                                                     // column D-1: X -> inf
+            if (k != D - 1) {
+                val = a0;
+                for (int s2 = 0; s2 < k + 1; s2++) val = f9_norm_red<P9, 2>(f9_add(val, dl));   // p_i(k + 1)
+            }
+            prod = f9_mul<P9>(prod, val);
+        }
+    }
+    __shared__ F9 red9[RA_THREADS / 64];
+    const F9 sres = f9_wave_sum<P9>(prod);
+    if ((threadIdx.x & 63) == 0) red9[threadIdx.x >> 6] = sres;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        F9 t = red9[0];
+        for (int w = 1; w < RA_THREADS / 64; w++) t = f9_norm_red<P9>(f9_add(t, red9[w]));
+        fe_store(partials + (size_t)blockIdx.x * D + k, f9_canon<P9>(t));
+    }
+}
+
 // booleanity phase 2 (booleanity.rs:254-276): per pair index j
 //   c = sum_i gamma_i h0 (h0 - 1),  e = sum_i gamma_i (h1 - h0)^2, folded with E_out * E_in
 __global__ __launch_bounds__(RA_THREADS) void k_bool_fold(const Fr* __restrict__ Hp, size_t stride, uint32_t d,
@@ -124,7 +160,9 @@ __global__ __launch_bounds__(RA_THREADS) void k_bool_fold(const Fr* __restrict__
     const Fr one = fr_one();
     for (size_t j = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; j < n_groups; j += (size_t)gridDim.x * RA_THREADS) {
         Fr c = fe_zero(), e = fe_zero();
-        for (uint32_t i = 0; i < d; i++) {
+        // blockIdx.y splits the d rows (the sums are additive): short instances put one row per thread
+        const uint32_t i0 = (uint32_t)(((uint64_t)d * blockIdx.y) / gridDim.y), i1 = (uint32_t)(((uint64_t)d * (blockIdx.y + 1)) / gridDim.y);
+        for (uint32_t i = i0; i < i1; i++) {
             const Fr* row = Hp + (size_t)i * stride;
             const Fr h0 = fe_load(row + 2 * j), h1 = fe_load(row + 2 * j + 1);
             const Fr b = fr_sub(h1, h0);
@@ -136,7 +174,7 @@ __global__ __launch_bounds__(RA_THREADS) void k_bool_fold(const Fr* __restrict__
         acc[0] = fr_add(acc[0], fr_mul(wgt, c));
         acc[1] = fr_add(acc[1], fr_mul(wgt, e));
     }
-    block_reduce_store<2>(acc, partials);
+    block_reduce_store<2>(acc, partials + (size_t)blockIdx.y * gridDim.x * 2);
 }
 
 // out[k] = sum_p partials[p * K + k]; one workgroup per column
@@ -198,7 +236,7 @@ struct RaRows {
         HIP_TRY(hipMalloc(&buf[1], d * (T > 1 ? T / 2 : 1) * sizeof(Fr)));
         stride[0] = T; stride[1] = T > 1 ? T / 2 : 1;
         const size_t blocks = (T / 2 + RA_THREADS - 1) / RA_THREADS + 1;
-        HIP_TRY(hipMalloc(&partials, blocks * K * sizeof(Fr)));
+        HIP_TRY(hipMalloc(&partials, (blocks * K > 4096 ? blocks * K : 4096) * sizeof(Fr)));   // room for the row-split launches of short instances
         HIP_TRY(hipMalloc(&d_sums, K * sizeof(Fr)));
         return ATLAS_OK;
     }
@@ -256,6 +294,10 @@ struct RaRows {
 
 template <int D>
 void launch_prod(const RaRows& R, const SplitEqView& E, size_t n_groups, unsigned blocks) {
+    if (n_groups <= ((size_t)1 << 13)) {      // latency regime: one column per thread
+        k_ra_prod_f9_col<D><<<dim3(blocks, D), RA_THREADS, 0, g.stream>>>(R.buf[R.cur], R.stride[R.cur], E, n_groups, R.partials);
+        return;
+    }
     constexpr int KA = D < 8 ? D : 8;
     k_ra_prod_f9<D, 0, KA><<<blocks, RA_THREADS, 0, g.stream>>>(R.buf[R.cur], R.stride[R.cur], E, n_groups, R.partials);
     if constexpr (D > 8)
@@ -326,7 +368,8 @@ struct Booleanity : atlas_instance {
     GseDev D;
     RaRows rows;
     Fr* d_gammas = nullptr;
-    H::Fr eq_r_r = H::zero();
+    H::Fr eq_r_r = H::zero(), eq_r_r_inv = H::zero();
+    bool have_eq_r_r_inv = false;
     ~Booleanity() override { rows.release(); D.release(); if (d_gammas) hipFree(d_gammas); }
     size_t rounds() const override { return log_k + log_T; }
     size_t degree() const override { return 3; }
@@ -364,12 +407,14 @@ struct Booleanity : atlas_instance {
         std::lock_guard<std::mutex> lk(g.mu);                        // compute_phase2_message
         const size_t n_groups = rows.len / 2;
         size_t blocks = (n_groups + RA_THREADS - 1) / RA_THREADS; if (blocks > 2048) blocks = 2048;
-        k_bool_fold<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(rows.buf[rows.cur], rows.stride[rows.cur], (uint32_t)d, d_gammas,
-                                                                  D.view(), n_groups, rows.partials);
+        const unsigned ysplit = n_groups <= ((size_t)1 << 13) ? (unsigned)d : 1u;   // latency regime: one row per thread
+        k_bool_fold<<<dim3((unsigned)blocks, ysplit), RA_THREADS, 0, g.stream>>>(rows.buf[rows.cur], rows.stride[rows.cur], (uint32_t)d, d_gammas,
+                                                                             D.view(), n_groups, rows.partials);
         H::Fr s[2];
-        int rc = rows.reduce_to_host((uint32_t)blocks, 2, s);
+        int rc = rows.reduce_to_host((uint32_t)(blocks * ysplit), 2, s);
         if (rc) return rc;
-        const H::Fr adj = H::mul(claim, H::inv(eq_r_r));
+        if (!have_eq_r_r_inv) { eq_r_r_inv = H::inv(eq_r_r); have_eq_r_r_inv = true; }   // constant over phase 2
+        const H::Fr adj = H::mul(claim, eq_r_r_inv);
         H::gruen_deg3(D.st, s[0], s[1], adj, coeffs.data());
         for (auto& c : coeffs) c = H::mul(c, eq_r_r);                // gruen_poly * eq_r_r (from_coeff)
         H::trim(coeffs);
