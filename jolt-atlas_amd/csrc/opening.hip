@@ -150,8 +150,8 @@ struct GseDevH {
     int q0(const T* P, size_t half, H::Fr* out) {
         const unsigned grid = grid_for(half);
         k_open_fold<T><<<grid, OP_THREADS, 0, g.stream>>>(P, half, view(), d_part, make_consts());
-        k_open_reduce<<<1, OP_THREADS, 0, g.stream>>>(d_part, grid, d_sum);
-        HIP_TRY(hipMemcpyAsync(g.h_pinned, d_sum, sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+        if (grid > 1) k_open_reduce<<<1, OP_THREADS, 0, g.stream>>>(d_part, grid, d_sum);
+        HIP_TRY(hipMemcpyAsync(g.h_pinned, grid > 1 ? d_sum : d_part, sizeof(Fr), hipMemcpyDeviceToHost, g.stream));   // one workgroup: its partial is the sum
         HIP_TRY(hipStreamSynchronize(g.stream));
         std::memcpy(out, g.h_pinned, sizeof(Fr));
         return ATLAS_OK;
@@ -181,9 +181,19 @@ struct DenseOpening : atlas_instance {
     }
     int ingest(const atlas_u128_t& r, size_t round) override {
         if (round != round_next || round >= n) return fail(ATLAS_ESTATE, "dense_opening: round out of order");
-        int rc = atlas_poly_bind(P, &r, ATLAS_HIGH_TO_LOW);
-        if (rc) return rc;
-        D.st.bind(H::challenge_to_fr(r.lo, r.hi, g.challenge_mode));
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        if (P->is_i32) {                                            // CompactPolynomial first bind: promotes to Fr (and syncs)
+            int rc = atlas_poly_bind(P, &r, ATLAS_HIGH_TO_LOW);
+            if (rc) return rc;
+        } else {                                                    // in place, stream-ordered, no host wait
+            std::lock_guard<std::mutex> lk(g.mu);
+            const size_t half = P->len / 2;
+            k_open_bind_hi<<<grid_for(half, 4096), OP_THREADS, 0, g.stream>>>((Fr*)P->d, half, to_dev(rf), g.challenge_mode == 0 ? 1 : 0);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return fail(ATLAS_ENODEV, "dense_opening: bind", e);
+            P->len = half;
+        }
+        D.st.bind(rf);
         round_next++;
         return ATLAS_OK;
     }

@@ -274,8 +274,8 @@ struct RaRows {
         return ATLAS_OK;
     }
     int reduce_to_host(uint32_t n_partials, uint32_t k, H::Fr* out) {
-        k_col_reduce<<<k, RA_THREADS, 0, g.stream>>>(partials, n_partials, k, d_sums);
-        HIP_TRY(hipMemcpyAsync(g.h_pinned, d_sums, k * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+        if (n_partials > 1) k_col_reduce<<<k, RA_THREADS, 0, g.stream>>>(partials, n_partials, k, d_sums);
+        HIP_TRY(hipMemcpyAsync(g.h_pinned, n_partials > 1 ? d_sums : partials, k * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
         std::memcpy(out, g.h_pinned, k * sizeof(Fr));
         return ATLAS_OK;
