@@ -89,11 +89,13 @@ __global__ __launch_bounds__(OP_THREADS) void k_open_bind_hi(Fr* z, size_t half,
 
 // G[k] = sum_{j : idx_j = k} E[j]: one workgroup per k (K <= 65536, T * K index reads)
 __global__ __launch_bounds__(OP_THREADS) void k_onehot_G(const int32_t* __restrict__ idx, const Fr* __restrict__ E, size_t T,
-                                                         Fr* __restrict__ G) {
+                                                         Fr* __restrict__ G /* [gridDim.y][K] partial sums per slice of T */) {
     __shared__ Fr red[OP_THREADS / 64];
     const int32_t k = (int32_t)blockIdx.x;
+    const size_t per = (T + gridDim.y - 1) / gridDim.y, j0 = (size_t)blockIdx.y * per, j1 = j0 + per < T ? j0 + per : T;
+    G += (size_t)blockIdx.y * gridDim.x;
     Fr acc = fe_zero();
-    for (size_t j = threadIdx.x; j < T; j += OP_THREADS)
+    for (size_t j = j0 + threadIdx.x; j < j1; j += OP_THREADS)
         if (idx[j] == k) acc = fr_add(acc, fe_load(E + j));
     acc = fr_wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -308,8 +310,10 @@ __global__ __launch_bounds__(OP_THREADS) void k_onehot_G_rows(const int32_t* __r
     const int32_t k = (int32_t)blockIdx.x;
     const size_t row = blockIdx.y;
     const int32_t* ix = idx + row * T;
+    const size_t per = (T + gridDim.z - 1) / gridDim.z, j0 = (size_t)blockIdx.z * per, j1 = j0 + per < T ? j0 + per : T;
+    G += (size_t)blockIdx.z * gridDim.y * K;                  // partial tables per slice of T
     Fr acc = fe_zero();
-    for (size_t j = threadIdx.x; j < T; j += OP_THREADS)
+    for (size_t j = j0 + threadIdx.x; j < j1; j += OP_THREADS)
         if (ix[j] == k) acc = fr_add(acc, fe_load(E + j));
     acc = fr_wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -517,13 +521,22 @@ int atlas_onehot_opening_new(const int32_t* nonzero_indices, size_t log_K, size_
     Fr* d_G = nullptr;
     hipError_t e = hipMalloc(&P->d_idx, T * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc(&P->d_H, T * sizeof(Fr));
-    if (e == hipSuccess) e = hipMalloc(&d_G, K * sizeof(Fr));
+    // slices of T so that about 2048 workgroups are in flight; the per-slice partial tables are summed on the host
+    size_t slices = 2048 / K; if (slices < 1) slices = 1; if (slices > (T + 4095) / 4096) slices = (T + 4095) / 4096;
+    std::vector<H::Fr> hG(slices * K);
+    if (e == hipSuccess) e = hipMalloc(&d_G, slices * K * sizeof(Fr));
     if (e == hipSuccess) e = hipMemcpyAsync(P->d_idx, nonzero_indices, T * sizeof(int32_t), hipMemcpyHostToDevice, g.stream);
     if (e == hipSuccess) {
-        k_onehot_G<<<(unsigned)K, OP_THREADS, 0, g.stream>>>(P->d_idx, (const Fr*)E->d, T, d_G);
-        e = hipMemcpyAsync(P->G.data(), d_G, K * sizeof(Fr), hipMemcpyDeviceToHost, g.stream);
+        k_onehot_G<<<dim3((unsigned)K, (unsigned)slices), OP_THREADS, 0, g.stream>>>(P->d_idx, (const Fr*)E->d, T, d_G);
+        e = hipMemcpyAsync(hG.data(), d_G, slices * K * sizeof(Fr), hipMemcpyDeviceToHost, g.stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    if (e == hipSuccess)
+        for (size_t k = 0; k < K; k++) {
+            H::Fr acc = H::zero();
+            for (size_t sl = 0; sl < slices; sl++) acc = H::add(acc, hG[sl * K + k]);
+            P->G[k] = acc;
+        }
     if (d_G) hipFree(d_G);
     if (e != hipSuccess) { delete P; hipFree(E->d); delete E; return fail(ATLAS_ENODEV, "onehot_opening_new", e); }
     hipFree(E->d); delete E;
@@ -550,15 +563,18 @@ int atlas_onehot_opening_group_new(const int32_t* const* nonzero_indices, size_t
     if (e == hipSuccess) e = hipMalloc(&Gp->d_H, R * T * sizeof(Fr));
     if (e == hipSuccess) e = hipMalloc(&Gp->d_part, R * 512 * sizeof(Fr));
     if (e == hipSuccess) e = hipMalloc(&Gp->d_q0, R * sizeof(Fr));
-    if (e == hipSuccess) e = hipMalloc(&d_G, R * K * sizeof(Fr));
+    size_t slices = 2048 / (K * R); if (slices < 1) slices = 1; if (slices > (T + 4095) / 4096) slices = (T + 4095) / 4096;
+    if (e == hipSuccess) e = hipMalloc(&d_G, slices * R * K * sizeof(Fr));
     for (size_t r = 0; r < R && e == hipSuccess; r++)
         e = hipMemcpyAsync(Gp->d_idx + r * T, nonzero_indices[r], T * sizeof(int32_t), hipMemcpyHostToDevice, g.stream);
-    std::vector<H::Fr> hG(R * K);
+    std::vector<H::Fr> hGs(slices * R * K), hG(R * K, H::zero());
     if (e == hipSuccess) {
-        k_onehot_G_rows<<<dim3((unsigned)K, (unsigned)R), OP_THREADS, 0, g.stream>>>(Gp->d_idx, (const Fr*)E->d, T, (uint32_t)K, d_G);
-        e = hipMemcpyAsync(hG.data(), d_G, R * K * sizeof(Fr), hipMemcpyDeviceToHost, g.stream);
+        k_onehot_G_rows<<<dim3((unsigned)K, (unsigned)R, (unsigned)slices), OP_THREADS, 0, g.stream>>>(Gp->d_idx, (const Fr*)E->d, T, (uint32_t)K, d_G);
+        e = hipMemcpyAsync(hGs.data(), d_G, slices * R * K * sizeof(Fr), hipMemcpyDeviceToHost, g.stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    for (size_t sl = 0; sl < slices && e == hipSuccess; sl++)
+        for (size_t q = 0; q < R * K; q++) hG[q] = H::add(hG[q], hGs[sl * R * K + q]);
     if (d_G) hipFree(d_G);
     hipFree(E->d); delete E;
     if (e != hipSuccess) { delete Gp; return fail(ATLAS_ENODEV, "onehot_opening_group_new", e); }
