@@ -81,6 +81,9 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
              const MsmMulti* multi = nullptr) {
     const size_t K = multi ? multi->K : 1;
     if (n == 0) { H::G1Aff z{H::q_zero(), H::q_zero()}; for (size_t k = 0; k < K; k++) to_out(z, out + k); return ATLAS_OK; }
+    // 32-bit positions: sorted entries, bucket offsets and tile bounds
+    if (n * (size_t)S.n_windows >= ((size_t)1 << 32) || K * (size_t)S.n_windows * S.bpw >= ((size_t)1 << 31))
+        return fail(ATLAS_EINVAL, "msm: more than 2^32 (scalar, window) pairs in one call; split the input");
     const uint32_t V = (uint32_t)K * S.n_windows;          // virtual windows
     const uint32_t TB = V * S.bpw;
     const uint32_t chunk = S.bpw < (uint32_t)MSM_CHUNK ? S.bpw : (uint32_t)MSM_CHUNK;
