@@ -152,6 +152,15 @@ int atlas_fold_i32_rows_batched(const int32_t *d_matrix, size_t n0, size_t n1, s
 int atlas_fold_i32_cols_batched(const int32_t *d_matrix, size_t B, size_t sB, size_t R, size_t sR, size_t C,
                                 size_t tB, size_t tC, atlas_poly_t eq, atlas_poly_t *out);
 
+/* two batch axes (ops/einsum/rbmk_rbnk_bmn.rs:219-289, the acbmk,kcn->cbmn left operand):
+ *   out[z0*tB0 + z1*tB1 + j*tC] = sum_{i<R} M[z0*sB0 + z1*sB1 + i*sR + j] * eq[i],  z0 < B0, z1 < B1, j < C */
+int atlas_fold_i32_cols_batched2(const int32_t *d_matrix, size_t B0, size_t sB0, size_t tB0, size_t B1, size_t sB1,
+                                 size_t tB1, size_t R, size_t sR, size_t C, size_t tC, atlas_poly_t eq,
+                                 atlas_poly_t *out);
+/* out[(r*repeat + q)*row_len + j] = base[r*row_len + j]: broadcast of a folded operand over batch axes it does not
+ * depend on (rbmk_rbnk_bmn.rs:270-289) */
+int atlas_poly_repeat_rows(atlas_poly_t base, size_t rows, size_t row_len, size_t repeat, atlas_poly_t *out);
+
 /* ---- Shout lookup argument: prover-side table builds
  *      (joltworks/src/subprotocols/shout.rs:193-262, 550-598) ---------------------------- */
 /* ReadRafProver::initialize: G[k] = sum_{j : lookup_indices[j] = k} E[j], E = eq_r (device

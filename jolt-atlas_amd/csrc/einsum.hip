@@ -161,18 +161,19 @@ __global__ __launch_bounds__(FOLD_THREADS) void k_fold_rows_batched(const int32_
 // j contiguous in memory so a wavefront reads 256 B per reduce step
 __global__ __launch_bounds__(FOLD_THREADS) void k_fold_cols_batched(const int32_t* __restrict__ M, const Fe* __restrict__ e,
                                                                     size_t sB, size_t R, size_t sR, size_t C, size_t tB, size_t tC,
-                                                                    Fe* __restrict__ out) {
+                                                                    size_t B1, size_t sB1, size_t tB1, Fe* __restrict__ out) {
     using P9 = Fr9Params;
-    const size_t j = (size_t)blockIdx.x * FOLD_THREADS + threadIdx.x, z = blockIdx.y;
+    // blockIdx.y = z0 * B1 + z1: two batch axes with independent input and output strides (B1 = 1: one axis)
+    const size_t j = (size_t)blockIdx.x * FOLD_THREADS + threadIdx.x, z0 = blockIdx.y / B1, z1 = blockIdx.y % B1;
     if (j >= C) return;
-    const int32_t* base = M + z * sB + j;
+    const int32_t* base = M + z0 * sB + z1 * sB1 + j;
     Cols s; cols_zero(s);
     int since = 0;
     for (size_t i = 0; i < R; i++) {
         cols_mad(s, base[i * sR], f9_load(e + i));
         if (++since == FOLD_NORM_EVERY) { cols_norm(s); since = 0; }
     }
-    fe_store(out + z * tB + j * tC, fold_finish(f9_norm_red<P9>(cols_redc(s))));
+    fe_store(out + z0 * tB + z1 * tB1 + j * tC, fold_finish(f9_norm_red<P9>(cols_redc(s))));
 }
 
 // out[j] = sum_i M[i*cols + j] * e[i] : one thread per column j, rows split over blockIdx.y
@@ -279,7 +280,47 @@ int atlas_fold_i32_cols_batched(const int32_t* d_matrix, size_t B, size_t sB, si
     int rc = make_poly(B * C, out);
     if (rc) return rc;
     k_fold_cols_batched<<<dim3((unsigned)((C + FOLD_THREADS - 1) / FOLD_THREADS), (unsigned)B), FOLD_THREADS, 0, g.stream>>>(
-        d_matrix, (const Fe*)eq->d, sB, R, sR, C, tB, tC, (Fe*)(*out)->d);
+        d_matrix, (const Fe*)eq->d, sB, R, sR, C, tB, tC, 1, 0, 0, (Fe*)(*out)->d);
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return ATLAS_OK;
+}
+
+int atlas_fold_i32_cols_batched2(const int32_t* d_matrix, size_t B0, size_t sB0, size_t tB0, size_t B1, size_t sB1, size_t tB1, size_t R,
+                                 size_t sR, size_t C, size_t tC, atlas_poly_t eq, atlas_poly_t* out) {
+    NEED_INIT();
+    if (!d_matrix || !eq || !out || B0 == 0 || B1 == 0 || C == 0 || R == 0 || !is_pow2(B0 * B1 * C)) return fail(ATLAS_EINVAL, "fold_i32_cols_batched2: B0*B1*C must be a power of two");
+    if (eq->is_i32 || eq->len != R) return fail(ATLAS_EINVAL, "fold_i32_cols_batched2: eq table length != R");
+    if ((B0 - 1) * tB0 + (B1 - 1) * tB1 + (C - 1) * tC >= B0 * B1 * C) return fail(ATLAS_EINVAL, "fold_i32_cols_batched2: output strides leave the output range");
+    std::lock_guard<std::mutex> lk(g.mu);
+    int rc = make_poly(B0 * B1 * C, out);
+    if (rc) return rc;
+    k_fold_cols_batched<<<dim3((unsigned)((C + FOLD_THREADS - 1) / FOLD_THREADS), (unsigned)(B0 * B1)), FOLD_THREADS, 0, g.stream>>>(
+        d_matrix, (const Fe*)eq->d, sB0, R, sR, C, tB0, tC, B1, sB1, tB1, (Fe*)(*out)->d);
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return ATLAS_OK;
+}
+
+// out[(r * repeat + q) * row_len + j] = base[r * row_len + j]: the broadcast of a folded operand over the batch axes it
+// does not depend on (build_acbmk_kcn_cbmn's `right`, ops/einsum/rbmk_rbnk_bmn.rs:270-289)
+__global__ __launch_bounds__(FOLD_THREADS) void k_repeat_rows(const Fe* __restrict__ base, size_t rows, size_t row_len, size_t repeat,
+                                                              Fe* __restrict__ out) {
+    const size_t total = rows * repeat * row_len;
+    for (size_t i = (size_t)blockIdx.x * FOLD_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * FOLD_THREADS) {
+        const size_t j = i % row_len, r = i / (row_len * repeat);
+        fe_store(out + i, fe_load(base + r * row_len + j));
+    }
+}
+
+int atlas_poly_repeat_rows(atlas_poly_t base, size_t rows, size_t row_len, size_t repeat, atlas_poly_t* out) {
+    NEED_INIT();
+    if (!base || !out || base->is_i32 || base->len != rows * row_len || repeat == 0 || !is_pow2(rows * row_len * repeat))
+        return fail(ATLAS_EINVAL, "poly_repeat_rows: base must hold rows*row_len Fr and the output length be a power of two");
+    std::lock_guard<std::mutex> lk(g.mu);
+    int rc = make_poly(rows * row_len * repeat, out);
+    if (rc) return rc;
+    const size_t total = rows * row_len * repeat;
+    size_t gb = (total + FOLD_THREADS - 1) / FOLD_THREADS; if (gb > 4096) gb = 4096;
+    k_repeat_rows<<<(unsigned)gb, FOLD_THREADS, 0, g.stream>>>((const Fe*)base->d, rows, row_len, repeat, (Fe*)(*out)->d);
     HIP_TRY(hipStreamSynchronize(g.stream));
     return ATLAS_OK;
 }

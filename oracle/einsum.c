@@ -78,3 +78,52 @@ void orc_einsum_fold_layout(int layout, const int32_t *left, const int32_t *righ
     }
     free(lo); free(ro);
 }
+
+/* rbmk,rbnk->bmn family, loops as written in ops/einsum/rbmk_rbnk_bmn.rs: variant 0 = abmk,abnk->abmn
+ * (build_abmk_abnk_abmn :163-217), 1 = acbmk,kcn->cbmn (build_acbmk_kcn_cbmn :219-290),
+ * 2 = cbmk,cbkn->amn (build_cbmk_cbkn_amn :292-338).  Dimensions a, c, b, m, n, k as in the reference
+ * (unused ones = 1).  left_out / right_out sized by the caller (batch * k, or c*b*a*k for variant 1). */
+void orc_einsum_fold_rbmk(int variant, const int32_t *left, const int32_t *right, size_t a, size_t c, size_t b, size_t m,
+                          size_t n, size_t k, const fr_t *eq_r_m, const fr_t *eq_r_n, fr_t *left_out, fr_t *right_out) {
+    fr_t x, t;
+    if (variant == 0) {
+        const size_t batch = a * b;
+        for (size_t hj = 0; hj < batch * k; hj++) {
+            const size_t h = hj / k, j = hj % k;
+            fr_t s; fr_zero(&s);
+            for (size_t i = 0; i < m; i++) { fr_from_i64(left[(h * m + i) * k + j], &x); fr_mul(&x, &eq_r_m[i], &t); fr_add(&s, &t, &s); }
+            left_out[hj] = s; fr_zero(&s);
+            for (size_t l = 0; l < n; l++) { fr_from_i64(right[(h * n + l) * k + j], &x); fr_mul(&x, &eq_r_n[l], &t); fr_add(&s, &t, &s); }
+            right_out[hj] = s;
+        }
+    } else if (variant == 1) {
+        const size_t cb = c * b;
+        fr_t *base = (fr_t *)malloc(c * k * sizeof(fr_t));
+        for (size_t ck = 0; ck < c * k; ck++) {
+            const size_t c_idx = ck / k, k_idx = ck % k;
+            fr_t s; fr_zero(&s);
+            for (size_t ni = 0; ni < n; ni++) { fr_from_i64(right[(k_idx * c + c_idx) * n + ni], &x); fr_mul(&x, &eq_r_n[ni], &t); fr_add(&s, &t, &s); }
+            base[ck] = s;
+        }
+        for (size_t hak = 0; hak < cb * a * k; hak++) {
+            const size_t h = hak / (a * k), rem = hak % (a * k), a_idx = rem / k, k_idx = rem % k, c_idx = h / b, b_idx = h % b;
+            fr_t s; fr_zero(&s);
+            for (size_t i = 0; i < m; i++) {
+                fr_from_i64(left[((((a_idx * c + c_idx) * b + b_idx) * m + i) * k) + k_idx], &x); fr_mul(&x, &eq_r_m[i], &t); fr_add(&s, &t, &s);
+            }
+            left_out[hak] = s;
+            right_out[hak] = base[c_idx * k + k_idx];
+        }
+        free(base);
+    } else {
+        const size_t cb = c * b;
+        for (size_t hk = 0; hk < cb * k; hk++) {
+            const size_t h = hk / k, k_idx = hk % k;
+            fr_t s; fr_zero(&s);
+            for (size_t i = 0; i < m; i++) { fr_from_i64(left[(h * m + i) * k + k_idx], &x); fr_mul(&x, &eq_r_m[i], &t); fr_add(&s, &t, &s); }
+            left_out[hk] = s; fr_zero(&s);
+            for (size_t l = 0; l < n; l++) { fr_from_i64(right[(h * k + k_idx) * n + l], &x); fr_mul(&x, &eq_r_n[l], &t); fr_add(&s, &t, &s); }
+            right_out[hk] = s;
+        }
+    }
+}

@@ -118,6 +118,8 @@ int orc_eval_reduction_prove(const fr_t *mle, size_t n, const fr_t *points, cons
 /* EinsumLayout::fold of the batched layouts (ops/einsum/bmk_rhs_mbn.rs, mbk_rhs_bmn.rs, k_nk_n.rs) */
 void orc_einsum_fold_layout(int layout, const int32_t *left, const int32_t *right, size_t b, size_t m, size_t k, size_t n,
                             const fr_t *eq_r_m, const fr_t *eq_r_n, fr_t *left_out, fr_t *right_out);
+void orc_einsum_fold_rbmk(int variant, const int32_t *left, const int32_t *right, size_t a, size_t c, size_t b, size_t m,
+                          size_t n, size_t k, const fr_t *eq_r_m, const fr_t *eq_r_n, fr_t *left_out, fr_t *right_out);
 /* build_materialized_rlc (poly/rlc_polynomial.rs:13-78) */
 void orc_rlc_build(const fr_t *const *dense_fr, const int32_t *const *dense_i32, const size_t *dense_len,
                    const fr_t *dense_coeff, size_t n_dense, const int32_t *const *oh_k, const size_t *oh_T,
