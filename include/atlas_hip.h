@@ -255,6 +255,14 @@ int atlas_batched_add_instance(atlas_batched_t b, atlas_instance_t i, const atla
 int atlas_ra_virtual_new(const int32_t *const *H_indices, size_t d, size_t log_k_chunk, size_t log_T,
                          const atlas_fr_t *r_address_chunks, const atlas_fr_t *r_cycle,
                          atlas_instance_t *out);
+/* The same provers straight from the T lookup indices: the d = ceil(log_K / log_k_chunk) chunk rows
+ * (compute_instruction_h_indices, shout.rs:532-547; OneHotParams::lookup_index_chunk, config.rs:73-75) are cut
+ * on the device and r_address (log_K Fr) is split by compute_r_address_chunks (config.rs:77-100). */
+int atlas_ra_virtual_from_lookups_new(const uint64_t *lookup_indices, size_t log_T, size_t log_K, size_t log_k_chunk,
+                                      const atlas_fr_t *r_address, const atlas_fr_t *r_cycle, atlas_instance_t *out);
+int atlas_booleanity_from_lookups_new(const atlas_fr_t *G, const uint64_t *lookup_indices, size_t log_T, size_t log_K,
+                                      size_t log_k_chunk, const atlas_fr_t *gammas, const atlas_fr_t *r_address,
+                                      const atlas_fr_t *r_cycle, atlas_instance_t *out);
 /* BooleanitySumcheckProver::gen (subprotocols/booleanity.rs:169-190): log_k_chunk address rounds
  * over G (d * 2^log_k_chunk Fr, from atlas_shout_ra_evals) then log_T cycle rounds over the
  * gathered H_i; degree 3; input claim 0.  gammas = field values of the d batching challenges. */

@@ -51,6 +51,20 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_gather(const int32_t* __restr
     }
 }
 
+// compute_instruction_h_indices (shout.rs:532-547) / OneHotParams::lookup_index_chunk (config.rs:73-75):
+// chunk i of a lookup index = (index >> (log_k_chunk * (d - 1 - i))) & (k_chunk - 1), i = 0 most significant
+__global__ __launch_bounds__(RA_THREADS) void k_ra_chunk_indices(const uint64_t* __restrict__ lookups, size_t T, uint32_t d,
+                                                                 uint32_t log_k_chunk, int32_t* __restrict__ out /* [d][T] */) {
+    const uint64_t mask = ((uint64_t)1 << log_k_chunk) - 1;
+    for (size_t j = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; j < T; j += (size_t)gridDim.x * RA_THREADS) {
+        const uint64_t v = lookups[j];
+        for (uint32_t i = 0; i < d; i++) {
+            const uint32_t shift = log_k_chunk * (d - 1 - i);
+            out[(size_t)i * T + j] = (int32_t)(shift >= 64 ? 0 : ((v >> shift) & mask));
+        }
+    }
+}
+
 // bind every row LowToHigh: dst[i][j] = src[i][2j] + r (src[i][2j+1] - src[i][2j])
 __global__ __launch_bounds__(RA_THREADS) void k_ra_bind(const Fr* __restrict__ src, size_t src_stride, Fr* __restrict__ dst,
                                                         size_t dst_stride, size_t half, Fr r, int r_hi_only) {
@@ -247,6 +261,22 @@ struct RaRows {
         for (size_t i = 0; i < d; i++)
             HIP_TRY(hipMemcpyAsync(d_idx + i * len, H_indices[i], len * sizeof(int32_t), hipMemcpyHostToDevice, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
+        return ATLAS_OK;
+    }
+    // the same from the T lookup indices themselves: the d chunk rows are cut on the device (8 T bytes over PCIe
+    // instead of 4 d T)
+    int upload_lookups(const uint64_t* lookups, uint32_t log_k_chunk) {
+        uint64_t* d_l = nullptr;
+        HIP_TRY(hipMalloc(&d_idx, d * len * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&d_l, len * sizeof(uint64_t)));
+        hipError_t e = hipMemcpyAsync(d_l, lookups, len * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream);
+        if (e == hipSuccess) {
+            size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
+            k_ra_chunk_indices<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(d_l, len, (uint32_t)d, log_k_chunk, d_idx);
+            e = hipStreamSynchronize(g.stream);
+        }
+        hipFree(d_l);
+        if (e != hipSuccess) return fail(ATLAS_ENODEV, "ra lookups upload", e);
         return ATLAS_OK;
     }
     // ra_i[j] = table_i[idx_i[j]] from device tables (d rows of f_stride Fr; f_stride 0 = shared table)
@@ -793,10 +823,32 @@ struct PsRelu : atlas_instance {
 
 extern "C" {
 
+static int ra_virtual_build(const int32_t* const* H_indices, const uint64_t* lookups, size_t d, size_t log_k_chunk, size_t log_T,
+                            const atlas_fr_t* r_address_chunks, const atlas_fr_t* r_cycle, atlas_instance_t* out);
+
 int atlas_ra_virtual_new(const int32_t* const* H_indices, size_t d, size_t log_k_chunk, size_t log_T,
                          const atlas_fr_t* r_address_chunks, const atlas_fr_t* r_cycle, atlas_instance_t* out) {
     NEED_INIT();
-    if (!H_indices || !r_address_chunks || (!r_cycle && log_T) || !out) return fail(ATLAS_EINVAL, "ra_virtual_new: null argument");
+    if (!H_indices) return fail(ATLAS_EINVAL, "ra_virtual_new: null argument");
+    return ra_virtual_build(H_indices, nullptr, d, log_k_chunk, log_T, r_address_chunks, r_cycle, out);
+}
+
+// RaSumcheckProver::gen from the lookup indices and r_address: OneHotParams::{lookup_index_chunk, compute_r_address_chunks}
+// (config.rs:73-100) done here — d = ceil(log_K / log_k_chunk), r_address left-padded with zeros to a multiple of the chunk
+int atlas_ra_virtual_from_lookups_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, size_t log_k_chunk,
+                                      const atlas_fr_t* r_address, const atlas_fr_t* r_cycle, atlas_instance_t* out) {
+    NEED_INIT();
+    if (!lookup_indices || !r_address || log_k_chunk == 0 || log_K == 0) return fail(ATLAS_EINVAL, "ra_virtual_from_lookups_new: null argument");
+    const size_t d = (log_K + log_k_chunk - 1) / log_k_chunk, pad = d * log_k_chunk - log_K;
+    std::vector<atlas_fr_t> chunks(d * log_k_chunk);
+    std::memset(chunks.data(), 0, pad * sizeof(atlas_fr_t));
+    std::memcpy(chunks.data() + pad, r_address, log_K * sizeof(atlas_fr_t));
+    return ra_virtual_build(nullptr, lookup_indices, d, log_k_chunk, log_T, chunks.data(), r_cycle, out);
+}
+
+static int ra_virtual_build(const int32_t* const* H_indices, const uint64_t* lookups, size_t d, size_t log_k_chunk, size_t log_T,
+                            const atlas_fr_t* r_address_chunks, const atlas_fr_t* r_cycle, atlas_instance_t* out) {
+    if (!r_address_chunks || (!r_cycle && log_T) || !out) return fail(ATLAS_EINVAL, "ra_virtual_new: null argument");
     if (d == 0 || d > RA_MAX_D) return fail(ATLAS_EINVAL, "ra_virtual_new: d must be in 1..16");
     if (log_k_chunk > 16 || log_T == 0 || log_T > 25) return fail(ATLAS_EINVAL, "ra_virtual_new: log_k_chunk <= 16, 1 <= log_T <= 25");
     std::lock_guard<std::mutex> lk(g.mu);
@@ -809,7 +861,7 @@ int atlas_ra_virtual_new(const int32_t* const* H_indices, size_t d, size_t log_k
     Fr* d_tabs = nullptr;
     int rc = upload_tables(tabs, K, &d_tabs);
     if (!rc) rc = P->rows.alloc(d, T);
-    if (!rc) rc = P->rows.upload_indices(H_indices);
+    if (!rc) rc = H_indices ? P->rows.upload_indices(H_indices) : P->rows.upload_lookups(lookups, (uint32_t)log_k_chunk);
     if (!rc) rc = P->rows.gather(d_tabs, (uint32_t)K);
     if (d_tabs) hipFree(d_tabs);
     if (!rc) rc = P->eq.init(reinterpret_cast<const H::Fr*>(r_cycle), log_T);
@@ -818,10 +870,29 @@ int atlas_ra_virtual_new(const int32_t* const* H_indices, size_t d, size_t log_k
     return ATLAS_OK;
 }
 
+static int booleanity_build(const atlas_fr_t* G, const int32_t* const* H_indices, const uint64_t* lookups, size_t d, size_t log_k_chunk,
+                            size_t log_T, const atlas_fr_t* gammas, const atlas_fr_t* r_address, const atlas_fr_t* r_cycle,
+                            atlas_instance_t* out);
+
 int atlas_booleanity_new(const atlas_fr_t* G, const int32_t* const* H_indices, size_t d, size_t log_k_chunk, size_t log_T,
                          const atlas_fr_t* gammas, const atlas_fr_t* r_address, const atlas_fr_t* r_cycle, atlas_instance_t* out) {
     NEED_INIT();
-    if (!G || !H_indices || !gammas || !r_address || (!r_cycle && log_T) || !out) return fail(ATLAS_EINVAL, "booleanity_new: null argument");
+    if (!H_indices) return fail(ATLAS_EINVAL, "booleanity_new: null argument");
+    return booleanity_build(G, H_indices, nullptr, d, log_k_chunk, log_T, gammas, r_address, r_cycle, out);
+}
+
+int atlas_booleanity_from_lookups_new(const atlas_fr_t* G, const uint64_t* lookup_indices, size_t log_T, size_t log_K, size_t log_k_chunk,
+                                      const atlas_fr_t* gammas, const atlas_fr_t* r_address, const atlas_fr_t* r_cycle,
+                                      atlas_instance_t* out) {
+    NEED_INIT();
+    if (!lookup_indices || log_k_chunk == 0 || log_K == 0) return fail(ATLAS_EINVAL, "booleanity_from_lookups_new: null argument");
+    return booleanity_build(G, nullptr, lookup_indices, (log_K + log_k_chunk - 1) / log_k_chunk, log_k_chunk, log_T, gammas, r_address, r_cycle, out);
+}
+
+static int booleanity_build(const atlas_fr_t* G, const int32_t* const* H_indices, const uint64_t* lookups, size_t d, size_t log_k_chunk,
+                            size_t log_T, const atlas_fr_t* gammas, const atlas_fr_t* r_address, const atlas_fr_t* r_cycle,
+                            atlas_instance_t* out) {
+    if (!G || !gammas || !r_address || (!r_cycle && log_T) || !out) return fail(ATLAS_EINVAL, "booleanity_new: null argument");
     if (d == 0 || log_k_chunk == 0 || log_k_chunk > 16 || log_T == 0 || log_T > 25)
         return fail(ATLAS_EINVAL, "booleanity_new: 1 <= log_k_chunk <= 16, 1 <= log_T <= 25");
     std::lock_guard<std::mutex> lk(g.mu);
@@ -839,7 +910,7 @@ int atlas_booleanity_new(const atlas_fr_t* G, const int32_t* const* H_indices, s
     P->B_in = H::eq_cached(ra + P->B.m, P->B.k_in);
     int rc = P->D.init(reinterpret_cast<const H::Fr*>(r_cycle), log_T);
     if (!rc) rc = P->rows.alloc(d, T);
-    if (!rc) rc = P->rows.upload_indices(H_indices);       // resident until the phase-2 gather
+    if (!rc) rc = H_indices ? P->rows.upload_indices(H_indices) : P->rows.upload_lookups(lookups, (uint32_t)log_k_chunk);   // resident until the phase-2 gather
     if (!rc) {
         hipError_t e = hipMalloc(&P->d_gammas, d * sizeof(Fr));
         if (e == hipSuccess) e = hipMemcpyAsync(P->d_gammas, gammas, d * sizeof(Fr), hipMemcpyHostToDevice, g.stream);

@@ -155,3 +155,23 @@ def ps_shout_ult(lookup_indices, r_node_output, gamma):
     h = C.c_void_p()
     _check(lib.atlas_ps_shout_ult_new(idx.ctypes.data_as(C.c_void_p), C.c_size_t(len(rn)), _p(rn), _p(g), C.byref(h)))
     return Instance(h)
+
+
+def ra_virtual_from_lookups(lookup_indices, log_K, log_k_chunk, r_address, r_cycle):
+    """RaSumcheckProver::gen from the lookup indices (chunks cut on the device, config.rs:73-100)."""
+    idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)
+    ra = np.ascontiguousarray(r_address, dtype=np.uint64); rc = np.ascontiguousarray(r_cycle, dtype=np.uint64)
+    h = C.c_void_p()
+    _check(lib.atlas_ra_virtual_from_lookups_new(idx.ctypes.data_as(C.c_void_p), C.c_size_t(len(rc)), C.c_size_t(log_K),
+                                                 C.c_size_t(log_k_chunk), _p(ra), _p(rc), C.byref(h)))
+    return Instance(h)
+
+
+def booleanity_from_lookups(G, lookup_indices, log_K, log_k_chunk, gammas, r_address, r_cycle):
+    idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)
+    G = np.ascontiguousarray(G, dtype=np.uint64); ga = np.ascontiguousarray(gammas, dtype=np.uint64)
+    ra = np.ascontiguousarray(r_address, dtype=np.uint64); rc = np.ascontiguousarray(r_cycle, dtype=np.uint64)
+    h = C.c_void_p()
+    _check(lib.atlas_booleanity_from_lookups_new(_p(G), idx.ctypes.data_as(C.c_void_p), C.c_size_t(len(rc)), C.c_size_t(log_K),
+                                                 C.c_size_t(log_k_chunk), _p(ga), _p(ra), _p(rc), C.byref(h)))
+    return Instance(h)

@@ -182,3 +182,40 @@ def test_batched_lookup_group_bit_exact(atlas, d, log_k, log_T):
     assert t_g.state == t_o.state_bytes()
     for x in gi:
         x.free()
+
+
+@pytest.mark.parametrize("log_K,log_k,log_T", [(32, 4, 8), (30, 4, 6), (16, 8, 7), (64, 4, 5)])
+def test_instances_from_lookup_indices(atlas, log_K, log_k, log_T):
+    """Chunk rows cut on the device (OneHotParams::lookup_index_chunk / compute_r_address_chunks, config.rs:73-100)
+    give the proofs of the explicit-H constructors, checked against the oracle."""
+    from oracle import orc, orc_ra as OR
+    from jolt_atlas_amd import instances as I
+    A = atlas
+    T = 1 << log_T
+    d = -(-log_K // log_k)
+    rng = np.random.default_rng(log_K + log_T)
+    lk = rng.integers(0, (1 << log_K) - 1 if log_K < 64 else (1 << 63), size=T, dtype=np.uint64, endpoint=True)
+    H = [((lk >> np.uint64(log_k * (d - 1 - i))) & np.uint64((1 << log_k) - 1)).astype(np.int32) for i in range(d)]
+    r_address, r_cycle = orc.random_fr(log_K, 1), orc.random_fr(log_T, 2)
+    pad = d * log_k - log_K
+    chunks = np.concatenate([np.zeros((pad, 4), dtype=np.uint64), r_address]).reshape(d, log_k, 4)
+    claim = _ra_claim(orc, H, chunks, r_cycle, log_k)
+    t_o = orc.new_transcript(b"ra_lk")
+    rows_o, ch_o = OR.ra_virtual(H, log_k, chunks, r_cycle).prove(claim, t_o)
+    inst = I.ra_virtual_from_lookups(lk, log_K, log_k, r_address, r_cycle)
+    assert inst.degree() == d + 1
+    t_g = A.Blake2bTranscript(b"ra_lk")
+    rows_g, ch_g = inst.prove(claim, t_g)
+    assert ch_g == ch_o and _rows_equal(rows_g, rows_o) and t_g.state == t_o.state_bytes()
+    inst.free()
+    # booleanity over the same chunk rows
+    gammas, r_a4 = orc.random_fr(d, 3), orc.random_fr(log_k, 4)
+    G = OR.ra_G(H, log_k, r_cycle)
+    zero = orc.fr_array(1)[0]
+    t_o = orc.new_transcript(b"bool_lk")
+    rows_o, ch_o = OR.booleanity(G, H, log_k, gammas, r_a4, r_cycle).prove(zero, t_o)
+    inst = I.booleanity_from_lookups(G, lk, log_K, log_k, gammas, r_a4, r_cycle)
+    t_g = A.Blake2bTranscript(b"bool_lk")
+    rows_g, ch_g = inst.prove(zero, t_g)
+    assert ch_g == ch_o and _rows_equal(rows_g, rows_o) and t_g.state == t_o.state_bytes()
+    inst.free()
