@@ -1,0 +1,205 @@
+// Shared device plumbing of the one-hot "ra" instances (ra.hip) and the prefix-suffix Shout read-raf
+// instances (psshout.hip): the LowToHigh split-eq device tables, the d-row ping-pong buffers of an
+// instance (gather from one-hot indices, bind, final claims) and the column reduction of per-block
+// partials.  Everything here has internal linkage; include it from one .hip translation unit at a time.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "../../include/atlas_hip.h"
+#include "host_poly.hpp"
+#include "instance.hpp"
+#include "runtime.hpp"
+#include "sc_consts.hpp"
+#include "spliteq_kernels.hip.h"
+#include "f9.hip.h"
+
+using namespace atlas;
+namespace H = atlas_host;
+using atlas_rt::fail;
+using atlas_rt::g;
+
+namespace {
+
+constexpr int RA_THREADS = 256;
+constexpr size_t RA_MAX_D = 16;
+
+inline Fr to_dev(const H::Fr& a) { Fr o; std::memcpy(&o, &a, 32); return o; }
+
+// ra_i[j] = idx_i[j] < 0 ? 0 : F_i[idx_i[j]]       (RaPolynomialRound1::get_bound_coeff)
+__global__ __launch_bounds__(RA_THREADS) void k_ra_gather(const int32_t* __restrict__ idx, const Fr* __restrict__ F,
+                                                          uint32_t f_stride, size_t T, Fr* __restrict__ out) {
+    const uint32_t i = blockIdx.y;
+    for (size_t j = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; j < T; j += (size_t)gridDim.x * RA_THREADS) {
+        const int32_t k = idx[(size_t)i * T + j];
+        fe_store(out + (size_t)i * T + j, k < 0 ? fe_zero() : fe_load(F + (size_t)i * f_stride + k));
+    }
+}
+
+// compute_instruction_h_indices (shout.rs:532-547) / OneHotParams::lookup_index_chunk (config.rs:73-75):
+// chunk i of a lookup index = (index >> (log_k_chunk * (d - 1 - i))) & (k_chunk - 1), i = 0 most significant
+__global__ __launch_bounds__(RA_THREADS) void k_ra_chunk_indices(const uint64_t* __restrict__ lookups, size_t T, uint32_t d,
+                                                                 uint32_t log_k_chunk, int32_t* __restrict__ out /* [d][T] */) {
+    const uint64_t mask = ((uint64_t)1 << log_k_chunk) - 1;
+    for (size_t j = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; j < T; j += (size_t)gridDim.x * RA_THREADS) {
+        const uint64_t v = lookups[j];
+        for (uint32_t i = 0; i < d; i++) {
+            const uint32_t shift = log_k_chunk * (d - 1 - i);
+            out[(size_t)i * T + j] = (int32_t)(shift >= 64 ? 0 : ((v >> shift) & mask));
+        }
+    }
+}
+
+// bind every row LowToHigh: dst[i][j] = src[i][2j] + r (src[i][2j+1] - src[i][2j])
+__global__ __launch_bounds__(RA_THREADS) void k_ra_bind(const Fr* __restrict__ src, size_t src_stride, Fr* __restrict__ dst,
+                                                        size_t dst_stride, size_t half, Fr r, int r_hi_only) {
+    const Fr* s = src + (size_t)blockIdx.y * src_stride;
+    Fr* d = dst + (size_t)blockIdx.y * dst_stride;
+    for (size_t j = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; j < half; j += (size_t)gridDim.x * RA_THREADS)
+        fe_store(d + j, bind_pair(fe_load(s + 2 * j), fe_load(s + 2 * j + 1), r, r_hi_only != 0));
+}
+
+__device__ __forceinline__ Fr gse_weight(const SplitEqView& E, size_t gidx) {
+    return fr_mul(fe_load(E.e_out + (gidx >> E.in_bits)), fe_load(E.e_in + (gidx & (((size_t)1 << E.in_bits) - 1))));
+}
+
+// compute_mles_product_sum_evals_generic: per pair index g the product of the D lines
+// p_i(X) = ra_i[2g] + X (ra_i[2g+1] - ra_i[2g]) on the grid [1, ..., D-1, inf], weighted by
+// E_out * E_in.  One g per thread; the KN running products of grid columns [K0, K0 + KN) live in
+// registers as 9 x 29-bit lazy limbs (f9.hip.h), so a launch covers at most 8 columns and D > 8
+// takes two launches (the rows are re-read through L2).  Every f9_mul carries 2^-5 relative to
+// the Montgomery radix: a stored sum is 32^-(D+1) times the true one, undone on the host.
+__global__ __launch_bounds__(RA_THREADS) void k_col_reduce(const Fr* __restrict__ partials, uint32_t n_partials, uint32_t K,
+                                                           Fr* __restrict__ out) {
+    __shared__ Fr red[RA_THREADS / 64];
+    const uint32_t k = blockIdx.x;
+    Fr acc = fe_zero();
+    for (uint32_t p = threadIdx.x; p < n_partials; p += RA_THREADS) acc = fr_add(acc, fe_load(partials + (size_t)p * K + k));
+    acc = fr_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Fr s = red[0];
+        for (int w = 1; w < RA_THREADS / 64; w++) s = fr_add(s, red[w]);
+        fe_store(out + k, s);
+    }
+}
+
+// device half of a LowToHigh GruenSplitEqPolynomial: the cached prefix tables
+struct GseDev {
+    H::GseState st;
+    Fr *d_w = nullptr, *d_eout = nullptr, *d_ein = nullptr;
+    int init(const H::Fr* w, size_t n) {
+        st.init(w, n);
+        if (st.k_out > 12 || st.k_in > 12) return fail(ATLAS_EINVAL, "split-eq: more than 25 variables not supported");
+        HIP_TRY(hipMalloc(&d_w, (n ? n : 1) * sizeof(Fr)));
+        HIP_TRY(hipMalloc(&d_eout, ((size_t)2 << st.k_out) * sizeof(Fr)));
+        HIP_TRY(hipMalloc(&d_ein, ((size_t)2 << st.k_in) * sizeof(Fr)));
+        if (n) HIP_TRY(hipMemcpyAsync(d_w, w, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+        k_eq_cached<<<1, 1024, 0, g.stream>>>(d_eout, d_w, (uint32_t)st.k_out);
+        k_eq_cached<<<1, 1024, 0, g.stream>>>(d_ein, d_w + st.m, (uint32_t)st.k_in);
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        return ATLAS_OK;
+    }
+    SplitEqView view() const {
+        SplitEqView E;
+        E.e_out = d_eout + (((size_t)1 << st.out_top) - 1);
+        E.e_in = d_ein + (((size_t)1 << st.in_top) - 1);
+        E.in_bits = (uint32_t)st.in_top;
+        return E;
+    }
+    void release() { if (d_w) hipFree(d_w); if (d_eout) hipFree(d_eout); if (d_ein) hipFree(d_ein); d_w = d_eout = d_ein = nullptr; }
+};
+
+// d rows of one instance, ping-pong bound
+struct RaRows {
+    size_t d = 0, len = 0;
+    Fr* buf[2] = {nullptr, nullptr};
+    size_t stride[2] = {0, 0};
+    int cur = 0;
+    Fr* partials = nullptr;     // ceil(T/2 / RA_THREADS) * max(d, 2) Fr
+    Fr* d_sums = nullptr;       // max(d, 2) Fr
+    size_t K = 0;
+
+    int alloc(size_t d_, size_t T) {
+        d = d_; len = T; K = d > 2 ? d : 2;
+        HIP_TRY(hipMalloc(&buf[0], d * T * sizeof(Fr)));
+        HIP_TRY(hipMalloc(&buf[1], d * (T > 1 ? T / 2 : 1) * sizeof(Fr)));
+        stride[0] = T; stride[1] = T > 1 ? T / 2 : 1;
+        const size_t blocks = (T / 2 + RA_THREADS - 1) / RA_THREADS + 1;
+        HIP_TRY(hipMalloc(&partials, (blocks * K > 4096 ? blocks * K : 4096) * sizeof(Fr)));   // room for the row-split launches of short instances
+        HIP_TRY(hipMalloc(&d_sums, K * sizeof(Fr)));
+        return ATLAS_OK;
+    }
+    // indices: d host rows of T int32 -> one device allocation (kept until the gather)
+    int32_t* d_idx = nullptr;
+    int upload_indices(const int32_t* const* H_indices) {
+        HIP_TRY(hipMalloc(&d_idx, d * len * sizeof(int32_t)));
+        for (size_t i = 0; i < d; i++)
+            HIP_TRY(hipMemcpyAsync(d_idx + i * len, H_indices[i], len * sizeof(int32_t), hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        return ATLAS_OK;
+    }
+    // the same from the T lookup indices themselves: the d chunk rows are cut on the device (8 T bytes over PCIe
+    // instead of 4 d T)
+    int upload_lookups(const uint64_t* lookups, uint32_t log_k_chunk) {
+        uint64_t* d_l = nullptr;
+        HIP_TRY(hipMalloc(&d_idx, d * len * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&d_l, len * sizeof(uint64_t)));
+        hipError_t e = hipMemcpyAsync(d_l, lookups, len * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream);
+        if (e == hipSuccess) {
+            size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
+            k_ra_chunk_indices<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(d_l, len, (uint32_t)d, log_k_chunk, d_idx);
+            e = hipStreamSynchronize(g.stream);
+        }
+        hipFree(d_l);
+        if (e != hipSuccess) return fail(ATLAS_ENODEV, "ra lookups upload", e);
+        return ATLAS_OK;
+    }
+    // ra_i[j] = table_i[idx_i[j]] from device tables (d rows of f_stride Fr; f_stride 0 = shared table)
+    int gather(const Fr* d_tables, uint32_t f_stride) {
+        if (!d_idx) return fail(ATLAS_ESTATE, "ra gather: indices not uploaded");
+        size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
+        k_ra_gather<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, g.stream>>>(d_idx, d_tables, f_stride, len, buf[0]);
+        hipError_t e = hipStreamSynchronize(g.stream);
+        hipFree(d_idx); d_idx = nullptr;
+        if (e != hipSuccess) return fail(ATLAS_ENODEV, "ra gather", e);
+        cur = 0; stride[0] = len;
+        return ATLAS_OK;
+    }
+    int bind(const atlas_u128_t& r) {
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        const size_t half = len / 2;
+        const int nxt = cur ^ 1;
+        stride[nxt] = half;
+        size_t gb = (half + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096; if (gb < 1) gb = 1;
+        k_ra_bind<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, g.stream>>>(buf[cur], stride[cur], buf[nxt], stride[nxt], half,
+                                                                               to_dev(rf), g.challenge_mode == 0 ? 1 : 0);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(ATLAS_ENODEV, "ra bind", e);
+        cur = nxt; len = half;
+        return ATLAS_OK;
+    }
+    int reduce_to_host(uint32_t n_partials, uint32_t k, H::Fr* out) {
+        if (n_partials > 1) k_col_reduce<<<k, RA_THREADS, 0, g.stream>>>(partials, n_partials, k, d_sums);
+        HIP_TRY(hipMemcpyAsync(g.h_pinned, n_partials > 1 ? d_sums : partials, k * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        std::memcpy(out, g.h_pinned, k * sizeof(Fr));
+        return ATLAS_OK;
+    }
+    int finals(std::vector<H::Fr>& out) {
+        if (len != 1) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
+        out.resize(d);
+        for (size_t i = 0; i < d; i++)
+            HIP_TRY(hipMemcpyAsync((uint8_t*)g.h_pinned + 32 * i, buf[cur] + i * stride[cur], sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        std::memcpy(out.data(), g.h_pinned, d * sizeof(Fr));
+        return ATLAS_OK;
+    }
+    void release() { for (auto& b : buf) if (b) hipFree(b); if (partials) hipFree(partials); if (d_sums) hipFree(d_sums); if (d_idx) hipFree(d_idx); buf[0] = buf[1] = partials = d_sums = nullptr; d_idx = nullptr; }
+};
+
+
+}  // namespace
