@@ -99,6 +99,76 @@ __global__ __launch_bounds__(HK_THREADS) void k_hk_scan_blocks(const Fr* __restr
     }
 }
 
+// Phase 3a of open: v[k][j] = Pi_j(u_k) for ALL the folded polynomials in two launches.  Pi_j starts at
+// 2n - 2n/2^j of `polys` and has n >> j coefficients; workgroup b of the grid owns 4096 coefficients of
+// one Pi_j (short polynomials take one workgroup each).  part[k][b] = u_k^(4096 b_local) * (the
+// workgroup's Horner total), so that Pi_j(u_k) is the plain sum of its workgroups' entries.
+__device__ __forceinline__ void hk_locate(size_t n, size_t& b, size_t& off, size_t& len, uint32_t& j) {
+    off = 0; len = n; j = 0;
+    for (;; j++) {
+        const size_t nb = (len + HK_BLOCK - 1) / HK_BLOCK;
+        if (b < nb) return;
+        b -= nb; off += len; len >>= 1;
+    }
+}
+
+__global__ __launch_bounds__(HK_THREADS) void k_hk_eval_blocks(const Fr* __restrict__ polys, size_t n, HkPowers P,
+                                                               Fr* __restrict__ part, size_t total_blocks) {
+    __shared__ Fr sm[HK_NP][HK_THREADS];
+    const uint32_t t = threadIdx.x;
+    size_t b = blockIdx.x, off, len; uint32_t j;
+    hk_locate(n, b, off, len, j);
+    const Fr* f = polys + off;
+    const size_t s = b * HK_BLOCK + (size_t)t * HK_CH;
+    Fr tot[HK_NP];
+#pragma unroll
+    for (int k = 0; k < HK_NP; k++) tot[k] = fe_zero();
+    for (int i = HK_CH - 1; i >= 0; i--) {
+        const size_t idx = s + i;
+        const Fr c = idx < len ? fe_load(f + idx) : fe_zero();
+#pragma unroll
+        for (int k = 0; k < HK_NP; k++) tot[k] = fr_add(fr_mul(tot[k], P.p2[k][0]), c);
+    }
+#pragma unroll
+    for (int k = 0; k < HK_NP; k++) sm[k][t] = tot[k];
+    __syncthreads();
+    // weighted tree: x[t] += u^(16 d) x[t + d] for t a multiple of 2d  (only x[0] is needed)
+    for (int lg = 0; lg < 8; lg++) {
+        const uint32_t d = 1u << lg;
+        if ((t & (2 * d - 1)) == 0) {
+#pragma unroll
+            for (int k = 0; k < HK_NP; k++) sm[k][t] = fr_add(sm[k][t], fr_mul(sm[k][t + d], P.p2[k][4 + lg]));
+        }
+        __syncthreads();
+    }
+    if (t < HK_NP) fe_store(part + (size_t)t * total_blocks + blockIdx.x, fr_mul(sm[t][0], hk_pow(P, (int)t, (uint32_t)(b * HK_BLOCK))));
+}
+
+// one workgroup per polynomial: out[k * ell + j] = sum of part[k][.] over Pi_j's workgroups
+__global__ __launch_bounds__(HK_THREADS) void k_hk_eval_sum(const Fr* __restrict__ part, size_t total_blocks, size_t n,
+                                                            uint32_t ell, Fr* __restrict__ out) {
+    __shared__ Fr sm[HK_NP][HK_THREADS];
+    const uint32_t t = threadIdx.x, j = blockIdx.x;
+    size_t start = 0, len = n;
+    for (uint32_t q = 0; q < j; q++) { start += (len + HK_BLOCK - 1) / HK_BLOCK; len >>= 1; }
+    const size_t nb = (len + HK_BLOCK - 1) / HK_BLOCK;
+#pragma unroll
+    for (int k = 0; k < HK_NP; k++) {
+        Fr acc = fe_zero();
+        for (size_t b = t; b < nb; b += HK_THREADS) acc = fr_add(acc, fe_load(part + (size_t)k * total_blocks + start + b));
+        sm[k][t] = acc;
+    }
+    __syncthreads();
+    for (uint32_t d = HK_THREADS / 2; d >= 1; d >>= 1) {
+        if (t < d) {
+#pragma unroll
+            for (int k = 0; k < HK_NP; k++) sm[k][t] = fr_add(sm[k][t], sm[k][t + d]);
+        }
+        __syncthreads();
+    }
+    if (t < HK_NP) fe_store(out + (size_t)t * ell + j, sm[t][0]);
+}
+
 // Level 3: suffix scan over workgroup totals (one workgroup, serial segments per thread).
 //   G[k][b] = g_k(end of workgroup b) = sum_{b' > b} blocktot[k][b'] u_k^(4096 (b' - b - 1))
 //   total[k] = g_k(0) = blocktot[k][0] + u_k^4096 * G[k][0]            (the evaluation f(u_k))

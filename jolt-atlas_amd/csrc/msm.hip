@@ -6,6 +6,8 @@
 //   HyperKZG::commit_one_hot                     hyperkzg/mod.rs:520-554
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -44,6 +46,7 @@ struct Workspace {
     }
 };
 Workspace ws;
+Workspace hk_arena;      // HyperKZG::open: Pi_0.., B, h_k and the scan scratch
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -76,10 +79,45 @@ void to_out(const H::G1Aff& a, atlas_g1_affine_t* out) {
 // in the concatenation, vector k = [offs[k], offs[k] + lens[k]); out[k] = its MSM.  K = 1 is the plain case.
 struct MsmMulti { size_t K; const size_t* lens; const size_t* offs; };
 
+// A lane = the stream and workspace one pipeline runs in.  The default lane is the library stream; HyperKZG's short
+// vectors run in a second lane next to the long ones.  With `pend` the call only enqueues; msm_finish() reads the
+// window sums back and runs the host Horner.
+struct MsmLane { hipStream_t st; Workspace* wk; };
+struct MsmPending {
+    hipStream_t st = nullptr; const G1Xyzz* wsum = nullptr; uint32_t V = 0; size_t K = 0, n = 0; MsmShape S{};
+    atlas_g1_affine_t* out = nullptr;
+    std::vector<MsmTile> tiles;      // host source of an enqueued H2D copy: alive until the finish
+};
+
+int msm_finish(const MsmPending& P) {
+    std::vector<H::G1X> hw(P.V);
+    hipError_t ce = hipMemcpyAsync(hw.data(), P.wsum, P.V * sizeof(G1Xyzz), hipMemcpyDeviceToHost, P.st);
+    if (ce == hipSuccess) ce = hipStreamSynchronize(P.st);
+    if (ce != hipSuccess) return fail(ATLAS_ENODEV, "msm result copy", ce);
+    const bool trace = getenv("ATLAS_TRACE") != nullptr;
+    const auto th0 = std::chrono::steady_clock::now();
+    // Horner over the windows of each vector: acc = 2^c * acc + W_w
+    for (size_t k = 0; k < P.K; k++) {
+        const H::G1X* hk = hw.data() + k * P.S.n_windows;
+        H::G1X acc = hk[P.S.n_windows - 1];
+        for (int w = (int)P.S.n_windows - 2; w >= 0; w--) {
+            for (uint32_t d = 0; d < P.S.c; d++) acc = H::gx_dbl(acc);
+            acc = H::gx_add(acc, hk[w]);
+        }
+        to_out(H::gx_to_aff(acc), P.out + k);
+    }
+    if (trace)
+        fprintf(stderr, "[atlas trace] msm n=%zu K=%zu c=%u host Horner %8.3f ms\n", P.n, P.K, P.S.c,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count());
+    return ATLAS_OK;
+}
+
 template <class DigitsFn>
 int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launch_digits, atlas_g1_affine_t* out,
-             const MsmMulti* multi = nullptr) {
+             const MsmMulti* multi = nullptr, const MsmLane* lane = nullptr, MsmPending* pend = nullptr) {
     const size_t K = multi ? multi->K : 1;
+    const hipStream_t st = lane ? lane->st : g.stream;
+    Workspace& wk = lane ? *lane->wk : ws;
     if (n == 0) { H::G1Aff z{H::q_zero(), H::q_zero()}; for (size_t k = 0; k < K; k++) to_out(z, out + k); return ATLAS_OK; }
     // 32-bit positions: sorted entries, bucket offsets and tile bounds
     if (n * (size_t)S.n_windows >= ((size_t)1 << 32) || K * (size_t)S.n_windows * S.bpw >= ((size_t)1 << 31))
@@ -89,6 +127,15 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
     const uint32_t chunk = S.bpw < (uint32_t)MSM_CHUNK ? S.bpw : (uint32_t)MSM_CHUNK;
     const uint32_t n_chunks = TB / chunk;
     const uint32_t chunks_per_window = S.bpw / chunk;
+
+    // tiles of the LDS counting sort: <= MSM_TILE consecutive scalars of one vector
+    std::vector<MsmTile> h_tiles;
+    for (size_t k = 0; k < K; k++) {
+        const size_t o = multi ? multi->offs[k] : 0, len = multi ? multi->lens[k] : n;
+        for (size_t t0 = 0; t0 < len; t0 += MSM_TILE)
+            h_tiles.push_back(MsmTile{(uint32_t)(o + t0), (uint32_t)(o + (t0 + MSM_TILE < len ? t0 + MSM_TILE : len)),
+                                      (uint32_t)(k * S.n_windows * S.bpw), (uint32_t)o});
+    }
 
     // workspace carve-up
     size_t off = 0;
@@ -112,9 +159,11 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
     const size_t o_buckets = carve((size_t)TB * sizeof(G1Xyzz));
     const size_t o_chunks = carve((size_t)n_chunks * sizeof(G1Xyzz));
     const size_t o_wsum = carve((size_t)V * sizeof(G1Xyzz));
-    int rc = ws.ensure(off);
+    const size_t o_tiles = carve(h_tiles.size() * sizeof(MsmTile));
+    int rc = wk.ensure(off);
     if (rc) return rc;
-    unsigned char* W = (unsigned char*)ws.p;
+    unsigned char* W = (unsigned char*)wk.p;
+    MsmTile* d_tiles = (MsmTile*)(W + o_tiles);
     int16_t* digits = (int16_t*)(W + o_digits);
     uint32_t* bsum = (uint32_t*)(W + o_bsum);
     uint32_t* boff = bsum + (n_scan_blocks + 1);
@@ -131,68 +180,49 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
     G1Xyzz* chunks = (G1Xyzz*)(W + o_chunks);
     G1Xyzz* wsum = (G1Xyzz*)(W + o_wsum);
 
+    const bool timing = g.timing && !pend;
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
-    if (g.timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2); hipEventCreate(&e3); hipEventRecord(e0, g.stream); }
+    if (timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2); hipEventCreate(&e3); hipEventRecord(e0, st); }
 
-    HIP_TRY(hipMemsetAsync(counts, 0, (size_t)(TB + 1) * 4, g.stream));
+    HIP_TRY(hipMemsetAsync(counts, 0, (size_t)(TB + 1) * 4, st));
     // signed digits once, window-major; histogram of all windows; scan; scatter window by window
-    launch_digits(digits);
+    launch_digits(digits, st);
     const bool lds_sort = S.bpw <= MSM_LDS_BPW;
     if (multi && !lds_sort) return fail(ATLAS_EINVAL, "msm: batched vectors need an LDS-sortable window width");
-    std::vector<MsmTile> h_tiles;
-    for (size_t k = 0; k < K; k++) {
-        const size_t o = multi ? multi->offs[k] : 0, len = multi ? multi->lens[k] : n;
-        for (size_t t0 = 0; t0 < len; t0 += MSM_TILE)
-            h_tiles.push_back(MsmTile{(uint32_t)(o + t0), (uint32_t)(o + (t0 + MSM_TILE < len ? t0 + MSM_TILE : len)),
-                                      (uint32_t)(k * S.n_windows * S.bpw), (uint32_t)o});
-    }
     const unsigned n_tiles = (unsigned)h_tiles.size();
-    MsmTile* d_tiles = nullptr;
-    if (lds_sort) {
-        HIP_TRY(hipMalloc(&d_tiles, h_tiles.size() * sizeof(MsmTile)));
-        HIP_TRY(hipMemcpyAsync(d_tiles, h_tiles.data(), h_tiles.size() * sizeof(MsmTile), hipMemcpyHostToDevice, g.stream));
-    }
-    if (lds_sort) k_msm_hist_lds<<<dim3(n_tiles, S.n_windows), MSM_THREADS, 0, g.stream>>>(digits, n, d_tiles, S, counts);
-    else k_msm_hist_w<<<dim3((unsigned)grid_for(n, 256), S.n_windows), MSM_THREADS, 0, g.stream>>>(digits, n, S, counts);
-    k_scan_block_sums<<<(unsigned)n_scan_blocks, 256, 0, g.stream>>>(counts, TB, bsum);
-    k_exclusive_scan<<<1, 1024, 0, g.stream>>>(bsum, (uint32_t)n_scan_blocks, boff, bcur);
-    k_scan_apply<<<(unsigned)n_scan_blocks, 256, 0, g.stream>>>(counts, TB, boff, offsets, cursor, (uint32_t)n_scan_blocks);
-    if (lds_sort) k_msm_scatter_lds<<<dim3(n_tiles, S.n_windows), MSM_THREADS, 0, g.stream>>>(digits, n, d_tiles, S.bpw, cursor, sorted);
+    if (lds_sort) HIP_TRY(hipMemcpyAsync(d_tiles, h_tiles.data(), h_tiles.size() * sizeof(MsmTile), hipMemcpyHostToDevice, st));
+    if (lds_sort) k_msm_hist_lds<<<dim3(n_tiles, S.n_windows), MSM_THREADS, 0, st>>>(digits, n, d_tiles, S, counts);
+    else k_msm_hist_w<<<dim3((unsigned)grid_for(n, 256), S.n_windows), MSM_THREADS, 0, st>>>(digits, n, S, counts);
+    k_scan_block_sums<<<(unsigned)n_scan_blocks, 256, 0, st>>>(counts, TB, bsum);
+    k_exclusive_scan<<<1, 1024, 0, st>>>(bsum, (uint32_t)n_scan_blocks, boff, bcur);
+    k_scan_apply<<<(unsigned)n_scan_blocks, 256, 0, st>>>(counts, TB, boff, offsets, cursor, (uint32_t)n_scan_blocks);
+    if (lds_sort) k_msm_scatter_lds<<<dim3(n_tiles, S.n_windows), MSM_THREADS, 0, st>>>(digits, n, d_tiles, S.bpw, cursor, sorted);
     else
         for (uint32_t w = 0; w < S.n_windows; w++)
-            k_msm_scatter_w<<<grid_for(n, 1024), MSM_THREADS, 0, g.stream>>>(digits + (size_t)w * n, n, cursor + (size_t)w * S.bpw, sorted);
-    if (g.timing) hipEventRecord(e1, g.stream);
-    k_msm_seg_counts<<<(TB + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, g.stream>>>(offsets, TB, seg_len, segc);
-    k_scan_block_sums<<<(unsigned)n_scan_blocks, 256, 0, g.stream>>>(segc, TB, bsum);
-    k_exclusive_scan<<<1, 1024, 0, g.stream>>>(bsum, (uint32_t)n_scan_blocks, boff, bcur);
-    k_scan_apply<<<(unsigned)n_scan_blocks, 256, 0, g.stream>>>(segc, TB, boff, seg_off, seg_cur, (uint32_t)n_scan_blocks);
-    k_msm_accumulate_seg<<<(unsigned)((s_max + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, g.stream>>>(bases, sorted, offsets, seg_off, TB, seg_len, partial);
-    k_msm_bucket_reduce_small<<<(TB + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, g.stream>>>(partial, seg_off, TB, buckets);
-    k_msm_bucket_reduce_big<<<TB, MSM_THREADS, 0, g.stream>>>(partial, seg_off, buckets);
-    if (g.timing) hipEventRecord(e2, g.stream);
-    k_msm_fold_chunks<<<(n_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, g.stream>>>(buckets, S, chunk, n_chunks, chunks);
-    k_g1_group_sum<<<V, MSM_THREADS, 0, g.stream>>>(chunks, chunks_per_window, wsum);
-    if (g.timing) hipEventRecord(e3, g.stream);
+            k_msm_scatter_w<<<grid_for(n, 1024), MSM_THREADS, 0, st>>>(digits + (size_t)w * n, n, cursor + (size_t)w * S.bpw, sorted);
+    if (timing) hipEventRecord(e1, st);
+    k_msm_seg_counts<<<(TB + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(offsets, TB, seg_len, segc);
+    k_scan_block_sums<<<(unsigned)n_scan_blocks, 256, 0, st>>>(segc, TB, bsum);
+    k_exclusive_scan<<<1, 1024, 0, st>>>(bsum, (uint32_t)n_scan_blocks, boff, bcur);
+    k_scan_apply<<<(unsigned)n_scan_blocks, 256, 0, st>>>(segc, TB, boff, seg_off, seg_cur, (uint32_t)n_scan_blocks);
+    k_msm_accumulate_seg<<<(unsigned)((s_max + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(bases, sorted, offsets, seg_off, TB, seg_len, partial);
+    k_msm_bucket_reduce_small<<<(TB + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(partial, seg_off, TB, buckets);
+    k_msm_bucket_reduce_big<<<TB, MSM_THREADS, 0, st>>>(partial, seg_off, buckets);
+    if (timing) hipEventRecord(e2, st);
+    k_msm_fold_chunks<<<(n_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(buckets, S, chunk, n_chunks, chunks);
+    k_g1_group_sum<<<V, MSM_THREADS, 0, st>>>(chunks, chunks_per_window, wsum);
+    if (timing) hipEventRecord(e3, st);
     hipError_t le = hipGetLastError();
-    if (le != hipSuccess) { if (d_tiles) hipFree(d_tiles); return fail(ATLAS_ENODEV, "msm launch", le); }
+    if (le != hipSuccess) return fail(ATLAS_ENODEV, "msm launch", le);
 
-    std::vector<H::G1X> hw(V);
-    hipError_t ce = hipMemcpyAsync(hw.data(), wsum, V * sizeof(G1Xyzz), hipMemcpyDeviceToHost, g.stream);
-    if (ce == hipSuccess) ce = hipStreamSynchronize(g.stream);
-    if (d_tiles) hipFree(d_tiles);
-    if (ce != hipSuccess) return fail(ATLAS_ENODEV, "msm result copy", ce);
-    // Horner over the windows of each vector: acc = 2^c * acc + W_w
-    for (size_t k = 0; k < K; k++) {
-        const H::G1X* hk = hw.data() + k * S.n_windows;
-        H::G1X acc = hk[S.n_windows - 1];
-        for (int w = (int)S.n_windows - 2; w >= 0; w--) {
-            for (uint32_t d = 0; d < S.c; d++) acc = H::gx_dbl(acc);
-            acc = H::gx_add(acc, hk[w]);
-        }
-        to_out(H::gx_to_aff(acc), out + k);
-    }
+    MsmPending P;
+    P.st = st; P.wsum = wsum; P.V = V; P.K = K; P.n = n; P.S = S; P.out = out;
+    P.tiles = std::move(h_tiles);
+    if (pend) { *pend = std::move(P); return ATLAS_OK; }      // (no timing events on deferred calls)
+    rc = msm_finish(P);
+    if (rc) return rc;
 
-    if (g.timing) {
+    if (timing) {
         float a = 0, b = 0, c = 0;
         hipEventElapsedTime(&a, e0, e1); hipEventElapsedTime(&b, e1, e2); hipEventElapsedTime(&c, e2, e3);
         atlas_timing_t t{};
@@ -208,21 +238,83 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
 // scalars are Montgomery Fr already on the device
 int msm_device(const G1Affine* bases, const Fr* d_scalars, size_t n, atlas_g1_affine_t* out) {
     const MsmShape S = pick_shape(n);
-    return msm_core(bases, n, S, [&](int16_t* digits) {
-        k_msm_digits<<<grid_for(n), MSM_THREADS, 0, g.stream>>>(d_scalars, n, S, digits);
+    return msm_core(bases, n, S, [&](int16_t* digits, hipStream_t st) {
+        k_msm_digits<<<grid_for(n), MSM_THREADS, 0, st>>>(d_scalars, n, S, digits);
     }, out);
 }
 
-// K vectors stored back to back in d_scalars (vector k at offs[k], lens[k] scalars), each against bases[0..lens[k])
+// K vectors stored in d_scalars (vector k at offs[k], lens[k] scalars), each against bases[0..lens[k]).  One pipeline
+// has one window width; vectors much shorter than the longest would pay for its 4096 buckets per window with a handful
+// of points each (HyperKZG's Pi_j halve from 2^(ell-1) down to 2), so they go through a second, narrower pipeline.
+constexpr size_t MSM_MULTI_SPLIT = (size_t)1 << 15;
+
+struct MsmGroup {
+    std::vector<size_t> idx, gl, go;
+    std::vector<atlas_g1_affine_t> res;
+    MsmPending pend;
+};
+
+static int msm_multi_group(const G1Affine* bases, const Fr* d_scalars, MsmGroup& G, const size_t* lens, const size_t* offs,
+                           const MsmShape S, const MsmLane* lane) {
+    size_t lo = SIZE_MAX, hi = 0;
+    for (size_t k : G.idx) { lo = offs[k] < lo ? offs[k] : lo; hi = offs[k] + lens[k] > hi ? offs[k] + lens[k] : hi; }
+    G.gl.resize(G.idx.size()); G.go.resize(G.idx.size()); G.res.resize(G.idx.size());
+    for (size_t i = 0; i < G.idx.size(); i++) { G.gl[i] = lens[G.idx[i]]; G.go[i] = offs[G.idx[i]] - lo; }
+    const MsmMulti M{G.idx.size(), G.gl.data(), G.go.data()};
+    const Fr* sc = d_scalars + lo;
+    const size_t n = hi - lo;
+    return msm_core(bases, n, S, [&](int16_t* digits, hipStream_t st) {
+        k_msm_digits<<<grid_for(n), MSM_THREADS, 0, st>>>(sc, n, S, digits);
+    }, G.res.data(), &M, lane, &G.pend);
+}
+
+Workspace ws_side;                 // second lane: the narrow pipeline of msm_device_multi
+hipStream_t side_stream = nullptr;
+hipEvent_t side_event = nullptr;
+
 int msm_device_multi(const G1Affine* bases, const Fr* d_scalars, size_t n_tot, size_t K, const size_t* lens, const size_t* offs,
                      atlas_g1_affine_t* out) {
+    (void)n_tot;
     size_t mx = 0;
     for (size_t k = 0; k < K; k++) mx = lens[k] > mx ? lens[k] : mx;
-    const MsmShape S = pick_shape(mx);
-    const MsmMulti M{K, lens, offs};
-    return msm_core(bases, n_tot, S, [&](int16_t* digits) {
-        k_msm_digits<<<grid_for(n_tot), MSM_THREADS, 0, g.stream>>>(d_scalars, n_tot, S, digits);
-    }, out, &M);
+    MsmGroup big, small;
+    size_t mx_small = 0;
+    for (size_t k = 0; k < K; k++) {
+        if (mx >= MSM_MULTI_SPLIT && lens[k] < MSM_MULTI_SPLIT) { small.idx.push_back(k); mx_small = lens[k] > mx_small ? lens[k] : mx_small; }
+        else big.idx.push_back(k);
+    }
+    if (!small.idx.empty()) {
+        // the narrow pipeline runs on a side stream behind whatever produced the scalars on the library stream,
+        // NOT behind the wide pipeline: the event is recorded before that one is enqueued
+        if (!side_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&side_event, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(side_event, g.stream));
+    }
+    int rc = msm_multi_group(bases, d_scalars, big, lens, offs, pick_shape(mx), nullptr);
+    if (rc) return rc;
+    if (!small.idx.empty()) {
+        // narrow pipeline: about 16 points per bucket for its longest vector; its latency-bound tail and host Horner
+        // overlap the wide pipeline's accumulation
+        uint32_t lg = 0;
+        while (((size_t)2 << lg) <= mx_small) lg++;
+        MsmShape S;
+        S.c = lg < 10 ? 6 : lg - 4 > 12 ? 12 : lg - 4;
+        S.n_windows = (255 + S.c - 1) / S.c;
+        S.bpw = 1u << (S.c - 1);
+        HIP_TRY(hipStreamWaitEvent(side_stream, side_event, 0));
+        const MsmLane side{side_stream, &ws_side};
+        rc = msm_multi_group(bases, d_scalars, small, lens, offs, S, &side);
+        if (rc) { hipStreamSynchronize(side_stream); hipStreamSynchronize(g.stream); return rc; }
+        rc = msm_finish(small.pend);
+        if (rc) { hipStreamSynchronize(g.stream); return rc; }
+        for (size_t i = 0; i < small.idx.size(); i++) out[small.idx[i]] = small.res[i];
+    }
+    rc = msm_finish(big.pend);
+    if (rc) return rc;
+    for (size_t i = 0; i < big.idx.size(); i++) out[big.idx[i]] = big.res[i];
+    return ATLAS_OK;
 }
 
 // narrow integer scalars (msm_u8 .. msm_u64 and the signed split of I32/I64Scalars,
@@ -250,8 +342,8 @@ int msm_small_device(const G1Affine* bases, const T* d_scalars, size_t n, atlas_
     S.c = (total + S.n_windows - 1) / S.n_windows;
     if (S.c < 2) S.c = 2;
     S.bpw = 1u << (S.c - 1);
-    return msm_core(bases, n, S, [&](int16_t* digits) {
-        k_msm_digits_small<T><<<grid_for(n), MSM_THREADS, 0, g.stream>>>(d_scalars, n, S, digits);
+    return msm_core(bases, n, S, [&](int16_t* digits, hipStream_t st) {
+        k_msm_digits_small<T><<<grid_for(n), MSM_THREADS, 0, st>>>(d_scalars, n, S, digits);
     }, out);
 }
 
@@ -441,6 +533,18 @@ int atlas_g1_sum_indexed(atlas_srs_t srs, const uint32_t* indices, size_t n, atl
 }
 
 // ------------------------------------------------------------------ HyperKZG::open
+// ATLAS_TRACE=1: wall-clock of the phases of one open on stderr (each mark drains the stream)
+struct HkTrace {
+    bool on = getenv("ATLAS_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void mark(const char* what) {
+        if (!on) return;
+        hipStreamSynchronize(g.stream);
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[atlas trace] hyperkzg_open %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 // hyperkzg/mod.rs:400-447 + kzg_open_batch :231-280.  poly is not consumed.
 //   com : ell-1 commitments to the folded polynomials Pi_1..Pi_{ell-1}
 //   w   : 3 witness commitments,  v : 3*ell evaluations, v[i*ell + j] = Pi_j(u_i)
@@ -457,19 +561,20 @@ int atlas_hyperkzg_open(atlas_srs_t srs, atlas_poly_t poly, const atlas_u128_t* 
     const int mode = g.challenge_mode;
 
     // one buffer for Pi_0..Pi_{ell-1} (2n - 2 coefficients), B, and the three h_k
-    Fr *polys = nullptr, *B = nullptr, *h = nullptr, *scr = nullptr;
+    // (kept between calls: the arena only grows — 6n Fr = 192 MB at 2^20 out of 288 GB)
     const size_t n_blocks = (n + HK_BLOCK - 1) / HK_BLOCK;
-    HIP_TRY(hipMalloc(&polys, 2 * n * sizeof(Fr)));
-    HIP_TRY(hipMalloc(&B, n * sizeof(Fr)));
-    HIP_TRY(hipMalloc(&h, 3 * n * sizeof(Fr)));
-    // scratch: xincl 3*(n_blocks*256) | blocktot 3*n_blocks | G 3*n_blocks | total 3 | pw16 3*257 | q ell
+    // scratch: xincl 3*(n_blocks*256) | blocktot 3*n_blocks | G 3*n_blocks | total 3 | pw16 3*257 | q ell | evpart 3*eval_blocks | evout 3*ell
     const size_t xs = n_blocks * HK_THREADS;
-    const size_t scr_elems = 3 * xs + 6 * n_blocks + 3 + 3 * 257 + ell;
-    HIP_TRY(hipMalloc(&scr, scr_elems * sizeof(Fr)));
+    size_t eval_blocks = 0;
+    for (size_t j = 0, len = n; j < ell; j++, len >>= 1) eval_blocks += (len + HK_BLOCK - 1) / HK_BLOCK;
+    const size_t scr_elems = 3 * xs + 6 * n_blocks + 3 + 3 * 257 + ell + 3 * eval_blocks + 3 * ell;
+    { int rc = hk_arena.ensure((6 * n + scr_elems) * sizeof(Fr)); if (rc) return rc; }
+    Fr* polys = (Fr*)hk_arena.p; Fr* B = polys + 2 * n; Fr* h = B + n; Fr* scr = h + 3 * n;
     Fr* xincl = scr; Fr* blocktot = xincl + 3 * xs; Fr* G = blocktot + 3 * n_blocks; Fr* total = G + 3 * n_blocks;
-    Fr* pw16 = total + 3; Fr* dq = pw16 + 3 * 257;
-    auto cleanup = [&]() { hipFree(polys); hipFree(B); hipFree(h); hipFree(scr); };
+    Fr* pw16 = total + 3; Fr* dq = pw16 + 3 * 257; Fr* evpart = dq + ell; Fr* evout = evpart + 3 * eval_blocks;
+    auto cleanup = [&]() {};
 
+    HkTrace tr;
     // Phase 1: folds (LowToHigh, variable point[ell-i-1])
     HIP_TRY(hipMemcpyAsync(polys, poly->d, n * sizeof(Fr), hipMemcpyDeviceToDevice, g.stream));
     {
@@ -481,6 +586,7 @@ int atlas_hyperkzg_open(atlas_srs_t srs, atlas_poly_t poly, const atlas_u128_t* 
             off += len; len >>= 1;
         }
     }
+    tr.mark("alloc + folds");
     // commitments to Pi_1.. (commit_variable_batch, kzg.rs:227-243)
     // Pi_1 .. Pi_{ell-1} lie back to back after Pi_0: one batched pipeline over all of them (n - 2 scalars)
     if (ell > 1) {
@@ -490,6 +596,7 @@ int atlas_hyperkzg_open(atlas_srs_t srs, atlas_poly_t poly, const atlas_u128_t* 
         int rc = msm_device_multi(srs->d, polys + n, off, ell - 1, lens.data(), offs.data(), com);
         if (rc) { cleanup(); return rc; }
     }
+    tr.mark("commit Pi_1..");
     // Phase 2: transcript, r, u = [r, -r, r^2]
     H::tr_append_message(T, "begin_append_vector");
     for (size_t i = 0; i + 1 < ell; i++) host_append_point(T, &com[i]);
@@ -506,20 +613,16 @@ int atlas_hyperkzg_open(atlas_srs_t srs, atlas_poly_t poly, const atlas_u128_t* 
         for (int j = 0; j <= 256; j++) { hpw16[k * 257 + j] = acc; acc = H::mul(acc, u16); }
     }
     HIP_TRY(hipMemcpyAsync(pw16, hpw16.data(), 3 * 257 * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
-    // Phase 3a: v[i][j] = Pi_j(u_i)
+    tr.mark("transcript + powers");
+    // Phase 3a: v[i][j] = Pi_j(u_i), all ell polynomials in two launches and one readback
     std::vector<H::Fr> hv(3 * ell);
     {
-        size_t off = 0, len = n;
-        for (size_t j = 0; j < ell; j++) {
-            const size_t nb = (len + HK_BLOCK - 1) / HK_BLOCK;
-            k_hk_scan_blocks<<<(unsigned)nb, HK_THREADS, 0, g.stream>>>(polys + off, len, P, nullptr, 0, blocktot, nb);
-            k_hk_scan_grid<<<1, HK_THREADS, 0, g.stream>>>(blocktot, nb, P, G, total);
-            HIP_TRY(hipMemcpyAsync(g.h_pinned, total, 3 * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
-            HIP_TRY(hipStreamSynchronize(g.stream));
-            for (int k = 0; k < 3; k++) std::memcpy(&hv[k * ell + j], (unsigned char*)g.h_pinned + k * sizeof(Fr), sizeof(Fr));
-            off += len; len >>= 1;
-        }
+        k_hk_eval_blocks<<<(unsigned)eval_blocks, HK_THREADS, 0, g.stream>>>(polys, n, P, evpart, eval_blocks);
+        k_hk_eval_sum<<<(unsigned)ell, HK_THREADS, 0, g.stream>>>(evpart, eval_blocks, n, (uint32_t)ell, evout);
+        HIP_TRY(hipMemcpyAsync(hv.data(), evout, 3 * ell * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
     }
+    tr.mark("evaluations v");
     std::memcpy(v, hv.data(), 3 * ell * sizeof(Fr));
     H::tr_append_scalars(T, hv.data(), 3 * ell);
     // q powers (challenge_scalar_powers, blake2b.rs:224-231), B = sum q^j Pi_j
@@ -533,16 +636,19 @@ int atlas_hyperkzg_open(atlas_srs_t srs, atlas_poly_t poly, const atlas_u128_t* 
     k_hk_witness<<<(unsigned)n_blocks, HK_THREADS, 0, g.stream>>>(B, n, P, xincl, xs, G, n_blocks, pw16, h, n);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { cleanup(); return fail(ATLAS_ENODEV, "hyperkzg launch", le); }
+    tr.mark("lincomb + witness polys");
     {   // the three witness commitments share the bases: one batched pipeline
         const size_t lens[3] = {n, n, n}, offs[3] = {0, n, 2 * n};
         int rc = msm_device_multi(srs->d, h, 3 * n, 3, lens, offs, w);
         if (rc) { cleanup(); return rc; }
     }
+    tr.mark("commit witnesses");
     H::tr_append_message(T, "begin_append_vector");
     for (int k = 0; k < 3; k++) host_append_point(T, &w[k]);
     H::tr_append_message(T, "end_append_vector");
     (void)H::tr_challenge_scalar(T);      // d_0: keeps the transcript in step with the verifier (:276-277)
     cleanup();
+    tr.mark("transcript + free");
     return ATLAS_OK;
 }
 
