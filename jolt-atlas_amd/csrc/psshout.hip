@@ -21,6 +21,89 @@
 
 namespace {
 
+// the NQ suffix-weighted copies of u for one lookup: val[q] = u * suffix_q(low `suffix_len` bits of k)
+template <int NQ>
+__device__ __forceinline__ void ps_entry_vals(uint64_t k, const Fr& u, uint32_t suffix_len, uint32_t bound, Fr val[NQ]) {
+    const uint64_t smask = suffix_len >= 64 ? ~0ull : (((uint64_t)1 << suffix_len) - 1);
+    const uint64_t sb = k & smask;
+    val[0] = u;
+    if constexpr (NQ == 4) {      // binary lookups: suffix = interleave(x, y) (utils/mod.rs:105-125 uninterleave_bits)
+        uint64_t xb = (sb >> 1) & 0x5555555555555555ull, yb = sb & 0x5555555555555555ull;
+        xb = (xb | (xb >> 1)) & 0x3333333333333333ull; xb = (xb | (xb >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+        xb = (xb | (xb >> 4)) & 0x00FF00FF00FF00FFull; xb = (xb | (xb >> 8)) & 0x0000FFFF0000FFFFull; xb = (xb | (xb >> 16)) & 0xFFFFFFFFull;
+        yb = (yb | (yb >> 1)) & 0x3333333333333333ull; yb = (yb | (yb >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+        yb = (yb | (yb >> 4)) & 0x00FF00FF00FF00FFull; yb = (yb | (yb >> 8)) & 0x0000FFFF0000FFFFull; yb = (yb | (yb >> 16)) & 0xFFFFFFFFull;
+        val[1] = xb < yb ? u : fe_zero();                                        // LessThan suffix
+        val[2] = xb ? fr_mul(u, fr_from_i64((int64_t)xb)) : fe_zero();           // left operand of the suffix
+        val[3] = yb ? fr_mul(u, fr_from_i64((int64_t)yb)) : fe_zero();           // right operand
+    } else {
+        val[1] = sb ? fr_mul(u, fr_from_i64((int64_t)sb)) : fe_zero();
+        if constexpr (NQ == 6) {
+            bool haz = true, hao = true;
+            uint64_t lw = sb;
+            if (suffix_len > bound) {
+                const uint64_t hi = sb >> bound, ones = (((uint64_t)1 << (suffix_len - bound)) - 1);
+                haz = hi == 0; hao = hi == ones;
+                lw = sb & (((uint64_t)1 << bound) - 1);
+            }
+            const Fr ul = ((haz || hao) && lw) ? fr_mul(u, fr_from_i64((int64_t)lw)) : fe_zero();
+            val[2] = haz ? u : fe_zero(); val[3] = haz ? ul : fe_zero();
+            val[4] = hao ? u : fe_zero(); val[5] = hao ? ul : fe_zero();
+        }
+    }
+}
+
+// Q tables of one phase, m = 2^log_m <= 256 bins.  A workgroup walks its slice of T in tiles of 256 lookups: every
+// thread computes the values of ONE lookup (all lanes busy in the multiplications), parks them in LDS, then acts as
+// (bin = tid % m, part = tid / m) and adds the tile entries of its part that fall into its bin.  One partial row of
+// NQ * m sums per workgroup; k_col_reduce adds the rows.
+template <int NQ>
+__global__ __launch_bounds__(RA_THREADS) void k_ps_q_tiled(const uint64_t* __restrict__ idx, const Fr* __restrict__ u0,
+                                                           const Fr* __restrict__ prod, size_t T, uint32_t suffix_len, uint32_t m,
+                                                           uint32_t bound, Fr* __restrict__ partials /* [blocks][NQ m] */) {
+    __shared__ Fr vals[NQ][RA_THREADS];
+    __shared__ uint32_t bins[RA_THREADS];
+    const uint32_t tid = threadIdx.x, parts = RA_THREADS / m, per_part = RA_THREADS / parts;
+    const uint32_t my_bin = tid % m, my_part = tid / m;
+    const size_t n_tiles = (T + RA_THREADS - 1) / RA_THREADS;
+    const size_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
+    const size_t tile0 = (size_t)blockIdx.x * per, tile1 = tile0 + per < n_tiles ? tile0 + per : n_tiles;
+    Fr acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) acc[q] = fe_zero();
+    for (size_t tile = tile0; tile < tile1; tile++) {
+        const size_t t = tile * RA_THREADS + tid;
+        uint32_t b = 0xFFFFFFFFu;
+        if (t < T) {
+            const uint64_t k = idx[t];
+            b = (uint32_t)(k >> suffix_len) & (m - 1);
+            Fr val[NQ];
+            ps_entry_vals<NQ>(k, fr_mul(fe_load(u0 + t), fe_load(prod + t)), suffix_len, bound, val);
+#pragma unroll
+            for (int q = 0; q < NQ; q++) vals[q][tid] = val[q];
+        }
+        bins[tid] = b;
+        __syncthreads();
+        for (uint32_t e = my_part * per_part; e < (my_part + 1) * per_part; e++) {
+            if (bins[e] != my_bin) continue;
+#pragma unroll
+            for (int q = 0; q < NQ; q++) acc[q] = fr_add(acc[q], vals[q][e]);
+        }
+        __syncthreads();
+    }
+    // add the parts of each bin
+#pragma unroll
+    for (int q = 0; q < NQ; q++) vals[q][tid] = acc[q];
+    __syncthreads();
+    for (uint32_t o = tid; o < NQ * m; o += RA_THREADS) {
+        const uint32_t y = o / NQ, q = o % NQ;
+        Fr s = vals[q][y];
+        for (uint32_t p = 1; p < parts; p++) s = fr_add(s, vals[q][p * m + y]);
+        fe_store(partials + (size_t)blockIdx.x * NQ * m + o, s);
+    }
+}
+
+// m > 256: one workgroup per (bin, slice of T), each filtering its slice for its bin
 template <int NQ>
 __global__ __launch_bounds__(RA_THREADS) void k_ps_q(const uint64_t* __restrict__ idx, const Fr* __restrict__ u0,
                                                      const Fr* __restrict__ prod, size_t T, uint32_t suffix_len, uint32_t m_mask,
@@ -31,39 +114,13 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_q(const uint64_t* __restrict_
     Fr acc[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) acc[q] = fe_zero();
-    const uint64_t smask = suffix_len >= 64 ? ~0ull : (((uint64_t)1 << suffix_len) - 1);
     for (size_t t = t0 + threadIdx.x; t < t1; t += RA_THREADS) {
         const uint64_t k = idx[t];
         if (((uint32_t)(k >> suffix_len) & m_mask) != y) continue;
-        const Fr u = fr_mul(fe_load(u0 + t), fe_load(prod + t));
-        acc[0] = fr_add(acc[0], u);
-        const uint64_t sb = k & smask;
-        if constexpr (NQ == 4) {      // binary lookups: suffix = interleave(x, y) (utils/mod.rs:105-125 uninterleave_bits)
-            uint64_t xb = (sb >> 1) & 0x5555555555555555ull, yb = sb & 0x5555555555555555ull;
-            xb = (xb | (xb >> 1)) & 0x3333333333333333ull; xb = (xb | (xb >> 2)) & 0x0F0F0F0F0F0F0F0Full;
-            xb = (xb | (xb >> 4)) & 0x00FF00FF00FF00FFull; xb = (xb | (xb >> 8)) & 0x0000FFFF0000FFFFull; xb = (xb | (xb >> 16)) & 0xFFFFFFFFull;
-            yb = (yb | (yb >> 1)) & 0x3333333333333333ull; yb = (yb | (yb >> 2)) & 0x0F0F0F0F0F0F0F0Full;
-            yb = (yb | (yb >> 4)) & 0x00FF00FF00FF00FFull; yb = (yb | (yb >> 8)) & 0x0000FFFF0000FFFFull; yb = (yb | (yb >> 16)) & 0xFFFFFFFFull;
-            if (xb < yb) acc[1] = fr_add(acc[1], u);                              // LessThan suffix
-            if (xb) acc[2] = fr_add(acc[2], fr_mul(u, fr_from_i64((int64_t)xb)));   // left operand of the suffix
-            if (yb) acc[3] = fr_add(acc[3], fr_mul(u, fr_from_i64((int64_t)yb)));   // right operand
-            continue;
-        }
-        if (sb) acc[1] = fr_add(acc[1], fr_mul(u, fr_from_i64((int64_t)sb)));
-        if constexpr (NQ == 6) {
-            bool haz = true, hao = true;
-            uint64_t lw = sb;
-            if (suffix_len > bound) {
-                const uint64_t hi = sb >> bound, ones = (((uint64_t)1 << (suffix_len - bound)) - 1);
-                haz = hi == 0; hao = hi == ones;
-                lw = sb & (((uint64_t)1 << bound) - 1);
-            }
-            if (haz || hao) {
-                const Fr ul = lw ? fr_mul(u, fr_from_i64((int64_t)lw)) : fe_zero();
-                if (haz) { acc[2] = fr_add(acc[2], u); acc[3] = fr_add(acc[3], ul); }
-                if (hao) { acc[4] = fr_add(acc[4], u); acc[5] = fr_add(acc[5], ul); }
-            }
-        }
+        Fr val[NQ];
+        ps_entry_vals<NQ>(k, fr_mul(fe_load(u0 + t), fe_load(prod + t)), suffix_len, bound, val);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) acc[q] = fr_add(acc[q], val[q]);
     }
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
@@ -115,7 +172,7 @@ struct PsLookup : atlas_instance {
     H::Fr lt_acc = H::zero(), eq_acc = H::one(), lop_acc = H::zero(), rop_acc = H::zero();   // mode 3 (UnsignedLessThan, binary)
     std::vector<H::Fr> r_addr;
     H::Fr word_acc = H::zero(), sid_acc = H::zero(), wv = H::zero();
-    static constexpr unsigned SLICES = 64;
+    static constexpr unsigned SLICES = 64, Q_BLOCKS = 512, Q_ROWS_MAX = 512;
 
     ~PsLookup() override { for (void* p : {(void*)d_idx, (void*)d_u0, (void*)d_v, (void*)d_qpart}) if (p) hipFree(p); rows.release(); eq.release(); }
     size_t rounds() const override { return N + log_T; }
@@ -127,12 +184,20 @@ struct PsLookup : atlas_instance {
     int build_Q(size_t phase) {           // init_phase: Q tables of `phase` from the current products
         const uint32_t suffix_len = (uint32_t)((phases - 1 - phase) * log_m);
         const size_t NQ = nq();
-        if (NQ == 4) k_ps_q<4><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), 0u, d_qpart);
+        unsigned n_rows = SLICES;            // partial rows to add
+        if (m <= RA_THREADS) {
+            const size_t n_tiles = (T + RA_THREADS - 1) / RA_THREADS;
+            n_rows = (unsigned)(n_tiles < Q_BLOCKS ? n_tiles : Q_BLOCKS);
+            if (NQ == 4) k_ps_q_tiled<4><<<n_rows, RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)m, 0u, d_qpart);
+            else if (NQ == 6) k_ps_q_tiled<6><<<n_rows, RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)m, (uint32_t)bound, d_qpart);
+            else k_ps_q_tiled<2><<<n_rows, RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)m, 0u, d_qpart);
+        } else if (NQ == 4) k_ps_q<4><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), 0u, d_qpart);
         else if (NQ == 6) k_ps_q<6><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), (uint32_t)bound, d_qpart);
         else k_ps_q<2><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), 0u, d_qpart);
-        k_col_reduce<<<(unsigned)(NQ * m), RA_THREADS, 0, g.stream>>>(d_qpart, SLICES, (uint32_t)(NQ * m), d_qpart + (size_t)SLICES * NQ * m);
+        Fr* d_qsum = d_qpart + (size_t)Q_ROWS_MAX * NQ * m;
+        k_col_reduce<<<(unsigned)(NQ * m), RA_THREADS, 0, g.stream>>>(d_qpart, n_rows, (uint32_t)(NQ * m), d_qsum);
         std::vector<H::Fr> q(NQ * m);
-        HIP_TRY(hipMemcpyAsync(q.data(), d_qpart + (size_t)SLICES * NQ * m, NQ * m * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipMemcpyAsync(q.data(), d_qsum, NQ * m * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
         Q.assign(NQ, std::vector<H::Fr>(m));
         for (size_t y = 0; y < m; y++) for (size_t k = 0; k < NQ; k++) Q[k][y] = q[NQ * y + k];
@@ -320,7 +385,7 @@ static int ps_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, si
     const size_t T = P->T, m = P->m;
     hipError_t e = hipMalloc(&P->d_idx, T * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc(&P->d_v, m * sizeof(Fr));
-    if (e == hipSuccess) e = hipMalloc(&P->d_qpart, ((size_t)PsLookup::SLICES + 1) * 6 * m * sizeof(Fr));
+    if (e == hipSuccess) e = hipMalloc(&P->d_qpart, ((size_t)PsLookup::Q_ROWS_MAX + 1) * 6 * m * sizeof(Fr));
     if (e == hipSuccess) e = hipMemcpyAsync(P->d_idx, lookup_indices, T * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream);
     if (e != hipSuccess) { delete P; return fail(ATLAS_ENOMEM, "ps_shout_new", e); }
     rc = P->rows.alloc(1, T);

@@ -81,7 +81,7 @@ def test_ps_shout_rejects_unsupported_widths(atlas):
         I.ps_shout_relu(np.zeros(4, dtype=np.uint64), 8, orc.random_fr(2, 1), orc.random_fr(1, 2)[0])
 
 
-@pytest.mark.parametrize("log_K,phases,log_T", [(8, 4, 2), (16, 8, 9), (16, 2, 5), (32, 8, 12), (64, 8, 7), (12, 3, 6)])
+@pytest.mark.parametrize("log_K,phases,log_T", [(8, 4, 2), (16, 8, 9), (16, 2, 5), (32, 8, 12), (64, 8, 7), (12, 3, 6), (20, 2, 6), (4, 4, 3)])
 def test_identity_range_check_bit_exact(atlas, log_K, phases, log_T):
     from oracle import orc, orc_ra as OR
     from jolt_atlas_amd import instances as I
