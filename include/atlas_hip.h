@@ -288,6 +288,12 @@ int atlas_ps_shout_relu_new(const uint64_t *lookup_indices, size_t log_T, size_t
 int atlas_ps_shout_clamp_new(const uint64_t *lookup_indices, size_t log_T, size_t xlen, size_t bound,
                              int symmetric, const atlas_fr_t *r_node_output, const atlas_fr_t *gamma,
                              atlas_instance_t *out);
+/* The same unary prover over RightShiftTable<XLEN> (joltworks/src/lookup_tables/right_shift.rs:17-60; used by
+ * the Sin / Cos trig downscale, jolt-atlas-core/src/onnx_proof/ops/sin.rs:108, cos.rs:113): Val(k) = k >> shift
+ * (unsigned; shift = TRIG_DOWNSCALE_BITS in the reference), prefix TrigRightShift, suffixes [One, TrigRightShift],
+ * RAF = SignedIdentity.  xlen = 16 or 32, shift < xlen. */
+int atlas_ps_shout_rshift_new(const uint64_t *lookup_indices, size_t log_T, size_t xlen, size_t shift,
+                              const atlas_fr_t *r_node_output, const atlas_fr_t *gamma, atlas_instance_t *out);
 /* The binary flavour (joltworks/src/subprotocols/ps_shout/binary.rs:148-200 ps_read_raf_prover) with
  * UnsignedLessThanTable<32> (lookup_tables/unsigned_less_than.rs): lookup index = interleave_bits(x, y)
  * (utils/mod.rs:146-164), 64 address rounds, summand ra * (LT(x,y) + gamma * SignedLeft + gamma^2 *

@@ -38,6 +38,10 @@ __device__ __forceinline__ void ps_entry_vals(uint64_t k, const Fr& u, uint32_t 
         val[3] = yb ? fr_mul(u, fr_from_i64((int64_t)yb)) : fe_zero();           // right operand
     } else {
         val[1] = sb ? fr_mul(u, fr_from_i64((int64_t)sb)) : fe_zero();
+        if constexpr (NQ == 3) {      // RightShiftSuffix: bits >> D, D passed in `bound` (suffixes/right_shift.rs:12-17)
+            const uint64_t rs = bound >= 64 ? 0 : sb >> bound;
+            val[2] = rs ? fr_mul(u, fr_from_i64((int64_t)rs)) : fe_zero();
+        }
         if constexpr (NQ == 6) {
             bool haz = true, hao = true;
             uint64_t lw = sb;
@@ -158,9 +162,9 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_fold(const Fr* __restrict__ r
 
 struct PsLookup : atlas_instance {
     size_t N = 0, log_m = 0, m = 0, log_T = 0, T = 0, round_next = 0, phases = 8;   // N = LOG_K
-    int mode = 0;                         // 0 = ReLU + gamma * SignedIdentity (unary read-raf), 1 = Identity (range check), 2 = clamp family
+    int mode = 0;                         // 0 = ReLU + gamma * SignedIdentity (unary read-raf), 1 = Identity (range check), 2 = clamp family, 3 = UnsignedLessThan (binary), 4 = RightShift
     size_t bound = 0; bool symmetric = true;   // ClampBoundedTable<N, BOUND, SYMMETRIC> (lookup_tables/clamp.rs)
-    size_t nq() const { return mode == 2 ? 6 : mode == 3 ? 4 : 2; }
+    size_t nq() const { return mode == 2 ? 6 : mode == 3 ? 4 : mode == 4 ? 3 : 2; }
     H::Fr gamma = H::zero();
     uint64_t* d_idx = nullptr;
     Fr *d_u0 = nullptr, *d_v = nullptr, *d_qpart = nullptr;
@@ -169,6 +173,7 @@ struct PsLookup : atlas_instance {
     std::vector<std::vector<H::Fr>> Q;    // current phase's suffix tables (bound HighToLow): 0 = One, 1 = suffix, 2..5 clamp
     std::vector<H::Fr> v;                 // expanding table of the phase
     H::Fr haz_acc = H::one(), hao_acc = H::one(), lw_acc = H::zero();
+    H::Fr rs_acc = H::zero();                                                                 // mode 4 (RightShift by `bound` bits)
     H::Fr lt_acc = H::zero(), eq_acc = H::one(), lop_acc = H::zero(), rop_acc = H::zero();   // mode 3 (UnsignedLessThan, binary)
     std::vector<H::Fr> r_addr;
     H::Fr word_acc = H::zero(), sid_acc = H::zero(), wv = H::zero();
@@ -179,6 +184,7 @@ struct PsLookup : atlas_instance {
     size_t degree() const override { return 2; }
 
     static H::Fr pow2(size_t k) { H::Fr o = H::one(); const H::Fr two = H::from_u64(2); for (size_t i = 0; i < k; i++) o = H::mul(o, two); return o; }
+    H::Fr rs_weight(size_t i) const { return (bound < N && i <= N - 1 - bound) ? pow2(N - 1 - i - bound) : H::zero(); }   // mode 4: bit i of k >> D
     H::Fr weight(size_t i) const { H::Fr w = pow2(N - 1 - i); return (i == 0 && mode != 1) ? H::sub(w, pow2(N)) : w; }   // (Signed)Identity coefficient of bit i
 
     int build_Q(size_t phase) {           // init_phase: Q tables of `phase` from the current products
@@ -190,9 +196,11 @@ struct PsLookup : atlas_instance {
             n_rows = (unsigned)(n_tiles < Q_BLOCKS ? n_tiles : Q_BLOCKS);
             if (NQ == 4) k_ps_q_tiled<4><<<n_rows, RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)m, 0u, d_qpart);
             else if (NQ == 6) k_ps_q_tiled<6><<<n_rows, RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)m, (uint32_t)bound, d_qpart);
+            else if (NQ == 3) k_ps_q_tiled<3><<<n_rows, RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)m, (uint32_t)bound, d_qpart);
             else k_ps_q_tiled<2><<<n_rows, RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)m, 0u, d_qpart);
         } else if (NQ == 4) k_ps_q<4><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), 0u, d_qpart);
         else if (NQ == 6) k_ps_q<6><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), (uint32_t)bound, d_qpart);
+        else if (NQ == 3) k_ps_q<3><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), (uint32_t)bound, d_qpart);
         else k_ps_q<2><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), 0u, d_qpart);
         Fr* d_qsum = d_qpart + (size_t)Q_ROWS_MAX * NQ * m;
         k_col_reduce<<<(unsigned)(NQ * m), RA_THREADS, 0, g.stream>>>(d_qpart, n_rows, (uint32_t)(NQ * m), d_qsum);
@@ -263,6 +271,13 @@ struct PsLookup : atlas_instance {
                     const H::Fr q1 = qv(0), qs = qv(1);
                     const H::Fr idt = H::add(H::mul(H::add(sid_c, bs), q1), qs);          // (Signed)Identity term
                     if (mode == 1) { acc = H::add(acc, idt); continue; }
+                    if (mode == 4) {     // RightShiftTable (right_shift.rs:54-58): prefix * One + suffix; all of it is linear in the bits
+                        const H::Fr rs_c = H::add(rs_acc, H::mul(c, rs_weight(j)));
+                        const uint64_t chunk_val = (uint64_t)b << suffix_len;         // the chunk's remaining bits at their significance
+                        const H::Fr val = H::add(H::mul(H::add(rs_c, H::from_u64(bound >= 64 ? 0 : chunk_val >> bound)), q1), qv(2));
+                        acc = H::add(acc, H::add(val, H::mul(gamma, idt)));
+                        continue;
+                    }
                     if (mode == 0) {
                         const H::Fr val = H::mul(not_msb, H::add(H::mul(H::add(word_c, bs), q1), qs));
                         acc = H::add(acc, H::add(val, H::mul(gamma, idt)));
@@ -314,6 +329,7 @@ struct PsLookup : atlas_instance {
             v.swap(nv);
             if (j >= 1) word_acc = H::add(word_acc, H::mul(rf, pow2(N - 1 - j)));
             sid_acc = H::add(sid_acc, H::mul(rf, weight(j)));
+            if (mode == 4) rs_acc = H::add(rs_acc, H::mul(rf, rs_weight(j)));
             if (mode == 3) {
                 const H::Fr w = j < 2 ? H::sub(pow2(31 - j / 2), pow2(32)) : pow2(31 - j / 2);
                 if (j % 2 == 0) lop_acc = H::add(lop_acc, H::mul(rf, w));
@@ -341,6 +357,7 @@ struct PsLookup : atlas_instance {
                 // val = Val~(r_address), raf_val = gamma * SId~(r_address)   (mod.rs:523-548)
                 const H::Fr val = H::mul(H::sub(H::one(), r_addr[0]), word_acc);
                 wv = mode == 1 ? sid_acc : H::add(val, H::mul(gamma, sid_acc));            // identity_range_check.rs:377-380
+                if (mode == 4) wv = H::add(rs_acc, H::mul(gamma, sid_acc));
                 if (mode == 3) wv = H::add(lt_acc, H::add(H::mul(gamma, lop_acc), H::mul(H::mul(gamma, gamma), rop_acc)));   // binary.rs:108-116
                 if (mode == 2) {                                      // ClampBoundedTable::evaluate_mle at r_address
                     const H::Fr U = H::from_u64(((uint64_t)1 << bound) - 1);
@@ -417,6 +434,15 @@ int atlas_ps_shout_clamp_new(const uint64_t* lookup_indices, size_t log_T, size_
     if (bound == 0 || bound + 1 >= xlen || bound > 31) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: 1 <= BOUND <= 31 and BOUND < X_LEN - 1");
     if (log_T == 0 || log_T > 25) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: 1 <= log_T <= 25");
     return ps_new(lookup_indices, log_T, xlen, 8, 2, r_node_output, gamma, out, bound, symmetric != 0);
+}
+
+int atlas_ps_shout_rshift_new(const uint64_t* lookup_indices, size_t log_T, size_t xlen, size_t shift, const atlas_fr_t* r_node_output,
+                              const atlas_fr_t* gamma, atlas_instance_t* out) {
+    NEED_INIT();
+    if (!lookup_indices || !r_node_output || !gamma || !out) return fail(ATLAS_EINVAL, "ps_shout_rshift_new: null argument");
+    if ((xlen != 16 && xlen != 32) || shift >= xlen || log_T == 0 || log_T > 25)
+        return fail(ATLAS_EINVAL, "ps_shout_rshift_new: xlen must be 16 or 32, shift < xlen, 1 <= log_T <= 25");
+    return ps_new(lookup_indices, log_T, xlen, 8, 4, r_node_output, gamma, out, shift, true);
 }
 
 int atlas_ps_shout_ult_new(const uint64_t* lookup_indices, size_t log_T, const atlas_fr_t* r_node_output, const atlas_fr_t* gamma,

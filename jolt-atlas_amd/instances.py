@@ -148,6 +148,16 @@ def ps_shout_clamp(lookup_indices, xlen, bound, symmetric, r_node_output, gamma)
     return Instance(h)
 
 
+def ps_shout_rshift(lookup_indices, xlen, shift, r_node_output, gamma):
+    """ps_read_raf_prover for RightShiftTable<xlen> by `shift` bits (lookup_tables/right_shift.rs; Sin/Cos downscale)."""
+    idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)
+    rn = np.ascontiguousarray(r_node_output, dtype=np.uint64); g = _fr(gamma)
+    h = C.c_void_p()
+    _check(lib.atlas_ps_shout_rshift_new(idx.ctypes.data_as(C.c_void_p), C.c_size_t(len(rn)), C.c_size_t(xlen), C.c_size_t(shift),
+                                         _p(rn), _p(g), C.byref(h)))
+    return Instance(h)
+
+
 def ps_shout_ult(lookup_indices, r_node_output, gamma):
     """binary ps_read_raf_prover with UnsignedLessThanTable<32> (ps_shout/binary.rs:148-200); indices = interleave_bits(x, y)."""
     idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)

@@ -133,6 +133,16 @@ def ps_relu(lookup_indices, N, r_node, gamma):
     return I
 
 
+def ps_rshift(lookup_indices, N, shift, r_node, gamma):
+    """The same unary read-raf prover over RightShiftTable<N> (lookup_tables/right_shift.rs), D = shift."""
+    idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)
+    rn = np.ascontiguousarray(r_node, dtype=np.uint64); g = np.ascontiguousarray(gamma, dtype=np.uint64).reshape(1, 4)
+    I = Instance(PS_RELU, N + len(rn))
+    I.keep = [idx, rn, g]
+    orc.lib.orc_ps_rshift_init(I.st, idx.ctypes.data_as(C.c_void_p), C.c_size_t(N), C.c_size_t(shift), C.c_size_t(len(rn)), orc._p(rn), orc._p(g))
+    return I
+
+
 PS_IDENTITY = 8
 
 

@@ -37,7 +37,8 @@ static void init_phase(orc_ps_relu *S, size_t phase) {                      /* m
         if (sb) { fr_t w, x; fr_from_i64((int64_t)sb, &w); fr_mul(&S->u[t], &w, &x); fr_add(&S->RQ[1][y], &x, &S->RQ[1][y]); }
         /* init_suffix_polys (mod.rs:304-335): suffixes [One, WordNoMSB], t as u32 */
         fr_add(&S->Q[0][y], &S->u[t], &S->Q[0][y]);
-        const uint32_t tw = (uint32_t)(sb % ((uint64_t)1 << (S->N - 1)));
+        /* table 1: suffixes [One, TrigRightShift], suffix_mle = bits >> D (suffixes/right_shift.rs:12-17) */
+        const uint32_t tw = S->table == 1 ? (uint32_t)(sb >> S->shift) : (uint32_t)(sb % ((uint64_t)1 << (S->N - 1)));
         if (tw) { fr_t w, x; fr_from_u64(tw, &w); fr_mul(&S->u[t], &w, &x); fr_add(&S->Q[1][y], &x, &S->Q[1][y]); }
     }
     S->Q_len = m;
@@ -58,8 +59,9 @@ static void init_phase(orc_ps_relu *S, size_t phase) {                      /* m
     fr_one(&S->v[phase][0]); S->v_len[phase] = 1;                           /* v[phase].reset(1) */
 }
 
-void orc_ps_relu_init(orc_ps_relu *S, const uint64_t *idx, size_t N, size_t log_T, const fr_t *r_node, const fr_t *gamma) {
+static void ps_unary_init(orc_ps_relu *S, const uint64_t *idx, size_t N, size_t log_T, const fr_t *r_node, const fr_t *gamma, int table, size_t shift) {
     memset(S, 0, sizeof *S);
+    S->table = table; S->shift = shift;
     S->N = N; S->log_T = log_T; S->log_m = N / 8; S->m = (size_t)1 << S->log_m; S->T = (size_t)1 << log_T;
     S->idx = idx; S->gamma = *gamma;
     S->u = (fr_t *)malloc(S->T * sizeof(fr_t)); orc_eq_evals(r_node, log_T, 0, S->u);        /* mod.rs:234 */
@@ -68,6 +70,13 @@ void orc_ps_relu_init(orc_ps_relu *S, const uint64_t *idx, size_t N, size_t log_
     for (int p = 0; p < 8; p++) S->v[p] = (fr_t *)calloc(S->m, sizeof(fr_t));
     gse_init(&S->eq, r_node, log_T);
     init_phase(S, 0);
+}
+
+void orc_ps_relu_init(orc_ps_relu *S, const uint64_t *idx, size_t N, size_t log_T, const fr_t *r_node, const fr_t *gamma) {
+    ps_unary_init(S, idx, N, log_T, r_node, gamma, 0, 0);
+}
+void orc_ps_rshift_init(orc_ps_relu *S, const uint64_t *idx, size_t N, size_t shift, size_t log_T, const fr_t *r_node, const fr_t *gamma) {
+    ps_unary_init(S, idx, N, log_T, r_node, gamma, 1, shift);
 }
 
 void orc_ps_relu_free(orc_ps_relu *S) {
@@ -106,6 +115,28 @@ static void prefix_word_no_msb(const orc_ps_relu *S, const fr_t *r_x, uint32_t c
     *o = word;
 }
 
+/* RightShiftPrefix::prefix_mle (prefixes/right_shift.rs:16-64), D = S->shift */
+static void prefix_rshift(const orc_ps_relu *S, const fr_t *r_x, uint32_t c, uint64_t b, size_t blen, size_t j, fr_t *o) {
+    const size_t XLEN = S->N, D = S->shift;
+    if (j + blen >= XLEN || D >= XLEN) { fr_zero(o); return; }
+    const size_t ubound_index = XLEN - D - 1;
+    fr_t result, w, t, cc; fr_from_u64(c, &cc);
+    if (S->has_rs) result = S->cp_rs; else fr_zero(&result);
+    if (r_x) {
+        if (j > 0) {
+            const size_t prev_index = j - 1;
+            if (prev_index <= ubound_index) { fr_pow2((unsigned)(ubound_index - prev_index), &w); fr_mul(&w, r_x, &t); fr_add(&result, &t, &result); }
+        }
+        if (j <= ubound_index) { fr_pow2((unsigned)(ubound_index - j), &w); fr_mul(&w, &cc, &t); fr_add(&result, &t, &result); }
+    } else if (j <= ubound_index) { fr_pow2((unsigned)(ubound_index - j), &w); fr_mul(&w, &cc, &t); fr_add(&result, &t, &result); }
+    const size_t left_shift = XLEN - 1 - j - blen;
+    fr_from_u64((b << left_shift) >> D, &t); fr_add(&result, &t, &result);
+    *o = result;
+}
+static void combine_rshift(const fr_t *prefix, const fr_t *s_one, const fr_t *s_rs, fr_t *o) {      /* right_shift.rs:54-58 */
+    fr_t a; fr_mul(prefix, s_one, &a); fr_add(&a, s_rs, o);
+}
+
 static void combine(const fr_t *p_notmsb, const fr_t *p_word, const fr_t *s_one, const fr_t *s_relu, fr_t *o) {   /* relu.rs:55-59 */
     fr_t a, b; fr_mul(p_notmsb, p_word, &a); fr_mul(&a, s_one, &a); fr_mul(p_notmsb, s_relu, &b); fr_add(&a, &b, o);
 }
@@ -118,6 +149,13 @@ size_t orc_ps_relu_message(orc_ps_relu *S, size_t round, const fr_t *claim, fr_t
         fr_t e0, e2l, e2h; fr_zero(&e0); fr_zero(&e2l); fr_zero(&e2h);
         for (size_t i = 0; i < half; i++) {                                  /* prover_msg_read_checking :354-417 */
             fr_t n0, w0, n2, w2, t;
+            if (S->table == 1) {
+                prefix_rshift(S, r_x, 0, i, blen, j, &w0); prefix_rshift(S, r_x, 2, i, blen, j, &w2);
+                combine_rshift(&w0, &S->Q[0][i], &S->Q[1][i], &t); fr_add(&e0, &t, &e0);
+                combine_rshift(&w2, &S->Q[0][i], &S->Q[1][i], &t); fr_add(&e2l, &t, &e2l);
+                combine_rshift(&w2, &S->Q[0][i + half], &S->Q[1][i + half], &t); fr_add(&e2h, &t, &e2h);
+                continue;
+            }
             prefix_not_msb(S, r_x, 0, j, &n0); prefix_word_no_msb(S, r_x, 0, i, blen, j, &w0);
             prefix_not_msb(S, r_x, 2, j, &n2); prefix_word_no_msb(S, r_x, 2, i, blen, j, &w2);
             combine(&n0, &w0, &S->Q[0][i], &S->Q[1][i], &t); fr_add(&e0, &t, &e0);
@@ -192,6 +230,13 @@ void orc_ps_relu_ingest(orc_ps_relu *S, size_t round, const fr_t *r) {      /* m
                 fr_pow2((unsigned)y_shift, &w); fr_mul(&w, r_y, &t); fr_add(&word, &t, &word);
                 S->cp_word = word; S->has_word = 1;
             }
+            if (S->table == 1 && S->shift < LOG_K) {                         /* prefixes/right_shift.rs:66-98 (suffix_len guard never fires) */
+                const size_t ubound_index = LOG_K - S->shift - 1;
+                fr_t res, w, t; if (S->has_rs) res = S->cp_rs; else fr_zero(&res);
+                if (j > 0 && j - 1 <= ubound_index) { fr_pow2((unsigned)(ubound_index - (j - 1)), &w); fr_mul(&w, r_x, &t); fr_add(&res, &t, &res); }
+                if (j <= ubound_index) { fr_pow2((unsigned)(ubound_index - j), &w); fr_mul(&w, r_y, &t); fr_add(&res, &t, &res); }
+                S->cp_rs = res; S->has_rs = 1;
+            }
         }
         if ((round + 1) % log_m == 0) {
             S->sid_cp = S->RP[0]; S->has_sid = 1;                            /* prefix_registry.update_checkpoints */
@@ -201,6 +246,7 @@ void orc_ps_relu_ingest(orc_ps_relu *S, size_t round, const fr_t *r) {      /* m
             /* val = combine(prefix checkpoints, suffix_mle(empty)) : One -> 1, WordNoMSB -> 0 */
             fr_t one, zero; fr_one(&one); fr_zero(&zero);
             combine(&S->cp_notmsb, &S->cp_word, &one, &zero, &S->val);
+            if (S->table == 1) { if (S->has_rs) S->val = S->cp_rs; else fr_zero(&S->val); }   /* One -> 1, RightShift suffix of no bits -> 0 */
             fr_mul(&S->gamma, &S->sid_cp, &S->raf_val);                       /* unary.rs:85-88 */
             S->ra = (fr_t *)malloc(S->T * sizeof(fr_t)); S->ra_len = S->T;    /* init_log_t_rounds :419-446 */
             for (size_t t = 0; t < S->T; t++) {

@@ -15,9 +15,14 @@ typedef struct {
     int has_notmsb, has_word, has_sid;
     fr_t r[160];
     gse_t eq;
+    int table;            /* 0 = ReluTable<N>, 1 = RightShiftTable<N> by `shift` bits (lookup_tables/right_shift.rs) */
+    size_t shift;
+    fr_t cp_rs; int has_rs;
 } orc_ps_relu;
 /* lookup indices: T = 2^log_T N-bit values; N = 16, 32 or 64; r_node: log_T Fr (big-endian) */
 void   orc_ps_relu_init(orc_ps_relu *S, const uint64_t *idx, size_t N, size_t log_T, const fr_t *r_node, const fr_t *gamma);
+/* same prover over RightShiftTable<N>: Val(k) = k >> shift (unsigned), RAF = SignedIdentity */
+void   orc_ps_rshift_init(orc_ps_relu *S, const uint64_t *idx, size_t N, size_t shift, size_t log_T, const fr_t *r_node, const fr_t *gamma);
 void   orc_ps_relu_free(orc_ps_relu *S);
 size_t orc_ps_relu_message(orc_ps_relu *S, size_t round, const fr_t *claim, fr_t *coeffs);
 void   orc_ps_relu_ingest(orc_ps_relu *S, size_t round, const fr_t *r);

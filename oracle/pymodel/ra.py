@@ -309,6 +309,21 @@ class PsReluModel:
         return [self.ra[0]]
 
 
+class PsRightShiftModel(PsReluModel):
+    """The same read-raf sumcheck over RightShiftTable<N> (lookup_tables/right_shift.rs:17-43): Val~(x) =
+    sum_{i <= N-1-D} x_i 2^(N-1-i-D), the multilinear extension of k >> D; RAF = SignedIdentity."""
+
+    def __init__(self, idx, N, shift, r_node, gamma):
+        super().__init__(idx, N, r_node, gamma)
+        self.shift = shift
+
+    def _W(self, x):
+        N, D = self.N, self.shift
+        val = sum(x[i] * (1 << (N - 1 - i - D)) for i in range(N - D)) % FR
+        sid = (sum(x[i] * (1 << (N - 1 - i)) for i in range(N)) - x[0] * (1 << N)) % FR
+        return (val + self.gamma * sid) % FR
+
+
 class PsIdentityModel(PsReluModel):
     """IdentityRC: sum_{k,t} eq(r_node,t) [k = idx_t] Id(k), Id~(x) = sum_i x_i 2^(L-1-i)
     (identity_range_check.rs:196-420), same closed-form evaluation as PsReluModel."""

@@ -72,6 +72,63 @@ def test_ps_shout_relu_bit_exact(atlas, N, log_T, mode):
 F_MINUS_ONE = 21888242871839275222246405745257275088548364400416034343698204186575808495616
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("N,shift,log_T", [(16, 1, 1), (16, 5, 6), (32, 1, 3), (32, 3, 10), (32, 7, 12), (32, 0, 4), (32, 31, 5)])
+def test_ps_shout_right_shift_bit_exact(atlas, N, shift, log_T, mode):
+    """RightShiftTable<N> read-raf (Sin / Cos trig downscale): device prover vs the oracle, both challenge modes."""
+    import ctypes as C
+    from oracle import orc, orc_ra as OR
+    from jolt_atlas_amd import instances as I
+    A = atlas
+    orc.lib.fr_from_i64.argtypes = [C.c_int64, C.c_void_p]
+    A.set_challenge_mode(mode); orc.lib.orc_set_challenge_mode(mode)
+    try:
+        T = 1 << log_T
+        rng = np.random.default_rng(N * 100 + shift * 7 + log_T)
+        idx = rng.integers(0, 1 << 20, size=T, dtype=np.uint64) if N == 32 else rng.integers(0, 1 << N, size=T, dtype=np.uint64)
+        idx[0] = (1 << N) - 1
+        if T > 2:
+            idx[1] = 0; idx[2] = 1 << (N - 1)
+        r_node, gamma = orc.random_fr(log_T, 5), orc.random_fr(1, 6)[0]
+        # input claim: sum_t eq(r_node, t) ((idx_t >> shift) + gamma * signed(idx_t))
+        E = orc.eq_evals(r_node)
+        acc = orc.from_ints([0])[0]
+        for t, k in enumerate(idx):
+            k = int(k)
+            x = k - (1 << N) if k >> (N - 1) else k
+            w = orc.fr_array(1)
+            orc.lib.fr_from_i64(x, orc._p(w))
+            term = orc.fr_add_arr(orc.from_ints([k >> shift])[0], orc.fr_mul_arr(gamma, w[0]))
+            acc = orc.fr_add_arr(acc, orc.fr_mul_arr(E[t], term))
+        claim = acc
+        t_o = orc.new_transcript(b"ps_rshift")
+        o = OR.ps_rshift(idx, N, shift, r_node, gamma)
+        rows_o, ch_o = o.prove(claim, t_o)
+        inst = I.ps_shout_rshift(idx, N, shift, r_node, gamma)
+        assert inst.num_rounds() == N + log_T and inst.degree() == 2
+        t_g = A.Blake2bTranscript(b"ps_rshift")
+        rows_g, ch_g = inst.prove(claim, t_g)
+        assert ch_g == ch_o
+        assert len(rows_g) == len(rows_o) and all(np.array_equal(a, b) for a, b in zip(rows_g, rows_o))
+        assert t_g.state == t_o.state_bytes()
+        if log_T <= 6:          # final claim: ra(r_address, r_cycle)
+            rs = orc.challenges_to_fr(ch_g)
+            r_addr, r_cyc = rs[:N], rs[N:][::-1]
+            one = orc.from_ints([1])[0]
+            vals = []
+            for k in idx:
+                w = one
+                for i in range(N):
+                    bit = (int(k) >> (N - 1 - i)) & 1
+                    f = r_addr[i] if bit else orc.fr_add_arr(one, orc.fr_mul_arr(orc.from_ints([F_MINUS_ONE])[0], r_addr[i]))
+                    w = orc.fr_mul_arr(w, f)
+                vals.append(w)
+            assert np.array_equal(inst.final_claims()[0], orc.evaluate(np.stack(vals), np.ascontiguousarray(r_cyc)))
+        inst.free()
+    finally:
+        A.set_challenge_mode(0); orc.lib.orc_set_challenge_mode(0)
+
+
 def test_ps_shout_rejects_unsupported_widths(atlas):
     from oracle import orc
     from jolt_atlas_amd import instances as I

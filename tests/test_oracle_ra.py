@@ -238,6 +238,32 @@ def test_ps_shout_relu_oracle_matches_closed_form_model(N, log_T):
     assert bytes(to.state) == tp.state
 
 
+@pytest.mark.parametrize("N,shift,log_T", [(16, 1, 2), (16, 5, 3), (32, 1, 2), (32, 3, 3), (32, 7, 1), (32, 0, 2), (16, 15, 2)])
+def test_ps_shout_right_shift_oracle_matches_closed_form_model(N, shift, log_T):
+    """RightShiftTable<N> (k >> D, lookup_tables/right_shift.rs) through the same unary read-raf prover: the
+    oracle's literal prefix checkpoints / suffix tables against the closed-form model."""
+    T = 1 << log_T
+    rng = np.random.default_rng(N + shift + log_T)
+    idx = [int(x) for x in rng.integers(0, 1 << N, size=T, dtype=np.uint64)]
+    idx[0] = (1 << N) - 1
+    if T > 2:
+        idx[1] = 0; idx[2] = (1 << shift) - 1 if shift else 1      # everything shifted out
+    r_node, gamma = _rand(log_T, 3), _rand(1, 4)[0] >> 130
+    model = PR.PsRightShiftModel(idx, N, shift, r_node, gamma)
+    for k in idx:                               # materialize_entry vs the MLE on boolean inputs
+        bits = [(k >> (N - 1 - i)) & 1 for i in range(N)]
+        signed = k - (1 << N) if k >> (N - 1) else k
+        assert model._W(bits) == ((k >> shift) + gamma * signed) % F.FR
+    claim = model.input_claim()
+    rows_p, raw_p, tp = _prove_py(model, claim, b"ps_rshift")
+    inst = OR.ps_rshift(idx, N, shift, orc.from_ints(r_node), orc.from_ints([gamma])[0])
+    to = orc.new_transcript(b"ps_rshift")
+    rows_o, raw_o = inst.prove(orc.from_ints([claim])[0], to)
+    assert raw_o == raw_p
+    assert [orc.to_ints(r) for r in rows_o] == rows_p
+    assert bytes(to.state) == tp.state
+
+
 @pytest.mark.parametrize("log_K,phases,log_T", [(8, 4, 2), (16, 8, 3), (16, 2, 1), (12, 3, 4), (32, 8, 2)])
 def test_identity_range_check_oracle_matches_closed_form_model(log_K, phases, log_T):
     T = 1 << log_T
