@@ -288,6 +288,16 @@ int atlas_ps_shout_relu_new(const uint64_t *lookup_indices, size_t log_T, size_t
 int atlas_ps_shout_clamp_new(const uint64_t *lookup_indices, size_t log_T, size_t xlen, size_t bound,
                              int symmetric, const atlas_fr_t *r_node_output, const atlas_fr_t *gamma,
                              atlas_instance_t *out);
+/* Element-wise operator provers (jolt-atlas-core/src/onnx_proof/ops/add.rs:283-304, sub.rs:267-288,
+ * neg.rs:206-222, square.rs:163-183, mul.rs:160-199, iff.rs:189-224, cube.rs:159-171): sum_x eq(r_node_output, x)
+ * f(operands(x)) with a LowToHigh GruenSplitEqPolynomial; n_vars rounds; degree 2 (Add, Sub, Neg), 3 (Square, Mul,
+ * Iff) or 4 (Cube, through compute_mle_product_sum).  `operands` in the order the reference caches their openings
+ * (Iff: mask, a, b), each an atlas_poly_t of 2^n_vars coefficients (LargeScalars or I32Scalars; not consumed).
+ * final claims = the operands' final claims in that order. */
+enum { ATLAS_EW_ADD = 0, ATLAS_EW_SUB = 1, ATLAS_EW_NEG = 2, ATLAS_EW_SQUARE = 3, ATLAS_EW_IFF = 4, ATLAS_EW_MUL = 5,
+       ATLAS_EW_CUBE = 6 };
+int atlas_elementwise_new(int op, const atlas_poly_t *operands, size_t n_operands, const atlas_fr_t *r_node_output,
+                          size_t n_vars, atlas_instance_t *out);
 /* The same unary prover over RightShiftTable<XLEN> (joltworks/src/lookup_tables/right_shift.rs:17-60; used by
  * the Sin / Cos trig downscale, jolt-atlas-core/src/onnx_proof/ops/sin.rs:108, cos.rs:113): Val(k) = k >> shift
  * (unsigned; shift = TRIG_DOWNSCALE_BITS in the reference), prefix TrigRightShift, suffixes [One, TrigRightShift],

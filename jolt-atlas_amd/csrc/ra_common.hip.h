@@ -123,8 +123,8 @@ struct RaRows {
     Fr* d_sums = nullptr;       // max(d, 2) Fr
     size_t K = 0;
 
-    int alloc(size_t d_, size_t T) {
-        d = d_; len = T; K = d > 2 ? d : 2;
+    int alloc(size_t d_, size_t T, size_t k_min = 2) {     // K = width of a row of partial sums
+        d = d_; len = T; K = d > k_min ? d : k_min;
         HIP_TRY(hipMalloc(&buf[0], d * T * sizeof(Fr)));
         HIP_TRY(hipMalloc(&buf[1], d * (T > 1 ? T / 2 : 1) * sizeof(Fr)));
         stride[0] = T; stride[1] = T > 1 ? T / 2 : 1;

@@ -148,6 +148,19 @@ def ps_shout_clamp(lookup_indices, xlen, bound, symmetric, r_node_output, gamma)
     return Instance(h)
 
 
+EW_ADD, EW_SUB, EW_NEG, EW_SQUARE, EW_IFF, EW_MUL, EW_CUBE = range(7)
+
+
+def elementwise(op, operands, r_node_output):
+    """Element-wise operator prover (ops/add.rs, sub.rs, neg.rs, square.rs, iff.rs, mul.rs, cube.rs) over device
+    polynomials (MultilinearPolynomial handles; not consumed)."""
+    rn = np.ascontiguousarray(r_node_output, dtype=np.uint64)
+    hs = (C.c_void_p * len(operands))(*[o.h for o in operands])
+    h = C.c_void_p()
+    _check(lib.atlas_elementwise_new(C.c_int(op), hs, C.c_size_t(len(operands)), _p(rn), C.c_size_t(len(rn)), C.byref(h)))
+    return Instance(h)
+
+
 def ps_shout_rshift(lookup_indices, xlen, shift, r_node_output, gamma):
     """ps_read_raf_prover for RightShiftTable<xlen> by `shift` bits (lookup_tables/right_shift.rs; Sin/Cos downscale)."""
     idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)

@@ -1,0 +1,103 @@
+/* TEST INFRASTRUCTURE ONLY — CPU oracle, never linked into or called by the product.
+ * parity unpinned by reference vectors (the reference holds none for these provers); pinned against the
+ * brute-force models in oracle/pymodel/ra.py (tests/test_oracle_ra.py).
+ *
+ * The element-wise operator provers of jolt-atlas-core/src/onnx_proof/ops/: one GruenSplitEqPolynomial over
+ * r_node_output (LowToHigh), operands bound LowToHigh, and per round
+ *   add.rs:283-296     [lo0 + ro0]                              gruen_poly_deg_2
+ *   sub.rs:267-280     [lo0 - ro0]                              gruen_poly_deg_2
+ *   neg.rs:206-217     [-o0]                                    gruen_poly_deg_2
+ *   square.rs:163-178  [o0 o0, o_inf o_inf]                     gruen_poly_deg_3
+ *   mul.rs:160-185     [lo0 ro0, lo_inf ro_inf]                 gruen_poly_deg_3
+ *   iff.rs:189-216     [m0 a0 + (1 - m0) b0, m_inf a_inf + f b_inf],  f = (1 - m1) - (1 - m0)   gruen_poly_deg_3
+ *   cube.rs:159-166    compute_mle_product_sum(3, operand)      (mles_product_sum.rs:41-55, degree 4)
+ * with par_fold_out_in_unreduced (split_eq_poly.rs:526-597) = sum_{x_out} E_out sum_{x_in} E_in f(g). */
+#include <stdlib.h>
+#include <string.h>
+#include "elementwise.h"
+
+void orc_elementwise_init(orc_elementwise *S, int op, const fr_t *const *operands, size_t n_ops, size_t n_vars, const fr_t *r_node_output) {
+    memset(S, 0, sizeof *S);
+    S->op = op; S->n_ops = n_ops; S->n_vars = n_vars; S->len = (size_t)1 << n_vars;
+    for (size_t i = 0; i < n_ops; i++) { S->x[i] = (fr_t *)malloc(S->len * sizeof(fr_t)); memcpy(S->x[i], operands[i], S->len * sizeof(fr_t)); }
+    gse_init(&S->eq, r_node_output, n_vars);
+}
+
+void orc_elementwise_free(orc_elementwise *S) { for (size_t i = 0; i < S->n_ops; i++) free(S->x[i]); gse_free(&S->eq); }
+
+/* gruen_poly_deg_2 (split_eq_poly.rs:379-428), LowToHigh */
+static size_t gruen_deg2(const gse_t *E, const fr_t *q0, const fr_t *claim, fr_t *coeffs) {
+    fr_t eq1, eq0, eqm, eq2, c0, c1, l1, l2, inv, ev2[2], hint;
+    fr_mul(&E->scalar, &E->w[E->current_index - 1], &eq1); fr_sub(&E->scalar, &eq1, &eq0);
+    fr_sub(&eq1, &eq0, &eqm); fr_add(&eq1, &eqm, &eq2);
+    fr_mul(&eq0, q0, &c0); fr_sub(claim, &c0, &c1);
+    fr_inv(&eq1, &inv); fr_mul(&c1, &inv, &l1);
+    fr_add(&l1, &l1, &l2); fr_sub(&l2, q0, &l2);
+    ev2[0] = c0; fr_mul(&eq2, &l2, &ev2[1]); fr_add(&c0, &c1, &hint);
+    return orc_unipoly_from_evals_and_hint(&hint, ev2, 2, coeffs);
+}
+
+size_t orc_elementwise_message(orc_elementwise *S, const fr_t *claim, fr_t *coeffs) {
+    const gse_t *E = &S->eq;
+    const fr_t *e_out = E->Eout[E->out_top], *e_in = E->Ein[E->in_top];
+    const size_t out_len = (size_t)1 << E->out_top, in_len = (size_t)1 << E->in_top;
+    if (S->op == ORC_EW_CUBE) {                     /* grid [1, 2, inf] of the product of three copies, then the shared finish */
+        fr_t sums[3], inner[3];
+        for (int k = 0; k < 3; k++) fr_zero(&sums[k]);
+        for (size_t xo = 0; xo < out_len; xo++) {
+            for (int k = 0; k < 3; k++) fr_zero(&inner[k]);
+            for (size_t xi = 0; xi < in_len; xi++) {
+                const size_t g = (xo << E->in_top) | xi;
+                fr_t p0 = S->x[0][2 * g], dl, p1, p2, v[3], t;
+                fr_sub(&S->x[0][2 * g + 1], &p0, &dl); fr_add(&p0, &dl, &p1); fr_add(&p1, &dl, &p2);
+                fr_mul(&p1, &p1, &v[0]); fr_mul(&v[0], &p1, &v[0]);
+                fr_mul(&p2, &p2, &v[1]); fr_mul(&v[1], &p2, &v[1]);
+                fr_mul(&dl, &dl, &v[2]); fr_mul(&v[2], &dl, &v[2]);
+                for (int k = 0; k < 3; k++) { fr_mul(&e_in[xi], &v[k], &t); fr_add(&inner[k], &t, &inner[k]); }
+            }
+            for (int k = 0; k < 3; k++) { fr_t t; fr_mul(&e_out[xo], &inner[k], &t); fr_add(&sums[k], &t, &sums[k]); }
+        }
+        for (int k = 0; k < 3; k++) fr_mul(&sums[k], &E->scalar, &sums[k]);
+        return orc_finish_product_sum(sums, 3, claim, E, coeffs);
+    }
+    fr_t q0, qe; fr_zero(&q0); fr_zero(&qe);
+    for (size_t xo = 0; xo < out_len; xo++) {
+        fr_t in0, ine; fr_zero(&in0); fr_zero(&ine);
+        for (size_t xi = 0; xi < in_len; xi++) {
+            const size_t g = (xo << E->in_top) | xi;
+            fr_t c0, e, t, u, one; fr_zero(&e); fr_one(&one);
+            const fr_t *a = S->x[0], *b = S->n_ops > 1 ? S->x[1] : 0, *c = S->n_ops > 2 ? S->x[2] : 0;
+            switch (S->op) {
+                case ORC_EW_ADD: fr_add(&a[2 * g], &b[2 * g], &c0); break;
+                case ORC_EW_SUB: fr_sub(&a[2 * g], &b[2 * g], &c0); break;
+                case ORC_EW_NEG: fr_zero(&t); fr_sub(&t, &a[2 * g], &c0); break;
+                case ORC_EW_SQUARE: fr_mul(&a[2 * g], &a[2 * g], &c0); fr_sub(&a[2 * g + 1], &a[2 * g], &t); fr_mul(&t, &t, &e); break;
+                case ORC_EW_MUL:
+                    fr_mul(&a[2 * g], &b[2 * g], &c0);
+                    fr_sub(&a[2 * g + 1], &a[2 * g], &t); fr_sub(&b[2 * g + 1], &b[2 * g], &u); fr_mul(&t, &u, &e); break;
+                default: {                          /* Iff: a = mask, b = a_operand, c = b_operand */
+                    fr_t m_inf, a_inf, b_inf, nm0, nm1, f;
+                    fr_sub(&a[2 * g + 1], &a[2 * g], &m_inf); fr_sub(&b[2 * g + 1], &b[2 * g], &a_inf); fr_sub(&c[2 * g + 1], &c[2 * g], &b_inf);
+                    fr_sub(&one, &a[2 * g], &nm0); fr_sub(&one, &a[2 * g + 1], &nm1);
+                    fr_mul(&a[2 * g], &b[2 * g], &t); fr_mul(&nm0, &c[2 * g], &u); fr_add(&t, &u, &c0);
+                    fr_sub(&nm1, &nm0, &f);
+                    fr_mul(&m_inf, &a_inf, &t); fr_mul(&f, &b_inf, &u); fr_add(&t, &u, &e);
+                }
+            }
+            fr_mul(&e_in[xi], &c0, &t); fr_add(&in0, &t, &in0);
+            fr_mul(&e_in[xi], &e, &t); fr_add(&ine, &t, &ine);
+        }
+        fr_t t; fr_mul(&e_out[xo], &in0, &t); fr_add(&q0, &t, &q0); fr_mul(&e_out[xo], &ine, &t); fr_add(&qe, &t, &qe);
+    }
+    if (S->op == ORC_EW_ADD || S->op == ORC_EW_SUB || S->op == ORC_EW_NEG) return gruen_deg2(E, &q0, claim, coeffs);
+    gse_gruen_deg3(E, &q0, &qe, claim, coeffs);
+    return 4;
+}
+
+void orc_elementwise_ingest(orc_elementwise *S, const fr_t *r) {
+    for (size_t i = 0; i < S->n_ops; i++) orc_bind(S->x[i], S->len, r, ORC_LOW_TO_HIGH);
+    S->len /= 2;
+    gse_bind(&S->eq, r);
+}
+
+void orc_elementwise_finals(const orc_elementwise *S, fr_t *out) { for (size_t i = 0; i < S->n_ops; i++) out[i] = S->x[i][0]; }

@@ -143,6 +143,28 @@ def ps_rshift(lookup_indices, N, shift, r_node, gamma):
     return I
 
 
+ELEMENTWISE = 11
+EW_ADD, EW_SUB, EW_NEG, EW_SQUARE, EW_IFF, EW_MUL, EW_CUBE = range(7)
+
+
+def elementwise(op, operands, r_node_output):
+    """Element-wise operator prover (ops/add.rs, sub.rs, neg.rs, square.rs, mul.rs, iff.rs, cube.rs)."""
+    ops = [np.ascontiguousarray(o, dtype=np.uint64) for o in operands]
+    rn = np.ascontiguousarray(r_node_output, dtype=np.uint64)
+    ptrs = (C.c_void_p * len(ops))(*[o.ctypes.data for o in ops])
+    I = Instance(ELEMENTWISE, len(rn))
+    I.keep = [ops, ptrs, rn]
+    orc.lib.orc_elementwise_init(I.st, C.c_int(op), ptrs, C.c_size_t(len(ops)), C.c_size_t(len(rn)), orc._p(rn))
+    I.n_ops = len(ops)
+
+    def finals():
+        out = orc.fr_array(I.n_ops)
+        orc.lib.orc_elementwise_finals(I.st, orc._p(out))
+        return out
+    I.finals = finals
+    return I
+
+
 PS_IDENTITY = 8
 
 

@@ -379,3 +379,52 @@ class PsUltModel(PsReluModel):
         lo = (lo - v[0] * (1 << 32)) % FR
         ro = (ro - v[1] * (1 << 32)) % FR
         return (lt + self.gamma * lo + self.gamma * self.gamma * ro) % FR
+
+
+class ElementwiseModel:
+    """sum_x eq(r_node_output, x) f(operands(x)) for the element-wise operators (ops/add.rs, sub.rs, neg.rs,
+    square.rs, mul.rs, iff.rs, cube.rs): dense tables, round polynomial by evaluation at 0..deg and
+    interpolation.  Add / Sub / Neg answer with 3 coefficients, Square / Mul / Iff with 4 (UniPoly::from_evals
+    keeps the length), Cube goes through from_coeff (trimmed) like every mles_product_sum user."""
+
+    F = {
+        "add": (2, lambda v: (v[0] + v[1]) % FR),
+        "sub": (2, lambda v: (v[0] - v[1]) % FR),
+        "neg": (2, lambda v: (-v[0]) % FR),
+        "square": (3, lambda v: v[0] * v[0] % FR),
+        "mul": (3, lambda v: v[0] * v[1] % FR),
+        "iff": (3, lambda v: (v[0] * v[1] + (1 - v[0]) * v[2]) % FR),
+        "cube": (4, lambda v: v[0] * v[0] % FR * v[0] % FR),
+    }
+
+    def __init__(self, op, operands, r_node_output):
+        self.op = op
+        self.deg, self.f = self.F[op]
+        self.x = [list(o) for o in operands]
+        self.eq = P.eq_evals(r_node_output)
+        self._n = len(r_node_output)
+
+    def num_rounds(self):
+        return self._n
+
+    def input_claim(self):
+        return sum(self.eq[j] * self.f([x[j] for x in self.x]) for j in range(len(self.eq))) % FR
+
+    def compute_message(self, rnd, previous_claim):
+        npts = self.deg + 1
+        ev = [0] * npts
+        for i in range(len(self.eq) // 2):
+            e = _ext(self.eq, i, npts)
+            cols = [_ext(x, i, npts) for x in self.x]
+            for X in range(npts):
+                ev[X] = (ev[X] + e[X] * self.f([c[X] for c in cols])) % FR
+        assert (ev[0] + ev[1]) % FR == previous_claim % FR
+        c = interpolate(ev)
+        return from_coeff(c) if self.op == "cube" else c
+
+    def ingest_challenge(self, r, rnd):
+        self.eq = P.bind(self.eq, r, L2H)
+        self.x = [P.bind(x, r, L2H) for x in self.x]
+
+    def finals(self):
+        return [x[0] for x in self.x]

@@ -16,6 +16,7 @@
 #include "ra.h"
 #include "opening.h"
 #include "psshout.h"
+#include "elementwise.h"
 
 /* ------------------------------------------------------------------ small helpers */
 static size_t trim(fr_t *c, size_t n) {                 /* UniPoly::from_coeff (unipoly.rs:39-52) */
@@ -142,7 +143,7 @@ void orc_ra_virtual_free(orc_ra_virtual *S) {
 }
 
 /* finish_mles_product_sum_from_evals (mles_product_sum.rs:330-376); returns the coefficient count */
-static size_t finish_product_sum(const fr_t *sum_evals, size_t d, const fr_t *claim, const gse_t *eq, fr_t *coeffs) {
+size_t orc_finish_product_sum(const fr_t *sum_evals, size_t d, const fr_t *claim, const gse_t *eq, fr_t *coeffs) {
     const fr_t r = eq->w[eq->current_index - 1];
     fr_t one, eq0, t, e0; fr_one(&one); fr_sub(&one, &r, &eq0);
     fr_mul(&r, &sum_evals[0], &t); fr_sub(claim, &t, &e0);
@@ -185,7 +186,7 @@ size_t orc_ra_virtual_message(orc_ra_virtual *S, const fr_t *claim, fr_t *coeffs
         for (size_t k = 0; k < d; k++) { fr_t t; fr_mul(&e_out[xo], &inner[k], &t); fr_add(&sums[k], &t, &sums[k]); }
     }
     for (size_t k = 0; k < d; k++) fr_mul(&sums[k], &E->scalar, &sums[k]);   /* :131 */
-    size_t n = finish_product_sum(sums, d, claim, E, coeffs);
+    size_t n = orc_finish_product_sum(sums, d, claim, E, coeffs);
     free(sums); free(inner); free(p0); free(dl);
     return n;
 }
@@ -337,6 +338,7 @@ static size_t inst_message(int kind, void *st, size_t round, const fr_t *claim, 
         case ORC_INST_PS_IDENTITY: return orc_ps_identity_message((orc_ps_identity *)st, round, claim, c);
         case ORC_INST_PS_CLAMP: return orc_ps_clamp_message((orc_ps_clamp *)st, round, claim, c);
         case ORC_INST_PS_ULT: return orc_ps_ult_message((orc_ps_ult *)st, round, claim, c);
+        case ORC_INST_ELEMENTWISE: return orc_elementwise_message((orc_elementwise *)st, claim, c);
         default: return orc_hamming_message((orc_hamming *)st, claim, c);
     }
 }
@@ -350,6 +352,7 @@ static void inst_ingest(int kind, void *st, size_t round, const fr_t *r) {
         case ORC_INST_PS_IDENTITY: orc_ps_identity_ingest((orc_ps_identity *)st, round, r); break;
         case ORC_INST_PS_CLAMP: orc_ps_clamp_ingest((orc_ps_clamp *)st, round, r); break;
         case ORC_INST_PS_ULT: orc_ps_ult_ingest((orc_ps_ult *)st, round, r); break;
+        case ORC_INST_ELEMENTWISE: orc_elementwise_ingest((orc_elementwise *)st, r); break;
         default: orc_hamming_ingest((orc_hamming *)st, r); break;
     }
 }

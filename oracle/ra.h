@@ -13,6 +13,8 @@ void gse_bind(gse_t *S, const fr_t *r);
 void gse_gruen_deg3(const gse_t *S, const fr_t *q0, const fr_t *qinf, const fr_t *claim, fr_t coeffs[4]);
 void orc_gauss_solve(fr_t *m, size_t n, fr_t *c);   /* rows of n+1 Fr: n x n system | rhs */
 void orc_unipoly_from_evals_toom(const fr_t *evals, size_t n, fr_t *coeffs);
+/* finish_mles_product_sum_from_evals (mles_product_sum.rs:330-376); returns the coefficient count */
+size_t orc_finish_product_sum(const fr_t *sum_evals, size_t d, const fr_t *claim, const gse_t *eq, fr_t *coeffs);
 
 enum { ORC_INST_RA_VIRTUAL = 2, ORC_INST_BOOLEANITY = 3, ORC_INST_HAMMING = 4 };
 

@@ -336,3 +336,31 @@ def test_ps_shout_unsigned_less_than_oracle_matches_closed_form_model(log_T):
     assert raw_o == raw_p
     assert [orc.to_ints(r) for r in rows_o] == rows_p
     assert bytes(to.state) == tp.state
+
+
+_EW = {"add": (0, 2), "sub": (1, 2), "neg": (2, 1), "square": (3, 1), "iff": (4, 3), "mul": (5, 2), "cube": (6, 1)}
+
+
+@pytest.mark.parametrize("op", sorted(_EW))
+@pytest.mark.parametrize("n_vars", [1, 2, 5])
+def test_elementwise_oracle_matches_naive_model(op, n_vars):
+    """oracle/elementwise.c (Gruen split-eq fold, gruen_poly_deg_2/3, product-sum finish for Cube) against the
+    dense-table model, transcript included."""
+    code, n_ops = _EW[op]
+    n = 1 << n_vars
+    rng = np.random.default_rng(code * 10 + n_vars)
+    # quantised tensors: small signed integers as field elements; the Iff mask is 0/1
+    operands = [[int(v) % F.FR for v in rng.integers(-(1 << 15), 1 << 15, size=n)] for _ in range(n_ops)]
+    if op == "iff":
+        operands[0] = [int(v) for v in rng.integers(0, 2, size=n)]
+    r_node = _rand(n_vars, 17)
+    model = PR.ElementwiseModel(op, operands, r_node)
+    claim = model.input_claim()
+    rows_p, raw_p, tp = _prove_py(model, claim, b"elementwise")
+    inst = OR.elementwise(code, [orc.from_ints(o) for o in operands], orc.from_ints(r_node))
+    to = orc.new_transcript(b"elementwise")
+    rows_o, raw_o = inst.prove(orc.from_ints([claim])[0], to)
+    assert raw_o == raw_p
+    assert [orc.to_ints(r) for r in rows_o] == rows_p
+    assert bytes(to.state) == tp.state
+    assert orc.to_ints(inst.finals()) == model.finals()
