@@ -295,9 +295,14 @@ int atlas_ps_shout_clamp_new(const uint64_t *lookup_indices, size_t log_T, size_
  * (Iff: mask, a, b), each an atlas_poly_t of 2^n_vars coefficients (LargeScalars or I32Scalars; not consumed).
  * final claims = the operands' final claims in that order. */
 enum { ATLAS_EW_ADD = 0, ATLAS_EW_SUB = 1, ATLAS_EW_NEG = 2, ATLAS_EW_SQUARE = 3, ATLAS_EW_IFF = 4, ATLAS_EW_MUL = 5,
-       ATLAS_EW_CUBE = 6 };
+       ATLAS_EW_CUBE = 6, ATLAS_EW_DIV = 7, ATLAS_EW_RSQRT = 8 };
+/* ATLAS_EW_DIV (ops/div.rs:329-362): operands (left, right, q, R), summand right q + R - left, degree 3.
+ * ATLAS_EW_RSQRT (ops/rsqrt.rs:390-433): operands (input, quotient, output, div_remainder, sqrt_remainder),
+ * constants (S^3, gamma), summand input quotient + div_remainder - S^3 + gamma (output^2 + sqrt_remainder -
+ * quotient), degree 3.  ScalarConstDiv (ops/scalar_const_div.rs:227-248) is ATLAS_EW_SUB over (left, R).
+ * `constants`: n_constants Fr, 2 for Rsqrt, 0 (may be NULL) otherwise. */
 int atlas_elementwise_new(int op, const atlas_poly_t *operands, size_t n_operands, const atlas_fr_t *r_node_output,
-                          size_t n_vars, atlas_instance_t *out);
+                          size_t n_vars, const atlas_fr_t *constants, size_t n_constants, atlas_instance_t *out);
 /* The same unary prover over RightShiftTable<XLEN> (joltworks/src/lookup_tables/right_shift.rs:17-60; used by
  * the Sin / Cos trig downscale, jolt-atlas-core/src/onnx_proof/ops/sin.rs:108, cos.rs:113): Val(k) = k >> shift
  * (unsigned; shift = TRIG_DOWNSCALE_BITS in the reference), prefix TrigRightShift, suffixes [One, TrigRightShift],

@@ -5,6 +5,8 @@
 //   add.rs:283-304  sub.rs:267-288  neg.rs:206-222      [q_constant]            gruen_poly_deg_2
 //   square.rs:163-183  mul.rs:160-199  iff.rs:189-224   [q_constant, q_quadratic] gruen_poly_deg_3
 //   cube.rs:159-171    compute_mle_product_sum(3, operand)  (mles_product_sum.rs:41-55): grid [1, 2, inf]
+//   div.rs:329-362 (left, right, q, R)   rsqrt.rs:390-433 (input, quotient, output, div_rem, sqrt_rem; S^3, gamma)
+//   scalar_const_div.rs:227-248 is the Sub fold over (left, R)
 // Operands are atlas_poly_t (Fr or I32Scalars; not consumed): the rows of the instance are Fr copies — the
 // first bind of a CompactPolynomial (compact_polynomial.rs:272-353) yields the same field values.
 // HBM per round: n_ops * len * 32 B read by the fold, the same read + half written by the bind.
@@ -13,10 +15,12 @@
 namespace {
 
 enum { EW_ADD = ATLAS_EW_ADD, EW_SUB = ATLAS_EW_SUB, EW_NEG = ATLAS_EW_NEG, EW_SQUARE = ATLAS_EW_SQUARE, EW_IFF = ATLAS_EW_IFF,
-       EW_MUL = ATLAS_EW_MUL, EW_CUBE = ATLAS_EW_CUBE };
+       EW_MUL = ATLAS_EW_MUL, EW_CUBE = ATLAS_EW_CUBE, EW_DIV = ATLAS_EW_DIV, EW_RSQRT = ATLAS_EW_RSQRT };
 
-constexpr int ew_outputs(int op) { return op == EW_CUBE ? 3 : (op == EW_SQUARE || op == EW_MUL || op == EW_IFF) ? 2 : 1; }
-constexpr int ew_operands(int op) { return op == EW_IFF ? 3 : (op == EW_ADD || op == EW_SUB || op == EW_MUL) ? 2 : 1; }
+struct EwConsts { Fr k[2]; };      // Rsqrt: S^3, gamma
+
+constexpr int ew_outputs(int op) { return op == EW_CUBE ? 3 : (op == EW_SQUARE || op == EW_MUL || op == EW_IFF || op == EW_DIV || op == EW_RSQRT) ? 2 : 1; }
+constexpr int ew_operands(int op) { return op == EW_RSQRT ? 5 : op == EW_DIV ? 4 : op == EW_IFF ? 3 : (op == EW_ADD || op == EW_SUB || op == EW_MUL) ? 2 : 1; }
 
 __global__ __launch_bounds__(RA_THREADS) void k_ew_from_i32(const int32_t* __restrict__ in, Fr* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * RA_THREADS)
@@ -26,7 +30,7 @@ __global__ __launch_bounds__(RA_THREADS) void k_ew_from_i32(const int32_t* __res
 // partials[block][k], k < ew_outputs(OP): the block's share of sum_g E_out E_in f_k(g)
 template <int OP>
 __global__ __launch_bounds__(RA_THREADS) void k_ew_fold(const Fr* __restrict__ rows, size_t stride, SplitEqView E, size_t n_groups,
-                                                        Fr* __restrict__ partials) {
+                                                        EwConsts C, Fr* __restrict__ partials) {
     constexpr int NQ = ew_outputs(OP);
     Fr acc[NQ];
 #pragma unroll
@@ -47,6 +51,19 @@ __global__ __launch_bounds__(RA_THREADS) void k_ew_fold(const Fr* __restrict__ r
             const Fr y0 = fe_load(rows + 2 * stride + 2 * g), y1 = fe_load(rows + 2 * stride + 2 * g + 1);
             v[0] = fr_add(y0, fr_mul(a0, fr_sub(x0, y0)));
             v[1] = fr_mul(fr_sub(a1, a0), fr_sub(fr_sub(x1, x0), fr_sub(y1, y0)));
+        } else if constexpr (OP == EW_DIV) {        // rows: left, right, q, R.  c0 = ro0 q0 + R0 - lo0;  e = ro_inf q_inf
+            const Fr r0 = fe_load(rows + stride + 2 * g), r1 = fe_load(rows + stride + 2 * g + 1);
+            const Fr q0 = fe_load(rows + 2 * stride + 2 * g), q1 = fe_load(rows + 2 * stride + 2 * g + 1);
+            v[0] = fr_sub(fr_add(fr_mul(r0, q0), fe_load(rows + 3 * stride + 2 * g)), a0);
+            v[1] = fr_mul(fr_sub(r1, r0), fr_sub(q1, q0));
+        } else if constexpr (OP == EW_RSQRT) {      // rows: input, quotient, output, div_rem, sqrt_rem
+            const Fr q0 = fe_load(rows + stride + 2 * g), q1 = fe_load(rows + stride + 2 * g + 1);
+            const Fr o0 = fe_load(rows + 2 * stride + 2 * g), o1 = fe_load(rows + 2 * stride + 2 * g + 1);
+            const Fr div0 = fr_sub(fr_add(fr_mul(a0, q0), fe_load(rows + 3 * stride + 2 * g)), C.k[0]);
+            const Fr sqrt0 = fr_sub(fr_add(fr_mul(o0, o0), fe_load(rows + 4 * stride + 2 * g)), q0);
+            const Fr od = fr_sub(o1, o0);
+            v[0] = fr_add(div0, fr_mul(C.k[1], sqrt0));
+            v[1] = fr_add(fr_mul(fr_sub(a1, a0), fr_sub(q1, q0)), fr_mul(C.k[1], fr_mul(od, od)));
         } else {                                    // cube: p(1)^3, p(2)^3, p_inf^3
             const Fr d = fr_sub(a1, a0), p2 = fr_add(a1, d);
             v[0] = fr_mul(fr_mul(a1, a1), a1); v[1] = fr_mul(fr_mul(p2, p2), p2); v[2] = fr_mul(fr_mul(d, d), d);
@@ -59,6 +76,7 @@ __global__ __launch_bounds__(RA_THREADS) void k_ew_fold(const Fr* __restrict__ r
 
 struct Elementwise : atlas_instance {
     int op = 0;
+    EwConsts consts{};
     RaRows rows;
     GseDev eq;
     size_t n_vars = 0, round_next = 0;
@@ -73,8 +91,8 @@ struct Elementwise : atlas_instance {
         const SplitEqView E = eq.view();
         const Fr* src = rows.buf[rows.cur]; const size_t st = rows.stride[rows.cur];
         switch (op) {
-#define EW_CASE(OP) case OP: k_ew_fold<OP><<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(src, st, E, n_groups, rows.partials); break;
-            EW_CASE(EW_ADD) EW_CASE(EW_SUB) EW_CASE(EW_NEG) EW_CASE(EW_SQUARE) EW_CASE(EW_IFF) EW_CASE(EW_MUL) EW_CASE(EW_CUBE)
+#define EW_CASE(OP) case OP: k_ew_fold<OP><<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(src, st, E, n_groups, consts, rows.partials); break;
+            EW_CASE(EW_ADD) EW_CASE(EW_SUB) EW_CASE(EW_NEG) EW_CASE(EW_SQUARE) EW_CASE(EW_IFF) EW_CASE(EW_MUL) EW_CASE(EW_CUBE) EW_CASE(EW_DIV) EW_CASE(EW_RSQRT)
 #undef EW_CASE
             default: return fail(ATLAS_EINVAL, "elementwise: unknown operator");
         }
@@ -116,10 +134,12 @@ struct Elementwise : atlas_instance {
 extern "C" {
 
 int atlas_elementwise_new(int op, const atlas_poly_t* operands, size_t n_operands, const atlas_fr_t* r_node_output, size_t n_vars,
-                          atlas_instance_t* out) {
+                          const atlas_fr_t* constants, size_t n_constants, atlas_instance_t* out) {
     NEED_INIT();
     if (!operands || !r_node_output || !out) return fail(ATLAS_EINVAL, "elementwise_new: null argument");
-    if (op < EW_ADD || op > EW_CUBE) return fail(ATLAS_EINVAL, "elementwise_new: unknown operator");
+    if (op < EW_ADD || op > EW_RSQRT) return fail(ATLAS_EINVAL, "elementwise_new: unknown operator");
+    if (n_constants != (op == EW_RSQRT ? 2u : 0u) || (n_constants && !constants))
+        return fail(ATLAS_EINVAL, "elementwise_new: Rsqrt takes the constants (S^3, gamma), the other operators none");
     if (n_operands != (size_t)ew_operands(op)) return fail(ATLAS_EINVAL, "elementwise_new: wrong operand count for the operator");
     if (n_vars == 0 || n_vars > 25) return fail(ATLAS_EINVAL, "elementwise_new: 1 <= n_vars <= 25");
     const size_t T = (size_t)1 << n_vars;
@@ -128,6 +148,7 @@ int atlas_elementwise_new(int op, const atlas_poly_t* operands, size_t n_operand
     std::lock_guard<std::mutex> lk(g.mu);
     Elementwise* P = new Elementwise();
     P->op = op; P->n_vars = n_vars;
+    for (size_t i = 0; i < n_constants; i++) std::memcpy(&P->consts.k[i], &constants[i], 32);
     int rc = P->rows.alloc(n_operands, T, 3);
     if (!rc) {
         size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;

@@ -148,16 +148,18 @@ def ps_shout_clamp(lookup_indices, xlen, bound, symmetric, r_node_output, gamma)
     return Instance(h)
 
 
-EW_ADD, EW_SUB, EW_NEG, EW_SQUARE, EW_IFF, EW_MUL, EW_CUBE = range(7)
+EW_ADD, EW_SUB, EW_NEG, EW_SQUARE, EW_IFF, EW_MUL, EW_CUBE, EW_DIV, EW_RSQRT = range(9)
 
 
-def elementwise(op, operands, r_node_output):
+def elementwise(op, operands, r_node_output, constants=None):
     """Element-wise operator prover (ops/add.rs, sub.rs, neg.rs, square.rs, iff.rs, mul.rs, cube.rs) over device
     polynomials (MultilinearPolynomial handles; not consumed)."""
     rn = np.ascontiguousarray(r_node_output, dtype=np.uint64)
     hs = (C.c_void_p * len(operands))(*[o.h for o in operands])
     h = C.c_void_p()
-    _check(lib.atlas_elementwise_new(C.c_int(op), hs, C.c_size_t(len(operands)), _p(rn), C.c_size_t(len(rn)), C.byref(h)))
+    k = np.ascontiguousarray(constants, dtype=np.uint64).reshape(-1, 4) if constants is not None else None
+    _check(lib.atlas_elementwise_new(C.c_int(op), hs, C.c_size_t(len(operands)), _p(rn), C.c_size_t(len(rn)),
+                                     _p(k) if k is not None else None, C.c_size_t(0 if k is None else len(k)), C.byref(h)))
     return Instance(h)
 
 

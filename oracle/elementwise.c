@@ -11,13 +11,18 @@
  *   mul.rs:160-185     [lo0 ro0, lo_inf ro_inf]                 gruen_poly_deg_3
  *   iff.rs:189-216     [m0 a0 + (1 - m0) b0, m_inf a_inf + f b_inf],  f = (1 - m1) - (1 - m0)   gruen_poly_deg_3
  *   cube.rs:159-166    compute_mle_product_sum(3, operand)      (mles_product_sum.rs:41-55, degree 4)
+ *   div.rs:329-351     [ro0 q0 + R0 - lo0, ro_inf q_inf]                                          gruen_poly_deg_3
+ *   rsqrt.rs:390-421   [x0 quot0 + dr0 - S^3 + gamma (out0^2 + sr0 - quot0), x_inf quot_inf + gamma out_inf^2]   gruen_poly_deg_3
+ *   (scalar_const_div.rs:227-241 [lo0 - R0] is the Sub fold)
  * with par_fold_out_in_unreduced (split_eq_poly.rs:526-597) = sum_{x_out} E_out sum_{x_in} E_in f(g). */
 #include <stdlib.h>
 #include <string.h>
 #include "elementwise.h"
 
-void orc_elementwise_init(orc_elementwise *S, int op, const fr_t *const *operands, size_t n_ops, size_t n_vars, const fr_t *r_node_output) {
+void orc_elementwise_init(orc_elementwise *S, int op, const fr_t *const *operands, size_t n_ops, size_t n_vars, const fr_t *r_node_output,
+                          const fr_t *constants, size_t n_constants) {
     memset(S, 0, sizeof *S);
+    for (size_t i = 0; i < n_constants && i < 2; i++) S->k[i] = constants[i];
     S->op = op; S->n_ops = n_ops; S->n_vars = n_vars; S->len = (size_t)1 << n_vars;
     for (size_t i = 0; i < n_ops; i++) { S->x[i] = (fr_t *)malloc(S->len * sizeof(fr_t)); memcpy(S->x[i], operands[i], S->len * sizeof(fr_t)); }
     gse_init(&S->eq, r_node_output, n_vars);
@@ -75,6 +80,21 @@ size_t orc_elementwise_message(orc_elementwise *S, const fr_t *claim, fr_t *coef
                 case ORC_EW_MUL:
                     fr_mul(&a[2 * g], &b[2 * g], &c0);
                     fr_sub(&a[2 * g + 1], &a[2 * g], &t); fr_sub(&b[2 * g + 1], &b[2 * g], &u); fr_mul(&t, &u, &e); break;
+                case ORC_EW_DIV: {                  /* x = left, right, q, R */
+                    const fr_t *lo = S->x[0], *ro = S->x[1], *q = S->x[2], *R = S->x[3];
+                    fr_mul(&ro[2 * g], &q[2 * g], &c0); fr_add(&c0, &R[2 * g], &c0); fr_sub(&c0, &lo[2 * g], &c0);
+                    fr_sub(&ro[2 * g + 1], &ro[2 * g], &t); fr_sub(&q[2 * g + 1], &q[2 * g], &u); fr_mul(&t, &u, &e); break;
+                }
+                case ORC_EW_RSQRT: {                /* x = input, quotient, output, div_remainder, sqrt_remainder; k = S^3, gamma */
+                    const fr_t *x = S->x[0], *qt = S->x[1], *o = S->x[2], *dr = S->x[3], *sr = S->x[4];
+                    fr_t div0, sqrt0, dq, sq;
+                    fr_mul(&x[2 * g], &qt[2 * g], &div0); fr_add(&div0, &dr[2 * g], &div0); fr_sub(&div0, &S->k[0], &div0);
+                    fr_mul(&o[2 * g], &o[2 * g], &sqrt0); fr_add(&sqrt0, &sr[2 * g], &sqrt0); fr_sub(&sqrt0, &qt[2 * g], &sqrt0);
+                    fr_sub(&x[2 * g + 1], &x[2 * g], &t); fr_sub(&qt[2 * g + 1], &qt[2 * g], &u); fr_mul(&t, &u, &dq);
+                    fr_sub(&o[2 * g + 1], &o[2 * g], &t); fr_mul(&t, &t, &sq);
+                    fr_mul(&S->k[1], &sqrt0, &t); fr_add(&div0, &t, &c0);
+                    fr_mul(&S->k[1], &sq, &t); fr_add(&dq, &t, &e); break;
+                }
                 default: {                          /* Iff: a = mask, b = a_operand, c = b_operand */
                     fr_t m_inf, a_inf, b_inf, nm0, nm1, f;
                     fr_sub(&a[2 * g + 1], &a[2 * g], &m_inf); fr_sub(&b[2 * g + 1], &b[2 * g], &a_inf); fr_sub(&c[2 * g + 1], &c[2 * g], &b_inf);

@@ -144,17 +144,19 @@ def ps_rshift(lookup_indices, N, shift, r_node, gamma):
 
 
 ELEMENTWISE = 11
-EW_ADD, EW_SUB, EW_NEG, EW_SQUARE, EW_IFF, EW_MUL, EW_CUBE = range(7)
+EW_ADD, EW_SUB, EW_NEG, EW_SQUARE, EW_IFF, EW_MUL, EW_CUBE, EW_DIV, EW_RSQRT = range(9)
 
 
-def elementwise(op, operands, r_node_output):
+def elementwise(op, operands, r_node_output, constants=None):
     """Element-wise operator prover (ops/add.rs, sub.rs, neg.rs, square.rs, mul.rs, iff.rs, cube.rs)."""
     ops = [np.ascontiguousarray(o, dtype=np.uint64) for o in operands]
     rn = np.ascontiguousarray(r_node_output, dtype=np.uint64)
     ptrs = (C.c_void_p * len(ops))(*[o.ctypes.data for o in ops])
     I = Instance(ELEMENTWISE, len(rn))
-    I.keep = [ops, ptrs, rn]
-    orc.lib.orc_elementwise_init(I.st, C.c_int(op), ptrs, C.c_size_t(len(ops)), C.c_size_t(len(rn)), orc._p(rn))
+    k = np.ascontiguousarray(constants, dtype=np.uint64).reshape(-1, 4) if constants is not None else np.zeros((0, 4), dtype=np.uint64)
+    I.keep = [ops, ptrs, rn, k]
+    orc.lib.orc_elementwise_init(I.st, C.c_int(op), ptrs, C.c_size_t(len(ops)), C.c_size_t(len(rn)), orc._p(rn),
+                                 orc._p(k) if len(k) else None, C.c_size_t(len(k)))
     I.n_ops = len(ops)
 
     def finals():

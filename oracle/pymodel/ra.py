@@ -397,9 +397,15 @@ class ElementwiseModel:
         "cube": (4, lambda v: v[0] * v[0] % FR * v[0] % FR),
     }
 
-    def __init__(self, op, operands, r_node_output):
+    def __init__(self, op, operands, r_node_output, constants=()):
         self.op = op
-        self.deg, self.f = self.F[op]
+        if op == "div":            # operands left, right, q, R: right * q + R - left   (ops/div.rs:329-351)
+            self.deg, self.f = 3, lambda v: (v[1] * v[2] + v[3] - v[0]) % FR
+        elif op == "rsqrt":        # input, quotient, output, div_rem, sqrt_rem; constants S^3, gamma (ops/rsqrt.rs:390-421)
+            s3, gam = constants
+            self.deg, self.f = 3, lambda v: (v[0] * v[1] + v[3] - s3 + gam * (v[2] * v[2] + v[4] - v[1])) % FR
+        else:
+            self.deg, self.f = self.F[op]
         self.x = [list(o) for o in operands]
         self.eq = P.eq_evals(r_node_output)
         self._n = len(r_node_output)

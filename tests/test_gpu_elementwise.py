@@ -4,7 +4,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-_EW = {"add": (0, 2), "sub": (1, 2), "neg": (2, 1), "square": (3, 1), "iff": (4, 3), "mul": (5, 2), "cube": (6, 1)}
+_EW = {"add": (0, 2), "sub": (1, 2), "neg": (2, 1), "square": (3, 1), "iff": (4, 3), "mul": (5, 2), "cube": (6, 1),
+       "div": (7, 4), "rsqrt": (8, 5)}
 
 
 def _operands(orc, op, n, seed, as_i32):
@@ -33,12 +34,13 @@ def test_elementwise_bit_exact(atlas, op, n_vars, as_i32, mode):
         ints, ops_fr = _operands(orc, op, n, 100 * code + n_vars, as_i32)
         r_node = orc.random_fr(n_vars, 3)
         claim = orc.random_fr(1, 4)[0]            # the driver never checks s(0) + s(1) = claim; Gruen uses it as given
-        o = OR.elementwise(code, ops_fr, r_node)
+        consts = np.stack([orc.from_ints([1 << 42])[0], orc.random_fr(1, 8)[0]]) if op == "rsqrt" else None
+        o = OR.elementwise(code, ops_fr, r_node, consts)
         t_o = orc.new_transcript(b"ew")
         rows_o, ch_o = o.prove(claim, t_o)
         polys = [A.MultilinearPolynomial.from_i32(v.astype(np.int32)) for v in ints] if as_i32 else \
                 [A.MultilinearPolynomial.from_fr(v) for v in ops_fr]
-        inst = I.elementwise(code, polys, r_node)
+        inst = I.elementwise(code, polys, r_node, consts)
         assert inst.num_rounds() == n_vars
         t_g = A.Blake2bTranscript(b"ew")
         rows_g, ch_g = inst.prove(claim, t_g)
@@ -66,4 +68,6 @@ def test_elementwise_errors(atlas):
         I.elementwise(2, [p], orc.random_fr(4, 2))            # length != 2^n_vars
     with pytest.raises(A.AtlasError):
         I.elementwise(9, [p], orc.random_fr(3, 2))            # unknown operator
+    with pytest.raises(A.AtlasError):
+        I.elementwise(8, [p] * 5, orc.random_fr(3, 2))        # Rsqrt without its constants
     p.free()

@@ -338,7 +338,8 @@ def test_ps_shout_unsigned_less_than_oracle_matches_closed_form_model(log_T):
     assert bytes(to.state) == tp.state
 
 
-_EW = {"add": (0, 2), "sub": (1, 2), "neg": (2, 1), "square": (3, 1), "iff": (4, 3), "mul": (5, 2), "cube": (6, 1)}
+_EW = {"add": (0, 2), "sub": (1, 2), "neg": (2, 1), "square": (3, 1), "iff": (4, 3), "mul": (5, 2), "cube": (6, 1),
+       "div": (7, 4), "rsqrt": (8, 5)}
 
 
 @pytest.mark.parametrize("op", sorted(_EW))
@@ -354,10 +355,11 @@ def test_elementwise_oracle_matches_naive_model(op, n_vars):
     if op == "iff":
         operands[0] = [int(v) for v in rng.integers(0, 2, size=n)]
     r_node = _rand(n_vars, 17)
-    model = PR.ElementwiseModel(op, operands, r_node)
+    consts = [(1 << 42) % F.FR, _rand(1, 23)[0]] if op == "rsqrt" else []
+    model = PR.ElementwiseModel(op, operands, r_node, consts)
     claim = model.input_claim()
     rows_p, raw_p, tp = _prove_py(model, claim, b"elementwise")
-    inst = OR.elementwise(code, [orc.from_ints(o) for o in operands], orc.from_ints(r_node))
+    inst = OR.elementwise(code, [orc.from_ints(o) for o in operands], orc.from_ints(r_node), orc.from_ints(consts) if consts else None)
     to = orc.new_transcript(b"elementwise")
     rows_o, raw_o = inst.prove(orc.from_ints([claim])[0], to)
     assert raw_o == raw_p
