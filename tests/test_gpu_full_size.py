@@ -1,0 +1,234 @@
+"""BASELINE.json's full sizes (2^22-coefficient witness): bit-exact against the oracle where the oracle finishes in
+seconds, and through size-independent identities (trapdoor MSM identity, trapdoor HyperKZG verification, sumcheck
+verification against CPU MLE evaluations) where it does not."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LOG_N = 22
+
+
+def test_sumcheck_2p22_bit_exact_and_final_claims(atlas):
+    from oracle import orc
+    A = atlas
+    n = 1 << LOG_N
+    L = orc.random_fr(n, 9001); R = orc.random_fr(n, 9002)
+    claim = orc.dot_claim(L, R, None, 0, 0, 0)
+    t_o = orc.new_transcript(b"full")
+    proof_o, ch_o, fin_o = orc.sumcheck_dot_prove(L, R, claim, t_o, None, 0, 0, 0)
+    prover = A.EinsumDotProver(A.MultilinearPolynomial.from_fr(L), A.MultilinearPolynomial.from_fr(R), None, 0, 0, 0)
+    assert np.array_equal(prover.input_claim(), claim[0])
+    t_g = A.Blake2bTranscript(b"full")
+    proof_g, ch_g, fin_g = A.Sumcheck.prove(prover, claim[0], t_g, LOG_N)
+    prover.free()
+    assert ch_g == ch_o and np.array_equal(proof_g, proof_o) and np.array_equal(fin_g, fin_o)
+    assert t_g.state == t_o.state_bytes() and t_g.n_rounds == t_o.n_rounds
+    # the final claims are the operands' MLEs at the challenge point (HighToLow: r_0 binds the top variable)
+    r = np.ascontiguousarray(orc.challenges_to_fr(ch_g))
+    assert np.array_equal(fin_g[0], orc.evaluate(L, r)) and np.array_equal(fin_g[1], orc.evaluate(R, r))
+
+
+def test_msm_and_hyperkzg_open_2p22_trapdoor(atlas):
+    from oracle import orc
+    A = atlas
+    n = 1 << LOG_N
+    tau = orc.random_fr(1, 4242)[0]
+    srs = A.SRS.generate(tau, n)
+    poly = orc.random_fr(n, 9003)
+    p = A.MultilinearPolynomial.from_fr(poly)
+    # commitment: sum_i poly_i tau^(i+1) G
+    Cm = A.HyperKZG.commit(srs, p)
+    k = orc.fr_array(1)
+    t = np.ascontiguousarray(tau).reshape(1, 4)
+    orc.lib.orc_eval_as_univariate(orc._p(np.ascontiguousarray(poly)), C.c_size_t(n), orc._p(t), orc._p(k))
+    assert orc.g1_eq(Cm, orc.g1_mul_generator(orc.fr_mul_arr(k[0], tau)))
+    # opening at a random point, verified with the trapdoor (no pairing): needs srs[0] only
+    rng = np.random.default_rng(5)
+    pt = [int.from_bytes(rng.bytes(16), "little") for _ in range(LOG_N)]
+    com, w, v = A.HyperKZG.open(srs, p, pt, A.Blake2bTranscript(b"full_open"))
+    y = orc.evaluate(poly, orc.challenges_to_fr(pt))
+    assert np.array_equal(A.evaluate(p, np.ascontiguousarray(orc.challenges_to_fr(pt))), y)
+    srs0 = srs.download(0, 1)
+    assert orc.hyperkzg_verify_trapdoor(srs0, tau, Cm, pt, y, com, w, v, orc.new_transcript(b"full_open"))
+    # a wrong evaluation must not verify
+    y_bad = orc.fr_add_arr(y, orc.from_ints([1])[0])
+    assert not orc.hyperkzg_verify_trapdoor(srs0, tau, Cm, pt, y_bad, com, w, v, orc.new_transcript(b"full_open"))
+    p.free(); srs.free()
+
+
+# ---- the throughput code paths of the host-stepped instances (grids past the latency-regime variants), against the
+# ---- oracle at sizes it finishes in seconds.  Claims are arbitrary: neither driver checks s(0) + s(1) = claim.
+
+def _rows_equal(a, b):
+    return len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def _indices(d, T, K, seed, none_frac=0.02):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(d):
+        a = rng.integers(0, K, size=T).astype(np.int32)
+        a[rng.random(T) < none_frac] = -1
+        out.append(a)
+    return out
+
+
+@pytest.mark.parametrize("d,log_T", [(4, 15), (8, 16), (16, 15), (3, 17)])
+def test_ra_virtual_large(atlas, d, log_T):
+    from oracle import orc, orc_ra as OR
+    from jolt_atlas_amd import instances as I
+    A = atlas
+    log_k = 4
+    H = _indices(d, 1 << log_T, 1 << log_k, 31 * d + log_T)
+    chunks = orc.random_fr(d * log_k, 5).reshape(d, log_k, 4)
+    r_cycle = orc.random_fr(log_T, 6)
+    claim = orc.random_fr(1, 7)[0]
+    t_o = orc.new_transcript(b"ra_large")
+    rows_o, ch_o = OR.ra_virtual(H, log_k, chunks, r_cycle).prove(claim, t_o)
+    inst = I.ra_virtual(H, log_k, chunks, r_cycle)
+    t_g = A.Blake2bTranscript(b"ra_large")
+    rows_g, ch_g = inst.prove(claim, t_g)
+    assert ch_g == ch_o and _rows_equal(rows_g, rows_o) and t_g.state == t_o.state_bytes()
+    fin = inst.final_claims()
+    rs = np.ascontiguousarray(orc.challenges_to_fr(ch_g)[::-1])
+    for i in range(d):
+        F = orc.eq_evals(chunks[i])
+        vec = F[np.maximum(H[i], 0)].copy(); vec[H[i] < 0] = 0
+        assert np.array_equal(fin[i], orc.evaluate(vec, rs))
+    inst.free()
+    # the constructor that cuts the chunk rows from the lookup indices, at the same size
+    rng = np.random.default_rng(d)
+    log_K = log_k * d
+    lookups = rng.integers(0, 1 << min(log_K, 62), size=1 << log_T, dtype=np.uint64)
+    r_address = orc.random_fr(log_K, 9)
+    Hl = [((lookups >> np.uint64(log_k * (d - 1 - i))) & np.uint64(15)).astype(np.int32) for i in range(d)]
+    t_o = orc.new_transcript(b"ra_large2")
+    rows_o, ch_o = OR.ra_virtual(Hl, log_k, r_address.reshape(d, log_k, 4), r_cycle).prove(claim, t_o)
+    inst = I.ra_virtual_from_lookups(lookups, log_K, log_k, r_address, r_cycle)
+    t_g = A.Blake2bTranscript(b"ra_large2")
+    rows_g, ch_g = inst.prove(claim, t_g)
+    assert ch_g == ch_o and _rows_equal(rows_g, rows_o) and t_g.state == t_o.state_bytes()
+    inst.free()
+
+
+@pytest.mark.parametrize("d,log_T", [(8, 16), (16, 15)])
+def test_booleanity_large(atlas, d, log_T):
+    from oracle import orc, orc_ra as OR
+    from jolt_atlas_amd import instances as I
+    A = atlas
+    log_k = 4
+    H = _indices(d, 1 << log_T, 1 << log_k, 17 * d + log_T)
+    r_address, r_cycle = orc.random_fr(log_k, 7), orc.random_fr(log_T, 8)
+    gammas = orc.random_fr(d, 9)
+    G = OR.ra_G(H, log_k, r_cycle)
+    zero = orc.fr_array(1)[0]
+    t_o = orc.new_transcript(b"bool_large")
+    rows_o, ch_o = OR.booleanity(G, H, log_k, gammas, r_address, r_cycle).prove(zero, t_o)
+    inst = I.booleanity(G, H, log_k, gammas, r_address, r_cycle)
+    t_g = A.Blake2bTranscript(b"bool_large")
+    rows_g, ch_g = inst.prove(zero, t_g)
+    assert ch_g == ch_o and _rows_equal(rows_g, rows_o) and t_g.state == t_o.state_bytes()
+    inst.free()
+
+
+def test_openings_large(atlas):
+    from oracle import orc, orc_ra as OR
+    from jolt_atlas_amd import instances as I
+    A = atlas
+    n = 20
+    poly, pt = orc.random_fr(1 << n, 1), orc.random_fr(n, 2)
+    claim = orc.evaluate(poly, pt)
+    t_o = orc.new_transcript(b"dense_large")
+    rows_o, ch_o = OR.dense_opening(poly, pt).prove(claim, t_o)
+    inst = I.dense_opening(A.MultilinearPolynomial.from_fr(poly), pt)
+    t_g = A.Blake2bTranscript(b"dense_large")
+    rows_g, ch_g = inst.prove(claim, t_g)
+    assert ch_g == ch_o and _rows_equal(rows_g, rows_o) and t_g.state == t_o.state_bytes()
+    assert np.array_equal(inst.final_claims()[0], orc.evaluate(poly, np.ascontiguousarray(orc.challenges_to_fr(ch_g))))
+    inst.free()
+    log_K, log_T = 4, 18
+    idx = _indices(1, 1 << log_T, 1 << log_K, 3)[0]
+    r_address, r_cycle = orc.random_fr(log_K, 5), orc.random_fr(log_T, 6)
+    claim = orc.random_fr(1, 7)[0]
+    t_o = orc.new_transcript(b"onehot_large")
+    rows_o, ch_o = OR.onehot_opening(idx, log_K, r_address, r_cycle).prove(claim, t_o)
+    inst = I.onehot_opening(idx, log_K, r_address, r_cycle)
+    t_g = A.Blake2bTranscript(b"onehot_large")
+    rows_g, ch_g = inst.prove(claim, t_g)
+    assert ch_g == ch_o and _rows_equal(rows_g, rows_o) and t_g.state == t_o.state_bytes()
+    rs = orc.challenges_to_fr(ch_g)
+    Fs = orc.eq_evals(np.ascontiguousarray(rs[:log_K]))
+    vec = Fs[np.maximum(idx, 0)].copy(); vec[idx < 0] = 0
+    assert np.array_equal(inst.final_claims()[0], orc.evaluate(vec, np.ascontiguousarray(rs[log_K:])))
+    inst.free()
+
+
+def test_eval_reduction_large(atlas):
+    from oracle import orc, orc_ra as OR
+    from jolt_atlas_amd import instances as I
+    A = atlas
+    n, N = 18, 3
+    mle = orc.random_fr(1 << n, 11)
+    pts = orc.random_fr(N * n, 12).reshape(N, n, 4)
+    claims = np.stack([orc.evaluate(mle, pts[j]) for j in range(N)])
+    t_o = orc.new_transcript(b"er_large")
+    h_o, r_o, c_o = OR.eval_reduction_prove(mle, pts, claims, t_o)
+    p = A.MultilinearPolynomial.from_fr(mle)
+    t_g = A.Blake2bTranscript(b"er_large")
+    h_g, r_g, c_g = I.eval_reduction_prove(p, pts, claims, t_g)
+    assert np.array_equal(h_g, h_o) and np.array_equal(r_g, r_o) and np.array_equal(c_g, c_o)
+    assert t_g.state == t_o.state_bytes()
+    assert np.array_equal(orc.evaluate(mle, r_g), c_g)
+    p.free()
+
+
+@pytest.mark.parametrize("kind", ["relu", "clamp", "rshift", "identity", "ult"])
+def test_ps_shout_large(atlas, kind):
+    from oracle import orc, orc_ra as OR
+    from jolt_atlas_amd import instances as I
+    A = atlas
+    log_T = 14 if kind == "ult" else 16
+    T = 1 << log_T
+    rng = np.random.default_rng(len(kind))
+    r_node, gamma, claim = orc.random_fr(log_T, 5), orc.random_fr(1, 6)[0], orc.random_fr(1, 7)[0]
+    if kind == "ult":
+        idx = rng.integers(0, 1 << 63, size=T, dtype=np.uint64)
+        o, g_ = OR.ps_ult(idx, r_node, gamma), I.ps_shout_ult(idx, r_node, gamma)
+    elif kind == "identity":
+        idx = rng.integers(0, 1 << 16, size=T, dtype=np.uint64)
+        o, g_ = OR.ps_identity(idx, 16, 4, r_node), I.identity_range_check(idx, 16, 4, r_node)
+    else:
+        idx = (rng.integers(-(1 << 16), 1 << 16, size=T, dtype=np.int64) & 0xFFFFFFFF).astype(np.uint64)
+        if kind == "relu":
+            o, g_ = OR.ps_relu(idx, 32, r_node, gamma), I.ps_shout_relu(idx, 32, r_node, gamma)
+        elif kind == "clamp":
+            o, g_ = OR.ps_clamp(idx, 32, 17, True, r_node, gamma), I.ps_shout_clamp(idx, 32, 17, True, r_node, gamma)
+        else:
+            o, g_ = OR.ps_rshift(idx, 32, 3, r_node, gamma), I.ps_shout_rshift(idx, 32, 3, r_node, gamma)
+    t_o = orc.new_transcript(b"ps_large")
+    rows_o, ch_o = o.prove(claim, t_o)
+    t_g = A.Blake2bTranscript(b"ps_large")
+    rows_g, ch_g = g_.prove(claim, t_g)
+    assert ch_g == ch_o and _rows_equal(rows_g, rows_o) and t_g.state == t_o.state_bytes()
+    g_.free()
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.int32, np.uint64])
+def test_msm_small_large(atlas, dtype):
+    """narrow-scalar MSM at 2^18 (13-bit windows, LDS counting sort), checked by the trapdoor identity."""
+    from oracle import orc
+    n = 1 << 18
+    tau = orc.random_fr(1, 4242)[0]
+    s = atlas.SRS.generate(tau, n)
+    info = np.iinfo(dtype)
+    sc = np.random.default_rng(1).integers(info.min, info.max, size=n, dtype=dtype, endpoint=True)
+    got = s.msm_small(sc)
+    fr = orc.from_ints([int(v) for v in sc])
+    k = orc.fr_array(1)
+    t = np.ascontiguousarray(tau).reshape(1, 4)
+    orc.lib.orc_eval_as_univariate(orc._p(np.ascontiguousarray(fr)), C.c_size_t(n), orc._p(t), orc._p(k))
+    assert orc.g1_eq(got, orc.g1_mul_generator(orc.fr_mul_arr(k[0], tau)))
+    s.free()
