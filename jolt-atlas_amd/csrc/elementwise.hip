@@ -7,6 +7,9 @@
 //   cube.rs:159-171    compute_mle_product_sum(3, operand)  (mles_product_sum.rs:41-55): grid [1, 2, inf]
 //   div.rs:329-362 (left, right, q, R)   rsqrt.rs:390-433 (input, quotient, output, div_rem, sqrt_rem; S^3, gamma)
 //   scalar_const_div.rs:227-248 is the Sub fold over (left, R)
+// and the selector-style provers WITHOUT an eq factor (sumcheck_evals at 0 and 2, UniPoly::from_evals_and_hint):
+//   reshape.rs:286-315, slice.rs:254-281 (input, selector); concat.rs:290-325 (input_t, selector_t per term);
+//   gather/mod.rs:232-268 (index_onehot, dictionary, identity; gamma)
 // Operands are atlas_poly_t (Fr or I32Scalars; not consumed): the rows of the instance are Fr copies — the
 // first bind of a CompactPolynomial (compact_polynomial.rs:272-353) yields the same field values.
 // HBM per round: n_ops * len * 32 B read by the fold, the same read + half written by the bind.
@@ -15,12 +18,14 @@
 namespace {
 
 enum { EW_ADD = ATLAS_EW_ADD, EW_SUB = ATLAS_EW_SUB, EW_NEG = ATLAS_EW_NEG, EW_SQUARE = ATLAS_EW_SQUARE, EW_IFF = ATLAS_EW_IFF,
-       EW_MUL = ATLAS_EW_MUL, EW_CUBE = ATLAS_EW_CUBE, EW_DIV = ATLAS_EW_DIV, EW_RSQRT = ATLAS_EW_RSQRT };
+       EW_MUL = ATLAS_EW_MUL, EW_CUBE = ATLAS_EW_CUBE, EW_DIV = ATLAS_EW_DIV, EW_RSQRT = ATLAS_EW_RSQRT,
+       EW_DOT = ATLAS_EW_DOT, EW_GATHER = ATLAS_EW_GATHER };
 
-struct EwConsts { Fr k[2]; };      // Rsqrt: S^3, gamma
+struct EwConsts { Fr k[2]; uint32_t n_terms; };      // Rsqrt: S^3, gamma; Gather: gamma; Dot: number of (input, selector) pairs
 
-constexpr int ew_outputs(int op) { return op == EW_CUBE ? 3 : (op == EW_SQUARE || op == EW_MUL || op == EW_IFF || op == EW_DIV || op == EW_RSQRT) ? 2 : 1; }
-constexpr int ew_operands(int op) { return op == EW_RSQRT ? 5 : op == EW_DIV ? 4 : op == EW_IFF ? 3 : (op == EW_ADD || op == EW_SUB || op == EW_MUL) ? 2 : 1; }
+constexpr bool ew_has_eq(int op) { return op != EW_DOT && op != EW_GATHER; }
+constexpr int ew_outputs(int op) { return op == EW_CUBE ? 3 : (op == EW_DOT || op == EW_GATHER || op == EW_SQUARE || op == EW_MUL || op == EW_IFF || op == EW_DIV || op == EW_RSQRT) ? 2 : 1; }
+constexpr int ew_operands(int op) { return op == EW_GATHER ? 3 : op == EW_RSQRT ? 5 : op == EW_DIV ? 4 : op == EW_IFF ? 3 : (op == EW_ADD || op == EW_SUB || op == EW_MUL) ? 2 : 1; }
 
 __global__ __launch_bounds__(RA_THREADS) void k_ew_from_i32(const int32_t* __restrict__ in, Fr* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * RA_THREADS)
@@ -36,7 +41,6 @@ __global__ __launch_bounds__(RA_THREADS) void k_ew_fold(const Fr* __restrict__ r
 #pragma unroll
     for (int k = 0; k < NQ; k++) acc[k] = fe_zero();
     for (size_t g = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; g < n_groups; g += (size_t)gridDim.x * RA_THREADS) {
-        const Fr w = gse_weight(E, g);
         const Fr a0 = fe_load(rows + 2 * g), a1 = fe_load(rows + 2 * g + 1);
         Fr v[NQ];
         if constexpr (OP == EW_ADD) v[0] = fr_add(a0, fe_load(rows + stride + 2 * g));
@@ -51,6 +55,20 @@ __global__ __launch_bounds__(RA_THREADS) void k_ew_fold(const Fr* __restrict__ r
             const Fr y0 = fe_load(rows + 2 * stride + 2 * g), y1 = fe_load(rows + 2 * stride + 2 * g + 1);
             v[0] = fr_add(y0, fr_mul(a0, fr_sub(x0, y0)));
             v[1] = fr_mul(fr_sub(a1, a0), fr_sub(fr_sub(x1, x0), fr_sub(y1, y0)));
+        } else if constexpr (OP == EW_DOT) {        // rows: (input_t, selector_t) pairs; values at X = 0 and X = 2
+            v[0] = fe_zero(); v[1] = fe_zero();
+            for (uint32_t tm = 0; tm < C.n_terms; tm++) {
+                const Fr* in = rows + (size_t)(2 * tm) * stride; const Fr* sel = in + stride;
+                const Fr i0 = fe_load(in + 2 * g), i1 = fe_load(in + 2 * g + 1), s0 = fe_load(sel + 2 * g), s1 = fe_load(sel + 2 * g + 1);
+                v[0] = fr_add(v[0], fr_mul(i0, s0));
+                v[1] = fr_add(v[1], fr_mul(fr_add(i1, fr_sub(i1, i0)), fr_add(s1, fr_sub(s1, s0))));
+            }
+        } else if constexpr (OP == EW_GATHER) {     // rows: ra, dictionary, identity: ra (dict + gamma id) at X = 0 and 2
+            const Fr d0 = fe_load(rows + stride + 2 * g), d1 = fe_load(rows + stride + 2 * g + 1);
+            const Fr j0 = fe_load(rows + 2 * stride + 2 * g), j1 = fe_load(rows + 2 * stride + 2 * g + 1);
+            const Fr a2 = fr_add(a1, fr_sub(a1, a0)), d2 = fr_add(d1, fr_sub(d1, d0)), j2 = fr_add(j1, fr_sub(j1, j0));
+            v[0] = fr_mul(a0, fr_add(d0, fr_mul(C.k[0], j0)));
+            v[1] = fr_mul(a2, fr_add(d2, fr_mul(C.k[0], j2)));
         } else if constexpr (OP == EW_DIV) {        // rows: left, right, q, R.  c0 = ro0 q0 + R0 - lo0;  e = ro_inf q_inf
             const Fr r0 = fe_load(rows + stride + 2 * g), r1 = fe_load(rows + stride + 2 * g + 1);
             const Fr q0 = fe_load(rows + 2 * stride + 2 * g), q1 = fe_load(rows + 2 * stride + 2 * g + 1);
@@ -68,8 +86,14 @@ __global__ __launch_bounds__(RA_THREADS) void k_ew_fold(const Fr* __restrict__ r
             const Fr d = fr_sub(a1, a0), p2 = fr_add(a1, d);
             v[0] = fr_mul(fr_mul(a1, a1), a1); v[1] = fr_mul(fr_mul(p2, p2), p2); v[2] = fr_mul(fr_mul(d, d), d);
         }
+        if constexpr (ew_has_eq(OP)) {
+            const Fr w = gse_weight(E, g);
 #pragma unroll
-        for (int k = 0; k < NQ; k++) acc[k] = fr_add(acc[k], fr_mul(w, v[k]));
+            for (int k = 0; k < NQ; k++) acc[k] = fr_add(acc[k], fr_mul(w, v[k]));
+        } else {
+#pragma unroll
+            for (int k = 0; k < NQ; k++) acc[k] = fr_add(acc[k], v[k]);
+        }
     }
     block_reduce_store<NQ>(acc, partials);
 }
@@ -82,17 +106,17 @@ struct Elementwise : atlas_instance {
     size_t n_vars = 0, round_next = 0;
     ~Elementwise() override { rows.release(); eq.release(); }
     size_t rounds() const override { return n_vars; }
-    size_t degree() const override { return op == EW_CUBE ? 4 : ew_outputs(op) + 1; }
+    size_t degree() const override { return op == EW_CUBE ? 4 : !ew_has_eq(op) ? 2 : ew_outputs(op) + 1; }
     int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
         if (round != round_next || round >= n_vars) return fail(ATLAS_ESTATE, "elementwise: round out of order");
         std::lock_guard<std::mutex> lk(g.mu);
         const size_t n_groups = rows.len / 2;
         size_t blocks = (n_groups + RA_THREADS - 1) / RA_THREADS; if (blocks > 1024) blocks = 1024;
-        const SplitEqView E = eq.view();
+        const SplitEqView E = ew_has_eq(op) ? eq.view() : SplitEqView{nullptr, nullptr, 0};
         const Fr* src = rows.buf[rows.cur]; const size_t st = rows.stride[rows.cur];
         switch (op) {
 #define EW_CASE(OP) case OP: k_ew_fold<OP><<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(src, st, E, n_groups, consts, rows.partials); break;
-            EW_CASE(EW_ADD) EW_CASE(EW_SUB) EW_CASE(EW_NEG) EW_CASE(EW_SQUARE) EW_CASE(EW_IFF) EW_CASE(EW_MUL) EW_CASE(EW_CUBE) EW_CASE(EW_DIV) EW_CASE(EW_RSQRT)
+            EW_CASE(EW_ADD) EW_CASE(EW_SUB) EW_CASE(EW_NEG) EW_CASE(EW_SQUARE) EW_CASE(EW_IFF) EW_CASE(EW_MUL) EW_CASE(EW_CUBE) EW_CASE(EW_DIV) EW_CASE(EW_RSQRT) EW_CASE(EW_DOT) EW_CASE(EW_GATHER)
 #undef EW_CASE
             default: return fail(ATLAS_EINVAL, "elementwise: unknown operator");
         }
@@ -100,7 +124,10 @@ struct Elementwise : atlas_instance {
         H::Fr s[3];
         int rc = rows.reduce_to_host((uint32_t)blocks, (uint32_t)nq, s);
         if (rc) return rc;
-        if (op == EW_CUBE) {
+        if (!ew_has_eq(op)) {
+            coeffs.assign(3, H::zero());
+            H::unipoly_from_evals_and_hint(claim, s, 2, coeffs.data());
+        } else if (op == EW_CUBE) {
             std::vector<H::Fr> sums(3);
             for (int k = 0; k < 3; k++) sums[k] = H::mul(s[k], eq.st.scalar);        // mles_product_sum.rs:131
             coeffs = H::finish_product_sum(sums, claim, eq.st);
@@ -118,7 +145,7 @@ struct Elementwise : atlas_instance {
         std::lock_guard<std::mutex> lk(g.mu);
         int rc = rows.bind(r);
         if (rc) return rc;
-        eq.st.bind(H::challenge_to_fr(r.lo, r.hi, g.challenge_mode));
+        if (ew_has_eq(op)) eq.st.bind(H::challenge_to_fr(r.lo, r.hi, g.challenge_mode));
         round_next++;
         return ATLAS_OK;
     }
@@ -136,11 +163,12 @@ extern "C" {
 int atlas_elementwise_new(int op, const atlas_poly_t* operands, size_t n_operands, const atlas_fr_t* r_node_output, size_t n_vars,
                           const atlas_fr_t* constants, size_t n_constants, atlas_instance_t* out) {
     NEED_INIT();
-    if (!operands || !r_node_output || !out) return fail(ATLAS_EINVAL, "elementwise_new: null argument");
-    if (op < EW_ADD || op > EW_RSQRT) return fail(ATLAS_EINVAL, "elementwise_new: unknown operator");
-    if (n_constants != (op == EW_RSQRT ? 2u : 0u) || (n_constants && !constants))
-        return fail(ATLAS_EINVAL, "elementwise_new: Rsqrt takes the constants (S^3, gamma), the other operators none");
-    if (n_operands != (size_t)ew_operands(op)) return fail(ATLAS_EINVAL, "elementwise_new: wrong operand count for the operator");
+    if (!operands || !out || (!r_node_output && op != EW_DOT && op != EW_GATHER)) return fail(ATLAS_EINVAL, "elementwise_new: null argument");
+    if (op < EW_ADD || op > EW_GATHER) return fail(ATLAS_EINVAL, "elementwise_new: unknown operator");
+    if (n_constants != (op == EW_RSQRT ? 2u : op == EW_GATHER ? 1u : 0u) || (n_constants && !constants))
+        return fail(ATLAS_EINVAL, "elementwise_new: Rsqrt takes the constants (S^3, gamma), Gather (gamma), the other operators none");
+    if (op == EW_DOT ? (n_operands < 2 || n_operands % 2 || n_operands > RA_MAX_D) : n_operands != (size_t)ew_operands(op))
+        return fail(ATLAS_EINVAL, "elementwise_new: wrong operand count for the operator");
     if (n_vars == 0 || n_vars > 25) return fail(ATLAS_EINVAL, "elementwise_new: 1 <= n_vars <= 25");
     const size_t T = (size_t)1 << n_vars;
     for (size_t i = 0; i < n_operands; i++)
@@ -149,6 +177,7 @@ int atlas_elementwise_new(int op, const atlas_poly_t* operands, size_t n_operand
     Elementwise* P = new Elementwise();
     P->op = op; P->n_vars = n_vars;
     for (size_t i = 0; i < n_constants; i++) std::memcpy(&P->consts.k[i], &constants[i], 32);
+    P->consts.n_terms = (uint32_t)(n_operands / 2);
     int rc = P->rows.alloc(n_operands, T, 3);
     if (!rc) {
         size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
@@ -159,7 +188,7 @@ int atlas_elementwise_new(int op, const atlas_poly_t* operands, size_t n_operand
         }
         if (e != hipSuccess) rc = fail(ATLAS_ENODEV, "elementwise_new: operand copy", e);
     }
-    if (!rc) rc = P->eq.init(reinterpret_cast<const H::Fr*>(r_node_output), n_vars);
+    if (!rc && ew_has_eq(op)) rc = P->eq.init(reinterpret_cast<const H::Fr*>(r_node_output), n_vars);
     if (rc) { delete P; return rc; }
     *out = P;
     return ATLAS_OK;

@@ -14,6 +14,9 @@
  *   div.rs:329-351     [ro0 q0 + R0 - lo0, ro_inf q_inf]                                          gruen_poly_deg_3
  *   rsqrt.rs:390-421   [x0 quot0 + dr0 - S^3 + gamma (out0^2 + sr0 - quot0), x_inf quot_inf + gamma out_inf^2]   gruen_poly_deg_3
  *   (scalar_const_div.rs:227-241 [lo0 - R0] is the Sub fold)
+ * and the selector-style provers without an eq factor (LowToHigh sumcheck_evals at 0 and 2, from_evals_and_hint):
+ *   reshape.rs:286-308, slice.rs:254-274   input * selector;  concat.rs:290-317   sum over terms of input_t * selector_t
+ *   gather/mod.rs:232-261                  ra * (dictionary + gamma * identity)
  * with par_fold_out_in_unreduced (split_eq_poly.rs:526-597) = sum_{x_out} E_out sum_{x_in} E_in f(g). */
 #include <stdlib.h>
 #include <string.h>
@@ -42,7 +45,27 @@ static size_t gruen_deg2(const gse_t *E, const fr_t *q0, const fr_t *claim, fr_t
     return orc_unipoly_from_evals_and_hint(&hint, ev2, 2, coeffs);
 }
 
+/* MultilinearPolynomial::sumcheck_evals(i, 2, LowToHigh): values at 0 and 2 of the pair (2i, 2i+1) */
+static void evals02(const fr_t *z, size_t i, fr_t o[2]) {
+    fr_t m; o[0] = z[2 * i]; fr_sub(&z[2 * i + 1], &z[2 * i], &m); fr_add(&z[2 * i + 1], &m, &o[1]);
+}
+
 size_t orc_elementwise_message(orc_elementwise *S, const fr_t *claim, fr_t *coeffs) {
+    if (S->op == ORC_EW_DOT || S->op == ORC_EW_GATHER) {
+        fr_t ev[2], t; fr_zero(&ev[0]); fr_zero(&ev[1]);
+        for (size_t i = 0; i < S->len / 2; i++) {
+            if (S->op == ORC_EW_DOT) {
+                for (size_t term = 0; term + 1 < S->n_ops; term += 2) {
+                    fr_t a[2], s[2]; evals02(S->x[term], i, a); evals02(S->x[term + 1], i, s);
+                    for (int k = 0; k < 2; k++) { fr_mul(&a[k], &s[k], &t); fr_add(&ev[k], &t, &ev[k]); }
+                }
+            } else {
+                fr_t ra[2], dc[2], id[2]; evals02(S->x[0], i, ra); evals02(S->x[1], i, dc); evals02(S->x[2], i, id);
+                for (int k = 0; k < 2; k++) { fr_mul(&id[k], &S->k[0], &t); fr_add(&dc[k], &t, &t); fr_mul(&ra[k], &t, &t); fr_add(&ev[k], &t, &ev[k]); }
+            }
+        }
+        return orc_unipoly_from_evals_and_hint(claim, ev, 2, coeffs);
+    }
     const gse_t *E = &S->eq;
     const fr_t *e_out = E->Eout[E->out_top], *e_in = E->Ein[E->in_top];
     const size_t out_len = (size_t)1 << E->out_top, in_len = (size_t)1 << E->in_top;
@@ -117,7 +140,7 @@ size_t orc_elementwise_message(orc_elementwise *S, const fr_t *claim, fr_t *coef
 void orc_elementwise_ingest(orc_elementwise *S, const fr_t *r) {
     for (size_t i = 0; i < S->n_ops; i++) orc_bind(S->x[i], S->len, r, ORC_LOW_TO_HIGH);
     S->len /= 2;
-    gse_bind(&S->eq, r);
+    if (S->op != ORC_EW_DOT && S->op != ORC_EW_GATHER) gse_bind(&S->eq, r);
 }
 
 void orc_elementwise_finals(const orc_elementwise *S, fr_t *out) { for (size_t i = 0; i < S->n_ops; i++) out[i] = S->x[i][0]; }

@@ -404,10 +404,16 @@ class ElementwiseModel:
         elif op == "rsqrt":        # input, quotient, output, div_rem, sqrt_rem; constants S^3, gamma (ops/rsqrt.rs:390-421)
             s3, gam = constants
             self.deg, self.f = 3, lambda v: (v[0] * v[1] + v[3] - s3 + gam * (v[2] * v[2] + v[4] - v[1])) % FR
+        elif op == "dot":          # pairs (input_t, selector_t), no eq factor (ops/reshape.rs, slice.rs, concat.rs)
+            self.deg, self.f = 2, lambda v: sum(v[i] * v[i + 1] for i in range(0, len(v), 2)) % FR
+        elif op == "gather":       # ra, dictionary, identity; constant gamma (ops/gather/mod.rs:232-261)
+            gam = constants[0]
+            self.deg, self.f = 2, lambda v: v[0] * (v[1] + gam * v[2]) % FR
         else:
             self.deg, self.f = self.F[op]
         self.x = [list(o) for o in operands]
-        self.eq = P.eq_evals(r_node_output)
+        self.eq = P.eq_evals(r_node_output) if op not in ("dot", "gather") else [1] * len(self.x[0])
+        self.no_eq = op in ("dot", "gather")
         self._n = len(r_node_output)
 
     def num_rounds(self):
@@ -429,7 +435,7 @@ class ElementwiseModel:
         return from_coeff(c) if self.op == "cube" else c
 
     def ingest_challenge(self, r, rnd):
-        self.eq = P.bind(self.eq, r, L2H)
+        self.eq = [1] * (len(self.eq) // 2) if self.no_eq else P.bind(self.eq, r, L2H)
         self.x = [P.bind(x, r, L2H) for x in self.x]
 
     def finals(self):
