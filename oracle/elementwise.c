@@ -14,6 +14,7 @@
  *   div.rs:329-351     [ro0 q0 + R0 - lo0, ro_inf q_inf]                                          gruen_poly_deg_3
  *   rsqrt.rs:390-421   [x0 quot0 + dr0 - S^3 + gamma (out0^2 + sr0 - quot0), x_inf quot_inf + gamma out_inf^2]   gruen_poly_deg_3
  *   (scalar_const_div.rs:227-241 [lo0 - R0] is the Sub fold)
+ *   joltworks/src/subprotocols/hamming_booleanity.rs:131-156   sum_d gamma_d [hw_d0 (hw_d0 - 1), hw_d_inf^2]   gruen_poly_deg_3
  * and the selector-style provers without an eq factor (LowToHigh sumcheck_evals at 0 and 2, from_evals_and_hint):
  *   reshape.rs:286-308, slice.rs:254-274   input * selector;  concat.rs:290-317   sum over terms of input_t * selector_t
  *   gather/mod.rs:232-261                  ra * (dictionary + gamma * identity)
@@ -25,7 +26,7 @@
 void orc_elementwise_init(orc_elementwise *S, int op, const fr_t *const *operands, size_t n_ops, size_t n_vars, const fr_t *r_node_output,
                           const fr_t *constants, size_t n_constants) {
     memset(S, 0, sizeof *S);
-    for (size_t i = 0; i < n_constants && i < 2; i++) S->k[i] = constants[i];
+    for (size_t i = 0; i < n_constants && i < 16; i++) S->k[i] = constants[i];
     S->op = op; S->n_ops = n_ops; S->n_vars = n_vars; S->len = (size_t)1 << n_vars;
     for (size_t i = 0; i < n_ops; i++) { S->x[i] = (fr_t *)malloc(S->len * sizeof(fr_t)); memcpy(S->x[i], operands[i], S->len * sizeof(fr_t)); }
     gse_init(&S->eq, r_node_output, n_vars);
@@ -103,6 +104,17 @@ size_t orc_elementwise_message(orc_elementwise *S, const fr_t *claim, fr_t *coef
                 case ORC_EW_MUL:
                     fr_mul(&a[2 * g], &b[2 * g], &c0);
                     fr_sub(&a[2 * g + 1], &a[2 * g], &t); fr_sub(&b[2 * g + 1], &b[2 * g], &u); fr_mul(&t, &u, &e); break;
+                case ORC_EW_HAMMING_BOOL: {         /* x = hw_0 .. hw_{d-1}; k = gamma_powers */
+                    fr_zero(&c0);
+                    for (size_t d = 0; d < S->n_ops; d++) {
+                        const fr_t *hw = S->x[d]; fr_t a2, cc;
+                        fr_sub(&hw[2 * g + 1], &hw[2 * g], &t); fr_mul(&t, &t, &a2);
+                        fr_sub(&hw[2 * g], &one, &u); fr_mul(&hw[2 * g], &u, &cc);
+                        fr_mul(&cc, &S->k[d], &cc); fr_add(&c0, &cc, &c0);
+                        fr_mul(&a2, &S->k[d], &a2); fr_add(&e, &a2, &e);
+                    }
+                    break;
+                }
                 case ORC_EW_DIV: {                  /* x = left, right, q, R */
                     const fr_t *lo = S->x[0], *ro = S->x[1], *q = S->x[2], *R = S->x[3];
                     fr_mul(&ro[2 * g], &q[2 * g], &c0); fr_add(&c0, &R[2 * g], &c0); fr_sub(&c0, &lo[2 * g], &c0);

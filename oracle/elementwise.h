@@ -6,13 +6,13 @@
 
 enum { ORC_INST_ELEMENTWISE = 11 };
 enum { ORC_EW_ADD = 0, ORC_EW_SUB = 1, ORC_EW_NEG = 2, ORC_EW_SQUARE = 3, ORC_EW_IFF = 4, ORC_EW_MUL = 5, ORC_EW_CUBE = 6, ORC_EW_DIV = 7, ORC_EW_RSQRT = 8,
-       ORC_EW_DOT = 9, ORC_EW_GATHER = 10 };   /* no eq factor: sum of products, UniPoly::from_evals_and_hint */
+       ORC_EW_DOT = 9, ORC_EW_GATHER = 10, ORC_EW_HAMMING_BOOL = 11 };   /* no eq factor: sum of products, UniPoly::from_evals_and_hint */
 
 typedef struct {
     int op; size_t n_ops, n_vars, len;
     fr_t *x[16];                /* operands in cache_openings order (Iff: mask, a, b; Div: left, right, q, R;
                                  * Rsqrt: input, quotient, output, div_remainder, sqrt_remainder) */
-    fr_t k[2];                  /* Rsqrt: S^3, gamma; Gather: gamma */
+    fr_t k[16];                 /* Rsqrt: S^3, gamma; Gather: gamma; HammingBooleanity: gamma_powers */
     gse_t eq;
 } orc_elementwise;
 /* operands: n_ops arrays of 2^n_vars Fr; r_node_output: n_vars Fr (big-endian) */
