@@ -296,7 +296,7 @@ int atlas_ps_shout_clamp_new(const uint64_t *lookup_indices, size_t log_T, size_
  * final claims = the operands' final claims in that order. */
 enum { ATLAS_EW_ADD = 0, ATLAS_EW_SUB = 1, ATLAS_EW_NEG = 2, ATLAS_EW_SQUARE = 3, ATLAS_EW_IFF = 4, ATLAS_EW_MUL = 5,
        ATLAS_EW_CUBE = 6, ATLAS_EW_DIV = 7, ATLAS_EW_RSQRT = 8, ATLAS_EW_DOT = 9, ATLAS_EW_GATHER = 10,
-       ATLAS_EW_HAMMING_BOOL = 11 };
+       ATLAS_EW_HAMMING_BOOL = 11, ATLAS_EW_TELEPORT_DIV = 12 };
 /* ATLAS_EW_DIV (ops/div.rs:329-362): operands (left, right, q, R), summand right q + R - left, degree 3.
  * ATLAS_EW_RSQRT (ops/rsqrt.rs:390-433): operands (input, quotient, output, div_remainder, sqrt_remainder),
  * constants (S^3, gamma), summand input quotient + div_remainder - S^3 + gamma (output^2 + sqrt_remainder -
@@ -307,7 +307,12 @@ enum { ATLAS_EW_ADD = 0, ATLAS_EW_SUB = 1, ATLAS_EW_NEG = 2, ATLAS_EW_SQUARE = 3
  * gamma, summand ra (dictionary + gamma identity), degree 2.
  * ATLAS_EW_HAMMING_BOOL (joltworks/src/subprotocols/hamming_booleanity.rs:131-165): operands hw_0 .. hw_{d-1} (d <= 16),
  * constants gamma_powers (d of them), summand sum_d gamma_d (hw_d^2 - hw_d), degree 3.
- * `constants`: n_constants Fr, 2 for Rsqrt, 1 for Gather, d for HammingBooleanity, 0 (may be NULL) otherwise. */
+ * ATLAS_EW_TELEPORT_DIV (jolt-atlas-core/src/onnx_proof/neural_teleport/division.rs:231-256): operands (input, quotient,
+ * remainder), constant tau, summand tau quotient + remainder - input, degree 2.
+ * ATLAS_EW_GATHER also serves the small-table activation / Sin / Cos execution provers (ops/activation_clamped/mod.rs:295-332,
+ * ops/sin.rs:456-492, cos.rs): ra (table + gamma identity); ATLAS_EW_DOT with one pair is GammaFoldProver
+ * (joltworks/src/subprotocols/gamma_fold.rs:131-158).
+ * `constants`: n_constants Fr, 2 for Rsqrt, 1 for Gather / TeleportDivision, d for HammingBooleanity, 0 (may be NULL) otherwise. */
 int atlas_elementwise_new(int op, const atlas_poly_t *operands, size_t n_operands, const atlas_fr_t *r_node_output,
                           size_t n_vars, const atlas_fr_t *constants, size_t n_constants, atlas_instance_t *out);
 /* The same unary prover over RightShiftTable<XLEN> (joltworks/src/lookup_tables/right_shift.rs:17-60; used by

@@ -8,6 +8,7 @@
 //   div.rs:329-362 (left, right, q, R)   rsqrt.rs:390-433 (input, quotient, output, div_rem, sqrt_rem; S^3, gamma)
 //   scalar_const_div.rs:227-248 is the Sub fold over (left, R)
 //   joltworks/src/subprotocols/hamming_booleanity.rs:131-165 (hw_0 .. hw_{d-1}; gamma_powers)
+//   neural_teleport/division.rs:231-256 (input, quotient, remainder; tau)
 // and the selector-style provers WITHOUT an eq factor (sumcheck_evals at 0 and 2, UniPoly::from_evals_and_hint):
 //   reshape.rs:286-315, slice.rs:254-281 (input, selector); concat.rs:290-325 (input_t, selector_t per term);
 //   gather/mod.rs:232-268 (index_onehot, dictionary, identity; gamma)
@@ -20,14 +21,15 @@ namespace {
 
 enum { EW_ADD = ATLAS_EW_ADD, EW_SUB = ATLAS_EW_SUB, EW_NEG = ATLAS_EW_NEG, EW_SQUARE = ATLAS_EW_SQUARE, EW_IFF = ATLAS_EW_IFF,
        EW_MUL = ATLAS_EW_MUL, EW_CUBE = ATLAS_EW_CUBE, EW_DIV = ATLAS_EW_DIV, EW_RSQRT = ATLAS_EW_RSQRT,
-       EW_DOT = ATLAS_EW_DOT, EW_GATHER = ATLAS_EW_GATHER, EW_HAMMING_BOOL = ATLAS_EW_HAMMING_BOOL };
+       EW_DOT = ATLAS_EW_DOT, EW_GATHER = ATLAS_EW_GATHER, EW_HAMMING_BOOL = ATLAS_EW_HAMMING_BOOL,
+       EW_TELEPORT_DIV = ATLAS_EW_TELEPORT_DIV };
 
 struct EwConsts { Fr k[16]; uint32_t n_terms; };     // Rsqrt: S^3, gamma; Gather: gamma; HammingBooleanity: gamma_powers (n_terms of them);
                                                      // Dot: n_terms = number of (input, selector) pairs
 
 constexpr bool ew_has_eq(int op) { return op != EW_DOT && op != EW_GATHER; }
 constexpr int ew_outputs(int op) { return op == EW_CUBE ? 3 : (op == EW_DOT || op == EW_GATHER || op == EW_HAMMING_BOOL || op == EW_SQUARE || op == EW_MUL || op == EW_IFF || op == EW_DIV || op == EW_RSQRT) ? 2 : 1; }
-constexpr int ew_operands(int op) { return op == EW_GATHER ? 3 : op == EW_RSQRT ? 5 : op == EW_DIV ? 4 : op == EW_IFF ? 3 : (op == EW_ADD || op == EW_SUB || op == EW_MUL) ? 2 : 1; }
+constexpr int ew_operands(int op) { return (op == EW_GATHER || op == EW_TELEPORT_DIV) ? 3 : op == EW_RSQRT ? 5 : op == EW_DIV ? 4 : op == EW_IFF ? 3 : (op == EW_ADD || op == EW_SUB || op == EW_MUL) ? 2 : 1; }
 
 __global__ __launch_bounds__(RA_THREADS) void k_ew_from_i32(const int32_t* __restrict__ in, Fr* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * RA_THREADS)
@@ -48,6 +50,8 @@ __global__ __launch_bounds__(RA_THREADS) void k_ew_fold(const Fr* __restrict__ r
         if constexpr (OP == EW_ADD) v[0] = fr_add(a0, fe_load(rows + stride + 2 * g));
         else if constexpr (OP == EW_SUB) v[0] = fr_sub(a0, fe_load(rows + stride + 2 * g));
         else if constexpr (OP == EW_NEG) v[0] = fr_sub(fe_zero(), a0);
+        else if constexpr (OP == EW_TELEPORT_DIV)      // rows: input, quotient, remainder: tau q0 + r0 - inp0
+            v[0] = fr_sub(fr_add(fr_mul(C.k[0], fe_load(rows + stride + 2 * g)), fe_load(rows + 2 * stride + 2 * g)), a0);
         else if constexpr (OP == EW_SQUARE) { const Fr d = fr_sub(a1, a0); v[0] = fr_mul(a0, a0); v[1] = fr_mul(d, d); }
         else if constexpr (OP == EW_MUL) {
             const Fr b0 = fe_load(rows + stride + 2 * g), b1 = fe_load(rows + stride + 2 * g + 1);
@@ -126,7 +130,7 @@ struct Elementwise : atlas_instance {
         const Fr* src = rows.buf[rows.cur]; const size_t st = rows.stride[rows.cur];
         switch (op) {
 #define EW_CASE(OP) case OP: k_ew_fold<OP><<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(src, st, E, n_groups, consts, rows.partials); break;
-            EW_CASE(EW_ADD) EW_CASE(EW_SUB) EW_CASE(EW_NEG) EW_CASE(EW_SQUARE) EW_CASE(EW_IFF) EW_CASE(EW_MUL) EW_CASE(EW_CUBE) EW_CASE(EW_DIV) EW_CASE(EW_RSQRT) EW_CASE(EW_DOT) EW_CASE(EW_GATHER) EW_CASE(EW_HAMMING_BOOL)
+            EW_CASE(EW_ADD) EW_CASE(EW_SUB) EW_CASE(EW_NEG) EW_CASE(EW_SQUARE) EW_CASE(EW_IFF) EW_CASE(EW_MUL) EW_CASE(EW_CUBE) EW_CASE(EW_DIV) EW_CASE(EW_RSQRT) EW_CASE(EW_DOT) EW_CASE(EW_GATHER) EW_CASE(EW_HAMMING_BOOL) EW_CASE(EW_TELEPORT_DIV)
 #undef EW_CASE
             default: return fail(ATLAS_EINVAL, "elementwise: unknown operator");
         }
@@ -174,9 +178,9 @@ int atlas_elementwise_new(int op, const atlas_poly_t* operands, size_t n_operand
                           const atlas_fr_t* constants, size_t n_constants, atlas_instance_t* out) {
     NEED_INIT();
     if (!operands || !out || (!r_node_output && op != EW_DOT && op != EW_GATHER)) return fail(ATLAS_EINVAL, "elementwise_new: null argument");
-    if (op < EW_ADD || op > EW_HAMMING_BOOL) return fail(ATLAS_EINVAL, "elementwise_new: unknown operator");
-    if (n_constants != (op == EW_RSQRT ? 2u : op == EW_GATHER ? 1u : op == EW_HAMMING_BOOL ? n_operands : 0u) || (n_constants && !constants))
-        return fail(ATLAS_EINVAL, "elementwise_new: constants are (S^3, gamma) for Rsqrt, (gamma) for Gather, one gamma power per operand for HammingBooleanity");
+    if (op < EW_ADD || op > EW_TELEPORT_DIV) return fail(ATLAS_EINVAL, "elementwise_new: unknown operator");
+    if (n_constants != (op == EW_RSQRT ? 2u : (op == EW_GATHER || op == EW_TELEPORT_DIV) ? 1u : op == EW_HAMMING_BOOL ? n_operands : 0u) || (n_constants && !constants))
+        return fail(ATLAS_EINVAL, "elementwise_new: constants are (S^3, gamma) for Rsqrt, (gamma) for Gather, (tau) for TeleportDivision, one gamma power per operand for HammingBooleanity");
     if (op == EW_DOT ? (n_operands < 2 || n_operands % 2 || n_operands > RA_MAX_D)
         : op == EW_HAMMING_BOOL ? (n_operands < 1 || n_operands > RA_MAX_D) : n_operands != (size_t)ew_operands(op))
         return fail(ATLAS_EINVAL, "elementwise_new: wrong operand count for the operator");

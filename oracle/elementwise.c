@@ -15,6 +15,7 @@
  *   rsqrt.rs:390-421   [x0 quot0 + dr0 - S^3 + gamma (out0^2 + sr0 - quot0), x_inf quot_inf + gamma out_inf^2]   gruen_poly_deg_3
  *   (scalar_const_div.rs:227-241 [lo0 - R0] is the Sub fold)
  *   joltworks/src/subprotocols/hamming_booleanity.rs:131-156   sum_d gamma_d [hw_d0 (hw_d0 - 1), hw_d_inf^2]   gruen_poly_deg_3
+ *   neural_teleport/division.rs:231-256   [tau q0 + r0 - inp0]   (input, quotient, remainder; tau)   gruen_poly_deg_2
  * and the selector-style provers without an eq factor (LowToHigh sumcheck_evals at 0 and 2, from_evals_and_hint):
  *   reshape.rs:286-308, slice.rs:254-274   input * selector;  concat.rs:290-317   sum over terms of input_t * selector_t
  *   gather/mod.rs:232-261                  ra * (dictionary + gamma * identity)
@@ -115,6 +116,8 @@ size_t orc_elementwise_message(orc_elementwise *S, const fr_t *claim, fr_t *coef
                     }
                     break;
                 }
+                case ORC_EW_TELEPORT_DIV:           /* x = input, quotient, remainder; k[0] = divisor */
+                    fr_mul(&S->k[0], &S->x[1][2 * g], &c0); fr_add(&c0, &S->x[2][2 * g], &c0); fr_sub(&c0, &S->x[0][2 * g], &c0); break;
                 case ORC_EW_DIV: {                  /* x = left, right, q, R */
                     const fr_t *lo = S->x[0], *ro = S->x[1], *q = S->x[2], *R = S->x[3];
                     fr_mul(&ro[2 * g], &q[2 * g], &c0); fr_add(&c0, &R[2 * g], &c0); fr_sub(&c0, &lo[2 * g], &c0);
@@ -144,7 +147,7 @@ size_t orc_elementwise_message(orc_elementwise *S, const fr_t *claim, fr_t *coef
         }
         fr_t t; fr_mul(&e_out[xo], &in0, &t); fr_add(&q0, &t, &q0); fr_mul(&e_out[xo], &ine, &t); fr_add(&qe, &t, &qe);
     }
-    if (S->op == ORC_EW_ADD || S->op == ORC_EW_SUB || S->op == ORC_EW_NEG) return gruen_deg2(E, &q0, claim, coeffs);
+    if (S->op == ORC_EW_ADD || S->op == ORC_EW_SUB || S->op == ORC_EW_NEG || S->op == ORC_EW_TELEPORT_DIV) return gruen_deg2(E, &q0, claim, coeffs);
     gse_gruen_deg3(E, &q0, &qe, claim, coeffs);
     return 4;
 }

@@ -6,7 +6,7 @@
 
 enum { ORC_INST_ELEMENTWISE = 11 };
 enum { ORC_EW_ADD = 0, ORC_EW_SUB = 1, ORC_EW_NEG = 2, ORC_EW_SQUARE = 3, ORC_EW_IFF = 4, ORC_EW_MUL = 5, ORC_EW_CUBE = 6, ORC_EW_DIV = 7, ORC_EW_RSQRT = 8,
-       ORC_EW_DOT = 9, ORC_EW_GATHER = 10, ORC_EW_HAMMING_BOOL = 11 };   /* no eq factor: sum of products, UniPoly::from_evals_and_hint */
+       ORC_EW_DOT = 9, ORC_EW_GATHER = 10, ORC_EW_HAMMING_BOOL = 11, ORC_EW_TELEPORT_DIV = 12 };   /* no eq factor: sum of products, UniPoly::from_evals_and_hint */
 
 typedef struct {
     int op; size_t n_ops, n_vars, len;

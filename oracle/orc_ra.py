@@ -144,7 +144,7 @@ def ps_rshift(lookup_indices, N, shift, r_node, gamma):
 
 
 ELEMENTWISE = 11
-EW_ADD, EW_SUB, EW_NEG, EW_SQUARE, EW_IFF, EW_MUL, EW_CUBE, EW_DIV, EW_RSQRT, EW_DOT, EW_GATHER, EW_HAMMING_BOOL = range(12)
+EW_ADD, EW_SUB, EW_NEG, EW_SQUARE, EW_IFF, EW_MUL, EW_CUBE, EW_DIV, EW_RSQRT, EW_DOT, EW_GATHER, EW_HAMMING_BOOL, EW_TELEPORT_DIV = range(13)
 
 
 def elementwise(op, operands, r_node_output, constants=None):

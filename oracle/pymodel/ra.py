@@ -407,6 +407,9 @@ class ElementwiseModel:
         elif op == "hamming_bool":  # hw_0 .. hw_{d-1}; constants gamma_powers (subprotocols/hamming_booleanity.rs:131-156)
             gp = list(constants)
             self.deg, self.f = 3, lambda v: sum(g_ * (h * h - h) for g_, h in zip(gp, v)) % FR
+        elif op == "teleport_div":  # input, quotient, remainder; constant tau (neural_teleport/division.rs:231-249)
+            tau = constants[0]
+            self.deg, self.f = 2, lambda v: (tau * v[1] + v[2] - v[0]) % FR
         elif op == "dot":          # pairs (input_t, selector_t), no eq factor (ops/reshape.rs, slice.rs, concat.rs)
             self.deg, self.f = 2, lambda v: sum(v[i] * v[i + 1] for i in range(0, len(v), 2)) % FR
         elif op == "gather":       # ra, dictionary, identity; constant gamma (ops/gather/mod.rs:232-261)

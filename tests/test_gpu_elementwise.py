@@ -5,7 +5,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 _EW = {"add": (0, 2), "sub": (1, 2), "neg": (2, 1), "square": (3, 1), "iff": (4, 3), "mul": (5, 2), "cube": (6, 1),
-       "div": (7, 4), "rsqrt": (8, 5), "dot": (9, 6), "gather": (10, 3), "hamming_bool": (11, 5)}
+       "div": (7, 4), "rsqrt": (8, 5), "dot": (9, 6), "gather": (10, 3), "hamming_bool": (11, 5), "teleport_div": (12, 3)}
 
 
 def _operands(orc, op, n, seed, as_i32):
@@ -35,7 +35,7 @@ def test_elementwise_bit_exact(atlas, op, n_vars, as_i32, mode):
         r_node = orc.random_fr(n_vars, 3)
         claim = orc.random_fr(1, 4)[0]            # the driver never checks s(0) + s(1) = claim; Gruen uses it as given
         consts = np.stack([orc.from_ints([1 << 42])[0], orc.random_fr(1, 8)[0]]) if op == "rsqrt" else \
-            orc.random_fr(1, 8) if op == "gather" else orc.random_fr(5, 8) if op == "hamming_bool" else None
+            orc.random_fr(1, 8) if op == "gather" else orc.random_fr(5, 8) if op == "hamming_bool" else orc.from_ints([12345]) if op == "teleport_div" else None
         o = OR.elementwise(code, ops_fr, r_node, consts)
         t_o = orc.new_transcript(b"ew")
         rows_o, ch_o = o.prove(claim, t_o)

@@ -339,7 +339,7 @@ def test_ps_shout_unsigned_less_than_oracle_matches_closed_form_model(log_T):
 
 
 _EW = {"add": (0, 2), "sub": (1, 2), "neg": (2, 1), "square": (3, 1), "iff": (4, 3), "mul": (5, 2), "cube": (6, 1),
-       "div": (7, 4), "rsqrt": (8, 5), "dot": (9, 6), "gather": (10, 3), "hamming_bool": (11, 5)}
+       "div": (7, 4), "rsqrt": (8, 5), "dot": (9, 6), "gather": (10, 3), "hamming_bool": (11, 5), "teleport_div": (12, 3)}
 
 
 @pytest.mark.parametrize("op", sorted(_EW))
@@ -355,7 +355,7 @@ def test_elementwise_oracle_matches_naive_model(op, n_vars):
     if op == "iff":
         operands[0] = [int(v) for v in rng.integers(0, 2, size=n)]
     r_node = _rand(n_vars, 17)
-    consts = [(1 << 42) % F.FR, _rand(1, 23)[0]] if op == "rsqrt" else [_rand(1, 23)[0]] if op == "gather" else _rand(5, 29) if op == "hamming_bool" else []
+    consts = [(1 << 42) % F.FR, _rand(1, 23)[0]] if op == "rsqrt" else [_rand(1, 23)[0]] if op == "gather" else _rand(5, 29) if op == "hamming_bool" else [12345] if op == "teleport_div" else []
     model = PR.ElementwiseModel(op, operands, r_node, consts)
     claim = model.input_claim()
     rows_p, raw_p, tp = _prove_py(model, claim, b"elementwise")
