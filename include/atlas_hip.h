@@ -315,6 +315,17 @@ enum { ATLAS_EW_ADD = 0, ATLAS_EW_SUB = 1, ATLAS_EW_NEG = 2, ATLAS_EW_SQUARE = 3
  * `constants`: n_constants Fr, 2 for Rsqrt, 1 for Gather / TeleportDivision, d for HammingBooleanity, 0 (may be NULL) otherwise. */
 int atlas_elementwise_new(int op, const atlas_poly_t *operands, size_t n_operands, const atlas_fr_t *r_node_output,
                           size_t n_vars, const atlas_fr_t *constants, size_t n_constants, atlas_instance_t *out);
+/* The two-phase provers of softmax_last_axis (jolt-atlas-core/src/onnx_proof/ops/softmax_last_axis/exp_sum.rs:146-197,
+ * max.rs:185-261, recip_mult.rs:196-268) and SumAxisProver (ops/sum/axis.rs:220-232).  Tensors are [k][j] with
+ * K = 2^log_K rows and N = 2^log_N last-axis entries, bound LowToHigh (last axis first); log_K + log_N rounds.
+ *   ATLAS_SM_EXP_SUM        a = exp_q;            r = r0_k (log_K Fr);  degree 2 (phase-1 messages have degree 1)
+ *   ATLAS_SM_MAX_INDICATOR  a = X, b = e;         r = r1_k (log_K Fr);  degree 3
+ *   ATLAS_SM_RECIP_MULT     a = exp_q, b = inv_sum (2^log_K);  r = the opening point (log_K + log_N Fr);  degree 3
+ *   ATLAS_SM_SUM_AXIS       a = operand (2^log_N, log_K = 0, HighToLow, r unused);  degree 1
+ * Operands are LargeScalars or I32Scalars handles (not consumed); final claims = a(r) [, b(r)]. */
+enum { ATLAS_SM_EXP_SUM = 0, ATLAS_SM_MAX_INDICATOR = 1, ATLAS_SM_RECIP_MULT = 2, ATLAS_SM_SUM_AXIS = 3 };
+int atlas_softmax_instance_new(int kind, atlas_poly_t a, atlas_poly_t b, size_t log_K, size_t log_N,
+                               const atlas_fr_t *r, atlas_instance_t *out);
 /* The same unary prover over RightShiftTable<XLEN> (joltworks/src/lookup_tables/right_shift.rs:17-60; used by
  * the Sin / Cos trig downscale, jolt-atlas-core/src/onnx_proof/ops/sin.rs:108, cos.rs:113): Val(k) = k >> shift
  * (unsigned; shift = TRIG_DOWNSCALE_BITS in the reference), prefix TrigRightShift, suffixes [One, TrigRightShift],

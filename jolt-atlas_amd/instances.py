@@ -163,6 +163,19 @@ def elementwise(op, operands, r_node_output, constants=None):
     return Instance(h)
 
 
+SM_EXP_SUM, SM_MAX_INDICATOR, SM_RECIP_MULT, SM_SUM_AXIS = range(4)
+
+
+def softmax_instance(kind, a, b, log_K, log_N, r):
+    """ExpSumProver / MaxIndicatorProver / RecipMultProver (ops/softmax_last_axis/) and SumAxisProver (ops/sum/axis.rs)
+    over device polynomials (not consumed)."""
+    rr = np.ascontiguousarray(r, dtype=np.uint64) if r is not None else None
+    h = C.c_void_p()
+    _check(lib.atlas_softmax_instance_new(C.c_int(kind), a.h, b.h if b is not None else None, C.c_size_t(log_K), C.c_size_t(log_N),
+                                          _p(rr) if rr is not None else None, C.byref(h)))
+    return Instance(h)
+
+
 def ps_shout_rshift(lookup_indices, xlen, shift, r_node_output, gamma):
     """ps_read_raf_prover for RightShiftTable<xlen> by `shift` bits (lookup_tables/right_shift.rs; Sin/Cos downscale)."""
     idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)

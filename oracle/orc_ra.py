@@ -167,6 +167,29 @@ def elementwise(op, operands, r_node_output, constants=None):
     return I
 
 
+SOFTMAX = 12
+SM_EXP_SUM, SM_MAX_INDICATOR, SM_RECIP_MULT, SM_SUM_AXIS = range(4)
+
+
+def softmax(kind, a, b, log_K, log_N, r):
+    """ExpSumProver / MaxIndicatorProver / RecipMultProver (ops/softmax_last_axis/) and SumAxisProver (ops/sum/axis.rs)."""
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64) if b is not None else None
+    r = np.ascontiguousarray(r, dtype=np.uint64) if r is not None else np.zeros((0, 4), dtype=np.uint64)
+    I = Instance(SOFTMAX, log_K + log_N)
+    I.keep = [a, b, r]
+    orc.lib.orc_softmax_init(I.st, C.c_int(kind), orc._p(a), orc._p(b) if b is not None else None, C.c_size_t(log_K), C.c_size_t(log_N),
+                             orc._p(r) if len(r) else None)
+    n_fin = 2 if b is not None else 1
+
+    def finals():
+        out = orc.fr_array(2)
+        orc.lib.orc_softmax_finals(I.st, orc._p(out))
+        return out[:n_fin]
+    I.finals = finals
+    return I
+
+
 PS_IDENTITY = 8
 
 

@@ -446,3 +446,72 @@ class ElementwiseModel:
 
     def finals(self):
         return [x[0] for x in self.x]
+
+
+class SoftmaxModel:
+    """Dense-table models of the softmax_last_axis provers (ops/softmax_last_axis/exp_sum.rs, max.rs, recip_mult.rs) and
+    of SumAxisProver (ops/sum/axis.rs): every factor — including the eq factor that the provers keep as a K-entry
+    table or a Gruen split — is a full table over (k, j); the round polynomial comes from evaluation and
+    interpolation, with the coefficient-vector lengths the reference produces (from_coeff trims the degree-1
+    messages; from_evals of 3 / 4 points keeps its length)."""
+
+    def __init__(self, kind, a, b, log_K, log_N, r):
+        self.kind, self.log_K, self.log_N = kind, log_K, log_N
+        N = 1 << log_N
+        self.tabs = [list(a)]
+        if kind == "max":
+            self.tabs.append(list(b))
+        if kind == "recip":
+            self.tabs.append([b[kj >> log_N] for kj in range(len(a))])
+        if kind in ("exp_sum", "max"):
+            ek = P.eq_evals(r)
+            self.tabs.append([ek[kj >> log_N] for kj in range(len(a))])
+        if kind == "recip":
+            self.tabs.append(P.eq_evals(r))
+        self.order = P.HIGH_TO_LOW if kind == "sum_axis" else L2H
+        self._n = log_K + log_N
+
+    def num_rounds(self):
+        return self._n
+
+    def input_claim(self):
+        acc = 0
+        for i in range(len(self.tabs[0])):
+            t = 1
+            for tab in self.tabs:
+                t = t * tab[i] % FR
+            acc = (acc + t) % FR
+        return acc
+
+    def _ext(self, z, i, npts):
+        half = len(z) // 2
+        a, b = (z[2 * i], z[2 * i + 1]) if self.order == L2H else (z[i], z[i + half])
+        m = (b - a) % FR
+        return [(a + x * m) % FR for x in range(npts)]
+
+    def compute_message(self, rnd, previous_claim):
+        phase1 = rnd < self.log_N
+        if self.kind in ("sum_axis",) or (self.kind == "exp_sum" and phase1):
+            n_co, trimmed = 2, True
+        elif (self.kind == "exp_sum" and not phase1) or (self.kind == "recip" and phase1):
+            n_co, trimmed = 3, False
+        else:
+            n_co, trimmed = 4, False
+        ev = [0] * n_co
+        for i in range(len(self.tabs[0]) // 2):
+            cols = [self._ext(t, i, n_co) for t in self.tabs]
+            for X in range(n_co):
+                t = 1
+                for c in cols:
+                    t = t * c[X] % FR
+                ev[X] = (ev[X] + t) % FR
+        assert (ev[0] + ev[1]) % FR == previous_claim % FR
+        c = interpolate(ev)
+        return from_coeff(c) if trimmed else c
+
+    def ingest_challenge(self, r, rnd):
+        self.tabs = [P.bind(t, r, self.order) for t in self.tabs]
+
+    def finals(self):
+        n = 2 if self.kind in ("max", "recip") else 1
+        return [t[0] for t in self.tabs[:n]]

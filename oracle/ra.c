@@ -17,6 +17,7 @@
 #include "opening.h"
 #include "psshout.h"
 #include "elementwise.h"
+#include "softmax.h"
 
 /* ------------------------------------------------------------------ small helpers */
 static size_t trim(fr_t *c, size_t n) {                 /* UniPoly::from_coeff (unipoly.rs:39-52) */
@@ -339,6 +340,7 @@ static size_t inst_message(int kind, void *st, size_t round, const fr_t *claim, 
         case ORC_INST_PS_CLAMP: return orc_ps_clamp_message((orc_ps_clamp *)st, round, claim, c);
         case ORC_INST_PS_ULT: return orc_ps_ult_message((orc_ps_ult *)st, round, claim, c);
         case ORC_INST_ELEMENTWISE: return orc_elementwise_message((orc_elementwise *)st, claim, c);
+        case ORC_INST_SOFTMAX: return orc_softmax_message((orc_softmax *)st, round, claim, c);
         default: return orc_hamming_message((orc_hamming *)st, claim, c);
     }
 }
@@ -353,6 +355,7 @@ static void inst_ingest(int kind, void *st, size_t round, const fr_t *r) {
         case ORC_INST_PS_CLAMP: orc_ps_clamp_ingest((orc_ps_clamp *)st, round, r); break;
         case ORC_INST_PS_ULT: orc_ps_ult_ingest((orc_ps_ult *)st, round, r); break;
         case ORC_INST_ELEMENTWISE: orc_elementwise_ingest((orc_elementwise *)st, r); break;
+        case ORC_INST_SOFTMAX: orc_softmax_ingest((orc_softmax *)st, round, r); break;
         default: orc_hamming_ingest((orc_hamming *)st, r); break;
     }
 }

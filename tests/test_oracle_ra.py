@@ -366,3 +366,33 @@ def test_elementwise_oracle_matches_naive_model(op, n_vars):
     assert [orc.to_ints(r) for r in rows_o] == rows_p
     assert bytes(to.state) == tp.state
     assert orc.to_ints(inst.finals()) == model.finals()
+
+
+@pytest.mark.parametrize("kind,log_K,log_N", [("exp_sum", 2, 3), ("exp_sum", 1, 1), ("exp_sum", 3, 2), ("max", 2, 3), ("max", 1, 2),
+                                              ("recip", 2, 3), ("recip", 3, 1), ("recip", 1, 4), ("sum_axis", 0, 4), ("sum_axis", 0, 1)])
+def test_softmax_and_sum_axis_oracle_matches_dense_model(kind, log_K, log_N):
+    """oracle/softmax.c (K-entry eq table in phase 1, Gruen split-eq in phase 2, degree-1 hint messages) against the
+    dense-table model."""
+    code = {"exp_sum": 0, "max": 1, "recip": 2, "sum_axis": 3}[kind]
+    n = 1 << (log_K + log_N)
+    rng = np.random.default_rng(code * 100 + log_K * 10 + log_N)
+    a = [int(v) % F.FR for v in rng.integers(-(1 << 15), 1 << 15, size=n)]
+    b = None
+    if kind == "max":                          # one-hot argmax indicator per row
+        b = [0] * n
+        for k in range(1 << log_K):
+            b[(k << log_N) + int(rng.integers(0, 1 << log_N))] = 1
+    if kind == "recip":
+        b = [int(v) for v in rng.integers(1, 1 << 20, size=1 << log_K)]
+    r = _rand(log_K + (log_N if kind == "recip" else 0), 31) if kind != "sum_axis" else []
+    model = PR.SoftmaxModel(kind, a, b, log_K, log_N, r)
+    claim = model.input_claim()
+    rows_p, raw_p, tp = _prove_py(model, claim, b"softmax")
+    inst = OR.softmax(code, orc.from_ints(a), orc.from_ints(b) if b is not None else None, log_K, log_N,
+                      orc.from_ints(r) if r else None)
+    to = orc.new_transcript(b"softmax")
+    rows_o, raw_o = inst.prove(orc.from_ints([claim])[0], to)
+    assert raw_o == raw_p
+    assert [orc.to_ints(x) for x in rows_o] == rows_p
+    assert bytes(to.state) == tp.state
+    assert orc.to_ints(inst.finals()) == model.finals()
