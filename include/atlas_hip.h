@@ -92,7 +92,10 @@ int atlas_poly_final_claim(atlas_poly_t p, atlas_fr_t *out);
  *       jolt-atlas-core/src/onnx_proof/ops/einsum/dot.rs:255-375) ---------------------- */
 typedef struct atlas_dot_prover *atlas_dot_prover_t;
 /* Takes ownership of left/right/eq (they are consumed by binding, like the reference's
- * `left`, `right`, `eq` fields).  eq may be NULL iff schedule == ATLAS_EQ_NONE. */
+ * `left`, `right`, `eq` fields).  eq may be NULL iff schedule == ATLAS_EQ_NONE.
+ * MeanOfSquaresReductionProver (jolt-atlas-core/src/onnx_proof/ops/mean_of_squares.rs:363-398) is this prover with
+ * left = right = the operand (two handles: atlas_poly_clone), eq = EqPolynomial::evals(r_node_output) and
+ * ATLAS_EQ_HIGH { sched_a = log_retained, sched_b = log_reduced }. */
 int atlas_dot_prover_new(atlas_poly_t left, atlas_poly_t right, atlas_poly_t eq, int schedule,
                          size_t sched_a, size_t sched_b, atlas_dot_prover_t *out);
 int atlas_dot_prover_free(atlas_dot_prover_t p);

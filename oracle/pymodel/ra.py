@@ -463,12 +463,14 @@ class SoftmaxModel:
             self.tabs.append(list(b))
         if kind == "recip":
             self.tabs.append([b[kj >> log_N] for kj in range(len(a))])
-        if kind in ("exp_sum", "max"):
+        if kind == "mean_sq":      # MeanOfSquaresReductionProver (ops/mean_of_squares.rs:363-398): operand^2 eq(retained), HighToLow
+            self.tabs.append(list(a))
+        if kind in ("exp_sum", "max", "mean_sq"):
             ek = P.eq_evals(r)
             self.tabs.append([ek[kj >> log_N] for kj in range(len(a))])
         if kind == "recip":
             self.tabs.append(P.eq_evals(r))
-        self.order = P.HIGH_TO_LOW if kind == "sum_axis" else L2H
+        self.order = P.HIGH_TO_LOW if kind in ("sum_axis", "mean_sq") else L2H
         self._n = log_K + log_N
 
     def num_rounds(self):

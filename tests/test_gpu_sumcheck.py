@@ -161,3 +161,16 @@ def test_errors_are_loud(atlas):
     with pytest.raises(A.AtlasError):
         p.final_claim()                                                         # not fully bound
     p.free(); q.free()
+
+
+@pytest.mark.parametrize("log_retained,log_reduced", [(3, 5), (1, 9), (6, 8)])
+def test_mean_of_squares_mapping(atlas, log_retained, log_reduced):
+    """MeanOfSquaresReductionProver = the dot prover with left = right = operand, EqSchedule::High (mean_of_squares.rs:363-398)."""
+    from oracle import orc
+    n = log_retained + log_reduced
+    op = orc.random_fr(1 << n, 77 + n)
+    eq = orc.eq_evals(orc.random_fr(log_retained, 78))
+    claim, proof_o, ch_o, fin_o, st_o, nr_o = _oracle_run(orc, op, op.copy(), eq, 1, log_retained, log_reduced)
+    proof_g, ch_g, fin_g, st_g, nr_g = _gpu_run(atlas, op, op.copy(), eq, 1, log_retained, log_reduced, claim)
+    assert ch_g == ch_o and np.array_equal(proof_g, proof_o) and np.array_equal(fin_g, fin_o) and st_g == st_o
+    assert np.array_equal(fin_g[0], fin_g[1])

@@ -396,3 +396,24 @@ def test_softmax_and_sum_axis_oracle_matches_dense_model(kind, log_K, log_N):
     assert [orc.to_ints(x) for x in rows_o] == rows_p
     assert bytes(to.state) == tp.state
     assert orc.to_ints(inst.finals()) == model.finals()
+
+
+@pytest.mark.parametrize("log_retained,log_reduced", [(2, 3), (0, 4), (3, 1), (1, 1)])
+def test_mean_of_squares_is_the_dot_prover_with_eq_high(log_retained, log_reduced):
+    """MeanOfSquaresReductionProver (ops/mean_of_squares.rs:363-398) = EinsumDotProver with left = right = operand and
+    EqSchedule::High { log_eq = log_retained, low_bits = log_reduced }: the oracle's dot prover against the dense model."""
+    n = 1 << (log_retained + log_reduced)
+    rng = np.random.default_rng(10 * log_retained + log_reduced)
+    a = [int(v) % F.FR for v in rng.integers(-(1 << 15), 1 << 15, size=n)]
+    r = _rand(log_retained, 41)
+    model = PR.SoftmaxModel("mean_sq", a, None, log_retained, log_reduced, r)
+    claim = model.input_claim()
+    rows_p, raw_p, tp = _prove_py(model, claim, b"mean_sq")
+    L = orc.from_ints(a)
+    eq = orc.eq_evals(orc.from_ints(r)) if log_retained else orc.from_ints([1])
+    to = orc.new_transcript(b"mean_sq")
+    proof, ch, fin = orc.sumcheck_dot_prove(L, L.copy(), orc.from_ints([claim]), to, eq, 1, log_retained, log_reduced)
+    assert ch == raw_p
+    assert [orc.to_ints(row) for row in proof] == rows_p
+    assert bytes(to.state_bytes()) == tp.state
+    assert orc.to_ints(fin[:1]) == model.finals()[:1]
