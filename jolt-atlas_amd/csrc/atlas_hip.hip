@@ -132,6 +132,8 @@ int atlas_shutdown(void) {
     std::lock_guard<std::mutex> lk(g.mu);
     if (!g.ready) return ATLAS_OK;
     hipStreamSynchronize(g.stream);
+    for (auto f : g.at_shutdown) f();
+    g.at_shutdown.clear();
     hipFree(g.d_partials); hipFree(g.d_ctx); hipFree(g.d_proof); hipFree(g.d_chal); hipFree(g.d_finals);
     hipHostFree(g.h_pinned);
     hipStreamDestroy(g.stream);

@@ -32,10 +32,14 @@ struct atlas_srs {
 namespace {
 
 // grow-only device workspace shared by MSM calls (serialised by g.mu)
+void release_arenas();
 struct Workspace {
     void* p = nullptr;
     size_t cap = 0;
     int ensure(size_t bytes) {
+        bool hooked = false;              // callers hold g.mu
+        for (auto f : g.at_shutdown) hooked |= f == &release_arenas;
+        if (!hooked) g.at_shutdown.push_back(&release_arenas);
         if (bytes <= cap) return ATLAS_OK;
         if (p) hipFree(p);
         p = nullptr; cap = 0;
@@ -271,6 +275,12 @@ static int msm_multi_group(const G1Affine* bases, const Fr* d_scalars, MsmGroup&
 Workspace ws_side;                 // second lane: the narrow pipeline of msm_device_multi
 hipStream_t side_stream = nullptr;
 hipEvent_t side_event = nullptr;
+
+void release_arenas() {            // atlas_shutdown
+    for (Workspace* w : {&ws, &hk_arena, &ws_side}) { if (w->p) hipFree(w->p); w->p = nullptr; w->cap = 0; }
+    if (side_stream) { hipStreamDestroy(side_stream); side_stream = nullptr; }
+    if (side_event) { hipEventDestroy(side_event); side_event = nullptr; }
+}
 
 int msm_device_multi(const G1Affine* bases, const Fr* d_scalars, size_t n_tot, size_t K, const size_t* lens, const size_t* offs,
                      atlas_g1_affine_t* out) {

@@ -4,6 +4,7 @@
 
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/atlas_hip.h"
 
@@ -37,6 +38,7 @@ struct Runtime {
     uint64_t* d_chal = nullptr;        // up to 64 rounds * 2
     atlas::Fe* d_finals = nullptr;     // 3 (+ scratch for reduced evals)
     void* h_pinned = nullptr;          // pinned staging for small D2H/H2D
+    std::vector<void (*)()> at_shutdown;   // release hooks of the translation units that keep device arenas
     std::mutex mu;
 };
 extern Runtime g;
