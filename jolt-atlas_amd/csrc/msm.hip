@@ -154,6 +154,7 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
     // load-balanced accumulation: segments of <= MSM_SEG_LEN sorted entries (see msm_kernels.hip.h)
     // segment length: full length for big problems, shorter when there would be fewer than ~2^17 segments
     uint32_t seg_len = MSM_SEG_LEN;
+    if (const char* e = getenv("ATLAS_MSM_SEG")) { int v = atoi(e); if (v >= 8 && v <= 4096 && (v & (v - 1)) == 0) seg_len = (uint32_t)v; }   // experiments
     while (seg_len > 8 && (n * (size_t)S.n_windows) / seg_len < ((size_t)1 << 17)) seg_len >>= 1;
     const size_t s_max = (n * (size_t)S.n_windows) / seg_len + TB + 1;
     const size_t o_segc = carve((size_t)(TB + 1) * 4);
@@ -211,7 +212,7 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
     k_scan_apply<<<(unsigned)n_scan_blocks, 256, 0, st>>>(segc, TB, boff, seg_off, seg_cur, (uint32_t)n_scan_blocks);
     k_msm_accumulate_seg<<<(unsigned)((s_max + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(bases, sorted, offsets, seg_off, TB, seg_len, partial);
     k_msm_bucket_reduce_small<<<(TB + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(partial, seg_off, TB, buckets);
-    k_msm_bucket_reduce_big<<<TB, MSM_THREADS, 0, st>>>(partial, seg_off, buckets);
+    k_msm_bucket_reduce_big<<<TB < 2048u ? TB : 2048u, MSM_THREADS, 0, st>>>(partial, seg_off, TB, buckets);
     if (timing) hipEventRecord(e2, st);
     k_msm_fold_chunks<<<(n_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(buckets, S, chunk, n_chunks, chunks);
     k_g1_group_sum<<<V, MSM_THREADS, 0, st>>>(chunks, chunks_per_window, wsum);

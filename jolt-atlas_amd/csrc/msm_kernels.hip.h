@@ -266,23 +266,26 @@ __global__ __launch_bounds__(MSM_THREADS) void k_msm_bucket_reduce_small(const G
     g1_store(buckets + b, acc);
 }
 
-// the long ones: one workgroup per bucket (workgroups of short buckets leave at once)
+// the long ones: a workgroup per bucket, the grid strides over the buckets (most have few segments and are skipped;
+// a grid of one workgroup per bucket spent ~0.27 ms at 2^22 launching 82 k workgroups that left at once)
 __global__ __launch_bounds__(MSM_THREADS) void k_msm_bucket_reduce_big(const G1Xyzz* __restrict__ partial,
-                                                                       const uint32_t* __restrict__ seg_off,
+                                                                       const uint32_t* __restrict__ seg_off, uint32_t n_buckets,
                                                                        G1Xyzz* __restrict__ buckets) {
     __shared__ G1Xyzz sm[MSM_THREADS];
-    const uint32_t b = blockIdx.x;
-    const uint32_t s0 = seg_off[b], cnt = seg_off[b + 1] - s0;
-    if (cnt <= MSM_SMALL_SEGS) return;
-    G1Xyzz acc = g1_inf();
-    for (uint32_t i = threadIdx.x; i < cnt; i += MSM_THREADS) acc = g1_add(acc, g1_load(partial + s0 + i));
-    sm[threadIdx.x] = acc;
-    __syncthreads();
-    for (uint32_t d = MSM_THREADS / 2; d >= 1; d >>= 1) {
-        if (threadIdx.x < d) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + d]);
+    for (uint32_t b = blockIdx.x; b < n_buckets; b += gridDim.x) {
+        const uint32_t s0 = seg_off[b], cnt = seg_off[b + 1] - s0;
+        if (cnt <= MSM_SMALL_SEGS) continue;                   // uniform per workgroup
+        G1Xyzz acc = g1_inf();
+        for (uint32_t i = threadIdx.x; i < cnt; i += MSM_THREADS) acc = g1_add(acc, g1_load(partial + s0 + i));
+        sm[threadIdx.x] = acc;
+        __syncthreads();
+        for (uint32_t d = MSM_THREADS / 2; d >= 1; d >>= 1) {
+            if (threadIdx.x < d) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + d]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) g1_store(buckets + b, sm[0]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) g1_store(buckets + b, sm[0]);
 }
 
 // buckets[b] = sum of its `seg` partials
