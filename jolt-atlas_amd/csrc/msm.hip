@@ -128,7 +128,9 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
         return fail(ATLAS_EINVAL, "msm: more than 2^32 (scalar, window) pairs in one call; split the input");
     const uint32_t V = (uint32_t)K * S.n_windows;          // virtual windows
     const uint32_t TB = V * S.bpw;
-    const uint32_t chunk = S.bpw < (uint32_t)MSM_CHUNK ? S.bpw : (uint32_t)MSM_CHUNK;
+    uint32_t chunk_max = (uint32_t)MSM_CHUNK;
+    if (const char* e = getenv("ATLAS_MSM_CHUNK")) { int v = atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) chunk_max = (uint32_t)v; }   // experiments
+    const uint32_t chunk = S.bpw < chunk_max ? S.bpw : chunk_max;
     const uint32_t n_chunks = TB / chunk;
     const uint32_t chunks_per_window = S.bpw / chunk;
 

@@ -88,10 +88,18 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_q_tiled(const uint64_t* __res
         }
         bins[tid] = b;
         __syncthreads();
-        for (uint32_t e = my_part * per_part; e < (my_part + 1) * per_part; e++) {
-            if (bins[e] != my_bin) continue;
+        // first mark this thread's matches among its part's entries (a bit per entry, 32 at a time), then add them: the
+        // additions run for max-over-lanes(popcount) steps instead of once per entry with a handful of lanes active
+        for (uint32_t e0 = my_part * per_part; e0 < (my_part + 1) * per_part; e0 += 32) {
+            const uint32_t span = per_part < 32 ? per_part : 32;
+            uint32_t mask = 0;
+            for (uint32_t i = 0; i < span; i++) mask |= (uint32_t)(bins[e0 + i] == my_bin) << i;
+            while (mask) {
+                const uint32_t e = e0 + (uint32_t)__builtin_ctz(mask);
+                mask &= mask - 1;
 #pragma unroll
-            for (int q = 0; q < NQ; q++) acc[q] = fr_add(acc[q], vals[q][e]);
+                for (int q = 0; q < NQ; q++) acc[q] = fr_add(acc[q], vals[q][e]);
+            }
         }
         __syncthreads();
     }
@@ -177,7 +185,10 @@ struct PsLookup : atlas_instance {
     H::Fr lt_acc = H::zero(), eq_acc = H::one(), lop_acc = H::zero(), rop_acc = H::zero();   // mode 3 (UnsignedLessThan, binary)
     std::vector<H::Fr> r_addr;
     H::Fr word_acc = H::zero(), sid_acc = H::zero(), wv = H::zero();
-    static constexpr unsigned SLICES = 64, Q_BLOCKS = 512, Q_ROWS_MAX = 512;
+    static constexpr unsigned SLICES = 64;
+    // partial rows of a Q build: one per workgroup of k_ps_q_tiled (a workgroup per few tiles keeps the latency chain of a
+    // phase short), at most 2^17 / m of them so that the rows stay a few MB
+    size_t q_rows_max() const { size_t r = ((size_t)1 << 17) / m; if (r > 2048) r = 2048; return r < SLICES ? SLICES : r; }
 
     ~PsLookup() override { for (void* p : {(void*)d_idx, (void*)d_u0, (void*)d_v, (void*)d_qpart}) if (p) hipFree(p); rows.release(); eq.release(); }
     size_t rounds() const override { return N + log_T; }
@@ -193,7 +204,7 @@ struct PsLookup : atlas_instance {
         unsigned n_rows = SLICES;            // partial rows to add
         if (m <= RA_THREADS) {
             const size_t n_tiles = (T + RA_THREADS - 1) / RA_THREADS;
-            n_rows = (unsigned)(n_tiles < Q_BLOCKS ? n_tiles : Q_BLOCKS);
+            n_rows = (unsigned)(n_tiles < q_rows_max() ? n_tiles : q_rows_max());
             if (NQ == 4) k_ps_q_tiled<4><<<n_rows, RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)m, 0u, d_qpart);
             else if (NQ == 6) k_ps_q_tiled<6><<<n_rows, RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)m, (uint32_t)bound, d_qpart);
             else if (NQ == 3) k_ps_q_tiled<3><<<n_rows, RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)m, (uint32_t)bound, d_qpart);
@@ -202,7 +213,7 @@ struct PsLookup : atlas_instance {
         else if (NQ == 6) k_ps_q<6><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), (uint32_t)bound, d_qpart);
         else if (NQ == 3) k_ps_q<3><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), (uint32_t)bound, d_qpart);
         else k_ps_q<2><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), 0u, d_qpart);
-        Fr* d_qsum = d_qpart + (size_t)Q_ROWS_MAX * NQ * m;
+        Fr* d_qsum = d_qpart + q_rows_max() * NQ * m;
         k_col_reduce<<<(unsigned)(NQ * m), RA_THREADS, 0, g.stream>>>(d_qpart, n_rows, (uint32_t)(NQ * m), d_qsum);
         std::vector<H::Fr> q(NQ * m);
         HIP_TRY(hipMemcpyAsync(q.data(), d_qsum, NQ * m * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
@@ -402,7 +413,7 @@ static int ps_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, si
     const size_t T = P->T, m = P->m;
     hipError_t e = hipMalloc(&P->d_idx, T * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc(&P->d_v, m * sizeof(Fr));
-    if (e == hipSuccess) e = hipMalloc(&P->d_qpart, ((size_t)PsLookup::Q_ROWS_MAX + 1) * 6 * m * sizeof(Fr));
+    if (e == hipSuccess) e = hipMalloc(&P->d_qpart, (P->q_rows_max() + 1) * 6 * m * sizeof(Fr));
     if (e == hipSuccess) e = hipMemcpyAsync(P->d_idx, lookup_indices, T * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream);
     if (e != hipSuccess) { delete P; return fail(ATLAS_ENOMEM, "ps_shout_new", e); }
     rc = P->rows.alloc(1, T);
