@@ -318,6 +318,16 @@ enum { ATLAS_EW_ADD = 0, ATLAS_EW_SUB = 1, ATLAS_EW_NEG = 2, ATLAS_EW_SQUARE = 3
  * `constants`: n_constants Fr, 2 for Rsqrt, 1 for Gather / TeleportDivision, d for HammingBooleanity, 0 (may be NULL) otherwise. */
 int atlas_elementwise_new(int op, const atlas_poly_t *operands, size_t n_operands, const atlas_fr_t *r_node_output,
                           size_t n_vars, const atlas_fr_t *constants, size_t n_constants, atlas_instance_t *out);
+/* Lookup indices resident in HBM.  Every constructor above and below that takes `const uint64_t *lookup_indices`
+ * accepts host memory or device memory (the copy is made with hipMemcpyDefault), so one upload — or none, when the
+ * indices are cut from operand tensors that already live on the device — serves the read-raf prover and the one-hot
+ * checks of an operator.
+ *   atlas_lookup_indices_from_operands: compute_lookup_indices_from_operands (jolt-atlas-core/src/utils/mod.rs:43-122):
+ *   d_right == NULL: `value as u32 as u64`; otherwise interleave_bits(left as u32, right as u32)
+ *   (joltworks/src/utils/mod.rs:146-164).  d_left / d_right: device Tensor<i32> (atlas_i32_upload). */
+int atlas_u64_upload(const uint64_t *host, size_t n, uint64_t **d_out);
+int atlas_u64_free(uint64_t *d);
+int atlas_lookup_indices_from_operands(const int32_t *d_left, const int32_t *d_right, size_t n, uint64_t **d_out);
 /* The two-phase provers of softmax_last_axis (jolt-atlas-core/src/onnx_proof/ops/softmax_last_axis/exp_sum.rs:146-197,
  * max.rs:185-261, recip_mult.rs:196-268) and SumAxisProver (ops/sum/axis.rs:220-232).  Tensors are [k][j] with
  * K = 2^log_K rows and N = 2^log_N last-axis entries, bound LowToHigh (last axis first); log_K + log_N rounds.

@@ -395,6 +395,23 @@ struct PsLookup : atlas_instance {
     }
 };
 
+// compute_lookup_indices_from_operands (jolt-atlas-core/src/utils/mod.rs:43-122): `value as u32 as u64`, or
+// interleave_bits(left as u32, right as u32) (joltworks/src/utils/mod.rs:146-164) for the binary lookups
+__device__ __forceinline__ uint64_t ps_spread_bits(uint32_t v) {
+    uint64_t x = v;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x;
+}
+__global__ __launch_bounds__(RA_THREADS) void k_lookup_indices(const int32_t* __restrict__ left, const int32_t* __restrict__ right, size_t n,
+                                                               uint64_t* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * RA_THREADS)
+        out[i] = right ? ((ps_spread_bits((uint32_t)left[i]) << 1) | ps_spread_bits((uint32_t)right[i])) : (uint64_t)(uint32_t)left[i];
+}
+
 }  // namespace
 
 extern "C" {
@@ -414,7 +431,7 @@ static int ps_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, si
     hipError_t e = hipMalloc(&P->d_idx, T * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc(&P->d_v, m * sizeof(Fr));
     if (e == hipSuccess) e = hipMalloc(&P->d_qpart, (P->q_rows_max() + 1) * 6 * m * sizeof(Fr));
-    if (e == hipSuccess) e = hipMemcpyAsync(P->d_idx, lookup_indices, T * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(P->d_idx, lookup_indices, T * sizeof(uint64_t), hipMemcpyDefault, g.stream);   // host or device source
     if (e != hipSuccess) { delete P; return fail(ATLAS_ENOMEM, "ps_shout_new", e); }
     rc = P->rows.alloc(1, T);
     if (!rc) {
@@ -472,6 +489,40 @@ int atlas_identity_range_check_new(const uint64_t* lookup_indices, size_t log_T,
         return fail(ATLAS_EINVAL, "identity_range_check_new: log_K must be a multiple of phases, chunks of at most 12 bits");
     if (log_T == 0 || log_T > 25) return fail(ATLAS_EINVAL, "identity_range_check_new: 1 <= log_T <= 25");
     return ps_new(lookup_indices, log_T, log_K, phases, 1, r_node_output, nullptr, out);
+}
+
+int atlas_u64_upload(const uint64_t* host, size_t n, uint64_t** d_out) {
+    NEED_INIT();
+    if (!host || !d_out || n == 0) return fail(ATLAS_EINVAL, "u64_upload");
+    uint64_t* d = nullptr;
+    hipError_t e = hipMalloc(&d, n * sizeof(uint64_t));
+    if (e != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(u64)", e);
+    std::lock_guard<std::mutex> lk(g.mu);
+    e = hipMemcpyAsync(d, host, n * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    if (e != hipSuccess) { hipFree(d); return fail(ATLAS_ENODEV, "u64_upload", e); }
+    *d_out = d;
+    return ATLAS_OK;
+}
+
+int atlas_u64_free(uint64_t* d) {
+    if (d) hipFree(d);
+    return ATLAS_OK;
+}
+
+int atlas_lookup_indices_from_operands(const int32_t* d_left, const int32_t* d_right, size_t n, uint64_t** d_out) {
+    NEED_INIT();
+    if (!d_left || !d_out || n == 0) return fail(ATLAS_EINVAL, "lookup_indices_from_operands: null argument");
+    uint64_t* d = nullptr;
+    hipError_t e = hipMalloc(&d, n * sizeof(uint64_t));
+    if (e != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(lookup indices)", e);
+    std::lock_guard<std::mutex> lk(g.mu);
+    size_t gb = (n + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
+    k_lookup_indices<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(d_left, d_right, n, d);
+    e = hipStreamSynchronize(g.stream);
+    if (e != hipSuccess) { hipFree(d); return fail(ATLAS_ENODEV, "lookup_indices_from_operands", e); }
+    *d_out = d;
+    return ATLAS_OK;
 }
 
 }  // extern "C"

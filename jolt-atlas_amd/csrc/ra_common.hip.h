@@ -148,7 +148,7 @@ struct RaRows {
         uint64_t* d_l = nullptr;
         HIP_TRY(hipMalloc(&d_idx, d * len * sizeof(int32_t)));
         HIP_TRY(hipMalloc(&d_l, len * sizeof(uint64_t)));
-        hipError_t e = hipMemcpyAsync(d_l, lookups, len * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream);
+        hipError_t e = hipMemcpyAsync(d_l, lookups, len * sizeof(uint64_t), hipMemcpyDefault, g.stream);   // host or device source
         if (e == hipSuccess) {
             size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
             k_ra_chunk_indices<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(d_l, len, (uint32_t)d, log_k_chunk, d_idx);

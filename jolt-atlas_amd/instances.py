@@ -118,32 +118,68 @@ def eval_reduction_prove(mle, points, claims, transcript):
     return h[:hl.value].copy(), r[:n].copy(), c
 
 
+class DeviceU64:
+    """T lookup indices resident in HBM (atlas_u64_upload / atlas_lookup_indices_from_operands); accepted wherever the
+    constructors below take `lookup_indices`."""
+
+    def __init__(self, ptr, n):
+        self.ptr, self.n = ptr, n
+
+    @classmethod
+    def upload(cls, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.uint64)
+        d = C.c_void_p()
+        _check(lib.atlas_u64_upload(arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.size), C.byref(d)))
+        return cls(d, arr.size)
+
+    @classmethod
+    def from_operands(cls, left, right=None):
+        """compute_lookup_indices_from_operands over device Tensor<i32> operands (TensorI32)."""
+        n = int(np.prod(left.shape))
+        d = C.c_void_p()
+        _check(lib.atlas_lookup_indices_from_operands(left.d, right.d if right is not None else None, C.c_size_t(n), C.byref(d)))
+        return cls(d, n)
+
+    def free(self):
+        if self.ptr:
+            lib.atlas_u64_free(self.ptr)
+            self.ptr = None
+
+
+def _lookup_arg(x):
+    """(pointer, keep-alive) for host arrays or DeviceU64"""
+    if isinstance(x, DeviceU64):
+        return x.ptr, x
+    a = np.ascontiguousarray(x, dtype=np.uint64)
+    return a.ctypes.data_as(C.c_void_p), a
+
+
 def ps_shout_relu(lookup_indices, xlen, r_node_output, gamma):
     """ps_read_raf_prover for ReluTable<xlen> (ps_shout/unary.rs:110-148)."""
-    idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)
+    idx_p, _keep = _lookup_arg(lookup_indices)
     rn = np.ascontiguousarray(r_node_output, dtype=np.uint64); g = _fr(gamma)
     h = C.c_void_p()
-    _check(lib.atlas_ps_shout_relu_new(idx.ctypes.data_as(C.c_void_p), C.c_size_t(len(rn)), C.c_size_t(xlen), _p(rn), _p(g),
+    _check(lib.atlas_ps_shout_relu_new(idx_p, C.c_size_t(len(rn)), C.c_size_t(xlen), _p(rn), _p(g),
                                        C.byref(h)))
     return Instance(h)
 
 
 def identity_range_check(lookup_indices, log_K, phases, r_node_output):
     """IdentityRCProver::gen (identity_range_check.rs:196-233)."""
-    idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)
+    idx_p, _keep = _lookup_arg(lookup_indices)
     rn = np.ascontiguousarray(r_node_output, dtype=np.uint64)
     h = C.c_void_p()
-    _check(lib.atlas_identity_range_check_new(idx.ctypes.data_as(C.c_void_p), C.c_size_t(len(rn)), C.c_size_t(log_K),
+    _check(lib.atlas_identity_range_check_new(idx_p, C.c_size_t(len(rn)), C.c_size_t(log_K),
                                               C.c_size_t(phases), _p(rn), C.byref(h)))
     return Instance(h)
 
 
 def ps_shout_clamp(lookup_indices, xlen, bound, symmetric, r_node_output, gamma):
     """ps_read_raf_prover for ClampBoundedTable<xlen, bound, symmetric> (lookup_tables/clamp.rs)."""
-    idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)
+    idx_p, _keep = _lookup_arg(lookup_indices)
     rn = np.ascontiguousarray(r_node_output, dtype=np.uint64); g = _fr(gamma)
     h = C.c_void_p()
-    _check(lib.atlas_ps_shout_clamp_new(idx.ctypes.data_as(C.c_void_p), C.c_size_t(len(rn)), C.c_size_t(xlen), C.c_size_t(bound),
+    _check(lib.atlas_ps_shout_clamp_new(idx_p, C.c_size_t(len(rn)), C.c_size_t(xlen), C.c_size_t(bound),
                                         C.c_int(1 if symmetric else 0), _p(rn), _p(g), C.byref(h)))
     return Instance(h)
 
@@ -178,38 +214,38 @@ def softmax_instance(kind, a, b, log_K, log_N, r):
 
 def ps_shout_rshift(lookup_indices, xlen, shift, r_node_output, gamma):
     """ps_read_raf_prover for RightShiftTable<xlen> by `shift` bits (lookup_tables/right_shift.rs; Sin/Cos downscale)."""
-    idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)
+    idx_p, _keep = _lookup_arg(lookup_indices)
     rn = np.ascontiguousarray(r_node_output, dtype=np.uint64); g = _fr(gamma)
     h = C.c_void_p()
-    _check(lib.atlas_ps_shout_rshift_new(idx.ctypes.data_as(C.c_void_p), C.c_size_t(len(rn)), C.c_size_t(xlen), C.c_size_t(shift),
+    _check(lib.atlas_ps_shout_rshift_new(idx_p, C.c_size_t(len(rn)), C.c_size_t(xlen), C.c_size_t(shift),
                                          _p(rn), _p(g), C.byref(h)))
     return Instance(h)
 
 
 def ps_shout_ult(lookup_indices, r_node_output, gamma):
     """binary ps_read_raf_prover with UnsignedLessThanTable<32> (ps_shout/binary.rs:148-200); indices = interleave_bits(x, y)."""
-    idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)
+    idx_p, _keep = _lookup_arg(lookup_indices)
     rn = np.ascontiguousarray(r_node_output, dtype=np.uint64); g = _fr(gamma)
     h = C.c_void_p()
-    _check(lib.atlas_ps_shout_ult_new(idx.ctypes.data_as(C.c_void_p), C.c_size_t(len(rn)), _p(rn), _p(g), C.byref(h)))
+    _check(lib.atlas_ps_shout_ult_new(idx_p, C.c_size_t(len(rn)), _p(rn), _p(g), C.byref(h)))
     return Instance(h)
 
 
 def ra_virtual_from_lookups(lookup_indices, log_K, log_k_chunk, r_address, r_cycle):
     """RaSumcheckProver::gen from the lookup indices (chunks cut on the device, config.rs:73-100)."""
-    idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)
+    idx_p, _keep = _lookup_arg(lookup_indices)
     ra = np.ascontiguousarray(r_address, dtype=np.uint64); rc = np.ascontiguousarray(r_cycle, dtype=np.uint64)
     h = C.c_void_p()
-    _check(lib.atlas_ra_virtual_from_lookups_new(idx.ctypes.data_as(C.c_void_p), C.c_size_t(len(rc)), C.c_size_t(log_K),
+    _check(lib.atlas_ra_virtual_from_lookups_new(idx_p, C.c_size_t(len(rc)), C.c_size_t(log_K),
                                                  C.c_size_t(log_k_chunk), _p(ra), _p(rc), C.byref(h)))
     return Instance(h)
 
 
 def booleanity_from_lookups(G, lookup_indices, log_K, log_k_chunk, gammas, r_address, r_cycle):
-    idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)
+    idx_p, _keep = _lookup_arg(lookup_indices)
     G = np.ascontiguousarray(G, dtype=np.uint64); ga = np.ascontiguousarray(gammas, dtype=np.uint64)
     ra = np.ascontiguousarray(r_address, dtype=np.uint64); rc = np.ascontiguousarray(r_cycle, dtype=np.uint64)
     h = C.c_void_p()
-    _check(lib.atlas_booleanity_from_lookups_new(_p(G), idx.ctypes.data_as(C.c_void_p), C.c_size_t(len(rc)), C.c_size_t(log_K),
+    _check(lib.atlas_booleanity_from_lookups_new(_p(G), idx_p, C.c_size_t(len(rc)), C.c_size_t(log_K),
                                                  C.c_size_t(log_k_chunk), _p(ga), _p(ra), _p(rc), C.byref(h)))
     return Instance(h)
