@@ -13,6 +13,9 @@
 //     compressed and absorbed like a single instance's (:118-121).
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -174,9 +177,15 @@ int atlas_instance_prove(atlas_instance_t inst, const atlas_fr_t* input_claim, a
     H::tr_append_scalar(T, prev);
     const size_t n = inst->rounds();
     std::vector<H::Fr> c;
+    const bool trace = getenv("ATLAS_TRACE") != nullptr;          // wall clock of the three parts of a round, summed
+    double t_msg = 0, t_fs = 0, t_ing = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     for (size_t round = 0; round < n; round++) {
+        const auto t0 = now();
         int rc = inst->message(round, prev, c);
         if (rc) return rc;
+        const auto t1 = now();
         std::vector<H::Fr> cc;
         if (c.size() < 2) cc = c;
         else { cc.push_back(c[0]); for (size_t k = 2; k < c.size(); k++) cc.push_back(c[k]); }
@@ -190,9 +199,14 @@ int atlas_instance_prove(atlas_instance_t inst, const atlas_fr_t* input_claim, a
         H::tr_challenge_u128(T, lo, hi);
         challenges[round].lo = lo; challenges[round].hi = hi;
         prev = eval_with_challenge(c, H::challenge_to_fr(lo, hi, g.challenge_mode));
+        const auto t2 = now();
         rc = inst->ingest(challenges[round], round);
         if (rc) return rc;
+        if (trace) { const auto t3 = now(); t_msg += ms(t0, t1); t_fs += ms(t1, t2); t_ing += ms(t2, t3); }
     }
+    if (trace)
+        fprintf(stderr, "[atlas trace] instance_prove %zu rounds: compute_message %.3f ms, transcript + evaluate %.3f ms, ingest_challenge %.3f ms\n",
+                n, t_msg, t_fs, t_ing);
     return ATLAS_OK;
 }
 

@@ -150,6 +150,21 @@ __device__ __forceinline__ F9 f9_norm(const F9& a) {
     return o;
 }
 
+// a + c * b for a small constant c (c * b.l[i] + a.l[i] < 2^63), carries propagated: normalized limbs, the value
+// is NOT reduced (a + c b must stay below 2^261; as the lazy operand of f9_mul it may be several p)
+__device__ __forceinline__ F9 f9_axpy_small(const F9& a, const F9& b, uint32_t c) {
+    F9 o;
+    uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint64_t s = (uint64_t)b.l[i] * c + a.l[i] + carry;
+        o.l[i] = (uint32_t)s & F9_MASK;
+        carry = s >> 29;
+    }
+    o.l[8] = (uint32_t)((uint64_t)b.l[8] * c + a.l[8] + carry);
+    return o;
+}
+
 // carry propagation + one conditional subtraction of 2p: for an input < ~4p the result is
 // normalized and < 2p(1 + 2^-20).  The decision uses a lower estimate of the top limb, so
 // the subtraction never underflows.

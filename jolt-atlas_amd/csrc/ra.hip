@@ -37,14 +37,14 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_prod_f9(const Fr* __restrict_
             const Fr* row = ra + (size_t)(i < D ? i : 0) * stride + 2 * gidx;
             const F9 a0 = f9_load(row), a1 = f9_load(row + 1);
             const F9 dl = f9_norm_red<P9, 2>(f9_sub<P9>(a1, a0));          // a1 - a0 (+4p), < 2.1p
-            F9 cur = a0;
-#pragma unroll
-            for (int s = 0; s < K0 + 1; s++) cur = f9_norm_red<P9, 2>(f9_add(cur, dl));   // p_i(K0 + 1)
+            // p_i(x) = a0 + x dl is the LAZY operand of f9_mul (normalized limbs, a value of several p): a carry pass per
+            // column, no reduction.  (Skipping the carry pass on some columns made the compiler spill the products.)
+            F9 cur = f9_axpy_small(a0, dl, K0 + 1);                             // p_i(K0 + 1)
 #pragma unroll
             for (int k = 0; k < KN; k++) {
                 const bool inf = (K0 + k == D - 1);                             // column D-1 = X -> inf
                 const F9 val = i == D ? wgt : (inf ? dl : cur);
-                if (!inf) cur = f9_norm_red<P9, 2>(f9_add(cur, dl));
+                if (!inf) cur = f9_norm(f9_add(cur, dl));
                 prod[k] = i == 0 ? val : f9_mul<P9>(prod[k], val);
             }
         }
@@ -81,11 +81,7 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_prod_f9_col(const Fr* __restr
             const Fr* row = ra + (size_t)i * stride + 2 * gidx;
             const F9 a0 = f9_load(row), a1 = f9_load(row + 1);
             const F9 dl = f9_norm_red<P9, 2>(f9_sub<P9>(a1, a0));
-            F9 val = dl;                                                     // column D-1: X -> inf
-            if (k != D - 1) {
-                val = a0;
-                for (int s2 = 0; s2 < k + 1; s2++) val = f9_norm_red<P9, 2>(f9_add(val, dl));   // p_i(k + 1)
-            }
+            const F9 val = k == D - 1 ? dl : f9_axpy_small(a0, dl, (uint32_t)k + 1);   // column D-1: X -> inf; else p_i(k + 1), lazy
             prod = f9_mul<P9>(prod, val);
         }
     }
