@@ -98,29 +98,45 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_prod_f9_col(const Fr* __restr
 
 // booleanity phase 2 (booleanity.rs:254-276): per pair index j
 //   c = sum_i gamma_i h0 (h0 - 1),  e = sum_i gamma_i (h1 - h0)^2, folded with E_out * E_in
+// on the 29-bit lazy limbs: h0 - 1 and h1 - h0 enter their products unreduced (the lazy operand of f9_mul), the row
+// sums are limb-wise adds with a carry + reduce pass every fourth row.  Four f9_mul stand behind every term (gamma h,
+// the second factor, E_out E_in, the weighting): a stored sum is 32^-4 times the true one, undone on the host.
 __global__ __launch_bounds__(RA_THREADS) void k_bool_fold(const Fr* __restrict__ Hp, size_t stride, uint32_t d,
                                                           const Fr* __restrict__ gammas, SplitEqView E, size_t n_groups,
                                                           Fr* __restrict__ partials) {
-    Fr acc[2];
-    acc[0] = fe_zero(); acc[1] = fe_zero();
-    const Fr one = fr_one();
+    using P9 = Fr9Params;
+    F9 acc0 = f9_zero(), acc1 = f9_zero();
+    const F9 one = f9_from_fe(fr_one());
     for (size_t j = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; j < n_groups; j += (size_t)gridDim.x * RA_THREADS) {
-        Fr c = fe_zero(), e = fe_zero();
+        F9 c = f9_zero(), e = f9_zero();
         // blockIdx.y splits the d rows (the sums are additive): short instances put one row per thread
         const uint32_t i0 = (uint32_t)(((uint64_t)d * blockIdx.y) / gridDim.y), i1 = (uint32_t)(((uint64_t)d * (blockIdx.y + 1)) / gridDim.y);
+#pragma unroll 1
         for (uint32_t i = i0; i < i1; i++) {
             const Fr* row = Hp + (size_t)i * stride;
-            const Fr h0 = fe_load(row + 2 * j), h1 = fe_load(row + 2 * j + 1);
-            const Fr b = fr_sub(h1, h0);
-            const Fr gm = fe_load(gammas + i);
-            c = fr_add(c, fr_mul(fr_mul(gm, h0), fr_sub(h0, one)));
-            e = fr_add(e, fr_mul(fr_mul(gm, b), b));
+            const F9 h0 = f9_load(row + 2 * j), h1 = f9_load(row + 2 * j + 1);
+            const F9 gm = f9_load(gammas + i);
+            const F9 b = f9_sub<P9>(h1, h0);                       // lazy: + 4p, limbs < 2^31
+            const F9 m1 = f9_sub<P9>(h0, one);
+            c = f9_add(c, f9_mul<P9>(f9_mul<P9>(gm, h0), m1));
+            e = f9_add(e, f9_mul<P9>(f9_mul<P9>(gm, b), b));
+            if ((i - i0) % 4 == 3) { c = f9_norm_red<P9, 4>(c); e = f9_norm_red<P9, 4>(e); }
         }
-        const Fr wgt = gse_weight(E, j);
-        acc[0] = fr_add(acc[0], fr_mul(wgt, c));
-        acc[1] = fr_add(acc[1], fr_mul(wgt, e));
+        c = f9_norm_red<P9, 4>(c); e = f9_norm_red<P9, 4>(e);
+        const F9 wgt = f9_mul<P9>(f9_load(E.e_out + (j >> E.in_bits)), f9_load(E.e_in + (j & (((size_t)1 << E.in_bits) - 1))));
+        acc0 = f9_norm_red<P9>(f9_add(acc0, f9_mul<P9>(wgt, c)));
+        acc1 = f9_norm_red<P9>(f9_add(acc1, f9_mul<P9>(wgt, e)));
     }
-    block_reduce_store<2>(acc, partials + (size_t)blockIdx.y * gridDim.x * 2);
+    __shared__ F9 red9[RA_THREADS / 64][2];
+    acc0 = f9_wave_sum<P9>(acc0); acc1 = f9_wave_sum<P9>(acc1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red9[wave][0] = acc0; red9[wave][1] = acc1; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        F9 s = red9[0][threadIdx.x];
+        for (int w = 1; w < RA_THREADS / 64; w++) s = f9_norm_red<P9>(f9_add(s, red9[w][threadIdx.x]));
+        fe_store(partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + threadIdx.x, f9_canon<P9>(s));
+    }
 }
 
 // out[k] = sum_p partials[p * K + k]; one workgroup per column
@@ -245,6 +261,8 @@ struct Booleanity : atlas_instance {
         H::Fr s[2];
         int rc = rows.reduce_to_host((uint32_t)(blocks * ysplit), 2, s);
         if (rc) return rc;
+        static const H::Fr fix = H::from_u64(1048576);               // 32^4: the 2^-5 of each of the four f9_mul behind a term
+        s[0] = H::mul(s[0], fix); s[1] = H::mul(s[1], fix);
         if (!have_eq_r_r_inv) { eq_r_r_inv = H::inv(eq_r_r); have_eq_r_r_inv = true; }   // constant over phase 2
         const H::Fr adj = H::mul(claim, eq_r_r_inv);
         H::gruen_deg3(D.st, s[0], s[1], adj, coeffs.data());
