@@ -28,6 +28,11 @@ __device__ __forceinline__ F9 f9_x32(const F9& a) { return f9_shl5(a); }
 // k*q (k = 0..5) test of a normalized value known to be in [0, 6q): true iff value == k q
 template <class P9>
 __device__ __forceinline__ bool f9_is_multiple_of_p(const F9& a) {
+    // the lowest limb decides almost always (a match has probability 6 / 2^29): six compares instead of six 9-limb ones
+    bool maybe = false;
+#pragma unroll
+    for (uint32_t k = 0; k <= 5; k++) maybe = maybe || a.l[0] == ((k * P9::p(0)) & F9_MASK);
+    if (!maybe) return false;
     bool any = false;
 #pragma unroll
     for (uint32_t k = 0; k <= 5; k++) {
