@@ -8,7 +8,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-LOG_N = 22
+import os
+
+LOG_N = int(os.environ.get("ATLAS_FULL_LOG_N", "22"))     # 24 = GPT-2's joint polynomial (max_num_vars = 24)
 
 
 def test_sumcheck_2p22_bit_exact_and_final_claims(atlas):
