@@ -154,10 +154,14 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
     const size_t o_cursor = carve((size_t)(TB + 1) * 4);
     const size_t o_sorted = carve(n * (size_t)S.n_windows * 4);
     // load-balanced accumulation: segments of <= MSM_SEG_LEN sorted entries (see msm_kernels.hip.h)
-    // segment length: full length for big problems, shorter when there would be fewer than ~2^17 segments
+    // segment length: 128 around 2^22 scalars; shorter when there would be fewer than ~2^17 segments, longer when there
+    // would be more than ~2^20 (at 2^24 scalars 128-entry segments leave 32 partial sums per bucket to add up: 16.7 ms
+    // of a 55 ms MSM went into that; 512-entry segments keep it at 8 per bucket)
     uint32_t seg_len = MSM_SEG_LEN;
-    if (const char* e = getenv("ATLAS_MSM_SEG")) { int v = atoi(e); if (v >= 8 && v <= 4096 && (v & (v - 1)) == 0) seg_len = (uint32_t)v; }   // experiments
+    const char* seg_env = getenv("ATLAS_MSM_SEG");                                       // experiments
+    if (seg_env) { int v = atoi(seg_env); if (v >= 8 && v <= 4096 && (v & (v - 1)) == 0) seg_len = (uint32_t)v; }
     while (seg_len > 8 && (n * (size_t)S.n_windows) / seg_len < ((size_t)1 << 17)) seg_len >>= 1;
+    while (!seg_env && seg_len < 2048 && (n * (size_t)S.n_windows) / seg_len > ((size_t)1 << 20)) seg_len <<= 1;
     const size_t s_max = (n * (size_t)S.n_windows) / seg_len + TB + 1;
     const size_t o_segc = carve((size_t)(TB + 1) * 4);
     const size_t o_segoff = carve((size_t)(TB + 1) * 4);

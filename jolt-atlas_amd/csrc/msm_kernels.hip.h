@@ -279,7 +279,9 @@ __global__ __launch_bounds__(MSM_THREADS) void k_msm_bucket_reduce_big(const G1X
         for (uint32_t i = threadIdx.x; i < cnt; i += MSM_THREADS) acc = g1_add(acc, g1_load(partial + s0 + i));
         sm[threadIdx.x] = acc;
         __syncthreads();
-        for (uint32_t d = MSM_THREADS / 2; d >= 1; d >>= 1) {
+        uint32_t top = MSM_THREADS / 2;                          // tree only as deep as the occupied slots
+        while (top >= cnt && top > 1) top >>= 1;
+        for (uint32_t d = top; d >= 1; d >>= 1) {
             if (threadIdx.x < d) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + d]);
             __syncthreads();
         }
