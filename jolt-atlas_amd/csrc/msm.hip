@@ -154,14 +154,18 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
     const size_t o_cursor = carve((size_t)(TB + 1) * 4);
     const size_t o_sorted = carve(n * (size_t)S.n_windows * 4);
     // load-balanced accumulation: segments of <= MSM_SEG_LEN sorted entries (see msm_kernels.hip.h)
-    // segment length: 128 around 2^22 scalars; shorter when there would be fewer than ~2^17 segments, longer when there
-    // would be more than ~2^20 (at 2^24 scalars 128-entry segments leave 32 partial sums per bucket to add up: 16.7 ms
-    // of a 55 ms MSM went into that; 512-entry segments keep it at 8 per bucket)
-    uint32_t seg_len = MSM_SEG_LEN;
-    const char* seg_env = getenv("ATLAS_MSM_SEG");                                       // experiments
-    if (seg_env) { int v = atoi(seg_env); if (v >= 8 && v <= 4096 && (v & (v - 1)) == 0) seg_len = (uint32_t)v; }
+    // segment length: about eight segments per bucket whatever the size (a bucket of a window holds ~ n / bpw entries;
+    // 128 at 2^22 scalars with 13-bit windows).  More segments per bucket than MSM_SMALL_SEGS would send every bucket
+    // through the workgroup-per-bucket reduction (measured: 23 ms instead of 6 ms at 2^21 with 32-entry segments, 16.7 ms
+    // of a 55 ms MSM at 2^24 with 128-entry ones); fewer leave the accumulation short of threads.
+    size_t n_vec = n;
+    if (multi) { n_vec = 0; for (size_t k = 0; k < K; k++) n_vec = multi->lens[k] > n_vec ? multi->lens[k] : n_vec; }
+    uint32_t seg_len = 8;
+    while (seg_len < 2048 && (size_t)seg_len * 8 * S.bpw < n_vec) seg_len <<= 1;
+    // ... but never fewer than ~2^17 segments in all (narrow scalars have one or two windows: few, very long buckets —
+    // there the workgroup-per-bucket reduction is the right tool and the accumulation needs the threads)
     while (seg_len > 8 && (n * (size_t)S.n_windows) / seg_len < ((size_t)1 << 17)) seg_len >>= 1;
-    while (!seg_env && seg_len < 2048 && (n * (size_t)S.n_windows) / seg_len > ((size_t)1 << 20)) seg_len <<= 1;
+    if (const char* e = getenv("ATLAS_MSM_SEG")) { int v = atoi(e); if (v >= 8 && v <= 4096 && (v & (v - 1)) == 0) seg_len = (uint32_t)v; }   // experiments
     const size_t s_max = (n * (size_t)S.n_windows) / seg_len + TB + 1;
     const size_t o_segc = carve((size_t)(TB + 1) * 4);
     const size_t o_segoff = carve((size_t)(TB + 1) * 4);
