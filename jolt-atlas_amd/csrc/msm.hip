@@ -58,7 +58,7 @@ MsmShape pick_shape(size_t n) {
     MsmShape S;
     // window width by problem size: bucket folding costs ~2 * n_windows * 2^(c-1) additions; c = 13 keeps a
     // window's 4096 counters in LDS for the counting sort (measured at 2^22: 11.9 ms vs 19.1 ms for c = 16)
-    S.c = n >= (1u << 18) ? 13 : n >= (1u << 13) ? 12 : n >= (1u << 8) ? 8 : 6;
+    S.c = n >= (1u << 24) ? 14 : n >= (1u << 18) ? 13 : n >= (1u << 13) ? 12 : n >= (1u << 8) ? 8 : 6;   // 2^24: 38.7 ms (c = 14) vs 40.1 ms
     if (const char* e = getenv("ATLAS_MSM_C")) { int v = atoi(e); if (v >= 2 && v <= 16) S.c = (uint32_t)v; }   // experiments
     S.n_windows = (255 + S.c - 1) / S.c;
     S.bpw = 1u << (S.c - 1);
