@@ -43,7 +43,8 @@ namespace {
 inline int grid_for(size_t work) {
     size_t b = (work + SC_THREADS - 1) / SC_THREADS;
     if (b < 1) b = 1;
-    if (b > (size_t)SC_MAX_BLOCKS) b = SC_MAX_BLOCKS;
+    static const size_t cap = [] { const char* e = getenv("ATLAS_SC_BLOCKS"); int v = e ? atoi(e) : 0; return (size_t)(v >= 1 && v <= SC_MAX_BLOCKS ? v : SC_MAX_BLOCKS); }();
+    if (b > cap) b = cap;
     return (int)b;
 }
 
