@@ -7,6 +7,9 @@
 // openings in BTreeMap<CommittedPoly> order.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -25,6 +28,15 @@ extern "C" int atlas_prove_reduced_openings(const atlas_opening_t* openings, siz
     if (!openings || n_open == 0 || !srs || !transcript || !sumcheck_rows || !n_coeffs || !challenges || !max_rounds_out ||
         !sumcheck_claims || !com || !w || !v)
         return fail(ATLAS_EINVAL, "prove_reduced_openings: null argument");
+    const bool trace = getenv("ATLAS_TRACE") != nullptr;            // wall clock of the stages on stderr
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!trace) return;
+        atlas_sync();
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[atlas trace] prove_reduced_openings %-26s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t_prev).count());
+        t_prev = t1;
+    };
     std::vector<atlas_instance_t> inst(n_open, nullptr);
     atlas_batched_t b = nullptr;
     atlas_poly_t joint = nullptr;
@@ -67,10 +79,12 @@ extern "C" int atlas_prove_reduced_openings(const atlas_opening_t* openings, siz
         rc = atlas_onehot_opening_group_new(idx.data(), members.size(), O.log_K, O.log_T, ra.data(), O.point + O.log_K, rows.data());
         for (size_t q = 0; q < members.size() && !rc; q++) { inst[members[q]] = rows[q]; done[members[q]] = 1; }
     }
+    mark("instances (prepare)");
     // prove_batch_opening_sumcheck: BatchedSumcheck::prove over the instances (degree 2: rows of 3)
     if (!rc) rc = atlas_batched_new(&b);
     for (size_t i = 0; i < n_open && !rc; i++) rc = atlas_batched_add_instance(b, inst[i], &openings[i].claim);
     if (!rc) rc = atlas_batched_prove(b, transcript, sumcheck_rows, 3, n_coeffs, challenges, max_rounds_out);
+    mark("batched sumcheck");
     // cache_openings -> sumcheck_claims (opening_reduction.rs:238-246), then finalize (:611-643)
     for (size_t i = 0; i < n_open && !rc; i++) {
         size_t nf = 0;
@@ -97,11 +111,13 @@ extern "C" int atlas_prove_reduced_openings(const atlas_opening_t* openings, siz
         }
     }
     rc = atlas_rlc_build(dense.data(), dense.size(), onehot.data(), onehot.size(), &joint);
+    mark("claims + joint polynomial");
     size_t jlen = 0;
     if (!rc) atlas_poly_len(joint, &jlen);
     if (!rc && jlen != ((size_t)1 << *max_rounds_out)) rc = fail(ATLAS_EINVAL, "prove_reduced_openings: joint polynomial length != 2^max_rounds");
     // PCS::prove(generators, &rlc, &r_sumcheck, None, transcript) = HyperKZG::open
     if (!rc) rc = atlas_hyperkzg_open(srs, joint, challenges, *max_rounds_out, transcript, com, w, v);
+    mark("HyperKZG::open");
     cleanup();
     return rc;
 }
