@@ -28,8 +28,8 @@ def small(n, seed, lo=-(1 << 15), hi=1 << 15):
     return [int(v) % F.FR for v in rng.integers(lo, hi, size=n)]
 
 
-def run(model, label):
-    claim = model.input_claim()
+def run(model, label, claim=None):
+    claim = model.input_claim() if claim is None else claim
     t = Blake2bTranscript(label)
     rows, rs, raw, last = PS.prove(model, claim, t)
     return dict(claim="%x" % claim, rows=[["%x" % c for c in r] for r in rows], challenges=["%x" % c for c in raw],
@@ -71,4 +71,47 @@ for N, shift, log_T in ((16, 3, 2), (32, 5, 1)):
     out = run(PR.PsRightShiftModel(idx, N, shift, r_node, gamma), b"golden_rs")
     cases.append(dict(family="ps_rshift", N=N, shift=shift, log_T=log_T, idx=["%x" % v for v in idx], r=["%x" % v for v in r_node],
                       gamma="%x" % gamma, **out))
+from oracle.pymodel import poly as P                                      # noqa: E402
+
+
+def hx(v):
+    return ["%x" % x for x in v]
+
+
+# ---- one-hot "ra" family, openings, prefix-suffix lookups (models: RaVirtualModel ... PsUltModel)
+rng = np.random.default_rng(77)
+d, log_k, log_T = 3, 2, 3
+H = [[int(v) for v in rng.integers(-1, 1 << log_k, size=1 << log_T)] for _ in range(d)]
+chunks = [rand(log_k, 400 + i) for i in range(d)]
+r_cycle = rand(log_T, 410)
+cases.append(dict(family="ra_virtual", log_k=log_k, H=H, chunks=[hx(c) for c in chunks], r_cycle=hx(r_cycle),
+                  **run(PR.RaVirtualModel(H, chunks, r_cycle), b"golden_ra")))
+d, log_k, log_T = 2, 2, 2
+H = [[int(v) for v in rng.integers(-1, 1 << log_k, size=1 << log_T)] for _ in range(d)]
+gammas, r_address, r_cycle = [g >> 130 for g in rand(d, 420)], rand(log_k, 421), rand(log_T, 422)
+E = P.eq_evals(r_cycle)
+G = [[sum(E[j] for j in range(1 << log_T) if h[j] == k) % F.FR for k in range(1 << log_k)] for h in H]
+cases.append(dict(family="booleanity", log_k=log_k, H=H, G=[hx(g) for g in G], gammas=hx(gammas), r_address=hx(r_address),
+                  r_cycle=hx(r_cycle), **run(PR.BooleanityModel(H, log_k, gammas, r_address, r_cycle), b"golden_bool", 0)))
+Gh, gp = [rand(1 << 2, 430 + i) for i in range(2)], rand(2, 432)
+cases.append(dict(family="hamming", log_k=2, G=[hx(g) for g in Gh], gamma_powers=hx(gp), **run(PR.HammingModel(Gh, gp), b"golden_hw", sum(g * sum(row) for g, row in zip(gp, Gh)) % F.FR)))
+poly, point = rand(1 << 4, 440), rand(4, 441)
+_dm = PR.DenseOpeningModel(poly, point)
+cases.append(dict(family="dense_opening", poly=hx(poly), point=hx(point),
+                  **run(_dm, b"golden_do", sum(e * p_ for e, p_ in zip(_dm.eq, poly)) % F.FR)))
+idx = [int(v) for v in rng.integers(-1, 4, size=8)]
+ra_, rc_ = rand(2, 450), rand(3, 451)
+cases.append(dict(family="onehot_opening", log_K=2, idx=idx, r_address=hx(ra_), r_cycle=hx(rc_),
+                  **run(PR.OneHotOpeningModel(idx, 2, ra_, rc_), b"golden_oh")))
+li = [int(v) for v in rng.integers(0, 1 << 16, size=4)]
+li[0] = (1 << 16) - 1
+r_node, gamma = rand(2, 460), rand(1, 461)[0] >> 130
+cases.append(dict(family="ps_relu", N=16, idx=hx(li), r=hx(r_node), gamma="%x" % gamma, **run(PR.PsReluModel(li, 16, r_node, gamma), b"golden_relu")))
+cases.append(dict(family="ps_clamp", N=16, bound=9, symmetric=1, idx=hx(li), r=hx(r_node), gamma="%x" % gamma,
+                  **run(PR.PsClampModel(li, 16, 9, True, r_node, gamma), b"golden_clamp")))
+l8 = [v & 0xff for v in li]
+cases.append(dict(family="ps_identity", log_K=8, phases=4, idx=hx(l8), r=hx(r_node), **run(PR.PsIdentityModel(l8, 8, r_node), b"golden_id")))
+lu = [int(v) for v in rng.integers(0, 1 << 63, size=2)]
+r1 = rand(1, 470)
+cases.append(dict(family="ps_ult", idx=hx(lu), r=hx(r1), gamma="%x" % gamma, **run(PR.PsUltModel(lu, r1, gamma), b"golden_ult")))
 json.dump(dict(generator="tests/golden/gen_golden_instances.py", cases=cases), sys.stdout, indent=0)

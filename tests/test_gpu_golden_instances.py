@@ -7,7 +7,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from _golden_instances import cases, check, ints          # noqa: E402
+from _golden_instances import build, cases, check, ints   # noqa: E402
 
 
 @pytest.mark.parametrize("case", cases(), ids=lambda c: c.get("name", c["family"]) + "_" + c["state"][:6])
@@ -29,12 +29,16 @@ def test_device_replays_golden_instance(atlas, case):
                                   orc.from_ints(ints(case["r"])) if case["r"] else None)
         label = b"golden_sm"
     else:
-        inst = I.ps_shout_rshift(np.array(ints(case["idx"]), dtype=np.uint64), case["N"], case["shift"], orc.from_ints(ints(case["r"])),
-                                 orc.from_ints([int(case["gamma"], 16)])[0])
-        label = b"golden_rs"
+        class Dev:                                           # the device constructors under the oracle wrapper's names
+            ra_virtual, booleanity, onehot_opening = I.ra_virtual, I.booleanity, I.onehot_opening
+            hamming = staticmethod(lambda G, log_k, gp: I.hamming_weight(G, log_k, gp))
+            dense_opening = staticmethod(lambda poly, pt: I.dense_opening(A.MultilinearPolynomial.from_fr(poly), pt))
+            ps_relu, ps_clamp, ps_ult, ps_rshift = I.ps_shout_relu, I.ps_shout_clamp, I.ps_shout_ult, I.ps_shout_rshift
+            ps_identity = I.identity_range_check
+        inst, label = build(case, Dev, orc)
     t = A.Blake2bTranscript(label)
     rows, raw = inst.prove(orc.from_ints([int(case["claim"], 16)])[0], t)
-    finals = inst.final_claims() if fam != "ps_rshift" else []
+    finals = inst.final_claims()                             # against the MODEL's final claims
     check(orc, case, rows, raw, t.state, finals)
     inst.free()
     for p_ in polys:

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from _golden_instances import cases, check, ints          # noqa: E402
+from _golden_instances import build, cases, check, ints   # noqa: E402
 from oracle import orc, orc_ra as OR                       # noqa: E402
 
 
@@ -24,9 +24,7 @@ def test_oracle_replays_golden_instance(case):
                           orc.from_ints(ints(case["r"])) if case["r"] else None)
         label = b"golden_sm"
     else:
-        inst = OR.ps_rshift(np.array(ints(case["idx"]), dtype=np.uint64), case["N"], case["shift"], orc.from_ints(ints(case["r"])),
-                            orc.from_ints([int(case["gamma"], 16)])[0])
-        label = b"golden_rs"
+        inst, label = build(case, OR, orc)
     t = orc.new_transcript(label)
     rows, raw = inst.prove(orc.from_ints([int(case["claim"], 16)])[0], t)
     finals = list(inst.finals()) if hasattr(inst, "finals") else []
