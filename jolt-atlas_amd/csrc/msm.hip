@@ -134,12 +134,14 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
     const uint32_t n_chunks = TB / chunk;
     const uint32_t chunks_per_window = S.bpw / chunk;
 
-    // tiles of the LDS counting sort: <= MSM_TILE consecutive scalars of one vector
+    // tiles of the LDS counting sort: <= `tile` consecutive scalars of one vector
+    size_t tile = MSM_TILE;
+    if (const char* e = getenv("ATLAS_MSM_TILE")) { long v = atol(e); if (v >= 1024 && v <= (1 << 22)) tile = (size_t)v; }   // experiments
     std::vector<MsmTile> h_tiles;
     for (size_t k = 0; k < K; k++) {
         const size_t o = multi ? multi->offs[k] : 0, len = multi ? multi->lens[k] : n;
-        for (size_t t0 = 0; t0 < len; t0 += MSM_TILE)
-            h_tiles.push_back(MsmTile{(uint32_t)(o + t0), (uint32_t)(o + (t0 + MSM_TILE < len ? t0 + MSM_TILE : len)),
+        for (size_t t0 = 0; t0 < len; t0 += tile)
+            h_tiles.push_back(MsmTile{(uint32_t)(o + t0), (uint32_t)(o + (t0 + tile < len ? t0 + tile : len)),
                                       (uint32_t)(k * S.n_windows * S.bpw), (uint32_t)o});
     }
 
