@@ -194,3 +194,63 @@ def test_fuzz_msm_and_openings(atlas, seed):
         assert ch_g == ch_o and _rows_equal(rows_g, rows_o) and t_g.state == t_o.state_bytes(), ("onehot", log_K, log_T)
         inst.free()
     srs.free()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_batched_mixes(atlas, seed):
+    """BatchedSumcheck::prove over random mixes of instance families with different round counts and degrees."""
+    from oracle import orc, orc_ra as OR, orc_batched as OB
+    from jolt_atlas_amd import instances as I
+    A = atlas
+    rng = np.random.default_rng(4000 + seed + OFF)
+    P = A.MultilinearPolynomial.from_fr
+    n_inst = int(rng.integers(2, 6))
+    gpu, oc, claims, keep = [], [], [], []
+    for _ in range(n_inst):
+        fam = int(rng.integers(0, 6))
+        s = int(rng.integers(1 << 30))
+        claim = orc.random_fr(1, s)[0]
+        if fam == 0:                                   # element-wise operator
+            op = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 9]))
+            n_ops = {0: 2, 1: 2, 2: 1, 3: 1, 4: 3, 5: 2, 6: 1, 7: 4, 9: 2}[op]
+            nv = int(rng.integers(1, 8))
+            ops = [orc.random_fr(1 << nv, s + i) for i in range(n_ops)]
+            r = orc.random_fr(nv, s + 9)
+            polys = [P(v) for v in ops]; keep += polys
+            gpu.append(I.elementwise(op, polys, r)); oc.append(OB.ra_instance(OR.elementwise(op, ops, r), claim))
+        elif fam == 1:                                 # softmax family
+            kind = int(rng.integers(0, 4))
+            log_K = 0 if kind == 3 else int(rng.integers(1, 4)); log_N = int(rng.integers(1, 5))
+            a = orc.random_fr(1 << (log_K + log_N), s)
+            b = orc.random_fr(1 << (log_K + log_N), s + 1) if kind == 1 else orc.random_fr(1 << log_K, s + 1) if kind == 2 else None
+            r = orc.random_fr(log_K + (log_N if kind == 2 else 0), s + 2) if kind != 3 else None
+            pa = P(a); pb = P(b) if b is not None else None; keep += [pa] + ([pb] if pb is not None else [])
+            gpu.append(I.softmax_instance(kind, pa, pb, log_K, log_N, r)); oc.append(OB.ra_instance(OR.softmax(kind, a, b, log_K, log_N, r), claim))
+        elif fam == 2:                                 # dense opening
+            nv = int(rng.integers(1, 9))
+            poly, pt = orc.random_fr(1 << nv, s), orc.random_fr(nv, s + 1)
+            gpu.append(I.dense_opening(P(poly), pt)); oc.append(OB.ra_instance(OR.dense_opening(poly, pt), claim))
+        elif fam == 3:                                 # hamming weight (host-only instance)
+            d, log_k = int(rng.integers(1, 5)), int(rng.choice([1, 2, 4]))
+            G, gp = orc.random_fr(d << log_k, s).reshape(d, 1 << log_k, 4), orc.random_fr(d, s + 1)
+            gpu.append(I.hamming_weight(G, log_k, gp)); oc.append(OB.ra_instance(OR.hamming(G, log_k, gp), claim))
+        elif fam == 4:                                 # RaVirtual
+            d, log_k, log_T = int(rng.integers(1, 6)), 2, int(rng.integers(1, 7))
+            H = [rng.integers(-1, 1 << log_k, size=1 << log_T).astype(np.int32) for _ in range(d)]
+            chunks, rc = orc.random_fr(d * log_k, s).reshape(d, log_k, 4), orc.random_fr(log_T, s + 1)
+            gpu.append(I.ra_virtual(H, log_k, chunks, rc)); oc.append(OB.ra_instance(OR.ra_virtual(H, log_k, chunks, rc), claim))
+        else:                                          # the dot prover through its adapter
+            nv = int(rng.integers(1, 9))
+            L, R = orc.random_fr(1 << nv, s), orc.random_fr(1 << nv, s + 1)
+            claim = orc.dot_claim(L, R)[0]
+            gpu.append(A.EinsumDotProver(P(L), P(R))); oc.append(OB.dot_instance(L, R, claim))
+        claims.append(claim)
+    t_o = orc.new_transcript(b"fz_batched")
+    rows_o, ch_o, _ = OB.batched_prove(oc, t_o)
+    t_g = A.Blake2bTranscript(b"fz_batched")
+    rows_g, ch_g = A.BatchedSumcheck.prove(gpu, claims, t_g)
+    assert ch_g == ch_o and _rows_equal(rows_g, rows_o) and t_g.state == t_o.state_bytes()
+    for x in gpu:
+        x.free()
+    for p_ in keep:
+        p_.free()
