@@ -254,3 +254,38 @@ def test_fuzz_batched_mixes(atlas, seed):
         x.free()
     for p_ in keep:
         p_.free()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_hyperkzg_open_degenerate_polynomials(atlas, seed):
+    """HyperKZG::open of zero, constant, one-nonzero-coefficient and random polynomials against the oracle (points at
+    infinity in the transcript, all-zero MSM vectors)."""
+    from oracle import orc
+    A = atlas
+    rng = np.random.default_rng(5000 + seed + OFF)
+    tau = orc.random_fr(1, 11)[0]
+    for _ in range(3):
+        ell = int(rng.integers(1, 10))
+        n = 1 << ell
+        kind = int(rng.integers(0, 4))
+        poly = orc.random_fr(n, int(rng.integers(1 << 30)))
+        if kind == 0:
+            poly[:] = 0
+        elif kind == 1:
+            poly[:] = poly[0]
+        elif kind == 2:
+            keep = poly[int(rng.integers(0, n))].copy(); poly[:] = 0; poly[int(rng.integers(0, n))] = keep
+        pt = [int.from_bytes(rng.bytes(16), "little") for _ in range(ell)]
+        srs = A.SRS.generate(tau, n)
+        ref = srs.download()
+        t_o = orc.new_transcript(b"fz_open")
+        com_o, w_o, v_o = orc.hyperkzg_open(ref, poly, pt, t_o)
+        p = A.MultilinearPolynomial.from_fr(poly)
+        t_g = A.Blake2bTranscript(b"fz_open")
+        com_g, w_g, v_g = A.HyperKZG.open(srs, p, pt, t_g)
+        assert np.array_equal(v_g, v_o), (ell, kind)
+        for a, b in list(zip(com_g, com_o)) + list(zip(w_g, w_o)):
+            assert orc.g1_eq(a, b), (ell, kind)
+        assert t_g.state == t_o.state_bytes(), (ell, kind)
+        assert orc.g1_eq(A.HyperKZG.commit(srs, p), orc.msm(ref, poly))
+        p.free(); srs.free()
