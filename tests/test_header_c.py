@@ -13,11 +13,15 @@ def test_header_is_c99_and_cxx17():
         assert r.returncode == 0, r.stderr
 
 
-def test_c_example_links(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("name", ["prove_dot", "commit_open"])
+def test_c_example_links(tmp_path, name):
     import jolt_atlas_amd as A
     libdir = os.path.dirname(A.LIB_PATH)
-    exe = str(tmp_path / "prove_dot")
-    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "prove_dot.c"),
+    exe = str(tmp_path / name)
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", name + ".c"),
                         "-L", libdir, "-latlas_hip", "-Wl,-rpath," + libdir, "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     # no GPU here: the program must fail loudly through the library's error path, not crash
