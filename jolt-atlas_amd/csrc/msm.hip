@@ -176,6 +176,7 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
     const size_t o_buckets = carve((size_t)TB * sizeof(G1Xyzz));
     const size_t o_chunks = carve((size_t)n_chunks * sizeof(G1Xyzz));
     const size_t o_wsum = carve((size_t)V * sizeof(G1Xyzz));
+    const size_t o_biglist = carve((size_t)(TB + 1) * 4);        // [0] = count, then the bucket ids
     const size_t o_tiles = carve(h_tiles.size() * sizeof(MsmTile));
     int rc = wk.ensure(off);
     if (rc) return rc;
@@ -196,6 +197,8 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
     uint32_t* seg_cur = (uint32_t*)(W + o_segcur);
     G1Xyzz* chunks = (G1Xyzz*)(W + o_chunks);
     G1Xyzz* wsum = (G1Xyzz*)(W + o_wsum);
+    uint32_t* big_cnt = (uint32_t*)(W + o_biglist);
+    uint32_t* big_list = big_cnt + 1;
 
     const bool timing = g.timing && !pend;
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
@@ -223,8 +226,9 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
     k_exclusive_scan<<<1, 1024, 0, st>>>(bsum, (uint32_t)n_scan_blocks, boff, bcur);
     k_scan_apply<<<(unsigned)n_scan_blocks, 256, 0, st>>>(segc, TB, boff, seg_off, seg_cur, (uint32_t)n_scan_blocks);
     k_msm_accumulate_seg<<<(unsigned)((s_max + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(bases, sorted, offsets, seg_off, TB, seg_len, partial);
-    k_msm_bucket_reduce_small<<<(TB + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(partial, seg_off, TB, buckets);
-    k_msm_bucket_reduce_big<<<TB < 2048u ? TB : 2048u, MSM_THREADS, 0, st>>>(partial, seg_off, TB, buckets);
+    hipMemsetAsync(big_cnt, 0, 4, st);
+    k_msm_bucket_reduce_small<<<(TB + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(partial, seg_off, TB, buckets, big_list, big_cnt);
+    k_msm_bucket_reduce_big<<<TB < 2048u ? TB : 2048u, MSM_THREADS, 0, st>>>(partial, seg_off, big_list, big_cnt, buckets);
     if (timing) hipEventRecord(e2, st);
     k_msm_fold_chunks<<<(n_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(buckets, S, chunk, n_chunks, chunks);
     k_g1_group_sum<<<V, MSM_THREADS, 0, st>>>(chunks, chunks_per_window, wsum);

@@ -251,30 +251,36 @@ __global__ __launch_bounds__(MSM_THREADS) void k_msm_accumulate_seg(const G1Affi
     g1_store(partial + t, g1_from_f9(acc));
 }
 
-// buckets with at most MSM_SMALL_SEGS segments: one thread sums them
+// buckets with at most MSM_SMALL_SEGS segments: one thread sums them; the others are put on a list for the
+// workgroup-per-bucket kernel (n_big must be zero on entry)
 constexpr uint32_t MSM_SMALL_SEGS = 12;
 __global__ __launch_bounds__(MSM_THREADS) void k_msm_bucket_reduce_small(const G1Xyzz* __restrict__ partial,
                                                                          const uint32_t* __restrict__ seg_off, uint32_t n_buckets,
-                                                                         G1Xyzz* __restrict__ buckets) {
+                                                                         G1Xyzz* __restrict__ buckets, uint32_t* __restrict__ big_list,
+                                                                         uint32_t* n_big) {
     const uint32_t b = blockIdx.x * MSM_THREADS + threadIdx.x;
     if (b >= n_buckets) return;
     const uint32_t s0 = seg_off[b], cnt = seg_off[b + 1] - s0;
-    if (cnt > MSM_SMALL_SEGS) return;
+    if (cnt > MSM_SMALL_SEGS) { big_list[atomicAdd(n_big, 1u)] = b; return; }
     G1Xyzz acc = g1_inf();
     if (cnt) acc = g1_load(partial + s0);
     for (uint32_t s = 1; s < cnt; s++) acc = g1_add(acc, g1_load(partial + s0 + s));
     g1_store(buckets + b, acc);
 }
 
-// the long ones: a workgroup per bucket, the grid strides over the buckets (most have few segments and are skipped;
-// a grid of one workgroup per bucket spent ~0.27 ms at 2^22 launching 82 k workgroups that left at once)
+// the long ones: a workgroup per listed bucket, the grid strides over the list.  (One workgroup per bucket of the
+// whole table spent 0.27 ms at 2^22 launching 82 k workgroups that left at once; a grid striding over all buckets
+// spent 1.4 ms in the batched HyperKZG pipeline on 200 dependent loads per workgroup just to skip them.)
 __global__ __launch_bounds__(MSM_THREADS) void k_msm_bucket_reduce_big(const G1Xyzz* __restrict__ partial,
-                                                                       const uint32_t* __restrict__ seg_off, uint32_t n_buckets,
+                                                                       const uint32_t* __restrict__ seg_off,
+                                                                       const uint32_t* __restrict__ big_list,
+                                                                       const uint32_t* __restrict__ n_big,
                                                                        G1Xyzz* __restrict__ buckets) {
     __shared__ G1Xyzz sm[MSM_THREADS];
-    for (uint32_t b = blockIdx.x; b < n_buckets; b += gridDim.x) {
+    const uint32_t n_list = *n_big;
+    for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+        const uint32_t b = big_list[li];
         const uint32_t s0 = seg_off[b], cnt = seg_off[b + 1] - s0;
-        if (cnt <= MSM_SMALL_SEGS) continue;                   // uniform per workgroup
         G1Xyzz acc = g1_inf();
         for (uint32_t i = threadIdx.x; i < cnt; i += MSM_THREADS) acc = g1_add(acc, g1_load(partial + s0 + i));
         sm[threadIdx.x] = acc;
