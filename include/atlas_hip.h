@@ -55,6 +55,15 @@ int  atlas_sync(void);                           /* drain the library stream */
  * the `mul_hi_bigint_u128` reading), 1 = canonical integer c<<128. */
 int  atlas_set_challenge_mode(int mode);
 int  atlas_get_challenge_mode(void);
+/* Where the Blake2b transcript of the whole-instance provers (atlas_sumcheck_prove_dot, ...) runs.
+ * ATLAS_FS_HOST (default): on the calling host thread, over the round channel — kernels of all rounds are
+ * enqueued up front, mail their partial sums into pinned memory and poll the round's challenge slot
+ * (the reference keeps the transcript on the host too, sumcheck.rs:578-590).  ATLAS_FS_DEVICE: on one
+ * wavefront between the data passes, nothing crosses PCIe until the proof is complete.  Same bytes. */
+#define ATLAS_FS_HOST   0
+#define ATLAS_FS_DEVICE 1
+int  atlas_set_fs_mode(int mode);
+int  atlas_get_fs_mode(void);
 
 /* ---- transcript (host side; joltworks/src/transcripts/transcript.rs:6-28,
  *      blake2b.rs:81-238) ---------------------------------------------------------- */

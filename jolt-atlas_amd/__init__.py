@@ -91,6 +91,18 @@ def set_challenge_mode(mode):
     _check(lib.atlas_set_challenge_mode(C.c_int(mode)))
 
 
+FS_HOST, FS_DEVICE = 0, 1
+
+
+def set_fs_mode(mode):
+    """ATLAS_FS_HOST (default): transcript on the host over the round channel; ATLAS_FS_DEVICE: on one wavefront."""
+    _check(lib.atlas_set_fs_mode(C.c_int(mode)))
+
+
+def get_fs_mode():
+    return int(lib.atlas_get_fs_mode())
+
+
 def set_timing(on):
     _check(lib.atlas_set_timing(C.c_int(1 if on else 0)))
 

@@ -7,6 +7,7 @@
 // fails with ATLAS_ENODEV when the HIP device is not usable.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -120,6 +121,14 @@ int atlas_init(int device_ordinal) {
     HIP_TRY(hipMalloc(&g.d_chal, sizeof(uint64_t) * MAX_ROUNDS * 2));
     HIP_TRY(hipMalloc(&g.d_finals, sizeof(Fr) * 8));
     HIP_TRY(hipHostMalloc(&g.h_pinned, PINNED_BYTES, hipHostMallocDefault));
+    HIP_TRY(g.chan.init());
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dot_tail_ch<2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (sizeof(Fr) << SC_TAIL_CH_LOG)));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dot_tail2_f9),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (sizeof(Fr) << SC_TAIL_CH_LOG)));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dot_tail_ch<3>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (sizeof(Fr) << SC_TAIL_LOG)));
+    if (const char* e = getenv("ATLAS_FS")) g.fs_mode = std::strcmp(e, "device") == 0 ? ATLAS_FS_DEVICE : ATLAS_FS_HOST;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dot_tail<2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (sizeof(Fr) << SC_TAIL_LOG)));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dot_tail<3>),
@@ -137,6 +146,7 @@ int atlas_shutdown(void) {
     g.at_shutdown.clear();
     hipFree(g.d_partials); hipFree(g.d_ctx); hipFree(g.d_proof); hipFree(g.d_chal); hipFree(g.d_finals);
     hipHostFree(g.h_pinned);
+    g.chan.release();
     hipStreamDestroy(g.stream);
     g.ready = false; g.stream = nullptr; g.d_partials = nullptr; g.d_ctx = nullptr; g.d_proof = nullptr;
     g.d_chal = nullptr; g.d_finals = nullptr; g.h_pinned = nullptr;
@@ -157,6 +167,13 @@ int atlas_set_challenge_mode(int mode) {
     return ATLAS_OK;
 }
 int atlas_get_challenge_mode(void) { return g.challenge_mode; }
+
+int atlas_set_fs_mode(int mode) {
+    if (mode != ATLAS_FS_HOST && mode != ATLAS_FS_DEVICE) return fail(ATLAS_EINVAL, "fs mode must be ATLAS_FS_HOST or ATLAS_FS_DEVICE");
+    g.fs_mode = mode;
+    return ATLAS_OK;
+}
+int atlas_get_fs_mode(void) { return g.fs_mode; }
 
 int atlas_set_timing(int enabled) { g.timing = enabled != 0; return ATLAS_OK; }
 int atlas_last_timing(atlas_timing_t* out) {
@@ -457,11 +474,11 @@ template <int DEG>
 static void launch_eval(const atlas_dot_prover* P, const EqView& eq, size_t half, int grid) {
     const ScConsts K = make_consts();
     if (P->left->is_i32)
-        k_dot_eval<DEG, int32_t><<<grid, SC_THREADS, 0, g.stream>>>((const int32_t*)P->left->d, (const int32_t*)P->right->d,
-                                                                 eq, half, g.d_partials, K);
+        k_dot_eval<DEG, int32_t, DevIo><<<grid, SC_THREADS, 0, g.stream>>>((const int32_t*)P->left->d, (const int32_t*)P->right->d,
+                                                                        eq, half, DevIo{g.d_ctx, g.d_partials}, K);
     else
-        k_dot_eval<DEG, Fr><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, eq, half,
-                                                            g.d_partials, K);
+        k_dot_eval<DEG, Fr, DevIo><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, eq, half,
+                                                                   DevIo{g.d_ctx, g.d_partials}, K);
 }
 
 extern "C" {
@@ -579,7 +596,7 @@ static int prove_dot_impl(atlas_dot_prover* P, const atlas_fr_t* input_claim, at
             const int grid = use_f9 ? grid_f9(half) : grid_for(half);
             EqView eq = eq_view_for_round(P, 0, eqp, eq_len);
             tm.begin(0, 2 * len * esz);
-            if (use_f9) k_dot_eval2_f9<<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, half, g.d_partials);
+            if (use_f9) k_dot_eval2_f9<DevIoF9><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, half, DevIoF9{g.d_ctx, g.d_partials});
             else launch_eval<DEG>(P, eq, half, grid);
             tm.end();
             tm.begin(1, 0);
@@ -609,9 +626,9 @@ static int prove_dot_impl(atlas_dot_prover* P, const atlas_fr_t* input_claim, at
                 Fr *Ld = nullptr, *Rd = nullptr;
                 HIP_TRY(hipMalloc(&Ld, (len / 2) * sizeof(Fr)));
                 HIP_TRY(hipMalloc(&Rd, (len / 2) * sizeof(Fr)));
-                k_dot_bind_eval<DEG, int32_t, false><<<grid, SC_THREADS, 0, g.stream>>>(
-                    (const int32_t*)P->left->d, (const int32_t*)P->right->d, Ld, Rd, nullptr, eq, q, g.d_ctx,
-                    g.d_partials, K, hi_only);
+                k_dot_bind_eval<DEG, int32_t, false, DevIo><<<grid, SC_THREADS, 0, g.stream>>>(
+                    (const int32_t*)P->left->d, (const int32_t*)P->right->d, Ld, Rd, nullptr, eq, q,
+                    DevIo{g.d_ctx, g.d_partials}, K, hi_only);
                 tm.end();
                 HIP_TRY(hipStreamSynchronize(g.stream));
                 if (P->left->owned) (void)hipFree(P->left->d);
@@ -619,22 +636,22 @@ static int prove_dot_impl(atlas_dot_prover* P, const atlas_fr_t* input_claim, at
                 P->left->d = Ld; P->left->is_i32 = false; P->left->owned = true;
                 P->right->d = Rd; P->right->is_i32 = false; P->right->owned = true;
             } else if (fuse_eq) {
-                k_dot_bind_eval<DEG, Fr, true><<<grid, SC_THREADS, 0, g.stream>>>(
+                k_dot_bind_eval<DEG, Fr, true, DevIo><<<grid, SC_THREADS, 0, g.stream>>>(
                     (const Fr*)P->left->d, (const Fr*)P->right->d, (Fr*)P->left->d, (Fr*)P->right->d, eqp, eq, q,
-                    g.d_ctx, g.d_partials, K, hi_only);
+                    DevIo{g.d_ctx, g.d_partials}, K, hi_only);
                 tm.end();
                 eq_len /= 2;
             } else if (use_f9) {
                 // last fused pass hands canonical residues to the LDS tail kernel
                 if (len / 2 <= ((size_t)1 << SC_TAIL_LOG))
-                    k_dot_bind_eval2_f9<true><<<grid, SC_THREADS, 0, g.stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, g.d_ctx, g.d_partials);
+                    k_dot_bind_eval2_f9<true, DevIoF9><<<grid, SC_THREADS, 0, g.stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, DevIoF9{g.d_ctx, g.d_partials});
                 else
-                    k_dot_bind_eval2_f9<false><<<grid, SC_THREADS, 0, g.stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, g.d_ctx, g.d_partials);
+                    k_dot_bind_eval2_f9<false, DevIoF9><<<grid, SC_THREADS, 0, g.stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, DevIoF9{g.d_ctx, g.d_partials});
                 tm.end();
             } else {
-                k_dot_bind_eval<DEG, Fr, false><<<grid, SC_THREADS, 0, g.stream>>>(
+                k_dot_bind_eval<DEG, Fr, false, DevIo><<<grid, SC_THREADS, 0, g.stream>>>(
                     (const Fr*)P->left->d, (const Fr*)P->right->d, (Fr*)P->left->d, (Fr*)P->right->d, nullptr, eq, q,
-                    g.d_ctx, g.d_partials, K, hi_only);
+                    DevIo{g.d_ctx, g.d_partials}, K, hi_only);
                 tm.end();
             }
             len /= 2;
@@ -684,6 +701,199 @@ static int prove_dot_impl(atlas_dot_prover* P, const atlas_fr_t* input_claim, at
     return ATLAS_OK;
 }
 
+// ---- whole-instance prove over the round channel: transcript on the host, every launch enqueued up front ----
+// One round of Sumcheck::prove on the host (sumcheck.rs:578-588) for a degree-2/3 message given as the
+// evaluations at 0, 2[, 3]: from_evals_and_hint, compress, append_to_transcript, challenge_scalar_optimized,
+// evaluate.  row <- compressed coefficients (DEG of them).
+static void host_fs_round(H::Transcript& T, int deg, const H::Fr* ev, H::Fr& claim, H::Fr* row, atlas_u128_t* chal, int mode) {
+    H::Fr c[4];
+    H::unipoly_from_evals_and_hint(claim, ev, deg, c);
+    H::tr_append_message(T, "UniPoly_begin");
+    H::tr_append_scalar(T, c[0]);
+    for (int k = 2; k <= deg; k++) H::tr_append_scalar(T, c[k]);
+    H::tr_append_message(T, "UniPoly_end");
+    H::tr_challenge_u128(T, chal->lo, chal->hi);
+    const H::Fr r = H::challenge_to_fr(chal->lo, chal->hi, mode);
+    H::Fr v = c[deg];
+    for (int k = deg - 1; k >= 0; k--) v = H::add(H::mul(v, r), c[k]);       // same value as UniPoly::evaluate (unipoly.rs:229-245)
+    claim = v;
+    row[0] = c[0];
+    for (int k = 2; k <= deg; k++) row[k - 1] = c[k];
+}
+
+template <int DEG>
+static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim, atlas_transcript_t* transcript,
+                             atlas_fr_t* compressed_polys, atlas_u128_t* challenges, atlas_fr_t final_claims[3]) {
+    using atlas_rt::Channel;
+    Channel& C = g.chan;
+    const ScConsts K = make_consts();
+    const size_t n = P->n_rounds;
+    const int mode = g.challenge_mode;
+    const int hi_only = mode == 0;
+    Timer tm;
+    if (C.abort_dirty) { HIP_TRY(hipMemsetAsync(C.d_abort, 0, 4, g.stream)); C.abort_dirty = false; }
+
+    // tags: records of round k = tag0 + k (k = n: the final claims), challenge of round k = tag0 + n + 1 + k
+    const uint32_t tag0 = C.next_tag; C.next_tag += (uint32_t)(2 * n + 2);
+    if (C.next_slot + n > Channel::RING) C.next_slot = 0;
+    const size_t slot0 = C.next_slot; C.next_slot += n;
+    auto mtag = [&](size_t k) { return tag0 + (uint32_t)k; };
+    auto rtag = [&](size_t k) { return tag0 + (uint32_t)(n + 1 + k); };
+    struct Mail { atlas::Chunk* base; size_t blocks; int radix, shl; };
+    std::vector<Mail> mails(n);
+    std::vector<size_t> waiters(n, 1);          // workgroups of the launches that wait for challenge k
+
+    size_t len = P->left->len;
+    size_t eq_len = P->eq ? P->eq->len : 0;
+    Fr* eqp = P->eq ? (Fr*)P->eq->d : nullptr;
+    size_t rounds_done = 0;
+    int pending = 0;
+    const bool was_i32 = P->left->is_i32;
+    const size_t esz = was_i32 ? sizeof(int32_t) : sizeof(Fr);
+    const bool use_f9 = DEG == 2 && !was_i32 && mode == 0;
+    auto grid_f9 = [](size_t work) { size_t b = (work + SC_THREADS - 1) / SC_THREADS; return (int)(b < 1 ? 1 : b > 256 ? 256 : b); };
+    const size_t tail_log = P->schedule == ATLAS_EQ_NONE ? SC_TAIL_CH_LOG : SC_TAIL_LOG;
+    void *old_l = nullptr, *old_r = nullptr;       // i32 sources replaced by the first fused pass
+
+    if (n > tail_log) {
+        {
+            const size_t half = len / 2;
+            const int grid = use_f9 ? grid_f9(half) : grid_for(half);
+            atlas::Chunk* reg = C.region();
+            const RoundIo io = C.io(reg, mtag(0), (size_t)-1, 0);
+            EqView eq = eq_view_for_round(P, 0, eqp, eq_len);
+            tm.begin(0, 2 * len * esz);
+            if (use_f9) k_dot_eval2_f9<ChanIoF9><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, half, ChanIoF9{io});
+            else if (was_i32) k_dot_eval<DEG, int32_t, ChanIo><<<grid, SC_THREADS, 0, g.stream>>>((const int32_t*)P->left->d, (const int32_t*)P->right->d, eq, half, ChanIo{io, mode}, K);
+            else k_dot_eval<DEG, Fr, ChanIo><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, eq, half, ChanIo{io, mode}, K);
+            tm.end();
+            mails[0] = Mail{reg, (size_t)grid, use_f9 ? 29 : 32, use_f9 ? 5 : 0};
+            rounds_done = 1; pending = 1;
+        }
+        while (len > ((size_t)1 << tail_log)) {
+            const size_t j = rounds_done - 1;          // challenge index being bound
+            const size_t q = len / 4;
+            const int grid = use_f9 ? grid_f9(q) : grid_for(q);
+            bool fuse_eq = false;
+            if (P->schedule == ATLAS_EQ_HIGH && j < P->a) {
+                tm.begin(0, (eq_len + eq_len / 2) * sizeof(Fr));
+                waiters[j] = (size_t)(grid_for(eq_len / 2) > grid ? grid_for(eq_len / 2) : grid);
+                k_bind_hi_io<ChanIo><<<grid_for(eq_len / 2), SC_THREADS, 0, g.stream>>>(eqp, eq_len / 2, ChanIo{C.io(nullptr, 0, slot0 + j, rtag(j), waiters[j]), mode}, hi_only);
+                tm.end();
+                eq_len /= 2;
+            } else if (P->schedule == ATLAS_EQ_LOW && j >= P->a) {
+                fuse_eq = true;
+            }
+            EqView eq = eq_view_for_round(P, j + 1, eqp, fuse_eq ? eq_len / 2 : eq_len);
+            uint64_t bytes = 2 * len * (P->left->is_i32 ? sizeof(int32_t) : sizeof(Fr)) + 2 * (len / 2) * sizeof(Fr);
+            if (fuse_eq) bytes += (eq_len + eq_len / 2) * sizeof(Fr);
+            atlas::Chunk* reg = C.region();
+            if (waiters[j] < (size_t)grid) waiters[j] = (size_t)grid;
+            const RoundIo io = C.io(reg, mtag(rounds_done), slot0 + j, rtag(j), waiters[j]);
+            tm.begin(0, bytes);
+            if (P->left->is_i32) {
+                Fr *Ld = nullptr, *Rd = nullptr;
+                hipError_t e = hipMalloc(&Ld, (len / 2) * sizeof(Fr));
+                if (e == hipSuccess) e = hipMalloc(&Rd, (len / 2) * sizeof(Fr));
+                if (e != hipSuccess) {
+                    if (Ld) (void)hipFree(Ld);
+                    for (size_t k = 0; k < n; k++) C.publish(slot0 + k, rtag(k), 0, 0, true);
+                    (void)hipStreamSynchronize(g.stream);
+                    P->consumed = true;
+                    return fail(ATLAS_ENOMEM, "hipMalloc(bound operands)", e);
+                }
+                k_dot_bind_eval<DEG, int32_t, false, ChanIo><<<grid, SC_THREADS, 0, g.stream>>>(
+                    (const int32_t*)P->left->d, (const int32_t*)P->right->d, Ld, Rd, nullptr, eq, q, ChanIo{io, mode}, K, hi_only);
+                old_l = P->left->owned ? P->left->d : nullptr; old_r = P->right->owned ? P->right->d : nullptr;
+                P->left->d = Ld; P->left->is_i32 = false; P->left->owned = true;
+                P->right->d = Rd; P->right->is_i32 = false; P->right->owned = true;
+            } else if (fuse_eq) {
+                k_dot_bind_eval<DEG, Fr, true, ChanIo><<<grid, SC_THREADS, 0, g.stream>>>(
+                    (const Fr*)P->left->d, (const Fr*)P->right->d, (Fr*)P->left->d, (Fr*)P->right->d, eqp, eq, q, ChanIo{io, mode}, K, hi_only);
+                eq_len /= 2;
+            } else if (use_f9) {
+                if (false)                                     // (the lazy-limb tail takes residues < 2.1p as they are)
+                    k_dot_bind_eval2_f9<true, ChanIoF9><<<grid, SC_THREADS, 0, g.stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, ChanIoF9{io});
+                else
+                    k_dot_bind_eval2_f9<false, ChanIoF9><<<grid, SC_THREADS, 0, g.stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, ChanIoF9{io});
+            } else {
+                k_dot_bind_eval<DEG, Fr, false, ChanIo><<<grid, SC_THREADS, 0, g.stream>>>(
+                    (const Fr*)P->left->d, (const Fr*)P->right->d, (Fr*)P->left->d, (Fr*)P->right->d, nullptr, eq, q, ChanIo{io, mode}, K, hi_only);
+            }
+            tm.end();
+            mails[rounds_done] = Mail{reg, (size_t)grid, use_f9 ? 29 : 32, use_f9 ? 5 : 0};
+            len /= 2;
+            rounds_done += 1;
+        }
+    }
+    // tail: all remaining rounds in one resident launch
+    atlas::Chunk* tail_reg = C.region();
+    const size_t tail_round0 = rounds_done;
+    {
+        TailChArgs A;
+        A.L = P->left->d; A.R = P->right->d; A.eq = eqp;
+        A.len = (uint32_t)len; A.eq_len = (uint32_t)eq_len;
+        A.src_i32 = P->left->is_i32 ? 1 : 0;
+        A.sched = P->schedule; A.a = (uint32_t)P->a; A.b = (uint32_t)P->b;
+        A.round0 = (uint32_t)rounds_done; A.n_rounds = (uint32_t)n;
+        A.pending_bind = pending; A.challenge_mode = mode; A.cap_log = (uint32_t)tail_log;
+        A.mail = tail_reg; A.r_host = C.rslots + Channel::SLOT_CHUNKS * slot0; A.r_slot_chunks = (uint32_t)Channel::SLOT_CHUNKS; A.abort_flag = C.d_abort;
+        A.tag_mail0 = mtag(0); A.tag_r0 = rtag(0);
+        const bool tail_f9 = DEG == 2 && mode == 0;
+        for (size_t k = rounds_done; k < n; k++) mails[k] = Mail{tail_reg + (k - rounds_done) * ch_stride(DEG), 1, tail_f9 ? 29 : 32, tail_f9 ? 5 : 0};
+        tm.begin(1, 0);
+        if (DEG == 2 && mode == 0) k_dot_tail2_f9<<<1, SC_TAIL_THREADS, 2 * (sizeof(Fr) << tail_log), g.stream>>>(A, K);
+        else k_dot_tail_ch<DEG><<<1, SC_TAIL_X_THREADS, (P->schedule == ATLAS_EQ_NONE ? 2 : 3) * (sizeof(Fr) << tail_log), g.stream>>>(A, K);
+        tm.end();
+    }
+    hipError_t le = hipGetLastError();
+
+    // the transcript, on this thread
+    H::Transcript T;
+    std::memcpy(&T, transcript, sizeof(T));
+    H::Fr claim;
+    std::memcpy(&claim, input_claim, 32);
+    H::tr_append_scalar(T, claim);                                   // sumcheck.rs:573-574
+    bool ok = le == hipSuccess;
+    static const bool trace = getenv("ATLAS_TRACE_CH") != nullptr;
+    auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    std::vector<double> tr_t;
+    double t_prev = trace ? now_us() : 0;
+    for (size_t round = 0; round < n; round++) {
+        uint64_t acc[DEG][9];
+        H::Fr ev[DEG];
+        double t_first = 0;
+        if (trace && ok) { uint64_t a1[1][9]; C.collect(mails[round].base, mtag(round), 1, 1, a1); t_first = now_us(); }
+        if (ok) ok = C.collect(mails[round].base, mtag(round), mails[round].blocks, DEG, acc);
+        if (!ok) { C.publish(slot0 + round, rtag(round), 0, 0, true); continue; }
+        const double t_coll = trace ? now_us() : 0;
+        for (int k = 0; k < DEG; k++) ev[k] = atlas_rt::sum_to_fr(acc[k], mails[round].radix, mails[round].shl);
+        host_fs_round(T, DEG, ev, claim, reinterpret_cast<H::Fr*>(compressed_polys) + round * DEG, &challenges[round], mode);
+        C.publish(slot0 + round, rtag(round), challenges[round].lo, challenges[round].hi);
+        if (trace) { const double t_pub = now_us(); tr_t.push_back(t_first - t_prev); tr_t.push_back(t_coll - t_first); tr_t.push_back(t_pub - t_coll); t_prev = t_pub; }
+    }
+    if (trace) {
+        fprintf(stderr, "[atlas trace] channel dot n=%zu: per round (us) wait-for-first-record / collect-rest / fs+publish\n", n);
+        for (size_t r = 0; r * 3 + 2 < tr_t.size(); r++) fprintf(stderr, "  round %2zu blocks %4zu: %7.2f %7.2f %7.2f\n", r, mails[r].blocks, tr_t[3 * r], tr_t[3 * r + 1], tr_t[3 * r + 2]);
+    }
+    uint32_t fin[3][9];
+    if (ok) ok = C.collect_raw(tail_reg + (n - tail_round0) * ch_stride(DEG), mtag(n), 3, fin);
+    P->consumed = true;
+    P->left->len = 1; P->right->len = 1;
+    if (P->eq) P->eq->len = 1;
+    if (old_l || old_r || !ok) (void)hipStreamSynchronize(g.stream);
+    if (old_l) (void)hipFree(old_l);
+    if (old_r) (void)hipFree(old_r);
+    if (!ok) {
+        tm.collect();
+        return le != hipSuccess ? fail(ATLAS_ENODEV, "sumcheck launch", le) : fail(ATLAS_ENODEV, "round channel: no answer from the device");
+    }
+    for (int k = 0; k < 3; k++) std::memcpy(&final_claims[k], fin[k], 32);
+    std::memcpy(transcript, &T, sizeof(T));
+    tm.collect();
+    return ATLAS_OK;
+}
+
 extern "C" {
 
 int atlas_sumcheck_prove_dot(atlas_dot_prover_t P, const atlas_fr_t* input_claim, atlas_transcript_t* transcript,
@@ -694,6 +904,10 @@ int atlas_sumcheck_prove_dot(atlas_dot_prover_t P, const atlas_fr_t* input_claim
     if (P->consumed) return fail(ATLAS_ESTATE, "sumcheck_prove_dot: prover already consumed");
     if (P->left->len != ((size_t)1 << P->n_rounds)) return fail(ATLAS_ESTATE, "sumcheck_prove_dot: rounds already run");
     std::lock_guard<std::mutex> lk(g.mu);
+    if (g.fs_mode == ATLAS_FS_HOST) {
+        if (P->schedule == ATLAS_EQ_NONE) return prove_dot_channel<2>(P, input_claim, transcript, compressed_polys, challenges, final_claims);
+        return prove_dot_channel<3>(P, input_claim, transcript, compressed_polys, challenges, final_claims);
+    }
     if (P->schedule == ATLAS_EQ_NONE) return prove_dot_impl<2>(P, input_claim, transcript, compressed_polys, challenges, final_claims);
     return prove_dot_impl<3>(P, input_claim, transcript, compressed_polys, challenges, final_claims);
 }
@@ -740,15 +954,15 @@ int atlas_dot_shard_local_message(atlas_dot_prover_t P, atlas_fr_t* out2) {
     if (!P->shard_pending) {          // first message: no bind
         const size_t half = len / 2;
         grid = (int)((half + SC_THREADS - 1) / SC_THREADS); if (grid > 256) grid = 256; if (grid < 1) grid = 1;
-        if (f9) k_dot_eval2_f9<<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, half, g.d_partials);
-        else k_dot_eval<2, Fr><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, eq, half, g.d_partials, K);
+        if (f9) k_dot_eval2_f9<DevIoF9><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, half, DevIoF9{g.d_ctx, g.d_partials});
+        else k_dot_eval<2, Fr, DevIo><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, eq, half, DevIo{g.d_ctx, g.d_partials}, K);
     } else {                          // bind the last challenge, evaluate the next message
         if (len < 4) return fail(ATLAS_ESTATE, "dot_shard_local_message: use atlas_dot_shard_local_final");
         const size_t q = len / 4;
         grid = (int)((q + SC_THREADS - 1) / SC_THREADS); if (grid > 256) grid = 256; if (grid < 1) grid = 1;
         // canonical residues in HBM: the exact kernels may read them later (local_final)
-        if (f9) k_dot_bind_eval2_f9<true><<<grid, SC_THREADS, 0, g.stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, g.d_ctx, g.d_partials);
-        else k_dot_bind_eval<2, Fr, false><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, (Fr*)P->left->d, (Fr*)P->right->d, nullptr, eq, q, g.d_ctx, g.d_partials, K, hi_only);
+        if (f9) k_dot_bind_eval2_f9<true, DevIoF9><<<grid, SC_THREADS, 0, g.stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, DevIoF9{g.d_ctx, g.d_partials});
+        else k_dot_bind_eval<2, Fr, false, DevIo><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, (Fr*)P->left->d, (Fr*)P->right->d, nullptr, eq, q, DevIo{g.d_ctx, g.d_partials}, K, hi_only);
         P->left->len = len / 2; P->right->len = len / 2;
         P->shard_pending = false;
     }

@@ -1,0 +1,147 @@
+// Round channel, host side (see channel.hip.h for the protocol and the measurements behind it).
+// The host thread that owns a sumcheck runs the Blake2b transcript (sumcheck.rs:578-590): it collects
+// the per-workgroup partial sums the kernels mailed into pinned memory, finishes the round polynomial,
+// hashes, and publishes the challenge in the round's slot, which launches enqueued earlier are polling.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+
+#include "channel.hip.h"
+#include "host_field.hpp"
+
+namespace atlas_rt {
+
+struct Channel {
+    static constexpr size_t REGIONS = 4;                    // mail regions, used round-robin by consecutive launches
+    static constexpr size_t REGION_CHUNKS = 2048 * 12;   // up to 2048 workgroups x ch_stride(3) chunks
+    static constexpr size_t RING = 128;                     // challenge slots (a sumcheck has at most 64 rounds)
+    static constexpr size_t SLOT_CHUNKS = 4;                                                   // host slot: one line
+    static constexpr size_t DEV_SLOT_CHUNKS = atlas::CH_MAX_REPLICAS * atlas::CH_REPLICA_CHUNKS;   // 256 HBM replicas of one line
+    atlas::Chunk* mail = nullptr;       // pinned
+    atlas::Chunk* rslots = nullptr;     // pinned, SLOT_CHUNKS per slot
+    atlas::Chunk* d_rslots = nullptr;   // HBM, DEV_SLOT_CHUNKS per slot
+    uint32_t* d_abort = nullptr;        // HBM
+    uint32_t next_tag = 1;
+    size_t next_region = 0, next_slot = 0;
+    bool abort_dirty = false;
+
+    hipError_t init() {
+        hipError_t e = hipHostMalloc(&mail, REGIONS * REGION_CHUNKS * sizeof(atlas::Chunk), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc(&rslots, RING * SLOT_CHUNKS * sizeof(atlas::Chunk), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc(&d_rslots, RING * DEV_SLOT_CHUNKS * sizeof(atlas::Chunk));
+        if (e == hipSuccess) e = hipMalloc(&d_abort, 64);
+        if (e != hipSuccess) return e;
+        std::memset(mail, 0, REGIONS * REGION_CHUNKS * sizeof(atlas::Chunk));
+        std::memset(rslots, 0, RING * SLOT_CHUNKS * sizeof(atlas::Chunk));
+        e = hipMemset(d_rslots, 0, RING * DEV_SLOT_CHUNKS * sizeof(atlas::Chunk));
+        if (e == hipSuccess) e = hipMemset(d_abort, 0, 64);
+        return e;
+    }
+    void release() {
+        if (mail) hipHostFree(mail);
+        if (rslots) hipHostFree(rslots);
+        if (d_rslots) hipFree(d_rslots);
+        if (d_abort) hipFree(d_abort);
+        mail = rslots = d_rslots = nullptr; d_abort = nullptr;
+    }
+
+    uint32_t tag() { uint32_t t = next_tag++; if (next_tag == 0) next_tag = 1; return t; }
+    atlas::Chunk* region() { atlas::Chunk* p = mail + (next_region % REGIONS) * REGION_CHUNKS; next_region++; return p; }
+    size_t slot() { return next_slot++ % RING; }
+
+    // kernel argument of a launch of `waiters` workgroups that mails `tag_mail` records into `mail_region` and
+    // (slot_r != npos) first waits for the challenge published in slot_r under tag_r
+    static uint32_t replicas_for(size_t waiters) { return (uint32_t)(waiters < 1 ? 1 : waiters > atlas::CH_MAX_REPLICAS ? atlas::CH_MAX_REPLICAS : waiters); }
+    atlas::RoundIo io(atlas::Chunk* mail_region, uint32_t tag_mail, size_t slot_r, uint32_t tag_r, size_t waiters = 1) const {
+        atlas::RoundIo o;
+        o.mail = mail_region;
+        o.r_host = slot_r == (size_t)-1 ? nullptr : rslots + SLOT_CHUNKS * slot_r;
+        o.r_dev = slot_r == (size_t)-1 ? nullptr : d_rslots + DEV_SLOT_CHUNKS * slot_r;
+        o.r_replicas = replicas_for(waiters);
+        o.abort_flag = d_abort;
+        o.tag_mail = tag_mail; o.tag_r = tag_r;
+        return o;
+    }
+
+    // host -> device: challenge (or an abort record) for the launches waiting on `slot`.  A chunk is written with
+    // one aligned 16-byte store, so its tag and payload arrive together.
+    void publish(size_t slot, uint32_t tag, uint64_t lo, uint64_t hi, bool abort = false) {
+        typedef uint32_t v4 __attribute__((vector_size(16)));
+        const v4 c0 = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, tag};
+        const v4 c1 = {(uint32_t)(hi >> 32), abort ? 1u : 0u, 0u, tag};
+        atlas::Chunk* s = rslots + SLOT_CHUNKS * slot;
+        *reinterpret_cast<volatile v4*>(s) = c0;
+        *reinterpret_cast<volatile v4*>(s + 1) = c1;
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+        if (abort) abort_dirty = true;
+    }
+
+    // device -> host: wait for n_blocks * n_vals records tagged `tag` and add word w of the k-th value of every
+    // workgroup into acc[k][w].  false on timeout (the device is gone or a kernel gave up).
+    bool collect(const atlas::Chunk* base, uint32_t tag, size_t n_blocks, int n_vals, uint64_t (*acc)[9], double timeout_s = 10.0) {
+        for (int k = 0; k < n_vals; k++) for (int w = 0; w < 9; w++) acc[k][w] = 0;
+        const size_t stride = atlas::ch_stride((uint32_t)n_vals);
+        for (size_t b = 0; b < n_blocks; b++) {
+            const volatile atlas::Chunk* c = base + b * stride;
+            for (int k = 0; k < n_vals; k++) {
+                for (int j = 0; j < 3; j++, c++) {
+                    if (c->tag != tag && !spin(c, tag, timeout_s)) { abort_dirty = true; return false; }
+                    // the tag was read first: x86 keeps load order, and the chunk arrived as one write
+                    acc[k][3 * j] += c->d[0]; acc[k][3 * j + 1] += c->d[1]; acc[k][3 * j + 2] += c->d[2];
+                }
+            }
+        }
+        return true;
+    }
+    // single records (final claims, ...): raw 9 words each
+    bool collect_raw(const atlas::Chunk* base, uint32_t tag, size_t n_rec, uint32_t (*out)[9], double timeout_s = 10.0) {
+        const volatile atlas::Chunk* c = base;
+        for (size_t r = 0; r < n_rec; r++)
+            for (int j = 0; j < 3; j++, c++) {
+                if (c->tag != tag && !spin(c, tag, timeout_s)) { abort_dirty = true; return false; }
+                out[r][3 * j] = c->d[0]; out[r][3 * j + 1] = c->d[1]; out[r][3 * j + 2] = c->d[2];
+            }
+        return true;
+    }
+
+private:
+    static bool spin(const volatile atlas::Chunk* c, uint32_t tag, double timeout_s) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            for (int i = 0; i < 4096; i++) {
+                if (c->tag == tag) return true;
+                __builtin_ia32_pause();
+            }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+        }
+    }
+};
+
+// sum of records -> Fr.  acc[w] = sum over records of word w; the value is sum_w acc[w] 2^(radix w), times 2^shl,
+// reduced mod p.  radix 32 / shl 0: canonical 8 x u32 Montgomery residues (exact kernels).  radix 29 / shl 5: lazy
+// 9 x 29-bit limbs of sums of f9_mul products, which carry 2^-5 relative to the Montgomery radix (f9.hip.h).
+inline atlas_host::Fr sum_to_fr(const uint64_t acc[9], int radix, int shl) {
+    typedef unsigned __int128 u128;
+    uint64_t v[6] = {0, 0, 0, 0, 0, 0};                   // 384 bits
+    for (int w = 0; w < 9; w++) {
+        if (!acc[w]) continue;
+        const int bit = radix * w + shl, limb = bit >> 6, off = bit & 63;
+        u128 x = (u128)acc[w] << off;                     // acc[w] < 2^44: fits 128 bits
+        u128 c = (u128)v[limb] + (uint64_t)x;
+        v[limb] = (uint64_t)c; c >>= 64;
+        c += (u128)v[limb + 1] + (uint64_t)(x >> 64);
+        v[limb + 1] = (uint64_t)c; c >>= 64;
+        for (int i = limb + 2; c && i < 6; i++) { c += v[i]; v[i] = (uint64_t)c; c >>= 64; }
+    }
+    // v < 2^300 = lo + hi 2^256.  With H::mul(a, b) = a b 2^-256 mod p (one operand < p suffices):
+    // lo mod p = mul(lo, 2^256 mod p), hi 2^256 mod p = mul(hi, 2^512 mod p)
+    namespace H = atlas_host;
+    const H::Fr lo{{v[0], v[1], v[2], v[3]}}, hi{{v[4], v[5], 0, 0}};
+    const H::Fr r2{{H::FR_R2[0], H::FR_R2[1], H::FR_R2[2], H::FR_R2[3]}};
+    return H::add(H::mul(lo, H::one()), H::mul(hi, r2));
+}
+
+}  // namespace atlas_rt

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/atlas_hip.h"
+#include "channel.hpp"
 
 namespace atlas {
 struct Fe;
@@ -29,6 +30,8 @@ struct Runtime {
     int device = -1;
     hipStream_t stream = nullptr;
     int challenge_mode = 0;
+    int fs_mode = ATLAS_FS_HOST;       // where the Fiat-Shamir transcript of the whole-instance provers runs
+    Channel chan;                      // round channel (pinned mailboxes + challenge slots), ATLAS_FS_HOST
     bool timing = false;
     atlas_timing_t last_timing{};
     std::string err;

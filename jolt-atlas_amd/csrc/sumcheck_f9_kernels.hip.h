@@ -32,9 +32,48 @@ __device__ __forceinline__ void f9_block_reduce_store2(F9 acc0, F9 acc2, Fr* par
     }
 }
 
+// the same reduction mailed to the host as lazy 9 x 29-bit limbs (value < 2.1p, still carrying the 2^-5 of
+// the 9-step reduction): the host sums the records limb-wise and reduces once (channel.hpp)
+__device__ __forceinline__ void f9_block_reduce_mail2(F9 acc0, F9 acc2, const RoundIo& io) {
+    using P9 = Fr9Params;
+    __shared__ F9 red9m[SC_THREADS / 64][2];
+    acc0 = f9_wave_sum<P9>(acc0);
+    acc2 = f9_wave_sum<P9>(acc2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red9m[wave][0] = acc0; red9m[wave][1] = acc2; }
+    __shared__ uint32_t stage9m[18];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        F9 s = f9_zero();
+        if (threadIdx.x < 2) {
+            s = red9m[0][threadIdx.x];
+            for (int w = 1; w < SC_THREADS / 64; w++) s = f9_norm_red<P9>(f9_add(s, red9m[w][threadIdx.x]));
+        }
+        ch_mail_wave_f9(io, blockIdx.x * ch_stride(2), 2, s, stage9m);
+    }
+}
+
+struct DevIoF9 {
+    const ScCtx* cx;
+    Fr* partials;
+    __device__ __forceinline__ bool challenge(Fr& r) const { r = fe_load(&cx->r); return true; }
+    __device__ __forceinline__ void emit2(const F9& a0, const F9& a2) const { f9_block_reduce_store2(a0, a2, partials); }
+};
+struct ChanIoF9 {
+    RoundIo io;
+    __device__ __forceinline__ bool challenge(Fr& r) const {
+        uint64_t lo, hi;
+        if (!ch_wait_r(io, lo, hi)) return false;
+        r = challenge_to_mont(lo, hi, 0);
+        return true;
+    }
+    __device__ __forceinline__ void emit2(const F9& a0, const F9& a2) const { f9_block_reduce_mail2(a0, a2, io); }
+};
+
 // round-0 message over untouched (canonical) operands
+template <class IO>
 __global__ __launch_bounds__(SC_THREADS) void k_dot_eval2_f9(const Fr* __restrict__ L, const Fr* __restrict__ R,
-                                                             size_t half, Fr* partials) {
+                                                             size_t half, IO out) {
     using P9 = Fr9Params;
     F9 acc0 = f9_zero(), acc2 = f9_zero();
     for (size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x; i < half; i += (size_t)gridDim.x * SC_THREADS) {
@@ -44,25 +83,26 @@ __global__ __launch_bounds__(SC_THREADS) void k_dot_eval2_f9(const Fr* __restric
         acc0 = f9_norm_red<P9>(f9_add(acc0, f9_mul<P9>(l0, r0)));
         acc2 = f9_norm_red<P9>(f9_add(acc2, f9_mul<P9>(l2, r2)));
     }
-    f9_block_reduce_store2(acc0, acc2, partials);
+    out.emit2(acc0, acc2);
 }
 
 // fused ingest_challenge(r_j) + compute_message(j+1); operands bound in place (thread i owns
 // i, i+q, i+2q, i+3q).  The next iteration's eight coefficients are requested before the
 // current ones are consumed, so HBM latency sits under ~700 multiply-adds.
-template <bool CANON_OUT>
-__global__ __launch_bounds__(SC_THREADS) void k_dot_bind_eval2_f9(Fr* L, Fr* R, size_t q, const ScCtx* cx,
-                                                                  Fr* partials) {
+template <bool CANON_OUT, class IO>
+__global__ __launch_bounds__(SC_THREADS) void k_dot_bind_eval2_f9(Fr* L, Fr* R, size_t q, IO io) {
     using P9 = Fr9Params;
-    const F9 r32 = f9_shl5(f9_from_fe(fe_load(&cx->r)));     // 32 * r: limbs 0..3 stay zero
     F9 acc0 = f9_zero(), acc2 = f9_zero();
     size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * SC_THREADS;
     Fe x0, x1, x2, x3, y0, y1, y2, y3;
-    if (i < q) {
+    if (i < q) {          // requested before the challenge is waited for: the first tile's HBM latency hides under the wait
         x0 = fe_load(L + i); x1 = fe_load(L + i + q); x2 = fe_load(L + i + 2 * q); x3 = fe_load(L + i + 3 * q);
         y0 = fe_load(R + i); y1 = fe_load(R + i + q); y2 = fe_load(R + i + 2 * q); y3 = fe_load(R + i + 3 * q);
     }
+    Fr r_fe;
+    if (!io.challenge(r_fe)) return;
+    const F9 r32 = f9_shl5(f9_from_fe(r_fe));     // 32 * r: limbs 0..3 stay zero
     for (; i < q; i += stride) {
         const F9 a0 = f9_from_fe(x0), a1 = f9_from_fe(x1), a2 = f9_from_fe(x2), a3 = f9_from_fe(x3);
         const F9 b0 = f9_from_fe(y0), b1 = f9_from_fe(y1), b2 = f9_from_fe(y2), b3 = f9_from_fe(y3);
@@ -87,7 +127,132 @@ __global__ __launch_bounds__(SC_THREADS) void k_dot_bind_eval2_f9(Fr* L, Fr* R, 
         acc0 = f9_norm_red<P9>(f9_add(acc0, f9_mul<P9>(l0, r0)));
         acc2 = f9_norm_red<P9>(f9_add(acc2, f9_mul<P9>(l2, r2)));
     }
-    f9_block_reduce_store2(acc0, acc2, partials);
+    io.emit2(acc0, acc2);
+}
+
+// ---- degree-2 tail over the round channel on the lazy limbs ---------------------------------------
+// Same contract as k_dot_tail_ch<2> (EqSchedule::None, challenge mode 0): every remaining round of an
+// instance of <= 2^11 coefficients in one resident launch, transcript on the host.  Laid out for the
+// latency of ONE round, which is all that is left at this size: the work of coefficient index i is
+// split over a lane pair — lane 2i binds the two L pairs, lane 2i+1 the two R pairs (two sparse
+// multiplications each), they swap results through DPP, then lane 2i multiplies l0*r0 and lane 2i+1
+// l2*r2 — so a round is 2 sparse + 1 full multiplication deep instead of 4 + 2.  Sums stay lazy
+// (9 x 29 bits, value < 2.1p, scaled by 2^-5) all the way to the host, which reduces them once.
+__device__ __forceinline__ F9 f9_dpp_swap1(const F9& a) {       // value of lane ^ 1
+    F9 o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.l[i], 0xB1, 0xf, 0xf, true);
+    return o;
+}
+
+static __global__ __launch_bounds__(SC_TAIL_THREADS) void k_dot_tail2_f9(TailChArgs A, ScConsts K) {
+    using P9 = Fr9Params;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    Fr* sL = reinterpret_cast<Fr*>(smem_raw);
+    Fr* sR = sL + (1u << A.cap_log);
+    __shared__ F9 red9t[SC_TAIL_THREADS / 64][2];
+    __shared__ uint64_t s_ch[3];
+    __shared__ uint32_t stage9t[27];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = tid & 1;
+
+    uint32_t len = A.len;
+    for (uint32_t i = tid; i < len; i += SC_TAIL_THREADS) {
+        if (A.src_i32) {
+            sL[i] = fr_from_i32(reinterpret_cast<const int32_t*>(A.L)[i], K.k32);
+            sR[i] = fr_from_i32(reinterpret_cast<const int32_t*>(A.R)[i], K.k32);
+        } else {
+            sL[i] = fe_load(reinterpret_cast<const Fr*>(A.L) + i);
+            sR[i] = fe_load(reinterpret_cast<const Fr*>(A.R) + i);
+        }
+    }
+    __syncthreads();
+
+    Fr* const S = h ? sR : sL;
+    int pending = A.pending_bind;
+    uint32_t round = A.round0;
+    for (;;) {
+        F9 acc = f9_zero();
+        uint32_t n_lanes = 0;                  // lanes that hold a product this round
+        if (pending) {
+            const uint32_t prev = round - 1;
+            if (tid == 0) {
+                uint64_t l = 0, hh = 0;
+                const bool ok = ch_poll_slot(A.r_host + (size_t)prev * A.r_slot_chunks, A.tag_r0 + prev, A.abort_flag, l, hh);
+                s_ch[0] = l; s_ch[1] = hh; s_ch[2] = ok ? 1 : 0;
+            }
+            __syncthreads();
+            if (!s_ch[2]) return;
+            const F9 r32 = f9_shl5(f9_from_fe(challenge_to_mont(s_ch[0], s_ch[1], 0)));
+            if (len == 2) {                    // last bind: no message follows
+                if (tid < 2) {
+                    const F9 a = f9_from_fe(S[0]), b = f9_from_fe(S[1]);
+                    S[0] = f9_to_fe(f9_norm_red<P9>(f9_add(a, f9_mul<P9, 4>(f9_sub<P9>(b, a), r32))));
+                }
+                len = 1;
+                __syncthreads();
+            } else {
+                // ingest_challenge(r_{round-1}) fused with compute_message(round) (dot.rs:290-375)
+                const uint32_t q = len / 4;
+                n_lanes = 2 * q < SC_TAIL_THREADS ? 2 * q : SC_TAIL_THREADS;
+                for (uint32_t idx = tid; idx < 2 * q; idx += SC_TAIL_THREADS) {
+                    const uint32_t i = idx >> 1;
+                    const F9 s0 = f9_from_fe(S[i]), s1 = f9_from_fe(S[i + q]), s2 = f9_from_fe(S[i + 2 * q]), s3 = f9_from_fe(S[i + 3 * q]);
+                    const F9 v0 = f9_norm_red<P9>(f9_add(s0, f9_mul<P9, 4>(f9_sub<P9>(s2, s0), r32)));
+                    const F9 v1 = f9_norm_red<P9>(f9_add(s1, f9_mul<P9, 4>(f9_sub<P9>(s3, s1), r32)));
+                    S[i] = f9_to_fe(v0); S[i + q] = f9_to_fe(v1);
+                    const F9 w0 = f9_dpp_swap1(v0), w1 = f9_dpp_swap1(v1);       // the partner's side
+                    F9 x, y;
+                    if (h == 0) { x = v0; y = w0; }                                  // l0 * r0
+                    else { x = f9_norm(f9_add(w1, f9_sub<P9>(w1, w0))); y = f9_norm(f9_add(v1, f9_sub<P9>(v1, v0))); }   // l2 * r2
+                    acc = f9_norm_red<P9>(f9_add(acc, f9_mul<P9>(x, y)));
+                }
+                len /= 2;
+            }
+        } else if (round < A.n_rounds) {
+            // compute_message(round) over untouched operands (a fresh instance that fits the tail)
+            const uint32_t half = len / 2;
+            n_lanes = 2 * half < SC_TAIL_THREADS ? 2 * half : SC_TAIL_THREADS;
+            for (uint32_t idx = tid; idx < 2 * half; idx += SC_TAIL_THREADS) {
+                const uint32_t i = idx >> 1;
+                const F9 l0 = f9_from_fe(sL[i]), r0 = f9_from_fe(sR[i]);
+                F9 x = l0, y = r0;
+                if (h) {
+                    const F9 l1 = f9_from_fe(sL[i + half]), r1 = f9_from_fe(sR[i + half]);
+                    x = f9_norm(f9_add(l1, f9_sub<P9>(l1, l0))); y = f9_norm(f9_add(r1, f9_sub<P9>(r1, r0)));
+                }
+                acc = f9_norm_red<P9>(f9_add(acc, f9_mul<P9>(x, y)));
+            }
+        }
+        if (round == A.n_rounds) break;
+
+        // lanes of equal parity hold the same kind of product: butterfly over masks 2 .. 32
+        const uint32_t n_waves = (n_lanes + 63) / 64;
+        if (wave < n_waves) {
+#pragma unroll
+            for (int m = 32; m >= 2; m >>= 1) acc = f9_norm_red<P9>(f9_add(acc, f9_shfl_xor(acc, m)));
+        }
+        const RoundIo io{A.mail, nullptr, nullptr, 1u, A.abort_flag, A.tag_mail0 + round, 0u};
+        if (n_waves == 1) {
+            if (wave == 0) ch_mail_wave_f9(io, (round - A.round0) * ch_stride(2), 2, acc, stage9t);
+        } else {
+            if (wave < n_waves && lane < 2) red9t[wave][h] = acc;
+            __syncthreads();
+            if (wave == 0) {
+                F9 t = lane < 2 * n_waves ? red9t[lane >> 1][h] : f9_zero();
+#pragma unroll
+                for (int m = 16; m >= 2; m >>= 1) t = f9_norm_red<P9>(f9_add(t, f9_shfl_xor(t, m)));
+                ch_mail_wave_f9(io, (round - A.round0) * ch_stride(2), 2, t, stage9t);
+            }
+        }
+        pending = 1;
+        round += 1;
+    }
+    // final_claim()s cached by cache_openings (dot.rs:377-400): canonical residues
+    if (tid < 64) {
+        const RoundIo io{A.mail, nullptr, nullptr, 1u, A.abort_flag, A.tag_mail0 + A.n_rounds, 0u};
+        const Fr f = tid < 2 ? f9_canon<P9>(f9_from_fe(S[0])) : fr_one();
+        ch_mail_wave_fe(io, (A.n_rounds - A.round0) * ch_stride(2), 3, f, stage9t);
+    }
 }
 
 }  // namespace atlas

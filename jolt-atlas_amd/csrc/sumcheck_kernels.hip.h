@@ -16,6 +16,7 @@
 // thread -> wavefront (__shfl_xor) -> LDS -> one partial per workgroup; the `fs` workgroup
 // folds the partials and runs the transcript, leaving r_{j+1} in HBM for the next pass.
 #pragma once
+#include "channel.hip.h"
 #include "f9.hip.h"
 #include "transcript.hip.h"
 
@@ -177,10 +178,50 @@ __device__ __forceinline__ void block_reduce_store(Fr acc[DEG], Fr* partials) {
     }
 }
 
+// ---- where a pass gets its challenge from and where its partial sums go ------------------
+// DevIo: transcript on the device (k_fs_round / k_dot_tail): challenge in the control block, one
+// canonical partial per workgroup in HBM.  ChanIo: transcript on the host over the round channel
+// (channel.hip.h): challenge from the round's slot, partials mailed to pinned host memory.
+struct DevIo {
+    const ScCtx* cx;
+    Fr* partials;
+    __device__ __forceinline__ bool challenge(Fr& r) const { r = fe_load(&cx->r); return true; }
+    template <int DEG> __device__ __forceinline__ void emit(Fr acc[DEG]) const { block_reduce_store<DEG>(acc, partials); }
+};
+struct ChanIo {
+    RoundIo io;
+    int challenge_mode;
+    __device__ __forceinline__ bool challenge(Fr& r) const {
+        uint64_t lo, hi;
+        if (!ch_wait_r(io, lo, hi)) return false;
+        r = challenge_to_mont(lo, hi, challenge_mode);
+        return true;
+    }
+    template <int DEG> __device__ __forceinline__ void emit(Fr acc[DEG]) const {
+        __shared__ Fr red[SC_THREADS / 64][DEG];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < DEG; k++) {
+            Fr s = fr_wave_sum(acc[k]);
+            if (lane == 0) red[wave][k] = s;
+        }
+        __shared__ uint32_t stage[9 * DEG];
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            Fr s = fe_zero();
+            if (threadIdx.x < DEG) {
+                s = red[0][threadIdx.x];
+                for (int w = 1; w < SC_THREADS / 64; w++) s = fr_add(s, red[w][threadIdx.x]);
+            }
+            ch_mail_wave_fe(io, blockIdx.x * ch_stride(DEG), DEG, s, stage);
+        }
+    }
+};
+
 // ---- round-0 message (no bind): compute_message over the untouched operands -----------
-template <int DEG, class T>
+template <int DEG, class T, class IO>
 __global__ __launch_bounds__(SC_THREADS) void k_dot_eval(const T* __restrict__ L, const T* __restrict__ R,
-                                                         EqView eq, size_t half, Fr* partials,
+                                                         EqView eq, size_t half, IO out,
                                                          ScConsts K) {
     Fr acc[DEG];
 #pragma unroll
@@ -191,7 +232,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_dot_eval(const T* __restrict__ L
         Fr r0 = Src<T>::get(R, i, K), r1 = Src<T>::get(R, i + half, K);
         accumulate<DEG>(acc, l0, l1, r0, r1, eq, i);
     }
-    block_reduce_store<DEG>(acc, partials);
+    out.template emit<DEG>(acc);
 }
 
 // input claim of the instance, sum_h L(h) R(h) [EQ(h)] over the whole cube (what the
@@ -216,15 +257,16 @@ __global__ __launch_bounds__(SC_THREADS) void k_dot_claim(const T* __restrict__ 
 // are read from Lsrc/Rsrc and the bound Fr written to Ldst/Rdst (len/2 entries).
 // BIND_EQ: the EQ table has the same length/indexing as L,R (EqSchedule::Low, rounds >=
 // log_k) and is bound in the same pass.
-template <int DEG, class T, bool BIND_EQ>
+template <int DEG, class T, bool BIND_EQ, class IO>
 __global__ __launch_bounds__(SC_THREADS) void k_dot_bind_eval(const T* Lsrc, const T* Rsrc, Fr* Ldst,
                                                               Fr* Rdst, Fr* eq_rw, EqView eq, size_t q,
-                                                              const ScCtx* cx, Fr* partials,
-                                                              ScConsts K, int r_hi_only) {
+                                                              IO io, ScConsts K, int r_hi_only) {
+    const ScCtx* cx = nullptr;
     Fr acc[DEG];
 #pragma unroll
     for (int k = 0; k < DEG; k++) acc[k] = fe_zero();
-    const Fr r = fe_load(&cx->r);
+    Fr r;
+    if (!io.challenge(r)) return;
     Fr r_s64;
     if constexpr (sizeof(T) == 4) r_s64 = fr_mul(r, K.k64);   // Montgomery(r * 2^64) for small-scalar binds
     const bool hi = r_hi_only != 0;
@@ -263,7 +305,19 @@ __global__ __launch_bounds__(SC_THREADS) void k_dot_bind_eval(const T* Lsrc, con
             accumulate<DEG>(acc, l0, l1, r0, r1, eq, i);
         }
     }
-    block_reduce_store<DEG>(acc, partials);
+    io.template emit<DEG>(acc);
+}
+
+// the same bind with the challenge taken from the IO policy (EQ tables bound ahead of a fused pass)
+template <class IO>
+static __global__ __launch_bounds__(SC_THREADS) void k_bind_hi_io(Fr* z, size_t half, IO io, int r_hi_only) {
+    Fr r;
+    if (!io.challenge(r)) return;
+    for (size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x; i < half;
+         i += (size_t)gridDim.x * SC_THREADS) {
+        Fr a = fe_load(z + i), b = fe_load(z + i + half);
+        fe_store(z + i, bind_pair(a, b, r, r_hi_only != 0));
+    }
 }
 
 // plain in-place high-to-low bind of one array (EQ tables bound ahead of a fused pass,
@@ -567,6 +621,131 @@ static __global__ __launch_bounds__(SC_THREADS) void k_dot_tail(TailArgs A, ScCt
         fe_store(finals + 0, sL[0]);
         fe_store(finals + 1, sR[0]);
         fe_store(finals + 2, A.sched ? sE[0] : fr_one());
+    }
+}
+
+// ---- tail over the round channel: every remaining round of an instance with len <= 2^cap_log in ONE
+// resident launch, transcript on the host.  Per round the workgroup mails DEG sums (exact arithmetic,
+// canonical residues) and thread 0 polls the round's challenge slot: 2.8 us device -> host -> device
+// (tools/exp_channel.hip) instead of five BLAKE2b compressions on one wavefront.  1024 threads: every
+// coefficient pair of a 2^11 instance has its own lane.
+constexpr int SC_TAIL_THREADS = 1024;     // k_dot_tail2_f9 (sumcheck_f9_kernels.hip.h)
+constexpr int SC_TAIL_X_THREADS = 512;    // k_dot_tail_ch (exact 8 x 32 arithmetic: 256 VGPRs per lane, no spills)
+constexpr int SC_TAIL_CH_LOG = 11;        // EqSchedule::None: L, R of 2^11 Fr = 128 KB of the 160 KB LDS
+
+struct TailChArgs {
+    const void* L; const void* R; Fr* eq;
+    uint32_t len, eq_len;
+    int src_i32;
+    int sched; uint32_t a, b;
+    uint32_t round0, n_rounds;
+    int pending_bind;                 // the challenge of round0 - 1 is still to be applied
+    int challenge_mode;
+    uint32_t cap_log;                 // LDS arrays hold 2^cap_log Fr each
+    Chunk* mail;                      // round k's DEG records start at record (k - round0) * DEG; finals follow the last round
+    const Chunk* r_host;              // slot of round 0 (round k: r_host + k * r_slot_chunks)
+    uint32_t r_slot_chunks;
+    uint32_t* abort_flag;
+    uint32_t tag_mail0, tag_r0;       // tags of round 0's records / challenge; round k adds k; finals use tag_mail0 + n_rounds
+};
+
+template <int DEG>
+static __global__ __launch_bounds__(SC_TAIL_X_THREADS) void k_dot_tail_ch(TailChArgs A, ScConsts K) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    Fr* sL = reinterpret_cast<Fr*>(smem_raw);
+    Fr* sR = sL + (1u << A.cap_log);
+    Fr* sE = sR + (1u << A.cap_log);
+    __shared__ Fr red[SC_TAIL_X_THREADS / 64][DEG];
+    __shared__ uint64_t s_ch[3];
+    __shared__ uint32_t stage[27];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool hi_only = A.challenge_mode == 0;
+
+    uint32_t len = A.len, eq_len = A.eq_len;
+    for (uint32_t i = tid; i < len; i += SC_TAIL_X_THREADS) {
+        if (A.src_i32) {
+            sL[i] = fr_from_i32(reinterpret_cast<const int32_t*>(A.L)[i], K.k32);
+            sR[i] = fr_from_i32(reinterpret_cast<const int32_t*>(A.R)[i], K.k32);
+        } else {
+            sL[i] = fe_load(reinterpret_cast<const Fr*>(A.L) + i);
+            sR[i] = fe_load(reinterpret_cast<const Fr*>(A.R) + i);
+        }
+    }
+    for (uint32_t i = tid; i < eq_len; i += SC_TAIL_X_THREADS) sE[i] = fe_load(A.eq + i);
+    __syncthreads();
+
+    int pending = A.pending_bind;
+    uint32_t round = A.round0;
+    for (;;) {
+        if (pending) {
+            // ingest_challenge(r_{round-1}) (dot.rs:352-375)
+            const uint32_t prev = round - 1;
+            if (tid == 0) {
+                uint64_t l = 0, h = 0;
+                const bool ok = ch_poll_slot(A.r_host + (size_t)prev * A.r_slot_chunks, A.tag_r0 + prev, A.abort_flag, l, h);
+                s_ch[0] = l; s_ch[1] = h; s_ch[2] = ok ? 1 : 0;
+            }
+            __syncthreads();
+            if (!s_ch[2]) return;
+            const Fr r = challenge_to_mont(s_ch[0], s_ch[1], A.challenge_mode);
+            const uint32_t half = len / 2;
+            for (uint32_t i = tid; i < half; i += SC_TAIL_X_THREADS) {
+                sL[i] = bind_pair(sL[i], sL[i + half], r, hi_only);
+                sR[i] = bind_pair(sR[i], sR[i + half], r, hi_only);
+            }
+            const bool bind_eq = (A.sched == 1 && prev < A.a) || (A.sched == 2 && prev >= A.a);
+            if (bind_eq) {
+                const uint32_t eh = eq_len / 2;
+                for (uint32_t i = tid; i < eh; i += SC_TAIL_X_THREADS) sE[i] = bind_pair(sE[i], sE[i + eh], r, hi_only);
+                eq_len = eh;
+            }
+            len = half;
+            __syncthreads();
+        }
+        if (round == A.n_rounds) break;
+
+        // compute_message(round) (dot.rs:290-350)
+        const uint32_t half = len / 2;
+        EqView eq;
+        eq.p = sE; eq.mode = EQ_NONE; eq.shift = 0; eq.mask = 0; eq.half = 0;
+        if (A.sched == 1) {
+            if (round < A.a) { eq.mode = EQ_PAIR; eq.shift = A.b; eq.half = eq_len / 2; }
+            else { eq.mode = EQ_IDX; eq.mask = 0; }
+        } else if (A.sched == 2) {
+            if (round < A.a) { eq.mode = EQ_IDX; eq.mask = (1u << A.b) - 1; }
+            else { eq.mode = EQ_PAIR; eq.shift = 0; eq.half = eq_len / 2; }
+        }
+        const uint32_t n_waves = half <= 64 ? 1 : (half + 63) / 64 > SC_TAIL_X_THREADS / 64 ? SC_TAIL_X_THREADS / 64 : (half + 63) / 64;
+        if (wave < n_waves) {
+            Fr acc[DEG];
+#pragma unroll
+            for (int k = 0; k < DEG; k++) acc[k] = fe_zero();
+            for (uint32_t i = tid; i < half; i += SC_TAIL_X_THREADS)
+                accumulate<DEG>(acc, sL[i], sL[i + half], sR[i], sR[i + half], eq, i);
+#pragma unroll
+            for (int k = 0; k < DEG; k++) {
+                Fr s = fr_wave_sum(acc[k]);
+                if (lane == 0) red[wave][k] = s;
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            Fr s = fe_zero();
+            if (tid < DEG) {
+                s = red[0][tid];
+                for (uint32_t w = 1; w < n_waves; w++) s = fr_add(s, red[w][tid]);
+            }
+            const RoundIo io{A.mail, nullptr, nullptr, 1u, A.abort_flag, A.tag_mail0 + round, 0u};
+            ch_mail_wave_fe(io, (round - A.round0) * ch_stride(DEG), DEG, s, stage);
+        }
+        pending = 1;
+        round += 1;
+    }
+    // final_claim()s cached by cache_openings (dot.rs:377-400)
+    if (tid < 64) {
+        const RoundIo io{A.mail, nullptr, nullptr, 1u, A.abort_flag, A.tag_mail0 + A.n_rounds, 0u};
+        const Fr f = tid == 0 ? sL[0] : tid == 1 ? sR[0] : (A.sched ? sE[0] : fr_one());
+        ch_mail_wave_fe(io, (A.n_rounds - A.round0) * ch_stride(DEG), 3, f, stage);
     }
 }
 

@@ -17,14 +17,19 @@ def _oracle_run(orc, L, R, eq, sched, a, b, label=b"synthetic_sc"):
     return claim, proof, ch, fin, t.state_bytes(), t.n_rounds
 
 
-def _gpu_run(A, L, R, eq, sched, a, b, claim, label=b"synthetic_sc", i32=False):
+def _gpu_run(A, L, R, eq, sched, a, b, claim, label=b"synthetic_sc", i32=False, fs=None):
     n = len(L).bit_length() - 1
+    if fs is not None:
+        A.set_fs_mode(fs)
     mk = A.MultilinearPolynomial.from_i32 if i32 else A.MultilinearPolynomial.from_fr
     pl, pr = mk(L), mk(R)
     pe = A.MultilinearPolynomial.from_fr(eq) if eq is not None else None
     prover = A.EinsumDotProver(pl, pr, pe, sched, a, b)
     t = A.Blake2bTranscript(label)
-    proof, ch, fin = A.Sumcheck.prove(prover, claim[0], t, n)
+    try:
+        proof, ch, fin = A.Sumcheck.prove(prover, claim[0], t, n)
+    finally:
+        A.set_fs_mode(A.FS_HOST)
     prover.free()
     return proof, ch, fin, t.state, t.n_rounds
 
@@ -38,8 +43,9 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("fs", [0, 1], ids=["fs_host", "fs_device"])
 @pytest.mark.parametrize("n,sched,a,b", CASES)
-def test_dot_sumcheck_bit_exact(atlas, n, sched, a, b):
+def test_dot_sumcheck_bit_exact(atlas, n, sched, a, b, fs):
     from oracle import orc
     L = orc.random_fr(1 << n, 1000 + n)
     R = orc.random_fr(1 << n, 2000 + n)
@@ -48,7 +54,7 @@ def test_dot_sumcheck_bit_exact(atlas, n, sched, a, b):
         nb = a if sched == 1 else b
         eq = orc.eq_evals(orc.random_fr(nb, 3000 + n)) if nb else orc.from_ints([1])
     claim, proof_o, ch_o, fin_o, st_o, nr_o = _oracle_run(orc, L, R, eq, sched, a, b)
-    proof_g, ch_g, fin_g, st_g, nr_g = _gpu_run(atlas, L, R, eq, sched, a, b, claim)
+    proof_g, ch_g, fin_g, st_g, nr_g = _gpu_run(atlas, L, R, eq, sched, a, b, claim, fs=fs)
     assert ch_g == ch_o
     assert np.array_equal(proof_g, proof_o)
     assert np.array_equal(fin_g, fin_o)
@@ -56,8 +62,9 @@ def test_dot_sumcheck_bit_exact(atlas, n, sched, a, b):
     assert orc.serialize_proof(proof_g) == orc.serialize_proof(proof_o)
 
 
+@pytest.mark.parametrize("fs", [0, 1], ids=["fs_host", "fs_device"])
 @pytest.mark.parametrize("n", [3, 10, 12, 15])
-def test_dot_sumcheck_i32_operands(atlas, n):
+def test_dot_sumcheck_i32_operands(atlas, n, fs):
     """I32Scalars operands (|x| < 2^14, MODEL_SCALE activations): compact first round."""
     from oracle import orc
     rng = np.random.default_rng(n)
@@ -70,7 +77,7 @@ def test_dot_sumcheck_i32_operands(atlas, n):
     claim = orc.dot_claim(Lf, Rf)
     t = orc.new_transcript(b"synthetic_sc")
     proof_o, ch_o, fin_o = orc.sumcheck_dot_prove_i32(L, R, claim, t)
-    proof_g, ch_g, fin_g, st_g, nr_g = _gpu_run(atlas, L, R, None, 0, 0, 0, claim, i32=True)
+    proof_g, ch_g, fin_g, st_g, nr_g = _gpu_run(atlas, L, R, None, 0, 0, 0, claim, i32=True, fs=fs)
     assert ch_g == ch_o
     assert np.array_equal(proof_g, proof_o)
     assert np.array_equal(fin_g, fin_o)
