@@ -734,9 +734,8 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
     if (C.abort_dirty) { HIP_TRY(hipMemsetAsync(C.d_abort, 0, 4, g.stream)); C.abort_dirty = false; }
 
     // tags: records of round k = tag0 + k (k = n: the final claims), challenge of round k = tag0 + n + 1 + k
-    const uint32_t tag0 = C.next_tag; C.next_tag += (uint32_t)(2 * n + 2);
-    if (C.next_slot + n > Channel::RING) C.next_slot = 0;
-    const size_t slot0 = C.next_slot; C.next_slot += n;
+    const uint32_t tag0 = C.take_tags(2 * n + 2);
+    const size_t slot0 = C.take_slots(n);
     auto mtag = [&](size_t k) { return tag0 + (uint32_t)k; };
     auto rtag = [&](size_t k) { return tag0 + (uint32_t)(n + 1 + k); };
     struct Mail { atlas::Chunk* base; size_t blocks; int radix, shl; };
@@ -759,7 +758,7 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
         {
             const size_t half = len / 2;
             const int grid = use_f9 ? grid_f9(half) : grid_for(half);
-            atlas::Chunk* reg = C.region();
+            atlas::Chunk* reg = C.alloc((size_t)grid * ch_stride(DEG));
             const RoundIo io = C.io(reg, mtag(0), (size_t)-1, 0);
             EqView eq = eq_view_for_round(P, 0, eqp, eq_len);
             tm.begin(0, 2 * len * esz);
@@ -787,7 +786,7 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
             EqView eq = eq_view_for_round(P, j + 1, eqp, fuse_eq ? eq_len / 2 : eq_len);
             uint64_t bytes = 2 * len * (P->left->is_i32 ? sizeof(int32_t) : sizeof(Fr)) + 2 * (len / 2) * sizeof(Fr);
             if (fuse_eq) bytes += (eq_len + eq_len / 2) * sizeof(Fr);
-            atlas::Chunk* reg = C.region();
+            atlas::Chunk* reg = C.alloc((size_t)grid * ch_stride(DEG));
             if (waiters[j] < (size_t)grid) waiters[j] = (size_t)grid;
             const RoundIo io = C.io(reg, mtag(rounds_done), slot0 + j, rtag(j), waiters[j]);
             tm.begin(0, bytes);
@@ -827,7 +826,7 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
         }
     }
     // tail: all remaining rounds in one resident launch
-    atlas::Chunk* tail_reg = C.region();
+    atlas::Chunk* tail_reg = C.alloc((n + 2) * ch_stride(3));
     const size_t tail_round0 = rounds_done;
     {
         TailChArgs A;

@@ -91,6 +91,90 @@ H::Fr eval_with_challenge(const std::vector<H::Fr>& c, const H::Fr& r) {        
 
 }  // namespace
 
+
+// ---- library-driven proving over the round channel -------------------------------------------------------
+// Every launch of every round is enqueued before the first challenge exists (instance.hpp: enqueue); the host
+// then walks the rounds: collect the mailed sums, finish the round polynomial(s), run the transcript, publish the
+// challenge in the round's slot.  Used when every instance of the proof supports it and the transcript is on the
+// host (atlas_set_fs_mode); otherwise the host-stepped loops below run.
+namespace {
+
+struct Lane {                     // one instance inside a pipelined proof
+    atlas_instance* inst;
+    size_t rounds, offset;        // first global round it takes part in
+    std::vector<atlas_mail_ref> mails;
+    atlas_mail_ref fin;
+};
+
+struct Pipeline {
+    atlas_rt::Channel& C = g.chan;
+    std::vector<Lane> lanes;
+    size_t max_rounds = 0, slot0 = 0;
+    uint32_t tag0 = 0;
+    uint32_t rtag(size_t R) const { return tag0 + (uint32_t)R; }
+    uint32_t mtag(size_t R, size_t lane) const { return tag0 + (uint32_t)(max_rounds + 1 + R * lanes.size() + lane); }   // R = max_rounds: finals
+
+    void abort_from(size_t R) { for (size_t k = R; k < max_rounds; k++) C.publish(slot0 + k, rtag(k), 0, 0, true); }
+
+    // The launches run ahead of the transcript by LOOKAHEAD rounds: a launch call costs the host ~4 us, so the
+    // rounds are enqueued while the device works on earlier ones instead of all before the first collect.
+    static constexpr size_t LOOKAHEAD = 3;
+    size_t next_enqueue = 0;
+    int begin() {               // the caller holds g.mu
+        for (auto& L : lanes) { max_rounds = L.rounds > max_rounds ? L.rounds : max_rounds; }
+        for (auto& L : lanes) { L.offset = max_rounds - L.rounds; L.mails.resize(L.rounds); }
+        if (max_rounds == 0 || max_rounds > atlas_rt::Channel::RING / 2) return fail(ATLAS_EINVAL, "pipelined prove: round count");
+        if (C.abort_dirty) { HIP_TRY(hipMemsetAsync(C.d_abort, 0, 4, g.stream)); C.abort_dirty = false; }
+        tag0 = C.take_tags((max_rounds + 2) * (lanes.size() + 1));
+        slot0 = C.take_slots(max_rounds);
+        return advance(0);
+    }
+    // make sure the launches of global rounds < R + LOOKAHEAD (and the final binds after the last) are enqueued
+    int advance(size_t R) {
+        while (next_enqueue <= max_rounds && next_enqueue < R + LOOKAHEAD) {
+            const size_t Q = next_enqueue++;
+            for (size_t li = 0; li < lanes.size(); li++) {
+                Lane& L = lanes[li];
+                if (Q < L.offset) continue;
+                const size_t local = Q - L.offset;
+                const bool bind_prev = local > 0, wait = bind_prev || Q == max_rounds;
+                atlas::Chunk* area = C.alloc(256 * atlas::ch_stride(4));
+                const atlas::RoundIo io = C.io(area, mtag(Q, li), wait ? slot0 + Q - 1 : (size_t)-1, wait ? rtag(Q - 1) : 0, 256);
+                int rc = Q < max_rounds ? L.inst->enqueue(local, io, bind_prev, L.mails[local]) : L.inst->enqueue_finals(io, L.fin);
+                if (rc) { abort_from(0); (void)hipStreamSynchronize(g.stream); return rc; }
+            }
+        }
+        return ATLAS_OK;
+    }
+    // sums of lane li at its local round -> Fr
+    bool collect(const atlas_mail_ref& m, uint32_t tag, H::Fr* out) {
+        uint64_t acc[16][9];
+        if (m.n_vals > 16 || !C.collect(m.base, tag, m.blocks, m.n_vals, acc)) return false;
+        for (int k = 0; k < m.n_vals; k++) out[k] = atlas_rt::sum_to_fr(acc[k], m.radix, m.shl);
+        return true;
+    }
+    int collect_finals() {
+        for (size_t li = 0; li < lanes.size(); li++) {
+            Lane& L = lanes[li];
+            uint32_t raw[16][9];
+            if (L.fin.n_vals > 16 || !C.collect_raw(L.fin.base, mtag(max_rounds, li), (size_t)L.fin.n_vals, raw)) return fail(ATLAS_ENODEV, "round channel: no answer from the device");
+            H::Fr v[16];
+            for (int k = 0; k < L.fin.n_vals; k++) std::memcpy(&v[k], raw[k], 32);
+            int rc = L.inst->set_finals(v, (size_t)L.fin.n_vals);
+            if (rc) return rc;
+        }
+        return ATLAS_OK;
+    }
+};
+
+bool all_pipelined(const std::vector<atlas_instance*>& v) {
+    if (g.fs_mode != ATLAS_FS_HOST || getenv("ATLAS_NO_PIPELINE")) return false;
+    for (auto* i : v) if (!i->pipelined()) return false;
+    return !v.empty();
+}
+
+}  // namespace
+
 struct atlas_batched {
     std::vector<Instance> inst;
     ~atlas_batched() { for (auto& I : inst) if (I.owned) delete I.inst; }
@@ -177,6 +261,38 @@ int atlas_instance_prove(atlas_instance_t inst, const atlas_fr_t* input_claim, a
     H::tr_append_scalar(T, prev);
     const size_t n = inst->rounds();
     std::vector<H::Fr> c;
+    if (n && all_pipelined({inst})) {
+        std::lock_guard<std::mutex> lk(g.mu);
+        Pipeline P;
+        P.lanes.push_back(Lane{inst, n, 0, {}, {}});
+        int rc = P.begin();
+        if (rc) return rc;
+        for (size_t round = 0; round < n; round++) {
+            H::Fr sums[16];
+            inst->prepare(round);
+            if (!P.collect(P.lanes[0].mails[round], P.mtag(round, 0), sums)) { P.abort_from(round); (void)hipStreamSynchronize(g.stream); return fail(ATLAS_ENODEV, "round channel: no answer from the device"); }
+            rc = inst->finish(round, prev, sums, c);
+            if (rc) { P.abort_from(round); (void)hipStreamSynchronize(g.stream); return rc; }
+            std::vector<H::Fr> cc;
+            if (c.size() < 2) cc = c;
+            else { cc.push_back(c[0]); for (size_t k = 2; k < c.size(); k++) cc.push_back(c[k]); }
+            if (cc.size() > row_stride) { P.abort_from(round); (void)hipStreamSynchronize(g.stream); return fail(ATLAS_EINVAL, "instance_prove: row_stride below the degree"); }
+            H::tr_append_message(T, "UniPoly_begin");
+            for (auto& x : cc) H::tr_append_scalar(T, x);
+            H::tr_append_message(T, "UniPoly_end");
+            n_coeffs[round] = (uint32_t)cc.size();
+            std::memcpy(&compressed[round * row_stride], cc.data(), cc.size() * 32);
+            uint64_t lo, hi;
+            H::tr_challenge_u128(T, lo, hi);
+            challenges[round].lo = lo; challenges[round].hi = hi;
+            P.C.publish(P.slot0 + round, P.rtag(round), lo, hi);
+            prev = eval_with_challenge(c, H::challenge_to_fr(lo, hi, g.challenge_mode));
+            rc = inst->host_ingest(challenges[round], round);
+            if (!rc) rc = P.advance(round + 1);
+            if (rc) { P.abort_from(round + 1); (void)hipStreamSynchronize(g.stream); return rc; }
+        }
+        return P.collect_finals();
+    }
     const bool trace = getenv("ATLAS_TRACE") != nullptr;          // wall clock of the three parts of a round, summed
     double t_msg = 0, t_fs = 0, t_ing = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -231,6 +347,20 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
     std::vector<H::Fr> claim(n);
     for (size_t i = 0; i < n; i++) claim[i] = mul_pow2(b->inst[i].input_claim, max_rounds - b->inst[i].rounds);
 
+    Pipeline PL;
+    bool piped = false;
+    {
+        std::vector<atlas_instance*> v;
+        for (auto& I : b->inst) v.push_back(I.inst);
+        piped = all_pipelined(v);
+    }
+    std::unique_lock<std::mutex> pipe_lock(g.mu, std::defer_lock);
+    if (piped) {
+        pipe_lock.lock();
+        for (auto& I : b->inst) PL.lanes.push_back(Lane{I.inst, I.rounds, 0, {}, {}});
+        int rc = PL.begin();
+        if (rc) return rc;
+    }
     for (size_t round = 0; round < max_rounds; round++) {
         const size_t remaining = max_rounds - round;
         std::vector<std::vector<H::Fr>> polys(n);
@@ -239,6 +369,13 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
             if (remaining > I.rounds) {
                 // constant polynomial, from_coeff (a zero claim stays [0])
                 polys[i] = {mul_pow2(I.input_claim, remaining - I.rounds - 1)};
+            } else if (piped) {
+                const size_t local = round - (max_rounds - I.rounds);
+                H::Fr sums[16];
+                I.inst->prepare(local);
+                int rc = PL.collect(PL.lanes[i].mails[local], PL.mtag(round, i), sums) ? ATLAS_OK : fail(ATLAS_ENODEV, "round channel: no answer from the device");
+                if (!rc) rc = I.inst->finish(local, claim[i], sums, polys[i]);
+                if (rc) { PL.abort_from(round); (void)hipStreamSynchronize(g.stream); return rc; }
             } else {
                 int rc = I.inst->message(round - (max_rounds - I.rounds), claim[i], polys[i]);
                 if (rc) return rc;
@@ -257,7 +394,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         std::vector<H::Fr> cc;
         if (batched.size() < 2) cc = batched;
         else { cc.push_back(batched[0]); for (size_t k = 2; k < batched.size(); k++) cc.push_back(batched[k]); }
-        if (cc.size() > row_stride) return fail(ATLAS_EINVAL, "batched_prove: row_stride below the batched degree");
+        if (cc.size() > row_stride) { if (piped) { PL.abort_from(round); (void)hipStreamSynchronize(g.stream); } return fail(ATLAS_EINVAL, "batched_prove: row_stride below the batched degree"); }
         H::tr_append_message(T, "UniPoly_begin");
         for (auto& x : cc) H::tr_append_scalar(T, x);
         H::tr_append_message(T, "UniPoly_end");
@@ -266,17 +403,21 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         uint64_t lo, hi;
         H::tr_challenge_u128(T, lo, hi);                                              // challenge_scalar_optimized :119
         challenges[round].lo = lo; challenges[round].hi = hi;
+        if (piped) PL.C.publish(PL.slot0 + round, PL.rtag(round), lo, hi);
         const H::Fr r = H::challenge_to_fr(lo, hi, g.challenge_mode);
         for (size_t i = 0; i < n; i++) claim[i] = eval_with_challenge(polys[i], r);    // :123-126
         for (size_t i = 0; i < n; i++) {
             Instance& I = b->inst[i];
             if (remaining <= I.rounds) {
-                int rc = I.inst->ingest(challenges[round], round - (max_rounds - I.rounds));
-                if (rc) return rc;
+                int rc = piped ? I.inst->host_ingest(challenges[round], round - (max_rounds - I.rounds))
+                               : I.inst->ingest(challenges[round], round - (max_rounds - I.rounds));
+                if (rc) { if (piped) { PL.abort_from(round + 1); (void)hipStreamSynchronize(g.stream); } return rc; }
             }
         }
+        if (piped) { int rc = PL.advance(round + 1); if (rc) return rc; }
     }
     *max_rounds_out = max_rounds;
+    if (piped) return PL.collect_finals();
     return ATLAS_OK;
 }
 

@@ -108,9 +108,9 @@ __device__ __forceinline__ bool ch_wait_r(const RoundIo& io, uint64_t& lo, uint6
     __syncthreads();
     lo = s_ch[0]; hi = s_ch[1];
     const bool ok = s_ch[2] != 0;
-    if (wg == 0 && io.r_replicas > 1 && threadIdx.x < io.r_replicas) {       // fan out (an abort travels through abort_flag)
-        if (ok) {
-            Chunk* p = io.r_dev + (size_t)threadIdx.x * CH_REPLICA_CHUNKS;
+    if (wg == 0 && ok && gridDim.x * gridDim.y > 1) {       // fan out (an abort travels through abort_flag)
+        for (uint32_t t = threadIdx.x; t < io.r_replicas; t += blockDim.x) {
+            Chunk* p = io.r_dev + (size_t)t * CH_REPLICA_CHUNKS;
             ch_store_dev(p, ch_u32x4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, io.tag_r});
             ch_store_dev(p + 1, ch_u32x4{(uint32_t)(hi >> 32), 0u, 0u, io.tag_r});
         }

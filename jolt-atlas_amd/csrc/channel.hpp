@@ -15,8 +15,9 @@
 namespace atlas_rt {
 
 struct Channel {
-    static constexpr size_t REGIONS = 4;                    // mail regions, used round-robin by consecutive launches
-    static constexpr size_t REGION_CHUNKS = 2048 * 12;   // up to 2048 workgroups x ch_stride(3) chunks
+    static constexpr size_t MAIL_CHUNKS = (size_t)1 << 19;  // 8 MB of mail, handed out round-robin (alloc): a launch's
+                                                            // records are consumed before the allocator comes round again,
+                                                            // because later rounds cannot run until the host has read them
     static constexpr size_t RING = 128;                     // challenge slots (a sumcheck has at most 64 rounds)
     static constexpr size_t SLOT_CHUNKS = 4;                                                   // host slot: one line
     static constexpr size_t DEV_SLOT_CHUNKS = atlas::CH_MAX_REPLICAS * atlas::CH_REPLICA_CHUNKS;   // 256 HBM replicas of one line
@@ -25,16 +26,16 @@ struct Channel {
     atlas::Chunk* d_rslots = nullptr;   // HBM, DEV_SLOT_CHUNKS per slot
     uint32_t* d_abort = nullptr;        // HBM
     uint32_t next_tag = 1;
-    size_t next_region = 0, next_slot = 0;
+    size_t next_chunk = 0, next_slot = 0;
     bool abort_dirty = false;
 
     hipError_t init() {
-        hipError_t e = hipHostMalloc(&mail, REGIONS * REGION_CHUNKS * sizeof(atlas::Chunk), hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(&mail, MAIL_CHUNKS * sizeof(atlas::Chunk), hipHostMallocDefault);
         if (e == hipSuccess) e = hipHostMalloc(&rslots, RING * SLOT_CHUNKS * sizeof(atlas::Chunk), hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc(&d_rslots, RING * DEV_SLOT_CHUNKS * sizeof(atlas::Chunk));
         if (e == hipSuccess) e = hipMalloc(&d_abort, 64);
         if (e != hipSuccess) return e;
-        std::memset(mail, 0, REGIONS * REGION_CHUNKS * sizeof(atlas::Chunk));
+        std::memset(mail, 0, MAIL_CHUNKS * sizeof(atlas::Chunk));
         std::memset(rslots, 0, RING * SLOT_CHUNKS * sizeof(atlas::Chunk));
         e = hipMemset(d_rslots, 0, RING * DEV_SLOT_CHUNKS * sizeof(atlas::Chunk));
         if (e == hipSuccess) e = hipMemset(d_abort, 0, 64);
@@ -49,7 +50,17 @@ struct Channel {
     }
 
     uint32_t tag() { uint32_t t = next_tag++; if (next_tag == 0) next_tag = 1; return t; }
-    atlas::Chunk* region() { atlas::Chunk* p = mail + (next_region % REGIONS) * REGION_CHUNKS; next_region++; return p; }
+    // mail area for one launch (n chunks, 64-byte aligned)
+    atlas::Chunk* alloc(size_t n) {
+        n = (n + 3) & ~(size_t)3;
+        if (next_chunk + n > MAIL_CHUNKS) next_chunk = 0;
+        atlas::Chunk* p = mail + next_chunk;
+        next_chunk += n;
+        return p;
+    }
+    // n consecutive challenge slots
+    size_t take_slots(size_t n) { if (next_slot + n > RING) next_slot = 0; const size_t s = next_slot; next_slot += n; return s; }
+    uint32_t take_tags(size_t n) { const uint32_t t = next_tag; next_tag += (uint32_t)n; if (next_tag < t) { next_tag = 1 + (uint32_t)n; return 1; } return t; }
     size_t slot() { return next_slot++ % RING; }
 
     // kernel argument of a launch of `waiters` workgroups that mails `tag_mail` records into `mail_region` and

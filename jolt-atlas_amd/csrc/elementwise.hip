@@ -36,63 +36,86 @@ __global__ __launch_bounds__(RA_THREADS) void k_ew_from_i32(const int32_t* __res
         fe_store(out + i, fr_from_i64((int64_t)in[i]));
 }
 
-// partials[block][k], k < ew_outputs(OP): the block's share of sum_g E_out E_in f_k(g)
-template <int OP>
-__global__ __launch_bounds__(RA_THREADS) void k_ew_fold(const Fr* __restrict__ rows, size_t stride, SplitEqView E, size_t n_groups,
-                                                        EwConsts C, Fr* __restrict__ partials) {
-    constexpr int NQ = ew_outputs(OP);
-    Fr acc[NQ];
-#pragma unroll
-    for (int k = 0; k < NQ; k++) acc[k] = fe_zero();
-    for (size_t g = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; g < n_groups; g += (size_t)gridDim.x * RA_THREADS) {
-        const Fr a0 = fe_load(rows + 2 * g), a1 = fe_load(rows + 2 * g + 1);
-        Fr v[NQ];
-        if constexpr (OP == EW_ADD) v[0] = fr_add(a0, fe_load(rows + stride + 2 * g));
-        else if constexpr (OP == EW_SUB) v[0] = fr_sub(a0, fe_load(rows + stride + 2 * g));
+// ---- how a fold reads pair g of row k ---------------------------------------------------------------
+// EwDirect: the rows are bound already.  EwBind: the previous round's challenge is applied on the fly
+// (LowToHigh: new[j] = old[2j] + r (old[2j+1] - old[2j])) and the bound pair is written to the other half of
+// the ping-pong — ingest_challenge(round-1) fused into compute_message(round), one launch per round.
+// Every row is visited exactly once per g (pair or lo), so a bind pass leaves every row bound.
+struct EwDirect {
+    const Fr* rows; size_t stride;
+    __device__ __forceinline__ void pair(uint32_t k, size_t g, Fr& a0, Fr& a1) const {
+        a0 = fe_load(rows + (size_t)k * stride + 2 * g); a1 = fe_load(rows + (size_t)k * stride + 2 * g + 1);
+    }
+    __device__ __forceinline__ Fr lo(uint32_t k, size_t g) const { return fe_load(rows + (size_t)k * stride + 2 * g); }
+};
+struct EwBind {
+    const Fr* src; size_t sstride; Fr* dst; size_t dstride; Fr r; bool hi;
+    __device__ __forceinline__ void pair(uint32_t k, size_t g, Fr& a0, Fr& a1) const {
+        const Fr* s = src + (size_t)k * sstride + 4 * g;
+        a0 = bind_pair(fe_load(s), fe_load(s + 1), r, hi); a1 = bind_pair(fe_load(s + 2), fe_load(s + 3), r, hi);
+        Fr* d = dst + (size_t)k * dstride + 2 * g;
+        fe_store(d, a0); fe_store(d + 1, a1);
+    }
+    __device__ __forceinline__ Fr lo(uint32_t k, size_t g) const { Fr a0, a1; pair(k, g, a0, a1); return a0; }
+};
+
+// the terms f_k(g) of operator OP at pair index g
+template <int OP, class LD>
+__device__ __forceinline__ void ew_terms(const LD& ld, size_t g, const EwConsts& C, Fr* v) {
+    if constexpr (OP == EW_DOT) {                   // rows: (input_t, selector_t) pairs; values at X = 0 and X = 2
+        v[0] = fe_zero(); v[1] = fe_zero();
+        for (uint32_t tm = 0; tm < C.n_terms; tm++) {
+            Fr i0, i1, s0, s1;
+            ld.pair(2 * tm, g, i0, i1); ld.pair(2 * tm + 1, g, s0, s1);
+            v[0] = fr_add(v[0], fr_mul(i0, s0));
+            v[1] = fr_add(v[1], fr_mul(fr_add(i1, fr_sub(i1, i0)), fr_add(s1, fr_sub(s1, s0))));
+        }
+        return;
+    } else if constexpr (OP == EW_HAMMING_BOOL) {   // rows hw_d: sum_d gamma_d [hw0 (hw0 - 1), (hw1 - hw0)^2]
+        v[0] = fe_zero(); v[1] = fe_zero();
+        for (uint32_t d = 0; d < C.n_terms; d++) {
+            Fr h0, h1;
+            ld.pair(d, g, h0, h1);
+            const Fr a = fr_sub(h1, h0);
+            v[0] = fr_add(v[0], fr_mul(C.k[d], fr_mul(h0, fr_sub(h0, fr_one()))));
+            v[1] = fr_add(v[1], fr_mul(C.k[d], fr_mul(a, a)));
+        }
+        return;
+    } else {
+        Fr a0, a1;
+        ld.pair(0, g, a0, a1);
+        if constexpr (OP == EW_ADD) v[0] = fr_add(a0, ld.lo(1, g));
+        else if constexpr (OP == EW_SUB) v[0] = fr_sub(a0, ld.lo(1, g));
         else if constexpr (OP == EW_NEG) v[0] = fr_sub(fe_zero(), a0);
-        else if constexpr (OP == EW_TELEPORT_DIV)      // rows: input, quotient, remainder: tau q0 + r0 - inp0
-            v[0] = fr_sub(fr_add(fr_mul(C.k[0], fe_load(rows + stride + 2 * g)), fe_load(rows + 2 * stride + 2 * g)), a0);
-        else if constexpr (OP == EW_SQUARE) { const Fr d = fr_sub(a1, a0); v[0] = fr_mul(a0, a0); v[1] = fr_mul(d, d); }
+        else if constexpr (OP == EW_TELEPORT_DIV) {    // rows: input, quotient, remainder: tau q0 + r0 - inp0
+            const Fr q0 = ld.lo(1, g), r0 = ld.lo(2, g);
+            v[0] = fr_sub(fr_add(fr_mul(C.k[0], q0), r0), a0);
+        } else if constexpr (OP == EW_SQUARE) { const Fr d = fr_sub(a1, a0); v[0] = fr_mul(a0, a0); v[1] = fr_mul(d, d); }
         else if constexpr (OP == EW_MUL) {
-            const Fr b0 = fe_load(rows + stride + 2 * g), b1 = fe_load(rows + stride + 2 * g + 1);
+            Fr b0, b1;
+            ld.pair(1, g, b0, b1);
             v[0] = fr_mul(a0, b0); v[1] = fr_mul(fr_sub(a1, a0), fr_sub(b1, b0));
         } else if constexpr (OP == EW_IFF) {        // rows: mask, a, b.  c0 = b0 + m0 (a0 - b0);  e = m_inf (a_inf - b_inf)
-            const Fr x0 = fe_load(rows + stride + 2 * g), x1 = fe_load(rows + stride + 2 * g + 1);
-            const Fr y0 = fe_load(rows + 2 * stride + 2 * g), y1 = fe_load(rows + 2 * stride + 2 * g + 1);
+            Fr x0, x1, y0, y1;
+            ld.pair(1, g, x0, x1); ld.pair(2, g, y0, y1);
             v[0] = fr_add(y0, fr_mul(a0, fr_sub(x0, y0)));
             v[1] = fr_mul(fr_sub(a1, a0), fr_sub(fr_sub(x1, x0), fr_sub(y1, y0)));
-        } else if constexpr (OP == EW_DOT) {        // rows: (input_t, selector_t) pairs; values at X = 0 and X = 2
-            v[0] = fe_zero(); v[1] = fe_zero();
-            for (uint32_t tm = 0; tm < C.n_terms; tm++) {
-                const Fr* in = rows + (size_t)(2 * tm) * stride; const Fr* sel = in + stride;
-                const Fr i0 = fe_load(in + 2 * g), i1 = fe_load(in + 2 * g + 1), s0 = fe_load(sel + 2 * g), s1 = fe_load(sel + 2 * g + 1);
-                v[0] = fr_add(v[0], fr_mul(i0, s0));
-                v[1] = fr_add(v[1], fr_mul(fr_add(i1, fr_sub(i1, i0)), fr_add(s1, fr_sub(s1, s0))));
-            }
         } else if constexpr (OP == EW_GATHER) {     // rows: ra, dictionary, identity: ra (dict + gamma id) at X = 0 and 2
-            const Fr d0 = fe_load(rows + stride + 2 * g), d1 = fe_load(rows + stride + 2 * g + 1);
-            const Fr j0 = fe_load(rows + 2 * stride + 2 * g), j1 = fe_load(rows + 2 * stride + 2 * g + 1);
+            Fr d0, d1, j0, j1;
+            ld.pair(1, g, d0, d1); ld.pair(2, g, j0, j1);
             const Fr a2 = fr_add(a1, fr_sub(a1, a0)), d2 = fr_add(d1, fr_sub(d1, d0)), j2 = fr_add(j1, fr_sub(j1, j0));
             v[0] = fr_mul(a0, fr_add(d0, fr_mul(C.k[0], j0)));
             v[1] = fr_mul(a2, fr_add(d2, fr_mul(C.k[0], j2)));
-        } else if constexpr (OP == EW_HAMMING_BOOL) {   // rows hw_d: sum_d gamma_d [hw0 (hw0 - 1), (hw1 - hw0)^2]
-            v[0] = fe_zero(); v[1] = fe_zero();
-            for (uint32_t d = 0; d < C.n_terms; d++) {
-                const Fr h0 = fe_load(rows + (size_t)d * stride + 2 * g), h1 = fe_load(rows + (size_t)d * stride + 2 * g + 1);
-                const Fr a = fr_sub(h1, h0);
-                v[0] = fr_add(v[0], fr_mul(C.k[d], fr_mul(h0, fr_sub(h0, fr_one()))));
-                v[1] = fr_add(v[1], fr_mul(C.k[d], fr_mul(a, a)));
-            }
         } else if constexpr (OP == EW_DIV) {        // rows: left, right, q, R.  c0 = ro0 q0 + R0 - lo0;  e = ro_inf q_inf
-            const Fr r0 = fe_load(rows + stride + 2 * g), r1 = fe_load(rows + stride + 2 * g + 1);
-            const Fr q0 = fe_load(rows + 2 * stride + 2 * g), q1 = fe_load(rows + 2 * stride + 2 * g + 1);
-            v[0] = fr_sub(fr_add(fr_mul(r0, q0), fe_load(rows + 3 * stride + 2 * g)), a0);
+            Fr r0, r1, q0, q1;
+            ld.pair(1, g, r0, r1); ld.pair(2, g, q0, q1);
+            v[0] = fr_sub(fr_add(fr_mul(r0, q0), ld.lo(3, g)), a0);
             v[1] = fr_mul(fr_sub(r1, r0), fr_sub(q1, q0));
         } else if constexpr (OP == EW_RSQRT) {      // rows: input, quotient, output, div_rem, sqrt_rem
-            const Fr q0 = fe_load(rows + stride + 2 * g), q1 = fe_load(rows + stride + 2 * g + 1);
-            const Fr o0 = fe_load(rows + 2 * stride + 2 * g), o1 = fe_load(rows + 2 * stride + 2 * g + 1);
-            const Fr div0 = fr_sub(fr_add(fr_mul(a0, q0), fe_load(rows + 3 * stride + 2 * g)), C.k[0]);
-            const Fr sqrt0 = fr_sub(fr_add(fr_mul(o0, o0), fe_load(rows + 4 * stride + 2 * g)), q0);
+            Fr q0, q1, o0, o1;
+            ld.pair(1, g, q0, q1); ld.pair(2, g, o0, o1);
+            const Fr div0 = fr_sub(fr_add(fr_mul(a0, q0), ld.lo(3, g)), C.k[0]);
+            const Fr sqrt0 = fr_sub(fr_add(fr_mul(o0, o0), ld.lo(4, g)), q0);
             const Fr od = fr_sub(o1, o0);
             v[0] = fr_add(div0, fr_mul(C.k[1], sqrt0));
             v[1] = fr_add(fr_mul(fr_sub(a1, a0), fr_sub(q1, q0)), fr_mul(C.k[1], fr_mul(od, od)));
@@ -100,6 +123,17 @@ __global__ __launch_bounds__(RA_THREADS) void k_ew_fold(const Fr* __restrict__ r
             const Fr d = fr_sub(a1, a0), p2 = fr_add(a1, d);
             v[0] = fr_mul(fr_mul(a1, a1), a1); v[1] = fr_mul(fr_mul(p2, p2), p2); v[2] = fr_mul(fr_mul(d, d), d);
         }
+    }
+}
+
+template <int OP, class LD>
+__device__ __forceinline__ void ew_fold_body(const LD& ld, const SplitEqView& E, size_t n_groups, const EwConsts& C, Fr* acc) {
+    constexpr int NQ = ew_outputs(OP);
+#pragma unroll
+    for (int k = 0; k < NQ; k++) acc[k] = fe_zero();
+    for (size_t g = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; g < n_groups; g += (size_t)gridDim.x * RA_THREADS) {
+        Fr v[NQ];
+        ew_terms<OP>(ld, g, C, v);
         if constexpr (ew_has_eq(OP)) {
             const Fr w = gse_weight(E, g);
 #pragma unroll
@@ -109,7 +143,43 @@ __global__ __launch_bounds__(RA_THREADS) void k_ew_fold(const Fr* __restrict__ r
             for (int k = 0; k < NQ; k++) acc[k] = fr_add(acc[k], v[k]);
         }
     }
+}
+
+// partials[block][k], k < ew_outputs(OP): the block's share of sum_g E_out E_in f_k(g)
+template <int OP>
+__global__ __launch_bounds__(RA_THREADS) void k_ew_fold(const Fr* __restrict__ rows, size_t stride, SplitEqView E, size_t n_groups,
+                                                        EwConsts C, Fr* __restrict__ partials) {
+    constexpr int NQ = ew_outputs(OP);
+    Fr acc[NQ];
+    ew_fold_body<OP>(EwDirect{rows, stride}, E, n_groups, C, acc);
     block_reduce_store<NQ>(acc, partials);
+}
+
+// the same over the round channel: (bind_prev: wait for the previous round's challenge, bind every row into dst,)
+// fold the bound pairs, mail the workgroup's sums to the host
+template <int OP>
+__global__ __launch_bounds__(RA_THREADS) void k_ew_fold_ch(const Fr* src, size_t sstride, Fr* dst, size_t dstride, SplitEqView E, size_t n_groups,
+                                                           EwConsts C, ChanIo io, int bind_prev, int hi_only) {
+    constexpr int NQ = ew_outputs(OP);
+    Fr acc[NQ];
+    if (bind_prev) {
+        Fr r;
+        if (!io.challenge(r)) return;
+        ew_fold_body<OP>(EwBind{src, sstride, dst, dstride, r, hi_only != 0}, E, n_groups, C, acc);
+    } else {
+        ew_fold_body<OP>(EwDirect{src, sstride}, E, n_groups, C, acc);
+    }
+    io.template emit<NQ>(acc);
+}
+
+// the last bind (rows of two coefficients -> the final claims), mailed one value per record
+__global__ __launch_bounds__(64) void k_ew_final_ch(const Fr* src, size_t sstride, uint32_t n_rows, ChanIo io, int hi_only) {
+    __shared__ uint32_t stage[9 * RA_MAX_D];
+    Fr r;
+    if (!io.challenge(r)) return;
+    Fr v = fe_zero();
+    if (threadIdx.x < n_rows) v = bind_pair(fe_load(src + (size_t)threadIdx.x * sstride), fe_load(src + (size_t)threadIdx.x * sstride + 1), r, hi_only != 0);
+    ch_mail_wave_fe(io.io, 0, n_rows, v, stage);
 }
 
 struct Elementwise : atlas_instance {
@@ -147,7 +217,7 @@ struct Elementwise : atlas_instance {
             coeffs = H::finish_product_sum(sums, claim, eq.st);
         } else if (nq == 1) {
             coeffs.assign(3, H::zero());
-            H::gruen_deg2(eq.st.scalar, eq.st.w_cur(), s[0], claim, coeffs.data());
+            H::gruen_deg2(eq.st, s[0], claim, coeffs.data());
         } else {
             coeffs.assign(4, H::zero());
             H::gruen_deg3(eq.st, s[0], s[1], claim, coeffs.data());
@@ -165,8 +235,79 @@ struct Elementwise : atlas_instance {
     }
     int finals(std::vector<H::Fr>& out) override {
         if (round_next != n_vars) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
+        if (have_finals) { out = mailed_finals; return ATLAS_OK; }
         std::lock_guard<std::mutex> lk(g.mu);
         return rows.finals(out);
+    }
+
+    // ---- round-channel stepping: one fused launch per round (instance.hpp)
+    bool have_finals = false;
+    std::vector<H::Fr> mailed_finals;
+    bool pipelined() const override { return n_vars >= 1; }
+    // rows of round k live in buf[k & 1] with stride T >> k (RaRows::bind keeps rows compact)
+    int enqueue(size_t round, const atlas::RoundIo& io, bool bind_prev, atlas_mail_ref& mail) override {
+        if (round >= n_vars || (round > 0) != bind_prev) return fail(ATLAS_ESTATE, "elementwise: enqueue out of order");
+        const size_t T = (size_t)1 << n_vars;
+        const size_t len = T >> round, n_groups = len / 2;
+        size_t blocks = (n_groups + RA_THREADS - 1) / RA_THREADS; if (blocks > 256) blocks = 256;     // one mail record per workgroup
+        SplitEqView E{nullptr, nullptr, 0};
+        if (ew_has_eq(op)) { size_t ot, it; eq.st.tops_after(round, ot, it); E = eq.view_at(ot, it); }
+        const Fr* src = bind_prev ? rows.buf[(round - 1) & 1] : rows.buf[0];
+        const size_t sst = bind_prev ? (T >> (round - 1)) : T;
+        Fr* dst = rows.buf[round & 1];
+        const ChanIo cio{io, g.challenge_mode};
+        const int hi = g.challenge_mode == 0 ? 1 : 0;
+        switch (op) {
+#define EW_CASE(OP) case OP: k_ew_fold_ch<OP><<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(src, sst, dst, len, E, n_groups, consts, cio, bind_prev ? 1 : 0, hi); break;
+            EW_CASE(EW_ADD) EW_CASE(EW_SUB) EW_CASE(EW_NEG) EW_CASE(EW_SQUARE) EW_CASE(EW_IFF) EW_CASE(EW_MUL) EW_CASE(EW_CUBE) EW_CASE(EW_DIV) EW_CASE(EW_RSQRT) EW_CASE(EW_DOT) EW_CASE(EW_GATHER) EW_CASE(EW_HAMMING_BOOL) EW_CASE(EW_TELEPORT_DIV)
+#undef EW_CASE
+            default: return fail(ATLAS_EINVAL, "elementwise: unknown operator");
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(ATLAS_ENODEV, "elementwise: launch", e);
+        mail.base = io.mail; mail.blocks = blocks; mail.n_vals = ew_outputs(op); mail.radix = 32; mail.shl = 0;
+        return ATLAS_OK;
+    }
+    void prepare(size_t round) override { if (ew_has_eq(op) && round == round_next) eq.st.prepare_inverses(ew_outputs(op) == 3 /* cube: 1 - w */); }
+    int finish(size_t round, const H::Fr& claim, const H::Fr* s, std::vector<H::Fr>& coeffs) override {
+        if (round != round_next || round >= n_vars) return fail(ATLAS_ESTATE, "elementwise: round out of order");
+        const int nq = ew_outputs(op);
+        if (!ew_has_eq(op)) {
+            coeffs.assign(3, H::zero());
+            H::unipoly_from_evals_and_hint(claim, s, 2, coeffs.data());
+        } else if (op == EW_CUBE) {
+            std::vector<H::Fr> sums(3);
+            for (int k = 0; k < 3; k++) sums[k] = H::mul(s[k], eq.st.scalar);        // mles_product_sum.rs:131
+            coeffs = H::finish_product_sum(sums, claim, eq.st);
+        } else if (nq == 1) {
+            coeffs.assign(3, H::zero());
+            H::gruen_deg2(eq.st, s[0], claim, coeffs.data());
+        } else {
+            coeffs.assign(4, H::zero());
+            H::gruen_deg3(eq.st, s[0], s[1], claim, coeffs.data());
+        }
+        return ATLAS_OK;
+    }
+    int host_ingest(const atlas_u128_t& r, size_t round) override {
+        if (round != round_next || round >= n_vars) return fail(ATLAS_ESTATE, "elementwise: round out of order");
+        if (ew_has_eq(op)) eq.st.bind(H::challenge_to_fr(r.lo, r.hi, g.challenge_mode));
+        rows.cur = (int)((round + 1) & 1); rows.len = ((size_t)1 << n_vars) >> (round + 1); rows.stride[rows.cur] = rows.len;
+        round_next++;
+        return ATLAS_OK;
+    }
+    int enqueue_finals(const atlas::RoundIo& io, atlas_mail_ref& mail) override {
+        const size_t T = (size_t)1 << n_vars;
+        const Fr* src = rows.buf[(n_vars - 1) & 1];
+        k_ew_final_ch<<<1, 64, 0, g.stream>>>(src, n_vars == 1 ? T : (T >> (n_vars - 1)), (uint32_t)rows.d, ChanIo{io, g.challenge_mode}, g.challenge_mode == 0 ? 1 : 0);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(ATLAS_ENODEV, "elementwise: launch", e);
+        mail.base = io.mail; mail.blocks = 1; mail.n_vals = (int)rows.d; mail.radix = 32; mail.shl = 0;
+        return ATLAS_OK;
+    }
+    int set_finals(const H::Fr* vals, size_t n) override {
+        if (n != rows.d) return fail(ATLAS_EINVAL, "elementwise: final claims");
+        mailed_finals.assign(vals, vals + n); have_finals = true;
+        return ATLAS_OK;
     }
 };
 

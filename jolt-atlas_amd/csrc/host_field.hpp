@@ -114,7 +114,7 @@ inline void halve_mod_p(uint64_t x[4]) {            // x / 2 mod p for x < p
 }
 }  // namespace detail
 
-inline Fr inv(const Fr& a) {
+inline Fr inv_binary_eea(const Fr& a) {
     using namespace detail;
     if (is_zero4(a.l)) return zero();
     uint64_t u[4], v[4], x1[4] = {1, 0, 0, 0}, x2[4] = {0, 0, 0, 0};
@@ -126,6 +126,133 @@ inline Fr inv(const Fr& a) {
         else { sub4(v, u); if (geq4(x2, x1)) sub4(x2, x1); else { add4(x2, FR_P); sub4(x2, x1); } }
     }
     Fr t; std::memcpy(t.l, is_one4(u) ? x1 : x2, 32);
+    static const Fr R3 = mul(Fr{{FR_R2[0], FR_R2[1], FR_R2[2], FR_R2[3]}}, Fr{{FR_R2[0], FR_R2[1], FR_R2[2], FR_R2[3]}});
+    return mul(t, R3);
+}
+
+
+// The same inverse by Bernstein-Yang divsteps in batches of 62 (the layout of libsecp256k1's modinv64, variable
+// time): the decisions of 62 steps need only the low words of f and g, so a batch is a 64-bit loop followed by one
+// 2x2 matrix applied to the 256-bit values.  ~1.3 us against 8 us for the bit-at-a-time loop above — the host
+// takes one inversion per sumcheck round for Gruen's division (split_eq_poly.rs:410-413), which made the
+// transcript thread the slowest stage of a pipelined round.
+namespace detail {
+struct S62 { int64_t v[5]; };
+struct T2x2 { int64_t u, v, q, r; };
+typedef __int128 i128;
+constexpr uint64_t M62 = ~(uint64_t)0 >> 2;
+inline S62 to_s62(const uint64_t a[4]) {
+    S62 o;
+    o.v[0] = (int64_t)(a[0] & M62);
+    o.v[1] = (int64_t)(((a[0] >> 62) | (a[1] << 2)) & M62);
+    o.v[2] = (int64_t)(((a[1] >> 60) | (a[2] << 4)) & M62);
+    o.v[3] = (int64_t)(((a[2] >> 58) | (a[3] << 6)) & M62);
+    o.v[4] = (int64_t)(a[3] >> 56);
+    return o;
+}
+inline int64_t divsteps_62_var(int64_t eta, uint64_t f0, uint64_t g0, T2x2& t) {
+    uint64_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0, m, w;
+    int i = 62, limit, zeros;
+    for (;;) {
+        zeros = __builtin_ctzll(g | (~(uint64_t)0 << i));
+        g >>= zeros; u <<= zeros; v <<= zeros; eta -= zeros; i -= zeros;
+        if (i == 0) break;
+        if (eta < 0) {
+            uint64_t tmp;
+            eta = -eta;
+            tmp = f; f = g; g = (uint64_t)0 - tmp;
+            tmp = u; u = q; q = (uint64_t)0 - tmp;
+            tmp = v; v = r; r = (uint64_t)0 - tmp;
+            limit = ((int)eta + 1) > i ? i : ((int)eta + 1);
+            m = (~(uint64_t)0 >> (64 - limit)) & 63u;
+            w = (f * g * (f * f - 2)) & m;
+        } else {
+            limit = ((int)eta + 1) > i ? i : ((int)eta + 1);
+            m = (~(uint64_t)0 >> (64 - limit)) & 15u;
+            w = f + (((f + 1) & 4) << 1);
+            w = ((uint64_t)0 - w) * g & m;
+        }
+        g += f * w; q += u * w; r += v * w;
+    }
+    t.u = (int64_t)u; t.v = (int64_t)v; t.q = (int64_t)q; t.r = (int64_t)r;
+    return eta;
+}
+inline void update_de_62(S62& d, S62& e, const T2x2& t, const S62& mod, uint64_t mod_inv62) {
+    const int64_t u = t.u, v = t.v, q = t.q, r = t.r;
+    const int64_t sd = d.v[4] >> 63, se = e.v[4] >> 63;
+    int64_t md = (u & sd) + (v & se), me = (q & sd) + (r & se);
+    i128 cd = (i128)u * d.v[0] + (i128)v * e.v[0], ce = (i128)q * d.v[0] + (i128)r * e.v[0];
+    md -= (int64_t)((mod_inv62 * (uint64_t)cd + (uint64_t)md) & M62);
+    me -= (int64_t)((mod_inv62 * (uint64_t)ce + (uint64_t)me) & M62);
+    cd += (i128)mod.v[0] * md; ce += (i128)mod.v[0] * me;
+    cd >>= 62; ce >>= 62;
+    for (int k = 1; k < 5; k++) {
+        cd += (i128)u * d.v[k] + (i128)v * e.v[k] + (i128)mod.v[k] * md;
+        ce += (i128)q * d.v[k] + (i128)r * e.v[k] + (i128)mod.v[k] * me;
+        if (k < 4) { d.v[k - 1] = (int64_t)((uint64_t)cd & M62); cd >>= 62; e.v[k - 1] = (int64_t)((uint64_t)ce & M62); ce >>= 62; }
+        else { d.v[3] = (int64_t)((uint64_t)cd & M62); cd >>= 62; e.v[3] = (int64_t)((uint64_t)ce & M62); ce >>= 62; }
+    }
+    d.v[4] = (int64_t)cd; e.v[4] = (int64_t)ce;
+}
+inline void update_fg_62_var(int len, S62& f, S62& g, const T2x2& t) {
+    const int64_t u = t.u, v = t.v, q = t.q, r = t.r;
+    i128 cf = (i128)u * f.v[0] + (i128)v * g.v[0], cg = (i128)q * f.v[0] + (i128)r * g.v[0];
+    cf >>= 62; cg >>= 62;
+    for (int i = 1; i < len; i++) {
+        cf += (i128)u * f.v[i] + (i128)v * g.v[i]; cg += (i128)q * f.v[i] + (i128)r * g.v[i];
+        f.v[i - 1] = (int64_t)((uint64_t)cf & M62); cf >>= 62;
+        g.v[i - 1] = (int64_t)((uint64_t)cg & M62); cg >>= 62;
+    }
+    f.v[len - 1] = (int64_t)cf; g.v[len - 1] = (int64_t)cg;
+}
+}  // namespace detail
+
+inline Fr inv(const Fr& a) {
+    using namespace detail;
+    if (is_zero4(a.l)) return zero();
+    static const S62 MOD = to_s62(FR_P);
+    static const uint64_t MOD_INV62 = [] { uint64_t x = FR_P[0]; for (int i = 0; i < 6; i++) x *= 2 - FR_P[0] * x; return x & M62; }();
+    S62 d{{0, 0, 0, 0, 0}}, e{{1, 0, 0, 0, 0}}, f = MOD, g = to_s62(a.l);
+    int len = 5;
+    int64_t eta = -1;
+    for (int it = 0; it < 16; it++) {          // 12 batches suffice for 256 bits (741 divsteps); the bound is a guard
+        T2x2 t;
+        eta = divsteps_62_var(eta, (uint64_t)f.v[0], (uint64_t)g.v[0], t);
+        update_de_62(d, e, t, MOD, MOD_INV62);
+        update_fg_62_var(len, f, g, t);
+        if (g.v[0] == 0) {
+            int64_t c = 0;
+            for (int j = 1; j < len; j++) c |= g.v[j];
+            if (c == 0) break;
+        }
+        const int64_t fn = f.v[len - 1], gn = g.v[len - 1];
+        int64_t c = ((int64_t)len - 2) >> 63;
+        c |= fn ^ (fn >> 63); c |= gn ^ (gn >> 63);
+        if (c == 0) { f.v[len - 2] |= (int64_t)((uint64_t)fn << 62); g.v[len - 2] |= (int64_t)((uint64_t)gn << 62); --len; }
+    }
+    // f = +-1 and d x = f (mod p) with d in (-2p, p): t = f d mod p.  Signed 62-bit limbs -> two's complement 320 bits
+    uint64_t w[5];
+    {
+        uint64_t lim[5];
+        for (int k = 0; k < 5; k++) lim[k] = (uint64_t)d.v[k];
+        w[0] = (lim[0] & M62) | (lim[1] << 62);
+        w[1] = ((lim[1] & M62) >> 2) | (lim[2] << 60);
+        w[2] = ((lim[2] & M62) >> 4) | (lim[3] << 58);
+        w[3] = ((lim[3] & M62) >> 6) | (lim[4] << 56);
+        w[4] = (uint64_t)(d.v[4] >> 8);
+    }
+    auto add_p = [&] { u128 c = 0; for (int k = 0; k < 5; k++) { c += (u128)w[k] + (k < 4 ? FR_P[k] : 0); w[k] = (uint64_t)c; c >>= 64; } };
+    while ((int64_t)w[4] < 0) add_p();
+    uint64_t t4[4] = {w[0], w[1], w[2], w[3]};
+    while (w[4] != 0 || geq_p(t4)) {           // not reached for d < p; kept as a guard
+        u128 br = 0;
+        for (int k = 0; k < 5; k++) { u128 dd = (u128)w[k] - (k < 4 ? FR_P[k] : 0) - br; w[k] = (uint64_t)dd; br = (dd >> 64) & 1; }
+        t4[0] = w[0]; t4[1] = w[1]; t4[2] = w[2]; t4[3] = w[3];
+    }
+    Fr t{{t4[0], t4[1], t4[2], t4[3]}};
+    bool f_neg = false;                                    // f = -1: the sign sits in its top non-zero limb
+    for (int k = len - 1; k >= 0; k--) if (f.v[k] != 0) { f_neg = f.v[k] < 0; break; }
+    if (f_neg) t = sub(zero(), t);
     static const Fr R3 = mul(Fr{{FR_R2[0], FR_R2[1], FR_R2[2], FR_R2[3]}}, Fr{{FR_R2[0], FR_R2[1], FR_R2[2], FR_R2[3]}});
     return mul(t, R3);
 }

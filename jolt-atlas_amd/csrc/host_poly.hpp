@@ -106,7 +106,30 @@ struct GseState {
         current_index -= 1;
         if (n / 2 < current_index && in_top > 0) in_top--;
         else if (0 < current_index && out_top > 0) out_top--;
+        have_inv_eq1 = have_inv_eq0w = false;
     }
+    // table tops after k binds (a function of k only: the launches of every round can be enqueued up front)
+    void tops_after(size_t k, size_t& ot, size_t& it) const {
+        ot = this->k_out; it = this->k_in;
+        size_t ci = n;
+        for (size_t j = 0; j < k; j++) {
+            ci -= 1;
+            if (n / 2 < ci && it > 0) it--;
+            else if (0 < ci && ot > 0) ot--;
+        }
+    }
+    // Gruen's division (split_eq_poly.rs:410-413) needs 1 / (scalar w_cur) [and the product-sum finish 1 / (1 - w_cur)];
+    // the operand is known as soon as the previous challenge is: computing it before the round's sums arrive takes the
+    // 8 us inversion off the critical path
+    mutable Fr inv_eq1, inv_eq0w;
+    mutable bool have_inv_eq1 = false, have_inv_eq0w = false;
+    void prepare_inverses(bool one_minus_w) const {
+        if (current_index == 0) return;
+        if (!have_inv_eq1) { inv_eq1 = inv(mul(scalar, w_cur())); have_inv_eq1 = true; }
+        if (one_minus_w && !have_inv_eq0w) { inv_eq0w = inv(sub(one(), w_cur())); have_inv_eq0w = true; }
+    }
+    const Fr& get_inv_eq1() const { if (!have_inv_eq1) { inv_eq1 = inv(mul(scalar, w_cur())); have_inv_eq1 = true; } return inv_eq1; }
+    const Fr& get_inv_eq0w() const { if (!have_inv_eq0w) { inv_eq0w = inv(sub(one(), w_cur())); have_inv_eq0w = true; } return inv_eq0w; }
 };
 
 // 4 coefficients (fixed length, UniPoly::from_evals of 4 points)
@@ -114,7 +137,7 @@ inline void gruen_deg3(const GseState& S, const Fr& q0, const Fr& qinf, const Fr
     const Fr eq1 = mul(S.scalar, S.w_cur()), eq0 = sub(S.scalar, eq1), eqm = sub(eq1, eq0);
     const Fr eq2 = add(eq1, eqm), eq3 = add(eq2, eqm);
     const Fr c0 = mul(eq0, q0), c1 = sub(claim, c0);
-    const Fr q1 = mul(c1, inv(eq1));
+    const Fr q1 = mul(c1, S.get_inv_eq1());
     const Fr e2 = add(qinf, qinf);
     const Fr q2 = add(sub(add(q1, q1), q0), e2);
     const Fr q3 = add(add(sub(add(q2, q1), q0), e2), e2);
@@ -128,7 +151,7 @@ inline std::vector<Fr> finish_product_sum(const std::vector<Fr>& sum_evals, cons
     const Fr r = S.w_cur();
     const Fr eq0 = sub(one(), r);
     Fr e0 = sub(claim, mul(r, sum_evals[0]));
-    if (d > 1) e0 = mul(e0, inv(eq0));
+    if (d > 1) e0 = mul(e0, S.get_inv_eq0w());
     std::vector<Fr> toom(d + 1);
     toom[0] = e0;
     for (size_t k = 0; k < d; k++) toom[k + 1] = sum_evals[k];
@@ -160,6 +183,16 @@ inline std::vector<std::vector<Fr>> eq_cached(const Fr* w, size_t k) {
 
 // EqPolynomial::evals, big-endian index (eq_poly.rs:77-101)
 inline std::vector<Fr> eq_evals(const Fr* r, size_t n) { return eq_cached(r, n)[n]; }
+
+// gruen_poly_deg_2 over a LowToHigh state (cached inverse)
+inline void gruen_deg2(const GseState& S, const Fr& q0, const Fr& claim, Fr coeffs[3]) {
+    const Fr eq1 = mul(S.scalar, S.w_cur()), eq0 = sub(S.scalar, eq1), eqm = sub(eq1, eq0), eq2 = add(eq1, eqm);
+    const Fr c0 = mul(eq0, q0), c1 = sub(claim, c0);
+    const Fr l1 = mul(c1, S.get_inv_eq1());
+    const Fr l2 = sub(add(l1, l1), q0);
+    const Fr ev[2] = {c0, mul(eq2, l2)};
+    unipoly_from_evals_and_hint(add(c0, c1), ev, 2, coeffs);
+}
 
 }  // namespace atlas_host
 

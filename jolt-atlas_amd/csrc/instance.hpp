@@ -4,7 +4,16 @@
 #include <vector>
 
 #include "../../include/atlas_hip.h"
+#include "channel.hpp"
 #include "host_field.hpp"
+
+// where the host finds the sums a pipelined round mailed (channel.hpp: Channel::collect)
+struct atlas_mail_ref {
+    atlas::Chunk* base = nullptr;
+    size_t blocks = 0;          // workgroups that mail a record
+    int n_vals = 0;             // values per workgroup
+    int radix = 32, shl = 0;    // word radix / scaling of the records (sum_to_fr)
+};
 
 struct atlas_instance {
     virtual ~atlas_instance() {}
@@ -15,4 +24,23 @@ struct atlas_instance {
     virtual int ingest(const atlas_u128_t& r, size_t round) = 0;
     // the final_claim()s cache_openings reads
     virtual int finals(std::vector<atlas_host::Fr>& out) = 0;
+
+    // ---- round-channel stepping (batched.hip): the library-driven provers enqueue the launches of EVERY round
+    // before the first challenge exists; a launch takes the challenge it binds from the round's slot and mails
+    // its sums to the host, which finishes the round polynomial and runs the transcript (channel.hip.h).
+    // Nothing an enqueue reads on the host may depend on a challenge.
+    virtual bool pipelined() const { return false; }
+    // launches of ingest_challenge(round - 1) [bind_prev: challenge from io's slot] + compute_message(round);
+    // io.mail / io.tag_mail name where and how the sums are mailed
+    virtual int enqueue(size_t /*round*/, const atlas::RoundIo& /*io*/, bool /*bind_prev*/, atlas_mail_ref& /*mail*/) { return ATLAS_ESTATE; }
+    // mailed sums (reduced by the driver) -> coefficients of the round polynomial; host arithmetic only
+    virtual int finish(size_t /*round*/, const atlas_host::Fr& /*claim*/, const atlas_host::Fr* /*sums*/, std::vector<atlas_host::Fr>& /*coeffs*/) { return ATLAS_ESTATE; }
+    // host half of ingest_challenge(r, round)
+    virtual int host_ingest(const atlas_u128_t& /*r*/, size_t /*round*/) { return ATLAS_ESTATE; }
+    // after the last round: bind the last challenge (from io's slot) and mail the final claims, one value per record
+    virtual int enqueue_finals(const atlas::RoundIo& /*io*/, atlas_mail_ref& /*mail*/) { return ATLAS_ESTATE; }
+    // the driver hands the mailed final claims back (canonical Montgomery residues)
+    virtual int set_finals(const atlas_host::Fr* /*vals*/, size_t /*n*/) { return ATLAS_ESTATE; }
+    // host work that does not need the sums of `round` (inversions, ...): called while the device computes them
+    virtual void prepare(size_t /*round*/) {}
 };

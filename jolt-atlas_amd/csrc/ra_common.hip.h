@@ -110,6 +110,13 @@ struct GseDev {
         E.in_bits = (uint32_t)st.in_top;
         return E;
     }
+    SplitEqView view_at(size_t out_top, size_t in_top) const {
+        SplitEqView E;
+        E.e_out = d_eout + (((size_t)1 << out_top) - 1);
+        E.e_in = d_ein + (((size_t)1 << in_top) - 1);
+        E.in_bits = (uint32_t)in_top;
+        return E;
+    }
     void release() { if (d_w) hipFree(d_w); if (d_eout) hipFree(d_eout); if (d_ein) hipFree(d_ein); d_w = d_eout = d_ein = nullptr; }
 };
 

@@ -20,14 +20,19 @@ def _operands(orc, op, n, seed, as_i32):
     return None, full
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode,pipe", [(0, True), (1, True), (0, False)], ids=["m0-pipelined", "m1-pipelined", "m0-hoststepped"])
 @pytest.mark.parametrize("op", sorted(_EW))
-@pytest.mark.parametrize("n_vars,as_i32", [(1, True), (4, False), (9, True), (14, False), (15, True)])
-def test_elementwise_bit_exact(atlas, op, n_vars, as_i32, mode):
+@pytest.mark.parametrize("n_vars,as_i32", [(1, True), (4, False), (9, True), (14, False), (15, True), (18, False)])
+def test_elementwise_bit_exact(atlas, op, n_vars, as_i32, mode, pipe):
+    """pipe: Sumcheck::prove over the round channel (every launch enqueued up front, transcript on the host thread);
+    otherwise the host-stepped loop over compute_message / ingest_challenge."""
+    import os
     from oracle import orc, orc_ra as OR
     from jolt_atlas_amd import instances as I
     A = atlas
     A.set_challenge_mode(mode); orc.lib.orc_set_challenge_mode(mode)
+    if not pipe:
+        os.environ["ATLAS_NO_PIPELINE"] = "1"
     try:
         n = 1 << n_vars
         code = _EW[op][0]
@@ -55,6 +60,7 @@ def test_elementwise_bit_exact(atlas, op, n_vars, as_i32, mode):
             p_.free()
         inst.free()
     finally:
+        os.environ.pop("ATLAS_NO_PIPELINE", None)
         A.set_challenge_mode(0); orc.lib.orc_set_challenge_mode(0)
 
 
