@@ -4,7 +4,10 @@ sumcheck (BASELINE.json north_star; SURVEY.md §8d "Synthetic sumcheck S(22)").
 
 A step = one complete `Sumcheck::prove` of the einsum dot-product instance
 (EqSchedule::None, two LargeScalars MLEs of 2^22 uniform Fr, Blake2b transcript included)
-with the operands already resident in HBM.  `value` = Fr field operations per second
+with the operands already resident in HBM.  The transcript runs on the calling host thread over
+the round channel (`--fs host`, default: every launch enqueued up front, partial sums mailed into
+pinned memory, challenges polled from pinned slots) or on one wavefront (`--fs device`); the other
+placement is timed beside it (`fs_ab`).  `value` = Fr field operations per second
 over the whole job (all ranks), counted as the reference's TrackedFr would
 (joltworks/src/utils/counters.rs): per hypercube index and round 4 mul + 10 add/sub
 (sumcheck_evals 2 sub + 2 add, products 2 mul, reduce 2 add, binds 2x(sub, mul, add)).
@@ -13,9 +16,14 @@ N > 1: one process per GPU, each proving its own independent instance (weak scal
 data-path collective); timing = barrier + sync on both sides, max over ranks.
 """
 import argparse
+import glob
 import json
 import os
+import shutil
+import sqlite3
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -103,6 +111,72 @@ def cpu_baseline(n_vars, budget_s=20.0):
                       f"oracle C port with OpenMP, best of thread sweep {cand}"}
 
 
+PASS_KERNELS = ("k_dot_eval", "k_dot_bind_eval")      # the data passes of the dot-product sumcheck
+
+
+def git_sha():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return None
+
+
+def pmc_traffic(n_vars, fs, instances=3):
+    """HBM bytes per step of the data-pass kernels, measured NOW: two child runs of this script (`--pmc-child`:
+    `instances` sumchecks, nothing else) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (the two do not
+    fit one pass, MI355X_MICROARCH.md "rocprofv3 PMC slots"), read back from the rocpd databases.  FETCH_SIZE is
+    doubled as that guide prescribes for gfx950 (wide coalesced reads are tallied at half their bytes); both
+    counters are in KB.  Returns None when rocprofv3 is not usable."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="atlas_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", str(instances), "--n-vars", str(n_vars), "--fs", fs]
+            r = subprocess.run(cmd, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None
+            tot, launches = 0.0, 0
+            for name, val in sqlite3.connect(dbs[0]).execute(
+                    "select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+                if any(k in name for k in PASS_KERNELS):
+                    tot += val
+                    launches += 1
+            out[counter] = (tot * 1024.0, launches)
+        rd = out["FETCH_SIZE"][0] * 2.0
+        wr = out["WRITE_SIZE"][0]
+        return {"bytes_per_step": int((rd + wr) / instances), "read_bytes_per_step": int(rd / instances),
+                "write_bytes_per_step": int(wr / instances), "launches_per_step": out["FETCH_SIZE"][1] / instances,
+                "method": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + --pmc WRITE_SIZE, separate child runs of "
+                          "%d instances in this bench run" % instances, "git": git_sha()}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def pmc_child(n_inst, n_vars, fs):
+    import jolt_atlas_amd as A
+    A.init(0)
+    A.set_fs_mode(A.FS_HOST if fs == "host" else A.FS_DEVICE)
+    L = A.random_fr(1 << n_vars, 0xA71A50000 + n_vars)
+    R = A.random_fr(1 << n_vars, 0xA71A51000 + n_vars)
+    ml, mr = A.MultilinearPolynomial.from_fr(L), A.MultilinearPolynomial.from_fr(R)
+    p = A.EinsumDotProver(ml.clone(), mr.clone(), None, A.EQ_NONE, 0, 0)
+    claim = p.input_claim()
+    p.free()
+    for _ in range(n_inst):
+        prover = A.EinsumDotProver(ml.clone(), mr.clone(), None, A.EQ_NONE, 0, 0)
+        A.Sumcheck.prove(prover, claim, A.Blake2bTranscript(b"synthetic_sc"), n_vars)
+        prover.free()
+    A.sync()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,9 +185,15 @@ def main():
     ap.add_argument("--n-vars", type=int, default=N_VARS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-msm", action="store_true")
+    ap.add_argument("--fs", choices=("host", "device"), default="host", help="where the Blake2b transcript runs (atlas_set_fs_mode)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs that measure roofline.traffic")
+    ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--shard", action="store_true",
                     help="N>1 only: additionally prove ONE 2^n instance sharded over the N GPUs (RCCL all-gather per round)")
     args = ap.parse_args()
+    if args.pmc_child:
+        pmc_child(args.pmc_child, args.n_vars, args.fs)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -131,6 +211,8 @@ def main():
 
     import jolt_atlas_amd as A
     A.init(local_rank)
+    fs_modes = {"host": A.FS_HOST, "device": A.FS_DEVICE}
+    A.set_fs_mode(fs_modes[args.fs])
 
     # synthetic witness: uniform Fr, per-rank seeds (independent instances)
     L = A.random_fr(1 << n_vars, 0xA71A50000 + n_vars + 7919 * rank)
@@ -175,6 +257,22 @@ def main():
     for i in range(1, total):
         assert np.array_equal(results[i][0][0], p0[0][0]) and results[i][1] == p0[1], "non-deterministic proof"
 
+    # the other transcript placement, same instance, beside it (5 steps): same proof bytes, different spine
+    other = "device" if args.fs == "host" else "host"
+    A.set_fs_mode(fs_modes[other])
+    ab_sets = [(master_l.clone(), master_r.clone()) for _ in range(6)]
+    ab_res = {}
+
+    def ab_step(i):
+        prover = A.EinsumDotProver(*ab_sets[i], None, A.EQ_NONE, 0, 0)
+        t = A.Blake2bTranscript(b"synthetic_sc")
+        ab_res[i] = (A.Sumcheck.prove(prover, claim, t, n_vars), t.state)
+        prover.free()
+
+    dt_ab = timed_steps(ab_step, 5, 1, sync, barrier, allreduce_max)
+    assert np.array_equal(ab_res[0][0][0], p0[0][0]) and ab_res[0][1] == p0[1], "transcript placement changed the proof"
+    A.set_fs_mode(fs_modes[args.fs])
+
     # roofline of the dominant kernel (fused bind+eval pass), HIP events on the library
     # stream around every data-pass launch of one extra instrumented step
     A.set_timing(True)
@@ -185,15 +283,11 @@ def main():
     tm = A.last_timing()
     A.set_timing(False)
     achieved = tm.pass_bytes / (tm.pass_ms * 1e-3) / 1e9 if tm.pass_ms > 0 else 0.0
-    # HBM bytes per step of the same data-pass kernels from the committed PMC profile
-    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot run inside this process)
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")))
-        if n_vars == 22:
-            traffic = int(pmc["data_pass_hbm_bytes_per_step"])
-    except Exception:
-        traffic = None
+    # HBM bytes per step of the same data-pass kernels, measured in this run by two rocprofv3 --pmc child runs
+    pmc = None
+    if rank == 0 and world == 1 and not args.no_pmc:
+        pmc = pmc_traffic(n_vars, args.fs)
+    traffic = pmc["bytes_per_step"] if pmc else None
 
     ms_per_step = dt * 1e3 / args.steps
     value = world * field_ops(n_vars) * args.steps / dt
@@ -203,14 +297,19 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32x8 (BN254 Fr, 254-bit Montgomery)", "data": "synthetic",
         "config": {"workload": "synthetic 2^%d-coeff degree-2 dot-product sumcheck (EinsumDot, EqSchedule::None), "
-                               "LargeScalars operands, Blake2b transcript on device" % n_vars,
-                   "n_vars": n_vars, "instances_per_gpu": 1, "parallelism": "independent instance per GPU"},
+                               "LargeScalars operands, Blake2b transcript on the %s" % (n_vars, "host thread (round channel)" if args.fs == "host" else "device (one wavefront)"),
+                   "n_vars": n_vars, "instances_per_gpu": 1, "parallelism": "independent instance per GPU", "fs": args.fs},
         "mulmod_per_s": world * MULS_PER_INDEX_ROUND * ((1 << n_vars) - 1) * args.steps / dt,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "k_dot_eval + k_dot_bind_eval (data passes)", "launches": int(tm.n_pass),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": pmc,
+                     "kernel": "k_dot_eval2_f9 + k_dot_bind_eval2_f9 (data passes; with --fs host a pass's duration "
+                               "includes its wait for the round's challenge)", "launches": int(tm.n_pass),
                      "bytes_per_step": int(tm.pass_bytes), "pass_ms": tm.pass_ms, "fs_ms": tm.fs_ms,
-                     "instrumented_total_ms": tm.total_ms},
+                     "instrumented_total_ms": tm.total_ms,
+                     "whole_step_frac": tm.pass_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "fs_ab": {args.fs + "_ms_per_step": ms_per_step, other + "_ms_per_step": dt_ab * 1e3 / 5,
+                  "note": "same instance, same proof bytes; transcript on the host thread over the round channel vs on one wavefront"},
+        "git": git_sha(),
     }
     # second leg: the HyperKZG MSM of the same size (2^n_vars points, full-width scalars),
     # reported beside the sumcheck line; bases = tau^(i+1) G resident in HBM.

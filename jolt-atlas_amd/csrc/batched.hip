@@ -286,6 +286,7 @@ int atlas_instance_prove(atlas_instance_t inst, const atlas_fr_t* input_claim, a
             H::tr_challenge_u128(T, lo, hi);
             challenges[round].lo = lo; challenges[round].hi = hi;
             P.C.publish(P.slot0 + round, P.rtag(round), lo, hi);
+            if ((round & 7) == 7) (void)hipStreamQuery(g.stream);   // lets the runtime retire completed launches while the device works (2.5 us)
             prev = eval_with_challenge(c, H::challenge_to_fr(lo, hi, g.challenge_mode));
             rc = inst->host_ingest(challenges[round], round);
             if (!rc) rc = P.advance(round + 1);
@@ -403,7 +404,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         uint64_t lo, hi;
         H::tr_challenge_u128(T, lo, hi);                                              // challenge_scalar_optimized :119
         challenges[round].lo = lo; challenges[round].hi = hi;
-        if (piped) PL.C.publish(PL.slot0 + round, PL.rtag(round), lo, hi);
+        if (piped) { PL.C.publish(PL.slot0 + round, PL.rtag(round), lo, hi); if ((round & 7) == 7) (void)hipStreamQuery(g.stream); }
         const H::Fr r = H::challenge_to_fr(lo, hi, g.challenge_mode);
         for (size_t i = 0; i < n; i++) claim[i] = eval_with_challenge(polys[i], r);    // :123-126
         for (size_t i = 0; i < n; i++) {
