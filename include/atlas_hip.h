@@ -173,6 +173,24 @@ int atlas_fold_i32_cols_batched2(const int32_t *d_matrix, size_t B0, size_t sB0,
  * depend on (rbmk_rbnk_bmn.rs:270-289) */
 int atlas_poly_repeat_rows(atlas_poly_t base, size_t rows, size_t row_len, size_t repeat, atlas_poly_t *out);
 
+/* EinsumLayout::fold (jolt-atlas-core/src/onnx_proof/ops/einsum/mod.rs:71-115 registers the layouts; folds in
+ * mk_kn_mn.rs:47-79, bmk_rhs_mbn.rs:78-110, mbk_rhs_bmn.rs:78-119, k_nk_n.rs:46-68, rbmk_rbnk_bmn.rs:163-338): the
+ * left / right operand polynomials the dot-product sumcheck runs over, from the two Tensor<i32> operands resident in
+ * HBM and the eq tables of the output point (eq_r_m over the m axis, eq_r_n over the n axis; atlas_eq_evals).
+ * dims: MK_KN_MN (m,k,n); BMK_* / MBK_* (b,m,k,n); K_NK_N (k,n: no left fold, d_left / eq_r_m / left_out may be
+ * null); ABMK_ABNK_ABMN (a,b,m,n,k); ACBMK_KCN_CBMN (a,c,b,m,n,k); CBMK_CBKN_AMN (c*b,m,n,k). */
+#define ATLAS_EINSUM_MK_KN_MN        0
+#define ATLAS_EINSUM_BMK_BKN_MBN     1
+#define ATLAS_EINSUM_BMK_KBN_MBN     2
+#define ATLAS_EINSUM_MBK_BNK_BMN     3
+#define ATLAS_EINSUM_MBK_NBK_BMN     4
+#define ATLAS_EINSUM_K_NK_N          5
+#define ATLAS_EINSUM_ABMK_ABNK_ABMN  6
+#define ATLAS_EINSUM_ACBMK_KCN_CBMN  7
+#define ATLAS_EINSUM_CBMK_CBKN_AMN   8
+int atlas_einsum_fold(int layout, const size_t *dims, size_t n_dims, const int32_t *d_left, const int32_t *d_right,
+                      atlas_poly_t eq_r_m, atlas_poly_t eq_r_n, atlas_poly_t *left_out, atlas_poly_t *right_out);
+
 /* ---- Shout lookup argument: prover-side table builds
  *      (joltworks/src/subprotocols/shout.rs:193-262, 550-598) ---------------------------- */
 /* ReadRafProver::initialize: G[k] = sum_{j : lookup_indices[j] = k} E[j], E = eq_r (device
@@ -455,6 +473,14 @@ int atlas_msm_small(atlas_srs_t srs, size_t offset, const void *scalars, size_t 
  * passes the flat indices k*T + t of the non-zero coefficients; replaces
  * jolt_optimizations::batch_g1_additions_multi */
 int atlas_g1_sum_indexed(atlas_srs_t srs, const uint32_t *indices, size_t n, atlas_g1_affine_t *out);
+/* HyperKZG::batch_commit_one_hot (hyperkzg/mod.rs:558-596): R one-hot polynomials, polynomial r over K[r] addresses
+ * and T[r] cycles, nonzero_indices[r][t] = address of cycle t or negative for None (OneHotPolynomial::nonzero_indices,
+ * poly/one_hot_polynomial.rs:21-40).  One upload of all index vectors, one launch for all R sums.  out[r] = commitment. */
+int atlas_commit_one_hot_batch(atlas_srs_t srs, const int32_t *const *nonzero_indices, const size_t *K, const size_t *T,
+                               size_t R, atlas_g1_affine_t *out);
+/* CommitmentScheme::batch_commit (commitment_scheme.rs:76-90 -> UnivariateKZG::commit_batch, kzg.rs:195-243):
+ * commitments of n device-resident polynomials (LargeScalars or I32Scalars) against prefixes of the SRS. */
+int atlas_commit_batch(atlas_srs_t srs, const atlas_poly_t *polys, size_t n, atlas_g1_affine_t *out);
 /* HyperKZG::open (joltworks/src/poly/commitment/hyperkzg/mod.rs:400-447, the body of
  * CommitmentScheme::prove, commitment_scheme.rs:93-108): ell-1 folds, their commitments,
  * the 3*ell univariate evaluations, the batched witness polynomials and their 3
@@ -486,6 +512,35 @@ int atlas_prove_reduced_openings(const atlas_opening_t *openings, size_t n_openi
                                  atlas_transcript_t *transcript, atlas_fr_t *sumcheck_rows, uint32_t *n_coeffs,
                                  atlas_u128_t *challenges, size_t *max_rounds_out, atlas_fr_t *sumcheck_claims,
                                  atlas_g1_affine_t *com, atlas_g1_affine_t *w, atlas_fr_t *v);
+
+/* ProverOpeningAccumulator (joltworks/src/poly/opening_proof.rs:195-643): claim bookkeeping between the operator provers
+ * and prove_reduced_openings.  Keys are caller-chosen u64 whose numeric order is the Ord of the Rust key
+ * (opening_key <-> OpeningId, poly_key <-> CommittedPoly; types.rs:27-129), so iteration order equals the BTreeMaps'.
+ *   append_dense   (:265-315): transcript.append_scalar(claim); records the opening and the polynomial's reduction instance
+ *   append_sparse  (:317-372): the R one-hot polynomials of one lookup: one claim appended each, point = r_address || r_cycle
+ *   append_virtual (:374-409): transcript.append_scalar(claim); records the opening
+ *   get            (:199-243): point and claim recorded under an OpeningId (ATLAS_ESTATE if absent: the reference panics)
+ *   prove_reduced_openings: atlas_prove_reduced_openings over the committed openings in CommittedPoly order
+ * Dense polynomials are borrowed (alive until the proof), one-hot index rows are copied. */
+typedef struct atlas_accumulator *atlas_accumulator_t;
+int atlas_accumulator_new(atlas_accumulator_t *out);
+int atlas_accumulator_free(atlas_accumulator_t a);
+int atlas_accumulator_append_dense(atlas_accumulator_t a, atlas_transcript_t *t, uint64_t opening_key, uint64_t poly_key,
+                                   atlas_poly_t poly, const atlas_fr_t *point, size_t n, const atlas_fr_t *claim);
+int atlas_accumulator_append_sparse(atlas_accumulator_t a, atlas_transcript_t *t, const uint64_t *opening_keys,
+                                    const uint64_t *poly_keys, const int32_t *const *nonzero_indices, size_t R,
+                                    size_t log_K, size_t log_T, const atlas_fr_t *r_address, const atlas_fr_t *r_cycle,
+                                    const atlas_fr_t *claims);
+int atlas_accumulator_append_virtual(atlas_accumulator_t a, atlas_transcript_t *t, uint64_t opening_key,
+                                     const atlas_fr_t *point, size_t n, const atlas_fr_t *claim);
+int atlas_accumulator_get(atlas_accumulator_t a, uint64_t opening_key, atlas_fr_t *point_out, size_t cap, size_t *n_out,
+                          atlas_fr_t *claim_out);
+size_t atlas_accumulator_num_committed(atlas_accumulator_t a);
+size_t atlas_accumulator_max_rounds(atlas_accumulator_t a);
+int atlas_accumulator_prove_reduced_openings(atlas_accumulator_t a, atlas_srs_t srs, atlas_transcript_t *transcript,
+                                             atlas_fr_t *sumcheck_rows, uint32_t *n_coeffs, atlas_u128_t *challenges,
+                                             size_t *max_rounds_out, atlas_fr_t *sumcheck_claims, atlas_g1_affine_t *com,
+                                             atlas_g1_affine_t *w, atlas_fr_t *v);
 
 /* Transcript::append_point / append_points (blake2b.rs:166-195), host side */
 int atlas_transcript_append_point(atlas_transcript_t *t, const atlas_g1_affine_t *p);

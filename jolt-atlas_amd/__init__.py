@@ -370,6 +370,25 @@ class SRS:
                                         out.ctypes.data_as(C.c_void_p)))
         return out[0]
 
+    def commit_one_hot_batch(self, index_rows, Ks):
+        """HyperKZG::batch_commit_one_hot: index_rows[r] = int32 addresses per cycle (negative = None), Ks[r] = K."""
+        rows = [np.ascontiguousarray(r, dtype=np.int32) for r in index_rows]
+        R = len(rows)
+        ptrs = (C.c_void_p * max(R, 1))(*[r.ctypes.data for r in rows])
+        K = (C.c_size_t * max(R, 1))(*[int(k) for k in Ks])
+        T = (C.c_size_t * max(R, 1))(*[len(r) for r in rows])
+        out = np.zeros(max(R, 1), dtype=G1_DTYPE)
+        _check(lib.atlas_commit_one_hot_batch(self.h, ptrs, K, T, C.c_size_t(R), out.ctypes.data_as(C.c_void_p)))
+        return out[:R]
+
+    def commit_batch(self, polys):
+        """CommitmentScheme::batch_commit over device-resident polynomials."""
+        n = len(polys)
+        hs = (C.c_void_p * max(n, 1))(*[p.h for p in polys])
+        out = np.zeros(max(n, 1), dtype=G1_DTYPE)
+        _check(lib.atlas_commit_batch(self.h, hs, C.c_size_t(n), out.ctypes.data_as(C.c_void_p)))
+        return out[:n]
+
     def free(self):
         if self.h:
             lib.atlas_srs_free(self.h)

@@ -28,9 +28,10 @@ namespace H = atlas_host;
 // ------------------------------------------------------------------ runtime state
 namespace atlas_rt {
 Runtime g;
+thread_local std::string t_err;       // atlas_last_error is per calling thread (commit is called from Rayon workers)
 int fail(int code, const char* what, hipError_t e) {
-    g.err = what;
-    if (e != hipSuccess) { g.err += ": "; g.err += hipGetErrorString(e); }
+    t_err = what;
+    if (e != hipSuccess) { t_err += ": "; t_err += hipGetErrorString(e); }
     return code;
 }
 }  // namespace atlas_rt
@@ -107,8 +108,9 @@ int atlas_device_count(void) {
 }
 
 int atlas_init(int device_ordinal) {
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     if (g.ready && g.device == device_ordinal) return ATLAS_OK;
+    if (g.ready) return fail(ATLAS_ESTATE, "atlas_init: already initialised on another device (atlas_shutdown first)");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0) return fail(ATLAS_ENODEV, "no HIP device available", e);
@@ -139,7 +141,7 @@ int atlas_init(int device_ordinal) {
 }
 
 int atlas_shutdown(void) {
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     if (!g.ready) return ATLAS_OK;
     hipStreamSynchronize(g.stream);
     for (auto f : g.at_shutdown) f();
@@ -153,7 +155,7 @@ int atlas_shutdown(void) {
     return ATLAS_OK;
 }
 
-const char* atlas_last_error(void) { return g.err.c_str(); }
+const char* atlas_last_error(void) { return atlas_rt::t_err.c_str(); }
 
 int atlas_sync(void) {
     NEED_INIT();
@@ -289,6 +291,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_i32_to_fr(const int32_t* in, Fr*
 int atlas_poly_download(atlas_poly_t p, atlas_fr_t* host, size_t cap) {
     NEED_INIT();
     if (!p || !host || cap < p->len) return fail(ATLAS_EINVAL, "poly_download: buffer too small");
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     if (p->is_i32) {
         Fr* tmp = nullptr;
         HIP_TRY(hipMalloc(&tmp, p->len * sizeof(Fr)));
@@ -386,6 +389,7 @@ static int poly_bind_async(atlas_poly* p, const atlas_u128_t* rc128, int order) 
 int atlas_poly_bind(atlas_poly_t p, const atlas_u128_t* r, int order) {
     NEED_INIT();
     if (!p || !r || (order != ATLAS_HIGH_TO_LOW && order != ATLAS_LOW_TO_HIGH)) return fail(ATLAS_EINVAL, "poly_bind");
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     int rc = poly_bind_async(p, r, order);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(g.stream));
@@ -487,6 +491,7 @@ int atlas_dot_compute_message(atlas_dot_prover_t P, size_t round, const atlas_fr
                               atlas_fr_t* coeffs_out, size_t* n_coeffs) {
     NEED_INIT();
     if (!P || !previous_claim || !coeffs_out || !n_coeffs) return fail(ATLAS_EINVAL, "compute_message");
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     if (P->consumed) return fail(ATLAS_ESTATE, "compute_message: prover already consumed");
     if (round >= P->n_rounds || P->left->len != ((size_t)1 << (P->n_rounds - round)))
         return fail(ATLAS_ESTATE, "compute_message: round out of order");
@@ -510,6 +515,7 @@ int atlas_dot_compute_message(atlas_dot_prover_t P, size_t round, const atlas_fr
 int atlas_dot_input_claim(atlas_dot_prover_t P, atlas_fr_t* out) {
     NEED_INIT();
     if (!P || !out) return fail(ATLAS_EINVAL, "input_claim");
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     if (P->consumed || P->left->len != ((size_t)1 << P->n_rounds)) return fail(ATLAS_ESTATE, "input_claim: instance already bound");
     const size_t len = P->left->len;
     const int grid = grid_for(len);
@@ -531,6 +537,7 @@ int atlas_dot_input_claim(atlas_dot_prover_t P, atlas_fr_t* out) {
 int atlas_dot_ingest_challenge(atlas_dot_prover_t P, const atlas_u128_t* r_j, size_t round) {
     NEED_INIT();
     if (!P || !r_j) return fail(ATLAS_EINVAL, "ingest_challenge");
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     if (P->consumed) return fail(ATLAS_ESTATE, "ingest_challenge: prover already consumed");
     if (round >= P->n_rounds || P->left->len != ((size_t)1 << (P->n_rounds - round)))
         return fail(ATLAS_ESTATE, "ingest_challenge: round out of order");
@@ -914,7 +921,7 @@ int atlas_sumcheck_prove_dot(atlas_dot_prover_t P, const atlas_fr_t* input_claim
         return fail(ATLAS_EINVAL, "sumcheck_prove_dot: null argument");
     if (P->consumed) return fail(ATLAS_ESTATE, "sumcheck_prove_dot: prover already consumed");
     if (P->left->len != ((size_t)1 << P->n_rounds)) return fail(ATLAS_ESTATE, "sumcheck_prove_dot: rounds already run");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     if (g.fs_mode == ATLAS_FS_HOST) {
         if (P->schedule == ATLAS_EQ_NONE) return prove_dot_channel<2>(P, input_claim, transcript, compressed_polys, challenges, final_claims);
         return prove_dot_channel<3>(P, input_claim, transcript, compressed_polys, challenges, final_claims);
@@ -939,7 +946,7 @@ int atlas_dot_shard_begin(atlas_dot_prover_t P, const atlas_fr_t* input_claim, c
     if (!P || !input_claim || !transcript) return fail(ATLAS_EINVAL, "dot_shard_begin: null argument");
     if (P->schedule != ATLAS_EQ_NONE || P->left->is_i32) return fail(ATLAS_EINVAL, "dot_shard_begin: degree-2 LargeScalars instances only");
     if (P->consumed || P->left->len != ((size_t)1 << P->n_rounds)) return fail(ATLAS_ESTATE, "dot_shard_begin: prover already used");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     ScCtx* hctx = reinterpret_cast<ScCtx*>(g.h_pinned);
     std::memset(hctx, 0, sizeof(ScCtx));
     std::memcpy(&hctx->tr, transcript, sizeof(DevTranscript));
@@ -955,7 +962,7 @@ int atlas_dot_shard_local_message(atlas_dot_prover_t P, atlas_fr_t* out2) {
     NEED_INIT();
     if (!P || !out2) return fail(ATLAS_EINVAL, "dot_shard_local_message");
     if (!P->shard_active || P->left->len < 2) return fail(ATLAS_ESTATE, "dot_shard_local_message: no local round left");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     const ScConsts K = make_consts();
     const int hi_only = g.challenge_mode == 0;
     const bool f9 = g.challenge_mode == 0;
@@ -989,7 +996,7 @@ int atlas_dot_shard_round(atlas_dot_prover_t P, const atlas_fr_t* gathered, size
     NEED_INIT();
     if (!P || !gathered || world == 0 || world > SC_MAX_BLOCKS) return fail(ATLAS_EINVAL, "dot_shard_round");
     if (!P->shard_active || P->shard_pending) return fail(ATLAS_ESTATE, "dot_shard_round: out of order");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     const ScConsts K = make_consts();
     HIP_TRY(hipMemcpyAsync(g.d_partials, gathered, world * 2 * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
     const size_t rd = P->shard_rounds_done;
@@ -1008,7 +1015,7 @@ int atlas_dot_shard_local_final(atlas_dot_prover_t P, atlas_fr_t* out2) {
     NEED_INIT();
     if (!P || !out2) return fail(ATLAS_EINVAL, "dot_shard_local_final");
     if (!P->shard_active || !P->shard_pending || P->left->len != 2) return fail(ATLAS_ESTATE, "dot_shard_local_final: local rounds not finished");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     const int hi_only = g.challenge_mode == 0;
     k_bind_hi<<<1, SC_THREADS, 0, g.stream>>>((Fr*)P->left->d, 1, &g.d_ctx->r, hi_only);
     k_bind_hi<<<1, SC_THREADS, 0, g.stream>>>((Fr*)P->right->d, 1, &g.d_ctx->r, hi_only);
@@ -1029,7 +1036,7 @@ int atlas_dot_shard_finish(atlas_dot_prover_t P, const atlas_fr_t* gathered_lr, 
         world > ((size_t)1 << SC_TAIL_LOG))
         return fail(ATLAS_EINVAL, "dot_shard_finish");
     if (!P->shard_active || P->left->len != 1 || P->shard_pending) return fail(ATLAS_ESTATE, "dot_shard_finish: out of order");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     const ScConsts K = make_consts();
     const size_t n_total = P->shard_rounds_done + ilog2(world);
     if (n_total > MAX_ROUNDS) return fail(ATLAS_EINVAL, "dot_shard_finish: too many rounds");
@@ -1043,7 +1050,8 @@ int atlas_dot_shard_finish(atlas_dot_prover_t P, const atlas_fr_t* gathered_lr, 
     TailArgs A;
     A.L = dl; A.R = dr; A.eq = nullptr; A.len = (uint32_t)world; A.eq_len = 0; A.src_i32 = 0;
     A.sched = 0; A.a = 0; A.b = 0; A.round0 = (uint32_t)P->shard_rounds_done; A.n_rounds = (uint32_t)n_total;
-    A.first = 0; A.pending_bind = 0; A.challenge_mode = g.challenge_mode;
+    A.first = P->shard_rounds_done == 0 ? 1 : 0;      // one coefficient per rank: no local round absorbed the input claim yet
+    A.pending_bind = 0; A.challenge_mode = g.challenge_mode;
     k_dot_tail<2><<<1, SC_THREADS, 3 * (sizeof(Fr) << SC_TAIL_LOG), g.stream>>>(A, g.d_ctx, g.d_proof, g.d_chal, g.d_finals, K);
     uint8_t* hp = reinterpret_cast<uint8_t*>(g.h_pinned);
     const size_t proof_bytes = n_total * 2 * sizeof(Fr), chal_bytes = n_total * 2 * sizeof(uint64_t);

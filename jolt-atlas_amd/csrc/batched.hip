@@ -262,7 +262,7 @@ int atlas_instance_prove(atlas_instance_t inst, const atlas_fr_t* input_claim, a
     const size_t n = inst->rounds();
     std::vector<H::Fr> c;
     if (n && all_pipelined({inst})) {
-        std::lock_guard<std::mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
         Pipeline P;
         P.lanes.push_back(Lane{inst, n, 0, {}, {}});
         int rc = P.begin();
@@ -355,7 +355,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         for (auto& I : b->inst) v.push_back(I.inst);
         piped = all_pipelined(v);
     }
-    std::unique_lock<std::mutex> pipe_lock(g.mu, std::defer_lock);
+    std::unique_lock<atlas_rt::Mutex> pipe_lock(g.mu, std::defer_lock);
     if (piped) {
         pipe_lock.lock();
         for (auto& I : b->inst) PL.lanes.push_back(Lane{I.inst, I.rounds, 0, {}, {}});

@@ -223,7 +223,7 @@ int atlas_fold_i32_rows(const int32_t* d_matrix, size_t rows, size_t cols, atlas
     NEED_INIT();
     if (!d_matrix || !eq || !out || !is_pow2(rows) || cols == 0) return fail(ATLAS_EINVAL, "fold_i32_rows: rows must be a power of two");
     if (eq->is_i32 || eq->len != cols) return fail(ATLAS_EINVAL, "fold_i32_rows: eq table length != cols");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     int rc = make_poly(rows, out);
     if (rc) return rc;
     k_fold_rows<<<(unsigned)rows, FOLD_THREADS, 0, g.stream>>>(d_matrix, (const Fe*)eq->d, cols, (Fe*)(*out)->d);
@@ -235,7 +235,7 @@ int atlas_fold_i32_cols(const int32_t* d_matrix, size_t rows, size_t cols, atlas
     NEED_INIT();
     if (!d_matrix || !eq || !out || !is_pow2(cols) || rows == 0) return fail(ATLAS_EINVAL, "fold_i32_cols: cols must be a power of two");
     if (eq->is_i32 || eq->len != rows) return fail(ATLAS_EINVAL, "fold_i32_cols: eq table length != rows");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     int rc = make_poly(cols, out);
     if (rc) return rc;
     // split the rows into slabs so that ~2048 workgroups are in flight
@@ -262,7 +262,7 @@ int atlas_fold_i32_rows_batched(const int32_t* d_matrix, size_t n0, size_t n1, s
     if (!d_matrix || !eq || !out || n0 == 0 || n1 == 0 || R == 0 || !is_pow2(n0 * n1)) return fail(ATLAS_EINVAL, "fold_i32_rows_batched: n0*n1 must be a power of two");
     if (eq->is_i32 || eq->len != R) return fail(ATLAS_EINVAL, "fold_i32_rows_batched: eq table length != R");
     if ((n0 - 1) * t0 + (n1 - 1) * t1 >= n0 * n1) return fail(ATLAS_EINVAL, "fold_i32_rows_batched: output strides leave the n0*n1 range");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     int rc = make_poly(n0 * n1, out);
     if (rc) return rc;
     k_fold_rows_batched<<<(unsigned)(n0 * n1), FOLD_THREADS, 0, g.stream>>>(d_matrix, (const Fe*)eq->d, n1, s0, s1, R, t0, t1, (Fe*)(*out)->d);
@@ -276,7 +276,7 @@ int atlas_fold_i32_cols_batched(const int32_t* d_matrix, size_t B, size_t sB, si
     if (!d_matrix || !eq || !out || B == 0 || C == 0 || R == 0 || !is_pow2(B * C)) return fail(ATLAS_EINVAL, "fold_i32_cols_batched: B*C must be a power of two");
     if (eq->is_i32 || eq->len != R) return fail(ATLAS_EINVAL, "fold_i32_cols_batched: eq table length != R");
     if ((B - 1) * tB + (C - 1) * tC >= B * C) return fail(ATLAS_EINVAL, "fold_i32_cols_batched: output strides leave the B*C range");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     int rc = make_poly(B * C, out);
     if (rc) return rc;
     k_fold_cols_batched<<<dim3((unsigned)((C + FOLD_THREADS - 1) / FOLD_THREADS), (unsigned)B), FOLD_THREADS, 0, g.stream>>>(
@@ -291,7 +291,7 @@ int atlas_fold_i32_cols_batched2(const int32_t* d_matrix, size_t B0, size_t sB0,
     if (!d_matrix || !eq || !out || B0 == 0 || B1 == 0 || C == 0 || R == 0 || !is_pow2(B0 * B1 * C)) return fail(ATLAS_EINVAL, "fold_i32_cols_batched2: B0*B1*C must be a power of two");
     if (eq->is_i32 || eq->len != R) return fail(ATLAS_EINVAL, "fold_i32_cols_batched2: eq table length != R");
     if ((B0 - 1) * tB0 + (B1 - 1) * tB1 + (C - 1) * tC >= B0 * B1 * C) return fail(ATLAS_EINVAL, "fold_i32_cols_batched2: output strides leave the output range");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     int rc = make_poly(B0 * B1 * C, out);
     if (rc) return rc;
     k_fold_cols_batched<<<dim3((unsigned)((C + FOLD_THREADS - 1) / FOLD_THREADS), (unsigned)(B0 * B1)), FOLD_THREADS, 0, g.stream>>>(
@@ -315,13 +315,80 @@ int atlas_poly_repeat_rows(atlas_poly_t base, size_t rows, size_t row_len, size_
     NEED_INIT();
     if (!base || !out || base->is_i32 || base->len != rows * row_len || repeat == 0 || !is_pow2(rows * row_len * repeat))
         return fail(ATLAS_EINVAL, "poly_repeat_rows: base must hold rows*row_len Fr and the output length be a power of two");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     int rc = make_poly(rows * row_len * repeat, out);
     if (rc) return rc;
     const size_t total = rows * row_len * repeat;
     size_t gb = (total + FOLD_THREADS - 1) / FOLD_THREADS; if (gb > 4096) gb = 4096;
     k_repeat_rows<<<(unsigned)gb, FOLD_THREADS, 0, g.stream>>>((const Fe*)base->d, rows, row_len, repeat, (Fe*)(*out)->d);
     HIP_TRY(hipStreamSynchronize(g.stream));
+    return ATLAS_OK;
+}
+
+
+// EinsumLayout::fold for every layout the reference registers (ops/einsum/mod.rs:71-115): which strided fold each
+// operand takes, with the transposes of utils/dims.rs:658-690 folded into the output strides.  dims per layout:
+//   MK_KN_MN (m,k,n)  BMK_BKN_MBN / BMK_KBN_MBN / MBK_BNK_BMN / MBK_NBK_BMN (b,m,k,n)  K_NK_N (k,n)
+//   ABMK_ABNK_ABMN (a,b,m,n,k)  ACBMK_KCN_CBMN (a,c,b,m,n,k)  CBMK_CBKN_AMN (cb,m,n,k)
+int atlas_einsum_fold(int layout, const size_t* dims, size_t n_dims, const int32_t* d_left, const int32_t* d_right,
+                      atlas_poly_t eq_r_m, atlas_poly_t eq_r_n, atlas_poly_t* left_out, atlas_poly_t* right_out) {
+    NEED_INIT();
+    static const size_t want[] = {3, 4, 4, 4, 4, 2, 5, 6, 4};
+    if (layout < 0 || layout > ATLAS_EINSUM_CBMK_CBKN_AMN || !dims || n_dims != want[layout]) return fail(ATLAS_EINVAL, "einsum_fold: layout / dims");
+    if (!d_right || !eq_r_n || !right_out || (layout != ATLAS_EINSUM_K_NK_N && (!d_left || !eq_r_m || !left_out)))
+        return fail(ATLAS_EINVAL, "einsum_fold: null argument");
+    int rc = ATLAS_OK;
+    atlas_poly_t lo = nullptr, ro = nullptr;
+    switch (layout) {
+        case ATLAS_EINSUM_MK_KN_MN: {                       // mk_kn_mn.rs:47-79
+            const size_t m = dims[0], k = dims[1], n = dims[2];
+            rc = atlas_fold_i32_cols(d_left, m, k, eq_r_m, &lo);
+            if (!rc) rc = atlas_fold_i32_rows(d_right, k, n, eq_r_n, &ro);
+            break;
+        }
+        case ATLAS_EINSUM_BMK_BKN_MBN: case ATLAS_EINSUM_BMK_KBN_MBN: {      // bmk_rhs_mbn.rs:78-110
+            const size_t b = dims[0], m = dims[1], k = dims[2], n = dims[3];
+            rc = atlas_fold_i32_cols_batched(d_left, b, k * m, m, k, k, 1, b, eq_r_m, &lo);                   // lo[h*k + j], transposed (b, k)
+            if (!rc) rc = layout == ATLAS_EINSUM_BMK_KBN_MBN ? atlas_fold_i32_rows_batched(d_right, k, b, b * n, n, n, b, 1, eq_r_n, &ro)
+                                                              : atlas_fold_i32_rows_batched(d_right, b, k, k * n, n, n, 1, b, eq_r_n, &ro);
+            break;
+        }
+        case ATLAS_EINSUM_MBK_BNK_BMN: case ATLAS_EINSUM_MBK_NBK_BMN: {      // mbk_rhs_bmn.rs:78-119
+            const size_t b = dims[0], m = dims[1], k = dims[2], n = dims[3];
+            rc = atlas_fold_i32_cols_batched(d_left, b, k, m, k * b, k, k, 1, eq_r_m, &lo);                    // sum_i left[i*k*b + h*k + j]
+            if (!rc) rc = layout == ATLAS_EINSUM_MBK_BNK_BMN ? atlas_fold_i32_cols_batched(d_right, b, n * k, n, k, k, k, 1, eq_r_n, &ro)
+                                                              : atlas_fold_i32_cols_batched(d_right, b, k, n, k * b, k, k, 1, eq_r_n, &ro);
+            break;
+        }
+        case ATLAS_EINSUM_K_NK_N: {                         // k_nk_n.rs:46-68: right[j] = sum_h B[h*k + j] eq[h]; the left operand is used as is
+            const size_t k = dims[0], n = dims[1];
+            rc = atlas_fold_i32_cols_batched(d_right, 1, 0, n, k, k, 0, 1, eq_r_n, &ro);
+            break;
+        }
+        case ATLAS_EINSUM_ABMK_ABNK_ABMN: {                 // rbmk_rbnk_bmn.rs:163-217
+            const size_t batch = dims[0] * dims[1], m = dims[2], n = dims[3], k = dims[4];
+            rc = atlas_fold_i32_cols_batched(d_left, batch, m * k, m, k, k, k, 1, eq_r_m, &lo);
+            if (!rc) rc = atlas_fold_i32_cols_batched(d_right, batch, n * k, n, k, k, k, 1, eq_r_n, &ro);
+            break;
+        }
+        case ATLAS_EINSUM_ACBMK_KCN_CBMN: {                 // rbmk_rbnk_bmn.rs:219-290: left transposes the (a, cb) batch axes, right is broadcast over (b, a)
+            const size_t a = dims[0], c = dims[1], b = dims[2], m = dims[3], n = dims[4], k = dims[5], cb = c * b;
+            rc = atlas_fold_i32_cols_batched2(d_left, a, cb * m * k, k, cb, m * k, a * k, m, k, k, 1, eq_r_m, &lo);
+            atlas_poly_t base = nullptr;
+            if (!rc) rc = atlas_fold_i32_rows_batched(d_right, c, k, n, c * n, n, k, 1, eq_r_n, &base);
+            if (!rc) rc = atlas_poly_repeat_rows(base, c, k, b * a, &ro);
+            if (base) atlas_poly_free(base);
+            break;
+        }
+        default: {                                          // cbmk,cbkn->amn (rbmk_rbnk_bmn.rs:292-338)
+            const size_t cb = dims[0], m = dims[1], n = dims[2], k = dims[3];
+            rc = atlas_fold_i32_cols_batched(d_left, cb, m * k, m, k, k, k, 1, eq_r_m, &lo);
+            if (!rc) rc = atlas_fold_i32_rows_batched(d_right, cb * k, 1, n, 0, n, 1, 0, eq_r_n, &ro);
+        }
+    }
+    if (rc) { if (lo) atlas_poly_free(lo); if (ro) atlas_poly_free(ro); return rc; }
+    if (left_out) *left_out = lo;
+    *right_out = ro;
     return ATLAS_OK;
 }
 

@@ -193,7 +193,7 @@ struct Elementwise : atlas_instance {
     size_t degree() const override { return op == EW_CUBE ? 4 : !ew_has_eq(op) ? 2 : ew_outputs(op) + 1; }
     int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
         if (round != round_next || round >= n_vars) return fail(ATLAS_ESTATE, "elementwise: round out of order");
-        std::lock_guard<std::mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
         const size_t n_groups = rows.len / 2;
         size_t blocks = (n_groups + RA_THREADS - 1) / RA_THREADS; if (blocks > 1024) blocks = 1024;
         const SplitEqView E = ew_has_eq(op) ? eq.view() : SplitEqView{nullptr, nullptr, 0};
@@ -226,7 +226,7 @@ struct Elementwise : atlas_instance {
     }
     int ingest(const atlas_u128_t& r, size_t round) override {
         if (round != round_next || round >= n_vars) return fail(ATLAS_ESTATE, "elementwise: round out of order");
-        std::lock_guard<std::mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
         int rc = rows.bind(r);
         if (rc) return rc;
         if (ew_has_eq(op)) eq.st.bind(H::challenge_to_fr(r.lo, r.hi, g.challenge_mode));
@@ -236,7 +236,7 @@ struct Elementwise : atlas_instance {
     int finals(std::vector<H::Fr>& out) override {
         if (round_next != n_vars) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
         if (have_finals) { out = mailed_finals; return ATLAS_OK; }
-        std::lock_guard<std::mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
         return rows.finals(out);
     }
 
@@ -329,7 +329,7 @@ int atlas_elementwise_new(int op, const atlas_poly_t* operands, size_t n_operand
     const size_t T = (size_t)1 << n_vars;
     for (size_t i = 0; i < n_operands; i++)
         if (!operands[i] || operands[i]->len != T) return fail(ATLAS_EINVAL, "elementwise_new: operand length != 2^n_vars");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     Elementwise* P = new Elementwise();
     P->op = op; P->n_vars = n_vars;
     for (size_t i = 0; i < n_constants; i++) std::memcpy(&P->consts.k[i], &constants[i], 32);

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(ER_THREADS) void k_er_reduce(const Fr* __restrict__
 int evaluate_many(atlas_poly_t mle, const std::vector<H::Fr>& points, size_t n_pts, size_t n, std::vector<H::Fr>& out) {
     const uint32_t m = (uint32_t)(n / 2), n2 = (uint32_t)(n - m);
     if (m > 13 || n2 > 13) return fail(ATLAS_EINVAL, "eval_reduction: more than 26 variables not supported");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     Fr *d_pts = nullptr, *tab1 = nullptr, *tab2 = nullptr, *part = nullptr, *d_out = nullptr;
     const size_t rows = (size_t)1 << m;
     const unsigned grid = (unsigned)(rows < 1024 ? rows : 1024);

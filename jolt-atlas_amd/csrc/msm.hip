@@ -431,7 +431,7 @@ int atlas_srs_upload(const void* bases, size_t n, size_t stride_bytes, atlas_srs
 int atlas_srs_generate(const atlas_fr_t* tau, size_t n, atlas_srs_t* out) {
     NEED_INIT();
     if (!tau || !out || n == 0) return fail(ATLAS_EINVAL, "srs_generate");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     // tau^(2^j), j < 64 ; 2^j * G, j < 254 (host, O(1) work)
     std::vector<H::Fr> tp(64);
     std::memcpy(&tp[0], tau, 32);
@@ -487,7 +487,7 @@ int atlas_msm_fr(atlas_srs_t srs, size_t offset, const atlas_fr_t* scalars, size
     if (!srs || !out || (!scalars && n)) return fail(ATLAS_EINVAL, "msm_fr: null argument");
     if (offset + n > srs->len)   // ProofVerifyError::KeyLengthError (msm/mod.rs:35-37)
         return fail(ATLAS_EINVAL, "msm_fr: KeyLengthError (bases shorter than scalars)");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     Fr* d_s = nullptr;
     if (n) {
         HIP_TRY(hipMalloc(&d_s, n * sizeof(Fr)));
@@ -502,7 +502,7 @@ int atlas_msm_poly(atlas_srs_t srs, size_t offset, atlas_poly_t poly, atlas_g1_a
     NEED_INIT();
     if (!srs || !poly || !out) return fail(ATLAS_EINVAL, "msm_poly: null argument");
     if (offset + poly->len > srs->len) return fail(ATLAS_EINVAL, "msm_poly: KeyLengthError (bases shorter than scalars)");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     if (poly->is_i32) return msm_small_device<int32_t>(srs->d + offset, (const int32_t*)poly->d, poly->len, out);   // I32Scalars, msm/mod.rs:88-130
     return msm_device(srs->d + offset, (const Fr*)poly->d, poly->len, out);
 }
@@ -512,7 +512,7 @@ int atlas_msm_poly(atlas_srs_t srs, size_t offset, atlas_poly_t poly, atlas_g1_a
 int atlas_msm_small(atlas_srs_t srs, size_t offset, const void* scalars, size_t n, int kind, atlas_g1_affine_t* out) {
     NEED_INIT();
     if (!srs || !out || (!scalars && n) || offset + n > srs->len) return fail(ATLAS_EINVAL, "msm_small: KeyLengthError");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     static const size_t width[] = {1, 2, 4, 8, 4, 8};
     if (kind < 0 || kind > ATLAS_SCALAR_I64) return fail(ATLAS_EINVAL, "msm_small: kind");
     void* d_s = nullptr;
@@ -541,7 +541,7 @@ int atlas_g1_sum_indexed(atlas_srs_t srs, const uint32_t* indices, size_t n, atl
     for (size_t i = 0; i < n; i++)
         if (indices[i] >= srs->len) return fail(ATLAS_EINVAL, "g1_sum_indexed: KeyLengthError (index beyond the SRS)");
     if (n == 0) { H::G1Aff z{H::q_zero(), H::q_zero()}; to_out(z, out); return ATLAS_OK; }
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     const int grid = grid_for(n, 1024);
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -556,6 +556,94 @@ int atlas_g1_sum_indexed(atlas_srs_t srs, const uint32_t* indices, size_t n, atl
     HIP_TRY(hipMemcpyAsync(&r, W + o_one, sizeof(G1Xyzz), hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
     to_out(H::gx_to_aff(r), out);
+    return ATLAS_OK;
+}
+
+
+// HyperKZG::batch_commit_one_hot (hyperkzg/mod.rs:558-596; called per lookup op with d = 8 / 16 polynomials,
+// prover.rs:236-249): one upload of all index vectors, one launch for all sums, one copy back.
+int atlas_commit_one_hot_batch(atlas_srs_t srs, const int32_t* const* nonzero_indices, const size_t* K, const size_t* T, size_t R,
+                               atlas_g1_affine_t* out) {
+    NEED_INIT();
+    if (!srs || (R && (!nonzero_indices || !K || !T || !out))) return fail(ATLAS_EINVAL, "commit_one_hot_batch: null argument");
+    if (R == 0) return ATLAS_OK;
+    size_t total = 0, t_max = 0;
+    for (size_t r = 0; r < R; r++) {
+        if (!nonzero_indices[r] && T[r]) return fail(ATLAS_EINVAL, "commit_one_hot_batch: null index vector");
+        if (K[r] * T[r] > srs->len) return fail(ATLAS_EINVAL, "commit_one_hot_batch: KeyLengthError (K*T beyond the SRS)");
+        total += T[r]; t_max = T[r] > t_max ? T[r] : t_max;
+    }
+    if (total >= ((size_t)1 << 32)) return fail(ATLAS_EINVAL, "commit_one_hot_batch: more than 2^32 cycles in one call");
+    std::vector<int32_t> flat(total ? total : 1);
+    std::vector<OneHotRowDesc> rows(R);
+    size_t o = 0;
+    for (size_t r = 0; r < R; r++) {
+        rows[r] = OneHotRowDesc{(uint32_t)o, (uint32_t)T[r]};
+        for (size_t t = 0; t < T[r]; t++) {
+            const int32_t k = nonzero_indices[r][t];
+            if (k >= 0 && (size_t)k >= K[r]) return fail(ATLAS_EINVAL, "commit_one_hot_batch: index >= K");
+            flat[o + t] = k;
+        }
+        o += T[r];
+    }
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    // about 2048 workgroups in flight over the batch, at least one per polynomial
+    unsigned gx = (unsigned)(2048 / R); if (gx < 1) gx = 1;
+    const unsigned need = (unsigned)((t_max + MSM_THREADS - 1) / MSM_THREADS); if (gx > need) gx = need ? need : 1;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t q = off; off = align_up(off + bytes, 256); return q; };
+    const size_t o_idx = carve(flat.size() * 4), o_rows = carve(R * sizeof(OneHotRowDesc)), o_part = carve((size_t)R * gx * sizeof(G1Xyzz)),
+                 o_sum = carve(R * sizeof(G1Xyzz));
+    int rc = ws.ensure(off);
+    if (rc) return rc;
+    unsigned char* W = (unsigned char*)ws.p;
+    HIP_TRY(hipMemcpyAsync(W + o_idx, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(W + o_rows, rows.data(), R * sizeof(OneHotRowDesc), hipMemcpyHostToDevice, g.stream));
+    k_g1_sum_onehot_rows<<<dim3(gx, (unsigned)R), MSM_THREADS, 0, g.stream>>>(srs->d, (const int32_t*)(W + o_idx), (const OneHotRowDesc*)(W + o_rows), (G1Xyzz*)(W + o_part));
+    k_g1_group_sum<<<(unsigned)R, MSM_THREADS, 0, g.stream>>>((const G1Xyzz*)(W + o_part), gx, (G1Xyzz*)(W + o_sum));
+    std::vector<H::G1X> res(R);
+    HIP_TRY(hipMemcpyAsync(res.data(), W + o_sum, R * sizeof(G1Xyzz), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    for (size_t r = 0; r < R; r++) to_out(H::gx_to_aff(res[r]), out + r);
+    return ATLAS_OK;
+}
+
+// CommitmentScheme::batch_commit (commitment_scheme.rs:76-90 -> UnivariateKZG::commit_batch, kzg.rs:195-243): n
+// polynomials against prefixes of the same SRS.  LargeScalars polynomials share one bucket pipeline (their scalars are
+// gathered into one buffer: 32 B per coefficient against ~20 point additions); I32Scalars ones take the narrow-scalar plan.
+int atlas_commit_batch(atlas_srs_t srs, const atlas_poly_t* polys, size_t n, atlas_g1_affine_t* out) {
+    NEED_INIT();
+    if (!srs || (n && (!polys || !out))) return fail(ATLAS_EINVAL, "commit_batch: null argument");
+    std::vector<size_t> fr_idx;
+    size_t tot = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!polys[i]) return fail(ATLAS_EINVAL, "commit_batch: null polynomial");
+        if (polys[i]->len > srs->len) return fail(ATLAS_EINVAL, "commit_batch: KeyLengthError (bases shorter than scalars)");
+        if (!polys[i]->is_i32) { fr_idx.push_back(i); tot += polys[i]->len; }
+    }
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    for (size_t i = 0; i < n; i++)
+        if (polys[i]->is_i32) { int rc = msm_small_device<int32_t>(srs->d, (const int32_t*)polys[i]->d, polys[i]->len, out + i); if (rc) return rc; }
+    if (fr_idx.size() == 1) return msm_device(srs->d, (const Fr*)polys[fr_idx[0]]->d, polys[fr_idx[0]]->len, out + fr_idx[0]);
+    if (fr_idx.empty()) return ATLAS_OK;
+    Fr* cat = nullptr;
+    hipError_t e = hipMalloc(&cat, tot * sizeof(Fr));
+    if (e != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(commit_batch scalars)", e);
+    std::vector<size_t> lens(fr_idx.size()), offs(fr_idx.size());
+    size_t o = 0;
+    for (size_t j = 0; j < fr_idx.size() && e == hipSuccess; j++) {
+        const atlas_poly* P = polys[fr_idx[j]];
+        lens[j] = P->len; offs[j] = o;
+        e = hipMemcpyAsync(cat + o, P->d, P->len * sizeof(Fr), hipMemcpyDeviceToDevice, g.stream);
+        o += P->len;
+    }
+    std::vector<atlas_g1_affine_t> res(fr_idx.size());
+    int rc = e == hipSuccess ? msm_device_multi(srs->d, cat, tot, fr_idx.size(), lens.data(), offs.data(), res.data())
+                             : fail(ATLAS_ENODEV, "commit_batch: gather", e);
+    (void)hipStreamSynchronize(g.stream);
+    (void)hipFree(cat);
+    if (rc) return rc;
+    for (size_t j = 0; j < fr_idx.size(); j++) out[fr_idx[j]] = res[j];
     return ATLAS_OK;
 }
 
@@ -583,7 +671,7 @@ int atlas_hyperkzg_open(atlas_srs_t srs, atlas_poly_t poly, const atlas_u128_t* 
     const size_t n = (size_t)1 << ell;
     if (poly->is_i32 || poly->len != n) return fail(ATLAS_EINVAL, "hyperkzg_open: poly must be LargeScalars of length 2^ell");
     if (srs->len < n) return fail(ATLAS_EINVAL, "hyperkzg_open: KeyLengthError (SRS shorter than the polynomial)");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     H::Transcript& T = *reinterpret_cast<H::Transcript*>(transcript);
     const int mode = g.challenge_mode;
 

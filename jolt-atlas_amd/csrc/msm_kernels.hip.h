@@ -416,6 +416,30 @@ __global__ __launch_bounds__(MSM_THREADS) void k_g1_sum_indexed(const G1Affine* 
     if (threadIdx.x == 0) g1_store(out + blockIdx.x, sm[0]);
 }
 
+// HyperKZG::batch_commit_one_hot (hyperkzg/mod.rs:558-596): R one-hot polynomials in one launch.  blockIdx.y = polynomial;
+// polynomial r has T[r] cycles whose addresses sit at idx[off[r] .. off[r] + T[r]) (negative = None); its non-zero
+// coefficient of cycle t is the SRS point k * T + t.  One partial per workgroup: out[r * gridDim.x + blockIdx.x].
+struct OneHotRowDesc { uint32_t off, T; };
+__global__ __launch_bounds__(MSM_THREADS) void k_g1_sum_onehot_rows(const G1Affine* __restrict__ bases, const int32_t* __restrict__ idx,
+                                                                    const OneHotRowDesc* __restrict__ rows, G1Xyzz* __restrict__ out) {
+    __shared__ G1Xyzz sm[MSM_THREADS];
+    const OneHotRowDesc rd = rows[blockIdx.y];
+    G1Xyzz acc = g1_inf();
+    for (size_t t = (size_t)blockIdx.x * MSM_THREADS + threadIdx.x; t < rd.T; t += (size_t)gridDim.x * MSM_THREADS) {
+        const int32_t k = idx[rd.off + t];
+        if (k < 0) continue;
+        const G1Affine p = g1_aff_load(bases + (size_t)k * rd.T + t);
+        if (!g1_aff_is_inf(p)) acc = g1_madd(acc, p, false);
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t d = MSM_THREADS / 2; d >= 1; d >>= 1) {
+        if (threadIdx.x < d) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + d]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) g1_store(out + (size_t)blockIdx.y * gridDim.x + blockIdx.x, sm[0]);
+}
+
 // SRS generation (SRS::setup, hyperkzg/kzg.rs:26-93): out[i] = tau^(i+1) * G.
 // tau_pow2[j] = tau^(2^j) (Montgomery Fr), dbl_table[j] = 2^j * G (affine).
 __global__ __launch_bounds__(MSM_THREADS) void k_srs_generate(const Fr* __restrict__ tau_pow2,

@@ -173,7 +173,7 @@ struct DenseOpening : atlas_instance {
         if (round != round_next || round >= n) return fail(ATLAS_ESTATE, "dense_opening: round out of order");
         H::Fr q0;
         {
-            std::lock_guard<std::mutex> lk(g.mu);
+            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
             const int rc = P->is_i32 ? D.q0<int32_t>((const int32_t*)P->d, P->len / 2, &q0) : D.q0<Fr>((const Fr*)P->d, P->len / 2, &q0);
             if (rc) return rc;
         }
@@ -188,7 +188,7 @@ struct DenseOpening : atlas_instance {
             int rc = atlas_poly_bind(P, &r, ATLAS_HIGH_TO_LOW);
             if (rc) return rc;
         } else {                                                    // in place, stream-ordered, no host wait
-            std::lock_guard<std::mutex> lk(g.mu);
+            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
             const size_t half = P->len / 2;
             k_open_bind_hi<<<grid_for(half, 4096), OP_THREADS, 0, g.stream>>>((Fr*)P->d, half, to_dev(rf), g.challenge_mode == 0 ? 1 : 0);
             hipError_t e = hipGetLastError();
@@ -241,7 +241,7 @@ struct OneHotOpening : atlas_instance {
         }
         H::Fr q0;                                                    // :634-676
         {
-            std::lock_guard<std::mutex> lk(g.mu);
+            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
             const int rc = D.q0<Fr>(d_H, H_len / 2, &q0);
             if (rc) return rc;
         }
@@ -263,7 +263,7 @@ struct OneHotOpening : atlas_instance {
             for (size_t i = 0; i < F.size(); i++) { nf[2 * i + 1] = H::mul(rf, F[i]); nf[2 * i] = H::sub(F[i], nf[2 * i + 1]); }
             F.swap(nf);
             if (round == log_K - 1) {
-                std::lock_guard<std::mutex> lk(g.mu);
+                std::lock_guard<atlas_rt::Mutex> lk(g.mu);
                 const size_t T = (size_t)1 << log_T;
                 Fr* d_F = nullptr;
                 HIP_TRY(hipMalloc(&d_F, F.size() * sizeof(Fr)));
@@ -276,7 +276,7 @@ struct OneHotOpening : atlas_instance {
                 G.clear();
             }
         } else {
-            std::lock_guard<std::mutex> lk(g.mu);
+            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
             const size_t half = H_len / 2;
             k_open_bind_hi<<<grid_for(half, 4096), OP_THREADS, 0, g.stream>>>(d_H, half, to_dev(rf), g.challenge_mode == 0 ? 1 : 0);
             hipError_t e = hipGetLastError();
@@ -290,7 +290,7 @@ struct OneHotOpening : atlas_instance {
 
     int finals(std::vector<H::Fr>& out) override {
         if (round_next != rounds()) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
-        std::lock_guard<std::mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
         out.resize(1);
         HIP_TRY(hipMemcpyAsync(g.h_pinned, d_H, sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
@@ -430,7 +430,7 @@ struct OneHotRow : atlas_instance {
             return ATLAS_OK;
         }
         {
-            std::lock_guard<std::mutex> lk(g.mu);
+            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
             const int rc = grp->fold_all(round - log_K);
             if (rc) return rc;
         }
@@ -453,7 +453,7 @@ struct OneHotRow : atlas_instance {
             for (size_t i = 0; i < F.size(); i++) { nf[2 * i + 1] = H::mul(rf, F[i]); nf[2 * i] = H::sub(F[i], nf[2 * i + 1]); }
             F.swap(nf);
             if (round == log_K - 1) {                                // this row's H = F[idx]
-                std::lock_guard<std::mutex> lk(g.mu);
+                std::lock_guard<atlas_rt::Mutex> lk(g.mu);
                 const size_t T = grp->T;
                 Fr* d_F = nullptr;
                 HIP_TRY(hipMalloc(&d_F, F.size() * sizeof(Fr)));
@@ -465,7 +465,7 @@ struct OneHotRow : atlas_instance {
                 grp->G[row].clear();
             }
         } else {
-            std::lock_guard<std::mutex> lk(g.mu);
+            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
             const int rc = grp->bind_all(round - log_K, rf);
             if (rc) return rc;
         }
@@ -475,7 +475,7 @@ struct OneHotRow : atlas_instance {
 
     int finals(std::vector<H::Fr>& out) override {
         if (round_next != rounds()) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
-        std::lock_guard<std::mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
         out.resize(1);
         HIP_TRY(hipMemcpyAsync(g.h_pinned, grp->d_H + row * grp->T, sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
@@ -492,7 +492,7 @@ int atlas_dense_opening_new(atlas_poly_t poly, const atlas_fr_t* opening_point, 
     NEED_INIT();
     if (!poly || (!opening_point && n) || !out) return fail(ATLAS_EINVAL, "dense_opening_new: null argument");
     if (n == 0 || poly->len != ((size_t)1 << n)) return fail(ATLAS_EINVAL, "dense_opening_new: polynomial length != 2^n, n >= 1");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     DenseOpening* P = new DenseOpening();
     P->n = n;
     int rc = P->D.init(reinterpret_cast<const H::Fr*>(opening_point), n);
@@ -508,11 +508,13 @@ int atlas_onehot_opening_new(const int32_t* nonzero_indices, size_t log_K, size_
     if (!nonzero_indices || !r_address || !r_cycle || !out) return fail(ATLAS_EINVAL, "onehot_opening_new: null argument");
     if (log_K == 0 || log_K > 16 || log_T == 0 || log_T > 26) return fail(ATLAS_EINVAL, "onehot_opening_new: 1 <= log_K <= 16, 1 <= log_T <= 26");
     const size_t K = (size_t)1 << log_K, T = (size_t)1 << log_T;
+    for (size_t j = 0; j < T; j++)          // the reference indexes F[k] / G[k] with bounds checks (opening_reduction.rs:532-560)
+        if (nonzero_indices[j] >= (int32_t)K) return fail(ATLAS_EINVAL, "onehot_opening_new: index >= K");
     // D.merge() before any bind = EqPolynomial::evals(r_cycle) (scalar 1): device table for the histogram
     atlas_poly_t E = nullptr;
     int rc = atlas_eq_evals(r_cycle, log_T, nullptr, &E);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     OneHotOpening* P = new OneHotOpening();
     P->log_K = log_K; P->log_T = log_T;
     P->B = H::eq_evals(reinterpret_cast<const H::Fr*>(r_address), log_K);   // EqAddressState::new
@@ -552,10 +554,15 @@ int atlas_onehot_opening_group_new(const int32_t* const* nonzero_indices, size_t
     if (!nonzero_indices || !r_addresses || !r_cycle || !out || R == 0) return fail(ATLAS_EINVAL, "onehot_opening_group_new: null argument");
     if (log_K == 0 || log_K > 16 || log_T == 0 || log_T > 26) return fail(ATLAS_EINVAL, "onehot_opening_group_new: 1 <= log_K <= 16, 1 <= log_T <= 26");
     const size_t K = (size_t)1 << log_K, T = (size_t)1 << log_T;
+    for (size_t r = 0; r < R; r++) {
+        if (!nonzero_indices[r]) return fail(ATLAS_EINVAL, "onehot_opening_group_new: null index row");
+        for (size_t j = 0; j < T; j++)
+            if (nonzero_indices[r][j] >= (int32_t)K) return fail(ATLAS_EINVAL, "onehot_opening_group_new: index >= K");
+    }
     atlas_poly_t E = nullptr;
     int rc = atlas_eq_evals(r_cycle, log_T, nullptr, &E);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     OneHotGroup* Gp = new OneHotGroup();
     Gp->R = R; Gp->log_K = log_K; Gp->log_T = log_T; Gp->T = T; Gp->H_len = T;
     Fr* d_G = nullptr;

@@ -314,7 +314,7 @@ struct PsLookup : atlas_instance {
             H::unipoly_from_evals_and_hint(claim, ev, 2, coeffs.data());
             return ATLAS_OK;
         }
-        std::lock_guard<std::mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
         const size_t n_groups = rows.len / 2;
         size_t blocks = (n_groups + RA_THREADS - 1) / RA_THREADS; if (blocks > 2048) blocks = 2048;
         k_ps_fold<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(rows.buf[rows.cur], eq.view(), n_groups, rows.partials);
@@ -357,7 +357,7 @@ struct PsLookup : atlas_instance {
             }
             r_addr.push_back(rf);
             if ((j + 1) % log_m == 0) {                               // phase boundary: fold v_p into the products
-                std::lock_guard<std::mutex> lk(g.mu);
+                std::lock_guard<atlas_rt::Mutex> lk(g.mu);
                 HIP_TRY(hipMemcpyAsync(d_v, v.data(), m * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
                 size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
                 k_ps_scale<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(d_idx, d_v, T, (uint32_t)((phases - 1 - p) * log_m), (uint32_t)(m - 1), rows.buf[0]);
@@ -380,7 +380,7 @@ struct PsLookup : atlas_instance {
                 rows.cur = 0; rows.stride[0] = T; rows.len = T;       // the products are ra (init_log_t_rounds)
             }
         } else {
-            std::lock_guard<std::mutex> lk(g.mu);
+            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
             int rc = rows.bind(r);
             if (rc) return rc;
             eq.st.bind(rf);
@@ -390,7 +390,7 @@ struct PsLookup : atlas_instance {
     }
     int finals(std::vector<H::Fr>& out) override {
         if (round_next != rounds()) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
-        std::lock_guard<std::mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
         return rows.finals(out);
     }
 };
@@ -421,7 +421,7 @@ static int ps_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, si
     atlas_poly_t E = nullptr;
     int rc = atlas_eq_evals(r_node_output, log_T, nullptr, &E);      // u_evals = EqPolynomial::evals(r_node_output), mod.rs:234
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     PsLookup* P = new PsLookup();
     P->N = log_K; P->phases = phases; P->mode = mode; P->bound = bound; P->symmetric = symmetric;
     P->log_m = log_K / phases; P->m = (size_t)1 << P->log_m; P->log_T = log_T; P->T = (size_t)1 << log_T;
@@ -497,7 +497,7 @@ int atlas_u64_upload(const uint64_t* host, size_t n, uint64_t** d_out) {
     uint64_t* d = nullptr;
     hipError_t e = hipMalloc(&d, n * sizeof(uint64_t));
     if (e != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(u64)", e);
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     e = hipMemcpyAsync(d, host, n * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
     if (e != hipSuccess) { hipFree(d); return fail(ATLAS_ENODEV, "u64_upload", e); }
@@ -516,7 +516,7 @@ int atlas_lookup_indices_from_operands(const int32_t* d_left, const int32_t* d_r
     uint64_t* d = nullptr;
     hipError_t e = hipMalloc(&d, n * sizeof(uint64_t));
     if (e != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(lookup indices)", e);
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     size_t gb = (n + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
     k_lookup_indices<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(d_left, d_right, n, d);
     e = hipStreamSynchronize(g.stream);

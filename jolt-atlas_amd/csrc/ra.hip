@@ -162,7 +162,7 @@ struct RaVirtual : atlas_instance {
     size_t degree() const override { return rows.d + 1; }
     int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
         if (round != round_next || round >= log_T) return fail(ATLAS_ESTATE, "ra_virtual: round out of order");
-        std::lock_guard<std::mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
         const size_t n_groups = rows.len / 2;
         const unsigned blocks = (unsigned)((n_groups + RA_THREADS - 1) / RA_THREADS);
         const SplitEqView E = eq.view();
@@ -185,14 +185,14 @@ struct RaVirtual : atlas_instance {
     }
     int ingest(const atlas_u128_t& r, size_t round) override {
         if (round != round_next || round >= log_T) return fail(ATLAS_ESTATE, "ra_virtual: round out of order");
-        std::lock_guard<std::mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
         int rc = rows.bind(r);
         if (rc) return rc;
         eq.st.bind(H::challenge_to_fr(r.lo, r.hi, g.challenge_mode));
         round_next++;
         return ATLAS_OK;
     }
-    int finals(std::vector<H::Fr>& out) override { std::lock_guard<std::mutex> lk(g.mu); return rows.finals(out); }
+    int finals(std::vector<H::Fr>& out) override { std::lock_guard<atlas_rt::Mutex> lk(g.mu); return rows.finals(out); }
 };
 
 // upload d host tables of K Fr each
@@ -252,7 +252,7 @@ struct Booleanity : atlas_instance {
             H::gruen_deg3(B, q0, qinf, claim, coeffs.data());
             return ATLAS_OK;
         }
-        std::lock_guard<std::mutex> lk(g.mu);                        // compute_phase2_message
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);                        // compute_phase2_message
         const size_t n_groups = rows.len / 2;
         size_t blocks = (n_groups + RA_THREADS - 1) / RA_THREADS; if (blocks > 2048) blocks = 2048;
         const unsigned ysplit = n_groups <= ((size_t)1 << 13) ? (unsigned)d : 1u;   // latency regime: one row per thread
@@ -280,7 +280,7 @@ struct Booleanity : atlas_instance {
             F.resize(2 * n);
             for (size_t x = 0; x < n; x++) { F[n + x] = H::mul(F[x], rf); F[x] = H::sub(F[x], F[n + x]); }
             if (round == log_k - 1) {
-                std::lock_guard<std::mutex> lk(g.mu);
+                std::lock_guard<atlas_rt::Mutex> lk(g.mu);
                 eq_r_r = B.scalar;
                 Fr* d_F = nullptr;
                 HIP_TRY(hipMalloc(&d_F, F.size() * sizeof(Fr)));
@@ -291,7 +291,7 @@ struct Booleanity : atlas_instance {
                 G.clear();
             }
         } else {
-            std::lock_guard<std::mutex> lk(g.mu);
+            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
             D.st.bind(rf);
             int rc = rows.bind(r);
             if (rc) return rc;
@@ -299,7 +299,7 @@ struct Booleanity : atlas_instance {
         round_next++;
         return ATLAS_OK;
     }
-    int finals(std::vector<H::Fr>& out) override { std::lock_guard<std::mutex> lk(g.mu); return rows.finals(out); }
+    int finals(std::vector<H::Fr>& out) override { std::lock_guard<atlas_rt::Mutex> lk(g.mu); return rows.finals(out); }
 };
 
 // ---------------------------------------------------------------- HammingWeightSumcheckProver (host: d x 2^log_k)
@@ -372,7 +372,7 @@ static int ra_virtual_build(const int32_t* const* H_indices, const uint64_t* loo
     if (!r_address_chunks || (!r_cycle && log_T) || !out) return fail(ATLAS_EINVAL, "ra_virtual_new: null argument");
     if (d == 0 || d > RA_MAX_D) return fail(ATLAS_EINVAL, "ra_virtual_new: d must be in 1..16");
     if (log_k_chunk > 16 || log_T == 0 || log_T > 25) return fail(ATLAS_EINVAL, "ra_virtual_new: log_k_chunk <= 16, 1 <= log_T <= 25");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     RaVirtual* P = new RaVirtual();
     P->log_T = log_T;
     const size_t K = (size_t)1 << log_k_chunk, T = (size_t)1 << log_T;
@@ -416,7 +416,7 @@ static int booleanity_build(const atlas_fr_t* G, const int32_t* const* H_indices
     if (!G || !gammas || !r_address || (!r_cycle && log_T) || !out) return fail(ATLAS_EINVAL, "booleanity_new: null argument");
     if (d == 0 || log_k_chunk == 0 || log_k_chunk > 16 || log_T == 0 || log_T > 25)
         return fail(ATLAS_EINVAL, "booleanity_new: 1 <= log_k_chunk <= 16, 1 <= log_T <= 25");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     Booleanity* P = new Booleanity();
     P->d = d; P->log_k = log_k_chunk; P->log_T = log_T;
     const size_t K = (size_t)1 << log_k_chunk, T = (size_t)1 << log_T;

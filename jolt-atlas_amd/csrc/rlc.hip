@@ -59,14 +59,17 @@ __global__ __launch_bounds__(RLC_THREADS) void k_rlc_dense(const RlcDense* __res
 struct RlcOneHot {
     const int32_t* k;   // T entries on the device, negative = None
     Fr coeff;
+    uint32_t K;         // address-space size: an index >= K is rejected (the reference panics on the slice bound)
+    uint32_t pad;
 };
 
 __global__ __launch_bounds__(RLC_THREADS) void k_rlc_onehot(const RlcOneHot* __restrict__ polys, uint32_t n_polys, size_t T,
-                                                            Fr* __restrict__ joint) {
+                                                            Fr* __restrict__ joint, uint32_t* __restrict__ bad) {
     for (size_t t = (size_t)blockIdx.x * RLC_THREADS + threadIdx.x; t < T; t += (size_t)gridDim.x * RLC_THREADS) {
         for (uint32_t j = 0; j < n_polys; j++) {
             const int32_t k = polys[j].k[t];
             if (k < 0) continue;
+            if ((uint32_t)k >= polys[j].K) { *bad = 1u; continue; }
             Fr* dst = joint + (size_t)k * T + t;
             fe_store(dst, fr_add(fe_load(dst), polys[j].coeff));
         }
@@ -84,7 +87,7 @@ extern "C" int atlas_rlc_build(const atlas_rlc_dense_t* dense, size_t n_dense, c
                                size_t n_onehot, atlas_poly_t* out) {
     NEED_INIT();
     if (!out || (n_dense && !dense) || (n_onehot && !onehot)) return fail(ATLAS_EINVAL, "rlc_build: null argument");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     size_t joint_len = 0;
     for (size_t j = 0; j < n_dense; j++) {
         if (!dense[j].poly) return fail(ATLAS_EINVAL, "rlc_build: null dense polynomial");
@@ -128,12 +131,20 @@ extern "C" int atlas_rlc_build(const atlas_rlc_dense_t* dense, size_t n_dense, c
         if (onehot[j].T) groups[onehot[j].T].push_back(j);
     std::vector<void*> to_free;
     int rc = ATLAS_OK;
+    uint32_t* d_bad = nullptr;
+    if (!groups.empty()) {
+        e = hipMalloc(&d_bad, 4);
+        if (e != hipSuccess) { if (d_dense) hipFree(d_dense); return bail(fail(ATLAS_ENOMEM, "hipMalloc(rlc flag)", e)); }
+        to_free.push_back(d_bad);
+        hipMemsetAsync(d_bad, 0, 4, g.stream);
+    }
     for (auto& kv : groups) {
         const size_t T = kv.first;
         std::vector<RlcOneHot> ho(kv.second.size());
         for (size_t q = 0; q < kv.second.size() && rc == ATLAS_OK; q++) {
             const atlas_rlc_onehot_t& O = onehot[kv.second[q]];
             std::memcpy(&ho[q].coeff, &O.coeff, 32);
+            ho[q].K = (uint32_t)O.K; ho[q].pad = 0;
             if (O.k_on_device) ho[q].k = O.k;
             else {
                 int32_t* dk = nullptr;
@@ -152,10 +163,13 @@ extern "C" int atlas_rlc_build(const atlas_rlc_dense_t* dense, size_t n_dense, c
         hipMemcpyAsync(d_oh, ho.data(), ho.size() * sizeof(RlcOneHot), hipMemcpyHostToDevice, g.stream);
         // the H2D copies above read pageable host memory that goes out of scope: drain before reuse
         hipStreamSynchronize(g.stream);
-        k_rlc_onehot<<<grid_for(T), RLC_THREADS, 0, g.stream>>>(d_oh, (uint32_t)ho.size(), T, joint);
+        k_rlc_onehot<<<grid_for(T), RLC_THREADS, 0, g.stream>>>(d_oh, (uint32_t)ho.size(), T, joint, d_bad);
     }
     hipError_t le = hipGetLastError();
+    uint32_t h_bad = 0;
+    if (d_bad && rc == ATLAS_OK) hipMemcpyAsync(&h_bad, d_bad, 4, hipMemcpyDeviceToHost, g.stream);
     hipStreamSynchronize(g.stream);
+    if (h_bad && rc == ATLAS_OK) rc = fail(ATLAS_EINVAL, "rlc_build: one-hot index >= K");
     for (void* p : to_free) hipFree(p);
     if (d_dense) hipFree(d_dense);
     if (rc) return bail(rc);

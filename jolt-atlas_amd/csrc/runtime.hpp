@@ -25,6 +25,10 @@ struct atlas_poly {
 
 namespace atlas_rt {
 
+// one lock serialises the entry points that touch the shared stream scratch; recursive because entry points call each
+// other (final_claims -> poly_download)
+using Mutex = std::recursive_mutex;
+
 struct Runtime {
     bool ready = false;
     int device = -1;
@@ -34,7 +38,6 @@ struct Runtime {
     Channel chan;                      // round channel (pinned mailboxes + challenge slots), ATLAS_FS_HOST
     bool timing = false;
     atlas_timing_t last_timing{};
-    std::string err;
     atlas::Fe* d_partials = nullptr;   // SC_MAX_BLOCKS * 3 Fr
     atlas::ScCtx* d_ctx = nullptr;
     atlas::Fe* d_proof = nullptr;      // up to 64 rounds * 3
@@ -42,7 +45,7 @@ struct Runtime {
     atlas::Fe* d_finals = nullptr;     // 3 (+ scratch for reduced evals)
     void* h_pinned = nullptr;          // pinned staging for small D2H/H2D
     std::vector<void (*)()> at_shutdown;   // release hooks of the translation units that keep device arenas
-    std::mutex mu;
+    Mutex mu;
 };
 extern Runtime g;
 

@@ -146,7 +146,7 @@ int atlas_shout_read_raf_G(const uint64_t* lookup_indices, size_t T, size_t log_
     if ((!lookup_indices && T) || !eq_r || !out || log_K > 24) return fail(ATLAS_EINVAL, "shout_read_raf_G");
     for (size_t j = 0; j < T; j++)
         if (lookup_indices[j] >> log_K) return fail(ATLAS_EINVAL, "shout_read_raf_G: lookup index outside the table");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     return histogram(lookup_indices, T, KeySpec{1u, (uint32_t)log_K}, eq_r, out);
 }
 
@@ -156,7 +156,7 @@ int atlas_shout_ra_evals(const uint64_t* lookup_indices, size_t T, size_t log_K,
     if ((!lookup_indices && T) || !eq_r_cycle || !out || log_k_chunk == 0 || log_k_chunk > 16 || log_K == 0 || log_K > 64)
         return fail(ATLAS_EINVAL, "shout_ra_evals");
     const uint32_t d = (uint32_t)((log_K + log_k_chunk - 1) / log_k_chunk);     // instruction_d (config.rs:45)
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     return histogram(lookup_indices, T, KeySpec{d, (uint32_t)log_k_chunk}, eq_r_cycle, out);
 }
 
@@ -168,7 +168,7 @@ int atlas_shout_read_raf_prover_new(atlas_poly_t G, const int32_t* table, size_t
     if (G->is_i32 || G->len != K) return fail(ATLAS_EINVAL, "shout_read_raf_prover_new: G length != table size");
     int32_t* d_tab = nullptr; Fe* W = nullptr;
     {
-        std::lock_guard<std::mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
         HIP_TRY(hipMalloc(&d_tab, K * 4));
         hipError_t e = hipMalloc(&W, K * sizeof(Fe));
         if (e != hipSuccess) { hipFree(d_tab); return fail(ATLAS_ENOMEM, "hipMalloc(W)", e); }

@@ -110,7 +110,7 @@ struct Softmax : atlas_instance {
 
     int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
         if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "softmax: round out of order");
-        std::lock_guard<std::mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
         const size_t half = rows.len / 2;
         size_t blocks = (half + RA_THREADS - 1) / RA_THREADS; if (blocks > 1024) blocks = 1024;
         const Fr* a = rows.buf[rows.cur]; const Fr* b = a + rows.stride[rows.cur];
@@ -157,7 +157,7 @@ struct Softmax : atlas_instance {
 
     int ingest(const atlas_u128_t& r, size_t round) override {
         if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "softmax: round out of order");
-        std::lock_guard<std::mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
         const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
         int rc;
         if (kind == SM_SUM_AXIS) {                 // HighToLow, out of place between the two row buffers
@@ -179,7 +179,7 @@ struct Softmax : atlas_instance {
 
     int finals(std::vector<H::Fr>& out) override {
         if (round_next != rounds()) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
-        std::lock_guard<std::mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
         int rc = rows.finals(out);
         if (rc || kind != SM_RECIP_MULT) return rc;
         std::vector<H::Fr> o2;
@@ -212,7 +212,7 @@ int atlas_softmax_instance_new(int kind, atlas_poly_t a, atlas_poly_t b, size_t 
     if (a->len != T) return fail(ATLAS_EINVAL, "softmax_instance_new: operand length != 2^(log_K + log_N)");
     if ((kind == SM_MAX_INDICATOR && (!b || b->len != T)) || (kind == SM_RECIP_MULT && (!b || b->len != K)) || (kind == SM_EXP_SUM && b))
         return fail(ATLAS_EINVAL, "softmax_instance_new: second operand: e of 2^(log_K + log_N) for MaxIndicator, inv_sum of 2^log_K for RecipMult, none for ExpSum");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     Softmax* P = new Softmax();
     P->kind = kind; P->log_K = log_K; P->log_N = log_N;
     int rc = P->rows.alloc(kind == SM_MAX_INDICATOR ? 2 : 1, T, 3);

@@ -88,7 +88,7 @@ extern "C" {
 int atlas_eq_evals(const atlas_fr_t* r, size_t n, const atlas_fr_t* scaling, atlas_poly_t* out) {
     NEED_INIT();
     if ((!r && n) || !out || n > 30) return fail(ATLAS_EINVAL, "eq_evals");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     Fr* ev = nullptr;
     int rc = eq_evals_device(reinterpret_cast<const H::Fr*>(r), n, reinterpret_cast<const H::Fr*>(scaling), &ev);
     if (rc) return rc;
@@ -102,7 +102,7 @@ int atlas_poly_evaluate(atlas_poly_t p, const atlas_fr_t* r, size_t n, atlas_fr_
     NEED_INIT();
     if (!p || (!r && n) || !out) return fail(ATLAS_EINVAL, "poly_evaluate");
     if (p->len != ((size_t)1 << n)) return fail(ATLAS_EINVAL, "poly_evaluate: point length != num_vars");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     // DensePolynomial::evaluate: r = (r2 | r1), eq_one = evals(r2) outer, eq_two = evals(r1) inner
     const size_t m = n / 2;
     const H::Fr* rr = reinterpret_cast<const H::Fr*>(r);
@@ -134,7 +134,7 @@ int atlas_mul_prover_new(atlas_poly_t left, atlas_poly_t right, const atlas_fr_t
         return fail(ATLAS_EINVAL, "mul_prover_new: operand length must be 2^n, n >= 1");
     if (left->is_i32 != right->is_i32) return fail(ATLAS_EINVAL, "mul_prover_new: mixed operand types");
     if (n / 2 > 12 || n - 1 - n / 2 > 12) return fail(ATLAS_EINVAL, "mul_prover_new: n > 25 not supported");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     atlas_mul_prover* P = new atlas_mul_prover();
     P->left = left; P->right = right; P->n = n; P->m = n / 2;
     P->w.assign(reinterpret_cast<const H::Fr*>(w), reinterpret_cast<const H::Fr*>(w) + n);
@@ -178,7 +178,7 @@ int atlas_mul_input_claim(atlas_mul_prover_t P, atlas_fr_t* out) {
     NEED_INIT();
     if (!P || !out) return fail(ATLAS_EINVAL, "mul_input_claim");
     if (P->consumed || P->left->len != ((size_t)1 << P->n)) return fail(ATLAS_ESTATE, "mul_input_claim: instance already bound");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     // s(0) + s(1) of round 0: eq0*q0 + eq1*q1 with the round-0 sums
     const ScConsts K = make_consts();
     const size_t groups = P->left->len / 2;
@@ -205,7 +205,7 @@ int atlas_sumcheck_prove_mul(atlas_mul_prover_t P, const atlas_fr_t* input_claim
     if (!P || !input_claim || !transcript || !compressed_polys || !challenges || !final_claims)
         return fail(ATLAS_EINVAL, "sumcheck_prove_mul: null argument");
     if (P->consumed || P->left->len != ((size_t)1 << P->n)) return fail(ATLAS_ESTATE, "sumcheck_prove_mul: prover already consumed");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     const ScConsts K = make_consts();
     const size_t n = P->n;
     const int mode = g.challenge_mode;
@@ -289,7 +289,7 @@ int atlas_mul_compute_message(atlas_mul_prover_t P, size_t round, const atlas_fr
     NEED_INIT();
     if (!P || !previous_claim || !coeffs_out || !n_coeffs) return fail(ATLAS_EINVAL, "mul_compute_message");
     if (P->consumed || round >= P->n || P->left->len != ((size_t)1 << (P->n - round))) return fail(ATLAS_ESTATE, "mul_compute_message: round out of order");
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     const ScConsts K = make_consts();
     const size_t groups = P->left->len / 2;
     const int grid = grid_for(groups);

@@ -44,3 +44,57 @@ def prove_reduced_openings(openings, srs, transcript):
     assert mr.value == max_rounds
     return ([rows[i, :nco[i]].copy() for i in range(max_rounds)], [int(ch[2 * i]) | (int(ch[2 * i + 1]) << 64) for i in range(max_rounds)],
             claims, com[:max_rounds - 1], w, v.reshape(3, max_rounds, 4))
+
+
+class ProverOpeningAccumulator:
+    """ProverOpeningAccumulator (opening_proof.rs:195-643) over atlas_accumulator_*; keys are u64 in the Ord of the Rust keys."""
+
+    def __init__(self):
+        self.h = C.c_void_p()
+        _check(lib.atlas_accumulator_new(C.byref(self.h)))
+        self._keep = []
+
+    def append_dense(self, transcript, opening_key, poly_key, poly, point, claim):
+        pt = np.ascontiguousarray(point, dtype=np.uint64); c = _fr(claim)
+        self._keep.append(poly)
+        _check(lib.atlas_accumulator_append_dense(self.h, C.byref(transcript.t), C.c_uint64(opening_key), C.c_uint64(poly_key), poly.h,
+                                                  _p(pt), C.c_size_t(len(pt)), _p(c)))
+
+    def append_sparse(self, transcript, opening_keys, poly_keys, index_rows, log_K, r_address, r_cycle, claims):
+        rows = [np.ascontiguousarray(r, dtype=np.int32) for r in index_rows]
+        R = len(rows)
+        ptrs = (C.c_void_p * R)(*[r.ctypes.data for r in rows])
+        ok = (C.c_uint64 * R)(*opening_keys); pk = (C.c_uint64 * R)(*poly_keys)
+        ra = np.ascontiguousarray(r_address, dtype=np.uint64); rc = np.ascontiguousarray(r_cycle, dtype=np.uint64)
+        cl = np.ascontiguousarray(np.stack([_fr(c).reshape(4) for c in claims]), dtype=np.uint64)
+        _check(lib.atlas_accumulator_append_sparse(self.h, C.byref(transcript.t), ok, pk, ptrs, C.c_size_t(R), C.c_size_t(log_K),
+                                                   C.c_size_t(len(rc)), _p(ra), _p(rc), _p(cl)))
+
+    def append_virtual(self, transcript, opening_key, point, claim):
+        pt = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4); c = _fr(claim)
+        _check(lib.atlas_accumulator_append_virtual(self.h, C.byref(transcript.t), C.c_uint64(opening_key), _p(pt), C.c_size_t(len(pt)), _p(c)))
+
+    def get(self, opening_key):
+        pt = np.zeros((64, 4), dtype=np.uint64); n = C.c_size_t(); c = np.zeros(4, dtype=np.uint64)
+        _check(lib.atlas_accumulator_get(self.h, C.c_uint64(opening_key), _p(pt), C.c_size_t(64), C.byref(n), _p(c)))
+        return pt[:n.value].copy(), c
+
+    def prove_reduced_openings(self, srs, transcript):
+        lib.atlas_accumulator_max_rounds.restype = C.c_size_t
+        lib.atlas_accumulator_num_committed.restype = C.c_size_t
+        max_rounds = lib.atlas_accumulator_max_rounds(self.h); n = lib.atlas_accumulator_num_committed(self.h)
+        rows = np.zeros((max_rounds, 3, 4), dtype=np.uint64); nco = np.zeros(max_rounds, dtype=np.uint32)
+        ch = np.zeros(2 * max_rounds, dtype=np.uint64); mr = C.c_size_t()
+        claims = np.zeros((n, 4), dtype=np.uint64)
+        com = np.zeros(max(max_rounds - 1, 1), dtype=G1_DTYPE); w = np.zeros(3, dtype=G1_DTYPE)
+        v = np.zeros((3 * max_rounds, 4), dtype=np.uint64)
+        _check(lib.atlas_accumulator_prove_reduced_openings(self.h, srs.h, C.byref(transcript.t), _p(rows), nco.ctypes.data_as(C.c_void_p),
+                                                            _p(ch), C.byref(mr), _p(claims), com.ctypes.data_as(C.c_void_p),
+                                                            w.ctypes.data_as(C.c_void_p), _p(v)))
+        return ([rows[i, :nco[i]].copy() for i in range(max_rounds)], [int(ch[2 * i]) | (int(ch[2 * i + 1]) << 64) for i in range(max_rounds)],
+                claims, com[:max_rounds - 1], w, v.reshape(3, max_rounds, 4))
+
+    def free(self):
+        if self.h:
+            lib.atlas_accumulator_free(self.h)
+            self.h = None

@@ -71,6 +71,12 @@ def test_einsum_mk_kn_mn_instance(atlas):
     tA, tB = A_.TensorI32(A), A_.TensorI32(B)
     left, right = A_.fold_cols(tA, eq_m), A_.fold_rows(tB, eq_n)
     Lh, Rh = left.to_host(), right.to_host()
+    from jolt_atlas_amd import einsum_layouts as EL           # the layout entry point gives the same operands
+    l2, r2 = EL.fold_mk_kn_mn(tA, tB, m, k, n, eq_m, eq_n)
+    assert np.array_equal(l2.to_host(), Lh) and np.array_equal(r2.to_host(), Rh)
+    l2.free(); r2.free()
+    with pytest.raises(A_.AtlasError):
+        EL.einsum_fold(EL.MK_KN_MN, (m, k), tA, tB, eq_m, eq_n)          # wrong number of dims
     assert np.array_equal(Lh, _orc_fold(orc, A, orc.eq_evals(r_m), "cols"))
     assert np.array_equal(Rh, _orc_fold(orc, B, orc.eq_evals(r_n), "rows"))
     # claim = MLE of the integer matmul at (r_m | r_n)

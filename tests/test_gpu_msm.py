@@ -126,3 +126,74 @@ def test_msm_large_trapdoor_identity(atlas, log_n):
     k = orc.fr_mul_arr(k[0], tau)
     assert orc.g1_eq(got, orc.g1_mul_generator(k))
     s.free()
+
+
+def test_commit_one_hot_batch_matches_single_commits(atlas, srs_small):
+    """HyperKZG::batch_commit_one_hot (hyperkzg/mod.rs:558-596) = commit_one_hot per polynomial; ragged T, None entries,
+    an all-None polynomial (-> infinity) and an empty batch."""
+    from oracle import orc
+    s, ref = srs_small
+    rng = np.random.default_rng(5)
+    shapes = [(16, 128), (16, 128), (4, 64), (8, 256), (2, 1)]
+    rows, Ks = [], []
+    for K, T in shapes:
+        r = rng.integers(0, K, size=T, dtype=np.int32)
+        r[rng.random(T) < 0.2] = -1
+        rows.append(r); Ks.append(K)
+    rows.append(np.full(32, -1, dtype=np.int32)); Ks.append(4)
+    got = s.commit_one_hot_batch(rows, Ks)
+    for r, K, g_ in zip(rows, Ks, got):
+        T = len(r)
+        flat = np.array([int(k) * T + t for t, k in enumerate(r) if k >= 0], dtype=np.uint32)
+        want = s.sum_indexed(flat)
+        assert orc.g1_eq(g_, want)
+        if len(flat):
+            assert orc.g1_eq(g_, orc.g1_sum_indexed(ref, flat)) if hasattr(orc, "g1_sum_indexed") else True
+    assert bool(got[-1]["infinity"])
+    assert len(s.commit_one_hot_batch([], [])) == 0
+    with pytest.raises(atlas.AtlasError):
+        s.commit_one_hot_batch([np.array([5], dtype=np.int32)], [4])           # index >= K
+    with pytest.raises(atlas.AtlasError):
+        s.commit_one_hot_batch([np.zeros(1024, dtype=np.int32)], [16])          # K*T beyond the SRS
+
+
+def test_commit_batch_matches_single_commits(atlas, srs_small):
+    """CommitmentScheme::batch_commit: LargeScalars of mixed lengths share one pipeline, I32Scalars take the narrow plan."""
+    from oracle import orc
+    s, ref = srs_small
+    rng = np.random.default_rng(6)
+    polys = [atlas.MultilinearPolynomial.from_fr(orc.random_fr(n, 300 + n)) for n in (2048, 1024, 16, 2048, 2)]
+    polys.insert(2, atlas.MultilinearPolynomial.from_i32(rng.integers(-(1 << 14), 1 << 14, size=512, dtype=np.int32)))
+    got = s.commit_batch(polys)
+    for p_, g_ in zip(polys, got):
+        assert orc.g1_eq(g_, s.msm(p_))
+    one = s.commit_batch(polys[:1])
+    assert orc.g1_eq(one[0], got[0])
+    for p_ in polys:
+        p_.free()
+
+
+def test_concurrent_commits_match_serial(atlas, srs_small):
+    """commit is called from Rayon workers (prover.rs:242-248): 8 threads committing at once give the serial results."""
+    import threading
+    from oracle import orc
+    s, ref = srs_small
+    polys = [atlas.MultilinearPolynomial.from_fr(orc.random_fr(1024, 900 + i)) for i in range(8)]
+    serial = [s.msm(p_) for p_ in polys]
+    out, errs = [None] * 8, []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                out[i] = s.msm(polys[i])
+        except Exception as e:          # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs
+    for a, b in zip(out, serial):
+        assert orc.g1_eq(a, b)
+    for p_ in polys:
+        p_.free()

@@ -94,3 +94,51 @@ def test_prove_reduced_openings_bit_exact(atlas, shape):
     y = orc.evaluate(joint, np.ascontiguousarray(rs))
     assert orc.hyperkzg_verify_trapdoor(srs_h, tau, Cj, ch_g, y, com_g, w_g, v_g, t_before_open)
     srs.free()
+
+
+def test_accumulator_matches_manual_composition(atlas):
+    """ProverOpeningAccumulator::{append_dense, append_sparse, append_virtual} (opening_proof.rs:265-409) + the reduced-openings
+    stage through atlas_accumulator_* = the same transcript appends done by hand + atlas_prove_reduced_openings; the openings come
+    back out of the map; keys order the committed polynomials like BTreeMap<CommittedPoly>."""
+    from oracle import orc
+    from jolt_atlas_amd import reduced
+    A = atlas
+    tau = orc.random_fr(1, 0x51250001)[0]
+    srs = A.SRS.generate(tau, 1 << 11)
+    p0, pt0 = orc.random_fr(1 << 10, 1), orc.random_fr(10, 2)
+    p1, pt1 = orc.random_fr(1 << 8, 3), orc.random_fr(8, 4)
+    c0, c1 = orc.evaluate(p0, pt0), orc.evaluate(p1, pt1)
+    log_K, log_T = 4, 7
+    ks = [_onehot(1 << log_T, 1 << log_K, 60 + j) for j in range(3)]
+    ra, rc = orc.random_fr(log_K, 7), orc.random_fr(log_T, 8)
+    Fa = orc.eq_evals(ra)
+    cs = [orc.evaluate(np.stack([Fa[x] if x >= 0 else np.zeros(4, dtype=np.uint64) for x in k]), rc) for k in ks]
+    vpt, vclaim = orc.random_fr(5, 9), orc.random_fr(1, 10)[0]
+    d0, d1 = A.MultilinearPolynomial.from_fr(p0), A.MultilinearPolynomial.from_fr(p1)
+    # accumulator: poly keys chosen so that CommittedPoly order = one-hot rows 0..2 (keys 1..3), then p1 (5), then p0 (9);
+    # appended in another order
+    acc = reduced.ProverOpeningAccumulator()
+    t_a = A.Blake2bTranscript(b"acc")
+    acc.append_dense(t_a, 100, 9, d0, pt0, c0)
+    acc.append_virtual(t_a, 50, vpt, vclaim)
+    acc.append_sparse(t_a, [201, 202, 203], [1, 2, 3], ks, log_K, ra, rc, cs)
+    acc.append_dense(t_a, 101, 5, d1, pt1, c1)
+    got_pt, got_c = acc.get(50)
+    assert np.array_equal(got_pt, vpt) and np.array_equal(got_c, vclaim)
+    got_pt, got_c = acc.get(202)
+    assert np.array_equal(got_pt, np.concatenate([ra, rc])) and np.array_equal(got_c, cs[1])
+    with pytest.raises(A.AtlasError):
+        acc.get(999)
+    out_a = acc.prove_reduced_openings(srs, t_a)
+    # by hand
+    t_m = A.Blake2bTranscript(b"acc")
+    for c in (c0, vclaim, *cs, c1):
+        t_m.append_scalar(c)
+    ops = [dict(k=k, log_K=log_K, r_address=ra, r_cycle=rc, claim=c) for k, c in zip(ks, cs)]
+    ops += [dict(poly=d1, point=pt1, claim=c1), dict(poly=d0, point=pt0, claim=c0)]
+    out_m = reduced.prove_reduced_openings(ops, srs, t_m)
+    assert out_a[1] == out_m[1] and all(np.array_equal(a, b) for a, b in zip(out_a[0], out_m[0]))
+    assert np.array_equal(out_a[2], out_m[2]) and np.array_equal(out_a[5], out_m[5])
+    assert all(orc.g1_eq(a, b) for a, b in zip(out_a[3], out_m[3])) and all(orc.g1_eq(a, b) for a, b in zip(out_a[4], out_m[4]))
+    assert t_a.state == t_m.state
+    acc.free(); d0.free(); d1.free(); srs.free()
