@@ -546,6 +546,33 @@ int atlas_accumulator_prove_reduced_openings(atlas_accumulator_t a, atlas_srs_t 
 int atlas_transcript_append_point(atlas_transcript_t *t, const atlas_g1_affine_t *p);
 int atlas_transcript_append_points(atlas_transcript_t *t, const atlas_g1_affine_t *p, size_t n);
 
+/* ---- wire formats: ark-serialize 0.5 `serialize_compressed` images, so that proofs and SRS files can be
+ *      exchanged with the reference (jolt-atlas-core/src/onnx_proof/proof_serialization.rs:29-224 composes these) -------
+ * Fr: 32 B LE canonical.  G1Affine compressed: x 32 B LE, last byte bit 7 = y is the larger of (y, -y), bit 6 = infinity;
+ * uncompressed: x || y with the flags on y's last byte.  Vec<T>: u64 LE length + items.  Deserializers validate like
+ * Validate::Yes (range, on-curve; BN254 G1 has cofactor 1) and return ATLAS_EINVAL on malformed input. */
+int atlas_fr_to_bytes(const atlas_fr_t *a, uint8_t out[32]);
+int atlas_fr_from_bytes(const uint8_t in[32], atlas_fr_t *out);
+int atlas_g1_to_bytes_compressed(const atlas_g1_affine_t *p, uint8_t out[32]);
+int atlas_g1_from_bytes_compressed(const uint8_t in[32], atlas_g1_affine_t *out);
+int atlas_g1_to_bytes_uncompressed(const atlas_g1_affine_t *p, uint8_t out[64]);
+/* SumcheckInstanceProof { compressed_polys: Vec<CompressedUniPoly> } (sumcheck.rs:624-640; unipoly.rs:27-30):
+ * rows[i*row_stride ..] = the n_coeffs[i] coefficients-except-linear of round i.  out == NULL: size query into *len. */
+int atlas_sumcheck_proof_serialize(const atlas_fr_t *rows, size_t row_stride, const uint32_t *n_coeffs, size_t n_rounds,
+                                   uint8_t *out, size_t cap, size_t *len);
+int atlas_sumcheck_proof_deserialize(const uint8_t *in, size_t len, atlas_fr_t *rows, size_t row_stride,
+                                     uint32_t *n_coeffs, size_t max_rounds, size_t *n_rounds, size_t *consumed);
+/* HyperKZGProof { com, w, v } (hyperkzg/mod.rs:172-177); 368 bytes at ell = 2 (hyperkzg/tests.rs:107-109) */
+int atlas_hyperkzg_proof_serialize(const atlas_g1_affine_t *com, size_t n_com, const atlas_g1_affine_t *w,
+                                   const atlas_fr_t *v, size_t ell, uint8_t *out, size_t cap, size_t *len);
+int atlas_hyperkzg_proof_deserialize(const uint8_t *in, size_t len, atlas_g1_affine_t *com, size_t cap_com, size_t *n_com,
+                                     atlas_g1_affine_t *w, atlas_fr_t *v, size_t cap_ell, size_t *ell, size_t *consumed);
+/* HyperKZGSRS::load_from_file / save_to_file (hyperkzg/mod.rs:60-95): SRS { g1_powers, g2_powers, g_products }
+ * compressed (kzg.rs:18-23).  load keeps the first max_points (0 = all) g1_powers, decompressed on the device;
+ * save writes g1_powers with empty g2_powers / g_products (the prover half). */
+int atlas_srs_load_file(const char *path, size_t max_points, atlas_srs_t *out);
+int atlas_srs_save_file(atlas_srs_t srs, const char *path);
+
 /* ---- one instance / one MSM sharded over the GPUs of a node (one process per GPU) -------
  * Rank g of `world` holds the strided shard L_g[k] = L[k*world + g] of each operand (the
  * HighToLow pairs (i, i + len/2) stay on one rank).  Per round: local partial message ->

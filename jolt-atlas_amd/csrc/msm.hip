@@ -18,16 +18,13 @@
 #include "hyperkzg_kernels.hip.h"
 #include "msm_kernels.hip.h"
 #include "runtime.hpp"
+#include "srs.hpp"
 
 using namespace atlas;
 namespace H = atlas_host;
 using atlas_rt::fail;
 using atlas_rt::g;
 
-struct atlas_srs {
-    G1Affine* d = nullptr;
-    size_t len = 0;
-};
 
 namespace {
 
