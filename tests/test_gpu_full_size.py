@@ -10,12 +10,20 @@ pytestmark = pytest.mark.gpu
 
 import os
 
-LOG_N = int(os.environ.get("ATLAS_FULL_LOG_N", "22"))     # 24 = GPT-2's joint polynomial (max_num_vars = 24)
+LOG_N = int(os.environ.get("ATLAS_FULL_LOG_N", "22"))     # the size of the remaining tests of this file
+# BASELINE.json configs: 2^20 (config 2: synthetic sumcheck), 2^22 (north_star witness + MSM), 2^24 (config 5 and GPT-2's
+# joint polynomial, max_num_vars = 24) — all three in the default run
+FULL_SIZES = [int(x) for x in os.environ.get("ATLAS_FULL_SIZES", "20,22,24").split(",")]
 
 
-def test_sumcheck_2p22_bit_exact_and_final_claims(atlas):
+@pytest.mark.parametrize("fs", [0, 1], ids=["fs_host", "fs_device"])
+@pytest.mark.parametrize("LOG_N", FULL_SIZES)
+def test_sumcheck_2p22_bit_exact_and_final_claims(atlas, LOG_N, fs):
     from oracle import orc
     A = atlas
+    if fs == 1 and LOG_N != 22:
+        pytest.skip("device-resident transcript: one size")
+    A.set_fs_mode(fs)
     n = 1 << LOG_N
     L = orc.random_fr(n, 9001); R = orc.random_fr(n, 9002)
     claim = orc.dot_claim(L, R, None, 0, 0, 0)
@@ -24,7 +32,10 @@ def test_sumcheck_2p22_bit_exact_and_final_claims(atlas):
     prover = A.EinsumDotProver(A.MultilinearPolynomial.from_fr(L), A.MultilinearPolynomial.from_fr(R), None, 0, 0, 0)
     assert np.array_equal(prover.input_claim(), claim[0])
     t_g = A.Blake2bTranscript(b"full")
-    proof_g, ch_g, fin_g = A.Sumcheck.prove(prover, claim[0], t_g, LOG_N)
+    try:
+        proof_g, ch_g, fin_g = A.Sumcheck.prove(prover, claim[0], t_g, LOG_N)
+    finally:
+        A.set_fs_mode(A.FS_HOST)
     prover.free()
     assert ch_g == ch_o and np.array_equal(proof_g, proof_o) and np.array_equal(fin_g, fin_o)
     assert t_g.state == t_o.state_bytes() and t_g.n_rounds == t_o.n_rounds
@@ -33,7 +44,8 @@ def test_sumcheck_2p22_bit_exact_and_final_claims(atlas):
     assert np.array_equal(fin_g[0], orc.evaluate(L, r)) and np.array_equal(fin_g[1], orc.evaluate(R, r))
 
 
-def test_msm_and_hyperkzg_open_2p22_trapdoor(atlas):
+@pytest.mark.parametrize("LOG_N", [x for x in FULL_SIZES if x >= 22])
+def test_msm_and_hyperkzg_open_2p22_trapdoor(atlas, LOG_N):
     from oracle import orc
     A = atlas
     n = 1 << LOG_N
