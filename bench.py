@@ -115,8 +115,15 @@ PASS_KERNELS = ("k_dot_eval", "k_dot_bind_eval")      # the data passes of the d
 
 
 def git_sha():
+    """commit of the tree when it is a git checkout; on the GPU box (a snapshot without .git) the hash of the measured
+    library instead, prefixed "so:"."""
     try:
         return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        pass
+    try:
+        import hashlib
+        return "so:" + hashlib.sha256(open(os.path.join(ROOT, "jolt-atlas_amd", "libatlas_hip.so"), "rb").read()).hexdigest()[:12]
     except Exception:
         return None
 
@@ -188,8 +195,7 @@ def main():
     ap.add_argument("--fs", choices=("host", "device"), default="host", help="where the Blake2b transcript runs (atlas_set_fs_mode)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs that measure roofline.traffic")
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
-    ap.add_argument("--shard", action="store_true",
-                    help="N>1 only: additionally prove ONE 2^n instance sharded over the N GPUs (RCCL all-gather per round)")
+    ap.add_argument("--no-shard", action="store_true", help="N>1: skip the leg that shards ONE instance / ONE MSM over the N GPUs")
     args = ap.parse_args()
     if args.pmc_child:
         pmc_child(args.pmc_child, args.n_vars, args.fs)
@@ -204,8 +210,14 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
+        # ATLAS_BENCH_BACKEND=gloo + fewer GPUs than ranks: the multi-rank legs on a one-GPU box (tests; not a measurement)
+        backend = os.environ.get("ATLAS_BENCH_BACKEND", "nccl")
+        local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import numpy as np
 
@@ -246,7 +258,7 @@ def main():
         if dist is None:
             return x
         import torch
-        tt = torch.tensor([x], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([x], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
@@ -336,28 +348,48 @@ def main():
                       "steps": msm_steps, "bucket_accumulate_ms": tmm.pass_ms, "sort_and_fold_ms": tmm.fs_ms,
                       "compulsory_GBps": tmm.pass_bytes / (tmm.total_ms * 1e-3) / 1e9 if tmm.total_ms > 0 else 0.0,
                       "compulsory_bytes": int(tmm.pass_bytes)}
-    # opt-in third leg (N > 1): ONE instance sharded over the ranks (strong scaling), RCCL exchange
-    if args.shard and dist is not None:
-        import torch
+    # third leg (N > 1): ONE 2^n instance and ONE 2^n-point MSM sharded over the N GPUs (strong scaling).  No collective on
+    # the data path: the ranks' 64-byte partial sums cross a POSIX shared-memory board (csrc/shard_group.hpp), every rank
+    # runs the same transcript step; the MSM is split by point range, one partial point per rank.
+    if dist is not None and not args.no_shard:
         from jolt_atlas_amd import sharded
-        dev = torch.device("cuda", local_rank)
+        grp = sharded.ShardGroup("/atlas_bench_%s" % os.environ.get("MASTER_PORT", "0"), world, rank)
         shard_len = (1 << n_vars) // world
         Ls = A.random_fr(shard_len, 0xA71A50000 + n_vars + 104729 * rank)
         Rs = A.random_fr(shard_len, 0xA71A51000 + n_vars + 104729 * rank)
         mlp, mrp = A.MultilinearPolynomial.from_fr(Ls), A.MultilinearPolynomial.from_fr(Rs)
-        shard_steps = 3
+        _ps = A.EinsumDotProver(mlp.clone(), mrp.clone(), None, A.EQ_NONE, 0, 0)
+        g_claim = sharded.fr_sum(grp.allgather(_ps.input_claim()))
+        _ps.free()
+        shard_steps = max(1, min(args.steps, 10))
+        shard_sets = [(mlp.clone(), mrp.clone()) for _ in range(shard_steps + 1)]
         states = []
 
         def shard_step(i):
             t = A.Blake2bTranscript(b"synthetic_sc")
-            sharded.prove_dot_sharded(dist, mlp.clone(), mrp.clone(), t, device=dev)
+            sharded.prove_dot_sharded_shm(grp, *shard_sets[i], t, input_claim=g_claim)
             states.append(t.state)
 
         dt_s = timed_steps(shard_step, shard_steps, 1, sync, barrier, allreduce_max)
         assert len(set(states)) == 1, "non-deterministic sharded proof"
-        out["sharded"] = {"instance": "one 2^%d degree-2 sumcheck over %d GPUs (strided shards, all_gather of 64 B/rank/round)"
-                                      % (n_vars, world), "ms_per_instance": dt_s * 1e3 / shard_steps, "steps": shard_steps,
-                          "scaling": "strong"}
+        all_states = grp.allgather(np.frombuffer(states[0], dtype=np.uint8))
+        assert all(bytes(x) == states[0] for x in all_states), "ranks disagree on the transcript"
+        out["sharded"] = {"instance": "one 2^%d degree-2 sumcheck over %d GPUs (strided shards; per-round exchange of 64 B per rank through "
+                                      "host shared memory, transcript on every rank)" % (n_vars, world),
+                          "ms_per_instance": dt_s * 1e3 / shard_steps, "steps": shard_steps, "scaling": "strong",
+                          "field_ops_per_s": field_ops(n_vars) * shard_steps / dt_s}
+        if not args.no_msm:
+            m = (1 << n_vars) // world
+            sc_slice = A.MultilinearPolynomial.from_fr(A.random_fr(m, 0x5CA1A5 + n_vars + 7919 * rank))
+            pts_s = {}
+
+            def msm_shard_step(i):                      # this rank's range of the SRS generated for the second leg
+                pts_s[i] = sharded.msm_sharded_shm(grp, srs, sc_slice, offset=rank * m)
+
+            dt_ms = timed_steps(msm_shard_step, 3, 1, sync, barrier, allreduce_max)
+            out["sharded"]["msm_ms"] = dt_ms * 1e3 / 3
+            out["sharded"]["msm"] = "one 2^%d-point MSM split by point range over %d GPUs, partial points through the board" % (n_vars, world)
+        grp.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n_vars)
     if rank == 0:

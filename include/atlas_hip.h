@@ -587,6 +587,22 @@ int atlas_dot_shard_finish(atlas_dot_prover_t p, const atlas_fr_t *gathered_lr, 
                            atlas_transcript_t *transcript, atlas_fr_t *compressed_polys,
                            atlas_u128_t *challenges, atlas_fr_t final_claims[3]);
 int atlas_fr_sum(const atlas_fr_t *v, size_t n, atlas_fr_t *out);                 /* host: sum of per-rank claims */
+/* The same instance in ONE call per rank, transcript on every rank's host thread: the launches of all local rounds are
+ * enqueued up front (round channel), the per-round exchange of the ranks' partial sums (64 B each) goes through a POSIX
+ * shared-memory board instead of a collective — the round is latency-bound and the sums are in host memory already —
+ * and the last log2(world) rounds are host arithmetic.  Every rank returns the same proof.
+ *   atlas_shard_group_open: `name` = a shm name unique to the job ("/atlas_<port>_<run>"), the same on every rank;
+ *   rank 0 creates the board, the call returns when all `world` ranks have joined.
+ *   atlas_shard_allgather: all[r*n_bytes ..] = rank r's record (<= 496 B); used for the claim and for MSM partials.
+ *   atlas_sumcheck_prove_dot_sharded: p = this rank's strided shard (len / world coefficients), input_claim = the claim
+ *   of the whole instance; outputs sized for num_rounds(p) + log2(world) rounds. */
+typedef struct atlas_shard_group *atlas_shard_group_t;
+int atlas_shard_group_open(const char *name, int world, int rank, atlas_shard_group_t *out);
+int atlas_shard_group_close(atlas_shard_group_t grp);
+int atlas_shard_allgather(atlas_shard_group_t grp, const void *mine, size_t n_bytes, void *all);
+int atlas_sumcheck_prove_dot_sharded(atlas_dot_prover_t p, atlas_shard_group_t grp, const atlas_fr_t *input_claim,
+                                     atlas_transcript_t *transcript, atlas_fr_t *compressed_polys,
+                                     atlas_u128_t *challenges, atlas_fr_t final_claims[3]);
 /* host: sum of the per-rank partial MSM results of a point-range sharded commitment */
 int atlas_g1_sum_affine(const atlas_g1_affine_t *pts, size_t n, atlas_g1_affine_t *out);
 

@@ -21,6 +21,7 @@
 #include "sumcheck_kernels.hip.h"
 #include "sc_consts.hpp"
 #include "sumcheck_f9_kernels.hip.h"
+#include "shard_group.hpp"
 
 using namespace atlas;
 namespace H = atlas_host;
@@ -728,9 +729,15 @@ static void host_fs_round(H::Transcript& T, int deg, const H::Fr* ev, H::Fr& cla
     for (int k = 2; k <= deg; k++) row[k - 1] = c[k];
 }
 
+// grp != null: P holds this rank's strided shard of ONE instance spread over grp->world ranks (coefficient k * world +
+// rank; HighToLow pairs stay on a rank).  Each round the ranks exchange their partial sums through the group's shared-
+// memory board and every rank runs the same transcript step; after the local rounds the `world` remaining coefficients
+// of each operand are exchanged and the last log2(world) rounds are host arithmetic on every rank.  input_claim = the
+// claim of the whole instance.  Degree-2 instances.
 template <int DEG>
 static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim, atlas_transcript_t* transcript,
-                             atlas_fr_t* compressed_polys, atlas_u128_t* challenges, atlas_fr_t final_claims[3]) {
+                             atlas_fr_t* compressed_polys, atlas_u128_t* challenges, atlas_fr_t final_claims[3],
+                             atlas_shard_group* grp = nullptr) {
     using atlas_rt::Channel;
     Channel& C = g.chan;
     const ScConsts K = make_consts();
@@ -874,6 +881,14 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
         if (!ok) { C.publish(slot0 + round, rtag(round), 0, 0, true); continue; }
         const double t_coll = trace ? now_us() : 0;
         for (int k = 0; k < DEG; k++) ev[k] = atlas_rt::sum_to_fr(acc[k], mails[round].radix, mails[round].shl);
+        if (grp) {                                  // the message of the whole instance = sum over the ranks' shards, in rank order
+            H::Fr all[atlas_shard_group::MAX_WORLD * DEG];
+            if (!grp->allgather(ev, sizeof(H::Fr) * DEG, all)) { ok = false; C.publish(slot0 + round, rtag(round), 0, 0, true); continue; }
+            for (int k = 0; k < DEG; k++) {
+                ev[k] = all[k];
+                for (int r = 1; r < grp->world; r++) ev[k] = H::add(ev[k], all[r * DEG + k]);
+            }
+        }
         host_fs_round(T, DEG, ev, claim, reinterpret_cast<H::Fr*>(compressed_polys) + round * DEG, &challenges[round], mode);
         C.publish(slot0 + round, rtag(round), challenges[round].lo, challenges[round].hi);
         // while the device works on the next pass: let the runtime retire the launches that have completed (otherwise it
@@ -898,6 +913,32 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
         return le != hipSuccess ? fail(ATLAS_ENODEV, "sumcheck launch", le) : fail(ATLAS_ENODEV, "round channel: no answer from the device");
     }
     for (int k = 0; k < 3; k++) std::memcpy(&final_claims[k], fin[k], 32);
+    if (grp) {
+        // the `world` coefficients left of each operand: rank g holds index g.  Rounds n .. n + log2(world) - 1 on the host.
+        const int W = grp->world;
+        H::Fr mine[2], all[atlas_shard_group::MAX_WORLD * 2];
+        std::memcpy(&mine[0], fin[0], 32); std::memcpy(&mine[1], fin[1], 32);
+        if (!grp->allgather(mine, sizeof(mine), all)) return fail(ATLAS_ENODEV, "sharded sumcheck: a rank did not answer");
+        std::vector<H::Fr> Lr(W), Rr(W);
+        for (int r = 0; r < W; r++) { Lr[r] = all[2 * r]; Rr[r] = all[2 * r + 1]; }
+        size_t round = n;
+        for (int len = W; len > 1; len /= 2, round++) {
+            const int half = len / 2;
+            H::Fr ev[2] = {H::zero(), H::zero()};
+            for (int i = 0; i < half; i++) {
+                ev[0] = H::add(ev[0], H::mul(Lr[i], Rr[i]));
+                const H::Fr l2 = H::sub(H::add(Lr[i + half], Lr[i + half]), Lr[i]), r2 = H::sub(H::add(Rr[i + half], Rr[i + half]), Rr[i]);
+                ev[1] = H::add(ev[1], H::mul(l2, r2));
+            }
+            host_fs_round(T, 2, ev, claim, reinterpret_cast<H::Fr*>(compressed_polys) + round * 2, &challenges[round], mode);
+            const H::Fr rf = H::challenge_to_fr(challenges[round].lo, challenges[round].hi, mode);
+            for (int i = 0; i < half; i++) {
+                Lr[i] = H::add(Lr[i], H::mul(rf, H::sub(Lr[i + half], Lr[i])));
+                Rr[i] = H::add(Rr[i], H::mul(rf, H::sub(Rr[i + half], Rr[i])));
+            }
+        }
+        std::memcpy(&final_claims[0], &Lr[0], 32); std::memcpy(&final_claims[1], &Rr[0], 32);
+    }
     std::memcpy(transcript, &T, sizeof(T));
     // the last launch has mailed its records and is retiring: observing its completion signal here costs microseconds
     // and keeps the runtime's next implicit device synchronisation (a hipFree of the operands) off its slow wait path
@@ -1068,6 +1109,37 @@ int atlas_dot_shard_finish(atlas_dot_prover_t P, const atlas_fr_t* gathered_lr, 
     std::memcpy(transcript, hp + 16384, sizeof(DevTranscript));
     P->consumed = true; P->shard_active = false;
     return ATLAS_OK;
+}
+
+// ---- the same over the round channel and a shared-memory board (shard_group.hpp): one call per rank proves the whole
+// instance, no per-round call into the library, no collective
+int atlas_shard_group_open(const char* name, int world, int rank, atlas_shard_group_t* out) {
+    if (!name || !out || world < 1 || world > (int)atlas_shard_group::MAX_WORLD || (world & (world - 1)) || rank < 0 || rank >= world)
+        return fail(ATLAS_EINVAL, "shard_group_open: world must be a power of two <= 64, 0 <= rank < world");
+    atlas_shard_group* g_ = new atlas_shard_group();
+    if (!g_->open(name, world, rank)) { g_->close(); delete g_; return fail(ATLAS_ENODEV, "shard_group_open: shared-memory board not available (shm_open / peers missing)"); }
+    *out = g_;
+    return ATLAS_OK;
+}
+int atlas_shard_group_close(atlas_shard_group_t grp) {
+    if (grp) { grp->close(); delete grp; }
+    return ATLAS_OK;
+}
+int atlas_shard_allgather(atlas_shard_group_t grp, const void* mine, size_t n_bytes, void* all) {
+    if (!grp || !mine || !all || n_bytes == 0 || n_bytes > atlas_shard_group::PAYLOAD) return fail(ATLAS_EINVAL, "shard_allgather: 1 .. 496 bytes per rank");
+    if (!grp->allgather(mine, n_bytes, all)) return fail(ATLAS_ENODEV, "shard_allgather: a rank did not answer");
+    return ATLAS_OK;
+}
+int atlas_sumcheck_prove_dot_sharded(atlas_dot_prover_t P, atlas_shard_group_t grp, const atlas_fr_t* input_claim, atlas_transcript_t* transcript,
+                                     atlas_fr_t* compressed_polys, atlas_u128_t* challenges, atlas_fr_t final_claims[3]) {
+    NEED_INIT();
+    if (!P || !grp || !input_claim || !transcript || !compressed_polys || !challenges || !final_claims)
+        return fail(ATLAS_EINVAL, "sumcheck_prove_dot_sharded: null argument");
+    if (P->schedule != ATLAS_EQ_NONE || P->left->is_i32) return fail(ATLAS_EINVAL, "sumcheck_prove_dot_sharded: degree-2 LargeScalars instances");
+    if (P->consumed || P->left->len != ((size_t)1 << P->n_rounds)) return fail(ATLAS_ESTATE, "sumcheck_prove_dot_sharded: prover already used");
+    if (P->n_rounds + ilog2((size_t)grp->world) > MAX_ROUNDS) return fail(ATLAS_EINVAL, "sumcheck_prove_dot_sharded: too many rounds");
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    return prove_dot_channel<2>(P, input_claim, transcript, compressed_polys, challenges, final_claims, grp);
 }
 
 size_t atlas_dot_num_rounds(atlas_dot_prover_t P) { return P ? P->n_rounds : 0; }

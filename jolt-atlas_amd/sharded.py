@@ -90,3 +90,53 @@ def msm_sharded(dist, srs_slice, scalars_slice, device=None):
     out = np.zeros(1, dtype=G1_DTYPE)
     _check(lib.atlas_g1_sum_affine(pts.ctypes.data_as(C.c_void_p), C.c_size_t(len(pts)), out.ctypes.data_as(C.c_void_p)))
     return out[0]
+
+
+# ---- the same without a collective: shared-memory board + round channel, one library call per rank -------------------
+class ShardGroup:
+    """atlas_shard_group_t: the ranks of one node exchanging 64-byte records through POSIX shared memory."""
+
+    def __init__(self, name, world, rank):
+        self.h = C.c_void_p()
+        self.world, self.rank = world, rank
+        _check(lib.atlas_shard_group_open(name.encode(), C.c_int(world), C.c_int(rank), C.byref(self.h)))
+
+    def allgather(self, arr):
+        a = np.ascontiguousarray(arr)
+        out = np.zeros((self.world,) + a.shape, dtype=a.dtype)
+        _check(lib.atlas_shard_allgather(self.h, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def close(self):
+        if self.h:
+            lib.atlas_shard_group_close(self.h)
+            self.h = None
+
+
+def prove_dot_sharded_shm(group: ShardGroup, left_shard, right_shard, transcript: Blake2bTranscript, input_claim=None):
+    """Sumcheck::prove of sum L*R, operands sharded (strided) over the group's ranks; one library call per rank
+    (atlas_sumcheck_prove_dot_sharded).  Returns (compressed_polys, challenges, final_claims, input_claim)."""
+    pl = left_shard if isinstance(left_shard, MultilinearPolynomial) else MultilinearPolynomial.from_fr(left_shard)
+    pr = right_shard if isinstance(right_shard, MultilinearPolynomial) else MultilinearPolynomial.from_fr(right_shard)
+    n_local = pl.len().bit_length() - 1
+    n_total = n_local + group.world.bit_length() - 1
+    prover = EinsumDotProver(pl, pr, None, EQ_NONE, 0, 0)
+    if input_claim is None:
+        input_claim = fr_sum(group.allgather(prover.input_claim()))
+    ic = _fr(input_claim)
+    proof = np.zeros((n_total * 2, 4), dtype=np.uint64)
+    ch = np.zeros(2 * n_total, dtype=np.uint64)
+    fin = np.zeros((3, 4), dtype=np.uint64)
+    _check(lib.atlas_sumcheck_prove_dot_sharded(prover.h, group.h, _p(ic), C.byref(transcript.t), _p(proof), _p(ch), _p(fin)))
+    prover.free()
+    return proof.reshape(n_total, 2, 4), [int(ch[2 * i]) | (int(ch[2 * i + 1]) << 64) for i in range(n_total)], fin, input_claim
+
+
+def msm_sharded_shm(group: ShardGroup, srs_slice, scalars_slice, offset=0):
+    """Point-range sharded MSM: one partial point per rank through the board, summed on every rank."""
+    part = np.zeros(1, dtype=G1_DTYPE)
+    part[0] = srs_slice.msm(scalars_slice, offset)
+    pts = np.ascontiguousarray(group.allgather(part.view(np.uint64).reshape(-1)).reshape(-1)).view(G1_DTYPE)
+    out = np.zeros(1, dtype=G1_DTYPE)
+    _check(lib.atlas_g1_sum_affine(pts.ctypes.data_as(C.c_void_p), C.c_size_t(len(pts)), out.ctypes.data_as(C.c_void_p)))
+    return out[0]

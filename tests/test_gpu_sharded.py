@@ -58,3 +58,47 @@ def test_sharded_sumcheck_and_msm(tmp_path, world, n):
                          capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     assert f"SHARDED_OK {world}" in out.stdout
+
+
+@pytest.mark.parametrize("world,n", [(2, 14), (4, 16), (8, 13), (2, 3)])
+def test_sharded_over_shared_memory_board(tmp_path, world, n):
+    """atlas_sumcheck_prove_dot_sharded: one call per rank, round channel + shared-memory board, no collective; every rank's
+    proof equals the oracle's proof of the whole instance.  Processes share the test box's GPU."""
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {ROOT!r})
+        import numpy as np
+        rank, world = int(sys.argv[1]), {world}
+        import jolt_atlas_amd as A
+        from jolt_atlas_amd import sharded
+        from oracle import orc
+        A.init(0)
+        n = {n}
+        L = orc.random_fr(1 << n, 11); R = orc.random_fr(1 << n, 12)
+        grp = sharded.ShardGroup(sys.argv[2], world, rank)
+        t = A.Blake2bTranscript(b"sharded")
+        proof, ch, fin, claim = sharded.prove_dot_sharded_shm(grp, sharded.strided_shard(L, rank, world), sharded.strided_shard(R, rank, world), t)
+        t_o = orc.new_transcript(b"sharded")
+        want_claim = orc.dot_claim(L, R)
+        proof_o, ch_o, fin_o = orc.sumcheck_dot_prove(L, R, want_claim, t_o)
+        assert np.array_equal(claim, want_claim[0])
+        assert ch == ch_o and np.array_equal(proof, proof_o) and np.array_equal(fin, fin_o)
+        assert t.state == t_o.state_bytes() and t.n_rounds == t_o.n_rounds
+        m = 1 << 10
+        tau = orc.random_fr(1, 5)[0]
+        srs_full = orc.srs_powers(tau, m)
+        sc = orc.random_fr(m, 6)
+        lo, hi = rank * m // world, (rank + 1) * m // world
+        srs = A.SRS.upload(srs_full[lo:hi])
+        assert orc.g1_eq(sharded.msm_sharded_shm(grp, srs, sc[lo:hi]), orc.msm(srs_full, sc))
+        grp.close()
+        print("SHM_SHARDED_OK", rank)
+    """))
+    name = f"/atlas_gpu_{os.getpid()}_{world}_{n}"
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), name], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for r, (p, (o, e)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, e[-3000:]
+        assert f"SHM_SHARDED_OK {r}" in o

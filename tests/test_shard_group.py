@@ -1,0 +1,53 @@
+"""CPU: the N > 1 host path of the sharded prover — the shared-memory exchange board (csrc/shard_group.hpp) — with 2 and 4
+processes: every rank sees every rank's record for every exchange, in order, including when the ring wraps; a missing rank
+is a timeout at open, not a hang."""
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(name, world, rank, rounds, q):
+    sys.path.insert(0, ROOT)
+    from jolt_atlas_amd import sharded
+    try:
+        g = sharded.ShardGroup(name, world, rank)
+        ok = True
+        for k in range(rounds):
+            mine = np.array([rank * 1000003 + k, k * k + rank, 7, rank], dtype=np.uint64)
+            allv = g.allgather(mine)
+            for r in range(world):
+                ok &= bool(np.array_equal(allv[r], np.array([r * 1000003 + k, k * k + r, 7, r], dtype=np.uint64)))
+        big = g.allgather(np.full(62, rank, dtype=np.uint64))            # 496 bytes: the largest record
+        ok &= all(int(big[r][0]) == r and int(big[r][61]) == r for r in range(world))
+        g.close()
+        q.put((rank, ok))
+    except Exception as e:             # noqa: BLE001
+        q.put((rank, repr(e)))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_allgather_over_shared_memory(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = f"/atlas_test_{os.getpid()}_{world}"
+    ps = [ctx.Process(target=_worker, args=(name, world, r, 50, q)) for r in range(world)]
+    for p in ps: p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps: p.join(timeout=30)
+    assert sorted(r for r, _ in res) == list(range(world))
+    assert all(ok is True for _, ok in res), res
+
+
+def test_bad_arguments():
+    sys.path.insert(0, ROOT)
+    import jolt_atlas_amd as A
+    from jolt_atlas_amd import sharded
+    with pytest.raises(A.AtlasError):
+        sharded.ShardGroup("/atlas_test_bad", 3, 0)          # not a power of two
+    with pytest.raises(A.AtlasError):
+        sharded.ShardGroup("/atlas_test_bad", 2, 2)          # rank out of range
