@@ -195,6 +195,7 @@ def main():
     ap.add_argument("--fs", choices=("host", "device"), default="host", help="where the Blake2b transcript runs (atlas_set_fs_mode)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs that measure roofline.traffic")
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--no-node", action="store_true", help="skip the operator-node leg (atlas_prove_einsum_node)")
     ap.add_argument("--no-shard", action="store_true", help="N>1: skip the leg that shards ONE instance / ONE MSM over the N GPUs")
     args = ap.parse_args()
     if args.pmc_child:
@@ -343,11 +344,48 @@ def main():
         srs.msm(scal)
         tmm = A.last_timing()
         A.set_timing(False)
+        c_bits = int(tmm.n_fs)
+        n_win = (255 + c_bits - 1) // c_bits
+        # bucket accumulation: one mixed XYZZ addition per (scalar, window) digit = 10 Fq multiplications of 162 multiply-adds on
+        # the 29-bit limbs (curve_f9.hip.h); the ceiling is the chip's v_mad_u64_u32 rate, measured in this run
+        mad_peak = A.measure_mad_peak()
+        mads = float(1 << n_vars) * n_win * 10 * 162
+        mad_rate = mads / (tmm.pass_ms * 1e-3) if tmm.pass_ms > 0 else 0.0
         out["msm"] = {"points": 1 << n_vars, "scalar_bits": 254, "window_bits": int(tmm.n_fs),
+                      "roofline": {"bound": "int-mul", "kernel": "k_msm_accumulate_seg", "achieved": mad_rate / 1e12, "peak": mad_peak / 1e12,
+                                   "unit": "T v_mad_u64_u32/s", "frac": mad_rate / mad_peak if mad_peak else None,
+                                   "mixed_additions": (1 << n_vars) * n_win, "mads_per_addition": 1620},
                       "ms_per_msm": dt_m * 1e3 / msm_steps, "points_per_s": world * (1 << n_vars) * msm_steps / dt_m,
                       "steps": msm_steps, "bucket_accumulate_ms": tmm.pass_ms, "sort_and_fold_ms": tmm.fs_ms,
                       "compulsory_GBps": tmm.pass_bytes / (tmm.total_ms * 1e-3) / 1e9 if tmm.total_ms > 0 else 0.0,
                       "compulsory_bytes": int(tmm.pass_bytes)}
+    # operator-node leg: the fused-rescale Einsum node of a GPT-2 MLP projection (16 x 768 . 768 x 3072, padded to powers of
+    # two: 16 x 1024 . 1024 x 4096, MODEL_SCALE = 14) composed as Einsum::prove composes it (atlas_prove_einsum_node): witness on
+    # the device, clamp PS-Shout + one-hot checks, contraction sumcheck, remainder range check + one-hot checks.  The first
+    # number that speaks to ONNXProof::prove (one node of it).
+    if rank == 0 and not args.no_node:
+        from jolt_atlas_amd import node as NODE
+        rngn = np.random.default_rng(14)
+        m_, k_, n_, S_ = 16, 1024, 4096, 14
+        tA = A.TensorI32(rngn.integers(-(1 << 14), 1 << 14, size=(m_, k_), dtype=np.int64).astype(np.int32))
+        tB = A.TensorI32(rngn.integers(-(1 << 14), 1 << 14, size=(k_, n_), dtype=np.int64).astype(np.int32))
+        r0 = A.random_fr(16, 0xE1)
+        best, stages, states_n = None, None, set()
+        for rep in range(4):
+            tn = A.Blake2bTranscript(b"einsum_node")
+            sync(); t0n = time.perf_counter()
+            _pf, _cl, st = NODE.prove_einsum_node(tA, tB, m_, k_, n_, S_, r0, tn)
+            sync(); dtn = time.perf_counter() - t0n
+            states_n.add(tn.state)
+            if rep and (best is None or dtn < best):
+                best, stages = dtn, st
+        assert len(states_n) == 1, "non-deterministic node proof"
+        out["node_einsum"] = {"node": "Einsum mk,kn->mn fused rescale, m=16 k=1024 n=4096 (GPT-2 MLP projection padded), scale 2^14; "
+                                      "5 sumcheck proofs, %d bytes" % sum(len(x) for x in _pf),
+                              "node_einsum_ms": best * 1e3,
+                              "stage_ms": dict(zip(("witness", "execution_clamp_ps_shout", "ra_one_hot_checks", "einsum_matmul", "range_check",
+                                                    "remainder_ra_checks"), [float(x) for x in stages]))}
+        tA.free(); tB.free()
     # third leg (N > 1): ONE 2^n instance and ONE 2^n-point MSM sharded over the N GPUs (strong scaling).  No collective on
     # the data path: the ranks' 64-byte partial sums cross a POSIX shared-memory board (csrc/shard_group.hpp), every rank
     # runs the same transcript step; the MSM is split by point range, one partial point per rank.

@@ -86,6 +86,7 @@ int atlas_poly_upload_fr(const atlas_fr_t *host, size_t len, atlas_poly_t *out);
 int atlas_poly_upload_i32(const int32_t *host, size_t len, atlas_poly_t *out);
 /* wrap memory that is already resident (device pointer), no copy, not owned */
 int atlas_poly_wrap_device_fr(void *dptr, size_t len, atlas_poly_t *out);
+int atlas_poly_wrap_device_i32(void *dptr, size_t len, atlas_poly_t *out);   /* I32Scalars view of resident int32, not owned */
 int atlas_poly_len(atlas_poly_t p, size_t *len);   /* current (bound) length */
 int atlas_poly_download(atlas_poly_t p, atlas_fr_t *host, size_t cap);  /* current coeffs */
 int atlas_poly_clone(atlas_poly_t p, atlas_poly_t *out);
@@ -542,6 +543,23 @@ int atlas_accumulator_prove_reduced_openings(atlas_accumulator_t a, atlas_srs_t 
                                              size_t *max_rounds_out, atlas_fr_t *sumcheck_claims, atlas_g1_affine_t *com,
                                              atlas_g1_affine_t *w, atlas_fr_t *v);
 
+/* ---- one operator node, composed as the reference composes it: the fused-rescale Einsum mk,kn->mn
+ *      (jolt-atlas-core/src/onnx_proof/ops/einsum/mod.rs:71-115 + fused_rebase.rs:215-285 + clamp_lookups/mod.rs:264-309):
+ * witness on the device (acc = A B in i64, rescaled = acc >> S, R = acc mod 2^S, output = SatClamp_i32(rescaled):
+ * try_rebase_intermediates, fused_rebase.rs:110-128), then remainder advice, clamp PS-Shout (Execution), one-hot checks
+ * (RaOneHotChecks), the contraction sumcheck (EinsumMatmul), the remainder range check (RangeCheck) and its one-hot checks
+ * (RescaleRemainderRaChecks), every accumulator append mirrored on the transcript in the reference's order.
+ *   d_A (m x k), d_B (k x n): Tensor<i32> in HBM; r_node_output: the log2(m n) entries of the node's reduced output opening;
+ *   output_claim: output(r_node_output), or NULL to evaluate it here; proofs: the five SumcheckInstanceProofs ark-serialized
+ *   back to back, proof_lens[i] bytes each; claims: the scalars appended to the accumulator, in order; d_output (optional):
+ *   receives the node output; stage_ms (optional, 6 doubles): witness, Execution, RaOneHotChecks, EinsumMatmul, RangeCheck,
+ *   RescaleRemainderRaChecks wall clock. */
+typedef struct { size_t m, k, n; uint32_t scale_bits; } atlas_einsum_node_t;
+int atlas_prove_einsum_node(const atlas_einsum_node_t *node, const int32_t *d_A, const int32_t *d_B,
+                            const atlas_fr_t *r_node_output, const atlas_fr_t *output_claim, atlas_transcript_t *t,
+                            uint8_t *proofs, size_t cap, size_t *proofs_len, size_t proof_lens[5], atlas_fr_t *claims,
+                            size_t claims_cap, size_t *n_claims, int32_t *d_output, double *stage_ms);
+
 /* Transcript::append_point / append_points (blake2b.rs:166-195), host side */
 int atlas_transcript_append_point(atlas_transcript_t *t, const atlas_g1_affine_t *p);
 int atlas_transcript_append_points(atlas_transcript_t *t, const atlas_g1_affine_t *p, size_t n);
@@ -616,6 +634,8 @@ typedef struct {
     uint32_t n_pass, n_fs;
 } atlas_timing_t;
 int atlas_set_timing(int enabled);   /* per-launch events; off by default */
+/* chip-wide 32x32->64 multiply-add rate (v_mad_u64_u32), measured now: the ceiling of the MSM bucket accumulation */
+int atlas_measure_mad_peak(double *mads_per_s);
 int atlas_last_timing(atlas_timing_t *out);
 
 #ifdef __cplusplus

@@ -103,6 +103,13 @@ def get_fs_mode():
     return int(lib.atlas_get_fs_mode())
 
 
+def measure_mad_peak():
+    """v_mad_u64_u32 per second over the whole chip, measured now."""
+    v = C.c_double()
+    _check(lib.atlas_measure_mad_peak(C.byref(v)))
+    return v.value
+
+
 def set_timing(on):
     _check(lib.atlas_set_timing(C.c_int(1 if on else 0)))
 

@@ -277,6 +277,15 @@ int atlas_poly_wrap_device_fr(void* dptr, size_t len, atlas_poly_t* out) {
     return ATLAS_OK;
 }
 
+int atlas_poly_wrap_device_i32(void* dptr, size_t len, atlas_poly_t* out) {
+    NEED_INIT();
+    if (!dptr || !out || !is_pow2(len)) return fail(ATLAS_EINVAL, "poly_wrap_device_i32");
+    atlas_poly* p = new atlas_poly();
+    p->d = dptr; p->len = len; p->cap_bytes = len * sizeof(int32_t); p->is_i32 = true; p->owned = false;
+    *out = p;
+    return ATLAS_OK;
+}
+
 int atlas_poly_len(atlas_poly_t p, size_t* len) {
     if (!p || !len) return fail(ATLAS_EINVAL, "poly_len");
     *len = p->len;

@@ -644,6 +644,45 @@ int atlas_commit_batch(atlas_srs_t srs, const atlas_poly_t* polys, size_t n, atl
     return ATLAS_OK;
 }
 
+
+// The ceiling the bucket accumulation runs against: chip-wide v_mad_u64_u32 rate, measured now (tools/microbench.hip k_mad;
+// the figure is not in MI355X_MICROARCH.md).  bench.py reports the accumulation's multiply-adds against it.
+__global__ void k_mad_peak(uint64_t* out, int iters) {
+    uint32_t a = threadIdx.x * 2654435761u + 1, b = blockIdx.x * 40503u + 7;
+    uint64_t x0 = a, x1 = b, x2 = a ^ b, x3 = a + b, x4 = 5, x5 = 6, x6 = 7, x7 = 8;
+    for (int i = 0; i < iters; i++) {
+        x0 = (uint64_t)(uint32_t)x0 * a + x0; x1 = (uint64_t)(uint32_t)x1 * b + x1;
+        x2 = (uint64_t)(uint32_t)x2 * a + x2; x3 = (uint64_t)(uint32_t)x3 * b + x3;
+        x4 = (uint64_t)(uint32_t)x4 * a + x4; x5 = (uint64_t)(uint32_t)x5 * b + x5;
+        x6 = (uint64_t)(uint32_t)x6 * a + x6; x7 = (uint64_t)(uint32_t)x7 * b + x7;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7;
+}
+
+extern "C" int atlas_measure_mad_peak(double* mads_per_s) {
+    NEED_INIT();
+    if (!mads_per_s) return fail(ATLAS_EINVAL, "measure_mad_peak");
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    const int blocks = 256 * 8, threads = 256, iters = 4096;
+    int rc = ws.ensure((size_t)blocks * threads * 8);
+    if (rc) return rc;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    k_mad_peak<<<blocks, threads, 0, g.stream>>>((uint64_t*)ws.p, 16);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; rep++) {
+        hipEventRecord(e0, g.stream);
+        k_mad_peak<<<blocks, threads, 0, g.stream>>>((uint64_t*)ws.p, iters);
+        hipEventRecord(e1, g.stream);
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *mads_per_s = (double)blocks * threads * iters * 8 / (best * 1e-3);
+    return ATLAS_OK;
+}
+
 // ------------------------------------------------------------------ HyperKZG::open
 // ATLAS_TRACE=1: wall-clock of the phases of one open on stderr (each mark drains the stream)
 struct HkTrace {

@@ -119,7 +119,7 @@ int histogram(const uint64_t* h_idx, size_t T, KeySpec S, const atlas_poly* E, a
     HIP_TRY(hipMalloc(&sorted, (T * S.d ? T * S.d : 1) * 4));
     hipError_t e = hipMalloc(&G, (size_t)n_buckets * sizeof(Fe));
     if (e != hipSuccess) { cleanup(); return fail(ATLAS_ENOMEM, "hipMalloc(G)", e); }
-    HIP_TRY(hipMemcpyAsync(d_idx, h_idx, T * 8, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(d_idx, h_idx, T * 8, hipMemcpyDefault, g.stream));   // host or device source
     HIP_TRY(hipMemsetAsync(counts, 0, (size_t)(n_buckets + 1) * 4, g.stream));
     k_sh_hist<<<grid_for(T), SH_THREADS, 0, g.stream>>>(d_idx, T, S, counts);
     k_exclusive_scan<<<1, 1024, 0, g.stream>>>(counts, n_buckets, offsets, cursor);

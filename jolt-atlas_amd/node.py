@@ -1,0 +1,27 @@
+"""Operator-node provers composed in the library (atlas_prove_einsum_node)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _check, _fr, _p, lib
+
+
+class _Node(C.Structure):
+    _fields_ = [("m", C.c_size_t), ("k", C.c_size_t), ("n", C.c_size_t), ("scale_bits", C.c_uint32)]
+
+
+def prove_einsum_node(tA, tB, m, k, n, scale_bits, r_node_output, transcript, output_claim=None):
+    """Einsum::prove for a fused-rescale mk,kn->mn node.  tA, tB: TensorI32.  Returns (proof_bytes list of 5, claims (c,4), stage_ms (6,))."""
+    nd = _Node(m, k, n, scale_bits)
+    rn = np.ascontiguousarray(r_node_output, dtype=np.uint64)
+    cap = 1 << 20
+    buf = (C.c_uint8 * cap)(); ln = C.c_size_t(); lens = (C.c_size_t * 5)()
+    claims = np.zeros((256, 4), dtype=np.uint64); nc = C.c_size_t(); st = (C.c_double * 6)()
+    oc = _p(_fr(output_claim)) if output_claim is not None else None
+    _check(lib.atlas_prove_einsum_node(C.byref(nd), tA.d, tB.d, _p(rn), oc, C.byref(transcript.t), buf, C.c_size_t(cap), C.byref(ln), lens,
+                                       _p(claims), C.c_size_t(256), C.byref(nc), None, st))
+    raw = bytes(buf[:ln.value])
+    out, o = [], 0
+    for i in range(5):
+        out.append(raw[o:o + lens[i]]); o += lens[i]
+    return out, claims[:nc.value].copy(), np.array(list(st))

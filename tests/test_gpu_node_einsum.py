@@ -1,0 +1,157 @@
+"""GPU: one real operator node through the C-ABI — the fused-rescale Einsum (mk,kn->mn) as Einsum::prove composes it
+(ops/einsum/mod.rs:71-115, fused_rebase.rs:215-285, clamp_lookups/mod.rs:264-309, shout.rs:399-466) — against the same
+composition written over the ORACLE's instances: witness, every accumulator append, every challenge draw, the five
+sumcheck proofs (bytes) and the final transcript state."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+FR = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+
+
+def _one(orc):
+    return orc.from_ints([1])[0]
+
+
+def _eq_bits(orc, r, value, nbits):
+    """prod_i (bit_i ? r_i : 1 - r_i), bit 0 of the product = MSB of value (big-endian point)."""
+    w = _one(orc)
+    minus1 = orc.from_ints([FR - 1])[0]
+    for i in range(nbits):
+        bit = (int(value) >> (nbits - 1 - i)) & 1
+        f = r[i] if bit else orc.fr_add_arr(_one(orc), orc.fr_mul_arr(minus1, r[i]))
+        w = orc.fr_mul_arr(w, f)
+    return w
+
+
+def _append(orc, t, x):
+    orc.lib.orc_transcript_append_scalar(C.byref(t), orc._p(np.ascontiguousarray(x, dtype=np.uint64).reshape(1, 4)))
+
+
+def _challenge_scalar(orc, t):
+    s = orc.fr_array(1); orc.lib.orc_transcript_challenge_scalar(C.byref(t), orc._p(s))
+    return s[0].copy()
+
+
+def _challenge_opt(orc, t):
+    raw = (C.c_uint64 * 2)(); r = orc.fr_array(1)
+    orc.lib.orc_transcript_challenge_optimized(C.byref(t), raw, orc._p(r))
+    return r[0].copy()
+
+
+def _ser(orc, rows):
+    from jolt_atlas_amd import wire
+    return wire.sumcheck_proof_to_bytes(rows)
+
+
+def _onehot_checks(orc, OR, OB, t, lookups, log_T, log_K, r_cycle, ra_point, ra_claim, claims):
+    lkc = 4
+    d = -(-log_K // lkc)
+    T = 1 << log_T
+    q = _challenge_scalar(orc, t)
+    gp = [_one(orc)]
+    for _ in range(1, d):
+        gp.append(orc.fr_mul_arr(gp[-1], q))
+    gp = np.stack(gp)
+    gammas = np.stack([_challenge_opt(orc, t) for _ in range(d)])
+    r_addr = np.stack([_challenge_opt(orc, t) for _ in range(lkc)])
+    H = [((lookups >> np.uint64(lkc * (d - 1 - i))) & np.uint64(15)).astype(np.int32) for i in range(d)]
+    G = OR.ra_G(H, lkc, r_cycle)
+    pad = d * lkc - log_K
+    chunks = np.concatenate([np.zeros((pad, 4), dtype=np.uint64), ra_point[:log_K]]).reshape(d, lkc, 4)
+    r_cyc_ra = np.ascontiguousarray(ra_point[log_K:])
+    hw_claim = orc.fr_array(1)[0]
+    for x in gp:
+        hw_claim = orc.fr_add_arr(hw_claim, x)
+    zero = orc.fr_array(1)[0]
+    insts = [OB.ra_instance(OR.ra_virtual(H, lkc, chunks, r_cyc_ra), ra_claim), OB.ra_instance(OR.hamming(G, lkc, gp), hw_claim),
+             OB.ra_instance(OR.booleanity(G, H, lkc, gammas, r_addr, r_cycle), zero)]
+    rows, ch, _ = OB.batched_prove(insts, t)
+    rs = orc.challenges_to_fr(ch)
+    mr = lkc + log_T
+    # cache_openings, in instance order; each instance used the last num_rounds challenges
+    ra_rs = np.ascontiguousarray(rs[mr - log_T:][::-1])
+    for i in range(d):                                                   # RaVirtual: MLE of the gathered rows at the reversed challenges
+        F = orc.eq_evals(chunks[i])
+        c = orc.evaluate(np.stack([F[k] for k in H[i]]), ra_rs)
+        _append(orc, t, c); claims.append(c)
+    hw_rs = np.ascontiguousarray(rs[mr - lkc:][::-1])
+    for i in range(d):                                                   # HammingWeight: G_i at the reversed challenges
+        c = orc.evaluate(G[i], hw_rs)
+        _append(orc, t, c); claims.append(c)
+    ba = np.ascontiguousarray(rs[:lkc][::-1]); bc = np.ascontiguousarray(rs[lkc:][::-1])
+    Fb = orc.eq_evals(ba)
+    for i in range(d):                                                   # Booleanity: H_i = eq(rho_address, idx_i(t)) at the reversed cycle challenges
+        c = orc.evaluate(np.stack([Fb[k] for k in H[i]]), bc)
+        _append(orc, t, c); claims.append(c)
+    return rows
+
+
+@pytest.mark.parametrize("m,k,n,S", [(2, 8, 16, 6), (4, 4, 4, 4), (1, 16, 32, 7)])
+def test_einsum_node_matches_oracle_composition(atlas, m, k, n, S):
+    from oracle import orc, orc_ra as OR, orc_batched as OB
+    from jolt_atlas_amd import node
+    A_ = atlas
+    rng = np.random.default_rng(m * 100 + k)
+    A = rng.integers(-(1 << 6), 1 << 6, size=(m, k), dtype=np.int64).astype(np.int32)
+    B = rng.integers(-(1 << 6), 1 << 6, size=(k, n), dtype=np.int64).astype(np.int32)
+    T = m * n; log_T = T.bit_length() - 1; log_m = m.bit_length() - 1
+    acc = (A.astype(np.int64) @ B.astype(np.int64)).reshape(-1)
+    quot = acc >> S
+    rem = acc - (quot << S)
+    assert ((rem >= 0) & (rem < (1 << S))).all()
+    outv = np.clip(quot, -(1 << 31), (1 << 31) - 1)
+    r0 = orc.random_fr(log_T, 77)
+    f = lambda v: orc.from_ints([int(x) % FR for x in v])
+    eval_R, acc_claim, out_claim = orc.evaluate(f(rem), r0), orc.evaluate(f(quot), r0), orc.evaluate(f(outv), r0)
+    claims = []
+    t = orc.new_transcript(b"einsum_node")
+    _append(orc, t, eval_R); claims.append(eval_R)
+    _append(orc, t, acc_claim); claims.append(acc_claim)
+    gamma = _challenge_scalar(orc, t)
+    cidx = quot.astype(np.int64).view(np.uint64).copy()
+    exec_claim = orc.fr_add_arr(out_claim, orc.fr_mul_arr(gamma, acc_claim))
+    rows_exec, ch = OR.ps_clamp(cidx, 64, 31, True, r0, gamma).prove(exec_claim, t)
+    rs = orc.challenges_to_fr(ch)
+    ra_point = np.concatenate([rs[:64], rs[64:][::-1]])
+    ra_claim = orc.evaluate(np.stack([_eq_bits(orc, ra_point[:64], v, 64) for v in cidx]), np.ascontiguousarray(ra_point[64:]))
+    _append(orc, t, ra_claim); claims.append(ra_claim)
+    rows_oh = _onehot_checks(orc, OR, OB, t, cidx, log_T, 64, r0, ra_point, ra_claim, claims)
+    # matmul
+    eq_m, eq_n = orc.eq_evals(np.ascontiguousarray(r0[:log_m])) if log_m else orc.from_ints([1]), orc.eq_evals(np.ascontiguousarray(r0[log_m:]))
+    left = np.stack([sum_fr(orc, [orc.fr_mul_arr(f([A[i, l]])[0], eq_m[i]) for i in range(m)]) for l in range(k)])
+    right = np.stack([sum_fr(orc, [orc.fr_mul_arr(f([B[l, j]])[0], eq_n[j]) for j in range(n)]) for l in range(k)])
+    in_claim = orc.fr_add_arr(orc.fr_mul_arr(acc_claim, f([1 << S])[0]), eval_R)
+    assert np.array_equal(orc.dot_claim(left, right)[0], in_claim)          # acc(r0) = rescaled(r0) 2^S + R(r0)
+    proof_mm, ch_mm, fin_mm = orc.sumcheck_dot_prove(left, right, in_claim.reshape(1, 4), t)
+    for c in (fin_mm[0], fin_mm[1]):
+        _append(orc, t, c); claims.append(c)
+    # remainder range check
+    ridx = rem.astype(np.uint64)
+    phases = 1 if S <= 2 else S // 4 if S % 4 == 0 else S // 2 if S % 2 == 0 else S
+    rows_rc, ch = OR.ps_identity(ridx, S, phases, r0).prove(eval_R, t)
+    rs = orc.challenges_to_fr(ch)
+    rr_point = np.concatenate([rs[:S], rs[S:][::-1]])
+    rr_claim = orc.evaluate(np.stack([_eq_bits(orc, rr_point[:S], v, S) for v in ridx]), np.ascontiguousarray(rr_point[S:]))
+    _append(orc, t, rr_claim); claims.append(rr_claim)
+    rows_oh2 = _onehot_checks(orc, OR, OB, t, ridx, log_T, S, r0, rr_point, rr_claim, claims)
+    # ---- device
+    tA, tB = A_.TensorI32(A), A_.TensorI32(B)
+    t_g = A_.Blake2bTranscript(b"einsum_node")
+    proofs, claims_g, stage_ms = node.prove_einsum_node(tA, tB, m, k, n, S, r0, t_g)
+    want = [_ser(orc, rows_exec), _ser(orc, rows_oh), _ser(orc, [proof_mm[i] for i in range(len(proof_mm))]), _ser(orc, rows_rc), _ser(orc, rows_oh2)]
+    assert np.array_equal(claims_g[:3], np.stack(claims[:3]))
+    for i, (a, b) in enumerate(zip(proofs, want)):
+        assert a == b, f"proof {i} differs"
+    assert np.array_equal(claims_g, np.stack(claims))
+    assert t_g.state == t.state_bytes()
+    tA.free(); tB.free()
+
+
+def sum_fr(orc, xs):
+    s = orc.fr_array(1)[0]
+    for x in xs:
+        s = orc.fr_add_arr(s, x)
+    return s
