@@ -454,6 +454,14 @@ int atlas_srs_generate(const atlas_fr_t *tau, size_t n, atlas_srs_t *out);
 int atlas_srs_len(atlas_srs_t s, size_t *len);
 int atlas_srs_download(atlas_srs_t s, size_t offset, size_t n, atlas_g1_affine_t *out);
 int atlas_srs_free(atlas_srs_t s);
+/* Fixed-base table for the first n_points powers (0 = all): 2^(c j) * g1_powers[i] for j < ceil(255 / c), kept in HBM
+ * next to the SRS (n_points * ceil(255 / c) * 64 bytes).  The prover key is fixed after setup
+ * (KZGProverKey::g1_powers, kzg.rs:107-143; built once in ONNXProof::setup_prover), so this is setup work: one call
+ * per key, ~0.2 s at 2^22 points.  window_bits = 0 lets the library choose (20 at 2^22 points).  Every MSM over Fr
+ * scalars whose points lie inside the table then needs ceil(255 / c) instead of 20 point additions per scalar;
+ * outputs are unchanged (same group elements).  ATLAS_MSM_TAB=0 in the environment ignores the table. */
+int atlas_srs_precompute(atlas_srs_t s, size_t n_points, uint32_t window_bits);
+int atlas_srs_table_info(atlas_srs_t s, size_t *n_points, uint32_t *window_bits, uint32_t *levels);
 /* VariableBaseMSM::msm / msm_field_elements over bases[offset .. offset+n)
  * (joltworks/src/msm/mod.rs:27-38,184-190; replaces the arkworks Pippenger call).
  * Fails with ATLAS_EINVAL ("KeyLengthError") when the SRS slice is shorter than n. */

@@ -347,6 +347,16 @@ class SRS:
         _check(lib.atlas_srs_download(self.h, C.c_size_t(offset), C.c_size_t(n), out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def precompute(self, n_points=0, window_bits=0):
+        """Fixed-base table 2^(c j) * g1_powers[i] for the first n_points powers (atlas_srs_precompute); setup-time work."""
+        _check(lib.atlas_srs_precompute(self.h, C.c_size_t(n_points), C.c_uint32(window_bits)))
+        return self.table_info()
+
+    def table_info(self):
+        n, c, lv = C.c_size_t(), C.c_uint32(), C.c_uint32()
+        _check(lib.atlas_srs_table_info(self.h, C.byref(n), C.byref(c), C.byref(lv)))
+        return {"n_points": n.value, "window_bits": c.value, "levels": lv.value}
+
     def msm(self, scalars, offset=0):
         """VariableBaseMSM::msm: scalars = (n,4) Fr array or a device MultilinearPolynomial."""
         out = np.zeros(1, dtype=G1_DTYPE)

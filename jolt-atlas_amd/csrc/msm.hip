@@ -17,6 +17,7 @@
 #include "host_field.hpp"
 #include "hyperkzg_kernels.hip.h"
 #include "msm_kernels.hip.h"
+#include "msm_tab_kernels.hip.h"
 #include "runtime.hpp"
 #include "srs.hpp"
 
@@ -88,7 +89,30 @@ struct MsmPending {
     hipStream_t st = nullptr; const G1Xyzz* wsum = nullptr; uint32_t V = 0; size_t K = 0, n = 0; MsmShape S{};
     atlas_g1_affine_t* out = nullptr;
     std::vector<MsmTile> tiles;      // host source of an enqueued H2D copy: alive until the finish
+    std::vector<TabTile> tab_tiles;
 };
+
+// bucket reduction (msm_kernels.hip.h): lists and run sums live in one carved block
+struct ReduceBufs {
+    uint32_t* n_lists; uint32_t* medium_list; uint32_t* big_list; uint32_t* big_run_off; G1Xyzz* run_sums;
+    static size_t bytes(size_t TB, size_t s_max) {
+        const size_t nb = s_max / MSM_MEDIUM_SEGS + 2, nr = s_max / MSM_BIG_RUN + nb + 2;
+        return align_up(16 + TB * 4 + nb * 4 * 2, 256) + nr * sizeof(G1Xyzz);
+    }
+    ReduceBufs(unsigned char* p, size_t TB, size_t s_max) {
+        const size_t nb = s_max / MSM_MEDIUM_SEGS + 2;
+        n_lists = (uint32_t*)p; medium_list = n_lists + 4; big_list = medium_list + TB; big_run_off = big_list + nb;
+        run_sums = (G1Xyzz*)(p + align_up(16 + TB * 4 + nb * 4 * 2, 256));
+    }
+};
+void launch_bucket_reduce(hipStream_t st, const G1Xyzz* partial, const SegMap map, uint32_t TB, G1Xyzz* buckets, const ReduceBufs& B) {
+    hipMemsetAsync(B.n_lists, 0, 16, st);
+    k_msm_bucket_reduce_small<<<(TB + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(partial, map, TB, buckets, B.medium_list, B.big_list, B.n_lists);
+    k_msm_bucket_reduce_medium<<<TB / 16 + 1 < 1024u ? TB / 16 + 1 : 1024u, MSM_THREADS, 0, st>>>(partial, map, B.medium_list, B.n_lists, buckets);
+    k_msm_big_prefix<<<1, 1024, 0, st>>>(map, B.big_list, B.n_lists, B.big_run_off);
+    k_msm_bucket_reduce_big1<<<2048, MSM_THREADS, 0, st>>>(partial, map, B.big_list, B.n_lists, B.big_run_off, B.run_sums);
+    k_msm_bucket_reduce_big2<<<256, MSM_THREADS, 0, st>>>(B.run_sums, B.big_list, B.n_lists, B.big_run_off, buckets);
+}
 
 int msm_finish(const MsmPending& P) {
     std::vector<H::G1X> hw(P.V);
@@ -173,7 +197,7 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
     const size_t o_buckets = carve((size_t)TB * sizeof(G1Xyzz));
     const size_t o_chunks = carve((size_t)n_chunks * sizeof(G1Xyzz));
     const size_t o_wsum = carve((size_t)V * sizeof(G1Xyzz));
-    const size_t o_biglist = carve((size_t)(TB + 1) * 4);        // [0] = count, then the bucket ids
+    const size_t o_biglist = carve(ReduceBufs::bytes(TB, s_max));
     const size_t o_tiles = carve(h_tiles.size() * sizeof(MsmTile));
     int rc = wk.ensure(off);
     if (rc) return rc;
@@ -194,8 +218,7 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
     uint32_t* seg_cur = (uint32_t*)(W + o_segcur);
     G1Xyzz* chunks = (G1Xyzz*)(W + o_chunks);
     G1Xyzz* wsum = (G1Xyzz*)(W + o_wsum);
-    uint32_t* big_cnt = (uint32_t*)(W + o_biglist);
-    uint32_t* big_list = big_cnt + 1;
+    const ReduceBufs rbufs(W + o_biglist, TB, s_max);
 
     const bool timing = g.timing && !pend;
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
@@ -223,9 +246,7 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
     k_exclusive_scan<<<1, 1024, 0, st>>>(bsum, (uint32_t)n_scan_blocks, boff, bcur);
     k_scan_apply<<<(unsigned)n_scan_blocks, 256, 0, st>>>(segc, TB, boff, seg_off, seg_cur, (uint32_t)n_scan_blocks);
     k_msm_accumulate_seg<<<(unsigned)((s_max + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(bases, sorted, offsets, seg_off, TB, seg_len, partial);
-    hipMemsetAsync(big_cnt, 0, 4, st);
-    k_msm_bucket_reduce_small<<<(TB + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(partial, seg_off, TB, buckets, big_list, big_cnt);
-    k_msm_bucket_reduce_big<<<TB < 2048u ? TB : 2048u, MSM_THREADS, 0, st>>>(partial, seg_off, big_list, big_cnt, buckets);
+    launch_bucket_reduce(st, partial, SegMap{seg_off, nullptr, 0}, TB, buckets, rbufs);
     if (timing) hipEventRecord(e2, st);
     k_msm_fold_chunks<<<(n_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(buckets, S, chunk, n_chunks, chunks);
     k_g1_group_sum<<<V, MSM_THREADS, 0, st>>>(chunks, chunks_per_window, wsum);
@@ -253,8 +274,178 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
     return ATLAS_OK;
 }
 
+
+// ---- fixed-base path (msm_tab_kernels.hip.h) ----------------------------------------------------------------------
+// Digit width for `n` scalars against a table of stride tab_c: the divisor c' = tab_c / q that minimises
+// n * ceil(255 / c') mixed additions + ~3 * q * 2^(c'-1) additions of bucket folding.  Returns q = 0 when the
+// variable-base plan (20 windows of 13 bits) is at least as cheap.
+bool tab_q_ok(uint32_t tab_c, uint32_t levels, uint32_t q) {
+    if (q == 0 || tab_c % q) return false;
+    const uint32_t c = tab_c / q;
+    if (c < 4 || c > 24) return false;
+    const uint32_t nd = (255 + c - 1) / c;
+    if ((nd + q - 1) / q > levels) return false;
+    const uint32_t hi = c - 1 > TAB_LO_BITS ? c - 1 - TAB_LO_BITS : 0;
+    return (q << hi) <= TAB_MAX_BINS;
+}
+uint32_t pick_tab_q(size_t n, uint32_t tab_c, uint32_t levels) {
+    if (const char* e = getenv("ATLAS_MSM_TAB")) { if (atoi(e) == 0) return 0; }
+    if (const char* e = getenv("ATLAS_MSM_TAB_Q")) { int v = atoi(e); if (v >= 1 && tab_q_ok(tab_c, levels, (uint32_t)v)) return (uint32_t)v; }   // experiments, tests
+    const MsmShape V = pick_shape(n);
+    double best = (double)n * V.n_windows + 3.0 * V.n_windows * V.bpw;
+    uint32_t best_q = 0;
+    for (uint32_t q = 1; q <= 4; q++) {
+        if (!tab_q_ok(tab_c, levels, q) || tab_c / q < 8) continue;
+        const uint32_t c = tab_c / q;
+        const double cost = (double)n * ((255 + c - 1) / c) + 3.0 * q * (double)(1u << (c - 1));
+        if (cost < best * 0.95) { best = cost; best_q = q; }
+    }
+    return best_q;
+}
+
+// K scalar vectors (vector k = d_scalars[offs[k] .. offs[k] + lens[k])) against table points [pt_off, pt_off + lens[k]).
+int msm_tab_core(const atlas_srs* srs, size_t pt_off, const Fr* d_scalars, size_t n, uint32_t q, atlas_g1_affine_t* out,
+                 const MsmMulti* multi = nullptr, const MsmLane* lane = nullptr, MsmPending* pend = nullptr) {
+    const size_t K = multi ? multi->K : 1;
+    const hipStream_t st = lane ? lane->st : g.stream;
+    Workspace& wk = lane ? *lane->wk : ws;
+    TabShape S;
+    S.c = srs->tab_c / q; S.q = q;
+    S.n_digits = (255 + S.c - 1) / S.c;
+    S.lo_bits = S.c - 1 < TAB_LO_BITS ? S.c - 1 : TAB_LO_BITS;
+    S.hi_bits = S.c - 1 - S.lo_bits;
+    S.level_stride = (uint32_t)srs->tab_len;
+    const uint32_t bpw = 1u << (S.c - 1);
+    const uint32_t bins_per_vec = q << S.hi_bits;
+    const size_t n_ent = n * (size_t)S.n_digits;
+    if (n_ent >= ((size_t)1 << 32) || K * (size_t)q * bpw >= ((size_t)1 << 31) ||
+        (size_t)srs->tab_levels * srs->tab_len >= ((size_t)1 << 31))
+        return fail(ATLAS_EINVAL, "msm: more than 2^32 (scalar, digit) pairs in one call; split the input");
+    const uint32_t V = (uint32_t)(K * q);                  // bucket sets
+    const uint32_t TB = V * bpw;
+    const uint32_t NB = (uint32_t)K * bins_per_vec;
+    uint32_t chunk_max = (uint32_t)MSM_CHUNK * 2;          // 2^19 buckets: 8 per thread keeps one wave per SIMD busy
+    if (const char* e = getenv("ATLAS_MSM_CHUNK")) { int v = atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) chunk_max = (uint32_t)v; }   // experiments
+    const uint32_t chunk = bpw < chunk_max ? bpw : chunk_max;
+    const uint32_t n_chunks = TB / chunk;
+    const uint32_t chunks_per_set = bpw / chunk;
+
+    std::vector<TabTile> h_tiles;
+    for (size_t k = 0; k < K; k++) {
+        const size_t o = multi ? multi->offs[k] : 0, len = multi ? multi->lens[k] : n;
+        for (size_t t0 = 0; t0 < len; t0 += TAB_TILE)
+            h_tiles.push_back(TabTile{(uint32_t)(o + t0), (uint32_t)(o + (t0 + TAB_TILE < len ? t0 + TAB_TILE : len)),
+                                      (uint32_t)(k * bins_per_vec), (uint32_t)(pt_off - o)});
+    }
+    const unsigned n_tiles = (unsigned)h_tiles.size();
+
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_ent = carve(n_ent * sizeof(uint2));
+    const size_t o_bins = carve((size_t)(NB + 1) * 4 * 3);
+    const size_t n_scan_blocks = ((size_t)TB + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    const size_t o_bsum = carve((n_scan_blocks + 1) * 4 * 3);
+    const size_t o_counts = carve((size_t)(TB + 1) * 4);
+    const size_t o_offsets = carve((size_t)(TB + 1) * 4);
+    const size_t o_cursor = carve((size_t)(TB + 1) * 4);
+    const size_t o_sorted = carve(n_ent * 4);
+    // even segments (k_msm_accumulate_even): 32 entries per thread, shorter while that leaves fewer than 2^19 threads
+    uint32_t seg_len = 64;
+    while (seg_len > 8 && n_ent / seg_len < ((size_t)1 << 19)) seg_len >>= 1;
+    while (seg_len < 1024 && (size_t)seg_len * 8 * TB < n_ent) seg_len <<= 1;      // ... but no more than ~8 partials per bucket
+    if (const char* e = getenv("ATLAS_MSM_SEG")) { int v = atoi(e); if (v >= 8 && v <= 4096 && (v & (v - 1)) == 0) seg_len = (uint32_t)v; }   // experiments
+    const size_t s_max = n_ent / seg_len + TB + 1;           // slots t + b of k_msm_accumulate_even
+    const size_t o_partial = carve(s_max * sizeof(G1Xyzz));
+    const size_t o_buckets = carve((size_t)TB * sizeof(G1Xyzz));
+    const size_t o_chunks = carve((size_t)n_chunks * sizeof(G1Xyzz));
+    const size_t o_wsum = carve((size_t)V * sizeof(G1Xyzz));
+    uint32_t gs_split = 1;
+    while (chunks_per_set / gs_split > 1024 && gs_split < 256) gs_split <<= 1;
+    const size_t o_gsum = carve((size_t)V * gs_split * sizeof(G1Xyzz));
+    const size_t o_biglist = carve(ReduceBufs::bytes(TB, s_max));
+    const size_t o_tiles = carve(h_tiles.size() * sizeof(TabTile));
+    int rc = wk.ensure(off);
+    if (rc) return rc;
+    unsigned char* W = (unsigned char*)wk.p;
+    uint2* ent = (uint2*)(W + o_ent);
+    uint32_t* bin_counts = (uint32_t*)(W + o_bins);
+    uint32_t* bin_off = bin_counts + (NB + 1);
+    uint32_t* bin_cur = bin_off + (NB + 1);
+    uint32_t* bsum = (uint32_t*)(W + o_bsum);
+    uint32_t* boff = bsum + (n_scan_blocks + 1);
+    uint32_t* bcur = boff + (n_scan_blocks + 1);
+    uint32_t* counts = (uint32_t*)(W + o_counts);
+    uint32_t* offsets = (uint32_t*)(W + o_offsets);
+    uint32_t* cursor = (uint32_t*)(W + o_cursor);
+    uint32_t* sorted = (uint32_t*)(W + o_sorted);
+    G1Xyzz* partial = (G1Xyzz*)(W + o_partial);
+    G1Xyzz* buckets = (G1Xyzz*)(W + o_buckets);
+    G1Xyzz* chunks = (G1Xyzz*)(W + o_chunks);
+    G1Xyzz* wsum = (G1Xyzz*)(W + o_wsum);
+    G1Xyzz* gsum = (G1Xyzz*)(W + o_gsum);
+    const ReduceBufs rbufs(W + o_biglist, TB, s_max);
+    TabTile* d_tiles = (TabTile*)(W + o_tiles);
+
+    const bool timing = g.timing && !pend;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+    if (timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2); hipEventCreate(&e3); hipEventRecord(e0, st); }
+
+    HIP_TRY(hipMemsetAsync(bin_counts, 0, (size_t)(NB + 1) * 4, st));
+    HIP_TRY(hipMemsetAsync(counts, 0, (size_t)(TB + 1) * 4, st));
+    HIP_TRY(hipMemcpyAsync(d_tiles, h_tiles.data(), h_tiles.size() * sizeof(TabTile), hipMemcpyHostToDevice, st));
+    k_tab_part_hist<<<n_tiles, MSM_THREADS, 0, st>>>(d_scalars, d_tiles, S, bin_counts);
+    k_exclusive_scan<<<1, 1024, 0, st>>>(bin_counts, NB, bin_off, bin_cur);
+    k_tab_part_scatter<<<n_tiles, MSM_THREADS, 0, st>>>(d_scalars, d_tiles, S, bin_cur, ent);
+    const unsigned n_chunk_wgs = (unsigned)((n_ent + TAB_CHUNK - 1) / TAB_CHUNK);
+    k_tab_bin_hist<<<n_chunk_wgs, MSM_THREADS, 0, st>>>(ent, bin_off, NB, S.lo_bits, counts);
+    k_scan_block_sums<<<(unsigned)n_scan_blocks, 256, 0, st>>>(counts, TB, bsum);
+    k_exclusive_scan<<<1, 1024, 0, st>>>(bsum, (uint32_t)n_scan_blocks, boff, bcur);
+    k_scan_apply<<<(unsigned)n_scan_blocks, 256, 0, st>>>(counts, TB, boff, offsets, cursor, (uint32_t)n_scan_blocks);
+    k_tab_bin_scatter<<<n_chunk_wgs, MSM_THREADS, 0, st>>>(ent, bin_off, NB, S.lo_bits, cursor, sorted);
+    if (timing) hipEventRecord(e1, st);
+    uint32_t seg_log = 0;
+    while ((1u << seg_log) < seg_len) seg_log++;
+    const SegMap smap{nullptr, offsets, seg_log};
+    k_msm_accumulate_even<<<(unsigned)(((n_ent >> seg_log) + 1 + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(srs->tab, sorted, offsets, TB, seg_log, partial);
+    launch_bucket_reduce(st, partial, smap, TB, buckets, rbufs);
+    if (timing) hipEventRecord(e2, st);
+    MsmShape SS; SS.c = S.c; SS.n_windows = q; SS.bpw = bpw;
+    k_msm_fold_chunks<<<(n_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(buckets, SS, chunk, n_chunks, chunks);
+    if (gs_split > 1) {      // a set has up to 2^20 chunk sums: one workgroup per set would add them 4096 deep
+        k_g1_group_sum<<<V * gs_split, MSM_THREADS, 0, st>>>(chunks, chunks_per_set / gs_split, gsum);
+        k_g1_group_sum<<<V, MSM_THREADS, 0, st>>>(gsum, gs_split, wsum);
+    } else k_g1_group_sum<<<V, MSM_THREADS, 0, st>>>(chunks, chunks_per_set, wsum);
+    if (timing) hipEventRecord(e3, st);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail(ATLAS_ENODEV, "msm launch", le);
+
+    MsmPending P;
+    P.st = st; P.wsum = wsum; P.V = V; P.K = K; P.n = n; P.S = SS; P.out = out;
+    P.tab_tiles = std::move(h_tiles);
+    if (pend) { *pend = std::move(P); return ATLAS_OK; }
+    rc = msm_finish(P);
+    if (rc) return rc;
+    if (timing) {
+        float a = 0, b = 0, c = 0;
+        hipEventElapsedTime(&a, e0, e1); hipEventElapsedTime(&b, e1, e2); hipEventElapsedTime(&c, e2, e3);
+        atlas_timing_t t{};
+        t.total_ms = a + b + c; t.pass_ms = b; t.fs_ms = a + c;
+        t.pass_bytes = (uint64_t)n * (sizeof(G1Affine) + sizeof(Fr));
+        t.n_pass = 1; t.n_fs = S.c;
+        g.last_timing = t;
+        hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2); hipEventDestroy(e3);
+    }
+    return ATLAS_OK;
+}
+
+// does the table cover points [pt_off, pt_off + n)?
+inline bool tab_covers(const atlas_srs* srs, size_t pt_off, size_t n) { return srs && srs->tab && pt_off + n <= srs->tab_len; }
+
 // scalars are Montgomery Fr already on the device
-int msm_device(const G1Affine* bases, const Fr* d_scalars, size_t n, atlas_g1_affine_t* out) {
+int msm_device(const G1Affine* bases, const Fr* d_scalars, size_t n, atlas_g1_affine_t* out, const atlas_srs* srs = nullptr,
+               size_t pt_off = 0) {
+    if (n && tab_covers(srs, pt_off, n))
+        if (const uint32_t q = pick_tab_q(n, srs->tab_c, srs->tab_levels)) return msm_tab_core(srs, pt_off, d_scalars, n, q, out);
     const MsmShape S = pick_shape(n);
     return msm_core(bases, n, S, [&](int16_t* digits, hipStream_t st) {
         k_msm_digits<<<grid_for(n), MSM_THREADS, 0, st>>>(d_scalars, n, S, digits);
@@ -286,41 +477,65 @@ static int msm_multi_group(const G1Affine* bases, const Fr* d_scalars, MsmGroup&
     }, G.res.data(), &M, lane, &G.pend);
 }
 
-Workspace ws_side;                 // second lane: the narrow pipeline of msm_device_multi
-hipStream_t side_stream = nullptr;
+Workspace ws_side, ws_tab;         // second lane: the narrow pipeline of msm_device_multi; third: its fixed-base pipeline
+hipStream_t side_stream = nullptr, side_stream2 = nullptr;
 hipEvent_t side_event = nullptr;
 
 void release_arenas() {            // atlas_shutdown
-    for (Workspace* w : {&ws, &hk_arena, &ws_side}) { if (w->p) hipFree(w->p); w->p = nullptr; w->cap = 0; }
+    for (Workspace* w : {&ws, &hk_arena, &ws_side, &ws_tab}) { if (w->p) hipFree(w->p); w->p = nullptr; w->cap = 0; }
     if (side_stream) { hipStreamDestroy(side_stream); side_stream = nullptr; }
+    if (side_stream2) { hipStreamDestroy(side_stream2); side_stream2 = nullptr; }
     if (side_event) { hipEventDestroy(side_event); side_event = nullptr; }
 }
 
+// Up to three pipelines side by side: the vectors long enough for the fixed-base table (when the SRS has one), the other
+// long ones (13-bit windows), and the short ones (narrow windows).
 int msm_device_multi(const G1Affine* bases, const Fr* d_scalars, size_t n_tot, size_t K, const size_t* lens, const size_t* offs,
-                     atlas_g1_affine_t* out) {
+                     atlas_g1_affine_t* out, const atlas_srs* srs = nullptr) {
     (void)n_tot;
     size_t mx = 0;
     for (size_t k = 0; k < K; k++) mx = lens[k] > mx ? lens[k] : mx;
-    MsmGroup big, small;
-    size_t mx_small = 0;
+    const uint32_t tab_q = tab_covers(srs, 0, mx) ? pick_tab_q(mx, srs->tab_c, srs->tab_levels) : 0;
+    MsmGroup tab, big, small;
+    size_t mx_small = 0, mx_big = 0;
     for (size_t k = 0; k < K; k++) {
-        if (mx >= MSM_MULTI_SPLIT && lens[k] < MSM_MULTI_SPLIT) { small.idx.push_back(k); mx_small = lens[k] > mx_small ? lens[k] : mx_small; }
-        else big.idx.push_back(k);
+        if (tab_q && pick_tab_q(lens[k], srs->tab_c, srs->tab_levels) == tab_q) tab.idx.push_back(k);
+        else if (mx >= MSM_MULTI_SPLIT && lens[k] < MSM_MULTI_SPLIT) { small.idx.push_back(k); mx_small = lens[k] > mx_small ? lens[k] : mx_small; }
+        else { big.idx.push_back(k); mx_big = lens[k] > mx_big ? lens[k] : mx_big; }
     }
-    if (!small.idx.empty()) {
-        // the narrow pipeline runs on a side stream behind whatever produced the scalars on the library stream,
-        // NOT behind the wide pipeline: the event is recorded before that one is enqueued
+    const int n_side = (small.idx.empty() ? 0 : 1) + ((!tab.idx.empty() && !big.idx.empty()) ? 1 : 0);
+    if (n_side) {
+        // side pipelines run behind whatever produced the scalars on the library stream, NOT behind the pipeline enqueued
+        // there: the event is recorded before that one is enqueued
         if (!side_stream) {
             HIP_TRY(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&side_stream2, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&side_event, hipEventDisableTiming));
         }
         HIP_TRY(hipEventRecord(side_event, g.stream));
     }
-    int rc = msm_multi_group(bases, d_scalars, big, lens, offs, pick_shape(mx), nullptr);
-    if (rc) return rc;
+    auto drain = [&]() { if (side_stream) { hipStreamSynchronize(side_stream); hipStreamSynchronize(side_stream2); } hipStreamSynchronize(g.stream); };
+    int rc = ATLAS_OK;
+    if (!tab.idx.empty()) {
+        size_t lo = SIZE_MAX, hi = 0;
+        for (size_t k : tab.idx) { lo = offs[k] < lo ? offs[k] : lo; hi = offs[k] + lens[k] > hi ? offs[k] + lens[k] : hi; }
+        tab.gl.resize(tab.idx.size()); tab.go.resize(tab.idx.size()); tab.res.resize(tab.idx.size());
+        for (size_t i = 0; i < tab.idx.size(); i++) { tab.gl[i] = lens[tab.idx[i]]; tab.go[i] = offs[tab.idx[i]] - lo; }
+        const MsmMulti M{tab.idx.size(), tab.gl.data(), tab.go.data()};
+        const MsmLane lane{g.stream, &ws_tab};
+        rc = msm_tab_core(srs, 0, d_scalars + lo, hi - lo, tab_q, tab.res.data(), &M, &lane, &tab.pend);
+        if (rc) { drain(); return rc; }
+    }
+    if (!big.idx.empty()) {
+        const bool aside = !tab.idx.empty();
+        if (aside) HIP_TRY(hipStreamWaitEvent(side_stream2, side_event, 0));
+        const MsmLane lane{aside ? side_stream2 : g.stream, &ws};
+        rc = msm_multi_group(bases, d_scalars, big, lens, offs, pick_shape(mx_big), &lane);
+        if (rc) { drain(); return rc; }
+    }
     if (!small.idx.empty()) {
         // narrow pipeline: about 16 points per bucket for its longest vector; its latency-bound tail and host Horner
-        // overlap the wide pipeline's accumulation
+        // overlap the wide pipelines' accumulation
         uint32_t lg = 0;
         while (((size_t)2 << lg) <= mx_small) lg++;
         MsmShape S;
@@ -330,14 +545,21 @@ int msm_device_multi(const G1Affine* bases, const Fr* d_scalars, size_t n_tot, s
         HIP_TRY(hipStreamWaitEvent(side_stream, side_event, 0));
         const MsmLane side{side_stream, &ws_side};
         rc = msm_multi_group(bases, d_scalars, small, lens, offs, S, &side);
-        if (rc) { hipStreamSynchronize(side_stream); hipStreamSynchronize(g.stream); return rc; }
+        if (rc) { drain(); return rc; }
         rc = msm_finish(small.pend);
-        if (rc) { hipStreamSynchronize(g.stream); return rc; }
+        if (rc) { drain(); return rc; }
         for (size_t i = 0; i < small.idx.size(); i++) out[small.idx[i]] = small.res[i];
     }
-    rc = msm_finish(big.pend);
-    if (rc) return rc;
-    for (size_t i = 0; i < big.idx.size(); i++) out[big.idx[i]] = big.res[i];
+    if (!big.idx.empty()) {
+        rc = msm_finish(big.pend);
+        if (rc) { drain(); return rc; }
+        for (size_t i = 0; i < big.idx.size(); i++) out[big.idx[i]] = big.res[i];
+    }
+    if (!tab.idx.empty()) {
+        rc = msm_finish(tab.pend);
+        if (rc) { drain(); return rc; }
+        for (size_t i = 0; i < tab.idx.size(); i++) out[tab.idx[i]] = tab.res[i];
+    }
     return ATLAS_OK;
 }
 
@@ -475,7 +697,53 @@ int atlas_srs_download(atlas_srs_t s, size_t offset, size_t n, atlas_g1_affine_t
 int atlas_srs_free(atlas_srs_t s) {
     if (!s) return ATLAS_OK;
     if (s->d) hipFree(s->d);
+    if (s->tab) hipFree(s->tab);
     delete s;
+    return ATLAS_OK;
+}
+
+// Fixed-base table over the first n_points points of the SRS (0 = all): levels 2^(c j) G_i, j < ceil(255 / c).
+// window_bits = 0 picks c from n_points (20 at 2^22).  One-time cost per prover key: ~c doublings per point and level.
+// MSMs over Fr scalars whose points lie inside the table use it (msm_tab_kernels.hip.h); results are the same group
+// elements, so every output stays bit-identical.  Calling it again replaces the table.
+int atlas_srs_precompute(atlas_srs_t srs, size_t n_points, uint32_t window_bits) {
+    NEED_INIT();
+    if (!srs) return fail(ATLAS_EINVAL, "srs_precompute: null SRS");
+    if (n_points == 0 || n_points > srs->len) n_points = srs->len;
+    uint32_t c = window_bits;
+    if (c == 0) {
+        uint32_t lg = 0;
+        while (((size_t)2 << lg) <= n_points) lg++;
+        // widths whose top digit is not a stub: 16 -> 16 digits, 17 -> 15, 20 -> 13, 22 -> 12 (measured: 2^20 3.5 ms at 20
+        // against 5.1 at 18; 2^22 8.7 ms at 20; 2^24 31 ms at 22 against 41 at 21)
+        c = lg >= 24 ? 22 : lg >= 19 ? 20 : lg >= 16 ? 17 : 16;
+    }
+    if (c < 8 || c > 24) return fail(ATLAS_EINVAL, "srs_precompute: window_bits must be 0 or 8..24");
+    const uint32_t levels = (255 + c - 1) / c;
+    if ((size_t)levels * n_points >= ((size_t)1 << 31)) return fail(ATLAS_EINVAL, "srs_precompute: table beyond 2^31 points");
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    if (srs->tab) { hipStreamSynchronize(g.stream); hipFree(srs->tab); srs->tab = nullptr; srs->tab_len = 0; srs->tab_c = srs->tab_levels = 0; }
+    G1Affine* tab = nullptr;
+    hipError_t e = hipMalloc(&tab, (size_t)levels * n_points * sizeof(G1Affine));
+    if (e != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(srs table)", e);
+    e = hipMemcpyAsync(tab, srs->d, n_points * sizeof(G1Affine), hipMemcpyDeviceToDevice, g.stream);
+    for (uint32_t l = 1; l < levels && e == hipSuccess; l++) {
+        k_tab_next_level<<<grid_for((n_points + TAB_INV_BATCH - 1) / TAB_INV_BATCH, 1 << 16), MSM_THREADS, 0, g.stream>>>(
+            tab + (size_t)(l - 1) * n_points, tab + (size_t)l * n_points, n_points, c);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    if (e != hipSuccess) { hipFree(tab); return fail(ATLAS_ENODEV, "srs_precompute", e); }
+    srs->tab = tab; srs->tab_len = n_points; srs->tab_c = c; srs->tab_levels = levels;
+    return ATLAS_OK;
+}
+
+// table parameters: window_bits = 0 when the SRS has no table
+int atlas_srs_table_info(atlas_srs_t srs, size_t* n_points, uint32_t* window_bits, uint32_t* levels) {
+    if (!srs) return fail(ATLAS_EINVAL, "srs_table_info: null SRS");
+    if (n_points) *n_points = srs->tab_len;
+    if (window_bits) *window_bits = srs->tab_c;
+    if (levels) *levels = srs->tab_levels;
     return ATLAS_OK;
 }
 
@@ -490,7 +758,7 @@ int atlas_msm_fr(atlas_srs_t srs, size_t offset, const atlas_fr_t* scalars, size
         HIP_TRY(hipMalloc(&d_s, n * sizeof(Fr)));
         HIP_TRY(hipMemcpyAsync(d_s, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
     }
-    int rc = msm_device(srs->d + offset, d_s, n, out);
+    int rc = msm_device(srs->d + offset, d_s, n, out, srs, offset);
     if (d_s) hipFree(d_s);
     return rc;
 }
@@ -501,7 +769,7 @@ int atlas_msm_poly(atlas_srs_t srs, size_t offset, atlas_poly_t poly, atlas_g1_a
     if (offset + poly->len > srs->len) return fail(ATLAS_EINVAL, "msm_poly: KeyLengthError (bases shorter than scalars)");
     std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     if (poly->is_i32) return msm_small_device<int32_t>(srs->d + offset, (const int32_t*)poly->d, poly->len, out);   // I32Scalars, msm/mod.rs:88-130
-    return msm_device(srs->d + offset, (const Fr*)poly->d, poly->len, out);
+    return msm_device(srs->d + offset, (const Fr*)poly->d, poly->len, out, srs, offset);
 }
 
 // msm over device-resident narrow scalars; kind = ATLAS_SCALAR_* (element type of the
@@ -621,7 +889,7 @@ int atlas_commit_batch(atlas_srs_t srs, const atlas_poly_t* polys, size_t n, atl
     std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     for (size_t i = 0; i < n; i++)
         if (polys[i]->is_i32) { int rc = msm_small_device<int32_t>(srs->d, (const int32_t*)polys[i]->d, polys[i]->len, out + i); if (rc) return rc; }
-    if (fr_idx.size() == 1) return msm_device(srs->d, (const Fr*)polys[fr_idx[0]]->d, polys[fr_idx[0]]->len, out + fr_idx[0]);
+    if (fr_idx.size() == 1) return msm_device(srs->d, (const Fr*)polys[fr_idx[0]]->d, polys[fr_idx[0]]->len, out + fr_idx[0], srs, 0);
     if (fr_idx.empty()) return ATLAS_OK;
     Fr* cat = nullptr;
     hipError_t e = hipMalloc(&cat, tot * sizeof(Fr));
@@ -635,7 +903,7 @@ int atlas_commit_batch(atlas_srs_t srs, const atlas_poly_t* polys, size_t n, atl
         o += P->len;
     }
     std::vector<atlas_g1_affine_t> res(fr_idx.size());
-    int rc = e == hipSuccess ? msm_device_multi(srs->d, cat, tot, fr_idx.size(), lens.data(), offs.data(), res.data())
+    int rc = e == hipSuccess ? msm_device_multi(srs->d, cat, tot, fr_idx.size(), lens.data(), offs.data(), res.data(), srs)
                              : fail(ATLAS_ENODEV, "commit_batch: gather", e);
     (void)hipStreamSynchronize(g.stream);
     (void)hipFree(cat);
@@ -744,7 +1012,7 @@ int atlas_hyperkzg_open(atlas_srs_t srs, atlas_poly_t poly, const atlas_u128_t* 
         std::vector<size_t> lens(ell - 1), offs(ell - 1);
         size_t off = 0, len = n >> 1;
         for (size_t i = 1; i < ell; i++) { lens[i - 1] = len; offs[i - 1] = off; off += len; len >>= 1; }
-        int rc = msm_device_multi(srs->d, polys + n, off, ell - 1, lens.data(), offs.data(), com);
+        int rc = msm_device_multi(srs->d, polys + n, off, ell - 1, lens.data(), offs.data(), com, srs);
         if (rc) { cleanup(); return rc; }
     }
     tr.mark("commit Pi_1..");
@@ -790,7 +1058,7 @@ int atlas_hyperkzg_open(atlas_srs_t srs, atlas_poly_t poly, const atlas_u128_t* 
     tr.mark("lincomb + witness polys");
     {   // the three witness commitments share the bases: one batched pipeline
         const size_t lens[3] = {n, n, n}, offs[3] = {0, n, 2 * n};
-        int rc = msm_device_multi(srs->d, h, 3 * n, 3, lens, offs, w);
+        int rc = msm_device_multi(srs->d, h, 3 * n, 3, lens, offs, w, srs);
         if (rc) { cleanup(); return rc; }
     }
     tr.mark("commit witnesses");

@@ -251,48 +251,201 @@ __global__ __launch_bounds__(MSM_THREADS) void k_msm_accumulate_seg(const G1Affi
     g1_store(partial + t, g1_from_f9(acc));
 }
 
-// buckets with at most MSM_SMALL_SEGS segments: one thread sums them; the others are put on a list for the
-// workgroup-per-bucket kernel (n_big must be zero on entry)
-constexpr uint32_t MSM_SMALL_SEGS = 12;
+// ---- even segments: thread t owns sorted entries [t * S, (t + 1) * S) whatever buckets they belong to and writes one
+// partial per bucket it touches, at slot t + b.  Slots are unique and ascending (thread t leaving bucket b for b + 1
+// writes t + b and t + b + 1; thread t + 1 continues bucket b + 1 at t + b + 2), so bucket b's partials are the
+// contiguous slots [offsets[b] / S + b, (offsets[b+1] - 1) / S + b].  Every thread does exactly S additions: no lane
+// waits for a longer segment of its wavefront, and no segment-count scan is needed.
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_accumulate_even(const G1Affine* __restrict__ bases,
+                                                                     const uint32_t* __restrict__ sorted,
+                                                                     const uint32_t* __restrict__ offsets, uint32_t n_buckets,
+                                                                     uint32_t seg_log, G1Xyzz* __restrict__ partial) {
+    const uint32_t t = blockIdx.x * MSM_THREADS + threadIdx.x;
+    const uint32_t total = offsets[n_buckets];
+    const uint64_t lo64 = (uint64_t)t << seg_log;
+    if (lo64 >= total) return;
+    const uint32_t lo = (uint32_t)lo64;
+    const uint32_t hi = lo64 + (1u << seg_log) < total ? lo + (1u << seg_log) : total;
+    uint32_t lo_b = 0, hi_b = n_buckets;              // largest b with offsets[b] <= lo: the bucket holding entry lo
+    while (hi_b - lo_b > 1) {
+        const uint32_t mid = (lo_b + hi_b) >> 1;
+        if (offsets[mid] <= lo) lo_b = mid; else hi_b = mid;
+    }
+    uint32_t b = lo_b, next = offsets[b + 1];
+    G1Xyzz9 acc;
+    acc.inf = true;
+    acc.x = f9_zero(); acc.y = f9_zero(); acc.zz = f9_zero(); acc.zzz = f9_zero();
+    for (uint32_t j = lo; j < hi; j++) {
+        if (j == next) {
+            g1_store(partial + (size_t)t + b, g1_from_f9(acc));
+            acc.inf = true;
+            acc.x = f9_zero(); acc.y = f9_zero(); acc.zz = f9_zero(); acc.zzz = f9_zero();
+            do { b++; next = offsets[b + 1]; } while (next <= j);
+        }
+        const uint32_t v = sorted[j];
+        const G1Affine p = g1_aff_load(bases + (v & 0x7fffffffu));
+        if (g1_aff_is_inf(p)) continue;
+        g1_madd_f9(acc, p, (v >> 31) != 0);
+    }
+    g1_store(partial + (size_t)t + b, g1_from_f9(acc));
+}
+
+// where bucket b's partials are: the scanned segment counts of k_msm_accumulate_seg, or the slots of k_msm_accumulate_even
+struct SegMap {
+    const uint32_t* seg_off;      // non-null: partials [seg_off[b], seg_off[b+1])
+    const uint32_t* offsets;      // else: from the bucket offsets and the segment length 2^seg_log
+    uint32_t seg_log;
+    __device__ __forceinline__ void get(uint32_t b, uint32_t& s0, uint32_t& cnt) const {
+        if (seg_off) { s0 = seg_off[b]; cnt = seg_off[b + 1] - s0; return; }
+        const uint32_t a = offsets[b], e = offsets[b + 1];
+        if (e == a) { s0 = 0; cnt = 0; return; }
+        s0 = (a >> seg_log) + b;
+        cnt = ((e - 1) >> seg_log) + b - s0 + 1;
+    }
+};
+
+// ---- bucket reduction: buckets[b] = sum of bucket b's partials.  Three regimes so that no distribution of scalars falls
+// off a cliff (uniform 254-bit scalars, a short top digit that fills a handful of buckets with a quarter of all entries,
+// field elements that are really small integers and all land in one bucket):
+//   <= MSM_SMALL_SEGS partials: one thread sums them (k_msm_bucket_reduce_small, which also sorts the rest into lists);
+//   <= MSM_MEDIUM_SEGS: 16 lanes per bucket, <= 16 partials per lane then a 4-level tree through shuffles;
+//   more: the bucket's partials are cut into runs of MSM_BIG_RUN, one workgroup per run wherever it lies (stage 1), then
+//         one workgroup per bucket sums the run results (stage 2) — a bucket holding every entry of a 2^24 MSM costs
+//         two ~0.2 ms kernels instead of a 10 ms serial chain in one workgroup.
+constexpr uint32_t MSM_SMALL_SEGS = 16;
+constexpr uint32_t MSM_MEDIUM_SEGS = 256;
+constexpr uint32_t MSM_BIG_RUN = 1024;
+
 __global__ __launch_bounds__(MSM_THREADS) void k_msm_bucket_reduce_small(const G1Xyzz* __restrict__ partial,
-                                                                         const uint32_t* __restrict__ seg_off, uint32_t n_buckets,
-                                                                         G1Xyzz* __restrict__ buckets, uint32_t* __restrict__ big_list,
-                                                                         uint32_t* n_big) {
+                                                                         const SegMap sm, uint32_t n_buckets,
+                                                                         G1Xyzz* __restrict__ buckets, uint32_t* __restrict__ medium_list,
+                                                                         uint32_t* __restrict__ big_list, uint32_t* n_lists) {
     const uint32_t b = blockIdx.x * MSM_THREADS + threadIdx.x;
     if (b >= n_buckets) return;
-    const uint32_t s0 = seg_off[b], cnt = seg_off[b + 1] - s0;
-    if (cnt > MSM_SMALL_SEGS) { big_list[atomicAdd(n_big, 1u)] = b; return; }
+    uint32_t s0, cnt;
+    sm.get(b, s0, cnt);
+    if (cnt > MSM_MEDIUM_SEGS) { big_list[atomicAdd(n_lists + 1, 1u)] = b; return; }
+    if (cnt > MSM_SMALL_SEGS) { medium_list[atomicAdd(n_lists, 1u)] = b; return; }
     G1Xyzz acc = g1_inf();
     if (cnt) acc = g1_load(partial + s0);
     for (uint32_t s = 1; s < cnt; s++) acc = g1_add(acc, g1_load(partial + s0 + s));
     g1_store(buckets + b, acc);
 }
 
-// the long ones: a workgroup per listed bucket, the grid strides over the list.  (One workgroup per bucket of the
-// whole table spent 0.27 ms at 2^22 launching 82 k workgroups that left at once; a grid striding over all buckets
-// spent 1.4 ms in the batched HyperKZG pipeline on 200 dependent loads per workgroup just to skip them.)
-__global__ __launch_bounds__(MSM_THREADS) void k_msm_bucket_reduce_big(const G1Xyzz* __restrict__ partial,
-                                                                       const uint32_t* __restrict__ seg_off,
-                                                                       const uint32_t* __restrict__ big_list,
-                                                                       const uint32_t* __restrict__ n_big,
-                                                                       G1Xyzz* __restrict__ buckets) {
-    __shared__ G1Xyzz sm[MSM_THREADS];
-    const uint32_t n_list = *n_big;
-    for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
-        const uint32_t b = big_list[li];
-        const uint32_t s0 = seg_off[b], cnt = seg_off[b + 1] - s0;
+__device__ __forceinline__ G1Xyzz g1_shfl_down16(const G1Xyzz& p, uint32_t d) {
+    G1Xyzz o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        o.x.v[i] = __shfl_down(p.x.v[i], d, 16);
+        o.y.v[i] = __shfl_down(p.y.v[i], d, 16);
+        o.zz.v[i] = __shfl_down(p.zz.v[i], d, 16);
+        o.zzz.v[i] = __shfl_down(p.zzz.v[i], d, 16);
+    }
+    return o;
+}
+
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_bucket_reduce_medium(const G1Xyzz* __restrict__ partial, const SegMap map,
+                                                                          const uint32_t* __restrict__ medium_list,
+                                                                          const uint32_t* __restrict__ n_lists,
+                                                                          G1Xyzz* __restrict__ buckets) {
+    const uint32_t n_list = n_lists[0];
+    const uint32_t lane = threadIdx.x & 15u;
+    const uint32_t groups = gridDim.x * (MSM_THREADS / 16);
+    // every 16-lane group of a wavefront runs the same number of rounds (shuffles need the whole wavefront)
+    const uint32_t g0 = (blockIdx.x * MSM_THREADS + threadIdx.x) / 16;
+    const uint32_t wave_first = g0 & ~3u;
+    for (uint32_t base = wave_first; base < n_list; base += groups) {
+        const uint32_t li = base + (g0 & 3u);
+        uint32_t b = 0, s0 = 0, cnt = 0;
+        if (li < n_list) { b = medium_list[li]; map.get(b, s0, cnt); }
         G1Xyzz acc = g1_inf();
-        for (uint32_t i = threadIdx.x; i < cnt; i += MSM_THREADS) acc = g1_add(acc, g1_load(partial + s0 + i));
-        sm[threadIdx.x] = acc;
-        __syncthreads();
-        uint32_t top = MSM_THREADS / 2;                          // tree only as deep as the occupied slots
-        while (top >= cnt && top > 1) top >>= 1;
-        for (uint32_t d = top; d >= 1; d >>= 1) {
-            if (threadIdx.x < d) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + d]);
-            __syncthreads();
+        for (uint32_t i = lane; i < cnt; i += 16) acc = g1_add(acc, g1_load(partial + s0 + i));
+        for (uint32_t d = 8; d >= 1; d >>= 1) {
+            const G1Xyzz o = g1_shfl_down16(acc, d);
+            if (lane < d) acc = g1_add(acc, o);
         }
-        if (threadIdx.x == 0) g1_store(buckets + b, sm[0]);
+        if (lane == 0 && li < n_list) g1_store(buckets + b, acc);
+    }
+}
+
+// big_run_off[li] = number of runs of the big buckets before list entry li (exclusive), [n_big] = total.  One workgroup.
+__global__ __launch_bounds__(1024) void k_msm_big_prefix(const SegMap map, const uint32_t* __restrict__ big_list,
+                                                         const uint32_t* __restrict__ n_lists, uint32_t* __restrict__ big_run_off) {
+    __shared__ uint32_t part[1024];
+    const uint32_t n = n_lists[1], t = threadIdx.x;
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; i++) { uint32_t s0, cnt; map.get(big_list[i], s0, cnt); s += (cnt + MSM_BIG_RUN - 1) / MSM_BIG_RUN; }
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = t >= d ? part[t - d] : 0;
         __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = t ? part[t - 1] : 0;
+    for (uint32_t i = lo; i < hi; i++) {
+        big_run_off[i] = run;
+        uint32_t s0, cnt; map.get(big_list[i], s0, cnt);
+        run += (cnt + MSM_BIG_RUN - 1) / MSM_BIG_RUN;
+    }
+    if (t == 1023) big_run_off[n] = part[1023];
+}
+
+__device__ __forceinline__ G1Xyzz g1_block_sum(G1Xyzz acc, G1Xyzz* sm) {      // result valid in thread 0
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t d = MSM_THREADS / 2; d >= 1; d >>= 1) {
+        if (threadIdx.x < d) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + d]);
+        __syncthreads();
+    }
+    const G1Xyzz r = sm[0];
+    __syncthreads();
+    return r;
+}
+
+// stage 1: run w of the big buckets (found by binary search in big_run_off) -> run_sums[w]
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_bucket_reduce_big1(const G1Xyzz* __restrict__ partial, const SegMap map,
+                                                                        const uint32_t* __restrict__ big_list,
+                                                                        const uint32_t* __restrict__ n_lists,
+                                                                        const uint32_t* __restrict__ big_run_off,
+                                                                        G1Xyzz* __restrict__ run_sums) {
+    __shared__ G1Xyzz sm[MSM_THREADS];
+    const uint32_t n_big = n_lists[1];
+    const uint32_t n_runs = big_run_off[n_big];
+    for (uint32_t w = blockIdx.x; w < n_runs; w += gridDim.x) {
+        uint32_t lo = 0, hi = n_big;                  // largest li with big_run_off[li] <= w
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (big_run_off[mid] <= w) lo = mid; else hi = mid;
+        }
+        uint32_t s0, cnt;
+        map.get(big_list[lo], s0, cnt);
+        const uint32_t r0 = (w - big_run_off[lo]) * MSM_BIG_RUN;
+        const uint32_t r1 = r0 + MSM_BIG_RUN < cnt ? r0 + MSM_BIG_RUN : cnt;
+        G1Xyzz acc = g1_inf();
+        for (uint32_t i = r0 + threadIdx.x; i < r1; i += MSM_THREADS) acc = g1_add(acc, g1_load(partial + s0 + i));
+        const G1Xyzz r = g1_block_sum(acc, sm);
+        if (threadIdx.x == 0) g1_store(run_sums + w, r);
+    }
+}
+
+// stage 2: a workgroup per big bucket sums its run results
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_bucket_reduce_big2(const G1Xyzz* __restrict__ run_sums,
+                                                                        const uint32_t* __restrict__ big_list,
+                                                                        const uint32_t* __restrict__ n_lists,
+                                                                        const uint32_t* __restrict__ big_run_off,
+                                                                        G1Xyzz* __restrict__ buckets) {
+    __shared__ G1Xyzz sm[MSM_THREADS];
+    const uint32_t n_big = n_lists[1];
+    for (uint32_t li = blockIdx.x; li < n_big; li += gridDim.x) {
+        const uint32_t w0 = big_run_off[li], w1 = big_run_off[li + 1];
+        G1Xyzz acc = g1_inf();
+        for (uint32_t w = w0 + threadIdx.x; w < w1; w += MSM_THREADS) acc = g1_add(acc, g1_load(run_sums + w));
+        const G1Xyzz r = g1_block_sum(acc, sm);
+        if (threadIdx.x == 0) g1_store(buckets + big_list[li], r);
     }
 }
 

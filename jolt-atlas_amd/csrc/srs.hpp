@@ -7,4 +7,9 @@
 struct atlas_srs {
     atlas::G1Affine* d = nullptr;     // 64-byte affine points, Montgomery Fq; (0, 0) = infinity
     size_t len = 0;
+    // fixed-base table (atlas_srs_precompute): level j of point i at tab[j * tab_len + i] = 2^(tab_c * j) * d[i];
+    // level 0 is a copy of d[0 .. tab_len) so that one base pointer serves every level
+    atlas::G1Affine* tab = nullptr;
+    size_t tab_len = 0;
+    uint32_t tab_c = 0, tab_levels = 0;
 };
