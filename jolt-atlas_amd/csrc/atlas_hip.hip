@@ -150,6 +150,7 @@ int atlas_shutdown(void) {
     hipFree(g.d_partials); hipFree(g.d_ctx); hipFree(g.d_proof); hipFree(g.d_chal); hipFree(g.d_finals);
     hipHostFree(g.h_pinned);
     g.chan.release();
+    atlas_rt::dev_pool().release();
     hipStreamDestroy(g.stream);
     g.ready = false; g.stream = nullptr; g.d_partials = nullptr; g.d_ctx = nullptr; g.d_proof = nullptr;
     g.d_chal = nullptr; g.d_finals = nullptr; g.h_pinned = nullptr;

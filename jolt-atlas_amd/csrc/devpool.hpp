@@ -1,0 +1,106 @@
+// Caching device allocator behind hipMalloc / hipFree inside the library.
+//
+// Why: an operator node is dozens of short-lived device buffers (witness columns, one-hot rows, eq tables, sort scratch);
+// hipMalloc costs 50-100 us each and hipFree waits for the device to go idle before it returns (0.4 ms when launches are in
+// flight) — about 2.4 of the 21 ms of the Einsum node (tools/time_node.py with ATLAS_TRACE=1).  Buffers are returned to
+// per-size free lists instead and handed out again without a runtime call.  Everything the library launches runs on
+// the library stream or on side streams that are drained before the entry point returns, so a block that is reused is
+// reused in stream order; nothing here relies on hipFree's implicit device synchronisation.
+//   * size classes: four per octave (<= 25 % slack), 256-byte minimum; blocks above POOL_MAX_BLOCK (1 GiB) bypass the pool;
+//   * at most POOL_MAX_CACHED bytes are kept; beyond that hipFree is real;
+//   * atlas_shutdown releases everything (runtime at_shutdown hook).  ATLAS_NO_POOL=1 disables the cache.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+namespace atlas_rt {
+
+struct DevPool {
+    static constexpr size_t POOL_MAX_BLOCK = (size_t)1 << 30;
+    static constexpr size_t POOL_MAX_CACHED = (size_t)24 << 30;
+    std::mutex mu;
+    std::unordered_map<void*, uint32_t> live;             // block -> size class (blocks handed out by the pool)
+    std::vector<std::vector<void*>> free_lists;           // by size class
+    size_t cached = 0;
+    bool off = getenv("ATLAS_NO_POOL") != nullptr;
+
+    static size_t class_bytes(uint32_t c) { return ((size_t)4 + (c & 3)) << (6 + (c >> 2)); }   // (4..7) * 2^(6 + c/4): 256, 320, 384, 448, 512, ...
+    static uint32_t class_of(size_t bytes) {
+        uint32_t c = 0;
+        while (class_bytes(c) < bytes) c++;
+        return c;
+    }
+    hipError_t alloc(void** out, size_t bytes) {
+        if (off || bytes == 0 || bytes > POOL_MAX_BLOCK) return hipMalloc(out, bytes);
+        const uint32_t c = class_of(bytes);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (c < free_lists.size() && !free_lists[c].empty()) {
+                void* p = free_lists[c].back();
+                free_lists[c].pop_back();
+                cached -= class_bytes(c);
+                live[p] = c;
+                *out = p;
+                return hipSuccess;
+            }
+        }
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, class_bytes(c));
+        if (e != hipSuccess) {                    // out of memory: give the cache back and try once more
+            (void)hipGetLastError();
+            release();
+            e = hipMalloc(&p, class_bytes(c));
+            if (e != hipSuccess) return e;
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        live[p] = c;
+        *out = p;
+        return hipSuccess;
+    }
+    hipError_t free(void* p) {
+        if (!p) return hipSuccess;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = live.find(p);
+            if (it != live.end()) {
+                const uint32_t c = it->second;
+                live.erase(it);
+                if (cached + class_bytes(c) <= POOL_MAX_CACHED) {
+                    if (free_lists.size() <= c) free_lists.resize(c + 1);
+                    free_lists[c].push_back(p);
+                    cached += class_bytes(c);
+                    return hipSuccess;
+                }
+            }
+        }
+        return hipFree(p);
+    }
+    void release() {                              // real hipFree of everything cached
+        std::vector<void*> all;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (auto& l : free_lists) { all.insert(all.end(), l.begin(), l.end()); l.clear(); }
+            cached = 0;
+        }
+        for (void* p : all) (void)hipFree(p);
+    }
+};
+
+inline DevPool& dev_pool() {
+    static DevPool* p = new DevPool();            // never destroyed: the HIP runtime may be gone at static-destruction time
+    return *p;
+}
+
+template <class T>
+inline hipError_t pool_malloc(T** out, size_t bytes) { return dev_pool().alloc((void**)out, bytes); }
+inline hipError_t pool_free(void* p) { return dev_pool().free(p); }
+
+}  // namespace atlas_rt
+
+// every hipMalloc / hipFree below this line in a translation unit of the library goes through the pool
+#define hipMalloc(p, n) atlas_rt::pool_malloc((p), (n))
+#define hipFree(p) atlas_rt::pool_free((void*)(p))

@@ -100,6 +100,15 @@ int prove_onehot_checks(const uint64_t* d_lookups, size_t log_T, size_t log_K, c
                         const H::Fr& ra_claim, atlas_transcript_t* t, Out& O) {
     const size_t lkc = 4, d = (log_K + lkc - 1) / lkc;               // OneHotParams::new: LOG_K_CHUNK = 4 (common/src/consts/general.rs:2)
     H::Transcript& T = *reinterpret_cast<H::Transcript*>(t);
+    const bool trace = getenv("ATLAS_TRACE") != nullptr;
+    auto tr0 = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!trace) return;
+        atlas_sync();
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[atlas trace] onehot_checks d=%zu %-24s %8.3f ms\n", d, what, std::chrono::duration<double, std::milli>(t1 - tr0).count());
+        tr0 = t1;
+    };
     std::vector<H::Fr> gamma_powers(d);                             // challenge_scalar_powers(d)
     { const H::Fr q = H::tr_challenge_scalar(T); gamma_powers[0] = H::one(); for (size_t i = 1; i < d; i++) gamma_powers[i] = H::mul(gamma_powers[i - 1], q); }
     std::vector<H::Fr> gammas(d), r_addr(lkc);                       // challenge_vector_optimized
@@ -114,11 +123,13 @@ int prove_onehot_checks(const uint64_t* d_lookups, size_t log_T, size_t log_K, c
     if (eq_rc) atlas_poly_free(eq_rc);
     if (Gp) atlas_poly_free(Gp);
     if (rc) return rc;
+    mark("ra_evals G");
     // RaVirtual: (r_address, r_cycle) = the ra opening point split at log_K
     atlas_instance_t ra = nullptr, hw = nullptr, bo = nullptr;
     rc = atlas_ra_virtual_from_lookups_new(d_lookups, log_T, log_K, lkc, ra_point.data(), ra_point.data() + log_K, &ra);
     if (!rc) rc = atlas_hamming_weight_new(G.data(), d, lkc, (const atlas_fr_t*)gamma_powers.data(), &hw);
     if (!rc) rc = atlas_booleanity_from_lookups_new(G.data(), d_lookups, log_T, log_K, lkc, (const atlas_fr_t*)gammas.data(), (const atlas_fr_t*)r_addr.data(), r_cycle, &bo);
+    mark("booleanity_new");
     atlas_batched_t b = nullptr;
     H::Fr hw_claim = H::zero();
     for (auto& x : gamma_powers) hw_claim = H::add(hw_claim, x);    // hamming_weight.rs:49-57
@@ -133,6 +144,7 @@ int prove_onehot_checks(const uint64_t* d_lookups, size_t log_T, size_t log_K, c
     std::vector<atlas_u128_t> ch(max_rounds);
     size_t mr = 0;
     if (!rc) rc = atlas_batched_prove(b, t, rows.data(), stride, nco.data(), ch.data(), &mr);
+    mark("batched_prove");
     for (atlas_instance_t inst : {ra, hw, bo}) {
         atlas_fr_t fin[64]; size_t nf = 0;
         if (!rc) rc = atlas_instance_final_claims(inst, fin, 64, &nf);
@@ -144,6 +156,7 @@ int prove_onehot_checks(const uint64_t* d_lookups, size_t log_T, size_t log_K, c
     if (!rc) rc = O.put_proof(rows, stride, nco, mr);
     if (b) atlas_batched_free(b);
     for (atlas_instance_t inst : {ra, hw, bo}) if (inst) atlas_instance_free(inst);
+    mark("finals + free");
     return rc;
 }
 

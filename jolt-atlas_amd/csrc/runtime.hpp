@@ -56,6 +56,8 @@ int fail(int code, const char* what, hipError_t e = hipSuccess);
 
 }  // namespace atlas_rt
 
+#include "devpool.hpp"
+
 #define HIP_TRY(x)                                                             \
     do {                                                                       \
         hipError_t e_ = (x);                                                   \

@@ -17,8 +17,10 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <vector>
 
 #include "../../include/atlas_hip.h"
+#include "channel.hpp"
 #include "f9.hip.h"
 #include "host_field.hpp"
 #include "scan.hip.h"
@@ -78,6 +80,31 @@ __global__ __launch_bounds__(SH_THREADS) void k_sh_bucket_sum_wg(const Fe* __res
     }
 }
 
+// few buckets (the 4-bit chunks of compute_ra_evals: d * 16 <= 256 of them): global counters would take T * d atomics
+// on a handful of addresses (measured 5.4 ms at T = 2^16, d = 16), so each workgroup sums the 32-bit words of E[j]
+// into 64-bit LDS accumulators per bucket, adds them to a global accumulator once, and the host reduces the
+// n_buckets x 8 word sums mod p (sum_to_fr).  No sort, one pass over the indices.
+constexpr uint32_t SH_SMALL_BUCKETS = 512;
+__global__ __launch_bounds__(SH_THREADS) void k_sh_hist_small(const uint64_t* __restrict__ idx, size_t T, KeySpec S,
+                                                              const Fe* __restrict__ E, unsigned long long* __restrict__ acc /* [n_buckets][8] */) {
+    __shared__ unsigned long long sm[SH_SMALL_BUCKETS * 8];
+    const uint32_t n_buckets = S.d << S.log_k_chunk;
+    for (uint32_t w = threadIdx.x; w < n_buckets * 8; w += SH_THREADS) sm[w] = 0;
+    __syncthreads();
+    for (size_t j = (size_t)blockIdx.x * SH_THREADS + threadIdx.x; j < T; j += (size_t)gridDim.x * SH_THREADS) {
+        const uint64_t v = idx[j];
+        const Fe e = fe_load(E + j);
+        for (uint32_t i = 0; i < S.d; i++) {
+            unsigned long long* b = sm + (size_t)key_of(v, i, S) * 8;
+#pragma unroll
+            for (int w = 0; w < 8; w++) atomicAdd(&b[w], (unsigned long long)e.v[w]);
+        }
+    }
+    __syncthreads();
+    for (uint32_t w = threadIdx.x; w < n_buckets * 8; w += SH_THREADS)
+        if (sm[w]) atomicAdd(&acc[w], sm[w]);
+}
+
 // one thread per bucket (large tables, short lists)
 __global__ __launch_bounds__(SH_THREADS) void k_sh_bucket_sum_thread(const Fe* __restrict__ E, const uint32_t* __restrict__ sorted,
                                                                      const uint32_t* __restrict__ offsets, uint32_t n_buckets,
@@ -109,6 +136,41 @@ int histogram(const uint64_t* h_idx, size_t T, KeySpec S, const atlas_poly* E, a
     const uint32_t n_buckets = S.d << S.log_k_chunk;
     if (E->is_i32 || E->len < T) return fail(ATLAS_EINVAL, "shout: eq table shorter than the index list");
     if (T >= (1ull << 31) || (uint64_t)T * S.d >= (1ull << 32)) return fail(ATLAS_EINVAL, "shout: too many lookups");
+    if (n_buckets <= SH_SMALL_BUCKETS && T < ((size_t)1 << 31)) {
+        // words of canonical residues < 2^32, at most 2^31 of them per accumulator: the sums fit 64 bits
+        unsigned long long* d_acc = nullptr; Fe* Gs = nullptr; uint64_t* d_ix = nullptr;
+        const size_t nw = (size_t)n_buckets * 8;
+        HIP_TRY(hipMalloc(&d_acc, nw * 8));
+        hipError_t e2 = hipMalloc(&Gs, (size_t)n_buckets * sizeof(Fe));
+        if (e2 == hipSuccess) e2 = hipMalloc(&d_ix, (T ? T : 1) * 8);
+        if (e2 != hipSuccess) { hipFree(d_acc); hipFree(Gs); return fail(ATLAS_ENOMEM, "hipMalloc(G)", e2); }
+        std::vector<unsigned long long> h_acc(nw);
+        std::vector<H::Fr> h_G(n_buckets);
+        e2 = hipMemsetAsync(d_acc, 0, nw * 8, g.stream);
+        if (e2 == hipSuccess) e2 = hipMemcpyAsync(d_ix, h_idx, T * 8, hipMemcpyDefault, g.stream);   // host or device source
+        if (e2 == hipSuccess) {
+            size_t blocks = (T + SH_THREADS - 1) / SH_THREADS; if (blocks < 1) blocks = 1; if (blocks > 512) blocks = 512;
+            k_sh_hist_small<<<(unsigned)blocks, SH_THREADS, 0, g.stream>>>(d_ix, T, S, (const Fe*)E->d, d_acc);
+            e2 = hipMemcpyAsync(h_acc.data(), d_acc, nw * 8, hipMemcpyDeviceToHost, g.stream);
+        }
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(g.stream);
+        if (e2 == hipSuccess) {
+            for (uint32_t b = 0; b < n_buckets; b++) {
+                uint64_t a9[9];
+                for (int w = 0; w < 8; w++) a9[w] = h_acc[(size_t)b * 8 + w];
+                a9[8] = 0;
+                h_G[b] = atlas_rt::sum_to_fr(a9, 32, 0);
+            }
+            e2 = hipMemcpyAsync(Gs, h_G.data(), (size_t)n_buckets * sizeof(Fe), hipMemcpyHostToDevice, g.stream);
+            if (e2 == hipSuccess) e2 = hipStreamSynchronize(g.stream);
+        }
+        hipFree(d_acc); hipFree(d_ix);
+        if (e2 != hipSuccess) { hipFree(Gs); return fail(ATLAS_ENODEV, "shout histogram", e2); }
+        atlas_poly* p = new atlas_poly();
+        p->d = Gs; p->len = n_buckets; p->cap_bytes = (size_t)n_buckets * sizeof(Fe); p->is_i32 = false; p->owned = true;
+        *out = p;
+        return ATLAS_OK;
+    }
     uint64_t* d_idx = nullptr; uint32_t *counts = nullptr, *offsets = nullptr, *cursor = nullptr, *sorted = nullptr;
     Fe* G = nullptr;
     auto cleanup = [&]() { hipFree(d_idx); hipFree(counts); hipFree(offsets); hipFree(cursor); hipFree(sorted); };
