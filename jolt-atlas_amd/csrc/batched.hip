@@ -362,6 +362,8 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         int rc = PL.begin();
         if (rc) return rc;
     }
+    const bool trace = getenv("ATLAS_TRACE") != nullptr;          // per instance: wall clock of compute_message / ingest_challenge, summed
+    std::vector<double> t_msg(n, 0.0), t_ing(n, 0.0);
     for (size_t round = 0; round < max_rounds; round++) {
         const size_t remaining = max_rounds - round;
         std::vector<std::vector<H::Fr>> polys(n);
@@ -378,8 +380,10 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
                 if (!rc) rc = I.inst->finish(local, claim[i], sums, polys[i]);
                 if (rc) { PL.abort_from(round); (void)hipStreamSynchronize(g.stream); return rc; }
             } else {
+                const auto tm0 = std::chrono::steady_clock::now();
                 int rc = I.inst->message(round - (max_rounds - I.rounds), claim[i], polys[i]);
                 if (rc) return rc;
+                if (trace) t_msg[i] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm0).count();
             }
         }
         // batched = sum coeff_i * poly_i, starting from UniPoly::from_coeff(vec![]) = [0]  (:109-116)
@@ -410,14 +414,20 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         for (size_t i = 0; i < n; i++) {
             Instance& I = b->inst[i];
             if (remaining <= I.rounds) {
+                const auto ti0 = std::chrono::steady_clock::now();
                 int rc = piped ? I.inst->host_ingest(challenges[round], round - (max_rounds - I.rounds))
                                : I.inst->ingest(challenges[round], round - (max_rounds - I.rounds));
                 if (rc) { if (piped) { PL.abort_from(round + 1); (void)hipStreamSynchronize(g.stream); } return rc; }
+                if (trace) t_ing[i] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti0).count();
             }
         }
         if (piped) { int rc = PL.advance(round + 1); if (rc) return rc; }
     }
     *max_rounds_out = max_rounds;
+    if (trace)
+        for (size_t i = 0; i < n; i++)
+            fprintf(stderr, "[atlas trace] batched_prove instance %zu (%zu rounds, degree %zu): compute_message %.3f ms, ingest_challenge %.3f ms\n",
+                    i, b->inst[i].rounds, b->inst[i].inst->degree(), t_msg[i], t_ing[i]);
     if (piped) return PL.collect_finals();
     return ATLAS_OK;
 }

@@ -10,7 +10,7 @@
 // suffix  (relu.rs:55-59; signed_identity_poly.rs:136-160), so two suffix tables per phase carry the
 // whole O(T) part:   Q1[y] = sum_{t : chunk_p(idx_t) = y} u_t,   Qs[y] = sum ... u_t * suffix_t,
 // u_t = eq(r_node, t) * prod_{q < p} v_q[chunk_q(idx_t)]  (mod.rs:269-335).  They are built by
-// k_ps_q (one workgroup per (bin, slice of T)); the per-round arithmetic over the 2^log_m entries —
+// k_ps_q_lds (64-bit word sums per bin in LDS; k_ps_q for more than 256 bins); the per-round arithmetic over the 2^log_m entries —
 // prefix evaluations, binding Q and the expanding table v_p — is host work.  The reference keeps the
 // WordNoMSB suffix as u32, which is exact for N <= 32; N = 64 is refused here for that reason.
 // spec of the suffix functions: mode 0/1 -> {1, suffix}; mode 2 (clamp, BOUND) additionally
@@ -57,62 +57,53 @@ __device__ __forceinline__ void ps_entry_vals(uint64_t k, const Fr& u, uint32_t 
     }
 }
 
-// Q tables of one phase, m = 2^log_m <= 256 bins.  A workgroup walks its slice of T in tiles of 256 lookups: every
-// thread computes the values of ONE lookup (all lanes busy in the multiplications), parks them in LDS, then acts as
-// (bin = tid % m, part = tid / m) and adds the tile entries of its part that fall into its bin.  One partial row of
-// NQ * m sums per workgroup; k_col_reduce adds the rows.
+// Q tables of one phase, m = 2^log_m <= 256 bins: no binning at all.  Every lookup adds the eight 32-bit words of its NQ values into 64-bit
+// LDS accumulators of its bin (ds_add_u64: words < 2^32, at most 2^25 lookups, so a sum stays below 2^57); a workgroup
+// flushes its non-zero accumulators to the global ones and k_ps_q_final turns the word sums back into residues.  (A
+// tiled variant in which every thread scanned its tile's entries for its bin took 168 us per phase at T = 2^16, NQ = 6,
+// m = 256.)  The accumulators are NQ * m * 64 bytes of dynamic LDS (96 KB for the clamp lookup).
 template <int NQ>
-__global__ __launch_bounds__(RA_THREADS) void k_ps_q_tiled(const uint64_t* __restrict__ idx, const Fr* __restrict__ u0,
-                                                           const Fr* __restrict__ prod, size_t T, uint32_t suffix_len, uint32_t m,
-                                                           uint32_t bound, Fr* __restrict__ partials /* [blocks][NQ m] */) {
-    __shared__ Fr vals[NQ][RA_THREADS];
-    __shared__ uint32_t bins[RA_THREADS];
-    const uint32_t tid = threadIdx.x, parts = RA_THREADS / m, per_part = RA_THREADS / parts;
-    const uint32_t my_bin = tid % m, my_part = tid / m;
-    const size_t n_tiles = (T + RA_THREADS - 1) / RA_THREADS;
-    const size_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
-    const size_t tile0 = (size_t)blockIdx.x * per, tile1 = tile0 + per < n_tiles ? tile0 + per : n_tiles;
-    Fr acc[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; q++) acc[q] = fe_zero();
-    for (size_t tile = tile0; tile < tile1; tile++) {
-        const size_t t = tile * RA_THREADS + tid;
-        uint32_t b = 0xFFFFFFFFu;
-        if (t < T) {
-            const uint64_t k = idx[t];
-            b = (uint32_t)(k >> suffix_len) & (m - 1);
-            Fr val[NQ];
-            ps_entry_vals<NQ>(k, fr_mul(fe_load(u0 + t), fe_load(prod + t)), suffix_len, bound, val);
-#pragma unroll
-            for (int q = 0; q < NQ; q++) vals[q][tid] = val[q];
-        }
-        bins[tid] = b;
-        __syncthreads();
-        // first mark this thread's matches among its part's entries (a bit per entry, 32 at a time), then add them: the
-        // additions run for max-over-lanes(popcount) steps instead of once per entry with a handful of lanes active
-        for (uint32_t e0 = my_part * per_part; e0 < (my_part + 1) * per_part; e0 += 32) {
-            const uint32_t span = per_part < 32 ? per_part : 32;
-            uint32_t mask = 0;
-            for (uint32_t i = 0; i < span; i++) mask |= (uint32_t)(bins[e0 + i] == my_bin) << i;
-            while (mask) {
-                const uint32_t e = e0 + (uint32_t)__builtin_ctz(mask);
-                mask &= mask - 1;
-#pragma unroll
-                for (int q = 0; q < NQ; q++) acc[q] = fr_add(acc[q], vals[q][e]);
-            }
-        }
-        __syncthreads();
-    }
-    // add the parts of each bin
-#pragma unroll
-    for (int q = 0; q < NQ; q++) vals[q][tid] = acc[q];
+__global__ __launch_bounds__(RA_THREADS) void k_ps_q_lds(const uint64_t* __restrict__ idx, const Fr* __restrict__ u0,
+                                                         const Fr* __restrict__ prod, size_t T, uint32_t suffix_len, uint32_t m,
+                                                         uint32_t bound, unsigned long long* __restrict__ acc /* [m][NQ][8] */) {
+    extern __shared__ unsigned long long ps_sm[];
+    const uint32_t n_words = m * NQ * 8;
+    for (uint32_t w = threadIdx.x; w < n_words; w += RA_THREADS) ps_sm[w] = 0;
     __syncthreads();
-    for (uint32_t o = tid; o < NQ * m; o += RA_THREADS) {
-        const uint32_t y = o / NQ, q = o % NQ;
-        Fr s = vals[q][y];
-        for (uint32_t p = 1; p < parts; p++) s = fr_add(s, vals[q][p * m + y]);
-        fe_store(partials + (size_t)blockIdx.x * NQ * m + o, s);
+    for (size_t t = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; t < T; t += (size_t)gridDim.x * RA_THREADS) {
+        const uint64_t k = idx[t];
+        const uint32_t b = (uint32_t)(k >> suffix_len) & (m - 1);
+        Fr val[NQ];
+        ps_entry_vals<NQ>(k, fr_mul(fe_load(u0 + t), fe_load(prod + t)), suffix_len, bound, val);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            if (fe_is_zero(val[q])) continue;
+            unsigned long long* a = ps_sm + ((size_t)b * NQ + q) * 8;
+#pragma unroll
+            for (int w = 0; w < 8; w++) atomicAdd(&a[w], (unsigned long long)val[q].v[w]);
+        }
     }
+    __syncthreads();
+    for (uint32_t w = threadIdx.x; w < n_words; w += RA_THREADS)
+        if (ps_sm[w]) atomicAdd(&acc[w], ps_sm[w]);
+}
+
+// word sums -> canonical Montgomery residues: V = lo + hi 2^256, V mod p = lo * R * R^-1 + hi * R^2 * R^-1
+__global__ __launch_bounds__(RA_THREADS) void k_ps_q_final(const unsigned long long* __restrict__ acc, uint32_t n_vals, Fr* __restrict__ out) {
+    const uint32_t i = blockIdx.x * RA_THREADS + threadIdx.x;
+    if (i >= n_vals) return;
+    Fr lo, hi, r2;
+    unsigned long long c = 0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        const unsigned long long s = acc[(size_t)i * 8 + w] + c;
+        lo.v[w] = (uint32_t)s;
+        c = s >> 32;
+    }
+#pragma unroll
+    for (int w = 0; w < 8; w++) { hi.v[w] = 0; r2.v[w] = FrParams::r2(w); }
+    hi.v[0] = (uint32_t)c; hi.v[1] = (uint32_t)(c >> 32);
+    fe_store(out + i, fr_add(fr_mul(lo, fr_one()), fr_mul(hi, r2)));
 }
 
 // m > 256: one workgroup per (bin, slice of T), each filtering its slice for its bin
@@ -186,8 +177,8 @@ struct PsLookup : atlas_instance {
     std::vector<H::Fr> r_addr;
     H::Fr word_acc = H::zero(), sid_acc = H::zero(), wv = H::zero();
     static constexpr unsigned SLICES = 64;
-    // partial rows of a Q build: one per workgroup of k_ps_q_tiled (a workgroup per few tiles keeps the latency chain of a
-    // phase short), at most 2^17 / m of them so that the rows stay a few MB
+    // partial rows of a Q build with m > 256 (k_ps_q), at most 2^17 / m of them so that the rows stay a few MB; the same
+    // area holds the word sums of k_ps_q_lds
     size_t q_rows_max() const { size_t r = ((size_t)1 << 17) / m; if (r > 2048) r = 2048; return r < SLICES ? SLICES : r; }
 
     ~PsLookup() override { for (void* p : {(void*)d_idx, (void*)d_u0, (void*)d_v, (void*)d_qpart}) if (p) hipFree(p); rows.release(); eq.release(); }
@@ -201,20 +192,31 @@ struct PsLookup : atlas_instance {
     int build_Q(size_t phase) {           // init_phase: Q tables of `phase` from the current products
         const uint32_t suffix_len = (uint32_t)((phases - 1 - phase) * log_m);
         const size_t NQ = nq();
-        unsigned n_rows = SLICES;            // partial rows to add
-        if (m <= RA_THREADS) {
-            const size_t n_tiles = (T + RA_THREADS - 1) / RA_THREADS;
-            n_rows = (unsigned)(n_tiles < q_rows_max() ? n_tiles : q_rows_max());
-            if (NQ == 4) k_ps_q_tiled<4><<<n_rows, RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)m, 0u, d_qpart);
-            else if (NQ == 6) k_ps_q_tiled<6><<<n_rows, RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)m, (uint32_t)bound, d_qpart);
-            else if (NQ == 3) k_ps_q_tiled<3><<<n_rows, RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)m, (uint32_t)bound, d_qpart);
-            else k_ps_q_tiled<2><<<n_rows, RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)m, 0u, d_qpart);
-        } else if (NQ == 4) k_ps_q<4><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), 0u, d_qpart);
-        else if (NQ == 6) k_ps_q<6><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), (uint32_t)bound, d_qpart);
-        else if (NQ == 3) k_ps_q<3><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), (uint32_t)bound, d_qpart);
-        else k_ps_q<2><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), 0u, d_qpart);
         Fr* d_qsum = d_qpart + q_rows_max() * NQ * m;
-        k_col_reduce<<<(unsigned)(NQ * m), RA_THREADS, 0, g.stream>>>(d_qpart, n_rows, (uint32_t)(NQ * m), d_qsum);
+        if (m <= RA_THREADS) {
+            unsigned long long* acc = (unsigned long long*)d_qpart;              // m * NQ * 8 word sums (the partial-row area is larger)
+            const size_t lds = m * NQ * 64;
+            size_t gb = T / 2048; if (gb < 16) gb = 16; if (gb > 256) gb = 256;
+            HIP_TRY(hipMemsetAsync(acc, 0, lds, g.stream));
+#define PS_Q_LDS(NQv, BND)                                                                                                         \
+            do {                                                                                                                   \
+                static bool attr_set = false;                                                                                      \
+                if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ps_q_lds<NQv>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * NQv * 64)); attr_set = true; } \
+                k_ps_q_lds<NQv><<<(unsigned)gb, RA_THREADS, lds, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)m, (uint32_t)(BND), acc); \
+            } while (0)
+            if (NQ == 4) PS_Q_LDS(4, 0u);
+            else if (NQ == 6) PS_Q_LDS(6, bound);
+            else if (NQ == 3) PS_Q_LDS(3, bound);
+            else PS_Q_LDS(2, 0u);
+#undef PS_Q_LDS
+            k_ps_q_final<<<(unsigned)((NQ * m + RA_THREADS - 1) / RA_THREADS), RA_THREADS, 0, g.stream>>>(acc, (uint32_t)(NQ * m), d_qsum);
+        } else {
+            if (NQ == 4) k_ps_q<4><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), 0u, d_qpart);
+            else if (NQ == 6) k_ps_q<6><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), (uint32_t)bound, d_qpart);
+            else if (NQ == 3) k_ps_q<3><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), (uint32_t)bound, d_qpart);
+            else k_ps_q<2><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), 0u, d_qpart);
+            k_col_reduce<<<(unsigned)(NQ * m), RA_THREADS, 0, g.stream>>>(d_qpart, SLICES, (uint32_t)(NQ * m), d_qsum);
+        }
         std::vector<H::Fr> q(NQ * m);
         HIP_TRY(hipMemcpyAsync(q.data(), d_qsum, NQ * m * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
@@ -247,67 +249,89 @@ struct PsLookup : atlas_instance {
                 const H::Fr hao_c = j < hbits ? H::mul(hao_acc, c) : hao_acc;
                 const H::Fr lw_c = (mode == 2 && j >= hbits) ? H::add(lw_acc, H::mul(c, pow2(N - 1 - j))) : lw_acc;
                 H::Fr acc = H::zero();
-                for (size_t b = 0; b < half; b++) {
-                    const H::Fr bs = H::mul(H::from_u64(b), sh);
-                    auto qv = [&](size_t k) { return ci ? H::sub(H::add(Q[k][b + half], Q[k][b + half]), Q[k][b]) : Q[k][b]; };
-                    if (mode == 3) {     // UnsignedLessThan over interleaved (x, y) pairs + gamma * Left + gamma^2 * Right
-                        H::Fr lt = lt_acc, eq = eq_acc, lo = lop_acc, ro = rop_acc;
-                        auto pair = [&](const H::Fr& x, const H::Fr& y) {              // unsigned_less_than.rs:33-41
-                            lt = H::add(lt, H::mul(eq, H::mul(H::sub(one, x), y)));
-                            eq = H::mul(eq, H::add(H::mul(x, y), H::mul(H::sub(one, x), H::sub(one, y))));
-                        };
-                        auto opw = [&](size_t var) { H::Fr w = pow2(31 - var / 2); return var < 2 ? H::sub(w, pow2(32)) : w; };
-                        size_t q = 0;                                                   // next bit of b (MSB first)
-                        auto bbit = [&](size_t qq) { return H::from_u64((b >> (blen - 1 - qq)) & 1); };
-                        if (j % 2 == 0) {
-                            const H::Fr y = bbit(0); q = 1;
-                            pair(c, y);
-                            lo = H::add(lo, H::mul(c, opw(j))); ro = H::add(ro, H::mul(y, opw(j + 1)));
-                        } else {
-                            pair(r_addr[j - 1], c);
-                            ro = H::add(ro, H::mul(c, opw(j)));
-                        }
-                        for (; q + 1 < blen + 1 && q < blen; q += 2) {
-                            const H::Fr x = bbit(q), y = bbit(q + 1);
-                            pair(x, y);
-                            lo = H::add(lo, H::mul(x, opw(j + 1 + q))); ro = H::add(ro, H::mul(y, opw(j + 2 + q)));
-                        }
-                        const H::Fr g2 = H::mul(gamma, gamma);
-                        H::Fr val = H::add(H::mul(lt, qv(0)), H::mul(eq, qv(1)));
-                        val = H::add(val, H::mul(gamma, H::add(H::mul(lo, qv(0)), qv(2))));
-                        val = H::add(val, H::mul(g2, H::add(H::mul(ro, qv(0)), qv(3))));
-                        acc = H::add(acc, val);
-                        continue;
+                // Everything but the bin index b is the same for all bins of a round, and b enters linearly (b * 2^suffix_len,
+                // the clamp's low-word bits): the sums over b of Q_k[b] and of (small integer)(b) * Q_k[b] are taken first
+                // (one small-integer multiplication per term) and the prefix factors are applied once.
+                if (mode != 3) {
+                    auto qv = [&](size_t k, size_t b) { return ci ? H::sub(H::add(Q[k][b + half], Q[k][b + half]), Q[k][b]) : Q[k][b]; };
+                    H::Fr s_q1 = H::zero(), s_bq1 = H::zero(), s_qs = H::zero();          // sum q1, sum b q1, sum qs
+                    for (size_t b = 0; b < half; b++) {
+                        const H::Fr q1 = qv(0, b);
+                        s_q1 = H::add(s_q1, q1);
+                        if (b) s_bq1 = H::add(s_bq1, H::mul(H::from_u64(b), q1));
+                        s_qs = H::add(s_qs, qv(1, b));
                     }
-                    const H::Fr q1 = qv(0), qs = qv(1);
-                    const H::Fr idt = H::add(H::mul(H::add(sid_c, bs), q1), qs);          // (Signed)Identity term
-                    if (mode == 1) { acc = H::add(acc, idt); continue; }
-                    if (mode == 4) {     // RightShiftTable (right_shift.rs:54-58): prefix * One + suffix; all of it is linear in the bits
+                    const H::Fr bs_q1 = H::mul(sh, s_bq1);                                 // sum (b 2^suffix_len) q1
+                    const H::Fr idt = H::add(H::add(H::mul(sid_c, s_q1), bs_q1), s_qs);    // sum ((sid_c + bs) q1 + qs)
+                    if (mode == 1) acc = idt;
+                    else if (mode == 0) acc = H::add(H::mul(not_msb, H::add(H::add(H::mul(word_c, s_q1), bs_q1), s_qs)), H::mul(gamma, idt));
+                    else if (mode == 4) {
                         const H::Fr rs_c = H::add(rs_acc, H::mul(c, rs_weight(j)));
-                        const uint64_t chunk_val = (uint64_t)b << suffix_len;         // the chunk's remaining bits at their significance
-                        const H::Fr val = H::add(H::mul(H::add(rs_c, H::from_u64(bound >= 64 ? 0 : chunk_val >> bound)), q1), qv(2));
-                        acc = H::add(acc, H::add(val, H::mul(gamma, idt)));
-                        continue;
+                        H::Fr s_cq1 = H::zero(), s_q2 = H::zero();                         // sum (chunk >> shift) q1, sum q2
+                        for (size_t b = 0; b < half; b++) {
+                            const uint64_t cv = bound >= 64 ? 0 : ((uint64_t)b << suffix_len) >> bound;
+                            if (cv) s_cq1 = H::add(s_cq1, H::mul(H::from_u64(cv), qv(0, b)));
+                            s_q2 = H::add(s_q2, qv(2, b));
+                        }
+                        acc = H::add(H::add(H::add(H::mul(rs_c, s_q1), s_cq1), s_q2), H::mul(gamma, idt));
+                    } else {      // clamp (clamp.rs:84-109): chunk bits of b at variable index j+1+q are high iff that index < hbits
+                        H::Fr z_q2 = H::zero(), z_lq2 = H::zero(), z_q3 = H::zero(), o_q4 = H::zero(), o_lq4 = H::zero(), o_q5 = H::zero();
+                        for (size_t b = 0; b < half; b++) {
+                            bool z = true, o = true;
+                            uint64_t lwb = 0;
+                            for (size_t q = 0; q < blen; q++) {
+                                const size_t var = j + 1 + q;
+                                const uint64_t bit = (b >> (blen - 1 - q)) & 1;
+                                if (var < hbits) { if (bit) z = false; else o = false; }
+                                else lwb |= bit << (N - 1 - var);
+                            }
+                            if (z) {
+                                const H::Fr q2 = qv(2, b);
+                                z_q2 = H::add(z_q2, q2); z_q3 = H::add(z_q3, qv(3, b));
+                                if (lwb) z_lq2 = H::add(z_lq2, H::mul(H::from_u64(lwb), q2));
+                            }
+                            if (o && symmetric) {
+                                const H::Fr q4 = qv(4, b);
+                                o_q4 = H::add(o_q4, q4); o_q5 = H::add(o_q5, qv(5, b));
+                                if (lwb) o_lq4 = H::add(o_lq4, H::mul(H::from_u64(lwb), q4));
+                            }
+                        }
+                        // sum_z haz_c ((lw_c + lwb - U) q2 + q3) + sum_o hao_c ((lw_c + lwb) q4 + q5)
+                        H::Fr val = H::mul(H::sub(U, H::mul(msb, LC)), s_q1);
+                        val = H::add(val, H::mul(haz_c, H::add(H::add(H::mul(H::sub(lw_c, U), z_q2), z_lq2), z_q3)));
+                        if (symmetric) val = H::add(val, H::mul(hao_c, H::add(H::add(H::mul(lw_c, o_q4), o_lq4), o_q5)));
+                        acc = H::add(val, H::mul(gamma, idt));
                     }
-                    if (mode == 0) {
-                        const H::Fr val = H::mul(not_msb, H::add(H::mul(H::add(word_c, bs), q1), qs));
-                        acc = H::add(acc, H::add(val, H::mul(gamma, idt)));
-                        continue;
+                } else
+                for (size_t b = 0; b < half; b++) {
+                    auto qv = [&](size_t k) { return ci ? H::sub(H::add(Q[k][b + half], Q[k][b + half]), Q[k][b]) : Q[k][b]; };
+                    // UnsignedLessThan over interleaved (x, y) pairs + gamma * Left + gamma^2 * Right
+                    H::Fr lt = lt_acc, eq = eq_acc, lo = lop_acc, ro = rop_acc;
+                    auto pair = [&](const H::Fr& x, const H::Fr& y) {              // unsigned_less_than.rs:33-41
+                        lt = H::add(lt, H::mul(eq, H::mul(H::sub(one, x), y)));
+                        eq = H::mul(eq, H::add(H::mul(x, y), H::mul(H::sub(one, x), H::sub(one, y))));
+                    };
+                    auto opw = [&](size_t var) { H::Fr w = pow2(31 - var / 2); return var < 2 ? H::sub(w, pow2(32)) : w; };
+                    size_t q = 0;                                                   // next bit of b (MSB first)
+                    auto bbit = [&](size_t qq) { return H::from_u64((b >> (blen - 1 - qq)) & 1); };
+                    if (j % 2 == 0) {
+                        const H::Fr y = bbit(0); q = 1;
+                        pair(c, y);
+                        lo = H::add(lo, H::mul(c, opw(j))); ro = H::add(ro, H::mul(y, opw(j + 1)));
+                    } else {
+                        pair(r_addr[j - 1], c);
+                        ro = H::add(ro, H::mul(c, opw(j)));
                     }
-                    // clamp (clamp.rs:84-109): chunk bits of b at variable index j+1+q are high iff that index < hbits
-                    bool z = true, o = true;
-                    uint64_t lwb = 0;
-                    for (size_t q = 0; q < blen; q++) {
-                        const size_t var = j + 1 + q;
-                        const uint64_t bit = (b >> (blen - 1 - q)) & 1;
-                        if (var < hbits) { if (bit) z = false; else o = false; }
-                        else lwb |= bit << (N - 1 - var);
+                    for (; q + 1 < blen + 1 && q < blen; q += 2) {
+                        const H::Fr x = bbit(q), y = bbit(q + 1);
+                        pair(x, y);
+                        lo = H::add(lo, H::mul(x, opw(j + 1 + q))); ro = H::add(ro, H::mul(y, opw(j + 2 + q)));
                     }
-                    H::Fr val = H::mul(H::sub(U, H::mul(msb, LC)), q1);
-                    const H::Fr lw = H::add(lw_c, H::from_u64(lwb));
-                    if (z) val = H::add(val, H::mul(haz_c, H::add(H::mul(H::sub(lw, U), qv(2)), qv(3))));
-                    if (o && symmetric) val = H::add(val, H::mul(hao_c, H::add(H::mul(lw, qv(4)), qv(5))));
-                    acc = H::add(acc, H::add(val, H::mul(gamma, idt)));
+                    const H::Fr g2 = H::mul(gamma, gamma);
+                    H::Fr val = H::add(H::mul(lt, qv(0)), H::mul(eq, qv(1)));
+                    val = H::add(val, H::mul(gamma, H::add(H::mul(lo, qv(0)), qv(2))));
+                    val = H::add(val, H::mul(g2, H::add(H::mul(ro, qv(0)), qv(3))));
+                    acc = H::add(acc, val);
                 }
                 ev[ci] = acc;
             }
@@ -361,8 +385,8 @@ struct PsLookup : atlas_instance {
                 HIP_TRY(hipMemcpyAsync(d_v, v.data(), m * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
                 size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
                 k_ps_scale<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(d_idx, d_v, T, (uint32_t)((phases - 1 - p) * log_m), (uint32_t)(m - 1), rows.buf[0]);
-                HIP_TRY(hipStreamSynchronize(g.stream));
-                if (p != phases - 1) { int rc = build_Q(p + 1); if (rc) return rc; }
+                if (p != phases - 1) { int rc = build_Q(p + 1); if (rc) return rc; }       // (ends with a stream synchronize: v may change after it)
+                else HIP_TRY(hipStreamSynchronize(g.stream));
             }
             if (j + 1 == N) {
                 // val = Val~(r_address), raf_val = gamma * SId~(r_address)   (mod.rs:523-548)

@@ -22,7 +22,7 @@ namespace {
 
 template <int D, int K0, int KN>
 __global__ __launch_bounds__(RA_THREADS) void k_ra_prod_f9(const Fr* __restrict__ ra, size_t stride, SplitEqView E,
-                                                           size_t n_groups, Fr* __restrict__ partials) {
+                                                           size_t n_groups, Fr* __restrict__ partials, MailTail tail) {
     using P9 = Fr9Params;
     const size_t gidx = (size_t)blockIdx.x * RA_THREADS + threadIdx.x;
     F9 prod[KN];
@@ -62,13 +62,14 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_prod_f9(const Fr* __restrict_
         for (int w = 1; w < RA_THREADS / 64; w++) sres = f9_norm_red<P9>(f9_add(sres, red9[w][threadIdx.x]));
         fe_store(partials + (size_t)blockIdx.x * D + K0 + threadIdx.x, f9_canon<P9>(sres));
     }
+    mail_tail(partials, tail);
 }
 
 // the same sums with one grid column per thread (blockIdx.y = column): for short instances the chain of D
 // multiplications per column is the latency of the round, so the columns go to different threads
 template <int D>
 __global__ __launch_bounds__(RA_THREADS) void k_ra_prod_f9_col(const Fr* __restrict__ ra, size_t stride, SplitEqView E,
-                                                               size_t n_groups, Fr* __restrict__ partials /* [gridDim.x][D] */) {
+                                                               size_t n_groups, Fr* __restrict__ partials /* [gridDim.x][D] */, MailTail tail) {
     using P9 = Fr9Params;
     const size_t gidx = (size_t)blockIdx.x * RA_THREADS + threadIdx.x;
     const int k = blockIdx.y;
@@ -76,13 +77,26 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_prod_f9_col(const Fr* __restr
     if (gidx < n_groups) {
         const size_t mask = ((size_t)1 << E.in_bits) - 1;
         prod = f9_mul<P9>(f9_load(E.e_out + (gidx >> E.in_bits)), f9_load(E.e_in + (gidx & mask)));
+        // rows in batches of RB: the 2 RB loads of a batch are in flight together, so a thread waits for memory
+        // ceil(D / RB) times instead of D times (24 us -> 9 us per round at d = 16 below 2^13 pairs)
+        constexpr int RB = D < 4 ? D : 4;
 #pragma unroll 1
-        for (int i = 0; i < D; i++) {
-            const Fr* row = ra + (size_t)i * stride + 2 * gidx;
-            const F9 a0 = f9_load(row), a1 = f9_load(row + 1);
-            const F9 dl = f9_norm_red<P9, 2>(f9_sub<P9>(a1, a0));
-            const F9 val = k == D - 1 ? dl : f9_axpy_small(a0, dl, (uint32_t)k + 1);   // column D-1: X -> inf; else p_i(k + 1), lazy
-            prod = f9_mul<P9>(prod, val);
+        for (int i0 = 0; i0 < D; i0 += RB) {
+            Fr a0[RB], a1[RB];
+#pragma unroll
+            for (int u = 0; u < RB; u++) {
+                const int i = i0 + u < D ? i0 + u : D - 1;
+                const Fr* row = ra + (size_t)i * stride + 2 * gidx;
+                a0[u] = fe_load(row); a1[u] = fe_load(row + 1);
+            }
+#pragma unroll
+            for (int u = 0; u < RB; u++) {
+                if (i0 + u >= D) break;
+                const F9 x0 = f9_from_fe(a0[u]), x1 = f9_from_fe(a1[u]);
+                const F9 dl = f9_norm_red<P9, 2>(f9_sub<P9>(x1, x0));
+                const F9 val = k == D - 1 ? dl : f9_axpy_small(x0, dl, (uint32_t)k + 1);   // column D-1: X -> inf; else p_i(k + 1), lazy
+                prod = f9_mul<P9>(prod, val);
+            }
         }
     }
     __shared__ F9 red9[RA_THREADS / 64];
@@ -94,6 +108,7 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_prod_f9_col(const Fr* __restr
         for (int w = 1; w < RA_THREADS / 64; w++) t = f9_norm_red<P9>(f9_add(t, red9[w]));
         fe_store(partials + (size_t)blockIdx.x * D + k, f9_canon<P9>(t));
     }
+    mail_tail(partials, tail);
 }
 
 // booleanity phase 2 (booleanity.rs:254-276): per pair index j
@@ -103,7 +118,7 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_prod_f9_col(const Fr* __restr
 // the second factor, E_out E_in, the weighting): a stored sum is 32^-4 times the true one, undone on the host.
 __global__ __launch_bounds__(RA_THREADS) void k_bool_fold(const Fr* __restrict__ Hp, size_t stride, uint32_t d,
                                                           const Fr* __restrict__ gammas, SplitEqView E, size_t n_groups,
-                                                          Fr* __restrict__ partials) {
+                                                          Fr* __restrict__ partials, MailTail tail) {
     using P9 = Fr9Params;
     F9 acc0 = f9_zero(), acc1 = f9_zero();
     const F9 one = f9_from_fe(fr_one());
@@ -137,19 +152,32 @@ __global__ __launch_bounds__(RA_THREADS) void k_bool_fold(const Fr* __restrict__
         for (int w = 1; w < RA_THREADS / 64; w++) s = f9_norm_red<P9>(f9_add(s, red9[w][threadIdx.x]));
         fe_store(partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + threadIdx.x, f9_canon<P9>(s));
     }
+    mail_tail(partials, tail);
 }
 
 // out[k] = sum_p partials[p * K + k]; one workgroup per column
 template <int D>
-void launch_prod(const RaRows& R, const SplitEqView& E, size_t n_groups, unsigned blocks) {
+void launch_prod(const Fr* buf, size_t stride, Fr* partials, const SplitEqView& E, size_t n_groups, unsigned blocks, MailTail tail) {
+    tail.n_rows = blocks; tail.K = D;
+    const MailTail none{tail.io, nullptr, 0, 0};
     if (n_groups <= ((size_t)1 << 13)) {      // latency regime: one column per thread
-        k_ra_prod_f9_col<D><<<dim3(blocks, D), RA_THREADS, 0, g.stream>>>(R.buf[R.cur], R.stride[R.cur], E, n_groups, R.partials);
+        k_ra_prod_f9_col<D><<<dim3(blocks, D), RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, tail);
         return;
     }
     constexpr int KA = D < 8 ? D : 8;
-    k_ra_prod_f9<D, 0, KA><<<blocks, RA_THREADS, 0, g.stream>>>(R.buf[R.cur], R.stride[R.cur], E, n_groups, R.partials);
+    k_ra_prod_f9<D, 0, KA><<<blocks, RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, D > 8 ? none : tail);
     if constexpr (D > 8)
-        k_ra_prod_f9<D, 8, D - 8><<<blocks, RA_THREADS, 0, g.stream>>>(R.buf[R.cur], R.stride[R.cur], E, n_groups, R.partials);
+        k_ra_prod_f9<D, 8, D - 8><<<blocks, RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, tail);   // mails all D columns
+}
+int launch_prod_d(size_t d, const Fr* buf, size_t stride, Fr* partials, const SplitEqView& E, size_t n_groups, unsigned blocks, const MailTail& tail) {
+    switch (d) {
+#define RA_CASE(D) case D: launch_prod<D>(buf, stride, partials, E, n_groups, blocks, tail); break;
+        RA_CASE(1) RA_CASE(2) RA_CASE(3) RA_CASE(4) RA_CASE(5) RA_CASE(6) RA_CASE(7) RA_CASE(8)
+        RA_CASE(9) RA_CASE(10) RA_CASE(11) RA_CASE(12) RA_CASE(13) RA_CASE(14) RA_CASE(15) RA_CASE(16)
+#undef RA_CASE
+        default: return fail(ATLAS_EINVAL, "ra_virtual: d > 16");
+    }
+    return ATLAS_OK;
 }
 
 // ---------------------------------------------------------------- RaSumcheckProver
@@ -165,17 +193,14 @@ struct RaVirtual : atlas_instance {
         std::lock_guard<atlas_rt::Mutex> lk(g.mu);
         const size_t n_groups = rows.len / 2;
         const unsigned blocks = (unsigned)((n_groups + RA_THREADS - 1) / RA_THREADS);
-        const SplitEqView E = eq.view();
-        switch (rows.d) {
-#define RA_CASE(D) case D: launch_prod<D>(rows, E, n_groups, blocks); break;
-            RA_CASE(1) RA_CASE(2) RA_CASE(3) RA_CASE(4) RA_CASE(5) RA_CASE(6) RA_CASE(7) RA_CASE(8)
-            RA_CASE(9) RA_CASE(10) RA_CASE(11) RA_CASE(12) RA_CASE(13) RA_CASE(14) RA_CASE(15) RA_CASE(16)
-#undef RA_CASE
-            default: return fail(ATLAS_EINVAL, "ra_virtual: d > 16");
-        }
-        std::vector<H::Fr> sums(rows.d);
-        int rc = rows.reduce_to_host(blocks, (uint32_t)rows.d, sums.data());
+        int rc = launch_prod_d(rows.d, rows.buf[rows.cur], rows.stride[rows.cur], rows.partials, eq.view(), n_groups, blocks, MailTail{{}, nullptr, 0, 0});
         if (rc) return rc;
+        std::vector<H::Fr> sums(rows.d);
+        rc = rows.reduce_to_host(blocks, (uint32_t)rows.d, sums.data());
+        if (rc) return rc;
+        return finish_sums(sums, claim, coeffs);
+    }
+    int finish_sums(std::vector<H::Fr>& sums, const H::Fr& claim, std::vector<H::Fr>& coeffs) {
         H::Fr fix = H::one();                                        // 32^(d+1): the 2^-5 per f9_mul
         for (size_t k = 0; k < rows.d + 1; k++) fix = H::mul(fix, H::from_u64(32));
         fix = H::mul(fix, eq.st.scalar);                             // mles_product_sum.rs:131
@@ -192,7 +217,61 @@ struct RaVirtual : atlas_instance {
         round_next++;
         return ATLAS_OK;
     }
-    int finals(std::vector<H::Fr>& out) override { std::lock_guard<atlas_rt::Mutex> lk(g.mu); return rows.finals(out); }
+    int finals(std::vector<H::Fr>& out) override {
+        if (have_finals) { out = mailed_finals; return ATLAS_OK; }
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        return rows.finals(out);
+    }
+
+    // ---- round-channel stepping (instance.hpp).  Rows of round k live in buf[k & 1] with stride T >> k.
+    bool have_finals = false;
+    std::vector<H::Fr> mailed_finals;
+    bool pipelined() const override { return true; }
+    int enqueue(size_t round, const atlas::RoundIo& io, bool bind_prev, atlas_mail_ref& mail) override {
+        if (round >= log_T || (round > 0) != bind_prev) return fail(ATLAS_ESTATE, "ra_virtual: enqueue out of order");
+        const size_t T = (size_t)1 << log_T, len = T >> round, n_groups = len / 2;
+        const ChanIo cio{io, g.challenge_mode};
+        if (bind_prev) {
+            size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
+            k_ra_bind_ch<<<dim3((unsigned)gb, (unsigned)rows.d), RA_THREADS, 0, g.stream>>>(rows.buf[(round - 1) & 1], T >> (round - 1), rows.buf[round & 1], len, len,
+                                                                                          cio, g.challenge_mode == 0 ? 1 : 0);
+        }
+        const unsigned blocks = (unsigned)((n_groups + RA_THREADS - 1) / RA_THREADS);
+        size_t ot, it;
+        eq.st.tops_after(round, ot, it);
+        int rc = launch_prod_d(rows.d, rows.buf[round & 1], len, rows.partials, eq.view_at(ot, it), n_groups, blocks, MailTail{io, rows.d_counter, 0, 0});
+        if (rc) return rc;
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(ATLAS_ENODEV, "ra_virtual: launch", e);
+        mail.base = io.mail; mail.blocks = 1; mail.n_vals = (int)rows.d; mail.radix = 32; mail.shl = 0;
+        return ATLAS_OK;
+    }
+    void prepare(size_t round) override { if (round == round_next) eq.st.prepare_inverses(true); }
+    int finish(size_t round, const H::Fr& claim, const H::Fr* s, std::vector<H::Fr>& coeffs) override {
+        if (round != round_next || round >= log_T) return fail(ATLAS_ESTATE, "ra_virtual: round out of order");
+        std::vector<H::Fr> sums(s, s + rows.d);
+        return finish_sums(sums, claim, coeffs);
+    }
+    int host_ingest(const atlas_u128_t& r, size_t round) override {
+        if (round != round_next || round >= log_T) return fail(ATLAS_ESTATE, "ra_virtual: round out of order");
+        eq.st.bind(H::challenge_to_fr(r.lo, r.hi, g.challenge_mode));
+        rows.cur = (int)((round + 1) & 1); rows.len = ((size_t)1 << log_T) >> (round + 1); rows.stride[rows.cur] = rows.len;
+        round_next++;
+        return ATLAS_OK;
+    }
+    int enqueue_finals(const atlas::RoundIo& io, atlas_mail_ref& mail) override {
+        const size_t T = (size_t)1 << log_T;
+        k_rows_final_ch<<<1, 64, 0, g.stream>>>(rows.buf[(log_T - 1) & 1], T >> (log_T - 1), (uint32_t)rows.d, ChanIo{io, g.challenge_mode}, g.challenge_mode == 0 ? 1 : 0);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(ATLAS_ENODEV, "ra_virtual: launch", e);
+        mail.base = io.mail; mail.blocks = 1; mail.n_vals = (int)rows.d; mail.radix = 32; mail.shl = 0;
+        return ATLAS_OK;
+    }
+    int set_finals(const H::Fr* vals, size_t n) override {
+        if (n != rows.d) return fail(ATLAS_EINVAL, "ra_virtual: final claims");
+        mailed_finals.assign(vals, vals + n); have_finals = true;
+        return ATLAS_OK;
+    }
 };
 
 // upload d host tables of K Fr each
@@ -206,6 +285,19 @@ int upload_tables(const std::vector<std::vector<H::Fr>>& t, size_t K, Fr** out) 
     return ATLAS_OK;
 }
 
+// ExpandingTable::update (LowToHigh) on the device for the pipelined Booleanity: F has n entries, the challenge of the
+// round just closed doubles it.  One workgroup; n <= 2^15.
+__global__ __launch_bounds__(RA_THREADS) void k_bool_expand_ch(Fr* F, uint32_t n, ChanIo io) {
+    Fr r;
+    if (!io.challenge(r)) return;
+    for (uint32_t x = threadIdx.x; x < n; x += RA_THREADS) {
+        const Fr f = fe_load(F + x), hi = fr_mul(f, r);
+        fe_store(F + n + x, hi);
+        fe_store(F + x, fr_sub(f, hi));
+    }
+}
+__global__ void k_bool_expand_init(Fr* F) { if (threadIdx.x == 0) fe_store(F, fr_one()); }
+
 // ---------------------------------------------------------------- BooleanitySumcheckProver
 struct Booleanity : atlas_instance {
     size_t d = 0, log_k = 0, log_T = 0, round_next = 0;
@@ -215,57 +307,65 @@ struct Booleanity : atlas_instance {
     std::vector<std::vector<H::Fr>> B_out, B_in;       // host prefix tables of B
     GseDev D;
     RaRows rows;
-    Fr* d_gammas = nullptr;
+    Fr *d_gammas = nullptr, *d_F = nullptr;          // d_F: 2^log_k entries, the device ExpandingTable of the pipelined path
     H::Fr eq_r_r = H::zero(), eq_r_r_inv = H::zero();
     bool have_eq_r_r_inv = false;
-    ~Booleanity() override { rows.release(); D.release(); if (d_gammas) hipFree(d_gammas); }
+    ~Booleanity() override { rows.release(); D.release(); if (d_gammas) hipFree(d_gammas); if (d_F) hipFree(d_F); }
     size_t rounds() const override { return log_k + log_T; }
     size_t degree() const override { return 3; }
 
+    int phase1_message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) {      // compute_phase1_message
+        const size_t m = round + 1;
+        const auto& e_out = B_out[B.out_top]; const auto& e_in = B_in[B.in_top];
+        H::Fr q0 = H::zero(), qinf = H::zero();
+        for (size_t xo = 0; xo < e_out.size(); xo++) {
+            H::Fr i0 = H::zero(), i1 = H::zero();
+            for (size_t xi = 0; xi < e_in.size(); xi++) {
+                const size_t kp = (xo << B.in_top) | xi;
+                H::Fr c0 = H::zero(), c1 = H::zero();
+                for (size_t i = 0; i < d; i++) {
+                    H::Fr s0 = H::zero(), s1 = H::zero();
+                    for (size_t k = 0; k < ((size_t)1 << m); k++) {
+                        const H::Fr& Gk = G[i][(kp << m) + k];
+                        const H::Fr& Fk = F[k % ((size_t)1 << (m - 1))];
+                        const H::Fr gf = H::mul(Gk, Fk), ei = H::mul(gf, Fk);
+                        if ((k >> (m - 1)) == 0) s0 = H::add(s0, H::sub(ei, gf));
+                        s1 = H::add(s1, ei);
+                    }
+                    c0 = H::add(c0, H::mul(gammas[i], s0)); c1 = H::add(c1, H::mul(gammas[i], s1));
+                }
+                i0 = H::add(i0, H::mul(e_in[xi], c0)); i1 = H::add(i1, H::mul(e_in[xi], c1));
+            }
+            q0 = H::add(q0, H::mul(e_out[xo], i0)); qinf = H::add(qinf, H::mul(e_out[xo], i1));
+        }
+        H::gruen_deg3(B, q0, qinf, claim, coeffs.data());
+        return ATLAS_OK;
+    }
     int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
         if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "booleanity: round out of order");
         coeffs.assign(4, H::zero());
-        if (round < log_k) {                                         // compute_phase1_message
-            const size_t m = round + 1;
-            const auto& e_out = B_out[B.out_top]; const auto& e_in = B_in[B.in_top];
-            H::Fr q0 = H::zero(), qinf = H::zero();
-            for (size_t xo = 0; xo < e_out.size(); xo++) {
-                H::Fr i0 = H::zero(), i1 = H::zero();
-                for (size_t xi = 0; xi < e_in.size(); xi++) {
-                    const size_t kp = (xo << B.in_top) | xi;
-                    H::Fr c0 = H::zero(), c1 = H::zero();
-                    for (size_t i = 0; i < d; i++) {
-                        H::Fr s0 = H::zero(), s1 = H::zero();
-                        for (size_t k = 0; k < ((size_t)1 << m); k++) {
-                            const H::Fr& Gk = G[i][(kp << m) + k];
-                            const H::Fr& Fk = F[k % ((size_t)1 << (m - 1))];
-                            const H::Fr gf = H::mul(Gk, Fk), ei = H::mul(gf, Fk);
-                            if ((k >> (m - 1)) == 0) s0 = H::add(s0, H::sub(ei, gf));
-                            s1 = H::add(s1, ei);
-                        }
-                        c0 = H::add(c0, H::mul(gammas[i], s0)); c1 = H::add(c1, H::mul(gammas[i], s1));
-                    }
-                    i0 = H::add(i0, H::mul(e_in[xi], c0)); i1 = H::add(i1, H::mul(e_in[xi], c1));
-                }
-                q0 = H::add(q0, H::mul(e_out[xo], i0)); qinf = H::add(qinf, H::mul(e_out[xo], i1));
-            }
-            H::gruen_deg3(B, q0, qinf, claim, coeffs.data());
-            return ATLAS_OK;
-        }
+        if (round < log_k) return phase1_message(round, claim, coeffs);
         std::lock_guard<atlas_rt::Mutex> lk(g.mu);                        // compute_phase2_message
         const size_t n_groups = rows.len / 2;
+        const uint32_t n_part = launch_fold(rows.buf[rows.cur], rows.stride[rows.cur], D.view(), n_groups);
+        H::Fr s[2];
+        int rc = rows.reduce_to_host(n_part, 2, s);
+        if (rc) return rc;
+        return finish_phase2(s, claim, coeffs);
+    }
+    uint32_t launch_fold(const Fr* buf, size_t stride, const SplitEqView& E, size_t n_groups, const atlas::RoundIo* io = nullptr) {
         size_t blocks = (n_groups + RA_THREADS - 1) / RA_THREADS; if (blocks > 2048) blocks = 2048;
         const unsigned ysplit = n_groups <= ((size_t)1 << 13) ? (unsigned)d : 1u;   // latency regime: one row per thread
-        k_bool_fold<<<dim3((unsigned)blocks, ysplit), RA_THREADS, 0, g.stream>>>(rows.buf[rows.cur], rows.stride[rows.cur], (uint32_t)d, d_gammas,
-                                                                             D.view(), n_groups, rows.partials);
-        H::Fr s[2];
-        int rc = rows.reduce_to_host((uint32_t)(blocks * ysplit), 2, s);
-        if (rc) return rc;
+        const MailTail tail = io ? MailTail{*io, rows.d_counter, (uint32_t)(blocks * ysplit), 2u} : MailTail{{}, nullptr, 0, 0};
+        k_bool_fold<<<dim3((unsigned)blocks, ysplit), RA_THREADS, 0, g.stream>>>(buf, stride, (uint32_t)d, d_gammas, E, n_groups, rows.partials, tail);
+        return (uint32_t)(blocks * ysplit);
+    }
+    int finish_phase2(const H::Fr* sums, const H::Fr& claim, std::vector<H::Fr>& coeffs) {
         static const H::Fr fix = H::from_u64(1048576);               // 32^4: the 2^-5 of each of the four f9_mul behind a term
-        s[0] = H::mul(s[0], fix); s[1] = H::mul(s[1], fix);
+        const H::Fr s0 = H::mul(sums[0], fix), s1 = H::mul(sums[1], fix);
         if (!have_eq_r_r_inv) { eq_r_r_inv = H::inv(eq_r_r); have_eq_r_r_inv = true; }   // constant over phase 2
         const H::Fr adj = H::mul(claim, eq_r_r_inv);
-        H::gruen_deg3(D.st, s[0], s[1], adj, coeffs.data());
+        H::gruen_deg3(D.st, s0, s1, adj, coeffs.data());
         for (auto& c : coeffs) c = H::mul(c, eq_r_r);                // gruen_poly * eq_r_r (from_coeff)
         H::trim(coeffs);
         return ATLAS_OK;
@@ -282,11 +382,11 @@ struct Booleanity : atlas_instance {
             if (round == log_k - 1) {
                 std::lock_guard<atlas_rt::Mutex> lk(g.mu);
                 eq_r_r = B.scalar;
-                Fr* d_F = nullptr;
-                HIP_TRY(hipMalloc(&d_F, F.size() * sizeof(Fr)));
-                HIP_TRY(hipMemcpyAsync(d_F, F.data(), F.size() * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
-                int rc = rows.gather(d_F, 0);                         // every H_i reads the same table F
-                hipFree(d_F);
+                Fr* d_Fh = nullptr;
+                HIP_TRY(hipMalloc(&d_Fh, F.size() * sizeof(Fr)));
+                HIP_TRY(hipMemcpyAsync(d_Fh, F.data(), F.size() * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+                int rc = rows.gather(d_Fh, 0);                        // every H_i reads the same table F
+                hipFree(d_Fh);
                 if (rc) return rc;
                 G.clear();
             }
@@ -299,7 +399,83 @@ struct Booleanity : atlas_instance {
         round_next++;
         return ATLAS_OK;
     }
-    int finals(std::vector<H::Fr>& out) override { std::lock_guard<atlas_rt::Mutex> lk(g.mu); return rows.finals(out); }
+    int finals(std::vector<H::Fr>& out) override {
+        if (have_finals) { out = mailed_finals; return ATLAS_OK; }
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        return rows.finals(out);
+    }
+
+    // ---- round-channel stepping (instance.hpp).  Phase 1 (the log_k address rounds) is host arithmetic: its enqueues
+    // only keep the device copy of the expanding table F in step (k_bool_expand_ch applies the challenge of the round
+    // just closed), so that the enqueue of the first cycle round can gather H_i = F[idx_i] without the host.  Phase-2
+    // round p has its rows in buf[p & 1] with stride T >> p.
+    bool have_finals = false;
+    std::vector<H::Fr> mailed_finals;
+    bool pipelined() const override { return log_k <= 15; }
+    int enqueue(size_t round, const atlas::RoundIo& io, bool bind_prev, atlas_mail_ref& mail) override {
+        if (round >= rounds() || (round > 0) != bind_prev) return fail(ATLAS_ESTATE, "booleanity: enqueue out of order");
+        const ChanIo cio{io, g.challenge_mode};
+        mail.base = io.mail; mail.blocks = 0; mail.n_vals = 0; mail.radix = 32; mail.shl = 0;
+        if (round == 0) {
+            if (!d_F) HIP_TRY(hipMalloc(&d_F, ((size_t)1 << log_k) * sizeof(Fr)));
+            k_bool_expand_init<<<1, 64, 0, g.stream>>>(d_F);
+        }
+        if (round >= 1 && round <= log_k) k_bool_expand_ch<<<1, RA_THREADS, 0, g.stream>>>(d_F, 1u << (round - 1), cio);
+        if (round < log_k) return ATLAS_OK;
+        const size_t T = (size_t)1 << log_T, p = round - log_k, len = T >> p, n_groups = len / 2;
+        if (p == 0) {
+            if (!rows.d_idx) return fail(ATLAS_ESTATE, "booleanity: indices not uploaded");
+            size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
+            k_ra_gather<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, g.stream>>>(rows.d_idx, d_F, 0u, T, rows.buf[0]);   // every H_i reads the same table F
+        } else {
+            size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
+            k_ra_bind_ch<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, g.stream>>>(rows.buf[(p - 1) & 1], T >> (p - 1), rows.buf[p & 1], len, len, cio,
+                                                                                     g.challenge_mode == 0 ? 1 : 0);
+        }
+        size_t ot, it;
+        D.st.tops_after(p, ot, it);
+        launch_fold(rows.buf[p & 1], len, D.view_at(ot, it), n_groups, &io);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(ATLAS_ENODEV, "booleanity: launch", e);
+        mail.blocks = 1; mail.n_vals = 2;
+        return ATLAS_OK;
+    }
+    void prepare(size_t round) override { if (round == round_next && round > log_k) D.st.prepare_inverses(false); }
+    int finish(size_t round, const H::Fr& claim, const H::Fr* s, std::vector<H::Fr>& coeffs) override {
+        if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "booleanity: round out of order");
+        coeffs.assign(4, H::zero());
+        return round < log_k ? phase1_message(round, claim, coeffs) : finish_phase2(s, claim, coeffs);
+    }
+    int host_ingest(const atlas_u128_t& r, size_t round) override {
+        if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "booleanity: round out of order");
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        if (round < log_k) {
+            B.bind(rf);
+            const size_t n = F.size();                               // ExpandingTable::update, LowToHigh (the host copy feeds phase1_message)
+            F.resize(2 * n);
+            for (size_t x = 0; x < n; x++) { F[n + x] = H::mul(F[x], rf); F[x] = H::sub(F[x], F[n + x]); }
+            if (round == log_k - 1) { eq_r_r = B.scalar; G.clear(); rows.cur = 0; rows.len = (size_t)1 << log_T; rows.stride[0] = rows.len; }
+        } else {
+            D.st.bind(rf);
+            const size_t p = round - log_k;
+            rows.cur = (int)((p + 1) & 1); rows.len = ((size_t)1 << log_T) >> (p + 1); rows.stride[rows.cur] = rows.len;
+        }
+        round_next++;
+        return ATLAS_OK;
+    }
+    int enqueue_finals(const atlas::RoundIo& io, atlas_mail_ref& mail) override {
+        const size_t T = (size_t)1 << log_T;
+        k_rows_final_ch<<<1, 64, 0, g.stream>>>(rows.buf[(log_T - 1) & 1], T >> (log_T - 1), (uint32_t)d, ChanIo{io, g.challenge_mode}, g.challenge_mode == 0 ? 1 : 0);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(ATLAS_ENODEV, "booleanity: launch", e);
+        mail.base = io.mail; mail.blocks = 1; mail.n_vals = (int)d; mail.radix = 32; mail.shl = 0;
+        return ATLAS_OK;
+    }
+    int set_finals(const H::Fr* vals, size_t n) override {
+        if (n != d) return fail(ATLAS_EINVAL, "booleanity: final claims");
+        mailed_finals.assign(vals, vals + n); have_finals = true;
+        return ATLAS_OK;
+    }
 };
 
 // ---------------------------------------------------------------- HammingWeightSumcheckProver (host: d x 2^log_k)
@@ -338,6 +514,13 @@ struct HammingWeight : atlas_instance {
         for (auto& p : ra) { if (p.size() != 1) return fail(ATLAS_ESTATE, "final_claims: rounds remaining"); out.push_back(p[0]); }
         return ATLAS_OK;
     }
+    // round-channel stepping: nothing to launch and nothing to collect, the rounds are host arithmetic
+    bool pipelined() const override { return true; }
+    int enqueue(size_t, const atlas::RoundIo& io, bool, atlas_mail_ref& mail) override { mail.base = io.mail; mail.blocks = 0; mail.n_vals = 0; return ATLAS_OK; }
+    int finish(size_t round, const H::Fr& claim, const H::Fr*, std::vector<H::Fr>& coeffs) override { return message(round, claim, coeffs); }
+    int host_ingest(const atlas_u128_t& r, size_t round) override { return ingest(r, round); }
+    int enqueue_finals(const atlas::RoundIo& io, atlas_mail_ref& mail) override { mail.base = io.mail; mail.blocks = 0; mail.n_vals = 0; return ATLAS_OK; }
+    int set_finals(const H::Fr*, size_t) override { return ATLAS_OK; }
 };
 
 }  // namespace

@@ -61,6 +61,76 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_bind(const Fr* __restrict__ s
         fe_store(d + j, bind_pair(fe_load(s + 2 * j), fe_load(s + 2 * j + 1), r, r_hi_only != 0));
 }
 
+// ---- round-channel versions (channel.hip.h): the challenge comes from the round's slot, the sums go to the host by mail
+__global__ __launch_bounds__(RA_THREADS) void k_ra_bind_ch(const Fr* __restrict__ src, size_t src_stride, Fr* __restrict__ dst,
+                                                           size_t dst_stride, size_t half, ChanIo io, int r_hi_only) {
+    Fr r;
+    if (!io.challenge(r)) return;
+    const Fr* s = src + (size_t)blockIdx.y * src_stride;
+    Fr* d = dst + (size_t)blockIdx.y * dst_stride;
+    for (size_t j = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; j < half; j += (size_t)gridDim.x * RA_THREADS)
+        fe_store(d + j, bind_pair(fe_load(s + 2 * j), fe_load(s + 2 * j + 1), r, r_hi_only != 0));
+}
+
+// column sums of a [n_partials][K] matrix of partial sums (K <= 16), mailed as ONE record of K values.  One workgroup:
+// thread t adds the rows t / 16, t / 16 + 16, ... of column t % 16; the 16 row groups meet in LDS.
+__device__ __forceinline__ void col_reduce_mail_body(const Fr* partials, uint32_t n_partials, uint32_t K, const RoundIo& io) {
+    __shared__ Fr red[RA_THREADS];
+    __shared__ uint32_t stage[9 * 16];
+    const uint32_t col = threadIdx.x & 15u, grp = threadIdx.x >> 4;
+    Fr acc = fe_zero();
+    if (col < K)
+        for (uint32_t p = grp; p < n_partials; p += RA_THREADS / 16) acc = fr_add(acc, fe_load(partials + (size_t)p * K + col));
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        Fr s = fe_zero();
+        if (threadIdx.x < 16) {
+            s = red[threadIdx.x];
+            for (uint32_t q = 1; q < RA_THREADS / 16; q++) s = fr_add(s, red[q * 16 + threadIdx.x]);
+        }
+        ch_mail_wave_fe(io, 0, K, s, stage);
+    }
+}
+__global__ __launch_bounds__(RA_THREADS) void k_col_reduce_mail(const Fr* __restrict__ partials, uint32_t n_partials, uint32_t K, RoundIo io) {
+    col_reduce_mail_body(partials, n_partials, K, io);
+}
+
+// The same as the tail of the kernel that produced the partial rows (saves a launch, ~6 us per round): every workgroup
+// calls this after it stored its row; the last one to arrive (agent-scope counter, fences on both sides) adds the rows
+// and mails the sums.  `tail.counter` is zero on entry and is left zero.  tail.counter == nullptr: no mail (host-stepped).
+struct MailTail {
+    RoundIo io;
+    uint32_t* counter;
+    uint32_t n_rows, K;
+};
+__device__ __forceinline__ void mail_tail(const Fr* partials, const MailTail& tail) {
+    if (!tail.counter) return;
+    __shared__ uint32_t s_last;
+    __threadfence();                                   // this workgroup's row is visible before it is counted
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = gridDim.x * gridDim.y;
+        const uint32_t t = atomicAdd(tail.counter, 1u);
+        s_last = t == total - 1;
+        if (t == total - 1) *tail.counter = 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();                                   // ... and the rows of the others before they are read
+    col_reduce_mail_body(partials, tail.n_rows, tail.K, tail.io);
+}
+
+// the last bind (rows of two coefficients -> the final claims), mailed one value per record
+__global__ __launch_bounds__(64) void k_rows_final_ch(const Fr* src, size_t sstride, uint32_t n_rows, ChanIo io, int hi_only) {
+    __shared__ uint32_t stage[9 * 16];
+    Fr r;
+    if (!io.challenge(r)) return;
+    Fr v = fe_zero();
+    if (threadIdx.x < n_rows) v = bind_pair(fe_load(src + (size_t)threadIdx.x * sstride), fe_load(src + (size_t)threadIdx.x * sstride + 1), r, hi_only != 0);
+    ch_mail_wave_fe(io.io, 0, n_rows, v, stage);
+}
+
 __device__ __forceinline__ Fr gse_weight(const SplitEqView& E, size_t gidx) {
     return fr_mul(fe_load(E.e_out + (gidx >> E.in_bits)), fe_load(E.e_in + (gidx & (((size_t)1 << E.in_bits) - 1))));
 }
@@ -71,12 +141,13 @@ __device__ __forceinline__ Fr gse_weight(const SplitEqView& E, size_t gidx) {
 // registers as 9 x 29-bit lazy limbs (f9.hip.h), so a launch covers at most 8 columns and D > 8
 // takes two launches (the rows are re-read through L2).  Every f9_mul carries 2^-5 relative to
 // the Montgomery radix: a stored sum is 32^-(D+1) times the true one, undone on the host.
+// out[k] = sum_p partials[p * K + k * col_stride]; one workgroup per column (col_stride = 1: rows of K sums)
 __global__ __launch_bounds__(RA_THREADS) void k_col_reduce(const Fr* __restrict__ partials, uint32_t n_partials, uint32_t K,
-                                                           Fr* __restrict__ out) {
+                                                           Fr* __restrict__ out, uint32_t col_stride = 1) {
     __shared__ Fr red[RA_THREADS / 64];
     const uint32_t k = blockIdx.x;
     Fr acc = fe_zero();
-    for (uint32_t p = threadIdx.x; p < n_partials; p += RA_THREADS) acc = fr_add(acc, fe_load(partials + (size_t)p * K + k));
+    for (uint32_t p = threadIdx.x; p < n_partials; p += RA_THREADS) acc = fr_add(acc, fe_load(partials + (size_t)p * K + (size_t)k * col_stride));
     acc = fr_wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -127,7 +198,7 @@ struct RaRows {
     size_t stride[2] = {0, 0};
     int cur = 0;
     Fr* partials = nullptr;     // ceil(T/2 / RA_THREADS) * max(d, 2) Fr
-    Fr* d_sums = nullptr;       // max(d, 2) Fr
+    uint32_t* d_counter = nullptr;   // arrival counter of mail_tail (zero between launches)
     size_t K = 0;
 
     int alloc(size_t d_, size_t T, size_t k_min = 2) {     // K = width of a row of partial sums
@@ -137,7 +208,8 @@ struct RaRows {
         stride[0] = T; stride[1] = T > 1 ? T / 2 : 1;
         const size_t blocks = (T / 2 + RA_THREADS - 1) / RA_THREADS + 1;
         HIP_TRY(hipMalloc(&partials, (blocks * K > 4096 ? blocks * K : 4096) * sizeof(Fr)));   // room for the row-split launches of short instances
-        HIP_TRY(hipMalloc(&d_sums, K * sizeof(Fr)));
+        HIP_TRY(hipMalloc(&d_counter, 256));
+        HIP_TRY(hipMemsetAsync(d_counter, 0, 256, g.stream));
         return ATLAS_OK;
     }
     // indices: d host rows of T int32 -> one device allocation (kept until the gather)
@@ -189,9 +261,10 @@ struct RaRows {
         cur = nxt; len = half;
         return ATLAS_OK;
     }
+    // The sums and the final claims go straight into the pinned staging area (device-visible host memory): a
+    // hipMemcpyAsync D2H of a few hundred bytes is a copy kernel of its own (4 us on the device, ~10 us end to end).
     int reduce_to_host(uint32_t n_partials, uint32_t k, H::Fr* out) {
-        if (n_partials > 1) k_col_reduce<<<k, RA_THREADS, 0, g.stream>>>(partials, n_partials, k, d_sums);
-        HIP_TRY(hipMemcpyAsync(g.h_pinned, n_partials > 1 ? d_sums : partials, k * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+        k_col_reduce<<<k, RA_THREADS, 0, g.stream>>>(partials, n_partials, k, (Fr*)g.h_pinned);
         HIP_TRY(hipStreamSynchronize(g.stream));
         std::memcpy(out, g.h_pinned, k * sizeof(Fr));
         return ATLAS_OK;
@@ -199,13 +272,12 @@ struct RaRows {
     int finals(std::vector<H::Fr>& out) {
         if (len != 1) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
         out.resize(d);
-        for (size_t i = 0; i < d; i++)
-            HIP_TRY(hipMemcpyAsync((uint8_t*)g.h_pinned + 32 * i, buf[cur] + i * stride[cur], sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+        k_col_reduce<<<(unsigned)d, RA_THREADS, 0, g.stream>>>(buf[cur], 1u, 1u, (Fr*)g.h_pinned, (uint32_t)stride[cur]);
         HIP_TRY(hipStreamSynchronize(g.stream));
         std::memcpy(out.data(), g.h_pinned, d * sizeof(Fr));
         return ATLAS_OK;
     }
-    void release() { for (auto& b : buf) if (b) hipFree(b); if (partials) hipFree(partials); if (d_sums) hipFree(d_sums); if (d_idx) hipFree(d_idx); buf[0] = buf[1] = partials = d_sums = nullptr; d_idx = nullptr; }
+    void release() { for (auto& b : buf) if (b) hipFree(b); if (partials) hipFree(partials); if (d_idx) hipFree(d_idx); if (d_counter) hipFree(d_counter); buf[0] = buf[1] = partials = nullptr; d_idx = nullptr; d_counter = nullptr; }
 };
 
 

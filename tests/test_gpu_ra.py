@@ -6,6 +6,17 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["pipelined", "hoststepped"])
+def stepping(request, monkeypatch):
+    """Every test runs twice: over the round channel (all launches enqueued up front, transcript on the host thread) and
+    host-stepped through compute_message / ingest_challenge (ATLAS_NO_PIPELINE=1)."""
+    if request.param == "hoststepped":
+        monkeypatch.setenv("ATLAS_NO_PIPELINE", "1")
+    else:
+        monkeypatch.delenv("ATLAS_NO_PIPELINE", raising=False)
+    return request.param
+
+
 def _indices(d, T, K, seed, none_frac=0.1):
     rng = np.random.default_rng(seed)
     out = []
