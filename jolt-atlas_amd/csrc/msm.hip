@@ -396,7 +396,7 @@ int msm_tab_core(const atlas_srs* srs, size_t pt_off, const Fr* d_scalars, size_
     k_tab_part_hist<<<n_tiles, MSM_THREADS, 0, st>>>(d_scalars, d_tiles, S, bin_counts);
     k_exclusive_scan<<<1, 1024, 0, st>>>(bin_counts, NB, bin_off, bin_cur);
     k_tab_part_scatter<<<n_tiles, MSM_THREADS, 0, st>>>(d_scalars, d_tiles, S, bin_cur, ent);
-    const unsigned n_chunk_wgs = (unsigned)((n_ent + TAB_CHUNK - 1) / TAB_CHUNK);
+    const unsigned n_chunk_wgs = (unsigned)(((n_ent + TAB_CHUNK - 1) / TAB_CHUNK + 7) / 8 * 8);      // a multiple of the XCD count (tab_chunk_of_block)
     k_tab_bin_hist<<<n_chunk_wgs, MSM_THREADS, 0, st>>>(ent, bin_off, NB, S.lo_bits, counts);
     k_scan_block_sums<<<(unsigned)n_scan_blocks, 256, 0, st>>>(counts, TB, bsum);
     k_exclusive_scan<<<1, 1024, 0, st>>>(bsum, (uint32_t)n_scan_blocks, boff, bcur);

@@ -171,12 +171,22 @@ __device__ __forceinline__ uint32_t tab_find_bin(const uint32_t* __restrict__ bi
     return lo;
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8); each XCD has its own 4 MB L2.  A chunk's scatter writes
+// 4-byte entries in ~8-byte runs all over its bin's output region (1.7 MB at 2^22), so the L2 must collect the runs of
+// many chunks of the SAME bin before a line leaves for HBM.  Chunk index = xcd * (chunks / 8) + k keeps every XCD on its
+// own contiguous eighth of the partitioned array (~3 bins in flight per XCD instead of ~25 spread over all of them).
+__device__ __forceinline__ uint32_t tab_chunk_of_block() {
+    const uint32_t per = (gridDim.x + 7) / 8;
+    return (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+}
+
 __global__ __launch_bounds__(MSM_THREADS) void k_tab_bin_hist(const uint2* __restrict__ ent, const uint32_t* __restrict__ bin_off,
                                                               uint32_t n_bins, uint32_t lo_bits, uint32_t* counts) {
     __shared__ uint32_t h[1u << TAB_LO_BITS];
     const uint32_t total = bin_off[n_bins];
-    const uint32_t start = blockIdx.x * TAB_CHUNK;
-    if (start >= total) return;
+    const uint64_t start64 = (uint64_t)tab_chunk_of_block() * TAB_CHUNK;
+    if (start64 >= total) return;
+    const uint32_t start = (uint32_t)start64;
     const uint32_t end = start + TAB_CHUNK < total ? start + TAB_CHUNK : total;
     const uint32_t nlo = 1u << lo_bits;
     uint32_t b = tab_find_bin(bin_off, n_bins, start);
@@ -211,8 +221,9 @@ __global__ __launch_bounds__(MSM_THREADS) void k_tab_bin_scatter(const uint2* __
     __shared__ uint32_t cnt[1u << TAB_LO_BITS];
     __shared__ uint32_t base[1u << TAB_LO_BITS];
     const uint32_t total = bin_off[n_bins];
-    const uint32_t start = blockIdx.x * TAB_CHUNK;
-    if (start >= total) return;
+    const uint64_t start64 = (uint64_t)tab_chunk_of_block() * TAB_CHUNK;
+    if (start64 >= total) return;
+    const uint32_t start = (uint32_t)start64;
     const uint32_t end = start + TAB_CHUNK < total ? start + TAB_CHUNK : total;
     const uint32_t nlo = 1u << lo_bits;
     uint32_t b = tab_find_bin(bin_off, n_bins, start);
