@@ -641,9 +641,10 @@ static int prove_dot_impl(atlas_dot_prover* P, const atlas_fr_t* input_claim, at
             if (fuse_eq) bytes += (eq_len + eq_len / 2) * sizeof(Fr);
             tm.begin(0, bytes);
             if (P->left->is_i32) {
-                Fr *Ld = nullptr, *Rd = nullptr;
-                HIP_TRY(hipMalloc(&Ld, (len / 2) * sizeof(Fr)));
-                HIP_TRY(hipMalloc(&Rd, (len / 2) * sizeof(Fr)));
+                DevBuf Lb, Rb;                              // handed to the operands below; freed here on an early return
+                HIP_TRY(Lb.alloc((len / 2) * sizeof(Fr)));
+                HIP_TRY(Rb.alloc((len / 2) * sizeof(Fr)));
+                Fr *Ld = Lb.as<Fr>(), *Rd = Rb.as<Fr>();
                 k_dot_bind_eval<DEG, int32_t, false, DevIo><<<grid, SC_THREADS, 0, g.stream>>>(
                     (const int32_t*)P->left->d, (const int32_t*)P->right->d, Ld, Rd, nullptr, eq, q,
                     DevIo{g.d_ctx, g.d_partials}, K, hi_only);
@@ -651,8 +652,8 @@ static int prove_dot_impl(atlas_dot_prover* P, const atlas_fr_t* input_claim, at
                 HIP_TRY(hipStreamSynchronize(g.stream));
                 if (P->left->owned) (void)hipFree(P->left->d);
                 if (P->right->owned) (void)hipFree(P->right->d);
-                P->left->d = Ld; P->left->is_i32 = false; P->left->owned = true;
-                P->right->d = Rd; P->right->is_i32 = false; P->right->owned = true;
+                P->left->d = Lb.release(); P->left->is_i32 = false; P->left->owned = true;
+                P->right->d = Rb.release(); P->right->is_i32 = false; P->right->owned = true;
             } else if (fuse_eq) {
                 k_dot_bind_eval<DEG, Fr, true, DevIo><<<grid, SC_THREADS, 0, g.stream>>>(
                     (const Fr*)P->left->d, (const Fr*)P->right->d, (Fr*)P->left->d, (Fr*)P->right->d, eqp, eq, q,

@@ -641,8 +641,9 @@ int atlas_srs_upload(const void* bases, size_t n, size_t stride_bytes, atlas_srs
     hipError_t e = hipMalloc(&s->d, n * sizeof(G1Affine));
     if (e != hipSuccess) { delete s; return fail(ATLAS_ENOMEM, "hipMalloc(srs)", e); }
     s->len = n;
-    HIP_TRY(hipMemcpyAsync(s->d, tmp.data(), n * sizeof(G1Affine), hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    e = hipMemcpyAsync(s->d, tmp.data(), n * sizeof(G1Affine), hipMemcpyHostToDevice, g.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    if (e != hipSuccess) { (void)hipFree(s->d); delete s; return fail(ATLAS_ENODEV, "srs_upload: copy", e); }
     *out = s;
     return ATLAS_OK;
 }
@@ -658,18 +659,17 @@ int atlas_srs_generate(const atlas_fr_t* tau, size_t n, atlas_srs_t* out) {
     std::vector<H::G1Aff> dt(254);
     H::G1X cur = H::gx_from_aff(H::G1Aff{H::q_from_u64(1), H::q_from_u64(2)});
     for (int j = 0; j < 254; j++) { dt[j] = H::gx_to_aff(cur); cur = H::gx_dbl(cur); }
-    Fr* d_tp = nullptr; G1Affine* d_dt = nullptr;
-    HIP_TRY(hipMalloc(&d_tp, 64 * sizeof(Fr)));
-    HIP_TRY(hipMalloc(&d_dt, 254 * sizeof(G1Affine)));
-    HIP_TRY(hipMemcpyAsync(d_tp, tp.data(), 64 * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipMemcpyAsync(d_dt, dt.data(), 254 * sizeof(G1Affine), hipMemcpyHostToDevice, g.stream));
+    DevBuf tpb, dtb;
+    HIP_TRY(tpb.alloc(64 * sizeof(Fr)));
+    HIP_TRY(dtb.alloc(254 * sizeof(G1Affine)));
+    HIP_TRY(hipMemcpyAsync(tpb.p, tp.data(), 64 * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(dtb.p, dt.data(), 254 * sizeof(G1Affine), hipMemcpyHostToDevice, g.stream));
     atlas_srs* s = new atlas_srs();
     hipError_t e = hipMalloc(&s->d, n * sizeof(G1Affine));
-    if (e != hipSuccess) { delete s; hipFree(d_tp); hipFree(d_dt); return fail(ATLAS_ENOMEM, "hipMalloc(srs)", e); }
+    if (e != hipSuccess) { delete s; return fail(ATLAS_ENOMEM, "hipMalloc(srs)", e); }
     s->len = n;
-    k_srs_generate<<<grid_for(n, 8192), MSM_THREADS, 0, g.stream>>>(d_tp, d_dt, n, s->d);
+    k_srs_generate<<<grid_for(n, 8192), MSM_THREADS, 0, g.stream>>>(tpb.as<Fr>(), dtb.as<G1Affine>(), n, s->d);
     hipError_t se = hipStreamSynchronize(g.stream);
-    hipFree(d_tp); hipFree(d_dt);
     if (se != hipSuccess) { hipFree(s->d); delete s; return fail(ATLAS_ENODEV, "srs_generate", se); }
     *out = s;
     return ATLAS_OK;

@@ -265,12 +265,11 @@ struct OneHotOpening : atlas_instance {
             if (round == log_K - 1) {
                 std::lock_guard<atlas_rt::Mutex> lk(g.mu);
                 const size_t T = (size_t)1 << log_T;
-                Fr* d_F = nullptr;
-                HIP_TRY(hipMalloc(&d_F, F.size() * sizeof(Fr)));
-                HIP_TRY(hipMemcpyAsync(d_F, F.data(), F.size() * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
-                k_onehot_gather<<<grid_for(T, 4096), OP_THREADS, 0, g.stream>>>(d_idx, d_F, T, d_H);
+                DevBuf Fb;
+                HIP_TRY(Fb.alloc(F.size() * sizeof(Fr)));
+                HIP_TRY(hipMemcpyAsync(Fb.p, F.data(), F.size() * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+                k_onehot_gather<<<grid_for(T, 4096), OP_THREADS, 0, g.stream>>>(d_idx, Fb.as<Fr>(), T, d_H);
                 hipError_t e = hipStreamSynchronize(g.stream);
-                hipFree(d_F);
                 if (e != hipSuccess) return fail(ATLAS_ENODEV, "onehot_opening: gather", e);
                 H_len = T;
                 G.clear();
@@ -455,12 +454,11 @@ struct OneHotRow : atlas_instance {
             if (round == log_K - 1) {                                // this row's H = F[idx]
                 std::lock_guard<atlas_rt::Mutex> lk(g.mu);
                 const size_t T = grp->T;
-                Fr* d_F = nullptr;
-                HIP_TRY(hipMalloc(&d_F, F.size() * sizeof(Fr)));
-                HIP_TRY(hipMemcpyAsync(d_F, F.data(), F.size() * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
-                k_onehot_gather<<<grid_for(T, 4096), OP_THREADS, 0, g.stream>>>(grp->d_idx + row * T, d_F, T, grp->d_H + row * T);
+                DevBuf Fb;
+                HIP_TRY(Fb.alloc(F.size() * sizeof(Fr)));
+                HIP_TRY(hipMemcpyAsync(Fb.p, F.data(), F.size() * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+                k_onehot_gather<<<grid_for(T, 4096), OP_THREADS, 0, g.stream>>>(grp->d_idx + row * T, Fb.as<Fr>(), T, grp->d_H + row * T);
                 hipError_t e = hipStreamSynchronize(g.stream);
-                hipFree(d_F);
                 if (e != hipSuccess) return fail(ATLAS_ENODEV, "onehot_opening: gather", e);
                 grp->G[row].clear();
             }

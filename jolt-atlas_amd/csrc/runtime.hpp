@@ -58,6 +58,18 @@ int fail(int code, const char* what, hipError_t e = hipSuccess);
 
 #include "devpool.hpp"
 
+// device buffer that is returned (to the pool) when the scope is left, whatever the exit path
+struct DevBuf {
+    void* p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+    void* release() { void* q = p; p = nullptr; return q; }
+};
+
 #define HIP_TRY(x)                                                             \
     do {                                                                       \
         hipError_t e_ = (x);                                                   \
