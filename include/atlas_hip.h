@@ -31,6 +31,7 @@ extern "C" {
 #define ATLAS_EINVAL   (-2)   /* bad argument (length not a power of two, null, ...) */
 #define ATLAS_ENOMEM   (-3)
 #define ATLAS_ESTATE   (-4)   /* handle used in the wrong state */
+#define ATLAS_EVERIFY  (-5)   /* a proof was rejected (ProofVerifyError) */
 
 typedef struct { uint64_t l[4]; } atlas_fr_t;
 typedef struct { uint64_t lo, hi; } atlas_u128_t;
@@ -645,6 +646,25 @@ int atlas_set_timing(int enabled);   /* per-launch events; off by default */
 /* chip-wide 32x32->64 multiply-add rate (v_mad_u64_u32), measured now: the ceiling of the MSM bucket accumulation */
 int atlas_measure_mad_peak(double *mads_per_s);
 int atlas_last_timing(atlas_timing_t *out);
+
+/* ---- verification (host arithmetic; the reference's verifier is CPU code as well) ----------------------------------
+ * SumcheckInstanceProof::verify (subprotocols/sumcheck.rs:653-686): replays the transcript over the compressed round
+ * polynomials (row i: n_coeffs[i] coefficients, linear term omitted) and returns e = g_v(r_v) and the raw challenges.
+ * ATLAS_EVERIFY when a round polynomial exceeds degree_bound (ProofVerifyError::InvalidInputLength).  As in the reference
+ * the last check, e == oracle(r), is the caller's. */
+int atlas_sumcheck_proof_verify(const atlas_fr_t *compressed, size_t row_stride, const uint32_t *n_coeffs, size_t n_rounds,
+                                size_t degree_bound, const atlas_fr_t *claim, atlas_transcript_t *transcript,
+                                atlas_fr_t *final_claim, atlas_u128_t *challenges);
+/* BatchedSumcheck::verify (sumcheck.rs:187-259) up to the output claim: input claims appended, one batching coefficient
+ * per instance drawn, claims combined with mul_pow_2(max_rounds - num_rounds[i]), then proof.verify with the largest degree.
+ * Instance i uses the last num_rounds[i] challenges.  The caller runs each instance's cache_openings (transcript!) and
+ * expected_output_claim, then atlas_batched_sumcheck_check compares (ATLAS_EVERIFY = SumcheckVerificationError). */
+int atlas_batched_sumcheck_verify(const atlas_fr_t *compressed, size_t row_stride, const uint32_t *n_coeffs, size_t max_rounds,
+                                  const atlas_fr_t *input_claims, const size_t *num_rounds, const size_t *degrees,
+                                  size_t n_instances, atlas_transcript_t *transcript, atlas_fr_t *batching_coeffs,
+                                  atlas_fr_t *output_claim, atlas_u128_t *challenges);
+int atlas_batched_sumcheck_check(const atlas_fr_t *batching_coeffs, const atlas_fr_t *expected_output_claims, size_t n_instances,
+                                 const atlas_fr_t *output_claim);
 
 #ifdef __cplusplus
 }

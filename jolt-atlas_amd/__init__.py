@@ -281,6 +281,30 @@ class Sumcheck:
         return proof[:n_rounds * deg].reshape(n_rounds, deg, 4), chal, fin
 
 
+    @staticmethod
+    def verify(rows, claim, transcript: Blake2bTranscript, degree_bound):
+        """SumcheckInstanceProof::verify (sumcheck.rs:653-686).  rows: (n_rounds, deg, 4) array or a list of (k, 4) compressed
+        coefficient arrays.  Returns (final_claim (4,), challenges [u128]); raises AtlasError (code -5) on a rejected proof."""
+        comp, nco, stride = _pack_rows(rows)
+        n = len(nco)
+        ch = np.zeros(2 * max(n, 1), dtype=np.uint64)
+        e = np.zeros(4, dtype=np.uint64)
+        c = _fr(claim)
+        _check(lib.atlas_sumcheck_proof_verify(_p(comp), C.c_size_t(stride), nco.ctypes.data_as(C.c_void_p), C.c_size_t(n),
+                                               C.c_size_t(degree_bound), _p(c), C.byref(transcript.t), _p(e), _p(ch)))
+        return e, [int(ch[2 * i]) | (int(ch[2 * i + 1]) << 64) for i in range(n)]
+
+
+def _pack_rows(rows):
+    """list of (k_i, 4) coefficient arrays (or an (n, k, 4) array) -> (n, stride, 4) buffer, n_coeffs, stride"""
+    rows = [np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4) for r in rows]
+    stride = max([len(r) for r in rows] + [1])
+    comp = np.zeros((max(len(rows), 1), stride, 4), dtype=np.uint64)
+    for i, r in enumerate(rows):
+        comp[i, :len(r)] = r
+    return comp, np.array([len(r) for r in rows], dtype=np.uint32), stride
+
+
 _FR_MOD = np.array([0x43e1f593f0000001, 0x2833e84879b97091, 0xb85045b68181585d, 0x30644e72e131a029], dtype=np.uint64)
 
 
@@ -520,6 +544,33 @@ class BatchedSumcheck:
             return rows, [int(ch[2 * i]) | (int(ch[2 * i + 1]) << 64) for i in range(mr.value)]
         finally:
             lib.atlas_batched_free(b)
+
+
+    @staticmethod
+    def verify(rows, input_claims, num_rounds, degrees, transcript: Blake2bTranscript):
+        """BatchedSumcheck::verify (sumcheck.rs:187-259) up to the output claim.  Returns (output_claim (4,), challenges
+        [u128], batching_coeffs (n, 4)); the caller computes the instances' expected output claims (after their
+        cache_openings) and calls BatchedSumcheck.check."""
+        comp, nco, stride = _pack_rows(rows)
+        n_inst = len(num_rounds)
+        ic = np.ascontiguousarray(np.stack([_fr(c) for c in input_claims]))
+        nr = (C.c_size_t * n_inst)(*[int(x) for x in num_rounds])
+        dg = (C.c_size_t * n_inst)(*[int(x) for x in degrees])
+        mr = len(nco)
+        ch = np.zeros(2 * max(mr, 1), dtype=np.uint64)
+        coeffs = np.zeros((n_inst, 4), dtype=np.uint64)
+        out = np.zeros(4, dtype=np.uint64)
+        _check(lib.atlas_batched_sumcheck_verify(_p(comp), C.c_size_t(stride), nco.ctypes.data_as(C.c_void_p), C.c_size_t(mr), _p(ic), nr, dg,
+                                                 C.c_size_t(n_inst), C.byref(transcript.t), _p(coeffs), _p(out), _p(ch)))
+        return out, [int(ch[2 * i]) | (int(ch[2 * i + 1]) << 64) for i in range(mr)], coeffs
+
+    @staticmethod
+    def check(batching_coeffs, expected_output_claims, output_claim):
+        """output_claim == sum coeff_i * expected_i, else AtlasError (SumcheckVerificationError)."""
+        co = np.ascontiguousarray(batching_coeffs, dtype=np.uint64).reshape(-1, 4)
+        ex = np.ascontiguousarray(np.stack([_fr(c) for c in expected_output_claims]))
+        oc = _fr(output_claim)
+        _check(lib.atlas_batched_sumcheck_check(_p(co), _p(ex), C.c_size_t(len(co)), _p(oc)))
 
 
 class Shout:

@@ -775,7 +775,8 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
     const bool was_i32 = P->left->is_i32;
     const size_t esz = was_i32 ? sizeof(int32_t) : sizeof(Fr);
     const bool use_f9 = DEG == 2 && !was_i32 && mode == 0;
-    auto grid_f9 = [](size_t work) { size_t b = (work + SC_THREADS - 1) / SC_THREADS; return (int)(b < 1 ? 1 : b > 256 ? 256 : b); };
+    static const size_t f9_cap = [] { const char* e = getenv("ATLAS_F9_BLOCKS"); int v = e ? atoi(e) : 0; return (size_t)(v >= 1 && v <= 2048 ? v : 256); }();   // experiments
+    auto grid_f9 = [](size_t work) { size_t b = (work + SC_THREADS - 1) / SC_THREADS; return (int)(b < 1 ? 1 : b > f9_cap ? f9_cap : b); };
     const size_t tail_log = P->schedule == ATLAS_EQ_NONE ? SC_TAIL_CH_LOG : SC_TAIL_LOG;
     void *old_l = nullptr, *old_r = nullptr;       // i32 sources replaced by the first fused pass
 
