@@ -17,6 +17,8 @@
 // {HAZ_s, HAZ_s * lw_s, HAO_s, HAO_s * lw_s} with HAZ_s / HAO_s = "the suffix bits of significance >= BOUND are
 // all zero / all one" and lw_s = the suffix bits below BOUND (suffixes/higher_all_zero.rs, hzero_mul_lword.rs,
 // hone_mul_lword.rs)
+#include <chrono>
+
 #include "ra_common.hip.h"
 
 namespace {
@@ -59,13 +61,16 @@ __device__ __forceinline__ void ps_entry_vals(uint64_t k, const Fr& u, uint32_t 
 
 // Q tables of one phase, m = 2^log_m <= 256 bins: no binning at all.  Every lookup adds the eight 32-bit words of its NQ values into 64-bit
 // LDS accumulators of its bin (ds_add_u64: words < 2^32, at most 2^25 lookups, so a sum stays below 2^57); a workgroup
-// flushes its non-zero accumulators to the global ones and k_ps_q_final turns the word sums back into residues.  (A
+// writes its accumulators to a slab of its own and k_ps_q_final adds the slabs and turns the word sums back into residues.
+// Lanes that share a bin serialise on its accumulators (the high chunks of sign-extended values take two values in all),
+// so the launch uses a workgroup per 256 lookups: one conflicted pass per wavefront instead of eight (164 -> ~10 us).
+// (Summing such lanes across the wavefront first with 64-bit shuffles was slower than the conflicts: 48 x 6 shuffles.)  (A
 // tiled variant in which every thread scanned its tile's entries for its bin took 168 us per phase at T = 2^16, NQ = 6,
 // m = 256.)  The accumulators are NQ * m * 64 bytes of dynamic LDS (96 KB for the clamp lookup).
 template <int NQ>
 __global__ __launch_bounds__(RA_THREADS) void k_ps_q_lds(const uint64_t* __restrict__ idx, const Fr* __restrict__ u0,
                                                          const Fr* __restrict__ prod, size_t T, uint32_t suffix_len, uint32_t m,
-                                                         uint32_t bound, unsigned long long* __restrict__ acc /* [m][NQ][8] */) {
+                                                         uint32_t bound, unsigned long long* __restrict__ acc /* [gridDim.x][m][NQ][8] */) {
     extern __shared__ unsigned long long ps_sm[];
     const uint32_t n_words = m * NQ * 8;
     for (uint32_t w = threadIdx.x; w < n_words; w += RA_THREADS) ps_sm[w] = 0;
@@ -84,19 +89,30 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_q_lds(const uint64_t* __restr
         }
     }
     __syncthreads();
-    for (uint32_t w = threadIdx.x; w < n_words; w += RA_THREADS)
-        if (ps_sm[w]) atomicAdd(&acc[w], ps_sm[w]);
+    unsigned long long* slab = acc + (size_t)blockIdx.x * n_words;      // this workgroup's sums; k_ps_q_final adds the slabs
+    for (uint32_t w = threadIdx.x; w < n_words; w += RA_THREADS) slab[w] = ps_sm[w];
 }
 
 // word sums -> canonical Montgomery residues: V = lo + hi 2^256, V mod p = lo * R * R^-1 + hi * R^2 * R^-1
-__global__ __launch_bounds__(RA_THREADS) void k_ps_q_final(const unsigned long long* __restrict__ acc, uint32_t n_vals, Fr* __restrict__ out) {
-    const uint32_t i = blockIdx.x * RA_THREADS + threadIdx.x;
-    if (i >= n_vals) return;
+// A workgroup takes 4 values (32 words): thread (word, part) adds every 8th slab, the 8 parts meet in LDS.
+__global__ __launch_bounds__(RA_THREADS) void k_ps_q_final(const unsigned long long* __restrict__ acc, uint32_t n_slabs, uint32_t n_vals, Fr* __restrict__ out) {
+    __shared__ unsigned long long sm[8][32];
+    const uint32_t word = threadIdx.x & 31u, part = threadIdx.x >> 5;
+    const size_t n_words = (size_t)n_vals * 8, widx = (size_t)blockIdx.x * 32 + word;
+    unsigned long long sum = 0;
+    if (widx < n_words)
+        for (uint32_t g2 = part; g2 < n_slabs; g2 += 8) sum += acc[(size_t)g2 * n_words + widx];
+    sm[part][word] = sum;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 4 + threadIdx.x;
+    if (threadIdx.x >= 4 || i >= n_vals) return;
     Fr lo, hi, r2;
     unsigned long long c = 0;
 #pragma unroll
     for (int w = 0; w < 8; w++) {
-        const unsigned long long s = acc[(size_t)i * 8 + w] + c;
+        unsigned long long s = c;
+#pragma unroll
+        for (int p2 = 0; p2 < 8; p2++) s += sm[p2][threadIdx.x * 8 + w];
         lo.v[w] = (uint32_t)s;
         c = s >> 32;
     }
@@ -159,6 +175,51 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_fold(const Fr* __restrict__ r
     block_reduce_store<1>(acc, partials);
 }
 
+// ---- round-channel pieces (instance.hpp): the expanding table v of a phase is kept on the device, one challenge at a
+// time, so that the phase boundary (scale the products by v, build the next Q) needs nothing from the host
+// ExpandingTable::update, HighToLow (expanding_table.rs:62-88), for ALL challenges of a phase in one launch: the table
+// starts as [1] in buf[0] and alternates between the two buffers, step k: dst[2i] = src[i] - r_k src[i], dst[2i+1] = r_k src[i].
+// One workgroup; thread 0 polls the host slots of the phase's rounds in order (all but the last were published long
+// ago).  A launch per round cost the host thread ~4.5 us each, on its critical path: the address rounds are host arithmetic.
+struct PsSlots {
+    const Chunk* host[12];
+    uint32_t tag[12];
+    uint32_t n;
+    uint32_t* abort_flag;
+    int challenge_mode;
+};
+__global__ __launch_bounds__(RA_THREADS) void k_ps_expand_all_ch(Fr* buf0, Fr* buf1, PsSlots S) {
+    __shared__ uint64_t s_r[3];
+    if (threadIdx.x == 0) fe_store(buf0, fr_one());
+    __syncthreads();
+    for (uint32_t k = 0; k < S.n; k++) {
+        if (threadIdx.x == 0) {
+            uint64_t lo = 0, hi = 0;
+            const bool ok = ch_poll_slot<true>(S.host[k], S.tag[k], S.abort_flag, lo, hi);
+            s_r[0] = lo; s_r[1] = hi; s_r[2] = ok ? 1 : 0;
+        }
+        __syncthreads();
+        if (!s_r[2]) return;
+        const Fr r = challenge_to_mont(s_r[0], s_r[1], S.challenge_mode);
+        const Fr* src = (k & 1) ? buf1 : buf0;
+        Fr* dst = (k & 1) ? buf0 : buf1;
+        for (uint32_t i = threadIdx.x; i < (1u << k); i += RA_THREADS) {
+            const Fr f = fe_load(src + i), hi = fr_mul(r, f);
+            fe_store(dst + 2 * i + 1, hi);
+            fe_store(dst + 2 * i, fr_sub(f, hi));
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+// the Q tables of a phase -> pinned host memory, then one tagged chunk: a host that sees the tag sees the tables
+__global__ __launch_bounds__(RA_THREADS) void k_ps_q_publish(const Fr* __restrict__ qsum, uint32_t n_vals, Fr* host_dst, Chunk* tag_chunk, uint32_t tag) {
+    for (uint32_t i = threadIdx.x; i < n_vals; i += RA_THREADS) fe_store(host_dst + i, fe_load(qsum + i));
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) ch_store_sys(tag_chunk, ch_u32x4{n_vals, 0u, 0u, tag});
+}
+
 struct PsLookup : atlas_instance {
     size_t N = 0, log_m = 0, m = 0, log_T = 0, T = 0, round_next = 0, phases = 8;   // N = LOG_K
     int mode = 0;                         // 0 = ReLU + gamma * SignedIdentity (unary read-raf), 1 = Identity (range check), 2 = clamp family, 3 = UnsignedLessThan (binary), 4 = RightShift
@@ -185,19 +246,41 @@ struct PsLookup : atlas_instance {
     size_t rounds() const override { return N + log_T; }
     size_t degree() const override { return 2; }
 
-    static H::Fr pow2(size_t k) { H::Fr o = H::one(); const H::Fr two = H::from_u64(2); for (size_t i = 0; i < k; i++) o = H::mul(o, two); return o; }
+    static H::Fr pow2(size_t k) {          // 2^k as a field element; k <= 64 from a table built once (the rounds ask for hundreds)
+        static const std::vector<H::Fr> tab = [] { std::vector<H::Fr> t(65); t[0] = H::one(); for (size_t i = 1; i <= 64; i++) t[i] = H::add(t[i - 1], t[i - 1]); return t; }();
+        if (k <= 64) return tab[k];
+        H::Fr o = tab[64];
+        for (size_t i = 64; i < k; i++) o = H::add(o, o);
+        return o;
+    }
     H::Fr rs_weight(size_t i) const { return (bound < N && i <= N - 1 - bound) ? pow2(N - 1 - i - bound) : H::zero(); }   // mode 4: bit i of k >> D
     H::Fr weight(size_t i) const { H::Fr w = pow2(N - 1 - i); return (i == 0 && mode != 1) ? H::sub(w, pow2(N)) : w; }   // (Signed)Identity coefficient of bit i
 
-    int build_Q(size_t phase) {           // init_phase: Q tables of `phase` from the current products
+    Fr* qsum_ptr() const { return d_qpart + q_rows_max() * nq() * m; }
+    int build_Q(size_t phase) {           // init_phase: Q tables of `phase` from the current products, fetched
+        int rc = launch_Q(phase);
+        if (rc) return rc;
+        const size_t NQ = nq();
+        std::vector<H::Fr> q(NQ * m);
+        HIP_TRY(hipMemcpyAsync(q.data(), qsum_ptr(), NQ * m * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        load_Q(q.data());
+        v.assign(1, H::one());
+        return ATLAS_OK;
+    }
+    void load_Q(const H::Fr* q) {
+        const size_t NQ = nq();
+        Q.assign(NQ, std::vector<H::Fr>(m));
+        for (size_t y = 0; y < m; y++) for (size_t k = 0; k < NQ; k++) Q[k][y] = q[NQ * y + k];
+    }
+    int launch_Q(size_t phase) {          // the launches only: the tables end up at qsum_ptr()
         const uint32_t suffix_len = (uint32_t)((phases - 1 - phase) * log_m);
         const size_t NQ = nq();
-        Fr* d_qsum = d_qpart + q_rows_max() * NQ * m;
+        Fr* d_qsum = qsum_ptr();
         if (m <= RA_THREADS) {
             unsigned long long* acc = (unsigned long long*)d_qpart;              // m * NQ * 8 word sums (the partial-row area is larger)
             const size_t lds = m * NQ * 64;
-            size_t gb = T / 2048; if (gb < 16) gb = 16; if (gb > 256) gb = 256;
-            HIP_TRY(hipMemsetAsync(acc, 0, lds, g.stream));
+            size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 256) gb = 256;      // slabs: gb * lds bytes <= the partial-row area
 #define PS_Q_LDS(NQv, BND)                                                                                                         \
             do {                                                                                                                   \
                 static bool attr_set = false;                                                                                      \
@@ -209,7 +292,7 @@ struct PsLookup : atlas_instance {
             else if (NQ == 3) PS_Q_LDS(3, bound);
             else PS_Q_LDS(2, 0u);
 #undef PS_Q_LDS
-            k_ps_q_final<<<(unsigned)((NQ * m + RA_THREADS - 1) / RA_THREADS), RA_THREADS, 0, g.stream>>>(acc, (uint32_t)(NQ * m), d_qsum);
+            k_ps_q_final<<<(unsigned)((NQ * m + 3) / 4), RA_THREADS, 0, g.stream>>>(acc, (uint32_t)gb, (uint32_t)(NQ * m), d_qsum);
         } else {
             if (NQ == 4) k_ps_q<4><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), 0u, d_qpart);
             else if (NQ == 6) k_ps_q<6><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), (uint32_t)bound, d_qpart);
@@ -217,19 +300,28 @@ struct PsLookup : atlas_instance {
             else k_ps_q<2><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), 0u, d_qpart);
             k_col_reduce<<<(unsigned)(NQ * m), RA_THREADS, 0, g.stream>>>(d_qpart, SLICES, (uint32_t)(NQ * m), d_qsum);
         }
-        std::vector<H::Fr> q(NQ * m);
-        HIP_TRY(hipMemcpyAsync(q.data(), d_qsum, NQ * m * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
-        Q.assign(NQ, std::vector<H::Fr>(m));
-        for (size_t y = 0; y < m; y++) for (size_t k = 0; k < NQ; k++) Q[k][y] = q[NQ * y + k];
-        v.assign(1, H::one());
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) return fail(ATLAS_ENODEV, "ps_shout: Q launch", le);
         return ATLAS_OK;
     }
 
     int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
         if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "ps_shout: round out of order");
         coeffs.assign(3, H::zero());
-        if (round < N) {
+        if (round < N) return address_message(round, claim, coeffs);
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        const size_t n_groups = rows.len / 2;
+        size_t blocks = (n_groups + RA_THREADS - 1) / RA_THREADS; if (blocks > 2048) blocks = 2048;
+        k_ps_fold<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(rows.buf[rows.cur], eq.view(), n_groups, rows.partials);
+        H::Fr s;
+        int rc = rows.reduce_to_host((uint32_t)blocks, 1, &s);
+        if (rc) return rc;
+        H::gruen_deg2(eq.st.scalar, eq.st.w_cur(), H::mul(s, wv), claim, coeffs.data());
+        return ATLAS_OK;
+    }
+    // prover_msg_read_checking (mod.rs:337-460): host arithmetic over the phase's 2^log_m-entry tables
+    int address_message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) {
+        {
             const size_t j = round, p = j / log_m, half = Q[0].size() / 2;
             const size_t suffix_len = N - (p + 1) * log_m;
             const size_t blen = log_m - (j % log_m) - 1;              // chunk bits still boolean after variable j
@@ -238,6 +330,8 @@ struct PsLookup : atlas_instance {
             const H::Fr U = mode == 2 ? H::from_u64(((uint64_t)1 << bound) - 1) : H::zero();
             const H::Fr LC = symmetric ? H::add(H::add(U, U), one) : U;
             H::Fr ev[2];
+            struct HalfSums { H::Fr s1, sb, ss, s2, sc1, z2, zl2, z3, o4, ol4, o5; };
+            HalfSums hs[2];                                           // sums over the lower / upper half of the bins
             for (int ci = 0; ci < 2; ci++) {
                 const H::Fr c = H::from_u64(ci ? 2 : 0);
                 const H::Fr not_msb = j == 0 ? H::sub(one, c) : H::sub(one, r_addr[0]);
@@ -249,57 +343,66 @@ struct PsLookup : atlas_instance {
                 const H::Fr hao_c = j < hbits ? H::mul(hao_acc, c) : hao_acc;
                 const H::Fr lw_c = (mode == 2 && j >= hbits) ? H::add(lw_acc, H::mul(c, pow2(N - 1 - j))) : lw_acc;
                 H::Fr acc = H::zero();
-                // Everything but the bin index b is the same for all bins of a round, and b enters linearly (b * 2^suffix_len,
-                // the clamp's low-word bits): the sums over b of Q_k[b] and of (small integer)(b) * Q_k[b] are taken first
-                // (one small-integer multiplication per term) and the prefix factors are applied once.
+                // Everything but the bin index b is the same for all bins of a round, and b enters through small integers that
+                // are linear in its bits (b 2^suffix_len, the clamp's low-word bits, the shifted chunk).  So per table the
+                // host takes plain sums over the bins, split by set bit of b (additions only), applies the bit weights once
+                // (<= log_m multiplications), and — the tables being evaluated at 0 and at 2 = 2 * upper - lower — does so
+                // for the lower and the upper half of the bins once instead of per evaluation point.
                 if (mode != 3) {
-                    auto qv = [&](size_t k, size_t b) { return ci ? H::sub(H::add(Q[k][b + half], Q[k][b + half]), Q[k][b]) : Q[k][b]; };
-                    H::Fr s_q1 = H::zero(), s_bq1 = H::zero(), s_qs = H::zero();          // sum q1, sum b q1, sum qs
-                    for (size_t b = 0; b < half; b++) {
-                        const H::Fr q1 = qv(0, b);
-                        s_q1 = H::add(s_q1, q1);
-                        if (b) s_bq1 = H::add(s_bq1, H::mul(H::from_u64(b), q1));
-                        s_qs = H::add(s_qs, qv(1, b));
+                    if (ci == 0) {
+                        size_t mhigh = 0;                               // bits of b that are clamp "high" variables
+                        H::Fr w_b[16], w_lw[16], w_cv[16];              // weights of bit i of b (i = 0 least significant)
+                        for (size_t i = 0; i < blen; i++) {
+                            const size_t var = j + 1 + (blen - 1 - i);
+                            w_b[i] = pow2(i);
+                            const bool hb = mode == 2 && var < hbits;
+                            if (hb) mhigh |= (size_t)1 << i;
+                            w_lw[i] = (mode == 2 && !hb) ? pow2(N - 1 - var) : H::zero();
+                            w_cv[i] = (mode == 4 && bound < 64 && i + suffix_len >= bound) ? pow2(i + suffix_len - bound) : H::zero();
+                        }
+                        // sum and weighted sum of table k over the bins [off, off + half) whose high bits are all `want`
+                        auto sums = [&](size_t k, size_t off, int want, const H::Fr* w, H::Fr& tot, H::Fr& wtot) {
+                            H::Fr bs[16];
+                            for (size_t i = 0; i < blen; i++) bs[i] = H::zero();
+                            tot = H::zero();
+                            for (size_t b = 0; b < half; b++) {
+                                if (want == 0 && (b & mhigh)) continue;
+                                if (want == 1 && (b & mhigh) != mhigh) continue;
+                                const H::Fr& q = Q[k][off + b];
+                                tot = H::add(tot, q);
+                                if (w) for (size_t x = b; x; x &= x - 1) { const int bit = __builtin_ctzll(x); bs[bit] = H::add(bs[bit], q); }
+                            }
+                            wtot = H::zero();
+                            if (w) for (size_t i = 0; i < blen; i++) wtot = H::add(wtot, H::mul(w[i], bs[i]));
+                        };
+                        for (int hf = 0; hf < 2; hf++) {
+                            const size_t off = hf ? half : 0;
+                            HalfSums& S = hs[hf];
+                            H::Fr unused;
+                            sums(0, off, -1, mode == 4 ? w_cv : w_b, S.s1, mode == 4 ? S.sc1 : S.sb);
+                            if (mode == 4) { H::Fr t; sums(0, off, -1, w_b, t, S.sb); }
+                            sums(1, off, -1, nullptr, S.ss, unused);
+                            if (mode == 4) sums(2, off, -1, nullptr, S.s2, unused);
+                            if (mode == 2) {
+                                sums(2, off, 0, w_lw, S.z2, S.zl2);
+                                sums(3, off, 0, nullptr, S.z3, unused);
+                                if (symmetric) { sums(4, off, 1, w_lw, S.o4, S.ol4); sums(5, off, 1, nullptr, S.o5, unused); }
+                            }
+                        }
                     }
-                    const H::Fr bs_q1 = H::mul(sh, s_bq1);                                 // sum (b 2^suffix_len) q1
+                    auto at = [&](H::Fr HalfSums::*f) { return ci ? H::sub(H::add(hs[1].*f, hs[1].*f), hs[0].*f) : hs[0].*f; };
+                    const H::Fr s_q1 = at(&HalfSums::s1), s_qs = at(&HalfSums::ss);
+                    const H::Fr bs_q1 = H::mul(sh, at(&HalfSums::sb));                     // sum (b 2^suffix_len) q1
                     const H::Fr idt = H::add(H::add(H::mul(sid_c, s_q1), bs_q1), s_qs);    // sum ((sid_c + bs) q1 + qs)
                     if (mode == 1) acc = idt;
                     else if (mode == 0) acc = H::add(H::mul(not_msb, H::add(H::add(H::mul(word_c, s_q1), bs_q1), s_qs)), H::mul(gamma, idt));
-                    else if (mode == 4) {
+                    else if (mode == 4) {                              // RightShiftTable (right_shift.rs:54-58): (rs_c + chunk >> shift) q1 + q2
                         const H::Fr rs_c = H::add(rs_acc, H::mul(c, rs_weight(j)));
-                        H::Fr s_cq1 = H::zero(), s_q2 = H::zero();                         // sum (chunk >> shift) q1, sum q2
-                        for (size_t b = 0; b < half; b++) {
-                            const uint64_t cv = bound >= 64 ? 0 : ((uint64_t)b << suffix_len) >> bound;
-                            if (cv) s_cq1 = H::add(s_cq1, H::mul(H::from_u64(cv), qv(0, b)));
-                            s_q2 = H::add(s_q2, qv(2, b));
-                        }
-                        acc = H::add(H::add(H::add(H::mul(rs_c, s_q1), s_cq1), s_q2), H::mul(gamma, idt));
-                    } else {      // clamp (clamp.rs:84-109): chunk bits of b at variable index j+1+q are high iff that index < hbits
-                        H::Fr z_q2 = H::zero(), z_lq2 = H::zero(), z_q3 = H::zero(), o_q4 = H::zero(), o_lq4 = H::zero(), o_q5 = H::zero();
-                        for (size_t b = 0; b < half; b++) {
-                            bool z = true, o = true;
-                            uint64_t lwb = 0;
-                            for (size_t q = 0; q < blen; q++) {
-                                const size_t var = j + 1 + q;
-                                const uint64_t bit = (b >> (blen - 1 - q)) & 1;
-                                if (var < hbits) { if (bit) z = false; else o = false; }
-                                else lwb |= bit << (N - 1 - var);
-                            }
-                            if (z) {
-                                const H::Fr q2 = qv(2, b);
-                                z_q2 = H::add(z_q2, q2); z_q3 = H::add(z_q3, qv(3, b));
-                                if (lwb) z_lq2 = H::add(z_lq2, H::mul(H::from_u64(lwb), q2));
-                            }
-                            if (o && symmetric) {
-                                const H::Fr q4 = qv(4, b);
-                                o_q4 = H::add(o_q4, q4); o_q5 = H::add(o_q5, qv(5, b));
-                                if (lwb) o_lq4 = H::add(o_lq4, H::mul(H::from_u64(lwb), q4));
-                            }
-                        }
-                        // sum_z haz_c ((lw_c + lwb - U) q2 + q3) + sum_o hao_c ((lw_c + lwb) q4 + q5)
+                        acc = H::add(H::add(H::add(H::mul(rs_c, s_q1), at(&HalfSums::sc1)), at(&HalfSums::s2)), H::mul(gamma, idt));
+                    } else {      // clamp (clamp.rs:84-109): sum_z haz_c ((lw_c + lwb - U) q2 + q3) + sum_o hao_c ((lw_c + lwb) q4 + q5)
                         H::Fr val = H::mul(H::sub(U, H::mul(msb, LC)), s_q1);
-                        val = H::add(val, H::mul(haz_c, H::add(H::add(H::mul(H::sub(lw_c, U), z_q2), z_lq2), z_q3)));
-                        if (symmetric) val = H::add(val, H::mul(hao_c, H::add(H::add(H::mul(lw_c, o_q4), o_lq4), o_q5)));
+                        val = H::add(val, H::mul(haz_c, H::add(H::add(H::mul(H::sub(lw_c, U), at(&HalfSums::z2)), at(&HalfSums::zl2)), at(&HalfSums::z3))));
+                        if (symmetric) val = H::add(val, H::mul(hao_c, H::add(H::add(H::mul(lw_c, at(&HalfSums::o4)), at(&HalfSums::ol4)), at(&HalfSums::o5))));
                         acc = H::add(val, H::mul(gamma, idt));
                     }
                 } else
@@ -338,18 +441,11 @@ struct PsLookup : atlas_instance {
             H::unipoly_from_evals_and_hint(claim, ev, 2, coeffs.data());
             return ATLAS_OK;
         }
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
-        const size_t n_groups = rows.len / 2;
-        size_t blocks = (n_groups + RA_THREADS - 1) / RA_THREADS; if (blocks > 2048) blocks = 2048;
-        k_ps_fold<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(rows.buf[rows.cur], eq.view(), n_groups, rows.partials);
-        H::Fr s;
-        int rc = rows.reduce_to_host((uint32_t)blocks, 1, &s);
-        if (rc) return rc;
-        H::gruen_deg2(eq.st.scalar, eq.st.w_cur(), H::mul(s, wv), claim, coeffs.data());
-        return ATLAS_OK;
     }
 
-    int ingest(const atlas_u128_t& r, size_t round) override {
+    int ingest(const atlas_u128_t& r, size_t round) override { return ingest_impl(r, round, true); }
+    // with_device = false: the host half only (round channel: the launches were enqueued ahead and take r from its slot)
+    int ingest_impl(const atlas_u128_t& r, size_t round, bool with_device) {
         if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "ps_shout: round out of order");
         const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
         if (round < N) {
@@ -359,9 +455,11 @@ struct PsLookup : atlas_instance {
                 for (size_t i = 0; i < half; i++) q[i] = H::add(q[i], H::mul(rf, H::sub(q[i + half], q[i])));
                 q.resize(half);
             }
-            std::vector<H::Fr> nv(2 * v.size());                      // ExpandingTable::update, HighToLow
-            for (size_t i = 0; i < v.size(); i++) { nv[2 * i + 1] = H::mul(rf, v[i]); nv[2 * i] = H::sub(v[i], nv[2 * i + 1]); }
-            v.swap(nv);
+            if (with_device) {
+                std::vector<H::Fr> nv(2 * v.size());                  // ExpandingTable::update, HighToLow
+                for (size_t i = 0; i < v.size(); i++) { nv[2 * i + 1] = H::mul(rf, v[i]); nv[2 * i] = H::sub(v[i], nv[2 * i + 1]); }
+                v.swap(nv);
+            }
             if (j >= 1) word_acc = H::add(word_acc, H::mul(rf, pow2(N - 1 - j)));
             sid_acc = H::add(sid_acc, H::mul(rf, weight(j)));
             if (mode == 4) rs_acc = H::add(rs_acc, H::mul(rf, rs_weight(j)));
@@ -380,7 +478,7 @@ struct PsLookup : atlas_instance {
                 else lw_acc = H::add(lw_acc, H::mul(rf, pow2(N - 1 - j)));
             }
             r_addr.push_back(rf);
-            if ((j + 1) % log_m == 0) {                               // phase boundary: fold v_p into the products
+            if ((j + 1) % log_m == 0 && with_device) {                // phase boundary: fold v_p into the products
                 std::lock_guard<atlas_rt::Mutex> lk(g.mu);
                 HIP_TRY(hipMemcpyAsync(d_v, v.data(), m * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
                 size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
@@ -403,19 +501,110 @@ struct PsLookup : atlas_instance {
                 }
                 rows.cur = 0; rows.stride[0] = T; rows.len = T;       // the products are ra (init_log_t_rounds)
             }
-        } else {
+        } else if (with_device) {
             std::lock_guard<atlas_rt::Mutex> lk(g.mu);
             int rc = rows.bind(r);
             if (rc) return rc;
             eq.st.bind(rf);
+        } else {
+            eq.st.bind(rf);
+            const size_t c = round - N;
+            rows.cur = (int)((c + 1) & 1); rows.len = T >> (c + 1); rows.stride[rows.cur] = rows.len;
         }
         round_next++;
         return ATLAS_OK;
     }
     int finals(std::vector<H::Fr>& out) override {
         if (round_next != rounds()) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
+        if (have_finals) { out = mailed_finals; return ATLAS_OK; }
         std::lock_guard<atlas_rt::Mutex> lk(g.mu);
         return rows.finals(out);
+    }
+
+    // ---- round-channel stepping (instance.hpp).  Address rounds are host arithmetic and launch nothing, except the first
+    // round of a phase: the finished phase's expanding table is rebuilt on the device from its challenge slots (d_v holds two
+    // tables of m entries, used alternately), the products are scaled by it and the new phase's Q is built; Q travels to the
+    // host through pinned memory (k_ps_q_publish) and is picked up by that round's finish().  Cycle round c has ra in buf[c & 1].
+    struct QBox { const volatile atlas::Chunk* tagc = nullptr; const H::Fr* data = nullptr; uint32_t tag = 0; };
+    std::vector<QBox> qbox;
+    PsSlots slots{};
+    bool have_finals = false;
+    std::vector<H::Fr> mailed_finals;
+    bool pipelined() const override { return log_m <= 11 && N + log_T <= atlas_rt::Channel::RING / 2; }
+    int enqueue(size_t round, const atlas::RoundIo& io, bool bind_prev, atlas_mail_ref& mail) override {
+        if (round >= rounds() || (round > 0) != bind_prev) return fail(ATLAS_ESTATE, "ps_shout: enqueue out of order");
+        const ChanIo cio{io, g.challenge_mode};
+        mail.base = io.mail; mail.blocks = 0; mail.n_vals = 0; mail.radix = 32; mail.shl = 0;
+        Fr* vt[2] = {d_v, d_v + m};
+        size_t gbT = (T + RA_THREADS - 1) / RA_THREADS; if (gbT > 4096) gbT = 4096;
+        if (round == 0) qbox.assign(phases, QBox{});
+        if (round >= 1 && round <= N) {                        // remember where the challenge of round - 1 will appear
+            const size_t pw = (round - 1) % log_m;
+            slots.host[pw] = io.r_host; slots.tag[pw] = io.tag_r;
+        }
+        if (round >= 1 && round <= N && round % log_m == 0) {  // a phase is complete: its table, folded into the products
+            const size_t p_done = round / log_m - 1;
+            slots.n = (uint32_t)log_m; slots.abort_flag = io.abort_flag; slots.challenge_mode = g.challenge_mode;
+            k_ps_expand_all_ch<<<1, RA_THREADS, 0, g.stream>>>(vt[0], vt[1], slots);
+            k_ps_scale<<<(unsigned)gbT, RA_THREADS, 0, g.stream>>>(d_idx, vt[log_m & 1], T, (uint32_t)((phases - 1 - p_done) * log_m), (uint32_t)(m - 1), rows.buf[0]);
+            if (round < N) {                                   // ... and build the Q of the phase that starts
+                const size_t p = round / log_m, n_vals = nq() * m;
+                int rc = launch_Q(p);
+                if (rc) return rc;
+                atlas::Chunk* box = g.chan.alloc(2 * n_vals + 4);
+                k_ps_q_publish<<<1, RA_THREADS, 0, g.stream>>>(qsum_ptr(), (uint32_t)n_vals, reinterpret_cast<Fr*>(box + 4), box, io.tag_mail);
+                qbox[p] = QBox{box, reinterpret_cast<const H::Fr*>(box + 4), io.tag_mail};
+            }
+        }
+        if (round >= N) {
+            const size_t c = round - N, len = T >> c, n_groups = len / 2;
+            if (c > 0) {
+                size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
+                k_ra_bind_ch<<<dim3((unsigned)gb, 1u), RA_THREADS, 0, g.stream>>>(rows.buf[(c - 1) & 1], T >> (c - 1), rows.buf[c & 1], len, len, cio,
+                                                                                g.challenge_mode == 0 ? 1 : 0);
+            }
+            size_t blocks = (n_groups + RA_THREADS - 1) / RA_THREADS; if (blocks > 2048) blocks = 2048;
+            size_t ot, it;
+            eq.st.tops_after(c, ot, it);
+            k_ps_fold<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(rows.buf[c & 1], eq.view_at(ot, it), n_groups, rows.partials);
+            k_col_reduce_mail<<<1, RA_THREADS, 0, g.stream>>>(rows.partials, (uint32_t)blocks, 1u, io);
+            mail.blocks = 1; mail.n_vals = 1;
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(ATLAS_ENODEV, "ps_shout: launch", e);
+        return ATLAS_OK;
+    }
+    int finish(size_t round, const H::Fr& claim, const H::Fr* s, std::vector<H::Fr>& coeffs) override {
+        if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "ps_shout: round out of order");
+        coeffs.assign(3, H::zero());
+        if (round >= N) {
+            H::gruen_deg2(eq.st.scalar, eq.st.w_cur(), H::mul(s[0], wv), claim, coeffs.data());
+            return ATLAS_OK;
+        }
+        if (round > 0 && round % log_m == 0) {                 // first round of a phase: its Q tables arrive through pinned memory
+            const QBox& B = qbox[round / log_m];
+            if (!B.tagc) return fail(ATLAS_ESTATE, "ps_shout: Q of the phase was not enqueued");
+            const auto t0 = std::chrono::steady_clock::now();
+            while (B.tagc->tag != B.tag) {
+                for (int i = 0; i < 1024 && B.tagc->tag != B.tag; i++) __builtin_ia32_pause();
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) { g.chan.abort_dirty = true; return fail(ATLAS_ENODEV, "round channel: no Q tables from the device"); }
+            }
+            load_Q(B.data);
+        }
+        return address_message(round, claim, coeffs);
+    }
+    int host_ingest(const atlas_u128_t& r, size_t round) override { return ingest_impl(r, round, false); }
+    int enqueue_finals(const atlas::RoundIo& io, atlas_mail_ref& mail) override {
+        k_rows_final_ch<<<1, 64, 0, g.stream>>>(rows.buf[(log_T - 1) & 1], T >> (log_T - 1), 1u, ChanIo{io, g.challenge_mode}, g.challenge_mode == 0 ? 1 : 0);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(ATLAS_ENODEV, "ps_shout: launch", e);
+        mail.base = io.mail; mail.blocks = 1; mail.n_vals = 1; mail.radix = 32; mail.shl = 0;
+        return ATLAS_OK;
+    }
+    int set_finals(const H::Fr* vals, size_t n) override {
+        if (n != 1) return fail(ATLAS_EINVAL, "ps_shout: final claims");
+        mailed_finals.assign(vals, vals + 1); have_finals = true;
+        return ATLAS_OK;
     }
 };
 
@@ -453,7 +642,7 @@ static int ps_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, si
     P->d_u0 = (Fr*)E->d; delete E;                                   // keep the table, drop the handle
     const size_t T = P->T, m = P->m;
     hipError_t e = hipMalloc(&P->d_idx, T * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipMalloc(&P->d_v, m * sizeof(Fr));
+    if (e == hipSuccess) e = hipMalloc(&P->d_v, 2 * m * sizeof(Fr));       // two tables: the pipelined path alternates
     if (e == hipSuccess) e = hipMalloc(&P->d_qpart, (P->q_rows_max() + 1) * 6 * m * sizeof(Fr));
     if (e == hipSuccess) e = hipMemcpyAsync(P->d_idx, lookup_indices, T * sizeof(uint64_t), hipMemcpyDefault, g.stream);   // host or device source
     if (e != hipSuccess) { delete P; return fail(ATLAS_ENOMEM, "ps_shout_new", e); }

@@ -5,6 +5,17 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["pipelined", "hoststepped"])
+def stepping(request, monkeypatch):
+    """Every test runs twice: over the round channel (all launches enqueued up front, transcript on the host thread) and
+    host-stepped through compute_message / ingest_challenge (ATLAS_NO_PIPELINE=1)."""
+    if request.param == "hoststepped":
+        monkeypatch.setenv("ATLAS_NO_PIPELINE", "1")
+    else:
+        monkeypatch.delenv("ATLAS_NO_PIPELINE", raising=False)
+    return request.param
+
+
 def _claim(orc, idx, N, r_node, gamma):
     """rv_claim + gamma * operand_claim = sum_t eq(r_node, t) (relu(x_t) + gamma x_t), x_t signed."""
     E = orc.eq_evals(r_node)
