@@ -406,6 +406,22 @@ def main():
                               "stage_ms": dict(zip(("witness", "execution_clamp_ps_shout", "ra_one_hot_checks", "einsum_matmul", "range_check",
                                                     "remainder_ra_checks"), [float(x) for x in stages]))}
         tA.free(); tB.free()
+        # a second node type: ReLU over 2^16 activations (16 x 3072 padded), ReLU::prove = PS-Shout over ReluTable<32> + one-hot checks
+        tX = A.TensorI32(rngn.integers(-(1 << 14), 1 << 14, size=1 << 16, dtype=np.int64).astype(np.int32))
+        best_r, st_r, states_r = None, None, set()
+        for rep in range(4):
+            tn = A.Blake2bTranscript(b"relu_node")
+            sync(); t0n = time.perf_counter()
+            _pf, _cl, st = NODE.prove_relu_node(tX, 16, r0, tn)
+            sync(); dtn = time.perf_counter() - t0n
+            states_r.add(tn.state)
+            if rep and (best_r is None or dtn < best_r):
+                best_r, st_r = dtn, st
+        assert len(states_r) == 1, "non-deterministic node proof"
+        out["node_relu"] = {"node": "ReLU over 2^16 i32 activations; 2 sumcheck proofs, %d bytes" % sum(len(x) for x in _pf),
+                            "node_relu_ms": best_r * 1e3,
+                            "stage_ms": dict(zip(("witness", "execution_ps_shout", "ra_one_hot_checks"), [float(x) for x in st_r]))}
+        tX.free()
     # third leg (N > 1): ONE 2^n instance and ONE 2^n-point MSM sharded over the N GPUs (strong scaling).  No collective on
     # the data path: the ranks' 64-byte partial sums cross a POSIX shared-memory board (csrc/shard_group.hpp), every rank
     # runs the same transcript step; the MSM is split by point range, one partial point per rank.

@@ -647,6 +647,15 @@ int atlas_set_timing(int enabled);   /* per-launch events; off by default */
 int atlas_measure_mad_peak(double *mads_per_s);
 int atlas_last_timing(atlas_timing_t *out);
 
+/* ReLU::prove (jolt-atlas-core/src/onnx_proof/ops/relu.rs:22-70) for one node: OpLookupProvider::read_raf_prove over
+ * ReluTable<32> (op_lookups/mod.rs:250-267), Sumcheck::prove with its ra opening, ra_onehot_provers + BatchedSumcheck::prove
+ * (shout.rs:399-466).  d_input: the operand, 2^log_T i32 on the device; r_node_output: the node-output opening point;
+ * output_claim: relu(x)~(r) or NULL (evaluated here); d_output: optional device buffer for the output tensor.  Two proofs
+ * (Execution, RaOneHotChecks) ark-serialized back to back, claims in accumulator order, stage_ms[3] optional. */
+int atlas_prove_relu_node(const int32_t *d_input, size_t log_T, const atlas_fr_t *r_node_output, const atlas_fr_t *output_claim,
+                          atlas_transcript_t *transcript, uint8_t *proofs, size_t cap, size_t *proofs_len, size_t proof_lens[2],
+                          atlas_fr_t *claims, size_t claims_cap, size_t *n_claims, int32_t *d_output, double *stage_ms);
+
 /* ---- verification (host arithmetic; the reference's verifier is CPU code as well) ----------------------------------
  * SumcheckInstanceProof::verify (subprotocols/sumcheck.rs:653-686): replays the transcript over the compressed round
  * polynomials (row i: n_coeffs[i] coefficients, linear term omitted) and returns e = g_v(r_v) and the raw challenges.

@@ -75,6 +75,15 @@ __global__ __launch_bounds__(256) void k_i64_to_fr(const int64_t* __restrict__ i
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) fe_store(out + i, fr_from_i64(in[i]));
 }
 
+// ReLU witness: the output tensor and the lookup indices `x as u32 as u64` (compute_lookup_indices_from_operands, utils/mod.rs:43-122)
+__global__ __launch_bounds__(256) void k_relu_witness(const int32_t* __restrict__ x, size_t n, int32_t* __restrict__ out, uint64_t* __restrict__ idx) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int32_t v = x[i];
+        if (out) out[i] = v > 0 ? v : 0;
+        idx[i] = (uint64_t)(uint32_t)v;
+    }
+}
+
 unsigned ilog2(size_t x) { unsigned n = 0; while (x > 1) { x >>= 1; n++; } return n; }
 bool pow2(size_t x) { return x && !(x & (x - 1)); }
 
@@ -306,6 +315,71 @@ extern "C" int atlas_prove_einsum_node(const atlas_einsum_node_t* node, const in
     if (!rc) rc = prove_onehot_checks(d_ridx, log_T, S, r_node_output, rr_point, rr_claim, t, O);
     if (stage_ms) stage_ms[5] = ms_since(t0);
     cleanup();
+    if (rc) return rc;
+    *proofs_len = O.len; *n_claims = O.n_claims;
+    return ATLAS_OK;
+}
+
+
+// ReLU::prove (jolt-atlas-core/src/onnx_proof/ops/relu.rs:22-70): OpLookupProvider::read_raf_prove over ReluTable<XLEN>
+// (op_lookups/mod.rs:250-267: the operand's claim at r_cycle appended, gamma drawn, UnaryReadRafSumcheckProver), Sumcheck::prove
+// + its ra opening, then ra_onehot_provers + BatchedSumcheck::prove (shout.rs:399-466).  d_input: the node's operand, 2^log_T
+// i32 on the device (padded by the caller); r_node_output: the node-output opening point (log_T challenges as field
+// elements); output_claim: relu(x)~(r) if the caller has it, else evaluated here.  Two proofs (Execution, RaOneHotChecks),
+// ark-serialized back to back; claims in accumulator order: operand, ra, then the 3 d one-hot claims.
+extern "C" int atlas_prove_relu_node(const int32_t* d_input, size_t log_T, const atlas_fr_t* r_node_output, const atlas_fr_t* output_claim,
+                                     atlas_transcript_t* t, uint8_t* proofs, size_t cap, size_t* proofs_len, size_t proof_lens[2],
+                                     atlas_fr_t* claims, size_t claims_cap, size_t* n_claims, int32_t* d_output, double* stage_ms) {
+    NEED_INIT();
+    if (!d_input || !r_node_output || !t || !proofs || !proofs_len || !proof_lens || !claims || !n_claims)
+        return fail(ATLAS_EINVAL, "prove_relu_node: null argument");
+    if (log_T == 0 || log_T > 25) return fail(ATLAS_EINVAL, "prove_relu_node: 1 <= log_T <= 25");
+    const size_t T = (size_t)1 << log_T, XLEN = 32;                  // common/src/consts/general.rs:1
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point a) { atlas_sync(); return std::chrono::duration<double, std::milli>(now() - a).count(); };
+    Out O{proofs, cap, 0, proof_lens, 0, claims, claims_cap, 0};
+    H::Transcript& Tr = *reinterpret_cast<H::Transcript*>(t);
+    auto t0 = now();
+    DevBuf idx_b, out_b;
+    HIP_TRY(idx_b.alloc(T * 8));
+    if (!d_output) { HIP_TRY(out_b.alloc(T * 4)); d_output = out_b.as<int32_t>(); }
+    {
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        size_t gb = (T + 255) / 256; if (gb > 4096) gb = 4096;
+        k_relu_witness<<<(unsigned)gb, 256, 0, g.stream>>>(d_input, T, d_output, idx_b.as<uint64_t>());
+    }
+    int rc = ATLAS_OK;
+    atlas_poly_t p_in = nullptr, p_out = nullptr;
+    H::Fr operand_claim, out_claim;
+    rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(d_input), T, &p_in);          // a read-only view: evaluate does not write
+    if (!rc) rc = atlas_poly_evaluate(p_in, r_node_output, log_T, (atlas_fr_t*)&operand_claim);
+    if (!rc) {
+        if (output_claim) std::memcpy(&out_claim, output_claim, 32);
+        else { rc = atlas_poly_wrap_device_i32(d_output, T, &p_out); if (!rc) rc = atlas_poly_evaluate(p_out, r_node_output, log_T, (atlas_fr_t*)&out_claim); }
+    }
+    for (atlas_poly_t p : {p_in, p_out}) if (p) atlas_poly_free(p);
+    if (stage_ms) stage_ms[0] = ms_since(t0);
+    if (rc) return rc;
+
+    t0 = now();
+    H::tr_append_scalar(Tr, operand_claim); rc = O.put_claim(operand_claim);      // append_raf_claims_prover (op_lookups/mod.rs:404-418)
+    const H::Fr gamma = H::tr_challenge_scalar(Tr);                               // ps_read_raf_prover (unary.rs:112)
+    atlas_instance_t exec = nullptr;
+    if (!rc) rc = atlas_ps_shout_relu_new(idx_b.as<uint64_t>(), log_T, XLEN, r_node_output, (const atlas_fr_t*)&gamma, &exec);
+    const H::Fr exec_claim = H::add(out_claim, H::mul(gamma, operand_claim));     // rv_claim + gamma * operand_claim (ps_shout/mod.rs:142-144)
+    std::vector<atlas_u128_t> ch;
+    H::Fr ra_claim;
+    if (!rc) rc = prove_single(exec, exec_claim, t, O, ch, &ra_claim);
+    if (exec) atlas_instance_free(exec);
+    std::vector<atlas_fr_t> ra_point(XLEN + log_T);                               // normalize_opening_point (ps_shout/mod.rs:150-158)
+    if (!rc) {
+        for (size_t i = 0; i < XLEN; i++) { const H::Fr f = H::challenge_to_fr(ch[i].lo, ch[i].hi, g.challenge_mode); std::memcpy(&ra_point[i], &f, 32); }
+        for (size_t i = 0; i < log_T; i++) { const H::Fr f = H::challenge_to_fr(ch[XLEN + log_T - 1 - i].lo, ch[XLEN + log_T - 1 - i].hi, g.challenge_mode); std::memcpy(&ra_point[XLEN + i], &f, 32); }
+    }
+    if (stage_ms) stage_ms[1] = ms_since(t0);
+    t0 = now();
+    if (!rc) rc = prove_onehot_checks(idx_b.as<uint64_t>(), log_T, XLEN, r_node_output, ra_point, ra_claim, t, O);
+    if (stage_ms) stage_ms[2] = ms_since(t0);
     if (rc) return rc;
     *proofs_len = O.len; *n_claims = O.n_claims;
     return ATLAS_OK;

@@ -155,3 +155,43 @@ def sum_fr(orc, xs):
     for x in xs:
         s = orc.fr_add_arr(s, x)
     return s
+
+
+@pytest.mark.parametrize("log_T", [3, 6, 9])
+def test_relu_node_matches_oracle_composition(atlas, log_T):
+    """ReLU::prove (ops/relu.rs:22-70) through atlas_prove_relu_node against the same composition over the oracle's instances:
+    operand claim appended, gamma, PS-Shout over ReluTable<32>, its ra opening, the batched one-hot checks and their claims."""
+    from oracle import orc, orc_ra as OR, orc_batched as OB
+    from jolt_atlas_amd import node
+    T = 1 << log_T
+    rng = np.random.default_rng(log_T)
+    x = rng.integers(-(1 << 12), 1 << 12, size=T, dtype=np.int64).astype(np.int32)
+    x[0] = -(1 << 31); x[-1] = (1 << 31) - 1                                  # extremes of the i32 range
+    out = np.maximum(x, 0)
+    r0 = orc.random_fr(log_T, 99)
+    f = lambda v: orc.from_ints([int(z) % FR for z in v])
+    operand_claim, out_claim = orc.evaluate(f(x), r0), orc.evaluate(f(out), r0)
+    claims = []
+    t = orc.new_transcript(b"relu_node")
+    _append(orc, t, operand_claim); claims.append(operand_claim)
+    gamma = _challenge_scalar(orc, t)
+    idx = x.astype(np.int64).astype(np.uint32).astype(np.uint64)             # `value as u32 as u64`
+    exec_claim = orc.fr_add_arr(out_claim, orc.fr_mul_arr(gamma, operand_claim))
+    rows_exec, ch = OR.ps_relu(idx, 32, r0, gamma).prove(exec_claim, t)
+    rs = orc.challenges_to_fr(ch)
+    ra_point = np.concatenate([rs[:32], rs[32:][::-1]])
+    ra_claim = orc.evaluate(np.stack([_eq_bits(orc, ra_point[:32], v, 32) for v in idx]), np.ascontiguousarray(ra_point[32:]))
+    _append(orc, t, ra_claim); claims.append(ra_claim)
+    rows_oh = _onehot_checks(orc, OR, OB, t, idx, log_T, 32, r0, ra_point, ra_claim, claims)
+    tX = atlas.TensorI32(x)
+    t_g = atlas.Blake2bTranscript(b"relu_node")
+    proofs, claims_g, stage_ms = node.prove_relu_node(tX, log_T, r0, t_g)
+    assert proofs[0] == _ser(orc, rows_exec), "execution proof differs"
+    assert proofs[1] == _ser(orc, rows_oh), "one-hot proof differs"
+    assert np.array_equal(claims_g, np.stack(claims))
+    assert t_g.state == t.state_bytes()
+    # the caller may hand the output claim over instead of having it evaluated
+    t_g2 = atlas.Blake2bTranscript(b"relu_node")
+    proofs2, claims_g2, _ = node.prove_relu_node(tX, log_T, r0, t_g2, output_claim=out_claim)
+    assert proofs2 == proofs and t_g2.state == t_g.state
+    tX.free()
