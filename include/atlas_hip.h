@@ -488,6 +488,11 @@ int atlas_g1_sum_indexed(atlas_srs_t srs, const uint32_t *indices, size_t n, atl
  * poly/one_hot_polynomial.rs:21-40).  One upload of all index vectors, one launch for all R sums.  out[r] = commitment. */
 int atlas_commit_one_hot_batch(atlas_srs_t srs, const int32_t *const *nonzero_indices, const size_t *K, const size_t *T,
                                size_t R, atlas_g1_affine_t *out);
+/* The d RaD witness commitments of one lookup from its 2^log_T lookup indices on the device (generate_node_witnesses,
+ * jolt-atlas-core/src/onnx_proof/witness.rs:136-200, + HyperKZG::batch_commit_one_hot, hyperkzg/mod.rs:558-596):
+ * d = ceil(log_K / log_k_chunk) one-hot polynomials of 2^log_k_chunk addresses, chunk 0 most significant; out[d]. */
+int atlas_commit_lookup_chunks(atlas_srs_t srs, const uint64_t *d_lookups, size_t log_T, size_t log_K, size_t log_k_chunk,
+                               atlas_g1_affine_t *out);
 /* CommitmentScheme::batch_commit (commitment_scheme.rs:76-90 -> UnivariateKZG::commit_batch, kzg.rs:195-243):
  * commitments of n device-resident polynomials (LargeScalars or I32Scalars) against prefixes of the SRS. */
 int atlas_commit_batch(atlas_srs_t srs, const atlas_poly_t *polys, size_t n, atlas_g1_affine_t *out);
@@ -646,6 +651,14 @@ int atlas_set_timing(int enabled);   /* per-launch events; off by default */
 /* chip-wide 32x32->64 multiply-add rate (v_mad_u64_u32), measured now: the ceiling of the MSM bucket accumulation */
 int atlas_measure_mad_peak(double *mads_per_s);
 int atlas_last_timing(atlas_timing_t *out);
+
+/* Mul::prove with fused rescaling (ops/mul.rs through impl_fused_rescale_proof_api, ops/mod.rs:569-612) for one node:
+ * out = (left * right) >> scale_bits element-wise over 2^log_T i32 values on the device.  Same five proofs and claim order as
+ * atlas_prove_einsum_node, with MulProver (Gruen split-eq of r_node_output, degree 3) as the operator's sumcheck. */
+int atlas_prove_mul_node(const int32_t *d_left, const int32_t *d_right, size_t log_T, uint32_t scale_bits,
+                         const atlas_fr_t *r_node_output, const atlas_fr_t *output_claim, atlas_transcript_t *transcript,
+                         uint8_t *proofs, size_t cap, size_t *proofs_len, size_t proof_lens[5], atlas_fr_t *claims,
+                         size_t claims_cap, size_t *n_claims, int32_t *d_output, double *stage_ms);
 
 /* ReLU::prove (jolt-atlas-core/src/onnx_proof/ops/relu.rs:22-70) for one node: OpLookupProvider::read_raf_prove over
  * ReluTable<32> (op_lookups/mod.rs:250-267), Sumcheck::prove with its ra opening, ra_onehot_provers + BatchedSumcheck::prove

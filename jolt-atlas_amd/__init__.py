@@ -422,6 +422,15 @@ class SRS:
         _check(lib.atlas_commit_one_hot_batch(self.h, ptrs, K, T, C.c_size_t(R), out.ctypes.data_as(C.c_void_p)))
         return out[:R]
 
+    def commit_lookup_chunks(self, d_lookups, log_T, log_K, log_k_chunk=4):
+        """The d RaD commitments of one lookup; d_lookups: instances.DeviceU64 (or a device address) of 2^log_T u64 lookup indices."""
+        d = -(-log_K // log_k_chunk)
+        out = np.zeros(d, dtype=G1_DTYPE)
+        ptr = d_lookups.ptr if hasattr(d_lookups, "ptr") else C.c_void_p(d_lookups)
+        _check(lib.atlas_commit_lookup_chunks(self.h, ptr, C.c_size_t(log_T), C.c_size_t(log_K), C.c_size_t(log_k_chunk),
+                                              out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def commit_batch(self, polys):
         """CommitmentScheme::batch_commit over device-resident polynomials."""
         n = len(polys)

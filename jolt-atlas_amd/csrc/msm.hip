@@ -873,6 +873,33 @@ int atlas_commit_one_hot_batch(atlas_srs_t srs, const int32_t* const* nonzero_in
     return ATLAS_OK;
 }
 
+// The d RaD commitments of one lookup from its T device-resident lookup indices (generate_node_witnesses, witness.rs:136-200
+// + HyperKZG::batch_commit_one_hot, hyperkzg/mod.rs:558-596): d = ceil(log_K / log_k_chunk) one-hot polynomials with
+// K_chunk = 2^log_k_chunk addresses each, chunk 0 most significant (OneHotParams::lookup_index_chunk, config.rs:73-75).
+int atlas_commit_lookup_chunks(atlas_srs_t srs, const uint64_t* d_lookups, size_t log_T, size_t log_K, size_t log_k_chunk, atlas_g1_affine_t* out) {
+    NEED_INIT();
+    if (!srs || !d_lookups || !out || log_k_chunk == 0 || log_k_chunk > 16 || log_K == 0 || log_K > 64 || log_T > 26)
+        return fail(ATLAS_EINVAL, "commit_lookup_chunks: bad argument");
+    const size_t T = (size_t)1 << log_T, d = (log_K + log_k_chunk - 1) / log_k_chunk;
+    if ((T << log_k_chunk) > srs->len) return fail(ATLAS_EINVAL, "commit_lookup_chunks: KeyLengthError (K*T beyond the SRS)");
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    unsigned gx = (unsigned)(2048 / d); if (gx < 1) gx = 1;
+    const unsigned need = (unsigned)((T + MSM_THREADS - 1) / MSM_THREADS); if (gx > need) gx = need ? need : 1;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t q = off; off = align_up(off + bytes, 256); return q; };
+    const size_t o_part = carve(d * gx * sizeof(G1Xyzz)), o_sum = carve(d * sizeof(G1Xyzz));
+    int rc = ws.ensure(off);
+    if (rc) return rc;
+    unsigned char* W = (unsigned char*)ws.p;
+    k_g1_sum_lookup_chunks<<<dim3(gx, (unsigned)d), MSM_THREADS, 0, g.stream>>>(srs->d, d_lookups, (uint32_t)T, (uint32_t)d, (uint32_t)log_k_chunk, (G1Xyzz*)(W + o_part));
+    k_g1_group_sum<<<(unsigned)d, MSM_THREADS, 0, g.stream>>>((const G1Xyzz*)(W + o_part), gx, (G1Xyzz*)(W + o_sum));
+    std::vector<H::G1X> res(d);
+    HIP_TRY(hipMemcpyAsync(res.data(), W + o_sum, d * sizeof(G1Xyzz), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    for (size_t r = 0; r < d; r++) to_out(H::gx_to_aff(res[r]), out + r);
+    return ATLAS_OK;
+}
+
 // CommitmentScheme::batch_commit (commitment_scheme.rs:76-90 -> UnivariateKZG::commit_batch, kzg.rs:195-243): n
 // polynomials against prefixes of the same SRS.  LargeScalars polynomials share one bucket pipeline (their scalars are
 // gathered into one buffer: 32 B per coefficient against ~20 point additions); I32Scalars ones take the narrow-scalar plan.

@@ -593,6 +593,29 @@ __global__ __launch_bounds__(MSM_THREADS) void k_g1_sum_onehot_rows(const G1Affi
     if (threadIdx.x == 0) g1_store(out + (size_t)blockIdx.y * gridDim.x + blockIdx.x, sm[0]);
 }
 
+// The RaD witness commitments of a lookup (witness.rs:136-200 builds one OneHotPolynomial per 4-bit chunk of the lookup
+// index and commits it with commit_one_hot): chunk i of cycle t selects SRS point chunk_i(idx_t) * T + t.  The chunks are cut
+// in the kernel, so the d commitments need only the T lookup indices already on the device.  blockIdx.y = chunk.
+__global__ __launch_bounds__(MSM_THREADS) void k_g1_sum_lookup_chunks(const G1Affine* __restrict__ bases, const uint64_t* __restrict__ lookups,
+                                                                      uint32_t T, uint32_t d, uint32_t log_k_chunk, G1Xyzz* __restrict__ out) {
+    __shared__ G1Xyzz sm[MSM_THREADS];
+    const uint32_t i = blockIdx.y, shift = log_k_chunk * (d - 1 - i);
+    const uint64_t mask = ((uint64_t)1 << log_k_chunk) - 1;
+    G1Xyzz acc = g1_inf();
+    for (size_t t = (size_t)blockIdx.x * MSM_THREADS + threadIdx.x; t < T; t += (size_t)gridDim.x * MSM_THREADS) {
+        const uint64_t k = shift >= 64 ? 0 : ((lookups[t] >> shift) & mask);
+        const G1Affine p = g1_aff_load(bases + (size_t)k * T + t);
+        if (!g1_aff_is_inf(p)) acc = g1_madd(acc, p, false);
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s2 = MSM_THREADS / 2; s2 >= 1; s2 >>= 1) {
+        if (threadIdx.x < s2) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + s2]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) g1_store(out + (size_t)blockIdx.y * gridDim.x + blockIdx.x, sm[0]);
+}
+
 // SRS generation (SRS::setup, hyperkzg/kzg.rs:26-93): out[i] = tau^(i+1) * G.
 // tau_pow2[j] = tau^(2^j) (Montgomery Fr), dbl_table[j] = 2^j * G (affine).
 __global__ __launch_bounds__(MSM_THREADS) void k_srs_generate(const Fr* __restrict__ tau_pow2,

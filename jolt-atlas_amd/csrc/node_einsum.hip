@@ -75,6 +75,11 @@ __global__ __launch_bounds__(256) void k_i64_to_fr(const int64_t* __restrict__ i
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) fe_store(out + i, fr_from_i64(in[i]));
 }
 
+// element-wise product accumulators of the fused-rescale Mul node
+__global__ __launch_bounds__(256) void k_mul_acc(const int32_t* __restrict__ l, const int32_t* __restrict__ r, size_t n, int64_t* __restrict__ acc) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc[i] = (int64_t)l[i] * (int64_t)r[i];
+}
+
 // ReLU witness: the output tensor and the lookup indices `x as u32 as u64` (compute_lookup_indices_from_operands, utils/mod.rs:43-122)
 __global__ __launch_bounds__(256) void k_relu_witness(const int32_t* __restrict__ x, size_t n, int32_t* __restrict__ out, uint64_t* __restrict__ idx) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -190,20 +195,22 @@ int prove_onehot_checks(const uint64_t* d_lookups, size_t log_T, size_t log_K, c
 
 }  // namespace
 
-extern "C" int atlas_prove_einsum_node(const atlas_einsum_node_t* node, const int32_t* d_A, const int32_t* d_B, const atlas_fr_t* r_node_output,
-                                       const atlas_fr_t* output_claim, atlas_transcript_t* t, uint8_t* proofs, size_t cap, size_t* proofs_len,
-                                       size_t proof_lens[5], atlas_fr_t* claims, size_t claims_cap, size_t* n_claims, int32_t* d_output,
-                                       double* stage_ms) {
-    NEED_INIT();
-    if (!node || !d_A || !d_B || !r_node_output || !t || !proofs || !proofs_len || !proof_lens || !claims || !n_claims)
-        return fail(ATLAS_EINVAL, "prove_einsum_node: null argument");
-    const size_t m = node->m, k = node->k, n = node->n, S = node->scale_bits;
-    if (!pow2(m) || !pow2(k) || !pow2(n) || m * n < 2 || k < 2 || S == 0 || S > 30 || m * n > ((size_t)1 << 26) || k > ((size_t)1 << 26))
-        return fail(ATLAS_EINVAL, "prove_einsum_node: m, k, n powers of two (m*n >= 2, k >= 2), 1 <= scale_bits <= 30");
-    const size_t T = m * n, log_T = ilog2(T), log_m = ilog2(m);
+namespace {
+
+// The fused-rescale operator flow shared by Einsum, Mul, ... (impl_fused_rescale_proof_api, ops/mod.rs:569-612):
+//   fused_rebase::prove_pre (fused_rebase.rs:215-250): remainder advice + rescaled-accumulator claim, saturating clamp lookup
+//   (PS-Shout over ClampBoundedTable<64, 31, true>) and its one-hot checks;
+//   the operator's own sumcheck over the i64 accumulator, input claim fused_input_claim = rescaled(r) 2^S + R(r);
+//   fused_rebase::prove_remainder_rc (:252-285): identity range check of the remainder in [0, 2^S) and its one-hot checks.
+// fill_acc launches the kernels that leave the T i64 accumulators in d_acc (library stream); inner(in_claim) runs the
+// operator's sumcheck, appends its openings and stores its proof.  stage_ms[6]: witness, clamp, one-hot checks, inner,
+// range check, remainder one-hot checks.
+template <class FillAcc, class Inner>
+int prove_fused_rescale(size_t T, size_t S, FillAcc&& fill_acc, Inner&& inner, const atlas_fr_t* r_node_output, const atlas_fr_t* output_claim,
+                        atlas_transcript_t* t, Out& O, int32_t* d_output, double* stage_ms) {
+    const size_t log_T = ilog2(T);
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point a) { atlas_sync(); return std::chrono::duration<double, std::milli>(now() - a).count(); };
-    Out O{proofs, cap, 0, proof_lens, 0, claims, claims_cap, 0};
     H::Transcript& Tr = *reinterpret_cast<H::Transcript*>(t);
 
     // ---- witness (f1): try_rebase_intermediates on the device
@@ -216,21 +223,16 @@ extern "C" int atlas_prove_einsum_node(const atlas_einsum_node_t* node, const in
     if (e == hipSuccess) e = hipMalloc(&d_ridx, T * 8);
     if (e == hipSuccess) e = hipMalloc(&d_qfr, T * sizeof(Fr));
     if (e == hipSuccess && !d_output) { e = hipMalloc(&d_out_own, T * 4); d_output = d_out_own; }
-    if (e != hipSuccess) { cleanup(); return fail(ATLAS_ENOMEM, "hipMalloc(einsum node witness)", e); }
+    if (e != hipSuccess) { cleanup(); return fail(ATLAS_ENOMEM, "hipMalloc(fused-rescale witness)", e); }
+    int rc = ATLAS_OK;
     {
         std::lock_guard<atlas_rt::Mutex> lk(g.mu);
         size_t gb = (T + 255) / 256; if (gb > 4096) gb = 4096;
-        // enough k-slices for ~2^16 threads
-        uint32_t slices = 1;
-        while (slices < 64 && (n * ((m + EB_ROWS - 1) / EB_ROWS)) * slices < ((size_t)1 << 16) && k / (slices * 2) >= 32) slices *= 2;
-        const uint32_t k_slice = (uint32_t)((k + slices - 1) / slices);
-        HIP_TRY(hipMemsetAsync(d_quot, 0, T * 8, g.stream));
-        k_einsum_acc_mk_kn<<<dim3((unsigned)((n + 255) / 256), (unsigned)((m + EB_ROWS - 1) / EB_ROWS), slices), 256, 0, g.stream>>>(
-            d_A, d_B, (uint32_t)m, (uint32_t)k, (uint32_t)n, k_slice, (unsigned long long*)d_quot);
+        rc = fill_acc(d_quot);
+        if (rc) { cleanup(); return rc; }
         k_einsum_rebase<<<(unsigned)gb, 256, 0, g.stream>>>(d_quot, T, (uint32_t)S, d_rem, d_output, d_cidx, d_ridx);
         k_i64_to_fr<<<(unsigned)gb, 256, 0, g.stream>>>(d_quot, d_qfr, T);
     }
-    int rc = ATLAS_OK;
     atlas_poly_t p_rem = nullptr, p_quot = nullptr, p_out = nullptr;
     {   // borrowed views for evaluate
         rc = atlas_poly_wrap_device_fr(d_qfr, T, &p_quot);
@@ -268,30 +270,12 @@ extern "C" int atlas_prove_einsum_node(const atlas_einsum_node_t* node, const in
     if (!rc) rc = prove_onehot_checks(d_cidx, log_T, 64, r_node_output, ra_point, ra_claim, t, O);
     if (stage_ms) stage_ms[2] = ms_since(t0);
 
-    // ---- EinsumMatmul
+    // ---- the operator's sumcheck over the accumulator
     t0 = now();
     if (!rc) {
-        atlas_poly_t eq_m = nullptr, eq_n = nullptr, left = nullptr, right = nullptr;
-        rc = atlas_eq_evals(r_node_output, log_m, nullptr, &eq_m);
-        if (!rc) rc = atlas_eq_evals(r_node_output + log_m, log_T - log_m, nullptr, &eq_n);
-        const size_t dims[3] = {m, k, n};
-        if (!rc) rc = atlas_einsum_fold(ATLAS_EINSUM_MK_KN_MN, dims, 3, d_A, d_B, eq_m, eq_n, &left, &right);
-        if (eq_m) atlas_poly_free(eq_m);
-        if (eq_n) atlas_poly_free(eq_n);
-        atlas_dot_prover_t dp = nullptr;
-        if (!rc) rc = atlas_dot_prover_new(left, right, nullptr, ATLAS_EQ_NONE, 0, 0, &dp);
-        if (rc) { if (left) atlas_poly_free(left); if (right) atlas_poly_free(right); }
-        const size_t nk = ilog2(k);
         // fused_input_claim: rescaled(r0) 2^S + R(r0)
         const H::Fr in_claim = H::add(H::mul(acc_claim, H::from_u64((uint64_t)1 << S)), eval_R);
-        std::vector<atlas_fr_t> rows(nk * 2); std::vector<atlas_u128_t> chm(nk); atlas_fr_t fin[3];
-        if (!rc) rc = atlas_sumcheck_prove_dot(dp, (const atlas_fr_t*)&in_claim, t, rows.data(), chm.data(), fin);
-        if (!rc) {                                                            // dot.rs:377-400: left then right operand opening
-            for (int q = 0; q < 2 && !rc; q++) { rc = atlas_transcript_append_scalar(t, &fin[q]); if (!rc) rc = O.put_claim(*reinterpret_cast<H::Fr*>(&fin[q])); }
-            std::vector<uint32_t> nco(nk, 2);
-            if (!rc) rc = O.put_proof(rows, 2, nco, nk);
-        }
-        if (dp) atlas_dot_prover_free(dp);
+        rc = inner(in_claim);
     }
     if (stage_ms) stage_ms[3] = ms_since(t0);
 
@@ -315,11 +299,109 @@ extern "C" int atlas_prove_einsum_node(const atlas_einsum_node_t* node, const in
     if (!rc) rc = prove_onehot_checks(d_ridx, log_T, S, r_node_output, rr_point, rr_claim, t, O);
     if (stage_ms) stage_ms[5] = ms_since(t0);
     cleanup();
+    return rc;
+}
+
+
+
+}  // namespace
+
+extern "C" int atlas_prove_einsum_node(const atlas_einsum_node_t* node, const int32_t* d_A, const int32_t* d_B, const atlas_fr_t* r_node_output,
+                                       const atlas_fr_t* output_claim, atlas_transcript_t* t, uint8_t* proofs, size_t cap, size_t* proofs_len,
+                                       size_t proof_lens[5], atlas_fr_t* claims, size_t claims_cap, size_t* n_claims, int32_t* d_output,
+                                       double* stage_ms) {
+    NEED_INIT();
+    if (!node || !d_A || !d_B || !r_node_output || !t || !proofs || !proofs_len || !proof_lens || !claims || !n_claims)
+        return fail(ATLAS_EINVAL, "prove_einsum_node: null argument");
+    const size_t m = node->m, k = node->k, n = node->n, S = node->scale_bits;
+    if (!pow2(m) || !pow2(k) || !pow2(n) || m * n < 2 || k < 2 || S == 0 || S > 30 || m * n > ((size_t)1 << 26) || k > ((size_t)1 << 26))
+        return fail(ATLAS_EINVAL, "prove_einsum_node: m, k, n powers of two (m*n >= 2, k >= 2), 1 <= scale_bits <= 30");
+    const size_t T = m * n, log_T = ilog2(T), log_m = ilog2(m);
+    Out O{proofs, cap, 0, proof_lens, 0, claims, claims_cap, 0};
+    auto fill_acc = [&](int64_t* d_acc) -> int {
+        // enough k-slices for ~2^16 threads
+        uint32_t slices = 1;
+        while (slices < 64 && (n * ((m + EB_ROWS - 1) / EB_ROWS)) * slices < ((size_t)1 << 16) && k / (slices * 2) >= 32) slices *= 2;
+        const uint32_t k_slice = (uint32_t)((k + slices - 1) / slices);
+        HIP_TRY(hipMemsetAsync(d_acc, 0, T * 8, g.stream));
+        k_einsum_acc_mk_kn<<<dim3((unsigned)((n + 255) / 256), (unsigned)((m + EB_ROWS - 1) / EB_ROWS), slices), 256, 0, g.stream>>>(
+            d_A, d_B, (uint32_t)m, (uint32_t)k, (uint32_t)n, k_slice, (unsigned long long*)d_acc);
+        return ATLAS_OK;
+    };
+    auto inner = [&](const H::Fr& in_claim) -> int {               // EinsumMatmul (ops/einsum/mod.rs:71-115)
+        int rc = ATLAS_OK;
+        atlas_poly_t eq_m = nullptr, eq_n = nullptr, left = nullptr, right = nullptr;
+        rc = atlas_eq_evals(r_node_output, log_m, nullptr, &eq_m);
+        if (!rc) rc = atlas_eq_evals(r_node_output + log_m, log_T - log_m, nullptr, &eq_n);
+        const size_t dims[3] = {m, k, n};
+        if (!rc) rc = atlas_einsum_fold(ATLAS_EINSUM_MK_KN_MN, dims, 3, d_A, d_B, eq_m, eq_n, &left, &right);
+        if (eq_m) atlas_poly_free(eq_m);
+        if (eq_n) atlas_poly_free(eq_n);
+        atlas_dot_prover_t dp = nullptr;
+        if (!rc) rc = atlas_dot_prover_new(left, right, nullptr, ATLAS_EQ_NONE, 0, 0, &dp);
+        if (rc) { if (left) atlas_poly_free(left); if (right) atlas_poly_free(right); }
+        const size_t nk = ilog2(k);
+        std::vector<atlas_fr_t> rows(nk * 2); std::vector<atlas_u128_t> chm(nk); atlas_fr_t fin[3];
+        if (!rc) rc = atlas_sumcheck_prove_dot(dp, (const atlas_fr_t*)&in_claim, t, rows.data(), chm.data(), fin);
+        if (!rc) {                                                            // dot.rs:377-400: left then right operand opening
+            for (int q = 0; q < 2 && !rc; q++) { rc = atlas_transcript_append_scalar(t, &fin[q]); if (!rc) rc = O.put_claim(*reinterpret_cast<H::Fr*>(&fin[q])); }
+            std::vector<uint32_t> nco(nk, 2);
+            if (!rc) rc = O.put_proof(rows, 2, nco, nk);
+        }
+        if (dp) atlas_dot_prover_free(dp);
+        return rc;
+    };
+    int rc = prove_fused_rescale(T, S, fill_acc, inner, r_node_output, output_claim, t, O, d_output, stage_ms);
     if (rc) return rc;
     *proofs_len = O.len; *n_claims = O.n_claims;
     return ATLAS_OK;
 }
 
+// Mul::prove with fused rescaling (ops/mul.rs via impl_fused_rescale_proof_api, ops/mod.rs:569-612): out = (left * right) >> S
+// element-wise.  The operator's own sumcheck is MulProver over the Gruen split-eq of r_node_output (mul.rs:125-200), input
+// claim rescaled(r) 2^S + R(r); cache_openings appends the left, then the right operand claim.  Five proofs like the Einsum node.
+extern "C" int atlas_prove_mul_node(const int32_t* d_left, const int32_t* d_right, size_t log_T, uint32_t scale_bits, const atlas_fr_t* r_node_output,
+                                    const atlas_fr_t* output_claim, atlas_transcript_t* t, uint8_t* proofs, size_t cap, size_t* proofs_len,
+                                    size_t proof_lens[5], atlas_fr_t* claims, size_t claims_cap, size_t* n_claims, int32_t* d_output, double* stage_ms) {
+    NEED_INIT();
+    if (!d_left || !d_right || !r_node_output || !t || !proofs || !proofs_len || !proof_lens || !claims || !n_claims)
+        return fail(ATLAS_EINVAL, "prove_mul_node: null argument");
+    const size_t S = scale_bits;
+    if (log_T == 0 || log_T > 25 || S == 0 || S > 30) return fail(ATLAS_EINVAL, "prove_mul_node: 1 <= log_T <= 25, 1 <= scale_bits <= 30");
+    const size_t T = (size_t)1 << log_T;
+    Out O{proofs, cap, 0, proof_lens, 0, claims, claims_cap, 0};
+    auto fill_acc = [&](int64_t* d_acc) -> int {
+        size_t gb = (T + 255) / 256; if (gb > 4096) gb = 4096;
+        k_mul_acc<<<(unsigned)gb, 256, 0, g.stream>>>(d_left, d_right, T, d_acc);
+        return ATLAS_OK;
+    };
+    auto inner = [&](const H::Fr& in_claim) -> int {
+        atlas_poly_t ops[2] = {nullptr, nullptr};
+        int rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(d_left), T, &ops[0]);          // read-only views
+        if (!rc) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(d_right), T, &ops[1]);
+        atlas_instance_t inst = nullptr;
+        if (!rc) rc = atlas_elementwise_new(ATLAS_EW_MUL, ops, 2, r_node_output, log_T, nullptr, 0, &inst);
+        for (atlas_poly_t p : ops) if (p) atlas_poly_free(p);
+        const size_t stride = 4;
+        std::vector<atlas_fr_t> rows(log_T * stride);
+        std::vector<uint32_t> nco(log_T);
+        std::vector<atlas_u128_t> ch(log_T);
+        if (!rc) rc = atlas_instance_prove(inst, (const atlas_fr_t*)&in_claim, t, rows.data(), stride, nco.data(), ch.data());
+        atlas_fr_t fin[8]; size_t nf = 0;
+        if (!rc) rc = atlas_instance_final_claims(inst, fin, 8, &nf);
+        for (int q = 0; q < 2 && !rc; q++) {                                    // append_nodeio(Input(0)), append_nodeio(Input(1))  (mul.rs:188-199)
+            rc = atlas_transcript_append_scalar(t, &fin[q]);
+            if (!rc) rc = O.put_claim(*reinterpret_cast<H::Fr*>(&fin[q]));
+        }
+        if (!rc) rc = O.put_proof(rows, stride, nco, log_T);
+        if (inst) atlas_instance_free(inst);
+        return rc;
+    };
+    int rc = prove_fused_rescale(T, S, fill_acc, inner, r_node_output, output_claim, t, O, d_output, stage_ms);
+    if (rc) return rc;
+    *proofs_len = O.len; *n_claims = O.n_claims;
+    return ATLAS_OK;
+}
 
 // ReLU::prove (jolt-atlas-core/src/onnx_proof/ops/relu.rs:22-70): OpLookupProvider::read_raf_prove over ReluTable<XLEN>
 // (op_lookups/mod.rs:250-267: the operand's claim at r_cycle appended, gamma drawn, UnaryReadRafSumcheckProver), Sumcheck::prove

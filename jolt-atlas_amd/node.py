@@ -38,3 +38,19 @@ def prove_relu_node(tX, log_T, r_node_output, transcript, output_claim=None):
                                      _p(claims), C.c_size_t(256), C.byref(nc), None, st))
     raw = bytes(buf[:ln.value])
     return [raw[:lens[0]], raw[lens[0]:lens[0] + lens[1]]], claims[:nc.value].copy(), np.array(list(st))
+
+
+def prove_mul_node(tL, tR, log_T, scale_bits, r_node_output, transcript, output_claim=None):
+    """Mul::prove (fused rescale) for one node.  tL, tR: TensorI32 of 2^log_T values.  Returns (proof_bytes list of 5, claims (c,4), stage_ms (6,))."""
+    rn = np.ascontiguousarray(r_node_output, dtype=np.uint64)
+    cap = 1 << 20
+    buf = (C.c_uint8 * cap)(); ln = C.c_size_t(); lens = (C.c_size_t * 5)()
+    claims = np.zeros((256, 4), dtype=np.uint64); nc = C.c_size_t(); st = (C.c_double * 6)()
+    oc = _p(_fr(output_claim)) if output_claim is not None else None
+    _check(lib.atlas_prove_mul_node(tL.d, tR.d, C.c_size_t(log_T), C.c_uint32(scale_bits), _p(rn), oc, C.byref(transcript.t), buf, C.c_size_t(cap),
+                                    C.byref(ln), lens, _p(claims), C.c_size_t(256), C.byref(nc), None, st))
+    raw = bytes(buf[:ln.value])
+    out, o = [], 0
+    for i in range(5):
+        out.append(raw[o:o + lens[i]]); o += lens[i]
+    return out, claims[:nc.value].copy(), np.array(list(st))

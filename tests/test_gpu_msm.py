@@ -197,3 +197,32 @@ def test_concurrent_commits_match_serial(atlas, srs_small):
         assert orc.g1_eq(a, b)
     for p_ in polys:
         p_.free()
+
+
+@pytest.mark.parametrize("log_K,lkc", [(16, 4), (14, 4), (64, 4), (8, 8)])
+def test_commit_lookup_chunks_matches_one_hot_commits(atlas, log_K, lkc):
+    """The d RaD witness commitments cut and committed on the device == commit_one_hot of each chunk's index vector
+    (hyperkzg/mod.rs:520-596, OneHotParams::lookup_index_chunk config.rs:73-75), against the oracle's indexed sum."""
+    from oracle import orc
+    from jolt_atlas_amd import instances as I
+    log_T = 5
+    T = 1 << log_T
+    K = 1 << lkc
+    n = K * T
+    tau = _tau(orc)
+    s = atlas.SRS.generate(tau, n)
+    ref = s.download()
+    rng = np.random.default_rng(log_K)
+    look = rng.integers(0, 1 << 62, size=T, dtype=np.uint64) if log_K == 64 else rng.integers(0, 1 << log_K, size=T, dtype=np.uint64)
+    if log_K == 64:
+        look[0] = np.uint64(0xFFFFFFFFFFFFFFFF); look[1] = np.uint64(0)
+    d = -(-log_K // lkc)
+    dev = I.DeviceU64.upload(look)
+    got = s.commit_lookup_chunks(dev, log_T, log_K, lkc)
+    assert len(got) == d
+    for i in range(d):
+        shift = lkc * (d - 1 - i)
+        chunk = ((look >> np.uint64(shift)) & np.uint64(K - 1)).astype(np.uint64) if shift < 64 else np.zeros(T, dtype=np.uint64)
+        idx = (chunk * np.uint64(T) + np.arange(T, dtype=np.uint64)).astype(np.uint32)
+        assert orc.g1_eq(got[i], orc.g1_sum_indexed(ref, idx)), f"chunk {i}"
+    dev.free(); s.free()

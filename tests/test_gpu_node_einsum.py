@@ -195,3 +195,72 @@ def test_relu_node_matches_oracle_composition(atlas, log_T):
     proofs2, claims_g2, _ = node.prove_relu_node(tX, log_T, r0, t_g2, output_claim=out_claim)
     assert proofs2 == proofs and t_g2.state == t_g.state
     tX.free()
+
+
+def _fused_rescale_oracle(orc, OR, OB, label, acc, S, r0, inner):
+    """The fused-rescale flow (prove_pre, the operator's sumcheck `inner(t, in_claim, claims) -> rows`, prove_remainder_rc)
+    over the oracle's instances.  acc: the i64 accumulators.  Returns (list of 5 row lists, claims, transcript)."""
+    T = len(acc); log_T = T.bit_length() - 1
+    quot = acc >> S
+    rem = acc - (quot << S)
+    outv = np.clip(quot, -(1 << 31), (1 << 31) - 1)
+    f = lambda v: orc.from_ints([int(x) % FR for x in v])
+    eval_R, acc_claim, out_claim = orc.evaluate(f(rem), r0), orc.evaluate(f(quot), r0), orc.evaluate(f(outv), r0)
+    claims = []
+    t = orc.new_transcript(label)
+    _append(orc, t, eval_R); claims.append(eval_R)
+    _append(orc, t, acc_claim); claims.append(acc_claim)
+    gamma = _challenge_scalar(orc, t)
+    cidx = quot.astype(np.int64).view(np.uint64).copy()
+    exec_claim = orc.fr_add_arr(out_claim, orc.fr_mul_arr(gamma, acc_claim))
+    rows_exec, ch = OR.ps_clamp(cidx, 64, 31, True, r0, gamma).prove(exec_claim, t)
+    rs = orc.challenges_to_fr(ch)
+    ra_point = np.concatenate([rs[:64], rs[64:][::-1]])
+    ra_claim = orc.evaluate(np.stack([_eq_bits(orc, ra_point[:64], v, 64) for v in cidx]), np.ascontiguousarray(ra_point[64:]))
+    _append(orc, t, ra_claim); claims.append(ra_claim)
+    rows_oh = _onehot_checks(orc, OR, OB, t, cidx, log_T, 64, r0, ra_point, ra_claim, claims)
+    in_claim = orc.fr_add_arr(orc.fr_mul_arr(acc_claim, f([1 << S])[0]), eval_R)
+    rows_inner = inner(t, in_claim, claims)
+    ridx = rem.astype(np.uint64)
+    phases = 1 if S <= 2 else S // 4 if S % 4 == 0 else S // 2 if S % 2 == 0 else S
+    rows_rc, ch = OR.ps_identity(ridx, S, phases, r0).prove(eval_R, t)
+    rs = orc.challenges_to_fr(ch)
+    rr_point = np.concatenate([rs[:S], rs[S:][::-1]])
+    rr_claim = orc.evaluate(np.stack([_eq_bits(orc, rr_point[:S], v, S) for v in ridx]), np.ascontiguousarray(rr_point[S:]))
+    _append(orc, t, rr_claim); claims.append(rr_claim)
+    rows_oh2 = _onehot_checks(orc, OR, OB, t, ridx, log_T, S, r0, rr_point, rr_claim, claims)
+    return [rows_exec, rows_oh, rows_inner, rows_rc, rows_oh2], claims, t
+
+
+@pytest.mark.parametrize("log_T,S", [(3, 5), (6, 7), (8, 4)])
+def test_mul_node_matches_oracle_composition(atlas, log_T, S):
+    """Mul::prove with fused rescaling (ops/mul.rs via impl_fused_rescale_proof_api) through atlas_prove_mul_node against the
+    same composition over the oracle's instances: MulProver between prove_pre and prove_remainder_rc."""
+    from oracle import orc, orc_ra as OR, orc_batched as OB
+    from jolt_atlas_amd import node
+    T = 1 << log_T
+    rng = np.random.default_rng(100 + log_T)
+    L = rng.integers(-(1 << 9), 1 << 9, size=T, dtype=np.int64).astype(np.int32)
+    R = rng.integers(-(1 << 9), 1 << 9, size=T, dtype=np.int64).astype(np.int32)
+    acc = L.astype(np.int64) * R.astype(np.int64)
+    r0 = orc.random_fr(log_T, 55)
+    f = lambda v: orc.from_ints([int(x) % FR for x in v])
+
+    def inner(t, in_claim, claims):
+        o = OR.elementwise(5, [f(L), f(R)], r0)                      # ATLAS_EW_MUL = MulProver
+        assert np.array_equal(in_claim, orc.evaluate(f(acc), r0))    # acc(r0) = rescaled(r0) 2^S + R(r0)
+        rows, _ch = o.prove(in_claim, t)
+        fin = o.finals()
+        for c in (fin[0], fin[1]):
+            _append(orc, t, c); claims.append(c)
+        return rows
+
+    rows5, claims, t = _fused_rescale_oracle(orc, OR, OB, b"mul_node", acc, S, r0, inner)
+    tL, tR = atlas.TensorI32(L), atlas.TensorI32(R)
+    t_g = atlas.Blake2bTranscript(b"mul_node")
+    proofs, claims_g, stage_ms = node.prove_mul_node(tL, tR, log_T, S, r0, t_g)
+    for i, (a, rows) in enumerate(zip(proofs, rows5)):
+        assert a == _ser(orc, rows), f"proof {i} differs"
+    assert np.array_equal(claims_g, np.stack(claims))
+    assert t_g.state == t.state_bytes()
+    tL.free(); tR.free()
