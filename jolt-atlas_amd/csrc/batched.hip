@@ -120,6 +120,15 @@ struct Pipeline {
     // rounds are enqueued while the device works on earlier ones instead of all before the first collect.
     static constexpr size_t LOOKAHEAD = 3;
     size_t next_enqueue = 0;
+    // The instances of a batch are independent until the host combines their round polynomials, and their kernels at
+    // lookup sizes (T = 2^16) are low-occupancy launches: each lane gets a stream of its own so that RaVirtual's products
+    // and Booleanity's folds overlap on the device instead of queueing behind each other.  Lane streams start behind
+    // the library stream (the constructors ran there) and the library stream waits for them when the proof is done.
+    static constexpr size_t N_SIDE = 4;
+    bool side = false;
+    static hipStream_t* side_streams() { static hipStream_t st[N_SIDE] = {nullptr, nullptr, nullptr, nullptr}; return st; }
+    static hipEvent_t* side_events() { static hipEvent_t ev[N_SIDE + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr}; return ev; }
+    hipStream_t lane_stream(size_t li) const { return side ? side_streams()[li % N_SIDE] : g.stream; }
     int begin() {               // the caller holds g.mu
         for (auto& L : lanes) { max_rounds = L.rounds > max_rounds ? L.rounds : max_rounds; }
         for (auto& L : lanes) { L.offset = max_rounds - L.rounds; L.mails.resize(L.rounds); }
@@ -127,8 +136,28 @@ struct Pipeline {
         if (C.abort_dirty) { HIP_TRY(hipMemsetAsync(C.d_abort, 0, 4, g.stream)); C.abort_dirty = false; }
         tag0 = C.take_tags((max_rounds + 2) * (lanes.size() + 1));
         slot0 = C.take_slots(max_rounds);
+        static const bool no_side = getenv("ATLAS_NO_LANE_STREAMS") != nullptr;
+        side = lanes.size() > 1 && !no_side;
+        if (side) {
+            hipStream_t* st = side_streams(); hipEvent_t* ev = side_events();
+            if (!st[0]) {
+                for (size_t i = 0; i < N_SIDE; i++) HIP_TRY(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
+                for (size_t i = 0; i <= N_SIDE; i++) HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+            }
+            HIP_TRY(hipEventRecord(ev[N_SIDE], g.stream));
+            for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) HIP_TRY(hipStreamWaitEvent(st[i], ev[N_SIDE], 0));
+        }
         return advance(0);
     }
+    // the library stream continues only after every lane stream has drained (called on every way out of a proof)
+    void join() {
+        if (!side) return;
+        hipStream_t* st = side_streams(); hipEvent_t* ev = side_events();
+        for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) { (void)hipEventRecord(ev[i], st[i]); (void)hipStreamWaitEvent(g.stream, ev[i], 0); }
+        side = false;
+    }
+    void query() { (void)hipStreamQuery(g.stream); if (side) for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) (void)hipStreamQuery(side_streams()[i]); }
+    void drain() { if (side) for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) (void)hipStreamSynchronize(side_streams()[i]); (void)hipStreamSynchronize(g.stream); join(); }
     // make sure the launches of global rounds < R + LOOKAHEAD (and the final binds after the last) are enqueued
     int advance(size_t R) {
         while (next_enqueue <= max_rounds && next_enqueue < R + LOOKAHEAD) {
@@ -140,8 +169,11 @@ struct Pipeline {
                 const bool bind_prev = local > 0, wait = bind_prev || Q == max_rounds;
                 atlas::Chunk* area = C.alloc(256 * atlas::ch_stride(4));
                 const atlas::RoundIo io = C.io(area, mtag(Q, li), wait ? slot0 + Q - 1 : (size_t)-1, wait ? rtag(Q - 1) : 0, 256);
+                const hipStream_t lib_stream = g.stream;          // the instance's launches go to its lane's stream
+                g.stream = lane_stream(li);
                 int rc = Q < max_rounds ? L.inst->enqueue(local, io, bind_prev, L.mails[local]) : L.inst->enqueue_finals(io, L.fin);
-                if (rc) { abort_from(0); (void)hipStreamSynchronize(g.stream); return rc; }
+                g.stream = lib_stream;
+                if (rc) { abort_from(0); drain(); return rc; }
             }
         }
         return ATLAS_OK;
@@ -157,12 +189,13 @@ struct Pipeline {
         for (size_t li = 0; li < lanes.size(); li++) {
             Lane& L = lanes[li];
             uint32_t raw[16][9];
-            if (L.fin.n_vals > 16 || !C.collect_raw(L.fin.base, mtag(max_rounds, li), (size_t)L.fin.n_vals, raw)) return fail(ATLAS_ENODEV, "round channel: no answer from the device");
+            if (L.fin.n_vals > 16 || !C.collect_raw(L.fin.base, mtag(max_rounds, li), (size_t)L.fin.n_vals, raw)) { drain(); return fail(ATLAS_ENODEV, "round channel: no answer from the device"); }
             H::Fr v[16];
             for (int k = 0; k < L.fin.n_vals; k++) std::memcpy(&v[k], raw[k], 32);
             int rc = L.inst->set_finals(v, (size_t)L.fin.n_vals);
-            if (rc) return rc;
+            if (rc) { join(); return rc; }
         }
+        join();
         return ATLAS_OK;
     }
 };
@@ -378,7 +411,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
                 I.inst->prepare(local);
                 int rc = PL.collect(PL.lanes[i].mails[local], PL.mtag(round, i), sums) ? ATLAS_OK : fail(ATLAS_ENODEV, "round channel: no answer from the device");
                 if (!rc) rc = I.inst->finish(local, claim[i], sums, polys[i]);
-                if (rc) { PL.abort_from(round); (void)hipStreamSynchronize(g.stream); return rc; }
+                if (rc) { PL.abort_from(round); PL.drain(); return rc; }
             } else {
                 const auto tm0 = std::chrono::steady_clock::now();
                 int rc = I.inst->message(round - (max_rounds - I.rounds), claim[i], polys[i]);
@@ -399,7 +432,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         std::vector<H::Fr> cc;
         if (batched.size() < 2) cc = batched;
         else { cc.push_back(batched[0]); for (size_t k = 2; k < batched.size(); k++) cc.push_back(batched[k]); }
-        if (cc.size() > row_stride) { if (piped) { PL.abort_from(round); (void)hipStreamSynchronize(g.stream); } return fail(ATLAS_EINVAL, "batched_prove: row_stride below the batched degree"); }
+        if (cc.size() > row_stride) { if (piped) { PL.abort_from(round); PL.drain(); } return fail(ATLAS_EINVAL, "batched_prove: row_stride below the batched degree"); }
         H::tr_append_message(T, "UniPoly_begin");
         for (auto& x : cc) H::tr_append_scalar(T, x);
         H::tr_append_message(T, "UniPoly_end");
@@ -408,7 +441,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         uint64_t lo, hi;
         H::tr_challenge_u128(T, lo, hi);                                              // challenge_scalar_optimized :119
         challenges[round].lo = lo; challenges[round].hi = hi;
-        if (piped) { PL.C.publish(PL.slot0 + round, PL.rtag(round), lo, hi); if ((round & 7) == 7) (void)hipStreamQuery(g.stream); }
+        if (piped) { PL.C.publish(PL.slot0 + round, PL.rtag(round), lo, hi); if ((round & 7) == 7) PL.query(); }
         const H::Fr r = H::challenge_to_fr(lo, hi, g.challenge_mode);
         for (size_t i = 0; i < n; i++) claim[i] = eval_with_challenge(polys[i], r);    // :123-126
         for (size_t i = 0; i < n; i++) {
@@ -417,11 +450,11 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
                 const auto ti0 = std::chrono::steady_clock::now();
                 int rc = piped ? I.inst->host_ingest(challenges[round], round - (max_rounds - I.rounds))
                                : I.inst->ingest(challenges[round], round - (max_rounds - I.rounds));
-                if (rc) { if (piped) { PL.abort_from(round + 1); (void)hipStreamSynchronize(g.stream); } return rc; }
+                if (rc) { if (piped) { PL.abort_from(round + 1); PL.drain(); } return rc; }
                 if (trace) t_ing[i] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti0).count();
             }
         }
-        if (piped) { int rc = PL.advance(round + 1); if (rc) return rc; }
+        if (piped) { int rc = PL.advance(round + 1); if (rc) return rc; }       // (advance drains on its own failures)
     }
     *max_rounds_out = max_rounds;
     if (trace)
