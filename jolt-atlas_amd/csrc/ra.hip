@@ -160,7 +160,10 @@ template <int D>
 void launch_prod(const Fr* buf, size_t stride, Fr* partials, const SplitEqView& E, size_t n_groups, unsigned blocks, MailTail tail) {
     tail.n_rows = blocks; tail.K = D;
     const MailTail none{tail.io, nullptr, 0, 0};
-    if (n_groups <= ((size_t)1 << 13)) {      // latency regime: one column per thread
+    // one column per thread up to 2^15 pairs: 16 x more workgroups than the register-tiled kernel, which runs at one wavefront
+    // per SIMD there (measured on the Einsum node: 2^15 is 2 % ahead of 2^13, 2^16 no better)
+    static const size_t col_log = [] { const char* e = getenv("ATLAS_RA_COL_LOG"); int v = e ? atoi(e) : 0; return (size_t)(v >= 8 && v <= 24 ? v : 15); }();   // experiments
+    if (n_groups <= ((size_t)1 << col_log)) {
         k_ra_prod_f9_col<D><<<dim3(blocks, D), RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, tail);
         return;
     }
@@ -355,7 +358,8 @@ struct Booleanity : atlas_instance {
     }
     uint32_t launch_fold(const Fr* buf, size_t stride, const SplitEqView& E, size_t n_groups, const atlas::RoundIo* io = nullptr) {
         size_t blocks = (n_groups + RA_THREADS - 1) / RA_THREADS; if (blocks > 2048) blocks = 2048;
-        const unsigned ysplit = n_groups <= ((size_t)1 << 13) ? (unsigned)d : 1u;   // latency regime: one row per thread
+        static const size_t split_log = [] { const char* e = getenv("ATLAS_BOOL_SPLIT_LOG"); int v = e ? atoi(e) : 0; return (size_t)(v >= 8 && v <= 24 ? v : 13); }();   // experiments
+        const unsigned ysplit = n_groups <= ((size_t)1 << split_log) ? (unsigned)d : 1u;   // latency regime: one row per thread
         const MailTail tail = io ? MailTail{*io, rows.d_counter, (uint32_t)(blocks * ysplit), 2u} : MailTail{{}, nullptr, 0, 0};
         k_bool_fold<<<dim3((unsigned)blocks, ysplit), RA_THREADS, 0, g.stream>>>(buf, stride, (uint32_t)d, d_gammas, E, n_groups, rows.partials, tail);
         return (uint32_t)(blocks * ysplit);

@@ -73,22 +73,24 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_bind_ch(const Fr* __restrict_
 }
 
 // column sums of a [n_partials][K] matrix of partial sums (K <= 16), mailed as ONE record of K values.  One workgroup:
-// thread t adds the rows t / 16, t / 16 + 16, ... of column t % 16; the 16 row groups meet in LDS.
+// thread t adds every (256 / K')-th row of column t % K' (K' = K rounded up to a power of two); the row groups meet in LDS.
 __device__ __forceinline__ void col_reduce_mail_body(const Fr* partials, uint32_t n_partials, uint32_t K, const RoundIo& io) {
     __shared__ Fr red[RA_THREADS];
     __shared__ uint32_t stage[9 * 16];
-    const uint32_t col = threadIdx.x & 15u, grp = threadIdx.x >> 4;
+    const uint32_t kp = K <= 2 ? 2u : K <= 4 ? 4u : K <= 8 ? 8u : 16u;          // columns padded to a power of two
+    const uint32_t n_grp = RA_THREADS / kp;
+    const uint32_t col = threadIdx.x % kp, grp = threadIdx.x / kp;
     Fr acc = fe_zero();
     if (col < K)
-        for (uint32_t p = grp; p < n_partials; p += RA_THREADS / 16) acc = fr_add(acc, fe_load(partials + (size_t)p * K + col));
+        for (uint32_t p = grp; p < n_partials; p += n_grp) acc = fr_add(acc, fe_load(partials + (size_t)p * K + col));
     red[threadIdx.x] = acc;
     __syncthreads();
+    for (uint32_t st = n_grp / 2; st >= 1; st >>= 1) {                          // tree over the row groups
+        if (grp < st) red[threadIdx.x] = fr_add(red[threadIdx.x], red[threadIdx.x + st * kp]);
+        __syncthreads();
+    }
     if (threadIdx.x < 64) {
-        Fr s = fe_zero();
-        if (threadIdx.x < 16) {
-            s = red[threadIdx.x];
-            for (uint32_t q = 1; q < RA_THREADS / 16; q++) s = fr_add(s, red[q * 16 + threadIdx.x]);
-        }
+        const Fr s = threadIdx.x < kp ? red[threadIdx.x] : fe_zero();
         ch_mail_wave_fe(io, 0, K, s, stage);
     }
 }
