@@ -660,6 +660,19 @@ int atlas_prove_mul_node(const int32_t *d_left, const int32_t *d_right, size_t l
                          uint8_t *proofs, size_t cap, size_t *proofs_len, size_t proof_lens[5], atlas_fr_t *claims,
                          size_t claims_cap, size_t *n_claims, int32_t *d_output, double *stage_ms);
 
+/* Square::prove with fused rescaling (ops/square.rs): out = (x * x) >> scale_bits; as atlas_prove_mul_node with one operand. */
+int atlas_prove_square_node(const int32_t *d_input, size_t log_T, uint32_t scale_bits, const atlas_fr_t *r_node_output,
+                            const atlas_fr_t *output_claim, atlas_transcript_t *transcript, uint8_t *proofs, size_t cap,
+                            size_t *proofs_len, size_t proof_lens[5], atlas_fr_t *claims, size_t claims_cap, size_t *n_claims,
+                            int32_t *d_output, double *stage_ms);
+/* Add::prove / Sub::prove (ops/add.rs:70-105, ops/sub.rs) for one node: prove_clamp_lookup over the i64 accumulation
+ * left +- right (clamp_lookups/mod.rs:264-309) and the operand tie left(r), right(r).  Two proofs (Execution,
+ * RaOneHotChecks); claims: acc, ra, the 3 d one-hot claims, left, right; stage_ms[3] optional. */
+int atlas_prove_addsub_node(const int32_t *d_left, const int32_t *d_right, size_t log_T, int subtract, const atlas_fr_t *r_node_output,
+                            const atlas_fr_t *output_claim, atlas_transcript_t *transcript, uint8_t *proofs, size_t cap,
+                            size_t *proofs_len, size_t proof_lens[2], atlas_fr_t *claims, size_t claims_cap, size_t *n_claims,
+                            int32_t *d_output, double *stage_ms);
+
 /* ReLU::prove (jolt-atlas-core/src/onnx_proof/ops/relu.rs:22-70) for one node: OpLookupProvider::read_raf_prove over
  * ReluTable<32> (op_lookups/mod.rs:250-267), Sumcheck::prove with its ra opening, ra_onehot_provers + BatchedSumcheck::prove
  * (shout.rs:399-466).  d_input: the operand, 2^log_T i32 on the device; r_node_output: the node-output opening point;

@@ -80,6 +80,17 @@ __global__ __launch_bounds__(256) void k_mul_acc(const int32_t* __restrict__ l, 
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc[i] = (int64_t)l[i] * (int64_t)r[i];
 }
 
+// Add / Sub accumulators, their saturated i32 output and the clamp lookup indices (`acc as u64`, clamp_lookups/mod.rs:243-251)
+__global__ __launch_bounds__(256) void k_addsub_witness(const int32_t* __restrict__ l, const int32_t* __restrict__ r, size_t n, int subtract,
+                                                        int64_t* __restrict__ acc, int32_t* __restrict__ out, uint64_t* __restrict__ idx) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int64_t a = subtract ? (int64_t)l[i] - (int64_t)r[i] : (int64_t)l[i] + (int64_t)r[i];
+        acc[i] = a;
+        if (out) out[i] = (int32_t)(a > 2147483647ll ? 2147483647ll : a < -2147483648ll ? -2147483648ll : a);
+        idx[i] = (uint64_t)a;
+    }
+}
+
 // ReLU witness: the output tensor and the lookup indices `x as u32 as u64` (compute_lookup_indices_from_operands, utils/mod.rs:43-122)
 __global__ __launch_bounds__(256) void k_relu_witness(const int32_t* __restrict__ x, size_t n, int32_t* __restrict__ out, uint64_t* __restrict__ idx) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -357,18 +368,16 @@ extern "C" int atlas_prove_einsum_node(const atlas_einsum_node_t* node, const in
     return ATLAS_OK;
 }
 
-// Mul::prove with fused rescaling (ops/mul.rs via impl_fused_rescale_proof_api, ops/mod.rs:569-612): out = (left * right) >> S
-// element-wise.  The operator's own sumcheck is MulProver over the Gruen split-eq of r_node_output (mul.rs:125-200), input
-// claim rescaled(r) 2^S + R(r); cache_openings appends the left, then the right operand claim.  Five proofs like the Einsum node.
-extern "C" int atlas_prove_mul_node(const int32_t* d_left, const int32_t* d_right, size_t log_T, uint32_t scale_bits, const atlas_fr_t* r_node_output,
-                                    const atlas_fr_t* output_claim, atlas_transcript_t* t, uint8_t* proofs, size_t cap, size_t* proofs_len,
-                                    size_t proof_lens[5], atlas_fr_t* claims, size_t claims_cap, size_t* n_claims, int32_t* d_output, double* stage_ms) {
-    NEED_INIT();
-    if (!d_left || !d_right || !r_node_output || !t || !proofs || !proofs_len || !proof_lens || !claims || !n_claims)
-        return fail(ATLAS_EINVAL, "prove_mul_node: null argument");
+// Mul::prove / Square::prove with fused rescaling (ops/mul.rs, ops/square.rs via impl_fused_rescale_proof_api, ops/mod.rs:569-612):
+// out = (left * right) >> S element-wise (Square: right = left, one operand).  The operator's own sumcheck is MulProver /
+// SquareProver over the Gruen split-eq of r_node_output, input claim rescaled(r) 2^S + R(r); cache_openings appends the
+// operand claim(s) in input order.  Five proofs like the Einsum node.
+static int prove_ew_fused_node(int op, const int32_t* d_left, const int32_t* d_right, size_t log_T, uint32_t scale_bits, const atlas_fr_t* r_node_output,
+                               const atlas_fr_t* output_claim, atlas_transcript_t* t, uint8_t* proofs, size_t cap, size_t* proofs_len,
+                               size_t proof_lens[5], atlas_fr_t* claims, size_t claims_cap, size_t* n_claims, int32_t* d_output, double* stage_ms) {
     const size_t S = scale_bits;
     if (log_T == 0 || log_T > 25 || S == 0 || S > 30) return fail(ATLAS_EINVAL, "prove_mul_node: 1 <= log_T <= 25, 1 <= scale_bits <= 30");
-    const size_t T = (size_t)1 << log_T;
+    const size_t T = (size_t)1 << log_T, n_ops = op == ATLAS_EW_SQUARE ? 1 : 2;
     Out O{proofs, cap, 0, proof_lens, 0, claims, claims_cap, 0};
     auto fill_acc = [&](int64_t* d_acc) -> int {
         size_t gb = (T + 255) / 256; if (gb > 4096) gb = 4096;
@@ -378,9 +387,9 @@ extern "C" int atlas_prove_mul_node(const int32_t* d_left, const int32_t* d_righ
     auto inner = [&](const H::Fr& in_claim) -> int {
         atlas_poly_t ops[2] = {nullptr, nullptr};
         int rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(d_left), T, &ops[0]);          // read-only views
-        if (!rc) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(d_right), T, &ops[1]);
+        if (!rc && n_ops == 2) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(d_right), T, &ops[1]);
         atlas_instance_t inst = nullptr;
-        if (!rc) rc = atlas_elementwise_new(ATLAS_EW_MUL, ops, 2, r_node_output, log_T, nullptr, 0, &inst);
+        if (!rc) rc = atlas_elementwise_new(op, ops, n_ops, r_node_output, log_T, nullptr, 0, &inst);
         for (atlas_poly_t p : ops) if (p) atlas_poly_free(p);
         const size_t stride = 4;
         std::vector<atlas_fr_t> rows(log_T * stride);
@@ -389,7 +398,7 @@ extern "C" int atlas_prove_mul_node(const int32_t* d_left, const int32_t* d_righ
         if (!rc) rc = atlas_instance_prove(inst, (const atlas_fr_t*)&in_claim, t, rows.data(), stride, nco.data(), ch.data());
         atlas_fr_t fin[8]; size_t nf = 0;
         if (!rc) rc = atlas_instance_final_claims(inst, fin, 8, &nf);
-        for (int q = 0; q < 2 && !rc; q++) {                                    // append_nodeio(Input(0)), append_nodeio(Input(1))  (mul.rs:188-199)
+        for (size_t q = 0; q < n_ops && !rc; q++) {                              // append_nodeio(Input(q))  (mul.rs:188-199, square.rs:186-197)
             rc = atlas_transcript_append_scalar(t, &fin[q]);
             if (!rc) rc = O.put_claim(*reinterpret_cast<H::Fr*>(&fin[q]));
         }
@@ -398,6 +407,95 @@ extern "C" int atlas_prove_mul_node(const int32_t* d_left, const int32_t* d_righ
         return rc;
     };
     int rc = prove_fused_rescale(T, S, fill_acc, inner, r_node_output, output_claim, t, O, d_output, stage_ms);
+    if (rc) return rc;
+    *proofs_len = O.len; *n_claims = O.n_claims;
+    return ATLAS_OK;
+}
+
+extern "C" int atlas_prove_mul_node(const int32_t* d_left, const int32_t* d_right, size_t log_T, uint32_t scale_bits, const atlas_fr_t* r_node_output,
+                                    const atlas_fr_t* output_claim, atlas_transcript_t* t, uint8_t* proofs, size_t cap, size_t* proofs_len,
+                                    size_t proof_lens[5], atlas_fr_t* claims, size_t claims_cap, size_t* n_claims, int32_t* d_output, double* stage_ms) {
+    NEED_INIT();
+    if (!d_left || !d_right || !r_node_output || !t || !proofs || !proofs_len || !proof_lens || !claims || !n_claims)
+        return fail(ATLAS_EINVAL, "prove_mul_node: null argument");
+    return prove_ew_fused_node(ATLAS_EW_MUL, d_left, d_right, log_T, scale_bits, r_node_output, output_claim, t, proofs, cap, proofs_len, proof_lens, claims,
+                               claims_cap, n_claims, d_output, stage_ms);
+}
+
+extern "C" int atlas_prove_square_node(const int32_t* d_input, size_t log_T, uint32_t scale_bits, const atlas_fr_t* r_node_output,
+                                       const atlas_fr_t* output_claim, atlas_transcript_t* t, uint8_t* proofs, size_t cap, size_t* proofs_len,
+                                       size_t proof_lens[5], atlas_fr_t* claims, size_t claims_cap, size_t* n_claims, int32_t* d_output, double* stage_ms) {
+    NEED_INIT();
+    if (!d_input || !r_node_output || !t || !proofs || !proofs_len || !proof_lens || !claims || !n_claims)
+        return fail(ATLAS_EINVAL, "prove_square_node: null argument");
+    return prove_ew_fused_node(ATLAS_EW_SQUARE, d_input, d_input, log_T, scale_bits, r_node_output, output_claim, t, proofs, cap, proofs_len, proof_lens, claims,
+                               claims_cap, n_claims, d_output, stage_ms);
+}
+
+// Add::prove / Sub::prove (ops/add.rs:70-105, ops/sub.rs): no sumcheck of their own — prove_clamp_lookup (clamp_lookups/mod.rs:264-309:
+// the i64 accumulation left +- right appended as the lookup's raf, gamma, PS-Shout over SaturationTable, its ra opening, the
+// one-hot checks), then the operand tie: left(r), right(r) appended in input order.  Two proofs (Execution, RaOneHotChecks);
+// claims: acc, ra, 3 d one-hot claims, left, right.  stage_ms[3]: witness, clamp lookup, one-hot checks (+ operand claims).
+extern "C" int atlas_prove_addsub_node(const int32_t* d_left, const int32_t* d_right, size_t log_T, int subtract, const atlas_fr_t* r_node_output,
+                                       const atlas_fr_t* output_claim, atlas_transcript_t* t, uint8_t* proofs, size_t cap, size_t* proofs_len,
+                                       size_t proof_lens[2], atlas_fr_t* claims, size_t claims_cap, size_t* n_claims, int32_t* d_output, double* stage_ms) {
+    NEED_INIT();
+    if (!d_left || !d_right || !r_node_output || !t || !proofs || !proofs_len || !proof_lens || !claims || !n_claims)
+        return fail(ATLAS_EINVAL, "prove_addsub_node: null argument");
+    if (log_T == 0 || log_T > 25) return fail(ATLAS_EINVAL, "prove_addsub_node: 1 <= log_T <= 25");
+    const size_t T = (size_t)1 << log_T;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point a) { atlas_sync(); return std::chrono::duration<double, std::milli>(now() - a).count(); };
+    Out O{proofs, cap, 0, proof_lens, 0, claims, claims_cap, 0};
+    H::Transcript& Tr = *reinterpret_cast<H::Transcript*>(t);
+    auto t0 = now();
+    DevBuf acc_b, idx_b, out_b, fr_b;
+    HIP_TRY(acc_b.alloc(T * 8)); HIP_TRY(idx_b.alloc(T * 8)); HIP_TRY(fr_b.alloc(T * sizeof(Fr)));
+    if (!d_output) { HIP_TRY(out_b.alloc(T * 4)); d_output = out_b.as<int32_t>(); }
+    {
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        size_t gb = (T + 255) / 256; if (gb > 4096) gb = 4096;
+        k_addsub_witness<<<(unsigned)gb, 256, 0, g.stream>>>(d_left, d_right, T, subtract ? 1 : 0, acc_b.as<int64_t>(), d_output, idx_b.as<uint64_t>());
+        k_i64_to_fr<<<(unsigned)gb, 256, 0, g.stream>>>(acc_b.as<int64_t>(), fr_b.as<Fr>(), T);
+    }
+    int rc = ATLAS_OK;
+    atlas_poly_t p_acc = nullptr, p_out = nullptr, p_l = nullptr, p_r = nullptr;
+    H::Fr acc_claim, out_claim, l_claim, r_claim;
+    rc = atlas_poly_wrap_device_fr(fr_b.p, T, &p_acc);
+    if (!rc) rc = atlas_poly_evaluate(p_acc, r_node_output, log_T, (atlas_fr_t*)&acc_claim);
+    if (!rc) {
+        if (output_claim) std::memcpy(&out_claim, output_claim, 32);
+        else { rc = atlas_poly_wrap_device_i32(d_output, T, &p_out); if (!rc) rc = atlas_poly_evaluate(p_out, r_node_output, log_T, (atlas_fr_t*)&out_claim); }
+    }
+    if (!rc) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(d_left), T, &p_l);
+    if (!rc) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(d_right), T, &p_r);
+    if (!rc) rc = atlas_poly_evaluate(p_l, r_node_output, log_T, (atlas_fr_t*)&l_claim);
+    if (!rc) rc = atlas_poly_evaluate(p_r, r_node_output, log_T, (atlas_fr_t*)&r_claim);
+    for (atlas_poly_t p : {p_acc, p_out, p_l, p_r}) if (p) atlas_poly_free(p);
+    if (stage_ms) stage_ms[0] = ms_since(t0);
+    if (rc) return rc;
+
+    t0 = now();
+    H::tr_append_scalar(Tr, acc_claim); rc = O.put_claim(acc_claim);             // append_raf_claims_prover
+    const H::Fr gamma = H::tr_challenge_scalar(Tr);                              // ps_read_raf_prover (unary.rs:112)
+    atlas_instance_t exec = nullptr;
+    if (!rc) rc = atlas_ps_shout_clamp_new(idx_b.as<uint64_t>(), log_T, 64, 31, 1, r_node_output, (const atlas_fr_t*)&gamma, &exec);
+    const H::Fr exec_claim = H::add(out_claim, H::mul(gamma, acc_claim));
+    std::vector<atlas_u128_t> ch;
+    H::Fr ra_claim;
+    if (!rc) rc = prove_single(exec, exec_claim, t, O, ch, &ra_claim);
+    if (exec) atlas_instance_free(exec);
+    std::vector<atlas_fr_t> ra_point(64 + log_T);
+    if (!rc) {
+        for (size_t i = 0; i < 64; i++) { const H::Fr f = H::challenge_to_fr(ch[i].lo, ch[i].hi, g.challenge_mode); std::memcpy(&ra_point[i], &f, 32); }
+        for (size_t i = 0; i < log_T; i++) { const H::Fr f = H::challenge_to_fr(ch[64 + log_T - 1 - i].lo, ch[64 + log_T - 1 - i].hi, g.challenge_mode); std::memcpy(&ra_point[64 + i], &f, 32); }
+    }
+    if (stage_ms) stage_ms[1] = ms_since(t0);
+    t0 = now();
+    if (!rc) rc = prove_onehot_checks(idx_b.as<uint64_t>(), log_T, 64, r_node_output, ra_point, ra_claim, t, O);
+    if (!rc) { H::tr_append_scalar(Tr, l_claim); rc = O.put_claim(l_claim); }    // operand tie (add.rs:95-102)
+    if (!rc) { H::tr_append_scalar(Tr, r_claim); rc = O.put_claim(r_claim); }
+    if (stage_ms) stage_ms[2] = ms_since(t0);
     if (rc) return rc;
     *proofs_len = O.len; *n_claims = O.n_claims;
     return ATLAS_OK;

@@ -54,3 +54,27 @@ def prove_mul_node(tL, tR, log_T, scale_bits, r_node_output, transcript, output_
     for i in range(5):
         out.append(raw[o:o + lens[i]]); o += lens[i]
     return out, claims[:nc.value].copy(), np.array(list(st))
+
+
+def _node_call(fn, args_head, n_proofs, n_stages, r_node_output, transcript, output_claim):
+    rn = np.ascontiguousarray(r_node_output, dtype=np.uint64)
+    cap = 1 << 20
+    buf = (C.c_uint8 * cap)(); ln = C.c_size_t(); lens = (C.c_size_t * n_proofs)()
+    claims = np.zeros((256, 4), dtype=np.uint64); nc = C.c_size_t(); st = (C.c_double * n_stages)()
+    oc = _p(_fr(output_claim)) if output_claim is not None else None
+    _check(fn(*args_head, _p(rn), oc, C.byref(transcript.t), buf, C.c_size_t(cap), C.byref(ln), lens, _p(claims), C.c_size_t(256), C.byref(nc), None, st))
+    raw = bytes(buf[:ln.value])
+    out, o = [], 0
+    for i in range(n_proofs):
+        out.append(raw[o:o + lens[i]]); o += lens[i]
+    return out, claims[:nc.value].copy(), np.array(list(st))
+
+
+def prove_square_node(tX, log_T, scale_bits, r_node_output, transcript, output_claim=None):
+    """Square::prove (fused rescale) for one node: 5 proofs."""
+    return _node_call(lib.atlas_prove_square_node, (tX.d, C.c_size_t(log_T), C.c_uint32(scale_bits)), 5, 6, r_node_output, transcript, output_claim)
+
+
+def prove_addsub_node(tL, tR, log_T, subtract, r_node_output, transcript, output_claim=None):
+    """Add::prove / Sub::prove for one node: 2 proofs (clamp lookup, one-hot checks) + the operand tie."""
+    return _node_call(lib.atlas_prove_addsub_node, (tL.d, tR.d, C.c_size_t(log_T), C.c_int(1 if subtract else 0)), 2, 3, r_node_output, transcript, output_claim)

@@ -264,3 +264,75 @@ def test_mul_node_matches_oracle_composition(atlas, log_T, S):
     assert np.array_equal(claims_g, np.stack(claims))
     assert t_g.state == t.state_bytes()
     tL.free(); tR.free()
+
+
+@pytest.mark.parametrize("log_T,S", [(4, 6), (7, 5)])
+def test_square_node_matches_oracle_composition(atlas, log_T, S):
+    """Square::prove with fused rescaling (ops/square.rs): SquareProver between prove_pre and prove_remainder_rc, one operand claim."""
+    from oracle import orc, orc_ra as OR, orc_batched as OB
+    from jolt_atlas_amd import node
+    T = 1 << log_T
+    x = np.random.default_rng(200 + log_T).integers(-(1 << 10), 1 << 10, size=T, dtype=np.int64).astype(np.int32)
+    acc = x.astype(np.int64) * x.astype(np.int64)
+    r0 = orc.random_fr(log_T, 56)
+    f = lambda v: orc.from_ints([int(z) % FR for z in v])
+
+    def inner(t, in_claim, claims):
+        o = OR.elementwise(3, [f(x)], r0)                            # ATLAS_EW_SQUARE
+        rows, _ch = o.prove(in_claim, t)
+        c = o.finals()[0]
+        _append(orc, t, c); claims.append(c)
+        return rows
+
+    rows5, claims, t = _fused_rescale_oracle(orc, OR, OB, b"square_node", acc, S, r0, inner)
+    tX = atlas.TensorI32(x)
+    t_g = atlas.Blake2bTranscript(b"square_node")
+    proofs, claims_g, _ = node.prove_square_node(tX, log_T, S, r0, t_g)
+    for i, (a, rows) in enumerate(zip(proofs, rows5)):
+        assert a == _ser(orc, rows), f"proof {i} differs"
+    assert np.array_equal(claims_g, np.stack(claims))
+    assert t_g.state == t.state_bytes()
+    tX.free()
+
+
+@pytest.mark.parametrize("subtract", [False, True])
+@pytest.mark.parametrize("log_T", [3, 7])
+def test_addsub_node_matches_oracle_composition(atlas, log_T, subtract):
+    """Add::prove / Sub::prove (ops/add.rs:70-105): prove_clamp_lookup over left +- right, then the operand tie; the extremes
+    of the i32 range make the saturating clamp bite."""
+    from oracle import orc, orc_ra as OR, orc_batched as OB
+    from jolt_atlas_amd import node
+    T = 1 << log_T
+    rng = np.random.default_rng(300 + log_T)
+    L = rng.integers(-(1 << 20), 1 << 20, size=T, dtype=np.int64).astype(np.int32)
+    R = rng.integers(-(1 << 20), 1 << 20, size=T, dtype=np.int64).astype(np.int32)
+    L[0], R[0] = (1 << 31) - 1, ((1 << 31) - 1) * (-1 if subtract else 1)          # overflows upwards
+    L[1], R[1] = -(1 << 31), (1 << 31) - 1 if subtract else -(1 << 31)              # overflows downwards
+    acc = L.astype(np.int64) - R.astype(np.int64) if subtract else L.astype(np.int64) + R.astype(np.int64)
+    outv = np.clip(acc, -(1 << 31), (1 << 31) - 1)
+    assert (outv != acc).any()
+    r0 = orc.random_fr(log_T, 57)
+    f = lambda v: orc.from_ints([int(z) % FR for z in v])
+    acc_claim, out_claim = orc.evaluate(f(acc), r0), orc.evaluate(f(outv), r0)
+    claims = []
+    label = b"sub_node" if subtract else b"add_node"
+    t = orc.new_transcript(label)
+    _append(orc, t, acc_claim); claims.append(acc_claim)
+    gamma = _challenge_scalar(orc, t)
+    cidx = acc.astype(np.int64).view(np.uint64).copy()
+    exec_claim = orc.fr_add_arr(out_claim, orc.fr_mul_arr(gamma, acc_claim))
+    rows_exec, ch = OR.ps_clamp(cidx, 64, 31, True, r0, gamma).prove(exec_claim, t)
+    rs = orc.challenges_to_fr(ch)
+    ra_point = np.concatenate([rs[:64], rs[64:][::-1]])
+    ra_claim = orc.evaluate(np.stack([_eq_bits(orc, ra_point[:64], v, 64) for v in cidx]), np.ascontiguousarray(ra_point[64:]))
+    _append(orc, t, ra_claim); claims.append(ra_claim)
+    rows_oh = _onehot_checks(orc, OR, OB, t, cidx, log_T, 64, r0, ra_point, ra_claim, claims)
+    for c in (orc.evaluate(f(L), r0), orc.evaluate(f(R), r0)):
+        _append(orc, t, c); claims.append(c)
+    tL, tR = atlas.TensorI32(L), atlas.TensorI32(R)
+    t_g = atlas.Blake2bTranscript(label)
+    proofs, claims_g, _ = node.prove_addsub_node(tL, tR, log_T, subtract, r0, t_g)
+    assert proofs[0] == _ser(orc, rows_exec) and proofs[1] == _ser(orc, rows_oh)
+    assert np.array_equal(claims_g, np.stack(claims))
+    assert t_g.state == t.state_bytes()
+    tL.free(); tR.free()
