@@ -18,7 +18,7 @@ struct Channel {
     static constexpr size_t MAIL_CHUNKS = (size_t)1 << 19;  // 8 MB of mail, handed out round-robin (alloc): a launch's
                                                             // records are consumed before the allocator comes round again,
                                                             // because later rounds cannot run until the host has read them
-    static constexpr size_t RING = 256;                     // challenge slots (a sumcheck has at most 64 rounds)
+    static constexpr size_t RING = 256;                     // challenge slots (a proof takes one per round: <= 89 for the 64-bit clamp lookup at T = 2^25)
     static constexpr size_t SLOT_CHUNKS = 4;                                                   // host slot: one line
     static constexpr size_t DEV_SLOT_CHUNKS = atlas::CH_MAX_REPLICAS * atlas::CH_REPLICA_CHUNKS;   // 256 HBM replicas of one line
     atlas::Chunk* mail = nullptr;       // pinned
