@@ -300,11 +300,18 @@ int atlas_instance_prove(atlas_instance_t inst, const atlas_fr_t* input_claim, a
         P.lanes.push_back(Lane{inst, n, 0, {}, {}});
         int rc = P.begin();
         if (rc) return rc;
+        static const bool ptrace = getenv("ATLAS_TRACE") != nullptr;   // host time per part of a round, summed (ATLAS_TRACE=1)
+        double tp[5] = {0, 0, 0, 0, 0};
+        auto nowp = [] { return std::chrono::steady_clock::now(); };
+        auto usp = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
         for (size_t round = 0; round < n; round++) {
             H::Fr sums[16];
+            const auto q0 = nowp();
             inst->prepare(round);
             if (!P.collect(P.lanes[0].mails[round], P.mtag(round, 0), sums)) { P.abort_from(round); (void)hipStreamSynchronize(g.stream); return fail(ATLAS_ENODEV, "round channel: no answer from the device"); }
+            const auto q1 = nowp();
             rc = inst->finish(round, prev, sums, c);
+            const auto q2 = nowp();
             if (rc) { P.abort_from(round); (void)hipStreamSynchronize(g.stream); return rc; }
             std::vector<H::Fr> cc;
             if (c.size() < 2) cc = c;
@@ -321,10 +328,16 @@ int atlas_instance_prove(atlas_instance_t inst, const atlas_fr_t* input_claim, a
             P.C.publish(P.slot0 + round, P.rtag(round), lo, hi);
             if ((round & 7) == 7) (void)hipStreamQuery(g.stream);   // lets the runtime retire completed launches while the device works (2.5 us)
             prev = eval_with_challenge(c, H::challenge_to_fr(lo, hi, g.challenge_mode));
+            const auto q3 = nowp();
             rc = inst->host_ingest(challenges[round], round);
+            const auto q4 = nowp();
             if (!rc) rc = P.advance(round + 1);
             if (rc) { P.abort_from(round + 1); (void)hipStreamSynchronize(g.stream); return rc; }
+            if (ptrace) { const auto q5 = nowp(); tp[0] += usp(q0, q1); tp[1] += usp(q1, q2); tp[2] += usp(q2, q3); tp[3] += usp(q3, q4); tp[4] += usp(q4, q5); }
         }
+        if (ptrace)
+            fprintf(stderr, "[atlas trace] instance_prove (round channel) %zu rounds: wait for sums %.1f us, finish %.1f, transcript + publish %.1f, host_ingest %.1f, enqueue %.1f\n",
+                    n, tp[0], tp[1], tp[2], tp[3], tp[4]);
         return P.collect_finals();
     }
     const bool trace = getenv("ATLAS_TRACE") != nullptr;          // wall clock of the three parts of a round, summed

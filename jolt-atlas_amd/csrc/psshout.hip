@@ -67,10 +67,13 @@ __device__ __forceinline__ void ps_entry_vals(uint64_t k, const Fr& u, uint32_t 
 // (Summing such lanes across the wavefront first with 64-bit shuffles was slower than the conflicts: 48 x 6 shuffles.)  (A
 // tiled variant in which every thread scanned its tile's entries for its bin took 168 us per phase at T = 2^16, NQ = 6,
 // m = 256.)  The accumulators are NQ * m * 64 bytes of dynamic LDS (96 KB for the clamp lookup).
+// v_prev != null: the finished phase's expanding table is folded into the products first (k_ps_scale fused: every lookup
+// is visited by exactly one thread), prod[t] *= v_prev[(idx_t >> shift_prev) & (m - 1)].
 template <int NQ>
 __global__ __launch_bounds__(RA_THREADS) void k_ps_q_lds(const uint64_t* __restrict__ idx, const Fr* __restrict__ u0,
-                                                         const Fr* __restrict__ prod, size_t T, uint32_t suffix_len, uint32_t m,
-                                                         uint32_t bound, unsigned long long* __restrict__ acc /* [gridDim.x][m][NQ][8] */) {
+                                                         Fr* __restrict__ prod, size_t T, uint32_t suffix_len, uint32_t m,
+                                                         uint32_t bound, unsigned long long* __restrict__ acc /* [gridDim.x][m][NQ][8] */,
+                                                         const Fr* __restrict__ v_prev, uint32_t shift_prev) {
     extern __shared__ unsigned long long ps_sm[];
     const uint32_t n_words = m * NQ * 8;
     for (uint32_t w = threadIdx.x; w < n_words; w += RA_THREADS) ps_sm[w] = 0;
@@ -78,8 +81,10 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_q_lds(const uint64_t* __restr
     for (size_t t = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; t < T; t += (size_t)gridDim.x * RA_THREADS) {
         const uint64_t k = idx[t];
         const uint32_t b = (uint32_t)(k >> suffix_len) & (m - 1);
+        Fr pr = fe_load(prod + t);
+        if (v_prev) { pr = fr_mul(pr, fe_load(v_prev + ((uint32_t)(k >> shift_prev) & (m - 1)))); fe_store(prod + t, pr); }
         Fr val[NQ];
-        ps_entry_vals<NQ>(k, fr_mul(fe_load(u0 + t), fe_load(prod + t)), suffix_len, bound, val);
+        ps_entry_vals<NQ>(k, fr_mul(fe_load(u0 + t), pr), suffix_len, bound, val);
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
             if (fe_is_zero(val[q])) continue;
@@ -95,7 +100,11 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_q_lds(const uint64_t* __restr
 
 // word sums -> canonical Montgomery residues: V = lo + hi 2^256, V mod p = lo * R * R^-1 + hi * R^2 * R^-1
 // A workgroup takes 4 values (32 words): thread (word, part) adds every 8th slab, the 8 parts meet in LDS.
-__global__ __launch_bounds__(RA_THREADS) void k_ps_q_final(const unsigned long long* __restrict__ acc, uint32_t n_slabs, uint32_t n_vals, Fr* __restrict__ out) {
+// pub.host_dst != null: the residues also go to pinned host memory and the last workgroup to arrive writes the tag the
+// host waits for (k_ps_q_publish fused; pub.counter is zero on entry and left zero).
+struct QPublish { Fr* host_dst; Chunk* tag_chunk; uint32_t tag; uint32_t* counter; };
+__global__ __launch_bounds__(RA_THREADS) void k_ps_q_final(const unsigned long long* __restrict__ acc, uint32_t n_slabs, uint32_t n_vals, Fr* __restrict__ out,
+                                                           QPublish pub) {
     __shared__ unsigned long long sm[8][32];
     const uint32_t word = threadIdx.x & 31u, part = threadIdx.x >> 5;
     const size_t n_words = (size_t)n_vals * 8, widx = (size_t)blockIdx.x * 32 + word;
@@ -105,21 +114,35 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_q_final(const unsigned long l
     sm[part][word] = sum;
     __syncthreads();
     const uint32_t i = blockIdx.x * 4 + threadIdx.x;
-    if (threadIdx.x >= 4 || i >= n_vals) return;
-    Fr lo, hi, r2;
-    unsigned long long c = 0;
+    if (threadIdx.x < 4 && i < n_vals) {
+        Fr lo, hi, r2;
+        unsigned long long c = 0;
 #pragma unroll
-    for (int w = 0; w < 8; w++) {
-        unsigned long long s = c;
+        for (int w = 0; w < 8; w++) {
+            unsigned long long s = c;
 #pragma unroll
-        for (int p2 = 0; p2 < 8; p2++) s += sm[p2][threadIdx.x * 8 + w];
-        lo.v[w] = (uint32_t)s;
-        c = s >> 32;
+            for (int p2 = 0; p2 < 8; p2++) s += sm[p2][threadIdx.x * 8 + w];
+            lo.v[w] = (uint32_t)s;
+            c = s >> 32;
+        }
+#pragma unroll
+        for (int w = 0; w < 8; w++) { hi.v[w] = 0; r2.v[w] = FrParams::r2(w); }
+        hi.v[0] = (uint32_t)c; hi.v[1] = (uint32_t)(c >> 32);
+        const Fr res = fr_add(fr_mul(lo, fr_one()), fr_mul(hi, r2));
+        fe_store(out + i, res);
+        if (pub.host_dst) fe_store(pub.host_dst + i, res);
     }
-#pragma unroll
-    for (int w = 0; w < 8; w++) { hi.v[w] = 0; r2.v[w] = FrParams::r2(w); }
-    hi.v[0] = (uint32_t)c; hi.v[1] = (uint32_t)(c >> 32);
-    fe_store(out + i, fr_add(fr_mul(lo, fr_one()), fr_mul(hi, r2)));
+    if (!pub.host_dst) return;
+    __threadfence_system();                            // this workgroup's values are in host memory before it is counted
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = atomicAdd(pub.counter, 1u);
+        if (t == gridDim.x - 1) {
+            *pub.counter = 0;
+            __threadfence_system();
+            ch_store_sys(pub.tag_chunk, ch_u32x4{n_vals, 0u, 0u, pub.tag});
+        }
+    }
 }
 
 // m > 256: one workgroup per (bin, slice of T), each filtering its slice for its bin
@@ -167,12 +190,31 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_fill_one(Fr* p, size_t T) {
 }
 
 // sum_j E_out E_in ra[2 j]   (mod.rs:463-484)
-__global__ __launch_bounds__(RA_THREADS) void k_ps_fold(const Fr* __restrict__ ra, SplitEqView E, size_t n_groups, Fr* __restrict__ partials) {
+__global__ __launch_bounds__(RA_THREADS) void k_ps_fold(const Fr* __restrict__ ra, SplitEqView E, size_t n_groups, Fr* __restrict__ partials, MailTail tail) {
     Fr acc[1];
     acc[0] = fe_zero();
     for (size_t j = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; j < n_groups; j += (size_t)gridDim.x * RA_THREADS)
         acc[0] = fr_add(acc[0], fr_mul(gse_weight(E, j), fe_load(ra + 2 * j)));
     block_reduce_store<1>(acc, partials);
+    mail_tail(partials, tail);
+}
+// a cycle round in ONE launch: wait for the challenge, bind ra (src of 4 n_groups values -> dst of 2 n_groups), fold the
+// bound pairs, and the last workgroup mails the sum.  (Three launches per round cost the host thread ~10 us of enqueue.)
+__global__ __launch_bounds__(RA_THREADS) void k_ps_bind_fold_ch(const Fr* __restrict__ src, Fr* __restrict__ dst, SplitEqView E, size_t n_groups,
+                                                               Fr* __restrict__ partials, ChanIo io, int hi_only, MailTail tail) {
+    Fr r;
+    if (!io.challenge(r)) return;
+    Fr acc[1];
+    acc[0] = fe_zero();
+    for (size_t j = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; j < n_groups; j += (size_t)gridDim.x * RA_THREADS) {
+        const Fr b0 = bind_pair(fe_load(src + 4 * j), fe_load(src + 4 * j + 1), r, hi_only != 0);
+        const Fr b1 = bind_pair(fe_load(src + 4 * j + 2), fe_load(src + 4 * j + 3), r, hi_only != 0);
+        fe_store(dst + 2 * j, b0);
+        fe_store(dst + 2 * j + 1, b1);
+        acc[0] = fr_add(acc[0], fr_mul(gse_weight(E, j), b0));
+    }
+    block_reduce_store<1>(acc, partials);
+    mail_tail(partials, tail);
 }
 
 // ---- round-channel pieces (instance.hpp): the expanding table v of a phase is kept on the device, one challenge at a
@@ -212,8 +254,8 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_expand_all_ch(Fr* buf0, Fr* b
         __syncthreads();
     }
 }
-// the Q tables of a phase -> pinned host memory, then one tagged chunk: a host that sees the tag sees the tables
-__global__ __launch_bounds__(RA_THREADS) void k_ps_q_publish(const Fr* __restrict__ qsum, uint32_t n_vals, Fr* host_dst, Chunk* tag_chunk, uint32_t tag) {
+// m > 256 (k_ps_q + k_col_reduce): the tables copied to pinned host memory by one workgroup, then the tag
+__global__ __launch_bounds__(RA_THREADS) void k_ps_q_copy_out(const Fr* __restrict__ qsum, uint32_t n_vals, Fr* host_dst, Chunk* tag_chunk, uint32_t tag) {
     for (uint32_t i = threadIdx.x; i < n_vals; i += RA_THREADS) fe_store(host_dst + i, fe_load(qsum + i));
     __threadfence_system();
     __syncthreads();
@@ -273,7 +315,9 @@ struct PsLookup : atlas_instance {
         Q.assign(NQ, std::vector<H::Fr>(m));
         for (size_t y = 0; y < m; y++) for (size_t k = 0; k < NQ; k++) Q[k][y] = q[NQ * y + k];
     }
-    int launch_Q(size_t phase) {          // the launches only: the tables end up at qsum_ptr()
+    // the launches only: the tables end up at qsum_ptr().  v_prev: fold the finished phase's table into the products on the way
+    // (m <= 256); pub: also publish the tables to the host
+    int launch_Q(size_t phase, const Fr* v_prev = nullptr, uint32_t shift_prev = 0, QPublish pub = QPublish{nullptr, nullptr, 0, nullptr}) {
         const uint32_t suffix_len = (uint32_t)((phases - 1 - phase) * log_m);
         const size_t NQ = nq();
         Fr* d_qsum = qsum_ptr();
@@ -285,20 +329,22 @@ struct PsLookup : atlas_instance {
             do {                                                                                                                   \
                 static bool attr_set = false;                                                                                      \
                 if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ps_q_lds<NQv>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * NQv * 64)); attr_set = true; } \
-                k_ps_q_lds<NQv><<<(unsigned)gb, RA_THREADS, lds, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)m, (uint32_t)(BND), acc); \
+                k_ps_q_lds<NQv><<<(unsigned)gb, RA_THREADS, lds, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)m, (uint32_t)(BND), acc, v_prev, shift_prev); \
             } while (0)
             if (NQ == 4) PS_Q_LDS(4, 0u);
             else if (NQ == 6) PS_Q_LDS(6, bound);
             else if (NQ == 3) PS_Q_LDS(3, bound);
             else PS_Q_LDS(2, 0u);
 #undef PS_Q_LDS
-            k_ps_q_final<<<(unsigned)((NQ * m + 3) / 4), RA_THREADS, 0, g.stream>>>(acc, (uint32_t)gb, (uint32_t)(NQ * m), d_qsum);
+            k_ps_q_final<<<(unsigned)((NQ * m + 3) / 4), RA_THREADS, 0, g.stream>>>(acc, (uint32_t)gb, (uint32_t)(NQ * m), d_qsum, pub);
         } else {
+            if (v_prev) { size_t gs = (T + RA_THREADS - 1) / RA_THREADS; if (gs > 4096) gs = 4096; k_ps_scale<<<(unsigned)gs, RA_THREADS, 0, g.stream>>>(d_idx, v_prev, T, shift_prev, (uint32_t)(m - 1), rows.buf[0]); }
             if (NQ == 4) k_ps_q<4><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), 0u, d_qpart);
             else if (NQ == 6) k_ps_q<6><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), (uint32_t)bound, d_qpart);
             else if (NQ == 3) k_ps_q<3><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), (uint32_t)bound, d_qpart);
             else k_ps_q<2><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), 0u, d_qpart);
             k_col_reduce<<<(unsigned)(NQ * m), RA_THREADS, 0, g.stream>>>(d_qpart, SLICES, (uint32_t)(NQ * m), d_qsum);
+            if (pub.host_dst) k_ps_q_copy_out<<<1, RA_THREADS, 0, g.stream>>>(d_qsum, (uint32_t)(NQ * m), pub.host_dst, pub.tag_chunk, pub.tag);
         }
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) return fail(ATLAS_ENODEV, "ps_shout: Q launch", le);
@@ -312,7 +358,7 @@ struct PsLookup : atlas_instance {
         std::lock_guard<atlas_rt::Mutex> lk(g.mu);
         const size_t n_groups = rows.len / 2;
         size_t blocks = (n_groups + RA_THREADS - 1) / RA_THREADS; if (blocks > 2048) blocks = 2048;
-        k_ps_fold<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(rows.buf[rows.cur], eq.view(), n_groups, rows.partials);
+        k_ps_fold<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(rows.buf[rows.cur], eq.view(), n_groups, rows.partials, MailTail{{}, nullptr, 0, 0});
         H::Fr s;
         int rc = rows.reduce_to_host((uint32_t)blocks, 1, &s);
         if (rc) return rc;
@@ -546,28 +592,26 @@ struct PsLookup : atlas_instance {
             const size_t p_done = round / log_m - 1;
             slots.n = (uint32_t)log_m; slots.abort_flag = io.abort_flag; slots.challenge_mode = g.challenge_mode;
             k_ps_expand_all_ch<<<1, RA_THREADS, 0, g.stream>>>(vt[0], vt[1], slots);
-            k_ps_scale<<<(unsigned)gbT, RA_THREADS, 0, g.stream>>>(d_idx, vt[log_m & 1], T, (uint32_t)((phases - 1 - p_done) * log_m), (uint32_t)(m - 1), rows.buf[0]);
-            if (round < N) {                                   // ... and build the Q of the phase that starts
+            const uint32_t shift_done = (uint32_t)((phases - 1 - p_done) * log_m);
+            if (round < N) {                                   // ... folded into the products while the Q of the phase that starts is built
                 const size_t p = round / log_m, n_vals = nq() * m;
-                int rc = launch_Q(p);
-                if (rc) return rc;
                 atlas::Chunk* box = g.chan.alloc(2 * n_vals + 4);
-                k_ps_q_publish<<<1, RA_THREADS, 0, g.stream>>>(qsum_ptr(), (uint32_t)n_vals, reinterpret_cast<Fr*>(box + 4), box, io.tag_mail);
+                int rc = launch_Q(p, vt[log_m & 1], shift_done, QPublish{reinterpret_cast<Fr*>(box + 4), box, io.tag_mail, rows.d_counter});
+                if (rc) return rc;
                 qbox[p] = QBox{box, reinterpret_cast<const H::Fr*>(box + 4), io.tag_mail};
+            } else {
+                k_ps_scale<<<(unsigned)gbT, RA_THREADS, 0, g.stream>>>(d_idx, vt[log_m & 1], T, shift_done, (uint32_t)(m - 1), rows.buf[0]);
             }
         }
         if (round >= N) {
             const size_t c = round - N, len = T >> c, n_groups = len / 2;
-            if (c > 0) {
-                size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
-                k_ra_bind_ch<<<dim3((unsigned)gb, 1u), RA_THREADS, 0, g.stream>>>(rows.buf[(c - 1) & 1], T >> (c - 1), rows.buf[c & 1], len, len, cio,
-                                                                                g.challenge_mode == 0 ? 1 : 0);
-            }
             size_t blocks = (n_groups + RA_THREADS - 1) / RA_THREADS; if (blocks > 2048) blocks = 2048;
             size_t ot, it;
             eq.st.tops_after(c, ot, it);
-            k_ps_fold<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(rows.buf[c & 1], eq.view_at(ot, it), n_groups, rows.partials);
-            k_col_reduce_mail<<<1, RA_THREADS, 0, g.stream>>>(rows.partials, (uint32_t)blocks, 1u, io);
+            const MailTail tail{io, rows.d_counter, (uint32_t)blocks, 1u};
+            if (c == 0) k_ps_fold<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(rows.buf[0], eq.view_at(ot, it), n_groups, rows.partials, tail);
+            else k_ps_bind_fold_ch<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(rows.buf[(c - 1) & 1], rows.buf[c & 1], eq.view_at(ot, it), n_groups, rows.partials, cio,
+                                                                              g.challenge_mode == 0 ? 1 : 0, tail);
             mail.blocks = 1; mail.n_vals = 1;
         }
         hipError_t e = hipGetLastError();
