@@ -660,6 +660,12 @@ int atlas_prove_mul_node(const int32_t *d_left, const int32_t *d_right, size_t l
                          uint8_t *proofs, size_t cap, size_t *proofs_len, size_t proof_lens[5], atlas_fr_t *claims,
                          size_t claims_cap, size_t *n_claims, int32_t *d_output, double *stage_ms);
 
+/* The operators proved by one sumcheck (impl_standard_sumcheck_proof_api, ops/mod.rs:505-560): op = ATLAS_EW_MUL for And
+ * (ops/and.rs: MulProver without rescaling, 2 operands) or ATLAS_EW_IFF (ops/iff.rs, 3 operands: mask, a, b).  output_claim =
+ * the node-output opening claim (the sumcheck's input claim).  One proof; claims: the operand claims in input order. */
+int atlas_prove_standard_node(int op, const int32_t *const *d_operands, size_t n_operands, size_t log_T, const atlas_fr_t *r_node_output,
+                              const atlas_fr_t *output_claim, atlas_transcript_t *transcript, uint8_t *proofs, size_t cap,
+                              size_t *proofs_len, size_t proof_lens[1], atlas_fr_t *claims, size_t claims_cap, size_t *n_claims);
 /* Square::prove with fused rescaling (ops/square.rs): out = (x * x) >> scale_bits; as atlas_prove_mul_node with one operand. */
 int atlas_prove_square_node(const int32_t *d_input, size_t log_T, uint32_t scale_bits, const atlas_fr_t *r_node_output,
                             const atlas_fr_t *output_claim, atlas_transcript_t *transcript, uint8_t *proofs, size_t cap,

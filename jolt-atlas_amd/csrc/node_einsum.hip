@@ -432,6 +432,48 @@ extern "C" int atlas_prove_square_node(const int32_t* d_input, size_t log_T, uin
                                claims_cap, n_claims, d_output, stage_ms);
 }
 
+// The operators proved by one sumcheck and nothing else (impl_standard_sumcheck_proof_api, ops/mod.rs:505-560: And = MulProver
+// without rescaling, Iff): Sumcheck::prove over the operator's element-wise prover with the node-output opening claim as the
+// input claim, then cache_openings = the operand claims in input order.  op: ATLAS_EW_MUL (And) or ATLAS_EW_IFF; operands:
+// n_operands device tensors of 2^log_T i32.  One proof (Execution); claims: one per operand.
+extern "C" int atlas_prove_standard_node(int op, const int32_t* const* d_operands, size_t n_operands, size_t log_T, const atlas_fr_t* r_node_output,
+                                         const atlas_fr_t* output_claim, atlas_transcript_t* t, uint8_t* proofs, size_t cap, size_t* proofs_len,
+                                         size_t proof_lens[1], atlas_fr_t* claims, size_t claims_cap, size_t* n_claims) {
+    NEED_INIT();
+    if (!d_operands || !r_node_output || !output_claim || !t || !proofs || !proofs_len || !proof_lens || !claims || !n_claims)
+        return fail(ATLAS_EINVAL, "prove_standard_node: null argument");
+    if ((op != ATLAS_EW_MUL && op != ATLAS_EW_IFF) || n_operands != (op == ATLAS_EW_IFF ? 3u : 2u))
+        return fail(ATLAS_EINVAL, "prove_standard_node: op must be ATLAS_EW_MUL (And: 2 operands) or ATLAS_EW_IFF (3 operands)");
+    if (log_T == 0 || log_T > 25) return fail(ATLAS_EINVAL, "prove_standard_node: 1 <= log_T <= 25");
+    const size_t T = (size_t)1 << log_T;
+    Out O{proofs, cap, 0, proof_lens, 0, claims, claims_cap, 0};
+    atlas_poly_t ops[3] = {nullptr, nullptr, nullptr};
+    int rc = ATLAS_OK;
+    for (size_t i = 0; i < n_operands && !rc; i++) {
+        if (!d_operands[i]) rc = fail(ATLAS_EINVAL, "prove_standard_node: null operand");
+        else rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(d_operands[i]), T, &ops[i]);          // read-only views
+    }
+    atlas_instance_t inst = nullptr;
+    if (!rc) rc = atlas_elementwise_new(op, ops, n_operands, r_node_output, log_T, nullptr, 0, &inst);
+    for (atlas_poly_t p : ops) if (p) atlas_poly_free(p);
+    const size_t stride = 4;
+    std::vector<atlas_fr_t> rows(log_T * stride);
+    std::vector<uint32_t> nco(log_T);
+    std::vector<atlas_u128_t> ch(log_T);
+    if (!rc) rc = atlas_instance_prove(inst, output_claim, t, rows.data(), stride, nco.data(), ch.data());
+    atlas_fr_t fin[8]; size_t nf = 0;
+    if (!rc) rc = atlas_instance_final_claims(inst, fin, 8, &nf);
+    for (size_t q = 0; q < n_operands && !rc; q++) {                              // append_nodeio(Input(q))  (mul.rs:188-199, iff.rs:228-241)
+        rc = atlas_transcript_append_scalar(t, &fin[q]);
+        if (!rc) rc = O.put_claim(*reinterpret_cast<H::Fr*>(&fin[q]));
+    }
+    if (!rc) rc = O.put_proof(rows, stride, nco, log_T);
+    if (inst) atlas_instance_free(inst);
+    if (rc) return rc;
+    *proofs_len = O.len; *n_claims = O.n_claims;
+    return ATLAS_OK;
+}
+
 // Add::prove / Sub::prove (ops/add.rs:70-105, ops/sub.rs): no sumcheck of their own — prove_clamp_lookup (clamp_lookups/mod.rs:264-309:
 // the i64 accumulation left +- right appended as the lookup's raf, gamma, PS-Shout over SaturationTable, its ra opening, the
 // one-hot checks), then the operand tie: left(r), right(r) appended in input order.  Two proofs (Execution, RaOneHotChecks);

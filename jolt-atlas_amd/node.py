@@ -78,3 +78,15 @@ def prove_square_node(tX, log_T, scale_bits, r_node_output, transcript, output_c
 def prove_addsub_node(tL, tR, log_T, subtract, r_node_output, transcript, output_claim=None):
     """Add::prove / Sub::prove for one node: 2 proofs (clamp lookup, one-hot checks) + the operand tie."""
     return _node_call(lib.atlas_prove_addsub_node, (tL.d, tR.d, C.c_size_t(log_T), C.c_int(1 if subtract else 0)), 2, 3, r_node_output, transcript, output_claim)
+
+
+def prove_standard_node(op, tensors, log_T, r_node_output, output_claim, transcript):
+    """And (op = 5, ATLAS_EW_MUL) / Iff (op = 4) node: one sumcheck + the operand claims.  Returns (proof bytes, claims (c,4))."""
+    rn = np.ascontiguousarray(r_node_output, dtype=np.uint64)
+    ptrs = (C.c_void_p * len(tensors))(*[C.cast(t_.d, C.c_void_p) for t_ in tensors])
+    cap = 1 << 18
+    buf = (C.c_uint8 * cap)(); ln = C.c_size_t(); lens = (C.c_size_t * 1)()
+    claims = np.zeros((8, 4), dtype=np.uint64); nc = C.c_size_t()
+    _check(lib.atlas_prove_standard_node(C.c_int(op), ptrs, C.c_size_t(len(tensors)), C.c_size_t(log_T), _p(rn), _p(_fr(output_claim)), C.byref(transcript.t),
+                                         buf, C.c_size_t(cap), C.byref(ln), lens, _p(claims), C.c_size_t(8), C.byref(nc)))
+    return bytes(buf[:ln.value]), claims[:nc.value].copy()

@@ -336,3 +336,37 @@ def test_addsub_node_matches_oracle_composition(atlas, log_T, subtract):
     assert np.array_equal(claims_g, np.stack(claims))
     assert t_g.state == t.state_bytes()
     tL.free(); tR.free()
+
+
+@pytest.mark.parametrize("op,n_ops", [(5, 2), (4, 3)])
+@pytest.mark.parametrize("log_T", [3, 8])
+def test_standard_node_matches_oracle_composition(atlas, op, n_ops, log_T):
+    """And (MulProver without rescaling) / Iff through atlas_prove_standard_node: Sumcheck::prove with the node-output claim as
+    the input claim, then the operand claims in input order (impl_standard_sumcheck_proof_api, ops/mod.rs:505-560)."""
+    from oracle import orc, orc_ra as OR
+    from jolt_atlas_amd import node
+    T = 1 << log_T
+    rng = np.random.default_rng(400 + log_T + op)
+    f = lambda v: orc.from_ints([int(z) % FR for z in v])
+    if op == 4:
+        xs = [rng.integers(0, 2, size=T).astype(np.int32), rng.integers(-100, 100, size=T).astype(np.int32), rng.integers(-100, 100, size=T).astype(np.int32)]
+        outv = np.where(xs[0] != 0, xs[1], xs[2])
+    else:
+        xs = [rng.integers(0, 2, size=T).astype(np.int32), rng.integers(0, 2, size=T).astype(np.int32)]
+        outv = xs[0] * xs[1]
+    r0 = orc.random_fr(log_T, 58)
+    out_claim = orc.evaluate(f(outv), r0)
+    t = orc.new_transcript(b"std_node")
+    o = OR.elementwise(op, [f(x) for x in xs], r0)
+    rows, _ch = o.prove(out_claim, t)
+    claims = []
+    for c in o.finals()[:n_ops]:
+        _append(orc, t, c); claims.append(c)
+    tens = [atlas.TensorI32(x) for x in xs]
+    t_g = atlas.Blake2bTranscript(b"std_node")
+    proof, claims_g = node.prove_standard_node(op, tens, log_T, r0, out_claim, t_g)
+    assert proof == _ser(orc, rows)
+    assert np.array_equal(claims_g, np.stack(claims))
+    assert t_g.state == t.state_bytes()
+    for x in tens:
+        x.free()
