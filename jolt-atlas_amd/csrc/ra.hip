@@ -277,6 +277,22 @@ struct RaVirtual : atlas_instance {
     }
 };
 
+// F_i = EqPolynomial::evals(r_address chunk i) for d chunks of log_k <= 8 challenges, built on the device from the d log_k
+// challenges (carried as a kernel argument): thread (i, k) multiplies the log_k factors of entry k, variable 0 = most
+// significant bit of k (eq_poly.rs:77-101: big-endian).  Same residues as the host table (field arithmetic is exact).
+__global__ __launch_bounds__(RA_THREADS) void k_ra_eq_tables(FrArgs r, uint32_t d, uint32_t log_k, Fr* __restrict__ out /* [d][2^log_k] */) {
+    const uint32_t K = 1u << log_k;
+    for (uint32_t t = blockIdx.x * RA_THREADS + threadIdx.x; t < d * K; t += gridDim.x * RA_THREADS) {
+        const uint32_t i = t / K, k = t % K;
+        Fr acc = fr_one();
+        for (uint32_t b = 0; b < log_k; b++) {
+            const Fr x = r.v[i * log_k + b];
+            acc = fr_mul(acc, ((k >> (log_k - 1 - b)) & 1u) ? x : fr_sub(fr_one(), x));
+        }
+        fe_store(out + t, acc);
+    }
+}
+
 // upload d host tables of K Fr each
 int upload_tables(const std::vector<std::vector<H::Fr>>& t, size_t K, Fr** out) {
     Fr* d = nullptr;
@@ -563,11 +579,19 @@ static int ra_virtual_build(const int32_t* const* H_indices, const uint64_t* loo
     RaVirtual* P = new RaVirtual();
     P->log_T = log_T;
     const size_t K = (size_t)1 << log_k_chunk, T = (size_t)1 << log_T;
-    std::vector<std::vector<H::Fr>> tabs(d);
     const H::Fr* ch = reinterpret_cast<const H::Fr*>(r_address_chunks);
-    for (size_t i = 0; i < d; i++) tabs[i] = H::eq_evals(ch + i * log_k_chunk, log_k_chunk);   // ra_virtual.rs:113-116
     Fr* d_tabs = nullptr;
-    int rc = upload_tables(tabs, K, &d_tabs);
+    int rc = ATLAS_OK;
+    if (log_k_chunk <= 8 && d * log_k_chunk <= 64) {                 // ra_virtual.rs:113-116, on the device
+        HIP_TRY(hipMalloc(&d_tabs, d * K * sizeof(Fr)));
+        FrArgs a;
+        std::memcpy(a.v, ch, d * log_k_chunk * sizeof(Fr));
+        k_ra_eq_tables<<<(unsigned)((d * K + RA_THREADS - 1) / RA_THREADS), RA_THREADS, 0, g.stream>>>(a, (uint32_t)d, (uint32_t)log_k_chunk, d_tabs);
+    } else {
+        std::vector<std::vector<H::Fr>> tabs(d);
+        for (size_t i = 0; i < d; i++) tabs[i] = H::eq_evals(ch + i * log_k_chunk, log_k_chunk);
+        rc = upload_tables(tabs, K, &d_tabs);
+    }
     if (!rc) rc = P->rows.alloc(d, T);
     if (!rc) rc = H_indices ? P->rows.upload_indices(H_indices) : P->rows.upload_lookups(lookups, (uint32_t)log_k_chunk);
     if (!rc) rc = P->rows.gather(d_tabs, (uint32_t)K);
@@ -621,9 +645,8 @@ static int booleanity_build(const atlas_fr_t* G, const int32_t* const* H_indices
     if (!rc) rc = H_indices ? P->rows.upload_indices(H_indices) : P->rows.upload_lookups(lookups, (uint32_t)log_k_chunk);   // resident until the phase-2 gather
     if (!rc) {
         hipError_t e = hipMalloc(&P->d_gammas, d * sizeof(Fr));
-        if (e == hipSuccess) e = hipMemcpyAsync(P->d_gammas, gammas, d * sizeof(Fr), hipMemcpyHostToDevice, g.stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
         if (e != hipSuccess) rc = fail(ATLAS_ENODEV, "booleanity_new: gammas", e);
+        else rc = store_small(reinterpret_cast<const H::Fr*>(gammas), d, P->d_gammas);
     }
     if (rc) { delete P; return rc; }
     *out = P;

@@ -160,6 +160,24 @@ __global__ __launch_bounds__(RA_THREADS) void k_col_reduce(const Fr* __restrict_
     }
 }
 
+// A handful of field elements (a point, batching coefficients) reach the device as a KERNEL ARGUMENT: the launch copies
+// them while it is being enqueued, so there is no staging buffer to keep alive and no synchronisation — a pageable
+// hipMemcpyAsync + hipStreamSynchronize per constructor was ~20 us each, a dozen of them per lookup node.
+struct FrArgs { Fr v[64]; };
+__global__ void k_store_fr_args(FrArgs a, uint32_t n, Fr* __restrict__ dst) {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) fe_store(dst + i, a.v[i]);
+}
+inline int store_small(const H::Fr* src, size_t n, Fr* dst) {      // n <= 64 per launch; longer arrays in pieces
+    for (size_t o = 0; o < n; o += 64) {
+        FrArgs a;
+        const size_t m = n - o < 64 ? n - o : 64;
+        std::memcpy(a.v, src + o, m * sizeof(Fr));
+        k_store_fr_args<<<1, 64, 0, g.stream>>>(a, (uint32_t)m, dst + o);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ATLAS_OK : fail(ATLAS_ENODEV, "store_small", e);
+}
+
 // device half of a LowToHigh GruenSplitEqPolynomial: the cached prefix tables
 struct GseDev {
     H::GseState st;
@@ -170,11 +188,10 @@ struct GseDev {
         HIP_TRY(hipMalloc(&d_w, (n ? n : 1) * sizeof(Fr)));
         HIP_TRY(hipMalloc(&d_eout, ((size_t)2 << st.k_out) * sizeof(Fr)));
         HIP_TRY(hipMalloc(&d_ein, ((size_t)2 << st.k_in) * sizeof(Fr)));
-        if (n) HIP_TRY(hipMemcpyAsync(d_w, w, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+        if (n) { int rc = store_small(w, n, d_w); if (rc) return rc; }
         k_eq_cached<<<1, 1024, 0, g.stream>>>(d_eout, d_w, (uint32_t)st.k_out);
         k_eq_cached<<<1, 1024, 0, g.stream>>>(d_ein, d_w + st.m, (uint32_t)st.k_in);
-        HIP_TRY(hipStreamSynchronize(g.stream));
-        return ATLAS_OK;
+        return ATLAS_OK;                      // (stream-ordered: every later use is on the library stream or behind it)
     }
     SplitEqView view() const {
         SplitEqView E;
@@ -233,7 +250,7 @@ struct RaRows {
         if (e == hipSuccess) {
             size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
             k_ra_chunk_indices<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(d_l, len, (uint32_t)d, log_k_chunk, d_idx);
-            e = hipStreamSynchronize(g.stream);
+            e = hipGetLastError();            // no synchronisation: d_l goes back to the pool, which hands it out in stream order
         }
         hipFree(d_l);
         if (e != hipSuccess) return fail(ATLAS_ENODEV, "ra lookups upload", e);
@@ -244,8 +261,8 @@ struct RaRows {
         if (!d_idx) return fail(ATLAS_ESTATE, "ra gather: indices not uploaded");
         size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
         k_ra_gather<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, g.stream>>>(d_idx, d_tables, f_stride, len, buf[0]);
-        hipError_t e = hipStreamSynchronize(g.stream);
-        hipFree(d_idx); d_idx = nullptr;
+        hipError_t e = hipGetLastError();
+        hipFree(d_idx); d_idx = nullptr;      // (pool: reused in stream order)
         if (e != hipSuccess) return fail(ATLAS_ENODEV, "ra gather", e);
         cur = 0; stride[0] = len;
         return ATLAS_OK;
