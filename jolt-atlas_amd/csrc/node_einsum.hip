@@ -24,6 +24,7 @@
 #include "../../include/atlas_hip.h"
 #include "field.hip.h"
 #include "host_field.hpp"
+#include "internal.hpp"
 #include "runtime.hpp"
 
 using namespace atlas;
@@ -159,14 +160,14 @@ int prove_onehot_checks(const uint64_t* d_lookups, size_t log_T, size_t log_K, c
     for (size_t i = 0; i < d; i++) { uint64_t lo, hi; H::tr_challenge_u128(T, lo, hi); gammas[i] = H::challenge_to_fr(lo, hi, g.challenge_mode); }
     for (size_t i = 0; i < lkc; i++) { uint64_t lo, hi; H::tr_challenge_u128(T, lo, hi); r_addr[i] = H::challenge_to_fr(lo, hi, g.challenge_mode); }
     // G = compute_ra_evals(lookup_indices, params, r_cycle) (shout.rs:550-598)
-    atlas_poly_t eq_rc = nullptr, Gp = nullptr;
+    atlas_poly_t eq_rc = nullptr;
     int rc = atlas_eq_evals(r_cycle, log_T, nullptr, &eq_rc);
-    if (!rc) rc = atlas_shout_ra_evals(d_lookups, (size_t)1 << log_T, log_K, lkc, eq_rc, &Gp);
-    std::vector<atlas_fr_t> G(d << lkc);
-    if (!rc) rc = atlas_poly_download(Gp, G.data(), G.size());
+    std::vector<H::Fr> Gh;
+    if (!rc) rc = atlas_rt_shout_ra_evals_host(d_lookups, (size_t)1 << log_T, log_K, lkc, eq_rc, Gh);
     if (eq_rc) atlas_poly_free(eq_rc);
-    if (Gp) atlas_poly_free(Gp);
     if (rc) return rc;
+    std::vector<atlas_fr_t> G(d << lkc);
+    std::memcpy(G.data(), Gh.data(), G.size() * sizeof(atlas_fr_t));
     mark("ra_evals G");
     // RaVirtual: (r_address, r_cycle) = the ra opening point split at log_K
     atlas_instance_t ra = nullptr, hw = nullptr, bo = nullptr;

@@ -23,6 +23,7 @@
 #include "channel.hpp"
 #include "f9.hip.h"
 #include "host_field.hpp"
+#include "internal.hpp"
 #include "scan.hip.h"
 #include "runtime.hpp"
 
@@ -131,40 +132,46 @@ inline int grid_for(size_t work) {
     return (int)(b < 1 ? 1 : b > 2048 ? 2048 : b);
 }
 
+// the few-bucket histogram with its result on the host (n_buckets <= SH_SMALL_BUCKETS): word sums in LDS, one D2H of
+// n_buckets x 8 words into the pinned staging area, reduction mod p on the host
+int histogram_small_host(const uint64_t* h_idx, size_t T, KeySpec S, const atlas_poly* E, std::vector<H::Fr>& out) {
+    const uint32_t n_buckets = S.d << S.log_k_chunk;
+    const size_t nw = (size_t)n_buckets * 8;
+    if (nw * 8 > atlas_rt::PINNED_BYTES) return fail(ATLAS_EINVAL, "shout: staging area too small");
+    DevBuf acc_b, ix_b;
+    HIP_TRY(acc_b.alloc(nw * 8));
+    HIP_TRY(ix_b.alloc((T ? T : 1) * 8));
+    HIP_TRY(hipMemsetAsync(acc_b.p, 0, nw * 8, g.stream));
+    HIP_TRY(hipMemcpyAsync(ix_b.p, h_idx, T * 8, hipMemcpyDefault, g.stream));          // host or device source
+    size_t blocks = (T + SH_THREADS - 1) / SH_THREADS; if (blocks < 1) blocks = 1; if (blocks > 512) blocks = 512;
+    k_sh_hist_small<<<(unsigned)blocks, SH_THREADS, 0, g.stream>>>(ix_b.as<uint64_t>(), T, S, (const Fe*)E->d, acc_b.as<unsigned long long>());
+    HIP_TRY(hipMemcpyAsync(g.h_pinned, acc_b.p, nw * 8, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    const unsigned long long* h_acc = reinterpret_cast<const unsigned long long*>(g.h_pinned);
+    out.resize(n_buckets);
+    for (uint32_t b = 0; b < n_buckets; b++) {
+        uint64_t a9[9];
+        for (int w = 0; w < 8; w++) a9[w] = h_acc[(size_t)b * 8 + w];       // words of canonical residues < 2^32, < 2^31 of them: 64 bits suffice
+        a9[8] = 0;
+        out[b] = atlas_rt::sum_to_fr(a9, 32, 0);
+    }
+    return ATLAS_OK;
+}
+
 // weighted histogram: G[key] = sum E[j] over the (j, i) pairs with that key; n_buckets = d * k_chunk
 int histogram(const uint64_t* h_idx, size_t T, KeySpec S, const atlas_poly* E, atlas_poly_t* out) {
     const uint32_t n_buckets = S.d << S.log_k_chunk;
     if (E->is_i32 || E->len < T) return fail(ATLAS_EINVAL, "shout: eq table shorter than the index list");
     if (T >= (1ull << 31) || (uint64_t)T * S.d >= (1ull << 32)) return fail(ATLAS_EINVAL, "shout: too many lookups");
     if (n_buckets <= SH_SMALL_BUCKETS && T < ((size_t)1 << 31)) {
-        // words of canonical residues < 2^32, at most 2^31 of them per accumulator: the sums fit 64 bits
-        unsigned long long* d_acc = nullptr; Fe* Gs = nullptr; uint64_t* d_ix = nullptr;
-        const size_t nw = (size_t)n_buckets * 8;
-        HIP_TRY(hipMalloc(&d_acc, nw * 8));
+        std::vector<H::Fr> h_G;
+        int rc = histogram_small_host(h_idx, T, S, E, h_G);
+        if (rc) return rc;
+        Fe* Gs = nullptr;
         hipError_t e2 = hipMalloc(&Gs, (size_t)n_buckets * sizeof(Fe));
-        if (e2 == hipSuccess) e2 = hipMalloc(&d_ix, (T ? T : 1) * 8);
-        if (e2 != hipSuccess) { hipFree(d_acc); hipFree(Gs); return fail(ATLAS_ENOMEM, "hipMalloc(G)", e2); }
-        std::vector<unsigned long long> h_acc(nw);
-        std::vector<H::Fr> h_G(n_buckets);
-        e2 = hipMemsetAsync(d_acc, 0, nw * 8, g.stream);
-        if (e2 == hipSuccess) e2 = hipMemcpyAsync(d_ix, h_idx, T * 8, hipMemcpyDefault, g.stream);   // host or device source
-        if (e2 == hipSuccess) {
-            size_t blocks = (T + SH_THREADS - 1) / SH_THREADS; if (blocks < 1) blocks = 1; if (blocks > 512) blocks = 512;
-            k_sh_hist_small<<<(unsigned)blocks, SH_THREADS, 0, g.stream>>>(d_ix, T, S, (const Fe*)E->d, d_acc);
-            e2 = hipMemcpyAsync(h_acc.data(), d_acc, nw * 8, hipMemcpyDeviceToHost, g.stream);
-        }
+        if (e2 != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(G)", e2);
+        e2 = hipMemcpyAsync(Gs, h_G.data(), (size_t)n_buckets * sizeof(Fe), hipMemcpyHostToDevice, g.stream);
         if (e2 == hipSuccess) e2 = hipStreamSynchronize(g.stream);
-        if (e2 == hipSuccess) {
-            for (uint32_t b = 0; b < n_buckets; b++) {
-                uint64_t a9[9];
-                for (int w = 0; w < 8; w++) a9[w] = h_acc[(size_t)b * 8 + w];
-                a9[8] = 0;
-                h_G[b] = atlas_rt::sum_to_fr(a9, 32, 0);
-            }
-            e2 = hipMemcpyAsync(Gs, h_G.data(), (size_t)n_buckets * sizeof(Fe), hipMemcpyHostToDevice, g.stream);
-            if (e2 == hipSuccess) e2 = hipStreamSynchronize(g.stream);
-        }
-        hipFree(d_acc); hipFree(d_ix);
         if (e2 != hipSuccess) { hipFree(Gs); return fail(ATLAS_ENODEV, "shout histogram", e2); }
         atlas_poly* p = new atlas_poly();
         p->d = Gs; p->len = n_buckets; p->cap_bytes = (size_t)n_buckets * sizeof(Fe); p->is_i32 = false; p->owned = true;
@@ -221,6 +228,22 @@ int atlas_shout_ra_evals(const uint64_t* lookup_indices, size_t T, size_t log_K,
     std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     return histogram(lookup_indices, T, KeySpec{d, (uint32_t)log_k_chunk}, eq_r_cycle, out);
 }
+
+}  // extern "C"
+
+// compute_ra_evals with the tables on the host (the node provers hand them to the HammingWeight / Booleanity constructors):
+// no device polynomial in between.  Not part of the C-ABI (internal.hpp).
+int atlas_rt_shout_ra_evals_host(const uint64_t* lookup_indices, size_t T, size_t log_K, size_t log_k_chunk, atlas_poly_t eq_r_cycle,
+                                 std::vector<atlas_host::Fr>& G) {
+    const uint32_t d = (uint32_t)((log_K + log_k_chunk - 1) / log_k_chunk);
+    if (!lookup_indices || !eq_r_cycle || log_k_chunk == 0 || log_k_chunk > 16 || ((size_t)d << log_k_chunk) > SH_SMALL_BUCKETS)
+        return fail(ATLAS_EINVAL, "shout_ra_evals_host");
+    if (eq_r_cycle->is_i32 || eq_r_cycle->len < T) return fail(ATLAS_EINVAL, "shout: eq table shorter than the index list");
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    return histogram_small_host(lookup_indices, T, KeySpec{d, (uint32_t)log_k_chunk}, eq_r_cycle, G);
+}
+
+extern "C" {
 
 int atlas_shout_read_raf_prover_new(atlas_poly_t G, const int32_t* table, size_t log_K, const atlas_fr_t* gamma,
                                     atlas_dot_prover_t* out) {
