@@ -61,21 +61,32 @@ __global__ __launch_bounds__(SC_THREADS) void k_reduce1(const Fr* partials, int 
     }
 }
 
+struct EqPointArgs { Fr v[32]; };
+__global__ void k_store_point(EqPointArgs a, uint32_t n, Fr* __restrict__ dst) {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) fe_store(dst + i, a.v[i]);
+}
+
 // EqPolynomial::evals into a fresh device buffer (2^n Fr)
 int eq_evals_device(const H::Fr* r, size_t n, const H::Fr* scaling, Fr** out) {
     const size_t len = (size_t)1 << n;
     Fr* ev = nullptr;
     hipError_t e = hipMalloc(&ev, len * sizeof(Fr));
     if (e != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(eq)", e);
+    // the point travels as a kernel argument (<= 30 field elements): no staging copy, no synchronisation — the table is
+    // complete in stream order, which is all its users (kernels on the library stream) need
     Fr* d_r = nullptr;
     HIP_TRY(hipMalloc(&d_r, (n ? n : 1) * sizeof(Fr)));
-    if (n) HIP_TRY(hipMemcpyAsync(d_r, r, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    if (n) {
+        EqPointArgs a;
+        std::memcpy(a.v, r, n * sizeof(Fr));
+        k_store_point<<<1, 64, 0, g.stream>>>(a, (uint32_t)n, d_r);
+    }
     const uint32_t head = n < 12 ? (uint32_t)n : 12u;
     k_eq_head<<<1, 1024, 0, g.stream>>>(ev, d_r, (uint32_t)n, head, to_dev(scaling ? *scaling : H::one()));
     for (size_t p = head; p < n; p++)
         k_eq_double<<<grid_for((size_t)1 << p), SC_THREADS, 0, g.stream>>>(ev, (size_t)1 << p, to_dev(r[n - 1 - p]));
-    hipError_t le = hipStreamSynchronize(g.stream);
-    hipFree(d_r);
+    hipError_t le = hipGetLastError();
+    hipFree(d_r);                                 // (pool: reused in stream order)
     if (le != hipSuccess) { hipFree(ev); return fail(ATLAS_ENODEV, "eq_evals", le); }
     *out = ev;
     return ATLAS_OK;
@@ -117,9 +128,8 @@ int atlas_poly_evaluate(atlas_poly_t p, const atlas_fr_t* r, size_t n, atlas_fr_
         k_mle_evaluate<int32_t><<<grid, SC_THREADS, 0, g.stream>>>((const int32_t*)p->d, p->len, eq1, eq2, (uint32_t)(n - m), g.d_partials, K);
     else
         k_mle_evaluate<Fr><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)p->d, p->len, eq1, eq2, (uint32_t)(n - m), g.d_partials, K);
-    k_reduce1<<<1, SC_THREADS, 0, g.stream>>>(g.d_partials, grid, g.d_finals + 3, 1);
-    hipError_t e = hipMemcpyAsync(g.h_pinned, g.d_finals + 3, sizeof(Fr), hipMemcpyDeviceToHost, g.stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    k_reduce1<<<1, SC_THREADS, 0, g.stream>>>(g.d_partials, grid, (Fr*)g.h_pinned, 1);      // straight into the pinned staging area
+    hipError_t e = hipStreamSynchronize(g.stream);
     hipFree(eq1); hipFree(eq2);
     if (e != hipSuccess) return fail(ATLAS_ENODEV, "poly_evaluate", e);
     std::memcpy(out, g.h_pinned, sizeof(Fr));
