@@ -142,6 +142,10 @@ int atlas_eq_evals(const atlas_fr_t *r, size_t n, const atlas_fr_t *scaling, atl
 /* PolynomialEvaluation::evaluate (multilinear_polynomial.rs:766-862; dense_mlpoly.rs:265-305):
  * P(r), r[0] = MSB variable; p is not modified */
 int atlas_poly_evaluate(atlas_poly_t p, const atlas_fr_t *r, size_t n, atlas_fr_t *out);
+/* MultilinearPolynomial::batch_evaluate (multilinear_polynomial.rs:682): `count` polynomials of
+ * 2^n coefficients at one point; out[i] = polys[i](r).  The eq tables are built once and the call
+ * synchronises once, whatever `count` (<= 64) is. */
+int atlas_poly_evaluate_many(const atlas_poly_t *polys, size_t count, const atlas_fr_t *r, size_t n, atlas_fr_t *out);
 
 /* ---- einsum operand folds: i32 matrix x Fr vector
  *      (EinsumLayout::fold, jolt-atlas-core/src/onnx_proof/ops/einsum/mk_kn_mn.rs:47-79;

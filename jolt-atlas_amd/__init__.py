@@ -445,7 +445,7 @@ class SRS:
             self.h = None
 
 
-for _name in ("atlas_eq_evals", "atlas_poly_evaluate", "atlas_mul_prover_new", "atlas_mul_prover_free",
+for _name in ("atlas_eq_evals", "atlas_poly_evaluate", "atlas_poly_evaluate_many", "atlas_mul_prover_new", "atlas_mul_prover_free",
               "atlas_mul_input_claim", "atlas_sumcheck_prove_mul"):
     getattr(lib, _name).restype = C.c_int
 
@@ -467,6 +467,16 @@ def evaluate(poly: MultilinearPolynomial, r_fr):
     r = _fr(r_fr).reshape(-1, 4)
     out = np.zeros(4, dtype=np.uint64)
     _check(lib.atlas_poly_evaluate(poly.h, _p(r) if len(r) else None, C.c_size_t(len(r)), _p(out)))
+    return out
+
+
+def batch_evaluate(polys, r_fr):
+    """PolynomialEvaluation::batch_evaluate (multilinear_polynomial.rs:682): every polynomial at the same
+    point, the eq tables built once and a single synchronisation; returns (len(polys), 4) u64."""
+    r = _fr(r_fr).reshape(-1, 4)
+    hs = (C.c_void_p * len(polys))(*[p.h for p in polys])
+    out = np.zeros((len(polys), 4), dtype=np.uint64)
+    _check(lib.atlas_poly_evaluate_many(hs, C.c_size_t(len(polys)), _p(r) if len(r) else None, C.c_size_t(len(r)), _p(out)))
     return out
 
 

@@ -252,9 +252,13 @@ int prove_fused_rescale(size_t T, size_t S, FillAcc&& fill_acc, Inner&& inner, c
         if (!rc) rc = atlas_poly_wrap_device_i32(d_output, T, &p_out);
     }
     H::Fr eval_R, acc_claim, out_claim;
-    if (!rc) rc = atlas_poly_evaluate(p_rem, r_node_output, log_T, (atlas_fr_t*)&eval_R);
-    if (!rc) rc = atlas_poly_evaluate(p_quot, r_node_output, log_T, (atlas_fr_t*)&acc_claim);
-    if (!rc) { if (output_claim) std::memcpy(&out_claim, output_claim, 32); else rc = atlas_poly_evaluate(p_out, r_node_output, log_T, (atlas_fr_t*)&out_claim); }
+    if (!rc) {   // the three openings at r_node_output share their eq tables and one synchronisation
+        const atlas_poly_t ps[3] = {p_rem, p_quot, p_out};
+        H::Fr ev[3];
+        rc = atlas_poly_evaluate_many(ps, output_claim ? 2 : 3, r_node_output, log_T, (atlas_fr_t*)ev);
+        eval_R = ev[0]; acc_claim = ev[1];
+        if (output_claim) std::memcpy(&out_claim, output_claim, 32); else out_claim = ev[2];
+    }
     for (atlas_poly_t p : {p_rem, p_quot, p_out}) if (p) atlas_poly_free(p);
     if (stage_ms) stage_ms[0] = ms_since(t0);
     if (rc) { cleanup(); return rc; }
@@ -505,15 +509,16 @@ extern "C" int atlas_prove_addsub_node(const int32_t* d_left, const int32_t* d_r
     atlas_poly_t p_acc = nullptr, p_out = nullptr, p_l = nullptr, p_r = nullptr;
     H::Fr acc_claim, out_claim, l_claim, r_claim;
     rc = atlas_poly_wrap_device_fr(fr_b.p, T, &p_acc);
-    if (!rc) rc = atlas_poly_evaluate(p_acc, r_node_output, log_T, (atlas_fr_t*)&acc_claim);
-    if (!rc) {
-        if (output_claim) std::memcpy(&out_claim, output_claim, 32);
-        else { rc = atlas_poly_wrap_device_i32(d_output, T, &p_out); if (!rc) rc = atlas_poly_evaluate(p_out, r_node_output, log_T, (atlas_fr_t*)&out_claim); }
-    }
     if (!rc) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(d_left), T, &p_l);
     if (!rc) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(d_right), T, &p_r);
-    if (!rc) rc = atlas_poly_evaluate(p_l, r_node_output, log_T, (atlas_fr_t*)&l_claim);
-    if (!rc) rc = atlas_poly_evaluate(p_r, r_node_output, log_T, (atlas_fr_t*)&r_claim);
+    if (!rc) rc = atlas_poly_wrap_device_i32(d_output, T, &p_out);
+    if (!rc) {
+        const atlas_poly_t ps[4] = {p_acc, p_l, p_r, p_out};
+        H::Fr ev[4];
+        rc = atlas_poly_evaluate_many(ps, output_claim ? 3 : 4, r_node_output, log_T, (atlas_fr_t*)ev);
+        acc_claim = ev[0]; l_claim = ev[1]; r_claim = ev[2];
+        if (output_claim) std::memcpy(&out_claim, output_claim, 32); else out_claim = ev[3];
+    }
     for (atlas_poly_t p : {p_acc, p_out, p_l, p_r}) if (p) atlas_poly_free(p);
     if (stage_ms) stage_ms[0] = ms_since(t0);
     if (rc) return rc;
@@ -575,10 +580,13 @@ extern "C" int atlas_prove_relu_node(const int32_t* d_input, size_t log_T, const
     atlas_poly_t p_in = nullptr, p_out = nullptr;
     H::Fr operand_claim, out_claim;
     rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(d_input), T, &p_in);          // a read-only view: evaluate does not write
-    if (!rc) rc = atlas_poly_evaluate(p_in, r_node_output, log_T, (atlas_fr_t*)&operand_claim);
+    if (!rc) rc = atlas_poly_wrap_device_i32(d_output, T, &p_out);
     if (!rc) {
-        if (output_claim) std::memcpy(&out_claim, output_claim, 32);
-        else { rc = atlas_poly_wrap_device_i32(d_output, T, &p_out); if (!rc) rc = atlas_poly_evaluate(p_out, r_node_output, log_T, (atlas_fr_t*)&out_claim); }
+        const atlas_poly_t ps[2] = {p_in, p_out};
+        H::Fr ev[2];
+        rc = atlas_poly_evaluate_many(ps, output_claim ? 1 : 2, r_node_output, log_T, (atlas_fr_t*)ev);
+        operand_claim = ev[0];
+        if (output_claim) std::memcpy(&out_claim, output_claim, 32); else out_claim = ev[1];
     }
     for (atlas_poly_t p : {p_in, p_out}) if (p) atlas_poly_free(p);
     if (stage_ms) stage_ms[0] = ms_since(t0);

@@ -109,12 +109,15 @@ int atlas_eq_evals(const atlas_fr_t* r, size_t n, const atlas_fr_t* scaling, atl
     return ATLAS_OK;
 }
 
-int atlas_poly_evaluate(atlas_poly_t p, const atlas_fr_t* r, size_t n, atlas_fr_t* out) {
+int atlas_poly_evaluate_many(const atlas_poly_t* polys, size_t count, const atlas_fr_t* r, size_t n, atlas_fr_t* out) {
     NEED_INIT();
-    if (!p || (!r && n) || !out) return fail(ATLAS_EINVAL, "poly_evaluate");
-    if (p->len != ((size_t)1 << n)) return fail(ATLAS_EINVAL, "poly_evaluate: point length != num_vars");
+    if (!polys || !count || count > 64 || (!r && n) || !out) return fail(ATLAS_EINVAL, "poly_evaluate_many");
+    for (size_t i = 0; i < count; ++i)
+        if (!polys[i] || polys[i]->len != ((size_t)1 << n)) return fail(ATLAS_EINVAL, "poly_evaluate: point length != num_vars");
     std::lock_guard<atlas_rt::Mutex> lk(g.mu);
-    // DensePolynomial::evaluate: r = (r2 | r1), eq_one = evals(r2) outer, eq_two = evals(r1) inner
+    // DensePolynomial::evaluate: r = (r2 | r1), eq_one = evals(r2) outer, eq_two = evals(r1) inner.
+    // The two tables are shared by every polynomial of the call; each result goes straight into
+    // the pinned staging area, so the whole call costs one synchronisation.
     const size_t m = n / 2;
     const H::Fr* rr = reinterpret_cast<const H::Fr*>(r);
     Fr *eq1 = nullptr, *eq2 = nullptr;
@@ -122,18 +125,26 @@ int atlas_poly_evaluate(atlas_poly_t p, const atlas_fr_t* r, size_t n, atlas_fr_
     if (rc) return rc;
     rc = eq_evals_device(rr + m, n - m, nullptr, &eq2);
     if (rc) { hipFree(eq1); return rc; }
-    const int grid = grid_for(p->len);
+    const int grid = grid_for((size_t)1 << n);
     const ScConsts K = make_consts();
-    if (p->is_i32)
-        k_mle_evaluate<int32_t><<<grid, SC_THREADS, 0, g.stream>>>((const int32_t*)p->d, p->len, eq1, eq2, (uint32_t)(n - m), g.d_partials, K);
-    else
-        k_mle_evaluate<Fr><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)p->d, p->len, eq1, eq2, (uint32_t)(n - m), g.d_partials, K);
-    k_reduce1<<<1, SC_THREADS, 0, g.stream>>>(g.d_partials, grid, (Fr*)g.h_pinned, 1);      // straight into the pinned staging area
+    for (size_t i = 0; i < count; ++i) {
+        const atlas_poly_t p = polys[i];
+        if (p->is_i32)
+            k_mle_evaluate<int32_t><<<grid, SC_THREADS, 0, g.stream>>>((const int32_t*)p->d, p->len, eq1, eq2, (uint32_t)(n - m), g.d_partials, K);
+        else
+            k_mle_evaluate<Fr><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)p->d, p->len, eq1, eq2, (uint32_t)(n - m), g.d_partials, K);
+        k_reduce1<<<1, SC_THREADS, 0, g.stream>>>(g.d_partials, grid, (Fr*)g.h_pinned + i, 1);
+    }
     hipError_t e = hipStreamSynchronize(g.stream);
     hipFree(eq1); hipFree(eq2);
     if (e != hipSuccess) return fail(ATLAS_ENODEV, "poly_evaluate", e);
-    std::memcpy(out, g.h_pinned, sizeof(Fr));
+    std::memcpy(out, g.h_pinned, count * sizeof(Fr));
     return ATLAS_OK;
+}
+
+int atlas_poly_evaluate(atlas_poly_t p, const atlas_fr_t* r, size_t n, atlas_fr_t* out) {
+    if (!p) return fail(ATLAS_EINVAL, "poly_evaluate");
+    return atlas_poly_evaluate_many(&p, 1, r, n, out);
 }
 
 // ------------------------------------------------------------------ MulProver

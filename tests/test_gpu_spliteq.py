@@ -40,6 +40,31 @@ def test_evaluate(atlas, n):
     p.free()
 
 
+@pytest.mark.parametrize("n", [0, 3, 13])
+def test_batch_evaluate(atlas, n):
+    """Mixed i32 / Fr polynomials at one point, one call."""
+    from oracle import orc
+    r = orc.random_fr(n, 31 + n) if n else np.zeros((0, 4), dtype=np.uint64)
+    polys, want = [], []
+    for k in range(5):
+        if k % 2:
+            zi = np.random.default_rng(n * 7 + k).integers(-(1 << 30), 1 << 30, size=1 << n, dtype=np.int32)
+            z = orc.fr_array(1 << n)
+            orc.lib.orc_i32_to_fr(zi.ctypes.data_as(orc.i32p), C.c_size_t(1 << n), orc._p(z))
+            polys.append(atlas.MultilinearPolynomial.from_i32(zi))
+        else:
+            z = orc.random_fr(1 << n, 90 + n + k)
+            polys.append(atlas.MultilinearPolynomial.from_fr(z))
+        want.append(orc.evaluate(z, r) if n else z[0])
+    got = atlas.batch_evaluate(polys, r)
+    for k in range(5):
+        assert np.array_equal(got[k], want[k])
+        assert np.array_equal(atlas.evaluate(polys[k], r), want[k])
+        polys[k].free()
+    with pytest.raises(atlas.AtlasError):
+        atlas.batch_evaluate([atlas.MultilinearPolynomial.from_fr(orc.random_fr(2, 1))], orc.random_fr(2, 2))
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 9, 10, 11, 12, 13, 15])
 def test_mul_sumcheck_bit_exact(atlas, n):
     """The device accumulates q(1) directly where the reference divides (split_eq_poly.rs:410);
