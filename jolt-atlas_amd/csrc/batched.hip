@@ -409,7 +409,8 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         if (rc) return rc;
     }
     const bool trace = getenv("ATLAS_TRACE") != nullptr;          // per instance: wall clock of compute_message / ingest_challenge, summed
-    std::vector<double> t_msg(n, 0.0), t_ing(n, 0.0);
+    std::vector<double> t_msg(n, 0.0), t_ing(n, 0.0), t_wait(n, 0.0);
+    double t_fs = 0, t_enq = 0;
     for (size_t round = 0; round < max_rounds; round++) {
         const size_t remaining = max_rounds - round;
         std::vector<std::vector<H::Fr>> polys(n);
@@ -421,9 +422,12 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
             } else if (piped) {
                 const size_t local = round - (max_rounds - I.rounds);
                 H::Fr sums[16];
+                const auto tc0 = std::chrono::steady_clock::now();
                 I.inst->prepare(local);
                 int rc = PL.collect(PL.lanes[i].mails[local], PL.mtag(round, i), sums) ? ATLAS_OK : fail(ATLAS_ENODEV, "round channel: no answer from the device");
+                const auto tc1 = std::chrono::steady_clock::now();
                 if (!rc) rc = I.inst->finish(local, claim[i], sums, polys[i]);
+                if (trace) { t_wait[i] += std::chrono::duration<double, std::milli>(tc1 - tc0).count(); t_msg[i] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc1).count(); }
                 if (rc) { PL.abort_from(round); PL.drain(); return rc; }
             } else {
                 const auto tm0 = std::chrono::steady_clock::now();
@@ -432,6 +436,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
                 if (trace) t_msg[i] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm0).count();
             }
         }
+        const auto tf0 = std::chrono::steady_clock::now();
         // batched = sum coeff_i * poly_i, starting from UniPoly::from_coeff(vec![]) = [0]  (:109-116)
         std::vector<H::Fr> batched = {H::zero()};
         for (size_t i = 0; i < n; i++) {
@@ -457,6 +462,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         if (piped) { PL.C.publish(PL.slot0 + round, PL.rtag(round), lo, hi); if ((round & 7) == 7) PL.query(); }
         const H::Fr r = H::challenge_to_fr(lo, hi, g.challenge_mode);
         for (size_t i = 0; i < n; i++) claim[i] = eval_with_challenge(polys[i], r);    // :123-126
+        if (trace) t_fs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf0).count();
         for (size_t i = 0; i < n; i++) {
             Instance& I = b->inst[i];
             if (remaining <= I.rounds) {
@@ -467,13 +473,19 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
                 if (trace) t_ing[i] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti0).count();
             }
         }
-        if (piped) { int rc = PL.advance(round + 1); if (rc) return rc; }       // (advance drains on its own failures)
+        if (piped) {
+            const auto te0 = std::chrono::steady_clock::now();
+            int rc = PL.advance(round + 1);       // (advance drains on its own failures)
+            if (rc) return rc;
+            if (trace) t_enq += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - te0).count();
+        }
     }
     *max_rounds_out = max_rounds;
     if (trace)
         for (size_t i = 0; i < n; i++)
-            fprintf(stderr, "[atlas trace] batched_prove instance %zu (%zu rounds, degree %zu): compute_message %.3f ms, ingest_challenge %.3f ms\n",
-                    i, b->inst[i].rounds, b->inst[i].inst->degree(), t_msg[i], t_ing[i]);
+            fprintf(stderr, "[atlas trace] batched_prove instance %zu (%zu rounds, degree %zu): wait for sums %.3f ms, compute_message / finish %.3f ms, ingest_challenge %.3f ms\n",
+                    i, b->inst[i].rounds, b->inst[i].inst->degree(), t_wait[i], t_msg[i], t_ing[i]);
+    if (trace) fprintf(stderr, "[atlas trace] batched_prove: combine + transcript + publish %.3f ms, enqueue %.3f ms\n", t_fs, t_enq);
     if (piped) return PL.collect_finals();
     return ATLAS_OK;
 }

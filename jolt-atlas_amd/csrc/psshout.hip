@@ -109,8 +109,18 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_q_final(const unsigned long l
     const uint32_t word = threadIdx.x & 31u, part = threadIdx.x >> 5;
     const size_t n_words = (size_t)n_vals * 8, widx = (size_t)blockIdx.x * 32 + word;
     unsigned long long sum = 0;
-    if (widx < n_words)
-        for (uint32_t g2 = part; g2 < n_slabs; g2 += 8) sum += acc[(size_t)g2 * n_words + widx];
+    if (widx < n_words) {                              // four loads in flight per thread: the loop is latency-bound otherwise
+        const unsigned long long* col = acc + widx;
+        unsigned long long s1 = 0, s2 = 0, s3 = 0;
+        uint32_t g2 = part;
+        for (; g2 + 24 < n_slabs; g2 += 32) {
+            const unsigned long long a0 = col[(size_t)g2 * n_words], a1 = col[(size_t)(g2 + 8) * n_words];
+            const unsigned long long a2 = col[(size_t)(g2 + 16) * n_words], a3 = col[(size_t)(g2 + 24) * n_words];
+            sum += a0; s1 += a1; s2 += a2; s3 += a3;
+        }
+        for (; g2 < n_slabs; g2 += 8) sum += col[(size_t)g2 * n_words];
+        sum += s1 + s2 + s3;
+    }
     sm[part][word] = sum;
     __syncthreads();
     const uint32_t i = blockIdx.x * 4 + threadIdx.x;
@@ -133,6 +143,9 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_q_final(const unsigned long l
         if (pub.host_dst) fe_store(pub.host_dst + i, res);
     }
     if (!pub.host_dst) return;
+    // (Publishing costs ~20 us per phase at 1536 values, whichever workgroups write: having only the last one to arrive
+    // copy the residues out, with or without contiguous 16-byte stores, took 34-36 us against 30 — the host link takes
+    // ~50 M device-initiated writes per second, tools/exp_channel2.hip.)
     __threadfence_system();                            // this workgroup's values are in host memory before it is counted
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -634,9 +647,17 @@ struct PsLookup : atlas_instance {
                 if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) { g.chan.abort_dirty = true; return fail(ATLAS_ENODEV, "round channel: no Q tables from the device"); }
             }
             load_Q(B.data);
+            if (ps_trace()) t_qwait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         }
-        return address_message(round, claim, coeffs);
+        if (!ps_trace()) return address_message(round, claim, coeffs);
+        const auto t1 = std::chrono::steady_clock::now();
+        const int rc = address_message(round, claim, coeffs);
+        t_addr += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+        if (round + 1 == N) fprintf(stderr, "[atlas trace] ps_shout address rounds: wait for Q + load %.1f us, messages %.1f us\n", 1e6 * t_qwait, 1e6 * t_addr);
+        return rc;
     }
+    double t_qwait = 0, t_addr = 0;
+    static bool ps_trace() { static const bool on = getenv("ATLAS_TRACE") != nullptr; return on; }
     int host_ingest(const atlas_u128_t& r, size_t round) override { return ingest_impl(r, round, false); }
     int enqueue_finals(const atlas::RoundIo& io, atlas_mail_ref& mail) override {
         k_rows_final_ch<<<1, 64, 0, g.stream>>>(rows.buf[(log_T - 1) & 1], T >> (log_T - 1), 1u, ChanIo{io, g.challenge_mode}, g.challenge_mode == 0 ? 1 : 0);
