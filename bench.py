@@ -397,6 +397,18 @@ def main():
             _pf, _cl, st = NODE.prove_einsum_node(tA, tB, m_, k_, n_, S_, r0, tn)
             sync(); dtn = time.perf_counter() - t0n
             states_n.add(tn.state)
+            if os.environ.get("ATLAS_BENCH_DEBUG"):
+                import hashlib
+                print("  parts", [hashlib.sha1(bytes(x)).hexdigest()[:6] for x in _pf], "claims", hashlib.sha1(np.ascontiguousarray(_cl).tobytes()).hexdigest()[:6] if not isinstance(_cl, (list, tuple, dict)) else [hashlib.sha1(np.ascontiguousarray(c).tobytes()).hexdigest()[:6] for c in (_cl.values() if isinstance(_cl, dict) else _cl)], file=sys.stderr, flush=True)
+            if os.environ.get("ATLAS_BENCH_DEBUG"):
+                if rep == 0: _pf0 = [bytes(x) for x in _pf]
+                for pi, x in enumerate(_pf):
+                    xb = bytes(x)
+                    if xb != _pf0[pi]:
+                        first = next(i for i in range(min(len(xb), len(_pf0[pi]))) if xb[i] != _pf0[pi][i])
+                        print("  part", pi, "len", len(xb), "first differing byte", first, "= 32-byte word", first // 32, file=sys.stderr, flush=True)
+                        break
+            if os.environ.get("ATLAS_BENCH_DEBUG"): print("node rep", rep, tn.state[:8].hex() if isinstance(tn.state, (bytes, bytearray)) else str(tn.state)[:40], file=sys.stderr, flush=True)
             if rep and (best is None or dtn < best):
                 best, stages = dtn, st
         assert len(states_n) == 1, "non-deterministic node proof"

@@ -127,7 +127,6 @@ struct Pipeline {
     static constexpr size_t N_SIDE = 4;
     bool side = false;
     static hipStream_t* side_streams() { static hipStream_t st[N_SIDE] = {nullptr, nullptr, nullptr, nullptr}; return st; }
-    static hipEvent_t* side_events() { static hipEvent_t ev[N_SIDE + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr}; return ev; }
     hipStream_t lane_stream(size_t li) const { return side ? side_streams()[li % N_SIDE] : g.stream; }
     int begin() {               // the caller holds g.mu
         for (auto& L : lanes) { max_rounds = L.rounds > max_rounds ? L.rounds : max_rounds; }
@@ -139,21 +138,22 @@ struct Pipeline {
         static const bool no_side = getenv("ATLAS_NO_LANE_STREAMS") != nullptr;
         side = lanes.size() > 1 && !no_side;
         if (side) {
-            hipStream_t* st = side_streams(); hipEvent_t* ev = side_events();
-            if (!st[0]) {
+            hipStream_t* st = side_streams();
+            if (!st[0])
                 for (size_t i = 0; i < N_SIDE; i++) HIP_TRY(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
-                for (size_t i = 0; i <= N_SIDE; i++) HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
-            }
-            HIP_TRY(hipEventRecord(ev[N_SIDE], g.stream));
-            for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) HIP_TRY(hipStreamWaitEvent(st[i], ev[N_SIDE], 0));
+            // The lanes start behind the library stream (the constructors ran there).  The host waits for it: an
+            // event recorded on the library stream and waited for by the lane streams did NOT order them reliably —
+            // in processes where a lane stream shares a hardware queue with the library stream (bench.py, after its
+            // other legs) the first bind of a lane read rows the constructor had not finished, one proof in three.
+            HIP_TRY(hipStreamSynchronize(g.stream));
         }
         return advance(0);
     }
     // the library stream continues only after every lane stream has drained (called on every way out of a proof)
     void join() {
         if (!side) return;
-        hipStream_t* st = side_streams(); hipEvent_t* ev = side_events();
-        for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) { (void)hipEventRecord(ev[i], st[i]); (void)hipStreamWaitEvent(g.stream, ev[i], 0); }
+        hipStream_t* st = side_streams();
+        for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) (void)hipStreamSynchronize(st[i]);   // (host waits, for the reason given in begin; the finals have been mailed, the lanes are about idle)
         side = false;
     }
     void query() { (void)hipStreamQuery(g.stream); if (side) for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) (void)hipStreamQuery(side_streams()[i]); }

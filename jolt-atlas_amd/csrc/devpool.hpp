@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <unordered_map>
@@ -24,9 +25,29 @@ struct DevPool {
     static constexpr size_t POOL_MAX_CACHED = (size_t)24 << 30;
     std::mutex mu;
     std::unordered_map<void*, uint32_t> live;             // block -> size class (blocks handed out by the pool)
-    std::vector<std::vector<void*>> free_lists;           // by size class
+    struct FreeBlock { void* p; hipStream_t freed_on; };  // the library's current stream when the block came back
+    std::vector<std::vector<FreeBlock>> free_lists;       // by size class
+    size_t double_free = 0;
+    size_t cross_stream = 0;                              // blocks passed over because they were freed under another stream
     size_t cached = 0;
-    bool off = getenv("ATLAS_NO_POOL") != nullptr;
+    // ATLAS_POOL_POISON=<byte>: no caching, and every block is filled with that byte before it is handed out (fresh
+    // blocks have no pending users, so the fill cannot disturb anything): a kernel that relies on zero-initialised memory
+    // shows up as a changed result.  ATLAS_POOL_POISON_MIN / _MAX (bytes) narrow the fill to a size range.
+    const char* poison_env = getenv("ATLAS_POOL_POISON");
+    bool off = getenv("ATLAS_NO_POOL") != nullptr || poison_env != nullptr;
+    hipStream_t poison_stream = nullptr;
+    hipError_t poisoned(void** out, size_t bytes) {
+        hipError_t e = hipMalloc(out, bytes);
+        if (e != hipSuccess || !poison_env || !bytes) return e;
+        static const size_t lo = getenv("ATLAS_POOL_POISON_MIN") ? strtoull(getenv("ATLAS_POOL_POISON_MIN"), nullptr, 0) : 0;
+        static const size_t hi = getenv("ATLAS_POOL_POISON_MAX") ? strtoull(getenv("ATLAS_POOL_POISON_MAX"), nullptr, 0) : ~(size_t)0;
+        if (bytes < lo || bytes > hi) return e;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!poison_stream) (void)hipStreamCreateWithFlags(&poison_stream, hipStreamNonBlocking);
+        (void)hipMemsetAsync(*out, atoi(poison_env), bytes, poison_stream);
+        (void)hipStreamSynchronize(poison_stream);
+        return e;
+    }
 
     static size_t class_bytes(uint32_t c) { return ((size_t)4 + (c & 3)) << (6 + (c >> 2)); }   // (4..7) * 2^(6 + c/4): 256, 320, 384, 448, 512, ...
     static uint32_t class_of(size_t bytes) {
@@ -35,17 +56,27 @@ struct DevPool {
         return c;
     }
     hipError_t alloc(void** out, size_t bytes) {
-        if (off || bytes == 0 || bytes > POOL_MAX_BLOCK) return hipMalloc(out, bytes);
+        if (off || bytes == 0 || bytes > POOL_MAX_BLOCK) return poisoned(out, bytes);
         const uint32_t c = class_of(bytes);
         {
             std::lock_guard<std::mutex> lk(mu);
             if (c < free_lists.size() && !free_lists[c].empty()) {
-                void* p = free_lists[c].back();
-                free_lists[c].pop_back();
-                cached -= class_bytes(c);
-                live[p] = c;
-                *out = p;
-                return hipSuccess;
+                // Reuse is in stream order only on the stream the block was freed under: the launches of a pipelined
+                // batch go to lane streams (batched.hip), so a block another stream gave back is passed over.
+                auto& fl = free_lists[c];
+                const hipStream_t cur = g.stream;
+                for (size_t k = fl.size(); k-- > 0;) {
+                    if (fl[k].freed_on != cur) continue;
+                    void* p = fl[k].p;
+                    fl.erase(fl.begin() + (ptrdiff_t)k);
+                    cached -= class_bytes(c);
+                    live[p] = c;
+                    *out = p;
+                    return hipSuccess;
+                }
+                cross_stream++;
+                static const bool dbg = getenv("ATLAS_POOL_DEBUG") != nullptr;
+                if (dbg) fprintf(stderr, "[atlas pool] class %u (%zu B): %zu cached block(s), none freed under the current stream\n", c, class_bytes(c), fl.size());
             }
         }
         void* p = nullptr;
@@ -66,12 +97,21 @@ struct DevPool {
         {
             std::lock_guard<std::mutex> lk(mu);
             auto it = live.find(p);
+            if (it == live.end()) {               // not handed out by the pool: a block of the pool freed twice must not reach hipFree
+                for (auto& l : free_lists)
+                    for (auto& b : l)
+                        if (b.p == p) {
+                            double_free++;
+                            fprintf(stderr, "[atlas pool] block %p freed twice (ignored)\n", p);
+                            return hipSuccess;
+                        }
+            }
             if (it != live.end()) {
                 const uint32_t c = it->second;
                 live.erase(it);
                 if (cached + class_bytes(c) <= POOL_MAX_CACHED) {
                     if (free_lists.size() <= c) free_lists.resize(c + 1);
-                    free_lists[c].push_back(p);
+                    free_lists[c].push_back(FreeBlock{p, g.stream});
                     cached += class_bytes(c);
                     return hipSuccess;
                 }
@@ -83,7 +123,7 @@ struct DevPool {
         std::vector<void*> all;
         {
             std::lock_guard<std::mutex> lk(mu);
-            for (auto& l : free_lists) { all.insert(all.end(), l.begin(), l.end()); l.clear(); }
+            for (auto& l : free_lists) { for (auto& b : l) all.push_back(b.p); l.clear(); }
             cached = 0;
         }
         for (void* p : all) (void)hipFree(p);

@@ -513,6 +513,9 @@ int msm_device_multi(const G1Affine* bases, const Fr* d_scalars, size_t n_tot, s
             HIP_TRY(hipEventCreateWithFlags(&side_event, hipEventDisableTiming));
         }
         HIP_TRY(hipEventRecord(side_event, g.stream));
+        // ... and the host waits for the library stream as well: the event alone did not order a side stream behind the
+        // library stream reliably when the two share a hardware queue (see Pipeline::begin in batched.hip)
+        HIP_TRY(hipStreamSynchronize(g.stream));
     }
     auto drain = [&]() { if (side_stream) { hipStreamSynchronize(side_stream); hipStreamSynchronize(side_stream2); } hipStreamSynchronize(g.stream); };
     int rc = ATLAS_OK;

@@ -18,5 +18,6 @@ for rep in range(int(os.environ.get("REPS", "4"))):
     pf, cl, st = NODE.prove_einsum_node(tA, tB, m, k, n, S, r0, tn)
     A.sync(); dt = time.perf_counter() - t0
     states.add(tn.state)
+    if os.environ.get("PRINT_STATE"): print("state", bytes(tn.state).hex()[:32] if not isinstance(tn.state, str) else tn.state[:32])
     print("node %.3f ms  " % (1e3 * dt) + "  ".join("%s %.2f" % (a, b) for a, b in zip(names, st)), flush=True)
 assert len(states) == 1
