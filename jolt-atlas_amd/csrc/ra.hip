@@ -111,62 +111,11 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_prod_f9_col(const Fr* __restr
     mail_tail(partials, tail);
 }
 
-// The last rounds of an instance (rows of at most RA_SMALL_LEN coefficients): the bind of the round before and the product
-// grid in ONE workgroup of D wavefronts.  Wavefront k takes grid column k; S = 2 or 4 lanes share a pair, each multiplies
-// D / S of the lines and the partial products meet through shuffles, so the chain of a round is D / S + log2 S
-// multiplications instead of D (the number of multiplications per pair, and with it the 32^-(D+1) the sums carry, does not
-// change: D + 2 factors take D + 1 products in any order).  The bound rows pass through LDS, the D sums are mailed by the
-// workgroup itself: no partial sums in HBM, no arrival counter, one launch per round instead of two.
-constexpr uint32_t RA_SMALL_LEN = 64;
-template <int D>
-__global__ __launch_bounds__(D * 64) void k_ra_bind_prod_small(const Fr* __restrict__ src, size_t src_stride, Fr* __restrict__ dst,
-                                                               uint32_t len /* = stride of dst */, SplitEqView E, ChanIo io, int r_hi_only) {
-    using P9 = Fr9Params;
-    __shared__ Fr rows[D * RA_SMALL_LEN];
-    __shared__ F9 red9[D];
-    __shared__ uint32_t stage[9 * 16];
-    Fr r;
-    if (!io.challenge(r)) return;
-    for (uint32_t e = threadIdx.x; e < D * len; e += D * 64) {
-        const uint32_t i = e / len, j = e % len;
-        const Fr* sp = src + (size_t)i * src_stride + 2 * j;
-        const Fr v = bind_pair(fe_load(sp), fe_load(sp + 1), r, r_hi_only != 0);
-        rows[i * RA_SMALL_LEN + j] = v;
-        fe_store(dst + (size_t)i * len + j, v);
-    }
-    __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, k = threadIdx.x >> 6, n_groups = len / 2;
-    uint32_t S = 64 / n_groups;                          // lanes per pair: a power of two, at most 4 and at most D
-    if (S > 4) S = 4;
-    while (S > (uint32_t)D) S >>= 1;
-    const uint32_t pair = lane / S, sub = lane % S;
-    const bool active = pair < n_groups;
-    F9 prod = f9_zero();
-    if (active) {
-        const uint32_t i0 = D * sub / S, i1 = D * (sub + 1) / S;
-        bool have = sub == 0;
-        if (have) prod = f9_mul<P9>(f9_load(E.e_out + (pair >> E.in_bits)), f9_load(E.e_in + (pair & ((1u << E.in_bits) - 1))));
-#pragma unroll 1
-        for (uint32_t i = i0; i < i1; i++) {
-            const F9 x0 = f9_from_fe(rows[i * RA_SMALL_LEN + 2 * pair]), x1 = f9_from_fe(rows[i * RA_SMALL_LEN + 2 * pair + 1]);
-            const F9 dl = f9_norm_red<P9, 2>(f9_sub<P9>(x1, x0));
-            const F9 val = k == D - 1 ? dl : f9_axpy_small(x0, dl, k + 1);      // column D-1: X -> inf; else p_i(k + 1), lazy
-            prod = have ? f9_mul<P9>(prod, val) : val;
-            have = true;
-        }
-    }
-    for (uint32_t m = 1; m < S; m <<= 1) prod = f9_mul<P9>(prod, f9_shfl_xor(prod, (int)m));   // every sub-lane ends with the whole product
-    if (!active || sub != 0) prod = f9_zero();
-    const F9 sres = f9_wave_sum<P9>(prod);
-    if (lane == 0) red9[k] = sres;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        Fr sum = fe_zero();
-        if (threadIdx.x < D) sum = f9_canon<P9>(red9[threadIdx.x]);
-        ch_mail_wave_fe(io.io, 0, D, sum, stage);
-    }
-}
-
+// (Measured and removed: the last rounds — rows of at most 64 coefficients — as ONE workgroup per round that binds, multiplies
+// with 2 or 4 lanes sharing a pair, and mails, for RaVirtual and for the booleanity fold.  No gain for RaVirtual (0.267 against
+// 0.272 ms at d = 16, T = 2^6; the Einsum node unchanged) and 20-30 % slower for booleanity (0.32 against 0.25 ms): sixteen
+// wavefronts in one workgroup leave 128 registers per lane for the f9_mul chains, and the round is bounded by the two host
+// link crossings, not by the second launch.)
 // booleanity phase 2 (booleanity.rs:254-276): per pair index j
 //   c = sum_i gamma_i h0 (h0 - 1),  e = sum_i gamma_i (h1 - h0)^2, folded with E_out * E_in
 // on the 29-bit lazy limbs: h0 - 1 and h1 - h0 enter their products unreduced (the lazy operand of f9_mul), the row
@@ -239,17 +188,6 @@ int launch_prod_d(size_t d, const Fr* buf, size_t stride, Fr* partials, const Sp
     return ATLAS_OK;
 }
 
-int launch_bind_prod_small(size_t d, const Fr* src, size_t src_stride, Fr* dst, uint32_t len, const SplitEqView& E, const ChanIo& io, int hi_only) {
-    switch (d) {
-#define RA_CASE(D) case D: k_ra_bind_prod_small<D><<<1, D * 64, 0, g.stream>>>(src, src_stride, dst, len, E, io, hi_only); break;
-        RA_CASE(1) RA_CASE(2) RA_CASE(3) RA_CASE(4) RA_CASE(5) RA_CASE(6) RA_CASE(7) RA_CASE(8)
-        RA_CASE(9) RA_CASE(10) RA_CASE(11) RA_CASE(12) RA_CASE(13) RA_CASE(14) RA_CASE(15) RA_CASE(16)
-#undef RA_CASE
-        default: return fail(ATLAS_EINVAL, "ra_virtual: d > 16");
-    }
-    return ATLAS_OK;
-}
-
 // ---------------------------------------------------------------- RaSumcheckProver
 struct RaVirtual : atlas_instance {
     RaRows rows;
@@ -301,24 +239,14 @@ struct RaVirtual : atlas_instance {
         if (round >= log_T || (round > 0) != bind_prev) return fail(ATLAS_ESTATE, "ra_virtual: enqueue out of order");
         const size_t T = (size_t)1 << log_T, len = T >> round, n_groups = len / 2;
         const ChanIo cio{io, g.challenge_mode};
-        size_t ot, it;
-        eq.st.tops_after(round, ot, it);
-        static const bool no_small = getenv("ATLAS_RA_NO_SMALL") != nullptr;     // experiments: the two-launch rounds throughout
-        if (bind_prev && len <= RA_SMALL_LEN && !no_small) {                      // the last rounds: one workgroup binds, multiplies and mails
-            int rc = launch_bind_prod_small(rows.d, rows.buf[(round - 1) & 1], T >> (round - 1), rows.buf[round & 1], (uint32_t)len, eq.view_at(ot, it), cio,
-                                            g.challenge_mode == 0 ? 1 : 0);
-            if (rc) return rc;
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess) return fail(ATLAS_ENODEV, "ra_virtual: launch", e);
-            mail.base = io.mail; mail.blocks = 1; mail.n_vals = (int)rows.d; mail.radix = 32; mail.shl = 0;
-            return ATLAS_OK;
-        }
         if (bind_prev) {
             size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
             k_ra_bind_ch<<<dim3((unsigned)gb, (unsigned)rows.d), RA_THREADS, 0, g.stream>>>(rows.buf[(round - 1) & 1], T >> (round - 1), rows.buf[round & 1], len, len,
                                                                                           cio, g.challenge_mode == 0 ? 1 : 0);
         }
         const unsigned blocks = (unsigned)((n_groups + RA_THREADS - 1) / RA_THREADS);
+        size_t ot, it;
+        eq.st.tops_after(round, ot, it);
         int rc = launch_prod_d(rows.d, rows.buf[round & 1], len, rows.partials, eq.view_at(ot, it), n_groups, blocks, MailTail{io, rows.d_counter, 0, 0});
         if (rc) return rc;
         hipError_t e = hipGetLastError();
