@@ -370,3 +370,47 @@ def test_standard_node_matches_oracle_composition(atlas, op, n_ops, log_T):
     assert t_g.state == t.state_bytes()
     for x in tens:
         x.free()
+
+
+def test_nodes_repeat_bit_for_bit(atlas):
+    """Twelve runs of the ReLU and the Einsum node give one transcript state each: the lanes of the batched one-hot checks
+    run on streams of their own, and an ordering slip between them and the library stream shows up as a changed proof
+    (seen in bench.py before the lane streams were synchronised from the host)."""
+    from jolt_atlas_amd import node as NODE
+    A = atlas
+    rng = np.random.default_rng(77)
+    x = A.TensorI32(rng.integers(-(1 << 14), 1 << 14, size=1 << 12, dtype=np.int64).astype(np.int32))
+    ta = A.TensorI32(rng.integers(-(1 << 14), 1 << 14, size=(4, 64), dtype=np.int64).astype(np.int32))
+    tb = A.TensorI32(rng.integers(-(1 << 14), 1 << 14, size=(64, 256), dtype=np.int64).astype(np.int32))
+    r12, r10 = A.random_fr(12, 5), A.random_fr(10, 6)
+    relu, eins = set(), set()
+    for _ in range(12):
+        t = A.Blake2bTranscript(b"repeat_relu")
+        NODE.prove_relu_node(x, 12, r12, t)
+        relu.add(bytes(t.state))
+        t = A.Blake2bTranscript(b"repeat_einsum")
+        NODE.prove_einsum_node(ta, tb, 4, 64, 256, 14, r10, t)
+        eins.add(bytes(t.state))
+    x.free(); ta.free(); tb.free()
+    assert len(relu) == 1 and len(eins) == 1
+
+
+def test_node_does_not_read_uninitialised_device_memory():
+    """The Einsum node in a child process whose device allocations are pre-filled (ATLAS_POOL_POISON, devpool.hpp) ends in the
+    same transcript state as an unpoisoned child."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    states = set()
+    for fill in (None, "165", "255"):
+        env = dict(os.environ, PRINT_STATE="1", REPS="1")
+        env.pop("ATLAS_POOL_POISON", None)
+        if fill:
+            env["ATLAS_POOL_POISON"] = fill
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "time_node.py")], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("state ")]
+        assert line, out.stdout[-2000:]
+        states.add(line[-1])
+    assert len(states) == 1, states

@@ -23,4 +23,4 @@ for l in 20 22 24; do LOG_N=$l timeout 300 python tools/time_open_tab.py; done >
 for x in exp_channel exp_channel2 exp_hostread; do
   timeout 200 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/$x.hip -o /tmp/$x 2> /tmp/$x.build.log && timeout 120 /tmp/$x > $O/r02_$x.txt 2>&1
 done
-tail -3 $O/${TAG}_small_instances.txt $O/${TAG}_hyperkzg_open.txt $O/${TAG}_node_einsum.txt
+for f in small_instances hyperkzg_open node_einsum; do tail -n 3 $O/${TAG}_$f.txt; done
