@@ -101,7 +101,7 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_q_lds(const uint64_t* __restr
 // word sums -> canonical Montgomery residues: V = lo + hi 2^256, V mod p = lo * R * R^-1 + hi * R^2 * R^-1
 // A workgroup takes 4 values (32 words): thread (word, part) adds every 8th slab, the 8 parts meet in LDS.
 // pub.host_dst != null: the residues also go to pinned host memory and the last workgroup to arrive writes the tag the
-// host waits for (k_ps_q_publish fused; pub.counter is zero on entry and left zero).
+// host waits for (pub.counter is zero on entry and left zero).
 struct QPublish { Fr* host_dst; Chunk* tag_chunk; uint32_t tag; uint32_t* counter; };
 __global__ __launch_bounds__(RA_THREADS) void k_ps_q_final(const unsigned long long* __restrict__ acc, uint32_t n_slabs, uint32_t n_vals, Fr* __restrict__ out,
                                                            QPublish pub) {
@@ -583,7 +583,7 @@ struct PsLookup : atlas_instance {
     // ---- round-channel stepping (instance.hpp).  Address rounds are host arithmetic and launch nothing, except the first
     // round of a phase: the finished phase's expanding table is rebuilt on the device from its challenge slots (d_v holds two
     // tables of m entries, used alternately), the products are scaled by it and the new phase's Q is built; Q travels to the
-    // host through pinned memory (k_ps_q_publish) and is picked up by that round's finish().  Cycle round c has ra in buf[c & 1].
+    // host through pinned memory (k_ps_q_final's QPublish) and is picked up by that round's finish().  Cycle round c has ra in buf[c & 1].
     struct QBox { const volatile atlas::Chunk* tagc = nullptr; const H::Fr* data = nullptr; uint32_t tag = 0; };
     std::vector<QBox> qbox;
     PsSlots slots{};
