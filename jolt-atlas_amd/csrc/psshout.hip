@@ -379,6 +379,7 @@ struct PsLookup : atlas_instance {
         return ATLAS_OK;
     }
     // prover_msg_read_checking (mod.rs:337-460): host arithmetic over the phase's 2^log_m-entry tables
+    std::vector<H::Fr> sum_tmp;            // scratch of address_message's per-bit sums
     int address_message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) {
         {
             const size_t j = round, p = j / log_m, half = Q[0].size() / 2;
@@ -421,18 +422,25 @@ struct PsLookup : atlas_instance {
                         }
                         // sum and weighted sum of table k over the bins [off, off + half) whose high bits are all `want`
                         auto sums = [&](size_t k, size_t off, int want, const H::Fr* w, H::Fr& tot, H::Fr& wtot) {
-                            H::Fr bs[16];
-                            for (size_t i = 0; i < blen; i++) bs[i] = H::zero();
-                            tot = H::zero();
-                            for (size_t b = 0; b < half; b++) {
-                                if (want == 0 && (b & mhigh)) continue;
-                                if (want == 1 && (b & mhigh) != mhigh) continue;
-                                const H::Fr& q = Q[k][off + b];
-                                tot = H::add(tot, q);
-                                if (w) for (size_t x = b; x; x &= x - 1) { const int bit = __builtin_ctzll(x); bs[bit] = H::add(bs[bit], q); }
-                            }
+                            const auto keep = [&](size_t b) { return want < 0 || (want == 0 ? (b & mhigh) == 0 : (b & mhigh) == mhigh); };
                             wtot = H::zero();
-                            if (w) for (size_t i = 0; i < blen; i++) wtot = H::add(wtot, H::mul(w[i], bs[i]));
+                            if (!w) {
+                                tot = H::zero();
+                                for (size_t b = 0; b < half; b++) if (keep(b)) tot = H::add(tot, Q[k][off + b]);
+                                return;
+                            }
+                            // per-bit sums by halving: the sum over the bins with bit i set is the sum of the upper half of
+                            // the array once the bits above i have been folded away — 2 * half additions in all instead of
+                            // half * (1 + blen / 2)
+                            sum_tmp.resize(half);
+                            for (size_t b = 0; b < half; b++) sum_tmp[b] = keep(b) ? Q[k][off + b] : H::zero();
+                            for (size_t i = blen; i-- > 0;) {
+                                const size_t h = (size_t)1 << i;
+                                H::Fr up = H::zero();
+                                for (size_t x = 0; x < h; x++) { up = H::add(up, sum_tmp[x + h]); sum_tmp[x] = H::add(sum_tmp[x], sum_tmp[x + h]); }
+                                wtot = H::add(wtot, H::mul(w[i], up));
+                            }
+                            tot = sum_tmp[0];
                         };
                         for (int hf = 0; hf < 2; hf++) {
                             const size_t off = hf ? half : 0;
