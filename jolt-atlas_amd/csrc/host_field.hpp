@@ -76,7 +76,8 @@ inline Fr mul_sos(const Fr& a, const Fr& b) {          // the old form, kept as 
     if (t[8] || geq_p(o.l)) sub_p(o.l);
     return o;
 }
-inline Fr mul(const Fr& a, const Fr& b) {
+template <int FIRST>
+inline Fr mul_from(const Fr& a, const Fr& b) {
     uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
     const uint64_t b0 = b.l[0], b1 = b.l[1], b2 = b.l[2], b3 = b.l[3];
     const uint64_t p0 = FR_P[0], p1 = FR_P[1], p2 = FR_P[2], p3 = FR_P[3];
@@ -94,12 +95,18 @@ inline Fr mul(const Fr& a, const Fr& b) {
         c += (u128)m * p3 + t3; t2 = (uint64_t)c; c >>= 64;                            \
         c += t4n; t3 = (uint64_t)c; t4 = (uint64_t)(c >> 64);                          \
     } while (0)
-    ATLAS_CIOS_STEP(a.l[0]); ATLAS_CIOS_STEP(a.l[1]); ATLAS_CIOS_STEP(a.l[2]); ATLAS_CIOS_STEP(a.l[3]);
+    if (!(FIRST == 2)) { ATLAS_CIOS_STEP(a.l[0]); ATLAS_CIOS_STEP(a.l[1]); }
+    ATLAS_CIOS_STEP(a.l[2]); ATLAS_CIOS_STEP(a.l[3]);
 #undef ATLAS_CIOS_STEP
     Fr o{{t0, t1, t2, t3}};
     if (t4 || geq_p(o.l)) sub_p(o.l);
     return o;
 }
+inline Fr mul(const Fr& a, const Fr& b) { return mul_from<0>(a, b); }
+// a * b for a left operand whose two low limbs are zero — a MontU128Challenge as challenge_to_fr(.., 0) returns it: the
+// first two CIOS steps leave the accumulator at zero (a_i = 0, so m = 0), skipping them is exact and halves the work
+inline Fr mul_hi2(const Fr& a, const Fr& b) { return mul_from<2>(a, b); }
+inline Fr mul_challenge(const Fr& r, const Fr& x) { return (r.l[0] | r.l[1]) == 0 ? mul_hi2(r, x) : mul(r, x); }
 inline Fr from_canonical(const uint64_t c[4]) { Fr t{{c[0], c[1], c[2], c[3]}}; Fr r2{{FR_R2[0], FR_R2[1], FR_R2[2], FR_R2[3]}}; return mul(t, r2); }
 inline Fr from_u64(uint64_t v) { uint64_t c[4] = {v, 0, 0, 0}; return from_canonical(c); }
 inline void to_canonical(const Fr& a, uint64_t c[4]) { Fr o = mul(a, Fr{{1, 0, 0, 0}}); std::memcpy(c, o.l, 32); }

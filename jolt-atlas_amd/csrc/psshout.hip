@@ -519,7 +519,7 @@ struct PsLookup : atlas_instance {
             const size_t j = round, p = j / log_m;
             const size_t half = Q[0].size() / 2;
             for (auto& q : Q) {                                       // suffix polys bind HighToLow
-                for (size_t i = 0; i < half; i++) q[i] = H::add(q[i], H::mul(rf, H::sub(q[i + half], q[i])));
+                for (size_t i = 0; i < half; i++) q[i] = H::add(q[i], H::mul_challenge(rf, H::sub(q[i + half], q[i])));   // (two CIOS steps for a 128-bit challenge)
                 q.resize(half);
             }
             if (with_device) {

@@ -24,6 +24,12 @@ int main() {
         if (H::geq_p(b.l)) H::sub_p(b.l);
         if (!(H::mul(a, b) == H::mul_sos(a, b))) bad++;
     }
+    // a sparse left operand (two low limbs zero: a 125-bit challenge in the upper half): the two-step form
+    for (int i = 0; i < 200000; i++) {
+        H::Fr r{{0, 0, rng(), rng() & 0x1fffffffffffffffULL}}, x{{rng(), rng(), rng(), rng() >> 2}};
+        if (H::geq_p(x.l)) H::sub_p(x.l);
+        if (!(H::mul_hi2(r, x) == H::mul(r, x)) || !(H::mul_challenge(r, x) == H::mul_sos(r, x)) || !(H::mul_challenge(x, r) == H::mul(x, r))) bad++;
+    }
     printf("mismatches %zu\n", bad);
     H::Fr a = H::from_u64(123456789), b = H::from_u64(987654321);
     auto t0 = std::chrono::steady_clock::now();
