@@ -711,6 +711,45 @@ int atlas_batched_sumcheck_verify(const atlas_fr_t *compressed, size_t row_strid
 int atlas_batched_sumcheck_check(const atlas_fr_t *batching_coeffs, const atlas_fr_t *expected_output_claims, size_t n_instances,
                                  const atlas_fr_t *output_claim);
 
+/* ---- the whole proof: ONNXProof::prove over a model graph resident in the library ---------
+ * The graph is the tracer's ComputationGraph (atlas-onnx-tracer/src/node/mod.rs:12-24: idx, operator, inputs, output_dims) in the
+ * tracer's operator vocabulary (atlas-onnx-tracer/src/ops/mod.rs:117-155).  Every dimension must be a power of two (the reference
+ * pads each dimension to the next power of two before it builds MLEs; a graph description pads its shapes up front).
+ * params / shape per operator:
+ *   INPUT, CONSTANT (constant = the tensor), IDENTITY, ADD, SUB, AND, IFF (mask, a, b), RELU, RESHAPE: none
+ *   MUL, SQUARE, CUBE: params[0] = scale (the fused rebase is by `scale` bits, 2 * scale for CUBE; fused_rebase.rs:71-79)
+ *   EINSUM: params[0] = ATLAS_EINSUM_* layout, params[1] = scale; shape = the layout's dims as atlas_einsum_fold takes them
+ *   MOVEAXIS: params[0] = source, params[1] = destination;  SLICE: params = axis, start, end;  BROADCAST: none (dims = target)
+ * Nodes are added in increasing index order; inputs name earlier nodes (the tracer's topological numbering). */
+enum { ATLAS_OP_INPUT = 0, ATLAS_OP_CONSTANT, ATLAS_OP_IDENTITY, ATLAS_OP_ADD, ATLAS_OP_SUB, ATLAS_OP_MUL, ATLAS_OP_SQUARE, ATLAS_OP_CUBE,
+       ATLAS_OP_AND, ATLAS_OP_IFF, ATLAS_OP_RELU, ATLAS_OP_EINSUM, ATLAS_OP_RESHAPE, ATLAS_OP_MOVEAXIS, ATLAS_OP_BROADCAST, ATLAS_OP_SLICE,
+       ATLAS_OP_CONCAT, ATLAS_OP_SUM, ATLAS_OP_SCALAR_CONST_DIV, ATLAS_OP_DIV, ATLAS_OP_MEAN_OF_SQUARES, ATLAS_OP_RSQRT, ATLAS_OP_SOFTMAX,
+       ATLAS_OP_TANH, ATLAS_OP_GATHER_LARGE, ATLAS_OP_GATHER_SMALL };
+typedef struct atlas_graph *atlas_graph_t;
+int atlas_graph_new(atlas_graph_t *out);
+int atlas_graph_free(atlas_graph_t g);
+int atlas_graph_add_node(atlas_graph_t g, size_t idx, int op, const size_t *inputs, size_t n_inputs, const size_t *dims, size_t n_dims,
+                         const int64_t *params, size_t n_params, const size_t *shape, size_t n_shape, const int32_t *constant);
+int atlas_graph_set_outputs(atlas_graph_t g, const size_t *idx, size_t n);
+size_t atlas_graph_num_nodes(atlas_graph_t g);
+/* Model::trace (atlas-onnx-tracer/src/model/trace.rs:8-21) on the device: one host tensor per Input node (ascending index);
+ * every node output stays in HBM together with the witness the prover derives from it (i64 accumulations, remainders,
+ * lookup indices: generate_node_witnesses, jolt-atlas-core/src/onnx_proof/witness.rs:136-200). */
+int atlas_graph_trace(atlas_graph_t g, const int32_t *const *inputs, size_t n_inputs);
+/* a traced node's output tensor (host_out == NULL: length query) */
+int atlas_graph_node_output(atlas_graph_t g, size_t idx, int32_t *host_out, size_t cap, size_t *len);
+/* ONNXProof::prove (jolt-atlas-core/src/onnx_proof/mod.rs:153-200): trace, append_inputs_to_transcript, commit_witness_polynomials,
+ * output_claim, iop (NodeEvalReduction + the operator provers in reverse node order), prove_reduced_openings, finalize.
+ * proof receives the ark-serialized ONNXProof (proof_serialization.rs:200-224: opening claims, proofs by ProofId, commitments,
+ * eval-reduction proofs, the reduced opening proof); proof == NULL: size query.  final_transcript (optional): the prover's
+ * transcript after the last append.  timing (optional): the stage split of the reference's tracing spans. */
+typedef struct {
+    double trace_ms, commit_ms, iop_ms, reduction_ms, hyperkzg_ms, total_ms;   /* reduction_ms excludes hyperkzg_ms */
+    size_t n_nodes, n_committed, n_sumchecks;
+} atlas_graph_timing_t;
+int atlas_prove_graph(atlas_graph_t g, atlas_srs_t srs, const int32_t *const *inputs, size_t n_inputs, uint8_t *proof, size_t cap,
+                      size_t *proof_len, atlas_transcript_t *final_transcript, atlas_graph_timing_t *timing);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,255 @@
+// Quantised model execution on the device: Model::trace (atlas-onnx-tracer/src/model/trace.rs:8-21 ->
+// execute.rs) for the operators the proving graph knows — every node's Tensor<i32> output stays in HBM, and the nodes
+// that fuse a rescale keep their i64 accumulation / remainder / lookup indices (the witness of f1) from the same pass.
+// Operator semantics follow atlas-onnx-tracer/src/ops/*.rs (cited per kernel).  Tensors are row-major; every dimension
+// must be a power of two (the reference pads each dimension to the next power of two before building MLEs,
+// tensor/mod.rs:474-481 — a graph description pads its shapes up front, e.g. vocab 65 -> 128).
+#include <hip/hip_runtime.h>
+
+#include "graph_state.hip.h"
+
+using gr::Node;
+
+namespace {
+
+constexpr int MAXR = 6;
+struct Strides { uint32_t n; uint32_t dim[MAXR]; uint32_t a[MAXR]; uint32_t b[MAXR]; };
+
+// acc[o] = sum_{l<K} L[loff(o) + l lsk] R[roff(o) + l rsk] in i64: einsum_acc_i64 (ops/einsum.rs:34-213) for the layouts with one
+// contraction axis; o runs over the output dims (row-major), S.a / S.b = each output axis' stride in the left / right operand
+__global__ __launch_bounds__(256) void k_einsum_acc_generic(const int32_t* __restrict__ L, const int32_t* __restrict__ R, Strides S, uint32_t K, uint32_t lsk,
+                                                            uint32_t rsk, size_t T, int64_t* __restrict__ acc) {
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < T; o += (size_t)gridDim.x * 256) {
+        size_t rem = o, lo = 0, ro = 0;
+        for (int d = (int)S.n - 1; d >= 0; d--) { const size_t c = rem % S.dim[d]; rem /= S.dim[d]; lo += c * S.a[d]; ro += c * S.b[d]; }
+        int64_t s = 0;
+        for (uint32_t l = 0; l < K; l++) s += (int64_t)L[lo + (size_t)l * lsk] * (int64_t)R[ro + (size_t)l * rsk];
+        acc[o] = s;
+    }
+}
+// Cube accumulators x^3 (ops/cube.rs:33-46)
+__global__ __launch_bounds__(256) void k_cube_acc(const int32_t* __restrict__ x, size_t n, int64_t* __restrict__ acc) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { const int64_t v = x[i]; acc[i] = v * v * v; }
+}
+// And = a * b, Iff = mask * a + (1 - mask) * b on 0/1 masks (tensor/ops.rs:42-71, 206-257)
+__global__ __launch_bounds__(256) void k_select(int op, const int32_t* __restrict__ a, const int32_t* __restrict__ b, const int32_t* __restrict__ c, size_t n,
+                                                int32_t* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = op == ATLAS_OP_AND ? a[i] * b[i] : (a[i] ? b[i] : c[i]);
+}
+// out[o] = in[sum_d coord_d(o) stride_d]: MoveAxis, Broadcast (stride 0 on expanded axes), Slice (with a base offset)
+__global__ __launch_bounds__(256) void k_gather_strided(const int32_t* __restrict__ in, Strides S, size_t base, size_t T, int32_t* __restrict__ out) {
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < T; o += (size_t)gridDim.x * 256) {
+        size_t rem = o, off = base;
+        for (int d = (int)S.n - 1; d >= 0; d--) { off += (rem % S.dim[d]) * S.a[d]; rem /= S.dim[d]; }
+        out[o] = in[off];
+    }
+}
+
+unsigned grid_for(size_t n) { size_t b = (n + 255) / 256; return (unsigned)(b > 4096 ? 4096 : b ? b : 1); }
+
+std::vector<size_t> row_major(const std::vector<size_t>& dims) {
+    std::vector<size_t> s(dims.size(), 1);
+    for (int d = (int)dims.size() - 2; d >= 0; d--) s[d] = s[d + 1] * dims[d + 1];
+    return s;
+}
+
+}  // namespace
+
+// the output strides of the two einsum operands for the layouts of ops/einsum/mod.rs:137-153 (dims as atlas_einsum_fold takes them)
+int atlas_rt_einsum_strides(int layout, const std::vector<size_t>& d, std::vector<size_t>& out_dims, std::vector<size_t>& la, std::vector<size_t>& ra, size_t& K,
+                            size_t& lsk, size_t& rsk) {
+    switch (layout) {
+        case ATLAS_EINSUM_MK_KN_MN: { if (d.size() != 3) return ATLAS_EINVAL; const size_t m = d[0], k = d[1], n = d[2]; out_dims = {m, n}; la = {k, 0}; ra = {0, 1}; K = k; lsk = 1; rsk = n; return 0; }
+        case ATLAS_EINSUM_BMK_BKN_MBN: { if (d.size() != 4) return ATLAS_EINVAL; const size_t b = d[0], m = d[1], k = d[2], n = d[3]; out_dims = {m, b, n}; la = {k, m * k, 0}; ra = {0, k * n, 1}; K = k; lsk = 1; rsk = n; return 0; }
+        case ATLAS_EINSUM_BMK_KBN_MBN: { if (d.size() != 4) return ATLAS_EINVAL; const size_t b = d[0], m = d[1], k = d[2], n = d[3]; out_dims = {m, b, n}; la = {k, m * k, 0}; ra = {0, n, 1}; K = k; lsk = 1; rsk = b * n; return 0; }
+        case ATLAS_EINSUM_MBK_BNK_BMN: { if (d.size() != 4) return ATLAS_EINVAL; const size_t b = d[0], m = d[1], k = d[2], n = d[3]; out_dims = {b, m, n}; la = {k, b * k, 0}; ra = {n * k, 0, k}; K = k; lsk = 1; rsk = 1; return 0; }
+        case ATLAS_EINSUM_MBK_NBK_BMN: { if (d.size() != 4) return ATLAS_EINVAL; const size_t b = d[0], m = d[1], k = d[2], n = d[3]; out_dims = {b, m, n}; la = {k, b * k, 0}; ra = {k, 0, b * k}; K = k; lsk = 1; rsk = 1; return 0; }
+        case ATLAS_EINSUM_K_NK_N: { if (d.size() != 2) return ATLAS_EINVAL; const size_t k = d[0], n = d[1]; out_dims = {n}; la = {0}; ra = {k}; K = k; lsk = 1; rsk = 1; return 0; }
+        default: return ATLAS_EINVAL;
+    }
+}
+
+// i64 accumulators of an Einsum node into d_acc (library stream; the caller holds g.mu)
+int atlas_rt_einsum_acc(const Node& nd, const int32_t* L, const int32_t* R, int64_t* d_acc) {
+    std::vector<size_t> od, la, ra; size_t K, lsk, rsk;
+    if (atlas_rt_einsum_strides((int)nd.p[0], nd.shape, od, la, ra, K, lsk, rsk)) return fail(ATLAS_EINVAL, "graph: einsum layout / dims");
+    Strides S{}; S.n = (uint32_t)od.size();
+    size_t T = 1;
+    for (size_t i = 0; i < od.size(); i++) { S.dim[i] = (uint32_t)od[i]; S.a[i] = (uint32_t)la[i]; S.b[i] = (uint32_t)ra[i]; T *= od[i]; }
+    k_einsum_acc_generic<<<grid_for(T), 256, 0, g.stream>>>(L, R, S, (uint32_t)K, (uint32_t)lsk, (uint32_t)rsk, T, d_acc);
+    return ATLAS_OK;
+}
+
+namespace {
+
+int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs, size_t& next_input) {
+    const size_t T = gr::padded_len(nd.dims);
+    DevBuf& out = G.out[nd.idx];
+    auto in = [&](size_t i) -> const int32_t* { return G.tensor(nd.inputs[i]); };
+    auto in_node = [&](size_t i) -> const Node& { return G.nodes.at(nd.inputs[i]); };
+    for (size_t i = 0; i < nd.inputs.size(); i++) if (!in(i)) return fail(ATLAS_ESTATE, "graph_trace: operand not executed yet (nodes must be in topological index order)");
+    auto need_inputs = [&](size_t n) { return nd.inputs.size() == n; };
+    auto same_len = [&]() { for (size_t i = 0; i < nd.inputs.size(); i++) if (gr::padded_len(in_node(i).dims) != T) return false; return true; };
+    if (nd.op != ATLAS_OP_EINSUM && nd.op != ATLAS_OP_MUL && nd.op != ATLAS_OP_SQUARE && nd.op != ATLAS_OP_CUBE) HIP_TRY(out.alloc(T * 4));
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    switch (nd.op) {
+        case ATLAS_OP_INPUT:
+            HIP_TRY(hipMemcpyAsync(out.p, host_inputs[next_input++], T * 4, hipMemcpyHostToDevice, g.stream));
+            HIP_TRY(hipStreamSynchronize(g.stream));
+            return ATLAS_OK;
+        case ATLAS_OP_CONSTANT:
+            if (nd.constant.size() != T) return fail(ATLAS_EINVAL, "graph: constant length != padded shape");
+            HIP_TRY(hipMemcpyAsync(out.p, nd.constant.data(), T * 4, hipMemcpyHostToDevice, g.stream));
+            HIP_TRY(hipStreamSynchronize(g.stream));
+            return ATLAS_OK;
+        case ATLAS_OP_IDENTITY: case ATLAS_OP_RESHAPE:                       // same flat order when every dimension is a power of two
+            if (!need_inputs(1) || !same_len()) return fail(ATLAS_EINVAL, "graph: Identity / Reshape operand length");
+            HIP_TRY(hipMemcpyAsync(out.p, in(0), T * 4, hipMemcpyDeviceToDevice, g.stream));
+            return ATLAS_OK;
+        case ATLAS_OP_ADD: case ATLAS_OP_SUB: {                               // sat_binop (ops/mod.rs:263-274) + the clamp lookup's witness
+            if (!need_inputs(2) || !same_len()) return fail(ATLAS_EINVAL, "graph: Add / Sub need two operands of the output's shape");
+            NodeWitness& W = G.wit[nd.idx];
+            HIP_TRY(W.acc.alloc(T * 8)); HIP_TRY(W.cidx.alloc(T * 8)); HIP_TRY(W.acc_fr.alloc(T * sizeof(Fr)));
+            k_addsub_witness<<<grid_for(T), 256, 0, g.stream>>>(in(0), in(1), T, nd.op == ATLAS_OP_SUB, W.acc.as<int64_t>(), out.as<int32_t>(), W.cidx.as<uint64_t>());
+            k_i64_to_fr<<<grid_for(T), 256, 0, g.stream>>>(W.acc.as<int64_t>(), W.acc_fr.as<Fr>(), T);
+            return ATLAS_OK;
+        }
+        case ATLAS_OP_AND: case ATLAS_OP_IFF:
+            if (!need_inputs(nd.op == ATLAS_OP_AND ? 2 : 3) || !same_len()) return fail(ATLAS_EINVAL, "graph: And / Iff operands");
+            k_select<<<grid_for(T), 256, 0, g.stream>>>(nd.op, in(0), in(1), nd.op == ATLAS_OP_IFF ? in(2) : nullptr, T, out.as<int32_t>());
+            return ATLAS_OK;
+        case ATLAS_OP_RELU: {
+            if (!need_inputs(1) || !same_len()) return fail(ATLAS_EINVAL, "graph: ReLU operand");
+            NodeWitness& W = G.wit[nd.idx];
+            HIP_TRY(W.lookups.alloc(T * 8));
+            k_relu_witness<<<grid_for(T), 256, 0, g.stream>>>(in(0), T, out.as<int32_t>(), W.lookups.as<uint64_t>());
+            return ATLAS_OK;
+        }
+        case ATLAS_OP_MOVEAXIS: case ATLAS_OP_BROADCAST: case ATLAS_OP_SLICE: {
+            if (!need_inputs(1)) return fail(ATLAS_EINVAL, "graph: one operand expected");
+            const std::vector<size_t>& idims = in_node(0).dims;
+            std::vector<size_t> istr = row_major(idims);
+            Strides S{}; S.n = (uint32_t)nd.dims.size();
+            if (S.n > MAXR) return fail(ATLAS_EINVAL, "graph: rank > 6");
+            size_t base = 0;
+            for (size_t i = 0; i < nd.dims.size(); i++) S.dim[i] = (uint32_t)nd.dims[i];
+            if (nd.op == ATLAS_OP_MOVEAXIS) {                                 // tensor move_axis(source, destination): out axes = in axes with `source` moved to `destination`
+                const size_t src = (size_t)nd.p[0], dst = (size_t)nd.p[1], r = idims.size();
+                if (r != nd.dims.size() || src >= r || dst >= r) return fail(ATLAS_EINVAL, "graph: MoveAxis axes");
+                std::vector<size_t> perm;                                     // perm[out axis] = in axis
+                for (size_t a = 0; a < r; a++) if (a != src) perm.push_back(a);
+                perm.insert(perm.begin() + dst, src);
+                for (size_t a = 0; a < r; a++) { if (nd.dims[a] != idims[perm[a]]) return fail(ATLAS_EINVAL, "graph: MoveAxis output dims"); S.a[a] = (uint32_t)istr[perm[a]]; }
+            } else if (nd.op == ATLAS_OP_BROADCAST) {                         // Tensor::expand (tensor/mod.rs:1042-1100): trailing alignment
+                if (idims.size() > nd.dims.size()) return fail(ATLAS_EINVAL, "graph: Broadcast rank");
+                const size_t off = nd.dims.size() - idims.size();
+                for (size_t a = 0; a < nd.dims.size(); a++) {
+                    if (a < off) { S.a[a] = 0; continue; }
+                    const size_t id = idims[a - off];
+                    if (id != nd.dims[a] && id != 1) return fail(ATLAS_EINVAL, "graph: Broadcast dims");
+                    S.a[a] = id == nd.dims[a] ? (uint32_t)istr[a - off] : 0;
+                }
+            } else {                                                          // Slice { axis, start, end } (ops/slice.rs)
+                const size_t ax = (size_t)nd.p[0], st = (size_t)nd.p[1], en = (size_t)nd.p[2];
+                if (idims.size() != nd.dims.size() || ax >= idims.size() || en <= st || en > idims[ax] || nd.dims[ax] != en - st) return fail(ATLAS_EINVAL, "graph: Slice");
+                for (size_t a = 0; a < idims.size(); a++) S.a[a] = (uint32_t)istr[a];
+                base = st * istr[ax];
+            }
+            k_gather_strided<<<grid_for(T), 256, 0, g.stream>>>(in(0), S, base, T, out.as<int32_t>());
+            return ATLAS_OK;
+        }
+        case ATLAS_OP_EINSUM: case ATLAS_OP_MUL: case ATLAS_OP_SQUARE: case ATLAS_OP_CUBE: {
+            const size_t S = nd.op == ATLAS_OP_EINSUM ? (size_t)nd.p[1] : nd.op == ATLAS_OP_CUBE ? 2 * (size_t)nd.p[0] : (size_t)nd.p[0];      // rebase_bits (fused_rebase.rs:71-79)
+            if (S == 0 || S > 30) return fail(ATLAS_EINVAL, "graph: fused rescale needs 1 <= bits <= 30 (unfused building-block products are not modelled)");
+            if (!need_inputs(nd.op == ATLAS_OP_EINSUM || nd.op == ATLAS_OP_MUL ? 2 : 1)) return fail(ATLAS_EINVAL, "graph: operand count");
+            if (nd.op != ATLAS_OP_EINSUM && !same_len()) return fail(ATLAS_EINVAL, "graph: element-wise operands must have the output's shape");
+            NodeWitness& W = G.wit[nd.idx];
+            W.rescale.reset(new RescaleWitness());
+            auto fill = [&](int64_t* d_acc) -> int {
+                if (nd.op == ATLAS_OP_EINSUM) return atlas_rt_einsum_acc(nd, in(0), in(1), d_acc);
+                if (nd.op == ATLAS_OP_CUBE) k_cube_acc<<<grid_for(T), 256, 0, g.stream>>>(in(0), T, d_acc);
+                else k_mul_acc<<<grid_for(T), 256, 0, g.stream>>>(in(0), nd.op == ATLAS_OP_SQUARE ? in(0) : in(1), T, d_acc);
+                return ATLAS_OK;
+            };
+            int rc = make_rescale_witness(T, S, fill, nullptr, *W.rescale);
+            if (rc) return rc;
+            out.p = W.rescale->out_own.release();                             // the node output = SatClamp_i32(acc >> S)
+            W.rescale->d_output = out.as<int32_t>();
+            return ATLAS_OK;
+        }
+        default: return fail(ATLAS_EINVAL, "graph_trace: operator not supported by the device executor");
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int atlas_graph_new(atlas_graph_t* out) {
+    if (!out) return fail(ATLAS_EINVAL, "graph_new");
+    *out = new atlas_graph();
+    return ATLAS_OK;
+}
+int atlas_graph_free(atlas_graph_t G) { delete G; return ATLAS_OK; }
+
+int atlas_graph_add_node(atlas_graph_t G, size_t idx, int op, const size_t* inputs, size_t n_inputs, const size_t* dims, size_t n_dims, const int64_t* params,
+                         size_t n_params, const size_t* shape, size_t n_shape, const int32_t* constant) {
+    if (!G || (!inputs && n_inputs) || !dims || n_dims == 0 || n_dims > MAXR || (!params && n_params) || n_params > 6 || (!shape && n_shape))
+        return fail(ATLAS_EINVAL, "graph_add_node: null / out-of-range argument");
+    if (G->nodes.count(idx)) return fail(ATLAS_EINVAL, "graph_add_node: node index already present");
+    Node nd; nd.idx = idx; nd.op = op;
+    nd.inputs.assign(inputs, inputs + n_inputs);
+    nd.dims.assign(dims, dims + n_dims);
+    if (!gr::all_pow2(nd.dims)) return fail(ATLAS_EINVAL, "graph_add_node: every dimension must be a power of two (pad the model's shapes)");
+    for (size_t i = 0; i < n_inputs; i++) if (inputs[i] >= idx || !G->nodes.count(inputs[i])) return fail(ATLAS_EINVAL, "graph_add_node: inputs must name earlier nodes");
+    for (size_t i = 0; i < n_params; i++) nd.p[i] = params[i];
+    if (n_shape) nd.shape.assign(shape, shape + n_shape);
+    if (op == ATLAS_OP_CONSTANT) {
+        if (!constant) return fail(ATLAS_EINVAL, "graph_add_node: Constant without data");
+        nd.constant.assign(constant, constant + nd.numel());
+    }
+    G->nodes[idx] = std::move(nd);
+    G->clear_trace();
+    return ATLAS_OK;
+}
+
+int atlas_graph_set_outputs(atlas_graph_t G, const size_t* idx, size_t n) {
+    if (!G || !idx || n == 0) return fail(ATLAS_EINVAL, "graph_set_outputs");
+    for (size_t i = 0; i < n; i++) if (!G->nodes.count(idx[i])) return fail(ATLAS_EINVAL, "graph_set_outputs: unknown node");
+    G->outputs.assign(idx, idx + n);
+    return ATLAS_OK;
+}
+
+size_t atlas_graph_num_nodes(atlas_graph_t G) { return G ? G->nodes.size() : 0; }
+
+// Model::trace: inputs in the order of the graph's Input nodes (ascending index), each padded_len(dims) i32 on the host
+int atlas_graph_trace(atlas_graph_t G, const int32_t* const* inputs, size_t n_inputs) {
+    NEED_INIT();
+    if (!G || (!inputs && n_inputs)) return fail(ATLAS_EINVAL, "graph_trace: null argument");
+    if (n_inputs != G->input_nodes().size()) return fail(ATLAS_EINVAL, "graph_trace: one tensor per Input node expected");
+    for (size_t i = 0; i < n_inputs; i++) if (!inputs[i]) return fail(ATLAS_EINVAL, "graph_trace: null input tensor");
+    G->clear_trace();
+    size_t next = 0;
+    for (auto& kv : G->nodes) {
+        int rc = exec_node(*G, kv.second, inputs, next);
+        if (rc) { G->clear_trace(); return rc; }
+    }
+    G->traced = true;
+    return ATLAS_OK;
+}
+
+int atlas_graph_node_output(atlas_graph_t G, size_t idx, int32_t* host_out, size_t cap, size_t* len) {
+    if (!G || !len) return fail(ATLAS_EINVAL, "graph_node_output: null argument");
+    auto it = G->nodes.find(idx);
+    if (it == G->nodes.end() || !G->tensor(idx)) return fail(ATLAS_ESTATE, "graph_node_output: node not traced");
+    *len = gr::padded_len(it->second.dims);
+    if (!host_out) return ATLAS_OK;
+    if (cap < *len) return fail(ATLAS_EINVAL, "graph_node_output: buffer too small");
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    HIP_TRY(hipMemcpyAsync(host_out, G->tensor(idx), *len * 4, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return ATLAS_OK;
+}
+
+}  // extern "C"

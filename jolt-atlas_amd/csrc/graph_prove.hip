@@ -1,0 +1,559 @@
+// ONNXProof::prove for a graph resident in the library (SURVEY §2 C1/C3/C4/C13, §8 x1 + B1):
+//   Model::trace                         (graph_exec.hip, f3)
+//   append_inputs_to_transcript          (onnx_proof/mod.rs:90-122)
+//   commit_witness_polynomials           (prover.rs:71-87, witness.rs:136-200): BTreeMap<CommittedPoly> order
+//   output_claim                         (prover.rs:89-121)
+//   iop: nodes in reverse index order    (prover.rs:127-138): NodeEvalReduction::prove (ops/eval_reduction.rs:17-40) then the
+//                                        operator's own composition (ops/*.rs)
+//   prove_reduced_openings               (prover.rs:141-176)
+//   finalize_proof + serialize           (prover.rs:178-205, proof_serialization.rs:200-224)
+// Host glue over the library's instance provers; the O(T) work is in their kernels.  Every scalar the reference appends
+// to the ProverOpeningAccumulator is appended here in the same order under the same OpeningId.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "graph_state.hip.h"
+
+using gr::Node;
+using gr::OpeningId;
+using gr::Point;
+using gr::PolyId;
+
+int atlas_rt_einsum_strides(int layout, const std::vector<size_t>& d, std::vector<size_t>& out_dims, std::vector<size_t>& la, std::vector<size_t>& ra, size_t& K,
+                            size_t& lsk, size_t& rsk);
+
+namespace {
+
+double ms_between(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); }
+
+struct Prover : FlowSink {
+    atlas_graph& G;
+    atlas_srs_t srs;
+    atlas_transcript_t t;
+    H::Transcript& Tr;
+    std::map<OpeningId, gr::Opening> openings;            // ProverOpeningAccumulator::openings
+    std::map<size_t, gr::Opening> reduced;                // ::reduced_evaluations
+    std::map<PolyId, gr::Committed*> committed;           // polynomial_map (BTreeMap<CommittedPoly, _>)
+    std::map<gr::ProofId, std::vector<uint8_t>> proofs;
+    std::map<size_t, std::vector<H::Fr>> evalred;         // eval_reduction_proofs: h coefficients
+    uint64_t cur = 0;
+
+    Prover(atlas_graph& g_, atlas_srs_t s) : G(g_), srs(s), Tr(*reinterpret_cast<H::Transcript*>(&t)) {}
+
+    // ---- FlowSink
+    void virt(const OpeningId& id, const Point& point, const H::Fr& claim) override { openings[id] = gr::Opening{point, claim}; }
+    void sparse(uint8_t cp_var, size_t chunk, uint8_t sc, const Point& point, const H::Fr& claim) override {
+        const PolyId p = gr::comm(cp_var, cur, chunk);
+        openings[gr::oid(p, sc)] = gr::Opening{point, claim};
+        auto it = committed.find(p);
+        if (it != committed.end()) { it->second->opened = true; it->second->point = point; it->second->claim = claim; }    // sumchecks.insert: the last append wins
+    }
+    void proof(uint8_t proof_type, const uint8_t* bytes, size_t len) override { proofs[gr::ProofId{cur, proof_type}].assign(bytes, bytes + len); }
+
+    Out out() { Out O{nullptr, 0, 0, nullptr, 0, nullptr, 0, 0}; O.sink = this; O.node = cur; return O; }
+    // AccOpeningProvider::append_nodeio(Target::Input(pos), claim) at `point` (utils/opening_access.rs)
+    int append_nodeio(const Node& nd, size_t pos, const Point& point, const H::Fr& claim) {
+        Out O = out();
+        return O.append_virtual(Tr, gr::node_exec(gr::virt(gr::VP_NodeOutput, nd.inputs[pos]), nd.idx), point, claim);
+    }
+    const gr::Opening& red(const Node& nd) const { return reduced.at(nd.idx); }
+
+    // MultilinearPolynomial::from(tensor.padded_next_power_of_two()).evaluate(point) for device tensors
+    int eval_i32(const int32_t* const* tensors, size_t count, size_t T, const Point& point, H::Fr* out_) {
+        std::vector<atlas_poly_t> ps(count, nullptr);
+        int rc = ATLAS_OK;
+        for (size_t i = 0; i < count && !rc; i++) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(tensors[i]), T, &ps[i]);
+        if (!rc) rc = atlas_poly_evaluate_many(ps.data(), count, (const atlas_fr_t*)point.data(), point.size(), (atlas_fr_t*)out_);
+        for (auto p : ps) if (p) atlas_poly_free(p);
+        return rc;
+    }
+
+    // Sumcheck::prove of one instance; returns the challenges (as field elements, in drawing order) and the final claims
+    int run_single(atlas_instance_t inst, const H::Fr& claim, uint8_t proof_type, std::vector<H::Fr>& rs, std::vector<H::Fr>& fin) {
+        const size_t n = atlas_instance_num_rounds(inst), stride = atlas_instance_degree(inst) + 1;
+        std::vector<atlas_fr_t> rows(n * stride); std::vector<uint32_t> nco(n); std::vector<atlas_u128_t> ch(n);
+        int rc = atlas_instance_prove(inst, (const atlas_fr_t*)&claim, &t, rows.data(), stride, nco.data(), ch.data());
+        if (rc) return rc;
+        atlas_fr_t f[64]; size_t nf = 0;
+        rc = atlas_instance_final_claims(inst, f, 64, &nf);
+        if (rc) return rc;
+        fin.resize(nf); std::memcpy(fin.data(), f, nf * 32);
+        rs.resize(n);
+        for (size_t i = 0; i < n; i++) rs[i] = ch_fr(ch[i]);
+        Out O = out();
+        return O.put_proof(rows, stride, nco, n, proof_type);
+    }
+    static Point reversed(const std::vector<H::Fr>& rs) { return Point(rs.rbegin(), rs.rend()); }     // LITTLE_ENDIAN -> BIG_ENDIAN
+
+    // ---------------------------------------------------------------- commit_witness_polynomials
+    // get_committed_polynomials of every node (ops/*.rs) over the witness the trace left in HBM
+    int collect_committed() {
+        for (auto& kv : G.nodes) {
+            const Node& nd = kv.second;
+            NodeWitness& W = G.wit[nd.idx];
+            W.committed.clear();
+            const size_t T = gr::padded_len(nd.dims), log_T = gr::log2u(T);
+            auto chunks = [&](uint8_t cp, const uint64_t* d_lookups, size_t log_K) {
+                const size_t d = (log_K + 3) / 4;
+                for (size_t i = 0; i < d; i++) {
+                    gr::Committed c; c.id = gr::comm(cp, nd.idx, i); c.kind = 1; c.d_lookups = d_lookups; c.log_T = log_T; c.log_K = log_K; c.chunk = i;
+                    W.committed.push_back(c);
+                }
+            };
+            if (T == 1) continue;                                             // is_scalar: no committed polynomials
+            switch (nd.op) {
+                case ATLAS_OP_ADD: case ATLAS_OP_SUB: chunks(gr::CP_ClampRaD, W.cidx.as<uint64_t>(), 64); break;       // clamp_committed_polys
+                case ATLAS_OP_EINSUM: case ATLAS_OP_MUL: case ATLAS_OP_SQUARE: case ATLAS_OP_CUBE:                     // fused_rebase::committed_polys
+                    chunks(gr::CP_RescaleRemainderRaD, W.rescale->ridx.as<uint64_t>(), W.rescale->S);
+                    chunks(gr::CP_ClampRaD, W.rescale->cidx.as<uint64_t>(), 64);
+                    break;
+                case ATLAS_OP_RELU: chunks(gr::CP_NodeOutputRaD, W.lookups.as<uint64_t>(), 32); break;                 // ops/relu.rs
+                default: break;
+            }
+            for (auto& c : W.committed) committed[c.id] = &c;
+        }
+        return ATLAS_OK;
+    }
+    int commit_all() {
+        // one batched call per lookup family: the d chunk commitments of one lookup come out of one launch
+        for (auto& kv : G.wit) {
+            auto& cs = kv.second.committed;
+            for (size_t i = 0; i < cs.size();) {
+                size_t j = i;
+                while (j < cs.size() && cs[j].kind == 1 && cs[j].d_lookups == cs[i].d_lookups) j++;
+                if (cs[i].kind == 1) {
+                    std::vector<atlas_g1_affine_t> pts(j - i);
+                    int rc = atlas_commit_lookup_chunks(srs, cs[i].d_lookups, cs[i].log_T, cs[i].log_K, 4, pts.data());
+                    if (rc) return rc;
+                    for (size_t q = i; q < j; q++) cs[q].commitment = pts[q - i];
+                } else {
+                    int rc = atlas_msm_poly(srs, 0, cs[i].dense, &cs[i].commitment);
+                    if (rc) return rc;
+                    j = i + 1;
+                }
+                i = j;
+            }
+        }
+        for (auto& kv : committed) {                                          // transcript.append_serializable(commitment), BTreeMap order
+            uint8_t b[64], rev[64];
+            int rc = atlas_g1_to_bytes_uncompressed(&kv.second->commitment, b);
+            if (rc) return rc;
+            for (int i = 0; i < 64; i++) rev[i] = b[63 - i];
+            H::tr_append_bytes(Tr, rev, 64);
+        }
+        return ATLAS_OK;
+    }
+
+    // ---------------------------------------------------------------- output_claim (prover.rs:89-121)
+    int output_claim() {
+        const Node& nd = G.nodes.at(G.outputs[0]);
+        const size_t T = gr::padded_len(nd.dims), n = gr::log2u(T);
+        Point r(n);
+        for (size_t i = 0; i < n; i++) { uint64_t lo, hi; H::tr_challenge_u128(Tr, lo, hi); r[i] = H::challenge_to_fr(lo, hi, g.challenge_mode); }
+        H::Fr claim;
+        const int32_t* tp = G.tensor(nd.idx);
+        int rc = eval_i32(&tp, 1, T, r, &claim);
+        if (rc) return rc;
+        cur = nd.idx;
+        Out O = out();
+        return O.append_virtual(Tr, gr::node_exec(gr::virt(gr::VP_NodeOutput, nd.idx), nd.idx + 1), r, claim);
+    }
+
+    // ---------------------------------------------------------------- NodeEvalReduction::prove
+    int eval_reduction(const Node& nd) {
+        const size_t T = gr::padded_len(nd.dims), n = gr::log2u(T);
+        const OpeningId lo = gr::node_exec(gr::virt(gr::VP_NodeOutput, nd.idx), nd.idx), hi = gr::node_exec(gr::virt(gr::VP_NodeOutput, nd.idx), ~(uint64_t)0);
+        std::vector<atlas_fr_t> pts, cls;
+        size_t N = 0;
+        for (auto it = openings.lower_bound(lo); it != openings.end() && !(hi < it->first); ++it) {
+            if (it->second.point.size() != n) return fail(ATLAS_ESTATE, "prove_graph: an opening of a node output has the wrong number of variables");
+            const size_t o = pts.size(); pts.resize(o + n);
+            if (n) std::memcpy(&pts[o], it->second.point.data(), n * 32);
+            atlas_fr_t c; std::memcpy(&c, &it->second.claim, 32); cls.push_back(c);
+            N++;
+        }
+        if (N == 0) return fail(ATLAS_ESTATE, "prove_graph: a node output without opening claims (every node must reach the output)");
+        atlas_poly_t mle = nullptr;
+        int rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(G.tensor(nd.idx)), T, &mle);
+        if (rc) return rc;
+        std::vector<atlas_fr_t> h(n * (N - 1) + 2), r(n ? n : 1);
+        size_t h_len = 0; atlas_fr_t claim;
+        rc = atlas_eval_reduction_prove(mle, pts.data(), cls.data(), N, n, &t, h.data(), h.size(), &h_len, r.data(), &claim);
+        atlas_poly_free(mle);
+        if (rc) return rc;
+        std::vector<H::Fr>& hv = evalred[nd.idx];
+        hv.resize(h_len); std::memcpy(hv.data(), h.data(), h_len * 32);
+        gr::Opening& R = reduced[nd.idx];
+        R.point.resize(n); if (n) std::memcpy(R.point.data(), r.data(), n * 32);
+        std::memcpy(&R.claim, &claim, 32);
+        return ATLAS_OK;
+    }
+
+    // ---------------------------------------------------------------- operators
+    // Add / Sub (ops/add.rs:70-105): prove_clamp_lookup over the i64 accumulation, then the operand tie
+    int op_addsub(const Node& nd) {
+        const size_t T = gr::padded_len(nd.dims), log_T = gr::log2u(T);
+        const gr::Opening& R = red(nd);
+        NodeWitness& W = G.wit[nd.idx];
+        Out O = out();
+        int rc = ATLAS_OK;
+        H::Fr lr[2];
+        const int32_t* ops[2] = {G.tensor(nd.inputs[0]), G.tensor(nd.inputs[1])};
+        if (T > 1) {
+            atlas_poly_t p_acc = nullptr;
+            H::Fr acc_claim;
+            rc = atlas_poly_wrap_device_fr(W.acc_fr.p, T, &p_acc);
+            if (!rc) rc = atlas_poly_evaluate(p_acc, (const atlas_fr_t*)R.point.data(), log_T, (atlas_fr_t*)&acc_claim);
+            if (p_acc) atlas_poly_free(p_acc);
+            if (!rc) rc = O.append_virtual(Tr, gr::node_exec(gr::virt(gr::VP_ClampAcc, nd.idx), nd.idx), R.point, acc_claim);       // append_raf_claims_prover
+            if (!rc) rc = prove_clamp_lookup_flow(W.cidx.as<uint64_t>(), log_T, (const atlas_fr_t*)R.point.data(), acc_claim, R.claim, &t, O, nullptr);
+        }
+        if (!rc) rc = eval_i32(ops, 2, T, R.point, lr);
+        if (!rc) rc = append_nodeio(nd, 0, R.point, lr[0]);
+        if (!rc) rc = append_nodeio(nd, 1, R.point, lr[1]);
+        return rc;
+    }
+
+    // the element-wise sumcheck of an operator (MulProver / SquareProver / CubeProver / IffProver, ...): LowToHigh over the
+    // Gruen split-eq of the reduced output point; cache_openings = the operand claims at the reversed challenges
+    int ew_sumcheck(const Node& nd, int ew_op, size_t n_ops, const H::Fr& in_claim, uint8_t proof_type) {
+        const size_t T = gr::padded_len(nd.dims), log_T = gr::log2u(T);
+        const gr::Opening& R = red(nd);
+        atlas_poly_t ops[3] = {nullptr, nullptr, nullptr};
+        int rc = ATLAS_OK;
+        for (size_t i = 0; i < n_ops && !rc; i++) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(G.tensor(nd.inputs[i])), T, &ops[i]);
+        atlas_instance_t inst = nullptr;
+        if (!rc) rc = atlas_elementwise_new(ew_op, ops, n_ops, (const atlas_fr_t*)R.point.data(), log_T, nullptr, 0, &inst);
+        for (atlas_poly_t p : ops) if (p) atlas_poly_free(p);
+        std::vector<H::Fr> rs, fin;
+        if (!rc) rc = run_single(inst, in_claim, proof_type, rs, fin);
+        if (inst) atlas_instance_free(inst);
+        const Point pt = reversed(rs);
+        for (size_t q = 0; q < n_ops && !rc; q++) rc = append_nodeio(nd, q, pt, fin[q]);
+        return rc;
+    }
+
+    // Mul / Square / Cube with fused rescaling (impl_fused_rescale_proof_api, ops/mod.rs:569-612) and Einsum (ops/einsum/mod.rs:57-115)
+    int op_fused(const Node& nd) {
+        const gr::Opening& R = red(nd);
+        NodeWitness& W = G.wit[nd.idx];
+        Out O = out();
+        auto inner = [&](const H::Fr& in_claim) -> int {
+            if (nd.op == ATLAS_OP_EINSUM) return einsum_matmul(nd, in_claim);
+            const int ew = nd.op == ATLAS_OP_MUL ? ATLAS_EW_MUL : nd.op == ATLAS_OP_SQUARE ? ATLAS_EW_SQUARE : ATLAS_EW_CUBE;
+            return ew_sumcheck(nd, ew, nd.op == ATLAS_OP_MUL ? 2 : 1, in_claim, gr::PT_RescaleArith);
+        };
+        return prove_fused_rescale(*W.rescale, inner, (const atlas_fr_t*)R.point.data(), (const atlas_fr_t*)&R.claim, &t, O, nullptr);
+    }
+
+    // EinsumProver::sumcheck + Sumcheck::prove (ProofType::EinsumMatmul): EinsumLayout::fold at the reduced point, the
+    // dot-product sumcheck (HighToLow, EqSchedule of the layout), operand openings at EinsumLayout::operand_points
+    int einsum_matmul(const Node& nd, const H::Fr& in_claim) {
+        const gr::Opening& R = red(nd);
+        const int layout = (int)nd.p[0];
+        const std::vector<size_t>& d = nd.shape;
+        size_t b = 1, m = 1, k = 1, n = 1;
+        switch (layout) {
+            case ATLAS_EINSUM_MK_KN_MN: m = d[0]; k = d[1]; n = d[2]; break;
+            case ATLAS_EINSUM_K_NK_N: k = d[0]; n = d[1]; break;
+            default: b = d[0]; m = d[1]; k = d[2]; n = d[3]; break;
+        }
+        const size_t lb = gr::log2u(b), lm = gr::log2u(m), lk = gr::log2u(k), ln = gr::log2u(n);
+        const H::Fr* r = R.point.data();
+        const H::Fr *r_b = nullptr, *r_m = nullptr, *r_n = nullptr;
+        int sched = ATLAS_EQ_NONE; size_t sa = 0, sb = 0;
+        switch (layout) {
+            case ATLAS_EINSUM_MK_KN_MN: r_m = r; r_n = r + lm; break;
+            case ATLAS_EINSUM_K_NK_N: r_n = r; break;
+            case ATLAS_EINSUM_BMK_BKN_MBN: case ATLAS_EINSUM_BMK_KBN_MBN: r_m = r; r_b = r + lm; r_n = r + lm + lb; sched = ATLAS_EQ_LOW; sa = lk; sb = lb; break;
+            case ATLAS_EINSUM_MBK_BNK_BMN: case ATLAS_EINSUM_MBK_NBK_BMN: r_b = r; r_m = r + lb; r_n = r + lb + lm; sched = ATLAS_EQ_HIGH; sa = lb; sb = lk; break;
+            default: return fail(ATLAS_EINVAL, "prove_graph: einsum layout not wired into the graph prover");
+        }
+        atlas_poly_t eq_m = nullptr, eq_n = nullptr, eq_b = nullptr, left = nullptr, right = nullptr;
+        int rc = ATLAS_OK;
+        if (r_m) rc = atlas_eq_evals((const atlas_fr_t*)r_m, lm, nullptr, &eq_m);
+        if (!rc) rc = atlas_eq_evals((const atlas_fr_t*)r_n, ln, nullptr, &eq_n);
+        if (!rc) rc = atlas_einsum_fold(layout, d.data(), d.size(), G.tensor(nd.inputs[0]), G.tensor(nd.inputs[1]), eq_m, eq_n, &left, &right);
+        if (eq_m) atlas_poly_free(eq_m);
+        if (eq_n) atlas_poly_free(eq_n);
+        if (!rc && layout == ATLAS_EINSUM_K_NK_N) {                          // left = the k-vector itself (k_nk_n.rs:46-68)
+            atlas_poly_t v = nullptr;
+            rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(G.tensor(nd.inputs[0])), k, &v);
+            if (!rc) rc = atlas_poly_clone(v, &left);
+            if (v) atlas_poly_free(v);
+        }
+        if (!rc && sched != ATLAS_EQ_NONE) rc = atlas_eq_evals((const atlas_fr_t*)r_b, lb, nullptr, &eq_b);
+        atlas_dot_prover_t dp = nullptr;
+        if (!rc) rc = atlas_dot_prover_new(left, right, eq_b, sched, sa, sb, &dp);
+        if (rc) { for (atlas_poly_t p : {left, right, eq_b}) if (p) atlas_poly_free(p); return rc; }
+        const size_t nr = atlas_dot_num_rounds(dp), deg = (size_t)atlas_dot_degree(dp);
+        std::vector<atlas_fr_t> rows(nr * deg); std::vector<atlas_u128_t> chm(nr); atlas_fr_t fin[3];
+        rc = atlas_sumcheck_prove_dot(dp, (const atlas_fr_t*)&in_claim, &t, rows.data(), chm.data(), fin);
+        atlas_dot_prover_free(dp);
+        if (rc) return rc;
+        Out O = out();
+        std::vector<uint32_t> nco(nr, (uint32_t)deg);
+        rc = O.put_proof(rows, deg, nco, nr, gr::PT_EinsumMatmul);
+        if (rc) return rc;
+        std::vector<H::Fr> ch(nr);
+        for (size_t i = 0; i < nr; i++) ch[i] = ch_fr(chm[i]);
+        auto cat = [](std::initializer_list<std::pair<const H::Fr*, size_t>> parts) { Point p; for (auto& x : parts) p.insert(p.end(), x.first, x.first + x.second); return p; };
+        Point lp, rp;
+        switch (layout) {                                                     // EinsumLayout::operand_points
+            case ATLAS_EINSUM_MK_KN_MN: lp = cat({{r_m, lm}, {ch.data(), lk}}); rp = cat({{ch.data(), lk}, {r_n, ln}}); break;
+            case ATLAS_EINSUM_K_NK_N: lp = cat({{ch.data(), lk}}); rp = cat({{r_n, ln}, {ch.data(), lk}}); break;
+            case ATLAS_EINSUM_BMK_BKN_MBN: case ATLAS_EINSUM_BMK_KBN_MBN: {   // (r_j, r_h) = challenges.split_at(log_k)
+                const H::Fr *rj = ch.data(), *rh = ch.data() + lk;
+                lp = cat({{rh, lb}, {r_m, lm}, {rj, lk}});
+                rp = layout == ATLAS_EINSUM_BMK_BKN_MBN ? cat({{rh, lb}, {rj, lk}, {r_n, ln}}) : cat({{rj, lk}, {rh, lb}, {r_n, ln}});
+                break;
+            }
+            default: {                                                        // MBK: (r_h, r_j) = challenges.split_at(log_b)
+                const H::Fr *rh = ch.data(), *rj = ch.data() + lb;
+                lp = cat({{r_m, lm}, {ch.data(), lb + lk}});
+                rp = layout == ATLAS_EINSUM_MBK_BNK_BMN ? cat({{rh, lb}, {r_n, ln}, {rj, lk}}) : cat({{r_n, ln}, {ch.data(), lb + lk}});
+                break;
+            }
+        }
+        rc = append_nodeio(nd, 0, lp, *reinterpret_cast<H::Fr*>(&fin[0]));
+        if (!rc) rc = append_nodeio(nd, 1, rp, *reinterpret_cast<H::Fr*>(&fin[1]));
+        return rc;
+    }
+
+    // ReLU (ops/relu.rs:22-70)
+    int op_relu(const Node& nd) {
+        const size_t T = gr::padded_len(nd.dims), log_T = gr::log2u(T), XLEN = 32;
+        const gr::Opening& R = red(nd);
+        NodeWitness& W = G.wit[nd.idx];
+        Out O = out();
+        H::Fr operand_claim;
+        const int32_t* tp = G.tensor(nd.inputs[0]);
+        int rc = eval_i32(&tp, 1, T, R.point, &operand_claim);
+        if (!rc) rc = append_nodeio(nd, 0, R.point, operand_claim);           // append_raf_claims_prover: witness_opening_id = Input(0)
+        if (rc) return rc;
+        const H::Fr gamma = H::tr_challenge_scalar(Tr);
+        atlas_instance_t exec = nullptr;
+        rc = atlas_ps_shout_relu_new(W.lookups.as<uint64_t>(), log_T, XLEN, (const atlas_fr_t*)R.point.data(), (const atlas_fr_t*)&gamma, &exec);
+        const H::Fr exec_claim = H::add(R.claim, H::mul(gamma, operand_claim));
+        std::vector<atlas_u128_t> ch; H::Fr ra_claim; std::vector<atlas_fr_t> ra_point;
+        if (!rc) rc = prove_single(exec, exec_claim, &t, O, ch, &ra_claim, XLEN, gr::VP_NodeOutputRa, gr::PT_Execution, &ra_point);
+        if (exec) atlas_instance_free(exec);
+        if (!rc) rc = prove_onehot_checks(W.lookups.as<uint64_t>(), log_T, XLEN, (const atlas_fr_t*)R.point.data(), ra_point, ra_claim, &t, O, gr::CP_NodeOutputRaD, gr::PT_RaOneHotChecks);
+        return rc;
+    }
+
+    // Reshape (ops/reshape.rs): sum_x input(x) selector(x), selector = the eq table of the reduced point carried over the
+    // flat index (identical order when every dimension is a power of two); LowToHigh, degree 2
+    int op_reshape(const Node& nd) {
+        const size_t T = gr::padded_len(nd.dims), log_T = gr::log2u(T);
+        const gr::Opening& R = red(nd);
+        atlas_poly_t ops[2] = {nullptr, nullptr};
+        int rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(G.tensor(nd.inputs[0])), T, &ops[0]);
+        if (!rc) rc = atlas_eq_evals((const atlas_fr_t*)R.point.data(), log_T, nullptr, &ops[1]);
+        atlas_instance_t inst = nullptr;
+        if (!rc) rc = atlas_elementwise_new(ATLAS_EW_DOT, ops, 2, nullptr, log_T, nullptr, 0, &inst);
+        for (atlas_poly_t p : ops) if (p) atlas_poly_free(p);
+        std::vector<H::Fr> rs, fin;
+        if (!rc) rc = run_single(inst, R.claim, gr::PT_Execution, rs, fin);
+        if (inst) atlas_instance_free(inst);
+        if (!rc) rc = append_nodeio(nd, 0, reversed(rs), fin[0]);
+        return rc;
+    }
+
+    // MoveAxis (ops/moveaxis.rs): permute_challenge_groups, no sumcheck
+    int op_moveaxis(const Node& nd) {
+        const gr::Opening& R = red(nd);
+        std::vector<Point> groups;
+        size_t off = 0;
+        for (size_t dim : nd.dims) { const size_t v = gr::log2u(dim); groups.emplace_back(R.point.begin() + off, R.point.begin() + off + v); off += v; }
+        const size_t src = (size_t)nd.p[0], dst = (size_t)nd.p[1];
+        Point gdst = groups[dst];
+        groups.erase(groups.begin() + dst);
+        groups.insert(groups.begin() + src, gdst);
+        Point r_in;
+        for (auto& gq : groups) r_in.insert(r_in.end(), gq.begin(), gq.end());
+        return append_nodeio(nd, 0, r_in, R.claim);
+    }
+
+    // Broadcast (ops/broadcast.rs): the operand at the variables of the non-broadcast axes
+    int op_broadcast(const Node& nd) {
+        const gr::Opening& R = red(nd);
+        const Node& in = G.nodes.at(nd.inputs[0]);
+        const size_t off = nd.dims.size() - in.dims.size();
+        Point r_in;
+        size_t pos = 0;
+        for (size_t a = 0; a < nd.dims.size(); a++) {
+            const size_t v = gr::log2u(nd.dims[a]);
+            const bool kept = a >= off && in.dims[a - off] == nd.dims[a];     // get_broadcast_dims: broadcast_dims[a] == 1
+            if (kept) r_in.insert(r_in.end(), R.point.begin() + pos, R.point.begin() + pos + v);
+            pos += v;
+        }
+        H::Fr claim;
+        const int32_t* tp = G.tensor(in.idx);
+        int rc = eval_i32(&tp, 1, gr::padded_len(in.dims), r_in, &claim);
+        if (!rc) rc = append_nodeio(nd, 0, r_in, claim);
+        return rc;
+    }
+
+    int prove_node(const Node& nd) {
+        cur = nd.idx;
+        int rc = eval_reduction(nd);                                           // ReductionFlow::Default
+        if (rc) return rc;
+        const gr::Opening& R = red(nd);
+        switch (nd.op) {
+            case ATLAS_OP_INPUT: case ATLAS_OP_CONSTANT: return ATLAS_OK;    // the verifier evaluates the public tensor itself
+            case ATLAS_OP_IDENTITY: return append_nodeio(nd, 0, R.point, R.claim);
+            case ATLAS_OP_ADD: case ATLAS_OP_SUB: return op_addsub(nd);
+            case ATLAS_OP_EINSUM: case ATLAS_OP_MUL: case ATLAS_OP_SQUARE: case ATLAS_OP_CUBE: return op_fused(nd);
+            case ATLAS_OP_AND: return ew_sumcheck(nd, ATLAS_EW_MUL, 2, R.claim, gr::PT_Execution);       // impl_standard_sumcheck_proof_api!(And, MulParams, ..)
+            case ATLAS_OP_IFF: return ew_sumcheck(nd, ATLAS_EW_IFF, 3, R.claim, gr::PT_Execution);
+            case ATLAS_OP_RELU: return op_relu(nd);
+            case ATLAS_OP_RESHAPE: return op_reshape(nd);
+            case ATLAS_OP_MOVEAXIS: return op_moveaxis(nd);
+            case ATLAS_OP_BROADCAST: return op_broadcast(nd);
+            default: return fail(ATLAS_EINVAL, "prove_graph: operator without a prover composition");
+        }
+    }
+
+    // ---------------------------------------------------------------- prove_reduced_openings (prover.rs:141-176)
+    struct Reduced {
+        std::vector<atlas_fr_t> rows; std::vector<uint32_t> nco; std::vector<atlas_u128_t> ch; size_t rounds = 0;
+        std::vector<atlas_fr_t> claims; std::vector<atlas_g1_affine_t> com, w; std::vector<atlas_fr_t> v;
+        bool present = false;
+    } ro;
+    int reduced_openings(double* ms_sumcheck_and_open) {
+        (void)ms_sumcheck_and_open;
+        if (committed.empty()) return ATLAS_OK;
+        std::vector<atlas_opening_t> ops;
+        std::vector<std::vector<int32_t>> rows;                               // one-hot index rows on the host (the opening instances take them there)
+        std::map<const uint64_t*, std::vector<uint64_t>> host_lookups;
+        for (auto& kv : committed) {
+            gr::Committed& c = *kv.second;
+            if (!c.opened) return fail(ATLAS_ESTATE, "prove_graph: a committed polynomial was never opened");
+            atlas_opening_t O; std::memset(&O, 0, sizeof(O));
+            O.kind = c.kind; O.point = (const atlas_fr_t*)c.point.data(); std::memcpy(&O.claim, &c.claim, 32);
+            if (c.kind == 1) {
+                const size_t T = (size_t)1 << c.log_T;
+                auto& hl = host_lookups[c.d_lookups];
+                if (hl.empty()) {
+                    hl.resize(T);
+                    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+                    HIP_TRY(hipMemcpyAsync(hl.data(), c.d_lookups, T * 8, hipMemcpyDeviceToHost, g.stream));
+                    HIP_TRY(hipStreamSynchronize(g.stream));
+                }
+                const size_t d = (c.log_K + 3) / 4, shift = 4 * (d - 1 - c.chunk);                     // OneHotParams::lookup_index_chunk
+                rows.emplace_back(T);
+                for (size_t j = 0; j < T; j++) rows.back()[j] = (int32_t)((hl[j] >> shift) & 15);
+                O.log_K = 4; O.log_T = c.log_T;
+            } else { O.poly = c.dense; O.n = c.log_T; }
+            ops.push_back(O);
+        }
+        size_t ri = 0;
+        for (auto& O : ops) if (O.kind == 1) O.k = rows[ri++].data();
+        size_t maxr = 0;
+        for (auto& O : ops) { const size_t n = O.kind ? O.log_K + O.log_T : O.n; maxr = n > maxr ? n : maxr; }
+        ro.rows.resize(maxr * 3); ro.nco.resize(maxr); ro.ch.resize(maxr); ro.claims.resize(ops.size());
+        ro.com.resize(maxr ? maxr - 1 : 0); ro.w.resize(3); ro.v.resize(3 * maxr);
+        int rc = atlas_prove_reduced_openings(ops.data(), ops.size(), srs, &t, ro.rows.data(), ro.nco.data(), ro.ch.data(), &ro.rounds, ro.claims.data(),
+                                              ro.com.data(), ro.w.data(), ro.v.data());
+        ro.present = rc == ATLAS_OK;
+        return rc;
+    }
+
+    // ---------------------------------------------------------------- the ONNXProof container (proof_serialization.rs:200-224)
+    static void put_u64(std::vector<uint8_t>& o, uint64_t v) { for (int i = 0; i < 8; i++) o.push_back((uint8_t)(v >> (8 * i))); }
+    static void put_fr(std::vector<uint8_t>& o, const H::Fr& f) { uint8_t b[32]; atlas_fr_to_bytes((const atlas_fr_t*)&f, b); o.insert(o.end(), b, b + 32); }
+    static void put_g1(std::vector<uint8_t>& o, const atlas_g1_affine_t& p) { uint8_t b[32]; atlas_g1_to_bytes_compressed(&p, b); o.insert(o.end(), b, b + 32); }
+    static void put_opening_id(std::vector<uint8_t>& o, const OpeningId& id) {              // opening_proof.rs:1313-1333 (Committed = tag 0, Virtual = tag 1)
+        o.push_back(id.poly.committed ? 0 : 1);
+        o.push_back(id.poly.var);                                                            // canonical_serde_enum!: u8 variant index, then the usize fields
+        const int ar = id.poly.committed ? gr::cp_arity(id.poly.var) : gr::vp_arity(id.poly.var);
+        if (ar >= 1) put_u64(o, id.poly.a);
+        if (ar >= 2) put_u64(o, id.poly.b);
+        o.push_back(id.sc);
+        if (id.sc == gr::SC_NodeExecution || id.sc == gr::SC_RLC) put_u64(o, id.sc_idx);
+    }
+    int serialize(std::vector<uint8_t>& o) {
+        put_u64(o, openings.size());                                          // Claims: (OpeningId, claim) pairs, points dropped
+        for (auto& kv : openings) { put_opening_id(o, kv.first); put_fr(o, kv.second.claim); }
+        put_u64(o, proofs.size());                                            // BTreeMap<ProofId, SumcheckInstanceProof>
+        for (auto& kv : proofs) { put_u64(o, kv.first.node); o.push_back(kv.first.type); o.insert(o.end(), kv.second.begin(), kv.second.end()); }
+        put_u64(o, committed.size());                                         // Vec<HyperKZGCommitment>
+        for (auto& kv : committed) put_g1(o, kv.second->commitment);
+        put_u64(o, evalred.size());                                           // BTreeMap<usize, EvalReductionProof { h: UniPoly { coeffs } }>
+        for (auto& kv : evalred) { put_u64(o, kv.first); put_u64(o, kv.second.size()); for (auto& c : kv.second) put_fr(o, c); }
+        o.push_back(ro.present ? 1 : 0);                                      // Option<ReducedOpeningProof>
+        if (ro.present) {
+            size_t l = 0;
+            int rc = atlas_sumcheck_proof_serialize(ro.rows.data(), 3, ro.nco.data(), ro.rounds, nullptr, 0, &l);
+            if (rc) return rc;
+            const size_t at = o.size(); o.resize(at + l);
+            rc = atlas_sumcheck_proof_serialize(ro.rows.data(), 3, ro.nco.data(), ro.rounds, o.data() + at, l, &l);
+            if (rc) return rc;
+            put_u64(o, ro.claims.size());
+            for (auto& c : ro.claims) put_fr(o, *reinterpret_cast<const H::Fr*>(&c));
+            rc = atlas_hyperkzg_proof_serialize(ro.com.data(), ro.com.size(), ro.w.data(), ro.v.data(), ro.rounds, nullptr, 0, &l);
+            if (rc) return rc;
+            const size_t at2 = o.size(); o.resize(at2 + l);
+            rc = atlas_hyperkzg_proof_serialize(ro.com.data(), ro.com.size(), ro.w.data(), ro.v.data(), ro.rounds, o.data() + at2, l, &l);
+            if (rc) return rc;
+        }
+        return ATLAS_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" int atlas_prove_graph(atlas_graph_t G, atlas_srs_t srs, const int32_t* const* inputs, size_t n_inputs, uint8_t* proof, size_t cap, size_t* proof_len,
+                                 atlas_transcript_t* final_transcript, atlas_graph_timing_t* timing) {
+    NEED_INIT();
+    if (!G || !srs || (!inputs && n_inputs) || !proof_len) return fail(ATLAS_EINVAL, "prove_graph: null argument");
+    if (G->outputs.empty()) return fail(ATLAS_EINVAL, "prove_graph: no output node marked");
+    auto now = [] { atlas_sync(); return std::chrono::steady_clock::now(); };
+    const auto t0 = now();
+    int rc = atlas_graph_trace(G, inputs, n_inputs);                          // pp.model().trace(inputs)
+    if (rc) return rc;
+    const auto t1 = now();
+    Prover P(*G, srs);
+    rc = atlas_transcript_new(&P.t, (const uint8_t*)"ONNXProof", 9);
+    if (rc) return rc;
+    {   // append_inputs_to_transcript (onnx_proof/mod.rs:90-122)
+        H::Transcript& Tr = P.Tr;
+        const std::vector<size_t> in_nodes = G->input_nodes();
+        H::tr_append_message(Tr, "model_inputs");
+        H::tr_append_u64(Tr, in_nodes.size());
+        H::tr_append_u64(Tr, in_nodes.size());
+        for (size_t i = 0; i < in_nodes.size(); i++) {
+            const Node& nd = G->nodes.at(in_nodes[i]);
+            H::tr_append_u64(Tr, nd.idx);
+            H::tr_append_u64(Tr, nd.dims.size());
+            for (size_t d : nd.dims) H::tr_append_u64(Tr, d);
+            H::tr_append_bytes(Tr, (const uint8_t*)inputs[i], nd.numel() * 4);                  // i32 little-endian
+        }
+    }
+    rc = P.collect_committed();
+    if (!rc) rc = P.commit_all();
+    const auto t2 = now();
+    if (!rc) rc = P.output_claim();
+    for (auto it = G->nodes.rbegin(); it != G->nodes.rend() && !rc; ++it) rc = P.prove_node(it->second);
+    const auto t3 = now();
+    if (!rc) rc = P.reduced_openings(nullptr);
+    const auto t4 = now();
+    if (rc) return rc;
+    std::vector<uint8_t> bytes;
+    rc = P.serialize(bytes);
+    if (rc) return rc;
+    *proof_len = bytes.size();
+    if (proof) {
+        if (cap < bytes.size()) return fail(ATLAS_EINVAL, "prove_graph: proof buffer too small (the needed size is in *proof_len)");
+        std::memcpy(proof, bytes.data(), bytes.size());
+    }
+    if (final_transcript) *final_transcript = P.t;
+    if (timing) {
+        timing->trace_ms = ms_between(t0, t1); timing->commit_ms = ms_between(t1, t2); timing->iop_ms = ms_between(t2, t3);
+        timing->hyperkzg_ms = atlas_rt_last_hyperkzg_ms(); timing->reduction_ms = ms_between(t3, t4) - timing->hyperkzg_ms; timing->total_ms = ms_between(t0, now());
+        timing->n_nodes = G->nodes.size(); timing->n_committed = P.committed.size(); timing->n_sumchecks = P.proofs.size() + (P.ro.present ? 1 : 0);
+    }
+    return ATLAS_OK;
+}

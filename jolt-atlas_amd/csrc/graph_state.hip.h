@@ -1,0 +1,34 @@
+// atlas_graph: the model (ComputationGraph), its execution trace in HBM (Trace: node index -> Tensor<i32>) and the
+// per-node witness artifacts the prover derives from it (accumulators, quotients / remainders, lookup indices) —
+// generate_node_witnesses (jolt-atlas-core/src/onnx_proof/witness.rs:136-200) keeps them only for the commitment; here
+// they stay resident for the IOP so that nothing is executed twice.
+#pragma once
+#include "graph.hpp"
+#include "node_flow.hip.h"
+
+struct NodeWitness {
+    std::unique_ptr<RescaleWitness> rescale;     // Einsum / Mul / Square / Cube (fused rescale)
+    DevBuf acc, acc_fr, cidx;                    // Add / Sub / Sum: i64 accumulation, its Fr image, the clamp lookup indices
+    DevBuf lookups;                              // ReLU and the other XLEN-bit unary lookups
+    std::vector<gr::Committed> committed;        // this node's committed polynomials, in get_committed_polynomials order
+};
+
+struct atlas_graph {
+    std::map<size_t, gr::Node> nodes;
+    std::vector<size_t> outputs;
+    // trace
+    bool traced = false;
+    std::map<size_t, DevBuf> out;                // node outputs, padded_next_power_of_two, i32
+    std::map<size_t, NodeWitness> wit;
+    std::vector<size_t> input_nodes() const { std::vector<size_t> v; for (auto& kv : nodes) if (kv.second.op == ATLAS_OP_INPUT) v.push_back(kv.first); return v; }
+    const int32_t* tensor(size_t idx) const { auto it = out.find(idx); return it == out.end() ? nullptr : it->second.as<int32_t>(); }
+    void clear_trace() { out.clear(); wit.clear(); traced = false; }
+};
+
+namespace gr {
+inline size_t next_pow2(size_t x) { size_t p = 1; while (p < x) p <<= 1; return p; }
+inline unsigned log2u(size_t x) { unsigned n = 0; while (x > 1) { x >>= 1; n++; } return n; }
+// pow2_padded_num_output_elements (node/mod.rs:52-57): every dimension padded on its own
+inline size_t padded_len(const std::vector<size_t>& dims) { size_t n = 1; for (size_t d : dims) n *= next_pow2(d); return n; }
+inline bool all_pow2(const std::vector<size_t>& dims) { for (size_t d : dims) if (d == 0 || (d & (d - 1))) return false; return true; }
+}  // namespace gr

@@ -8,3 +8,5 @@
 // compute_ra_evals (shout.rs:550-598) with the d x 2^log_k_chunk tables returned on the host (shout.hip)
 int atlas_rt_shout_ra_evals_host(const uint64_t* lookup_indices, size_t T, size_t log_K, size_t log_k_chunk, atlas_poly_t eq_r_cycle,
                                  std::vector<atlas_host::Fr>& G);
+// wall clock of the HyperKZG::open inside the last atlas_prove_reduced_openings call (reduced_openings.hip)
+double atlas_rt_last_hyperkzg_ms();

@@ -15,10 +15,14 @@
 
 #include "../../include/atlas_hip.h"
 #include "host_field.hpp"
+#include "internal.hpp"
 #include "runtime.hpp"
 
 namespace H = atlas_host;
 using atlas_rt::fail;
+
+static double g_last_open_ms = 0;
+double atlas_rt_last_hyperkzg_ms() { return g_last_open_ms; }
 
 extern "C" int atlas_prove_reduced_openings(const atlas_opening_t* openings, size_t n_open, atlas_srs_t srs,
                                             atlas_transcript_t* transcript, atlas_fr_t* sumcheck_rows, uint32_t* n_coeffs,
@@ -116,7 +120,11 @@ extern "C" int atlas_prove_reduced_openings(const atlas_opening_t* openings, siz
     if (!rc) atlas_poly_len(joint, &jlen);
     if (!rc && jlen != ((size_t)1 << *max_rounds_out)) rc = fail(ATLAS_EINVAL, "prove_reduced_openings: joint polynomial length != 2^max_rounds");
     // PCS::prove(generators, &rlc, &r_sumcheck, None, transcript) = HyperKZG::open
+    atlas_sync();
+    const auto t_open = std::chrono::steady_clock::now();
     if (!rc) rc = atlas_hyperkzg_open(srs, joint, challenges, *max_rounds_out, transcript, com, w, v);
+    atlas_sync();
+    g_last_open_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_open).count();
     mark("HyperKZG::open");
     cleanup();
     return rc;

@@ -1,0 +1,632 @@
+"""TEST INFRASTRUCTURE ONLY (the checker, never the product): ONNXProof::prove for a model-graph description, composed on
+the CPU from the oracle's instances exactly as the reference composes them.
+
+  prove                jolt-atlas-core/src/onnx_proof/mod.rs:153-200
+  inputs -> transcript mod.rs:90-122
+  commit               prover.rs:71-87, witness.rs:136-200 (BTreeMap<CommittedPoly> order), hyperkzg/mod.rs:520-554
+  output_claim         prover.rs:89-121
+  iop                  prover.rs:127-138; ops/mod.rs:315-349 (NodeEvalReduction then the operator)
+  operators            ops/{add,sub,mul,square,cube,and,iff,relu,reshape,moveaxis,broadcast,identity,input,constant}.rs,
+                       ops/einsum/{mod,dot,mk_kn_mn,bmk_rhs_mbn,mbk_rhs_bmn,k_nk_n}.rs, fused_rebase.rs, clamp_lookups/mod.rs,
+                       op_lookups/mod.rs, joltworks shout.rs:399-466
+  reduced openings     prover.rs:141-176, opening_proof.rs:447-532,611-643
+  container            proof_serialization.rs:200-224, types.rs:27-129, opening_proof.rs:1167-1333, common/src/lib.rs
+
+The executor is a numpy statement of the tracer's integer semantics (atlas-onnx-tracer/src/ops/*.rs).  Parity unpinned
+against a run of the reference (no Rust toolchain here): this pins the device path against a second, independent
+composition — same reading of the reference, different code (Python over oracle/*.c)."""
+import ctypes as C
+
+import numpy as np
+
+from . import orc, orc_batched as OB, orc_ra as OR
+
+FR = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+FQ = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47
+
+# ---- identifiers (variant index = declaration order in common/src/lib.rs; the u8 tag of canonical_serde_enum!)
+VP = {n: i for i, n in enumerate(
+    "NodeOutput NodeOutputRa CosRa SinRa TrigDownscaleRa SoftmaxSumOutput SoftmaxMaxOutput SoftmaxMaxIndex HammingWeight DivRangeCheckRa "
+    "SqrtRangeCheckRa TeleportRangeCheckRa MeanOfSquaresRangeCheckRa DivRemainder SqrtRemainder TeleportQuotient TeleportRemainder TrigDownscaled "
+    "SoftmaxExpSum SoftmaxExpQ SoftmaxRemainderRa SoftmaxExpHi SoftmaxExpLo SoftmaxExpRemainder SoftmaxExpRemainderRa SoftmaxZHi SoftmaxZLo "
+    "SoftmaxZHiRa SoftmaxZLoRa SoftmaxClampWitness SoftmaxClampRa SoftmaxRecipMultRemainder ClampAcc ClampRa RescaleRemainder RescaleRemainderRa "
+    "SymmetricClampRa ActivationClampedOutput ActivationClampRa ActivationSmallRa".split())}
+CP = {n: i for i, n in enumerate(
+    "NodeOutputRaD CosRaD SinRaD TrigDownscaleRaD DivRangeCheckRaD SqrtDivRangeCheckRaD MeanOfSquaresRangeCheckRaD SqrtRangeCheckRaD "
+    "TeleportRangeCheckRaD DivNodeQuotient ScalarConstDivNodeRemainder RsqrtQuotient TeleportNodeQuotient GatherRa GatherRaD SoftmaxRemainderRaD "
+    "SoftmaxExpRemainderRaD SoftmaxZHiRaD SoftmaxZLoRaD ClampRaD RescaleRemainderRaD SymmetricClampRaD ActivationClampRaD ActivationSmallRaD "
+    "SoftmaxClampRaD".split())}
+SC = {n: i for i, n in enumerate("NodeExecution Raf RaVirtualization RamHammingBooleanity RamHammingWeight Booleanity HammingWeight RLC "
+                                 "BlindFoldBatchOpening NTEvalShift".split())}
+PT = {n: i for i, n in enumerate("Execution NeuralTeleport RaOneHotChecks RaHammingWeight RangeCheck SoftmaxStage1 SoftmaxStage2 SoftmaxStage3 "
+                                 "SoftmaxStage4 SumReduction EinsumMatmul RescaleRemainderRaChecks RescaleArith TrigDownscaleRaChecks".split())}
+
+
+def vp_arity(v):
+    return 0 if v == VP["HammingWeight"] else 2 if VP["SoftmaxSumOutput"] <= v <= VP["SoftmaxMaxIndex"] else 1
+
+
+def cp_arity(v):
+    return 1 if CP["DivNodeQuotient"] <= v <= CP["GatherRa"] else 2
+
+
+def virt(name, a=0, b=0):
+    return (0, VP[name], a, b)
+
+
+def comm(name, a=0, b=0):
+    return (1, CP[name], a, b)
+
+
+def oid(poly, sc, idx=0):
+    """OpeningId as a tuple whose Python order is the derived Ord of the Rust struct (Virtual < Committed)."""
+    return poly + (SC[sc], idx)
+
+
+def node_exec(poly, node):
+    return oid(poly, "NodeExecution", node)
+
+
+# ---- small helpers over the oracle
+def fr(vals):
+    return orc.from_ints([int(v) % FR for v in np.asarray(vals).reshape(-1)])
+
+
+def one():
+    return orc.from_ints([1])[0]
+
+
+def ilog2(x):
+    return int(x).bit_length() - 1
+
+
+class T:
+    """Blake2bTranscript over oracle/transcript.c"""
+
+    def __init__(self, label):
+        self.t = orc.new_transcript(label)
+
+    def append_scalar(self, x):
+        orc.lib.orc_transcript_append_scalar(C.byref(self.t), orc._p(np.ascontiguousarray(x, dtype=np.uint64).reshape(1, 4)))
+
+    def append_scalars(self, xs):
+        xs = np.ascontiguousarray(xs, dtype=np.uint64)
+        orc.lib.orc_transcript_append_scalars(C.byref(self.t), orc._p(xs), C.c_size_t(len(xs)))
+
+    def append_message(self, m):
+        orc.lib.orc_transcript_append_message(C.byref(self.t), m)
+
+    def append_u64(self, v):
+        orc.lib.orc_transcript_append_u64(C.byref(self.t), C.c_uint64(v))
+
+    def append_bytes(self, b):
+        buf = (C.c_uint8 * len(b)).from_buffer_copy(b)
+        orc.lib.orc_transcript_append_bytes(C.byref(self.t), buf, C.c_size_t(len(b)))
+
+    def challenge_scalar(self):
+        s = orc.fr_array(1)
+        orc.lib.orc_transcript_challenge_scalar(C.byref(self.t), orc._p(s))
+        return s[0].copy()
+
+    def challenge_opt(self):
+        raw = (C.c_uint64 * 2)(); r = orc.fr_array(1)
+        orc.lib.orc_transcript_challenge_optimized(C.byref(self.t), raw, orc._p(r))
+        return r[0].copy()
+
+    def challenge_vector_opt(self, n):
+        return np.stack([self.challenge_opt() for _ in range(n)]) if n else orc.fr_array(0)
+
+    def state(self):
+        return self.t.state_bytes()
+
+
+def canon_fq(mont):
+    return sum(int(x) << (64 * i) for i, x in enumerate(mont)) * pow(1 << 256, -1, FQ) % FQ
+
+
+def g1_uncompressed(pt):
+    """ark serialize_uncompressed of G1Affine: x LE || y LE with the flags on y's last byte."""
+    if int(pt["infinity"]):
+        return bytes(63) + b"\x40"
+    x, y = canon_fq(pt["x"]), canon_fq(pt["y"])
+    b = bytearray(x.to_bytes(32, "little") + y.to_bytes(32, "little"))
+    if y > FQ - y:
+        b[63] |= 0x80
+    return bytes(b)
+
+
+def g1_compressed(pt):
+    if int(pt["infinity"]):
+        return bytes(31) + b"\x40"
+    x, y = canon_fq(pt["x"]), canon_fq(pt["y"])
+    b = bytearray(x.to_bytes(32, "little"))
+    if y > FQ - y:
+        b[31] |= 0x80
+    return bytes(b)
+
+
+def fr_bytes(x):
+    return orc.to_ints(np.asarray(x).reshape(1, 4))[0].to_bytes(32, "little")
+
+
+def u64(v):
+    return int(v).to_bytes(8, "little")
+
+
+def sumcheck_proof_bytes(rows):
+    """SumcheckInstanceProof { compressed_polys: Vec<CompressedUniPoly { coeffs_except_linear_term: Vec<F> }> }"""
+    out = u64(len(rows))
+    for row in rows:
+        out += u64(len(row)) + b"".join(fr_bytes(c) for c in row)
+    return out
+
+
+def opening_id_bytes(k):
+    committed, var, a, b, sc, idx = k
+    out = bytes([0 if committed else 1, var])
+    ar = cp_arity(var) if committed else vp_arity(var)
+    if ar >= 1:
+        out += u64(a)
+    if ar >= 2:
+        out += u64(b)
+    out += bytes([sc])
+    if sc in (SC["NodeExecution"], SC["RLC"]):
+        out += u64(idx)
+    return out
+
+
+# ---- the integer semantics of the tracer (atlas-onnx-tracer/src/ops/*.rs)
+def clamp_i32(a):
+    return np.clip(a, -(1 << 31), (1 << 31) - 1).astype(np.int32)
+
+
+EINSUM_NP = {"mk,kn->mn": "mk,kn->mn", "bmk,bkn->mbn": "bmk,bkn->mbn", "bmk,kbn->mbn": "bmk,kbn->mbn", "mbk,bnk->bmn": "mbk,bnk->bmn",
+             "mbk,nbk->bmn": "mbk,nbk->bmn", "k,nk->n": "k,nk->n"}
+
+
+def einsum_operand_shapes(nd):
+    s = nd["shape"]
+    lay = nd["layout"]
+    if lay == "mk,kn->mn":
+        m, k, n = s; return (m, k), (k, n)
+    if lay == "k,nk->n":
+        k, n = s; return (k,), (n, k)
+    b, m, k, n = s
+    return {"bmk,bkn->mbn": ((b, m, k), (b, k, n)), "bmk,kbn->mbn": ((b, m, k), (k, b, n)), "mbk,bnk->bmn": ((m, b, k), (b, n, k)),
+            "mbk,nbk->bmn": ((m, b, k), (n, b, k))}[lay]
+
+
+def rebase_bits(nd):
+    return {"Einsum": nd.get("scale"), "Mul": nd.get("scale"), "Square": nd.get("scale"), "Cube": 2 * nd.get("scale", 0)}.get(nd["op"])
+
+
+def accumulate(nd, ins):
+    """the i64 accumulation of a fused-rescale node (einsum_acc_i64, mul_acc_i64, cube_acc_i64)"""
+    op = nd["op"]
+    a = ins[0].astype(np.int64)
+    if op == "Einsum":
+        ls, rs = einsum_operand_shapes(nd)
+        return np.einsum(EINSUM_NP[nd["layout"]], a.reshape(ls), ins[1].astype(np.int64).reshape(rs)).reshape(-1)
+    if op == "Mul":
+        return a * ins[1].astype(np.int64)
+    if op == "Square":
+        return a * a
+    if op == "Cube":
+        return a * a * a
+    raise ValueError(op)
+
+
+def execute(nodes, inputs):
+    """Model::trace: node idx -> flat int32 output (every dimension is a power of two, so padded == raw)."""
+    out, wit = {}, {}
+    it = iter(inputs)
+    for nd in nodes:
+        op, ins = nd["op"], [out[i] for i in nd["inputs"]]
+        if op == "Input":
+            o = np.ascontiguousarray(next(it), dtype=np.int32).reshape(-1)
+        elif op == "Constant":
+            o = np.ascontiguousarray(nd["data"], dtype=np.int32).reshape(-1)
+        elif op in ("Identity", "Reshape"):
+            o = ins[0].copy()
+        elif op in ("Add", "Sub"):
+            acc = ins[0].astype(np.int64) + ins[1].astype(np.int64) if op == "Add" else ins[0].astype(np.int64) - ins[1].astype(np.int64)
+            wit[nd["idx"]] = dict(acc=acc)
+            o = clamp_i32(acc)
+        elif op in ("Einsum", "Mul", "Square", "Cube"):
+            S = rebase_bits(nd)
+            acc = accumulate(nd, ins)
+            q = acc >> S                                       # div_euclid by 2^S
+            r = acc - (q << S)                                 # rem_euclid
+            assert ((r >= 0) & (r < (1 << S))).all()
+            wit[nd["idx"]] = dict(quot=q, rem=r.astype(np.int32), S=S)
+            o = clamp_i32(q)
+        elif op == "And":
+            o = (ins[0] * ins[1]).astype(np.int32)
+        elif op == "Iff":
+            o = np.where(ins[0] != 0, ins[1], ins[2]).astype(np.int32)
+        elif op == "ReLU":
+            o = np.maximum(ins[0], 0).astype(np.int32)
+        elif op == "MoveAxis":
+            idims = next(n for n in nodes if n["idx"] == nd["inputs"][0])["dims"]
+            o = np.moveaxis(ins[0].reshape(idims), nd["source"], nd["destination"]).reshape(-1).copy()
+        elif op == "Broadcast":
+            idims = next(n for n in nodes if n["idx"] == nd["inputs"][0])["dims"]
+            o = np.broadcast_to(ins[0].reshape(idims), nd["dims"]).reshape(-1).copy()
+        else:
+            raise ValueError(f"oracle graph executor: operator {op}")
+        assert len(o) == int(np.prod(nd["dims"])), (nd, len(o))
+        out[nd["idx"]] = o
+    return out, wit
+
+
+class Prover:
+    def __init__(self, nodes, outputs, srs_host):
+        self.nodes = {nd["idx"]: nd for nd in nodes}
+        self.order = [nd["idx"] for nd in nodes]
+        self.outputs = outputs
+        self.srs = srs_host
+        self.openings = {}          # OpeningId tuple -> (point (n,4), claim (4,))
+        self.reduced = {}
+        self.committed = {}         # CommittedPoly tuple -> dict(idx rows, log_T, commitment, point, claim)
+        self.proofs = {}            # (node, proof type) -> rows
+        self.evalred = {}
+        self.t = T(b"ONNXProof")
+
+    # ---- accumulator
+    def append_virtual(self, key, point, claim):
+        self.t.append_scalar(claim)
+        self.openings[key] = (np.array(point, dtype=np.uint64).reshape(-1, 4).copy(), np.array(claim, dtype=np.uint64).copy())
+
+    def append_nodeio(self, nd, pos, point, claim):
+        self.append_virtual(node_exec(virt("NodeOutput", nd["inputs"][pos]), nd["idx"]), point, claim)
+
+    def append_sparse(self, cp_name, node, chunk, sc, point, claim):
+        self.t.append_scalar(claim)
+        p = comm(cp_name, node, chunk)
+        self.openings[oid(p, sc)] = (np.array(point, dtype=np.uint64).copy(), np.array(claim, dtype=np.uint64).copy())
+        if p in self.committed:                                # sumchecks.insert(label, ..): the last append wins
+            self.committed[p]["point"], self.committed[p]["claim"] = np.array(point, dtype=np.uint64).copy(), np.array(claim, dtype=np.uint64).copy()
+
+    def mle(self, idx):
+        return fr(self.trace[idx])
+
+    # ---- witness + commitments
+    def lookup_families(self, nd):
+        """[(CommittedPoly name, lookup indices (u64), log_K)] in get_committed_polynomials order"""
+        op, i = nd["op"], nd["idx"]
+        if int(np.prod(nd["dims"])) == 1:
+            return []
+        if op in ("Add", "Sub"):
+            return [("ClampRaD", self.wit[i]["acc"].astype(np.int64).view(np.uint64), 64)]
+        if op in ("Einsum", "Mul", "Square", "Cube"):
+            w = self.wit[i]
+            return [("RescaleRemainderRaD", w["rem"].astype(np.uint64), w["S"]), ("ClampRaD", w["quot"].astype(np.int64).view(np.uint64), 64)]
+        if op == "ReLU":
+            return [("NodeOutputRaD", self.trace[nd["inputs"][0]].astype(np.uint32).astype(np.uint64), 32)]
+        return []
+
+    def commit(self):
+        for i in self.order:
+            nd = self.nodes[i]
+            for name, lookups, log_K in self.lookup_families(nd):
+                d = -(-log_K // 4)
+                Tn = len(lookups)
+                for c in range(d):
+                    row = ((lookups >> np.uint64(4 * (d - 1 - c))) & np.uint64(15)).astype(np.int64)
+                    flat = (row * Tn + np.arange(Tn)).astype(np.uint64)              # one-hot coefficient k * T + t (one_hot_polynomial.rs:104-113)
+                    self.committed[comm(name, i, c)] = dict(row=row.astype(np.int32), log_T=ilog2(Tn), commitment=orc.g1_sum_indexed(self.srs, flat))
+        for key in sorted(self.committed):
+            self.t.append_bytes(g1_uncompressed(self.committed[key]["commitment"])[::-1])       # append_serializable
+
+    # ---- generic pieces
+    def run(self, inst, claim, node, ptype):
+        rows, ch = inst.prove(claim, self.t.t)
+        self.proofs[(node, PT[ptype])] = rows
+        return orc.challenges_to_fr(ch)
+
+    def onehot_checks(self, nd, lookups, log_K, r_cycle, ra_point, ra_claim, cp_name, ptype):
+        lkc, node = 4, nd["idx"]
+        d = -(-log_K // lkc)
+        log_T = len(r_cycle)
+        q = self.t.challenge_scalar()
+        gp = [one()]
+        for _ in range(1, d):
+            gp.append(orc.fr_mul_arr(gp[-1], q))
+        gp = np.stack(gp)
+        gammas = self.t.challenge_vector_opt(d)
+        r_addr = self.t.challenge_vector_opt(lkc)
+        Hs = [((lookups >> np.uint64(lkc * (d - 1 - i))) & np.uint64(15)).astype(np.int32) for i in range(d)]
+        G = OR.ra_G(Hs, lkc, r_cycle)
+        pad = d * lkc - log_K
+        chunks = np.concatenate([np.zeros((pad, 4), dtype=np.uint64), ra_point[:log_K]]).reshape(d, lkc, 4)
+        r_cyc_ra = np.ascontiguousarray(ra_point[log_K:])
+        hw_claim = orc.fr_array(1)[0]
+        for x in gp:
+            hw_claim = orc.fr_add_arr(hw_claim, x)
+        insts = [OB.ra_instance(OR.ra_virtual(Hs, lkc, chunks, r_cyc_ra), ra_claim), OB.ra_instance(OR.hamming(G, lkc, gp), hw_claim),
+                 OB.ra_instance(OR.booleanity(G, Hs, lkc, gammas, r_addr, r_cycle), orc.fr_array(1)[0])]
+        rows, ch, _ = OB.batched_prove(insts, self.t.t)
+        self.proofs[(node, PT[ptype])] = rows
+        rs = orc.challenges_to_fr(ch)
+        mr = lkc + log_T
+        ra_rs = np.ascontiguousarray(rs[mr - log_T:][::-1])
+        for i in range(d):                                                   # RaVirtual::cache_openings
+            F = orc.eq_evals(chunks[i])
+            c = orc.evaluate(np.stack([F[k] for k in Hs[i]]), ra_rs)
+            self.append_sparse(cp_name, node, i, "RaVirtualization", np.concatenate([chunks[i], ra_rs]), c)
+        hw_rs = np.ascontiguousarray(rs[mr - lkc:][::-1])
+        for i in range(d):                                                   # HammingWeight::cache_openings
+            c = orc.evaluate(G[i], hw_rs)
+            self.append_sparse(cp_name, node, i, "HammingWeight", np.concatenate([hw_rs, r_cycle]), c)
+        ba = np.ascontiguousarray(rs[:lkc][::-1]); bc = np.ascontiguousarray(rs[lkc:][::-1])
+        Fb = orc.eq_evals(ba)
+        for i in range(d):                                                   # Booleanity::cache_openings
+            c = orc.evaluate(np.stack([Fb[k] for k in Hs[i]]), bc)
+            self.append_sparse(cp_name, node, i, "Booleanity", np.concatenate([ba, bc]), c)
+
+    def read_raf(self, nd, inst, claim, lookups, log_K, ra_vp, ptype):
+        """Sumcheck::prove of a read-raf instance + its ra opening at (address challenges, reversed cycle challenges)"""
+        rs = self.run(inst, claim, nd["idx"], ptype)
+        ra_point = np.concatenate([rs[:log_K], rs[log_K:][::-1]])
+        ra_claim = orc.evaluate(np.stack([eq_bits(ra_point[:log_K], v, log_K) for v in lookups]), np.ascontiguousarray(ra_point[log_K:]))
+        self.append_virtual(node_exec(virt(ra_vp, nd["idx"]), nd["idx"]), ra_point, ra_claim)
+        return ra_point, ra_claim
+
+    def clamp_lookup(self, nd, cidx, r0, acc_claim, out_claim):
+        """prove_clamp_lookup after its raf claim (clamp_lookups/mod.rs:264-309)"""
+        gamma = self.t.challenge_scalar()
+        exec_claim = orc.fr_add_arr(out_claim, orc.fr_mul_arr(gamma, acc_claim))
+        ra_point, ra_claim = self.read_raf(nd, OR.ps_clamp(cidx, 64, 31, True, r0, gamma), exec_claim, cidx, 64, "ClampRa", "Execution")
+        self.onehot_checks(nd, cidx, 64, r0, ra_point, ra_claim, "ClampRaD", "RaOneHotChecks")
+
+    # ---- stages
+    def output_claim(self):
+        nd = self.nodes[self.outputs[0]]
+        n = ilog2(len(self.trace[nd["idx"]]))
+        r = self.t.challenge_vector_opt(n)
+        self.append_virtual(node_exec(virt("NodeOutput", nd["idx"]), nd["idx"] + 1), r, orc.evaluate(self.mle(nd["idx"]), r))
+
+    def eval_reduction(self, nd):
+        i = nd["idx"]
+        lo, hi = node_exec(virt("NodeOutput", i), i), node_exec(virt("NodeOutput", i), 1 << 64)
+        ks = sorted(k for k in self.openings if lo <= k <= hi)
+        assert ks, f"node {i} has no opening claims"
+        pts = np.stack([self.openings[k][0] for k in ks]); cls = np.stack([self.openings[k][1] for k in ks])
+        h, r, c = OR.eval_reduction_prove(self.mle(i), pts, cls, self.t.t)
+        self.evalred[i] = h
+        self.reduced[i] = (r, c)
+
+    def ew_sumcheck(self, nd, ew, n_ops, in_claim, ptype):
+        r0, _ = self.reduced[nd["idx"]]
+        I = OR.elementwise(ew, [self.mle(j) for j in nd["inputs"][:n_ops]], r0)
+        rs = self.run(I, in_claim, nd["idx"], ptype)
+        fin = I.finals()
+        pt = np.ascontiguousarray(rs[::-1])
+        for q in range(n_ops):
+            self.append_nodeio(nd, q, pt, fin[q])
+
+    def einsum_matmul(self, nd, in_claim):
+        r0, _ = self.reduced[nd["idx"]]
+        lay, s = nd["layout"], nd["shape"]
+        A, B = self.trace[nd["inputs"][0]], self.trace[nd["inputs"][1]]
+        if lay == "mk,kn->mn":
+            m, k, n = s; b = 1
+        elif lay == "k,nk->n":
+            k, n = s; b = m = 1
+        else:
+            b, m, k, n = s
+        lb, lm, lk, ln = ilog2(b), ilog2(m), ilog2(k), ilog2(n)
+        eq = None; sched = 0; sa = sb = 0
+        if lay == "mk,kn->mn":
+            r_m, r_n = r0[:lm], r0[lm:]
+            eq_m = orc.eq_evals(np.ascontiguousarray(r_m)) if lm else orc.from_ints([1]); eq_n = orc.eq_evals(np.ascontiguousarray(r_n)) if ln else orc.from_ints([1])
+            left, right = orc.fr_array(k), orc.fr_array(k)
+            orc.lib.orc_fold_i32_cols(A.ctypes.data_as(C.c_void_p), C.c_size_t(m), C.c_size_t(k), orc._p(eq_m), orc._p(left))
+            orc.lib.orc_fold_i32_rows(B.ctypes.data_as(C.c_void_p), C.c_size_t(k), C.c_size_t(n), orc._p(eq_n), orc._p(right))
+        elif lay == "k,nk->n":
+            r_n = r0
+            eq_n = orc.eq_evals(np.ascontiguousarray(r_n))
+            left = fr(A)
+            lo, right = orc.fr_array(k), orc.fr_array(k)
+            orc.lib.orc_einsum_fold_layout(C.c_int(4), B.ctypes.data_as(C.c_void_p), B.ctypes.data_as(C.c_void_p), *(C.c_size_t(x) for x in (1, 1, k, n)),
+                                           orc._p(eq_n), orc._p(eq_n), orc._p(lo), orc._p(right))
+        else:
+            code = {"bmk,bkn->mbn": 0, "bmk,kbn->mbn": 1, "mbk,bnk->bmn": 2, "mbk,nbk->bmn": 3}[lay]
+            if code <= 1:
+                r_m, r_b, r_n = r0[:lm], r0[lm:lm + lb], r0[lm + lb:]; sched, sa, sb = 2, lk, lb
+            else:
+                r_b, r_m, r_n = r0[:lb], r0[lb:lb + lm], r0[lb + lm:]; sched, sa, sb = 1, lb, lk
+            eq_m = orc.eq_evals(np.ascontiguousarray(r_m)) if lm else orc.from_ints([1]); eq_n = orc.eq_evals(np.ascontiguousarray(r_n)) if ln else orc.from_ints([1])
+            left, right = orc.fr_array(k * b), orc.fr_array(k * b)
+            orc.lib.orc_einsum_fold_layout(C.c_int(code), A.ctypes.data_as(C.c_void_p), B.ctypes.data_as(C.c_void_p), *(C.c_size_t(x) for x in (b, m, k, n)),
+                                           orc._p(eq_m), orc._p(eq_n), orc._p(left), orc._p(right))
+            eq = orc.eq_evals(np.ascontiguousarray(r_b)) if lb else orc.from_ints([1])
+        assert np.array_equal(orc.dot_claim(left, right, eq, sched, sa, sb)[0], in_claim), "einsum input claim"
+        proof, ch, fin = orc.sumcheck_dot_prove(left, right, np.ascontiguousarray(in_claim).reshape(1, 4), self.t.t, eq, sched, sa, sb)
+        self.proofs[(nd["idx"], PT["EinsumMatmul"])] = [row for row in proof]
+        c = orc.challenges_to_fr(ch)
+        if lay == "mk,kn->mn":
+            lp, rp = np.concatenate([r_m, c]), np.concatenate([c, r_n])
+        elif lay == "k,nk->n":
+            lp, rp = c, np.concatenate([r_n, c])
+        elif lay.startswith("bmk"):
+            rj, rh = c[:lk], c[lk:]
+            lp = np.concatenate([rh, r_m, rj])
+            rp = np.concatenate([rh, rj, r_n]) if lay == "bmk,bkn->mbn" else np.concatenate([rj, rh, r_n])
+        else:
+            rh, rj = c[:lb], c[lb:]
+            lp = np.concatenate([r_m, c])
+            rp = np.concatenate([rh, r_n, rj]) if lay == "mbk,bnk->bmn" else np.concatenate([r_n, c])
+        self.append_nodeio(nd, 0, lp, fin[0])
+        self.append_nodeio(nd, 1, rp, fin[1])
+
+    def op_fused(self, nd):
+        i = nd["idx"]
+        r0, out_claim = self.reduced[i]
+        w = self.wit[i]; S = w["S"]
+        eval_R, acc_claim = orc.evaluate(fr(w["rem"]), r0), orc.evaluate(fr(w["quot"]), r0)
+        self.append_virtual(node_exec(virt("RescaleRemainder", i), i), r0, eval_R)                     # cache_remainder_prove
+        self.append_virtual(node_exec(virt("ClampAcc", i), i), r0, acc_claim)                          # append_raf_claims_prover
+        cidx = w["quot"].astype(np.int64).view(np.uint64).copy()
+        self.clamp_lookup(nd, cidx, r0, acc_claim, out_claim)
+        in_claim = orc.fr_add_arr(orc.fr_mul_arr(acc_claim, fr([1 << S])[0]), eval_R)                 # fused_input_claim
+        if nd["op"] == "Einsum":
+            self.einsum_matmul(nd, in_claim)
+        else:
+            ew = {"Mul": OR.EW_MUL, "Square": OR.EW_SQUARE, "Cube": OR.EW_CUBE}[nd["op"]]
+            self.ew_sumcheck(nd, ew, 2 if nd["op"] == "Mul" else 1, in_claim, "RescaleArith")
+        ridx = w["rem"].astype(np.uint64)                                                              # prove_remainder_rc
+        phases = 1 if S <= 2 else S // 4 if S % 4 == 0 else S // 2 if S % 2 == 0 else S
+        rr_point, rr_claim = self.read_raf(nd, OR.ps_identity(ridx, S, phases, r0), eval_R, ridx, S, "RescaleRemainderRa", "RangeCheck")
+        self.onehot_checks(nd, ridx, S, r0, rr_point, rr_claim, "RescaleRemainderRaD", "RescaleRemainderRaChecks")
+
+    def op_addsub(self, nd):
+        i = nd["idx"]
+        r0, out_claim = self.reduced[i]
+        acc = self.wit[i]["acc"]
+        if len(acc) > 1:
+            acc_claim = orc.evaluate(fr(acc), r0)
+            self.append_virtual(node_exec(virt("ClampAcc", i), i), r0, acc_claim)
+            self.clamp_lookup(nd, acc.astype(np.int64).view(np.uint64).copy(), r0, acc_claim, out_claim)
+        for q in range(2):
+            self.append_nodeio(nd, q, r0, orc.evaluate(self.mle(nd["inputs"][q]), r0))
+
+    def op_relu(self, nd):
+        i = nd["idx"]
+        r0, out_claim = self.reduced[i]
+        x = self.trace[nd["inputs"][0]]
+        operand_claim = orc.evaluate(fr(x), r0)
+        self.append_nodeio(nd, 0, r0, operand_claim)
+        gamma = self.t.challenge_scalar()
+        lookups = x.astype(np.uint32).astype(np.uint64)
+        exec_claim = orc.fr_add_arr(out_claim, orc.fr_mul_arr(gamma, operand_claim))
+        ra_point, ra_claim = self.read_raf(nd, OR.ps_relu(lookups, 32, r0, gamma), exec_claim, lookups, 32, "NodeOutputRa", "Execution")
+        self.onehot_checks(nd, lookups, 32, r0, ra_point, ra_claim, "NodeOutputRaD", "RaOneHotChecks")
+
+    def prove_node(self, nd):
+        self.eval_reduction(nd)
+        op, i = nd["op"], nd["idx"]
+        r0, claim = self.reduced[i]
+        if op in ("Input", "Constant"):
+            return
+        if op == "Identity":
+            self.append_nodeio(nd, 0, r0, claim)
+        elif op in ("Add", "Sub"):
+            self.op_addsub(nd)
+        elif op in ("Einsum", "Mul", "Square", "Cube"):
+            self.op_fused(nd)
+        elif op == "And":
+            self.ew_sumcheck(nd, OR.EW_MUL, 2, claim, "Execution")
+        elif op == "Iff":
+            self.ew_sumcheck(nd, OR.EW_IFF, 3, claim, "Execution")
+        elif op == "ReLU":
+            self.op_relu(nd)
+        elif op == "Reshape":
+            I = OR.elementwise(OR.EW_DOT, [self.mle(nd["inputs"][0]), orc.eq_evals(np.ascontiguousarray(r0))], r0)
+            rs = self.run(I, claim, i, "Execution")
+            self.append_nodeio(nd, 0, np.ascontiguousarray(rs[::-1]), I.finals()[0])
+        elif op == "MoveAxis":
+            groups, off = [], 0
+            for dim in nd["dims"]:
+                v = ilog2(dim); groups.append(r0[off:off + v]); off += v
+            g = groups.pop(nd["destination"])
+            groups.insert(nd["source"], g)
+            self.append_nodeio(nd, 0, np.concatenate(groups) if groups else r0, claim)
+        elif op == "Broadcast":
+            idims = self.nodes[nd["inputs"][0]]["dims"]
+            offd = len(nd["dims"]) - len(idims)
+            parts, pos = [], 0
+            for a, dim in enumerate(nd["dims"]):
+                v = ilog2(dim)
+                if a >= offd and idims[a - offd] == dim:
+                    parts.append(r0[pos:pos + v])
+                pos += v
+            r_in = np.concatenate(parts) if parts else orc.fr_array(0)
+            self.append_nodeio(nd, 0, r_in, orc.evaluate(self.mle(nd["inputs"][0]), np.ascontiguousarray(r_in)))
+        else:
+            raise ValueError(op)
+
+    def reduced_openings(self):
+        if not self.committed:
+            self.ro = None
+            return
+        keys = sorted(self.committed)
+        insts, kinds = [], []
+        for k in keys:
+            c = self.committed[k]
+            assert "point" in c, f"committed polynomial {k} never opened"
+            ra, rc = c["point"][:4], c["point"][4:]
+            insts.append(OB.ra_instance(OR.onehot_opening(c["row"], 4, ra, rc), c["claim"]))
+        rows, ch, _ = OB.batched_prove(insts, self.t.t)
+        rs = orc.challenges_to_fr(ch)
+        fin = []
+        for k in keys:
+            c = self.committed[k]
+            sl = rs[len(rs) - 4 - c["log_T"]:]
+            Fs = orc.eq_evals(np.ascontiguousarray(sl[:4]))
+            fin.append(orc.evaluate(np.stack([Fs[x] for x in c["row"]]), np.ascontiguousarray(sl[4:])))
+        fin = np.stack(fin)
+        self.t.append_scalars(fin)
+        q = self.t.challenge_scalar()
+        gam = [one()]
+        for _ in range(1, len(fin)):
+            gam.append(orc.fr_mul_arr(gam[-1], q))
+        joint = OB.rlc_build([], [(self.committed[k]["row"], 16, g) for k, g in zip(keys, gam)])
+        assert len(joint) == 1 << len(ch)
+        com, w, v = orc.hyperkzg_open(self.srs, joint, ch, self.t.t)
+        self.ro = dict(rows=rows, claims=fin, com=com, w=w, v=v, ch=ch, joint=joint)
+
+    def prove(self, inputs):
+        nodes = [self.nodes[i] for i in self.order]
+        self.trace, self.wit = execute(nodes, inputs)
+        in_nodes = [nd for nd in nodes if nd["op"] == "Input"]
+        t = self.t
+        t.append_message(b"model_inputs"); t.append_u64(len(in_nodes)); t.append_u64(len(in_nodes))          # append_inputs_to_transcript
+        for nd, x in zip(in_nodes, inputs):
+            t.append_u64(nd["idx"]); t.append_u64(len(nd["dims"]))
+            for d in nd["dims"]:
+                t.append_u64(d)
+            t.append_bytes(np.ascontiguousarray(x, dtype="<i4").tobytes())
+        self.commit()
+        self.output_claim()
+        for i in reversed(self.order):
+            self.prove_node(self.nodes[i])
+        self.reduced_openings()
+        return self.serialize()
+
+    def serialize(self):
+        """ONNXProof::serialize_compressed (proof_serialization.rs:200-224)"""
+        out = u64(len(self.openings))
+        for k in sorted(self.openings):
+            out += opening_id_bytes(k) + fr_bytes(self.openings[k][1])
+        out += u64(len(self.proofs))
+        for k in sorted(self.proofs):
+            out += u64(k[0]) + bytes([k[1]]) + sumcheck_proof_bytes(self.proofs[k])
+        keys = sorted(self.committed)
+        out += u64(len(keys)) + b"".join(g1_compressed(self.committed[k]["commitment"]) for k in keys)
+        out += u64(len(self.evalred))
+        for k in sorted(self.evalred):
+            h = self.evalred[k]
+            out += u64(k) + u64(len(h)) + b"".join(fr_bytes(c) for c in h)
+        if self.ro is None:
+            return out + b"\x00"
+        ro = self.ro
+        out += b"\x01" + sumcheck_proof_bytes(ro["rows"]) + u64(len(ro["claims"])) + b"".join(fr_bytes(c) for c in ro["claims"])
+        ell = len(ro["ch"])
+        out += u64(len(ro["com"])) + b"".join(g1_compressed(p) for p in ro["com"])                            # HyperKZGProof { com, w, v }
+        out += u64(3) + b"".join(g1_compressed(p) for p in ro["w"])
+        out += u64(3)
+        for i in range(3):
+            out += u64(ell) + b"".join(fr_bytes(c) for c in ro["v"][i])
+        return out
+
+
+def eq_bits(r, value, nbits):
+    """prod_i (bit_i ? r_i : 1 - r_i), r[0] <-> MSB of value"""
+    w = one()
+    minus1 = orc.from_ints([FR - 1])[0]
+    for i in range(nbits):
+        bit = (int(value) >> (nbits - 1 - i)) & 1
+        f = r[i] if bit else orc.fr_add_arr(one(), orc.fr_mul_arr(minus1, r[i]))
+        w = orc.fr_mul_arr(w, f)
+    return w
