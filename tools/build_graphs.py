@@ -1,0 +1,105 @@
+"""Graph descriptions for atlas_prove_graph / oracle.graph (the tracer's ComputationGraph vocabulary,
+atlas-onnx-tracer/src/node/mod.rs:12-24, ops/mod.rs:117-155), built with synthetic random-init weights:
+
+  transformer(...)      a GPT-style decoder stack with the operator decomposition the tracer produces for nanoGPT / GPT-2
+                        (atlas-onnx-tracer/models/nanoGPT/network.onnx: MatMul -> Einsum, Pow -> Square / Cube, ReduceMean ->
+                        Sum + ScalarConstDiv / MeanOfSquares, Sqrt + Div -> Rsqrt, Where -> Iff, tanh-GELU -> Cube / Mul / Tanh,
+                        Softmax -> SoftmaxLastAxis, Gather -> GatherLarge), shapes padded to powers of two (vocab 65 -> 128)
+  nanogpt()             seq 64, d_model 64, 4 heads, 4 layers, vocab 128   (BASELINE config 3 shape)
+  gpt2_layer()          seq 16, d_model 768 -> 1024, 12 -> 16 heads, one layer + lm-head slice (BASELINE config 4 shape, one layer)
+
+`level` selects how much of the decomposition is emitted, following what the graph prover composes:
+  0  linear algebra + residuals only (Einsum / Add / Mul / ReLU / Reshape / Iff)      [round-3 first slice]
+  1  + LayerNorm (Sum, ScalarConstDiv, Sub, Square, MeanOfSquares / Rsqrt)
+  2  + SoftmaxLastAxis, tanh-GELU (Cube, Tanh), GatherLarge embedding
+
+The tensors are synthetic (there is no tracer here); the operator list per layer and the shapes are the model's."""
+import numpy as np
+
+
+class B:
+    def __init__(self, seed):
+        self.nodes, self.rng = [], np.random.default_rng(seed)
+
+    def add(self, op, inputs, dims, **kw):
+        nd = {"idx": len(self.nodes), "op": op, "inputs": list(inputs), "dims": list(dims)}
+        nd.update(kw)
+        self.nodes.append(nd)
+        return nd["idx"]
+
+    def const(self, dims, lo, hi):
+        return self.add("Constant", [], dims, data=self.rng.integers(lo, hi, size=int(np.prod(dims))).astype(np.int32))
+
+    def const_data(self, dims, data):
+        return self.add("Constant", [], dims, data=np.ascontiguousarray(data, dtype=np.int32).reshape(-1))
+
+    def matmul(self, x, w, m, k, n, S):
+        return self.add("Einsum", [x, w], [m, n], layout="mk,kn->mn", scale=S, shape=[m, k, n])
+
+
+def transformer(layers, seq, d_model, heads, vocab, S=7, level=0, seed=0, mlp_mult=4, final_head=True):
+    b = B(seed)
+    hd = d_model // heads
+    wlim = 1 << (S - 1)                      # weights ~ U(-2^(S-1), 2^(S-1)): |w| < 1.0 at scale S
+    x = b.add("Input", [], [seq, d_model])
+    mask = b.const_data([seq, seq], np.tril(np.ones((seq, seq), dtype=np.int32)))
+    maskb = b.add("Broadcast", [mask], [heads, seq, seq])
+    neg = b.const_data([heads, seq, seq], np.full(heads * seq * seq, -(1 << (S + 3)), dtype=np.int32))
+
+    def norm(h):
+        if level < 1:
+            return h
+        raise NotImplementedError
+
+    for _ in range(layers):
+        h = norm(x)
+        # attention: q, k, v projections (one Einsum each: the tracer splits the fused qkv Gemm through Slice nodes)
+        q = b.matmul(h, b.const([d_model, d_model], -wlim, wlim), seq, d_model, d_model, S)
+        k = b.matmul(h, b.const([d_model, d_model], -wlim, wlim), seq, d_model, d_model, S)
+        v = b.matmul(h, b.const([d_model, d_model], -wlim, wlim), seq, d_model, d_model, S)
+        qh = b.add("Reshape", [q], [seq, heads, hd])
+        kh = b.add("Reshape", [k], [seq, heads, hd])
+        vh = b.add("Reshape", [v], [seq, heads, hd])
+        att = b.add("Einsum", [qh, kh], [heads, seq, seq], layout="mbk,nbk->bmn", scale=S, shape=[heads, seq, hd, seq])
+        att = b.add("Iff", [maskb, att, neg], [heads, seq, seq])
+        if level >= 2:
+            raise NotImplementedError
+        else:
+            att = b.add("ReLU", [att], [heads, seq, seq])
+        y = b.add("Einsum", [att, vh], [seq, heads, hd], layout="bmk,kbn->mbn", scale=S, shape=[heads, seq, seq, hd])
+        y = b.add("Reshape", [y], [seq, d_model])
+        y = b.matmul(y, b.const([d_model, d_model], -wlim, wlim), seq, d_model, d_model, S)
+        x = b.add("Add", [x, y], [seq, d_model])
+        # MLP
+        h = norm(x)
+        f = b.matmul(h, b.const([d_model, mlp_mult * d_model], -wlim, wlim), seq, d_model, mlp_mult * d_model, S)
+        f = b.add("Add", [f, b.const([seq, mlp_mult * d_model], -wlim, wlim)], [seq, mlp_mult * d_model])
+        if level >= 2:
+            raise NotImplementedError
+        else:
+            f = b.add("ReLU", [f], [seq, mlp_mult * d_model])
+        f = b.matmul(f, b.const([mlp_mult * d_model, d_model], -wlim, wlim), seq, mlp_mult * d_model, d_model, S)
+        x = b.add("Add", [x, f], [seq, d_model])
+    x = norm(x)
+    if final_head:
+        x = b.matmul(x, b.const([d_model, vocab], -wlim, wlim), seq, d_model, vocab, S)
+    inputs = [np.random.default_rng(seed + 1).integers(-(1 << S), 1 << S, size=seq * d_model).astype(np.int32)]
+    return b.nodes, [x], inputs
+
+
+def nanogpt(level=0, seed=0):
+    return transformer(layers=4, seq=64, d_model=64, heads=4, vocab=128, S=7, level=level, seed=seed)
+
+
+def gpt2_layer(level=0, seed=0):
+    # d_model 768 and 12 heads padded to 1024 / 16 (every dimension a power of two); the lm head is a 2^14-column slice
+    return transformer(layers=1, seq=16, d_model=1024, heads=16, vocab=1 << 14, S=7, level=level, seed=seed)
+
+
+def tiny(level=0, seed=0, layers=2):
+    return transformer(layers=layers, seq=4, d_model=8, heads=2, vocab=16, S=5, level=level, seed=seed, mlp_mult=2)
+
+
+def max_vars(nodes):
+    """log2 of the largest committed polynomial: a one-hot chunk has 16 x T coefficients"""
+    return 4 + max(int(np.log2(np.prod(nd["dims"]))) for nd in nodes)
