@@ -46,6 +46,63 @@ __global__ __launch_bounds__(256) void k_gather_strided(const int32_t* __restric
     }
 }
 
+// Sum over one axis of a [m][n] tensor in i64 (sum_axes_i64, ops/sum.rs:18-58): axis 0 -> n outputs, axis 1 -> m outputs; the clamped
+// output and the clamp lookup index; with `squares`: sum of squares (mos_acc_i64, ops/mean_of_squares.rs:19-52)
+__global__ __launch_bounds__(256) void k_sum_axis(const int32_t* __restrict__ x, uint32_t m, uint32_t n, int axis, int squares, int64_t* __restrict__ acc) {
+    const uint32_t outs = axis == 0 ? n : m, len = axis == 0 ? m : n;
+    for (uint32_t o = blockIdx.x * 256 + threadIdx.x; o < outs; o += gridDim.x * 256) {
+        int64_t s = 0;
+        for (uint32_t l = 0; l < len; l++) { const int64_t v = axis == 0 ? x[(size_t)l * n + o] : x[(size_t)o * n + l]; s += squares ? v * v : v; }
+        acc[o] = s;
+    }
+}
+__global__ __launch_bounds__(256) void k_clamp_acc(const int64_t* __restrict__ acc, size_t n, int32_t* __restrict__ out, uint64_t* __restrict__ idx) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int64_t a = acc[i];
+        out[i] = (int32_t)(a > 2147483647ll ? 2147483647ll : a < -2147483648ll ? -2147483648ll : a);
+        idx[i] = (uint64_t)a;
+    }
+}
+// floor division with the remainder of the divisor's sign (ops/div.rs:9-23, scalar_const_div.rs:9-22; utils/mod.rs:24-30 adjusted_remainder);
+// b == nullptr: the scalar constant `c`
+__global__ __launch_bounds__(256) void k_floor_div(const int32_t* __restrict__ a, const int32_t* __restrict__ b, int32_t c, size_t n, int32_t* __restrict__ q,
+                                                   int32_t* __restrict__ r) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int32_t x = a[i], d = b ? b[i] : c;
+        int32_t qq = d ? x / d : 0, rr = d ? x % d : 0;
+        if ((rr < 0 && d > 0) || (rr > 0 && d < 0)) { qq -= 1; rr += d; }
+        q[i] = qq; r[i] = rr;
+    }
+}
+// mean of squares: quotient / remainder of the accumulation by D = count 2^scale (mos_intermediate_and_remainder), the clamp lookup
+// index, the clamped output and the constant bound tensor of the range check
+__global__ __launch_bounds__(256) void k_mos_rebase(int64_t* __restrict__ acc /* in: sums, out: quotients */, size_t n, int64_t D, int32_t* __restrict__ rem,
+                                                    int32_t* __restrict__ out, uint64_t* __restrict__ cidx, int32_t* __restrict__ bound) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int64_t a = acc[i];
+        int64_t q = a / D, r = a % D;
+        if (r < 0) { r += D; q -= 1; }
+        acc[i] = q; rem[i] = (int32_t)r; cidx[i] = (uint64_t)q; bound[i] = (int32_t)D;
+        out[i] = (int32_t)(q > 2147483647ll ? 2147483647ll : q < -2147483648ll ? -2147483648ll : q);
+    }
+}
+// Rsqrt (ops/rsqrt.rs:18-29 + jolt-atlas-core ops/rsqrt.rs:238-250): out = isqrt(2^(3 scale) / x), quotient, both remainders and the
+// second range check's bound 2 out + 1
+__global__ __launch_bounds__(256) void k_rsqrt(const int32_t* __restrict__ x, size_t n, int64_t s_cubed, int32_t* __restrict__ out, int64_t* __restrict__ quot,
+                                               int32_t* __restrict__ div_rem, int32_t* __restrict__ sqrt_rem, int32_t* __restrict__ bound) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int64_t v = x[i];
+        int64_t q = 0, dr = 0, o = 0;
+        if (v > 0) {
+            q = s_cubed / v; dr = s_cubed % v;
+            o = (int64_t)sqrt((double)q);
+            while (o * o > q) o--;
+            while ((o + 1) * (o + 1) <= q) o++;
+        }
+        out[i] = (int32_t)o; quot[i] = q; div_rem[i] = (int32_t)dr; sqrt_rem[i] = (int32_t)(q - o * o); bound[i] = (int32_t)(2 * o + 1);
+    }
+}
+
 unsigned grid_for(size_t n) { size_t b = (n + 255) / 256; return (unsigned)(b > 4096 ? 4096 : b ? b : 1); }
 
 std::vector<size_t> row_major(const std::vector<size_t>& dims) {
@@ -81,6 +138,15 @@ int atlas_rt_einsum_acc(const Node& nd, const int32_t* L, const int32_t* R, int6
     return ATLAS_OK;
 }
 
+// sum_config (jolt-atlas-core/src/utils/dims.rs:545-607): leading dimensions of 1 are dropped until the operand is [m][n]; a 1-d operand is [m][1], axis 0
+int atlas_rt_sum_config(const std::vector<size_t>& idims, size_t axis, size_t& m, size_t& n, int& ax) {
+    std::vector<size_t> d = idims;
+    while (d.size() > 2) { if (d[0] != 1 || axis == 0) return fail(ATLAS_EINVAL, "graph: Sum supports a leading batch of 1 only"); d.erase(d.begin()); axis--; }
+    if (d.size() == 1) { m = d[0]; n = 1; ax = 0; return axis == 0 ? ATLAS_OK : fail(ATLAS_EINVAL, "graph: Sum axis"); }
+    m = d[0]; n = d[1]; ax = (int)axis;
+    return axis < 2 ? ATLAS_OK : fail(ATLAS_EINVAL, "graph: Sum axis");
+}
+
 namespace {
 
 int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs, size_t& next_input) {
@@ -92,6 +158,7 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
     auto need_inputs = [&](size_t n) { return nd.inputs.size() == n; };
     auto same_len = [&]() { for (size_t i = 0; i < nd.inputs.size(); i++) if (gr::padded_len(in_node(i).dims) != T) return false; return true; };
     if (nd.op != ATLAS_OP_EINSUM && nd.op != ATLAS_OP_MUL && nd.op != ATLAS_OP_SQUARE && nd.op != ATLAS_OP_CUBE) HIP_TRY(out.alloc(T * 4));
+    if (T > ((size_t)1 << 26)) return fail(ATLAS_EINVAL, "graph: a node output above 2^26 elements");
     std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     switch (nd.op) {
         case ATLAS_OP_INPUT:
@@ -176,6 +243,57 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
             if (rc) return rc;
             out.p = W.rescale->out_own.release();                             // the node output = SatClamp_i32(acc >> S)
             W.rescale->d_output = out.as<int32_t>();
+            return ATLAS_OK;
+        }
+        case ATLAS_OP_SUM: {                                                  // Sum { axes: [a] } over a 2-d operand (utils/dims.rs:545-607 normalises to 2-d)
+            if (!need_inputs(1) || nd.shape.size() != 1) return fail(ATLAS_EINVAL, "graph: Sum needs one operand and one axis");
+            size_t m, n; int axis;
+            if (int rc = atlas_rt_sum_config(in_node(0).dims, nd.shape[0], m, n, axis)) return rc;
+            if (T != (axis == 0 ? n : m)) return fail(ATLAS_EINVAL, "graph: Sum output dims");
+            NodeWitness& W = G.wit[nd.idx];
+            HIP_TRY(W.acc.alloc(T * 8)); HIP_TRY(W.cidx.alloc(T * 8)); HIP_TRY(W.acc_fr.alloc(T * sizeof(Fr)));
+            k_sum_axis<<<grid_for(T), 256, 0, g.stream>>>(in(0), (uint32_t)m, (uint32_t)n, axis, 0, W.acc.as<int64_t>());
+            k_clamp_acc<<<grid_for(T), 256, 0, g.stream>>>(W.acc.as<int64_t>(), T, out.as<int32_t>(), W.cidx.as<uint64_t>());
+            k_i64_to_fr<<<grid_for(T), 256, 0, g.stream>>>(W.acc.as<int64_t>(), W.acc_fr.as<Fr>(), T);
+            return ATLAS_OK;
+        }
+        case ATLAS_OP_SCALAR_CONST_DIV: case ATLAS_OP_DIV: {
+            const bool sc = nd.op == ATLAS_OP_SCALAR_CONST_DIV;
+            if (!need_inputs(sc ? 1 : 2) || !same_len()) return fail(ATLAS_EINVAL, "graph: Div / ScalarConstDiv operands");
+            if (sc && nd.p[0] == 0) return fail(ATLAS_EINVAL, "graph: ScalarConstDiv by zero");
+            NodeWitness& W = G.wit[nd.idx];
+            HIP_TRY(W.rem.alloc(T * 4));
+            k_floor_div<<<grid_for(T), 256, 0, g.stream>>>(in(0), sc ? nullptr : in(1), (int32_t)nd.p[0], T, out.as<int32_t>(), W.rem.as<int32_t>());
+            if (!sc) { uint64_t* lk2 = nullptr; int rc = atlas_lookup_indices_from_operands(W.rem.as<int32_t>(), in(1), T, &lk2); if (rc) return rc; W.lookups.p = lk2; }   // interleave(R, divisor)
+            return ATLAS_OK;
+        }
+        case ATLAS_OP_MEAN_OF_SQUARES: {                                      // MeanOfSquares { axes: [last], scale, count, padded_count }: operand [K][N]
+            if (!need_inputs(1)) return fail(ATLAS_EINVAL, "graph: MeanOfSquares operand");
+            const size_t N = in_node(0).dims.back(), K = gr::padded_len(in_node(0).dims) / N;
+            const int64_t D = ((int64_t)1 << nd.p[0]) * (int64_t)nd.p[1];
+            if (T != K || nd.p[1] <= 0 || (size_t)nd.p[1] > N || D > 2147483647ll) return fail(ATLAS_EINVAL, "graph: MeanOfSquares dims / count / divisor");
+            NodeWitness& W = G.wit[nd.idx];
+            W.rescale.reset(new RescaleWitness());
+            RescaleWitness& R = *W.rescale;
+            R.T = T; R.S = 0;
+            HIP_TRY(R.quot.alloc(T * 8)); HIP_TRY(R.rem.alloc(T * 4)); HIP_TRY(R.cidx.alloc(T * 8)); HIP_TRY(R.qfr.alloc(T * sizeof(Fr))); HIP_TRY(W.bound.alloc(T * 4));
+            k_sum_axis<<<grid_for(T), 256, 0, g.stream>>>(in(0), (uint32_t)K, (uint32_t)N, 1, 1, R.quot.as<int64_t>());
+            k_mos_rebase<<<grid_for(T), 256, 0, g.stream>>>(R.quot.as<int64_t>(), T, D, R.rem.as<int32_t>(), out.as<int32_t>(), R.cidx.as<uint64_t>(), W.bound.as<int32_t>());
+            k_i64_to_fr<<<grid_for(T), 256, 0, g.stream>>>(R.quot.as<int64_t>(), R.qfr.as<Fr>(), T);
+            R.d_output = out.as<int32_t>();
+            { uint64_t* lk2 = nullptr; int rc = atlas_lookup_indices_from_operands(R.rem.as<int32_t>(), W.bound.as<int32_t>(), T, &lk2); if (rc) return rc; W.lookups.p = lk2; }
+            return ATLAS_OK;
+        }
+        case ATLAS_OP_RSQRT: {
+            if (!need_inputs(1) || !same_len() || nd.p[0] <= 0 || nd.p[0] > 14) return fail(ATLAS_EINVAL, "graph: Rsqrt operand / scale (1..14)");
+            NodeWitness& W = G.wit[nd.idx];
+            DevBuf q64;
+            HIP_TRY(q64.alloc(T * 8)); HIP_TRY(W.quot_fr.alloc(T * sizeof(Fr))); HIP_TRY(W.rem.alloc(T * 4)); HIP_TRY(W.rem2.alloc(T * 4)); HIP_TRY(W.bound.alloc(T * 4));
+            k_rsqrt<<<grid_for(T), 256, 0, g.stream>>>(in(0), T, (int64_t)1 << (3 * nd.p[0]), out.as<int32_t>(), q64.as<int64_t>(), W.rem.as<int32_t>(), W.rem2.as<int32_t>(), W.bound.as<int32_t>());
+            k_i64_to_fr<<<grid_for(T), 256, 0, g.stream>>>(q64.as<int64_t>(), W.quot_fr.as<Fr>(), T);
+            HIP_TRY(hipStreamSynchronize(g.stream));                          // q64 leaves scope
+            { uint64_t* lk2 = nullptr; int rc = atlas_lookup_indices_from_operands(W.rem.as<int32_t>(), in(0), T, &lk2); if (rc) return rc; W.lookups.p = lk2; }
+            { uint64_t* lk2 = nullptr; int rc = atlas_lookup_indices_from_operands(W.rem2.as<int32_t>(), W.bound.as<int32_t>(), T, &lk2); if (rc) return rc; W.lookups2.p = lk2; }
             return ATLAS_OK;
         }
         default: return fail(ATLAS_EINVAL, "graph_trace: operator not supported by the device executor");

@@ -23,7 +23,24 @@ using gr::PolyId;
 int atlas_rt_einsum_strides(int layout, const std::vector<size_t>& d, std::vector<size_t>& out_dims, std::vector<size_t>& la, std::vector<size_t>& ra, size_t& K,
                             size_t& lsk, size_t& rsk);
 
+int atlas_rt_sum_config(const std::vector<size_t>& idims, size_t axis, size_t& m, size_t& n, int& ax);
+
 namespace {
+
+__global__ __launch_bounds__(256) void k_i32_to_fr(const int32_t* __restrict__ in, Fr* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) fe_store(out + i, fr_from_i64((int64_t)in[i]));
+}
+// build_slice_selector (ops/slice.rs): selector[input index of output cell o] = eq(r_output, o), zero elsewhere
+struct SliceMap { uint32_t n; uint32_t dim[6]; uint32_t stride[6]; };
+__global__ __launch_bounds__(256) void k_slice_selector(const Fr* __restrict__ eq, SliceMap M, size_t base, size_t T_out, Fr* __restrict__ sel /* zeroed */) {
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < T_out; o += (size_t)gridDim.x * 256) {
+        size_t rem = o, off = base;
+        for (int d = (int)M.n - 1; d >= 0; d--) { off += (rem % M.dim[d]) * M.stride[d]; rem /= M.dim[d]; }
+        sel[off] = eq[o];
+    }
+}
+unsigned grid_of(size_t n) { size_t b = (n + 255) / 256; return (unsigned)(b > 4096 ? 4096 : b ? b : 1); }
+H::Fr fr_from_i64_host(int64_t v) { return v >= 0 ? H::from_u64((uint64_t)v) : H::neg(H::from_u64((uint64_t)(-v))); }
 
 double ms_between(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); }
 
@@ -56,6 +73,21 @@ struct Prover : FlowSink {
     int append_nodeio(const Node& nd, size_t pos, const Point& point, const H::Fr& claim) {
         Out O = out();
         return O.append_virtual(Tr, gr::node_exec(gr::virt(gr::VP_NodeOutput, nd.inputs[pos]), nd.idx), point, claim);
+    }
+    // append_advice(CommittedPoly::X) -> ProverOpeningAccumulator::append_dense (opening_proof.rs:265-315): a dense committed
+    // polynomial of this node opened at `point`
+    int append_dense(const Node& nd, uint8_t cp_var, const Point& point, const H::Fr& claim) {
+        H::tr_append_scalar(Tr, claim);
+        const PolyId p = gr::comm(cp_var, nd.idx);
+        openings[gr::node_exec(p, nd.idx)] = gr::Opening{point, claim};
+        auto it = committed.find(p);
+        if (it == committed.end()) return fail(ATLAS_ESTATE, "prove_graph: dense opening of a polynomial that was not committed");
+        it->second->opened = true; it->second->point = point; it->second->claim = claim;
+        return ATLAS_OK;
+    }
+    int append_advice(const Node& nd, uint8_t vp, const Point& point, const H::Fr& claim) {
+        Out O = out();
+        return O.append_virtual(Tr, gr::node_exec(gr::virt(vp, nd.idx), nd.idx), point, claim);
     }
     const gr::Opening& red(const Node& nd) const { return reduced.at(nd.idx); }
 
@@ -93,6 +125,8 @@ struct Prover : FlowSink {
             const Node& nd = kv.second;
             NodeWitness& W = G.wit[nd.idx];
             W.committed.clear();
+            for (auto pv : W.dense_views) if (pv) atlas_poly_free(pv);
+            W.dense_views.clear();
             const size_t T = gr::padded_len(nd.dims), log_T = gr::log2u(T);
             auto chunks = [&](uint8_t cp, const uint64_t* d_lookups, size_t log_K) {
                 const size_t d = (log_K + 3) / 4;
@@ -101,7 +135,16 @@ struct Prover : FlowSink {
                     W.committed.push_back(c);
                 }
             };
-            if (T == 1) continue;                                             // is_scalar: no committed polynomials
+            int drc = ATLAS_OK;
+            auto dense = [&](uint8_t cp, void* d_data, bool is_i32) {
+                atlas_poly_t v = nullptr;
+                drc = is_i32 ? atlas_poly_wrap_device_i32((int32_t*)d_data, T, &v) : atlas_poly_wrap_device_fr(d_data, T, &v);
+                if (drc) return;
+                W.dense_views.push_back(v);
+                gr::Committed c; c.id = gr::comm(cp, nd.idx); c.kind = 0; c.dense = v; c.log_T = log_T;
+                W.committed.push_back(c);
+            };
+            if (T == 1 && nd.op != ATLAS_OP_SCALAR_CONST_DIV) continue;       // is_scalar: no committed polynomials
             switch (nd.op) {
                 case ATLAS_OP_ADD: case ATLAS_OP_SUB: chunks(gr::CP_ClampRaD, W.cidx.as<uint64_t>(), 64); break;       // clamp_committed_polys
                 case ATLAS_OP_EINSUM: case ATLAS_OP_MUL: case ATLAS_OP_SQUARE: case ATLAS_OP_CUBE:                     // fused_rebase::committed_polys
@@ -109,8 +152,24 @@ struct Prover : FlowSink {
                     chunks(gr::CP_ClampRaD, W.rescale->cidx.as<uint64_t>(), 64);
                     break;
                 case ATLAS_OP_RELU: chunks(gr::CP_NodeOutputRaD, W.lookups.as<uint64_t>(), 32); break;                 // ops/relu.rs
+                case ATLAS_OP_SUM: chunks(gr::CP_ClampRaD, W.cidx.as<uint64_t>(), 64); break;                           // ops/sum/mod.rs
+                case ATLAS_OP_SCALAR_CONST_DIV: dense(gr::CP_ScalarConstDivNodeRemainder, W.rem.p, true); break;         // ops/scalar_const_div.rs
+                case ATLAS_OP_DIV:                                                                                       // ops/div.rs
+                    dense(gr::CP_DivNodeQuotient, G.out[nd.idx].p, true);
+                    chunks(gr::CP_DivRangeCheckRaD, W.lookups.as<uint64_t>(), 64);
+                    break;
+                case ATLAS_OP_MEAN_OF_SQUARES:                                                                           // ops/mean_of_squares.rs
+                    chunks(gr::CP_ClampRaD, W.rescale->cidx.as<uint64_t>(), 64);
+                    chunks(gr::CP_MeanOfSquaresRangeCheckRaD, W.lookups.as<uint64_t>(), 64);
+                    break;
+                case ATLAS_OP_RSQRT:                                                                                     // ops/rsqrt.rs
+                    dense(gr::CP_RsqrtQuotient, W.quot_fr.p, false);
+                    chunks(gr::CP_SqrtDivRangeCheckRaD, W.lookups.as<uint64_t>(), 64);
+                    chunks(gr::CP_SqrtRangeCheckRaD, W.lookups2.as<uint64_t>(), 64);
+                    break;
                 default: break;
             }
+            if (drc) return drc;
             for (auto& c : W.committed) committed[c.id] = &c;
         }
         return ATLAS_OK;
@@ -396,8 +455,264 @@ struct Prover : FlowSink {
         return rc;
     }
 
+    // the binary range check `remainder < bound` (range_checking/mod.rs:37-100, ps_shout/binary.rs:148-200): gamma, PS-Shout over
+    // UnsignedLessThanTable<32> on interleave(remainder, bound), input claim 1 + gamma left + gamma^2 right
+    int range_check_new(const uint64_t* d_lookups, size_t log_T, const Point& r_cycle, const H::Fr& left, const H::Fr& right, atlas_instance_t* inst, H::Fr* claim) {
+        const H::Fr gamma = H::tr_challenge_scalar(Tr);
+        *claim = H::add(H::one(), H::add(H::mul(gamma, left), H::mul(H::mul(gamma, gamma), right)));
+        return atlas_ps_shout_ult_new(d_lookups, log_T, (const atlas_fr_t*)r_cycle.data(), (const atlas_fr_t*)&gamma, inst);
+    }
+    // one range check on its own Sumcheck::prove + its one-hot checks (ops/div.rs:453-497, mean_of_squares.rs:104-133)
+    int range_and_onehot(const Node& nd, const uint64_t* d_lookups, const Point& r_cycle, const H::Fr& left, const H::Fr& right, uint8_t ra_vp, uint8_t rad_cp,
+                         uint8_t pt_onehot) {
+        const size_t log_T = r_cycle.size();
+        Out O = out();
+        atlas_instance_t inst = nullptr; H::Fr claim;
+        int rc = range_check_new(d_lookups, log_T, r_cycle, left, right, &inst, &claim);
+        std::vector<atlas_u128_t> ch; H::Fr ra_claim; std::vector<atlas_fr_t> ra_point;
+        if (!rc) rc = prove_single(inst, claim, &t, O, ch, &ra_claim, 64, ra_vp, gr::PT_RangeCheck, &ra_point);
+        if (inst) atlas_instance_free(inst);
+        if (!rc) rc = prove_onehot_checks(d_lookups, log_T, 64, (const atlas_fr_t*)r_cycle.data(), ra_point, ra_claim, &t, O, rad_cp, pt_onehot);
+        return rc;
+    }
+    Point challenge_point(size_t n) {
+        Point r(n);
+        for (size_t i = 0; i < n; i++) { uint64_t lo, hi; H::tr_challenge_u128(Tr, lo, hi); r[i] = H::challenge_to_fr(lo, hi, g.challenge_mode); }
+        return r;
+    }
+
+    // Sum (ops/sum/mod.rs:53-86): the clamp lookup over the i64 accumulation, then SumAxisProver over the reduced axis
+    int op_sum(const Node& nd) {
+        const size_t T = gr::padded_len(nd.dims), log_T = gr::log2u(T);
+        const gr::Opening& R = red(nd);
+        NodeWitness& W = G.wit[nd.idx];
+        Out O = out();
+        size_t m, n; int axis;
+        int rc = atlas_rt_sum_config(G.nodes.at(nd.inputs[0]).dims, nd.shape[0], m, n, axis);
+        if (rc) return rc;
+        atlas_poly_t p_acc = nullptr;
+        H::Fr acc_claim;
+        rc = atlas_poly_wrap_device_fr(W.acc_fr.p, T, &p_acc);
+        if (!rc) rc = atlas_poly_evaluate(p_acc, (const atlas_fr_t*)R.point.data(), log_T, (atlas_fr_t*)&acc_claim);
+        if (p_acc) atlas_poly_free(p_acc);
+        if (!rc) rc = O.append_virtual(Tr, gr::node_exec(gr::virt(gr::VP_ClampAcc, nd.idx), nd.idx), R.point, acc_claim);           // prove_append_acc / append_raf_claims_prover
+        if (!rc && T > 1) rc = prove_clamp_lookup_flow(W.cidx.as<uint64_t>(), log_T, (const atlas_fr_t*)R.point.data(), acc_claim, R.claim, &t, O, nullptr);
+        if (rc) return rc;
+        atlas_poly_t eq = nullptr, v = nullptr;
+        rc = atlas_eq_evals((const atlas_fr_t*)R.point.data(), log_T, nullptr, &eq);
+        if (!rc) rc = axis == 0 ? atlas_fold_i32_rows(G.tensor(nd.inputs[0]), m, n, eq, &v) : atlas_fold_i32_cols(G.tensor(nd.inputs[0]), m, n, eq, &v);
+        if (eq) atlas_poly_free(eq);
+        atlas_instance_t inst = nullptr;
+        if (!rc) rc = atlas_softmax_instance_new(ATLAS_SM_SUM_AXIS, v, nullptr, 0, gr::log2u(axis == 0 ? m : n), nullptr, &inst);
+        if (v) atlas_poly_free(v);
+        std::vector<H::Fr> rs, fin;
+        if (!rc) rc = run_single(inst, acc_claim, gr::PT_SumReduction, rs, fin);
+        if (inst) atlas_instance_free(inst);
+        if (rc) return rc;
+        Point pt;                                                             // axis.rs:244-262: (challenges | r) for Axis0, (r | challenges) for Axis1
+        if (axis == 0) { pt = rs; pt.insert(pt.end(), R.point.begin(), R.point.end()); }
+        else { pt = R.point; pt.insert(pt.end(), rs.begin(), rs.end()); }
+        return append_nodeio(nd, 0, pt, fin[0]);
+    }
+
+    // ScalarConstDiv (ops/scalar_const_div.rs): sum_x eq(r, x) (left(x) - R(x)) = q(r) * divisor
+    int op_scalar_const_div(const Node& nd) {
+        const size_t T = gr::padded_len(nd.dims), log_T = gr::log2u(T);
+        const gr::Opening& R = red(nd);
+        NodeWitness& W = G.wit[nd.idx];
+        atlas_poly_t ops[2] = {nullptr, nullptr};
+        int rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(G.tensor(nd.inputs[0])), T, &ops[0]);
+        if (!rc) rc = atlas_poly_wrap_device_i32(W.rem.as<int32_t>(), T, &ops[1]);
+        atlas_instance_t inst = nullptr;
+        if (!rc) rc = atlas_elementwise_new(ATLAS_EW_SUB, ops, 2, (const atlas_fr_t*)R.point.data(), log_T, nullptr, 0, &inst);
+        for (atlas_poly_t p : ops) if (p) atlas_poly_free(p);
+        std::vector<H::Fr> rs, fin;
+        if (!rc) rc = run_single(inst, H::mul(R.claim, fr_from_i64_host(nd.p[0])), gr::PT_Execution, rs, fin);
+        if (inst) atlas_instance_free(inst);
+        const Point pt = reversed(rs);
+        if (!rc) rc = append_nodeio(nd, 0, pt, fin[0]);
+        if (!rc) rc = append_dense(nd, gr::CP_ScalarConstDivNodeRemainder, pt, fin[1]);
+        return rc;
+    }
+
+    // Slice (ops/slice.rs): sum_x input(x) selector(x) over the INPUT's hypercube
+    int op_slice(const Node& nd) {
+        const Node& in = G.nodes.at(nd.inputs[0]);
+        const size_t T_out = gr::padded_len(nd.dims), T_in = gr::padded_len(in.dims), log_in = gr::log2u(T_in);
+        const gr::Opening& R = red(nd);
+        atlas_poly_t eq = nullptr, ops[2] = {nullptr, nullptr};
+        DevBuf sel;
+        HIP_TRY(sel.alloc(T_in * sizeof(Fr)));
+        int rc = atlas_eq_evals((const atlas_fr_t*)R.point.data(), gr::log2u(T_out), nullptr, &eq);
+        if (!rc) {
+            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+            SliceMap M{}; M.n = (uint32_t)nd.dims.size();
+            size_t stride = 1;
+            for (int a = (int)in.dims.size() - 1; a >= 0; a--) { M.dim[a] = (uint32_t)nd.dims[a]; M.stride[a] = (uint32_t)stride; stride *= in.dims[a]; }
+            const size_t base = (size_t)nd.p[1] * M.stride[nd.p[0]];
+            HIP_TRY(hipMemsetAsync(sel.p, 0, T_in * sizeof(Fr), g.stream));
+            k_slice_selector<<<grid_of(T_out), 256, 0, g.stream>>>((const Fr*)eq->d, M, base, T_out, sel.as<Fr>());
+            HIP_TRY(hipStreamSynchronize(g.stream));
+        }
+        if (eq) atlas_poly_free(eq);
+        if (!rc) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(G.tensor(in.idx)), T_in, &ops[0]);
+        if (!rc) rc = atlas_poly_wrap_device_fr(sel.p, T_in, &ops[1]);
+        atlas_instance_t inst = nullptr;
+        if (!rc) rc = atlas_elementwise_new(ATLAS_EW_DOT, ops, 2, nullptr, log_in, nullptr, 0, &inst);
+        for (atlas_poly_t p : ops) if (p) atlas_poly_free(p);
+        std::vector<H::Fr> rs, fin;
+        if (!rc) rc = run_single(inst, R.claim, gr::PT_Execution, rs, fin);
+        if (inst) atlas_instance_free(inst);
+        if (!rc) rc = append_nodeio(nd, 0, reversed(rs), fin[0]);
+        return rc;
+    }
+
+    // Div (ops/div.rs, ReductionFlow::Custom): the division sumcheck at a FRESH point, then the node's eval reduction, the committed
+    // quotient at the reduced point, the range check R < divisor and its one-hot checks
+    int op_div(const Node& nd) {
+        const size_t T = gr::padded_len(nd.dims), log_T = gr::log2u(T);
+        NodeWitness& W = G.wit[nd.idx];
+        const Point r = challenge_point(log_T);                              // DivParams::new
+        atlas_poly_t ops[4] = {nullptr, nullptr, nullptr, nullptr};
+        const int32_t* src[4] = {G.tensor(nd.inputs[0]), G.tensor(nd.inputs[1]), G.tensor(nd.idx), W.rem.as<int32_t>()};
+        int rc = ATLAS_OK;
+        for (int i = 0; i < 4 && !rc; i++) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(src[i]), T, &ops[i]);
+        atlas_instance_t inst = nullptr;
+        if (!rc) rc = atlas_elementwise_new(ATLAS_EW_DIV, ops, 4, (const atlas_fr_t*)r.data(), log_T, nullptr, 0, &inst);
+        for (atlas_poly_t p : ops) if (p) atlas_poly_free(p);
+        std::vector<H::Fr> rs, fin;
+        if (!rc) rc = run_single(inst, H::zero(), gr::PT_Execution, rs, fin);
+        if (inst) atlas_instance_free(inst);
+        if (rc) return rc;
+        const Point pt = reversed(rs);
+        rc = append_nodeio(nd, 0, pt, fin[0]);
+        if (!rc) rc = append_nodeio(nd, 1, pt, fin[1]);
+        if (!rc) { Out O = out(); rc = O.append_virtual(Tr, gr::node_exec(gr::virt(gr::VP_NodeOutput, nd.idx), nd.idx), pt, fin[2]); }     // Target::Current
+        if (!rc) rc = append_advice(nd, gr::VP_DivRemainder, pt, fin[3]);
+        if (!rc) rc = eval_reduction(nd);
+        if (rc) return rc;
+        const gr::Opening& R = red(nd);
+        rc = append_dense(nd, gr::CP_DivNodeQuotient, R.point, R.claim);
+        if (rc || T == 1) return rc;
+        return range_and_onehot(nd, W.lookups.as<uint64_t>(), pt, fin[3], fin[1], gr::VP_DivRangeCheckRa, gr::CP_DivRangeCheckRaD, gr::PT_RaOneHotChecks);
+    }
+
+    // MeanOfSquares (ops/mean_of_squares.rs:50-133)
+    int op_mean_of_squares(const Node& nd) {
+        const size_t T = gr::padded_len(nd.dims), log_T = gr::log2u(T);
+        const gr::Opening& R = red(nd);
+        NodeWitness& W = G.wit[nd.idx];
+        RescaleWitness& RW = *W.rescale;
+        const Node& in = G.nodes.at(nd.inputs[0]);
+        const size_t T_in = gr::padded_len(in.dims), log_red = gr::log2u(T_in) - log_T;
+        const int64_t D = ((int64_t)1 << nd.p[0]) * (int64_t)nd.p[1];
+        Out O = out();
+        atlas_poly_t p_rem = nullptr, p_quot = nullptr;
+        int rc = atlas_poly_wrap_device_fr(RW.qfr.p, T, &p_quot);
+        if (!rc) rc = atlas_poly_wrap_device_i32(RW.rem.as<int32_t>(), T, &p_rem);
+        H::Fr ev[2];
+        if (!rc) { const atlas_poly_t ps[2] = {p_rem, p_quot}; rc = atlas_poly_evaluate_many(ps, 2, (const atlas_fr_t*)R.point.data(), log_T, (atlas_fr_t*)ev); }
+        for (atlas_poly_t p : {p_rem, p_quot}) if (p) atlas_poly_free(p);
+        if (rc) return rc;
+        const H::Fr eval_R = ev[0], acc_claim = ev[1];
+        rc = append_advice(nd, gr::VP_RescaleRemainder, R.point, eval_R);                                                // fused_rebase::prove_pre
+        if (!rc) rc = append_advice(nd, gr::VP_ClampAcc, R.point, acc_claim);
+        if (!rc && T > 1) rc = prove_clamp_lookup_flow(RW.cidx.as<uint64_t>(), log_T, (const atlas_fr_t*)R.point.data(), acc_claim, R.claim, &t, O, nullptr);
+        if (rc) return rc;
+        // MeanOfSquaresReductionProver: sum_{k,j} eq(r, k) x[k,j]^2 = rescaled(r) D + R(r); HighToLow, EqSchedule::High { log_retained, log_reduced }
+        DevBuf lbuf, rbuf;
+        HIP_TRY(lbuf.alloc(T_in * sizeof(Fr))); HIP_TRY(rbuf.alloc(T_in * sizeof(Fr)));
+        {
+            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+            k_i32_to_fr<<<grid_of(T_in), 256, 0, g.stream>>>(G.tensor(in.idx), lbuf.as<Fr>(), T_in);
+            HIP_TRY(hipMemcpyAsync(rbuf.p, lbuf.p, T_in * sizeof(Fr), hipMemcpyDeviceToDevice, g.stream));
+        }
+        atlas_poly_t left = nullptr, right = nullptr, eq = nullptr;
+        rc = atlas_poly_wrap_device_fr(lbuf.p, T_in, &left);
+        if (!rc) rc = atlas_poly_wrap_device_fr(rbuf.p, T_in, &right);
+        if (!rc) rc = atlas_eq_evals((const atlas_fr_t*)R.point.data(), log_T, nullptr, &eq);
+        atlas_dot_prover_t dp = nullptr;
+        if (!rc) rc = atlas_dot_prover_new(left, right, eq, ATLAS_EQ_HIGH, log_T, log_red, &dp);
+        if (rc) { for (atlas_poly_t p : {left, right, eq}) if (p) atlas_poly_free(p); return rc; }
+        const size_t nr = log_T + log_red;
+        std::vector<atlas_fr_t> rows(nr * 3); std::vector<atlas_u128_t> chm(nr); atlas_fr_t fin[3];
+        const H::Fr in_claim = H::add(H::mul(acc_claim, H::from_u64((uint64_t)D)), eval_R);
+        rc = atlas_sumcheck_prove_dot(dp, (const atlas_fr_t*)&in_claim, &t, rows.data(), chm.data(), fin);
+        atlas_dot_prover_free(dp);
+        if (rc) return rc;
+        std::vector<uint32_t> nco(nr, 3);
+        rc = O.put_proof(rows, 3, nco, nr, gr::PT_RescaleArith);
+        Point pt(nr);
+        for (size_t i = 0; i < nr; i++) pt[i] = ch_fr(chm[i]);
+        if (!rc) rc = append_nodeio(nd, 0, pt, *reinterpret_cast<H::Fr*>(&fin[0]));
+        if (rc || T == 1) return rc;
+        return range_and_onehot(nd, W.lookups.as<uint64_t>(), R.point, eval_R, fr_from_i64_host(D), gr::VP_MeanOfSquaresRangeCheckRa, gr::CP_MeanOfSquaresRangeCheckRaD,
+                                gr::PT_RescaleRemainderRaChecks);
+    }
+
+    // Rsqrt (ops/rsqrt.rs, ReductionFlow::Custom): x q + r_d = S^3 and out^2 + r_s = q in one sumcheck at a fresh point, the eval
+    // reduction, then BOTH range checks in one BatchedSumcheck and their six one-hot instances in another
+    int op_rsqrt(const Node& nd) {
+        const size_t T = gr::padded_len(nd.dims), log_T = gr::log2u(T);
+        NodeWitness& W = G.wit[nd.idx];
+        const Point r = challenge_point(log_T);
+        const H::Fr gamma = H::tr_challenge_scalar(Tr);
+        atlas_poly_t ops[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        int rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(G.tensor(nd.inputs[0])), T, &ops[0]);
+        if (!rc) rc = atlas_poly_wrap_device_fr(W.quot_fr.p, T, &ops[1]);
+        if (!rc) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(G.tensor(nd.idx)), T, &ops[2]);
+        if (!rc) rc = atlas_poly_wrap_device_i32(W.rem.as<int32_t>(), T, &ops[3]);
+        if (!rc) rc = atlas_poly_wrap_device_i32(W.rem2.as<int32_t>(), T, &ops[4]);
+        const H::Fr consts[2] = {H::from_u64((uint64_t)1 << (3 * nd.p[0])), gamma};
+        atlas_instance_t inst = nullptr;
+        if (!rc) rc = atlas_elementwise_new(ATLAS_EW_RSQRT, ops, 5, (const atlas_fr_t*)r.data(), log_T, (const atlas_fr_t*)consts, 2, &inst);
+        for (atlas_poly_t p : ops) if (p) atlas_poly_free(p);
+        std::vector<H::Fr> rs, fin;
+        if (!rc) rc = run_single(inst, H::zero(), gr::PT_Execution, rs, fin);
+        if (inst) atlas_instance_free(inst);
+        if (rc) return rc;
+        const Point pt = reversed(rs);
+        rc = append_nodeio(nd, 0, pt, fin[0]);
+        if (!rc) rc = append_dense(nd, gr::CP_RsqrtQuotient, pt, fin[1]);
+        if (!rc) { Out O = out(); rc = O.append_virtual(Tr, gr::node_exec(gr::virt(gr::VP_NodeOutput, nd.idx), nd.idx), pt, fin[2]); }
+        if (!rc) rc = append_advice(nd, gr::VP_DivRemainder, pt, fin[3]);
+        if (!rc) rc = append_advice(nd, gr::VP_SqrtRemainder, pt, fin[4]);
+        if (!rc) rc = eval_reduction(nd);
+        if (rc) return rc;
+        // prove_range_and_onehot (rsqrt.rs:527-586)
+        Out O = out();
+        atlas_instance_t rc_i[2] = {nullptr, nullptr}; H::Fr cl[2];
+        rc = range_check_new(W.lookups.as<uint64_t>(), log_T, pt, fin[3], fin[0], &rc_i[0], &cl[0]);                      // RiRangeCheckOperands: r_d < x
+        if (!rc) rc = range_check_new(W.lookups2.as<uint64_t>(), log_T, pt, fin[4], H::add(H::add(fin[2], fin[2]), H::one()), &rc_i[1], &cl[1]);     // Rs: r_s < 2 out + 1
+        atlas_batched_t b = nullptr;
+        if (!rc) rc = atlas_batched_new(&b);
+        for (int i = 0; i < 2 && !rc; i++) rc = atlas_batched_add_instance(b, rc_i[i], (const atlas_fr_t*)&cl[i]);
+        const size_t mr0 = 64 + log_T;
+        std::vector<atlas_fr_t> rows(mr0 * 3); std::vector<uint32_t> nco(mr0); std::vector<atlas_u128_t> ch(mr0); size_t mr = 0;
+        if (!rc) rc = atlas_batched_prove(b, &t, rows.data(), 3, nco.data(), ch.data(), &mr);
+        std::vector<OneHotFamily> fams(2);
+        for (int i = 0; i < 2 && !rc; i++) {                                  // cache_openings: the ra claim of each read-raf instance
+            atlas_fr_t f[64]; size_t nf = 0;
+            rc = atlas_instance_final_claims(rc_i[i], f, 64, &nf);
+            Point rp(mr);
+            for (size_t q = 0; q < mr; q++) rp[q] = ch_fr(q < 64 ? ch[q] : ch[64 + (mr - 1 - q)]);
+            if (!rc) rc = O.append_virtual(Tr, gr::node_exec(gr::virt(i == 0 ? gr::VP_DivRangeCheckRa : gr::VP_SqrtRangeCheckRa, nd.idx), nd.idx), rp, *reinterpret_cast<H::Fr*>(&f[0]));
+            fams[i].d_lookups = i == 0 ? W.lookups.as<uint64_t>() : W.lookups2.as<uint64_t>(); fams[i].log_K = 64; fams[i].r_cycle = (const atlas_fr_t*)pt.data();
+            fams[i].ra_point.resize(mr); std::memcpy(fams[i].ra_point.data(), rp.data(), mr * 32);
+            std::memcpy(&fams[i].ra_claim, &f[0], 32);
+            fams[i].rad_cp = i == 0 ? gr::CP_SqrtDivRangeCheckRaD : gr::CP_SqrtRangeCheckRaD;
+        }
+        if (!rc) rc = O.put_proof(rows, 3, nco, mr, gr::PT_RangeCheck);
+        if (b) atlas_batched_free(b);
+        for (auto i : rc_i) if (i) atlas_instance_free(i);
+        if (!rc) rc = prove_onehot_checks_multi(fams, log_T, &t, O, gr::PT_RaOneHotChecks);
+        return rc;
+    }
+
     int prove_node(const Node& nd) {
         cur = nd.idx;
+        if (nd.op == ATLAS_OP_DIV) return op_div(nd);                          // ReductionFlow::Custom
+        if (nd.op == ATLAS_OP_RSQRT) return op_rsqrt(nd);
         int rc = eval_reduction(nd);                                           // ReductionFlow::Default
         if (rc) return rc;
         const gr::Opening& R = red(nd);
@@ -412,6 +727,10 @@ struct Prover : FlowSink {
             case ATLAS_OP_RESHAPE: return op_reshape(nd);
             case ATLAS_OP_MOVEAXIS: return op_moveaxis(nd);
             case ATLAS_OP_BROADCAST: return op_broadcast(nd);
+            case ATLAS_OP_SUM: return op_sum(nd);
+            case ATLAS_OP_SCALAR_CONST_DIV: return op_scalar_const_div(nd);
+            case ATLAS_OP_SLICE: return op_slice(nd);
+            case ATLAS_OP_MEAN_OF_SQUARES: return op_mean_of_squares(nd);
             default: return fail(ATLAS_EINVAL, "prove_graph: operator without a prover composition");
         }
     }

@@ -9,7 +9,14 @@
 struct NodeWitness {
     std::unique_ptr<RescaleWitness> rescale;     // Einsum / Mul / Square / Cube (fused rescale)
     DevBuf acc, acc_fr, cidx;                    // Add / Sub / Sum: i64 accumulation, its Fr image, the clamp lookup indices
-    DevBuf lookups;                              // ReLU and the other XLEN-bit unary lookups
+    DevBuf lookups;                              // ReLU and the other XLEN-bit unary lookups; Div / MeanOfSquares: the range check's interleaved pairs
+    DevBuf rem;                                  // ScalarConstDiv / Div: the remainder tensor (i32); Rsqrt: div_remainder
+    DevBuf quot_fr, rem2, lookups2, bound;       // Rsqrt: quotient as Fr, sqrt_remainder, the second range check's pairs and its bound 2 out + 1
+    std::vector<atlas_poly_t> dense_views;       // borrowed polynomial views of the dense committed polynomials
+    ~NodeWitness() { for (auto p : dense_views) if (p) atlas_poly_free(p); }
+    NodeWitness() = default;
+    NodeWitness(const NodeWitness&) = delete;
+    NodeWitness& operator=(const NodeWitness&) = delete;
     std::vector<gr::Committed> committed;        // this node's committed polynomials, in get_committed_polynomials order
 };
 

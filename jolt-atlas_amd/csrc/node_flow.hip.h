@@ -171,10 +171,17 @@ int prove_single(atlas_instance_t inst, const H::Fr& input_claim, atlas_transcri
 }
 
 // ra_onehot_provers (shout.rs:399-466) + BatchedSumcheck::prove over [RaVirtual, HammingWeight, Booleanity] and their
-// cache_openings (ra_virtual.rs:157-184, hamming_weight.rs:149-168, booleanity.rs:350-368): d claims each
-int prove_onehot_checks(const uint64_t* d_lookups, size_t log_T, size_t log_K, const atlas_fr_t* r_cycle, const std::vector<atlas_fr_t>& ra_point,
-                        const H::Fr& ra_claim, atlas_transcript_t* t, Out& O, uint8_t rad_cp = 0, uint8_t proof_type = gr::PT_RaOneHotChecks) {
-    const size_t lkc = 4, d = (log_K + lkc - 1) / lkc;               // OneHotParams::new: LOG_K_CHUNK = 4 (common/src/consts/general.rs:2)
+// cache_openings (ra_virtual.rs:157-184, hamming_weight.rs:149-168, booleanity.rs:350-368): d claims each.  Several lookup
+// families of one node (Rsqrt: its two range checks, ops/rsqrt.rs:558-583) share ONE batched sumcheck: the families draw their
+// challenges in order, the instances are batched as [ra, hw, bool] per family, the openings cached in that order.
+struct OneHotFamily {
+    const uint64_t* d_lookups; size_t log_K;
+    const atlas_fr_t* r_cycle;                   // the r_cycle_source opening point (log_T)
+    std::vector<atlas_fr_t> ra_point; H::Fr ra_claim;
+    uint8_t rad_cp;
+};
+int prove_onehot_checks_multi(std::vector<OneHotFamily>& fams, size_t log_T, atlas_transcript_t* t, Out& O, uint8_t proof_type) {
+    const size_t lkc = 4;                                            // OneHotParams::new: LOG_K_CHUNK = 4 (common/src/consts/general.rs:2)
     H::Transcript& T = *reinterpret_cast<H::Transcript*>(t);
     const bool trace = getenv("ATLAS_TRACE") != nullptr;
     auto tr0 = std::chrono::steady_clock::now();
@@ -182,39 +189,47 @@ int prove_onehot_checks(const uint64_t* d_lookups, size_t log_T, size_t log_K, c
         if (!trace) return;
         atlas_sync();
         const auto t1 = std::chrono::steady_clock::now();
-        fprintf(stderr, "[atlas trace] onehot_checks d=%zu %-24s %8.3f ms\n", d, what, std::chrono::duration<double, std::milli>(t1 - tr0).count());
+        fprintf(stderr, "[atlas trace] onehot_checks x%zu %-24s %8.3f ms\n", fams.size(), what, std::chrono::duration<double, std::milli>(t1 - tr0).count());
         tr0 = t1;
     };
-    std::vector<H::Fr> gamma_powers(d);                             // challenge_scalar_powers(d)
-    { const H::Fr q = H::tr_challenge_scalar(T); gamma_powers[0] = H::one(); for (size_t i = 1; i < d; i++) gamma_powers[i] = H::mul(gamma_powers[i - 1], q); }
-    std::vector<H::Fr> gammas(d), r_addr(lkc);                       // challenge_vector_optimized
-    for (size_t i = 0; i < d; i++) { uint64_t lo, hi; H::tr_challenge_u128(T, lo, hi); gammas[i] = H::challenge_to_fr(lo, hi, g.challenge_mode); }
-    for (size_t i = 0; i < lkc; i++) { uint64_t lo, hi; H::tr_challenge_u128(T, lo, hi); r_addr[i] = H::challenge_to_fr(lo, hi, g.challenge_mode); }
-    // G = compute_ra_evals(lookup_indices, params, r_cycle) (shout.rs:550-598)
-    atlas_poly_t eq_rc = nullptr;
-    int rc = atlas_eq_evals(r_cycle, log_T, nullptr, &eq_rc);
-    std::vector<H::Fr> Gh;
-    if (!rc) rc = atlas_rt_shout_ra_evals_host(d_lookups, (size_t)1 << log_T, log_K, lkc, eq_rc, Gh);
-    if (eq_rc) atlas_poly_free(eq_rc);
-    if (rc) return rc;
-    std::vector<atlas_fr_t> G(d << lkc);
-    std::memcpy(G.data(), Gh.data(), G.size() * sizeof(atlas_fr_t));
-    mark("ra_evals G");
-    // RaVirtual: (r_address, r_cycle) = the ra opening point split at log_K
-    atlas_instance_t ra = nullptr, hw = nullptr, bo = nullptr;
-    rc = atlas_ra_virtual_from_lookups_new(d_lookups, log_T, log_K, lkc, ra_point.data(), ra_point.data() + log_K, &ra);
-    if (!rc) rc = atlas_hamming_weight_new(G.data(), d, lkc, (const atlas_fr_t*)gamma_powers.data(), &hw);
-    if (!rc) rc = atlas_booleanity_from_lookups_new(G.data(), d_lookups, log_T, log_K, lkc, (const atlas_fr_t*)gammas.data(), (const atlas_fr_t*)r_addr.data(), r_cycle, &bo);
-    mark("booleanity_new");
+    std::vector<atlas_instance_t> insts;
     atlas_batched_t b = nullptr;
-    H::Fr hw_claim = H::zero();
-    for (auto& x : gamma_powers) hw_claim = H::add(hw_claim, x);    // hamming_weight.rs:49-57
+    int rc = atlas_batched_new(&b);
+    size_t dmax = 0;
     const H::Fr zero = H::zero();
-    if (!rc) rc = atlas_batched_new(&b);
-    if (!rc) rc = atlas_batched_add_instance(b, ra, (const atlas_fr_t*)&ra_claim);
-    if (!rc) rc = atlas_batched_add_instance(b, hw, (const atlas_fr_t*)&hw_claim);
-    if (!rc) rc = atlas_batched_add_instance(b, bo, (const atlas_fr_t*)&zero);
-    size_t stride = d + 2, max_rounds = lkc + log_T;
+    for (auto& F : fams) {
+        const size_t d = (F.log_K + lkc - 1) / lkc;
+        dmax = d > dmax ? d : dmax;
+        std::vector<H::Fr> gamma_powers(d);                         // challenge_scalar_powers(d)
+        { const H::Fr q = H::tr_challenge_scalar(T); gamma_powers[0] = H::one(); for (size_t i = 1; i < d; i++) gamma_powers[i] = H::mul(gamma_powers[i - 1], q); }
+        std::vector<H::Fr> gammas(d), r_addr(lkc);                   // challenge_vector_optimized
+        for (size_t i = 0; i < d; i++) { uint64_t lo, hi; H::tr_challenge_u128(T, lo, hi); gammas[i] = H::challenge_to_fr(lo, hi, g.challenge_mode); }
+        for (size_t i = 0; i < lkc; i++) { uint64_t lo, hi; H::tr_challenge_u128(T, lo, hi); r_addr[i] = H::challenge_to_fr(lo, hi, g.challenge_mode); }
+        // G = compute_ra_evals(lookup_indices, params, r_cycle) (shout.rs:550-598)
+        atlas_poly_t eq_rc = nullptr;
+        if (!rc) rc = atlas_eq_evals(F.r_cycle, log_T, nullptr, &eq_rc);
+        std::vector<H::Fr> Gh;
+        if (!rc) rc = atlas_rt_shout_ra_evals_host(F.d_lookups, (size_t)1 << log_T, F.log_K, lkc, eq_rc, Gh);
+        if (eq_rc) atlas_poly_free(eq_rc);
+        if (rc) break;
+        std::vector<atlas_fr_t> G(d << lkc);
+        std::memcpy(G.data(), Gh.data(), G.size() * sizeof(atlas_fr_t));
+        mark("ra_evals G");
+        // RaVirtual: (r_address, r_cycle) = the ra opening point split at log_K
+        atlas_instance_t ra = nullptr, hw = nullptr, bo = nullptr;
+        rc = atlas_ra_virtual_from_lookups_new(F.d_lookups, log_T, F.log_K, lkc, F.ra_point.data(), F.ra_point.data() + F.log_K, &ra);
+        if (!rc) rc = atlas_hamming_weight_new(G.data(), d, lkc, (const atlas_fr_t*)gamma_powers.data(), &hw);
+        if (!rc) rc = atlas_booleanity_from_lookups_new(G.data(), F.d_lookups, log_T, F.log_K, lkc, (const atlas_fr_t*)gammas.data(), (const atlas_fr_t*)r_addr.data(), F.r_cycle, &bo);
+        mark("booleanity_new");
+        for (atlas_instance_t i : {ra, hw, bo}) insts.push_back(i);
+        H::Fr hw_claim = H::zero();
+        for (auto& x : gamma_powers) hw_claim = H::add(hw_claim, x);    // hamming_weight.rs:49-57
+        if (!rc) rc = atlas_batched_add_instance(b, ra, (const atlas_fr_t*)&F.ra_claim);
+        if (!rc) rc = atlas_batched_add_instance(b, hw, (const atlas_fr_t*)&hw_claim);
+        if (!rc) rc = atlas_batched_add_instance(b, bo, (const atlas_fr_t*)&zero);
+        if (rc) break;
+    }
+    size_t stride = dmax + 2, max_rounds = lkc + log_T;
     std::vector<atlas_fr_t> rows(max_rounds * stride);
     std::vector<uint32_t> nco(max_rounds);
     std::vector<atlas_u128_t> ch(max_rounds);
@@ -224,36 +239,43 @@ int prove_onehot_checks(const uint64_t* d_lookups, size_t log_T, size_t log_K, c
     // cache_openings in instance order; an instance of n rounds sees the LAST n challenges (sumcheck.rs:150-170)
     std::vector<H::Fr> rs(mr);
     for (size_t i = 0; i < mr && !rc; i++) rs[i] = ch_fr(ch[i]);
-    const size_t pad = d * lkc - log_K;
-    int which = 0;
-    for (atlas_instance_t inst : {ra, hw, bo}) {
-        atlas_fr_t fin[64]; size_t nf = 0;
-        if (!rc) rc = atlas_instance_final_claims(inst, fin, 64, &nf);
-        for (size_t i = 0; i < d && !rc; i++) {                      // append_sparse: one transcript append per claim (:335-339)
-            gr::Point pt;
-            if (O.sink) {
-                pt.resize(lkc + log_T);
-                if (which == 0) {            // RaVirtual (ra_virtual.rs:157-184): chunk i of the zero-padded r_address, reversed cycle challenges
-                    for (size_t q = 0; q < lkc; q++) { const size_t pos = i * lkc + q; pt[q] = pos < pad ? H::zero() : *reinterpret_cast<const H::Fr*>(&ra_point[pos - pad]); }
-                    for (size_t q = 0; q < log_T; q++) pt[lkc + q] = rs[mr - 1 - q];
-                } else if (which == 1) {     // HammingWeight (hamming_weight.rs:149-168): reversed address challenges, r_cycle of the source opening
-                    for (size_t q = 0; q < lkc; q++) pt[q] = rs[mr - 1 - q];
-                    for (size_t q = 0; q < log_T; q++) pt[lkc + q] = *reinterpret_cast<const H::Fr*>(&r_cycle[q]);
-                } else {                     // Booleanity (booleanity.rs:71-76, 350-368): both halves reversed
-                    for (size_t q = 0; q < lkc; q++) pt[q] = rs[lkc - 1 - q];
-                    for (size_t q = 0; q < log_T; q++) pt[lkc + q] = rs[mr - 1 - q];
+    for (size_t f = 0; f < fams.size() && !rc; f++) {
+        OneHotFamily& F = fams[f];
+        const size_t d = (F.log_K + lkc - 1) / lkc, pad = d * lkc - F.log_K;
+        for (int which = 0; which < 3 && !rc; which++) {
+            atlas_fr_t fin[64]; size_t nf = 0;
+            rc = atlas_instance_final_claims(insts[3 * f + which], fin, 64, &nf);
+            for (size_t i = 0; i < d && !rc; i++) {                  // append_sparse: one transcript append per claim (:335-339)
+                gr::Point pt;
+                if (O.sink) {
+                    pt.resize(lkc + log_T);
+                    if (which == 0) {            // RaVirtual (ra_virtual.rs:157-184): chunk i of the zero-padded r_address, reversed cycle challenges
+                        for (size_t q = 0; q < lkc; q++) { const size_t pos = i * lkc + q; pt[q] = pos < pad ? H::zero() : *reinterpret_cast<const H::Fr*>(&F.ra_point[pos - pad]); }
+                        for (size_t q = 0; q < log_T; q++) pt[lkc + q] = rs[mr - 1 - q];
+                    } else if (which == 1) {     // HammingWeight (hamming_weight.rs:149-168): reversed address challenges, r_cycle of the source opening
+                        for (size_t q = 0; q < lkc; q++) pt[q] = rs[mr - 1 - q];
+                        for (size_t q = 0; q < log_T; q++) pt[lkc + q] = *reinterpret_cast<const H::Fr*>(&F.r_cycle[q]);
+                    } else {                     // Booleanity (booleanity.rs:71-76, 350-368): both halves reversed
+                        for (size_t q = 0; q < lkc; q++) pt[q] = rs[lkc - 1 - q];
+                        for (size_t q = 0; q < log_T; q++) pt[lkc + q] = rs[mr - 1 - q];
+                    }
                 }
+                rc = O.append_sparse(T, F.rad_cp, i, which == 0 ? gr::SC_RaVirtualization : which == 1 ? gr::SC_HammingWeight : gr::SC_Booleanity, pt,
+                                     *reinterpret_cast<H::Fr*>(&fin[i]));
             }
-            rc = O.append_sparse(T, rad_cp, i, which == 0 ? gr::SC_RaVirtualization : which == 1 ? gr::SC_HammingWeight : gr::SC_Booleanity, pt,
-                                 *reinterpret_cast<H::Fr*>(&fin[i]));
         }
-        which++;
     }
     if (!rc) rc = O.put_proof(rows, stride, nco, mr, proof_type);
     if (b) atlas_batched_free(b);
-    for (atlas_instance_t inst : {ra, hw, bo}) if (inst) atlas_instance_free(inst);
+    for (atlas_instance_t inst : insts) if (inst) atlas_instance_free(inst);
     mark("finals + free");
     return rc;
+}
+int prove_onehot_checks(const uint64_t* d_lookups, size_t log_T, size_t log_K, const atlas_fr_t* r_cycle, const std::vector<atlas_fr_t>& ra_point,
+                        const H::Fr& ra_claim, atlas_transcript_t* t, Out& O, uint8_t rad_cp = 0, uint8_t proof_type = gr::PT_RaOneHotChecks) {
+    std::vector<OneHotFamily> f(1);
+    f[0].d_lookups = d_lookups; f[0].log_K = log_K; f[0].r_cycle = r_cycle; f[0].ra_point = ra_point; f[0].ra_claim = ra_claim; f[0].rad_cp = rad_cp;
+    return prove_onehot_checks_multi(f, log_T, t, O, proof_type);
 }
 
 }  // namespace

@@ -43,7 +43,7 @@ def node_params(nd):
     if op in ("Rsqrt", "SoftmaxLastAxis", "Tanh"):
         return [nd["scale"]], []
     if op == "MeanOfSquares":
-        return [nd["scale"]], list(nd["axes"])
+        return [nd["scale"], nd["count"]], list(nd["axes"])
     if op in ("GatherLarge", "GatherSmall"):
         return [nd["axis"], nd["dict_len"]], []
     return [], []

@@ -252,6 +252,38 @@ def execute(nodes, inputs):
         elif op == "Broadcast":
             idims = next(n for n in nodes if n["idx"] == nd["inputs"][0])["dims"]
             o = np.broadcast_to(ins[0].reshape(idims), nd["dims"]).reshape(-1).copy()
+        elif op == "Slice":
+            idims = next(n for n in nodes if n["idx"] == nd["inputs"][0])["dims"]
+            sl = [slice(None)] * len(idims); sl[nd["axis"]] = slice(nd["start"], nd["end"])
+            o = ins[0].reshape(idims)[tuple(sl)].reshape(-1).copy()
+        elif op == "Sum":
+            idims = next(n for n in nodes if n["idx"] == nd["inputs"][0])["dims"]
+            acc = ins[0].astype(np.int64).reshape(idims).sum(axis=nd["axes"][0]).reshape(-1)
+            wit[nd["idx"]] = dict(acc=acc)
+            o = clamp_i32(acc)
+        elif op in ("ScalarConstDiv", "Div"):
+            b = np.full(len(ins[0]), nd["divisor"], dtype=np.int64) if op == "ScalarConstDiv" else ins[1].astype(np.int64)
+            a = ins[0].astype(np.int64)
+            q = np.floor_divide(a, b); r = a - q * b             # remainder with the divisor's sign (adjusted_remainder)
+            wit[nd["idx"]] = dict(rem=r.astype(np.int32))
+            o = q.astype(np.int32)
+        elif op == "MeanOfSquares":
+            idims = next(n for n in nodes if n["idx"] == nd["inputs"][0])["dims"]
+            N = idims[-1]
+            acc = (ins[0].astype(np.int64) ** 2).reshape(-1, N).sum(axis=1)
+            D = (1 << nd["scale"]) * nd["count"]
+            q = np.floor_divide(acc, D); r = acc - q * D
+            wit[nd["idx"]] = dict(quot=q, rem=r.astype(np.int32), D=D)
+            o = clamp_i32(q)
+        elif op == "Rsqrt":
+            s3 = 1 << (3 * nd["scale"])
+            x = ins[0].astype(np.int64)
+            assert (x > 0).all(), "Rsqrt of a non-positive value"
+            q = s3 // x; dr = s3 % x
+            out_ = np.array([int(np.floor(np.sqrt(float(v)))) for v in q], dtype=np.int64)
+            out_ = np.where(out_ * out_ > q, out_ - 1, out_); out_ = np.where((out_ + 1) * (out_ + 1) <= q, out_ + 1, out_)
+            wit[nd["idx"]] = dict(quot=q, div_rem=dr.astype(np.int32), sqrt_rem=(q - out_ * out_).astype(np.int32), bound=(2 * out_ + 1).astype(np.int32))
+            o = out_.astype(np.int32)
         else:
             raise ValueError(f"oracle graph executor: operator {op}")
         assert len(o) == int(np.prod(nd["dims"])), (nd, len(o))
@@ -287,6 +319,15 @@ class Prover:
         if p in self.committed:                                # sumchecks.insert(label, ..): the last append wins
             self.committed[p]["point"], self.committed[p]["claim"] = np.array(point, dtype=np.uint64).copy(), np.array(claim, dtype=np.uint64).copy()
 
+    def append_dense(self, nd, cp_name, point, claim):
+        self.t.append_scalar(claim)
+        p = comm(cp_name, nd["idx"])
+        self.openings[node_exec(p, nd["idx"])] = (np.array(point, dtype=np.uint64).copy(), np.array(claim, dtype=np.uint64).copy())
+        self.committed[p]["point"], self.committed[p]["claim"] = np.array(point, dtype=np.uint64).copy(), np.array(claim, dtype=np.uint64).copy()
+
+    def append_advice(self, nd, vp_name, point, claim):
+        self.append_virtual(node_exec(virt(vp_name, nd["idx"]), nd["idx"]), point, claim)
+
     def mle(self, idx):
         return fr(self.trace[idx])
 
@@ -303,6 +344,29 @@ class Prover:
             return [("RescaleRemainderRaD", w["rem"].astype(np.uint64), w["S"]), ("ClampRaD", w["quot"].astype(np.int64).view(np.uint64), 64)]
         if op == "ReLU":
             return [("NodeOutputRaD", self.trace[nd["inputs"][0]].astype(np.uint32).astype(np.uint64), 32)]
+        if op == "Sum":
+            return [("ClampRaD", self.wit[i]["acc"].astype(np.int64).view(np.uint64), 64)]
+        if op == "Div":
+            return [("DivRangeCheckRaD", interleave_arr(self.wit[i]["rem"], self.trace[nd["inputs"][1]]), 64)]
+        if op == "MeanOfSquares":
+            w = self.wit[i]
+            return [("ClampRaD", w["quot"].astype(np.int64).view(np.uint64), 64),
+                    ("MeanOfSquaresRangeCheckRaD", interleave_arr(w["rem"], np.full(len(w["rem"]), w["D"], dtype=np.int32)), 64)]
+        if op == "Rsqrt":
+            w = self.wit[i]
+            return [("SqrtDivRangeCheckRaD", interleave_arr(w["div_rem"], self.trace[nd["inputs"][0]]), 64),
+                    ("SqrtRangeCheckRaD", interleave_arr(w["sqrt_rem"], w["bound"]), 64)]
+        return []
+
+    def dense_committed(self, nd):
+        """[(CommittedPoly name, coefficients as Fr)]: the dense advice polynomials of a node"""
+        op, i = nd["op"], nd["idx"]
+        if op == "ScalarConstDiv":
+            return [("ScalarConstDivNodeRemainder", fr(self.wit[i]["rem"]))]
+        if op == "Div":
+            return [("DivNodeQuotient", fr(self.trace[i]))]
+        if op == "Rsqrt":
+            return [("RsqrtQuotient", fr(self.wit[i]["quot"]))]
         return []
 
     def commit(self):
@@ -315,6 +379,9 @@ class Prover:
                     row = ((lookups >> np.uint64(4 * (d - 1 - c))) & np.uint64(15)).astype(np.int64)
                     flat = (row * Tn + np.arange(Tn)).astype(np.uint64)              # one-hot coefficient k * T + t (one_hot_polynomial.rs:104-113)
                     self.committed[comm(name, i, c)] = dict(row=row.astype(np.int32), log_T=ilog2(Tn), commitment=orc.g1_sum_indexed(self.srs, flat))
+            if int(np.prod(nd["dims"])) > 1 or nd["op"] == "ScalarConstDiv":
+                for name, coeffs in self.dense_committed(nd):
+                    self.committed[comm(name, i)] = dict(dense=coeffs, log_T=ilog2(len(coeffs)), commitment=orc.msm(self.srs[:len(coeffs)], coeffs))
         for key in sorted(self.committed):
             self.t.append_bytes(g1_uncompressed(self.committed[key]["commitment"])[::-1])       # append_serializable
 
@@ -325,44 +392,52 @@ class Prover:
         return orc.challenges_to_fr(ch)
 
     def onehot_checks(self, nd, lookups, log_K, r_cycle, ra_point, ra_claim, cp_name, ptype):
+        self.onehot_checks_multi(nd, [(lookups, log_K, r_cycle, ra_point, ra_claim, cp_name)], ptype)
+
+    def onehot_checks_multi(self, nd, fams, ptype):
+        """ra_onehot_provers per family (draws in order), ONE BatchedSumcheck over [ra, hw, bool] x families, cache_openings in order"""
         lkc, node = 4, nd["idx"]
-        d = -(-log_K // lkc)
-        log_T = len(r_cycle)
-        q = self.t.challenge_scalar()
-        gp = [one()]
-        for _ in range(1, d):
-            gp.append(orc.fr_mul_arr(gp[-1], q))
-        gp = np.stack(gp)
-        gammas = self.t.challenge_vector_opt(d)
-        r_addr = self.t.challenge_vector_opt(lkc)
-        Hs = [((lookups >> np.uint64(lkc * (d - 1 - i))) & np.uint64(15)).astype(np.int32) for i in range(d)]
-        G = OR.ra_G(Hs, lkc, r_cycle)
-        pad = d * lkc - log_K
-        chunks = np.concatenate([np.zeros((pad, 4), dtype=np.uint64), ra_point[:log_K]]).reshape(d, lkc, 4)
-        r_cyc_ra = np.ascontiguousarray(ra_point[log_K:])
-        hw_claim = orc.fr_array(1)[0]
-        for x in gp:
-            hw_claim = orc.fr_add_arr(hw_claim, x)
-        insts = [OB.ra_instance(OR.ra_virtual(Hs, lkc, chunks, r_cyc_ra), ra_claim), OB.ra_instance(OR.hamming(G, lkc, gp), hw_claim),
-                 OB.ra_instance(OR.booleanity(G, Hs, lkc, gammas, r_addr, r_cycle), orc.fr_array(1)[0])]
+        insts, st = [], []
+        for lookups, log_K, r_cycle, ra_point, ra_claim, cp_name in fams:
+            d = -(-log_K // lkc)
+            q = self.t.challenge_scalar()
+            gp = [one()]
+            for _ in range(1, d):
+                gp.append(orc.fr_mul_arr(gp[-1], q))
+            gp = np.stack(gp)
+            gammas = self.t.challenge_vector_opt(d)
+            r_addr = self.t.challenge_vector_opt(lkc)
+            Hs = [((lookups >> np.uint64(lkc * (d - 1 - i))) & np.uint64(15)).astype(np.int32) for i in range(d)]
+            G = OR.ra_G(Hs, lkc, r_cycle)
+            pad = d * lkc - log_K
+            chunks = np.concatenate([np.zeros((pad, 4), dtype=np.uint64), ra_point[:log_K]]).reshape(d, lkc, 4)
+            r_cyc_ra = np.ascontiguousarray(ra_point[log_K:])
+            hw_claim = orc.fr_array(1)[0]
+            for x in gp:
+                hw_claim = orc.fr_add_arr(hw_claim, x)
+            insts += [OB.ra_instance(OR.ra_virtual(Hs, lkc, chunks, r_cyc_ra), ra_claim), OB.ra_instance(OR.hamming(G, lkc, gp), hw_claim),
+                      OB.ra_instance(OR.booleanity(G, Hs, lkc, gammas, r_addr, r_cycle), orc.fr_array(1)[0])]
+            st.append((d, Hs, G, chunks, r_cycle, cp_name))
         rows, ch, _ = OB.batched_prove(insts, self.t.t)
         self.proofs[(node, PT[ptype])] = rows
         rs = orc.challenges_to_fr(ch)
-        mr = lkc + log_T
-        ra_rs = np.ascontiguousarray(rs[mr - log_T:][::-1])
-        for i in range(d):                                                   # RaVirtual::cache_openings
-            F = orc.eq_evals(chunks[i])
-            c = orc.evaluate(np.stack([F[k] for k in Hs[i]]), ra_rs)
-            self.append_sparse(cp_name, node, i, "RaVirtualization", np.concatenate([chunks[i], ra_rs]), c)
-        hw_rs = np.ascontiguousarray(rs[mr - lkc:][::-1])
-        for i in range(d):                                                   # HammingWeight::cache_openings
-            c = orc.evaluate(G[i], hw_rs)
-            self.append_sparse(cp_name, node, i, "HammingWeight", np.concatenate([hw_rs, r_cycle]), c)
-        ba = np.ascontiguousarray(rs[:lkc][::-1]); bc = np.ascontiguousarray(rs[lkc:][::-1])
-        Fb = orc.eq_evals(ba)
-        for i in range(d):                                                   # Booleanity::cache_openings
-            c = orc.evaluate(np.stack([Fb[k] for k in Hs[i]]), bc)
-            self.append_sparse(cp_name, node, i, "Booleanity", np.concatenate([ba, bc]), c)
+        for d, Hs, G, chunks, r_cycle, cp_name in st:
+            log_T = len(r_cycle)
+            mr = lkc + log_T
+            ra_rs = np.ascontiguousarray(rs[mr - log_T:][::-1])
+            for i in range(d):                                               # RaVirtual::cache_openings
+                F = orc.eq_evals(chunks[i])
+                c = orc.evaluate(np.stack([F[k] for k in Hs[i]]), ra_rs)
+                self.append_sparse(cp_name, node, i, "RaVirtualization", np.concatenate([chunks[i], ra_rs]), c)
+            hw_rs = np.ascontiguousarray(rs[mr - lkc:][::-1])
+            for i in range(d):                                               # HammingWeight::cache_openings
+                c = orc.evaluate(G[i], hw_rs)
+                self.append_sparse(cp_name, node, i, "HammingWeight", np.concatenate([hw_rs, r_cycle]), c)
+            ba = np.ascontiguousarray(rs[:lkc][::-1]); bc = np.ascontiguousarray(rs[lkc:][::-1])
+            Fb = orc.eq_evals(ba)
+            for i in range(d):                                               # Booleanity::cache_openings
+                c = orc.evaluate(np.stack([Fb[k] for k in Hs[i]]), bc)
+                self.append_sparse(cp_name, node, i, "Booleanity", np.concatenate([ba, bc]), c)
 
     def read_raf(self, nd, inst, claim, lookups, log_K, ra_vp, ptype):
         """Sumcheck::prove of a read-raf instance + its ra opening at (address challenges, reversed cycle challenges)"""
@@ -503,12 +578,144 @@ class Prover:
         ra_point, ra_claim = self.read_raf(nd, OR.ps_relu(lookups, 32, r0, gamma), exec_claim, lookups, 32, "NodeOutputRa", "Execution")
         self.onehot_checks(nd, lookups, 32, r0, ra_point, ra_claim, "NodeOutputRaD", "RaOneHotChecks")
 
-    def prove_node(self, nd):
+    def range_check(self, lookups, r_cycle, left, right):
+        """ps_read_raf_prover (binary): gamma, UnsignedLessThan over interleave(remainder, bound); claim 1 + gamma left + gamma^2 right"""
+        gamma = self.t.challenge_scalar()
+        claim = orc.fr_add_arr(one(), orc.fr_add_arr(orc.fr_mul_arr(gamma, left), orc.fr_mul_arr(orc.fr_mul_arr(gamma, gamma), right)))
+        return OR.ps_ult(lookups, r_cycle, gamma), claim
+
+    def range_and_onehot(self, nd, lookups, r_cycle, left, right, ra_vp, cp_name, pt_onehot):
+        inst, claim = self.range_check(lookups, r_cycle, left, right)
+        ra_point, ra_claim = self.read_raf(nd, inst, claim, lookups, 64, ra_vp, "RangeCheck")
+        self.onehot_checks(nd, lookups, 64, r_cycle, ra_point, ra_claim, cp_name, pt_onehot)
+
+    def op_sum(self, nd):
+        i = nd["idx"]
+        r0, out_claim = self.reduced[i]
+        acc = self.wit[i]["acc"]
+        acc_claim = orc.evaluate(fr(acc), r0)
+        self.append_virtual(node_exec(virt("ClampAcc", i), i), r0, acc_claim)
+        if len(acc) > 1:
+            self.clamp_lookup(nd, acc.astype(np.int64).view(np.uint64).copy(), r0, acc_claim, out_claim)
+        idims = list(self.nodes[nd["inputs"][0]]["dims"]); axis = nd["axes"][0]
+        while len(idims) > 2:
+            assert idims[0] == 1; idims.pop(0); axis -= 1
+        if len(idims) == 1:
+            idims = [idims[0], 1]
+        m, n = idims
+        X = fr(self.trace[nd["inputs"][0]]).reshape(m, n, 4)
+        eq = orc.eq_evals(np.ascontiguousarray(r0)) if len(r0) else orc.from_ints([1])
+        if axis == 0:
+            v = np.stack([sum_fr([orc.fr_mul_arr(X[h, j], eq[j]) for j in range(n)]) for h in range(m)])
+        else:
+            v = np.stack([sum_fr([orc.fr_mul_arr(X[h, j], eq[h]) for h in range(m)]) for j in range(n)])
+        I = OR.softmax(OR.SM_SUM_AXIS, v, None, 0, ilog2(len(v)), None)
+        rs = self.run(I, acc_claim, i, "SumReduction")
+        pt = np.concatenate([rs, r0]) if axis == 0 else np.concatenate([r0, rs])
+        self.append_nodeio(nd, 0, pt, I.finals()[0])
+
+    def op_scalar_const_div(self, nd):
+        i = nd["idx"]
+        r0, claim = self.reduced[i]
+        I = OR.elementwise(OR.EW_SUB, [self.mle(nd["inputs"][0]), fr(self.wit[i]["rem"])], r0)
+        rs = self.run(I, orc.fr_mul_arr(claim, fr([nd["divisor"]])[0]), i, "Execution")
+        fin = I.finals(); pt = np.ascontiguousarray(rs[::-1])
+        self.append_nodeio(nd, 0, pt, fin[0])
+        self.append_dense(nd, "ScalarConstDivNodeRemainder", pt, fin[1])
+
+    def op_slice(self, nd):
+        i = nd["idx"]
+        r0, claim = self.reduced[i]
+        idims = self.nodes[nd["inputs"][0]]["dims"]
+        eq = orc.eq_evals(np.ascontiguousarray(r0))
+        sel = orc.fr_array(int(np.prod(idims))).reshape(*idims, 4)
+        sl = [slice(None)] * len(idims); sl[nd["axis"]] = slice(nd["start"], nd["end"])
+        sel[tuple(sl)] = eq.reshape(*nd["dims"], 4)
+        I = OR.elementwise(OR.EW_DOT, [self.mle(nd["inputs"][0]), np.ascontiguousarray(sel.reshape(-1, 4))], orc.fr_array(ilog2(int(np.prod(idims)))))
+        rs = self.run(I, claim, i, "Execution")
+        self.append_nodeio(nd, 0, np.ascontiguousarray(rs[::-1]), I.finals()[0])
+
+    def op_div(self, nd):
+        i = nd["idx"]
+        n = ilog2(len(self.trace[i]))
+        r = self.t.challenge_vector_opt(n)
+        rem = self.wit[i]["rem"]
+        I = OR.elementwise(OR.EW_DIV, [self.mle(nd["inputs"][0]), self.mle(nd["inputs"][1]), self.mle(i), fr(rem)], r)
+        rs = self.run(I, orc.fr_array(1)[0], i, "Execution")
+        fin = I.finals(); pt = np.ascontiguousarray(rs[::-1])
+        self.append_nodeio(nd, 0, pt, fin[0]); self.append_nodeio(nd, 1, pt, fin[1])
+        self.append_virtual(node_exec(virt("NodeOutput", i), i), pt, fin[2])
+        self.append_advice(nd, "DivRemainder", pt, fin[3])
         self.eval_reduction(nd)
+        r0, claim = self.reduced[i]
+        self.append_dense(nd, "DivNodeQuotient", r0, claim)
+        if len(rem) > 1:
+            self.range_and_onehot(nd, interleave_arr(rem, self.trace[nd["inputs"][1]]), pt, fin[3], fin[1], "DivRangeCheckRa", "DivRangeCheckRaD", "RaOneHotChecks")
+
+    def op_mean_of_squares(self, nd):
+        i = nd["idx"]
+        r0, out_claim = self.reduced[i]
+        w = self.wit[i]; D = w["D"]
+        eval_R, acc_claim = orc.evaluate(fr(w["rem"]), r0), orc.evaluate(fr(w["quot"]), r0)
+        self.append_advice(nd, "RescaleRemainder", r0, eval_R)
+        self.append_advice(nd, "ClampAcc", r0, acc_claim)
+        if len(w["rem"]) > 1:
+            self.clamp_lookup(nd, w["quot"].astype(np.int64).view(np.uint64).copy(), r0, acc_claim, out_claim)
+        X = self.mle(nd["inputs"][0])
+        log_ret, log_red = len(r0), ilog2(len(X)) - len(r0)
+        eq = orc.eq_evals(np.ascontiguousarray(r0)) if log_ret else orc.from_ints([1])
+        in_claim = orc.fr_add_arr(orc.fr_mul_arr(acc_claim, fr([D])[0]), eval_R)
+        assert np.array_equal(orc.dot_claim(X, X, eq, 1, log_ret, log_red)[0], in_claim), "mean-of-squares input claim"
+        proof, ch, fin = orc.sumcheck_dot_prove(X, X.copy(), np.ascontiguousarray(in_claim).reshape(1, 4), self.t.t, eq, 1, log_ret, log_red)
+        self.proofs[(i, PT["RescaleArith"])] = [row for row in proof]
+        self.append_nodeio(nd, 0, orc.challenges_to_fr(ch), fin[0])
+        if len(w["rem"]) > 1:
+            lookups = interleave_arr(w["rem"], np.full(len(w["rem"]), D, dtype=np.int32))
+            self.range_and_onehot(nd, lookups, r0, eval_R, fr([D])[0], "MeanOfSquaresRangeCheckRa", "MeanOfSquaresRangeCheckRaD", "RescaleRemainderRaChecks")
+
+    def op_rsqrt(self, nd):
+        i = nd["idx"]
+        w = self.wit[i]
+        n = ilog2(len(self.trace[i]))
+        r = self.t.challenge_vector_opt(n)
+        gamma = self.t.challenge_scalar()
+        x = self.trace[nd["inputs"][0]]
+        I = OR.elementwise(OR.EW_RSQRT, [fr(x), fr(w["quot"]), self.mle(i), fr(w["div_rem"]), fr(w["sqrt_rem"])], r,
+                           constants=np.stack([fr([1 << (3 * nd["scale"])])[0], gamma]))
+        rs = self.run(I, orc.fr_array(1)[0], i, "Execution")
+        fin = I.finals(); pt = np.ascontiguousarray(rs[::-1])
+        self.append_nodeio(nd, 0, pt, fin[0])
+        self.append_dense(nd, "RsqrtQuotient", pt, fin[1])
+        self.append_virtual(node_exec(virt("NodeOutput", i), i), pt, fin[2])
+        self.append_advice(nd, "DivRemainder", pt, fin[3])
+        self.append_advice(nd, "SqrtRemainder", pt, fin[4])
+        self.eval_reduction(nd)
+        lk1, lk2 = interleave_arr(w["div_rem"], x), interleave_arr(w["sqrt_rem"], w["bound"])
+        i1, c1 = self.range_check(lk1, pt, fin[3], fin[0])
+        i2, c2 = self.range_check(lk2, pt, fin[4], orc.fr_add_arr(orc.fr_add_arr(fin[2], fin[2]), one()))
+        rows, ch, _ = OB.batched_prove([OB.ra_instance(i1, c1), OB.ra_instance(i2, c2)], self.t.t)
+        self.proofs[(i, PT["RangeCheck"])] = rows
+        rs2 = orc.challenges_to_fr(ch)
+        ra_point = np.concatenate([rs2[:64], rs2[64:][::-1]])
+        fams = []
+        for lk, vp, cp in ((lk1, "DivRangeCheckRa", "SqrtDivRangeCheckRaD"), (lk2, "SqrtRangeCheckRa", "SqrtRangeCheckRaD")):
+            ra_claim = orc.evaluate(np.stack([eq_bits(ra_point[:64], v, 64) for v in lk]), np.ascontiguousarray(ra_point[64:]))
+            self.append_virtual(node_exec(virt(vp, i), i), ra_point, ra_claim)
+            fams.append((lk, 64, pt, ra_point, ra_claim, cp))
+        self.onehot_checks_multi(nd, fams, "RaOneHotChecks")
+
+    def prove_node(self, nd):
         op, i = nd["op"], nd["idx"]
+        if op == "Div":
+            return self.op_div(nd)                                           # ReductionFlow::Custom
+        if op == "Rsqrt":
+            return self.op_rsqrt(nd)
+        self.eval_reduction(nd)
         r0, claim = self.reduced[i]
         if op in ("Input", "Constant"):
             return
+        if op in ("Sum", "ScalarConstDiv", "Slice", "MeanOfSquares"):
+            return {"Sum": self.op_sum, "ScalarConstDiv": self.op_scalar_const_div, "Slice": self.op_slice, "MeanOfSquares": self.op_mean_of_squares}[op](nd)
         if op == "Identity":
             self.append_nodeio(nd, 0, r0, claim)
         elif op in ("Add", "Sub"):
@@ -551,17 +758,22 @@ class Prover:
             self.ro = None
             return
         keys = sorted(self.committed)
-        insts, kinds = [], []
+        insts = []
         for k in keys:
             c = self.committed[k]
             assert "point" in c, f"committed polynomial {k} never opened"
-            ra, rc = c["point"][:4], c["point"][4:]
-            insts.append(OB.ra_instance(OR.onehot_opening(c["row"], 4, ra, rc), c["claim"]))
+            if "dense" in c:
+                insts.append(OB.ra_instance(OR.dense_opening(c["dense"].copy(), c["point"]), c["claim"]))
+            else:
+                insts.append(OB.ra_instance(OR.onehot_opening(c["row"], 4, c["point"][:4], c["point"][4:]), c["claim"]))
         rows, ch, _ = OB.batched_prove(insts, self.t.t)
         rs = orc.challenges_to_fr(ch)
         fin = []
         for k in keys:
             c = self.committed[k]
+            if "dense" in c:
+                fin.append(orc.evaluate(c["dense"], np.ascontiguousarray(rs[len(rs) - c["log_T"]:])))
+                continue
             sl = rs[len(rs) - 4 - c["log_T"]:]
             Fs = orc.eq_evals(np.ascontiguousarray(sl[:4]))
             fin.append(orc.evaluate(np.stack([Fs[x] for x in c["row"]]), np.ascontiguousarray(sl[4:])))
@@ -571,7 +783,9 @@ class Prover:
         gam = [one()]
         for _ in range(1, len(fin)):
             gam.append(orc.fr_mul_arr(gam[-1], q))
-        joint = OB.rlc_build([], [(self.committed[k]["row"], 16, g) for k, g in zip(keys, gam)])
+        dense = [(self.committed[k]["dense"], g) for k, g in zip(keys, gam) if "dense" in self.committed[k]]
+        onehot = [(self.committed[k]["row"], 16, g) for k, g in zip(keys, gam) if "dense" not in self.committed[k]]
+        joint = OB.rlc_build(dense, onehot)
         assert len(joint) == 1 << len(ch)
         com, w, v = orc.hyperkzg_open(self.srs, joint, ch, self.t.t)
         self.ro = dict(rows=rows, claims=fin, com=com, w=w, v=v, ch=ch, joint=joint)
@@ -619,6 +833,26 @@ class Prover:
         for i in range(3):
             out += u64(ell) + b"".join(fr_bytes(c) for c in ro["v"][i])
         return out
+
+
+def interleave_arr(x, y):
+    """interleave_bits(x as u32, y as u32) per element (joltworks utils/mod.rs:146-164): x on the odd bit positions, y on the even ones"""
+    def spread(v):
+        v = np.asarray(v).astype(np.int64).astype(np.uint32).astype(np.uint64)
+        v = (v | (v << np.uint64(16))) & np.uint64(0x0000FFFF0000FFFF)
+        v = (v | (v << np.uint64(8))) & np.uint64(0x00FF00FF00FF00FF)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x0F0F0F0F0F0F0F0F)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x3333333333333333)
+        v = (v | (v << np.uint64(1))) & np.uint64(0x5555555555555555)
+        return v
+    return (spread(x) << np.uint64(1)) | spread(y)
+
+
+def sum_fr(xs):
+    acc = orc.fr_array(1)[0]
+    for x in xs:
+        acc = orc.fr_add_arr(acc, x)
+    return acc
 
 
 def eq_bits(r, value, nbits):

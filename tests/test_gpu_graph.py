@@ -53,12 +53,35 @@ def shape_graph(rng, t=4, b=2, hd=4, S=4):
     ], [17], [rng.integers(-32, 32, size=t * c).astype(np.int32)]
 
 
+def norm_graph(rng, t=4, c=8, S=6):
+    """the LayerNorm-shaped slice: mean (Sum + ScalarConstDiv), centring (Broadcast + Sub), MeanOfSquares, Add eps, Rsqrt, Broadcast,
+    Mul; then a Div by a positive tensor and a Slice"""
+    one = 1 << S
+    return [
+        {"idx": 0, "op": "Input", "inputs": [], "dims": [t, c]},
+        {"idx": 1, "op": "Sum", "inputs": [0], "dims": [t, 1], "axes": [1]},
+        {"idx": 2, "op": "ScalarConstDiv", "inputs": [1], "dims": [t, 1], "divisor": c},
+        {"idx": 3, "op": "Broadcast", "inputs": [2], "dims": [t, c]},
+        {"idx": 4, "op": "Sub", "inputs": [0, 3], "dims": [t, c]},
+        {"idx": 5, "op": "MeanOfSquares", "inputs": [4], "dims": [t, 1], "axes": [1], "scale": S, "count": c},
+        {"idx": 6, "op": "Constant", "inputs": [], "dims": [t, 1], "data": np.full(t, 3, dtype=np.int32)},
+        {"idx": 7, "op": "Add", "inputs": [5, 6], "dims": [t, 1]},
+        {"idx": 8, "op": "Rsqrt", "inputs": [7], "dims": [t, 1], "scale": S},
+        {"idx": 9, "op": "Broadcast", "inputs": [8], "dims": [t, c]},
+        {"idx": 10, "op": "Mul", "inputs": [4, 9], "dims": [t, c], "scale": S},
+        {"idx": 11, "op": "Constant", "inputs": [], "dims": [t, c], "data": rng.integers(1, 9, size=t * c).astype(np.int32)},
+        {"idx": 12, "op": "Div", "inputs": [10, 11], "dims": [t, c]},
+        {"idx": 13, "op": "Slice", "inputs": [12], "dims": [t, c // 2], "axis": 1, "start": c // 2, "end": c},
+        {"idx": 14, "op": "Sum", "inputs": [13], "dims": [1, c // 2], "axes": [0]},
+    ], [14], [rng.integers(-4 * one, 4 * one, size=t * c).astype(np.int32)]
+
+
 def _max_vars(nodes):
     # the largest committed polynomial is a one-hot chunk: K = 16 addresses x T cycles
     return 4 + max(int(np.log2(np.prod(nd["dims"]))) for nd in nodes)
 
 
-@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2)])
+@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3)])
 def test_graph_proof_matches_oracle(atlas, builder, seed):
     from oracle import graph as OG, orc
     from jolt_atlas_amd import graph as GG
