@@ -6,6 +6,8 @@
 // tensor/mod.rs:474-481 — a graph description pads its shapes up front, e.g. vocab 65 -> 128).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
 #include "graph_state.hip.h"
 
 using gr::Node;
@@ -103,6 +105,27 @@ __global__ __launch_bounds__(256) void k_rsqrt(const int32_t* __restrict__ x, si
     }
 }
 
+// Tanh (atlas-onnx-tracer ops/tanh.rs:9-14): clamp to [-2^B, 2^B - 1], then the table; witness: the clamped tensor, its (B+1)-bit
+// two's-complement table index (n_bits_to_usize) and the raw input's `as u32 as u64` lookup index of the clamp table
+__global__ __launch_bounds__(256) void k_tanh(const int32_t* __restrict__ x, size_t n, uint32_t B, const int32_t* __restrict__ table, int32_t* __restrict__ out,
+                                              int32_t* __restrict__ clamped, uint64_t* __restrict__ idx_small, uint64_t* __restrict__ idx_clamp) {
+    const int32_t bound = 1 << B;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int32_t v = x[i], c = v < -bound ? -bound : v > bound - 1 ? bound - 1 : v;
+        const uint32_t k = c < 0 ? (uint32_t)(c + (1 << (B + 1))) : (uint32_t)c;
+        clamped[i] = c; idx_small[i] = k; idx_clamp[i] = (uint64_t)(uint32_t)v; out[i] = table[k];
+    }
+}
+// Gather along axis 0 (ops/gather.rs): out[j][w] = dict[idx[j]][w]
+__global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__ dict, const int32_t* __restrict__ idx, size_t n_idx, size_t word, int32_t* __restrict__ out,
+                                                     uint64_t* __restrict__ lookups) {
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < n_idx * word; o += (size_t)gridDim.x * 256) {
+        const size_t j = o / word, w = o % word;
+        out[o] = dict[(size_t)idx[j] * word + w];
+        if (w == 0) lookups[j] = (uint64_t)(uint32_t)idx[j];
+    }
+}
+
 unsigned grid_for(size_t n) { size_t b = (n + 255) / 256; return (unsigned)(b > 4096 ? 4096 : b ? b : 1); }
 
 std::vector<size_t> row_major(const std::vector<size_t>& dims) {
@@ -145,6 +168,30 @@ int atlas_rt_sum_config(const std::vector<size_t>& idims, size_t axis, size_t& m
     if (d.size() == 1) { m = d[0]; n = 1; ax = 0; return axis == 0 ? ATLAS_OK : fail(ATLAS_EINVAL, "graph: Sum axis"); }
     m = d[0]; n = d[1]; ax = (int)axis;
     return axis < 2 ? ATLAS_OK : fail(ATLAS_EINVAL, "graph: Sum axis");
+}
+
+int atlas_rt_tanh_table(const int32_t** d_table, const std::vector<int32_t>** h_table) {
+    static std::vector<int32_t> host;
+    static int32_t* dev = nullptr;
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    if (host.empty()) {
+        const size_t n = (size_t)1 << gr::ACTIVATION_TABLE_VARS;
+        const double scale = (double)((uint64_t)1 << gr::MODEL_SCALE);
+        host.resize(n);
+        for (size_t i = 0; i < n; i++) {                                      // usize_to_n_bits, then tensor::ops::nonlinearities::tanh (tensor/ops.rs:3583-3591)
+            const int32_t v = i >= n / 2 ? (int32_t)i - (int32_t)n : (int32_t)i;
+            host[i] = (int32_t)std::round(scale * std::tanh((double)v / scale));
+        }
+    }
+    if (d_table && !dev) {
+        HIP_TRY(hipMalloc(&dev, host.size() * 4));
+        HIP_TRY(hipMemcpyAsync(dev, host.data(), host.size() * 4, hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        g.at_shutdown.push_back([] { if (dev) { (void)hipFree(dev); dev = nullptr; } });
+    }
+    if (d_table) *d_table = dev;
+    if (h_table) *h_table = &host;
+    return ATLAS_OK;
 }
 
 namespace {
@@ -294,6 +341,24 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
             HIP_TRY(hipStreamSynchronize(g.stream));                          // q64 leaves scope
             { uint64_t* lk2 = nullptr; int rc = atlas_lookup_indices_from_operands(W.rem.as<int32_t>(), in(0), T, &lk2); if (rc) return rc; W.lookups.p = lk2; }
             { uint64_t* lk2 = nullptr; int rc = atlas_lookup_indices_from_operands(W.rem2.as<int32_t>(), W.bound.as<int32_t>(), T, &lk2); if (rc) return rc; W.lookups2.p = lk2; }
+            return ATLAS_OK;
+        }
+        case ATLAS_OP_TANH: {
+            if (!need_inputs(1) || !same_len() || nd.p[0] != (int64_t)gr::MODEL_SCALE) return fail(ATLAS_EINVAL, "graph: Tanh needs one operand and scale = MODEL_SCALE (14): the prover's table is compiled for it");
+            const int32_t* d_table = nullptr;
+            if (int rc = atlas_rt_tanh_table(&d_table, nullptr)) return rc;
+            NodeWitness& W = G.wit[nd.idx];
+            HIP_TRY(W.clamped.alloc(T * 4)); HIP_TRY(W.lookups.alloc(T * 8)); HIP_TRY(W.lookups2.alloc(T * 8));
+            k_tanh<<<grid_for(T), 256, 0, g.stream>>>(in(0), T, (uint32_t)gr::ACTIVATION_BOUND, d_table, out.as<int32_t>(), W.clamped.as<int32_t>(), W.lookups2.as<uint64_t>(), W.lookups.as<uint64_t>());
+            return ATLAS_OK;
+        }
+        case ATLAS_OP_GATHER_LARGE: {                                         // inputs (dictionary [V][D...], indexes [N]); output [N][D...]
+            if (!need_inputs(2) || nd.p[0] != 0) return fail(ATLAS_EINVAL, "graph: Gather needs (dictionary, indexes) and axis 0");
+            const size_t V = in_node(0).dims[0], word = gr::padded_len(in_node(0).dims) / V, N = gr::padded_len(in_node(1).dims);
+            if (T != N * word || (size_t)nd.p[1] > V) return fail(ATLAS_EINVAL, "graph: Gather dims / dict_len");
+            NodeWitness& W = G.wit[nd.idx];
+            HIP_TRY(W.lookups.alloc(N * 8));
+            k_gather_rows<<<grid_for(T), 256, 0, g.stream>>>(in(0), in(1), N, word, out.as<int32_t>(), W.lookups.as<uint64_t>());
             return ATLAS_OK;
         }
         default: return fail(ATLAS_EINVAL, "graph_trace: operator not supported by the device executor");

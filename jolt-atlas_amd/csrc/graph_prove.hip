@@ -167,6 +167,18 @@ struct Prover : FlowSink {
                     chunks(gr::CP_SqrtDivRangeCheckRaD, W.lookups.as<uint64_t>(), 64);
                     chunks(gr::CP_SqrtRangeCheckRaD, W.lookups2.as<uint64_t>(), 64);
                     break;
+                case ATLAS_OP_TANH:                                                                                      // clamped_activation_committed_polynomials
+                    chunks(gr::CP_ActivationClampRaD, W.lookups.as<uint64_t>(), 32);
+                    chunks(gr::CP_ActivationSmallRaD, W.lookups2.as<uint64_t>(), gr::ACTIVATION_TABLE_VARS);
+                    break;
+                case ATLAS_OP_GATHER_LARGE: {                                                                            // ops/gather/large.rs:105-111
+                    const size_t N = gr::padded_len(G.nodes.at(nd.inputs[1]).dims), V = G.nodes.at(nd.inputs[0]).dims[0], lk = gr::log2u(V), d = (lk + 3) / 4;
+                    for (size_t i = 0; i < d; i++) {
+                        gr::Committed c; c.id = gr::comm(gr::CP_GatherRaD, nd.idx, i); c.kind = 1; c.d_lookups = W.lookups.as<uint64_t>(); c.log_T = gr::log2u(N); c.log_K = lk; c.chunk = i;
+                        W.committed.push_back(c);
+                    }
+                    break;
+                }
                 default: break;
             }
             if (drc) return drc;
@@ -709,6 +721,105 @@ struct Prover : FlowSink {
         return rc;
     }
 
+    // Tanh (ops/tanh.rs -> activation_clamped/mod.rs:440-527): Execution = the 2^18-entry table lookup of the clamped input
+    // (gamma-batched with the signed identity), NeuralTeleport = the clamp lookup tying `clamped` to the raw input, then both
+    // lookups' one-hot checks in ONE batched sumcheck
+    int op_tanh(const Node& nd) {
+        const size_t T = gr::padded_len(nd.dims), log_T = gr::log2u(T), LK = gr::ACTIVATION_TABLE_VARS, K = (size_t)1 << LK;
+        const gr::Opening& R = red(nd);
+        NodeWitness& W = G.wit[nd.idx];
+        Out O = out();
+        const H::Fr gamma = H::tr_challenge_scalar(Tr);                      // SmallTableParams::new
+        const int32_t* cl = W.clamped.as<int32_t>();
+        H::Fr clamped_claim;
+        int rc = eval_i32(&cl, 1, T, R.point, &clamped_claim);
+        if (!rc) rc = append_advice(nd, gr::VP_ActivationClampedOutput, R.point, clamped_claim);
+        if (rc) return rc;
+        // input_onehot[k] = sum_{j : idx_j = k} eq(r, j); table and signed identity as polynomials over the 18 address bits
+        atlas_poly_t eq = nullptr, ops[3] = {nullptr, nullptr, nullptr};
+        rc = atlas_eq_evals((const atlas_fr_t*)R.point.data(), log_T, nullptr, &eq);
+        if (!rc) rc = atlas_shout_read_raf_G(W.lookups2.as<uint64_t>(), T, LK, eq, &ops[0]);
+        if (eq) atlas_poly_free(eq);
+        const int32_t* d_table = nullptr;
+        if (!rc) rc = atlas_rt_tanh_table(&d_table, nullptr);
+        if (!rc) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(d_table), K, &ops[1]);
+        std::vector<int32_t> ident(K);
+        for (size_t i = 0; i < K; i++) ident[i] = i >= K / 2 ? (int32_t)i - (int32_t)K : (int32_t)i;      // SignedIdentityPoly (signed_identity_poly.rs)
+        if (!rc) rc = atlas_poly_upload_i32(ident.data(), K, &ops[2]);
+        atlas_instance_t inst = nullptr;
+        if (!rc) rc = atlas_elementwise_new(ATLAS_EW_GATHER, ops, 3, nullptr, LK, (const atlas_fr_t*)&gamma, 1, &inst);
+        for (atlas_poly_t p : ops) if (p) atlas_poly_free(p);
+        std::vector<H::Fr> rs, fin;
+        if (!rc) rc = run_single(inst, H::add(R.claim, H::mul(gamma, clamped_claim)), gr::PT_Execution, rs, fin);
+        if (inst) atlas_instance_free(inst);
+        if (rc) return rc;
+        Point small_pt = reversed(rs);                                        // ActivationSmallRa at (r_table | r_node_output)
+        small_pt.insert(small_pt.end(), R.point.begin(), R.point.end());
+        rc = append_advice(nd, gr::VP_ActivationSmallRa, small_pt, fin[0]);
+        // ActivationClamp: read_raf_prove over ActivationClampTable<32> = ClampBoundedTable<32, 17, true> (ProofType::NeuralTeleport)
+        H::Fr operand_claim;
+        const int32_t* tp = G.tensor(nd.inputs[0]);
+        if (!rc) rc = eval_i32(&tp, 1, T, R.point, &operand_claim);
+        if (!rc) rc = append_nodeio(nd, 0, R.point, operand_claim);           // append_raf_claims_prover
+        if (rc) return rc;
+        const H::Fr gamma2 = H::tr_challenge_scalar(Tr);
+        atlas_instance_t cinst = nullptr;
+        rc = atlas_ps_shout_clamp_new(W.lookups.as<uint64_t>(), log_T, 32, gr::ACTIVATION_BOUND, 1, (const atlas_fr_t*)R.point.data(), (const atlas_fr_t*)&gamma2, &cinst);
+        std::vector<atlas_u128_t> ch; H::Fr ra_claim; std::vector<atlas_fr_t> ra_point;
+        if (!rc) rc = prove_single(cinst, H::add(clamped_claim, H::mul(gamma2, operand_claim)), &t, O, ch, &ra_claim, 32, gr::VP_ActivationClampRa, gr::PT_NeuralTeleport, &ra_point);
+        if (cinst) atlas_instance_free(cinst);
+        if (rc) return rc;
+        std::vector<OneHotFamily> fams(2);
+        fams[0].d_lookups = W.lookups2.as<uint64_t>(); fams[0].log_K = LK; fams[0].r_cycle = (const atlas_fr_t*)R.point.data();
+        fams[0].ra_point.resize(small_pt.size()); std::memcpy(fams[0].ra_point.data(), small_pt.data(), small_pt.size() * 32);
+        fams[0].ra_claim = fin[0]; fams[0].rad_cp = gr::CP_ActivationSmallRaD;
+        fams[1].d_lookups = W.lookups.as<uint64_t>(); fams[1].log_K = 32; fams[1].r_cycle = (const atlas_fr_t*)R.point.data();
+        fams[1].ra_point = ra_point; fams[1].ra_claim = ra_claim; fams[1].rad_cp = gr::CP_ActivationClampRaD;
+        return prove_onehot_checks_multi(fams, log_T, &t, O, gr::PT_RaOneHotChecks);
+    }
+
+    // GatherLarge (ops/gather/large.rs + mod.rs): out[j][w] = dict[idx_j][w] as sum_k ra(k) (dict_r(k) + gamma k)
+    int op_gather(const Node& nd) {
+        const Node& dict = G.nodes.at(nd.inputs[0]);
+        const Node& idxn = G.nodes.at(nd.inputs[1]);
+        const size_t V = dict.dims[0], word = gr::padded_len(dict.dims) / V, N = gr::padded_len(idxn.dims), lv = gr::log2u(V), ln = gr::log2u(N), lw = gr::log2u(word);
+        const gr::Opening& R = red(nd);
+        NodeWitness& W = G.wit[nd.idx];
+        Out O = out();
+        const H::Fr gamma = H::tr_challenge_scalar(Tr);                      // GatherParams::new
+        const Point r_index(R.point.begin(), R.point.begin() + ln), r_word(R.point.begin() + ln, R.point.end());
+        H::Fr index_claim;
+        const int32_t* ip = G.tensor(idxn.idx);
+        int rc = eval_i32(&ip, 1, N, r_index, &index_claim);
+        if (!rc) rc = append_nodeio(nd, 1, r_index, index_claim);
+        if (rc) return rc;
+        atlas_poly_t eq_i = nullptr, eq_w = nullptr, ops[3] = {nullptr, nullptr, nullptr};
+        rc = atlas_eq_evals((const atlas_fr_t*)r_index.data(), ln, nullptr, &eq_i);
+        if (!rc) rc = atlas_shout_read_raf_G(W.lookups.as<uint64_t>(), N, lv, eq_i, &ops[0]);          // compute_ra_evals(r_index, indexes, num_words)
+        if (!rc) rc = atlas_eq_evals((const atlas_fr_t*)r_word.data(), lw, nullptr, &eq_w);
+        if (!rc) rc = atlas_fold_i32_rows(G.tensor(dict.idx), V, word, eq_w, &ops[1]);                  // fold_dictionary(r_word, dictionary)
+        for (atlas_poly_t p : {eq_i, eq_w}) if (p) atlas_poly_free(p);
+        std::vector<int32_t> ident(V);
+        for (size_t i = 0; i < V; i++) ident[i] = (int32_t)i;                // IdentityPolynomial
+        if (!rc) rc = atlas_poly_upload_i32(ident.data(), V, &ops[2]);
+        atlas_instance_t inst = nullptr;
+        if (!rc) rc = atlas_elementwise_new(ATLAS_EW_GATHER, ops, 3, nullptr, lv, (const atlas_fr_t*)&gamma, 1, &inst);
+        for (atlas_poly_t p : ops) if (p) atlas_poly_free(p);
+        std::vector<H::Fr> rs, fin;
+        if (!rc) rc = run_single(inst, H::add(R.claim, H::mul(gamma, index_claim)), gr::PT_Execution, rs, fin);
+        if (inst) atlas_instance_free(inst);
+        if (rc) return rc;
+        Point ra_pt = reversed(rs), dict_pt = ra_pt;
+        ra_pt.insert(ra_pt.end(), r_index.begin(), r_index.end());
+        dict_pt.insert(dict_pt.end(), r_word.begin(), r_word.end());
+        rc = append_advice(nd, gr::VP_NodeOutputRa, ra_pt, fin[0]);
+        if (!rc) rc = append_nodeio(nd, 0, dict_pt, fin[1]);
+        if (rc) return rc;
+        std::vector<atlas_fr_t> rap(ra_pt.size());
+        std::memcpy(rap.data(), ra_pt.data(), ra_pt.size() * 32);
+        return prove_onehot_checks(W.lookups.as<uint64_t>(), ln, lv, (const atlas_fr_t*)r_index.data(), rap, fin[0], &t, O, gr::CP_GatherRaD, gr::PT_RaOneHotChecks);
+    }
+
     int prove_node(const Node& nd) {
         cur = nd.idx;
         if (nd.op == ATLAS_OP_DIV) return op_div(nd);                          // ReductionFlow::Custom
@@ -731,6 +842,8 @@ struct Prover : FlowSink {
             case ATLAS_OP_SCALAR_CONST_DIV: return op_scalar_const_div(nd);
             case ATLAS_OP_SLICE: return op_slice(nd);
             case ATLAS_OP_MEAN_OF_SQUARES: return op_mean_of_squares(nd);
+            case ATLAS_OP_TANH: return op_tanh(nd);
+            case ATLAS_OP_GATHER_LARGE: return op_gather(nd);
             default: return fail(ATLAS_EINVAL, "prove_graph: operator without a prover composition");
         }
     }

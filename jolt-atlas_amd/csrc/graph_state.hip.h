@@ -12,6 +12,7 @@ struct NodeWitness {
     DevBuf lookups;                              // ReLU and the other XLEN-bit unary lookups; Div / MeanOfSquares: the range check's interleaved pairs
     DevBuf rem;                                  // ScalarConstDiv / Div: the remainder tensor (i32); Rsqrt: div_remainder
     DevBuf quot_fr, rem2, lookups2, bound;       // Rsqrt: quotient as Fr, sqrt_remainder, the second range check's pairs and its bound 2 out + 1
+    DevBuf clamped;                              // Tanh: clamp(input, ACTIVATION_BOUND) (i32); its 18-bit lookups in `lookups2`, the raw-input lookups in `lookups`
     std::vector<atlas_poly_t> dense_views;       // borrowed polynomial views of the dense committed polynomials
     ~NodeWitness() { for (auto p : dense_views) if (p) atlas_poly_free(p); }
     NodeWitness() = default;
@@ -32,7 +33,12 @@ struct atlas_graph {
     void clear_trace() { out.clear(); wit.clear(); traced = false; }
 };
 
+// the small activation table of Tanh (ops/tanh.rs:22-32 -> neural_teleport/utils.rs:67-85): Table[i] = round(2^14 tanh(signed18(i) / 2^14)),
+// built once on the host (the reference's f64 arithmetic) and kept in HBM; graph_exec.hip
+int atlas_rt_tanh_table(const int32_t** d_table, const std::vector<int32_t>** h_table);
+
 namespace gr {
+constexpr size_t MODEL_SCALE = 14, ACTIVATION_BOUND = MODEL_SCALE + 3, ACTIVATION_TABLE_VARS = ACTIVATION_BOUND + 1;      // common/src/consts
 inline size_t next_pow2(size_t x) { size_t p = 1; while (p < x) p <<= 1; return p; }
 inline unsigned log2u(size_t x) { unsigned n = 0; while (x > 1) { x >>= 1; n++; } return n; }
 // pow2_padded_num_output_elements (node/mod.rs:52-57): every dimension padded on its own

@@ -72,6 +72,14 @@ def fr(vals):
     return orc.from_ints([int(v) % FR for v in np.asarray(vals).reshape(-1)])
 
 
+def fr_fast(vals):
+    """small signed integers -> Montgomery Fr through the oracle's own conversion (orc_i32_to_fr)"""
+    v = np.ascontiguousarray(vals, dtype=np.int32)
+    out = orc.fr_array(len(v))
+    orc.lib.orc_i32_to_fr(v.ctypes.data_as(C.c_void_p), C.c_size_t(len(v)), orc._p(out))
+    return out
+
+
 def one():
     return orc.from_ints([1])[0]
 
@@ -173,6 +181,29 @@ def opening_id_bytes(k):
     if sc in (SC["NodeExecution"], SC["RLC"]):
         out += u64(idx)
     return out
+
+
+MODEL_SCALE = 14
+ACTIVATION_BOUND = MODEL_SCALE + 3
+ACTIVATION_TABLE_VARS = ACTIVATION_BOUND + 1
+_TANH = None
+
+
+def tanh_table():
+    """materialize_signed_activation_table (neural_teleport/utils.rs:67-85) with nonlinearities::tanh (tensor/ops.rs:3583-3591):
+    Table[i] = round(2^14 tanh(signed18(i) / 2^14)) in f64, round-half-away-from-zero like f64::round"""
+    global _TANH
+    if _TANH is None:
+        import math
+        n = 1 << ACTIVATION_TABLE_VARS
+        sc = float(1 << MODEL_SCALE)
+        out = np.zeros(n, dtype=np.int64)
+        for i in range(n):
+            v = i - n if i >= n // 2 else i
+            f = sc * math.tanh(v / sc)
+            out[i] = int(math.floor(abs(f) + 0.5)) * (1 if f >= 0 else -1)
+        _TANH = out
+    return _TANH
 
 
 # ---- the integer semantics of the tracer (atlas-onnx-tracer/src/ops/*.rs)
@@ -284,6 +315,15 @@ def execute(nodes, inputs):
             out_ = np.where(out_ * out_ > q, out_ - 1, out_); out_ = np.where((out_ + 1) * (out_ + 1) <= q, out_ + 1, out_)
             wit[nd["idx"]] = dict(quot=q, div_rem=dr.astype(np.int32), sqrt_rem=(q - out_ * out_).astype(np.int32), bound=(2 * out_ + 1).astype(np.int32))
             o = out_.astype(np.int32)
+        elif op == "Tanh":
+            assert nd["scale"] == MODEL_SCALE
+            c = np.clip(ins[0], -(1 << ACTIVATION_BOUND), (1 << ACTIVATION_BOUND) - 1).astype(np.int32)
+            k = np.where(c < 0, c.astype(np.int64) + (1 << ACTIVATION_TABLE_VARS), c.astype(np.int64))
+            wit[nd["idx"]] = dict(clamped=c, small_idx=k.astype(np.uint64))
+            o = tanh_table()[k].astype(np.int32)
+        elif op == "GatherLarge":
+            ddims = next(n for n in nodes if n["idx"] == nd["inputs"][0])["dims"]
+            o = ins[0].reshape(ddims[0], -1)[ins[1]].reshape(-1).astype(np.int32)
         else:
             raise ValueError(f"oracle graph executor: operator {op}")
         assert len(o) == int(np.prod(nd["dims"])), (nd, len(o))
@@ -346,6 +386,12 @@ class Prover:
             return [("NodeOutputRaD", self.trace[nd["inputs"][0]].astype(np.uint32).astype(np.uint64), 32)]
         if op == "Sum":
             return [("ClampRaD", self.wit[i]["acc"].astype(np.int64).view(np.uint64), 64)]
+        if op == "Tanh":
+            return [("ActivationClampRaD", self.trace[nd["inputs"][0]].astype(np.uint32).astype(np.uint64), 32),
+                    ("ActivationSmallRaD", self.wit[i]["small_idx"], ACTIVATION_TABLE_VARS)]
+        if op == "GatherLarge":
+            V = self.nodes[nd["inputs"][0]]["dims"][0]
+            return [("GatherRaD", self.trace[nd["inputs"][1]].astype(np.uint32).astype(np.uint64), ilog2(V))]
         if op == "Div":
             return [("DivRangeCheckRaD", interleave_arr(self.wit[i]["rem"], self.trace[nd["inputs"][1]]), 64)]
         if op == "MeanOfSquares":
@@ -704,6 +750,64 @@ class Prover:
             fams.append((lk, 64, pt, ra_point, ra_claim, cp))
         self.onehot_checks_multi(nd, fams, "RaOneHotChecks")
 
+    def ra_histogram(self, lookups, K, r):
+        """compute_ra_evals: ra[k] = sum_{j : idx_j = k} eq(r, j)"""
+        E = orc.eq_evals(np.ascontiguousarray(r)) if len(r) else orc.from_ints([1])
+        out = orc.fr_array(K)
+        for j, k in enumerate(lookups):
+            out[int(k)] = orc.fr_add_arr(out[int(k)], E[j])
+        return out
+
+    def op_tanh(self, nd):
+        i = nd["idx"]
+        r0, out_claim = self.reduced[i]
+        w = self.wit[i]
+        LK = ACTIVATION_TABLE_VARS; K = 1 << LK
+        gamma = self.t.challenge_scalar()
+        clamped_claim = orc.evaluate(fr(w["clamped"]), r0)
+        self.append_advice(nd, "ActivationClampedOutput", r0, clamped_claim)
+        ra = self.ra_histogram(w["small_idx"], K, r0)
+        ident = np.arange(K, dtype=np.int64); ident[K // 2:] -= K
+        I = OR.elementwise(OR.EW_GATHER, [ra, fr_fast(tanh_table()), fr_fast(ident)], orc.fr_array(LK), constants=gamma.reshape(1, 4))
+        rs = self.run(I, orc.fr_add_arr(out_claim, orc.fr_mul_arr(gamma, clamped_claim)), i, "Execution")
+        small_pt = np.concatenate([rs[::-1], r0])
+        ra_small = I.finals()[0]
+        self.append_advice(nd, "ActivationSmallRa", small_pt, ra_small)
+        x = self.trace[nd["inputs"][0]]
+        operand_claim = orc.evaluate(fr(x), r0)
+        self.append_nodeio(nd, 0, r0, operand_claim)
+        gamma2 = self.t.challenge_scalar()
+        lookups = x.astype(np.uint32).astype(np.uint64)
+        claim2 = orc.fr_add_arr(clamped_claim, orc.fr_mul_arr(gamma2, operand_claim))
+        ra_point, ra_claim = self.read_raf(nd, OR.ps_clamp(lookups, 32, ACTIVATION_BOUND, True, r0, gamma2), claim2, lookups, 32, "ActivationClampRa", "NeuralTeleport")
+        self.onehot_checks_multi(nd, [(w["small_idx"], LK, r0, small_pt, ra_small, "ActivationSmallRaD"),
+                                      (lookups, 32, r0, ra_point, ra_claim, "ActivationClampRaD")], "RaOneHotChecks")
+
+    def op_gather(self, nd):
+        i = nd["idx"]
+        r0, out_claim = self.reduced[i]
+        ddims = self.nodes[nd["inputs"][0]]["dims"]
+        V = ddims[0]; word = int(np.prod(ddims)) // V
+        idx = self.trace[nd["inputs"][1]]
+        ln, lv = ilog2(len(idx)), ilog2(V)
+        gamma = self.t.challenge_scalar()
+        r_index, r_word = r0[:ln], r0[ln:]
+        index_claim = orc.evaluate(fr(idx), np.ascontiguousarray(r_index))
+        self.append_nodeio(nd, 1, r_index, index_claim)
+        lookups = idx.astype(np.uint32).astype(np.uint64)
+        ra = self.ra_histogram(lookups, V, r_index)
+        eq_w = orc.eq_evals(np.ascontiguousarray(r_word)) if len(r_word) else orc.from_ints([1])
+        D = fr(self.trace[nd["inputs"][0]]).reshape(V, word, 4)
+        dict_r = np.stack([sum_fr([orc.fr_mul_arr(D[k, wv], eq_w[wv]) for wv in range(word)]) for k in range(V)])
+        I = OR.elementwise(OR.EW_GATHER, [ra, dict_r, fr(np.arange(V))], orc.fr_array(lv), constants=gamma.reshape(1, 4))
+        rs = self.run(I, orc.fr_add_arr(out_claim, orc.fr_mul_arr(gamma, index_claim)), i, "Execution")
+        fin = I.finals()
+        pt = rs[::-1]
+        ra_pt, dict_pt = np.concatenate([pt, r_index]), np.concatenate([pt, r_word])
+        self.append_advice(nd, "NodeOutputRa", ra_pt, fin[0])
+        self.append_nodeio(nd, 0, dict_pt, fin[1])
+        self.onehot_checks(nd, lookups, lv, np.ascontiguousarray(r_index), ra_pt, fin[0], "GatherRaD", "RaOneHotChecks")
+
     def prove_node(self, nd):
         op, i = nd["op"], nd["idx"]
         if op == "Div":
@@ -714,8 +818,9 @@ class Prover:
         r0, claim = self.reduced[i]
         if op in ("Input", "Constant"):
             return
-        if op in ("Sum", "ScalarConstDiv", "Slice", "MeanOfSquares"):
-            return {"Sum": self.op_sum, "ScalarConstDiv": self.op_scalar_const_div, "Slice": self.op_slice, "MeanOfSquares": self.op_mean_of_squares}[op](nd)
+        if op in ("Sum", "ScalarConstDiv", "Slice", "MeanOfSquares", "Tanh", "GatherLarge"):
+            return {"Sum": self.op_sum, "ScalarConstDiv": self.op_scalar_const_div, "Slice": self.op_slice, "MeanOfSquares": self.op_mean_of_squares,
+                    "Tanh": self.op_tanh, "GatherLarge": self.op_gather}[op](nd)
         if op == "Identity":
             self.append_nodeio(nd, 0, r0, claim)
         elif op in ("Add", "Sub"):

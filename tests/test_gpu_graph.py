@@ -76,12 +76,27 @@ def norm_graph(rng, t=4, c=8, S=6):
     ], [14], [rng.integers(-4 * one, 4 * one, size=t * c).astype(np.int32)]
 
 
+def act_graph(rng, n=4, d=4, v=8, S=14):
+    """embedding + activation: GatherLarge of a [v][d] dictionary, Mul by a constant, Tanh (scale 14: the prover's table), Add"""
+    dict_ = rng.integers(-(1 << 16), 1 << 16, size=v * d).astype(np.int32)
+    big = rng.integers(-(1 << 19), 1 << 19, size=n * d).astype(np.int32)
+    return [
+        {"idx": 0, "op": "Input", "inputs": [], "dims": [n]},
+        {"idx": 1, "op": "Constant", "inputs": [], "dims": [v, d], "data": dict_},
+        {"idx": 2, "op": "GatherLarge", "inputs": [1, 0], "dims": [n, d], "axis": 0, "dict_len": v},
+        {"idx": 3, "op": "Constant", "inputs": [], "dims": [n, d], "data": big},
+        {"idx": 4, "op": "Add", "inputs": [2, 3], "dims": [n, d]},
+        {"idx": 5, "op": "Tanh", "inputs": [4], "dims": [n, d], "scale": S},
+        {"idx": 6, "op": "Add", "inputs": [5, 2], "dims": [n, d]},
+    ], [6], [rng.integers(0, v, size=n).astype(np.int32)]
+
+
 def _max_vars(nodes):
     # the largest committed polynomial is a one-hot chunk: K = 16 addresses x T cycles
     return 4 + max(int(np.log2(np.prod(nd["dims"]))) for nd in nodes)
 
 
-@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3)])
+@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4)])
 def test_graph_proof_matches_oracle(atlas, builder, seed):
     from oracle import graph as OG, orc
     from jolt_atlas_amd import graph as GG
