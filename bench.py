@@ -197,6 +197,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs that measure roofline.traffic")
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-node", action="store_true", help="skip the operator-node leg (atlas_prove_einsum_node)")
+    ap.add_argument("--no-graph", action="store_true", help="skip the whole-proof leg (atlas_prove_graph on the nanoGPT- / GPT-2-layer-shaped graphs)")
     ap.add_argument("--no-shard", action="store_true", help="N>1: skip the leg that shards ONE instance / ONE MSM over the N GPUs")
     args = ap.parse_args()
     if args.pmc_child:
@@ -452,6 +453,41 @@ def main():
                            "stage_ms": dict(zip(("witness", "execution_clamp_ps_shout", "ra_one_hot_checks", "mul_sumcheck", "range_check",
                                                  "remainder_ra_checks"), [float(x) for x in st_m]))}
         tL.free(); tR.free()
+    # whole-proof leg: ONNXProof::prove (atlas_prove_graph: trace on the device, witness commitments, output claim, the node loop
+    # with NodeEvalReduction, reduced openings, HyperKZG) on graphs with nanoGPT's and one GPT-2 layer's operator list and shapes
+    # (tools/build_graphs.py).  SYNTHETIC-TRACE PROXY of BASELINE's first metric: random-init weights, shapes padded to powers of two,
+    # SoftmaxLastAxis replaced by a ReLU stand-in (its composition is not in the graph prover yet).  The reference's own numbers
+    # (README, MacBook M3): nanoGPT prove 2.288 s; GPT-2 (12 layers) prove 14.889 s = commit 0.762 + iop 5.997 + reduction 1.899 +
+    # HyperKZG 2.392 (+ trace).
+    if rank == 0 and not args.no_graph:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        import build_graphs as BG
+        from jolt_atlas_amd import graph as GG
+        out["prove_graph"] = {"note": "synthetic-trace proxy of ONNXProof::prove: the model's operator list and (padded) shapes, random-init weights, "
+                                      "softmax replaced by a ReLU stand-in; reference (M3 CPU): nanoGPT 2.288 s, GPT-2 12 layers 14.889 s"}
+        for gname in ("nanogpt", "gpt2_layer"):
+            nodes_g, outs_g, ins_g = getattr(BG, gname)()
+            nv = BG.max_vars(nodes_g)
+            t0s = time.perf_counter()
+            srs_g = A.SRS.generate(np.array([0x1234567, 0, 0, 0], dtype=np.uint64), 1 << nv)
+            if not args.no_msm_table and nv >= 16:
+                srs_g.precompute()
+            sync(); setup_s = time.perf_counter() - t0s
+            Gg = GG.Graph(nodes_g, outs_g)
+            best_g, states_g = None, set()
+            for rep in range(3):
+                pf_g, st_g, tm_g = Gg.prove(srs_g, ins_g)
+                states_g.add(st_g)
+                if rep and (best_g is None or tm_g["total_ms"] < best_g["total_ms"]):
+                    best_g = tm_g
+            assert len(states_g) == 1, "non-deterministic graph proof"
+            from collections import Counter
+            out["prove_graph"][gname] = {"prove_graph_ms": best_g["total_ms"],
+                                         "stage_ms": {k: best_g[k] for k in ("trace_ms", "commit_ms", "iop_ms", "reduction_ms", "hyperkzg_ms")},
+                                         "nodes": best_g["n_nodes"], "committed_polys": best_g["n_committed"], "sumcheck_proofs": best_g["n_sumchecks"],
+                                         "proof_bytes": len(pf_g), "max_num_vars": nv, "setup_prover_s": setup_s,
+                                         "operators": dict(Counter(n["op"] for n in nodes_g))}
+            Gg.free(); srs_g.free()
     # third leg (N > 1): ONE 2^n instance and ONE 2^n-point MSM sharded over the N GPUs (strong scaling).  No collective on
     # the data path: the ranks' 64-byte partial sums cross a POSIX shared-memory board (csrc/shard_group.hpp), every rank
     # runs the same transcript step; the MSM is split by point range, one partial point per rank.

@@ -96,7 +96,15 @@ def _max_vars(nodes):
     return 4 + max(int(np.log2(np.prod(nd["dims"]))) for nd in nodes)
 
 
-@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4)])
+def toy_transformer(rng):
+    """two decoder layers (tools/build_graphs.py: embedding gather, LayerNorm, attention einsums, tanh-GELU MLP, lm head), seq 4, d_model 8"""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import build_graphs as BG
+    return BG.tiny(layers=2)
+
+
+@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5)])
 def test_graph_proof_matches_oracle(atlas, builder, seed):
     from oracle import graph as OG, orc
     from jolt_atlas_amd import graph as GG

@@ -37,19 +37,52 @@ class B:
         return self.add("Einsum", [x, w], [m, n], layout="mk,kn->mn", scale=S, shape=[m, k, n])
 
 
-def transformer(layers, seq, d_model, heads, vocab, S=7, level=0, seed=0, mlp_mult=4, final_head=True):
+def transformer(layers, seq, d_model, heads, vocab, S=14, level=2, seed=0, mlp_mult=4, final_head=True):
     b = B(seed)
     hd = d_model // heads
-    wlim = 1 << (S - 1)                      # weights ~ U(-2^(S-1), 2^(S-1)): |w| < 1.0 at scale S
-    x = b.add("Input", [], [seq, d_model])
+    wlim = 1 << (S - 2)                      # weights ~ U(-0.25, 0.25) at scale S
+    ff = mlp_mult * d_model
+    one = 1 << S
+    if level >= 2:                           # token + position embedding: GatherLarge(wte, tokens) + wpe
+        tok = b.add("Input", [], [seq])
+        wte = b.const([vocab, d_model], -one, one)
+        x = b.add("GatherLarge", [wte, tok], [seq, d_model], axis=0, dict_len=vocab)
+        x = b.add("Add", [x, b.const([seq, d_model], -wlim, wlim)], [seq, d_model])
+    else:
+        x = b.add("Input", [], [seq, d_model])
     mask = b.const_data([seq, seq], np.tril(np.ones((seq, seq), dtype=np.int32)))
     maskb = b.add("Broadcast", [mask], [heads, seq, seq])
     neg = b.const_data([heads, seq, seq], np.full(heads * seq * seq, -(1 << (S + 3)), dtype=np.int32))
 
+    def full(dims, v):
+        return b.const_data(dims, np.full(int(np.prod(dims)), v, dtype=np.int32))
+
     def norm(h):
+        """LayerNorm: (h - mean) * rsqrt(mean((h - mean)^2) + eps) * w + bias"""
         if level < 1:
             return h
-        raise NotImplementedError
+        s = b.add("Sum", [h], [seq, 1], axes=[1])
+        mean = b.add("ScalarConstDiv", [s], [seq, 1], divisor=d_model)
+        c = b.add("Sub", [h, b.add("Broadcast", [mean], [seq, d_model])], [seq, d_model])
+        var = b.add("MeanOfSquares", [c], [seq, 1], axes=[1], scale=S, count=d_model)
+        var = b.add("Add", [var, full([seq, 1], 1)], [seq, 1])
+        rs = b.add("Rsqrt", [var], [seq, 1], scale=S)
+        y = b.add("Mul", [c, b.add("Broadcast", [rs], [seq, d_model])], [seq, d_model], scale=S)
+        w = b.add("Broadcast", [b.const([d_model], one // 2, one + one // 2)], [seq, d_model])
+        y = b.add("Mul", [y, w], [seq, d_model], scale=S)
+        return b.add("Add", [y, b.add("Broadcast", [b.const([d_model], -wlim, wlim)], [seq, d_model])], [seq, d_model])
+
+    def gelu(f):
+        """tanh-GELU: 0.5 f (1 + tanh(0.79788 (f + 0.044715 f^3)))"""
+        if level < 2:
+            return b.add("ReLU", [f], [seq, ff])
+        f3 = b.add("Cube", [f], [seq, ff], scale=S)
+        u = b.add("Add", [f, b.add("Mul", [f3, full([seq, ff], int(0.044715 * one))], [seq, ff], scale=S)], [seq, ff])
+        v = b.add("Mul", [u, full([seq, ff], int(0.7978845608 * one))], [seq, ff], scale=S)
+        th = b.add("Tanh", [v], [seq, ff], scale=S)
+        w = b.add("Add", [th, full([seq, ff], one)], [seq, ff])
+        hx = b.add("Mul", [f, full([seq, ff], one // 2)], [seq, ff], scale=S)
+        return b.add("Mul", [hx, w], [seq, ff], scale=S)
 
     for _ in range(layers):
         h = norm(x)
@@ -62,42 +95,37 @@ def transformer(layers, seq, d_model, heads, vocab, S=7, level=0, seed=0, mlp_mu
         vh = b.add("Reshape", [v], [seq, heads, hd])
         att = b.add("Einsum", [qh, kh], [heads, seq, seq], layout="mbk,nbk->bmn", scale=S, shape=[heads, seq, hd, seq])
         att = b.add("Iff", [maskb, att, neg], [heads, seq, seq])
-        if level >= 2:
-            raise NotImplementedError
-        else:
-            att = b.add("ReLU", [att], [heads, seq, seq])
+        att = b.add("ReLU", [att], [heads, seq, seq])     # stand-in for SoftmaxLastAxis (its composition is not in the graph prover yet)
         y = b.add("Einsum", [att, vh], [seq, heads, hd], layout="bmk,kbn->mbn", scale=S, shape=[heads, seq, seq, hd])
         y = b.add("Reshape", [y], [seq, d_model])
         y = b.matmul(y, b.const([d_model, d_model], -wlim, wlim), seq, d_model, d_model, S)
         x = b.add("Add", [x, y], [seq, d_model])
         # MLP
         h = norm(x)
-        f = b.matmul(h, b.const([d_model, mlp_mult * d_model], -wlim, wlim), seq, d_model, mlp_mult * d_model, S)
-        f = b.add("Add", [f, b.const([seq, mlp_mult * d_model], -wlim, wlim)], [seq, mlp_mult * d_model])
-        if level >= 2:
-            raise NotImplementedError
-        else:
-            f = b.add("ReLU", [f], [seq, mlp_mult * d_model])
-        f = b.matmul(f, b.const([mlp_mult * d_model, d_model], -wlim, wlim), seq, mlp_mult * d_model, d_model, S)
+        f = b.matmul(h, b.const([d_model, ff], -wlim, wlim), seq, d_model, ff, S)
+        f = b.add("Add", [f, b.add("Broadcast", [b.const([ff], -wlim, wlim)], [seq, ff])], [seq, ff])
+        f = gelu(f)
+        f = b.matmul(f, b.const([ff, d_model], -wlim, wlim), seq, ff, d_model, S)
         x = b.add("Add", [x, f], [seq, d_model])
     x = norm(x)
     if final_head:
         x = b.matmul(x, b.const([d_model, vocab], -wlim, wlim), seq, d_model, vocab, S)
-    inputs = [np.random.default_rng(seed + 1).integers(-(1 << S), 1 << S, size=seq * d_model).astype(np.int32)]
+    rng = np.random.default_rng(seed + 1)
+    inputs = [rng.integers(0, vocab, size=seq).astype(np.int32)] if level >= 2 else [rng.integers(-one, one, size=seq * d_model).astype(np.int32)]
     return b.nodes, [x], inputs
 
 
-def nanogpt(level=0, seed=0):
-    return transformer(layers=4, seq=64, d_model=64, heads=4, vocab=128, S=7, level=level, seed=seed)
+def nanogpt(level=2, seed=0):
+    return transformer(layers=4, seq=64, d_model=64, heads=4, vocab=128, level=level, seed=seed)
 
 
-def gpt2_layer(level=0, seed=0):
+def gpt2_layer(level=2, seed=0):
     # d_model 768 and 12 heads padded to 1024 / 16 (every dimension a power of two); the lm head is a 2^14-column slice
-    return transformer(layers=1, seq=16, d_model=1024, heads=16, vocab=1 << 14, S=7, level=level, seed=seed)
+    return transformer(layers=1, seq=16, d_model=1024, heads=16, vocab=1 << 14, level=level, seed=seed)
 
 
-def tiny(level=0, seed=0, layers=2):
-    return transformer(layers=layers, seq=4, d_model=8, heads=2, vocab=16, S=5, level=level, seed=seed, mlp_mult=2)
+def tiny(level=2, seed=0, layers=2):
+    return transformer(layers=layers, seq=4, d_model=8, heads=2, vocab=16, level=level, seed=seed, mlp_mult=2)
 
 
 def max_vars(nodes):

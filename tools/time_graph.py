@@ -21,7 +21,7 @@ def run(name, level, reps):
     tau = np.array([0x1234567, 0, 0, 0], dtype=np.uint64)
     t0 = time.time()
     srs = A.SRS.generate(tau, 1 << nv)
-    if os.environ.get("ATLAS_GRAPH_TAB", "1") != "0":
+    if os.environ.get("ATLAS_GRAPH_TAB", "1") != "0" and nv >= 16:
         srs.precompute()
     setup_s = time.time() - t0
     G = GG.Graph(nodes, outputs)
