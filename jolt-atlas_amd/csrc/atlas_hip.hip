@@ -29,6 +29,7 @@ namespace H = atlas_host;
 // ------------------------------------------------------------------ runtime state
 namespace atlas_rt {
 Runtime g;
+thread_local hipStream_t tl_lane_stream = nullptr;
 thread_local std::string t_err;       // atlas_last_error is per calling thread (commit is called from Rayon workers)
 int fail(int code, const char* what, hipError_t e) {
     t_err = what;
@@ -118,6 +119,7 @@ int atlas_init(int device_ordinal) {
     if (device_ordinal < 0 || device_ordinal >= n) return fail(ATLAS_EINVAL, "device ordinal out of range");
     HIP_TRY(hipSetDevice(device_ordinal));
     if (!g.stream) HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    g.lib_stream = g.stream;
     HIP_TRY(hipMalloc(&g.d_partials, sizeof(Fr) * SC_MAX_BLOCKS * 3));
     HIP_TRY(hipMalloc(&g.d_ctx, sizeof(ScCtx)));
     HIP_TRY(hipMalloc(&g.d_proof, sizeof(Fr) * MAX_ROUNDS * 3));
@@ -152,7 +154,7 @@ int atlas_shutdown(void) {
     g.chan.release();
     atlas_rt::dev_pool().release();
     hipStreamDestroy(g.stream);
-    g.ready = false; g.stream = nullptr; g.d_partials = nullptr; g.d_ctx = nullptr; g.d_proof = nullptr;
+    g.ready = false; g.stream = nullptr; g.lib_stream = nullptr; g.d_partials = nullptr; g.d_ctx = nullptr; g.d_proof = nullptr;
     g.d_chal = nullptr; g.d_finals = nullptr; g.h_pinned = nullptr;
     return ATLAS_OK;
 }
@@ -252,6 +254,7 @@ static int poly_alloc(size_t bytes, bool is_i32, size_t len, atlas_poly_t* out) 
 int atlas_poly_upload_fr(const atlas_fr_t* host, size_t len, atlas_poly_t* out) {
     NEED_INIT();
     if (!host || !out || !is_pow2(len)) return fail(ATLAS_EINVAL, "poly_upload_fr: len must be a power of two");
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);                    // g.stream is read: not while another thread's pipeline has it on a lane
     int rc = poly_alloc(len * sizeof(Fr), false, len, out);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync((*out)->d, host, len * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
@@ -262,6 +265,7 @@ int atlas_poly_upload_fr(const atlas_fr_t* host, size_t len, atlas_poly_t* out) 
 int atlas_poly_upload_i32(const int32_t* host, size_t len, atlas_poly_t* out) {
     NEED_INIT();
     if (!host || !out || !is_pow2(len)) return fail(ATLAS_EINVAL, "poly_upload_i32: len must be a power of two");
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     int rc = poly_alloc(len * sizeof(int32_t), true, len, out);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync((*out)->d, host, len * sizeof(int32_t), hipMemcpyHostToDevice, g.stream));

@@ -127,6 +127,9 @@ struct Pipeline {
     static constexpr size_t N_SIDE = 4;
     bool side = false;
     static hipStream_t* side_streams() { static hipStream_t st[N_SIDE] = {nullptr, nullptr, nullptr, nullptr}; return st; }
+    // ATLAS_LANE_EVENTS=1 (diagnosis only, tools/stress_lanes.py): order the lanes behind the library stream with events instead of host waits
+    static hipEvent_t* side_events() { static hipEvent_t ev[N_SIDE + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr}; return ev; }
+    static bool lane_events() { static const bool v = getenv("ATLAS_LANE_EVENTS") != nullptr; return v; }
     hipStream_t lane_stream(size_t li) const { return side ? side_streams()[li % N_SIDE] : g.stream; }
     int begin() {               // the caller holds g.mu
         for (auto& L : lanes) { max_rounds = L.rounds > max_rounds ? L.rounds : max_rounds; }
@@ -145,7 +148,13 @@ struct Pipeline {
             // event recorded on the library stream and waited for by the lane streams did NOT order them reliably —
             // in processes where a lane stream shares a hardware queue with the library stream (bench.py, after its
             // other legs) the first bind of a lane read rows the constructor had not finished, one proof in three.
-            HIP_TRY(hipStreamSynchronize(g.stream));
+            if (lane_events()) {
+                hipEvent_t* ev = side_events();
+                if (!ev[0]) for (size_t i = 0; i <= N_SIDE; i++) HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+                HIP_TRY(hipEventRecord(ev[N_SIDE], g.stream));
+                for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) HIP_TRY(hipStreamWaitEvent(st[i], ev[N_SIDE], 0));
+            } else
+                HIP_TRY(hipStreamSynchronize(g.stream));
         }
         return advance(0);
     }
@@ -153,6 +162,12 @@ struct Pipeline {
     void join() {
         if (!side) return;
         hipStream_t* st = side_streams();
+        if (lane_events()) {
+            hipEvent_t* ev = side_events();
+            for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) { (void)hipEventRecord(ev[i], st[i]); (void)hipStreamWaitEvent(g.stream, ev[i], 0); }
+            side = false;
+            return;
+        }
         for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) (void)hipStreamSynchronize(st[i]);   // (host waits, for the reason given in begin; the finals have been mailed, the lanes are about idle)
         side = false;
     }
@@ -171,8 +186,11 @@ struct Pipeline {
                 const atlas::RoundIo io = C.io(area, mtag(Q, li), wait ? slot0 + Q - 1 : (size_t)-1, wait ? rtag(Q - 1) : 0, 256);
                 const hipStream_t lib_stream = g.stream;          // the instance's launches go to its lane's stream
                 g.stream = lane_stream(li);
+                atlas_rt::tl_lane_stream = side ? g.stream : nullptr;
+                if (side && wait) atlas::k_ch_gate<<<1, 64, 0, g.stream>>>(io);      // the lane's wide launches start behind their challenge (channel.hip.h)
                 int rc = Q < max_rounds ? L.inst->enqueue(local, io, bind_prev, L.mails[local]) : L.inst->enqueue_finals(io, L.fin);
                 g.stream = lib_stream;
+                atlas_rt::tl_lane_stream = nullptr;
                 if (rc) { abort_from(0); drain(); return rc; }
             }
         }

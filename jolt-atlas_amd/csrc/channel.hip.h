@@ -118,6 +118,18 @@ __device__ __forceinline__ bool ch_wait_r(const RoundIo& io, uint64_t& lo, uint6
     return ok;
 }
 
+// The gate of a lane (batched.hip Pipeline::advance): ONE wavefront that waits for a round's challenge slot and exits.  It is
+// enqueued on a lane stream in front of the wide launches of the next round when several lanes run on streams of their own, so
+// that a wide launch only STARTS once its challenge exists: without it the workgroups of a fast lane's next round (thousands,
+// all spinning in ch_wait_r) can occupy every workgroup slot of the chip while the slow lane's current round — which the
+// challenge depends on — still has launches queued, and the proof stalls until the 2 s timeout (forward progress across streams
+// is not guaranteed for spinning kernels).  With the gate at most one wavefront per lane spins.
+static __global__ void k_ch_gate(RoundIo io) {
+    if (threadIdx.x != 0) return;
+    uint64_t lo, hi;
+    (void)ch_poll_slot<true>(io.r_host, io.tag_r, io.abort_flag, lo, hi);
+}
+
 // Mail `n_vals` values of one workgroup (9 words each) with ONE store instruction: lane k < n_vals of the calling
 // wavefront holds value k in w[]; the words are staged through LDS so that lane c < 3 n_vals stores chunk c.  One
 // instruction = contiguous bytes = a few PCIe writes; six single-lane stores per workgroup arrive 30 us late when

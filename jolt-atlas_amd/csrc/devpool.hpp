@@ -64,9 +64,10 @@ struct DevPool {
                 // Reuse is in stream order only on the stream the block was freed under: the launches of a pipelined
                 // batch go to lane streams (batched.hip), so a block another stream gave back is passed over.
                 auto& fl = free_lists[c];
-                const hipStream_t cur = g.stream;
+                const hipStream_t cur = pool_tag_stream();
                 for (size_t k = fl.size(); k-- > 0;) {
-                    if (fl[k].freed_on != cur) continue;
+                    static const bool any_stream = getenv("ATLAS_POOL_ANYSTREAM") != nullptr;     // diagnosis only: the pre-4a34137 reuse rule
+                    if (fl[k].freed_on != cur && !any_stream) continue;
                     void* p = fl[k].p;
                     fl.erase(fl.begin() + (ptrdiff_t)k);
                     cached -= class_bytes(c);
@@ -111,7 +112,7 @@ struct DevPool {
                 live.erase(it);
                 if (cached + class_bytes(c) <= POOL_MAX_CACHED) {
                     if (free_lists.size() <= c) free_lists.resize(c + 1);
-                    free_lists[c].push_back(FreeBlock{p, g.stream});
+                    free_lists[c].push_back(FreeBlock{p, pool_tag_stream()});
                     cached += class_bytes(c);
                     return hipSuccess;
                 }

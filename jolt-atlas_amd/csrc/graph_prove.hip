@@ -968,7 +968,14 @@ extern "C" int atlas_prove_graph(atlas_graph_t G, atlas_srs_t srs, const int32_t
     if (!rc) rc = P.commit_all();
     const auto t2 = now();
     if (!rc) rc = P.output_claim();
-    for (auto it = G->nodes.rbegin(); it != G->nodes.rend() && !rc; ++it) rc = P.prove_node(it->second);
+    const bool gtrace = getenv("ATLAS_GRAPH_TRACE") != nullptr;             // per-operator wall clock of the node loop on stderr
+    std::map<int, std::pair<double, size_t>> per_op;
+    for (auto it = G->nodes.rbegin(); it != G->nodes.rend() && !rc; ++it) {
+        const auto tn0 = gtrace ? now() : t2;
+        rc = P.prove_node(it->second);
+        if (gtrace) { auto& e = per_op[it->second.op]; e.first += ms_between(tn0, now()); e.second++; }
+    }
+    if (gtrace) for (auto& kv : per_op) fprintf(stderr, "[atlas graph] op %2d  x%-4zu %9.3f ms  (%.3f ms each)\n", kv.first, kv.second.second, kv.second.first, kv.second.first / kv.second.second);
     const auto t3 = now();
     if (!rc) rc = P.reduced_openings(nullptr);
     const auto t4 = now();

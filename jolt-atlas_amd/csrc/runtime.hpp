@@ -32,7 +32,9 @@ using Mutex = std::recursive_mutex;
 struct Runtime {
     bool ready = false;
     int device = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // where the entry points launch; Pipeline::advance (batched.hip) points it at a lane stream
+                                       // for the duration of one enqueue() call, under g.mu
+    hipStream_t lib_stream = nullptr;  // the library stream itself: never swapped (the device pool's tag for threads outside a lane)
     int challenge_mode = 0;
     int fs_mode = ATLAS_FS_HOST;       // where the Fiat-Shamir transcript of the whole-instance provers runs
     Channel chan;                      // round channel (pinned mailboxes + challenge slots), ATLAS_FS_HOST
@@ -48,6 +50,11 @@ struct Runtime {
     Mutex mu;
 };
 extern Runtime g;
+// the lane stream the calling thread is enqueueing on (set by Pipeline::advance around enqueue()), nullptr otherwise.  The device
+// pool tags a returned block with THIS thread's stream, so a thread that frees a buffer while another thread's pipeline has
+// g.stream pointed at a lane cannot mislabel it.
+extern thread_local hipStream_t tl_lane_stream;
+inline hipStream_t pool_tag_stream() { return tl_lane_stream ? tl_lane_stream : g.lib_stream; }
 
 constexpr size_t MAX_ROUNDS = 64;
 constexpr size_t PINNED_BYTES = 1 << 16;

@@ -128,6 +128,17 @@ def tiny(level=2, seed=0, layers=2):
     return transformer(layers=layers, seq=4, d_model=8, heads=2, vocab=16, level=level, seed=seed, mlp_mult=2)
 
 
+NO_COMMIT = {"Input", "Constant", "Identity", "Reshape", "MoveAxis", "Broadcast", "Slice", "Iff", "And", "Concat"}
+
+
 def max_vars(nodes):
-    """log2 of the largest committed polynomial: a one-hot chunk has 16 x T coefficients"""
-    return 4 + max(int(np.log2(np.prod(nd["dims"]))) for nd in nodes)
+    """log2 of the largest committed polynomial (AtlasSharedPreprocessing::max_num_vars): a one-hot chunk has 16 x T coefficients, T = the
+    node's (padded) element count (GatherLarge: its index count); dense advice polynomials have T coefficients"""
+    byidx = {nd["idx"]: nd for nd in nodes}
+    best = 4
+    for nd in nodes:
+        if nd["op"] in NO_COMMIT:
+            continue
+        T = int(np.prod(byidx[nd["inputs"][1]]["dims"])) if nd["op"] == "GatherLarge" else int(np.prod(nd["dims"]))
+        best = max(best, 4 + int(np.log2(max(T, 1))))
+    return best
