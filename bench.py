@@ -456,7 +456,7 @@ def main():
     # whole-proof leg: ONNXProof::prove (atlas_prove_graph: trace on the device, witness commitments, output claim, the node loop
     # with NodeEvalReduction, reduced openings, HyperKZG) on graphs with nanoGPT's and one GPT-2 layer's operator list and shapes
     # (tools/build_graphs.py).  SYNTHETIC-TRACE PROXY of BASELINE's first metric: random-init weights, shapes padded to powers of two,
-    # SoftmaxLastAxis replaced by a ReLU stand-in (its composition is not in the graph prover yet).  The reference's own numbers
+    # the full operator decomposition incl. SoftmaxLastAxis (four batched stages), tanh-GELU, LayerNorm, embedding gather.  The reference's own numbers
     # (README, MacBook M3): nanoGPT prove 2.288 s; GPT-2 (12 layers) prove 14.889 s = commit 0.762 + iop 5.997 + reduction 1.899 +
     # HyperKZG 2.392 (+ trace).
     if rank == 0 and not args.no_graph:
@@ -464,7 +464,7 @@ def main():
         import build_graphs as BG
         from jolt_atlas_amd import graph as GG
         out["prove_graph"] = {"note": "synthetic-trace proxy of ONNXProof::prove: the model's operator list and (padded) shapes, random-init weights, "
-                                      "softmax replaced by a ReLU stand-in; reference (M3 CPU): nanoGPT 2.288 s, GPT-2 12 layers 14.889 s"}
+                                      "full operator decomposition (SoftmaxLastAxis, tanh-GELU, LayerNorm, GatherLarge); reference (M3 CPU): nanoGPT 2.288 s, GPT-2 12 layers 14.889 s"}
         for gname in ("nanogpt", "gpt2_layer"):
             nodes_g, outs_g, ins_g = getattr(BG, gname)()
             nv = BG.max_vars(nodes_g)

@@ -130,7 +130,8 @@ struct Pipeline {
     // ATLAS_LANE_EVENTS=1 (diagnosis only, tools/stress_lanes.py): order the lanes behind the library stream with events instead of host waits
     static hipEvent_t* side_events() { static hipEvent_t ev[N_SIDE + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr}; return ev; }
     static bool lane_events() { static const bool v = getenv("ATLAS_LANE_EVENTS") != nullptr; return v; }
-    hipStream_t lane_stream(size_t li) const { return side ? side_streams()[li % N_SIDE] : g.stream; }
+    static bool one_side_stream() { static const bool v = getenv("ATLAS_LANE_ONE_STREAM") != nullptr; return v; }   // diagnosis: every lane on side stream 0
+    hipStream_t lane_stream(size_t li) const { return side ? side_streams()[one_side_stream() ? 0 : li % N_SIDE] : g.stream; }
     int begin() {               // the caller holds g.mu
         for (auto& L : lanes) { max_rounds = L.rounds > max_rounds ? L.rounds : max_rounds; }
         for (auto& L : lanes) { L.offset = max_rounds - L.rounds; L.mails.resize(L.rounds); }
@@ -187,7 +188,8 @@ struct Pipeline {
                 const hipStream_t lib_stream = g.stream;          // the instance's launches go to its lane's stream
                 g.stream = lane_stream(li);
                 atlas_rt::tl_lane_stream = side ? g.stream : nullptr;
-                if (side && wait) atlas::k_ch_gate<<<1, 64, 0, g.stream>>>(io);      // the lane's wide launches start behind their challenge (channel.hip.h)
+                static const bool no_gate = getenv("ATLAS_LANE_NO_GATE") != nullptr;                     // diagnosis only (tools/bisect_lanes.sh)
+                if (side && wait && !no_gate) atlas::k_ch_gate<<<1, 64, 0, g.stream>>>(io);      // the lane's wide launches start behind their challenge (channel.hip.h)
                 int rc = Q < max_rounds ? L.inst->enqueue(local, io, bind_prev, L.mails[local]) : L.inst->enqueue_finals(io, L.fin);
                 g.stream = lib_stream;
                 atlas_rt::tl_lane_stream = nullptr;

@@ -101,14 +101,14 @@ __device__ __forceinline__ bool ch_wait_r(const RoundIo& io, uint64_t& lo, uint6
     const uint32_t wg = blockIdx.x + blockIdx.y * gridDim.x;
     if (threadIdx.x == 0) {
         uint64_t l = 0, h = 0;
-        const bool ok = wg == 0 ? ch_poll_slot<true>(io.r_host, io.tag_r, io.abort_flag, l, h)
+        const bool ok = wg == 0 || io.r_replicas == 0 ? ch_poll_slot<true>(io.r_host, io.tag_r, io.abort_flag, l, h)
                                 : ch_poll_slot<false>(io.r_dev + (size_t)(wg % io.r_replicas) * CH_REPLICA_CHUNKS, io.tag_r, io.abort_flag, l, h);
         s_ch[0] = l; s_ch[1] = h; s_ch[2] = ok ? 1 : 0;
     }
     __syncthreads();
     lo = s_ch[0]; hi = s_ch[1];
     const bool ok = s_ch[2] != 0;
-    if (wg == 0 && ok && gridDim.x * gridDim.y > 1) {       // fan out (an abort travels through abort_flag)
+    if (wg == 0 && ok && io.r_replicas && gridDim.x * gridDim.y > 1) {       // fan out (an abort travels through abort_flag)
         for (uint32_t t = threadIdx.x; t < io.r_replicas; t += blockDim.x) {
             Chunk* p = io.r_dev + (size_t)t * CH_REPLICA_CHUNKS;
             ch_store_dev(p, ch_u32x4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, io.tag_r});

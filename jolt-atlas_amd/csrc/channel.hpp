@@ -71,7 +71,8 @@ struct Channel {
         o.mail = mail_region;
         o.r_host = slot_r == (size_t)-1 ? nullptr : rslots + SLOT_CHUNKS * slot_r;
         o.r_dev = slot_r == (size_t)-1 ? nullptr : d_rslots + DEV_SLOT_CHUNKS * slot_r;
-        o.r_replicas = replicas_for(waiters);
+        static const bool host_poll = getenv("ATLAS_CH_HOST_POLL") != nullptr;     // diagnosis: every workgroup polls the host slot, no HBM replicas
+        o.r_replicas = host_poll ? 0 : replicas_for(waiters);
         o.abort_flag = d_abort;
         o.tag_mail = tag_mail; o.tag_r = tag_r;
         return o;

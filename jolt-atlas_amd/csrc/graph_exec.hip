@@ -126,6 +126,53 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
     }
 }
 
+// SoftmaxLastAxis (atlas-onnx-tracer/src/ops/softmax.rs:74-214), one workgroup per row of the last axis: max and first argmax,
+// z = max - x saturated to the sub-table range, the two digit lookups, exp_q = floor(hi lo / S) with its remainder, the row sum,
+// inv_sum = floor(S^2 / sum), softmax_q = floor(exp_q inv_sum / S) with its remainder; plus the lookup-index vectors of the prover
+struct SoftmaxOut {
+    int32_t *out, *R, *exp_q, *exp_hi, *exp_lo, *r_exp, *z, *z_hi, *z_lo, *e, *max_k, *argmax_k, *exp_sum, *inv_sum;
+    uint64_t *idx_R, *idx_rexp, *idx_z, *idx_zhi, *idx_zlo;
+};
+__global__ __launch_bounds__(256) void k_softmax_rows(const int32_t* __restrict__ x, uint32_t N, int32_t S, uint32_t log2_base, int32_t z_bound,
+                                                      const int32_t* __restrict__ lut_hi, const int32_t* __restrict__ lut_lo, SoftmaxOut O) {
+    __shared__ int32_t s_v[256];
+    __shared__ uint32_t s_p[256];
+    const size_t k = blockIdx.x, off = k * (size_t)N;
+    const uint32_t tid = threadIdx.x;
+    int32_t mv = -2147483647 - 1; uint32_t mp = 0xffffffffu;
+    for (uint32_t j = tid; j < N; j += 256) { const int32_t v = x[off + j]; if (v > mv || (v == mv && j < mp)) { mv = v; mp = j; } }
+    s_v[tid] = mv; s_p[tid] = mp;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (tid < s) { const int32_t v = s_v[tid + s]; const uint32_t q = s_p[tid + s]; if (v > s_v[tid] || (v == s_v[tid] && q < s_p[tid])) { s_v[tid] = v; s_p[tid] = q; } }
+        __syncthreads();
+    }
+    mv = s_v[0]; mp = s_p[0];
+    __syncthreads();
+    const int32_t base_mask = (1 << log2_base) - 1;
+    int32_t part = 0;
+    for (uint32_t j = tid; j < N; j += 256) {
+        const size_t i = off + j;
+        const int32_t z = mv - x[i], zc = z < z_bound - 1 ? z : z_bound - 1;
+        const int32_t zh = zc >> log2_base, zl = zc & base_mask, hi = lut_hi[zh], lo = lut_lo[zl];
+        const int64_t prod = (int64_t)hi * lo;
+        const int32_t eq = (int32_t)(prod / S), re = (int32_t)(prod - (int64_t)eq * S);
+        O.z[i] = z; O.z_hi[i] = zh; O.z_lo[i] = zl; O.exp_hi[i] = hi; O.exp_lo[i] = lo; O.exp_q[i] = eq; O.r_exp[i] = re; O.e[i] = j == mp ? 1 : 0;
+        O.idx_z[i] = (uint64_t)(uint32_t)z; O.idx_zhi[i] = (uint64_t)zh; O.idx_zlo[i] = (uint64_t)zl; O.idx_rexp[i] = (uint64_t)re;
+        part += eq;
+    }
+    s_v[tid] = part;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) { if (tid < s) s_v[tid] += s_v[tid + s]; __syncthreads(); }
+    const int32_t sum = s_v[0], inv = sum ? (S * S) / sum : 0;
+    if (tid == 0) { O.max_k[k] = mv; O.argmax_k[k] = (int32_t)mp; O.exp_sum[k] = sum; O.inv_sum[k] = inv; }
+    for (uint32_t j = tid; j < N; j += 256) {
+        const size_t i = off + j;
+        const int32_t p = O.exp_q[i] * inv, sq = p / S, rem = p - sq * S;
+        O.out[i] = sq; O.R[i] = rem; O.idx_R[i] = (uint64_t)rem;
+    }
+}
+
 unsigned grid_for(size_t n) { size_t b = (n + 255) / 256; return (unsigned)(b > 4096 ? 4096 : b ? b : 1); }
 
 std::vector<size_t> row_major(const std::vector<size_t>& dims) {
@@ -191,6 +238,33 @@ int atlas_rt_tanh_table(const int32_t** d_table, const std::vector<int32_t>** h_
     }
     if (d_table) *d_table = dev;
     if (h_table) *h_table = &host;
+    return ATLAS_OK;
+}
+
+int atlas_rt_exp_lut(const ExpLut** out) {
+    static ExpLut L;
+    static int32_t* dev = nullptr;
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    if (L.hi.empty()) {
+        const double sf = (double)((uint64_t)1 << gr::MODEL_SCALE);
+        const size_t needed = (size_t)std::ceil(sf * std::log(2.0 * sf)) + 2;                  // the flat LUT's cutoff exp(-i/S) S < 0.5
+        const unsigned log2_b = (unsigned)std::ceil(std::log2((double)needed) / 2.0);
+        const size_t base = (size_t)1 << log2_b, hi_size = needed / base + 2;
+        auto entry = [&](double v) { const double r = std::round(v); return (int32_t)(r > 0.0 ? r : 0.0); };
+        for (size_t h = 0; h < hi_size; h++) L.hi.push_back(entry(sf * std::exp(-((double)h * (double)base) / sf)));
+        for (size_t l = 0; l < base; l++) L.lo.push_back(entry(sf * std::exp(-(double)l / sf)));
+        L.hi.resize(gr::next_pow2(L.hi.size()), 0);
+        L.log2_base = log2_b;
+    }
+    if (!dev) {
+        HIP_TRY(hipMalloc(&dev, (L.hi.size() + L.lo.size()) * 4));
+        HIP_TRY(hipMemcpyAsync(dev, L.hi.data(), L.hi.size() * 4, hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(hipMemcpyAsync(dev + L.hi.size(), L.lo.data(), L.lo.size() * 4, hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        L.d_hi = dev; L.d_lo = dev + L.hi.size();
+        g.at_shutdown.push_back([] { if (dev) { (void)hipFree(dev); dev = nullptr; L.d_hi = L.d_lo = nullptr; } });
+    }
+    *out = &L;
     return ATLAS_OK;
 }
 
@@ -359,6 +433,28 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
             NodeWitness& W = G.wit[nd.idx];
             HIP_TRY(W.lookups.alloc(N * 8));
             k_gather_rows<<<grid_for(T), 256, 0, g.stream>>>(in(0), in(1), N, word, out.as<int32_t>(), W.lookups.as<uint64_t>());
+            return ATLAS_OK;
+        }
+        case ATLAS_OP_SOFTMAX: {                                              // SoftmaxLastAxis { scale }: rows = the leading dimensions, N = the last one
+            if (!need_inputs(1) || !same_len() || nd.p[0] != (int64_t)gr::MODEL_SCALE)
+                return fail(ATLAS_EINVAL, "graph: SoftmaxLastAxis needs one operand of the output's shape and scale = MODEL_SCALE (14): its clamp table is compiled for it");
+            const size_t N = nd.dims.back(), F = T / N;
+            if (F < 2 || N < 2 || N > 65536) return fail(ATLAS_EINVAL, "graph: SoftmaxLastAxis needs at least two rows and 2 <= last axis <= 65536");
+            const ExpLut* L = nullptr;
+            if (int rc = atlas_rt_exp_lut(&L)) return rc;
+            NodeWitness& W = G.wit[nd.idx];
+            W.softmax.reset(new SoftmaxWitness());
+            SoftmaxWitness& Sm = *W.softmax;
+            Sm.F = F; Sm.N = N; Sm.log2_base = L->log2_base; Sm.lk_hi = gr::log2u(L->hi.size()); Sm.lk_lo = gr::log2u(L->lo.size());
+            for (DevBuf* b : {&Sm.R, &Sm.exp_q, &Sm.exp_hi, &Sm.exp_lo, &Sm.r_exp, &Sm.z, &Sm.z_hi, &Sm.z_lo, &Sm.e}) HIP_TRY(b->alloc(T * 4));
+            for (DevBuf* b : {&Sm.max_k, &Sm.argmax_k, &Sm.exp_sum, &Sm.inv_sum}) HIP_TRY(b->alloc(F * 4));
+            for (DevBuf* b : {&Sm.idx_R, &Sm.idx_rexp, &Sm.idx_z, &Sm.idx_zhi, &Sm.idx_zlo}) HIP_TRY(b->alloc(T * 8));
+            SoftmaxOut O{out.as<int32_t>(), Sm.R.as<int32_t>(), Sm.exp_q.as<int32_t>(), Sm.exp_hi.as<int32_t>(), Sm.exp_lo.as<int32_t>(), Sm.r_exp.as<int32_t>(),
+                         Sm.z.as<int32_t>(), Sm.z_hi.as<int32_t>(), Sm.z_lo.as<int32_t>(), Sm.e.as<int32_t>(), Sm.max_k.as<int32_t>(), Sm.argmax_k.as<int32_t>(),
+                         Sm.exp_sum.as<int32_t>(), Sm.inv_sum.as<int32_t>(), Sm.idx_R.as<uint64_t>(), Sm.idx_rexp.as<uint64_t>(), Sm.idx_z.as<uint64_t>(),
+                         Sm.idx_zhi.as<uint64_t>(), Sm.idx_zlo.as<uint64_t>()};
+            k_softmax_rows<<<(unsigned)F, 256, 0, g.stream>>>(in(0), (uint32_t)N, (int32_t)1 << gr::MODEL_SCALE, (uint32_t)L->log2_base,
+                                                             (int32_t)(L->hi.size() << L->log2_base), L->d_hi, L->d_lo, O);
             return ATLAS_OK;
         }
         default: return fail(ATLAS_EINVAL, "graph_trace: operator not supported by the device executor");

@@ -171,6 +171,15 @@ struct Prover : FlowSink {
                     chunks(gr::CP_ActivationClampRaD, W.lookups.as<uint64_t>(), 32);
                     chunks(gr::CP_ActivationSmallRaD, W.lookups2.as<uint64_t>(), gr::ACTIVATION_TABLE_VARS);
                     break;
+                case ATLAS_OP_SOFTMAX: {                                                                                 // ops/softmax_last_axis/mod.rs:136-159
+                    SoftmaxWitness& Sm = *W.softmax;
+                    chunks(gr::CP_SoftmaxRemainderRaD, Sm.idx_R.as<uint64_t>(), gr::MODEL_SCALE);
+                    chunks(gr::CP_SoftmaxExpRemainderRaD, Sm.idx_rexp.as<uint64_t>(), gr::MODEL_SCALE);
+                    chunks(gr::CP_SoftmaxClampRaD, Sm.idx_z.as<uint64_t>(), 32);
+                    chunks(gr::CP_SoftmaxZHiRaD, Sm.idx_zhi.as<uint64_t>(), Sm.lk_hi);
+                    chunks(gr::CP_SoftmaxZLoRaD, Sm.idx_zlo.as<uint64_t>(), Sm.lk_lo);
+                    break;
+                }
                 case ATLAS_OP_GATHER_LARGE: {                                                                            // ops/gather/large.rs:105-111
                     const size_t N = gr::padded_len(G.nodes.at(nd.inputs[1]).dims), V = G.nodes.at(nd.inputs[0]).dims[0], lk = gr::log2u(V), d = (lk + 3) / 4;
                     for (size_t i = 0; i < d; i++) {
@@ -820,6 +829,226 @@ struct Prover : FlowSink {
         return prove_onehot_checks(W.lookups.as<uint64_t>(), ln, lv, (const atlas_fr_t*)r_index.data(), rap, fin[0], &t, O, gr::CP_GatherRaD, gr::PT_RaOneHotChecks);
     }
 
+    // ---- SoftmaxLastAxis (ops/softmax_last_axis/mod.rs:177-262): the auxiliary vectors, then four BatchedSumcheck stages
+    // one BatchedSumcheck::prove over the members already added to `b`: proof rows under `proof_type`, the challenges as field elements
+    int run_batch(atlas_batched_t b, size_t stride, size_t rounds_cap, uint8_t proof_type, std::vector<H::Fr>& rs) {
+        std::vector<atlas_fr_t> rows(rounds_cap * stride); std::vector<uint32_t> nco(rounds_cap); std::vector<atlas_u128_t> ch(rounds_cap);
+        size_t mr = 0;
+        int rc = atlas_batched_prove(b, &t, rows.data(), stride, nco.data(), ch.data(), &mr);
+        if (rc) return rc;
+        rs.resize(mr);
+        for (size_t i = 0; i < mr; i++) rs[i] = ch_fr(ch[i]);
+        Out O = out();
+        return O.put_proof(rows, stride, nco, mr, proof_type);
+    }
+    // cache_openings of a PS-Shout / IdentityRC member of n = log_K + log_T rounds: its ra polynomial at (address challenges as drawn,
+    // cycle challenges reversed) (identity_range_check.rs, ps_shout/mod.rs:150-158)
+    int ra_opening(const Node& nd, atlas_instance_t inst, uint8_t vp, size_t log_K, size_t log_T, const std::vector<H::Fr>& rs, std::vector<atlas_fr_t>& ra_point, H::Fr& ra_claim) {
+        const size_t n = log_K + log_T, o = rs.size() - n;
+        atlas_fr_t f[64]; size_t nf = 0;
+        int rc = atlas_instance_final_claims(inst, f, 64, &nf);
+        if (rc) return rc;
+        std::memcpy(&ra_claim, &f[0], 32);
+        Point pt(n);
+        for (size_t q = 0; q < n; q++) pt[q] = q < log_K ? rs[o + q] : rs[o + log_K + (n - 1 - q)];
+        ra_point.resize(n); std::memcpy(ra_point.data(), pt.data(), n * 32);
+        return append_advice(nd, vp, pt, ra_claim);
+    }
+    int op_softmax(const Node& nd) {
+        const size_t T = gr::padded_len(nd.dims), log_T = gr::log2u(T), LS = gr::MODEL_SCALE;
+        const gr::Opening& R = red(nd);
+        NodeWitness& W = G.wit[nd.idx];
+        SoftmaxWitness& Sm = *W.softmax;
+        const size_t F = Sm.F, lf = gr::log2u(F), ln = gr::log2u(Sm.N);
+        const H::Fr S_fr = H::from_u64((uint64_t)1 << LS);
+        const size_t phases = LS % 4 == 0 ? LS / 4 : LS / 2;                 // IdentityRCProvider::phases (identity_range_check.rs:506-518)
+        const ExpLut* L = nullptr;
+        int rc = atlas_rt_exp_lut(&L);
+        if (rc) return rc;
+        // send_auxiliary_vectors (:392-413): exp_sum_q[k], max_k[k], argmax_k[k] as F::from_u32(v as u32), at the empty point
+        std::vector<int32_t> aux(3 * F);
+        {
+            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+            HIP_TRY(hipMemcpyAsync(aux.data(), Sm.exp_sum.p, F * 4, hipMemcpyDeviceToHost, g.stream));
+            HIP_TRY(hipMemcpyAsync(aux.data() + F, Sm.max_k.p, F * 4, hipMemcpyDeviceToHost, g.stream));
+            HIP_TRY(hipMemcpyAsync(aux.data() + 2 * F, Sm.argmax_k.p, F * 4, hipMemcpyDeviceToHost, g.stream));
+            HIP_TRY(hipStreamSynchronize(g.stream));
+        }
+        {
+            Out O = out();
+            const Point empty;
+            for (size_t k = 0; k < F && !rc; k++) {
+                const uint8_t vps[3] = {gr::VP_SoftmaxSumOutput, gr::VP_SoftmaxMaxOutput, gr::VP_SoftmaxMaxIndex};
+                for (int q = 0; q < 3 && !rc; q++)
+                    rc = O.append_virtual(Tr, gr::node_exec(gr::virt(vps[q], nd.idx, k), nd.idx), empty, H::from_u64((uint64_t)(uint32_t)aux[q * F + k]));
+            }
+            if (rc) return rc;
+        }
+        auto wrap = [&](const DevBuf& b, size_t len, atlas_poly_t* p) { return atlas_poly_wrap_device_i32(b.as<int32_t>(), len, p); };
+        auto eval1 = [&](const DevBuf& b, size_t len, const Point& pt, H::Fr* o) { const int32_t* tp = b.as<int32_t>(); return eval_i32(&tp, 1, len, pt, o); };
+        const Point& r0 = R.point;
+        const Point r_lead(r0.begin(), r0.begin() + lf);
+        H::Fr exp_sum_claim, R_claim;
+        rc = eval1(Sm.exp_sum, F, r_lead, &exp_sum_claim);
+        if (!rc) rc = append_advice(nd, gr::VP_SoftmaxExpSum, r_lead, exp_sum_claim);                       // cache_exp_sum
+        if (!rc) rc = eval1(Sm.R, T, r0, &R_claim);
+        if (!rc) rc = append_advice(nd, gr::VP_SoftmaxRecipMultRemainder, r0, R_claim);                     // cache_R
+        if (rc) return rc;
+
+        std::vector<H::Fr> rs;
+        std::vector<atlas_fr_t> Rra_point, Era_point, Cra_point;
+        H::Fr Rra_claim, Era_claim, Cra_claim, exp_q_claim;
+        Point r1, r2;
+        {   // ---- stage 1: RecipMult, ExpSum, IdentityRC of R (build_stage1_instances :450-495)
+            atlas_poly_t p_expq = nullptr, p_inv = nullptr;
+            atlas_instance_t i_recip = nullptr, i_sum = nullptr, i_rc = nullptr;
+            atlas_batched_t b = nullptr;
+            rc = wrap(Sm.exp_q, T, &p_expq);
+            if (!rc) rc = wrap(Sm.inv_sum, F, &p_inv);
+            if (!rc) rc = atlas_softmax_instance_new(ATLAS_SM_RECIP_MULT, p_expq, p_inv, lf, ln, (const atlas_fr_t*)r0.data(), &i_recip);
+            if (!rc) rc = atlas_softmax_instance_new(ATLAS_SM_EXP_SUM, p_expq, nullptr, lf, ln, (const atlas_fr_t*)r_lead.data(), &i_sum);
+            if (!rc) rc = atlas_identity_range_check_new(Sm.idx_R.as<uint64_t>(), log_T, LS, phases, (const atlas_fr_t*)r0.data(), &i_rc);
+            const H::Fr c_recip = H::add(H::mul(R.claim, S_fr), R_claim);                                    // RecipMultParams::input_claim
+            if (!rc) rc = atlas_batched_new(&b);
+            if (!rc) rc = atlas_batched_add_instance(b, i_recip, (const atlas_fr_t*)&c_recip);
+            if (!rc) rc = atlas_batched_add_instance(b, i_sum, (const atlas_fr_t*)&exp_sum_claim);
+            if (!rc) rc = atlas_batched_add_instance(b, i_rc, (const atlas_fr_t*)&R_claim);
+            if (!rc) rc = run_batch(b, 8, LS + log_T, gr::PT_SoftmaxStage1, rs);
+            if (!rc) {
+                r1.assign(rs.rbegin(), rs.rbegin() + log_T);                                                 // LITTLE_ENDIAN challenges of the last log_T rounds -> BIG_ENDIAN
+                atlas_fr_t f[64]; size_t nf = 0;
+                rc = atlas_instance_final_claims(i_recip, f, 64, &nf);
+                std::memcpy(&exp_q_claim, &f[0], 32);
+                if (!rc) rc = append_advice(nd, gr::VP_SoftmaxExpQ, r1, exp_q_claim);                        // RecipMultProver::cache_openings
+                if (!rc) rc = atlas_instance_final_claims(i_sum, f, 64, &nf);
+                if (!rc) rc = append_advice(nd, gr::VP_SoftmaxExpQ, r1, *reinterpret_cast<H::Fr*>(&f[0]));   // ExpSumProver::cache_openings (the same opening again)
+                if (!rc) rc = ra_opening(nd, i_rc, gr::VP_SoftmaxRemainderRa, LS, log_T, rs, Rra_point, Rra_claim);
+            }
+            if (b) atlas_batched_free(b);
+            for (atlas_instance_t i : {i_recip, i_sum, i_rc}) if (i) atlas_instance_free(i);
+            for (atlas_poly_t p : {p_expq, p_inv}) if (p) atlas_poly_free(p);
+            if (rc) return rc;
+        }
+        H::Fr exp_hi_claim, exp_lo_claim;
+        {   // ---- stage 2: Mult, MaxIndicator, IdentityRC of r_exp, the one-hot checks of R (build_stage2_instances :521-579)
+            H::Fr r_exp_claim, max_k_eval;
+            rc = eval1(Sm.r_exp, T, r1, &r_exp_claim);
+            if (!rc) rc = append_advice(nd, gr::VP_SoftmaxExpRemainder, r1, r_exp_claim);                    // cache_r_exp
+            const Point r1_k(r1.begin(), r1.begin() + lf);
+            if (!rc) rc = eval1(Sm.max_k, F, r1_k, &max_k_eval);
+            atlas_poly_t p_hi = nullptr, p_lo = nullptr, p_x = nullptr, p_e = nullptr;
+            atlas_instance_t i_mult = nullptr, i_max = nullptr, i_rc = nullptr;
+            atlas_batched_t b = nullptr;
+            std::vector<atlas_instance_t> oh;
+            std::vector<OneHotFamily> fams(1);
+            if (!rc) rc = wrap(Sm.exp_hi, T, &p_hi);
+            if (!rc) rc = wrap(Sm.exp_lo, T, &p_lo);
+            if (!rc) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(G.tensor(nd.inputs[0])), T, &p_x);
+            if (!rc) rc = wrap(Sm.e, T, &p_e);
+            if (!rc) { atlas_poly_t ops[2] = {p_hi, p_lo}; rc = atlas_elementwise_new(ATLAS_EW_MUL, ops, 2, (const atlas_fr_t*)r1.data(), log_T, nullptr, 0, &i_mult); }
+            if (!rc) rc = atlas_softmax_instance_new(ATLAS_SM_MAX_INDICATOR, p_x, p_e, lf, ln, (const atlas_fr_t*)r1_k.data(), &i_max);
+            if (!rc) rc = atlas_identity_range_check_new(Sm.idx_rexp.as<uint64_t>(), log_T, LS, phases, (const atlas_fr_t*)r1.data(), &i_rc);
+            const H::Fr c_mult = H::add(H::mul(exp_q_claim, S_fr), r_exp_claim);                             // MultParams::input_claim
+            if (!rc) rc = atlas_batched_new(&b);
+            if (!rc) rc = atlas_batched_add_instance(b, i_mult, (const atlas_fr_t*)&c_mult);
+            if (!rc) rc = atlas_batched_add_instance(b, i_max, (const atlas_fr_t*)&max_k_eval);
+            if (!rc) rc = atlas_batched_add_instance(b, i_rc, (const atlas_fr_t*)&r_exp_claim);
+            fams[0].d_lookups = Sm.idx_R.as<uint64_t>(); fams[0].log_K = LS; fams[0].r_cycle = (const atlas_fr_t*)r0.data();       // SoftmaxRaEncoding::remainder
+            fams[0].ra_point = Rra_point; fams[0].ra_claim = Rra_claim; fams[0].rad_cp = gr::CP_SoftmaxRemainderRaD;
+            if (!rc) rc = onehot_families_build(fams, log_T, &t, b, oh, nullptr);
+            if (!rc) rc = run_batch(b, 8, LS + log_T, gr::PT_SoftmaxStage2, rs);
+            if (!rc) {
+                r2.assign(rs.rbegin(), rs.rbegin() + log_T);
+                atlas_fr_t f[64]; size_t nf = 0;
+                rc = atlas_instance_final_claims(i_mult, f, 64, &nf);
+                std::memcpy(&exp_hi_claim, &f[0], 32); std::memcpy(&exp_lo_claim, &f[1], 32);
+                if (!rc) rc = append_advice(nd, gr::VP_SoftmaxExpHi, r2, exp_hi_claim);                      // MultProver::cache_openings
+                if (!rc) rc = append_advice(nd, gr::VP_SoftmaxExpLo, r2, exp_lo_claim);
+                if (!rc) rc = atlas_instance_final_claims(i_max, f, 64, &nf);
+                if (!rc) rc = append_nodeio(nd, 0, r2, *reinterpret_cast<H::Fr*>(&f[0]));                    // MaxIndicatorProver::cache_openings: X(r2)
+                if (!rc) rc = ra_opening(nd, i_rc, gr::VP_SoftmaxExpRemainderRa, LS, log_T, rs, Era_point, Era_claim);
+                Out O = out();
+                if (!rc) rc = onehot_families_cache(fams, oh.data(), log_T, rs, &t, O);
+            }
+            if (b) atlas_batched_free(b);
+            for (atlas_instance_t i : {i_mult, i_max, i_rc}) if (i) atlas_instance_free(i);
+            for (atlas_instance_t i : oh) if (i) atlas_instance_free(i);
+            for (atlas_poly_t p : {p_hi, p_lo, p_x, p_e}) if (p) atlas_poly_free(p);
+            if (rc) return rc;
+        }
+        std::vector<atlas_fr_t> hi_point, lo_point;
+        H::Fr hi_claim, lo_claim;
+        {   // ---- stage 3: the two exp-digit Shout lookups, the significance clamp lookup, the one-hot checks of r_exp (:611-671)
+            H::Fr zc[3];                                                                                     // z_hi(r2), z_lo(r2), z(r2)
+            const int32_t* zs[3] = {Sm.z_hi.as<int32_t>(), Sm.z_lo.as<int32_t>(), Sm.z.as<int32_t>()};
+            rc = eval_i32(zs, 3, T, r2, zc);
+            if (!rc) rc = append_advice(nd, gr::VP_SoftmaxZHi, r2, zc[0]);                                   // cache_z_hi_lo
+            if (!rc) rc = append_advice(nd, gr::VP_SoftmaxZLo, r2, zc[1]);
+            if (rc) return rc;
+            atlas_poly_t eq = nullptr, G_hi = nullptr, G_lo = nullptr;
+            atlas_dot_prover_t d_hi = nullptr, d_lo = nullptr;
+            atlas_instance_t i_clamp = nullptr;
+            atlas_batched_t b = nullptr;
+            std::vector<atlas_instance_t> oh;
+            std::vector<OneHotFamily> fams(1);
+            rc = atlas_eq_evals((const atlas_fr_t*)r2.data(), log_T, nullptr, &eq);
+            const H::Fr g_hi = H::tr_challenge_scalar(Tr);                                                   // ReadRafParams::new (shout.rs:112-130)
+            if (!rc) rc = atlas_shout_read_raf_G(Sm.idx_zhi.as<uint64_t>(), T, Sm.lk_hi, eq, &G_hi);
+            if (!rc) { rc = atlas_shout_read_raf_prover_new(G_hi, L->hi.data(), Sm.lk_hi, (const atlas_fr_t*)&g_hi, &d_hi); if (rc && G_hi) atlas_poly_free(G_hi); }
+            const H::Fr g_lo = H::tr_challenge_scalar(Tr);
+            if (!rc) rc = atlas_shout_read_raf_G(Sm.idx_zlo.as<uint64_t>(), T, Sm.lk_lo, eq, &G_lo);
+            if (!rc) { rc = atlas_shout_read_raf_prover_new(G_lo, L->lo.data(), Sm.lk_lo, (const atlas_fr_t*)&g_lo, &d_lo); if (rc && G_lo) atlas_poly_free(G_lo); }
+            if (eq) atlas_poly_free(eq);
+            if (!rc) rc = append_advice(nd, gr::VP_SoftmaxClampWitness, r2, zc[2]);                          // append_raf_claims_prover (op_lookups/mod.rs:404-418)
+            const H::Fr g_c = H::tr_challenge_scalar(Tr);                                                    // ps_read_raf_prover (unary.rs:112)
+            const size_t bound = Sm.lk_hi + Sm.log2_base;                                                    // SOFTMAX_CLAMP_BOUND (common/src/consts/softmax.rs)
+            if (!rc) rc = atlas_ps_shout_clamp_new(Sm.idx_z.as<uint64_t>(), log_T, 32, bound, 0, (const atlas_fr_t*)r2.data(), (const atlas_fr_t*)&g_c, &i_clamp);
+            const H::Fr c_hi = H::add(exp_hi_claim, H::mul(g_hi, zc[0])), c_lo = H::add(exp_lo_claim, H::mul(g_lo, zc[1]));      // rv_claim + gamma raf_claim
+            const H::Fr rv = H::add(H::mul(zc[0], H::from_u64((uint64_t)1 << Sm.log2_base)), zc[1]);         // significance_clamp.rs:61-69
+            const H::Fr c_clamp = H::add(rv, H::mul(g_c, zc[2]));
+            if (!rc) rc = atlas_batched_new(&b);
+            if (!rc) rc = atlas_batched_add_dot(b, d_hi, (const atlas_fr_t*)&c_hi);
+            if (!rc) rc = atlas_batched_add_dot(b, d_lo, (const atlas_fr_t*)&c_lo);
+            if (!rc) rc = atlas_batched_add_instance(b, i_clamp, (const atlas_fr_t*)&c_clamp);
+            fams[0].d_lookups = Sm.idx_rexp.as<uint64_t>(); fams[0].log_K = LS; fams[0].r_cycle = (const atlas_fr_t*)r1.data();     // SoftmaxRaEncoding::exp_remainder
+            fams[0].ra_point = Era_point; fams[0].ra_claim = Era_claim; fams[0].rad_cp = gr::CP_SoftmaxExpRemainderRaD;
+            if (!rc) rc = onehot_families_build(fams, log_T, &t, b, oh, nullptr);
+            if (!rc) rc = run_batch(b, 8, 32 + log_T, gr::PT_SoftmaxStage3, rs);
+            if (!rc) {
+                const size_t mr = rs.size();
+                auto shout_open = [&](atlas_dot_prover_t dp, size_t lk, uint8_t vp, std::vector<atlas_fr_t>& pt_out, H::Fr& claim) {     // ReadRafProver::cache_openings: [challenges | r]
+                    atlas_fr_t f[3];
+                    int rc2 = atlas_dot_final_claims(dp, f);
+                    if (rc2) return rc2;
+                    std::memcpy(&claim, &f[0], 32);
+                    Point pt(rs.begin() + (mr - lk), rs.end());
+                    pt.insert(pt.end(), r2.begin(), r2.end());
+                    pt_out.resize(pt.size()); std::memcpy(pt_out.data(), pt.data(), pt.size() * 32);
+                    return append_advice(nd, vp, pt, claim);
+                };
+                rc = shout_open(d_hi, Sm.lk_hi, gr::VP_SoftmaxZHiRa, hi_point, hi_claim);
+                if (!rc) rc = shout_open(d_lo, Sm.lk_lo, gr::VP_SoftmaxZLoRa, lo_point, lo_claim);
+                if (!rc) rc = ra_opening(nd, i_clamp, gr::VP_SoftmaxClampRa, 32, log_T, rs, Cra_point, Cra_claim);
+                Out O = out();
+                if (!rc) rc = onehot_families_cache(fams, oh.data(), log_T, rs, &t, O);
+            }
+            if (b) atlas_batched_free(b);
+            if (d_hi) atlas_dot_prover_free(d_hi);
+            if (d_lo) atlas_dot_prover_free(d_lo);
+            if (i_clamp) atlas_instance_free(i_clamp);
+            for (atlas_instance_t i : oh) if (i) atlas_instance_free(i);
+            if (rc) return rc;
+        }
+        // ---- stage 4: the one-hot checks of z_hi, z_lo and the clamp lookup in one BatchedSumcheck (build_stage4_instances :686-730)
+        std::vector<OneHotFamily> fams(3);
+        fams[0].d_lookups = Sm.idx_zhi.as<uint64_t>(); fams[0].log_K = Sm.lk_hi; fams[0].ra_point = hi_point; fams[0].ra_claim = hi_claim; fams[0].rad_cp = gr::CP_SoftmaxZHiRaD;
+        fams[1].d_lookups = Sm.idx_zlo.as<uint64_t>(); fams[1].log_K = Sm.lk_lo; fams[1].ra_point = lo_point; fams[1].ra_claim = lo_claim; fams[1].rad_cp = gr::CP_SoftmaxZLoRaD;
+        fams[2].d_lookups = Sm.idx_z.as<uint64_t>(); fams[2].log_K = 32; fams[2].ra_point = Cra_point; fams[2].ra_claim = Cra_claim; fams[2].rad_cp = gr::CP_SoftmaxClampRaD;
+        for (auto& f : fams) f.r_cycle = (const atlas_fr_t*)r2.data();       // the points of SoftmaxExpHi / SoftmaxExpLo / SoftmaxZHi: all r2
+        Out O = out();
+        return prove_onehot_checks_multi(fams, log_T, &t, O, gr::PT_SoftmaxStage4);
+    }
+
     int prove_node(const Node& nd) {
         cur = nd.idx;
         if (nd.op == ATLAS_OP_DIV) return op_div(nd);                          // ReductionFlow::Custom
@@ -844,6 +1073,7 @@ struct Prover : FlowSink {
             case ATLAS_OP_MEAN_OF_SQUARES: return op_mean_of_squares(nd);
             case ATLAS_OP_TANH: return op_tanh(nd);
             case ATLAS_OP_GATHER_LARGE: return op_gather(nd);
+            case ATLAS_OP_SOFTMAX: return op_softmax(nd);
             default: return fail(ATLAS_EINVAL, "prove_graph: operator without a prover composition");
         }
     }

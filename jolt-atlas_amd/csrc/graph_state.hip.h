@@ -6,8 +6,18 @@
 #include "graph.hpp"
 #include "node_flow.hip.h"
 
+// SoftmaxLastAxisTrace (atlas-onnx-tracer/src/ops/softmax.rs:24-66) in HBM: [F][N] i32 tensors, the per-row vectors and the five
+// lookup-index vectors of the node's one-hot families
+struct SoftmaxWitness {
+    size_t F = 0, N = 0, log2_base = 0, lk_hi = 0, lk_lo = 0;
+    DevBuf R, exp_q, exp_hi, exp_lo, r_exp, z, z_hi, z_lo, e;           // i32 [F][N]; e = the argmax indicator (max.rs:70-74)
+    DevBuf max_k, argmax_k, exp_sum, inv_sum;                             // i32 [F]
+    DevBuf idx_R, idx_rexp, idx_z, idx_zhi, idx_zlo;                      // u64 [F][N]
+};
+
 struct NodeWitness {
     std::unique_ptr<RescaleWitness> rescale;     // Einsum / Mul / Square / Cube (fused rescale)
+    std::unique_ptr<SoftmaxWitness> softmax;     // SoftmaxLastAxis
     DevBuf acc, acc_fr, cidx;                    // Add / Sub / Sum: i64 accumulation, its Fr image, the clamp lookup indices
     DevBuf lookups;                              // ReLU and the other XLEN-bit unary lookups; Div / MeanOfSquares: the range check's interleaved pairs
     DevBuf rem;                                  // ScalarConstDiv / Div: the remainder tensor (i32); Rsqrt: div_remainder
@@ -36,6 +46,10 @@ struct atlas_graph {
 // the small activation table of Tanh (ops/tanh.rs:22-32 -> neural_teleport/utils.rs:67-85): Table[i] = round(2^14 tanh(signed18(i) / 2^14)),
 // built once on the host (the reference's f64 arithmetic) and kept in HBM; graph_exec.hip
 int atlas_rt_tanh_table(const int32_t** d_table, const std::vector<int32_t>** h_table);
+// the decomposed exp sub-tables of SoftmaxLastAxis at MODEL_SCALE (generate_exp_lut_decomposed, atlas-onnx-tracer/src/ops/softmax.rs:239-269;
+// lut_hi zero-padded to a power of two, :94-96), built once on the host in the reference's f64 arithmetic; graph_exec.hip
+struct ExpLut { std::vector<int32_t> hi, lo; size_t log2_base = 0; const int32_t *d_hi = nullptr, *d_lo = nullptr; };
+int atlas_rt_exp_lut(const ExpLut** out);
 
 namespace gr {
 constexpr size_t MODEL_SCALE = 14, ACTIVATION_BOUND = MODEL_SCALE + 3, ACTIVATION_TABLE_VARS = ACTIVATION_BOUND + 1;      // common/src/consts

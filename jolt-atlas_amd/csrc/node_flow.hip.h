@@ -180,7 +180,9 @@ struct OneHotFamily {
     std::vector<atlas_fr_t> ra_point; H::Fr ra_claim;
     uint8_t rad_cp;
 };
-int prove_onehot_checks_multi(std::vector<OneHotFamily>& fams, size_t log_T, atlas_transcript_t* t, Out& O, uint8_t proof_type) {
+// ra_onehot_provers of every family, in order (the challenge draws of each: HammingWeight's gamma powers, Booleanity's gammas and
+// r_address): appends [RaVirtual, HammingWeight, Booleanity] per family to the batch and to `insts` (owned by the caller)
+int onehot_families_build(std::vector<OneHotFamily>& fams, size_t log_T, atlas_transcript_t* t, atlas_batched_t b, std::vector<atlas_instance_t>& insts, size_t* dmax_out) {
     const size_t lkc = 4;                                            // OneHotParams::new: LOG_K_CHUNK = 4 (common/src/consts/general.rs:2)
     H::Transcript& T = *reinterpret_cast<H::Transcript*>(t);
     const bool trace = getenv("ATLAS_TRACE") != nullptr;
@@ -192,9 +194,7 @@ int prove_onehot_checks_multi(std::vector<OneHotFamily>& fams, size_t log_T, atl
         fprintf(stderr, "[atlas trace] onehot_checks x%zu %-24s %8.3f ms\n", fams.size(), what, std::chrono::duration<double, std::milli>(t1 - tr0).count());
         tr0 = t1;
     };
-    std::vector<atlas_instance_t> insts;
-    atlas_batched_t b = nullptr;
-    int rc = atlas_batched_new(&b);
+    int rc = ATLAS_OK;
     size_t dmax = 0;
     const H::Fr zero = H::zero();
     for (auto& F : fams) {
@@ -229,16 +229,15 @@ int prove_onehot_checks_multi(std::vector<OneHotFamily>& fams, size_t log_T, atl
         if (!rc) rc = atlas_batched_add_instance(b, bo, (const atlas_fr_t*)&zero);
         if (rc) break;
     }
-    size_t stride = dmax + 2, max_rounds = lkc + log_T;
-    std::vector<atlas_fr_t> rows(max_rounds * stride);
-    std::vector<uint32_t> nco(max_rounds);
-    std::vector<atlas_u128_t> ch(max_rounds);
-    size_t mr = 0;
-    if (!rc) rc = atlas_batched_prove(b, t, rows.data(), stride, nco.data(), ch.data(), &mr);
-    mark("batched_prove");
-    // cache_openings in instance order; an instance of n rounds sees the LAST n challenges (sumcheck.rs:150-170)
-    std::vector<H::Fr> rs(mr);
-    for (size_t i = 0; i < mr && !rc; i++) rs[i] = ch_fr(ch[i]);
+    if (dmax_out) *dmax_out = dmax;
+    return rc;
+}
+// cache_openings of the families' instances (insts[3 f + {0, 1, 2}]) after a BatchedSumcheck of `mr` rounds with challenges rs: an
+// instance of n rounds sees the LAST n challenges (sumcheck.rs:150-170)
+int onehot_families_cache(std::vector<OneHotFamily>& fams, const atlas_instance_t* insts, size_t log_T, const std::vector<H::Fr>& rs, atlas_transcript_t* t, Out& O) {
+    const size_t lkc = 4, mr = rs.size(), b0 = mr - lkc - log_T;     // b0: where Booleanity's lkc + log_T challenges start
+    H::Transcript& T = *reinterpret_cast<H::Transcript*>(t);
+    int rc = ATLAS_OK;
     for (size_t f = 0; f < fams.size() && !rc; f++) {
         OneHotFamily& F = fams[f];
         const size_t d = (F.log_K + lkc - 1) / lkc, pad = d * lkc - F.log_K;
@@ -256,7 +255,7 @@ int prove_onehot_checks_multi(std::vector<OneHotFamily>& fams, size_t log_T, atl
                         for (size_t q = 0; q < lkc; q++) pt[q] = rs[mr - 1 - q];
                         for (size_t q = 0; q < log_T; q++) pt[lkc + q] = *reinterpret_cast<const H::Fr*>(&F.r_cycle[q]);
                     } else {                     // Booleanity (booleanity.rs:71-76, 350-368): both halves reversed
-                        for (size_t q = 0; q < lkc; q++) pt[q] = rs[lkc - 1 - q];
+                        for (size_t q = 0; q < lkc; q++) pt[q] = rs[b0 + lkc - 1 - q];
                         for (size_t q = 0; q < log_T; q++) pt[lkc + q] = rs[mr - 1 - q];
                     }
                 }
@@ -265,10 +264,27 @@ int prove_onehot_checks_multi(std::vector<OneHotFamily>& fams, size_t log_T, atl
             }
         }
     }
+    return rc;
+}
+int prove_onehot_checks_multi(std::vector<OneHotFamily>& fams, size_t log_T, atlas_transcript_t* t, Out& O, uint8_t proof_type) {
+    const size_t lkc = 4;
+    std::vector<atlas_instance_t> insts;
+    atlas_batched_t b = nullptr;
+    int rc = atlas_batched_new(&b);
+    size_t dmax = 0;
+    if (!rc) rc = onehot_families_build(fams, log_T, t, b, insts, &dmax);
+    size_t stride = dmax + 2, max_rounds = lkc + log_T;
+    std::vector<atlas_fr_t> rows(max_rounds * stride);
+    std::vector<uint32_t> nco(max_rounds);
+    std::vector<atlas_u128_t> ch(max_rounds);
+    size_t mr = 0;
+    if (!rc) rc = atlas_batched_prove(b, t, rows.data(), stride, nco.data(), ch.data(), &mr);
+    std::vector<H::Fr> rs(mr);
+    for (size_t i = 0; i < mr && !rc; i++) rs[i] = ch_fr(ch[i]);
+    if (!rc) rc = onehot_families_cache(fams, insts.data(), log_T, rs, t, O);
     if (!rc) rc = O.put_proof(rows, stride, nco, mr, proof_type);
     if (b) atlas_batched_free(b);
     for (atlas_instance_t inst : insts) if (inst) atlas_instance_free(inst);
-    mark("finals + free");
     return rc;
 }
 int prove_onehot_checks(const uint64_t* d_lookups, size_t log_T, size_t log_K, const atlas_fr_t* r_cycle, const std::vector<atlas_fr_t>& ra_point,

@@ -165,6 +165,17 @@ template <int D>
 void launch_prod(const Fr* buf, size_t stride, Fr* partials, const SplitEqView& E, size_t n_groups, unsigned blocks, MailTail tail) {
     tail.n_rows = blocks; tail.K = D;
     const MailTail none{tail.io, nullptr, 0, 0};
+    static const bool no_tail = getenv("ATLAS_NO_MAIL_TAIL") != nullptr;      // diagnosis (tools/stress_lanes.py): the column sums in a launch of their own
+    if (no_tail && tail.counter) {
+        if (n_groups <= ((size_t)1 << 15)) k_ra_prod_f9_col<D><<<dim3(blocks, D), RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, none);
+        else {
+            constexpr int KA0 = D < 8 ? D : 8;
+            k_ra_prod_f9<D, 0, KA0><<<blocks, RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, none);
+            if constexpr (D > 8) k_ra_prod_f9<D, 8, D - 8><<<blocks, RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, none);
+        }
+        k_col_reduce_mail<<<1, RA_THREADS, 0, g.stream>>>(partials, blocks, (uint32_t)D, tail.io);
+        return;
+    }
     // one column per thread up to 2^15 pairs: 16 x more workgroups than the register-tiled kernel, which runs at one wavefront
     // per SIMD there (measured on the Einsum node: 2^15 is 2 % ahead of 2^13, 2^16 no better)
     static const size_t col_log = [] { const char* e = getenv("ATLAS_RA_COL_LOG"); int v = e ? atoi(e) : 0; return (size_t)(v >= 8 && v <= 24 ? v : 15); }();   // experiments
@@ -382,6 +393,12 @@ struct Booleanity : atlas_instance {
         static const size_t split_log = [] { const char* e = getenv("ATLAS_BOOL_SPLIT_LOG"); int v = e ? atoi(e) : 0; return (size_t)(v >= 8 && v <= 24 ? v : 13); }();   // experiments
         const unsigned ysplit = n_groups <= ((size_t)1 << split_log) ? (unsigned)d : 1u;   // latency regime: one row per thread
         const MailTail tail = io ? MailTail{*io, rows.d_counter, (uint32_t)(blocks * ysplit), 2u} : MailTail{{}, nullptr, 0, 0};
+        static const bool no_tail = getenv("ATLAS_NO_MAIL_TAIL") != nullptr;  // diagnosis (tools/stress_lanes.py)
+        if (no_tail && io) {
+            k_bool_fold<<<dim3((unsigned)blocks, ysplit), RA_THREADS, 0, g.stream>>>(buf, stride, (uint32_t)d, d_gammas, E, n_groups, rows.partials, MailTail{{}, nullptr, 0, 0});
+            k_col_reduce_mail<<<1, RA_THREADS, 0, g.stream>>>(rows.partials, (uint32_t)(blocks * ysplit), 2u, *io);
+            return (uint32_t)(blocks * ysplit);
+        }
         k_bool_fold<<<dim3((unsigned)blocks, ysplit), RA_THREADS, 0, g.stream>>>(buf, stride, (uint32_t)d, d_gammas, E, n_groups, rows.partials, tail);
         return (uint32_t)(blocks * ysplit);
     }

@@ -206,6 +206,53 @@ def tanh_table():
     return _TANH
 
 
+_EXP_LUT = {}
+
+
+def exp_lut(scale):
+    """generate_exp_lut_decomposed (atlas-onnx-tracer/src/ops/softmax.rs:239-269) in f64 with f64::round (half away from zero);
+    lut_hi zero-padded to the next power of two (softmax.rs:94-96).  Returns (lut_hi, lut_lo, log2_base)."""
+    if scale not in _EXP_LUT:
+        import math
+        sf = float(scale)
+        needed = int(math.ceil(sf * math.log(2.0 * sf))) + 2
+        log2_b = int(math.ceil(math.log2(float(needed)) / 2.0))
+        base = 1 << log2_b
+        hi_size = needed // base + 2
+
+        def rnd(f):
+            return max(int(math.floor(abs(f) + 0.5)) * (1 if f >= 0 else -1), 0)
+        hi = [rnd(sf * math.exp(-(float(h) * float(base)) / sf)) for h in range(hi_size)]
+        lo = [rnd(sf * math.exp(-float(l) / sf)) for l in range(base)]
+        hp = 1 << (hi_size - 1).bit_length()
+        _EXP_LUT[scale] = (np.array(hi + [0] * (hp - hi_size), dtype=np.int64), np.array(lo, dtype=np.int64), log2_b)
+    return _EXP_LUT[scale]
+
+
+def softmax_trace(x, F, N, S):
+    """softmax_last_axis_decomposed (atlas-onnx-tracer/src/ops/softmax.rs:74-214): the output and the SoftmaxLastAxisTrace"""
+    hi, lo, lb = exp_lut(S)
+    base = 1 << lb
+    z_bound = len(hi) * base
+    X = x.astype(np.int64).reshape(F, N)
+    mx = X.max(axis=1); am = X.argmax(axis=1)                      # first position of the maximum
+    z = mx[:, None] - X
+    zc = np.minimum(z, z_bound - 1)
+    z_hi, z_lo = zc >> lb, zc & (base - 1)
+    e_hi, e_lo = hi[z_hi], lo[z_lo]
+    prod = e_hi * e_lo
+    exp_q = prod // S; r_exp = prod - exp_q * S
+    assert ((r_exp >= 0) & (r_exp < S)).all()
+    ssum = exp_q.sum(axis=1)
+    inv = (S * S) // ssum
+    p = exp_q * inv[:, None]
+    sq = p // S; R = p - sq * S
+    assert ((R >= 0) & (R < S)).all()
+    f = lambda a: a.reshape(-1).astype(np.int32)
+    return f(sq), dict(max_k=f(mx), argmax_k=f(am), z=f(z), exp_q=f(exp_q), exp_sum_q=f(ssum), inv_sum=f(inv), R=f(R), z_hi=f(z_hi), z_lo=f(z_lo),
+                       exp_hi=f(e_hi), exp_lo=f(e_lo), r_exp=f(r_exp), F=F, N=N, S=S, log2_base=lb, lut_hi=hi.astype(np.int32), lut_lo=lo.astype(np.int32))
+
+
 # ---- the integer semantics of the tracer (atlas-onnx-tracer/src/ops/*.rs)
 def clamp_i32(a):
     return np.clip(a, -(1 << 31), (1 << 31) - 1).astype(np.int32)
@@ -324,6 +371,10 @@ def execute(nodes, inputs):
         elif op == "GatherLarge":
             ddims = next(n for n in nodes if n["idx"] == nd["inputs"][0])["dims"]
             o = ins[0].reshape(ddims[0], -1)[ins[1]].reshape(-1).astype(np.int32)
+        elif op == "SoftmaxLastAxis":
+            assert nd["scale"] == MODEL_SCALE
+            N = nd["dims"][-1]
+            o, wit[nd["idx"]] = softmax_trace(ins[0], int(np.prod(nd["dims"])) // N, N, 1 << nd["scale"])
         else:
             raise ValueError(f"oracle graph executor: operator {op}")
         assert len(o) == int(np.prod(nd["dims"])), (nd, len(o))
@@ -392,6 +443,11 @@ class Prover:
         if op == "GatherLarge":
             V = self.nodes[nd["inputs"][0]]["dims"][0]
             return [("GatherRaD", self.trace[nd["inputs"][1]].astype(np.uint32).astype(np.uint64), ilog2(V))]
+        if op == "SoftmaxLastAxis":                                # ops/softmax_last_axis/mod.rs:136-159
+            w = self.wit[i]
+            u = lambda a: a.astype(np.uint32).astype(np.uint64)
+            return [("SoftmaxRemainderRaD", u(w["R"]), MODEL_SCALE), ("SoftmaxExpRemainderRaD", u(w["r_exp"]), MODEL_SCALE), ("SoftmaxClampRaD", u(w["z"]), 32),
+                    ("SoftmaxZHiRaD", u(w["z_hi"]), ilog2(len(w["lut_hi"]))), ("SoftmaxZLoRaD", u(w["z_lo"]), ilog2(len(w["lut_lo"])))]
         if op == "Div":
             return [("DivRangeCheckRaD", interleave_arr(self.wit[i]["rem"], self.trace[nd["inputs"][1]]), 64)]
         if op == "MeanOfSquares":
@@ -440,9 +496,9 @@ class Prover:
     def onehot_checks(self, nd, lookups, log_K, r_cycle, ra_point, ra_claim, cp_name, ptype):
         self.onehot_checks_multi(nd, [(lookups, log_K, r_cycle, ra_point, ra_claim, cp_name)], ptype)
 
-    def onehot_checks_multi(self, nd, fams, ptype):
-        """ra_onehot_provers per family (draws in order), ONE BatchedSumcheck over [ra, hw, bool] x families, cache_openings in order"""
-        lkc, node = 4, nd["idx"]
+    def onehot_build(self, fams):
+        """ra_onehot_provers per family (shout.rs:399-466; draws in order): the [ra, hw, bool] batch members and what cache_openings needs"""
+        lkc = 4
         insts, st = [], []
         for lookups, log_K, r_cycle, ra_point, ra_claim, cp_name in fams:
             d = -(-log_K // lkc)
@@ -464,12 +520,13 @@ class Prover:
             insts += [OB.ra_instance(OR.ra_virtual(Hs, lkc, chunks, r_cyc_ra), ra_claim), OB.ra_instance(OR.hamming(G, lkc, gp), hw_claim),
                       OB.ra_instance(OR.booleanity(G, Hs, lkc, gammas, r_addr, r_cycle), orc.fr_array(1)[0])]
             st.append((d, Hs, G, chunks, r_cycle, cp_name))
-        rows, ch, _ = OB.batched_prove(insts, self.t.t)
-        self.proofs[(node, PT[ptype])] = rows
-        rs = orc.challenges_to_fr(ch)
+        return insts, st
+
+    def onehot_cache(self, node, st, rs):
+        """cache_openings of [RaVirtual, HammingWeight, Booleanity] per family; an instance of n rounds sees the LAST n challenges"""
+        lkc, mr = 4, len(rs)
         for d, Hs, G, chunks, r_cycle, cp_name in st:
             log_T = len(r_cycle)
-            mr = lkc + log_T
             ra_rs = np.ascontiguousarray(rs[mr - log_T:][::-1])
             for i in range(d):                                               # RaVirtual::cache_openings
                 F = orc.eq_evals(chunks[i])
@@ -479,11 +536,19 @@ class Prover:
             for i in range(d):                                               # HammingWeight::cache_openings
                 c = orc.evaluate(G[i], hw_rs)
                 self.append_sparse(cp_name, node, i, "HammingWeight", np.concatenate([hw_rs, r_cycle]), c)
-            ba = np.ascontiguousarray(rs[:lkc][::-1]); bc = np.ascontiguousarray(rs[lkc:][::-1])
+            sl = rs[mr - lkc - log_T:]
+            ba = np.ascontiguousarray(sl[:lkc][::-1]); bc = np.ascontiguousarray(sl[lkc:][::-1])
             Fb = orc.eq_evals(ba)
             for i in range(d):                                               # Booleanity::cache_openings
                 c = orc.evaluate(np.stack([Fb[k] for k in Hs[i]]), bc)
                 self.append_sparse(cp_name, node, i, "Booleanity", np.concatenate([ba, bc]), c)
+
+    def onehot_checks_multi(self, nd, fams, ptype):
+        """ra_onehot_provers per family (draws in order), ONE BatchedSumcheck over [ra, hw, bool] x families, cache_openings in order"""
+        insts, st = self.onehot_build(fams)
+        rows, ch, _ = OB.batched_prove(insts, self.t.t)
+        self.proofs[(nd["idx"], PT[ptype])] = rows
+        self.onehot_cache(nd["idx"], st, orc.challenges_to_fr(ch))
 
     def read_raf(self, nd, inst, claim, lookups, log_K, ra_vp, ptype):
         """Sumcheck::prove of a read-raf instance + its ra opening at (address challenges, reversed cycle challenges)"""
@@ -808,6 +873,98 @@ class Prover:
         self.append_nodeio(nd, 0, dict_pt, fin[1])
         self.onehot_checks(nd, lookups, lv, np.ascontiguousarray(r_index), ra_pt, fin[0], "GatherRaD", "RaOneHotChecks")
 
+    def ra_opening(self, nd, vp, lookups, log_K, sl):
+        """cache_openings of a PS-Shout / IdentityRC instance whose challenge slice is `sl`: ra at (address challenges, reversed cycle challenges)"""
+        ra_point = np.concatenate([sl[:log_K], sl[log_K:][::-1]])
+        ra_claim = orc.evaluate(np.stack([eq_bits(ra_point[:log_K], v, log_K) for v in lookups]), np.ascontiguousarray(ra_point[log_K:]))
+        self.append_advice(nd, vp, ra_point, ra_claim)
+        return ra_point, ra_claim
+
+    def op_softmax(self, nd):
+        """SoftmaxLastAxisProver::prove (ops/softmax_last_axis/mod.rs:177-262): auxiliary vectors, then four BatchedSumcheck stages"""
+        i = nd["idx"]
+        r0, out_claim = self.reduced[i]
+        w = self.wit[i]
+        F, N, S = w["F"], w["N"], w["S"]
+        lf, ln, LS = ilog2(F), ilog2(N), MODEL_SCALE
+        assert lf >= 1 and ln >= 1
+        log_T = lf + ln
+        u = lambda a: a.astype(np.uint32).astype(np.uint64)
+        phases = LS // 4 if LS % 4 == 0 else LS // 2
+        empty = orc.fr_array(0)
+        for k in range(F):                                                   # send_auxiliary_vectors (:392-413): F::from_u32(v as u32)
+            self.append_virtual(node_exec(virt("SoftmaxSumOutput", i, k), i), empty, fr([int(np.uint32(w["exp_sum_q"][k]))])[0])
+            self.append_virtual(node_exec(virt("SoftmaxMaxOutput", i, k), i), empty, fr([int(np.uint32(w["max_k"][k]))])[0])
+            self.append_virtual(node_exec(virt("SoftmaxMaxIndex", i, k), i), empty, fr([int(np.uint32(w["argmax_k"][k]))])[0])
+        r_lead = np.ascontiguousarray(r0[:lf])
+        exp_sum_claim = orc.evaluate(fr(w["exp_sum_q"]), r_lead)
+        self.append_advice(nd, "SoftmaxExpSum", r_lead, exp_sum_claim)                                       # cache_exp_sum
+        R_claim = orc.evaluate(fr(w["R"]), r0)
+        self.append_advice(nd, "SoftmaxRecipMultRemainder", r0, R_claim)                                     # cache_R
+        # ---- stage 1: RecipMult, ExpSum, IdentityRC(R)
+        exp_q = fr(w["exp_q"])
+        insts = [OB.ra_instance(OR.softmax(OR.SM_RECIP_MULT, exp_q, fr(w["inv_sum"]), lf, ln, r0), orc.fr_add_arr(orc.fr_mul_arr(out_claim, fr([S])[0]), R_claim)),
+                 OB.ra_instance(OR.softmax(OR.SM_EXP_SUM, exp_q, None, lf, ln, r_lead), exp_sum_claim),
+                 OB.ra_instance(OR.ps_identity(u(w["R"]), LS, phases, r0), R_claim)]
+        rows, ch, _ = OB.batched_prove(insts, self.t.t)
+        self.proofs[(i, PT["SoftmaxStage1"])] = rows
+        rs = orc.challenges_to_fr(ch); mr = len(rs)
+        r1 = np.ascontiguousarray(rs[mr - log_T:][::-1])
+        exp_q_claim = orc.evaluate(exp_q, r1)
+        self.append_advice(nd, "SoftmaxExpQ", r1, exp_q_claim)                                               # RecipMult::cache_openings
+        self.append_advice(nd, "SoftmaxExpQ", r1, exp_q_claim)                                               # ExpSum::cache_openings
+        Rra_point, Rra_claim = self.ra_opening(nd, "SoftmaxRemainderRa", u(w["R"]), LS, rs[mr - LS - log_T:])
+        # ---- stage 2: Mult, MaxIndicator, IdentityRC(r_exp), one-hot checks of R
+        r_exp_claim = orc.evaluate(fr(w["r_exp"]), r1)
+        self.append_advice(nd, "SoftmaxExpRemainder", r1, r_exp_claim)                                       # cache_r_exp
+        max_k_eval = orc.evaluate(fr(w["max_k"]), np.ascontiguousarray(r1[:lf]))
+        e = np.zeros(F * N, dtype=np.int32); e[np.arange(F) * N + w["argmax_k"]] = 1
+        X = self.mle(nd["inputs"][0])
+        insts = [OB.ra_instance(OR.elementwise(OR.EW_MUL, [fr(w["exp_hi"]), fr(w["exp_lo"])], r1), orc.fr_add_arr(orc.fr_mul_arr(exp_q_claim, fr([S])[0]), r_exp_claim)),
+                 OB.ra_instance(OR.softmax(OR.SM_MAX_INDICATOR, X, fr(e), lf, ln, np.ascontiguousarray(r1[:lf])), max_k_eval),
+                 OB.ra_instance(OR.ps_identity(u(w["r_exp"]), LS, phases, r1), r_exp_claim)]
+        oh, st = self.onehot_build([(u(w["R"]), LS, r0, Rra_point, Rra_claim, "SoftmaxRemainderRaD")])
+        rows, ch, _ = OB.batched_prove(insts + oh, self.t.t)
+        self.proofs[(i, PT["SoftmaxStage2"])] = rows
+        rs = orc.challenges_to_fr(ch); mr = len(rs)
+        r2 = np.ascontiguousarray(rs[mr - log_T:][::-1])
+        self.append_advice(nd, "SoftmaxExpHi", r2, orc.evaluate(fr(w["exp_hi"]), r2))                        # Mult::cache_openings
+        self.append_advice(nd, "SoftmaxExpLo", r2, orc.evaluate(fr(w["exp_lo"]), r2))
+        self.append_nodeio(nd, 0, r2, orc.evaluate(X, r2))                                                   # MaxIndicator::cache_openings
+        Era_point, Era_claim = self.ra_opening(nd, "SoftmaxExpRemainderRa", u(w["r_exp"]), LS, rs[mr - LS - log_T:])
+        self.onehot_cache(i, st, rs)
+        # ---- stage 3: the exp-digit Shout lookups, the significance clamp lookup, one-hot checks of r_exp
+        exp_hi_claim, exp_lo_claim = self.openings[node_exec(virt("SoftmaxExpHi", i), i)][1], self.openings[node_exec(virt("SoftmaxExpLo", i), i)][1]
+        z_hi_claim, z_lo_claim = orc.evaluate(fr(w["z_hi"]), r2), orc.evaluate(fr(w["z_lo"]), r2)
+        self.append_advice(nd, "SoftmaxZHi", r2, z_hi_claim)                                                 # cache_z_hi_lo
+        self.append_advice(nd, "SoftmaxZLo", r2, z_lo_claim)
+        lk_hi, lk_lo = ilog2(len(w["lut_hi"])), ilog2(len(w["lut_lo"]))
+        g_hi = self.t.challenge_scalar()                                                                     # ReadRafParams::new (shout.rs:112-130)
+        I_hi = OR.shout_read_raf(u(w["z_hi"]), w["lut_hi"], lk_hi, r2, g_hi)
+        g_lo = self.t.challenge_scalar()
+        I_lo = OR.shout_read_raf(u(w["z_lo"]), w["lut_lo"], lk_lo, r2, g_lo)
+        z_claim = orc.evaluate(fr(w["z"]), r2)
+        self.append_advice(nd, "SoftmaxClampWitness", r2, z_claim)                                           # append_raf_claims_prover (op_lookups/mod.rs:404-418)
+        g_c = self.t.challenge_scalar()                                                                      # ps_read_raf_prover (unary.rs:112)
+        rv = orc.fr_add_arr(orc.fr_mul_arr(z_hi_claim, fr([1 << w["log2_base"]])[0]), z_lo_claim)            # significance_clamp.rs:61-69
+        bound = lk_hi + w["log2_base"]                                                                        # SOFTMAX_CLAMP_BOUND = log2(padded hi_size * base)
+        insts = [OB.ra_instance(I_hi, orc.fr_add_arr(exp_hi_claim, orc.fr_mul_arr(g_hi, z_hi_claim))),
+                 OB.ra_instance(I_lo, orc.fr_add_arr(exp_lo_claim, orc.fr_mul_arr(g_lo, z_lo_claim))),
+                 OB.ra_instance(OR.ps_clamp(u(w["z"]), 32, bound, False, r2, g_c), orc.fr_add_arr(rv, orc.fr_mul_arr(g_c, z_claim)))]
+        oh, st = self.onehot_build([(u(w["r_exp"]), LS, r1, Era_point, Era_claim, "SoftmaxExpRemainderRaD")])
+        rows, ch, _ = OB.batched_prove(insts + oh, self.t.t)
+        self.proofs[(i, PT["SoftmaxStage3"])] = rows
+        rs = orc.challenges_to_fr(ch); mr = len(rs)
+        hi_point = np.concatenate([rs[mr - lk_hi:], r2]); hi_claim = I_hi.final()                            # ReadRafProver::cache_openings: [challenges | r]
+        self.append_advice(nd, "SoftmaxZHiRa", hi_point, hi_claim)
+        lo_point = np.concatenate([rs[mr - lk_lo:], r2]); lo_claim = I_lo.final()
+        self.append_advice(nd, "SoftmaxZLoRa", lo_point, lo_claim)
+        Cra_point, Cra_claim = self.ra_opening(nd, "SoftmaxClampRa", u(w["z"]), 32, rs[mr - 32 - log_T:])
+        self.onehot_cache(i, st, rs)
+        # ---- stage 4: one-hot checks of z_hi, z_lo and the clamp lookup
+        self.onehot_checks_multi(nd, [(u(w["z_hi"]), lk_hi, r2, hi_point, hi_claim, "SoftmaxZHiRaD"), (u(w["z_lo"]), lk_lo, r2, lo_point, lo_claim, "SoftmaxZLoRaD"),
+                                      (u(w["z"]), 32, r2, Cra_point, Cra_claim, "SoftmaxClampRaD")], "SoftmaxStage4")
+
     def prove_node(self, nd):
         op, i = nd["op"], nd["idx"]
         if op == "Div":
@@ -818,9 +975,9 @@ class Prover:
         r0, claim = self.reduced[i]
         if op in ("Input", "Constant"):
             return
-        if op in ("Sum", "ScalarConstDiv", "Slice", "MeanOfSquares", "Tanh", "GatherLarge"):
+        if op in ("Sum", "ScalarConstDiv", "Slice", "MeanOfSquares", "Tanh", "GatherLarge", "SoftmaxLastAxis"):
             return {"Sum": self.op_sum, "ScalarConstDiv": self.op_scalar_const_div, "Slice": self.op_slice, "MeanOfSquares": self.op_mean_of_squares,
-                    "Tanh": self.op_tanh, "GatherLarge": self.op_gather}[op](nd)
+                    "Tanh": self.op_tanh, "GatherLarge": self.op_gather, "SoftmaxLastAxis": self.op_softmax}[op](nd)
         if op == "Identity":
             self.append_nodeio(nd, 0, r0, claim)
         elif op in ("Add", "Sub"):

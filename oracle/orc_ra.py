@@ -236,3 +236,28 @@ def interleave(x, y):
         out |= ((int(x) >> i) & 1) << (2 * i + 1)
         out |= ((int(y) >> i) & 1) << (2 * i)
     return out
+
+
+SHOUT = 13
+
+
+def shout_read_raf(lookup_indices, table, log_K, r_cycle, gamma):
+    """ReadRafProver (joltworks shout.rs:193-277) as a batch member: G[k] = sum_{j : idx_j = k} eq(r_cycle, j), then
+    sum_k G[k] (table[k] + gamma k), HighToLow, degree 2.  final() = G(r)."""
+    idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)
+    tab = np.ascontiguousarray(table, dtype=np.int32)
+    assert len(tab) == 1 << log_K
+    E = orc.eq_evals(np.ascontiguousarray(r_cycle, dtype=np.uint64))
+    G = orc.fr_array(1 << log_K)
+    orc.lib.orc_shout_G(idx.ctypes.data_as(C.c_void_p), C.c_size_t(len(idx)), C.c_size_t(log_K), orc._p(E), orc._p(G))
+    g = np.ascontiguousarray(gamma, dtype=np.uint64).reshape(1, 4)
+    I = Instance(SHOUT, log_K)
+    I.keep = [idx, tab, G, g]
+    orc.lib.orc_shout_inst_init(I.st, orc._p(G), tab.ctypes.data_as(C.c_void_p), C.c_size_t(log_K), orc._p(g))
+
+    def final():
+        out = orc.fr_array(1)
+        orc.lib.orc_shout_inst_final(I.st, orc._p(out))
+        return out[0]
+    I.final = final
+    return I

@@ -18,6 +18,7 @@
 #include "psshout.h"
 #include "elementwise.h"
 #include "softmax.h"
+#include "shout.h"
 
 /* ------------------------------------------------------------------ small helpers */
 static size_t trim(fr_t *c, size_t n) {                 /* UniPoly::from_coeff (unipoly.rs:39-52) */
@@ -341,6 +342,7 @@ static size_t inst_message(int kind, void *st, size_t round, const fr_t *claim, 
         case ORC_INST_PS_ULT: return orc_ps_ult_message((orc_ps_ult *)st, round, claim, c);
         case ORC_INST_ELEMENTWISE: return orc_elementwise_message((orc_elementwise *)st, claim, c);
         case ORC_INST_SOFTMAX: return orc_softmax_message((orc_softmax *)st, round, claim, c);
+        case ORC_INST_SHOUT: return orc_shout_inst_message((orc_shout_inst *)st, claim, c);
         default: return orc_hamming_message((orc_hamming *)st, claim, c);
     }
 }
@@ -356,6 +358,7 @@ static void inst_ingest(int kind, void *st, size_t round, const fr_t *r) {
         case ORC_INST_PS_ULT: orc_ps_ult_ingest((orc_ps_ult *)st, round, r); break;
         case ORC_INST_ELEMENTWISE: orc_elementwise_ingest((orc_elementwise *)st, r); break;
         case ORC_INST_SOFTMAX: orc_softmax_ingest((orc_softmax *)st, round, r); break;
+        case ORC_INST_SHOUT: orc_shout_inst_ingest((orc_shout_inst *)st, r); break;
         default: orc_hamming_ingest((orc_hamming *)st, r); break;
     }
 }

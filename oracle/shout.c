@@ -5,6 +5,7 @@
  *     IdentityPolynomial (poly/identity_poly.rs:21-118) bound separately, HighToLow
  *   compute_ra_evals :550-598, OneHotParams::lookup_index_chunk (config.rs:73-75) */
 #include "oracle.h"
+#include "shout.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -72,3 +73,36 @@ void orc_readraf_claim(const fr_t *G, const int32_t *table, size_t log_K, const 
     }
     *out = acc;
 }
+
+/* ---- the same prover as a SumcheckInstanceProver (a member of the softmax stage-3 BatchedSumcheck,
+ *      ops/softmax_last_axis/mod.rs:611-671): state between compute_message and ingest_challenge */
+void orc_shout_inst_init(orc_shout_inst *S, const fr_t *G, const int32_t *table, size_t log_K, const fr_t *gamma) {
+    S->log_K = log_K; S->len = (size_t)1 << log_K; S->num_bound = 0; fr_zero(&S->int_bound); S->gamma = *gamma;
+    S->G = (fr_t *)malloc(S->len * sizeof(fr_t)); memcpy(S->G, G, S->len * sizeof(fr_t));
+    S->val = (fr_t *)malloc(S->len * sizeof(fr_t)); orc_i32_to_fr(table, S->len, S->val);
+}
+void orc_shout_inst_free(orc_shout_inst *S) { free(S->G); free(S->val); }
+
+size_t orc_shout_inst_message(orc_shout_inst *S, const fr_t *claim, fr_t *coeffs) {       /* shout.rs:233-255 */
+    const size_t half = S->len / 2;
+    fr_t e0, e2, m; fr_zero(&e0); fr_zero(&e2);
+    { uint64_t c[4] = {0, 0, 0, 0}; c[0] = (uint64_t)1 << (S->log_K - 1 - S->num_bound); fp_from_canonical(&ORC_FR, c, &m); }
+    for (size_t i = 0; i < half; i++) {
+        fr_t v0 = S->val[i], v2, g0 = S->G[i], g2, d, i0, i2, t0, t2, fi;
+        fr_sub(&S->val[i + half], &v0, &d); fr_add(&S->val[i + half], &d, &v2);
+        fr_sub(&S->G[i + half], &g0, &d); fr_add(&S->G[i + half], &d, &g2);
+        fr_add(&m, &m, &d); fr_mul(&S->int_bound, &d, &i0); fr_from_u64(i, &fi); fr_add(&i0, &fi, &i0);   /* identity_poly.rs:102-116 */
+        fr_add(&i0, &d, &i2);
+        fr_mul(&S->gamma, &i0, &t0); fr_add(&v0, &t0, &t0); fr_mul(&g0, &t0, &t0); fr_add(&e0, &t0, &e0);
+        fr_mul(&S->gamma, &i2, &t2); fr_add(&v2, &t2, &t2); fr_mul(&g2, &t2, &t2); fr_add(&e2, &t2, &e2);
+    }
+    fr_t ev[2] = {e0, e2};
+    return orc_unipoly_from_evals_and_hint(claim, ev, 2, coeffs);
+}
+
+void orc_shout_inst_ingest(orc_shout_inst *S, const fr_t *r) {                             /* shout.rs:257-262 */
+    orc_bind(S->val, S->len, r, ORC_HIGH_TO_LOW); orc_bind(S->G, S->len, r, ORC_HIGH_TO_LOW);
+    fr_add(&S->int_bound, &S->int_bound, &S->int_bound); fr_add(&S->int_bound, r, &S->int_bound);   /* identity_poly.rs:49-52 */
+    S->num_bound++; S->len /= 2;
+}
+void orc_shout_inst_final(const orc_shout_inst *S, fr_t *out) { *out = S->G[0]; }

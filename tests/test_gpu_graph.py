@@ -91,6 +91,19 @@ def act_graph(rng, n=4, d=4, v=8, S=14):
     ], [6], [rng.integers(0, v, size=n).astype(np.int32)]
 
 
+def softmax_graph(rng, b=2, t=4, n=8, S=14):
+    """SoftmaxLastAxis over [b][t][n] scores (scale 14: the clamp table of the prover), with masked entries far below the row maximum
+    (beyond the exp tables: the saturating clamp) and ties for the maximum; followed by an einsum that consumes the probabilities"""
+    x = rng.integers(-(1 << 16), 1 << 16, size=b * t * n).astype(np.int32).reshape(b, t, n)
+    x[0, 1, 3:] = -(1 << 19); x[1, 2, 5] = -(1 << 17); x[1, 0, :] = 777; x[0, 3, 2] = x[0, 3].max()
+    return [
+        {"idx": 0, "op": "Input", "inputs": [], "dims": [b, t, n]},
+        {"idx": 1, "op": "SoftmaxLastAxis", "inputs": [0], "dims": [b, t, n], "scale": S},
+        _const(2, rng, [n, b, 4], -(1 << 12), 1 << 12),
+        {"idx": 3, "op": "Einsum", "inputs": [1, 2], "dims": [t, b, 4], "layout": "bmk,kbn->mbn", "scale": S, "shape": [b, t, n, 4]},
+    ], [3], [x.reshape(-1)]
+
+
 def _max_vars(nodes):
     # the largest committed polynomial is a one-hot chunk: K = 16 addresses x T cycles
     return 4 + max(int(np.log2(np.prod(nd["dims"]))) for nd in nodes)
@@ -104,7 +117,7 @@ def toy_transformer(rng):
     return BG.tiny(layers=2)
 
 
-@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5)])
+@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6)])
 def test_graph_proof_matches_oracle(atlas, builder, seed):
     from oracle import graph as OG, orc
     from jolt_atlas_amd import graph as GG

@@ -4,7 +4,9 @@ found one bench.py run in three giving a different one-hot-check proof when the 
 round 3 reproduced it (ATLAS_LANE_EVENTS=1, 4 runs of 5), showed that it needs wide lane launches spinning for their challenge (a
 one-wavefront gate launch in front of them, channel.hip.h k_ch_gate, removes it: 0 of 8) and keeps both the gate and the host-side
 waits.  Also: lanes at T = 2^18 / 2^20, where the waiting grids exceed the resident workgroups (forward progress), must give the
-single-stream proof."""
+single-stream proof.  The streams created ahead of the library's come from the library's own HIP runtime (a second runtime in the
+process, torch's bundled one, cannot open the device once another has).  tools/bisect_lanes.sh runs the same stress under one diagnosis
+knob at a time (profiles/r03b_bisect_lanes.txt, r03c_bisect_lanes_nogate.txt)."""
 import os
 import subprocess
 import sys

@@ -95,7 +95,7 @@ def transformer(layers, seq, d_model, heads, vocab, S=14, level=2, seed=0, mlp_m
         vh = b.add("Reshape", [v], [seq, heads, hd])
         att = b.add("Einsum", [qh, kh], [heads, seq, seq], layout="mbk,nbk->bmn", scale=S, shape=[heads, seq, hd, seq])
         att = b.add("Iff", [maskb, att, neg], [heads, seq, seq])
-        att = b.add("ReLU", [att], [heads, seq, seq])     # stand-in for SoftmaxLastAxis (its composition is not in the graph prover yet)
+        att = b.add("SoftmaxLastAxis", [att], [heads, seq, seq], scale=S) if level >= 2 and S == 14 else b.add("ReLU", [att], [heads, seq, seq])
         y = b.add("Einsum", [att, vh], [seq, heads, hd], layout="bmk,kbn->mbn", scale=S, shape=[heads, seq, seq, hd])
         y = b.add("Reshape", [y], [seq, d_model])
         y = b.matmul(y, b.const([d_model, d_model], -wlim, wlim), seq, d_model, d_model, S)
