@@ -530,7 +530,7 @@ class Prover:
             ra_rs = np.ascontiguousarray(rs[mr - log_T:][::-1])
             for i in range(d):                                               # RaVirtual::cache_openings
                 F = orc.eq_evals(chunks[i])
-                c = orc.evaluate(np.stack([F[k] for k in Hs[i]]), ra_rs)
+                c = orc.evaluate(np.ascontiguousarray(F[Hs[i]]), ra_rs)
                 self.append_sparse(cp_name, node, i, "RaVirtualization", np.concatenate([chunks[i], ra_rs]), c)
             hw_rs = np.ascontiguousarray(rs[mr - lkc:][::-1])
             for i in range(d):                                               # HammingWeight::cache_openings
@@ -540,7 +540,7 @@ class Prover:
             ba = np.ascontiguousarray(sl[:lkc][::-1]); bc = np.ascontiguousarray(sl[lkc:][::-1])
             Fb = orc.eq_evals(ba)
             for i in range(d):                                               # Booleanity::cache_openings
-                c = orc.evaluate(np.stack([Fb[k] for k in Hs[i]]), bc)
+                c = orc.evaluate(np.ascontiguousarray(Fb[Hs[i]]), bc)
                 self.append_sparse(cp_name, node, i, "Booleanity", np.concatenate([ba, bc]), c)
 
     def onehot_checks_multi(self, nd, fams, ptype):
@@ -554,7 +554,7 @@ class Prover:
         """Sumcheck::prove of a read-raf instance + its ra opening at (address challenges, reversed cycle challenges)"""
         rs = self.run(inst, claim, nd["idx"], ptype)
         ra_point = np.concatenate([rs[:log_K], rs[log_K:][::-1]])
-        ra_claim = orc.evaluate(np.stack([eq_bits(ra_point[:log_K], v, log_K) for v in lookups]), np.ascontiguousarray(ra_point[log_K:]))
+        ra_claim = OR.ra_claim(lookups, log_K, ra_point)
         self.append_virtual(node_exec(virt(ra_vp, nd["idx"]), nd["idx"]), ra_point, ra_claim)
         return ra_point, ra_claim
 
@@ -810,7 +810,7 @@ class Prover:
         ra_point = np.concatenate([rs2[:64], rs2[64:][::-1]])
         fams = []
         for lk, vp, cp in ((lk1, "DivRangeCheckRa", "SqrtDivRangeCheckRaD"), (lk2, "SqrtRangeCheckRa", "SqrtRangeCheckRaD")):
-            ra_claim = orc.evaluate(np.stack([eq_bits(ra_point[:64], v, 64) for v in lk]), np.ascontiguousarray(ra_point[64:]))
+            ra_claim = OR.ra_claim(lk, 64, ra_point)
             self.append_virtual(node_exec(virt(vp, i), i), ra_point, ra_claim)
             fams.append((lk, 64, pt, ra_point, ra_claim, cp))
         self.onehot_checks_multi(nd, fams, "RaOneHotChecks")
@@ -876,7 +876,7 @@ class Prover:
     def ra_opening(self, nd, vp, lookups, log_K, sl):
         """cache_openings of a PS-Shout / IdentityRC instance whose challenge slice is `sl`: ra at (address challenges, reversed cycle challenges)"""
         ra_point = np.concatenate([sl[:log_K], sl[log_K:][::-1]])
-        ra_claim = orc.evaluate(np.stack([eq_bits(ra_point[:log_K], v, log_K) for v in lookups]), np.ascontiguousarray(ra_point[log_K:]))
+        ra_claim = OR.ra_claim(lookups, log_K, ra_point)
         self.append_advice(nd, vp, ra_point, ra_claim)
         return ra_point, ra_claim
 

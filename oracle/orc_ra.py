@@ -261,3 +261,14 @@ def shout_read_raf(lookup_indices, table, log_K, r_cycle, gamma):
         return out[0]
     I.final = final
     return I
+
+
+def ra_claim(lookup_indices, log_K, point):
+    """ra(r_address | r_cycle) of the one-hot read-address polynomial of the lookups (point = log_K address coordinates, then log_T cycle ones)"""
+    idx = np.ascontiguousarray(lookup_indices, dtype=np.uint64)
+    pt = np.ascontiguousarray(point, dtype=np.uint64)
+    log_T = len(pt) - log_K
+    assert len(idx) == 1 << log_T
+    out = orc.fr_array(1)
+    orc.lib.orc_ra_claim(idx.ctypes.data_as(C.c_void_p), C.c_size_t(log_T), C.c_size_t(log_K), orc._p(pt[:log_K].copy()), orc._p(pt[log_K:].copy()), orc._p(out))
+    return out[0]

@@ -106,3 +106,25 @@ void orc_shout_inst_ingest(orc_shout_inst *S, const fr_t *r) {                  
     S->num_bound++; S->len /= 2;
 }
 void orc_shout_inst_final(const orc_shout_inst *S, fr_t *out) { *out = S->G[0]; }
+
+/* the one-hot read-address polynomial of T lookups at (r_address | r_cycle):  sum_j eq(r_cycle, j) prod_i (bit_i(idx_j) ? r_i : 1 - r_i),
+ * r_address[0] <-> the most significant of the log_K index bits (what a read-raf prover's cache_openings appends as its ra claim) */
+void orc_ra_claim(const uint64_t *idx, size_t log_T, size_t log_K, const fr_t *r_address, const fr_t *r_cycle, fr_t *out) {
+    const size_t T = (size_t)1 << log_T;
+    fr_t *E = (fr_t *)malloc(T * sizeof(fr_t));
+    orc_eq_evals(r_cycle, log_T, 0, E);
+    fr_t one, *nr = (fr_t *)malloc((log_K ? log_K : 1) * sizeof(fr_t));
+    fr_from_u64(1, &one);
+    for (size_t i = 0; i < log_K; i++) fr_sub(&one, &r_address[i], &nr[i]);
+    fr_t acc; fr_zero(&acc);
+    for (size_t j = 0; j < T; j++) {
+        fr_t w = E[j];
+        for (size_t i = 0; i < log_K; i++) {
+            const int bit = (int)((idx[j] >> (log_K - 1 - i)) & 1);
+            fr_mul(&w, bit ? &r_address[i] : &nr[i], &w);
+        }
+        fr_add(&acc, &w, &acc);
+    }
+    *out = acc;
+    free(E); free(nr);
+}

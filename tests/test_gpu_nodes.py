@@ -75,7 +75,7 @@ def _onehot_checks(orc, OR, OB, t, lookups, log_T, log_K, r_cycle, ra_point, ra_
     ra_rs = np.ascontiguousarray(rs[mr - log_T:][::-1])
     for i in range(d):                                                   # RaVirtual: MLE of the gathered rows at the reversed challenges
         F = orc.eq_evals(chunks[i])
-        c = orc.evaluate(np.stack([F[k] for k in H[i]]), ra_rs)
+        c = orc.evaluate(np.ascontiguousarray(F[H[i]]), ra_rs)
         _append(orc, t, c); claims.append(c)
     hw_rs = np.ascontiguousarray(rs[mr - lkc:][::-1])
     for i in range(d):                                                   # HammingWeight: G_i at the reversed challenges
@@ -84,19 +84,31 @@ def _onehot_checks(orc, OR, OB, t, lookups, log_T, log_K, r_cycle, ra_point, ra_
     ba = np.ascontiguousarray(rs[:lkc][::-1]); bc = np.ascontiguousarray(rs[lkc:][::-1])
     Fb = orc.eq_evals(ba)
     for i in range(d):                                                   # Booleanity: H_i = eq(rho_address, idx_i(t)) at the reversed cycle challenges
-        c = orc.evaluate(np.stack([Fb[k] for k in H[i]]), bc)
+        c = orc.evaluate(np.ascontiguousarray(Fb[H[i]]), bc)
         _append(orc, t, c); claims.append(c)
     return rows
 
 
-@pytest.mark.parametrize("m,k,n,S", [(2, 8, 16, 6), (4, 4, 4, 4), (1, 16, 32, 7)])
+def _fr_ints(orc, v):
+    """Fr images of an integer vector: small values through the oracle's own i32 conversion, anything wider through Python integers"""
+    v = np.asarray(v)
+    if len(v) and np.abs(v.astype(np.int64)).max() < (1 << 31):
+        from oracle import graph as OG
+        return OG.fr_fast(v.astype(np.int32))
+    return orc.from_ints([int(x) % FR for x in v])
+
+
+# the last two cases are the sizes bench.py times (T = 2^12 and the GPT-2 MLP projection 16 x 1024 . 1024 x 4096, T = 2^16, scale 2^14): the
+# k-sliced accumulation kernel with 64-bit atomics, k_ra_prod_f9 / _col at d = 16, the 96 KB-LDS Q build of the 64-bit clamp lookup
+@pytest.mark.parametrize("m,k,n,S", [(2, 8, 16, 6), (4, 4, 4, 4), (1, 16, 32, 7), (4, 64, 1024, 14), (16, 1024, 4096, 14)])
 def test_einsum_node_matches_oracle_composition(atlas, m, k, n, S):
     from oracle import orc, orc_ra as OR, orc_batched as OB
     from jolt_atlas_amd import node
     A_ = atlas
     rng = np.random.default_rng(m * 100 + k)
-    A = rng.integers(-(1 << 6), 1 << 6, size=(m, k), dtype=np.int64).astype(np.int32)
-    B = rng.integers(-(1 << 6), 1 << 6, size=(k, n), dtype=np.int64).astype(np.int32)
+    lim = 1 << (6 if S < 14 else 14)                                   # bench size: activations and weights at scale 2^14
+    A = rng.integers(-lim, lim, size=(m, k), dtype=np.int64).astype(np.int32)
+    B = rng.integers(-lim, lim, size=(k, n), dtype=np.int64).astype(np.int32)
     T = m * n; log_T = T.bit_length() - 1; log_m = m.bit_length() - 1
     acc = (A.astype(np.int64) @ B.astype(np.int64)).reshape(-1)
     quot = acc >> S
@@ -104,7 +116,7 @@ def test_einsum_node_matches_oracle_composition(atlas, m, k, n, S):
     assert ((rem >= 0) & (rem < (1 << S))).all()
     outv = np.clip(quot, -(1 << 31), (1 << 31) - 1)
     r0 = orc.random_fr(log_T, 77)
-    f = lambda v: orc.from_ints([int(x) % FR for x in v])
+    f = lambda v: _fr_ints(orc, v)
     eval_R, acc_claim, out_claim = orc.evaluate(f(rem), r0), orc.evaluate(f(quot), r0), orc.evaluate(f(outv), r0)
     claims = []
     t = orc.new_transcript(b"einsum_node")
@@ -116,13 +128,19 @@ def test_einsum_node_matches_oracle_composition(atlas, m, k, n, S):
     rows_exec, ch = OR.ps_clamp(cidx, 64, 31, True, r0, gamma).prove(exec_claim, t)
     rs = orc.challenges_to_fr(ch)
     ra_point = np.concatenate([rs[:64], rs[64:][::-1]])
-    ra_claim = orc.evaluate(np.stack([_eq_bits(orc, ra_point[:64], v, 64) for v in cidx]), np.ascontiguousarray(ra_point[64:]))
+    ra_claim = OR.ra_claim(cidx, 64, ra_point)
     _append(orc, t, ra_claim); claims.append(ra_claim)
     rows_oh = _onehot_checks(orc, OR, OB, t, cidx, log_T, 64, r0, ra_point, ra_claim, claims)
     # matmul
     eq_m, eq_n = orc.eq_evals(np.ascontiguousarray(r0[:log_m])) if log_m else orc.from_ints([1]), orc.eq_evals(np.ascontiguousarray(r0[log_m:]))
-    left = np.stack([sum_fr(orc, [orc.fr_mul_arr(f([A[i, l]])[0], eq_m[i]) for i in range(m)]) for l in range(k)])
-    right = np.stack([sum_fr(orc, [orc.fr_mul_arr(f([B[l, j]])[0], eq_n[j]) for j in range(n)]) for l in range(k)])
+    if m * k + k * n <= 4096:
+        left = np.stack([sum_fr(orc, [orc.fr_mul_arr(f([A[i, l]])[0], eq_m[i]) for i in range(m)]) for l in range(k)])
+        right = np.stack([sum_fr(orc, [orc.fr_mul_arr(f([B[l, j]])[0], eq_n[j]) for j in range(n)]) for l in range(k)])
+    else:                                                            # MkKnMnLayout::fold through the oracle's C statement (pinned against the loop above at the small sizes)
+        left, right = orc.fr_array(k), orc.fr_array(k)
+        Ac, Bc = np.ascontiguousarray(A), np.ascontiguousarray(B)
+        orc.lib.orc_fold_i32_cols(Ac.ctypes.data_as(C.c_void_p), C.c_size_t(m), C.c_size_t(k), orc._p(eq_m), orc._p(left))
+        orc.lib.orc_fold_i32_rows(Bc.ctypes.data_as(C.c_void_p), C.c_size_t(k), C.c_size_t(n), orc._p(eq_n), orc._p(right))
     in_claim = orc.fr_add_arr(orc.fr_mul_arr(acc_claim, f([1 << S])[0]), eval_R)
     assert np.array_equal(orc.dot_claim(left, right)[0], in_claim)          # acc(r0) = rescaled(r0) 2^S + R(r0)
     proof_mm, ch_mm, fin_mm = orc.sumcheck_dot_prove(left, right, in_claim.reshape(1, 4), t)
@@ -134,7 +152,7 @@ def test_einsum_node_matches_oracle_composition(atlas, m, k, n, S):
     rows_rc, ch = OR.ps_identity(ridx, S, phases, r0).prove(eval_R, t)
     rs = orc.challenges_to_fr(ch)
     rr_point = np.concatenate([rs[:S], rs[S:][::-1]])
-    rr_claim = orc.evaluate(np.stack([_eq_bits(orc, rr_point[:S], v, S) for v in ridx]), np.ascontiguousarray(rr_point[S:]))
+    rr_claim = OR.ra_claim(ridx, S, rr_point)
     _append(orc, t, rr_claim); claims.append(rr_claim)
     rows_oh2 = _onehot_checks(orc, OR, OB, t, ridx, log_T, S, r0, rr_point, rr_claim, claims)
     # ---- device
@@ -157,7 +175,7 @@ def sum_fr(orc, xs):
     return s
 
 
-@pytest.mark.parametrize("log_T", [3, 6, 9])
+@pytest.mark.parametrize("log_T", [3, 6, 9, 12, 16])
 def test_relu_node_matches_oracle_composition(atlas, log_T):
     """ReLU::prove (ops/relu.rs:22-70) through atlas_prove_relu_node against the same composition over the oracle's instances:
     operand claim appended, gamma, PS-Shout over ReluTable<32>, its ra opening, the batched one-hot checks and their claims."""
@@ -169,7 +187,7 @@ def test_relu_node_matches_oracle_composition(atlas, log_T):
     x[0] = -(1 << 31); x[-1] = (1 << 31) - 1                                  # extremes of the i32 range
     out = np.maximum(x, 0)
     r0 = orc.random_fr(log_T, 99)
-    f = lambda v: orc.from_ints([int(z) % FR for z in v])
+    f = lambda v: _fr_ints(orc, v)
     operand_claim, out_claim = orc.evaluate(f(x), r0), orc.evaluate(f(out), r0)
     claims = []
     t = orc.new_transcript(b"relu_node")
@@ -180,7 +198,7 @@ def test_relu_node_matches_oracle_composition(atlas, log_T):
     rows_exec, ch = OR.ps_relu(idx, 32, r0, gamma).prove(exec_claim, t)
     rs = orc.challenges_to_fr(ch)
     ra_point = np.concatenate([rs[:32], rs[32:][::-1]])
-    ra_claim = orc.evaluate(np.stack([_eq_bits(orc, ra_point[:32], v, 32) for v in idx]), np.ascontiguousarray(ra_point[32:]))
+    ra_claim = OR.ra_claim(idx, 32, ra_point)
     _append(orc, t, ra_claim); claims.append(ra_claim)
     rows_oh = _onehot_checks(orc, OR, OB, t, idx, log_T, 32, r0, ra_point, ra_claim, claims)
     tX = atlas.TensorI32(x)
@@ -204,7 +222,7 @@ def _fused_rescale_oracle(orc, OR, OB, label, acc, S, r0, inner):
     quot = acc >> S
     rem = acc - (quot << S)
     outv = np.clip(quot, -(1 << 31), (1 << 31) - 1)
-    f = lambda v: orc.from_ints([int(x) % FR for x in v])
+    f = lambda v: _fr_ints(orc, v)
     eval_R, acc_claim, out_claim = orc.evaluate(f(rem), r0), orc.evaluate(f(quot), r0), orc.evaluate(f(outv), r0)
     claims = []
     t = orc.new_transcript(label)
@@ -216,7 +234,7 @@ def _fused_rescale_oracle(orc, OR, OB, label, acc, S, r0, inner):
     rows_exec, ch = OR.ps_clamp(cidx, 64, 31, True, r0, gamma).prove(exec_claim, t)
     rs = orc.challenges_to_fr(ch)
     ra_point = np.concatenate([rs[:64], rs[64:][::-1]])
-    ra_claim = orc.evaluate(np.stack([_eq_bits(orc, ra_point[:64], v, 64) for v in cidx]), np.ascontiguousarray(ra_point[64:]))
+    ra_claim = OR.ra_claim(cidx, 64, ra_point)
     _append(orc, t, ra_claim); claims.append(ra_claim)
     rows_oh = _onehot_checks(orc, OR, OB, t, cidx, log_T, 64, r0, ra_point, ra_claim, claims)
     in_claim = orc.fr_add_arr(orc.fr_mul_arr(acc_claim, f([1 << S])[0]), eval_R)
@@ -226,13 +244,13 @@ def _fused_rescale_oracle(orc, OR, OB, label, acc, S, r0, inner):
     rows_rc, ch = OR.ps_identity(ridx, S, phases, r0).prove(eval_R, t)
     rs = orc.challenges_to_fr(ch)
     rr_point = np.concatenate([rs[:S], rs[S:][::-1]])
-    rr_claim = orc.evaluate(np.stack([_eq_bits(orc, rr_point[:S], v, S) for v in ridx]), np.ascontiguousarray(rr_point[S:]))
+    rr_claim = OR.ra_claim(ridx, S, rr_point)
     _append(orc, t, rr_claim); claims.append(rr_claim)
     rows_oh2 = _onehot_checks(orc, OR, OB, t, ridx, log_T, S, r0, rr_point, rr_claim, claims)
     return [rows_exec, rows_oh, rows_inner, rows_rc, rows_oh2], claims, t
 
 
-@pytest.mark.parametrize("log_T,S", [(3, 5), (6, 7), (8, 4)])
+@pytest.mark.parametrize("log_T,S", [(3, 5), (6, 7), (8, 4), (12, 14), (16, 14)])
 def test_mul_node_matches_oracle_composition(atlas, log_T, S):
     """Mul::prove with fused rescaling (ops/mul.rs via impl_fused_rescale_proof_api) through atlas_prove_mul_node against the
     same composition over the oracle's instances: MulProver between prove_pre and prove_remainder_rc."""
@@ -240,11 +258,12 @@ def test_mul_node_matches_oracle_composition(atlas, log_T, S):
     from jolt_atlas_amd import node
     T = 1 << log_T
     rng = np.random.default_rng(100 + log_T)
-    L = rng.integers(-(1 << 9), 1 << 9, size=T, dtype=np.int64).astype(np.int32)
-    R = rng.integers(-(1 << 9), 1 << 9, size=T, dtype=np.int64).astype(np.int32)
+    lim = 1 << (9 if S < 14 else 15)
+    L = rng.integers(-lim, lim, size=T, dtype=np.int64).astype(np.int32)
+    R = rng.integers(-lim, lim, size=T, dtype=np.int64).astype(np.int32)
     acc = L.astype(np.int64) * R.astype(np.int64)
     r0 = orc.random_fr(log_T, 55)
-    f = lambda v: orc.from_ints([int(x) % FR for x in v])
+    f = lambda v: _fr_ints(orc, v)
 
     def inner(t, in_claim, claims):
         o = OR.elementwise(5, [f(L), f(R)], r0)                      # ATLAS_EW_MUL = MulProver
@@ -324,7 +343,7 @@ def test_addsub_node_matches_oracle_composition(atlas, log_T, subtract):
     rows_exec, ch = OR.ps_clamp(cidx, 64, 31, True, r0, gamma).prove(exec_claim, t)
     rs = orc.challenges_to_fr(ch)
     ra_point = np.concatenate([rs[:64], rs[64:][::-1]])
-    ra_claim = orc.evaluate(np.stack([_eq_bits(orc, ra_point[:64], v, 64) for v in cidx]), np.ascontiguousarray(ra_point[64:]))
+    ra_claim = OR.ra_claim(cidx, 64, ra_point)
     _append(orc, t, ra_claim); claims.append(ra_claim)
     rows_oh = _onehot_checks(orc, OR, OB, t, cidx, log_T, 64, r0, ra_point, ra_claim, claims)
     for c in (orc.evaluate(f(L), r0), orc.evaluate(f(R), r0)):

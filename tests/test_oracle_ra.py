@@ -417,3 +417,42 @@ def test_mean_of_squares_is_the_dot_prover_with_eq_high(log_retained, log_reduce
     assert [orc.to_ints(row) for row in proof] == rows_p
     assert bytes(to.state_bytes()) == tp.state
     assert orc.to_ints(fin[:1]) == model.finals()[:1]
+
+
+def test_ra_claim_helper_matches_bit_products():
+    """orc_ra_claim (the C shortcut the bench-size node tests use) against the definition: sum_j eq(r_cycle, j) prod_i (bit_i ? r_i : 1 - r_i)"""
+    from oracle import graph as OG
+    rng = np.random.default_rng(9)
+    for log_K, log_T in ((14, 5), (32, 3), (64, 4), (9, 6)):
+        idx = rng.integers(0, 1 << min(log_K, 62), size=1 << log_T).astype(np.uint64)
+        if log_K == 64:
+            idx |= np.uint64(1) << np.uint64(63)
+        pt = orc.random_fr(log_K + log_T, 40 + log_K)
+        want = orc.evaluate(np.stack([OG.eq_bits(pt[:log_K], v, log_K) for v in idx]), np.ascontiguousarray(pt[log_K:]))
+        assert np.array_equal(OR.ra_claim(idx, log_K, pt), want)
+
+
+def test_shout_batch_member_matches_standalone_prover():
+    """the dense Shout ReadRafProver as an instance (orc_shout_inst_*, a member of the softmax stage-3 batch) against the reference's
+    three-polynomial loop run on its own (orc_sumcheck_readraf_prove)"""
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    log_K, log_T = 5, 6
+    K, T = 1 << log_K, 1 << log_T
+    idx = rng.integers(0, K, size=T).astype(np.uint64)
+    table = rng.integers(-1000, 1000, size=K).astype(np.int32)
+    r = orc.random_fr(log_T, 3); gamma = orc.random_fr(1, 4)[0]
+    E = orc.eq_evals(r)
+    G = orc.fr_array(K)
+    orc.lib.orc_shout_G(idx.ctypes.data_as(C.c_void_p), C.c_size_t(T), C.c_size_t(log_K), orc._p(E), orc._p(G))
+    claim = orc.fr_array(1)
+    orc.lib.orc_readraf_claim(orc._p(G), table.ctypes.data_as(C.c_void_p), C.c_size_t(log_K), orc._p(gamma.reshape(1, 4)), orc._p(claim))
+    t1 = orc.new_transcript(b"shout"); t2 = orc.new_transcript(b"shout")
+    proof = orc.fr_array(2 * log_K); ch = np.zeros(2 * log_K, dtype=np.uint64); fin = orc.fr_array(1)
+    orc.lib.orc_sumcheck_readraf_prove(orc._p(G.copy()), table.ctypes.data_as(C.c_void_p), C.c_size_t(log_K), orc._p(gamma.reshape(1, 4)), orc._p(claim),
+                                       C.byref(t1), orc._p(proof), orc._p(ch), orc._p(fin))
+    I = OR.shout_read_raf(idx, table, log_K, r, gamma)
+    rows, ch2 = I.prove(claim[0], t2)
+    assert np.array_equal(np.concatenate(rows), proof)
+    assert t1.state_bytes() == t2.state_bytes()
+    assert np.array_equal(I.final(), fin[0])
