@@ -526,6 +526,12 @@ typedef struct {
     size_t log_K, log_T;      /* one-hot */
     const atlas_fr_t *point;  /* dense: n Fr; one-hot: r_address (log_K) followed by r_cycle (log_T) */
     atlas_fr_t claim;         /* the opening claim P(point) */
+    /* one-hot, instead of `k` (k == NULL): the T device-resident lookup indices the chunk polynomial was committed from
+     * (atlas_commit_lookup_chunks) and its shift: nonzero index = (d_lookups[t] >> chunk_shift) & (2^log_K - 1)
+     * (OneHotParams::lookup_index_chunk, config.rs:73-75).  When EVERY one-hot opening of the call is given this way (log_K <= 4)
+     * they are stepped together: one fold / bind launch and one synchronisation per round for all of them. */
+    const uint64_t *d_lookups;
+    size_t chunk_shift;
 } atlas_opening_t;
 int atlas_prove_reduced_openings(const atlas_opening_t *openings, size_t n_openings, atlas_srs_t srs,
                                  atlas_transcript_t *transcript, atlas_fr_t *sumcheck_rows, uint32_t *n_coeffs,

@@ -1088,31 +1088,18 @@ struct Prover : FlowSink {
         (void)ms_sumcheck_and_open;
         if (committed.empty()) return ATLAS_OK;
         std::vector<atlas_opening_t> ops;
-        std::vector<std::vector<int32_t>> rows;                               // one-hot index rows on the host (the opening instances take them there)
-        std::map<const uint64_t*, std::vector<uint64_t>> host_lookups;
-        for (auto& kv : committed) {
+        for (auto& kv : committed) {                                          // BTreeMap<CommittedPoly> order; the one-hot chunks stay on the device (lookups + shift)
             gr::Committed& c = *kv.second;
             if (!c.opened) return fail(ATLAS_ESTATE, "prove_graph: a committed polynomial was never opened");
             atlas_opening_t O; std::memset(&O, 0, sizeof(O));
             O.kind = c.kind; O.point = (const atlas_fr_t*)c.point.data(); std::memcpy(&O.claim, &c.claim, 32);
             if (c.kind == 1) {
-                const size_t T = (size_t)1 << c.log_T;
-                auto& hl = host_lookups[c.d_lookups];
-                if (hl.empty()) {
-                    hl.resize(T);
-                    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
-                    HIP_TRY(hipMemcpyAsync(hl.data(), c.d_lookups, T * 8, hipMemcpyDeviceToHost, g.stream));
-                    HIP_TRY(hipStreamSynchronize(g.stream));
-                }
-                const size_t d = (c.log_K + 3) / 4, shift = 4 * (d - 1 - c.chunk);                     // OneHotParams::lookup_index_chunk
-                rows.emplace_back(T);
-                for (size_t j = 0; j < T; j++) rows.back()[j] = (int32_t)((hl[j] >> shift) & 15);
+                const size_t d = (c.log_K + 3) / 4;
+                O.d_lookups = c.d_lookups; O.chunk_shift = 4 * (d - 1 - c.chunk);                                          // OneHotParams::lookup_index_chunk
                 O.log_K = 4; O.log_T = c.log_T;
             } else { O.poly = c.dense; O.n = c.log_T; }
             ops.push_back(O);
         }
-        size_t ri = 0;
-        for (auto& O : ops) if (O.kind == 1) O.k = rows[ri++].data();
         size_t maxr = 0;
         for (auto& O : ops) { const size_t n = O.kind ? O.log_K + O.log_T : O.n; maxr = n > maxr ? n : maxr; }
         ro.rows.resize(maxr * 3); ro.nco.resize(maxr); ro.ch.resize(maxr); ro.claims.resize(ops.size());

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include "../../include/atlas_hip.h"
@@ -26,6 +27,8 @@ using namespace atlas;
 namespace H = atlas_host;
 using atlas_rt::fail;
 using atlas_rt::g;
+
+int atlas_rt_eq_evals_into(const H::Fr* r, size_t n, Fr* ev);      // spliteq.hip
 
 namespace {
 
@@ -482,7 +485,394 @@ struct OneHotRow : atlas_instance {
     }
 };
 
+// ---------------------------------------------------------------- every one-hot opening of a proof in one set of launches
+// prove_reduced_openings of a model graph registers thousands of one-hot chunk polynomials (nanoGPT: ~3000, in ~400 groups of
+// equal r_cycle); stepping the groups one by one is ~400 fold + reduce + copy + synchronise per round (207 ms of a 1.25 s proof).
+// OneHotPool steps ALL of them together: per global round ONE fold launch over every row in its cycle phase (a row descriptor
+// carries its current half length and its group's split-eq tables), one reduction, one copy and one synchronisation; one bind
+// launch; one gather launch for the rows whose address phase ends.  The rows come straight from the device-resident lookup
+// indices of the node witnesses (nonzero index = (lookup >> shift) & (K - 1)): no host rows, no uploads.
+// Rows of fewer rounds start later (front-loaded batching, sumcheck.rs:30-184): row r takes part in global rounds
+// [max_rounds - rounds(r), max_rounds).
+struct PoolRowDev {
+    Fr* H; const int32_t* idx; const Fr* aux;        // aux: fold: unused; gather: the row's F table (K Fr)
+    const Fr *e_out, *e_in;
+    uint32_t half, in_bits, slot, T;
+};
+constexpr unsigned POOL_GX = 32;                     // workgroups along a row (a row of 2^14 entries: 8192 pairs = 32 x 256)
+__global__ __launch_bounds__(OP_THREADS) void k_pool_chunk_rows(const uint64_t* const* __restrict__ lookups, const uint32_t* __restrict__ shift,
+                                                                const uint64_t* __restrict__ off, const uint32_t* __restrict__ Ts, uint32_t mask,
+                                                                int32_t* __restrict__ idx) {
+    const size_t r = blockIdx.y;
+    const uint64_t* lk = lookups[r];
+    int32_t* o = idx + off[r];
+    const uint32_t sh = shift[r], T = Ts[r];
+    for (size_t j = (size_t)blockIdx.x * OP_THREADS + threadIdx.x; j < T; j += (size_t)gridDim.x * OP_THREADS)
+        o[j] = (int32_t)(sh >= 64 ? 0 : ((lk[j] >> sh) & mask));
+}
+// G[r][k] = sum_{j : idx_r[j] = k} E_g(r)[j] as 64-bit sums of the eight 32-bit words of the (Montgomery) residues per bin, K <= 16
+__global__ __launch_bounds__(OP_THREADS) void k_pool_hist(const int32_t* __restrict__ idx, const uint64_t* __restrict__ off, const uint32_t* __restrict__ Ts,
+                                                          const Fr* const* __restrict__ E, uint32_t K, unsigned long long* __restrict__ out /* [rows][K][8] */) {
+    __shared__ unsigned long long acc[16 * 8];
+    const size_t r = blockIdx.x;
+    for (uint32_t i = threadIdx.x; i < 16 * 8; i += OP_THREADS) acc[i] = 0;
+    __syncthreads();
+    const int32_t* ix = idx + off[r];
+    const Fr* e = E[r];
+    const uint32_t T = Ts[r];
+    for (uint32_t j = threadIdx.x; j < T; j += OP_THREADS) {
+        const Fr v = fe_load(e + j);
+        const int32_t k = ix[j];
+#pragma unroll
+        for (int w = 0; w < 8; w++) atomicAdd(&acc[k * 8 + w], (unsigned long long)v.v[w]);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < K * 8; i += OP_THREADS) out[r * 16 * 8 + i] = acc[i];
+}
+__global__ __launch_bounds__(OP_THREADS) void k_pool_gather(const PoolRowDev* __restrict__ rows) {
+    const PoolRowDev R = rows[blockIdx.y];
+    for (size_t j = (size_t)blockIdx.x * OP_THREADS + threadIdx.x; j < R.T; j += (size_t)gridDim.x * OP_THREADS) fe_store(R.H + j, fe_load(R.aux + R.idx[j]));
+}
+__global__ __launch_bounds__(OP_THREADS) void k_pool_fold(const PoolRowDev* __restrict__ rows, Fr* __restrict__ partials /* [rows][POOL_GX] */) {
+    const PoolRowDev R = rows[blockIdx.y];
+    Fr acc[1];
+    acc[0] = fe_zero();
+    const size_t mask = ((size_t)1 << R.in_bits) - 1;
+    for (size_t j = (size_t)blockIdx.x * OP_THREADS + threadIdx.x; j < R.half; j += (size_t)gridDim.x * OP_THREADS) {
+        const Fr w = fr_mul(fe_load(R.e_out + (j >> R.in_bits)), fe_load(R.e_in + (j & mask)));
+        acc[0] = fr_add(acc[0], fr_mul(w, fe_load(R.H + j)));
+    }
+    block_reduce_store<1>(acc, partials + (size_t)R.slot * gridDim.x);
+}
+__global__ __launch_bounds__(64) void k_pool_reduce(const Fr* __restrict__ partials, uint32_t gx, Fr* __restrict__ out) {
+    Fr acc = fe_zero();
+    for (uint32_t i = threadIdx.x; i < gx; i += 64) acc = fr_add(acc, fe_load(partials + (size_t)blockIdx.x * gx + i));
+    acc = fr_wave_sum(acc);
+    if (threadIdx.x == 0) fe_store(out + blockIdx.x, acc);
+}
+__global__ __launch_bounds__(OP_THREADS) void k_pool_bind(const PoolRowDev* __restrict__ rows, Fr r, int r_hi_only) {
+    const PoolRowDev R = rows[blockIdx.y];
+    for (size_t i = (size_t)blockIdx.x * OP_THREADS + threadIdx.x; i < R.half; i += (size_t)gridDim.x * OP_THREADS)
+        fe_store(R.H + i, bind_pair(fe_load(R.H + i), fe_load(R.H + i + R.half), r, r_hi_only != 0));
+}
+__global__ __launch_bounds__(OP_THREADS) void k_pool_heads(const Fr* __restrict__ H, const uint64_t* __restrict__ off, uint32_t n, Fr* __restrict__ out) {
+    for (uint32_t r = blockIdx.x * OP_THREADS + threadIdx.x; r < n; r += gridDim.x * OP_THREADS) fe_store(out + r, fe_load(H + off[r]));
+}
+
+struct OneHotPool {
+    size_t log_K = 0, K = 0, max_rounds = 0, refs = 0;
+    struct Group { size_t log_T = 0, T = 0, off = 0; H::GseStateH st; Fr *d_ein = nullptr, *d_eout = nullptr; std::vector<size_t> rows; H::Fr inv_eq1; size_t inv_round = (size_t)-1; };
+    struct Row { size_t group = 0; uint64_t off = 0; std::vector<H::Fr> B, F, G; H::Fr eqa_inv, q0, fin; bool gathered = false; };
+    std::vector<Group> groups;
+    std::vector<Row> rows;
+    // device: the rows' index vectors and H vectors back to back, the groups' split-eq tables, scratch
+    int32_t* d_idx = nullptr;
+    Fr *d_H = nullptr, *d_tabs = nullptr, *d_part = nullptr, *d_q0 = nullptr, *d_F = nullptr;
+    uint64_t* d_off = nullptr;
+    PoolRowDev *d_desc = nullptr, *h_desc = nullptr;       // h_desc: pinned staging, three regions of rows.size() descriptors (fold, bind, gather)
+    Fr* h_q0 = nullptr;                                     // pinned
+    size_t folded = (size_t)-1, bound = (size_t)-1;         // global rounds already folded / bound
+    bool have_finals = false;
+    ~OneHotPool() {
+        for (void* p : {(void*)d_idx, (void*)d_H, (void*)d_tabs, (void*)d_part, (void*)d_q0, (void*)d_F, (void*)d_off, (void*)d_desc}) if (p) hipFree(p);
+        if (h_desc) (void)hipHostFree(h_desc);
+        if (h_q0) (void)hipHostFree(h_q0);
+    }
+    size_t row_rounds(const Row& r) const { return log_K + groups[r.group].log_T; }
+    size_t row_off(const Row& r) const { return max_rounds - row_rounds(r); }
+    // cycle round of group g at global round R, or -1
+    long cycle_of(const Group& G, size_t R) const { const long c = (long)R - (long)(max_rounds - (log_K + G.log_T)) - (long)log_K; return c >= 0 && c < (long)G.log_T ? c : -1; }
+    SplitEqView view(const Group& G) const {
+        SplitEqView E;
+        E.e_out = G.d_ein + (((size_t)1 << G.st.in_top) - 1);
+        E.e_in = G.d_eout + (((size_t)1 << G.st.out_top) - 1);
+        E.in_bits = (uint32_t)G.st.out_top;
+        return E;
+    }
+    // the caller holds g.mu.  H = F[idx] for the rows whose address phase ended in the round before R (their ingests have all run)
+    int gather_pending(size_t R) {
+        std::vector<size_t> todo;
+        for (auto& G : groups) if (cycle_of(G, R) == 0) for (size_t r : G.rows) if (!rows[r].gathered) todo.push_back(r);
+        if (todo.empty()) return ATLAS_OK;
+        std::vector<H::Fr> Fh(todo.size() * K), b0(todo.size());
+        PoolRowDev* hd = h_desc + 2 * rows.size();
+        for (size_t q = 0; q < todo.size(); q++) {
+            Row& Rw = rows[todo[q]];
+            const Group& G = groups[Rw.group];
+            std::memcpy(&Fh[q * K], Rw.F.data(), K * sizeof(H::Fr));
+            b0[q] = Rw.B[0];
+            hd[q] = PoolRowDev{d_H + Rw.off, d_idx + Rw.off, d_F + q * K, nullptr, nullptr, 0, 0, 0, (uint32_t)G.T};
+            Rw.gathered = true; Rw.G.clear();
+        }
+        {   // eq(r_address, rho)^-1 of every row at once (Montgomery's trick: one inversion)
+            std::vector<H::Fr> pre(todo.size());
+            H::Fr acc = H::one();
+            for (size_t q = 0; q < todo.size(); q++) { pre[q] = acc; acc = H::mul(acc, b0[q]); }
+            H::Fr inv = H::inv(acc);
+            for (size_t q = todo.size(); q-- > 0;) { rows[todo[q]].eqa_inv = H::mul(inv, pre[q]); inv = H::mul(inv, b0[q]); }
+        }
+        size_t maxT = 0;
+        for (size_t r : todo) maxT = groups[rows[r].group].T > maxT ? groups[rows[r].group].T : maxT;
+        HIP_TRY(hipMemcpyAsync(d_F, Fh.data(), Fh.size() * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(hipMemcpyAsync(d_desc + 2 * rows.size(), hd, todo.size() * sizeof(PoolRowDev), hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));                 // Fh leaves scope (pageable source)
+        k_pool_gather<<<dim3(grid_for(maxT, POOL_GX), (unsigned)todo.size()), OP_THREADS, 0, g.stream>>>(d_desc + 2 * rows.size());
+        return ATLAS_OK;
+    }
+    int fold_all(size_t R) {
+        if (folded == R) return ATLAS_OK;
+        int rc = gather_pending(R);
+        if (rc) return rc;
+        size_t n = 0, max_half = 0;
+        for (auto& G : groups) {
+            const long c = cycle_of(G, R);
+            if (c < 0) continue;
+            const size_t half = G.T >> (c + 1);
+            const SplitEqView E = view(G);
+            for (size_t r : G.rows) { h_desc[n] = PoolRowDev{d_H + rows[r].off, nullptr, nullptr, E.e_out, E.e_in, (uint32_t)half, E.in_bits, (uint32_t)n, (uint32_t)G.T}; n++; }
+            max_half = half > max_half ? half : max_half;
+        }
+        folded = R;
+        if (n == 0) return ATLAS_OK;
+        const unsigned gx = grid_for(max_half, POOL_GX);
+        HIP_TRY(hipMemcpyAsync(d_desc, h_desc, n * sizeof(PoolRowDev), hipMemcpyHostToDevice, g.stream));
+        k_pool_fold<<<dim3(gx, (unsigned)n), OP_THREADS, 0, g.stream>>>(d_desc, d_part);
+        k_pool_reduce<<<(unsigned)n, 64, 0, g.stream>>>(d_part, gx, d_q0);
+        HIP_TRY(hipMemcpyAsync(h_q0, d_q0, n * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        n = 0;
+        for (auto& G : groups) {
+            if (cycle_of(G, R) < 0) continue;
+            for (size_t r : G.rows) std::memcpy(&rows[r].q0, &h_q0[n++], sizeof(Fr));
+            G.inv_eq1 = H::inv(H::mul(G.st.scalar, G.st.w_cur())); G.inv_round = R;        // shared by the rows of the group (gruen_poly_deg_2's division)
+        }
+        return ATLAS_OK;
+    }
+    int bind_all(size_t R, const H::Fr& rf) {
+        if (bound == R) return ATLAS_OK;
+        bound = R;
+        size_t n = 0, max_half = 0;
+        PoolRowDev* hd = h_desc + rows.size();
+        for (auto& G : groups) {
+            const long c = cycle_of(G, R);
+            if (c < 0) continue;
+            const size_t half = G.T >> (c + 1);
+            for (size_t r : G.rows) hd[n++] = PoolRowDev{d_H + rows[r].off, nullptr, nullptr, nullptr, nullptr, (uint32_t)half, 0, 0, (uint32_t)G.T};
+            max_half = half > max_half ? half : max_half;
+            G.st.bind(rf);
+        }
+        if (n == 0) return ATLAS_OK;
+        HIP_TRY(hipMemcpyAsync(d_desc + rows.size(), hd, n * sizeof(PoolRowDev), hipMemcpyHostToDevice, g.stream));
+        k_pool_bind<<<dim3(grid_for(max_half, POOL_GX), (unsigned)n), OP_THREADS, 0, g.stream>>>(d_desc + rows.size(), to_dev(rf), g.challenge_mode == 0 ? 1 : 0);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? ATLAS_OK : fail(ATLAS_ENODEV, "onehot pool bind", e);
+    }
+    int fetch_finals() {
+        if (have_finals) return ATLAS_OK;
+        const size_t n = rows.size();
+        k_pool_heads<<<grid_for(n, 64), OP_THREADS, 0, g.stream>>>(d_H, d_off, (uint32_t)n, d_q0);
+        std::vector<H::Fr> f(n);
+        HIP_TRY(hipMemcpyAsync(f.data(), d_q0, n * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        for (size_t r = 0; r < n; r++) rows[r].fin = f[r];
+        have_finals = true;
+        return ATLAS_OK;
+    }
+};
+
+struct OneHotPoolRow : atlas_instance {
+    OneHotPool* P = nullptr;
+    size_t row = 0, round_next = 0;
+    ~OneHotPoolRow() override { if (P && --P->refs == 0) delete P; }
+    size_t rounds() const override { return P->row_rounds(P->rows[row]); }
+    size_t degree() const override { return 2; }
+    int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
+        if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "onehot_opening: round out of order");
+        OneHotPool::Row& Rw = P->rows[row];
+        coeffs.assign(3, H::zero());
+        const size_t log_K = P->log_K, K = P->K;
+        if (round < log_K) {                                         // opening_reduction.rs:583-633
+            const size_t unbound = log_K - round, half = Rw.B.size() / 2;
+            H::Fr e0 = H::zero(), e2 = H::zero();
+            for (size_t kp = 0; kp < half; kp++) {
+                const H::Fr b0 = Rw.B[kp], b2 = H::add(Rw.B[kp + half], H::sub(Rw.B[kp + half], b0));
+                H::Fr s0 = H::zero(), s2 = H::zero();
+                for (size_t k = kp; k < K; k += half) {
+                    const H::Fr gf = H::mul(Rw.G[k], Rw.F[k >> unbound]);
+                    if (((k >> (unbound - 1)) & 1) == 0) { s0 = H::add(s0, gf); s2 = H::sub(s2, gf); }
+                    else s2 = H::add(s2, H::add(gf, gf));
+                }
+                e0 = H::add(e0, H::mul(b0, s0)); e2 = H::add(e2, H::mul(b2, s2));
+            }
+            const H::Fr ev[2] = {e0, e2};
+            H::unipoly_from_evals_and_hint(claim, ev, 2, coeffs.data());
+            return ATLAS_OK;
+        }
+        const size_t R = round + P->row_off(Rw);
+        {
+            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+            const int rc = P->fold_all(R);
+            if (rc) return rc;
+        }
+        // gruen_poly_deg_2 (split_eq_poly.rs:379-428) on claim / eq(r_address, rho), the division by eq(1) through the group's shared inverse
+        const OneHotPool::Group& G = P->groups[Rw.group];
+        const H::Fr eqa = Rw.B[0], cl = H::mul(claim, Rw.eqa_inv);
+        const H::Fr eq1 = H::mul(G.st.scalar, G.st.w_cur()), eq0 = H::sub(G.st.scalar, eq1), eqm = H::sub(eq1, eq0), eq2 = H::add(eq1, eqm);
+        const H::Fr c0 = H::mul(eq0, Rw.q0), c1 = H::sub(cl, c0);
+        const H::Fr l1 = H::mul(c1, G.inv_eq1), l2 = H::sub(H::add(l1, l1), Rw.q0);
+        const H::Fr ev[2] = {c0, H::mul(eq2, l2)};
+        H::unipoly_from_evals_and_hint(H::add(c0, c1), ev, 2, coeffs.data());
+        for (auto& c : coeffs) c = H::mul(c, eqa);                   // UniPoly * F -> from_coeff
+        H::trim(coeffs);
+        return ATLAS_OK;
+    }
+    int ingest(const atlas_u128_t& r, size_t round) override {      // :679-718
+        if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "onehot_opening: round out of order");
+        OneHotPool::Row& Rw = P->rows[row];
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        if (round < P->log_K) {
+            const size_t half = Rw.B.size() / 2;
+            for (size_t i = 0; i < half; i++) Rw.B[i] = H::add(Rw.B[i], H::mul(rf, H::sub(Rw.B[i + half], Rw.B[i])));
+            Rw.B.resize(half);
+            std::vector<H::Fr> nf(2 * Rw.F.size());                  // ExpandingTable::update, HighToLow
+            for (size_t i = 0; i < Rw.F.size(); i++) { nf[2 * i + 1] = H::mul(rf, Rw.F[i]); nf[2 * i] = H::sub(Rw.F[i], nf[2 * i + 1]); }
+            Rw.F.swap(nf);                                           // the gather H = F[idx] runs with the next round's fold (gather_pending)
+        } else {
+            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+            const int rc = P->bind_all(round + P->row_off(Rw), rf);
+            if (rc) return rc;
+        }
+        round_next++;
+        return ATLAS_OK;
+    }
+    int finals(std::vector<H::Fr>& out) override {
+        if (round_next != rounds()) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        const int rc = P->fetch_finals();
+        if (rc) return rc;
+        out.assign(1, P->rows[row].fin);
+        return ATLAS_OK;
+    }
+};
+
 }  // namespace
+
+// One-hot opening instances over device-resident lookup indices, stepped together (OneHotPool).  rows[i]: the T = 2^log_T lookups, the
+// chunk's shift, the opening point (log_K address coordinates, then log_T cycle ones).  batch_max_rounds: the round count of the whole
+// BatchedSumcheck the rows will sit in (>= log_K + the largest log_T).  d_idx_rows[i] (optional) receives the device int32 index row of
+// polynomial i, alive as long as any of the instances (for build_materialized_rlc).  Internal to the library (reduced_openings.hip).
+struct atlas_rt_pool_row { const uint64_t* d_lookups; size_t shift, log_T; const atlas_fr_t* point; };
+int atlas_rt_onehot_pool_new(const atlas_rt_pool_row* in, size_t n, size_t log_K, size_t batch_max_rounds, atlas_instance_t* out, const int32_t** d_idx_rows) {
+    if (!in || !out || n == 0 || log_K == 0 || log_K > 4) return fail(ATLAS_EINVAL, "onehot_pool_new: 1 <= log_K <= 4");
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::unique_ptr<OneHotPool> P(new OneHotPool());
+    P->log_K = log_K; P->K = (size_t)1 << log_K; P->max_rounds = batch_max_rounds;
+    P->rows.resize(n);
+    uint64_t total = 0;
+    size_t tab_total = 0, w_total = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!in[i].d_lookups || !in[i].point || in[i].log_T == 0 || in[i].log_T > 26 || log_K + in[i].log_T > batch_max_rounds) return fail(ATLAS_EINVAL, "onehot_pool_new: row");
+        const atlas_fr_t* rc_ = in[i].point + log_K;
+        size_t gi = P->groups.size();
+        for (size_t q = P->groups.size(); q-- > 0;) {             // same r_cycle -> same group (the rows of one lookup family arrive together)
+            OneHotPool::Group& G = P->groups[q];
+            if (G.log_T == in[i].log_T && std::memcmp(G.st.w.data(), rc_, G.log_T * 32) == 0) { gi = q; break; }
+            if (P->groups.size() - q > 8) break;
+        }
+        if (gi == P->groups.size()) {
+            P->groups.emplace_back();
+            OneHotPool::Group& G = P->groups.back();
+            G.log_T = in[i].log_T; G.T = (size_t)1 << G.log_T;
+            G.st.init(reinterpret_cast<const H::Fr*>(rc_), G.log_T);
+            if (G.st.k_in > 13 || G.st.k_out > 13) return fail(ATLAS_EINVAL, "onehot_pool_new: more than 26 cycle variables");
+            tab_total += ((size_t)2 << G.st.k_in) + ((size_t)2 << G.st.k_out); w_total += G.log_T;
+        }
+        P->groups[gi].rows.push_back(i);
+        OneHotPool::Row& R = P->rows[i];
+        R.group = gi; R.off = total; total += P->groups[gi].T;
+        R.B = H::eq_evals(reinterpret_cast<const H::Fr*>(in[i].point), log_K);     // EqAddressState::new
+        R.F = {H::one()};
+    }
+    const size_t NG = P->groups.size();
+    // device state
+    Fr *d_w = nullptr, *d_E = nullptr;
+    const uint64_t** d_lk = nullptr; uint32_t *d_shift = nullptr, *d_Ts = nullptr; const Fr** d_Eptr = nullptr; unsigned long long* d_hist = nullptr;
+    struct Tmp { std::vector<void*> v; ~Tmp() { for (void* p : v) if (p) hipFree(p); } } tmp;
+    auto tmalloc = [&](void** p, size_t bytes) { hipError_t e = hipMalloc(p, bytes); if (e == hipSuccess) tmp.v.push_back(*p); return e; };
+    size_t E_total = 0;
+    for (auto& G : P->groups) E_total += G.T;
+    HIP_TRY(hipMalloc(&P->d_idx, total * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&P->d_H, total * sizeof(Fr)));
+    HIP_TRY(hipMalloc(&P->d_tabs, tab_total * sizeof(Fr)));
+    HIP_TRY(hipMalloc(&P->d_part, n * POOL_GX * sizeof(Fr)));
+    HIP_TRY(hipMalloc(&P->d_q0, n * sizeof(Fr)));
+    HIP_TRY(hipMalloc(&P->d_F, n * P->K * sizeof(Fr)));
+    HIP_TRY(hipMalloc(&P->d_off, n * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc(&P->d_desc, 3 * n * sizeof(PoolRowDev)));
+    HIP_TRY(hipHostMalloc(&P->h_desc, 3 * n * sizeof(PoolRowDev), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&P->h_q0, n * sizeof(Fr), hipHostMallocDefault));
+    HIP_TRY(tmalloc((void**)&d_w, (w_total ? w_total : 1) * sizeof(Fr)));
+    HIP_TRY(tmalloc((void**)&d_E, E_total * sizeof(Fr)));
+    HIP_TRY(tmalloc((void**)&d_lk, n * sizeof(void*)));
+    HIP_TRY(tmalloc((void**)&d_shift, n * 4));
+    HIP_TRY(tmalloc((void**)&d_Ts, n * 4));
+    HIP_TRY(tmalloc((void**)&d_Eptr, n * sizeof(void*)));
+    HIP_TRY(tmalloc((void**)&d_hist, n * 16 * 8 * 8));
+    std::vector<H::Fr> w_all; w_all.reserve(w_total);
+    std::vector<const uint64_t*> lkp(n); std::vector<uint32_t> sh(n), Ts(n); std::vector<uint64_t> off(n); std::vector<const Fr*> Eptr(n);
+    std::vector<size_t> g_w(NG), g_E(NG);
+    {
+        size_t wo = 0, to = 0, eo = 0;
+        for (size_t q = 0; q < NG; q++) {
+            OneHotPool::Group& G = P->groups[q];
+            g_w[q] = wo; g_E[q] = eo;
+            w_all.insert(w_all.end(), G.st.w.begin(), G.st.w.end());
+            G.d_ein = P->d_tabs + to; to += (size_t)2 << G.st.k_in;
+            G.d_eout = P->d_tabs + to; to += (size_t)2 << G.st.k_out;
+            wo += G.log_T; eo += G.T;
+        }
+    }
+    size_t maxT = 0;
+    for (size_t i = 0; i < n; i++) {
+        const OneHotPool::Group& G = P->groups[P->rows[i].group];
+        lkp[i] = in[i].d_lookups; sh[i] = (uint32_t)in[i].shift; Ts[i] = (uint32_t)G.T; off[i] = P->rows[i].off; Eptr[i] = d_E + g_E[P->rows[i].group];
+        maxT = G.T > maxT ? G.T : maxT;
+    }
+    HIP_TRY(hipMemcpyAsync(d_w, w_all.data(), w_all.size() * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(d_lk, lkp.data(), n * sizeof(void*), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(d_shift, sh.data(), n * 4, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(d_Ts, Ts.data(), n * 4, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(P->d_off, off.data(), n * 8, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(d_Eptr, Eptr.data(), n * sizeof(void*), hipMemcpyHostToDevice, g.stream));
+    k_pool_chunk_rows<<<dim3(grid_for(maxT, POOL_GX), (unsigned)n), OP_THREADS, 0, g.stream>>>(d_lk, d_shift, P->d_off, d_Ts, (uint32_t)(P->K - 1), P->d_idx);
+    for (size_t q = 0; q < NG; q++) {
+        OneHotPool::Group& G = P->groups[q];
+        // the split-eq suffix tables (GseDevH::init) and D.merge() before any bind = EqPolynomial::evals(r_cycle) for the histogram
+        k_eq_cached_rev<<<1, 1024, 0, g.stream>>>(G.d_ein, d_w + g_w[q] + 1, (uint32_t)G.st.k_in);
+        k_eq_cached_rev<<<1, 1024, 0, g.stream>>>(G.d_eout, d_w + g_w[q] + 1 + G.st.k_in, (uint32_t)G.st.k_out);
+        int rc = atlas_rt_eq_evals_into(G.st.w.data(), G.log_T, d_E + g_E[q]);
+        if (rc) return rc;
+    }
+    k_pool_hist<<<(unsigned)n, OP_THREADS, 0, g.stream>>>(P->d_idx, P->d_off, d_Ts, d_Eptr, (uint32_t)P->K, d_hist);
+    std::vector<unsigned long long> hist(n * 16 * 8);
+    HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, hist.size() * 8, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    for (size_t i = 0; i < n; i++) {
+        OneHotPool::Row& R = P->rows[i];
+        R.G.resize(P->K);
+        for (size_t k = 0; k < P->K; k++) {
+            uint64_t acc[9];
+            for (int w = 0; w < 8; w++) acc[w] = hist[(i * 16 + k) * 8 + w];
+            acc[8] = 0;
+            R.G[k] = atlas_rt::sum_to_fr(acc, 32, 0);
+        }
+        if (d_idx_rows) d_idx_rows[i] = P->d_idx + R.off;
+    }
+    P->refs = n;
+    OneHotPool* raw = P.release();
+    for (size_t i = 0; i < n; i++) { OneHotPoolRow* I = new OneHotPoolRow(); I->P = raw; I->row = i; out[i] = I; }
+    return ATLAS_OK;
+}
 
 extern "C" {
 

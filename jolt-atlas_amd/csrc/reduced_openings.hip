@@ -21,6 +21,9 @@
 namespace H = atlas_host;
 using atlas_rt::fail;
 
+struct atlas_rt_pool_row { const uint64_t* d_lookups; size_t shift, log_T; const atlas_fr_t* point; };
+int atlas_rt_onehot_pool_new(const atlas_rt_pool_row* in, size_t n, size_t log_K, size_t batch_max_rounds, atlas_instance_t* out, const int32_t** d_idx_rows);   // opening.hip
+
 static double g_last_open_ms = 0;
 double atlas_rt_last_hyperkzg_ms() { return g_last_open_ms; }
 
@@ -55,6 +58,47 @@ extern "C" int atlas_prove_reduced_openings(const atlas_opening_t* openings, siz
     // one-hot openings with the same (log_K, log_T, r_cycle) share their cycle-phase launches (EqCycleState sharing,
     // opening_proof.rs:339-343)
     std::vector<char> done(n_open, 0);
+    // every one-hot opening over device-resident lookups, equal log_K <= 4: one pool, stepped together (opening.hip OneHotPool)
+    std::vector<const int32_t*> pool_idx(n_open, nullptr);
+    {
+        bool pool = getenv("ATLAS_NO_OPENING_POOL") == nullptr;
+        size_t n_oh = 0, lk = 0, batch_rounds = 0;
+        for (size_t i = 0; i < n_open; i++) {
+            const atlas_opening_t& O = openings[i];
+            const size_t nr = O.kind ? O.log_K + O.log_T : O.n;
+            batch_rounds = nr > batch_rounds ? nr : batch_rounds;
+            if (O.kind != 1) continue;
+            if (!O.d_lookups || O.k || !O.point || O.log_K > 4 || (n_oh && O.log_K != lk)) pool = false;
+            lk = O.log_K; n_oh++;
+        }
+        if (pool && n_oh) {
+            std::vector<atlas_rt_pool_row> rows; std::vector<size_t> where;
+            for (size_t i = 0; i < n_open; i++)
+                if (openings[i].kind == 1) { rows.push_back(atlas_rt_pool_row{openings[i].d_lookups, openings[i].chunk_shift, openings[i].log_T, openings[i].point}); where.push_back(i); }
+            std::vector<atlas_instance_t> pi(rows.size(), nullptr); std::vector<const int32_t*> px(rows.size(), nullptr);
+            rc = atlas_rt_onehot_pool_new(rows.data(), rows.size(), lk, batch_rounds, pi.data(), px.data());
+            for (size_t q = 0; q < rows.size() && !rc; q++) { inst[where[q]] = pi[q]; pool_idx[where[q]] = px[q]; done[where[q]] = 1; }
+        }
+    }
+    // openings given by device lookups outside the pool (mixed log_K, or ATLAS_NO_OPENING_POOL): their index rows on the host
+    std::vector<atlas_opening_t> local(openings, openings + n_open);
+    std::vector<std::vector<int32_t>> host_rows;
+    host_rows.reserve(n_open);
+    for (size_t i = 0; i < n_open && !rc; i++) {
+        atlas_opening_t& O = local[i];
+        if (O.kind != 1 || done[i] || O.k || !O.d_lookups) continue;
+        const size_t T = (size_t)1 << O.log_T;
+        std::vector<uint64_t> lk(T);
+        {
+            std::lock_guard<atlas_rt::Mutex> lkg(atlas_rt::g.mu);
+            HIP_TRY(hipMemcpyAsync(lk.data(), O.d_lookups, T * 8, hipMemcpyDeviceToHost, atlas_rt::g.stream));
+            HIP_TRY(hipStreamSynchronize(atlas_rt::g.stream));
+        }
+        host_rows.emplace_back(T);
+        for (size_t j = 0; j < T; j++) host_rows.back()[j] = (int32_t)(O.chunk_shift >= 64 ? 0 : ((lk[j] >> O.chunk_shift) & (((uint64_t)1 << O.log_K) - 1)));
+        O.k = host_rows.back().data();
+    }
+    openings = local.data();
     for (size_t i = 0; i < n_open && !rc; i++) {
         const atlas_opening_t& O = openings[i];
         if (O.kind == 0) {
@@ -110,7 +154,7 @@ extern "C" int atlas_prove_reduced_openings(const atlas_opening_t* openings, siz
         const atlas_opening_t& O = openings[i];
         if (O.kind == 0) { atlas_rlc_dense_t d; d.poly = O.poly; std::memcpy(&d.coeff, &gamma[i], 32); dense.push_back(d); }
         else {
-            atlas_rlc_onehot_t o; o.k = O.k; o.T = (size_t)1 << O.log_T; o.K = (size_t)1 << O.log_K; o.k_on_device = 0;
+            atlas_rlc_onehot_t o; o.k = pool_idx[i] ? pool_idx[i] : O.k; o.T = (size_t)1 << O.log_T; o.K = (size_t)1 << O.log_K; o.k_on_device = pool_idx[i] ? 1 : 0;
             std::memcpy(&o.coeff, &gamma[i], 32); onehot.push_back(o);
         }
     }

@@ -94,6 +94,24 @@ int eq_evals_device(const H::Fr* r, size_t n, const H::Fr* scaling, Fr** out) {
 
 }  // namespace
 
+// EqPolynomial::evals into a caller-provided device buffer of 2^n Fr (library stream; the caller holds g.mu): opening.hip's pool
+int atlas_rt_eq_evals_into(const H::Fr* r, size_t n, Fr* ev) {
+    Fr* d_r = nullptr;
+    HIP_TRY(hipMalloc(&d_r, (n ? n : 1) * sizeof(Fr)));
+    if (n) {
+        EqPointArgs a;
+        std::memcpy(a.v, r, n * sizeof(Fr));
+        k_store_point<<<1, 64, 0, g.stream>>>(a, (uint32_t)n, d_r);
+    }
+    const uint32_t head = n < 12 ? (uint32_t)n : 12u;
+    k_eq_head<<<1, 1024, 0, g.stream>>>(ev, d_r, (uint32_t)n, head, to_dev(H::one()));
+    for (size_t p = head; p < n; p++)
+        k_eq_double<<<grid_for((size_t)1 << p), SC_THREADS, 0, g.stream>>>(ev, (size_t)1 << p, to_dev(r[n - 1 - p]));
+    hipError_t le = hipGetLastError();
+    hipFree(d_r);                                 // (pool: reused in stream order)
+    return le == hipSuccess ? ATLAS_OK : fail(ATLAS_ENODEV, "eq_evals_into", le);
+}
+
 extern "C" {
 
 int atlas_eq_evals(const atlas_fr_t* r, size_t n, const atlas_fr_t* scaling, atlas_poly_t* out) {

@@ -8,12 +8,12 @@ from . import G1_DTYPE, U128, _check, _fr, _p, lib
 
 class _Opening(C.Structure):
     _fields_ = [("kind", C.c_int), ("poly", C.c_void_p), ("n", C.c_size_t), ("k", C.c_void_p), ("log_K", C.c_size_t),
-                ("log_T", C.c_size_t), ("point", C.c_void_p), ("claim", C.c_uint64 * 4)]
+                ("log_T", C.c_size_t), ("point", C.c_void_p), ("claim", C.c_uint64 * 4), ("d_lookups", C.c_void_p), ("chunk_shift", C.c_size_t)]
 
 
 def prove_reduced_openings(openings, srs, transcript):
     """openings: list of dicts {"poly": MultilinearPolynomial, "point": (n,4), "claim": (4,)} (dense) or
-    {"k": int32 array, "log_K": int, "r_address": (log_K,4), "r_cycle": (log_T,4), "claim": (4,)} (one-hot),
+    {"k": int32 array | "d_lookups": device address + "chunk_shift", "log_K": int, "r_address": (log_K,4), "r_cycle": (log_T,4), "claim": (4,)} (one-hot),
     in CommittedPoly order.  Returns (rows, challenges, sumcheck_claims, com, w, v)."""
     n = len(openings)
     arr = (_Opening * n)()
@@ -28,9 +28,13 @@ def prove_reduced_openings(openings, srs, transcript):
             arr[i].kind = 0; arr[i].poly = o["poly"].h; arr[i].n = len(pt); arr[i].point = pt.ctypes.data
             max_rounds = max(max_rounds, len(pt))
         else:
-            k = np.ascontiguousarray(o["k"], dtype=np.int32)
-            pt = np.ascontiguousarray(np.concatenate([o["r_address"], o["r_cycle"]]), dtype=np.uint64); keep += [k, pt]
-            arr[i].kind = 1; arr[i].k = k.ctypes.data; arr[i].log_K = o["log_K"]; arr[i].log_T = len(o["r_cycle"])
+            pt = np.ascontiguousarray(np.concatenate([o["r_address"], o["r_cycle"]]), dtype=np.uint64); keep.append(pt)
+            arr[i].kind = 1; arr[i].log_K = o["log_K"]; arr[i].log_T = len(o["r_cycle"])
+            if "d_lookups" in o:                       # device-resident lookup indices (int address) + the chunk's shift
+                arr[i].d_lookups = o["d_lookups"]; arr[i].chunk_shift = o["chunk_shift"]
+            else:
+                k = np.ascontiguousarray(o["k"], dtype=np.int32); keep.append(k)
+                arr[i].k = k.ctypes.data
             arr[i].point = pt.ctypes.data
             max_rounds = max(max_rounds, o["log_K"] + len(o["r_cycle"]))
     rows = np.zeros((max_rounds, 3, 4), dtype=np.uint64); nco = np.zeros(max_rounds, dtype=np.uint32)
