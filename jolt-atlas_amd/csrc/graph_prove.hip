@@ -69,6 +69,16 @@ struct Prover : FlowSink {
     void proof(uint8_t proof_type, const uint8_t* bytes, size_t len) override { proofs[gr::ProofId{cur, proof_type}].assign(bytes, bytes + len); }
 
     Out out() { Out O{nullptr, 0, 0, nullptr, 0, nullptr, 0, 0}; O.sink = this; O.node = cur; return O; }
+    // ATLAS_GRAPH_TRACE=2: wall clock between the marks of an operator flow on stderr (synchronises the device: diagnosis only)
+    std::chrono::steady_clock::time_point mark_t;
+    void mark(const char* what) {
+        static const bool on = getenv("ATLAS_GRAPH_TRACE") && atoi(getenv("ATLAS_GRAPH_TRACE")) >= 2;
+        if (!on) return;
+        atlas_sync();
+        const auto n = std::chrono::steady_clock::now();
+        if (what) fprintf(stderr, "[atlas graph]   node %llu %-28s %8.3f ms\n", (unsigned long long)cur, what, ms_between(mark_t, n));
+        mark_t = n;
+    }
     // AccOpeningProvider::append_nodeio(Target::Input(pos), claim) at `point` (utils/opening_access.rs)
     int append_nodeio(const Node& nd, size_t pos, const Point& point, const H::Fr& claim) {
         Out O = out();
@@ -738,6 +748,7 @@ struct Prover : FlowSink {
         const gr::Opening& R = red(nd);
         NodeWitness& W = G.wit[nd.idx];
         Out O = out();
+        mark(nullptr);
         const H::Fr gamma = H::tr_challenge_scalar(Tr);                      // SmallTableParams::new
         const int32_t* cl = W.clamped.as<int32_t>();
         H::Fr clamped_claim;
@@ -749,6 +760,7 @@ struct Prover : FlowSink {
         rc = atlas_eq_evals((const atlas_fr_t*)R.point.data(), log_T, nullptr, &eq);
         if (!rc) rc = atlas_shout_read_raf_G(W.lookups2.as<uint64_t>(), T, LK, eq, &ops[0]);
         if (eq) atlas_poly_free(eq);
+        mark("tanh: clamped claim + G");
         const int32_t* d_table = nullptr;
         if (!rc) rc = atlas_rt_tanh_table(&d_table, nullptr);
         if (!rc) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(d_table), K, &ops[1]);
@@ -758,9 +770,11 @@ struct Prover : FlowSink {
         atlas_instance_t inst = nullptr;
         if (!rc) rc = atlas_elementwise_new(ATLAS_EW_GATHER, ops, 3, nullptr, LK, (const atlas_fr_t*)&gamma, 1, &inst);
         for (atlas_poly_t p : ops) if (p) atlas_poly_free(p);
+        mark("tanh: table operands + instance");
         std::vector<H::Fr> rs, fin;
         if (!rc) rc = run_single(inst, H::add(R.claim, H::mul(gamma, clamped_claim)), gr::PT_Execution, rs, fin);
         if (inst) atlas_instance_free(inst);
+        mark("tanh: table sumcheck");
         if (rc) return rc;
         Point small_pt = reversed(rs);                                        // ActivationSmallRa at (r_table | r_node_output)
         small_pt.insert(small_pt.end(), R.point.begin(), R.point.end());
@@ -777,6 +791,7 @@ struct Prover : FlowSink {
         std::vector<atlas_u128_t> ch; H::Fr ra_claim; std::vector<atlas_fr_t> ra_point;
         if (!rc) rc = prove_single(cinst, H::add(clamped_claim, H::mul(gamma2, operand_claim)), &t, O, ch, &ra_claim, 32, gr::VP_ActivationClampRa, gr::PT_NeuralTeleport, &ra_point);
         if (cinst) atlas_instance_free(cinst);
+        mark("tanh: clamp lookup");
         if (rc) return rc;
         std::vector<OneHotFamily> fams(2);
         fams[0].d_lookups = W.lookups2.as<uint64_t>(); fams[0].log_K = LK; fams[0].r_cycle = (const atlas_fr_t*)R.point.data();
@@ -865,6 +880,7 @@ struct Prover : FlowSink {
         const ExpLut* L = nullptr;
         int rc = atlas_rt_exp_lut(&L);
         if (rc) return rc;
+        mark(nullptr);
         // send_auxiliary_vectors (:392-413): exp_sum_q[k], max_k[k], argmax_k[k] as F::from_u32(v as u32), at the empty point
         std::vector<int32_t> aux(3 * F);
         {
@@ -895,6 +911,7 @@ struct Prover : FlowSink {
         if (!rc) rc = append_advice(nd, gr::VP_SoftmaxRecipMultRemainder, r0, R_claim);                     // cache_R
         if (rc) return rc;
 
+        mark("softmax: aux vectors + claims");
         std::vector<H::Fr> rs;
         std::vector<atlas_fr_t> Rra_point, Era_point, Cra_point;
         H::Fr Rra_claim, Era_claim, Cra_claim, exp_q_claim;
@@ -913,7 +930,9 @@ struct Prover : FlowSink {
             if (!rc) rc = atlas_batched_add_instance(b, i_recip, (const atlas_fr_t*)&c_recip);
             if (!rc) rc = atlas_batched_add_instance(b, i_sum, (const atlas_fr_t*)&exp_sum_claim);
             if (!rc) rc = atlas_batched_add_instance(b, i_rc, (const atlas_fr_t*)&R_claim);
+            mark("softmax: stage 1 instances");
             if (!rc) rc = run_batch(b, 8, LS + log_T, gr::PT_SoftmaxStage1, rs);
+            mark("softmax: stage 1 sumcheck");
             if (!rc) {
                 r1.assign(rs.rbegin(), rs.rbegin() + log_T);                                                 // LITTLE_ENDIAN challenges of the last log_T rounds -> BIG_ENDIAN
                 atlas_fr_t f[64]; size_t nf = 0;
@@ -956,7 +975,9 @@ struct Prover : FlowSink {
             fams[0].d_lookups = Sm.idx_R.as<uint64_t>(); fams[0].log_K = LS; fams[0].r_cycle = (const atlas_fr_t*)r0.data();       // SoftmaxRaEncoding::remainder
             fams[0].ra_point = Rra_point; fams[0].ra_claim = Rra_claim; fams[0].rad_cp = gr::CP_SoftmaxRemainderRaD;
             if (!rc) rc = onehot_families_build(fams, log_T, &t, b, oh, nullptr);
+            mark("softmax: stage 2 instances");
             if (!rc) rc = run_batch(b, 8, LS + log_T, gr::PT_SoftmaxStage2, rs);
+            mark("softmax: stage 2 sumcheck");
             if (!rc) {
                 r2.assign(rs.rbegin(), rs.rbegin() + log_T);
                 atlas_fr_t f[64]; size_t nf = 0;
@@ -1013,7 +1034,9 @@ struct Prover : FlowSink {
             fams[0].d_lookups = Sm.idx_rexp.as<uint64_t>(); fams[0].log_K = LS; fams[0].r_cycle = (const atlas_fr_t*)r1.data();     // SoftmaxRaEncoding::exp_remainder
             fams[0].ra_point = Era_point; fams[0].ra_claim = Era_claim; fams[0].rad_cp = gr::CP_SoftmaxExpRemainderRaD;
             if (!rc) rc = onehot_families_build(fams, log_T, &t, b, oh, nullptr);
+            mark("softmax: stage 3 instances");
             if (!rc) rc = run_batch(b, 8, 32 + log_T, gr::PT_SoftmaxStage3, rs);
+            mark("softmax: stage 3 sumcheck");
             if (!rc) {
                 const size_t mr = rs.size();
                 auto shout_open = [&](atlas_dot_prover_t dp, size_t lk, uint8_t vp, std::vector<atlas_fr_t>& pt_out, H::Fr& claim) {     // ReadRafProver::cache_openings: [challenges | r]
@@ -1046,7 +1069,10 @@ struct Prover : FlowSink {
         fams[2].d_lookups = Sm.idx_z.as<uint64_t>(); fams[2].log_K = 32; fams[2].ra_point = Cra_point; fams[2].ra_claim = Cra_claim; fams[2].rad_cp = gr::CP_SoftmaxClampRaD;
         for (auto& f : fams) f.r_cycle = (const atlas_fr_t*)r2.data();       // the points of SoftmaxExpHi / SoftmaxExpLo / SoftmaxZHi: all r2
         Out O = out();
-        return prove_onehot_checks_multi(fams, log_T, &t, O, gr::PT_SoftmaxStage4);
+        mark("softmax: stage 3 openings");
+        rc = prove_onehot_checks_multi(fams, log_T, &t, O, gr::PT_SoftmaxStage4);
+        mark("softmax: stage 4");
+        return rc;
     }
 
     int prove_node(const Node& nd) {
