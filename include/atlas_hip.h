@@ -497,6 +497,11 @@ int atlas_commit_one_hot_batch(atlas_srs_t srs, const int32_t *const *nonzero_in
  * d = ceil(log_K / log_k_chunk) one-hot polynomials of 2^log_k_chunk addresses, chunk 0 most significant; out[d]. */
 int atlas_commit_lookup_chunks(atlas_srs_t srs, const uint64_t *d_lookups, size_t log_T, size_t log_K, size_t log_k_chunk,
                                atlas_g1_affine_t *out);
+/* The same for the lookups of a whole model graph (commit_witness_polynomials, prover.rs:71-87): the chunk polynomials of n_families
+ * lookups in one launch and one synchronisation; out receives ceil(log_K_f / log_k_chunk) commitments per family, family after family. */
+typedef struct { const uint64_t *d_lookups; size_t log_T, log_K; } atlas_lookup_family_t;
+int atlas_commit_lookup_chunks_multi(atlas_srs_t srs, const atlas_lookup_family_t *families, size_t n_families, size_t log_k_chunk,
+                                     atlas_g1_affine_t *out);
 /* CommitmentScheme::batch_commit (commitment_scheme.rs:76-90 -> UnivariateKZG::commit_batch, kzg.rs:195-243):
  * commitments of n device-resident polynomials (LargeScalars or I32Scalars) against prefixes of the SRS. */
 int atlas_commit_batch(atlas_srs_t srs, const atlas_poly_t *polys, size_t n, atlas_g1_affine_t *out);

@@ -431,6 +431,22 @@ class SRS:
                                               out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def commit_lookup_chunks_multi(self, families, log_k_chunk=4):
+        """The RaD commitments of several lookups in one launch; families: [(DeviceU64 | device address, log_T, log_K)].  Returns one array."""
+        class _Fam(C.Structure):
+            _fields_ = [("d_lookups", C.c_void_p), ("log_T", C.c_size_t), ("log_K", C.c_size_t)]
+        n = len(families)
+        arr = (_Fam * n)()
+        total = 0
+        for i, (dl, log_T, log_K) in enumerate(families):
+            ptr = dl.ptr if hasattr(dl, "ptr") else C.c_void_p(dl)
+            arr[i].d_lookups = ptr.value if hasattr(ptr, "value") else ptr
+            arr[i].log_T = log_T; arr[i].log_K = log_K
+            total += -(-log_K // log_k_chunk)
+        out = np.zeros(total, dtype=G1_DTYPE)
+        _check(lib.atlas_commit_lookup_chunks_multi(self.h, arr, C.c_size_t(n), C.c_size_t(log_k_chunk), out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def commit_batch(self, polys):
         """CommitmentScheme::batch_commit over device-resident polynomials."""
         n = len(polys)

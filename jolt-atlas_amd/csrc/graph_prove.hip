@@ -206,24 +206,32 @@ struct Prover : FlowSink {
         return ATLAS_OK;
     }
     int commit_all() {
-        // one batched call per lookup family: the d chunk commitments of one lookup come out of one launch
+        // every lookup family of the graph in ONE launch (its d chunk commitments are consecutive rows); the dense advice polynomials one by one
+        std::vector<atlas_lookup_family_t> fams;
+        std::vector<gr::Committed*> first;                                    // first chunk of each family
         for (auto& kv : G.wit) {
             auto& cs = kv.second.committed;
             for (size_t i = 0; i < cs.size();) {
-                size_t j = i;
-                while (j < cs.size() && cs[j].kind == 1 && cs[j].d_lookups == cs[i].d_lookups) j++;
+                size_t j = i + 1;
                 if (cs[i].kind == 1) {
-                    std::vector<atlas_g1_affine_t> pts(j - i);
-                    int rc = atlas_commit_lookup_chunks(srs, cs[i].d_lookups, cs[i].log_T, cs[i].log_K, 4, pts.data());
-                    if (rc) return rc;
-                    for (size_t q = i; q < j; q++) cs[q].commitment = pts[q - i];
+                    while (j < cs.size() && cs[j].kind == 1 && cs[j].d_lookups == cs[i].d_lookups) j++;
+                    fams.push_back(atlas_lookup_family_t{cs[i].d_lookups, cs[i].log_T, cs[i].log_K});
+                    first.push_back(&cs[i]);
                 } else {
                     int rc = atlas_msm_poly(srs, 0, cs[i].dense, &cs[i].commitment);
                     if (rc) return rc;
-                    j = i + 1;
                 }
                 i = j;
             }
+        }
+        if (!fams.empty()) {
+            size_t total = 0;
+            for (auto& f : fams) total += (f.log_K + 3) / 4;
+            std::vector<atlas_g1_affine_t> pts(total);
+            int rc = atlas_commit_lookup_chunks_multi(srs, fams.data(), fams.size(), 4, pts.data());
+            if (rc) return rc;
+            size_t o = 0;
+            for (size_t f = 0; f < fams.size(); f++) { const size_t d = (fams[f].log_K + 3) / 4; for (size_t q = 0; q < d; q++) first[f][q].commitment = pts[o++]; }
         }
         for (auto& kv : committed) {                                          // transcript.append_serializable(commitment), BTreeMap order
             uint8_t b[64], rev[64];

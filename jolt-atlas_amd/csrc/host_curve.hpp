@@ -111,4 +111,22 @@ inline G1Aff gx_to_aff(const G1X& p) {
     return G1Aff{q_mul(p.x, izz), q_mul(p.y, izzz)};
 }
 
+// many XYZZ points -> affine with ONE field inversion (Montgomery's trick over the zzz coordinates): q_inv is a 254-bit
+// exponentiation (~23 us), which is what a graph's thousands of witness commitments used to pay one by one
+inline void gx_batch_to_aff(const G1X* p, size_t n, G1Aff* out) {
+    if (n == 0) return;
+    Fq* pre = new Fq[n];
+    Fq acc = q_one();
+    for (size_t i = 0; i < n; i++) { pre[i] = acc; if (!gx_is_inf(p[i])) acc = q_mul(acc, p[i].zzz); }
+    Fq inv = q_inv(acc);
+    for (size_t i = n; i-- > 0;) {
+        if (gx_is_inf(p[i])) { out[i] = G1Aff{q_zero(), q_zero()}; continue; }
+        const Fq izzz = q_mul(inv, pre[i]);
+        inv = q_mul(inv, p[i].zzz);
+        const Fq izz = q_sqr(q_mul(izzz, p[i].zz));
+        out[i] = G1Aff{q_mul(p[i].x, izz), q_mul(p[i].y, izzz)};
+    }
+    delete[] pre;
+}
+
 }  // namespace atlas_host

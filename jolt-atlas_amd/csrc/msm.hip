@@ -903,6 +903,41 @@ int atlas_commit_lookup_chunks(atlas_srs_t srs, const uint64_t* d_lookups, size_
     return ATLAS_OK;
 }
 
+// commit_witness_polynomials over the lookups of a whole graph (prover.rs:71-87, witness.rs:136-200): the chunk polynomials of n
+// lookup families in ONE launch, one copy and one synchronisation, affine through one shared inversion.  out: the d_f commitments
+// of family f after those of family f - 1.
+int atlas_commit_lookup_chunks_multi(atlas_srs_t srs, const atlas_lookup_family_t* fams, size_t n, size_t log_k_chunk, atlas_g1_affine_t* out) {
+    NEED_INIT();
+    if (!srs || !fams || !out || n == 0 || log_k_chunk == 0 || log_k_chunk > 16) return fail(ATLAS_EINVAL, "commit_lookup_chunks_multi: bad argument");
+    std::vector<LookupChunkRow> rows;
+    size_t maxT = 0;
+    for (size_t f = 0; f < n; f++) {
+        if (!fams[f].d_lookups || fams[f].log_K == 0 || fams[f].log_K > 64 || fams[f].log_T > 26) return fail(ATLAS_EINVAL, "commit_lookup_chunks_multi: family");
+        const size_t T = (size_t)1 << fams[f].log_T, d = (fams[f].log_K + log_k_chunk - 1) / log_k_chunk;
+        if ((T << log_k_chunk) > srs->len) return fail(ATLAS_EINVAL, "commit_lookup_chunks_multi: KeyLengthError (K*T beyond the SRS)");
+        for (size_t i = 0; i < d; i++) rows.push_back(LookupChunkRow{fams[f].d_lookups, (uint32_t)T, (uint32_t)(log_k_chunk * (d - 1 - i))});
+        maxT = T > maxT ? T : maxT;
+    }
+    const size_t R = rows.size();
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    unsigned gx = (unsigned)((maxT + 4 * MSM_THREADS - 1) / (4 * MSM_THREADS)); if (gx < 1) gx = 1; if (gx > 64) gx = 64;
+    while ((size_t)gx * R < 2048 && gx < 64 && (size_t)gx * MSM_THREADS < maxT) gx *= 2;
+    DevBuf d_rows, d_part, d_sum;
+    HIP_TRY(d_rows.alloc(R * sizeof(LookupChunkRow)));
+    HIP_TRY(d_part.alloc(R * gx * sizeof(G1Xyzz)));
+    HIP_TRY(d_sum.alloc(R * sizeof(G1Xyzz)));
+    HIP_TRY(hipMemcpyAsync(d_rows.p, rows.data(), R * sizeof(LookupChunkRow), hipMemcpyHostToDevice, g.stream));
+    k_g1_sum_lookup_rows<<<dim3(gx, (unsigned)R), MSM_THREADS, 0, g.stream>>>(srs->d, d_rows.as<LookupChunkRow>(), (uint32_t)(((uint64_t)1 << log_k_chunk) - 1), d_part.as<G1Xyzz>());
+    k_g1_group_sum<<<(unsigned)R, MSM_THREADS, 0, g.stream>>>(d_part.as<G1Xyzz>(), gx, d_sum.as<G1Xyzz>());
+    std::vector<H::G1X> res(R);
+    HIP_TRY(hipMemcpyAsync(res.data(), d_sum.p, R * sizeof(G1Xyzz), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    std::vector<H::G1Aff> aff(R);
+    H::gx_batch_to_aff(res.data(), R, aff.data());
+    for (size_t r = 0; r < R; r++) to_out(aff[r], out + r);
+    return ATLAS_OK;
+}
+
 // CommitmentScheme::batch_commit (commitment_scheme.rs:76-90 -> UnivariateKZG::commit_batch, kzg.rs:195-243): n
 // polynomials against prefixes of the same SRS.  LargeScalars polynomials share one bucket pipeline (their scalars are
 // gathered into one buffer: 32 B per coefficient against ~20 point additions); I32Scalars ones take the narrow-scalar plan.

@@ -616,6 +616,27 @@ __global__ __launch_bounds__(MSM_THREADS) void k_g1_sum_lookup_chunks(const G1Af
     if (threadIdx.x == 0) g1_store(out + (size_t)blockIdx.y * gridDim.x + blockIdx.x, sm[0]);
 }
 
+// the same for the chunk polynomials of MANY lookups in one launch (a model graph commits thousands): blockIdx.y = chunk polynomial
+struct LookupChunkRow { const uint64_t* lookups; uint32_t T, shift; };
+__global__ __launch_bounds__(MSM_THREADS) void k_g1_sum_lookup_rows(const G1Affine* __restrict__ bases, const LookupChunkRow* __restrict__ rows, uint32_t mask,
+                                                                    G1Xyzz* __restrict__ out) {
+    __shared__ G1Xyzz sm[MSM_THREADS];
+    const LookupChunkRow R = rows[blockIdx.y];
+    G1Xyzz acc = g1_inf();
+    for (size_t t = (size_t)blockIdx.x * MSM_THREADS + threadIdx.x; t < R.T; t += (size_t)gridDim.x * MSM_THREADS) {
+        const uint64_t k = R.shift >= 64 ? 0 : ((R.lookups[t] >> R.shift) & mask);
+        const G1Affine p = g1_aff_load(bases + (size_t)k * R.T + t);
+        if (!g1_aff_is_inf(p)) acc = g1_madd(acc, p, false);
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s2 = MSM_THREADS / 2; s2 >= 1; s2 >>= 1) {
+        if (threadIdx.x < s2) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + s2]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) g1_store(out + (size_t)blockIdx.y * gridDim.x + blockIdx.x, sm[0]);
+}
+
 // SRS generation (SRS::setup, hyperkzg/kzg.rs:26-93): out[i] = tau^(i+1) * G.
 // tau_pow2[j] = tau^(2^j) (Montgomery Fr), dbl_table[j] = 2^j * G (affine).
 __global__ __launch_bounds__(MSM_THREADS) void k_srs_generate(const Fr* __restrict__ tau_pow2,

@@ -226,3 +226,30 @@ def test_commit_lookup_chunks_matches_one_hot_commits(atlas, log_K, lkc):
         idx = (chunk * np.uint64(T) + np.arange(T, dtype=np.uint64)).astype(np.uint32)
         assert orc.g1_eq(got[i], orc.g1_sum_indexed(ref, idx)), f"chunk {i}"
     dev.free(); s.free()
+
+
+def test_commit_lookup_chunks_multi_matches_single_calls(atlas):
+    """commit_witness_polynomials over several lookups at once (one launch, one shared inversion to affine) == the per-lookup calls,
+    which are checked against the oracle above; families of different T and log_K, an all-zero lookup (every chunk selects SRS row 0)."""
+    from oracle import orc
+    from jolt_atlas_amd import instances as I
+    s = atlas.SRS.generate(_tau(orc), 16 << 9)
+    rng = np.random.default_rng(77)
+    fams, devs = [], []
+    for log_T, log_K in ((5, 64), (9, 14), (3, 32), (7, 9), (6, 18), (4, 64)):
+        look = rng.integers(0, 1 << min(log_K, 62), size=1 << log_T, dtype=np.uint64)
+        if log_T == 4:
+            look[:] = 0
+        dev = I.DeviceU64.upload(look); devs.append(dev)
+        fams.append((dev, log_T, log_K))
+    got = s.commit_lookup_chunks_multi(fams)
+    o = 0
+    for dev, log_T, log_K in fams:
+        want = s.commit_lookup_chunks(dev, log_T, log_K, 4)
+        for w in want:
+            assert orc.g1_eq(got[o], w), (log_T, log_K, o)
+            o += 1
+    assert o == len(got)
+    for dev in devs:
+        dev.free()
+    s.free()
