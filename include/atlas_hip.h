@@ -722,6 +722,26 @@ int atlas_batched_sumcheck_verify(const atlas_fr_t *compressed, size_t row_strid
 int atlas_batched_sumcheck_check(const atlas_fr_t *batching_coeffs, const atlas_fr_t *expected_output_claims, size_t n_instances,
                                  const atlas_fr_t *output_claim);
 
+/* ---- HyperKZG::verify (joltworks/src/poly/commitment/hyperkzg/mod.rs:451-509 verify_inner, :283-366 kzg_verify_batch) on the
+ *      host: the transcript replay of atlas_hyperkzg_open, the consistency of (Y, ypos, yneg), the batched KZG check
+ *      e(L, vk.g2) = e(R, vk.beta_g2) through a BN254 pairing (the arithmetic lives in arkworks, external to the reference;
+ *      csrc/host_pairing.hpp states it).  G2 points: x = x[0] + x[1] u, y likewise, Montgomery Fq limbs (the ark_bn254 G2Affine image).
+ *      ATLAS_OK = accept, ATLAS_EVERIFY = ProofVerifyError::InternalError. ---- */
+typedef struct { atlas_fq_t x[2], y[2]; uint64_t infinity; } atlas_g2_affine_t;
+typedef struct { atlas_g1_affine_t g1; atlas_g2_affine_t g2, beta_g2; } atlas_hyperkzg_vk_t;      /* HyperKZGVerifierKey { kzg_vk } (kzg.rs:146-166) */
+int atlas_g2_generator(atlas_g2_affine_t *out);
+int atlas_g2_mul(const atlas_g2_affine_t *p, const atlas_fr_t *k, atlas_g2_affine_t *out);
+/* Pairing::multi_pairing(p, q).is_zero(): is prod_i e(p_i, q_i) the identity of G_T? */
+int atlas_pairing_check(const atlas_g1_affine_t *p, const atlas_g2_affine_t *q, size_t n, int *is_one);
+/* the verifier key of an SRS generated from a known trapdoor (atlas_srs_generate: tests and benches): g1 = the SRS's first power,
+ * g2 = the G2 generator, beta_g2 = tau g2.  A key from a ceremony is filled in by the caller from its own g2 powers. */
+int atlas_hyperkzg_vk_from_trapdoor(const atlas_fr_t *tau, const atlas_g1_affine_t *g1, atlas_hyperkzg_vk_t *out);
+/* commitment = C, point = the ell opening-point challenges (raw u128, as atlas_hyperkzg_open takes them), y = the claimed P(point),
+ * com / w / v = HyperKZGProof { com (ell - 1), w (3), v (3 x ell) }; the transcript advances exactly as the prover's did */
+int atlas_hyperkzg_verify(const atlas_hyperkzg_vk_t *vk, const atlas_g1_affine_t *commitment, const atlas_u128_t *point, size_t ell,
+                          const atlas_fr_t *y, const atlas_g1_affine_t *com, const atlas_g1_affine_t *w, const atlas_fr_t *v,
+                          atlas_transcript_t *transcript);
+
 /* ---- the whole proof: ONNXProof::prove over a model graph resident in the library ---------
  * The graph is the tracer's ComputationGraph (atlas-onnx-tracer/src/node/mod.rs:12-24: idx, operator, inputs, output_dims) in the
  * tracer's operator vocabulary (atlas-onnx-tracer/src/ops/mod.rs:117-155).  Every dimension must be a power of two (the reference

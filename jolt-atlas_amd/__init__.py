@@ -679,8 +679,56 @@ def fold_cols(t: TensorI32, eq: MultilinearPolynomial):
     return MultilinearPolynomial(h)
 
 
+G2_DTYPE = np.dtype([("x", np.uint64, (2, 4)), ("y", np.uint64, (2, 4)), ("infinity", np.uint64)])
+VK_DTYPE = np.dtype([("g1", G1_DTYPE), ("g2", G2_DTYPE), ("beta_g2", G2_DTYPE)])
+
+
+def g2_generator():
+    out = np.zeros(1, dtype=G2_DTYPE)
+    _check(lib.atlas_g2_generator(out.ctypes.data_as(C.c_void_p)))
+    return out[0]
+
+
+def g2_mul(p, k_fr):
+    out = np.zeros(1, dtype=G2_DTYPE); pp = np.array([p], dtype=G2_DTYPE); k = _fr(np.asarray(k_fr).reshape(1, 4))
+    _check(lib.atlas_g2_mul(pp.ctypes.data_as(C.c_void_p), _p(k), out.ctypes.data_as(C.c_void_p)))
+    return out[0]
+
+
+def pairing_check(g1_points, g2_points):
+    """multi_pairing(g1_points, g2_points).is_zero()"""
+    p = np.ascontiguousarray(g1_points, dtype=G1_DTYPE); q = np.ascontiguousarray(g2_points, dtype=G2_DTYPE)
+    assert len(p) == len(q)
+    r = C.c_int()
+    _check(lib.atlas_pairing_check(p.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p), C.c_size_t(len(p)), C.byref(r)))
+    return bool(r.value)
+
+
 class HyperKZG:
     """CommitmentScheme arithmetic for HyperKZG (commitment_scheme.rs:11-131)."""
+
+    @staticmethod
+    def vk_from_trapdoor(tau_fr, g1_first_power):
+        """HyperKZGVerifierKey of an SRS generated from a known trapdoor (g1 = the SRS's first power)."""
+        vk = np.zeros(1, dtype=VK_DTYPE); g1 = np.array([g1_first_power], dtype=G1_DTYPE); t = _fr(np.asarray(tau_fr).reshape(1, 4))
+        _check(lib.atlas_hyperkzg_vk_from_trapdoor(_p(t), g1.ctypes.data_as(C.c_void_p), vk.ctypes.data_as(C.c_void_p)))
+        return vk
+
+    @staticmethod
+    def verify(vk, commitment, point_u128, y_fr, com, w, v, transcript):
+        """HyperKZG::verify: True = accept, False = ProofVerifyError (the transcript advances like the prover's)."""
+        ell = len(point_u128)
+        pts = (U128 * ell)(*[U128(c & ((1 << 64) - 1), c >> 64) for c in point_u128])
+        cm = np.array([commitment], dtype=G1_DTYPE); y = _fr(np.asarray(y_fr).reshape(1, 4))
+        com_ = np.ascontiguousarray(com, dtype=G1_DTYPE) if ell > 1 else np.zeros(1, dtype=G1_DTYPE)
+        w_ = np.ascontiguousarray(w, dtype=G1_DTYPE); v_ = np.ascontiguousarray(v, dtype=np.uint64).reshape(3 * ell, 4)
+        rc = lib.atlas_hyperkzg_verify(vk.ctypes.data_as(C.c_void_p), cm.ctypes.data_as(C.c_void_p), pts, C.c_size_t(ell), _p(y),
+                                       com_.ctypes.data_as(C.c_void_p), w_.ctypes.data_as(C.c_void_p), _p(v_), C.byref(transcript.t))
+        if rc == 0:
+            return True
+        if rc == -5:                                   # ATLAS_EVERIFY
+            return False
+        _check(rc)
 
     @staticmethod
     def commit(srs: SRS, poly: MultilinearPolynomial):

@@ -70,6 +70,10 @@ def test_msm_and_hyperkzg_open_2p22_trapdoor(atlas, LOG_N):
     # a wrong evaluation must not verify
     y_bad = orc.fr_add_arr(y, orc.from_ints([1])[0])
     assert not orc.hyperkzg_verify_trapdoor(srs0, tau, Cm, pt, y_bad, com, w, v, orc.new_transcript(b"full_open"))
+    # and through the pairing, as HyperKZG::verify does it
+    vk = A.HyperKZG.vk_from_trapdoor(tau, srs0[0])
+    assert A.HyperKZG.verify(vk, Cm, pt, y, com, w, v, A.Blake2bTranscript(b"full_open"))
+    assert not A.HyperKZG.verify(vk, Cm, pt, y_bad, com, w, v, A.Blake2bTranscript(b"full_open"))
     p.free(); srs.free()
 
 

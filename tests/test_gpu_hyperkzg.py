@@ -44,6 +44,11 @@ def test_open_matches_oracle_and_verifies(atlas, ell):
     assert orc.g1_eq(C_, orc.msm(srs_o, poly))
     y = orc.evaluate(poly, orc.challenges_to_fr(pt))
     assert orc.hyperkzg_verify_trapdoor(srs_o, tau, C_, pt, y, com_g, w_g, v_g, orc.new_transcript(b"TestEval"))
+    # HyperKZG::verify through the pairing (no trapdoor): accept, the transcript of the prover, a wrong evaluation rejected
+    vk = A.HyperKZG.vk_from_trapdoor(tau, srs_g.download(0, 1)[0])
+    tv = A.Blake2bTranscript(b"TestEval")
+    assert A.HyperKZG.verify(vk, C_, pt, y, com_g, w_g, v_g, tv) and tv.state == t_g.state
+    assert not A.HyperKZG.verify(vk, C_, pt, orc.fr_add_arr(y, orc.from_ints([1])[0]), com_g, w_g, v_g, A.Blake2bTranscript(b"TestEval"))
     p.free(); srs_g.free()
 
 

@@ -92,7 +92,13 @@ def test_prove_reduced_openings_bit_exact(atlas, shape):
     # the joint opening verifies against C = commit(joint), y = joint(r_sumcheck) (hyperkzg/mod.rs:451-509)
     Cj = orc.msm(srs_h, joint)
     y = orc.evaluate(joint, np.ascontiguousarray(rs))
+    tv = A.Blake2bTranscript(b"x")                       # the product verifier from the same transcript state, through the pairing
+    for i in range(32):
+        tv.t.state[i] = t_before_open.state[i]
+    tv.t.n_rounds = t_before_open.n_rounds
     assert orc.hyperkzg_verify_trapdoor(srs_h, tau, Cj, ch_g, y, com_g, w_g, v_g, t_before_open)
+    vk = A.HyperKZG.vk_from_trapdoor(tau, srs.download(0, 1)[0])
+    assert A.HyperKZG.verify(vk, Cj, ch_g, y, com_g, w_g, v_g, tv) and tv.state == t_g.state
     srs.free()
 
 

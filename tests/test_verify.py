@@ -90,3 +90,87 @@ def test_device_proofs_are_accepted(atlas, n):
     e, chv = atlas.Sumcheck.verify(proof, claim, tv, 2)
     assert chv == ch and tv.state == t.state
     assert np.array_equal(e, orc.fr_mul_arr(fin[0], fin[1]))
+
+
+# ---------------------------------------------------------------- pairing + HyperKZG::verify (host arithmetic: no GPU needed)
+def _mont_to_int(limbs, modulus):
+    return sum(int(x) << (64 * i) for i, x in enumerate(limbs)) * pow(1 << 256, -1, modulus) % modulus
+
+
+def _g2_ints(p):
+    from oracle.pymodel import pairing as PR
+    if int(p["infinity"]):
+        return None
+    return tuple(tuple(_mont_to_int(p[c][k], PR.P) for k in range(2)) for c in ("x", "y"))
+
+
+def _g1_ints(p):
+    from oracle.pymodel import pairing as PR
+    return None if int(p["inf"] if "inf" in p.dtype.names else p["infinity"]) else (_mont_to_int(p["x"], PR.P), _mont_to_int(p["y"], PR.P))
+
+
+def test_g2_and_pairing_match_the_integer_model():
+    """atlas_g2_mul / atlas_pairing_check against oracle/pymodel/pairing.py: the same G2 multiples, bilinearity e(aG, bH) e(-abG, H) = 1,
+    rejection of a wrong exponent, points at infinity"""
+    from oracle.pymodel import pairing as PR
+    Hg = A.g2_generator()
+    assert _g2_ints(Hg) == PR.G2_GEN and PR.g2_on_curve(_g2_ints(Hg))
+    for seed in (1, 2):
+        a, b = orc.random_fr(1, 100 + seed)[0], orc.random_fr(1, 200 + seed)[0]
+        ai, bi = orc.to_ints(a.reshape(1, 4))[0], orc.to_ints(b.reshape(1, 4))[0]
+        bH = A.g2_mul(Hg, b)
+        assert _g2_ints(bH) == PR.g2_mul(PR.G2_GEN, bi)
+        aG = orc.g1_mul_generator(a)
+        abG = orc.g1_mul_generator(orc.fr_mul_arr(a, b))
+        neg = abG.copy(); neg["y"] = orc.from_ints([(PR.P - _g1_ints(abG)[1]) % PR.P])[0] if False else neg["y"]
+        # -abG through the Fq image: y -> p - y (Montgomery form of the negated integer)
+        yi = (PR.P - _g1_ints(abG)[1]) % PR.P
+        ym = yi * (1 << 256) % PR.P
+        neg["y"] = np.array([(ym >> (64 * i)) & ((1 << 64) - 1) for i in range(4)], dtype=np.uint64)
+        g1 = np.zeros(2, dtype=A.G1_DTYPE)
+        for k, src in enumerate((aG, neg)):
+            g1[k]["x"] = src["x"]; g1[k]["y"] = src["y"]; g1[k]["infinity"] = 0
+        assert A.pairing_check(g1, np.array([bH, Hg], dtype=A.G2_DTYPE))
+        assert PR.multi_pairing_is_one([(_g1_ints(aG), _g2_ints(bH)), ((_g1_ints(abG)[0], yi), PR.G2_GEN)])
+        wrong = A.g2_mul(Hg, orc.fr_add_arr(b, orc.from_ints([1])[0]))
+        assert not A.pairing_check(g1, np.array([wrong, Hg], dtype=A.G2_DTYPE))
+    inf1 = np.zeros(1, dtype=A.G1_DTYPE); inf1[0]["infinity"] = 1
+    assert A.pairing_check(inf1, np.array([Hg], dtype=A.G2_DTYPE))
+
+
+def _as_atlas_g1(p):
+    o = np.zeros(1, dtype=A.G1_DTYPE)[0]
+    o["x"] = p["x"]; o["y"] = p["y"]; o["infinity"] = p["inf"] if "inf" in p.dtype.names else p["infinity"]
+    return o
+
+
+@pytest.mark.parametrize("ell", [1, 2, 4, 6])
+def test_hyperkzg_verify_accepts_and_rejects(ell):
+    """HyperKZG::verify through the pairing on proofs of the oracle's HyperKZG::open: accepted, transcript in step with the prover's,
+    the same decisions as the oracle's trapdoor check; a wrong evaluation, a tampered v, a tampered witness commitment, a wrong point and a
+    verifier key for another trapdoor are rejected"""
+    tau = orc.random_fr(1, 0x51250001)[0]
+    srs = orc.srs_powers(tau, 1 << ell)
+    poly = orc.random_fr(1 << ell, 7 + ell)
+    pt = [int(x) for x in np.random.default_rng(ell).integers(1, 1 << 62, size=ell)]
+    pt = [(p << 60) | 12345 + i for i, p in enumerate(pt)]
+    Cm = orc.msm(srs, poly)
+    y = orc.evaluate(poly, orc.challenges_to_fr(pt))
+    t = orc.new_transcript(b"TestEval")
+    com, w, v = orc.hyperkzg_open(srs, poly, pt, t)
+    vk = A.HyperKZG.vk_from_trapdoor(tau, _as_atlas_g1(srs[0]))
+    g1 = lambda arr: np.array([_as_atlas_g1(p) for p in arr], dtype=A.G1_DTYPE)
+    tv = A.Blake2bTranscript(b"TestEval")
+    assert A.HyperKZG.verify(vk, _as_atlas_g1(Cm), pt, y, g1(com), g1(w), v, tv)
+    assert tv.state == t.state_bytes()
+    assert orc.hyperkzg_verify_trapdoor(srs, tau, Cm, pt, y, com, w, v, orc.new_transcript(b"TestEval"))
+    bad_y = orc.fr_add_arr(y, orc.from_ints([1])[0])
+    assert not A.HyperKZG.verify(vk, _as_atlas_g1(Cm), pt, bad_y, g1(com), g1(w), v, A.Blake2bTranscript(b"TestEval"))
+    vbad = v.copy(); vbad[0, 0] = orc.fr_add_arr(vbad[0, 0], orc.from_ints([1])[0])
+    assert not A.HyperKZG.verify(vk, _as_atlas_g1(Cm), pt, y, g1(com), g1(w), vbad, A.Blake2bTranscript(b"TestEval"))
+    wbad = g1(w); wbad[1] = _as_atlas_g1(srs[0])                  # (w[1] = w[0] would be no tampering at ell = 1: the three quotients of a linear polynomial coincide)
+    assert not A.HyperKZG.verify(vk, _as_atlas_g1(Cm), pt, y, g1(com), wbad, v, A.Blake2bTranscript(b"TestEval"))
+    pbad = list(pt); pbad[0] ^= 1 << 70
+    assert not A.HyperKZG.verify(vk, _as_atlas_g1(Cm), pbad, y, g1(com), g1(w), v, A.Blake2bTranscript(b"TestEval"))
+    vk2 = A.HyperKZG.vk_from_trapdoor(orc.fr_add_arr(tau, orc.from_ints([1])[0]), _as_atlas_g1(srs[0]))
+    assert not A.HyperKZG.verify(vk2, _as_atlas_g1(Cm), pt, y, g1(com), g1(w), v, A.Blake2bTranscript(b"TestEval"))
