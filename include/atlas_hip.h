@@ -781,6 +781,19 @@ typedef struct {
 int atlas_prove_graph(atlas_graph_t g, atlas_srs_t srs, const int32_t *const *inputs, size_t n_inputs, uint8_t *proof, size_t cap,
                       size_t *proof_len, atlas_transcript_t *final_transcript, atlas_graph_timing_t *timing);
 
+/* EvalReductionInstance::verify (joltworks/src/subprotocols/evaluation_reduction.rs:150-210): the verifier's half of
+ * atlas_eval_reduction_prove.  h = the proof's polynomial (ignored for N = 1).  ATLAS_EVERIFY = InvalidOpeningProof. */
+int atlas_eval_reduction_verify(const atlas_fr_t *points, const atlas_fr_t *claims, size_t N, size_t n, const atlas_fr_t *h, size_t h_len,
+                                atlas_transcript_t *transcript, atlas_fr_t *r_out, atlas_fr_t *claim_out);
+/* ONNXProof::verify (jolt-atlas-core/src/onnx_proof/mod.rs:207-241, verifier.rs) for a graph built with atlas_graph_add_node: the
+ * serialized ONNXProof of atlas_prove_graph against the model (its constants), the inputs and the claimed output tensor
+ * (ModelExecutionIO) under a HyperKZG verifier key.  Host arithmetic; the device evaluates the public tensors and adds up the joint
+ * commitment.  Nothing of a prover's trace is read.  ATLAS_OK = accept; ATLAS_EVERIFY = ProofVerifyError; ATLAS_EINVAL = the graph holds
+ * an operator without a verifier composition (composed: Input, Constant, Identity, Add, Sub, Mul, Square, Cube, Einsum, And, Iff, ReLU,
+ * Reshape, MoveAxis, Broadcast). */
+int atlas_verify_graph(atlas_graph_t g, const atlas_hyperkzg_vk_t *vk, const int32_t *const *inputs, size_t n_inputs, const int32_t *output,
+                       size_t output_len, const uint8_t *proof, size_t proof_len, atlas_transcript_t *final_transcript);
+
 #ifdef __cplusplus
 }
 #endif

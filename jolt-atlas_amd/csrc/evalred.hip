@@ -220,3 +220,36 @@ extern "C" int atlas_eval_reduction_prove(atlas_poly_t mle, const atlas_fr_t* po
     *h_len = h.size();
     return ATLAS_OK;
 }
+
+// EvalReductionInstance::verify (evaluation_reduction.rs:150-210): h(i) = claim_i for every opening, the degree bound, then the
+// reduced instance (l(x'), h(x')) at the transcript's challenge.  One opening: the short path (nothing enters the transcript).
+extern "C" int atlas_eval_reduction_verify(const atlas_fr_t* points, const atlas_fr_t* claims, size_t N, size_t n, const atlas_fr_t* h_, size_t h_len,
+                                           atlas_transcript_t* transcript, atlas_fr_t* r_out, atlas_fr_t* claim_out) {
+    if ((!points && n) || !claims || !transcript || (!r_out && n) || !claim_out || (!h_ && h_len)) return fail(ATLAS_EINVAL, "eval_reduction_verify: null argument");
+    if (N == 0) return fail(ATLAS_EVERIFY, "eval_reduction_verify: EmptyInput");
+    const H::Fr* pts = reinterpret_cast<const H::Fr*>(points);
+    const H::Fr* cl = reinterpret_cast<const H::Fr*>(claims);
+    if (N == 1) { if (n) std::memcpy(r_out, points, n * 32); std::memcpy(claim_out, claims, 32); return ATLAS_OK; }
+    std::vector<H::Fr> h(reinterpret_cast<const H::Fr*>(h_), reinterpret_cast<const H::Fr*>(h_) + h_len);
+    if (h.empty() || h.size() - 1 > n * (N - 1)) return fail(ATLAS_EVERIFY, "eval_reduction_verify: InvalidOpeningProof (degree of h)");
+    for (size_t i = 0; i < N; i++) {
+        const H::Fr v = horner(h, H::from_u64(i));
+        if (std::memcmp(&v, &cl[i], 32) != 0) return fail(ATLAS_EVERIFY, "eval_reduction_verify: InvalidOpeningProof (h does not match an opening claim)");
+    }
+    H::Transcript& T = *reinterpret_cast<H::Transcript*>(transcript);
+    H::tr_append_message(T, "UncompressedUniPoly_begin");
+    for (auto& c : h) H::tr_append_scalar(T, c);
+    H::tr_append_message(T, "UncompressedUniPoly_end");
+    uint64_t lo, hi;
+    H::tr_challenge_u128(T, lo, hi);
+    const H::Fr xp = H::challenge_to_fr(lo, hi, g.challenge_mode);
+    for (size_t i = 0; i < n; i++) {                                  // eval_on_l: the per-variable interpolants through (j, points[j][i])
+        std::vector<H::Fr> ev(N);
+        for (size_t j = 0; j < N; j++) ev[j] = pts[j * n + i];
+        const H::Fr v = horner(interpolate_consecutive(ev), xp);
+        std::memcpy(&r_out[i], &v, 32);
+    }
+    const H::Fr v = horner(h, xp);
+    std::memcpy(claim_out, &v, 32);
+    return ATLAS_OK;
+}

@@ -100,6 +100,20 @@ class Graph:
             break
         return bytes(buf[:n.value]), bytes(ts.state), tm.as_dict()
 
+    def verify(self, vk, inputs, output, proof):
+        """ONNXProof::verify against the model, the inputs and the claimed output tensor.  True = accept, False = ProofVerifyError;
+        raises for a graph with an operator the verifier does not compose.  Returns (accepted, final transcript state)."""
+        arrs, ptrs = self._inputs(inputs)
+        out = np.ascontiguousarray(output, dtype=np.int32).reshape(-1)
+        buf = (C.c_uint8 * len(proof)).from_buffer_copy(proof)
+        ts = TranscriptState()
+        rc = lib.atlas_verify_graph(self.h, vk.ctypes.data_as(C.c_void_p), ptrs, C.c_size_t(len(arrs)), out.ctypes.data_as(C.POINTER(C.c_int32)),
+                                    C.c_size_t(len(out)), buf, C.c_size_t(len(proof)), C.byref(ts))
+        if rc == -5:                                   # ATLAS_EVERIFY
+            return False, None
+        _check(rc)
+        return True, bytes(ts.state)
+
     def free(self):
         if self.h:
             lib.atlas_graph_free(self.h)

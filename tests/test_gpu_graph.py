@@ -140,3 +140,37 @@ def test_graph_proof_matches_oracle(atlas, builder, seed):
     assert got == want, "ONNXProof bytes"
     assert tm["n_nodes"] == len(nodes) and tm["n_committed"] == len(P.committed)
     G.free(); srs.free()
+
+
+@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2)])
+def test_graph_proof_is_accepted_by_the_verifier(atlas, builder, seed):
+    """ONNXProof::verify (atlas_verify_graph: opening claims from the proof, the node loop's verifier instances, the opening-reduction
+    sumcheck, the joint commitment, HyperKZG::verify through the pairing) accepts the device's proof with the prover's final transcript
+    state, and rejects a wrong output tensor, a tampered opening claim, a tampered round polynomial and a tampered commitment."""
+    from oracle import orc
+    from jolt_atlas_amd import graph as GG
+    rng = np.random.default_rng(seed)
+    nodes, outputs, inputs = builder(rng)
+    nv = _max_vars(nodes)
+    tau = orc.random_fr(1, 0x51250001)[0]
+    srs = atlas.SRS.generate(tau, 1 << nv)
+    vk = atlas.HyperKZG.vk_from_trapdoor(tau, srs.download(0, 1)[0])
+    G = GG.Graph(nodes, outputs)
+    proof, state, _ = G.prove(srs, inputs)
+    out = G.node_output(outputs[0])
+    V = GG.Graph(nodes, outputs)                         # a verifier's graph: never traced
+    ok, vstate = V.verify(vk, inputs, out, proof)
+    assert ok and vstate == state
+    bad_out = out.copy(); bad_out[0] += 1
+    assert not V.verify(vk, inputs, bad_out, proof)[0]
+    n_open = int.from_bytes(proof[:8], "little")
+    assert n_open > 10
+    for off in (8 + 13 + 5,                              # inside the first opening claim
+                len(proof) // 2,                         # somewhere in the sumcheck proofs / commitments
+                len(proof) - 40):                        # the last HyperKZG evaluation
+        bad = bytearray(proof); bad[off] ^= 1
+        try:
+            assert not V.verify(vk, inputs, out, bytes(bad))[0], off
+        except atlas.AtlasError:
+            pass                                         # a flipped bit that breaks the ark encoding is rejected as malformed
+    G.free(); V.free(); srs.free()
