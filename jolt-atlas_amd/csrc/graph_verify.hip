@@ -5,15 +5,19 @@
 //   verify_reduced_openings     verifier.rs:140-187    the batched opening-reduction sumcheck, the joint commitment, HyperKZG::verify
 // Host arithmetic, like the reference's verifier; the device only evaluates the PUBLIC tensors (inputs, constants, output) at the
 // verifier's points and adds up the joint commitment.  Nothing of the prover's trace is read.
-// Operators with a verifier composition: Input, Constant, Identity, Add, Sub, Mul, Square, Cube, Einsum, And, Iff, ReLU, Reshape, MoveAxis,
-// Broadcast (the fused-rescale family, the clamp / ReLU lookups with their one-hot checks, the shape operators).  The other operators of the
-// graph prover (Sum, ScalarConstDiv, Div, MeanOfSquares, Rsqrt, Slice, Tanh, GatherLarge, SoftmaxLastAxis) return ATLAS_EINVAL.
+// Every operator the graph prover composes has its verifier composition here: Input, Constant, Identity, Add, Sub, Mul, Square, Cube, Einsum,
+// And, Iff, ReLU, Reshape, MoveAxis, Broadcast, Sum, ScalarConstDiv, Slice, Div, MeanOfSquares, Rsqrt, Tanh, GatherLarge, SoftmaxLastAxis.
+// A verifier instance is a VInst (input claim, rounds, degree, and a closure = cache_openings + expected_output_claim); `run_single` is
+// Sumcheck::verify, `batch` is BatchedSumcheck::verify (an instance of n rounds sees the LAST n challenges, sumcheck.rs:150-170).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <functional>
 
 #include "graph_state.hip.h"
 #include "host_curve.hpp"
+
+int atlas_rt_sum_config(const std::vector<size_t>& idims, size_t axis, size_t& m, size_t& n, int& ax);
 
 using gr::Node;
 using gr::OpeningId;
@@ -70,6 +74,43 @@ H::Fr clamp_mle(const H::Fr* r, size_t xlen, size_t bound, bool symmetric) {
     for (size_t i = ub + 1; i < xlen; i++) lw = H::add(lw, H::mul(r[i], pow2_fr(xlen - i - 1)));
     const H::Fr cu = H::sub(pow2_fr(bound), one), lc = symmetric ? H::add(H::add(cu, cu), one) : cu;
     return H::add(H::add(H::sub(cu, H::mul(msb, lc)), H::mul(haz, H::sub(lw, cu))), H::mul(hao, lw));
+}
+
+H::Fr fr_i64(int64_t v) { return v >= 0 ? H::from_u64((uint64_t)v) : H::neg(H::from_u64((uint64_t)(-v))); }
+// UnsignedLessThanTable<XLEN>::evaluate_mle over interleaved operands (unsigned_less_than.rs:26-43)
+H::Fr ult_mle(const H::Fr* r, size_t xlen) {
+    const H::Fr one = H::one();
+    H::Fr res = H::zero(), eqt = one;
+    for (size_t i = 0; i < xlen; i++) {
+        const H::Fr x = r[2 * i], y = r[2 * i + 1];
+        res = H::add(res, H::mul(H::mul(H::sub(one, x), y), eqt));
+        eqt = H::mul(eqt, H::add(H::mul(x, y), H::mul(H::sub(one, x), H::sub(one, y))));
+    }
+    return res;
+}
+// SignedOperandPoly::evaluate (signed_identity_poly.rs:255-274): the two's-complement value of one interleaved operand (shift 0 = left, 1 = right)
+H::Fr signed_operand_mle(const H::Fr* r, size_t xlen, size_t shift) {
+    H::Fr y = H::zero();
+    for (size_t i = 0; i < xlen; i++) y = H::add(y, H::mul(r[2 * i + shift], pow2_fr(xlen - 1 - i)));
+    return H::sub(y, H::mul(r[shift], pow2_fr(xlen)));
+}
+// EqPolynomial::evals: big-endian table of eq(r, .)
+std::vector<H::Fr> eq_table(const H::Fr* r, size_t n) {
+    std::vector<H::Fr> ev((size_t)1 << n);
+    ev[0] = H::one();
+    size_t len = 1;
+    for (size_t i = 0; i < n; i++) {
+        for (size_t j = len; j-- > 0;) { const H::Fr hi = H::mul(ev[j], r[i]); ev[2 * j + 1] = hi; ev[2 * j] = H::sub(ev[j], hi); }
+        len <<= 1;
+    }
+    return ev;
+}
+// MultilinearPolynomial::from(Vec<i32>).evaluate(point) of a short public vector
+H::Fr mle_i32(const std::vector<int32_t>& v, const H::Fr* r, size_t n) {
+    const std::vector<H::Fr> ev = eq_table(r, n);
+    H::Fr acc = H::zero();
+    for (size_t i = 0; i < v.size() && i < ev.size(); i++) acc = H::add(acc, H::mul(ev[i], fr_i64(v[i])));
+    return acc;
 }
 
 struct Verifier {
@@ -147,107 +188,191 @@ struct Verifier {
     static Point reversed(const std::vector<H::Fr>& v, size_t from = 0) { return Point(v.rbegin(), v.rend() - from); }
     static bool same(const H::Fr& a, const H::Fr& b) { return std::memcmp(&a, &b, 32) == 0; }
 
-    // ---- a unary prefix-suffix lookup: read_raf_verify (op_lookups/mod.rs:270-283) + Sumcheck::verify (ps_shout/mod.rs:612-643)
-    enum Table { T_RELU, T_CLAMP_SYM };
-    int ps_unary(const Node& nd, Table tab, size_t xlen, size_t bound, const OpeningId& witness_id, const H::Fr& rv_claim, const Point& r_cycle, uint8_t ra_vp,
-                 uint8_t proof_type, Point* ra_point) {
+    // ---- verifier instances
+    struct VInst { H::Fr claim; size_t rounds = 0, degree = 0; std::function<int(const H::Fr* ch, H::Fr* expected)> finish; };
+    // Sumcheck::verify (sumcheck.rs:103-138): cache_openings, then the final claim against expected_output_claim
+    int run_single(uint8_t proof_type, const VInst& I, const char* what) {
+        H::Fr e, expect; std::vector<H::Fr> rs;
+        int rc = single(proof_type, I.rounds, I.degree, I.claim, &e, rs);
+        if (!rc) rc = I.finish(rs.data(), &expect);
+        if (rc) return rc;
+        return same(e, expect) ? ATLAS_OK : bad(what);
+    }
+    // BatchedSumcheck::verify (sumcheck.rs:252-330)
+    int batch(uint8_t proof_type, const std::vector<VInst>& I) {
+        auto it = proofs.find(gr::ProofId{cur, proof_type});
+        if (it == proofs.end()) return bad("verify_graph: MissingProof (batched sumcheck)");
+        const Rows& R = it->second;
+        const size_t n = I.size();
+        std::vector<H::Fr> ic(n), coeff(n), expect(n); std::vector<size_t> nr(n), deg(n);
+        size_t mr = 0;
+        for (size_t i = 0; i < n; i++) { ic[i] = I[i].claim; nr[i] = I[i].rounds; deg[i] = I[i].degree; mr = nr[i] > mr ? nr[i] : mr; }
+        if (R.rounds != mr) return bad("verify_graph: a batched sumcheck with the wrong number of rounds");
+        std::vector<atlas_u128_t> ch(mr ? mr : 1);
+        H::Fr e;
+        int rc = atlas_batched_sumcheck_verify(R.c.data(), R.stride, R.n.data(), mr, (const atlas_fr_t*)ic.data(), nr.data(), deg.data(), n, &t, (atlas_fr_t*)coeff.data(), (atlas_fr_t*)&e, ch.data());
+        if (rc) return rc;
+        std::vector<H::Fr> rs(mr);
+        for (size_t i = 0; i < mr; i++) rs[i] = ch_fr(ch[i]);
+        for (size_t i = 0; i < n && !rc; i++) rc = I[i].finish(rs.data() + (mr - nr[i]), &expect[i]);
+        if (rc) return rc;
+        return atlas_batched_sumcheck_check((const atlas_fr_t*)coeff.data(), (const atlas_fr_t*)expect.data(), n, (const atlas_fr_t*)&e);
+    }
+    // the opening point of a read-raf ra polynomial: address challenges as drawn, cycle challenges reversed (ps_shout/mod.rs:150-158)
+    static Point ra_point_of(const H::Fr* ch, size_t log_K, size_t log_T) {
+        Point pt(ch, ch + log_K);
+        for (size_t q = 0; q < log_T; q++) pt.push_back(ch[log_K + log_T - 1 - q]);
+        return pt;
+    }
+
+    // ---- a unary prefix-suffix lookup: read_raf_verify (op_lookups/mod.rs:270-283) + its verifier instance (ps_shout/mod.rs:612-643)
+    enum Table { T_RELU, T_CLAMP_SYM, T_CLAMP };
+    int inst_ps_unary(const Node& nd, Table tab, size_t xlen, size_t bound, const OpeningId& witness_id, const H::Fr& rv_claim, const Point& r_cycle, uint8_t ra_vp, Point* ra_point, VInst* out) {
         int rc = append_virtual(witness_id, r_cycle);                        // append_raf_claims_verifier
         if (rc) return rc;
         const H::Fr gamma = H::tr_challenge_scalar(Tr);                      // ps_read_raf_verifier
-        const H::Fr operand = claim_of(witness_id);
         const size_t log_T = r_cycle.size();
-        H::Fr e; std::vector<H::Fr> rs;
-        rc = single(proof_type, xlen + log_T, 2, H::add(rv_claim, H::mul(gamma, operand)), &e, rs);
-        if (rc) return rc;
-        Point pt(rs.begin(), rs.begin() + xlen);
-        for (size_t q = 0; q < log_T; q++) pt.push_back(rs[xlen + log_T - 1 - q]);
-        rc = append_advice(nd, ra_vp, pt);                                   // cache_openings
-        if (rc) return rc;
-        const H::Fr val = tab == T_RELU ? relu_mle(pt.data(), xlen) : clamp_mle(pt.data(), xlen, bound, true);
-        const H::Fr expect = H::mul(H::mul(eq_mle(r_cycle.data(), pt.data() + xlen, log_T), advice_claim(nd, ra_vp)), H::add(val, H::mul(gamma, signed_identity_mle(pt.data(), xlen))));
-        if (!same(e, expect)) return bad("verify_graph: SumcheckVerificationError (prefix-suffix lookup)");
-        *ra_point = pt;
+        const Node* np = &nd;
+        out->claim = H::add(rv_claim, H::mul(gamma, claim_of(witness_id))); out->rounds = xlen + log_T; out->degree = 2;
+        out->finish = [=](const H::Fr* ch, H::Fr* expect) {
+            const Point pt = ra_point_of(ch, xlen, log_T);
+            int rc2 = append_advice(*np, ra_vp, pt);                         // cache_openings
+            if (rc2) return rc2;
+            const H::Fr val = tab == T_RELU ? relu_mle(pt.data(), xlen) : clamp_mle(pt.data(), xlen, bound, tab == T_CLAMP_SYM);
+            *expect = H::mul(H::mul(eq_mle(r_cycle.data(), pt.data() + xlen, log_T), advice_claim(*np, ra_vp)), H::add(val, H::mul(gamma, signed_identity_mle(pt.data(), xlen))));
+            *ra_point = pt;
+            return (int)ATLAS_OK;
+        };
         return ATLAS_OK;
+    }
+    int ps_unary(const Node& nd, Table tab, size_t xlen, size_t bound, const OpeningId& witness_id, const H::Fr& rv_claim, const Point& r_cycle, uint8_t ra_vp,
+                 uint8_t proof_type, Point* ra_point) {
+        VInst I;
+        int rc = inst_ps_unary(nd, tab, xlen, bound, witness_id, rv_claim, r_cycle, ra_vp, ra_point, &I);
+        if (!rc) rc = run_single(proof_type, I, "verify_graph: SumcheckVerificationError (prefix-suffix lookup)");
+        return rc;
+    }
+    // the binary range check `left < right` (range_checking/mod.rs:37-100, ps_shout/binary.rs): UnsignedLessThanTable<32> on the interleaved
+    // operands; every lookup's value is 1, the operands ride along as gamma left + gamma^2 right
+    VInst inst_range_check(const Node& nd, const Point& r_cycle, const H::Fr& left, const H::Fr& right, uint8_t ra_vp, Point* ra_point) {
+        const H::Fr gamma = H::tr_challenge_scalar(Tr);
+        const size_t log_T = r_cycle.size();
+        const Node* np = &nd;
+        VInst I;
+        I.claim = H::add(H::one(), H::add(H::mul(gamma, left), H::mul(H::mul(gamma, gamma), right))); I.rounds = 64 + log_T; I.degree = 2;
+        I.finish = [=](const H::Fr* ch, H::Fr* expect) {
+            const Point pt = ra_point_of(ch, 64, log_T);
+            int rc2 = append_advice(*np, ra_vp, pt);
+            if (rc2) return rc2;
+            const H::Fr val = H::add(ult_mle(pt.data(), 32), H::mul(gamma, H::add(signed_operand_mle(pt.data(), 32, 0), H::mul(gamma, signed_operand_mle(pt.data(), 32, 1)))));
+            *expect = H::mul(H::mul(eq_mle(r_cycle.data(), pt.data() + 64, log_T), advice_claim(*np, ra_vp)), val);
+            *ra_point = pt;
+            return (int)ATLAS_OK;
+        };
+        return I;
     }
     // IdentityRCVerifier (identity_range_check.rs:455-473)
-    int identity_rc(const Node& nd, size_t log_K, const H::Fr& input_claim, const Point& r_cycle, uint8_t ra_vp, uint8_t proof_type, Point* ra_point) {
+    VInst inst_identity_rc(const Node& nd, size_t log_K, const H::Fr& input_claim, const Point& r_cycle, uint8_t ra_vp, Point* ra_point) {
         const size_t log_T = r_cycle.size();
-        H::Fr e; std::vector<H::Fr> rs;
-        int rc = single(proof_type, log_K + log_T, 2, input_claim, &e, rs);
-        if (rc) return rc;
-        Point pt(rs.begin(), rs.begin() + log_K);
-        for (size_t q = 0; q < log_T; q++) pt.push_back(rs[log_K + log_T - 1 - q]);
-        rc = append_advice(nd, ra_vp, pt);
-        if (rc) return rc;
-        const H::Fr expect = H::mul(H::mul(eq_mle(r_cycle.data(), pt.data() + log_K, log_T), advice_claim(nd, ra_vp)), identity_mle(pt.data(), log_K));
-        if (!same(e, expect)) return bad("verify_graph: SumcheckVerificationError (identity range check)");
-        *ra_point = pt;
-        return ATLAS_OK;
+        const Node* np = &nd;
+        VInst I;
+        I.claim = input_claim; I.rounds = log_K + log_T; I.degree = 2;
+        I.finish = [=](const H::Fr* ch, H::Fr* expect) {
+            const Point pt = ra_point_of(ch, log_K, log_T);
+            int rc2 = append_advice(*np, ra_vp, pt);
+            if (rc2) return rc2;
+            *expect = H::mul(H::mul(eq_mle(r_cycle.data(), pt.data() + log_K, log_T), advice_claim(*np, ra_vp)), identity_mle(pt.data(), log_K));
+            *ra_point = pt;
+            return (int)ATLAS_OK;
+        };
+        return I;
     }
-    // ra_onehot_verifiers + BatchedSumcheck::verify over [RaVirtual, HammingWeight, Booleanity] (shout.rs:474-529)
-    int onehot_checks(const Node& nd, size_t log_K, const Point& r_cycle, const Point& ra_point, const H::Fr& ra_claim, uint8_t rad_cp, uint8_t proof_type) {
+    int identity_rc(const Node& nd, size_t log_K, const H::Fr& input_claim, const Point& r_cycle, uint8_t ra_vp, uint8_t proof_type, Point* ra_point) {
+        return run_single(proof_type, inst_identity_rc(nd, log_K, input_claim, r_cycle, ra_vp, ra_point), "verify_graph: SumcheckVerificationError (identity range check)");
+    }
+    // the dense Shout read-raf verifier (shout.rs:330-420): sum_k ra(k) (table(k) + gamma k); ra opened at (challenges | r_cycle)
+    VInst inst_shout(const Node& nd, const std::vector<int32_t>& table, size_t log_K, const H::Fr& rv_claim, const H::Fr& raf_claim, const Point& r_cycle, uint8_t ra_vp, Point* ra_point) {
+        const H::Fr gamma = H::tr_challenge_scalar(Tr);                      // ReadRafParams::new
+        const Node* np = &nd;
+        const std::vector<int32_t>* tp = &table;
+        VInst I;
+        I.claim = H::add(rv_claim, H::mul(gamma, raf_claim)); I.rounds = log_K; I.degree = 2;
+        I.finish = [=](const H::Fr* ch, H::Fr* expect) {
+            Point pt(ch, ch + log_K);
+            pt.insert(pt.end(), r_cycle.begin(), r_cycle.end());
+            int rc2 = append_advice(*np, ra_vp, pt);
+            if (rc2) return rc2;
+            *expect = H::mul(advice_claim(*np, ra_vp), H::add(mle_i32(*tp, ch, log_K), H::mul(gamma, identity_mle(ch, log_K))));
+            *ra_point = pt;
+            return (int)ATLAS_OK;
+        };
+        return I;
+    }
+    // ra_onehot_verifiers (shout.rs:474-529): [RaVirtual, HammingWeight, Booleanity] of one lookup family, appended to `out`
+    void onehot_insts(const Node& nd, size_t log_K, const Point& r_cycle, const Point& ra_point, const H::Fr& ra_claim, uint8_t rad_cp, std::vector<VInst>& out) {
         const size_t lkc = 4, d = (log_K + lkc - 1) / lkc, log_T = r_cycle.size(), pad = d * lkc - log_K;
         std::vector<H::Fr> gp(d);
         { const H::Fr q = H::tr_challenge_scalar(Tr); gp[0] = H::one(); for (size_t i = 1; i < d; i++) gp[i] = H::mul(gp[i - 1], q); }
         const Point gammas = challenge_point(d), r_addr = challenge_point(lkc);
         H::Fr hw_claim = H::zero();
         for (auto& x : gp) hw_claim = H::add(hw_claim, x);
-        auto it = proofs.find(gr::ProofId{cur, proof_type});
-        if (it == proofs.end()) return bad("verify_graph: MissingProof (one-hot checks)");
-        const Rows& R = it->second;
-        const H::Fr ic[3] = {ra_claim, hw_claim, H::zero()};
-        const size_t nr[3] = {log_T, lkc, lkc + log_T}, deg[3] = {d + 1, 1, 3};
-        H::Fr coeff[3], e;
-        const size_t mr = lkc + log_T;
-        if (R.rounds != mr) return bad("verify_graph: one-hot checks with the wrong number of rounds");
-        std::vector<atlas_u128_t> ch(mr);
-        int rc = atlas_batched_sumcheck_verify(R.c.data(), R.stride, R.n.data(), mr, (const atlas_fr_t*)ic, nr, deg, 3, &t, (atlas_fr_t*)coeff, (atlas_fr_t*)&e, ch.data());
-        if (rc) return rc;
-        std::vector<H::Fr> rs(mr);
-        for (size_t i = 0; i < mr; i++) rs[i] = ch_fr(ch[i]);
-        H::Fr expect[3];
+        const Node* np = &nd;
+        VInst ra, hw, bo;
         // RaVirtual: openings at (chunk i of the zero-padded r_address | reversed cycle challenges); eq(r_cycle_ra, .) prod ra_i
-        {
+        ra.claim = ra_claim; ra.rounds = log_T; ra.degree = d + 1;
+        ra.finish = [=](const H::Fr* ch, H::Fr* expect) {
             Point rc_rev(log_T);
-            for (size_t q = 0; q < log_T; q++) rc_rev[q] = rs[mr - 1 - q];
+            for (size_t q = 0; q < log_T; q++) rc_rev[q] = ch[log_T - 1 - q];
             H::Fr prod = H::one();
             for (size_t i = 0; i < d; i++) {
                 Point pt(lkc + log_T);
                 for (size_t q = 0; q < lkc; q++) { const size_t pos = i * lkc + q; pt[q] = pos < pad ? H::zero() : ra_point[pos - pad]; }
                 std::copy(rc_rev.begin(), rc_rev.end(), pt.begin() + lkc);
-                rc = append_sparse(rad_cp, nd, i, gr::SC_RaVirtualization, pt);
-                if (rc) return rc;
-                prod = H::mul(prod, claim_of(gr::oid(gr::comm(rad_cp, nd.idx, i), gr::SC_RaVirtualization)));
+                int rc2 = append_sparse(rad_cp, *np, i, gr::SC_RaVirtualization, pt);
+                if (rc2) return rc2;
+                prod = H::mul(prod, claim_of(gr::oid(gr::comm(rad_cp, np->idx, i), gr::SC_RaVirtualization)));
             }
-            expect[0] = H::mul(eq_mle(ra_point.data() + log_K, rc_rev.data(), log_T), prod);
-        }
-        {   // HammingWeight: (reversed address challenges | r_cycle); sum gamma^i ra_i
+            *expect = H::mul(eq_mle(ra_point.data() + log_K, rc_rev.data(), log_T), prod);
+            return (int)ATLAS_OK;
+        };
+        // HammingWeight: (reversed address challenges | r_cycle); sum gamma^i ra_i
+        hw.claim = hw_claim; hw.rounds = lkc; hw.degree = 1;
+        hw.finish = [=](const H::Fr* ch, H::Fr* expect) {
             Point pt(lkc + log_T);
-            for (size_t q = 0; q < lkc; q++) pt[q] = rs[mr - 1 - q];
+            for (size_t q = 0; q < lkc; q++) pt[q] = ch[lkc - 1 - q];
             std::copy(r_cycle.begin(), r_cycle.end(), pt.begin() + lkc);
             H::Fr s = H::zero();
             for (size_t i = 0; i < d; i++) {
-                rc = append_sparse(rad_cp, nd, i, gr::SC_HammingWeight, pt);
-                if (rc) return rc;
-                s = H::add(s, H::mul(claim_of(gr::oid(gr::comm(rad_cp, nd.idx, i), gr::SC_HammingWeight)), gp[i]));
+                int rc2 = append_sparse(rad_cp, *np, i, gr::SC_HammingWeight, pt);
+                if (rc2) return rc2;
+                s = H::add(s, H::mul(claim_of(gr::oid(gr::comm(rad_cp, np->idx, i), gr::SC_HammingWeight)), gp[i]));
             }
-            expect[1] = s;
-        }
-        {   // Booleanity: both halves reversed; eq(challenges, rev(r_address) | rev(r_cycle)) sum gamma_i (ra_i^2 - ra_i)
-            Point pt(lkc + log_T), comb(lkc + log_T);
-            for (size_t q = 0; q < lkc; q++) { pt[q] = rs[lkc - 1 - q]; comb[q] = r_addr[lkc - 1 - q]; }
-            for (size_t q = 0; q < log_T; q++) { pt[lkc + q] = rs[mr - 1 - q]; comb[lkc + q] = r_cycle[log_T - 1 - q]; }
+            *expect = s;
+            return (int)ATLAS_OK;
+        };
+        // Booleanity: both halves reversed; eq(challenges, rev(r_address) | rev(r_cycle)) sum gamma_i (ra_i^2 - ra_i)
+        bo.claim = H::zero(); bo.rounds = lkc + log_T; bo.degree = 3;
+        bo.finish = [=](const H::Fr* ch, H::Fr* expect) {
+            const size_t mr = lkc + log_T;
+            Point pt(mr), comb(mr);
+            for (size_t q = 0; q < lkc; q++) { pt[q] = ch[lkc - 1 - q]; comb[q] = r_addr[lkc - 1 - q]; }
+            for (size_t q = 0; q < log_T; q++) { pt[lkc + q] = ch[mr - 1 - q]; comb[lkc + q] = r_cycle[log_T - 1 - q]; }
             H::Fr s = H::zero();
             for (size_t i = 0; i < d; i++) {
-                rc = append_sparse(rad_cp, nd, i, gr::SC_Booleanity, pt);
-                if (rc) return rc;
-                const H::Fr ra = claim_of(gr::oid(gr::comm(rad_cp, nd.idx, i), gr::SC_Booleanity));
-                s = H::add(s, H::mul(H::sub(H::mul(ra, ra), ra), gammas[i]));
+                int rc2 = append_sparse(rad_cp, *np, i, gr::SC_Booleanity, pt);
+                if (rc2) return rc2;
+                const H::Fr c = claim_of(gr::oid(gr::comm(rad_cp, np->idx, i), gr::SC_Booleanity));
+                s = H::add(s, H::mul(H::sub(H::mul(c, c), c), gammas[i]));
             }
-            expect[2] = H::mul(eq_mle(rs.data(), comb.data(), mr), s);
-        }
-        rc = atlas_batched_sumcheck_check((const atlas_fr_t*)coeff, (const atlas_fr_t*)expect, 3, (const atlas_fr_t*)&e);
-        return rc;
+            *expect = H::mul(eq_mle(ch, comb.data(), mr), s);
+            return (int)ATLAS_OK;
+        };
+        out.push_back(std::move(ra)); out.push_back(std::move(hw)); out.push_back(std::move(bo));
+    }
+    int onehot_checks(const Node& nd, size_t log_K, const Point& r_cycle, const Point& ra_point, const H::Fr& ra_claim, uint8_t rad_cp, uint8_t proof_type) {
+        std::vector<VInst> I;
+        onehot_insts(nd, log_K, r_cycle, ra_point, ra_claim, rad_cp, I);
+        return batch(proof_type, I);
     }
     // verify_clamp_lookup (clamp_lookups/mod.rs:311-346): SaturationTable = ClampBoundedTable<64, 31, true>, witness = ClampAcc
     int clamp_lookup(const Node& nd) {
@@ -257,6 +382,37 @@ struct Verifier {
         if (!rc) rc = onehot_checks(nd, 64, R.point, ra_point, advice_claim(nd, gr::VP_ClampRa), gr::CP_ClampRaD, gr::PT_RaOneHotChecks);
         return rc;
     }
+    // verify_scalar_clamp (clamp_lookups/mod.rs): a scalar node's accumulation opens in the clear
+    int scalar_clamp(const Node& nd) {
+        const OpeningId id = gr::node_exec(gr::virt(gr::VP_ClampAcc, nd.idx), nd.idx);
+        int rc = append_virtual(id, reduced.at(nd.idx).point);
+        if (rc) return rc;
+        uint64_t c[4], m[4];
+        H::to_canonical(claim_of(id), c);
+        H::to_canonical(H::neg(claim_of(id)), m);
+        int64_t acc;
+        if (!c[1] && !c[2] && !c[3] && c[0] < ((uint64_t)1 << 63)) acc = (int64_t)c[0];
+        else if (!m[1] && !m[2] && !m[3] && m[0] <= ((uint64_t)1 << 63)) acc = (int64_t)(0 - m[0]);
+        else return bad("verify_graph: InvalidOpeningProof (a scalar accumulation outside i64)");
+        const int64_t cl = acc > INT32_MAX ? INT32_MAX : acc < INT32_MIN ? INT32_MIN : acc;
+        return same(fr_i64(cl), reduced.at(nd.idx).claim) ? ATLAS_OK : bad("verify_graph: InvalidOpeningProof (scalar clamp)");
+    }
+    // a dense committed polynomial of this node (VerifierOpeningAccumulator::append_dense)
+    int append_dense(const Node& nd, uint8_t cp, const Point& pt) {
+        const PolyId p = gr::comm(cp, nd.idx);
+        const OpeningId id = gr::node_exec(p, nd.idx);
+        auto it = claims.find(id);
+        if (it == claims.end()) return bad("verify_graph: a dense opening claim is not in the proof");
+        H::tr_append_scalar(Tr, it->second);
+        points[id] = pt;
+        auto c = committed.find(p);
+        if (c == committed.end()) return bad("verify_graph: an opening of a polynomial that is not committed");
+        c->second.opened = true; c->second.point = pt; c->second.claim = it->second;
+        return ATLAS_OK;
+    }
+    H::Fr dense_claim(const Node& nd, uint8_t cp) const { return claims.at(gr::node_exec(gr::comm(cp, nd.idx), nd.idx)); }
+    H::Fr current_claim(const Node& nd) const { return claims.at(gr::node_exec(gr::virt(gr::VP_NodeOutput, nd.idx), nd.idx)); }
+    int append_current(const Node& nd, const Point& pt) { return append_virtual(gr::node_exec(gr::virt(gr::VP_NodeOutput, nd.idx), nd.idx), pt); }
 
     // ---- stages
     int output_claim() {
@@ -406,6 +562,379 @@ struct Verifier {
         if (rc) return rc;
         return same(e, H::mul(nodeio_claim(nd, 0), eq_mle(R.point.data(), pt.data(), n))) ? ATLAS_OK : bad("verify_graph: SumcheckVerificationError (reshape)");
     }
+    // range_check + its one-hot checks on their own proofs (ops/div.rs verify_range_and_onehot, mean_of_squares.rs)
+    int range_and_onehot(const Node& nd, const Point& r_cycle, const H::Fr& left, const H::Fr& right, uint8_t ra_vp, uint8_t rad_cp, uint8_t pt_onehot) {
+        Point ra_point;
+        int rc = run_single(gr::PT_RangeCheck, inst_range_check(nd, r_cycle, left, right, ra_vp, &ra_point), "verify_graph: SumcheckVerificationError (range check)");
+        if (!rc) rc = onehot_checks(nd, 64, r_cycle, ra_point, advice_claim(nd, ra_vp), rad_cp, pt_onehot);
+        return rc;
+    }
+    // Sum (ops/sum/mod.rs verify): output = SatClamp(acc), then SumAxisVerifier over the reduced axis (sum/axis.rs)
+    int op_sum(const Node& nd) {
+        const gr::Opening& R = reduced.at(nd.idx);
+        size_t m, n; int axis;
+        int rc = atlas_rt_sum_config(G.nodes.at(nd.inputs[0]).dims, nd.shape[0], m, n, axis);
+        if (!rc) rc = R.point.empty() ? scalar_clamp(nd) : clamp_lookup(nd);
+        if (rc) return rc;
+        const Node* np = &nd;
+        const Point r0 = R.point;
+        const size_t nr = gr::log2u(axis == 0 ? m : n);
+        VInst I;
+        I.claim = advice_claim(nd, gr::VP_ClampAcc); I.rounds = nr; I.degree = 1;
+        I.finish = [=](const H::Fr* ch, H::Fr* expect) {
+            Point pt;
+            if (axis == 0) { pt.assign(ch, ch + nr); pt.insert(pt.end(), r0.begin(), r0.end()); }
+            else { pt = r0; pt.insert(pt.end(), ch, ch + nr); }
+            int rc2 = append_nodeio(*np, 0, pt);
+            if (!rc2) *expect = nodeio_claim(*np, 0);
+            return rc2;
+        };
+        return run_single(gr::PT_SumReduction, I, "verify_graph: SumcheckVerificationError (sum over an axis)");
+    }
+    // ScalarConstDiv (ops/scalar_const_div.rs): eq(r0, r') (left - R) against q(r0) divisor
+    int op_scalar_const_div(const Node& nd) {
+        const gr::Opening& R = reduced.at(nd.idx);
+        const Node* np = &nd;
+        const Point r0 = R.point;
+        VInst I;
+        I.claim = H::mul(R.claim, fr_i64(nd.p[0])); I.rounds = r0.size(); I.degree = 2;
+        I.finish = [=](const H::Fr* ch, H::Fr* expect) {
+            Point pt(r0.size());
+            for (size_t q = 0; q < pt.size(); q++) pt[q] = ch[pt.size() - 1 - q];
+            int rc2 = append_nodeio(*np, 0, pt);
+            if (!rc2) rc2 = append_dense(*np, gr::CP_ScalarConstDivNodeRemainder, pt);
+            if (!rc2) *expect = H::mul(eq_mle(r0.data(), pt.data(), pt.size()), H::sub(nodeio_claim(*np, 0), dense_claim(*np, gr::CP_ScalarConstDivNodeRemainder)));
+            return rc2;
+        };
+        return run_single(gr::PT_Execution, I, "verify_graph: SumcheckVerificationError (division by a constant)");
+    }
+    // Slice (ops/slice.rs): input(r') selector~(r'), the selector = eq(r0, o) at the input index of output cell o
+    int op_slice(const Node& nd) {
+        const gr::Opening& R = reduced.at(nd.idx);
+        const Node& in = G.nodes.at(nd.inputs[0]);
+        const size_t T_out = gr::padded_len(nd.dims), log_in = gr::log2u(gr::padded_len(in.dims));
+        const Node* np = &nd; const Node* ip = &in;
+        const Point r0 = R.point;
+        VInst I;
+        I.claim = R.claim; I.rounds = log_in; I.degree = 2;
+        I.finish = [=](const H::Fr* ch, H::Fr* expect) {
+            Point pt(log_in);
+            for (size_t q = 0; q < log_in; q++) pt[q] = ch[log_in - 1 - q];
+            int rc2 = append_nodeio(*np, 0, pt);
+            if (rc2) return rc2;
+            const std::vector<H::Fr> eo = eq_table(r0.data(), r0.size()), ei = eq_table(pt.data(), log_in);
+            std::vector<size_t> stride(ip->dims.size());
+            size_t st = 1;
+            for (int a = (int)ip->dims.size() - 1; a >= 0; a--) { stride[a] = st; st *= ip->dims[a]; }
+            const size_t base = (size_t)np->p[1] * stride[np->p[0]];
+            H::Fr sel = H::zero();
+            for (size_t o = 0; o < T_out; o++) {
+                size_t rem = o, off = base;
+                for (int d = (int)np->dims.size() - 1; d >= 0; d--) { off += (rem % np->dims[d]) * stride[d]; rem /= np->dims[d]; }
+                sel = H::add(sel, H::mul(eo[o], ei[off]));
+            }
+            *expect = H::mul(nodeio_claim(*np, 0), sel);
+            return (int)ATLAS_OK;
+        };
+        return run_single(gr::PT_Execution, I, "verify_graph: SumcheckVerificationError (slice)");
+    }
+    // Div (ops/div.rs verify_with_reduction, ReductionFlow::Custom)
+    int op_div(const Node& nd) {
+        const size_t log_T = gr::log2u(gr::padded_len(nd.dims));
+        const Point r = challenge_point(log_T);                              // DivParams::new
+        const Node* np = &nd;
+        Point pt_out;
+        Point* ptp = &pt_out;
+        VInst I;
+        I.claim = H::zero(); I.rounds = log_T; I.degree = 3;
+        I.finish = [=](const H::Fr* ch, H::Fr* expect) {
+            Point pt(log_T);
+            for (size_t q = 0; q < log_T; q++) pt[q] = ch[log_T - 1 - q];
+            int rc2 = append_nodeio(*np, 0, pt);
+            if (!rc2) rc2 = append_nodeio(*np, 1, pt);
+            if (!rc2) rc2 = append_current(*np, pt);
+            if (!rc2) rc2 = append_advice(*np, gr::VP_DivRemainder, pt);
+            if (rc2) return rc2;
+            *expect = H::mul(eq_mle(r.data(), pt.data(), log_T), H::sub(H::add(H::mul(nodeio_claim(*np, 1), current_claim(*np)), advice_claim(*np, gr::VP_DivRemainder)), nodeio_claim(*np, 0)));
+            *ptp = pt;
+            return (int)ATLAS_OK;
+        };
+        int rc = run_single(gr::PT_Execution, I, "verify_graph: SumcheckVerificationError (division)");
+        if (!rc) rc = eval_reduction(nd);
+        if (rc) return rc;
+        const gr::Opening& R = reduced.at(nd.idx);
+        rc = append_dense(nd, gr::CP_DivNodeQuotient, R.point);
+        if (rc) return rc;
+        if (!same(dense_claim(nd, gr::CP_DivNodeQuotient), R.claim)) return bad("verify_graph: InvalidOpeningProof (Div quotient claim does not match the reduced node-output claim)");
+        if (log_T == 0) return ATLAS_OK;
+        return range_and_onehot(nd, pt_out, advice_claim(nd, gr::VP_DivRemainder), nodeio_claim(nd, 1), gr::VP_DivRangeCheckRa, gr::CP_DivRangeCheckRaD, gr::PT_RaOneHotChecks);
+    }
+    // MeanOfSquares (ops/mean_of_squares.rs): fused-rescale pre, eq(r0, retained) x^2 over the input's hypercube, the remainder's range check
+    int op_mean_of_squares(const Node& nd) {
+        const gr::Opening& R = reduced.at(nd.idx);
+        const size_t log_T = R.point.size(), log_red = gr::log2u(gr::padded_len(G.nodes.at(nd.inputs[0]).dims)) - log_T;
+        const int64_t D = ((int64_t)1 << nd.p[0]) * (int64_t)nd.p[1];
+        int rc = append_advice(nd, gr::VP_RescaleRemainder, R.point);
+        if (!rc) rc = log_T ? clamp_lookup(nd) : scalar_clamp(nd);
+        if (rc) return rc;
+        const H::Fr eval_R = advice_claim(nd, gr::VP_RescaleRemainder);
+        const Node* np = &nd;
+        const Point r0 = R.point;
+        VInst I;
+        I.claim = H::add(H::mul(advice_claim(nd, gr::VP_ClampAcc), fr_i64(D)), eval_R); I.rounds = log_T + log_red; I.degree = 3;
+        I.finish = [=](const H::Fr* ch, H::Fr* expect) {
+            const Point pt(ch, ch + log_T + log_red);
+            int rc2 = append_nodeio(*np, 0, pt);
+            if (rc2) return rc2;
+            const H::Fr x = nodeio_claim(*np, 0);
+            *expect = H::mul(eq_mle(r0.data(), ch, log_T), H::mul(x, x));
+            return (int)ATLAS_OK;
+        };
+        rc = run_single(gr::PT_RescaleArith, I, "verify_graph: SumcheckVerificationError (mean of squares)");
+        if (rc || log_T == 0) return rc;
+        return range_and_onehot(nd, R.point, eval_R, fr_i64(D), gr::VP_MeanOfSquaresRangeCheckRa, gr::CP_MeanOfSquaresRangeCheckRaD, gr::PT_RescaleRemainderRaChecks);
+    }
+    // Rsqrt (ops/rsqrt.rs, ReductionFlow::Custom): x q + r_d = S^3 and out^2 + r_s = q at a fresh point, then both range checks batched
+    int op_rsqrt(const Node& nd) {
+        const size_t log_T = gr::log2u(gr::padded_len(nd.dims));
+        const Point r = challenge_point(log_T);
+        const H::Fr gamma = H::tr_challenge_scalar(Tr);
+        const H::Fr s_cubed = pow2_fr(3 * (size_t)nd.p[0]);
+        const Node* np = &nd;
+        Point pt_out;
+        Point* ptp = &pt_out;
+        VInst I;
+        I.claim = H::zero(); I.rounds = log_T; I.degree = 3;
+        I.finish = [=](const H::Fr* ch, H::Fr* expect) {
+            Point pt(log_T);
+            for (size_t q = 0; q < log_T; q++) pt[q] = ch[log_T - 1 - q];
+            int rc2 = append_nodeio(*np, 0, pt);
+            if (!rc2) rc2 = append_dense(*np, gr::CP_RsqrtQuotient, pt);
+            if (!rc2) rc2 = append_current(*np, pt);
+            if (!rc2) rc2 = append_advice(*np, gr::VP_DivRemainder, pt);
+            if (!rc2) rc2 = append_advice(*np, gr::VP_SqrtRemainder, pt);
+            if (rc2) return rc2;
+            const H::Fr x = nodeio_claim(*np, 0), q = dense_claim(*np, gr::CP_RsqrtQuotient), o = current_claim(*np), rd = advice_claim(*np, gr::VP_DivRemainder), rs_ = advice_claim(*np, gr::VP_SqrtRemainder);
+            const H::Fr a = H::sub(H::add(H::mul(x, q), rd), s_cubed), b = H::sub(H::add(H::mul(o, o), rs_), q);
+            *expect = H::mul(eq_mle(r.data(), pt.data(), log_T), H::add(a, H::mul(gamma, b)));
+            *ptp = pt;
+            return (int)ATLAS_OK;
+        };
+        int rc = run_single(gr::PT_Execution, I, "verify_graph: SumcheckVerificationError (rsqrt)");
+        if (!rc) rc = eval_reduction(nd);
+        if (rc || log_T == 0) return rc;
+        // verify_range_and_onehot (rsqrt.rs): r_d < x and r_s < 2 out + 1
+        const H::Fr o = current_claim(nd);
+        Point ra0, ra1;
+        std::vector<VInst> B;
+        B.push_back(inst_range_check(nd, pt_out, advice_claim(nd, gr::VP_DivRemainder), nodeio_claim(nd, 0), gr::VP_DivRangeCheckRa, &ra0));
+        B.push_back(inst_range_check(nd, pt_out, advice_claim(nd, gr::VP_SqrtRemainder), H::add(H::add(o, o), H::one()), gr::VP_SqrtRangeCheckRa, &ra1));
+        rc = batch(gr::PT_RangeCheck, B);
+        if (rc) return rc;
+        std::vector<VInst> O;
+        onehot_insts(nd, 64, pt_out, ra0, advice_claim(nd, gr::VP_DivRangeCheckRa), gr::CP_SqrtDivRangeCheckRaD, O);
+        onehot_insts(nd, 64, pt_out, ra1, advice_claim(nd, gr::VP_SqrtRangeCheckRa), gr::CP_SqrtRangeCheckRaD, O);
+        return batch(gr::PT_RaOneHotChecks, O);
+    }
+    // Tanh (ops/tanh.rs -> activation_clamped/mod.rs verify_clamped_activation): the small-table lookup of the clamped input, the clamp
+    // lookup tying `clamped` to the raw input, both families' one-hot checks in one batch
+    int op_tanh(const Node& nd) {
+        const gr::Opening& R = reduced.at(nd.idx);
+        const size_t LK = gr::ACTIVATION_TABLE_VARS, log_T = R.point.size();
+        const H::Fr gamma = H::tr_challenge_scalar(Tr);                      // SmallTableParams::new
+        int rc = append_advice(nd, gr::VP_ActivationClampedOutput, R.point);
+        if (rc) return rc;
+        const std::vector<int32_t>* table = nullptr;
+        const int32_t* d_table = nullptr;
+        rc = atlas_rt_tanh_table(&d_table, &table);
+        if (rc) return rc;
+        const H::Fr clamped = advice_claim(nd, gr::VP_ActivationClampedOutput);
+        const Node* np = &nd;
+        const Point r0 = R.point;
+        Point small_pt; Point* spp = &small_pt;
+        VInst I;
+        I.claim = H::add(R.claim, H::mul(gamma, clamped)); I.rounds = LK; I.degree = 2;
+        I.finish = [=](const H::Fr* ch, H::Fr* expect) {
+            Point ra(LK);
+            for (size_t q = 0; q < LK; q++) ra[q] = ch[LK - 1 - q];
+            Point pt = ra;
+            pt.insert(pt.end(), r0.begin(), r0.end());
+            int rc2 = append_advice(*np, gr::VP_ActivationSmallRa, pt);
+            if (rc2) return rc2;
+            H::Fr tv;
+            rc2 = eval_public(table->data(), table->size(), ra, &tv);
+            if (rc2) return rc2;
+            *expect = H::mul(advice_claim(*np, gr::VP_ActivationSmallRa), H::add(tv, H::mul(gamma, signed_identity_mle(ra.data(), LK))));
+            *spp = pt;
+            return (int)ATLAS_OK;
+        };
+        rc = run_single(gr::PT_Execution, I, "verify_graph: SumcheckVerificationError (activation table)");
+        if (rc) return rc;
+        Point clamp_pt;
+        rc = ps_unary(nd, T_CLAMP_SYM, 32, gr::ACTIVATION_BOUND, gr::node_exec(gr::virt(gr::VP_NodeOutput, nd.inputs[0]), nd.idx), clamped, R.point, gr::VP_ActivationClampRa, gr::PT_NeuralTeleport, &clamp_pt);
+        if (rc) return rc;
+        (void)log_T;
+        std::vector<VInst> O;
+        onehot_insts(nd, LK, R.point, small_pt, advice_claim(nd, gr::VP_ActivationSmallRa), gr::CP_ActivationSmallRaD, O);
+        onehot_insts(nd, 32, R.point, clamp_pt, advice_claim(nd, gr::VP_ActivationClampRa), gr::CP_ActivationClampRaD, O);
+        return batch(gr::PT_RaOneHotChecks, O);
+    }
+    // GatherLarge (ops/gather/mod.rs + large.rs): sum_k ra(k) (dict_r(k) + gamma k), then the one-hot checks over the index cycle
+    int op_gather(const Node& nd) {
+        const gr::Opening& R = reduced.at(nd.idx);
+        const Node& dict = G.nodes.at(nd.inputs[0]);
+        const Node& idxn = G.nodes.at(nd.inputs[1]);
+        const size_t V = dict.dims[0], lv = gr::log2u(V), ln = gr::log2u(gr::padded_len(idxn.dims));
+        const H::Fr gamma = H::tr_challenge_scalar(Tr);                      // GatherParams::new
+        const Point r_index(R.point.begin(), R.point.begin() + ln), r_word(R.point.begin() + ln, R.point.end());
+        int rc = append_nodeio(nd, 1, r_index);
+        if (rc) return rc;
+        const Node* np = &nd;
+        Point ra_pt; Point* rpp = &ra_pt;
+        VInst I;
+        I.claim = H::add(R.claim, H::mul(gamma, nodeio_claim(nd, 1))); I.rounds = lv; I.degree = 2;
+        I.finish = [=](const H::Fr* ch, H::Fr* expect) {
+            Point ra(lv);
+            for (size_t q = 0; q < lv; q++) ra[q] = ch[lv - 1 - q];
+            Point p_ra = ra, p_dict = ra;
+            p_ra.insert(p_ra.end(), r_index.begin(), r_index.end());
+            p_dict.insert(p_dict.end(), r_word.begin(), r_word.end());
+            int rc2 = append_advice(*np, gr::VP_NodeOutputRa, p_ra);
+            if (!rc2) rc2 = append_nodeio(*np, 0, p_dict);
+            if (rc2) return rc2;
+            *expect = H::mul(advice_claim(*np, gr::VP_NodeOutputRa), H::add(nodeio_claim(*np, 0), H::mul(gamma, identity_mle(ra.data(), lv))));
+            *rpp = p_ra;
+            return (int)ATLAS_OK;
+        };
+        rc = run_single(gr::PT_Execution, I, "verify_graph: SumcheckVerificationError (gather)");
+        if (!rc) rc = onehot_checks(nd, lv, r_index, ra_pt, advice_claim(nd, gr::VP_NodeOutputRa), gr::CP_GatherRaD, gr::PT_RaOneHotChecks);
+        return rc;
+    }
+    // SoftmaxLastAxis (ops/softmax_last_axis/mod.rs:286-333, 742-1135): the auxiliary vectors, four BatchedSumcheck stages, the operand link
+    int op_softmax(const Node& nd) {
+        const gr::Opening& R = reduced.at(nd.idx);
+        const size_t LS = gr::MODEL_SCALE, N = nd.dims.back(), T = gr::padded_len(nd.dims), F = T / gr::next_pow2(N), lf = gr::log2u(F), log_T = gr::log2u(T);
+        const ExpLut* L = nullptr;
+        int rc = atlas_rt_exp_lut(&L);
+        if (rc) return rc;
+        const size_t lk_hi = gr::log2u(L->hi.size()), lk_lo = gr::log2u(L->lo.size());
+        const Node* np = &nd;
+        // SoftmaxLastAxisVerifier::new: exp_sum_q[k], max_k[k], argmax_k[k] from the proof, as u64 -> i32
+        std::vector<int32_t> exp_sum(F), max_k(F), inv_sum(F); std::vector<size_t> argmax(F);
+        {
+            const Point empty;
+            const uint8_t vps[3] = {gr::VP_SoftmaxSumOutput, gr::VP_SoftmaxMaxOutput, gr::VP_SoftmaxMaxIndex};
+            for (size_t k = 0; k < F; k++)
+                for (int q = 0; q < 3; q++) {
+                    const OpeningId id = gr::node_exec(gr::virt(vps[q], nd.idx, k), nd.idx);
+                    rc = append_virtual(id, empty);
+                    if (rc) return rc;
+                    uint64_t c[4];
+                    H::to_canonical(claim_of(id), c);
+                    if (c[1] || c[2] || c[3]) return bad("verify_graph: an auxiliary softmax scalar does not fit 64 bits");
+                    if (q == 0) exp_sum[k] = (int32_t)(uint32_t)c[0]; else if (q == 1) max_k[k] = (int32_t)(uint32_t)c[0]; else argmax[k] = (size_t)c[0];
+                    if (q == 0) {                                           // inv_sum_evals: floor(S^2 / exp_sum_q[k])
+                        if ((int64_t)c[0] == 0) return bad("verify_graph: InvalidOpeningProof (exp_sum_q is zero)");
+                        inv_sum[k] = (int32_t)((((int64_t)1 << LS) * ((int64_t)1 << LS)) / (int64_t)c[0]);
+                    }
+                }
+        }
+        const Point r0 = R.point, r_lead(r0.begin(), r0.begin() + lf);
+        rc = append_advice(nd, gr::VP_SoftmaxExpSum, r_lead);                // cache_exp_sum
+        if (rc) return rc;
+        if (!same(mle_i32(exp_sum, r_lead.data(), lf), advice_claim(nd, gr::VP_SoftmaxExpSum))) return bad("verify_graph: InvalidOpeningProof (exp_sum evaluation mismatch)");
+        rc = append_advice(nd, gr::VP_SoftmaxRecipMultRemainder, r0);        // cache_R
+        if (rc) return rc;
+        const H::Fr S_fr = pow2_fr(LS), R_claim = advice_claim(nd, gr::VP_SoftmaxRecipMultRemainder);
+        auto rev = [](const H::Fr* ch, size_t n) { Point p(n); for (size_t q = 0; q < n; q++) p[q] = ch[n - 1 - q]; return p; };
+        Point r1, r2, Rra, Era, hi_pt, lo_pt, Cra;
+        Point *r1p = &r1, *r2p = &r2;
+        {   // ---- stage 1: RecipMult, ExpSum, IdentityRC of R
+            std::vector<VInst> B(2);
+            B[0].claim = H::add(H::mul(R.claim, S_fr), R_claim); B[0].rounds = log_T; B[0].degree = 3;
+            B[0].finish = [=](const H::Fr* ch, H::Fr* expect) {
+                const Point p = rev(ch, log_T);
+                int rc2 = append_advice(*np, gr::VP_SoftmaxExpQ, p);
+                if (rc2) return rc2;
+                *expect = H::mul(eq_mle(r0.data(), p.data(), log_T), H::mul(advice_claim(*np, gr::VP_SoftmaxExpQ), mle_i32(inv_sum, p.data(), lf)));
+                *r1p = p;
+                return (int)ATLAS_OK;
+            };
+            B[1].claim = advice_claim(nd, gr::VP_SoftmaxExpSum); B[1].rounds = log_T; B[1].degree = 2;
+            B[1].finish = [=](const H::Fr* ch, H::Fr* expect) {
+                const Point p = rev(ch, log_T);
+                int rc2 = append_advice(*np, gr::VP_SoftmaxExpQ, p);
+                if (rc2) return rc2;
+                *expect = H::mul(eq_mle(r0.data(), p.data(), lf), advice_claim(*np, gr::VP_SoftmaxExpQ));
+                return (int)ATLAS_OK;
+            };
+            B.push_back(inst_identity_rc(nd, LS, R_claim, r0, gr::VP_SoftmaxRemainderRa, &Rra));
+            rc = batch(gr::PT_SoftmaxStage1, B);
+            if (rc) return rc;
+        }
+        {   // ---- stage 2: Mult, MaxIndicator, IdentityRC of r_exp, the one-hot checks of R
+            rc = append_advice(nd, gr::VP_SoftmaxExpRemainder, r1);          // cache_r_exp
+            if (rc) return rc;
+            const H::Fr r_exp_claim = advice_claim(nd, gr::VP_SoftmaxExpRemainder);
+            const Point r1c = r1;
+            std::vector<VInst> B(2);
+            B[0].claim = H::add(H::mul(advice_claim(nd, gr::VP_SoftmaxExpQ), S_fr), r_exp_claim); B[0].rounds = log_T; B[0].degree = 3;
+            B[0].finish = [=](const H::Fr* ch, H::Fr* expect) {
+                const Point p = rev(ch, log_T);
+                int rc2 = append_advice(*np, gr::VP_SoftmaxExpHi, p);
+                if (!rc2) rc2 = append_advice(*np, gr::VP_SoftmaxExpLo, p);
+                if (rc2) return rc2;
+                *expect = H::mul(eq_mle(r1c.data(), p.data(), log_T), H::mul(advice_claim(*np, gr::VP_SoftmaxExpHi), advice_claim(*np, gr::VP_SoftmaxExpLo)));
+                *r2p = p;
+                return (int)ATLAS_OK;
+            };
+            B[1].claim = mle_i32(max_k, r1.data(), lf); B[1].rounds = log_T; B[1].degree = 3;
+            B[1].finish = [=](const H::Fr* ch, H::Fr* expect) {
+                const Point p = rev(ch, log_T);
+                int rc2 = append_nodeio(*np, 0, p);
+                if (rc2) return rc2;
+                const std::vector<H::Fr> ek = eq_table(p.data(), lf);       // e~(r_k, r_j) = sum_k eq(r_k, k) eq(r_j, bits(argmax_k))
+                const size_t ln = log_T - lf;
+                H::Fr e_claim = H::zero();
+                for (size_t k = 0; k < F; k++) {
+                    H::Fr y = ek[k];
+                    for (size_t q = 0; q < ln; q++) { const bool bit = (argmax[k] >> (ln - 1 - q)) & 1; y = H::mul(y, bit ? p[lf + q] : H::sub(H::one(), p[lf + q])); }
+                    e_claim = H::add(e_claim, y);
+                }
+                *expect = H::mul(H::mul(eq_mle(r1c.data(), p.data(), lf), e_claim), nodeio_claim(*np, 0));
+                return (int)ATLAS_OK;
+            };
+            B.push_back(inst_identity_rc(nd, LS, r_exp_claim, r1, gr::VP_SoftmaxExpRemainderRa, &Era));
+            onehot_insts(nd, LS, r0, Rra, advice_claim(nd, gr::VP_SoftmaxRemainderRa), gr::CP_SoftmaxRemainderRaD, B);
+            rc = batch(gr::PT_SoftmaxStage2, B);
+            if (rc) return rc;
+        }
+        {   // ---- stage 3: the two exp-digit Shout lookups, the significance clamp, the one-hot checks of r_exp
+            rc = append_advice(nd, gr::VP_SoftmaxZHi, r2);                   // cache_z_hi_lo
+            if (!rc) rc = append_advice(nd, gr::VP_SoftmaxZLo, r2);
+            if (rc) return rc;
+            const H::Fr zhi = advice_claim(nd, gr::VP_SoftmaxZHi), zlo = advice_claim(nd, gr::VP_SoftmaxZLo);
+            std::vector<VInst> B;
+            B.push_back(inst_shout(nd, L->hi, lk_hi, advice_claim(nd, gr::VP_SoftmaxExpHi), zhi, r2, gr::VP_SoftmaxZHiRa, &hi_pt));
+            B.push_back(inst_shout(nd, L->lo, lk_lo, advice_claim(nd, gr::VP_SoftmaxExpLo), zlo, r2, gr::VP_SoftmaxZLoRa, &lo_pt));
+            VInst C;
+            const H::Fr rv = H::add(H::mul(zhi, pow2_fr(L->log2_base)), zlo);                                 // significance_clamp.rs:61-69
+            rc = inst_ps_unary(nd, T_CLAMP, 32, lk_hi + L->log2_base, gr::node_exec(gr::virt(gr::VP_SoftmaxClampWitness, nd.idx), nd.idx), rv, r2, gr::VP_SoftmaxClampRa, &Cra, &C);
+            if (rc) return rc;
+            B.push_back(std::move(C));
+            onehot_insts(nd, LS, r1, Era, advice_claim(nd, gr::VP_SoftmaxExpRemainderRa), gr::CP_SoftmaxExpRemainderRaD, B);
+            rc = batch(gr::PT_SoftmaxStage3, B);
+            if (rc) return rc;
+        }
+        // operand_link: X(r2) = max_k(r2_lead) - z(r2)
+        if (!same(nodeio_claim(nd, 0), H::sub(mle_i32(max_k, r2.data(), lf), advice_claim(nd, gr::VP_SoftmaxClampWitness))))
+            return bad("verify_graph: InvalidOpeningProof (operand link: X(r2) does not match max_k - z)");
+        std::vector<VInst> B;                                                // ---- stage 4
+        onehot_insts(nd, lk_hi, r2, hi_pt, advice_claim(nd, gr::VP_SoftmaxZHiRa), gr::CP_SoftmaxZHiRaD, B);
+        onehot_insts(nd, lk_lo, r2, lo_pt, advice_claim(nd, gr::VP_SoftmaxZLoRa), gr::CP_SoftmaxZLoRaD, B);
+        onehot_insts(nd, 32, r2, Cra, advice_claim(nd, gr::VP_SoftmaxClampRa), gr::CP_SoftmaxClampRaD, B);
+        return batch(gr::PT_SoftmaxStage4, B);
+    }
     int public_tensor(const Node& nd, const int32_t* host) {                  // Input / Constant: the verifier evaluates the tensor itself
         const gr::Opening& R = reduced.at(nd.idx);
         H::Fr expect;
@@ -415,6 +944,8 @@ struct Verifier {
     }
     int verify_node(const Node& nd, size_t& next_input_from_end) {
         cur = nd.idx;
+        if (nd.op == ATLAS_OP_DIV) return op_div(nd);                          // ReductionFlow::Custom
+        if (nd.op == ATLAS_OP_RSQRT) return op_rsqrt(nd);
         int rc = eval_reduction(nd);
         if (rc) return rc;
         const gr::Opening& R = reduced.at(nd.idx);
@@ -445,6 +976,13 @@ struct Verifier {
             case ATLAS_OP_IFF: return ew_verify(nd, 3, 3, R.claim, gr::PT_Execution, 1);
             case ATLAS_OP_RELU: return op_relu(nd);
             case ATLAS_OP_RESHAPE: return op_reshape(nd);
+            case ATLAS_OP_SUM: return op_sum(nd);
+            case ATLAS_OP_SCALAR_CONST_DIV: return op_scalar_const_div(nd);
+            case ATLAS_OP_SLICE: return op_slice(nd);
+            case ATLAS_OP_MEAN_OF_SQUARES: return op_mean_of_squares(nd);
+            case ATLAS_OP_TANH: return op_tanh(nd);
+            case ATLAS_OP_GATHER_LARGE: return op_gather(nd);
+            case ATLAS_OP_SOFTMAX: return op_softmax(nd);
             default: return fail(ATLAS_EINVAL, "verify_graph: operator without a verifier composition");
         }
     }
@@ -454,8 +992,9 @@ struct Verifier {
         for (auto& kv : G.nodes) {
             const Node& nd = kv.second;
             const size_t T = gr::padded_len(nd.dims), log_T = gr::log2u(T);
-            if (T == 1) continue;
+            if (T == 1 && nd.op != ATLAS_OP_SCALAR_CONST_DIV) continue;
             auto chunks = [&](uint8_t cp, size_t log_K) { for (size_t i = 0; i < (log_K + 3) / 4; i++) committed[gr::comm(cp, nd.idx, i)].log_T = log_T; };
+            auto dense = [&](uint8_t cp) { committed[gr::comm(cp, nd.idx)].log_T = log_T; };
             switch (nd.op) {
                 case ATLAS_OP_ADD: case ATLAS_OP_SUB: chunks(gr::CP_ClampRaD, 64); break;
                 case ATLAS_OP_EINSUM: case ATLAS_OP_MUL: case ATLAS_OP_SQUARE: case ATLAS_OP_CUBE:
@@ -463,6 +1002,25 @@ struct Verifier {
                     chunks(gr::CP_ClampRaD, 64);
                     break;
                 case ATLAS_OP_RELU: chunks(gr::CP_NodeOutputRaD, 32); break;
+                case ATLAS_OP_SUM: chunks(gr::CP_ClampRaD, 64); break;
+                case ATLAS_OP_SCALAR_CONST_DIV: dense(gr::CP_ScalarConstDivNodeRemainder); break;
+                case ATLAS_OP_DIV: dense(gr::CP_DivNodeQuotient); chunks(gr::CP_DivRangeCheckRaD, 64); break;
+                case ATLAS_OP_MEAN_OF_SQUARES: chunks(gr::CP_ClampRaD, 64); chunks(gr::CP_MeanOfSquaresRangeCheckRaD, 64); break;
+                case ATLAS_OP_RSQRT: dense(gr::CP_RsqrtQuotient); chunks(gr::CP_SqrtDivRangeCheckRaD, 64); chunks(gr::CP_SqrtRangeCheckRaD, 64); break;
+                case ATLAS_OP_TANH: chunks(gr::CP_ActivationClampRaD, 32); chunks(gr::CP_ActivationSmallRaD, gr::ACTIVATION_TABLE_VARS); break;
+                case ATLAS_OP_SOFTMAX: {
+                    const ExpLut* L = nullptr;
+                    int rc = atlas_rt_exp_lut(&L);
+                    if (rc) return rc;
+                    chunks(gr::CP_SoftmaxRemainderRaD, gr::MODEL_SCALE); chunks(gr::CP_SoftmaxExpRemainderRaD, gr::MODEL_SCALE); chunks(gr::CP_SoftmaxClampRaD, 32);
+                    chunks(gr::CP_SoftmaxZHiRaD, gr::log2u(L->hi.size())); chunks(gr::CP_SoftmaxZLoRaD, gr::log2u(L->lo.size()));
+                    break;
+                }
+                case ATLAS_OP_GATHER_LARGE: {
+                    const size_t ln = gr::log2u(gr::padded_len(G.nodes.at(nd.inputs[1]).dims)), lv = gr::log2u(G.nodes.at(nd.inputs[0]).dims[0]);
+                    for (size_t i = 0; i < (lv + 3) / 4; i++) committed[gr::comm(gr::CP_GatherRaD, nd.idx, i)].log_T = ln;
+                    break;
+                }
                 default: break;
             }
         }

@@ -142,7 +142,7 @@ def test_graph_proof_matches_oracle(atlas, builder, seed):
     G.free(); srs.free()
 
 
-@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2)])
+@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6)])
 def test_graph_proof_is_accepted_by_the_verifier(atlas, builder, seed):
     """ONNXProof::verify (atlas_verify_graph: opening claims from the proof, the node loop's verifier instances, the opening-reduction
     sumcheck, the joint commitment, HyperKZG::verify through the pairing) accepts the device's proof with the prover's final transcript
@@ -165,9 +165,11 @@ def test_graph_proof_is_accepted_by_the_verifier(atlas, builder, seed):
     assert not V.verify(vk, inputs, bad_out, proof)[0]
     n_open = int.from_bytes(proof[:8], "little")
     assert n_open > 10
-    for off in (8 + 13 + 5,                              # inside the first opening claim
-                len(proof) // 2,                         # somewhere in the sumcheck proofs / commitments
-                len(proof) - 40):                        # the last HyperKZG evaluation
+    offs = [8 + 13 + 5,                                  # inside the first opening claim
+            len(proof) // 2,                             # somewhere in the sumcheck proofs / commitments
+            len(proof) - 40]                             # the last HyperKZG evaluation
+    offs += [int(x) for x in np.random.default_rng(seed + 100).integers(8, len(proof), 6)]
+    for off in offs:
         bad = bytearray(proof); bad[off] ^= 1
         try:
             assert not V.verify(vk, inputs, out, bytes(bad))[0], off

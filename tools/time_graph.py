@@ -33,6 +33,14 @@ def run(name, level, reps):
         if best is None or tm["total_ms"] < best["total_ms"]:
             best = tm
     best.update(graph=name, level=level, proof_bytes=len(proof), max_vars=nv, setup_s=setup_s, state=state.hex()[:16])
+    if os.environ.get("ATLAS_GRAPH_VERIFY", "1") != "0":      # ONNXProof::verify of the proof just made (host arithmetic + the pairing)
+        vk = A.HyperKZG.vk_from_trapdoor(tau, srs.download(0, 1)[0])
+        out = G.node_output(outputs[0])
+        V = GG.Graph(nodes, outputs)
+        t0 = time.time()
+        ok, vstate = V.verify(vk, inputs, out, proof)
+        best.update(verify_ms=(time.time() - t0) * 1e3, verified=bool(ok and vstate == state))
+        V.free()
     print(json.dumps(best))
     G.free(); srs.free()
 
