@@ -46,6 +46,18 @@ struct Fr9Params {
                                    0x4b6d0300u, 0x429b8502u, 0x597098ceu, 0x00c19137u};
         return V[i];
     }
+    // 2^261 - 2p, normalized limbs: adding it and dropping bit 29 of the top limb subtracts 2p
+    __device__ __host__ static constexpr uint32_t comp2p(int i) {
+        constexpr uint32_t V[9] = {0x1ffffffeu, 0x01e0a6c0u, 0x0347b75eu, 0x105ede19u, 0x14f45af9u,
+                                   0x1a497e7eu, 0x1eb23d7du, 0x0347b397u, 0x1f9f3763u};
+        return V[i];
+    }
+    // t * INV29 mod 2^32: INV29 = 2^28 - 1, two full-rate instructions instead of a quarter-rate v_mul_lo_u32
+    __device__ static __forceinline__ uint32_t mul_inv29(uint32_t t) {
+        uint32_t sh = t << 28;
+        asm("" : "+v"(sh));                 // keeps instcombine from folding the pair back into a multiply
+        return sh - t;
+    }
     using Base = FrParams;
     // Montgomery(32) = 32 * 2^256 mod p, as 8 x u32 (multiplying by it undoes the 2^-5 of mont9)
     __device__ __host__ static constexpr uint32_t mont32(int i) {
@@ -73,6 +85,12 @@ struct Fq9Params {
                                    0x4b6d0300u, 0x429b8502u, 0x597098ceu, 0x00c19137u};
         return V[i];
     }
+    __device__ __host__ static constexpr uint32_t comp2p(int i) {
+        constexpr uint32_t V[9] = {0x0f060572u, 0x1df73e92u, 0x071ab961u, 0x1a55ba5eu, 0x14f44d0fu,
+                                   0x1a497e7eu, 0x1eb23d7du, 0x0347b397u, 0x1f9f3763u};
+        return V[i];
+    }
+    __device__ static __forceinline__ uint32_t mul_inv29(uint32_t t) { return t * INV29; }
     using Base = FqParams;
     __device__ __host__ static constexpr uint32_t mont32(int i) {
         constexpr uint32_t V[8] = {0x157ccc21u, 0x4e8384ebu, 0x0ce148c3u, 0xfb90a602u,
@@ -202,7 +220,7 @@ __device__ __forceinline__ F9 f9_mul(const F9& a, const F9& b) {
         const uint32_t bi = b.l[i];
 #pragma unroll
         for (int j = 0; j < 9; j++) t[j] += (uint64_t)a.l[j] * bi;
-        const uint32_t m = ((uint32_t)t[0] * P9::INV29) & F9_MASK;
+        const uint32_t m = P9::mul_inv29((uint32_t)t[0]) & F9_MASK;
 #pragma unroll
         for (int j = 0; j < 9; j++) t[j] += (uint64_t)m * P9::p(j);
         const uint64_t carry = t[0] >> 29;
@@ -216,6 +234,45 @@ __device__ __forceinline__ F9 f9_mul(const F9& a, const F9& b) {
 #pragma unroll
     for (int j = 0; j < 8; j++) { c += t[j]; o.l[j] = (uint32_t)c & F9_MASK; c >>= 29; }
     o.l[8] = (uint32_t)(c + t[8]);
+    return o;
+}
+
+// (s - [s >= 2p] 2p) + A*B*2^-261: the multiplication with a running sum folded in.  s normalized (limbs < 2^29, value
+// < 2^256).  Limb k of the addend rides as the START value of the accumulator that ends up at index k — t[9] of reduction
+// step k, which the Montgomery steps never see at index 0 — so the addition costs no instruction beyond the multiply-add it
+// seeds; the conditional subtraction is "+ (2^261 - 2p)" on those limbs with bit 29 of the top limb dropped at the end.
+// Output normalized; value < 2p(1 + 2^-22) + p + A*B/2^261 (a fixed point for running sums and for a + r(b - a)): it
+// replaces f9_norm_red(f9_add(s, f9_mul(a, b))), whose carry chain with a multiply per limb was a tenth of the data pass.
+template <class P9, int LO = 0>
+__device__ __forceinline__ F9 f9_mul_addred(const F9& a, const F9& b, const F9& s) {
+    const uint32_t mask = s.l[8] > P9::TOP2P ? 0xffffffffu : 0u;        // s.l[8] >= TOP2P + 1  =>  s > 2p
+    uint32_t x[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) x[i] = s.l[i] + (P9::comp2p(i) & mask);
+    uint64_t t[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) t[i] = 0;
+#pragma unroll
+    for (int k = 0; k < LO; k++) t[9 - LO + k] = x[k];                   // skipped steps: the limbs they would have seeded
+#pragma unroll
+    for (int i = LO; i < 9; i++) {
+        const uint32_t bi = b.l[i];
+        t[9] = x[i];
+#pragma unroll
+        for (int j = 0; j < 9; j++) t[j] += (uint64_t)a.l[j] * bi;
+        const uint32_t m = P9::mul_inv29((uint32_t)t[0]) & F9_MASK;
+#pragma unroll
+        for (int j = 0; j < 9; j++) t[j] += (uint64_t)m * P9::p(j);
+        const uint64_t carry = t[0] >> 29;
+#pragma unroll
+        for (int j = 0; j < 9; j++) t[j] = t[j + 1];
+        t[0] += carry;
+    }
+    F9 o;
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { c += t[j]; o.l[j] = (uint32_t)c & F9_MASK; c >>= 29; }
+    o.l[8] = (uint32_t)(c + t[8]) & F9_MASK;
     return o;
 }
 

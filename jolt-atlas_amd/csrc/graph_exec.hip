@@ -48,6 +48,15 @@ __global__ __launch_bounds__(256) void k_gather_strided(const int32_t* __restric
     }
 }
 
+// Concat: out[o(i)] = in[i], i over one operand (S.dim = its dims, S.a = the OUTPUT's strides, base = its offset along the axis)
+__global__ __launch_bounds__(256) void k_scatter_strided(const int32_t* __restrict__ in, Strides S, size_t base, size_t T, int32_t* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < T; i += (size_t)gridDim.x * 256) {
+        size_t rem = i, off = base;
+        for (int d = (int)S.n - 1; d >= 0; d--) { off += (rem % S.dim[d]) * S.a[d]; rem /= S.dim[d]; }
+        out[off] = in[i];
+    }
+}
+
 // Sum over one axis of a [m][n] tensor in i64 (sum_axes_i64, ops/sum.rs:18-58): axis 0 -> n outputs, axis 1 -> m outputs; the clamped
 // output and the clamp lookup index; with `squares`: sum of squares (mos_acc_i64, ops/mean_of_squares.rs:19-52)
 __global__ __launch_bounds__(256) void k_sum_axis(const int32_t* __restrict__ x, uint32_t m, uint32_t n, int axis, int squares, int64_t* __restrict__ acc) {
@@ -345,6 +354,24 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
                 base = st * istr[ax];
             }
             k_gather_strided<<<grid_for(T), 256, 0, g.stream>>>(in(0), S, base, T, out.as<int32_t>());
+            return ATLAS_OK;
+        }
+        case ATLAS_OP_CONCAT: {                                               // tensor::ops::concat along p[0] (atlas-onnx-tracer/src/tensor/ops.rs:2772)
+            const size_t ax = (size_t)nd.p[0], r = nd.dims.size();
+            if (nd.inputs.empty() || nd.inputs.size() > 8 || ax >= r || r > MAXR) return fail(ATLAS_EINVAL, "graph: Concat takes 1..8 operands and an axis of the output");
+            const std::vector<size_t> ostr = row_major(nd.dims);
+            size_t off = 0;
+            for (size_t k = 0; k < nd.inputs.size(); k++) {
+                const std::vector<size_t>& idims = in_node(k).dims;
+                if (idims.size() != r) return fail(ATLAS_EINVAL, "graph: Concat operand rank");
+                for (size_t a = 0; a < r; a++) if (a != ax && idims[a] != nd.dims[a]) return fail(ATLAS_EINVAL, "graph: Concat non-axis dimensions must match");
+                Strides S{}; S.n = (uint32_t)r;
+                for (size_t a = 0; a < r; a++) { S.dim[a] = (uint32_t)idims[a]; S.a[a] = (uint32_t)ostr[a]; }
+                const size_t Ti = gr::padded_len(idims);
+                k_scatter_strided<<<grid_for(Ti), 256, 0, g.stream>>>(in(k), S, off * ostr[ax], Ti, out.as<int32_t>());
+                off += idims[ax];
+            }
+            if (off != nd.dims[ax]) return fail(ATLAS_EINVAL, "graph: Concat output axis dimension must equal the sum of the operands'");
             return ATLAS_OK;
         }
         case ATLAS_OP_EINSUM: case ATLAS_OP_MUL: case ATLAS_OP_SQUARE: case ATLAS_OP_CUBE: {

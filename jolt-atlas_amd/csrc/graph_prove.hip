@@ -39,6 +39,19 @@ __global__ __launch_bounds__(256) void k_slice_selector(const Fr* __restrict__ e
         sel[off] = eq[o];
     }
 }
+// Concat operands over the largest input's hypercube (ops/concat.rs:429-443, 445-487): an input of fewer variables repeated over the low
+// ones, ext[i] = in[i >> shift]; its selector = eq(r_output, .) at the output index of input cell c, placed at c << shift (zero elsewhere)
+__global__ __launch_bounds__(256) void k_concat_extend(const int32_t* __restrict__ in, uint32_t shift, size_t len, Fr* __restrict__ ext) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (size_t)gridDim.x * 256) fe_store(ext + i, fr_from_i64((int64_t)in[i >> shift]));
+}
+__global__ __launch_bounds__(256) void k_concat_selector(const Fr* __restrict__ eq, SliceMap M /* dim = operand dims, stride = output strides */, size_t base, uint32_t shift,
+                                                         size_t T_in, Fr* __restrict__ sel /* zeroed */) {
+    for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < T_in; c += (size_t)gridDim.x * 256) {
+        size_t rem = c, off = base;
+        for (int d = (int)M.n - 1; d >= 0; d--) { off += (rem % M.dim[d]) * M.stride[d]; rem /= M.dim[d]; }
+        sel[c << shift] = eq[off];
+    }
+}
 unsigned grid_of(size_t n) { size_t b = (n + 255) / 256; return (unsigned)(b > 4096 ? 4096 : b ? b : 1); }
 H::Fr fr_from_i64_host(int64_t v) { return v >= 0 ? H::from_u64((uint64_t)v) : H::neg(H::from_u64((uint64_t)(-v))); }
 
@@ -606,6 +619,52 @@ struct Prover : FlowSink {
         return rc;
     }
 
+    // Concat (ops/concat.rs): sum_t input_t(x) selector_t(x) over the largest operand's hypercube; each operand opened at the leading
+    // variables of the (reversed) challenges
+    int op_concat(const Node& nd) {
+        const gr::Opening& R = red(nd);
+        const size_t n_in = nd.inputs.size(), ax = (size_t)nd.p[0], r = nd.dims.size();
+        size_t mx = 0;
+        std::vector<size_t> nv(n_in);
+        for (size_t k = 0; k < n_in; k++) { nv[k] = gr::log2u(gr::padded_len(G.nodes.at(nd.inputs[k]).dims)); mx = nv[k] > mx ? nv[k] : mx; }
+        const size_t len = (size_t)1 << mx;
+        std::vector<size_t> ostr(r);
+        { size_t st = 1; for (int a = (int)r - 1; a >= 0; a--) { ostr[a] = st; st *= nd.dims[a]; } }
+        atlas_poly_t eq = nullptr;
+        int rc = atlas_eq_evals((const atlas_fr_t*)R.point.data(), R.point.size(), nullptr, &eq);
+        std::vector<DevBuf> bufs(2 * n_in);
+        std::vector<atlas_poly_t> ops(2 * n_in, nullptr);
+        size_t off = 0;
+        for (size_t k = 0; k < n_in && !rc; k++) {
+            const Node& in = G.nodes.at(nd.inputs[k]);
+            const size_t T_in = gr::padded_len(in.dims);
+            const uint32_t shift = (uint32_t)(mx - nv[k]);
+            HIP_TRY(bufs[2 * k].alloc(len * sizeof(Fr))); HIP_TRY(bufs[2 * k + 1].alloc(len * sizeof(Fr)));
+            {
+                std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+                SliceMap M{}; M.n = (uint32_t)r;
+                for (size_t a = 0; a < r; a++) { M.dim[a] = (uint32_t)in.dims[a]; M.stride[a] = (uint32_t)ostr[a]; }
+                k_concat_extend<<<grid_of(len), 256, 0, g.stream>>>(G.tensor(in.idx), shift, len, bufs[2 * k].as<Fr>());
+                HIP_TRY(hipMemsetAsync(bufs[2 * k + 1].p, 0, len * sizeof(Fr), g.stream));
+                k_concat_selector<<<grid_of(T_in), 256, 0, g.stream>>>((const Fr*)eq->d, M, off * ostr[ax], shift, T_in, bufs[2 * k + 1].as<Fr>());
+                HIP_TRY(hipStreamSynchronize(g.stream));
+            }
+            off += in.dims[ax];
+            rc = atlas_poly_wrap_device_fr(bufs[2 * k].p, len, &ops[2 * k]);
+            if (!rc) rc = atlas_poly_wrap_device_fr(bufs[2 * k + 1].p, len, &ops[2 * k + 1]);
+        }
+        if (eq) atlas_poly_free(eq);
+        atlas_instance_t inst = nullptr;
+        if (!rc) rc = atlas_elementwise_new(ATLAS_EW_DOT, ops.data(), 2 * n_in, nullptr, mx, nullptr, 0, &inst);
+        for (atlas_poly_t p : ops) if (p) atlas_poly_free(p);
+        std::vector<H::Fr> rs, fin;
+        if (!rc) rc = run_single(inst, R.claim, gr::PT_Execution, rs, fin);
+        if (inst) atlas_instance_free(inst);
+        const Point pt = reversed(rs);
+        for (size_t k = 0; k < n_in && !rc; k++) rc = append_nodeio(nd, k, Point(pt.begin(), pt.begin() + nv[k]), fin[2 * k]);
+        return rc;
+    }
+
     // Div (ops/div.rs, ReductionFlow::Custom): the division sumcheck at a FRESH point, then the node's eval reduction, the committed
     // quotient at the reduced point, the range check R < divisor and its one-hot checks
     int op_div(const Node& nd) {
@@ -1104,6 +1163,7 @@ struct Prover : FlowSink {
             case ATLAS_OP_SUM: return op_sum(nd);
             case ATLAS_OP_SCALAR_CONST_DIV: return op_scalar_const_div(nd);
             case ATLAS_OP_SLICE: return op_slice(nd);
+            case ATLAS_OP_CONCAT: return op_concat(nd);
             case ATLAS_OP_MEAN_OF_SQUARES: return op_mean_of_squares(nd);
             case ATLAS_OP_TANH: return op_tanh(nd);
             case ATLAS_OP_GATHER_LARGE: return op_gather(nd);

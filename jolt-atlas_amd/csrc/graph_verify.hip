@@ -6,7 +6,7 @@
 // Host arithmetic, like the reference's verifier; the device only evaluates the PUBLIC tensors (inputs, constants, output) at the
 // verifier's points and adds up the joint commitment.  Nothing of the prover's trace is read.
 // Every operator the graph prover composes has its verifier composition here: Input, Constant, Identity, Add, Sub, Mul, Square, Cube, Einsum,
-// And, Iff, ReLU, Reshape, MoveAxis, Broadcast, Sum, ScalarConstDiv, Slice, Div, MeanOfSquares, Rsqrt, Tanh, GatherLarge, SoftmaxLastAxis.
+// And, Iff, ReLU, Reshape, MoveAxis, Broadcast, Sum, ScalarConstDiv, Slice, Concat, Div, MeanOfSquares, Rsqrt, Tanh, GatherLarge, SoftmaxLastAxis.
 // A verifier instance is a VInst (input claim, rounds, degree, and a closure = cache_openings + expected_output_claim); `run_single` is
 // Sumcheck::verify, `batch` is BatchedSumcheck::verify (an instance of n rounds sees the LAST n challenges, sumcheck.rs:150-170).
 #include <hip/hip_runtime.h>
@@ -638,6 +638,43 @@ struct Verifier {
         };
         return run_single(gr::PT_Execution, I, "verify_graph: SumcheckVerificationError (slice)");
     }
+    // Concat (ops/concat.rs:372-425): sum_t input_t(r'_lead) selector_t~(r')
+    int op_concat(const Node& nd) {
+        const gr::Opening& R = reduced.at(nd.idx);
+        const size_t n_in = nd.inputs.size(), ax = (size_t)nd.p[0], r = nd.dims.size();
+        size_t mx = 0;
+        std::vector<size_t> nv(n_in);
+        for (size_t k = 0; k < n_in; k++) { nv[k] = gr::log2u(gr::padded_len(G.nodes.at(nd.inputs[k]).dims)); mx = nv[k] > mx ? nv[k] : mx; }
+        const Node* np = &nd;
+        const Point r0 = R.point;
+        VInst I;
+        I.claim = R.claim; I.rounds = mx; I.degree = 2;
+        I.finish = [=](const H::Fr* ch, H::Fr* expect) {
+            Point pt(mx);
+            for (size_t q = 0; q < mx; q++) pt[q] = ch[mx - 1 - q];
+            for (size_t k = 0; k < n_in; k++) { int rc2 = append_nodeio(*np, k, Point(pt.begin(), pt.begin() + nv[k])); if (rc2) return rc2; }
+            const std::vector<H::Fr> eo = eq_table(r0.data(), r0.size()), ei = eq_table(pt.data(), mx);
+            std::vector<size_t> ostr(r);
+            { size_t st = 1; for (int a = (int)r - 1; a >= 0; a--) { ostr[a] = st; st *= np->dims[a]; } }
+            H::Fr acc = H::zero();
+            size_t off = 0;
+            for (size_t k = 0; k < n_in; k++) {
+                const Node& in = G.nodes.at(np->inputs[k]);
+                const size_t T_in = gr::padded_len(in.dims), shift = mx - nv[k];
+                H::Fr sel = H::zero();
+                for (size_t c = 0; c < T_in; c++) {
+                    size_t rem = c, o = off * ostr[ax];
+                    for (int d = (int)r - 1; d >= 0; d--) { o += (rem % in.dims[d]) * ostr[d]; rem /= in.dims[d]; }
+                    sel = H::add(sel, H::mul(eo[o], ei[c << shift]));
+                }
+                acc = H::add(acc, H::mul(nodeio_claim(*np, k), sel));
+                off += in.dims[ax];
+            }
+            *expect = acc;
+            return (int)ATLAS_OK;
+        };
+        return run_single(gr::PT_Execution, I, "verify_graph: SumcheckVerificationError (concat)");
+    }
     // Div (ops/div.rs verify_with_reduction, ReductionFlow::Custom)
     int op_div(const Node& nd) {
         const size_t log_T = gr::log2u(gr::padded_len(nd.dims));
@@ -979,6 +1016,7 @@ struct Verifier {
             case ATLAS_OP_SUM: return op_sum(nd);
             case ATLAS_OP_SCALAR_CONST_DIV: return op_scalar_const_div(nd);
             case ATLAS_OP_SLICE: return op_slice(nd);
+            case ATLAS_OP_CONCAT: return op_concat(nd);
             case ATLAS_OP_MEAN_OF_SQUARES: return op_mean_of_squares(nd);
             case ATLAS_OP_TANH: return op_tanh(nd);
             case ATLAS_OP_GATHER_LARGE: return op_gather(nd);

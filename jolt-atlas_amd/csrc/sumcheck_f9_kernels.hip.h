@@ -79,11 +79,11 @@ __global__ __launch_bounds__(SC_THREADS) void k_dot_eval2_f9(const Fr* __restric
     for (size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x; i < half; i += (size_t)gridDim.x * SC_THREADS) {
         const F9 l0 = f9_load(L + i), l1 = f9_load(L + i + half);
         const F9 r0 = f9_load(R + i), r1 = f9_load(R + i + half);
-        const F9 l2 = f9_norm(f9_add(l1, f9_sub<P9>(l1, l0))), r2 = f9_norm(f9_add(r1, f9_sub<P9>(r1, r0)));
-        acc0 = f9_norm_red<P9>(f9_add(acc0, f9_mul<P9>(l0, r0)));
-        acc2 = f9_norm_red<P9>(f9_add(acc2, f9_mul<P9>(l2, r2)));
+        const F9 l2 = f9_norm(f9_add(l1, f9_sub<P9>(l1, l0))), r2 = f9_add(r1, f9_sub<P9>(r1, r0));      // r2: lazy limbs < 2^31.4
+        acc0 = f9_mul_addred<P9>(l0, r0, acc0);
+        acc2 = f9_mul_addred<P9>(l2, r2, acc2);
     }
-    out.emit2(acc0, acc2);
+    out.emit2(f9_norm_red<P9, 1>(acc0), f9_norm_red<P9, 1>(acc2));
 }
 
 // fused ingest_challenge(r_j) + compute_message(j+1); operands bound in place (thread i owns
@@ -111,11 +111,12 @@ __global__ __launch_bounds__(SC_THREADS) void k_dot_bind_eval2_f9(Fr* L, Fr* R, 
             x0 = fe_load(L + nx); x1 = fe_load(L + nx + q); x2 = fe_load(L + nx + 2 * q); x3 = fe_load(L + nx + 3 * q);
             y0 = fe_load(R + nx); y1 = fe_load(R + nx + q); y2 = fe_load(R + nx + 2 * q); y3 = fe_load(R + nx + 3 * q);
         }
-        // a + r*(b - a): the difference carries +4p and limbs < 2^31, the product is < 1.03p
-        F9 l0 = f9_norm_red<P9>(f9_add(a0, f9_mul<P9, 4>(f9_sub<P9>(a2, a0), r32)));
-        F9 l1 = f9_norm_red<P9>(f9_add(a1, f9_mul<P9, 4>(f9_sub<P9>(a3, a1), r32)));
-        F9 r0 = f9_norm_red<P9>(f9_add(b0, f9_mul<P9, 4>(f9_sub<P9>(b2, b0), r32)));
-        F9 r1 = f9_norm_red<P9>(f9_add(b1, f9_mul<P9, 4>(f9_sub<P9>(b3, b1), r32)));
+        // a + r*(b - a): the difference carries +4p and limbs < 2^31, the product is < 1.03p; with the conditional 2p of
+        // f9_mul_addred the bound values stay < 3.04p (< 2^256: they are stored as 8 x 32)
+        F9 l0 = f9_mul_addred<P9, 4>(f9_sub<P9>(a2, a0), r32, a0);
+        F9 l1 = f9_mul_addred<P9, 4>(f9_sub<P9>(a3, a1), r32, a1);
+        F9 r0 = f9_mul_addred<P9, 4>(f9_sub<P9>(b2, b0), r32, b0);
+        F9 r1 = f9_mul_addred<P9, 4>(f9_sub<P9>(b3, b1), r32, b1);
         if constexpr (CANON_OUT) {
             fe_store(L + i, f9_canon<P9>(l0)); fe_store(L + i + q, f9_canon<P9>(l1));
             fe_store(R + i, f9_canon<P9>(r0)); fe_store(R + i + q, f9_canon<P9>(r1));
@@ -123,11 +124,11 @@ __global__ __launch_bounds__(SC_THREADS) void k_dot_bind_eval2_f9(Fr* L, Fr* R, 
             fe_store(L + i, f9_to_fe(l0)); fe_store(L + i + q, f9_to_fe(l1));
             fe_store(R + i, f9_to_fe(r0)); fe_store(R + i + q, f9_to_fe(r1));
         }
-        const F9 l2 = f9_norm(f9_add(l1, f9_sub<P9>(l1, l0))), r2 = f9_norm(f9_add(r1, f9_sub<P9>(r1, r0)));
-        acc0 = f9_norm_red<P9>(f9_add(acc0, f9_mul<P9>(l0, r0)));
-        acc2 = f9_norm_red<P9>(f9_add(acc2, f9_mul<P9>(l2, r2)));
+        const F9 l2 = f9_norm(f9_add(l1, f9_sub<P9>(l1, l0))), r2 = f9_add(r1, f9_sub<P9>(r1, r0));      // r2: lazy limbs < 2^31.4
+        acc0 = f9_mul_addred<P9>(l0, r0, acc0);
+        acc2 = f9_mul_addred<P9>(l2, r2, acc2);
     }
-    io.emit2(acc0, acc2);
+    io.emit2(f9_norm_red<P9, 1>(acc0), f9_norm_red<P9, 1>(acc2));
 }
 
 // ---- degree-2 tail over the round channel on the lazy limbs ---------------------------------------

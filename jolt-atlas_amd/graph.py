@@ -36,6 +36,8 @@ def node_params(nd):
         return [nd["source"], nd["destination"]], []
     if op == "Slice":
         return [nd["axis"], nd["start"], nd["end"]], []
+    if op == "Concat":
+        return [nd["axis"]], []
     if op == "ScalarConstDiv":
         return [nd["divisor"]], []
     if op == "Sum":

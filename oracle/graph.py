@@ -334,6 +334,9 @@ def execute(nodes, inputs):
             idims = next(n for n in nodes if n["idx"] == nd["inputs"][0])["dims"]
             sl = [slice(None)] * len(idims); sl[nd["axis"]] = slice(nd["start"], nd["end"])
             o = ins[0].reshape(idims)[tuple(sl)].reshape(-1).copy()
+        elif op == "Concat":                                     # tensor::ops::concat (atlas-onnx-tracer/src/tensor/ops.rs:2772)
+            parts = [ins[k].reshape(next(n for n in nodes if n["idx"] == j)["dims"]) for k, j in enumerate(nd["inputs"])]
+            o = np.concatenate(parts, axis=nd["axis"]).reshape(-1).copy()
         elif op == "Sum":
             idims = next(n for n in nodes if n["idx"] == nd["inputs"][0])["dims"]
             acc = ins[0].astype(np.int64).reshape(idims).sum(axis=nd["axes"][0]).reshape(-1)
@@ -746,6 +749,30 @@ class Prover:
         rs = self.run(I, claim, i, "Execution")
         self.append_nodeio(nd, 0, np.ascontiguousarray(rs[::-1]), I.finals()[0])
 
+    def op_concat(self, nd):
+        """Concat (ops/concat.rs:44-66, 210-372): sum over the inputs of input_t(x) selector_t(x) over the LARGEST input's hypercube, LowToHigh;
+        a shorter input is repeated over the low variables (extend_input_to_max_domain), its selector sits at index << shift (build_concat_selector)"""
+        i = nd["idx"]
+        r0, claim = self.reduced[i]
+        eq = orc.eq_evals(np.ascontiguousarray(r0)).reshape(*nd["dims"], 4)
+        idims = [self.nodes[j]["dims"] for j in nd["inputs"]]
+        nvs = [ilog2(int(np.prod(d))) for d in idims]
+        mx = max(nvs)
+        ops, off = [], 0
+        for k, j in enumerate(nd["inputs"]):
+            shift = mx - nvs[k]
+            ext = np.repeat(self.mle(j), 1 << shift, axis=0)
+            sl = [slice(None)] * len(idims[k]); sl[nd["axis"]] = slice(off, off + idims[k][nd["axis"]])
+            off += idims[k][nd["axis"]]
+            sel = orc.fr_array(1 << mx)
+            sel[:: 1 << shift] = eq[tuple(sl)].reshape(-1, 4)
+            ops += [np.ascontiguousarray(ext), sel]
+        I = OR.elementwise(OR.EW_DOT, ops, orc.fr_array(mx))
+        rs = self.run(I, claim, i, "Execution")
+        pt = np.ascontiguousarray(rs[::-1]); fin = I.finals()
+        for k in range(len(nd["inputs"])):
+            self.append_nodeio(nd, k, np.ascontiguousarray(pt[:nvs[k]]), fin[2 * k])
+
     def op_div(self, nd):
         i = nd["idx"]
         n = ilog2(len(self.trace[i]))
@@ -975,6 +1002,8 @@ class Prover:
         r0, claim = self.reduced[i]
         if op in ("Input", "Constant"):
             return
+        if op == "Concat":
+            return self.op_concat(nd)
         if op in ("Sum", "ScalarConstDiv", "Slice", "MeanOfSquares", "Tanh", "GatherLarge", "SoftmaxLastAxis"):
             return {"Sum": self.op_sum, "ScalarConstDiv": self.op_scalar_const_div, "Slice": self.op_slice, "MeanOfSquares": self.op_mean_of_squares,
                     "Tanh": self.op_tanh, "GatherLarge": self.op_gather, "SoftmaxLastAxis": self.op_softmax}[op](nd)

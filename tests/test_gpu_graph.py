@@ -104,6 +104,20 @@ def softmax_graph(rng, b=2, t=4, n=8, S=14):
     ], [3], [x.reshape(-1)]
 
 
+def concat_graph(rng):
+    """Concat (ops/concat.rs) along the last axis of three operands of unequal size (the smaller ones are repeated over the low variables of the
+    largest one's hypercube), an Add over the result, then a second Concat along axis 0 whose output carries the output claim"""
+    return [
+        {"idx": 0, "op": "Input", "inputs": [], "dims": [4, 2]},
+        _const(1, rng, [4, 2]),
+        _const(2, rng, [4, 4]),
+        {"idx": 3, "op": "Concat", "inputs": [0, 1, 2], "dims": [4, 8], "axis": 1},
+        _const(4, rng, [4, 8]),
+        {"idx": 5, "op": "Add", "inputs": [3, 4], "dims": [4, 8]},
+        {"idx": 6, "op": "Concat", "inputs": [5, 3], "dims": [8, 8], "axis": 0},
+    ], [6], [rng.integers(-64, 64, size=8).astype(np.int32)]
+
+
 def _max_vars(nodes):
     # the largest committed polynomial is a one-hot chunk: K = 16 addresses x T cycles
     return 4 + max(int(np.log2(np.prod(nd["dims"]))) for nd in nodes)
@@ -117,7 +131,7 @@ def toy_transformer(rng):
     return BG.tiny(layers=2)
 
 
-@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6)])
+@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6), (concat_graph, 7)])
 def test_graph_proof_matches_oracle(atlas, builder, seed):
     from oracle import graph as OG, orc
     from jolt_atlas_amd import graph as GG
@@ -142,7 +156,7 @@ def test_graph_proof_matches_oracle(atlas, builder, seed):
     G.free(); srs.free()
 
 
-@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6)])
+@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6), (concat_graph, 7)])
 def test_graph_proof_is_accepted_by_the_verifier(atlas, builder, seed):
     """ONNXProof::verify (atlas_verify_graph: opening claims from the proof, the node loop's verifier instances, the opening-reduction
     sumcheck, the joint commitment, HyperKZG::verify through the pairing) accepts the device's proof with the prover's final transcript
