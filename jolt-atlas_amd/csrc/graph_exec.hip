@@ -226,27 +226,48 @@ int atlas_rt_sum_config(const std::vector<size_t>& idims, size_t axis, size_t& m
     return axis < 2 ? ATLAS_OK : fail(ATLAS_EINVAL, "graph: Sum axis");
 }
 
-int atlas_rt_tanh_table(const int32_t** d_table, const std::vector<int32_t>** h_table) {
-    static std::vector<int32_t> host;
-    static int32_t* dev = nullptr;
+// erffunc of the tracer (tensor/ops.rs:3671-3735): Chebyshev fit of erfc with the coefficients below, the same operations in the same order
+static double atlas_erf_cheb(double x) {
+    static const double COF[28] = {-1.3026537197817094, 6.419697923564902e-1, 1.9476473204185836e-2, -9.56151478680863e-3, -9.46595344482036e-4,
+                                   3.66839497852761e-4, 4.2523324806907e-5, -2.0278578112534e-5, -1.624290004647e-6, 1.303655835580e-6,
+                                   1.5626441722e-8, -8.5238095915e-8, 6.529054439e-9, 5.059343495e-9, -9.91364156e-10,
+                                   -2.27365122e-10, 9.6467911e-11, 2.394038e-12, -6.886027e-12, 8.94487e-13,
+                                   3.13092e-13, -1.12708e-13, 3.81e-16, 7.106e-15, -1.523e-15,
+                                   -9.4e-17, 1.21e-16, -2.8e-17};
+    auto erfccheb = [&](double z) {
+        double d = 0.0, dd = 0.0;
+        const double t = 2.0 / (2.0 + z), ty = 4.0 * t - 2.0;
+        for (int j = 28 - 2; j >= 1; j--) { const double tmp = d; d = ty * d - dd + COF[j]; dd = tmp; }
+        return t * std::exp(-(z * z) + 0.5 * (COF[0] + ty * d) - dd);
+    };
+    return x >= 0.0 ? 1.0 - erfccheb(x) : erfccheb(-x) - 1.0;
+}
+int atlas_rt_activation_table(int op, const int32_t** d_table, const std::vector<int32_t>** h_table) {
+    static std::vector<int32_t> host[3];
+    static int32_t* dev[3] = {nullptr, nullptr, nullptr};
+    const int k = op == ATLAS_OP_TANH ? 0 : op == ATLAS_OP_ERF ? 1 : op == ATLAS_OP_SIGMOID ? 2 : -1;
+    if (k < 0) return fail(ATLAS_EINVAL, "activation_table: not a small-table activation");
     std::lock_guard<atlas_rt::Mutex> lk(g.mu);
-    if (host.empty()) {
+    if (host[k].empty()) {
         const size_t n = (size_t)1 << gr::ACTIVATION_TABLE_VARS;
         const double scale = (double)((uint64_t)1 << gr::MODEL_SCALE);
-        host.resize(n);
-        for (size_t i = 0; i < n; i++) {                                      // usize_to_n_bits, then tensor::ops::nonlinearities::tanh (tensor/ops.rs:3583-3591)
+        host[k].resize(n);
+        for (size_t i = 0; i < n; i++) {                                      // usize_to_n_bits, then tensor::ops::nonlinearities::{tanh, erffunc, sigmoid} (tensor/ops.rs:3583-3591, 3671-3735, 3101-3109)
             const int32_t v = i >= n / 2 ? (int32_t)i - (int32_t)n : (int32_t)i;
-            host[i] = (int32_t)std::round(scale * std::tanh((double)v / scale));
+            const double x = (double)v / scale;
+            const double f = k == 0 ? scale * std::tanh(x) : k == 1 ? scale * atlas_erf_cheb(x) : scale / (1.0 + std::exp(-x));
+            host[k][i] = (int32_t)std::round(f);
         }
     }
-    if (d_table && !dev) {
-        HIP_TRY(hipMalloc(&dev, host.size() * 4));
-        HIP_TRY(hipMemcpyAsync(dev, host.data(), host.size() * 4, hipMemcpyHostToDevice, g.stream));
+    if (d_table && !dev[k]) {
+        HIP_TRY(hipMalloc(&dev[k], host[k].size() * 4));
+        HIP_TRY(hipMemcpyAsync(dev[k], host[k].data(), host[k].size() * 4, hipMemcpyHostToDevice, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
-        g.at_shutdown.push_back([] { if (dev) { (void)hipFree(dev); dev = nullptr; } });
+        static bool registered = false;
+        if (!registered) { registered = true; g.at_shutdown.push_back([] { for (auto& d : dev) if (d) { (void)hipFree(d); d = nullptr; } registered = false; }); }
     }
-    if (d_table) *d_table = dev;
-    if (h_table) *h_table = &host;
+    if (d_table) *d_table = dev[k];
+    if (h_table) *h_table = &host[k];
     return ATLAS_OK;
 }
 
@@ -444,10 +465,10 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
             { uint64_t* lk2 = nullptr; int rc = atlas_lookup_indices_from_operands(W.rem2.as<int32_t>(), W.bound.as<int32_t>(), T, &lk2); if (rc) return rc; W.lookups2.p = lk2; }
             return ATLAS_OK;
         }
-        case ATLAS_OP_TANH: {
-            if (!need_inputs(1) || !same_len() || nd.p[0] != (int64_t)gr::MODEL_SCALE) return fail(ATLAS_EINVAL, "graph: Tanh needs one operand and scale = MODEL_SCALE (14): the prover's table is compiled for it");
+        case ATLAS_OP_TANH: case ATLAS_OP_ERF: case ATLAS_OP_SIGMOID: {       // ops/{tanh,erf,sigmoid}.rs of the tracer: clamp, then the function = the table
+            if (!need_inputs(1) || !same_len() || nd.p[0] != (int64_t)gr::MODEL_SCALE) return fail(ATLAS_EINVAL, "graph: Tanh / Erf / Sigmoid need one operand and scale = MODEL_SCALE (14): the prover's table is compiled for it");
             const int32_t* d_table = nullptr;
-            if (int rc = atlas_rt_tanh_table(&d_table, nullptr)) return rc;
+            if (int rc = atlas_rt_activation_table(nd.op, &d_table, nullptr)) return rc;
             NodeWitness& W = G.wit[nd.idx];
             HIP_TRY(W.clamped.alloc(T * 4)); HIP_TRY(W.lookups.alloc(T * 8)); HIP_TRY(W.lookups2.alloc(T * 8));
             k_tanh<<<grid_for(T), 256, 0, g.stream>>>(in(0), T, (uint32_t)gr::ACTIVATION_BOUND, d_table, out.as<int32_t>(), W.clamped.as<int32_t>(), W.lookups2.as<uint64_t>(), W.lookups.as<uint64_t>());

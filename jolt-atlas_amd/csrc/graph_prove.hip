@@ -190,7 +190,7 @@ struct Prover : FlowSink {
                     chunks(gr::CP_SqrtDivRangeCheckRaD, W.lookups.as<uint64_t>(), 64);
                     chunks(gr::CP_SqrtRangeCheckRaD, W.lookups2.as<uint64_t>(), 64);
                     break;
-                case ATLAS_OP_TANH:                                                                                      // clamped_activation_committed_polynomials
+                case ATLAS_OP_TANH: case ATLAS_OP_ERF: case ATLAS_OP_SIGMOID:                                            // clamped_activation_committed_polynomials
                     chunks(gr::CP_ActivationClampRaD, W.lookups.as<uint64_t>(), 32);
                     chunks(gr::CP_ActivationSmallRaD, W.lookups2.as<uint64_t>(), gr::ACTIVATION_TABLE_VARS);
                     break;
@@ -829,7 +829,7 @@ struct Prover : FlowSink {
         if (eq) atlas_poly_free(eq);
         mark("tanh: clamped claim + G");
         const int32_t* d_table = nullptr;
-        if (!rc) rc = atlas_rt_tanh_table(&d_table, nullptr);
+        if (!rc) rc = atlas_rt_activation_table(nd.op, &d_table, nullptr);
         if (!rc) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(d_table), K, &ops[1]);
         std::vector<int32_t> ident(K);
         for (size_t i = 0; i < K; i++) ident[i] = i >= K / 2 ? (int32_t)i - (int32_t)K : (int32_t)i;      // SignedIdentityPoly (signed_identity_poly.rs)
@@ -1165,7 +1165,7 @@ struct Prover : FlowSink {
             case ATLAS_OP_SLICE: return op_slice(nd);
             case ATLAS_OP_CONCAT: return op_concat(nd);
             case ATLAS_OP_MEAN_OF_SQUARES: return op_mean_of_squares(nd);
-            case ATLAS_OP_TANH: return op_tanh(nd);
+            case ATLAS_OP_TANH: case ATLAS_OP_ERF: case ATLAS_OP_SIGMOID: return op_tanh(nd);      // prove_clamped_activation<Table>
             case ATLAS_OP_GATHER_LARGE: return op_gather(nd);
             case ATLAS_OP_SOFTMAX: return op_softmax(nd);
             default: return fail(ATLAS_EINVAL, "prove_graph: operator without a prover composition");

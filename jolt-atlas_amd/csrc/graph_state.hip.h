@@ -43,9 +43,11 @@ struct atlas_graph {
     void clear_trace() { out.clear(); wit.clear(); traced = false; }
 };
 
-// the small activation table of Tanh (ops/tanh.rs:22-32 -> neural_teleport/utils.rs:67-85): Table[i] = round(2^14 tanh(signed18(i) / 2^14)),
-// built once on the host (the reference's f64 arithmetic) and kept in HBM; graph_exec.hip
-int atlas_rt_tanh_table(const int32_t** d_table, const std::vector<int32_t>** h_table);
+// the small activation tables of Tanh / Erf / Sigmoid (ops/tanh.rs:22-32, erf.rs:22-32, sigmoid.rs:22-32 -> neural_teleport/utils.rs:67-85):
+// Table[i] = round(2^14 f(signed18(i) / 2^14)), built once on the host (the reference's f64 arithmetic) and kept in HBM; graph_exec.hip.
+// op = ATLAS_OP_TANH / ATLAS_OP_ERF / ATLAS_OP_SIGMOID
+int atlas_rt_activation_table(int op, const int32_t** d_table, const std::vector<int32_t>** h_table);
+inline bool atlas_rt_is_activation(int op) { return op == ATLAS_OP_TANH || op == ATLAS_OP_ERF || op == ATLAS_OP_SIGMOID; }
 // the decomposed exp sub-tables of SoftmaxLastAxis at MODEL_SCALE (generate_exp_lut_decomposed, atlas-onnx-tracer/src/ops/softmax.rs:239-269;
 // lut_hi zero-padded to a power of two, :94-96), built once on the host in the reference's f64 arithmetic; graph_exec.hip
 struct ExpLut { std::vector<int32_t> hi, lo; size_t log2_base = 0; const int32_t *d_hi = nullptr, *d_lo = nullptr; };

@@ -6,7 +6,7 @@
 // Host arithmetic, like the reference's verifier; the device only evaluates the PUBLIC tensors (inputs, constants, output) at the
 // verifier's points and adds up the joint commitment.  Nothing of the prover's trace is read.
 // Every operator the graph prover composes has its verifier composition here: Input, Constant, Identity, Add, Sub, Mul, Square, Cube, Einsum,
-// And, Iff, ReLU, Reshape, MoveAxis, Broadcast, Sum, ScalarConstDiv, Slice, Concat, Div, MeanOfSquares, Rsqrt, Tanh, GatherLarge, SoftmaxLastAxis.
+// And, Iff, ReLU, Reshape, MoveAxis, Broadcast, Sum, ScalarConstDiv, Slice, Concat, Div, MeanOfSquares, Rsqrt, Tanh, Erf, Sigmoid, GatherLarge, SoftmaxLastAxis.
 // A verifier instance is a VInst (input claim, rounds, degree, and a closure = cache_openings + expected_output_claim); `run_single` is
 // Sumcheck::verify, `batch` is BatchedSumcheck::verify (an instance of n rounds sees the LAST n challenges, sumcheck.rs:150-170).
 #include <hip/hip_runtime.h>
@@ -782,8 +782,7 @@ struct Verifier {
         int rc = append_advice(nd, gr::VP_ActivationClampedOutput, R.point);
         if (rc) return rc;
         const std::vector<int32_t>* table = nullptr;
-        const int32_t* d_table = nullptr;
-        rc = atlas_rt_tanh_table(&d_table, &table);
+        rc = atlas_rt_activation_table(nd.op, nullptr, &table);
         if (rc) return rc;
         const H::Fr clamped = advice_claim(nd, gr::VP_ActivationClampedOutput);
         const Node* np = &nd;
@@ -1018,7 +1017,7 @@ struct Verifier {
             case ATLAS_OP_SLICE: return op_slice(nd);
             case ATLAS_OP_CONCAT: return op_concat(nd);
             case ATLAS_OP_MEAN_OF_SQUARES: return op_mean_of_squares(nd);
-            case ATLAS_OP_TANH: return op_tanh(nd);
+            case ATLAS_OP_TANH: case ATLAS_OP_ERF: case ATLAS_OP_SIGMOID: return op_tanh(nd);      // verify_clamped_activation<Table>
             case ATLAS_OP_GATHER_LARGE: return op_gather(nd);
             case ATLAS_OP_SOFTMAX: return op_softmax(nd);
             default: return fail(ATLAS_EINVAL, "verify_graph: operator without a verifier composition");
@@ -1045,7 +1044,7 @@ struct Verifier {
                 case ATLAS_OP_DIV: dense(gr::CP_DivNodeQuotient); chunks(gr::CP_DivRangeCheckRaD, 64); break;
                 case ATLAS_OP_MEAN_OF_SQUARES: chunks(gr::CP_ClampRaD, 64); chunks(gr::CP_MeanOfSquaresRangeCheckRaD, 64); break;
                 case ATLAS_OP_RSQRT: dense(gr::CP_RsqrtQuotient); chunks(gr::CP_SqrtDivRangeCheckRaD, 64); chunks(gr::CP_SqrtRangeCheckRaD, 64); break;
-                case ATLAS_OP_TANH: chunks(gr::CP_ActivationClampRaD, 32); chunks(gr::CP_ActivationSmallRaD, gr::ACTIVATION_TABLE_VARS); break;
+                case ATLAS_OP_TANH: case ATLAS_OP_ERF: case ATLAS_OP_SIGMOID: chunks(gr::CP_ActivationClampRaD, 32); chunks(gr::CP_ActivationSmallRaD, gr::ACTIVATION_TABLE_VARS); break;
                 case ATLAS_OP_SOFTMAX: {
                     const ExpLut* L = nullptr;
                     int rc = atlas_rt_exp_lut(&L);

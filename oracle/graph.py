@@ -206,6 +206,43 @@ def tanh_table():
     return _TANH
 
 
+_ACT = {}
+
+
+def _erf_cheb(x):
+    """erffunc of the tracer (atlas-onnx-tracer/src/tensor/ops.rs:3671-3735): a Chebyshev fit of erfc, the same f64 operations in the same order"""
+    import math
+    COF = [-1.3026537197817094, 6.419697923564902e-1, 1.9476473204185836e-2, -9.56151478680863e-3, -9.46595344482036e-4, 3.66839497852761e-4,
+           4.2523324806907e-5, -2.0278578112534e-5, -1.624290004647e-6, 1.303655835580e-6, 1.5626441722e-8, -8.5238095915e-8, 6.529054439e-9,
+           5.059343495e-9, -9.91364156e-10, -2.27365122e-10, 9.6467911e-11, 2.394038e-12, -6.886027e-12, 8.94487e-13, 3.13092e-13, -1.12708e-13,
+           3.81e-16, 7.106e-15, -1.523e-15, -9.4e-17, 1.21e-16, -2.8e-17]
+
+    def erfccheb(z):
+        d = dd = 0.0
+        t = 2.0 / (2.0 + z); ty = 4.0 * t - 2.0
+        for j in range(26, 0, -1):
+            d, dd = ty * d - dd + COF[j], d
+        return t * math.exp(-(z * z) + 0.5 * (COF[0] + ty * d) - dd)
+    return 1.0 - erfccheb(x) if x >= 0.0 else erfccheb(-x) - 1.0
+
+
+def activation_table(op):
+    """materialize_signed_activation_table (neural_teleport/utils.rs:67-85) for Tanh / Erf / Sigmoid (ops/tanh.rs, erf.rs, sigmoid.rs:22-32)"""
+    if op == "Tanh":
+        return tanh_table()
+    if op not in _ACT:
+        import math
+        n = 1 << ACTIVATION_TABLE_VARS
+        sc = float(1 << MODEL_SCALE)
+        out = np.zeros(n, dtype=np.int64)
+        for i in range(n):
+            v = i - n if i >= n // 2 else i
+            f = sc * _erf_cheb(v / sc) if op == "Erf" else sc / (1.0 + math.exp(-(v / sc)))
+            out[i] = int(math.floor(abs(f) + 0.5)) * (1 if f >= 0 else -1)
+        _ACT[op] = out
+    return _ACT[op]
+
+
 _EXP_LUT = {}
 
 
@@ -365,12 +402,12 @@ def execute(nodes, inputs):
             out_ = np.where(out_ * out_ > q, out_ - 1, out_); out_ = np.where((out_ + 1) * (out_ + 1) <= q, out_ + 1, out_)
             wit[nd["idx"]] = dict(quot=q, div_rem=dr.astype(np.int32), sqrt_rem=(q - out_ * out_).astype(np.int32), bound=(2 * out_ + 1).astype(np.int32))
             o = out_.astype(np.int32)
-        elif op == "Tanh":
+        elif op in ("Tanh", "Erf", "Sigmoid"):
             assert nd["scale"] == MODEL_SCALE
             c = np.clip(ins[0], -(1 << ACTIVATION_BOUND), (1 << ACTIVATION_BOUND) - 1).astype(np.int32)
             k = np.where(c < 0, c.astype(np.int64) + (1 << ACTIVATION_TABLE_VARS), c.astype(np.int64))
             wit[nd["idx"]] = dict(clamped=c, small_idx=k.astype(np.uint64))
-            o = tanh_table()[k].astype(np.int32)
+            o = activation_table(op)[k].astype(np.int32)
         elif op == "GatherLarge":
             ddims = next(n for n in nodes if n["idx"] == nd["inputs"][0])["dims"]
             o = ins[0].reshape(ddims[0], -1)[ins[1]].reshape(-1).astype(np.int32)
@@ -440,7 +477,7 @@ class Prover:
             return [("NodeOutputRaD", self.trace[nd["inputs"][0]].astype(np.uint32).astype(np.uint64), 32)]
         if op == "Sum":
             return [("ClampRaD", self.wit[i]["acc"].astype(np.int64).view(np.uint64), 64)]
-        if op == "Tanh":
+        if op in ("Tanh", "Erf", "Sigmoid"):
             return [("ActivationClampRaD", self.trace[nd["inputs"][0]].astype(np.uint32).astype(np.uint64), 32),
                     ("ActivationSmallRaD", self.wit[i]["small_idx"], ACTIVATION_TABLE_VARS)]
         if op == "GatherLarge":
@@ -860,7 +897,7 @@ class Prover:
         self.append_advice(nd, "ActivationClampedOutput", r0, clamped_claim)
         ra = self.ra_histogram(w["small_idx"], K, r0)
         ident = np.arange(K, dtype=np.int64); ident[K // 2:] -= K
-        I = OR.elementwise(OR.EW_GATHER, [ra, fr_fast(tanh_table()), fr_fast(ident)], orc.fr_array(LK), constants=gamma.reshape(1, 4))
+        I = OR.elementwise(OR.EW_GATHER, [ra, fr_fast(activation_table(nd["op"])), fr_fast(ident)], orc.fr_array(LK), constants=gamma.reshape(1, 4))
         rs = self.run(I, orc.fr_add_arr(out_claim, orc.fr_mul_arr(gamma, clamped_claim)), i, "Execution")
         small_pt = np.concatenate([rs[::-1], r0])
         ra_small = I.finals()[0]
@@ -1004,6 +1041,8 @@ class Prover:
             return
         if op == "Concat":
             return self.op_concat(nd)
+        if op in ("Erf", "Sigmoid"):
+            return self.op_tanh(nd)                                          # prove_clamped_activation::<_, _, Table>
         if op in ("Sum", "ScalarConstDiv", "Slice", "MeanOfSquares", "Tanh", "GatherLarge", "SoftmaxLastAxis"):
             return {"Sum": self.op_sum, "ScalarConstDiv": self.op_scalar_const_div, "Slice": self.op_slice, "MeanOfSquares": self.op_mean_of_squares,
                     "Tanh": self.op_tanh, "GatherLarge": self.op_gather, "SoftmaxLastAxis": self.op_softmax}[op](nd)

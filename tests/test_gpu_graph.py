@@ -104,6 +104,21 @@ def softmax_graph(rng, b=2, t=4, n=8, S=14):
     ], [3], [x.reshape(-1)]
 
 
+def erf_sigmoid_graph(rng, n=4, d=8, S=14):
+    """the other two small-table activations (ops/erf.rs, sigmoid.rs = prove_clamped_activation with their own tables): Erf of a wide-range
+    input (beyond the clamp on both sides), Sigmoid of a product"""
+    x = rng.integers(-(1 << 18), 1 << 18, size=n * d).astype(np.int32)
+    x[:4] = [0, -1, (1 << 17) - 1, -(1 << 17)]
+    return [
+        {"idx": 0, "op": "Input", "inputs": [], "dims": [n, d]},
+        {"idx": 1, "op": "Erf", "inputs": [0], "dims": [n, d], "scale": S},
+        _const(2, rng, [n, d], -(1 << 15), 1 << 15),
+        {"idx": 3, "op": "Mul", "inputs": [1, 2], "dims": [n, d], "scale": S},
+        {"idx": 4, "op": "Sigmoid", "inputs": [3], "dims": [n, d], "scale": S},
+        {"idx": 5, "op": "Add", "inputs": [4, 1], "dims": [n, d]},
+    ], [5], [x]
+
+
 def concat_graph(rng):
     """Concat (ops/concat.rs) along the last axis of three operands of unequal size (the smaller ones are repeated over the low variables of the
     largest one's hypercube), an Add over the result, then a second Concat along axis 0 whose output carries the output claim"""
@@ -131,7 +146,7 @@ def toy_transformer(rng):
     return BG.tiny(layers=2)
 
 
-@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6), (concat_graph, 7)])
+@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6), (concat_graph, 7), (erf_sigmoid_graph, 8)])
 def test_graph_proof_matches_oracle(atlas, builder, seed):
     from oracle import graph as OG, orc
     from jolt_atlas_amd import graph as GG
@@ -156,7 +171,7 @@ def test_graph_proof_matches_oracle(atlas, builder, seed):
     G.free(); srs.free()
 
 
-@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6), (concat_graph, 7)])
+@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6), (concat_graph, 7), (erf_sigmoid_graph, 8)])
 def test_graph_proof_is_accepted_by_the_verifier(atlas, builder, seed):
     """ONNXProof::verify (atlas_verify_graph: opening claims from the proof, the node loop's verifier instances, the opening-reduction
     sumcheck, the joint commitment, HyperKZG::verify through the pairing) accepts the device's proof with the prover's final transcript
