@@ -48,6 +48,17 @@ __global__ __launch_bounds__(256) void k_gather_strided(const int32_t* __restric
     }
 }
 
+// Neg / Clamp (tensor::ops::nonlinearities::clamp, tensor/ops.rs:3216-3220; the lookup index is `value as u32 as u64`)
+__global__ __launch_bounds__(256) void k_neg(const int32_t* __restrict__ x, size_t n, int32_t* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = (int32_t)(0u - (uint32_t)x[i]);
+}
+__global__ __launch_bounds__(256) void k_clamp_witness(const int32_t* __restrict__ x, size_t n, int32_t bound, int32_t* __restrict__ out, uint64_t* __restrict__ lookups) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int32_t v = x[i];
+        out[i] = v < -bound ? -bound : v > bound - 1 ? bound - 1 : v;
+        lookups[i] = (uint64_t)(uint32_t)v;
+    }
+}
 // Concat: out[o(i)] = in[i], i over one operand (S.dim = its dims, S.a = the OUTPUT's strides, base = its offset along the axis)
 __global__ __launch_bounds__(256) void k_scatter_strided(const int32_t* __restrict__ in, Strides S, size_t base, size_t T, int32_t* __restrict__ out) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < T; i += (size_t)gridDim.x * 256) {
@@ -342,6 +353,21 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
             NodeWitness& W = G.wit[nd.idx];
             HIP_TRY(W.lookups.alloc(T * 8));
             k_relu_witness<<<grid_for(T), 256, 0, g.stream>>>(in(0), T, out.as<int32_t>(), W.lookups.as<uint64_t>());
+            return ATLAS_OK;
+        }
+        case ATLAS_OP_NEG:                                                    // ops/neg.rs of the tracer (wrapping, like i32 negation in release builds)
+            if (!need_inputs(1) || !same_len()) return fail(ATLAS_EINVAL, "graph: Neg operand");
+            k_neg<<<grid_for(T), 256, 0, g.stream>>>(in(0), T, out.as<int32_t>());
+            return ATLAS_OK;
+        case ATLAS_OP_IS_NAN:                                                 // quantised tensors hold no NaN: all zeros
+            if (!need_inputs(1) || !same_len()) return fail(ATLAS_EINVAL, "graph: IsNan operand");
+            HIP_TRY(hipMemsetAsync(out.p, 0, T * 4, g.stream));
+            return ATLAS_OK;
+        case ATLAS_OP_CLAMP: {
+            if (!need_inputs(1) || !same_len() || nd.p[0] != (int64_t)gr::CLAMP_BOUND) return fail(ATLAS_EINVAL, "graph: Clamp needs one operand and bound_log = CLAMP_BOUND (9): the prover's table is compiled for it");
+            NodeWitness& W = G.wit[nd.idx];
+            HIP_TRY(W.lookups.alloc(T * 8));
+            k_clamp_witness<<<grid_for(T), 256, 0, g.stream>>>(in(0), T, (int32_t)1 << gr::CLAMP_BOUND, out.as<int32_t>(), W.lookups.as<uint64_t>());
             return ATLAS_OK;
         }
         case ATLAS_OP_MOVEAXIS: case ATLAS_OP_BROADCAST: case ATLAS_OP_SLICE: {

@@ -175,6 +175,7 @@ struct Prover : FlowSink {
                     chunks(gr::CP_ClampRaD, W.rescale->cidx.as<uint64_t>(), 64);
                     break;
                 case ATLAS_OP_RELU: chunks(gr::CP_NodeOutputRaD, W.lookups.as<uint64_t>(), 32); break;                 // ops/relu.rs
+                case ATLAS_OP_CLAMP: chunks(gr::CP_SymmetricClampRaD, W.lookups.as<uint64_t>(), 32); break;            // ops/clamp.rs
                 case ATLAS_OP_SUM: chunks(gr::CP_ClampRaD, W.cidx.as<uint64_t>(), 64); break;                           // ops/sum/mod.rs
                 case ATLAS_OP_SCALAR_CONST_DIV: dense(gr::CP_ScalarConstDivNodeRemainder, W.rem.p, true); break;         // ops/scalar_const_div.rs
                 case ATLAS_OP_DIV:                                                                                       // ops/div.rs
@@ -432,12 +433,24 @@ struct Prover : FlowSink {
         return rc;
     }
 
-    // ReLU (ops/relu.rs:22-70)
+    // Neg / IsNan (ops/neg.rs, is_nan.rs): no sumcheck, the operand opened at the reduced point
+    int op_operand_at_point(const Node& nd) {
+        const gr::Opening& R = red(nd);
+        H::Fr operand_claim;
+        const int32_t* tp = G.tensor(nd.inputs[0]);
+        int rc = eval_i32(&tp, 1, gr::padded_len(G.nodes.at(nd.inputs[0]).dims), R.point, &operand_claim);
+        if (!rc) rc = append_nodeio(nd, 0, R.point, operand_claim);
+        return rc;
+    }
+
+    // ReLU (ops/relu.rs:22-70); Clamp (ops/clamp.rs) is the same flow over ClampTable<32> = ClampBoundedTable<32, 9, true> under SymmetricClampRa(D)
     int op_relu(const Node& nd) {
         const size_t T = gr::padded_len(nd.dims), log_T = gr::log2u(T), XLEN = 32;
         const gr::Opening& R = red(nd);
         NodeWitness& W = G.wit[nd.idx];
         Out O = out();
+        const bool clamp = nd.op == ATLAS_OP_CLAMP;
+        const uint8_t ra_vp = clamp ? gr::VP_SymmetricClampRa : gr::VP_NodeOutputRa, rad_cp = clamp ? gr::CP_SymmetricClampRaD : gr::CP_NodeOutputRaD;
         H::Fr operand_claim;
         const int32_t* tp = G.tensor(nd.inputs[0]);
         int rc = eval_i32(&tp, 1, T, R.point, &operand_claim);
@@ -445,12 +458,13 @@ struct Prover : FlowSink {
         if (rc) return rc;
         const H::Fr gamma = H::tr_challenge_scalar(Tr);
         atlas_instance_t exec = nullptr;
-        rc = atlas_ps_shout_relu_new(W.lookups.as<uint64_t>(), log_T, XLEN, (const atlas_fr_t*)R.point.data(), (const atlas_fr_t*)&gamma, &exec);
+        rc = clamp ? atlas_ps_shout_clamp_new(W.lookups.as<uint64_t>(), log_T, XLEN, gr::CLAMP_BOUND, 1, (const atlas_fr_t*)R.point.data(), (const atlas_fr_t*)&gamma, &exec)
+                   : atlas_ps_shout_relu_new(W.lookups.as<uint64_t>(), log_T, XLEN, (const atlas_fr_t*)R.point.data(), (const atlas_fr_t*)&gamma, &exec);
         const H::Fr exec_claim = H::add(R.claim, H::mul(gamma, operand_claim));
         std::vector<atlas_u128_t> ch; H::Fr ra_claim; std::vector<atlas_fr_t> ra_point;
-        if (!rc) rc = prove_single(exec, exec_claim, &t, O, ch, &ra_claim, XLEN, gr::VP_NodeOutputRa, gr::PT_Execution, &ra_point);
+        if (!rc) rc = prove_single(exec, exec_claim, &t, O, ch, &ra_claim, XLEN, ra_vp, gr::PT_Execution, &ra_point);
         if (exec) atlas_instance_free(exec);
-        if (!rc) rc = prove_onehot_checks(W.lookups.as<uint64_t>(), log_T, XLEN, (const atlas_fr_t*)R.point.data(), ra_point, ra_claim, &t, O, gr::CP_NodeOutputRaD, gr::PT_RaOneHotChecks);
+        if (!rc) rc = prove_onehot_checks(W.lookups.as<uint64_t>(), log_T, XLEN, (const atlas_fr_t*)R.point.data(), ra_point, ra_claim, &t, O, rad_cp, gr::PT_RaOneHotChecks);
         return rc;
     }
 
@@ -1156,7 +1170,8 @@ struct Prover : FlowSink {
             case ATLAS_OP_EINSUM: case ATLAS_OP_MUL: case ATLAS_OP_SQUARE: case ATLAS_OP_CUBE: return op_fused(nd);
             case ATLAS_OP_AND: return ew_sumcheck(nd, ATLAS_EW_MUL, 2, R.claim, gr::PT_Execution);       // impl_standard_sumcheck_proof_api!(And, MulParams, ..)
             case ATLAS_OP_IFF: return ew_sumcheck(nd, ATLAS_EW_IFF, 3, R.claim, gr::PT_Execution);
-            case ATLAS_OP_RELU: return op_relu(nd);
+            case ATLAS_OP_RELU: case ATLAS_OP_CLAMP: return op_relu(nd);
+            case ATLAS_OP_NEG: case ATLAS_OP_IS_NAN: return op_operand_at_point(nd);
             case ATLAS_OP_RESHAPE: return op_reshape(nd);
             case ATLAS_OP_MOVEAXIS: return op_moveaxis(nd);
             case ATLAS_OP_BROADCAST: return op_broadcast(nd);

@@ -55,6 +55,7 @@ int atlas_rt_exp_lut(const ExpLut** out);
 
 namespace gr {
 constexpr size_t MODEL_SCALE = 14, ACTIVATION_BOUND = MODEL_SCALE + 3, ACTIVATION_TABLE_VARS = ACTIVATION_BOUND + 1;      // common/src/consts
+constexpr size_t CLAMP_BOUND = 9;                                // the ONNX Clamp op's table (joltworks/src/lookup_tables/clamp.rs:197-211)
 inline size_t next_pow2(size_t x) { size_t p = 1; while (p < x) p <<= 1; return p; }
 inline unsigned log2u(size_t x) { unsigned n = 0; while (x > 1) { x >>= 1; n++; } return n; }
 // pow2_padded_num_output_elements (node/mod.rs:52-57): every dimension padded on its own

@@ -6,7 +6,7 @@
 // Host arithmetic, like the reference's verifier; the device only evaluates the PUBLIC tensors (inputs, constants, output) at the
 // verifier's points and adds up the joint commitment.  Nothing of the prover's trace is read.
 // Every operator the graph prover composes has its verifier composition here: Input, Constant, Identity, Add, Sub, Mul, Square, Cube, Einsum,
-// And, Iff, ReLU, Reshape, MoveAxis, Broadcast, Sum, ScalarConstDiv, Slice, Concat, Div, MeanOfSquares, Rsqrt, Tanh, Erf, Sigmoid, GatherLarge, SoftmaxLastAxis.
+// And, Iff, ReLU, Clamp, Neg, IsNan, Reshape, MoveAxis, Broadcast, Sum, ScalarConstDiv, Slice, Concat, Div, MeanOfSquares, Rsqrt, Tanh, Erf, Sigmoid, GatherLarge, SoftmaxLastAxis.
 // A verifier instance is a VInst (input claim, rounds, degree, and a closure = cache_openings + expected_output_claim); `run_single` is
 // Sumcheck::verify, `batch` is BatchedSumcheck::verify (an instance of n rounds sees the LAST n challenges, sumcheck.rs:150-170).
 #include <hip/hip_runtime.h>
@@ -544,11 +544,13 @@ struct Verifier {
         const H::Fr l = nodeio_claim(nd, 0), r = nodeio_claim(nd, 1), acc = advice_claim(nd, gr::VP_ClampAcc);
         return same(nd.op == ATLAS_OP_ADD ? H::add(l, r) : H::sub(l, r), acc) ? ATLAS_OK : bad("verify_graph: InvalidOpeningProof (left +- right must equal the accumulation)");
     }
-    int op_relu(const Node& nd) {
+    int op_relu(const Node& nd) {                                             // ReLU (ops/relu.rs) and Clamp (ops/clamp.rs: ClampTable<32> = ClampBoundedTable<32, 9, true>)
         const gr::Opening& R = reduced.at(nd.idx);
+        const bool clamp = nd.op == ATLAS_OP_CLAMP;
+        const uint8_t ra_vp = clamp ? gr::VP_SymmetricClampRa : gr::VP_NodeOutputRa, rad_cp = clamp ? gr::CP_SymmetricClampRaD : gr::CP_NodeOutputRaD;
         Point ra_point;
-        int rc = ps_unary(nd, T_RELU, 32, 0, gr::node_exec(gr::virt(gr::VP_NodeOutput, nd.inputs[0]), nd.idx), R.claim, R.point, gr::VP_NodeOutputRa, gr::PT_Execution, &ra_point);
-        if (!rc) rc = onehot_checks(nd, 32, R.point, ra_point, advice_claim(nd, gr::VP_NodeOutputRa), gr::CP_NodeOutputRaD, gr::PT_RaOneHotChecks);
+        int rc = ps_unary(nd, clamp ? T_CLAMP_SYM : T_RELU, 32, clamp ? gr::CLAMP_BOUND : 0, gr::node_exec(gr::virt(gr::VP_NodeOutput, nd.inputs[0]), nd.idx), R.claim, R.point, ra_vp, gr::PT_Execution, &ra_point);
+        if (!rc) rc = onehot_checks(nd, 32, R.point, ra_point, advice_claim(nd, ra_vp), rad_cp, gr::PT_RaOneHotChecks);
         return rc;
     }
     int op_reshape(const Node& nd) {                                          // selector = the eq table of the reduced point over the flat index
@@ -1010,7 +1012,13 @@ struct Verifier {
             case ATLAS_OP_EINSUM: case ATLAS_OP_MUL: case ATLAS_OP_SQUARE: case ATLAS_OP_CUBE: return op_fused(nd);
             case ATLAS_OP_AND: return ew_verify(nd, 2, 3, R.claim, gr::PT_Execution, 0);
             case ATLAS_OP_IFF: return ew_verify(nd, 3, 3, R.claim, gr::PT_Execution, 1);
-            case ATLAS_OP_RELU: return op_relu(nd);
+            case ATLAS_OP_RELU: case ATLAS_OP_CLAMP: return op_relu(nd);
+            case ATLAS_OP_NEG: case ATLAS_OP_IS_NAN: {                        // ops/neg.rs, is_nan.rs: no sumcheck
+                rc = append_nodeio(nd, 0, R.point);
+                if (rc) return rc;
+                if (nd.op == ATLAS_OP_NEG) return same(H::neg(nodeio_claim(nd, 0)), R.claim) ? ATLAS_OK : bad("verify_graph: InvalidOpeningProof (-operand(r) must equal output(r))");
+                return same(R.claim, H::zero()) ? ATLAS_OK : bad("verify_graph: InvalidOpeningProof (isNan claim should be zero)");
+            }
             case ATLAS_OP_RESHAPE: return op_reshape(nd);
             case ATLAS_OP_SUM: return op_sum(nd);
             case ATLAS_OP_SCALAR_CONST_DIV: return op_scalar_const_div(nd);
@@ -1039,6 +1047,7 @@ struct Verifier {
                     chunks(gr::CP_ClampRaD, 64);
                     break;
                 case ATLAS_OP_RELU: chunks(gr::CP_NodeOutputRaD, 32); break;
+                case ATLAS_OP_CLAMP: chunks(gr::CP_SymmetricClampRaD, 32); break;
                 case ATLAS_OP_SUM: chunks(gr::CP_ClampRaD, 64); break;
                 case ATLAS_OP_SCALAR_CONST_DIV: dense(gr::CP_ScalarConstDivNodeRemainder); break;
                 case ATLAS_OP_DIV: dense(gr::CP_DivNodeQuotient); chunks(gr::CP_DivRangeCheckRaD, 64); break;

@@ -11,7 +11,7 @@ import numpy as np
 from . import TranscriptState, _check, lib
 
 OPS = ["Input", "Constant", "Identity", "Add", "Sub", "Mul", "Square", "Cube", "And", "Iff", "ReLU", "Einsum", "Reshape", "MoveAxis", "Broadcast",
-       "Slice", "Concat", "Sum", "ScalarConstDiv", "Div", "MeanOfSquares", "Rsqrt", "SoftmaxLastAxis", "Tanh", "GatherLarge", "GatherSmall", "Erf", "Sigmoid"]
+       "Slice", "Concat", "Sum", "ScalarConstDiv", "Div", "MeanOfSquares", "Rsqrt", "SoftmaxLastAxis", "Tanh", "GatherLarge", "GatherSmall", "Erf", "Sigmoid", "Neg", "IsNan", "Clamp"]
 OP = {n: i for i, n in enumerate(OPS)}
 LAYOUTS = {"mk,kn->mn": 0, "bmk,bkn->mbn": 1, "bmk,kbn->mbn": 2, "mbk,bnk->bmn": 3, "mbk,nbk->bmn": 4, "k,nk->n": 5}
 
@@ -38,6 +38,8 @@ def node_params(nd):
         return [nd["axis"], nd["start"], nd["end"]], []
     if op == "Concat":
         return [nd["axis"]], []
+    if op == "Clamp":
+        return [nd["bound_log"]], []
     if op == "ScalarConstDiv":
         return [nd["divisor"]], []
     if op == "Sum":

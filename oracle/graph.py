@@ -186,6 +186,7 @@ def opening_id_bytes(k):
 MODEL_SCALE = 14
 ACTIVATION_BOUND = MODEL_SCALE + 3
 ACTIVATION_TABLE_VARS = ACTIVATION_BOUND + 1
+CLAMP_BOUND = 9                  # joltworks/src/lookup_tables/clamp.rs:197-211
 _TANH = None
 
 
@@ -361,6 +362,13 @@ def execute(nodes, inputs):
             o = np.where(ins[0] != 0, ins[1], ins[2]).astype(np.int32)
         elif op == "ReLU":
             o = np.maximum(ins[0], 0).astype(np.int32)
+        elif op == "Neg":
+            o = (0 - ins[0].astype(np.int64)).astype(np.int32)
+        elif op == "IsNan":
+            o = np.zeros(int(np.prod(nd["dims"])), dtype=np.int32)
+        elif op == "Clamp":                                      # nonlinearities::clamp (tensor/ops.rs:3216-3220), bound_log = CLAMP_BOUND
+            assert nd["bound_log"] == CLAMP_BOUND
+            o = np.clip(ins[0], -(1 << CLAMP_BOUND), (1 << CLAMP_BOUND) - 1).astype(np.int32)
         elif op == "MoveAxis":
             idims = next(n for n in nodes if n["idx"] == nd["inputs"][0])["dims"]
             o = np.moveaxis(ins[0].reshape(idims), nd["source"], nd["destination"]).reshape(-1).copy()
@@ -475,6 +483,8 @@ class Prover:
             return [("RescaleRemainderRaD", w["rem"].astype(np.uint64), w["S"]), ("ClampRaD", w["quot"].astype(np.int64).view(np.uint64), 64)]
         if op == "ReLU":
             return [("NodeOutputRaD", self.trace[nd["inputs"][0]].astype(np.uint32).astype(np.uint64), 32)]
+        if op == "Clamp":
+            return [("SymmetricClampRaD", self.trace[nd["inputs"][0]].astype(np.uint32).astype(np.uint64), 32)]
         if op == "Sum":
             return [("ClampRaD", self.wit[i]["acc"].astype(np.int64).view(np.uint64), 64)]
         if op in ("Tanh", "Erf", "Sigmoid"):
@@ -726,6 +736,10 @@ class Prover:
         gamma = self.t.challenge_scalar()
         lookups = x.astype(np.uint32).astype(np.uint64)
         exec_claim = orc.fr_add_arr(out_claim, orc.fr_mul_arr(gamma, operand_claim))
+        if nd["op"] == "Clamp":                                              # ops/clamp.rs: ClampTable<32> = ClampBoundedTable<32, CLAMP_BOUND, true>
+            ra_point, ra_claim = self.read_raf(nd, OR.ps_clamp(lookups, 32, CLAMP_BOUND, True, r0, gamma), exec_claim, lookups, 32, "SymmetricClampRa", "Execution")
+            self.onehot_checks(nd, lookups, 32, r0, ra_point, ra_claim, "SymmetricClampRaD", "RaOneHotChecks")
+            return
         ra_point, ra_claim = self.read_raf(nd, OR.ps_relu(lookups, 32, r0, gamma), exec_claim, lookups, 32, "NodeOutputRa", "Execution")
         self.onehot_checks(nd, lookups, 32, r0, ra_point, ra_claim, "NodeOutputRaD", "RaOneHotChecks")
 
@@ -1056,8 +1070,10 @@ class Prover:
             self.ew_sumcheck(nd, OR.EW_MUL, 2, claim, "Execution")
         elif op == "Iff":
             self.ew_sumcheck(nd, OR.EW_IFF, 3, claim, "Execution")
-        elif op == "ReLU":
+        elif op in ("ReLU", "Clamp"):
             self.op_relu(nd)
+        elif op in ("Neg", "IsNan"):                                         # ops/neg.rs, is_nan.rs: no sumcheck, the operand at the reduced point
+            self.append_nodeio(nd, 0, r0, orc.evaluate(self.mle(nd["inputs"][0]), r0))
         elif op == "Reshape":
             I = OR.elementwise(OR.EW_DOT, [self.mle(nd["inputs"][0]), orc.eq_evals(np.ascontiguousarray(r0))], r0)
             rs = self.run(I, claim, i, "Execution")

@@ -119,6 +119,21 @@ def erf_sigmoid_graph(rng, n=4, d=8, S=14):
     ], [5], [x]
 
 
+def small_ops_graph(rng, n=4, d=8):
+    """Neg and IsNan (no sumcheck: the operand opened at the reduced point) and the ONNX Clamp (ops/clamp.rs: ClampTable<32>, bound 2^9) on an
+    input that exceeds the bound on both sides"""
+    x = rng.integers(-(1 << 12), 1 << 12, size=n * d).astype(np.int32)
+    x[:6] = [0, -1, 511, 512, -512, -513]
+    return [
+        {"idx": 0, "op": "Input", "inputs": [], "dims": [n, d]},
+        {"idx": 1, "op": "Neg", "inputs": [0], "dims": [n, d]},
+        {"idx": 2, "op": "Clamp", "inputs": [0], "dims": [n, d], "bound_log": 9},
+        {"idx": 3, "op": "Add", "inputs": [1, 2], "dims": [n, d]},
+        {"idx": 4, "op": "IsNan", "inputs": [0], "dims": [n, d]},
+        {"idx": 5, "op": "Add", "inputs": [3, 4], "dims": [n, d]},
+    ], [5], [x]
+
+
 def concat_graph(rng):
     """Concat (ops/concat.rs) along the last axis of three operands of unequal size (the smaller ones are repeated over the low variables of the
     largest one's hypercube), an Add over the result, then a second Concat along axis 0 whose output carries the output claim"""
@@ -146,7 +161,7 @@ def toy_transformer(rng):
     return BG.tiny(layers=2)
 
 
-@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6), (concat_graph, 7), (erf_sigmoid_graph, 8)])
+@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6), (concat_graph, 7), (erf_sigmoid_graph, 8), (small_ops_graph, 9)])
 def test_graph_proof_matches_oracle(atlas, builder, seed):
     from oracle import graph as OG, orc
     from jolt_atlas_amd import graph as GG
@@ -171,7 +186,7 @@ def test_graph_proof_matches_oracle(atlas, builder, seed):
     G.free(); srs.free()
 
 
-@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6), (concat_graph, 7), (erf_sigmoid_graph, 8)])
+@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6), (concat_graph, 7), (erf_sigmoid_graph, 8), (small_ops_graph, 9)])
 def test_graph_proof_is_accepted_by_the_verifier(atlas, builder, seed):
     """ONNXProof::verify (atlas_verify_graph: opening claims from the proof, the node loop's verifier instances, the opening-reduction
     sumcheck, the joint commitment, HyperKZG::verify through the pairing) accepts the device's proof with the prover's final transcript
