@@ -185,8 +185,81 @@ def test_ref_hyperkzg_device(fx, atlas):
     poly.free(); srs.free()
 
 
+# ---- whole ONNXProof::prove runs (tools/export_ref_graph_fixtures.rs): operator compositions + the proof container --------------------
+GPATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_graph_fixtures.json")
+GSELF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "selfcheck_graph_fixtures.json")
+GUNPINNED = ("PARITY UNPINNED: tests/golden/ref_graph_fixtures.json is absent — export it from the reference with "
+             "tools/export_ref_graph_fixtures.rs (needs cargo; cannot run in this image) to pin the operator compositions and the proof container")
+needs_graph_fixture = pytest.mark.parametrize("gfx", ["reference", "selfcheck"], indirect=True)
+
+
+@pytest.fixture(scope="module")
+def gfx(request):
+    if request.param == "reference":
+        if not os.path.exists(GPATH):
+            pytest.skip(GUNPINNED)
+        return json.load(open(GPATH))
+    return json.load(open(GSELF))
+
+
+def _g1_array(orc, hexes):
+    """compressed ark points -> the oracle's / the library's affine Montgomery layout"""
+    out = np.zeros(len(hexes), dtype=orc.G1_DTYPE)
+    for i, hx in enumerate(hexes):
+        xy = _decompress(hx)
+        if xy is None:
+            out[i]["infinity"] = 1
+            continue
+        for name, v in zip(("x", "y"), xy):
+            m = v * (1 << 256) % FQ
+            out[i][name] = [(m >> (64 * k)) & ((1 << 64) - 1) for k in range(4)]
+    return out
+
+
+def _graph_of(g):
+    nodes = []
+    for nd in g["nodes"]:
+        d = dict(nd)
+        if "data" in d:
+            d["data"] = np.asarray(d["data"], dtype=np.int32)
+        nodes.append(d)
+    return nodes, g["outputs"], [np.asarray(a, dtype=np.int32) for a in g["inputs"]]
+
+
+@needs_graph_fixture
+def test_ref_graph_proofs_oracle(gfx):
+    """oracle/graph.py over the file's SRS powers reproduces the file's ONNXProof bytes (serialize_proof) and output tensor"""
+    from oracle import graph as OG, orc
+    for g in gfx["graphs"]:
+        nodes, outputs, inputs = _graph_of(g)
+        P = OG.Prover(nodes, outputs, _g1_array(orc, g["srs_g1"]))
+        proof = P.prove(inputs)
+        assert [int(x) for x in P.trace[outputs[0]]] == g["output"], g["name"]
+        assert proof.hex() == g["proof"], "ONNXProof bytes of " + g["name"]
+
+
+@needs_graph_fixture
+@pytest.mark.gpu
+def test_ref_graph_proofs_device(gfx, atlas):
+    """atlas_prove_graph over the file's SRS powers reproduces the file's ONNXProof bytes; atlas_verify_graph accepts them"""
+    from oracle import orc
+    from jolt_atlas_amd import graph as GG
+    for g in gfx["graphs"]:
+        nodes, outputs, inputs = _graph_of(g)
+        srs = atlas.SRS.upload(_g1_array(orc, g["srs_g1"]))
+        G = GG.Graph(nodes, outputs)
+        proof, _state, _tm = G.prove(srs, inputs)
+        assert [int(x) for x in G.node_output(outputs[0])] == g["output"], g["name"]
+        assert proof.hex() == g["proof"], "ONNXProof bytes of " + g["name"]
+        G.free(); srs.free()
+
+
 def test_fixture_status_is_reported():
     """always runs: states in the test log whether the oracle is pinned against the reference."""
+    if os.path.exists(GPATH):
+        print("reference graph fixtures present: operator compositions and the proof container pinned against the reference")
+    else:
+        print("PARITY UNPINNED: no reference graph fixtures (tools/export_ref_graph_fixtures.rs has not been run)")
     if os.path.exists(PATH):
         print("reference fixtures present: oracle pinned against the reference")
     else:
