@@ -464,7 +464,7 @@ def main():
         import build_graphs as BG
         from jolt_atlas_amd import graph as GG
         out["prove_graph"] = {"note": "synthetic-trace proxy of ONNXProof::prove: the model's operator list and (padded) shapes, random-init weights, "
-                                      "full operator decomposition (SoftmaxLastAxis, tanh-GELU, LayerNorm, GatherLarge); reference (M3 CPU): nanoGPT 2.288 s, GPT-2 12 layers 14.889 s"}
+                                      "full operator decomposition (SoftmaxLastAxis, tanh-GELU, LayerNorm, GatherSmall); reference (M3 CPU): nanoGPT 2.288 s, GPT-2 12 layers 14.889 s"}
         for gname in ("nanogpt", "gpt2_layer"):
             nodes_g, outs_g, ins_g = getattr(BG, gname)()
             nv = BG.max_vars(nodes_g)

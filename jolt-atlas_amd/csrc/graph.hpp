@@ -83,7 +83,8 @@ struct Node {
 // indices, or a dense vector of small scalars
 struct Committed {
     PolyId id;
-    int kind = 1;                            // 1 one-hot (log_K_chunk = 4), 0 dense
+    int kind = 1;                            // 1 one-hot, 0 dense
+    size_t lkc = 4;                          // one-hot: log_K_chunk (4 = LOG_K_CHUNK of the RaD families; GatherRa of GatherSmall: the whole log_K)
     const uint64_t* d_lookups = nullptr;     // one-hot: T lookup indices in HBM (borrowed from the node witness)
     size_t log_T = 0, log_K = 0, chunk = 0;  // one-hot: chunk `chunk` of the log_K-bit index (OneHotParams::lookup_index_chunk)
     atlas_poly_t dense = nullptr;            // dense (owned by the node witness)

@@ -500,10 +500,11 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
             k_tanh<<<grid_for(T), 256, 0, g.stream>>>(in(0), T, (uint32_t)gr::ACTIVATION_BOUND, d_table, out.as<int32_t>(), W.clamped.as<int32_t>(), W.lookups2.as<uint64_t>(), W.lookups.as<uint64_t>());
             return ATLAS_OK;
         }
-        case ATLAS_OP_GATHER_LARGE: {                                         // inputs (dictionary [V][D...], indexes [N]); output [N][D...]
+        case ATLAS_OP_GATHER_LARGE: case ATLAS_OP_GATHER_SMALL: {             // inputs (dictionary [V][D...], indexes [N]); output [N][D...]
             if (!need_inputs(2) || nd.p[0] != 0) return fail(ATLAS_EINVAL, "graph: Gather needs (dictionary, indexes) and axis 0");
             const size_t V = in_node(0).dims[0], word = gr::padded_len(in_node(0).dims) / V, N = gr::padded_len(in_node(1).dims);
             if (T != N * word || (size_t)nd.p[1] > V) return fail(ATLAS_EINVAL, "graph: Gather dims / dict_len");
+            if (nd.op == ATLAS_OP_GATHER_SMALL && (V > 65536 || V < 2 || N < 2)) return fail(ATLAS_EINVAL, "graph: GatherSmall is the tracer's choice for dictionaries of at most 2^16 words (handlers/index.rs:33-45)");
             NodeWitness& W = G.wit[nd.idx];
             HIP_TRY(W.lookups.alloc(N * 8));
             k_gather_rows<<<grid_for(T), 256, 0, g.stream>>>(in(0), in(1), N, word, out.as<int32_t>(), W.lookups.as<uint64_t>());

@@ -204,6 +204,12 @@ struct Prover : FlowSink {
                     chunks(gr::CP_SoftmaxZLoRaD, Sm.idx_zlo.as<uint64_t>(), Sm.lk_lo);
                     break;
                 }
+                case ATLAS_OP_GATHER_SMALL: {                                                                            // ops/gather/small.rs:119-121: ONE one-hot polynomial, dict_len addresses
+                    gr::Committed c; c.id = gr::comm(gr::CP_GatherRa, nd.idx); c.kind = 1; c.d_lookups = W.lookups.as<uint64_t>();
+                    c.log_T = gr::log2u(gr::padded_len(G.nodes.at(nd.inputs[1]).dims)); c.log_K = gr::log2u(G.nodes.at(nd.inputs[0]).dims[0]); c.chunk = 0; c.lkc = c.log_K;
+                    W.committed.push_back(c);
+                    break;
+                }
                 case ATLAS_OP_GATHER_LARGE: {                                                                            // ops/gather/large.rs:105-111
                     const size_t N = gr::padded_len(G.nodes.at(nd.inputs[1]).dims), V = G.nodes.at(nd.inputs[0]).dims[0], lk = gr::log2u(V), d = (lk + 3) / 4;
                     for (size_t i = 0; i < d; i++) {
@@ -227,7 +233,10 @@ struct Prover : FlowSink {
             auto& cs = kv.second.committed;
             for (size_t i = 0; i < cs.size();) {
                 size_t j = i + 1;
-                if (cs[i].kind == 1) {
+                if (cs[i].kind == 1 && cs[i].lkc != 4) {                     // GatherRa: one polynomial over all log_K address bits
+                    int rc = atlas_commit_lookup_chunks(srs, cs[i].d_lookups, cs[i].log_T, cs[i].log_K, cs[i].lkc, &cs[i].commitment);
+                    if (rc) return rc;
+                } else if (cs[i].kind == 1) {
                     while (j < cs.size() && cs[j].kind == 1 && cs[j].d_lookups == cs[i].d_lookups) j++;
                     fams.push_back(atlas_lookup_family_t{cs[i].d_lookups, cs[i].log_T, cs[i].log_K});
                     first.push_back(&cs[i]);
@@ -920,9 +929,71 @@ struct Prover : FlowSink {
         rc = append_advice(nd, gr::VP_NodeOutputRa, ra_pt, fin[0]);
         if (!rc) rc = append_nodeio(nd, 0, dict_pt, fin[1]);
         if (rc) return rc;
+        if (nd.op == ATLAS_OP_GATHER_SMALL) return gather_small_checks(nd, r_index, lv, ln);
         std::vector<atlas_fr_t> rap(ra_pt.size());
         std::memcpy(rap.data(), ra_pt.data(), ra_pt.size() * 32);
         return prove_onehot_checks(W.lookups.as<uint64_t>(), ln, lv, (const atlas_fr_t*)r_index.data(), rap, fin[0], &t, O, gr::CP_GatherRaD, gr::PT_RaOneHotChecks);
+    }
+
+    // GatherSmall after the execution sumcheck (ops/gather/small.rs:44-62, 124-168, 290-312): ONE committed one-hot polynomial GatherRa over all
+    // dict_len addresses; BatchedSumcheck [HammingBooleanity of the all-ones hamming weight vector, Booleanity with d = 1 and log_k_chunk =
+    // log dict_len, gamma = Challenge::from(1)] under RaOneHotChecks, then HammingWeight (d = 1) on its own under RaHammingWeight.  r_cycle of
+    // all three = the point the index operand was opened at.
+    int gather_small_checks(const Node& nd, const Point& r_index, size_t lv, size_t ln) {
+        NodeWitness& W = G.wit[nd.idx];
+        const size_t N = (size_t)1 << ln, K = (size_t)1 << lv;
+        const uint64_t* lookups = W.lookups.as<uint64_t>();
+        const Point r_address = challenge_point(lv);                          // ra_booleanity_params: challenge_vector_optimized(log num_words)
+        // compute_ra_evals(r_cycle, indexes, num_words): the histogram of eq(r_index, .) over the addresses, on the host for the two instances
+        atlas_poly_t eq_i = nullptr, Gp = nullptr;
+        int rc = atlas_eq_evals((const atlas_fr_t*)r_index.data(), ln, nullptr, &eq_i);
+        if (!rc) rc = atlas_shout_read_raf_G(lookups, N, lv, eq_i, &Gp);
+        if (eq_i) atlas_poly_free(eq_i);
+        std::vector<atlas_fr_t> Gh(K);
+        if (!rc) rc = atlas_poly_download(Gp, Gh.data(), K);
+        if (Gp) atlas_poly_free(Gp);
+        if (rc) return rc;
+        // hw = [1; N] (every lookup reads exactly one word)
+        std::vector<H::Fr> ones(N, H::one());
+        atlas_poly_t hw = nullptr;
+        rc = atlas_poly_upload_fr((const atlas_fr_t*)ones.data(), N, &hw);
+        const H::Fr one = H::one(), zero = H::zero();
+        const H::Fr gamma_b = H::challenge_to_fr(1, 0, g.challenge_mode);   // F::Challenge::from(1): the challenge READING of the integer 1
+        atlas_instance_t i_hb = nullptr, i_bool = nullptr, i_hw = nullptr;
+        if (!rc) rc = atlas_elementwise_new(ATLAS_EW_HAMMING_BOOL, &hw, 1, (const atlas_fr_t*)r_index.data(), ln, (const atlas_fr_t*)&one, 1, &i_hb);
+        if (hw) atlas_poly_free(hw);
+        if (!rc) rc = atlas_booleanity_from_lookups_new(Gh.data(), lookups, ln, lv, lv, (const atlas_fr_t*)&gamma_b, (const atlas_fr_t*)r_address.data(), (const atlas_fr_t*)r_index.data(), &i_bool);
+        atlas_batched_t b = nullptr;
+        if (!rc) rc = atlas_batched_new(&b);
+        if (!rc) rc = atlas_batched_add_instance(b, i_hb, (const atlas_fr_t*)&zero);
+        if (!rc) rc = atlas_batched_add_instance(b, i_bool, (const atlas_fr_t*)&zero);
+        std::vector<H::Fr> rs;
+        if (!rc) rc = run_batch(b, 8, lv + ln, gr::PT_RaOneHotChecks, rs);
+        Out O = out();
+        if (!rc) {
+            const size_t mr = rs.size();                                      // = lv + ln; HammingBooleanity sees the last ln challenges
+            atlas_fr_t f[64]; size_t nf = 0;
+            rc = atlas_instance_final_claims(i_hb, f, 64, &nf);
+            Point p_hb(ln), p_bo(lv + ln);
+            for (size_t q = 0; q < ln; q++) p_hb[q] = rs[mr - 1 - q];
+            if (!rc) rc = O.append_virtual(Tr, gr::oid(gr::virt(gr::VP_HammingWeight), gr::SC_RamHammingBooleanity), p_hb, *reinterpret_cast<H::Fr*>(&f[0]));
+            if (!rc) rc = atlas_instance_final_claims(i_bool, f, 64, &nf);
+            for (size_t q = 0; q < lv; q++) p_bo[q] = rs[lv - 1 - q];
+            for (size_t q = 0; q < ln; q++) p_bo[lv + q] = rs[mr - 1 - q];
+            if (!rc) rc = O.append_sparse(Tr, gr::CP_GatherRa, 0, gr::SC_Booleanity, p_bo, *reinterpret_cast<H::Fr*>(&f[0]));
+        }
+        if (b) atlas_batched_free(b);
+        for (atlas_instance_t i : {i_hb, i_bool}) if (i) atlas_instance_free(i);
+        if (rc) return rc;
+        // stage 3: HammingWeightSumcheckProver, d = 1, gamma_powers = [1]: sum_k ra(k, r_cycle) = 1
+        rc = atlas_hamming_weight_new(Gh.data(), 1, lv, (const atlas_fr_t*)&one, &i_hw);
+        std::vector<H::Fr> rs3, fin3;
+        if (!rc) rc = run_single(i_hw, one, gr::PT_RaHammingWeight, rs3, fin3);
+        if (i_hw) atlas_instance_free(i_hw);
+        if (rc) return rc;
+        Point p_hw = reversed(rs3);
+        p_hw.insert(p_hw.end(), r_index.begin(), r_index.end());
+        return O.append_sparse(Tr, gr::CP_GatherRa, 0, gr::SC_HammingWeight, p_hw, fin3[0]);
     }
 
     // ---- SoftmaxLastAxis (ops/softmax_last_axis/mod.rs:177-262): the auxiliary vectors, then four BatchedSumcheck stages
@@ -1181,7 +1252,7 @@ struct Prover : FlowSink {
             case ATLAS_OP_CONCAT: return op_concat(nd);
             case ATLAS_OP_MEAN_OF_SQUARES: return op_mean_of_squares(nd);
             case ATLAS_OP_TANH: case ATLAS_OP_ERF: case ATLAS_OP_SIGMOID: return op_tanh(nd);      // prove_clamped_activation<Table>
-            case ATLAS_OP_GATHER_LARGE: return op_gather(nd);
+            case ATLAS_OP_GATHER_LARGE: case ATLAS_OP_GATHER_SMALL: return op_gather(nd);
             case ATLAS_OP_SOFTMAX: return op_softmax(nd);
             default: return fail(ATLAS_EINVAL, "prove_graph: operator without a prover composition");
         }
@@ -1203,9 +1274,9 @@ struct Prover : FlowSink {
             atlas_opening_t O; std::memset(&O, 0, sizeof(O));
             O.kind = c.kind; O.point = (const atlas_fr_t*)c.point.data(); std::memcpy(&O.claim, &c.claim, 32);
             if (c.kind == 1) {
-                const size_t d = (c.log_K + 3) / 4;
-                O.d_lookups = c.d_lookups; O.chunk_shift = 4 * (d - 1 - c.chunk);                                          // OneHotParams::lookup_index_chunk
-                O.log_K = 4; O.log_T = c.log_T;
+                const size_t d = (c.log_K + c.lkc - 1) / c.lkc;
+                O.d_lookups = c.d_lookups; O.chunk_shift = c.lkc * (d - 1 - c.chunk);                                      // OneHotParams::lookup_index_chunk
+                O.log_K = c.lkc; O.log_T = c.log_T;
             } else { O.poly = c.dense; O.n = c.log_T; }
             ops.push_back(O);
         }

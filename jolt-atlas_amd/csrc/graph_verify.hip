@@ -6,7 +6,7 @@
 // Host arithmetic, like the reference's verifier; the device only evaluates the PUBLIC tensors (inputs, constants, output) at the
 // verifier's points and adds up the joint commitment.  Nothing of the prover's trace is read.
 // Every operator the graph prover composes has its verifier composition here: Input, Constant, Identity, Add, Sub, Mul, Square, Cube, Einsum,
-// And, Iff, ReLU, Clamp, Neg, IsNan, Reshape, MoveAxis, Broadcast, Sum, ScalarConstDiv, Slice, Concat, Div, MeanOfSquares, Rsqrt, Tanh, Erf, Sigmoid, GatherLarge, SoftmaxLastAxis.
+// And, Iff, ReLU, Clamp, Neg, IsNan, Reshape, MoveAxis, Broadcast, Sum, ScalarConstDiv, Slice, Concat, Div, MeanOfSquares, Rsqrt, Tanh, Erf, Sigmoid, GatherLarge, GatherSmall, SoftmaxLastAxis.
 // A verifier instance is a VInst (input claim, rounds, degree, and a closure = cache_openings + expected_output_claim); `run_single` is
 // Sumcheck::verify, `batch` is BatchedSumcheck::verify (an instance of n rounds sees the LAST n challenges, sumcheck.rs:150-170).
 #include <hip/hip_runtime.h>
@@ -845,8 +845,48 @@ struct Verifier {
             return (int)ATLAS_OK;
         };
         rc = run_single(gr::PT_Execution, I, "verify_graph: SumcheckVerificationError (gather)");
-        if (!rc) rc = onehot_checks(nd, lv, r_index, ra_pt, advice_claim(nd, gr::VP_NodeOutputRa), gr::CP_GatherRaD, gr::PT_RaOneHotChecks);
-        return rc;
+        if (rc) return rc;
+        if (nd.op == ATLAS_OP_GATHER_LARGE) return onehot_checks(nd, lv, r_index, ra_pt, advice_claim(nd, gr::VP_NodeOutputRa), gr::CP_GatherRaD, gr::PT_RaOneHotChecks);
+        // GatherSmall (ops/gather/small.rs:64-110, 170-255, 314-377): [HammingBooleanity, Booleanity (d = 1, log_k_chunk = log dict_len)], then HammingWeight
+        const Point r_address = challenge_point(lv);                         // ra_booleanity_params
+        const H::Fr gamma_b = H::challenge_to_fr(1, 0, mode());              // F::Challenge::from(1)
+        std::vector<VInst> B(2);
+        B[0].claim = H::zero(); B[0].rounds = ln; B[0].degree = 3;           // hamming_booleanity.rs:175-192
+        B[0].finish = [=](const H::Fr* ch, H::Fr* expect) {
+            Point pt(ln);
+            for (size_t q = 0; q < ln; q++) pt[q] = ch[ln - 1 - q];
+            const OpeningId id = gr::oid(gr::virt(gr::VP_HammingWeight), gr::SC_RamHammingBooleanity);
+            int rc2 = append_virtual(id, pt);
+            if (rc2) return rc2;
+            const H::Fr hw = claim_of(id);
+            *expect = H::mul(eq_mle(r_index.data(), pt.data(), ln), H::mul(hw, H::sub(hw, H::one())));
+            return (int)ATLAS_OK;
+        };
+        B[1].claim = H::zero(); B[1].rounds = lv + ln; B[1].degree = 3;      // booleanity.rs:391-419 with d = 1
+        B[1].finish = [=](const H::Fr* ch, H::Fr* expect) {
+            const size_t mr = lv + ln;
+            Point pt(mr), comb(mr);
+            for (size_t q = 0; q < lv; q++) { pt[q] = ch[lv - 1 - q]; comb[q] = r_address[lv - 1 - q]; }
+            for (size_t q = 0; q < ln; q++) { pt[lv + q] = ch[mr - 1 - q]; comb[lv + q] = r_index[ln - 1 - q]; }
+            int rc2 = append_sparse(gr::CP_GatherRa, *np, 0, gr::SC_Booleanity, pt);
+            if (rc2) return rc2;
+            const H::Fr c = claim_of(gr::oid(gr::comm(gr::CP_GatherRa, np->idx), gr::SC_Booleanity));
+            *expect = H::mul(eq_mle(ch, comb.data(), mr), H::mul(gamma_b, H::sub(H::mul(c, c), c)));
+            return (int)ATLAS_OK;
+        };
+        rc = batch(gr::PT_RaOneHotChecks, B);
+        if (rc) return rc;
+        VInst W;
+        W.claim = H::one(); W.rounds = lv; W.degree = 1;                     // hamming_weight.rs:193-207 with d = 1, gamma_powers = [1]
+        W.finish = [=](const H::Fr* ch, H::Fr* expect) {
+            Point pt(lv);
+            for (size_t q = 0; q < lv; q++) pt[q] = ch[lv - 1 - q];
+            pt.insert(pt.end(), r_index.begin(), r_index.end());
+            int rc2 = append_sparse(gr::CP_GatherRa, *np, 0, gr::SC_HammingWeight, pt);
+            if (!rc2) *expect = claim_of(gr::oid(gr::comm(gr::CP_GatherRa, np->idx), gr::SC_HammingWeight));
+            return rc2;
+        };
+        return run_single(gr::PT_RaHammingWeight, W, "verify_graph: SumcheckVerificationError (gather hamming weight)");
     }
     // SoftmaxLastAxis (ops/softmax_last_axis/mod.rs:286-333, 742-1135): the auxiliary vectors, four BatchedSumcheck stages, the operand link
     int op_softmax(const Node& nd) {
@@ -1026,7 +1066,7 @@ struct Verifier {
             case ATLAS_OP_CONCAT: return op_concat(nd);
             case ATLAS_OP_MEAN_OF_SQUARES: return op_mean_of_squares(nd);
             case ATLAS_OP_TANH: case ATLAS_OP_ERF: case ATLAS_OP_SIGMOID: return op_tanh(nd);      // verify_clamped_activation<Table>
-            case ATLAS_OP_GATHER_LARGE: return op_gather(nd);
+            case ATLAS_OP_GATHER_LARGE: case ATLAS_OP_GATHER_SMALL: return op_gather(nd);
             case ATLAS_OP_SOFTMAX: return op_softmax(nd);
             default: return fail(ATLAS_EINVAL, "verify_graph: operator without a verifier composition");
         }
@@ -1062,6 +1102,7 @@ struct Verifier {
                     chunks(gr::CP_SoftmaxZHiRaD, gr::log2u(L->hi.size())); chunks(gr::CP_SoftmaxZLoRaD, gr::log2u(L->lo.size()));
                     break;
                 }
+                case ATLAS_OP_GATHER_SMALL: committed[gr::comm(gr::CP_GatherRa, nd.idx)].log_T = gr::log2u(gr::padded_len(G.nodes.at(nd.inputs[1]).dims)); break;
                 case ATLAS_OP_GATHER_LARGE: {
                     const size_t ln = gr::log2u(gr::padded_len(G.nodes.at(nd.inputs[1]).dims)), lv = gr::log2u(G.nodes.at(nd.inputs[0]).dims[0]);
                     for (size_t i = 0; i < (lv + 3) / 4; i++) committed[gr::comm(gr::CP_GatherRaD, nd.idx, i)].log_T = ln;

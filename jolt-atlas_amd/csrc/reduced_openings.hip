@@ -58,23 +58,22 @@ extern "C" int atlas_prove_reduced_openings(const atlas_opening_t* openings, siz
     // one-hot openings with the same (log_K, log_T, r_cycle) share their cycle-phase launches (EqCycleState sharing,
     // opening_proof.rs:339-343)
     std::vector<char> done(n_open, 0);
-    // every one-hot opening over device-resident lookups, equal log_K <= 4: one pool, stepped together (opening.hip OneHotPool)
+    // the one-hot openings over device-resident lookups with log_K <= 4 (and equal: the RaD chunk polynomials): one pool, stepped together
+    // (opening.hip OneHotPool); the others (GatherRa of GatherSmall: all the dictionary's address bits in one polynomial) take the grouped path below
     std::vector<const int32_t*> pool_idx(n_open, nullptr);
     {
-        bool pool = getenv("ATLAS_NO_OPENING_POOL") == nullptr;
-        size_t n_oh = 0, lk = 0, batch_rounds = 0;
+        const bool pool = getenv("ATLAS_NO_OPENING_POOL") == nullptr;
+        size_t lk = 0, batch_rounds = 0;
         for (size_t i = 0; i < n_open; i++) {
             const atlas_opening_t& O = openings[i];
             const size_t nr = O.kind ? O.log_K + O.log_T : O.n;
             batch_rounds = nr > batch_rounds ? nr : batch_rounds;
-            if (O.kind != 1) continue;
-            if (!O.d_lookups || O.k || !O.point || O.log_K > 4 || (n_oh && O.log_K != lk)) pool = false;
-            lk = O.log_K; n_oh++;
         }
-        if (pool && n_oh) {
-            std::vector<atlas_rt_pool_row> rows; std::vector<size_t> where;
-            for (size_t i = 0; i < n_open; i++)
-                if (openings[i].kind == 1) { rows.push_back(atlas_rt_pool_row{openings[i].d_lookups, openings[i].chunk_shift, openings[i].log_T, openings[i].point}); where.push_back(i); }
+        auto eligible = [&](const atlas_opening_t& O) { return O.kind == 1 && O.d_lookups && !O.k && O.point && O.log_K <= 4 && (lk == 0 || O.log_K == lk); };
+        std::vector<atlas_rt_pool_row> rows; std::vector<size_t> where;
+        for (size_t i = 0; i < n_open && pool; i++)
+            if (eligible(openings[i])) { lk = openings[i].log_K; rows.push_back(atlas_rt_pool_row{openings[i].d_lookups, openings[i].chunk_shift, openings[i].log_T, openings[i].point}); where.push_back(i); }
+        if (!rows.empty()) {
             std::vector<atlas_instance_t> pi(rows.size(), nullptr); std::vector<const int32_t*> px(rows.size(), nullptr);
             rc = atlas_rt_onehot_pool_new(rows.data(), rows.size(), lk, batch_rounds, pi.data(), px.data());
             for (size_t q = 0; q < rows.size() && !rc; q++) { inst[where[q]] = pi[q]; pool_idx[where[q]] = px[q]; done[where[q]] = 1; }

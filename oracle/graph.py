@@ -416,7 +416,7 @@ def execute(nodes, inputs):
             k = np.where(c < 0, c.astype(np.int64) + (1 << ACTIVATION_TABLE_VARS), c.astype(np.int64))
             wit[nd["idx"]] = dict(clamped=c, small_idx=k.astype(np.uint64))
             o = activation_table(op)[k].astype(np.int32)
-        elif op == "GatherLarge":
+        elif op in ("GatherLarge", "GatherSmall"):
             ddims = next(n for n in nodes if n["idx"] == nd["inputs"][0])["dims"]
             o = ins[0].reshape(ddims[0], -1)[ins[1]].reshape(-1).astype(np.int32)
         elif op == "SoftmaxLastAxis":
@@ -524,6 +524,11 @@ class Prover:
     def commit(self):
         for i in self.order:
             nd = self.nodes[i]
+            if nd["op"] == "GatherSmall":                                    # ops/gather/small.rs:119-121: GatherRa, one polynomial over all dict_len addresses
+                V = self.nodes[nd["inputs"][0]]["dims"][0]
+                row = self.trace[nd["inputs"][1]].astype(np.int64); Tn = len(row)
+                self.committed[comm("GatherRa", i)] = dict(row=row.astype(np.int32), log_T=ilog2(Tn), lk=ilog2(V),
+                                                           commitment=orc.g1_sum_indexed(self.srs, (row * Tn + np.arange(Tn)).astype(np.uint64)))
             for name, lookups, log_K in self.lookup_families(nd):
                 d = -(-log_K // 4)
                 Tn = len(lookups)
@@ -949,7 +954,34 @@ class Prover:
         ra_pt, dict_pt = np.concatenate([pt, r_index]), np.concatenate([pt, r_word])
         self.append_advice(nd, "NodeOutputRa", ra_pt, fin[0])
         self.append_nodeio(nd, 0, dict_pt, fin[1])
+        if nd["op"] == "GatherSmall":
+            return self.gather_small_checks(nd, idx.astype(np.int32), np.ascontiguousarray(r_index), lv, ln)
         self.onehot_checks(nd, lookups, lv, np.ascontiguousarray(r_index), ra_pt, fin[0], "GatherRaD", "RaOneHotChecks")
+
+    def gather_small_checks(self, nd, rows, r_index, lv, ln):
+        """GatherSmall after the execution sumcheck (ops/gather/small.rs:44-62, 124-168, 216-255, 290-312, 358-377): BatchedSumcheck
+        [HammingBooleanity of hw = [1; N] (d = 1, gamma_powers [1], r_cycle = the index operand's point), Booleanity with d = 1,
+        log_k_chunk = log dict_len, gammas = [Challenge::from(1)]], then HammingWeight (d = 1, gamma_powers [1]) on its own"""
+        i = nd["idx"]
+        r_address = self.t.challenge_vector_opt(lv)                          # ra_booleanity_params
+        G = OR.ra_G([rows], lv, r_index)                                     # compute_ra_evals(r_cycle, indexes, num_words)
+        hw = np.stack([one()] * (1 << ln))
+        gamma_b = orc.challenges_to_fr([1])                                  # F::Challenge::from(1)
+        I_hb = OR.elementwise(OR.EW_HAMMING_BOOL, [hw], r_index, constants=one().reshape(1, 4))
+        I_bo = OR.booleanity(G, [rows], lv, gamma_b, r_address, r_index)
+        zero = orc.fr_array(1)[0]
+        proof, ch, _ = OB.batched_prove([OB.ra_instance(I_hb, zero), OB.ra_instance(I_bo, zero)], self.t.t)
+        self.proofs[(i, PT["RaOneHotChecks"])] = proof
+        rs = orc.challenges_to_fr(ch); mr = len(rs)
+        p_hb = np.ascontiguousarray(rs[mr - ln:][::-1])
+        self.append_virtual(oid(virt("HammingWeight"), "RamHammingBooleanity"), p_hb, I_hb.finals()[0])
+        ba = np.ascontiguousarray(rs[:lv][::-1]); bc = np.ascontiguousarray(rs[lv:][::-1])
+        Fb = orc.eq_evals(ba)
+        self.append_sparse("GatherRa", i, 0, "Booleanity", np.concatenate([ba, bc]), orc.evaluate(np.ascontiguousarray(Fb[rows]), bc))
+        I_hw = OR.hamming(G, lv, one().reshape(1, 4))
+        rs3 = self.run(I_hw, one(), i, "RaHammingWeight")
+        hw_rs = np.ascontiguousarray(rs3[::-1])
+        self.append_sparse("GatherRa", i, 0, "HammingWeight", np.concatenate([hw_rs, r_index]), orc.evaluate(G[0], hw_rs))
 
     def ra_opening(self, nd, vp, lookups, log_K, sl):
         """cache_openings of a PS-Shout / IdentityRC instance whose challenge slice is `sl`: ra at (address challenges, reversed cycle challenges)"""
@@ -1056,7 +1088,9 @@ class Prover:
         if op == "Concat":
             return self.op_concat(nd)
         if op in ("Erf", "Sigmoid"):
-            return self.op_tanh(nd)                                          # prove_clamped_activation::<_, _, Table>
+            return self.op_tanh(nd)
+        if op == "GatherSmall":
+            return self.op_gather(nd)                                          # prove_clamped_activation::<_, _, Table>
         if op in ("Sum", "ScalarConstDiv", "Slice", "MeanOfSquares", "Tanh", "GatherLarge", "SoftmaxLastAxis"):
             return {"Sum": self.op_sum, "ScalarConstDiv": self.op_scalar_const_div, "Slice": self.op_slice, "MeanOfSquares": self.op_mean_of_squares,
                     "Tanh": self.op_tanh, "GatherLarge": self.op_gather, "SoftmaxLastAxis": self.op_softmax}[op](nd)
@@ -1111,7 +1145,8 @@ class Prover:
             if "dense" in c:
                 insts.append(OB.ra_instance(OR.dense_opening(c["dense"].copy(), c["point"]), c["claim"]))
             else:
-                insts.append(OB.ra_instance(OR.onehot_opening(c["row"], 4, c["point"][:4], c["point"][4:]), c["claim"]))
+                lk = c.get("lk", 4)
+                insts.append(OB.ra_instance(OR.onehot_opening(c["row"], lk, c["point"][:lk], c["point"][lk:]), c["claim"]))
         rows, ch, _ = OB.batched_prove(insts, self.t.t)
         rs = orc.challenges_to_fr(ch)
         fin = []
@@ -1120,9 +1155,10 @@ class Prover:
             if "dense" in c:
                 fin.append(orc.evaluate(c["dense"], np.ascontiguousarray(rs[len(rs) - c["log_T"]:])))
                 continue
-            sl = rs[len(rs) - 4 - c["log_T"]:]
-            Fs = orc.eq_evals(np.ascontiguousarray(sl[:4]))
-            fin.append(orc.evaluate(np.stack([Fs[x] for x in c["row"]]), np.ascontiguousarray(sl[4:])))
+            lk = c.get("lk", 4)
+            sl = rs[len(rs) - lk - c["log_T"]:]
+            Fs = orc.eq_evals(np.ascontiguousarray(sl[:lk]))
+            fin.append(orc.evaluate(np.stack([Fs[x] for x in c["row"]]), np.ascontiguousarray(sl[lk:])))
         fin = np.stack(fin)
         self.t.append_scalars(fin)
         q = self.t.challenge_scalar()
@@ -1130,7 +1166,7 @@ class Prover:
         for _ in range(1, len(fin)):
             gam.append(orc.fr_mul_arr(gam[-1], q))
         dense = [(self.committed[k]["dense"], g) for k, g in zip(keys, gam) if "dense" in self.committed[k]]
-        onehot = [(self.committed[k]["row"], 16, g) for k, g in zip(keys, gam) if "dense" not in self.committed[k]]
+        onehot = [(self.committed[k]["row"], 1 << self.committed[k].get("lk", 4), g) for k, g in zip(keys, gam) if "dense" not in self.committed[k]]
         joint = OB.rlc_build(dense, onehot)
         assert len(joint) == 1 << len(ch)
         com, w, v = orc.hyperkzg_open(self.srs, joint, ch, self.t.t)

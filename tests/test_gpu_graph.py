@@ -134,6 +134,19 @@ def small_ops_graph(rng, n=4, d=8):
     ], [5], [x]
 
 
+def gather_small_graph(rng, n=8, d=4, v=32):
+    """the embedding as the tracer emits it for vocabularies of at most 2^16 words (handlers/index.rs:33-45): GatherSmall — ONE committed
+    one-hot polynomial over all v addresses, HammingBooleanity + Booleanity (d = 1) batched, HammingWeight on its own — then a Mul"""
+    dict_ = rng.integers(-(1 << 14), 1 << 14, size=v * d).astype(np.int32)
+    return [
+        {"idx": 0, "op": "Input", "inputs": [], "dims": [n]},
+        {"idx": 1, "op": "Constant", "inputs": [], "dims": [v, d], "data": dict_},
+        {"idx": 2, "op": "GatherSmall", "inputs": [1, 0], "dims": [n, d], "axis": 0, "dict_len": v},
+        _const(3, rng, [n, d], -(1 << 14), 1 << 14),
+        {"idx": 4, "op": "Mul", "inputs": [2, 3], "dims": [n, d], "scale": 14},
+    ], [4], [rng.integers(0, v, size=n).astype(np.int32)]
+
+
 def concat_graph(rng):
     """Concat (ops/concat.rs) along the last axis of three operands of unequal size (the smaller ones are repeated over the low variables of the
     largest one's hypercube), an Add over the result, then a second Concat along axis 0 whose output carries the output claim"""
@@ -149,8 +162,10 @@ def concat_graph(rng):
 
 
 def _max_vars(nodes):
-    # the largest committed polynomial is a one-hot chunk: K = 16 addresses x T cycles
-    return 4 + max(int(np.log2(np.prod(nd["dims"]))) for nd in nodes)
+    # the largest committed polynomial is a one-hot chunk: K = 16 addresses x T cycles (GatherSmall: dict_len addresses x the index count)
+    by_idx = {nd["idx"]: nd for nd in nodes}
+    gs = [int(np.log2(nd["dict_len"])) + int(np.log2(np.prod(by_idx[nd["inputs"][1]]["dims"]))) for nd in nodes if nd["op"] == "GatherSmall"]
+    return max([4 + max(int(np.log2(np.prod(nd["dims"]))) for nd in nodes)] + gs)
 
 
 def toy_transformer(rng):
@@ -161,7 +176,7 @@ def toy_transformer(rng):
     return BG.tiny(layers=2)
 
 
-@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6), (concat_graph, 7), (erf_sigmoid_graph, 8), (small_ops_graph, 9)])
+@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6), (concat_graph, 7), (erf_sigmoid_graph, 8), (small_ops_graph, 9), (gather_small_graph, 10)])
 def test_graph_proof_matches_oracle(atlas, builder, seed):
     from oracle import graph as OG, orc
     from jolt_atlas_amd import graph as GG
@@ -186,7 +201,7 @@ def test_graph_proof_matches_oracle(atlas, builder, seed):
     G.free(); srs.free()
 
 
-@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6), (concat_graph, 7), (erf_sigmoid_graph, 8), (small_ops_graph, 9)])
+@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6), (concat_graph, 7), (erf_sigmoid_graph, 8), (small_ops_graph, 9), (gather_small_graph, 10)])
 def test_graph_proof_is_accepted_by_the_verifier(atlas, builder, seed):
     """ONNXProof::verify (atlas_verify_graph: opening claims from the proof, the node loop's verifier instances, the opening-reduction
     sumcheck, the joint commitment, HyperKZG::verify through the pairing) accepts the device's proof with the prover's final transcript

@@ -4,14 +4,14 @@ atlas-onnx-tracer/src/node/mod.rs:12-24, ops/mod.rs:117-155), built with synthet
   transformer(...)      a GPT-style decoder stack with the operator decomposition the tracer produces for nanoGPT / GPT-2
                         (atlas-onnx-tracer/models/nanoGPT/network.onnx: MatMul -> Einsum, Pow -> Square / Cube, ReduceMean ->
                         Sum + ScalarConstDiv / MeanOfSquares, Sqrt + Div -> Rsqrt, Where -> Iff, tanh-GELU -> Cube / Mul / Tanh,
-                        Softmax -> SoftmaxLastAxis, Gather -> GatherLarge), shapes padded to powers of two (vocab 65 -> 128)
+                        Softmax -> SoftmaxLastAxis, Gather -> GatherSmall for dictionaries of at most 2^16 words, handlers/index.rs:33-45), shapes padded to powers of two (vocab 65 -> 128)
   nanogpt()             seq 64, d_model 64, 4 heads, 4 layers, vocab 128   (BASELINE config 3 shape)
   gpt2_layer()          seq 16, d_model 768 -> 1024, 12 -> 16 heads, one layer + lm-head slice (BASELINE config 4 shape, one layer)
 
 `level` selects how much of the decomposition is emitted, following what the graph prover composes:
   0  linear algebra + residuals only (Einsum / Add / Mul / ReLU / Reshape / Iff)      [round-3 first slice]
   1  + LayerNorm (Sum, ScalarConstDiv, Sub, Square, MeanOfSquares / Rsqrt)
-  2  + SoftmaxLastAxis, tanh-GELU (Cube, Tanh), GatherLarge embedding
+  2  + SoftmaxLastAxis, tanh-GELU (Cube, Tanh), the embedding gather (GatherSmall, as the tracer picks it for these vocabularies)
 
 The tensors are synthetic (there is no tracer here); the operator list per layer and the shapes are the model's."""
 import numpy as np
@@ -43,10 +43,10 @@ def transformer(layers, seq, d_model, heads, vocab, S=14, level=2, seed=0, mlp_m
     wlim = 1 << (S - 2)                      # weights ~ U(-0.25, 0.25) at scale S
     ff = mlp_mult * d_model
     one = 1 << S
-    if level >= 2:                           # token + position embedding: GatherLarge(wte, tokens) + wpe
+    if level >= 2:                           # token + position embedding: Gather(wte, tokens) + wpe
         tok = b.add("Input", [], [seq])
         wte = b.const([vocab, d_model], -one, one)
-        x = b.add("GatherLarge", [wte, tok], [seq, d_model], axis=0, dict_len=vocab)
+        x = b.add("GatherSmall" if vocab <= 65536 else "GatherLarge", [wte, tok], [seq, d_model], axis=0, dict_len=vocab)
         x = b.add("Add", [x, b.const([seq, d_model], -wlim, wlim)], [seq, d_model])
     else:
         x = b.add("Input", [], [seq, d_model])
@@ -133,12 +133,13 @@ NO_COMMIT = {"Input", "Constant", "Identity", "Reshape", "MoveAxis", "Broadcast"
 
 def max_vars(nodes):
     """log2 of the largest committed polynomial (AtlasSharedPreprocessing::max_num_vars): a one-hot chunk has 16 x T coefficients, T = the
-    node's (padded) element count (GatherLarge: its index count); dense advice polynomials have T coefficients"""
+    node's (padded) element count (Gather: its index count; GatherSmall's one polynomial has dict_len x T); dense advice polynomials have T coefficients"""
     byidx = {nd["idx"]: nd for nd in nodes}
     best = 4
     for nd in nodes:
         if nd["op"] in NO_COMMIT:
             continue
-        T = int(np.prod(byidx[nd["inputs"][1]]["dims"])) if nd["op"] == "GatherLarge" else int(np.prod(nd["dims"]))
-        best = max(best, 4 + int(np.log2(max(T, 1))))
+        T = int(np.prod(byidx[nd["inputs"][1]]["dims"])) if nd["op"] in ("GatherLarge", "GatherSmall") else int(np.prod(nd["dims"]))
+        lk = int(np.log2(byidx[nd["inputs"][0]]["dims"][0])) if nd["op"] == "GatherSmall" else 4        # GatherRa: all of the dictionary's address bits
+        best = max(best, lk + int(np.log2(max(T, 1))))
     return best
