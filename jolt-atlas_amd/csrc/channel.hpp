@@ -30,11 +30,12 @@ struct Channel {
     bool abort_dirty = false;
 
     hipError_t init() {
-        hipError_t e = hipHostMalloc(&mail, MAIL_CHUNKS * sizeof(atlas::Chunk), hipHostMallocDefault);
-        if (e == hipSuccess) e = hipHostMalloc(&rslots, RING * SLOT_CHUNKS * sizeof(atlas::Chunk), hipHostMallocDefault);
+        // fine-grained (coherent) whatever HIP_HOST_COHERENT says: the device polls these lines while the host writes them
+        hipError_t e = hipHostMalloc(&mail, MAIL_CHUNKS * sizeof(atlas::Chunk), hipHostMallocCoherent);
+        if (e == hipSuccess) e = hipHostMalloc(&rslots, RING * SLOT_CHUNKS * sizeof(atlas::Chunk), hipHostMallocCoherent);
         if (e == hipSuccess) e = hipMalloc(&d_rslots, RING * DEV_SLOT_CHUNKS * sizeof(atlas::Chunk));
         if (e == hipSuccess) e = hipMalloc(&d_abort, 64);
-        if (e != hipSuccess) return e;
+        if (e != hipSuccess) { release(); return e; }
         std::memset(mail, 0, MAIL_CHUNKS * sizeof(atlas::Chunk));
         std::memset(rslots, 0, RING * SLOT_CHUNKS * sizeof(atlas::Chunk));
         e = hipMemset(d_rslots, 0, RING * DEV_SLOT_CHUNKS * sizeof(atlas::Chunk));

@@ -26,7 +26,7 @@ struct atlas_shard_group {
     static constexpr uint64_t MAGIC = 0x61746c6173736864ull;     // "atlasshd"
     static constexpr size_t RING = 4, PAYLOAD = 496, MAX_WORLD = 64;
     struct Slot { std::atomic<uint64_t> tag; uint8_t pad[8]; uint8_t payload[PAYLOAD]; };     // 512 bytes
-    struct Header { std::atomic<uint64_t> ready; uint64_t epoch; uint32_t world; uint32_t pad; std::atomic<uint32_t> joined; uint8_t fill[4096 - 28]; };
+    struct Header { std::atomic<uint64_t> ready; uint64_t epoch; uint32_t world; uint32_t pad; std::atomic<uint32_t> joined; uint32_t pad2; uint64_t created_s; uint8_t fill[4096 - 40]; };
     int world = 0, rank = 0;
     std::string name;
     void* base = nullptr;
@@ -48,23 +48,39 @@ struct atlas_shard_group {
             fd = shm_open(nm, O_CREAT | O_EXCL | O_RDWR, 0600);
             if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) { if (fd >= 0) ::close(fd); return false; }
         } else {
+            // A segment left by a crashed run under the same name must not be joined: a fresh board still misses this rank (joined < world)
+            // and was created within this call's patience; anything else is unmapped and looked up again until rank 0 has replaced it.
             for (;;) {
                 fd = shm_open(nm, O_RDWR, 0600);
                 struct stat st;
-                if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= bytes) break;
+                if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= bytes) {
+                    void* b = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+                    ::close(fd); fd = -1;
+                    if (b != MAP_FAILED) {
+                        Header* h = reinterpret_cast<Header*>(b);
+                        const uint64_t now_s = (uint64_t)std::chrono::duration_cast<std::chrono::seconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+                        const bool ready = h->ready.load(std::memory_order_acquire) == MAGIC;
+                        const bool stale = ready && (h->joined.load(std::memory_order_acquire) >= h->world || h->created_s + (uint64_t)timeout_s + 60 < now_s);
+                        if (!stale) { base = b; break; }            // not ready yet (rank 0 is initialising it) or fresh
+                        munmap(b, bytes);
+                    }
+                }
                 if (fd >= 0) ::close(fd);
                 if (late()) return false;
                 usleep(200);
             }
         }
-        base = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        ::close(fd);
-        if (base == MAP_FAILED) { base = nullptr; return false; }
+        if (rank == 0) {
+            base = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            ::close(fd);
+            if (base == MAP_FAILED) { base = nullptr; return false; }
+        }
         if (rank == 0) {
             std::memset(base, 0, bytes);
             std::random_device rd;
             hdr()->epoch = (((uint64_t)rd() << 32) | rd()) >> 2 | 1;
             hdr()->world = (uint32_t)world;
+            hdr()->created_s = (uint64_t)std::chrono::duration_cast<std::chrono::seconds>(std::chrono::system_clock::now().time_since_epoch()).count();
             hdr()->joined.store(1, std::memory_order_relaxed);
             hdr()->ready.store(MAGIC, std::memory_order_release);
         } else {

@@ -277,9 +277,14 @@ int atlas_srs_load_file(const char* path, size_t max_points, atlas_srs_t* out) {
     uint8_t hdr[8];
     if (std::fread(hdr, 1, 8, f) != 8) { std::fclose(f); return fail(ATLAS_EINVAL, "srs_load_file: truncated"); }
     const uint64_t n_file = get_u64(hdr);
+    // the header's length is untrusted: it must fit the file (and the multiplication below)
+    long file_size = -1;
+    if (std::fseek(f, 0, SEEK_END) == 0) file_size = std::ftell(f);
+    if (file_size < 8 || std::fseek(f, 8, SEEK_SET) != 0 || n_file > ((uint64_t)file_size - 8) / 32) { std::fclose(f); return fail(ATLAS_EINVAL, "srs_load_file: the g1_powers length in the header exceeds the file"); }
     const size_t n = max_points && max_points < n_file ? max_points : (size_t)n_file;
     if (n == 0) { std::fclose(f); return fail(ATLAS_EINVAL, "srs_load_file: empty g1_powers"); }
-    std::vector<uint8_t> buf(n * 32);
+    std::vector<uint8_t> buf;
+    try { buf.resize(n * 32); } catch (const std::exception&) { std::fclose(f); return fail(ATLAS_ENOMEM, "srs_load_file: host buffer"); }
     const size_t got = std::fread(buf.data(), 1, buf.size(), f);
     std::fclose(f);
     if (got != buf.size()) return fail(ATLAS_EINVAL, "srs_load_file: truncated");

@@ -43,6 +43,44 @@ def test_allgather_over_shared_memory(world):
     assert all(ok is True for _, ok in res), res
 
 
+def _crash_worker(name, world, rank, q):
+    """joins the board and exits WITHOUT closing it: the segment stays behind, complete (joined == world), as after a crashed run"""
+    sys.path.insert(0, ROOT)
+    from jolt_atlas_amd import sharded
+    g = sharded.ShardGroup(name, world, rank)
+    g.allgather(np.array([rank], dtype=np.uint64))
+    q.put(rank)
+    q.close(); q.join_thread()         # flush the feeder thread, then leave without any cleanup
+    os._exit(0)
+
+
+def _late_rank0_worker(name, world, rank, delay, q):
+    import time
+    time.sleep(delay)
+    _worker(name, world, rank, 5, q)
+
+
+def test_stale_segment_of_a_crashed_run_is_not_joined():
+    """a rank that starts BEFORE rank 0 has replaced a complete segment left under the same name must not map the old one (its epoch and
+    slots are dead): it waits for the fresh board, and the exchange works"""
+    ctx = mp.get_context("spawn")
+    name = f"/atlas_test_stale_{os.getpid()}"
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_crash_worker, args=(name, 2, r, q)) for r in range(2)]
+    for p in ps: p.start()
+    for _ in ps: q.get(timeout=60)
+    for p in ps: p.join(timeout=30)
+    assert os.path.exists("/dev/shm" + name), "the crashed run must leave its segment behind for this test to mean anything"
+    q2 = ctx.Queue()
+    early = ctx.Process(target=_worker, args=(name, 2, 1, 5, q2))                    # rank 1 first: it finds the stale segment
+    late = ctx.Process(target=_late_rank0_worker, args=(name, 2, 0, 1.0, q2))        # rank 0 a second later
+    early.start(); late.start()
+    res = [q2.get(timeout=120) for _ in range(2)]
+    early.join(timeout=30); late.join(timeout=30)
+    assert all(ok is True for _, ok in res), res
+    assert not os.path.exists("/dev/shm" + name)                                     # rank 0's close unlinked the fresh board
+
+
 def test_bad_arguments():
     sys.path.insert(0, ROOT)
     import jolt_atlas_amd as A
