@@ -563,6 +563,22 @@ def main():
                                       "host shared memory, transcript on every rank)" % (n_vars, world),
                           "ms_per_instance": dt_s * 1e3 / shard_steps, "steps": shard_steps, "scaling": "strong",
                           "field_ops_per_s": field_ops(n_vars) * shard_steps / dt_s}
+        # the same instance with the per-round exchange as a collective (torch.distributed all_gather of the ranks' 64-byte records:
+        # RCCL over xGMI with the nccl backend, host sockets with gloo), for an A/B against the board on a multi-GPU node
+        coll_steps = max(1, min(shard_steps, 3))
+        coll_sets = [(mlp.clone(), mrp.clone()) for _ in range(coll_steps + 1)]
+        coll_states = []
+        coll_dev = torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else None
+
+        def coll_step(i):
+            t = A.Blake2bTranscript(b"synthetic_sc")
+            sharded.prove_dot_sharded(dist, *coll_sets[i], t, device=coll_dev, input_claim=g_claim)
+            coll_states.append(t.state)
+
+        dt_c = timed_steps(coll_step, coll_steps, 1, sync, barrier, allreduce_max)
+        assert set(coll_states) == {states[0]}, "the collective exchange and the board disagree on the transcript"
+        out["sharded"]["collective_ms_per_instance"] = dt_c * 1e3 / coll_steps
+        out["sharded"]["collective"] = "torch.distributed all_gather per round, backend %s" % dist.get_backend()
         if not args.no_msm:
             m = (1 << n_vars) // world
             sc_slice = A.MultilinearPolynomial.from_fr(A.random_fr(m, 0x5CA1A5 + n_vars + 7919 * rank))

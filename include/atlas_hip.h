@@ -790,8 +790,7 @@ int atlas_eval_reduction_verify(const atlas_fr_t *points, const atlas_fr_t *clai
  * serialized ONNXProof of atlas_prove_graph against the model (its constants), the inputs and the claimed output tensor
  * (ModelExecutionIO) under a HyperKZG verifier key.  Host arithmetic; the device evaluates the public tensors and adds up the joint
  * commitment.  Nothing of a prover's trace is read.  ATLAS_OK = accept; ATLAS_EVERIFY = ProofVerifyError; ATLAS_EINVAL = the graph holds
- * an operator without a verifier composition (composed: Input, Constant, Identity, Add, Sub, Mul, Square, Cube, Einsum, And, Iff, ReLU,
- * Reshape, MoveAxis, Broadcast). */
+ * an operator without a verifier composition (composed: every operator atlas_prove_graph composes). */
 int atlas_verify_graph(atlas_graph_t g, const atlas_hyperkzg_vk_t *vk, const int32_t *const *inputs, size_t n_inputs, const int32_t *output,
                        size_t output_len, const uint8_t *proof, size_t proof_len, atlas_transcript_t *final_transcript);
 
