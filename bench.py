@@ -590,6 +590,22 @@ def main():
             dt_ms = timed_steps(msm_shard_step, 3, 1, sync, barrier, allreduce_max)
             out["sharded"]["msm_ms"] = dt_ms * 1e3 / 3
             out["sharded"]["msm"] = "one 2^%d-point MSM split by point range over %d GPUs, partial points through the board" % (n_vars, world)
+            # HyperKZG::open of one 2^n polynomial with its four commitment groups split by point range (atlas_hyperkzg_open_sharded)
+            open_poly = A.MultilinearPolynomial.from_fr(A.random_fr(1 << n_vars, 0x0BE7 + n_vars))
+            rng_o = np.random.default_rng(n_vars)
+            open_point = [int.from_bytes(rng_o.bytes(16), "little") & ((1 << 125) - 1) for _ in range(n_vars)]
+            open_states = []
+
+            def open_step(i):
+                t = A.Blake2bTranscript(b"sharded_open")
+                sharded.hyperkzg_open_sharded_shm(grp, srs, open_poly, open_point, t)
+                open_states.append(t.state)
+
+            dt_o = timed_steps(open_step, 2, 1, sync, barrier, allreduce_max)
+            assert len(set(open_states)) == 1
+            out["sharded"]["open_ms"] = dt_o * 1e3 / 2
+            out["sharded"]["open"] = "HyperKZG::open of one 2^%d polynomial, commitments split by point range over %d GPUs (polynomial passes replicated)" % (n_vars, world)
+            open_poly.free()
         grp.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n_vars)

@@ -646,6 +646,11 @@ int atlas_fr_sum(const atlas_fr_t *v, size_t n, atlas_fr_t *out);               
 typedef struct atlas_shard_group *atlas_shard_group_t;
 int atlas_shard_group_open(const char *name, int world, int rank, atlas_shard_group_t *out);
 int atlas_shard_group_close(atlas_shard_group_t grp);
+/* HyperKZG::open (hyperkzg/mod.rs:400-447) with its commitments split by point range over the group's ranks: every rank
+ * passes the whole polynomial and its copy of the SRS, runs the same transcript and returns the same HyperKZGProof as atlas_hyperkzg_open
+ * (same bytes); the MSMs — Pi_1.. and the three witness polynomials, ~95 % of the open — are 1/world each, two exchanges of partial points. */
+int atlas_hyperkzg_open_sharded(atlas_srs_t srs, atlas_shard_group_t group, atlas_poly_t poly, const atlas_u128_t *point, size_t ell,
+                                atlas_transcript_t *transcript, atlas_g1_affine_t *com, atlas_g1_affine_t *w, atlas_fr_t *v);
 int atlas_shard_allgather(atlas_shard_group_t grp, const void *mine, size_t n_bytes, void *all);
 int atlas_sumcheck_prove_dot_sharded(atlas_dot_prover_t p, atlas_shard_group_t grp, const atlas_fr_t *input_claim,
                                      atlas_transcript_t *transcript, atlas_fr_t *compressed_polys,

@@ -14,6 +14,7 @@
 
 #include "../../include/atlas_hip.h"
 #include "host_curve.hpp"
+#include "shard_group.hpp"
 #include "host_field.hpp"
 #include "hyperkzg_kernels.hip.h"
 #include "msm_kernels.hip.h"
@@ -1032,8 +1033,55 @@ struct HkTrace {
 // hyperkzg/mod.rs:400-447 + kzg_open_batch :231-280.  poly is not consumed.
 //   com : ell-1 commitments to the folded polynomials Pi_1..Pi_{ell-1}
 //   w   : 3 witness commitments,  v : 3*ell evaluations, v[i*ell + j] = Pi_j(u_i)
-int atlas_hyperkzg_open(atlas_srs_t srs, atlas_poly_t poly, const atlas_u128_t* point, size_t ell,
-                        atlas_transcript_t* transcript, atlas_g1_affine_t* com, atlas_g1_affine_t* w, atlas_fr_t* v) {
+// K commitments of one group (the Pi_j of the open, or its three witness polynomials) with the points split by contiguous range over the
+// ranks of a shard group (SURVEY §8e "MSM: by point range"): rank r commits coefficients [r len / world, (r + 1) len / world) of every
+// vector against the same range of the SRS, the partial points cross the board and every rank adds them up (the sum of the ranks'
+// points is the same group element whatever the split, so the affine coordinates — and the proof bytes — are those of one GPU).
+// Vectors shorter than 1024 per rank stay whole on rank 0 (the others contribute the identity).
+static int commit_group_sharded(const atlas_srs* srs, const Fr* d_scalars, size_t K, const size_t* lens, const size_t* offs, atlas_shard_group* sh,
+                                atlas_g1_affine_t* out) {
+    const size_t world = (size_t)sh->world, rank = (size_t)sh->rank;
+    std::vector<atlas_g1_affine_t> mine(K);
+    for (auto& p : mine) { std::memset(&p, 0, sizeof(p)); p.infinity = 1; }
+    std::vector<size_t> small_idx;
+    for (size_t k = 0; k < K; k++) {
+        const size_t part = lens[k] / world;
+        if (part < 1024) { small_idx.push_back(k); continue; }
+        int rc = msm_device(srs->d + rank * part, d_scalars + offs[k] + rank * part, part, &mine[k], srs, rank * part);
+        if (rc) return rc;
+    }
+    if (rank == 0 && !small_idx.empty()) {
+        std::vector<size_t> sl(small_idx.size()), so(small_idx.size());
+        for (size_t i = 0; i < small_idx.size(); i++) { sl[i] = lens[small_idx[i]]; so[i] = offs[small_idx[i]]; }
+        std::vector<atlas_g1_affine_t> res(small_idx.size());
+        size_t hi = 0;
+        for (size_t i = 0; i < sl.size(); i++) hi = so[i] + sl[i] > hi ? so[i] + sl[i] : hi;
+        int rc = msm_device_multi(srs->d, d_scalars, hi, small_idx.size(), sl.data(), so.data(), res.data(), srs);
+        if (rc) return rc;
+        for (size_t i = 0; i < small_idx.size(); i++) mine[small_idx[i]] = res[i];
+    }
+    // exchange: 6 points (432 B) per record
+    std::vector<atlas_g1_affine_t> all(6 * world);
+    for (size_t k0 = 0; k0 < K; k0 += 6) {
+        const size_t cnt = K - k0 < 6 ? K - k0 : 6;
+        int rc = atlas_shard_allgather(sh, &mine[k0], cnt * sizeof(atlas_g1_affine_t), all.data());
+        if (rc) return rc;
+        for (size_t q = 0; q < cnt; q++) {
+            H::G1X acc = H::gx_inf();
+            for (size_t r = 0; r < world; r++) {
+                const atlas_g1_affine_t& pt = all[r * cnt + q];
+                if (pt.infinity) continue;
+                H::G1Aff a; std::memcpy(a.x.l, pt.x.l, 32); std::memcpy(a.y.l, pt.y.l, 32);
+                acc = H::gx_add(acc, H::gx_from_aff(a));
+            }
+            to_out(H::gx_to_aff(acc), &out[k0 + q]);
+        }
+    }
+    return ATLAS_OK;
+}
+
+static int hyperkzg_open_impl(atlas_srs_t srs, atlas_poly_t poly, const atlas_u128_t* point, size_t ell,
+                              atlas_transcript_t* transcript, atlas_g1_affine_t* com, atlas_g1_affine_t* w, atlas_fr_t* v, atlas_shard_group* sh) {
     NEED_INIT();
     if (!srs || !poly || !point || !transcript || !w || !v || ell == 0 || ell > 30 || (!com && ell > 1))
         return fail(ATLAS_EINVAL, "hyperkzg_open: bad argument");
@@ -1077,7 +1125,8 @@ int atlas_hyperkzg_open(atlas_srs_t srs, atlas_poly_t poly, const atlas_u128_t* 
         std::vector<size_t> lens(ell - 1), offs(ell - 1);
         size_t off = 0, len = n >> 1;
         for (size_t i = 1; i < ell; i++) { lens[i - 1] = len; offs[i - 1] = off; off += len; len >>= 1; }
-        int rc = msm_device_multi(srs->d, polys + n, off, ell - 1, lens.data(), offs.data(), com, srs);
+        int rc = sh ? commit_group_sharded(srs, polys + n, ell - 1, lens.data(), offs.data(), sh, com)
+                    : msm_device_multi(srs->d, polys + n, off, ell - 1, lens.data(), offs.data(), com, srs);
         if (rc) { cleanup(); return rc; }
     }
     tr.mark("commit Pi_1..");
@@ -1123,7 +1172,7 @@ int atlas_hyperkzg_open(atlas_srs_t srs, atlas_poly_t poly, const atlas_u128_t* 
     tr.mark("lincomb + witness polys");
     {   // the three witness commitments share the bases: one batched pipeline
         const size_t lens[3] = {n, n, n}, offs[3] = {0, n, 2 * n};
-        int rc = msm_device_multi(srs->d, h, 3 * n, 3, lens, offs, w, srs);
+        int rc = sh ? commit_group_sharded(srs, h, 3, lens, offs, sh, w) : msm_device_multi(srs->d, h, 3 * n, 3, lens, offs, w, srs);
         if (rc) { cleanup(); return rc; }
     }
     tr.mark("commit witnesses");
@@ -1134,6 +1183,19 @@ int atlas_hyperkzg_open(atlas_srs_t srs, atlas_poly_t poly, const atlas_u128_t* 
     cleanup();
     tr.mark("transcript + free");
     return ATLAS_OK;
+}
+
+int atlas_hyperkzg_open(atlas_srs_t srs, atlas_poly_t poly, const atlas_u128_t* point, size_t ell,
+                        atlas_transcript_t* transcript, atlas_g1_affine_t* com, atlas_g1_affine_t* w, atlas_fr_t* v) {
+    return hyperkzg_open_impl(srs, poly, point, ell, transcript, com, w, v, nullptr);
+}
+// HyperKZG::open with its four commitment groups (Pi_1.., the three witness polynomials: ~95 % of the open) split by point range over the
+// ranks of a shard group.  Every rank passes the WHOLE polynomial (the replicated folds, evaluations and quotients are HBM-bound passes:
+// ~1 ms of a 39 ms open at 2^22) and its copy of the SRS, runs the same transcript and returns the same proof; two board exchanges.
+int atlas_hyperkzg_open_sharded(atlas_srs_t srs, atlas_shard_group_t group, atlas_poly_t poly, const atlas_u128_t* point, size_t ell,
+                                atlas_transcript_t* transcript, atlas_g1_affine_t* com, atlas_g1_affine_t* w, atlas_fr_t* v) {
+    if (!group) return fail(ATLAS_EINVAL, "hyperkzg_open_sharded: null group");
+    return hyperkzg_open_impl(srs, poly, point, ell, transcript, com, w, v, group->world > 1 ? group : nullptr);
 }
 
 // sum of n affine points on the host: combines the per-rank partial MSMs of a point-range

@@ -132,6 +132,21 @@ def prove_dot_sharded_shm(group: ShardGroup, left_shard, right_shard, transcript
     return proof.reshape(n_total, 2, 4), [int(ch[2 * i]) | (int(ch[2 * i + 1]) << 64) for i in range(n_total)], fin, input_claim
 
 
+def hyperkzg_open_sharded_shm(group: ShardGroup, srs, poly: MultilinearPolynomial, point_u128, transcript: Blake2bTranscript):
+    """HyperKZG::open with its commitment MSMs split by point range over the group's ranks (atlas_hyperkzg_open_sharded): every rank holds
+    the whole polynomial and SRS and gets the whole proof.  Returns (com (ell-1,), w (3,), v (3, ell, 4)) as HyperKZG.open does."""
+    from . import U128
+    ell = len(point_u128)
+    pts = (U128 * ell)(*[U128(c & ((1 << 64) - 1), c >> 64) for c in point_u128])
+    com = np.zeros(max(ell - 1, 1), dtype=G1_DTYPE)
+    w = np.zeros(3, dtype=G1_DTYPE)
+    v = np.zeros((3 * ell, 4), dtype=np.uint64)
+    lib.atlas_hyperkzg_open_sharded.restype = C.c_int
+    _check(lib.atlas_hyperkzg_open_sharded(srs.h, group.h, poly.h, pts, C.c_size_t(ell), C.byref(transcript.t),
+                                           com.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), _p(v)))
+    return com[:ell - 1], w, v.reshape(3, ell, 4)
+
+
 def msm_sharded_shm(group: ShardGroup, srs_slice, scalars_slice, offset=0):
     """Point-range sharded MSM: one partial point per rank through the board, summed on every rank."""
     part = np.zeros(1, dtype=G1_DTYPE)

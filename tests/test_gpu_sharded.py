@@ -102,3 +102,51 @@ def test_sharded_over_shared_memory_board(tmp_path, world, n):
     for r, (p, (o, e)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, e[-3000:]
         assert f"SHM_SHARDED_OK {r}" in o
+
+
+@pytest.mark.parametrize("world,ell", [(2, 13), (4, 14), (2, 5)])
+def test_sharded_hyperkzg_open(tmp_path, world, ell):
+    """atlas_hyperkzg_open_sharded: the four commitment groups of HyperKZG::open split by point range over the ranks (partial points through
+    the shared-memory board); every rank's proof and transcript state equal the oracle's single-process open.  ell = 5: every vector is
+    below the per-rank threshold and stays whole on rank 0.  Processes share the test box's GPU."""
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {ROOT!r})
+        import numpy as np
+        rank, world = int(sys.argv[1]), {world}
+        import jolt_atlas_amd as A
+        from jolt_atlas_amd import sharded
+        from oracle import orc
+        A.init(0)
+        ell = {ell}
+        n = 1 << ell
+        tau = orc.random_fr(1, 0x5A)[0]
+        srs_h = orc.srs_powers(tau, n)
+        pv = orc.random_fr(n, 0x5B)
+        rng = np.random.default_rng(7)
+        point = [int.from_bytes(rng.bytes(16), "little") & ((1 << 125) - 1) for _ in range(ell)]
+        t_o = orc.new_transcript(b"sharded_open")
+        c_o, w_o, v_o = orc.hyperkzg_open(srs_h, pv, point, t_o)
+        srs = A.SRS.upload(srs_h)
+        if os.environ.get("SHARD_TAB") and ell >= 13:
+            srs.precompute()
+        poly = A.MultilinearPolynomial.from_fr(pv)
+        grp = sharded.ShardGroup(sys.argv[2], world, rank)
+        t = A.Blake2bTranscript(b"sharded_open")
+        c, w, v = sharded.hyperkzg_open_sharded_shm(grp, srs, poly, point, t)
+        assert all(orc.g1_eq(a, b) for a, b in zip(c, c_o)) and all(orc.g1_eq(a, b) for a, b in zip(w, w_o))
+        assert np.array_equal(np.asarray(v).reshape(-1, 4), np.asarray(v_o).reshape(-1, 4))
+        assert t.state == t_o.state_bytes()
+        grp.close()
+        print("SHARDED_OPEN_OK", rank)
+    """))
+    for tab in ("", "1"):
+        name = f"/atlas_open_{os.getpid()}_{world}_{ell}_{tab}"
+        env = dict(os.environ, SHARD_TAB=tab)
+        procs = [subprocess.Popen([sys.executable, str(script), str(r), name], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+                 for r in range(world)]
+        outs = [p.communicate(timeout=600) for p in procs]
+        for r, (p, (o, e)) in enumerate(zip(procs, outs)):
+            assert p.returncode == 0, e[-3000:]
+            assert f"SHARDED_OPEN_OK {r}" in o
