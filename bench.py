@@ -197,6 +197,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs that measure roofline.traffic")
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-node", action="store_true", help="skip the operator-node leg (atlas_prove_einsum_node)")
+    ap.add_argument("--no-gpt2-full", action="store_true", help="skip the 12-layer GPT-2-shaped graph of the whole-proof leg (1.1 GB of synthetic weights)")
     ap.add_argument("--no-graph", action="store_true", help="skip the whole-proof leg (atlas_prove_graph on the nanoGPT- / GPT-2-layer-shaped graphs)")
     ap.add_argument("--no-shard", action="store_true", help="N>1: skip the leg that shards ONE instance / ONE MSM over the N GPUs")
     args = ap.parse_args()
@@ -465,7 +466,7 @@ def main():
         from jolt_atlas_amd import graph as GG
         out["prove_graph"] = {"note": "synthetic-trace proxy of ONNXProof::prove: the model's operator list and (padded) shapes, random-init weights, "
                                       "full operator decomposition (SoftmaxLastAxis, tanh-GELU, LayerNorm, GatherSmall); reference (M3 CPU): nanoGPT 2.288 s, GPT-2 12 layers 14.889 s"}
-        for gname in ("nanogpt", "gpt2_layer"):
+        for gname in ("nanogpt", "gpt2_layer") + (() if args.no_gpt2_full else ("gpt2",)):
             nodes_g, outs_g, ins_g = getattr(BG, gname)()
             nv = BG.max_vars(nodes_g)
             t0s = time.perf_counter()

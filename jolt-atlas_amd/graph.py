@@ -93,7 +93,7 @@ class Graph:
         """ONNXProof::prove.  Returns (proof bytes, final transcript state bytes, timing dict)."""
         arrs, ptrs = self._inputs(inputs)
         n = C.c_size_t(); tm = GraphTiming(); ts = TranscriptState()
-        cap = 1 << 22
+        cap = getattr(self, "_proof_cap", 1 << 22)      # a second proof of the same graph starts from the first one's size
         while True:
             buf = (C.c_uint8 * cap)()
             rc = lib.atlas_prove_graph(self.h, srs.h, ptrs, C.c_size_t(len(arrs)), buf, C.c_size_t(cap), C.byref(n), C.byref(ts), C.byref(tm))
@@ -102,6 +102,7 @@ class Graph:
                 continue
             _check(rc)
             break
+        self._proof_cap = max(cap, 1 << 22)
         return bytes(buf[:n.value]), bytes(ts.state), tm.as_dict()
 
     def verify(self, vk, inputs, output, proof):

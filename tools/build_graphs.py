@@ -7,6 +7,7 @@ atlas-onnx-tracer/src/node/mod.rs:12-24, ops/mod.rs:117-155), built with synthet
                         Softmax -> SoftmaxLastAxis, Gather -> GatherSmall for dictionaries of at most 2^16 words, handlers/index.rs:33-45), shapes padded to powers of two (vocab 65 -> 128)
   nanogpt()             seq 64, d_model 64, 4 heads, 4 layers, vocab 128   (BASELINE config 3 shape)
   gpt2_layer()          seq 16, d_model 768 -> 1024, 12 -> 16 heads, one layer + lm-head slice (BASELINE config 4 shape, one layer)
+  gpt2()                the same with all 12 layers and the whole (padded) vocabulary: 2^16-word embedding and lm head
 
 `level` selects how much of the decomposition is emitted, following what the graph prover composes:
   0  linear algebra + residuals only (Einsum / Add / Mul / ReLU / Reshape / Iff)      [round-3 first slice]
@@ -122,6 +123,11 @@ def nanogpt(level=2, seed=0):
 def gpt2_layer(level=2, seed=0):
     # d_model 768 and 12 heads padded to 1024 / 16 (every dimension a power of two); the lm head is a 2^14-column slice
     return transformer(layers=1, seq=16, d_model=1024, heads=16, vocab=1 << 14, level=level, seed=seed)
+
+
+def gpt2(level=2, seed=0):
+    # GPT-2 125M's operator list: 12 layers, d_model 768 -> 1024, 12 -> 16 heads, vocabulary 50257 -> 2^16 (embedding gather and lm head), seq 16
+    return transformer(layers=12, seq=16, d_model=1024, heads=16, vocab=1 << 16, level=level, seed=seed)
 
 
 def tiny(level=2, seed=0, layers=2):
