@@ -580,6 +580,23 @@ def main():
         assert set(coll_states) == {states[0]}, "the collective exchange and the board disagree on the transcript"
         out["sharded"]["collective_ms_per_instance"] = dt_c * 1e3 / coll_steps
         out["sharded"]["collective"] = "torch.distributed all_gather per round, backend %s" % dist.get_backend()
+        # one Mul operator sumcheck (eq(r, x) a(x) b(x), LowToHigh over the split-eq) sharded by contiguous blocks: atlas_elementwise_prove_sharded
+        from jolt_atlas_amd import instances as INST
+        blk = (1 << n_vars) // world
+        a_blk = A.MultilinearPolynomial.from_fr(A.random_fr(blk, 0x3A0 + n_vars + 7 * rank))
+        b_blk = A.MultilinearPolynomial.from_fr(A.random_fr(blk, 0x3B0 + n_vars + 7 * rank))
+        r_mul = A.random_fr(n_vars, 0x3C0 + n_vars)
+        mul_states = []
+
+        def mul_step(i):
+            t = A.Blake2bTranscript(b"sharded_mul")
+            sharded.prove_elementwise_sharded_shm(grp, INST.EW_MUL, [a_blk, b_blk], r_mul, t, np.array([1, 0, 0, 0], dtype=np.uint64))
+            mul_states.append(t.state)
+
+        dt_m = timed_steps(mul_step, 3, 1, sync, barrier, allreduce_max)
+        out["sharded"]["mul_ms"] = dt_m * 1e3 / 3
+        out["sharded"]["mul"] = "one Mul operator sumcheck over 2^%d elements, contiguous blocks over %d GPUs (timing run: arbitrary input claim)" % (n_vars, world)
+        a_blk.free(); b_blk.free()
         if not args.no_msm:
             m = (1 << n_vars) // world
             sc_slice = A.MultilinearPolynomial.from_fr(A.random_fr(m, 0x5CA1A5 + n_vars + 7919 * rank))

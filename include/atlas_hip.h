@@ -649,6 +649,14 @@ int atlas_shard_group_close(atlas_shard_group_t grp);
 /* HyperKZG::open (hyperkzg/mod.rs:400-447) with its commitments split by point range over the group's ranks: every rank
  * passes the whole polynomial and its copy of the SRS, runs the same transcript and returns the same HyperKZGProof as atlas_hyperkzg_open
  * (same bytes); the MSMs — Pi_1.. and the three witness polynomials, ~95 % of the open — are 1/world each, two exchanges of partial points. */
+/* One element-wise operator sumcheck (Mul, Add, Sub, Square, Iff, Div, Rsqrt, Cube: LowToHigh over the Gruen split-eq, mul.rs:160-199)
+ * sharded by contiguous blocks: `inst` = atlas_elementwise_new over this rank's block of 2^(n - log2 world) coefficients per
+ * operand with the LOW coordinates r_node_output[log2 world ..]; r_high = the leading log2 world coordinates.  One 32..96-byte record per
+ * rank and round through the board, then the operands' world final values once; every rank gets the whole proof (n rows), the challenges
+ * and the operands' final claims — the same bytes as the unsharded instance. */
+int atlas_elementwise_prove_sharded(atlas_instance_t inst, atlas_shard_group_t grp, const atlas_fr_t *r_high, const atlas_fr_t *input_claim,
+                                    atlas_transcript_t *transcript, atlas_fr_t *compressed, size_t row_stride, uint32_t *n_coeffs,
+                                    atlas_u128_t *challenges, atlas_fr_t *finals, size_t finals_cap, size_t *n_finals);
 int atlas_hyperkzg_open_sharded(atlas_srs_t srs, atlas_shard_group_t group, atlas_poly_t poly, const atlas_u128_t *point, size_t ell,
                                 atlas_transcript_t *transcript, atlas_g1_affine_t *com, atlas_g1_affine_t *w, atlas_fr_t *v);
 int atlas_shard_allgather(atlas_shard_group_t grp, const void *mine, size_t n_bytes, void *all);

@@ -16,6 +16,7 @@
 // first bind of a CompactPolynomial (compact_polynomial.rs:272-353) yields the same field values.
 // HBM per round: n_ops * len * 32 B read by the fold, the same read + half written by the bind.
 #include "ra_common.hip.h"
+#include "shard_group.hpp"
 
 namespace {
 
@@ -192,6 +193,14 @@ struct Elementwise : atlas_instance {
     size_t rounds() const override { return n_vars; }
     size_t degree() const override { return op == EW_CUBE ? 4 : !ew_has_eq(op) ? 2 : ew_outputs(op) + 1; }
     int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
+        H::Fr s[3];
+        int rc = local_sums(round, s);
+        if (rc) return rc;
+        return finish(round, claim, s, coeffs);
+    }
+    // the round's fold over THIS instance's rows: q_constant (, q_quadratic (, ...)) before the Gruen finish — what a rank of a sharded
+    // instance contributes to the round (atlas_elementwise_prove_sharded)
+    int local_sums(size_t round, H::Fr* s) {
         if (round != round_next || round >= n_vars) return fail(ATLAS_ESTATE, "elementwise: round out of order");
         std::lock_guard<atlas_rt::Mutex> lk(g.mu);
         const size_t n_groups = rows.len / 2;
@@ -204,25 +213,7 @@ struct Elementwise : atlas_instance {
 #undef EW_CASE
             default: return fail(ATLAS_EINVAL, "elementwise: unknown operator");
         }
-        const int nq = ew_outputs(op);
-        H::Fr s[3];
-        int rc = rows.reduce_to_host((uint32_t)blocks, (uint32_t)nq, s);
-        if (rc) return rc;
-        if (!ew_has_eq(op)) {
-            coeffs.assign(3, H::zero());
-            H::unipoly_from_evals_and_hint(claim, s, 2, coeffs.data());
-        } else if (op == EW_CUBE) {
-            std::vector<H::Fr> sums(3);
-            for (int k = 0; k < 3; k++) sums[k] = H::mul(s[k], eq.st.scalar);        // mles_product_sum.rs:131
-            coeffs = H::finish_product_sum(sums, claim, eq.st);
-        } else if (nq == 1) {
-            coeffs.assign(3, H::zero());
-            H::gruen_deg2(eq.st, s[0], claim, coeffs.data());
-        } else {
-            coeffs.assign(4, H::zero());
-            H::gruen_deg3(eq.st, s[0], s[1], claim, coeffs.data());
-        }
-        return ATLAS_OK;
+        return rows.reduce_to_host((uint32_t)blocks, (uint32_t)ew_outputs(op), s);
     }
     int ingest(const atlas_u128_t& r, size_t round) override {
         if (round != round_next || round >= n_vars) return fail(ATLAS_ESTATE, "elementwise: round out of order");
@@ -347,6 +338,103 @@ int atlas_elementwise_new(int op, const atlas_poly_t* operands, size_t n_operand
     if (!rc && ew_has_eq(op)) rc = P->eq.init(reinterpret_cast<const H::Fr*>(r_node_output), n_vars);
     if (rc) { delete P; return rc; }
     *out = P;
+    return ATLAS_OK;
+}
+
+// One element-wise operator sumcheck (LowToHigh over the Gruen split-eq: Mul, Add, Sub, Square, Iff, Div, ... — mul.rs:160-199) sharded over
+// the ranks of a group by CONTIGUOUS blocks: `inst` is this rank's instance over its block of 2^(n - log2 world) coefficients,
+// built with the LOW coordinates of the opening point (r_node_output[log2 world ..]); r_high = the leading log2 world coordinates.  LowToHigh
+// pairs (2i, 2i + 1) stay on a rank, so the first n - log2 world rounds exchange only the round's sums: a rank's sums weigh eq(r_high, rank)
+// in the total (the eq table factorises), every rank adds the world records in rank order and runs the same Gruen finish and transcript step.
+// Then the world final values of each operand cross the board once and the last log2 world rounds run on every rank over those (a small
+// instance that inherits the split-eq scalar).  Same proof on every rank, the same bytes as the unsharded instance.
+int atlas_elementwise_prove_sharded(atlas_instance_t inst, atlas_shard_group_t grp, const atlas_fr_t* r_high, const atlas_fr_t* input_claim,
+                                    atlas_transcript_t* transcript, atlas_fr_t* compressed, size_t row_stride, uint32_t* n_coeffs, atlas_u128_t* challenges,
+                                    atlas_fr_t* finals, size_t finals_cap, size_t* n_finals) {
+    NEED_INIT();
+    Elementwise* P = dynamic_cast<Elementwise*>(inst);
+    if (!P || !grp || !input_claim || !transcript || !compressed || !n_coeffs || !challenges || !finals || !n_finals) return fail(ATLAS_EINVAL, "elementwise_prove_sharded: null argument / not an element-wise instance");
+    if (!ew_has_eq(P->op)) return fail(ATLAS_EINVAL, "elementwise_prove_sharded: the selector-style operators (no eq factor) are not sharded");
+    const size_t world = (size_t)grp->world, rank = (size_t)grp->rank;
+    size_t lw = 0; while (((size_t)1 << lw) < world) lw++;
+    if (lw && !r_high) return fail(ATLAS_EINVAL, "elementwise_prove_sharded: r_high");
+    const int nq = ew_outputs(P->op);
+    if (row_stride < P->degree()) return fail(ATLAS_EINVAL, "elementwise_prove_sharded: row_stride below the degree");
+    H::Transcript& T = *reinterpret_cast<H::Transcript*>(transcript);
+    const H::Fr* rh = reinterpret_cast<const H::Fr*>(r_high);
+    H::Fr weight = H::one();                                                  // eq(r_high, bits(rank)), r_high[0] = the most significant bit
+    for (size_t q = 0; q < lw; q++) weight = H::mul(weight, ((rank >> (lw - 1 - q)) & 1) ? rh[q] : H::sub(H::one(), rh[q]));
+    H::Fr prev = *reinterpret_cast<const H::Fr*>(input_claim);
+    H::tr_append_scalar(T, prev);
+    std::vector<H::Fr> c;
+    size_t out_round = 0;
+    auto step = [&](Elementwise* I, size_t round, bool exchange) -> int {
+        H::Fr s[3], tot[3];
+        int rc = I->local_sums(round, s);
+        if (rc) return rc;
+        if (exchange) {
+            H::Fr mine[3], all[atlas_shard_group::MAX_WORLD * 3];
+            for (int k = 0; k < nq; k++) mine[k] = H::mul(s[k], weight);
+            rc = atlas_shard_allgather(grp, mine, (size_t)nq * 32, all);
+            if (rc) return rc;
+            for (int k = 0; k < nq; k++) { tot[k] = H::zero(); for (size_t r = 0; r < world; r++) tot[k] = H::add(tot[k], all[r * nq + k]); }
+        } else for (int k = 0; k < nq; k++) tot[k] = s[k];
+        I->prepare(round);
+        rc = I->finish(round, prev, tot, c);
+        if (rc) return rc;
+        std::vector<H::Fr> cc;
+        if (c.size() < 2) cc = c;
+        else { cc.push_back(c[0]); for (size_t k = 2; k < c.size(); k++) cc.push_back(c[k]); }
+        if (cc.size() > row_stride) return fail(ATLAS_EINVAL, "elementwise_prove_sharded: row_stride below the degree");
+        H::tr_append_message(T, "UniPoly_begin");
+        for (auto& x : cc) H::tr_append_scalar(T, x);
+        H::tr_append_message(T, "UniPoly_end");
+        n_coeffs[out_round] = (uint32_t)cc.size();
+        std::memcpy(&compressed[out_round * row_stride], cc.data(), cc.size() * 32);
+        uint64_t lo, hi;
+        H::tr_challenge_u128(T, lo, hi);
+        challenges[out_round].lo = lo; challenges[out_round].hi = hi;
+        const H::Fr rf = H::challenge_to_fr(lo, hi, g.challenge_mode);
+        H::Fr ev = c[0], pw = rf;                                             // UniPoly::evaluate
+        for (size_t i = 1; i < c.size(); i++) { ev = H::add(ev, H::mul(pw, c[i])); pw = H::mul(pw, rf); }
+        prev = ev;
+        out_round++;
+        return I->ingest(challenges[out_round - 1], round);
+    };
+    for (size_t round = 0; round < P->n_vars; round++) { int rc = step(P, round, world > 1); if (rc) return rc; }
+    std::vector<H::Fr> f;
+    int rc = P->finals(f);
+    if (rc) return rc;
+    if (world == 1) {
+        if (f.size() > finals_cap) return fail(ATLAS_EINVAL, "elementwise_prove_sharded: finals buffer");
+        std::memcpy(finals, f.data(), f.size() * 32); *n_finals = f.size();
+        return ATLAS_OK;
+    }
+    // the operands' remaining world values (rank b holds index b: contiguous blocks), a small instance over them on every rank
+    const size_t n_ops = f.size();
+    if (n_ops * 32 > atlas_shard_group::PAYLOAD) return fail(ATLAS_EINVAL, "elementwise_prove_sharded: too many operands for one record");
+    std::vector<H::Fr> all(world * n_ops);
+    rc = atlas_shard_allgather(grp, f.data(), n_ops * 32, all.data());
+    if (rc) return rc;
+    std::vector<atlas_poly_t> polys(n_ops, nullptr);
+    for (size_t o = 0; o < n_ops && !rc; o++) {
+        std::vector<H::Fr> col(world);
+        for (size_t r = 0; r < world; r++) col[r] = all[r * n_ops + o];
+        rc = atlas_poly_upload_fr((const atlas_fr_t*)col.data(), world, &polys[o]);
+    }
+    const size_t n_consts = P->op == EW_RSQRT ? 2 : (P->op == EW_GATHER || P->op == EW_TELEPORT_DIV) ? 1 : P->op == EW_HAMMING_BOOL ? n_ops : 0;
+    atlas_instance_t tail_h = nullptr;
+    if (!rc) rc = atlas_elementwise_new(P->op, polys.data(), n_ops, r_high, lw, n_consts ? (const atlas_fr_t*)P->consts.k : nullptr, n_consts, &tail_h);
+    for (atlas_poly_t q : polys) if (q) atlas_poly_free(q);
+    if (rc) return rc;
+    Elementwise* Tl = static_cast<Elementwise*>(tail_h);
+    Tl->eq.st.scalar = P->eq.st.scalar;                                       // the eq factors of the variables bound so far
+    for (size_t round = 0; round < lw && !rc; round++) rc = step(Tl, round, false);
+    if (!rc) rc = Tl->finals(f);
+    atlas_instance_free(tail_h);
+    if (rc) return rc;
+    if (f.size() > finals_cap) return fail(ATLAS_EINVAL, "elementwise_prove_sharded: finals buffer");
+    std::memcpy(finals, f.data(), f.size() * 32); *n_finals = f.size();
     return ATLAS_OK;
 }
 

@@ -132,6 +132,27 @@ def prove_dot_sharded_shm(group: ShardGroup, left_shard, right_shard, transcript
     return proof.reshape(n_total, 2, 4), [int(ch[2 * i]) | (int(ch[2 * i + 1]) << 64) for i in range(n_total)], fin, input_claim
 
 
+def prove_elementwise_sharded_shm(group: ShardGroup, op, operand_blocks, r_node_output, transcript: Blake2bTranscript, input_claim, constants=None):
+    """One element-wise operator sumcheck (instances.elementwise: Mul, Add, Sub, Square, Iff, ...) sharded by contiguous blocks
+    (atlas_elementwise_prove_sharded).  operand_blocks: this rank's block of every operand (device polynomials of 2^(n - log2 world)
+    coefficients); r_node_output: the whole opening point (n coordinates).  Returns (rows of compressed coefficients, challenges, final claims)."""
+    from . import instances, U128
+    rn = np.ascontiguousarray(r_node_output, dtype=np.uint64).reshape(-1, 4)
+    lw = group.world.bit_length() - 1
+    n = len(rn)
+    inst = instances.elementwise(op, operand_blocks, rn[lw:], constants)
+    stride = inst.degree() + 1
+    comp = np.zeros((n, stride, 4), dtype=np.uint64)
+    nco = np.zeros(n, dtype=np.uint32); ch = np.zeros(2 * n, dtype=np.uint64)
+    fin = np.zeros((16, 4), dtype=np.uint64); nf = C.c_size_t()
+    ic = _fr(input_claim); rh = np.ascontiguousarray(rn[:lw]) if lw else np.zeros((1, 4), dtype=np.uint64)
+    lib.atlas_elementwise_prove_sharded.restype = C.c_int
+    _check(lib.atlas_elementwise_prove_sharded(inst.h, group.h, _p(rh), _p(ic), C.byref(transcript.t), _p(comp), C.c_size_t(stride),
+                                               nco.ctypes.data_as(C.c_void_p), _p(ch), _p(fin), C.c_size_t(16), C.byref(nf)))
+    inst.free()
+    return [comp[i, :nco[i]].copy() for i in range(n)], [int(ch[2 * i]) | (int(ch[2 * i + 1]) << 64) for i in range(n)], fin[:nf.value].copy()
+
+
 def hyperkzg_open_sharded_shm(group: ShardGroup, srs, poly: MultilinearPolynomial, point_u128, transcript: Blake2bTranscript):
     """HyperKZG::open with its commitment MSMs split by point range over the group's ranks (atlas_hyperkzg_open_sharded): every rank holds
     the whole polynomial and SRS and gets the whole proof.  Returns (com (ell-1,), w (3,), v (3, ell, 4)) as HyperKZG.open does."""
