@@ -173,7 +173,7 @@ extern "C" int atlas_eval_reduction_prove(atlas_poly_t mle, const atlas_fr_t* po
                                           size_t n, atlas_transcript_t* transcript, atlas_fr_t* h_out, size_t h_cap,
                                           size_t* h_len, atlas_fr_t* r_out, atlas_fr_t* claim_out) {
     NEED_INIT();
-    if (!mle || !points || !claims || !transcript || !h_out || !h_len || !r_out || !claim_out) return fail(ATLAS_EINVAL, "eval_reduction: null argument");
+    if (!mle || (!points && n) || !claims || !transcript || !h_out || !h_len || (!r_out && n) || !claim_out) return fail(ATLAS_EINVAL, "eval_reduction: null argument");
     if (N == 0) return fail(ATLAS_EINVAL, "eval_reduction: EmptyInput");
     size_t len = 0;
     atlas_poly_len(mle, &len);
@@ -182,7 +182,8 @@ extern "C" int atlas_eval_reduction_prove(atlas_poly_t mle, const atlas_fr_t* po
     if (N == 1) {                                                   // short path, evaluation_reduction.rs:113-127
         if (h_cap < 1) return fail(ATLAS_EINVAL, "eval_reduction: h buffer too small");
         std::memcpy(h_out, claims, 32); *h_len = 1;
-        std::memcpy(r_out, points, n * 32); std::memcpy(claim_out, claims, 32);
+        if (n) std::memcpy(r_out, points, n * 32);
+        std::memcpy(claim_out, claims, 32);
         return ATLAS_OK;
     }
     const size_t D = n * (N - 1);
@@ -200,7 +201,12 @@ extern "C" int atlas_eval_reduction_prove(atlas_poly_t mle, const atlas_fr_t* po
         const H::Fr x = H::from_u64(t);
         for (size_t i = 0; i < n; i++) lpts[t * n + i] = horner(var[i], x);
     }
-    {
+    if (n == 0) {                                                   // a scalar node: h is the constant polynomial of its one value
+        atlas_fr_t c0;
+        int rc = atlas_poly_download(mle, &c0, 1);
+        if (rc) return rc;
+        hev.assign(1, *reinterpret_cast<H::Fr*>(&c0));
+    } else {
         int rc = evaluate_many(mle, lpts, D + 1, n, hev);
         if (rc) return rc;
     }

@@ -1253,7 +1253,10 @@ extern "C" int atlas_verify_graph(atlas_graph_t G, const atlas_hyperkzg_vk_t* vk
     }
     rc = V.output_claim();
     size_t dummy = 0;
-    for (auto it = G->nodes.rbegin(); it != G->nodes.rend() && !rc; ++it) rc = V.verify_node(it->second, dummy);
+    for (auto it = G->nodes.rbegin(); it != G->nodes.rend() && !rc; ++it) {
+        rc = V.verify_node(it->second, dummy);
+        if (rc && getenv("ATLAS_GRAPH_TRACE")) fprintf(stderr, "[atlas graph] verify: node %zu (operator %d) -> %d\n", it->second.idx, it->second.op, rc);
+    }
     if (!rc) rc = V.reduced_openings();
     if (!rc && final_transcript) *final_transcript = V.t;
     return rc;
