@@ -7,7 +7,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def random_chain(seed, steps=9):
+def random_chain(seed, steps=9, wide=False):
     rng = np.random.default_rng(seed)
     m, n = int(rng.choice([2, 4, 8])), int(rng.choice([2, 4, 8]))
     nodes = [{"idx": 0, "op": "Input", "inputs": [], "dims": [m, n]}]
@@ -40,6 +40,8 @@ def random_chain(seed, steps=9):
 
     for _ in range(steps):
         r = rng.random()
+        if wide and rng.random() < 0.45:
+            r = 0.94 + 0.06 * rng.random()
         if r < 0.22:
             op = str(rng.choice(["Add", "Sub"]))
             p = same_shape_partner()
@@ -87,10 +89,37 @@ def random_chain(seed, steps=9):
                 nd_ = list(dims); nd_[ax] = 2 * dims[ax]
                 cur = add("Concat", [cur, other] if rng.random() < 0.5 else [other, cur], nd_, axis=ax)
                 dims = nd_
-        elif len(dims) == 2 and dims[1] >= 2:
+        elif r < (0.94 if wide else 2.0) and len(dims) == 2 and dims[1] >= 2:
             s = add("Sum", [cur], [dims[0], 1], axes=[1])
             b = add("Broadcast", [s], dims)
             cur = add("Sub", [cur, b], dims)
+        elif wide and r < 0.95:
+            cur = add("ScalarConstDiv", [cur], dims, divisor=int(rng.integers(2, 100)))
+        elif wide and r < 0.96:
+            d_ = add("Constant", [], dims, data=rng.integers(1, 1 << int(rng.integers(1, 12)), size=int(np.prod(dims))).astype(np.int32))
+            bits[d_] = 12
+            cur = add("Div", [cur, d_], dims)
+        elif wide and r < 0.97 and len(dims) == 2 and dims[1] >= 2 and 2 * bits[cur] + 3 < 62:
+            S = int(rng.integers(4, 12))
+            ms = add("MeanOfSquares", [cur], [dims[0], 1], axes=[1], scale=S, count=dims[1])
+            bits[ms] = min(31, max(0, 2 * bits[cur] - S))
+            eps = add("Constant", [], [dims[0], 1], data=np.full(dims[0], int(rng.integers(1, 5)), dtype=np.int32)); bits[eps] = 3
+            v_ = add("Add", [ms, eps], [dims[0], 1])
+            rs = add("Rsqrt", [v_], [dims[0], 1], scale=S); bits[rs] = 3 * S // 2 + 1
+            b = add("Broadcast", [rs], dims)
+            if bits[cur] + bits[b] < 62:
+                cur = add("Mul", [cur, b], dims, scale=S)
+            else:
+                cur = add("Add", [cur, b], dims)
+        elif wide and r < 0.98:
+            op = str(rng.choice(["Tanh", "Erf", "Sigmoid"]))
+            cur = add(op, [cur], dims, scale=14); bits[cur] = 15
+        elif wide and r < 0.99 and len(dims) == 2 and dims[0] >= 2 and dims[1] >= 2:
+            cur = add("SoftmaxLastAxis", [cur], dims, scale=14); bits[cur] = 15
+        elif wide:
+            mask = add("Constant", [], dims, data=rng.integers(0, 2, size=int(np.prod(dims))).astype(np.int32)); bits[mask] = 1
+            other = same_shape_partner()
+            cur = add("Iff", [mask, cur, other], dims); bits[cur] = max(bits[nodes[cur]["inputs"][1]], bits[other])
     if nodes[cur]["op"] in ("Input", "Constant"):
         cur = add("ReLU", [cur], dims)
     return nodes, [cur], [x_in]
@@ -122,4 +151,27 @@ def test_random_operator_chain(atlas, seed):
         assert not V.verify(vk, inputs, out, bytes(bad))[0], off
     except atlas.AtlasError:
         pass
+    G.free(); V.free(); srs.free()
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_operator_chain_wide(atlas, seed):
+    """the same with the lookup-heavy operators in the draw: ScalarConstDiv, Div, MeanOfSquares + Rsqrt, Tanh / Erf / Sigmoid, SoftmaxLastAxis, Iff"""
+    from oracle import graph as OG, orc
+    from jolt_atlas_amd import graph as GG
+    nodes, outputs, inputs = random_chain(5000 + seed, steps=11, wide=True)
+    nv = 4 + max(int(np.log2(max(int(np.prod(nd["dims"])), 1))) for nd in nodes)
+    tau = orc.random_fr(1, 0x51250003)[0]
+    srs = atlas.SRS.generate(tau, 1 << nv)
+    P = OG.Prover(nodes, outputs, orc.srs_powers(tau, 1 << nv))
+    want = P.prove(inputs)
+    G = GG.Graph(nodes, outputs)
+    got, state, _ = G.prove(srs, inputs)
+    for nd in nodes:
+        assert np.array_equal(G.node_output(nd["idx"]), P.trace[nd["idx"]]), f"trace of node {nd['idx']} ({nd['op']}), seed {seed}"
+    assert state == P.t.state() and got == want, [nd["op"] for nd in nodes]
+    vk = atlas.HyperKZG.vk_from_trapdoor(tau, srs.download(0, 1)[0])
+    V = GG.Graph(nodes, outputs)
+    ok, vstate = V.verify(vk, inputs, G.node_output(outputs[0]), got)
+    assert ok and vstate == state, [nd["op"] for nd in nodes]
     G.free(); V.free(); srs.free()
