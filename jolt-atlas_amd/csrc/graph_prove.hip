@@ -116,6 +116,7 @@ struct Prover : FlowSink {
 
     // MultilinearPolynomial::from(tensor.padded_next_power_of_two()).evaluate(point) for device tensors
     int eval_i32(const int32_t* const* tensors, size_t count, size_t T, const Point& point, H::Fr* out_) {
+        if (T == 1) { int rc1 = ATLAS_OK; for (size_t i = 0; i < count && !rc1; i++) rc1 = scalar_of(tensors[i], &out_[i]); return rc1; }
         std::vector<atlas_poly_t> ps(count, nullptr);
         int rc = ATLAS_OK;
         for (size_t i = 0; i < count && !rc; i++) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(tensors[i]), T, &ps[i]);
@@ -140,6 +141,22 @@ struct Prover : FlowSink {
         return O.put_proof(rows, stride, nco, n, proof_type);
     }
     static Point reversed(const std::vector<H::Fr>& rs) { return Point(rs.rbegin(), rs.rend()); }     // LITTLE_ENDIAN -> BIG_ENDIAN
+    // Sumcheck::prove of an instance over ZERO variables (a scalar node): the input claim enters the transcript, no round follows, the proof
+    // is the empty SumcheckInstanceProof; the caller's cache_openings appends the operands' single values
+    int zero_rounds(const H::Fr& claim, uint8_t proof_type) {
+        H::tr_append_scalar(Tr, claim);
+        const uint8_t empty[8] = {0, 0, 0, 0, 0, 0, 0, 0};                     // compressed_polys: Vec of length 0
+        proof(proof_type, empty, 8);
+        return ATLAS_OK;
+    }
+    int scalar_of(const int32_t* d_tensor, H::Fr* out_) {
+        int32_t v = 0;
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        HIP_TRY(hipMemcpyAsync(&v, d_tensor, 4, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        *out_ = fr_from_i64_host((int64_t)v);
+        return ATLAS_OK;
+    }
 
     // ---------------------------------------------------------------- commit_witness_polynomials
     // get_committed_polynomials of every node (ops/*.rs) over the witness the trace left in HBM
@@ -343,6 +360,11 @@ struct Prover : FlowSink {
         const gr::Opening& R = red(nd);
         atlas_poly_t ops[3] = {nullptr, nullptr, nullptr};
         int rc = ATLAS_OK;
+        if (log_T == 0) {                                                     // a scalar node
+            rc = zero_rounds(in_claim, proof_type);
+            for (size_t q = 0; q < n_ops && !rc; q++) { H::Fr v; rc = scalar_of(G.tensor(nd.inputs[q]), &v); if (!rc) rc = append_nodeio(nd, q, Point(), v); }
+            return rc;
+        }
         for (size_t i = 0; i < n_ops && !rc; i++) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(G.tensor(nd.inputs[i])), T, &ops[i]);
         atlas_instance_t inst = nullptr;
         if (!rc) rc = atlas_elementwise_new(ew_op, ops, n_ops, (const atlas_fr_t*)R.point.data(), log_T, nullptr, 0, &inst);
@@ -596,6 +618,7 @@ struct Prover : FlowSink {
         const gr::Opening& R = red(nd);
         NodeWitness& W = G.wit[nd.idx];
         atlas_poly_t ops[2] = {nullptr, nullptr};
+        if (log_T == 0) return fail(ATLAS_EINVAL, "prove_graph: ScalarConstDiv of a scalar is not composed (its one-coefficient committed remainder would need a zero-round member in the opening reduction)");
         int rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(G.tensor(nd.inputs[0])), T, &ops[0]);
         if (!rc) rc = atlas_poly_wrap_device_i32(W.rem.as<int32_t>(), T, &ops[1]);
         atlas_instance_t inst = nullptr;

@@ -178,6 +178,7 @@ struct Verifier {
         const Rows& R = it->second;
         if (R.rounds != n_rounds) return bad("verify_graph: a sumcheck proof with the wrong number of rounds");
         H::tr_append_scalar(Tr, input_claim);
+        if (n_rounds == 0) { *e = input_claim; rs.clear(); return ATLAS_OK; }     // a scalar node: the claim is compared with the expected claim as it is
         std::vector<atlas_u128_t> ch(n_rounds ? n_rounds : 1);
         int rc = atlas_sumcheck_proof_verify(R.c.data(), R.stride, R.n.data(), n_rounds, degree, (const atlas_fr_t*)&input_claim, &t, (atlas_fr_t*)e, ch.data());
         if (rc) return rc;
@@ -382,20 +383,28 @@ struct Verifier {
         if (!rc) rc = onehot_checks(nd, 64, R.point, ra_point, advice_claim(nd, gr::VP_ClampRa), gr::CP_ClampRaD, gr::PT_RaOneHotChecks);
         return rc;
     }
-    // verify_scalar_clamp (clamp_lookups/mod.rs): a scalar node's accumulation opens in the clear
+    // recover_small_int (clamp_lookups/mod.rs:78-86)
+    static bool small_int(const H::Fr& x, int64_t* out) {
+        uint64_t c[4], m[4];
+        H::to_canonical(x, c);
+        H::to_canonical(H::neg(x), m);
+        if (!c[1] && !c[2] && !c[3] && c[0] < ((uint64_t)1 << 63)) { *out = (int64_t)c[0]; return true; }
+        if (!m[1] && !m[2] && !m[3] && m[0] < ((uint64_t)1 << 63)) { *out = -(int64_t)m[0]; return true; }
+        return false;
+    }
+    // verify_scalar_clamp (clamp_lookups/mod.rs:365-382): output == SatClamp_i32(the accumulation read in the clear)
+    int scalar_clamp_of(const H::Fr& combined, const H::Fr& output_claim) {
+        int64_t acc;
+        if (!small_int(combined, &acc)) return bad("verify_graph: InvalidOpeningProof (scalar: the accumulation claim is not a small signed integer)");
+        const int64_t cl = acc > INT32_MAX ? INT32_MAX : acc < INT32_MIN ? INT32_MIN : acc;
+        return same(fr_i64(cl), output_claim) ? ATLAS_OK : bad("verify_graph: InvalidOpeningProof (scalar: output must equal SatClamp(input))");
+    }
+    // verify_append_acc + verify_scalar_clamp: a scalar node's accumulation opens in the clear
     int scalar_clamp(const Node& nd) {
         const OpeningId id = gr::node_exec(gr::virt(gr::VP_ClampAcc, nd.idx), nd.idx);
         int rc = append_virtual(id, reduced.at(nd.idx).point);
         if (rc) return rc;
-        uint64_t c[4], m[4];
-        H::to_canonical(claim_of(id), c);
-        H::to_canonical(H::neg(claim_of(id)), m);
-        int64_t acc;
-        if (!c[1] && !c[2] && !c[3] && c[0] < ((uint64_t)1 << 63)) acc = (int64_t)c[0];
-        else if (!m[1] && !m[2] && !m[3] && m[0] <= ((uint64_t)1 << 63)) acc = (int64_t)(0 - m[0]);
-        else return bad("verify_graph: InvalidOpeningProof (a scalar accumulation outside i64)");
-        const int64_t cl = acc > INT32_MAX ? INT32_MAX : acc < INT32_MIN ? INT32_MIN : acc;
-        return same(fr_i64(cl), reduced.at(nd.idx).claim) ? ATLAS_OK : bad("verify_graph: InvalidOpeningProof (scalar clamp)");
+        return scalar_clamp_of(claim_of(id), reduced.at(nd.idx).claim);
     }
     // a dense committed polynomial of this node (VerifierOpeningAccumulator::append_dense)
     int append_dense(const Node& nd, uint8_t cp, const Point& pt) {
@@ -519,16 +528,22 @@ struct Verifier {
     // impl_fused_rescale_proof_api / Einsum::verify: verify_pre, the operator's sumcheck, verify_post (fused_rebase.rs:281-340)
     int op_fused(const Node& nd) {
         const gr::Opening& R = reduced.at(nd.idx);
-        if (R.point.empty()) return fail(ATLAS_EINVAL, "verify_graph: scalar fused-rescale nodes are not composed");
+        const bool scalar = R.point.empty();                                   // is_scalar: verify_append_acc instead of the lookup (fused_rebase.rs:281-293)
+        if (scalar && nd.op == ATLAS_OP_EINSUM) return fail(ATLAS_EINVAL, "verify_graph: an Einsum with a scalar output is not composed");
         const size_t S = nd.op == ATLAS_OP_EINSUM ? (size_t)nd.p[1] : nd.op == ATLAS_OP_CUBE ? 2 * (size_t)nd.p[0] : (size_t)nd.p[0];
         int rc = append_advice(nd, gr::VP_RescaleRemainder, R.point);        // cache_remainder_verify
-        if (!rc) rc = clamp_lookup(nd);
+        if (!rc) rc = scalar ? append_advice(nd, gr::VP_ClampAcc, R.point) : clamp_lookup(nd);
         if (rc) return rc;
         const H::Fr eval_R = advice_claim(nd, gr::VP_RescaleRemainder), acc = advice_claim(nd, gr::VP_ClampAcc);
         const H::Fr in_claim = H::add(H::mul(acc, pow2_fr(S)), eval_R);      // fused_input_claim
         if (nd.op == ATLAS_OP_EINSUM) rc = einsum_verify(nd, in_claim);
         else rc = ew_verify(nd, nd.op == ATLAS_OP_MUL ? 2 : 1, nd.op == ATLAS_OP_CUBE ? 4 : 3, in_claim, gr::PT_RescaleArith, 0);
         if (rc) return rc;
+        if (scalar) {                                                         // verify_post, scalar: remainder in [0, 2^S) and the clamp, in the clear
+            int64_t rv;
+            if (!small_int(eval_R, &rv) || rv < 0 || rv >= ((int64_t)1 << S)) return bad("verify_graph: InvalidOpeningProof (scalar fused rescale: remainder must lie in [0, 2^S))");
+            return scalar_clamp_of(acc, R.claim);
+        }
         Point rr_point;
         rc = identity_rc(nd, S, eval_R, R.point, gr::VP_RescaleRemainderRa, gr::PT_RangeCheck, &rr_point);
         if (!rc) rc = onehot_checks(nd, S, R.point, rr_point, advice_claim(nd, gr::VP_RescaleRemainderRa), gr::CP_RescaleRemainderRaD, gr::PT_RescaleRemainderRaChecks);
@@ -536,11 +551,12 @@ struct Verifier {
     }
     int op_addsub(const Node& nd) {
         const gr::Opening& R = reduced.at(nd.idx);
-        if (R.point.empty()) return fail(ATLAS_EINVAL, "verify_graph: scalar Add / Sub nodes are not composed");
-        int rc = clamp_lookup(nd);
+        const bool scalar = R.point.empty();                                   // is_scalar (ops/add.rs:107-150): no lookup, the operands open in the clear
+        int rc = scalar ? (int)ATLAS_OK : clamp_lookup(nd);
         if (!rc) rc = append_nodeio(nd, 0, R.point);
         if (!rc) rc = append_nodeio(nd, 1, R.point);
         if (rc) return rc;
+        if (scalar) { const H::Fr a = nodeio_claim(nd, 0), b = nodeio_claim(nd, 1); return scalar_clamp_of(nd.op == ATLAS_OP_ADD ? H::add(a, b) : H::sub(a, b), R.claim); }
         const H::Fr l = nodeio_claim(nd, 0), r = nodeio_claim(nd, 1), acc = advice_claim(nd, gr::VP_ClampAcc);
         return same(nd.op == ATLAS_OP_ADD ? H::add(l, r) : H::sub(l, r), acc) ? ATLAS_OK : bad("verify_graph: InvalidOpeningProof (left +- right must equal the accumulation)");
     }

@@ -392,7 +392,10 @@ int prove_fused_rescale(RescaleWitness& W, Inner&& inner, const atlas_fr_t* r_no
     // ---- prove_pre: remainder advice (cache_remainder_prove), the rescaled accumulator's raf claim, clamp lookup
     rc = O.append_virtual(Tr, gr::node_exec(gr::virt(gr::VP_RescaleRemainder, O.node), O.node), r0, eval_R);
     if (!rc) rc = O.append_virtual(Tr, gr::node_exec(gr::virt(gr::VP_ClampAcc, O.node), O.node), r0, acc_claim);      // append_raf_claims_prover
-    if (!rc) rc = prove_clamp_lookup_flow(W.cidx.as<uint64_t>(), log_T, r_node_output, acc_claim, out_claim, t, O, stage_ms ? stage_ms + 1 : nullptr);
+    // (a scalar node — is_scalar, clamp_lookups/mod.rs:67 — has no lookups: prove_append_acc only, fused_rebase.rs:215-231; its verifier reads
+    // the accumulation and the remainder in the clear)
+    const bool scalar = T == 1;
+    if (!rc && !scalar) rc = prove_clamp_lookup_flow(W.cidx.as<uint64_t>(), log_T, r_node_output, acc_claim, out_claim, t, O, stage_ms ? stage_ms + 1 : nullptr);
 
     // ---- the operator's sumcheck over the accumulator
     t0 = now();
@@ -403,6 +406,7 @@ int prove_fused_rescale(RescaleWitness& W, Inner&& inner, const atlas_fr_t* r_no
     }
     if (stage_ms) stage_ms[3] = ms_since(t0);
 
+    if (scalar) return rc;
     // ---- prove_remainder_rc
     t0 = now();
     std::vector<atlas_fr_t> rr_point;

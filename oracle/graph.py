@@ -708,14 +708,18 @@ class Prover:
         eval_R, acc_claim = orc.evaluate(fr(w["rem"]), r0), orc.evaluate(fr(w["quot"]), r0)
         self.append_virtual(node_exec(virt("RescaleRemainder", i), i), r0, eval_R)                     # cache_remainder_prove
         self.append_virtual(node_exec(virt("ClampAcc", i), i), r0, acc_claim)                          # append_raf_claims_prover
+        scalar = len(w["rem"]) == 1                                                                    # is_scalar: prove_append_acc only (fused_rebase.rs:215-231)
         cidx = w["quot"].astype(np.int64).view(np.uint64).copy()
-        self.clamp_lookup(nd, cidx, r0, acc_claim, out_claim)
+        if not scalar:
+            self.clamp_lookup(nd, cidx, r0, acc_claim, out_claim)
         in_claim = orc.fr_add_arr(orc.fr_mul_arr(acc_claim, fr([1 << S])[0]), eval_R)                 # fused_input_claim
         if nd["op"] == "Einsum":
             self.einsum_matmul(nd, in_claim)
         else:
             ew = {"Mul": OR.EW_MUL, "Square": OR.EW_SQUARE, "Cube": OR.EW_CUBE}[nd["op"]]
             self.ew_sumcheck(nd, ew, 2 if nd["op"] == "Mul" else 1, in_claim, "RescaleArith")
+        if scalar:                                                                                     # ops/mod.rs:604: no remainder range check
+            return
         ridx = w["rem"].astype(np.uint64)                                                              # prove_remainder_rc
         phases = 1 if S <= 2 else S // 4 if S % 4 == 0 else S // 2 if S % 2 == 0 else S
         rr_point, rr_claim = self.read_raf(nd, OR.ps_identity(ridx, S, phases, r0), eval_R, ridx, S, "RescaleRemainderRa", "RangeCheck")

@@ -147,6 +147,26 @@ def gather_small_graph(rng, n=8, d=4, v=32):
     ], [4], [rng.integers(0, v, size=n).astype(np.int32)]
 
 
+def scalar_graph(rng):
+    """scalar nodes (one element: `is_scalar`, clamp_lookups/mod.rs:67): no lookups, the accumulation opens in the clear and the verifier
+    recomputes the clamp — Sum down to one element, Add, fused-rescale Mul, Square and Cube of scalars, Sub, then back to a vector"""
+    return [
+        {"idx": 0, "op": "Input", "inputs": [], "dims": [2, 2]},
+        {"idx": 1, "op": "Sum", "inputs": [0], "dims": [2, 1], "axes": [1]},
+        {"idx": 2, "op": "Sum", "inputs": [1], "dims": [1, 1], "axes": [0]},
+        _const(3, rng, [1, 1]),
+        {"idx": 4, "op": "Add", "inputs": [2, 3], "dims": [1, 1]},
+        _const(5, rng, [1, 1]),
+        {"idx": 6, "op": "Mul", "inputs": [4, 5], "dims": [1, 1], "scale": 3},
+        {"idx": 7, "op": "Square", "inputs": [6], "dims": [1, 1], "scale": 4},
+        {"idx": 8, "op": "Cube", "inputs": [6], "dims": [1, 1], "scale": 5},
+        {"idx": 9, "op": "Sub", "inputs": [8, 7], "dims": [1, 1]},
+        {"idx": 10, "op": "Broadcast", "inputs": [9], "dims": [1, 2]},
+        _const(11, rng, [1, 2]),
+        {"idx": 12, "op": "Add", "inputs": [10, 11], "dims": [1, 2]},
+    ], [12], [rng.integers(-100, 100, size=4).astype(np.int32)]
+
+
 def concat_graph(rng):
     """Concat (ops/concat.rs) along the last axis of three operands of unequal size (the smaller ones are repeated over the low variables of the
     largest one's hypercube), an Add over the result, then a second Concat along axis 0 whose output carries the output claim"""
@@ -176,7 +196,7 @@ def toy_transformer(rng):
     return BG.tiny(layers=2)
 
 
-@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6), (concat_graph, 7), (erf_sigmoid_graph, 8), (small_ops_graph, 9), (gather_small_graph, 10)])
+@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6), (concat_graph, 7), (erf_sigmoid_graph, 8), (small_ops_graph, 9), (gather_small_graph, 10), (scalar_graph, 11)])
 def test_graph_proof_matches_oracle(atlas, builder, seed):
     from oracle import graph as OG, orc
     from jolt_atlas_amd import graph as GG
@@ -201,7 +221,7 @@ def test_graph_proof_matches_oracle(atlas, builder, seed):
     G.free(); srs.free()
 
 
-@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6), (concat_graph, 7), (erf_sigmoid_graph, 8), (small_ops_graph, 9), (gather_small_graph, 10)])
+@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6), (concat_graph, 7), (erf_sigmoid_graph, 8), (small_ops_graph, 9), (gather_small_graph, 10), (scalar_graph, 11)])
 def test_graph_proof_is_accepted_by_the_verifier(atlas, builder, seed):
     """ONNXProof::verify (atlas_verify_graph: opening claims from the proof, the node loop's verifier instances, the opening-reduction
     sumcheck, the joint commitment, HyperKZG::verify through the pairing) accepts the device's proof with the prover's final transcript
