@@ -505,6 +505,13 @@ struct Prover : FlowSink {
         const size_t T = gr::padded_len(nd.dims), log_T = gr::log2u(T);
         const gr::Opening& R = red(nd);
         atlas_poly_t ops[2] = {nullptr, nullptr};
+        if (log_T == 0) {                                                     // a scalar: zero rounds, the operand's one value
+            H::Fr v;
+            int rc0 = zero_rounds(R.claim, gr::PT_Execution);
+            if (!rc0) rc0 = scalar_of(G.tensor(nd.inputs[0]), &v);
+            if (!rc0) rc0 = append_nodeio(nd, 0, Point(), v);
+            return rc0;
+        }
         int rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(G.tensor(nd.inputs[0])), T, &ops[0]);
         if (!rc) rc = atlas_eq_evals((const atlas_fr_t*)R.point.data(), log_T, nullptr, &ops[1]);
         atlas_instance_t inst = nullptr;
@@ -674,6 +681,11 @@ struct Prover : FlowSink {
         std::vector<size_t> nv(n_in);
         for (size_t k = 0; k < n_in; k++) { nv[k] = gr::log2u(gr::padded_len(G.nodes.at(nd.inputs[k]).dims)); mx = nv[k] > mx ? nv[k] : mx; }
         const size_t len = (size_t)1 << mx;
+        if (mx == 0) {                                                        // every operand a scalar: zero rounds
+            int rc0 = zero_rounds(R.claim, gr::PT_Execution);
+            for (size_t k = 0; k < n_in && !rc0; k++) { H::Fr v; rc0 = scalar_of(G.tensor(nd.inputs[k]), &v); if (!rc0) rc0 = append_nodeio(nd, k, Point(), v); }
+            return rc0;
+        }
         std::vector<size_t> ostr(r);
         { size_t st = 1; for (int a = (int)r - 1; a >= 0; a--) { ostr[a] = st; st *= nd.dims[a]; } }
         atlas_poly_t eq = nullptr;
@@ -1252,6 +1264,8 @@ struct Prover : FlowSink {
 
     int prove_node(const Node& nd) {
         cur = nd.idx;
+        if (gr::padded_len(nd.dims) == 1 && (nd.op == ATLAS_OP_RELU || nd.op == ATLAS_OP_CLAMP || atlas_rt_is_activation(nd.op)))
+            return fail(ATLAS_EINVAL, "prove_graph: a lookup operator (ReLU / Clamp / Tanh / Erf / Sigmoid) over ONE element is not composed (a read-raf instance without cycle variables)");
         if (nd.op == ATLAS_OP_DIV) return op_div(nd);                          // ReductionFlow::Custom
         if (nd.op == ATLAS_OP_RSQRT) return op_rsqrt(nd);
         int rc = eval_reduction(nd);                                           // ReductionFlow::Default

@@ -7,9 +7,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def random_chain(seed, steps=9, wide=False):
+def random_chain(seed, steps=9, wide=False, sizes=(2, 4, 8)):
     rng = np.random.default_rng(seed)
-    m, n = int(rng.choice([2, 4, 8])), int(rng.choice([2, 4, 8]))
+    m, n = int(rng.choice(sizes)), int(rng.choice(sizes))
     nodes = [{"idx": 0, "op": "Input", "inputs": [], "dims": [m, n]}]
     x_in = rng.integers(-(1 << 11), 1 << 11, size=m * n).astype(np.int32)
     cur, dims = 0, [m, n]
@@ -152,6 +152,37 @@ def test_random_operator_chain(atlas, seed):
     except atlas.AtlasError:
         pass
     G.free(); V.free(); srs.free()
+
+
+def _run(atlas, nodes, outputs, inputs, seed):
+    from oracle import graph as OG, orc
+    from jolt_atlas_amd import graph as GG
+    nv = 4 + max(int(np.log2(max(int(np.prod(nd["dims"])), 1))) for nd in nodes)
+    tau = orc.random_fr(1, 0x51250004)[0]
+    srs = atlas.SRS.generate(tau, 1 << nv)
+    P = OG.Prover(nodes, outputs, orc.srs_powers(tau, 1 << nv))
+    want = P.prove(inputs)
+    G = GG.Graph(nodes, outputs)
+    got, state, _ = G.prove(srs, inputs)
+    for nd in nodes:
+        assert np.array_equal(G.node_output(nd["idx"]), P.trace[nd["idx"]]), f"trace of node {nd['idx']} ({nd['op']}), seed {seed}"
+    assert state == P.t.state() and got == want, [(nd["op"], nd["dims"]) for nd in nodes]
+    vk = atlas.HyperKZG.vk_from_trapdoor(tau, srs.download(0, 1)[0])
+    V = GG.Graph(nodes, outputs)
+    ok, vstate = V.verify(vk, inputs, G.node_output(outputs[0]), got)
+    assert ok and vstate == state, [(nd["op"], nd["dims"]) for nd in nodes]
+    G.free(); V.free(); srs.free()
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_operator_chain_tiny_shapes(atlas, seed):
+    """axes of one and two elements: scalar nodes (no lookups, zero-round sumchecks, clear-text checks in the verifier) between vector ones"""
+    nodes, outputs, inputs = random_chain(9000 + seed, steps=8, sizes=(1, 2))
+    if any(nd["op"] in ("Einsum",) and (int(np.prod(nd["dims"])) == 1 or nd["shape"][1] == 1) for nd in nodes):
+        pytest.skip("a scalar-output / one-element-contraction Einsum is not composed")
+    if any(nd["op"] in ("ReLU", "Clamp") and int(np.prod(nd["dims"])) == 1 for nd in nodes):
+        pytest.skip("a lookup operator over one element is not composed")
+    _run(atlas, nodes, outputs, inputs, seed)
 
 
 @pytest.mark.parametrize("seed", list(range(10)))
