@@ -1264,6 +1264,8 @@ struct Prover : FlowSink {
 
     int prove_node(const Node& nd) {
         cur = nd.idx;
+        if (gr::padded_len(nd.dims) == 1 && (nd.op == ATLAS_OP_RSQRT || nd.op == ATLAS_OP_DIV))
+            return fail(ATLAS_EINVAL, "prove_graph: Rsqrt / Div of ONE element is not composed (its one-coefficient committed quotient would need a zero-round member in the opening reduction)");
         if (gr::padded_len(nd.dims) == 1 && (nd.op == ATLAS_OP_RELU || nd.op == ATLAS_OP_CLAMP || atlas_rt_is_activation(nd.op)))
             return fail(ATLAS_EINVAL, "prove_graph: a lookup operator (ReLU / Clamp / Tanh / Erf / Sigmoid) over ONE element is not composed (a read-raf instance without cycle variables)");
         if (nd.op == ATLAS_OP_DIV) return op_div(nd);                          // ReductionFlow::Custom
