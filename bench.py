@@ -539,6 +539,7 @@ def main():
     # runs the same transcript step; the MSM is split by point range, one partial point per rank.
     if dist is not None and not args.no_shard:
         from jolt_atlas_amd import sharded
+        barrier()                          # rank 0 comes from the node / whole-proof legs: the board's 60 s open patience starts here for everybody
         grp = sharded.ShardGroup("/atlas_bench_%s" % os.environ.get("MASTER_PORT", "0"), world, rank)
         shard_len = (1 << n_vars) // world
         Ls = A.random_fr(shard_len, 0xA71A50000 + n_vars + 104729 * rank)
