@@ -314,6 +314,7 @@ namespace {
 int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs, size_t& next_input) {
     const size_t T = gr::padded_len(nd.dims);
     DevBuf& out = G.out[nd.idx];
+    if (nd.op == ATLAS_OP_CONSTANT && out.p) return ATLAS_OK;                 // uploaded by an earlier trace of this model
     auto in = [&](size_t i) -> const int32_t* { return G.tensor(nd.inputs[i]); };
     auto in_node = [&](size_t i) -> const Node& { return G.nodes.at(nd.inputs[i]); };
     for (size_t i = 0; i < nd.inputs.size(); i++) if (!in(i)) return fail(ATLAS_ESTATE, "graph_trace: operand not executed yet (nodes must be in topological index order)");
@@ -583,7 +584,7 @@ int atlas_graph_trace(atlas_graph_t G, const int32_t* const* inputs, size_t n_in
     if (!G || (!inputs && n_inputs)) return fail(ATLAS_EINVAL, "graph_trace: null argument");
     if (n_inputs != G->input_nodes().size()) return fail(ATLAS_EINVAL, "graph_trace: one tensor per Input node expected");
     for (size_t i = 0; i < n_inputs; i++) if (!inputs[i]) return fail(ATLAS_EINVAL, "graph_trace: null input tensor");
-    G->clear_trace();
+    G->clear_trace_keep_constants();
     size_t next = 0;
     for (auto& kv : G->nodes) {
         int rc = exec_node(*G, kv.second, inputs, next);

@@ -41,6 +41,11 @@ struct atlas_graph {
     std::vector<size_t> input_nodes() const { std::vector<size_t> v; for (auto& kv : nodes) if (kv.second.op == ATLAS_OP_INPUT) v.push_back(kv.first); return v; }
     const int32_t* tensor(size_t idx) const { auto it = out.find(idx); return it == out.end() ? nullptr : it->second.as<int32_t>(); }
     void clear_trace() { out.clear(); wit.clear(); traced = false; }
+    // a new trace of the same model: the Constant nodes' tensors (the weights) stay in HBM, everything derived from the inputs goes
+    void clear_trace_keep_constants() {
+        for (auto it = out.begin(); it != out.end();) { auto nd = nodes.find(it->first); if (nd != nodes.end() && nd->second.op == ATLAS_OP_CONSTANT) ++it; else it = out.erase(it); }
+        wit.clear(); traced = false;
+    }
 };
 
 // the small activation tables of Tanh / Erf / Sigmoid (ops/tanh.rs:22-32, erf.rs:22-32, sigmoid.rs:22-32 -> neural_teleport/utils.rs:67-85):
