@@ -769,7 +769,7 @@ enum { ATLAS_OP_INPUT = 0, ATLAS_OP_CONSTANT, ATLAS_OP_IDENTITY, ATLAS_OP_ADD, A
        ATLAS_OP_AND, ATLAS_OP_IFF, ATLAS_OP_RELU, ATLAS_OP_EINSUM, ATLAS_OP_RESHAPE, ATLAS_OP_MOVEAXIS, ATLAS_OP_BROADCAST, ATLAS_OP_SLICE,
        ATLAS_OP_CONCAT, ATLAS_OP_SUM, ATLAS_OP_SCALAR_CONST_DIV, ATLAS_OP_DIV, ATLAS_OP_MEAN_OF_SQUARES, ATLAS_OP_RSQRT, ATLAS_OP_SOFTMAX,
        ATLAS_OP_TANH, ATLAS_OP_GATHER_LARGE, ATLAS_OP_GATHER_SMALL, ATLAS_OP_ERF, ATLAS_OP_SIGMOID,
-       ATLAS_OP_NEG, ATLAS_OP_IS_NAN, ATLAS_OP_CLAMP };
+       ATLAS_OP_NEG, ATLAS_OP_IS_NAN, ATLAS_OP_CLAMP, ATLAS_OP_SIN, ATLAS_OP_COS };
 typedef struct atlas_graph *atlas_graph_t;
 int atlas_graph_new(atlas_graph_t *out);
 int atlas_graph_free(atlas_graph_t g);

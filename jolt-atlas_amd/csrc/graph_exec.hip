@@ -136,6 +136,22 @@ __global__ __launch_bounds__(256) void k_tanh(const int32_t* __restrict__ x, siz
         clamped[i] = c; idx_small[i] = k; idx_clamp[i] = (uint64_t)(uint32_t)v; out[i] = table[k];
     }
 }
+// Sin / Cos (eval_trig, atlas-onnx-tracer/src/ops/mod.rs:317-336; compute_division, neural_teleport/division.rs:48-66): Euclidean quotient and
+// remainder by the period modulus, the remainder shifted down, the table (already rescaled by 2^DOWNSCALE_BITS)
+__global__ __launch_bounds__(256) void k_trig(const int32_t* __restrict__ x, size_t n, int32_t tau, uint32_t shift, const int32_t* __restrict__ table, int32_t* __restrict__ out,
+                                              int32_t* __restrict__ quot, int32_t* __restrict__ rem, int32_t* __restrict__ down, uint64_t* __restrict__ idx_rem,
+                                              uint64_t* __restrict__ idx_down) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int32_t v = x[i];
+        int32_t r = v % tau, q = v / tau;
+        if (r < 0) { r += tau; q -= 1; }
+        const int32_t d = r >> shift;
+        quot[i] = q; rem[i] = r; down[i] = d; idx_rem[i] = (uint64_t)(uint32_t)r; idx_down[i] = (uint64_t)(uint32_t)d; out[i] = table[d];
+    }
+}
+__global__ __launch_bounds__(256) void k_fill_i32(int32_t* p, size_t n, int32_t v) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
+}
 // Gather along axis 0 (ops/gather.rs): out[j][w] = dict[idx[j]][w]
 __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__ dict, const int32_t* __restrict__ idx, size_t n_idx, size_t word, int32_t* __restrict__ out,
                                                      uint64_t* __restrict__ lookups) {
@@ -252,6 +268,32 @@ static double atlas_erf_cheb(double x) {
         return t * std::exp(-(z * z) + 0.5 * (COF[0] + ty * d) - dd);
     };
     return x >= 0.0 ? 1.0 - erfccheb(x) : erfccheb(-x) - 1.0;
+}
+int atlas_rt_trig_table(int op, const int32_t** d_table, const std::vector<int32_t>** h_table) {
+    static std::vector<int32_t> host[2];
+    static int32_t* dev[2] = {nullptr, nullptr};
+    const int k = op == ATLAS_OP_SIN ? 0 : op == ATLAS_OP_COS ? 1 : -1;
+    if (k < 0) return fail(ATLAS_EINVAL, "trig_table: not Sin / Cos");
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    if (host[k].empty()) {                                                    // SinTable / CosTable::materialize (neural_teleport/sin.rs:26-41)
+        const size_t n = (size_t)1 << gr::TRIG_TABLE_VARS;
+        const double scale = (double)((uint64_t)1 << (gr::MODEL_SCALE - gr::TRIG_DOWNSCALE_BITS));
+        host[k].resize(n);
+        for (size_t i = 0; i < n; i++) {
+            const double xx = (double)(int32_t)i / scale;
+            host[k][i] = (int32_t)std::round(scale * (k == 0 ? std::sin(xx) : std::cos(xx))) * (int32_t)(1 << gr::TRIG_DOWNSCALE_BITS);
+        }
+    }
+    if (d_table && !dev[k]) {
+        HIP_TRY(hipMalloc(&dev[k], host[k].size() * 4));
+        HIP_TRY(hipMemcpyAsync(dev[k], host[k].data(), host[k].size() * 4, hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        static bool registered = false;
+        if (!registered) { registered = true; g.at_shutdown.push_back([] { for (auto& d : dev) if (d) { (void)hipFree(d); d = nullptr; } registered = false; }); }
+    }
+    if (d_table) *d_table = dev[k];
+    if (h_table) *h_table = &host[k];
+    return ATLAS_OK;
 }
 int atlas_rt_activation_table(int op, const int32_t** d_table, const std::vector<int32_t>** h_table) {
     static std::vector<int32_t> host[3];
@@ -499,6 +541,21 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
             NodeWitness& W = G.wit[nd.idx];
             HIP_TRY(W.clamped.alloc(T * 4)); HIP_TRY(W.lookups.alloc(T * 8)); HIP_TRY(W.lookups2.alloc(T * 8));
             k_tanh<<<grid_for(T), 256, 0, g.stream>>>(in(0), T, (uint32_t)gr::ACTIVATION_BOUND, d_table, out.as<int32_t>(), W.clamped.as<int32_t>(), W.lookups2.as<uint64_t>(), W.lookups.as<uint64_t>());
+            return ATLAS_OK;
+        }
+        case ATLAS_OP_SIN: case ATLAS_OP_COS: {
+            if (!need_inputs(1) || !same_len() || nd.p[0] != (int64_t)gr::MODEL_SCALE) return fail(ATLAS_EINVAL, "graph: Sin / Cos need one operand and scale = MODEL_SCALE (14): the period modulus and the table are compiled for it");
+            const int32_t* d_table = nullptr;
+            if (int rc = atlas_rt_trig_table(nd.op, &d_table, nullptr)) return rc;
+            NodeWitness& W = G.wit[nd.idx];
+            // rem = the teleportation remainder, rem2 = the quotient, clamped = the downscaled remainder; lookups = the remainder (the right-shift
+            // lookup), lookups2 = the table index, cidx = interleave(remainder, tau) (the range check)
+            HIP_TRY(W.rem.alloc(T * 4)); HIP_TRY(W.rem2.alloc(T * 4)); HIP_TRY(W.clamped.alloc(T * 4)); HIP_TRY(W.bound.alloc(T * 4));
+            HIP_TRY(W.lookups.alloc(T * 8)); HIP_TRY(W.lookups2.alloc(T * 8));
+            k_trig<<<grid_for(T), 256, 0, g.stream>>>(in(0), T, (int32_t)gr::TRIG_PERIOD_MODULUS, (uint32_t)gr::TRIG_DOWNSCALE_BITS, d_table, out.as<int32_t>(), W.rem2.as<int32_t>(),
+                                                      W.rem.as<int32_t>(), W.clamped.as<int32_t>(), W.lookups.as<uint64_t>(), W.lookups2.as<uint64_t>());
+            k_fill_i32<<<grid_for(T), 256, 0, g.stream>>>(W.bound.as<int32_t>(), T, (int32_t)gr::TRIG_PERIOD_MODULUS);
+            { uint64_t* lk2 = nullptr; int rc = atlas_lookup_indices_from_operands(W.rem.as<int32_t>(), W.bound.as<int32_t>(), T, &lk2); if (rc) return rc; W.cidx.p = lk2; }
             return ATLAS_OK;
         }
         case ATLAS_OP_GATHER_LARGE: case ATLAS_OP_GATHER_SMALL: {             // inputs (dictionary [V][D...], indexes [N]); output [N][D...]

@@ -221,6 +221,12 @@ struct Prover : FlowSink {
                     chunks(gr::CP_SoftmaxZLoRaD, Sm.idx_zlo.as<uint64_t>(), Sm.lk_lo);
                     break;
                 }
+                case ATLAS_OP_SIN: case ATLAS_OP_COS:                                                                    // ops/sin.rs:169-186
+                    dense(gr::CP_TeleportNodeQuotient, W.rem2.p, true);
+                    chunks(gr::CP_TrigDownscaleRaD, W.lookups.as<uint64_t>(), 32);
+                    chunks(nd.op == ATLAS_OP_SIN ? gr::CP_SinRaD : gr::CP_CosRaD, W.lookups2.as<uint64_t>(), gr::TRIG_TABLE_VARS);
+                    chunks(gr::CP_TeleportRangeCheckRaD, W.cidx.as<uint64_t>(), 64);
+                    break;
                 case ATLAS_OP_GATHER_SMALL: {                                                                            // ops/gather/small.rs:119-121: ONE one-hot polynomial, dict_len addresses
                     gr::Committed c; c.id = gr::comm(gr::CP_GatherRa, nd.idx); c.kind = 1; c.d_lookups = W.lookups.as<uint64_t>();
                     c.log_T = gr::log2u(gr::padded_len(G.nodes.at(nd.inputs[1]).dims)); c.log_K = gr::log2u(G.nodes.at(nd.inputs[0]).dims[0]); c.chunk = 0; c.lkc = c.log_K;
@@ -1262,6 +1268,115 @@ struct Prover : FlowSink {
         return rc;
     }
 
+    // Sin / Cos by neural teleportation (ops/sin.rs:56-186, cos.rs; ReductionFlow::Custom): the Euclidean division by the period modulus at a
+    // FRESH point (NeuralTeleport), the downscaling right-shift lookup batched with the table read-raf (Execution), the downscale lookup's
+    // one-hot checks (TrigDownscaleRaChecks), the committed quotient, the node's eval reduction, then prove_range_and_onehot
+    // (neural_teleport/range_and_onehot.rs:68-140): the remainder's range check batched with the table lookup's one-hot checks
+    // (RaOneHotChecks), and the range check's own one-hot checks (RaHammingWeight)
+    int op_trig(const Node& nd) {
+        const size_t T = gr::padded_len(nd.dims), log_T = gr::log2u(T), LK = gr::TRIG_TABLE_VARS, K = (size_t)1 << LK;
+        if (log_T == 0) return fail(ATLAS_EINVAL, "prove_graph: Sin / Cos of ONE element is not composed");
+        NodeWitness& W = G.wit[nd.idx];
+        const uint8_t vp_ra = nd.op == ATLAS_OP_SIN ? gr::VP_SinRa : gr::VP_CosRa, cp_rad = nd.op == ATLAS_OP_SIN ? gr::CP_SinRaD : gr::CP_CosRaD;
+        const H::Fr tau = fr_from_i64_host(gr::TRIG_PERIOD_MODULUS);
+        Out O = out();
+        // ---- 1a: TeleportDivisionProver at a point from the transcript
+        const Point r = challenge_point(log_T);
+        atlas_poly_t dops[3] = {nullptr, nullptr, nullptr};
+        int rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(G.tensor(nd.inputs[0])), T, &dops[0]);
+        if (!rc) rc = atlas_poly_wrap_device_i32(W.rem2.as<int32_t>(), T, &dops[1]);
+        if (!rc) rc = atlas_poly_wrap_device_i32(W.rem.as<int32_t>(), T, &dops[2]);
+        atlas_instance_t i_div = nullptr;
+        if (!rc) rc = atlas_elementwise_new(ATLAS_EW_TELEPORT_DIV, dops, 3, (const atlas_fr_t*)r.data(), log_T, (const atlas_fr_t*)&tau, 1, &i_div);
+        for (atlas_poly_t p : dops) if (p) atlas_poly_free(p);
+        std::vector<H::Fr> rs, fin;
+        if (!rc) rc = run_single(i_div, H::zero(), gr::PT_NeuralTeleport, rs, fin);
+        if (i_div) atlas_instance_free(i_div);
+        if (rc) return rc;
+        const Point pt = reversed(rs);
+        rc = append_nodeio(nd, 0, pt, fin[0]);
+        if (!rc) rc = append_advice(nd, gr::VP_TeleportQuotient, pt, fin[1]);
+        if (!rc) rc = append_advice(nd, gr::VP_TeleportRemainder, pt, fin[2]);
+        if (rc) return rc;
+        const H::Fr q_claim = fin[1], rem_claim = fin[2];
+        // ---- 1b: cache_downscaled_prove, the right-shift read-raf (witness = the remainder, appended again as its raf claim), the table read-raf
+        H::Fr ev[2];
+        { const int32_t* tp[2] = {W.clamped.as<int32_t>(), G.tensor(nd.idx)}; rc = eval_i32(tp, 2, T, pt, ev); }
+        const H::Fr down_claim = ev[0], out_claim = ev[1];
+        if (!rc) rc = append_advice(nd, gr::VP_TrigDownscaled, pt, down_claim);
+        if (!rc) rc = append_advice(nd, gr::VP_TeleportRemainder, pt, rem_claim);                              // append_raf_claims_prover
+        if (rc) return rc;
+        const H::Fr g_d = H::tr_challenge_scalar(Tr);
+        atlas_instance_t i_dsc = nullptr, i_tab = nullptr;
+        rc = atlas_ps_shout_rshift_new(W.lookups.as<uint64_t>(), log_T, 32, gr::TRIG_DOWNSCALE_BITS, (const atlas_fr_t*)pt.data(), (const atlas_fr_t*)&g_d, &i_dsc);
+        const H::Fr g_s = H::tr_challenge_scalar(Tr);                                                           // SinParams::new
+        if (!rc) rc = O.append_virtual(Tr, gr::node_exec(gr::virt(gr::VP_NodeOutput, nd.idx), nd.idx), pt, out_claim);     // SinProver::initialize: Target::Current
+        {
+            atlas_poly_t eq = nullptr, tops[3] = {nullptr, nullptr, nullptr};
+            if (!rc) rc = atlas_eq_evals((const atlas_fr_t*)pt.data(), log_T, nullptr, &eq);
+            if (!rc) rc = atlas_shout_read_raf_G(W.lookups2.as<uint64_t>(), T, LK, eq, &tops[0]);               // compute_ra_evals_direct
+            if (eq) atlas_poly_free(eq);
+            const int32_t* d_table = nullptr;
+            if (!rc) rc = atlas_rt_trig_table(nd.op, &d_table, nullptr);
+            if (!rc) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(d_table), K, &tops[1]);
+            std::vector<int32_t> ident(K);
+            for (size_t i = 0; i < K; i++) ident[i] = (int32_t)i;
+            if (!rc) rc = atlas_poly_upload_i32(ident.data(), K, &tops[2]);
+            if (!rc) rc = atlas_elementwise_new(ATLAS_EW_GATHER, tops, 3, nullptr, LK, (const atlas_fr_t*)&g_s, 1, &i_tab);
+            for (atlas_poly_t p : tops) if (p) atlas_poly_free(p);
+        }
+        std::vector<atlas_fr_t> Dra_point, tab_point;
+        H::Fr Dra_claim, tab_claim;
+        {
+            atlas_batched_t b = nullptr;
+            const H::Fr c_dsc = H::add(down_claim, H::mul(g_d, rem_claim)), c_tab = H::add(out_claim, H::mul(g_s, down_claim));
+            if (!rc) rc = atlas_batched_new(&b);
+            if (!rc) rc = atlas_batched_add_instance(b, i_dsc, (const atlas_fr_t*)&c_dsc);
+            if (!rc) rc = atlas_batched_add_instance(b, i_tab, (const atlas_fr_t*)&c_tab);
+            if (!rc) rc = run_batch(b, 8, 32 + log_T, gr::PT_Execution, rs);
+            if (!rc) rc = ra_opening(nd, i_dsc, gr::VP_TrigDownscaleRa, 32, log_T, rs, Dra_point, Dra_claim);
+            if (!rc) {
+                atlas_fr_t f[64]; size_t nf = 0;
+                rc = atlas_instance_final_claims(i_tab, f, 64, &nf);
+                std::memcpy(&tab_claim, &f[0], 32);
+                Point tp(rs.rbegin(), rs.rbegin() + LK);                                                        // the last LK challenges, reversed
+                tp.insert(tp.end(), pt.begin(), pt.end());
+                tab_point.resize(tp.size()); std::memcpy(tab_point.data(), tp.data(), tp.size() * 32);
+                if (!rc) rc = append_advice(nd, vp_ra, tp, tab_claim);
+            }
+            if (b) atlas_batched_free(b);
+        }
+        for (atlas_instance_t i : {i_dsc, i_tab}) if (i) atlas_instance_free(i);
+        // ---- 1c: the downscale lookup's one-hot checks
+        if (!rc) rc = prove_onehot_checks(W.lookups.as<uint64_t>(), log_T, 32, (const atlas_fr_t*)pt.data(), Dra_point, Dra_claim, &t, O, gr::CP_TrigDownscaleRaD, gr::PT_TrigDownscaleRaChecks);
+        // ---- the committed quotient at the quotient's point, the eval reduction
+        if (!rc) rc = append_dense(nd, gr::CP_TeleportNodeQuotient, pt, q_claim);
+        if (!rc) rc = eval_reduction(nd);
+        if (rc) return rc;
+        // ---- prove_range_and_onehot
+        std::vector<atlas_fr_t> Rra_point; H::Fr Rra_claim;
+        {
+            atlas_instance_t rc_i = nullptr; H::Fr cl;
+            atlas_batched_t b = nullptr;
+            std::vector<atlas_instance_t> oh;
+            std::vector<OneHotFamily> fams(1);
+            rc = range_check_new(W.cidx.as<uint64_t>(), log_T, pt, rem_claim, tau, &rc_i, &cl);
+            if (!rc) rc = atlas_batched_new(&b);
+            if (!rc) rc = atlas_batched_add_instance(b, rc_i, (const atlas_fr_t*)&cl);
+            fams[0].d_lookups = W.lookups2.as<uint64_t>(); fams[0].log_K = LK; fams[0].r_cycle = (const atlas_fr_t*)pt.data();
+            fams[0].ra_point = tab_point; fams[0].ra_claim = tab_claim; fams[0].rad_cp = cp_rad;
+            if (!rc) rc = onehot_families_build(fams, log_T, &t, b, oh, nullptr);
+            if (!rc) rc = run_batch(b, 8, 64 + log_T, gr::PT_RaOneHotChecks, rs);
+            if (!rc) rc = ra_opening(nd, rc_i, gr::VP_TeleportRangeCheckRa, 64, log_T, rs, Rra_point, Rra_claim);
+            if (!rc) rc = onehot_families_cache(fams, oh.data(), log_T, rs, &t, O);
+            if (b) atlas_batched_free(b);
+            if (rc_i) atlas_instance_free(rc_i);
+            for (atlas_instance_t i : oh) if (i) atlas_instance_free(i);
+        }
+        if (!rc) rc = prove_onehot_checks(W.cidx.as<uint64_t>(), log_T, 64, (const atlas_fr_t*)pt.data(), Rra_point, Rra_claim, &t, O, gr::CP_TeleportRangeCheckRaD, gr::PT_RaHammingWeight);
+        return rc;
+    }
+
     int prove_node(const Node& nd) {
         cur = nd.idx;
         if (gr::padded_len(nd.dims) == 1 && (nd.op == ATLAS_OP_RSQRT || nd.op == ATLAS_OP_DIV))
@@ -1270,6 +1385,7 @@ struct Prover : FlowSink {
             return fail(ATLAS_EINVAL, "prove_graph: a lookup operator (ReLU / Clamp / Tanh / Erf / Sigmoid) over ONE element is not composed (a read-raf instance without cycle variables)");
         if (nd.op == ATLAS_OP_DIV) return op_div(nd);                          // ReductionFlow::Custom
         if (nd.op == ATLAS_OP_RSQRT) return op_rsqrt(nd);
+        if (nd.op == ATLAS_OP_SIN || nd.op == ATLAS_OP_COS) return op_trig(nd);
         int rc = eval_reduction(nd);                                           // ReductionFlow::Default
         if (rc) return rc;
         const gr::Opening& R = red(nd);

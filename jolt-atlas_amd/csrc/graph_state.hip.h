@@ -52,6 +52,11 @@ struct atlas_graph {
 // Table[i] = round(2^14 f(signed18(i) / 2^14)), built once on the host (the reference's f64 arithmetic) and kept in HBM; graph_exec.hip.
 // op = ATLAS_OP_TANH / ATLAS_OP_ERF / ATLAS_OP_SIGMOID
 int atlas_rt_activation_table(int op, const int32_t** d_table, const std::vector<int32_t>** h_table);
+// Sin / Cos by neural teleportation (common/src/consts/trig.rs, neural_teleport/{sin,cos}.rs): the period modulus round(k 2 pi 2^14) for the
+// smallest k within the tolerance (k = 24: 2470649, 22 bits), remainders shifted down by 6 bits into a 2^16-entry table
+// Table[i] = round(2^8 f(i / 2^8)) * 2^6
+namespace gr { constexpr int64_t TRIG_PERIOD_MODULUS = 2470649; constexpr size_t TRIG_DOWNSCALE_BITS = 6, TRIG_TABLE_VARS = 16; }
+int atlas_rt_trig_table(int op, const int32_t** d_table, const std::vector<int32_t>** h_table);
 inline bool atlas_rt_is_activation(int op) { return op == ATLAS_OP_TANH || op == ATLAS_OP_ERF || op == ATLAS_OP_SIGMOID; }
 // the decomposed exp sub-tables of SoftmaxLastAxis at MODEL_SCALE (generate_exp_lut_decomposed, atlas-onnx-tracer/src/ops/softmax.rs:239-269;
 // lut_hi zero-padded to a power of two, :94-96), built once on the host in the reference's f64 arithmetic; graph_exec.hip

@@ -6,7 +6,7 @@
 // Host arithmetic, like the reference's verifier; the device only evaluates the PUBLIC tensors (inputs, constants, output) at the
 // verifier's points and adds up the joint commitment.  Nothing of the prover's trace is read.
 // Every operator the graph prover composes has its verifier composition here: Input, Constant, Identity, Add, Sub, Mul, Square, Cube, Einsum,
-// And, Iff, ReLU, Clamp, Neg, IsNan, Reshape, MoveAxis, Broadcast, Sum, ScalarConstDiv, Slice, Concat, Div, MeanOfSquares, Rsqrt, Tanh, Erf, Sigmoid, GatherLarge, GatherSmall, SoftmaxLastAxis.
+// And, Iff, ReLU, Clamp, Neg, IsNan, Reshape, MoveAxis, Broadcast, Sum, ScalarConstDiv, Slice, Concat, Div, MeanOfSquares, Rsqrt, Tanh, Erf, Sigmoid, Sin, Cos, GatherLarge, GatherSmall, SoftmaxLastAxis.
 // A verifier instance is a VInst (input claim, rounds, degree, and a closure = cache_openings + expected_output_claim); `run_single` is
 // Sumcheck::verify, `batch` is BatchedSumcheck::verify (an instance of n rounds sees the LAST n challenges, sumcheck.rs:150-170).
 #include <hip/hip_runtime.h>
@@ -76,6 +76,12 @@ H::Fr clamp_mle(const H::Fr* r, size_t xlen, size_t bound, bool symmetric) {
     return H::add(H::add(H::sub(cu, H::mul(msb, lc)), H::mul(haz, H::sub(lw, cu))), H::mul(hao, lw));
 }
 
+// RightShiftTable<XLEN>::evaluate_mle by D bits (lookup_tables/right_shift.rs): bit i (MSB first) weighs 2^(XLEN - 1 - i - D) while it stays above the cut
+H::Fr rshift_mle(const H::Fr* r, size_t xlen, size_t D) {
+    H::Fr y = H::zero();
+    for (size_t i = 0; i + D < xlen; i++) y = H::add(y, H::mul(r[i], pow2_fr(xlen - 1 - i - D)));
+    return y;
+}
 H::Fr fr_i64(int64_t v) { return v >= 0 ? H::from_u64((uint64_t)v) : H::neg(H::from_u64((uint64_t)(-v))); }
 // UnsignedLessThanTable<XLEN>::evaluate_mle over interleaved operands (unsigned_less_than.rs:26-43)
 H::Fr ult_mle(const H::Fr* r, size_t xlen) {
@@ -227,7 +233,7 @@ struct Verifier {
     }
 
     // ---- a unary prefix-suffix lookup: read_raf_verify (op_lookups/mod.rs:270-283) + its verifier instance (ps_shout/mod.rs:612-643)
-    enum Table { T_RELU, T_CLAMP_SYM, T_CLAMP };
+    enum Table { T_RELU, T_CLAMP_SYM, T_CLAMP, T_RSHIFT };
     int inst_ps_unary(const Node& nd, Table tab, size_t xlen, size_t bound, const OpeningId& witness_id, const H::Fr& rv_claim, const Point& r_cycle, uint8_t ra_vp, Point* ra_point, VInst* out) {
         int rc = append_virtual(witness_id, r_cycle);                        // append_raf_claims_verifier
         if (rc) return rc;
@@ -239,7 +245,7 @@ struct Verifier {
             const Point pt = ra_point_of(ch, xlen, log_T);
             int rc2 = append_advice(*np, ra_vp, pt);                         // cache_openings
             if (rc2) return rc2;
-            const H::Fr val = tab == T_RELU ? relu_mle(pt.data(), xlen) : clamp_mle(pt.data(), xlen, bound, tab == T_CLAMP_SYM);
+            const H::Fr val = tab == T_RELU ? relu_mle(pt.data(), xlen) : tab == T_RSHIFT ? rshift_mle(pt.data(), xlen, bound) : clamp_mle(pt.data(), xlen, bound, tab == T_CLAMP_SYM);
             *expect = H::mul(H::mul(eq_mle(r_cycle.data(), pt.data() + xlen, log_T), advice_claim(*np, ra_vp)), H::add(val, H::mul(gamma, signed_identity_mle(pt.data(), xlen))));
             *ra_point = pt;
             return (int)ATLAS_OK;
@@ -833,6 +839,81 @@ struct Verifier {
         onehot_insts(nd, 32, R.point, clamp_pt, advice_claim(nd, gr::VP_ActivationClampRa), gr::CP_ActivationClampRaD, O);
         return batch(gr::PT_RaOneHotChecks, O);
     }
+    // Sin / Cos (ops/sin.rs:188-285 verify + verify_with_reduction; neural_teleport/division.rs, trig_downscale.rs, range_and_onehot.rs:142-181)
+    int op_trig(const Node& nd) {
+        const size_t log_T = gr::log2u(gr::padded_len(nd.dims)), LK = gr::TRIG_TABLE_VARS;
+        const uint8_t vp_ra = nd.op == ATLAS_OP_SIN ? gr::VP_SinRa : gr::VP_CosRa, cp_rad = nd.op == ATLAS_OP_SIN ? gr::CP_SinRaD : gr::CP_CosRaD;
+        const H::Fr tau = fr_i64(gr::TRIG_PERIOD_MODULUS);
+        const Node* np = &nd;
+        // 1a: TeleportDivisionVerifier::new_from_transcript
+        const Point r = challenge_point(log_T);
+        Point pt_out; Point* ptp = &pt_out;
+        VInst D;
+        D.claim = H::zero(); D.rounds = log_T; D.degree = 2;
+        D.finish = [=](const H::Fr* ch, H::Fr* expect) {
+            Point pt(log_T);
+            for (size_t q = 0; q < log_T; q++) pt[q] = ch[log_T - 1 - q];
+            int rc2 = append_nodeio(*np, 0, pt);
+            if (!rc2) rc2 = append_advice(*np, gr::VP_TeleportQuotient, pt);
+            if (!rc2) rc2 = append_advice(*np, gr::VP_TeleportRemainder, pt);
+            if (rc2) return rc2;
+            *expect = H::mul(eq_mle(r.data(), pt.data(), log_T), H::sub(H::add(H::mul(tau, advice_claim(*np, gr::VP_TeleportQuotient)), advice_claim(*np, gr::VP_TeleportRemainder)), nodeio_claim(*np, 0)));
+            *ptp = pt;
+            return (int)ATLAS_OK;
+        };
+        int rc = run_single(gr::PT_NeuralTeleport, D, "verify_graph: SumcheckVerificationError (teleport division)");
+        if (rc) return rc;
+        const Point pt = pt_out;
+        // 1b: cache_downscaled_verify, the right-shift read-raf (its witness claim = the remainder, appended again), the table read-raf
+        rc = append_advice(nd, gr::VP_TrigDownscaled, pt);
+        if (rc) return rc;
+        const H::Fr down = advice_claim(nd, gr::VP_TrigDownscaled);
+        Point Dra, tab_pt; Point* tpp = &tab_pt;
+        std::vector<VInst> B(1);
+        rc = inst_ps_unary(nd, T_RSHIFT, 32, gr::TRIG_DOWNSCALE_BITS, gr::node_exec(gr::virt(gr::VP_TeleportRemainder, nd.idx), nd.idx), down, pt, gr::VP_TrigDownscaleRa, &Dra, &B[0]);
+        if (rc) return rc;
+        const H::Fr g_s = H::tr_challenge_scalar(Tr);                        // SinParams::new
+        rc = append_current(nd, pt);                                         // SinVerifier::new: Target::Current
+        if (rc) return rc;
+        const std::vector<int32_t>* table = nullptr;
+        rc = atlas_rt_trig_table(nd.op, nullptr, &table);
+        if (rc) return rc;
+        VInst S;
+        S.claim = H::add(current_claim(nd), H::mul(g_s, down)); S.rounds = LK; S.degree = 2;
+        S.finish = [=](const H::Fr* ch, H::Fr* expect) {
+            Point ra(LK);
+            for (size_t q = 0; q < LK; q++) ra[q] = ch[LK - 1 - q];
+            Point p = ra;
+            p.insert(p.end(), pt.begin(), pt.end());
+            int rc2 = append_advice(*np, vp_ra, p);
+            if (rc2) return rc2;
+            H::Fr tv;
+            rc2 = eval_public(table->data(), table->size(), ra, &tv);
+            if (rc2) return rc2;
+            *expect = H::mul(advice_claim(*np, vp_ra), H::add(tv, H::mul(g_s, identity_mle(ra.data(), LK))));
+            *tpp = p;
+            return (int)ATLAS_OK;
+        };
+        B.push_back(std::move(S));
+        rc = batch(gr::PT_Execution, B);
+        // 1c: the downscale lookup's one-hot checks
+        if (!rc) rc = onehot_checks(nd, 32, pt, Dra, advice_claim(nd, gr::VP_TrigDownscaleRa), gr::CP_TrigDownscaleRaD, gr::PT_TrigDownscaleRaChecks);
+        if (rc) return rc;
+        // verify_with_reduction: the committed quotient at the quotient's point, equal claims; the eval reduction
+        rc = append_dense(nd, gr::CP_TeleportNodeQuotient, pt);
+        if (rc) return rc;
+        if (!same(dense_claim(nd, gr::CP_TeleportNodeQuotient), advice_claim(nd, gr::VP_TeleportQuotient))) return bad("verify_graph: InvalidOpeningProof (teleport quotient claim does not match the committed quotient claim)");
+        rc = eval_reduction(nd);
+        if (rc) return rc;
+        // verify_range_and_onehot: [range check R < tau, the table lookup's one-hot triple], then the range check's own triple
+        Point Rra;
+        std::vector<VInst> C;
+        C.push_back(inst_range_check(nd, pt, advice_claim(nd, gr::VP_TeleportRemainder), tau, gr::VP_TeleportRangeCheckRa, &Rra));
+        onehot_insts(nd, LK, pt, tab_pt, advice_claim(nd, vp_ra), cp_rad, C);
+        rc = batch(gr::PT_RaOneHotChecks, C);
+        if (!rc) rc = onehot_checks(nd, 64, pt, Rra, advice_claim(nd, gr::VP_TeleportRangeCheckRa), gr::CP_TeleportRangeCheckRaD, gr::PT_RaHammingWeight);
+        return rc;
+    }
     // GatherLarge (ops/gather/mod.rs + large.rs): sum_k ra(k) (dict_r(k) + gamma k), then the one-hot checks over the index cycle
     int op_gather(const Node& nd) {
         const gr::Opening& R = reduced.at(nd.idx);
@@ -1040,6 +1121,7 @@ struct Verifier {
         cur = nd.idx;
         if (nd.op == ATLAS_OP_DIV) return op_div(nd);                          // ReductionFlow::Custom
         if (nd.op == ATLAS_OP_RSQRT) return op_rsqrt(nd);
+        if (nd.op == ATLAS_OP_SIN || nd.op == ATLAS_OP_COS) return op_trig(nd);
         int rc = eval_reduction(nd);
         if (rc) return rc;
         const gr::Opening& R = reduced.at(nd.idx);
@@ -1118,6 +1200,10 @@ struct Verifier {
                     chunks(gr::CP_SoftmaxZHiRaD, gr::log2u(L->hi.size())); chunks(gr::CP_SoftmaxZLoRaD, gr::log2u(L->lo.size()));
                     break;
                 }
+                case ATLAS_OP_SIN: case ATLAS_OP_COS:
+                    dense(gr::CP_TeleportNodeQuotient); chunks(gr::CP_TrigDownscaleRaD, 32); chunks(nd.op == ATLAS_OP_SIN ? gr::CP_SinRaD : gr::CP_CosRaD, gr::TRIG_TABLE_VARS);
+                    chunks(gr::CP_TeleportRangeCheckRaD, 64);
+                    break;
                 case ATLAS_OP_GATHER_SMALL: committed[gr::comm(gr::CP_GatherRa, nd.idx)].log_T = gr::log2u(gr::padded_len(G.nodes.at(nd.inputs[1]).dims)); break;
                 case ATLAS_OP_GATHER_LARGE: {
                     const size_t ln = gr::log2u(gr::padded_len(G.nodes.at(nd.inputs[1]).dims)), lv = gr::log2u(G.nodes.at(nd.inputs[0]).dims[0]);

@@ -11,7 +11,7 @@ import numpy as np
 from . import TranscriptState, _check, lib
 
 OPS = ["Input", "Constant", "Identity", "Add", "Sub", "Mul", "Square", "Cube", "And", "Iff", "ReLU", "Einsum", "Reshape", "MoveAxis", "Broadcast",
-       "Slice", "Concat", "Sum", "ScalarConstDiv", "Div", "MeanOfSquares", "Rsqrt", "SoftmaxLastAxis", "Tanh", "GatherLarge", "GatherSmall", "Erf", "Sigmoid", "Neg", "IsNan", "Clamp"]
+       "Slice", "Concat", "Sum", "ScalarConstDiv", "Div", "MeanOfSquares", "Rsqrt", "SoftmaxLastAxis", "Tanh", "GatherLarge", "GatherSmall", "Erf", "Sigmoid", "Neg", "IsNan", "Clamp", "Sin", "Cos"]
 OP = {n: i for i, n in enumerate(OPS)}
 LAYOUTS = {"mk,kn->mn": 0, "bmk,bkn->mbn": 1, "bmk,kbn->mbn": 2, "mbk,bnk->bmn": 3, "mbk,nbk->bmn": 4, "k,nk->n": 5}
 
@@ -44,7 +44,7 @@ def node_params(nd):
         return [nd["divisor"]], []
     if op == "Sum":
         return [], list(nd["axes"])
-    if op in ("Rsqrt", "SoftmaxLastAxis", "Tanh", "Erf", "Sigmoid"):
+    if op in ("Rsqrt", "SoftmaxLastAxis", "Tanh", "Erf", "Sigmoid", "Sin", "Cos"):
         return [nd["scale"]], []
     if op == "MeanOfSquares":
         return [nd["scale"], nd["count"]], list(nd["axes"])

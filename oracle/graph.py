@@ -244,6 +244,24 @@ def activation_table(op):
     return _ACT[op]
 
 
+TRIG_PERIOD_MODULUS, TRIG_DOWNSCALE_BITS, TRIG_TABLE_VARS = 2470649, 6, 16     # common/src/consts/trig.rs at MODEL_SCALE = 14 (k = 24)
+_TRIG = {}
+
+
+def trig_table(op):
+    """SinTable / CosTable::materialize (neural_teleport/sin.rs:26-41): round(2^8 f(i / 2^8)) * 2^6 over 2^16 indices"""
+    if op not in _TRIG:
+        import math
+        sc = float(1 << (MODEL_SCALE - TRIG_DOWNSCALE_BITS))
+        f = math.sin if op == "Sin" else math.cos
+        out = np.zeros(1 << TRIG_TABLE_VARS, dtype=np.int64)
+        for i in range(1 << TRIG_TABLE_VARS):
+            v = sc * f(i / sc)
+            out[i] = int(math.floor(abs(v) + 0.5)) * (1 if v >= 0 else -1) * (1 << TRIG_DOWNSCALE_BITS)
+        _TRIG[op] = out
+    return _TRIG[op]
+
+
 _EXP_LUT = {}
 
 
@@ -416,6 +434,13 @@ def execute(nodes, inputs):
             k = np.where(c < 0, c.astype(np.int64) + (1 << ACTIVATION_TABLE_VARS), c.astype(np.int64))
             wit[nd["idx"]] = dict(clamped=c, small_idx=k.astype(np.uint64))
             o = activation_table(op)[k].astype(np.int32)
+        elif op in ("Sin", "Cos"):                               # eval_trig (atlas-onnx-tracer/src/ops/mod.rs:317-336), compute_division (Euclidean)
+            assert nd["scale"] == MODEL_SCALE
+            x = ins[0].astype(np.int64)
+            q = np.floor_divide(x, TRIG_PERIOD_MODULUS); rem = x - q * TRIG_PERIOD_MODULUS
+            down = rem >> TRIG_DOWNSCALE_BITS
+            wit[nd["idx"]] = dict(quot=q.astype(np.int32), rem=rem.astype(np.int32), down=down.astype(np.int32))
+            o = trig_table(op)[down].astype(np.int32)
         elif op in ("GatherLarge", "GatherSmall"):
             ddims = next(n for n in nodes if n["idx"] == nd["inputs"][0])["dims"]
             o = ins[0].reshape(ddims[0], -1)[ins[1]].reshape(-1).astype(np.int32)
@@ -483,6 +508,11 @@ class Prover:
             return [("RescaleRemainderRaD", w["rem"].astype(np.uint64), w["S"]), ("ClampRaD", w["quot"].astype(np.int64).view(np.uint64), 64)]
         if op == "ReLU":
             return [("NodeOutputRaD", self.trace[nd["inputs"][0]].astype(np.uint32).astype(np.uint64), 32)]
+        if op in ("Sin", "Cos"):                                             # ops/sin.rs:169-186
+            w = self.wit[i]
+            tau = np.full(len(w["rem"]), TRIG_PERIOD_MODULUS, dtype=np.int32)
+            return [("TrigDownscaleRaD", w["rem"].astype(np.uint32).astype(np.uint64), 32), ("SinRaD" if op == "Sin" else "CosRaD", w["down"].astype(np.uint64), TRIG_TABLE_VARS),
+                    ("TeleportRangeCheckRaD", interleave_arr(w["rem"], tau), 64)]
         if op == "Clamp":
             return [("SymmetricClampRaD", self.trace[nd["inputs"][0]].astype(np.uint32).astype(np.uint64), 32)]
         if op == "Sum":
@@ -519,6 +549,8 @@ class Prover:
             return [("DivNodeQuotient", fr(self.trace[i]))]
         if op == "Rsqrt":
             return [("RsqrtQuotient", fr(self.wit[i]["quot"]))]
+        if op in ("Sin", "Cos"):
+            return [("TeleportNodeQuotient", fr(self.wit[i]["quot"]))]
         return []
 
     def commit(self):
@@ -902,6 +934,54 @@ class Prover:
             fams.append((lk, 64, pt, ra_point, ra_claim, cp))
         self.onehot_checks_multi(nd, fams, "RaOneHotChecks")
 
+    def op_trig(self, nd):
+        """Sin / Cos by neural teleportation (ops/sin.rs:56-186; ReductionFlow::Custom): division by the period modulus at a fresh point, the
+        downscale right-shift lookup batched with the table read-raf, the downscale one-hot checks, the committed quotient, the eval reduction,
+        prove_range_and_onehot (neural_teleport/range_and_onehot.rs:68-140)"""
+        i = nd["idx"]; w = self.wit[i]; op = nd["op"]
+        n = ilog2(len(self.trace[i])); LK = TRIG_TABLE_VARS; K = 1 << LK
+        tau = fr([TRIG_PERIOD_MODULUS])[0]
+        r = self.t.challenge_vector_opt(n)                                                                  # TeleportDivisionParams::new_from_transcript
+        x = self.trace[nd["inputs"][0]]
+        I = OR.elementwise(OR.EW_TELEPORT_DIV, [fr(x), fr(w["quot"]), fr(w["rem"])], r, constants=tau.reshape(1, 4))
+        rs = self.run(I, orc.fr_array(1)[0], i, "NeuralTeleport")
+        fin = I.finals(); pt = np.ascontiguousarray(rs[::-1])
+        self.append_nodeio(nd, 0, pt, fin[0])
+        self.append_advice(nd, "TeleportQuotient", pt, fin[1])
+        self.append_advice(nd, "TeleportRemainder", pt, fin[2])
+        q_claim, rem_claim = fin[1], fin[2]
+        down_claim = orc.evaluate(fr(w["down"]), pt)
+        self.append_advice(nd, "TrigDownscaled", pt, down_claim)                                            # cache_downscaled_prove
+        self.append_advice(nd, "TeleportRemainder", pt, rem_claim)                                          # append_raf_claims_prover of the downscale lookup
+        g_d = self.t.challenge_scalar()
+        lk_rem = w["rem"].astype(np.uint32).astype(np.uint64)
+        I_dsc = OR.ps_rshift(lk_rem, 32, TRIG_DOWNSCALE_BITS, pt, g_d)
+        g_s = self.t.challenge_scalar()                                                                     # SinParams::new
+        out_claim = orc.evaluate(self.mle(i), pt)
+        self.append_virtual(node_exec(virt("NodeOutput", i), i), pt, out_claim)                             # SinProver::initialize: Target::Current
+        lk_down = w["down"].astype(np.uint64)
+        ra = self.ra_histogram(lk_down, K, pt)
+        I_tab = OR.elementwise(OR.EW_GATHER, [ra, fr_fast(trig_table(op)), fr_fast(np.arange(K, dtype=np.int64))], orc.fr_array(LK), constants=g_s.reshape(1, 4))
+        c_dsc = orc.fr_add_arr(down_claim, orc.fr_mul_arr(g_d, rem_claim)); c_tab = orc.fr_add_arr(out_claim, orc.fr_mul_arr(g_s, down_claim))
+        rows, ch, _ = OB.batched_prove([OB.ra_instance(I_dsc, c_dsc), OB.ra_instance(I_tab, c_tab)], self.t.t)
+        self.proofs[(i, PT["Execution"])] = rows
+        rs2 = orc.challenges_to_fr(ch); mr = len(rs2)
+        Dra_point, Dra_claim = self.ra_opening(nd, "TrigDownscaleRa", lk_rem, 32, rs2)
+        tab_point = np.concatenate([rs2[mr - LK:][::-1], pt]); tab_claim = I_tab.finals()[0]
+        self.append_advice(nd, "SinRa" if op == "Sin" else "CosRa", tab_point, tab_claim)
+        self.onehot_checks(nd, lk_rem, 32, pt, Dra_point, Dra_claim, "TrigDownscaleRaD", "TrigDownscaleRaChecks")
+        self.append_dense(nd, "TeleportNodeQuotient", pt, q_claim)
+        self.eval_reduction(nd)
+        lk_rc = interleave_arr(w["rem"], np.full(len(w["rem"]), TRIG_PERIOD_MODULUS, dtype=np.int32))
+        I_rc, c_rc = self.range_check(lk_rc, pt, rem_claim, tau)
+        oh, st = self.onehot_build([(lk_down, LK, pt, tab_point, tab_claim, "SinRaD" if op == "Sin" else "CosRaD")])
+        rows, ch, _ = OB.batched_prove([OB.ra_instance(I_rc, c_rc)] + oh, self.t.t)
+        self.proofs[(i, PT["RaOneHotChecks"])] = rows
+        rs3 = orc.challenges_to_fr(ch)
+        Rra_point, Rra_claim = self.ra_opening(nd, "TeleportRangeCheckRa", lk_rc, 64, rs3)
+        self.onehot_cache(i, st, rs3)
+        self.onehot_checks(nd, lk_rc, 64, pt, Rra_point, Rra_claim, "TeleportRangeCheckRaD", "RaHammingWeight")
+
     def ra_histogram(self, lookups, K, r):
         """compute_ra_evals: ra[k] = sum_{j : idx_j = k} eq(r, j)"""
         E = orc.eq_evals(np.ascontiguousarray(r)) if len(r) else orc.from_ints([1])
@@ -1085,6 +1165,8 @@ class Prover:
             return self.op_div(nd)                                           # ReductionFlow::Custom
         if op == "Rsqrt":
             return self.op_rsqrt(nd)
+        if op in ("Sin", "Cos"):
+            return self.op_trig(nd)
         self.eval_reduction(nd)
         r0, claim = self.reduced[i]
         if op in ("Input", "Constant"):

@@ -167,6 +167,21 @@ def scalar_graph(rng):
     ], [12], [rng.integers(-100, 100, size=4).astype(np.int32)]
 
 
+def trig_graph(rng):
+    """Sin and Cos by neural teleportation (ops/sin.rs, cos.rs): inputs around multiples of the period modulus (the reference's own boundary
+    cases, ops/sin.rs test_sin_periodic_boundary_inputs) and random ones; Cos of the Sin output; an Add on top"""
+    M = 2470649
+    x = rng.integers(-50000, 50000, size=16).astype(np.int32)
+    x[:8] = [-M - 1, -M, -1, 0, 1, M - 1, M, M + 1]
+    return [
+        {"idx": 0, "op": "Input", "inputs": [], "dims": [2, 8]},
+        {"idx": 1, "op": "Sin", "inputs": [0], "dims": [2, 8], "scale": 14},
+        {"idx": 2, "op": "Cos", "inputs": [1], "dims": [2, 8], "scale": 14},
+        {"idx": 3, "op": "Cos", "inputs": [0], "dims": [2, 8], "scale": 14},
+        {"idx": 4, "op": "Add", "inputs": [2, 3], "dims": [2, 8]},
+    ], [4], [x]
+
+
 def concat_graph(rng):
     """Concat (ops/concat.rs) along the last axis of three operands of unequal size (the smaller ones are repeated over the low variables of the
     largest one's hypercube), an Add over the result, then a second Concat along axis 0 whose output carries the output claim"""
@@ -196,7 +211,7 @@ def toy_transformer(rng):
     return BG.tiny(layers=2)
 
 
-@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6), (concat_graph, 7), (erf_sigmoid_graph, 8), (small_ops_graph, 9), (gather_small_graph, 10), (scalar_graph, 11)])
+@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6), (concat_graph, 7), (erf_sigmoid_graph, 8), (small_ops_graph, 9), (gather_small_graph, 10), (scalar_graph, 11), (trig_graph, 12)])
 def test_graph_proof_matches_oracle(atlas, builder, seed):
     from oracle import graph as OG, orc
     from jolt_atlas_amd import graph as GG
@@ -221,7 +236,7 @@ def test_graph_proof_matches_oracle(atlas, builder, seed):
     G.free(); srs.free()
 
 
-@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6), (concat_graph, 7), (erf_sigmoid_graph, 8), (small_ops_graph, 9), (gather_small_graph, 10), (scalar_graph, 11)])
+@pytest.mark.parametrize("builder,seed", [(mlp_graph, 1), (shape_graph, 2), (norm_graph, 3), (act_graph, 4), (toy_transformer, 5), (softmax_graph, 6), (concat_graph, 7), (erf_sigmoid_graph, 8), (small_ops_graph, 9), (gather_small_graph, 10), (scalar_graph, 11), (trig_graph, 12)])
 def test_graph_proof_is_accepted_by_the_verifier(atlas, builder, seed):
     """ONNXProof::verify (atlas_verify_graph: opening claims from the proof, the node loop's verifier instances, the opening-reduction
     sumcheck, the joint commitment, HyperKZG::verify through the pairing) accepts the device's proof with the prover's final transcript
