@@ -112,7 +112,7 @@ def random_chain(seed, steps=9, wide=False, sizes=(2, 4, 8)):
             else:
                 cur = add("Add", [cur, b], dims)
         elif wide and r < 0.98:
-            op = str(rng.choice(["Tanh", "Erf", "Sigmoid"]))
+            op = str(rng.choice(["Tanh", "Erf", "Sigmoid", "Sin", "Cos"]))
             cur = add(op, [cur], dims, scale=14); bits[cur] = 15
         elif wide and r < 0.99 and len(dims) == 2 and dims[0] >= 2 and dims[1] >= 2:
             cur = add("SoftmaxLastAxis", [cur], dims, scale=14); bits[cur] = 15
@@ -180,14 +180,14 @@ def test_random_operator_chain_tiny_shapes(atlas, seed):
     nodes, outputs, inputs = random_chain(9000 + seed, steps=8, sizes=(1, 2))
     if any(nd["op"] in ("Einsum",) and (int(np.prod(nd["dims"])) == 1 or nd["shape"][1] == 1) for nd in nodes):
         pytest.skip("a scalar-output / one-element-contraction Einsum is not composed")
-    if any(nd["op"] in ("ReLU", "Clamp", "Rsqrt", "Div") and int(np.prod(nd["dims"])) == 1 for nd in nodes):
+    if any(nd["op"] in ("ReLU", "Clamp", "Rsqrt", "Div", "Sin", "Cos") and int(np.prod(nd["dims"])) == 1 for nd in nodes):
         pytest.skip("a lookup operator over one element is not composed")
     _run(atlas, nodes, outputs, inputs, seed)
 
 
 @pytest.mark.parametrize("seed", list(range(10)))
 def test_random_operator_chain_wide(atlas, seed):
-    """the same with the lookup-heavy operators in the draw: ScalarConstDiv, Div, MeanOfSquares + Rsqrt, Tanh / Erf / Sigmoid, SoftmaxLastAxis, Iff"""
+    """the same with the lookup-heavy operators in the draw: ScalarConstDiv, Div, MeanOfSquares + Rsqrt, Tanh / Erf / Sigmoid / Sin / Cos, SoftmaxLastAxis, Iff"""
     from oracle import graph as OG, orc
     from jolt_atlas_amd import graph as GG
     nodes, outputs, inputs = random_chain(5000 + seed, steps=11, wide=True)
