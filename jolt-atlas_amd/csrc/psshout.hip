@@ -140,9 +140,11 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_q_final(const unsigned long l
         hi.v[0] = (uint32_t)c; hi.v[1] = (uint32_t)(c >> 32);
         const Fr res = fr_add(fr_mul(lo, fr_one()), fr_mul(hi, r2));
         fe_store(out + i, res);
-        if (pub.host_dst) fe_store(pub.host_dst + i, res);
+        if (pub.host_dst && !fe_is_zero(res)) fe_store(pub.host_dst + i, res);      // the host zeroed the box: a bin no lookup falls into costs no write
     }
     if (!pub.host_dst) return;
+    // (The host zeroes the box before the launch and only non-zero residues cross the link: the phases over the sign extension of a
+    // 64-bit lookup index fill 2 of 256 bins.)
     // (Publishing costs ~20 us per phase at 1536 values, whichever workgroups write: having only the last one to arrive
     // copy the residues out, with or without contiguous 16-byte stores, took 34-36 us against 30 — the host link takes
     // ~50 M device-initiated writes per second, tools/exp_channel2.hip.)
@@ -266,6 +268,36 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_expand_all_ch(Fr* buf0, Fr* b
         __threadfence_block();
         __syncthreads();
     }
+}
+// The same for m <= RA_THREADS (every lookup of the graph prover: 8-bit phases), where the phase boundary is on the critical path of
+// the host's address rounds: lane k of the first wavefront polls slot k, so the host link is crossed once and not S.n times in turn
+// (~2.5 us per crossing), and the table grows in LDS — the launch with one polling thread and the two global buffers took 25-38 us of
+// the ~67 us between a phase's last challenge and the next phase's tables on the host (profiles/r03p_add_node_timeline.txt).
+// The finished table lands where the stepwise launch leaves it: buf0 for an even number of challenges, buf1 for an odd one.
+__global__ __launch_bounds__(RA_THREADS) void k_ps_expand_lds_ch(Fr* buf0, Fr* buf1, PsSlots S) {
+    __shared__ uint64_t s_r[12][2];
+    __shared__ uint32_t s_bad;
+    __shared__ Fr tab[RA_THREADS];
+    if (threadIdx.x == 0) { s_bad = 0; tab[0] = fr_one(); }
+    __syncthreads();
+    if (threadIdx.x < S.n) {
+        uint64_t lo = 0, hi = 0;
+        if (!ch_poll_slot<true>(S.host[threadIdx.x], S.tag[threadIdx.x], S.abort_flag, lo, hi)) atomicOr(&s_bad, 1u);
+        s_r[threadIdx.x][0] = lo; s_r[threadIdx.x][1] = hi;
+    }
+    __syncthreads();
+    if (s_bad) return;
+    for (uint32_t k = 0; k < S.n; k++) {
+        const Fr r = challenge_to_mont(s_r[k][0], s_r[k][1], S.challenge_mode);
+        const bool act = threadIdx.x < (1u << k);
+        Fr f = fe_zero(), hi = fe_zero();
+        if (act) { f = tab[threadIdx.x]; hi = fr_mul(r, f); }
+        __syncthreads();
+        if (act) { tab[2 * threadIdx.x + 1] = hi; tab[2 * threadIdx.x] = fr_sub(f, hi); }
+        __syncthreads();
+    }
+    Fr* dst = (S.n & 1) ? buf1 : buf0;
+    if (threadIdx.x < (1u << S.n)) fe_store(dst + threadIdx.x, tab[threadIdx.x]);
 }
 // m > 256 (k_ps_q + k_col_reduce): the tables copied to pinned host memory by one workgroup, then the tag
 __global__ __launch_bounds__(RA_THREADS) void k_ps_q_copy_out(const Fr* __restrict__ qsum, uint32_t n_vals, Fr* host_dst, Chunk* tag_chunk, uint32_t tag) {
@@ -612,11 +644,13 @@ struct PsLookup : atlas_instance {
         if (round >= 1 && round <= N && round % log_m == 0) {  // a phase is complete: its table, folded into the products
             const size_t p_done = round / log_m - 1;
             slots.n = (uint32_t)log_m; slots.abort_flag = io.abort_flag; slots.challenge_mode = g.challenge_mode;
-            k_ps_expand_all_ch<<<1, RA_THREADS, 0, g.stream>>>(vt[0], vt[1], slots);
+            if (m <= RA_THREADS) k_ps_expand_lds_ch<<<1, RA_THREADS, 0, g.stream>>>(vt[0], vt[1], slots);
+            else k_ps_expand_all_ch<<<1, RA_THREADS, 0, g.stream>>>(vt[0], vt[1], slots);
             const uint32_t shift_done = (uint32_t)((phases - 1 - p_done) * log_m);
             if (round < N) {                                   // ... folded into the products while the Q of the phase that starts is built
                 const size_t p = round / log_m, n_vals = nq() * m;
                 atlas::Chunk* box = g.chan.alloc(2 * n_vals + 4);
+                if (m <= RA_THREADS) std::memset(box + 4, 0, n_vals * sizeof(Fr));      // k_ps_q_final publishes the non-zero residues only
                 int rc = launch_Q(p, vt[log_m & 1], shift_done, QPublish{reinterpret_cast<Fr*>(box + 4), box, io.tag_mail, rows.d_counter});
                 if (rc) return rc;
                 qbox[p] = QBox{box, reinterpret_cast<const H::Fr*>(box + 4), io.tag_mail};
