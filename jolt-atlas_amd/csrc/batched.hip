@@ -189,7 +189,7 @@ struct Pipeline {
                 g.stream = lane_stream(li);
                 atlas_rt::tl_lane_stream = side ? g.stream : nullptr;
                 static const bool no_gate = getenv("ATLAS_LANE_NO_GATE") != nullptr;                     // diagnosis only (tools/bisect_lanes.sh)
-                if (side && wait && !no_gate) atlas::k_ch_gate<<<1, 64, 0, g.stream>>>(io);      // the lane's wide launches start behind their challenge (channel.hip.h)
+                if (side && wait && !no_gate && L.inst->wide_wait(local)) atlas::k_ch_gate<<<1, 64, 0, g.stream>>>(io);      // the lane's wide launches start behind their challenge (channel.hip.h)
                 int rc = Q < max_rounds ? L.inst->enqueue(local, io, bind_prev, L.mails[local]) : L.inst->enqueue_finals(io, L.fin);
                 g.stream = lib_stream;
                 atlas_rt::tl_lane_stream = nullptr;

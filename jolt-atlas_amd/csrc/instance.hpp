@@ -43,4 +43,10 @@ struct atlas_instance {
     virtual int set_finals(const atlas_host::Fr* /*vals*/, size_t /*n*/) { return ATLAS_ESTATE; }
     // host work that does not need the sums of `round` (inversions, ...): called while the device computes them
     virtual void prepare(size_t /*round*/) {}
+    // Do the launches of enqueue(round) [round == rounds(): enqueue_finals] that wait for a challenge spin with more than
+    // WIDE_WAIT_WGS workgroups?  Such a round of a lane on a stream of its own goes behind a one-wavefront gate
+    // (k_ch_gate, channel.hip.h); a round that launches nothing, or a few workgroups, does not need one (a gate is a
+    // launch: ~3 us of the host thread and a kernel boundary on the lane per round).
+    static constexpr size_t WIDE_WAIT_WGS = 256;
+    virtual bool wide_wait(size_t /*round*/) const { return true; }
 };

@@ -630,6 +630,11 @@ struct PsLookup : atlas_instance {
     bool have_finals = false;
     std::vector<H::Fr> mailed_finals;
     bool pipelined() const override { return log_m <= 11 && N + log_T <= atlas_rt::Channel::RING / 2; }
+    bool wide_wait(size_t round) const override {                 // address rounds and the first cycle round: only the one-workgroup table rebuild waits
+        if (round <= N || round >= rounds()) return false;
+        const size_t n_groups = (T >> (round - N)) / 2;
+        return (n_groups + RA_THREADS - 1) / RA_THREADS > WIDE_WAIT_WGS;
+    }
     int enqueue(size_t round, const atlas::RoundIo& io, bool bind_prev, atlas_mail_ref& mail) override {
         if (round >= rounds() || (round > 0) != bind_prev) return fail(ATLAS_ESTATE, "ps_shout: enqueue out of order");
         const ChanIo cio{io, g.challenge_mode};

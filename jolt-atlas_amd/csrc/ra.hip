@@ -246,6 +246,11 @@ struct RaVirtual : atlas_instance {
     bool have_finals = false;
     std::vector<H::Fr> mailed_finals;
     bool pipelined() const override { return true; }
+    bool wide_wait(size_t round) const override {                 // the bind of `round`: ceil(len / RA_THREADS) x d workgroups; the finals: one
+        if (round >= log_T) return false;
+        const size_t len = ((size_t)1 << log_T) >> round;
+        return ((len + RA_THREADS - 1) / RA_THREADS) * rows.d > WIDE_WAIT_WGS;
+    }
     int enqueue(size_t round, const atlas::RoundIo& io, bool bind_prev, atlas_mail_ref& mail) override {
         if (round >= log_T || (round > 0) != bind_prev) return fail(ATLAS_ESTATE, "ra_virtual: enqueue out of order");
         const size_t T = (size_t)1 << log_T, len = T >> round, n_groups = len / 2;
@@ -454,6 +459,11 @@ struct Booleanity : atlas_instance {
     bool have_finals = false;
     std::vector<H::Fr> mailed_finals;
     bool pipelined() const override { return log_k <= 15; }
+    bool wide_wait(size_t round) const override {                 // address rounds: one workgroup steps F; cycle round p >= 1: the bind
+        if (round <= log_k || round >= rounds()) return false;
+        const size_t len = ((size_t)1 << log_T) >> (round - log_k);
+        return ((len + RA_THREADS - 1) / RA_THREADS) * d > WIDE_WAIT_WGS;
+    }
     int enqueue(size_t round, const atlas::RoundIo& io, bool bind_prev, atlas_mail_ref& mail) override {
         if (round >= rounds() || (round > 0) != bind_prev) return fail(ATLAS_ESTATE, "booleanity: enqueue out of order");
         const ChanIo cio{io, g.challenge_mode};
@@ -558,6 +568,7 @@ struct HammingWeight : atlas_instance {
     }
     // round-channel stepping: nothing to launch and nothing to collect, the rounds are host arithmetic
     bool pipelined() const override { return true; }
+    bool wide_wait(size_t) const override { return false; }
     int enqueue(size_t, const atlas::RoundIo& io, bool, atlas_mail_ref& mail) override { mail.base = io.mail; mail.blocks = 0; mail.n_vals = 0; return ATLAS_OK; }
     int finish(size_t round, const H::Fr& claim, const H::Fr*, std::vector<H::Fr>& coeffs) override { return message(round, claim, coeffs); }
     int host_ingest(const atlas_u128_t& r, size_t round) override { return ingest(r, round); }
