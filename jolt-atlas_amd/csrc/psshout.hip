@@ -693,6 +693,7 @@ struct PsLookup : atlas_instance {
                 for (int i = 0; i < 1024 && B.tagc->tag != B.tag; i++) __builtin_ia32_pause();
                 if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) { g.chan.abort_dirty = true; return fail(ATLAS_ENODEV, "round channel: no Q tables from the device"); }
             }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);          // the residues are read through a plain pointer: not before the tag (the device wrote them, fenced, then the tag)
             load_Q(B.data);
             if (ps_trace()) t_qwait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         }
