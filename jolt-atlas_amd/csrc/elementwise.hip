@@ -235,6 +235,7 @@ struct Elementwise : atlas_instance {
     bool have_finals = false;
     std::vector<H::Fr> mailed_finals;
     bool pipelined() const override { return n_vars >= 1; }
+    bool wide_wait(size_t) const override { return false; }     // at most 256 workgroups per round (one mail record each), one for the finals
     // rows of round k live in buf[k & 1] with stride T >> k (RaRows::bind keeps rows compact)
     int enqueue(size_t round, const atlas::RoundIo& io, bool bind_prev, atlas_mail_ref& mail) override {
         if (round >= n_vars || (round > 0) != bind_prev) return fail(ATLAS_ESTATE, "elementwise: enqueue out of order");

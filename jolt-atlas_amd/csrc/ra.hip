@@ -111,6 +111,57 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_prod_f9_col(const Fr* __restr
     mail_tail(partials, tail);
 }
 
+// Bind and product of a round in ONE launch, for rounds of at most RA_FUSE_MAX pairs (the cycle rounds of every lookup of T <= 2^13,
+// and the later rounds of the larger ones): a workgroup takes 16 pairs, thread (pair, k) binds row k of its pair — four coefficients of
+// the previous round's rows -> the two of this round's, stored for the next round — and leaves (x0, x1 - x0) as lazy limbs in LDS; after
+// the barrier it is column k of the pair and runs the same chain as k_ra_prod_f9_col over the 16 rows in LDS.  Against k_ra_bind_ch +
+// k_ra_prod_f9_col the round loses a kernel boundary, the trip of the bound rows through HBM and the four batches of row loads: RaVirtual is
+// the long lane of a one-hot batch, so this is the batch's round time.  Same sums: the chain is weight x the d values, d + 1
+// multiplications of 2^-5 each as before; the partial rows are canonical.
+constexpr size_t RA_FUSE_MAX = 4096;
+constexpr int RA_FUSE_PAIRS = 16;
+__global__ __launch_bounds__(RA_THREADS) void k_ra_bind_prod_f9(const Fr* __restrict__ src, size_t src_stride, Fr* __restrict__ dst, size_t dst_stride,
+                                                                uint32_t D, SplitEqView E, size_t n_groups, Fr* __restrict__ partials /* [gridDim.x][D] */,
+                                                                ChanIo io, int r_hi_only, MailTail tail) {
+    using P9 = Fr9Params;
+    __shared__ F9 sh_x0[RA_FUSE_PAIRS][16], sh_dl[RA_FUSE_PAIRS][16], sh_red[RA_FUSE_PAIRS][16];
+    Fr r;
+    if (!io.challenge(r)) return;
+    const uint32_t p = threadIdx.x >> 4, k = threadIdx.x & 15u;
+    const size_t gidx = (size_t)blockIdx.x * RA_FUSE_PAIRS + p;
+    const bool live = gidx < n_groups && k < D;
+    if (live) {
+        const Fr* s4 = src + (size_t)k * src_stride + 4 * gidx;
+        const Fr a0 = fe_load(s4), a1 = fe_load(s4 + 1), a2 = fe_load(s4 + 2), a3 = fe_load(s4 + 3);
+        const Fr b0 = bind_pair(a0, a1, r, r_hi_only != 0), b1 = bind_pair(a2, a3, r, r_hi_only != 0);
+        Fr* d2 = dst + (size_t)k * dst_stride + 2 * gidx;
+        fe_store(d2, b0); fe_store(d2 + 1, b1);
+        const F9 x0 = f9_from_fe(b0), x1 = f9_from_fe(b1);
+        sh_x0[p][k] = x0;
+        sh_dl[p][k] = f9_norm_red<P9, 2>(f9_sub<P9>(x1, x0));
+    }
+    __syncthreads();
+    F9 prod = f9_zero();
+    if (live) {
+        const size_t mask = ((size_t)1 << E.in_bits) - 1;
+        prod = f9_mul<P9>(f9_load(E.e_out + (gidx >> E.in_bits)), f9_load(E.e_in + (gidx & mask)));
+#pragma unroll 1
+        for (uint32_t i = 0; i < D; i++) {
+            const F9 x0 = sh_x0[p][i], dl = sh_dl[p][i];
+            const F9 val = k == D - 1 ? dl : f9_axpy_small(x0, dl, k + 1);          // column D-1: X -> inf; else p_i(k + 1), lazy
+            prod = f9_mul<P9>(prod, val);
+        }
+    }
+    sh_red[p][k] = prod;
+    __syncthreads();
+    if (threadIdx.x < D) {
+        F9 t = sh_red[0][threadIdx.x];
+        for (int q = 1; q < RA_FUSE_PAIRS; q++) t = f9_norm_red<P9>(f9_add(t, sh_red[q][threadIdx.x]));
+        fe_store(partials + (size_t)blockIdx.x * D + threadIdx.x, f9_canon<P9>(t));
+    }
+    mail_tail(partials, tail);
+}
+
 // (Measured and removed: the last rounds — rows of at most 64 coefficients — as ONE workgroup per round that binds, multiplies
 // with 2 or 4 lanes sharing a pair, and mails, for RaVirtual and for the booleanity fold.  No gain for RaVirtual (0.267 against
 // 0.272 ms at d = 16, T = 2^6; the Einsum node unchanged) and 20-30 % slower for booleanity (0.32 against 0.25 ms): sixteen
@@ -146,6 +197,47 @@ __global__ __launch_bounds__(RA_THREADS) void k_bool_fold(const Fr* __restrict__
         const F9 wgt = f9_mul<P9>(f9_load(E.e_out + (j >> E.in_bits)), f9_load(E.e_in + (j & (((size_t)1 << E.in_bits) - 1))));
         acc0 = f9_norm_red<P9>(f9_add(acc0, f9_mul<P9>(wgt, c)));
         acc1 = f9_norm_red<P9>(f9_add(acc1, f9_mul<P9>(wgt, e)));
+    }
+    __shared__ F9 red9[RA_THREADS / 64][2];
+    acc0 = f9_wave_sum<P9>(acc0); acc1 = f9_wave_sum<P9>(acc1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red9[wave][0] = acc0; red9[wave][1] = acc1; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        F9 s = red9[0][threadIdx.x];
+        for (int w = 1; w < RA_THREADS / 64; w++) s = f9_norm_red<P9>(f9_add(s, red9[w][threadIdx.x]));
+        fe_store(partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + threadIdx.x, f9_canon<P9>(s));
+    }
+    mail_tail(partials, tail);
+}
+
+// The bind of a booleanity cycle round and its fold in ONE launch, one (row, pair) per thread (the latency regime of k_bool_fold, at most
+// RA_FUSE_MAX pairs): four coefficients of the previous round's row -> the two of this round's, stored for the next round, and the same
+// two terms — the same four f9_mul behind each.  With RaVirtual's bind fused into its product (k_ra_bind_prod_f9) this lane would
+// otherwise be the long one of a one-hot batch.
+__global__ __launch_bounds__(RA_THREADS) void k_bool_bind_fold(const Fr* __restrict__ src, size_t src_stride, Fr* __restrict__ dst, size_t dst_stride,
+                                                               const Fr* __restrict__ gammas, SplitEqView E, size_t n_groups, Fr* __restrict__ partials,
+                                                               ChanIo io, int r_hi_only, MailTail tail) {
+    using P9 = Fr9Params;
+    Fr r;
+    if (!io.challenge(r)) return;
+    F9 acc0 = f9_zero(), acc1 = f9_zero();
+    const size_t j = (size_t)blockIdx.x * RA_THREADS + threadIdx.x;
+    const uint32_t i = blockIdx.y;
+    if (j < n_groups) {
+        const Fr* s4 = src + (size_t)i * src_stride + 4 * j;
+        const Fr a0 = fe_load(s4), a1 = fe_load(s4 + 1), a2 = fe_load(s4 + 2), a3 = fe_load(s4 + 3);
+        const Fr b0 = bind_pair(a0, a1, r, r_hi_only != 0), b1 = bind_pair(a2, a3, r, r_hi_only != 0);
+        Fr* d2 = dst + (size_t)i * dst_stride + 2 * j;
+        fe_store(d2, b0); fe_store(d2 + 1, b1);
+        const F9 one = f9_from_fe(fr_one());
+        const F9 h0 = f9_from_fe(b0), h1 = f9_from_fe(b1), gm = f9_load(gammas + i);
+        const F9 b = f9_sub<P9>(h1, h0), m1 = f9_sub<P9>(h0, one);
+        const F9 c = f9_norm_red<P9, 4>(f9_mul<P9>(f9_mul<P9>(gm, h0), m1));
+        const F9 e = f9_norm_red<P9, 4>(f9_mul<P9>(f9_mul<P9>(gm, b), b));
+        const F9 wgt = f9_mul<P9>(f9_load(E.e_out + (j >> E.in_bits)), f9_load(E.e_in + (j & (((size_t)1 << E.in_bits) - 1))));
+        acc0 = f9_norm_red<P9>(f9_mul<P9>(wgt, c));
+        acc1 = f9_norm_red<P9>(f9_mul<P9>(wgt, e));
     }
     __shared__ F9 red9[RA_THREADS / 64][2];
     acc0 = f9_wave_sum<P9>(acc0); acc1 = f9_wave_sum<P9>(acc1);
@@ -246,25 +338,34 @@ struct RaVirtual : atlas_instance {
     bool have_finals = false;
     std::vector<H::Fr> mailed_finals;
     bool pipelined() const override { return true; }
-    bool wide_wait(size_t round) const override {                 // the bind of `round`: ceil(len / RA_THREADS) x d workgroups; the finals: one
+    static bool fuse_off() { static const bool v = getenv("ATLAS_RA_NO_FUSE") != nullptr; return v; }   // diagnosis / A-B: bind and product as two launches
+    bool fused(size_t round) const { return round >= 1 && round < log_T && (((size_t)1 << log_T) >> round) / 2 <= RA_FUSE_MAX && !fuse_off(); }
+    bool wide_wait(size_t round) const override {                 // the bind of `round`: ceil(len / RA_THREADS) x d workgroups (fused: a workgroup per 16 pairs); the finals: one
         if (round >= log_T) return false;
         const size_t len = ((size_t)1 << log_T) >> round;
+        if (fused(round)) return (len / 2 + RA_FUSE_PAIRS - 1) / RA_FUSE_PAIRS > WIDE_WAIT_WGS;
         return ((len + RA_THREADS - 1) / RA_THREADS) * rows.d > WIDE_WAIT_WGS;
     }
     int enqueue(size_t round, const atlas::RoundIo& io, bool bind_prev, atlas_mail_ref& mail) override {
         if (round >= log_T || (round > 0) != bind_prev) return fail(ATLAS_ESTATE, "ra_virtual: enqueue out of order");
         const size_t T = (size_t)1 << log_T, len = T >> round, n_groups = len / 2;
         const ChanIo cio{io, g.challenge_mode};
-        if (bind_prev) {
-            size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
-            k_ra_bind_ch<<<dim3((unsigned)gb, (unsigned)rows.d), RA_THREADS, 0, g.stream>>>(rows.buf[(round - 1) & 1], T >> (round - 1), rows.buf[round & 1], len, len,
-                                                                                          cio, g.challenge_mode == 0 ? 1 : 0);
-        }
-        const unsigned blocks = (unsigned)((n_groups + RA_THREADS - 1) / RA_THREADS);
         size_t ot, it;
         eq.st.tops_after(round, ot, it);
-        int rc = launch_prod_d(rows.d, rows.buf[round & 1], len, rows.partials, eq.view_at(ot, it), n_groups, blocks, MailTail{io, rows.d_counter, 0, 0});
-        if (rc) return rc;
+        if (fused(round)) {                                       // bind + product in one launch (k_ra_bind_prod_f9)
+            const unsigned fb = (unsigned)((n_groups + RA_FUSE_PAIRS - 1) / RA_FUSE_PAIRS);
+            k_ra_bind_prod_f9<<<fb, RA_THREADS, 0, g.stream>>>(rows.buf[(round - 1) & 1], T >> (round - 1), rows.buf[round & 1], len, (uint32_t)rows.d, eq.view_at(ot, it),
+                                                               n_groups, rows.partials, cio, g.challenge_mode == 0 ? 1 : 0, MailTail{io, rows.d_counter, fb, (uint32_t)rows.d});
+        } else {
+            if (bind_prev) {
+                size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
+                k_ra_bind_ch<<<dim3((unsigned)gb, (unsigned)rows.d), RA_THREADS, 0, g.stream>>>(rows.buf[(round - 1) & 1], T >> (round - 1), rows.buf[round & 1], len, len,
+                                                                                              cio, g.challenge_mode == 0 ? 1 : 0);
+            }
+            const unsigned blocks = (unsigned)((n_groups + RA_THREADS - 1) / RA_THREADS);
+            int rc = launch_prod_d(rows.d, rows.buf[round & 1], len, rows.partials, eq.view_at(ot, it), n_groups, blocks, MailTail{io, rows.d_counter, 0, 0});
+            if (rc) return rc;
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(ATLAS_ENODEV, "ra_virtual: launch", e);
         mail.base = io.mail; mail.blocks = 1; mail.n_vals = (int)rows.d; mail.radix = 32; mail.shl = 0;
@@ -459,9 +560,15 @@ struct Booleanity : atlas_instance {
     bool have_finals = false;
     std::vector<H::Fr> mailed_finals;
     bool pipelined() const override { return log_k <= 15; }
+    // cycle round p >= 1 in one launch (k_bool_bind_fold); ATLAS_RA_NO_FUSE / ATLAS_NO_MAIL_TAIL: the separate launches (diagnosis, A-B)
+    bool fused(size_t p) const {
+        static const bool off = getenv("ATLAS_RA_NO_FUSE") != nullptr || getenv("ATLAS_BOOL_NO_FUSE") != nullptr || getenv("ATLAS_NO_MAIL_TAIL") != nullptr;
+        return p >= 1 && p < log_T && (((size_t)1 << log_T) >> p) / 2 <= RA_FUSE_MAX && !off;
+    }
     bool wide_wait(size_t round) const override {                 // address rounds: one workgroup steps F; cycle round p >= 1: the bind
         if (round <= log_k || round >= rounds()) return false;
         const size_t len = ((size_t)1 << log_T) >> (round - log_k);
+        if (fused(round - log_k)) return ((len / 2 + RA_THREADS - 1) / RA_THREADS) * d > WIDE_WAIT_WGS;
         return ((len + RA_THREADS - 1) / RA_THREADS) * d > WIDE_WAIT_WGS;
     }
     int enqueue(size_t round, const atlas::RoundIo& io, bool bind_prev, atlas_mail_ref& mail) override {
@@ -479,14 +586,20 @@ struct Booleanity : atlas_instance {
             if (!rows.d_idx) return fail(ATLAS_ESTATE, "booleanity: indices not uploaded");
             size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
             k_ra_gather<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, g.stream>>>(rows.d_idx, d_F, 0u, T, rows.buf[0]);   // every H_i reads the same table F
-        } else {
+        } else if (!fused(p)) {
             size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
             k_ra_bind_ch<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, g.stream>>>(rows.buf[(p - 1) & 1], T >> (p - 1), rows.buf[p & 1], len, len, cio,
                                                                                      g.challenge_mode == 0 ? 1 : 0);
         }
         size_t ot, it;
         D.st.tops_after(p, ot, it);
-        launch_fold(rows.buf[p & 1], len, D.view_at(ot, it), n_groups, &io);
+        if (fused(p)) {
+            const unsigned fb = (unsigned)((n_groups + RA_THREADS - 1) / RA_THREADS);
+            k_bool_bind_fold<<<dim3(fb, (unsigned)d), RA_THREADS, 0, g.stream>>>(rows.buf[(p - 1) & 1], T >> (p - 1), rows.buf[p & 1], len, d_gammas, D.view_at(ot, it), n_groups,
+                                                                                rows.partials, cio, g.challenge_mode == 0 ? 1 : 0,
+                                                                                MailTail{io, rows.d_counter, (uint32_t)(fb * d), 2u});
+        } else
+            launch_fold(rows.buf[p & 1], len, D.view_at(ot, it), n_groups, &io);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(ATLAS_ENODEV, "booleanity: launch", e);
         mail.blocks = 1; mail.n_vals = 2;
