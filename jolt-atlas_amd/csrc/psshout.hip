@@ -160,6 +160,62 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_q_final(const unsigned long l
     }
 }
 
+// The same for at most 32 slabs (T <= 2^13, every lookup of the nanoGPT-shaped graph): 32 values per workgroup, a thread adds one word
+// over all slabs — 48 workgroups instead of 384 behind the arrival counter of the publication.
+__global__ __launch_bounds__(RA_THREADS) void k_ps_q_final_few(const unsigned long long* __restrict__ acc, uint32_t n_slabs, uint32_t n_vals, Fr* __restrict__ out,
+                                                           QPublish pub) {
+    __shared__ unsigned long long sm[RA_THREADS];
+    const size_t n_words = (size_t)n_vals * 8, widx = (size_t)blockIdx.x * RA_THREADS + threadIdx.x;
+    unsigned long long sum = 0;
+    if (widx < n_words) {
+        const unsigned long long* col = acc + widx;
+        unsigned long long s1 = 0, s2 = 0, s3 = 0;
+        uint32_t g2 = 0;
+        for (; g2 + 3 < n_slabs; g2 += 4) {
+            const unsigned long long a0 = col[(size_t)g2 * n_words], a1 = col[(size_t)(g2 + 1) * n_words];
+            const unsigned long long a2 = col[(size_t)(g2 + 2) * n_words], a3 = col[(size_t)(g2 + 3) * n_words];
+            sum += a0; s1 += a1; s2 += a2; s3 += a3;
+        }
+        for (; g2 < n_slabs; g2++) sum += col[(size_t)g2 * n_words];
+        sum += s1 + s2 + s3;
+    }
+    sm[threadIdx.x] = sum;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 32 + threadIdx.x;
+    if (threadIdx.x < 32 && i < n_vals) {
+        Fr lo, hi, r2;
+        unsigned long long c = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            const unsigned long long s = c + sm[threadIdx.x * 8 + w];
+            lo.v[w] = (uint32_t)s;
+            c = s >> 32;
+        }
+#pragma unroll
+        for (int w = 0; w < 8; w++) { hi.v[w] = 0; r2.v[w] = FrParams::r2(w); }
+        hi.v[0] = (uint32_t)c; hi.v[1] = (uint32_t)(c >> 32);
+        const Fr res = fr_add(fr_mul(lo, fr_one()), fr_mul(hi, r2));
+        fe_store(out + i, res);
+        if (pub.host_dst && !fe_is_zero(res)) fe_store(pub.host_dst + i, res);      // the host zeroed the box: a bin no lookup falls into costs no write
+    }
+    if (!pub.host_dst) return;
+    // (The host zeroes the box before the launch and only non-zero residues cross the link: the phases over the sign extension of a
+    // 64-bit lookup index fill 2 of 256 bins.)
+    // (Publishing costs ~20 us per phase at 1536 values, whichever workgroups write: having only the last one to arrive
+    // copy the residues out, with or without contiguous 16-byte stores, took 34-36 us against 30 — the host link takes
+    // ~50 M device-initiated writes per second, tools/exp_channel2.hip.)
+    __threadfence_system();                            // this workgroup's values are in host memory before it is counted
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = atomicAdd(pub.counter, 1u);
+        if (t == gridDim.x - 1) {
+            *pub.counter = 0;
+            __threadfence_system();
+            ch_store_sys(pub.tag_chunk, ch_u32x4{n_vals, 0u, 0u, pub.tag});
+        }
+    }
+}
+
 // m > 256: one workgroup per (bin, slice of T), each filtering its slice for its bin
 template <int NQ>
 __global__ __launch_bounds__(RA_THREADS) void k_ps_q(const uint64_t* __restrict__ idx, const Fr* __restrict__ u0,
@@ -381,7 +437,9 @@ struct PsLookup : atlas_instance {
             else if (NQ == 3) PS_Q_LDS(3, bound);
             else PS_Q_LDS(2, 0u);
 #undef PS_Q_LDS
-            k_ps_q_final<<<(unsigned)((NQ * m + 3) / 4), RA_THREADS, 0, g.stream>>>(acc, (uint32_t)gb, (uint32_t)(NQ * m), d_qsum, pub);
+            static const bool few_off = getenv("ATLAS_PS_NO_FEW") != nullptr;     // A-B
+            if (gb <= 32 && !few_off) k_ps_q_final_few<<<(unsigned)((NQ * m + 31) / 32), RA_THREADS, 0, g.stream>>>(acc, (uint32_t)gb, (uint32_t)(NQ * m), d_qsum, pub);
+            else k_ps_q_final<<<(unsigned)((NQ * m + 3) / 4), RA_THREADS, 0, g.stream>>>(acc, (uint32_t)gb, (uint32_t)(NQ * m), d_qsum, pub);
         } else {
             if (v_prev) { size_t gs = (T + RA_THREADS - 1) / RA_THREADS; if (gs > 4096) gs = 4096; k_ps_scale<<<(unsigned)gs, RA_THREADS, 0, g.stream>>>(d_idx, v_prev, T, shift_prev, (uint32_t)(m - 1), rows.buf[0]); }
             if (NQ == 4) k_ps_q<4><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), 0u, d_qpart);
