@@ -160,7 +160,7 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_q_final(const unsigned long l
     }
 }
 
-// The same for at most 32 slabs (T <= 2^13, every lookup of the nanoGPT-shaped graph): 32 values per workgroup, a thread adds one word
+// The same for at most 64 slabs (T <= 2^14, every lookup of the nanoGPT- and GPT-2-shaped graphs): 32 values per workgroup, a thread adds one word
 // over all slabs — 48 workgroups instead of 384 behind the arrival counter of the publication.
 __global__ __launch_bounds__(RA_THREADS) void k_ps_q_final_few(const unsigned long long* __restrict__ acc, uint32_t n_slabs, uint32_t n_vals, Fr* __restrict__ out,
                                                            QPublish pub) {
@@ -171,10 +171,12 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_q_final_few(const unsigned lo
         const unsigned long long* col = acc + widx;
         unsigned long long s1 = 0, s2 = 0, s3 = 0;
         uint32_t g2 = 0;
-        for (; g2 + 3 < n_slabs; g2 += 4) {
+        for (; g2 + 7 < n_slabs; g2 += 8) {                // eight loads in flight: the loop is latency-bound
             const unsigned long long a0 = col[(size_t)g2 * n_words], a1 = col[(size_t)(g2 + 1) * n_words];
             const unsigned long long a2 = col[(size_t)(g2 + 2) * n_words], a3 = col[(size_t)(g2 + 3) * n_words];
-            sum += a0; s1 += a1; s2 += a2; s3 += a3;
+            const unsigned long long a4 = col[(size_t)(g2 + 4) * n_words], a5 = col[(size_t)(g2 + 5) * n_words];
+            const unsigned long long a6 = col[(size_t)(g2 + 6) * n_words], a7 = col[(size_t)(g2 + 7) * n_words];
+            sum += a0 + a4; s1 += a1 + a5; s2 += a2 + a6; s3 += a3 + a7;
         }
         for (; g2 < n_slabs; g2++) sum += col[(size_t)g2 * n_words];
         sum += s1 + s2 + s3;
@@ -438,7 +440,7 @@ struct PsLookup : atlas_instance {
             else PS_Q_LDS(2, 0u);
 #undef PS_Q_LDS
             static const bool few_off = getenv("ATLAS_PS_NO_FEW") != nullptr;     // A-B
-            if (gb <= 32 && !few_off) k_ps_q_final_few<<<(unsigned)((NQ * m + 31) / 32), RA_THREADS, 0, g.stream>>>(acc, (uint32_t)gb, (uint32_t)(NQ * m), d_qsum, pub);
+            if (gb <= 64 && !few_off) k_ps_q_final_few<<<(unsigned)((NQ * m + 31) / 32), RA_THREADS, 0, g.stream>>>(acc, (uint32_t)gb, (uint32_t)(NQ * m), d_qsum, pub);
             else k_ps_q_final<<<(unsigned)((NQ * m + 3) / 4), RA_THREADS, 0, g.stream>>>(acc, (uint32_t)gb, (uint32_t)(NQ * m), d_qsum, pub);
         } else {
             if (v_prev) { size_t gs = (T + RA_THREADS - 1) / RA_THREADS; if (gs > 4096) gs = 4096; k_ps_scale<<<(unsigned)gs, RA_THREADS, 0, g.stream>>>(d_idx, v_prev, T, shift_prev, (uint32_t)(m - 1), rows.buf[0]); }
