@@ -611,7 +611,10 @@ struct PsLookup : atlas_instance {
             const size_t j = round, p = j / log_m;
             const size_t half = Q[0].size() / 2;
             for (auto& q : Q) {                                       // suffix polys bind HighToLow
-                for (size_t i = 0; i < half; i++) q[i] = H::add(q[i], H::mul_challenge(rf, H::sub(q[i + half], q[i])));   // (two CIOS steps for a 128-bit challenge)
+                for (size_t i = 0; i < half; i++) {
+                    if (H::detail::is_zero4(q[i].l) && H::detail::is_zero4(q[i + half].l)) continue;       // an empty pair of bins stays empty (the phases over a sign extension fill 2 bins of 256)
+                    q[i] = H::add(q[i], H::mul_challenge(rf, H::sub(q[i + half], q[i])));   // (two CIOS steps for a 128-bit challenge)
+                }
                 q.resize(half);
             }
             if (with_device) {
