@@ -187,24 +187,40 @@ MODEL_SCALE = 14
 ACTIVATION_BOUND = MODEL_SCALE + 3
 ACTIVATION_TABLE_VARS = ACTIVATION_BOUND + 1
 CLAMP_BOUND = 9                  # joltworks/src/lookup_tables/clamp.rs:197-211
-_TANH = None
+
+
+def round_half_away(f):
+    """f64::round: half away from zero"""
+    import math
+    return int(math.floor(abs(f) + 0.5)) * (1 if f >= 0 else -1)
+
+
+def nonlinearity_value(op, v, sc):
+    """One element of tensor::ops::nonlinearities::{tanh, erffunc, sigmoid, sin, cos} (atlas-onnx-tracer/src/tensor/ops.rs:3583-3591,
+    3737-3745, 3101-3109, 3420-3428, 3312-3320) at multiplier `sc`: round(sc f(v / sc)) in f64.  The tables below are this function at
+    sc = 2^14 (2^8 for the trig tables); the reference's doc-test vectors at other multipliers replay through it
+    (tests/test_ref_tensor_ops.py)."""
+    import math
+    x = v / sc
+    if op == "Tanh":
+        f = sc * math.tanh(x)
+    elif op == "Erf":
+        f = sc * _erf_cheb(x)
+    elif op == "Sigmoid":
+        f = sc / (1.0 + math.exp(-x))
+    elif op == "Sin":
+        f = sc * math.sin(x)
+    elif op == "Cos":
+        f = sc * math.cos(x)
+    else:
+        raise ValueError(op)
+    return round_half_away(f)
 
 
 def tanh_table():
     """materialize_signed_activation_table (neural_teleport/utils.rs:67-85) with nonlinearities::tanh (tensor/ops.rs:3583-3591):
     Table[i] = round(2^14 tanh(signed18(i) / 2^14)) in f64, round-half-away-from-zero like f64::round"""
-    global _TANH
-    if _TANH is None:
-        import math
-        n = 1 << ACTIVATION_TABLE_VARS
-        sc = float(1 << MODEL_SCALE)
-        out = np.zeros(n, dtype=np.int64)
-        for i in range(n):
-            v = i - n if i >= n // 2 else i
-            f = sc * math.tanh(v / sc)
-            out[i] = int(math.floor(abs(f) + 0.5)) * (1 if f >= 0 else -1)
-        _TANH = out
-    return _TANH
+    return activation_table("Tanh")
 
 
 _ACT = {}
@@ -229,17 +245,12 @@ def _erf_cheb(x):
 
 def activation_table(op):
     """materialize_signed_activation_table (neural_teleport/utils.rs:67-85) for Tanh / Erf / Sigmoid (ops/tanh.rs, erf.rs, sigmoid.rs:22-32)"""
-    if op == "Tanh":
-        return tanh_table()
     if op not in _ACT:
-        import math
         n = 1 << ACTIVATION_TABLE_VARS
         sc = float(1 << MODEL_SCALE)
         out = np.zeros(n, dtype=np.int64)
         for i in range(n):
-            v = i - n if i >= n // 2 else i
-            f = sc * _erf_cheb(v / sc) if op == "Erf" else sc / (1.0 + math.exp(-(v / sc)))
-            out[i] = int(math.floor(abs(f) + 0.5)) * (1 if f >= 0 else -1)
+            out[i] = nonlinearity_value(op, i - n if i >= n // 2 else i, sc)
         _ACT[op] = out
     return _ACT[op]
 
@@ -251,13 +262,10 @@ _TRIG = {}
 def trig_table(op):
     """SinTable / CosTable::materialize (neural_teleport/sin.rs:26-41): round(2^8 f(i / 2^8)) * 2^6 over 2^16 indices"""
     if op not in _TRIG:
-        import math
         sc = float(1 << (MODEL_SCALE - TRIG_DOWNSCALE_BITS))
-        f = math.sin if op == "Sin" else math.cos
         out = np.zeros(1 << TRIG_TABLE_VARS, dtype=np.int64)
         for i in range(1 << TRIG_TABLE_VARS):
-            v = sc * f(i / sc)
-            out[i] = int(math.floor(abs(v) + 0.5)) * (1 if v >= 0 else -1) * (1 << TRIG_DOWNSCALE_BITS)
+            out[i] = nonlinearity_value(op, i, sc) * (1 << TRIG_DOWNSCALE_BITS)
         _TRIG[op] = out
     return _TRIG[op]
 
