@@ -503,18 +503,9 @@ def main():
     # the same composition with the output claim and the reduced openings around it)
     if rank == 0 and not args.no_node and not args.no_graph:
         from jolt_atlas_amd import graph as GG
-        rngv = np.random.default_rng(15)
-        def rnd(n): return rngv.integers(-(1 << 14), 1 << 14, size=n, dtype=np.int64).astype(np.int32)
-        shapes = {
-            "einsum": ([{"idx": 0, "op": "Input", "inputs": [], "dims": [16, 1024]},
-                        {"idx": 1, "op": "Constant", "inputs": [], "dims": [1024, 4096], "data": rnd(1024 * 4096)},
-                        {"idx": 2, "op": "Einsum", "inputs": [0, 1], "dims": [16, 4096], "layout": "mk,kn->mn", "scale": 14, "shape": [16, 1024, 4096]}], [rnd(16 * 1024)]),
-            "relu": ([{"idx": 0, "op": "Input", "inputs": [], "dims": [16, 4096]},
-                      {"idx": 1, "op": "ReLU", "inputs": [0], "dims": [16, 4096]}], [rnd(1 << 16)]),
-            "mul": ([{"idx": 0, "op": "Input", "inputs": [], "dims": [16, 4096]},
-                     {"idx": 1, "op": "Constant", "inputs": [], "dims": [16, 4096], "data": rnd(1 << 16)},
-                     {"idx": 2, "op": "Mul", "inputs": [0, 1], "dims": [16, 4096], "scale": 14}], [rnd(1 << 16)]),
-        }
+        # tools/build_graphs.py node_einsum / node_relu / node_mul: the shapes timed above; tests/test_gpu_graph_golden.py proves the same three
+        # graphs against committed oracle results
+        shapes = {nm: (lambda t: (t[0], t[2]))(getattr(BG, "node_" + nm)()) for nm in ("einsum", "relu", "mul")}
         tau_v = np.array([0x1234567, 0, 0, 0], dtype=np.uint64)
         srs_v = A.SRS.generate(tau_v, 1 << 20)            # the largest committed polynomial is a one-hot chunk: 16 addresses x 2^16 cycles
         vk_v = A.HyperKZG.vk_from_trapdoor(tau_v, srs_v.download(0, 1)[0])

@@ -357,6 +357,7 @@ int atlas_elementwise_prove_sharded(atlas_instance_t inst, atlas_shard_group_t g
     if (!P || !grp || !input_claim || !transcript || !compressed || !n_coeffs || !challenges || !finals || !n_finals) return fail(ATLAS_EINVAL, "elementwise_prove_sharded: null argument / not an element-wise instance");
     if (!ew_has_eq(P->op)) return fail(ATLAS_EINVAL, "elementwise_prove_sharded: the selector-style operators (no eq factor) are not sharded");
     const size_t world = (size_t)grp->world, rank = (size_t)grp->rank;
+    if (world == 0 || (world & (world - 1)) || rank >= world) return fail(ATLAS_EINVAL, "elementwise_prove_sharded: the world size must be a power of two (contiguous blocks of a hypercube)");
     size_t lw = 0; while (((size_t)1 << lw) < world) lw++;
     if (lw && !r_high) return fail(ATLAS_EINVAL, "elementwise_prove_sharded: r_high");
     const int nq = ew_outputs(P->op);

@@ -351,9 +351,128 @@ int atlas_rt_exp_lut(const ExpLut** out) {
     return ATLAS_OK;
 }
 
+// Everything exec_node would refuse, decided from the description alone (operand counts and shapes, operator parameters, the
+// scales / bounds the prover's tables are compiled for).  atlas_prove_graph and atlas_verify_graph call it for every node before
+// they touch one: a verifier's graph is never traced, and its operator formulas index nd.dims / nd.p / nd.shape without checks of
+// their own, so a model that would fail to trace is refused here instead of being verified under other semantics.
+int atlas_rt_validate_node(const atlas_graph& G, const Node& nd) {
+    auto bad = [&](const char* what) { return fail(ATLAS_EINVAL, what); };
+    if (nd.dims.empty() || nd.dims.size() > MAXR || !gr::all_pow2(nd.dims)) return bad("graph: a node needs 1..6 dimensions, each a power of two");
+    const size_t T = gr::padded_len(nd.dims);
+    if (T > ((size_t)1 << 26)) return bad("graph: a node output above 2^26 elements");
+    for (size_t i : nd.inputs) { auto it = G.nodes.find(i); if (it == G.nodes.end() || i >= nd.idx) return bad("graph: inputs must name earlier nodes"); }
+    auto in_node = [&](size_t i) -> const Node& { return G.nodes.at(nd.inputs[i]); };
+    auto need_inputs = [&](size_t n) { return nd.inputs.size() == n; };
+    auto same_len = [&]() { for (size_t i = 0; i < nd.inputs.size(); i++) if (gr::padded_len(in_node(i).dims) != T) return false; return true; };
+    switch (nd.op) {
+        case ATLAS_OP_INPUT: return need_inputs(0) ? ATLAS_OK : bad("graph: Input takes no operands");
+        case ATLAS_OP_CONSTANT: return need_inputs(0) && nd.constant.size() == T ? ATLAS_OK : bad("graph: constant length != padded shape");
+        case ATLAS_OP_IDENTITY: case ATLAS_OP_RESHAPE: case ATLAS_OP_RELU: case ATLAS_OP_NEG: case ATLAS_OP_IS_NAN:
+            return need_inputs(1) && same_len() ? ATLAS_OK : bad("graph: one operand of the output's length expected");
+        case ATLAS_OP_ADD: case ATLAS_OP_SUB: case ATLAS_OP_AND:
+            return need_inputs(2) && same_len() ? ATLAS_OK : bad("graph: two operands of the output's shape expected");
+        case ATLAS_OP_IFF: return need_inputs(3) && same_len() ? ATLAS_OK : bad("graph: Iff takes (mask, a, b) of the output's shape");
+        case ATLAS_OP_CLAMP:
+            return need_inputs(1) && same_len() && nd.p[0] == (int64_t)gr::CLAMP_BOUND ? ATLAS_OK
+                   : bad("graph: Clamp needs one operand and bound_log = CLAMP_BOUND (9): the prover's table is compiled for it");
+        case ATLAS_OP_MOVEAXIS: {
+            if (!need_inputs(1)) return bad("graph: one operand expected");
+            const std::vector<size_t>& idims = in_node(0).dims;
+            const size_t r = idims.size();
+            if (nd.p[0] < 0 || nd.p[1] < 0 || r != nd.dims.size() || (size_t)nd.p[0] >= r || (size_t)nd.p[1] >= r) return bad("graph: MoveAxis axes");
+            std::vector<size_t> perm;
+            for (size_t a = 0; a < r; a++) if (a != (size_t)nd.p[0]) perm.push_back(a);
+            perm.insert(perm.begin() + nd.p[1], (size_t)nd.p[0]);
+            for (size_t a = 0; a < r; a++) if (nd.dims[a] != idims[perm[a]]) return bad("graph: MoveAxis output dims");
+            return ATLAS_OK;
+        }
+        case ATLAS_OP_BROADCAST: {
+            if (!need_inputs(1)) return bad("graph: one operand expected");
+            const std::vector<size_t>& idims = in_node(0).dims;
+            if (idims.size() > nd.dims.size()) return bad("graph: Broadcast rank");
+            const size_t off = nd.dims.size() - idims.size();
+            for (size_t a = off; a < nd.dims.size(); a++) if (idims[a - off] != nd.dims[a] && idims[a - off] != 1) return bad("graph: Broadcast dims");
+            return ATLAS_OK;
+        }
+        case ATLAS_OP_SLICE: {
+            if (!need_inputs(1)) return bad("graph: one operand expected");
+            const std::vector<size_t>& idims = in_node(0).dims;
+            if (nd.p[0] < 0 || nd.p[1] < 0 || nd.p[2] < 0) return bad("graph: Slice");
+            const size_t ax = (size_t)nd.p[0], st = (size_t)nd.p[1], en = (size_t)nd.p[2];
+            if (idims.size() != nd.dims.size() || ax >= idims.size() || en <= st || en > idims[ax] || nd.dims[ax] != en - st) return bad("graph: Slice");
+            for (size_t a = 0; a < idims.size(); a++) if (a != ax && idims[a] != nd.dims[a]) return bad("graph: Slice non-axis dimensions must match");
+            return ATLAS_OK;
+        }
+        case ATLAS_OP_CONCAT: {
+            const size_t r = nd.dims.size();
+            if (nd.inputs.empty() || nd.inputs.size() > 8 || nd.p[0] < 0 || (size_t)nd.p[0] >= r) return bad("graph: Concat takes 1..8 operands and an axis of the output");
+            size_t off = 0;
+            for (size_t k = 0; k < nd.inputs.size(); k++) {
+                const std::vector<size_t>& idims = in_node(k).dims;
+                if (idims.size() != r) return bad("graph: Concat operand rank");
+                for (size_t a = 0; a < r; a++) if (a != (size_t)nd.p[0] && idims[a] != nd.dims[a]) return bad("graph: Concat non-axis dimensions must match");
+                off += idims[(size_t)nd.p[0]];
+            }
+            return off == nd.dims[(size_t)nd.p[0]] ? ATLAS_OK : bad("graph: Concat output axis dimension must equal the sum of the operands'");
+        }
+        case ATLAS_OP_EINSUM: case ATLAS_OP_MUL: case ATLAS_OP_SQUARE: case ATLAS_OP_CUBE: {
+            const int64_t bits = nd.op == ATLAS_OP_EINSUM ? nd.p[1] : nd.op == ATLAS_OP_CUBE ? 2 * nd.p[0] : nd.p[0];
+            if (bits < 1 || bits > 30) return bad("graph: fused rescale needs 1 <= bits <= 30 (unfused building-block products are not modelled)");
+            if (!need_inputs(nd.op == ATLAS_OP_EINSUM || nd.op == ATLAS_OP_MUL ? 2 : 1)) return bad("graph: operand count");
+            if (nd.op != ATLAS_OP_EINSUM) return same_len() ? ATLAS_OK : bad("graph: element-wise operands must have the output's shape");
+            std::vector<size_t> od, la, ra; size_t K, lsk, rsk;
+            if (!gr::all_pow2(nd.shape) || atlas_rt_einsum_strides((int)nd.p[0], nd.shape, od, la, ra, K, lsk, rsk)) return bad("graph: einsum layout / dims");
+            size_t To = 1; for (size_t d : od) To *= d;
+            const size_t b = nd.shape.size() == 4 ? nd.shape[0] : 1, m = nd.shape.size() == 2 ? 1 : nd.shape[nd.shape.size() - 3], n = nd.shape.back();
+            if (To != T || gr::padded_len(in_node(0).dims) != b * m * K || gr::padded_len(in_node(1).dims) != b * K * n) return bad("graph: einsum operand / output sizes do not match its dims");
+            return ATLAS_OK;
+        }
+        case ATLAS_OP_SUM: {
+            if (!need_inputs(1) || nd.shape.size() != 1) return bad("graph: Sum needs one operand and one axis");
+            size_t m, n; int axis;
+            if (int rc = atlas_rt_sum_config(in_node(0).dims, nd.shape[0], m, n, axis)) return rc;
+            return T == (axis == 0 ? n : m) ? ATLAS_OK : bad("graph: Sum output dims");
+        }
+        case ATLAS_OP_SCALAR_CONST_DIV:
+            if (nd.p[0] == 0 || nd.p[0] > 2147483647ll || nd.p[0] < -2147483648ll) return bad("graph: ScalarConstDiv divisor");
+            return need_inputs(1) && same_len() ? ATLAS_OK : bad("graph: Div / ScalarConstDiv operands");
+        case ATLAS_OP_DIV: return need_inputs(2) && same_len() ? ATLAS_OK : bad("graph: Div / ScalarConstDiv operands");
+        case ATLAS_OP_MEAN_OF_SQUARES: {
+            if (!need_inputs(1) || nd.p[0] < 0 || nd.p[0] > 30) return bad("graph: MeanOfSquares operand / scale");
+            const size_t N = in_node(0).dims.back(), K = gr::padded_len(in_node(0).dims) / N;
+            const int64_t D = ((int64_t)1 << nd.p[0]) * nd.p[1];
+            return T == K && nd.p[1] > 0 && (size_t)nd.p[1] <= N && D <= 2147483647ll ? ATLAS_OK : bad("graph: MeanOfSquares dims / count / divisor");
+        }
+        case ATLAS_OP_RSQRT: return need_inputs(1) && same_len() && nd.p[0] > 0 && nd.p[0] <= 14 ? ATLAS_OK : bad("graph: Rsqrt operand / scale (1..14)");
+        case ATLAS_OP_TANH: case ATLAS_OP_ERF: case ATLAS_OP_SIGMOID: case ATLAS_OP_SIN: case ATLAS_OP_COS:
+            return need_inputs(1) && same_len() && nd.p[0] == (int64_t)gr::MODEL_SCALE ? ATLAS_OK
+                   : bad("graph: Tanh / Erf / Sigmoid / Sin / Cos need one operand and scale = MODEL_SCALE (14): the prover's tables and the period modulus are compiled for it");
+        case ATLAS_OP_GATHER_LARGE: case ATLAS_OP_GATHER_SMALL: {
+            if (!need_inputs(2) || nd.p[0] != 0) return bad("graph: Gather needs (dictionary, indexes) and axis 0");
+            const size_t V = in_node(0).dims[0], word = gr::padded_len(in_node(0).dims) / V, N = gr::padded_len(in_node(1).dims);
+            if (T != N * word || nd.p[1] < 0 || (size_t)nd.p[1] > V) return bad("graph: Gather dims / dict_len");
+            if (nd.op == ATLAS_OP_GATHER_SMALL && (V > 65536 || V < 2 || N < 2)) return bad("graph: GatherSmall is the tracer's choice for dictionaries of at most 2^16 words (handlers/index.rs:33-45)");
+            return ATLAS_OK;
+        }
+        case ATLAS_OP_SOFTMAX: {
+            if (!need_inputs(1) || !same_len() || nd.p[0] != (int64_t)gr::MODEL_SCALE)
+                return bad("graph: SoftmaxLastAxis needs one operand of the output's shape and scale = MODEL_SCALE (14): its clamp table is compiled for it");
+            const size_t N = nd.dims.back(), F = T / N;
+            return F >= 2 && N >= 2 && N <= 65536 ? ATLAS_OK : bad("graph: SoftmaxLastAxis needs at least two rows and 2 <= last axis <= 65536");
+        }
+        default: return bad("graph: operator not supported");
+    }
+}
+int atlas_rt_validate_graph(const atlas_graph& G) {
+    if (G.nodes.empty() || G.outputs.empty()) return fail(ATLAS_EINVAL, "graph: no nodes / no outputs");
+    for (auto& kv : G.nodes) if (int rc = atlas_rt_validate_node(G, kv.second)) return rc;
+    return ATLAS_OK;
+}
+
 namespace {
 
 int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs, size_t& next_input) {
+    if (int rc = atlas_rt_validate_node(G, nd)) return rc;
     const size_t T = gr::padded_len(nd.dims);
     DevBuf& out = G.out[nd.idx];
     if (nd.op == ATLAS_OP_CONSTANT && out.p) return ATLAS_OK;                 // uploaded by an earlier trace of this model

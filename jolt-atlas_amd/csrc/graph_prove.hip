@@ -1494,6 +1494,7 @@ extern "C" int atlas_prove_graph(atlas_graph_t G, atlas_srs_t srs, const int32_t
     NEED_INIT();
     if (!G || !srs || (!inputs && n_inputs) || !proof_len) return fail(ATLAS_EINVAL, "prove_graph: null argument");
     if (G->outputs.empty()) return fail(ATLAS_EINVAL, "prove_graph: no output node marked");
+    if (int vrc = atlas_rt_validate_graph(*G)) return vrc;
     auto now = [] { atlas_sync(); return std::chrono::steady_clock::now(); };
     const auto t0 = now();
     int rc = atlas_graph_trace(G, inputs, n_inputs);                          // pp.model().trace(inputs)

@@ -48,6 +48,11 @@ struct atlas_graph {
     }
 };
 
+// what exec_node would refuse, from the description alone (graph_exec.hip): called per node by the trace and, over the whole graph, by
+// atlas_prove_graph and atlas_verify_graph before they read a node's dims / parameters
+int atlas_rt_validate_node(const atlas_graph& G, const gr::Node& nd);
+int atlas_rt_validate_graph(const atlas_graph& G);
+
 // the small activation tables of Tanh / Erf / Sigmoid (ops/tanh.rs:22-32, erf.rs:22-32, sigmoid.rs:22-32 -> neural_teleport/utils.rs:67-85):
 // Table[i] = round(2^14 f(signed18(i) / 2^14)), built once on the host (the reference's f64 arithmetic) and kept in HBM; graph_exec.hip.
 // op = ATLAS_OP_TANH / ATLAS_OP_ERF / ATLAS_OP_SIGMOID

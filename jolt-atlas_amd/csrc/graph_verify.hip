@@ -1325,6 +1325,10 @@ extern "C" int atlas_verify_graph(atlas_graph_t G, const atlas_hyperkzg_vk_t* vk
     NEED_INIT();
     if (!G || !vk || (!inputs && n_inputs) || !output || !proof) return fail(ATLAS_EINVAL, "verify_graph: null argument");
     if (G->outputs.empty() || n_inputs != G->input_nodes().size()) return fail(ATLAS_EINVAL, "verify_graph: outputs / inputs");
+    // a verifier's graph is never traced: refuse here what the trace would refuse (operand shapes, axes, layouts, a scale or bound the
+    // compiled-in tables are not for), before any operator formula reads nd.dims / nd.p / nd.shape
+    if (int vrc = atlas_rt_validate_graph(*G)) return vrc;
+    for (size_t i = 0; i < n_inputs; i++) if (!inputs[i]) return fail(ATLAS_EINVAL, "verify_graph: null input tensor");
     Verifier V(*G, vk);
     V.inputs = inputs; V.output = output; V.output_len = output_len;
     int rc = atlas_transcript_new(&V.t, (const uint8_t*)"ONNXProof", 9);

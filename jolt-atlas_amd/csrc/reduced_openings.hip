@@ -90,8 +90,9 @@ extern "C" int atlas_prove_reduced_openings(const atlas_opening_t* openings, siz
         std::vector<uint64_t> lk(T);
         {
             std::lock_guard<atlas_rt::Mutex> lkg(atlas_rt::g.mu);
-            HIP_TRY(hipMemcpyAsync(lk.data(), O.d_lookups, T * 8, hipMemcpyDeviceToHost, atlas_rt::g.stream));
-            HIP_TRY(hipStreamSynchronize(atlas_rt::g.stream));
+            hipError_t e = hipMemcpyAsync(lk.data(), O.d_lookups, T * 8, hipMemcpyDeviceToHost, atlas_rt::g.stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(atlas_rt::g.stream);
+            if (e != hipSuccess) { rc = atlas_rt::fail(ATLAS_ENODEV, "prove_reduced_openings: lookup indices to the host", e); break; }   // falls through to cleanup()
         }
         host_rows.emplace_back(T);
         for (size_t j = 0; j < T; j++) host_rows.back()[j] = (int32_t)(O.chunk_shift >= 64 ? 0 : ((lk[j] >> O.chunk_shift) & (((uint64_t)1 << O.log_K) - 1)));

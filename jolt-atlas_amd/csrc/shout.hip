@@ -47,6 +47,13 @@ __device__ __forceinline__ uint32_t key_of(uint64_t idx, uint32_t i, KeySpec S) 
     return (i << S.log_k_chunk) + chunk;
 }
 
+// a lookup index of log_K bits or fewer?  ORs 1 into *flag otherwise (key_of masks the index, so an out-of-range one would wrap into the table)
+__global__ __launch_bounds__(SH_THREADS) void k_sh_range_flag(const uint64_t* __restrict__ idx, size_t T, uint32_t log_K, uint32_t* flag) {
+    uint32_t bad = 0;
+    for (size_t j = (size_t)blockIdx.x * SH_THREADS + threadIdx.x; j < T; j += (size_t)gridDim.x * SH_THREADS) bad |= (log_K < 64 && (idx[j] >> log_K)) ? 1u : 0u;
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
 __global__ __launch_bounds__(SH_THREADS) void k_sh_hist(const uint64_t* __restrict__ idx, size_t T, KeySpec S, uint32_t* counts) {
     for (size_t j = (size_t)blockIdx.x * SH_THREADS + threadIdx.x; j < T; j += (size_t)gridDim.x * SH_THREADS) {
         const uint64_t v = idx[j];
@@ -213,17 +220,29 @@ extern "C" {
 int atlas_shout_read_raf_G(const uint64_t* lookup_indices, size_t T, size_t log_K, atlas_poly_t eq_r, atlas_poly_t* out) {
     NEED_INIT();
     if ((!lookup_indices && T) || !eq_r || !out || log_K > 24) return fail(ATLAS_EINVAL, "shout_read_raf_G");
-    // host indices are range-checked here (the reference indexes the table with bounds checks); device-resident ones come from the
-    // library's own witness kernels — reading them through the host mapping of HBM costs ~1.3 us per element (21 ms of a Tanh node)
+    // the reference indexes the table with bounds checks.  Host indices are range-checked here; device-resident ones by a kernel that
+    // runs ahead of the histogram on the same stream (reading them through the host mapping of HBM costs ~1.3 us per element: 21 ms of a
+    // Tanh node), its flag read back after the histogram's own synchronisation
     hipPointerAttribute_t attr;
     const bool on_device = T && hipPointerGetAttributes(&attr, lookup_indices) == hipSuccess && attr.type == hipMemoryTypeDevice;
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    DevBuf flag;
     if (!on_device) {
         (void)hipGetLastError();
         for (size_t j = 0; j < T; j++)
             if (lookup_indices[j] >> log_K) return fail(ATLAS_EINVAL, "shout_read_raf_G: lookup index outside the table");
+    } else {
+        HIP_TRY(flag.alloc(4));
+        HIP_TRY(hipMemsetAsync(flag.p, 0, 4, g.stream));
+        k_sh_range_flag<<<grid_for(T), SH_THREADS, 0, g.stream>>>(lookup_indices, T, (uint32_t)log_K, flag.as<uint32_t>());
     }
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
-    return histogram(lookup_indices, T, KeySpec{1u, (uint32_t)log_K}, eq_r, out);
+    int rc = histogram(lookup_indices, T, KeySpec{1u, (uint32_t)log_K}, eq_r, out);
+    if (!rc && on_device) {
+        uint32_t bad = 0;
+        HIP_TRY(hipMemcpy(&bad, flag.p, 4, hipMemcpyDeviceToHost));
+        if (bad) { atlas_poly_free(*out); *out = nullptr; return fail(ATLAS_EINVAL, "shout_read_raf_G: lookup index outside the table"); }
+    }
+    return rc;
 }
 
 int atlas_shout_ra_evals(const uint64_t* lookup_indices, size_t T, size_t log_K, size_t log_k_chunk, atlas_poly_t eq_r_cycle,

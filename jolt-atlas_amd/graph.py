@@ -75,6 +75,13 @@ class Graph:
 
     def _inputs(self, inputs):
         arrs = [np.ascontiguousarray(x, dtype=np.int32).reshape(-1) for x in inputs]
+        # the C entry points read padded_len(dims) words from each pointer: a short array would be an out-of-bounds host read
+        in_nodes = [nd for nd in self.nodes if nd["op"] == "Input"]
+        if len(arrs) != len(in_nodes):
+            raise ValueError(f"{len(in_nodes)} input tensors expected (one per Input node), got {len(arrs)}")
+        for a, nd in zip(arrs, in_nodes):
+            if a.size != int(np.prod(nd["dims"])):
+                raise ValueError(f"input of node {nd['idx']}: {int(np.prod(nd['dims']))} elements expected for dims {nd['dims']}, got {a.size}")
         ptrs = (C.POINTER(C.c_int32) * max(len(arrs), 1))(*[a.ctypes.data_as(C.POINTER(C.c_int32)) for a in arrs])
         return arrs, ptrs
 

@@ -181,12 +181,22 @@ def challenge_to_fr(c128):
 G1_DTYPE = np.dtype([("x", np.uint64, (4,)), ("y", np.uint64, (4,)), ("infinity", np.uint64)])  # g1_aff_t
 
 
+_SRS_CACHE = {}
+
+
 def srs_powers(tau_fr, n):
-    """bases[i] = tau^(i+1) * G as a G1_DTYPE array (orc_srs_powers)."""
-    out = np.zeros(n, dtype=G1_DTYPE)
+    """bases[i] = tau^(i+1) * G as a G1_DTYPE array (orc_srs_powers).  The powers of one tau are prefixes of each other, so the longest
+    request per tau is kept and shorter ones are slices of it (a test session asks for the same tau at many sizes)."""
     t = np.ascontiguousarray(tau_fr, dtype=np.uint64).reshape(1, 4)
-    lib.orc_srs_powers(_p(t), C.c_size_t(n), out.ctypes.data_as(C.c_void_p))
-    return out
+    key = t.tobytes()
+    have = _SRS_CACHE.get(key)
+    if have is None or len(have) < n:
+        out = np.zeros(n, dtype=G1_DTYPE)
+        lib.orc_srs_powers(_p(t), C.c_size_t(n), out.ctypes.data_as(C.c_void_p))
+        if n <= (1 << 18):
+            _SRS_CACHE[key] = out
+        return out.copy()
+    return have[:n].copy()
 
 
 def msm(bases, scalars, naive=False):

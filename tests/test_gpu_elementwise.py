@@ -8,6 +8,9 @@ _EW = {"add": (0, 2), "sub": (1, 2), "neg": (2, 1), "square": (3, 1), "iff": (4,
        "div": (7, 4), "rsqrt": (8, 5), "dot": (9, 6), "gather": (10, 3), "hamming_bool": (11, 5), "teleport_div": (12, 3)}
 
 
+_ORACLE = {}
+
+
 def _operands(orc, op, n, seed, as_i32):
     rng = np.random.default_rng(seed)
     n_ops = _EW[op][1]
@@ -15,7 +18,8 @@ def _operands(orc, op, n, seed, as_i32):
     if op == "iff":
         ints[0] = rng.integers(0, 2, size=n, dtype=np.int64)
     if as_i32:
-        return ints, [orc.from_ints([int(x) for x in v]) for v in ints]
+        from oracle import graph as OG
+        return ints, [OG.fr_fast(v.astype(np.int32)) for v in ints]     # orc_i32_to_fr (pinned against the Python integers in tests/test_oracle_golden.py)
     full = [orc.random_fr(n, seed + 10 + i) for i in range(n_ops)]
     return None, full
 
@@ -41,9 +45,13 @@ def test_elementwise_bit_exact(atlas, op, n_vars, as_i32, mode, pipe):
         claim = orc.random_fr(1, 4)[0]            # the driver never checks s(0) + s(1) = claim; Gruen uses it as given
         consts = np.stack([orc.from_ints([1 << 42])[0], orc.random_fr(1, 8)[0]]) if op == "rsqrt" else \
             orc.random_fr(1, 8) if op == "gather" else orc.random_fr(5, 8) if op == "hamming_bool" else orc.from_ints([12345]) if op == "teleport_div" else None
-        o = OR.elementwise(code, ops_fr, r_node, consts)
-        t_o = orc.new_transcript(b"ew")
-        rows_o, ch_o = o.prove(claim, t_o)
+        key = (op, n_vars, as_i32, mode)                 # the oracle's proof does not depend on how the device is driven: once per case
+        if key not in _ORACLE:
+            o = OR.elementwise(code, ops_fr, r_node, consts)
+            t_o = orc.new_transcript(b"ew")
+            rows_o, ch_o = o.prove(claim, t_o)
+            _ORACLE[key] = (rows_o, ch_o, t_o.state_bytes(), o.finals())
+        rows_o, ch_o, state_o, finals_o = _ORACLE[key]
         polys = [A.MultilinearPolynomial.from_i32(v.astype(np.int32)) for v in ints] if as_i32 else \
                 [A.MultilinearPolynomial.from_fr(v) for v in ops_fr]
         inst = I.elementwise(code, polys, r_node, consts)
@@ -52,8 +60,8 @@ def test_elementwise_bit_exact(atlas, op, n_vars, as_i32, mode, pipe):
         rows_g, ch_g = inst.prove(claim, t_g)
         assert ch_g == ch_o
         assert len(rows_g) == len(rows_o) and all(np.array_equal(a, b) for a, b in zip(rows_g, rows_o))
-        assert t_g.state == t_o.state_bytes()
-        assert np.array_equal(np.stack(inst.final_claims()), o.finals())
+        assert t_g.state == state_o
+        assert np.array_equal(np.stack(inst.final_claims()), finals_o)
         for p_, v in zip(polys, ops_fr):          # operands are not consumed
             if not as_i32:
                 assert np.array_equal(p_.to_host(), v)

@@ -1,0 +1,62 @@
+"""GPU: ONNXProof::prove at the model shapes of BASELINE.json (config 1: microgpt-shaped; config 3: nanoGPT-shaped; one GPT-2 layer)
+against COMMITTED oracle results (tests/golden/graph_proofs.json, made in the build container by tests/golden/gen_graph_proofs.py:
+oracle/graph.py takes minutes on these graphs, so the GPU box does not recompute it): per-node trace hashes, sha256 of the proof bytes,
+the final transcript state, the number of committed polynomials — then ONNXProof::verify of the device's proof.
+
+What is pinned: the device against the in-repo oracle composition (not against a run of the reference)."""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "graph_proofs.json")))
+
+
+def _build(name):
+    import build_graphs as BG
+    return {"microgpt": BG.microgpt, "nanogpt": BG.nanogpt, "gpt2_layer": BG.gpt2_layer, "tiny4": lambda: BG.tiny(layers=4), "tiny2": lambda: BG.tiny(layers=2),
+            "node_einsum": BG.node_einsum, "node_relu": BG.node_relu, "node_mul": BG.node_mul}[name]()
+
+
+def _h(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.int32).tobytes()).hexdigest()[:16]
+
+
+@pytest.mark.parametrize("name", ["microgpt", "tiny2", "tiny4", "nanogpt", "gpt2_layer", "node_einsum", "node_relu", "node_mul"])
+def test_model_shaped_proof_matches_committed_oracle_result(atlas, name):
+    import build_graphs as BG
+    from oracle import orc
+    from jolt_atlas_amd import graph as GG
+    if name not in GOLD["graphs"]:
+        pytest.fail(f"tests/golden/graph_proofs.json has no entry for {name}: run tests/golden/gen_graph_proofs.py {name}")
+    want = GOLD["graphs"][name]
+    nodes, outputs, inputs = _build(name)
+    assert len(nodes) == want["n_nodes"] and [_h(x) for x in inputs] == want["input_sha256"], "the builder no longer yields the graph the fixture was made from"
+    nv = BG.max_vars(nodes)
+    assert nv == want["max_vars"]
+    tau = orc.random_fr(1, GOLD["tau_seed"])[0]
+    srs = atlas.SRS.generate(tau, 1 << nv)
+    G = GG.Graph(nodes, outputs)
+    G.trace(inputs)
+    for nd, hw in zip(nodes, want["trace"]):
+        assert _h(G.node_output(nd["idx"])) == hw, f"trace of node {nd['idx']} ({nd['op']})"
+    proof, state, tm = G.prove(srs, inputs)
+    assert tm["n_committed"] == want["n_committed"]
+    assert state.hex() == want["state"], "final transcript state"
+    assert len(proof) == want["proof_len"] and hashlib.sha256(proof).hexdigest() == want["proof_sha256"], "ONNXProof bytes"
+    # ONNXProof::verify on a graph that was never traced
+    vk = atlas.HyperKZG.vk_from_trapdoor(tau, srs.download(0, 1)[0])
+    out = G.node_output(outputs[0])
+    V = GG.Graph(nodes, outputs)
+    ok, vstate = V.verify(vk, inputs, out, proof)
+    assert ok and vstate == state
+    bad = out.copy(); bad[len(bad) // 2] ^= 1
+    assert not V.verify(vk, inputs, bad, proof)[0]
+    G.free(); V.free(); srs.free()

@@ -98,9 +98,11 @@ def _fr_ints(orc, v):
     return orc.from_ints([int(x) % FR for x in v])
 
 
-# the last two cases are the sizes bench.py times (T = 2^12 and the GPT-2 MLP projection 16 x 1024 . 1024 x 4096, T = 2^16, scale 2^14): the
-# k-sliced accumulation kernel with 64-bit atomics, k_ra_prod_f9 / _col at d = 16, the 96 KB-LDS Q build of the 64-bit clamp lookup
-@pytest.mark.parametrize("m,k,n,S", [(2, 8, 16, 6), (4, 4, 4, 4), (1, 16, 32, 7), (4, 64, 1024, 14), (16, 1024, 4096, 14)])
+# the last case is the smaller size bench.py times (T = 2^12, scale 2^14).  The bench's T = 2^16 shapes (16 x 1024 . 1024 x 4096: the k-sliced
+# accumulation kernel with 64-bit atomics, k_ra_prod_f9 / _col at d = 16, the 96 KB-LDS Q build of the 64-bit clamp lookup; ReLU and Mul over
+# 2^16 elements) run as one-operator graphs against COMMITTED oracle results in tests/test_gpu_graph_golden.py (node_einsum / node_relu /
+# node_mul): the oracle side of those three cases cost the GPU box 117 s per run here.
+@pytest.mark.parametrize("m,k,n,S", [(2, 8, 16, 6), (4, 4, 4, 4), (1, 16, 32, 7), (4, 64, 1024, 14)])
 def test_einsum_node_matches_oracle_composition(atlas, m, k, n, S):
     from oracle import orc, orc_ra as OR, orc_batched as OB
     from jolt_atlas_amd import node
@@ -175,7 +177,7 @@ def sum_fr(orc, xs):
     return s
 
 
-@pytest.mark.parametrize("log_T", [3, 6, 9, 12, 16])
+@pytest.mark.parametrize("log_T", [3, 6, 9, 12])
 def test_relu_node_matches_oracle_composition(atlas, log_T):
     """ReLU::prove (ops/relu.rs:22-70) through atlas_prove_relu_node against the same composition over the oracle's instances:
     operand claim appended, gamma, PS-Shout over ReluTable<32>, its ra opening, the batched one-hot checks and their claims."""
@@ -250,7 +252,7 @@ def _fused_rescale_oracle(orc, OR, OB, label, acc, S, r0, inner):
     return [rows_exec, rows_oh, rows_inner, rows_rc, rows_oh2], claims, t
 
 
-@pytest.mark.parametrize("log_T,S", [(3, 5), (6, 7), (8, 4), (12, 14), (16, 14)])
+@pytest.mark.parametrize("log_T,S", [(3, 5), (6, 7), (8, 4), (12, 14)])
 def test_mul_node_matches_oracle_composition(atlas, log_T, S):
     """Mul::prove with fused rescaling (ops/mul.rs via impl_fused_rescale_proof_api) through atlas_prove_mul_node against the
     same composition over the oracle's instances: MulProver between prove_pre and prove_remainder_rc."""

@@ -5,6 +5,7 @@ atlas-onnx-tracer/src/node/mod.rs:12-24, ops/mod.rs:117-155), built with synthet
                         (atlas-onnx-tracer/models/nanoGPT/network.onnx: MatMul -> Einsum, Pow -> Square / Cube, ReduceMean ->
                         Sum + ScalarConstDiv / MeanOfSquares, Sqrt + Div -> Rsqrt, Where -> Iff, tanh-GELU -> Cube / Mul / Tanh,
                         Softmax -> SoftmaxLastAxis, Gather -> GatherSmall for dictionaries of at most 2^16 words, handlers/index.rs:33-45), shapes padded to powers of two (vocab 65 -> 128)
+  microgpt()            seq 16, d_model 16, 4 heads, 1 layer, vocab 32; RMSNorm, ReLU MLP, no biases   (BASELINE config 1 shape)
   nanogpt()             seq 64, d_model 64, 4 heads, 4 layers, vocab 128   (BASELINE config 3 shape)
   gpt2_layer()          seq 16, d_model 768 -> 1024, 12 -> 16 heads, one layer + lm-head slice (BASELINE config 4 shape, one layer)
   gpt2()                the same with all 12 layers and the whole (padded) vocabulary: 2^16-word embedding and lm head
@@ -38,7 +39,8 @@ class B:
         return self.add("Einsum", [x, w], [m, n], layout="mk,kn->mn", scale=S, shape=[m, k, n])
 
 
-def transformer(layers, seq, d_model, heads, vocab, S=14, level=2, seed=0, mlp_mult=4, final_head=True):
+def transformer(layers, seq, d_model, heads, vocab, S=14, level=2, seed=0, mlp_mult=4, final_head=True, norm_kind="layer", act="gelu",
+                bias=True, norm0=False, final_norm=True, att_scale=False, mask_fill=None):
     b = B(seed)
     hd = d_model // heads
     wlim = 1 << (S - 2)                      # weights ~ U(-0.25, 0.25) at scale S
@@ -53,7 +55,7 @@ def transformer(layers, seq, d_model, heads, vocab, S=14, level=2, seed=0, mlp_m
         x = b.add("Input", [], [seq, d_model])
     mask = b.const_data([seq, seq], np.tril(np.ones((seq, seq), dtype=np.int32)))
     maskb = b.add("Broadcast", [mask], [heads, seq, seq])
-    neg = b.const_data([heads, seq, seq], np.full(heads * seq * seq, -(1 << (S + 3)), dtype=np.int32))
+    neg = b.const_data([heads, seq, seq], np.full(heads * seq * seq, -(1 << (S + 3)) if mask_fill is None else mask_fill, dtype=np.int32))
 
     def full(dims, v):
         return b.const_data(dims, np.full(int(np.prod(dims)), v, dtype=np.int32))
@@ -62,6 +64,11 @@ def transformer(layers, seq, d_model, heads, vocab, S=14, level=2, seed=0, mlp_m
         """LayerNorm: (h - mean) * rsqrt(mean((h - mean)^2) + eps) * w + bias"""
         if level < 1:
             return h
+        if norm_kind == "rms":               # RMSNorm without learned parameters: h * rsqrt(mean(h^2) + eps)   (models/microgpt/gen.py:29-37)
+            ms = b.add("MeanOfSquares", [h], [seq, 1], axes=[1], scale=S, count=d_model)
+            ms = b.add("Add", [ms, full([seq, 1], 1)], [seq, 1])
+            rs = b.add("Rsqrt", [ms], [seq, 1], scale=S)
+            return b.add("Mul", [h, b.add("Broadcast", [rs], [seq, d_model])], [seq, d_model], scale=S)
         s = b.add("Sum", [h], [seq, 1], axes=[1])
         mean = b.add("ScalarConstDiv", [s], [seq, 1], divisor=d_model)
         c = b.add("Sub", [h, b.add("Broadcast", [mean], [seq, d_model])], [seq, d_model])
@@ -75,7 +82,7 @@ def transformer(layers, seq, d_model, heads, vocab, S=14, level=2, seed=0, mlp_m
 
     def gelu(f):
         """tanh-GELU: 0.5 f (1 + tanh(0.79788 (f + 0.044715 f^3)))"""
-        if level < 2:
+        if level < 2 or act == "relu":
             return b.add("ReLU", [f], [seq, ff])
         f3 = b.add("Cube", [f], [seq, ff], scale=S)
         u = b.add("Add", [f, b.add("Mul", [f3, full([seq, ff], int(0.044715 * one))], [seq, ff], scale=S)], [seq, ff])
@@ -85,6 +92,8 @@ def transformer(layers, seq, d_model, heads, vocab, S=14, level=2, seed=0, mlp_m
         hx = b.add("Mul", [f, full([seq, ff], one // 2)], [seq, ff], scale=S)
         return b.add("Mul", [hx, w], [seq, ff], scale=S)
 
+    if norm0:
+        x = norm(x)
     for _ in range(layers):
         h = norm(x)
         # attention: q, k, v projections (one Einsum each: the tracer splits the fused qkv Gemm through Slice nodes)
@@ -95,6 +104,8 @@ def transformer(layers, seq, d_model, heads, vocab, S=14, level=2, seed=0, mlp_m
         kh = b.add("Reshape", [k], [seq, heads, hd])
         vh = b.add("Reshape", [v], [seq, heads, hd])
         att = b.add("Einsum", [qh, kh], [heads, seq, seq], layout="mbk,nbk->bmn", scale=S, shape=[heads, seq, hd, seq])
+        if att_scale:                        # (q k^T) * (1 / sqrt(head_dim)) as a fused-rescale Mul by a constant
+            att = b.add("Mul", [att, full([heads, seq, seq], int(round(one / np.sqrt(hd))))], [heads, seq, seq], scale=S)
         att = b.add("Iff", [maskb, att, neg], [heads, seq, seq])
         att = b.add("SoftmaxLastAxis", [att], [heads, seq, seq], scale=S) if level >= 2 and S == 14 else b.add("ReLU", [att], [heads, seq, seq])
         y = b.add("Einsum", [att, vh], [seq, heads, hd], layout="bmk,kbn->mbn", scale=S, shape=[heads, seq, seq, hd])
@@ -104,11 +115,13 @@ def transformer(layers, seq, d_model, heads, vocab, S=14, level=2, seed=0, mlp_m
         # MLP
         h = norm(x)
         f = b.matmul(h, b.const([d_model, ff], -wlim, wlim), seq, d_model, ff, S)
-        f = b.add("Add", [f, b.add("Broadcast", [b.const([ff], -wlim, wlim)], [seq, ff])], [seq, ff])
+        if bias:
+            f = b.add("Add", [f, b.add("Broadcast", [b.const([ff], -wlim, wlim)], [seq, ff])], [seq, ff])
         f = gelu(f)
         f = b.matmul(f, b.const([ff, d_model], -wlim, wlim), seq, ff, d_model, S)
         x = b.add("Add", [x, f], [seq, d_model])
-    x = norm(x)
+    if final_norm:
+        x = norm(x)
     if final_head:
         x = b.matmul(x, b.const([d_model, vocab], -wlim, wlim), seq, d_model, vocab, S)
     rng = np.random.default_rng(seed + 1)
@@ -118,6 +131,14 @@ def transformer(layers, seq, d_model, heads, vocab, S=14, level=2, seed=0, mlp_m
 
 def nanogpt(level=2, seed=0):
     return transformer(layers=4, seq=64, d_model=64, heads=4, vocab=128, level=level, seed=seed)
+
+
+def microgpt(level=2, seed=0):
+    """the shape of atlas-onnx-tracer/models/microgpt (gen.py:180-186; jolt-atlas-core/examples/microgpt.rs:20-31): vocab 32, n_embd 16, 4 heads,
+    1 layer, block 16; RMSNorm without parameters (one right after the embedding, none before the head), ReLU MLP, no biases, the 1/sqrt(head_dim)
+    score scale, masked scores filled with -10 (BASELINE config 1 shape)"""
+    return transformer(layers=1, seq=16, d_model=16, heads=4, vocab=32, level=level, seed=seed, norm_kind="rms", act="relu", bias=False, norm0=True,
+                       final_norm=False, att_scale=True, mask_fill=-10 * (1 << 14))
 
 
 def gpt2_layer(level=2, seed=0):
@@ -132,6 +153,36 @@ def gpt2(level=2, seed=0):
 
 def tiny(level=2, seed=0, layers=2):
     return transformer(layers=layers, seq=4, d_model=8, heads=2, vocab=16, level=level, seed=seed, mlp_mult=2)
+
+
+def _node_rng():
+    return np.random.default_rng(15)
+
+
+def _rnd(rng, n):
+    return rng.integers(-(1 << 14), 1 << 14, size=n, dtype=np.int64).astype(np.int32)
+
+
+def node_einsum():
+    """one operator at the size bench.py times: the GPT-2 MLP projection 16 x 1024 . 1024 x 4096 at scale 2^14 (T = 2^16, k = 1024)"""
+    rng = _node_rng()
+    w = _rnd(rng, 1024 * 4096)
+    return [{"idx": 0, "op": "Input", "inputs": [], "dims": [16, 1024]},
+            {"idx": 1, "op": "Constant", "inputs": [], "dims": [1024, 4096], "data": w},
+            {"idx": 2, "op": "Einsum", "inputs": [0, 1], "dims": [16, 4096], "layout": "mk,kn->mn", "scale": 14, "shape": [16, 1024, 4096]}], [2], [_rnd(rng, 16 * 1024)]
+
+
+def node_relu():
+    rng = _node_rng()
+    return [{"idx": 0, "op": "Input", "inputs": [], "dims": [16, 4096]}, {"idx": 1, "op": "ReLU", "inputs": [0], "dims": [16, 4096]}], [1], [_rnd(rng, 1 << 16)]
+
+
+def node_mul():
+    rng = _node_rng()
+    c = _rnd(rng, 1 << 16)
+    return [{"idx": 0, "op": "Input", "inputs": [], "dims": [16, 4096]},
+            {"idx": 1, "op": "Constant", "inputs": [], "dims": [16, 4096], "data": c},
+            {"idx": 2, "op": "Mul", "inputs": [0, 1], "dims": [16, 4096], "scale": 14}], [2], [_rnd(rng, 1 << 16)]
 
 
 NO_COMMIT = {"Input", "Constant", "Identity", "Reshape", "MoveAxis", "Broadcast", "Slice", "Iff", "And", "Concat"}
