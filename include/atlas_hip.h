@@ -794,6 +794,14 @@ typedef struct {
 } atlas_graph_timing_t;
 int atlas_prove_graph(atlas_graph_t g, atlas_srs_t srs, const int32_t *const *inputs, size_t n_inputs, uint8_t *proof, size_t cap,
                       size_t *proof_len, atlas_transcript_t *final_transcript, atlas_graph_timing_t *timing);
+/* ONNXProof::prove over the GPUs of a node, one process per GPU (BASELINE config 4): every rank of `grp` holds the model, the inputs
+ * and the SRS and makes this call with the same arguments.  The trace and the IOP run on every rank (a serial Fiat-Shamir chain);
+ * commit_witness_polynomials is split by polynomial range (jolt-atlas-core/src/onnx_proof/prover.rs:71-87) and the commitment groups of
+ * HyperKZG::open over the joint polynomial by point range (prover.rs:141-176; joltworks/src/poly/commitment/hyperkzg/mod.rs:400-447);
+ * partial results cross the shared-memory board of the group.  Every rank returns the same bytes as atlas_prove_graph on one GPU. */
+int atlas_prove_graph_sharded(atlas_graph_t g, atlas_srs_t srs, atlas_shard_group_t grp, const int32_t *const *inputs, size_t n_inputs,
+                              uint8_t *proof, size_t cap, size_t *proof_len, atlas_transcript_t *final_transcript,
+                              atlas_graph_timing_t *timing);
 
 /* EvalReductionInstance::verify (joltworks/src/subprotocols/evaluation_reduction.rs:150-210): the verifier's half of
  * atlas_eval_reduction_prove.  h = the proof's polynomial (ignored for N = 1).  ATLAS_EVERIFY = InvalidOpeningProof. */

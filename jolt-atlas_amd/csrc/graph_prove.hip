@@ -14,6 +14,8 @@
 #include <algorithm>
 
 #include "graph_state.hip.h"
+#include "internal.hpp"
+#include "shard_group.hpp"
 
 using gr::Node;
 using gr::OpeningId;
@@ -68,6 +70,7 @@ struct Prover : FlowSink {
     std::map<gr::ProofId, std::vector<uint8_t>> proofs;
     std::map<size_t, std::vector<H::Fr>> evalred;         // eval_reduction_proofs: h coefficients
     uint64_t cur = 0;
+    atlas_shard_group* sh = nullptr;                      // the ranks of a sharded whole proof (atlas_prove_graph_sharded); NULL: one GPU
 
     Prover(atlas_graph& g_, atlas_srs_t s) : G(g_), srs(s), Tr(*reinterpret_cast<H::Transcript*>(&t)) {}
 
@@ -274,7 +277,29 @@ struct Prover : FlowSink {
             size_t total = 0;
             for (auto& f : fams) total += (f.log_K + 3) / 4;
             std::vector<atlas_g1_affine_t> pts(total);
-            int rc = atlas_commit_lookup_chunks_multi(srs, fams.data(), fams.size(), 4, pts.data());
+            int rc = ATLAS_OK;
+            if (!sh || sh->world < 2) rc = atlas_commit_lookup_chunks_multi(srs, fams.data(), fams.size(), 4, pts.data());
+            else {
+                // commit_witness_polynomials by polynomial range over the ranks (prover.rs:71-87 commits them independently): a
+                // contiguous range of families per rank, cut where the running cost d T (chunk polynomials x cycles = point additions) passes
+                // rank / world of the total; every rank commits its range against its copy of the SRS, the commitments cross the board.
+                const size_t world = (size_t)sh->world, rank = (size_t)sh->rank;
+                std::vector<double> pre(fams.size() + 1, 0.0);
+                for (size_t f = 0; f < fams.size(); f++) pre[f + 1] = pre[f] + (double)((fams[f].log_K + 3) / 4) * (double)((size_t)1 << fams[f].log_T);
+                std::vector<size_t> cut(world + 1, fams.size());
+                cut[0] = 0;
+                for (size_t r = 1, f = 0; r < world; r++) { while (f < fams.size() && pre[f] < pre.back() * (double)r / (double)world) f++; cut[r] = f; }
+                std::vector<size_t> row0(fams.size() + 1, 0);
+                for (size_t f = 0; f < fams.size(); f++) row0[f + 1] = row0[f] + (fams[f].log_K + 3) / 4;
+                size_t max_rows = 0;
+                for (size_t r = 0; r < world; r++) max_rows = std::max(max_rows, row0[cut[r + 1]] - row0[cut[r]]);
+                std::vector<atlas_g1_affine_t> mine(max_rows), all(max_rows * world);
+                std::memset(mine.data(), 0, mine.size() * sizeof(atlas_g1_affine_t));
+                if (cut[rank + 1] > cut[rank]) rc = atlas_commit_lookup_chunks_multi(srs, fams.data() + cut[rank], cut[rank + 1] - cut[rank], 4, mine.data());
+                if (rc) return rc;
+                if (!sh->allgather_bulk(mine.data(), max_rows * sizeof(atlas_g1_affine_t), all.data())) return fail(ATLAS_ENODEV, "prove_graph_sharded: a rank did not answer (commitments)");
+                for (size_t r = 0; r < world; r++) std::memcpy(pts.data() + row0[cut[r]], all.data() + r * max_rows, (row0[cut[r + 1]] - row0[cut[r]]) * sizeof(atlas_g1_affine_t));
+            }
             if (rc) return rc;
             size_t o = 0;
             for (size_t f = 0; f < fams.size(); f++) { const size_t d = (fams[f].log_K + 3) / 4; for (size_t q = 0; q < d; q++) first[f][q].commitment = pts[o++]; }
@@ -1439,8 +1464,8 @@ struct Prover : FlowSink {
         for (auto& O : ops) { const size_t n = O.kind ? O.log_K + O.log_T : O.n; maxr = n > maxr ? n : maxr; }
         ro.rows.resize(maxr * 3); ro.nco.resize(maxr); ro.ch.resize(maxr); ro.claims.resize(ops.size());
         ro.com.resize(maxr ? maxr - 1 : 0); ro.w.resize(3); ro.v.resize(3 * maxr);
-        int rc = atlas_prove_reduced_openings(ops.data(), ops.size(), srs, &t, ro.rows.data(), ro.nco.data(), ro.ch.data(), &ro.rounds, ro.claims.data(),
-                                              ro.com.data(), ro.w.data(), ro.v.data());
+        int rc = atlas_rt_prove_reduced_openings(ops.data(), ops.size(), srs, &t, ro.rows.data(), ro.nco.data(), ro.ch.data(), &ro.rounds, ro.claims.data(),
+                                                 ro.com.data(), ro.w.data(), ro.v.data(), sh && sh->world > 1 ? sh : nullptr);
         ro.present = rc == ATLAS_OK;
         return rc;
     }
@@ -1489,8 +1514,8 @@ struct Prover : FlowSink {
 
 }  // namespace
 
-extern "C" int atlas_prove_graph(atlas_graph_t G, atlas_srs_t srs, const int32_t* const* inputs, size_t n_inputs, uint8_t* proof, size_t cap, size_t* proof_len,
-                                 atlas_transcript_t* final_transcript, atlas_graph_timing_t* timing) {
+static int prove_graph_impl(atlas_graph_t G, atlas_srs_t srs, atlas_shard_group_t sh, const int32_t* const* inputs, size_t n_inputs, uint8_t* proof, size_t cap,
+                            size_t* proof_len, atlas_transcript_t* final_transcript, atlas_graph_timing_t* timing) {
     NEED_INIT();
     if (!G || !srs || (!inputs && n_inputs) || !proof_len) return fail(ATLAS_EINVAL, "prove_graph: null argument");
     if (G->outputs.empty()) return fail(ATLAS_EINVAL, "prove_graph: no output node marked");
@@ -1501,6 +1526,7 @@ extern "C" int atlas_prove_graph(atlas_graph_t G, atlas_srs_t srs, const int32_t
     if (rc) return rc;
     const auto t1 = now();
     Prover P(*G, srs);
+    P.sh = sh;
     rc = atlas_transcript_new(&P.t, (const uint8_t*)"ONNXProof", 9);
     if (rc) return rc;
     {   // append_inputs_to_transcript (onnx_proof/mod.rs:90-122)
@@ -1548,4 +1574,19 @@ extern "C" int atlas_prove_graph(atlas_graph_t G, atlas_srs_t srs, const int32_t
         timing->n_nodes = G->nodes.size(); timing->n_committed = P.committed.size(); timing->n_sumchecks = P.proofs.size() + (P.ro.present ? 1 : 0);
     }
     return ATLAS_OK;
+}
+
+extern "C" int atlas_prove_graph(atlas_graph_t G, atlas_srs_t srs, const int32_t* const* inputs, size_t n_inputs, uint8_t* proof, size_t cap, size_t* proof_len,
+                                 atlas_transcript_t* final_transcript, atlas_graph_timing_t* timing) {
+    return prove_graph_impl(G, srs, nullptr, inputs, n_inputs, proof, cap, proof_len, final_transcript, timing);
+}
+// ONNXProof::prove with the ranks of a shard group (one process per GPU, BASELINE config 4): every rank holds the model, the inputs and the SRS and
+// calls this with the same arguments.  The trace and the IOP (a serial Fiat-Shamir chain of latency-bound sumchecks) run on every rank; the stages
+// that are sums over independent terms are split: commit_witness_polynomials by polynomial range (prover.rs:71-87), the four commitment groups of
+// HyperKZG::open over the joint polynomial by point range (prover.rs:141-176, hyperkzg/mod.rs:400-447).  Partial results cross the shared-memory
+// board, every rank runs the same transcript and returns the SAME proof bytes as atlas_prove_graph on one GPU.
+extern "C" int atlas_prove_graph_sharded(atlas_graph_t G, atlas_srs_t srs, atlas_shard_group_t grp, const int32_t* const* inputs, size_t n_inputs, uint8_t* proof,
+                                         size_t cap, size_t* proof_len, atlas_transcript_t* final_transcript, atlas_graph_timing_t* timing) {
+    if (!grp) return fail(ATLAS_EINVAL, "prove_graph_sharded: null group");
+    return prove_graph_impl(G, srs, grp, inputs, n_inputs, proof, cap, proof_len, final_transcript, timing);
 }

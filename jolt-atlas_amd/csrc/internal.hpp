@@ -10,3 +10,7 @@ int atlas_rt_shout_ra_evals_host(const uint64_t* lookup_indices, size_t T, size_
                                  std::vector<atlas_host::Fr>& G);
 // wall clock of the HyperKZG::open inside the last atlas_prove_reduced_openings call (reduced_openings.hip)
 double atlas_rt_last_hyperkzg_ms();
+// atlas_prove_reduced_openings with the ranks of a sharded whole proof (NULL: one GPU); reduced_openings.hip
+int atlas_rt_prove_reduced_openings(const atlas_opening_t* openings, size_t n_open, atlas_srs_t srs, atlas_transcript_t* transcript, atlas_fr_t* sumcheck_rows,
+                                    uint32_t* n_coeffs, atlas_u128_t* challenges, size_t* max_rounds_out, atlas_fr_t* sumcheck_claims, atlas_g1_affine_t* com,
+                                    atlas_g1_affine_t* w, atlas_fr_t* v, atlas_shard_group_t sh);

@@ -27,10 +27,12 @@ int atlas_rt_onehot_pool_new(const atlas_rt_pool_row* in, size_t n, size_t log_K
 static double g_last_open_ms = 0;
 double atlas_rt_last_hyperkzg_ms() { return g_last_open_ms; }
 
-extern "C" int atlas_prove_reduced_openings(const atlas_opening_t* openings, size_t n_open, atlas_srs_t srs,
-                                            atlas_transcript_t* transcript, atlas_fr_t* sumcheck_rows, uint32_t* n_coeffs,
-                                            atlas_u128_t* challenges, size_t* max_rounds_out, atlas_fr_t* sumcheck_claims,
-                                            atlas_g1_affine_t* com, atlas_g1_affine_t* w, atlas_fr_t* v) {
+// `sh` (may be NULL): the ranks of a sharded whole proof (atlas_prove_graph_sharded).  Every rank runs the reduction sumcheck and builds the
+// joint polynomial; the opening's commitment groups are split by point range over the ranks (atlas_hyperkzg_open_sharded).
+int atlas_rt_prove_reduced_openings(const atlas_opening_t* openings, size_t n_open, atlas_srs_t srs,
+                                    atlas_transcript_t* transcript, atlas_fr_t* sumcheck_rows, uint32_t* n_coeffs,
+                                    atlas_u128_t* challenges, size_t* max_rounds_out, atlas_fr_t* sumcheck_claims,
+                                    atlas_g1_affine_t* com, atlas_g1_affine_t* w, atlas_fr_t* v, atlas_shard_group_t sh) {
     NEED_INIT();
     if (!openings || n_open == 0 || !srs || !transcript || !sumcheck_rows || !n_coeffs || !challenges || !max_rounds_out ||
         !sumcheck_claims || !com || !w || !v)
@@ -166,10 +168,18 @@ extern "C" int atlas_prove_reduced_openings(const atlas_opening_t* openings, siz
     // PCS::prove(generators, &rlc, &r_sumcheck, None, transcript) = HyperKZG::open
     atlas_sync();
     const auto t_open = std::chrono::steady_clock::now();
-    if (!rc) rc = atlas_hyperkzg_open(srs, joint, challenges, *max_rounds_out, transcript, com, w, v);
+    if (!rc) rc = sh ? atlas_hyperkzg_open_sharded(srs, sh, joint, challenges, *max_rounds_out, transcript, com, w, v)
+                     : atlas_hyperkzg_open(srs, joint, challenges, *max_rounds_out, transcript, com, w, v);
     atlas_sync();
     g_last_open_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_open).count();
     mark("HyperKZG::open");
     cleanup();
     return rc;
+}
+
+extern "C" int atlas_prove_reduced_openings(const atlas_opening_t* openings, size_t n_open, atlas_srs_t srs,
+                                            atlas_transcript_t* transcript, atlas_fr_t* sumcheck_rows, uint32_t* n_coeffs,
+                                            atlas_u128_t* challenges, size_t* max_rounds_out, atlas_fr_t* sumcheck_claims,
+                                            atlas_g1_affine_t* com, atlas_g1_affine_t* w, atlas_fr_t* v) {
+    return atlas_rt_prove_reduced_openings(openings, n_open, srs, transcript, sumcheck_rows, n_coeffs, challenges, max_rounds_out, sumcheck_claims, com, w, v, nullptr);
 }

@@ -21,6 +21,7 @@
 #include <cstring>
 #include <random>
 #include <string>
+#include <vector>
 
 struct atlas_shard_group {
     static constexpr uint64_t MAGIC = 0x61746c6173736864ull;     // "atlasshd"
@@ -115,6 +116,17 @@ struct atlas_shard_group {
                 }
             }
             std::memcpy((uint8_t*)all + (size_t)r * n, q->payload, n);
+        }
+        return true;
+    }
+    // all[r * n .. ) <- rank r's `n` bytes for records of any size (the witness commitments of a sharded whole proof: 64 B per committed
+    // polynomial, hundreds of KB per graph): PAYLOAD-sized exchanges one after the other, ~1 us each.
+    bool allgather_bulk(const void* mine, size_t n, void* all, double timeout_s = 30.0) {
+        std::vector<uint8_t> part((size_t)world * PAYLOAD);
+        for (size_t off = 0; off < n; off += PAYLOAD) {
+            const size_t cnt = n - off < PAYLOAD ? n - off : PAYLOAD;
+            if (!allgather((const uint8_t*)mine + off, cnt, part.data(), timeout_s)) return false;
+            for (int r = 0; r < world; r++) std::memcpy((uint8_t*)all + (size_t)r * n + off, part.data() + (size_t)r * cnt, cnt);
         }
         return true;
     }

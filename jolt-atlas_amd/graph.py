@@ -96,14 +96,19 @@ class Graph:
         _check(lib.atlas_graph_node_output(self.h, C.c_size_t(idx), out.ctypes.data_as(C.POINTER(C.c_int32)), n, C.byref(n)))
         return out
 
-    def prove(self, srs, inputs):
-        """ONNXProof::prove.  Returns (proof bytes, final transcript state bytes, timing dict)."""
+    def prove(self, srs, inputs, group=None):
+        """ONNXProof::prove.  Returns (proof bytes, final transcript state bytes, timing dict).  group: a sharded.ShardGroup — every rank of
+        it makes the same call (atlas_prove_graph_sharded: commitments by polynomial range, the opening's MSMs by point range) and gets
+        the same bytes as one GPU does."""
         arrs, ptrs = self._inputs(inputs)
         n = C.c_size_t(); tm = GraphTiming(); ts = TranscriptState()
         cap = getattr(self, "_proof_cap", 1 << 22)      # a second proof of the same graph starts from the first one's size
         while True:
             buf = (C.c_uint8 * cap)()
-            rc = lib.atlas_prove_graph(self.h, srs.h, ptrs, C.c_size_t(len(arrs)), buf, C.c_size_t(cap), C.byref(n), C.byref(ts), C.byref(tm))
+            if group is None:
+                rc = lib.atlas_prove_graph(self.h, srs.h, ptrs, C.c_size_t(len(arrs)), buf, C.c_size_t(cap), C.byref(n), C.byref(ts), C.byref(tm))
+            else:
+                rc = lib.atlas_prove_graph_sharded(self.h, srs.h, group.h, ptrs, C.c_size_t(len(arrs)), buf, C.c_size_t(cap), C.byref(n), C.byref(ts), C.byref(tm))
             if rc != 0 and n.value > cap:
                 cap = n.value
                 continue

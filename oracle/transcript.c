@@ -2,6 +2,7 @@
  * BLAKE2b-256 (RFC 7693; the reference uses crate `blake2` 0.10.6, Cargo.lock:352-354)
  * and the Blake2bTranscript of joltworks/src/transcripts/blake2b.rs. */
 #include "oracle.h"
+#include <stdlib.h>
 #include <string.h>
 
 static const uint64_t B2B_IV[8] = {
@@ -76,14 +77,16 @@ void orc_blake2b256(const uint8_t *in, size_t len, uint8_t out[32]) {
 
 /* blake2b.rs:31-37 + update_state :64-78 — hash(state || 0^28 || n_rounds_be || payload) */
 static void tr_absorb(orc_transcript *t, const uint8_t *payload, size_t n) {
-    uint8_t buf[64 + 256];
+    uint8_t stack[64 + 256];
     uint8_t dig[32];
+    uint8_t *buf = n <= 256 ? stack : (uint8_t *)malloc(64 + n);   /* append_bytes of a model input: 4 bytes per element, any length */
     memcpy(buf, t->state, 32);
     memset(buf + 32, 0, 28);
     buf[60] = (uint8_t)(t->n_rounds >> 24); buf[61] = (uint8_t)(t->n_rounds >> 16);
     buf[62] = (uint8_t)(t->n_rounds >> 8);  buf[63] = (uint8_t)t->n_rounds;
     memcpy(buf + 64, payload, n);
     orc_blake2b256(buf, 64 + n, dig);
+    if (buf != stack) free(buf);
     memcpy(t->state, dig, 32);
     t->n_rounds += 1;
     if (t->history && t->history_len < t->history_cap)

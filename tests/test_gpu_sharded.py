@@ -208,3 +208,55 @@ def test_sharded_elementwise_operator(tmp_path, world, n):
     for r, (p, (o, e)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, e[-3000:]
         assert f"SHARDED_EW_OK {r}" in o
+
+
+@pytest.mark.parametrize("world,name", [(2, "tiny2"), (4, "microgpt"), (2, "nanogpt")])
+def test_sharded_prove_graph(tmp_path, world, name):
+    """atlas_prove_graph_sharded (x2 / BASELINE config 4: the whole ONNXProof::prove over the GPUs of a node, one process per GPU): every rank
+    traces the model and runs the IOP, the witness commitments are split by polynomial range and the opening's commitment groups by point
+    range, partial results cross the shared-memory board.  Every rank's proof bytes and final transcript state equal the ONE-GPU proof's —
+    pinned by the committed oracle result of tests/golden/graph_proofs.json — and rank 0 has the proof accepted by atlas_verify_graph.
+    Processes share the test box's GPU."""
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent(f"""
+        import hashlib, json, os, sys
+        sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, "tools"))
+        import numpy as np
+        rank, world = int(sys.argv[1]), {world}
+        import build_graphs as BG
+        import jolt_atlas_amd as A
+        from jolt_atlas_amd import sharded, graph as GG
+        from oracle import orc
+        A.init(0)
+        gold = json.load(open(os.path.join({ROOT!r}, "tests", "golden", "graph_proofs.json")))
+        want = gold["graphs"][{name!r}]
+        nodes, outputs, inputs = {{"tiny2": lambda: BG.tiny(layers=2), "microgpt": BG.microgpt, "nanogpt": BG.nanogpt}}[{name!r}]()
+        nv = BG.max_vars(nodes)
+        tau = orc.random_fr(1, gold["tau_seed"])[0]
+        srs = A.SRS.generate(tau, 1 << nv)
+        if nv >= 16:
+            srs.precompute()                               # the fixed-base table: the sharded MSMs index it by their point range
+        G = GG.Graph(nodes, outputs)
+        grp = sharded.ShardGroup(sys.argv[2], world, rank)
+        proof, state, tm = G.prove(srs, inputs, group=grp)
+        assert tm["n_committed"] == want["n_committed"]
+        assert state.hex() == want["state"], "final transcript state differs from the one-GPU proof"
+        assert hashlib.sha256(proof).hexdigest() == want["proof_sha256"], "proof bytes differ from the one-GPU proof"
+        proof2, state2, _ = G.prove(srs, inputs, group=grp)            # a second proof over the same board
+        assert proof2 == proof and state2 == state
+        if rank == 0:
+            vk = A.HyperKZG.vk_from_trapdoor(tau, srs.download(0, 1)[0])
+            V = GG.Graph(nodes, outputs)
+            ok, vstate = V.verify(vk, inputs, G.node_output(outputs[0]), proof)
+            assert ok and vstate == state
+            V.free()
+        grp.close(); G.free(); srs.free()
+        print("SHARDED_GRAPH_OK", rank)
+    """))
+    gname = f"/atlas_graph_{os.getpid()}_{world}_{name}"
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), gname], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for r, (p, (o, e)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, e[-3000:]
+        assert f"SHARDED_GRAPH_OK {r}" in o
