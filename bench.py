@@ -111,6 +111,54 @@ def cpu_baseline(n_vars, budget_s=20.0):
                       f"oracle C port with OpenMP, best of thread sweep {cand}"}
 
 
+def cpu_baseline_msm(A, log_n, budget_s=20.0):
+    """The oracle's bucket MSM (arkworks' VariableBaseMSM shape: unsigned c-bit windows with c = ln(n) + 2, windows in parallel,
+    running-sum bucket reduction, Horner over the windows; oracle/curve.c orc_msm_pippenger) on this box's host cores over the SAME
+    2^log_n points the GPU leg multiplies (bases downloaded from the device SRS, uniform Fr scalars)."""
+    import ctypes as C
+    from oracle import orc
+    omp = C.CDLL("libgomp.so.1")
+    n = 1 << log_n
+    tau = A.random_fr(1, 0x51250001)[0]
+    srs = A.SRS.generate(tau, n)
+    bases = srs.download(0, n)
+    srs.free()
+    scal = A.random_fr(n, 0x5CA1A5 + log_n)
+    import math
+    c = int(math.log(n) * 69 / 100) + 2
+    nwin = (254 + c - 1) // c
+    threads = max(1, min(_effective_cores(), nwin))              # the windows are the parallel dimension
+    omp.omp_set_num_threads(threads)
+    times, pt = [], None
+    t_start = time.perf_counter()
+    while len(times) < 3 and (not times or time.perf_counter() - t_start < budget_s):
+        t0 = time.perf_counter()
+        pt = orc.msm(bases, scal)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": n / med, "unit": "points/s", "ms_per_msm": med * 1e3, "cores": int(threads), "kind": "port", "window_bits": c, "windows": nwin,
+            "sample": f"{len(times)} full 2^{log_n}-point MSMs with 254-bit scalars (median), oracle C port of the bucket method with OpenMP over the windows"}, pt
+
+
+def cpu_baseline_prove_graph(budget_s=30.0):
+    """ONNXProof::prove by the oracle composition (oracle/graph.py: Python over the oracle's C instances, OpenMP inside them) on this box's
+    host cores.  Bounded sample: the microgpt-shaped graph (BASELINE config 1's shape, 53 nodes) — the nanoGPT-shaped one takes the
+    oracle minutes; the GPU time of the SAME graph is prove_graph.microgpt in this line."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import build_graphs as BG
+    from oracle import graph as OG, orc
+    nodes, outputs, inputs = BG.microgpt()
+    nv = BG.max_vars(nodes)
+    tau = orc.random_fr(1, 0x51250001)[0]
+    srs_h = orc.srs_powers(tau, 1 << nv)
+    t0 = time.perf_counter()
+    proof = OG.Prover(nodes, outputs, srs_h).prove(inputs)
+    dt = time.perf_counter() - t0
+    return {"value": dt, "unit": "s", "higher_is_better": False, "cores": _effective_cores(), "kind": "port", "proof_bytes": len(proof),
+            "sample": "one ONNXProof::prove of the microgpt-shaped graph (53 nodes, max_num_vars %d) by the oracle composition; compare prove_graph.microgpt" % nv}
+
+
 PASS_KERNELS = ("k_dot_eval", "k_dot_bind_eval")      # the data passes of the dot-product sumcheck
 
 
@@ -329,6 +377,7 @@ def main():
     }
     # second leg: the HyperKZG MSM of the same size (2^n_vars points, full-width scalars),
     # reported beside the sumcheck line; bases = tau^(i+1) G resident in HBM.
+    msm_point = None
     if not args.no_msm:
         for p, q in sets:
             p.free(); q.free()
@@ -359,6 +408,7 @@ def main():
         t_build = time.perf_counter() - t_build
         dt_m, tmm, pt_t = msm_leg() if tab["window_bits"] else (dt_v, tm_v, pt_v)
         assert bytes(pt_t) == bytes(pt_v), "fixed-base MSM disagrees with the variable-base MSM"
+        msm_point = pt_v
         c_bits = int(tmm.n_fs)
         n_win = (255 + c_bits - 1) // c_bits
         # bucket accumulation: one mixed XYZZ addition per (scalar, digit) = 10 Fq multiplications of 162 multiply-adds on
@@ -466,7 +516,7 @@ def main():
         from jolt_atlas_amd import graph as GG
         out["prove_graph"] = {"note": "synthetic-trace proxy of ONNXProof::prove: the model's operator list and (padded) shapes, random-init weights, "
                                       "full operator decomposition (SoftmaxLastAxis, tanh-GELU, LayerNorm, GatherSmall); reference (M3 CPU): nanoGPT 2.288 s, GPT-2 12 layers 14.889 s"}
-        for gname in ("nanogpt", "gpt2_layer") + (() if args.no_gpt2_full else ("gpt2",)):
+        for gname in ("microgpt", "nanogpt", "gpt2_layer") + (() if args.no_gpt2_full else ("gpt2",)):
             nodes_g, outs_g, ins_g = getattr(BG, gname)()
             nv = BG.max_vars(nodes_g)
             t0s = time.perf_counter()
@@ -495,7 +545,7 @@ def main():
             out["prove_graph"][gname] = {"prove_graph_ms": best_g["total_ms"], "verified": True, "verify_ms": verify_ms,
                                          "stage_ms": {k: best_g[k] for k in ("trace_ms", "commit_ms", "iop_ms", "reduction_ms", "hyperkzg_ms")},
                                          "nodes": best_g["n_nodes"], "committed_polys": best_g["n_committed"], "sumcheck_proofs": best_g["n_sumchecks"],
-                                         "proof_bytes": len(pf_g), "max_num_vars": nv, "setup_prover_s": setup_s,
+                                         "proof_bytes": len(pf_g), "proof_sha16": __import__("hashlib").sha256(pf_g).hexdigest()[:16], "max_num_vars": nv, "setup_prover_s": setup_s,
                                          "operators": dict(Counter(n["op"] for n in nodes_g))}
             Gg.free(); srs_g.free()
     # the three node shapes timed above, as one-operator graphs: proved by atlas_prove_graph and ACCEPTED by atlas_verify_graph
@@ -616,9 +666,57 @@ def main():
             out["sharded"]["open_ms"] = dt_o * 1e3 / 2
             out["sharded"]["open"] = "HyperKZG::open of one 2^%d polynomial, commitments split by point range over %d GPUs (polynomial passes replicated)" % (n_vars, world)
             open_poly.free()
+        # BASELINE config 4: the WHOLE ONNXProof::prove of the GPT-2-shaped graphs over the N ranks (atlas_prove_graph_sharded: trace and IOP on every
+        # rank, witness commitments by polynomial range, the opening's commitment groups by point range; same proof bytes as one GPU)
+        if not args.no_graph:
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+            import build_graphs as BG
+            from jolt_atlas_amd import graph as GG
+            out["prove_graph_sharded"] = {"world": world, "note": "every rank proves the same graph with the same inputs; stage split of the slowest repetition-best on rank 0; "
+                                                                  "prove_graph (one GPU, rank 0) is in this line for the same graphs"}
+            for gname in ("gpt2_layer",) + (() if args.no_gpt2_full else ("gpt2",)):
+                nodes_s, outs_s, ins_s = getattr(BG, gname)()
+                nv_s = BG.max_vars(nodes_s)
+                tau_s = np.array([0x1234567, 0, 0, 0], dtype=np.uint64)
+                srs_s = A.SRS.generate(tau_s, 1 << nv_s)
+                if nv_s >= 16:
+                    srs_s.precompute()
+                Gs = GG.Graph(nodes_s, outs_s)
+                best_s, states_s, wall_s = None, set(), None
+                for rep in range(3):
+                    barrier(); sync(); t0s = time.perf_counter()
+                    pf_s, st_s, tm_s = Gs.prove(srs_s, ins_s, group=grp)
+                    sync(); dts = allreduce_max(time.perf_counter() - t0s)
+                    states_s.add(st_s)
+                    if rep and (wall_s is None or dts < wall_s):
+                        wall_s, best_s = dts, tm_s
+                assert len(states_s) == 1, "non-deterministic sharded graph proof"
+                all_st = grp.allgather(np.frombuffer(st_s, dtype=np.uint8))
+                assert all(bytes(x) == st_s for x in all_st), "ranks disagree on the whole proof's transcript"
+                entry = {"prove_graph_ms": wall_s * 1e3, "stage_ms": {k: best_s[k] for k in ("trace_ms", "commit_ms", "iop_ms", "reduction_ms", "hyperkzg_ms")},
+                         "nodes": best_s["n_nodes"], "committed_polys": best_s["n_committed"], "proof_bytes": len(pf_s), "max_num_vars": nv_s}
+                if rank == 0:                         # ONNXProof::verify of the sharded proof
+                    vk_s = A.HyperKZG.vk_from_trapdoor(tau_s, srs_s.download(0, 1)[0])
+                    Vs = GG.Graph(nodes_s, outs_s)
+                    ok_s, vst_s = Vs.verify(vk_s, ins_s, Gs.node_output(outs_s[0]), pf_s)
+                    assert ok_s and vst_s == st_s, "the verifier rejected the sharded graph proof"
+                    entry["verified"] = True
+                    Vs.free()
+                    same = out.get("prove_graph", {}).get(gname)
+                    if same:
+                        entry["one_gpu_ms"] = same["prove_graph_ms"]; entry["same_proof_bytes_as_one_gpu"] = bool(same.get("proof_sha16") == __import__("hashlib").sha256(pf_s).hexdigest()[:16])
+                out["prove_graph_sharded"][gname] = entry
+                Gs.free(); srs_s.free()
         grp.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n_vars)
+        # the other two legs of the line beside their CPU statements, each a bounded sample
+        if not args.no_msm:
+            out["cpu_baseline"]["msm"], cpu_pt = cpu_baseline_msm(A, n_vars)
+            out["cpu_baseline"]["msm"]["same_point_as_gpu"] = bool(msm_point is not None and np.array_equal(np.asarray(cpu_pt["x"]), np.asarray(msm_point["x"]))
+                                                                   and np.array_equal(np.asarray(cpu_pt["y"]), np.asarray(msm_point["y"])))
+        if not args.no_graph:
+            out["cpu_baseline"]["prove_graph"] = cpu_baseline_prove_graph()
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -7,6 +7,7 @@
 //   finish_mles_product_sum_from_evals   subprotocols/mles_product_sum.rs:330-376
 //   GruenSplitEqPolynomial::{new,bind} (LowToHigh) poly/split_eq_poly.rs:97-121,331-348
 #pragma once
+#include <array>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -78,12 +79,85 @@ inline const std::vector<std::vector<Fr>>& toom_inverse(size_t n) {
     return cache.emplace(n, std::move(invm)).first->second;
 }
 
-inline std::vector<Fr> from_evals_toom(const std::vector<Fr>& evals) {
+inline std::vector<Fr> from_evals_toom_matrix(const std::vector<Fr>& evals) {       // n^2 multiplications: kept as the cross-check of tools/check_host_poly.cpp
     const size_t n = evals.size();
     const auto& M = toom_inverse(n);
     std::vector<Fr> c(n, zero());
     for (size_t i = 0; i < n; i++)
         for (size_t j = 0; j < n; j++) c[i] = add(c[i], mul(M[i][j], evals[j]));
+    return c;
+}
+
+// a * k for a small integer k (k < 64): the five-limb product minus j p, j estimated from the bits above 2^244 (p / 2^244 = 774.3: the
+// estimate is low by at most one), then one conditional subtraction.  ~1/3 of a Montgomery multiplication; same residue.
+inline Fr mul_small(const Fr& a, uint32_t k) {
+    static const std::vector<std::array<uint64_t, 5>> KP = [] {
+        std::vector<std::array<uint64_t, 5>> t(65);
+        t[0] = {0, 0, 0, 0, 0};
+        for (size_t j = 1; j <= 64; j++) { u128 c = 0; for (int i = 0; i < 4; i++) { c += (u128)t[j - 1][i] + FR_P[i]; t[j][i] = (uint64_t)c; c >>= 64; } t[j][4] = t[j - 1][4] + (uint64_t)c; }
+        return t;
+    }();
+    uint64_t t[5]; u128 c = 0;
+    for (int i = 0; i < 4; i++) { c += (u128)a.l[i] * k; t[i] = (uint64_t)c; c >>= 64; }
+    t[4] = (uint64_t)c;
+    const uint64_t top = (t[4] << 12) | (t[3] >> 52);
+    const uint64_t* kp = KP[top / 775].data();
+    u128 br = 0;
+    for (int i = 0; i < 5; i++) { const u128 d = (u128)t[i] - kp[i] - br; t[i] = (uint64_t)d; br = (d >> 64) & 1; }
+    Fr o{{t[0], t[1], t[2], t[3]}};
+    if (t[4] || geq_p(o.l)) sub_p(o.l);
+    if (geq_p(o.l)) sub_p(o.l);
+    return o;
+}
+
+// The same coefficients in O(n) multiplications: with c = the value at infinity (the leading coefficient, degree D = n - 1),
+// q(x) = p(x) - c x^D has degree < D and is known at 0 .. D - 1; its forward differences at 0 divided by k! are its coefficients in the
+// falling-factorial basis, and Horner over (x - k) with the small integers k turns that basis into monomials.  Against the n x n
+// matrix-vector product (289 multiplications for the degree-17 round polynomial of a 64-bit one-hot check, once per round on the host's
+// critical path): 2 (n - 3) multiplications, n^2 / 2 small ones and n^2 additions.  The interpolant is unique: same coefficients.
+inline std::vector<Fr> from_evals_toom(const std::vector<Fr>& evals) {
+    const size_t n = evals.size();
+    if (n < 3 || n > 64) return from_evals_toom_matrix(evals);
+    const size_t D = n - 1;
+    struct Consts { std::vector<Fr> powD, invfact; };
+    static std::mutex mu;
+    static std::map<size_t, Consts> cache;
+    const Consts* K;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find(n);
+        if (it == cache.end()) {
+            Consts c;
+            c.powD.resize(D); c.invfact.resize(D);
+            Fr f = one();
+            for (size_t i = 0; i < D; i++) {
+                Fr pw = one(); const Fr x = from_u64(i);
+                for (size_t j = 0; j < D; j++) pw = mul(pw, x);
+                c.powD[i] = pw;
+                if (i) f = mul(f, x);
+                c.invfact[i] = inv(f);
+            }
+            it = cache.emplace(n, std::move(c)).first;
+        }
+        K = &it->second;
+    }
+    const Fr& lead = evals[D];
+    Fr d[64];
+    d[0] = evals[0]; d[1] = sub(evals[1], lead);
+    for (size_t i = 2; i < D; i++) d[i] = sub(evals[i], mul(lead, K->powD[i]));
+    for (size_t k = 1; k < D; k++)                                   // after pass k: d[i] = Delta^k q(i - k) for i >= k; d[k] = Delta^k q(0) stays
+        for (size_t i = D - 1; i >= k; i--) d[i] = sub(d[i], d[i - 1]);
+    for (size_t k = 2; k < D; k++) d[k] = mul(d[k], K->invfact[k]);
+    std::vector<Fr> c(n, zero());
+    size_t len = 1;                                                   // c[0 .. len) = the polynomial built so far, highest basis element first
+    c[0] = d[D - 1];
+    for (size_t k = D - 1; k-- > 0;) {                                // poly = poly * (x - k) + d[k]
+        c[len] = c[len - 1];
+        for (size_t j = len - 1; j >= 1; j--) c[j] = sub(c[j - 1], mul_small(c[j], (uint32_t)k));
+        c[0] = sub(d[k], mul_small(c[0], (uint32_t)k));
+        len++;
+    }
+    c[D] = lead;
     return c;
 }
 

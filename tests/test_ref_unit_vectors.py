@@ -81,6 +81,13 @@ def test_product_host_helpers_against_reference_vectors(host_poly):
     assert host_poly("from_evals_and_hint", 3, lq["hint"], val(0), val(2), val(3)) == s
 
 
+def test_product_toom_interpolation_matches_the_matrix_form(host_poly):
+    """from_evals_toom (UniPoly::from_evals_toom, unipoly.rs:103-134) runs in O(n) multiplications on the host's critical path (Newton
+    differences + Horner over small integers); the n x n matrix form it replaced stays as the cross-check: 0 mismatches over lengths
+    2 .. 40 x 20 inputs, and mul_small against the full multiplication on 200000 operands"""
+    assert host_poly("toom_selfcheck") == [0]
+
+
 def test_oracle_interleave_against_reference_doctest():
     from oracle import graph as OG
     from oracle import orc_ra
