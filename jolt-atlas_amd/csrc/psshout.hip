@@ -17,6 +17,7 @@
 // {HAZ_s, HAZ_s * lw_s, HAO_s, HAO_s * lw_s} with HAZ_s / HAO_s = "the suffix bits of significance >= BOUND are
 // all zero / all one" and lw_s = the suffix bits below BOUND (suffixes/higher_all_zero.rs, hzero_mul_lword.rs,
 // hone_mul_lword.rs)
+#include <algorithm>
 #include <chrono>
 
 #include "ra_common.hip.h"
@@ -413,10 +414,20 @@ struct PsLookup : atlas_instance {
         v.assign(1, H::one());
         return ATLAS_OK;
     }
+    // bins of the current tables that hold a non-zero value in any of them, ascending.  The phases over a sign extension (five of the
+    // eight phases of a 64-bit lookup over 20-bit values) fill 1 or 2 bins of 256: the round's sums and the folds then walk this list
+    // instead of the tables (same sums: exact arithmetic in another order).
+    std::vector<uint32_t> nz;
+    static constexpr size_t NZ_SPARSE = 8;
     void load_Q(const H::Fr* q) {
         const size_t NQ = nq();
         Q.assign(NQ, std::vector<H::Fr>(m));
-        for (size_t y = 0; y < m; y++) for (size_t k = 0; k < NQ; k++) Q[k][y] = q[NQ * y + k];
+        nz.clear();
+        for (size_t y = 0; y < m; y++) {
+            bool any = false;
+            for (size_t k = 0; k < NQ; k++) { Q[k][y] = q[NQ * y + k]; any = any || !H::detail::is_zero4(Q[k][y].l); }
+            if (any) nz.push_back((uint32_t)y);
+        }
     }
     // the launches only: the tables end up at qsum_ptr().  v_prev: fold the finished phase's table into the products on the way
     // (m <= 256); pub: also publish the tables to the host
@@ -472,6 +483,7 @@ struct PsLookup : atlas_instance {
     }
     // prover_msg_read_checking (mod.rs:337-460): host arithmetic over the phase's 2^log_m-entry tables
     std::vector<H::Fr> sum_tmp;            // scratch of address_message's per-bit sums
+    std::vector<uint32_t> pairs3;          // mode 3: the bin pairs of the round that hold something
     int address_message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) {
         {
             const size_t j = round, p = j / log_m, half = Q[0].size() / 2;
@@ -516,6 +528,22 @@ struct PsLookup : atlas_instance {
                         auto sums = [&](size_t k, size_t off, int want, const H::Fr* w, H::Fr& tot, H::Fr& wtot) {
                             const auto keep = [&](size_t b) { return want < 0 || (want == 0 ? (b & mhigh) == 0 : (b & mhigh) == mhigh); };
                             wtot = H::zero();
+                            if (nz.size() <= NZ_SPARSE) {              // a handful of non-empty bins: walk them
+                                tot = H::zero();
+                                H::Fr up[16]; uint32_t touched = 0;
+                                for (uint32_t b : nz) {
+                                    if (b < off || b >= off + half) continue;
+                                    const size_t bb = b - off;
+                                    if (!keep(bb)) continue;
+                                    const H::Fr& val = Q[k][b];
+                                    if (H::detail::is_zero4(val.l)) continue;
+                                    tot = H::add(tot, val);
+                                    if (!w) continue;
+                                    for (size_t i = 0; i < blen; i++) if ((bb >> i) & 1) { up[i] = (touched >> i) & 1 ? H::add(up[i], val) : val; touched |= 1u << i; }
+                                }
+                                for (size_t i = 0; i < blen; i++) if ((touched >> i) & 1) wtot = H::add(wtot, H::mul(w[i], up[i]));
+                                return;
+                            }
                             if (!w) {
                                 tot = H::zero();
                                 for (size_t b = 0; b < half; b++) if (keep(b)) tot = H::add(tot, Q[k][off + b]);
@@ -564,8 +592,18 @@ struct PsLookup : atlas_instance {
                         if (symmetric) val = H::add(val, H::mul(hao_c, H::add(H::add(H::mul(lw_c, at(&HalfSums::o4)), at(&HalfSums::ol4)), at(&HalfSums::o5))));
                         acc = H::add(val, H::mul(gamma, idt));
                     }
-                } else
-                for (size_t b = 0; b < half; b++) {
+                } else {
+                // an empty pair of bins adds nothing: in the sparse phases the loop walks the handful of pairs that hold something
+                const bool sparse3 = nz.size() <= 4 * NZ_SPARSE;
+                if (sparse3 && ci == 0) {
+                    pairs3.clear();
+                    for (uint32_t x : nz) pairs3.push_back(x >= half ? x - (uint32_t)half : x);
+                    std::sort(pairs3.begin(), pairs3.end());
+                    pairs3.erase(std::unique(pairs3.begin(), pairs3.end()), pairs3.end());
+                }
+                const size_t n_iter = sparse3 ? pairs3.size() : half;
+                for (size_t bi = 0; bi < n_iter; bi++) {
+                    const size_t b = sparse3 ? pairs3[bi] : bi;
                     auto qv = [&](size_t k) { return ci ? H::sub(H::add(Q[k][b + half], Q[k][b + half]), Q[k][b]) : Q[k][b]; };
                     // UnsignedLessThan over interleaved (x, y) pairs + gamma * Left + gamma^2 * Right
                     H::Fr lt = lt_acc, eq = eq_acc, lo = lop_acc, ro = rop_acc;
@@ -595,6 +633,7 @@ struct PsLookup : atlas_instance {
                     val = H::add(val, H::mul(g2, H::add(H::mul(ro, qv(0)), qv(3))));
                     acc = H::add(acc, val);
                 }
+                }
                 ev[ci] = acc;
             }
             H::unipoly_from_evals_and_hint(claim, ev, 2, coeffs.data());
@@ -610,12 +649,31 @@ struct PsLookup : atlas_instance {
         if (round < N) {
             const size_t j = round, p = j / log_m;
             const size_t half = Q[0].size() / 2;
-            for (auto& q : Q) {                                       // suffix polys bind HighToLow
-                for (size_t i = 0; i < half; i++) {
-                    if (H::detail::is_zero4(q[i].l) && H::detail::is_zero4(q[i + half].l)) continue;       // an empty pair of bins stays empty (the phases over a sign extension fill 2 bins of 256)
-                    q[i] = H::add(q[i], H::mul_challenge(rf, H::sub(q[i + half], q[i])));   // (two CIOS steps for a 128-bit challenge)
+            if (nz.size() <= 4 * NZ_SPARSE) {                          // few non-empty bins: their pairs only
+                std::vector<uint32_t> low;
+                low.reserve(nz.size());
+                for (uint32_t b : nz) low.push_back(b >= half ? b - (uint32_t)half : b);
+                std::sort(low.begin(), low.end());
+                low.erase(std::unique(low.begin(), low.end()), low.end());
+                for (auto& q : Q) {
+                    for (uint32_t i : low) q[i] = H::add(q[i], H::mul_challenge(rf, H::sub(q[i + half], q[i])));
+                    q.resize(half);
                 }
-                q.resize(half);
+                nz.swap(low);
+            } else {
+                for (auto& q : Q) {                                   // suffix polys bind HighToLow
+                    for (size_t i = 0; i < half; i++) {
+                        if (H::detail::is_zero4(q[i].l) && H::detail::is_zero4(q[i + half].l)) continue;       // an empty pair of bins stays empty
+                        q[i] = H::add(q[i], H::mul_challenge(rf, H::sub(q[i + half], q[i])));   // (two CIOS steps for a 128-bit challenge)
+                    }
+                    q.resize(half);
+                }
+                std::vector<uint32_t> low;                           // the list: indices above `half` fold onto their partners
+                low.reserve(nz.size());
+                for (uint32_t b : nz) low.push_back(b >= half ? b - (uint32_t)half : b);
+                std::sort(low.begin(), low.end());
+                low.erase(std::unique(low.begin(), low.end()), low.end());
+                nz.swap(low);
             }
             if (with_device) {
                 std::vector<H::Fr> nv(2 * v.size());                  // ExpandingTable::update, HighToLow

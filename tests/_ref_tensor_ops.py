@@ -171,6 +171,14 @@ def plan(case):
         # scale 0: D = 2^0 * count, the record's plain mean (ops/mean_of_squares.rs)
         nodes.append({"idx": 1, "op": "MeanOfSquares", "inputs": [0], "dims": list(exp["dims"]), "axes": axes, "scale": 0, "count": x["dims"][-1]})
         return ("graph", nodes, inputs, 1, None)
+    if fn == "Tensor::move_axis":                            # the MoveAxis operator (ops/move_axis.rs -> Tensor::move_axis)
+        nodes, inputs = _inputs_and_nodes([args[0]["tensor"]])
+        nodes.append({"idx": 1, "op": "MoveAxis", "inputs": [0], "dims": list(exp["dims"]), "source": args[1]["num"], "destination": args[2]["num"]})
+        return ("graph", nodes, inputs, 1, None)
+    if fn == "Tensor::expand":                               # the Broadcast operator (ops/broadcast.rs -> Tensor::expand)
+        nodes, inputs = _inputs_and_nodes([args[0]["tensor"]])
+        nodes.append({"idx": 1, "op": "Broadcast", "inputs": [0], "dims": list(args[1]["list"])})
+        return ("graph", nodes, inputs, 1, None)
     if fn == "max_axes":
         return ("formula", "softmax_max")
     if fn in ("tanh", "erffunc", "sigmoid", "sin", "cos"):
@@ -204,6 +212,8 @@ def pad_plan(nodes, inputs, out_idx):
             p = np.full(q["dims"], fill, dtype=np.int32)
             p[tuple(slice(0, d) for d in nd["dims"])] = x
             pin.append(p.reshape(-1))
+        elif op == "MoveAxis" and any(next_pow2(d) != d for d in nd["dims"]):
+            return None, "MoveAxis of a shape with a dimension that is not a power of two: the padded elements would move with the axis"
         elif op == "Concat":
             ax = nd["axis"]
             if any(next_pow2(by[j]["dims"][ax]) != by[j]["dims"][ax] for j in nd["inputs"]) or next_pow2(nd["dims"][ax]) != nd["dims"][ax]:

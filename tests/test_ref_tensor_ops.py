@@ -1,5 +1,5 @@
 """Reference-HELD vectors under `Model::trace` (f1 / f3): the literal inputs and expected tensors of the doc tests in
-/root/reference/atlas-onnx-tracer/src/tensor/ops.rs (tests/golden/ref_tensor_ops.json; data only, extracted by
+/root/reference/atlas-onnx-tracer/src/tensor/ops.rs and of Tensor::move_axis / Tensor::expand in tensor/mod.rs (tests/golden/ref_tensor_ops.json; data only, extracted by
 tools/extract_ref_doctests.py in the build container), replayed
 
   * on the CPU through oracle/graph.py:execute and the oracle's table formulas (this pins the ORACLE against the reference), and
@@ -23,13 +23,13 @@ IDS = [f"{c['fn']}@{c['line']}#{i}" for i, c in enumerate(CASES)]
 
 
 def test_fixture_shape():
-    assert DOC["n_cases"] == len(CASES) == 101
+    assert DOC["n_cases"] == len(CASES) == 105
     kinds = [p[0] for p in PLANS]
-    # 30 records map onto operators / table formulas of the path; the other 71 are tensor functions no ONNXProof operator executes
-    assert kinds.count("graph") + kinds.count("formula") == 30, (kinds.count("graph"), kinds.count("formula"))
+    # 34 records map onto operators / table formulas of the path; the other 71 are tensor functions no ONNXProof operator executes
+    assert kinds.count("graph") + kinds.count("formula") == 34, (kinds.count("graph"), kinds.count("formula"))
     mapped_fns = {c["fn"] for c, p in zip(CASES, PLANS) if p[0] != "unmapped"}
     assert mapped_fns == {"add", "sub", "iff", "and", "neg", "einsum", "sum_axes", "gather", "concat", "slice", "sra", "div", "const_div",
-                          "const_rem", "mean_of_squares_axes", "max_axes", "tanh", "erffunc", "sigmoid", "sin", "cos"}
+                          "const_rem", "mean_of_squares_axes", "max_axes", "tanh", "erffunc", "sigmoid", "sin", "cos", "Tensor::move_axis", "Tensor::expand"}
 
 
 def test_unmapped_records_are_listed_with_a_reason():

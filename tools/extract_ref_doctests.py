@@ -167,6 +167,42 @@ def parse_block(line, fn, body):
     return cases, skipped
 
 
+REF_METHODS = "/root/reference/atlas-onnx-tracer/src/tensor/mod.rs"
+
+
+def method_cases():
+    """Tensor::move_axis / Tensor::expand (tensor/mod.rs: what the MoveAxis and Broadcast operators execute): the method-call examples
+    `let b = a.move_axis(s, d).unwrap(); assert_eq!(b, expected)` and `assert_eq!(a.expand(&[..]).unwrap(), expected)`"""
+    out = []
+    for line, fn, body in doc_blocks(open(REF_METHODS).read().split("\n")):
+        if fn not in ("move_axis", "expand"):
+            continue
+        text = " ".join(re.sub(r"(^|\s)//.*$", "", l) for l in body)
+        env, res = {}, {}
+        for st in split_top(text, ";"):
+            st = st.strip()
+            m = re.match(r"let\s+(?:mut\s+)?(\w+)\s*(?::[^=]+)?=\s*(.*)$", st, re.S)
+            if m and "Tensor" in m.group(2) and "new(" in m.group(2):
+                t = parse_tensor(m.group(2))
+                if t is not None:
+                    env[m.group(1)] = t
+                continue
+            call = re.search(r"(\w+)\.(move_axis|expand)\((.*?)\)\.unwrap\(\)", st)
+            if m and call and call.group(1) in env:
+                res[m.group(1)] = (call.group(2), env[call.group(1)], [parse_arg(a, env) for a in split_top(call.group(3), ",")])
+                continue
+            if st.startswith("assert_eq!"):
+                inner = st[st.index("(") + 1:st.rindex(")")]
+                a, b = [x.strip() for x in split_top(inner, ",")][:2]
+                got = res.get(a)
+                if got is None and call and call.group(1) in env:
+                    got = (call.group(2), env[call.group(1)], [parse_arg(x, env) for x in split_top(call.group(3), ",")])
+                if got is not None and isinstance(env.get(b), dict) and all(x is not None for x in got[2]):
+                    out.append({"fn": "Tensor::" + got[0], "line": line, "args": [{"tensor": got[1]}] + got[2], "expected": env[b], "documents": fn,
+                                "file": "tensor/mod.rs"})
+    return out
+
+
 def main():
     lines = open(REF).read().split("\n")
     cases, skipped, n_blocks = [], [], 0
@@ -177,8 +213,9 @@ def main():
             x["documents"] = fn
         cases += c
         skipped += [{"line": line, "fn": fn, "why": w} for w in s]
-    out = {"source": "atlas-onnx-tracer/src/tensor/ops.rs (doc tests; data only)", "generator": "tools/extract_ref_doctests.py",
-           "n_blocks": n_blocks, "n_cases": len(cases), "cases": cases, "unparsed": skipped}
+    cases += method_cases()
+    out = {"source": "atlas-onnx-tracer/src/tensor/ops.rs + Tensor::move_axis / Tensor::expand of tensor/mod.rs (doc tests; data only)",
+           "generator": "tools/extract_ref_doctests.py", "n_blocks": n_blocks, "n_cases": len(cases), "cases": cases, "unparsed": skipped}
     with open(OUT, "w") as f:
         json.dump(out, f, separators=(",", ":"))
         f.write("\n")
