@@ -21,6 +21,7 @@
 
 #include "../../include/atlas_hip.h"
 #include "host_field.hpp"
+#include "host_threads.hpp"
 #include "instance.hpp"
 #include "runtime.hpp"
 
@@ -68,7 +69,10 @@ struct Instance {
     size_t rounds;
 };
 
-H::Fr mul_pow2(H::Fr x, size_t pow) {      // JoltField::mul_pow_2 (field/mod.rs:274-284): same value, x * 2^pow
+H::Fr mul_pow2(H::Fr x, size_t pow) {      // JoltField::mul_pow_2 (field/mod.rs:274-284): same value, x * 2^pow — one multiplication by a tabled power
+    static const std::vector<H::Fr> tab = [] { std::vector<H::Fr> t(129); t[0] = H::one(); for (size_t i = 1; i <= 128; i++) t[i] = H::add(t[i - 1], t[i - 1]); return t; }();
+    if (pow == 0) return x;
+    if (pow <= 128) return H::mul(x, tab[pow]);
     const H::Fr two = H::from_u64(2);
     for (size_t i = 0; i < pow; i++) x = H::mul(x, two);
     return x;
@@ -431,6 +435,90 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
     const bool trace = getenv("ATLAS_TRACE") != nullptr;          // per instance: wall clock of compute_message / ingest_challenge, summed
     std::vector<double> t_msg(n, 0.0), t_ing(n, 0.0), t_wait(n, 0.0);
     double t_fs = 0, t_enq = 0;
+    // A batch of thousands of host-stepped instances (the opening-reduction sumcheck of a whole graph: one row per committed one-hot
+    // polynomial) spends the round in per-instance arithmetic — ~1 us each: 3-9 ms per round on this thread.  The instances that allow it
+    // (host_parallel: the rows of a OneHotPool) go to a few worker threads, after the first of them has run here (it does the shared
+    // launches of the round); the reference runs the same loop under Rayon.  Field sums are exact: the split changes no value.
+    H::HostThreads* HT = (!piped && n >= 1024) ? &H::HostThreads::get() : nullptr;
+    if (HT && HT->threads() < 2) HT = nullptr;
+    std::vector<uint8_t> par(n, 0);
+    if (HT) for (size_t i = 0; i < n; i++) par[i] = b->inst[i].inst->host_parallel() ? 1 : 0;
+    for (size_t round = 0; round < max_rounds && HT; round++) {
+        const size_t remaining = max_rounds - round;
+        std::vector<std::vector<H::Fr>> polys(n);
+        std::vector<int> rcs(HT->threads(), ATLAS_OK);
+        // compute_message: the constant members and the serial ones here, then the first parallel one, then the rest on the workers
+        bool first_done = false;
+        std::vector<size_t> todo;
+        todo.reserve(n);
+        for (size_t i = 0; i < n; i++) {
+            Instance& I = b->inst[i];
+            if (remaining > I.rounds) { polys[i] = {mul_pow2(I.input_claim, remaining - I.rounds - 1)}; continue; }
+            if (par[i] && first_done) { todo.push_back(i); continue; }
+            int rc = I.inst->message(round - (max_rounds - I.rounds), claim[i], polys[i]);
+            if (rc) return rc;
+            if (par[i]) first_done = true;
+        }
+        HT->parallel_for(todo.size(), [&](size_t lo, size_t hi, size_t part) {
+            for (size_t q = lo; q < hi && rcs[part] == ATLAS_OK; q++) {
+                Instance& I = b->inst[todo[q]];
+                rcs[part] = I.inst->message(round - (max_rounds - I.rounds), claim[todo[q]], polys[todo[q]]);
+            }
+        });
+        for (int rc : rcs) if (rc) return rc;
+        // batched = sum coeff_i * poly_i (from_coeff trimming per term, the sum keeps the longest length): partial sums per thread
+        std::vector<std::vector<H::Fr>> partial(HT->threads());
+        HT->parallel_for(n, [&](size_t lo, size_t hi, size_t part) {
+            std::vector<H::Fr>& acc = partial[part];
+            for (size_t i = lo; i < hi; i++) {
+                const std::vector<H::Fr> t = trimmed_scale(polys[i], coeff[i]);
+                for (size_t k = 0; k < t.size(); k++) {
+                    if (k < acc.size()) acc[k] = H::add(acc[k], t[k]);
+                    else acc.push_back(t[k]);
+                }
+            }
+        });
+        std::vector<H::Fr> batched = {H::zero()};
+        for (auto& acc : partial)
+            for (size_t k = 0; k < acc.size(); k++) {
+                if (k < batched.size()) batched[k] = H::add(batched[k], acc[k]);
+                else batched.push_back(acc[k]);
+            }
+        std::vector<H::Fr> cc;
+        if (batched.size() < 2) cc = batched;
+        else { cc.push_back(batched[0]); for (size_t k = 2; k < batched.size(); k++) cc.push_back(batched[k]); }
+        if (cc.size() > row_stride) return fail(ATLAS_EINVAL, "batched_prove: row_stride below the batched degree");
+        H::tr_append_message(T, "UniPoly_begin");
+        for (auto& x : cc) H::tr_append_scalar(T, x);
+        H::tr_append_message(T, "UniPoly_end");
+        n_coeffs[round] = (uint32_t)cc.size();
+        std::memcpy(&compressed[round * row_stride], cc.data(), cc.size() * 32);
+        uint64_t lo64, hi64;
+        H::tr_challenge_u128(T, lo64, hi64);
+        challenges[round].lo = lo64; challenges[round].hi = hi64;
+        const H::Fr r = H::challenge_to_fr(lo64, hi64, g.challenge_mode);
+        HT->parallel_for(n, [&](size_t lo, size_t hi, size_t) { for (size_t i = lo; i < hi; i++) claim[i] = eval_with_challenge(polys[i], r); });
+        // ingest_challenge, in the same three steps
+        first_done = false;
+        todo.clear();
+        for (size_t i = 0; i < n; i++) {
+            Instance& I = b->inst[i];
+            if (remaining > I.rounds) continue;
+            if (par[i] && first_done) { todo.push_back(i); continue; }
+            int rc = I.inst->ingest(challenges[round], round - (max_rounds - I.rounds));
+            if (rc) return rc;
+            if (par[i]) first_done = true;
+        }
+        std::fill(rcs.begin(), rcs.end(), ATLAS_OK);
+        HT->parallel_for(todo.size(), [&](size_t lo, size_t hi, size_t part) {
+            for (size_t q = lo; q < hi && rcs[part] == ATLAS_OK; q++) {
+                Instance& I = b->inst[todo[q]];
+                rcs[part] = I.inst->ingest(challenges[round], round - (max_rounds - I.rounds));
+            }
+        });
+        for (int rc : rcs) if (rc) return rc;
+    }
+    if (HT) { *max_rounds_out = max_rounds; return ATLAS_OK; }
     for (size_t round = 0; round < max_rounds; round++) {
         const size_t remaining = max_rounds - round;
         std::vector<std::vector<H::Fr>> polys(n);

@@ -47,6 +47,10 @@ struct atlas_instance {
     // WIDE_WAIT_WGS workgroups?  Such a round of a lane on a stream of its own goes behind a one-wavefront gate
     // (k_ch_gate, channel.hip.h); a round that launches nothing, or a few workgroups, does not need one (a gate is a
     // launch: ~3 us of the host thread and a kernel boundary on the lane per round).
+    // May message() / ingest() of this instance run on a worker thread, concurrently with those of OTHER instances that say so too, once one
+    // instance of the batch has made the call for the round on the driver's thread (it does the work the instances share: launches, copies)?
+    // The rows of a OneHotPool do: their round arithmetic is per row.  (batched.hip: batches of thousands of instances)
+    virtual bool host_parallel() const { return false; }
     static constexpr size_t WIDE_WAIT_WGS = 256;
     virtual bool wide_wait(size_t /*round*/) const { return true; }
 };

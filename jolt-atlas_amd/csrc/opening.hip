@@ -12,6 +12,7 @@
 // address phase (K = 16 .. 256) is host arithmetic between launches.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -571,7 +572,9 @@ struct OneHotPool {
     uint64_t* d_off = nullptr;
     PoolRowDev *d_desc = nullptr, *h_desc = nullptr;       // h_desc: pinned staging, three regions of rows.size() descriptors (fold, bind, gather)
     Fr* h_q0 = nullptr;                                     // pinned
-    size_t folded = (size_t)-1, bound = (size_t)-1;         // global rounds already folded / bound
+    // global rounds already folded / bound.  Written LAST by fold_all / bind_all (under g.mu): a row that reads the current round here without
+    // the lock (worker threads of a large batch, host_parallel) sees everything those calls wrote
+    std::atomic<size_t> folded{(size_t)-1}, bound{(size_t)-1};
     bool have_finals = false;
     ~OneHotPool() {
         for (void* p : {(void*)d_idx, (void*)d_H, (void*)d_tabs, (void*)d_part, (void*)d_q0, (void*)d_F, (void*)d_off, (void*)d_desc}) if (p) hipFree(p);
@@ -620,7 +623,7 @@ struct OneHotPool {
         return ATLAS_OK;
     }
     int fold_all(size_t R) {
-        if (folded == R) return ATLAS_OK;
+        if (folded.load(std::memory_order_acquire) == R) return ATLAS_OK;
         int rc = gather_pending(R);
         if (rc) return rc;
         size_t n = 0, max_half = 0;
@@ -632,8 +635,7 @@ struct OneHotPool {
             for (size_t r : G.rows) { h_desc[n] = PoolRowDev{d_H + rows[r].off, nullptr, nullptr, E.e_out, E.e_in, (uint32_t)half, E.in_bits, (uint32_t)n, (uint32_t)G.T}; n++; }
             max_half = half > max_half ? half : max_half;
         }
-        folded = R;
-        if (n == 0) return ATLAS_OK;
+        if (n == 0) { folded.store(R, std::memory_order_release); return ATLAS_OK; }
         const unsigned gx = grid_for(max_half, POOL_GX);
         HIP_TRY(hipMemcpyAsync(d_desc, h_desc, n * sizeof(PoolRowDev), hipMemcpyHostToDevice, g.stream));
         k_pool_fold<<<dim3(gx, (unsigned)n), OP_THREADS, 0, g.stream>>>(d_desc, d_part);
@@ -646,11 +648,11 @@ struct OneHotPool {
             for (size_t r : G.rows) std::memcpy(&rows[r].q0, &h_q0[n++], sizeof(Fr));
             G.inv_eq1 = H::inv(H::mul(G.st.scalar, G.st.w_cur())); G.inv_round = R;        // shared by the rows of the group (gruen_poly_deg_2's division)
         }
+        folded.store(R, std::memory_order_release);
         return ATLAS_OK;
     }
     int bind_all(size_t R, const H::Fr& rf) {
-        if (bound == R) return ATLAS_OK;
-        bound = R;
+        if (bound.load(std::memory_order_acquire) == R) return ATLAS_OK;
         size_t n = 0, max_half = 0;
         PoolRowDev* hd = h_desc + rows.size();
         for (auto& G : groups) {
@@ -661,10 +663,11 @@ struct OneHotPool {
             max_half = half > max_half ? half : max_half;
             G.st.bind(rf);
         }
-        if (n == 0) return ATLAS_OK;
+        if (n == 0) { bound.store(R, std::memory_order_release); return ATLAS_OK; }
         HIP_TRY(hipMemcpyAsync(d_desc + rows.size(), hd, n * sizeof(PoolRowDev), hipMemcpyHostToDevice, g.stream));
         k_pool_bind<<<dim3(grid_for(max_half, POOL_GX), (unsigned)n), OP_THREADS, 0, g.stream>>>(d_desc + rows.size(), to_dev(rf), g.challenge_mode == 0 ? 1 : 0);
         hipError_t e = hipGetLastError();
+        bound.store(R, std::memory_order_release);
         return e == hipSuccess ? ATLAS_OK : fail(ATLAS_ENODEV, "onehot pool bind", e);
     }
     int fetch_finals() {
@@ -709,7 +712,7 @@ struct OneHotPoolRow : atlas_instance {
             return ATLAS_OK;
         }
         const size_t R = round + P->row_off(Rw);
-        {
+        if (P->folded.load(std::memory_order_acquire) != R) {        // the first row to ask does the shared fold; the others (worker threads: host_parallel) find it done
             std::lock_guard<atlas_rt::Mutex> lk(g.mu);
             const int rc = P->fold_all(R);
             if (rc) return rc;
@@ -737,7 +740,7 @@ struct OneHotPoolRow : atlas_instance {
             std::vector<H::Fr> nf(2 * Rw.F.size());                  // ExpandingTable::update, HighToLow
             for (size_t i = 0; i < Rw.F.size(); i++) { nf[2 * i + 1] = H::mul(rf, Rw.F[i]); nf[2 * i] = H::sub(Rw.F[i], nf[2 * i + 1]); }
             Rw.F.swap(nf);                                           // the gather H = F[idx] runs with the next round's fold (gather_pending)
-        } else {
+        } else if (P->bound.load(std::memory_order_acquire) != round + P->row_off(Rw)) {
             std::lock_guard<atlas_rt::Mutex> lk(g.mu);
             const int rc = P->bind_all(round + P->row_off(Rw), rf);
             if (rc) return rc;
@@ -745,6 +748,7 @@ struct OneHotPoolRow : atlas_instance {
         round_next++;
         return ATLAS_OK;
     }
+    bool host_parallel() const override { return true; }
     int finals(std::vector<H::Fr>& out) override {
         if (round_next != rounds()) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
         std::lock_guard<atlas_rt::Mutex> lk(g.mu);

@@ -64,7 +64,20 @@ def test_sharded_sumcheck_and_msm(tmp_path, world, n):
 @pytest.mark.parametrize("world,n", [(2, 14), (4, 16), (8, 13), (2, 3)])
 def test_sharded_over_shared_memory_board(tmp_path, world, n):
     """atlas_sumcheck_prove_dot_sharded: one call per rank, round channel + shared-memory board, no collective; every rank's
-    proof equals the oracle's proof of the whole instance.  Processes share the test box's GPU."""
+    proof equals the oracle's proof of the whole instance.  Processes share the test box's GPU.  The oracle's proof and MSM are computed
+    once here and handed to the ranks in a file."""
+    from oracle import orc
+    L = orc.random_fr(1 << n, 11); R = orc.random_fr(1 << n, 12)
+    t_o = orc.new_transcript(b"sharded")
+    want_claim = orc.dot_claim(L, R)
+    proof_o, ch_o, fin_o = orc.sumcheck_dot_prove(L.copy(), R.copy(), want_claim, t_o)
+    m = 1 << 10
+    tau = orc.random_fr(1, 5)[0]
+    srs_full = orc.srs_powers(tau, m)
+    sc = orc.random_fr(m, 6)
+    want = tmp_path / "want.npz"
+    np.savez(want, L=L, R=R, claim=want_claim[0], proof=proof_o, ch=np.array([[c & (2**64 - 1), c >> 64] for c in ch_o], dtype=np.uint64), fin=fin_o,
+             state=np.frombuffer(t_o.state_bytes(), dtype=np.uint8), n_rounds=np.array([t_o.n_rounds]), srs=srs_full, sc=sc, msm=np.asarray(orc.msm(srs_full, sc)).reshape(1))
     script = tmp_path / "w.py"
     script.write_text(textwrap.dedent(f"""
         import os, sys
@@ -75,24 +88,19 @@ def test_sharded_over_shared_memory_board(tmp_path, world, n):
         from jolt_atlas_amd import sharded
         from oracle import orc
         A.init(0)
-        n = {n}
-        L = orc.random_fr(1 << n, 11); R = orc.random_fr(1 << n, 12)
+        W = np.load({str(want)!r})
+        L, R = W["L"], W["R"]
         grp = sharded.ShardGroup(sys.argv[2], world, rank)
         t = A.Blake2bTranscript(b"sharded")
         proof, ch, fin, claim = sharded.prove_dot_sharded_shm(grp, sharded.strided_shard(L, rank, world), sharded.strided_shard(R, rank, world), t)
-        t_o = orc.new_transcript(b"sharded")
-        want_claim = orc.dot_claim(L, R)
-        proof_o, ch_o, fin_o = orc.sumcheck_dot_prove(L, R, want_claim, t_o)
-        assert np.array_equal(claim, want_claim[0])
-        assert ch == ch_o and np.array_equal(proof, proof_o) and np.array_equal(fin, fin_o)
-        assert t.state == t_o.state_bytes() and t.n_rounds == t_o.n_rounds
+        assert np.array_equal(claim, W["claim"])
+        assert ch == [int(lo) | (int(hi) << 64) for lo, hi in W["ch"]] and np.array_equal(proof, W["proof"]) and np.array_equal(fin, W["fin"])
+        assert t.state == W["state"].tobytes() and t.n_rounds == int(W["n_rounds"][0])
         m = 1 << 10
-        tau = orc.random_fr(1, 5)[0]
-        srs_full = orc.srs_powers(tau, m)
-        sc = orc.random_fr(m, 6)
+        srs_full, sc = W["srs"], W["sc"]
         lo, hi = rank * m // world, (rank + 1) * m // world
         srs = A.SRS.upload(srs_full[lo:hi])
-        assert orc.g1_eq(sharded.msm_sharded_shm(grp, srs, sc[lo:hi]), orc.msm(srs_full, sc))
+        assert orc.g1_eq(sharded.msm_sharded_shm(grp, srs, sc[lo:hi]), W["msm"][0])
         grp.close()
         print("SHM_SHARDED_OK", rank)
     """))
