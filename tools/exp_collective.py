@@ -85,7 +85,8 @@ def spawn(mode, world, extra):
     outs = [p.communicate(timeout=300) for p in procs]
     if any(p.returncode for p in procs):
         return {"error": outs[0][1][-300:]}
-    return json.loads(outs[0][0].strip().splitlines()[-1])
+    lines = [l for l in outs[0][0].splitlines() if l.strip().startswith("{")]        # the runtime may print lines of its own
+    return json.loads(lines[-1]) if lines else {"error": "no result line", "stdout": outs[0][0][-300:], "stderr": outs[0][1][-300:]}
 
 
 if __name__ == "__main__":
