@@ -148,7 +148,7 @@ def cpu_baseline_prove_graph(budget_s=30.0):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import build_graphs as BG
     from oracle import graph as OG, orc
-    nodes, outputs, inputs = BG.microgpt()
+    nodes, outputs, inputs = BG.microgpt_model()
     nv = BG.max_vars(nodes)
     tau = orc.random_fr(1, 0x51250001)[0]
     srs_h = orc.srs_powers(tau, 1 << nv)
@@ -514,10 +514,12 @@ def main():
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
         import build_graphs as BG
         from jolt_atlas_amd import graph as GG
-        out["prove_graph"] = {"note": "synthetic-trace proxy of ONNXProof::prove: the model's operator list and (padded) shapes, random-init weights, "
+        out["prove_graph"] = {"note": "ONNXProof::prove over the builder's reading of the loader's operator decomposition, shapes padded to powers of two; microgpt / nanogpt: the model files' tensors and example inputs, GPT-2 shapes: random-init; "
                                       "full operator decomposition (SoftmaxLastAxis, tanh-GELU, LayerNorm, GatherSmall); reference (M3 CPU): nanoGPT 2.288 s, GPT-2 12 layers 14.889 s"}
+        # microgpt / nanogpt: the model files' own tensors (quantised at 2^14) and example token ids (tests/golden/ref_models.npz, tools/extract_ref_model.py) over the
+        # builder's reading of the loader's operator decomposition; the GPT-2 shapes: random-init (no GPT-2 file in the reference tree)
         for gname in ("microgpt", "nanogpt", "gpt2_layer") + (() if args.no_gpt2_full else ("gpt2",)):
-            nodes_g, outs_g, ins_g = getattr(BG, gname)()
+            nodes_g, outs_g, ins_g = getattr(BG, gname + "_model" if gname in ("microgpt", "nanogpt") else gname)()
             nv = BG.max_vars(nodes_g)
             t0s = time.perf_counter()
             srs_g = A.SRS.generate(np.array([0x1234567, 0, 0, 0], dtype=np.uint64), 1 << nv)
@@ -546,7 +548,8 @@ def main():
                                          "stage_ms": {k: best_g[k] for k in ("trace_ms", "commit_ms", "iop_ms", "reduction_ms", "hyperkzg_ms")},
                                          "nodes": best_g["n_nodes"], "committed_polys": best_g["n_committed"], "sumcheck_proofs": best_g["n_sumchecks"],
                                          "proof_bytes": len(pf_g), "proof_sha16": __import__("hashlib").sha256(pf_g).hexdigest()[:16], "max_num_vars": nv, "setup_prover_s": setup_s,
-                                         "operators": dict(Counter(n["op"] for n in nodes_g))}
+                                         "operators": dict(Counter(n["op"] for n in nodes_g)),
+                                         "weights": "model file (network.onnx tensors, example input)" if gname in ("microgpt", "nanogpt") else "random-init"}
             Gg.free(); srs_g.free()
     # the three node shapes timed above, as one-operator graphs: proved by atlas_prove_graph and ACCEPTED by atlas_verify_graph
     # (the node entry points take their opening point from the caller, so their proofs have no stand-alone verifier; the graph form is

@@ -443,10 +443,14 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
     if (HT && HT->threads() < 2) HT = nullptr;
     std::vector<uint8_t> par(n, 0);
     if (HT) for (size_t i = 0; i < n; i++) par[i] = b->inst[i].inst->host_parallel() ? 1 : 0;
+    double tt[6] = {0, 0, 0, 0, 0, 0};                   // ATLAS_TRACE: message serial / parallel, combine + transcript, claim update, ingest serial / parallel
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     for (size_t round = 0; round < max_rounds && HT; round++) {
         const size_t remaining = max_rounds - round;
         std::vector<std::vector<H::Fr>> polys(n);
         std::vector<int> rcs(HT->threads(), ATLAS_OK);
+        const auto q0 = tnow();
         // compute_message: the constant members and the serial ones here, then the first parallel one, then the rest on the workers
         bool first_done = false;
         std::vector<size_t> todo;
@@ -459,6 +463,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
             if (rc) return rc;
             if (par[i]) first_done = true;
         }
+        const auto q1 = tnow();
         HT->parallel_for(todo.size(), [&](size_t lo, size_t hi, size_t part) {
             for (size_t q = lo; q < hi && rcs[part] == ATLAS_OK; q++) {
                 Instance& I = b->inst[todo[q]];
@@ -466,6 +471,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
             }
         });
         for (int rc : rcs) if (rc) return rc;
+        const auto q2 = tnow();
         // batched = sum coeff_i * poly_i (from_coeff trimming per term, the sum keeps the longest length): partial sums per thread
         std::vector<std::vector<H::Fr>> partial(HT->threads());
         HT->parallel_for(n, [&](size_t lo, size_t hi, size_t part) {
@@ -497,7 +503,9 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         H::tr_challenge_u128(T, lo64, hi64);
         challenges[round].lo = lo64; challenges[round].hi = hi64;
         const H::Fr r = H::challenge_to_fr(lo64, hi64, g.challenge_mode);
+        const auto q3 = tnow();
         HT->parallel_for(n, [&](size_t lo, size_t hi, size_t) { for (size_t i = lo; i < hi; i++) claim[i] = eval_with_challenge(polys[i], r); });
+        const auto q4 = tnow();
         // ingest_challenge, in the same three steps
         first_done = false;
         todo.clear();
@@ -510,6 +518,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
             if (par[i]) first_done = true;
         }
         std::fill(rcs.begin(), rcs.end(), ATLAS_OK);
+        const auto q5 = tnow();
         HT->parallel_for(todo.size(), [&](size_t lo, size_t hi, size_t part) {
             for (size_t q = lo; q < hi && rcs[part] == ATLAS_OK; q++) {
                 Instance& I = b->inst[todo[q]];
@@ -517,8 +526,15 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
             }
         });
         for (int rc : rcs) if (rc) return rc;
+        const auto q6 = tnow();
+        tt[0] += tms(q0, q1); tt[1] += tms(q1, q2); tt[2] += tms(q2, q3); tt[3] += tms(q3, q4); tt[4] += tms(q4, q5); tt[5] += tms(q5, q6);
     }
-    if (HT) { *max_rounds_out = max_rounds; return ATLAS_OK; }
+    if (HT) {
+        if (trace) fprintf(stderr, "[atlas trace] batched_prove (%zu instances on %zu host threads, %zu rounds): message first + serial %.3f ms, message parallel %.3f ms, combine + transcript %.3f ms, "
+                                   "claim update %.3f ms, ingest first + serial %.3f ms, ingest parallel %.3f ms\n", n, HT->threads(), max_rounds, tt[0], tt[1], tt[2], tt[3], tt[4], tt[5]);
+        *max_rounds_out = max_rounds;
+        return ATLAS_OK;
+    }
     for (size_t round = 0; round < max_rounds; round++) {
         const size_t remaining = max_rounds - round;
         std::vector<std::vector<H::Fr>> polys(n);

@@ -13,6 +13,9 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -560,6 +563,72 @@ __global__ __launch_bounds__(OP_THREADS) void k_pool_heads(const Fr* __restrict_
     for (uint32_t r = blockIdx.x * OP_THREADS + threadIdx.x; r < n; r += gridDim.x * OP_THREADS) fe_store(out + r, fe_load(H + off[r]));
 }
 
+// The eq tables of ALL groups of a pool in two launches (a group = one lookup family's r_cycle; a graph has hundreds): per group the
+// constructor used to enqueue k_store_point + k_eq_head + the doubling steps + two k_eq_cached_rev — ~8 launches of one or a few
+// workgroups each, 30-50 us per group on the host thread and as many tiny kernels in a row on the device.
+struct PoolEqJob { Fr* out; const Fr* w; uint32_t n; uint32_t pad; };
+// job = (tabs, r, k) of k_eq_cached_rev; one workgroup per job
+__global__ __launch_bounds__(1024) void k_pool_eq_cached_rev(const PoolEqJob* __restrict__ jobs) {
+    const PoolEqJob J = jobs[blockIdx.x];
+    Fr* tabs = J.out; const Fr* r = J.w; const uint32_t k = J.n;
+    if (threadIdx.x == 0) fe_store(tabs, fr_one());
+    __syncthreads();
+    for (uint32_t j = 0; j < k; j++) {
+        const Fr rv = fe_load(r + (k - 1 - j));
+        const uint32_t size = 1u << j;
+        const Fr* cur = tabs + (size - 1);
+        Fr* nxt = tabs + (2 * size - 1);
+        for (uint32_t i = threadIdx.x; i < size; i += 1024) {
+            const Fr s = fe_load(cur + i);
+            const Fr hi = fr_mul(s, rv);
+            fe_store(nxt + i + size, hi);
+            fe_store(nxt + i, fr_sub(s, hi));
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+// EqPolynomial::evals(w[0..n)) (big-endian index: w[0] <-> the most significant bit, eq_poly.rs:77-101) of group blockIdx.y: the table over the
+// low L = min(n, 8) variables grows in LDS, a workgroup takes 64 values of the high index bits — their factors by direct products — and writes
+// 64 x 2^L entries, one multiplication each.  Exact field arithmetic: the same residues as the doubling passes of atlas_rt_eq_evals_into.
+constexpr uint32_t POOL_EQ_HI = 64;
+__global__ __launch_bounds__(256) void k_pool_eq_full(const PoolEqJob* __restrict__ jobs) {
+    __shared__ Fr tab[256];
+    __shared__ Fr hif[POOL_EQ_HI];
+    const PoolEqJob J = jobs[blockIdx.y];
+    const uint32_t n = J.n, L = n < 8 ? n : 8, nh = n - L;
+    const uint64_t n_hi = (uint64_t)1 << nh, hi0 = (uint64_t)blockIdx.x * POOL_EQ_HI;
+    if (hi0 >= n_hi) return;
+    if (threadIdx.x == 0) tab[0] = fr_one();
+    __syncthreads();
+    for (uint32_t s = 0; s < L; s++) {
+        const Fr v = fe_load(J.w + nh + s);
+        const bool act = threadIdx.x < (1u << s);
+        Fr f = fe_zero(), hi = fe_zero();
+        if (act) { f = tab[threadIdx.x]; hi = fr_mul(f, v); }
+        __syncthreads();
+        if (act) { tab[2 * threadIdx.x + 1] = hi; tab[2 * threadIdx.x] = fr_sub(f, hi); }
+        __syncthreads();
+    }
+    const uint32_t cnt = (uint32_t)(n_hi - hi0 < POOL_EQ_HI ? n_hi - hi0 : POOL_EQ_HI);
+    if (threadIdx.x < cnt) {
+        const uint64_t hi = hi0 + threadIdx.x;
+        Fr f = fr_one();
+        const Fr one = fr_one();
+        for (uint32_t i = 0; i < nh; i++) {
+            const Fr wv = fe_load(J.w + i);
+            f = fr_mul(f, ((hi >> (nh - 1 - i)) & 1) ? wv : fr_sub(one, wv));
+        }
+        hif[threadIdx.x] = f;
+    }
+    __syncthreads();
+    const uint32_t width = 1u << L;
+    for (uint32_t e = threadIdx.x; e < cnt * width; e += 256) {
+        const uint32_t h = e >> L, t = e & (width - 1);
+        fe_store(J.out + ((hi0 + h) << L) + t, fr_mul(hif[h], tab[t]));
+    }
+}
+
 struct OneHotPool {
     size_t log_K = 0, K = 0, max_rounds = 0, refs = 0;
     struct Group { size_t log_T = 0, T = 0, off = 0; H::GseStateH st; Fr *d_ein = nullptr, *d_eout = nullptr; std::vector<size_t> rows; H::Fr inv_eq1; size_t inv_round = (size_t)-1; };
@@ -576,7 +645,10 @@ struct OneHotPool {
     // the lock (worker threads of a large batch, host_parallel) sees everything those calls wrote
     std::atomic<size_t> folded{(size_t)-1}, bound{(size_t)-1};
     bool have_finals = false;
+    double t_fold = 0, t_bind = 0, t_gather = 0;          // ATLAS_TRACE: wall clock of the shared steps (the driver's thread)
+    static bool pool_trace() { static const bool on = getenv("ATLAS_TRACE") != nullptr; return on; }
     ~OneHotPool() {
+        if (pool_trace()) fprintf(stderr, "[atlas trace] onehot pool (%zu rows, %zu groups): gather %.3f ms, fold + reduce + copy %.3f ms, bind %.3f ms\n", rows.size(), groups.size(), t_gather, t_fold, t_bind);
         for (void* p : {(void*)d_idx, (void*)d_H, (void*)d_tabs, (void*)d_part, (void*)d_q0, (void*)d_F, (void*)d_off, (void*)d_desc}) if (p) hipFree(p);
         if (h_desc) (void)hipHostFree(h_desc);
         if (h_q0) (void)hipHostFree(h_q0);
@@ -624,8 +696,12 @@ struct OneHotPool {
     }
     int fold_all(size_t R) {
         if (folded.load(std::memory_order_acquire) == R) return ATLAS_OK;
+        const auto tq0 = std::chrono::steady_clock::now();
         int rc = gather_pending(R);
         if (rc) return rc;
+        const auto tq1 = std::chrono::steady_clock::now();
+        t_gather += std::chrono::duration<double, std::milli>(tq1 - tq0).count();
+        struct Acc { double& t; std::chrono::steady_clock::time_point a; ~Acc() { t += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); } } acc_{t_fold, tq1};
         size_t n = 0, max_half = 0;
         for (auto& G : groups) {
             const long c = cycle_of(G, R);
@@ -653,6 +729,7 @@ struct OneHotPool {
     }
     int bind_all(size_t R, const H::Fr& rf) {
         if (bound.load(std::memory_order_acquire) == R) return ATLAS_OK;
+        struct Acc { double& t; std::chrono::steady_clock::time_point a; ~Acc() { t += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); } } acc_{t_bind, std::chrono::steady_clock::now()};
         size_t n = 0, max_half = 0;
         PoolRowDev* hd = h_desc + rows.size();
         for (auto& G : groups) {
@@ -849,14 +926,22 @@ int atlas_rt_onehot_pool_new(const atlas_rt_pool_row* in, size_t n, size_t log_K
     HIP_TRY(hipMemcpyAsync(P->d_off, off.data(), n * 8, hipMemcpyHostToDevice, g.stream));
     HIP_TRY(hipMemcpyAsync(d_Eptr, Eptr.data(), n * sizeof(void*), hipMemcpyHostToDevice, g.stream));
     k_pool_chunk_rows<<<dim3(grid_for(maxT, POOL_GX), (unsigned)n), OP_THREADS, 0, g.stream>>>(d_lk, d_shift, P->d_off, d_Ts, (uint32_t)(P->K - 1), P->d_idx);
+    // the split-eq suffix tables (GseDevH::init) and D.merge() before any bind = EqPolynomial::evals(r_cycle) for the histogram: all groups at once
+    std::vector<PoolEqJob> jobs(3 * NG);
+    PoolEqJob* d_jobs = nullptr;
+    HIP_TRY(tmalloc((void**)&d_jobs, jobs.size() * sizeof(PoolEqJob)));
+    size_t max_hi_blocks = 1;
     for (size_t q = 0; q < NG; q++) {
         OneHotPool::Group& G = P->groups[q];
-        // the split-eq suffix tables (GseDevH::init) and D.merge() before any bind = EqPolynomial::evals(r_cycle) for the histogram
-        k_eq_cached_rev<<<1, 1024, 0, g.stream>>>(G.d_ein, d_w + g_w[q] + 1, (uint32_t)G.st.k_in);
-        k_eq_cached_rev<<<1, 1024, 0, g.stream>>>(G.d_eout, d_w + g_w[q] + 1 + G.st.k_in, (uint32_t)G.st.k_out);
-        int rc = atlas_rt_eq_evals_into(G.st.w.data(), G.log_T, d_E + g_E[q]);
-        if (rc) return rc;
+        jobs[2 * q] = PoolEqJob{G.d_ein, d_w + g_w[q] + 1, (uint32_t)G.st.k_in, 0};
+        jobs[2 * q + 1] = PoolEqJob{G.d_eout, d_w + g_w[q] + 1 + G.st.k_in, (uint32_t)G.st.k_out, 0};
+        jobs[2 * NG + q] = PoolEqJob{d_E + g_E[q], d_w + g_w[q], (uint32_t)G.log_T, 0};
+        const size_t nh = G.log_T < 8 ? 0 : G.log_T - 8, hb = (((size_t)1 << nh) + POOL_EQ_HI - 1) / POOL_EQ_HI;
+        max_hi_blocks = hb > max_hi_blocks ? hb : max_hi_blocks;
     }
+    HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(PoolEqJob), hipMemcpyHostToDevice, g.stream));      // (jobs lives until the synchronisation below)
+    k_pool_eq_cached_rev<<<(unsigned)(2 * NG), 1024, 0, g.stream>>>(d_jobs);
+    k_pool_eq_full<<<dim3((unsigned)max_hi_blocks, (unsigned)NG), 256, 0, g.stream>>>(d_jobs + 2 * NG);
     k_pool_hist<<<(unsigned)n, OP_THREADS, 0, g.stream>>>(P->d_idx, P->d_off, d_Ts, d_Eptr, (uint32_t)P->K, d_hist);
     std::vector<unsigned long long> hist(n * 16 * 8);
     HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, hist.size() * 8, hipMemcpyDeviceToHost, g.stream));

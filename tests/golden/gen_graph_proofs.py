@@ -30,7 +30,8 @@ def cases():
     import build_graphs as BG
     return {
         "microgpt": lambda: BG.microgpt(),
-        "nanogpt": lambda: BG.nanogpt(),
+        # the model files' own tensors and example inputs (tests/golden/ref_models.npz)
+        "microgpt_model": BG.microgpt_model, "nanogpt_model": BG.nanogpt_model,
         "gpt2_layer": lambda: BG.gpt2_layer(),
         "tiny4": lambda: BG.tiny(layers=4),
         "tiny2": lambda: BG.tiny(layers=2),

@@ -1,5 +1,5 @@
 """GPU: ONNXProof::prove at the model shapes of BASELINE.json (config 1: microgpt-shaped; config 3: nanoGPT-shaped; one GPT-2 layer)
-against COMMITTED oracle results (tests/golden/graph_proofs.json, made in the build container by tests/golden/gen_graph_proofs.py:
+(microgpt_model / nanogpt_model: over the model files' own tensors and example inputs, tests/golden/ref_models.npz) against COMMITTED oracle results (tests/golden/graph_proofs.json, made in the build container by tests/golden/gen_graph_proofs.py:
 oracle/graph.py takes minutes on these graphs, so the GPU box does not recompute it): per-node trace hashes, sha256 of the proof bytes,
 the final transcript state, the number of committed polynomials — then ONNXProof::verify of the device's proof.
 
@@ -21,7 +21,7 @@ GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "graph_proofs.json")
 
 def _build(name):
     import build_graphs as BG
-    return {"microgpt": BG.microgpt, "nanogpt": BG.nanogpt, "gpt2_layer": BG.gpt2_layer, "tiny4": lambda: BG.tiny(layers=4), "tiny2": lambda: BG.tiny(layers=2),
+    return {"microgpt": BG.microgpt, "microgpt_model": BG.microgpt_model, "nanogpt_model": BG.nanogpt_model, "gpt2_layer": BG.gpt2_layer, "tiny4": lambda: BG.tiny(layers=4), "tiny2": lambda: BG.tiny(layers=2),
             "node_einsum": BG.node_einsum, "node_relu": BG.node_relu, "node_mul": BG.node_mul}[name]()
 
 
@@ -29,7 +29,7 @@ def _h(a):
     return hashlib.sha256(np.ascontiguousarray(a, dtype=np.int32).tobytes()).hexdigest()[:16]
 
 
-@pytest.mark.parametrize("name", ["microgpt", "tiny2", "tiny4", "nanogpt", "gpt2_layer", "node_einsum", "node_relu", "node_mul"])
+@pytest.mark.parametrize("name", ["microgpt", "microgpt_model", "tiny2", "tiny4", "nanogpt_model", "gpt2_layer", "node_einsum", "node_relu", "node_mul"])
 def test_model_shaped_proof_matches_committed_oracle_result(atlas, name):
     import build_graphs as BG
     from oracle import orc

@@ -40,17 +40,36 @@ class B:
 
 
 def transformer(layers, seq, d_model, heads, vocab, S=14, level=2, seed=0, mlp_mult=4, final_head=True, norm_kind="layer", act="gelu",
-                bias=True, norm0=False, final_norm=True, att_scale=False, mask_fill=None):
+                bias=True, norm0=False, final_norm=True, att_scale=False, mask_fill=None, fused_qkv=False, cube_as_muls=False, weights=None, round_consts=False):
+    """weights (optional): the model file's tensors quantized at scale S — {"wte": [vocab][d], "wpe": [seq][d], "ln": [vectors in order of use],
+    "mats": [matrices [in][out] in order of use]}, each padded to powers of two with zeros (tests/golden/ref_models.npz, tools/extract_ref_model.py);
+    None: random-init.  round_consts: the scalar constants of the graph rounded as quantize_float rounds (utils/quantize.rs:137-185) instead of truncated."""
     b = B(seed)
+    wq_ = {k: list(v) if isinstance(v, (list, tuple)) else v for k, v in (weights or {}).items()}
+    qc = (lambda f: int(np.floor(abs(f) * (1 << S) + 0.5)) * (1 if f >= 0 else -1)) if (round_consts or weights is not None) else (lambda f: int(f * (1 << S)))
+
+    def mat(k, n):
+        if weights is None:
+            return b.const([k, n], -wlim, wlim)
+        w = np.asarray(wq_["mats"].pop(0), dtype=np.int32)
+        assert w.shape == (k, n), (w.shape, k, n)
+        return b.const_data([k, n], w)
+
+    def lnw():
+        if weights is None:
+            return b.const([d_model], one // 2, one + one // 2)
+        w = np.asarray(wq_["ln"].pop(0), dtype=np.int32)
+        assert w.shape == (d_model,)
+        return b.const_data([d_model], w)
     hd = d_model // heads
     wlim = 1 << (S - 2)                      # weights ~ U(-0.25, 0.25) at scale S
     ff = mlp_mult * d_model
     one = 1 << S
     if level >= 2:                           # token + position embedding: Gather(wte, tokens) + wpe
         tok = b.add("Input", [], [seq])
-        wte = b.const([vocab, d_model], -one, one)
+        wte = b.const([vocab, d_model], -one, one) if weights is None else b.const_data([vocab, d_model], np.asarray(wq_["wte"], dtype=np.int32))
         x = b.add("GatherSmall" if vocab <= 65536 else "GatherLarge", [wte, tok], [seq, d_model], axis=0, dict_len=vocab)
-        x = b.add("Add", [x, b.const([seq, d_model], -wlim, wlim)], [seq, d_model])
+        x = b.add("Add", [x, b.const([seq, d_model], -wlim, wlim) if weights is None else b.const_data([seq, d_model], np.asarray(wq_["wpe"], dtype=np.int32))], [seq, d_model])
     else:
         x = b.add("Input", [], [seq, d_model])
     mask = b.const_data([seq, seq], np.tril(np.ones((seq, seq), dtype=np.int32)))
@@ -76,17 +95,22 @@ def transformer(layers, seq, d_model, heads, vocab, S=14, level=2, seed=0, mlp_m
         var = b.add("Add", [var, full([seq, 1], 1)], [seq, 1])
         rs = b.add("Rsqrt", [var], [seq, 1], scale=S)
         y = b.add("Mul", [c, b.add("Broadcast", [rs], [seq, d_model])], [seq, d_model], scale=S)
-        w = b.add("Broadcast", [b.const([d_model], one // 2, one + one // 2)], [seq, d_model])
+        w = b.add("Broadcast", [lnw()], [seq, d_model])
         y = b.add("Mul", [y, w], [seq, d_model], scale=S)
+        if not bias:                         # LayerNorm(ndim, bias=False): the weight only (models/nanoGPT/gen.py:28-37, config bias=False)
+            return y
         return b.add("Add", [y, b.add("Broadcast", [b.const([d_model], -wlim, wlim)], [seq, d_model])], [seq, d_model])
 
     def gelu(f):
         """tanh-GELU: 0.5 f (1 + tanh(0.79788 (f + 0.044715 f^3)))"""
         if level < 2 or act == "relu":
             return b.add("ReLU", [f], [seq, ff])
-        f3 = b.add("Cube", [f], [seq, ff], scale=S)
-        u = b.add("Add", [f, b.add("Mul", [f3, full([seq, ff], int(0.044715 * one))], [seq, ff], scale=S)], [seq, ff])
-        v = b.add("Mul", [u, full([seq, ff], int(0.7978845608 * one))], [seq, ff], scale=S)
+        if cube_as_muls:                     # x * x * x as the model file writes it (two Mul nodes; torch.pow(x, 3) would be a Pow -> Cube)
+            f3 = b.add("Mul", [b.add("Mul", [f, f], [seq, ff], scale=S), f], [seq, ff], scale=S)
+        else:
+            f3 = b.add("Cube", [f], [seq, ff], scale=S)
+        u = b.add("Add", [f, b.add("Mul", [f3, full([seq, ff], qc(0.044715))], [seq, ff], scale=S)], [seq, ff])
+        v = b.add("Mul", [u, full([seq, ff], qc(0.7978845608028654))], [seq, ff], scale=S)
         th = b.add("Tanh", [v], [seq, ff], scale=S)
         w = b.add("Add", [th, full([seq, ff], one)], [seq, ff])
         hx = b.add("Mul", [f, full([seq, ff], one // 2)], [seq, ff], scale=S)
@@ -97,9 +121,19 @@ def transformer(layers, seq, d_model, heads, vocab, S=14, level=2, seed=0, mlp_m
     for _ in range(layers):
         h = norm(x)
         # attention: q, k, v projections (one Einsum each: the tracer splits the fused qkv Gemm through Slice nodes)
-        q = b.matmul(h, b.const([d_model, d_model], -wlim, wlim), seq, d_model, d_model, S)
-        k = b.matmul(h, b.const([d_model, d_model], -wlim, wlim), seq, d_model, d_model, S)
-        v = b.matmul(h, b.const([d_model, d_model], -wlim, wlim), seq, d_model, d_model, S)
+        if fused_qkv:                        # c_attn: ONE MatMul into 3 d_model columns (padded to 4 d_model), then Split -> three Slice nodes
+            if weights is None:
+                wq = b.rng.integers(-wlim, wlim, size=(d_model, 4 * d_model)).astype(np.int32)
+                wq[:, 3 * d_model:] = 0      # the loader's zero padding of 3 d_model -> the next power of two
+                wqkv = b.const_data([d_model, 4 * d_model], wq)
+            else:
+                wqkv = mat(d_model, 4 * d_model)
+            qkv = b.matmul(h, wqkv, seq, d_model, 4 * d_model, S)
+            q, k, v = (b.add("Slice", [qkv], [seq, d_model], axis=1, start=j * d_model, end=(j + 1) * d_model) for j in range(3))
+        else:
+            q = b.matmul(h, mat(d_model, d_model), seq, d_model, d_model, S)
+            k = b.matmul(h, mat(d_model, d_model), seq, d_model, d_model, S)
+            v = b.matmul(h, mat(d_model, d_model), seq, d_model, d_model, S)
         qh = b.add("Reshape", [q], [seq, heads, hd])
         kh = b.add("Reshape", [k], [seq, heads, hd])
         vh = b.add("Reshape", [v], [seq, heads, hd])
@@ -110,35 +144,61 @@ def transformer(layers, seq, d_model, heads, vocab, S=14, level=2, seed=0, mlp_m
         att = b.add("SoftmaxLastAxis", [att], [heads, seq, seq], scale=S) if level >= 2 and S == 14 else b.add("ReLU", [att], [heads, seq, seq])
         y = b.add("Einsum", [att, vh], [seq, heads, hd], layout="bmk,kbn->mbn", scale=S, shape=[heads, seq, seq, hd])
         y = b.add("Reshape", [y], [seq, d_model])
-        y = b.matmul(y, b.const([d_model, d_model], -wlim, wlim), seq, d_model, d_model, S)
+        y = b.matmul(y, mat(d_model, d_model), seq, d_model, d_model, S)
         x = b.add("Add", [x, y], [seq, d_model])
         # MLP
         h = norm(x)
-        f = b.matmul(h, b.const([d_model, ff], -wlim, wlim), seq, d_model, ff, S)
+        f = b.matmul(h, mat(d_model, ff), seq, d_model, ff, S)
         if bias:
             f = b.add("Add", [f, b.add("Broadcast", [b.const([ff], -wlim, wlim)], [seq, ff])], [seq, ff])
         f = gelu(f)
-        f = b.matmul(f, b.const([ff, d_model], -wlim, wlim), seq, ff, d_model, S)
+        f = b.matmul(f, mat(ff, d_model), seq, ff, d_model, S)
         x = b.add("Add", [x, f], [seq, d_model])
     if final_norm:
         x = norm(x)
     if final_head:
-        x = b.matmul(x, b.const([d_model, vocab], -wlim, wlim), seq, d_model, vocab, S)
+        x = b.matmul(x, mat(d_model, vocab), seq, d_model, vocab, S)
     rng = np.random.default_rng(seed + 1)
     inputs = [rng.integers(0, vocab, size=seq).astype(np.int32)] if level >= 2 else [rng.integers(-one, one, size=seq * d_model).astype(np.int32)]
+    if weights is not None and "tokens" in weights:
+        inputs = [np.asarray(weights["tokens"], dtype=np.int32)]
     return b.nodes, [x], inputs
 
 
-def nanogpt(level=2, seed=0):
-    return transformer(layers=4, seq=64, d_model=64, heads=4, vocab=128, level=level, seed=seed)
+def nanogpt(level=2, seed=0, weights=None):
+    """the shape of atlas-onnx-tracer/models/nanoGPT (gen.py:208-209: block 64, vocab 65 -> 128, 4 layers, 4 heads, n_embd 64, bias=False): LayerNorm
+    with a weight and no bias, Linear layers without bias, the fused c_attn MatMul (64 x 192 -> 256) split three ways, the 1/sqrt(head_dim) score
+    scale, masked scores filled with -10, tanh-GELU with x * x * x as two Mul nodes.  tests/test_model_shapes.py holds the operator counts of this
+    graph against those of the model file (tests/golden/ref_model_ops.json)."""
+    return transformer(layers=4, seq=64, d_model=64, heads=4, vocab=128, level=level, seed=seed, bias=False, att_scale=True, mask_fill=-10 * (1 << 14),
+                       fused_qkv=True, cube_as_muls=True, weights=weights, round_consts=True)
 
 
-def microgpt(level=2, seed=0):
+def microgpt(level=2, seed=0, weights=None):
     """the shape of atlas-onnx-tracer/models/microgpt (gen.py:180-186; jolt-atlas-core/examples/microgpt.rs:20-31): vocab 32, n_embd 16, 4 heads,
     1 layer, block 16; RMSNorm without parameters (one right after the embedding, none before the head), ReLU MLP, no biases, the 1/sqrt(head_dim)
     score scale, masked scores filled with -10 (BASELINE config 1 shape)"""
     return transformer(layers=1, seq=16, d_model=16, heads=4, vocab=32, level=level, seed=seed, norm_kind="rms", act="relu", bias=False, norm0=True,
-                       final_norm=False, att_scale=True, mask_fill=-10 * (1 << 14))
+                       final_norm=False, att_scale=True, mask_fill=-10 * (1 << 14), weights=weights)
+
+
+def _model_weights(key, n_ln):
+    """tests/golden/ref_models.npz (tools/extract_ref_model.py): the model file's tensors quantized at 2^14 and padded, its example token ids"""
+    import os
+    Z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ref_models.npz"))
+    lns = [Z[k] for k in sorted(Z.files) if k.startswith(key + "/ln")]
+    return {"wte": Z[key + "/wte"], "wpe": Z[key + "/wpe"], "mats": [Z[k] for k in sorted(Z.files) if k.startswith(key + "/mat")],
+            "ln": [lns[0]] * n_ln if lns else [], "tokens": Z[key + "/tokens"]}           # the exporter keeps ONE copy of the (identical) LayerNorm weights
+
+
+def nanogpt_model():
+    """nanogpt() over the tensors of atlas-onnx-tracer/models/nanoGPT/network.onnx and the example input of models/nanoGPT/input.json (BASELINE config 3)"""
+    return nanogpt(weights=_model_weights("nanogpt", 9))
+
+
+def microgpt_model():
+    """microgpt() over the tensors of atlas-onnx-tracer/models/microgpt/network.onnx and its example input (BASELINE config 1)"""
+    return microgpt(weights=_model_weights("microgpt", 0))
 
 
 def gpt2_layer(level=2, seed=0):
