@@ -158,8 +158,10 @@ struct Pipeline {
                 if (!ev[0]) for (size_t i = 0; i <= N_SIDE; i++) HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
                 HIP_TRY(hipEventRecord(ev[N_SIDE], g.stream));
                 for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) HIP_TRY(hipStreamWaitEvent(st[i], ev[N_SIDE], 0));
-            } else
+            } else {
                 HIP_TRY(hipStreamSynchronize(g.stream));
+                atlas_rt::dev_pool().retag_all();            // nothing is in flight: a block the library stream returned may go to a lane
+            }
         }
         return advance(0);
     }
@@ -174,6 +176,7 @@ struct Pipeline {
             return;
         }
         for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) (void)hipStreamSynchronize(st[i]);   // (host waits, for the reason given in begin; the finals have been mailed, the lanes are about idle)
+        atlas_rt::dev_pool().retag_all();                    // the lanes have drained: what they returned may go to the library stream
         side = false;
     }
     void query() { (void)hipStreamQuery(g.stream); if (side) for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) (void)hipStreamQuery(side_streams()[i]); }

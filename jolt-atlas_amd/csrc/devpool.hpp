@@ -12,6 +12,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -30,6 +32,8 @@ struct DevPool {
     size_t double_free = 0;
     size_t cross_stream = 0;                              // blocks passed over because they were freed under another stream
     size_t cached = 0;
+    size_t n_real = 0;                                    // hipMalloc calls that reached the runtime (misses), and what they cost
+    double real_ms = 0;
     // ATLAS_POOL_POISON=<byte>: no caching, and every block is filled with that byte before it is handed out (fresh
     // blocks have no pending users, so the fill cannot disturb anything): a kernel that relies on zero-initialised memory
     // shows up as a changed result.  ATLAS_POOL_POISON_MIN / _MAX (bytes) narrow the fill to a size range.
@@ -67,7 +71,7 @@ struct DevPool {
                 const hipStream_t cur = pool_tag_stream();
                 for (size_t k = fl.size(); k-- > 0;) {
                     static const bool any_stream = getenv("ATLAS_POOL_ANYSTREAM") != nullptr;     // diagnosis only: the pre-4a34137 reuse rule
-                    if (fl[k].freed_on != cur && !any_stream) continue;
+                    if (fl[k].freed_on != cur && fl[k].freed_on != ANY_STREAM && !any_stream) continue;
                     void* p = fl[k].p;
                     fl.erase(fl.begin() + (ptrdiff_t)k);
                     cached -= class_bytes(c);
@@ -81,7 +85,9 @@ struct DevPool {
             }
         }
         void* p = nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(&p, class_bytes(c));
+        { std::lock_guard<std::mutex> lk(mu); n_real++; real_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
         if (e != hipSuccess) {                    // out of memory: give the cache back and try once more
             (void)hipGetLastError();
             release();
@@ -119,6 +125,15 @@ struct DevPool {
             }
         }
         return hipFree(p);
+    }
+    // Every cached block becomes reusable under ANY stream.  Called where the host has just waited for the streams that could still be using
+    // freed blocks: Pipeline::begin (after the library stream drained, before the lanes start) and Pipeline::join (after every lane drained).
+    // Without it a block a lane returned is passed over by the library stream's next request and the request goes to the runtime
+    // (hipMalloc: 50-500 us on the host thread that runs the transcript).
+    static inline const hipStream_t ANY_STREAM = (hipStream_t)(uintptr_t)1;
+    void retag_all() {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto& l : free_lists) for (auto& b : l) b.freed_on = ANY_STREAM;
     }
     void release() {                              // real hipFree of everything cached
         std::vector<void*> all;

@@ -1554,6 +1554,8 @@ static int prove_graph_impl(atlas_graph_t G, atlas_srs_t srs, atlas_shard_group_
         rc = P.prove_node(it->second);
         if (gtrace) { auto& e = per_op[it->second.op]; e.first += ms_between(tn0, now()); e.second++; }
     }
+    if (gtrace) fprintf(stderr, "[atlas graph] device pool: %zu requests reached hipMalloc so far in this process (%.3f ms), %zu passed over for their stream\n",
+                        atlas_rt::dev_pool().n_real, atlas_rt::dev_pool().real_ms, atlas_rt::dev_pool().cross_stream);
     if (gtrace) for (auto& kv : per_op) fprintf(stderr, "[atlas graph] op %2d  x%-4zu %9.3f ms  (%.3f ms each)\n", kv.first, kv.second.second, kv.second.first, kv.second.first / kv.second.second);
     const auto t3 = now();
     if (!rc) rc = P.reduced_openings(nullptr);
