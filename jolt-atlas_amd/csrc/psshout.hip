@@ -767,6 +767,7 @@ struct PsLookup : atlas_instance {
             const size_t pw = (round - 1) % log_m;
             slots.host[pw] = io.r_host; slots.tag[pw] = io.tag_r;
         }
+        if (round < N && round % log_m != 0) return ATLAS_OK;  // an address round inside a phase launches nothing (56 of the 64 rounds of a 64-bit lookup: no runtime call at all)
         if (round >= 1 && round <= N && round % log_m == 0) {  // a phase is complete: its table, folded into the products
             const size_t p_done = round / log_m - 1;
             slots.n = (uint32_t)log_m; slots.abort_flag = io.abort_flag; slots.challenge_mode = g.challenge_mode;
