@@ -319,4 +319,48 @@ __device__ __forceinline__ F9 f9_wave_sum(F9 a) {
     return a;
 }
 
+// ---- small signed linear combinations (the extrapolation steps of the split product, ra.hip)
+// V = sum t[i] 2^(29 i) with signed 64-bit columns, |V| < 2^16.5 p, |t[i]| < 2^46  ->  the representative of V mod p in (0.99 p, 2.01 p),
+// normalized.  q = floor(V / p) - 1 is estimated from the two top columns in single precision: the top columns give V / 2^232 within
+// [-1, +2), their shift by 8 bits is exact in an int32, and the float product is off by less than 0.005 (tools/model_split16.py walks
+// the bounds with exact integers); the quotient then rides through the same signed carry pass as the columns.
+template <class P9>
+__device__ __forceinline__ F9 f9_reduce_i64(int64_t (&t)[9]) {
+    const int64_t vt = t[8] + (t[7] >> 29);
+    constexpr float INV = 256.0f / 3171406.4487f;                                   // 2^240 / p
+    const int32_t q = (int32_t)__builtin_floorf((float)(int32_t)(vt >> 8) * INV) - 1;
+    F9 o;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int64_t s = t[i] - (int64_t)q * (int32_t)P9::p(i) + c;
+        o.l[i] = (uint32_t)s & F9_MASK;
+        c = s >> 29;
+    }
+    o.l[8] = (uint32_t)(t[8] - (int64_t)q * (int32_t)P9::p(8) + c);
+    return o;
+}
+
+// sum_j c[j] * v[j] mod p for small signed constants (sum |c[j]| v[j] < 2^16.5 p; v[j] normalized): (0.99 p, 2.01 p), normalized
+template <class P9, int N>
+__device__ __forceinline__ F9 f9_lincomb(const F9* const (&v)[N], const int (&c)[N]) {
+    int64_t t[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        t[i] = 0;
+#pragma unroll
+        for (int j = 0; j < N; j++) t[i] += (int64_t)(int32_t)v[j]->l[i] * c[j];
+    }
+    return f9_reduce_i64<P9>(t);
+}
+
+// the limbs of another lane by a DPP pattern (quad_perm 0x00-0xff, row_shr 0x110 + n, row_ror 0x120 + n); every lane must be active
+template <int CTRL>
+__device__ __forceinline__ F9 f9_dpp(const F9& a) {
+    F9 o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.l[i], CTRL, 0xf, 0xf, false);
+    return o;
+}
+
 }  // namespace atlas

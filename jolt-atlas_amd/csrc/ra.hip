@@ -111,6 +111,122 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_prod_f9_col(const Fr* __restr
     mail_tail(partials, tail);
 }
 
+// d = 16 as a tree of half products (the count of mles_product_sum.rs:871-949 — eval_prod_16_assign over eval_linear_prod_8_internal / _4_internal —
+// restated for lazy limbs): the product of two lines on {1, 2, inf} (3 multiplications), of two such quadratics on {1..4, inf} (5), of two
+// quartics on {1..8, inf} (9) and of the two halves on {1..15, inf} (16): 2 (4 * 3 + 2 * 5 + 9) + 16 = 78 multiplications per pair instead
+// of 16 * 17, with the values a level needs beyond the ones it multiplied obtained from the constant top difference n! * c of a degree-n
+// polynomial with leading coefficient c (small signed combinations: f9_lincomb, no field multiplication).
+//   * TWO lanes per pair: lane h = 0 / 1 owns rows 0-7 / 8-15 (so a launch has twice the lanes of one-pair-per-thread; a round of 2^15
+//     pairs fills the chip once).  Lane 0 folds E_out into its first row and lane 1 folds E_in into its (two multiplications each, not one
+//     per column).  The last level is split by columns: in step i both lanes extend their half by one point (9 + i), lane 0 multiplies the
+//     halves at point 1 + i (the oldest value of its window and of its neighbour's), lane 1 at point 9 + i (step 7: at infinity).
+//   * every column of the result has the same 17 f9_mul behind it as the chain kernels (rows 0 and 8 carry one more, every product level
+//     one): a stored sum is 32^-17 times the true one, as before.
+//   * the body is three rolled loops (row pairs, last level, final sum): ~45 KB of code instead of ~100 KB unrolled.
+//   * sums over pairs: limb-wise adds over the 8 lanes of a 16-lane row that own the same columns (DPP, no carries: 8 * 2^29 fits), then 16
+//     row slots per column in LDS, added in 64-bit columns and reduced once (f9_reduce_i64).
+// Measured (profiles/r04g_split_trace.txt; MI355X): 2^15 pairs 65 us against 190 us (k_ra_prod_f9_col<16>), 2^14 50 / 104, 2^13 44 / 62, 2^19 1.07 ms;
+// a whole RaVirtual proof of d = 16: T = 2^16 0.97 -> 0.76 ms, 2^18 1.85 -> 1.18, 2^20 5.89 -> 3.01 (the rounds under 2^12 pairs are unchanged:
+// they are the latency of a round trip, not multiplications).  Per wavefront the kernel takes ~65 us at any occupancy: 41 f9_mul are ~20 us of
+// that (tools/exp_mad.hip: 0.47 us per multiplication per wavefront), the rest is the 23 small combinations, carries and moves.
+constexpr int RA_SPLIT_PAIRS = RA_THREADS / 2;
+__global__ __launch_bounds__(RA_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ra_prod16_split(const Fr* __restrict__ ra, size_t stride, SplitEqView E, size_t n_groups,
+                                                                Fr* __restrict__ partials /* [gridDim.x][16] */, MailTail tail) {
+    using P9 = Fr9Params;
+    __shared__ F9 red[RA_THREADS / 16][16];
+    const uint32_t h = threadIdx.x & 1u;
+    size_t gidx = (size_t)blockIdx.x * RA_SPLIT_PAIRS + (threadIdx.x >> 1);
+    const bool live = gidx < n_groups;
+    if (!live) gidx = 0;
+    const size_t mask = ((size_t)1 << E.in_bits) - 1;
+    F9 wgt = f9_load(h ? E.e_in + (gidx & mask) : E.e_out + (gidx >> E.in_bits));
+    if (!live) wgt = f9_zero();                                   // a pair beyond the end contributes multiples of p
+    // Live state: the rolled loop carries what it declares outside across every iteration, so the half itself (9 values) is formed after
+    // it, and the first quartic stays on five points until then: 256 registers, no scratch.  (Formed inside the loop: 381-409 registers with
+    // the overflow in AGPRs, one wavefront per SIMD — the same times: a wavefront of f9_mul chains keeps its SIMD's multiplier busy alone,
+    // tools/exp_mad.hip.)
+    F9 P[5], Pp[5], Q0[5];                                        // this row pair / quartic, the previous row pair and the first quartic, on {1..4, inf}
+#pragma unroll 1
+    for (int t = 0; t < 4; t++) {
+        // (loading rows 2 t + 2, 2 t + 3 ahead of this iteration's products changed nothing: the kernel is bound by its own instructions)
+        const Fr* row = ra + (size_t)(8 * h + 2 * t) * stride + 2 * gidx;
+        F9 a0 = f9_load(row), a1 = f9_load(row + 1), b0 = f9_load(row + stride), b1 = f9_load(row + stride + 1);
+        F9 da = f9_norm_red<P9, 2>(f9_sub<P9>(a1, a0)), db = f9_norm_red<P9, 2>(f9_sub<P9>(b1, b0));
+        if (t == 0) { a0 = f9_mul<P9>(a0, wgt); da = f9_mul<P9>(da, wgt); }
+        const F9 A1 = f9_norm(f9_add(a0, da)), A2 = f9_norm(f9_add(A1, da));            // lazy operands: < 6.5 p
+        const F9 B1 = f9_norm(f9_add(b0, db)), B2 = f9_norm(f9_add(B1, db));
+        P[0] = f9_mul<P9>(A1, B1); P[1] = f9_mul<P9>(A2, B2); P[4] = f9_mul<P9>(da, db);
+        {   // f(x + 2) = 2 c - f(x) + 2 f(x + 1), from the base values
+            const F9* const v[3] = {&P[0], &P[1], &P[4]};
+            P[2] = f9_lincomb<P9, 3>(v, {-1, 2, 2});
+            P[3] = f9_lincomb<P9, 3>(v, {-2, 3, 6});
+        }
+        if (t & 1) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) P[k] = f9_mul<P9>(P[k], Pp[k]);               // the quartic of rows 4 (t - 1) / 2 .. + 3 on {1..4, inf}
+            if (t == 1) {
+#pragma unroll
+                for (int k = 0; k < 5; k++) Q0[k] = P[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 5; k++) Pp[k] = P[k];
+        }
+    }
+    F9 Qp[9];                                                     // the half = the two quartics multiplied on {1..8, inf}
+    {
+        // points 5..8 of either quartic: the cubic through f(1..4) carried on, plus c (x - 1)(x - 2)(x - 3)(x - 4)
+        const F9* const v[5] = {&P[0], &P[1], &P[2], &P[3], &P[4]};
+        const F9* const v0[5] = {&Q0[0], &Q0[1], &Q0[2], &Q0[3], &Q0[4]};
+#define RA_OCT(k, ...) { const F9 e1 = f9_lincomb<P9, 5>(v, __VA_ARGS__), e0 = f9_lincomb<P9, 5>(v0, __VA_ARGS__); Qp[k] = f9_mul<P9>(e1, e0); }
+        RA_OCT(4, {-1, 4, -6, 4, 24}) RA_OCT(5, {-4, 15, -20, 10, 120}) RA_OCT(6, {-10, 36, -45, 20, 360}) RA_OCT(7, {-20, 70, -84, 35, 840})
+#undef RA_OCT
+#define RA_OCT(k, j) Qp[k] = f9_mul<P9>(P[j], Q0[j]);
+        RA_OCT(0, 0) RA_OCT(1, 1) RA_OCT(2, 2) RA_OCT(3, 3) RA_OCT(8, 4)
+#undef RA_OCT
+    }
+    // Qp = this lane's half on {1..8, inf}.  Window w = the half at 8 consecutive points; f(x + 8) = 8! c - f(x) + 8 f(x+1) - 28 f(x+2) + ...
+    const int lane = threadIdx.x & 63, slot = (threadIdx.x >> 6) * 4 + (lane >> 4);
+#pragma unroll 1
+    for (int i = 0; i < 8; i++) {
+        F9 nw = Qp[8];
+        if (i < 7) {
+            const F9* const v[9] = {&Qp[0], &Qp[1], &Qp[2], &Qp[3], &Qp[4], &Qp[5], &Qp[6], &Qp[7], &Qp[8]};
+            nw = f9_lincomb<P9, 9>(v, {-1, 8, -28, 56, -70, 56, -28, 8, 40320});
+        }
+        F9 keep, send;
+#pragma unroll
+        for (int l = 0; l < 9; l++) { keep.l[l] = h ? nw.l[l] : Qp[0].l[l]; send.l[l] = h ? Qp[0].l[l] : nw.l[l]; }
+        F9 out = f9_mul<P9>(keep, f9_dpp<0xb1>(send));            // the neighbour lane (xor 1)
+        out = f9_add(out, f9_dpp<0x4e>(out));                     // + lane xor 2, + the lanes 4, 8, 12 further round the row: the 8 lanes of this half
+        out = f9_add(out, f9_dpp<0x124>(out));
+        out = f9_add(out, f9_dpp<0x128>(out));
+        if ((lane & 15) < 2) red[slot][8 * h + i] = out;
+#pragma unroll
+        for (int k = 0; k < 7; k++) Qp[k] = Qp[k + 1];
+        Qp[7] = nw;
+    }
+    __syncthreads();
+    // 16 row slots per (column, limb): thread 9 c + l adds the slots of limb l of column c (16 LDS reads each, not 144 by one thread per
+    // column), thread c then reduces its nine 64-bit columns
+    __shared__ uint64_t cols[16][9];
+    if (threadIdx.x < 144) {
+        const uint32_t c = threadIdx.x / 9, l = threadIdx.x % 9;
+        uint64_t acc = 0;
+#pragma unroll
+        for (int r = 0; r < RA_THREADS / 16; r++) acc += red[r][c].l[l];
+        cols[c][l] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        int64_t t[9];
+#pragma unroll
+        for (int l = 0; l < 9; l++) t[l] = (int64_t)cols[threadIdx.x][l];
+        fe_store(partials + (size_t)blockIdx.x * 16 + threadIdx.x, f9_canon<P9>(f9_reduce_i64<P9>(t)));
+    }
+    mail_tail(partials, tail);
+}
+
 // Bind and product of a round in ONE launch, for rounds of at most RA_FUSE_MAX pairs (the cycle rounds of every lookup of T <= 2^13,
 // and the later rounds of the larger ones): a workgroup takes 16 pairs, thread (pair, k) binds row k of its pair — four coefficients of
 // the previous round's rows -> the two of this round's, stored for the next round — and leaves (x0, x1 - x0) as lazy limbs in LDS; after
@@ -253,8 +369,25 @@ __global__ __launch_bounds__(RA_THREADS) void k_bool_bind_fold(const Fr* __restr
 }
 
 // out[k] = sum_p partials[p * K + k]; one workgroup per column
+// `blocks` = ceil(n_groups / RA_THREADS) on entry; on return the number of partial rows the launch wrote
 template <int D>
-void launch_prod(const Fr* buf, size_t stride, Fr* partials, const SplitEqView& E, size_t n_groups, unsigned blocks, MailTail tail) {
+void launch_prod(const Fr* buf, size_t stride, Fr* partials, const SplitEqView& E, size_t n_groups, unsigned& blocks, MailTail tail) {
+    if constexpr (D == 16) {
+        // the split product from RA_SPLIT_MIN pairs up (below that the round is the latency of one thread's chain, and sixteen short chains
+        // per pair beat two long ones).  ATLAS_RA_SPLIT_MIN=<log2> moves the switch (experiments; 31 = never)
+        static const size_t split_min = [] { const char* e = getenv("ATLAS_RA_SPLIT_MIN"); int v = e ? atoi(e) : -1; return (size_t)1 << (v >= 0 && v <= 31 ? v : 12); }();
+        if (n_groups >= split_min) {
+            blocks = (unsigned)((n_groups + RA_SPLIT_PAIRS - 1) / RA_SPLIT_PAIRS);
+            tail.n_rows = blocks; tail.K = 16;
+            static const bool no_tail16 = getenv("ATLAS_NO_MAIL_TAIL") != nullptr;
+            if (no_tail16 && tail.counter) {
+                k_ra_prod16_split<<<blocks, RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, MailTail{tail.io, nullptr, 0, 0});
+                k_col_reduce_mail<<<1, RA_THREADS, 0, g.stream>>>(partials, blocks, 16u, tail.io);
+            } else
+                k_ra_prod16_split<<<blocks, RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, tail);
+            return;
+        }
+    }
     tail.n_rows = blocks; tail.K = D;
     const MailTail none{tail.io, nullptr, 0, 0};
     static const bool no_tail = getenv("ATLAS_NO_MAIL_TAIL") != nullptr;      // diagnosis (tools/stress_lanes.py): the column sums in a launch of their own
@@ -280,7 +413,7 @@ void launch_prod(const Fr* buf, size_t stride, Fr* partials, const SplitEqView& 
     if constexpr (D > 8)
         k_ra_prod_f9<D, 8, D - 8><<<blocks, RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, tail);   // mails all D columns
 }
-int launch_prod_d(size_t d, const Fr* buf, size_t stride, Fr* partials, const SplitEqView& E, size_t n_groups, unsigned blocks, const MailTail& tail) {
+int launch_prod_d(size_t d, const Fr* buf, size_t stride, Fr* partials, const SplitEqView& E, size_t n_groups, unsigned& blocks, const MailTail& tail) {
     switch (d) {
 #define RA_CASE(D) case D: launch_prod<D>(buf, stride, partials, E, n_groups, blocks, tail); break;
         RA_CASE(1) RA_CASE(2) RA_CASE(3) RA_CASE(4) RA_CASE(5) RA_CASE(6) RA_CASE(7) RA_CASE(8)
@@ -303,7 +436,7 @@ struct RaVirtual : atlas_instance {
         if (round != round_next || round >= log_T) return fail(ATLAS_ESTATE, "ra_virtual: round out of order");
         std::lock_guard<atlas_rt::Mutex> lk(g.mu);
         const size_t n_groups = rows.len / 2;
-        const unsigned blocks = (unsigned)((n_groups + RA_THREADS - 1) / RA_THREADS);
+        unsigned blocks = (unsigned)((n_groups + RA_THREADS - 1) / RA_THREADS);
         int rc = launch_prod_d(rows.d, rows.buf[rows.cur], rows.stride[rows.cur], rows.partials, eq.view(), n_groups, blocks, MailTail{{}, nullptr, 0, 0});
         if (rc) return rc;
         std::vector<H::Fr> sums(rows.d);
@@ -362,7 +495,7 @@ struct RaVirtual : atlas_instance {
                 k_ra_bind_ch<<<dim3((unsigned)gb, (unsigned)rows.d), RA_THREADS, 0, g.stream>>>(rows.buf[(round - 1) & 1], T >> (round - 1), rows.buf[round & 1], len, len,
                                                                                               cio, g.challenge_mode == 0 ? 1 : 0);
             }
-            const unsigned blocks = (unsigned)((n_groups + RA_THREADS - 1) / RA_THREADS);
+            unsigned blocks = (unsigned)((n_groups + RA_THREADS - 1) / RA_THREADS);
             int rc = launch_prod_d(rows.d, rows.buf[round & 1], len, rows.partials, eq.view_at(ot, it), n_groups, blocks, MailTail{io, rows.d_counter, 0, 0});
             if (rc) return rc;
         }

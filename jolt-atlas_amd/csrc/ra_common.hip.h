@@ -216,7 +216,7 @@ struct RaRows {
     Fr* buf[2] = {nullptr, nullptr};
     size_t stride[2] = {0, 0};
     int cur = 0;
-    Fr* partials = nullptr;     // ceil(T/2 / RA_THREADS) * max(d, 2) Fr
+    Fr* partials = nullptr;     // (ceil(T/2 / (RA_THREADS / 2)) + 1) * max(d, 2) Fr
     uint32_t* d_counter = nullptr;   // arrival counter of mail_tail (zero between launches)
     size_t K = 0;
 
@@ -225,7 +225,7 @@ struct RaRows {
         HIP_TRY(hipMalloc(&buf[0], d * T * sizeof(Fr)));
         HIP_TRY(hipMalloc(&buf[1], d * (T > 1 ? T / 2 : 1) * sizeof(Fr)));
         stride[0] = T; stride[1] = T > 1 ? T / 2 : 1;
-        const size_t blocks = (T / 2 + RA_THREADS - 1) / RA_THREADS + 1;
+        const size_t blocks = (T / 2 + RA_THREADS / 2 - 1) / (RA_THREADS / 2) + 1;       // a row per RA_THREADS / 2 pairs: the split product of d = 16 (ra.hip)
         HIP_TRY(hipMalloc(&partials, (blocks * K > 4096 ? blocks * K : 4096) * sizeof(Fr)));   // room for the row-split launches of short instances
         HIP_TRY(hipMalloc(&d_counter, 256));
         HIP_TRY(hipMemsetAsync(d_counter, 0, 256, g.stream));

@@ -49,7 +49,7 @@ def _ra_claim(orc, H, chunks, r_cycle, log_k):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("d,log_k,log_T", [(1, 4, 3), (2, 4, 9), (3, 2, 1), (4, 4, 11), (8, 4, 10), (16, 4, 9), (5, 8, 6)])
+@pytest.mark.parametrize("d,log_k,log_T", [(1, 4, 3), (2, 4, 9), (3, 2, 1), (4, 4, 11), (8, 4, 10), (16, 4, 9), (5, 8, 6), (16, 4, 13)])     # (16, 4, 13): round 0 takes the split product (k_ra_prod16_split)
 def test_ra_virtual_bit_exact(atlas, d, log_k, log_T, mode):
     from oracle import orc, orc_ra as OR
     from jolt_atlas_amd import instances as I

@@ -6,6 +6,7 @@ profiles/r02f_*_pmc_sq.txt: 0.70 for the largest pass at one wavefront per SIMD)
 SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES.
 usage: pmc_sq_summary.py <results.db> <out.txt> <name substring> [...]      (PMC runs never carry --stats / other trace domains)"""
 import collections
+import re
 import sqlite3
 import sys
 
@@ -16,7 +17,8 @@ n_disp = collections.Counter()
 for name, counter, val in db.execute("select kernel_name, counter_name, value from counters_collection"):
     if want and not any(w in name for w in want):
         continue
-    short = name.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "").replace("atlas::", "")[:48]
+    m = re.search(r"k_\w+(<[^>(]*>)?", name)                      # the kernel's own name (names in an anonymous namespace start with a parenthesis)
+    short = (m.group(0) if m else name.split("(")[0].replace("void ", "").replace("atlas::", ""))[:48]
     acc[short][counter] += val
     if counter == "SQ_WAVES":
         n_disp[short] += 1
