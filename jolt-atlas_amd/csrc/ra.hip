@@ -130,10 +130,15 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_prod_f9_col(const Fr* __restr
 // they are the latency of a round trip, not multiplications).  Per wavefront the kernel takes ~65 us at any occupancy: 41 f9_mul are ~20 us of
 // that (tools/exp_mad.hip: 0.47 us per multiplication per wavefront), the rest is the 23 small combinations, carries and moves.
 constexpr int RA_SPLIT_PAIRS = RA_THREADS / 2;
+template <bool TIMING>
 __global__ __launch_bounds__(RA_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ra_prod16_split(const Fr* __restrict__ ra, size_t stride, SplitEqView E, size_t n_groups,
                                                                 Fr* __restrict__ partials /* [gridDim.x][16] */, MailTail tail) {
     using P9 = Fr9Params;
     __shared__ F9 red[RA_THREADS / 16][16];
+    // TIMING (ATLAS_RA_SPLIT_TIMING=1, diagnosis): the first wavefront of three workgroups prints its shader-clock and 100 MHz wall-clock stamps per phase
+    uint64_t ck[6], wk[6];
+#define RA_STAMP(i) if constexpr (TIMING) { ck[i] = clock64(); wk[i] = wall_clock64(); }
+    RA_STAMP(0)
     const uint32_t h = threadIdx.x & 1u;
     size_t gidx = (size_t)blockIdx.x * RA_SPLIT_PAIRS + (threadIdx.x >> 1);
     const bool live = gidx < n_groups;
@@ -173,6 +178,7 @@ __global__ __launch_bounds__(RA_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             for (int k = 0; k < 5; k++) Pp[k] = P[k];
         }
     }
+    RA_STAMP(1)
     F9 Qp[9];                                                     // the half = the two quartics multiplied on {1..8, inf}
     {
         // points 5..8 of either quartic: the cubic through f(1..4) carried on, plus c (x - 1)(x - 2)(x - 3)(x - 4)
@@ -185,6 +191,7 @@ __global__ __launch_bounds__(RA_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         RA_OCT(0, 0) RA_OCT(1, 1) RA_OCT(2, 2) RA_OCT(3, 3) RA_OCT(8, 4)
 #undef RA_OCT
     }
+    RA_STAMP(2)
     // Qp = this lane's half on {1..8, inf}.  Window w = the half at 8 consecutive points; f(x + 8) = 8! c - f(x) + 8 f(x+1) - 28 f(x+2) + ...
     const int lane = threadIdx.x & 63, slot = (threadIdx.x >> 6) * 4 + (lane >> 4);
 #pragma unroll 1
@@ -206,6 +213,7 @@ __global__ __launch_bounds__(RA_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         for (int k = 0; k < 7; k++) Qp[k] = Qp[k + 1];
         Qp[7] = nw;
     }
+    RA_STAMP(3)
     __syncthreads();
     // 16 row slots per (column, limb): thread 9 c + l adds the slots of limb l of column c (16 LDS reads each, not 144 by one thread per
     // column), thread c then reduces its nine 64-bit columns
@@ -224,7 +232,16 @@ __global__ __launch_bounds__(RA_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         for (int l = 0; l < 9; l++) t[l] = (int64_t)cols[threadIdx.x][l];
         fe_store(partials + (size_t)blockIdx.x * 16 + threadIdx.x, f9_canon<P9>(f9_reduce_i64<P9>(t)));
     }
+    RA_STAMP(4)
     mail_tail(partials, tail);
+    RA_STAMP(5)
+#undef RA_STAMP
+    if constexpr (TIMING) {
+        if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1))
+            printf("[split timing] wg %u of %u: shader clocks rows %llu half %llu last level %llu sums %llu tail %llu | wall 10 ns ticks %llu %llu %llu %llu %llu\n", blockIdx.x, gridDim.x,
+                   (unsigned long long)(ck[1] - ck[0]), (unsigned long long)(ck[2] - ck[1]), (unsigned long long)(ck[3] - ck[2]), (unsigned long long)(ck[4] - ck[3]), (unsigned long long)(ck[5] - ck[4]),
+                   (unsigned long long)(wk[1] - wk[0]), (unsigned long long)(wk[2] - wk[1]), (unsigned long long)(wk[3] - wk[2]), (unsigned long long)(wk[4] - wk[3]), (unsigned long long)(wk[5] - wk[4]));
+    }
 }
 
 // Bind and product of a round in ONE launch, for rounds of at most RA_FUSE_MAX pairs (the cycle rounds of every lookup of T <= 2^13,
@@ -380,11 +397,14 @@ void launch_prod(const Fr* buf, size_t stride, Fr* partials, const SplitEqView& 
             blocks = (unsigned)((n_groups + RA_SPLIT_PAIRS - 1) / RA_SPLIT_PAIRS);
             tail.n_rows = blocks; tail.K = 16;
             static const bool no_tail16 = getenv("ATLAS_NO_MAIL_TAIL") != nullptr;
+            static const bool timing = getenv("ATLAS_RA_SPLIT_TIMING") != nullptr;
             if (no_tail16 && tail.counter) {
-                k_ra_prod16_split<<<blocks, RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, MailTail{tail.io, nullptr, 0, 0});
+                k_ra_prod16_split<false><<<blocks, RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, MailTail{tail.io, nullptr, 0, 0});
                 k_col_reduce_mail<<<1, RA_THREADS, 0, g.stream>>>(partials, blocks, 16u, tail.io);
-            } else
-                k_ra_prod16_split<<<blocks, RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, tail);
+            } else if (timing)
+                k_ra_prod16_split<true><<<blocks, RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, tail);
+            else
+                k_ra_prod16_split<false><<<blocks, RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, tail);
             return;
         }
     }
