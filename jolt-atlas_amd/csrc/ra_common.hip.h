@@ -101,6 +101,8 @@ __global__ __launch_bounds__(RA_THREADS) void k_col_reduce_mail(const Fr* __rest
 // The same as the tail of the kernel that produced the partial rows (saves a launch, ~6 us per round): every workgroup
 // calls this after it stored its row; the last one to arrive (agent-scope counter, fences on both sides) adds the rows
 // and mails the sums.  `tail.counter` is zero on entry and is left zero.  tail.counter == nullptr: no mail (host-stepped).
+constexpr uint32_t MAIL_TAIL_FLAT = 32, MAIL_TAIL_SUBS = 16, MAIL_TAIL_STRIDE = 64;      // u32 units: 256 bytes between counters
+constexpr size_t MAIL_TAIL_COUNTER_BYTES = (size_t)4 * MAIL_TAIL_STRIDE * (1 + MAIL_TAIL_SUBS);
 struct MailTail {
     RoundIo io;
     uint32_t* counter;
@@ -113,9 +115,26 @@ __device__ __forceinline__ void mail_tail(const Fr* partials, const MailTail& ta
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t total = gridDim.x * gridDim.y;
-        const uint32_t t = atomicAdd(tail.counter, 1u);
-        s_last = t == total - 1;
-        if (t == total - 1) *tail.counter = 0;
+        if (total <= MAIL_TAIL_FLAT) {
+            const uint32_t t = atomicAdd(tail.counter, 1u);
+            s_last = t == total - 1;
+            if (t == total - 1) *tail.counter = 0;
+        } else {
+            // Two levels: MAIL_TAIL_SUBS counters on cache lines of their own take the arrivals of the workgroups congruent to them, the last
+            // arrival of each moves on to the first counter.  Every workgroup of a launch finishes within a few microseconds of the others, and
+            // read-modify-writes of ONE address are served one after the other (~33 ns each: 8.5 us of a 65 us launch of 256 workgroups, 2.3 us
+            // at 64 — profiles/r04g_split_phases.txt); sixteen addresses are served side by side.
+            const uint32_t wg = blockIdx.y * gridDim.x + blockIdx.x, sub = wg % MAIL_TAIL_SUBS;
+            uint32_t* const sc = tail.counter + MAIL_TAIL_STRIDE * (1 + sub);
+            const uint32_t mine = (total - sub + MAIL_TAIL_SUBS - 1) / MAIL_TAIL_SUBS;        // workgroups congruent to `sub`
+            bool last = false;
+            if (atomicAdd(sc, 1u) == mine - 1) {
+                *sc = 0;
+                __threadfence();                       // what the others of this counter published is ordered before the arrival at the first
+                if (atomicAdd(tail.counter, 1u) == MAIL_TAIL_SUBS - 1) { *tail.counter = 0; last = true; }
+            }
+            s_last = last;
+        }
     }
     __syncthreads();
     if (!s_last) return;
@@ -227,8 +246,8 @@ struct RaRows {
         stride[0] = T; stride[1] = T > 1 ? T / 2 : 1;
         const size_t blocks = (T / 2 + RA_THREADS / 2 - 1) / (RA_THREADS / 2) + 1;       // a row per RA_THREADS / 2 pairs: the split product of d = 16 (ra.hip)
         HIP_TRY(hipMalloc(&partials, (blocks * K > 4096 ? blocks * K : 4096) * sizeof(Fr)));   // room for the row-split launches of short instances
-        HIP_TRY(hipMalloc(&d_counter, 256));
-        HIP_TRY(hipMemsetAsync(d_counter, 0, 256, g.stream));
+        HIP_TRY(hipMalloc(&d_counter, MAIL_TAIL_COUNTER_BYTES));
+        HIP_TRY(hipMemsetAsync(d_counter, 0, MAIL_TAIL_COUNTER_BYTES, g.stream));
         return ATLAS_OK;
     }
     // indices: d host rows of T int32 -> one device allocation (kept until the gather)

@@ -79,6 +79,20 @@ def main():
         ra_once()
         out[f"ra_virtual_d{d}_T2^{a.log_t}_prove_ms"] = 1e3 * float(np.median([ra_once() for _ in range(3)]))
 
+        if d == 16:                                        # the same at T = 2^16 and 2^18 (where the split product of d = 16 starts to pay: tools/time_ra_split.py)
+            for lt in (16, 18):
+                Hs = [h[:1 << lt] for h in H]; rcs = A.random_fr(lt, 7)
+
+                def ra_small():
+                    inst = I.ra_virtual(Hs, 4, chunks, rcs)
+                    t0 = time.perf_counter()
+                    inst.prove(A.random_fr(1, 1)[0], A.Blake2bTranscript(b"t"))
+                    dt = time.perf_counter() - t0
+                    inst.free()
+                    return dt
+                ra_small()
+                out[f"ra_virtual_d16_T2^{lt}_prove_ms"] = 1e3 * float(np.median([ra_small() for _ in range(5)]))
+
         G = np.zeros((d, 16, 4), dtype=np.uint64)
 
         def bool_once():
