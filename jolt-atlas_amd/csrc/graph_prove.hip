@@ -16,6 +16,7 @@
 #include "graph_state.hip.h"
 #include "internal.hpp"
 #include "shard_group.hpp"
+#include "host_sampler.hpp"
 
 using gr::Node;
 using gr::OpeningId;
@@ -1520,6 +1521,7 @@ static int prove_graph_impl(atlas_graph_t G, atlas_srs_t srs, atlas_shard_group_
     if (!G || !srs || (!inputs && n_inputs) || !proof_len) return fail(ATLAS_EINVAL, "prove_graph: null argument");
     if (G->outputs.empty()) return fail(ATLAS_EINVAL, "prove_graph: no output node marked");
     if (int vrc = atlas_rt_validate_graph(*G)) return vrc;
+    atlas_rt::HostSampler::Scope host_samples;                                // ATLAS_HOST_SAMPLE=<file>: backtraces of this thread every 50 us (diagnosis)
     auto now = [] { atlas_sync(); return std::chrono::steady_clock::now(); };
     const auto t0 = now();
     int rc = atlas_graph_trace(G, inputs, n_inputs);                          // pp.model().trace(inputs)

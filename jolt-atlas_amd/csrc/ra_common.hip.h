@@ -101,8 +101,7 @@ __global__ __launch_bounds__(RA_THREADS) void k_col_reduce_mail(const Fr* __rest
 // The same as the tail of the kernel that produced the partial rows (saves a launch, ~6 us per round): every workgroup
 // calls this after it stored its row; the last one to arrive (agent-scope counter, fences on both sides) adds the rows
 // and mails the sums.  `tail.counter` is zero on entry and is left zero.  tail.counter == nullptr: no mail (host-stepped).
-constexpr uint32_t MAIL_TAIL_FLAT = 32, MAIL_TAIL_SUBS = 16, MAIL_TAIL_STRIDE = 64;      // u32 units: 256 bytes between counters
-constexpr size_t MAIL_TAIL_COUNTER_BYTES = (size_t)4 * MAIL_TAIL_STRIDE * (1 + MAIL_TAIL_SUBS);
+constexpr size_t MAIL_TAIL_COUNTER_BYTES = 256;
 struct MailTail {
     RoundIo io;
     uint32_t* counter;
@@ -115,26 +114,12 @@ __device__ __forceinline__ void mail_tail(const Fr* partials, const MailTail& ta
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t total = gridDim.x * gridDim.y;
-        if (total <= MAIL_TAIL_FLAT) {
-            const uint32_t t = atomicAdd(tail.counter, 1u);
-            s_last = t == total - 1;
-            if (t == total - 1) *tail.counter = 0;
-        } else {
-            // Two levels: MAIL_TAIL_SUBS counters on cache lines of their own take the arrivals of the workgroups congruent to them, the last
-            // arrival of each moves on to the first counter.  Every workgroup of a launch finishes within a few microseconds of the others, and
-            // read-modify-writes of ONE address are served one after the other (~33 ns each: 8.5 us of a 65 us launch of 256 workgroups, 2.3 us
-            // at 64 — profiles/r04g_split_phases.txt); sixteen addresses are served side by side.
-            const uint32_t wg = blockIdx.y * gridDim.x + blockIdx.x, sub = wg % MAIL_TAIL_SUBS;
-            uint32_t* const sc = tail.counter + MAIL_TAIL_STRIDE * (1 + sub);
-            const uint32_t mine = (total - sub + MAIL_TAIL_SUBS - 1) / MAIL_TAIL_SUBS;        // workgroups congruent to `sub`
-            bool last = false;
-            if (atomicAdd(sc, 1u) == mine - 1) {
-                *sc = 0;
-                __threadfence();                       // what the others of this counter published is ordered before the arrival at the first
-                if (atomicAdd(tail.counter, 1u) == MAIL_TAIL_SUBS - 1) { *tail.counter = 0; last = true; }
-            }
-            s_last = last;
-        }
+        // (Two levels of counters — sixteen on cache lines of their own, the last arrival of each moving on to this one — changed nothing: 8.5 -> 8.8 us
+        // for the tail of a 256-workgroup launch, profiles/r04g_split_phases.txt / r04h_subset.txt.  The time is the release fence above: at
+        // agent scope it writes the dirty lines of this XCD's L2 back, once per workgroup.)
+        const uint32_t t = atomicAdd(tail.counter, 1u);
+        s_last = t == total - 1;
+        if (t == total - 1) *tail.counter = 0;
     }
     __syncthreads();
     if (!s_last) return;
