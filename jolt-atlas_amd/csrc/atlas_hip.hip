@@ -780,7 +780,10 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
     const size_t esz = was_i32 ? sizeof(int32_t) : sizeof(Fr);
     const bool use_f9 = DEG == 2 && !was_i32 && mode == 0;
     static const size_t f9_cap = [] { const char* e = getenv("ATLAS_F9_BLOCKS"); int v = e ? atoi(e) : 0; return (size_t)(v >= 1 && v <= 2048 ? v : 256); }();   // experiments
-    auto grid_f9 = [](size_t work) { size_t b = (work + SC_THREADS - 1) / SC_THREADS; return (int)(b < 1 ? 1 : b > f9_cap ? f9_cap : b); };
+    // experiments: a second cap for the passes of at least 2^ATLAS_F9_BIG_MIN_LOG quads (two wavefronts per SIMD issue the non-multiply instructions at twice the rate, tools/exp_mad.hip)
+    static const size_t f9_big_cap = [] { const char* e = getenv("ATLAS_F9_BIG_BLOCKS"); int v = e ? atoi(e) : 0; return (size_t)(v >= 1 && v <= 2048 ? v : 0); }();
+    static const size_t f9_big_min = [] { const char* e = getenv("ATLAS_F9_BIG_MIN_LOG"); int v = e ? atoi(e) : 19; return (size_t)1 << (v >= 10 && v <= 30 ? v : 19); }();
+    auto grid_f9 = [](size_t work) { const size_t cap = f9_big_cap && work >= f9_big_min ? f9_big_cap : f9_cap; size_t b = (work + SC_THREADS - 1) / SC_THREADS; return (int)(b < 1 ? 1 : b > cap ? cap : b); };
     const size_t tail_log = P->schedule == ATLAS_EQ_NONE ? SC_TAIL_CH_LOG : SC_TAIL_LOG;
     void *old_l = nullptr, *old_r = nullptr;       // i32 sources replaced by the first fused pass
 

@@ -188,7 +188,8 @@ struct Prover : FlowSink {
                 gr::Committed c; c.id = gr::comm(cp, nd.idx); c.kind = 0; c.dense = v; c.log_T = log_T;
                 W.committed.push_back(c);
             };
-            if (T == 1 && nd.op != ATLAS_OP_SCALAR_CONST_DIV) continue;       // is_scalar: no committed polynomials
+            // one element: the is_scalar operators commit nothing; ScalarConstDiv keeps its remainder and Div its quotient (ops/div.rs:157-160)
+            if (T == 1 && nd.op != ATLAS_OP_SCALAR_CONST_DIV && nd.op != ATLAS_OP_DIV) continue;
             switch (nd.op) {
                 case ATLAS_OP_ADD: case ATLAS_OP_SUB: chunks(gr::CP_ClampRaD, W.cidx.as<uint64_t>(), 64); break;       // clamp_committed_polys
                 case ATLAS_OP_EINSUM: case ATLAS_OP_MUL: case ATLAS_OP_SQUARE: case ATLAS_OP_CUBE:                     // fused_rebase::committed_polys
@@ -201,7 +202,7 @@ struct Prover : FlowSink {
                 case ATLAS_OP_SCALAR_CONST_DIV: dense(gr::CP_ScalarConstDivNodeRemainder, W.rem.p, true); break;         // ops/scalar_const_div.rs
                 case ATLAS_OP_DIV:                                                                                       // ops/div.rs
                     dense(gr::CP_DivNodeQuotient, G.out[nd.idx].p, true);
-                    chunks(gr::CP_DivRangeCheckRaD, W.lookups.as<uint64_t>(), 64);
+                    if (T > 1) chunks(gr::CP_DivRangeCheckRaD, W.lookups.as<uint64_t>(), 64);
                     break;
                 case ATLAS_OP_MEAN_OF_SQUARES:                                                                           // ops/mean_of_squares.rs
                     chunks(gr::CP_ClampRaD, W.rescale->cidx.as<uint64_t>(), 64);
@@ -447,7 +448,7 @@ struct Prover : FlowSink {
         }
         atlas_poly_t eq_m = nullptr, eq_n = nullptr, eq_b = nullptr, left = nullptr, right = nullptr;
         int rc = ATLAS_OK;
-        if (r_m) rc = atlas_eq_evals((const atlas_fr_t*)r_m, lm, nullptr, &eq_m);
+        if (layout != ATLAS_EINSUM_K_NK_N) rc = atlas_eq_evals((const atlas_fr_t*)r_m, lm, nullptr, &eq_m);     // (a scalar output: the empty point, the one-entry table)
         if (!rc) rc = atlas_eq_evals((const atlas_fr_t*)r_n, ln, nullptr, &eq_n);
         if (!rc) rc = atlas_einsum_fold(layout, d.data(), d.size(), G.tensor(nd.inputs[0]), G.tensor(nd.inputs[1]), eq_m, eq_n, &left, &right);
         if (eq_m) atlas_poly_free(eq_m);
@@ -657,7 +658,15 @@ struct Prover : FlowSink {
         const gr::Opening& R = red(nd);
         NodeWitness& W = G.wit[nd.idx];
         atlas_poly_t ops[2] = {nullptr, nullptr};
-        if (log_T == 0) return fail(ATLAS_EINVAL, "prove_graph: ScalarConstDiv of a scalar is not composed (its one-coefficient committed remainder would need a zero-round member in the opening reduction)");
+        if (log_T == 0) {                                                     // one element: zero rounds; the operand and the one-coefficient remainder open at the empty point
+            int rc0 = zero_rounds(H::mul(R.claim, fr_from_i64_host(nd.p[0])), gr::PT_Execution);
+            H::Fr v_in, v_rem;
+            if (!rc0) rc0 = scalar_of(G.tensor(nd.inputs[0]), &v_in);
+            if (!rc0) rc0 = scalar_of(W.rem.as<int32_t>(), &v_rem);
+            if (!rc0) rc0 = append_nodeio(nd, 0, Point(), v_in);
+            if (!rc0) rc0 = append_dense(nd, gr::CP_ScalarConstDivNodeRemainder, Point(), v_rem);
+            return rc0;
+        }
         int rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(G.tensor(nd.inputs[0])), T, &ops[0]);
         if (!rc) rc = atlas_poly_wrap_device_i32(W.rem.as<int32_t>(), T, &ops[1]);
         atlas_instance_t inst = nullptr;
@@ -764,13 +773,19 @@ struct Prover : FlowSink {
         atlas_poly_t ops[4] = {nullptr, nullptr, nullptr, nullptr};
         const int32_t* src[4] = {G.tensor(nd.inputs[0]), G.tensor(nd.inputs[1]), G.tensor(nd.idx), W.rem.as<int32_t>()};
         int rc = ATLAS_OK;
-        for (int i = 0; i < 4 && !rc; i++) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(src[i]), T, &ops[i]);
-        atlas_instance_t inst = nullptr;
-        if (!rc) rc = atlas_elementwise_new(ATLAS_EW_DIV, ops, 4, (const atlas_fr_t*)r.data(), log_T, nullptr, 0, &inst);
-        for (atlas_poly_t p : ops) if (p) atlas_poly_free(p);
         std::vector<H::Fr> rs, fin;
-        if (!rc) rc = run_single(inst, H::zero(), gr::PT_Execution, rs, fin);
-        if (inst) atlas_instance_free(inst);
+        if (log_T == 0) {                                                     // one element (ops/div.rs:93, 146-160): zero rounds, the four single values; the quotient only, no range check
+            rc = zero_rounds(H::zero(), gr::PT_Execution);
+            fin.resize(4);
+            for (int i = 0; i < 4 && !rc; i++) rc = scalar_of(src[i], &fin[i]);
+        } else {
+            for (int i = 0; i < 4 && !rc; i++) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(src[i]), T, &ops[i]);
+            atlas_instance_t inst = nullptr;
+            if (!rc) rc = atlas_elementwise_new(ATLAS_EW_DIV, ops, 4, (const atlas_fr_t*)r.data(), log_T, nullptr, 0, &inst);
+            for (atlas_poly_t p : ops) if (p) atlas_poly_free(p);
+            if (!rc) rc = run_single(inst, H::zero(), gr::PT_Execution, rs, fin);
+            if (inst) atlas_instance_free(inst);
+        }
         if (rc) return rc;
         const Point pt = reversed(rs);
         rc = append_nodeio(nd, 0, pt, fin[0]);
@@ -1405,8 +1420,8 @@ struct Prover : FlowSink {
 
     int prove_node(const Node& nd) {
         cur = nd.idx;
-        if (gr::padded_len(nd.dims) == 1 && (nd.op == ATLAS_OP_RSQRT || nd.op == ATLAS_OP_DIV))
-            return fail(ATLAS_EINVAL, "prove_graph: Rsqrt / Div of ONE element is not composed (its one-coefficient committed quotient would need a zero-round member in the opening reduction)");
+        if (gr::padded_len(nd.dims) == 1 && nd.op == ATLAS_OP_RSQRT)
+            return fail(ATLAS_EINVAL, "prove_graph: Rsqrt of ONE element is not composed (its range checks are read-raf instances without cycle variables)");
         if (gr::padded_len(nd.dims) == 1 && (nd.op == ATLAS_OP_RELU || nd.op == ATLAS_OP_CLAMP || atlas_rt_is_activation(nd.op)))
             return fail(ATLAS_EINVAL, "prove_graph: a lookup operator (ReLU / Clamp / Tanh / Erf / Sigmoid) over ONE element is not composed (a read-raf instance without cycle variables)");
         if (nd.op == ATLAS_OP_DIV) return op_div(nd);                          // ReductionFlow::Custom

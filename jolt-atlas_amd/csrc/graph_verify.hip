@@ -535,7 +535,6 @@ struct Verifier {
     int op_fused(const Node& nd) {
         const gr::Opening& R = reduced.at(nd.idx);
         const bool scalar = R.point.empty();                                   // is_scalar: verify_append_acc instead of the lookup (fused_rebase.rs:281-293)
-        if (scalar && nd.op == ATLAS_OP_EINSUM) return fail(ATLAS_EINVAL, "verify_graph: an Einsum with a scalar output is not composed");
         const size_t S = nd.op == ATLAS_OP_EINSUM ? (size_t)nd.p[1] : nd.op == ATLAS_OP_CUBE ? 2 * (size_t)nd.p[0] : (size_t)nd.p[0];
         int rc = append_advice(nd, gr::VP_RescaleRemainder, R.point);        // cache_remainder_verify
         if (!rc) rc = scalar ? append_advice(nd, gr::VP_ClampAcc, R.point) : clamp_lookup(nd);
@@ -1175,7 +1174,7 @@ struct Verifier {
         for (auto& kv : G.nodes) {
             const Node& nd = kv.second;
             const size_t T = gr::padded_len(nd.dims), log_T = gr::log2u(T);
-            if (T == 1 && nd.op != ATLAS_OP_SCALAR_CONST_DIV) continue;
+            if (T == 1 && nd.op != ATLAS_OP_SCALAR_CONST_DIV && nd.op != ATLAS_OP_DIV) continue;      // one element: ScalarConstDiv keeps its remainder, Div its quotient (ops/div.rs:157-160)
             auto chunks = [&](uint8_t cp, size_t log_K) { for (size_t i = 0; i < (log_K + 3) / 4; i++) committed[gr::comm(cp, nd.idx, i)].log_T = log_T; };
             auto dense = [&](uint8_t cp) { committed[gr::comm(cp, nd.idx)].log_T = log_T; };
             switch (nd.op) {
@@ -1188,7 +1187,7 @@ struct Verifier {
                 case ATLAS_OP_CLAMP: chunks(gr::CP_SymmetricClampRaD, 32); break;
                 case ATLAS_OP_SUM: chunks(gr::CP_ClampRaD, 64); break;
                 case ATLAS_OP_SCALAR_CONST_DIV: dense(gr::CP_ScalarConstDivNodeRemainder); break;
-                case ATLAS_OP_DIV: dense(gr::CP_DivNodeQuotient); chunks(gr::CP_DivRangeCheckRaD, 64); break;
+                case ATLAS_OP_DIV: dense(gr::CP_DivNodeQuotient); if (T > 1) chunks(gr::CP_DivRangeCheckRaD, 64); break;
                 case ATLAS_OP_MEAN_OF_SQUARES: chunks(gr::CP_ClampRaD, 64); chunks(gr::CP_MeanOfSquaresRangeCheckRaD, 64); break;
                 case ATLAS_OP_RSQRT: dense(gr::CP_RsqrtQuotient); chunks(gr::CP_SqrtDivRangeCheckRaD, 64); chunks(gr::CP_SqrtRangeCheckRaD, 64); break;
                 case ATLAS_OP_TANH: case ATLAS_OP_ERF: case ATLAS_OP_SIGMOID: chunks(gr::CP_ActivationClampRaD, 32); chunks(gr::CP_ActivationSmallRaD, gr::ACTIVATION_TABLE_VARS); break;

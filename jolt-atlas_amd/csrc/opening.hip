@@ -968,11 +968,13 @@ extern "C" {
 int atlas_dense_opening_new(atlas_poly_t poly, const atlas_fr_t* opening_point, size_t n, atlas_instance_t* out) {
     NEED_INIT();
     if (!poly || (!opening_point && n) || !out) return fail(ATLAS_EINVAL, "dense_opening_new: null argument");
-    if (n == 0 || poly->len != ((size_t)1 << n)) return fail(ATLAS_EINVAL, "dense_opening_new: polynomial length != 2^n, n >= 1");
+    if (poly->len != ((size_t)1 << n)) return fail(ATLAS_EINVAL, "dense_opening_new: polynomial length != 2^n");
     std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     DenseOpening* P = new DenseOpening();
     P->n = n;
-    int rc = P->D.init(reinterpret_cast<const H::Fr*>(opening_point), n);
+    // n == 0: a one-coefficient polynomial (the committed remainder / quotient of a one-element ScalarConstDiv / Div) — a member of the
+    // batch without rounds of its own (opening_proof.rs:447-532: its claim rides scaled by 2^max_rounds, its final claim is the coefficient)
+    int rc = n ? P->D.init(reinterpret_cast<const H::Fr*>(opening_point), n) : ATLAS_OK;
     if (rc) { delete P; return rc; }
     P->P = poly;                                                     // ownership moves (bound in place)
     *out = P;

@@ -105,7 +105,7 @@ int atlas_rt_prove_reduced_openings(const atlas_opening_t* openings, size_t n_op
         const atlas_opening_t& O = openings[i];
         if (O.kind == 0) {
             atlas_poly_t c = nullptr;
-            if (!O.poly || !O.point) { rc = fail(ATLAS_EINVAL, "prove_reduced_openings: dense opening without polynomial/point"); break; }
+            if (!O.poly || (!O.point && O.n)) { rc = fail(ATLAS_EINVAL, "prove_reduced_openings: dense opening without polynomial/point"); break; }
             rc = atlas_poly_clone(O.poly, &c);
             if (!rc) { rc = atlas_dense_opening_new(c, O.point, O.n, &inst[i]); if (rc) atlas_poly_free(c); }
             continue;

@@ -576,7 +576,9 @@ class Prover:
                     row = ((lookups >> np.uint64(4 * (d - 1 - c))) & np.uint64(15)).astype(np.int64)
                     flat = (row * Tn + np.arange(Tn)).astype(np.uint64)              # one-hot coefficient k * T + t (one_hot_polynomial.rs:104-113)
                     self.committed[comm(name, i, c)] = dict(row=row.astype(np.int32), log_T=ilog2(Tn), commitment=orc.g1_sum_indexed(self.srs, flat))
-            if int(np.prod(nd["dims"])) > 1 or nd["op"] == "ScalarConstDiv":
+            # one element: the is_scalar operators have no committed polynomial; ScalarConstDiv keeps its remainder (generic flow) and Div its
+            # quotient (ops/div.rs:157-160: `if node.is_scalar() { return polys; }` after DivNodeQuotient)
+            if int(np.prod(nd["dims"])) > 1 or nd["op"] in ("ScalarConstDiv", "Div"):
                 for name, coeffs in self.dense_committed(nd):
                     self.committed[comm(name, i)] = dict(dense=coeffs, log_T=ilog2(len(coeffs)), commitment=orc.msm(self.srs[:len(coeffs)], coeffs))
         for key in sorted(self.committed):

@@ -1,0 +1,80 @@
+"""One-element corner cases that the reference's flows cover by construction (`-m gpu`): a ScalarConstDiv and a Div of ONE element — a
+committed polynomial with one coefficient, i.e. a zero-round member of the opening reduction (`opening_proof.rs:447-532`; Div:
+`ops/div.rs:93-160`, `if node.is_scalar()`: the quotient only, no range check) — and an Einsum with a scalar output (fused rescale,
+`is_scalar`: the accumulation opens in the clear, `fused_rebase.rs:224-310`).  Each graph: the device's proof against the in-repo oracle's,
+then ONNXProof::verify of the device's proof, and a wrong output rejected."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _wrap(mid, x0):
+    """Input[2,2] -> Sum -> Sum -> one element s; mid(s) -> one-element node(s); Broadcast -> [1,2]; Add of a constant"""
+    nodes = [{"idx": 0, "op": "Input", "inputs": [], "dims": [2, 2]},
+             {"idx": 1, "op": "Sum", "inputs": [0], "dims": [2, 1], "axes": [1]},
+             {"idx": 2, "op": "Sum", "inputs": [1], "dims": [1, 1], "axes": [0]}]
+    nodes += mid(2, 3)
+    last = nodes[-1]["idx"]
+    nodes += [{"idx": last + 1, "op": "Broadcast", "inputs": [last], "dims": [1, 2]},
+              {"idx": last + 2, "op": "Constant", "inputs": [], "dims": [1, 2], "data": np.array([3, -4], dtype=np.int32)},
+              {"idx": last + 3, "op": "Add", "inputs": [last + 1, last + 2], "dims": [1, 2]}]
+    return nodes, [last + 3], [np.asarray(x0, dtype=np.int32)]
+
+
+def scd_graph():
+    return _wrap(lambda s, i: [{"idx": i, "op": "ScalarConstDiv", "inputs": [s], "dims": [1, 1], "divisor": 7}], [11, -25, 300, 41])
+
+
+def scd_negative_graph():
+    return _wrap(lambda s, i: [{"idx": i, "op": "ScalarConstDiv", "inputs": [s], "dims": [1, 1], "divisor": 5}], [-11, -25, -300, -41])
+
+
+def div_graph():
+    return _wrap(lambda s, i: [{"idx": i, "op": "Constant", "inputs": [], "dims": [1, 1], "data": np.array([70000], dtype=np.int32)},
+                               {"idx": i + 1, "op": "Div", "inputs": [i, s], "dims": [1, 1]}], [5000, 6000, 7000, 8000])
+
+
+def einsum_scalar_graph():
+    return ([{"idx": 0, "op": "Input", "inputs": [], "dims": [1, 4]},
+             {"idx": 1, "op": "Constant", "inputs": [], "dims": [4, 1], "data": np.array([3, -2, 5, 7], dtype=np.int32)},
+             {"idx": 2, "op": "Einsum", "inputs": [0, 1], "dims": [1, 1], "layout": "mk,kn->mn", "scale": 2, "shape": [1, 4, 1]},
+             {"idx": 3, "op": "Broadcast", "inputs": [2], "dims": [1, 2]},
+             {"idx": 4, "op": "Constant", "inputs": [], "dims": [1, 2], "data": np.array([1, 2], dtype=np.int32)},
+             {"idx": 5, "op": "Add", "inputs": [3, 4], "dims": [1, 2]}], [5], [np.array([10, 20, -30, 40], dtype=np.int32)])
+
+
+GRAPHS = [scd_graph, scd_negative_graph, div_graph, einsum_scalar_graph]
+
+
+@pytest.mark.parametrize("builder", GRAPHS, ids=[b.__name__ for b in GRAPHS])
+def test_one_element_proof_matches_oracle_and_verifies(atlas, builder):
+    from oracle import graph as OG, orc
+    from jolt_atlas_amd import graph as GG
+    nodes, outputs, inputs = builder()
+    tau = orc.random_fr(1, 0x51250001)[0]
+    srs_h = orc.srs_powers(tau, 1 << 8)
+    srs = atlas.SRS.generate(tau, 1 << 8)
+    vk = atlas.HyperKZG.vk_from_trapdoor(tau, srs.download(0, 1)[0])
+    P = OG.Prover(nodes, outputs, srs_h)
+    want = P.prove(inputs)
+    G = GG.Graph(nodes, outputs)
+    try:
+        G.trace(inputs)
+        for nd in nodes:
+            assert np.array_equal(G.node_output(nd["idx"]), P.trace[nd["idx"]]), f"trace of node {nd['idx']} ({nd['op']})"
+        got, state, tm = G.prove(srs, inputs)
+        assert state == P.t.state(), "final transcript state"
+        assert got == want, "ONNXProof bytes"
+        assert tm["n_committed"] == len(P.committed)
+        out = G.node_output(outputs[0])
+        V = GG.Graph(nodes, outputs)
+        try:
+            ok, vstate = V.verify(vk, inputs, out, got)
+            assert ok and vstate == state
+            bad = out.copy(); bad[0] += 1
+            assert not V.verify(vk, inputs, bad, got)[0]
+        finally:
+            V.free()
+    finally:
+        G.free(); srs.free()
