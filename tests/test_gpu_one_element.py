@@ -78,3 +78,73 @@ def test_one_element_proof_matches_oracle_and_verifies(atlas, builder):
             V.free()
     finally:
         G.free(); srs.free()
+
+
+def random_one_element_chain(seed):
+    """Input -> Sum -> Sum -> one element, then a seeded sequence of one-element operators (the is_scalar arithmetic of round 3 together with
+    ScalarConstDiv and Div), then back to a vector"""
+    rng = np.random.default_rng(seed)
+    nodes = [{"idx": 0, "op": "Input", "inputs": [], "dims": [2, 2]},
+             {"idx": 1, "op": "Sum", "inputs": [0], "dims": [2, 1], "axes": [1]},
+             {"idx": 2, "op": "Sum", "inputs": [1], "dims": [1, 1], "axes": [0]}]
+    cur = 2
+
+    def add(op, inputs, **kw):
+        nd = {"idx": len(nodes), "op": op, "inputs": list(inputs), "dims": [1, 1]}
+        nd.update(kw); nodes.append(nd)
+        return nd["idx"]
+
+    def const(lo, hi):
+        return add("Constant", [], data=np.array([int(rng.integers(lo, hi))], dtype=np.int32))
+
+    for _ in range(int(rng.integers(3, 7))):
+        r = rng.random()
+        if r < 0.25:
+            cur = add("ScalarConstDiv", [cur], divisor=int(rng.integers(2, 60)))
+        elif r < 0.50:
+            c = const(1, 1 << 10)                                   # a positive divisor
+            cur = add("Div", [cur, c])
+        elif r < 0.70:
+            c = const(-(1 << 12), 1 << 12)
+            cur = add(str(rng.choice(["Add", "Sub"])), [cur, c] if rng.random() < 0.5 else [c, cur])
+        elif r < 0.85:
+            c = const(-(1 << 8), 1 << 8)
+            cur = add("Mul", [cur, c], scale=int(rng.integers(2, 6)))
+        else:
+            cur = add("Square", [cur], scale=int(rng.integers(6, 12)))
+    last = cur
+    nodes += [{"idx": len(nodes), "op": "Broadcast", "inputs": [last], "dims": [1, 2]}]
+    nodes += [{"idx": len(nodes), "op": "Constant", "inputs": [], "dims": [1, 2], "data": rng.integers(-100, 100, size=2).astype(np.int32)}]
+    nodes += [{"idx": len(nodes), "op": "Add", "inputs": [len(nodes) - 2, len(nodes) - 1], "dims": [1, 2]}]
+    return nodes, [len(nodes) - 1], [rng.integers(-(1 << 10), 1 << 10, size=4).astype(np.int32)]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_one_element_chain(atlas, seed):
+    """the fuzz draw over the one-element operators: device proof == oracle proof, accepted by the verifier, one flipped byte rejected"""
+    from oracle import graph as OG, orc
+    from jolt_atlas_amd import graph as GG
+    nodes, outputs, inputs = random_one_element_chain(seed)
+    tau = orc.random_fr(1, 0x51250001)[0]
+    srs_h = orc.srs_powers(tau, 1 << 8)
+    srs = atlas.SRS.generate(tau, 1 << 8)
+    vk = atlas.HyperKZG.vk_from_trapdoor(tau, srs.download(0, 1)[0])
+    P = OG.Prover(nodes, outputs, srs_h)
+    want = P.prove(inputs)
+    G = GG.Graph(nodes, outputs)
+    try:
+        got, state, _ = G.prove(srs, inputs)
+        for nd in nodes:
+            assert np.array_equal(G.node_output(nd["idx"]), P.trace[nd["idx"]]), f"trace of node {nd['idx']} ({nd['op']})"
+        assert state == P.t.state() and got == want, [n["op"] for n in nodes]
+        out = G.node_output(outputs[0])
+        V = GG.Graph(nodes, outputs)
+        try:
+            ok, vstate = V.verify(vk, inputs, out, got)
+            assert ok and vstate == state
+            flipped = bytearray(got); flipped[len(flipped) // 2] ^= 1
+            assert not V.verify(vk, inputs, out, bytes(flipped))[0]
+        finally:
+            V.free()
+    finally:
+        G.free(); srs.free()
