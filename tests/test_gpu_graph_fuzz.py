@@ -178,9 +178,8 @@ def _run(atlas, nodes, outputs, inputs, seed):
 def test_random_operator_chain_tiny_shapes(atlas, seed):
     """axes of one and two elements: scalar nodes (no lookups, zero-round sumchecks, clear-text checks in the verifier) between vector ones"""
     nodes, outputs, inputs = random_chain(9000 + seed, steps=8, sizes=(1, 2))
-    if any(nd["op"] in ("Einsum",) and (int(np.prod(nd["dims"])) == 1 or nd["shape"][1] == 1) for nd in nodes):
-        pytest.skip("a scalar-output / one-element-contraction Einsum is not composed")
-    if any(nd["op"] in ("ReLU", "Clamp", "Rsqrt", "Div", "Sin", "Cos") and int(np.prod(nd["dims"])) == 1 for nd in nodes):
+    # (round 4: a scalar-output Einsum, a contraction over one element and a Div of one element are composed: tests/test_gpu_one_element.py)
+    if any(nd["op"] in ("ReLU", "Clamp", "Rsqrt", "Sin", "Cos") and int(np.prod(nd["dims"])) == 1 for nd in nodes):
         pytest.skip("a lookup operator over one element is not composed")
     _run(atlas, nodes, outputs, inputs, seed)
 
