@@ -54,6 +54,8 @@ def test_ra_virtual_bit_exact(atlas, d, log_k, log_T, mode):
     from oracle import orc, orc_ra as OR
     from jolt_atlas_amd import instances as I
     A = atlas
+    if log_T == 13 and mode == 1:
+        pytest.skip("the split-product case runs under challenge mode 0 only (8 s of oracle time per variant; the kernel does not see the mode)")
     A.set_challenge_mode(mode); orc.lib.orc_set_challenge_mode(mode)
     try:
         T, K = 1 << log_T, 1 << log_k
