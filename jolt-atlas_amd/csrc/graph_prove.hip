@@ -153,6 +153,13 @@ struct Prover : FlowSink {
         proof(proof_type, empty, 8);
         return ATLAS_OK;
     }
+    // the one value of a one-coefficient Fr polynomial in HBM
+    int scalar_fr_of(const void* d_fr, H::Fr* out_) {
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        HIP_TRY(hipMemcpyAsync(out_, d_fr, sizeof(H::Fr), hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        return ATLAS_OK;
+    }
     int scalar_of(const int32_t* d_tensor, H::Fr* out_) {
         int32_t v = 0;
         std::lock_guard<atlas_rt::Mutex> lk(g.mu);
@@ -171,15 +178,44 @@ struct Prover : FlowSink {
             W.committed.clear();
             for (auto pv : W.dense_views) if (pv) atlas_poly_free(pv);
             W.dense_views.clear();
+            W.one_cycle_rows.clear();
             const size_t T = gr::padded_len(nd.dims), log_T = gr::log2u(T);
+            int drc = ATLAS_OK;
             auto chunks = [&](uint8_t cp, const uint64_t* d_lookups, size_t log_K) {
                 const size_t d = (log_K + 3) / 4;
+                if (T == 1) {
+                    // ONE cycle: the one-hot polynomial of chunk i has K x 1 = 16 coefficients, a single one at the chunk's value — committed, opened
+                    // and folded into the joint polynomial as the 16-coefficient dense row it is (same commitment g1[k], same round polynomials:
+                    // both openings bind the four address variables HighToLow over eq(r_address, .)); the reference's generic flow at T = 1
+                    uint64_t lk = 0;
+                    {
+                        std::lock_guard<atlas_rt::Mutex> lk_(g.mu);
+                        if (hipMemcpyAsync(&lk, d_lookups, 8, hipMemcpyDeviceToHost, g.stream) != hipSuccess || hipStreamSynchronize(g.stream) != hipSuccess) { drc = fail(ATLAS_ENODEV, "prove_graph: lookup index of a one-element node"); return; }
+                    }
+                    for (size_t i = 0; i < d && !drc; i++) {
+                        int32_t row[16] = {0};
+                        row[(lk >> (4 * (d - 1 - i))) & 15] = 1;
+                        W.one_cycle_rows.emplace_back(new DevBuf());
+                        DevBuf& B = *W.one_cycle_rows.back();
+                        if (B.alloc(sizeof(row)) != hipSuccess) { drc = fail(ATLAS_ENOMEM, "prove_graph: one-cycle chunk row"); return; }
+                        {
+                            std::lock_guard<atlas_rt::Mutex> lk_(g.mu);
+                            if (hipMemcpyAsync(B.p, row, sizeof(row), hipMemcpyHostToDevice, g.stream) != hipSuccess || hipStreamSynchronize(g.stream) != hipSuccess) { drc = fail(ATLAS_ENODEV, "prove_graph: one-cycle chunk row"); return; }
+                        }
+                        atlas_poly_t v = nullptr;
+                        drc = atlas_poly_wrap_device_i32(B.as<int32_t>(), 16, &v);
+                        if (drc) return;
+                        W.dense_views.push_back(v);
+                        gr::Committed c; c.id = gr::comm(cp, nd.idx, i); c.kind = 0; c.dense = v; c.log_T = 4;
+                        W.committed.push_back(c);
+                    }
+                    return;
+                }
                 for (size_t i = 0; i < d; i++) {
                     gr::Committed c; c.id = gr::comm(cp, nd.idx, i); c.kind = 1; c.d_lookups = d_lookups; c.log_T = log_T; c.log_K = log_K; c.chunk = i;
                     W.committed.push_back(c);
                 }
             };
-            int drc = ATLAS_OK;
             auto dense = [&](uint8_t cp, void* d_data, bool is_i32) {
                 atlas_poly_t v = nullptr;
                 drc = is_i32 ? atlas_poly_wrap_device_i32((int32_t*)d_data, T, &v) : atlas_poly_wrap_device_fr(d_data, T, &v);
@@ -189,7 +225,8 @@ struct Prover : FlowSink {
                 W.committed.push_back(c);
             };
             // one element: the is_scalar operators commit nothing; ScalarConstDiv keeps its remainder and Div its quotient (ops/div.rs:157-160)
-            if (T == 1 && nd.op != ATLAS_OP_SCALAR_CONST_DIV && nd.op != ATLAS_OP_DIV) continue;
+            if (T == 1 && nd.op != ATLAS_OP_SCALAR_CONST_DIV && nd.op != ATLAS_OP_DIV && nd.op != ATLAS_OP_RELU && nd.op != ATLAS_OP_CLAMP && !atlas_rt_is_activation(nd.op) &&
+                nd.op != ATLAS_OP_RSQRT && nd.op != ATLAS_OP_SIN && nd.op != ATLAS_OP_COS) continue;      // (the lookup operators proper run their generic flows over one cycle)
             switch (nd.op) {
                 case ATLAS_OP_ADD: case ATLAS_OP_SUB: chunks(gr::CP_ClampRaD, W.cidx.as<uint64_t>(), 64); break;       // clamp_committed_polys
                 case ATLAS_OP_EINSUM: case ATLAS_OP_MUL: case ATLAS_OP_SQUARE: case ATLAS_OP_CUBE:                     // fused_rebase::committed_polys
@@ -861,18 +898,29 @@ struct Prover : FlowSink {
         const Point r = challenge_point(log_T);
         const H::Fr gamma = H::tr_challenge_scalar(Tr);
         atlas_poly_t ops[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-        int rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(G.tensor(nd.inputs[0])), T, &ops[0]);
-        if (!rc) rc = atlas_poly_wrap_device_fr(W.quot_fr.p, T, &ops[1]);
-        if (!rc) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(G.tensor(nd.idx)), T, &ops[2]);
-        if (!rc) rc = atlas_poly_wrap_device_i32(W.rem.as<int32_t>(), T, &ops[3]);
-        if (!rc) rc = atlas_poly_wrap_device_i32(W.rem2.as<int32_t>(), T, &ops[4]);
-        const H::Fr consts[2] = {H::from_u64((uint64_t)1 << (3 * nd.p[0])), gamma};
-        atlas_instance_t inst = nullptr;
-        if (!rc) rc = atlas_elementwise_new(ATLAS_EW_RSQRT, ops, 5, (const atlas_fr_t*)r.data(), log_T, (const atlas_fr_t*)consts, 2, &inst);
-        for (atlas_poly_t p : ops) if (p) atlas_poly_free(p);
+        int rc = ATLAS_OK;
         std::vector<H::Fr> rs, fin;
-        if (!rc) rc = run_single(inst, H::zero(), gr::PT_Execution, rs, fin);
-        if (inst) atlas_instance_free(inst);
+        if (log_T == 0) {                                                     // one element: zero rounds, the five single values (the generic flow at T = 1)
+            rc = zero_rounds(H::zero(), gr::PT_Execution);
+            fin.resize(5);
+            if (!rc) rc = scalar_of(G.tensor(nd.inputs[0]), &fin[0]);
+            if (!rc) rc = scalar_fr_of(W.quot_fr.p, &fin[1]);
+            if (!rc) rc = scalar_of(G.tensor(nd.idx), &fin[2]);
+            if (!rc) rc = scalar_of(W.rem.as<int32_t>(), &fin[3]);
+            if (!rc) rc = scalar_of(W.rem2.as<int32_t>(), &fin[4]);
+        } else {
+            rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(G.tensor(nd.inputs[0])), T, &ops[0]);
+            if (!rc) rc = atlas_poly_wrap_device_fr(W.quot_fr.p, T, &ops[1]);
+            if (!rc) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(G.tensor(nd.idx)), T, &ops[2]);
+            if (!rc) rc = atlas_poly_wrap_device_i32(W.rem.as<int32_t>(), T, &ops[3]);
+            if (!rc) rc = atlas_poly_wrap_device_i32(W.rem2.as<int32_t>(), T, &ops[4]);
+            const H::Fr consts[2] = {H::from_u64((uint64_t)1 << (3 * nd.p[0])), gamma};
+            atlas_instance_t inst = nullptr;
+            if (!rc) rc = atlas_elementwise_new(ATLAS_EW_RSQRT, ops, 5, (const atlas_fr_t*)r.data(), log_T, (const atlas_fr_t*)consts, 2, &inst);
+            for (atlas_poly_t p : ops) if (p) atlas_poly_free(p);
+            if (!rc) rc = run_single(inst, H::zero(), gr::PT_Execution, rs, fin);
+            if (inst) atlas_instance_free(inst);
+        }
         if (rc) return rc;
         const Point pt = reversed(rs);
         rc = append_nodeio(nd, 0, pt, fin[0]);
@@ -1316,7 +1364,6 @@ struct Prover : FlowSink {
     // (RaOneHotChecks), and the range check's own one-hot checks (RaHammingWeight)
     int op_trig(const Node& nd) {
         const size_t T = gr::padded_len(nd.dims), log_T = gr::log2u(T), LK = gr::TRIG_TABLE_VARS, K = (size_t)1 << LK;
-        if (log_T == 0) return fail(ATLAS_EINVAL, "prove_graph: Sin / Cos of ONE element is not composed");
         NodeWitness& W = G.wit[nd.idx];
         const uint8_t vp_ra = nd.op == ATLAS_OP_SIN ? gr::VP_SinRa : gr::VP_CosRa, cp_rad = nd.op == ATLAS_OP_SIN ? gr::CP_SinRaD : gr::CP_CosRaD;
         const H::Fr tau = fr_from_i64_host(gr::TRIG_PERIOD_MODULUS);
@@ -1324,15 +1371,24 @@ struct Prover : FlowSink {
         // ---- 1a: TeleportDivisionProver at a point from the transcript
         const Point r = challenge_point(log_T);
         atlas_poly_t dops[3] = {nullptr, nullptr, nullptr};
-        int rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(G.tensor(nd.inputs[0])), T, &dops[0]);
-        if (!rc) rc = atlas_poly_wrap_device_i32(W.rem2.as<int32_t>(), T, &dops[1]);
-        if (!rc) rc = atlas_poly_wrap_device_i32(W.rem.as<int32_t>(), T, &dops[2]);
-        atlas_instance_t i_div = nullptr;
-        if (!rc) rc = atlas_elementwise_new(ATLAS_EW_TELEPORT_DIV, dops, 3, (const atlas_fr_t*)r.data(), log_T, (const atlas_fr_t*)&tau, 1, &i_div);
-        for (atlas_poly_t p : dops) if (p) atlas_poly_free(p);
+        int rc = ATLAS_OK;
         std::vector<H::Fr> rs, fin;
-        if (!rc) rc = run_single(i_div, H::zero(), gr::PT_NeuralTeleport, rs, fin);
-        if (i_div) atlas_instance_free(i_div);
+        if (log_T == 0) {                                                     // one element: zero rounds, the three single values
+            rc = zero_rounds(H::zero(), gr::PT_NeuralTeleport);
+            fin.resize(3);
+            if (!rc) rc = scalar_of(G.tensor(nd.inputs[0]), &fin[0]);
+            if (!rc) rc = scalar_of(W.rem2.as<int32_t>(), &fin[1]);
+            if (!rc) rc = scalar_of(W.rem.as<int32_t>(), &fin[2]);
+        } else {
+            rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(G.tensor(nd.inputs[0])), T, &dops[0]);
+            if (!rc) rc = atlas_poly_wrap_device_i32(W.rem2.as<int32_t>(), T, &dops[1]);
+            if (!rc) rc = atlas_poly_wrap_device_i32(W.rem.as<int32_t>(), T, &dops[2]);
+            atlas_instance_t i_div = nullptr;
+            if (!rc) rc = atlas_elementwise_new(ATLAS_EW_TELEPORT_DIV, dops, 3, (const atlas_fr_t*)r.data(), log_T, (const atlas_fr_t*)&tau, 1, &i_div);
+            for (atlas_poly_t p : dops) if (p) atlas_poly_free(p);
+            if (!rc) rc = run_single(i_div, H::zero(), gr::PT_NeuralTeleport, rs, fin);
+            if (i_div) atlas_instance_free(i_div);
+        }
         if (rc) return rc;
         const Point pt = reversed(rs);
         rc = append_nodeio(nd, 0, pt, fin[0]);
@@ -1420,10 +1476,6 @@ struct Prover : FlowSink {
 
     int prove_node(const Node& nd) {
         cur = nd.idx;
-        if (gr::padded_len(nd.dims) == 1 && nd.op == ATLAS_OP_RSQRT)
-            return fail(ATLAS_EINVAL, "prove_graph: Rsqrt of ONE element is not composed (its range checks are read-raf instances without cycle variables)");
-        if (gr::padded_len(nd.dims) == 1 && (nd.op == ATLAS_OP_RELU || nd.op == ATLAS_OP_CLAMP || atlas_rt_is_activation(nd.op)))
-            return fail(ATLAS_EINVAL, "prove_graph: a lookup operator (ReLU / Clamp / Tanh / Erf / Sigmoid) over ONE element is not composed (a read-raf instance without cycle variables)");
         if (nd.op == ATLAS_OP_DIV) return op_div(nd);                          // ReductionFlow::Custom
         if (nd.op == ATLAS_OP_RSQRT) return op_rsqrt(nd);
         if (nd.op == ATLAS_OP_SIN || nd.op == ATLAS_OP_COS) return op_trig(nd);

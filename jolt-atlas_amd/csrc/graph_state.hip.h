@@ -23,6 +23,7 @@ struct NodeWitness {
     DevBuf rem;                                  // ScalarConstDiv / Div: the remainder tensor (i32); Rsqrt: div_remainder
     DevBuf quot_fr, rem2, lookups2, bound;       // Rsqrt: quotient as Fr, sqrt_remainder, the second range check's pairs and its bound 2 out + 1
     DevBuf clamped;                              // Tanh: clamp(input, ACTIVATION_BOUND) (i32); its 18-bit lookups in `lookups2`, the raw-input lookups in `lookups`
+    std::vector<std::unique_ptr<DevBuf>> one_cycle_rows;    // a lookup operator over ONE element: its K x 1 one-hot chunk polynomials as 16-coefficient dense rows
     std::vector<atlas_poly_t> dense_views;       // borrowed polynomial views of the dense committed polynomials
     ~NodeWitness() { for (auto p : dense_views) if (p) atlas_poly_free(p); }
     NodeWitness() = default;

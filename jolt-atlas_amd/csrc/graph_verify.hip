@@ -782,7 +782,7 @@ struct Verifier {
         };
         int rc = run_single(gr::PT_Execution, I, "verify_graph: SumcheckVerificationError (rsqrt)");
         if (!rc) rc = eval_reduction(nd);
-        if (rc || log_T == 0) return rc;
+        if (rc) return rc;                                                    // (one element: no is_scalar branch in ops/rsqrt.rs — the range checks run over one cycle)
         // verify_range_and_onehot (rsqrt.rs): r_d < x and r_s < 2 out + 1
         const H::Fr o = current_claim(nd);
         Point ra0, ra1;
@@ -1174,7 +1174,8 @@ struct Verifier {
         for (auto& kv : G.nodes) {
             const Node& nd = kv.second;
             const size_t T = gr::padded_len(nd.dims), log_T = gr::log2u(T);
-            if (T == 1 && nd.op != ATLAS_OP_SCALAR_CONST_DIV && nd.op != ATLAS_OP_DIV) continue;      // one element: ScalarConstDiv keeps its remainder, Div its quotient (ops/div.rs:157-160)
+            if (T == 1 && nd.op != ATLAS_OP_SCALAR_CONST_DIV && nd.op != ATLAS_OP_DIV && nd.op != ATLAS_OP_RELU && nd.op != ATLAS_OP_CLAMP && !atlas_rt_is_activation(nd.op) &&
+                nd.op != ATLAS_OP_RSQRT && nd.op != ATLAS_OP_SIN && nd.op != ATLAS_OP_COS) continue;      // (the lookup operators proper run their generic flows over one cycle)      // one element: ScalarConstDiv keeps its remainder, Div its quotient (ops/div.rs:157-160)
             auto chunks = [&](uint8_t cp, size_t log_K) { for (size_t i = 0; i < (log_K + 3) / 4; i++) committed[gr::comm(cp, nd.idx, i)].log_T = log_T; };
             auto dense = [&](uint8_t cp) { committed[gr::comm(cp, nd.idx)].log_T = log_T; };
             switch (nd.op) {

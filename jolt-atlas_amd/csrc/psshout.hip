@@ -389,7 +389,8 @@ struct PsLookup : atlas_instance {
     size_t q_rows_max() const { size_t r = ((size_t)1 << 17) / m; if (r > 2048) r = 2048; return r < SLICES ? SLICES : r; }
 
     ~PsLookup() override { for (void* p : {(void*)d_idx, (void*)d_u0, (void*)d_v, (void*)d_qpart}) if (p) hipFree(p); rows.release(); eq.release(); }
-    size_t rounds() const override { return N + log_T; }
+    bool one_cycle = false;               // log_T == 0 held as two cycles, the second of weight zero (ps_new)
+    size_t rounds() const override { return one_cycle ? N : N + log_T; }
     size_t degree() const override { return 2; }
 
     static H::Fr pow2(size_t k) {          // 2^k as a field element; k <= 64 from a table built once (the rounds ask for hundreds)
@@ -738,6 +739,7 @@ struct PsLookup : atlas_instance {
         if (round_next != rounds()) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
         if (have_finals) { out = mailed_finals; return ATLAS_OK; }
         std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        if (one_cycle) rows.len = 1;                                  // ra of the one lookup: entry 0 of the products (the second entry is the weight-zero cycle)
         return rows.finals(out);
     }
 
@@ -750,7 +752,7 @@ struct PsLookup : atlas_instance {
     PsSlots slots{};
     bool have_finals = false;
     std::vector<H::Fr> mailed_finals;
-    bool pipelined() const override { return log_m <= 11 && N + log_T <= atlas_rt::Channel::RING / 2; }
+    bool pipelined() const override { return !one_cycle && log_m <= 11 && N + log_T <= atlas_rt::Channel::RING / 2; }
     bool wide_wait(size_t round) const override {                 // address rounds and the first cycle round: only the one-workgroup table rebuild waits
         if (round <= N || round >= rounds()) return false;
         const size_t n_groups = (T >> (round - N)) / 2;
@@ -866,26 +868,40 @@ extern "C" {
 
 static int ps_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, size_t phases, int mode, const atlas_fr_t* r_node_output,
                   const atlas_fr_t* gamma, atlas_instance_t* out, size_t bound = 0, bool symmetric = true) {
+    // log_T == 0 — a read-raf instance WITHOUT cycle variables (ps_shout/mod.rs:419-446 at T = 1: log_K address rounds, then the ra value of the one
+    // lookup).  Held as TWO cycles of which the second has weight u = 0 and index 0: every sum over cycles of the address rounds is the one-cycle
+    // sum, no kernel meets a length of one; the instance reports log_K rounds, is stepped by the host (the fold of the last phase's table
+    // happens in its ingest) and its final claim is entry 0 of the products.
+    const bool one_cycle = log_T == 0;
+    if (one_cycle) log_T = 1;
     atlas_poly_t E = nullptr;
-    int rc = atlas_eq_evals(r_node_output, log_T, nullptr, &E);      // u_evals = EqPolynomial::evals(r_node_output), mod.rs:234
+    int rc = atlas_eq_evals(r_node_output, one_cycle ? 0 : log_T, nullptr, &E);      // u_evals = EqPolynomial::evals(r_node_output), mod.rs:234
     if (rc) return rc;
     std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     PsLookup* P = new PsLookup();
+    P->one_cycle = one_cycle;
     P->N = log_K; P->phases = phases; P->mode = mode; P->bound = bound; P->symmetric = symmetric;
     P->log_m = log_K / phases; P->m = (size_t)1 << P->log_m; P->log_T = log_T; P->T = (size_t)1 << log_T;
     if (gamma) std::memcpy(&P->gamma, gamma, 32);
-    P->d_u0 = (Fr*)E->d; delete E;                                   // keep the table, drop the handle
     const size_t T = P->T, m = P->m;
-    hipError_t e = hipMalloc(&P->d_idx, T * sizeof(uint64_t));
+    hipError_t e = hipSuccess;
+    if (one_cycle) {                                                 // u = (1, 0)
+        e = hipMalloc(&P->d_u0, 2 * sizeof(Fr));
+        if (e == hipSuccess) e = hipMemsetAsync(P->d_u0, 0, 2 * sizeof(Fr), g.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(P->d_u0, E->d, sizeof(Fr), hipMemcpyDeviceToDevice, g.stream);
+        atlas_poly_free(E);
+    } else { P->d_u0 = (Fr*)E->d; delete E; }                        // keep the table, drop the handle
+    if (e == hipSuccess) e = hipMalloc(&P->d_idx, T * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc(&P->d_v, 2 * m * sizeof(Fr));       // two tables: the pipelined path alternates
     if (e == hipSuccess) e = hipMalloc(&P->d_qpart, (P->q_rows_max() + 1) * 6 * m * sizeof(Fr));
-    if (e == hipSuccess) e = hipMemcpyAsync(P->d_idx, lookup_indices, T * sizeof(uint64_t), hipMemcpyDefault, g.stream);   // host or device source
+    if (e == hipSuccess && one_cycle) e = hipMemsetAsync(P->d_idx, 0, T * sizeof(uint64_t), g.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(P->d_idx, lookup_indices, (one_cycle ? 1 : T) * sizeof(uint64_t), hipMemcpyDefault, g.stream);   // host or device source
     if (e != hipSuccess) { delete P; return fail(ATLAS_ENOMEM, "ps_shout_new", e); }
     rc = P->rows.alloc(1, T);
     if (!rc) {
         size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
         k_ps_fill_one<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(P->rows.buf[0], T);
-        rc = P->eq.init(reinterpret_cast<const H::Fr*>(r_node_output), log_T);
+        if (!one_cycle) rc = P->eq.init(reinterpret_cast<const H::Fr*>(r_node_output), log_T);       // (the split eq of the cycle rounds: none here)
     }
     if (!rc) rc = P->build_Q(0);
     if (rc) { delete P; return rc; }
@@ -896,27 +912,27 @@ static int ps_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, si
 int atlas_ps_shout_relu_new(const uint64_t* lookup_indices, size_t log_T, size_t xlen, const atlas_fr_t* r_node_output,
                             const atlas_fr_t* gamma, atlas_instance_t* out) {
     NEED_INIT();
-    if (!lookup_indices || !r_node_output || !gamma || !out) return fail(ATLAS_EINVAL, "ps_shout_relu_new: null argument");
+    if (!lookup_indices || (!r_node_output && log_T) || !gamma || !out) return fail(ATLAS_EINVAL, "ps_shout_relu_new: null argument");
     if (xlen != 16 && xlen != 32) return fail(ATLAS_EINVAL, "ps_shout_relu_new: X_LEN must be 16 or 32 (the reference's WordNoMSB suffix is a u32)");
-    if (log_T == 0 || log_T > 25) return fail(ATLAS_EINVAL, "ps_shout_relu_new: 1 <= log_T <= 25");
+    if (log_T > 25) return fail(ATLAS_EINVAL, "ps_shout_relu_new: log_T <= 25");
     return ps_new(lookup_indices, log_T, xlen, 8, 0, r_node_output, gamma, out);
 }
 
 int atlas_ps_shout_clamp_new(const uint64_t* lookup_indices, size_t log_T, size_t xlen, size_t bound, int symmetric,
                              const atlas_fr_t* r_node_output, const atlas_fr_t* gamma, atlas_instance_t* out) {
     NEED_INIT();
-    if (!lookup_indices || !r_node_output || !gamma || !out) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: null argument");
+    if (!lookup_indices || (!r_node_output && log_T) || !gamma || !out) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: null argument");
     if (xlen != 16 && xlen != 32 && xlen != 64) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: X_LEN must be 16, 32 or 64");
     if (bound == 0 || bound + 1 >= xlen || bound > 31) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: 1 <= BOUND <= 31 and BOUND < X_LEN - 1");
-    if (log_T == 0 || log_T > 25) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: 1 <= log_T <= 25");
+    if (log_T > 25) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: log_T <= 25");
     return ps_new(lookup_indices, log_T, xlen, 8, 2, r_node_output, gamma, out, bound, symmetric != 0);
 }
 
 int atlas_ps_shout_rshift_new(const uint64_t* lookup_indices, size_t log_T, size_t xlen, size_t shift, const atlas_fr_t* r_node_output,
                               const atlas_fr_t* gamma, atlas_instance_t* out) {
     NEED_INIT();
-    if (!lookup_indices || !r_node_output || !gamma || !out) return fail(ATLAS_EINVAL, "ps_shout_rshift_new: null argument");
-    if ((xlen != 16 && xlen != 32) || shift >= xlen || log_T == 0 || log_T > 25)
+    if (!lookup_indices || (!r_node_output && log_T) || !gamma || !out) return fail(ATLAS_EINVAL, "ps_shout_rshift_new: null argument");
+    if ((xlen != 16 && xlen != 32) || shift >= xlen || log_T > 25)
         return fail(ATLAS_EINVAL, "ps_shout_rshift_new: xlen must be 16 or 32, shift < xlen, 1 <= log_T <= 25");
     return ps_new(lookup_indices, log_T, xlen, 8, 4, r_node_output, gamma, out, shift, true);
 }
@@ -924,18 +940,18 @@ int atlas_ps_shout_rshift_new(const uint64_t* lookup_indices, size_t log_T, size
 int atlas_ps_shout_ult_new(const uint64_t* lookup_indices, size_t log_T, const atlas_fr_t* r_node_output, const atlas_fr_t* gamma,
                            atlas_instance_t* out) {
     NEED_INIT();
-    if (!lookup_indices || !r_node_output || !gamma || !out) return fail(ATLAS_EINVAL, "ps_shout_ult_new: null argument");
-    if (log_T == 0 || log_T > 25) return fail(ATLAS_EINVAL, "ps_shout_ult_new: 1 <= log_T <= 25");
+    if (!lookup_indices || (!r_node_output && log_T) || !gamma || !out) return fail(ATLAS_EINVAL, "ps_shout_ult_new: null argument");
+    if (log_T > 25) return fail(ATLAS_EINVAL, "ps_shout_ult_new: log_T <= 25");
     return ps_new(lookup_indices, log_T, 64, 8, 3, r_node_output, gamma, out);
 }
 
 int atlas_identity_range_check_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, size_t phases,
                                    const atlas_fr_t* r_node_output, atlas_instance_t* out) {
     NEED_INIT();
-    if (!lookup_indices || !r_node_output || !out) return fail(ATLAS_EINVAL, "identity_range_check_new: null argument");
+    if (!lookup_indices || (!r_node_output && log_T) || !out) return fail(ATLAS_EINVAL, "identity_range_check_new: null argument");
     if (phases == 0 || log_K == 0 || log_K > 64 || log_K % phases || log_K / phases > 12)
         return fail(ATLAS_EINVAL, "identity_range_check_new: log_K must be a multiple of phases, chunks of at most 12 bits");
-    if (log_T == 0 || log_T > 25) return fail(ATLAS_EINVAL, "identity_range_check_new: 1 <= log_T <= 25");
+    if (log_T > 25) return fail(ATLAS_EINVAL, "identity_range_check_new: log_T <= 25");
     return ps_new(lookup_indices, log_T, log_K, phases, 1, r_node_output, nullptr, out);
 }
 

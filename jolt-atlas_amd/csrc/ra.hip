@@ -490,7 +490,7 @@ struct RaVirtual : atlas_instance {
     // ---- round-channel stepping (instance.hpp).  Rows of round k live in buf[k & 1] with stride T >> k.
     bool have_finals = false;
     std::vector<H::Fr> mailed_finals;
-    bool pipelined() const override { return true; }
+    bool pipelined() const override { return log_T >= 1; }
     static bool fuse_off() { static const bool v = getenv("ATLAS_RA_NO_FUSE") != nullptr; return v; }   // diagnosis / A-B: bind and product as two launches
     bool fused(size_t round) const { return round >= 1 && round < log_T && (((size_t)1 << log_T) >> round) / 2 <= RA_FUSE_MAX && !fuse_off(); }
     bool wide_wait(size_t round) const override {                 // the bind of `round`: ceil(len / RA_THREADS) x d workgroups (fused: a workgroup per 16 pairs); the finals: one
@@ -712,7 +712,7 @@ struct Booleanity : atlas_instance {
     // round p has its rows in buf[p & 1] with stride T >> p.
     bool have_finals = false;
     std::vector<H::Fr> mailed_finals;
-    bool pipelined() const override { return log_k <= 15; }
+    bool pipelined() const override { return log_k <= 15 && log_T >= 1; }
     // cycle round p >= 1 in one launch (k_bool_bind_fold); ATLAS_RA_NO_FUSE / ATLAS_NO_MAIL_TAIL: the separate launches (diagnosis, A-B)
     bool fused(size_t p) const {
         static const bool off = getenv("ATLAS_RA_NO_FUSE") != nullptr || getenv("ATLAS_BOOL_NO_FUSE") != nullptr || getenv("ATLAS_NO_MAIL_TAIL") != nullptr;
@@ -873,7 +873,8 @@ static int ra_virtual_build(const int32_t* const* H_indices, const uint64_t* loo
                             const atlas_fr_t* r_address_chunks, const atlas_fr_t* r_cycle, atlas_instance_t* out) {
     if (!r_address_chunks || (!r_cycle && log_T) || !out) return fail(ATLAS_EINVAL, "ra_virtual_new: null argument");
     if (d == 0 || d > RA_MAX_D) return fail(ATLAS_EINVAL, "ra_virtual_new: d must be in 1..16");
-    if (log_k_chunk > 16 || log_T == 0 || log_T > 25) return fail(ATLAS_EINVAL, "ra_virtual_new: log_k_chunk <= 16, 1 <= log_T <= 25");
+    // log_T == 0: ONE cycle — a member without rounds (its claim is the product of the d gathered values); stepped by the host, never started
+    if (log_k_chunk > 16 || log_T > 25) return fail(ATLAS_EINVAL, "ra_virtual_new: log_k_chunk <= 16, log_T <= 25");
     std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     RaVirtual* P = new RaVirtual();
     P->log_T = log_T;
@@ -895,7 +896,7 @@ static int ra_virtual_build(const int32_t* const* H_indices, const uint64_t* loo
     if (!rc) rc = H_indices ? P->rows.upload_indices(H_indices) : P->rows.upload_lookups(lookups, (uint32_t)log_k_chunk);
     if (!rc) rc = P->rows.gather(d_tabs, (uint32_t)K);
     if (d_tabs) hipFree(d_tabs);
-    if (!rc) rc = P->eq.init(reinterpret_cast<const H::Fr*>(r_cycle), log_T);
+    if (!rc && log_T) rc = P->eq.init(reinterpret_cast<const H::Fr*>(r_cycle), log_T);
     if (rc) { delete P; return rc; }
     *out = P;
     return ATLAS_OK;
@@ -924,8 +925,9 @@ static int booleanity_build(const atlas_fr_t* G, const int32_t* const* H_indices
                             size_t log_T, const atlas_fr_t* gammas, const atlas_fr_t* r_address, const atlas_fr_t* r_cycle,
                             atlas_instance_t* out) {
     if (!G || !gammas || !r_address || (!r_cycle && log_T) || !out) return fail(ATLAS_EINVAL, "booleanity_new: null argument");
-    if (d == 0 || log_k_chunk == 0 || log_k_chunk > 16 || log_T == 0 || log_T > 25)
-        return fail(ATLAS_EINVAL, "booleanity_new: 1 <= log_k_chunk <= 16, 1 <= log_T <= 25");
+    // log_T == 0: ONE cycle — the log_k address rounds only (host arithmetic), then H_i = F[idx_i] gathered as the final claims
+    if (d == 0 || log_k_chunk == 0 || log_k_chunk > 16 || log_T > 25)
+        return fail(ATLAS_EINVAL, "booleanity_new: 1 <= log_k_chunk <= 16, log_T <= 25");
     std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     Booleanity* P = new Booleanity();
     P->d = d; P->log_k = log_k_chunk; P->log_T = log_T;
@@ -939,7 +941,7 @@ static int booleanity_build(const atlas_fr_t* G, const int32_t* const* H_indices
     P->B.init(ra, log_k_chunk);
     P->B_out = H::eq_cached(ra, P->B.k_out);
     P->B_in = H::eq_cached(ra + P->B.m, P->B.k_in);
-    int rc = P->D.init(reinterpret_cast<const H::Fr*>(r_cycle), log_T);
+    int rc = log_T ? P->D.init(reinterpret_cast<const H::Fr*>(r_cycle), log_T) : ATLAS_OK;
     if (!rc) rc = P->rows.alloc(d, T);
     if (!rc) rc = H_indices ? P->rows.upload_indices(H_indices) : P->rows.upload_lookups(lookups, (uint32_t)log_k_chunk);   // resident until the phase-2 gather
     if (!rc) {

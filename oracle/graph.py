@@ -507,7 +507,10 @@ class Prover:
     def lookup_families(self, nd):
         """[(CommittedPoly name, lookup indices (u64), log_K)] in get_committed_polynomials order"""
         op, i = nd["op"], nd["idx"]
-        if int(np.prod(nd["dims"])) == 1:
+        # one element: the is_scalar operators (add, sub, sum, the fused-rescale family, mean_of_squares; Div by its own branch) commit nothing;
+        # the lookup operators proper (ReLU, Clamp, the activations, Rsqrt, Sin / Cos) have no such branch in the reference (ops/relu.rs,
+        # clamp.rs, tanh.rs, rsqrt.rs, sin.rs ...): their generic flows run over one cycle, with one-hot polynomials of K x 1 coefficients
+        if int(np.prod(nd["dims"])) == 1 and op not in ("ReLU", "Clamp", "Tanh", "Erf", "Sigmoid", "Rsqrt", "Sin", "Cos"):
             return []
         if op in ("Add", "Sub"):
             return [("ClampRaD", self.wit[i]["acc"].astype(np.int64).view(np.uint64), 64)]
@@ -578,7 +581,7 @@ class Prover:
                     self.committed[comm(name, i, c)] = dict(row=row.astype(np.int32), log_T=ilog2(Tn), commitment=orc.g1_sum_indexed(self.srs, flat))
             # one element: the is_scalar operators have no committed polynomial; ScalarConstDiv keeps its remainder (generic flow) and Div its
             # quotient (ops/div.rs:157-160: `if node.is_scalar() { return polys; }` after DivNodeQuotient)
-            if int(np.prod(nd["dims"])) > 1 or nd["op"] in ("ScalarConstDiv", "Div"):
+            if int(np.prod(nd["dims"])) > 1 or nd["op"] in ("ScalarConstDiv", "Div", "Rsqrt", "Sin", "Cos"):
                 for name, coeffs in self.dense_committed(nd):
                     self.committed[comm(name, i)] = dict(dense=coeffs, log_T=ilog2(len(coeffs)), commitment=orc.msm(self.srs[:len(coeffs)], coeffs))
         for key in sorted(self.committed):

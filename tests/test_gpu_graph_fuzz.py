@@ -178,9 +178,8 @@ def _run(atlas, nodes, outputs, inputs, seed):
 def test_random_operator_chain_tiny_shapes(atlas, seed):
     """axes of one and two elements: scalar nodes (no lookups, zero-round sumchecks, clear-text checks in the verifier) between vector ones"""
     nodes, outputs, inputs = random_chain(9000 + seed, steps=8, sizes=(1, 2))
-    # (round 4: a scalar-output Einsum, a contraction over one element and a Div of one element are composed: tests/test_gpu_one_element.py)
-    if any(nd["op"] in ("ReLU", "Clamp", "Rsqrt", "Sin", "Cos") and int(np.prod(nd["dims"])) == 1 for nd in nodes):
-        pytest.skip("a lookup operator over one element is not composed")
+    # (round 4: the one-element corner cases are composed — a scalar-output Einsum, Div, and the lookup operators over one cycle:
+    # tests/test_gpu_one_element.py — so nothing of this draw is skipped any more)
     _run(atlas, nodes, outputs, inputs, seed)
 
 
