@@ -283,7 +283,10 @@ int atlas_instance_prove(atlas_instance_t i, const atlas_fr_t *input_claim, atla
 int atlas_batched_add_instance(atlas_batched_t b, atlas_instance_t i, const atlas_fr_t *input_claim);
 
 /* ---- one-hot "ra" instances of the lookup arguments.  H_indices = d host arrays of T = 2^log_T
- *      int32 (the reference's Vec<Vec<Option<u8>>> / Option<u16>, negative = None) ----------- */
+ *      int32 (the reference's Vec<Vec<Option<u8>>> / Option<u16>, negative = None).
+ *      log_T = 0 (ONE cycle: a lookup operator over a one-element tensor) is accepted by the ra / booleanity /
+ *      prefix-suffix read-raf constructors below: the instances then have their address rounds only (RaVirtual:
+ *      no round at all) and r_cycle / r_node_output may be NULL -------------------------------- */
 /* RaSumcheckProver::gen (subprotocols/ra_virtual.rs:97-125): sum_j eq(r_cycle, j) prod_i ra_i(j),
  * degree d + 1, log_T rounds LowToHigh.  r_address_chunks = d * log_k_chunk Fr, row i = chunk i
  * (OneHotParams::compute_r_address_chunks, config.rs:77-100); r_cycle = log_T Fr, big-endian.
