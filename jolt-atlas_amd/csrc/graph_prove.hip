@@ -1476,6 +1476,10 @@ struct Prover : FlowSink {
 
     int prove_node(const Node& nd) {
         cur = nd.idx;
+        // (the lookup operators over ONE element are composed — DESIGN 11.8b; a gather of one index and a softmax over one element are not:
+        // their dictionary / per-row machinery was never walked at one cycle, and no model of the reference's zoo has them)
+        if (gr::padded_len(nd.dims) == 1 && (nd.op == ATLAS_OP_GATHER_LARGE || nd.op == ATLAS_OP_GATHER_SMALL || nd.op == ATLAS_OP_SOFTMAX))
+            return fail(ATLAS_EINVAL, "prove_graph: Gather / SoftmaxLastAxis with a ONE-element output is not composed");
         if (nd.op == ATLAS_OP_DIV) return op_div(nd);                          // ReductionFlow::Custom
         if (nd.op == ATLAS_OP_RSQRT) return op_rsqrt(nd);
         if (nd.op == ATLAS_OP_SIN || nd.op == ATLAS_OP_COS) return op_trig(nd);

@@ -1118,6 +1118,8 @@ struct Verifier {
     }
     int verify_node(const Node& nd, size_t& next_input_from_end) {
         cur = nd.idx;
+        if (gr::padded_len(nd.dims) == 1 && (nd.op == ATLAS_OP_GATHER_LARGE || nd.op == ATLAS_OP_GATHER_SMALL || nd.op == ATLAS_OP_SOFTMAX))
+            return fail(ATLAS_EINVAL, "verify_graph: Gather / SoftmaxLastAxis with a ONE-element output is not composed");
         if (nd.op == ATLAS_OP_DIV) return op_div(nd);                          // ReductionFlow::Custom
         if (nd.op == ATLAS_OP_RSQRT) return op_rsqrt(nd);
         if (nd.op == ATLAS_OP_SIN || nd.op == ATLAS_OP_COS) return op_trig(nd);
