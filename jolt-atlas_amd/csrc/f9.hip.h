@@ -319,6 +319,30 @@ __device__ __forceinline__ F9 f9_wave_sum(F9 a) {
     return a;
 }
 
+// Wavefront sum WITHOUT reductions: limb-wise adds, a carry pass after every third doubling (8 x (2^29 - 1) fits a word).  Input: normalized
+// limbs, value < ~4 p.  Output in EVERY lane: normalized limbs (the top limb unmasked), value = the exact integer sum (< 64 x the input bound:
+// top limb < 2^31) — for sums that are mailed as lazy limbs and reduced once on the host (channel.hpp: sum_to_fr), or reduced once by
+// f9_reduce_i64.  The steps inside a 16-lane row are DPP moves (no LDS crossbar): 72 of the 108 ds_bpermute of f9_wave_sum go, and all
+// twelve reductions with their per-limb multiplies (the wavefront sum of two accumulators was 1 150 of the ~1 400 instructions behind the
+// loop of a data pass: 2 us on the critical path of every pass).
+template <int CTRL>
+__device__ __forceinline__ F9 f9_add_dpp(const F9& a) {
+    F9 o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o.l[i] = a.l[i] + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.l[i], CTRL, 0xf, 0xf, false);
+    return o;
+}
+__device__ __forceinline__ F9 f9_wave_sum_lazy(F9 a) {
+    a = f9_add_dpp<0xb1>(a);                 // + lane ^ 1
+    a = f9_add_dpp<0x4e>(a);                 // + lane ^ 2: the quad
+    a = f9_add_dpp<0x124>(a);                // + the quad 4 lanes round the row: 8 lanes
+    a = f9_norm(a);
+    a = f9_add_dpp<0x128>(a);                // + 8 lanes round the row: the 16-lane row
+    a = f9_add(a, f9_shfl_xor(a, 16));
+    a = f9_add(a, f9_shfl_xor(a, 32));
+    return f9_norm(a);
+}
+
 // ---- small signed linear combinations (the extrapolation steps of the split product, ra.hip)
 // V = sum t[i] 2^(29 i) with signed 64-bit columns, |V| < 2^16.5 p, |t[i]| < 2^46  ->  the representative of V mod p in (0.99 p, 2.01 p),
 // normalized.  q = floor(V / p) - 1 is estimated from the two top columns in single precision: the top columns give V / 2^232 within

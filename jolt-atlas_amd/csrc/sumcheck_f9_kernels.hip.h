@@ -32,13 +32,14 @@ __device__ __forceinline__ void f9_block_reduce_store2(F9 acc0, F9 acc2, Fr* par
     }
 }
 
-// the same reduction mailed to the host as lazy 9 x 29-bit limbs (value < 2.1p, still carrying the 2^-5 of
-// the 9-step reduction): the host sums the records limb-wise and reduces once (channel.hpp)
+// the same sums mailed to the host as lazy 9 x 29-bit limbs (still carrying the 2^-5 of the 9-step reduction): the host sums the
+// records limb-wise and reduces once (channel.hpp: sum_to_fr takes any 32-bit limbs), so nothing is reduced here — the wavefront and
+// workgroup sums are plain integer sums with carry passes (f9_wave_sum_lazy; inputs < 2.1 p: the workgroup's sum is < 540 p, its top
+// limb < 2^31)
 __device__ __forceinline__ void f9_block_reduce_mail2(F9 acc0, F9 acc2, const RoundIo& io) {
-    using P9 = Fr9Params;
     __shared__ F9 red9m[SC_THREADS / 64][2];
-    acc0 = f9_wave_sum<P9>(acc0);
-    acc2 = f9_wave_sum<P9>(acc2);
+    acc0 = f9_wave_sum_lazy(acc0);
+    acc2 = f9_wave_sum_lazy(acc2);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { red9m[wave][0] = acc0; red9m[wave][1] = acc2; }
     __shared__ uint32_t stage9m[18];
@@ -47,7 +48,9 @@ __device__ __forceinline__ void f9_block_reduce_mail2(F9 acc0, F9 acc2, const Ro
         F9 s = f9_zero();
         if (threadIdx.x < 2) {
             s = red9m[0][threadIdx.x];
-            for (int w = 1; w < SC_THREADS / 64; w++) s = f9_norm_red<P9>(f9_add(s, red9m[w][threadIdx.x]));
+#pragma unroll
+            for (int w = 1; w < SC_THREADS / 64; w++) s = f9_add(s, red9m[w][threadIdx.x]);     // four normalized values: limbs < 2^31
+            s = f9_norm(s);
         }
         ch_mail_wave_f9(io, blockIdx.x * ch_stride(2), 2, s, stage9m);
     }
