@@ -229,11 +229,16 @@ static __global__ __launch_bounds__(SC_TAIL_THREADS) void k_dot_tail2_f9(TailChA
         }
         if (round == A.n_rounds) break;
 
-        // lanes of equal parity hold the same kind of product: butterfly over masks 2 .. 32
+        // lanes of equal parity hold the same kind of product: their sum over the wavefront, as a plain integer sum with carry passes (the host
+        // reduces the mailed limbs once: no reduction here; DPP inside the 16-lane row).  Whole wavefronts take the branch: DPP needs every lane.
         const uint32_t n_waves = (n_lanes + 63) / 64;
         if (wave < n_waves) {
-#pragma unroll
-            for (int m = 32; m >= 2; m >>= 1) acc = f9_norm_red<P9>(f9_add(acc, f9_shfl_xor(acc, m)));
+            acc = f9_add_dpp<0x4e>(acc);                      // + lane ^ 2
+            acc = f9_add_dpp<0x124>(acc);                     // + 4 lanes round the row
+            acc = f9_add_dpp<0x128>(acc);                     // + 8 lanes round the row: the 8 lanes of this parity in the row
+            acc = f9_norm(acc);
+            acc = f9_add(acc, f9_shfl_xor(acc, 16));
+            acc = f9_norm(f9_add(acc, f9_shfl_xor(acc, 32)));
         }
         const RoundIo io{A.mail, nullptr, nullptr, 1u, A.abort_flag, A.tag_mail0 + round, 0u};
         if (n_waves == 1) {
@@ -241,10 +246,13 @@ static __global__ __launch_bounds__(SC_TAIL_THREADS) void k_dot_tail2_f9(TailChA
         } else {
             if (wave < n_waves && lane < 2) red9t[wave][h] = acc;
             __syncthreads();
-            if (wave == 0) {
+            if (wave == 0) {                                  // lane 2 w + h holds wavefront w's sum (< 64 p, normalized): at most 16 of them per parity
                 F9 t = lane < 2 * n_waves ? red9t[lane >> 1][h] : f9_zero();
-#pragma unroll
-                for (int m = 16; m >= 2; m >>= 1) t = f9_norm_red<P9>(f9_add(t, f9_shfl_xor(t, m)));
+                t = f9_add_dpp<0x4e>(t);
+                t = f9_add_dpp<0x124>(t);
+                t = f9_add_dpp<0x128>(t);
+                t = f9_norm(t);
+                t = f9_norm(f9_add(t, f9_shfl_xor(t, 16)));     // < 1100 p: the top limb fits its word
                 ch_mail_wave_f9(io, (round - A.round0) * ch_stride(2), 2, t, stage9t);
             }
         }
