@@ -365,6 +365,15 @@ __device__ __forceinline__ F9 f9_reduce_i64(int64_t (&t)[9]) {
     return o;
 }
 
+// the same for a value held as limbs of up to 32 bits (the output of f9_wave_sum_lazy, or a few of them added): (0.99 p, 2.01 p), normalized
+template <class P9>
+__device__ __forceinline__ F9 f9_reduce_lazy(const F9& a) {
+    int64_t t[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) t[i] = (int64_t)a.l[i];
+    return f9_reduce_i64<P9>(t);
+}
+
 // sum_j c[j] * v[j] mod p for small signed constants (sum |c[j]| v[j] < 2^16.5 p; v[j] normalized): (0.99 p, 2.01 p), normalized
 template <class P9, int N>
 __device__ __forceinline__ F9 f9_lincomb(const F9* const (&v)[N], const int (&c)[N]) {

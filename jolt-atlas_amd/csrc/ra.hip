@@ -49,18 +49,20 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_prod_f9(const Fr* __restrict_
             }
         }
     }
+    // sums over the workgroup as plain integer sums (f9_wave_sum_lazy: DPP in the row, carry passes), ONE reduction per column at the end
     __shared__ F9 red9[RA_THREADS / 64][KN];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < KN; k++) {
-        const F9 sres = f9_wave_sum<P9>(prod[k]);
+        const F9 sres = f9_wave_sum_lazy(prod[k]);
         if (lane == 0) red9[wave][k] = sres;
     }
     __syncthreads();
     if (threadIdx.x < KN) {
         F9 sres = red9[0][threadIdx.x];
-        for (int w = 1; w < RA_THREADS / 64; w++) sres = f9_norm_red<P9>(f9_add(sres, red9[w][threadIdx.x]));
-        fe_store(partials + (size_t)blockIdx.x * D + K0 + threadIdx.x, f9_canon<P9>(sres));
+#pragma unroll
+        for (int w = 1; w < RA_THREADS / 64; w++) sres = f9_add(sres, red9[w][threadIdx.x]);        // four normalized values: limbs < 2^31
+        fe_store(partials + (size_t)blockIdx.x * D + K0 + threadIdx.x, f9_canon<P9>(f9_reduce_lazy<P9>(f9_norm(sres))));
     }
     mail_tail(partials, tail);
 }
@@ -100,13 +102,14 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_prod_f9_col(const Fr* __restr
         }
     }
     __shared__ F9 red9[RA_THREADS / 64];
-    const F9 sres = f9_wave_sum<P9>(prod);
+    const F9 sres = f9_wave_sum_lazy(prod);
     if ((threadIdx.x & 63) == 0) red9[threadIdx.x >> 6] = sres;
     __syncthreads();
     if (threadIdx.x == 0) {
         F9 t = red9[0];
-        for (int w = 1; w < RA_THREADS / 64; w++) t = f9_norm_red<P9>(f9_add(t, red9[w]));
-        fe_store(partials + (size_t)blockIdx.x * D + k, f9_canon<P9>(t));
+#pragma unroll
+        for (int w = 1; w < RA_THREADS / 64; w++) t = f9_add(t, red9[w]);
+        fe_store(partials + (size_t)blockIdx.x * D + k, f9_canon<P9>(f9_reduce_lazy<P9>(f9_norm(t))));
     }
     mail_tail(partials, tail);
 }
@@ -287,10 +290,15 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_bind_prod_f9(const Fr* __rest
     }
     sh_red[p][k] = prod;
     __syncthreads();
-    if (threadIdx.x < D) {
-        F9 t = sh_red[0][threadIdx.x];
-        for (int q = 1; q < RA_FUSE_PAIRS; q++) t = f9_norm_red<P9>(f9_add(t, sh_red[q][threadIdx.x]));
-        fe_store(partials + (size_t)blockIdx.x * D + threadIdx.x, f9_canon<P9>(t));
+    if (threadIdx.x < D) {                                    // the sixteen pairs' products of column k: 64-bit limb sums, one reduction
+        int64_t t[9];
+#pragma unroll
+        for (int l = 0; l < 9; l++) t[l] = 0;
+        for (int q = 0; q < RA_FUSE_PAIRS; q++) {
+#pragma unroll
+            for (int l = 0; l < 9; l++) t[l] += (int64_t)sh_red[q][threadIdx.x].l[l];
+        }
+        fe_store(partials + (size_t)blockIdx.x * D + threadIdx.x, f9_canon<P9>(f9_reduce_i64<P9>(t)));
     }
     mail_tail(partials, tail);
 }
@@ -332,14 +340,15 @@ __global__ __launch_bounds__(RA_THREADS) void k_bool_fold(const Fr* __restrict__
         acc1 = f9_norm_red<P9>(f9_add(acc1, f9_mul<P9>(wgt, e)));
     }
     __shared__ F9 red9[RA_THREADS / 64][2];
-    acc0 = f9_wave_sum<P9>(acc0); acc1 = f9_wave_sum<P9>(acc1);
+    acc0 = f9_wave_sum_lazy(acc0); acc1 = f9_wave_sum_lazy(acc1);      // plain integer sums; one reduction per term below
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { red9[wave][0] = acc0; red9[wave][1] = acc1; }
     __syncthreads();
     if (threadIdx.x < 2) {
         F9 s = red9[0][threadIdx.x];
-        for (int w = 1; w < RA_THREADS / 64; w++) s = f9_norm_red<P9>(f9_add(s, red9[w][threadIdx.x]));
-        fe_store(partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + threadIdx.x, f9_canon<P9>(s));
+#pragma unroll
+        for (int w = 1; w < RA_THREADS / 64; w++) s = f9_add(s, red9[w][threadIdx.x]);
+        fe_store(partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + threadIdx.x, f9_canon<P9>(f9_reduce_lazy<P9>(f9_norm(s))));
     }
     mail_tail(partials, tail);
 }
@@ -373,14 +382,15 @@ __global__ __launch_bounds__(RA_THREADS) void k_bool_bind_fold(const Fr* __restr
         acc1 = f9_norm_red<P9>(f9_mul<P9>(wgt, e));
     }
     __shared__ F9 red9[RA_THREADS / 64][2];
-    acc0 = f9_wave_sum<P9>(acc0); acc1 = f9_wave_sum<P9>(acc1);
+    acc0 = f9_wave_sum_lazy(acc0); acc1 = f9_wave_sum_lazy(acc1);      // plain integer sums; one reduction per term below
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { red9[wave][0] = acc0; red9[wave][1] = acc1; }
     __syncthreads();
     if (threadIdx.x < 2) {
         F9 s = red9[0][threadIdx.x];
-        for (int w = 1; w < RA_THREADS / 64; w++) s = f9_norm_red<P9>(f9_add(s, red9[w][threadIdx.x]));
-        fe_store(partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + threadIdx.x, f9_canon<P9>(s));
+#pragma unroll
+        for (int w = 1; w < RA_THREADS / 64; w++) s = f9_add(s, red9[w][threadIdx.x]);
+        fe_store(partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + threadIdx.x, f9_canon<P9>(f9_reduce_lazy<P9>(f9_norm(s))));
     }
     mail_tail(partials, tail);
 }
