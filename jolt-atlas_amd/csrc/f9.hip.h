@@ -324,7 +324,8 @@ __device__ __forceinline__ F9 f9_wave_sum(F9 a) {
 // top limb < 2^31) — for sums that are mailed as lazy limbs and reduced once on the host (channel.hpp: sum_to_fr), or reduced once by
 // f9_reduce_i64.  The steps inside a 16-lane row are DPP moves (no LDS crossbar): 72 of the 108 ds_bpermute of f9_wave_sum go, and all
 // twelve reductions with their per-limb multiplies (the wavefront sum of two accumulators was 1 150 of the ~1 400 instructions behind the
-// loop of a data pass: 2 us on the critical path of every pass).
+// loop of a data pass: 2 us on the critical path of every pass).  EVERY lane of the wavefront must be active (DPP reads disabled lanes as
+// whatever they hold): call it outside divergent code, with zero in the lanes that have nothing to add.
 template <int CTRL>
 __device__ __forceinline__ F9 f9_add_dpp(const F9& a) {
     F9 o;

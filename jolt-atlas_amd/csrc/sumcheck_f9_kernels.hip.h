@@ -20,15 +20,16 @@ namespace atlas {
 __device__ __forceinline__ void f9_block_reduce_store2(F9 acc0, F9 acc2, Fr* partials) {
     using P9 = Fr9Params;
     __shared__ F9 red9[SC_THREADS / 64][2];
-    acc0 = f9_wave_sum<P9>(acc0);
-    acc2 = f9_wave_sum<P9>(acc2);
+    acc0 = f9_wave_sum_lazy(acc0);                            // plain integer sums (f9.hip.h), one reduction per sum below
+    acc2 = f9_wave_sum_lazy(acc2);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { red9[wave][0] = acc0; red9[wave][1] = acc2; }
     __syncthreads();
     if (threadIdx.x < 2) {
         F9 s = red9[0][threadIdx.x];
-        for (int w = 1; w < SC_THREADS / 64; w++) s = f9_norm_red<P9>(f9_add(s, red9[w][threadIdx.x]));
-        fe_store(partials + (size_t)blockIdx.x * 2 + threadIdx.x, f9_canon_x32<P9>(s));
+#pragma unroll
+        for (int w = 1; w < SC_THREADS / 64; w++) s = f9_add(s, red9[w][threadIdx.x]);
+        fe_store(partials + (size_t)blockIdx.x * 2 + threadIdx.x, f9_canon_x32<P9>(f9_reduce_lazy<P9>(f9_norm(s))));
     }
 }
 
