@@ -805,7 +805,10 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
         while (len > ((size_t)1 << tail_log)) {
             const size_t j = rounds_done - 1;          // challenge index being bound
             const size_t q = len / 4;
-            const int grid = use_f9 ? grid_f9(q) : grid_for(q);
+            // at most 2^15 quads: two lanes per quad (k_dot_bind_eval2_f9_pair); ATLAS_F9_NO_PAIR=1 is the A/B
+            static const bool no_pair = getenv("ATLAS_F9_NO_PAIR") != nullptr;
+            const bool pair_pass = use_f9 && !no_pair && 2 * q <= (size_t)256 * SC_THREADS && !(P->schedule == ATLAS_EQ_LOW && j >= P->a) && !P->left->is_i32;
+            const int grid = pair_pass ? (int)((2 * q + SC_THREADS - 1) / SC_THREADS) : use_f9 ? grid_f9(q) : grid_for(q);
             bool fuse_eq = false;
             if (P->schedule == ATLAS_EQ_HIGH && j < P->a) {
                 tm.begin(0, (eq_len + eq_len / 2) * sizeof(Fr));
@@ -843,6 +846,8 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
                 k_dot_bind_eval<DEG, Fr, true, ChanIo><<<grid, SC_THREADS, 0, g.stream>>>(
                     (const Fr*)P->left->d, (const Fr*)P->right->d, (Fr*)P->left->d, (Fr*)P->right->d, eqp, eq, q, ChanIo{io, mode}, K, hi_only);
                 eq_len /= 2;
+            } else if (pair_pass) {
+                k_dot_bind_eval2_f9_pair<ChanIoF9><<<grid, SC_THREADS, 0, g.stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, ChanIoF9{io});
             } else if (use_f9) {
                 if (false)                                     // (the lazy-limb tail takes residues < 2.1p as they are)
                     k_dot_bind_eval2_f9<true, ChanIoF9><<<grid, SC_THREADS, 0, g.stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, ChanIoF9{io});

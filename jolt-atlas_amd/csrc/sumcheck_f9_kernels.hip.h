@@ -135,6 +135,59 @@ __global__ __launch_bounds__(SC_THREADS) void k_dot_bind_eval2_f9(Fr* L, Fr* R, 
     io.emit2(f9_norm_red<P9, 1>(acc0), f9_norm_red<P9, 1>(acc2));
 }
 
+// The same pass for AT MOST 2^15 quads (the rounds of 2^17 .. 2^13 coefficients, where a launch is one quad per thread and the round is the
+// latency of that thread's chain: 4 sparse + 2 full multiplications, ~3.5 us): TWO lanes per quad, as the tail kernel below does in LDS — lane
+// 2i binds the two L pairs of quad i, lane 2i+1 the two R pairs (two sparse multiplications each), they swap the bound values by DPP, lane 2i
+// multiplies l0 * r0 and lane 2i+1 l2 * r2: a chain of 2 sparse + 1 full multiplication.  Same sums (exact arithmetic in another order), same
+// mail format: value 0 = the l0 r0 sum, value 1 = the l2 r2 sum of the workgroup, lazy limbs.
+__device__ __forceinline__ F9 f9_dpp_swap1(const F9& a);
+template <class IO>
+__global__ __launch_bounds__(SC_THREADS) void k_dot_bind_eval2_f9_pair(Fr* L, Fr* R, size_t q, IO io) {
+    using P9 = Fr9Params;
+    const size_t i = ((size_t)blockIdx.x * SC_THREADS + threadIdx.x) >> 1;
+    const uint32_t h = threadIdx.x & 1u;
+    Fr* const S = h ? R : L;
+    const bool live = i < q;
+    Fe s0 = fe_zero(), s1 = fe_zero(), s2 = fe_zero(), s3 = fe_zero();
+    if (live) { s0 = fe_load(S + i); s1 = fe_load(S + i + q); s2 = fe_load(S + i + 2 * q); s3 = fe_load(S + i + 3 * q); }     // in flight while the challenge is waited for
+    Fr r_fe;
+    if (!io.challenge(r_fe)) return;
+    const F9 r32 = f9_shl5(f9_from_fe(r_fe));
+    // every lane runs the arithmetic (the DPP moves need the whole wavefront; a lane beyond the end holds zeros and contributes multiples of p)
+    const F9 a0 = f9_from_fe(s0), a1 = f9_from_fe(s1), a2 = f9_from_fe(s2), a3 = f9_from_fe(s3);
+    const F9 v0 = f9_mul_addred<P9, 4>(f9_sub<P9>(a2, a0), r32, a0);
+    const F9 v1 = f9_mul_addred<P9, 4>(f9_sub<P9>(a3, a1), r32, a1);
+    if (live) { fe_store(S + i, f9_to_fe(v0)); fe_store(S + i + q, f9_to_fe(v1)); }
+    const F9 w0 = f9_dpp_swap1(v0), w1 = f9_dpp_swap1(v1);        // the partner's side of the quad
+    const F9 l2 = f9_norm(f9_add(w1, f9_sub<P9>(w1, w0))), r2 = f9_add(v1, f9_sub<P9>(v1, v0));      // (used by the odd lane: w = L side, v = R side)
+    F9 x, y;
+#pragma unroll
+    for (int k = 0; k < 9; k++) { x.l[k] = h ? l2.l[k] : v0.l[k]; y.l[k] = h ? r2.l[k] : w0.l[k]; }
+    F9 acc = f9_mul<P9>(x, y);
+    // lanes of equal parity hold the same kind of product: plain integer sums (f9.hip.h), mailed as lazy limbs
+    acc = f9_add_dpp<0x4e>(acc);
+    acc = f9_add_dpp<0x124>(acc);
+    acc = f9_add_dpp<0x128>(acc);
+    acc = f9_norm(acc);
+    acc = f9_add(acc, f9_shfl_xor(acc, 16));
+    acc = f9_norm(f9_add(acc, f9_shfl_xor(acc, 32)));
+    __shared__ F9 red9p[SC_THREADS / 64][2];
+    __shared__ uint32_t stage9p[18];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 2) red9p[wave][lane] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        F9 t = f9_zero();
+        if (threadIdx.x < 2) {
+            t = red9p[0][threadIdx.x];
+#pragma unroll
+            for (int w = 1; w < SC_THREADS / 64; w++) t = f9_add(t, red9p[w][threadIdx.x]);
+            t = f9_norm(t);
+        }
+        ch_mail_wave_f9(io.io, blockIdx.x * ch_stride(2), 2, t, stage9p);
+    }
+}
+
 // ---- degree-2 tail over the round channel on the lazy limbs ---------------------------------------
 // Same contract as k_dot_tail_ch<2> (EqSchedule::None, challenge mode 0): every remaining round of an
 // instance of <= 2^11 coefficients in one resident launch, transcript on the host.  Laid out for the
