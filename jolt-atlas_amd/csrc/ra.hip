@@ -248,49 +248,62 @@ __global__ __launch_bounds__(RA_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 }
 
 // Bind and product of a round in ONE launch, for rounds of at most RA_FUSE_MAX pairs (the cycle rounds of every lookup of T <= 2^13,
-// and the later rounds of the larger ones): a workgroup takes 16 pairs, thread (pair, k) binds row k of its pair — four coefficients of
-// the previous round's rows -> the two of this round's, stored for the next round — and leaves (x0, x1 - x0) as lazy limbs in LDS; after
-// the barrier it is column k of the pair and runs the same chain as k_ra_prod_f9_col over the 16 rows in LDS.  Against k_ra_bind_ch +
+// and the later rounds of the larger ones): a workgroup takes 8 pairs, the two lanes of (pair, k) bind row k of their pair — four coefficients
+// of the previous round's rows -> the two of this round's, stored for the next round — and leave (x0, x1 - x0) as lazy limbs in LDS; after
+// the barrier they are column k of the pair and run the chain of k_ra_prod_f9_col over the rows in LDS, half of the rows each (see below).  Against k_ra_bind_ch +
 // k_ra_prod_f9_col the round loses a kernel boundary, the trip of the bound rows through HBM and the four batches of row loads: RaVirtual is
 // the long lane of a one-hot batch, so this is the batch's round time.  Same sums: the chain is weight x the d values, d + 1
 // multiplications of 2^-5 each as before; the partial rows are canonical.
 constexpr size_t RA_FUSE_MAX = 4096;
-constexpr int RA_FUSE_PAIRS = 16;
+constexpr int RA_FUSE_PAIRS = 8;
+// Layout: thread (pair p, column k, half h) = 32 lanes per pair, 8 pairs per workgroup.  The round is the latency of one thread's chain, so the
+// chain is cut in two: in the bind, half 0 binds the first and half 1 the second coefficient pair of row k (one multiplication each instead of
+// two; the difference x1 - x0 is formed after a DPP swap); in the product, half 1 multiplies the weight and rows D/2 .. D-1 of column k, half 0
+// rows 0 .. D/2-1, and half 0 multiplies the two (after a DPP swap): 1 + D/2 + 1 multiplications deep instead of 1 + D.  The number of f9_mul
+// behind a column is unchanged (half 0 starts from its first value: D/2 - 1; half 1: 1 + (D - D/2); the join: 1), so is the host's 32^(D+1).
 __global__ __launch_bounds__(RA_THREADS) void k_ra_bind_prod_f9(const Fr* __restrict__ src, size_t src_stride, Fr* __restrict__ dst, size_t dst_stride,
                                                                 uint32_t D, SplitEqView E, size_t n_groups, Fr* __restrict__ partials /* [gridDim.x][D] */,
                                                                 ChanIo io, int r_hi_only, MailTail tail) {
     using P9 = Fr9Params;
     __shared__ F9 sh_x0[RA_FUSE_PAIRS][16], sh_dl[RA_FUSE_PAIRS][16], sh_red[RA_FUSE_PAIRS][16];
-    Fr r;
-    if (!io.challenge(r)) return;
-    const uint32_t p = threadIdx.x >> 4, k = threadIdx.x & 15u;
+    const uint32_t p = threadIdx.x >> 5, k = (threadIdx.x >> 1) & 15u, h = threadIdx.x & 1u;
     const size_t gidx = (size_t)blockIdx.x * RA_FUSE_PAIRS + p;
     const bool live = gidx < n_groups && k < D;
+    const size_t emask = ((size_t)1 << E.in_bits) - 1;
+    // requested before the challenge is waited for: the two coefficients this lane binds, and (half 1) the weight's factors
+    Fr a0 = fe_zero(), a1 = fe_zero(), w_out = fe_zero(), w_in = fe_zero();
     if (live) {
-        const Fr* s4 = src + (size_t)k * src_stride + 4 * gidx;
-        const Fr a0 = fe_load(s4), a1 = fe_load(s4 + 1), a2 = fe_load(s4 + 2), a3 = fe_load(s4 + 3);
-        const Fr b0 = bind_pair(a0, a1, r, r_hi_only != 0), b1 = bind_pair(a2, a3, r, r_hi_only != 0);
-        Fr* d2 = dst + (size_t)k * dst_stride + 2 * gidx;
-        fe_store(d2, b0); fe_store(d2 + 1, b1);
-        const F9 x0 = f9_from_fe(b0), x1 = f9_from_fe(b1);
-        sh_x0[p][k] = x0;
-        sh_dl[p][k] = f9_norm_red<P9, 2>(f9_sub<P9>(x1, x0));
+        const Fr* s2 = src + (size_t)k * src_stride + 4 * gidx + 2 * h;
+        a0 = fe_load(s2); a1 = fe_load(s2 + 1);
+        if (h) { w_out = fe_load(E.e_out + (gidx >> E.in_bits)); w_in = fe_load(E.e_in + (gidx & emask)); }
+    }
+    Fr r;
+    if (!io.challenge(r)) return;
+    // every lane runs the arithmetic (the DPP swaps need whole wavefronts); a lane beyond the end holds zeros and stores nothing
+    const Fr b = bind_pair(a0, a1, r, r_hi_only != 0);
+    if (live) fe_store(dst + (size_t)k * dst_stride + 2 * gidx + h, b);
+    const F9 x = f9_from_fe(b), xo = f9_dpp<0xb1>(x);             // this lane's bound coefficient and its neighbour's
+    if (live) {
+        if (h == 0) sh_x0[p][k] = x;
+        else sh_dl[p][k] = f9_norm_red<P9, 2>(f9_sub<P9>(x, xo)); // x1 - x0
     }
     __syncthreads();
+    const uint32_t hd = D / 2, i0 = h ? hd : 0, i1 = h ? D : hd;  // D = 1: half 0 has no row, its product is the neutral start below
     F9 prod = f9_zero();
     if (live) {
-        const size_t mask = ((size_t)1 << E.in_bits) - 1;
-        prod = f9_mul<P9>(f9_load(E.e_out + (gidx >> E.in_bits)), f9_load(E.e_in + (gidx & mask)));
+        if (h) prod = f9_mul<P9>(f9_from_fe(w_out), f9_from_fe(w_in));
 #pragma unroll 1
-        for (uint32_t i = 0; i < D; i++) {
+        for (uint32_t i = i0; i < i1; i++) {
             const F9 x0 = sh_x0[p][i], dl = sh_dl[p][i];
             const F9 val = k == D - 1 ? dl : f9_axpy_small(x0, dl, k + 1);          // column D-1: X -> inf; else p_i(k + 1), lazy
-            prod = f9_mul<P9>(prod, val);
+            prod = (h == 0 && i == 0) ? f9_norm(val) : f9_mul<P9>(prod, val);      // half 0 starts from its first value
         }
     }
-    sh_red[p][k] = prod;
+    const F9 other = f9_dpp<0xb1>(prod);
+    if (live && h == 0) prod = hd ? f9_mul<P9>(prod, other) : other;               // the join (D = 1: half 1 holds the whole product)
+    if (h == 0) sh_red[p][k] = live ? prod : f9_zero();
     __syncthreads();
-    if (threadIdx.x < D) {                                    // the sixteen pairs' products of column k: 64-bit limb sums, one reduction
+    if (threadIdx.x < D) {                                    // the pairs' products of column k: 64-bit limb sums, one reduction
         int64_t t[9];
 #pragma unroll
         for (int l = 0; l < 9; l++) t[l] = 0;

@@ -230,7 +230,7 @@ struct RaRows {
         HIP_TRY(hipMalloc(&buf[1], d * (T > 1 ? T / 2 : 1) * sizeof(Fr)));
         stride[0] = T; stride[1] = T > 1 ? T / 2 : 1;
         const size_t blocks = (T / 2 + RA_THREADS / 2 - 1) / (RA_THREADS / 2) + 1;       // a row per RA_THREADS / 2 pairs: the split product of d = 16 (ra.hip)
-        HIP_TRY(hipMalloc(&partials, (blocks * K > 4096 ? blocks * K : 4096) * sizeof(Fr)));   // room for the row-split launches of short instances
+        HIP_TRY(hipMalloc(&partials, (blocks * K > 8192 ? blocks * K : 8192) * sizeof(Fr)));   // room for the row-split launches of short instances (k_ra_bind_prod_f9: 512 rows of 16)
         HIP_TRY(hipMalloc(&d_counter, MAIL_TAIL_COUNTER_BYTES));
         HIP_TRY(hipMemsetAsync(d_counter, 0, MAIL_TAIL_COUNTER_BYTES, g.stream));
         return ATLAS_OK;
