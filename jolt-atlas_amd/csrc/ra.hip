@@ -373,31 +373,44 @@ __global__ __launch_bounds__(RA_THREADS) void k_bool_fold(const Fr* __restrict__
 __global__ __launch_bounds__(RA_THREADS) void k_bool_bind_fold(const Fr* __restrict__ src, size_t src_stride, Fr* __restrict__ dst, size_t dst_stride,
                                                                const Fr* __restrict__ gammas, SplitEqView E, size_t n_groups, Fr* __restrict__ partials,
                                                                ChanIo io, int r_hi_only, MailTail tail) {
+    // TWO lanes per (row, pair) — the round is the latency of one thread's chain: lane h binds coefficient pair h of the four (one multiplication
+    // instead of two), the two swap their bound values by DPP, lane 0 carries the term gamma h0 (h0 - 1) and lane 1 the term gamma (h1 - h0)^2,
+    // each with the weight E_out E_in: bind + 4 multiplications deep instead of 2 + 7.  The same four f9_mul stand behind each term.
     using P9 = Fr9Params;
+    const size_t j = ((size_t)blockIdx.x * RA_THREADS + threadIdx.x) >> 1;
+    const uint32_t i = blockIdx.y, h = threadIdx.x & 1u;
+    const bool live = j < n_groups;
+    Fr a0 = fe_zero(), a1 = fe_zero(), w_out = fe_zero(), w_in = fe_zero(), gmf = fe_zero();
+    if (live) {                                                    // requested before the challenge is waited for
+        const Fr* s2 = src + (size_t)i * src_stride + 4 * j + 2 * h;
+        a0 = fe_load(s2); a1 = fe_load(s2 + 1);
+        w_out = fe_load(E.e_out + (j >> E.in_bits)); w_in = fe_load(E.e_in + (j & (((size_t)1 << E.in_bits) - 1)));
+        gmf = fe_load(gammas + i);
+    }
     Fr r;
     if (!io.challenge(r)) return;
-    F9 acc0 = f9_zero(), acc1 = f9_zero();
-    const size_t j = (size_t)blockIdx.x * RA_THREADS + threadIdx.x;
-    const uint32_t i = blockIdx.y;
-    if (j < n_groups) {
-        const Fr* s4 = src + (size_t)i * src_stride + 4 * j;
-        const Fr a0 = fe_load(s4), a1 = fe_load(s4 + 1), a2 = fe_load(s4 + 2), a3 = fe_load(s4 + 3);
-        const Fr b0 = bind_pair(a0, a1, r, r_hi_only != 0), b1 = bind_pair(a2, a3, r, r_hi_only != 0);
-        Fr* d2 = dst + (size_t)i * dst_stride + 2 * j;
-        fe_store(d2, b0); fe_store(d2 + 1, b1);
-        const F9 one = f9_from_fe(fr_one());
-        const F9 h0 = f9_from_fe(b0), h1 = f9_from_fe(b1), gm = f9_load(gammas + i);
-        const F9 b = f9_sub<P9>(h1, h0), m1 = f9_sub<P9>(h0, one);
-        const F9 c = f9_norm_red<P9, 4>(f9_mul<P9>(f9_mul<P9>(gm, h0), m1));
-        const F9 e = f9_norm_red<P9, 4>(f9_mul<P9>(f9_mul<P9>(gm, b), b));
-        const F9 wgt = f9_mul<P9>(f9_load(E.e_out + (j >> E.in_bits)), f9_load(E.e_in + (j & (((size_t)1 << E.in_bits) - 1))));
-        acc0 = f9_norm_red<P9>(f9_mul<P9>(wgt, c));
-        acc1 = f9_norm_red<P9>(f9_mul<P9>(wgt, e));
-    }
+    const Fr bnd = bind_pair(a0, a1, r, r_hi_only != 0);
+    if (live) fe_store(dst + (size_t)i * dst_stride + 2 * j + h, bnd);
+    const F9 x = f9_from_fe(bnd), xo = f9_dpp<0xb1>(x);            // every lane: the swap needs whole wavefronts (a lane beyond the end holds zeros)
+    const F9 h0 = h ? xo : x, h1 = h ? x : xo;
+    const F9 one = f9_from_fe(fr_one()), gm = f9_from_fe(gmf);
+    const F9 bd = f9_sub<P9>(h1, h0), m1 = f9_sub<P9>(h0, one);    // lazy: + 4p, limbs < 2^31
+    F9 u, v;
+#pragma unroll
+    for (int l = 0; l < 9; l++) { u.l[l] = h ? bd.l[l] : h0.l[l]; v.l[l] = h ? bd.l[l] : m1.l[l]; }
+    const F9 term = f9_norm_red<P9, 4>(f9_mul<P9>(f9_mul<P9>(gm, u), v));          // lane 0: gamma h0 (h0 - 1); lane 1: gamma (h1 - h0)^2
+    const F9 wgt = f9_mul<P9>(f9_from_fe(w_out), f9_from_fe(w_in));
+    F9 acc = f9_mul<P9>(wgt, term);                               // normalized, < 1.1 p; zero weight beyond the end
+    // sums by parity over the workgroup as plain integer sums (f9.hip.h), one reduction per term
+    acc = f9_add_dpp<0x4e>(acc);
+    acc = f9_add_dpp<0x124>(acc);
+    acc = f9_add_dpp<0x128>(acc);
+    acc = f9_norm(acc);
+    acc = f9_add(acc, f9_shfl_xor(acc, 16));
+    acc = f9_norm(f9_add(acc, f9_shfl_xor(acc, 32)));
     __shared__ F9 red9[RA_THREADS / 64][2];
-    acc0 = f9_wave_sum_lazy(acc0); acc1 = f9_wave_sum_lazy(acc1);      // plain integer sums; one reduction per term below
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { red9[wave][0] = acc0; red9[wave][1] = acc1; }
+    if (lane < 2) red9[wave][lane] = acc;
     __syncthreads();
     if (threadIdx.x < 2) {
         F9 s = red9[0][threadIdx.x];
@@ -516,7 +529,7 @@ struct RaVirtual : atlas_instance {
     bool pipelined() const override { return log_T >= 1; }
     static bool fuse_off() { static const bool v = getenv("ATLAS_RA_NO_FUSE") != nullptr; return v; }   // diagnosis / A-B: bind and product as two launches
     bool fused(size_t round) const { return round >= 1 && round < log_T && (((size_t)1 << log_T) >> round) / 2 <= RA_FUSE_MAX && !fuse_off(); }
-    bool wide_wait(size_t round) const override {                 // the bind of `round`: ceil(len / RA_THREADS) x d workgroups (fused: a workgroup per 16 pairs); the finals: one
+    bool wide_wait(size_t round) const override {                 // the bind of `round`: ceil(len / RA_THREADS) x d workgroups (fused: a workgroup per 8 pairs); the finals: one
         if (round >= log_T) return false;
         const size_t len = ((size_t)1 << log_T) >> round;
         if (fused(round)) return (len / 2 + RA_FUSE_PAIRS - 1) / RA_FUSE_PAIRS > WIDE_WAIT_WGS;
@@ -744,8 +757,7 @@ struct Booleanity : atlas_instance {
     bool wide_wait(size_t round) const override {                 // address rounds: one workgroup steps F; cycle round p >= 1: the bind
         if (round <= log_k || round >= rounds()) return false;
         const size_t len = ((size_t)1 << log_T) >> (round - log_k);
-        if (fused(round - log_k)) return ((len / 2 + RA_THREADS - 1) / RA_THREADS) * d > WIDE_WAIT_WGS;
-        return ((len + RA_THREADS - 1) / RA_THREADS) * d > WIDE_WAIT_WGS;
+        return ((len + RA_THREADS - 1) / RA_THREADS) * d > WIDE_WAIT_WGS;          // (the fused launch has two lanes per pair: the same count)
     }
     int enqueue(size_t round, const atlas::RoundIo& io, bool bind_prev, atlas_mail_ref& mail) override {
         if (round >= rounds() || (round > 0) != bind_prev) return fail(ATLAS_ESTATE, "booleanity: enqueue out of order");
@@ -770,7 +782,7 @@ struct Booleanity : atlas_instance {
         size_t ot, it;
         D.st.tops_after(p, ot, it);
         if (fused(p)) {
-            const unsigned fb = (unsigned)((n_groups + RA_THREADS - 1) / RA_THREADS);
+            const unsigned fb = (unsigned)((2 * n_groups + RA_THREADS - 1) / RA_THREADS);       // two lanes per pair
             k_bool_bind_fold<<<dim3(fb, (unsigned)d), RA_THREADS, 0, g.stream>>>(rows.buf[(p - 1) & 1], T >> (p - 1), rows.buf[p & 1], len, d_gammas, D.view_at(ot, it), n_groups,
                                                                                 rows.partials, cio, g.challenge_mode == 0 ? 1 : 0,
                                                                                 MailTail{io, rows.d_counter, (uint32_t)(fb * d), 2u});
