@@ -1,3 +1,6 @@
+# Same-box A/B of two builds of the library over whole proofs (through gpurun from the repo root).  Beside jolt-atlas_amd/libatlas_hip.so (the new
+# build) it expects jolt-atlas_amd/libatlas_hip_prev.so: check out the sources of the commit to compare against, `make -C jolt-atlas_amd`, copy the
+# result to that name, restore the sources, `make` again.  (*.so is git-ignored but travels to the GPU box.)
 cd jolt-atlas_amd; cp libatlas_hip.so libatlas_hip_new.so; cd ..
 for rep in 1 2 3 4; do
   for which in prev new; do
