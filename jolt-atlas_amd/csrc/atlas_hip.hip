@@ -274,6 +274,7 @@ int atlas_poly_upload_i32(const int32_t* host, size_t len, atlas_poly_t* out) {
 }
 
 int atlas_poly_wrap_device_fr(void* dptr, size_t len, atlas_poly_t* out) {
+    PROF("atlas_poly_wrap_device_fr");
     NEED_INIT();
     if (!dptr || !out || !is_pow2(len)) return fail(ATLAS_EINVAL, "poly_wrap_device_fr");
     atlas_poly* p = new atlas_poly();
@@ -283,6 +284,7 @@ int atlas_poly_wrap_device_fr(void* dptr, size_t len, atlas_poly_t* out) {
 }
 
 int atlas_poly_wrap_device_i32(void* dptr, size_t len, atlas_poly_t* out) {
+    PROF("atlas_poly_wrap_device_i32");
     NEED_INIT();
     if (!dptr || !out || !is_pow2(len)) return fail(ATLAS_EINVAL, "poly_wrap_device_i32");
     atlas_poly* p = new atlas_poly();
@@ -323,6 +325,7 @@ int atlas_poly_download(atlas_poly_t p, atlas_fr_t* host, size_t cap) {
 }
 
 int atlas_poly_clone(atlas_poly_t p, atlas_poly_t* out) {
+    PROF("atlas_poly_clone");
     NEED_INIT();
     if (!p || !out) return fail(ATLAS_EINVAL, "poly_clone");
     size_t bytes = p->len * (p->is_i32 ? sizeof(int32_t) : sizeof(Fr));
@@ -334,6 +337,7 @@ int atlas_poly_clone(atlas_poly_t p, atlas_poly_t* out) {
 }
 
 int atlas_poly_free(atlas_poly_t p) {
+    PROF("atlas_poly_free");
     if (!p) return ATLAS_OK;
     if (p->owned && p->d) hipFree(p->d);
     delete p;
@@ -433,6 +437,7 @@ static EqView eq_view_for_round(const atlas_dot_prover* P, size_t round, const F
 
 int atlas_dot_prover_new(atlas_poly_t left, atlas_poly_t right, atlas_poly_t eq, int schedule, size_t a, size_t b,
                          atlas_dot_prover_t* out) {
+    PROF("atlas_dot_prover_new");
     NEED_INIT();
     if (!left || !right || !out) return fail(ATLAS_EINVAL, "dot_prover_new: null operand");
     if (left->len != right->len || !is_pow2(left->len)) return fail(ATLAS_EINVAL, "dot_prover_new: operand lengths");
@@ -790,7 +795,9 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
     if (n > tail_log) {
         {
             const size_t half = len / 2;
-            const int grid = use_f9 ? grid_f9(half) : grid_for(half);
+            static const size_t f9_r0_cap = [] { const char* e = getenv("ATLAS_F9_R0_BLOCKS"); int v = e ? atoi(e) : 0; return (size_t)(v >= 1 && v <= 2048 ? v : 0); }();   // experiments: round 0 alone
+            int grid = use_f9 ? grid_f9(half) : grid_for(half);
+            if (use_f9 && f9_r0_cap) { const size_t b = (half + SC_THREADS - 1) / SC_THREADS; grid = (int)(b > f9_r0_cap ? f9_r0_cap : b); }
             atlas::Chunk* reg = C.alloc((size_t)grid * ch_stride(DEG));
             const RoundIo io = C.io(reg, mtag(0), (size_t)-1, 0);
             EqView eq = eq_view_for_round(P, 0, eqp, eq_len);
@@ -981,6 +988,7 @@ extern "C" {
 
 int atlas_sumcheck_prove_dot(atlas_dot_prover_t P, const atlas_fr_t* input_claim, atlas_transcript_t* transcript,
                              atlas_fr_t* compressed_polys, atlas_u128_t* challenges, atlas_fr_t final_claims[3]) {
+    PROF("atlas_sumcheck_prove_dot");
     NEED_INIT();
     if (!P || !input_claim || !transcript || !compressed_polys || !challenges || !final_claims)
         return fail(ATLAS_EINVAL, "sumcheck_prove_dot: null argument");

@@ -249,12 +249,14 @@ static int add_instance(atlas_batched_t b, atlas_instance* inst, bool owned, con
 extern "C" {
 
 int atlas_batched_new(atlas_batched_t* out) {
+    PROF("atlas_batched_new");
     if (!out) return fail(ATLAS_EINVAL, "batched_new");
     *out = new atlas_batched();
     return ATLAS_OK;
 }
 
 int atlas_batched_free(atlas_batched_t b) {
+    PROF("atlas_batched_free");
     delete b;          // instances stay owned by the caller
     return ATLAS_OK;
 }
@@ -270,6 +272,7 @@ int atlas_batched_add_mul(atlas_batched_t b, atlas_mul_prover_t p, const atlas_f
 }
 
 int atlas_batched_add_instance(atlas_batched_t b, atlas_instance_t inst, const atlas_fr_t* input_claim) {
+    PROF("atlas_batched_add_instance");
     if (!b || !inst || !input_claim) return fail(ATLAS_EINVAL, "batched_add_instance");
     return add_instance(b, inst, false, input_claim);
 }
@@ -298,6 +301,7 @@ int atlas_instance_ingest_challenge(atlas_instance_t i, const atlas_u128_t* r_j,
 }
 
 int atlas_instance_final_claims(atlas_instance_t i, atlas_fr_t* out, size_t cap, size_t* n) {
+    PROF("atlas_instance_final_claims");
     NEED_INIT();
     if (!i || !out || !n) return fail(ATLAS_EINVAL, "instance_final_claims");
     std::vector<H::Fr> f;
@@ -309,11 +313,13 @@ int atlas_instance_final_claims(atlas_instance_t i, atlas_fr_t* out, size_t cap,
     return ATLAS_OK;
 }
 
-int atlas_instance_free(atlas_instance_t i) { delete i; return ATLAS_OK; }
+int atlas_instance_free(atlas_instance_t i) {
+    PROF("atlas_instance_free"); delete i; return ATLAS_OK; }
 
 // Sumcheck::prove (sumcheck.rs:565-599) over one generic instance, host-stepped
 int atlas_instance_prove(atlas_instance_t inst, const atlas_fr_t* input_claim, atlas_transcript_t* transcript,
                          atlas_fr_t* compressed, size_t row_stride, uint32_t* n_coeffs, atlas_u128_t* challenges) {
+    PROF("atlas_instance_prove");
     NEED_INIT();
     if (!inst || !input_claim || !transcript || !compressed || !n_coeffs || !challenges) return fail(ATLAS_EINVAL, "instance_prove");
     H::Transcript& T = *reinterpret_cast<H::Transcript*>(transcript);
@@ -325,7 +331,8 @@ int atlas_instance_prove(atlas_instance_t inst, const atlas_fr_t* input_claim, a
         std::lock_guard<atlas_rt::Mutex> lk(g.mu);
         Pipeline P;
         P.lanes.push_back(Lane{inst, n, 0, {}, {}});
-        int rc = P.begin();
+        int rc;
+        { PROF("instance_prove: Pipeline::begin"); rc = P.begin(); }
         if (rc) return rc;
         static const bool ptrace = getenv("ATLAS_TRACE") != nullptr;   // host time per part of a round, summed (ATLAS_TRACE=1)
         double tp[5] = {0, 0, 0, 0, 0};
@@ -335,15 +342,17 @@ int atlas_instance_prove(atlas_instance_t inst, const atlas_fr_t* input_claim, a
             H::Fr sums[16];
             const auto q0 = nowp();
             inst->prepare(round);
-            if (!P.collect(P.lanes[0].mails[round], P.mtag(round, 0), sums)) { P.abort_from(round); (void)hipStreamSynchronize(g.stream); return fail(ATLAS_ENODEV, "round channel: no answer from the device"); }
+            { PROF("instance_prove: collect (wait for the device)");
+              if (!P.collect(P.lanes[0].mails[round], P.mtag(round, 0), sums)) { P.abort_from(round); (void)hipStreamSynchronize(g.stream); return fail(ATLAS_ENODEV, "round channel: no answer from the device"); } }
             const auto q1 = nowp();
-            rc = inst->finish(round, prev, sums, c);
+            { PROF("instance_prove: finish"); rc = inst->finish(round, prev, sums, c); }
             const auto q2 = nowp();
             if (rc) { P.abort_from(round); (void)hipStreamSynchronize(g.stream); return rc; }
             std::vector<H::Fr> cc;
             if (c.size() < 2) cc = c;
             else { cc.push_back(c[0]); for (size_t k = 2; k < c.size(); k++) cc.push_back(c[k]); }
             if (cc.size() > row_stride) { P.abort_from(round); (void)hipStreamSynchronize(g.stream); return fail(ATLAS_EINVAL, "instance_prove: row_stride below the degree"); }
+            const double pt0 = atlas_rt::Prof::on() ? atlas_rt::Prof::now_us() : 0;
             H::tr_append_message(T, "UniPoly_begin");
             for (auto& x : cc) H::tr_append_scalar(T, x);
             H::tr_append_message(T, "UniPoly_end");
@@ -353,18 +362,20 @@ int atlas_instance_prove(atlas_instance_t inst, const atlas_fr_t* input_claim, a
             H::tr_challenge_u128(T, lo, hi);
             challenges[round].lo = lo; challenges[round].hi = hi;
             P.C.publish(P.slot0 + round, P.rtag(round), lo, hi);
+            if (atlas_rt::Prof::on()) atlas_rt::Prof::get().add("instance_prove: transcript + publish", atlas_rt::Prof::now_us() - pt0);
             if ((round & 7) == 7) (void)hipStreamQuery(g.stream);   // lets the runtime retire completed launches while the device works (2.5 us)
             prev = eval_with_challenge(c, H::challenge_to_fr(lo, hi, g.challenge_mode));
             const auto q3 = nowp();
-            rc = inst->host_ingest(challenges[round], round);
+            { PROF("instance_prove: host_ingest"); rc = inst->host_ingest(challenges[round], round); }
             const auto q4 = nowp();
-            if (!rc) rc = P.advance(round + 1);
+            if (!rc) { PROF("instance_prove: advance (enqueue)"); rc = P.advance(round + 1); }
             if (rc) { P.abort_from(round + 1); (void)hipStreamSynchronize(g.stream); return rc; }
             if (ptrace) { const auto q5 = nowp(); tp[0] += usp(q0, q1); tp[1] += usp(q1, q2); tp[2] += usp(q2, q3); tp[3] += usp(q3, q4); tp[4] += usp(q4, q5); }
         }
         if (ptrace)
             fprintf(stderr, "[atlas trace] instance_prove (round channel) %zu rounds: wait for sums %.1f us, finish %.1f, transcript + publish %.1f, host_ingest %.1f, enqueue %.1f\n",
                     n, tp[0], tp[1], tp[2], tp[3], tp[4]);
+        PROF("instance_prove: collect_finals + join");
         return P.collect_finals();
     }
     const bool trace = getenv("ATLAS_TRACE") != nullptr;          // wall clock of the three parts of a round, summed
@@ -408,6 +419,7 @@ int atlas_instance_prove(atlas_instance_t inst, const atlas_fr_t* input_claim, a
 // read with atlas_dot_final_claims / atlas_mul_final_claims; cache_openings is the caller's).
 int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas_fr_t* compressed, size_t row_stride,
                         uint32_t* n_coeffs, atlas_u128_t* challenges, size_t* max_rounds_out) {
+    PROF("atlas_batched_prove");
     NEED_INIT();
     if (!b || !transcript || !compressed || !n_coeffs || !challenges || !max_rounds_out || b->inst.empty())
         return fail(ATLAS_EINVAL, "batched_prove");
@@ -432,6 +444,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
     if (piped) {
         pipe_lock.lock();
         for (auto& I : b->inst) PL.lanes.push_back(Lane{I.inst, I.rounds, 0, {}, {}});
+        PROF("batched_prove: Pipeline::begin");
         int rc = PL.begin();
         if (rc) return rc;
     }
@@ -551,9 +564,10 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
                 H::Fr sums[16];
                 const auto tc0 = std::chrono::steady_clock::now();
                 I.inst->prepare(local);
-                int rc = PL.collect(PL.lanes[i].mails[local], PL.mtag(round, i), sums) ? ATLAS_OK : fail(ATLAS_ENODEV, "round channel: no answer from the device");
+                int rc;
+                { PROF("batched_prove: collect (wait for the device)"); rc = PL.collect(PL.lanes[i].mails[local], PL.mtag(round, i), sums) ? ATLAS_OK : fail(ATLAS_ENODEV, "round channel: no answer from the device"); }
                 const auto tc1 = std::chrono::steady_clock::now();
-                if (!rc) rc = I.inst->finish(local, claim[i], sums, polys[i]);
+                if (!rc) { PROF("batched_prove: finish"); rc = I.inst->finish(local, claim[i], sums, polys[i]); }
                 if (trace) { t_wait[i] += std::chrono::duration<double, std::milli>(tc1 - tc0).count(); t_msg[i] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc1).count(); }
                 if (rc) { PL.abort_from(round); PL.drain(); return rc; }
             } else {
@@ -564,6 +578,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
             }
         }
         const auto tf0 = std::chrono::steady_clock::now();
+        const double pf0 = atlas_rt::Prof::on() ? atlas_rt::Prof::now_us() : 0;
         // batched = sum coeff_i * poly_i, starting from UniPoly::from_coeff(vec![]) = [0]  (:109-116)
         std::vector<H::Fr> batched = {H::zero()};
         for (size_t i = 0; i < n; i++) {
@@ -578,6 +593,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         if (batched.size() < 2) cc = batched;
         else { cc.push_back(batched[0]); for (size_t k = 2; k < batched.size(); k++) cc.push_back(batched[k]); }
         if (cc.size() > row_stride) { if (piped) { PL.abort_from(round); PL.drain(); } return fail(ATLAS_EINVAL, "batched_prove: row_stride below the batched degree"); }
+        const double pf1 = atlas_rt::Prof::on() ? atlas_rt::Prof::now_us() : 0;
         H::tr_append_message(T, "UniPoly_begin");
         for (auto& x : cc) H::tr_append_scalar(T, x);
         H::tr_append_message(T, "UniPoly_end");
@@ -588,12 +604,20 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         challenges[round].lo = lo; challenges[round].hi = hi;
         if (piped) { PL.C.publish(PL.slot0 + round, PL.rtag(round), lo, hi); if ((round & 7) == 7) PL.query(); }
         const H::Fr r = H::challenge_to_fr(lo, hi, g.challenge_mode);
+        const double pf2 = atlas_rt::Prof::on() ? atlas_rt::Prof::now_us() : 0;
         for (size_t i = 0; i < n; i++) claim[i] = eval_with_challenge(polys[i], r);    // :123-126
+        if (atlas_rt::Prof::on()) {
+            const double pf3 = atlas_rt::Prof::now_us();
+            atlas_rt::Prof::get().add("batched_prove: combine (scale + sum)", pf1 - pf0);
+            atlas_rt::Prof::get().add("batched_prove: transcript + publish", pf2 - pf1);
+            atlas_rt::Prof::get().add("batched_prove: claim update", pf3 - pf2);
+        }
         if (trace) t_fs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf0).count();
         for (size_t i = 0; i < n; i++) {
             Instance& I = b->inst[i];
             if (remaining <= I.rounds) {
                 const auto ti0 = std::chrono::steady_clock::now();
+                PROF("batched_prove: ingest");
                 int rc = piped ? I.inst->host_ingest(challenges[round], round - (max_rounds - I.rounds))
                                : I.inst->ingest(challenges[round], round - (max_rounds - I.rounds));
                 if (rc) { if (piped) { PL.abort_from(round + 1); PL.drain(); } return rc; }
@@ -602,6 +626,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         }
         if (piped) {
             const auto te0 = std::chrono::steady_clock::now();
+            PROF("batched_prove: advance (enqueue)");
             int rc = PL.advance(round + 1);       // (advance drains on its own failures)
             if (rc) return rc;
             if (trace) t_enq += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - te0).count();
@@ -613,7 +638,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
             fprintf(stderr, "[atlas trace] batched_prove instance %zu (%zu rounds, degree %zu): wait for sums %.3f ms, compute_message / finish %.3f ms, ingest_challenge %.3f ms\n",
                     i, b->inst[i].rounds, b->inst[i].inst->degree(), t_wait[i], t_msg[i], t_ing[i]);
     if (trace) fprintf(stderr, "[atlas trace] batched_prove: combine + transcript + publish %.3f ms, enqueue %.3f ms\n", t_fs, t_enq);
-    if (piped) return PL.collect_finals();
+    if (piped) { PROF("batched_prove: collect_finals + join"); return PL.collect_finals(); }
     return ATLAS_OK;
 }
 

@@ -332,6 +332,7 @@ int atlas_poly_repeat_rows(atlas_poly_t base, size_t rows, size_t row_len, size_
 //   ABMK_ABNK_ABMN (a,b,m,n,k)  ACBMK_KCN_CBMN (a,c,b,m,n,k)  CBMK_CBKN_AMN (cb,m,n,k)
 int atlas_einsum_fold(int layout, const size_t* dims, size_t n_dims, const int32_t* d_left, const int32_t* d_right,
                       atlas_poly_t eq_r_m, atlas_poly_t eq_r_n, atlas_poly_t* left_out, atlas_poly_t* right_out) {
+    PROF("atlas_einsum_fold");
     NEED_INIT();
     static const size_t want[] = {3, 4, 4, 4, 4, 2, 5, 6, 4};
     if (layout < 0 || layout > ATLAS_EINSUM_CBMK_CBKN_AMN || !dims || n_dims != want[layout]) return fail(ATLAS_EINVAL, "einsum_fold: layout / dims");

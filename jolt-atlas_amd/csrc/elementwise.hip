@@ -309,6 +309,7 @@ extern "C" {
 
 int atlas_elementwise_new(int op, const atlas_poly_t* operands, size_t n_operands, const atlas_fr_t* r_node_output, size_t n_vars,
                           const atlas_fr_t* constants, size_t n_constants, atlas_instance_t* out) {
+    PROF("atlas_elementwise_new");
     NEED_INIT();
     if (!operands || !out || (!r_node_output && op != EW_DOT && op != EW_GATHER)) return fail(ATLAS_EINVAL, "elementwise_new: null argument");
     if (op < EW_ADD || op > EW_TELEPORT_DIV) return fail(ATLAS_EINVAL, "elementwise_new: unknown operator");

@@ -172,6 +172,7 @@ H::Fr horner(const std::vector<H::Fr>& c, const H::Fr& x) {
 extern "C" int atlas_eval_reduction_prove(atlas_poly_t mle, const atlas_fr_t* points, const atlas_fr_t* claims, size_t N,
                                           size_t n, atlas_transcript_t* transcript, atlas_fr_t* h_out, size_t h_cap,
                                           size_t* h_len, atlas_fr_t* r_out, atlas_fr_t* claim_out) {
+    PROF("atlas_eval_reduction_prove");
     NEED_INIT();
     if (!mle || (!points && n) || !claims || !transcript || !h_out || !h_len || (!r_out && n) || !claim_out) return fail(ATLAS_EINVAL, "eval_reduction: null argument");
     if (N == 0) return fail(ATLAS_EINVAL, "eval_reduction: EmptyInput");

@@ -756,6 +756,7 @@ size_t atlas_graph_num_nodes(atlas_graph_t G) { return G ? G->nodes.size() : 0; 
 
 // Model::trace: inputs in the order of the graph's Input nodes (ascending index), each padded_len(dims) i32 on the host
 int atlas_graph_trace(atlas_graph_t G, const int32_t* const* inputs, size_t n_inputs) {
+    PROF("atlas_graph_trace");
     NEED_INIT();
     if (!G || (!inputs && n_inputs)) return fail(ATLAS_EINVAL, "graph_trace: null argument");
     if (n_inputs != G->input_nodes().size()) return fail(ATLAS_EINVAL, "graph_trace: one tensor per Input node expected");

@@ -88,12 +88,12 @@ struct Prover : FlowSink {
     Out out() { Out O{nullptr, 0, 0, nullptr, 0, nullptr, 0, 0}; O.sink = this; O.node = cur; return O; }
     // ATLAS_GRAPH_TRACE=2: wall clock between the marks of an operator flow on stderr (synchronises the device: diagnosis only)
     std::chrono::steady_clock::time_point mark_t;
-    void mark(const char* what) {
+    void mark(const char* what) override {
         static const bool on = getenv("ATLAS_GRAPH_TRACE") && atoi(getenv("ATLAS_GRAPH_TRACE")) >= 2;
         if (!on) return;
         atlas_sync();
         const auto n = std::chrono::steady_clock::now();
-        if (what) fprintf(stderr, "[atlas graph]   node %llu %-28s %8.3f ms\n", (unsigned long long)cur, what, ms_between(mark_t, n));
+        if (what) fprintf(stderr, "[atlas graph]   node %llu op %d | %s | %8.3f ms\n", (unsigned long long)cur, G.nodes.at(cur).op, what, ms_between(mark_t, n));
         mark_t = n;
     }
     // AccOpeningProvider::append_nodeio(Target::Input(pos), claim) at `point` (utils/opening_access.rs)
@@ -1158,7 +1158,7 @@ struct Prover : FlowSink {
         SoftmaxWitness& Sm = *W.softmax;
         const size_t F = Sm.F, lf = gr::log2u(F), ln = gr::log2u(Sm.N);
         const H::Fr S_fr = H::from_u64((uint64_t)1 << LS);
-        const size_t phases = LS % 4 == 0 ? LS / 4 : LS / 2;                 // IdentityRCProvider::phases (identity_range_check.rs:506-518)
+        const size_t phases = identity_rc_phases(LS);                        // (node_flow.hip.h: the prover's own cut of the address rounds)
         const ExpLut* L = nullptr;
         int rc = atlas_rt_exp_lut(&L);
         if (rc) return rc;
@@ -1476,6 +1476,12 @@ struct Prover : FlowSink {
 
     int prove_node(const Node& nd) {
         cur = nd.idx;
+        mark(nullptr);
+        const int rc = prove_node_flow(nd);
+        mark("(rest of the node)");
+        return rc;
+    }
+    int prove_node_flow(const Node& nd) {
         // (the lookup operators over ONE element are composed — DESIGN 11.8b; a gather of one index and a softmax over one element are not:
         // their dictionary / per-row machinery was never walked at one cycle, and no model of the reference's zoo has them)
         if (gr::padded_len(nd.dims) == 1 && (nd.op == ATLAS_OP_GATHER_LARGE || nd.op == ATLAS_OP_GATHER_SMALL || nd.op == ATLAS_OP_SOFTMAX))
@@ -1485,6 +1491,7 @@ struct Prover : FlowSink {
         if (nd.op == ATLAS_OP_SIN || nd.op == ATLAS_OP_COS) return op_trig(nd);
         int rc = eval_reduction(nd);                                           // ReductionFlow::Default
         if (rc) return rc;
+        mark("eval reduction");
         const gr::Opening& R = red(nd);
         switch (nd.op) {
             case ATLAS_OP_INPUT: case ATLAS_OP_CONSTANT: return ATLAS_OK;    // the verifier evaluates the public tensor itself
@@ -1620,6 +1627,7 @@ static int prove_graph_impl(atlas_graph_t G, atlas_srs_t srs, atlas_shard_group_
     if (!rc) rc = P.commit_all();
     const auto t2 = now();
     if (!rc) rc = P.output_claim();
+    if (atlas_rt::Prof::on()) atlas_rt::Prof::get().reset();
     const bool gtrace = getenv("ATLAS_GRAPH_TRACE") != nullptr;             // per-operator wall clock of the node loop on stderr
     std::map<int, std::pair<double, size_t>> per_op;
     for (auto it = G->nodes.rbegin(); it != G->nodes.rend() && !rc; ++it) {
@@ -1629,6 +1637,7 @@ static int prove_graph_impl(atlas_graph_t G, atlas_srs_t srs, atlas_shard_group_
     }
     if (gtrace) fprintf(stderr, "[atlas graph] device pool: %zu requests reached hipMalloc so far in this process (%.3f ms), %zu passed over for their stream\n",
                         atlas_rt::dev_pool().n_real, atlas_rt::dev_pool().real_ms, atlas_rt::dev_pool().cross_stream);
+    if (atlas_rt::Prof::on()) { atlas_rt::Prof::get().dump(stderr, "node loop (iop)"); atlas_rt::Prof::get().reset(); }
     if (gtrace) for (auto& kv : per_op) fprintf(stderr, "[atlas graph] op %2d  x%-4zu %9.3f ms  (%.3f ms each)\n", kv.first, kv.second.second, kv.second.first, kv.second.first / kv.second.second);
     const auto t3 = now();
     if (!rc) rc = P.reduced_openings(nullptr);

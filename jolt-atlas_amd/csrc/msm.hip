@@ -768,6 +768,7 @@ int atlas_msm_fr(atlas_srs_t srs, size_t offset, const atlas_fr_t* scalars, size
 }
 
 int atlas_msm_poly(atlas_srs_t srs, size_t offset, atlas_poly_t poly, atlas_g1_affine_t* out) {
+    PROF("atlas_msm_poly");
     NEED_INIT();
     if (!srs || !poly || !out) return fail(ATLAS_EINVAL, "msm_poly: null argument");
     if (offset + poly->len > srs->len) return fail(ATLAS_EINVAL, "msm_poly: KeyLengthError (bases shorter than scalars)");
@@ -881,6 +882,7 @@ int atlas_commit_one_hot_batch(atlas_srs_t srs, const int32_t* const* nonzero_in
 // + HyperKZG::batch_commit_one_hot, hyperkzg/mod.rs:558-596): d = ceil(log_K / log_k_chunk) one-hot polynomials with
 // K_chunk = 2^log_k_chunk addresses each, chunk 0 most significant (OneHotParams::lookup_index_chunk, config.rs:73-75).
 int atlas_commit_lookup_chunks(atlas_srs_t srs, const uint64_t* d_lookups, size_t log_T, size_t log_K, size_t log_k_chunk, atlas_g1_affine_t* out) {
+    PROF("atlas_commit_lookup_chunks");
     NEED_INIT();
     if (!srs || !d_lookups || !out || log_k_chunk == 0 || log_k_chunk > 16 || log_K == 0 || log_K > 64 || log_T > 26)
         return fail(ATLAS_EINVAL, "commit_lookup_chunks: bad argument");
@@ -908,6 +910,7 @@ int atlas_commit_lookup_chunks(atlas_srs_t srs, const uint64_t* d_lookups, size_
 // lookup families in ONE launch, one copy and one synchronisation, affine through one shared inversion.  out: the d_f commitments
 // of family f after those of family f - 1.
 int atlas_commit_lookup_chunks_multi(atlas_srs_t srs, const atlas_lookup_family_t* fams, size_t n, size_t log_k_chunk, atlas_g1_affine_t* out) {
+    PROF("atlas_commit_lookup_chunks_multi");
     NEED_INIT();
     if (!srs || !fams || !out || n == 0 || log_k_chunk == 0 || log_k_chunk > 16) return fail(ATLAS_EINVAL, "commit_lookup_chunks_multi: bad argument");
     std::vector<LookupChunkRow> rows;
@@ -1187,6 +1190,7 @@ static int hyperkzg_open_impl(atlas_srs_t srs, atlas_poly_t poly, const atlas_u1
 
 int atlas_hyperkzg_open(atlas_srs_t srs, atlas_poly_t poly, const atlas_u128_t* point, size_t ell,
                         atlas_transcript_t* transcript, atlas_g1_affine_t* com, atlas_g1_affine_t* w, atlas_fr_t* v) {
+    PROF("atlas_hyperkzg_open");
     return hyperkzg_open_impl(srs, poly, point, ell, transcript, com, w, v, nullptr);
 }
 // HyperKZG::open with its four commitment groups (Pi_1.., the three witness polynomials: ~95 % of the open) split by point range over the

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -24,6 +25,7 @@ struct FlowSink {
     // append_sparse of ONE committed one-hot chunk polynomial CommittedPoly::<cp_var>(node, chunk) under SumcheckId `sc`
     virtual void sparse(uint8_t cp_var, size_t chunk, uint8_t sc, const gr::Point& point, const atlas_host::Fr& claim) = 0;
     virtual void proof(uint8_t proof_type, const uint8_t* bytes, size_t len) = 0;
+    virtual void mark(const char*) {}                                         // ATLAS_GRAPH_TRACE=2: a stage of the node's flow ends here
 };
 // the identifiers of one lookup family: its virtual ra polynomial and its committed chunks
 struct RaIds { uint8_t ra_vp, rad_cp; };
@@ -120,6 +122,7 @@ struct Out {
         if (sink) sink->sparse(cp_var, chunk, sc, point, c);
         return put_claim(c);
     }
+    void mark(const char* what) { if (sink) sink->mark(what); }
     int put_claim(const H::Fr& c) {
         if (!claims) return ATLAS_OK;
         if (n_claims >= claims_cap) return fail(ATLAS_EINVAL, "prove_einsum_node: claims buffer too small");
@@ -327,6 +330,19 @@ int make_rescale_witness(size_t T, size_t S, FillAcc&& fill_acc, int32_t* d_outp
     return ATLAS_OK;
 }
 
+// How many phases the address rounds of an identity range check over log_K bits are cut into.  The reference's default
+// (IdentityRCProvider::phases, identity_range_check.rs:506-518) is log_m = 4, or 2 when 4 does not divide log_K: seven phases for the
+// 14-bit remainder of every fused rescale.  The cut is the PROVER's bookkeeping — round j's polynomial is sum over the remaining
+// variables of the summand at (r_0 .. r_{j-1}, X, .), whatever tables it is accumulated through — and every phase boundary costs a pass
+// over T plus a table hand-over (~45 us at these sizes).  So: the largest chunk of at most 8 bits that divides log_K (14 -> two phases
+// of 7 bits: one boundary instead of six); ATLAS_RC_REF_PHASES=1 restores the reference's cut (A-B: same proof bytes).
+inline size_t identity_rc_phases(size_t log_K) {
+    static const bool ref_cut = getenv("ATLAS_RC_REF_PHASES") != nullptr;
+    if (ref_cut) return log_K <= 2 ? 1 : log_K % 4 == 0 ? log_K / 4 : log_K % 2 == 0 ? log_K / 2 : log_K;
+    for (size_t log_m = 8; log_m >= 1; log_m--) if (log_K % log_m == 0) return log_K / log_m;
+    return log_K;
+}
+
 // prove_clamp_lookup (clamp_lookups/mod.rs:264-309) after its raf claim: gamma, PS-Shout read-raf over SaturationTable =
 // ClampBoundedTable<64, 31, true> (ProofType::Execution) with its ClampRa opening, then ra_onehot_provers + BatchedSumcheck
 // (ProofType::RaOneHotChecks) over the ClampRaD chunks.  acc_claim = the i64 accumulation's opening (already appended),
@@ -347,9 +363,11 @@ inline int prove_clamp_lookup_flow(const uint64_t* d_cidx, size_t log_T, const a
     if (!rc) rc = prove_single(exec, exec_claim, t, O, ch, &ra_claim, 64, gr::VP_ClampRa, gr::PT_Execution, &ra_point);
     if (exec) atlas_instance_free(exec);
     if (stage_ms) stage_ms[0] = ms_since(t0);
+    O.mark("clamp lookup: read-raf (64)");
     t0 = now();
     if (!rc) rc = prove_onehot_checks(d_cidx, log_T, 64, r_node_output, ra_point, ra_claim, t, O, gr::CP_ClampRaD, gr::PT_RaOneHotChecks);
     if (stage_ms) stage_ms[1] = ms_since(t0);
+    O.mark("clamp lookup: one-hot (d=16)");
     return rc;
 }
 
@@ -388,6 +406,7 @@ int prove_fused_rescale(RescaleWitness& W, Inner&& inner, const atlas_fr_t* r_no
     for (atlas_poly_t p : {p_rem, p_quot, p_out}) if (p) atlas_poly_free(p);
     if (stage_ms) stage_ms[0] = ms_since(t0);
     if (rc) return rc;
+    O.mark("fused: witness openings");
 
     // ---- prove_pre: remainder advice (cache_remainder_prove), the rescaled accumulator's raf claim, clamp lookup
     rc = O.append_virtual(Tr, gr::node_exec(gr::virt(gr::VP_RescaleRemainder, O.node), O.node), r0, eval_R);
@@ -405,6 +424,7 @@ int prove_fused_rescale(RescaleWitness& W, Inner&& inner, const atlas_fr_t* r_no
         rc = inner(in_claim);
     }
     if (stage_ms) stage_ms[3] = ms_since(t0);
+    O.mark("fused: operator sumcheck");
 
     if (scalar) return rc;
     // ---- prove_remainder_rc
@@ -413,16 +433,18 @@ int prove_fused_rescale(RescaleWitness& W, Inner&& inner, const atlas_fr_t* r_no
     std::vector<atlas_u128_t> ch;
     H::Fr rr_claim;
     if (!rc) {
-        size_t phases = S <= 2 ? 1 : S % 4 == 0 ? S / 4 : S % 2 == 0 ? S / 2 : S;      // IdentityRCProvider::phases (identity_range_check.rs:506-518)
+        const size_t phases = identity_rc_phases(S);
         atlas_instance_t rcq = nullptr;
         rc = atlas_identity_range_check_new(W.ridx.as<uint64_t>(), log_T, S, phases, r_node_output, &rcq);
         if (!rc) rc = prove_single(rcq, eval_R, t, O, ch, &rr_claim, S, gr::VP_RescaleRemainderRa, gr::PT_RangeCheck, &rr_point);
         if (rcq) atlas_instance_free(rcq);
     }
     if (stage_ms) stage_ms[4] = ms_since(t0);
+    O.mark("fused: remainder range check");
     t0 = now();
     if (!rc) rc = prove_onehot_checks(W.ridx.as<uint64_t>(), log_T, S, r_node_output, rr_point, rr_claim, t, O, gr::CP_RescaleRemainderRaD, gr::PT_RescaleRemainderRaChecks);
     if (stage_ms) stage_ms[5] = ms_since(t0);
+    O.mark("fused: remainder one-hot");
     return rc;
 }
 

@@ -966,6 +966,7 @@ int atlas_rt_onehot_pool_new(const atlas_rt_pool_row* in, size_t n, size_t log_K
 extern "C" {
 
 int atlas_dense_opening_new(atlas_poly_t poly, const atlas_fr_t* opening_point, size_t n, atlas_instance_t* out) {
+    PROF("atlas_dense_opening_new");
     NEED_INIT();
     if (!poly || (!opening_point && n) || !out) return fail(ATLAS_EINVAL, "dense_opening_new: null argument");
     if (poly->len != ((size_t)1 << n)) return fail(ATLAS_EINVAL, "dense_opening_new: polynomial length != 2^n");

@@ -813,6 +813,7 @@ struct PsLookup : atlas_instance {
             const QBox& B = qbox[round / log_m];
             if (!B.tagc) return fail(ATLAS_ESTATE, "ps_shout: Q of the phase was not enqueued");
             const auto t0 = std::chrono::steady_clock::now();
+            PROF("ps_shout: wait for the phase's Q tables + load");
             while (B.tagc->tag != B.tag) {
                 for (int i = 0; i < 1024 && B.tagc->tag != B.tag; i++) __builtin_ia32_pause();
                 if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) { g.chan.abort_dirty = true; return fail(ATLAS_ENODEV, "round channel: no Q tables from the device"); }
@@ -911,6 +912,7 @@ static int ps_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, si
 
 int atlas_ps_shout_relu_new(const uint64_t* lookup_indices, size_t log_T, size_t xlen, const atlas_fr_t* r_node_output,
                             const atlas_fr_t* gamma, atlas_instance_t* out) {
+    PROF("atlas_ps_shout_relu_new");
     NEED_INIT();
     if (!lookup_indices || (!r_node_output && log_T) || !gamma || !out) return fail(ATLAS_EINVAL, "ps_shout_relu_new: null argument");
     if (xlen != 16 && xlen != 32) return fail(ATLAS_EINVAL, "ps_shout_relu_new: X_LEN must be 16 or 32 (the reference's WordNoMSB suffix is a u32)");
@@ -920,6 +922,7 @@ int atlas_ps_shout_relu_new(const uint64_t* lookup_indices, size_t log_T, size_t
 
 int atlas_ps_shout_clamp_new(const uint64_t* lookup_indices, size_t log_T, size_t xlen, size_t bound, int symmetric,
                              const atlas_fr_t* r_node_output, const atlas_fr_t* gamma, atlas_instance_t* out) {
+    PROF("atlas_ps_shout_clamp_new");
     NEED_INIT();
     if (!lookup_indices || (!r_node_output && log_T) || !gamma || !out) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: null argument");
     if (xlen != 16 && xlen != 32 && xlen != 64) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: X_LEN must be 16, 32 or 64");
@@ -930,6 +933,7 @@ int atlas_ps_shout_clamp_new(const uint64_t* lookup_indices, size_t log_T, size_
 
 int atlas_ps_shout_rshift_new(const uint64_t* lookup_indices, size_t log_T, size_t xlen, size_t shift, const atlas_fr_t* r_node_output,
                               const atlas_fr_t* gamma, atlas_instance_t* out) {
+    PROF("atlas_ps_shout_rshift_new");
     NEED_INIT();
     if (!lookup_indices || (!r_node_output && log_T) || !gamma || !out) return fail(ATLAS_EINVAL, "ps_shout_rshift_new: null argument");
     if ((xlen != 16 && xlen != 32) || shift >= xlen || log_T > 25)
@@ -939,6 +943,7 @@ int atlas_ps_shout_rshift_new(const uint64_t* lookup_indices, size_t log_T, size
 
 int atlas_ps_shout_ult_new(const uint64_t* lookup_indices, size_t log_T, const atlas_fr_t* r_node_output, const atlas_fr_t* gamma,
                            atlas_instance_t* out) {
+    PROF("atlas_ps_shout_ult_new");
     NEED_INIT();
     if (!lookup_indices || (!r_node_output && log_T) || !gamma || !out) return fail(ATLAS_EINVAL, "ps_shout_ult_new: null argument");
     if (log_T > 25) return fail(ATLAS_EINVAL, "ps_shout_ult_new: log_T <= 25");
@@ -947,6 +952,7 @@ int atlas_ps_shout_ult_new(const uint64_t* lookup_indices, size_t log_T, const a
 
 int atlas_identity_range_check_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, size_t phases,
                                    const atlas_fr_t* r_node_output, atlas_instance_t* out) {
+    PROF("atlas_identity_range_check_new");
     NEED_INIT();
     if (!lookup_indices || (!r_node_output && log_T) || !out) return fail(ATLAS_EINVAL, "identity_range_check_new: null argument");
     if (phases == 0 || log_K == 0 || log_K > 64 || log_K % phases || log_K / phases > 12)
@@ -975,6 +981,7 @@ int atlas_u64_free(uint64_t* d) {
 }
 
 int atlas_lookup_indices_from_operands(const int32_t* d_left, const int32_t* d_right, size_t n, uint64_t** d_out) {
+    PROF("atlas_lookup_indices_from_operands");
     NEED_INIT();
     if (!d_left || !d_out || n == 0) return fail(ATLAS_EINVAL, "lookup_indices_from_operands: null argument");
     uint64_t* d = nullptr;

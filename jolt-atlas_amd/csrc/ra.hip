@@ -895,6 +895,7 @@ int atlas_ra_virtual_new(const int32_t* const* H_indices, size_t d, size_t log_k
 // (config.rs:73-100) done here — d = ceil(log_K / log_k_chunk), r_address left-padded with zeros to a multiple of the chunk
 int atlas_ra_virtual_from_lookups_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, size_t log_k_chunk,
                                       const atlas_fr_t* r_address, const atlas_fr_t* r_cycle, atlas_instance_t* out) {
+    PROF("atlas_ra_virtual_from_lookups_new");
     NEED_INIT();
     if (!lookup_indices || !r_address || log_k_chunk == 0 || log_K == 0) return fail(ATLAS_EINVAL, "ra_virtual_from_lookups_new: null argument");
     const size_t d = (log_K + log_k_chunk - 1) / log_k_chunk, pad = d * log_k_chunk - log_K;
@@ -951,6 +952,7 @@ int atlas_booleanity_new(const atlas_fr_t* G, const int32_t* const* H_indices, s
 int atlas_booleanity_from_lookups_new(const atlas_fr_t* G, const uint64_t* lookup_indices, size_t log_T, size_t log_K, size_t log_k_chunk,
                                       const atlas_fr_t* gammas, const atlas_fr_t* r_address, const atlas_fr_t* r_cycle,
                                       atlas_instance_t* out) {
+    PROF("atlas_booleanity_from_lookups_new");
     NEED_INIT();
     if (!lookup_indices || log_k_chunk == 0 || log_K == 0) return fail(ATLAS_EINVAL, "booleanity_from_lookups_new: null argument");
     return booleanity_build(G, nullptr, lookup_indices, (log_K + log_k_chunk - 1) / log_k_chunk, log_k_chunk, log_T, gammas, r_address, r_cycle, out);
@@ -994,6 +996,7 @@ static int booleanity_build(const atlas_fr_t* G, const int32_t* const* H_indices
 }
 
 int atlas_hamming_weight_new(const atlas_fr_t* G, size_t d, size_t log_k_chunk, const atlas_fr_t* gamma_powers, atlas_instance_t* out) {
+    PROF("atlas_hamming_weight_new");
     if (!G || !gamma_powers || !out || d == 0 || log_k_chunk > 20) return fail(ATLAS_EINVAL, "hamming_weight_new");
     HammingWeight* P = new HammingWeight();
     P->log_k = log_k_chunk;

@@ -85,6 +85,7 @@ inline int grid_for(size_t work) {
 
 extern "C" int atlas_rlc_build(const atlas_rlc_dense_t* dense, size_t n_dense, const atlas_rlc_onehot_t* onehot,
                                size_t n_onehot, atlas_poly_t* out) {
+    PROF("atlas_rlc_build");
     NEED_INIT();
     if (!out || (n_dense && !dense) || (n_onehot && !onehot)) return fail(ATLAS_EINVAL, "rlc_build: null argument");
     std::lock_guard<atlas_rt::Mutex> lk(g.mu);

@@ -8,6 +8,7 @@
 
 #include "../../include/atlas_hip.h"
 #include "channel.hpp"
+#include "prof.hpp"
 
 namespace atlas {
 struct Fe;

@@ -16,6 +16,7 @@
 // gives the same residue.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -51,7 +52,7 @@ __device__ __forceinline__ uint32_t key_of(uint64_t idx, uint32_t i, KeySpec S) 
 __global__ __launch_bounds__(SH_THREADS) void k_sh_range_flag(const uint64_t* __restrict__ idx, size_t T, uint32_t log_K, uint32_t* flag) {
     uint32_t bad = 0;
     for (size_t j = (size_t)blockIdx.x * SH_THREADS + threadIdx.x; j < T; j += (size_t)gridDim.x * SH_THREADS) bad |= (log_K < 64 && (idx[j] >> log_K)) ? 1u : 0u;
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+    if (bad) atomicOr(flag, 1u);                                          // (rare: every offending lane reports, whatever the wavefront width)
 }
 
 __global__ __launch_bounds__(SH_THREADS) void k_sh_hist(const uint64_t* __restrict__ idx, size_t T, KeySpec S, uint32_t* counts) {
@@ -111,6 +112,42 @@ __global__ __launch_bounds__(SH_THREADS) void k_sh_hist_small(const uint64_t* __
     __syncthreads();
     for (uint32_t w = threadIdx.x; w < n_buckets * 8; w += SH_THREADS)
         if (sm[w]) atomicAdd(&acc[w], sm[w]);
+}
+
+// medium tables (the 2^16 .. 2^18-entry activation / exp tables of Tanh and SoftmaxLastAxis, T <= 2^20 lookups): no sort either.  Every lookup
+// adds the eight 32-bit words of E[j] to 64-bit accumulators of its bucket in HBM (distinct buckets mostly: the atomics spread over the L2
+// channels), one thread per bucket turns the word sums back into a residue (lo R R^-1 + hi R^2 R^-1, as k_ps_q_final does).  The counting
+// sort below spent ~1.6 ms per call in its one-workgroup scan over 2^18 counters — 66 ms of a GPT-2-shaped proof.
+__global__ __launch_bounds__(SH_THREADS) void k_sh_hist_words(const uint64_t* __restrict__ idx, size_t T, KeySpec S, const Fe* __restrict__ E,
+                                                              unsigned long long* __restrict__ acc /* [n_buckets][8], zeroed */) {
+    for (size_t j = (size_t)blockIdx.x * SH_THREADS + threadIdx.x; j < T; j += (size_t)gridDim.x * SH_THREADS) {
+        const uint64_t v = idx[j];
+        const Fe e = fe_load(E + j);
+        for (uint32_t i = 0; i < S.d; i++) {
+            unsigned long long* b = acc + (size_t)key_of(v, i, S) * 8;
+#pragma unroll
+            for (int w = 0; w < 8; w++) atomicAdd(&b[w], (unsigned long long)e.v[w]);
+        }
+    }
+}
+__global__ __launch_bounds__(SH_THREADS) void k_sh_words_final(const unsigned long long* __restrict__ acc, uint32_t n_buckets, Fe* __restrict__ G) {
+    const uint32_t b = blockIdx.x * SH_THREADS + threadIdx.x;
+    if (b >= n_buckets) return;
+    Fe lo, hi, r2;
+    unsigned long long c = 0, any = 0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        const unsigned long long a = acc[(size_t)b * 8 + w];
+        any |= a;
+        const unsigned long long s2 = c + (a & 0xffffffffull);
+        lo.v[w] = (uint32_t)s2;
+        c = (s2 >> 32) + (a >> 32);
+    }
+    if (!any) { fe_store(G + b, fe_zero()); return; }
+#pragma unroll
+    for (int w = 0; w < 8; w++) { hi.v[w] = 0; r2.v[w] = FrParams::r2(w); }
+    hi.v[0] = (uint32_t)c; hi.v[1] = (uint32_t)(c >> 32);
+    fe_store(G + b, fr_add(fr_mul(lo, fr_one()), fr_mul(hi, r2)));
 }
 
 // one thread per bucket (large tables, short lists)
@@ -185,6 +222,28 @@ int histogram(const uint64_t* h_idx, size_t T, KeySpec S, const atlas_poly* E, a
         *out = p;
         return ATLAS_OK;
     }
+    static const bool no_words = getenv("ATLAS_SH_NO_WORDS") != nullptr;      // A-B
+    if (n_buckets <= (1u << 20) && !no_words) {
+        hipPointerAttribute_t attr;
+        const bool on_device = T && hipPointerGetAttributes(&attr, h_idx) == hipSuccess && attr.type == hipMemoryTypeDevice;
+        (void)hipGetLastError();
+        DevBuf acc_b, ix_b;
+        HIP_TRY(acc_b.alloc((size_t)n_buckets * 64));
+        if (!on_device) { HIP_TRY(ix_b.alloc((T ? T : 1) * 8)); HIP_TRY(hipMemcpyAsync(ix_b.p, h_idx, T * 8, hipMemcpyHostToDevice, g.stream)); }
+        Fe* Gw = nullptr;
+        hipError_t e3 = hipMalloc(&Gw, (size_t)n_buckets * sizeof(Fe));
+        if (e3 != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(G)", e3);
+        HIP_TRY(hipMemsetAsync(acc_b.p, 0, (size_t)n_buckets * 64, g.stream));
+        k_sh_hist_words<<<grid_for(T), SH_THREADS, 0, g.stream>>>(on_device ? h_idx : ix_b.as<uint64_t>(), T, S, (const Fe*)E->d, acc_b.as<unsigned long long>());
+        k_sh_words_final<<<(n_buckets + SH_THREADS - 1) / SH_THREADS, SH_THREADS, 0, g.stream>>>(acc_b.as<unsigned long long>(), n_buckets, Gw);
+        // (stream order is all the caller needs: G is consumed by launches on this stream; the scratch returns to the pool under this stream's tag)
+        e3 = hipGetLastError();
+        if (e3 != hipSuccess) { hipFree(Gw); return fail(ATLAS_ENODEV, "shout histogram", e3); }
+        atlas_poly* p = new atlas_poly();
+        p->d = Gw; p->len = n_buckets; p->cap_bytes = (size_t)n_buckets * sizeof(Fe); p->is_i32 = false; p->owned = true;
+        *out = p;
+        return ATLAS_OK;
+    }
     uint64_t* d_idx = nullptr; uint32_t *counts = nullptr, *offsets = nullptr, *cursor = nullptr, *sorted = nullptr;
     Fe* G = nullptr;
     auto cleanup = [&]() { hipFree(d_idx); hipFree(counts); hipFree(offsets); hipFree(cursor); hipFree(sorted); };
@@ -218,6 +277,7 @@ int histogram(const uint64_t* h_idx, size_t T, KeySpec S, const atlas_poly* E, a
 extern "C" {
 
 int atlas_shout_read_raf_G(const uint64_t* lookup_indices, size_t T, size_t log_K, atlas_poly_t eq_r, atlas_poly_t* out) {
+    PROF("atlas_shout_read_raf_G");
     NEED_INIT();
     if ((!lookup_indices && T) || !eq_r || !out || log_K > 24) return fail(ATLAS_EINVAL, "shout_read_raf_G");
     // the reference indexes the table with bounds checks.  Host indices are range-checked here; device-resident ones by a kernel that
@@ -239,7 +299,8 @@ int atlas_shout_read_raf_G(const uint64_t* lookup_indices, size_t T, size_t log_
     int rc = histogram(lookup_indices, T, KeySpec{1u, (uint32_t)log_K}, eq_r, out);
     if (!rc && on_device) {
         uint32_t bad = 0;
-        HIP_TRY(hipMemcpy(&bad, flag.p, 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpyAsync(&bad, flag.p, 4, hipMemcpyDeviceToHost, g.stream));      // on the library's (non-blocking) stream, behind the flag kernel
+        HIP_TRY(hipStreamSynchronize(g.stream));
         if (bad) { atlas_poly_free(*out); *out = nullptr; return fail(ATLAS_EINVAL, "shout_read_raf_G: lookup index outside the table"); }
     }
     return rc;
@@ -261,6 +322,7 @@ int atlas_shout_ra_evals(const uint64_t* lookup_indices, size_t T, size_t log_K,
 // no device polynomial in between.  Not part of the C-ABI (internal.hpp).
 int atlas_rt_shout_ra_evals_host(const uint64_t* lookup_indices, size_t T, size_t log_K, size_t log_k_chunk, atlas_poly_t eq_r_cycle,
                                  std::vector<atlas_host::Fr>& G) {
+    PROF("atlas_rt_shout_ra_evals_host");
     const uint32_t d = (uint32_t)((log_K + log_k_chunk - 1) / log_k_chunk);
     if (!lookup_indices || !eq_r_cycle || log_k_chunk == 0 || log_k_chunk > 16 || ((size_t)d << log_k_chunk) > SH_SMALL_BUCKETS)
         return fail(ATLAS_EINVAL, "shout_ra_evals_host");
@@ -273,6 +335,7 @@ extern "C" {
 
 int atlas_shout_read_raf_prover_new(atlas_poly_t G, const int32_t* table, size_t log_K, const atlas_fr_t* gamma,
                                     atlas_dot_prover_t* out) {
+    PROF("atlas_shout_read_raf_prover_new");
     NEED_INIT();
     if (!G || !table || !gamma || !out) return fail(ATLAS_EINVAL, "shout_read_raf_prover_new");
     const size_t K = (size_t)1 << log_K;

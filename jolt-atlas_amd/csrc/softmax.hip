@@ -202,6 +202,7 @@ extern "C" {
 
 int atlas_softmax_instance_new(int kind, atlas_poly_t a, atlas_poly_t b, size_t log_K, size_t log_N, const atlas_fr_t* r,
                                atlas_instance_t* out) {
+    PROF("atlas_softmax_instance_new");
     NEED_INIT();
     if (!a || !out) return fail(ATLAS_EINVAL, "softmax_instance_new: null argument");
     if (kind < SM_EXP_SUM || kind > SM_SUM_AXIS) return fail(ATLAS_EINVAL, "softmax_instance_new: unknown kind");

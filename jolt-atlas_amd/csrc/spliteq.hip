@@ -115,6 +115,7 @@ int atlas_rt_eq_evals_into(const H::Fr* r, size_t n, Fr* ev) {
 extern "C" {
 
 int atlas_eq_evals(const atlas_fr_t* r, size_t n, const atlas_fr_t* scaling, atlas_poly_t* out) {
+    PROF("atlas_eq_evals");
     NEED_INIT();
     if ((!r && n) || !out || n > 30) return fail(ATLAS_EINVAL, "eq_evals");
     std::lock_guard<atlas_rt::Mutex> lk(g.mu);
@@ -128,6 +129,7 @@ int atlas_eq_evals(const atlas_fr_t* r, size_t n, const atlas_fr_t* scaling, atl
 }
 
 int atlas_poly_evaluate_many(const atlas_poly_t* polys, size_t count, const atlas_fr_t* r, size_t n, atlas_fr_t* out) {
+    PROF("atlas_poly_evaluate_many");
     NEED_INIT();
     if (!polys || !count || count > 64 || (!r && n) || !out) return fail(ATLAS_EINVAL, "poly_evaluate_many");
     for (size_t i = 0; i < count; ++i)
@@ -161,6 +163,7 @@ int atlas_poly_evaluate_many(const atlas_poly_t* polys, size_t count, const atla
 }
 
 int atlas_poly_evaluate(atlas_poly_t p, const atlas_fr_t* r, size_t n, atlas_fr_t* out) {
+    PROF("atlas_poly_evaluate");
     if (!p) return fail(ATLAS_EINVAL, "poly_evaluate");
     return atlas_poly_evaluate_many(&p, 1, r, n, out);
 }
