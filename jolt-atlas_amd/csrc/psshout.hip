@@ -70,20 +70,29 @@ __device__ __forceinline__ void ps_entry_vals(uint64_t k, const Fr& u, uint32_t 
 // m = 256.)  The accumulators are NQ * m * 64 bytes of dynamic LDS (96 KB for the clamp lookup).
 // v_prev != null: the finished phase's expanding table is folded into the products first (k_ps_scale fused: every lookup
 // is visited by exactly one thread), prod[t] *= v_prev[(idx_t >> shift_prev) & (m - 1)].
+// The sign classes of the shortcut below (PsSign): cls.only >= 0 keeps the lookups whose bit cls.sign_bit equals it (the class tables of the
+// first mixed phase); cls.scal != null multiplies the product of a lookup by scal[its class] on the way (the factor the skipped phases owe).
+struct PsClass { int only; uint32_t sign_bit; const Fr* scal; };
 template <int NQ>
 __global__ __launch_bounds__(RA_THREADS) void k_ps_q_lds(const uint64_t* __restrict__ idx, const Fr* __restrict__ u0,
                                                          Fr* __restrict__ prod, size_t T, uint32_t suffix_len, uint32_t m,
                                                          uint32_t bound, unsigned long long* __restrict__ acc /* [gridDim.x][m][NQ][8] */,
-                                                         const Fr* __restrict__ v_prev, uint32_t shift_prev) {
+                                                         const Fr* __restrict__ v_prev, uint32_t shift_prev, PsClass cls) {
     extern __shared__ unsigned long long ps_sm[];
     const uint32_t n_words = m * NQ * 8;
     for (uint32_t w = threadIdx.x; w < n_words; w += RA_THREADS) ps_sm[w] = 0;
     __syncthreads();
     for (size_t t = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; t < T; t += (size_t)gridDim.x * RA_THREADS) {
         const uint64_t k = idx[t];
+        const uint32_t sgn = (uint32_t)(k >> cls.sign_bit) & 1u;
+        if (cls.only >= 0 && (int)sgn != cls.only) continue;
         const uint32_t b = (uint32_t)(k >> suffix_len) & (m - 1);
         Fr pr = fe_load(prod + t);
-        if (v_prev) { pr = fr_mul(pr, fe_load(v_prev + ((uint32_t)(k >> shift_prev) & (m - 1)))); fe_store(prod + t, pr); }
+        if (v_prev) {
+            pr = fr_mul(pr, fe_load(v_prev + ((uint32_t)(k >> shift_prev) & (m - 1))));
+            if (cls.scal) pr = fr_mul(pr, fe_load(cls.scal + sgn));
+            fe_store(prod + t, pr);
+        }
         Fr val[NQ];
         ps_entry_vals<NQ>(k, fr_mul(fe_load(u0 + t), pr), suffix_len, bound, val);
 #pragma unroll
@@ -253,9 +262,111 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_q(const uint64_t* __restrict_
 
 // prod[t] *= v[chunk(idx_t)]   (u_evals rescale, mod.rs:275-284, and the ra product, :429-441)
 __global__ __launch_bounds__(RA_THREADS) void k_ps_scale(const uint64_t* __restrict__ idx, const Fr* __restrict__ v, size_t T,
-                                                         uint32_t shift, uint32_t m_mask, Fr* __restrict__ prod) {
-    for (size_t t = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; t < T; t += (size_t)gridDim.x * RA_THREADS)
-        fe_store(prod + t, fr_mul(fe_load(prod + t), fe_load(v + ((uint32_t)(idx[t] >> shift) & m_mask))));
+                                                         uint32_t shift, uint32_t m_mask, Fr* __restrict__ prod, PsClass cls = PsClass{-1, 0u, nullptr}) {
+    for (size_t t = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; t < T; t += (size_t)gridDim.x * RA_THREADS) {
+        const uint64_t k = idx[t];
+        Fr pr = fr_mul(fe_load(prod + t), fe_load(v + ((uint32_t)(k >> shift) & m_mask)));
+        if (cls.scal) pr = fr_mul(pr, fe_load(cls.scal + ((uint32_t)(k >> cls.sign_bit) & 1u)));
+        fe_store(prod + t, pr);
+    }
+}
+
+// ---- the sign-extension shortcut ------------------------------------------------------------------------------------------
+// The lookup index of a clamp / ReLU lookup is a sign-extended integer: `acc as u64` of an i64 accumulation that is a few thousand at most.
+// Its leading chunks are 0x00.. or 0xFF.. for EVERY lookup, so through the first P phases ("pure" phases) the product of the expanding
+// tables a lookup has collected depends on its sign class s alone:  u_t(p) = eq_t A_s(p),  A_s(p) = prod_{q < p} E_q[x_s]  (x_0 = 0,
+// x_1 = m - 1; E_q[0] = prod (1 - r), E_q[m-1] = prod r over the phase's challenges).  Hence for p <= P
+//     Q_p^f[y] = sum_s A_s(p) S_{p,s}^f[y],     S_{p,s}^f[y] = sum_{t in s, chunk_p(t) = y} eq_t f_p(t)
+// and the S do not depend on any challenge: ONE pass at construction yields them — for a pure phase only bin x_s of class s is hit (NQ sums per
+// class), for the first mixed phase P two class tables — and the host scales them by two scalars it keeps itself.  The P phase boundaries
+// that would each have cost a pass over T and a hand-over of tables (~45 us) take no device work at all; the products on the device receive
+// A_s(P) E_P[chunk_P] in the first pass that does run.  Same tables, hence the same round polynomials (exact arithmetic in another order).
+//
+// k_ps_sign_scan: per lookup the number of leading chunks that equal its sign pattern (minimum over T -> P) and, for the phases it is pure
+// in, the word sums of its NQ suffix-weighted values per (phase, class).  The last workgroup turns the sums into residues and publishes
+// them with the minimum.  Sums of a phase are complete iff every lookup is pure there, i.e. for p < the published minimum.
+constexpr uint32_t PS_SIGN_PMAX = 7;
+struct PsSignOut { unsigned long long* acc /* [PMAX][2][NQ][8], zeroed */; uint32_t* min_lz /* = phases on entry */; uint32_t* counter; Fr* host_dst; Chunk* tag_chunk; uint32_t tag; };
+template <int NQ>
+__global__ __launch_bounds__(RA_THREADS) void k_ps_sign_scan(const uint64_t* __restrict__ idx, const Fr* __restrict__ u0, size_t T, uint32_t N, uint32_t log_m,
+                                                             uint32_t phases, uint32_t bound, PsSignOut O) {
+    __shared__ unsigned long long sm[PS_SIGN_PMAX * 2 * NQ * 8];
+    __shared__ uint32_t s_min, s_last;
+    constexpr uint32_t n_words = PS_SIGN_PMAX * 2 * NQ * 8;
+    for (uint32_t w = threadIdx.x; w < n_words; w += RA_THREADS) sm[w] = 0;
+    if (threadIdx.x == 0) s_min = phases;
+    __syncthreads();
+    const uint32_t m_mask = (1u << log_m) - 1u;
+    const uint32_t p_cap = phases - 1 < PS_SIGN_PMAX ? phases - 1 : PS_SIGN_PMAX;
+    for (size_t t = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; t < T; t += (size_t)gridDim.x * RA_THREADS) {
+        const uint64_t k = idx[t];
+        const uint32_t sgn = (uint32_t)(k >> (N - 1)) & 1u, pat = sgn ? m_mask : 0u;
+        uint32_t lz = 0;
+        while (lz < phases && ((uint32_t)(k >> ((phases - 1 - lz) * log_m)) & m_mask) == pat) lz++;
+        atomicMin(&s_min, lz);
+        const Fr u = fe_load(u0 + t);
+        const uint32_t pe = lz < p_cap ? lz : p_cap;
+        for (uint32_t p = 0; p < pe; p++) {
+            Fr val[NQ];
+            ps_entry_vals<NQ>(k, u, (phases - 1 - p) * log_m, bound, val);
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                if (fe_is_zero(val[q])) continue;
+                unsigned long long* a = sm + ((size_t)(p * 2 + sgn) * NQ + q) * 8;
+#pragma unroll
+                for (int w = 0; w < 8; w++) atomicAdd(&a[w], (unsigned long long)val[q].v[w]);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t w = threadIdx.x; w < n_words; w += RA_THREADS) if (sm[w]) atomicAdd(&O.acc[w], sm[w]);
+    if (threadIdx.x == 0) atomicMin(O.min_lz, s_min);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tk = atomicAdd(O.counter, 1u);
+        s_last = tk == gridDim.x - 1;
+        if (s_last) *O.counter = 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    constexpr uint32_t n_vals = PS_SIGN_PMAX * 2 * NQ;
+    if (threadIdx.x < n_vals) {
+        Fr lo, hi, r2;
+        unsigned long long c = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            const unsigned long long a = __hip_atomic_load(&O.acc[(size_t)threadIdx.x * 8 + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long s2 = c + (a & 0xffffffffull);
+            lo.v[w] = (uint32_t)s2;
+            c = (s2 >> 32) + (a >> 32);
+        }
+#pragma unroll
+        for (int w = 0; w < 8; w++) { hi.v[w] = 0; r2.v[w] = FrParams::r2(w); }
+        hi.v[0] = (uint32_t)c; hi.v[1] = (uint32_t)(c >> 32);
+        fe_store(O.host_dst + threadIdx.x, fr_add(fr_mul(lo, fr_one()), fr_mul(hi, r2)));
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t mn = __hip_atomic_load(O.min_lz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ch_store_sys(O.tag_chunk, ch_u32x4{n_vals, mn, 0u, O.tag});
+    }
+}
+// A_0 = prod (1 - r_i), A_1 = prod r_i over the n <= 64 challenges of the pure phases (slots of consecutive rounds, published long ago)
+__global__ __launch_bounds__(64) void k_ps_class_scalars(const Chunk* slot0, uint32_t tag0, uint32_t n, uint32_t* abort_flag, int challenge_mode, Fr* __restrict__ out) {
+    Fr x = fr_one(), y = fr_one();
+    bool ok = true;
+    if (threadIdx.x < n) {
+        uint64_t lo = 0, hi = 0;
+        ok = ch_poll_slot<true>(slot0 + (size_t)threadIdx.x * 4, tag0 + threadIdx.x, abort_flag, lo, hi);
+        x = challenge_to_mont(lo, hi, challenge_mode);
+        y = fr_sub(fr_one(), x);
+    }
+    if (__any(!ok)) return;
+    for (int st = 1; st < 64; st <<= 1) { x = fr_mul(x, fe_shfl_xor(x, st)); y = fr_mul(y, fe_shfl_xor(y, st)); }
+    if (threadIdx.x == 0) { fe_store(out, y); fe_store(out + 1, x); }
 }
 
 __global__ __launch_bounds__(RA_THREADS) void k_ps_fill_one(Fr* p, size_t T) {
@@ -430,9 +541,110 @@ struct PsLookup : atlas_instance {
             if (any) nz.push_back((uint32_t)y);
         }
     }
+    // ---- the sign-extension shortcut (kernels above): phases 0 .. sgn_P - 1 are pure, phase sgn_P is the first the device works for
+    struct QBox { const volatile atlas::Chunk* tagc = nullptr; const H::Fr* data = nullptr; uint32_t tag = 0; };
+    size_t sgn_P = 0;                                   // 0: off
+    std::vector<H::Fr> sgn_S;                           // [p][class][q], p < sgn_P
+    H::Fr sgn_A[2] = {H::one(), H::one()};              // A_s(p) over the phases finished so far
+    QBox sgn_box[2];                                    // class tables of phase sgn_P (published at construction)
+    DevBuf sgn_scratch;                                 // word sums, minimum, counter; then the two class scalars
+    const atlas::Chunk* sgn_slot0 = nullptr; uint32_t sgn_tag0 = 0;      // where the challenge of round 0 appears
+    Fr* sgn_scal() const { return reinterpret_cast<Fr*>(static_cast<char*>(sgn_scratch.p) + 8192); }
+    static bool wait_tag(const volatile atlas::Chunk* c, uint32_t tag) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (c->tag != tag) {
+            for (int i = 0; i < 1024 && c->tag != tag; i++) __builtin_ia32_pause();
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) return false;
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        return true;
+    }
+    // tables of a pure phase p < sgn_P: bin x_s of class s only
+    void load_Q_pure(size_t p) {
+        const size_t NQ = nq();
+        Q.assign(NQ, std::vector<H::Fr>(m));
+        nz.clear();
+        for (int cl = 0; cl < 2; cl++) {
+            const size_t y = cl ? m - 1 : 0;
+            bool any = false;
+            for (size_t k = 0; k < NQ; k++) {
+                const H::Fr& sv = sgn_S[(p * 2 + cl) * NQ + k];
+                if (H::detail::is_zero4(sv.l)) continue;
+                Q[k][y] = H::mul(sgn_A[cl], sv); any = true;
+            }
+            if (any) nz.push_back((uint32_t)y);
+        }
+    }
+    // tables of the first mixed phase: A_0 T_0 + A_1 T_1 over the published class tables
+    int load_Q_mixed() {
+        const size_t NQ = nq();
+        for (int cl = 0; cl < 2; cl++)
+            if (!wait_tag(sgn_box[cl].tagc, sgn_box[cl].tag)) { g.chan.abort_dirty = true; return fail(ATLAS_ENODEV, "round channel: no class tables from the device"); }
+        Q.assign(NQ, std::vector<H::Fr>(m));
+        nz.clear();
+        for (size_t y = 0; y < m; y++) {
+            bool any = false;
+            for (size_t k = 0; k < NQ; k++) {
+                const H::Fr &a = sgn_box[0].data[NQ * y + k], &b = sgn_box[1].data[NQ * y + k];
+                const bool za = H::detail::is_zero4(a.l), zb = H::detail::is_zero4(b.l);
+                if (za && zb) continue;
+                Q[k][y] = za ? H::mul(sgn_A[1], b) : zb ? H::mul(sgn_A[0], a) : H::add(H::mul(sgn_A[0], a), H::mul(sgn_A[1], b));
+                any = true;
+            }
+            if (any) nz.push_back((uint32_t)y);
+        }
+        return ATLAS_OK;
+    }
+    // at construction (the caller holds g.mu): scan, wait for the minimum, launch the class tables of phase P.  Leaves sgn_P = 0 and the
+    // ordinary tables of phase 0 when no phase is pure.
+    int sign_setup() {
+        const size_t NQ = nq(), n_vals = PS_SIGN_PMAX * 2 * NQ;
+        hipError_t e = sgn_scratch.alloc(8192 + 2 * sizeof(Fr));
+        if (e != hipSuccess) return fail(ATLAS_ENOMEM, "ps_shout: sign scratch", e);
+        unsigned long long* acc = static_cast<unsigned long long*>(sgn_scratch.p);
+        uint32_t* mn = reinterpret_cast<uint32_t*>(static_cast<char*>(sgn_scratch.p) + 7168);
+        HIP_TRY(hipMemsetAsync(sgn_scratch.p, 0, 8192, g.stream));
+        const uint32_t ph = (uint32_t)phases;
+        HIP_TRY(hipMemsetAsync(mn, 0xFF, 4, g.stream));                                // the minimum starts above any count
+        atlas::Chunk* box = g.chan.alloc(2 * n_vals + 4);
+        const uint32_t tag = g.chan.tag();
+        size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 256) gb = 256;
+        const PsSignOut O{acc, mn, mn + 16, reinterpret_cast<Fr*>(box + 4), box, tag};
+        if (NQ == 6) k_ps_sign_scan<6><<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(d_idx, d_u0, T, (uint32_t)N, (uint32_t)log_m, ph, (uint32_t)bound, O);
+        else k_ps_sign_scan<2><<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(d_idx, d_u0, T, (uint32_t)N, (uint32_t)log_m, ph, 0u, O);
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) return fail(ATLAS_ENODEV, "ps_shout: sign scan", le);
+        if (!wait_tag(box, tag)) { g.chan.abort_dirty = true; return fail(ATLAS_ENODEV, "round channel: no sign scan from the device"); }
+        size_t P = box->d[1];
+        if (P > phases - 1) P = phases - 1;
+        if (P > PS_SIGN_PMAX) P = PS_SIGN_PMAX;
+        if (P == 0) return build_Q(0);
+        sgn_S.assign(reinterpret_cast<const H::Fr*>(box + 4), reinterpret_cast<const H::Fr*>(box + 4) + P * 2 * NQ);
+        sgn_P = P;
+        for (int cl = 0; cl < 2; cl++) {                       // the class tables of phase P: needed 8 P rounds from now
+            atlas::Chunk* tb = g.chan.alloc(2 * NQ * m + 4);
+            std::memset(tb + 4, 0, NQ * m * sizeof(Fr));
+            const uint32_t tg = g.chan.tag();
+            int rc = launch_Q(P, nullptr, 0, QPublish{reinterpret_cast<Fr*>(tb + 4), tb, tg, rows.d_counter}, PsClass{cl, (uint32_t)(N - 1), nullptr});
+            if (rc) return rc;
+            sgn_box[cl] = QBox{tb, reinterpret_cast<const H::Fr*>(tb + 4), tg};
+        }
+        load_Q_pure(0);
+        v.assign(1, H::one());
+        return ATLAS_OK;
+    }
+    // a host-stepped caller (message / ingest with the device half) meets an instance built for the shortcut: the ordinary tables instead
+    int sign_off() {
+        if (!sgn_P) return ATLAS_OK;
+        if (round_next != 0) return fail(ATLAS_ESTATE, "ps_shout: host-stepped call in the middle of a pipelined proof");
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        sgn_P = 0;
+        return build_Q(0);
+    }
     // the launches only: the tables end up at qsum_ptr().  v_prev: fold the finished phase's table into the products on the way
     // (m <= 256); pub: also publish the tables to the host
-    int launch_Q(size_t phase, const Fr* v_prev = nullptr, uint32_t shift_prev = 0, QPublish pub = QPublish{nullptr, nullptr, 0, nullptr}) {
+    int launch_Q(size_t phase, const Fr* v_prev = nullptr, uint32_t shift_prev = 0, QPublish pub = QPublish{nullptr, nullptr, 0, nullptr},
+                 PsClass cls = PsClass{-1, 0u, nullptr}) {
         const uint32_t suffix_len = (uint32_t)((phases - 1 - phase) * log_m);
         const size_t NQ = nq();
         Fr* d_qsum = qsum_ptr();
@@ -444,7 +656,7 @@ struct PsLookup : atlas_instance {
             do {                                                                                                                   \
                 static bool attr_set = false;                                                                                      \
                 if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ps_q_lds<NQv>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * NQv * 64)); attr_set = true; } \
-                k_ps_q_lds<NQv><<<(unsigned)gb, RA_THREADS, lds, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)m, (uint32_t)(BND), acc, v_prev, shift_prev); \
+                k_ps_q_lds<NQv><<<(unsigned)gb, RA_THREADS, lds, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)m, (uint32_t)(BND), acc, v_prev, shift_prev, cls); \
             } while (0)
             if (NQ == 4) PS_Q_LDS(4, 0u);
             else if (NQ == 6) PS_Q_LDS(6, bound);
@@ -470,6 +682,7 @@ struct PsLookup : atlas_instance {
 
     int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
         if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "ps_shout: round out of order");
+        if (sgn_P) { int rc = sign_off(); if (rc) return rc; }
         coeffs.assign(3, H::zero());
         if (round < N) return address_message(round, claim, coeffs);
         std::lock_guard<atlas_rt::Mutex> lk(g.mu);
@@ -646,9 +859,11 @@ struct PsLookup : atlas_instance {
     // with_device = false: the host half only (round channel: the launches were enqueued ahead and take r from its slot)
     int ingest_impl(const atlas_u128_t& r, size_t round, bool with_device) {
         if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "ps_shout: round out of order");
+        if (with_device && sgn_P) { int rc = sign_off(); if (rc) return rc; }
         const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
         if (round < N) {
             const size_t j = round, p = j / log_m;
+            if (p < sgn_P) { sgn_A[0] = H::mul(sgn_A[0], H::sub(H::one(), rf)); sgn_A[1] = H::mul(sgn_A[1], rf); }      // a pure phase: E_p[0], E_p[m - 1] factor by factor
             const size_t half = Q[0].size() / 2;
             if (nz.size() <= 4 * NZ_SPARSE) {                          // few non-empty bins: their pairs only
                 std::vector<uint32_t> low;
@@ -747,7 +962,6 @@ struct PsLookup : atlas_instance {
     // round of a phase: the finished phase's expanding table is rebuilt on the device from its challenge slots (d_v holds two
     // tables of m entries, used alternately), the products are scaled by it and the new phase's Q is built; Q travels to the
     // host through pinned memory (k_ps_q_final's QPublish) and is picked up by that round's finish().  Cycle round c has ra in buf[c & 1].
-    struct QBox { const volatile atlas::Chunk* tagc = nullptr; const H::Fr* data = nullptr; uint32_t tag = 0; };
     std::vector<QBox> qbox;
     PsSlots slots{};
     bool have_finals = false;
@@ -768,8 +982,16 @@ struct PsLookup : atlas_instance {
         if (round >= 1 && round <= N) {                        // remember where the challenge of round - 1 will appear
             const size_t pw = (round - 1) % log_m;
             slots.host[pw] = io.r_host; slots.tag[pw] = io.tag_r;
+            if (round == 1) { sgn_slot0 = io.r_host; sgn_tag0 = io.tag_r; }
         }
         if (round < N && round % log_m != 0) return ATLAS_OK;  // an address round inside a phase launches nothing (56 of the 64 rounds of a 64-bit lookup: no runtime call at all)
+        if (sgn_P && round >= 1 && round <= N && round % log_m == 0 && round / log_m - 1 < sgn_P) return ATLAS_OK;      // a pure phase ends: nothing for the device (PsSign)
+        PsClass cls{-1, (uint32_t)(N - 1), nullptr};
+        if (sgn_P && round >= 1 && round <= N && round % log_m == 0 && round / log_m - 1 == sgn_P) {
+            // the first boundary the device works at: the products still miss the class factor A_s(P) of the pure phases
+            k_ps_class_scalars<<<1, 64, 0, g.stream>>>(sgn_slot0, sgn_tag0, (uint32_t)(sgn_P * log_m), io.abort_flag, g.challenge_mode, sgn_scal());
+            cls.scal = sgn_scal();
+        }
         if (round >= 1 && round <= N && round % log_m == 0) {  // a phase is complete: its table, folded into the products
             const size_t p_done = round / log_m - 1;
             slots.n = (uint32_t)log_m; slots.abort_flag = io.abort_flag; slots.challenge_mode = g.challenge_mode;
@@ -780,11 +1002,11 @@ struct PsLookup : atlas_instance {
                 const size_t p = round / log_m, n_vals = nq() * m;
                 atlas::Chunk* box = g.chan.alloc(2 * n_vals + 4);
                 if (m <= RA_THREADS) std::memset(box + 4, 0, n_vals * sizeof(Fr));      // k_ps_q_final publishes the non-zero residues only
-                int rc = launch_Q(p, vt[log_m & 1], shift_done, QPublish{reinterpret_cast<Fr*>(box + 4), box, io.tag_mail, rows.d_counter});
+                int rc = launch_Q(p, vt[log_m & 1], shift_done, QPublish{reinterpret_cast<Fr*>(box + 4), box, io.tag_mail, rows.d_counter}, cls);
                 if (rc) return rc;
                 qbox[p] = QBox{box, reinterpret_cast<const H::Fr*>(box + 4), io.tag_mail};
             } else {
-                k_ps_scale<<<(unsigned)gbT, RA_THREADS, 0, g.stream>>>(d_idx, vt[log_m & 1], T, shift_done, (uint32_t)(m - 1), rows.buf[0]);
+                k_ps_scale<<<(unsigned)gbT, RA_THREADS, 0, g.stream>>>(d_idx, vt[log_m & 1], T, shift_done, (uint32_t)(m - 1), rows.buf[0], cls);
             }
         }
         if (round >= N) {
@@ -809,7 +1031,11 @@ struct PsLookup : atlas_instance {
             H::gruen_deg2(eq.st.scalar, eq.st.w_cur(), H::mul(s[0], wv), claim, coeffs.data());
             return ATLAS_OK;
         }
-        if (round > 0 && round % log_m == 0) {                 // first round of a phase: its Q tables arrive through pinned memory
+        if (sgn_P && round > 0 && round % log_m == 0 && round / log_m <= sgn_P) {      // a phase whose tables are class sums times two scalars (PsSign)
+            PROF("ps_shout: tables of a sign phase");
+            if (round / log_m < sgn_P) load_Q_pure(round / log_m);
+            else { int rc = load_Q_mixed(); if (rc) return rc; }
+        } else if (round > 0 && round % log_m == 0) {          // first round of a phase: its Q tables arrive through pinned memory
             const QBox& B = qbox[round / log_m];
             if (!B.tagc) return fail(ATLAS_ESTATE, "ps_shout: Q of the phase was not enqueued");
             const auto t0 = std::chrono::steady_clock::now();
@@ -904,7 +1130,10 @@ static int ps_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, si
         k_ps_fill_one<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(P->rows.buf[0], T);
         if (!one_cycle) rc = P->eq.init(reinterpret_cast<const H::Fr*>(r_node_output), log_T);       // (the split eq of the cycle rounds: none here)
     }
-    if (!rc) rc = P->build_Q(0);
+    // (the shortcut serves the round-channel drivers; a host-stepped caller falls back in its first call)
+    static const bool no_sign = getenv("ATLAS_PS_NO_SIGN") != nullptr || getenv("ATLAS_NO_PIPELINE") != nullptr;     // A-B
+    const bool try_sign = (mode == 0 || mode == 2) && !one_cycle && m <= RA_THREADS && phases >= 3 && phases - 1 <= PS_SIGN_PMAX && g.fs_mode == ATLAS_FS_HOST && !no_sign;
+    if (!rc) rc = try_sign ? P->sign_setup() : P->build_Q(0);
     if (rc) { delete P; return rc; }
     *out = P;
     return ATLAS_OK;
