@@ -191,7 +191,8 @@ struct Pipeline {
                 const size_t local = Q - L.offset;
                 const bool bind_prev = local > 0, wait = bind_prev || Q == max_rounds;
                 atlas::Chunk* area = C.alloc(256 * atlas::ch_stride(4));
-                const atlas::RoundIo io = C.io(area, mtag(Q, li), wait ? slot0 + Q - 1 : (size_t)-1, wait ? rtag(Q - 1) : 0, 256);
+                atlas::RoundIo io = C.io(area, mtag(Q, li), wait ? slot0 + Q - 1 : (size_t)-1, wait ? rtag(Q - 1) : 0, 256);
+                io.tag_step = (uint32_t)lanes.size();                // mtag(Q + 1, li) - mtag(Q, li)
                 const hipStream_t lib_stream = g.stream;          // the instance's launches go to its lane's stream
                 g.stream = lane_stream(li);
                 atlas_rt::tl_lane_stream = side ? g.stream : nullptr;

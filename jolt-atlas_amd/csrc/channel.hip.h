@@ -41,7 +41,10 @@ struct RoundIo {              // kernel argument
     uint32_t* abort_flag;     // HBM word; non-zero = some wait gave up, every later launch returns at once
     uint32_t tag_mail;        // tag of the records this launch writes
     uint32_t tag_r;           // tag of the challenge slot this launch waits for
+    uint32_t tag_step;        // a RESIDENT launch that serves several rounds of its instance (the tails): the mail tag of the round after is
+                              // tag_mail + tag_step, its challenge slot r_host + CH_SLOT_CHUNKS under tag_r + 1 (batched.hip hands out both in round order)
 };
+constexpr uint32_t CH_SLOT_CHUNKS = 4;                  // chunks per host challenge slot (Channel::SLOT_CHUNKS)
 
 constexpr uint32_t CH_REPLICA_CHUNKS = 4;               // one 64-byte line per replica
 constexpr uint32_t CH_MAX_REPLICAS = 256;

@@ -19,7 +19,7 @@ struct Channel {
                                                             // records are consumed before the allocator comes round again,
                                                             // because later rounds cannot run until the host has read them
     static constexpr size_t RING = 256;                     // challenge slots (a proof takes one per round: <= 89 for the 64-bit clamp lookup at T = 2^25)
-    static constexpr size_t SLOT_CHUNKS = 4;                                                   // host slot: one line
+    static constexpr size_t SLOT_CHUNKS = atlas::CH_SLOT_CHUNKS;                                                   // host slot: one line
     static constexpr size_t DEV_SLOT_CHUNKS = atlas::CH_MAX_REPLICAS * atlas::CH_REPLICA_CHUNKS;   // 256 HBM replicas of one line
     atlas::Chunk* mail = nullptr;       // pinned
     atlas::Chunk* rslots = nullptr;     // pinned, SLOT_CHUNKS per slot
@@ -75,7 +75,7 @@ struct Channel {
         static const bool host_poll = getenv("ATLAS_CH_HOST_POLL") != nullptr;     // diagnosis: every workgroup polls the host slot, no HBM replicas
         o.r_replicas = host_poll ? 0 : replicas_for(waiters);
         o.abort_flag = d_abort;
-        o.tag_mail = tag_mail; o.tag_r = tag_r;
+        o.tag_mail = tag_mail; o.tag_r = tag_r; o.tag_step = 1;
         return o;
     }
 

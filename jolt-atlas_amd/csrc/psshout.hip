@@ -402,6 +402,78 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_bind_fold_ch(const Fr* __rest
     mail_tail(partials, tail);
 }
 
+// ---- the cycle rounds of at most 2^PS_TAIL_LOG coefficients in ONE resident launch (what k_dot_tail2_f9 is for the dot product).
+// A cycle round at these sizes is a round trip, not arithmetic: as a launch of its own it pays a kernel boundary, the fan-out of the
+// challenge, the arrival counter and the second reduction stage of mail_tail — ~15 us; one workgroup that keeps the row in LDS, polls the
+// round's slot itself and mails its one sum pays the two link crossings and ~3 us.  Tail round i is cycle round c0 + i: wait for the challenge
+// of the round before (slot r_host + i, tag tag_r0 + i), bind the row LowToHigh (the first time from HBM), fold the even coefficients with the
+// split-eq weights of that round, mail one canonical sum under tag_mail0 + i * tag_step at record i.  After the last round the final bind
+// is mailed as record n_rounds (what k_rows_final_ch sends).  Same sums as k_ps_bind_fold_ch: exact arithmetic, another order.
+constexpr uint32_t PS_TAIL_LOG = 11, PS_TAIL_THREADS = 1024;
+struct PsTailArgs {
+    const Fr* src; uint32_t len_src;          // the row as the launch before left it: T >> (c0 - 1) coefficients
+    const Fr* e_out; const Fr* e_in;          // the cached prefix tables (GseDev::d_eout, d_ein)
+    uint8_t ot[16], it[16];                   // table tops of tail round i
+    uint32_t n_rounds;
+    Chunk* mail; const Chunk* r_host; uint32_t* abort_flag;
+    uint32_t tag_mail0, tag_step, tag_r0;
+    int challenge_mode, hi_only;
+};
+__global__ __launch_bounds__(PS_TAIL_THREADS) void k_ps_tail_ch(PsTailArgs A) {
+    extern __shared__ __align__(16) unsigned char ps_tail_raw[];
+    Fr* sv = reinterpret_cast<Fr*>(ps_tail_raw);
+    __shared__ Fr red[PS_TAIL_THREADS / 64];
+    __shared__ uint64_t s_ch[3];
+    __shared__ uint32_t stage[9];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t len = A.len_src;
+    for (uint32_t i = 0; i <= A.n_rounds; i++) {
+        if (tid == 0) {
+            uint64_t l = 0, h = 0;
+            const bool ok = ch_poll_slot<true>(A.r_host + (size_t)i * CH_SLOT_CHUNKS, A.tag_r0 + i, A.abort_flag, l, h);
+            s_ch[0] = l; s_ch[1] = h; s_ch[2] = ok ? 1 : 0;
+        }
+        __syncthreads();
+        if (!s_ch[2]) return;
+        const Fr r = challenge_to_mont(s_ch[0], s_ch[1], A.challenge_mode);
+        const RoundIo io{A.mail, nullptr, nullptr, 1u, A.abort_flag, A.tag_mail0 + i * A.tag_step, 0u, 1u};
+        if (i == A.n_rounds) {                                       // the final claim: the last two coefficients bound
+            if (wave == 0) {
+                Fr v = fe_zero();
+                if (lane == 0) v = bind_pair(sv[0], sv[1], r, A.hi_only != 0);
+                ch_mail_wave_fe(io, i * ch_stride(1), 1, v, stage);
+            }
+            return;
+        }
+        const uint32_t half = len / 2;                              // coefficients after this bind (<= 2^PS_TAIL_LOG)
+        Fr b[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint32_t j = tid + u * PS_TAIL_THREADS;
+            if (j < half) b[u] = i == 0 ? bind_pair(fe_load(A.src + 2 * j), fe_load(A.src + 2 * j + 1), r, A.hi_only != 0)
+                                        : bind_pair(sv[2 * j], sv[2 * j + 1], r, A.hi_only != 0);
+        }
+        __syncthreads();                                            // every pair has been read before its slot is overwritten
+#pragma unroll
+        for (int u = 0; u < 2; u++) { const uint32_t j = tid + u * PS_TAIL_THREADS; if (j < half) sv[j] = b[u]; }
+        __syncthreads();
+        const uint32_t n_groups = half / 2, in_bits = A.it[i];
+        const Fr* eo = A.e_out + (((size_t)1 << A.ot[i]) - 1);
+        const Fr* ei = A.e_in + (((size_t)1 << in_bits) - 1);
+        Fr acc = fe_zero();
+        if (tid < n_groups) acc = fr_mul(fr_mul(fe_load(eo + (tid >> in_bits)), fe_load(ei + (tid & ((1u << in_bits) - 1u)))), sv[2 * tid]);
+        acc = fr_wave_sum(acc);
+        if (lane == 0) red[wave] = acc;
+        __syncthreads();
+        if (wave == 0) {
+            Fr t = lane < PS_TAIL_THREADS / 64 ? red[lane] : fe_zero();
+            t = fr_wave_sum(t);
+            ch_mail_wave_fe(io, i * ch_stride(1), 1, t, stage);
+        }
+        len = half;
+    }
+}
+
 // ---- round-channel pieces (instance.hpp): the expanding table v of a phase is kept on the device, one challenge at a
 // time, so that the phase boundary (scale the products by v, build the next Q) needs nothing from the host
 // ExpandingTable::update, HighToLow (expanding_table.rs:62-88), for ALL challenges of a phase in one launch: the table
@@ -969,6 +1041,7 @@ struct PsLookup : atlas_instance {
     bool pipelined() const override { return !one_cycle && log_m <= 11 && N + log_T <= atlas_rt::Channel::RING / 2; }
     bool wide_wait(size_t round) const override {                 // address rounds and the first cycle round: only the one-workgroup table rebuild waits
         if (round <= N || round >= rounds()) return false;
+        if (tail_c0() && round - N >= tail_c0()) return false;  // the resident tail: one workgroup
         const size_t n_groups = (T >> (round - N)) / 2;
         return (n_groups + RA_THREADS - 1) / RA_THREADS > WIDE_WAIT_WGS;
     }
@@ -1008,6 +1081,27 @@ struct PsLookup : atlas_instance {
             } else {
                 k_ps_scale<<<(unsigned)gbT, RA_THREADS, 0, g.stream>>>(d_idx, vt[log_m & 1], T, shift_done, (uint32_t)(m - 1), rows.buf[0], cls);
             }
+        }
+        if (round >= N && tail_c0() && round - N >= tail_c0()) {        // the resident tail (k_ps_tail_ch): launched with its first round
+            const size_t c0 = tail_c0(), c = round - N;
+            if (c == c0) {
+                PsTailArgs A;
+                A.src = rows.buf[(c0 - 1) & 1]; A.len_src = (uint32_t)(T >> (c0 - 1));
+                A.e_out = eq.d_eout; A.e_in = eq.d_ein;
+                A.n_rounds = (uint32_t)(log_T - c0);
+                for (size_t i = 0; i < A.n_rounds; i++) { size_t ot, it; eq.st.tops_after(c0 + i, ot, it); A.ot[i] = (uint8_t)ot; A.it[i] = (uint8_t)it; }
+                A.mail = io.mail; A.r_host = io.r_host; A.abort_flag = io.abort_flag;
+                A.tag_mail0 = io.tag_mail; A.tag_step = io.tag_step; A.tag_r0 = io.tag_r;
+                A.challenge_mode = g.challenge_mode; A.hi_only = g.challenge_mode == 0 ? 1 : 0;
+                static bool attr_set = false;
+                if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ps_tail_ch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(Fr) << PS_TAIL_LOG))); attr_set = true; }
+                k_ps_tail_ch<<<1, PS_TAIL_THREADS, sizeof(Fr) << PS_TAIL_LOG, g.stream>>>(A);
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess) return fail(ATLAS_ENODEV, "ps_shout: tail launch", e);
+                tail_mail = io.mail;
+            }
+            mail.base = tail_mail + (c - c0) * atlas::ch_stride(1); mail.blocks = 1; mail.n_vals = 1;
+            return ATLAS_OK;
         }
         if (round >= N) {
             const size_t c = round - N, len = T >> c, n_groups = len / 2;
@@ -1058,7 +1152,20 @@ struct PsLookup : atlas_instance {
     double t_qwait = 0, t_addr = 0;
     static bool ps_trace() { static const bool on = getenv("ATLAS_TRACE") != nullptr; return on; }
     int host_ingest(const atlas_u128_t& r, size_t round) override { return ingest_impl(r, round, false); }
+    // ---- the resident tail: cycle rounds c0 .. log_T - 1 and the final bind in one launch; 0 = none (ATLAS_PS_NO_TAIL=1 is the A-B)
+    atlas::Chunk* tail_mail = nullptr;
+    size_t tail_c0() const {
+        static const bool off = getenv("ATLAS_PS_NO_TAIL") != nullptr;
+        if (off || log_T < 2 || one_cycle || io_tag_step_unknown) return 0;
+        return log_T > PS_TAIL_LOG + 1 ? log_T - PS_TAIL_LOG : 1;      // the first bind of the tail leaves at most 2^PS_TAIL_LOG coefficients
+    }
+    bool io_tag_step_unknown = false;
     int enqueue_finals(const atlas::RoundIo& io, atlas_mail_ref& mail) override {
+        if (tail_c0()) {                                            // the tail mails the final claim as its last record
+            if (!tail_mail) return fail(ATLAS_ESTATE, "ps_shout: finals before the tail");
+            mail.base = tail_mail + (log_T - tail_c0()) * atlas::ch_stride(1); mail.blocks = 1; mail.n_vals = 1; mail.radix = 32; mail.shl = 0;
+            return ATLAS_OK;
+        }
         k_rows_final_ch<<<1, 64, 0, g.stream>>>(rows.buf[(log_T - 1) & 1], T >> (log_T - 1), 1u, ChanIo{io, g.challenge_mode}, g.challenge_mode == 0 ? 1 : 0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(ATLAS_ENODEV, "ps_shout: launch", e);
