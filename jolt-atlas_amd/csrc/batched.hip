@@ -124,6 +124,7 @@ struct Pipeline {
     // rounds are enqueued while the device works on earlier ones instead of all before the first collect.
     static constexpr size_t LOOKAHEAD = 3;
     size_t next_enqueue = 0;
+    size_t next_enqueue_launched = 0;       // bumped by every enqueue that may have launched something (atlas_instance::silent_round says which do not)
     // The instances of a batch are independent until the host combines their round polynomials, and their kernels at
     // lookup sizes (T = 2^16) are low-occupancy launches: each lane gets a stream of its own so that RaVirtual's products
     // and Booleanity's folds overlap on the device instead of queueing behind each other.  Lane streams start behind
@@ -199,6 +200,7 @@ struct Pipeline {
                 static const bool no_gate = getenv("ATLAS_LANE_NO_GATE") != nullptr;                     // diagnosis only (tools/bisect_lanes.sh)
                 if (side && wait && !no_gate && L.inst->wide_wait(local)) atlas::k_ch_gate<<<1, 64, 0, g.stream>>>(io);      // the lane's wide launches start behind their challenge (channel.hip.h)
                 int rc = Q < max_rounds ? L.inst->enqueue(local, io, bind_prev, L.mails[local]) : L.inst->enqueue_finals(io, L.fin);
+                if (Q >= max_rounds || !L.inst->silent_round(local)) next_enqueue_launched++;
                 g.stream = lib_stream;
                 atlas_rt::tl_lane_stream = nullptr;
                 if (rc) { abort_from(0); drain(); return rc; }
@@ -339,6 +341,7 @@ int atlas_instance_prove(atlas_instance_t inst, const atlas_fr_t* input_claim, a
         double tp[5] = {0, 0, 0, 0, 0};
         auto nowp = [] { return std::chrono::steady_clock::now(); };
         auto usp = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        size_t queried_at = 0;
         for (size_t round = 0; round < n; round++) {
             H::Fr sums[16];
             const auto q0 = nowp();
@@ -364,14 +367,20 @@ int atlas_instance_prove(atlas_instance_t inst, const atlas_fr_t* input_claim, a
             challenges[round].lo = lo; challenges[round].hi = hi;
             P.C.publish(P.slot0 + round, P.rtag(round), lo, hi);
             if (atlas_rt::Prof::on()) atlas_rt::Prof::get().add("instance_prove: transcript + publish", atlas_rt::Prof::now_us() - pt0);
-            if ((round & 7) == 7) (void)hipStreamQuery(g.stream);   // lets the runtime retire completed launches while the device works (2.5 us)
+            // lets the runtime retire completed launches while the device works — when there are any: a query costs 2.5-6 us of this thread,
+            // and 56 of the 64 address rounds of a 64-bit lookup (all of them in its pure phases) launch nothing
+            if ((round & 7) == 7 && P.next_enqueue_launched != queried_at) { (void)hipStreamQuery(g.stream); queried_at = P.next_enqueue_launched; }
             prev = eval_with_challenge(c, H::challenge_to_fr(lo, hi, g.challenge_mode));
             const auto q3 = nowp();
             { PROF("instance_prove: host_ingest"); rc = inst->host_ingest(challenges[round], round); }
             const auto q4 = nowp();
             if (!rc) { PROF("instance_prove: advance (enqueue)"); rc = P.advance(round + 1); }
             if (rc) { P.abort_from(round + 1); (void)hipStreamSynchronize(g.stream); return rc; }
-            if (ptrace) { const auto q5 = nowp(); tp[0] += usp(q0, q1); tp[1] += usp(q1, q2); tp[2] += usp(q2, q3); tp[3] += usp(q3, q4); tp[4] += usp(q4, q5); }
+            if (ptrace) {
+                const auto q5 = nowp(); tp[0] += usp(q0, q1); tp[1] += usp(q1, q2); tp[2] += usp(q2, q3); tp[3] += usp(q3, q4); tp[4] += usp(q4, q5);
+                static const bool per_round = getenv("ATLAS_TRACE_ROUNDS") != nullptr;
+                if (per_round) fprintf(stderr, "[atlas trace]   round %3zu: wait %6.1f  finish %6.1f  transcript %5.1f  ingest %5.1f  enqueue %5.1f us\n", round, usp(q0, q1), usp(q1, q2), usp(q2, q3), usp(q3, q4), usp(q4, q5));
+            }
         }
         if (ptrace)
             fprintf(stderr, "[atlas trace] instance_prove (round channel) %zu rounds: wait for sums %.1f us, finish %.1f, transcript + publish %.1f, host_ingest %.1f, enqueue %.1f\n",
@@ -435,6 +444,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
     for (size_t i = 0; i < n; i++) claim[i] = mul_pow2(b->inst[i].input_claim, max_rounds - b->inst[i].rounds);
 
     Pipeline PL;
+    size_t batch_queried_at = 0;
     bool piped = false;
     {
         std::vector<atlas_instance*> v;
@@ -554,6 +564,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
     }
     for (size_t round = 0; round < max_rounds; round++) {
         const size_t remaining = max_rounds - round;
+        const auto tr_round0 = std::chrono::steady_clock::now();
         std::vector<std::vector<H::Fr>> polys(n);
         for (size_t i = 0; i < n; i++) {
             Instance& I = b->inst[i];
@@ -603,7 +614,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         uint64_t lo, hi;
         H::tr_challenge_u128(T, lo, hi);                                              // challenge_scalar_optimized :119
         challenges[round].lo = lo; challenges[round].hi = hi;
-        if (piped) { PL.C.publish(PL.slot0 + round, PL.rtag(round), lo, hi); if ((round & 7) == 7) PL.query(); }
+        if (piped) { PL.C.publish(PL.slot0 + round, PL.rtag(round), lo, hi); if ((round & 7) == 7 && PL.next_enqueue_launched != batch_queried_at) { PL.query(); batch_queried_at = PL.next_enqueue_launched; } }
         const H::Fr r = H::challenge_to_fr(lo, hi, g.challenge_mode);
         const double pf2 = atlas_rt::Prof::on() ? atlas_rt::Prof::now_us() : 0;
         for (size_t i = 0; i < n; i++) claim[i] = eval_with_challenge(polys[i], r);    // :123-126
@@ -631,6 +642,13 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
             int rc = PL.advance(round + 1);       // (advance drains on its own failures)
             if (rc) return rc;
             if (trace) t_enq += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - te0).count();
+            static const bool per_round = getenv("ATLAS_TRACE_ROUNDS") != nullptr;
+            if (trace && per_round) {
+                const auto te1 = std::chrono::steady_clock::now();
+                fprintf(stderr, "[atlas trace]   batch round %3zu: collect+finish (all lanes) %6.1f  combine..ingest %5.1f  enqueue %5.1f us\n", round,
+                        std::chrono::duration<double, std::micro>(tf0 - tr_round0).count(), std::chrono::duration<double, std::micro>(te0 - tf0).count(),
+                        std::chrono::duration<double, std::micro>(te1 - te0).count());
+            }
         }
     }
     *max_rounds_out = max_rounds;

@@ -51,6 +51,8 @@ struct atlas_instance {
     // instance of the batch has made the call for the round on the driver's thread (it does the work the instances share: launches, copies)?
     // The rows of a OneHotPool do: their round arithmetic is per row.  (batched.hip: batches of thousands of instances)
     virtual bool host_parallel() const { return false; }
+    // does enqueue(round) launch nothing at all (host-only rounds: the driver then has nothing new for the runtime to retire)?
+    virtual bool silent_round(size_t /*round*/) const { return false; }
     static constexpr size_t WIDE_WAIT_WGS = 256;
     virtual bool wide_wait(size_t /*round*/) const { return true; }
 };

@@ -380,7 +380,7 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_fold(const Fr* __restrict__ r
     acc[0] = fe_zero();
     for (size_t j = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; j < n_groups; j += (size_t)gridDim.x * RA_THREADS)
         acc[0] = fr_add(acc[0], fr_mul(gse_weight(E, j), fe_load(ra + 2 * j)));
-    block_reduce_store<1>(acc, partials);
+    block_reduce_put<1>(acc, partials, tail);
     mail_tail(partials, tail);
 }
 // a cycle round in ONE launch: wait for the challenge, bind ra (src of 4 n_groups values -> dst of 2 n_groups), fold the
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_bind_fold_ch(const Fr* __rest
         fe_store(dst + 2 * j + 1, b1);
         acc[0] = fr_add(acc[0], fr_mul(gse_weight(E, j), b0));
     }
-    block_reduce_store<1>(acc, partials);
+    block_reduce_put<1>(acc, partials, tail);
     mail_tail(partials, tail);
 }
 
@@ -1045,6 +1045,10 @@ struct PsLookup : atlas_instance {
         const size_t n_groups = (T >> (round - N)) / 2;
         return (n_groups + RA_THREADS - 1) / RA_THREADS > WIDE_WAIT_WGS;
     }
+    bool silent_round(size_t round) const override {
+        if (round < N) return round % log_m != 0 || round == 0 || (sgn_P && round / log_m - 1 < sgn_P);
+        return tail_c0() && round - N > tail_c0();
+    }
     int enqueue(size_t round, const atlas::RoundIo& io, bool bind_prev, atlas_mail_ref& mail) override {
         if (round >= rounds() || (round > 0) != bind_prev) return fail(ATLAS_ESTATE, "ps_shout: enqueue out of order");
         const ChanIo cio{io, g.challenge_mode};
@@ -1108,7 +1112,7 @@ struct PsLookup : atlas_instance {
             size_t blocks = (n_groups + RA_THREADS - 1) / RA_THREADS; if (blocks > 2048) blocks = 2048;
             size_t ot, it;
             eq.st.tops_after(c, ot, it);
-            const MailTail tail{io, rows.d_counter, (uint32_t)blocks, 1u};
+            const MailTail tail{io, rows.d_counter, (uint32_t)blocks, 1u, rows.tg()};
             if (c == 0) k_ps_fold<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(rows.buf[0], eq.view_at(ot, it), n_groups, rows.partials, tail);
             else k_ps_bind_fold_ch<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(rows.buf[(c - 1) & 1], rows.buf[c & 1], eq.view_at(ot, it), n_groups, rows.partials, cio,
                                                                               g.challenge_mode == 0 ? 1 : 0, tail);

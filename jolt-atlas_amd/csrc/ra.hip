@@ -109,7 +109,9 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_prod_f9_col(const Fr* __restr
         F9 t = red9[0];
 #pragma unroll
         for (int w = 1; w < RA_THREADS / 64; w++) t = f9_add(t, red9[w]);
-        fe_store(partials + (size_t)blockIdx.x * D + k, f9_canon<P9>(f9_reduce_lazy<P9>(f9_norm(t))));
+        const Fr v = f9_canon<P9>(f9_reduce_lazy<P9>(f9_norm(t)));
+        if (tail.tagged) tail_put(tail, blockIdx.x, (uint32_t)k, v);
+        else fe_store(partials + (size_t)blockIdx.x * D + k, v);
     }
     mail_tail(partials, tail);
 }
@@ -233,7 +235,9 @@ __global__ __launch_bounds__(RA_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         int64_t t[9];
 #pragma unroll
         for (int l = 0; l < 9; l++) t[l] = (int64_t)cols[threadIdx.x][l];
-        fe_store(partials + (size_t)blockIdx.x * 16 + threadIdx.x, f9_canon<P9>(f9_reduce_i64<P9>(t)));
+        const Fr v = f9_canon<P9>(f9_reduce_i64<P9>(t));
+        if (tail.tagged) tail_put(tail, blockIdx.x, threadIdx.x, v);
+        else fe_store(partials + (size_t)blockIdx.x * 16 + threadIdx.x, v);
     }
     RA_STAMP(4)
     mail_tail(partials, tail);
@@ -311,7 +315,9 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_bind_prod_f9(const Fr* __rest
 #pragma unroll
             for (int l = 0; l < 9; l++) t[l] += (int64_t)sh_red[q][threadIdx.x].l[l];
         }
-        fe_store(partials + (size_t)blockIdx.x * D + threadIdx.x, f9_canon<P9>(f9_reduce_i64<P9>(t)));
+        const Fr v = f9_canon<P9>(f9_reduce_i64<P9>(t));
+        if (tail.tagged) tail_put(tail, blockIdx.x, threadIdx.x, v);
+        else fe_store(partials + (size_t)blockIdx.x * D + threadIdx.x, v);
     }
     mail_tail(partials, tail);
 }
@@ -361,7 +367,9 @@ __global__ __launch_bounds__(RA_THREADS) void k_bool_fold(const Fr* __restrict__
         F9 s = red9[0][threadIdx.x];
 #pragma unroll
         for (int w = 1; w < RA_THREADS / 64; w++) s = f9_add(s, red9[w][threadIdx.x]);
-        fe_store(partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + threadIdx.x, f9_canon<P9>(f9_reduce_lazy<P9>(f9_norm(s))));
+        const Fr v = f9_canon<P9>(f9_reduce_lazy<P9>(f9_norm(s)));
+        if (tail.tagged) tail_put(tail, blockIdx.y * gridDim.x + blockIdx.x, threadIdx.x, v);
+        else fe_store(partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + threadIdx.x, v);
     }
     mail_tail(partials, tail);
 }
@@ -416,7 +424,9 @@ __global__ __launch_bounds__(RA_THREADS) void k_bool_bind_fold(const Fr* __restr
         F9 s = red9[0][threadIdx.x];
 #pragma unroll
         for (int w = 1; w < RA_THREADS / 64; w++) s = f9_add(s, red9[w][threadIdx.x]);
-        fe_store(partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + threadIdx.x, f9_canon<P9>(f9_reduce_lazy<P9>(f9_norm(s))));
+        const Fr v = f9_canon<P9>(f9_reduce_lazy<P9>(f9_norm(s)));
+        if (tail.tagged) tail_put(tail, blockIdx.y * gridDim.x + blockIdx.x, threadIdx.x, v);
+        else fe_store(partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + threadIdx.x, v);
     }
     mail_tail(partials, tail);
 }
@@ -465,6 +475,7 @@ void launch_prod(const Fr* buf, size_t stride, Fr* partials, const SplitEqView& 
         return;
     }
     constexpr int KA = D < 8 ? D : 8;
+    tail.tagged = nullptr;                     // (its rows are assembled by two launches: plain rows behind the arrival counter)
     k_ra_prod_f9<D, 0, KA><<<blocks, RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, D > 8 ? none : tail);
     if constexpr (D > 8)
         k_ra_prod_f9<D, 8, D - 8><<<blocks, RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, tail);   // mails all D columns
@@ -544,7 +555,7 @@ struct RaVirtual : atlas_instance {
         if (fused(round)) {                                       // bind + product in one launch (k_ra_bind_prod_f9)
             const unsigned fb = (unsigned)((n_groups + RA_FUSE_PAIRS - 1) / RA_FUSE_PAIRS);
             k_ra_bind_prod_f9<<<fb, RA_THREADS, 0, g.stream>>>(rows.buf[(round - 1) & 1], T >> (round - 1), rows.buf[round & 1], len, (uint32_t)rows.d, eq.view_at(ot, it),
-                                                               n_groups, rows.partials, cio, g.challenge_mode == 0 ? 1 : 0, MailTail{io, rows.d_counter, fb, (uint32_t)rows.d});
+                                                               n_groups, rows.partials, cio, g.challenge_mode == 0 ? 1 : 0, MailTail{io, rows.d_counter, fb, (uint32_t)rows.d, rows.tg()});
         } else {
             if (bind_prev) {
                 size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
@@ -552,7 +563,7 @@ struct RaVirtual : atlas_instance {
                                                                                               cio, g.challenge_mode == 0 ? 1 : 0);
             }
             unsigned blocks = (unsigned)((n_groups + RA_THREADS - 1) / RA_THREADS);
-            int rc = launch_prod_d(rows.d, rows.buf[round & 1], len, rows.partials, eq.view_at(ot, it), n_groups, blocks, MailTail{io, rows.d_counter, 0, 0});
+            int rc = launch_prod_d(rows.d, rows.buf[round & 1], len, rows.partials, eq.view_at(ot, it), n_groups, blocks, MailTail{io, rows.d_counter, 0, 0, rows.tg()});
             if (rc) return rc;
         }
         hipError_t e = hipGetLastError();
@@ -687,7 +698,7 @@ struct Booleanity : atlas_instance {
         size_t blocks = (n_groups + RA_THREADS - 1) / RA_THREADS; if (blocks > 2048) blocks = 2048;
         static const size_t split_log = [] { const char* e = getenv("ATLAS_BOOL_SPLIT_LOG"); int v = e ? atoi(e) : 0; return (size_t)(v >= 8 && v <= 24 ? v : 13); }();   // experiments
         const unsigned ysplit = n_groups <= ((size_t)1 << split_log) ? (unsigned)d : 1u;   // latency regime: one row per thread
-        const MailTail tail = io ? MailTail{*io, rows.d_counter, (uint32_t)(blocks * ysplit), 2u} : MailTail{{}, nullptr, 0, 0};
+        const MailTail tail = io ? MailTail{*io, rows.d_counter, (uint32_t)(blocks * ysplit), 2u, rows.tg()} : MailTail{{}, nullptr, 0, 0};
         static const bool no_tail = getenv("ATLAS_NO_MAIL_TAIL") != nullptr;  // diagnosis (tools/stress_lanes.py)
         if (no_tail && io) {
             k_bool_fold<<<dim3((unsigned)blocks, ysplit), RA_THREADS, 0, g.stream>>>(buf, stride, (uint32_t)d, d_gammas, E, n_groups, rows.partials, MailTail{{}, nullptr, 0, 0});
@@ -785,7 +796,7 @@ struct Booleanity : atlas_instance {
             const unsigned fb = (unsigned)((2 * n_groups + RA_THREADS - 1) / RA_THREADS);       // two lanes per pair
             k_bool_bind_fold<<<dim3(fb, (unsigned)d), RA_THREADS, 0, g.stream>>>(rows.buf[(p - 1) & 1], T >> (p - 1), rows.buf[p & 1], len, d_gammas, D.view_at(ot, it), n_groups,
                                                                                 rows.partials, cio, g.challenge_mode == 0 ? 1 : 0,
-                                                                                MailTail{io, rows.d_counter, (uint32_t)(fb * d), 2u});
+                                                                                MailTail{io, rows.d_counter, (uint32_t)(fb * d), 2u, rows.tg()});
         } else
             launch_fold(rows.buf[p & 1], len, D.view_at(ot, it), n_groups, &io);
         hipError_t e = hipGetLastError();

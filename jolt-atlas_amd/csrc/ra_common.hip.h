@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -106,8 +107,77 @@ struct MailTail {
     RoundIo io;
     uint32_t* counter;
     uint32_t n_rows, K;
+    Chunk* tagged = nullptr;     // != null: the tagged-row protocol below (tail_put / tail_reduce) instead of the arrival counter
 };
+
+// The same hand-over WITHOUT the arrival counter.  Behind the counter every workgroup pays an agent-scope release fence (the dirty lines of
+// its XCD's L2 written back) and a read-modify-write of one address: ~0.2 us per workgroup, one after the other — 120 us for the 512
+// workgroups of a one-hot round of 2^12 pairs, the whole round.  Here a partial value travels like mail does to the host: three 16-byte
+// chunks {payload words, tag}, each ONE device-scope store (a reader that sees the tag sees the payload: no fence), into a row area of HBM;
+// workgroup (0, 0) — once its own values are out — polls the n_rows x K values with device-scope loads, adds them word by word (32-bit words
+// of canonical residues in 64-bit sums), reduces once per column and mails the K sums.  The tag is the launch's mail tag: it never repeats,
+// so the area needs no clearing.  A value costs 48 bytes instead of 32.
+__device__ __forceinline__ void tail_put(const MailTail& tail, uint32_t row, uint32_t k, const Fr& v) {
+    if (!tail.tagged) return;
+    Chunk* c = tail.tagged + ((size_t)row * tail.K + k) * 3;
+    const uint32_t tag = tail.io.tag_mail;
+    ch_store_dev(c, ch_u32x4{v.v[0], v.v[1], v.v[2], tag});
+    ch_store_dev(c + 1, ch_u32x4{v.v[3], v.v[4], v.v[5], tag});
+    ch_store_dev(c + 2, ch_u32x4{v.v[6], v.v[7], 0u, tag});
+}
+// every thread of every workgroup calls this last; blockDim.x = RA_THREADS
+__device__ __forceinline__ void tail_reduce(const MailTail& tail) {
+    if (!tail.tagged || blockIdx.x != 0 || blockIdx.y != 0) return;
+    __shared__ unsigned long long tr_sm[RA_THREADS][3];
+    __shared__ uint32_t tr_bad;
+    __shared__ uint32_t tr_stage[9 * 16];
+    const uint32_t nchunk = 3 * tail.K, n_grp = RA_THREADS / nchunk;           // K <= 16: at least 5 row groups
+    const uint32_t c = threadIdx.x % nchunk, grp = threadIdx.x / nchunk, tag = tail.io.tag_mail;
+    if (threadIdx.x == 0) tr_bad = 0;
+    __syncthreads();
+    unsigned long long s0 = 0, s1 = 0, s2 = 0;
+    if (grp < n_grp) {
+        const uint64_t t0 = wall_clock64();
+        for (uint32_t row = grp; row < tail.n_rows; row += n_grp) {
+            const Chunk* p = tail.tagged + (size_t)row * nchunk + c;
+            ch_u32x4 x = ch_load_dev(p);
+            uint32_t spins = 0;
+            while (x.w != tag) {
+                if ((++spins & 63u) == 0 && (__hip_atomic_load(tail.io.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > CH_TIMEOUT_TICKS)) { tr_bad = 1; break; }
+                __builtin_amdgcn_s_sleep(2);
+                x = ch_load_dev(p);
+            }
+            if (x.w != tag) break;
+            s0 += x.x; s1 += x.y; s2 += x.z;
+        }
+    }
+    tr_sm[threadIdx.x][0] = s0; tr_sm[threadIdx.x][1] = s1; tr_sm[threadIdx.x][2] = s2;
+    __syncthreads();
+    if (tr_bad) return;                                                       // a workgroup of this launch gave up (abort): nothing to mail
+    if (threadIdx.x < 64) {
+        Fr res = fe_zero();
+        if (threadIdx.x < tail.K) {
+            // value k: word w sits in chunk 3 k + w / 3, component w % 3; sum over the row groups, then V = lo + hi 2^256 -> residue
+            Fr lo, hi, r2;
+            unsigned long long carry = 0;
+#pragma unroll
+            for (int w = 0; w < 8; w++) {
+                unsigned long long a = 0;
+                for (uint32_t g2 = 0; g2 < n_grp; g2++) a += tr_sm[g2 * nchunk + 3 * threadIdx.x + w / 3][w % 3];
+                const unsigned long long t = carry + (a & 0xffffffffull);
+                lo.v[w] = (uint32_t)t;
+                carry = (t >> 32) + (a >> 32);
+            }
+#pragma unroll
+            for (int w = 0; w < 8; w++) { hi.v[w] = 0; r2.v[w] = FrParams::r2(w); }
+            hi.v[0] = (uint32_t)carry; hi.v[1] = (uint32_t)(carry >> 32);
+            res = fr_add(fr_mul(lo, fr_one()), fr_mul(hi, r2));
+        }
+        ch_mail_wave_fe(tail.io, 0, tail.K, res, tr_stage);
+    }
+}
 __device__ __forceinline__ void mail_tail(const Fr* partials, const MailTail& tail) {
+    if (tail.tagged) { tail_reduce(tail); return; }     // (the values went out through tail_put)
     if (!tail.counter) return;
     __shared__ uint32_t s_last;
     __threadfence();                                   // this workgroup's row is visible before it is counted
@@ -125,6 +195,25 @@ __device__ __forceinline__ void mail_tail(const Fr* partials, const MailTail& ta
     if (!s_last) return;
     __threadfence();                                   // ... and the rows of the others before they are read
     col_reduce_mail_body(partials, tail.n_rows, tail.K, tail.io);
+}
+
+// block_reduce_store<DEG> (sumcheck_kernels.hip.h) with the workgroup's row also handed to the tagged-row protocol (row = blockIdx.x)
+template <int DEG>
+__device__ __forceinline__ void block_reduce_put(Fr acc[DEG], Fr* partials, const MailTail& tail) {
+    __shared__ Fr red[RA_THREADS / 64][DEG];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        Fr s = fr_wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < DEG) {
+        Fr s = red[0][threadIdx.x];
+        for (int w = 1; w < RA_THREADS / 64; w++) s = fr_add(s, red[w][threadIdx.x]);
+        if (tail.tagged) tail_put(tail, blockIdx.x, threadIdx.x, s);
+        else fe_store(partials + (size_t)blockIdx.x * DEG + threadIdx.x, s);
+    }
 }
 
 // the last bind (rows of two coefficients -> the final claims), mailed one value per record
@@ -221,8 +310,11 @@ struct RaRows {
     size_t stride[2] = {0, 0};
     int cur = 0;
     Fr* partials = nullptr;     // (ceil(T/2 / (RA_THREADS / 2)) + 1) * max(d, 2) Fr
+    atlas::Chunk* tagged = nullptr;  // the tagged-row area behind them (tail_put): 48 bytes per partial value
     uint32_t* d_counter = nullptr;   // arrival counter of mail_tail (zero between launches)
     size_t K = 0;
+    static bool tagged_off() { static const bool v = getenv("ATLAS_NO_TAGGED_ROWS") != nullptr; return v; }      // A-B: the arrival counter
+    atlas::Chunk* tg() const { return tagged_off() ? nullptr : tagged; }
 
     int alloc(size_t d_, size_t T, size_t k_min = 2) {     // K = width of a row of partial sums
         d = d_; len = T; K = d > k_min ? d : k_min;
@@ -230,7 +322,9 @@ struct RaRows {
         HIP_TRY(hipMalloc(&buf[1], d * (T > 1 ? T / 2 : 1) * sizeof(Fr)));
         stride[0] = T; stride[1] = T > 1 ? T / 2 : 1;
         const size_t blocks = (T / 2 + RA_THREADS / 2 - 1) / (RA_THREADS / 2) + 1;       // a row per RA_THREADS / 2 pairs: the split product of d = 16 (ra.hip)
-        HIP_TRY(hipMalloc(&partials, (blocks * K > 8192 ? blocks * K : 8192) * sizeof(Fr)));   // room for the row-split launches of short instances (k_ra_bind_prod_f9: 512 rows of 16)
+        const size_t cap = blocks * K > 8192 ? blocks * K : 8192;                                // room for the row-split launches of short instances (k_ra_bind_prod_f9: 512 rows of 16)
+        HIP_TRY(hipMalloc(&partials, cap * sizeof(Fr) + cap * 3 * sizeof(atlas::Chunk)));
+        tagged = reinterpret_cast<atlas::Chunk*>(partials + cap);
         HIP_TRY(hipMalloc(&d_counter, MAIL_TAIL_COUNTER_BYTES));
         HIP_TRY(hipMemsetAsync(d_counter, 0, MAIL_TAIL_COUNTER_BYTES, g.stream));
         return ATLAS_OK;

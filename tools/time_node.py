@@ -6,7 +6,7 @@ import jolt_atlas_amd as A
 from jolt_atlas_amd import node as NODE
 A.init(0)
 rng = np.random.default_rng(14)
-m, k, n, S = 16, 1024, 4096, 14
+m, k, n, S = [int(x) for x in os.environ.get("DIMS", "16,1024,4096,14").split(",")]
 tA = A.TensorI32(rng.integers(-(1 << 14), 1 << 14, size=(m, k), dtype=np.int64).astype(np.int32))
 tB = A.TensorI32(rng.integers(-(1 << 14), 1 << 14, size=(k, n), dtype=np.int64).astype(np.int32))
 r0 = A.random_fr(16, 0xE1)
