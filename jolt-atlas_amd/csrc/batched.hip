@@ -478,17 +478,27 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         std::vector<std::vector<H::Fr>> polys(n);
         std::vector<int> rcs(HT->threads(), ATLAS_OK);
         const auto q0 = tnow();
-        // compute_message: the constant members and the serial ones here, then the first parallel one, then the rest on the workers
-        bool first_done = false;
+        // compute_message: the constant members and the serial ones here; for the parallel ones first everything they share (a pool's launches
+        // of the round — whichever of its rows is in its cycle phase, however many pools the batch holds) on THIS thread, then the per-member
+        // arithmetic on the workers, which never touch the device
         std::vector<size_t> todo;
         todo.reserve(n);
         for (size_t i = 0; i < n; i++) {
             Instance& I = b->inst[i];
             if (remaining > I.rounds) { polys[i] = {mul_pow2(I.input_claim, remaining - I.rounds - 1)}; continue; }
-            if (par[i] && first_done) { todo.push_back(i); continue; }
+            if (par[i]) {
+                int rc = I.inst->shared_message_step(round - (max_rounds - I.rounds));
+                if (rc) return rc;
+                todo.push_back(i);
+                continue;
+            }
             int rc = I.inst->message(round - (max_rounds - I.rounds), claim[i], polys[i]);
             if (rc) return rc;
-            if (par[i]) first_done = true;
+        }
+        if (g.pending_async) {                                   // one wait for everything the shared steps launched without waiting
+            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+            g.pending_async = 0;
+            HIP_TRY(hipStreamSynchronize(g.stream));
         }
         const auto q1 = tnow();
         HT->parallel_for(todo.size(), [&](size_t lo, size_t hi, size_t part) {
@@ -497,7 +507,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
                 rcs[part] = I.inst->message(round - (max_rounds - I.rounds), claim[todo[q]], polys[todo[q]]);
             }
         });
-        for (int rc : rcs) if (rc) return rc;
+        for (int rc : rcs) if (rc) return fail(rc, "batched_prove: a member's compute_message failed on a worker thread");
         const auto q2 = tnow();
         // batched = sum coeff_i * poly_i (from_coeff trimming per term, the sum keeps the longest length): partial sums per thread
         std::vector<std::vector<H::Fr>> partial(HT->threads());
@@ -533,16 +543,19 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         const auto q3 = tnow();
         HT->parallel_for(n, [&](size_t lo, size_t hi, size_t) { for (size_t i = lo; i < hi; i++) claim[i] = eval_with_challenge(polys[i], r); });
         const auto q4 = tnow();
-        // ingest_challenge, in the same three steps
-        first_done = false;
+        // ingest_challenge, in the same steps
         todo.clear();
         for (size_t i = 0; i < n; i++) {
             Instance& I = b->inst[i];
             if (remaining > I.rounds) continue;
-            if (par[i] && first_done) { todo.push_back(i); continue; }
+            if (par[i]) {
+                int rc = I.inst->shared_ingest_step(challenges[round], round - (max_rounds - I.rounds));
+                if (rc) return rc;
+                todo.push_back(i);
+                continue;
+            }
             int rc = I.inst->ingest(challenges[round], round - (max_rounds - I.rounds));
             if (rc) return rc;
-            if (par[i]) first_done = true;
         }
         std::fill(rcs.begin(), rcs.end(), ATLAS_OK);
         const auto q5 = tnow();
@@ -552,7 +565,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
                 rcs[part] = I.inst->ingest(challenges[round], round - (max_rounds - I.rounds));
             }
         });
-        for (int rc : rcs) if (rc) return rc;
+        for (int rc : rcs) if (rc) return fail(rc, "batched_prove: a member's ingest_challenge failed on a worker thread");
         const auto q6 = tnow();
         tt[0] += tms(q0, q1); tt[1] += tms(q1, q2); tt[2] += tms(q2, q3); tt[3] += tms(q3, q4); tt[4] += tms(q4, q5); tt[5] += tms(q5, q6);
     }

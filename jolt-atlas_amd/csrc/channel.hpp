@@ -54,9 +54,22 @@ struct Channel {
     // mail area for one launch (n chunks, 64-byte aligned)
     atlas::Chunk* alloc(size_t n) {
         n = (n + 3) & ~(size_t)3;
-        if (next_chunk + n > MAIL_CHUNKS) next_chunk = 0;
+        if (next_chunk + n > MAIL_CHUNKS - LONG_CHUNKS) next_chunk = 0;
         atlas::Chunk* p = mail + next_chunk;
         next_chunk += n;
+        return p;
+    }
+    // Mail of a launch that outlives its round — a resident tail that mails a record per round, tables published at construction and read
+    // dozens of rounds later: the round-robin above comes round after 128 launches (4 lanes x 32 rounds), so these take their areas from a
+    // ring of their own at the top of the mail (1 MB: hundreds of tails; one or two are alive at a time).
+    static constexpr size_t LONG_CHUNKS = (size_t)1 << 16;
+    size_t next_long = 0;
+    atlas::Chunk* alloc_long(size_t n) {
+        n = (n + 3) & ~(size_t)3;
+        if (n > LONG_CHUNKS) return alloc(n);
+        if (next_long + n > LONG_CHUNKS) next_long = 0;
+        atlas::Chunk* p = mail + (MAIL_CHUNKS - LONG_CHUNKS) + next_long;
+        next_long += n;
         return p;
     }
     // n consecutive challenge slots

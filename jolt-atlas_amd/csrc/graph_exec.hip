@@ -440,8 +440,9 @@ int atlas_rt_validate_node(const atlas_graph& G, const Node& nd) {
         case ATLAS_OP_MEAN_OF_SQUARES: {
             if (!need_inputs(1) || nd.p[0] < 0 || nd.p[0] > 30) return bad("graph: MeanOfSquares operand / scale");
             const size_t N = in_node(0).dims.back(), K = gr::padded_len(in_node(0).dims) / N;
-            const int64_t D = ((int64_t)1 << nd.p[0]) * nd.p[1];
-            return T == K && nd.p[1] > 0 && (size_t)nd.p[1] <= N && D <= 2147483647ll ? ATLAS_OK : bad("graph: MeanOfSquares dims / count / divisor");
+            if (nd.p[1] <= 0 || (uint64_t)nd.p[1] > (uint64_t)N || N > ((size_t)1 << 31)) return bad("graph: MeanOfSquares dims / count / divisor");   // (bounded before the product: a hostile count must not overflow it)
+            const int64_t D = ((int64_t)1 << nd.p[0]) * nd.p[1];       // < 2^30 * 2^31
+            return T == K && D <= 2147483647ll ? ATLAS_OK : bad("graph: MeanOfSquares dims / count / divisor");
         }
         case ATLAS_OP_RSQRT: return need_inputs(1) && same_len() && nd.p[0] > 0 && nd.p[0] <= 14 ? ATLAS_OK : bad("graph: Rsqrt operand / scale (1..14)");
         case ATLAS_OP_TANH: case ATLAS_OP_ERF: case ATLAS_OP_SIGMOID: case ATLAS_OP_SIN: case ATLAS_OP_COS:

@@ -332,12 +332,22 @@ struct Prover : FlowSink {
                 for (size_t f = 0; f < fams.size(); f++) row0[f + 1] = row0[f] + (fams[f].log_K + 3) / 4;
                 size_t max_rows = 0;
                 for (size_t r = 0; r < world; r++) max_rows = std::max(max_rows, row0[cut[r + 1]] - row0[cut[r]]);
-                std::vector<atlas_g1_affine_t> mine(max_rows), all(max_rows * world);
+                // record 0 of a rank's payload is its status word: a rank whose commit failed still ENTERS the exchange (the others would wait for the
+                // timeout and the board's sequence numbers would part), and every rank returns the same error
+                const size_t rec = max_rows + 1;
+                std::vector<atlas_g1_affine_t> mine(rec), all(rec * world);
                 std::memset(mine.data(), 0, mine.size() * sizeof(atlas_g1_affine_t));
-                if (cut[rank + 1] > cut[rank]) rc = atlas_commit_lookup_chunks_multi(srs, fams.data() + cut[rank], cut[rank + 1] - cut[rank], 4, mine.data());
+                if (cut[rank + 1] > cut[rank]) rc = atlas_commit_lookup_chunks_multi(srs, fams.data() + cut[rank], cut[rank + 1] - cut[rank], 4, mine.data() + 1);
+                const int32_t my_rc = (int32_t)rc;
+                std::memcpy(mine.data(), &my_rc, sizeof(my_rc));
+                if (!sh->allgather_bulk(mine.data(), rec * sizeof(atlas_g1_affine_t), all.data())) return fail(ATLAS_ENODEV, "prove_graph_sharded: a rank did not answer (commitments)");
                 if (rc) return rc;
-                if (!sh->allgather_bulk(mine.data(), max_rows * sizeof(atlas_g1_affine_t), all.data())) return fail(ATLAS_ENODEV, "prove_graph_sharded: a rank did not answer (commitments)");
-                for (size_t r = 0; r < world; r++) std::memcpy(pts.data() + row0[cut[r]], all.data() + r * max_rows, (row0[cut[r + 1]] - row0[cut[r]]) * sizeof(atlas_g1_affine_t));
+                for (size_t r = 0; r < world; r++) {
+                    int32_t their_rc = 0;
+                    std::memcpy(&their_rc, all.data() + r * rec, sizeof(their_rc));
+                    if (their_rc) return fail(their_rc, "prove_graph_sharded: the witness commitments of another rank failed");
+                }
+                for (size_t r = 0; r < world; r++) std::memcpy(pts.data() + row0[cut[r]], all.data() + r * rec + 1, (row0[cut[r + 1]] - row0[cut[r]]) * sizeof(atlas_g1_affine_t));
             }
             if (rc) return rc;
             size_t o = 0;

@@ -149,7 +149,7 @@ inline std::vector<Fr> from_evals_toom(const std::vector<Fr>& evals) {
         for (size_t i = D - 1; i >= k; i--) d[i] = sub(d[i], d[i - 1]);
     for (size_t k = 2; k < D; k++) d[k] = mul(d[k], K->invfact[k]);
     std::vector<Fr> c(n, zero());
-    size_t len = 1;                                                   // c[0 .. len) = the polynomial built so far, highest basis element first
+    size_t len = 1;                                                   // c[0 .. len) = the polynomial built so far, coefficients in ASCENDING order (c[0] = the constant term)
     c[0] = d[D - 1];
     for (size_t k = D - 1; k-- > 0;) {                                // poly = poly * (x - k) + d[k]
         c[len] = c[len - 1];

@@ -14,6 +14,14 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
+#if defined(__x86_64__) || defined(__i386__)
+#define ATLAS_CPU_RELAX() __builtin_ia32_pause()
+#else
+#define ATLAS_CPU_RELAX() std::this_thread::yield()
+#endif
+
 namespace atlas_host {
 
 class HostThreads {
@@ -23,7 +31,7 @@ public:
     // f(lo, hi, part): part in [0, parts)
     void parallel_for(size_t n, const std::function<void(size_t, size_t, size_t)>& f) {
         const size_t parts = n_ < n ? n_ : (n ? n : 1);
-        if (parts <= 1) { f(0, n, 0); return; }
+        if (parts <= 1 || getpid() != pid_) { f(0, n, 0); return; }     // (a forked child inherits the object without its threads: serial there)
         std::unique_lock<std::mutex> job_lock(job_mu_);                  // one job at a time
         {
             std::lock_guard<std::mutex> lk(mu_);
@@ -35,11 +43,11 @@ public:
         f(0, n / parts, 0);
         const auto t0 = std::chrono::steady_clock::now();
         for (int spin = 0; pending_.load(std::memory_order_acquire) != 0; spin++) {      // the ranges are equal: the others finish about now
-            if ((spin & 255) != 255 || std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(2)) { __builtin_ia32_pause(); continue; }
+            if ((spin & 255) != 255 || std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(2)) { ATLAS_CPU_RELAX(); continue; }
             std::unique_lock<std::mutex> lk(mu_);
             done_cv_.wait(lk, [&] { return pending_.load(std::memory_order_acquire) == 0; });
         }
-        fn_ = nullptr;
+        { std::lock_guard<std::mutex> lk(mu_); fn_ = nullptr; }          // (a late worker reads fn_ under mu_)
     }
 
 private:
@@ -49,6 +57,7 @@ private:
         if (const char* e = getenv("ATLAS_HOST_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) want = (size_t)v; }
         if (hw && want > hw / 2) want = hw / 2;                          // leave cores for the transcript thread's neighbours: spinning workers on every core stall each other
         n_ = want < 1 ? 1 : want;
+        pid_ = getpid();
         for (size_t w = 1; w < n_; w++) workers_.emplace_back([this, w] { run(w); });
     }
     ~HostThreads() {
@@ -65,7 +74,7 @@ private:
             {
                 const auto t0 = std::chrono::steady_clock::now();
                 for (int spin = 0; epoch_.load(std::memory_order_acquire) == seen; spin++) {
-                    __builtin_ia32_pause();
+                    ATLAS_CPU_RELAX();
                     if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
                 }
             }
@@ -83,6 +92,7 @@ private:
         }
     }
     size_t n_ = 1;
+    pid_t pid_ = 0;
     std::vector<std::thread> workers_;
     std::mutex mu_, job_mu_;
     std::condition_variable cv_, done_cv_;

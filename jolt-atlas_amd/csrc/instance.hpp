@@ -51,6 +51,11 @@ struct atlas_instance {
     // instance of the batch has made the call for the round on the driver's thread (it does the work the instances share: launches, copies)?
     // The rows of a OneHotPool do: their round arithmetic is per row.  (batched.hip: batches of thousands of instances)
     virtual bool host_parallel() const { return false; }
+    // The work of message(round) / ingest(r, round) that a host_parallel instance SHARES with others (a pool's launches for the round), done
+    // on the calling thread; idempotent per round.  The driver makes these calls for every member on its own thread before it hands the
+    // members to the workers, so that no worker ever touches the device (batched.hip).
+    virtual int shared_message_step(size_t /*round*/) { return ATLAS_OK; }
+    virtual int shared_ingest_step(const atlas_u128_t& /*r*/, size_t /*round*/) { return ATLAS_OK; }
     // does enqueue(round) launch nothing at all (host-only rounds: the driver then has nothing new for the runtime to retire)?
     virtual bool silent_round(size_t /*round*/) const { return false; }
     static constexpr size_t WIDE_WAIT_WGS = 256;

@@ -924,15 +924,39 @@ int atlas_commit_lookup_chunks_multi(atlas_srs_t srs, const atlas_lookup_family_
     }
     const size_t R = rows.size();
     std::lock_guard<atlas_rt::Mutex> lk(g.mu);
-    unsigned gx = (unsigned)((maxT + 4 * MSM_THREADS - 1) / (4 * MSM_THREADS)); if (gx < 1) gx = 1; if (gx > 64) gx = 64;
-    while ((size_t)gx * R < 2048 && gx < 64 && (size_t)gx * MSM_THREADS < maxT) gx *= 2;
-    DevBuf d_rows, d_part, d_sum;
+    static const bool old_cut = getenv("ATLAS_COMMIT_OLD_CUT") != nullptr;      // A-B: one slice count for the whole launch
+    DevBuf d_rows, d_part, d_sum, d_slices, d_off;
     HIP_TRY(d_rows.alloc(R * sizeof(LookupChunkRow)));
-    HIP_TRY(d_part.alloc(R * gx * sizeof(G1Xyzz)));
     HIP_TRY(d_sum.alloc(R * sizeof(G1Xyzz)));
     HIP_TRY(hipMemcpyAsync(d_rows.p, rows.data(), R * sizeof(LookupChunkRow), hipMemcpyHostToDevice, g.stream));
-    k_g1_sum_lookup_rows<<<dim3(gx, (unsigned)R), MSM_THREADS, 0, g.stream>>>(srs->d, d_rows.as<LookupChunkRow>(), (uint32_t)(((uint64_t)1 << log_k_chunk) - 1), d_part.as<G1Xyzz>());
-    k_g1_group_sum<<<(unsigned)R, MSM_THREADS, 0, g.stream>>>(d_part.as<G1Xyzz>(), gx, d_sum.as<G1Xyzz>());
+    std::vector<LookupSlice> slices;                // (kept alive until the synchronisation below: pageable sources of asynchronous copies)
+    std::vector<uint32_t> offs;
+    if (old_cut) {
+        unsigned gx = (unsigned)((maxT + 4 * MSM_THREADS - 1) / (4 * MSM_THREADS)); if (gx < 1) gx = 1; if (gx > 64) gx = 64;
+        while ((size_t)gx * R < 2048 && gx < 64 && (size_t)gx * MSM_THREADS < maxT) gx *= 2;
+        HIP_TRY(d_part.alloc(R * gx * sizeof(G1Xyzz)));
+        k_g1_sum_lookup_rows<<<dim3(gx, (unsigned)R), MSM_THREADS, 0, g.stream>>>(srs->d, d_rows.as<LookupChunkRow>(), (uint32_t)(((uint64_t)1 << log_k_chunk) - 1), d_part.as<G1Xyzz>());
+        k_g1_group_sum<<<(unsigned)R, MSM_THREADS, 0, g.stream>>>(d_part.as<G1Xyzz>(), gx, d_sum.as<G1Xyzz>());
+    } else {
+        // slices per row: ~32 points per thread, at most 64 slices; with few rows more slices, so that the launch still fills the chip
+        size_t pts = 32;
+        { size_t tot = 0; for (auto& r : rows) tot += (r.T + MSM_THREADS * pts - 1) / (MSM_THREADS * pts); while (pts > 1 && tot < 1024) { pts /= 2; tot *= 2; } }
+        offs.assign(R + 1, 0);
+        for (size_t r = 0; r < R; r++) {
+            size_t ns = (rows[r].T + MSM_THREADS * pts - 1) / (MSM_THREADS * pts);
+            ns = ns < 1 ? 1 : ns > 64 ? 64 : ns;
+            offs[r + 1] = offs[r] + (uint32_t)ns;
+            for (size_t q = 0; q < ns; q++) slices.push_back(LookupSlice{(uint32_t)r, (uint32_t)q, (uint32_t)ns});
+        }
+        HIP_TRY(d_slices.alloc(slices.size() * sizeof(LookupSlice)));
+        HIP_TRY(d_off.alloc(offs.size() * sizeof(uint32_t)));
+        HIP_TRY(d_part.alloc(slices.size() * sizeof(G1Xyzz)));
+        HIP_TRY(hipMemcpyAsync(d_slices.p, slices.data(), slices.size() * sizeof(LookupSlice), hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(hipMemcpyAsync(d_off.p, offs.data(), offs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+        k_g1_sum_lookup_slices<<<(unsigned)slices.size(), MSM_THREADS, 0, g.stream>>>(srs->d, d_rows.as<LookupChunkRow>(), d_slices.as<LookupSlice>(), (uint32_t)(((uint64_t)1 << log_k_chunk) - 1),
+                                                                                    d_part.as<G1Xyzz>());
+        k_g1_group_sum_var<<<(unsigned)R, 64, 0, g.stream>>>(d_part.as<G1Xyzz>(), d_off.as<uint32_t>(), d_sum.as<G1Xyzz>());
+    }
     std::vector<H::G1X> res(R);
     HIP_TRY(hipMemcpyAsync(res.data(), d_sum.p, R * sizeof(G1Xyzz), hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));

@@ -637,6 +637,45 @@ __global__ __launch_bounds__(MSM_THREADS) void k_g1_sum_lookup_rows(const G1Affi
     if (threadIdx.x == 0) g1_store(out + (size_t)blockIdx.y * gridDim.x + blockIdx.x, sm[0]);
 }
 
+// The same with the slices cut PER ROW (a graph's rows run from 2^6 to 2^20 cycles): a workgroup takes slice `slice` of `n_slices` of its row, a
+// thread ~32 points of it.  With one slice count for the whole launch (sized for the longest row) a row of 2^14 cycles was spread over 64
+// workgroups of ONE point per thread, each followed by the 8-level tree of full additions: the trees were the launch — 8823 rows x 64
+// workgroups, 117 ms for the witness commitments of the GPT-2-shaped graph.
+struct LookupSlice { uint32_t row, slice, n_slices; };
+__global__ __launch_bounds__(MSM_THREADS) void k_g1_sum_lookup_slices(const G1Affine* __restrict__ bases, const LookupChunkRow* __restrict__ rows,
+                                                                      const LookupSlice* __restrict__ slices, uint32_t mask, G1Xyzz* __restrict__ out) {
+    __shared__ G1Xyzz sm[MSM_THREADS];
+    const LookupSlice S = slices[blockIdx.x];
+    const LookupChunkRow R = rows[S.row];
+    G1Xyzz acc = g1_inf();
+    for (size_t t = (size_t)S.slice * MSM_THREADS + threadIdx.x; t < R.T; t += (size_t)S.n_slices * MSM_THREADS) {
+        const uint64_t k = R.shift >= 64 ? 0 : ((R.lookups[t] >> R.shift) & mask);
+        const G1Affine p = g1_aff_load(bases + (size_t)k * R.T + t);
+        if (!g1_aff_is_inf(p)) acc = g1_madd(acc, p, false);
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s2 = MSM_THREADS / 2; s2 >= 1; s2 >>= 1) {
+        if (threadIdx.x < s2) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + s2]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) g1_store(out + blockIdx.x, sm[0]);
+}
+// out[r] = sum of pts[off[r] .. off[r + 1]) (at most 64 partials of a row): one wavefront per row
+__global__ __launch_bounds__(64) void k_g1_group_sum_var(const G1Xyzz* __restrict__ pts, const uint32_t* __restrict__ off, G1Xyzz* __restrict__ out) {
+    __shared__ G1Xyzz sm[64];
+    const uint32_t lo = off[blockIdx.x], hi = off[blockIdx.x + 1];
+    G1Xyzz acc = g1_inf();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 64) acc = g1_add(acc, g1_load(pts + i));
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t d = 32; d >= 1; d >>= 1) {
+        if (threadIdx.x < d && lo + threadIdx.x + d < hi) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + d]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) g1_store(out + blockIdx.x, sm[0]);
+}
+
 // SRS generation (SRS::setup, hyperkzg/kzg.rs:26-93): out[i] = tau^(i+1) * G.
 // tau_pow2[j] = tau^(2^j) (Montgomery Fr), dbl_table[j] = 2^j * G (affine).
 __global__ __launch_bounds__(MSM_THREADS) void k_srs_generate(const Fr* __restrict__ tau_pow2,

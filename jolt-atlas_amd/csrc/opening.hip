@@ -155,6 +155,15 @@ struct GseDevH {
         return E;
     }
     // q(0) = sum over the lower half of P weighted by the current tables
+    // the same without the wait: the sum lands in `host_slot` (pinned, device-visible) once the stream has been synchronised by the caller
+    template <class T>
+    int q0_async(const T* P, size_t half, Fr* host_slot) {
+        const unsigned grid = grid_for(half);
+        k_open_fold<T><<<grid, OP_THREADS, 0, g.stream>>>(P, half, view(), d_part, make_consts());
+        k_open_reduce<<<1, OP_THREADS, 0, g.stream>>>(d_part, grid, host_slot);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? ATLAS_OK : fail(ATLAS_ENODEV, "dense_opening: fold", e);
+    }
     template <class T>
     int q0(const T* P, size_t half, H::Fr* out) {
         const unsigned grid = grid_for(half);
@@ -176,10 +185,29 @@ struct DenseOpening : atlas_instance {
     ~DenseOpening() override { if (P) atlas_poly_free(P); D.release(); }
     size_t rounds() const override { return n; }
     size_t degree() const override { return 2; }
+    // In a batch of thousands (the opening reduction of a graph holds ~50 dense members beside the one-hot rows) a synchronisation per dense
+    // member and round was 1.3 ms per round: the driver calls shared_message_step of every member first — this one launches its fold, the sum
+    // going to a pinned slot — synchronises ONCE (g.pending_async), and message() finds the sum there.
+    atlas::Chunk* slot = nullptr;
+    size_t slot_round = (size_t)-1;
+    bool host_parallel() const override { return true; }
+    int shared_message_step(size_t round) override {
+        if (round != round_next || round >= n) return ATLAS_OK;
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        if (!slot) slot = g.chan.alloc_long(2);
+        const int rc = P->is_i32 ? D.q0_async<int32_t>((const int32_t*)P->d, P->len / 2, reinterpret_cast<Fr*>(slot)) : D.q0_async<Fr>((const Fr*)P->d, P->len / 2, reinterpret_cast<Fr*>(slot));
+        if (rc) return rc;
+        slot_round = round;
+        g.pending_async++;
+        return ATLAS_OK;
+    }
     int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
         if (round != round_next || round >= n) return fail(ATLAS_ESTATE, "dense_opening: round out of order");
         H::Fr q0;
-        {
+        if (slot_round == round) {                                  // launched by shared_message_step; the driver has synchronised since
+            std::memcpy(&q0, slot, sizeof(q0));
+            slot_round = (size_t)-1;
+        } else {
             std::lock_guard<atlas_rt::Mutex> lk(g.mu);
             const int rc = P->is_i32 ? D.q0<int32_t>((const int32_t*)P->d, P->len / 2, &q0) : D.q0<Fr>((const Fr*)P->d, P->len / 2, &q0);
             if (rc) return rc;
@@ -188,8 +216,10 @@ struct DenseOpening : atlas_instance {
         H::gruen_deg2(D.st.scalar, D.st.w_cur(), q0, claim, coeffs.data());
         return ATLAS_OK;
     }
-    int ingest(const atlas_u128_t& r, size_t round) override {
-        if (round != round_next || round >= n) return fail(ATLAS_ESTATE, "dense_opening: round out of order");
+    // the device half of ingest_challenge (the driver's thread calls it through shared_ingest_step before the workers run ingest())
+    size_t bound_round = (size_t)-1;
+    int bind_device(const atlas_u128_t& r, size_t round) {
+        if (bound_round == round) return ATLAS_OK;
         const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
         if (P->is_i32) {                                            // CompactPolynomial first bind: promotes to Fr (and syncs)
             int rc = atlas_poly_bind(P, &r, ATLAS_HIGH_TO_LOW);
@@ -202,7 +232,18 @@ struct DenseOpening : atlas_instance {
             if (e != hipSuccess) return fail(ATLAS_ENODEV, "dense_opening: bind", e);
             P->len = half;
         }
-        D.st.bind(rf);
+        bound_round = round;
+        return ATLAS_OK;
+    }
+    int shared_ingest_step(const atlas_u128_t& r, size_t round) override {
+        if (round != round_next || round >= n) return ATLAS_OK;
+        return bind_device(r, round);
+    }
+    int ingest(const atlas_u128_t& r, size_t round) override {
+        if (round != round_next || round >= n) return fail(ATLAS_ESTATE, "dense_opening: round out of order");
+        const int rc = bind_device(r, round);
+        if (rc) return rc;
+        D.st.bind(H::challenge_to_fr(r.lo, r.hi, g.challenge_mode));
         round_next++;
         return ATLAS_OK;
     }
@@ -826,6 +867,21 @@ struct OneHotPoolRow : atlas_instance {
         return ATLAS_OK;
     }
     bool host_parallel() const override { return true; }
+    // the pool's launches of a global round, on the caller's thread (the driver's): the rows' own calls then find them done
+    int shared_message_step(size_t round) override {
+        if (round != round_next || round >= rounds() || round < P->log_K) return ATLAS_OK;
+        const size_t R = round + P->row_off(P->rows[row]);
+        if (P->folded.load(std::memory_order_acquire) == R) return ATLAS_OK;
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        return P->fold_all(R);
+    }
+    int shared_ingest_step(const atlas_u128_t& r, size_t round) override {
+        if (round != round_next || round >= rounds() || round < P->log_K) return ATLAS_OK;
+        const size_t R = round + P->row_off(P->rows[row]);
+        if (P->bound.load(std::memory_order_acquire) == R) return ATLAS_OK;
+        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        return P->bind_all(R, H::challenge_to_fr(r.lo, r.hi, g.challenge_mode));
+    }
     int finals(std::vector<H::Fr>& out) override {
         if (round_next != rounds()) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
         std::lock_guard<atlas_rt::Mutex> lk(g.mu);

@@ -678,7 +678,7 @@ struct PsLookup : atlas_instance {
         HIP_TRY(hipMemsetAsync(sgn_scratch.p, 0, 8192, g.stream));
         const uint32_t ph = (uint32_t)phases;
         HIP_TRY(hipMemsetAsync(mn, 0xFF, 4, g.stream));                                // the minimum starts above any count
-        atlas::Chunk* box = g.chan.alloc(2 * n_vals + 4);
+        atlas::Chunk* box = g.chan.alloc_long(2 * n_vals + 4);
         const uint32_t tag = g.chan.tag();
         size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 256) gb = 256;
         const PsSignOut O{acc, mn, mn + 16, reinterpret_cast<Fr*>(box + 4), box, tag};
@@ -694,7 +694,7 @@ struct PsLookup : atlas_instance {
         sgn_S.assign(reinterpret_cast<const H::Fr*>(box + 4), reinterpret_cast<const H::Fr*>(box + 4) + P * 2 * NQ);
         sgn_P = P;
         for (int cl = 0; cl < 2; cl++) {                       // the class tables of phase P: needed 8 P rounds from now
-            atlas::Chunk* tb = g.chan.alloc(2 * NQ * m + 4);
+            atlas::Chunk* tb = g.chan.alloc_long(2 * NQ * m + 4);
             std::memset(tb + 4, 0, NQ * m * sizeof(Fr));
             const uint32_t tg = g.chan.tag();
             int rc = launch_Q(P, nullptr, 0, QPublish{reinterpret_cast<Fr*>(tb + 4), tb, tg, rows.d_counter}, PsClass{cl, (uint32_t)(N - 1), nullptr});
@@ -1094,7 +1094,8 @@ struct PsLookup : atlas_instance {
                 A.e_out = eq.d_eout; A.e_in = eq.d_ein;
                 A.n_rounds = (uint32_t)(log_T - c0);
                 for (size_t i = 0; i < A.n_rounds; i++) { size_t ot, it; eq.st.tops_after(c0 + i, ot, it); A.ot[i] = (uint8_t)ot; A.it[i] = (uint8_t)it; }
-                A.mail = io.mail; A.r_host = io.r_host; A.abort_flag = io.abort_flag;
+                tail_mail = g.chan.alloc_long((A.n_rounds + 2) * atlas::ch_stride(1));       // (not io.mail: the per-round areas are recycled while the tail lives)
+                A.mail = tail_mail; A.r_host = io.r_host; A.abort_flag = io.abort_flag;
                 A.tag_mail0 = io.tag_mail; A.tag_step = io.tag_step; A.tag_r0 = io.tag_r;
                 A.challenge_mode = g.challenge_mode; A.hi_only = g.challenge_mode == 0 ? 1 : 0;
                 static bool attr_set = false;
@@ -1102,7 +1103,6 @@ struct PsLookup : atlas_instance {
                 k_ps_tail_ch<<<1, PS_TAIL_THREADS, sizeof(Fr) << PS_TAIL_LOG, g.stream>>>(A);
                 hipError_t e = hipGetLastError();
                 if (e != hipSuccess) return fail(ATLAS_ENODEV, "ps_shout: tail launch", e);
-                tail_mail = io.mail;
             }
             mail.base = tail_mail + (c - c0) * atlas::ch_stride(1); mail.blocks = 1; mail.n_vals = 1;
             return ATLAS_OK;

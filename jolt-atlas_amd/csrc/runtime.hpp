@@ -47,6 +47,7 @@ struct Runtime {
     uint64_t* d_chal = nullptr;        // up to 64 rounds * 2
     atlas::Fe* d_finals = nullptr;     // 3 (+ scratch for reduced evals)
     void* h_pinned = nullptr;          // pinned staging for small D2H/H2D
+    int pending_async = 0;             // launches of shared_message_step calls whose results the driver has not waited for yet (batched.hip)
     std::vector<void (*)()> at_shutdown;   // release hooks of the translation units that keep device arenas
     Mutex mu;
 };

@@ -38,6 +38,8 @@ def cases():
         # the one-operator graphs bench.py times (T = 2^16): the sizes of the k-sliced accumulation kernel, k_ra_prod_f9 at d = 16 and the
         # 96 KB-LDS Q build of the 64-bit clamp lookup
         "node_einsum": BG.node_einsum, "node_relu": BG.node_relu, "node_mul": BG.node_mul,
+        # BASELINE config 4 at size: the 12-layer GPT-2-shaped graph (--trace-only)
+        "gpt2": lambda: BG.gpt2(),
     }
 
 
@@ -48,12 +50,31 @@ def node_hash(a):
 def main():
     import build_graphs as BG
     from oracle import graph as OG, orc
-    names = sys.argv[1:] or list(cases())
+    trace_only = "--trace-only" in sys.argv          # execution only (oracle/graph.py:execute): the 12-layer GPT-2-shaped graph, whose oracle PROOF takes hours
+    names = [a for a in sys.argv[1:] if not a.startswith("--")] or list(cases())
     doc = json.load(open(OUT)) if os.path.exists(OUT) else {"generator": "tests/golden/gen_graph_proofs.py", "tau_seed": TAU_SEED,
                                                             "pins": "device vs in-repo oracle (not the reference)", "graphs": {}}
     for name in names:
         nodes, outputs, inputs = cases()[name]()
         nv = BG.max_vars(nodes)
+        if trace_only:
+            t0 = time.time()
+            trace = OG.execute(nodes, inputs)
+            trace = trace[0] if isinstance(trace, tuple) else trace
+            prev = doc["graphs"].get(name, {})
+            doc["graphs"][name] = {
+                "n_nodes": len(nodes), "max_vars": nv,
+                "input_sha256": [hashlib.sha256(np.ascontiguousarray(x, dtype=np.int32).tobytes()).hexdigest()[:16] for x in inputs],
+                "trace": [node_hash(trace[nd["idx"]]) for nd in nodes], "oracle_seconds": round(time.time() - t0, 1),
+                "trace_only": "the oracle EXECUTED this graph (per-node hashes); its proof was not computed — hours for 854 nodes at max_num_vars 24. "
+                              "device_proof_sha256 / device_state / n_committed / proof_len are the DEVICE's own (tools/record_device_proof.py on an MI355X): a regression pin, not an oracle pin",
+                **{k: prev[k] for k in ("device_proof_sha256", "device_state", "n_committed", "proof_len") if k in prev},
+            }
+            print(name, {k: v for k, v in doc["graphs"][name].items() if k != "trace"}, flush=True)
+            with open(OUT, "w") as f:
+                json.dump(doc, f, indent=1)
+                f.write("\n")
+            continue
         tau = orc.random_fr(1, TAU_SEED)[0]
         t0 = time.time()
         srs_h = orc.srs_powers(tau, 1 << nv)

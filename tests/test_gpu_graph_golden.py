@@ -60,3 +60,44 @@ def test_model_shaped_proof_matches_committed_oracle_result(atlas, name):
     bad = out.copy(); bad[len(bad) // 2] ^= 1
     assert not V.verify(vk, inputs, bad, proof)[0]
     G.free(); V.free(); srs.free()
+
+
+def test_gpt2_12_layers_config4(atlas):
+    """BASELINE config 4 at size on one GPU: the 12-layer GPT-2-shaped graph (854 nodes, 8823 committed polynomials, max_num_vars 24;
+    jolt-atlas-core/examples/gpt2.rs:88-118 in shape — the reference downloads the model file, there is none in its tree).  The oracle EXECUTED this graph in the
+    build container (per-node trace hashes, tests/golden/gen_graph_proofs.py --trace-only); its PROOF takes hours there and was not computed, so
+    the proof bytes are held to the device's own committed sha256 (a regression pin: the fixture says so), and the independent check of the proof
+    is atlas_verify_graph — written from the reference's verifier side — accepting it and rejecting a flipped output."""
+    import build_graphs as BG
+    from oracle import orc
+    from jolt_atlas_amd import graph as GG
+    want = GOLD["graphs"].get("gpt2")
+    if not want:
+        pytest.fail("tests/golden/graph_proofs.json has no entry for gpt2: run tests/golden/gen_graph_proofs.py --trace-only gpt2")
+    nodes, outputs, inputs = BG.gpt2()
+    assert len(nodes) == want["n_nodes"] and [_h(x) for x in inputs] == want["input_sha256"], "the builder no longer yields the graph the fixture was made from"
+    nv = BG.max_vars(nodes)
+    assert nv == want["max_vars"] == 24
+    tau = orc.random_fr(1, GOLD["tau_seed"])[0]
+    srs = atlas.SRS.generate(tau, 1 << nv)
+    srs.precompute()
+    G = GG.Graph(nodes, outputs)
+    G.trace(inputs)
+    for nd, hw in zip(nodes, want["trace"]):
+        if nd["op"] == "Constant":
+            continue                                   # (1.1 GB of weights: their upload is covered by every node that reads them)
+        assert _h(G.node_output(nd["idx"])) == hw, f"trace of node {nd['idx']} ({nd['op']})"
+    proof, state, tm = G.prove(srs, inputs)
+    assert tm["n_nodes"] == 854 and tm["n_committed"] == want["n_committed"] == 8823
+    assert len(proof) == want["proof_len"] and hashlib.sha256(proof).hexdigest() == want["device_proof_sha256"], "ONNXProof bytes (device regression pin)"
+    assert state.hex() == want["device_state"]
+    vk = atlas.HyperKZG.vk_from_trapdoor(tau, srs.download(0, 1)[0])
+    out = G.node_output(outputs[0])
+    V = GG.Graph(nodes, outputs)
+    ok, vstate = V.verify(vk, inputs, out, proof)
+    assert ok and vstate == state
+    bad = out.copy(); bad[len(bad) // 2] ^= 1
+    assert not V.verify(vk, inputs, bad, proof)[0]
+    tampered = bytearray(proof); tampered[len(tampered) // 3] ^= 0x10
+    assert not V.verify(vk, inputs, out, bytes(tampered))[0]
+    G.free(); V.free(); srs.free()

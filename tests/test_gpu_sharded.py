@@ -218,7 +218,7 @@ def test_sharded_elementwise_operator(tmp_path, world, n):
         assert f"SHARDED_EW_OK {r}" in o
 
 
-@pytest.mark.parametrize("world,name", [(2, "tiny2"), (4, "microgpt"), (2, "nanogpt_model")])
+@pytest.mark.parametrize("world,name", [(2, "tiny2"), (4, "microgpt"), (2, "nanogpt_model"), (2, "gpt2")])
 def test_sharded_prove_graph(tmp_path, world, name):
     """atlas_prove_graph_sharded (x2 / BASELINE config 4: the whole ONNXProof::prove over the GPUs of a node, one process per GPU): every rank
     traces the model and runs the IOP, the witness commitments are split by polynomial range and the opening's commitment groups by point
@@ -238,7 +238,9 @@ def test_sharded_prove_graph(tmp_path, world, name):
         A.init(0)
         gold = json.load(open(os.path.join({ROOT!r}, "tests", "golden", "graph_proofs.json")))
         want = gold["graphs"][{name!r}]
-        nodes, outputs, inputs = {{"tiny2": lambda: BG.tiny(layers=2), "microgpt": BG.microgpt, "nanogpt_model": BG.nanogpt_model}}[{name!r}]()
+        nodes, outputs, inputs = {{"tiny2": lambda: BG.tiny(layers=2), "microgpt": BG.microgpt, "nanogpt_model": BG.nanogpt_model, "gpt2": BG.gpt2}}[{name!r}]()
+        if "proof_sha256" not in want:                   # the 12-layer graph (config 4): the one-GPU DEVICE proof is the committed value (fixture: trace_only)
+            want = dict(want, proof_sha256=want["device_proof_sha256"], state=want["device_state"])
         nv = BG.max_vars(nodes)
         tau = orc.random_fr(1, gold["tau_seed"])[0]
         srs = A.SRS.generate(tau, 1 << nv)
