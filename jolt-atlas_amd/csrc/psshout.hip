@@ -1055,7 +1055,7 @@ struct PsLookup : atlas_instance {
         mail.base = io.mail; mail.blocks = 0; mail.n_vals = 0; mail.radix = 32; mail.shl = 0;
         Fr* vt[2] = {d_v, d_v + m};
         size_t gbT = (T + RA_THREADS - 1) / RA_THREADS; if (gbT > 4096) gbT = 4096;
-        if (round == 0) qbox.assign(phases, QBox{});
+        if (round == 0) { qbox.assign(phases, QBox{}); n_lanes = io.tag_step; }
         if (round >= 1 && round <= N) {                        // remember where the challenge of round - 1 will appear
             const size_t pw = (round - 1) % log_m;
             slots.host[pw] = io.r_host; slots.tag[pw] = io.tag_r;
@@ -1160,10 +1160,13 @@ struct PsLookup : atlas_instance {
     atlas::Chunk* tail_mail = nullptr;
     size_t tail_c0() const {
         static const bool off = getenv("ATLAS_PS_NO_TAIL") != nullptr;
-        if (off || log_T < 2 || one_cycle || io_tag_step_unknown) return 0;
+        // Only as the ONE lane of its proof: a resident launch waits for challenges that depend on the OTHER lanes' later launches, and HIP
+        // multiplexes streams onto a few hardware queues — a lane whose stream shares the tail's queue would have those launches queued
+        // behind it (seen as a 2 s stall in the Sin / Cos flow, whose shift lookup is batched with the table read).
+        if (off || log_T < 2 || one_cycle || n_lanes != 1) return 0;
         return log_T > PS_TAIL_LOG + 1 ? log_T - PS_TAIL_LOG : 1;      // the first bind of the tail leaves at most 2^PS_TAIL_LOG coefficients
     }
-    bool io_tag_step_unknown = false;
+    uint32_t n_lanes = 0;                                           // lanes of the proof this instance runs in (RoundIo::tag_step of its first enqueue)
     int enqueue_finals(const atlas::RoundIo& io, atlas_mail_ref& mail) override {
         if (tail_c0()) {                                            // the tail mails the final claim as its last record
             if (!tail_mail) return fail(ATLAS_ESTATE, "ps_shout: finals before the tail");
