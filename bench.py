@@ -356,7 +356,7 @@ def main():
     ms_per_step = dt * 1e3 / args.steps
     value = world * field_ops(n_vars) * args.steps / dt
     out = {
-        "metric": "BN254 Fr field-ops/s, ONNXProof::prove hot path (synthetic 2^%d-coefficient sumcheck)" % n_vars,
+        "metric": "BN254 Fr field-ops/s, ONNXProof::prove hot path (synthetic 2^%d-coefficient sumcheck; a field op = TrackedFr's count, 14 per index-round: 4 mul + 10 add/sub — SURVEY 8(d) says ~10; mulmod_per_s is the unambiguous figure)" % n_vars,
         "value": value, "unit": "field-ops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32x8 (BN254 Fr, 254-bit Montgomery)", "data": "synthetic",

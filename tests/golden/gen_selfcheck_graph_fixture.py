@@ -31,7 +31,7 @@ def g1_hex(p):
 
 rng = np.random.default_rng(0xA71A5)
 models = []
-# the four models of the exporter, same shapes and operators (other random data: this file is not the reference's)
+# the first four models of the exporter, same shapes and operators (other random data: this file is not the reference's)
 models.append(("relu16", [{"idx": 0, "op": "Input", "inputs": [], "dims": [16]}, {"idx": 1, "op": "ReLU", "inputs": [0], "dims": [16]}], [1],
                [rng.integers(-(1 << 12), 1 << 12, size=16).astype(np.int32)]))
 c = rng.integers(-(1 << 20), 1 << 20, size=16).astype(np.int32)
@@ -44,11 +44,36 @@ models.append(("einsum_relu", [{"idx": 0, "op": "Input", "inputs": [], "dims": [
 k = rng.integers(-(1 << 14), 1 << 14, size=32).astype(np.int32)
 models.append(("mul4x8", [{"idx": 0, "op": "Input", "inputs": [], "dims": [4, 8]}, {"idx": 1, "op": "Constant", "inputs": [], "dims": [4, 8], "data": k},
                           {"idx": 2, "op": "Mul", "inputs": [0, 1], "dims": [4, 8], "scale": 14}], [2], [rng.integers(-(1 << 14), 1 << 14, size=32).astype(np.int32)]))
+# round 5: the seven models the exporter gained (SoftmaxLastAxis, Tanh, GatherSmall, Div, Rsqrt, a one-element Div, a LayerNorm-shaped chain)
+models.append(("softmax2x4x8", [{"idx": 0, "op": "Input", "inputs": [], "dims": [2, 4, 8]}, {"idx": 1, "op": "SoftmaxLastAxis", "inputs": [0], "dims": [2, 4, 8], "scale": 14}], [1],
+               [rng.integers(-(1 << 15), 1 << 15, size=64).astype(np.int32)]))
+models.append(("tanh4x4", [{"idx": 0, "op": "Input", "inputs": [], "dims": [4, 4]}, {"idx": 1, "op": "Tanh", "inputs": [0], "dims": [4, 4], "scale": 14}], [1],
+               [rng.integers(-(1 << 18), 1 << 18, size=16).astype(np.int32)]))
+dict_ = rng.integers(-(1 << 14), 1 << 14, size=64).astype(np.int32)
+models.append(("gather8of16", [{"idx": 0, "op": "Input", "inputs": [], "dims": [8]}, {"idx": 1, "op": "Constant", "inputs": [], "dims": [16, 4], "data": dict_},
+                               {"idx": 2, "op": "GatherSmall", "inputs": [1, 0], "dims": [8, 4], "axis": 0, "dict_len": 16}], [2], [rng.integers(0, 16, size=8).astype(np.int32)]))
+den = rng.integers(1, 1 << 10, size=16).astype(np.int32)
+models.append(("div4x4", [{"idx": 0, "op": "Input", "inputs": [], "dims": [4, 4]}, {"idx": 1, "op": "Constant", "inputs": [], "dims": [4, 4], "data": den},
+                          {"idx": 2, "op": "Div", "inputs": [0, 1], "dims": [4, 4]}], [2], [rng.integers(-(1 << 20), 1 << 20, size=16).astype(np.int32)]))
+models.append(("rsqrt4x4", [{"idx": 0, "op": "Input", "inputs": [], "dims": [4, 4]}, {"idx": 1, "op": "Rsqrt", "inputs": [0], "dims": [4, 4], "scale": 14}], [1],
+               [rng.integers(1, 1 << 20, size=16).astype(np.int32)]))
+models.append(("div1", [{"idx": 0, "op": "Input", "inputs": [], "dims": [2, 2]}, {"idx": 1, "op": "Sum", "inputs": [0], "dims": [2, 1], "axes": [1]},
+                        {"idx": 2, "op": "Sum", "inputs": [1], "dims": [1, 1], "axes": [0]}, {"idx": 3, "op": "Constant", "inputs": [], "dims": [1, 1], "data": np.array([70000], dtype=np.int32)},
+                        {"idx": 4, "op": "Div", "inputs": [3, 2], "dims": [1, 1]}, {"idx": 5, "op": "Broadcast", "inputs": [4], "dims": [1, 2]},
+                        {"idx": 6, "op": "Constant", "inputs": [], "dims": [1, 2], "data": np.array([3, -4], dtype=np.int32)}, {"idx": 7, "op": "Add", "inputs": [5, 6], "dims": [1, 2]}], [7],
+               [np.array([5000, 6000, 7000, 8000], dtype=np.int32)]))
+models.append(("layernorm4x8", [{"idx": 0, "op": "Input", "inputs": [], "dims": [4, 8]}, {"idx": 1, "op": "Sum", "inputs": [0], "dims": [4, 1], "axes": [1]},
+                                {"idx": 2, "op": "ScalarConstDiv", "inputs": [1], "dims": [4, 1], "divisor": 8}, {"idx": 3, "op": "Broadcast", "inputs": [2], "dims": [4, 8]},
+                                {"idx": 4, "op": "Sub", "inputs": [0, 3], "dims": [4, 8]}, {"idx": 5, "op": "MeanOfSquares", "inputs": [4], "dims": [4, 1], "axes": [1], "scale": 14, "count": 8},
+                                {"idx": 6, "op": "Rsqrt", "inputs": [5], "dims": [4, 1], "scale": 14}, {"idx": 7, "op": "Broadcast", "inputs": [6], "dims": [4, 8]},
+                                {"idx": 8, "op": "Mul", "inputs": [4, 7], "dims": [4, 8], "scale": 14}], [8], [rng.integers(-(1 << 15), 1 << 15, size=32).astype(np.int32)]))
 
 tau = orc.random_fr(1, 0x51250001)[0]
 out = {"graphs": []}
 for name, nodes, outputs, inputs in models:
-    nv = 4 + max(int(np.log2(np.prod(nd["dims"]))) for nd in nodes)          # the reference's max_num_vars: a one-hot chunk, 16 addresses x T cycles
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import build_graphs as BG
+    nv = max(BG.max_vars(nodes), 4 + max(int(np.log2(np.prod(nd["dims"]))) for nd in nodes))      # the reference's max_num_vars: a one-hot chunk, 16 addresses x T cycles
     srs = orc.srs_powers(tau, 1 << nv)
     P = OG.Prover(nodes, outputs, srs)
     proof = P.prove(inputs)
