@@ -571,7 +571,8 @@ struct PsLookup : atlas_instance {
     // area holds the word sums of k_ps_q_lds
     size_t q_rows_max() const { size_t r = ((size_t)1 << 17) / m; if (r > 2048) r = 2048; return r < SLICES ? SLICES : r; }
 
-    ~PsLookup() override { for (void* p : {(void*)d_idx, (void*)d_u0, (void*)d_v, (void*)d_qpart}) if (p) hipFree(p); rows.release(); eq.release(); }
+    bool idx_borrowed = false;            // d_idx is the caller's device vector (it outlives the instance: a node's witness), not a copy
+    ~PsLookup() override { for (void* p : {(void*)(idx_borrowed ? nullptr : d_idx), (void*)d_u0, (void*)d_v, (void*)d_qpart}) if (p) hipFree(p); rows.release(); eq.release(); }
     bool one_cycle = false;               // log_T == 0 held as two cycles, the second of weight zero (ps_new)
     size_t rounds() const override { return one_cycle ? N : N + log_T; }
     size_t degree() const override { return 2; }
@@ -1232,11 +1233,18 @@ static int ps_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, si
         if (e == hipSuccess) e = hipMemcpyAsync(P->d_u0, E->d, sizeof(Fr), hipMemcpyDeviceToDevice, g.stream);
         atlas_poly_free(E);
     } else { P->d_u0 = (Fr*)E->d; delete E; }                        // keep the table, drop the handle
-    if (e == hipSuccess) e = hipMalloc(&P->d_idx, T * sizeof(uint64_t));
+    {   // device-resident indices (the graph prover's witness vectors, alive until the graph is freed) are read in place
+        hipPointerAttribute_t attr;
+        const bool on_device = !one_cycle && hipPointerGetAttributes(&attr, lookup_indices) == hipSuccess && attr.type == hipMemoryTypeDevice;
+        (void)hipGetLastError();
+        static const bool no_borrow = getenv("ATLAS_PS_COPY_IDX") != nullptr;
+        if (on_device && !no_borrow) { P->d_idx = const_cast<uint64_t*>(lookup_indices); P->idx_borrowed = true; }
+    }
+    if (e == hipSuccess && !P->idx_borrowed) e = hipMalloc(&P->d_idx, T * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc(&P->d_v, 2 * m * sizeof(Fr));       // two tables: the pipelined path alternates
     if (e == hipSuccess) e = hipMalloc(&P->d_qpart, (P->q_rows_max() + 1) * 6 * m * sizeof(Fr));
     if (e == hipSuccess && one_cycle) e = hipMemsetAsync(P->d_idx, 0, T * sizeof(uint64_t), g.stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(P->d_idx, lookup_indices, (one_cycle ? 1 : T) * sizeof(uint64_t), hipMemcpyDefault, g.stream);   // host or device source
+    if (e == hipSuccess && !P->idx_borrowed) e = hipMemcpyAsync(P->d_idx, lookup_indices, (one_cycle ? 1 : T) * sizeof(uint64_t), hipMemcpyDefault, g.stream);   // host or device source
     if (e != hipSuccess) { delete P; return fail(ATLAS_ENOMEM, "ps_shout_new", e); }
     rc = P->rows.alloc(1, T);
     if (!rc) {

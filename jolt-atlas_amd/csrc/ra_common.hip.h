@@ -343,14 +343,20 @@ struct RaRows {
     int upload_lookups(const uint64_t* lookups, uint32_t log_k_chunk) {
         uint64_t* d_l = nullptr;
         HIP_TRY(hipMalloc(&d_idx, d * len * sizeof(int32_t)));
-        HIP_TRY(hipMalloc(&d_l, len * sizeof(uint64_t)));
-        hipError_t e = hipMemcpyAsync(d_l, lookups, len * sizeof(uint64_t), hipMemcpyDefault, g.stream);   // host or device source
+        hipPointerAttribute_t attr;
+        const bool on_device = hipPointerGetAttributes(&attr, lookups) == hipSuccess && attr.type == hipMemoryTypeDevice;      // a device vector is cut in place
+        (void)hipGetLastError();
+        hipError_t e = hipSuccess;
+        if (!on_device) {
+            HIP_TRY(hipMalloc(&d_l, len * sizeof(uint64_t)));
+            e = hipMemcpyAsync(d_l, lookups, len * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream);
+        }
         if (e == hipSuccess) {
             size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
-            k_ra_chunk_indices<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(d_l, len, (uint32_t)d, log_k_chunk, d_idx);
+            k_ra_chunk_indices<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(on_device ? lookups : d_l, len, (uint32_t)d, log_k_chunk, d_idx);
             e = hipGetLastError();            // no synchronisation: d_l goes back to the pool, which hands it out in stream order
         }
-        hipFree(d_l);
+        if (d_l) hipFree(d_l);
         if (e != hipSuccess) return fail(ATLAS_ENODEV, "ra lookups upload", e);
         return ATLAS_OK;
     }

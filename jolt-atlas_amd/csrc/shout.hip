@@ -184,11 +184,13 @@ int histogram_small_host(const uint64_t* h_idx, size_t T, KeySpec S, const atlas
     if (nw * 8 > atlas_rt::PINNED_BYTES) return fail(ATLAS_EINVAL, "shout: staging area too small");
     DevBuf acc_b, ix_b;
     HIP_TRY(acc_b.alloc(nw * 8));
-    HIP_TRY(ix_b.alloc((T ? T : 1) * 8));
+    hipPointerAttribute_t attr;
+    const bool on_device = T && hipPointerGetAttributes(&attr, h_idx) == hipSuccess && attr.type == hipMemoryTypeDevice;      // (read in place: no copy of a device vector)
+    (void)hipGetLastError();
     HIP_TRY(hipMemsetAsync(acc_b.p, 0, nw * 8, g.stream));
-    HIP_TRY(hipMemcpyAsync(ix_b.p, h_idx, T * 8, hipMemcpyDefault, g.stream));          // host or device source
+    if (!on_device) { HIP_TRY(ix_b.alloc((T ? T : 1) * 8)); HIP_TRY(hipMemcpyAsync(ix_b.p, h_idx, T * 8, hipMemcpyHostToDevice, g.stream)); }
     size_t blocks = (T + SH_THREADS - 1) / SH_THREADS; if (blocks < 1) blocks = 1; if (blocks > 512) blocks = 512;
-    k_sh_hist_small<<<(unsigned)blocks, SH_THREADS, 0, g.stream>>>(ix_b.as<uint64_t>(), T, S, (const Fe*)E->d, acc_b.as<unsigned long long>());
+    k_sh_hist_small<<<(unsigned)blocks, SH_THREADS, 0, g.stream>>>(on_device ? h_idx : ix_b.as<uint64_t>(), T, S, (const Fe*)E->d, acc_b.as<unsigned long long>());
     HIP_TRY(hipMemcpyAsync(g.h_pinned, acc_b.p, nw * 8, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
     const unsigned long long* h_acc = reinterpret_cast<const unsigned long long*>(g.h_pinned);

@@ -6,6 +6,7 @@
 //   Sumcheck::prove                        joltworks/src/subprotocols/sumcheck.rs:565-599
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -66,12 +67,61 @@ __global__ void k_store_point(EqPointArgs a, uint32_t n, Fr* __restrict__ dst) {
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) fe_store(dst + i, a.v[i]);
 }
 
+// EqPolynomial::evals of at most 16 variables in ONE launch: the point is a kernel argument; every workgroup grows the ten-level head in LDS
+// (k_eq_head's passes), owns 4096 entries of the table and multiplies in the factors of the bits above — two direct ones and the product
+// over its own index bits, formed once.  Four launches (point, head, two doublings) were one constructor step of every instance over an eq
+// table (~1800 per GPT-2-shaped proof, on the critical path).  Same residues: x - x r = x (1 - r), exact arithmetic.
+__global__ __launch_bounds__(1024) void k_eq_full(Fr* ev, EqPointArgs pt, uint32_t n, Fr scale) {
+    __shared__ Fr tab[1024];
+    __shared__ Fr s_wg;
+    const uint32_t LL = n < 10 ? n : 10;
+    if (threadIdx.x == 0) {
+        tab[0] = scale;
+        Fr f = fr_one();                                           // the bits of this workgroup's index: table bits 12, 13, ...
+        for (uint32_t q = 12; q < n; q++) { const Fr rq = pt.v[n - 1 - q]; f = fr_mul(f, ((blockIdx.x >> (q - 12)) & 1u) ? rq : fr_sub(fr_one(), rq)); }
+        s_wg = f;
+    }
+    __syncthreads();
+    for (uint32_t p = 0; p < LL; p++) {
+        const uint32_t size = 1u << p;
+        const Fr rp = pt.v[n - 1 - p];
+        const bool act = threadIdx.x < size;
+        Fr x = fe_zero(), y = fe_zero();
+        if (act) { x = tab[threadIdx.x]; y = fr_mul(x, rp); }
+        if (act) { tab[threadIdx.x + size] = y; tab[threadIdx.x] = fr_sub(x, y); }
+        __syncthreads();
+    }
+    const uint32_t top = n < 12 ? n : 12, per_wg = 1u << top, mask = (1u << LL) - 1;
+    Fr hi_r[2], hi_c[2];
+    for (uint32_t q = 0; q + LL < top; q++) { hi_r[q] = pt.v[n - 1 - (LL + q)]; hi_c[q] = fr_sub(fr_one(), hi_r[q]); }
+    const Fr wgf = s_wg;
+    for (uint32_t i = threadIdx.x; i < per_wg; i += 1024) {
+        Fr v = tab[i & mask];
+        for (uint32_t q = 0; q + LL < top; q++) v = fr_mul(v, ((i >> (LL + q)) & 1) ? hi_r[q] : hi_c[q]);
+        if (n > 12) v = fr_mul(v, wgf);
+        fe_store(ev + (size_t)blockIdx.x * per_wg + i, v);
+    }
+}
+inline bool eq_full_on() { static const bool off = getenv("ATLAS_NO_EQ_FULL") != nullptr; return !off; }      // A-B
+inline void launch_eq_full(const H::Fr* r, size_t n, const H::Fr* scaling, Fr* ev) {
+    EqPointArgs a;
+    if (n) std::memcpy(a.v, r, n * sizeof(Fr));
+    k_eq_full<<<n > 12 ? 1u << (n - 12) : 1u, 1024, 0, g.stream>>>(ev, a, (uint32_t)n, to_dev(scaling ? *scaling : H::one()));
+}
+
 // EqPolynomial::evals into a fresh device buffer (2^n Fr)
 int eq_evals_device(const H::Fr* r, size_t n, const H::Fr* scaling, Fr** out) {
     const size_t len = (size_t)1 << n;
     Fr* ev = nullptr;
     hipError_t e = hipMalloc(&ev, len * sizeof(Fr));
     if (e != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(eq)", e);
+    if (n <= 16 && eq_full_on()) {
+        launch_eq_full(r, n, scaling, ev);
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) { hipFree(ev); return fail(ATLAS_ENODEV, "eq_evals", le); }
+        *out = ev;
+        return ATLAS_OK;
+    }
     // the point travels as a kernel argument (<= 30 field elements): no staging copy, no synchronisation — the table is
     // complete in stream order, which is all its users (kernels on the library stream) need
     Fr* d_r = nullptr;
@@ -96,6 +146,11 @@ int eq_evals_device(const H::Fr* r, size_t n, const H::Fr* scaling, Fr** out) {
 
 // EqPolynomial::evals into a caller-provided device buffer of 2^n Fr (library stream; the caller holds g.mu): opening.hip's pool
 int atlas_rt_eq_evals_into(const H::Fr* r, size_t n, Fr* ev) {
+    if (n <= 16 && eq_full_on()) {
+        launch_eq_full(r, n, nullptr, ev);
+        hipError_t le0 = hipGetLastError();
+        return le0 == hipSuccess ? ATLAS_OK : fail(ATLAS_ENODEV, "eq_evals_into", le0);
+    }
     Fr* d_r = nullptr;
     HIP_TRY(hipMalloc(&d_r, (n ? n : 1) * sizeof(Fr)));
     if (n) {
