@@ -421,11 +421,14 @@ struct Prover : FlowSink {
         if (T > 1) {
             atlas_poly_t p_acc = nullptr;
             H::Fr acc_claim;
-            rc = atlas_poly_wrap_device_fr(W.acc_fr.p, T, &p_acc);
+            NodePre pre;                                                      // eq(r) and the clamp lookup's G table: in flight under the evaluation's wait
+            rc = pre.begin((const atlas_fr_t*)R.point.data(), log_T, {{W.cidx.as<uint64_t>(), (size_t)64}});
+            if (!rc) rc = atlas_poly_wrap_device_fr(W.acc_fr.p, T, &p_acc);
             if (!rc) rc = atlas_poly_evaluate(p_acc, (const atlas_fr_t*)R.point.data(), log_T, (atlas_fr_t*)&acc_claim);
             if (p_acc) atlas_poly_free(p_acc);
+            if (!rc) rc = pre.collect(false);
             if (!rc) rc = O.append_virtual(Tr, gr::node_exec(gr::virt(gr::VP_ClampAcc, nd.idx), nd.idx), R.point, acc_claim);       // append_raf_claims_prover
-            if (!rc) rc = prove_clamp_lookup_flow(W.cidx.as<uint64_t>(), log_T, (const atlas_fr_t*)R.point.data(), acc_claim, R.claim, &t, O, nullptr);
+            if (!rc) rc = prove_clamp_lookup_flow(W.cidx.as<uint64_t>(), log_T, (const atlas_fr_t*)R.point.data(), acc_claim, R.claim, &t, O, nullptr, &pre);
         }
         if (!rc) rc = eval_i32(ops, 2, T, R.point, lr);
         if (!rc) rc = append_nodeio(nd, 0, R.point, lr[0]);

@@ -14,3 +14,16 @@ double atlas_rt_last_hyperkzg_ms();
 int atlas_rt_prove_reduced_openings(const atlas_opening_t* openings, size_t n_open, atlas_srs_t srs, atlas_transcript_t* transcript, atlas_fr_t* sumcheck_rows,
                                     uint32_t* n_coeffs, atlas_u128_t* challenges, size_t* max_rounds_out, atlas_fr_t* sumcheck_claims, atlas_g1_affine_t* com,
                                     atlas_g1_affine_t* w, atlas_fr_t* v, atlas_shard_group_t sh);
+
+// compute_ra_evals in two halves (shout.hip): the launch — word sums into a pinned box, no wait — and the reduction on the host once the caller
+// has waited for the library stream anyway (a node starts with such a wait: its witness openings).  finish(wait = true) waits itself.
+struct atlas_rt_ra_ticket;
+int atlas_rt_shout_ra_evals_launch(const uint64_t* lookup_indices, size_t T, size_t log_K, size_t log_k_chunk, atlas_poly_t eq_r_cycle, atlas_rt_ra_ticket** out);
+int atlas_rt_shout_ra_evals_finish(atlas_rt_ra_ticket* t, bool wait, std::vector<atlas_host::Fr>& G);
+void atlas_rt_shout_ra_evals_drop(atlas_rt_ra_ticket* t);
+// the prefix-suffix constructors over an eq table the caller holds (EqPolynomial::evals(r_node_output), T Fr on the device; it must outlive
+// the instance): psshout.hip
+int atlas_rt_ps_shout_clamp_new(const uint64_t* lookup_indices, size_t log_T, size_t xlen, size_t bound, int symmetric, const atlas_fr_t* r_node_output,
+                                const atlas_fr_t* gamma, atlas_poly_t eq_shared, atlas_instance_t* out);
+int atlas_rt_identity_range_check_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, size_t phases, const atlas_fr_t* r_node_output,
+                                      atlas_poly_t eq_shared, atlas_instance_t* out);

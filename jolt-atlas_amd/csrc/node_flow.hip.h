@@ -182,6 +182,48 @@ struct OneHotFamily {
     const atlas_fr_t* r_cycle;                   // the r_cycle_source opening point (log_T)
     std::vector<atlas_fr_t> ra_point; H::Fr ra_claim;
     uint8_t rad_cp;
+    const std::vector<H::Fr>* G_pre = nullptr;    // compute_ra_evals(lookups, r_cycle) computed ahead (NodePre); null: computed here
+};
+
+// What the flows of ONE node share at its reduced opening point r (log_T variables), launched before the node's first wait so that the wait
+// covers them: EqPolynomial::evals(r) on the device — u_evals of the clamp lookup and of the remainder range check, the weights of the
+// one-hot G tables — and compute_ra_evals of the node's lookup families (shout.rs:550-598: they depend on r_cycle = r alone, not on
+// anything the sumchecks in between draw).  Was: the table rebuilt four times per fused-rescale node and a synchronisation per G table.
+struct NodePre {
+    atlas_poly_t eq = nullptr;
+    struct Fam { const uint64_t* lookups; size_t log_K; atlas_rt_ra_ticket* ticket; std::vector<H::Fr> G; bool have; };
+    std::vector<Fam> fams;
+    static bool on() { static const bool off = getenv("ATLAS_NO_NODE_PRE") != nullptr; return !off; }      // A-B
+    // launches only (library stream)
+    int begin(const atlas_fr_t* r, size_t log_T, std::initializer_list<std::pair<const uint64_t*, size_t>> lookups) {
+        if (!on() || log_T == 0 || log_T > 16) return ATLAS_OK;
+        int rc = atlas_eq_evals(r, log_T, nullptr, &eq);
+        for (auto& lk : lookups) {
+            if (rc) break;
+            fams.push_back(Fam{lk.first, lk.second, nullptr, {}, false});
+            rc = atlas_rt_shout_ra_evals_launch(lk.first, (size_t)1 << log_T, lk.second, 4, eq, &fams.back().ticket);
+        }
+        return rc;
+    }
+    // after the caller has waited for the library stream (or wait = true)
+    int collect(bool wait) {
+        for (auto& F : fams) {
+            if (F.have || !F.ticket) continue;
+            int rc = atlas_rt_shout_ra_evals_finish(F.ticket, wait, F.G);
+            if (rc) return rc;
+            wait = false;
+            F.have = true;
+        }
+        return ATLAS_OK;
+    }
+    const std::vector<H::Fr>* G_for(const uint64_t* lookups, size_t log_K) const {
+        for (auto& F : fams) if (F.have && F.lookups == lookups && F.log_K == log_K) return &F.G;
+        return nullptr;
+    }
+    ~NodePre() { for (auto& F : fams) if (F.ticket) atlas_rt_shout_ra_evals_drop(F.ticket); if (eq) atlas_poly_free(eq); }
+    NodePre() = default;
+    NodePre(const NodePre&) = delete;
+    NodePre& operator=(const NodePre&) = delete;
 };
 // ra_onehot_provers of every family, in order (the challenge draws of each: HammingWeight's gamma powers, Booleanity's gammas and
 // r_address): appends [RaVirtual, HammingWeight, Booleanity] per family to the batch and to `insts` (owned by the caller)
@@ -209,11 +251,14 @@ int onehot_families_build(std::vector<OneHotFamily>& fams, size_t log_T, atlas_t
         for (size_t i = 0; i < d; i++) { uint64_t lo, hi; H::tr_challenge_u128(T, lo, hi); gammas[i] = H::challenge_to_fr(lo, hi, g.challenge_mode); }
         for (size_t i = 0; i < lkc; i++) { uint64_t lo, hi; H::tr_challenge_u128(T, lo, hi); r_addr[i] = H::challenge_to_fr(lo, hi, g.challenge_mode); }
         // G = compute_ra_evals(lookup_indices, params, r_cycle) (shout.rs:550-598)
-        atlas_poly_t eq_rc = nullptr;
-        if (!rc) rc = atlas_eq_evals(F.r_cycle, log_T, nullptr, &eq_rc);
         std::vector<H::Fr> Gh;
-        if (!rc) rc = atlas_rt_shout_ra_evals_host(F.d_lookups, (size_t)1 << log_T, F.log_K, lkc, eq_rc, Gh);
-        if (eq_rc) atlas_poly_free(eq_rc);
+        if (F.G_pre) Gh = *F.G_pre;
+        else {
+            atlas_poly_t eq_rc = nullptr;
+            if (!rc) rc = atlas_eq_evals(F.r_cycle, log_T, nullptr, &eq_rc);
+            if (!rc) rc = atlas_rt_shout_ra_evals_host(F.d_lookups, (size_t)1 << log_T, F.log_K, lkc, eq_rc, Gh);
+            if (eq_rc) atlas_poly_free(eq_rc);
+        }
         if (rc) break;
         std::vector<atlas_fr_t> G(d << lkc);
         std::memcpy(G.data(), Gh.data(), G.size() * sizeof(atlas_fr_t));
@@ -291,9 +336,11 @@ int prove_onehot_checks_multi(std::vector<OneHotFamily>& fams, size_t log_T, atl
     return rc;
 }
 int prove_onehot_checks(const uint64_t* d_lookups, size_t log_T, size_t log_K, const atlas_fr_t* r_cycle, const std::vector<atlas_fr_t>& ra_point,
-                        const H::Fr& ra_claim, atlas_transcript_t* t, Out& O, uint8_t rad_cp = 0, uint8_t proof_type = gr::PT_RaOneHotChecks) {
+                        const H::Fr& ra_claim, atlas_transcript_t* t, Out& O, uint8_t rad_cp = 0, uint8_t proof_type = gr::PT_RaOneHotChecks,
+                        const NodePre* pre = nullptr) {
     std::vector<OneHotFamily> f(1);
     f[0].d_lookups = d_lookups; f[0].log_K = log_K; f[0].r_cycle = r_cycle; f[0].ra_point = ra_point; f[0].ra_claim = ra_claim; f[0].rad_cp = rad_cp;
+    if (pre) f[0].G_pre = pre->G_for(d_lookups, log_K);
     return prove_onehot_checks_multi(f, log_T, t, O, proof_type);
 }
 
@@ -348,14 +395,15 @@ inline size_t identity_rc_phases(size_t log_K) {
 // (ProofType::RaOneHotChecks) over the ClampRaD chunks.  acc_claim = the i64 accumulation's opening (already appended),
 // out_claim = the node output's reduced opening.  stage_ms[0..1]: lookup, one-hot checks.
 inline int prove_clamp_lookup_flow(const uint64_t* d_cidx, size_t log_T, const atlas_fr_t* r_node_output, const H::Fr& acc_claim, const H::Fr& out_claim,
-                                   atlas_transcript_t* t, Out& O, double* stage_ms) {
+                                   atlas_transcript_t* t, Out& O, double* stage_ms, const NodePre* pre = nullptr) {
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point a) { atlas_sync(); return std::chrono::duration<double, std::milli>(now() - a).count(); };
     H::Transcript& Tr = *reinterpret_cast<H::Transcript*>(t);
     auto t0 = now();
     const H::Fr gamma = H::tr_challenge_scalar(Tr);                          // ps_read_raf_prover (unary.rs:112)
     atlas_instance_t exec = nullptr;
-    int rc = atlas_ps_shout_clamp_new(d_cidx, log_T, 64, 31, 1, r_node_output, (const atlas_fr_t*)&gamma, &exec);
+    int rc = pre && pre->eq ? atlas_rt_ps_shout_clamp_new(d_cidx, log_T, 64, 31, 1, r_node_output, (const atlas_fr_t*)&gamma, pre->eq, &exec)
+                            : atlas_ps_shout_clamp_new(d_cidx, log_T, 64, 31, 1, r_node_output, (const atlas_fr_t*)&gamma, &exec);
     const H::Fr exec_claim = H::add(out_claim, H::mul(gamma, acc_claim));     // rv_claim + gamma * operand_claim (ps_shout/mod.rs:142-144)
     std::vector<atlas_u128_t> ch;
     H::Fr ra_claim;
@@ -365,7 +413,7 @@ inline int prove_clamp_lookup_flow(const uint64_t* d_cidx, size_t log_T, const a
     if (stage_ms) stage_ms[0] = ms_since(t0);
     O.mark("clamp lookup: read-raf (64)");
     t0 = now();
-    if (!rc) rc = prove_onehot_checks(d_cidx, log_T, 64, r_node_output, ra_point, ra_claim, t, O, gr::CP_ClampRaD, gr::PT_RaOneHotChecks);
+    if (!rc) rc = prove_onehot_checks(d_cidx, log_T, 64, r_node_output, ra_point, ra_claim, t, O, gr::CP_ClampRaD, gr::PT_RaOneHotChecks, pre);
     if (stage_ms) stage_ms[1] = ms_since(t0);
     O.mark("clamp lookup: one-hot (d=16)");
     return rc;
@@ -389,6 +437,9 @@ int prove_fused_rescale(RescaleWitness& W, Inner&& inner, const atlas_fr_t* r_no
 
     auto t0 = now();
     int rc = ATLAS_OK;
+    NodePre pre;                                                             // eq(r_node_output) and the G tables of both lookups: in flight under the wait below
+    if (T > 1) rc = pre.begin(r_node_output, log_T, {{W.cidx.as<uint64_t>(), (size_t)64}, {W.ridx.as<uint64_t>(), S}});
+    if (rc) return rc;
     atlas_poly_t p_rem = nullptr, p_quot = nullptr, p_out = nullptr;
     {   // borrowed views for evaluate
         rc = atlas_poly_wrap_device_fr(W.qfr.p, T, &p_quot);
@@ -404,6 +455,7 @@ int prove_fused_rescale(RescaleWitness& W, Inner&& inner, const atlas_fr_t* r_no
         if (output_claim) std::memcpy(&out_claim, output_claim, 32); else out_claim = ev[2];
     }
     for (atlas_poly_t p : {p_rem, p_quot, p_out}) if (p) atlas_poly_free(p);
+    if (!rc) rc = pre.collect(false);                                        // (atlas_poly_evaluate_many waited for the library stream)
     if (stage_ms) stage_ms[0] = ms_since(t0);
     if (rc) return rc;
     O.mark("fused: witness openings");
@@ -414,7 +466,7 @@ int prove_fused_rescale(RescaleWitness& W, Inner&& inner, const atlas_fr_t* r_no
     // (a scalar node — is_scalar, clamp_lookups/mod.rs:67 — has no lookups: prove_append_acc only, fused_rebase.rs:215-231; its verifier reads
     // the accumulation and the remainder in the clear)
     const bool scalar = T == 1;
-    if (!rc && !scalar) rc = prove_clamp_lookup_flow(W.cidx.as<uint64_t>(), log_T, r_node_output, acc_claim, out_claim, t, O, stage_ms ? stage_ms + 1 : nullptr);
+    if (!rc && !scalar) rc = prove_clamp_lookup_flow(W.cidx.as<uint64_t>(), log_T, r_node_output, acc_claim, out_claim, t, O, stage_ms ? stage_ms + 1 : nullptr, &pre);
 
     // ---- the operator's sumcheck over the accumulator
     t0 = now();
@@ -435,14 +487,15 @@ int prove_fused_rescale(RescaleWitness& W, Inner&& inner, const atlas_fr_t* r_no
     if (!rc) {
         const size_t phases = identity_rc_phases(S);
         atlas_instance_t rcq = nullptr;
-        rc = atlas_identity_range_check_new(W.ridx.as<uint64_t>(), log_T, S, phases, r_node_output, &rcq);
+        rc = pre.eq ? atlas_rt_identity_range_check_new(W.ridx.as<uint64_t>(), log_T, S, phases, r_node_output, pre.eq, &rcq)
+                    : atlas_identity_range_check_new(W.ridx.as<uint64_t>(), log_T, S, phases, r_node_output, &rcq);
         if (!rc) rc = prove_single(rcq, eval_R, t, O, ch, &rr_claim, S, gr::VP_RescaleRemainderRa, gr::PT_RangeCheck, &rr_point);
         if (rcq) atlas_instance_free(rcq);
     }
     if (stage_ms) stage_ms[4] = ms_since(t0);
     O.mark("fused: remainder range check");
     t0 = now();
-    if (!rc) rc = prove_onehot_checks(W.ridx.as<uint64_t>(), log_T, S, r_node_output, rr_point, rr_claim, t, O, gr::CP_RescaleRemainderRaD, gr::PT_RescaleRemainderRaChecks);
+    if (!rc) rc = prove_onehot_checks(W.ridx.as<uint64_t>(), log_T, S, r_node_output, rr_point, rr_claim, t, O, gr::CP_RescaleRemainderRaD, gr::PT_RescaleRemainderRaChecks, &pre);
     if (stage_ms) stage_ms[5] = ms_since(t0);
     O.mark("fused: remainder one-hot");
     return rc;

@@ -572,7 +572,8 @@ struct PsLookup : atlas_instance {
     size_t q_rows_max() const { size_t r = ((size_t)1 << 17) / m; if (r > 2048) r = 2048; return r < SLICES ? SLICES : r; }
 
     bool idx_borrowed = false;            // d_idx is the caller's device vector (it outlives the instance: a node's witness), not a copy
-    ~PsLookup() override { for (void* p : {(void*)(idx_borrowed ? nullptr : d_idx), (void*)d_u0, (void*)d_v, (void*)d_qpart}) if (p) hipFree(p); rows.release(); eq.release(); }
+    bool u0_borrowed = false;
+    ~PsLookup() override { for (void* p : {(void*)(idx_borrowed ? nullptr : d_idx), (void*)(u0_borrowed ? nullptr : d_u0), (void*)d_v, (void*)d_qpart}) if (p) hipFree(p); rows.release(); eq.release(); }
     bool one_cycle = false;               // log_T == 0 held as two cycles, the second of weight zero (ps_new)
     size_t rounds() const override { return one_cycle ? N : N + log_T; }
     size_t degree() const override { return 2; }
@@ -1209,7 +1210,7 @@ __global__ __launch_bounds__(RA_THREADS) void k_lookup_indices(const int32_t* __
 extern "C" {
 
 static int ps_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, size_t phases, int mode, const atlas_fr_t* r_node_output,
-                  const atlas_fr_t* gamma, atlas_instance_t* out, size_t bound = 0, bool symmetric = true) {
+                  const atlas_fr_t* gamma, atlas_instance_t* out, size_t bound = 0, bool symmetric = true, atlas_poly_t eq_shared = nullptr) {
     // log_T == 0 — a read-raf instance WITHOUT cycle variables (ps_shout/mod.rs:419-446 at T = 1: log_K address rounds, then the ra value of the one
     // lookup).  Held as TWO cycles of which the second has weight u = 0 and index 0: every sum over cycles of the address rounds is the one-cycle
     // sum, no kernel meets a length of one; the instance reports log_K rounds, is stepped by the host (the fold of the last phase's table
@@ -1217,7 +1218,8 @@ static int ps_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, si
     const bool one_cycle = log_T == 0;
     if (one_cycle) log_T = 1;
     atlas_poly_t E = nullptr;
-    int rc = atlas_eq_evals(r_node_output, one_cycle ? 0 : log_T, nullptr, &E);      // u_evals = EqPolynomial::evals(r_node_output), mod.rs:234
+    if (eq_shared && (one_cycle || eq_shared->is_i32 || eq_shared->len != ((size_t)1 << log_T))) return fail(ATLAS_EINVAL, "ps_shout_new: shared eq table of the wrong length");
+    int rc = eq_shared ? ATLAS_OK : atlas_eq_evals(r_node_output, one_cycle ? 0 : log_T, nullptr, &E);      // u_evals = EqPolynomial::evals(r_node_output), mod.rs:234
     if (rc) return rc;
     std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     PsLookup* P = new PsLookup();
@@ -1232,7 +1234,8 @@ static int ps_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, si
         if (e == hipSuccess) e = hipMemsetAsync(P->d_u0, 0, 2 * sizeof(Fr), g.stream);
         if (e == hipSuccess) e = hipMemcpyAsync(P->d_u0, E->d, sizeof(Fr), hipMemcpyDeviceToDevice, g.stream);
         atlas_poly_free(E);
-    } else { P->d_u0 = (Fr*)E->d; delete E; }                        // keep the table, drop the handle
+    } else if (eq_shared) { P->d_u0 = (Fr*)eq_shared->d; P->u0_borrowed = true; }      // the caller's table (it outlives the instance)
+    else { P->d_u0 = (Fr*)E->d; delete E; }                          // keep the table, drop the handle
     {   // device-resident indices (the graph prover's witness vectors, alive until the graph is freed) are read in place
         hipPointerAttribute_t attr;
         const bool on_device = !one_cycle && hipPointerGetAttributes(&attr, lookup_indices) == hipSuccess && attr.type == hipMemoryTypeDevice;
@@ -1281,6 +1284,29 @@ int atlas_ps_shout_clamp_new(const uint64_t* lookup_indices, size_t log_T, size_
     if (log_T > 25) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: log_T <= 25");
     return ps_new(lookup_indices, log_T, xlen, 8, 2, r_node_output, gamma, out, bound, symmetric != 0);
 }
+
+}  // extern "C"
+int atlas_rt_ps_shout_clamp_new(const uint64_t* lookup_indices, size_t log_T, size_t xlen, size_t bound, int symmetric, const atlas_fr_t* r_node_output,
+                                const atlas_fr_t* gamma, atlas_poly_t eq_shared, atlas_instance_t* out) {
+    PROF("atlas_ps_shout_clamp_new");
+    NEED_INIT();
+    if (!lookup_indices || (!r_node_output && log_T) || !gamma || !out) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: null argument");
+    if (xlen != 16 && xlen != 32 && xlen != 64) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: X_LEN must be 16, 32 or 64");
+    if (bound == 0 || bound + 1 >= xlen || bound > 31) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: 1 <= BOUND <= 31 and BOUND < X_LEN - 1");
+    if (log_T > 25) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: log_T <= 25");
+    return ps_new(lookup_indices, log_T, xlen, 8, 2, r_node_output, gamma, out, bound, symmetric != 0, log_T ? eq_shared : nullptr);
+}
+int atlas_rt_identity_range_check_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, size_t phases, const atlas_fr_t* r_node_output,
+                                      atlas_poly_t eq_shared, atlas_instance_t* out) {
+    PROF("atlas_identity_range_check_new");
+    NEED_INIT();
+    if (!lookup_indices || (!r_node_output && log_T) || !out) return fail(ATLAS_EINVAL, "identity_range_check_new: null argument");
+    if (phases == 0 || log_K == 0 || log_K > 64 || log_K % phases || log_K / phases > 12)
+        return fail(ATLAS_EINVAL, "identity_range_check_new: log_K must be a multiple of phases, chunks of at most 12 bits");
+    if (log_T > 25) return fail(ATLAS_EINVAL, "identity_range_check_new: log_T <= 25");
+    return ps_new(lookup_indices, log_T, log_K, phases, 1, r_node_output, nullptr, out, 0, true, log_T ? eq_shared : nullptr);
+}
+extern "C" {
 
 int atlas_ps_shout_rshift_new(const uint64_t* lookup_indices, size_t log_T, size_t xlen, size_t shift, const atlas_fr_t* r_node_output,
                               const atlas_fr_t* gamma, atlas_instance_t* out) {

@@ -18,6 +18,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include "../../include/atlas_hip.h"
@@ -332,6 +333,44 @@ int atlas_rt_shout_ra_evals_host(const uint64_t* lookup_indices, size_t T, size_
     std::lock_guard<atlas_rt::Mutex> lk(g.mu);
     return histogram_small_host(lookup_indices, T, KeySpec{d, (uint32_t)log_k_chunk}, eq_r_cycle, G);
 }
+
+struct atlas_rt_ra_ticket { DevBuf acc; const unsigned long long* box = nullptr; uint32_t n_buckets = 0; };
+int atlas_rt_shout_ra_evals_launch(const uint64_t* lookup_indices, size_t T, size_t log_K, size_t log_k_chunk, atlas_poly_t eq_r_cycle, atlas_rt_ra_ticket** out) {
+    PROF("atlas_rt_shout_ra_evals_launch");
+    const uint32_t d = (uint32_t)((log_K + log_k_chunk - 1) / log_k_chunk);
+    if (!lookup_indices || !eq_r_cycle || !out || log_k_chunk == 0 || log_k_chunk > 16 || ((size_t)d << log_k_chunk) > SH_SMALL_BUCKETS)
+        return fail(ATLAS_EINVAL, "shout_ra_evals_launch");
+    if (eq_r_cycle->is_i32 || eq_r_cycle->len < T) return fail(ATLAS_EINVAL, "shout: eq table shorter than the index list");
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, lookup_indices) != hipSuccess || attr.type != hipMemoryTypeDevice) { (void)hipGetLastError(); return fail(ATLAS_EINVAL, "shout_ra_evals_launch: device-resident indices expected"); }
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::unique_ptr<atlas_rt_ra_ticket> tk(new atlas_rt_ra_ticket());
+    const KeySpec S{d, (uint32_t)log_k_chunk};
+    tk->n_buckets = d << log_k_chunk;
+    const size_t nw = (size_t)tk->n_buckets * 8;
+    HIP_TRY(tk->acc.alloc(nw * 8));
+    HIP_TRY(hipMemsetAsync(tk->acc.p, 0, nw * 8, g.stream));
+    size_t blocks = (T + SH_THREADS - 1) / SH_THREADS; if (blocks < 1) blocks = 1; if (blocks > 512) blocks = 512;
+    k_sh_hist_small<<<(unsigned)blocks, SH_THREADS, 0, g.stream>>>(lookup_indices, T, S, (const Fe*)eq_r_cycle->d, tk->acc.as<unsigned long long>());
+    atlas::Chunk* box = g.chan.alloc_long((nw * 8 + 15) / 16);          // pinned: the copy lands there in stream order
+    HIP_TRY(hipMemcpyAsync(box, tk->acc.p, nw * 8, hipMemcpyDeviceToHost, g.stream));
+    tk->box = reinterpret_cast<const unsigned long long*>(box);
+    *out = tk.release();
+    return ATLAS_OK;
+}
+int atlas_rt_shout_ra_evals_finish(atlas_rt_ra_ticket* tk, bool wait, std::vector<atlas_host::Fr>& G) {
+    if (!tk) return fail(ATLAS_EINVAL, "shout_ra_evals_finish");
+    if (wait) { std::lock_guard<atlas_rt::Mutex> lk(g.mu); HIP_TRY(hipStreamSynchronize(g.stream)); }
+    G.resize(tk->n_buckets);
+    for (uint32_t b = 0; b < tk->n_buckets; b++) {
+        uint64_t a9[9];
+        for (int w = 0; w < 8; w++) a9[w] = tk->box[(size_t)b * 8 + w];
+        a9[8] = 0;
+        G[b] = atlas_rt::sum_to_fr(a9, 32, 0);
+    }
+    return ATLAS_OK;
+}
+void atlas_rt_shout_ra_evals_drop(atlas_rt_ra_ticket* tk) { delete tk; }
 
 extern "C" {
 
