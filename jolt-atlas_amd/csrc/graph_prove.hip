@@ -679,11 +679,14 @@ struct Prover : FlowSink {
         if (rc) return rc;
         atlas_poly_t p_acc = nullptr;
         H::Fr acc_claim;
-        rc = atlas_poly_wrap_device_fr(W.acc_fr.p, T, &p_acc);
+        NodePre pre;
+        if (T > 1) rc = pre.begin((const atlas_fr_t*)R.point.data(), log_T, {{W.cidx.as<uint64_t>(), (size_t)64}});
+        if (!rc) rc = atlas_poly_wrap_device_fr(W.acc_fr.p, T, &p_acc);
         if (!rc) rc = atlas_poly_evaluate(p_acc, (const atlas_fr_t*)R.point.data(), log_T, (atlas_fr_t*)&acc_claim);
         if (p_acc) atlas_poly_free(p_acc);
+        if (!rc) rc = pre.collect(T == 1);
         if (!rc) rc = O.append_virtual(Tr, gr::node_exec(gr::virt(gr::VP_ClampAcc, nd.idx), nd.idx), R.point, acc_claim);           // prove_append_acc / append_raf_claims_prover
-        if (!rc && T > 1) rc = prove_clamp_lookup_flow(W.cidx.as<uint64_t>(), log_T, (const atlas_fr_t*)R.point.data(), acc_claim, R.claim, &t, O, nullptr);
+        if (!rc && T > 1) rc = prove_clamp_lookup_flow(W.cidx.as<uint64_t>(), log_T, (const atlas_fr_t*)R.point.data(), acc_claim, R.claim, &t, O, nullptr, &pre);
         if (rc) return rc;
         atlas_poly_t eq = nullptr, v = nullptr;
         rc = atlas_eq_evals((const atlas_fr_t*)R.point.data(), log_T, nullptr, &eq);
@@ -861,16 +864,19 @@ struct Prover : FlowSink {
         const int64_t D = ((int64_t)1 << nd.p[0]) * (int64_t)nd.p[1];
         Out O = out();
         atlas_poly_t p_rem = nullptr, p_quot = nullptr;
-        int rc = atlas_poly_wrap_device_fr(RW.qfr.p, T, &p_quot);
+        NodePre pre;
+        int rc = T > 1 ? pre.begin((const atlas_fr_t*)R.point.data(), log_T, {{RW.cidx.as<uint64_t>(), (size_t)64}}) : ATLAS_OK;
+        if (!rc) rc = atlas_poly_wrap_device_fr(RW.qfr.p, T, &p_quot);
         if (!rc) rc = atlas_poly_wrap_device_i32(RW.rem.as<int32_t>(), T, &p_rem);
         H::Fr ev[2];
         if (!rc) { const atlas_poly_t ps[2] = {p_rem, p_quot}; rc = atlas_poly_evaluate_many(ps, 2, (const atlas_fr_t*)R.point.data(), log_T, (atlas_fr_t*)ev); }
         for (atlas_poly_t p : {p_rem, p_quot}) if (p) atlas_poly_free(p);
+        if (!rc) rc = pre.collect(false);
         if (rc) return rc;
         const H::Fr eval_R = ev[0], acc_claim = ev[1];
         rc = append_advice(nd, gr::VP_RescaleRemainder, R.point, eval_R);                                                // fused_rebase::prove_pre
         if (!rc) rc = append_advice(nd, gr::VP_ClampAcc, R.point, acc_claim);
-        if (!rc && T > 1) rc = prove_clamp_lookup_flow(RW.cidx.as<uint64_t>(), log_T, (const atlas_fr_t*)R.point.data(), acc_claim, R.claim, &t, O, nullptr);
+        if (!rc && T > 1) rc = prove_clamp_lookup_flow(RW.cidx.as<uint64_t>(), log_T, (const atlas_fr_t*)R.point.data(), acc_claim, R.claim, &t, O, nullptr, &pre);
         if (rc) return rc;
         // MeanOfSquaresReductionProver: sum_{k,j} eq(r, k) x[k,j]^2 = rescaled(r) D + R(r); HighToLow, EqSchedule::High { log_retained, log_reduced }
         DevBuf lbuf, rbuf;

@@ -668,6 +668,7 @@ struct Booleanity : atlas_instance {
                     H::Fr s0 = H::zero(), s1 = H::zero();
                     for (size_t k = 0; k < ((size_t)1 << m); k++) {
                         const H::Fr& Gk = G[i][(kp << m) + k];
+                        if (H::detail::is_zero4(Gk.l)) continue;          // (an address no lookup reads adds nothing: GatherSmall's table has 2^16 addresses and 16 lookups)
                         const H::Fr& Fk = F[k % ((size_t)1 << (m - 1))];
                         const H::Fr gf = H::mul(Gk, Fk), ei = H::mul(gf, Fk);
                         if ((k >> (m - 1)) == 0) s0 = H::add(s0, H::sub(ei, gf));
@@ -867,7 +868,10 @@ struct HammingWeight : atlas_instance {
         const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
         for (auto& p : ra) {
             const size_t half = p.size() / 2;
-            for (size_t k = 0; k < half; k++) p[k] = H::add(p[2 * k], H::mul(rf, H::sub(p[2 * k + 1], p[2 * k])));
+            for (size_t k = 0; k < half; k++) {
+                if (H::detail::is_zero4(p[2 * k].l) && H::detail::is_zero4(p[2 * k + 1].l)) { p[k] = H::zero(); continue; }     // (GatherSmall: 2^16 addresses, a handful read)
+                p[k] = H::add(p[2 * k], H::mul(rf, H::sub(p[2 * k + 1], p[2 * k])));
+            }
             p.resize(half);
         }
         round_next++;
