@@ -685,6 +685,7 @@ struct PsLookup : atlas_instance {
         size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 256) gb = 256;
         const PsSignOut O{acc, mn, mn + 16, reinterpret_cast<Fr*>(box + 4), box, tag};
         if (NQ == 6) k_ps_sign_scan<6><<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(d_idx, d_u0, T, (uint32_t)N, (uint32_t)log_m, ph, (uint32_t)bound, O);
+        else if (NQ == 4) k_ps_sign_scan<4><<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(d_idx, d_u0, T, (uint32_t)N, (uint32_t)log_m, ph, 0u, O);
         else k_ps_sign_scan<2><<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(d_idx, d_u0, T, (uint32_t)N, (uint32_t)log_m, ph, 0u, O);
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) return fail(ATLAS_ENODEV, "ps_shout: sign scan", le);
@@ -1257,7 +1258,8 @@ static int ps_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, si
     }
     // (the shortcut serves the round-channel drivers; a host-stepped caller falls back in its first call)
     static const bool no_sign = getenv("ATLAS_PS_NO_SIGN") != nullptr || getenv("ATLAS_NO_PIPELINE") != nullptr;     // A-B
-    const bool try_sign = (mode == 0 || mode == 2) && !one_cycle && m <= RA_THREADS && phases >= 3 && phases - 1 <= PS_SIGN_PMAX && g.fs_mode == ATLAS_FS_HOST && !no_sign;
+    // (mode 3, the binary UnsignedLessThan range checks: the interleaved operands are small non-negative integers — one class, leading zero chunks)
+    const bool try_sign = (mode == 0 || mode == 2 || mode == 3) && !one_cycle && m <= RA_THREADS && phases >= 3 && phases - 1 <= PS_SIGN_PMAX && g.fs_mode == ATLAS_FS_HOST && !no_sign;
     if (!rc) rc = try_sign ? P->sign_setup() : P->build_Q(0);
     if (rc) { delete P; return rc; }
     *out = P;

@@ -1,0 +1,5 @@
+timeout 600 python -m pytest tests/test_gpu_psshout.py tests/test_gpu_graph.py -q -m gpu -x 2>&1 | tail -3
+for i in 1 2; do
+ATLAS_GRAPH_VERIFY=0 python tools/time_graph.py gpt2 2 2 2>&1 | tail -1 | cut -c1-200
+done
+python tools/time_graph.py nanogpt_model,gpt2_layer,microgpt_model 2 3 2>&1 | tail -3 | cut -c1-250
