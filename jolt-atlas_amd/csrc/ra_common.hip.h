@@ -138,17 +138,34 @@ __device__ __forceinline__ void tail_reduce(const MailTail& tail) {
     unsigned long long s0 = 0, s1 = 0, s2 = 0;
     if (grp < n_grp) {
         const uint64_t t0 = wall_clock64();
-        for (uint32_t row = grp; row < tail.n_rows; row += n_grp) {
-            const Chunk* p = tail.tagged + (size_t)row * nchunk + c;
-            ch_u32x4 x = ch_load_dev(p);
-            uint32_t spins = 0;
-            while (x.w != tag) {
-                if ((++spins & 63u) == 0 && (__hip_atomic_load(tail.io.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > CH_TIMEOUT_TICKS)) { tr_bad = 1; break; }
-                __builtin_amdgcn_s_sleep(2);
-                x = ch_load_dev(p);
+        // four rows per trip, their loads in flight together (a device-scope load is ~0.7 us of latency; one at a time the 96 chunks a thread
+        // owns in a 512-row launch were the round: 65 us); a chunk whose tag has not arrived is polled on its own
+        for (uint32_t row = grp; row < tail.n_rows; row += 4 * n_grp) {
+            const Chunk* p[4];
+            ch_u32x4 x[4];
+            bool live[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t ru = row + (uint32_t)u * n_grp;
+                live[u] = ru < tail.n_rows;
+                p[u] = tail.tagged + (size_t)(live[u] ? ru : row) * nchunk + c;
             }
-            if (x.w != tag) break;
-            s0 += x.x; s1 += x.y; s2 += x.z;
+            asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]) : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]) : "memory");
+            bool bad = false;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (!live[u]) continue;
+                uint32_t spins = 0;
+                while (x[u].w != tag) {
+                    if ((++spins & 63u) == 0 && (__hip_atomic_load(tail.io.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > CH_TIMEOUT_TICKS)) { tr_bad = 1; bad = true; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                    x[u] = ch_load_dev(p[u]);
+                }
+                if (bad) break;
+                s0 += x[u].x; s1 += x[u].y; s2 += x[u].z;
+            }
+            if (bad) break;
         }
     }
     tr_sm[threadIdx.x][0] = s0; tr_sm[threadIdx.x][1] = s1; tr_sm[threadIdx.x][2] = s2;
