@@ -424,7 +424,7 @@ struct Prover : FlowSink {
             NodePre pre;                                                      // eq(r) and the clamp lookup's G table: in flight under the evaluation's wait
             rc = pre.begin((const atlas_fr_t*)R.point.data(), log_T, {{W.cidx.as<uint64_t>(), (size_t)64}});
             if (!rc) rc = atlas_poly_wrap_device_fr(W.acc_fr.p, T, &p_acc);
-            if (!rc) rc = atlas_poly_evaluate(p_acc, (const atlas_fr_t*)R.point.data(), log_T, (atlas_fr_t*)&acc_claim);
+            if (!rc) rc = pre.eq ? atlas_rt_evaluate_with_eq(&p_acc, 1, pre.eq, (atlas_fr_t*)&acc_claim) : atlas_poly_evaluate(p_acc, (const atlas_fr_t*)R.point.data(), log_T, (atlas_fr_t*)&acc_claim);
             if (p_acc) atlas_poly_free(p_acc);
             if (!rc) rc = pre.collect(false);
             if (!rc) rc = O.append_virtual(Tr, gr::node_exec(gr::virt(gr::VP_ClampAcc, nd.idx), nd.idx), R.point, acc_claim);       // append_raf_claims_prover
@@ -869,7 +869,7 @@ struct Prover : FlowSink {
         if (!rc) rc = atlas_poly_wrap_device_fr(RW.qfr.p, T, &p_quot);
         if (!rc) rc = atlas_poly_wrap_device_i32(RW.rem.as<int32_t>(), T, &p_rem);
         H::Fr ev[2];
-        if (!rc) { const atlas_poly_t ps[2] = {p_rem, p_quot}; rc = atlas_poly_evaluate_many(ps, 2, (const atlas_fr_t*)R.point.data(), log_T, (atlas_fr_t*)ev); }
+        if (!rc) { const atlas_poly_t ps[2] = {p_rem, p_quot}; rc = pre.eq ? atlas_rt_evaluate_with_eq(ps, 2, pre.eq, (atlas_fr_t*)ev) : atlas_poly_evaluate_many(ps, 2, (const atlas_fr_t*)R.point.data(), log_T, (atlas_fr_t*)ev); }
         for (atlas_poly_t p : {p_rem, p_quot}) if (p) atlas_poly_free(p);
         if (!rc) rc = pre.collect(false);
         if (rc) return rc;

@@ -27,3 +27,5 @@ int atlas_rt_ps_shout_clamp_new(const uint64_t* lookup_indices, size_t log_T, si
                                 const atlas_fr_t* gamma, atlas_poly_t eq_shared, atlas_instance_t* out);
 int atlas_rt_identity_range_check_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, size_t phases, const atlas_fr_t* r_node_output,
                                       atlas_poly_t eq_shared, atlas_instance_t* out);
+// MultilinearPolynomial::evaluate of <= 3 polynomials against a full eq table on the device (spliteq.hip); waits for the library stream
+int atlas_rt_evaluate_with_eq(const atlas_poly_t* polys, size_t count, atlas_poly_t eq_full, atlas_fr_t* out);

@@ -450,7 +450,8 @@ int prove_fused_rescale(RescaleWitness& W, Inner&& inner, const atlas_fr_t* r_no
     if (!rc) {   // the three openings at r_node_output share their eq tables and one synchronisation
         const atlas_poly_t ps[3] = {p_rem, p_quot, p_out};
         H::Fr ev[3];
-        rc = atlas_poly_evaluate_many(ps, output_claim ? 2 : 3, r_node_output, log_T, (atlas_fr_t*)ev);
+        rc = pre.eq ? atlas_rt_evaluate_with_eq(ps, output_claim ? 2 : 3, pre.eq, (atlas_fr_t*)ev)                  // (one pass against the node's eq table)
+                    : atlas_poly_evaluate_many(ps, output_claim ? 2 : 3, r_node_output, log_T, (atlas_fr_t*)ev);
         eval_R = ev[0]; acc_claim = ev[1];
         if (output_claim) std::memcpy(&out_claim, output_claim, 32); else out_claim = ev[2];
     }

@@ -217,6 +217,49 @@ int atlas_poly_evaluate_many(const atlas_poly_t* polys, size_t count, const atla
     return ATLAS_OK;
 }
 
+}  // extern "C"
+
+// MultilinearPolynomial::evaluate of up to three polynomials at the point whose FULL eq table the caller holds (node_flow.hip.h: NodePre):
+// one pass — sum_i eq[i] Z_q[i] for every q — and one reduction, against two tables, a pass and a reduction per polynomial above.
+namespace {
+struct EvalEqArgs { const void* p[3]; uint32_t is_i32[3]; uint32_t count; };
+__global__ __launch_bounds__(SC_THREADS) void k_eval_with_eq(EvalEqArgs A, const Fr* __restrict__ eq, size_t len, Fr* partials, ScConsts K) {
+    Fr acc[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) acc[q] = fe_zero();
+    for (size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x; i < len; i += (size_t)gridDim.x * SC_THREADS) {
+        const Fr e = fe_load(eq + i);
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            if (q >= (int)A.count) break;
+            const Fr z = A.is_i32[q] ? fr_from_i32(reinterpret_cast<const int32_t*>(A.p[q])[i], K.k32) : fe_load(reinterpret_cast<const Fr*>(A.p[q]) + i);
+            acc[q] = fr_add(acc[q], fr_mul(e, z));
+        }
+    }
+    block_reduce_store<3>(acc, partials);
+}
+}  // namespace
+int atlas_rt_evaluate_with_eq(const atlas_poly_t* polys, size_t count, atlas_poly_t eq_full, atlas_fr_t* out) {
+    PROF("atlas_rt_evaluate_with_eq");
+    NEED_INIT();
+    if (!polys || !count || count > 3 || !eq_full || eq_full->is_i32 || !out) return fail(ATLAS_EINVAL, "evaluate_with_eq");
+    EvalEqArgs A{};
+    A.count = (uint32_t)count;
+    for (size_t q = 0; q < count; q++) {
+        if (!polys[q] || polys[q]->len != eq_full->len) return fail(ATLAS_EINVAL, "evaluate_with_eq: length != the eq table's");
+        A.p[q] = polys[q]->d; A.is_i32[q] = polys[q]->is_i32 ? 1u : 0u;
+    }
+    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    const int grid = grid_for(eq_full->len);
+    k_eval_with_eq<<<grid, SC_THREADS, 0, g.stream>>>(A, (const Fr*)eq_full->d, eq_full->len, g.d_partials, make_consts());
+    k_reduce1<<<1, SC_THREADS, 0, g.stream>>>(g.d_partials, grid, (Fr*)g.h_pinned, 3);
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    std::memcpy(out, g.h_pinned, count * sizeof(Fr));
+    return ATLAS_OK;
+}
+
+extern "C" {
+
 int atlas_poly_evaluate(atlas_poly_t p, const atlas_fr_t* r, size_t n, atlas_fr_t* out) {
     PROF("atlas_poly_evaluate");
     if (!p) return fail(ATLAS_EINVAL, "poly_evaluate");
