@@ -240,6 +240,19 @@ int atlas_rt_einsum_acc(const Node& nd, const int32_t* L, const int32_t* R, int6
     Strides S{}; S.n = (uint32_t)od.size();
     size_t T = 1;
     for (size_t i = 0; i < od.size(); i++) { S.dim[i] = (uint32_t)od[i]; S.a[i] = (uint32_t)la[i]; S.b[i] = (uint32_t)ra[i]; T *= od[i]; }
+    static const bool generic_only = getenv("ATLAS_EINSUM_GENERIC") != nullptr;      // A-B
+    if ((int)nd.p[0] == ATLAS_EINSUM_MK_KN_MN && !generic_only) {
+        // the projections (and the lm head: 16 x 1024 . 1024 x 65536): a thread owns a column of B for 8 rows of A and a slice of k, so B is read
+        // once per row TILE — the one-thread-per-output kernel below re-reads it once per row of A: 42 of the 52 ms of a GPT-2-shaped trace
+        const size_t m = nd.shape[0], k = nd.shape[1], n = nd.shape[2];
+        uint32_t slices = 1;
+        while (slices < 64 && (n * ((m + EB_ROWS - 1) / EB_ROWS)) * slices < ((size_t)1 << 16) && k / (slices * 2) >= 32) slices *= 2;
+        const uint32_t k_slice = (uint32_t)((k + slices - 1) / slices);
+        HIP_TRY(hipMemsetAsync(d_acc, 0, T * 8, g.stream));
+        k_einsum_acc_mk_kn<<<dim3((unsigned)((n + 255) / 256), (unsigned)((m + EB_ROWS - 1) / EB_ROWS), slices), 256, 0, g.stream>>>(
+            L, R, (uint32_t)m, (uint32_t)k, (uint32_t)n, k_slice, (unsigned long long*)d_acc);
+        return ATLAS_OK;
+    }
     k_einsum_acc_generic<<<grid_for(T), 256, 0, g.stream>>>(L, R, S, (uint32_t)K, (uint32_t)lsk, (uint32_t)rsk, T, d_acc);
     return ATLAS_OK;
 }
@@ -473,6 +486,11 @@ int atlas_rt_validate_graph(const atlas_graph& G) {
 namespace {
 
 int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs, size_t& next_input) {
+    static const char* const op_names[] = {"trace Input", "trace Constant", "trace Identity", "trace Add", "trace Sub", "trace Mul", "trace Square", "trace Cube", "trace And", "trace Iff",
+                                           "trace ReLU", "trace Einsum", "trace Reshape", "trace MoveAxis", "trace Broadcast", "trace Slice", "trace Concat", "trace Sum",
+                                           "trace ScalarConstDiv", "trace Div", "trace MeanOfSquares", "trace Rsqrt", "trace SoftmaxLastAxis", "trace Tanh", "trace GatherLarge",
+                                           "trace GatherSmall", "trace Erf", "trace Sigmoid", "trace Neg", "trace IsNan", "trace Clamp", "trace Sin", "trace Cos"};
+    PROF(nd.op >= 0 && nd.op < (int)(sizeof(op_names) / sizeof(op_names[0])) ? op_names[nd.op] : "trace ?");
     if (int rc = atlas_rt_validate_node(G, nd)) return rc;
     const size_t T = gr::padded_len(nd.dims);
     DevBuf& out = G.out[nd.idx];

@@ -1621,9 +1621,11 @@ static int prove_graph_impl(atlas_graph_t G, atlas_srs_t srs, atlas_shard_group_
     atlas_rt::HostSampler::Scope host_samples;                                // ATLAS_HOST_SAMPLE=<file>: backtraces of this thread every 50 us (diagnosis)
     auto now = [] { atlas_sync(); return std::chrono::steady_clock::now(); };
     const auto t0 = now();
+    if (atlas_rt::Prof::on()) atlas_rt::Prof::get().reset();
     int rc = atlas_graph_trace(G, inputs, n_inputs);                          // pp.model().trace(inputs)
     if (rc) return rc;
     const auto t1 = now();
+    if (atlas_rt::Prof::on()) { atlas_rt::Prof::get().dump(stderr, "Model::trace"); atlas_rt::Prof::get().reset(); }
     Prover P(*G, srs);
     P.sh = sh;
     rc = atlas_transcript_new(&P.t, (const uint8_t*)"ONNXProof", 9);
@@ -1661,6 +1663,7 @@ static int prove_graph_impl(atlas_graph_t G, atlas_srs_t srs, atlas_shard_group_
     const auto t3 = now();
     if (!rc) rc = P.reduced_openings(nullptr);
     const auto t4 = now();
+    if (atlas_rt::Prof::on()) { atlas_rt::Prof::get().dump(stderr, "prove_reduced_openings"); atlas_rt::Prof::get().reset(); }
     if (rc) return rc;
     std::vector<uint8_t> bytes;
     rc = P.serialize(bytes);

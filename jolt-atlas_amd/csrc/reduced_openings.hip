@@ -77,7 +77,7 @@ int atlas_rt_prove_reduced_openings(const atlas_opening_t* openings, size_t n_op
             if (eligible(openings[i])) { lk = openings[i].log_K; rows.push_back(atlas_rt_pool_row{openings[i].d_lookups, openings[i].chunk_shift, openings[i].log_T, openings[i].point}); where.push_back(i); }
         if (!rows.empty()) {
             std::vector<atlas_instance_t> pi(rows.size(), nullptr); std::vector<const int32_t*> px(rows.size(), nullptr);
-            rc = atlas_rt_onehot_pool_new(rows.data(), rows.size(), lk, batch_rounds, pi.data(), px.data());
+            { PROF("reduced: onehot pool new"); rc = atlas_rt_onehot_pool_new(rows.data(), rows.size(), lk, batch_rounds, pi.data(), px.data()); }
             for (size_t q = 0; q < rows.size() && !rc; q++) { inst[where[q]] = pi[q]; pool_idx[where[q]] = px[q]; done[where[q]] = 1; }
         }
     }
@@ -106,6 +106,7 @@ int atlas_rt_prove_reduced_openings(const atlas_opening_t* openings, size_t n_op
         if (O.kind == 0) {
             atlas_poly_t c = nullptr;
             if (!O.poly || (!O.point && O.n)) { rc = fail(ATLAS_EINVAL, "prove_reduced_openings: dense opening without polynomial/point"); break; }
+            PROF("reduced: dense clone + new");
             rc = atlas_poly_clone(O.poly, &c);
             if (!rc) { rc = atlas_dense_opening_new(c, O.point, O.n, &inst[i]); if (rc) atlas_poly_free(c); }
             continue;
@@ -126,7 +127,7 @@ int atlas_rt_prove_reduced_openings(const atlas_opening_t* openings, size_t n_op
             idx[q] = openings[members[q]].k;
             std::memcpy(&ra[q * O.log_K], openings[members[q]].point, O.log_K * sizeof(atlas_fr_t));
         }
-        rc = atlas_onehot_opening_group_new(idx.data(), members.size(), O.log_K, O.log_T, ra.data(), O.point + O.log_K, rows.data());
+        { PROF("reduced: onehot group new (outside the pool)"); rc = atlas_onehot_opening_group_new(idx.data(), members.size(), O.log_K, O.log_T, ra.data(), O.point + O.log_K, rows.data()); }
         for (size_t q = 0; q < members.size() && !rc; q++) { inst[members[q]] = rows[q]; done[members[q]] = 1; }
     }
     mark("instances (prepare)");

@@ -1,0 +1,3 @@
+timeout 900 python -m pytest tests/test_gpu_graph_golden.py tests/test_gpu_graph.py tests/test_gpu_einsum_layouts.py tests/test_model_fidelity.py tests/test_ref_tensor_ops.py -q -m gpu -x 2>&1 | tail -3
+for i in 1 2 3; do ATLAS_GRAPH_VERIFY=0 python tools/time_graph.py gpt2 2 2 2>&1 | tail -1 | cut -c1-200; done
+python tools/time_graph.py nanogpt_model,gpt2_layer 2 3 2>&1 | tail -2 | cut -c1-200
