@@ -481,15 +481,12 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         // compute_message: the constant members and the serial ones here; for the parallel ones first everything they share (a pool's launches
         // of the round — whichever of its rows is in its cycle phase, however many pools the batch holds) on THIS thread, then the per-member
         // arithmetic on the workers, which never touch the device
-        std::vector<size_t> todo;
-        todo.reserve(n);
         for (size_t i = 0; i < n; i++) {
             Instance& I = b->inst[i];
-            if (remaining > I.rounds) { polys[i] = {mul_pow2(I.input_claim, remaining - I.rounds - 1)}; continue; }
+            if (remaining > I.rounds) continue;                   // (its constant polynomial: with the parallel part below)
             if (par[i]) {
                 int rc = I.inst->shared_message_step(round - (max_rounds - I.rounds));
                 if (rc) return rc;
-                todo.push_back(i);
                 continue;
             }
             int rc = I.inst->message(round - (max_rounds - I.rounds), claim[i], polys[i]);
@@ -501,10 +498,12 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
             HIP_TRY(hipStreamSynchronize(g.stream));
         }
         const auto q1 = tnow();
-        HT->parallel_for(todo.size(), [&](size_t lo, size_t hi, size_t part) {
-            for (size_t q = lo; q < hi && rcs[part] == ATLAS_OK; q++) {
-                Instance& I = b->inst[todo[q]];
-                rcs[part] = I.inst->message(round - (max_rounds - I.rounds), claim[todo[q]], polys[todo[q]]);
+        // the members that have not started (a constant polynomial each: thousands of them in the first rounds) and the parallel ones, in ranges of [0, n)
+        HT->parallel_for(n, [&](size_t lo, size_t hi, size_t part) {
+            for (size_t i = lo; i < hi && rcs[part] == ATLAS_OK; i++) {
+                Instance& I = b->inst[i];
+                if (remaining > I.rounds) polys[i] = {mul_pow2(I.input_claim, remaining - I.rounds - 1)};
+                else if (par[i]) rcs[part] = I.inst->message(round - (max_rounds - I.rounds), claim[i], polys[i]);
             }
         });
         for (int rc : rcs) if (rc) return fail(rc, "batched_prove: a member's compute_message failed on a worker thread");
@@ -544,14 +543,12 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         HT->parallel_for(n, [&](size_t lo, size_t hi, size_t) { for (size_t i = lo; i < hi; i++) claim[i] = eval_with_challenge(polys[i], r); });
         const auto q4 = tnow();
         // ingest_challenge, in the same steps
-        todo.clear();
         for (size_t i = 0; i < n; i++) {
             Instance& I = b->inst[i];
             if (remaining > I.rounds) continue;
             if (par[i]) {
                 int rc = I.inst->shared_ingest_step(challenges[round], round - (max_rounds - I.rounds));
                 if (rc) return rc;
-                todo.push_back(i);
                 continue;
             }
             int rc = I.inst->ingest(challenges[round], round - (max_rounds - I.rounds));
@@ -559,10 +556,10 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         }
         std::fill(rcs.begin(), rcs.end(), ATLAS_OK);
         const auto q5 = tnow();
-        HT->parallel_for(todo.size(), [&](size_t lo, size_t hi, size_t part) {
-            for (size_t q = lo; q < hi && rcs[part] == ATLAS_OK; q++) {
-                Instance& I = b->inst[todo[q]];
-                rcs[part] = I.inst->ingest(challenges[round], round - (max_rounds - I.rounds));
+        HT->parallel_for(n, [&](size_t lo, size_t hi, size_t part) {
+            for (size_t i = lo; i < hi && rcs[part] == ATLAS_OK; i++) {
+                Instance& I = b->inst[i];
+                if (remaining <= I.rounds && par[i]) rcs[part] = I.inst->ingest(challenges[round], round - (max_rounds - I.rounds));
             }
         });
         for (int rc : rcs) if (rc) return fail(rc, "batched_prove: a member's ingest_challenge failed on a worker thread");
