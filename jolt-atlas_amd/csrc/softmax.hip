@@ -24,16 +24,17 @@ __global__ __launch_bounds__(RA_THREADS) void k_sm_from_i32(const int32_t* __res
 
 // phase 1, ExpSum: sum_kj exp_q[2 kj] eq_k[kj >> shift]
 __global__ __launch_bounds__(RA_THREADS) void k_sm_expsum_p1(const Fr* __restrict__ a, const Fr* __restrict__ eq_k, uint32_t shift,
-                                                             size_t half, Fr* __restrict__ partials) {
+                                                             size_t half, Fr* __restrict__ partials, MailTail tail) {
     Fr acc[1]; acc[0] = fe_zero();
     for (size_t kj = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; kj < half; kj += (size_t)gridDim.x * RA_THREADS)
         acc[0] = fr_add(acc[0], fr_mul(fe_load(a + 2 * kj), fe_load(eq_k + (kj >> shift))));
-    block_reduce_store<1>(acc, partials);
+    block_reduce_put<1>(acc, partials, tail);
+    mail_tail(partials, tail);
 }
 
 // phase 1, MaxIndicator: eq_k[k] X e at 0, 2, 3
 __global__ __launch_bounds__(RA_THREADS) void k_sm_max_p1(const Fr* __restrict__ X, const Fr* __restrict__ e, const Fr* __restrict__ eq_k,
-                                                          uint32_t shift, size_t half, Fr* __restrict__ partials) {
+                                                          uint32_t shift, size_t half, Fr* __restrict__ partials, MailTail tail) {
     Fr acc[3]; acc[0] = fe_zero(); acc[1] = fe_zero(); acc[2] = fe_zero();
     for (size_t kj = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; kj < half; kj += (size_t)gridDim.x * RA_THREADS) {
         const Fr w = fe_load(eq_k + (kj >> shift));
@@ -44,22 +45,24 @@ __global__ __launch_bounds__(RA_THREADS) void k_sm_max_p1(const Fr* __restrict__
         acc[1] = fr_add(acc[1], fr_mul(w, fr_mul(x2, e2)));
         acc[2] = fr_add(acc[2], fr_mul(w, fr_mul(x3, e3)));
     }
-    block_reduce_store<3>(acc, partials);
+    block_reduce_put<3>(acc, partials, tail);
+    mail_tail(partials, tail);
 }
 
 // phase 1, RecipMult: sum_kj E_out E_in exp_q[2 kj] inv_sum[kj >> shift]
 __global__ __launch_bounds__(RA_THREADS) void k_sm_recip_p1(const Fr* __restrict__ a, const Fr* __restrict__ inv_sum, uint32_t shift,
-                                                            SplitEqView E, size_t n_groups, Fr* __restrict__ partials) {
+                                                            SplitEqView E, size_t n_groups, Fr* __restrict__ partials, MailTail tail) {
     Fr acc[1]; acc[0] = fe_zero();
     for (size_t kj = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; kj < n_groups; kj += (size_t)gridDim.x * RA_THREADS)
         acc[0] = fr_add(acc[0], fr_mul(gse_weight(E, kj), fr_mul(fe_load(a + 2 * kj), fe_load(inv_sum + (kj >> shift)))));
-    block_reduce_store<1>(acc, partials);
+    block_reduce_put<1>(acc, partials, tail);
+    mail_tail(partials, tail);
 }
 
 // phase 2: sum_g E_out E_in [a0] (ExpSum) or [a0 b0, a_inf b_inf] (MaxIndicator, RecipMult)
 template <int NQ>
 __global__ __launch_bounds__(RA_THREADS) void k_sm_p2(const Fr* __restrict__ a, const Fr* __restrict__ b, SplitEqView E, size_t n_groups,
-                                                      Fr* __restrict__ partials) {
+                                                      Fr* __restrict__ partials, MailTail tail) {
     Fr acc[NQ];
 #pragma unroll
     for (int k = 0; k < NQ; k++) acc[k] = fe_zero();
@@ -73,15 +76,36 @@ __global__ __launch_bounds__(RA_THREADS) void k_sm_p2(const Fr* __restrict__ a, 
             acc[1] = fr_add(acc[1], fr_mul(w, fr_mul(fr_sub(a1, a0), fr_sub(b1, b0))));
         }
     }
-    block_reduce_store<NQ>(acc, partials);
+    block_reduce_put<NQ>(acc, partials, tail);
+    mail_tail(partials, tail);
 }
 
 // SumAxis: sum of the low half (HighToLow: the pair of i is (i, i + half))
-__global__ __launch_bounds__(RA_THREADS) void k_sm_sum_half(const Fr* __restrict__ a, size_t half, Fr* __restrict__ partials) {
+__global__ __launch_bounds__(RA_THREADS) void k_sm_sum_half(const Fr* __restrict__ a, size_t half, Fr* __restrict__ partials, MailTail tail) {
     Fr acc[1]; acc[0] = fe_zero();
     for (size_t i = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; i < half; i += (size_t)gridDim.x * RA_THREADS)
         acc[0] = fr_add(acc[0], fe_load(a + i));
-    block_reduce_store<1>(acc, partials);
+    block_reduce_put<1>(acc, partials, tail);
+    mail_tail(partials, tail);
+}
+// the same bind with the challenge from the round's slot (round channel)
+__global__ __launch_bounds__(RA_THREADS) void k_sm_bind_hi_ch(const Fr* __restrict__ a, size_t half, ChanIo io, int r_hi_only, Fr* __restrict__ out) {
+    Fr r;
+    if (!io.challenge(r)) return;
+    for (size_t i = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; i < half; i += (size_t)gridDim.x * RA_THREADS) {
+        const Fr lo = fe_load(a + i), d = fr_sub(fe_load(a + i + half), lo);
+        fe_store(out + i, fr_add(lo, r_hi_only ? fr_mul_hi(d, r) : fr_mul(d, r)));
+    }
+}
+// the last bind of every row (two coefficients each) and, for RecipMult, of inv_sum: the final claims, one value per record
+__global__ __launch_bounds__(64) void k_sm_finals_ch(const Fr* rows, size_t stride, uint32_t n_rows, const Fr* inv, ChanIo io, int hi_only) {
+    __shared__ uint32_t stage[9 * 16];
+    Fr r;
+    if (!io.challenge(r)) return;
+    Fr v = fe_zero();
+    if (threadIdx.x < n_rows) v = bind_pair(fe_load(rows + (size_t)threadIdx.x * stride), fe_load(rows + (size_t)threadIdx.x * stride + 1), r, hi_only != 0);
+    else if (inv && threadIdx.x == n_rows) v = bind_pair(fe_load(inv), fe_load(inv + 1), r, hi_only != 0);
+    ch_mail_wave_fe(io.io, 0, n_rows + (inv ? 1u : 0u), v, stage);
 }
 // out[i] = a[i] + r (a[i + half] - a[i])
 __global__ __launch_bounds__(RA_THREADS) void k_sm_bind_hi(const Fr* __restrict__ a, size_t half, Fr r, int r_hi_only, Fr* __restrict__ out) {
@@ -117,7 +141,7 @@ struct Softmax : atlas_instance {
         H::Fr s[3];
         int rc;
         if (kind == SM_SUM_AXIS) {
-            k_sm_sum_half<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, half, rows.partials);
+            k_sm_sum_half<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, half, rows.partials, MailTail{{}, nullptr, 0, 0});
             if ((rc = rows.reduce_to_host((uint32_t)blocks, 1, s))) return rc;
             linear_from_eval0(claim, s[0], coeffs);
             return ATLAS_OK;
@@ -125,16 +149,16 @@ struct Softmax : atlas_instance {
         if (round < log_N) {
             const uint32_t shift = (uint32_t)(log_N - (round + 1));
             if (kind == SM_EXP_SUM) {
-                k_sm_expsum_p1<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, d_eq_k, shift, half, rows.partials);
+                k_sm_expsum_p1<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, d_eq_k, shift, half, rows.partials, MailTail{{}, nullptr, 0, 0});
                 if ((rc = rows.reduce_to_host((uint32_t)blocks, 1, s))) return rc;
                 linear_from_eval0(claim, s[0], coeffs);
             } else if (kind == SM_MAX_INDICATOR) {
-                k_sm_max_p1<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, b, d_eq_k, shift, half, rows.partials);
+                k_sm_max_p1<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, b, d_eq_k, shift, half, rows.partials, MailTail{{}, nullptr, 0, 0});
                 if ((rc = rows.reduce_to_host((uint32_t)blocks, 3, s))) return rc;
                 coeffs.assign(4, H::zero());
                 H::unipoly_from_evals_and_hint(claim, s, 3, coeffs.data());
             } else {
-                k_sm_recip_p1<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, inv.buf[inv.cur], shift, gs.view(), half, rows.partials);
+                k_sm_recip_p1<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, inv.buf[inv.cur], shift, gs.view(), half, rows.partials, MailTail{{}, nullptr, 0, 0});
                 if ((rc = rows.reduce_to_host((uint32_t)blocks, 1, s))) return rc;
                 coeffs.assign(3, H::zero());
                 H::gruen_deg2(gs.st.scalar, gs.st.w_cur(), s[0], claim, coeffs.data());
@@ -142,12 +166,12 @@ struct Softmax : atlas_instance {
             return ATLAS_OK;
         }
         if (kind == SM_EXP_SUM) {
-            k_sm_p2<1><<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, nullptr, gs.view(), half, rows.partials);
+            k_sm_p2<1><<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, nullptr, gs.view(), half, rows.partials, MailTail{{}, nullptr, 0, 0});
             if ((rc = rows.reduce_to_host((uint32_t)blocks, 1, s))) return rc;
             coeffs.assign(3, H::zero());
             H::gruen_deg2(gs.st.scalar, gs.st.w_cur(), s[0], claim, coeffs.data());
         } else {
-            k_sm_p2<2><<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, kind == SM_RECIP_MULT ? inv.buf[inv.cur] : b, gs.view(), half, rows.partials);
+            k_sm_p2<2><<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, kind == SM_RECIP_MULT ? inv.buf[inv.cur] : b, gs.view(), half, rows.partials, MailTail{{}, nullptr, 0, 0});
             if ((rc = rows.reduce_to_host((uint32_t)blocks, 2, s))) return rc;
             coeffs.assign(4, H::zero());
             H::gruen_deg3(gs.st, s[0], s[1], claim, coeffs.data());
@@ -177,8 +201,102 @@ struct Softmax : atlas_instance {
         return ATLAS_OK;
     }
 
+    // ---- round-channel stepping (instance.hpp): ingest_challenge(round - 1) — the binds, challenge from the round's slot — then the fold of
+    // compute_message(round), its sums mailed (tagged rows, ra_common.hip.h).  Rows of round k live in buf[k & 1] with stride T >> k; inv_sum of
+    // RecipMult's phase-2 round p in inv.buf[p & 1].  A softmax stage is a batch of these with a range check and one-hot lanes: host-stepped
+    // it paid a synchronisation per member and round (~100 us per round of a six-member batch).
+    bool have_finals = false;
+    std::vector<H::Fr> mailed_finals;
+    size_t T0() const { return (size_t)1 << (log_K + log_N); }
+    static bool pipe_off() { static const bool v = getenv("ATLAS_SM_NO_PIPELINE") != nullptr; return v; }      // A-B
+    bool pipelined() const override { return !pipe_off() && log_K + log_N >= 1; }
+    int n_sums(size_t round) const {
+        if (kind == SM_SUM_AXIS || kind == SM_EXP_SUM) return 1;
+        if (kind == SM_MAX_INDICATOR) return round < log_N ? 3 : 2;
+        return round < log_N ? 1 : 2;                               // RecipMult
+    }
+    bool wide_wait(size_t round) const override {
+        if (round == 0 || round > rounds()) return false;
+        const size_t len = T0() >> round;
+        return ((len + RA_THREADS - 1) / RA_THREADS) * rows.d > WIDE_WAIT_WGS;
+    }
+    int enqueue(size_t round, const atlas::RoundIo& io, bool bind_prev, atlas_mail_ref& mail) override {
+        if (round >= rounds() || (round > 0) != bind_prev) return fail(ATLAS_ESTATE, "softmax: enqueue out of order");
+        const ChanIo cio{io, g.challenge_mode};
+        const int hi = g.challenge_mode == 0 ? 1 : 0;
+        const size_t len = T0() >> round, half = len / 2, K = (size_t)1 << log_K;
+        Fr* cur = rows.buf[round & 1];
+        if (bind_prev) {
+            const Fr* prev = rows.buf[(round - 1) & 1];
+            size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096; if (gb < 1) gb = 1;
+            if (kind == SM_SUM_AXIS) k_sm_bind_hi_ch<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(prev, len, cio, hi, cur);
+            else k_ra_bind_ch<<<dim3((unsigned)gb, (unsigned)rows.d), RA_THREADS, 0, g.stream>>>(prev, T0() >> (round - 1), cur, len, len, cio, hi);
+            if (kind == SM_RECIP_MULT && round - 1 >= log_N) {      // inv_sum binds with the phase-2 challenges
+                const size_t p = round - 1 - log_N, ilen = K >> (p + 1);
+                size_t gi = (ilen + RA_THREADS - 1) / RA_THREADS; if (gi < 1) gi = 1;
+                k_ra_bind_ch<<<dim3((unsigned)gi, 1u), RA_THREADS, 0, g.stream>>>(inv.buf[p & 1], K >> p, inv.buf[(p + 1) & 1], ilen ? ilen : 1, ilen, cio, hi);
+            }
+        }
+        size_t blocks = (half + RA_THREADS - 1) / RA_THREADS; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+        const int ns = n_sums(round);
+        const MailTail tail{io, rows.d_counter, (uint32_t)blocks, (uint32_t)ns, rows.tg()};
+        const Fr* a = cur; const Fr* b = a + len;                   // (d = 2: row 1 at the current stride)
+        if (kind == SM_SUM_AXIS) k_sm_sum_half<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, half, rows.partials, tail);
+        else if (round < log_N) {
+            const uint32_t shift = (uint32_t)(log_N - (round + 1));
+            if (kind == SM_EXP_SUM) k_sm_expsum_p1<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, d_eq_k, shift, half, rows.partials, tail);
+            else if (kind == SM_MAX_INDICATOR) k_sm_max_p1<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, b, d_eq_k, shift, half, rows.partials, tail);
+            else { size_t ot, it; gs.st.tops_after(round, ot, it); k_sm_recip_p1<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, inv.buf[0], shift, gs.view_at(ot, it), half, rows.partials, tail); }
+        } else {
+            size_t ot, it;
+            gs.st.tops_after(kind == SM_RECIP_MULT ? round : round - log_N, ot, it);
+            const SplitEqView E = gs.view_at(ot, it);
+            if (kind == SM_EXP_SUM) k_sm_p2<1><<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, nullptr, E, half, rows.partials, tail);
+            else k_sm_p2<2><<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, kind == SM_RECIP_MULT ? inv.buf[(round - log_N) & 1] : b, E, half, rows.partials, tail);
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(ATLAS_ENODEV, "softmax: launch", e);
+        mail.base = io.mail; mail.blocks = 1; mail.n_vals = ns; mail.radix = 32; mail.shl = 0;
+        return ATLAS_OK;
+    }
+    void prepare(size_t round) override { if (round == round_next && kind != SM_SUM_AXIS && (kind == SM_RECIP_MULT || round >= log_N)) gs.st.prepare_inverses(false); }
+    int finish(size_t round, const H::Fr& claim, const H::Fr* s, std::vector<H::Fr>& coeffs) override {
+        if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "softmax: round out of order");
+        if (kind == SM_SUM_AXIS || (kind == SM_EXP_SUM && round < log_N)) { linear_from_eval0(claim, s[0], coeffs); return ATLAS_OK; }
+        if (kind == SM_MAX_INDICATOR && round < log_N) { coeffs.assign(4, H::zero()); H::unipoly_from_evals_and_hint(claim, s, 3, coeffs.data()); return ATLAS_OK; }
+        if ((kind == SM_RECIP_MULT && round < log_N) || kind == SM_EXP_SUM) { coeffs.assign(3, H::zero()); H::gruen_deg2(gs.st.scalar, gs.st.w_cur(), s[0], claim, coeffs.data()); return ATLAS_OK; }
+        coeffs.assign(4, H::zero());
+        H::gruen_deg3(gs.st, s[0], s[1], claim, coeffs.data());
+        return ATLAS_OK;
+    }
+    int host_ingest(const atlas_u128_t& r, size_t round) override {
+        if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "softmax: round out of order");
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        if (kind == SM_RECIP_MULT) gs.st.bind(rf);
+        else if (kind != SM_SUM_AXIS && round >= log_N) gs.st.bind(rf);
+        rows.cur = (int)((round + 1) & 1); rows.len = T0() >> (round + 1); rows.stride[rows.cur] = rows.len;
+        if (kind == SM_RECIP_MULT && round >= log_N) { const size_t p = round - log_N; inv.cur = (int)((p + 1) & 1); inv.len = ((size_t)1 << log_K) >> (p + 1); inv.stride[inv.cur] = inv.len; }
+        round_next++;
+        return ATLAS_OK;
+    }
+    int enqueue_finals(const atlas::RoundIo& io, atlas_mail_ref& mail) override {
+        const size_t n = rounds();
+        const Fr* iv = kind == SM_RECIP_MULT ? inv.buf[(log_K - 1) & 1] : nullptr;
+        k_sm_finals_ch<<<1, 64, 0, g.stream>>>(rows.buf[(n - 1) & 1], T0() >> (n - 1), (uint32_t)rows.d, iv, ChanIo{io, g.challenge_mode}, g.challenge_mode == 0 ? 1 : 0);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(ATLAS_ENODEV, "softmax: launch", e);
+        mail.base = io.mail; mail.blocks = 1; mail.n_vals = (int)rows.d + (iv ? 1 : 0); mail.radix = 32; mail.shl = 0;
+        return ATLAS_OK;
+    }
+    int set_finals(const H::Fr* vals, size_t n) override {
+        if (n != rows.d + (kind == SM_RECIP_MULT ? 1 : 0)) return fail(ATLAS_EINVAL, "softmax: final claims");
+        mailed_finals.assign(vals, vals + n); have_finals = true;
+        return ATLAS_OK;
+    }
+
     int finals(std::vector<H::Fr>& out) override {
         if (round_next != rounds()) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
+        if (have_finals) { out = mailed_finals; return ATLAS_OK; }
         std::lock_guard<atlas_rt::Mutex> lk(g.mu);
         int rc = rows.finals(out);
         if (rc || kind != SM_RECIP_MULT) return rc;
