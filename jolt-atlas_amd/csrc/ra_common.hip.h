@@ -288,6 +288,29 @@ inline int store_small(const H::Fr* src, size_t n, Fr* dst) {      // n <= 64 pe
     return e == hipSuccess ? ATLAS_OK : fail(ATLAS_ENODEV, "store_small", e);
 }
 
+// Both cached prefix tables of a split eq in ONE launch, the point as kernel argument (at most 32 variables here; longer points take the
+// three launches below): workgroup 0 builds the tables of w[0 .. k_out), workgroup 1 those of w[m .. m + k_in) — evals_cached
+// (eq_poly.rs:174-192), table j at offset 2^j - 1, as k_eq_cached.  Every instance over a Gruen split eq starts with this.
+struct GsePointArgs { Fr v[32]; };
+__global__ __launch_bounds__(1024) void k_gse_init(GsePointArgs w, uint32_t m, uint32_t k_out, uint32_t k_in, Fr* __restrict__ t_out, Fr* __restrict__ t_in) {
+    Fr* tabs = blockIdx.x ? t_in : t_out;
+    const uint32_t k = blockIdx.x ? k_in : k_out, off = blockIdx.x ? m : 0;
+    if (threadIdx.x == 0) fe_store(tabs, fr_one());
+    __syncthreads();
+    for (uint32_t j = 0; j < k; j++) {
+        const Fr wj = w.v[off + j];
+        const Fr* cur = tabs + ((1u << j) - 1);
+        Fr* nxt = tabs + ((2u << j) - 1);
+        for (uint32_t i = threadIdx.x; i < (1u << j); i += 1024) {
+            const Fr s = fe_load(cur + i), hi = fr_mul(s, wj);
+            fe_store(nxt + 2 * i + 1, hi);
+            fe_store(nxt + 2 * i, fr_sub(s, hi));
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 // device half of a LowToHigh GruenSplitEqPolynomial: the cached prefix tables
 struct GseDev {
     H::GseState st;
@@ -295,9 +318,17 @@ struct GseDev {
     int init(const H::Fr* w, size_t n) {
         st.init(w, n);
         if (st.k_out > 12 || st.k_in > 12) return fail(ATLAS_EINVAL, "split-eq: more than 25 variables not supported");
-        HIP_TRY(hipMalloc(&d_w, (n ? n : 1) * sizeof(Fr)));
         HIP_TRY(hipMalloc(&d_eout, ((size_t)2 << st.k_out) * sizeof(Fr)));
         HIP_TRY(hipMalloc(&d_ein, ((size_t)2 << st.k_in) * sizeof(Fr)));
+        static const bool one_launch = getenv("ATLAS_GSE_3_LAUNCHES") == nullptr;      // A-B
+        if (n <= 32 && one_launch) {
+            GsePointArgs a;
+            if (n) std::memcpy(a.v, w, n * sizeof(Fr));
+            k_gse_init<<<2, 1024, 0, g.stream>>>(a, (uint32_t)st.m, (uint32_t)st.k_out, (uint32_t)st.k_in, d_eout, d_ein);
+            hipError_t e = hipGetLastError();
+            return e == hipSuccess ? ATLAS_OK : fail(ATLAS_ENODEV, "split-eq init", e);
+        }
+        HIP_TRY(hipMalloc(&d_w, (n ? n : 1) * sizeof(Fr)));
         if (n) { int rc = store_small(w, n, d_w); if (rc) return rc; }
         k_eq_cached<<<1, 1024, 0, g.stream>>>(d_eout, d_w, (uint32_t)st.k_out);
         k_eq_cached<<<1, 1024, 0, g.stream>>>(d_ein, d_w + st.m, (uint32_t)st.k_in);
