@@ -782,9 +782,10 @@ struct Booleanity : atlas_instance {
         if (round < log_k) return ATLAS_OK;
         const size_t T = (size_t)1 << log_T, p = round - log_k, len = T >> p, n_groups = len / 2;
         if (p == 0) {
-            if (!rows.d_idx) return fail(ATLAS_ESTATE, "booleanity: indices not uploaded");
+            if (!rows.d_idx && !rows.lk) return fail(ATLAS_ESTATE, "booleanity: indices not uploaded");
             size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
-            k_ra_gather<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, g.stream>>>(rows.d_idx, d_F, 0u, T, rows.buf[0]);   // every H_i reads the same table F
+            if (rows.lk) k_ra_gather_lk<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, g.stream>>>(rows.lk, d_F, 0u, T, (uint32_t)d, rows.lk_log, rows.buf[0]);
+            else k_ra_gather<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, g.stream>>>(rows.d_idx, d_F, 0u, T, rows.buf[0]);   // every H_i reads the same table F
         } else if (!fused(p)) {
             size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
             k_ra_bind_ch<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, g.stream>>>(rows.buf[(p - 1) & 1], T >> (p - 1), rows.buf[p & 1], len, len, cio,

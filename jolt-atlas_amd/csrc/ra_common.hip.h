@@ -39,6 +39,18 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_gather(const int32_t* __restr
     }
 }
 
+// The same gather straight from the T lookup indices (chunk i = (index >> log_k (d - 1 - i)) & (2^log_k - 1), i = 0 most significant:
+// OneHotParams::lookup_index_chunk, config.rs:73-75): no chunk-index rows in between (a launch and d T int32 per instance).
+__global__ __launch_bounds__(RA_THREADS) void k_ra_gather_lk(const uint64_t* __restrict__ lookups, const Fr* __restrict__ F, uint32_t f_stride, size_t T, uint32_t d,
+                                                             uint32_t log_k, Fr* __restrict__ out) {
+    const uint32_t i = blockIdx.y, shift = log_k * (d - 1 - i);
+    const uint64_t mask = ((uint64_t)1 << log_k) - 1;
+    for (size_t j = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; j < T; j += (size_t)gridDim.x * RA_THREADS) {
+        const uint64_t k = shift >= 64 ? 0 : ((lookups[j] >> shift) & mask);
+        fe_store(out + (size_t)i * T + j, fe_load(F + (size_t)i * f_stride + k));
+    }
+}
+
 // compute_instruction_h_indices (shout.rs:532-547) / OneHotParams::lookup_index_chunk (config.rs:73-75):
 // chunk i of a lookup index = (index >> (log_k_chunk * (d - 1 - i))) & (k_chunk - 1), i = 0 most significant
 __global__ __launch_bounds__(RA_THREADS) void k_ra_chunk_indices(const uint64_t* __restrict__ lookups, size_t T, uint32_t d,
@@ -388,12 +400,16 @@ struct RaRows {
     }
     // the same from the T lookup indices themselves: the d chunk rows are cut on the device (8 T bytes over PCIe
     // instead of 4 d T)
+    const uint64_t* lk = nullptr;      // device-resident lookups read in place by the gather (k_ra_gather_lk): no index rows
+    uint32_t lk_log = 0;
     int upload_lookups(const uint64_t* lookups, uint32_t log_k_chunk) {
         uint64_t* d_l = nullptr;
-        HIP_TRY(hipMalloc(&d_idx, d * len * sizeof(int32_t)));
         hipPointerAttribute_t attr;
         const bool on_device = hipPointerGetAttributes(&attr, lookups) == hipSuccess && attr.type == hipMemoryTypeDevice;      // a device vector is cut in place
         (void)hipGetLastError();
+        static const bool rows_always = getenv("ATLAS_RA_INDEX_ROWS") != nullptr;      // A-B
+        if (on_device && !rows_always) { lk = lookups; lk_log = log_k_chunk; return ATLAS_OK; }
+        HIP_TRY(hipMalloc(&d_idx, d * len * sizeof(int32_t)));
         hipError_t e = hipSuccess;
         if (!on_device) {
             HIP_TRY(hipMalloc(&d_l, len * sizeof(uint64_t)));
@@ -410,8 +426,15 @@ struct RaRows {
     }
     // ra_i[j] = table_i[idx_i[j]] from device tables (d rows of f_stride Fr; f_stride 0 = shared table)
     int gather(const Fr* d_tables, uint32_t f_stride) {
-        if (!d_idx) return fail(ATLAS_ESTATE, "ra gather: indices not uploaded");
         size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
+        if (lk) {
+            k_ra_gather_lk<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, g.stream>>>(lk, d_tables, f_stride, len, (uint32_t)d, lk_log, buf[0]);
+            hipError_t e0 = hipGetLastError();
+            if (e0 != hipSuccess) return fail(ATLAS_ENODEV, "ra gather", e0);
+            cur = 0; stride[0] = len;
+            return ATLAS_OK;
+        }
+        if (!d_idx) return fail(ATLAS_ESTATE, "ra gather: indices not uploaded");
         k_ra_gather<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, g.stream>>>(d_idx, d_tables, f_stride, len, buf[0]);
         hipError_t e = hipGetLastError();
         hipFree(d_idx); d_idx = nullptr;      // (pool: reused in stream order)
