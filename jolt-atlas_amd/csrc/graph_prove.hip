@@ -1309,6 +1309,9 @@ struct Prover : FlowSink {
             if (rc) return rc;
             atlas_poly_t eq = nullptr, G_hi = nullptr, G_lo = nullptr;
             atlas_dot_prover_t d_hi = nullptr, d_lo = nullptr;
+            atlas_instance_t i_hi = nullptr, i_lo = nullptr;               // the same two lookups as host-arithmetic instances (tables of <= 4096 entries)
+            static const bool host_raf_off = getenv("ATLAS_SM_DEVICE_RAF") != nullptr;      // A-B
+            const bool host_raf = !host_raf_off && Sm.lk_hi <= 12 && Sm.lk_lo <= 12;
             atlas_instance_t i_clamp = nullptr;
             atlas_batched_t b = nullptr;
             std::vector<atlas_instance_t> oh;
@@ -1316,10 +1319,12 @@ struct Prover : FlowSink {
             rc = atlas_eq_evals((const atlas_fr_t*)r2.data(), log_T, nullptr, &eq);
             const H::Fr g_hi = H::tr_challenge_scalar(Tr);                                                   // ReadRafParams::new (shout.rs:112-130)
             if (!rc) rc = atlas_shout_read_raf_G(Sm.idx_zhi.as<uint64_t>(), T, Sm.lk_hi, eq, &G_hi);
-            if (!rc) { rc = atlas_shout_read_raf_prover_new(G_hi, L->hi.data(), Sm.lk_hi, (const atlas_fr_t*)&g_hi, &d_hi); if (rc && G_hi) atlas_poly_free(G_hi); }
+            if (!rc && host_raf) { rc = atlas_rt_shout_read_raf_host_new(G_hi, L->hi.data(), Sm.lk_hi, (const atlas_fr_t*)&g_hi, &i_hi); if (G_hi) atlas_poly_free(G_hi); }
+            else if (!rc) { rc = atlas_shout_read_raf_prover_new(G_hi, L->hi.data(), Sm.lk_hi, (const atlas_fr_t*)&g_hi, &d_hi); if (rc && G_hi) atlas_poly_free(G_hi); }
             const H::Fr g_lo = H::tr_challenge_scalar(Tr);
             if (!rc) rc = atlas_shout_read_raf_G(Sm.idx_zlo.as<uint64_t>(), T, Sm.lk_lo, eq, &G_lo);
-            if (!rc) { rc = atlas_shout_read_raf_prover_new(G_lo, L->lo.data(), Sm.lk_lo, (const atlas_fr_t*)&g_lo, &d_lo); if (rc && G_lo) atlas_poly_free(G_lo); }
+            if (!rc && host_raf) { rc = atlas_rt_shout_read_raf_host_new(G_lo, L->lo.data(), Sm.lk_lo, (const atlas_fr_t*)&g_lo, &i_lo); if (G_lo) atlas_poly_free(G_lo); }
+            else if (!rc) { rc = atlas_shout_read_raf_prover_new(G_lo, L->lo.data(), Sm.lk_lo, (const atlas_fr_t*)&g_lo, &d_lo); if (rc && G_lo) atlas_poly_free(G_lo); }
             if (eq) atlas_poly_free(eq);
             if (!rc) rc = append_advice(nd, gr::VP_SoftmaxClampWitness, r2, zc[2]);                          // append_raf_claims_prover (op_lookups/mod.rs:404-418)
             const H::Fr g_c = H::tr_challenge_scalar(Tr);                                                    // ps_read_raf_prover (unary.rs:112)
@@ -1329,8 +1334,8 @@ struct Prover : FlowSink {
             const H::Fr rv = H::add(H::mul(zc[0], H::from_u64((uint64_t)1 << Sm.log2_base)), zc[1]);         // significance_clamp.rs:61-69
             const H::Fr c_clamp = H::add(rv, H::mul(g_c, zc[2]));
             if (!rc) rc = atlas_batched_new(&b);
-            if (!rc) rc = atlas_batched_add_dot(b, d_hi, (const atlas_fr_t*)&c_hi);
-            if (!rc) rc = atlas_batched_add_dot(b, d_lo, (const atlas_fr_t*)&c_lo);
+            if (!rc) rc = host_raf ? atlas_batched_add_instance(b, i_hi, (const atlas_fr_t*)&c_hi) : atlas_batched_add_dot(b, d_hi, (const atlas_fr_t*)&c_hi);
+            if (!rc) rc = host_raf ? atlas_batched_add_instance(b, i_lo, (const atlas_fr_t*)&c_lo) : atlas_batched_add_dot(b, d_lo, (const atlas_fr_t*)&c_lo);
             if (!rc) rc = atlas_batched_add_instance(b, i_clamp, (const atlas_fr_t*)&c_clamp);
             fams[0].d_lookups = Sm.idx_rexp.as<uint64_t>(); fams[0].log_K = LS; fams[0].r_cycle = (const atlas_fr_t*)r1.data();     // SoftmaxRaEncoding::exp_remainder
             fams[0].ra_point = Era_point; fams[0].ra_claim = Era_claim; fams[0].rad_cp = gr::CP_SoftmaxExpRemainderRaD;
@@ -1340,9 +1345,9 @@ struct Prover : FlowSink {
             mark("softmax: stage 3 sumcheck");
             if (!rc) {
                 const size_t mr = rs.size();
-                auto shout_open = [&](atlas_dot_prover_t dp, size_t lk, uint8_t vp, std::vector<atlas_fr_t>& pt_out, H::Fr& claim) {     // ReadRafProver::cache_openings: [challenges | r]
-                    atlas_fr_t f[3];
-                    int rc2 = atlas_dot_final_claims(dp, f);
+                auto shout_open = [&](atlas_dot_prover_t dp, atlas_instance_t ip, size_t lk, uint8_t vp, std::vector<atlas_fr_t>& pt_out, H::Fr& claim) {     // ReadRafProver::cache_openings: [challenges | r]
+                    atlas_fr_t f[64]; size_t nf = 0;
+                    int rc2 = ip ? atlas_instance_final_claims(ip, f, 64, &nf) : atlas_dot_final_claims(dp, f);
                     if (rc2) return rc2;
                     std::memcpy(&claim, &f[0], 32);
                     Point pt(rs.begin() + (mr - lk), rs.end());
@@ -1350,8 +1355,8 @@ struct Prover : FlowSink {
                     pt_out.resize(pt.size()); std::memcpy(pt_out.data(), pt.data(), pt.size() * 32);
                     return append_advice(nd, vp, pt, claim);
                 };
-                rc = shout_open(d_hi, Sm.lk_hi, gr::VP_SoftmaxZHiRa, hi_point, hi_claim);
-                if (!rc) rc = shout_open(d_lo, Sm.lk_lo, gr::VP_SoftmaxZLoRa, lo_point, lo_claim);
+                rc = shout_open(d_hi, i_hi, Sm.lk_hi, gr::VP_SoftmaxZHiRa, hi_point, hi_claim);
+                if (!rc) rc = shout_open(d_lo, i_lo, Sm.lk_lo, gr::VP_SoftmaxZLoRa, lo_point, lo_claim);
                 if (!rc) rc = ra_opening(nd, i_clamp, gr::VP_SoftmaxClampRa, 32, log_T, rs, Cra_point, Cra_claim);
                 Out O = out();
                 if (!rc) rc = onehot_families_cache(fams, oh.data(), log_T, rs, &t, O);
@@ -1359,6 +1364,7 @@ struct Prover : FlowSink {
             if (b) atlas_batched_free(b);
             if (d_hi) atlas_dot_prover_free(d_hi);
             if (d_lo) atlas_dot_prover_free(d_lo);
+            for (atlas_instance_t i : {i_hi, i_lo}) if (i) atlas_instance_free(i);
             if (i_clamp) atlas_instance_free(i_clamp);
             for (atlas_instance_t i : oh) if (i) atlas_instance_free(i);
             if (rc) return rc;

@@ -334,6 +334,79 @@ int atlas_rt_shout_ra_evals_host(const uint64_t* lookup_indices, size_t T, size_
     return histogram_small_host(lookup_indices, T, KeySpec{d, (uint32_t)log_k_chunk}, eq_r_cycle, G);
 }
 
+// ReadRafProver (shout.rs:193-262) over a SMALL table on the host: the same dot-product instance sum_k G[k] W[k], W = val + gamma * int,
+// HighToLow, degree 2 — as host arithmetic (2^log_K <= 4096 entries: a few microseconds per round), stepped over the round channel without
+// a launch.  The exp-digit lookups of SoftmaxLastAxis read 512-entry tables; as device dot provers they were the one member that kept the
+// whole stage-3 batch (a clamp lookup and a one-hot family beside them) on the host-stepped driver, a synchronisation per member and round.
+#include "instance.hpp"
+namespace {
+struct HostDot : atlas_instance {
+    std::vector<H::Fr> L, R;
+    size_t n = 0, round_next = 0;
+    size_t rounds() const override { return n; }
+    size_t degree() const override { return 2; }
+    int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
+        if (round != round_next || round >= n) return fail(ATLAS_ESTATE, "host read-raf: round out of order");
+        const size_t h = L.size() / 2;
+        H::Fr e0 = H::zero(), e2 = H::zero();
+        for (size_t i = 0; i < h; i++) {
+            if (H::detail::is_zero4(L[i].l) && H::detail::is_zero4(L[i + h].l)) continue;          // (G is a histogram: mostly empty)
+            e0 = H::add(e0, H::mul(L[i], R[i]));
+            const H::Fr l2 = H::sub(H::add(L[i + h], L[i + h]), L[i]), r2 = H::sub(H::add(R[i + h], R[i + h]), R[i]);
+            e2 = H::add(e2, H::mul(l2, r2));
+        }
+        const H::Fr ev[2] = {e0, e2};
+        coeffs.assign(3, H::zero());
+        H::unipoly_from_evals_and_hint(claim, ev, 2, coeffs.data());
+        return ATLAS_OK;
+    }
+    int ingest(const atlas_u128_t& r, size_t round) override {
+        if (round != round_next || round >= n) return fail(ATLAS_ESTATE, "host read-raf: round out of order");
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        const size_t h = L.size() / 2;
+        for (size_t i = 0; i < h; i++) {
+            if (!(H::detail::is_zero4(L[i].l) && H::detail::is_zero4(L[i + h].l))) L[i] = H::add(L[i], H::mul(rf, H::sub(L[i + h], L[i])));
+            R[i] = H::add(R[i], H::mul(rf, H::sub(R[i + h], R[i])));
+        }
+        L.resize(h); R.resize(h);
+        round_next++;
+        return ATLAS_OK;
+    }
+    int finals(std::vector<H::Fr>& out) override {
+        if (round_next != n) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
+        out = {L[0], R[0], H::one()};
+        return ATLAS_OK;
+    }
+    bool pipelined() const override { return true; }
+    bool wide_wait(size_t) const override { return false; }
+    bool silent_round(size_t) const override { return true; }
+    int enqueue(size_t, const atlas::RoundIo& io, bool, atlas_mail_ref& mail) override { mail.base = io.mail; mail.blocks = 0; mail.n_vals = 0; return ATLAS_OK; }
+    int finish(size_t round, const H::Fr& claim, const H::Fr*, std::vector<H::Fr>& coeffs) override { return message(round, claim, coeffs); }
+    int host_ingest(const atlas_u128_t& r, size_t round) override { return ingest(r, round); }
+    int enqueue_finals(const atlas::RoundIo& io, atlas_mail_ref& mail) override { mail.base = io.mail; mail.blocks = 0; mail.n_vals = 0; return ATLAS_OK; }
+    int set_finals(const H::Fr*, size_t) override { return ATLAS_OK; }
+};
+}  // namespace
+int atlas_rt_shout_read_raf_host_new(atlas_poly_t G, const int32_t* table, size_t log_K, const atlas_fr_t* gamma, atlas_instance_t* out) {
+    PROF("atlas_rt_shout_read_raf_host_new");
+    if (!G || !table || !gamma || !out || log_K == 0 || log_K > 12) return fail(ATLAS_EINVAL, "shout_read_raf_host_new");
+    const size_t K = (size_t)1 << log_K;
+    if (G->is_i32 || G->len != K) return fail(ATLAS_EINVAL, "shout_read_raf_host_new: G length != table size");
+    std::unique_ptr<HostDot> P(new HostDot());
+    P->n = log_K;
+    P->L.resize(K); P->R.resize(K);
+    int rc = atlas_poly_download(G, reinterpret_cast<atlas_fr_t*>(P->L.data()), K);
+    if (rc) return rc;
+    const H::Fr gm = *reinterpret_cast<const H::Fr*>(gamma);
+    for (size_t k = 0; k < K; k++) {
+        const int64_t v = table[k];
+        const H::Fr fv = v >= 0 ? H::from_u64((uint64_t)v) : H::neg(H::from_u64((uint64_t)(-v)));
+        P->R[k] = H::add(fv, H::mul(gm, H::from_u64((uint64_t)k)));
+    }
+    *out = P.release();
+    return ATLAS_OK;
+}
+
 struct atlas_rt_ra_ticket { DevBuf acc; const unsigned long long* box = nullptr; uint32_t n_buckets = 0; };
 int atlas_rt_shout_ra_evals_launch(const uint64_t* lookup_indices, size_t T, size_t log_K, size_t log_k_chunk, atlas_poly_t eq_r_cycle, atlas_rt_ra_ticket** out) {
     PROF("atlas_rt_shout_ra_evals_launch");
