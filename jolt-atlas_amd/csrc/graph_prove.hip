@@ -567,18 +567,28 @@ struct Prover : FlowSink {
         const uint8_t ra_vp = clamp ? gr::VP_SymmetricClampRa : gr::VP_NodeOutputRa, rad_cp = clamp ? gr::CP_SymmetricClampRaD : gr::CP_NodeOutputRaD;
         H::Fr operand_claim;
         const int32_t* tp = G.tensor(nd.inputs[0]);
-        int rc = eval_i32(&tp, 1, T, R.point, &operand_claim);
+        NodePre pre;                                                          // eq(r) and the lookup's G table: in flight under the operand's evaluation
+        int rc = T > 1 ? pre.begin((const atlas_fr_t*)R.point.data(), log_T, {{W.lookups.as<uint64_t>(), XLEN}}) : ATLAS_OK;
+        if (!rc && pre.eq) {
+            atlas_poly_t pv = nullptr;
+            rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(tp), T, &pv);
+            if (!rc) rc = atlas_rt_evaluate_with_eq(&pv, 1, pre.eq, (atlas_fr_t*)&operand_claim);
+            if (pv) atlas_poly_free(pv);
+        } else if (!rc) rc = eval_i32(&tp, 1, T, R.point, &operand_claim);
+        if (!rc) rc = pre.collect(false);
         if (!rc) rc = append_nodeio(nd, 0, R.point, operand_claim);           // append_raf_claims_prover: witness_opening_id = Input(0)
         if (rc) return rc;
         const H::Fr gamma = H::tr_challenge_scalar(Tr);
         atlas_instance_t exec = nullptr;
+        if (pre.eq && !clamp) rc = atlas_rt_ps_shout_relu_new(W.lookups.as<uint64_t>(), log_T, XLEN, (const atlas_fr_t*)R.point.data(), (const atlas_fr_t*)&gamma, pre.eq, &exec);
+        else
         rc = clamp ? atlas_ps_shout_clamp_new(W.lookups.as<uint64_t>(), log_T, XLEN, gr::CLAMP_BOUND, 1, (const atlas_fr_t*)R.point.data(), (const atlas_fr_t*)&gamma, &exec)
                    : atlas_ps_shout_relu_new(W.lookups.as<uint64_t>(), log_T, XLEN, (const atlas_fr_t*)R.point.data(), (const atlas_fr_t*)&gamma, &exec);
         const H::Fr exec_claim = H::add(R.claim, H::mul(gamma, operand_claim));
         std::vector<atlas_u128_t> ch; H::Fr ra_claim; std::vector<atlas_fr_t> ra_point;
         if (!rc) rc = prove_single(exec, exec_claim, &t, O, ch, &ra_claim, XLEN, ra_vp, gr::PT_Execution, &ra_point);
         if (exec) atlas_instance_free(exec);
-        if (!rc) rc = prove_onehot_checks(W.lookups.as<uint64_t>(), log_T, XLEN, (const atlas_fr_t*)R.point.data(), ra_point, ra_claim, &t, O, rad_cp, gr::PT_RaOneHotChecks);
+        if (!rc) rc = prove_onehot_checks(W.lookups.as<uint64_t>(), log_T, XLEN, (const atlas_fr_t*)R.point.data(), ra_point, ra_claim, &t, O, rad_cp, gr::PT_RaOneHotChecks, &pre);
         return rc;
     }
 

@@ -1298,6 +1298,15 @@ int atlas_rt_ps_shout_clamp_new(const uint64_t* lookup_indices, size_t log_T, si
     if (log_T > 25) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: log_T <= 25");
     return ps_new(lookup_indices, log_T, xlen, 8, 2, r_node_output, gamma, out, bound, symmetric != 0, log_T ? eq_shared : nullptr);
 }
+int atlas_rt_ps_shout_relu_new(const uint64_t* lookup_indices, size_t log_T, size_t xlen, const atlas_fr_t* r_node_output, const atlas_fr_t* gamma,
+                               atlas_poly_t eq_shared, atlas_instance_t* out) {
+    PROF("atlas_ps_shout_relu_new");
+    NEED_INIT();
+    if (!lookup_indices || (!r_node_output && log_T) || !gamma || !out) return fail(ATLAS_EINVAL, "ps_shout_relu_new: null argument");
+    if (xlen != 16 && xlen != 32) return fail(ATLAS_EINVAL, "ps_shout_relu_new: X_LEN must be 16 or 32 (the reference's WordNoMSB suffix is a u32)");
+    if (log_T > 25) return fail(ATLAS_EINVAL, "ps_shout_relu_new: log_T <= 25");
+    return ps_new(lookup_indices, log_T, xlen, 8, 0, r_node_output, gamma, out, 0, true, log_T ? eq_shared : nullptr);
+}
 int atlas_rt_identity_range_check_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, size_t phases, const atlas_fr_t* r_node_output,
                                       atlas_poly_t eq_shared, atlas_instance_t* out) {
     PROF("atlas_identity_range_check_new");
