@@ -91,6 +91,8 @@ struct MsmPending {
     atlas_g1_affine_t* out = nullptr;
     std::vector<MsmTile> tiles;      // host source of an enqueued H2D copy: alive until the finish
     std::vector<TabTile> tab_tiles;
+    const G1Xyzz* fin = nullptr;     // wide-set fold: 1 + fin_bits points per set, the Horner over them is the host's (msm_finish)
+    uint32_t fin_bits = 0, chunk_log = 0;
 };
 
 // bucket reduction (msm_kernels.hip.h): lists and run sums live in one carved block
@@ -117,9 +119,24 @@ void launch_bucket_reduce(hipStream_t st, const G1Xyzz* partial, const SegMap ma
 
 int msm_finish(const MsmPending& P) {
     std::vector<H::G1X> hw(P.V);
-    hipError_t ce = hipMemcpyAsync(hw.data(), P.wsum, P.V * sizeof(G1Xyzz), hipMemcpyDeviceToHost, P.st);
-    if (ce == hipSuccess) ce = hipStreamSynchronize(P.st);
-    if (ce != hipSuccess) return fail(ATLAS_ENODEV, "msm result copy", ce);
+    if (P.fin) {       // set sum = fin[0] + 2^chunk_log * sum_b 2^b fin[1 + b]  (k_msm_fold_sets)
+        const uint32_t nf = 1 + P.fin_bits;
+        std::vector<H::G1X> hf((size_t)P.V * nf);
+        hipError_t ce = hipMemcpyAsync(hf.data(), P.fin, hf.size() * sizeof(G1Xyzz), hipMemcpyDeviceToHost, P.st);
+        if (ce == hipSuccess) ce = hipStreamSynchronize(P.st);
+        if (ce != hipSuccess) return fail(ATLAS_ENODEV, "msm result copy", ce);
+        for (uint32_t v = 0; v < P.V; v++) {
+            const H::G1X* f = hf.data() + (size_t)v * nf;
+            H::G1X acc = f[P.fin_bits];
+            for (int b = (int)P.fin_bits - 1; b >= 1; b--) acc = H::gx_add(H::gx_dbl(acc), f[b]);
+            for (uint32_t d = 0; d < P.chunk_log; d++) acc = H::gx_dbl(acc);
+            hw[v] = H::gx_add(acc, f[0]);
+        }
+    } else {
+        hipError_t ce = hipMemcpyAsync(hw.data(), P.wsum, P.V * sizeof(G1Xyzz), hipMemcpyDeviceToHost, P.st);
+        if (ce == hipSuccess) ce = hipStreamSynchronize(P.st);
+        if (ce != hipSuccess) return fail(ATLAS_ENODEV, "msm result copy", ce);
+    }
     const bool trace = getenv("ATLAS_TRACE") != nullptr;
     const auto th0 = std::chrono::steady_clock::now();
     // Horner over the windows of each vector: acc = 2^c * acc + W_w
@@ -280,13 +297,21 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
 // Digit width for `n` scalars against a table of stride tab_c: the divisor c' = tab_c / q that minimises
 // n * ceil(255 / c') mixed additions + ~3 * q * 2^(c'-1) additions of bucket folding.  Returns q = 0 when the
 // variable-base plan (20 windows of 13 bits) is at least as cheap.
+// bucket bits resolved by the second (LDS) pass of the sort; the first pass partitions by the rest
+uint32_t tab_lo_bits() {
+    static const uint32_t v = [] {
+        if (const char* e = getenv("ATLAS_TAB_LO")) { const int x = atoi(e); if (x >= 6 && x <= (int)TAB_LO_BITS) return (uint32_t)x; }   // experiments
+        return TAB_LO_BITS;
+    }();
+    return v;
+}
 bool tab_q_ok(uint32_t tab_c, uint32_t levels, uint32_t q) {
     if (q == 0 || tab_c % q) return false;
     const uint32_t c = tab_c / q;
     if (c < 4 || c > 24) return false;
     const uint32_t nd = (255 + c - 1) / c;
     if ((nd + q - 1) / q > levels) return false;
-    const uint32_t hi = c - 1 > TAB_LO_BITS ? c - 1 - TAB_LO_BITS : 0;
+    const uint32_t hi = c - 1 > tab_lo_bits() ? c - 1 - tab_lo_bits() : 0;
     return (q << hi) <= TAB_MAX_BINS;
 }
 uint32_t pick_tab_q(size_t n, uint32_t tab_c, uint32_t levels) {
@@ -313,7 +338,7 @@ int msm_tab_core(const atlas_srs* srs, size_t pt_off, const Fr* d_scalars, size_
     TabShape S;
     S.c = srs->tab_c / q; S.q = q;
     S.n_digits = (255 + S.c - 1) / S.c;
-    S.lo_bits = S.c - 1 < TAB_LO_BITS ? S.c - 1 : TAB_LO_BITS;
+    S.lo_bits = S.c - 1 < tab_lo_bits() ? S.c - 1 : tab_lo_bits();
     S.hi_bits = S.c - 1 - S.lo_bits;
     S.level_stride = (uint32_t)srs->tab_len;
     const uint32_t bpw = 1u << (S.c - 1);
@@ -363,6 +388,16 @@ int msm_tab_core(const atlas_srs* srs, size_t pt_off, const Fr* d_scalars, size_
     uint32_t gs_split = 1;
     while (chunks_per_set / gs_split > 1024 && gs_split < 256) gs_split <<= 1;
     const size_t o_gsum = carve((size_t)V * gs_split * sizeof(G1Xyzz));
+    // wide sets (>= 256 chunks each): the fold without scalar multiples (msm_kernels.hip.h, k_msm_fold_pairs)
+    const bool wide_fold = chunks_per_set >= MSM_THREADS && chunks_per_set % MSM_THREADS == 0 && !getenv("ATLAS_MSM_FOLD_MUL");
+    const uint32_t f_groups = wide_fold ? chunks_per_set / MSM_THREADS : 0;
+    uint32_t f_hi = 0, chunk_log = 0;
+    while ((1u << f_hi) < f_groups) f_hi++;
+    while ((1u << chunk_log) < chunk) chunk_log++;
+    const uint32_t f_bits = 8 + f_hi;
+    const size_t o_fruns = carve(wide_fold ? (size_t)n_chunks * sizeof(G1Xyzz) : 0);
+    const size_t o_fpart = carve(wide_fold ? (size_t)V * 10 * f_groups * sizeof(G1Xyzz) : 0);
+    const size_t o_ffin = carve(wide_fold ? (size_t)V * (1 + f_bits) * sizeof(G1Xyzz) : 0);
     const size_t o_biglist = carve(ReduceBufs::bytes(TB, s_max));
     const size_t o_tiles = carve(h_tiles.size() * sizeof(TabTile));
     int rc = wk.ensure(off);
@@ -411,17 +446,29 @@ int msm_tab_core(const atlas_srs* srs, size_t pt_off, const Fr* d_scalars, size_
     launch_bucket_reduce(st, partial, smap, TB, buckets, rbufs);
     if (timing) hipEventRecord(e2, st);
     MsmShape SS; SS.c = S.c; SS.n_windows = q; SS.bpw = bpw;
+    const bool host_horner = wide_fold && V <= 4;
+    if (wide_fold) {
+        G1Xyzz* fruns = (G1Xyzz*)(W + o_fruns);
+        G1Xyzz* fpart = (G1Xyzz*)(W + o_fpart);
+        G1Xyzz* ffin = (G1Xyzz*)(W + o_ffin);
+        k_msm_fold_pairs<<<(n_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(buckets, chunk, n_chunks, chunks, fruns);
+        k_msm_fold_groups<<<dim3(f_groups, 2, V), MSM_THREADS, 2 * MSM_THREADS * sizeof(G1Xyzz), st>>>(chunks, fruns, chunks_per_set, fpart);
+        k_msm_fold_sets<<<dim3(10 + (f_hi > 8 ? f_hi - 8 : 0), V), MSM_THREADS, 2 * MSM_THREADS * sizeof(G1Xyzz), st>>>(fpart, f_groups, f_hi, ffin);
+        if (!host_horner) k_msm_fold_horner<<<(V + 63) / 64, 64, 0, st>>>(ffin, V, f_bits, chunk_log, wsum);
+    } else {
     k_msm_fold_chunks<<<(n_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(buckets, SS, chunk, n_chunks, chunks);
     if (gs_split > 1) {      // a set has up to 2^20 chunk sums: one workgroup per set would add them 4096 deep
         k_g1_group_sum<<<V * gs_split, MSM_THREADS, 0, st>>>(chunks, chunks_per_set / gs_split, gsum);
         k_g1_group_sum<<<V, MSM_THREADS, 0, st>>>(gsum, gs_split, wsum);
     } else k_g1_group_sum<<<V, MSM_THREADS, 0, st>>>(chunks, chunks_per_set, wsum);
+    }
     if (timing) hipEventRecord(e3, st);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail(ATLAS_ENODEV, "msm launch", le);
 
     MsmPending P;
     P.st = st; P.wsum = wsum; P.V = V; P.K = K; P.n = n; P.S = SS; P.out = out;
+    if (host_horner) { P.fin = (const G1Xyzz*)(W + o_ffin); P.fin_bits = f_bits; P.chunk_log = chunk_log; }
     P.tab_tiles = std::move(h_tiles);
     if (pend) { *pend = std::move(P); return ATLAS_OK; }
     rc = msm_finish(P);

@@ -533,6 +533,109 @@ __global__ __launch_bounds__(MSM_THREADS) void k_msm_fold_chunks(const G1Xyzz* _
     g1_store(out + t, acc);
 }
 
+// ---- the fold of a wide bucket set (fixed-base path: 2^19 buckets in ONE set), without scalar multiples ----------------
+// sum_k (k+1) B_k over bpw buckets, chunk = C consecutive buckets per thread, j = chunk index:
+//     = sum_j acc_j + C * sum_j j * S_j,   acc_j = sum_i (i+1) B_{jC+i},  S_j = sum_i B_{jC+i}           (level 1, 2C additions deep)
+//     sum_j j * S_j = sum_b 2^b * M_b,     M_b = sum of the S_j whose index has bit b set                (plain masked sums)
+// k_msm_fold_chunks pays ~19 doublings + as many (divergent) additions per thread for j*C * S_j — 3/4 of its time — and the
+// additions of a point chain cost ~12 us each whatever the occupancy (14 dependent field products), so what counts here is the
+// DEPTH: level 1 (2C), two tree levels of 8 (k_msm_fold_groups over 256 chunks, k_msm_fold_sets over the groups), and the
+// Horner over the ~17 masked sums on the host (0.4 us per operation there) or, for many sets, one thread per set.
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_fold_pairs(const G1Xyzz* __restrict__ buckets, uint32_t chunk, uint32_t n_chunks_total,
+                                                                G1Xyzz* __restrict__ acc_out, G1Xyzz* __restrict__ run_out) {
+    const uint32_t t = blockIdx.x * MSM_THREADS + threadIdx.x;
+    if (t >= n_chunks_total) return;
+    const G1Xyzz* base = buckets + (size_t)t * chunk;
+    G1Xyzz run = g1_load(base + chunk - 1), acc = run;
+    for (int k = (int)chunk - 2; k >= 0; k--) {
+        run = g1_add(run, g1_load(base + k));
+        acc = g1_add(acc, run);
+    }
+    g1_store(acc_out + t, acc);
+    g1_store(run_out + t, run);
+}
+
+// One tree over 256 points p_t that yields their sum AND the eight masked sums M_b = sum of the p_t with bit b of t set: a node of
+// level L (2^L consecutive points) carries its sum and M_0 .. M_{L-1}; merging two level-b nodes costs b + 1 additions (M_i = M_i' + M_i''
+// for i < b, M_b = the right node's sum, S = S' + S''), one per lane, so a level is ONE addition deep and at most two wavefronts wide
+// (128, 128, 96, 64, 40, 24, 14, 8 lanes) — ten separate masked trees were 2.3 x the wavefront-additions of this one and took 0.54 ms.
+// sS: 256 points (in: the points; out: [0] = sum), sM: 2 x 128 points (out: sM[0 .. 8) = M_0 .. M_7).  Every thread calls.
+__device__ __forceinline__ void g1_block_bit_sums(G1Xyzz* sS, G1Xyzz* sM) {
+#pragma unroll 1
+    for (uint32_t b = 0; b < 8; b++) {
+        const uint32_t items = (128u >> b) * (b + 1);
+        G1Xyzz* oldM = sM + (b & 1u) * 128u;
+        G1Xyzz* newM = sM + ((b + 1) & 1u) * 128u;
+        if (threadIdx.x < items) {
+            const uint32_t m = threadIdx.x / (b + 1), i = threadIdx.x % (b + 1);
+            const bool mm = i < b;                  // ONE addition per lane and level, whichever kind (two call sites would run one after the other)
+            const G1Xyzz* pa = mm ? oldM + (2 * m) * b + i : sS + ((2 * m) << b);
+            const G1Xyzz* pb = mm ? oldM + (2 * m + 1) * b + i : sS + ((2 * m + 1) << b);
+            const G1Xyzz A = *pa, B = *pb;
+            const G1Xyzz r = g1_add(A, B);
+            if (mm) newM[m * (b + 1) + i] = r;
+            else { newM[m * (b + 1) + b] = B; sS[(2 * m) << b] = r; }
+        }
+        __syncthreads();
+    }
+}
+
+// grid (groups of 256 chunks, 2, sets): y = 0: the sum of the group's acc -> row 0; y = 1: the sum of its S -> row 1 and the masked
+// sums by bit b of the chunk index -> row 2 + b.  out[(set * 10 + row) * groups + group]
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_fold_groups(const G1Xyzz* __restrict__ acc_in, const G1Xyzz* __restrict__ run_in,
+                                                                 uint32_t chunks_per_set, G1Xyzz* __restrict__ out) {
+    extern __shared__ G1Xyzz sm[];          // 256 points (y = 0) or 512 (y = 1)
+    const uint32_t grp = blockIdx.x, set = blockIdx.z, groups = gridDim.x;
+    const size_t t = (size_t)set * chunks_per_set + (size_t)grp * MSM_THREADS + threadIdx.x;
+    G1Xyzz* o = out + (size_t)set * 10 * groups + grp;
+    if (blockIdx.y == 0) {
+        const G1Xyzz r = g1_block_sum(g1_load(acc_in + t), sm);
+        if (threadIdx.x == 0) g1_store(o, r);
+        return;
+    }
+    sm[threadIdx.x] = g1_load(run_in + t);
+    __syncthreads();
+    g1_block_bit_sums(sm, sm + MSM_THREADS);
+    if (threadIdx.x == 0) g1_store(o + groups, sm[0]);
+    else if (threadIdx.x <= 8) g1_store(o + (size_t)(1 + threadIdx.x) * groups, sm[MSM_THREADS + threadIdx.x - 1]);
+}
+
+// grid (10 + max(hi_bits - 8, 0), sets): x < 9: the plain sums over the groups of rows 0 (-> fin 0) and 2 + b (-> fin 1 + b); x = 9: the masked
+// sums of row 1 by bits 0..7 of the group index -> fin 9 + h; x = 10 + e: by bit 8 + e (more than 256 groups) -> fin 17 + e.
+__global__ __launch_bounds__(MSM_THREADS) void k_msm_fold_sets(const G1Xyzz* __restrict__ part, uint32_t groups, uint32_t hi_bits,
+                                                               G1Xyzz* __restrict__ fin) {
+    extern __shared__ G1Xyzz sm[];
+    const uint32_t x = blockIdx.x, set = blockIdx.y;
+    const uint32_t row = x == 0 ? 0u : x < 9 ? x + 1u : 1u;
+    const uint32_t mask = x > 9 ? 1u << (x - 2) : 0u;
+    const G1Xyzz* src = part + ((size_t)set * 10 + row) * groups;
+    G1Xyzz* f = fin + (size_t)set * (9 + hi_bits);
+    G1Xyzz p = g1_inf();
+    for (uint32_t gi = threadIdx.x; gi < groups; gi += MSM_THREADS)
+        if (!mask || (gi & mask)) p = gi < MSM_THREADS ? g1_load(src + gi) : g1_add(p, g1_load(src + gi));
+    if (x != 9) {
+        const G1Xyzz r = g1_block_sum(p, sm);
+        if (threadIdx.x == 0) g1_store(f + (x < 9 ? x : x + 7), r);
+        return;
+    }
+    sm[threadIdx.x] = p;
+    __syncthreads();
+    g1_block_bit_sums(sm, sm + MSM_THREADS);
+    if (threadIdx.x < (hi_bits < 8 ? hi_bits : 8u)) g1_store(f + 9 + threadIdx.x, sm[MSM_THREADS + threadIdx.x]);
+}
+
+// many sets: the Horner over a set's masked sums, one thread per set (a few sets: msm_finish does it on the host)
+__global__ __launch_bounds__(64) void k_msm_fold_horner(const G1Xyzz* __restrict__ fin, uint32_t n_sets, uint32_t n_bits, uint32_t chunk_log,
+                                                        G1Xyzz* __restrict__ wsum) {
+    const uint32_t set = blockIdx.x * 64 + threadIdx.x;
+    if (set >= n_sets) return;
+    const G1Xyzz* f = fin + (size_t)set * (1 + n_bits);
+    G1Xyzz acc = g1_inf();
+    for (int b = (int)n_bits - 1; b >= 0; b--) acc = g1_add(g1_dbl(acc), g1_load(f + 1 + b));
+    for (uint32_t d = 0; d < chunk_log; d++) acc = g1_dbl(acc);
+    g1_store(wsum + set, g1_add(acc, g1_load(f)));
+}
+
 // sum groups of `per_group` points: one workgroup per group, tree in LDS
 __global__ __launch_bounds__(MSM_THREADS) void k_g1_group_sum(const G1Xyzz* __restrict__ pts, uint32_t per_group,
                                                               G1Xyzz* __restrict__ out) {

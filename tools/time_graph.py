@@ -16,7 +16,7 @@ from jolt_atlas_amd import graph as GG  # noqa: E402
 
 
 def run(name, level, reps):
-    nodes, outputs, inputs = getattr(BG, name)() if name.endswith("_model") else getattr(BG, name)(level=level)
+    nodes, outputs, inputs = getattr(BG, name)() if name.endswith("_model") or name.startswith("node_") else getattr(BG, name)(level=level)
     nv = BG.max_vars(nodes)
     tau = np.array([0x1234567, 0, 0, 0], dtype=np.uint64)
     t0 = time.time()
