@@ -303,7 +303,29 @@ struct Elementwise : atlas_instance {
     }
 };
 
+// A member of a BatchedSumcheck that has NO rounds of its own (an instance over zero variables: HammingBooleanity of a gather with ONE index):
+// the batch absorbs its input claim, draws its coefficient, scales the claim by 2^max_rounds and never starts it (sumcheck.rs:620-700); what
+// is left of the instance is its final claims.
+struct ConstMember : atlas_instance {
+    size_t deg = 1;
+    std::vector<H::Fr> vals;
+    size_t rounds() const override { return 0; }
+    size_t degree() const override { return deg; }
+    int message(size_t, const H::Fr&, std::vector<H::Fr>&) override { return fail(ATLAS_ESTATE, "a member without rounds has no round polynomial"); }
+    int ingest(const atlas_u128_t&, size_t) override { return fail(ATLAS_ESTATE, "a member without rounds binds nothing"); }
+    int finals(std::vector<H::Fr>& out) override { out = vals; return ATLAS_OK; }
+};
+
 }  // namespace
+
+int atlas_rt_const_member_new(const atlas_fr_t* finals, size_t n, size_t degree, atlas_instance_t* out) {
+    if (!finals || !n || !out) return fail(ATLAS_EINVAL, "const_member_new: null argument");
+    ConstMember* P = new ConstMember();
+    P->deg = degree;
+    P->vals.assign(reinterpret_cast<const H::Fr*>(finals), reinterpret_cast<const H::Fr*>(finals) + n);
+    *out = P;
+    return ATLAS_OK;
+}
 
 extern "C" {
 

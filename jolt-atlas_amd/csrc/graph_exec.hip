@@ -465,7 +465,7 @@ int atlas_rt_validate_node(const atlas_graph& G, const Node& nd) {
             if (!need_inputs(2) || nd.p[0] != 0) return bad("graph: Gather needs (dictionary, indexes) and axis 0");
             const size_t V = in_node(0).dims[0], word = gr::padded_len(in_node(0).dims) / V, N = gr::padded_len(in_node(1).dims);
             if (T != N * word || nd.p[1] < 0 || (size_t)nd.p[1] > V) return bad("graph: Gather dims / dict_len");
-            if (nd.op == ATLAS_OP_GATHER_SMALL && (V > 65536 || V < 2 || N < 2)) return bad("graph: GatherSmall is the tracer's choice for dictionaries of at most 2^16 words (handlers/index.rs:33-45)");
+            if (nd.op == ATLAS_OP_GATHER_SMALL && (V > 65536 || V < 2)) return bad("graph: GatherSmall is the tracer's choice for dictionaries of at most 2^16 words (handlers/index.rs:33-45)");
             return ATLAS_OK;
         }
         case ATLAS_OP_SOFTMAX: {
@@ -700,7 +700,7 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
             if (!need_inputs(2) || nd.p[0] != 0) return fail(ATLAS_EINVAL, "graph: Gather needs (dictionary, indexes) and axis 0");
             const size_t V = in_node(0).dims[0], word = gr::padded_len(in_node(0).dims) / V, N = gr::padded_len(in_node(1).dims);
             if (T != N * word || (size_t)nd.p[1] > V) return fail(ATLAS_EINVAL, "graph: Gather dims / dict_len");
-            if (nd.op == ATLAS_OP_GATHER_SMALL && (V > 65536 || V < 2 || N < 2)) return fail(ATLAS_EINVAL, "graph: GatherSmall is the tracer's choice for dictionaries of at most 2^16 words (handlers/index.rs:33-45)");
+            if (nd.op == ATLAS_OP_GATHER_SMALL && (V > 65536 || V < 2)) return fail(ATLAS_EINVAL, "graph: GatherSmall is the tracer's choice for dictionaries of at most 2^16 words (handlers/index.rs:33-45)");
             NodeWitness& W = G.wit[nd.idx];
             HIP_TRY(W.lookups.alloc(N * 8));
             k_gather_rows<<<grid_for(T), 256, 0, g.stream>>>(in(0), in(1), N, word, out.as<int32_t>(), W.lookups.as<uint64_t>());

@@ -181,34 +181,36 @@ struct Prover : FlowSink {
             W.one_cycle_rows.clear();
             const size_t T = gr::padded_len(nd.dims), log_T = gr::log2u(T);
             int drc = ATLAS_OK;
-            auto chunks = [&](uint8_t cp, const uint64_t* d_lookups, size_t log_K) {
+            // ONE cycle: a one-hot polynomial over K addresses has K x 1 coefficients, a single one at the address read — committed, opened and folded
+            // into the joint polynomial as the K-coefficient dense row it is (same commitment g1[k], same round polynomials: both openings bind the
+            // address variables HighToLow over eq(r_address, .)); the reference's generic flow at T = 1
+            auto first_lookup = [&](const uint64_t* d_lookups, uint64_t* lk) {
+                std::lock_guard<atlas_rt::Mutex> lk_(g.mu);
+                if (hipMemcpyAsync(lk, d_lookups, 8, hipMemcpyDeviceToHost, g.stream) != hipSuccess || hipStreamSynchronize(g.stream) != hipSuccess) drc = fail(ATLAS_ENODEV, "prove_graph: lookup index of a one-element node");
+            };
+            auto one_cycle_row = [&](gr::PolyId id, size_t hot, size_t width) {
+                std::vector<int32_t> row(width, 0);
+                row[hot] = 1;
+                W.one_cycle_rows.emplace_back(new DevBuf());
+                DevBuf& B = *W.one_cycle_rows.back();
+                if (B.alloc(width * 4) != hipSuccess) { drc = fail(ATLAS_ENOMEM, "prove_graph: one-cycle chunk row"); return; }
+                {
+                    std::lock_guard<atlas_rt::Mutex> lk_(g.mu);
+                    if (hipMemcpyAsync(B.p, row.data(), width * 4, hipMemcpyHostToDevice, g.stream) != hipSuccess || hipStreamSynchronize(g.stream) != hipSuccess) { drc = fail(ATLAS_ENODEV, "prove_graph: one-cycle chunk row"); return; }
+                }
+                atlas_poly_t v = nullptr;
+                drc = atlas_poly_wrap_device_i32(B.as<int32_t>(), width, &v);
+                if (drc) return;
+                W.dense_views.push_back(v);
+                gr::Committed c; c.id = id; c.kind = 0; c.dense = v; c.log_T = gr::log2u(width);
+                W.committed.push_back(c);
+            };
+            auto chunks = [&](uint8_t cp, const uint64_t* d_lookups, size_t log_K, bool one_cycle) {
                 const size_t d = (log_K + 3) / 4;
-                if (T == 1) {
-                    // ONE cycle: the one-hot polynomial of chunk i has K x 1 = 16 coefficients, a single one at the chunk's value — committed, opened
-                    // and folded into the joint polynomial as the 16-coefficient dense row it is (same commitment g1[k], same round polynomials:
-                    // both openings bind the four address variables HighToLow over eq(r_address, .)); the reference's generic flow at T = 1
+                if (one_cycle) {
                     uint64_t lk = 0;
-                    {
-                        std::lock_guard<atlas_rt::Mutex> lk_(g.mu);
-                        if (hipMemcpyAsync(&lk, d_lookups, 8, hipMemcpyDeviceToHost, g.stream) != hipSuccess || hipStreamSynchronize(g.stream) != hipSuccess) { drc = fail(ATLAS_ENODEV, "prove_graph: lookup index of a one-element node"); return; }
-                    }
-                    for (size_t i = 0; i < d && !drc; i++) {
-                        int32_t row[16] = {0};
-                        row[(lk >> (4 * (d - 1 - i))) & 15] = 1;
-                        W.one_cycle_rows.emplace_back(new DevBuf());
-                        DevBuf& B = *W.one_cycle_rows.back();
-                        if (B.alloc(sizeof(row)) != hipSuccess) { drc = fail(ATLAS_ENOMEM, "prove_graph: one-cycle chunk row"); return; }
-                        {
-                            std::lock_guard<atlas_rt::Mutex> lk_(g.mu);
-                            if (hipMemcpyAsync(B.p, row, sizeof(row), hipMemcpyHostToDevice, g.stream) != hipSuccess || hipStreamSynchronize(g.stream) != hipSuccess) { drc = fail(ATLAS_ENODEV, "prove_graph: one-cycle chunk row"); return; }
-                        }
-                        atlas_poly_t v = nullptr;
-                        drc = atlas_poly_wrap_device_i32(B.as<int32_t>(), 16, &v);
-                        if (drc) return;
-                        W.dense_views.push_back(v);
-                        gr::Committed c; c.id = gr::comm(cp, nd.idx, i); c.kind = 0; c.dense = v; c.log_T = 4;
-                        W.committed.push_back(c);
-                    }
+                    first_lookup(d_lookups, &lk);
+                    for (size_t i = 0; i < d && !drc; i++) one_cycle_row(gr::comm(cp, nd.idx, i), (lk >> (4 * (d - 1 - i))) & 15, 16);
                     return;
                 }
                 for (size_t i = 0; i < d; i++) {
@@ -226,50 +228,56 @@ struct Prover : FlowSink {
             };
             // one element: the is_scalar operators commit nothing; ScalarConstDiv keeps its remainder and Div its quotient (ops/div.rs:157-160)
             if (T == 1 && nd.op != ATLAS_OP_SCALAR_CONST_DIV && nd.op != ATLAS_OP_DIV && nd.op != ATLAS_OP_RELU && nd.op != ATLAS_OP_CLAMP && !atlas_rt_is_activation(nd.op) &&
-                nd.op != ATLAS_OP_RSQRT && nd.op != ATLAS_OP_SIN && nd.op != ATLAS_OP_COS) continue;      // (the lookup operators proper run their generic flows over one cycle)
+                nd.op != ATLAS_OP_RSQRT && nd.op != ATLAS_OP_SIN && nd.op != ATLAS_OP_COS && nd.op != ATLAS_OP_GATHER_SMALL && nd.op != ATLAS_OP_GATHER_LARGE) continue;      // (the lookup operators proper run their generic flows over one cycle)
             switch (nd.op) {
-                case ATLAS_OP_ADD: case ATLAS_OP_SUB: chunks(gr::CP_ClampRaD, W.cidx.as<uint64_t>(), 64); break;       // clamp_committed_polys
+                case ATLAS_OP_ADD: case ATLAS_OP_SUB: chunks(gr::CP_ClampRaD, W.cidx.as<uint64_t>(), 64, T == 1); break;       // clamp_committed_polys
                 case ATLAS_OP_EINSUM: case ATLAS_OP_MUL: case ATLAS_OP_SQUARE: case ATLAS_OP_CUBE:                     // fused_rebase::committed_polys
-                    chunks(gr::CP_RescaleRemainderRaD, W.rescale->ridx.as<uint64_t>(), W.rescale->S);
-                    chunks(gr::CP_ClampRaD, W.rescale->cidx.as<uint64_t>(), 64);
+                    chunks(gr::CP_RescaleRemainderRaD, W.rescale->ridx.as<uint64_t>(), W.rescale->S, T == 1);
+                    chunks(gr::CP_ClampRaD, W.rescale->cidx.as<uint64_t>(), 64, T == 1);
                     break;
-                case ATLAS_OP_RELU: chunks(gr::CP_NodeOutputRaD, W.lookups.as<uint64_t>(), 32); break;                 // ops/relu.rs
-                case ATLAS_OP_CLAMP: chunks(gr::CP_SymmetricClampRaD, W.lookups.as<uint64_t>(), 32); break;            // ops/clamp.rs
-                case ATLAS_OP_SUM: chunks(gr::CP_ClampRaD, W.cidx.as<uint64_t>(), 64); break;                           // ops/sum/mod.rs
+                case ATLAS_OP_RELU: chunks(gr::CP_NodeOutputRaD, W.lookups.as<uint64_t>(), 32, T == 1); break;                 // ops/relu.rs
+                case ATLAS_OP_CLAMP: chunks(gr::CP_SymmetricClampRaD, W.lookups.as<uint64_t>(), 32, T == 1); break;            // ops/clamp.rs
+                case ATLAS_OP_SUM: chunks(gr::CP_ClampRaD, W.cidx.as<uint64_t>(), 64, T == 1); break;                           // ops/sum/mod.rs
                 case ATLAS_OP_SCALAR_CONST_DIV: dense(gr::CP_ScalarConstDivNodeRemainder, W.rem.p, true); break;         // ops/scalar_const_div.rs
                 case ATLAS_OP_DIV:                                                                                       // ops/div.rs
                     dense(gr::CP_DivNodeQuotient, G.out[nd.idx].p, true);
-                    if (T > 1) chunks(gr::CP_DivRangeCheckRaD, W.lookups.as<uint64_t>(), 64);
+                    if (T > 1) chunks(gr::CP_DivRangeCheckRaD, W.lookups.as<uint64_t>(), 64, T == 1);
                     break;
                 case ATLAS_OP_MEAN_OF_SQUARES:                                                                           // ops/mean_of_squares.rs
-                    chunks(gr::CP_ClampRaD, W.rescale->cidx.as<uint64_t>(), 64);
-                    chunks(gr::CP_MeanOfSquaresRangeCheckRaD, W.lookups.as<uint64_t>(), 64);
+                    chunks(gr::CP_ClampRaD, W.rescale->cidx.as<uint64_t>(), 64, T == 1);
+                    chunks(gr::CP_MeanOfSquaresRangeCheckRaD, W.lookups.as<uint64_t>(), 64, T == 1);
                     break;
                 case ATLAS_OP_RSQRT:                                                                                     // ops/rsqrt.rs
                     dense(gr::CP_RsqrtQuotient, W.quot_fr.p, false);
-                    chunks(gr::CP_SqrtDivRangeCheckRaD, W.lookups.as<uint64_t>(), 64);
-                    chunks(gr::CP_SqrtRangeCheckRaD, W.lookups2.as<uint64_t>(), 64);
+                    chunks(gr::CP_SqrtDivRangeCheckRaD, W.lookups.as<uint64_t>(), 64, T == 1);
+                    chunks(gr::CP_SqrtRangeCheckRaD, W.lookups2.as<uint64_t>(), 64, T == 1);
                     break;
                 case ATLAS_OP_TANH: case ATLAS_OP_ERF: case ATLAS_OP_SIGMOID:                                            // clamped_activation_committed_polynomials
-                    chunks(gr::CP_ActivationClampRaD, W.lookups.as<uint64_t>(), 32);
-                    chunks(gr::CP_ActivationSmallRaD, W.lookups2.as<uint64_t>(), gr::ACTIVATION_TABLE_VARS);
+                    chunks(gr::CP_ActivationClampRaD, W.lookups.as<uint64_t>(), 32, T == 1);
+                    chunks(gr::CP_ActivationSmallRaD, W.lookups2.as<uint64_t>(), gr::ACTIVATION_TABLE_VARS, T == 1);
                     break;
                 case ATLAS_OP_SOFTMAX: {                                                                                 // ops/softmax_last_axis/mod.rs:136-159
                     SoftmaxWitness& Sm = *W.softmax;
-                    chunks(gr::CP_SoftmaxRemainderRaD, Sm.idx_R.as<uint64_t>(), gr::MODEL_SCALE);
-                    chunks(gr::CP_SoftmaxExpRemainderRaD, Sm.idx_rexp.as<uint64_t>(), gr::MODEL_SCALE);
-                    chunks(gr::CP_SoftmaxClampRaD, Sm.idx_z.as<uint64_t>(), 32);
-                    chunks(gr::CP_SoftmaxZHiRaD, Sm.idx_zhi.as<uint64_t>(), Sm.lk_hi);
-                    chunks(gr::CP_SoftmaxZLoRaD, Sm.idx_zlo.as<uint64_t>(), Sm.lk_lo);
+                    chunks(gr::CP_SoftmaxRemainderRaD, Sm.idx_R.as<uint64_t>(), gr::MODEL_SCALE, T == 1);
+                    chunks(gr::CP_SoftmaxExpRemainderRaD, Sm.idx_rexp.as<uint64_t>(), gr::MODEL_SCALE, T == 1);
+                    chunks(gr::CP_SoftmaxClampRaD, Sm.idx_z.as<uint64_t>(), 32, T == 1);
+                    chunks(gr::CP_SoftmaxZHiRaD, Sm.idx_zhi.as<uint64_t>(), Sm.lk_hi, T == 1);
+                    chunks(gr::CP_SoftmaxZLoRaD, Sm.idx_zlo.as<uint64_t>(), Sm.lk_lo, T == 1);
                     break;
                 }
                 case ATLAS_OP_SIN: case ATLAS_OP_COS:                                                                    // ops/sin.rs:169-186
                     dense(gr::CP_TeleportNodeQuotient, W.rem2.p, true);
-                    chunks(gr::CP_TrigDownscaleRaD, W.lookups.as<uint64_t>(), 32);
-                    chunks(nd.op == ATLAS_OP_SIN ? gr::CP_SinRaD : gr::CP_CosRaD, W.lookups2.as<uint64_t>(), gr::TRIG_TABLE_VARS);
-                    chunks(gr::CP_TeleportRangeCheckRaD, W.cidx.as<uint64_t>(), 64);
+                    chunks(gr::CP_TrigDownscaleRaD, W.lookups.as<uint64_t>(), 32, T == 1);
+                    chunks(nd.op == ATLAS_OP_SIN ? gr::CP_SinRaD : gr::CP_CosRaD, W.lookups2.as<uint64_t>(), gr::TRIG_TABLE_VARS, T == 1);
+                    chunks(gr::CP_TeleportRangeCheckRaD, W.cidx.as<uint64_t>(), 64, T == 1);
                     break;
                 case ATLAS_OP_GATHER_SMALL: {                                                                            // ops/gather/small.rs:119-121: ONE one-hot polynomial, dict_len addresses
+                    if (gr::padded_len(G.nodes.at(nd.inputs[1]).dims) == 1) {                                               // ONE index: the dict_len x 1 coefficients as a dense row
+                        uint64_t lk = 0;
+                        first_lookup(W.lookups.as<uint64_t>(), &lk);
+                        if (!drc) one_cycle_row(gr::comm(gr::CP_GatherRa, nd.idx), (size_t)lk, gr::next_pow2(G.nodes.at(nd.inputs[0]).dims[0]));
+                        break;
+                    }
                     gr::Committed c; c.id = gr::comm(gr::CP_GatherRa, nd.idx); c.kind = 1; c.d_lookups = W.lookups.as<uint64_t>();
                     c.log_T = gr::log2u(gr::padded_len(G.nodes.at(nd.inputs[1]).dims)); c.log_K = gr::log2u(G.nodes.at(nd.inputs[0]).dims[0]); c.chunk = 0; c.lkc = c.log_K;
                     W.committed.push_back(c);
@@ -277,6 +285,7 @@ struct Prover : FlowSink {
                 }
                 case ATLAS_OP_GATHER_LARGE: {                                                                            // ops/gather/large.rs:105-111
                     const size_t N = gr::padded_len(G.nodes.at(nd.inputs[1]).dims), V = G.nodes.at(nd.inputs[0]).dims[0], lk = gr::log2u(V), d = (lk + 3) / 4;
+                    if (N == 1) { chunks(gr::CP_GatherRaD, W.lookups.as<uint64_t>(), lk, true); break; }                      // ONE index
                     for (size_t i = 0; i < d; i++) {
                         gr::Committed c; c.id = gr::comm(gr::CP_GatherRaD, nd.idx, i); c.kind = 1; c.d_lookups = W.lookups.as<uint64_t>(); c.log_T = gr::log2u(N); c.log_K = lk; c.chunk = i;
                         W.committed.push_back(c);
@@ -1119,9 +1128,12 @@ struct Prover : FlowSink {
         const H::Fr one = H::one(), zero = H::zero();
         const H::Fr gamma_b = H::challenge_to_fr(1, 0, g.challenge_mode);   // F::Challenge::from(1): the challenge READING of the integer 1
         atlas_instance_t i_hb = nullptr, i_bool = nullptr, i_hw = nullptr;
-        if (!rc) rc = atlas_elementwise_new(ATLAS_EW_HAMMING_BOOL, &hw, 1, (const atlas_fr_t*)r_index.data(), ln, (const atlas_fr_t*)&one, 1, &i_hb);
+        const atlas_fr_t no_point{};
+        const atlas_fr_t* rix = ln ? (const atlas_fr_t*)r_index.data() : &no_point;          // ONE index: r_cycle is the empty point
+        if (!rc) rc = ln ? atlas_elementwise_new(ATLAS_EW_HAMMING_BOOL, &hw, 1, rix, ln, (const atlas_fr_t*)&one, 1, &i_hb)
+                         : atlas_rt_const_member_new((const atlas_fr_t*)&one, 1, 3, &i_hb);  // hw over zero variables: no rounds, final claim hw[0] = 1
         if (hw) atlas_poly_free(hw);
-        if (!rc) rc = atlas_booleanity_from_lookups_new(Gh.data(), lookups, ln, lv, lv, (const atlas_fr_t*)&gamma_b, (const atlas_fr_t*)r_address.data(), (const atlas_fr_t*)r_index.data(), &i_bool);
+        if (!rc) rc = atlas_booleanity_from_lookups_new(Gh.data(), lookups, ln, lv, lv, (const atlas_fr_t*)&gamma_b, (const atlas_fr_t*)r_address.data(), rix, &i_bool);
         atlas_batched_t b = nullptr;
         if (!rc) rc = atlas_batched_new(&b);
         if (!rc) rc = atlas_batched_add_instance(b, i_hb, (const atlas_fr_t*)&zero);
@@ -1517,10 +1529,11 @@ struct Prover : FlowSink {
         return rc;
     }
     int prove_node_flow(const Node& nd) {
-        // (the lookup operators over ONE element are composed — DESIGN 11.8b; a gather of one index and a softmax over one element are not:
-        // their dictionary / per-row machinery was never walked at one cycle, and no model of the reference's zoo has them)
-        if (gr::padded_len(nd.dims) == 1 && (nd.op == ATLAS_OP_GATHER_LARGE || nd.op == ATLAS_OP_GATHER_SMALL || nd.op == ATLAS_OP_SOFTMAX))
-            return fail(ATLAS_EINVAL, "prove_graph: Gather / SoftmaxLastAxis with a ONE-element output is not composed");
+        // (the lookup operators and the gathers over ONE element / ONE index are composed — DESIGN 11.8b, 12.10; a softmax with ONE row or rows of ONE
+        // element is refused when the graph is built (graph_exec.hip): the four batched stages of ops/softmax_last_axis bind (row, position) pairs and
+        // the device instances of softmax.hip were never walked with one of the two variable groups empty; the oracle composes [1, N] and [1, 1])
+        if (nd.op == ATLAS_OP_SOFTMAX && gr::padded_len(nd.dims) == 1)
+            return fail(ATLAS_EINVAL, "prove_graph: SoftmaxLastAxis over ONE element is not composed");
         if (nd.op == ATLAS_OP_DIV) return op_div(nd);                          // ReductionFlow::Custom
         if (nd.op == ATLAS_OP_RSQRT) return op_rsqrt(nd);
         if (nd.op == ATLAS_OP_SIN || nd.op == ATLAS_OP_COS) return op_trig(nd);

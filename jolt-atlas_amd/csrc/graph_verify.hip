@@ -1118,8 +1118,8 @@ struct Verifier {
     }
     int verify_node(const Node& nd, size_t& next_input_from_end) {
         cur = nd.idx;
-        if (gr::padded_len(nd.dims) == 1 && (nd.op == ATLAS_OP_GATHER_LARGE || nd.op == ATLAS_OP_GATHER_SMALL || nd.op == ATLAS_OP_SOFTMAX))
-            return fail(ATLAS_EINVAL, "verify_graph: Gather / SoftmaxLastAxis with a ONE-element output is not composed");
+        if (nd.op == ATLAS_OP_SOFTMAX && gr::padded_len(nd.dims) == 1)
+            return fail(ATLAS_EINVAL, "verify_graph: SoftmaxLastAxis over ONE element is not composed");
         if (nd.op == ATLAS_OP_DIV) return op_div(nd);                          // ReductionFlow::Custom
         if (nd.op == ATLAS_OP_RSQRT) return op_rsqrt(nd);
         if (nd.op == ATLAS_OP_SIN || nd.op == ATLAS_OP_COS) return op_trig(nd);
@@ -1177,7 +1177,7 @@ struct Verifier {
             const Node& nd = kv.second;
             const size_t T = gr::padded_len(nd.dims), log_T = gr::log2u(T);
             if (T == 1 && nd.op != ATLAS_OP_SCALAR_CONST_DIV && nd.op != ATLAS_OP_DIV && nd.op != ATLAS_OP_RELU && nd.op != ATLAS_OP_CLAMP && !atlas_rt_is_activation(nd.op) &&
-                nd.op != ATLAS_OP_RSQRT && nd.op != ATLAS_OP_SIN && nd.op != ATLAS_OP_COS) continue;      // (the lookup operators proper run their generic flows over one cycle)      // one element: ScalarConstDiv keeps its remainder, Div its quotient (ops/div.rs:157-160)
+                nd.op != ATLAS_OP_RSQRT && nd.op != ATLAS_OP_SIN && nd.op != ATLAS_OP_COS && nd.op != ATLAS_OP_GATHER_SMALL && nd.op != ATLAS_OP_GATHER_LARGE) continue;      // (the lookup operators proper and the gathers run their generic flows over one cycle)      // one element: ScalarConstDiv keeps its remainder, Div its quotient (ops/div.rs:157-160)
             auto chunks = [&](uint8_t cp, size_t log_K) { for (size_t i = 0; i < (log_K + 3) / 4; i++) committed[gr::comm(cp, nd.idx, i)].log_T = log_T; };
             auto dense = [&](uint8_t cp) { committed[gr::comm(cp, nd.idx)].log_T = log_T; };
             switch (nd.op) {

@@ -31,5 +31,7 @@ int atlas_rt_identity_range_check_new(const uint64_t* lookup_indices, size_t log
 int atlas_rt_evaluate_with_eq(const atlas_poly_t* polys, size_t count, atlas_poly_t eq_full, atlas_fr_t* out);
 // ReadRafProver over a table of at most 2^12 entries as a host-arithmetic instance (shout.hip): G = the device histogram (downloaded)
 int atlas_rt_shout_read_raf_host_new(atlas_poly_t G, const int32_t* table, size_t log_K, const atlas_fr_t* gamma, atlas_instance_t* out);
+// a BatchedSumcheck member over zero variables: no rounds, the given final claims (elementwise.hip)
+int atlas_rt_const_member_new(const atlas_fr_t* finals, size_t n, size_t degree, atlas_instance_t* out);
 int atlas_rt_ps_shout_relu_new(const uint64_t* lookup_indices, size_t log_T, size_t xlen, const atlas_fr_t* r_node_output, const atlas_fr_t* gamma,
                                atlas_poly_t eq_shared, atlas_instance_t* out);

@@ -510,7 +510,8 @@ class Prover:
         # one element: the is_scalar operators (add, sub, sum, the fused-rescale family, mean_of_squares; Div by its own branch) commit nothing;
         # the lookup operators proper (ReLU, Clamp, the activations, Rsqrt, Sin / Cos) have no such branch in the reference (ops/relu.rs,
         # clamp.rs, tanh.rs, rsqrt.rs, sin.rs ...): their generic flows run over one cycle, with one-hot polynomials of K x 1 coefficients
-        if int(np.prod(nd["dims"])) == 1 and op not in ("ReLU", "Clamp", "Tanh", "Erf", "Sigmoid", "Rsqrt", "Sin", "Cos"):
+        # (nor has GatherLarge: ops/gather/large.rs:106-112 commits its d chunks whatever the shape)
+        if int(np.prod(nd["dims"])) == 1 and op not in ("ReLU", "Clamp", "Tanh", "Erf", "Sigmoid", "Rsqrt", "Sin", "Cos", "GatherLarge"):
             return []
         if op in ("Add", "Sub"):
             return [("ClampRaD", self.wit[i]["acc"].astype(np.int64).view(np.uint64), 64)]
@@ -1094,7 +1095,7 @@ class Prover:
         w = self.wit[i]
         F, N, S = w["F"], w["N"], w["S"]
         lf, ln, LS = ilog2(F), ilog2(N), MODEL_SCALE
-        assert lf >= 1 and ln >= 1
+        assert ln >= 1 or lf == 0         # ONE row and ONE element run the generic flow; several rows of ONE element were never walked
         log_T = lf + ln
         u = lambda a: a.astype(np.uint32).astype(np.uint64)
         phases = LS // 4 if LS % 4 == 0 else LS // 2

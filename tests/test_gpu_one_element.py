@@ -69,7 +69,56 @@ tanh_graph, erf_graph, sigmoid_graph = _act("Tanh", [1100, 2500, 300, 41]), _act
 rsqrt_graph = _act("Rsqrt", [5000, 6000, 7000, 8000])
 sin_graph, cos_graph = _act("Sin", [500000, 600000, 700000, 8000]), _act("Cos", [-5000, -6000, -7000, -8000])
 
-GRAPHS = [scd_graph, scd_negative_graph, div_graph, einsum_scalar_graph, relu_graph, relu_negative_graph, clamp_graph,
+def _gather(op, V, idx, seed=5):
+    """ONE index into a dictionary of V one-element words (ops/gather/{small,large}.rs have no is_scalar branch: the execution sumcheck runs over
+    the log V address variables, the one-hot checks over one cycle)"""
+    def g():
+        rng = np.random.default_rng(seed)
+        return ([{"idx": 0, "op": "Input", "inputs": [], "dims": [1]},
+                 {"idx": 1, "op": "Constant", "inputs": [], "dims": [V, 1], "data": rng.integers(-(1 << 14), 1 << 14, size=V).astype(np.int32)},
+                 {"idx": 2, "op": op, "inputs": [1, 0], "dims": [1, 1], "axis": 0, "dict_len": V},
+                 {"idx": 3, "op": "Broadcast", "inputs": [2], "dims": [1, 2]},
+                 {"idx": 4, "op": "Constant", "inputs": [], "dims": [1, 2], "data": np.array([1, 2], dtype=np.int32)},
+                 {"idx": 5, "op": "Add", "inputs": [3, 4], "dims": [1, 2]}], [5], [np.array([idx], dtype=np.int32)])
+    g.__name__ = "%s_%d_of_%d_graph" % (op.lower(), idx, V)
+    return g
+
+
+def _gather_row(op, V, word, idx, seed=11):
+    """ONE index, a word of several elements (a single token's embedding row): no cycle variables, log word output variables"""
+    def g():
+        rng = np.random.default_rng(seed)
+        return ([{"idx": 0, "op": "Input", "inputs": [], "dims": [1]},
+                 {"idx": 1, "op": "Constant", "inputs": [], "dims": [V, word], "data": rng.integers(-(1 << 14), 1 << 14, size=V * word).astype(np.int32)},
+                 {"idx": 2, "op": op, "inputs": [1, 0], "dims": [1, word], "axis": 0, "dict_len": V},
+                 {"idx": 3, "op": "Constant", "inputs": [], "dims": [1, word], "data": rng.integers(-9, 9, size=word).astype(np.int32)},
+                 {"idx": 4, "op": "Add", "inputs": [2, 3], "dims": [1, word]}], [4], [np.array([idx], dtype=np.int32)])
+    g.__name__ = "%s_row_%d_of_%dx%d_graph" % (op.lower(), idx, V, word)
+    return g
+
+
+GATHERS = [_gather_row("GatherSmall", 16, 4, 9), _gather_row("GatherLarge", 64, 8, 63),
+           _gather("GatherSmall", 4, 2), _gather("GatherSmall", 16, 0, 6), _gather("GatherSmall", 16, 15, 7),
+           _gather("GatherLarge", 64, 37), _gather("GatherLarge", 256, 255, 8), _gather("GatherLarge", 64, 0, 9)]
+
+def _softmax(dims, seed=3):
+    """SoftmaxLastAxis over ONE row (no leading variables) and over ONE element (no variables at all): ops/softmax_last_axis has no is_scalar branch"""
+    def g():
+        n = int(np.prod(dims))
+        nodes = [{"idx": 0, "op": "Input", "inputs": [], "dims": list(dims)},
+                 {"idx": 1, "op": "SoftmaxLastAxis", "inputs": [0], "dims": list(dims), "scale": 14}]
+        if n == 1:
+            nodes += [{"idx": 2, "op": "Broadcast", "inputs": [1], "dims": [1, 2]},
+                      {"idx": 3, "op": "Constant", "inputs": [], "dims": [1, 2], "data": np.array([1, 2], dtype=np.int32)},
+                      {"idx": 4, "op": "Add", "inputs": [2, 3], "dims": [1, 2]}]
+        return nodes, [nodes[-1]["idx"]], [np.random.default_rng(seed).integers(-(1 << 15), 1 << 15, size=n).astype(np.int32)]
+    g.__name__ = "softmax_%s_graph" % "x".join(str(d) for d in dims)
+    return g
+
+
+SOFTMAXES = [_softmax([1, 8]), _softmax([1, 1, 16], 4), _softmax([1, 1]), _softmax([1, 1], 5)]
+
+GRAPHS = GATHERS + [scd_graph, scd_negative_graph, div_graph, einsum_scalar_graph, relu_graph, relu_negative_graph, clamp_graph,
           tanh_graph, erf_graph, sigmoid_graph, rsqrt_graph, sin_graph, cos_graph]
 
 
@@ -177,3 +226,20 @@ def test_random_one_element_chain(atlas, seed):
             V.free()
     finally:
         G.free(); srs.free()
+
+
+@pytest.mark.parametrize("builder", SOFTMAXES, ids=[b.__name__ for b in SOFTMAXES])
+def test_softmax_of_one_row_is_refused_by_name(atlas, builder):
+    """the last refusal: the device's softmax instances need two rows of two elements (the oracle composes ONE row and ONE element — its proof is
+    what a device path would have to reproduce); the refusal names the operator when the graph is traced, nothing is proved"""
+    from oracle import graph as OG, orc
+    from jolt_atlas_amd import graph as GG
+    nodes, outputs, inputs = builder()
+    srs_h = orc.srs_powers(orc.random_fr(1, 0x51250001)[0], 1 << 8)
+    assert len(OG.Prover(nodes, outputs, srs_h).prove(inputs)) > 0
+    with pytest.raises(atlas.AtlasError, match="SoftmaxLastAxis"):
+        G = GG.Graph(nodes, outputs)
+        try:
+            G.trace(inputs)
+        finally:
+            G.free()
