@@ -472,7 +472,7 @@ int atlas_rt_validate_node(const atlas_graph& G, const Node& nd) {
             if (!need_inputs(1) || !same_len() || nd.p[0] != (int64_t)gr::MODEL_SCALE)
                 return bad("graph: SoftmaxLastAxis needs one operand of the output's shape and scale = MODEL_SCALE (14): its clamp table is compiled for it");
             const size_t N = nd.dims.back(), F = T / N;
-            return F >= 2 && N >= 2 && N <= 65536 ? ATLAS_OK : bad("graph: SoftmaxLastAxis needs at least two rows and 2 <= last axis <= 65536");
+            return F >= 1 && N >= 2 && N <= 65536 ? ATLAS_OK : bad("graph: SoftmaxLastAxis needs 2 <= last axis <= 65536");
         }
         default: return bad("graph: operator not supported");
     }
@@ -710,7 +710,7 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
             if (!need_inputs(1) || !same_len() || nd.p[0] != (int64_t)gr::MODEL_SCALE)
                 return fail(ATLAS_EINVAL, "graph: SoftmaxLastAxis needs one operand of the output's shape and scale = MODEL_SCALE (14): its clamp table is compiled for it");
             const size_t N = nd.dims.back(), F = T / N;
-            if (F < 2 || N < 2 || N > 65536) return fail(ATLAS_EINVAL, "graph: SoftmaxLastAxis needs at least two rows and 2 <= last axis <= 65536");
+            if (F < 1 || N < 2 || N > 65536) return fail(ATLAS_EINVAL, "graph: SoftmaxLastAxis needs 2 <= last axis <= 65536");
             const ExpLut* L = nullptr;
             if (int rc = atlas_rt_exp_lut(&L)) return rc;
             NodeWitness& W = G.wit[nd.idx];

@@ -1529,9 +1529,9 @@ struct Prover : FlowSink {
         return rc;
     }
     int prove_node_flow(const Node& nd) {
-        // (the lookup operators and the gathers over ONE element / ONE index are composed — DESIGN 11.8b, 12.10; a softmax with ONE row or rows of ONE
-        // element is refused when the graph is built (graph_exec.hip): the four batched stages of ops/softmax_last_axis bind (row, position) pairs and
-        // the device instances of softmax.hip were never walked with one of the two variable groups empty; the oracle composes [1, N] and [1, 1])
+        // (the lookup operators, the gathers over ONE element / ONE index and a softmax of ONE row are composed — DESIGN 11.8b, 12.10; rows of ONE
+        // element are refused when the graph is built (graph_exec.hip: 2 <= last axis): the four batched stages of ops/softmax_last_axis bind
+        // (position, row) pairs and the instances of softmax.hip were never walked without position variables; the oracle composes [1, 1])
         if (nd.op == ATLAS_OP_SOFTMAX && gr::padded_len(nd.dims) == 1)
             return fail(ATLAS_EINVAL, "prove_graph: SoftmaxLastAxis over ONE element is not composed");
         if (nd.op == ATLAS_OP_DIV) return op_div(nd);                          // ReductionFlow::Custom

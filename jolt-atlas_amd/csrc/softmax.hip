@@ -209,7 +209,7 @@ struct Softmax : atlas_instance {
     std::vector<H::Fr> mailed_finals;
     size_t T0() const { return (size_t)1 << (log_K + log_N); }
     static bool pipe_off() { static const bool v = getenv("ATLAS_SM_NO_PIPELINE") != nullptr; return v; }      // A-B
-    bool pipelined() const override { return !pipe_off() && log_K + log_N >= 1; }
+    bool pipelined() const override { return !pipe_off() && log_K >= 1; }      // (ONE row: no phase 2, inv_sum is never bound — stepped by the host)
     int n_sums(size_t round) const {
         if (kind == SM_SUM_AXIS || kind == SM_EXP_SUM) return 1;
         if (kind == SM_MAX_INDICATOR) return round < log_N ? 3 : 2;
@@ -324,8 +324,8 @@ int atlas_softmax_instance_new(int kind, atlas_poly_t a, atlas_poly_t b, size_t 
     NEED_INIT();
     if (!a || !out) return fail(ATLAS_EINVAL, "softmax_instance_new: null argument");
     if (kind < SM_EXP_SUM || kind > SM_SUM_AXIS) return fail(ATLAS_EINVAL, "softmax_instance_new: unknown kind");
-    if (kind == SM_SUM_AXIS ? (log_K != 0 || b || log_N == 0) : (!r || log_N == 0 || log_K == 0))
-        return fail(ATLAS_EINVAL, "softmax_instance_new: SumAxis takes one operand of 2^log_N (log_K = 0); the softmax provers need log_K, log_N >= 1 and r");
+    if (kind == SM_SUM_AXIS ? (log_K != 0 || b || log_N == 0) : ((!r && (log_K || kind == SM_RECIP_MULT)) || log_N == 0))
+        return fail(ATLAS_EINVAL, "softmax_instance_new: SumAxis takes one operand of 2^log_N (log_K = 0); the softmax provers need log_N >= 1 and r (ONE row, log_K = 0: r_k is the empty point)");
     if (log_K + log_N > 25) return fail(ATLAS_EINVAL, "softmax_instance_new: more than 25 variables");
     const size_t T = (size_t)1 << (log_K + log_N), K = (size_t)1 << log_K;
     if (a->len != T) return fail(ATLAS_EINVAL, "softmax_instance_new: operand length != 2^(log_K + log_N)");
@@ -344,7 +344,7 @@ int atlas_softmax_instance_new(int kind, atlas_poly_t a, atlas_poly_t b, size_t 
         if (e == hipSuccess) e = hipMemcpyAsync(P->d_eq_k, ek.data(), K * sizeof(Fr), hipMemcpyHostToDevice, g.stream);
         if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
         if (e != hipSuccess) rc = fail(ATLAS_ENOMEM, "softmax_instance_new: eq table", e);
-        if (!rc) rc = P->gs.init(reinterpret_cast<const H::Fr*>(r), log_K);     // used from round log_N on
+        if (!rc && log_K) rc = P->gs.init(reinterpret_cast<const H::Fr*>(r), log_K);     // used from round log_N on (ONE row: never)
     }
     if (!rc && kind == SM_RECIP_MULT) rc = P->gs.init(reinterpret_cast<const H::Fr*>(r), log_K + log_N);
     if (!rc) { hipError_t e = hipStreamSynchronize(g.stream); if (e != hipSuccess) rc = fail(ATLAS_ENODEV, "softmax_instance_new", e); }

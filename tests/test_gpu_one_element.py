@@ -116,9 +116,10 @@ def _softmax(dims, seed=3):
     return g
 
 
-SOFTMAXES = [_softmax([1, 8]), _softmax([1, 1, 16], 4), _softmax([1, 1]), _softmax([1, 1], 5)]
+SOFTMAX_ROWS = [_softmax([1, 8]), _softmax([1, 1, 16], 4), _softmax([1, 2], 6), _softmax([1, 4], 7)]
+SOFTMAXES = [_softmax([1, 1]), _softmax([1, 1], 5)]
 
-GRAPHS = GATHERS + [scd_graph, scd_negative_graph, div_graph, einsum_scalar_graph, relu_graph, relu_negative_graph, clamp_graph,
+GRAPHS = GATHERS + SOFTMAX_ROWS + [scd_graph, scd_negative_graph, div_graph, einsum_scalar_graph, relu_graph, relu_negative_graph, clamp_graph,
           tanh_graph, erf_graph, sigmoid_graph, rsqrt_graph, sin_graph, cos_graph]
 
 
@@ -229,9 +230,9 @@ def test_random_one_element_chain(atlas, seed):
 
 
 @pytest.mark.parametrize("builder", SOFTMAXES, ids=[b.__name__ for b in SOFTMAXES])
-def test_softmax_of_one_row_is_refused_by_name(atlas, builder):
-    """the last refusal: the device's softmax instances need two rows of two elements (the oracle composes ONE row and ONE element — its proof is
-    what a device path would have to reproduce); the refusal names the operator when the graph is traced, nothing is proved"""
+def test_softmax_over_one_element_is_refused_by_name(atlas, builder):
+    """the last refusal: the device's softmax instances need rows of two elements (ONE row is composed — SOFTMAX_ROWS; the oracle composes ONE
+    element too: its proof is what a device path would have to reproduce); the refusal names the operator when the graph is built, nothing is proved"""
     from oracle import graph as OG, orc
     from jolt_atlas_amd import graph as GG
     nodes, outputs, inputs = builder()
