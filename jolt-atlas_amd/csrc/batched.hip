@@ -473,9 +473,11 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
     double tt[6] = {0, 0, 0, 0, 0, 0};                   // ATLAS_TRACE: message serial / parallel, combine + transcript, claim update, ingest serial / parallel
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    std::vector<std::vector<H::Fr>> ht_polys(HT ? n : 0);       // the members' round polynomials: allocated once, refilled every round (thousands of members:
+    std::vector<std::vector<H::Fr>> ht_partial(HT ? HT->threads() : 0);   // a vector each per round was ~0.4 M allocations per GPT-2-shaped reduction)
     for (size_t round = 0; round < max_rounds && HT; round++) {
         const size_t remaining = max_rounds - round;
-        std::vector<std::vector<H::Fr>> polys(n);
+        std::vector<std::vector<H::Fr>>& polys = ht_polys;
         std::vector<int> rcs(HT->threads(), ATLAS_OK);
         const auto q0 = tnow();
         // compute_message: the constant members and the serial ones here; for the parallel ones first everything they share (a pool's launches
@@ -502,19 +504,25 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         HT->parallel_for(n, [&](size_t lo, size_t hi, size_t part) {
             for (size_t i = lo; i < hi && rcs[part] == ATLAS_OK; i++) {
                 Instance& I = b->inst[i];
-                if (remaining > I.rounds) polys[i] = {mul_pow2(I.input_claim, remaining - I.rounds - 1)};
+                if (remaining > I.rounds) polys[i].assign(1, mul_pow2(I.input_claim, remaining - I.rounds - 1));
                 else if (par[i]) rcs[part] = I.inst->message(round - (max_rounds - I.rounds), claim[i], polys[i]);
             }
         });
         for (int rc : rcs) if (rc) return fail(rc, "batched_prove: a member's compute_message failed on a worker thread");
         const auto q2 = tnow();
         // batched = sum coeff_i * poly_i (from_coeff trimming per term, the sum keeps the longest length): partial sums per thread
-        std::vector<std::vector<H::Fr>> partial(HT->threads());
+        std::vector<std::vector<H::Fr>>& partial = ht_partial;
+        for (auto& acc : partial) acc.clear();
         HT->parallel_for(n, [&](size_t lo, size_t hi, size_t part) {
             std::vector<H::Fr>& acc = partial[part];
-            for (size_t i = lo; i < hi; i++) {
-                const std::vector<H::Fr> t = trimmed_scale(polys[i], coeff[i]);
-                for (size_t k = 0; k < t.size(); k++) {
+            H::Fr t[32];
+            for (size_t i = lo; i < hi; i++) {                    // += trimmed_scale(polys[i], coeff[i]), without the temporary
+                const std::vector<H::Fr>& p = polys[i];
+                if (p.size() > 32) { const std::vector<H::Fr> tv = trimmed_scale(p, coeff[i]); for (size_t k = 0; k < tv.size(); k++) { if (k < acc.size()) acc[k] = H::add(acc[k], tv[k]); else acc.push_back(tv[k]); } continue; }
+                size_t len = 0;
+                for (size_t k = 0; k < p.size(); k++) { t[k] = H::mul(p[k], coeff[i]); if (!(t[k] == H::zero())) len = k + 1; }
+                if (len == 0) { t[0] = H::zero(); len = 1; }
+                for (size_t k = 0; k < len; k++) {
                     if (k < acc.size()) acc[k] = H::add(acc[k], t[k]);
                     else acc.push_back(t[k]);
                 }

@@ -237,6 +237,14 @@ def node_relu():
     return [{"idx": 0, "op": "Input", "inputs": [], "dims": [16, 4096]}, {"idx": 1, "op": "ReLU", "inputs": [0], "dims": [16, 4096]}], [1], [_rnd(rng, 1 << 16)]
 
 
+def node_add():
+    rng = _node_rng()
+    c = _rnd(rng, 1 << 16)
+    return [{"idx": 0, "op": "Input", "inputs": [], "dims": [16, 4096]},
+            {"idx": 1, "op": "Constant", "inputs": [], "dims": [16, 4096], "data": c},
+            {"idx": 2, "op": "Add", "inputs": [0, 1], "dims": [16, 4096]}], [2], [_rnd(rng, 1 << 16)]
+
+
 def node_mul():
     rng = _node_rng()
     c = _rnd(rng, 1 << 16)
