@@ -49,6 +49,14 @@ typedef struct { uint8_t state[32]; uint32_t n_rounds; uint32_t pad_[3]; } atlas
 /* ---- runtime ------------------------------------------------------------------ */
 int  atlas_init(int device_ordinal);            /* hipSetDevice + stream; idempotent */
 int  atlas_shutdown(void);
+/* One process, N devices: the reference is one Rust process (jolt-atlas-core/src/onnx_proof/mod.rs:153-156), so a drop-in `prove` over the
+ * GPUs of a node is N threads of it.  atlas_init_thread gives the CALLING THREAD a runtime of its own on `device_ordinal` (stream set, round
+ * channel, device allocator, MSM workspace); every later call of that thread uses it, threads that never call it share the process runtime
+ * of atlas_init.  Handles (polynomials, SRS, graphs) are plain device memory and may be created under one runtime and read under another on
+ * the same device; an object is proved with by ONE thread at a time.  With atlas_prove_graph_sharded: thread r calls atlas_init_thread(r),
+ * builds its graph + SRS handles and joins the shard group as rank r (tests/test_gpu_sharded.py::test_sharded_prove_graph_one_process). */
+int  atlas_init_thread(int device_ordinal);
+int  atlas_shutdown_thread(void);
 const char *atlas_last_error(void);
 int  atlas_device_count(void);
 int  atlas_sync(void);                           /* drain the library stream */

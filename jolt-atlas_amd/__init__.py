@@ -83,6 +83,15 @@ def init(device=0):
     _check(lib.atlas_init(C.c_int(device)))
 
 
+def init_thread(device=0):
+    """one process, N devices: give the CALLING THREAD a runtime of its own on `device` (include/atlas_hip.h: atlas_init_thread)"""
+    _check(lib.atlas_init_thread(C.c_int(device)))
+
+
+def shutdown_thread():
+    _check(lib.atlas_shutdown_thread())
+
+
 def device_count():
     return lib.atlas_device_count()
 

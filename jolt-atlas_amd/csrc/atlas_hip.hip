@@ -28,7 +28,8 @@ namespace H = atlas_host;
 
 // ------------------------------------------------------------------ runtime state
 namespace atlas_rt {
-Runtime g;
+Runtime g_default;
+thread_local Runtime* g_cur = nullptr;
 thread_local hipStream_t tl_lane_stream = nullptr;
 thread_local std::string t_err;       // atlas_last_error is per calling thread (commit is called from Rayon workers)
 int fail(int code, const char* what, hipError_t e) {
@@ -38,7 +39,7 @@ int fail(int code, const char* what, hipError_t e) {
 }
 }  // namespace atlas_rt
 using atlas_rt::fail;
-using atlas_rt::g;
+using atlas_rt::rt;
 using atlas_rt::MAX_ROUNDS;
 using atlas_rt::PINNED_BYTES;
 
@@ -61,14 +62,14 @@ struct Timer {
     std::vector<int> kind;          // 0 = data pass, 1 = fs/tail
     std::vector<uint64_t> bytes;
     void begin(int k, uint64_t b) {
-        if (!g.timing) return;
+        if (!rt().timing) return;
         hipEvent_t a, c; hipEventCreate(&a); hipEventCreate(&c);
-        hipEventRecord(a, g.stream); ev.push_back(a); ev.push_back(c); kind.push_back(k); bytes.push_back(b);
+        hipEventRecord(a, rt().stream); ev.push_back(a); ev.push_back(c); kind.push_back(k); bytes.push_back(b);
     }
-    void end() { if (g.timing) hipEventRecord(ev.back(), g.stream); }
+    void end() { if (rt().timing) hipEventRecord(ev.back(), rt().stream); }
     void collect() {
         atlas_timing_t t{};
-        if (g.timing && !ev.empty()) {
+        if (rt().timing && !ev.empty()) {
             hipEventSynchronize(ev.back());
             float ms = 0;
             for (size_t i = 0; i < kind.size(); i++) {
@@ -80,7 +81,7 @@ struct Timer {
             t.total_ms = ms;
             for (auto e : ev) hipEventDestroy(e);
         }
-        g.last_timing = t;
+        rt().last_timing = t;
         ev.clear(); kind.clear(); bytes.clear();
     }
 };
@@ -110,81 +111,100 @@ int atlas_device_count(void) {
 }
 
 int atlas_init(int device_ordinal) {
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
-    if (g.ready && g.device == device_ordinal) return ATLAS_OK;
-    if (g.ready) return fail(ATLAS_ESTATE, "atlas_init: already initialised on another device (atlas_shutdown first)");
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+    if (rt().ready && rt().device == device_ordinal) return ATLAS_OK;
+    if (rt().ready) return fail(ATLAS_ESTATE, "atlas_init: already initialised on another device (atlas_shutdown first)");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0) return fail(ATLAS_ENODEV, "no HIP device available", e);
     if (device_ordinal < 0 || device_ordinal >= n) return fail(ATLAS_EINVAL, "device ordinal out of range");
     HIP_TRY(hipSetDevice(device_ordinal));
-    if (!g.stream) HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-    g.lib_stream = g.stream;
-    HIP_TRY(hipMalloc(&g.d_partials, sizeof(Fr) * SC_MAX_BLOCKS * 3));
-    HIP_TRY(hipMalloc(&g.d_ctx, sizeof(ScCtx)));
-    HIP_TRY(hipMalloc(&g.d_proof, sizeof(Fr) * MAX_ROUNDS * 3));
-    HIP_TRY(hipMalloc(&g.d_chal, sizeof(uint64_t) * MAX_ROUNDS * 2));
-    HIP_TRY(hipMalloc(&g.d_finals, sizeof(Fr) * 8));
-    HIP_TRY(hipHostMalloc(&g.h_pinned, PINNED_BYTES, hipHostMallocDefault));
-    HIP_TRY(g.chan.init());
+    if (!rt().stream) HIP_TRY(hipStreamCreateWithFlags(&rt().stream, hipStreamNonBlocking));
+    rt().lib_stream = rt().stream;
+    HIP_TRY(hipMalloc(&rt().d_partials, sizeof(Fr) * SC_MAX_BLOCKS * 3));
+    HIP_TRY(hipMalloc(&rt().d_ctx, sizeof(ScCtx)));
+    HIP_TRY(hipMalloc(&rt().d_proof, sizeof(Fr) * MAX_ROUNDS * 3));
+    HIP_TRY(hipMalloc(&rt().d_chal, sizeof(uint64_t) * MAX_ROUNDS * 2));
+    HIP_TRY(hipMalloc(&rt().d_finals, sizeof(Fr) * 8));
+    HIP_TRY(hipHostMalloc(&rt().h_pinned, PINNED_BYTES, hipHostMallocDefault));
+    HIP_TRY(rt().chan.init());
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dot_tail_ch<2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (sizeof(Fr) << SC_TAIL_CH_LOG)));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dot_tail2_f9),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (sizeof(Fr) << SC_TAIL_CH_LOG)));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dot_tail_ch<3>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (sizeof(Fr) << SC_TAIL_LOG)));
-    if (const char* e = getenv("ATLAS_FS")) g.fs_mode = std::strcmp(e, "device") == 0 ? ATLAS_FS_DEVICE : ATLAS_FS_HOST;
+    if (const char* e = getenv("ATLAS_FS")) rt().fs_mode = std::strcmp(e, "device") == 0 ? ATLAS_FS_DEVICE : ATLAS_FS_HOST;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dot_tail<2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (sizeof(Fr) << SC_TAIL_LOG)));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dot_tail<3>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (sizeof(Fr) << SC_TAIL_LOG)));
-    g.device = device_ordinal;
-    g.ready = true;
+    rt().device = device_ordinal;
+    rt().ready = true;
     return ATLAS_OK;
 }
 
 int atlas_shutdown(void) {
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
-    if (!g.ready) return ATLAS_OK;
-    hipStreamSynchronize(g.stream);
-    for (auto f : g.at_shutdown) f();
-    g.at_shutdown.clear();
-    hipFree(g.d_partials); hipFree(g.d_ctx); hipFree(g.d_proof); hipFree(g.d_chal); hipFree(g.d_finals);
-    hipHostFree(g.h_pinned);
-    g.chan.release();
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+    if (!rt().ready) return ATLAS_OK;
+    hipStreamSynchronize(rt().stream);
+    for (auto f : rt().at_shutdown) f();
+    rt().at_shutdown.clear();
+    hipFree(rt().d_partials); hipFree(rt().d_ctx); hipFree(rt().d_proof); hipFree(rt().d_chal); hipFree(rt().d_finals);
+    hipHostFree(rt().h_pinned);
+    rt().chan.release();
     atlas_rt::dev_pool().release();
-    hipStreamDestroy(g.stream);
-    g.ready = false; g.stream = nullptr; g.lib_stream = nullptr; g.d_partials = nullptr; g.d_ctx = nullptr; g.d_proof = nullptr;
-    g.d_chal = nullptr; g.d_finals = nullptr; g.h_pinned = nullptr;
+    hipStreamDestroy(rt().stream);
+    rt().ready = false; rt().stream = nullptr; rt().lib_stream = nullptr; rt().d_partials = nullptr; rt().d_ctx = nullptr; rt().d_proof = nullptr;
+    rt().d_chal = nullptr; rt().d_finals = nullptr; rt().h_pinned = nullptr;
     return ATLAS_OK;
+}
+
+// One process, N devices (include/atlas_hip.h): the calling thread gets a runtime of its own on `device_ordinal` — stream, round channel,
+// allocator, MSM workspace — and every later call of THIS thread uses it; other threads keep the process runtime (atlas_init) or their own.
+// A thread that already has one on another device must atlas_shutdown_thread first.
+int atlas_init_thread(int device_ordinal) {
+    if (atlas_rt::g_cur && atlas_rt::g_cur->ready) return atlas_init(device_ordinal);      // same device: no-op; another: ATLAS_ESTATE
+    if (!atlas_rt::g_cur) atlas_rt::g_cur = new atlas_rt::Runtime();
+    const int rc = atlas_init(device_ordinal);
+    if (rc) { delete atlas_rt::g_cur; atlas_rt::g_cur = nullptr; }
+    return rc;
+}
+int atlas_shutdown_thread(void) {
+    if (!atlas_rt::g_cur) return ATLAS_OK;
+    const int rc = atlas_shutdown();
+    delete atlas_rt::g_cur->pool;
+    delete atlas_rt::g_cur;
+    atlas_rt::g_cur = nullptr;
+    return rc;
 }
 
 const char* atlas_last_error(void) { return atlas_rt::t_err.c_str(); }
 
 int atlas_sync(void) {
     NEED_INIT();
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     return ATLAS_OK;
 }
 
 int atlas_set_challenge_mode(int mode) {
     if (mode != 0 && mode != 1) return fail(ATLAS_EINVAL, "challenge mode must be 0 or 1");
-    g.challenge_mode = mode;
+    rt().challenge_mode = mode;
     return ATLAS_OK;
 }
-int atlas_get_challenge_mode(void) { return g.challenge_mode; }
+int atlas_get_challenge_mode(void) { return rt().challenge_mode; }
 
 int atlas_set_fs_mode(int mode) {
     if (mode != ATLAS_FS_HOST && mode != ATLAS_FS_DEVICE) return fail(ATLAS_EINVAL, "fs mode must be ATLAS_FS_HOST or ATLAS_FS_DEVICE");
-    g.fs_mode = mode;
+    rt().fs_mode = mode;
     return ATLAS_OK;
 }
-int atlas_get_fs_mode(void) { return g.fs_mode; }
+int atlas_get_fs_mode(void) { return rt().fs_mode; }
 
-int atlas_set_timing(int enabled) { g.timing = enabled != 0; return ATLAS_OK; }
+int atlas_set_timing(int enabled) { rt().timing = enabled != 0; return ATLAS_OK; }
 int atlas_last_timing(atlas_timing_t* out) {
     if (!out) return fail(ATLAS_EINVAL, "null out");
-    *out = g.last_timing;
+    *out = rt().last_timing;
     return ATLAS_OK;
 }
 
@@ -236,7 +256,7 @@ int atlas_transcript_challenge_scalar(atlas_transcript_t* t, atlas_fr_t* out) {
 }
 int atlas_challenge_to_fr(const atlas_u128_t* c, atlas_fr_t* out) {
     if (!c || !out) return fail(ATLAS_EINVAL, "challenge_to_fr");
-    H::Fr f = H::challenge_to_fr(c->lo, c->hi, g.challenge_mode);
+    H::Fr f = H::challenge_to_fr(c->lo, c->hi, rt().challenge_mode);
     std::memcpy(out, &f, 32);
     return ATLAS_OK;
 }
@@ -254,22 +274,22 @@ static int poly_alloc(size_t bytes, bool is_i32, size_t len, atlas_poly_t* out) 
 int atlas_poly_upload_fr(const atlas_fr_t* host, size_t len, atlas_poly_t* out) {
     NEED_INIT();
     if (!host || !out || !is_pow2(len)) return fail(ATLAS_EINVAL, "poly_upload_fr: len must be a power of two");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);                    // g.stream is read: not while another thread's pipeline has it on a lane
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);                    // rt().stream is read: not while another thread's pipeline has it on a lane
     int rc = poly_alloc(len * sizeof(Fr), false, len, out);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync((*out)->d, host, len * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync((*out)->d, host, len * sizeof(Fr), hipMemcpyHostToDevice, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     return ATLAS_OK;
 }
 
 int atlas_poly_upload_i32(const int32_t* host, size_t len, atlas_poly_t* out) {
     NEED_INIT();
     if (!host || !out || !is_pow2(len)) return fail(ATLAS_EINVAL, "poly_upload_i32: len must be a power of two");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     int rc = poly_alloc(len * sizeof(int32_t), true, len, out);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync((*out)->d, host, len * sizeof(int32_t), hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync((*out)->d, host, len * sizeof(int32_t), hipMemcpyHostToDevice, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     return ATLAS_OK;
 }
 
@@ -308,19 +328,19 @@ __global__ __launch_bounds__(SC_THREADS) void k_i32_to_fr(const int32_t* in, Fr*
 int atlas_poly_download(atlas_poly_t p, atlas_fr_t* host, size_t cap) {
     NEED_INIT();
     if (!p || !host || cap < p->len) return fail(ATLAS_EINVAL, "poly_download: buffer too small");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     if (p->is_i32) {
         Fr* tmp = nullptr;
         HIP_TRY(hipMalloc(&tmp, p->len * sizeof(Fr)));
-        k_i32_to_fr<<<grid_for(p->len), SC_THREADS, 0, g.stream>>>((const int32_t*)p->d, tmp, p->len, make_consts());
-        hipError_t e = hipMemcpyAsync(host, tmp, p->len * sizeof(Fr), hipMemcpyDeviceToHost, g.stream);
-        hipStreamSynchronize(g.stream);
+        k_i32_to_fr<<<grid_for(p->len), SC_THREADS, 0, rt().stream>>>((const int32_t*)p->d, tmp, p->len, make_consts());
+        hipError_t e = hipMemcpyAsync(host, tmp, p->len * sizeof(Fr), hipMemcpyDeviceToHost, rt().stream);
+        hipStreamSynchronize(rt().stream);
         hipFree(tmp);
         if (e != hipSuccess) return fail(ATLAS_ENODEV, "poly_download", e);
         return ATLAS_OK;
     }
-    HIP_TRY(hipMemcpyAsync(host, p->d, p->len * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(host, p->d, p->len * sizeof(Fr), hipMemcpyDeviceToHost, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     return ATLAS_OK;
 }
 
@@ -331,8 +351,8 @@ int atlas_poly_clone(atlas_poly_t p, atlas_poly_t* out) {
     size_t bytes = p->len * (p->is_i32 ? sizeof(int32_t) : sizeof(Fr));
     int rc = poly_alloc(bytes, p->is_i32, p->len, out);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync((*out)->d, p->d, bytes, hipMemcpyDeviceToDevice, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync((*out)->d, p->d, bytes, hipMemcpyDeviceToDevice, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     return ATLAS_OK;
 }
 
@@ -374,8 +394,8 @@ static Fr host_to_dev(const H::Fr& f) { Fr o; std::memcpy(o.v, f.l, 32); return 
 static int poly_bind_async(atlas_poly* p, const atlas_u128_t* rc128, int order) {
     if (p->len < 2) return fail(ATLAS_ESTATE, "bind: polynomial is fully bound");
     const size_t half = p->len / 2;
-    H::Fr rh = H::challenge_to_fr(rc128->lo, rc128->hi, g.challenge_mode);
-    const int hi_only = g.challenge_mode == 0;
+    H::Fr rh = H::challenge_to_fr(rc128->lo, rc128->hi, rt().challenge_mode);
+    const int hi_only = rt().challenge_mode == 0;
     if (p->is_i32) {
         static const uint64_t two64[4] = {0, 1, 0, 0};
         static const H::Fr k64 = H::from_canonical(two64);
@@ -383,20 +403,20 @@ static int poly_bind_async(atlas_poly* p, const atlas_u128_t* rc128, int order) 
         Fr* out = nullptr;
         hipError_t e = hipMalloc(&out, half * sizeof(Fr));
         if (e != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(bind_i32)", e);
-        k_bind_i32<<<grid_for(half), SC_THREADS, 0, g.stream>>>((const int32_t*)p->d, out, half, order,
+        k_bind_i32<<<grid_for(half), SC_THREADS, 0, rt().stream>>>((const int32_t*)p->d, out, half, order,
                                                                host_to_dev(rs), make_consts());
-        if (p->owned) { hipStreamSynchronize(g.stream); hipFree(p->d); }
+        if (p->owned) { hipStreamSynchronize(rt().stream); hipFree(p->d); }
         p->d = out; p->is_i32 = false; p->owned = true; p->cap_bytes = half * sizeof(Fr);
     } else if (order == ATLAS_HIGH_TO_LOW) {
-        k_bind_hi_val<<<grid_for(half), SC_THREADS, 0, g.stream>>>((Fr*)p->d, half, host_to_dev(rh), hi_only);
+        k_bind_hi_val<<<grid_for(half), SC_THREADS, 0, rt().stream>>>((Fr*)p->d, half, host_to_dev(rh), hi_only);
     } else {
         Fr* out = nullptr;
         hipError_t e = hipMalloc(&out, half * sizeof(Fr));
         if (e != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(bind_lo)", e);
-        k_bind_lo_val<<<grid_for(half), SC_THREADS, 0, g.stream>>>((const Fr*)p->d, out, half, host_to_dev(rh), hi_only);
+        k_bind_lo_val<<<grid_for(half), SC_THREADS, 0, rt().stream>>>((const Fr*)p->d, out, half, host_to_dev(rh), hi_only);
         // keep the caller's buffer: copy back in place (stream-ordered), drop the scratch
-        hipMemcpyAsync(p->d, out, half * sizeof(Fr), hipMemcpyDeviceToDevice, g.stream);
-        hipStreamSynchronize(g.stream);
+        hipMemcpyAsync(p->d, out, half * sizeof(Fr), hipMemcpyDeviceToDevice, rt().stream);
+        hipStreamSynchronize(rt().stream);
         hipFree(out);
     }
     p->len = half;
@@ -408,10 +428,10 @@ static int poly_bind_async(atlas_poly* p, const atlas_u128_t* rc128, int order) 
 int atlas_poly_bind(atlas_poly_t p, const atlas_u128_t* r, int order) {
     NEED_INIT();
     if (!p || !r || (order != ATLAS_HIGH_TO_LOW && order != ATLAS_LOW_TO_HIGH)) return fail(ATLAS_EINVAL, "poly_bind");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     int rc = poly_bind_async(p, r, order);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     return ATLAS_OK;
 }
 
@@ -498,11 +518,11 @@ template <int DEG>
 static void launch_eval(const atlas_dot_prover* P, const EqView& eq, size_t half, int grid) {
     const ScConsts K = make_consts();
     if (P->left->is_i32)
-        k_dot_eval<DEG, int32_t, DevIo><<<grid, SC_THREADS, 0, g.stream>>>((const int32_t*)P->left->d, (const int32_t*)P->right->d,
-                                                                        eq, half, DevIo{g.d_ctx, g.d_partials}, K);
+        k_dot_eval<DEG, int32_t, DevIo><<<grid, SC_THREADS, 0, rt().stream>>>((const int32_t*)P->left->d, (const int32_t*)P->right->d,
+                                                                        eq, half, DevIo{rt().d_ctx, rt().d_partials}, K);
     else
-        k_dot_eval<DEG, Fr, DevIo><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, eq, half,
-                                                                   DevIo{g.d_ctx, g.d_partials}, K);
+        k_dot_eval<DEG, Fr, DevIo><<<grid, SC_THREADS, 0, rt().stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, eq, half,
+                                                                   DevIo{rt().d_ctx, rt().d_partials}, K);
 }
 
 extern "C" {
@@ -511,7 +531,7 @@ int atlas_dot_compute_message(atlas_dot_prover_t P, size_t round, const atlas_fr
                               atlas_fr_t* coeffs_out, size_t* n_coeffs) {
     NEED_INIT();
     if (!P || !previous_claim || !coeffs_out || !n_coeffs) return fail(ATLAS_EINVAL, "compute_message");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     if (P->consumed) return fail(ATLAS_ESTATE, "compute_message: prover already consumed");
     if (round >= P->n_rounds || P->left->len != ((size_t)1 << (P->n_rounds - round)))
         return fail(ATLAS_ESTATE, "compute_message: round out of order");
@@ -519,12 +539,12 @@ int atlas_dot_compute_message(atlas_dot_prover_t P, size_t round, const atlas_fr
     const size_t half = P->left->len / 2;
     const int grid = grid_for(half);
     EqView eq = eq_view_for_round(P, round, P->eq ? (const Fr*)P->eq->d : nullptr, P->eq ? P->eq->len : 0);
-    if (deg == 2) { launch_eval<2>(P, eq, half, grid); k_reduce_partials<2><<<1, SC_THREADS, 0, g.stream>>>(g.d_partials, grid, g.d_finals + 3); }
-    else { launch_eval<3>(P, eq, half, grid); k_reduce_partials<3><<<1, SC_THREADS, 0, g.stream>>>(g.d_partials, grid, g.d_finals + 3); }
+    if (deg == 2) { launch_eval<2>(P, eq, half, grid); k_reduce_partials<2><<<1, SC_THREADS, 0, rt().stream>>>(rt().d_partials, grid, rt().d_finals + 3); }
+    else { launch_eval<3>(P, eq, half, grid); k_reduce_partials<3><<<1, SC_THREADS, 0, rt().stream>>>(rt().d_partials, grid, rt().d_finals + 3); }
     H::Fr ev[3];
-    HIP_TRY(hipMemcpyAsync(g.h_pinned, g.d_finals + 3, deg * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
-    std::memcpy(ev, g.h_pinned, deg * sizeof(Fr));
+    HIP_TRY(hipMemcpyAsync(rt().h_pinned, rt().d_finals + 3, deg * sizeof(Fr), hipMemcpyDeviceToHost, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
+    std::memcpy(ev, rt().h_pinned, deg * sizeof(Fr));
     H::Fr c[4];
     int nc = H::unipoly_from_evals_and_hint(*reinterpret_cast<const H::Fr*>(previous_claim), ev, deg, c);
     std::memcpy(coeffs_out, c, nc * sizeof(H::Fr));
@@ -535,7 +555,7 @@ int atlas_dot_compute_message(atlas_dot_prover_t P, size_t round, const atlas_fr
 int atlas_dot_input_claim(atlas_dot_prover_t P, atlas_fr_t* out) {
     NEED_INIT();
     if (!P || !out) return fail(ATLAS_EINVAL, "input_claim");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     if (P->consumed || P->left->len != ((size_t)1 << P->n_rounds)) return fail(ATLAS_ESTATE, "input_claim: instance already bound");
     const size_t len = P->left->len;
     const int grid = grid_for(len);
@@ -544,20 +564,20 @@ int atlas_dot_input_claim(atlas_dot_prover_t P, atlas_fr_t* out) {
     if (P->schedule == ATLAS_EQ_LOW) { eq.mode = EQ_IDX; eq.mask = (uint32_t)((1ull << P->b) - 1); }
     const ScConsts K = make_consts();
     if (P->left->is_i32)
-        k_dot_claim<int32_t><<<grid, SC_THREADS, 0, g.stream>>>((const int32_t*)P->left->d, (const int32_t*)P->right->d, eq, len, g.d_partials, K);
+        k_dot_claim<int32_t><<<grid, SC_THREADS, 0, rt().stream>>>((const int32_t*)P->left->d, (const int32_t*)P->right->d, eq, len, rt().d_partials, K);
     else
-        k_dot_claim<Fr><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, eq, len, g.d_partials, K);
-    k_reduce_partials<1><<<1, SC_THREADS, 0, g.stream>>>(g.d_partials, grid, g.d_finals + 3);
-    HIP_TRY(hipMemcpyAsync(g.h_pinned, g.d_finals + 3, sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
-    std::memcpy(out, g.h_pinned, sizeof(Fr));
+        k_dot_claim<Fr><<<grid, SC_THREADS, 0, rt().stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, eq, len, rt().d_partials, K);
+    k_reduce_partials<1><<<1, SC_THREADS, 0, rt().stream>>>(rt().d_partials, grid, rt().d_finals + 3);
+    HIP_TRY(hipMemcpyAsync(rt().h_pinned, rt().d_finals + 3, sizeof(Fr), hipMemcpyDeviceToHost, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
+    std::memcpy(out, rt().h_pinned, sizeof(Fr));
     return ATLAS_OK;
 }
 
 int atlas_dot_ingest_challenge(atlas_dot_prover_t P, const atlas_u128_t* r_j, size_t round) {
     NEED_INIT();
     if (!P || !r_j) return fail(ATLAS_EINVAL, "ingest_challenge");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     if (P->consumed) return fail(ATLAS_ESTATE, "ingest_challenge: prover already consumed");
     if (round >= P->n_rounds || P->left->len != ((size_t)1 << (P->n_rounds - round)))
         return fail(ATLAS_ESTATE, "ingest_challenge: round out of order");
@@ -566,7 +586,7 @@ int atlas_dot_ingest_challenge(atlas_dot_prover_t P, const atlas_u128_t* r_j, si
     if (!rc && P->schedule == ATLAS_EQ_HIGH && round < P->a) rc = poly_bind_async(P->eq, r_j, ATLAS_HIGH_TO_LOW);
     if (!rc && P->schedule == ATLAS_EQ_LOW && round >= P->a) rc = poly_bind_async(P->eq, r_j, ATLAS_HIGH_TO_LOW);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     return ATLAS_OK;
 }
 
@@ -595,16 +615,16 @@ static int prove_dot_impl(atlas_dot_prover* P, const atlas_fr_t* input_claim, at
                           atlas_fr_t* compressed_polys, atlas_u128_t* challenges, atlas_fr_t final_claims[3]) {
     const ScConsts K = make_consts();
     const size_t n = P->n_rounds;
-    const int mode = g.challenge_mode;
+    const int mode = rt().challenge_mode;
     const int hi_only = mode == 0;
     Timer tm;
 
     // control block: transcript + running claim
-    ScCtx* hctx = reinterpret_cast<ScCtx*>(g.h_pinned);
+    ScCtx* hctx = reinterpret_cast<ScCtx*>(rt().h_pinned);
     std::memset(hctx, 0, sizeof(ScCtx));
     std::memcpy(&hctx->tr, transcript, sizeof(DevTranscript));
     std::memcpy(&hctx->claim, input_claim, sizeof(Fr));
-    HIP_TRY(hipMemcpyAsync(g.d_ctx, hctx, sizeof(ScCtx), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(rt().d_ctx, hctx, sizeof(ScCtx), hipMemcpyHostToDevice, rt().stream));
 
     size_t len = P->left->len;
     size_t eq_len = P->eq ? P->eq->len : 0;
@@ -623,11 +643,11 @@ static int prove_dot_impl(atlas_dot_prover* P, const atlas_fr_t* input_claim, at
             const int grid = use_f9 ? grid_f9(half) : grid_for(half);
             EqView eq = eq_view_for_round(P, 0, eqp, eq_len);
             tm.begin(0, 2 * len * esz);
-            if (use_f9) k_dot_eval2_f9<DevIoF9><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, half, DevIoF9{g.d_ctx, g.d_partials});
+            if (use_f9) k_dot_eval2_f9<DevIoF9><<<grid, SC_THREADS, 0, rt().stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, half, DevIoF9{rt().d_ctx, rt().d_partials});
             else launch_eval<DEG>(P, eq, half, grid);
             tm.end();
             tm.begin(1, 0);
-            k_fs_round<DEG><<<1, SC_THREADS, 0, g.stream>>>(g.d_ctx, g.d_partials, grid, g.d_proof, g.d_chal, K, 1, mode);
+            k_fs_round<DEG><<<1, SC_THREADS, 0, rt().stream>>>(rt().d_ctx, rt().d_partials, grid, rt().d_proof, rt().d_chal, K, 1, mode);
             tm.end();
             rounds_done = 1; pending = 1;
         }
@@ -639,7 +659,7 @@ static int prove_dot_impl(atlas_dot_prover* P, const atlas_fr_t* input_claim, at
             bool fuse_eq = false;
             if (P->schedule == ATLAS_EQ_HIGH && j < P->a) {
                 tm.begin(0, (eq_len + eq_len / 2) * sizeof(Fr));
-                k_bind_hi<<<grid_for(eq_len / 2), SC_THREADS, 0, g.stream>>>(eqp, eq_len / 2, &g.d_ctx->r, hi_only);
+                k_bind_hi<<<grid_for(eq_len / 2), SC_THREADS, 0, rt().stream>>>(eqp, eq_len / 2, &rt().d_ctx->r, hi_only);
                 tm.end();
                 eq_len /= 2;
             } else if (P->schedule == ATLAS_EQ_LOW && j >= P->a) {
@@ -654,38 +674,38 @@ static int prove_dot_impl(atlas_dot_prover* P, const atlas_fr_t* input_claim, at
                 HIP_TRY(Lb.alloc((len / 2) * sizeof(Fr)));
                 HIP_TRY(Rb.alloc((len / 2) * sizeof(Fr)));
                 Fr *Ld = Lb.as<Fr>(), *Rd = Rb.as<Fr>();
-                k_dot_bind_eval<DEG, int32_t, false, DevIo><<<grid, SC_THREADS, 0, g.stream>>>(
+                k_dot_bind_eval<DEG, int32_t, false, DevIo><<<grid, SC_THREADS, 0, rt().stream>>>(
                     (const int32_t*)P->left->d, (const int32_t*)P->right->d, Ld, Rd, nullptr, eq, q,
-                    DevIo{g.d_ctx, g.d_partials}, K, hi_only);
+                    DevIo{rt().d_ctx, rt().d_partials}, K, hi_only);
                 tm.end();
-                HIP_TRY(hipStreamSynchronize(g.stream));
+                HIP_TRY(hipStreamSynchronize(rt().stream));
                 if (P->left->owned) (void)hipFree(P->left->d);
                 if (P->right->owned) (void)hipFree(P->right->d);
                 P->left->d = Lb.release(); P->left->is_i32 = false; P->left->owned = true;
                 P->right->d = Rb.release(); P->right->is_i32 = false; P->right->owned = true;
             } else if (fuse_eq) {
-                k_dot_bind_eval<DEG, Fr, true, DevIo><<<grid, SC_THREADS, 0, g.stream>>>(
+                k_dot_bind_eval<DEG, Fr, true, DevIo><<<grid, SC_THREADS, 0, rt().stream>>>(
                     (const Fr*)P->left->d, (const Fr*)P->right->d, (Fr*)P->left->d, (Fr*)P->right->d, eqp, eq, q,
-                    DevIo{g.d_ctx, g.d_partials}, K, hi_only);
+                    DevIo{rt().d_ctx, rt().d_partials}, K, hi_only);
                 tm.end();
                 eq_len /= 2;
             } else if (use_f9) {
                 // last fused pass hands canonical residues to the LDS tail kernel
                 if (len / 2 <= ((size_t)1 << SC_TAIL_LOG))
-                    k_dot_bind_eval2_f9<true, DevIoF9><<<grid, SC_THREADS, 0, g.stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, DevIoF9{g.d_ctx, g.d_partials});
+                    k_dot_bind_eval2_f9<true, DevIoF9><<<grid, SC_THREADS, 0, rt().stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, DevIoF9{rt().d_ctx, rt().d_partials});
                 else
-                    k_dot_bind_eval2_f9<false, DevIoF9><<<grid, SC_THREADS, 0, g.stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, DevIoF9{g.d_ctx, g.d_partials});
+                    k_dot_bind_eval2_f9<false, DevIoF9><<<grid, SC_THREADS, 0, rt().stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, DevIoF9{rt().d_ctx, rt().d_partials});
                 tm.end();
             } else {
-                k_dot_bind_eval<DEG, Fr, false, DevIo><<<grid, SC_THREADS, 0, g.stream>>>(
+                k_dot_bind_eval<DEG, Fr, false, DevIo><<<grid, SC_THREADS, 0, rt().stream>>>(
                     (const Fr*)P->left->d, (const Fr*)P->right->d, (Fr*)P->left->d, (Fr*)P->right->d, nullptr, eq, q,
-                    DevIo{g.d_ctx, g.d_partials}, K, hi_only);
+                    DevIo{rt().d_ctx, rt().d_partials}, K, hi_only);
                 tm.end();
             }
             len /= 2;
             tm.begin(1, 0);
-            k_fs_round<DEG><<<1, SC_THREADS, 0, g.stream>>>(g.d_ctx, g.d_partials, grid, g.d_proof + rounds_done * DEG,
-                                                          g.d_chal + 2 * rounds_done, K, 0, mode);
+            k_fs_round<DEG><<<1, SC_THREADS, 0, rt().stream>>>(rt().d_ctx, rt().d_partials, grid, rt().d_proof + rounds_done * DEG,
+                                                          rt().d_chal + 2 * rounds_done, K, 0, mode);
             tm.end();
             rounds_done += 1;
         }
@@ -703,21 +723,21 @@ static int prove_dot_impl(atlas_dot_prover* P, const atlas_fr_t* input_claim, at
         A.pending_bind = pending;
         A.challenge_mode = mode;
         tm.begin(1, 0);
-        k_dot_tail<DEG><<<1, SC_THREADS, 3 * (sizeof(Fr) << SC_TAIL_LOG), g.stream>>>(A, g.d_ctx, g.d_proof, g.d_chal,
-                                                                                     g.d_finals, K);
+        k_dot_tail<DEG><<<1, SC_THREADS, 3 * (sizeof(Fr) << SC_TAIL_LOG), rt().stream>>>(A, rt().d_ctx, rt().d_proof, rt().d_chal,
+                                                                                     rt().d_finals, K);
         tm.end();
     }
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail(ATLAS_ENODEV, "sumcheck launch", le);
 
     // results: one D2H each, stream ordered
-    uint8_t* hp = reinterpret_cast<uint8_t*>(g.h_pinned);
+    uint8_t* hp = reinterpret_cast<uint8_t*>(rt().h_pinned);
     const size_t proof_bytes = n * DEG * sizeof(Fr), chal_bytes = n * 2 * sizeof(uint64_t);
-    HIP_TRY(hipMemcpyAsync(hp, g.d_proof, proof_bytes ? proof_bytes : 32, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipMemcpyAsync(hp + 8192, g.d_chal, chal_bytes ? chal_bytes : 16, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipMemcpyAsync(hp + 12288, g.d_finals, 3 * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipMemcpyAsync(hp + 16384, g.d_ctx, sizeof(ScCtx), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(hp, rt().d_proof, proof_bytes ? proof_bytes : 32, hipMemcpyDeviceToHost, rt().stream));
+    HIP_TRY(hipMemcpyAsync(hp + 8192, rt().d_chal, chal_bytes ? chal_bytes : 16, hipMemcpyDeviceToHost, rt().stream));
+    HIP_TRY(hipMemcpyAsync(hp + 12288, rt().d_finals, 3 * sizeof(Fr), hipMemcpyDeviceToHost, rt().stream));
+    HIP_TRY(hipMemcpyAsync(hp + 16384, rt().d_ctx, sizeof(ScCtx), hipMemcpyDeviceToHost, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     std::memcpy(compressed_polys, hp, proof_bytes);
     std::memcpy(challenges, hp + 8192, chal_bytes);
     std::memcpy(final_claims, hp + 12288, 3 * sizeof(Fr));
@@ -759,13 +779,13 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
                              atlas_fr_t* compressed_polys, atlas_u128_t* challenges, atlas_fr_t final_claims[3],
                              atlas_shard_group* grp = nullptr) {
     using atlas_rt::Channel;
-    Channel& C = g.chan;
+    Channel& C = rt().chan;
     const ScConsts K = make_consts();
     const size_t n = P->n_rounds;
-    const int mode = g.challenge_mode;
+    const int mode = rt().challenge_mode;
     const int hi_only = mode == 0;
     Timer tm;
-    if (C.abort_dirty) { HIP_TRY(hipMemsetAsync(C.d_abort, 0, 4, g.stream)); C.abort_dirty = false; }
+    if (C.abort_dirty) { HIP_TRY(hipMemsetAsync(C.d_abort, 0, 4, rt().stream)); C.abort_dirty = false; }
 
     // tags: records of round k = tag0 + k (k = n: the final claims), challenge of round k = tag0 + n + 1 + k
     const uint32_t tag0 = C.take_tags(2 * n + 2);
@@ -802,9 +822,9 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
             const RoundIo io = C.io(reg, mtag(0), (size_t)-1, 0);
             EqView eq = eq_view_for_round(P, 0, eqp, eq_len);
             tm.begin(0, 2 * len * esz);
-            if (use_f9) k_dot_eval2_f9<ChanIoF9><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, half, ChanIoF9{io});
-            else if (was_i32) k_dot_eval<DEG, int32_t, ChanIo><<<grid, SC_THREADS, 0, g.stream>>>((const int32_t*)P->left->d, (const int32_t*)P->right->d, eq, half, ChanIo{io, mode}, K);
-            else k_dot_eval<DEG, Fr, ChanIo><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, eq, half, ChanIo{io, mode}, K);
+            if (use_f9) k_dot_eval2_f9<ChanIoF9><<<grid, SC_THREADS, 0, rt().stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, half, ChanIoF9{io});
+            else if (was_i32) k_dot_eval<DEG, int32_t, ChanIo><<<grid, SC_THREADS, 0, rt().stream>>>((const int32_t*)P->left->d, (const int32_t*)P->right->d, eq, half, ChanIo{io, mode}, K);
+            else k_dot_eval<DEG, Fr, ChanIo><<<grid, SC_THREADS, 0, rt().stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, eq, half, ChanIo{io, mode}, K);
             tm.end();
             mails[0] = Mail{reg, (size_t)grid, use_f9 ? 29 : 32, use_f9 ? 5 : 0};
             rounds_done = 1; pending = 1;
@@ -820,7 +840,7 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
             if (P->schedule == ATLAS_EQ_HIGH && j < P->a) {
                 tm.begin(0, (eq_len + eq_len / 2) * sizeof(Fr));
                 waiters[j] = (size_t)(grid_for(eq_len / 2) > grid ? grid_for(eq_len / 2) : grid);
-                k_bind_hi_io<ChanIo><<<grid_for(eq_len / 2), SC_THREADS, 0, g.stream>>>(eqp, eq_len / 2, ChanIo{C.io(nullptr, 0, slot0 + j, rtag(j), waiters[j]), mode}, hi_only);
+                k_bind_hi_io<ChanIo><<<grid_for(eq_len / 2), SC_THREADS, 0, rt().stream>>>(eqp, eq_len / 2, ChanIo{C.io(nullptr, 0, slot0 + j, rtag(j), waiters[j]), mode}, hi_only);
                 tm.end();
                 eq_len /= 2;
             } else if (P->schedule == ATLAS_EQ_LOW && j >= P->a) {
@@ -840,28 +860,28 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
                 if (e != hipSuccess) {
                     if (Ld) (void)hipFree(Ld);
                     for (size_t k = 0; k < n; k++) C.publish(slot0 + k, rtag(k), 0, 0, true);
-                    (void)hipStreamSynchronize(g.stream);
+                    (void)hipStreamSynchronize(rt().stream);
                     P->consumed = true;
                     return fail(ATLAS_ENOMEM, "hipMalloc(bound operands)", e);
                 }
-                k_dot_bind_eval<DEG, int32_t, false, ChanIo><<<grid, SC_THREADS, 0, g.stream>>>(
+                k_dot_bind_eval<DEG, int32_t, false, ChanIo><<<grid, SC_THREADS, 0, rt().stream>>>(
                     (const int32_t*)P->left->d, (const int32_t*)P->right->d, Ld, Rd, nullptr, eq, q, ChanIo{io, mode}, K, hi_only);
                 old_l = P->left->owned ? P->left->d : nullptr; old_r = P->right->owned ? P->right->d : nullptr;
                 P->left->d = Ld; P->left->is_i32 = false; P->left->owned = true;
                 P->right->d = Rd; P->right->is_i32 = false; P->right->owned = true;
             } else if (fuse_eq) {
-                k_dot_bind_eval<DEG, Fr, true, ChanIo><<<grid, SC_THREADS, 0, g.stream>>>(
+                k_dot_bind_eval<DEG, Fr, true, ChanIo><<<grid, SC_THREADS, 0, rt().stream>>>(
                     (const Fr*)P->left->d, (const Fr*)P->right->d, (Fr*)P->left->d, (Fr*)P->right->d, eqp, eq, q, ChanIo{io, mode}, K, hi_only);
                 eq_len /= 2;
             } else if (pair_pass) {
-                k_dot_bind_eval2_f9_pair<ChanIoF9><<<grid, SC_THREADS, 0, g.stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, ChanIoF9{io});
+                k_dot_bind_eval2_f9_pair<ChanIoF9><<<grid, SC_THREADS, 0, rt().stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, ChanIoF9{io});
             } else if (use_f9) {
                 if (false)                                     // (the lazy-limb tail takes residues < 2.1p as they are)
-                    k_dot_bind_eval2_f9<true, ChanIoF9><<<grid, SC_THREADS, 0, g.stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, ChanIoF9{io});
+                    k_dot_bind_eval2_f9<true, ChanIoF9><<<grid, SC_THREADS, 0, rt().stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, ChanIoF9{io});
                 else
-                    k_dot_bind_eval2_f9<false, ChanIoF9><<<grid, SC_THREADS, 0, g.stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, ChanIoF9{io});
+                    k_dot_bind_eval2_f9<false, ChanIoF9><<<grid, SC_THREADS, 0, rt().stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, ChanIoF9{io});
             } else {
-                k_dot_bind_eval<DEG, Fr, false, ChanIo><<<grid, SC_THREADS, 0, g.stream>>>(
+                k_dot_bind_eval<DEG, Fr, false, ChanIo><<<grid, SC_THREADS, 0, rt().stream>>>(
                     (const Fr*)P->left->d, (const Fr*)P->right->d, (Fr*)P->left->d, (Fr*)P->right->d, nullptr, eq, q, ChanIo{io, mode}, K, hi_only);
             }
             tm.end();
@@ -886,8 +906,8 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
         const bool tail_f9 = DEG == 2 && mode == 0;
         for (size_t k = rounds_done; k < n; k++) mails[k] = Mail{tail_reg + (k - rounds_done) * ch_stride(DEG), 1, tail_f9 ? 29 : 32, tail_f9 ? 5 : 0};
         tm.begin(1, 0);
-        if (DEG == 2 && mode == 0) k_dot_tail2_f9<<<1, SC_TAIL_THREADS, 2 * (sizeof(Fr) << tail_log), g.stream>>>(A, K);
-        else k_dot_tail_ch<DEG><<<1, SC_TAIL_X_THREADS, (P->schedule == ATLAS_EQ_NONE ? 2 : 3) * (sizeof(Fr) << tail_log), g.stream>>>(A, K);
+        if (DEG == 2 && mode == 0) k_dot_tail2_f9<<<1, SC_TAIL_THREADS, 2 * (sizeof(Fr) << tail_log), rt().stream>>>(A, K);
+        else k_dot_tail_ch<DEG><<<1, SC_TAIL_X_THREADS, (P->schedule == ATLAS_EQ_NONE ? 2 : 3) * (sizeof(Fr) << tail_log), rt().stream>>>(A, K);
         tm.end();
     }
     hipError_t le = hipGetLastError();
@@ -924,7 +944,7 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
         C.publish(slot0 + round, rtag(round), challenges[round].lo, challenges[round].hi);
         // while the device works on the next pass: let the runtime retire the launches that have completed (otherwise it
         // reaps all of them inside the final synchronisation: ~170 us for the 14 launches of a 2^22 instance)
-        if (round < tail_round0) (void)hipStreamQuery(g.stream);
+        if (round < tail_round0) (void)hipStreamQuery(rt().stream);
         if (trace) { const double t_pub = now_us(); tr_t.push_back(t_first - t_prev); tr_t.push_back(t_coll - t_first); tr_t.push_back(t_pub - t_coll); t_prev = t_pub; }
     }
     if (trace) {
@@ -936,7 +956,7 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
     P->consumed = true;
     P->left->len = 1; P->right->len = 1;
     if (P->eq) P->eq->len = 1;
-    if (old_l || old_r || !ok) (void)hipStreamSynchronize(g.stream);
+    if (old_l || old_r || !ok) (void)hipStreamSynchronize(rt().stream);
     if (old_l) (void)hipFree(old_l);
     if (old_r) (void)hipFree(old_r);
     if (!ok) {
@@ -976,8 +996,8 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
     {
         const double t0 = trace ? now_us() : 0;
         static const bool spin_query = getenv("ATLAS_SYNC_QUERY") != nullptr;
-        if (spin_query) { while (hipStreamQuery(g.stream) == hipErrorNotReady) {} }
-        else (void)hipStreamSynchronize(g.stream);
+        if (spin_query) { while (hipStreamQuery(rt().stream) == hipErrorNotReady) {} }
+        else (void)hipStreamSynchronize(rt().stream);
         if (trace) fprintf(stderr, "[atlas trace] final stream sync %.2f us\n", now_us() - t0);
     }
     tm.collect();
@@ -994,8 +1014,8 @@ int atlas_sumcheck_prove_dot(atlas_dot_prover_t P, const atlas_fr_t* input_claim
         return fail(ATLAS_EINVAL, "sumcheck_prove_dot: null argument");
     if (P->consumed) return fail(ATLAS_ESTATE, "sumcheck_prove_dot: prover already consumed");
     if (P->left->len != ((size_t)1 << P->n_rounds)) return fail(ATLAS_ESTATE, "sumcheck_prove_dot: rounds already run");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
-    if (g.fs_mode == ATLAS_FS_HOST) {
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+    if (rt().fs_mode == ATLAS_FS_HOST) {
         if (P->schedule == ATLAS_EQ_NONE) return prove_dot_channel<2>(P, input_claim, transcript, compressed_polys, challenges, final_claims);
         return prove_dot_channel<3>(P, input_claim, transcript, compressed_polys, challenges, final_claims);
     }
@@ -1019,13 +1039,13 @@ int atlas_dot_shard_begin(atlas_dot_prover_t P, const atlas_fr_t* input_claim, c
     if (!P || !input_claim || !transcript) return fail(ATLAS_EINVAL, "dot_shard_begin: null argument");
     if (P->schedule != ATLAS_EQ_NONE || P->left->is_i32) return fail(ATLAS_EINVAL, "dot_shard_begin: degree-2 LargeScalars instances only");
     if (P->consumed || P->left->len != ((size_t)1 << P->n_rounds)) return fail(ATLAS_ESTATE, "dot_shard_begin: prover already used");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
-    ScCtx* hctx = reinterpret_cast<ScCtx*>(g.h_pinned);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+    ScCtx* hctx = reinterpret_cast<ScCtx*>(rt().h_pinned);
     std::memset(hctx, 0, sizeof(ScCtx));
     std::memcpy(&hctx->tr, transcript, sizeof(DevTranscript));
     std::memcpy(&hctx->claim, input_claim, sizeof(Fr));
-    HIP_TRY(hipMemcpyAsync(g.d_ctx, hctx, sizeof(ScCtx), hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(rt().d_ctx, hctx, sizeof(ScCtx), hipMemcpyHostToDevice, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     P->shard_rounds_done = 0; P->shard_pending = false; P->shard_active = true;
     return ATLAS_OK;
 }
@@ -1035,32 +1055,32 @@ int atlas_dot_shard_local_message(atlas_dot_prover_t P, atlas_fr_t* out2) {
     NEED_INIT();
     if (!P || !out2) return fail(ATLAS_EINVAL, "dot_shard_local_message");
     if (!P->shard_active || P->left->len < 2) return fail(ATLAS_ESTATE, "dot_shard_local_message: no local round left");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     const ScConsts K = make_consts();
-    const int hi_only = g.challenge_mode == 0;
-    const bool f9 = g.challenge_mode == 0;
+    const int hi_only = rt().challenge_mode == 0;
+    const bool f9 = rt().challenge_mode == 0;
     const size_t len = P->left->len;
     int grid;
     EqView eq; eq.p = nullptr; eq.mode = EQ_NONE; eq.shift = 0; eq.mask = 0; eq.half = 0;
     if (!P->shard_pending) {          // first message: no bind
         const size_t half = len / 2;
         grid = (int)((half + SC_THREADS - 1) / SC_THREADS); if (grid > 256) grid = 256; if (grid < 1) grid = 1;
-        if (f9) k_dot_eval2_f9<DevIoF9><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, half, DevIoF9{g.d_ctx, g.d_partials});
-        else k_dot_eval<2, Fr, DevIo><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, eq, half, DevIo{g.d_ctx, g.d_partials}, K);
+        if (f9) k_dot_eval2_f9<DevIoF9><<<grid, SC_THREADS, 0, rt().stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, half, DevIoF9{rt().d_ctx, rt().d_partials});
+        else k_dot_eval<2, Fr, DevIo><<<grid, SC_THREADS, 0, rt().stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, eq, half, DevIo{rt().d_ctx, rt().d_partials}, K);
     } else {                          // bind the last challenge, evaluate the next message
         if (len < 4) return fail(ATLAS_ESTATE, "dot_shard_local_message: use atlas_dot_shard_local_final");
         const size_t q = len / 4;
         grid = (int)((q + SC_THREADS - 1) / SC_THREADS); if (grid > 256) grid = 256; if (grid < 1) grid = 1;
         // canonical residues in HBM: the exact kernels may read them later (local_final)
-        if (f9) k_dot_bind_eval2_f9<true, DevIoF9><<<grid, SC_THREADS, 0, g.stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, DevIoF9{g.d_ctx, g.d_partials});
-        else k_dot_bind_eval<2, Fr, false, DevIo><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, (Fr*)P->left->d, (Fr*)P->right->d, nullptr, eq, q, DevIo{g.d_ctx, g.d_partials}, K, hi_only);
+        if (f9) k_dot_bind_eval2_f9<true, DevIoF9><<<grid, SC_THREADS, 0, rt().stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, DevIoF9{rt().d_ctx, rt().d_partials});
+        else k_dot_bind_eval<2, Fr, false, DevIo><<<grid, SC_THREADS, 0, rt().stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, (Fr*)P->left->d, (Fr*)P->right->d, nullptr, eq, q, DevIo{rt().d_ctx, rt().d_partials}, K, hi_only);
         P->left->len = len / 2; P->right->len = len / 2;
         P->shard_pending = false;
     }
-    k_reduce_partials<2><<<1, SC_THREADS, 0, g.stream>>>(g.d_partials, grid, g.d_finals + 3);
-    HIP_TRY(hipMemcpyAsync(g.h_pinned, g.d_finals + 3, 2 * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
-    std::memcpy(out2, g.h_pinned, 2 * sizeof(Fr));
+    k_reduce_partials<2><<<1, SC_THREADS, 0, rt().stream>>>(rt().d_partials, grid, rt().d_finals + 3);
+    HIP_TRY(hipMemcpyAsync(rt().h_pinned, rt().d_finals + 3, 2 * sizeof(Fr), hipMemcpyDeviceToHost, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
+    std::memcpy(out2, rt().h_pinned, 2 * sizeof(Fr));
     return ATLAS_OK;
 }
 
@@ -1069,14 +1089,14 @@ int atlas_dot_shard_round(atlas_dot_prover_t P, const atlas_fr_t* gathered, size
     NEED_INIT();
     if (!P || !gathered || world == 0 || world > SC_MAX_BLOCKS) return fail(ATLAS_EINVAL, "dot_shard_round");
     if (!P->shard_active || P->shard_pending) return fail(ATLAS_ESTATE, "dot_shard_round: out of order");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     const ScConsts K = make_consts();
-    HIP_TRY(hipMemcpyAsync(g.d_partials, gathered, world * 2 * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(rt().d_partials, gathered, world * 2 * sizeof(Fr), hipMemcpyHostToDevice, rt().stream));
     const size_t rd = P->shard_rounds_done;
     if (rd >= MAX_ROUNDS) return fail(ATLAS_ESTATE, "dot_shard_round: too many rounds");
-    k_fs_round<2><<<1, SC_THREADS, 0, g.stream>>>(g.d_ctx, g.d_partials, (int)world, g.d_proof + rd * 2, g.d_chal + 2 * rd, K,
-                                                 rd == 0 ? 1 : 0, g.challenge_mode);
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    k_fs_round<2><<<1, SC_THREADS, 0, rt().stream>>>(rt().d_ctx, rt().d_partials, (int)world, rt().d_proof + rd * 2, rt().d_chal + 2 * rd, K,
+                                                 rd == 0 ? 1 : 0, rt().challenge_mode);
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     P->shard_rounds_done = rd + 1;
     P->shard_pending = true;
     return ATLAS_OK;
@@ -1088,14 +1108,14 @@ int atlas_dot_shard_local_final(atlas_dot_prover_t P, atlas_fr_t* out2) {
     NEED_INIT();
     if (!P || !out2) return fail(ATLAS_EINVAL, "dot_shard_local_final");
     if (!P->shard_active || !P->shard_pending || P->left->len != 2) return fail(ATLAS_ESTATE, "dot_shard_local_final: local rounds not finished");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
-    const int hi_only = g.challenge_mode == 0;
-    k_bind_hi<<<1, SC_THREADS, 0, g.stream>>>((Fr*)P->left->d, 1, &g.d_ctx->r, hi_only);
-    k_bind_hi<<<1, SC_THREADS, 0, g.stream>>>((Fr*)P->right->d, 1, &g.d_ctx->r, hi_only);
-    HIP_TRY(hipMemcpyAsync(g.h_pinned, P->left->d, sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipMemcpyAsync((char*)g.h_pinned + sizeof(Fr), P->right->d, sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
-    std::memcpy(out2, g.h_pinned, 2 * sizeof(Fr));
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+    const int hi_only = rt().challenge_mode == 0;
+    k_bind_hi<<<1, SC_THREADS, 0, rt().stream>>>((Fr*)P->left->d, 1, &rt().d_ctx->r, hi_only);
+    k_bind_hi<<<1, SC_THREADS, 0, rt().stream>>>((Fr*)P->right->d, 1, &rt().d_ctx->r, hi_only);
+    HIP_TRY(hipMemcpyAsync(rt().h_pinned, P->left->d, sizeof(Fr), hipMemcpyDeviceToHost, rt().stream));
+    HIP_TRY(hipMemcpyAsync((char*)rt().h_pinned + sizeof(Fr), P->right->d, sizeof(Fr), hipMemcpyDeviceToHost, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
+    std::memcpy(out2, rt().h_pinned, 2 * sizeof(Fr));
     P->left->len = 1; P->right->len = 1; P->shard_pending = false;
     return ATLAS_OK;
 }
@@ -1109,7 +1129,7 @@ int atlas_dot_shard_finish(atlas_dot_prover_t P, const atlas_fr_t* gathered_lr, 
         world > ((size_t)1 << SC_TAIL_LOG))
         return fail(ATLAS_EINVAL, "dot_shard_finish");
     if (!P->shard_active || P->left->len != 1 || P->shard_pending) return fail(ATLAS_ESTATE, "dot_shard_finish: out of order");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     const ScConsts K = make_consts();
     const size_t n_total = P->shard_rounds_done + ilog2(world);
     if (n_total > MAX_ROUNDS) return fail(ATLAS_EINVAL, "dot_shard_finish: too many rounds");
@@ -1118,21 +1138,21 @@ int atlas_dot_shard_finish(atlas_dot_prover_t P, const atlas_fr_t* gathered_lr, 
     for (size_t i = 0; i < world; i++) { std::memcpy(&hl[i], &gathered_lr[2 * i], sizeof(Fr)); std::memcpy(&hr[i], &gathered_lr[2 * i + 1], sizeof(Fr)); }
     Fr *dl = nullptr, *dr = nullptr;
     HIP_TRY(hipMalloc(&dl, world * sizeof(Fr))); HIP_TRY(hipMalloc(&dr, world * sizeof(Fr)));
-    HIP_TRY(hipMemcpyAsync(dl, hl.data(), world * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipMemcpyAsync(dr, hr.data(), world * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(dl, hl.data(), world * sizeof(Fr), hipMemcpyHostToDevice, rt().stream));
+    HIP_TRY(hipMemcpyAsync(dr, hr.data(), world * sizeof(Fr), hipMemcpyHostToDevice, rt().stream));
     TailArgs A;
     A.L = dl; A.R = dr; A.eq = nullptr; A.len = (uint32_t)world; A.eq_len = 0; A.src_i32 = 0;
     A.sched = 0; A.a = 0; A.b = 0; A.round0 = (uint32_t)P->shard_rounds_done; A.n_rounds = (uint32_t)n_total;
     A.first = P->shard_rounds_done == 0 ? 1 : 0;      // one coefficient per rank: no local round absorbed the input claim yet
-    A.pending_bind = 0; A.challenge_mode = g.challenge_mode;
-    k_dot_tail<2><<<1, SC_THREADS, 3 * (sizeof(Fr) << SC_TAIL_LOG), g.stream>>>(A, g.d_ctx, g.d_proof, g.d_chal, g.d_finals, K);
-    uint8_t* hp = reinterpret_cast<uint8_t*>(g.h_pinned);
+    A.pending_bind = 0; A.challenge_mode = rt().challenge_mode;
+    k_dot_tail<2><<<1, SC_THREADS, 3 * (sizeof(Fr) << SC_TAIL_LOG), rt().stream>>>(A, rt().d_ctx, rt().d_proof, rt().d_chal, rt().d_finals, K);
+    uint8_t* hp = reinterpret_cast<uint8_t*>(rt().h_pinned);
     const size_t proof_bytes = n_total * 2 * sizeof(Fr), chal_bytes = n_total * 2 * sizeof(uint64_t);
-    hipError_t e = hipMemcpyAsync(hp, g.d_proof, proof_bytes, hipMemcpyDeviceToHost, g.stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(hp + 8192, g.d_chal, chal_bytes, hipMemcpyDeviceToHost, g.stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(hp + 12288, g.d_finals, 3 * sizeof(Fr), hipMemcpyDeviceToHost, g.stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(hp + 16384, g.d_ctx, sizeof(ScCtx), hipMemcpyDeviceToHost, g.stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    hipError_t e = hipMemcpyAsync(hp, rt().d_proof, proof_bytes, hipMemcpyDeviceToHost, rt().stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hp + 8192, rt().d_chal, chal_bytes, hipMemcpyDeviceToHost, rt().stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hp + 12288, rt().d_finals, 3 * sizeof(Fr), hipMemcpyDeviceToHost, rt().stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hp + 16384, rt().d_ctx, sizeof(ScCtx), hipMemcpyDeviceToHost, rt().stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(rt().stream);
     hipFree(dl); hipFree(dr);
     if (e != hipSuccess) return fail(ATLAS_ENODEV, "dot_shard_finish", e);
     std::memcpy(compressed_polys, hp, proof_bytes);
@@ -1170,7 +1190,7 @@ int atlas_sumcheck_prove_dot_sharded(atlas_dot_prover_t P, atlas_shard_group_t g
     if (P->schedule != ATLAS_EQ_NONE || P->left->is_i32) return fail(ATLAS_EINVAL, "sumcheck_prove_dot_sharded: degree-2 LargeScalars instances");
     if (P->consumed || P->left->len != ((size_t)1 << P->n_rounds)) return fail(ATLAS_ESTATE, "sumcheck_prove_dot_sharded: prover already used");
     if (P->n_rounds + ilog2((size_t)grp->world) > MAX_ROUNDS) return fail(ATLAS_EINVAL, "sumcheck_prove_dot_sharded: too many rounds");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     return prove_dot_channel<2>(P, input_claim, transcript, compressed_polys, challenges, final_claims, grp);
 }
 

@@ -27,7 +27,7 @@
 
 namespace H = atlas_host;
 using atlas_rt::fail;
-using atlas_rt::g;
+using atlas_rt::rt;
 
 namespace {
 
@@ -111,7 +111,7 @@ struct Lane {                     // one instance inside a pipelined proof
 };
 
 struct Pipeline {
-    atlas_rt::Channel& C = g.chan;
+    atlas_rt::Channel& C = rt().chan;
     std::vector<Lane> lanes;
     size_t max_rounds = 0, slot0 = 0;
     uint32_t tag0 = 0;
@@ -131,17 +131,17 @@ struct Pipeline {
     // the library stream (the constructors ran there) and the library stream waits for them when the proof is done.
     static constexpr size_t N_SIDE = 4;
     bool side = false;
-    static hipStream_t* side_streams() { static hipStream_t st[N_SIDE] = {nullptr, nullptr, nullptr, nullptr}; return st; }
+    static hipStream_t* side_streams() { static thread_local hipStream_t st[N_SIDE] = {nullptr, nullptr, nullptr, nullptr}; return st; }
     // ATLAS_LANE_EVENTS=1 (diagnosis only, tools/stress_lanes.py): order the lanes behind the library stream with events instead of host waits
-    static hipEvent_t* side_events() { static hipEvent_t ev[N_SIDE + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr}; return ev; }
+    static hipEvent_t* side_events() { static thread_local hipEvent_t ev[N_SIDE + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr}; return ev; }
     static bool lane_events() { static const bool v = getenv("ATLAS_LANE_EVENTS") != nullptr; return v; }
     static bool one_side_stream() { static const bool v = getenv("ATLAS_LANE_ONE_STREAM") != nullptr; return v; }   // diagnosis: every lane on side stream 0
-    hipStream_t lane_stream(size_t li) const { return side ? side_streams()[one_side_stream() ? 0 : li % N_SIDE] : g.stream; }
-    int begin() {               // the caller holds g.mu
+    hipStream_t lane_stream(size_t li) const { return side ? side_streams()[one_side_stream() ? 0 : li % N_SIDE] : rt().stream; }
+    int begin() {               // the caller holds rt().mu
         for (auto& L : lanes) { max_rounds = L.rounds > max_rounds ? L.rounds : max_rounds; }
         for (auto& L : lanes) { L.offset = max_rounds - L.rounds; L.mails.resize(L.rounds); }
         if (max_rounds == 0 || max_rounds > atlas_rt::Channel::RING / 2) return fail(ATLAS_EINVAL, "pipelined prove: round count");
-        if (C.abort_dirty) { HIP_TRY(hipMemsetAsync(C.d_abort, 0, 4, g.stream)); C.abort_dirty = false; }
+        if (C.abort_dirty) { HIP_TRY(hipMemsetAsync(C.d_abort, 0, 4, rt().stream)); C.abort_dirty = false; }
         tag0 = C.take_tags((max_rounds + 2) * (lanes.size() + 1));
         slot0 = C.take_slots(max_rounds);
         static const bool no_side = getenv("ATLAS_NO_LANE_STREAMS") != nullptr;
@@ -157,10 +157,10 @@ struct Pipeline {
             if (lane_events()) {
                 hipEvent_t* ev = side_events();
                 if (!ev[0]) for (size_t i = 0; i <= N_SIDE; i++) HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
-                HIP_TRY(hipEventRecord(ev[N_SIDE], g.stream));
+                HIP_TRY(hipEventRecord(ev[N_SIDE], rt().stream));
                 for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) HIP_TRY(hipStreamWaitEvent(st[i], ev[N_SIDE], 0));
             } else {
-                HIP_TRY(hipStreamSynchronize(g.stream));
+                HIP_TRY(hipStreamSynchronize(rt().stream));
                 atlas_rt::dev_pool().retag_all();            // nothing is in flight: a block the library stream returned may go to a lane
             }
         }
@@ -172,7 +172,7 @@ struct Pipeline {
         hipStream_t* st = side_streams();
         if (lane_events()) {
             hipEvent_t* ev = side_events();
-            for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) { (void)hipEventRecord(ev[i], st[i]); (void)hipStreamWaitEvent(g.stream, ev[i], 0); }
+            for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) { (void)hipEventRecord(ev[i], st[i]); (void)hipStreamWaitEvent(rt().stream, ev[i], 0); }
             side = false;
             return;
         }
@@ -180,8 +180,8 @@ struct Pipeline {
         atlas_rt::dev_pool().retag_all();                    // the lanes have drained: what they returned may go to the library stream
         side = false;
     }
-    void query() { (void)hipStreamQuery(g.stream); if (side) for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) (void)hipStreamQuery(side_streams()[i]); }
-    void drain() { if (side) for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) (void)hipStreamSynchronize(side_streams()[i]); (void)hipStreamSynchronize(g.stream); join(); }
+    void query() { (void)hipStreamQuery(rt().stream); if (side) for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) (void)hipStreamQuery(side_streams()[i]); }
+    void drain() { if (side) for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) (void)hipStreamSynchronize(side_streams()[i]); (void)hipStreamSynchronize(rt().stream); join(); }
     // make sure the launches of global rounds < R + LOOKAHEAD (and the final binds after the last) are enqueued
     int advance(size_t R) {
         while (next_enqueue <= max_rounds && next_enqueue < R + LOOKAHEAD) {
@@ -194,14 +194,14 @@ struct Pipeline {
                 atlas::Chunk* area = C.alloc(256 * atlas::ch_stride(4));
                 atlas::RoundIo io = C.io(area, mtag(Q, li), wait ? slot0 + Q - 1 : (size_t)-1, wait ? rtag(Q - 1) : 0, 256);
                 io.tag_step = (uint32_t)lanes.size();                // mtag(Q + 1, li) - mtag(Q, li)
-                const hipStream_t lib_stream = g.stream;          // the instance's launches go to its lane's stream
-                g.stream = lane_stream(li);
-                atlas_rt::tl_lane_stream = side ? g.stream : nullptr;
+                const hipStream_t lib_stream = rt().stream;          // the instance's launches go to its lane's stream
+                rt().stream = lane_stream(li);
+                atlas_rt::tl_lane_stream = side ? rt().stream : nullptr;
                 static const bool no_gate = getenv("ATLAS_LANE_NO_GATE") != nullptr;                     // diagnosis only (tools/bisect_lanes.sh)
-                if (side && wait && !no_gate && L.inst->wide_wait(local)) atlas::k_ch_gate<<<1, 64, 0, g.stream>>>(io);      // the lane's wide launches start behind their challenge (channel.hip.h)
+                if (side && wait && !no_gate && L.inst->wide_wait(local)) atlas::k_ch_gate<<<1, 64, 0, rt().stream>>>(io);      // the lane's wide launches start behind their challenge (channel.hip.h)
                 int rc = Q < max_rounds ? L.inst->enqueue(local, io, bind_prev, L.mails[local]) : L.inst->enqueue_finals(io, L.fin);
                 if (Q >= max_rounds || !L.inst->silent_round(local)) next_enqueue_launched++;
-                g.stream = lib_stream;
+                rt().stream = lib_stream;
                 atlas_rt::tl_lane_stream = nullptr;
                 if (rc) { abort_from(0); drain(); return rc; }
             }
@@ -231,7 +231,7 @@ struct Pipeline {
 };
 
 bool all_pipelined(const std::vector<atlas_instance*>& v) {
-    if (g.fs_mode != ATLAS_FS_HOST || getenv("ATLAS_NO_PIPELINE")) return false;
+    if (rt().fs_mode != ATLAS_FS_HOST || getenv("ATLAS_NO_PIPELINE")) return false;
     for (auto* i : v) if (!i->pipelined()) return false;
     return !v.empty();
 }
@@ -331,7 +331,7 @@ int atlas_instance_prove(atlas_instance_t inst, const atlas_fr_t* input_claim, a
     const size_t n = inst->rounds();
     std::vector<H::Fr> c;
     if (n && all_pipelined({inst})) {
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
         Pipeline P;
         P.lanes.push_back(Lane{inst, n, 0, {}, {}});
         int rc;
@@ -347,15 +347,15 @@ int atlas_instance_prove(atlas_instance_t inst, const atlas_fr_t* input_claim, a
             const auto q0 = nowp();
             inst->prepare(round);
             { PROF("instance_prove: collect (wait for the device)");
-              if (!P.collect(P.lanes[0].mails[round], P.mtag(round, 0), sums)) { P.abort_from(round); (void)hipStreamSynchronize(g.stream); return fail(ATLAS_ENODEV, "round channel: no answer from the device"); } }
+              if (!P.collect(P.lanes[0].mails[round], P.mtag(round, 0), sums)) { P.abort_from(round); (void)hipStreamSynchronize(rt().stream); return fail(ATLAS_ENODEV, "round channel: no answer from the device"); } }
             const auto q1 = nowp();
             { PROF("instance_prove: finish"); rc = inst->finish(round, prev, sums, c); }
             const auto q2 = nowp();
-            if (rc) { P.abort_from(round); (void)hipStreamSynchronize(g.stream); return rc; }
+            if (rc) { P.abort_from(round); (void)hipStreamSynchronize(rt().stream); return rc; }
             std::vector<H::Fr> cc;
             if (c.size() < 2) cc = c;
             else { cc.push_back(c[0]); for (size_t k = 2; k < c.size(); k++) cc.push_back(c[k]); }
-            if (cc.size() > row_stride) { P.abort_from(round); (void)hipStreamSynchronize(g.stream); return fail(ATLAS_EINVAL, "instance_prove: row_stride below the degree"); }
+            if (cc.size() > row_stride) { P.abort_from(round); (void)hipStreamSynchronize(rt().stream); return fail(ATLAS_EINVAL, "instance_prove: row_stride below the degree"); }
             const double pt0 = atlas_rt::Prof::on() ? atlas_rt::Prof::now_us() : 0;
             H::tr_append_message(T, "UniPoly_begin");
             for (auto& x : cc) H::tr_append_scalar(T, x);
@@ -369,13 +369,13 @@ int atlas_instance_prove(atlas_instance_t inst, const atlas_fr_t* input_claim, a
             if (atlas_rt::Prof::on()) atlas_rt::Prof::get().add("instance_prove: transcript + publish", atlas_rt::Prof::now_us() - pt0);
             // lets the runtime retire completed launches while the device works — when there are any: a query costs 2.5-6 us of this thread,
             // and 56 of the 64 address rounds of a 64-bit lookup (all of them in its pure phases) launch nothing
-            if ((round & 7) == 7 && P.next_enqueue_launched != queried_at) { (void)hipStreamQuery(g.stream); queried_at = P.next_enqueue_launched; }
-            prev = eval_with_challenge(c, H::challenge_to_fr(lo, hi, g.challenge_mode));
+            if ((round & 7) == 7 && P.next_enqueue_launched != queried_at) { (void)hipStreamQuery(rt().stream); queried_at = P.next_enqueue_launched; }
+            prev = eval_with_challenge(c, H::challenge_to_fr(lo, hi, rt().challenge_mode));
             const auto q3 = nowp();
             { PROF("instance_prove: host_ingest"); rc = inst->host_ingest(challenges[round], round); }
             const auto q4 = nowp();
             if (!rc) { PROF("instance_prove: advance (enqueue)"); rc = P.advance(round + 1); }
-            if (rc) { P.abort_from(round + 1); (void)hipStreamSynchronize(g.stream); return rc; }
+            if (rc) { P.abort_from(round + 1); (void)hipStreamSynchronize(rt().stream); return rc; }
             if (ptrace) {
                 const auto q5 = nowp(); tp[0] += usp(q0, q1); tp[1] += usp(q1, q2); tp[2] += usp(q2, q3); tp[3] += usp(q3, q4); tp[4] += usp(q4, q5);
                 static const bool per_round = getenv("ATLAS_TRACE_ROUNDS") != nullptr;
@@ -409,7 +409,7 @@ int atlas_instance_prove(atlas_instance_t inst, const atlas_fr_t* input_claim, a
         uint64_t lo, hi;
         H::tr_challenge_u128(T, lo, hi);
         challenges[round].lo = lo; challenges[round].hi = hi;
-        prev = eval_with_challenge(c, H::challenge_to_fr(lo, hi, g.challenge_mode));
+        prev = eval_with_challenge(c, H::challenge_to_fr(lo, hi, rt().challenge_mode));
         const auto t2 = now();
         rc = inst->ingest(challenges[round], round);
         if (rc) return rc;
@@ -451,7 +451,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         for (auto& I : b->inst) v.push_back(I.inst);
         piped = all_pipelined(v);
     }
-    std::unique_lock<atlas_rt::Mutex> pipe_lock(g.mu, std::defer_lock);
+    std::unique_lock<atlas_rt::Mutex> pipe_lock(rt().mu, std::defer_lock);
     if (piped) {
         pipe_lock.lock();
         for (auto& I : b->inst) PL.lanes.push_back(Lane{I.inst, I.rounds, 0, {}, {}});
@@ -473,6 +473,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
     double tt[6] = {0, 0, 0, 0, 0, 0};                   // ATLAS_TRACE: message serial / parallel, combine + transcript, claim update, ingest serial / parallel
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    atlas_rt::Runtime* const rt_owner = atlas_rt::g_cur;          // the pool's workers run the members' arithmetic under THIS thread's runtime
     std::vector<std::vector<H::Fr>> ht_polys(HT ? n : 0);       // the members' round polynomials: allocated once, refilled every round (thousands of members:
     std::vector<std::vector<H::Fr>> ht_partial(HT ? HT->threads() : 0);   // a vector each per round was ~0.4 M allocations per GPT-2-shaped reduction)
     for (size_t round = 0; round < max_rounds && HT; round++) {
@@ -494,14 +495,15 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
             int rc = I.inst->message(round - (max_rounds - I.rounds), claim[i], polys[i]);
             if (rc) return rc;
         }
-        if (g.pending_async) {                                   // one wait for everything the shared steps launched without waiting
-            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
-            g.pending_async = 0;
-            HIP_TRY(hipStreamSynchronize(g.stream));
+        if (rt().pending_async) {                                   // one wait for everything the shared steps launched without waiting
+            std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+            rt().pending_async = 0;
+            HIP_TRY(hipStreamSynchronize(rt().stream));
         }
         const auto q1 = tnow();
         // the members that have not started (a constant polynomial each: thousands of them in the first rounds) and the parallel ones, in ranges of [0, n)
         HT->parallel_for(n, [&](size_t lo, size_t hi, size_t part) {
+            const atlas_rt::RtScope rt_scope(rt_owner);
             for (size_t i = lo; i < hi && rcs[part] == ATLAS_OK; i++) {
                 Instance& I = b->inst[i];
                 if (remaining > I.rounds) polys[i].assign(1, mul_pow2(I.input_claim, remaining - I.rounds - 1));
@@ -514,6 +516,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         std::vector<std::vector<H::Fr>>& partial = ht_partial;
         for (auto& acc : partial) acc.clear();
         HT->parallel_for(n, [&](size_t lo, size_t hi, size_t part) {
+            const atlas_rt::RtScope rt_scope(rt_owner);
             std::vector<H::Fr>& acc = partial[part];
             H::Fr t[32];
             for (size_t i = lo; i < hi; i++) {                    // += trimmed_scale(polys[i], coeff[i]), without the temporary
@@ -546,7 +549,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         uint64_t lo64, hi64;
         H::tr_challenge_u128(T, lo64, hi64);
         challenges[round].lo = lo64; challenges[round].hi = hi64;
-        const H::Fr r = H::challenge_to_fr(lo64, hi64, g.challenge_mode);
+        const H::Fr r = H::challenge_to_fr(lo64, hi64, rt().challenge_mode);
         const auto q3 = tnow();
         HT->parallel_for(n, [&](size_t lo, size_t hi, size_t) { for (size_t i = lo; i < hi; i++) claim[i] = eval_with_challenge(polys[i], r); });
         const auto q4 = tnow();
@@ -565,6 +568,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         std::fill(rcs.begin(), rcs.end(), ATLAS_OK);
         const auto q5 = tnow();
         HT->parallel_for(n, [&](size_t lo, size_t hi, size_t part) {
+            const atlas_rt::RtScope rt_scope(rt_owner);
             for (size_t i = lo; i < hi && rcs[part] == ATLAS_OK; i++) {
                 Instance& I = b->inst[i];
                 if (remaining <= I.rounds && par[i]) rcs[part] = I.inst->ingest(challenges[round], round - (max_rounds - I.rounds));
@@ -633,7 +637,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         H::tr_challenge_u128(T, lo, hi);                                              // challenge_scalar_optimized :119
         challenges[round].lo = lo; challenges[round].hi = hi;
         if (piped) { PL.C.publish(PL.slot0 + round, PL.rtag(round), lo, hi); if ((round & 7) == 7 && PL.next_enqueue_launched != batch_queried_at) { PL.query(); batch_queried_at = PL.next_enqueue_launched; } }
-        const H::Fr r = H::challenge_to_fr(lo, hi, g.challenge_mode);
+        const H::Fr r = H::challenge_to_fr(lo, hi, rt().challenge_mode);
         const double pf2 = atlas_rt::Prof::on() ? atlas_rt::Prof::now_us() : 0;
         for (size_t i = 0; i < n; i++) claim[i] = eval_with_challenge(polys[i], r);    // :123-126
         if (atlas_rt::Prof::on()) {

@@ -146,9 +146,14 @@ struct DevPool {
     }
 };
 
-inline DevPool& dev_pool() {
-    static DevPool* p = new DevPool();            // never destroyed: the HIP runtime may be gone at static-destruction time
-    return *p;
+inline DevPool& dev_pool() {                      // the calling thread's runtime's pool; never destroyed: the HIP runtime may be gone at static-destruction time
+    Runtime& R = rt();
+    if (!R.pool) {
+        static std::mutex create_mu;
+        std::lock_guard<std::mutex> lk(create_mu);
+        if (!R.pool) R.pool = new DevPool();
+    }
+    return *R.pool;
 }
 
 template <class T>

@@ -21,7 +21,7 @@
 
 using namespace atlas;
 using atlas_rt::fail;
-using atlas_rt::g;
+using atlas_rt::rt;
 
 namespace {
 
@@ -223,11 +223,11 @@ int atlas_fold_i32_rows(const int32_t* d_matrix, size_t rows, size_t cols, atlas
     NEED_INIT();
     if (!d_matrix || !eq || !out || !is_pow2(rows) || cols == 0) return fail(ATLAS_EINVAL, "fold_i32_rows: rows must be a power of two");
     if (eq->is_i32 || eq->len != cols) return fail(ATLAS_EINVAL, "fold_i32_rows: eq table length != cols");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     int rc = make_poly(rows, out);
     if (rc) return rc;
-    k_fold_rows<<<(unsigned)rows, FOLD_THREADS, 0, g.stream>>>(d_matrix, (const Fe*)eq->d, cols, (Fe*)(*out)->d);
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    k_fold_rows<<<(unsigned)rows, FOLD_THREADS, 0, rt().stream>>>(d_matrix, (const Fe*)eq->d, cols, (Fe*)(*out)->d);
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     return ATLAS_OK;
 }
 
@@ -235,7 +235,7 @@ int atlas_fold_i32_cols(const int32_t* d_matrix, size_t rows, size_t cols, atlas
     NEED_INIT();
     if (!d_matrix || !eq || !out || !is_pow2(cols) || rows == 0) return fail(ATLAS_EINVAL, "fold_i32_cols: cols must be a power of two");
     if (eq->is_i32 || eq->len != rows) return fail(ATLAS_EINVAL, "fold_i32_cols: eq table length != rows");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     int rc = make_poly(cols, out);
     if (rc) return rc;
     // split the rows into slabs so that ~2048 workgroups are in flight
@@ -247,10 +247,10 @@ int atlas_fold_i32_cols(const int32_t* d_matrix, size_t rows, size_t cols, atlas
     n_slabs = (rows + rows_per_slab - 1) / rows_per_slab;
     Fe* partial = nullptr;
     HIP_TRY(hipMalloc(&partial, n_slabs * cols * sizeof(Fe)));
-    k_fold_cols<<<dim3((unsigned)col_blocks, (unsigned)n_slabs), FOLD_THREADS, 0, g.stream>>>(
+    k_fold_cols<<<dim3((unsigned)col_blocks, (unsigned)n_slabs), FOLD_THREADS, 0, rt().stream>>>(
         d_matrix, (const Fe*)eq->d, rows, cols, rows_per_slab, partial);
-    k_fold_cols_finish<<<(unsigned)col_blocks, FOLD_THREADS, 0, g.stream>>>(partial, cols, n_slabs, (Fe*)(*out)->d);
-    hipError_t e = hipStreamSynchronize(g.stream);
+    k_fold_cols_finish<<<(unsigned)col_blocks, FOLD_THREADS, 0, rt().stream>>>(partial, cols, n_slabs, (Fe*)(*out)->d);
+    hipError_t e = hipStreamSynchronize(rt().stream);
     hipFree(partial);
     if (e != hipSuccess) return fail(ATLAS_ENODEV, "fold_i32_cols", e);
     return ATLAS_OK;
@@ -262,11 +262,11 @@ int atlas_fold_i32_rows_batched(const int32_t* d_matrix, size_t n0, size_t n1, s
     if (!d_matrix || !eq || !out || n0 == 0 || n1 == 0 || R == 0 || !is_pow2(n0 * n1)) return fail(ATLAS_EINVAL, "fold_i32_rows_batched: n0*n1 must be a power of two");
     if (eq->is_i32 || eq->len != R) return fail(ATLAS_EINVAL, "fold_i32_rows_batched: eq table length != R");
     if ((n0 - 1) * t0 + (n1 - 1) * t1 >= n0 * n1) return fail(ATLAS_EINVAL, "fold_i32_rows_batched: output strides leave the n0*n1 range");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     int rc = make_poly(n0 * n1, out);
     if (rc) return rc;
-    k_fold_rows_batched<<<(unsigned)(n0 * n1), FOLD_THREADS, 0, g.stream>>>(d_matrix, (const Fe*)eq->d, n1, s0, s1, R, t0, t1, (Fe*)(*out)->d);
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    k_fold_rows_batched<<<(unsigned)(n0 * n1), FOLD_THREADS, 0, rt().stream>>>(d_matrix, (const Fe*)eq->d, n1, s0, s1, R, t0, t1, (Fe*)(*out)->d);
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     return ATLAS_OK;
 }
 
@@ -276,12 +276,12 @@ int atlas_fold_i32_cols_batched(const int32_t* d_matrix, size_t B, size_t sB, si
     if (!d_matrix || !eq || !out || B == 0 || C == 0 || R == 0 || !is_pow2(B * C)) return fail(ATLAS_EINVAL, "fold_i32_cols_batched: B*C must be a power of two");
     if (eq->is_i32 || eq->len != R) return fail(ATLAS_EINVAL, "fold_i32_cols_batched: eq table length != R");
     if ((B - 1) * tB + (C - 1) * tC >= B * C) return fail(ATLAS_EINVAL, "fold_i32_cols_batched: output strides leave the B*C range");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     int rc = make_poly(B * C, out);
     if (rc) return rc;
-    k_fold_cols_batched<<<dim3((unsigned)((C + FOLD_THREADS - 1) / FOLD_THREADS), (unsigned)B), FOLD_THREADS, 0, g.stream>>>(
+    k_fold_cols_batched<<<dim3((unsigned)((C + FOLD_THREADS - 1) / FOLD_THREADS), (unsigned)B), FOLD_THREADS, 0, rt().stream>>>(
         d_matrix, (const Fe*)eq->d, sB, R, sR, C, tB, tC, 1, 0, 0, (Fe*)(*out)->d);
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     return ATLAS_OK;
 }
 
@@ -291,12 +291,12 @@ int atlas_fold_i32_cols_batched2(const int32_t* d_matrix, size_t B0, size_t sB0,
     if (!d_matrix || !eq || !out || B0 == 0 || B1 == 0 || C == 0 || R == 0 || !is_pow2(B0 * B1 * C)) return fail(ATLAS_EINVAL, "fold_i32_cols_batched2: B0*B1*C must be a power of two");
     if (eq->is_i32 || eq->len != R) return fail(ATLAS_EINVAL, "fold_i32_cols_batched2: eq table length != R");
     if ((B0 - 1) * tB0 + (B1 - 1) * tB1 + (C - 1) * tC >= B0 * B1 * C) return fail(ATLAS_EINVAL, "fold_i32_cols_batched2: output strides leave the output range");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     int rc = make_poly(B0 * B1 * C, out);
     if (rc) return rc;
-    k_fold_cols_batched<<<dim3((unsigned)((C + FOLD_THREADS - 1) / FOLD_THREADS), (unsigned)(B0 * B1)), FOLD_THREADS, 0, g.stream>>>(
+    k_fold_cols_batched<<<dim3((unsigned)((C + FOLD_THREADS - 1) / FOLD_THREADS), (unsigned)(B0 * B1)), FOLD_THREADS, 0, rt().stream>>>(
         d_matrix, (const Fe*)eq->d, sB0, R, sR, C, tB0, tC, B1, sB1, tB1, (Fe*)(*out)->d);
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     return ATLAS_OK;
 }
 
@@ -315,13 +315,13 @@ int atlas_poly_repeat_rows(atlas_poly_t base, size_t rows, size_t row_len, size_
     NEED_INIT();
     if (!base || !out || base->is_i32 || base->len != rows * row_len || repeat == 0 || !is_pow2(rows * row_len * repeat))
         return fail(ATLAS_EINVAL, "poly_repeat_rows: base must hold rows*row_len Fr and the output length be a power of two");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     int rc = make_poly(rows * row_len * repeat, out);
     if (rc) return rc;
     const size_t total = rows * row_len * repeat;
     size_t gb = (total + FOLD_THREADS - 1) / FOLD_THREADS; if (gb > 4096) gb = 4096;
-    k_repeat_rows<<<(unsigned)gb, FOLD_THREADS, 0, g.stream>>>((const Fe*)base->d, rows, row_len, repeat, (Fe*)(*out)->d);
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    k_repeat_rows<<<(unsigned)gb, FOLD_THREADS, 0, rt().stream>>>((const Fe*)base->d, rows, row_len, repeat, (Fe*)(*out)->d);
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     return ATLAS_OK;
 }
 
@@ -400,8 +400,8 @@ int atlas_i32_upload(const int32_t* host, size_t n, int32_t** d_out) {
     int32_t* d = nullptr;
     hipError_t e = hipMalloc(&d, n * sizeof(int32_t));
     if (e != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(i32)", e);
-    HIP_TRY(hipMemcpyAsync(d, host, n * sizeof(int32_t), hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(d, host, n * sizeof(int32_t), hipMemcpyHostToDevice, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     *d_out = d;
     return ATLAS_OK;
 }

@@ -202,13 +202,13 @@ struct Elementwise : atlas_instance {
     // instance contributes to the round (atlas_elementwise_prove_sharded)
     int local_sums(size_t round, H::Fr* s) {
         if (round != round_next || round >= n_vars) return fail(ATLAS_ESTATE, "elementwise: round out of order");
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
         const size_t n_groups = rows.len / 2;
         size_t blocks = (n_groups + RA_THREADS - 1) / RA_THREADS; if (blocks > 1024) blocks = 1024;
         const SplitEqView E = ew_has_eq(op) ? eq.view() : SplitEqView{nullptr, nullptr, 0};
         const Fr* src = rows.buf[rows.cur]; const size_t st = rows.stride[rows.cur];
         switch (op) {
-#define EW_CASE(OP) case OP: k_ew_fold<OP><<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(src, st, E, n_groups, consts, rows.partials); break;
+#define EW_CASE(OP) case OP: k_ew_fold<OP><<<(unsigned)blocks, RA_THREADS, 0, rt().stream>>>(src, st, E, n_groups, consts, rows.partials); break;
             EW_CASE(EW_ADD) EW_CASE(EW_SUB) EW_CASE(EW_NEG) EW_CASE(EW_SQUARE) EW_CASE(EW_IFF) EW_CASE(EW_MUL) EW_CASE(EW_CUBE) EW_CASE(EW_DIV) EW_CASE(EW_RSQRT) EW_CASE(EW_DOT) EW_CASE(EW_GATHER) EW_CASE(EW_HAMMING_BOOL) EW_CASE(EW_TELEPORT_DIV)
 #undef EW_CASE
             default: return fail(ATLAS_EINVAL, "elementwise: unknown operator");
@@ -217,17 +217,17 @@ struct Elementwise : atlas_instance {
     }
     int ingest(const atlas_u128_t& r, size_t round) override {
         if (round != round_next || round >= n_vars) return fail(ATLAS_ESTATE, "elementwise: round out of order");
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
         int rc = rows.bind(r);
         if (rc) return rc;
-        if (ew_has_eq(op)) eq.st.bind(H::challenge_to_fr(r.lo, r.hi, g.challenge_mode));
+        if (ew_has_eq(op)) eq.st.bind(H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode));
         round_next++;
         return ATLAS_OK;
     }
     int finals(std::vector<H::Fr>& out) override {
         if (round_next != n_vars) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
         if (have_finals) { out = mailed_finals; return ATLAS_OK; }
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
         return rows.finals(out);
     }
 
@@ -247,10 +247,10 @@ struct Elementwise : atlas_instance {
         const Fr* src = bind_prev ? rows.buf[(round - 1) & 1] : rows.buf[0];
         const size_t sst = bind_prev ? (T >> (round - 1)) : T;
         Fr* dst = rows.buf[round & 1];
-        const ChanIo cio{io, g.challenge_mode};
-        const int hi = g.challenge_mode == 0 ? 1 : 0;
+        const ChanIo cio{io, rt().challenge_mode};
+        const int hi = rt().challenge_mode == 0 ? 1 : 0;
         switch (op) {
-#define EW_CASE(OP) case OP: k_ew_fold_ch<OP><<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(src, sst, dst, len, E, n_groups, consts, cio, bind_prev ? 1 : 0, hi); break;
+#define EW_CASE(OP) case OP: k_ew_fold_ch<OP><<<(unsigned)blocks, RA_THREADS, 0, rt().stream>>>(src, sst, dst, len, E, n_groups, consts, cio, bind_prev ? 1 : 0, hi); break;
             EW_CASE(EW_ADD) EW_CASE(EW_SUB) EW_CASE(EW_NEG) EW_CASE(EW_SQUARE) EW_CASE(EW_IFF) EW_CASE(EW_MUL) EW_CASE(EW_CUBE) EW_CASE(EW_DIV) EW_CASE(EW_RSQRT) EW_CASE(EW_DOT) EW_CASE(EW_GATHER) EW_CASE(EW_HAMMING_BOOL) EW_CASE(EW_TELEPORT_DIV)
 #undef EW_CASE
             default: return fail(ATLAS_EINVAL, "elementwise: unknown operator");
@@ -282,7 +282,7 @@ struct Elementwise : atlas_instance {
     }
     int host_ingest(const atlas_u128_t& r, size_t round) override {
         if (round != round_next || round >= n_vars) return fail(ATLAS_ESTATE, "elementwise: round out of order");
-        if (ew_has_eq(op)) eq.st.bind(H::challenge_to_fr(r.lo, r.hi, g.challenge_mode));
+        if (ew_has_eq(op)) eq.st.bind(H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode));
         rows.cur = (int)((round + 1) & 1); rows.len = ((size_t)1 << n_vars) >> (round + 1); rows.stride[rows.cur] = rows.len;
         round_next++;
         return ATLAS_OK;
@@ -290,7 +290,7 @@ struct Elementwise : atlas_instance {
     int enqueue_finals(const atlas::RoundIo& io, atlas_mail_ref& mail) override {
         const size_t T = (size_t)1 << n_vars;
         const Fr* src = rows.buf[(n_vars - 1) & 1];
-        k_ew_final_ch<<<1, 64, 0, g.stream>>>(src, n_vars == 1 ? T : (T >> (n_vars - 1)), (uint32_t)rows.d, ChanIo{io, g.challenge_mode}, g.challenge_mode == 0 ? 1 : 0);
+        k_ew_final_ch<<<1, 64, 0, rt().stream>>>(src, n_vars == 1 ? T : (T >> (n_vars - 1)), (uint32_t)rows.d, ChanIo{io, rt().challenge_mode}, rt().challenge_mode == 0 ? 1 : 0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(ATLAS_ENODEV, "elementwise: launch", e);
         mail.base = io.mail; mail.blocks = 1; mail.n_vals = (int)rows.d; mail.radix = 32; mail.shl = 0;
@@ -344,7 +344,7 @@ int atlas_elementwise_new(int op, const atlas_poly_t* operands, size_t n_operand
     const size_t T = (size_t)1 << n_vars;
     for (size_t i = 0; i < n_operands; i++)
         if (!operands[i] || operands[i]->len != T) return fail(ATLAS_EINVAL, "elementwise_new: operand length != 2^n_vars");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     Elementwise* P = new Elementwise();
     P->op = op; P->n_vars = n_vars;
     for (size_t i = 0; i < n_constants; i++) std::memcpy(&P->consts.k[i], &constants[i], 32);
@@ -354,8 +354,8 @@ int atlas_elementwise_new(int op, const atlas_poly_t* operands, size_t n_operand
         size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
         hipError_t e = hipSuccess;
         for (size_t i = 0; i < n_operands && e == hipSuccess; i++) {
-            if (operands[i]->is_i32) k_ew_from_i32<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>((const int32_t*)operands[i]->d, P->rows.buf[0] + i * T, T);
-            else e = hipMemcpyAsync(P->rows.buf[0] + i * T, operands[i]->d, T * sizeof(Fr), hipMemcpyDeviceToDevice, g.stream);
+            if (operands[i]->is_i32) k_ew_from_i32<<<(unsigned)gb, RA_THREADS, 0, rt().stream>>>((const int32_t*)operands[i]->d, P->rows.buf[0] + i * T, T);
+            else e = hipMemcpyAsync(P->rows.buf[0] + i * T, operands[i]->d, T * sizeof(Fr), hipMemcpyDeviceToDevice, rt().stream);
         }
         if (e != hipSuccess) rc = fail(ATLAS_ENODEV, "elementwise_new: operand copy", e);
     }
@@ -419,7 +419,7 @@ int atlas_elementwise_prove_sharded(atlas_instance_t inst, atlas_shard_group_t g
         uint64_t lo, hi;
         H::tr_challenge_u128(T, lo, hi);
         challenges[out_round].lo = lo; challenges[out_round].hi = hi;
-        const H::Fr rf = H::challenge_to_fr(lo, hi, g.challenge_mode);
+        const H::Fr rf = H::challenge_to_fr(lo, hi, rt().challenge_mode);
         H::Fr ev = c[0], pw = rf;                                             // UniPoly::evaluate
         for (size_t i = 1; i < c.size(); i++) { ev = H::add(ev, H::mul(pw, c[i])); pw = H::mul(pw, rf); }
         prev = ev;

@@ -22,7 +22,7 @@
 using namespace atlas;
 namespace H = atlas_host;
 using atlas_rt::fail;
-using atlas_rt::g;
+using atlas_rt::rt;
 
 namespace {
 
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(ER_THREADS) void k_er_reduce(const Fr* __restrict__
 int evaluate_many(atlas_poly_t mle, const std::vector<H::Fr>& points, size_t n_pts, size_t n, std::vector<H::Fr>& out) {
     const uint32_t m = (uint32_t)(n / 2), n2 = (uint32_t)(n - m);
     if (m > 13 || n2 > 13) return fail(ATLAS_EINVAL, "eval_reduction: more than 26 variables not supported");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     Fr *d_pts = nullptr, *tab1 = nullptr, *tab2 = nullptr, *part = nullptr, *d_out = nullptr;
     const size_t rows = (size_t)1 << m;
     const unsigned grid = (unsigned)(rows < 1024 ? rows : 1024);
@@ -117,18 +117,18 @@ int evaluate_many(atlas_poly_t mle, const std::vector<H::Fr>& points, size_t n_p
     if (e == hipSuccess) e = hipMalloc(&tab2, (n_pts << n2) * sizeof(Fr));
     if (e == hipSuccess) e = hipMalloc(&part, (size_t)grid * ER_GROUP * sizeof(Fr));
     if (e == hipSuccess) e = hipMalloc(&d_out, (n_pts + ER_GROUP) * sizeof(Fr));
-    if (e == hipSuccess && n) e = hipMemcpyAsync(d_pts, points.data(), n_pts * n * sizeof(Fr), hipMemcpyHostToDevice, g.stream);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(d_pts, points.data(), n_pts * n * sizeof(Fr), hipMemcpyHostToDevice, rt().stream);
     if (e != hipSuccess) { cleanup(); return fail(ATLAS_ENOMEM, "eval_reduction workspace", e); }
-    k_er_tables<<<dim3((unsigned)n_pts, 2), 1024, 0, g.stream>>>(d_pts, (uint32_t)n, m, tab1, tab2);
+    k_er_tables<<<dim3((unsigned)n_pts, 2), 1024, 0, rt().stream>>>(d_pts, (uint32_t)n, m, tab1, tab2);
     const ScConsts K = make_consts();
     for (size_t t0 = 0; t0 < n_pts; t0 += ER_GROUP) {
-        if (mle->is_i32) k_er_eval<int32_t, ER_GROUP><<<grid, ER_THREADS, 0, g.stream>>>((const int32_t*)mle->d, (uint32_t)n, m, tab1, tab2, (uint32_t)t0, (uint32_t)n_pts, part, K);
-        else k_er_eval<Fr, ER_GROUP><<<grid, ER_THREADS, 0, g.stream>>>((const Fr*)mle->d, (uint32_t)n, m, tab1, tab2, (uint32_t)t0, (uint32_t)n_pts, part, K);
-        k_er_reduce<<<ER_GROUP, ER_THREADS, 0, g.stream>>>(part, grid, ER_GROUP, d_out + t0);
+        if (mle->is_i32) k_er_eval<int32_t, ER_GROUP><<<grid, ER_THREADS, 0, rt().stream>>>((const int32_t*)mle->d, (uint32_t)n, m, tab1, tab2, (uint32_t)t0, (uint32_t)n_pts, part, K);
+        else k_er_eval<Fr, ER_GROUP><<<grid, ER_THREADS, 0, rt().stream>>>((const Fr*)mle->d, (uint32_t)n, m, tab1, tab2, (uint32_t)t0, (uint32_t)n_pts, part, K);
+        k_er_reduce<<<ER_GROUP, ER_THREADS, 0, rt().stream>>>(part, grid, ER_GROUP, d_out + t0);
     }
     out.resize(n_pts + ER_GROUP);
-    e = hipMemcpyAsync(out.data(), d_out, (n_pts + ER_GROUP) * sizeof(Fr), hipMemcpyDeviceToHost, g.stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    e = hipMemcpyAsync(out.data(), d_out, (n_pts + ER_GROUP) * sizeof(Fr), hipMemcpyDeviceToHost, rt().stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(rt().stream);
     if (e == hipSuccess) e = hipGetLastError();
     cleanup();
     if (e != hipSuccess) return fail(ATLAS_ENODEV, "eval_reduction", e);
@@ -219,7 +219,7 @@ extern "C" int atlas_eval_reduction_prove(atlas_poly_t mle, const atlas_fr_t* po
     H::tr_append_message(T, "UncompressedUniPoly_end");
     uint64_t lo, hi;
     H::tr_challenge_u128(T, lo, hi);
-    const H::Fr xp = H::challenge_to_fr(lo, hi, g.challenge_mode);
+    const H::Fr xp = H::challenge_to_fr(lo, hi, rt().challenge_mode);
     for (size_t i = 0; i < n; i++) { const H::Fr v = horner(var[i], xp); std::memcpy(&r_out[i], &v, 32); }   // eval_on_l
     const H::Fr v = horner(h, xp);
     std::memcpy(claim_out, &v, 32);
@@ -249,7 +249,7 @@ extern "C" int atlas_eval_reduction_verify(const atlas_fr_t* points, const atlas
     H::tr_append_message(T, "UncompressedUniPoly_end");
     uint64_t lo, hi;
     H::tr_challenge_u128(T, lo, hi);
-    const H::Fr xp = H::challenge_to_fr(lo, hi, g.challenge_mode);
+    const H::Fr xp = H::challenge_to_fr(lo, hi, rt().challenge_mode);
     for (size_t i = 0; i < n; i++) {                                  // eval_on_l: the per-variable interpolants through (j, points[j][i])
         std::vector<H::Fr> ev(N);
         for (size_t j = 0; j < N; j++) ev[j] = pts[j * n + i];

@@ -233,7 +233,7 @@ int atlas_rt_einsum_strides(int layout, const std::vector<size_t>& d, std::vecto
     }
 }
 
-// i64 accumulators of an Einsum node into d_acc (library stream; the caller holds g.mu)
+// i64 accumulators of an Einsum node into d_acc (library stream; the caller holds rt().mu)
 int atlas_rt_einsum_acc(const Node& nd, const int32_t* L, const int32_t* R, int64_t* d_acc) {
     std::vector<size_t> od, la, ra; size_t K, lsk, rsk;
     if (atlas_rt_einsum_strides((int)nd.p[0], nd.shape, od, la, ra, K, lsk, rsk)) return fail(ATLAS_EINVAL, "graph: einsum layout / dims");
@@ -248,12 +248,12 @@ int atlas_rt_einsum_acc(const Node& nd, const int32_t* L, const int32_t* R, int6
         uint32_t slices = 1;
         while (slices < 64 && (n * ((m + EB_ROWS - 1) / EB_ROWS)) * slices < ((size_t)1 << 16) && k / (slices * 2) >= 32) slices *= 2;
         const uint32_t k_slice = (uint32_t)((k + slices - 1) / slices);
-        HIP_TRY(hipMemsetAsync(d_acc, 0, T * 8, g.stream));
-        k_einsum_acc_mk_kn<<<dim3((unsigned)((n + 255) / 256), (unsigned)((m + EB_ROWS - 1) / EB_ROWS), slices), 256, 0, g.stream>>>(
+        HIP_TRY(hipMemsetAsync(d_acc, 0, T * 8, rt().stream));
+        k_einsum_acc_mk_kn<<<dim3((unsigned)((n + 255) / 256), (unsigned)((m + EB_ROWS - 1) / EB_ROWS), slices), 256, 0, rt().stream>>>(
             L, R, (uint32_t)m, (uint32_t)k, (uint32_t)n, k_slice, (unsigned long long*)d_acc);
         return ATLAS_OK;
     }
-    k_einsum_acc_generic<<<grid_for(T), 256, 0, g.stream>>>(L, R, S, (uint32_t)K, (uint32_t)lsk, (uint32_t)rsk, T, d_acc);
+    k_einsum_acc_generic<<<grid_for(T), 256, 0, rt().stream>>>(L, R, S, (uint32_t)K, (uint32_t)lsk, (uint32_t)rsk, T, d_acc);
     return ATLAS_OK;
 }
 
@@ -283,11 +283,11 @@ static double atlas_erf_cheb(double x) {
     return x >= 0.0 ? 1.0 - erfccheb(x) : erfccheb(-x) - 1.0;
 }
 int atlas_rt_trig_table(int op, const int32_t** d_table, const std::vector<int32_t>** h_table) {
-    static std::vector<int32_t> host[2];
-    static int32_t* dev[2] = {nullptr, nullptr};
+    static thread_local std::vector<int32_t> host[2];      // (per thread: a thread may own a runtime on a device of its own, runtime.hpp)
+    static thread_local int32_t* dev[2] = {nullptr, nullptr};
     const int k = op == ATLAS_OP_SIN ? 0 : op == ATLAS_OP_COS ? 1 : -1;
     if (k < 0) return fail(ATLAS_EINVAL, "trig_table: not Sin / Cos");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     if (host[k].empty()) {                                                    // SinTable / CosTable::materialize (neural_teleport/sin.rs:26-41)
         const size_t n = (size_t)1 << gr::TRIG_TABLE_VARS;
         const double scale = (double)((uint64_t)1 << (gr::MODEL_SCALE - gr::TRIG_DOWNSCALE_BITS));
@@ -299,21 +299,21 @@ int atlas_rt_trig_table(int op, const int32_t** d_table, const std::vector<int32
     }
     if (d_table && !dev[k]) {
         HIP_TRY(hipMalloc(&dev[k], host[k].size() * 4));
-        HIP_TRY(hipMemcpyAsync(dev[k], host[k].data(), host[k].size() * 4, hipMemcpyHostToDevice, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
-        static bool registered = false;
-        if (!registered) { registered = true; g.at_shutdown.push_back([] { for (auto& d : dev) if (d) { (void)hipFree(d); d = nullptr; } registered = false; }); }
+        HIP_TRY(hipMemcpyAsync(dev[k], host[k].data(), host[k].size() * 4, hipMemcpyHostToDevice, rt().stream));
+        HIP_TRY(hipStreamSynchronize(rt().stream));
+        static thread_local bool registered = false;
+        if (!registered) { registered = true; rt().at_shutdown.push_back([] { for (auto& d : dev) if (d) { (void)hipFree(d); d = nullptr; } registered = false; }); }
     }
     if (d_table) *d_table = dev[k];
     if (h_table) *h_table = &host[k];
     return ATLAS_OK;
 }
 int atlas_rt_activation_table(int op, const int32_t** d_table, const std::vector<int32_t>** h_table) {
-    static std::vector<int32_t> host[3];
-    static int32_t* dev[3] = {nullptr, nullptr, nullptr};
+    static thread_local std::vector<int32_t> host[3];
+    static thread_local int32_t* dev[3] = {nullptr, nullptr, nullptr};
     const int k = op == ATLAS_OP_TANH ? 0 : op == ATLAS_OP_ERF ? 1 : op == ATLAS_OP_SIGMOID ? 2 : -1;
     if (k < 0) return fail(ATLAS_EINVAL, "activation_table: not a small-table activation");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     if (host[k].empty()) {
         const size_t n = (size_t)1 << gr::ACTIVATION_TABLE_VARS;
         const double scale = (double)((uint64_t)1 << gr::MODEL_SCALE);
@@ -327,10 +327,10 @@ int atlas_rt_activation_table(int op, const int32_t** d_table, const std::vector
     }
     if (d_table && !dev[k]) {
         HIP_TRY(hipMalloc(&dev[k], host[k].size() * 4));
-        HIP_TRY(hipMemcpyAsync(dev[k], host[k].data(), host[k].size() * 4, hipMemcpyHostToDevice, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
-        static bool registered = false;
-        if (!registered) { registered = true; g.at_shutdown.push_back([] { for (auto& d : dev) if (d) { (void)hipFree(d); d = nullptr; } registered = false; }); }
+        HIP_TRY(hipMemcpyAsync(dev[k], host[k].data(), host[k].size() * 4, hipMemcpyHostToDevice, rt().stream));
+        HIP_TRY(hipStreamSynchronize(rt().stream));
+        static thread_local bool registered = false;
+        if (!registered) { registered = true; rt().at_shutdown.push_back([] { for (auto& d : dev) if (d) { (void)hipFree(d); d = nullptr; } registered = false; }); }
     }
     if (d_table) *d_table = dev[k];
     if (h_table) *h_table = &host[k];
@@ -338,9 +338,9 @@ int atlas_rt_activation_table(int op, const int32_t** d_table, const std::vector
 }
 
 int atlas_rt_exp_lut(const ExpLut** out) {
-    static ExpLut L;
-    static int32_t* dev = nullptr;
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    static thread_local ExpLut L;
+    static thread_local int32_t* dev = nullptr;
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     if (L.hi.empty()) {
         const double sf = (double)((uint64_t)1 << gr::MODEL_SCALE);
         const size_t needed = (size_t)std::ceil(sf * std::log(2.0 * sf)) + 2;                  // the flat LUT's cutoff exp(-i/S) S < 0.5
@@ -354,11 +354,11 @@ int atlas_rt_exp_lut(const ExpLut** out) {
     }
     if (!dev) {
         HIP_TRY(hipMalloc(&dev, (L.hi.size() + L.lo.size()) * 4));
-        HIP_TRY(hipMemcpyAsync(dev, L.hi.data(), L.hi.size() * 4, hipMemcpyHostToDevice, g.stream));
-        HIP_TRY(hipMemcpyAsync(dev + L.hi.size(), L.lo.data(), L.lo.size() * 4, hipMemcpyHostToDevice, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
+        HIP_TRY(hipMemcpyAsync(dev, L.hi.data(), L.hi.size() * 4, hipMemcpyHostToDevice, rt().stream));
+        HIP_TRY(hipMemcpyAsync(dev + L.hi.size(), L.lo.data(), L.lo.size() * 4, hipMemcpyHostToDevice, rt().stream));
+        HIP_TRY(hipStreamSynchronize(rt().stream));
         L.d_hi = dev; L.d_lo = dev + L.hi.size();
-        g.at_shutdown.push_back([] { if (dev) { (void)hipFree(dev); dev = nullptr; L.d_hi = L.d_lo = nullptr; } });
+        rt().at_shutdown.push_back([] { if (dev) { (void)hipFree(dev); dev = nullptr; L.d_hi = L.d_lo = nullptr; } });
     }
     *out = &L;
     return ATLAS_OK;
@@ -502,53 +502,53 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
     auto same_len = [&]() { for (size_t i = 0; i < nd.inputs.size(); i++) if (gr::padded_len(in_node(i).dims) != T) return false; return true; };
     if (nd.op != ATLAS_OP_EINSUM && nd.op != ATLAS_OP_MUL && nd.op != ATLAS_OP_SQUARE && nd.op != ATLAS_OP_CUBE) HIP_TRY(out.alloc(T * 4));
     if (T > ((size_t)1 << 26)) return fail(ATLAS_EINVAL, "graph: a node output above 2^26 elements");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     switch (nd.op) {
         case ATLAS_OP_INPUT:
-            HIP_TRY(hipMemcpyAsync(out.p, host_inputs[next_input++], T * 4, hipMemcpyHostToDevice, g.stream));
-            HIP_TRY(hipStreamSynchronize(g.stream));
+            HIP_TRY(hipMemcpyAsync(out.p, host_inputs[next_input++], T * 4, hipMemcpyHostToDevice, rt().stream));
+            HIP_TRY(hipStreamSynchronize(rt().stream));
             return ATLAS_OK;
         case ATLAS_OP_CONSTANT:
             if (nd.constant.size() != T) return fail(ATLAS_EINVAL, "graph: constant length != padded shape");
-            HIP_TRY(hipMemcpyAsync(out.p, nd.constant.data(), T * 4, hipMemcpyHostToDevice, g.stream));
-            HIP_TRY(hipStreamSynchronize(g.stream));
+            HIP_TRY(hipMemcpyAsync(out.p, nd.constant.data(), T * 4, hipMemcpyHostToDevice, rt().stream));
+            HIP_TRY(hipStreamSynchronize(rt().stream));
             return ATLAS_OK;
         case ATLAS_OP_IDENTITY: case ATLAS_OP_RESHAPE:                       // same flat order when every dimension is a power of two
             if (!need_inputs(1) || !same_len()) return fail(ATLAS_EINVAL, "graph: Identity / Reshape operand length");
-            HIP_TRY(hipMemcpyAsync(out.p, in(0), T * 4, hipMemcpyDeviceToDevice, g.stream));
+            HIP_TRY(hipMemcpyAsync(out.p, in(0), T * 4, hipMemcpyDeviceToDevice, rt().stream));
             return ATLAS_OK;
         case ATLAS_OP_ADD: case ATLAS_OP_SUB: {                               // sat_binop (ops/mod.rs:263-274) + the clamp lookup's witness
             if (!need_inputs(2) || !same_len()) return fail(ATLAS_EINVAL, "graph: Add / Sub need two operands of the output's shape");
             NodeWitness& W = G.wit[nd.idx];
             HIP_TRY(W.acc.alloc(T * 8)); HIP_TRY(W.cidx.alloc(T * 8)); HIP_TRY(W.acc_fr.alloc(T * sizeof(Fr)));
-            k_addsub_witness<<<grid_for(T), 256, 0, g.stream>>>(in(0), in(1), T, nd.op == ATLAS_OP_SUB, W.acc.as<int64_t>(), out.as<int32_t>(), W.cidx.as<uint64_t>());
-            k_i64_to_fr<<<grid_for(T), 256, 0, g.stream>>>(W.acc.as<int64_t>(), W.acc_fr.as<Fr>(), T);
+            k_addsub_witness<<<grid_for(T), 256, 0, rt().stream>>>(in(0), in(1), T, nd.op == ATLAS_OP_SUB, W.acc.as<int64_t>(), out.as<int32_t>(), W.cidx.as<uint64_t>());
+            k_i64_to_fr<<<grid_for(T), 256, 0, rt().stream>>>(W.acc.as<int64_t>(), W.acc_fr.as<Fr>(), T);
             return ATLAS_OK;
         }
         case ATLAS_OP_AND: case ATLAS_OP_IFF:
             if (!need_inputs(nd.op == ATLAS_OP_AND ? 2 : 3) || !same_len()) return fail(ATLAS_EINVAL, "graph: And / Iff operands");
-            k_select<<<grid_for(T), 256, 0, g.stream>>>(nd.op, in(0), in(1), nd.op == ATLAS_OP_IFF ? in(2) : nullptr, T, out.as<int32_t>());
+            k_select<<<grid_for(T), 256, 0, rt().stream>>>(nd.op, in(0), in(1), nd.op == ATLAS_OP_IFF ? in(2) : nullptr, T, out.as<int32_t>());
             return ATLAS_OK;
         case ATLAS_OP_RELU: {
             if (!need_inputs(1) || !same_len()) return fail(ATLAS_EINVAL, "graph: ReLU operand");
             NodeWitness& W = G.wit[nd.idx];
             HIP_TRY(W.lookups.alloc(T * 8));
-            k_relu_witness<<<grid_for(T), 256, 0, g.stream>>>(in(0), T, out.as<int32_t>(), W.lookups.as<uint64_t>());
+            k_relu_witness<<<grid_for(T), 256, 0, rt().stream>>>(in(0), T, out.as<int32_t>(), W.lookups.as<uint64_t>());
             return ATLAS_OK;
         }
         case ATLAS_OP_NEG:                                                    // ops/neg.rs of the tracer (wrapping, like i32 negation in release builds)
             if (!need_inputs(1) || !same_len()) return fail(ATLAS_EINVAL, "graph: Neg operand");
-            k_neg<<<grid_for(T), 256, 0, g.stream>>>(in(0), T, out.as<int32_t>());
+            k_neg<<<grid_for(T), 256, 0, rt().stream>>>(in(0), T, out.as<int32_t>());
             return ATLAS_OK;
         case ATLAS_OP_IS_NAN:                                                 // quantised tensors hold no NaN: all zeros
             if (!need_inputs(1) || !same_len()) return fail(ATLAS_EINVAL, "graph: IsNan operand");
-            HIP_TRY(hipMemsetAsync(out.p, 0, T * 4, g.stream));
+            HIP_TRY(hipMemsetAsync(out.p, 0, T * 4, rt().stream));
             return ATLAS_OK;
         case ATLAS_OP_CLAMP: {
             if (!need_inputs(1) || !same_len() || nd.p[0] != (int64_t)gr::CLAMP_BOUND) return fail(ATLAS_EINVAL, "graph: Clamp needs one operand and bound_log = CLAMP_BOUND (9): the prover's table is compiled for it");
             NodeWitness& W = G.wit[nd.idx];
             HIP_TRY(W.lookups.alloc(T * 8));
-            k_clamp_witness<<<grid_for(T), 256, 0, g.stream>>>(in(0), T, (int32_t)1 << gr::CLAMP_BOUND, out.as<int32_t>(), W.lookups.as<uint64_t>());
+            k_clamp_witness<<<grid_for(T), 256, 0, rt().stream>>>(in(0), T, (int32_t)1 << gr::CLAMP_BOUND, out.as<int32_t>(), W.lookups.as<uint64_t>());
             return ATLAS_OK;
         }
         case ATLAS_OP_MOVEAXIS: case ATLAS_OP_BROADCAST: case ATLAS_OP_SLICE: {
@@ -581,7 +581,7 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
                 for (size_t a = 0; a < idims.size(); a++) S.a[a] = (uint32_t)istr[a];
                 base = st * istr[ax];
             }
-            k_gather_strided<<<grid_for(T), 256, 0, g.stream>>>(in(0), S, base, T, out.as<int32_t>());
+            k_gather_strided<<<grid_for(T), 256, 0, rt().stream>>>(in(0), S, base, T, out.as<int32_t>());
             return ATLAS_OK;
         }
         case ATLAS_OP_CONCAT: {                                               // tensor::ops::concat along p[0] (atlas-onnx-tracer/src/tensor/ops.rs:2772)
@@ -596,7 +596,7 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
                 Strides S{}; S.n = (uint32_t)r;
                 for (size_t a = 0; a < r; a++) { S.dim[a] = (uint32_t)idims[a]; S.a[a] = (uint32_t)ostr[a]; }
                 const size_t Ti = gr::padded_len(idims);
-                k_scatter_strided<<<grid_for(Ti), 256, 0, g.stream>>>(in(k), S, off * ostr[ax], Ti, out.as<int32_t>());
+                k_scatter_strided<<<grid_for(Ti), 256, 0, rt().stream>>>(in(k), S, off * ostr[ax], Ti, out.as<int32_t>());
                 off += idims[ax];
             }
             if (off != nd.dims[ax]) return fail(ATLAS_EINVAL, "graph: Concat output axis dimension must equal the sum of the operands'");
@@ -611,8 +611,8 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
             W.rescale.reset(new RescaleWitness());
             auto fill = [&](int64_t* d_acc) -> int {
                 if (nd.op == ATLAS_OP_EINSUM) return atlas_rt_einsum_acc(nd, in(0), in(1), d_acc);
-                if (nd.op == ATLAS_OP_CUBE) k_cube_acc<<<grid_for(T), 256, 0, g.stream>>>(in(0), T, d_acc);
-                else k_mul_acc<<<grid_for(T), 256, 0, g.stream>>>(in(0), nd.op == ATLAS_OP_SQUARE ? in(0) : in(1), T, d_acc);
+                if (nd.op == ATLAS_OP_CUBE) k_cube_acc<<<grid_for(T), 256, 0, rt().stream>>>(in(0), T, d_acc);
+                else k_mul_acc<<<grid_for(T), 256, 0, rt().stream>>>(in(0), nd.op == ATLAS_OP_SQUARE ? in(0) : in(1), T, d_acc);
                 return ATLAS_OK;
             };
             int rc = make_rescale_witness(T, S, fill, nullptr, *W.rescale);
@@ -628,9 +628,9 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
             if (T != (axis == 0 ? n : m)) return fail(ATLAS_EINVAL, "graph: Sum output dims");
             NodeWitness& W = G.wit[nd.idx];
             HIP_TRY(W.acc.alloc(T * 8)); HIP_TRY(W.cidx.alloc(T * 8)); HIP_TRY(W.acc_fr.alloc(T * sizeof(Fr)));
-            k_sum_axis<<<grid_for(T), 256, 0, g.stream>>>(in(0), (uint32_t)m, (uint32_t)n, axis, 0, W.acc.as<int64_t>());
-            k_clamp_acc<<<grid_for(T), 256, 0, g.stream>>>(W.acc.as<int64_t>(), T, out.as<int32_t>(), W.cidx.as<uint64_t>());
-            k_i64_to_fr<<<grid_for(T), 256, 0, g.stream>>>(W.acc.as<int64_t>(), W.acc_fr.as<Fr>(), T);
+            k_sum_axis<<<grid_for(T), 256, 0, rt().stream>>>(in(0), (uint32_t)m, (uint32_t)n, axis, 0, W.acc.as<int64_t>());
+            k_clamp_acc<<<grid_for(T), 256, 0, rt().stream>>>(W.acc.as<int64_t>(), T, out.as<int32_t>(), W.cidx.as<uint64_t>());
+            k_i64_to_fr<<<grid_for(T), 256, 0, rt().stream>>>(W.acc.as<int64_t>(), W.acc_fr.as<Fr>(), T);
             return ATLAS_OK;
         }
         case ATLAS_OP_SCALAR_CONST_DIV: case ATLAS_OP_DIV: {
@@ -639,7 +639,7 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
             if (sc && nd.p[0] == 0) return fail(ATLAS_EINVAL, "graph: ScalarConstDiv by zero");
             NodeWitness& W = G.wit[nd.idx];
             HIP_TRY(W.rem.alloc(T * 4));
-            k_floor_div<<<grid_for(T), 256, 0, g.stream>>>(in(0), sc ? nullptr : in(1), (int32_t)nd.p[0], T, out.as<int32_t>(), W.rem.as<int32_t>());
+            k_floor_div<<<grid_for(T), 256, 0, rt().stream>>>(in(0), sc ? nullptr : in(1), (int32_t)nd.p[0], T, out.as<int32_t>(), W.rem.as<int32_t>());
             if (!sc) { uint64_t* lk2 = nullptr; int rc = atlas_lookup_indices_from_operands(W.rem.as<int32_t>(), in(1), T, &lk2); if (rc) return rc; W.lookups.p = lk2; }   // interleave(R, divisor)
             return ATLAS_OK;
         }
@@ -653,9 +653,9 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
             RescaleWitness& R = *W.rescale;
             R.T = T; R.S = 0;
             HIP_TRY(R.quot.alloc(T * 8)); HIP_TRY(R.rem.alloc(T * 4)); HIP_TRY(R.cidx.alloc(T * 8)); HIP_TRY(R.qfr.alloc(T * sizeof(Fr))); HIP_TRY(W.bound.alloc(T * 4));
-            k_sum_axis<<<grid_for(T), 256, 0, g.stream>>>(in(0), (uint32_t)K, (uint32_t)N, 1, 1, R.quot.as<int64_t>());
-            k_mos_rebase<<<grid_for(T), 256, 0, g.stream>>>(R.quot.as<int64_t>(), T, D, R.rem.as<int32_t>(), out.as<int32_t>(), R.cidx.as<uint64_t>(), W.bound.as<int32_t>());
-            k_i64_to_fr<<<grid_for(T), 256, 0, g.stream>>>(R.quot.as<int64_t>(), R.qfr.as<Fr>(), T);
+            k_sum_axis<<<grid_for(T), 256, 0, rt().stream>>>(in(0), (uint32_t)K, (uint32_t)N, 1, 1, R.quot.as<int64_t>());
+            k_mos_rebase<<<grid_for(T), 256, 0, rt().stream>>>(R.quot.as<int64_t>(), T, D, R.rem.as<int32_t>(), out.as<int32_t>(), R.cidx.as<uint64_t>(), W.bound.as<int32_t>());
+            k_i64_to_fr<<<grid_for(T), 256, 0, rt().stream>>>(R.quot.as<int64_t>(), R.qfr.as<Fr>(), T);
             R.d_output = out.as<int32_t>();
             { uint64_t* lk2 = nullptr; int rc = atlas_lookup_indices_from_operands(R.rem.as<int32_t>(), W.bound.as<int32_t>(), T, &lk2); if (rc) return rc; W.lookups.p = lk2; }
             return ATLAS_OK;
@@ -665,9 +665,9 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
             NodeWitness& W = G.wit[nd.idx];
             DevBuf q64;
             HIP_TRY(q64.alloc(T * 8)); HIP_TRY(W.quot_fr.alloc(T * sizeof(Fr))); HIP_TRY(W.rem.alloc(T * 4)); HIP_TRY(W.rem2.alloc(T * 4)); HIP_TRY(W.bound.alloc(T * 4));
-            k_rsqrt<<<grid_for(T), 256, 0, g.stream>>>(in(0), T, (int64_t)1 << (3 * nd.p[0]), out.as<int32_t>(), q64.as<int64_t>(), W.rem.as<int32_t>(), W.rem2.as<int32_t>(), W.bound.as<int32_t>());
-            k_i64_to_fr<<<grid_for(T), 256, 0, g.stream>>>(q64.as<int64_t>(), W.quot_fr.as<Fr>(), T);
-            HIP_TRY(hipStreamSynchronize(g.stream));                          // q64 leaves scope
+            k_rsqrt<<<grid_for(T), 256, 0, rt().stream>>>(in(0), T, (int64_t)1 << (3 * nd.p[0]), out.as<int32_t>(), q64.as<int64_t>(), W.rem.as<int32_t>(), W.rem2.as<int32_t>(), W.bound.as<int32_t>());
+            k_i64_to_fr<<<grid_for(T), 256, 0, rt().stream>>>(q64.as<int64_t>(), W.quot_fr.as<Fr>(), T);
+            HIP_TRY(hipStreamSynchronize(rt().stream));                          // q64 leaves scope
             { uint64_t* lk2 = nullptr; int rc = atlas_lookup_indices_from_operands(W.rem.as<int32_t>(), in(0), T, &lk2); if (rc) return rc; W.lookups.p = lk2; }
             { uint64_t* lk2 = nullptr; int rc = atlas_lookup_indices_from_operands(W.rem2.as<int32_t>(), W.bound.as<int32_t>(), T, &lk2); if (rc) return rc; W.lookups2.p = lk2; }
             return ATLAS_OK;
@@ -678,7 +678,7 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
             if (int rc = atlas_rt_activation_table(nd.op, &d_table, nullptr)) return rc;
             NodeWitness& W = G.wit[nd.idx];
             HIP_TRY(W.clamped.alloc(T * 4)); HIP_TRY(W.lookups.alloc(T * 8)); HIP_TRY(W.lookups2.alloc(T * 8));
-            k_tanh<<<grid_for(T), 256, 0, g.stream>>>(in(0), T, (uint32_t)gr::ACTIVATION_BOUND, d_table, out.as<int32_t>(), W.clamped.as<int32_t>(), W.lookups2.as<uint64_t>(), W.lookups.as<uint64_t>());
+            k_tanh<<<grid_for(T), 256, 0, rt().stream>>>(in(0), T, (uint32_t)gr::ACTIVATION_BOUND, d_table, out.as<int32_t>(), W.clamped.as<int32_t>(), W.lookups2.as<uint64_t>(), W.lookups.as<uint64_t>());
             return ATLAS_OK;
         }
         case ATLAS_OP_SIN: case ATLAS_OP_COS: {
@@ -690,9 +690,9 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
             // lookup), lookups2 = the table index, cidx = interleave(remainder, tau) (the range check)
             HIP_TRY(W.rem.alloc(T * 4)); HIP_TRY(W.rem2.alloc(T * 4)); HIP_TRY(W.clamped.alloc(T * 4)); HIP_TRY(W.bound.alloc(T * 4));
             HIP_TRY(W.lookups.alloc(T * 8)); HIP_TRY(W.lookups2.alloc(T * 8));
-            k_trig<<<grid_for(T), 256, 0, g.stream>>>(in(0), T, (int32_t)gr::TRIG_PERIOD_MODULUS, (uint32_t)gr::TRIG_DOWNSCALE_BITS, d_table, out.as<int32_t>(), W.rem2.as<int32_t>(),
+            k_trig<<<grid_for(T), 256, 0, rt().stream>>>(in(0), T, (int32_t)gr::TRIG_PERIOD_MODULUS, (uint32_t)gr::TRIG_DOWNSCALE_BITS, d_table, out.as<int32_t>(), W.rem2.as<int32_t>(),
                                                       W.rem.as<int32_t>(), W.clamped.as<int32_t>(), W.lookups.as<uint64_t>(), W.lookups2.as<uint64_t>());
-            k_fill_i32<<<grid_for(T), 256, 0, g.stream>>>(W.bound.as<int32_t>(), T, (int32_t)gr::TRIG_PERIOD_MODULUS);
+            k_fill_i32<<<grid_for(T), 256, 0, rt().stream>>>(W.bound.as<int32_t>(), T, (int32_t)gr::TRIG_PERIOD_MODULUS);
             { uint64_t* lk2 = nullptr; int rc = atlas_lookup_indices_from_operands(W.rem.as<int32_t>(), W.bound.as<int32_t>(), T, &lk2); if (rc) return rc; W.cidx.p = lk2; }
             return ATLAS_OK;
         }
@@ -703,7 +703,7 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
             if (nd.op == ATLAS_OP_GATHER_SMALL && (V > 65536 || V < 2)) return fail(ATLAS_EINVAL, "graph: GatherSmall is the tracer's choice for dictionaries of at most 2^16 words (handlers/index.rs:33-45)");
             NodeWitness& W = G.wit[nd.idx];
             HIP_TRY(W.lookups.alloc(N * 8));
-            k_gather_rows<<<grid_for(T), 256, 0, g.stream>>>(in(0), in(1), N, word, out.as<int32_t>(), W.lookups.as<uint64_t>());
+            k_gather_rows<<<grid_for(T), 256, 0, rt().stream>>>(in(0), in(1), N, word, out.as<int32_t>(), W.lookups.as<uint64_t>());
             return ATLAS_OK;
         }
         case ATLAS_OP_SOFTMAX: {                                              // SoftmaxLastAxis { scale }: rows = the leading dimensions, N = the last one
@@ -724,7 +724,7 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
                          Sm.z.as<int32_t>(), Sm.z_hi.as<int32_t>(), Sm.z_lo.as<int32_t>(), Sm.e.as<int32_t>(), Sm.max_k.as<int32_t>(), Sm.argmax_k.as<int32_t>(),
                          Sm.exp_sum.as<int32_t>(), Sm.inv_sum.as<int32_t>(), Sm.idx_R.as<uint64_t>(), Sm.idx_rexp.as<uint64_t>(), Sm.idx_z.as<uint64_t>(),
                          Sm.idx_zhi.as<uint64_t>(), Sm.idx_zlo.as<uint64_t>()};
-            k_softmax_rows<<<(unsigned)F, 256, 0, g.stream>>>(in(0), (uint32_t)N, (int32_t)1 << gr::MODEL_SCALE, (uint32_t)L->log2_base,
+            k_softmax_rows<<<(unsigned)F, 256, 0, rt().stream>>>(in(0), (uint32_t)N, (int32_t)1 << gr::MODEL_SCALE, (uint32_t)L->log2_base,
                                                              (int32_t)(L->hi.size() << L->log2_base), L->d_hi, L->d_lo, O);
             return ATLAS_OK;
         }
@@ -797,9 +797,9 @@ int atlas_graph_node_output(atlas_graph_t G, size_t idx, int32_t* host_out, size
     *len = gr::padded_len(it->second.dims);
     if (!host_out) return ATLAS_OK;
     if (cap < *len) return fail(ATLAS_EINVAL, "graph_node_output: buffer too small");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
-    HIP_TRY(hipMemcpyAsync(host_out, G->tensor(idx), *len * 4, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+    HIP_TRY(hipMemcpyAsync(host_out, G->tensor(idx), *len * 4, hipMemcpyDeviceToHost, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     return ATLAS_OK;
 }
 

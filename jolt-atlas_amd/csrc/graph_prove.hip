@@ -155,16 +155,16 @@ struct Prover : FlowSink {
     }
     // the one value of a one-coefficient Fr polynomial in HBM
     int scalar_fr_of(const void* d_fr, H::Fr* out_) {
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
-        HIP_TRY(hipMemcpyAsync(out_, d_fr, sizeof(H::Fr), hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+        HIP_TRY(hipMemcpyAsync(out_, d_fr, sizeof(H::Fr), hipMemcpyDeviceToHost, rt().stream));
+        HIP_TRY(hipStreamSynchronize(rt().stream));
         return ATLAS_OK;
     }
     int scalar_of(const int32_t* d_tensor, H::Fr* out_) {
         int32_t v = 0;
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
-        HIP_TRY(hipMemcpyAsync(&v, d_tensor, 4, hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+        HIP_TRY(hipMemcpyAsync(&v, d_tensor, 4, hipMemcpyDeviceToHost, rt().stream));
+        HIP_TRY(hipStreamSynchronize(rt().stream));
         *out_ = fr_from_i64_host((int64_t)v);
         return ATLAS_OK;
     }
@@ -185,8 +185,8 @@ struct Prover : FlowSink {
             // into the joint polynomial as the K-coefficient dense row it is (same commitment g1[k], same round polynomials: both openings bind the
             // address variables HighToLow over eq(r_address, .)); the reference's generic flow at T = 1
             auto first_lookup = [&](const uint64_t* d_lookups, uint64_t* lk) {
-                std::lock_guard<atlas_rt::Mutex> lk_(g.mu);
-                if (hipMemcpyAsync(lk, d_lookups, 8, hipMemcpyDeviceToHost, g.stream) != hipSuccess || hipStreamSynchronize(g.stream) != hipSuccess) drc = fail(ATLAS_ENODEV, "prove_graph: lookup index of a one-element node");
+                std::lock_guard<atlas_rt::Mutex> lk_(rt().mu);
+                if (hipMemcpyAsync(lk, d_lookups, 8, hipMemcpyDeviceToHost, rt().stream) != hipSuccess || hipStreamSynchronize(rt().stream) != hipSuccess) drc = fail(ATLAS_ENODEV, "prove_graph: lookup index of a one-element node");
             };
             auto one_cycle_row = [&](gr::PolyId id, size_t hot, size_t width) {
                 std::vector<int32_t> row(width, 0);
@@ -195,8 +195,8 @@ struct Prover : FlowSink {
                 DevBuf& B = *W.one_cycle_rows.back();
                 if (B.alloc(width * 4) != hipSuccess) { drc = fail(ATLAS_ENOMEM, "prove_graph: one-cycle chunk row"); return; }
                 {
-                    std::lock_guard<atlas_rt::Mutex> lk_(g.mu);
-                    if (hipMemcpyAsync(B.p, row.data(), width * 4, hipMemcpyHostToDevice, g.stream) != hipSuccess || hipStreamSynchronize(g.stream) != hipSuccess) { drc = fail(ATLAS_ENODEV, "prove_graph: one-cycle chunk row"); return; }
+                    std::lock_guard<atlas_rt::Mutex> lk_(rt().mu);
+                    if (hipMemcpyAsync(B.p, row.data(), width * 4, hipMemcpyHostToDevice, rt().stream) != hipSuccess || hipStreamSynchronize(rt().stream) != hipSuccess) { drc = fail(ATLAS_ENODEV, "prove_graph: one-cycle chunk row"); return; }
                 }
                 atlas_poly_t v = nullptr;
                 drc = atlas_poly_wrap_device_i32(B.as<int32_t>(), width, &v);
@@ -377,7 +377,7 @@ struct Prover : FlowSink {
         const Node& nd = G.nodes.at(G.outputs[0]);
         const size_t T = gr::padded_len(nd.dims), n = gr::log2u(T);
         Point r(n);
-        for (size_t i = 0; i < n; i++) { uint64_t lo, hi; H::tr_challenge_u128(Tr, lo, hi); r[i] = H::challenge_to_fr(lo, hi, g.challenge_mode); }
+        for (size_t i = 0; i < n; i++) { uint64_t lo, hi; H::tr_challenge_u128(Tr, lo, hi); r[i] = H::challenge_to_fr(lo, hi, rt().challenge_mode); }
         H::Fr claim;
         const int32_t* tp = G.tensor(nd.idx);
         int rc = eval_i32(&tp, 1, T, r, &claim);
@@ -683,7 +683,7 @@ struct Prover : FlowSink {
     }
     Point challenge_point(size_t n) {
         Point r(n);
-        for (size_t i = 0; i < n; i++) { uint64_t lo, hi; H::tr_challenge_u128(Tr, lo, hi); r[i] = H::challenge_to_fr(lo, hi, g.challenge_mode); }
+        for (size_t i = 0; i < n; i++) { uint64_t lo, hi; H::tr_challenge_u128(Tr, lo, hi); r[i] = H::challenge_to_fr(lo, hi, rt().challenge_mode); }
         return r;
     }
 
@@ -763,14 +763,14 @@ struct Prover : FlowSink {
         HIP_TRY(sel.alloc(T_in * sizeof(Fr)));
         int rc = atlas_eq_evals((const atlas_fr_t*)R.point.data(), gr::log2u(T_out), nullptr, &eq);
         if (!rc) {
-            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+            std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
             SliceMap M{}; M.n = (uint32_t)nd.dims.size();
             size_t stride = 1;
             for (int a = (int)in.dims.size() - 1; a >= 0; a--) { M.dim[a] = (uint32_t)nd.dims[a]; M.stride[a] = (uint32_t)stride; stride *= in.dims[a]; }
             const size_t base = (size_t)nd.p[1] * M.stride[nd.p[0]];
-            HIP_TRY(hipMemsetAsync(sel.p, 0, T_in * sizeof(Fr), g.stream));
-            k_slice_selector<<<grid_of(T_out), 256, 0, g.stream>>>((const Fr*)eq->d, M, base, T_out, sel.as<Fr>());
-            HIP_TRY(hipStreamSynchronize(g.stream));
+            HIP_TRY(hipMemsetAsync(sel.p, 0, T_in * sizeof(Fr), rt().stream));
+            k_slice_selector<<<grid_of(T_out), 256, 0, rt().stream>>>((const Fr*)eq->d, M, base, T_out, sel.as<Fr>());
+            HIP_TRY(hipStreamSynchronize(rt().stream));
         }
         if (eq) atlas_poly_free(eq);
         if (!rc) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(G.tensor(in.idx)), T_in, &ops[0]);
@@ -812,13 +812,13 @@ struct Prover : FlowSink {
             const uint32_t shift = (uint32_t)(mx - nv[k]);
             HIP_TRY(bufs[2 * k].alloc(len * sizeof(Fr))); HIP_TRY(bufs[2 * k + 1].alloc(len * sizeof(Fr)));
             {
-                std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+                std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
                 SliceMap M{}; M.n = (uint32_t)r;
                 for (size_t a = 0; a < r; a++) { M.dim[a] = (uint32_t)in.dims[a]; M.stride[a] = (uint32_t)ostr[a]; }
-                k_concat_extend<<<grid_of(len), 256, 0, g.stream>>>(G.tensor(in.idx), shift, len, bufs[2 * k].as<Fr>());
-                HIP_TRY(hipMemsetAsync(bufs[2 * k + 1].p, 0, len * sizeof(Fr), g.stream));
-                k_concat_selector<<<grid_of(T_in), 256, 0, g.stream>>>((const Fr*)eq->d, M, off * ostr[ax], shift, T_in, bufs[2 * k + 1].as<Fr>());
-                HIP_TRY(hipStreamSynchronize(g.stream));
+                k_concat_extend<<<grid_of(len), 256, 0, rt().stream>>>(G.tensor(in.idx), shift, len, bufs[2 * k].as<Fr>());
+                HIP_TRY(hipMemsetAsync(bufs[2 * k + 1].p, 0, len * sizeof(Fr), rt().stream));
+                k_concat_selector<<<grid_of(T_in), 256, 0, rt().stream>>>((const Fr*)eq->d, M, off * ostr[ax], shift, T_in, bufs[2 * k + 1].as<Fr>());
+                HIP_TRY(hipStreamSynchronize(rt().stream));
             }
             off += in.dims[ax];
             rc = atlas_poly_wrap_device_fr(bufs[2 * k].p, len, &ops[2 * k]);
@@ -901,9 +901,9 @@ struct Prover : FlowSink {
         DevBuf lbuf, rbuf;
         HIP_TRY(lbuf.alloc(T_in * sizeof(Fr))); HIP_TRY(rbuf.alloc(T_in * sizeof(Fr)));
         {
-            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
-            k_i32_to_fr<<<grid_of(T_in), 256, 0, g.stream>>>(G.tensor(in.idx), lbuf.as<Fr>(), T_in);
-            HIP_TRY(hipMemcpyAsync(rbuf.p, lbuf.p, T_in * sizeof(Fr), hipMemcpyDeviceToDevice, g.stream));
+            std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+            k_i32_to_fr<<<grid_of(T_in), 256, 0, rt().stream>>>(G.tensor(in.idx), lbuf.as<Fr>(), T_in);
+            HIP_TRY(hipMemcpyAsync(rbuf.p, lbuf.p, T_in * sizeof(Fr), hipMemcpyDeviceToDevice, rt().stream));
         }
         atlas_poly_t left = nullptr, right = nullptr, eq = nullptr;
         rc = atlas_poly_wrap_device_fr(lbuf.p, T_in, &left);
@@ -1126,7 +1126,7 @@ struct Prover : FlowSink {
         atlas_poly_t hw = nullptr;
         rc = atlas_poly_upload_fr((const atlas_fr_t*)ones.data(), N, &hw);
         const H::Fr one = H::one(), zero = H::zero();
-        const H::Fr gamma_b = H::challenge_to_fr(1, 0, g.challenge_mode);   // F::Challenge::from(1): the challenge READING of the integer 1
+        const H::Fr gamma_b = H::challenge_to_fr(1, 0, rt().challenge_mode);   // F::Challenge::from(1): the challenge READING of the integer 1
         atlas_instance_t i_hb = nullptr, i_bool = nullptr, i_hw = nullptr;
         const atlas_fr_t no_point{};
         const atlas_fr_t* rix = ln ? (const atlas_fr_t*)r_index.data() : &no_point;          // ONE index: r_cycle is the empty point
@@ -1207,11 +1207,11 @@ struct Prover : FlowSink {
         // send_auxiliary_vectors (:392-413): exp_sum_q[k], max_k[k], argmax_k[k] as F::from_u32(v as u32), at the empty point
         std::vector<int32_t> aux(3 * F);
         {
-            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
-            HIP_TRY(hipMemcpyAsync(aux.data(), Sm.exp_sum.p, F * 4, hipMemcpyDeviceToHost, g.stream));
-            HIP_TRY(hipMemcpyAsync(aux.data() + F, Sm.max_k.p, F * 4, hipMemcpyDeviceToHost, g.stream));
-            HIP_TRY(hipMemcpyAsync(aux.data() + 2 * F, Sm.argmax_k.p, F * 4, hipMemcpyDeviceToHost, g.stream));
-            HIP_TRY(hipStreamSynchronize(g.stream));
+            std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+            HIP_TRY(hipMemcpyAsync(aux.data(), Sm.exp_sum.p, F * 4, hipMemcpyDeviceToHost, rt().stream));
+            HIP_TRY(hipMemcpyAsync(aux.data() + F, Sm.max_k.p, F * 4, hipMemcpyDeviceToHost, rt().stream));
+            HIP_TRY(hipMemcpyAsync(aux.data() + 2 * F, Sm.argmax_k.p, F * 4, hipMemcpyDeviceToHost, rt().stream));
+            HIP_TRY(hipStreamSynchronize(rt().stream));
         }
         {
             Out O = out();

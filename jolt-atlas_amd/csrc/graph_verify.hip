@@ -137,7 +137,7 @@ struct Verifier {
 
     Verifier(atlas_graph& g_, const atlas_hyperkzg_vk_t* v) : G(g_), vk(v), Tr(*reinterpret_cast<H::Transcript*>(&t)) {}
     static int bad(const char* what) { return fail(ATLAS_EVERIFY, what); }
-    int mode() const { return g.challenge_mode; }
+    int mode() const { return rt().challenge_mode; }
 
     // VerifierOpeningAccumulator::append_virtual: the claim comes from the proof
     int append_virtual(const OpeningId& id, const Point& pt) {

@@ -25,20 +25,20 @@
 using namespace atlas;
 namespace H = atlas_host;
 using atlas_rt::fail;
-using atlas_rt::g;
+using atlas_rt::rt;
 
 
 namespace {
 
-// grow-only device workspace shared by MSM calls (serialised by g.mu)
+// grow-only device workspace shared by MSM calls (serialised by rt().mu)
 void release_arenas();
 struct Workspace {
     void* p = nullptr;
     size_t cap = 0;
     int ensure(size_t bytes) {
-        bool hooked = false;              // callers hold g.mu
-        for (auto f : g.at_shutdown) hooked |= f == &release_arenas;
-        if (!hooked) g.at_shutdown.push_back(&release_arenas);
+        bool hooked = false;              // callers hold rt().mu
+        for (auto f : rt().at_shutdown) hooked |= f == &release_arenas;
+        if (!hooked) rt().at_shutdown.push_back(&release_arenas);
         if (bytes <= cap) return ATLAS_OK;
         if (p) hipFree(p);
         p = nullptr; cap = 0;
@@ -48,8 +48,26 @@ struct Workspace {
         return ATLAS_OK;
     }
 };
-Workspace ws;
-Workspace hk_arena;      // HyperKZG::open: Pi_0.., B, h_k and the scan scratch
+// the arenas and side streams of a runtime (one per process by default, one per thread that owns a device: runtime.hpp)
+struct MsmState {
+    Workspace ws;
+    Workspace hk_arena;            // HyperKZG::open: Pi_0.., B, h_k and the scan scratch
+    Workspace ws_side, ws_tab;     // second lane: the narrow pipeline of msm_device_multi; third: its fixed-base pipeline
+    hipStream_t side_stream = nullptr, side_stream2 = nullptr;
+    hipEvent_t side_event = nullptr;
+};
+inline MsmState& msm_state() {       // callers hold rt().mu
+    atlas_rt::Runtime& R = rt();
+    if (!R.msm_ws) R.msm_ws = new MsmState();
+    return *static_cast<MsmState*>(R.msm_ws);
+}
+#define ws (msm_state().ws)
+#define hk_arena (msm_state().hk_arena)
+#define ws_side (msm_state().ws_side)
+#define ws_tab (msm_state().ws_tab)
+#define side_stream (msm_state().side_stream)
+#define side_stream2 (msm_state().side_stream2)
+#define side_event (msm_state().side_event)
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -159,7 +177,7 @@ template <class DigitsFn>
 int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launch_digits, atlas_g1_affine_t* out,
              const MsmMulti* multi = nullptr, const MsmLane* lane = nullptr, MsmPending* pend = nullptr) {
     const size_t K = multi ? multi->K : 1;
-    const hipStream_t st = lane ? lane->st : g.stream;
+    const hipStream_t st = lane ? lane->st : rt().stream;
     Workspace& wk = lane ? *lane->wk : ws;
     if (n == 0) { H::G1Aff z{H::q_zero(), H::q_zero()}; for (size_t k = 0; k < K; k++) to_out(z, out + k); return ATLAS_OK; }
     // 32-bit positions: sorted entries, bucket offsets and tile bounds
@@ -238,7 +256,7 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
     G1Xyzz* wsum = (G1Xyzz*)(W + o_wsum);
     const ReduceBufs rbufs(W + o_biglist, TB, s_max);
 
-    const bool timing = g.timing && !pend;
+    const bool timing = rt().timing && !pend;
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
     if (timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2); hipEventCreate(&e3); hipEventRecord(e0, st); }
 
@@ -286,7 +304,7 @@ int msm_core(const G1Affine* bases, size_t n, const MsmShape S, DigitsFn&& launc
         t.total_ms = a + b + c; t.pass_ms = b; t.fs_ms = a + c;
         t.pass_bytes = (uint64_t)n * (sizeof(G1Affine) + sizeof(Fr));
         t.n_pass = 1; t.n_fs = S.c;   // n_fs carries the window width for the caller
-        g.last_timing = t;
+        rt().last_timing = t;
         hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2); hipEventDestroy(e3);
     }
     return ATLAS_OK;
@@ -333,7 +351,7 @@ uint32_t pick_tab_q(size_t n, uint32_t tab_c, uint32_t levels) {
 int msm_tab_core(const atlas_srs* srs, size_t pt_off, const Fr* d_scalars, size_t n, uint32_t q, atlas_g1_affine_t* out,
                  const MsmMulti* multi = nullptr, const MsmLane* lane = nullptr, MsmPending* pend = nullptr) {
     const size_t K = multi ? multi->K : 1;
-    const hipStream_t st = lane ? lane->st : g.stream;
+    const hipStream_t st = lane ? lane->st : rt().stream;
     Workspace& wk = lane ? *lane->wk : ws;
     TabShape S;
     S.c = srs->tab_c / q; S.q = q;
@@ -422,7 +440,7 @@ int msm_tab_core(const atlas_srs* srs, size_t pt_off, const Fr* d_scalars, size_
     const ReduceBufs rbufs(W + o_biglist, TB, s_max);
     TabTile* d_tiles = (TabTile*)(W + o_tiles);
 
-    const bool timing = g.timing && !pend;
+    const bool timing = rt().timing && !pend;
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
     if (timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2); hipEventCreate(&e3); hipEventRecord(e0, st); }
 
@@ -480,7 +498,7 @@ int msm_tab_core(const atlas_srs* srs, size_t pt_off, const Fr* d_scalars, size_
         t.total_ms = a + b + c; t.pass_ms = b; t.fs_ms = a + c;
         t.pass_bytes = (uint64_t)n * (sizeof(G1Affine) + sizeof(Fr));
         t.n_pass = 1; t.n_fs = S.c;
-        g.last_timing = t;
+        rt().last_timing = t;
         hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2); hipEventDestroy(e3);
     }
     return ATLAS_OK;
@@ -525,9 +543,6 @@ static int msm_multi_group(const G1Affine* bases, const Fr* d_scalars, MsmGroup&
     }, G.res.data(), &M, lane, &G.pend);
 }
 
-Workspace ws_side, ws_tab;         // second lane: the narrow pipeline of msm_device_multi; third: its fixed-base pipeline
-hipStream_t side_stream = nullptr, side_stream2 = nullptr;
-hipEvent_t side_event = nullptr;
 
 void release_arenas() {            // atlas_shutdown
     for (Workspace* w : {&ws, &hk_arena, &ws_side, &ws_tab}) { if (w->p) hipFree(w->p); w->p = nullptr; w->cap = 0; }
@@ -560,12 +575,12 @@ int msm_device_multi(const G1Affine* bases, const Fr* d_scalars, size_t n_tot, s
             HIP_TRY(hipStreamCreateWithFlags(&side_stream2, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&side_event, hipEventDisableTiming));
         }
-        HIP_TRY(hipEventRecord(side_event, g.stream));
+        HIP_TRY(hipEventRecord(side_event, rt().stream));
         // ... and the host waits for the library stream as well: the event alone did not order a side stream behind the
         // library stream reliably when the two share a hardware queue (see Pipeline::begin in batched.hip)
-        HIP_TRY(hipStreamSynchronize(g.stream));
+        HIP_TRY(hipStreamSynchronize(rt().stream));
     }
-    auto drain = [&]() { if (side_stream) { hipStreamSynchronize(side_stream); hipStreamSynchronize(side_stream2); } hipStreamSynchronize(g.stream); };
+    auto drain = [&]() { if (side_stream) { hipStreamSynchronize(side_stream); hipStreamSynchronize(side_stream2); } hipStreamSynchronize(rt().stream); };
     int rc = ATLAS_OK;
     if (!tab.idx.empty()) {
         size_t lo = SIZE_MAX, hi = 0;
@@ -573,14 +588,14 @@ int msm_device_multi(const G1Affine* bases, const Fr* d_scalars, size_t n_tot, s
         tab.gl.resize(tab.idx.size()); tab.go.resize(tab.idx.size()); tab.res.resize(tab.idx.size());
         for (size_t i = 0; i < tab.idx.size(); i++) { tab.gl[i] = lens[tab.idx[i]]; tab.go[i] = offs[tab.idx[i]] - lo; }
         const MsmMulti M{tab.idx.size(), tab.gl.data(), tab.go.data()};
-        const MsmLane lane{g.stream, &ws_tab};
+        const MsmLane lane{rt().stream, &ws_tab};
         rc = msm_tab_core(srs, 0, d_scalars + lo, hi - lo, tab_q, tab.res.data(), &M, &lane, &tab.pend);
         if (rc) { drain(); return rc; }
     }
     if (!big.idx.empty()) {
         const bool aside = !tab.idx.empty();
         if (aside) HIP_TRY(hipStreamWaitEvent(side_stream2, side_event, 0));
-        const MsmLane lane{aside ? side_stream2 : g.stream, &ws};
+        const MsmLane lane{aside ? side_stream2 : rt().stream, &ws};
         rc = msm_multi_group(bases, d_scalars, big, lens, offs, pick_shape(mx_big), &lane);
         if (rc) { drain(); return rc; }
     }
@@ -624,11 +639,11 @@ int msm_small_device(const G1Affine* bases, const T* d_scalars, size_t n, atlas_
     int rc = ws.ensure(256);
     if (rc) return rc;
     unsigned long long* d_max = (unsigned long long*)ws.p;
-    HIP_TRY(hipMemsetAsync(d_max, 0, 8, g.stream));
-    k_abs_max<T><<<grid_for(n, 1024), MSM_THREADS, 0, g.stream>>>(d_scalars, n, d_max);
+    HIP_TRY(hipMemsetAsync(d_max, 0, 8, rt().stream));
+    k_abs_max<T><<<grid_for(n, 1024), MSM_THREADS, 0, rt().stream>>>(d_scalars, n, d_max);
     unsigned long long mx = 0;
-    HIP_TRY(hipMemcpyAsync(&mx, d_max, 8, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(&mx, d_max, 8, hipMemcpyDeviceToHost, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     if (mx == 0) { H::G1Aff z{H::q_zero(), H::q_zero()}; to_out(z, out); return ATLAS_OK; }
     const uint32_t bits = 64 - (uint32_t)__builtin_clzll(mx);
     // the top window must stay below half after the incoming carry (digits >= half go negative)
@@ -692,8 +707,8 @@ int atlas_srs_upload(const void* bases, size_t n, size_t stride_bytes, atlas_srs
     hipError_t e = hipMalloc(&s->d, n * sizeof(G1Affine));
     if (e != hipSuccess) { delete s; return fail(ATLAS_ENOMEM, "hipMalloc(srs)", e); }
     s->len = n;
-    e = hipMemcpyAsync(s->d, tmp.data(), n * sizeof(G1Affine), hipMemcpyHostToDevice, g.stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    e = hipMemcpyAsync(s->d, tmp.data(), n * sizeof(G1Affine), hipMemcpyHostToDevice, rt().stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(rt().stream);
     if (e != hipSuccess) { (void)hipFree(s->d); delete s; return fail(ATLAS_ENODEV, "srs_upload: copy", e); }
     *out = s;
     return ATLAS_OK;
@@ -702,7 +717,7 @@ int atlas_srs_upload(const void* bases, size_t n, size_t stride_bytes, atlas_srs
 int atlas_srs_generate(const atlas_fr_t* tau, size_t n, atlas_srs_t* out) {
     NEED_INIT();
     if (!tau || !out || n == 0) return fail(ATLAS_EINVAL, "srs_generate");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     // tau^(2^j), j < 64 ; 2^j * G, j < 254 (host, O(1) work)
     std::vector<H::Fr> tp(64);
     std::memcpy(&tp[0], tau, 32);
@@ -713,14 +728,14 @@ int atlas_srs_generate(const atlas_fr_t* tau, size_t n, atlas_srs_t* out) {
     DevBuf tpb, dtb;
     HIP_TRY(tpb.alloc(64 * sizeof(Fr)));
     HIP_TRY(dtb.alloc(254 * sizeof(G1Affine)));
-    HIP_TRY(hipMemcpyAsync(tpb.p, tp.data(), 64 * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipMemcpyAsync(dtb.p, dt.data(), 254 * sizeof(G1Affine), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(tpb.p, tp.data(), 64 * sizeof(Fr), hipMemcpyHostToDevice, rt().stream));
+    HIP_TRY(hipMemcpyAsync(dtb.p, dt.data(), 254 * sizeof(G1Affine), hipMemcpyHostToDevice, rt().stream));
     atlas_srs* s = new atlas_srs();
     hipError_t e = hipMalloc(&s->d, n * sizeof(G1Affine));
     if (e != hipSuccess) { delete s; return fail(ATLAS_ENOMEM, "hipMalloc(srs)", e); }
     s->len = n;
-    k_srs_generate<<<grid_for(n, 8192), MSM_THREADS, 0, g.stream>>>(tpb.as<Fr>(), dtb.as<G1Affine>(), n, s->d);
-    hipError_t se = hipStreamSynchronize(g.stream);
+    k_srs_generate<<<grid_for(n, 8192), MSM_THREADS, 0, rt().stream>>>(tpb.as<Fr>(), dtb.as<G1Affine>(), n, s->d);
+    hipError_t se = hipStreamSynchronize(rt().stream);
     if (se != hipSuccess) { hipFree(s->d); delete s; return fail(ATLAS_ENODEV, "srs_generate", se); }
     *out = s;
     return ATLAS_OK;
@@ -736,8 +751,8 @@ int atlas_srs_download(atlas_srs_t s, size_t offset, size_t n, atlas_g1_affine_t
     NEED_INIT();
     if (!s || !out || offset + n > s->len) return fail(ATLAS_EINVAL, "srs_download: range");
     std::vector<G1Affine> tmp(n);
-    HIP_TRY(hipMemcpyAsync(tmp.data(), s->d + offset, n * sizeof(G1Affine), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(tmp.data(), s->d + offset, n * sizeof(G1Affine), hipMemcpyDeviceToHost, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     for (size_t i = 0; i < n; i++) {
         H::G1Aff a; std::memcpy(&a, &tmp[i], 64);
         to_out(a, &out[i]);
@@ -772,18 +787,18 @@ int atlas_srs_precompute(atlas_srs_t srs, size_t n_points, uint32_t window_bits)
     if (c < 8 || c > 24) return fail(ATLAS_EINVAL, "srs_precompute: window_bits must be 0 or 8..24");
     const uint32_t levels = (255 + c - 1) / c;
     if ((size_t)levels * n_points >= ((size_t)1 << 31)) return fail(ATLAS_EINVAL, "srs_precompute: table beyond 2^31 points");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
-    if (srs->tab) { hipStreamSynchronize(g.stream); hipFree(srs->tab); srs->tab = nullptr; srs->tab_len = 0; srs->tab_c = srs->tab_levels = 0; }
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+    if (srs->tab) { hipStreamSynchronize(rt().stream); hipFree(srs->tab); srs->tab = nullptr; srs->tab_len = 0; srs->tab_c = srs->tab_levels = 0; }
     G1Affine* tab = nullptr;
     hipError_t e = hipMalloc(&tab, (size_t)levels * n_points * sizeof(G1Affine));
     if (e != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(srs table)", e);
-    e = hipMemcpyAsync(tab, srs->d, n_points * sizeof(G1Affine), hipMemcpyDeviceToDevice, g.stream);
+    e = hipMemcpyAsync(tab, srs->d, n_points * sizeof(G1Affine), hipMemcpyDeviceToDevice, rt().stream);
     for (uint32_t l = 1; l < levels && e == hipSuccess; l++) {
-        k_tab_next_level<<<grid_for((n_points + TAB_INV_BATCH - 1) / TAB_INV_BATCH, 1 << 16), MSM_THREADS, 0, g.stream>>>(
+        k_tab_next_level<<<grid_for((n_points + TAB_INV_BATCH - 1) / TAB_INV_BATCH, 1 << 16), MSM_THREADS, 0, rt().stream>>>(
             tab + (size_t)(l - 1) * n_points, tab + (size_t)l * n_points, n_points, c);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(rt().stream);
     if (e != hipSuccess) { hipFree(tab); return fail(ATLAS_ENODEV, "srs_precompute", e); }
     srs->tab = tab; srs->tab_len = n_points; srs->tab_c = c; srs->tab_levels = levels;
     return ATLAS_OK;
@@ -803,11 +818,11 @@ int atlas_msm_fr(atlas_srs_t srs, size_t offset, const atlas_fr_t* scalars, size
     if (!srs || !out || (!scalars && n)) return fail(ATLAS_EINVAL, "msm_fr: null argument");
     if (offset + n > srs->len)   // ProofVerifyError::KeyLengthError (msm/mod.rs:35-37)
         return fail(ATLAS_EINVAL, "msm_fr: KeyLengthError (bases shorter than scalars)");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     Fr* d_s = nullptr;
     if (n) {
         HIP_TRY(hipMalloc(&d_s, n * sizeof(Fr)));
-        HIP_TRY(hipMemcpyAsync(d_s, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(hipMemcpyAsync(d_s, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, rt().stream));
     }
     int rc = msm_device(srs->d + offset, d_s, n, out, srs, offset);
     if (d_s) hipFree(d_s);
@@ -819,7 +834,7 @@ int atlas_msm_poly(atlas_srs_t srs, size_t offset, atlas_poly_t poly, atlas_g1_a
     NEED_INIT();
     if (!srs || !poly || !out) return fail(ATLAS_EINVAL, "msm_poly: null argument");
     if (offset + poly->len > srs->len) return fail(ATLAS_EINVAL, "msm_poly: KeyLengthError (bases shorter than scalars)");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     if (poly->is_i32) return msm_small_device<int32_t>(srs->d + offset, (const int32_t*)poly->d, poly->len, out);   // I32Scalars, msm/mod.rs:88-130
     return msm_device(srs->d + offset, (const Fr*)poly->d, poly->len, out, srs, offset);
 }
@@ -829,13 +844,13 @@ int atlas_msm_poly(atlas_srs_t srs, size_t offset, atlas_poly_t poly, atlas_g1_a
 int atlas_msm_small(atlas_srs_t srs, size_t offset, const void* scalars, size_t n, int kind, atlas_g1_affine_t* out) {
     NEED_INIT();
     if (!srs || !out || (!scalars && n) || offset + n > srs->len) return fail(ATLAS_EINVAL, "msm_small: KeyLengthError");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     static const size_t width[] = {1, 2, 4, 8, 4, 8};
     if (kind < 0 || kind > ATLAS_SCALAR_I64) return fail(ATLAS_EINVAL, "msm_small: kind");
     void* d_s = nullptr;
     if (n) {
         HIP_TRY(hipMalloc(&d_s, n * width[kind]));
-        hipError_t e = hipMemcpyAsync(d_s, scalars, n * width[kind], hipMemcpyHostToDevice, g.stream);
+        hipError_t e = hipMemcpyAsync(d_s, scalars, n * width[kind], hipMemcpyHostToDevice, rt().stream);
         if (e != hipSuccess) { hipFree(d_s); return fail(ATLAS_ENODEV, "msm_small copy", e); }
     }
     int rc = ATLAS_EINVAL;
@@ -858,7 +873,7 @@ int atlas_g1_sum_indexed(atlas_srs_t srs, const uint32_t* indices, size_t n, atl
     for (size_t i = 0; i < n; i++)
         if (indices[i] >= srs->len) return fail(ATLAS_EINVAL, "g1_sum_indexed: KeyLengthError (index beyond the SRS)");
     if (n == 0) { H::G1Aff z{H::q_zero(), H::q_zero()}; to_out(z, out); return ATLAS_OK; }
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     const int grid = grid_for(n, 1024);
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -866,12 +881,12 @@ int atlas_g1_sum_indexed(atlas_srs_t srs, const uint32_t* indices, size_t n, atl
     int rc = ws.ensure(off);
     if (rc) return rc;
     unsigned char* W = (unsigned char*)ws.p;
-    HIP_TRY(hipMemcpyAsync(W + o_idx, indices, n * 4, hipMemcpyHostToDevice, g.stream));
-    k_g1_sum_indexed<<<grid, MSM_THREADS, 0, g.stream>>>(srs->d, (const uint32_t*)(W + o_idx), n, (G1Xyzz*)(W + o_part));
-    k_g1_group_sum<<<1, MSM_THREADS, 0, g.stream>>>((const G1Xyzz*)(W + o_part), (uint32_t)grid, (G1Xyzz*)(W + o_one));
+    HIP_TRY(hipMemcpyAsync(W + o_idx, indices, n * 4, hipMemcpyHostToDevice, rt().stream));
+    k_g1_sum_indexed<<<grid, MSM_THREADS, 0, rt().stream>>>(srs->d, (const uint32_t*)(W + o_idx), n, (G1Xyzz*)(W + o_part));
+    k_g1_group_sum<<<1, MSM_THREADS, 0, rt().stream>>>((const G1Xyzz*)(W + o_part), (uint32_t)grid, (G1Xyzz*)(W + o_one));
     H::G1X r;
-    HIP_TRY(hipMemcpyAsync(&r, W + o_one, sizeof(G1Xyzz), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(&r, W + o_one, sizeof(G1Xyzz), hipMemcpyDeviceToHost, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     to_out(H::gx_to_aff(r), out);
     return ATLAS_OK;
 }
@@ -903,7 +918,7 @@ int atlas_commit_one_hot_batch(atlas_srs_t srs, const int32_t* const* nonzero_in
         }
         o += T[r];
     }
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     // about 2048 workgroups in flight over the batch, at least one per polynomial
     unsigned gx = (unsigned)(2048 / R); if (gx < 1) gx = 1;
     const unsigned need = (unsigned)((t_max + MSM_THREADS - 1) / MSM_THREADS); if (gx > need) gx = need ? need : 1;
@@ -914,13 +929,13 @@ int atlas_commit_one_hot_batch(atlas_srs_t srs, const int32_t* const* nonzero_in
     int rc = ws.ensure(off);
     if (rc) return rc;
     unsigned char* W = (unsigned char*)ws.p;
-    HIP_TRY(hipMemcpyAsync(W + o_idx, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipMemcpyAsync(W + o_rows, rows.data(), R * sizeof(OneHotRowDesc), hipMemcpyHostToDevice, g.stream));
-    k_g1_sum_onehot_rows<<<dim3(gx, (unsigned)R), MSM_THREADS, 0, g.stream>>>(srs->d, (const int32_t*)(W + o_idx), (const OneHotRowDesc*)(W + o_rows), (G1Xyzz*)(W + o_part));
-    k_g1_group_sum<<<(unsigned)R, MSM_THREADS, 0, g.stream>>>((const G1Xyzz*)(W + o_part), gx, (G1Xyzz*)(W + o_sum));
+    HIP_TRY(hipMemcpyAsync(W + o_idx, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, rt().stream));
+    HIP_TRY(hipMemcpyAsync(W + o_rows, rows.data(), R * sizeof(OneHotRowDesc), hipMemcpyHostToDevice, rt().stream));
+    k_g1_sum_onehot_rows<<<dim3(gx, (unsigned)R), MSM_THREADS, 0, rt().stream>>>(srs->d, (const int32_t*)(W + o_idx), (const OneHotRowDesc*)(W + o_rows), (G1Xyzz*)(W + o_part));
+    k_g1_group_sum<<<(unsigned)R, MSM_THREADS, 0, rt().stream>>>((const G1Xyzz*)(W + o_part), gx, (G1Xyzz*)(W + o_sum));
     std::vector<H::G1X> res(R);
-    HIP_TRY(hipMemcpyAsync(res.data(), W + o_sum, R * sizeof(G1Xyzz), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(res.data(), W + o_sum, R * sizeof(G1Xyzz), hipMemcpyDeviceToHost, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     for (size_t r = 0; r < R; r++) to_out(H::gx_to_aff(res[r]), out + r);
     return ATLAS_OK;
 }
@@ -935,7 +950,7 @@ int atlas_commit_lookup_chunks(atlas_srs_t srs, const uint64_t* d_lookups, size_
         return fail(ATLAS_EINVAL, "commit_lookup_chunks: bad argument");
     const size_t T = (size_t)1 << log_T, d = (log_K + log_k_chunk - 1) / log_k_chunk;
     if ((T << log_k_chunk) > srs->len) return fail(ATLAS_EINVAL, "commit_lookup_chunks: KeyLengthError (K*T beyond the SRS)");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     unsigned gx = (unsigned)(2048 / d); if (gx < 1) gx = 1;
     const unsigned need = (unsigned)((T + MSM_THREADS - 1) / MSM_THREADS); if (gx > need) gx = need ? need : 1;
     size_t off = 0;
@@ -944,11 +959,11 @@ int atlas_commit_lookup_chunks(atlas_srs_t srs, const uint64_t* d_lookups, size_
     int rc = ws.ensure(off);
     if (rc) return rc;
     unsigned char* W = (unsigned char*)ws.p;
-    k_g1_sum_lookup_chunks<<<dim3(gx, (unsigned)d), MSM_THREADS, 0, g.stream>>>(srs->d, d_lookups, (uint32_t)T, (uint32_t)d, (uint32_t)log_k_chunk, (G1Xyzz*)(W + o_part));
-    k_g1_group_sum<<<(unsigned)d, MSM_THREADS, 0, g.stream>>>((const G1Xyzz*)(W + o_part), gx, (G1Xyzz*)(W + o_sum));
+    k_g1_sum_lookup_chunks<<<dim3(gx, (unsigned)d), MSM_THREADS, 0, rt().stream>>>(srs->d, d_lookups, (uint32_t)T, (uint32_t)d, (uint32_t)log_k_chunk, (G1Xyzz*)(W + o_part));
+    k_g1_group_sum<<<(unsigned)d, MSM_THREADS, 0, rt().stream>>>((const G1Xyzz*)(W + o_part), gx, (G1Xyzz*)(W + o_sum));
     std::vector<H::G1X> res(d);
-    HIP_TRY(hipMemcpyAsync(res.data(), W + o_sum, d * sizeof(G1Xyzz), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(res.data(), W + o_sum, d * sizeof(G1Xyzz), hipMemcpyDeviceToHost, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     for (size_t r = 0; r < d; r++) to_out(H::gx_to_aff(res[r]), out + r);
     return ATLAS_OK;
 }
@@ -970,20 +985,20 @@ int atlas_commit_lookup_chunks_multi(atlas_srs_t srs, const atlas_lookup_family_
         maxT = T > maxT ? T : maxT;
     }
     const size_t R = rows.size();
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     static const bool old_cut = getenv("ATLAS_COMMIT_OLD_CUT") != nullptr;      // A-B: one slice count for the whole launch
     DevBuf d_rows, d_part, d_sum, d_slices, d_off;
     HIP_TRY(d_rows.alloc(R * sizeof(LookupChunkRow)));
     HIP_TRY(d_sum.alloc(R * sizeof(G1Xyzz)));
-    HIP_TRY(hipMemcpyAsync(d_rows.p, rows.data(), R * sizeof(LookupChunkRow), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(d_rows.p, rows.data(), R * sizeof(LookupChunkRow), hipMemcpyHostToDevice, rt().stream));
     std::vector<LookupSlice> slices;                // (kept alive until the synchronisation below: pageable sources of asynchronous copies)
     std::vector<uint32_t> offs;
     if (old_cut) {
         unsigned gx = (unsigned)((maxT + 4 * MSM_THREADS - 1) / (4 * MSM_THREADS)); if (gx < 1) gx = 1; if (gx > 64) gx = 64;
         while ((size_t)gx * R < 2048 && gx < 64 && (size_t)gx * MSM_THREADS < maxT) gx *= 2;
         HIP_TRY(d_part.alloc(R * gx * sizeof(G1Xyzz)));
-        k_g1_sum_lookup_rows<<<dim3(gx, (unsigned)R), MSM_THREADS, 0, g.stream>>>(srs->d, d_rows.as<LookupChunkRow>(), (uint32_t)(((uint64_t)1 << log_k_chunk) - 1), d_part.as<G1Xyzz>());
-        k_g1_group_sum<<<(unsigned)R, MSM_THREADS, 0, g.stream>>>(d_part.as<G1Xyzz>(), gx, d_sum.as<G1Xyzz>());
+        k_g1_sum_lookup_rows<<<dim3(gx, (unsigned)R), MSM_THREADS, 0, rt().stream>>>(srs->d, d_rows.as<LookupChunkRow>(), (uint32_t)(((uint64_t)1 << log_k_chunk) - 1), d_part.as<G1Xyzz>());
+        k_g1_group_sum<<<(unsigned)R, MSM_THREADS, 0, rt().stream>>>(d_part.as<G1Xyzz>(), gx, d_sum.as<G1Xyzz>());
     } else {
         // slices per row: ~32 points per thread, at most 64 slices; with few rows more slices, so that the launch still fills the chip
         size_t pts = 32;
@@ -998,15 +1013,15 @@ int atlas_commit_lookup_chunks_multi(atlas_srs_t srs, const atlas_lookup_family_
         HIP_TRY(d_slices.alloc(slices.size() * sizeof(LookupSlice)));
         HIP_TRY(d_off.alloc(offs.size() * sizeof(uint32_t)));
         HIP_TRY(d_part.alloc(slices.size() * sizeof(G1Xyzz)));
-        HIP_TRY(hipMemcpyAsync(d_slices.p, slices.data(), slices.size() * sizeof(LookupSlice), hipMemcpyHostToDevice, g.stream));
-        HIP_TRY(hipMemcpyAsync(d_off.p, offs.data(), offs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
-        k_g1_sum_lookup_slices<<<(unsigned)slices.size(), MSM_THREADS, 0, g.stream>>>(srs->d, d_rows.as<LookupChunkRow>(), d_slices.as<LookupSlice>(), (uint32_t)(((uint64_t)1 << log_k_chunk) - 1),
+        HIP_TRY(hipMemcpyAsync(d_slices.p, slices.data(), slices.size() * sizeof(LookupSlice), hipMemcpyHostToDevice, rt().stream));
+        HIP_TRY(hipMemcpyAsync(d_off.p, offs.data(), offs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, rt().stream));
+        k_g1_sum_lookup_slices<<<(unsigned)slices.size(), MSM_THREADS, 0, rt().stream>>>(srs->d, d_rows.as<LookupChunkRow>(), d_slices.as<LookupSlice>(), (uint32_t)(((uint64_t)1 << log_k_chunk) - 1),
                                                                                     d_part.as<G1Xyzz>());
-        k_g1_group_sum_var<<<(unsigned)R, 64, 0, g.stream>>>(d_part.as<G1Xyzz>(), d_off.as<uint32_t>(), d_sum.as<G1Xyzz>());
+        k_g1_group_sum_var<<<(unsigned)R, 64, 0, rt().stream>>>(d_part.as<G1Xyzz>(), d_off.as<uint32_t>(), d_sum.as<G1Xyzz>());
     }
     std::vector<H::G1X> res(R);
-    HIP_TRY(hipMemcpyAsync(res.data(), d_sum.p, R * sizeof(G1Xyzz), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(res.data(), d_sum.p, R * sizeof(G1Xyzz), hipMemcpyDeviceToHost, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     std::vector<H::G1Aff> aff(R);
     H::gx_batch_to_aff(res.data(), R, aff.data());
     for (size_t r = 0; r < R; r++) to_out(aff[r], out + r);
@@ -1026,7 +1041,7 @@ int atlas_commit_batch(atlas_srs_t srs, const atlas_poly_t* polys, size_t n, atl
         if (polys[i]->len > srs->len) return fail(ATLAS_EINVAL, "commit_batch: KeyLengthError (bases shorter than scalars)");
         if (!polys[i]->is_i32) { fr_idx.push_back(i); tot += polys[i]->len; }
     }
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     for (size_t i = 0; i < n; i++)
         if (polys[i]->is_i32) { int rc = msm_small_device<int32_t>(srs->d, (const int32_t*)polys[i]->d, polys[i]->len, out + i); if (rc) return rc; }
     if (fr_idx.size() == 1) return msm_device(srs->d, (const Fr*)polys[fr_idx[0]]->d, polys[fr_idx[0]]->len, out + fr_idx[0], srs, 0);
@@ -1039,13 +1054,13 @@ int atlas_commit_batch(atlas_srs_t srs, const atlas_poly_t* polys, size_t n, atl
     for (size_t j = 0; j < fr_idx.size() && e == hipSuccess; j++) {
         const atlas_poly* P = polys[fr_idx[j]];
         lens[j] = P->len; offs[j] = o;
-        e = hipMemcpyAsync(cat + o, P->d, P->len * sizeof(Fr), hipMemcpyDeviceToDevice, g.stream);
+        e = hipMemcpyAsync(cat + o, P->d, P->len * sizeof(Fr), hipMemcpyDeviceToDevice, rt().stream);
         o += P->len;
     }
     std::vector<atlas_g1_affine_t> res(fr_idx.size());
     int rc = e == hipSuccess ? msm_device_multi(srs->d, cat, tot, fr_idx.size(), lens.data(), offs.data(), res.data(), srs)
                              : fail(ATLAS_ENODEV, "commit_batch: gather", e);
-    (void)hipStreamSynchronize(g.stream);
+    (void)hipStreamSynchronize(rt().stream);
     (void)hipFree(cat);
     if (rc) return rc;
     for (size_t j = 0; j < fr_idx.size(); j++) out[fr_idx[j]] = res[j];
@@ -1070,18 +1085,18 @@ __global__ void k_mad_peak(uint64_t* out, int iters) {
 extern "C" int atlas_measure_mad_peak(double* mads_per_s) {
     NEED_INIT();
     if (!mads_per_s) return fail(ATLAS_EINVAL, "measure_mad_peak");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     const int blocks = 256 * 8, threads = 256, iters = 4096;
     int rc = ws.ensure((size_t)blocks * threads * 8);
     if (rc) return rc;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    k_mad_peak<<<blocks, threads, 0, g.stream>>>((uint64_t*)ws.p, 16);
+    k_mad_peak<<<blocks, threads, 0, rt().stream>>>((uint64_t*)ws.p, 16);
     float best = 1e30f;
     for (int rep = 0; rep < 3; rep++) {
-        hipEventRecord(e0, g.stream);
-        k_mad_peak<<<blocks, threads, 0, g.stream>>>((uint64_t*)ws.p, iters);
-        hipEventRecord(e1, g.stream);
+        hipEventRecord(e0, rt().stream);
+        k_mad_peak<<<blocks, threads, 0, rt().stream>>>((uint64_t*)ws.p, iters);
+        hipEventRecord(e1, rt().stream);
         HIP_TRY(hipEventSynchronize(e1));
         float ms = 0; hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
@@ -1098,7 +1113,7 @@ struct HkTrace {
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     void mark(const char* what) {
         if (!on) return;
-        hipStreamSynchronize(g.stream);
+        hipStreamSynchronize(rt().stream);
         auto t1 = std::chrono::steady_clock::now();
         fprintf(stderr, "[atlas trace] hyperkzg_open %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
         t0 = t1;
@@ -1162,9 +1177,9 @@ static int hyperkzg_open_impl(atlas_srs_t srs, atlas_poly_t poly, const atlas_u1
     const size_t n = (size_t)1 << ell;
     if (poly->is_i32 || poly->len != n) return fail(ATLAS_EINVAL, "hyperkzg_open: poly must be LargeScalars of length 2^ell");
     if (srs->len < n) return fail(ATLAS_EINVAL, "hyperkzg_open: KeyLengthError (SRS shorter than the polynomial)");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     H::Transcript& T = *reinterpret_cast<H::Transcript*>(transcript);
-    const int mode = g.challenge_mode;
+    const int mode = rt().challenge_mode;
 
     // one buffer for Pi_0..Pi_{ell-1} (2n - 2 coefficients), B, and the three h_k
     // (kept between calls: the arena only grows — 6n Fr = 192 MB at 2^20 out of 288 GB)
@@ -1182,13 +1197,13 @@ static int hyperkzg_open_impl(atlas_srs_t srs, atlas_poly_t poly, const atlas_u1
 
     HkTrace tr;
     // Phase 1: folds (LowToHigh, variable point[ell-i-1])
-    HIP_TRY(hipMemcpyAsync(polys, poly->d, n * sizeof(Fr), hipMemcpyDeviceToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(polys, poly->d, n * sizeof(Fr), hipMemcpyDeviceToDevice, rt().stream));
     {
         size_t off = 0, len = n;
         for (size_t i = 0; i + 1 < ell; i++) {
             H::Fr x = H::challenge_to_fr(point[ell - i - 1].lo, point[ell - i - 1].hi, mode);
             Fr xd; std::memcpy(xd.v, x.l, 32);
-            k_hk_fold<<<grid_for(len / 2, 2048), HK_THREADS, 0, g.stream>>>(polys + off, polys + off + len, len / 2, xd, mode == 0);
+            k_hk_fold<<<grid_for(len / 2, 2048), HK_THREADS, 0, rt().stream>>>(polys + off, polys + off + len, len / 2, xd, mode == 0);
             off += len; len >>= 1;
         }
     }
@@ -1219,15 +1234,15 @@ static int hyperkzg_open_impl(atlas_srs_t srs, atlas_poly_t poly, const atlas_u1
         H::Fr acc = H::one();
         for (int j = 0; j <= 256; j++) { hpw16[k * 257 + j] = acc; acc = H::mul(acc, u16); }
     }
-    HIP_TRY(hipMemcpyAsync(pw16, hpw16.data(), 3 * 257 * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(pw16, hpw16.data(), 3 * 257 * sizeof(Fr), hipMemcpyHostToDevice, rt().stream));
     tr.mark("transcript + powers");
     // Phase 3a: v[i][j] = Pi_j(u_i), all ell polynomials in two launches and one readback
     std::vector<H::Fr> hv(3 * ell);
     {
-        k_hk_eval_blocks<<<(unsigned)eval_blocks, HK_THREADS, 0, g.stream>>>(polys, n, P, evpart, eval_blocks);
-        k_hk_eval_sum<<<(unsigned)ell, HK_THREADS, 0, g.stream>>>(evpart, eval_blocks, n, (uint32_t)ell, evout);
-        HIP_TRY(hipMemcpyAsync(hv.data(), evout, 3 * ell * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
+        k_hk_eval_blocks<<<(unsigned)eval_blocks, HK_THREADS, 0, rt().stream>>>(polys, n, P, evpart, eval_blocks);
+        k_hk_eval_sum<<<(unsigned)ell, HK_THREADS, 0, rt().stream>>>(evpart, eval_blocks, n, (uint32_t)ell, evout);
+        HIP_TRY(hipMemcpyAsync(hv.data(), evout, 3 * ell * sizeof(Fr), hipMemcpyDeviceToHost, rt().stream));
+        HIP_TRY(hipStreamSynchronize(rt().stream));
     }
     tr.mark("evaluations v");
     std::memcpy(v, hv.data(), 3 * ell * sizeof(Fr));
@@ -1235,12 +1250,12 @@ static int hyperkzg_open_impl(atlas_srs_t srs, atlas_poly_t poly, const atlas_u1
     // q powers (challenge_scalar_powers, blake2b.rs:224-231), B = sum q^j Pi_j
     std::vector<H::Fr> q(ell);
     { H::Fr q1 = H::tr_challenge_scalar(T); q[0] = H::one(); for (size_t j = 1; j < ell; j++) q[j] = H::mul(q[j - 1], q1); }
-    HIP_TRY(hipMemcpyAsync(dq, q.data(), ell * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
-    k_hk_lincomb<<<grid_for(n, 2048), HK_THREADS, 0, g.stream>>>(polys, n, (uint32_t)ell, dq, B);
+    HIP_TRY(hipMemcpyAsync(dq, q.data(), ell * sizeof(Fr), hipMemcpyHostToDevice, rt().stream));
+    k_hk_lincomb<<<grid_for(n, 2048), HK_THREADS, 0, rt().stream>>>(polys, n, (uint32_t)ell, dq, B);
     // Phase 3b: witness polynomials h_k = B / (x - u_k) and their commitments
-    k_hk_scan_blocks<<<(unsigned)n_blocks, HK_THREADS, 0, g.stream>>>(B, n, P, xincl, xs, blocktot, n_blocks);
-    k_hk_scan_grid<<<1, HK_THREADS, 0, g.stream>>>(blocktot, n_blocks, P, G, total);
-    k_hk_witness<<<(unsigned)n_blocks, HK_THREADS, 0, g.stream>>>(B, n, P, xincl, xs, G, n_blocks, pw16, h, n);
+    k_hk_scan_blocks<<<(unsigned)n_blocks, HK_THREADS, 0, rt().stream>>>(B, n, P, xincl, xs, blocktot, n_blocks);
+    k_hk_scan_grid<<<1, HK_THREADS, 0, rt().stream>>>(blocktot, n_blocks, P, G, total);
+    k_hk_witness<<<(unsigned)n_blocks, HK_THREADS, 0, rt().stream>>>(B, n, P, xincl, xs, G, n_blocks, pw16, h, n);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { cleanup(); return fail(ATLAS_ENODEV, "hyperkzg launch", le); }
     tr.mark("lincomb + witness polys");

@@ -34,8 +34,8 @@ extern "C" int atlas_prove_einsum_node(const atlas_einsum_node_t* node, const in
         uint32_t slices = 1;
         while (slices < 64 && (n * ((m + EB_ROWS - 1) / EB_ROWS)) * slices < ((size_t)1 << 16) && k / (slices * 2) >= 32) slices *= 2;
         const uint32_t k_slice = (uint32_t)((k + slices - 1) / slices);
-        HIP_TRY(hipMemsetAsync(d_acc, 0, T * 8, g.stream));
-        k_einsum_acc_mk_kn<<<dim3((unsigned)((n + 255) / 256), (unsigned)((m + EB_ROWS - 1) / EB_ROWS), slices), 256, 0, g.stream>>>(
+        HIP_TRY(hipMemsetAsync(d_acc, 0, T * 8, rt().stream));
+        k_einsum_acc_mk_kn<<<dim3((unsigned)((n + 255) / 256), (unsigned)((m + EB_ROWS - 1) / EB_ROWS), slices), 256, 0, rt().stream>>>(
             d_A, d_B, (uint32_t)m, (uint32_t)k, (uint32_t)n, k_slice, (unsigned long long*)d_acc);
         return ATLAS_OK;
     };
@@ -87,7 +87,7 @@ static int prove_ew_fused_node(int op, const int32_t* d_left, const int32_t* d_r
     Out O{proofs, cap, 0, proof_lens, 0, claims, claims_cap, 0};
     auto fill_acc = [&](int64_t* d_acc) -> int {
         size_t gb = (T + 255) / 256; if (gb > 4096) gb = 4096;
-        k_mul_acc<<<(unsigned)gb, 256, 0, g.stream>>>(d_left, d_right, T, d_acc);
+        k_mul_acc<<<(unsigned)gb, 256, 0, rt().stream>>>(d_left, d_right, T, d_acc);
         return ATLAS_OK;
     };
     auto inner = [&](const H::Fr& in_claim) -> int {
@@ -207,10 +207,10 @@ extern "C" int atlas_prove_addsub_node(const int32_t* d_left, const int32_t* d_r
     HIP_TRY(acc_b.alloc(T * 8)); HIP_TRY(idx_b.alloc(T * 8)); HIP_TRY(fr_b.alloc(T * sizeof(Fr)));
     if (!d_output) { HIP_TRY(out_b.alloc(T * 4)); d_output = out_b.as<int32_t>(); }
     {
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
         size_t gb = (T + 255) / 256; if (gb > 4096) gb = 4096;
-        k_addsub_witness<<<(unsigned)gb, 256, 0, g.stream>>>(d_left, d_right, T, subtract ? 1 : 0, acc_b.as<int64_t>(), d_output, idx_b.as<uint64_t>());
-        k_i64_to_fr<<<(unsigned)gb, 256, 0, g.stream>>>(acc_b.as<int64_t>(), fr_b.as<Fr>(), T);
+        k_addsub_witness<<<(unsigned)gb, 256, 0, rt().stream>>>(d_left, d_right, T, subtract ? 1 : 0, acc_b.as<int64_t>(), d_output, idx_b.as<uint64_t>());
+        k_i64_to_fr<<<(unsigned)gb, 256, 0, rt().stream>>>(acc_b.as<int64_t>(), fr_b.as<Fr>(), T);
     }
     int rc = ATLAS_OK;
     atlas_poly_t p_acc = nullptr, p_out = nullptr, p_l = nullptr, p_r = nullptr;
@@ -242,8 +242,8 @@ extern "C" int atlas_prove_addsub_node(const int32_t* d_left, const int32_t* d_r
     if (exec) atlas_instance_free(exec);
     std::vector<atlas_fr_t> ra_point(64 + log_T);
     if (!rc) {
-        for (size_t i = 0; i < 64; i++) { const H::Fr f = H::challenge_to_fr(ch[i].lo, ch[i].hi, g.challenge_mode); std::memcpy(&ra_point[i], &f, 32); }
-        for (size_t i = 0; i < log_T; i++) { const H::Fr f = H::challenge_to_fr(ch[64 + log_T - 1 - i].lo, ch[64 + log_T - 1 - i].hi, g.challenge_mode); std::memcpy(&ra_point[64 + i], &f, 32); }
+        for (size_t i = 0; i < 64; i++) { const H::Fr f = H::challenge_to_fr(ch[i].lo, ch[i].hi, rt().challenge_mode); std::memcpy(&ra_point[i], &f, 32); }
+        for (size_t i = 0; i < log_T; i++) { const H::Fr f = H::challenge_to_fr(ch[64 + log_T - 1 - i].lo, ch[64 + log_T - 1 - i].hi, rt().challenge_mode); std::memcpy(&ra_point[64 + i], &f, 32); }
     }
     if (stage_ms) stage_ms[1] = ms_since(t0);
     t0 = now();
@@ -279,9 +279,9 @@ extern "C" int atlas_prove_relu_node(const int32_t* d_input, size_t log_T, const
     HIP_TRY(idx_b.alloc(T * 8));
     if (!d_output) { HIP_TRY(out_b.alloc(T * 4)); d_output = out_b.as<int32_t>(); }
     {
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
         size_t gb = (T + 255) / 256; if (gb > 4096) gb = 4096;
-        k_relu_witness<<<(unsigned)gb, 256, 0, g.stream>>>(d_input, T, d_output, idx_b.as<uint64_t>());
+        k_relu_witness<<<(unsigned)gb, 256, 0, rt().stream>>>(d_input, T, d_output, idx_b.as<uint64_t>());
     }
     int rc = ATLAS_OK;
     atlas_poly_t p_in = nullptr, p_out = nullptr;
@@ -311,8 +311,8 @@ extern "C" int atlas_prove_relu_node(const int32_t* d_input, size_t log_T, const
     if (exec) atlas_instance_free(exec);
     std::vector<atlas_fr_t> ra_point(XLEN + log_T);                               // normalize_opening_point (ps_shout/mod.rs:150-158)
     if (!rc) {
-        for (size_t i = 0; i < XLEN; i++) { const H::Fr f = H::challenge_to_fr(ch[i].lo, ch[i].hi, g.challenge_mode); std::memcpy(&ra_point[i], &f, 32); }
-        for (size_t i = 0; i < log_T; i++) { const H::Fr f = H::challenge_to_fr(ch[XLEN + log_T - 1 - i].lo, ch[XLEN + log_T - 1 - i].hi, g.challenge_mode); std::memcpy(&ra_point[XLEN + i], &f, 32); }
+        for (size_t i = 0; i < XLEN; i++) { const H::Fr f = H::challenge_to_fr(ch[i].lo, ch[i].hi, rt().challenge_mode); std::memcpy(&ra_point[i], &f, 32); }
+        for (size_t i = 0; i < log_T; i++) { const H::Fr f = H::challenge_to_fr(ch[XLEN + log_T - 1 - i].lo, ch[XLEN + log_T - 1 - i].hi, rt().challenge_mode); std::memcpy(&ra_point[XLEN + i], &f, 32); }
     }
     if (stage_ms) stage_ms[1] = ms_since(t0);
     t0 = now();

@@ -33,7 +33,7 @@ struct RaIds { uint8_t ra_vp, rad_cp; };
 using namespace atlas;
 namespace H = atlas_host;
 using atlas_rt::fail;
-using atlas_rt::g;
+using atlas_rt::rt;
 
 namespace {
 
@@ -148,7 +148,7 @@ struct Out {
 };
 
 inline gr::Point to_point(const atlas_fr_t* r, size_t n) { gr::Point p(n); if (n) std::memcpy(p.data(), r, n * 32); return p; }
-inline H::Fr ch_fr(const atlas_u128_t& c) { return H::challenge_to_fr(c.lo, c.hi, g.challenge_mode); }
+inline H::Fr ch_fr(const atlas_u128_t& c) { return H::challenge_to_fr(c.lo, c.hi, rt().challenge_mode); }
 
 // Sumcheck::prove of one read-raf instance (PS-Shout / IdentityRC: log_K address rounds then log_T cycle rounds) + its
 // single cache_openings claim: append_virtual(ra_vp(node), NodeExecution(node)) at normalize_opening_point = the address
@@ -248,8 +248,8 @@ int onehot_families_build(std::vector<OneHotFamily>& fams, size_t log_T, atlas_t
         std::vector<H::Fr> gamma_powers(d);                         // challenge_scalar_powers(d)
         { const H::Fr q = H::tr_challenge_scalar(T); gamma_powers[0] = H::one(); for (size_t i = 1; i < d; i++) gamma_powers[i] = H::mul(gamma_powers[i - 1], q); }
         std::vector<H::Fr> gammas(d), r_addr(lkc);                   // challenge_vector_optimized
-        for (size_t i = 0; i < d; i++) { uint64_t lo, hi; H::tr_challenge_u128(T, lo, hi); gammas[i] = H::challenge_to_fr(lo, hi, g.challenge_mode); }
-        for (size_t i = 0; i < lkc; i++) { uint64_t lo, hi; H::tr_challenge_u128(T, lo, hi); r_addr[i] = H::challenge_to_fr(lo, hi, g.challenge_mode); }
+        for (size_t i = 0; i < d; i++) { uint64_t lo, hi; H::tr_challenge_u128(T, lo, hi); gammas[i] = H::challenge_to_fr(lo, hi, rt().challenge_mode); }
+        for (size_t i = 0; i < lkc; i++) { uint64_t lo, hi; H::tr_challenge_u128(T, lo, hi); r_addr[i] = H::challenge_to_fr(lo, hi, rt().challenge_mode); }
         // G = compute_ra_evals(lookup_indices, params, r_cycle) (shout.rs:550-598)
         std::vector<H::Fr> Gh;
         if (F.G_pre) Gh = *F.G_pre;
@@ -368,12 +368,12 @@ int make_rescale_witness(size_t T, size_t S, FillAcc&& fill_acc, int32_t* d_outp
     if (e == hipSuccess && !d_output) { e = W.out_own.alloc(T * 4); d_output = W.out_own.as<int32_t>(); }
     if (e != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(fused-rescale witness)", e);
     W.d_output = d_output;
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     size_t gb = (T + 255) / 256; if (gb > 4096) gb = 4096;
     int rc = fill_acc(W.quot.as<int64_t>());
     if (rc) return rc;
-    k_einsum_rebase<<<(unsigned)gb, 256, 0, g.stream>>>(W.quot.as<int64_t>(), T, (uint32_t)S, W.rem.as<int32_t>(), d_output, W.cidx.as<uint64_t>(), W.ridx.as<uint64_t>());
-    k_i64_to_fr<<<(unsigned)gb, 256, 0, g.stream>>>(W.quot.as<int64_t>(), W.qfr.as<Fr>(), T);
+    k_einsum_rebase<<<(unsigned)gb, 256, 0, rt().stream>>>(W.quot.as<int64_t>(), T, (uint32_t)S, W.rem.as<int32_t>(), d_output, W.cidx.as<uint64_t>(), W.ridx.as<uint64_t>());
+    k_i64_to_fr<<<(unsigned)gb, 256, 0, rt().stream>>>(W.quot.as<int64_t>(), W.qfr.as<Fr>(), T);
     return ATLAS_OK;
 }
 

@@ -30,7 +30,7 @@
 using namespace atlas;
 namespace H = atlas_host;
 using atlas_rt::fail;
-using atlas_rt::g;
+using atlas_rt::rt;
 
 int atlas_rt_eq_evals_into(const H::Fr* r, size_t n, Fr* ev);      // spliteq.hip
 
@@ -141,10 +141,10 @@ struct GseDevH {
         HIP_TRY(hipMalloc(&d_eout, ((size_t)2 << st.k_out) * sizeof(Fr)));
         HIP_TRY(hipMalloc(&d_part, 2048 * sizeof(Fr)));
         HIP_TRY(hipMalloc(&d_sum, sizeof(Fr)));
-        if (n) HIP_TRY(hipMemcpyAsync(d_w, w, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
-        k_eq_cached_rev<<<1, 1024, 0, g.stream>>>(d_ein, d_w + (n ? 1 : 0), (uint32_t)st.k_in);
-        k_eq_cached_rev<<<1, 1024, 0, g.stream>>>(d_eout, d_w + (n ? 1 : 0) + st.k_in, (uint32_t)st.k_out);
-        HIP_TRY(hipStreamSynchronize(g.stream));
+        if (n) HIP_TRY(hipMemcpyAsync(d_w, w, n * sizeof(Fr), hipMemcpyHostToDevice, rt().stream));
+        k_eq_cached_rev<<<1, 1024, 0, rt().stream>>>(d_ein, d_w + (n ? 1 : 0), (uint32_t)st.k_in);
+        k_eq_cached_rev<<<1, 1024, 0, rt().stream>>>(d_eout, d_w + (n ? 1 : 0) + st.k_in, (uint32_t)st.k_out);
+        HIP_TRY(hipStreamSynchronize(rt().stream));
         return ATLAS_OK;
     }
     SplitEqView view() const {     // high index bits <- w_in suffix, low bits <- w_out suffix
@@ -159,19 +159,19 @@ struct GseDevH {
     template <class T>
     int q0_async(const T* P, size_t half, Fr* host_slot) {
         const unsigned grid = grid_for(half);
-        k_open_fold<T><<<grid, OP_THREADS, 0, g.stream>>>(P, half, view(), d_part, make_consts());
-        k_open_reduce<<<1, OP_THREADS, 0, g.stream>>>(d_part, grid, host_slot);
+        k_open_fold<T><<<grid, OP_THREADS, 0, rt().stream>>>(P, half, view(), d_part, make_consts());
+        k_open_reduce<<<1, OP_THREADS, 0, rt().stream>>>(d_part, grid, host_slot);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? ATLAS_OK : fail(ATLAS_ENODEV, "dense_opening: fold", e);
     }
     template <class T>
     int q0(const T* P, size_t half, H::Fr* out) {
         const unsigned grid = grid_for(half);
-        k_open_fold<T><<<grid, OP_THREADS, 0, g.stream>>>(P, half, view(), d_part, make_consts());
-        if (grid > 1) k_open_reduce<<<1, OP_THREADS, 0, g.stream>>>(d_part, grid, d_sum);
-        HIP_TRY(hipMemcpyAsync(g.h_pinned, grid > 1 ? d_sum : d_part, sizeof(Fr), hipMemcpyDeviceToHost, g.stream));   // one workgroup: its partial is the sum
-        HIP_TRY(hipStreamSynchronize(g.stream));
-        std::memcpy(out, g.h_pinned, sizeof(Fr));
+        k_open_fold<T><<<grid, OP_THREADS, 0, rt().stream>>>(P, half, view(), d_part, make_consts());
+        if (grid > 1) k_open_reduce<<<1, OP_THREADS, 0, rt().stream>>>(d_part, grid, d_sum);
+        HIP_TRY(hipMemcpyAsync(rt().h_pinned, grid > 1 ? d_sum : d_part, sizeof(Fr), hipMemcpyDeviceToHost, rt().stream));   // one workgroup: its partial is the sum
+        HIP_TRY(hipStreamSynchronize(rt().stream));
+        std::memcpy(out, rt().h_pinned, sizeof(Fr));
         return ATLAS_OK;
     }
     void release() { for (Fr* p : {d_w, d_ein, d_eout, d_part, d_sum}) if (p) hipFree(p); d_w = d_ein = d_eout = d_part = d_sum = nullptr; }
@@ -187,18 +187,18 @@ struct DenseOpening : atlas_instance {
     size_t degree() const override { return 2; }
     // In a batch of thousands (the opening reduction of a graph holds ~50 dense members beside the one-hot rows) a synchronisation per dense
     // member and round was 1.3 ms per round: the driver calls shared_message_step of every member first — this one launches its fold, the sum
-    // going to a pinned slot — synchronises ONCE (g.pending_async), and message() finds the sum there.
+    // going to a pinned slot — synchronises ONCE (rt().pending_async), and message() finds the sum there.
     atlas::Chunk* slot = nullptr;
     size_t slot_round = (size_t)-1;
     bool host_parallel() const override { return true; }
     int shared_message_step(size_t round) override {
         if (round != round_next || round >= n) return ATLAS_OK;
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
-        if (!slot) slot = g.chan.alloc_long(2);
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+        if (!slot) slot = rt().chan.alloc_long(2);
         const int rc = P->is_i32 ? D.q0_async<int32_t>((const int32_t*)P->d, P->len / 2, reinterpret_cast<Fr*>(slot)) : D.q0_async<Fr>((const Fr*)P->d, P->len / 2, reinterpret_cast<Fr*>(slot));
         if (rc) return rc;
         slot_round = round;
-        g.pending_async++;
+        rt().pending_async++;
         return ATLAS_OK;
     }
     int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
@@ -208,7 +208,7 @@ struct DenseOpening : atlas_instance {
             std::memcpy(&q0, slot, sizeof(q0));
             slot_round = (size_t)-1;
         } else {
-            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+            std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
             const int rc = P->is_i32 ? D.q0<int32_t>((const int32_t*)P->d, P->len / 2, &q0) : D.q0<Fr>((const Fr*)P->d, P->len / 2, &q0);
             if (rc) return rc;
         }
@@ -220,14 +220,14 @@ struct DenseOpening : atlas_instance {
     size_t bound_round = (size_t)-1;
     int bind_device(const atlas_u128_t& r, size_t round) {
         if (bound_round == round) return ATLAS_OK;
-        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode);
         if (P->is_i32) {                                            // CompactPolynomial first bind: promotes to Fr (and syncs)
             int rc = atlas_poly_bind(P, &r, ATLAS_HIGH_TO_LOW);
             if (rc) return rc;
         } else {                                                    // in place, stream-ordered, no host wait
-            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+            std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
             const size_t half = P->len / 2;
-            k_open_bind_hi<<<grid_for(half, 4096), OP_THREADS, 0, g.stream>>>((Fr*)P->d, half, to_dev(rf), g.challenge_mode == 0 ? 1 : 0);
+            k_open_bind_hi<<<grid_for(half, 4096), OP_THREADS, 0, rt().stream>>>((Fr*)P->d, half, to_dev(rf), rt().challenge_mode == 0 ? 1 : 0);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail(ATLAS_ENODEV, "dense_opening: bind", e);
             P->len = half;
@@ -243,7 +243,7 @@ struct DenseOpening : atlas_instance {
         if (round != round_next || round >= n) return fail(ATLAS_ESTATE, "dense_opening: round out of order");
         const int rc = bind_device(r, round);
         if (rc) return rc;
-        D.st.bind(H::challenge_to_fr(r.lo, r.hi, g.challenge_mode));
+        D.st.bind(H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode));
         round_next++;
         return ATLAS_OK;
     }
@@ -289,7 +289,7 @@ struct OneHotOpening : atlas_instance {
         }
         H::Fr q0;                                                    // :634-676
         {
-            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+            std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
             const int rc = D.q0<Fr>(d_H, H_len / 2, &q0);
             if (rc) return rc;
         }
@@ -302,7 +302,7 @@ struct OneHotOpening : atlas_instance {
 
     int ingest(const atlas_u128_t& r, size_t round) override {      // :679-718
         if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "onehot_opening: round out of order");
-        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode);
         if (round < log_K) {
             const size_t half = B.size() / 2;
             for (size_t i = 0; i < half; i++) B[i] = H::add(B[i], H::mul(rf, H::sub(B[i + half], B[i])));
@@ -311,21 +311,21 @@ struct OneHotOpening : atlas_instance {
             for (size_t i = 0; i < F.size(); i++) { nf[2 * i + 1] = H::mul(rf, F[i]); nf[2 * i] = H::sub(F[i], nf[2 * i + 1]); }
             F.swap(nf);
             if (round == log_K - 1) {
-                std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+                std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
                 const size_t T = (size_t)1 << log_T;
                 DevBuf Fb;
                 HIP_TRY(Fb.alloc(F.size() * sizeof(Fr)));
-                HIP_TRY(hipMemcpyAsync(Fb.p, F.data(), F.size() * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
-                k_onehot_gather<<<grid_for(T, 4096), OP_THREADS, 0, g.stream>>>(d_idx, Fb.as<Fr>(), T, d_H);
-                hipError_t e = hipStreamSynchronize(g.stream);
+                HIP_TRY(hipMemcpyAsync(Fb.p, F.data(), F.size() * sizeof(Fr), hipMemcpyHostToDevice, rt().stream));
+                k_onehot_gather<<<grid_for(T, 4096), OP_THREADS, 0, rt().stream>>>(d_idx, Fb.as<Fr>(), T, d_H);
+                hipError_t e = hipStreamSynchronize(rt().stream);
                 if (e != hipSuccess) return fail(ATLAS_ENODEV, "onehot_opening: gather", e);
                 H_len = T;
                 G.clear();
             }
         } else {
-            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+            std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
             const size_t half = H_len / 2;
-            k_open_bind_hi<<<grid_for(half, 4096), OP_THREADS, 0, g.stream>>>(d_H, half, to_dev(rf), g.challenge_mode == 0 ? 1 : 0);
+            k_open_bind_hi<<<grid_for(half, 4096), OP_THREADS, 0, rt().stream>>>(d_H, half, to_dev(rf), rt().challenge_mode == 0 ? 1 : 0);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail(ATLAS_ENODEV, "onehot_opening: bind", e);
             H_len = half;
@@ -337,11 +337,11 @@ struct OneHotOpening : atlas_instance {
 
     int finals(std::vector<H::Fr>& out) override {
         if (round_next != rounds()) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
         out.resize(1);
-        HIP_TRY(hipMemcpyAsync(g.h_pinned, d_H, sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
-        std::memcpy(out.data(), g.h_pinned, sizeof(Fr));
+        HIP_TRY(hipMemcpyAsync(rt().h_pinned, d_H, sizeof(Fr), hipMemcpyDeviceToHost, rt().stream));
+        HIP_TRY(hipStreamSynchronize(rt().stream));
+        std::memcpy(out.data(), rt().h_pinned, sizeof(Fr));
         return ATLAS_OK;
     }
 };
@@ -423,18 +423,18 @@ struct OneHotGroup {
         if (bound_rounds != cycle_round) return fail(ATLAS_ESTATE, "onehot group: rows of a group must advance round by round together");
         const size_t half = H_len / 2;
         const unsigned grid = grid_for(half, 512);
-        k_open_fold_rows<<<dim3(grid, (unsigned)R), OP_THREADS, 0, g.stream>>>(d_H, T, half, D.view(), d_part);
-        k_open_reduce_rows<<<(unsigned)R, OP_THREADS, 0, g.stream>>>(d_part, grid, d_q0);
+        k_open_fold_rows<<<dim3(grid, (unsigned)R), OP_THREADS, 0, rt().stream>>>(d_H, T, half, D.view(), d_part);
+        k_open_reduce_rows<<<(unsigned)R, OP_THREADS, 0, rt().stream>>>(d_part, grid, d_q0);
         q0.resize(R);
-        HIP_TRY(hipMemcpyAsync(q0.data(), d_q0, R * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
+        HIP_TRY(hipMemcpyAsync(q0.data(), d_q0, R * sizeof(Fr), hipMemcpyDeviceToHost, rt().stream));
+        HIP_TRY(hipStreamSynchronize(rt().stream));
         q0_round = cycle_round; q0_scalar = D.st.scalar; q0_w = D.st.w_cur();
         return ATLAS_OK;
     }
     int bind_all(size_t cycle_round, const H::Fr& rf) {   // "if num_variables_bound <= round" (opening_reduction.rs:686-698)
         if (bound_rounds > cycle_round) return ATLAS_OK;
         const size_t half = H_len / 2;
-        k_open_bind_hi_rows<<<dim3(grid_for(half, 1024), (unsigned)R), OP_THREADS, 0, g.stream>>>(d_H, T, half, to_dev(rf), g.challenge_mode == 0 ? 1 : 0);
+        k_open_bind_hi_rows<<<dim3(grid_for(half, 1024), (unsigned)R), OP_THREADS, 0, rt().stream>>>(d_H, T, half, to_dev(rf), rt().challenge_mode == 0 ? 1 : 0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(ATLAS_ENODEV, "onehot group bind", e);
         H_len = half;
@@ -477,7 +477,7 @@ struct OneHotRow : atlas_instance {
             return ATLAS_OK;
         }
         {
-            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+            std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
             const int rc = grp->fold_all(round - log_K);
             if (rc) return rc;
         }
@@ -490,7 +490,7 @@ struct OneHotRow : atlas_instance {
 
     int ingest(const atlas_u128_t& r, size_t round) override {
         if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "onehot_opening: round out of order");
-        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode);
         const size_t log_K = grp->log_K;
         if (round < log_K) {
             const size_t half = B.size() / 2;
@@ -500,18 +500,18 @@ struct OneHotRow : atlas_instance {
             for (size_t i = 0; i < F.size(); i++) { nf[2 * i + 1] = H::mul(rf, F[i]); nf[2 * i] = H::sub(F[i], nf[2 * i + 1]); }
             F.swap(nf);
             if (round == log_K - 1) {                                // this row's H = F[idx]
-                std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+                std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
                 const size_t T = grp->T;
                 DevBuf Fb;
                 HIP_TRY(Fb.alloc(F.size() * sizeof(Fr)));
-                HIP_TRY(hipMemcpyAsync(Fb.p, F.data(), F.size() * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
-                k_onehot_gather<<<grid_for(T, 4096), OP_THREADS, 0, g.stream>>>(grp->d_idx + row * T, Fb.as<Fr>(), T, grp->d_H + row * T);
-                hipError_t e = hipStreamSynchronize(g.stream);
+                HIP_TRY(hipMemcpyAsync(Fb.p, F.data(), F.size() * sizeof(Fr), hipMemcpyHostToDevice, rt().stream));
+                k_onehot_gather<<<grid_for(T, 4096), OP_THREADS, 0, rt().stream>>>(grp->d_idx + row * T, Fb.as<Fr>(), T, grp->d_H + row * T);
+                hipError_t e = hipStreamSynchronize(rt().stream);
                 if (e != hipSuccess) return fail(ATLAS_ENODEV, "onehot_opening: gather", e);
                 grp->G[row].clear();
             }
         } else {
-            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+            std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
             const int rc = grp->bind_all(round - log_K, rf);
             if (rc) return rc;
         }
@@ -521,11 +521,11 @@ struct OneHotRow : atlas_instance {
 
     int finals(std::vector<H::Fr>& out) override {
         if (round_next != rounds()) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
         out.resize(1);
-        HIP_TRY(hipMemcpyAsync(g.h_pinned, grp->d_H + row * grp->T, sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
-        std::memcpy(out.data(), g.h_pinned, sizeof(Fr));
+        HIP_TRY(hipMemcpyAsync(rt().h_pinned, grp->d_H + row * grp->T, sizeof(Fr), hipMemcpyDeviceToHost, rt().stream));
+        HIP_TRY(hipStreamSynchronize(rt().stream));
+        std::memcpy(out.data(), rt().h_pinned, sizeof(Fr));
         return ATLAS_OK;
     }
 };
@@ -682,7 +682,7 @@ struct OneHotPool {
     uint64_t* d_off = nullptr;
     PoolRowDev *d_desc = nullptr, *h_desc = nullptr;       // h_desc: pinned staging, three regions of rows.size() descriptors (fold, bind, gather)
     Fr* h_q0 = nullptr;                                     // pinned
-    // global rounds already folded / bound.  Written LAST by fold_all / bind_all (under g.mu): a row that reads the current round here without
+    // global rounds already folded / bound.  Written LAST by fold_all / bind_all (under rt().mu): a row that reads the current round here without
     // the lock (worker threads of a large batch, host_parallel) sees everything those calls wrote
     std::atomic<size_t> folded{(size_t)-1}, bound{(size_t)-1};
     bool have_finals = false;
@@ -705,7 +705,7 @@ struct OneHotPool {
         E.in_bits = (uint32_t)G.st.out_top;
         return E;
     }
-    // the caller holds g.mu.  H = F[idx] for the rows whose address phase ended in the round before R (their ingests have all run)
+    // the caller holds rt().mu.  H = F[idx] for the rows whose address phase ended in the round before R (their ingests have all run)
     int gather_pending(size_t R) {
         std::vector<size_t> todo;
         for (auto& G : groups) if (cycle_of(G, R) == 0) for (size_t r : G.rows) if (!rows[r].gathered) todo.push_back(r);
@@ -729,10 +729,10 @@ struct OneHotPool {
         }
         size_t maxT = 0;
         for (size_t r : todo) maxT = groups[rows[r].group].T > maxT ? groups[rows[r].group].T : maxT;
-        HIP_TRY(hipMemcpyAsync(d_F, Fh.data(), Fh.size() * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
-        HIP_TRY(hipMemcpyAsync(d_desc + 2 * rows.size(), hd, todo.size() * sizeof(PoolRowDev), hipMemcpyHostToDevice, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));                 // Fh leaves scope (pageable source)
-        k_pool_gather<<<dim3(grid_for(maxT, POOL_GX), (unsigned)todo.size()), OP_THREADS, 0, g.stream>>>(d_desc + 2 * rows.size());
+        HIP_TRY(hipMemcpyAsync(d_F, Fh.data(), Fh.size() * sizeof(Fr), hipMemcpyHostToDevice, rt().stream));
+        HIP_TRY(hipMemcpyAsync(d_desc + 2 * rows.size(), hd, todo.size() * sizeof(PoolRowDev), hipMemcpyHostToDevice, rt().stream));
+        HIP_TRY(hipStreamSynchronize(rt().stream));                 // Fh leaves scope (pageable source)
+        k_pool_gather<<<dim3(grid_for(maxT, POOL_GX), (unsigned)todo.size()), OP_THREADS, 0, rt().stream>>>(d_desc + 2 * rows.size());
         return ATLAS_OK;
     }
     int fold_all(size_t R) {
@@ -754,11 +754,11 @@ struct OneHotPool {
         }
         if (n == 0) { folded.store(R, std::memory_order_release); return ATLAS_OK; }
         const unsigned gx = grid_for(max_half, POOL_GX);
-        HIP_TRY(hipMemcpyAsync(d_desc, h_desc, n * sizeof(PoolRowDev), hipMemcpyHostToDevice, g.stream));
-        k_pool_fold<<<dim3(gx, (unsigned)n), OP_THREADS, 0, g.stream>>>(d_desc, d_part);
-        k_pool_reduce<<<(unsigned)n, 64, 0, g.stream>>>(d_part, gx, d_q0);
-        HIP_TRY(hipMemcpyAsync(h_q0, d_q0, n * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
+        HIP_TRY(hipMemcpyAsync(d_desc, h_desc, n * sizeof(PoolRowDev), hipMemcpyHostToDevice, rt().stream));
+        k_pool_fold<<<dim3(gx, (unsigned)n), OP_THREADS, 0, rt().stream>>>(d_desc, d_part);
+        k_pool_reduce<<<(unsigned)n, 64, 0, rt().stream>>>(d_part, gx, d_q0);
+        HIP_TRY(hipMemcpyAsync(h_q0, d_q0, n * sizeof(Fr), hipMemcpyDeviceToHost, rt().stream));
+        HIP_TRY(hipStreamSynchronize(rt().stream));
         n = 0;
         for (auto& G : groups) {
             if (cycle_of(G, R) < 0) continue;
@@ -782,8 +782,8 @@ struct OneHotPool {
             G.st.bind(rf);
         }
         if (n == 0) { bound.store(R, std::memory_order_release); return ATLAS_OK; }
-        HIP_TRY(hipMemcpyAsync(d_desc + rows.size(), hd, n * sizeof(PoolRowDev), hipMemcpyHostToDevice, g.stream));
-        k_pool_bind<<<dim3(grid_for(max_half, POOL_GX), (unsigned)n), OP_THREADS, 0, g.stream>>>(d_desc + rows.size(), to_dev(rf), g.challenge_mode == 0 ? 1 : 0);
+        HIP_TRY(hipMemcpyAsync(d_desc + rows.size(), hd, n * sizeof(PoolRowDev), hipMemcpyHostToDevice, rt().stream));
+        k_pool_bind<<<dim3(grid_for(max_half, POOL_GX), (unsigned)n), OP_THREADS, 0, rt().stream>>>(d_desc + rows.size(), to_dev(rf), rt().challenge_mode == 0 ? 1 : 0);
         hipError_t e = hipGetLastError();
         bound.store(R, std::memory_order_release);
         return e == hipSuccess ? ATLAS_OK : fail(ATLAS_ENODEV, "onehot pool bind", e);
@@ -791,10 +791,10 @@ struct OneHotPool {
     int fetch_finals() {
         if (have_finals) return ATLAS_OK;
         const size_t n = rows.size();
-        k_pool_heads<<<grid_for(n, 64), OP_THREADS, 0, g.stream>>>(d_H, d_off, (uint32_t)n, d_q0);
+        k_pool_heads<<<grid_for(n, 64), OP_THREADS, 0, rt().stream>>>(d_H, d_off, (uint32_t)n, d_q0);
         std::vector<H::Fr> f(n);
-        HIP_TRY(hipMemcpyAsync(f.data(), d_q0, n * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
+        HIP_TRY(hipMemcpyAsync(f.data(), d_q0, n * sizeof(Fr), hipMemcpyDeviceToHost, rt().stream));
+        HIP_TRY(hipStreamSynchronize(rt().stream));
         for (size_t r = 0; r < n; r++) rows[r].fin = f[r];
         have_finals = true;
         return ATLAS_OK;
@@ -831,7 +831,7 @@ struct OneHotPoolRow : atlas_instance {
         }
         const size_t R = round + P->row_off(Rw);
         if (P->folded.load(std::memory_order_acquire) != R) {        // the first row to ask does the shared fold; the others (worker threads: host_parallel) find it done
-            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+            std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
             const int rc = P->fold_all(R);
             if (rc) return rc;
         }
@@ -850,7 +850,7 @@ struct OneHotPoolRow : atlas_instance {
     int ingest(const atlas_u128_t& r, size_t round) override {      // :679-718
         if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "onehot_opening: round out of order");
         OneHotPool::Row& Rw = P->rows[row];
-        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode);
         if (round < P->log_K) {
             const size_t half = Rw.B.size() / 2;
             for (size_t i = 0; i < half; i++) Rw.B[i] = H::add(Rw.B[i], H::mul(rf, H::sub(Rw.B[i + half], Rw.B[i])));
@@ -859,7 +859,7 @@ struct OneHotPoolRow : atlas_instance {
             for (size_t i = 0; i < Rw.F.size(); i++) { nf[2 * i + 1] = H::mul(rf, Rw.F[i]); nf[2 * i] = H::sub(Rw.F[i], nf[2 * i + 1]); }
             Rw.F.swap(nf);                                           // the gather H = F[idx] runs with the next round's fold (gather_pending)
         } else if (P->bound.load(std::memory_order_acquire) != round + P->row_off(Rw)) {
-            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+            std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
             const int rc = P->bind_all(round + P->row_off(Rw), rf);
             if (rc) return rc;
         }
@@ -872,19 +872,19 @@ struct OneHotPoolRow : atlas_instance {
         if (round != round_next || round >= rounds() || round < P->log_K) return ATLAS_OK;
         const size_t R = round + P->row_off(P->rows[row]);
         if (P->folded.load(std::memory_order_acquire) == R) return ATLAS_OK;
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
         return P->fold_all(R);
     }
     int shared_ingest_step(const atlas_u128_t& r, size_t round) override {
         if (round != round_next || round >= rounds() || round < P->log_K) return ATLAS_OK;
         const size_t R = round + P->row_off(P->rows[row]);
         if (P->bound.load(std::memory_order_acquire) == R) return ATLAS_OK;
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
-        return P->bind_all(R, H::challenge_to_fr(r.lo, r.hi, g.challenge_mode));
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+        return P->bind_all(R, H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode));
     }
     int finals(std::vector<H::Fr>& out) override {
         if (round_next != rounds()) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
         const int rc = P->fetch_finals();
         if (rc) return rc;
         out.assign(1, P->rows[row].fin);
@@ -901,7 +901,7 @@ struct OneHotPoolRow : atlas_instance {
 struct atlas_rt_pool_row { const uint64_t* d_lookups; size_t shift, log_T; const atlas_fr_t* point; };
 int atlas_rt_onehot_pool_new(const atlas_rt_pool_row* in, size_t n, size_t log_K, size_t batch_max_rounds, atlas_instance_t* out, const int32_t** d_idx_rows) {
     if (!in || !out || n == 0 || log_K == 0 || log_K > 4) return fail(ATLAS_EINVAL, "onehot_pool_new: 1 <= log_K <= 4");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     std::unique_ptr<OneHotPool> P(new OneHotPool());
     P->log_K = log_K; P->K = (size_t)1 << log_K; P->max_rounds = batch_max_rounds;
     P->rows.resize(n);
@@ -975,13 +975,13 @@ int atlas_rt_onehot_pool_new(const atlas_rt_pool_row* in, size_t n, size_t log_K
         lkp[i] = in[i].d_lookups; sh[i] = (uint32_t)in[i].shift; Ts[i] = (uint32_t)G.T; off[i] = P->rows[i].off; Eptr[i] = d_E + g_E[P->rows[i].group];
         maxT = G.T > maxT ? G.T : maxT;
     }
-    HIP_TRY(hipMemcpyAsync(d_w, w_all.data(), w_all.size() * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipMemcpyAsync(d_lk, lkp.data(), n * sizeof(void*), hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipMemcpyAsync(d_shift, sh.data(), n * 4, hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipMemcpyAsync(d_Ts, Ts.data(), n * 4, hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipMemcpyAsync(P->d_off, off.data(), n * 8, hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipMemcpyAsync(d_Eptr, Eptr.data(), n * sizeof(void*), hipMemcpyHostToDevice, g.stream));
-    k_pool_chunk_rows<<<dim3(grid_for(maxT, POOL_GX), (unsigned)n), OP_THREADS, 0, g.stream>>>(d_lk, d_shift, P->d_off, d_Ts, (uint32_t)(P->K - 1), P->d_idx);
+    HIP_TRY(hipMemcpyAsync(d_w, w_all.data(), w_all.size() * sizeof(Fr), hipMemcpyHostToDevice, rt().stream));
+    HIP_TRY(hipMemcpyAsync(d_lk, lkp.data(), n * sizeof(void*), hipMemcpyHostToDevice, rt().stream));
+    HIP_TRY(hipMemcpyAsync(d_shift, sh.data(), n * 4, hipMemcpyHostToDevice, rt().stream));
+    HIP_TRY(hipMemcpyAsync(d_Ts, Ts.data(), n * 4, hipMemcpyHostToDevice, rt().stream));
+    HIP_TRY(hipMemcpyAsync(P->d_off, off.data(), n * 8, hipMemcpyHostToDevice, rt().stream));
+    HIP_TRY(hipMemcpyAsync(d_Eptr, Eptr.data(), n * sizeof(void*), hipMemcpyHostToDevice, rt().stream));
+    k_pool_chunk_rows<<<dim3(grid_for(maxT, POOL_GX), (unsigned)n), OP_THREADS, 0, rt().stream>>>(d_lk, d_shift, P->d_off, d_Ts, (uint32_t)(P->K - 1), P->d_idx);
     // the split-eq suffix tables (GseDevH::init) and D.merge() before any bind = EqPolynomial::evals(r_cycle) for the histogram: all groups at once
     std::vector<PoolEqJob> jobs(3 * NG);
     PoolEqJob* d_jobs = nullptr;
@@ -995,13 +995,13 @@ int atlas_rt_onehot_pool_new(const atlas_rt_pool_row* in, size_t n, size_t log_K
         const size_t nh = G.log_T < 8 ? 0 : G.log_T - 8, hb = (((size_t)1 << nh) + POOL_EQ_HI - 1) / POOL_EQ_HI;
         max_hi_blocks = hb > max_hi_blocks ? hb : max_hi_blocks;
     }
-    HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(PoolEqJob), hipMemcpyHostToDevice, g.stream));      // (jobs lives until the synchronisation below)
-    k_pool_eq_cached_rev<<<(unsigned)(2 * NG), 1024, 0, g.stream>>>(d_jobs);
-    k_pool_eq_full<<<dim3((unsigned)max_hi_blocks, (unsigned)NG), 256, 0, g.stream>>>(d_jobs + 2 * NG);
-    k_pool_hist<<<(unsigned)n, OP_THREADS, 0, g.stream>>>(P->d_idx, P->d_off, d_Ts, d_Eptr, (uint32_t)P->K, d_hist);
+    HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(PoolEqJob), hipMemcpyHostToDevice, rt().stream));      // (jobs lives until the synchronisation below)
+    k_pool_eq_cached_rev<<<(unsigned)(2 * NG), 1024, 0, rt().stream>>>(d_jobs);
+    k_pool_eq_full<<<dim3((unsigned)max_hi_blocks, (unsigned)NG), 256, 0, rt().stream>>>(d_jobs + 2 * NG);
+    k_pool_hist<<<(unsigned)n, OP_THREADS, 0, rt().stream>>>(P->d_idx, P->d_off, d_Ts, d_Eptr, (uint32_t)P->K, d_hist);
     std::vector<unsigned long long> hist(n * 16 * 8);
-    HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, hist.size() * 8, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, hist.size() * 8, hipMemcpyDeviceToHost, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     for (size_t i = 0; i < n; i++) {
         OneHotPool::Row& R = P->rows[i];
         R.G.resize(P->K);
@@ -1026,7 +1026,7 @@ int atlas_dense_opening_new(atlas_poly_t poly, const atlas_fr_t* opening_point, 
     NEED_INIT();
     if (!poly || (!opening_point && n) || !out) return fail(ATLAS_EINVAL, "dense_opening_new: null argument");
     if (poly->len != ((size_t)1 << n)) return fail(ATLAS_EINVAL, "dense_opening_new: polynomial length != 2^n");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     DenseOpening* P = new DenseOpening();
     P->n = n;
     // n == 0: a one-coefficient polynomial (the committed remainder / quotient of a one-element ScalarConstDiv / Div) — a member of the
@@ -1050,7 +1050,7 @@ int atlas_onehot_opening_new(const int32_t* nonzero_indices, size_t log_K, size_
     atlas_poly_t E = nullptr;
     int rc = atlas_eq_evals(r_cycle, log_T, nullptr, &E);
     if (rc) return rc;
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     OneHotOpening* P = new OneHotOpening();
     P->log_K = log_K; P->log_T = log_T;
     P->B = H::eq_evals(reinterpret_cast<const H::Fr*>(r_address), log_K);   // EqAddressState::new
@@ -1063,12 +1063,12 @@ int atlas_onehot_opening_new(const int32_t* nonzero_indices, size_t log_K, size_
     size_t slices = 2048 / K; if (slices < 1) slices = 1; if (slices > (T + 4095) / 4096) slices = (T + 4095) / 4096;
     std::vector<H::Fr> hG(slices * K);
     if (e == hipSuccess) e = hipMalloc(&d_G, slices * K * sizeof(Fr));
-    if (e == hipSuccess) e = hipMemcpyAsync(P->d_idx, nonzero_indices, T * sizeof(int32_t), hipMemcpyHostToDevice, g.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(P->d_idx, nonzero_indices, T * sizeof(int32_t), hipMemcpyHostToDevice, rt().stream);
     if (e == hipSuccess) {
-        k_onehot_G<<<dim3((unsigned)K, (unsigned)slices), OP_THREADS, 0, g.stream>>>(P->d_idx, (const Fr*)E->d, T, d_G);
-        e = hipMemcpyAsync(hG.data(), d_G, slices * K * sizeof(Fr), hipMemcpyDeviceToHost, g.stream);
+        k_onehot_G<<<dim3((unsigned)K, (unsigned)slices), OP_THREADS, 0, rt().stream>>>(P->d_idx, (const Fr*)E->d, T, d_G);
+        e = hipMemcpyAsync(hG.data(), d_G, slices * K * sizeof(Fr), hipMemcpyDeviceToHost, rt().stream);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(rt().stream);
     if (e == hipSuccess)
         for (size_t k = 0; k < K; k++) {
             H::Fr acc = H::zero();
@@ -1098,7 +1098,7 @@ int atlas_onehot_opening_group_new(const int32_t* const* nonzero_indices, size_t
     atlas_poly_t E = nullptr;
     int rc = atlas_eq_evals(r_cycle, log_T, nullptr, &E);
     if (rc) return rc;
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     OneHotGroup* Gp = new OneHotGroup();
     Gp->R = R; Gp->log_K = log_K; Gp->log_T = log_T; Gp->T = T; Gp->H_len = T;
     Fr* d_G = nullptr;
@@ -1109,13 +1109,13 @@ int atlas_onehot_opening_group_new(const int32_t* const* nonzero_indices, size_t
     size_t slices = 2048 / (K * R); if (slices < 1) slices = 1; if (slices > (T + 4095) / 4096) slices = (T + 4095) / 4096;
     if (e == hipSuccess) e = hipMalloc(&d_G, slices * R * K * sizeof(Fr));
     for (size_t r = 0; r < R && e == hipSuccess; r++)
-        e = hipMemcpyAsync(Gp->d_idx + r * T, nonzero_indices[r], T * sizeof(int32_t), hipMemcpyHostToDevice, g.stream);
+        e = hipMemcpyAsync(Gp->d_idx + r * T, nonzero_indices[r], T * sizeof(int32_t), hipMemcpyHostToDevice, rt().stream);
     std::vector<H::Fr> hGs(slices * R * K), hG(R * K, H::zero());
     if (e == hipSuccess) {
-        k_onehot_G_rows<<<dim3((unsigned)K, (unsigned)R, (unsigned)slices), OP_THREADS, 0, g.stream>>>(Gp->d_idx, (const Fr*)E->d, T, (uint32_t)K, d_G);
-        e = hipMemcpyAsync(hGs.data(), d_G, slices * R * K * sizeof(Fr), hipMemcpyDeviceToHost, g.stream);
+        k_onehot_G_rows<<<dim3((unsigned)K, (unsigned)R, (unsigned)slices), OP_THREADS, 0, rt().stream>>>(Gp->d_idx, (const Fr*)E->d, T, (uint32_t)K, d_G);
+        e = hipMemcpyAsync(hGs.data(), d_G, slices * R * K * sizeof(Fr), hipMemcpyDeviceToHost, rt().stream);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(rt().stream);
     for (size_t sl = 0; sl < slices && e == hipSuccess; sl++)
         for (size_t q = 0; q < R * K; q++) hG[q] = H::add(hG[q], hGs[sl * R * K + q]);
     if (d_G) hipFree(d_G);

@@ -594,8 +594,8 @@ struct PsLookup : atlas_instance {
         if (rc) return rc;
         const size_t NQ = nq();
         std::vector<H::Fr> q(NQ * m);
-        HIP_TRY(hipMemcpyAsync(q.data(), qsum_ptr(), NQ * m * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
+        HIP_TRY(hipMemcpyAsync(q.data(), qsum_ptr(), NQ * m * sizeof(Fr), hipMemcpyDeviceToHost, rt().stream));
+        HIP_TRY(hipStreamSynchronize(rt().stream));
         load_Q(q.data());
         v.assign(1, H::one());
         return ATLAS_OK;
@@ -653,7 +653,7 @@ struct PsLookup : atlas_instance {
     int load_Q_mixed() {
         const size_t NQ = nq();
         for (int cl = 0; cl < 2; cl++)
-            if (!wait_tag(sgn_box[cl].tagc, sgn_box[cl].tag)) { g.chan.abort_dirty = true; return fail(ATLAS_ENODEV, "round channel: no class tables from the device"); }
+            if (!wait_tag(sgn_box[cl].tagc, sgn_box[cl].tag)) { rt().chan.abort_dirty = true; return fail(ATLAS_ENODEV, "round channel: no class tables from the device"); }
         Q.assign(NQ, std::vector<H::Fr>(m));
         nz.clear();
         for (size_t y = 0; y < m; y++) {
@@ -669,7 +669,7 @@ struct PsLookup : atlas_instance {
         }
         return ATLAS_OK;
     }
-    // at construction (the caller holds g.mu): scan, wait for the minimum, launch the class tables of phase P.  Leaves sgn_P = 0 and the
+    // at construction (the caller holds rt().mu): scan, wait for the minimum, launch the class tables of phase P.  Leaves sgn_P = 0 and the
     // ordinary tables of phase 0 when no phase is pure.
     int sign_setup() {
         const size_t NQ = nq(), n_vals = PS_SIGN_PMAX * 2 * NQ;
@@ -677,19 +677,19 @@ struct PsLookup : atlas_instance {
         if (e != hipSuccess) return fail(ATLAS_ENOMEM, "ps_shout: sign scratch", e);
         unsigned long long* acc = static_cast<unsigned long long*>(sgn_scratch.p);
         uint32_t* mn = reinterpret_cast<uint32_t*>(static_cast<char*>(sgn_scratch.p) + 7168);
-        HIP_TRY(hipMemsetAsync(sgn_scratch.p, 0, 8192, g.stream));
+        HIP_TRY(hipMemsetAsync(sgn_scratch.p, 0, 8192, rt().stream));
         const uint32_t ph = (uint32_t)phases;
-        HIP_TRY(hipMemsetAsync(mn, 0xFF, 4, g.stream));                                // the minimum starts above any count
-        atlas::Chunk* box = g.chan.alloc_long(2 * n_vals + 4);
-        const uint32_t tag = g.chan.tag();
+        HIP_TRY(hipMemsetAsync(mn, 0xFF, 4, rt().stream));                                // the minimum starts above any count
+        atlas::Chunk* box = rt().chan.alloc_long(2 * n_vals + 4);
+        const uint32_t tag = rt().chan.tag();
         size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 256) gb = 256;
         const PsSignOut O{acc, mn, mn + 16, reinterpret_cast<Fr*>(box + 4), box, tag};
-        if (NQ == 6) k_ps_sign_scan<6><<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(d_idx, d_u0, T, (uint32_t)N, (uint32_t)log_m, ph, (uint32_t)bound, O);
-        else if (NQ == 4) k_ps_sign_scan<4><<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(d_idx, d_u0, T, (uint32_t)N, (uint32_t)log_m, ph, 0u, O);
-        else k_ps_sign_scan<2><<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(d_idx, d_u0, T, (uint32_t)N, (uint32_t)log_m, ph, 0u, O);
+        if (NQ == 6) k_ps_sign_scan<6><<<(unsigned)gb, RA_THREADS, 0, rt().stream>>>(d_idx, d_u0, T, (uint32_t)N, (uint32_t)log_m, ph, (uint32_t)bound, O);
+        else if (NQ == 4) k_ps_sign_scan<4><<<(unsigned)gb, RA_THREADS, 0, rt().stream>>>(d_idx, d_u0, T, (uint32_t)N, (uint32_t)log_m, ph, 0u, O);
+        else k_ps_sign_scan<2><<<(unsigned)gb, RA_THREADS, 0, rt().stream>>>(d_idx, d_u0, T, (uint32_t)N, (uint32_t)log_m, ph, 0u, O);
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) return fail(ATLAS_ENODEV, "ps_shout: sign scan", le);
-        if (!wait_tag(box, tag)) { g.chan.abort_dirty = true; return fail(ATLAS_ENODEV, "round channel: no sign scan from the device"); }
+        if (!wait_tag(box, tag)) { rt().chan.abort_dirty = true; return fail(ATLAS_ENODEV, "round channel: no sign scan from the device"); }
         size_t P = box->d[1];
         if (P > phases - 1) P = phases - 1;
         if (P > PS_SIGN_PMAX) P = PS_SIGN_PMAX;
@@ -697,9 +697,9 @@ struct PsLookup : atlas_instance {
         sgn_S.assign(reinterpret_cast<const H::Fr*>(box + 4), reinterpret_cast<const H::Fr*>(box + 4) + P * 2 * NQ);
         sgn_P = P;
         for (int cl = 0; cl < 2; cl++) {                       // the class tables of phase P: needed 8 P rounds from now
-            atlas::Chunk* tb = g.chan.alloc_long(2 * NQ * m + 4);
+            atlas::Chunk* tb = rt().chan.alloc_long(2 * NQ * m + 4);
             std::memset(tb + 4, 0, NQ * m * sizeof(Fr));
-            const uint32_t tg = g.chan.tag();
+            const uint32_t tg = rt().chan.tag();
             int rc = launch_Q(P, nullptr, 0, QPublish{reinterpret_cast<Fr*>(tb + 4), tb, tg, rows.d_counter}, PsClass{cl, (uint32_t)(N - 1), nullptr});
             if (rc) return rc;
             sgn_box[cl] = QBox{tb, reinterpret_cast<const H::Fr*>(tb + 4), tg};
@@ -712,7 +712,7 @@ struct PsLookup : atlas_instance {
     int sign_off() {
         if (!sgn_P) return ATLAS_OK;
         if (round_next != 0) return fail(ATLAS_ESTATE, "ps_shout: host-stepped call in the middle of a pipelined proof");
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
         sgn_P = 0;
         return build_Q(0);
     }
@@ -729,9 +729,9 @@ struct PsLookup : atlas_instance {
             size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 256) gb = 256;      // slabs: gb * lds bytes <= the partial-row area
 #define PS_Q_LDS(NQv, BND)                                                                                                         \
             do {                                                                                                                   \
-                static bool attr_set = false;                                                                                      \
+                static thread_local bool attr_set = false;                                                                                      \
                 if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ps_q_lds<NQv>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * NQv * 64)); attr_set = true; } \
-                k_ps_q_lds<NQv><<<(unsigned)gb, RA_THREADS, lds, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)m, (uint32_t)(BND), acc, v_prev, shift_prev, cls); \
+                k_ps_q_lds<NQv><<<(unsigned)gb, RA_THREADS, lds, rt().stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)m, (uint32_t)(BND), acc, v_prev, shift_prev, cls); \
             } while (0)
             if (NQ == 4) PS_Q_LDS(4, 0u);
             else if (NQ == 6) PS_Q_LDS(6, bound);
@@ -739,16 +739,16 @@ struct PsLookup : atlas_instance {
             else PS_Q_LDS(2, 0u);
 #undef PS_Q_LDS
             static const bool few_off = getenv("ATLAS_PS_NO_FEW") != nullptr;     // A-B
-            if (gb <= 64 && !few_off) k_ps_q_final_few<<<(unsigned)((NQ * m + 31) / 32), RA_THREADS, 0, g.stream>>>(acc, (uint32_t)gb, (uint32_t)(NQ * m), d_qsum, pub);
-            else k_ps_q_final<<<(unsigned)((NQ * m + 3) / 4), RA_THREADS, 0, g.stream>>>(acc, (uint32_t)gb, (uint32_t)(NQ * m), d_qsum, pub);
+            if (gb <= 64 && !few_off) k_ps_q_final_few<<<(unsigned)((NQ * m + 31) / 32), RA_THREADS, 0, rt().stream>>>(acc, (uint32_t)gb, (uint32_t)(NQ * m), d_qsum, pub);
+            else k_ps_q_final<<<(unsigned)((NQ * m + 3) / 4), RA_THREADS, 0, rt().stream>>>(acc, (uint32_t)gb, (uint32_t)(NQ * m), d_qsum, pub);
         } else {
-            if (v_prev) { size_t gs = (T + RA_THREADS - 1) / RA_THREADS; if (gs > 4096) gs = 4096; k_ps_scale<<<(unsigned)gs, RA_THREADS, 0, g.stream>>>(d_idx, v_prev, T, shift_prev, (uint32_t)(m - 1), rows.buf[0]); }
-            if (NQ == 4) k_ps_q<4><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), 0u, d_qpart);
-            else if (NQ == 6) k_ps_q<6><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), (uint32_t)bound, d_qpart);
-            else if (NQ == 3) k_ps_q<3><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), (uint32_t)bound, d_qpart);
-            else k_ps_q<2><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, g.stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), 0u, d_qpart);
-            k_col_reduce<<<(unsigned)(NQ * m), RA_THREADS, 0, g.stream>>>(d_qpart, SLICES, (uint32_t)(NQ * m), d_qsum);
-            if (pub.host_dst) k_ps_q_copy_out<<<1, RA_THREADS, 0, g.stream>>>(d_qsum, (uint32_t)(NQ * m), pub.host_dst, pub.tag_chunk, pub.tag);
+            if (v_prev) { size_t gs = (T + RA_THREADS - 1) / RA_THREADS; if (gs > 4096) gs = 4096; k_ps_scale<<<(unsigned)gs, RA_THREADS, 0, rt().stream>>>(d_idx, v_prev, T, shift_prev, (uint32_t)(m - 1), rows.buf[0]); }
+            if (NQ == 4) k_ps_q<4><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, rt().stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), 0u, d_qpart);
+            else if (NQ == 6) k_ps_q<6><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, rt().stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), (uint32_t)bound, d_qpart);
+            else if (NQ == 3) k_ps_q<3><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, rt().stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), (uint32_t)bound, d_qpart);
+            else k_ps_q<2><<<dim3((unsigned)m, SLICES), RA_THREADS, 0, rt().stream>>>(d_idx, d_u0, rows.buf[0], T, suffix_len, (uint32_t)(m - 1), 0u, d_qpart);
+            k_col_reduce<<<(unsigned)(NQ * m), RA_THREADS, 0, rt().stream>>>(d_qpart, SLICES, (uint32_t)(NQ * m), d_qsum);
+            if (pub.host_dst) k_ps_q_copy_out<<<1, RA_THREADS, 0, rt().stream>>>(d_qsum, (uint32_t)(NQ * m), pub.host_dst, pub.tag_chunk, pub.tag);
         }
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) return fail(ATLAS_ENODEV, "ps_shout: Q launch", le);
@@ -760,10 +760,10 @@ struct PsLookup : atlas_instance {
         if (sgn_P) { int rc = sign_off(); if (rc) return rc; }
         coeffs.assign(3, H::zero());
         if (round < N) return address_message(round, claim, coeffs);
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
         const size_t n_groups = rows.len / 2;
         size_t blocks = (n_groups + RA_THREADS - 1) / RA_THREADS; if (blocks > 2048) blocks = 2048;
-        k_ps_fold<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(rows.buf[rows.cur], eq.view(), n_groups, rows.partials, MailTail{{}, nullptr, 0, 0});
+        k_ps_fold<<<(unsigned)blocks, RA_THREADS, 0, rt().stream>>>(rows.buf[rows.cur], eq.view(), n_groups, rows.partials, MailTail{{}, nullptr, 0, 0});
         H::Fr s;
         int rc = rows.reduce_to_host((uint32_t)blocks, 1, &s);
         if (rc) return rc;
@@ -935,7 +935,7 @@ struct PsLookup : atlas_instance {
     int ingest_impl(const atlas_u128_t& r, size_t round, bool with_device) {
         if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "ps_shout: round out of order");
         if (with_device && sgn_P) { int rc = sign_off(); if (rc) return rc; }
-        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode);
         if (round < N) {
             const size_t j = round, p = j / log_m;
             if (p < sgn_P) { sgn_A[0] = H::mul(sgn_A[0], H::sub(H::one(), rf)); sgn_A[1] = H::mul(sgn_A[1], rf); }      // a pure phase: E_p[0], E_p[m - 1] factor by factor
@@ -990,12 +990,12 @@ struct PsLookup : atlas_instance {
             }
             r_addr.push_back(rf);
             if ((j + 1) % log_m == 0 && with_device) {                // phase boundary: fold v_p into the products
-                std::lock_guard<atlas_rt::Mutex> lk(g.mu);
-                HIP_TRY(hipMemcpyAsync(d_v, v.data(), m * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+                std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+                HIP_TRY(hipMemcpyAsync(d_v, v.data(), m * sizeof(Fr), hipMemcpyHostToDevice, rt().stream));
                 size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
-                k_ps_scale<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(d_idx, d_v, T, (uint32_t)((phases - 1 - p) * log_m), (uint32_t)(m - 1), rows.buf[0]);
+                k_ps_scale<<<(unsigned)gb, RA_THREADS, 0, rt().stream>>>(d_idx, d_v, T, (uint32_t)((phases - 1 - p) * log_m), (uint32_t)(m - 1), rows.buf[0]);
                 if (p != phases - 1) { int rc = build_Q(p + 1); if (rc) return rc; }       // (ends with a stream synchronize: v may change after it)
-                else HIP_TRY(hipStreamSynchronize(g.stream));
+                else HIP_TRY(hipStreamSynchronize(rt().stream));
             }
             if (j + 1 == N) {
                 // val = Val~(r_address), raf_val = gamma * SId~(r_address)   (mod.rs:523-548)
@@ -1013,7 +1013,7 @@ struct PsLookup : atlas_instance {
                 rows.cur = 0; rows.stride[0] = T; rows.len = T;       // the products are ra (init_log_t_rounds)
             }
         } else if (with_device) {
-            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+            std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
             int rc = rows.bind(r);
             if (rc) return rc;
             eq.st.bind(rf);
@@ -1028,7 +1028,7 @@ struct PsLookup : atlas_instance {
     int finals(std::vector<H::Fr>& out) override {
         if (round_next != rounds()) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
         if (have_finals) { out = mailed_finals; return ATLAS_OK; }
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
         if (one_cycle) rows.len = 1;                                  // ra of the one lookup: entry 0 of the products (the second entry is the weight-zero cycle)
         return rows.finals(out);
     }
@@ -1054,7 +1054,7 @@ struct PsLookup : atlas_instance {
     }
     int enqueue(size_t round, const atlas::RoundIo& io, bool bind_prev, atlas_mail_ref& mail) override {
         if (round >= rounds() || (round > 0) != bind_prev) return fail(ATLAS_ESTATE, "ps_shout: enqueue out of order");
-        const ChanIo cio{io, g.challenge_mode};
+        const ChanIo cio{io, rt().challenge_mode};
         mail.base = io.mail; mail.blocks = 0; mail.n_vals = 0; mail.radix = 32; mail.shl = 0;
         Fr* vt[2] = {d_v, d_v + m};
         size_t gbT = (T + RA_THREADS - 1) / RA_THREADS; if (gbT > 4096) gbT = 4096;
@@ -1069,24 +1069,24 @@ struct PsLookup : atlas_instance {
         PsClass cls{-1, (uint32_t)(N - 1), nullptr};
         if (sgn_P && round >= 1 && round <= N && round % log_m == 0 && round / log_m - 1 == sgn_P) {
             // the first boundary the device works at: the products still miss the class factor A_s(P) of the pure phases
-            k_ps_class_scalars<<<1, 64, 0, g.stream>>>(sgn_slot0, sgn_tag0, (uint32_t)(sgn_P * log_m), io.abort_flag, g.challenge_mode, sgn_scal());
+            k_ps_class_scalars<<<1, 64, 0, rt().stream>>>(sgn_slot0, sgn_tag0, (uint32_t)(sgn_P * log_m), io.abort_flag, rt().challenge_mode, sgn_scal());
             cls.scal = sgn_scal();
         }
         if (round >= 1 && round <= N && round % log_m == 0) {  // a phase is complete: its table, folded into the products
             const size_t p_done = round / log_m - 1;
-            slots.n = (uint32_t)log_m; slots.abort_flag = io.abort_flag; slots.challenge_mode = g.challenge_mode;
-            if (m <= RA_THREADS) k_ps_expand_lds_ch<<<1, RA_THREADS, 0, g.stream>>>(vt[0], vt[1], slots);
-            else k_ps_expand_all_ch<<<1, RA_THREADS, 0, g.stream>>>(vt[0], vt[1], slots);
+            slots.n = (uint32_t)log_m; slots.abort_flag = io.abort_flag; slots.challenge_mode = rt().challenge_mode;
+            if (m <= RA_THREADS) k_ps_expand_lds_ch<<<1, RA_THREADS, 0, rt().stream>>>(vt[0], vt[1], slots);
+            else k_ps_expand_all_ch<<<1, RA_THREADS, 0, rt().stream>>>(vt[0], vt[1], slots);
             const uint32_t shift_done = (uint32_t)((phases - 1 - p_done) * log_m);
             if (round < N) {                                   // ... folded into the products while the Q of the phase that starts is built
                 const size_t p = round / log_m, n_vals = nq() * m;
-                atlas::Chunk* box = g.chan.alloc(2 * n_vals + 4);
+                atlas::Chunk* box = rt().chan.alloc(2 * n_vals + 4);
                 if (m <= RA_THREADS) std::memset(box + 4, 0, n_vals * sizeof(Fr));      // k_ps_q_final publishes the non-zero residues only
                 int rc = launch_Q(p, vt[log_m & 1], shift_done, QPublish{reinterpret_cast<Fr*>(box + 4), box, io.tag_mail, rows.d_counter}, cls);
                 if (rc) return rc;
                 qbox[p] = QBox{box, reinterpret_cast<const H::Fr*>(box + 4), io.tag_mail};
             } else {
-                k_ps_scale<<<(unsigned)gbT, RA_THREADS, 0, g.stream>>>(d_idx, vt[log_m & 1], T, shift_done, (uint32_t)(m - 1), rows.buf[0], cls);
+                k_ps_scale<<<(unsigned)gbT, RA_THREADS, 0, rt().stream>>>(d_idx, vt[log_m & 1], T, shift_done, (uint32_t)(m - 1), rows.buf[0], cls);
             }
         }
         if (round >= N && tail_c0() && round - N >= tail_c0()) {        // the resident tail (k_ps_tail_ch): launched with its first round
@@ -1097,13 +1097,13 @@ struct PsLookup : atlas_instance {
                 A.e_out = eq.d_eout; A.e_in = eq.d_ein;
                 A.n_rounds = (uint32_t)(log_T - c0);
                 for (size_t i = 0; i < A.n_rounds; i++) { size_t ot, it; eq.st.tops_after(c0 + i, ot, it); A.ot[i] = (uint8_t)ot; A.it[i] = (uint8_t)it; }
-                tail_mail = g.chan.alloc_long((A.n_rounds + 2) * atlas::ch_stride(1));       // (not io.mail: the per-round areas are recycled while the tail lives)
+                tail_mail = rt().chan.alloc_long((A.n_rounds + 2) * atlas::ch_stride(1));       // (not io.mail: the per-round areas are recycled while the tail lives)
                 A.mail = tail_mail; A.r_host = io.r_host; A.abort_flag = io.abort_flag;
                 A.tag_mail0 = io.tag_mail; A.tag_step = io.tag_step; A.tag_r0 = io.tag_r;
-                A.challenge_mode = g.challenge_mode; A.hi_only = g.challenge_mode == 0 ? 1 : 0;
-                static bool attr_set = false;
+                A.challenge_mode = rt().challenge_mode; A.hi_only = rt().challenge_mode == 0 ? 1 : 0;
+                static thread_local bool attr_set = false;
                 if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ps_tail_ch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(Fr) << PS_TAIL_LOG))); attr_set = true; }
-                k_ps_tail_ch<<<1, PS_TAIL_THREADS, sizeof(Fr) << PS_TAIL_LOG, g.stream>>>(A);
+                k_ps_tail_ch<<<1, PS_TAIL_THREADS, sizeof(Fr) << PS_TAIL_LOG, rt().stream>>>(A);
                 hipError_t e = hipGetLastError();
                 if (e != hipSuccess) return fail(ATLAS_ENODEV, "ps_shout: tail launch", e);
             }
@@ -1116,9 +1116,9 @@ struct PsLookup : atlas_instance {
             size_t ot, it;
             eq.st.tops_after(c, ot, it);
             const MailTail tail{io, rows.d_counter, (uint32_t)blocks, 1u, rows.tg()};
-            if (c == 0) k_ps_fold<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(rows.buf[0], eq.view_at(ot, it), n_groups, rows.partials, tail);
-            else k_ps_bind_fold_ch<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(rows.buf[(c - 1) & 1], rows.buf[c & 1], eq.view_at(ot, it), n_groups, rows.partials, cio,
-                                                                              g.challenge_mode == 0 ? 1 : 0, tail);
+            if (c == 0) k_ps_fold<<<(unsigned)blocks, RA_THREADS, 0, rt().stream>>>(rows.buf[0], eq.view_at(ot, it), n_groups, rows.partials, tail);
+            else k_ps_bind_fold_ch<<<(unsigned)blocks, RA_THREADS, 0, rt().stream>>>(rows.buf[(c - 1) & 1], rows.buf[c & 1], eq.view_at(ot, it), n_groups, rows.partials, cio,
+                                                                              rt().challenge_mode == 0 ? 1 : 0, tail);
             mail.blocks = 1; mail.n_vals = 1;
         }
         hipError_t e = hipGetLastError();
@@ -1143,7 +1143,7 @@ struct PsLookup : atlas_instance {
             PROF("ps_shout: wait for the phase's Q tables + load");
             while (B.tagc->tag != B.tag) {
                 for (int i = 0; i < 1024 && B.tagc->tag != B.tag; i++) __builtin_ia32_pause();
-                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) { g.chan.abort_dirty = true; return fail(ATLAS_ENODEV, "round channel: no Q tables from the device"); }
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) { rt().chan.abort_dirty = true; return fail(ATLAS_ENODEV, "round channel: no Q tables from the device"); }
             }
             __atomic_thread_fence(__ATOMIC_ACQUIRE);          // the residues are read through a plain pointer: not before the tag (the device wrote them, fenced, then the tag)
             load_Q(B.data);
@@ -1176,7 +1176,7 @@ struct PsLookup : atlas_instance {
             mail.base = tail_mail + (log_T - tail_c0()) * atlas::ch_stride(1); mail.blocks = 1; mail.n_vals = 1; mail.radix = 32; mail.shl = 0;
             return ATLAS_OK;
         }
-        k_rows_final_ch<<<1, 64, 0, g.stream>>>(rows.buf[(log_T - 1) & 1], T >> (log_T - 1), 1u, ChanIo{io, g.challenge_mode}, g.challenge_mode == 0 ? 1 : 0);
+        k_rows_final_ch<<<1, 64, 0, rt().stream>>>(rows.buf[(log_T - 1) & 1], T >> (log_T - 1), 1u, ChanIo{io, rt().challenge_mode}, rt().challenge_mode == 0 ? 1 : 0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(ATLAS_ENODEV, "ps_shout: launch", e);
         mail.base = io.mail; mail.blocks = 1; mail.n_vals = 1; mail.radix = 32; mail.shl = 0;
@@ -1222,7 +1222,7 @@ static int ps_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, si
     if (eq_shared && (one_cycle || eq_shared->is_i32 || eq_shared->len != ((size_t)1 << log_T))) return fail(ATLAS_EINVAL, "ps_shout_new: shared eq table of the wrong length");
     int rc = eq_shared ? ATLAS_OK : atlas_eq_evals(r_node_output, one_cycle ? 0 : log_T, nullptr, &E);      // u_evals = EqPolynomial::evals(r_node_output), mod.rs:234
     if (rc) return rc;
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     PsLookup* P = new PsLookup();
     P->one_cycle = one_cycle;
     P->N = log_K; P->phases = phases; P->mode = mode; P->bound = bound; P->symmetric = symmetric;
@@ -1232,8 +1232,8 @@ static int ps_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, si
     hipError_t e = hipSuccess;
     if (one_cycle) {                                                 // u = (1, 0)
         e = hipMalloc(&P->d_u0, 2 * sizeof(Fr));
-        if (e == hipSuccess) e = hipMemsetAsync(P->d_u0, 0, 2 * sizeof(Fr), g.stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(P->d_u0, E->d, sizeof(Fr), hipMemcpyDeviceToDevice, g.stream);
+        if (e == hipSuccess) e = hipMemsetAsync(P->d_u0, 0, 2 * sizeof(Fr), rt().stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(P->d_u0, E->d, sizeof(Fr), hipMemcpyDeviceToDevice, rt().stream);
         atlas_poly_free(E);
     } else if (eq_shared) { P->d_u0 = (Fr*)eq_shared->d; P->u0_borrowed = true; }      // the caller's table (it outlives the instance)
     else { P->d_u0 = (Fr*)E->d; delete E; }                          // keep the table, drop the handle
@@ -1247,19 +1247,19 @@ static int ps_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, si
     if (e == hipSuccess && !P->idx_borrowed) e = hipMalloc(&P->d_idx, T * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc(&P->d_v, 2 * m * sizeof(Fr));       // two tables: the pipelined path alternates
     if (e == hipSuccess) e = hipMalloc(&P->d_qpart, (P->q_rows_max() + 1) * 6 * m * sizeof(Fr));
-    if (e == hipSuccess && one_cycle) e = hipMemsetAsync(P->d_idx, 0, T * sizeof(uint64_t), g.stream);
-    if (e == hipSuccess && !P->idx_borrowed) e = hipMemcpyAsync(P->d_idx, lookup_indices, (one_cycle ? 1 : T) * sizeof(uint64_t), hipMemcpyDefault, g.stream);   // host or device source
+    if (e == hipSuccess && one_cycle) e = hipMemsetAsync(P->d_idx, 0, T * sizeof(uint64_t), rt().stream);
+    if (e == hipSuccess && !P->idx_borrowed) e = hipMemcpyAsync(P->d_idx, lookup_indices, (one_cycle ? 1 : T) * sizeof(uint64_t), hipMemcpyDefault, rt().stream);   // host or device source
     if (e != hipSuccess) { delete P; return fail(ATLAS_ENOMEM, "ps_shout_new", e); }
     rc = P->rows.alloc(1, T);
     if (!rc) {
         size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
-        k_ps_fill_one<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(P->rows.buf[0], T);
+        k_ps_fill_one<<<(unsigned)gb, RA_THREADS, 0, rt().stream>>>(P->rows.buf[0], T);
         if (!one_cycle) rc = P->eq.init(reinterpret_cast<const H::Fr*>(r_node_output), log_T);       // (the split eq of the cycle rounds: none here)
     }
     // (the shortcut serves the round-channel drivers; a host-stepped caller falls back in its first call)
     static const bool no_sign = getenv("ATLAS_PS_NO_SIGN") != nullptr || getenv("ATLAS_NO_PIPELINE") != nullptr;     // A-B
     // (mode 3, the binary UnsignedLessThan range checks: the interleaved operands are small non-negative integers — one class, leading zero chunks)
-    const bool try_sign = (mode == 0 || mode == 2 || mode == 3) && !one_cycle && m <= RA_THREADS && phases >= 3 && phases - 1 <= PS_SIGN_PMAX && g.fs_mode == ATLAS_FS_HOST && !no_sign;
+    const bool try_sign = (mode == 0 || mode == 2 || mode == 3) && !one_cycle && m <= RA_THREADS && phases >= 3 && phases - 1 <= PS_SIGN_PMAX && rt().fs_mode == ATLAS_FS_HOST && !no_sign;
     if (!rc) rc = try_sign ? P->sign_setup() : P->build_Q(0);
     if (rc) { delete P; return rc; }
     *out = P;
@@ -1355,9 +1355,9 @@ int atlas_u64_upload(const uint64_t* host, size_t n, uint64_t** d_out) {
     uint64_t* d = nullptr;
     hipError_t e = hipMalloc(&d, n * sizeof(uint64_t));
     if (e != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(u64)", e);
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
-    e = hipMemcpyAsync(d, host, n * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+    e = hipMemcpyAsync(d, host, n * sizeof(uint64_t), hipMemcpyHostToDevice, rt().stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(rt().stream);
     if (e != hipSuccess) { hipFree(d); return fail(ATLAS_ENODEV, "u64_upload", e); }
     *d_out = d;
     return ATLAS_OK;
@@ -1375,10 +1375,10 @@ int atlas_lookup_indices_from_operands(const int32_t* d_left, const int32_t* d_r
     uint64_t* d = nullptr;
     hipError_t e = hipMalloc(&d, n * sizeof(uint64_t));
     if (e != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(lookup indices)", e);
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     size_t gb = (n + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
-    k_lookup_indices<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(d_left, d_right, n, d);
-    e = hipStreamSynchronize(g.stream);
+    k_lookup_indices<<<(unsigned)gb, RA_THREADS, 0, rt().stream>>>(d_left, d_right, n, d);
+    e = hipStreamSynchronize(rt().stream);
     if (e != hipSuccess) { hipFree(d); return fail(ATLAS_ENODEV, "lookup_indices_from_operands", e); }
     *d_out = d;
     return ATLAS_OK;

@@ -445,12 +445,12 @@ void launch_prod(const Fr* buf, size_t stride, Fr* partials, const SplitEqView& 
             static const bool no_tail16 = getenv("ATLAS_NO_MAIL_TAIL") != nullptr;
             static const bool timing = getenv("ATLAS_RA_SPLIT_TIMING") != nullptr;
             if (no_tail16 && tail.counter) {
-                k_ra_prod16_split<false><<<blocks, RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, MailTail{tail.io, nullptr, 0, 0});
-                k_col_reduce_mail<<<1, RA_THREADS, 0, g.stream>>>(partials, blocks, 16u, tail.io);
+                k_ra_prod16_split<false><<<blocks, RA_THREADS, 0, rt().stream>>>(buf, stride, E, n_groups, partials, MailTail{tail.io, nullptr, 0, 0});
+                k_col_reduce_mail<<<1, RA_THREADS, 0, rt().stream>>>(partials, blocks, 16u, tail.io);
             } else if (timing)
-                k_ra_prod16_split<true><<<blocks, RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, tail);
+                k_ra_prod16_split<true><<<blocks, RA_THREADS, 0, rt().stream>>>(buf, stride, E, n_groups, partials, tail);
             else
-                k_ra_prod16_split<false><<<blocks, RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, tail);
+                k_ra_prod16_split<false><<<blocks, RA_THREADS, 0, rt().stream>>>(buf, stride, E, n_groups, partials, tail);
             return;
         }
     }
@@ -458,27 +458,27 @@ void launch_prod(const Fr* buf, size_t stride, Fr* partials, const SplitEqView& 
     const MailTail none{tail.io, nullptr, 0, 0};
     static const bool no_tail = getenv("ATLAS_NO_MAIL_TAIL") != nullptr;      // diagnosis (tools/stress_lanes.py): the column sums in a launch of their own
     if (no_tail && tail.counter) {
-        if (n_groups <= ((size_t)1 << 15)) k_ra_prod_f9_col<D><<<dim3(blocks, D), RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, none);
+        if (n_groups <= ((size_t)1 << 15)) k_ra_prod_f9_col<D><<<dim3(blocks, D), RA_THREADS, 0, rt().stream>>>(buf, stride, E, n_groups, partials, none);
         else {
             constexpr int KA0 = D < 8 ? D : 8;
-            k_ra_prod_f9<D, 0, KA0><<<blocks, RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, none);
-            if constexpr (D > 8) k_ra_prod_f9<D, 8, D - 8><<<blocks, RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, none);
+            k_ra_prod_f9<D, 0, KA0><<<blocks, RA_THREADS, 0, rt().stream>>>(buf, stride, E, n_groups, partials, none);
+            if constexpr (D > 8) k_ra_prod_f9<D, 8, D - 8><<<blocks, RA_THREADS, 0, rt().stream>>>(buf, stride, E, n_groups, partials, none);
         }
-        k_col_reduce_mail<<<1, RA_THREADS, 0, g.stream>>>(partials, blocks, (uint32_t)D, tail.io);
+        k_col_reduce_mail<<<1, RA_THREADS, 0, rt().stream>>>(partials, blocks, (uint32_t)D, tail.io);
         return;
     }
     // one column per thread up to 2^15 pairs: 16 x more workgroups than the register-tiled kernel, which runs at one wavefront
     // per SIMD there (measured on the Einsum node: 2^15 is 2 % ahead of 2^13, 2^16 no better)
     static const size_t col_log = [] { const char* e = getenv("ATLAS_RA_COL_LOG"); int v = e ? atoi(e) : 0; return (size_t)(v >= 8 && v <= 24 ? v : 15); }();   // experiments
     if (n_groups <= ((size_t)1 << col_log)) {
-        k_ra_prod_f9_col<D><<<dim3(blocks, D), RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, tail);
+        k_ra_prod_f9_col<D><<<dim3(blocks, D), RA_THREADS, 0, rt().stream>>>(buf, stride, E, n_groups, partials, tail);
         return;
     }
     constexpr int KA = D < 8 ? D : 8;
     tail.tagged = nullptr;                     // (its rows are assembled by two launches: plain rows behind the arrival counter)
-    k_ra_prod_f9<D, 0, KA><<<blocks, RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, D > 8 ? none : tail);
+    k_ra_prod_f9<D, 0, KA><<<blocks, RA_THREADS, 0, rt().stream>>>(buf, stride, E, n_groups, partials, D > 8 ? none : tail);
     if constexpr (D > 8)
-        k_ra_prod_f9<D, 8, D - 8><<<blocks, RA_THREADS, 0, g.stream>>>(buf, stride, E, n_groups, partials, tail);   // mails all D columns
+        k_ra_prod_f9<D, 8, D - 8><<<blocks, RA_THREADS, 0, rt().stream>>>(buf, stride, E, n_groups, partials, tail);   // mails all D columns
 }
 int launch_prod_d(size_t d, const Fr* buf, size_t stride, Fr* partials, const SplitEqView& E, size_t n_groups, unsigned& blocks, const MailTail& tail) {
     switch (d) {
@@ -501,7 +501,7 @@ struct RaVirtual : atlas_instance {
     size_t degree() const override { return rows.d + 1; }
     int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
         if (round != round_next || round >= log_T) return fail(ATLAS_ESTATE, "ra_virtual: round out of order");
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
         const size_t n_groups = rows.len / 2;
         unsigned blocks = (unsigned)((n_groups + RA_THREADS - 1) / RA_THREADS);
         int rc = launch_prod_d(rows.d, rows.buf[rows.cur], rows.stride[rows.cur], rows.partials, eq.view(), n_groups, blocks, MailTail{{}, nullptr, 0, 0});
@@ -521,16 +521,16 @@ struct RaVirtual : atlas_instance {
     }
     int ingest(const atlas_u128_t& r, size_t round) override {
         if (round != round_next || round >= log_T) return fail(ATLAS_ESTATE, "ra_virtual: round out of order");
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
         int rc = rows.bind(r);
         if (rc) return rc;
-        eq.st.bind(H::challenge_to_fr(r.lo, r.hi, g.challenge_mode));
+        eq.st.bind(H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode));
         round_next++;
         return ATLAS_OK;
     }
     int finals(std::vector<H::Fr>& out) override {
         if (have_finals) { out = mailed_finals; return ATLAS_OK; }
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
         return rows.finals(out);
     }
 
@@ -549,18 +549,18 @@ struct RaVirtual : atlas_instance {
     int enqueue(size_t round, const atlas::RoundIo& io, bool bind_prev, atlas_mail_ref& mail) override {
         if (round >= log_T || (round > 0) != bind_prev) return fail(ATLAS_ESTATE, "ra_virtual: enqueue out of order");
         const size_t T = (size_t)1 << log_T, len = T >> round, n_groups = len / 2;
-        const ChanIo cio{io, g.challenge_mode};
+        const ChanIo cio{io, rt().challenge_mode};
         size_t ot, it;
         eq.st.tops_after(round, ot, it);
         if (fused(round)) {                                       // bind + product in one launch (k_ra_bind_prod_f9)
             const unsigned fb = (unsigned)((n_groups + RA_FUSE_PAIRS - 1) / RA_FUSE_PAIRS);
-            k_ra_bind_prod_f9<<<fb, RA_THREADS, 0, g.stream>>>(rows.buf[(round - 1) & 1], T >> (round - 1), rows.buf[round & 1], len, (uint32_t)rows.d, eq.view_at(ot, it),
-                                                               n_groups, rows.partials, cio, g.challenge_mode == 0 ? 1 : 0, MailTail{io, rows.d_counter, fb, (uint32_t)rows.d, rows.tg()});
+            k_ra_bind_prod_f9<<<fb, RA_THREADS, 0, rt().stream>>>(rows.buf[(round - 1) & 1], T >> (round - 1), rows.buf[round & 1], len, (uint32_t)rows.d, eq.view_at(ot, it),
+                                                               n_groups, rows.partials, cio, rt().challenge_mode == 0 ? 1 : 0, MailTail{io, rows.d_counter, fb, (uint32_t)rows.d, rows.tg()});
         } else {
             if (bind_prev) {
                 size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
-                k_ra_bind_ch<<<dim3((unsigned)gb, (unsigned)rows.d), RA_THREADS, 0, g.stream>>>(rows.buf[(round - 1) & 1], T >> (round - 1), rows.buf[round & 1], len, len,
-                                                                                              cio, g.challenge_mode == 0 ? 1 : 0);
+                k_ra_bind_ch<<<dim3((unsigned)gb, (unsigned)rows.d), RA_THREADS, 0, rt().stream>>>(rows.buf[(round - 1) & 1], T >> (round - 1), rows.buf[round & 1], len, len,
+                                                                                              cio, rt().challenge_mode == 0 ? 1 : 0);
             }
             unsigned blocks = (unsigned)((n_groups + RA_THREADS - 1) / RA_THREADS);
             int rc = launch_prod_d(rows.d, rows.buf[round & 1], len, rows.partials, eq.view_at(ot, it), n_groups, blocks, MailTail{io, rows.d_counter, 0, 0, rows.tg()});
@@ -579,14 +579,14 @@ struct RaVirtual : atlas_instance {
     }
     int host_ingest(const atlas_u128_t& r, size_t round) override {
         if (round != round_next || round >= log_T) return fail(ATLAS_ESTATE, "ra_virtual: round out of order");
-        eq.st.bind(H::challenge_to_fr(r.lo, r.hi, g.challenge_mode));
+        eq.st.bind(H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode));
         rows.cur = (int)((round + 1) & 1); rows.len = ((size_t)1 << log_T) >> (round + 1); rows.stride[rows.cur] = rows.len;
         round_next++;
         return ATLAS_OK;
     }
     int enqueue_finals(const atlas::RoundIo& io, atlas_mail_ref& mail) override {
         const size_t T = (size_t)1 << log_T;
-        k_rows_final_ch<<<1, 64, 0, g.stream>>>(rows.buf[(log_T - 1) & 1], T >> (log_T - 1), (uint32_t)rows.d, ChanIo{io, g.challenge_mode}, g.challenge_mode == 0 ? 1 : 0);
+        k_rows_final_ch<<<1, 64, 0, rt().stream>>>(rows.buf[(log_T - 1) & 1], T >> (log_T - 1), (uint32_t)rows.d, ChanIo{io, rt().challenge_mode}, rt().challenge_mode == 0 ? 1 : 0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(ATLAS_ENODEV, "ra_virtual: launch", e);
         mail.base = io.mail; mail.blocks = 1; mail.n_vals = (int)rows.d; mail.radix = 32; mail.shl = 0;
@@ -620,8 +620,8 @@ int upload_tables(const std::vector<std::vector<H::Fr>>& t, size_t K, Fr** out) 
     Fr* d = nullptr;
     HIP_TRY(hipMalloc(&d, t.size() * K * sizeof(Fr)));
     for (size_t i = 0; i < t.size(); i++)
-        HIP_TRY(hipMemcpyAsync(d + i * K, t[i].data(), K * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+        HIP_TRY(hipMemcpyAsync(d + i * K, t[i].data(), K * sizeof(Fr), hipMemcpyHostToDevice, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     *out = d;
     return ATLAS_OK;
 }
@@ -686,7 +686,7 @@ struct Booleanity : atlas_instance {
         if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "booleanity: round out of order");
         coeffs.assign(4, H::zero());
         if (round < log_k) return phase1_message(round, claim, coeffs);
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);                        // compute_phase2_message
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);                        // compute_phase2_message
         const size_t n_groups = rows.len / 2;
         const uint32_t n_part = launch_fold(rows.buf[rows.cur], rows.stride[rows.cur], D.view(), n_groups);
         H::Fr s[2];
@@ -701,11 +701,11 @@ struct Booleanity : atlas_instance {
         const MailTail tail = io ? MailTail{*io, rows.d_counter, (uint32_t)(blocks * ysplit), 2u, rows.tg()} : MailTail{{}, nullptr, 0, 0};
         static const bool no_tail = getenv("ATLAS_NO_MAIL_TAIL") != nullptr;  // diagnosis (tools/stress_lanes.py)
         if (no_tail && io) {
-            k_bool_fold<<<dim3((unsigned)blocks, ysplit), RA_THREADS, 0, g.stream>>>(buf, stride, (uint32_t)d, d_gammas, E, n_groups, rows.partials, MailTail{{}, nullptr, 0, 0});
-            k_col_reduce_mail<<<1, RA_THREADS, 0, g.stream>>>(rows.partials, (uint32_t)(blocks * ysplit), 2u, *io);
+            k_bool_fold<<<dim3((unsigned)blocks, ysplit), RA_THREADS, 0, rt().stream>>>(buf, stride, (uint32_t)d, d_gammas, E, n_groups, rows.partials, MailTail{{}, nullptr, 0, 0});
+            k_col_reduce_mail<<<1, RA_THREADS, 0, rt().stream>>>(rows.partials, (uint32_t)(blocks * ysplit), 2u, *io);
             return (uint32_t)(blocks * ysplit);
         }
-        k_bool_fold<<<dim3((unsigned)blocks, ysplit), RA_THREADS, 0, g.stream>>>(buf, stride, (uint32_t)d, d_gammas, E, n_groups, rows.partials, tail);
+        k_bool_fold<<<dim3((unsigned)blocks, ysplit), RA_THREADS, 0, rt().stream>>>(buf, stride, (uint32_t)d, d_gammas, E, n_groups, rows.partials, tail);
         return (uint32_t)(blocks * ysplit);
     }
     int finish_phase2(const H::Fr* sums, const H::Fr& claim, std::vector<H::Fr>& coeffs) {
@@ -721,25 +721,25 @@ struct Booleanity : atlas_instance {
 
     int ingest(const atlas_u128_t& r, size_t round) override {
         if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "booleanity: round out of order");
-        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode);
         if (round < log_k) {
             B.bind(rf);
             const size_t n = F.size();                               // ExpandingTable::update, LowToHigh
             F.resize(2 * n);
             for (size_t x = 0; x < n; x++) { F[n + x] = H::mul(F[x], rf); F[x] = H::sub(F[x], F[n + x]); }
             if (round == log_k - 1) {
-                std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+                std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
                 eq_r_r = B.scalar;
                 Fr* d_Fh = nullptr;
                 HIP_TRY(hipMalloc(&d_Fh, F.size() * sizeof(Fr)));
-                HIP_TRY(hipMemcpyAsync(d_Fh, F.data(), F.size() * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+                HIP_TRY(hipMemcpyAsync(d_Fh, F.data(), F.size() * sizeof(Fr), hipMemcpyHostToDevice, rt().stream));
                 int rc = rows.gather(d_Fh, 0);                        // every H_i reads the same table F
                 hipFree(d_Fh);
                 if (rc) return rc;
                 G.clear();
             }
         } else {
-            std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+            std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
             D.st.bind(rf);
             int rc = rows.bind(r);
             if (rc) return rc;
@@ -749,7 +749,7 @@ struct Booleanity : atlas_instance {
     }
     int finals(std::vector<H::Fr>& out) override {
         if (have_finals) { out = mailed_finals; return ATLAS_OK; }
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
         return rows.finals(out);
     }
 
@@ -772,31 +772,31 @@ struct Booleanity : atlas_instance {
     }
     int enqueue(size_t round, const atlas::RoundIo& io, bool bind_prev, atlas_mail_ref& mail) override {
         if (round >= rounds() || (round > 0) != bind_prev) return fail(ATLAS_ESTATE, "booleanity: enqueue out of order");
-        const ChanIo cio{io, g.challenge_mode};
+        const ChanIo cio{io, rt().challenge_mode};
         mail.base = io.mail; mail.blocks = 0; mail.n_vals = 0; mail.radix = 32; mail.shl = 0;
         if (round == 0) {
             if (!d_F) HIP_TRY(hipMalloc(&d_F, ((size_t)1 << log_k) * sizeof(Fr)));
-            k_bool_expand_init<<<1, 64, 0, g.stream>>>(d_F);
+            k_bool_expand_init<<<1, 64, 0, rt().stream>>>(d_F);
         }
-        if (round >= 1 && round <= log_k) k_bool_expand_ch<<<1, RA_THREADS, 0, g.stream>>>(d_F, 1u << (round - 1), cio);
+        if (round >= 1 && round <= log_k) k_bool_expand_ch<<<1, RA_THREADS, 0, rt().stream>>>(d_F, 1u << (round - 1), cio);
         if (round < log_k) return ATLAS_OK;
         const size_t T = (size_t)1 << log_T, p = round - log_k, len = T >> p, n_groups = len / 2;
         if (p == 0) {
             if (!rows.d_idx && !rows.lk) return fail(ATLAS_ESTATE, "booleanity: indices not uploaded");
             size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
-            if (rows.lk) k_ra_gather_lk<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, g.stream>>>(rows.lk, d_F, 0u, T, (uint32_t)d, rows.lk_log, rows.buf[0]);
-            else k_ra_gather<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, g.stream>>>(rows.d_idx, d_F, 0u, T, rows.buf[0]);   // every H_i reads the same table F
+            if (rows.lk) k_ra_gather_lk<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, rt().stream>>>(rows.lk, d_F, 0u, T, (uint32_t)d, rows.lk_log, rows.buf[0]);
+            else k_ra_gather<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, rt().stream>>>(rows.d_idx, d_F, 0u, T, rows.buf[0]);   // every H_i reads the same table F
         } else if (!fused(p)) {
             size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
-            k_ra_bind_ch<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, g.stream>>>(rows.buf[(p - 1) & 1], T >> (p - 1), rows.buf[p & 1], len, len, cio,
-                                                                                     g.challenge_mode == 0 ? 1 : 0);
+            k_ra_bind_ch<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, rt().stream>>>(rows.buf[(p - 1) & 1], T >> (p - 1), rows.buf[p & 1], len, len, cio,
+                                                                                     rt().challenge_mode == 0 ? 1 : 0);
         }
         size_t ot, it;
         D.st.tops_after(p, ot, it);
         if (fused(p)) {
             const unsigned fb = (unsigned)((2 * n_groups + RA_THREADS - 1) / RA_THREADS);       // two lanes per pair
-            k_bool_bind_fold<<<dim3(fb, (unsigned)d), RA_THREADS, 0, g.stream>>>(rows.buf[(p - 1) & 1], T >> (p - 1), rows.buf[p & 1], len, d_gammas, D.view_at(ot, it), n_groups,
-                                                                                rows.partials, cio, g.challenge_mode == 0 ? 1 : 0,
+            k_bool_bind_fold<<<dim3(fb, (unsigned)d), RA_THREADS, 0, rt().stream>>>(rows.buf[(p - 1) & 1], T >> (p - 1), rows.buf[p & 1], len, d_gammas, D.view_at(ot, it), n_groups,
+                                                                                rows.partials, cio, rt().challenge_mode == 0 ? 1 : 0,
                                                                                 MailTail{io, rows.d_counter, (uint32_t)(fb * d), 2u, rows.tg()});
         } else
             launch_fold(rows.buf[p & 1], len, D.view_at(ot, it), n_groups, &io);
@@ -813,7 +813,7 @@ struct Booleanity : atlas_instance {
     }
     int host_ingest(const atlas_u128_t& r, size_t round) override {
         if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "booleanity: round out of order");
-        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode);
         if (round < log_k) {
             B.bind(rf);
             const size_t n = F.size();                               // ExpandingTable::update, LowToHigh (the host copy feeds phase1_message)
@@ -830,7 +830,7 @@ struct Booleanity : atlas_instance {
     }
     int enqueue_finals(const atlas::RoundIo& io, atlas_mail_ref& mail) override {
         const size_t T = (size_t)1 << log_T;
-        k_rows_final_ch<<<1, 64, 0, g.stream>>>(rows.buf[(log_T - 1) & 1], T >> (log_T - 1), (uint32_t)d, ChanIo{io, g.challenge_mode}, g.challenge_mode == 0 ? 1 : 0);
+        k_rows_final_ch<<<1, 64, 0, rt().stream>>>(rows.buf[(log_T - 1) & 1], T >> (log_T - 1), (uint32_t)d, ChanIo{io, rt().challenge_mode}, rt().challenge_mode == 0 ? 1 : 0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(ATLAS_ENODEV, "booleanity: launch", e);
         mail.base = io.mail; mail.blocks = 1; mail.n_vals = (int)d; mail.radix = 32; mail.shl = 0;
@@ -865,7 +865,7 @@ struct HammingWeight : atlas_instance {
     }
     int ingest(const atlas_u128_t& r, size_t round) override {
         if (round != round_next || round >= log_k) return fail(ATLAS_ESTATE, "hamming_weight: round out of order");
-        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode);
         for (auto& p : ra) {
             const size_t half = p.size() / 2;
             for (size_t k = 0; k < half; k++) {
@@ -926,7 +926,7 @@ static int ra_virtual_build(const int32_t* const* H_indices, const uint64_t* loo
     if (d == 0 || d > RA_MAX_D) return fail(ATLAS_EINVAL, "ra_virtual_new: d must be in 1..16");
     // log_T == 0: ONE cycle — a member without rounds (its claim is the product of the d gathered values); stepped by the host, never started
     if (log_k_chunk > 16 || log_T > 25) return fail(ATLAS_EINVAL, "ra_virtual_new: log_k_chunk <= 16, log_T <= 25");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     RaVirtual* P = new RaVirtual();
     P->log_T = log_T;
     const size_t K = (size_t)1 << log_k_chunk, T = (size_t)1 << log_T;
@@ -937,7 +937,7 @@ static int ra_virtual_build(const int32_t* const* H_indices, const uint64_t* loo
         HIP_TRY(hipMalloc(&d_tabs, d * K * sizeof(Fr)));
         FrArgs a;
         std::memcpy(a.v, ch, d * log_k_chunk * sizeof(Fr));
-        k_ra_eq_tables<<<(unsigned)((d * K + RA_THREADS - 1) / RA_THREADS), RA_THREADS, 0, g.stream>>>(a, (uint32_t)d, (uint32_t)log_k_chunk, d_tabs);
+        k_ra_eq_tables<<<(unsigned)((d * K + RA_THREADS - 1) / RA_THREADS), RA_THREADS, 0, rt().stream>>>(a, (uint32_t)d, (uint32_t)log_k_chunk, d_tabs);
     } else {
         std::vector<std::vector<H::Fr>> tabs(d);
         for (size_t i = 0; i < d; i++) tabs[i] = H::eq_evals(ch + i * log_k_chunk, log_k_chunk);
@@ -980,7 +980,7 @@ static int booleanity_build(const atlas_fr_t* G, const int32_t* const* H_indices
     // log_T == 0: ONE cycle — the log_k address rounds only (host arithmetic), then H_i = F[idx_i] gathered as the final claims
     if (d == 0 || log_k_chunk == 0 || log_k_chunk > 16 || log_T > 25)
         return fail(ATLAS_EINVAL, "booleanity_new: 1 <= log_k_chunk <= 16, log_T <= 25");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     Booleanity* P = new Booleanity();
     P->d = d; P->log_k = log_k_chunk; P->log_T = log_T;
     const size_t K = (size_t)1 << log_k_chunk, T = (size_t)1 << log_T;

@@ -20,7 +20,7 @@
 using namespace atlas;
 namespace H = atlas_host;
 using atlas_rt::fail;
-using atlas_rt::g;
+using atlas_rt::rt;
 
 namespace {
 
@@ -294,7 +294,7 @@ inline int store_small(const H::Fr* src, size_t n, Fr* dst) {      // n <= 64 pe
         FrArgs a;
         const size_t m = n - o < 64 ? n - o : 64;
         std::memcpy(a.v, src + o, m * sizeof(Fr));
-        k_store_fr_args<<<1, 64, 0, g.stream>>>(a, (uint32_t)m, dst + o);
+        k_store_fr_args<<<1, 64, 0, rt().stream>>>(a, (uint32_t)m, dst + o);
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ATLAS_OK : fail(ATLAS_ENODEV, "store_small", e);
@@ -336,14 +336,14 @@ struct GseDev {
         if (n <= 32 && one_launch) {
             GsePointArgs a;
             if (n) std::memcpy(a.v, w, n * sizeof(Fr));
-            k_gse_init<<<2, 1024, 0, g.stream>>>(a, (uint32_t)st.m, (uint32_t)st.k_out, (uint32_t)st.k_in, d_eout, d_ein);
+            k_gse_init<<<2, 1024, 0, rt().stream>>>(a, (uint32_t)st.m, (uint32_t)st.k_out, (uint32_t)st.k_in, d_eout, d_ein);
             hipError_t e = hipGetLastError();
             return e == hipSuccess ? ATLAS_OK : fail(ATLAS_ENODEV, "split-eq init", e);
         }
         HIP_TRY(hipMalloc(&d_w, (n ? n : 1) * sizeof(Fr)));
         if (n) { int rc = store_small(w, n, d_w); if (rc) return rc; }
-        k_eq_cached<<<1, 1024, 0, g.stream>>>(d_eout, d_w, (uint32_t)st.k_out);
-        k_eq_cached<<<1, 1024, 0, g.stream>>>(d_ein, d_w + st.m, (uint32_t)st.k_in);
+        k_eq_cached<<<1, 1024, 0, rt().stream>>>(d_eout, d_w, (uint32_t)st.k_out);
+        k_eq_cached<<<1, 1024, 0, rt().stream>>>(d_ein, d_w + st.m, (uint32_t)st.k_in);
         return ATLAS_OK;                      // (stream-ordered: every later use is on the library stream or behind it)
     }
     SplitEqView view() const {
@@ -386,7 +386,7 @@ struct RaRows {
         HIP_TRY(hipMalloc(&partials, cap * sizeof(Fr) + cap * 3 * sizeof(atlas::Chunk)));
         tagged = reinterpret_cast<atlas::Chunk*>(partials + cap);
         HIP_TRY(hipMalloc(&d_counter, MAIL_TAIL_COUNTER_BYTES));
-        HIP_TRY(hipMemsetAsync(d_counter, 0, MAIL_TAIL_COUNTER_BYTES, g.stream));
+        HIP_TRY(hipMemsetAsync(d_counter, 0, MAIL_TAIL_COUNTER_BYTES, rt().stream));
         return ATLAS_OK;
     }
     // indices: d host rows of T int32 -> one device allocation (kept until the gather)
@@ -394,8 +394,8 @@ struct RaRows {
     int upload_indices(const int32_t* const* H_indices) {
         HIP_TRY(hipMalloc(&d_idx, d * len * sizeof(int32_t)));
         for (size_t i = 0; i < d; i++)
-            HIP_TRY(hipMemcpyAsync(d_idx + i * len, H_indices[i], len * sizeof(int32_t), hipMemcpyHostToDevice, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
+            HIP_TRY(hipMemcpyAsync(d_idx + i * len, H_indices[i], len * sizeof(int32_t), hipMemcpyHostToDevice, rt().stream));
+        HIP_TRY(hipStreamSynchronize(rt().stream));
         return ATLAS_OK;
     }
     // the same from the T lookup indices themselves: the d chunk rows are cut on the device (8 T bytes over PCIe
@@ -413,11 +413,11 @@ struct RaRows {
         hipError_t e = hipSuccess;
         if (!on_device) {
             HIP_TRY(hipMalloc(&d_l, len * sizeof(uint64_t)));
-            e = hipMemcpyAsync(d_l, lookups, len * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream);
+            e = hipMemcpyAsync(d_l, lookups, len * sizeof(uint64_t), hipMemcpyHostToDevice, rt().stream);
         }
         if (e == hipSuccess) {
             size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
-            k_ra_chunk_indices<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(on_device ? lookups : d_l, len, (uint32_t)d, log_k_chunk, d_idx);
+            k_ra_chunk_indices<<<(unsigned)gb, RA_THREADS, 0, rt().stream>>>(on_device ? lookups : d_l, len, (uint32_t)d, log_k_chunk, d_idx);
             e = hipGetLastError();            // no synchronisation: d_l goes back to the pool, which hands it out in stream order
         }
         if (d_l) hipFree(d_l);
@@ -428,14 +428,14 @@ struct RaRows {
     int gather(const Fr* d_tables, uint32_t f_stride) {
         size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
         if (lk) {
-            k_ra_gather_lk<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, g.stream>>>(lk, d_tables, f_stride, len, (uint32_t)d, lk_log, buf[0]);
+            k_ra_gather_lk<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, rt().stream>>>(lk, d_tables, f_stride, len, (uint32_t)d, lk_log, buf[0]);
             hipError_t e0 = hipGetLastError();
             if (e0 != hipSuccess) return fail(ATLAS_ENODEV, "ra gather", e0);
             cur = 0; stride[0] = len;
             return ATLAS_OK;
         }
         if (!d_idx) return fail(ATLAS_ESTATE, "ra gather: indices not uploaded");
-        k_ra_gather<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, g.stream>>>(d_idx, d_tables, f_stride, len, buf[0]);
+        k_ra_gather<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, rt().stream>>>(d_idx, d_tables, f_stride, len, buf[0]);
         hipError_t e = hipGetLastError();
         hipFree(d_idx); d_idx = nullptr;      // (pool: reused in stream order)
         if (e != hipSuccess) return fail(ATLAS_ENODEV, "ra gather", e);
@@ -443,13 +443,13 @@ struct RaRows {
         return ATLAS_OK;
     }
     int bind(const atlas_u128_t& r) {
-        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode);
         const size_t half = len / 2;
         const int nxt = cur ^ 1;
         stride[nxt] = half;
         size_t gb = (half + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096; if (gb < 1) gb = 1;
-        k_ra_bind<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, g.stream>>>(buf[cur], stride[cur], buf[nxt], stride[nxt], half,
-                                                                               to_dev(rf), g.challenge_mode == 0 ? 1 : 0);
+        k_ra_bind<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, rt().stream>>>(buf[cur], stride[cur], buf[nxt], stride[nxt], half,
+                                                                               to_dev(rf), rt().challenge_mode == 0 ? 1 : 0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(ATLAS_ENODEV, "ra bind", e);
         cur = nxt; len = half;
@@ -458,17 +458,17 @@ struct RaRows {
     // The sums and the final claims go straight into the pinned staging area (device-visible host memory): a
     // hipMemcpyAsync D2H of a few hundred bytes is a copy kernel of its own (4 us on the device, ~10 us end to end).
     int reduce_to_host(uint32_t n_partials, uint32_t k, H::Fr* out) {
-        k_col_reduce<<<k, RA_THREADS, 0, g.stream>>>(partials, n_partials, k, (Fr*)g.h_pinned);
-        HIP_TRY(hipStreamSynchronize(g.stream));
-        std::memcpy(out, g.h_pinned, k * sizeof(Fr));
+        k_col_reduce<<<k, RA_THREADS, 0, rt().stream>>>(partials, n_partials, k, (Fr*)rt().h_pinned);
+        HIP_TRY(hipStreamSynchronize(rt().stream));
+        std::memcpy(out, rt().h_pinned, k * sizeof(Fr));
         return ATLAS_OK;
     }
     int finals(std::vector<H::Fr>& out) {
         if (len != 1) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
         out.resize(d);
-        k_col_reduce<<<(unsigned)d, RA_THREADS, 0, g.stream>>>(buf[cur], 1u, 1u, (Fr*)g.h_pinned, (uint32_t)stride[cur]);
-        HIP_TRY(hipStreamSynchronize(g.stream));
-        std::memcpy(out.data(), g.h_pinned, d * sizeof(Fr));
+        k_col_reduce<<<(unsigned)d, RA_THREADS, 0, rt().stream>>>(buf[cur], 1u, 1u, (Fr*)rt().h_pinned, (uint32_t)stride[cur]);
+        HIP_TRY(hipStreamSynchronize(rt().stream));
+        std::memcpy(out.data(), rt().h_pinned, d * sizeof(Fr));
         return ATLAS_OK;
     }
     void release() { for (auto& b : buf) if (b) hipFree(b); if (partials) hipFree(partials); if (d_idx) hipFree(d_idx); if (d_counter) hipFree(d_counter); buf[0] = buf[1] = partials = nullptr; d_idx = nullptr; d_counter = nullptr; }

@@ -24,7 +24,7 @@ using atlas_rt::fail;
 struct atlas_rt_pool_row { const uint64_t* d_lookups; size_t shift, log_T; const atlas_fr_t* point; };
 int atlas_rt_onehot_pool_new(const atlas_rt_pool_row* in, size_t n, size_t log_K, size_t batch_max_rounds, atlas_instance_t* out, const int32_t** d_idx_rows);   // opening.hip
 
-static double g_last_open_ms = 0;
+static thread_local double g_last_open_ms = 0;
 double atlas_rt_last_hyperkzg_ms() { return g_last_open_ms; }
 
 // `sh` (may be NULL): the ranks of a sharded whole proof (atlas_prove_graph_sharded).  Every rank runs the reduction sumcheck and builds the
@@ -91,9 +91,9 @@ int atlas_rt_prove_reduced_openings(const atlas_opening_t* openings, size_t n_op
         const size_t T = (size_t)1 << O.log_T;
         std::vector<uint64_t> lk(T);
         {
-            std::lock_guard<atlas_rt::Mutex> lkg(atlas_rt::g.mu);
-            hipError_t e = hipMemcpyAsync(lk.data(), O.d_lookups, T * 8, hipMemcpyDeviceToHost, atlas_rt::g.stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(atlas_rt::g.stream);
+            std::lock_guard<atlas_rt::Mutex> lkg(atlas_rt::rt().mu);
+            hipError_t e = hipMemcpyAsync(lk.data(), O.d_lookups, T * 8, hipMemcpyDeviceToHost, atlas_rt::rt().stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(atlas_rt::rt().stream);
             if (e != hipSuccess) { rc = atlas_rt::fail(ATLAS_ENODEV, "prove_reduced_openings: lookup indices to the host", e); break; }   // falls through to cleanup()
         }
         host_rows.emplace_back(T);

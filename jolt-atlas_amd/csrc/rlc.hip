@@ -21,7 +21,7 @@
 
 using namespace atlas;
 using atlas_rt::fail;
-using atlas_rt::g;
+using atlas_rt::rt;
 
 namespace {
 
@@ -88,7 +88,7 @@ extern "C" int atlas_rlc_build(const atlas_rlc_dense_t* dense, size_t n_dense, c
     PROF("atlas_rlc_build");
     NEED_INIT();
     if (!out || (n_dense && !dense) || (n_onehot && !onehot)) return fail(ATLAS_EINVAL, "rlc_build: null argument");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     size_t joint_len = 0;
     for (size_t j = 0; j < n_dense; j++) {
         if (!dense[j].poly) return fail(ATLAS_EINVAL, "rlc_build: null dense polynomial");
@@ -122,9 +122,9 @@ extern "C" int atlas_rlc_build(const atlas_rlc_dense_t* dense, size_t n_dense, c
     if (n_dense) {
         e = hipMalloc(&d_dense, n_dense * sizeof(RlcDense));
         if (e != hipSuccess) return bail(fail(ATLAS_ENOMEM, "hipMalloc(rlc table)", e));
-        hipMemcpyAsync(d_dense, hd.data(), n_dense * sizeof(RlcDense), hipMemcpyHostToDevice, g.stream);
+        hipMemcpyAsync(d_dense, hd.data(), n_dense * sizeof(RlcDense), hipMemcpyHostToDevice, rt().stream);
     }
-    k_rlc_dense<<<grid_for(joint_len), RLC_THREADS, 0, g.stream>>>(d_dense, (uint32_t)n_dense, joint, joint_len);
+    k_rlc_dense<<<grid_for(joint_len), RLC_THREADS, 0, rt().stream>>>(d_dense, (uint32_t)n_dense, joint, joint_len);
 
     // one-hot part, grouped by T
     std::map<size_t, std::vector<size_t>> groups;
@@ -137,7 +137,7 @@ extern "C" int atlas_rlc_build(const atlas_rlc_dense_t* dense, size_t n_dense, c
         e = hipMalloc(&d_bad, 4);
         if (e != hipSuccess) { if (d_dense) hipFree(d_dense); return bail(fail(ATLAS_ENOMEM, "hipMalloc(rlc flag)", e)); }
         to_free.push_back(d_bad);
-        hipMemsetAsync(d_bad, 0, 4, g.stream);
+        hipMemsetAsync(d_bad, 0, 4, rt().stream);
     }
     for (auto& kv : groups) {
         const size_t T = kv.first;
@@ -152,7 +152,7 @@ extern "C" int atlas_rlc_build(const atlas_rlc_dense_t* dense, size_t n_dense, c
                 e = hipMalloc(&dk, T * 4);
                 if (e != hipSuccess) { rc = fail(ATLAS_ENOMEM, "hipMalloc(rlc indices)", e); break; }
                 to_free.push_back(dk);
-                hipMemcpyAsync(dk, O.k, T * 4, hipMemcpyHostToDevice, g.stream);
+                hipMemcpyAsync(dk, O.k, T * 4, hipMemcpyHostToDevice, rt().stream);
                 ho[q].k = dk;
             }
         }
@@ -161,15 +161,15 @@ extern "C" int atlas_rlc_build(const atlas_rlc_dense_t* dense, size_t n_dense, c
         e = hipMalloc(&d_oh, ho.size() * sizeof(RlcOneHot));
         if (e != hipSuccess) { rc = fail(ATLAS_ENOMEM, "hipMalloc(rlc one-hot table)", e); break; }
         to_free.push_back(d_oh);
-        hipMemcpyAsync(d_oh, ho.data(), ho.size() * sizeof(RlcOneHot), hipMemcpyHostToDevice, g.stream);
+        hipMemcpyAsync(d_oh, ho.data(), ho.size() * sizeof(RlcOneHot), hipMemcpyHostToDevice, rt().stream);
         // the H2D copies above read pageable host memory that goes out of scope: drain before reuse
-        hipStreamSynchronize(g.stream);
-        k_rlc_onehot<<<grid_for(T), RLC_THREADS, 0, g.stream>>>(d_oh, (uint32_t)ho.size(), T, joint, d_bad);
+        hipStreamSynchronize(rt().stream);
+        k_rlc_onehot<<<grid_for(T), RLC_THREADS, 0, rt().stream>>>(d_oh, (uint32_t)ho.size(), T, joint, d_bad);
     }
     hipError_t le = hipGetLastError();
     uint32_t h_bad = 0;
-    if (d_bad && rc == ATLAS_OK) hipMemcpyAsync(&h_bad, d_bad, 4, hipMemcpyDeviceToHost, g.stream);
-    hipStreamSynchronize(g.stream);
+    if (d_bad && rc == ATLAS_OK) hipMemcpyAsync(&h_bad, d_bad, 4, hipMemcpyDeviceToHost, rt().stream);
+    hipStreamSynchronize(rt().stream);
     if (h_bad && rc == ATLAS_OK) rc = fail(ATLAS_EINVAL, "rlc_build: one-hot index >= K");
     for (void* p : to_free) hipFree(p);
     if (d_dense) hipFree(d_dense);

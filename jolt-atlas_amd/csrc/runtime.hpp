@@ -34,7 +34,7 @@ struct Runtime {
     bool ready = false;
     int device = -1;
     hipStream_t stream = nullptr;      // where the entry points launch; Pipeline::advance (batched.hip) points it at a lane stream
-                                       // for the duration of one enqueue() call, under g.mu
+                                       // for the duration of one enqueue() call, under rt().mu
     hipStream_t lib_stream = nullptr;  // the library stream itself: never swapped (the device pool's tag for threads outside a lane)
     int challenge_mode = 0;
     int fs_mode = ATLAS_FS_HOST;       // where the Fiat-Shamir transcript of the whole-instance provers runs
@@ -49,14 +49,28 @@ struct Runtime {
     void* h_pinned = nullptr;          // pinned staging for small D2H/H2D
     int pending_async = 0;             // launches of shared_message_step calls whose results the driver has not waited for yet (batched.hip)
     std::vector<void (*)()> at_shutdown;   // release hooks of the translation units that keep device arenas
+    struct DevPool* pool = nullptr;        // the caching allocator of this runtime (devpool.hpp): blocks are reused in the order of ITS streams
+    void* msm_ws = nullptr;                // msm.hip's workspace (one per runtime: it lives on the runtime's device)
     Mutex mu;
 };
-extern Runtime g;
+// One Runtime per PROCESS by default (g_default: what every thread sees that never asked for its own), and one per THREAD for the threads
+// that call atlas_init_thread(device): the shape a single Rust `prove` call over the GPUs of a node needs — N threads of one process, a
+// device, stream set, round channel, allocator and MSM workspace each (the reference is one process: onnx_proof/mod.rs:153-156).  A thread's
+// runtime is also what the host-thread pool's workers of THAT thread see (host_threads.hpp hands the pointer over with every job).
+extern Runtime g_default;
+extern thread_local Runtime* g_cur;
+inline Runtime& rt() { Runtime* p = g_cur; return p ? *p : g_default; }
+// a worker thread that runs a range of the owner's job sees the owner's runtime for the length of the range (batched.hip: the host-thread pool)
+struct RtScope {
+    Runtime* saved;
+    explicit RtScope(Runtime* owner) : saved(g_cur) { g_cur = owner; }
+    ~RtScope() { g_cur = saved; }
+};
 // the lane stream the calling thread is enqueueing on (set by Pipeline::advance around enqueue()), nullptr otherwise.  The device
 // pool tags a returned block with THIS thread's stream, so a thread that frees a buffer while another thread's pipeline has
-// g.stream pointed at a lane cannot mislabel it.
+// rt().stream pointed at a lane cannot mislabel it.
 extern thread_local hipStream_t tl_lane_stream;
-inline hipStream_t pool_tag_stream() { return tl_lane_stream ? tl_lane_stream : g.lib_stream; }
+inline hipStream_t pool_tag_stream() { return tl_lane_stream ? tl_lane_stream : rt().lib_stream; }
 
 constexpr size_t MAX_ROUNDS = 64;
 constexpr size_t PINNED_BYTES = 1 << 16;
@@ -86,8 +100,8 @@ struct DevBuf {
     } while (0)
 #define NEED_INIT()                                                            \
     do {                                                                       \
-        if (!atlas_rt::g.ready) {                                              \
-            int rc_ = atlas_init(atlas_rt::g.device < 0 ? 0 : atlas_rt::g.device); \
+        if (!atlas_rt::rt().ready) {                                              \
+            int rc_ = atlas_init(atlas_rt::rt().device < 0 ? 0 : atlas_rt::rt().device); \
             if (rc_) return rc_;                                               \
         }                                                                      \
     } while (0)

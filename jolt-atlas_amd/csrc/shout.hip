@@ -32,7 +32,7 @@
 using namespace atlas;
 namespace H = atlas_host;
 using atlas_rt::fail;
-using atlas_rt::g;
+using atlas_rt::rt;
 
 namespace {
 
@@ -188,13 +188,13 @@ int histogram_small_host(const uint64_t* h_idx, size_t T, KeySpec S, const atlas
     hipPointerAttribute_t attr;
     const bool on_device = T && hipPointerGetAttributes(&attr, h_idx) == hipSuccess && attr.type == hipMemoryTypeDevice;      // (read in place: no copy of a device vector)
     (void)hipGetLastError();
-    HIP_TRY(hipMemsetAsync(acc_b.p, 0, nw * 8, g.stream));
-    if (!on_device) { HIP_TRY(ix_b.alloc((T ? T : 1) * 8)); HIP_TRY(hipMemcpyAsync(ix_b.p, h_idx, T * 8, hipMemcpyHostToDevice, g.stream)); }
+    HIP_TRY(hipMemsetAsync(acc_b.p, 0, nw * 8, rt().stream));
+    if (!on_device) { HIP_TRY(ix_b.alloc((T ? T : 1) * 8)); HIP_TRY(hipMemcpyAsync(ix_b.p, h_idx, T * 8, hipMemcpyHostToDevice, rt().stream)); }
     size_t blocks = (T + SH_THREADS - 1) / SH_THREADS; if (blocks < 1) blocks = 1; if (blocks > 512) blocks = 512;
-    k_sh_hist_small<<<(unsigned)blocks, SH_THREADS, 0, g.stream>>>(on_device ? h_idx : ix_b.as<uint64_t>(), T, S, (const Fe*)E->d, acc_b.as<unsigned long long>());
-    HIP_TRY(hipMemcpyAsync(g.h_pinned, acc_b.p, nw * 8, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
-    const unsigned long long* h_acc = reinterpret_cast<const unsigned long long*>(g.h_pinned);
+    k_sh_hist_small<<<(unsigned)blocks, SH_THREADS, 0, rt().stream>>>(on_device ? h_idx : ix_b.as<uint64_t>(), T, S, (const Fe*)E->d, acc_b.as<unsigned long long>());
+    HIP_TRY(hipMemcpyAsync(rt().h_pinned, acc_b.p, nw * 8, hipMemcpyDeviceToHost, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
+    const unsigned long long* h_acc = reinterpret_cast<const unsigned long long*>(rt().h_pinned);
     out.resize(n_buckets);
     for (uint32_t b = 0; b < n_buckets; b++) {
         uint64_t a9[9];
@@ -217,8 +217,8 @@ int histogram(const uint64_t* h_idx, size_t T, KeySpec S, const atlas_poly* E, a
         Fe* Gs = nullptr;
         hipError_t e2 = hipMalloc(&Gs, (size_t)n_buckets * sizeof(Fe));
         if (e2 != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(G)", e2);
-        e2 = hipMemcpyAsync(Gs, h_G.data(), (size_t)n_buckets * sizeof(Fe), hipMemcpyHostToDevice, g.stream);
-        if (e2 == hipSuccess) e2 = hipStreamSynchronize(g.stream);
+        e2 = hipMemcpyAsync(Gs, h_G.data(), (size_t)n_buckets * sizeof(Fe), hipMemcpyHostToDevice, rt().stream);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(rt().stream);
         if (e2 != hipSuccess) { hipFree(Gs); return fail(ATLAS_ENODEV, "shout histogram", e2); }
         atlas_poly* p = new atlas_poly();
         p->d = Gs; p->len = n_buckets; p->cap_bytes = (size_t)n_buckets * sizeof(Fe); p->is_i32 = false; p->owned = true;
@@ -232,13 +232,13 @@ int histogram(const uint64_t* h_idx, size_t T, KeySpec S, const atlas_poly* E, a
         (void)hipGetLastError();
         DevBuf acc_b, ix_b;
         HIP_TRY(acc_b.alloc((size_t)n_buckets * 64));
-        if (!on_device) { HIP_TRY(ix_b.alloc((T ? T : 1) * 8)); HIP_TRY(hipMemcpyAsync(ix_b.p, h_idx, T * 8, hipMemcpyHostToDevice, g.stream)); }
+        if (!on_device) { HIP_TRY(ix_b.alloc((T ? T : 1) * 8)); HIP_TRY(hipMemcpyAsync(ix_b.p, h_idx, T * 8, hipMemcpyHostToDevice, rt().stream)); }
         Fe* Gw = nullptr;
         hipError_t e3 = hipMalloc(&Gw, (size_t)n_buckets * sizeof(Fe));
         if (e3 != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(G)", e3);
-        HIP_TRY(hipMemsetAsync(acc_b.p, 0, (size_t)n_buckets * 64, g.stream));
-        k_sh_hist_words<<<grid_for(T), SH_THREADS, 0, g.stream>>>(on_device ? h_idx : ix_b.as<uint64_t>(), T, S, (const Fe*)E->d, acc_b.as<unsigned long long>());
-        k_sh_words_final<<<(n_buckets + SH_THREADS - 1) / SH_THREADS, SH_THREADS, 0, g.stream>>>(acc_b.as<unsigned long long>(), n_buckets, Gw);
+        HIP_TRY(hipMemsetAsync(acc_b.p, 0, (size_t)n_buckets * 64, rt().stream));
+        k_sh_hist_words<<<grid_for(T), SH_THREADS, 0, rt().stream>>>(on_device ? h_idx : ix_b.as<uint64_t>(), T, S, (const Fe*)E->d, acc_b.as<unsigned long long>());
+        k_sh_words_final<<<(n_buckets + SH_THREADS - 1) / SH_THREADS, SH_THREADS, 0, rt().stream>>>(acc_b.as<unsigned long long>(), n_buckets, Gw);
         // (stream order is all the caller needs: G is consumed by launches on this stream; the scratch returns to the pool under this stream's tag)
         e3 = hipGetLastError();
         if (e3 != hipSuccess) { hipFree(Gw); return fail(ATLAS_ENODEV, "shout histogram", e3); }
@@ -257,16 +257,16 @@ int histogram(const uint64_t* h_idx, size_t T, KeySpec S, const atlas_poly* E, a
     HIP_TRY(hipMalloc(&sorted, (T * S.d ? T * S.d : 1) * 4));
     hipError_t e = hipMalloc(&G, (size_t)n_buckets * sizeof(Fe));
     if (e != hipSuccess) { cleanup(); return fail(ATLAS_ENOMEM, "hipMalloc(G)", e); }
-    HIP_TRY(hipMemcpyAsync(d_idx, h_idx, T * 8, hipMemcpyDefault, g.stream));   // host or device source
-    HIP_TRY(hipMemsetAsync(counts, 0, (size_t)(n_buckets + 1) * 4, g.stream));
-    k_sh_hist<<<grid_for(T), SH_THREADS, 0, g.stream>>>(d_idx, T, S, counts);
-    k_exclusive_scan<<<1, 1024, 0, g.stream>>>(counts, n_buckets, offsets, cursor);
-    k_sh_scatter<<<grid_for(T), SH_THREADS, 0, g.stream>>>(d_idx, T, S, cursor, sorted);
+    HIP_TRY(hipMemcpyAsync(d_idx, h_idx, T * 8, hipMemcpyDefault, rt().stream));   // host or device source
+    HIP_TRY(hipMemsetAsync(counts, 0, (size_t)(n_buckets + 1) * 4, rt().stream));
+    k_sh_hist<<<grid_for(T), SH_THREADS, 0, rt().stream>>>(d_idx, T, S, counts);
+    k_exclusive_scan<<<1, 1024, 0, rt().stream>>>(counts, n_buckets, offsets, cursor);
+    k_sh_scatter<<<grid_for(T), SH_THREADS, 0, rt().stream>>>(d_idx, T, S, cursor, sorted);
     if (n_buckets <= 8192)
-        k_sh_bucket_sum_wg<<<n_buckets, SH_THREADS, 0, g.stream>>>((const Fe*)E->d, sorted, offsets, G);
+        k_sh_bucket_sum_wg<<<n_buckets, SH_THREADS, 0, rt().stream>>>((const Fe*)E->d, sorted, offsets, G);
     else
-        k_sh_bucket_sum_thread<<<(n_buckets + SH_THREADS - 1) / SH_THREADS, SH_THREADS, 0, g.stream>>>((const Fe*)E->d, sorted, offsets, n_buckets, G);
-    e = hipStreamSynchronize(g.stream);
+        k_sh_bucket_sum_thread<<<(n_buckets + SH_THREADS - 1) / SH_THREADS, SH_THREADS, 0, rt().stream>>>((const Fe*)E->d, sorted, offsets, n_buckets, G);
+    e = hipStreamSynchronize(rt().stream);
     cleanup();
     if (e != hipSuccess) { hipFree(G); return fail(ATLAS_ENODEV, "shout histogram", e); }
     atlas_poly* p = new atlas_poly();
@@ -288,7 +288,7 @@ int atlas_shout_read_raf_G(const uint64_t* lookup_indices, size_t T, size_t log_
     // Tanh node), its flag read back after the histogram's own synchronisation
     hipPointerAttribute_t attr;
     const bool on_device = T && hipPointerGetAttributes(&attr, lookup_indices) == hipSuccess && attr.type == hipMemoryTypeDevice;
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     DevBuf flag;
     if (!on_device) {
         (void)hipGetLastError();
@@ -296,14 +296,14 @@ int atlas_shout_read_raf_G(const uint64_t* lookup_indices, size_t T, size_t log_
             if (lookup_indices[j] >> log_K) return fail(ATLAS_EINVAL, "shout_read_raf_G: lookup index outside the table");
     } else {
         HIP_TRY(flag.alloc(4));
-        HIP_TRY(hipMemsetAsync(flag.p, 0, 4, g.stream));
-        k_sh_range_flag<<<grid_for(T), SH_THREADS, 0, g.stream>>>(lookup_indices, T, (uint32_t)log_K, flag.as<uint32_t>());
+        HIP_TRY(hipMemsetAsync(flag.p, 0, 4, rt().stream));
+        k_sh_range_flag<<<grid_for(T), SH_THREADS, 0, rt().stream>>>(lookup_indices, T, (uint32_t)log_K, flag.as<uint32_t>());
     }
     int rc = histogram(lookup_indices, T, KeySpec{1u, (uint32_t)log_K}, eq_r, out);
     if (!rc && on_device) {
         uint32_t bad = 0;
-        HIP_TRY(hipMemcpyAsync(&bad, flag.p, 4, hipMemcpyDeviceToHost, g.stream));      // on the library's (non-blocking) stream, behind the flag kernel
-        HIP_TRY(hipStreamSynchronize(g.stream));
+        HIP_TRY(hipMemcpyAsync(&bad, flag.p, 4, hipMemcpyDeviceToHost, rt().stream));      // on the library's (non-blocking) stream, behind the flag kernel
+        HIP_TRY(hipStreamSynchronize(rt().stream));
         if (bad) { atlas_poly_free(*out); *out = nullptr; return fail(ATLAS_EINVAL, "shout_read_raf_G: lookup index outside the table"); }
     }
     return rc;
@@ -315,7 +315,7 @@ int atlas_shout_ra_evals(const uint64_t* lookup_indices, size_t T, size_t log_K,
     if ((!lookup_indices && T) || !eq_r_cycle || !out || log_k_chunk == 0 || log_k_chunk > 16 || log_K == 0 || log_K > 64)
         return fail(ATLAS_EINVAL, "shout_ra_evals");
     const uint32_t d = (uint32_t)((log_K + log_k_chunk - 1) / log_k_chunk);     // instruction_d (config.rs:45)
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     return histogram(lookup_indices, T, KeySpec{d, (uint32_t)log_k_chunk}, eq_r_cycle, out);
 }
 
@@ -330,7 +330,7 @@ int atlas_rt_shout_ra_evals_host(const uint64_t* lookup_indices, size_t T, size_
     if (!lookup_indices || !eq_r_cycle || log_k_chunk == 0 || log_k_chunk > 16 || ((size_t)d << log_k_chunk) > SH_SMALL_BUCKETS)
         return fail(ATLAS_EINVAL, "shout_ra_evals_host");
     if (eq_r_cycle->is_i32 || eq_r_cycle->len < T) return fail(ATLAS_EINVAL, "shout: eq table shorter than the index list");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     return histogram_small_host(lookup_indices, T, KeySpec{d, (uint32_t)log_k_chunk}, eq_r_cycle, G);
 }
 
@@ -362,7 +362,7 @@ struct HostDot : atlas_instance {
     }
     int ingest(const atlas_u128_t& r, size_t round) override {
         if (round != round_next || round >= n) return fail(ATLAS_ESTATE, "host read-raf: round out of order");
-        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode);
         const size_t h = L.size() / 2;
         for (size_t i = 0; i < h; i++) {
             if (!(H::detail::is_zero4(L[i].l) && H::detail::is_zero4(L[i + h].l))) L[i] = H::add(L[i], H::mul(rf, H::sub(L[i + h], L[i])));
@@ -416,24 +416,24 @@ int atlas_rt_shout_ra_evals_launch(const uint64_t* lookup_indices, size_t T, siz
     if (eq_r_cycle->is_i32 || eq_r_cycle->len < T) return fail(ATLAS_EINVAL, "shout: eq table shorter than the index list");
     hipPointerAttribute_t attr;
     if (hipPointerGetAttributes(&attr, lookup_indices) != hipSuccess || attr.type != hipMemoryTypeDevice) { (void)hipGetLastError(); return fail(ATLAS_EINVAL, "shout_ra_evals_launch: device-resident indices expected"); }
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     std::unique_ptr<atlas_rt_ra_ticket> tk(new atlas_rt_ra_ticket());
     const KeySpec S{d, (uint32_t)log_k_chunk};
     tk->n_buckets = d << log_k_chunk;
     const size_t nw = (size_t)tk->n_buckets * 8;
     HIP_TRY(tk->acc.alloc(nw * 8));
-    HIP_TRY(hipMemsetAsync(tk->acc.p, 0, nw * 8, g.stream));
+    HIP_TRY(hipMemsetAsync(tk->acc.p, 0, nw * 8, rt().stream));
     size_t blocks = (T + SH_THREADS - 1) / SH_THREADS; if (blocks < 1) blocks = 1; if (blocks > 512) blocks = 512;
-    k_sh_hist_small<<<(unsigned)blocks, SH_THREADS, 0, g.stream>>>(lookup_indices, T, S, (const Fe*)eq_r_cycle->d, tk->acc.as<unsigned long long>());
-    atlas::Chunk* box = g.chan.alloc_long((nw * 8 + 15) / 16);          // pinned: the copy lands there in stream order
-    HIP_TRY(hipMemcpyAsync(box, tk->acc.p, nw * 8, hipMemcpyDeviceToHost, g.stream));
+    k_sh_hist_small<<<(unsigned)blocks, SH_THREADS, 0, rt().stream>>>(lookup_indices, T, S, (const Fe*)eq_r_cycle->d, tk->acc.as<unsigned long long>());
+    atlas::Chunk* box = rt().chan.alloc_long((nw * 8 + 15) / 16);          // pinned: the copy lands there in stream order
+    HIP_TRY(hipMemcpyAsync(box, tk->acc.p, nw * 8, hipMemcpyDeviceToHost, rt().stream));
     tk->box = reinterpret_cast<const unsigned long long*>(box);
     *out = tk.release();
     return ATLAS_OK;
 }
 int atlas_rt_shout_ra_evals_finish(atlas_rt_ra_ticket* tk, bool wait, std::vector<atlas_host::Fr>& G) {
     if (!tk) return fail(ATLAS_EINVAL, "shout_ra_evals_finish");
-    if (wait) { std::lock_guard<atlas_rt::Mutex> lk(g.mu); HIP_TRY(hipStreamSynchronize(g.stream)); }
+    if (wait) { std::lock_guard<atlas_rt::Mutex> lk(rt().mu); HIP_TRY(hipStreamSynchronize(rt().stream)); }
     G.resize(tk->n_buckets);
     for (uint32_t b = 0; b < tk->n_buckets; b++) {
         uint64_t a9[9];
@@ -456,14 +456,14 @@ int atlas_shout_read_raf_prover_new(atlas_poly_t G, const int32_t* table, size_t
     if (G->is_i32 || G->len != K) return fail(ATLAS_EINVAL, "shout_read_raf_prover_new: G length != table size");
     int32_t* d_tab = nullptr; Fe* W = nullptr;
     {
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
         HIP_TRY(hipMalloc(&d_tab, K * 4));
         hipError_t e = hipMalloc(&W, K * sizeof(Fe));
         if (e != hipSuccess) { hipFree(d_tab); return fail(ATLAS_ENOMEM, "hipMalloc(W)", e); }
-        HIP_TRY(hipMemcpyAsync(d_tab, table, K * 4, hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(hipMemcpyAsync(d_tab, table, K * 4, hipMemcpyHostToDevice, rt().stream));
         Fe gm; std::memcpy(gm.v, gamma, 32);
-        k_sh_build_w<<<grid_for(K), SH_THREADS, 0, g.stream>>>(d_tab, K, gm, W);
-        e = hipStreamSynchronize(g.stream);
+        k_sh_build_w<<<grid_for(K), SH_THREADS, 0, rt().stream>>>(d_tab, K, gm, W);
+        e = hipStreamSynchronize(rt().stream);
         hipFree(d_tab);
         if (e != hipSuccess) { hipFree(W); return fail(ATLAS_ENODEV, "shout build W", e); }
     }

@@ -134,14 +134,14 @@ struct Softmax : atlas_instance {
 
     int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
         if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "softmax: round out of order");
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
         const size_t half = rows.len / 2;
         size_t blocks = (half + RA_THREADS - 1) / RA_THREADS; if (blocks > 1024) blocks = 1024;
         const Fr* a = rows.buf[rows.cur]; const Fr* b = a + rows.stride[rows.cur];
         H::Fr s[3];
         int rc;
         if (kind == SM_SUM_AXIS) {
-            k_sm_sum_half<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, half, rows.partials, MailTail{{}, nullptr, 0, 0});
+            k_sm_sum_half<<<(unsigned)blocks, RA_THREADS, 0, rt().stream>>>(a, half, rows.partials, MailTail{{}, nullptr, 0, 0});
             if ((rc = rows.reduce_to_host((uint32_t)blocks, 1, s))) return rc;
             linear_from_eval0(claim, s[0], coeffs);
             return ATLAS_OK;
@@ -149,16 +149,16 @@ struct Softmax : atlas_instance {
         if (round < log_N) {
             const uint32_t shift = (uint32_t)(log_N - (round + 1));
             if (kind == SM_EXP_SUM) {
-                k_sm_expsum_p1<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, d_eq_k, shift, half, rows.partials, MailTail{{}, nullptr, 0, 0});
+                k_sm_expsum_p1<<<(unsigned)blocks, RA_THREADS, 0, rt().stream>>>(a, d_eq_k, shift, half, rows.partials, MailTail{{}, nullptr, 0, 0});
                 if ((rc = rows.reduce_to_host((uint32_t)blocks, 1, s))) return rc;
                 linear_from_eval0(claim, s[0], coeffs);
             } else if (kind == SM_MAX_INDICATOR) {
-                k_sm_max_p1<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, b, d_eq_k, shift, half, rows.partials, MailTail{{}, nullptr, 0, 0});
+                k_sm_max_p1<<<(unsigned)blocks, RA_THREADS, 0, rt().stream>>>(a, b, d_eq_k, shift, half, rows.partials, MailTail{{}, nullptr, 0, 0});
                 if ((rc = rows.reduce_to_host((uint32_t)blocks, 3, s))) return rc;
                 coeffs.assign(4, H::zero());
                 H::unipoly_from_evals_and_hint(claim, s, 3, coeffs.data());
             } else {
-                k_sm_recip_p1<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, inv.buf[inv.cur], shift, gs.view(), half, rows.partials, MailTail{{}, nullptr, 0, 0});
+                k_sm_recip_p1<<<(unsigned)blocks, RA_THREADS, 0, rt().stream>>>(a, inv.buf[inv.cur], shift, gs.view(), half, rows.partials, MailTail{{}, nullptr, 0, 0});
                 if ((rc = rows.reduce_to_host((uint32_t)blocks, 1, s))) return rc;
                 coeffs.assign(3, H::zero());
                 H::gruen_deg2(gs.st.scalar, gs.st.w_cur(), s[0], claim, coeffs.data());
@@ -166,12 +166,12 @@ struct Softmax : atlas_instance {
             return ATLAS_OK;
         }
         if (kind == SM_EXP_SUM) {
-            k_sm_p2<1><<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, nullptr, gs.view(), half, rows.partials, MailTail{{}, nullptr, 0, 0});
+            k_sm_p2<1><<<(unsigned)blocks, RA_THREADS, 0, rt().stream>>>(a, nullptr, gs.view(), half, rows.partials, MailTail{{}, nullptr, 0, 0});
             if ((rc = rows.reduce_to_host((uint32_t)blocks, 1, s))) return rc;
             coeffs.assign(3, H::zero());
             H::gruen_deg2(gs.st.scalar, gs.st.w_cur(), s[0], claim, coeffs.data());
         } else {
-            k_sm_p2<2><<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, kind == SM_RECIP_MULT ? inv.buf[inv.cur] : b, gs.view(), half, rows.partials, MailTail{{}, nullptr, 0, 0});
+            k_sm_p2<2><<<(unsigned)blocks, RA_THREADS, 0, rt().stream>>>(a, kind == SM_RECIP_MULT ? inv.buf[inv.cur] : b, gs.view(), half, rows.partials, MailTail{{}, nullptr, 0, 0});
             if ((rc = rows.reduce_to_host((uint32_t)blocks, 2, s))) return rc;
             coeffs.assign(4, H::zero());
             H::gruen_deg3(gs.st, s[0], s[1], claim, coeffs.data());
@@ -181,13 +181,13 @@ struct Softmax : atlas_instance {
 
     int ingest(const atlas_u128_t& r, size_t round) override {
         if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "softmax: round out of order");
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
-        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode);
         int rc;
         if (kind == SM_SUM_AXIS) {                 // HighToLow, out of place between the two row buffers
             const size_t half = rows.len / 2; const int nxt = rows.cur ^ 1;
             size_t gb = (half + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096; if (gb < 1) gb = 1;
-            k_sm_bind_hi<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(rows.buf[rows.cur], half, to_dev(rf), g.challenge_mode == 0 ? 1 : 0, rows.buf[nxt]);
+            k_sm_bind_hi<<<(unsigned)gb, RA_THREADS, 0, rt().stream>>>(rows.buf[rows.cur], half, to_dev(rf), rt().challenge_mode == 0 ? 1 : 0, rows.buf[nxt]);
             rows.stride[nxt] = half; rows.cur = nxt; rows.len = half;
             round_next++;
             return ATLAS_OK;
@@ -222,37 +222,37 @@ struct Softmax : atlas_instance {
     }
     int enqueue(size_t round, const atlas::RoundIo& io, bool bind_prev, atlas_mail_ref& mail) override {
         if (round >= rounds() || (round > 0) != bind_prev) return fail(ATLAS_ESTATE, "softmax: enqueue out of order");
-        const ChanIo cio{io, g.challenge_mode};
-        const int hi = g.challenge_mode == 0 ? 1 : 0;
+        const ChanIo cio{io, rt().challenge_mode};
+        const int hi = rt().challenge_mode == 0 ? 1 : 0;
         const size_t len = T0() >> round, half = len / 2, K = (size_t)1 << log_K;
         Fr* cur = rows.buf[round & 1];
         if (bind_prev) {
             const Fr* prev = rows.buf[(round - 1) & 1];
             size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096; if (gb < 1) gb = 1;
-            if (kind == SM_SUM_AXIS) k_sm_bind_hi_ch<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>(prev, len, cio, hi, cur);
-            else k_ra_bind_ch<<<dim3((unsigned)gb, (unsigned)rows.d), RA_THREADS, 0, g.stream>>>(prev, T0() >> (round - 1), cur, len, len, cio, hi);
+            if (kind == SM_SUM_AXIS) k_sm_bind_hi_ch<<<(unsigned)gb, RA_THREADS, 0, rt().stream>>>(prev, len, cio, hi, cur);
+            else k_ra_bind_ch<<<dim3((unsigned)gb, (unsigned)rows.d), RA_THREADS, 0, rt().stream>>>(prev, T0() >> (round - 1), cur, len, len, cio, hi);
             if (kind == SM_RECIP_MULT && round - 1 >= log_N) {      // inv_sum binds with the phase-2 challenges
                 const size_t p = round - 1 - log_N, ilen = K >> (p + 1);
                 size_t gi = (ilen + RA_THREADS - 1) / RA_THREADS; if (gi < 1) gi = 1;
-                k_ra_bind_ch<<<dim3((unsigned)gi, 1u), RA_THREADS, 0, g.stream>>>(inv.buf[p & 1], K >> p, inv.buf[(p + 1) & 1], ilen ? ilen : 1, ilen, cio, hi);
+                k_ra_bind_ch<<<dim3((unsigned)gi, 1u), RA_THREADS, 0, rt().stream>>>(inv.buf[p & 1], K >> p, inv.buf[(p + 1) & 1], ilen ? ilen : 1, ilen, cio, hi);
             }
         }
         size_t blocks = (half + RA_THREADS - 1) / RA_THREADS; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
         const int ns = n_sums(round);
         const MailTail tail{io, rows.d_counter, (uint32_t)blocks, (uint32_t)ns, rows.tg()};
         const Fr* a = cur; const Fr* b = a + len;                   // (d = 2: row 1 at the current stride)
-        if (kind == SM_SUM_AXIS) k_sm_sum_half<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, half, rows.partials, tail);
+        if (kind == SM_SUM_AXIS) k_sm_sum_half<<<(unsigned)blocks, RA_THREADS, 0, rt().stream>>>(a, half, rows.partials, tail);
         else if (round < log_N) {
             const uint32_t shift = (uint32_t)(log_N - (round + 1));
-            if (kind == SM_EXP_SUM) k_sm_expsum_p1<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, d_eq_k, shift, half, rows.partials, tail);
-            else if (kind == SM_MAX_INDICATOR) k_sm_max_p1<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, b, d_eq_k, shift, half, rows.partials, tail);
-            else { size_t ot, it; gs.st.tops_after(round, ot, it); k_sm_recip_p1<<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, inv.buf[0], shift, gs.view_at(ot, it), half, rows.partials, tail); }
+            if (kind == SM_EXP_SUM) k_sm_expsum_p1<<<(unsigned)blocks, RA_THREADS, 0, rt().stream>>>(a, d_eq_k, shift, half, rows.partials, tail);
+            else if (kind == SM_MAX_INDICATOR) k_sm_max_p1<<<(unsigned)blocks, RA_THREADS, 0, rt().stream>>>(a, b, d_eq_k, shift, half, rows.partials, tail);
+            else { size_t ot, it; gs.st.tops_after(round, ot, it); k_sm_recip_p1<<<(unsigned)blocks, RA_THREADS, 0, rt().stream>>>(a, inv.buf[0], shift, gs.view_at(ot, it), half, rows.partials, tail); }
         } else {
             size_t ot, it;
             gs.st.tops_after(kind == SM_RECIP_MULT ? round : round - log_N, ot, it);
             const SplitEqView E = gs.view_at(ot, it);
-            if (kind == SM_EXP_SUM) k_sm_p2<1><<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, nullptr, E, half, rows.partials, tail);
-            else k_sm_p2<2><<<(unsigned)blocks, RA_THREADS, 0, g.stream>>>(a, kind == SM_RECIP_MULT ? inv.buf[(round - log_N) & 1] : b, E, half, rows.partials, tail);
+            if (kind == SM_EXP_SUM) k_sm_p2<1><<<(unsigned)blocks, RA_THREADS, 0, rt().stream>>>(a, nullptr, E, half, rows.partials, tail);
+            else k_sm_p2<2><<<(unsigned)blocks, RA_THREADS, 0, rt().stream>>>(a, kind == SM_RECIP_MULT ? inv.buf[(round - log_N) & 1] : b, E, half, rows.partials, tail);
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(ATLAS_ENODEV, "softmax: launch", e);
@@ -271,7 +271,7 @@ struct Softmax : atlas_instance {
     }
     int host_ingest(const atlas_u128_t& r, size_t round) override {
         if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "softmax: round out of order");
-        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, g.challenge_mode);
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode);
         if (kind == SM_RECIP_MULT) gs.st.bind(rf);
         else if (kind != SM_SUM_AXIS && round >= log_N) gs.st.bind(rf);
         rows.cur = (int)((round + 1) & 1); rows.len = T0() >> (round + 1); rows.stride[rows.cur] = rows.len;
@@ -282,7 +282,7 @@ struct Softmax : atlas_instance {
     int enqueue_finals(const atlas::RoundIo& io, atlas_mail_ref& mail) override {
         const size_t n = rounds();
         const Fr* iv = kind == SM_RECIP_MULT ? inv.buf[(log_K - 1) & 1] : nullptr;
-        k_sm_finals_ch<<<1, 64, 0, g.stream>>>(rows.buf[(n - 1) & 1], T0() >> (n - 1), (uint32_t)rows.d, iv, ChanIo{io, g.challenge_mode}, g.challenge_mode == 0 ? 1 : 0);
+        k_sm_finals_ch<<<1, 64, 0, rt().stream>>>(rows.buf[(n - 1) & 1], T0() >> (n - 1), (uint32_t)rows.d, iv, ChanIo{io, rt().challenge_mode}, rt().challenge_mode == 0 ? 1 : 0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(ATLAS_ENODEV, "softmax: launch", e);
         mail.base = io.mail; mail.blocks = 1; mail.n_vals = (int)rows.d + (iv ? 1 : 0); mail.radix = 32; mail.shl = 0;
@@ -297,7 +297,7 @@ struct Softmax : atlas_instance {
     int finals(std::vector<H::Fr>& out) override {
         if (round_next != rounds()) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
         if (have_finals) { out = mailed_finals; return ATLAS_OK; }
-        std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
         int rc = rows.finals(out);
         if (rc || kind != SM_RECIP_MULT) return rc;
         std::vector<H::Fr> o2;
@@ -309,8 +309,8 @@ struct Softmax : atlas_instance {
 
 int load_row(atlas_poly_t p, Fr* dst, size_t n) {
     size_t gb = (n + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
-    if (p->is_i32) { k_sm_from_i32<<<(unsigned)gb, RA_THREADS, 0, g.stream>>>((const int32_t*)p->d, dst, n); return ATLAS_OK; }
-    HIP_TRY(hipMemcpyAsync(dst, p->d, n * sizeof(Fr), hipMemcpyDeviceToDevice, g.stream));
+    if (p->is_i32) { k_sm_from_i32<<<(unsigned)gb, RA_THREADS, 0, rt().stream>>>((const int32_t*)p->d, dst, n); return ATLAS_OK; }
+    HIP_TRY(hipMemcpyAsync(dst, p->d, n * sizeof(Fr), hipMemcpyDeviceToDevice, rt().stream));
     return ATLAS_OK;
 }
 
@@ -331,7 +331,7 @@ int atlas_softmax_instance_new(int kind, atlas_poly_t a, atlas_poly_t b, size_t 
     if (a->len != T) return fail(ATLAS_EINVAL, "softmax_instance_new: operand length != 2^(log_K + log_N)");
     if ((kind == SM_MAX_INDICATOR && (!b || b->len != T)) || (kind == SM_RECIP_MULT && (!b || b->len != K)) || (kind == SM_EXP_SUM && b))
         return fail(ATLAS_EINVAL, "softmax_instance_new: second operand: e of 2^(log_K + log_N) for MaxIndicator, inv_sum of 2^log_K for RecipMult, none for ExpSum");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     Softmax* P = new Softmax();
     P->kind = kind; P->log_K = log_K; P->log_N = log_N;
     int rc = P->rows.alloc(kind == SM_MAX_INDICATOR ? 2 : 1, T, 3);
@@ -341,13 +341,13 @@ int atlas_softmax_instance_new(int kind, atlas_poly_t a, atlas_poly_t b, size_t 
     if (!rc && (kind == SM_EXP_SUM || kind == SM_MAX_INDICATOR)) {
         const std::vector<H::Fr> ek = H::eq_evals(reinterpret_cast<const H::Fr*>(r), log_K);
         hipError_t e = hipMalloc(&P->d_eq_k, K * sizeof(Fr));
-        if (e == hipSuccess) e = hipMemcpyAsync(P->d_eq_k, ek.data(), K * sizeof(Fr), hipMemcpyHostToDevice, g.stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(P->d_eq_k, ek.data(), K * sizeof(Fr), hipMemcpyHostToDevice, rt().stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(rt().stream);
         if (e != hipSuccess) rc = fail(ATLAS_ENOMEM, "softmax_instance_new: eq table", e);
         if (!rc && log_K) rc = P->gs.init(reinterpret_cast<const H::Fr*>(r), log_K);     // used from round log_N on (ONE row: never)
     }
     if (!rc && kind == SM_RECIP_MULT) rc = P->gs.init(reinterpret_cast<const H::Fr*>(r), log_K + log_N);
-    if (!rc) { hipError_t e = hipStreamSynchronize(g.stream); if (e != hipSuccess) rc = fail(ATLAS_ENODEV, "softmax_instance_new", e); }
+    if (!rc) { hipError_t e = hipStreamSynchronize(rt().stream); if (e != hipSuccess) rc = fail(ATLAS_ENODEV, "softmax_instance_new", e); }
     if (rc) { delete P; return rc; }
     *out = P;
     return ATLAS_OK;

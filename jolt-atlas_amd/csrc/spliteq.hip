@@ -19,7 +19,7 @@
 using namespace atlas;
 namespace H = atlas_host;
 using atlas_rt::fail;
-using atlas_rt::g;
+using atlas_rt::rt;
 using atlas_rt::MAX_ROUNDS;
 
 struct atlas_mul_prover {
@@ -106,7 +106,7 @@ inline bool eq_full_on() { static const bool off = getenv("ATLAS_NO_EQ_FULL") !=
 inline void launch_eq_full(const H::Fr* r, size_t n, const H::Fr* scaling, Fr* ev) {
     EqPointArgs a;
     if (n) std::memcpy(a.v, r, n * sizeof(Fr));
-    k_eq_full<<<n > 12 ? 1u << (n - 12) : 1u, 1024, 0, g.stream>>>(ev, a, (uint32_t)n, to_dev(scaling ? *scaling : H::one()));
+    k_eq_full<<<n > 12 ? 1u << (n - 12) : 1u, 1024, 0, rt().stream>>>(ev, a, (uint32_t)n, to_dev(scaling ? *scaling : H::one()));
 }
 
 // EqPolynomial::evals into a fresh device buffer (2^n Fr)
@@ -129,12 +129,12 @@ int eq_evals_device(const H::Fr* r, size_t n, const H::Fr* scaling, Fr** out) {
     if (n) {
         EqPointArgs a;
         std::memcpy(a.v, r, n * sizeof(Fr));
-        k_store_point<<<1, 64, 0, g.stream>>>(a, (uint32_t)n, d_r);
+        k_store_point<<<1, 64, 0, rt().stream>>>(a, (uint32_t)n, d_r);
     }
     const uint32_t head = n < 12 ? (uint32_t)n : 12u;
-    k_eq_head<<<1, 1024, 0, g.stream>>>(ev, d_r, (uint32_t)n, head, to_dev(scaling ? *scaling : H::one()));
+    k_eq_head<<<1, 1024, 0, rt().stream>>>(ev, d_r, (uint32_t)n, head, to_dev(scaling ? *scaling : H::one()));
     for (size_t p = head; p < n; p++)
-        k_eq_double<<<grid_for((size_t)1 << p), SC_THREADS, 0, g.stream>>>(ev, (size_t)1 << p, to_dev(r[n - 1 - p]));
+        k_eq_double<<<grid_for((size_t)1 << p), SC_THREADS, 0, rt().stream>>>(ev, (size_t)1 << p, to_dev(r[n - 1 - p]));
     hipError_t le = hipGetLastError();
     hipFree(d_r);                                 // (pool: reused in stream order)
     if (le != hipSuccess) { hipFree(ev); return fail(ATLAS_ENODEV, "eq_evals", le); }
@@ -144,7 +144,7 @@ int eq_evals_device(const H::Fr* r, size_t n, const H::Fr* scaling, Fr** out) {
 
 }  // namespace
 
-// EqPolynomial::evals into a caller-provided device buffer of 2^n Fr (library stream; the caller holds g.mu): opening.hip's pool
+// EqPolynomial::evals into a caller-provided device buffer of 2^n Fr (library stream; the caller holds rt().mu): opening.hip's pool
 int atlas_rt_eq_evals_into(const H::Fr* r, size_t n, Fr* ev) {
     if (n <= 16 && eq_full_on()) {
         launch_eq_full(r, n, nullptr, ev);
@@ -156,12 +156,12 @@ int atlas_rt_eq_evals_into(const H::Fr* r, size_t n, Fr* ev) {
     if (n) {
         EqPointArgs a;
         std::memcpy(a.v, r, n * sizeof(Fr));
-        k_store_point<<<1, 64, 0, g.stream>>>(a, (uint32_t)n, d_r);
+        k_store_point<<<1, 64, 0, rt().stream>>>(a, (uint32_t)n, d_r);
     }
     const uint32_t head = n < 12 ? (uint32_t)n : 12u;
-    k_eq_head<<<1, 1024, 0, g.stream>>>(ev, d_r, (uint32_t)n, head, to_dev(H::one()));
+    k_eq_head<<<1, 1024, 0, rt().stream>>>(ev, d_r, (uint32_t)n, head, to_dev(H::one()));
     for (size_t p = head; p < n; p++)
-        k_eq_double<<<grid_for((size_t)1 << p), SC_THREADS, 0, g.stream>>>(ev, (size_t)1 << p, to_dev(r[n - 1 - p]));
+        k_eq_double<<<grid_for((size_t)1 << p), SC_THREADS, 0, rt().stream>>>(ev, (size_t)1 << p, to_dev(r[n - 1 - p]));
     hipError_t le = hipGetLastError();
     hipFree(d_r);                                 // (pool: reused in stream order)
     return le == hipSuccess ? ATLAS_OK : fail(ATLAS_ENODEV, "eq_evals_into", le);
@@ -173,7 +173,7 @@ int atlas_eq_evals(const atlas_fr_t* r, size_t n, const atlas_fr_t* scaling, atl
     PROF("atlas_eq_evals");
     NEED_INIT();
     if ((!r && n) || !out || n > 30) return fail(ATLAS_EINVAL, "eq_evals");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     Fr* ev = nullptr;
     int rc = eq_evals_device(reinterpret_cast<const H::Fr*>(r), n, reinterpret_cast<const H::Fr*>(scaling), &ev);
     if (rc) return rc;
@@ -189,7 +189,7 @@ int atlas_poly_evaluate_many(const atlas_poly_t* polys, size_t count, const atla
     if (!polys || !count || count > 64 || (!r && n) || !out) return fail(ATLAS_EINVAL, "poly_evaluate_many");
     for (size_t i = 0; i < count; ++i)
         if (!polys[i] || polys[i]->len != ((size_t)1 << n)) return fail(ATLAS_EINVAL, "poly_evaluate: point length != num_vars");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     // DensePolynomial::evaluate: r = (r2 | r1), eq_one = evals(r2) outer, eq_two = evals(r1) inner.
     // The two tables are shared by every polynomial of the call; each result goes straight into
     // the pinned staging area, so the whole call costs one synchronisation.
@@ -205,15 +205,15 @@ int atlas_poly_evaluate_many(const atlas_poly_t* polys, size_t count, const atla
     for (size_t i = 0; i < count; ++i) {
         const atlas_poly_t p = polys[i];
         if (p->is_i32)
-            k_mle_evaluate<int32_t><<<grid, SC_THREADS, 0, g.stream>>>((const int32_t*)p->d, p->len, eq1, eq2, (uint32_t)(n - m), g.d_partials, K);
+            k_mle_evaluate<int32_t><<<grid, SC_THREADS, 0, rt().stream>>>((const int32_t*)p->d, p->len, eq1, eq2, (uint32_t)(n - m), rt().d_partials, K);
         else
-            k_mle_evaluate<Fr><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)p->d, p->len, eq1, eq2, (uint32_t)(n - m), g.d_partials, K);
-        k_reduce1<<<1, SC_THREADS, 0, g.stream>>>(g.d_partials, grid, (Fr*)g.h_pinned + i, 1);
+            k_mle_evaluate<Fr><<<grid, SC_THREADS, 0, rt().stream>>>((const Fr*)p->d, p->len, eq1, eq2, (uint32_t)(n - m), rt().d_partials, K);
+        k_reduce1<<<1, SC_THREADS, 0, rt().stream>>>(rt().d_partials, grid, (Fr*)rt().h_pinned + i, 1);
     }
-    hipError_t e = hipStreamSynchronize(g.stream);
+    hipError_t e = hipStreamSynchronize(rt().stream);
     hipFree(eq1); hipFree(eq2);
     if (e != hipSuccess) return fail(ATLAS_ENODEV, "poly_evaluate", e);
-    std::memcpy(out, g.h_pinned, count * sizeof(Fr));
+    std::memcpy(out, rt().h_pinned, count * sizeof(Fr));
     return ATLAS_OK;
 }
 
@@ -249,12 +249,12 @@ int atlas_rt_evaluate_with_eq(const atlas_poly_t* polys, size_t count, atlas_pol
         if (!polys[q] || polys[q]->len != eq_full->len) return fail(ATLAS_EINVAL, "evaluate_with_eq: length != the eq table's");
         A.p[q] = polys[q]->d; A.is_i32[q] = polys[q]->is_i32 ? 1u : 0u;
     }
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     const int grid = grid_for(eq_full->len);
-    k_eval_with_eq<<<grid, SC_THREADS, 0, g.stream>>>(A, (const Fr*)eq_full->d, eq_full->len, g.d_partials, make_consts());
-    k_reduce1<<<1, SC_THREADS, 0, g.stream>>>(g.d_partials, grid, (Fr*)g.h_pinned, 3);
-    HIP_TRY(hipStreamSynchronize(g.stream));
-    std::memcpy(out, g.h_pinned, count * sizeof(Fr));
+    k_eval_with_eq<<<grid, SC_THREADS, 0, rt().stream>>>(A, (const Fr*)eq_full->d, eq_full->len, rt().d_partials, make_consts());
+    k_reduce1<<<1, SC_THREADS, 0, rt().stream>>>(rt().d_partials, grid, (Fr*)rt().h_pinned, 3);
+    HIP_TRY(hipStreamSynchronize(rt().stream));
+    std::memcpy(out, rt().h_pinned, count * sizeof(Fr));
     return ATLAS_OK;
 }
 
@@ -274,7 +274,7 @@ int atlas_mul_prover_new(atlas_poly_t left, atlas_poly_t right, const atlas_fr_t
         return fail(ATLAS_EINVAL, "mul_prover_new: operand length must be 2^n, n >= 1");
     if (left->is_i32 != right->is_i32) return fail(ATLAS_EINVAL, "mul_prover_new: mixed operand types");
     if (n / 2 > 12 || n - 1 - n / 2 > 12) return fail(ATLAS_EINVAL, "mul_prover_new: n > 25 not supported");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     atlas_mul_prover* P = new atlas_mul_prover();
     P->left = left; P->right = right; P->n = n; P->m = n / 2;
     P->w.assign(reinterpret_cast<const H::Fr*>(w), reinterpret_cast<const H::Fr*>(w) + n);
@@ -283,11 +283,11 @@ int atlas_mul_prover_new(atlas_poly_t left, atlas_poly_t right, const atlas_fr_t
     HIP_TRY(hipMalloc(&P->d_w, n * sizeof(Fr)));
     HIP_TRY(hipMalloc(&P->d_eout, (((size_t)2 << k_out)) * sizeof(Fr)));
     HIP_TRY(hipMalloc(&P->d_ein, (((size_t)2 << k_in)) * sizeof(Fr)));
-    HIP_TRY(hipMemcpyAsync(P->d_w, w, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(P->d_w, w, n * sizeof(Fr), hipMemcpyHostToDevice, rt().stream));
     // GruenSplitEqPolynomial::new, LowToHigh: w = [w_out | w_in | w_last] (split_eq_poly.rs:97-121)
-    k_eq_cached<<<1, 1024, 0, g.stream>>>(P->d_eout, P->d_w, (uint32_t)k_out);
-    k_eq_cached<<<1, 1024, 0, g.stream>>>(P->d_ein, P->d_w + P->m, (uint32_t)k_in);
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    k_eq_cached<<<1, 1024, 0, rt().stream>>>(P->d_eout, P->d_w, (uint32_t)k_out);
+    k_eq_cached<<<1, 1024, 0, rt().stream>>>(P->d_ein, P->d_w + P->m, (uint32_t)k_in);
+    HIP_TRY(hipStreamSynchronize(rt().stream));
     *out = P;
     return ATLAS_OK;
 }
@@ -318,18 +318,18 @@ int atlas_mul_input_claim(atlas_mul_prover_t P, atlas_fr_t* out) {
     NEED_INIT();
     if (!P || !out) return fail(ATLAS_EINVAL, "mul_input_claim");
     if (P->consumed || P->left->len != ((size_t)1 << P->n)) return fail(ATLAS_ESTATE, "mul_input_claim: instance already bound");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     // s(0) + s(1) of round 0: eq0*q0 + eq1*q1 with the round-0 sums
     const ScConsts K = make_consts();
     const size_t groups = P->left->len / 2;
     const int grid = grid_for(groups);
     SplitEqView E = view_for_round(P, 0);
-    if (P->left->is_i32) k_mul_eval<int32_t><<<grid, SC_THREADS, 0, g.stream>>>((const int32_t*)P->left->d, (const int32_t*)P->right->d, E, groups, g.d_partials, K);
-    else k_mul_eval<Fr><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, E, groups, g.d_partials, K);
-    k_reduce1<<<1, SC_THREADS, 0, g.stream>>>(g.d_partials, grid, g.d_finals + 3, 3);
-    HIP_TRY(hipMemcpyAsync(g.h_pinned, g.d_finals + 3, 3 * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
-    H::Fr s[3]; std::memcpy(s, g.h_pinned, sizeof s);
+    if (P->left->is_i32) k_mul_eval<int32_t><<<grid, SC_THREADS, 0, rt().stream>>>((const int32_t*)P->left->d, (const int32_t*)P->right->d, E, groups, rt().d_partials, K);
+    else k_mul_eval<Fr><<<grid, SC_THREADS, 0, rt().stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, E, groups, rt().d_partials, K);
+    k_reduce1<<<1, SC_THREADS, 0, rt().stream>>>(rt().d_partials, grid, rt().d_finals + 3, 3);
+    HIP_TRY(hipMemcpyAsync(rt().h_pinned, rt().d_finals + 3, 3 * sizeof(Fr), hipMemcpyDeviceToHost, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
+    H::Fr s[3]; std::memcpy(s, rt().h_pinned, sizeof s);
     const H::Fr wl = P->w[P->n - 1];
     H::Fr claim = H::add(H::mul(H::sub(H::one(), wl), s[0]), H::mul(wl, s[1]));
     std::memcpy(out, &claim, 32);
@@ -345,20 +345,20 @@ int atlas_sumcheck_prove_mul(atlas_mul_prover_t P, const atlas_fr_t* input_claim
     if (!P || !input_claim || !transcript || !compressed_polys || !challenges || !final_claims)
         return fail(ATLAS_EINVAL, "sumcheck_prove_mul: null argument");
     if (P->consumed || P->left->len != ((size_t)1 << P->n)) return fail(ATLAS_ESTATE, "sumcheck_prove_mul: prover already consumed");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     const ScConsts K = make_consts();
     const size_t n = P->n;
-    const int mode = g.challenge_mode;
+    const int mode = rt().challenge_mode;
     const int hi_only = mode == 0;
 
-    MulCtx* d_cx = reinterpret_cast<MulCtx*>(g.d_ctx);          // same scratch block (sizeof(MulCtx) <= sizeof(ScCtx))
+    MulCtx* d_cx = reinterpret_cast<MulCtx*>(rt().d_ctx);          // same scratch block (sizeof(MulCtx) <= sizeof(ScCtx))
     static_assert(sizeof(MulCtx) <= sizeof(ScCtx), "control block size");
-    MulCtx* hcx = reinterpret_cast<MulCtx*>(g.h_pinned);
+    MulCtx* hcx = reinterpret_cast<MulCtx*>(rt().h_pinned);
     std::memset(hcx, 0, sizeof(MulCtx));
     std::memcpy(&hcx->tr, transcript, sizeof(DevTranscript));
     std::memcpy(&hcx->claim, input_claim, sizeof(Fr));
     H::Fr one = H::one(); std::memcpy(&hcx->scalar, &one, sizeof(Fr));
-    HIP_TRY(hipMemcpyAsync(d_cx, hcx, sizeof(MulCtx), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(d_cx, hcx, sizeof(MulCtx), hipMemcpyHostToDevice, rt().stream));
 
     size_t len = P->left->len;
     size_t rounds_done = 0;
@@ -375,9 +375,9 @@ int atlas_sumcheck_prove_mul(atlas_mul_prover_t P, const atlas_fr_t* input_claim
             const size_t groups = len / 2;
             const int grid = grid_for(groups);
             SplitEqView E = view_for_round(P, 0);
-            if (cur_i32) k_mul_eval<int32_t><<<grid, SC_THREADS, 0, g.stream>>>((const int32_t*)curL, (const int32_t*)curR, E, groups, g.d_partials, K);
-            else k_mul_eval<Fr><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)curL, (const Fr*)curR, E, groups, g.d_partials, K);
-            k_mul_fs_round<<<1, SC_THREADS, 0, g.stream>>>(d_cx, g.d_partials, grid, P->d_w + (n - 1), g.d_proof, g.d_chal, K, 1, mode);
+            if (cur_i32) k_mul_eval<int32_t><<<grid, SC_THREADS, 0, rt().stream>>>((const int32_t*)curL, (const int32_t*)curR, E, groups, rt().d_partials, K);
+            else k_mul_eval<Fr><<<grid, SC_THREADS, 0, rt().stream>>>((const Fr*)curL, (const Fr*)curR, E, groups, rt().d_partials, K);
+            k_mul_fs_round<<<1, SC_THREADS, 0, rt().stream>>>(d_cx, rt().d_partials, grid, P->d_w + (n - 1), rt().d_proof, rt().d_chal, K, 1, mode);
             rounds_done = 1; pending = 1;
         }
         while (len > ((size_t)1 << SC_TAIL_LOG)) {
@@ -386,13 +386,13 @@ int atlas_sumcheck_prove_mul(atlas_mul_prover_t P, const atlas_fr_t* input_claim
             SplitEqView E = view_for_round(P, rounds_done);
             Fr* dL = pp[which][0]; Fr* dR = pp[which][1];
             if (cur_i32)
-                k_mul_bind_eval<int32_t><<<grid, SC_THREADS, 0, g.stream>>>((const int32_t*)curL, (const int32_t*)curR, dL, dR, E, groups_new, d_cx, g.d_partials, K, hi_only);
+                k_mul_bind_eval<int32_t><<<grid, SC_THREADS, 0, rt().stream>>>((const int32_t*)curL, (const int32_t*)curR, dL, dR, E, groups_new, d_cx, rt().d_partials, K, hi_only);
             else
-                k_mul_bind_eval<Fr><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)curL, (const Fr*)curR, dL, dR, E, groups_new, d_cx, g.d_partials, K, hi_only);
+                k_mul_bind_eval<Fr><<<grid, SC_THREADS, 0, rt().stream>>>((const Fr*)curL, (const Fr*)curR, dL, dR, E, groups_new, d_cx, rt().d_partials, K, hi_only);
             curL = dL; curR = dR; cur_i32 = false; which ^= 1;
             len /= 2;
-            k_mul_fs_round<<<1, SC_THREADS, 0, g.stream>>>(d_cx, g.d_partials, grid, P->d_w + (n - 1 - rounds_done),
-                                                        g.d_proof + rounds_done * 3, g.d_chal + 2 * rounds_done, K, 0, mode);
+            k_mul_fs_round<<<1, SC_THREADS, 0, rt().stream>>>(d_cx, rt().d_partials, grid, P->d_w + (n - 1 - rounds_done),
+                                                        rt().d_proof + rounds_done * 3, rt().d_chal + 2 * rounds_done, K, 0, mode);
             rounds_done += 1;
         }
     }
@@ -402,16 +402,16 @@ int atlas_sumcheck_prove_mul(atlas_mul_prover_t P, const atlas_fr_t* input_claim
         A.e_out_tabs = P->d_eout; A.e_in_tabs = P->d_ein; A.w = P->d_w;
         A.n = (uint32_t)n; A.m = (uint32_t)P->m; A.round0 = (uint32_t)rounds_done;
         A.first = rounds_done == 0 ? 1 : 0; A.pending_bind = pending; A.challenge_mode = mode;
-        k_mul_tail<<<1, SC_THREADS, 3 * (sizeof(Fr) << SC_TAIL_LOG), g.stream>>>(A, d_cx, g.d_proof, g.d_chal, g.d_finals, K);
+        k_mul_tail<<<1, SC_THREADS, 3 * (sizeof(Fr) << SC_TAIL_LOG), rt().stream>>>(A, d_cx, rt().d_proof, rt().d_chal, rt().d_finals, K);
     }
     hipError_t le = hipGetLastError();
-    uint8_t* hp = reinterpret_cast<uint8_t*>(g.h_pinned);
+    uint8_t* hp = reinterpret_cast<uint8_t*>(rt().h_pinned);
     const size_t proof_bytes = n * 3 * sizeof(Fr), chal_bytes = n * 2 * sizeof(uint64_t);
-    if (le == hipSuccess) le = hipMemcpyAsync(hp, g.d_proof, proof_bytes, hipMemcpyDeviceToHost, g.stream);
-    if (le == hipSuccess) le = hipMemcpyAsync(hp + 8192, g.d_chal, chal_bytes, hipMemcpyDeviceToHost, g.stream);
-    if (le == hipSuccess) le = hipMemcpyAsync(hp + 12288, g.d_finals, 3 * sizeof(Fr), hipMemcpyDeviceToHost, g.stream);
-    if (le == hipSuccess) le = hipMemcpyAsync(hp + 16384, d_cx, sizeof(MulCtx), hipMemcpyDeviceToHost, g.stream);
-    if (le == hipSuccess) le = hipStreamSynchronize(g.stream);
+    if (le == hipSuccess) le = hipMemcpyAsync(hp, rt().d_proof, proof_bytes, hipMemcpyDeviceToHost, rt().stream);
+    if (le == hipSuccess) le = hipMemcpyAsync(hp + 8192, rt().d_chal, chal_bytes, hipMemcpyDeviceToHost, rt().stream);
+    if (le == hipSuccess) le = hipMemcpyAsync(hp + 12288, rt().d_finals, 3 * sizeof(Fr), hipMemcpyDeviceToHost, rt().stream);
+    if (le == hipSuccess) le = hipMemcpyAsync(hp + 16384, d_cx, sizeof(MulCtx), hipMemcpyDeviceToHost, rt().stream);
+    if (le == hipSuccess) le = hipStreamSynchronize(rt().stream);
     for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) if (pp[a][b]) hipFree(pp[a][b]);
     if (le != hipSuccess) return fail(ATLAS_ENODEV, "sumcheck_prove_mul", le);
     std::memcpy(compressed_polys, hp, proof_bytes);
@@ -429,17 +429,17 @@ int atlas_mul_compute_message(atlas_mul_prover_t P, size_t round, const atlas_fr
     NEED_INIT();
     if (!P || !previous_claim || !coeffs_out || !n_coeffs) return fail(ATLAS_EINVAL, "mul_compute_message");
     if (P->consumed || round >= P->n || P->left->len != ((size_t)1 << (P->n - round))) return fail(ATLAS_ESTATE, "mul_compute_message: round out of order");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     const ScConsts K = make_consts();
     const size_t groups = P->left->len / 2;
     const int grid = grid_for(groups);
     SplitEqView E = view_for_round(P, round);
-    if (P->left->is_i32) k_mul_eval<int32_t><<<grid, SC_THREADS, 0, g.stream>>>((const int32_t*)P->left->d, (const int32_t*)P->right->d, E, groups, g.d_partials, K);
-    else k_mul_eval<Fr><<<grid, SC_THREADS, 0, g.stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, E, groups, g.d_partials, K);
-    k_reduce1<<<1, SC_THREADS, 0, g.stream>>>(g.d_partials, grid, g.d_finals + 3, 3);
-    HIP_TRY(hipMemcpyAsync(g.h_pinned, g.d_finals + 3, 3 * sizeof(Fr), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
-    H::Fr s[3]; std::memcpy(s, g.h_pinned, sizeof s);
+    if (P->left->is_i32) k_mul_eval<int32_t><<<grid, SC_THREADS, 0, rt().stream>>>((const int32_t*)P->left->d, (const int32_t*)P->right->d, E, groups, rt().d_partials, K);
+    else k_mul_eval<Fr><<<grid, SC_THREADS, 0, rt().stream>>>((const Fr*)P->left->d, (const Fr*)P->right->d, E, groups, rt().d_partials, K);
+    k_reduce1<<<1, SC_THREADS, 0, rt().stream>>>(rt().d_partials, grid, rt().d_finals + 3, 3);
+    HIP_TRY(hipMemcpyAsync(rt().h_pinned, rt().d_finals + 3, 3 * sizeof(Fr), hipMemcpyDeviceToHost, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
+    H::Fr s[3]; std::memcpy(s, rt().h_pinned, sizeof s);
     // gruen_poly_deg_3 (split_eq_poly.rs:379-429) with q(1) taken from the third running sum
     const H::Fr w_cur = P->w[P->n - 1 - round];
     const H::Fr eq1 = H::mul(P->scalar, w_cur), eq0 = H::sub(P->scalar, eq1), eqm = H::sub(eq1, eq0);
@@ -463,7 +463,7 @@ int atlas_mul_ingest_challenge(atlas_mul_prover_t P, const atlas_u128_t* r_j, si
     if (!rc) rc = atlas_poly_bind(P->right, r_j, ATLAS_LOW_TO_HIGH);
     if (rc) return rc;
     // GruenSplitEqPolynomial::bind: current_scalar *= 1 - w - r + 2 w r (split_eq_poly.rs:336-339)
-    const H::Fr r = H::challenge_to_fr(r_j->lo, r_j->hi, g.challenge_mode);
+    const H::Fr r = H::challenge_to_fr(r_j->lo, r_j->hi, rt().challenge_mode);
     const H::Fr w_cur = P->w[P->n - 1 - round];
     const H::Fr wr = H::mul(w_cur, r);
     P->scalar = H::mul(P->scalar, H::add(H::add(H::sub(H::sub(H::one(), w_cur), r), wr), wr));

@@ -56,7 +56,7 @@ int atlas_sumcheck_proof_verify(const atlas_fr_t* compressed, size_t row_stride,
     for (size_t i = 0; i < n_rounds; i++) {
         if (n_coeffs[i] > row_stride) return fail(ATLAS_EINVAL, "sumcheck_proof_verify: n_coeffs beyond row_stride");
         int rc = verify_round(T, reinterpret_cast<const H::Fr*>(compressed) + i * row_stride, n_coeffs[i], degree_bound, e, &challenges[i],
-                              atlas_rt::g.challenge_mode);
+                              atlas_rt::rt().challenge_mode);
         if (rc) return rc;
     }
     std::memcpy(final_claim, &e, 32);
@@ -86,7 +86,7 @@ int atlas_batched_sumcheck_verify(const atlas_fr_t* compressed, size_t row_strid
     }
     for (size_t i = 0; i < max_rounds; i++) {                                                    // proof.verify :231-232
         if (n_coeffs[i] > row_stride) return fail(ATLAS_EINVAL, "batched_sumcheck_verify: n_coeffs beyond row_stride");
-        int rc = verify_round(T, reinterpret_cast<const H::Fr*>(compressed) + i * row_stride, n_coeffs[i], md, e, &challenges[i], atlas_rt::g.challenge_mode);
+        int rc = verify_round(T, reinterpret_cast<const H::Fr*>(compressed) + i * row_stride, n_coeffs[i], md, e, &challenges[i], atlas_rt::rt().challenge_mode);
         if (rc) return rc;
     }
     std::memcpy(output_claim, &e, 32);
@@ -198,7 +198,7 @@ int atlas_hyperkzg_verify(const atlas_hyperkzg_vk_t* vk, const atlas_g1_affine_t
     H::Transcript& T = *reinterpret_cast<H::Transcript*>(transcript);
     const H::Fr* v = reinterpret_cast<const H::Fr*>(v_);
     const H::Fr y = *reinterpret_cast<const H::Fr*>(y_);
-    const int mode = atlas_rt::g.challenge_mode;
+    const int mode = atlas_rt::rt().challenge_mode;
     // verify_inner (:451-509)
     append_points(T, com, ell - 1);
     const H::Fr r = H::tr_challenge_scalar(T);

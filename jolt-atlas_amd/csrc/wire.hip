@@ -29,7 +29,7 @@
 using namespace atlas;
 namespace H = atlas_host;
 using atlas_rt::fail;
-using atlas_rt::g;
+using atlas_rt::rt;
 
 namespace {
 
@@ -288,23 +288,23 @@ int atlas_srs_load_file(const char* path, size_t max_points, atlas_srs_t* out) {
     const size_t got = std::fread(buf.data(), 1, buf.size(), f);
     std::fclose(f);
     if (got != buf.size()) return fail(ATLAS_EINVAL, "srs_load_file: truncated");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     atlas_srs* s = new atlas_srs();
     uint8_t* d_in = nullptr; uint32_t* d_bad = nullptr;
     hipError_t e = hipMalloc(&s->d, n * sizeof(G1Affine));
     if (e == hipSuccess) e = hipMalloc(&d_in, buf.size());
     if (e == hipSuccess) e = hipMalloc(&d_bad, 4);
-    if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, 4, g.stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_in, buf.data(), buf.size(), hipMemcpyHostToDevice, g.stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, 4, rt().stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, buf.data(), buf.size(), hipMemcpyHostToDevice, rt().stream);
     uint32_t bad = 0;
     if (e == hipSuccess) {
         FqExp ex;
         for (int k = 0; k < 4; k++) { ex.w[2 * k] = (uint32_t)FQ_SQRT_EXP[k]; ex.w[2 * k + 1] = (uint32_t)(FQ_SQRT_EXP[k] >> 32); }
         size_t gb = (n + 255) / 256; if (gb > 8192) gb = 8192;
-        k_g1_decompress<<<(unsigned)gb, 256, 0, g.stream>>>(d_in, n, ex, s->d, d_bad);
-        e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, g.stream);
+        k_g1_decompress<<<(unsigned)gb, 256, 0, rt().stream>>>(d_in, n, ex, s->d, d_bad);
+        e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, rt().stream);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(rt().stream);
     if (d_in) (void)hipFree(d_in);
     if (d_bad) (void)hipFree(d_bad);
     if (e != hipSuccess || bad) {
@@ -321,15 +321,15 @@ int atlas_srs_load_file(const char* path, size_t max_points, atlas_srs_t* out) {
 int atlas_srs_save_file(atlas_srs_t srs, const char* path) {
     NEED_INIT();
     if (!srs || !path) return fail(ATLAS_EINVAL, "srs_save_file: null argument");
-    std::lock_guard<atlas_rt::Mutex> lk(g.mu);
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     std::vector<uint8_t> buf(srs->len * 32);
     uint8_t* d_out = nullptr;
     hipError_t e = hipMalloc(&d_out, buf.size());
     if (e != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(srs_save_file)", e);
     size_t gb = (srs->len + 255) / 256; if (gb > 8192) gb = 8192;
-    k_g1_compress<<<(unsigned)gb, 256, 0, g.stream>>>(srs->d, srs->len, d_out);
-    e = hipMemcpyAsync(buf.data(), d_out, buf.size(), hipMemcpyDeviceToHost, g.stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    k_g1_compress<<<(unsigned)gb, 256, 0, rt().stream>>>(srs->d, srs->len, d_out);
+    e = hipMemcpyAsync(buf.data(), d_out, buf.size(), hipMemcpyDeviceToHost, rt().stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(rt().stream);
     (void)hipFree(d_out);
     if (e != hipSuccess) return fail(ATLAS_ENODEV, "srs_save_file", e);
     FILE* f = std::fopen(path, "wb");

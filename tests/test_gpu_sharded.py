@@ -270,3 +270,62 @@ def test_sharded_prove_graph(tmp_path, world, name):
     for r, (p, (o, e)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, e[-3000:]
         assert f"SHARDED_GRAPH_OK {r}" in o
+
+
+@pytest.mark.parametrize("world,name", [(2, "tiny2"), (2, "microgpt")])
+def test_sharded_prove_graph_one_process(tmp_path, world, name):
+    """One process, N devices (the reference is ONE Rust process: onnx_proof/mod.rs:153-156): `world` THREADS of one process, each with a
+    runtime of its own (atlas_init_thread: stream set, round channel, allocator, MSM workspace), its own graph + SRS handles, joined as the
+    ranks of a shard group; every rank's bytes and final transcript state equal the one-GPU proof's.  The threads share the test box's GPU
+    (device 0 each), as the processes of test_sharded_prove_graph do; run in a child process so that the test session's own runtime is not
+    involved."""
+    script = tmp_path / "t.py"
+    script.write_text(textwrap.dedent(f"""
+        import hashlib, json, os, sys, threading, traceback
+        sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, "tools"))
+        import numpy as np
+        import build_graphs as BG
+        import jolt_atlas_amd as A
+        from jolt_atlas_amd import sharded, graph as GG
+        from oracle import orc
+        world = {world}
+        gold = json.load(open(os.path.join({ROOT!r}, "tests", "golden", "graph_proofs.json")))
+        want = gold["graphs"][{name!r}]
+        nodes, outputs, inputs = {{"tiny2": lambda: BG.tiny(layers=2), "microgpt": BG.microgpt}}[{name!r}]()
+        nv = BG.max_vars(nodes)
+        tau = orc.random_fr(1, gold["tau_seed"])[0]
+        errors, done = [], []
+
+        def rank_thread(rank):
+            try:
+                A.init_thread(0)                                   # this thread's own runtime (on a node: device `rank`)
+                srs = A.SRS.generate(tau, 1 << nv)
+                G = GG.Graph(nodes, outputs)
+                grp = sharded.ShardGroup(sys.argv[1], world, rank)
+                for rep in range(2):
+                    proof, state, tm = G.prove(srs, inputs, group=grp)
+                    assert tm["n_committed"] == want["n_committed"]
+                    assert state.hex() == want["state"], "final transcript state differs from the one-GPU proof"
+                    assert hashlib.sha256(proof).hexdigest() == want["proof_sha256"], "proof bytes differ from the one-GPU proof"
+                if rank == 0:
+                    vk = A.HyperKZG.vk_from_trapdoor(tau, srs.download(0, 1)[0])
+                    V = GG.Graph(nodes, outputs)
+                    ok, vstate = V.verify(vk, inputs, G.node_output(outputs[0]), proof)
+                    assert ok and vstate == state
+                    V.free()
+                grp.close(); G.free(); srs.free()
+                A.shutdown_thread()
+                done.append(rank)
+            except Exception:
+                errors.append((rank, traceback.format_exc()))
+
+        ts = [threading.Thread(target=rank_thread, args=(r,)) for r in range(world)]
+        for t in ts: t.start()
+        for t in ts: t.join(600)
+        assert not errors, errors
+        assert sorted(done) == list(range(world)), done
+        print("ONE_PROCESS_OK")
+    """))
+    gname = f"/atlas_graph1p_{os.getpid()}_{world}_{name}"
+    p = subprocess.run([sys.executable, str(script), gname], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "ONE_PROCESS_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
