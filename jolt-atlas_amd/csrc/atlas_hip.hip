@@ -30,6 +30,7 @@ namespace H = atlas_host;
 namespace atlas_rt {
 Runtime g_default;
 thread_local Runtime* g_cur = nullptr;
+int g_thread_runtimes = 0;
 thread_local hipStream_t tl_lane_stream = nullptr;
 thread_local std::string t_err;       // atlas_last_error is per calling thread (commit is called from Rayon workers)
 int fail(int code, const char* what, hipError_t e) {
@@ -165,9 +166,9 @@ int atlas_shutdown(void) {
 // A thread that already has one on another device must atlas_shutdown_thread first.
 int atlas_init_thread(int device_ordinal) {
     if (atlas_rt::g_cur && atlas_rt::g_cur->ready) return atlas_init(device_ordinal);      // same device: no-op; another: ATLAS_ESTATE
-    if (!atlas_rt::g_cur) atlas_rt::g_cur = new atlas_rt::Runtime();
+    if (!atlas_rt::g_cur) { atlas_rt::g_cur = new atlas_rt::Runtime(); __atomic_fetch_add(&atlas_rt::g_thread_runtimes, 1, __ATOMIC_SEQ_CST); }
     const int rc = atlas_init(device_ordinal);
-    if (rc) { delete atlas_rt::g_cur; atlas_rt::g_cur = nullptr; }
+    if (rc) { delete atlas_rt::g_cur; atlas_rt::g_cur = nullptr; __atomic_fetch_sub(&atlas_rt::g_thread_runtimes, 1, __ATOMIC_SEQ_CST); }
     return rc;
 }
 int atlas_shutdown_thread(void) {
@@ -176,6 +177,7 @@ int atlas_shutdown_thread(void) {
     delete atlas_rt::g_cur->pool;
     delete atlas_rt::g_cur;
     atlas_rt::g_cur = nullptr;
+    __atomic_fetch_sub(&atlas_rt::g_thread_runtimes, 1, __ATOMIC_SEQ_CST);
     return rc;
 }
 

@@ -272,7 +272,7 @@ def test_sharded_prove_graph(tmp_path, world, name):
         assert f"SHARDED_GRAPH_OK {r}" in o
 
 
-@pytest.mark.parametrize("world,name", [(2, "tiny2"), (2, "microgpt")])
+@pytest.mark.parametrize("world,name", [(2, "tiny2"), (2, "microgpt"), (2, "nanogpt_model")])
 def test_sharded_prove_graph_one_process(tmp_path, world, name):
     """One process, N devices (the reference is ONE Rust process: onnx_proof/mod.rs:153-156): `world` THREADS of one process, each with a
     runtime of its own (atlas_init_thread: stream set, round channel, allocator, MSM workspace), its own graph + SRS handles, joined as the
@@ -291,7 +291,7 @@ def test_sharded_prove_graph_one_process(tmp_path, world, name):
         world = {world}
         gold = json.load(open(os.path.join({ROOT!r}, "tests", "golden", "graph_proofs.json")))
         want = gold["graphs"][{name!r}]
-        nodes, outputs, inputs = {{"tiny2": lambda: BG.tiny(layers=2), "microgpt": BG.microgpt}}[{name!r}]()
+        nodes, outputs, inputs = {{"tiny2": lambda: BG.tiny(layers=2), "microgpt": BG.microgpt, "nanogpt_model": BG.nanogpt_model}}[{name!r}]()
         nv = BG.max_vars(nodes)
         tau = orc.random_fr(1, gold["tau_seed"])[0]
         errors, done = [], []
@@ -300,6 +300,8 @@ def test_sharded_prove_graph_one_process(tmp_path, world, name):
             try:
                 A.init_thread(0)                                   # this thread's own runtime (on a node: device `rank`)
                 srs = A.SRS.generate(tau, 1 << nv)
+                if nv >= 16:
+                    srs.precompute()                               # the fixed-base table: the sharded MSMs index it by their point range
                 G = GG.Graph(nodes, outputs)
                 grp = sharded.ShardGroup(sys.argv[1], world, rank)
                 for rep in range(2):
