@@ -135,9 +135,11 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_prod_f9_col(const Fr* __restr
 // they are the latency of a round trip, not multiplications).  Per wavefront the kernel takes ~65 us at any occupancy: 41 f9_mul are ~20 us of
 // that (tools/exp_mad.hip: 0.47 us per multiplication per wavefront), the rest is the 23 small combinations, carries and moves.
 constexpr int RA_SPLIT_PAIRS = RA_THREADS / 2;
-template <bool TIMING>
+// MODE 0: the rows are in memory.  MODE 1 / 2 (lazy rounds 0 / 1, ra_common.hip.h): `lookups` = the packed chunk indices of the cycles, `ra` =
+// the table the row values come from — F (stride 16) in round 0, T1 (stride 256) in round 1; the loads change, the arithmetic does not.
+template <bool TIMING, int MODE = 0>
 __global__ __launch_bounds__(RA_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ra_prod16_split(const Fr* __restrict__ ra, size_t stride, SplitEqView E, size_t n_groups,
-                                                                Fr* __restrict__ partials /* [gridDim.x][16] */, MailTail tail) {
+                                                                Fr* __restrict__ partials /* [gridDim.x][16] */, MailTail tail, const uint64_t* __restrict__ lookups = nullptr) {
     using P9 = Fr9Params;
     __shared__ F9 red[RA_THREADS / 16][16];
     // TIMING (ATLAS_RA_SPLIT_TIMING=1, diagnosis): the first wavefront of three workgroups prints its shader-clock and 100 MHz wall-clock stamps per phase
@@ -156,11 +158,27 @@ __global__ __launch_bounds__(RA_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     // the overflow in AGPRs, one wavefront per SIMD — the same times: a wavefront of f9_mul chains keeps its SIMD's multiplier busy alone,
     // tools/exp_mad.hip.)
     F9 P[5], Pp[5], Q0[5];                                        // this row pair / quartic, the previous row pair and the first quartic, on {1..4, inf}
+    uint64_t lw[MODE == 2 ? 4 : MODE == 1 ? 2 : 1] = {};
+    if constexpr (MODE == 1) { lw[0] = lookups[2 * gidx]; lw[1] = lookups[2 * gidx + 1]; }
+    if constexpr (MODE == 2) { lw[0] = lookups[4 * gidx]; lw[1] = lookups[4 * gidx + 1]; lw[2] = lookups[4 * gidx + 2]; lw[3] = lookups[4 * gidx + 3]; }
 #pragma unroll 1
     for (int t = 0; t < 4; t++) {
         // (loading rows 2 t + 2, 2 t + 3 ahead of this iteration's products changed nothing: the kernel is bound by its own instructions)
-        const Fr* row = ra + (size_t)(8 * h + 2 * t) * stride + 2 * gidx;
-        F9 a0 = f9_load(row), a1 = f9_load(row + 1), b0 = f9_load(row + stride), b1 = f9_load(row + stride + 1);
+        F9 a0, a1, b0, b1;
+        if constexpr (MODE == 0) {
+            const Fr* row = ra + (size_t)(8 * h + 2 * t) * stride + 2 * gidx;
+            a0 = f9_load(row); a1 = f9_load(row + 1); b0 = f9_load(row + stride); b1 = f9_load(row + stride + 1);
+        } else {
+            const uint32_t i = 8 * h + 2 * t, sa = 4 * (15 - i), sb = sa - 4;      // chunk i = nibble 15 - i of a cycle's word (d = 16)
+            const Fr* ta = ra + (size_t)i * stride; const Fr* tb = ta + stride;
+            if constexpr (MODE == 1) {
+                a0 = f9_load(ta + ((lw[0] >> sa) & 15u)); a1 = f9_load(ta + ((lw[1] >> sa) & 15u));
+                b0 = f9_load(tb + ((lw[0] >> sb) & 15u)); b1 = f9_load(tb + ((lw[1] >> sb) & 15u));
+            } else {
+                a0 = f9_load(ta + (((lw[0] >> sa) & 15u) * 16u + ((lw[1] >> sa) & 15u))); a1 = f9_load(ta + (((lw[2] >> sa) & 15u) * 16u + ((lw[3] >> sa) & 15u)));
+                b0 = f9_load(tb + (((lw[0] >> sb) & 15u) * 16u + ((lw[1] >> sb) & 15u))); b1 = f9_load(tb + (((lw[2] >> sb) & 15u) * 16u + ((lw[3] >> sb) & 15u)));
+            }
+        }
         F9 da = f9_norm_red<P9, 2>(f9_sub<P9>(a1, a0)), db = f9_norm_red<P9, 2>(f9_sub<P9>(b1, b0));
         if (t == 0) { a0 = f9_mul<P9>(a0, wgt); da = f9_mul<P9>(da, wgt); }
         const F9 A1 = f9_norm(f9_add(a0, da)), A2 = f9_norm(f9_add(A1, da));            // lazy operands: < 6.5 p
@@ -496,15 +514,40 @@ struct RaVirtual : atlas_instance {
     RaRows rows;
     GseDev eq;
     size_t log_T = 0, round_next = 0;
-    ~RaVirtual() override { rows.release(); eq.release(); }
+    // lazy rounds 0 and 1 (ra_common.hip.h; poly/ra_poly.rs:21-110): d = 16, log_k = 4, T >= 2^RA_LAZY_LOG, stepped through the round channel.  The rows
+    // are allocated from T / 4 on (buf[0]: round 2, buf[1]: round 3); `lazy_lk` = the packed chunk indices (borrowed device lookups or `lazy_own`).
+    bool lazy = false;
+    const uint64_t* lazy_lk = nullptr;
+    uint64_t* lazy_own = nullptr;
+    Fr* d_F = nullptr;            // [16][16]
+    Fr* d_T1 = nullptr;           // [16][256], built by round 1's launch
+    ~RaVirtual() override { rows.release(); eq.release(); if (lazy_own) hipFree(lazy_own); if (d_F) hipFree(d_F); if (d_T1) hipFree(d_T1); }
+    // a host-stepped caller of a lazy instance: the gathered rows after all (callers hold rt().mu)
+    int unlazy() {
+        if (!lazy) return ATLAS_OK;
+        if (round_next != 0) return fail(ATLAS_ESTATE, "ra_virtual: a lazy instance cannot change to host stepping after its first round");
+        const size_t T = (size_t)1 << log_T;
+        for (auto& b : rows.buf) { if (b) hipFree(b); b = nullptr; }
+        HIP_TRY(hipMalloc(&rows.buf[0], rows.d * T * sizeof(Fr)));
+        HIP_TRY(hipMalloc(&rows.buf[1], rows.d * (T / 2) * sizeof(Fr)));
+        rows.stride[0] = T; rows.stride[1] = T / 2; rows.len = T; rows.cur = 0;
+        size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
+        k_ra_gather_lk<<<dim3((unsigned)gb, (unsigned)rows.d), RA_THREADS, 0, rt().stream>>>(lazy_lk, d_F, 16u, T, (uint32_t)rows.d, 4u, rows.buf[0]);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(ATLAS_ENODEV, "ra_virtual: gather", e);
+        lazy = false;
+        return ATLAS_OK;
+    }
     size_t rounds() const override { return log_T; }
     size_t degree() const override { return rows.d + 1; }
     int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
         if (round != round_next || round >= log_T) return fail(ATLAS_ESTATE, "ra_virtual: round out of order");
         std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+        int rc = unlazy();
+        if (rc) return rc;
         const size_t n_groups = rows.len / 2;
         unsigned blocks = (unsigned)((n_groups + RA_THREADS - 1) / RA_THREADS);
-        int rc = launch_prod_d(rows.d, rows.buf[rows.cur], rows.stride[rows.cur], rows.partials, eq.view(), n_groups, blocks, MailTail{{}, nullptr, 0, 0});
+        rc = launch_prod_d(rows.d, rows.buf[rows.cur], rows.stride[rows.cur], rows.partials, eq.view(), n_groups, blocks, MailTail{{}, nullptr, 0, 0});
         if (rc) return rc;
         std::vector<H::Fr> sums(rows.d);
         rc = rows.reduce_to_host(blocks, (uint32_t)rows.d, sums.data());
@@ -552,7 +595,22 @@ struct RaVirtual : atlas_instance {
         const ChanIo cio{io, rt().challenge_mode};
         size_t ot, it;
         eq.st.tops_after(round, ot, it);
-        if (fused(round)) {                                       // bind + product in one launch (k_ra_bind_prod_f9)
+        if (lazy && round <= 2) {
+            const int hi = rt().challenge_mode == 0 ? 1 : 0;
+            if (round < 2) {                                      // the split product over the packed indices and a table
+                if (round == 1) k_ra_lazy_t1<<<1, RA_THREADS, 0, rt().stream>>>(d_F, 16u, 16u, d_T1, cio, hi);
+                const unsigned blocks = (unsigned)((n_groups + RA_SPLIT_PAIRS - 1) / RA_SPLIT_PAIRS);
+                const MailTail tail{io, rows.d_counter, blocks, 16u, rows.tg()};
+                if (round == 0) k_ra_prod16_split<false, 1><<<blocks, RA_THREADS, 0, rt().stream>>>(d_F, 16, eq.view_at(ot, it), n_groups, rows.partials, tail, lazy_lk);
+                else k_ra_prod16_split<false, 2><<<blocks, RA_THREADS, 0, rt().stream>>>(d_T1, 256, eq.view_at(ot, it), n_groups, rows.partials, tail, lazy_lk);
+            } else {                                              // the rows at last, bound through r1 (T / 4 long), and the product over them
+                size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
+                k_ra_lazy_rows<<<dim3((unsigned)gb, 16u), RA_THREADS, 0, rt().stream>>>(lazy_lk, d_T1, 16u, len, rows.buf[0], len, cio, hi);
+                unsigned blocks = (unsigned)((n_groups + RA_THREADS - 1) / RA_THREADS);
+                int rc = launch_prod_d(rows.d, rows.buf[0], len, rows.partials, eq.view_at(ot, it), n_groups, blocks, MailTail{io, rows.d_counter, 0, 0, rows.tg()});
+                if (rc) return rc;
+            }
+        } else if (fused(round)) {                                // bind + product in one launch (k_ra_bind_prod_f9)
             const unsigned fb = (unsigned)((n_groups + RA_FUSE_PAIRS - 1) / RA_FUSE_PAIRS);
             k_ra_bind_prod_f9<<<fb, RA_THREADS, 0, rt().stream>>>(rows.buf[(round - 1) & 1], T >> (round - 1), rows.buf[round & 1], len, (uint32_t)rows.d, eq.view_at(ot, it),
                                                                n_groups, rows.partials, cio, rt().challenge_mode == 0 ? 1 : 0, MailTail{io, rows.d_counter, fb, (uint32_t)rows.d, rows.tg()});
@@ -943,9 +1001,47 @@ static int ra_virtual_build(const int32_t* const* H_indices, const uint64_t* loo
         for (size_t i = 0; i < d; i++) tabs[i] = H::eq_evals(ch + i * log_k_chunk, log_k_chunk);
         rc = upload_tables(tabs, K, &d_tabs);
     }
-    if (!rc) rc = P->rows.alloc(d, T);
-    if (!rc) rc = H_indices ? P->rows.upload_indices(H_indices) : P->rows.upload_lookups(lookups, (uint32_t)log_k_chunk);
-    if (!rc) rc = P->rows.gather(d_tabs, (uint32_t)K);
+    // lazy rounds 0 and 1 (RaVirtual::lazy): 16 chunks of 4 bits, T >= 2^18 (ATLAS_RA_LAZY_LOG moves it, 31 = never), the round channel
+    static const size_t lazy_log = [] { const char* e = getenv("ATLAS_RA_LAZY_LOG"); const int v = e ? atoi(e) : 18; return (size_t)(v >= 14 && v <= 31 ? v : 18); }();
+    static const bool no_pipe = getenv("ATLAS_NO_PIPELINE") != nullptr;
+    bool lazy = !rc && d == 16 && log_k_chunk == 4 && log_T >= lazy_log && d_tabs && rt().fs_mode == ATLAS_FS_HOST && !no_pipe;
+    if (lazy) {
+        P->rows.d = d; P->rows.len = T;
+        if (H_indices) {                                          // host chunk rows: packed on the device; an index outside 0..15 (None) -> gathered rows
+            rc = P->rows.upload_indices(H_indices);
+            uint32_t* d_bad = nullptr;
+            if (!rc) { HIP_TRY(hipMalloc(&P->lazy_own, T * sizeof(uint64_t))); HIP_TRY(hipMalloc(&d_bad, 4)); HIP_TRY(hipMemsetAsync(d_bad, 0, 4, rt().stream)); }
+            uint32_t bad = 1;
+            if (!rc) {
+                size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
+                k_ra_pack_nibbles<<<(unsigned)gb, RA_THREADS, 0, rt().stream>>>(P->rows.d_idx, T, (uint32_t)d, P->lazy_own, d_bad);
+                HIP_TRY(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, rt().stream));
+                HIP_TRY(hipStreamSynchronize(rt().stream));
+            }
+            if (d_bad) hipFree(d_bad);
+            if (bad) { lazy = false; hipFree(P->lazy_own); P->lazy_own = nullptr; }
+            else { hipFree(P->rows.d_idx); P->rows.d_idx = nullptr; P->lazy_lk = P->lazy_own; }
+        } else {
+            rc = P->rows.upload_lookups(lookups, (uint32_t)log_k_chunk);
+            if (!rc && P->rows.lk) P->lazy_lk = P->rows.lk; else lazy = false;
+        }
+    }
+    if (!rc && lazy) {
+        rc = P->rows.alloc(d, T / 4, 2, T);
+        P->rows.len = T;
+        if (!rc) { HIP_TRY(hipMalloc(&P->d_T1, 16 * 256 * sizeof(Fr))); }
+        P->d_F = d_tabs; d_tabs = nullptr;
+        P->lazy = true;
+        static const bool trace = getenv("ATLAS_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "[atlas trace] ra_virtual d=16 T=2^%zu: lazy rounds 0-1 (packed indices + tables), rows from round 2\n", log_T);
+    } else if (!rc) {
+        const bool have_idx = P->rows.d_idx != nullptr || P->rows.lk != nullptr;      // (the lazy attempt above may have uploaded them already)
+        int32_t* keep_idx = P->rows.d_idx; const uint64_t* keep_lk = P->rows.lk; const uint32_t keep_log = P->rows.lk_log;
+        rc = P->rows.alloc(d, T);
+        P->rows.d_idx = keep_idx; P->rows.lk = keep_lk; P->rows.lk_log = keep_log;
+        if (!rc && !have_idx) rc = H_indices ? P->rows.upload_indices(H_indices) : P->rows.upload_lookups(lookups, (uint32_t)log_k_chunk);
+        if (!rc) rc = P->rows.gather(d_tabs, (uint32_t)K);
+    }
     if (d_tabs) hipFree(d_tabs);
     if (!rc && log_T) rc = P->eq.init(reinterpret_cast<const H::Fr*>(r_cycle), log_T);
     if (rc) { delete P; return rc; }

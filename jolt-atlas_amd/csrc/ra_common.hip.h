@@ -51,6 +51,47 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_gather_lk(const uint64_t* __r
     }
 }
 
+// ---- lazy rounds of RaPolynomial (poly/ra_poly.rs:21-110: the reference keeps (index, table) for the first binds) --------------------------
+// With log_k = 4 and d <= 16 the d chunk indices of a cycle are the nibbles of ONE 64-bit word (chunk i = nibble d - 1 - i): the word is all a
+// round needs while the row values come from a table — F_i (16 entries) in round 0, T1_i[a, b] = F_i[a] + r0 (F_i[b] - F_i[a]) (256 entries) in
+// round 1 — so rounds 0 and 1 read 8 bytes per cycle instead of 32 d, and the rows are materialised bound through r1 (T / 4 long) for round 2.
+// d rows of T int32 chunk indices -> the packed words; *bad is raised by an index outside 0..15 (a None lookup: the caller gathers rows instead)
+__global__ __launch_bounds__(RA_THREADS) void k_ra_pack_nibbles(const int32_t* __restrict__ idx /* [d][T] */, size_t T, uint32_t d, uint64_t* __restrict__ out, uint32_t* bad) {
+    for (size_t j = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; j < T; j += (size_t)gridDim.x * RA_THREADS) {
+        uint64_t w = 0;
+        bool b = false;
+        for (uint32_t i = 0; i < d; i++) {
+            const int32_t v = idx[(size_t)i * T + j];
+            b |= v < 0 || v > 15;
+            w |= (uint64_t)(v & 15) << (4 * (d - 1 - i));
+        }
+        out[j] = w;
+        if (b) atomicOr(bad, 1u);
+    }
+}
+// T1[i][16 a + b] = bind(F_i[a], F_i[b]; r0): one workgroup, waits for round 0's challenge
+__global__ __launch_bounds__(RA_THREADS) void k_ra_lazy_t1(const Fr* __restrict__ F, uint32_t f_stride, uint32_t d, Fr* __restrict__ T1, ChanIo io, int r_hi_only) {
+    Fr r;
+    if (!io.challenge(r)) return;
+    for (uint32_t t = threadIdx.x; t < d * 256u; t += RA_THREADS) {
+        const uint32_t i = t >> 8, a = (t >> 4) & 15u, b = t & 15u;
+        fe_store(T1 + t, bind_pair(fe_load(F + (size_t)i * f_stride + a), fe_load(F + (size_t)i * f_stride + b), r, r_hi_only != 0));
+    }
+}
+// rows of round 2: out[i][j] = bind(T1_i[cycles 4j, 4j + 1], T1_i[cycles 4j + 2, 4j + 3]; r1); grid (x, d), waits for round 1's challenge
+__global__ __launch_bounds__(RA_THREADS) void k_ra_lazy_rows(const uint64_t* __restrict__ lookups, const Fr* __restrict__ T1, uint32_t d, size_t quarter,
+                                                             Fr* __restrict__ out, size_t out_stride, ChanIo io, int r_hi_only) {
+    Fr r;
+    if (!io.challenge(r)) return;
+    const uint32_t i = blockIdx.y, sh = 4 * (d - 1 - i);
+    const Fr* t1 = T1 + (size_t)i * 256;
+    for (size_t j = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; j < quarter; j += (size_t)gridDim.x * RA_THREADS) {
+        const uint64_t w0 = lookups[4 * j], w1 = lookups[4 * j + 1], w2 = lookups[4 * j + 2], w3 = lookups[4 * j + 3];
+        const uint32_t p0 = (uint32_t)((w0 >> sh) & 15u) * 16u + (uint32_t)((w1 >> sh) & 15u), p1 = (uint32_t)((w2 >> sh) & 15u) * 16u + (uint32_t)((w3 >> sh) & 15u);
+        fe_store(out + (size_t)i * out_stride + j, bind_pair(fe_load(t1 + p0), fe_load(t1 + p1), r, r_hi_only != 0));
+    }
+}
+
 // compute_instruction_h_indices (shout.rs:532-547) / OneHotParams::lookup_index_chunk (config.rs:73-75):
 // chunk i of a lookup index = (index >> (log_k_chunk * (d - 1 - i))) & (k_chunk - 1), i = 0 most significant
 __global__ __launch_bounds__(RA_THREADS) void k_ra_chunk_indices(const uint64_t* __restrict__ lookups, size_t T, uint32_t d,
@@ -376,11 +417,13 @@ struct RaRows {
     static bool tagged_off() { static const bool v = getenv("ATLAS_NO_TAGGED_ROWS") != nullptr; return v; }      // A-B: the arrival counter
     atlas::Chunk* tg() const { return tagged_off() ? nullptr : tagged; }
 
-    int alloc(size_t d_, size_t T, size_t k_min = 2) {     // K = width of a row of partial sums
+    // T_rounds: the length the ROUNDS start from when the buffers start later (lazy RaVirtual: buffers of T / 4, partial rows for T / 2 pairs)
+    int alloc(size_t d_, size_t T, size_t k_min = 2, size_t T_rounds = 0) {     // K = width of a row of partial sums
         d = d_; len = T; K = d > k_min ? d : k_min;
         HIP_TRY(hipMalloc(&buf[0], d * T * sizeof(Fr)));
         HIP_TRY(hipMalloc(&buf[1], d * (T > 1 ? T / 2 : 1) * sizeof(Fr)));
         stride[0] = T; stride[1] = T > 1 ? T / 2 : 1;
+        if (T_rounds > T) T = T_rounds;
         const size_t blocks = (T / 2 + RA_THREADS / 2 - 1) / (RA_THREADS / 2) + 1;       // a row per RA_THREADS / 2 pairs: the split product of d = 16 (ra.hip)
         const size_t cap = blocks * K > 8192 ? blocks * K : 8192;                                // room for the row-split launches of short instances (k_ra_bind_prod_f9: 512 rows of 16)
         HIP_TRY(hipMalloc(&partials, cap * sizeof(Fr) + cap * 3 * sizeof(atlas::Chunk)));

@@ -186,6 +186,31 @@ def test_ra_virtual_large(atlas, d, log_T):
     inst.free()
 
 
+@pytest.mark.parametrize("log_T", [18, 20])
+def test_ra_virtual_lazy(atlas, log_T):
+    """RaVirtual with d = 16 chunks of 4 bits at T >= 2^18: rounds 0 and 1 read the packed chunk indices (8 bytes per cycle) and a 16- / 256-entry
+    table per chunk, the rows are materialised bound through r1 (csrc/ra.hip: RaVirtual::lazy; poly/ra_poly.rs:21-110 keeps (index, table) the same
+    way).  Same round polynomials as the gathered rows: the digest of the oracle's proof (tests/golden/full_size_oracle.json, CPU, minutes) and
+    two of the sixteen final claims against the oracle's evaluation."""
+    from oracle import orc
+    from jolt_atlas_amd import instances as I
+    A = atlas
+    d = 16
+    log_k, _, _, r_cycle, claim, log_K, lookups, r_address = ra_large_inputs(d, log_T)
+    want = _oracle_digest(f"ra_large2[{d}-{log_T}]", lambda: ra_large_oracle(d, log_T, True))
+    Hl = [((lookups >> np.uint64(log_k * (d - 1 - i))) & np.uint64(15)).astype(np.int32) for i in range(d)]
+    chunks = r_address.reshape(d, log_k, 4)
+    inst = I.ra_virtual(Hl, log_k, chunks, r_cycle)
+    t_g = A.Blake2bTranscript(b"ra_large2")
+    rows_g, ch_g = inst.prove(claim, t_g)
+    assert _digest(rows_g, ch_g, t_g.state) == want
+    fin = inst.final_claims()
+    rs = np.ascontiguousarray(orc.challenges_to_fr(ch_g)[::-1])
+    for i in (0, 15):
+        assert np.array_equal(fin[i], orc.evaluate(np.ascontiguousarray(orc.eq_evals(chunks[i])[Hl[i]]), rs))
+    inst.free()
+
+
 @pytest.mark.parametrize("d,log_T", [(8, 16), (16, 15)])
 def test_booleanity_large(atlas, d, log_T):
     from oracle import orc, orc_ra as OR
