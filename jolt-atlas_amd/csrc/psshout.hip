@@ -409,7 +409,7 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_bind_fold_ch(const Fr* __rest
 // of the round before (slot r_host + i, tag tag_r0 + i), bind the row LowToHigh (the first time from HBM), fold the even coefficients with the
 // split-eq weights of that round, mail one canonical sum under tag_mail0 + i * tag_step at record i.  After the last round the final bind
 // is mailed as record n_rounds (what k_rows_final_ch sends).  Same sums as k_ps_bind_fold_ch: exact arithmetic, another order.
-constexpr uint32_t PS_TAIL_LOG = 11, PS_TAIL_THREADS = 1024;
+constexpr uint32_t PS_TAIL_LOG = 11, PS_TAIL_THREADS = 1024, PS_TAIL_PER = (1u << PS_TAIL_LOG) / PS_TAIL_THREADS;      // (2^12 — 128 KB of LDS, one more resident round — measured: no change on the ReLU / Add / Mul nodes)
 struct PsTailArgs {
     const Fr* src; uint32_t len_src;          // the row as the launch before left it: T >> (c0 - 1) coefficients
     const Fr* e_out; const Fr* e_in;          // the cached prefix tables (GseDev::d_eout, d_ein)
@@ -446,22 +446,23 @@ __global__ __launch_bounds__(PS_TAIL_THREADS) void k_ps_tail_ch(PsTailArgs A) {
             return;
         }
         const uint32_t half = len / 2;                              // coefficients after this bind (<= 2^PS_TAIL_LOG)
-        Fr b[2];
+        Fr b[PS_TAIL_PER];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (uint32_t u = 0; u < PS_TAIL_PER; u++) {
             const uint32_t j = tid + u * PS_TAIL_THREADS;
             if (j < half) b[u] = i == 0 ? bind_pair(fe_load(A.src + 2 * j), fe_load(A.src + 2 * j + 1), r, A.hi_only != 0)
                                         : bind_pair(sv[2 * j], sv[2 * j + 1], r, A.hi_only != 0);
         }
         __syncthreads();                                            // every pair has been read before its slot is overwritten
 #pragma unroll
-        for (int u = 0; u < 2; u++) { const uint32_t j = tid + u * PS_TAIL_THREADS; if (j < half) sv[j] = b[u]; }
+        for (uint32_t u = 0; u < PS_TAIL_PER; u++) { const uint32_t j = tid + u * PS_TAIL_THREADS; if (j < half) sv[j] = b[u]; }
         __syncthreads();
         const uint32_t n_groups = half / 2, in_bits = A.it[i];
         const Fr* eo = A.e_out + (((size_t)1 << A.ot[i]) - 1);
         const Fr* ei = A.e_in + (((size_t)1 << in_bits) - 1);
         Fr acc = fe_zero();
-        if (tid < n_groups) acc = fr_mul(fr_mul(fe_load(eo + (tid >> in_bits)), fe_load(ei + (tid & ((1u << in_bits) - 1u)))), sv[2 * tid]);
+        for (uint32_t gq = tid; gq < n_groups; gq += PS_TAIL_THREADS)
+            acc = fr_add(acc, fr_mul(fr_mul(fe_load(eo + (gq >> in_bits)), fe_load(ei + (gq & ((1u << in_bits) - 1u)))), sv[2 * gq]));
         acc = fr_wave_sum(acc);
         if (lane == 0) red[wave] = acc;
         __syncthreads();
