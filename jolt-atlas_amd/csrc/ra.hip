@@ -350,9 +350,14 @@ __global__ __launch_bounds__(RA_THREADS) void k_ra_bind_prod_f9(const Fr* __rest
 // on the 29-bit lazy limbs: h0 - 1 and h1 - h0 enter their products unreduced (the lazy operand of f9_mul), the row
 // sums are limb-wise adds with a carry + reduce pass every fourth row.  Four f9_mul stand behind every term (gamma h,
 // the second factor, E_out E_in, the weighting): a stored sum is 32^-4 times the true one, undone on the host.
+// LAZY (the FIRST cycle round of an instance over packed 4-bit chunk indices, Booleanity::lazy): every H_i reads the same 16-entry table F, so
+// the two terms of a (row, pair) take 16 / 256 values — gamma_i F[a] (F[a] - 1) and gamma_i (F[b] - F[a])^2, built by k_bool_lazy_tables with
+// the same two f9_mul each — and the round is two table reads and two additions per (row, pair) instead of four multiplications.
+// Hp = Ctab [d][16], gammas = Etab [d][256], lookups = the cycles' words (chunk i = nibble d - 1 - i).
+template <bool LAZY = false>
 __global__ __launch_bounds__(RA_THREADS) void k_bool_fold(const Fr* __restrict__ Hp, size_t stride, uint32_t d,
                                                           const Fr* __restrict__ gammas, SplitEqView E, size_t n_groups,
-                                                          Fr* __restrict__ partials, MailTail tail) {
+                                                          Fr* __restrict__ partials, MailTail tail, const uint64_t* __restrict__ lookups = nullptr) {
     using P9 = Fr9Params;
     F9 acc0 = f9_zero(), acc1 = f9_zero();
     const F9 one = f9_from_fe(fr_one());
@@ -360,8 +365,17 @@ __global__ __launch_bounds__(RA_THREADS) void k_bool_fold(const Fr* __restrict__
         F9 c = f9_zero(), e = f9_zero();
         // blockIdx.y splits the d rows (the sums are additive): short instances put one row per thread
         const uint32_t i0 = (uint32_t)(((uint64_t)d * blockIdx.y) / gridDim.y), i1 = (uint32_t)(((uint64_t)d * (blockIdx.y + 1)) / gridDim.y);
+        uint64_t w0 = 0, w1 = 0;
+        if constexpr (LAZY) { w0 = lookups[2 * j]; w1 = lookups[2 * j + 1]; }
 #pragma unroll 1
         for (uint32_t i = i0; i < i1; i++) {
+            if constexpr (LAZY) {
+                const uint32_t sh = 4 * (d - 1 - i), a = (uint32_t)((w0 >> sh) & 15u), b = (uint32_t)((w1 >> sh) & 15u);
+                c = f9_add(c, f9_load(Hp + i * 16 + a));
+                e = f9_add(e, f9_load(gammas + i * 256 + a * 16 + b));
+                if ((i - i0) % 4 == 3) { c = f9_norm_red<P9, 4>(c); e = f9_norm_red<P9, 4>(e); }
+                continue;
+            }
             const Fr* row = Hp + (size_t)i * stride;
             const F9 h0 = f9_load(row + 2 * j), h1 = f9_load(row + 2 * j + 1);
             const F9 gm = f9_load(gammas + i);
@@ -390,6 +404,29 @@ __global__ __launch_bounds__(RA_THREADS) void k_bool_fold(const Fr* __restrict__
         else fe_store(partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + threadIdx.x, v);
     }
     mail_tail(partials, tail);
+}
+
+// the two tables of k_bool_fold<true>: the SAME products the rows path forms per (row, pair), once per (row, value) / (row, value pair)
+__global__ __launch_bounds__(RA_THREADS) void k_bool_lazy_tables(const Fr* __restrict__ F /* 16 */, const Fr* __restrict__ gammas, uint32_t d,
+                                                                 Fr* __restrict__ Ctab /* [d][16] */, Fr* __restrict__ Etab /* [d][256] */) {
+    using P9 = Fr9Params;
+    const F9 one = f9_from_fe(fr_one());
+    for (uint32_t t = blockIdx.x * RA_THREADS + threadIdx.x; t < d * 256u; t += gridDim.x * RA_THREADS) {
+        const uint32_t i = t >> 8, a = (t >> 4) & 15u, b = t & 15u;
+        const F9 h0 = f9_load(F + a), h1 = f9_load(F + b), gm = f9_load(gammas + i);
+        const F9 df = f9_sub<P9>(h1, h0);
+        fe_store(Etab + t, f9_canon<P9>(f9_reduce_lazy<P9>(f9_norm(f9_mul<P9>(f9_mul<P9>(gm, df), df)))));
+        if (b == 0) fe_store(Ctab + i * 16 + a, f9_canon<P9>(f9_reduce_lazy<P9>(f9_norm(f9_mul<P9>(f9_mul<P9>(gm, h0), f9_sub<P9>(h0, one))))));
+    }
+}
+// the rows of cycle round 1 (T / 2 long): out[i][j] = bind(F[chunk i of cycle 2j], F[chunk i of cycle 2j + 1]; r); grid (x, d), waits for the challenge
+__global__ __launch_bounds__(RA_THREADS) void k_bool_lazy_rows(const uint64_t* __restrict__ lookups, const Fr* __restrict__ F, uint32_t d, size_t half,
+                                                               Fr* __restrict__ out, size_t out_stride, ChanIo io, int r_hi_only) {
+    Fr r;
+    if (!io.challenge(r)) return;
+    const uint32_t i = blockIdx.y, sh = 4 * (d - 1 - i);
+    for (size_t j = (size_t)blockIdx.x * RA_THREADS + threadIdx.x; j < half; j += (size_t)gridDim.x * RA_THREADS)
+        fe_store(out + (size_t)i * out_stride + j, bind_pair(fe_load(F + ((lookups[2 * j] >> sh) & 15u)), fe_load(F + ((lookups[2 * j + 1] >> sh) & 15u)), r, r_hi_only != 0));
 }
 
 // The bind of a booleanity cycle round and its fold in ONE launch, one (row, pair) per thread (the latency regime of k_bool_fold, at most
@@ -710,7 +747,21 @@ struct Booleanity : atlas_instance {
     Fr *d_gammas = nullptr, *d_F = nullptr;          // d_F: 2^log_k entries, the device ExpandingTable of the pipelined path
     H::Fr eq_r_r = H::zero(), eq_r_r_inv = H::zero();
     bool have_eq_r_r_inv = false;
-    ~Booleanity() override { rows.release(); D.release(); if (d_gammas) hipFree(d_gammas); if (d_F) hipFree(d_F); }
+    // lazy first cycle round (k_bool_fold<true>): log_k = 4, device-resident lookup words, T >= 2^18 (ATLAS_BOOL_LAZY_LOG), the round channel.  No gather: cycle round 0
+    // reads the words and two tables, cycle round 1's rows (T / 2) come from the words and F bound with its challenge; buf[1] holds T / 2, buf[0] T / 4.
+    bool lazy = false;
+    Fr* d_tabs = nullptr;                              // Ctab [d][16] then Etab [d][256]
+    ~Booleanity() override { rows.release(); D.release(); if (d_gammas) hipFree(d_gammas); if (d_F) hipFree(d_F); if (d_tabs) hipFree(d_tabs); }
+    int unlazy() {                                     // a host-stepped caller: the full-length buffers after all (callers hold rt().mu)
+        if (!lazy) return ATLAS_OK;
+        const size_t T = (size_t)1 << log_T;
+        for (auto& b : rows.buf) { if (b) hipFree(b); b = nullptr; }
+        HIP_TRY(hipMalloc(&rows.buf[0], d * T * sizeof(Fr)));
+        HIP_TRY(hipMalloc(&rows.buf[1], d * (T / 2) * sizeof(Fr)));
+        rows.stride[0] = T; rows.stride[1] = T / 2; rows.len = T; rows.cur = 0;
+        lazy = false;
+        return ATLAS_OK;
+    }
     size_t rounds() const override { return log_k + log_T; }
     size_t degree() const override { return 3; }
 
@@ -759,11 +810,11 @@ struct Booleanity : atlas_instance {
         const MailTail tail = io ? MailTail{*io, rows.d_counter, (uint32_t)(blocks * ysplit), 2u, rows.tg()} : MailTail{{}, nullptr, 0, 0};
         static const bool no_tail = getenv("ATLAS_NO_MAIL_TAIL") != nullptr;  // diagnosis (tools/stress_lanes.py)
         if (no_tail && io) {
-            k_bool_fold<<<dim3((unsigned)blocks, ysplit), RA_THREADS, 0, rt().stream>>>(buf, stride, (uint32_t)d, d_gammas, E, n_groups, rows.partials, MailTail{{}, nullptr, 0, 0});
+            k_bool_fold<false><<<dim3((unsigned)blocks, ysplit), RA_THREADS, 0, rt().stream>>>(buf, stride, (uint32_t)d, d_gammas, E, n_groups, rows.partials, MailTail{{}, nullptr, 0, 0});
             k_col_reduce_mail<<<1, RA_THREADS, 0, rt().stream>>>(rows.partials, (uint32_t)(blocks * ysplit), 2u, *io);
             return (uint32_t)(blocks * ysplit);
         }
-        k_bool_fold<<<dim3((unsigned)blocks, ysplit), RA_THREADS, 0, rt().stream>>>(buf, stride, (uint32_t)d, d_gammas, E, n_groups, rows.partials, tail);
+        k_bool_fold<false><<<dim3((unsigned)blocks, ysplit), RA_THREADS, 0, rt().stream>>>(buf, stride, (uint32_t)d, d_gammas, E, n_groups, rows.partials, tail);
         return (uint32_t)(blocks * ysplit);
     }
     int finish_phase2(const H::Fr* sums, const H::Fr& claim, std::vector<H::Fr>& coeffs) {
@@ -791,7 +842,8 @@ struct Booleanity : atlas_instance {
                 Fr* d_Fh = nullptr;
                 HIP_TRY(hipMalloc(&d_Fh, F.size() * sizeof(Fr)));
                 HIP_TRY(hipMemcpyAsync(d_Fh, F.data(), F.size() * sizeof(Fr), hipMemcpyHostToDevice, rt().stream));
-                int rc = rows.gather(d_Fh, 0);                        // every H_i reads the same table F
+                int rc = unlazy();
+                if (!rc) rc = rows.gather(d_Fh, 0);                   // every H_i reads the same table F
                 hipFree(d_Fh);
                 if (rc) return rc;
                 G.clear();
@@ -839,6 +891,24 @@ struct Booleanity : atlas_instance {
         if (round >= 1 && round <= log_k) k_bool_expand_ch<<<1, RA_THREADS, 0, rt().stream>>>(d_F, 1u << (round - 1), cio);
         if (round < log_k) return ATLAS_OK;
         const size_t T = (size_t)1 << log_T, p = round - log_k, len = T >> p, n_groups = len / 2;
+        if (lazy && p <= 1) {
+            size_t ot0, it0;
+            D.st.tops_after(p, ot0, it0);
+            if (p == 0) {                                             // two tables from F and the gammas, then the fold over the words
+                k_bool_lazy_tables<<<(unsigned)((d * 256 + RA_THREADS - 1) / RA_THREADS), RA_THREADS, 0, rt().stream>>>(d_F, d_gammas, (uint32_t)d, d_tabs, d_tabs + d * 16);
+                size_t blocks = (n_groups + RA_THREADS - 1) / RA_THREADS; if (blocks > 2048) blocks = 2048;
+                k_bool_fold<true><<<dim3((unsigned)blocks, 1u), RA_THREADS, 0, rt().stream>>>(d_tabs, 0, (uint32_t)d, d_tabs + d * 16, D.view_at(ot0, it0), n_groups, rows.partials,
+                                                                                      MailTail{io, rows.d_counter, (uint32_t)blocks, 2u, rows.tg()}, rows.lk);
+            } else {                                                  // the rows of cycle round 1 straight from the words, bound with round 0's challenge
+                size_t gb = (len + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
+                k_bool_lazy_rows<<<dim3((unsigned)gb, (unsigned)d), RA_THREADS, 0, rt().stream>>>(rows.lk, d_F, (uint32_t)d, len, rows.buf[1], len, cio, rt().challenge_mode == 0 ? 1 : 0);
+                launch_fold(rows.buf[1], len, D.view_at(ot0, it0), n_groups, &io);
+            }
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return fail(ATLAS_ENODEV, "booleanity: launch", e);
+            mail.blocks = 1; mail.n_vals = 2;
+            return ATLAS_OK;
+        }
         if (p == 0) {
             if (!rows.d_idx && !rows.lk) return fail(ATLAS_ESTATE, "booleanity: indices not uploaded");
             size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 4096) gb = 4096;
@@ -1094,8 +1164,28 @@ static int booleanity_build(const atlas_fr_t* G, const int32_t* const* H_indices
     P->B_out = H::eq_cached(ra, P->B.k_out);
     P->B_in = H::eq_cached(ra + P->B.m, P->B.k_in);
     int rc = log_T ? P->D.init(reinterpret_cast<const H::Fr*>(r_cycle), log_T) : ATLAS_OK;
-    if (!rc) rc = P->rows.alloc(d, T);
-    if (!rc) rc = H_indices ? P->rows.upload_indices(H_indices) : P->rows.upload_lookups(lookups, (uint32_t)log_k_chunk);   // resident until the phase-2 gather
+    static const size_t lazy_log = [] { const char* e = getenv("ATLAS_BOOL_LAZY_LOG"); const int v = e ? atoi(e) : 18; return (size_t)(v >= 15 && v <= 31 ? v : 18); }();   // 31 = never; from 2^15 on: no faster on the T = 2^16 nodes (the RaVirtual lane is the batch's long one), so it is used where the rows' memory counts
+    static const bool no_pipe = getenv("ATLAS_NO_PIPELINE") != nullptr;
+    bool lazy = !rc && !H_indices && log_k_chunk == 4 && d * 4 <= 64 && log_T >= lazy_log && rt().fs_mode == ATLAS_FS_HOST && !no_pipe;
+    if (lazy) {
+        P->rows.d = d; P->rows.len = T;
+        rc = P->rows.upload_lookups(lookups, (uint32_t)log_k_chunk);
+        if (rc || !P->rows.lk) lazy = false;              // host lookups are cut into index rows: the gathered path
+    }
+    if (!rc && lazy) {
+        int32_t* keep_idx = P->rows.d_idx; const uint64_t* keep_lk = P->rows.lk; const uint32_t keep_log = P->rows.lk_log;
+        rc = P->rows.alloc(d, T / 2, 2, T);              // T / 2 and T / 4 coefficients per row ...
+        std::swap(P->rows.buf[0], P->rows.buf[1]);       // ... the longer in buf[1] (cycle round 1), the shorter in buf[0] (round 2)
+        P->rows.d_idx = keep_idx; P->rows.lk = keep_lk; P->rows.lk_log = keep_log; P->rows.len = T;
+        if (!rc) { hipError_t e = hipMalloc(&P->d_tabs, d * (16 + 256) * sizeof(Fr)); if (e != hipSuccess) rc = fail(ATLAS_ENODEV, "booleanity_new: tables", e); }
+        P->lazy = !rc;
+    } else if (!rc) {
+        const bool have = P->rows.d_idx != nullptr || P->rows.lk != nullptr;
+        int32_t* keep_idx = P->rows.d_idx; const uint64_t* keep_lk = P->rows.lk; const uint32_t keep_log = P->rows.lk_log;
+        rc = P->rows.alloc(d, T);
+        P->rows.d_idx = keep_idx; P->rows.lk = keep_lk; P->rows.lk_log = keep_log;
+        if (!rc && !have) rc = H_indices ? P->rows.upload_indices(H_indices) : P->rows.upload_lookups(lookups, (uint32_t)log_k_chunk);   // resident until the phase-2 gather
+    }
     if (!rc) {
         hipError_t e = hipMalloc(&P->d_gammas, d * sizeof(Fr));
         if (e != hipSuccess) rc = fail(ATLAS_ENODEV, "booleanity_new: gammas", e);
