@@ -21,6 +21,7 @@
 
 #include "../../include/atlas_hip.h"
 #include "host_field.hpp"
+#include "shard_group.hpp"
 #include "host_threads.hpp"
 #include "instance.hpp"
 #include "runtime.hpp"
@@ -67,6 +68,8 @@ struct Instance {
     bool owned;               // adapter created here
     H::Fr input_claim;
     size_t rounds;
+    bool remote = false;      // a member another rank of the batch's shard group steps (inst == nullptr): its claim and its coefficient are part of
+                              // this rank's transcript, its round polynomials reach the sum through the group's exchange
 };
 
 H::Fr mul_pow2(H::Fr x, size_t pow) {      // JoltField::mul_pow_2 (field/mod.rs:274-284): same value, x * 2^pow — one multiplication by a tabled power
@@ -240,8 +243,43 @@ bool all_pipelined(const std::vector<atlas_instance*>& v) {
 
 struct atlas_batched {
     std::vector<Instance> inst;
+    atlas_shard_group* shard = nullptr;      // != null: the members are split over the ranks (atlas_rt_batched_set_shard)
     ~atlas_batched() { for (auto& I : inst) if (I.owned) delete I.inst; }
 };
+
+// BatchedSumcheck::prove with the members split over the ranks of a shard group (the opening-reduction sumcheck of a sharded whole proof,
+// reduced_openings.hip): every rank holds the SAME member list — input claims, round counts: the transcript absorbs all of them and draws
+// all coefficients — but steps only its own members; the others are added with atlas_rt_batched_add_remote.  The batched round polynomial
+// is linear in the members, so per round every rank sums its members' scaled polynomials (and the constant polynomials of its members that
+// have not started), the ranks exchange {length, coefficients} through the board (one record each) and add them in rank order: the same
+// polynomial, transcript step and challenge everywhere.
+int atlas_rt_batched_set_shard(atlas_batched_t b, atlas_shard_group_t sh) {
+    if (!b) return fail(ATLAS_EINVAL, "batched_set_shard");
+    b->shard = sh;
+    return ATLAS_OK;
+}
+int atlas_rt_batched_add_remote(atlas_batched_t b, size_t rounds, const atlas_fr_t* input_claim) {
+    if (!b || !input_claim) return fail(ATLAS_EINVAL, "batched_add_remote");
+    Instance I; I.inst = nullptr; I.owned = false; std::memcpy(&I.input_claim, input_claim, 32); I.rounds = rounds; I.remote = true;
+    b->inst.push_back(I);
+    return ATLAS_OK;
+}
+// sum over the ranks of a batched round polynomial; its length is the longest any rank holds (the reference's sum keeps the longest term)
+static int shard_sum_poly(atlas_shard_group* sh, std::vector<H::Fr>& batched) {
+    constexpr size_t MAXC = 8;
+    if (batched.size() > MAXC) return fail(ATLAS_EINVAL, "batched_prove (sharded): more than 8 coefficients");
+    struct Rec { uint64_t len; uint64_t pad[3]; H::Fr c[MAXC]; } mine{};
+    mine.len = batched.size();
+    for (size_t k = 0; k < batched.size(); k++) mine.c[k] = batched[k];
+    for (size_t k = batched.size(); k < MAXC; k++) mine.c[k] = H::zero();
+    std::vector<Rec> all((size_t)sh->world);
+    if (!sh->allgather(&mine, sizeof(Rec), all.data())) return fail(ATLAS_ENODEV, "batched_prove (sharded): a rank did not answer");
+    size_t len = 0;
+    for (auto& r : all) len = r.len > len ? (size_t)r.len : len;
+    batched.assign(len, H::zero());
+    for (auto& r : all) for (size_t k = 0; k < len; k++) batched[k] = H::add(batched[k], r.c[k]);
+    return ATLAS_OK;
+}
 
 static int add_instance(atlas_batched_t b, atlas_instance* inst, bool owned, const atlas_fr_t* input_claim) {
     Instance I; I.inst = inst; I.owned = owned; std::memcpy(&I.input_claim, input_claim, 32); I.rounds = inst->rounds();
@@ -448,8 +486,8 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
     bool piped = false;
     {
         std::vector<atlas_instance*> v;
-        for (auto& I : b->inst) v.push_back(I.inst);
-        piped = all_pipelined(v);
+        for (auto& I : b->inst) if (!I.remote) v.push_back(I.inst);
+        piped = !b->shard && all_pipelined(v);       // (a split batch is stepped by the host: its rounds cross the board)
     }
     std::unique_lock<atlas_rt::Mutex> pipe_lock(rt().mu, std::defer_lock);
     if (piped) {
@@ -469,7 +507,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
     H::HostThreads* HT = (!piped && n >= 1024) ? &H::HostThreads::get() : nullptr;
     if (HT && HT->threads() < 2) HT = nullptr;
     std::vector<uint8_t> par(n, 0);
-    if (HT) for (size_t i = 0; i < n; i++) par[i] = b->inst[i].inst->host_parallel() ? 1 : 0;
+    if (HT) for (size_t i = 0; i < n; i++) par[i] = !b->inst[i].remote && b->inst[i].inst->host_parallel() ? 1 : 0;
     double tt[6] = {0, 0, 0, 0, 0, 0};                   // ATLAS_TRACE: message serial / parallel, combine + transcript, claim update, ingest serial / parallel
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -486,7 +524,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         // arithmetic on the workers, which never touch the device
         for (size_t i = 0; i < n; i++) {
             Instance& I = b->inst[i];
-            if (remaining > I.rounds) continue;                   // (its constant polynomial: with the parallel part below)
+            if (remaining > I.rounds || I.remote) continue;       // (its constant polynomial: with the parallel part below)
             if (par[i]) {
                 int rc = I.inst->shared_message_step(round - (max_rounds - I.rounds));
                 if (rc) return rc;
@@ -506,7 +544,8 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
             const atlas_rt::RtScope rt_scope(rt_owner);
             for (size_t i = lo; i < hi && rcs[part] == ATLAS_OK; i++) {
                 Instance& I = b->inst[i];
-                if (remaining > I.rounds) polys[i].assign(1, mul_pow2(I.input_claim, remaining - I.rounds - 1));
+                if (I.remote) polys[i].assign(1, H::zero());
+                else if (remaining > I.rounds) polys[i].assign(1, mul_pow2(I.input_claim, remaining - I.rounds - 1));
                 else if (par[i]) rcs[part] = I.inst->message(round - (max_rounds - I.rounds), claim[i], polys[i]);
             }
         });
@@ -537,6 +576,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
                 if (k < batched.size()) batched[k] = H::add(batched[k], acc[k]);
                 else batched.push_back(acc[k]);
             }
+        if (b->shard) { const int rc = shard_sum_poly(b->shard, batched); if (rc) return rc; }
         std::vector<H::Fr> cc;
         if (batched.size() < 2) cc = batched;
         else { cc.push_back(batched[0]); for (size_t k = 2; k < batched.size(); k++) cc.push_back(batched[k]); }
@@ -556,7 +596,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         // ingest_challenge, in the same steps
         for (size_t i = 0; i < n; i++) {
             Instance& I = b->inst[i];
-            if (remaining > I.rounds) continue;
+            if (remaining > I.rounds || I.remote) continue;
             if (par[i]) {
                 int rc = I.inst->shared_ingest_step(challenges[round], round - (max_rounds - I.rounds));
                 if (rc) return rc;
@@ -590,7 +630,8 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         std::vector<std::vector<H::Fr>> polys(n);
         for (size_t i = 0; i < n; i++) {
             Instance& I = b->inst[i];
-            if (remaining > I.rounds) {
+            if (I.remote) polys[i] = {H::zero()};
+            else if (remaining > I.rounds) {
                 // constant polynomial, from_coeff (a zero claim stays [0])
                 polys[i] = {mul_pow2(I.input_claim, remaining - I.rounds - 1)};
             } else if (piped) {
@@ -622,6 +663,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
                 else batched.push_back(t[k]);
             }
         }
+        if (b->shard) { const int rc = shard_sum_poly(b->shard, batched); if (rc) return rc; }
         // compress (unipoly.rs:307-318) + append_to_transcript (:550-558)
         std::vector<H::Fr> cc;
         if (batched.size() < 2) cc = batched;
@@ -649,7 +691,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         if (trace) t_fs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf0).count();
         for (size_t i = 0; i < n; i++) {
             Instance& I = b->inst[i];
-            if (remaining <= I.rounds) {
+            if (remaining <= I.rounds && !I.remote) {
                 const auto ti0 = std::chrono::steady_clock::now();
                 PROF("batched_prove: ingest");
                 int rc = piped ? I.inst->host_ingest(challenges[round], round - (max_rounds - I.rounds))
@@ -677,7 +719,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
     if (trace)
         for (size_t i = 0; i < n; i++)
             fprintf(stderr, "[atlas trace] batched_prove instance %zu (%zu rounds, degree %zu): wait for sums %.3f ms, compute_message / finish %.3f ms, ingest_challenge %.3f ms\n",
-                    i, b->inst[i].rounds, b->inst[i].inst->degree(), t_wait[i], t_msg[i], t_ing[i]);
+                    i, b->inst[i].rounds, b->inst[i].remote ? (size_t)0 : b->inst[i].inst->degree(), t_wait[i], t_msg[i], t_ing[i]);
     if (trace) fprintf(stderr, "[atlas trace] batched_prove: combine + transcript + publish %.3f ms, enqueue %.3f ms\n", t_fs, t_enq);
     if (piped) { PROF("batched_prove: collect_finals + join"); return PL.collect_finals(); }
     return ATLAS_OK;

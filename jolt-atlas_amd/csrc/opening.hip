@@ -899,6 +899,36 @@ struct OneHotPoolRow : atlas_instance {
 // BatchedSumcheck the rows will sit in (>= log_K + the largest log_T).  d_idx_rows[i] (optional) receives the device int32 index row of
 // polynomial i, alive as long as any of the instances (for build_materialized_rlc).  Internal to the library (reduced_openings.hip).
 struct atlas_rt_pool_row { const uint64_t* d_lookups; size_t shift, log_T; const atlas_fr_t* point; };
+// The int32 index rows of n one-hot polynomials cut from their device lookups, WITHOUT instances: what build_materialized_rlc needs of the
+// rows another rank of a sharded reduction steps (reduced_openings.hip).  One allocation (*d_buf, the caller's to hipFree), rows[i] inside it.
+int atlas_rt_chunk_index_rows(const atlas_rt_pool_row* in, size_t n, size_t log_K, int32_t** d_buf, const int32_t** rows) {
+    if (!in || !n || !d_buf || !rows || log_K == 0 || log_K > 4) return fail(ATLAS_EINVAL, "chunk_index_rows");
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+    std::vector<const uint64_t*> lkp(n); std::vector<uint32_t> sh(n), Ts(n); std::vector<uint64_t> off(n);
+    uint64_t total = 0; size_t maxT = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!in[i].d_lookups || in[i].log_T > 26) return fail(ATLAS_EINVAL, "chunk_index_rows: row");
+        const size_t T = (size_t)1 << in[i].log_T;
+        lkp[i] = in[i].d_lookups; sh[i] = (uint32_t)in[i].shift; Ts[i] = (uint32_t)T; off[i] = total; total += T; maxT = T > maxT ? T : maxT;
+    }
+    int32_t* buf = nullptr;
+    HIP_TRY(hipMalloc(&buf, total * sizeof(int32_t)));
+    DevBuf d_lk, d_sh, d_Ts, d_off;
+    HIP_TRY(d_lk.alloc(n * sizeof(void*))); HIP_TRY(d_sh.alloc(n * 4)); HIP_TRY(d_Ts.alloc(n * 4)); HIP_TRY(d_off.alloc(n * 8));
+    HIP_TRY(hipMemcpyAsync(d_lk.p, lkp.data(), n * sizeof(void*), hipMemcpyHostToDevice, rt().stream));
+    HIP_TRY(hipMemcpyAsync(d_sh.p, sh.data(), n * 4, hipMemcpyHostToDevice, rt().stream));
+    HIP_TRY(hipMemcpyAsync(d_Ts.p, Ts.data(), n * 4, hipMemcpyHostToDevice, rt().stream));
+    HIP_TRY(hipMemcpyAsync(d_off.p, off.data(), n * 8, hipMemcpyHostToDevice, rt().stream));
+    k_pool_chunk_rows<<<dim3(grid_for(maxT, POOL_GX), (unsigned)n), OP_THREADS, 0, rt().stream>>>(d_lk.as<const uint64_t*>(), d_sh.as<uint32_t>(), d_off.as<uint64_t>(), d_Ts.as<uint32_t>(),
+                                                                                       (uint32_t)(((size_t)1 << log_K) - 1), buf);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(rt().stream);            // (the host vectors above are the sources of the copies)
+    if (e != hipSuccess) { hipFree(buf); return fail(ATLAS_ENODEV, "chunk_index_rows", e); }
+    for (size_t i = 0; i < n; i++) rows[i] = buf + off[i];
+    *d_buf = buf;
+    return ATLAS_OK;
+}
+
 int atlas_rt_onehot_pool_new(const atlas_rt_pool_row* in, size_t n, size_t log_K, size_t batch_max_rounds, atlas_instance_t* out, const int32_t** d_idx_rows) {
     if (!in || !out || n == 0 || log_K == 0 || log_K > 4) return fail(ATLAS_EINVAL, "onehot_pool_new: 1 <= log_K <= 4");
     std::lock_guard<atlas_rt::Mutex> lk(rt().mu);

@@ -17,6 +17,7 @@
 #include "host_field.hpp"
 #include "internal.hpp"
 #include "runtime.hpp"
+#include "shard_group.hpp"
 
 namespace H = atlas_host;
 using atlas_rt::fail;
@@ -25,6 +26,9 @@ struct atlas_rt_pool_row { const uint64_t* d_lookups; size_t shift, log_T; const
 int atlas_rt_onehot_pool_new(const atlas_rt_pool_row* in, size_t n, size_t log_K, size_t batch_max_rounds, atlas_instance_t* out, const int32_t** d_idx_rows);   // opening.hip
 
 static thread_local double g_last_open_ms = 0;
+int atlas_rt_chunk_index_rows(const atlas_rt_pool_row* in, size_t n, size_t log_K, int32_t** d_buf, const int32_t** rows);      // opening.hip
+int atlas_rt_batched_set_shard(atlas_batched_t b, atlas_shard_group_t sh);                                                        // batched.hip
+int atlas_rt_batched_add_remote(atlas_batched_t b, size_t rounds, const atlas_fr_t* input_claim);
 double atlas_rt_last_hyperkzg_ms() { return g_last_open_ms; }
 
 // `sh` (may be NULL): the ranks of a sharded whole proof (atlas_prove_graph_sharded).  Every rank runs the reduction sumcheck and builds the
@@ -50,16 +54,25 @@ int atlas_rt_prove_reduced_openings(const atlas_opening_t* openings, size_t n_op
     atlas_batched_t b = nullptr;
     atlas_poly_t joint = nullptr;
     int rc = ATLAS_OK;
+    int32_t* d_remote_idx = nullptr;              // sharded: the index rows of the pool rows other ranks step (for the joint polynomial)
     auto cleanup = [&]() {
         for (auto i : inst) if (i) atlas_instance_free(i);
         if (b) atlas_batched_free(b);
         if (joint) atlas_poly_free(joint);
+        if (d_remote_idx) { std::lock_guard<atlas_rt::Mutex> lkg(atlas_rt::rt().mu); hipFree(d_remote_idx); d_remote_idx = nullptr; }
     };
     // prepare_for_sumcheck: one opening-reduction instance per committed polynomial (the dense ones work on a
     // copy: the joint polynomial needs the originals)
     // one-hot openings with the same (log_K, log_T, r_cycle) share their cycle-phase launches (EqCycleState sharing,
     // opening_proof.rs:339-343)
     std::vector<char> done(n_open, 0);
+    // A sharded whole proof (review item 4a): the members of the reduction sumcheck are split over the ranks — the pooled one-hot rows (all but
+    // a handful of the members of a transformer: 8772 of 8823 for the GPT-2-shaped graph) in contiguous shares, everything else on rank 0.
+    // owner[i] = the rank that steps member i; the others carry it as a remote member of the batch (batched.hip: atlas_rt_batched_add_remote).
+    // ATLAS_REDUCTION_REPLICATED=1: every rank steps every member, as before (A/B).
+    const int world = sh ? sh->world : 1, my_rank = sh ? sh->rank : 0;
+    const bool split = world > 1 && getenv("ATLAS_REDUCTION_REPLICATED") == nullptr;
+    std::vector<int> owner(n_open, split ? 0 : my_rank);
     // the one-hot openings over device-resident lookups with log_K <= 4 (and equal: the RaD chunk polynomials): one pool, stepped together
     // (opening.hip OneHotPool); the others (GatherRa of GatherSmall: all the dictionary's address bits in one polynomial) take the grouped path below
     std::vector<const int32_t*> pool_idx(n_open, nullptr);
@@ -75,7 +88,25 @@ int atlas_rt_prove_reduced_openings(const atlas_opening_t* openings, size_t n_op
         std::vector<atlas_rt_pool_row> rows; std::vector<size_t> where;
         for (size_t i = 0; i < n_open && pool; i++)
             if (eligible(openings[i])) { lk = openings[i].log_K; rows.push_back(atlas_rt_pool_row{openings[i].d_lookups, openings[i].chunk_shift, openings[i].log_T, openings[i].point}); where.push_back(i); }
-        if (!rows.empty()) {
+        if (!rows.empty() && split) {
+            // this rank's share of the pool: instances for it, bare index rows for the rest (the joint polynomial needs every row)
+            const size_t np = rows.size(), lo = np * (size_t)my_rank / (size_t)world, hi = np * (size_t)(my_rank + 1) / (size_t)world;
+            for (size_t q = 0; q < np; q++) { int r = 0; while (!(np * (size_t)r / (size_t)world <= q && q < np * (size_t)(r + 1) / (size_t)world)) r++; owner[where[q]] = r; }
+            std::vector<atlas_rt_pool_row> mine(rows.begin() + (ptrdiff_t)lo, rows.begin() + (ptrdiff_t)hi), rest;
+            std::vector<size_t> rest_where;
+            for (size_t q = 0; q < np; q++) if (q < lo || q >= hi) { rest.push_back(rows[q]); rest_where.push_back(where[q]); }
+            if (!mine.empty()) {
+                std::vector<atlas_instance_t> pi(mine.size(), nullptr); std::vector<const int32_t*> px(mine.size(), nullptr);
+                { PROF("reduced: onehot pool new"); rc = atlas_rt_onehot_pool_new(mine.data(), mine.size(), lk, batch_rounds, pi.data(), px.data()); }
+                for (size_t q = 0; q < mine.size() && !rc; q++) { inst[where[lo + q]] = pi[q]; pool_idx[where[lo + q]] = px[q]; }
+            }
+            if (!rc && !rest.empty()) {
+                std::vector<const int32_t*> px(rest.size(), nullptr);
+                rc = atlas_rt_chunk_index_rows(rest.data(), rest.size(), lk, &d_remote_idx, px.data());
+                for (size_t q = 0; q < rest.size() && !rc; q++) pool_idx[rest_where[q]] = px[q];
+            }
+            for (size_t q = 0; q < np; q++) done[where[q]] = 1;
+        } else if (!rows.empty()) {
             std::vector<atlas_instance_t> pi(rows.size(), nullptr); std::vector<const int32_t*> px(rows.size(), nullptr);
             { PROF("reduced: onehot pool new"); rc = atlas_rt_onehot_pool_new(rows.data(), rows.size(), lk, batch_rounds, pi.data(), px.data()); }
             for (size_t q = 0; q < rows.size() && !rc; q++) { inst[where[q]] = pi[q]; pool_idx[where[q]] = px[q]; done[where[q]] = 1; }
@@ -103,6 +134,7 @@ int atlas_rt_prove_reduced_openings(const atlas_opening_t* openings, size_t n_op
     openings = local.data();
     for (size_t i = 0; i < n_open && !rc; i++) {
         const atlas_opening_t& O = openings[i];
+        if (owner[i] != my_rank) continue;                 // (another rank steps it; the members outside the pool all belong to rank 0)
         if (O.kind == 0) {
             atlas_poly_t c = nullptr;
             if (!O.poly || (!O.point && O.n)) { rc = fail(ATLAS_EINVAL, "prove_reduced_openings: dense opening without polynomial/point"); break; }
@@ -116,7 +148,7 @@ int atlas_rt_prove_reduced_openings(const atlas_opening_t* openings, size_t n_op
         std::vector<size_t> members;
         for (size_t q = i; q < n_open; q++) {
             const atlas_opening_t& Q = openings[q];
-            if (Q.kind == 1 && !done[q] && Q.k && Q.point && Q.log_K == O.log_K && Q.log_T == O.log_T &&
+            if (Q.kind == 1 && !done[q] && owner[q] == my_rank && Q.k && Q.point && Q.log_K == O.log_K && Q.log_T == O.log_T &&
                 std::memcmp(Q.point + Q.log_K, O.point + O.log_K, O.log_T * sizeof(atlas_fr_t)) == 0)
                 members.push_back(q);
         }
@@ -133,13 +165,23 @@ int atlas_rt_prove_reduced_openings(const atlas_opening_t* openings, size_t n_op
     mark("instances (prepare)");
     // prove_batch_opening_sumcheck: BatchedSumcheck::prove over the instances (degree 2: rows of 3)
     if (!rc) rc = atlas_batched_new(&b);
-    for (size_t i = 0; i < n_open && !rc; i++) rc = atlas_batched_add_instance(b, inst[i], &openings[i].claim);
+    if (!rc && split) rc = atlas_rt_batched_set_shard(b, sh);
+    for (size_t i = 0; i < n_open && !rc; i++) {
+        const atlas_opening_t& O = openings[i];
+        rc = owner[i] == my_rank ? atlas_batched_add_instance(b, inst[i], &O.claim) : atlas_rt_batched_add_remote(b, O.kind ? O.log_K + O.log_T : O.n, &O.claim);
+    }
     if (!rc) rc = atlas_batched_prove(b, transcript, sumcheck_rows, 3, n_coeffs, challenges, max_rounds_out);
     mark("batched sumcheck");
     // cache_openings -> sumcheck_claims (opening_reduction.rs:238-246), then finalize (:611-643)
     for (size_t i = 0; i < n_open && !rc; i++) {
         size_t nf = 0;
-        rc = atlas_instance_final_claims(inst[i], &sumcheck_claims[i], 1, &nf);
+        if (owner[i] == my_rank) rc = atlas_instance_final_claims(inst[i], &sumcheck_claims[i], 1, &nf);
+        else std::memset(&sumcheck_claims[i], 0, sizeof(atlas_fr_t));
+    }
+    if (!rc && split) {                                             // every rank needs every member's final claim: its owner's record
+        std::vector<atlas_fr_t> all((size_t)world * n_open);
+        if (!sh->allgather_bulk(sumcheck_claims, n_open * sizeof(atlas_fr_t), all.data())) rc = fail(ATLAS_ENODEV, "prove_reduced_openings (sharded): a rank did not answer");
+        for (size_t i = 0; i < n_open && !rc; i++) sumcheck_claims[i] = all[(size_t)owner[i] * n_open + i];
     }
     if (rc) { cleanup(); return rc; }
     H::Transcript& T = *reinterpret_cast<H::Transcript*>(transcript);
