@@ -25,6 +25,11 @@ for d, log_T in [(16, 18), (16, 20)]:
         doc[f"ra_large2[{d}-{log_T}]"] = T._digest(*T.ra_large_oracle(d, log_T, True))
         print("ra_large2", d, log_T, flush=True)
         json.dump(doc, open(out_path, "w"), indent=0, sort_keys=True)
+for d, log_T in [(16, 18), (8, 18)]:                                  # Booleanity's lazy first rounds (test_booleanity_lazy)
+    if f"bool_lazy[{d}-{log_T}]" not in doc:
+        doc[f"bool_lazy[{d}-{log_T}]"] = T._digest(*T.bool_lazy_oracle(d, log_T))
+        print("bool_lazy", d, log_T, flush=True)
+        json.dump(doc, open(out_path, "w"), indent=0, sort_keys=True)
 for d, log_T in [(4, 15), (8, 16), (16, 15), (3, 17)]:
     if f"ra_large[{d}-{log_T}]" in doc and f"ra_large2[{d}-{log_T}]" in doc:
         continue

@@ -149,6 +149,29 @@ def bool_large_oracle(d, log_T):
     return rows_o, ch_o, t_o.state_bytes()
 
 
+def bool_lazy_inputs(d, log_T):
+    """Booleanity over DEVICE-RESIDENT lookup words (the graph prover's form): all chunks valid, d chunks of 4 bits"""
+    from oracle import orc
+    log_k = 4
+    rng = np.random.default_rng(100 + d + log_T)
+    lookups = rng.integers(0, 1 << 62, size=1 << log_T, dtype=np.uint64) | (rng.integers(0, 4, size=1 << log_T, dtype=np.uint64) << np.uint64(62))
+    if d < 16:
+        lookups &= np.uint64((1 << (4 * d)) - 1)
+    H = [((lookups >> np.uint64(log_k * (d - 1 - i))) & np.uint64(15)).astype(np.int32) for i in range(d)]
+    r_address, r_cycle = orc.random_fr(log_k, 17), orc.random_fr(log_T, 18)
+    gammas = orc.random_fr(d, 19)
+    return log_k, lookups, H, r_address, r_cycle, gammas
+
+
+def bool_lazy_oracle(d, log_T):
+    from oracle import orc, orc_ra as OR
+    log_k, lookups, H, r_address, r_cycle, gammas = bool_lazy_inputs(d, log_T)
+    G = OR.ra_G(H, log_k, r_cycle)
+    t_o = orc.new_transcript(b"bool_lazy")
+    rows_o, ch_o = OR.booleanity(G, H, log_k, gammas, r_address, r_cycle).prove(orc.fr_array(1)[0], t_o)
+    return rows_o, ch_o, t_o.state_bytes()
+
+
 def _indices(d, T, K, seed, none_frac=0.02):
     rng = np.random.default_rng(seed)
     out = []
@@ -224,6 +247,25 @@ def test_booleanity_large(atlas, d, log_T):
     rows_g, ch_g = inst.prove(orc.fr_array(1)[0], t_g)
     assert _digest(rows_g, ch_g, t_g.state) == want
     inst.free()
+
+
+@pytest.mark.parametrize("d,log_T", [(16, 18), (8, 18)])
+def test_booleanity_lazy(atlas, d, log_T):
+    """Booleanity from device-resident lookup words at T >= 2^18 (csrc/ra.hip: Booleanity::lazy): the first cycle round from two tables of
+    gamma_i F[a] (F[a] - 1) and gamma_i (F[b] - F[a])^2, the second round's rows straight from the words — no gathered rows.  The digest of the
+    oracle's proof over the same chunk rows (tests/golden/full_size_oracle.json) and the final claims against the oracle's evaluation."""
+    from oracle import orc, orc_ra as OR
+    from jolt_atlas_amd import instances as I
+    A = atlas
+    log_k, lookups, H, r_address, r_cycle, gammas = bool_lazy_inputs(d, log_T)
+    want = _oracle_digest(f"bool_lazy[{d}-{log_T}]", lambda: bool_lazy_oracle(d, log_T))
+    G = OR.ra_G(H, log_k, r_cycle)
+    dev = I.DeviceU64.upload(lookups)
+    inst = I.booleanity_from_lookups(G, dev, log_k * d, log_k, gammas, r_address, r_cycle)
+    t_g = A.Blake2bTranscript(b"bool_lazy")
+    rows_g, ch_g = inst.prove(orc.fr_array(1)[0], t_g)
+    assert _digest(rows_g, ch_g, t_g.state) == want
+    inst.free(); dev.free()
 
 
 def test_openings_large(atlas):
