@@ -911,8 +911,9 @@ int atlas_rt_chunk_index_rows(const atlas_rt_pool_row* in, size_t n, size_t log_
         const size_t T = (size_t)1 << in[i].log_T;
         lkp[i] = in[i].d_lookups; sh[i] = (uint32_t)in[i].shift; Ts[i] = (uint32_t)T; off[i] = total; total += T; maxT = T > maxT ? T : maxT;
     }
-    int32_t* buf = nullptr;
-    HIP_TRY(hipMalloc(&buf, total * sizeof(int32_t)));
+    DevBuf bufh;                                    // (released to the caller on success; an early return gives it back)
+    HIP_TRY(bufh.alloc(total * sizeof(int32_t)));
+    int32_t* buf = bufh.as<int32_t>();
     DevBuf d_lk, d_sh, d_Ts, d_off;
     HIP_TRY(d_lk.alloc(n * sizeof(void*))); HIP_TRY(d_sh.alloc(n * 4)); HIP_TRY(d_Ts.alloc(n * 4)); HIP_TRY(d_off.alloc(n * 8));
     HIP_TRY(hipMemcpyAsync(d_lk.p, lkp.data(), n * sizeof(void*), hipMemcpyHostToDevice, rt().stream));
@@ -923,9 +924,9 @@ int atlas_rt_chunk_index_rows(const atlas_rt_pool_row* in, size_t n, size_t log_
                                                                                        (uint32_t)(((size_t)1 << log_K) - 1), buf);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(rt().stream);            // (the host vectors above are the sources of the copies)
-    if (e != hipSuccess) { hipFree(buf); return fail(ATLAS_ENODEV, "chunk_index_rows", e); }
+    if (e != hipSuccess) return fail(ATLAS_ENODEV, "chunk_index_rows", e);
     for (size_t i = 0; i < n; i++) rows[i] = buf + off[i];
-    *d_buf = buf;
+    *d_buf = static_cast<int32_t*>(bufh.release());
     return ATLAS_OK;
 }
 
