@@ -244,3 +244,67 @@ def test_softmax_over_one_element_is_refused_by_name(atlas, builder):
             G.trace(inputs)
         finally:
             G.free()
+
+
+def random_one_cycle_graph(seed):
+    """the seeded draw over the one-cycle gathers and one-row softmaxes (review item 8): a gather of ONE index from a dictionary of 2..256 words of
+    1..8 elements (GatherSmall or GatherLarge), or SoftmaxLastAxis over ONE row of 2..16 elements, followed by an Add of a constant"""
+    rng = np.random.default_rng(1000 + seed)
+    if rng.random() < 0.6:
+        op = str(rng.choice(["GatherSmall", "GatherLarge"]))
+        V = int(2 ** rng.integers(1, 9)); word = int(2 ** rng.integers(0, 4))
+        if op == "GatherLarge" and V < 16:
+            V = 16
+        idx = int(rng.integers(0, V))
+        nodes = [{"idx": 0, "op": "Input", "inputs": [], "dims": [1]},
+                 {"idx": 1, "op": "Constant", "inputs": [], "dims": [V, word], "data": rng.integers(-(1 << 14), 1 << 14, size=V * word).astype(np.int32)},
+                 {"idx": 2, "op": op, "inputs": [1, 0], "dims": [1, word], "axis": 0, "dict_len": V}]
+        inputs = [np.array([idx], dtype=np.int32)]
+        width = word
+    else:
+        N = int(2 ** rng.integers(1, 5))
+        nodes = [{"idx": 0, "op": "Input", "inputs": [], "dims": [1, N]},
+                 {"idx": 1, "op": "SoftmaxLastAxis", "inputs": [0], "dims": [1, N], "scale": 14}]
+        inputs = [rng.integers(-(1 << 15), 1 << 15, size=N).astype(np.int32)]
+        width = N
+    last = nodes[-1]["idx"]
+    if width == 1:
+        nodes += [{"idx": last + 1, "op": "Broadcast", "inputs": [last], "dims": [1, 2]}]
+        last, width = last + 1, 2
+    nodes += [{"idx": last + 1, "op": "Constant", "inputs": [], "dims": [1, width], "data": rng.integers(-9, 9, size=width).astype(np.int32)},
+              {"idx": last + 2, "op": "Add", "inputs": [last, last + 1], "dims": [1, width]}]
+    return nodes, [last + 2], inputs
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_one_cycle_graph(atlas, seed):
+    from oracle import graph as OG, orc
+    from jolt_atlas_amd import graph as GG
+    nodes, outputs, inputs = random_one_cycle_graph(seed)
+    tau = orc.random_fr(1, 0x51250001)[0]
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import build_graphs as BG
+    nv = max(BG.max_vars(nodes), 8)
+    srs_h = orc.srs_powers(tau, 1 << nv)
+    srs = atlas.SRS.generate(tau, 1 << nv)
+    vk = atlas.HyperKZG.vk_from_trapdoor(tau, srs.download(0, 1)[0])
+    P = OG.Prover(nodes, outputs, srs_h)
+    want = P.prove(inputs)
+    G = GG.Graph(nodes, outputs)
+    try:
+        got, state, _ = G.prove(srs, inputs)
+        for nd in nodes:
+            assert np.array_equal(G.node_output(nd["idx"]), P.trace[nd["idx"]]), f"trace of node {nd['idx']} ({nd['op']})"
+        assert state == P.t.state() and got == want, [n["op"] for n in nodes]
+        out = G.node_output(outputs[0])
+        V = GG.Graph(nodes, outputs)
+        try:
+            ok, vstate = V.verify(vk, inputs, out, got)
+            assert ok and vstate == state
+            flipped = bytearray(got); flipped[len(flipped) // 2] ^= 1
+            assert not V.verify(vk, inputs, out, bytes(flipped))[0]
+        finally:
+            V.free()
+    finally:
+        G.free(); srs.free()
