@@ -304,7 +304,11 @@ int atlas_ra_virtual_new(const int32_t *const *H_indices, size_t d, size_t log_k
                          atlas_instance_t *out);
 /* The same provers straight from the T lookup indices: the d = ceil(log_K / log_k_chunk) chunk rows
  * (compute_instruction_h_indices, shout.rs:532-547; OneHotParams::lookup_index_chunk, config.rs:73-75) are cut
- * on the device and r_address (log_K Fr) is split by compute_r_address_chunks (config.rs:77-100). */
+ * on the device and r_address (log_K Fr) is split by compute_r_address_chunks (config.rs:77-100).
+ * LIFETIME: lookup_indices may be a host or a device pointer.  A host vector is copied by the call.  A DEVICE vector is
+ * BORROWED — the instance reads it in place during its proof (the row gather of Booleanity's first cycle round, the lazy
+ * rounds of both provers), not at construction — so it must stay allocated and unchanged until atlas_instance_free of
+ * every instance built over it (the graph prover passes the node's witness vectors, which outlive the node's flow). */
 int atlas_ra_virtual_from_lookups_new(const uint64_t *lookup_indices, size_t log_T, size_t log_K, size_t log_k_chunk,
                                       const atlas_fr_t *r_address, const atlas_fr_t *r_cycle, atlas_instance_t *out);
 int atlas_booleanity_from_lookups_new(const atlas_fr_t *G, const uint64_t *lookup_indices, size_t log_T, size_t log_K,
@@ -657,6 +661,21 @@ int atlas_fr_sum(const atlas_fr_t *v, size_t n, atlas_fr_t *out);               
 typedef struct atlas_shard_group *atlas_shard_group_t;
 int atlas_shard_group_open(const char *name, int world, int rank, atlas_shard_group_t *out);
 int atlas_shard_group_close(atlas_shard_group_t grp);
+/* The board's failure handshake.  A rank whose part of a sharded call fails calls atlas_shard_fail_exchange(grp, code) INSTEAD of the
+ * exchange the other ranks are about to make (the sharded entry points of this library do so themselves): the others' exchange returns
+ * ATLAS_ENODEV at once instead of after the board's timeout, atlas_shard_remote_failed tells them which rank gave up and why (rank -1:
+ * nobody did — the exchange timed out), and every rank has made the same number of exchanges, so the group stays usable. */
+int atlas_shard_fail_exchange(atlas_shard_group_t grp, int code);
+int atlas_shard_remote_failed(atlas_shard_group_t grp, int *rank, int *code);
+/* How long a wait may last before a proof is given up, in seconds (<= 0 keeps a setting; defaults 2 / 10 / 30, or ATLAS_DEVICE_WAIT_S /
+ * ATLAS_HOST_WAIT_S / ATLAS_BOARD_WAIT_S at atlas_init / atlas_shard_group_open):
+ *   device_wait_s  a launch's wait for a round's challenge (a RUNTIME word next to the channel's abort flag, read by every polling launch);
+ *   host_wait_s    the proving thread's wait for the sums / tables a launch mails;
+ *   board_wait_s   a rank's wait for the other ranks' records (groups opened afterwards).
+ * The first two belong to the calling thread's runtime.  A device shared by several ranks' processes (time-sliced) needs more than the
+ * defaults: atlas_prove_graph_sharded multiplies the first two by its world size for the length of the call. */
+int atlas_set_timeouts(double device_wait_s, double host_wait_s, double board_wait_s);
+int atlas_get_timeouts(double *device_wait_s, double *host_wait_s, double *board_wait_s);
 /* HyperKZG::open (hyperkzg/mod.rs:400-447) with its commitments split by point range over the group's ranks: every rank
  * passes the whole polynomial and its copy of the SRS, runs the same transcript and returns the same HyperKZGProof as atlas_hyperkzg_open
  * (same bytes); the MSMs — Pi_1.. and the three witness polynomials, ~95 % of the open — are 1/world each, two exchanges of partial points. */

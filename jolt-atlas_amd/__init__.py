@@ -96,6 +96,18 @@ def device_count():
     return lib.atlas_device_count()
 
 
+def set_timeouts(device_wait_s=0.0, host_wait_s=0.0, board_wait_s=0.0):
+    """atlas_set_timeouts: how long a launch waits for a challenge / the host for mail / a rank for the board, in seconds (0 keeps a setting)"""
+    lib.atlas_set_timeouts.argtypes = [C.c_double, C.c_double, C.c_double]
+    _check(lib.atlas_set_timeouts(device_wait_s, host_wait_s, board_wait_s))
+
+
+def get_timeouts():
+    d, h, b = C.c_double(), C.c_double(), C.c_double()
+    _check(lib.atlas_get_timeouts(C.byref(d), C.byref(h), C.byref(b)))
+    return d.value, h.value, b.value
+
+
 def set_challenge_mode(mode):
     _check(lib.atlas_set_challenge_mode(C.c_int(mode)))
 

@@ -189,6 +189,23 @@ int atlas_sync(void) {
     return ATLAS_OK;
 }
 
+// How long the waits of the round channel and of the shard board may last (include/atlas_hip.h).  A value <= 0 keeps the setting.
+static double g_board_wait_s = 30.0;
+int atlas_set_timeouts(double device_wait_s, double host_wait_s, double board_wait_s) {
+    NEED_INIT();
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+    if (host_wait_s > 0) rt().chan.host_wait_s = host_wait_s;
+    if (board_wait_s > 0) g_board_wait_s = board_wait_s;
+    if (device_wait_s > 0) { HIP_TRY(hipStreamSynchronize(rt().stream)); HIP_TRY(rt().chan.set_device_timeout(device_wait_s, rt().stream)); }
+    return ATLAS_OK;
+}
+int atlas_get_timeouts(double* device_wait_s, double* host_wait_s, double* board_wait_s) {
+    if (device_wait_s) *device_wait_s = rt().chan.device_wait_s;
+    if (host_wait_s) *host_wait_s = rt().chan.host_wait_s;
+    if (board_wait_s) *board_wait_s = g_board_wait_s;
+    return ATLAS_OK;
+}
+
 int atlas_set_challenge_mode(int mode) {
     if (mode != 0 && mode != 1) return fail(ATLAS_EINVAL, "challenge mode must be 0 or 1");
     rt().challenge_mode = mode;
@@ -1172,7 +1189,21 @@ int atlas_shard_group_open(const char* name, int world, int rank, atlas_shard_gr
         return fail(ATLAS_EINVAL, "shard_group_open: world must be a power of two <= 64, 0 <= rank < world");
     atlas_shard_group* g_ = new atlas_shard_group();
     if (!g_->open(name, world, rank)) { g_->close(); delete g_; return fail(ATLAS_ENODEV, "shard_group_open: shared-memory board not available (shm_open / peers missing)"); }
+    if (const char* v = getenv("ATLAS_BOARD_WAIT_S")) { const double x = atof(v); if (x > 0) g_board_wait_s = x; }
+    g_->timeout_s_default = g_board_wait_s;
     *out = g_;
+    return ATLAS_OK;
+}
+// the failure handshake of the board (shard_group.hpp): a rank that gives up on a sharded call marks the exchange the others are about to make
+int atlas_shard_fail_exchange(atlas_shard_group_t grp, int code) {
+    if (!grp) return fail(ATLAS_EINVAL, "shard_fail_exchange: null group");
+    grp->fail_exchange((uint64_t)(uint32_t)code);
+    return ATLAS_OK;
+}
+// after an exchange returned an error: *rank = the rank that had given up (-1: none — a timeout), *code = what it passed
+int atlas_shard_remote_failed(atlas_shard_group_t grp, int* rank, int* code) {
+    if (!grp || !rank || !code) return fail(ATLAS_EINVAL, "shard_remote_failed: null argument");
+    *rank = grp->remote_failed; *code = (int)(uint32_t)grp->remote_code;
     return ATLAS_OK;
 }
 int atlas_shard_group_close(atlas_shard_group_t grp) {
@@ -1181,7 +1212,7 @@ int atlas_shard_group_close(atlas_shard_group_t grp) {
 }
 int atlas_shard_allgather(atlas_shard_group_t grp, const void* mine, size_t n_bytes, void* all) {
     if (!grp || !mine || !all || n_bytes == 0 || n_bytes > atlas_shard_group::PAYLOAD) return fail(ATLAS_EINVAL, "shard_allgather: 1 .. 496 bytes per rank");
-    if (!grp->allgather(mine, n_bytes, all)) return fail(ATLAS_ENODEV, "shard_allgather: a rank did not answer");
+    if (!grp->allgather(mine, n_bytes, all)) return fail(ATLAS_ENODEV, grp->remote_failed >= 0 ? "shard_allgather: another rank gave up on the call (atlas_shard_remote_failed)" : "shard_allgather: a rank did not answer");
     return ATLAS_OK;
 }
 int atlas_sumcheck_prove_dot_sharded(atlas_dot_prover_t P, atlas_shard_group_t grp, const atlas_fr_t* input_claim, atlas_transcript_t* transcript,

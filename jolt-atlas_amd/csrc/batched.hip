@@ -273,7 +273,8 @@ static int shard_sum_poly(atlas_shard_group* sh, std::vector<H::Fr>& batched) {
     for (size_t k = 0; k < batched.size(); k++) mine.c[k] = batched[k];
     for (size_t k = batched.size(); k < MAXC; k++) mine.c[k] = H::zero();
     std::vector<Rec> all((size_t)sh->world);
-    if (!sh->allgather(&mine, sizeof(Rec), all.data())) return fail(ATLAS_ENODEV, "batched_prove (sharded): a rank did not answer");
+    if (!sh->allgather(&mine, sizeof(Rec), all.data()))
+        return fail(ATLAS_ENODEV, sh->remote_failed >= 0 ? "batched_prove (sharded): another rank gave up (its members failed)" : "batched_prove (sharded): a rank did not answer");
     size_t len = 0;
     for (auto& r : all) len = r.len > len ? (size_t)r.len : len;
     batched.assign(len, H::zero());

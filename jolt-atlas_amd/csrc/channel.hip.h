@@ -19,7 +19,8 @@
 //     challenge 45 us late); one shared HBM copy (0.45 us per waiting workgroup: the uncached reads of
 //     255 pollers queue on one memory channel).
 // Tags are a 32-bit counter that never repeats within a process, so slots can be reused without
-// clearing.  A wait gives up after CH_TIMEOUT_TICKS (2 s) or when the abort word is set; the host
+// clearing.  A wait gives up after the channel's device timeout (2 s by default; a RUNTIME setting — atlas_set_timeouts,
+// ATLAS_DEVICE_WAIT_S — kept next to the abort word in HBM, ch_timeout_ticks) or when the abort word is set; the host
 // publishes an abort record on its own error paths, so a failed call cannot leave a kernel spinning.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -49,7 +50,14 @@ constexpr uint32_t CH_SLOT_CHUNKS = 4;                  // chunks per host chall
 constexpr uint32_t CH_REPLICA_CHUNKS = 4;               // one 64-byte line per replica
 constexpr uint32_t CH_MAX_REPLICAS = 256;
 
-constexpr uint64_t CH_TIMEOUT_TICKS = 200000000ull;      // s_memrealtime runs at 100 MHz
+constexpr uint64_t CH_TIMEOUT_TICKS = 200000000ull;      // the DEFAULT: 2 s of s_memrealtime's 100 MHz
+// The abort area (RoundIo::abort_flag, 64 bytes of HBM): word 0 = the abort flag, bytes 8..15 = how many ticks a wait may last.  An
+// oversubscribed or time-sliced device (several ranks' processes on ONE GPU) needs more than the default; the host writes it
+// (Channel::set_device_timeout) before the launches that read it.
+__device__ __forceinline__ uint64_t ch_timeout_ticks(const uint32_t* abort_flag) {
+    const uint64_t t = *reinterpret_cast<const volatile uint64_t*>(abort_flag + 2);
+    return t ? t : CH_TIMEOUT_TICKS;
+}
 
 typedef uint32_t ch_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -73,7 +81,7 @@ __device__ __forceinline__ ch_u32x4 ch_load_sys(const void* p) {
 // One polling thread.  Returns false on abort / timeout.
 template <bool FROM_HOST = true>
 __device__ __forceinline__ bool ch_poll_slot(const Chunk* slot, uint32_t tag_r, uint32_t* abort_flag, uint64_t& lo, uint64_t& hi) {
-    const uint64_t t0 = wall_clock64();
+    const uint64_t t0 = wall_clock64(), t_max = ch_timeout_ticks(abort_flag);
     ch_u32x4 a, b;
     uint32_t spins = 0;
     for (;;) {
@@ -82,7 +90,7 @@ __device__ __forceinline__ bool ch_poll_slot(const Chunk* slot, uint32_t tag_r, 
         if (a.w == tag_r && b.w == tag_r) break;
         if ((++spins & 63u) == 0) {
             if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-            if (wall_clock64() - t0 > CH_TIMEOUT_TICKS) {
+            if (wall_clock64() - t0 > t_max) {
                 __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return false;
             }

@@ -7,6 +7,7 @@
 
 #include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #include "channel.hip.h"
@@ -28,6 +29,18 @@ struct Channel {
     uint32_t next_tag = 1;
     size_t next_chunk = 0, next_slot = 0;
     bool abort_dirty = false;
+    // how long a wait may last before the proof is given up: the host's waits for mail (and for tables a launch publishes) and the device's
+    // waits for a challenge.  Runtime settings (atlas_set_timeouts; ATLAS_HOST_WAIT_S / ATLAS_DEVICE_WAIT_S at init): a time-sliced device
+    // — several ranks' processes sharing ONE GPU — needs more than the defaults, and atlas_prove_graph_sharded scales them with its world.
+    double host_wait_s = 10.0, device_wait_s = 2.0;
+    hipError_t set_device_timeout(double s, hipStream_t st = nullptr) {
+        if (s > 0) device_wait_s = s;
+        if (!d_abort) return hipSuccess;
+        const uint64_t ticks = (uint64_t)(device_wait_s * 1e8);
+        hipError_t e = hipMemcpyAsync(reinterpret_cast<char*>(d_abort) + 8, &ticks, 8, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        return e;
+    }
 
     hipError_t init() {
         // fine-grained (coherent) whatever HIP_HOST_COHERENT says: the device polls these lines while the host writes them
@@ -40,6 +53,9 @@ struct Channel {
         std::memset(rslots, 0, RING * SLOT_CHUNKS * sizeof(atlas::Chunk));
         e = hipMemset(d_rslots, 0, RING * DEV_SLOT_CHUNKS * sizeof(atlas::Chunk));
         if (e == hipSuccess) e = hipMemset(d_abort, 0, 64);
+        if (const char* v = getenv("ATLAS_HOST_WAIT_S")) { const double x = atof(v); if (x > 0) host_wait_s = x; }
+        if (const char* v = getenv("ATLAS_DEVICE_WAIT_S")) { const double x = atof(v); if (x > 0) device_wait_s = x; }
+        if (e == hipSuccess) e = set_device_timeout(0);
         return e;
     }
     void release() {
@@ -107,7 +123,8 @@ struct Channel {
 
     // device -> host: wait for n_blocks * n_vals records tagged `tag` and add word w of the k-th value of every
     // workgroup into acc[k][w].  false on timeout (the device is gone or a kernel gave up).
-    bool collect(const atlas::Chunk* base, uint32_t tag, size_t n_blocks, int n_vals, uint64_t (*acc)[9], double timeout_s = 10.0) {
+    bool collect(const atlas::Chunk* base, uint32_t tag, size_t n_blocks, int n_vals, uint64_t (*acc)[9]) {
+        const double timeout_s = host_wait_s;
         for (int k = 0; k < n_vals; k++) for (int w = 0; w < 9; w++) acc[k][w] = 0;
         const size_t stride = atlas::ch_stride((uint32_t)n_vals);
         for (size_t b = 0; b < n_blocks; b++) {
@@ -123,7 +140,8 @@ struct Channel {
         return true;
     }
     // single records (final claims, ...): raw 9 words each
-    bool collect_raw(const atlas::Chunk* base, uint32_t tag, size_t n_rec, uint32_t (*out)[9], double timeout_s = 10.0) {
+    bool collect_raw(const atlas::Chunk* base, uint32_t tag, size_t n_rec, uint32_t (*out)[9]) {
+        const double timeout_s = host_wait_s;
         const volatile atlas::Chunk* c = base;
         for (size_t r = 0; r < n_rec; r++)
             for (int j = 0; j < 3; j++, c++) {

@@ -153,12 +153,17 @@ __global__ __launch_bounds__(256) void k_fill_i32(int32_t* p, size_t n, int32_t 
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
 }
 // Gather along axis 0 (ops/gather.rs): out[j][w] = dict[idx[j]][w]
-__global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__ dict, const int32_t* __restrict__ idx, size_t n_idx, size_t word, int32_t* __restrict__ out,
-                                                     uint64_t* __restrict__ lookups) {
+// An index outside [0, V) — the reference's tensor indexing panics on it — raises *err (the trace fails after its last launch) and reads row 0
+// instead of memory outside the dictionary.
+__global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__ dict, const int32_t* __restrict__ idx, size_t n_idx, size_t word, size_t V, int32_t* __restrict__ out,
+                                                     uint64_t* __restrict__ lookups, uint32_t* __restrict__ err) {
     for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < n_idx * word; o += (size_t)gridDim.x * 256) {
         const size_t j = o / word, w = o % word;
-        out[o] = dict[(size_t)idx[j] * word + w];
-        if (w == 0) lookups[j] = (uint64_t)(uint32_t)idx[j];
+        const int32_t k = idx[j];
+        const bool ok = k >= 0 && (size_t)k < V;
+        if (!ok && w == 0) atomicOr(err, 1u);
+        out[o] = dict[(size_t)(ok ? k : 0) * word + w];
+        if (w == 0) lookups[j] = ok ? (uint64_t)(uint32_t)k : 0;
     }
 }
 
@@ -703,7 +708,8 @@ int exec_node(atlas_graph& G, const Node& nd, const int32_t* const* host_inputs,
             if (nd.op == ATLAS_OP_GATHER_SMALL && (V > 65536 || V < 2)) return fail(ATLAS_EINVAL, "graph: GatherSmall is the tracer's choice for dictionaries of at most 2^16 words (handlers/index.rs:33-45)");
             NodeWitness& W = G.wit[nd.idx];
             HIP_TRY(W.lookups.alloc(N * 8));
-            k_gather_rows<<<grid_for(T), 256, 0, rt().stream>>>(in(0), in(1), N, word, out.as<int32_t>(), W.lookups.as<uint64_t>());
+            if (!G.trace_err.p) { HIP_TRY(G.trace_err.alloc(4)); HIP_TRY(hipMemsetAsync(G.trace_err.p, 0, 4, rt().stream)); }
+            k_gather_rows<<<grid_for(T), 256, 0, rt().stream>>>(in(0), in(1), N, word, V, out.as<int32_t>(), W.lookups.as<uint64_t>(), G.trace_err.as<uint32_t>());
             return ATLAS_OK;
         }
         case ATLAS_OP_SOFTMAX: {                                              // SoftmaxLastAxis { scale }: rows = the leading dimensions, N = the last one
@@ -781,10 +787,19 @@ int atlas_graph_trace(atlas_graph_t G, const int32_t* const* inputs, size_t n_in
     if (n_inputs != G->input_nodes().size()) return fail(ATLAS_EINVAL, "graph_trace: one tensor per Input node expected");
     for (size_t i = 0; i < n_inputs; i++) if (!inputs[i]) return fail(ATLAS_EINVAL, "graph_trace: null input tensor");
     G->clear_trace_keep_constants();
+    G->trace_err.free();
     size_t next = 0;
     for (auto& kv : G->nodes) {
         int rc = exec_node(*G, kv.second, inputs, next);
         if (rc) { G->clear_trace(); return rc; }
+    }
+    if (G->trace_err.p) {                          // a Gather ran: did every index name a row of its dictionary?  (one word back, one wait)
+        uint32_t bad = 0;
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+        hipError_t e = hipMemcpyAsync(&bad, G->trace_err.p, 4, hipMemcpyDeviceToHost, rt().stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(rt().stream);
+        if (e != hipSuccess) { G->clear_trace(); return fail(ATLAS_ENODEV, "graph_trace: reading the gather range flag", e); }
+        if (bad) { G->clear_trace(); return fail(ATLAS_EINVAL, "graph_trace: a Gather index lies outside its dictionary (the reference's tensor indexing panics)"); }
     }
     G->traced = true;
     return ATLAS_OK;

@@ -189,6 +189,7 @@ struct Prover : FlowSink {
                 if (hipMemcpyAsync(lk, d_lookups, 8, hipMemcpyDeviceToHost, rt().stream) != hipSuccess || hipStreamSynchronize(rt().stream) != hipSuccess) drc = fail(ATLAS_ENODEV, "prove_graph: lookup index of a one-element node");
             };
             auto one_cycle_row = [&](gr::PolyId id, size_t hot, size_t width) {
+                if (hot >= width) { drc = fail(ATLAS_EINVAL, "prove_graph: the lookup index of a one-element node lies outside its table"); return; }
                 std::vector<int32_t> row(width, 0);
                 row[hot] = 1;
                 W.one_cycle_rows.emplace_back(new DevBuf());
@@ -1723,5 +1724,34 @@ extern "C" int atlas_prove_graph(atlas_graph_t G, atlas_srs_t srs, const int32_t
 extern "C" int atlas_prove_graph_sharded(atlas_graph_t G, atlas_srs_t srs, atlas_shard_group_t grp, const int32_t* const* inputs, size_t n_inputs, uint8_t* proof,
                                          size_t cap, size_t* proof_len, atlas_transcript_t* final_transcript, atlas_graph_timing_t* timing) {
     if (!grp) return fail(ATLAS_EINVAL, "prove_graph_sharded: null group");
-    return prove_graph_impl(G, srs, grp, inputs, n_inputs, proof, cap, proof_len, final_transcript, timing);
+    // the channel's waits scaled with the world for the length of the call: N ranks' processes may share ONE device (the test box), where a
+    // launch waits for its challenge through the other ranks' time slices
+    const double dev_wait = rt().chan.device_wait_s, host_wait = rt().chan.host_wait_s;
+    if (grp->world > 1 && rt().ready) {
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+        rt().chan.host_wait_s = host_wait * grp->world;
+        (void)hipStreamSynchronize(rt().stream);
+        (void)rt().chan.set_device_timeout(dev_wait * grp->world, rt().stream);
+    }
+    int rc = prove_graph_impl(G, srs, grp, inputs, n_inputs, proof, cap, proof_len, final_transcript, timing);
+    if (grp->world > 1 && rt().ready) {
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+        rt().chan.host_wait_s = host_wait;
+        (void)hipStreamSynchronize(rt().stream);
+        (void)rt().chan.set_device_timeout(dev_wait, rt().stream);
+    }
+    if (grp->world > 1) {
+        // The failure handshake (shard_group.hpp): a rank whose part failed for a reason of its own — not because another rank said so —
+        // marks the exchange the others are about to make, so that nobody waits for the board's timeout and the exchange numbers stay equal;
+        // a proof that succeeded here ends with one status exchange, which is where a failure after the last data exchange is learnt.
+        if (rc) { if (grp->remote_failed < 0) grp->fail_exchange((uint64_t)(uint32_t)rc); }
+        else {
+            uint64_t ok = 0;
+            std::vector<uint64_t> all((size_t)grp->world);
+            if (!grp->allgather(&ok, sizeof(ok), all.data()))
+                rc = grp->remote_failed >= 0 ? fail((int)(uint32_t)grp->remote_code ? (int)(uint32_t)grp->remote_code : ATLAS_ENODEV, "prove_graph_sharded: another rank's proof failed")
+                                             : fail(ATLAS_ENODEV, "prove_graph_sharded: a rank did not answer (final status)");
+        }
+    }
+    return rc;
 }

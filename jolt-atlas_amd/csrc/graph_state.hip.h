@@ -39,6 +39,7 @@ struct atlas_graph {
     bool traced = false;
     std::map<size_t, DevBuf> out;                // node outputs, padded_next_power_of_two, i32
     std::map<size_t, NodeWitness> wit;
+    DevBuf trace_err;                            // one word the trace's Gather kernels raise on an index outside the dictionary (graph_exec.hip)
     std::vector<size_t> input_nodes() const { std::vector<size_t> v; for (auto& kv : nodes) if (kv.second.op == ATLAS_OP_INPUT) v.push_back(kv.first); return v; }
     const int32_t* tensor(size_t idx) const { auto it = out.find(idx); return it == out.end() ? nullptr : it->second.as<int32_t>(); }
     void clear_trace() { out.clear(); wit.clear(); traced = false; }

@@ -629,7 +629,7 @@ struct PsLookup : atlas_instance {
         const auto t0 = std::chrono::steady_clock::now();
         while (c->tag != tag) {
             for (int i = 0; i < 1024 && c->tag != tag; i++) __builtin_ia32_pause();
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) return false;
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > rt().chan.host_wait_s) return false;
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         return true;
@@ -1144,7 +1144,7 @@ struct PsLookup : atlas_instance {
             PROF("ps_shout: wait for the phase's Q tables + load");
             while (B.tagc->tag != B.tag) {
                 for (int i = 0; i < 1024 && B.tagc->tag != B.tag; i++) __builtin_ia32_pause();
-                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) { rt().chan.abort_dirty = true; return fail(ATLAS_ENODEV, "round channel: no Q tables from the device"); }
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > rt().chan.host_wait_s) { rt().chan.abort_dirty = true; return fail(ATLAS_ENODEV, "round channel: no Q tables from the device"); }
             }
             __atomic_thread_fence(__ATOMIC_ACQUIRE);          // the residues are read through a plain pointer: not before the tag (the device wrote them, fenced, then the tag)
             load_Q(B.data);

@@ -190,7 +190,7 @@ __device__ __forceinline__ void tail_reduce(const MailTail& tail) {
     __syncthreads();
     unsigned long long s0 = 0, s1 = 0, s2 = 0;
     if (grp < n_grp) {
-        const uint64_t t0 = wall_clock64();
+        const uint64_t t0 = wall_clock64(), t_max = ch_timeout_ticks(tail.io.abort_flag);
         // four rows per trip, their loads in flight together (a device-scope load is ~0.7 us of latency; one at a time the 96 chunks a thread
         // owns in a 512-row launch were the round: 65 us); a chunk whose tag has not arrived is polled on its own
         for (uint32_t row = grp; row < tail.n_rows; row += 4 * n_grp) {
@@ -211,7 +211,7 @@ __device__ __forceinline__ void tail_reduce(const MailTail& tail) {
                 if (!live[u]) continue;
                 uint32_t spins = 0;
                 while (x[u].w != tag) {
-                    if ((++spins & 63u) == 0 && (__hip_atomic_load(tail.io.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > CH_TIMEOUT_TICKS)) { tr_bad = 1; bad = true; break; }
+                    if ((++spins & 63u) == 0 && (__hip_atomic_load(tail.io.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > t_max)) { tr_bad = 1; bad = true; break; }
                     __builtin_amdgcn_s_sleep(2);
                     x[u] = ch_load_dev(p[u]);
                 }

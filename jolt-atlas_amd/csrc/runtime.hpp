@@ -97,6 +97,7 @@ struct DevBuf {
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
     template <class T> T* as() const { return static_cast<T*>(p); }
     void* release() { void* q = p; p = nullptr; return q; }
+    void free() { if (p) (void)hipFree(p); p = nullptr; }
 };
 
 #define HIP_TRY(x)                                                             \

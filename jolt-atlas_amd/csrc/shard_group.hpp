@@ -26,13 +26,21 @@
 struct atlas_shard_group {
     static constexpr uint64_t MAGIC = 0x61746c6173736864ull;     // "atlasshd"
     static constexpr size_t RING = 4, PAYLOAD = 496, MAX_WORLD = 64;
-    struct Slot { std::atomic<uint64_t> tag; uint8_t pad[8]; uint8_t payload[PAYLOAD]; };     // 512 bytes
+    // `failed` != 0: the rank gave up on the call this exchange belongs to (fail_exchange) and carries its error code; written before the tag
+    struct Slot { std::atomic<uint64_t> tag; uint64_t failed; uint8_t payload[PAYLOAD]; };     // 512 bytes
     struct Header { std::atomic<uint64_t> ready; uint64_t epoch; uint32_t world; uint32_t pad; std::atomic<uint32_t> joined; uint32_t pad2; uint64_t created_s; uint8_t fill[4096 - 40]; };
     int world = 0, rank = 0;
     std::string name;
     void* base = nullptr;
     size_t bytes = 0;
     uint64_t seq = 0;
+    // the failure handshake: a rank whose part of a sharded call fails does not leave the others waiting for the board's timeout (and does not
+    // let the exchange numbers drift apart): it posts ONE record marked `failed` in the place of the exchange the others are about to make
+    // (fail_exchange) and returns; every other rank finds the mark in that exchange, finishes reading it, and returns an error too — all at
+    // the same exchange number.  remote_failed / remote_code say that an allgather returned false for that reason (not a timeout).
+    int remote_failed = -1;
+    uint64_t remote_code = 0;
+    double timeout_s_default = 30.0;             // atlas_set_timeouts: scaled with the world size by the caller
 
     Header* hdr() const { return reinterpret_cast<Header*>(base); }
     Slot* slot(uint64_t s, int r) const { return reinterpret_cast<Slot*>((uint8_t*)base + sizeof(Header)) + (s % RING) * world + r; }
@@ -99,12 +107,16 @@ struct atlas_shard_group {
         if (rank == 0 && !name.empty()) shm_unlink(name.c_str());
     }
     // all[r * n .. ) <- rank r's `n` bytes (n <= PAYLOAD).  false on timeout (a rank died).
-    bool allgather(const void* mine, size_t n, void* all, double timeout_s = 30.0) {
+    bool allgather(const void* mine, size_t n, void* all, double timeout_s = -1.0) {
         if (!base || n > PAYLOAD) return false;
+        if (timeout_s < 0) timeout_s = timeout_s_default;
+        remote_failed = -1;
         seq += 1;
         Slot* s = slot(seq, rank);
         std::memcpy(s->payload, mine, n);
+        s->failed = 0;
         s->tag.store(seq, std::memory_order_release);
+        bool ok = true;
         for (int r = 0; r < world; r++) {
             Slot* q = slot(seq, r);
             if (q->tag.load(std::memory_order_acquire) != seq) {
@@ -115,13 +127,22 @@ struct atlas_shard_group {
                     if ((spins & 0xffff) == 0xffff && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
                 }
             }
+            if (q->failed) { remote_failed = r; remote_code = q->failed; ok = false; continue; }     // (the others' records are still read: the exchange completes)
             std::memcpy((uint8_t*)all + (size_t)r * n, q->payload, n);
         }
-        return true;
+        return ok;
+    }
+    // this rank gives up: one record in the place of the next exchange, no waiting
+    void fail_exchange(uint64_t code) {
+        if (!base) return;
+        seq += 1;
+        Slot* s = slot(seq, rank);
+        s->failed = code ? code : 1;
+        s->tag.store(seq, std::memory_order_release);
     }
     // all[r * n .. ) <- rank r's `n` bytes for records of any size (the witness commitments of a sharded whole proof: 64 B per committed
     // polynomial, hundreds of KB per graph): PAYLOAD-sized exchanges one after the other, ~1 us each.
-    bool allgather_bulk(const void* mine, size_t n, void* all, double timeout_s = 30.0) {
+    bool allgather_bulk(const void* mine, size_t n, void* all, double timeout_s = -1.0) {
         std::vector<uint8_t> part((size_t)world * PAYLOAD);
         for (size_t off = 0; off < n; off += PAYLOAD) {
             const size_t cnt = n - off < PAYLOAD ? n - off : PAYLOAD;

@@ -107,6 +107,16 @@ class ShardGroup:
         _check(lib.atlas_shard_allgather(self.h, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def fail_exchange(self, code):
+        """this rank gives up on the sharded call in progress: marks the exchange the others are about to make (atlas_shard_fail_exchange)"""
+        _check(lib.atlas_shard_fail_exchange(self.h, C.c_int(code)))
+
+    def remote_failed(self):
+        """after an exchange raised: (rank that had given up, its code); rank -1 = nobody did (a timeout)"""
+        r, c = C.c_int(-1), C.c_int(0)
+        _check(lib.atlas_shard_remote_failed(self.h, C.byref(r), C.byref(c)))
+        return r.value, c.value
+
     def close(self):
         if self.h:
             lib.atlas_shard_group_close(self.h)

@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-OUT = os.path.join(HERE, "graph_proofs.json")
+OUT = os.environ.get("GRAPH_PROOFS_OUT", os.path.join(HERE, "graph_proofs.json"))   # a long run writes a file of its own (merged afterwards)
 TAU_SEED = 0x51250001
 
 

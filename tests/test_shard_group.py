@@ -89,3 +89,46 @@ def test_bad_arguments():
         sharded.ShardGroup("/atlas_test_bad", 3, 0)          # not a power of two
     with pytest.raises(A.AtlasError):
         sharded.ShardGroup("/atlas_test_bad", 2, 2)          # rank out of range
+
+
+def _giving_up_worker(name, world, rank, q):
+    """ranks exchange three records; rank 1 then gives up INSTEAD of the fourth exchange; afterwards every rank exchanges once more"""
+    sys.path.insert(0, ROOT)
+    import time
+    from jolt_atlas_amd import sharded
+    try:
+        g = sharded.ShardGroup(name, world, rank)
+        for k in range(3): g.allgather(np.array([rank, k], dtype=np.uint64))
+        seen = None
+        if rank == 1:
+            g.fail_exchange(-5)
+        else:
+            t0 = time.time()
+            try:
+                g.allgather(np.array([rank, 3], dtype=np.uint64))
+                seen = "no error"
+            except Exception:              # noqa: BLE001
+                seen = g.remote_failed() + (time.time() - t0 < 5.0,)
+        after = g.allgather(np.array([rank, 99], dtype=np.uint64))          # the exchange numbers still agree
+        ok_after = all(int(after[r][0]) == r and int(after[r][1]) == 99 for r in range(world))
+        g.close()
+        q.put((rank, seen, ok_after))
+    except Exception as e:             # noqa: BLE001
+        q.put((rank, repr(e), False))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_a_rank_that_gives_up_is_learnt_at_once_and_the_board_stays_in_step(world):
+    """the failure handshake (csrc/shard_group.hpp: fail_exchange): no rank waits for the board's 30 s timeout, each learns who gave up and
+    why, and all of them have made the same number of exchanges"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = f"/atlas_test_fail_{os.getpid()}_{world}"
+    ps = [ctx.Process(target=_giving_up_worker, args=(name, world, r, q)) for r in range(world)]
+    for p in ps: p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps: p.join(timeout=30)
+    for rank, seen, ok_after in res:
+        assert ok_after is True, res
+        if rank == 1: assert seen is None
+        else: assert seen == (1, -5, True), res

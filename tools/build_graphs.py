@@ -201,14 +201,17 @@ def microgpt_model():
     return microgpt(weights=_model_weights("microgpt", 0))
 
 
-def gpt2_layer(level=2, seed=0):
-    # d_model 768 and 12 heads padded to 1024 / 16 (every dimension a power of two); the lm head is a 2^14-column slice
-    return transformer(layers=1, seq=16, d_model=1024, heads=16, vocab=1 << 14, level=level, seed=seed)
+def gpt2_layer(level=2, seed=0, fused_qkv=True):
+    # d_model 768 and 12 heads padded to 1024 / 16 (every dimension a power of two); the lm head is a 2^14-column slice; c_attn as in gpt2()
+    return transformer(layers=1, seq=16, d_model=1024, heads=16, vocab=1 << 14, level=level, seed=seed, fused_qkv=fused_qkv)
 
 
-def gpt2(level=2, seed=0):
-    # GPT-2 125M's operator list: 12 layers, d_model 768 -> 1024, 12 -> 16 heads, vocabulary 50257 -> 2^16 (embedding gather and lm head), seq 16
-    return transformer(layers=12, seq=16, d_model=1024, heads=16, vocab=1 << 16, level=level, seed=seed)
+def gpt2(level=2, seed=0, fused_qkv=True):
+    # GPT-2 125M's operator list: 12 layers, d_model 768 -> 1024, 12 -> 16 heads, vocabulary 50257 -> 2^16 (embedding gather and lm head), seq 16.
+    # c_attn is ONE MatMul 768 -> 2304 followed by a three-way Split, as the HF export jolt-atlas-core/examples/gpt2.rs:88-118 loads has it: padded
+    # the way the loader pads (768 -> 1024 rows, 2304 -> 4096 columns), then three Slice nodes.  fused_qkv=False is the three 1024-wide projections
+    # rounds 3-5 timed.
+    return transformer(layers=12, seq=16, d_model=1024, heads=16, vocab=1 << 16, level=level, seed=seed, fused_qkv=fused_qkv)
 
 
 def tiny(level=2, seed=0, layers=2):
