@@ -199,6 +199,14 @@ int atlas_set_timeouts(double device_wait_s, double host_wait_s, double board_wa
     if (device_wait_s > 0) { HIP_TRY(hipStreamSynchronize(rt().stream)); HIP_TRY(rt().chan.set_device_timeout(device_wait_s, rt().stream)); }
     return ATLAS_OK;
 }
+// diagnosis (ATLAS_DEV_STAMPS=1): write the device's and the host's stamps of the rounds since the last dump to `path` and reset them
+int atlas_rt_stamps_dump(const char* path) {
+    NEED_INIT();
+    if (!path) return fail(ATLAS_EINVAL, "stamps_dump");
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+    HIP_TRY(rt().chan.stamps_dump(path));
+    return ATLAS_OK;
+}
 int atlas_get_timeouts(double* device_wait_s, double* host_wait_s, double* board_wait_s) {
     if (device_wait_s) *device_wait_s = rt().chan.device_wait_s;
     if (host_wait_s) *host_wait_s = rt().chan.host_wait_s;

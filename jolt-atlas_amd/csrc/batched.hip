@@ -387,6 +387,7 @@ int atlas_instance_prove(atlas_instance_t inst, const atlas_fr_t* input_claim, a
             inst->prepare(round);
             { PROF("instance_prove: collect (wait for the device)");
               if (!P.collect(P.lanes[0].mails[round], P.mtag(round, 0), sums)) { P.abort_from(round); (void)hipStreamSynchronize(rt().stream); return fail(ATLAS_ENODEV, "round channel: no answer from the device"); } }
+            P.C.host_mark(101, P.mtag(round, 0));
             const auto q1 = nowp();
             { PROF("instance_prove: finish"); rc = inst->finish(round, prev, sums, c); }
             const auto q2 = nowp();
@@ -405,6 +406,7 @@ int atlas_instance_prove(atlas_instance_t inst, const atlas_fr_t* input_claim, a
             H::tr_challenge_u128(T, lo, hi);
             challenges[round].lo = lo; challenges[round].hi = hi;
             P.C.publish(P.slot0 + round, P.rtag(round), lo, hi);
+            P.C.host_mark(100, P.rtag(round));
             if (atlas_rt::Prof::on()) atlas_rt::Prof::get().add("instance_prove: transcript + publish", atlas_rt::Prof::now_us() - pt0);
             // lets the runtime retire completed launches while the device works — when there are any: a query costs 2.5-6 us of this thread,
             // and 56 of the 64 address rounds of a 64-bit lookup (all of them in its pure phases) launch nothing
@@ -642,6 +644,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
                 I.inst->prepare(local);
                 int rc;
                 { PROF("batched_prove: collect (wait for the device)"); rc = PL.collect(PL.lanes[i].mails[local], PL.mtag(round, i), sums) ? ATLAS_OK : fail(ATLAS_ENODEV, "round channel: no answer from the device"); }
+                PL.C.host_mark(101, PL.mtag(round, i));
                 const auto tc1 = std::chrono::steady_clock::now();
                 if (!rc) { PROF("batched_prove: finish"); rc = I.inst->finish(local, claim[i], sums, polys[i]); }
                 if (trace) { t_wait[i] += std::chrono::duration<double, std::milli>(tc1 - tc0).count(); t_msg[i] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc1).count(); }
@@ -679,7 +682,7 @@ int atlas_batched_prove(atlas_batched_t b, atlas_transcript_t* transcript, atlas
         uint64_t lo, hi;
         H::tr_challenge_u128(T, lo, hi);                                              // challenge_scalar_optimized :119
         challenges[round].lo = lo; challenges[round].hi = hi;
-        if (piped) { PL.C.publish(PL.slot0 + round, PL.rtag(round), lo, hi); if ((round & 7) == 7 && PL.next_enqueue_launched != batch_queried_at) { PL.query(); batch_queried_at = PL.next_enqueue_launched; } }
+        if (piped) { PL.C.publish(PL.slot0 + round, PL.rtag(round), lo, hi); PL.C.host_mark(100, PL.rtag(round)); if ((round & 7) == 7 && PL.next_enqueue_launched != batch_queried_at) { PL.query(); batch_queried_at = PL.next_enqueue_launched; } }
         const H::Fr r = H::challenge_to_fr(lo, hi, rt().challenge_mode);
         const double pf2 = atlas_rt::Prof::on() ? atlas_rt::Prof::now_us() : 0;
         for (size_t i = 0; i < n; i++) claim[i] = eval_with_challenge(polys[i], r);    // :123-126

@@ -59,6 +59,20 @@ __device__ __forceinline__ uint64_t ch_timeout_ticks(const uint32_t* abort_flag)
     return t ? t : CH_TIMEOUT_TICKS;
 }
 
+// Diagnosis (ATLAS_DEV_STAMPS=1, tools/dev_stamps.py): bytes 16..23 of the abort area hold a pointer to a stamp ring in HBM —
+// {next index, capacity} then 16-byte records {event, tag, s_memrealtime} — or null; the host copies it out when asked (atlas_rt_stamps_dump).  ONE lane of a launch calls ch_stamp at the points
+// of a round that matter (entry, challenge seen, partial rows complete, mail sent), so that a round's time can be split on the DEVICE's
+// clock: S(challenge seen) - S(mail sent of the round before) = the host's share plus the two link crossings, the rest is the launch's.
+enum : uint32_t { CH_EV_ENTRY = 1, CH_EV_CHALLENGE = 2, CH_EV_REDUCE_BEGIN = 3, CH_EV_ROWS_IN = 4, CH_EV_MAILED = 5, CH_EV_WORK_DONE = 6 };
+__device__ __forceinline__ void ch_stamp(const uint32_t* abort_flag, uint32_t ev, uint32_t tag) {
+    unsigned long long* ring = *reinterpret_cast<unsigned long long* const volatile*>(abort_flag + 4);
+    if (!ring) return;
+    const unsigned long long i = atomicAdd(ring, 1ull);
+    if (i >= ring[1]) return;
+    ring[2 + 2 * i] = ((unsigned long long)tag << 32) | ev;
+    ring[3 + 2 * i] = wall_clock64();
+}
+
 typedef uint32_t ch_u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void ch_store_sys(void* p, ch_u32x4 v) {
@@ -112,8 +126,10 @@ __device__ __forceinline__ bool ch_wait_r(const RoundIo& io, uint64_t& lo, uint6
     const uint32_t wg = blockIdx.x + blockIdx.y * gridDim.x;
     if (threadIdx.x == 0) {
         uint64_t l = 0, h = 0;
+        if (wg == 0) ch_stamp(io.abort_flag, CH_EV_ENTRY, io.tag_mail);
         const bool ok = wg == 0 || io.r_replicas == 0 ? ch_poll_slot<true>(io.r_host, io.tag_r, io.abort_flag, l, h)
                                 : ch_poll_slot<false>(io.r_dev + (size_t)(wg % io.r_replicas) * CH_REPLICA_CHUNKS, io.tag_r, io.abort_flag, l, h);
+        if (wg == 0) ch_stamp(io.abort_flag, CH_EV_CHALLENGE, io.tag_mail);
         s_ch[0] = l; s_ch[1] = h; s_ch[2] = ok ? 1 : 0;
     }
     __syncthreads();

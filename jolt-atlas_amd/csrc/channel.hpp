@@ -9,6 +9,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
+#include <vector>
 
 #include "channel.hip.h"
 #include "host_field.hpp"
@@ -42,6 +44,47 @@ struct Channel {
         return e;
     }
 
+    // diagnosis: the device stamp ring (channel.hip.h: ch_stamp), ATLAS_DEV_STAMPS=1.  Device records live in HBM and are copied out by dump;
+    // the host's own marks (publish / collected, on ITS clock) are kept beside them.
+    unsigned long long* d_stamps = nullptr;
+    static constexpr size_t STAMP_CAP = (size_t)1 << 20;
+    struct HostMark { uint32_t ev, tag; unsigned long long ns; };
+    std::vector<HostMark> host_marks;
+    hipError_t stamps_on() {
+        if (d_stamps) return hipSuccess;
+        hipError_t e = hipMalloc(&d_stamps, (2 + 2 * STAMP_CAP) * 8);
+        if (e != hipSuccess) return e;
+        const unsigned long long head[2] = {0, STAMP_CAP};
+        e = hipMemcpy(d_stamps, head, 16, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(reinterpret_cast<char*>(d_abort) + 16, &d_stamps, 8, hipMemcpyHostToDevice);
+        host_marks.reserve(1 << 20);
+        return e;
+    }
+    void host_mark(uint32_t ev, uint32_t tag) {
+        if (!d_stamps) return;
+        host_marks.push_back(HostMark{ev, tag, (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count()});
+    }
+    // text dump: "D ev tag ticks" (device, 100 MHz) and "H ev tag ns" (host) lines; resets both
+    hipError_t stamps_dump(const char* path) {
+        if (!d_stamps) return hipSuccess;
+        hipError_t e = hipDeviceSynchronize();
+        unsigned long long head[2] = {0, 0};
+        if (e == hipSuccess) e = hipMemcpy(head, d_stamps, 16, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return e;
+        const size_t n = head[0] < STAMP_CAP ? (size_t)head[0] : STAMP_CAP;
+        std::vector<unsigned long long> rec(2 * n);
+        if (n) e = hipMemcpy(rec.data(), d_stamps + 2, 16 * n, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return e;
+        if (FILE* f = fopen(path, "w")) {
+            for (size_t i = 0; i < n; i++) fprintf(f, "D %u %u %llu\n", (unsigned)(rec[2 * i] & 0xffffffffu), (unsigned)(rec[2 * i] >> 32), rec[2 * i + 1]);
+            for (auto& m : host_marks) fprintf(f, "H %u %u %llu\n", m.ev, m.tag, m.ns);
+            fclose(f);
+        }
+        host_marks.clear();
+        const unsigned long long zero = 0;
+        return hipMemcpy(d_stamps, &zero, 8, hipMemcpyHostToDevice);
+    }
+
     hipError_t init() {
         // fine-grained (coherent) whatever HIP_HOST_COHERENT says: the device polls these lines while the host writes them
         hipError_t e = hipHostMalloc(&mail, MAIL_CHUNKS * sizeof(atlas::Chunk), hipHostMallocCoherent);
@@ -56,6 +99,7 @@ struct Channel {
         if (const char* v = getenv("ATLAS_HOST_WAIT_S")) { const double x = atof(v); if (x > 0) host_wait_s = x; }
         if (const char* v = getenv("ATLAS_DEVICE_WAIT_S")) { const double x = atof(v); if (x > 0) device_wait_s = x; }
         if (e == hipSuccess) e = set_device_timeout(0);
+        if (e == hipSuccess && getenv("ATLAS_DEV_STAMPS")) e = stamps_on();
         return e;
     }
     void release() {
@@ -63,6 +107,7 @@ struct Channel {
         if (rslots) hipHostFree(rslots);
         if (d_rslots) hipFree(d_rslots);
         if (d_abort) hipFree(d_abort);
+        if (d_stamps) { hipFree(d_stamps); d_stamps = nullptr; }
         mail = rslots = d_rslots = nullptr; d_abort = nullptr;
     }
 

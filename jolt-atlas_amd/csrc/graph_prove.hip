@@ -433,6 +433,7 @@ struct Prover : FlowSink {
             H::Fr acc_claim;
             NodePre pre;                                                      // eq(r) and the clamp lookup's G table: in flight under the evaluation's wait
             rc = pre.begin((const atlas_fr_t*)R.point.data(), log_T, {{W.cidx.as<uint64_t>(), (size_t)64}});
+            if (!rc) rc = pre.prebuild_clamp(W.cidx.as<uint64_t>(), log_T, (const atlas_fr_t*)R.point.data());
             if (!rc) rc = atlas_poly_wrap_device_fr(W.acc_fr.p, T, &p_acc);
             if (!rc) rc = pre.eq ? atlas_rt_evaluate_with_eq(&p_acc, 1, pre.eq, (atlas_fr_t*)&acc_claim) : atlas_poly_evaluate(p_acc, (const atlas_fr_t*)R.point.data(), log_T, (atlas_fr_t*)&acc_claim);
             if (p_acc) atlas_poly_free(p_acc);
@@ -579,6 +580,7 @@ struct Prover : FlowSink {
         const int32_t* tp = G.tensor(nd.inputs[0]);
         NodePre pre;                                                          // eq(r) and the lookup's G table: in flight under the operand's evaluation
         int rc = T > 1 ? pre.begin((const atlas_fr_t*)R.point.data(), log_T, {{W.lookups.as<uint64_t>(), XLEN}}) : ATLAS_OK;
+        if (!rc && T > 1 && !clamp) rc = pre.prebuild_relu(W.lookups.as<uint64_t>(), log_T, XLEN, (const atlas_fr_t*)R.point.data());
         if (!rc && pre.eq) {
             atlas_poly_t pv = nullptr;
             rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(tp), T, &pv);
@@ -589,8 +591,9 @@ struct Prover : FlowSink {
         if (!rc) rc = append_nodeio(nd, 0, R.point, operand_claim);           // append_raf_claims_prover: witness_opening_id = Input(0)
         if (rc) return rc;
         const H::Fr gamma = H::tr_challenge_scalar(Tr);
-        atlas_instance_t exec = nullptr;
-        if (pre.eq && !clamp) rc = atlas_rt_ps_shout_relu_new(W.lookups.as<uint64_t>(), log_T, XLEN, (const atlas_fr_t*)R.point.data(), (const atlas_fr_t*)&gamma, pre.eq, &exec);
+        atlas_instance_t exec = pre.take(pre.relu);                           // built ahead (NodePre::prebuild_relu)?
+        if (exec) rc = atlas_rt_ps_set_gamma(exec, (const atlas_fr_t*)&gamma);
+        else if (pre.eq && !clamp) rc = atlas_rt_ps_shout_relu_new(W.lookups.as<uint64_t>(), log_T, XLEN, (const atlas_fr_t*)R.point.data(), (const atlas_fr_t*)&gamma, pre.eq, &exec);
         else
         rc = clamp ? atlas_ps_shout_clamp_new(W.lookups.as<uint64_t>(), log_T, XLEN, gr::CLAMP_BOUND, 1, (const atlas_fr_t*)R.point.data(), (const atlas_fr_t*)&gamma, &exec)
                    : atlas_ps_shout_relu_new(W.lookups.as<uint64_t>(), log_T, XLEN, (const atlas_fr_t*)R.point.data(), (const atlas_fr_t*)&gamma, &exec);
@@ -701,6 +704,7 @@ struct Prover : FlowSink {
         H::Fr acc_claim;
         NodePre pre;
         if (T > 1) rc = pre.begin((const atlas_fr_t*)R.point.data(), log_T, {{W.cidx.as<uint64_t>(), (size_t)64}});
+        if (!rc && T > 1) rc = pre.prebuild_clamp(W.cidx.as<uint64_t>(), log_T, (const atlas_fr_t*)R.point.data());
         if (!rc) rc = atlas_poly_wrap_device_fr(W.acc_fr.p, T, &p_acc);
         if (!rc) rc = atlas_poly_evaluate(p_acc, (const atlas_fr_t*)R.point.data(), log_T, (atlas_fr_t*)&acc_claim);
         if (p_acc) atlas_poly_free(p_acc);
@@ -886,6 +890,7 @@ struct Prover : FlowSink {
         atlas_poly_t p_rem = nullptr, p_quot = nullptr;
         NodePre pre;
         int rc = T > 1 ? pre.begin((const atlas_fr_t*)R.point.data(), log_T, {{RW.cidx.as<uint64_t>(), (size_t)64}}) : ATLAS_OK;
+        if (!rc && T > 1) rc = pre.prebuild_clamp(RW.cidx.as<uint64_t>(), log_T, (const atlas_fr_t*)R.point.data());
         if (!rc) rc = atlas_poly_wrap_device_fr(RW.qfr.p, T, &p_quot);
         if (!rc) rc = atlas_poly_wrap_device_i32(RW.rem.as<int32_t>(), T, &p_rem);
         H::Fr ev[2];

@@ -24,9 +24,12 @@ void atlas_rt_shout_ra_evals_drop(atlas_rt_ra_ticket* t);
 // the prefix-suffix constructors over an eq table the caller holds (EqPolynomial::evals(r_node_output), T Fr on the device; it must outlive
 // the instance): psshout.hip
 int atlas_rt_ps_shout_clamp_new(const uint64_t* lookup_indices, size_t log_T, size_t xlen, size_t bound, int symmetric, const atlas_fr_t* r_node_output,
-                                const atlas_fr_t* gamma, atlas_poly_t eq_shared, atlas_instance_t* out);
+                                const atlas_fr_t* gamma, atlas_poly_t eq_shared, atlas_instance_t* out, bool defer = false);
 int atlas_rt_identity_range_check_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, size_t phases, const atlas_fr_t* r_node_output,
-                                      atlas_poly_t eq_shared, atlas_instance_t* out);
+                                      atlas_poly_t eq_shared, atlas_instance_t* out, bool defer = false);
+// defer = true: the launches of the constructor only (no wait for the device) — for an instance built AHEAD of its proof, under a wait its node
+// makes anyway (node_flow.hip.h: NodePre); gamma may be null then and is handed over with atlas_rt_ps_set_gamma once it has been drawn
+int atlas_rt_ps_set_gamma(atlas_instance_t inst, const atlas_fr_t* gamma);
 // MultilinearPolynomial::evaluate of <= 3 polynomials against a full eq table on the device (spliteq.hip); waits for the library stream
 int atlas_rt_evaluate_with_eq(const atlas_poly_t* polys, size_t count, atlas_poly_t eq_full, atlas_fr_t* out);
 // ReadRafProver over a table of at most 2^12 entries as a host-arithmetic instance (shout.hip): G = the device histogram (downloaded)
@@ -34,4 +37,4 @@ int atlas_rt_shout_read_raf_host_new(atlas_poly_t G, const int32_t* table, size_
 // a BatchedSumcheck member over zero variables: no rounds, the given final claims (elementwise.hip)
 int atlas_rt_const_member_new(const atlas_fr_t* finals, size_t n, size_t degree, atlas_instance_t* out);
 int atlas_rt_ps_shout_relu_new(const uint64_t* lookup_indices, size_t log_T, size_t xlen, const atlas_fr_t* r_node_output, const atlas_fr_t* gamma,
-                               atlas_poly_t eq_shared, atlas_instance_t* out);
+                               atlas_poly_t eq_shared, atlas_instance_t* out, bool defer = false);

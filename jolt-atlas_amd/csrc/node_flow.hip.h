@@ -220,7 +220,31 @@ struct NodePre {
         for (auto& F : fams) if (F.have && F.lookups == lookups && F.log_K == log_K) return &F.G;
         return nullptr;
     }
-    ~NodePre() { for (auto& F : fams) if (F.ticket) atlas_rt_shout_ra_evals_drop(F.ticket); if (eq) atlas_poly_free(eq); }
+    // The node's prefix-suffix read-raf instances built AHEAD, behind the launches above and still before the node's first wait: their
+    // constructors depend on r_node_output and the witness alone (u_evals = the shared eq table, the sign scan, phase 0's tables; gamma only
+    // enters the host's round arithmetic and is set when it has been drawn), so their launches — ~45 us of this thread per instance — and the
+    // device's work for them sit under a wait the node makes anyway, and nothing waits for them when their proofs start.
+    // ATLAS_NO_PREBUILD=1 is the A-B.
+    atlas_instance_t clamp = nullptr, rc_inst = nullptr, relu = nullptr;
+    static bool prebuild_on() { static const bool off = getenv("ATLAS_NO_PREBUILD") != nullptr; return !off && on(); }
+    int prebuild_clamp(const uint64_t* d_cidx, size_t log_T, const atlas_fr_t* r) {
+        if (!prebuild_on() || !eq) return ATLAS_OK;
+        return atlas_rt_ps_shout_clamp_new(d_cidx, log_T, 64, 31, 1, r, nullptr, eq, &clamp, true);
+    }
+    int prebuild_rc(const uint64_t* d_ridx, size_t log_T, size_t S, size_t phases, const atlas_fr_t* r) {
+        if (!prebuild_on() || !eq) return ATLAS_OK;
+        return atlas_rt_identity_range_check_new(d_ridx, log_T, S, phases, r, eq, &rc_inst, true);
+    }
+    int prebuild_relu(const uint64_t* d_lookups, size_t log_T, size_t xlen, const atlas_fr_t* r) {
+        if (!prebuild_on() || !eq) return ATLAS_OK;
+        return atlas_rt_ps_shout_relu_new(d_lookups, log_T, xlen, r, nullptr, eq, &relu, true);
+    }
+    atlas_instance_t take(atlas_instance_t& slot) { atlas_instance_t i = slot; slot = nullptr; return i; }
+    ~NodePre() {
+        for (atlas_instance_t i : {clamp, rc_inst, relu}) if (i) atlas_instance_free(i);      // (before the eq table they borrow)
+        for (auto& F : fams) if (F.ticket) atlas_rt_shout_ra_evals_drop(F.ticket);
+        if (eq) atlas_poly_free(eq);
+    }
     NodePre() = default;
     NodePre(const NodePre&) = delete;
     NodePre& operator=(const NodePre&) = delete;
@@ -395,14 +419,15 @@ inline size_t identity_rc_phases(size_t log_K) {
 // (ProofType::RaOneHotChecks) over the ClampRaD chunks.  acc_claim = the i64 accumulation's opening (already appended),
 // out_claim = the node output's reduced opening.  stage_ms[0..1]: lookup, one-hot checks.
 inline int prove_clamp_lookup_flow(const uint64_t* d_cidx, size_t log_T, const atlas_fr_t* r_node_output, const H::Fr& acc_claim, const H::Fr& out_claim,
-                                   atlas_transcript_t* t, Out& O, double* stage_ms, const NodePre* pre = nullptr) {
+                                   atlas_transcript_t* t, Out& O, double* stage_ms, NodePre* pre = nullptr) {
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point a) { atlas_sync(); return std::chrono::duration<double, std::milli>(now() - a).count(); };
     H::Transcript& Tr = *reinterpret_cast<H::Transcript*>(t);
     auto t0 = now();
     const H::Fr gamma = H::tr_challenge_scalar(Tr);                          // ps_read_raf_prover (unary.rs:112)
-    atlas_instance_t exec = nullptr;
-    int rc = pre && pre->eq ? atlas_rt_ps_shout_clamp_new(d_cidx, log_T, 64, 31, 1, r_node_output, (const atlas_fr_t*)&gamma, pre->eq, &exec)
+    atlas_instance_t exec = pre ? pre->take(pre->clamp) : nullptr;           // built ahead (NodePre::prebuild_clamp)?
+    int rc = exec ? atlas_rt_ps_set_gamma(exec, (const atlas_fr_t*)&gamma)
+           : pre && pre->eq ? atlas_rt_ps_shout_clamp_new(d_cidx, log_T, 64, 31, 1, r_node_output, (const atlas_fr_t*)&gamma, pre->eq, &exec)
                             : atlas_ps_shout_clamp_new(d_cidx, log_T, 64, 31, 1, r_node_output, (const atlas_fr_t*)&gamma, &exec);
     const H::Fr exec_claim = H::add(out_claim, H::mul(gamma, acc_claim));     // rv_claim + gamma * operand_claim (ps_shout/mod.rs:142-144)
     std::vector<atlas_u128_t> ch;
@@ -439,6 +464,8 @@ int prove_fused_rescale(RescaleWitness& W, Inner&& inner, const atlas_fr_t* r_no
     int rc = ATLAS_OK;
     NodePre pre;                                                             // eq(r_node_output) and the G tables of both lookups: in flight under the wait below
     if (T > 1) rc = pre.begin(r_node_output, log_T, {{W.cidx.as<uint64_t>(), (size_t)64}, {W.ridx.as<uint64_t>(), S}});
+    if (!rc && T > 1) rc = pre.prebuild_clamp(W.cidx.as<uint64_t>(), log_T, r_node_output);
+    if (!rc && T > 1) rc = pre.prebuild_rc(W.ridx.as<uint64_t>(), log_T, S, identity_rc_phases(S), r_node_output);
     if (rc) return rc;
     atlas_poly_t p_rem = nullptr, p_quot = nullptr, p_out = nullptr;
     {   // borrowed views for evaluate
@@ -487,9 +514,9 @@ int prove_fused_rescale(RescaleWitness& W, Inner&& inner, const atlas_fr_t* r_no
     H::Fr rr_claim;
     if (!rc) {
         const size_t phases = identity_rc_phases(S);
-        atlas_instance_t rcq = nullptr;
-        rc = pre.eq ? atlas_rt_identity_range_check_new(W.ridx.as<uint64_t>(), log_T, S, phases, r_node_output, pre.eq, &rcq)
-                    : atlas_identity_range_check_new(W.ridx.as<uint64_t>(), log_T, S, phases, r_node_output, &rcq);
+        atlas_instance_t rcq = pre.take(pre.rc_inst);                         // built ahead (NodePre::prebuild_rc)?
+        if (!rcq) rc = pre.eq ? atlas_rt_identity_range_check_new(W.ridx.as<uint64_t>(), log_T, S, phases, r_node_output, pre.eq, &rcq)
+                              : atlas_identity_range_check_new(W.ridx.as<uint64_t>(), log_T, S, phases, r_node_output, &rcq);
         if (!rc) rc = prove_single(rcq, eval_R, t, O, ch, &rr_claim, S, gr::VP_RescaleRemainderRa, gr::PT_RangeCheck, &rr_point);
         if (rcq) atlas_instance_free(rcq);
     }

@@ -555,6 +555,16 @@ struct PsLookup : atlas_instance {
     int mode = 0;                         // 0 = ReLU + gamma * SignedIdentity (unary read-raf), 1 = Identity (range check), 2 = clamp family, 3 = UnsignedLessThan (binary), 4 = RightShift
     size_t bound = 0; bool symmetric = true;   // ClampBoundedTable<N, BOUND, SYMMETRIC> (lookup_tables/clamp.rs)
     size_t nq() const { return mode == 2 ? 6 : mode == 3 ? 4 : mode == 4 ? 3 : 2; }
+    // The clamp family's four extra suffix functions (HAZ, HAZ lw, HAO, HAO lw) look at the suffix bits of significance >= BOUND: once a phase's
+    // suffix lies below BOUND entirely (suffix_len <= bound: phases 4..7 of the 64-bit saturation lookup) there are none — HAZ = HAO = 1 and
+    // lw = the suffix (ps_entry_vals) — so tables 2, 4 ARE table 0 and tables 3, 5 ARE table 1.  Such a phase builds, reduces, publishes, loads
+    // and binds TWO tables instead of six (Q.size() == 2, Qk() maps the six names onto them): the same residues, a third of the work on
+    // both sides of the link.  ATLAS_PS_NO_DUP=1 is the A-B.
+    size_t nq_at(size_t phase) const {
+        static const bool off = getenv("ATLAS_PS_NO_DUP") != nullptr;
+        return (mode == 2 && !off && (phases - 1 - phase) * log_m <= bound) ? 2 : nq();
+    }
+    const std::vector<H::Fr>& Qk(size_t k) const { return Q.size() == 2 ? Q[k & 1] : Q[k]; }
     H::Fr gamma = H::zero();
     uint64_t* d_idx = nullptr;
     Fr *d_u0 = nullptr, *d_v = nullptr, *d_qpart = nullptr;
@@ -593,11 +603,11 @@ struct PsLookup : atlas_instance {
     int build_Q(size_t phase) {           // init_phase: Q tables of `phase` from the current products, fetched
         int rc = launch_Q(phase);
         if (rc) return rc;
-        const size_t NQ = nq();
+        const size_t NQ = nq_at(phase);
         std::vector<H::Fr> q(NQ * m);
         HIP_TRY(hipMemcpyAsync(q.data(), qsum_ptr(), NQ * m * sizeof(Fr), hipMemcpyDeviceToHost, rt().stream));
         HIP_TRY(hipStreamSynchronize(rt().stream));
-        load_Q(q.data());
+        load_Q(q.data(), NQ);
         v.assign(1, H::one());
         return ATLAS_OK;
     }
@@ -606,8 +616,7 @@ struct PsLookup : atlas_instance {
     // instead of the tables (same sums: exact arithmetic in another order).
     std::vector<uint32_t> nz;
     static constexpr size_t NZ_SPARSE = 8;
-    void load_Q(const H::Fr* q) {
-        const size_t NQ = nq();
+    void load_Q(const H::Fr* q, size_t NQ) {            // NQ = nq_at(the phase): the tables the device built
         Q.assign(NQ, std::vector<H::Fr>(m));
         nz.clear();
         for (size_t y = 0; y < m; y++) {
@@ -636,14 +645,14 @@ struct PsLookup : atlas_instance {
     }
     // tables of a pure phase p < sgn_P: bin x_s of class s only
     void load_Q_pure(size_t p) {
-        const size_t NQ = nq();
+        const size_t NQs = nq(), NQ = nq_at(p);             // the scan's sums are laid out for all nq() functions; tables 2.. of a phase below BOUND are copies
         Q.assign(NQ, std::vector<H::Fr>(m));
         nz.clear();
         for (int cl = 0; cl < 2; cl++) {
             const size_t y = cl ? m - 1 : 0;
             bool any = false;
             for (size_t k = 0; k < NQ; k++) {
-                const H::Fr& sv = sgn_S[(p * 2 + cl) * NQ + k];
+                const H::Fr& sv = sgn_S[(p * 2 + cl) * NQs + k];
                 if (H::detail::is_zero4(sv.l)) continue;
                 Q[k][y] = H::mul(sgn_A[cl], sv); any = true;
             }
@@ -652,7 +661,7 @@ struct PsLookup : atlas_instance {
     }
     // tables of the first mixed phase: A_0 T_0 + A_1 T_1 over the published class tables
     int load_Q_mixed() {
-        const size_t NQ = nq();
+        const size_t NQ = nq_at(sgn_P);
         for (int cl = 0; cl < 2; cl++)
             if (!wait_tag(sgn_box[cl].tagc, sgn_box[cl].tag)) { rt().chan.abort_dirty = true; return fail(ATLAS_ENODEV, "round channel: no class tables from the device"); }
         Q.assign(NQ, std::vector<H::Fr>(m));
@@ -672,7 +681,33 @@ struct PsLookup : atlas_instance {
     }
     // at construction (the caller holds rt().mu): scan, wait for the minimum, launch the class tables of phase P.  Leaves sgn_P = 0 and the
     // ordinary tables of phase 0 when no phase is pure.
-    int sign_setup() {
+    // `defer`: the launches only — the instance was built AHEAD of its use (NodePre: under the node's first wait) and finish_setup() runs when
+    // its proof starts, by which time the scan has long answered; nothing here waits for the device.
+    bool setup_pending = false;
+    atlas::Chunk* scan_box = nullptr; uint32_t scan_tag = 0;
+    QBox q0box;                                         // phase 0's tables of an instance without the shortcut, published instead of fetched
+    int finish_setup() {
+        if (!setup_pending) return ATLAS_OK;
+        setup_pending = false;
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+        if (scan_box) return sign_finish();
+        if (!wait_tag(q0box.tagc, q0box.tag)) { rt().chan.abort_dirty = true; return fail(ATLAS_ENODEV, "round channel: no tables of phase 0 from the device"); }
+        load_Q(q0box.data, nq_at(0));
+        v.assign(1, H::one());
+        return ATLAS_OK;
+    }
+    int deferred_Q0() {                                 // build_Q(0) without the wait
+        const size_t n_vals = nq_at(0) * m;
+        atlas::Chunk* box = rt().chan.alloc_long(2 * n_vals + 4);
+        if (m <= RA_THREADS) std::memset(box + 4, 0, n_vals * sizeof(Fr));
+        const uint32_t tg = rt().chan.tag();
+        int rc = launch_Q(0, nullptr, 0, QPublish{reinterpret_cast<Fr*>(box + 4), box, tg, rows.d_counter});
+        if (rc) return rc;
+        q0box = QBox{box, reinterpret_cast<const H::Fr*>(box + 4), tg};
+        setup_pending = true;
+        return ATLAS_OK;
+    }
+    int sign_setup(bool defer = false) {
         const size_t NQ = nq(), n_vals = PS_SIGN_PMAX * 2 * NQ;
         hipError_t e = sgn_scratch.alloc(8192 + 2 * sizeof(Fr));
         if (e != hipSuccess) return fail(ATLAS_ENOMEM, "ps_shout: sign scratch", e);
@@ -690,16 +725,24 @@ struct PsLookup : atlas_instance {
         else k_ps_sign_scan<2><<<(unsigned)gb, RA_THREADS, 0, rt().stream>>>(d_idx, d_u0, T, (uint32_t)N, (uint32_t)log_m, ph, 0u, O);
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) return fail(ATLAS_ENODEV, "ps_shout: sign scan", le);
-        if (!wait_tag(box, tag)) { rt().chan.abort_dirty = true; return fail(ATLAS_ENODEV, "round channel: no sign scan from the device"); }
+        scan_box = box; scan_tag = tag;
+        if (defer) { setup_pending = true; return ATLAS_OK; }
+        return sign_finish();
+    }
+    int sign_finish() {
+        const size_t NQ = nq();
+        atlas::Chunk* box = scan_box;
+        if (!wait_tag(box, scan_tag)) { rt().chan.abort_dirty = true; return fail(ATLAS_ENODEV, "round channel: no sign scan from the device"); }
         size_t P = box->d[1];
         if (P > phases - 1) P = phases - 1;
         if (P > PS_SIGN_PMAX) P = PS_SIGN_PMAX;
         if (P == 0) return build_Q(0);
         sgn_S.assign(reinterpret_cast<const H::Fr*>(box + 4), reinterpret_cast<const H::Fr*>(box + 4) + P * 2 * NQ);
         sgn_P = P;
+        const size_t NQP = nq_at(P);
         for (int cl = 0; cl < 2; cl++) {                       // the class tables of phase P: needed 8 P rounds from now
-            atlas::Chunk* tb = rt().chan.alloc_long(2 * NQ * m + 4);
-            std::memset(tb + 4, 0, NQ * m * sizeof(Fr));
+            atlas::Chunk* tb = rt().chan.alloc_long(2 * NQP * m + 4);
+            std::memset(tb + 4, 0, NQP * m * sizeof(Fr));
             const uint32_t tg = rt().chan.tag();
             int rc = launch_Q(P, nullptr, 0, QPublish{reinterpret_cast<Fr*>(tb + 4), tb, tg, rows.d_counter}, PsClass{cl, (uint32_t)(N - 1), nullptr});
             if (rc) return rc;
@@ -722,7 +765,7 @@ struct PsLookup : atlas_instance {
     int launch_Q(size_t phase, const Fr* v_prev = nullptr, uint32_t shift_prev = 0, QPublish pub = QPublish{nullptr, nullptr, 0, nullptr},
                  PsClass cls = PsClass{-1, 0u, nullptr}) {
         const uint32_t suffix_len = (uint32_t)((phases - 1 - phase) * log_m);
-        const size_t NQ = nq();
+        const size_t NQ = nq_at(phase);
         Fr* d_qsum = qsum_ptr();
         if (m <= RA_THREADS) {
             unsigned long long* acc = (unsigned long long*)d_qpart;              // m * NQ * 8 word sums (the partial-row area is larger)
@@ -758,6 +801,7 @@ struct PsLookup : atlas_instance {
 
     int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
         if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "ps_shout: round out of order");
+        if (setup_pending) { int rc = finish_setup(); if (rc) return rc; }
         if (sgn_P) { int rc = sign_off(); if (rc) return rc; }
         coeffs.assign(3, H::zero());
         if (round < N) return address_message(round, claim, coeffs);
@@ -825,7 +869,7 @@ struct PsLookup : atlas_instance {
                                     if (b < off || b >= off + half) continue;
                                     const size_t bb = b - off;
                                     if (!keep(bb)) continue;
-                                    const H::Fr& val = Q[k][b];
+                                    const H::Fr& val = Qk(k)[b];
                                     if (H::detail::is_zero4(val.l)) continue;
                                     tot = H::add(tot, val);
                                     if (!w) continue;
@@ -836,14 +880,14 @@ struct PsLookup : atlas_instance {
                             }
                             if (!w) {
                                 tot = H::zero();
-                                for (size_t b = 0; b < half; b++) if (keep(b)) tot = H::add(tot, Q[k][off + b]);
+                                for (size_t b = 0; b < half; b++) if (keep(b)) tot = H::add(tot, Qk(k)[off + b]);
                                 return;
                             }
                             // per-bit sums by halving: the sum over the bins with bit i set is the sum of the upper half of
                             // the array once the bits above i have been folded away — 2 * half additions in all instead of
                             // half * (1 + blen / 2)
                             sum_tmp.resize(half);
-                            for (size_t b = 0; b < half; b++) sum_tmp[b] = keep(b) ? Q[k][off + b] : H::zero();
+                            for (size_t b = 0; b < half; b++) sum_tmp[b] = keep(b) ? Qk(k)[off + b] : H::zero();
                             for (size_t i = blen; i-- > 0;) {
                                 const size_t h = (size_t)1 << i;
                                 H::Fr up = H::zero();
@@ -860,7 +904,12 @@ struct PsLookup : atlas_instance {
                             if (mode == 4) { H::Fr t; sums(0, off, -1, w_b, t, S.sb); }
                             sums(1, off, -1, nullptr, S.ss, unused);
                             if (mode == 4) sums(2, off, -1, nullptr, S.s2, unused);
-                            if (mode == 2) {
+                            if (mode == 2 && Q.size() == 2 && mhigh == 0) {
+                                // two tables (nq_at) and no clamp "high" variable left among the chunk's bits: every bin is kept by both filters, tables
+                                // 2, 4 are table 0 and 3, 5 table 1, and the low-word weight of bin b is b 2^suffix_len — the sums above, reused
+                                S.z2 = S.s1; S.zl2 = H::mul(sh, S.sb); S.z3 = S.ss;
+                                if (symmetric) { S.o4 = S.s1; S.ol4 = S.zl2; S.o5 = S.ss; }
+                            } else if (mode == 2) {
                                 sums(2, off, 0, w_lw, S.z2, S.zl2);
                                 sums(3, off, 0, nullptr, S.z3, unused);
                                 if (symmetric) { sums(4, off, 1, w_lw, S.o4, S.ol4); sums(5, off, 1, nullptr, S.o5, unused); }
@@ -935,6 +984,7 @@ struct PsLookup : atlas_instance {
     // with_device = false: the host half only (round channel: the launches were enqueued ahead and take r from its slot)
     int ingest_impl(const atlas_u128_t& r, size_t round, bool with_device) {
         if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "ps_shout: round out of order");
+        if (setup_pending) { int rc = finish_setup(); if (rc) return rc; }
         if (with_device && sgn_P) { int rc = sign_off(); if (rc) return rc; }
         const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode);
         if (round < N) {
@@ -1055,6 +1105,7 @@ struct PsLookup : atlas_instance {
     }
     int enqueue(size_t round, const atlas::RoundIo& io, bool bind_prev, atlas_mail_ref& mail) override {
         if (round >= rounds() || (round > 0) != bind_prev) return fail(ATLAS_ESTATE, "ps_shout: enqueue out of order");
+        if (setup_pending) { int rc = finish_setup(); if (rc) return rc; }      // (built ahead: the scan's answer, the class tables' launches)
         const ChanIo cio{io, rt().challenge_mode};
         mail.base = io.mail; mail.blocks = 0; mail.n_vals = 0; mail.radix = 32; mail.shl = 0;
         Fr* vt[2] = {d_v, d_v + m};
@@ -1080,7 +1131,7 @@ struct PsLookup : atlas_instance {
             else k_ps_expand_all_ch<<<1, RA_THREADS, 0, rt().stream>>>(vt[0], vt[1], slots);
             const uint32_t shift_done = (uint32_t)((phases - 1 - p_done) * log_m);
             if (round < N) {                                   // ... folded into the products while the Q of the phase that starts is built
-                const size_t p = round / log_m, n_vals = nq() * m;
+                const size_t p = round / log_m, n_vals = nq_at(p) * m;
                 atlas::Chunk* box = rt().chan.alloc(2 * n_vals + 4);
                 if (m <= RA_THREADS) std::memset(box + 4, 0, n_vals * sizeof(Fr));      // k_ps_q_final publishes the non-zero residues only
                 int rc = launch_Q(p, vt[log_m & 1], shift_done, QPublish{reinterpret_cast<Fr*>(box + 4), box, io.tag_mail, rows.d_counter}, cls);
@@ -1147,7 +1198,7 @@ struct PsLookup : atlas_instance {
                 if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > rt().chan.host_wait_s) { rt().chan.abort_dirty = true; return fail(ATLAS_ENODEV, "round channel: no Q tables from the device"); }
             }
             __atomic_thread_fence(__ATOMIC_ACQUIRE);          // the residues are read through a plain pointer: not before the tag (the device wrote them, fenced, then the tag)
-            load_Q(B.data);
+            load_Q(B.data, nq_at(round / log_m));
             if (ps_trace()) t_qwait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         }
         if (!ps_trace()) return address_message(round, claim, coeffs);
@@ -1212,7 +1263,7 @@ __global__ __launch_bounds__(RA_THREADS) void k_lookup_indices(const int32_t* __
 extern "C" {
 
 static int ps_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, size_t phases, int mode, const atlas_fr_t* r_node_output,
-                  const atlas_fr_t* gamma, atlas_instance_t* out, size_t bound = 0, bool symmetric = true, atlas_poly_t eq_shared = nullptr) {
+                  const atlas_fr_t* gamma, atlas_instance_t* out, size_t bound = 0, bool symmetric = true, atlas_poly_t eq_shared = nullptr, bool defer = false) {
     // log_T == 0 — a read-raf instance WITHOUT cycle variables (ps_shout/mod.rs:419-446 at T = 1: log_K address rounds, then the ra value of the one
     // lookup).  Held as TWO cycles of which the second has weight u = 0 and index 0: every sum over cycles of the address rounds is the one-cycle
     // sum, no kernel meets a length of one; the instance reports log_K rounds, is stepped by the host (the fold of the last phase's table
@@ -1261,9 +1312,18 @@ static int ps_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, si
     static const bool no_sign = getenv("ATLAS_PS_NO_SIGN") != nullptr || getenv("ATLAS_NO_PIPELINE") != nullptr;     // A-B
     // (mode 3, the binary UnsignedLessThan range checks: the interleaved operands are small non-negative integers — one class, leading zero chunks)
     const bool try_sign = (mode == 0 || mode == 2 || mode == 3) && !one_cycle && m <= RA_THREADS && phases >= 3 && phases - 1 <= PS_SIGN_PMAX && rt().fs_mode == ATLAS_FS_HOST && !no_sign;
-    if (!rc) rc = try_sign ? P->sign_setup() : P->build_Q(0);
+    // defer (NodePre: the instance is built ahead of its proof, under a wait its node makes anyway): launches only, finish_setup() at first use
+    const bool can_defer = defer && !one_cycle && P->log_m <= 11 && rt().fs_mode == ATLAS_FS_HOST && getenv("ATLAS_NO_PIPELINE") == nullptr;
+    if (!rc) rc = try_sign ? P->sign_setup(can_defer) : can_defer ? P->deferred_Q0() : P->build_Q(0);
     if (rc) { delete P; return rc; }
     *out = P;
+    return ATLAS_OK;
+}
+// the batching challenge of an instance built before it was drawn (the constructors read it for nothing: it enters the host's round arithmetic)
+int atlas_rt_ps_set_gamma(atlas_instance_t inst, const atlas_fr_t* gamma) {
+    PsLookup* P = dynamic_cast<PsLookup*>(inst);
+    if (!P || !gamma) return fail(ATLAS_EINVAL, "ps_set_gamma: not a prefix-suffix instance");
+    std::memcpy(&P->gamma, gamma, 32);
     return ATLAS_OK;
 }
 
@@ -1290,33 +1350,33 @@ int atlas_ps_shout_clamp_new(const uint64_t* lookup_indices, size_t log_T, size_
 
 }  // extern "C"
 int atlas_rt_ps_shout_clamp_new(const uint64_t* lookup_indices, size_t log_T, size_t xlen, size_t bound, int symmetric, const atlas_fr_t* r_node_output,
-                                const atlas_fr_t* gamma, atlas_poly_t eq_shared, atlas_instance_t* out) {
+                                const atlas_fr_t* gamma, atlas_poly_t eq_shared, atlas_instance_t* out, bool defer) {
     PROF("atlas_ps_shout_clamp_new");
     NEED_INIT();
-    if (!lookup_indices || (!r_node_output && log_T) || !gamma || !out) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: null argument");
+    if (!lookup_indices || (!r_node_output && log_T) || (!gamma && !defer) || !out) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: null argument");
     if (xlen != 16 && xlen != 32 && xlen != 64) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: X_LEN must be 16, 32 or 64");
     if (bound == 0 || bound + 1 >= xlen || bound > 31) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: 1 <= BOUND <= 31 and BOUND < X_LEN - 1");
     if (log_T > 25) return fail(ATLAS_EINVAL, "ps_shout_clamp_new: log_T <= 25");
-    return ps_new(lookup_indices, log_T, xlen, 8, 2, r_node_output, gamma, out, bound, symmetric != 0, log_T ? eq_shared : nullptr);
+    return ps_new(lookup_indices, log_T, xlen, 8, 2, r_node_output, gamma, out, bound, symmetric != 0, log_T ? eq_shared : nullptr, defer);
 }
 int atlas_rt_ps_shout_relu_new(const uint64_t* lookup_indices, size_t log_T, size_t xlen, const atlas_fr_t* r_node_output, const atlas_fr_t* gamma,
-                               atlas_poly_t eq_shared, atlas_instance_t* out) {
+                               atlas_poly_t eq_shared, atlas_instance_t* out, bool defer) {
     PROF("atlas_ps_shout_relu_new");
     NEED_INIT();
-    if (!lookup_indices || (!r_node_output && log_T) || !gamma || !out) return fail(ATLAS_EINVAL, "ps_shout_relu_new: null argument");
+    if (!lookup_indices || (!r_node_output && log_T) || (!gamma && !defer) || !out) return fail(ATLAS_EINVAL, "ps_shout_relu_new: null argument");
     if (xlen != 16 && xlen != 32) return fail(ATLAS_EINVAL, "ps_shout_relu_new: X_LEN must be 16 or 32 (the reference's WordNoMSB suffix is a u32)");
     if (log_T > 25) return fail(ATLAS_EINVAL, "ps_shout_relu_new: log_T <= 25");
-    return ps_new(lookup_indices, log_T, xlen, 8, 0, r_node_output, gamma, out, 0, true, log_T ? eq_shared : nullptr);
+    return ps_new(lookup_indices, log_T, xlen, 8, 0, r_node_output, gamma, out, 0, true, log_T ? eq_shared : nullptr, defer);
 }
 int atlas_rt_identity_range_check_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, size_t phases, const atlas_fr_t* r_node_output,
-                                      atlas_poly_t eq_shared, atlas_instance_t* out) {
+                                      atlas_poly_t eq_shared, atlas_instance_t* out, bool defer) {
     PROF("atlas_identity_range_check_new");
     NEED_INIT();
     if (!lookup_indices || (!r_node_output && log_T) || !out) return fail(ATLAS_EINVAL, "identity_range_check_new: null argument");
     if (phases == 0 || log_K == 0 || log_K > 64 || log_K % phases || log_K / phases > 12)
         return fail(ATLAS_EINVAL, "identity_range_check_new: log_K must be a multiple of phases, chunks of at most 12 bits");
     if (log_T > 25) return fail(ATLAS_EINVAL, "identity_range_check_new: log_T <= 25");
-    return ps_new(lookup_indices, log_T, log_K, phases, 1, r_node_output, nullptr, out, 0, true, log_T ? eq_shared : nullptr);
+    return ps_new(lookup_indices, log_T, log_K, phases, 1, r_node_output, nullptr, out, 0, true, log_T ? eq_shared : nullptr, defer);
 }
 extern "C" {
 

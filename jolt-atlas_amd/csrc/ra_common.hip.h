@@ -186,7 +186,7 @@ __device__ __forceinline__ void tail_reduce(const MailTail& tail) {
     __shared__ uint32_t tr_stage[9 * 16];
     const uint32_t nchunk = 3 * tail.K, n_grp = RA_THREADS / nchunk;           // K <= 16: at least 5 row groups
     const uint32_t c = threadIdx.x % nchunk, grp = threadIdx.x / nchunk, tag = tail.io.tag_mail;
-    if (threadIdx.x == 0) tr_bad = 0;
+    if (threadIdx.x == 0) { tr_bad = 0; ch_stamp(tail.io.abort_flag, CH_EV_REDUCE_BEGIN, tag); }
     __syncthreads();
     unsigned long long s0 = 0, s1 = 0, s2 = 0;
     if (grp < n_grp) {
@@ -223,6 +223,7 @@ __device__ __forceinline__ void tail_reduce(const MailTail& tail) {
     }
     tr_sm[threadIdx.x][0] = s0; tr_sm[threadIdx.x][1] = s1; tr_sm[threadIdx.x][2] = s2;
     __syncthreads();
+    if (threadIdx.x == 0) ch_stamp(tail.io.abort_flag, CH_EV_ROWS_IN, tag);
     if (tr_bad) return;                                                       // a workgroup of this launch gave up (abort): nothing to mail
     if (threadIdx.x < 64) {
         Fr res = fe_zero();
@@ -244,6 +245,7 @@ __device__ __forceinline__ void tail_reduce(const MailTail& tail) {
             res = fr_add(fr_mul(lo, fr_one()), fr_mul(hi, r2));
         }
         ch_mail_wave_fe(tail.io, 0, tail.K, res, tr_stage);
+        if (threadIdx.x == 0) ch_stamp(tail.io.abort_flag, CH_EV_MAILED, tag);
     }
 }
 __device__ __forceinline__ void mail_tail(const Fr* partials, const MailTail& tail) {

@@ -1095,7 +1095,12 @@ class Prover:
         w = self.wit[i]
         F, N, S = w["F"], w["N"], w["S"]
         lf, ln, LS = ilog2(F), ilog2(N), MODEL_SCALE
-        assert ln >= 1 or lf == 0         # ONE row and ONE element run the generic flow; several rows of ONE element were never walked
+        # ONE row ([1, N]) and ONE element ([1, 1]) run the generic flow.  SEVERAL rows of ONE element ([F, 1], F >= 2) are not provable by the
+        # reference either: ExpSumProver / MaxIndicatorProver create their split eq at `round == log_N() - 1` (exp_sum.rs:187, max.rs:251) — with
+        # log_N = 0 the usize subtraction overflows (a panic in debug; in release it wraps, the Option stays None and compute_phase_2_message's
+        # unwrap() panics at exp_sum.rs:163 / max.rs:217) while their log_F phase-2 rounds do run.  Refused here as the reference refuses it.
+        if ln == 0 and lf > 0:
+            raise ValueError("SoftmaxLastAxis over several rows of ONE element: the reference's ExpSum / MaxIndicator provers panic (log_N() - 1 at log_N = 0)")
         log_T = lf + ln
         u = lambda a: a.astype(np.uint32).astype(np.uint64)
         phases = LS // 4 if LS % 4 == 0 else LS // 2

@@ -63,11 +63,12 @@ def test_model_shaped_proof_matches_committed_oracle_result(atlas, name):
 
 
 def test_gpt2_12_layers_config4(atlas):
-    """BASELINE config 4 at size on one GPU: the 12-layer GPT-2-shaped graph (854 nodes, 8823 committed polynomials, max_num_vars 24;
-    jolt-atlas-core/examples/gpt2.rs:88-118 in shape — the reference downloads the model file, there is none in its tree).  The oracle EXECUTED this graph in the
-    build container (per-node trace hashes) and PROVED it there once (tests/golden/gen_graph_proofs.py gpt2: 6747 s on 4 threads): the device's
-    proof is held to the oracle's sha256 and final transcript state (the device's own earlier pin, device_proof_sha256, is the same value), and
-    atlas_verify_graph — written from the reference's verifier side — accepts it and rejects a flipped output."""
+    """BASELINE config 4 at size on one GPU: the 12-layer GPT-2-shaped graph (842 nodes, 8343 committed polynomials, max_num_vars 24;
+    jolt-atlas-core/examples/gpt2.rs:88-118 in shape — c_attn as ONE 768 -> 2304 MatMul padded to 1024 x 4096 and split three ways, as the HF export
+    the example downloads has it; there is no model file in the reference's tree).  The oracle EXECUTED this graph in the build container (per-node
+    trace hashes) and PROVED it there (tests/golden/gen_graph_proofs.py gpt2: about two hours on 4 threads): the device's proof is held to the
+    oracle's sha256 and final transcript state (the device's own pin recorded before that, device_proof_sha256, must be the same value), and
+    atlas_verify_graph — written from the reference's verifier side — accepts it and rejects a flipped output and a flipped proof byte."""
     import build_graphs as BG
     from oracle import orc
     from jolt_atlas_amd import graph as GG
@@ -88,7 +89,8 @@ def test_gpt2_12_layers_config4(atlas):
             continue                                   # (1.1 GB of weights: their upload is covered by every node that reads them)
         assert _h(G.node_output(nd["idx"])) == hw, f"trace of node {nd['idx']} ({nd['op']})"
     proof, state, tm = G.prove(srs, inputs)
-    assert tm["n_nodes"] == 854 and tm["n_committed"] == want["n_committed"] == 8823
+    assert tm["n_nodes"] == want["n_nodes"] == 842 and tm["n_committed"] == want["n_committed"] == 8343
+    assert "proof_sha256" in want, "the fixture holds the device's pin only: merge the oracle's proof of this graph (gen_graph_proofs.py gpt2) before trusting it"
     assert want["proof_sha256"] == want["device_proof_sha256"] and want["state"] == want["device_state"]
     assert len(proof) == want["proof_len"] and hashlib.sha256(proof).hexdigest() == want["proof_sha256"], "ONNXProof bytes (oracle's proof of the same graph)"
     assert state.hex() == want["state"]
