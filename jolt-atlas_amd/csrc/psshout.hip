@@ -1320,7 +1320,7 @@ static int ps_new(const uint64_t* lookup_indices, size_t log_T, size_t log_K, si
     return ATLAS_OK;
 }
 // the batching challenge of an instance built before it was drawn (the constructors read it for nothing: it enters the host's round arithmetic)
-int atlas_rt_ps_set_gamma(atlas_instance_t inst, const atlas_fr_t* gamma) {
+extern "C++" int atlas_rt_ps_set_gamma(atlas_instance_t inst, const atlas_fr_t* gamma) {
     PsLookup* P = dynamic_cast<PsLookup*>(inst);
     if (!P || !gamma) return fail(ATLAS_EINVAL, "ps_set_gamma: not a prefix-suffix instance");
     std::memcpy(&P->gamma, gamma, 32);

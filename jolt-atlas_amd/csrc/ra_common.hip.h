@@ -225,26 +225,34 @@ __device__ __forceinline__ void tail_reduce(const MailTail& tail) {
     __syncthreads();
     if (threadIdx.x == 0) ch_stamp(tail.io.abort_flag, CH_EV_ROWS_IN, tag);
     if (tr_bad) return;                                                       // a workgroup of this launch gave up (abort): nothing to mail
+    // The K column sums leave as the INTEGERS they are — eight 32-bit words and the carry word, V = sum_w word_w 2^(32 w) < 2^288 — and the
+    // host reduces them (Channel::collect adds records word by word and sum_to_fr takes V mod p: the value a canonical residue would have
+    // given).  The reduction on this side — two Montgomery products and an addition per column behind a serial walk over the row groups —
+    // was 3-6 us of every round of every lane, after the last partial row had arrived.  Stage 1: thread (value k, word w) adds its word
+    // over the row groups; stage 2: lane k carries its eight sums into nine words and the wavefront mails them.
+    __shared__ unsigned long long tr_col[16][8];
+    if (threadIdx.x < 8 * tail.K) {
+        const uint32_t k = threadIdx.x >> 3, w = threadIdx.x & 7u;
+        unsigned long long a = 0;
+        for (uint32_t g2 = 0; g2 < n_grp; g2++) a += tr_sm[g2 * nchunk + 3 * k + w / 3][w % 3];
+        tr_col[k][w] = a;
+    }
+    __syncthreads();
     if (threadIdx.x < 64) {
-        Fr res = fe_zero();
+        uint32_t w9[9];
+#pragma unroll
+        for (int w = 0; w < 9; w++) w9[w] = 0;
         if (threadIdx.x < tail.K) {
-            // value k: word w sits in chunk 3 k + w / 3, component w % 3; sum over the row groups, then V = lo + hi 2^256 -> residue
-            Fr lo, hi, r2;
             unsigned long long carry = 0;
 #pragma unroll
             for (int w = 0; w < 8; w++) {
-                unsigned long long a = 0;
-                for (uint32_t g2 = 0; g2 < n_grp; g2++) a += tr_sm[g2 * nchunk + 3 * threadIdx.x + w / 3][w % 3];
-                const unsigned long long t = carry + (a & 0xffffffffull);
-                lo.v[w] = (uint32_t)t;
+                const unsigned long long a = tr_col[threadIdx.x][w], t = carry + (a & 0xffffffffull);
+                w9[w] = (uint32_t)t;
                 carry = (t >> 32) + (a >> 32);
             }
-#pragma unroll
-            for (int w = 0; w < 8; w++) { hi.v[w] = 0; r2.v[w] = FrParams::r2(w); }
-            hi.v[0] = (uint32_t)carry; hi.v[1] = (uint32_t)(carry >> 32);
-            res = fr_add(fr_mul(lo, fr_one()), fr_mul(hi, r2));
+            w9[8] = (uint32_t)carry;                                          // rows x 2^32 at most: one word
         }
-        ch_mail_wave_fe(tail.io, 0, tail.K, res, tr_stage);
+        ch_mail_wave(tail.io, 0, tail.K, w9, tr_stage);
         if (threadIdx.x == 0) ch_stamp(tail.io.abort_flag, CH_EV_MAILED, tag);
     }
 }
