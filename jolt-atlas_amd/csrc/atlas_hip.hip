@@ -856,71 +856,84 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
             mails[0] = Mail{reg, (size_t)grid, use_f9 ? 29 : 32, use_f9 ? 5 : 0};
             rounds_done = 1; pending = 1;
         }
-        while (len > ((size_t)1 << tail_log)) {
-            const size_t j = rounds_done - 1;          // challenge index being bound
-            const size_t q = len / 4;
-            // at most 2^15 quads: two lanes per quad (k_dot_bind_eval2_f9_pair); ATLAS_F9_NO_PAIR=1 is the A/B
-            static const bool no_pair = getenv("ATLAS_F9_NO_PAIR") != nullptr;
-            const bool pair_pass = use_f9 && !no_pair && 2 * q <= (size_t)256 * SC_THREADS && !(P->schedule == ATLAS_EQ_LOW && j >= P->a) && !P->left->is_i32;
-            const int grid = pair_pass ? (int)((2 * q + SC_THREADS - 1) / SC_THREADS) : use_f9 ? grid_f9(q) : grid_for(q);
-            bool fuse_eq = false;
-            if (P->schedule == ATLAS_EQ_HIGH && j < P->a) {
-                tm.begin(0, (eq_len + eq_len / 2) * sizeof(Fr));
-                waiters[j] = (size_t)(grid_for(eq_len / 2) > grid ? grid_for(eq_len / 2) : grid);
-                k_bind_hi_io<ChanIo><<<grid_for(eq_len / 2), SC_THREADS, 0, rt().stream>>>(eqp, eq_len / 2, ChanIo{C.io(nullptr, 0, slot0 + j, rtag(j), waiters[j]), mode}, hi_only);
-                tm.end();
-                eq_len /= 2;
-            } else if (P->schedule == ATLAS_EQ_LOW && j >= P->a) {
-                fuse_eq = true;
-            }
-            EqView eq = eq_view_for_round(P, j + 1, eqp, fuse_eq ? eq_len / 2 : eq_len);
-            uint64_t bytes = 2 * len * (P->left->is_i32 ? sizeof(int32_t) : sizeof(Fr)) + 2 * (len / 2) * sizeof(Fr);
-            if (fuse_eq) bytes += (eq_len + eq_len / 2) * sizeof(Fr);
-            atlas::Chunk* reg = C.alloc((size_t)grid * ch_stride(DEG));
-            if (waiters[j] < (size_t)grid) waiters[j] = (size_t)grid;
-            const RoundIo io = C.io(reg, mtag(rounds_done), slot0 + j, rtag(j), waiters[j]);
-            tm.begin(0, bytes);
-            if (P->left->is_i32) {
-                Fr *Ld = nullptr, *Rd = nullptr;
-                hipError_t e = hipMalloc(&Ld, (len / 2) * sizeof(Fr));
-                if (e == hipSuccess) e = hipMalloc(&Rd, (len / 2) * sizeof(Fr));
-                if (e != hipSuccess) {
-                    if (Ld) (void)hipFree(Ld);
-                    for (size_t k = 0; k < n; k++) C.publish(slot0 + k, rtag(k), 0, 0, true);
-                    (void)hipStreamSynchronize(rt().stream);
-                    P->consumed = true;
-                    return fail(ATLAS_ENOMEM, "hipMalloc(bound operands)", e);
-                }
-                k_dot_bind_eval<DEG, int32_t, false, ChanIo><<<grid, SC_THREADS, 0, rt().stream>>>(
-                    (const int32_t*)P->left->d, (const int32_t*)P->right->d, Ld, Rd, nullptr, eq, q, ChanIo{io, mode}, K, hi_only);
-                old_l = P->left->owned ? P->left->d : nullptr; old_r = P->right->owned ? P->right->d : nullptr;
-                P->left->d = Ld; P->left->is_i32 = false; P->left->owned = true;
-                P->right->d = Rd; P->right->is_i32 = false; P->right->owned = true;
-            } else if (fuse_eq) {
-                k_dot_bind_eval<DEG, Fr, true, ChanIo><<<grid, SC_THREADS, 0, rt().stream>>>(
-                    (const Fr*)P->left->d, (const Fr*)P->right->d, (Fr*)P->left->d, (Fr*)P->right->d, eqp, eq, q, ChanIo{io, mode}, K, hi_only);
-                eq_len /= 2;
-            } else if (pair_pass) {
-                k_dot_bind_eval2_f9_pair<ChanIoF9><<<grid, SC_THREADS, 0, rt().stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, ChanIoF9{io});
-            } else if (use_f9) {
-                if (false)                                     // (the lazy-limb tail takes residues < 2.1p as they are)
-                    k_dot_bind_eval2_f9<true, ChanIoF9><<<grid, SC_THREADS, 0, rt().stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, ChanIoF9{io});
-                else
-                    k_dot_bind_eval2_f9<false, ChanIoF9><<<grid, SC_THREADS, 0, rt().stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, ChanIoF9{io});
-            } else {
-                k_dot_bind_eval<DEG, Fr, false, ChanIo><<<grid, SC_THREADS, 0, rt().stream>>>(
-                    (const Fr*)P->left->d, (const Fr*)P->right->d, (Fr*)P->left->d, (Fr*)P->right->d, nullptr, eq, q, ChanIo{io, mode}, K, hi_only);
-            }
-            tm.end();
-            mails[rounds_done] = Mail{reg, (size_t)grid, use_f9 ? 29 : 32, use_f9 ? 5 : 0};
-            len /= 2;
-            rounds_done += 1;
-        }
     }
-    // tail: all remaining rounds in one resident launch
-    atlas::Chunk* tail_reg = C.alloc((n + 2) * ch_stride(3));
-    const size_t tail_round0 = rounds_done;
-    {
+    // Review item 3 (round 6): the first bind pass of a 2^22 instance had grown 77 -> 99 us under the tracer while round 0 got faster.  The
+    // device's own clock (ATLAS_DEV_STAMPS=1, tools/bind_wait_split.py -> profiles/r06g_bind_wait_split*.txt) says the pass WAITS 3.6 us — one poll
+    // of a challenge that is already there — and works 59 us; entry to entry it is 76 us, as in round 4.  The growth is the tracer's: every
+    // launch costs this thread more under it, the dozen launches in front of the transcript's first step then end after round 0's sums have
+    // arrived, and the resident bind pass shows the host's lateness as its own duration.  Two orders of enqueueing are kept:
+    //   * all launches up front (default: 0.426-0.431 ms per step untraced);
+    //   * ATLAS_SC_ENQUEUE_LAZY=1: two launches ahead of the transcript, more only while the current round's first record has not arrived
+    //     (the host is never late at round 0; 0.433-0.438 ms untraced — the launches that fall into the short rounds cost more than the
+    //     lateness did; strictly two ahead: 0.461-0.471 ms).
+    bool tail_enqueued = false;
+    size_t tail_round0 = 0;
+    atlas::Chunk* tail_reg = nullptr;
+    int enq_rc = ATLAS_OK;
+    auto enqueue_pass = [&]() -> int {
+        const size_t j = rounds_done - 1;          // challenge index being bound
+        const size_t q = len / 4;
+        // at most 2^15 quads: two lanes per quad (k_dot_bind_eval2_f9_pair); ATLAS_F9_NO_PAIR=1 is the A/B
+        static const bool no_pair = getenv("ATLAS_F9_NO_PAIR") != nullptr;
+        const bool pair_pass = use_f9 && !no_pair && 2 * q <= (size_t)256 * SC_THREADS && !(P->schedule == ATLAS_EQ_LOW && j >= P->a) && !P->left->is_i32;
+        const int grid = pair_pass ? (int)((2 * q + SC_THREADS - 1) / SC_THREADS) : use_f9 ? grid_f9(q) : grid_for(q);
+        bool fuse_eq = false;
+        if (P->schedule == ATLAS_EQ_HIGH && j < P->a) {
+            tm.begin(0, (eq_len + eq_len / 2) * sizeof(Fr));
+            waiters[j] = (size_t)(grid_for(eq_len / 2) > grid ? grid_for(eq_len / 2) : grid);
+            k_bind_hi_io<ChanIo><<<grid_for(eq_len / 2), SC_THREADS, 0, rt().stream>>>(eqp, eq_len / 2, ChanIo{C.io(nullptr, 0, slot0 + j, rtag(j), waiters[j]), mode}, hi_only);
+            tm.end();
+            eq_len /= 2;
+        } else if (P->schedule == ATLAS_EQ_LOW && j >= P->a) {
+            fuse_eq = true;
+        }
+        EqView eq = eq_view_for_round(P, j + 1, eqp, fuse_eq ? eq_len / 2 : eq_len);
+        uint64_t bytes = 2 * len * (P->left->is_i32 ? sizeof(int32_t) : sizeof(Fr)) + 2 * (len / 2) * sizeof(Fr);
+        if (fuse_eq) bytes += (eq_len + eq_len / 2) * sizeof(Fr);
+        atlas::Chunk* reg = C.alloc((size_t)grid * ch_stride(DEG));
+        if (waiters[j] < (size_t)grid) waiters[j] = (size_t)grid;
+        const RoundIo io = C.io(reg, mtag(rounds_done), slot0 + j, rtag(j), waiters[j]);
+        tm.begin(0, bytes);
+        if (P->left->is_i32) {
+            Fr *Ld = nullptr, *Rd = nullptr;
+            hipError_t e = hipMalloc(&Ld, (len / 2) * sizeof(Fr));
+            if (e == hipSuccess) e = hipMalloc(&Rd, (len / 2) * sizeof(Fr));
+            if (e != hipSuccess) {
+                if (Ld) (void)hipFree(Ld);
+                for (size_t k = 0; k < n; k++) C.publish(slot0 + k, rtag(k), 0, 0, true);
+                (void)hipStreamSynchronize(rt().stream);
+                P->consumed = true;
+                return fail(ATLAS_ENOMEM, "hipMalloc(bound operands)", e);
+            }
+            k_dot_bind_eval<DEG, int32_t, false, ChanIo><<<grid, SC_THREADS, 0, rt().stream>>>(
+                (const int32_t*)P->left->d, (const int32_t*)P->right->d, Ld, Rd, nullptr, eq, q, ChanIo{io, mode}, K, hi_only);
+            old_l = P->left->owned ? P->left->d : nullptr; old_r = P->right->owned ? P->right->d : nullptr;
+            P->left->d = Ld; P->left->is_i32 = false; P->left->owned = true;
+            P->right->d = Rd; P->right->is_i32 = false; P->right->owned = true;
+        } else if (fuse_eq) {
+            k_dot_bind_eval<DEG, Fr, true, ChanIo><<<grid, SC_THREADS, 0, rt().stream>>>(
+                (const Fr*)P->left->d, (const Fr*)P->right->d, (Fr*)P->left->d, (Fr*)P->right->d, eqp, eq, q, ChanIo{io, mode}, K, hi_only);
+            eq_len /= 2;
+        } else if (pair_pass) {
+            k_dot_bind_eval2_f9_pair<ChanIoF9><<<grid, SC_THREADS, 0, rt().stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, ChanIoF9{io});
+        } else if (use_f9) {
+            if (false)                                     // (the lazy-limb tail takes residues < 2.1p as they are)
+                k_dot_bind_eval2_f9<true, ChanIoF9><<<grid, SC_THREADS, 0, rt().stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, ChanIoF9{io});
+            else
+                k_dot_bind_eval2_f9<false, ChanIoF9><<<grid, SC_THREADS, 0, rt().stream>>>((Fr*)P->left->d, (Fr*)P->right->d, q, ChanIoF9{io});
+        } else {
+            k_dot_bind_eval<DEG, Fr, false, ChanIo><<<grid, SC_THREADS, 0, rt().stream>>>(
+                (const Fr*)P->left->d, (const Fr*)P->right->d, (Fr*)P->left->d, (Fr*)P->right->d, nullptr, eq, q, ChanIo{io, mode}, K, hi_only);
+        }
+        tm.end();
+        mails[rounds_done] = Mail{reg, (size_t)grid, use_f9 ? 29 : 32, use_f9 ? 5 : 0};
+        len /= 2;
+        rounds_done += 1;
+        return ATLAS_OK;
+    };
+    auto enqueue_tail = [&]() {
+        tail_reg = C.alloc((n + 2) * ch_stride(3));
+        tail_round0 = rounds_done;
         TailChArgs A;
         A.L = P->left->d; A.R = P->right->d; A.eq = eqp;
         A.len = (uint32_t)len; A.eq_len = (uint32_t)eq_len;
@@ -936,7 +949,19 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
         if (DEG == 2 && mode == 0) k_dot_tail2_f9<<<1, SC_TAIL_THREADS, 2 * (sizeof(Fr) << tail_log), rt().stream>>>(A, K);
         else k_dot_tail_ch<DEG><<<1, SC_TAIL_X_THREADS, (P->schedule == ATLAS_EQ_NONE ? 2 : 3) * (sizeof(Fr) << tail_log), rt().stream>>>(A, K);
         tm.end();
-    }
+        tail_enqueued = true;
+    };
+    // launches for every round up to `upto` (and the tail once the passes are out)
+    auto enqueue_more = [&](size_t upto) {
+        while (!tail_enqueued && !enq_rc && rounds_done <= upto) {
+            if (n > tail_log && len > ((size_t)1 << tail_log)) enq_rc = enqueue_pass();
+            else enqueue_tail();
+        }
+    };
+    static const bool enqueue_all = getenv("ATLAS_SC_ENQUEUE_LAZY") == nullptr;
+    constexpr size_t SC_LOOKAHEAD = 2;
+    enqueue_more(enqueue_all ? n : SC_LOOKAHEAD);
+    if (enq_rc) return enq_rc;
     hipError_t le = hipGetLastError();
 
     // the transcript, on this thread
@@ -954,6 +979,13 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
         uint64_t acc[DEG][9];
         H::Fr ev[DEG];
         double t_first = 0;
+        if (ok && !tail_enqueued) {
+            enqueue_more(round + SC_LOOKAHEAD);
+            // ... and whatever else fits into this round's wait: one launch at a time until its first record is there
+            while (!tail_enqueued && !enq_rc && reinterpret_cast<const volatile atlas::Chunk*>(mails[round].base)->tag != mtag(round)) enqueue_more(rounds_done);
+            if (enq_rc) { P->consumed = true; return enq_rc; }
+            if (hipGetLastError() != hipSuccess) ok = false;
+        }
         if (trace && ok) { uint64_t a1[1][9]; C.collect(mails[round].base, mtag(round), 1, 1, a1); t_first = now_us(); }
         if (ok) ok = C.collect(mails[round].base, mtag(round), mails[round].blocks, DEG, acc);
         if (!ok) { C.publish(slot0 + round, rtag(round), 0, 0, true); continue; }
@@ -971,7 +1003,7 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
         C.publish(slot0 + round, rtag(round), challenges[round].lo, challenges[round].hi);
         // while the device works on the next pass: let the runtime retire the launches that have completed (otherwise it
         // reaps all of them inside the final synchronisation: ~170 us for the 14 launches of a 2^22 instance)
-        if (round < tail_round0) (void)hipStreamQuery(rt().stream);
+        if (!tail_enqueued || round < tail_round0) (void)hipStreamQuery(rt().stream);
         if (trace) { const double t_pub = now_us(); tr_t.push_back(t_first - t_prev); tr_t.push_back(t_coll - t_first); tr_t.push_back(t_pub - t_coll); t_prev = t_pub; }
     }
     if (trace) {

@@ -179,10 +179,16 @@ struct Pipeline {
             side = false;
             return;
         }
-        for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) (void)hipStreamSynchronize(st[i]);   // (host waits, for the reason given in begin; the finals have been mailed, the lanes are about idle)
-        atlas_rt::dev_pool().retag_all();                    // the lanes have drained: what they returned may go to the library stream
+        // (Measured and not adopted: no host wait when the proof ended in order — once the host holds every lane's final claims nothing on a
+        // lane touches the instances' buffers any more.  ATLAS_JOIN_NO_WAIT=1 takes that path; the two waits meet idle lanes and cost nothing
+        // measurable over whole proofs, profiles/r06f_join_ab.txt.)
+        static const bool no_wait = getenv("ATLAS_JOIN_NO_WAIT") != nullptr;
+        if (!finals_in || !no_wait)
+            for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) (void)hipStreamSynchronize(st[i]);   // (host waits, for the reason given in begin; the finals have been mailed, the lanes are about idle)
+        atlas_rt::dev_pool().retag_all();
         side = false;
     }
+    bool finals_in = false;
     void query() { (void)hipStreamQuery(rt().stream); if (side) for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) (void)hipStreamQuery(side_streams()[i]); }
     void drain() { if (side) for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) (void)hipStreamSynchronize(side_streams()[i]); (void)hipStreamSynchronize(rt().stream); join(); }
     // make sure the launches of global rounds < R + LOOKAHEAD (and the final binds after the last) are enqueued
@@ -228,6 +234,8 @@ struct Pipeline {
             int rc = L.inst->set_finals(v, (size_t)L.fin.n_vals);
             if (rc) { join(); return rc; }
         }
+        finals_in = true;
+        for (auto& L : lanes) if (L.fin.n_vals == 0 && L.rounds && !L.inst->silent_lane()) finals_in = false;     // a lane whose last launch mails nothing: wait for it
         join();
         return ATLAS_OK;
     }

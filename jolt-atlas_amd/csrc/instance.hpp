@@ -58,6 +58,8 @@ struct atlas_instance {
     virtual int shared_ingest_step(const atlas_u128_t& /*r*/, size_t /*round*/) { return ATLAS_OK; }
     // does enqueue(round) launch nothing at all (host-only rounds: the driver then has nothing new for the runtime to retire)?
     virtual bool silent_round(size_t /*round*/) const { return false; }
+    // does this instance never launch anything when it is stepped through the round channel (HammingWeight: host arithmetic only)?
+    virtual bool silent_lane() const { return false; }
     static constexpr size_t WIDE_WAIT_WGS = 256;
     virtual bool wide_wait(size_t /*round*/) const { return true; }
 };

@@ -1013,6 +1013,7 @@ struct HammingWeight : atlas_instance {
     // round-channel stepping: nothing to launch and nothing to collect, the rounds are host arithmetic
     bool pipelined() const override { return true; }
     bool wide_wait(size_t) const override { return false; }
+    bool silent_lane() const override { return true; }
     int enqueue(size_t, const atlas::RoundIo& io, bool, atlas_mail_ref& mail) override { mail.base = io.mail; mail.blocks = 0; mail.n_vals = 0; return ATLAS_OK; }
     int finish(size_t round, const H::Fr& claim, const H::Fr*, std::vector<H::Fr>& coeffs) override { return message(round, claim, coeffs); }
     int host_ingest(const atlas_u128_t& r, size_t round) override { return ingest(r, round); }

@@ -62,9 +62,12 @@ struct DevIoF9 {
     Fr* partials;
     __device__ __forceinline__ bool challenge(Fr& r) const { r = fe_load(&cx->r); return true; }
     __device__ __forceinline__ void emit2(const F9& a0, const F9& a2) const { f9_block_reduce_store2(a0, a2, partials); }
+    __device__ __forceinline__ void stamp(uint32_t) const {}
 };
 struct ChanIoF9 {
     RoundIo io;
+    // diagnosis (ATLAS_DEV_STAMPS=1): workgroup 0's stamp of an event of this launch (its entry and the challenge's arrival are stamped by ch_wait_r)
+    __device__ __forceinline__ void stamp(uint32_t ev) const { if (blockIdx.x == 0 && threadIdx.x == 0) ch_stamp(io.abort_flag, ev, io.tag_mail); }
     __device__ __forceinline__ bool challenge(Fr& r) const {
         uint64_t lo, hi;
         if (!ch_wait_r(io, lo, hi)) return false;
@@ -141,7 +144,9 @@ __global__ __launch_bounds__(SC_THREADS) void k_dot_bind_eval2_f9(Fr* L, Fr* R, 
         acc0 = f9_mul_addred<P9>(l0, r0, acc0);
         acc2 = f9_mul_addred<P9>(l2, r2, acc2);
     }
+    io.stamp(CH_EV_WORK_DONE);
     io.emit2(f9_norm_red<P9, 1>(acc0), f9_norm_red<P9, 1>(acc2));
+    io.stamp(CH_EV_MAILED);
 }
 
 // The same pass for AT MOST 2^15 quads (the rounds of 2^17 .. 2^13 coefficients, where a launch is one quad per thread and the round is the
