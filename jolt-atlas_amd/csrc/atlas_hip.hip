@@ -931,6 +931,41 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
         rounds_done += 1;
         return ATLAS_OK;
     };
+    // Measured and NOT adopted (round 6; ATLAS_SC_RESIDENT=1 enables it): every bind pass from 2^ATLAS_SC_RESIDENT_LOG coefficients (default: all)
+    // down to the tail's size in ONE resident launch (k_dot_resident2_f9) instead of a launch per round.  Bit-exact (tools/dbg_resident.py: 420 proofs
+    // of 2^12 .. 2^22 against the per-round passes) and no faster: 0.450-0.454 ms per 2^22 step against 0.439-0.456 for the launches on the same box,
+    // any starting size (profiles/r06i_resident_sweep.txt) — a dependent kernel boundary is ~1.5 us and the launches are enqueued ahead, so what a
+    // round costs beyond its bytes is the challenge's way down (poll, fan-out to the replicas) and the 256 records' way up, which a resident grid
+    // pays as well.  What the experiment did find: an inline-asm store needs `s_nop 1` behind it (channel.hip.h).
+    static const bool no_resident = getenv("ATLAS_SC_RESIDENT") == nullptr;
+    static const size_t res_log = [] { const char* e = getenv("ATLAS_SC_RESIDENT_LOG"); const int v = e ? atoi(e) : 0; return (size_t)(v >= 12 && v <= 30 ? v : 30); }();
+    const bool resident_ok = use_f9 && !no_resident && P->schedule == ATLAS_EQ_NONE && (f9_cap & (f9_cap - 1)) == 0;
+    auto enqueue_resident = [&]() {
+        const size_t W = f9_cap;                                       // workgroups: one per CU
+        size_t n_mid = 0;
+        for (size_t l = len; l > ((size_t)1 << tail_log); l >>= 1) n_mid++;
+        const size_t region = W * ch_stride(2);
+        atlas::Chunk* reg = C.alloc(n_mid * region);
+        const size_t k0 = rounds_done;                                 // first message round served; it binds challenge k0 - 1
+        DotResidentArgs A;
+        A.L = (Fr*)P->left->d; A.R = (Fr*)P->right->d; A.len = len;
+        A.round0 = (uint32_t)k0; A.n_mid = (uint32_t)n_mid;
+        A.mail = reg; A.region_chunks = (uint32_t)region;
+        A.r_host0 = C.rslots + Channel::SLOT_CHUNKS * (slot0 + k0 - 1); A.r_dev0 = C.d_rslots + Channel::DEV_SLOT_CHUNKS * (slot0 + k0 - 1);
+        A.dev_slot_chunks = (uint32_t)Channel::DEV_SLOT_CHUNKS; A.r_replicas = Channel::replicas_for(W);
+        A.abort_flag = C.d_abort; A.tag_mail0 = mtag(k0); A.tag_r0 = rtag(k0 - 1);
+        uint64_t bytes = 0;
+        size_t l = len;
+        for (size_t t = 0; t < n_mid; t++, l >>= 1) {
+            const size_t q = l / 4, blocks = q >= W * SC_THREADS ? W : (2 * q + SC_THREADS - 1) / SC_THREADS;
+            mails[k0 + t] = Mail{reg + t * region, blocks, 29, 5};
+            bytes += 3 * l * sizeof(Fr);                               // two operands read, half of each written back
+        }
+        tm.begin(0, bytes);
+        k_dot_resident2_f9<<<(unsigned)W, SC_THREADS, 0, rt().stream>>>(A);
+        tm.end();
+        len = l; rounds_done = k0 + n_mid;
+    };
     auto enqueue_tail = [&]() {
         tail_reg = C.alloc((n + 2) * ch_stride(3));
         tail_round0 = rounds_done;
@@ -954,8 +989,10 @@ static int prove_dot_channel(atlas_dot_prover* P, const atlas_fr_t* input_claim,
     // launches for every round up to `upto` (and the tail once the passes are out)
     auto enqueue_more = [&](size_t upto) {
         while (!tail_enqueued && !enq_rc && rounds_done <= upto) {
-            if (n > tail_log && len > ((size_t)1 << tail_log)) enq_rc = enqueue_pass();
-            else enqueue_tail();
+            if (n > tail_log && len > ((size_t)1 << tail_log)) {
+                if (resident_ok && len <= ((size_t)1 << res_log)) enqueue_resident();
+                else enq_rc = enqueue_pass();
+            } else enqueue_tail();
         }
     };
     static const bool enqueue_all = getenv("ATLAS_SC_ENQUEUE_LAZY") == nullptr;

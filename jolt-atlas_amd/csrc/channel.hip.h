@@ -76,10 +76,10 @@ __device__ __forceinline__ void ch_stamp(const uint32_t* abort_flag, uint32_t ev
 typedef uint32_t ch_u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void ch_store_sys(void* p, ch_u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");      // (s_nop 1: the data registers are read a cycle after the issue; nothing is padded behind inline asm)
 }
 __device__ __forceinline__ void ch_store_dev(void* p, ch_u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ ch_u32x4 ch_load_dev(const void* p) {
     ch_u32x4 v;

@@ -202,6 +202,153 @@ __global__ __launch_bounds__(SC_THREADS) void k_dot_bind_eval2_f9_pair(Fr* L, Fr
     }
 }
 
+// ---- every bind pass of an instance in ONE resident launch ------------------------------------------------------------------------
+// k_dot_bind_eval2_f9 / _pair are a launch per round: behind every round's arithmetic stood a kernel boundary (the grid drains, the next one
+// is dispatched and its first workgroup starts polling: ~5 us), a launch call on the host thread that runs the transcript, and — under a
+// tracer — the host's lateness.  Here the W workgroups of one launch stay resident over the rounds round0 .. round0 + n_mid - 1:
+// per round every workgroup waits for the challenge (workgroup 0 polls the host slot and fans it out to the HBM replicas, ch_wait_r),
+// binds its share IN PLACE and mails its two sums, exactly as the per-round kernels do — same products, same sums, same records:
+//   * q = len / 4 >= W * 256 quads ("owned" rounds): thread g of the grid takes the quads i = g, g + G, ... (G = W * 256), all four
+//     coefficients of a quad and both halves of what it leaves belong to the same thread in every such round (G divides q), so no round
+//     needs anything another thread wrote: plain loads and stores, the next tile requested before the current one is consumed;
+//   * fewer quads ("pair" rounds): two lanes per quad (lane 2i binds the L pairs, 2i + 1 the R pairs, one product each after a DPP swap),
+//     quad i on workgroup 2 i / 256 — ownership moves between workgroups from round to round, so what a round stores is stored WRITE-THROUGH
+//     (sc1) and drained before the workgroup mails, and read with sc1 loads (past the CU's L1): the host publishes the next challenge only
+//     when it holds every workgroup's record, i.e. after every store of the round has left its CU (MI355X_MICROARCH: sc1 payload + drain).
+//     The last owned round stores write-through as well (the first pair round reads it).  A workgroup without quads in a pair round
+//     has none in any later round and leaves.
+// The rounds below 2^tail_log coefficients stay with k_dot_tail2_f9 (one workgroup, rows in LDS).
+struct DotResidentArgs {
+    Fr* L; Fr* R;
+    unsigned long long len;           // coefficients per operand when the launch starts (the challenge of round round0 - 1 is still to be bound)
+    uint32_t round0, n_mid;           // message rounds served: round0 .. round0 + n_mid - 1 (round k binds challenge k - 1 first)
+    Chunk* mail; uint32_t region_chunks;     // round round0 + t mails into mail + t * region_chunks, a record per workgroup (ch_stride(2) apart)
+    const Chunk* r_host0; Chunk* r_dev0;     // slot / replicas of challenge round0 - 1; challenge j later: + j * CH_SLOT_CHUNKS / + j * dev_slot_chunks
+    uint32_t dev_slot_chunks, r_replicas;
+    uint32_t* abort_flag;
+    uint32_t tag_mail0, tag_r0;       // tag of round round0's records / of challenge round0 - 1; later ones count up
+};
+typedef uint32_t rs_u32x4 __attribute__((ext_vector_type(4)));
+// four coefficients past the L1 (sc1), all eight loads in flight before the one wait
+__device__ __forceinline__ void rs_load4_sc1(const Fr* p0, const Fr* p1, const Fr* p2, const Fr* p3, Fe& a, Fe& b, Fe& c, Fe& d) {
+    rs_u32x4 v0, v1, v2, v3, v4, v5, v6, v7;
+    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %9, off sc1\n\tglobal_load_dwordx4 %3, %9, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %4, %10, off sc1\n\tglobal_load_dwordx4 %5, %10, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %6, %11, off sc1\n\tglobal_load_dwordx4 %7, %11, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+    a.v[0] = v0.x; a.v[1] = v0.y; a.v[2] = v0.z; a.v[3] = v0.w; a.v[4] = v1.x; a.v[5] = v1.y; a.v[6] = v1.z; a.v[7] = v1.w;
+    b.v[0] = v2.x; b.v[1] = v2.y; b.v[2] = v2.z; b.v[3] = v2.w; b.v[4] = v3.x; b.v[5] = v3.y; b.v[6] = v3.z; b.v[7] = v3.w;
+    c.v[0] = v4.x; c.v[1] = v4.y; c.v[2] = v4.z; c.v[3] = v4.w; c.v[4] = v5.x; c.v[5] = v5.y; c.v[6] = v5.z; c.v[7] = v5.w;
+    d.v[0] = v6.x; d.v[1] = v6.y; d.v[2] = v6.z; d.v[3] = v6.w; d.v[4] = v7.x; d.v[5] = v7.y; d.v[6] = v7.z; d.v[7] = v7.w;
+}
+__device__ __forceinline__ void rs_store_sc1(Fr* p, const Fe& a) {
+    const rs_u32x4 lo = {a.v[0], a.v[1], a.v[2], a.v[3]}, hi = {a.v[4], a.v[5], a.v[6], a.v[7]};
+    // (s_nop 1 closes the string: a store of more than 8 bytes reads its data registers a cycle after it issues, and hipcc pads nothing
+    // behind inline asm — without it the next instruction overwrote v[hi] and every bound value of an owned write-through round went out wrong)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1\n\ts_nop 1" ::"v"(p), "v"(lo), "v"(hi) : "memory");
+}
+__device__ __forceinline__ F9 f9_dpp_swap1(const F9& a);
+static __global__ __launch_bounds__(SC_THREADS) void k_dot_resident2_f9(DotResidentArgs A) {
+    using P9 = Fr9Params;
+    __shared__ F9 red9r[SC_THREADS / 64][2];
+    __shared__ uint32_t stage9r[18];
+    const size_t G = (size_t)gridDim.x * SC_THREADS, g = (size_t)blockIdx.x * SC_THREADS + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    size_t len = (size_t)A.len;
+    for (uint32_t t = 0; t < A.n_mid; t++, len >>= 1) {
+        const size_t q = len / 4;
+        const bool owned = q >= G;
+        if (!owned && (size_t)blockIdx.x * SC_THREADS >= 2 * q) return;        // no quad for this workgroup in this round, nor in any later one
+        RoundIo io;
+        io.mail = A.mail + (size_t)t * A.region_chunks;
+        io.r_host = A.r_host0 + (size_t)t * CH_SLOT_CHUNKS; io.r_dev = A.r_dev0 + (size_t)t * A.dev_slot_chunks; io.r_replicas = A.r_replicas;
+        io.abort_flag = A.abort_flag; io.tag_mail = A.tag_mail0 + t; io.tag_r = A.tag_r0 + t; io.tag_step = 1;
+        F9 acc0 = f9_zero(), acc2 = f9_zero();
+        if (owned) {
+            // the LAST owned round stores write-through: the pair round that follows reads it from other CUs.  (Only that one: a write-through
+            // store does not refresh the line this CU's L1 holds from its own earlier plain load, so an owned round that read sc1-stored data
+            // with plain loads saw the values of two rounds before — the n = 20 instance of tests/test_gpu_full_size.py.)
+            const bool wt = q < 2 * G;
+            size_t i = g;
+            Fe x0, x1, x2, x3, y0, y1, y2, y3;
+            x0 = fe_load(A.L + i); x1 = fe_load(A.L + i + q); x2 = fe_load(A.L + i + 2 * q); x3 = fe_load(A.L + i + 3 * q);       // in flight under the wait
+            y0 = fe_load(A.R + i); y1 = fe_load(A.R + i + q); y2 = fe_load(A.R + i + 2 * q); y3 = fe_load(A.R + i + 3 * q);
+            uint64_t lo, hi;
+            if (!ch_wait_r(io, lo, hi)) return;
+            const F9 r32 = f9_shl5(f9_from_fe(challenge_to_mont(lo, hi, 0)));
+            for (; i < q; i += G) {
+                const F9 a0 = f9_from_fe(x0), a1 = f9_from_fe(x1), a2 = f9_from_fe(x2), a3 = f9_from_fe(x3);
+                const F9 b0 = f9_from_fe(y0), b1 = f9_from_fe(y1), b2 = f9_from_fe(y2), b3 = f9_from_fe(y3);
+                const size_t nx = i + G;
+                if (nx < q) {
+                    x0 = fe_load(A.L + nx); x1 = fe_load(A.L + nx + q); x2 = fe_load(A.L + nx + 2 * q); x3 = fe_load(A.L + nx + 3 * q);
+                    y0 = fe_load(A.R + nx); y1 = fe_load(A.R + nx + q); y2 = fe_load(A.R + nx + 2 * q); y3 = fe_load(A.R + nx + 3 * q);
+                }
+                const F9 l0 = f9_mul_addred<P9, 4>(f9_sub<P9>(a2, a0), r32, a0), l1 = f9_mul_addred<P9, 4>(f9_sub<P9>(a3, a1), r32, a1);
+                const F9 r0 = f9_mul_addred<P9, 4>(f9_sub<P9>(b2, b0), r32, b0), r1 = f9_mul_addred<P9, 4>(f9_sub<P9>(b3, b1), r32, b1);
+                if (wt) {
+                    rs_store_sc1(A.L + i, f9_to_fe(l0)); rs_store_sc1(A.L + i + q, f9_to_fe(l1));
+                    rs_store_sc1(A.R + i, f9_to_fe(r0)); rs_store_sc1(A.R + i + q, f9_to_fe(r1));
+                } else {
+                    fe_store(A.L + i, f9_to_fe(l0)); fe_store(A.L + i + q, f9_to_fe(l1));
+                    fe_store(A.R + i, f9_to_fe(r0)); fe_store(A.R + i + q, f9_to_fe(r1));
+                }
+                const F9 l2 = f9_norm(f9_add(l1, f9_sub<P9>(l1, l0))), r2 = f9_add(r1, f9_sub<P9>(r1, r0));
+                acc0 = f9_mul_addred<P9>(l0, r0, acc0);
+                acc2 = f9_mul_addred<P9>(l2, r2, acc2);
+            }
+            if (wt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wavefront's stores have left the CU before its workgroup mails
+            acc0 = f9_wave_sum_lazy(f9_norm_red<P9, 1>(acc0));
+            acc2 = f9_wave_sum_lazy(f9_norm_red<P9, 1>(acc2));
+            if (lane == 0) { red9r[wave][0] = acc0; red9r[wave][1] = acc2; }
+        } else {
+            const size_t i = g >> 1;
+            const uint32_t h = threadIdx.x & 1u;
+            Fr* const S = h ? A.R : A.L;
+            const bool live = i < q;
+            uint64_t lo, hi;
+            if (!ch_wait_r(io, lo, hi)) return;                                   // (the loads wait for the challenge: what they read was stored in the round before)
+            const F9 r32 = f9_shl5(f9_from_fe(challenge_to_mont(lo, hi, 0)));
+            Fe s0 = fe_zero(), s1 = fe_zero(), s2 = fe_zero(), s3 = fe_zero();
+            const size_t ii = live ? i : 0;
+            rs_load4_sc1(S + ii, S + ii + q, S + ii + 2 * q, S + ii + 3 * q, s0, s1, s2, s3);
+            if (!live) { s0 = fe_zero(); s1 = fe_zero(); s2 = fe_zero(); s3 = fe_zero(); }
+            const F9 a0 = f9_from_fe(s0), a1 = f9_from_fe(s1), a2 = f9_from_fe(s2), a3 = f9_from_fe(s3);
+            const F9 v0 = f9_mul_addred<P9, 4>(f9_sub<P9>(a2, a0), r32, a0);
+            const F9 v1 = f9_mul_addred<P9, 4>(f9_sub<P9>(a3, a1), r32, a1);
+            if (live) { rs_store_sc1(S + i, f9_to_fe(v0)); rs_store_sc1(S + i + q, f9_to_fe(v1)); }
+            const F9 w0 = f9_dpp_swap1(v0), w1 = f9_dpp_swap1(v1);
+            const F9 l2 = f9_norm(f9_add(w1, f9_sub<P9>(w1, w0))), r2 = f9_add(v1, f9_sub<P9>(v1, v0));
+            F9 x, y;
+#pragma unroll
+            for (int k = 0; k < 9; k++) { x.l[k] = h ? l2.l[k] : v0.l[k]; y.l[k] = h ? r2.l[k] : w0.l[k]; }
+            F9 acc = f9_mul<P9>(x, y);
+            acc = f9_add_dpp<0x4e>(acc);
+            acc = f9_add_dpp<0x124>(acc);
+            acc = f9_add_dpp<0x128>(acc);
+            acc = f9_norm(acc);
+            acc = f9_add(acc, f9_shfl_xor(acc, 16));
+            acc = f9_norm(f9_add(acc, f9_shfl_xor(acc, 32)));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the stores above have left the CU
+            if (lane < 2) red9r[wave][lane] = acc;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            F9 sres = f9_zero();
+            if (threadIdx.x < 2) {
+                sres = red9r[0][threadIdx.x];
+#pragma unroll
+                for (int w = 1; w < SC_THREADS / 64; w++) sres = f9_add(sres, red9r[w][threadIdx.x]);
+                sres = f9_norm(sres);
+            }
+            ch_mail_wave_f9(io, blockIdx.x * ch_stride(2), 2, sres, stage9r);
+        }
+        __syncthreads();                                                          // red9r / ch_wait_r's slot are reused by the next round
+    }
+}
+
 // ---- degree-2 tail over the round channel on the lazy limbs ---------------------------------------
 // Same contract as k_dot_tail_ch<2> (EqSchedule::None, challenge mode 0): every remaining round of an
 // instance of <= 2^11 coefficients in one resident launch, transcript on the host.  Laid out for the
