@@ -515,7 +515,8 @@ def main():
         import build_graphs as BG
         from jolt_atlas_amd import graph as GG
         out["prove_graph"] = {"note": "ONNXProof::prove over the builder's reading of the loader's operator decomposition, shapes padded to powers of two; microgpt / nanogpt: the model files' tensors and example inputs, GPT-2 shapes: random-init; "
-                                      "full operator decomposition (SoftmaxLastAxis, tanh-GELU, LayerNorm, GatherSmall); reference (M3 CPU): nanoGPT 2.288 s, GPT-2 12 layers 14.889 s"}
+                                      "full operator decomposition (SoftmaxLastAxis, tanh-GELU, LayerNorm, GatherSmall); the GPT-2 shapes build c_attn as ONE 768 -> 2304 MatMul padded to 1024 x 4096 + a three-way split, "
+                                      "as the HF export jolt-atlas-core/examples/gpt2.rs loads has it (round 6; rounds 3-5 timed three 1024-wide projections: 854 nodes, 8823 polynomials); reference (M3 CPU): nanoGPT 2.288 s, GPT-2 12 layers 14.889 s"}
         # microgpt / nanogpt: the model files' own tensors (quantised at 2^14) and example token ids (tests/golden/ref_models.npz, tools/extract_ref_model.py) over the
         # builder's reading of the loader's operator decomposition; the GPT-2 shapes: random-init (no GPT-2 file in the reference tree)
         for gname in ("microgpt", "nanogpt", "gpt2_layer") + (() if args.no_gpt2_full else ("gpt2",)):
