@@ -143,6 +143,9 @@ struct Pipeline {
     int begin() {               // the caller holds rt().mu
         for (auto& L : lanes) { max_rounds = L.rounds > max_rounds ? L.rounds : max_rounds; }
         for (auto& L : lanes) { L.offset = max_rounds - L.rounds; L.mails.resize(L.rounds); }
+        host_only = max_rounds;
+        for (auto& L : lanes) { const size_t hp = L.offset + (L.inst->host_prefix() < L.rounds ? L.inst->host_prefix() : L.rounds); host_only = hp < host_only ? hp : host_only; }
+        if (lanes.size() < 2) host_only = 0;
         if (max_rounds == 0 || max_rounds > atlas_rt::Channel::RING / 2) return fail(ATLAS_EINVAL, "pipelined prove: round count");
         if (C.abort_dirty) { HIP_TRY(hipMemsetAsync(C.d_abort, 0, 4, rt().stream)); C.abort_dirty = false; }
         tag0 = C.take_tags((max_rounds + 2) * (lanes.size() + 1));
@@ -192,8 +195,15 @@ struct Pipeline {
     void query() { (void)hipStreamQuery(rt().stream); if (side) for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) (void)hipStreamQuery(side_streams()[i]); }
     void drain() { if (side) for (size_t i = 0; i < N_SIDE && i < lanes.size(); i++) (void)hipStreamSynchronize(side_streams()[i]); (void)hipStreamSynchronize(rt().stream); join(); }
     // make sure the launches of global rounds < R + LOOKAHEAD (and the final binds after the last) are enqueued
+    // host_only = the leading global rounds in which no lane waits for the device (a one-hot batch: Booleanity's four address rounds, RaVirtual
+    // not started yet).  Those rounds are ~3 us of host arithmetic each, so every launch made between them is on the batch's critical path:
+    // everything up to the first device round is enqueued at once in begin() (RaVirtual's first product runs under the address rounds), nothing
+    // more until they are over, and the usual lookahead from there on — when a round's launches hide in the wait for the round before.
+    size_t host_only = 0;
     int advance(size_t R) {
-        while (next_enqueue <= max_rounds && next_enqueue < R + LOOKAHEAD) {
+        static const bool flat = getenv("ATLAS_LOOKAHEAD_FLAT") != nullptr;          // A-B
+        const size_t limit = (!flat && R < host_only) ? host_only + 1 : R + LOOKAHEAD;
+        while (next_enqueue <= max_rounds && next_enqueue < limit) {
             const size_t Q = next_enqueue++;
             for (size_t li = 0; li < lanes.size(); li++) {
                 Lane& L = lanes[li];

@@ -58,6 +58,9 @@ struct atlas_instance {
     virtual int shared_ingest_step(const atlas_u128_t& /*r*/, size_t /*round*/) { return ATLAS_OK; }
     // does enqueue(round) launch nothing at all (host-only rounds: the driver then has nothing new for the runtime to retire)?
     virtual bool silent_round(size_t /*round*/) const { return false; }
+    // how many of this instance's FIRST rounds wait for nothing from the device (Booleanity's address rounds; every round of HammingWeight):
+    // while every lane of a batch is inside such a prefix the rounds are host arithmetic, and a launch made there is on the critical path
+    virtual size_t host_prefix() const { return 0; }
     // does this instance never launch anything when it is stepped through the round channel (HammingWeight: host arithmetic only)?
     virtual bool silent_lane() const { return false; }
     static constexpr size_t WIDE_WAIT_WGS = 256;

@@ -733,6 +733,31 @@ __global__ __launch_bounds__(RA_THREADS) void k_bool_expand_ch(Fr* F, uint32_t n
     }
 }
 __global__ void k_bool_expand_init(Fr* F) { if (threadIdx.x == 0) fe_store(F, fr_one()); }
+// The same table for ALL n <= 8 address challenges in ONE launch (every lookup of the graph prover: chunks of 4 bits): lane k of the first
+// wavefront polls slot k — one crossing of the host link, not n in turn — and the table doubles in LDS.  A launch per address round was five
+// launches (~5 us of the host thread each) in rounds that are host arithmetic otherwise, i.e. on the batch's critical path.
+struct BoolSlots { const Chunk* host[8]; uint32_t tag[8]; uint32_t n; uint32_t* abort_flag; int challenge_mode; };
+__global__ __launch_bounds__(RA_THREADS) void k_bool_expand_all_ch(Fr* F, BoolSlots S) {
+    __shared__ uint64_t s_r[8][2];
+    __shared__ uint32_t s_bad;
+    __shared__ Fr tab[RA_THREADS];
+    if (threadIdx.x == 0) { s_bad = 0; tab[0] = fr_one(); }
+    __syncthreads();
+    if (threadIdx.x < S.n) {
+        uint64_t lo = 0, hi = 0;
+        if (!ch_poll_slot<true>(S.host[threadIdx.x], S.tag[threadIdx.x], S.abort_flag, lo, hi)) atomicOr(&s_bad, 1u);
+        s_r[threadIdx.x][0] = lo; s_r[threadIdx.x][1] = hi;
+    }
+    __syncthreads();
+    if (s_bad) return;
+    for (uint32_t k = 0; k < S.n; k++) {                 // ExpandingTable::update, LowToHigh: F[n + x] = r F[x], F[x] -= F[n + x]
+        const Fr r = challenge_to_mont(s_r[k][0], s_r[k][1], S.challenge_mode);
+        const uint32_t n = 1u << k;
+        if (threadIdx.x < n) { const Fr f = tab[threadIdx.x], hi = fr_mul(f, r); tab[n + threadIdx.x] = hi; tab[threadIdx.x] = fr_sub(f, hi); }
+        __syncthreads();
+    }
+    if (threadIdx.x < (1u << S.n)) fe_store(F + threadIdx.x, tab[threadIdx.x]);
+}
 
 // ---------------------------------------------------------------- BooleanitySumcheckProver
 struct Booleanity : atlas_instance {
@@ -870,6 +895,10 @@ struct Booleanity : atlas_instance {
     bool have_finals = false;
     std::vector<H::Fr> mailed_finals;
     bool pipelined() const override { return log_k <= 15 && log_T >= 1; }
+    BoolSlots slots{};
+    bool one_expand() const { static const bool off = getenv("ATLAS_BOOL_EXPAND_PER_ROUND") != nullptr; return log_k >= 1 && log_k <= 8 && !off; }     // A-B
+    bool silent_round(size_t round) const override { return round < log_k && one_expand(); }     // the address rounds launch nothing
+    size_t host_prefix() const override { return one_expand() ? log_k : 0; }
     // cycle round p >= 1 in one launch (k_bool_bind_fold); ATLAS_RA_NO_FUSE / ATLAS_NO_MAIL_TAIL: the separate launches (diagnosis, A-B)
     bool fused(size_t p) const {
         static const bool off = getenv("ATLAS_RA_NO_FUSE") != nullptr || getenv("ATLAS_BOOL_NO_FUSE") != nullptr || getenv("ATLAS_NO_MAIL_TAIL") != nullptr;
@@ -884,11 +913,17 @@ struct Booleanity : atlas_instance {
         if (round >= rounds() || (round > 0) != bind_prev) return fail(ATLAS_ESTATE, "booleanity: enqueue out of order");
         const ChanIo cio{io, rt().challenge_mode};
         mail.base = io.mail; mail.blocks = 0; mail.n_vals = 0; mail.radix = 32; mail.shl = 0;
-        if (round == 0) {
-            if (!d_F) HIP_TRY(hipMalloc(&d_F, ((size_t)1 << log_k) * sizeof(Fr)));
-            k_bool_expand_init<<<1, 64, 0, rt().stream>>>(d_F);
+        if (round == 0 && !d_F) HIP_TRY(hipMalloc(&d_F, ((size_t)1 << log_k) * sizeof(Fr)));
+        if (one_expand()) {                                           // the expanding table in one launch, with the first cycle round (k_bool_expand_all_ch)
+            if (round >= 1 && round <= log_k) { slots.host[round - 1] = io.r_host; slots.tag[round - 1] = io.tag_r; }
+            if (round == log_k) {
+                slots.n = (uint32_t)log_k; slots.abort_flag = io.abort_flag; slots.challenge_mode = rt().challenge_mode;
+                k_bool_expand_all_ch<<<1, RA_THREADS, 0, rt().stream>>>(d_F, slots);
+            }
+        } else {
+            if (round == 0) k_bool_expand_init<<<1, 64, 0, rt().stream>>>(d_F);
+            if (round >= 1 && round <= log_k) k_bool_expand_ch<<<1, RA_THREADS, 0, rt().stream>>>(d_F, 1u << (round - 1), cio);
         }
-        if (round >= 1 && round <= log_k) k_bool_expand_ch<<<1, RA_THREADS, 0, rt().stream>>>(d_F, 1u << (round - 1), cio);
         if (round < log_k) return ATLAS_OK;
         const size_t T = (size_t)1 << log_T, p = round - log_k, len = T >> p, n_groups = len / 2;
         if (lazy && p <= 1) {
@@ -1014,6 +1049,8 @@ struct HammingWeight : atlas_instance {
     bool pipelined() const override { return true; }
     bool wide_wait(size_t) const override { return false; }
     bool silent_lane() const override { return true; }
+    size_t host_prefix() const override { return log_k; }
+    bool silent_round(size_t) const override { return true; }
     int enqueue(size_t, const atlas::RoundIo& io, bool, atlas_mail_ref& mail) override { mail.base = io.mail; mail.blocks = 0; mail.n_vals = 0; return ATLAS_OK; }
     int finish(size_t round, const H::Fr& claim, const H::Fr*, std::vector<H::Fr>& coeffs) override { return message(round, claim, coeffs); }
     int host_ingest(const atlas_u128_t& r, size_t round) override { return ingest(r, round); }
