@@ -5,6 +5,9 @@
 // joltworks/src/transcripts/blake2b.rs.  This is product code: it shares nothing with
 // oracle/.
 #pragma once
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -309,7 +312,7 @@ struct Blake2b256 {
         h[0] ^= 0x01010020ULL; buflen = 0; t = 0;
     }
     static uint64_t rotr(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
-    void compress(const uint8_t* block, bool last) {
+    void compress_portable(const uint8_t* block, bool last) {
         static const uint64_t IV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL,
                                        0xa54ff53a5f1d36f1ULL, 0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL,
                                        0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
@@ -336,6 +339,62 @@ struct Blake2b256 {
         }
         for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8];
     }
+    // The same compression on AVX2 (rows of the 4 x 4 state as four 256-bit vectors, the column and diagonal steps of a round as two vector
+    // G's with lane rotations in between — the layout of the BLAKE2 reference's blake2b-round.h).  Measured and NOT adopted (round 6): 1.3x
+    // faster per call in a loop of its own, and 2-3 % SLOWER over whole proofs on the GPU box's host in three alternations
+    // (profiles/r06m_blake_ab.txt: nanoGPT iop 303-310 ms against 287-296) — a compression every few microseconds between scalar field
+    // arithmetic pays for the vector unit's state more than it saves.  ATLAS_BLAKE_AVX2=1 selects it; same function (checked against the loop
+    // on 20 000 random blocks and hashlib's vectors).  What IS kept from the experiment: a transcript step is ONE block built in place (tr_absorb).
+#if defined(__x86_64__)
+    __attribute__((target("avx2"))) void compress_avx2(const uint8_t* block, bool last) {
+        static const uint64_t IV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL,
+                                       0xa54ff53a5f1d36f1ULL, 0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL,
+                                       0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+        static const uint8_t S[12][16] = {
+            {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+            {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+            {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+            {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+            {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
+            {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
+        uint64_t m[16];
+        std::memcpy(m, block, 128);
+        __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(h)), b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(h + 4));
+        __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(IV));
+        __m256i d = _mm256_xor_si256(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(IV + 4)), _mm256_set_epi64x(0, last ? -1LL : 0, 0, (long long)t));
+        const __m256i a0 = a, b0 = b;
+        const __m256i r24 = _mm256_setr_epi8(3, 4, 5, 6, 7, 0, 1, 2, 11, 12, 13, 14, 15, 8, 9, 10, 3, 4, 5, 6, 7, 0, 1, 2, 11, 12, 13, 14, 15, 8, 9, 10);
+        const __m256i r16 = _mm256_setr_epi8(2, 3, 4, 5, 6, 7, 0, 1, 10, 11, 12, 13, 14, 15, 8, 9, 2, 3, 4, 5, 6, 7, 0, 1, 10, 11, 12, 13, 14, 15, 8, 9);
+#define ATLAS_B2_G(x, y)                                                                                                   \
+        a = _mm256_add_epi64(_mm256_add_epi64(a, b), x); d = _mm256_shuffle_epi32(_mm256_xor_si256(d, a), 0xB1);          \
+        c = _mm256_add_epi64(c, d); b = _mm256_shuffle_epi8(_mm256_xor_si256(b, c), r24);                                 \
+        a = _mm256_add_epi64(_mm256_add_epi64(a, b), y); d = _mm256_shuffle_epi8(_mm256_xor_si256(d, a), r16);            \
+        c = _mm256_add_epi64(c, d); { const __m256i bc = _mm256_xor_si256(b, c); b = _mm256_xor_si256(_mm256_srli_epi64(bc, 63), _mm256_add_epi64(bc, bc)); }
+        for (int r = 0; r < 12; r++) {
+            const uint8_t* s = S[r];
+            {   // columns
+                const __m256i x = _mm256_set_epi64x((long long)m[s[6]], (long long)m[s[4]], (long long)m[s[2]], (long long)m[s[0]]);
+                const __m256i y = _mm256_set_epi64x((long long)m[s[7]], (long long)m[s[5]], (long long)m[s[3]], (long long)m[s[1]]);
+                ATLAS_B2_G(x, y)
+            }
+            b = _mm256_permute4x64_epi64(b, 0x39); c = _mm256_permute4x64_epi64(c, 0x4E); d = _mm256_permute4x64_epi64(d, 0x93);
+            {   // diagonals
+                const __m256i x = _mm256_set_epi64x((long long)m[s[14]], (long long)m[s[12]], (long long)m[s[10]], (long long)m[s[8]]);
+                const __m256i y = _mm256_set_epi64x((long long)m[s[15]], (long long)m[s[13]], (long long)m[s[11]], (long long)m[s[9]]);
+                ATLAS_B2_G(x, y)
+            }
+            b = _mm256_permute4x64_epi64(b, 0x93); c = _mm256_permute4x64_epi64(c, 0x4E); d = _mm256_permute4x64_epi64(d, 0x39);
+        }
+#undef ATLAS_B2_G
+        _mm256_storeu_si256(reinterpret_cast<__m256i*>(h), _mm256_xor_si256(a0, _mm256_xor_si256(a, c)));
+        _mm256_storeu_si256(reinterpret_cast<__m256i*>(h + 4), _mm256_xor_si256(b0, _mm256_xor_si256(b, d)));
+    }
+    static bool use_avx2() { static const bool v = __builtin_cpu_supports("avx2") && getenv("ATLAS_BLAKE_AVX2") != nullptr; return v; }
+#else
+    void compress_avx2(const uint8_t* block, bool last) { compress_portable(block, last); }
+    static bool use_avx2() { return false; }
+#endif
+    void compress(const uint8_t* block, bool last) { if (use_avx2()) compress_avx2(block, last); else compress_portable(block, last); }
     void update(const uint8_t* in, size_t n) {
         while (n) {
             if (buflen == 128) { t += 128; compress(buf, false); buflen = 0; }
@@ -354,6 +413,19 @@ struct Transcript {   // same image as atlas_transcript_t
     uint8_t state[32]; uint32_t n_rounds; uint32_t pad_[3];
 };
 inline void tr_absorb(Transcript& T, const uint8_t* p1, size_t n1, const uint8_t* p2 = nullptr, size_t n2 = 0) {
+    if (n1 + n2 <= 64) {                                       // state | round | <= 64 bytes: ONE block, built in place (every scalar, label and challenge step)
+        Blake2b256 H;
+        uint8_t* blk = H.buf;
+        std::memcpy(blk, T.state, 32);
+        std::memset(blk + 32, 0, 96);
+        blk[60] = (uint8_t)(T.n_rounds >> 24); blk[61] = (uint8_t)(T.n_rounds >> 16); blk[62] = (uint8_t)(T.n_rounds >> 8); blk[63] = (uint8_t)T.n_rounds;
+        if (n1) std::memcpy(blk + 64, p1, n1);
+        if (n2) std::memcpy(blk + 64 + n1, p2, n2);
+        H.t = 64 + n1 + n2;
+        H.compress(blk, true);
+        std::memcpy(T.state, H.h, 32); T.n_rounds += 1;
+        return;
+    }
     Blake2b256 H; uint8_t pre[32] = {0};
     pre[28] = (uint8_t)(T.n_rounds >> 24); pre[29] = (uint8_t)(T.n_rounds >> 16);
     pre[30] = (uint8_t)(T.n_rounds >> 8); pre[31] = (uint8_t)T.n_rounds;
