@@ -377,10 +377,22 @@ int atlas_instance_free(atlas_instance_t i) {
     PROF("atlas_instance_free"); delete i; return ATLAS_OK; }
 
 // Sumcheck::prove (sumcheck.rs:565-599) over one generic instance, host-stepped
+static int instance_prove_impl(atlas_instance_t inst, const atlas_fr_t* input_claim, atlas_transcript_t* transcript,
+                              atlas_fr_t* compressed, size_t row_stride, uint32_t* n_coeffs, atlas_u128_t* challenges);
 int atlas_instance_prove(atlas_instance_t inst, const atlas_fr_t* input_claim, atlas_transcript_t* transcript,
                          atlas_fr_t* compressed, size_t row_stride, uint32_t* n_coeffs, atlas_u128_t* challenges) {
     PROF("atlas_instance_prove");
     NEED_INIT();
+    // a stand-alone caller's proof is the scope of its long-lived mail (channel.hpp); inside the graph prover the node is
+    if (rt().chan.long_scoped) return instance_prove_impl(inst, input_claim, transcript, compressed, row_stride, n_coeffs, challenges);
+    rt().chan.long_used = 0;                                                 // (what the instance took at construction stays valid: the count restarts, the flag is the caller's)
+    int rc = instance_prove_impl(inst, input_claim, transcript, compressed, row_stride, n_coeffs, challenges);
+    if (!rc && !rt().chan.long_check()) rc = fail(ATLAS_ESTATE, "instance_prove: the long-lived mail ring wrapped inside one proof");
+    rt().chan.long_overflow = false;
+    return rc;
+}
+static int instance_prove_impl(atlas_instance_t inst, const atlas_fr_t* input_claim, atlas_transcript_t* transcript,
+                              atlas_fr_t* compressed, size_t row_stride, uint32_t* n_coeffs, atlas_u128_t* challenges) {
     if (!inst || !input_claim || !transcript || !compressed || !n_coeffs || !challenges) return fail(ATLAS_EINVAL, "instance_prove");
     H::Transcript& T = *reinterpret_cast<H::Transcript*>(transcript);
     H::Fr prev = *reinterpret_cast<const H::Fr*>(input_claim);

@@ -123,10 +123,20 @@ struct Channel {
     // Mail of a launch that outlives its round — a resident tail that mails a record per round, tables published at construction and read
     // dozens of rounds later: the round-robin above comes round after 128 launches (4 lanes x 32 rounds), so these take their areas from a
     // ring of their own at the top of the mail (1 MB: hundreds of tails; one or two are alive at a time).
+    // Liveness: the ring does not know what is still read.  Everything taken from it lives inside ONE scope — a node of the graph prover
+    // (instances built ahead, class tables, tails), the opening reduction, or one library-driven proof of a stand-alone caller — so the scope's
+    // owner calls long_mark() when it starts and long_check() when it ends: more than the ring's size handed out in between (or a request the
+    // ring cannot hold, which falls back to the short-lived area) means live mail may have been overwritten, and the proof is refused
+    // (ATLAS_ESTATE) instead of returned with sums nobody can vouch for.
     static constexpr size_t LONG_CHUNKS = (size_t)1 << 16;
-    size_t next_long = 0;
+    size_t next_long = 0, long_used = 0;
+    bool long_overflow = false, long_scoped = false;       // long_scoped: an outer owner (the graph prover) holds the scope
+    void long_mark() { long_used = 0; long_overflow = false; }
+    bool long_check() const { return !long_overflow; }
     atlas::Chunk* alloc_long(size_t n) {
         n = (n + 3) & ~(size_t)3;
+        long_used += n;
+        if (n > LONG_CHUNKS || long_used > LONG_CHUNKS) long_overflow = true;
         if (n > LONG_CHUNKS) return alloc(n);
         if (next_long + n > LONG_CHUNKS) next_long = 0;
         atlas::Chunk* p = mail + (MAIL_CHUNKS - LONG_CHUNKS) + next_long;

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <mutex>
 
 #include "graph_state.hip.h"
 
@@ -287,12 +288,33 @@ static double atlas_erf_cheb(double x) {
     };
     return x >= 0.0 ? 1.0 - erfccheb(x) : erfccheb(-x) - 1.0;
 }
+// The device copies of the tables below hang off the RUNTIME they were uploaded under (Runtime::graph_tables) and go with it in atlas_shutdown:
+// several threads may share the process runtime, a thread may own one on another device, and a runtime may be shut down and brought up again
+// on another device — a thread_local pointer freed by whichever thread happened to shut down served stale memory afterwards.  The host tables
+// are values only: one copy per process, built once under g_host_tables_mu.
+struct GraphDevTables { int32_t* trig[2] = {nullptr, nullptr}; int32_t* act[3] = {nullptr, nullptr, nullptr}; int32_t* exp = nullptr; ExpLut exp_lut; };
+static std::mutex g_host_tables_mu;
+static GraphDevTables& graph_dev_tables() {                 // callers hold rt().mu
+    atlas_rt::Runtime& R = rt();
+    if (!R.graph_tables) {
+        R.graph_tables = new GraphDevTables();
+        R.at_shutdown.push_back([] {
+            GraphDevTables* t = static_cast<GraphDevTables*>(rt().graph_tables);
+            if (!t) return;
+            for (int32_t* p : {t->trig[0], t->trig[1], t->act[0], t->act[1], t->act[2], t->exp}) if (p) (void)hipFree(p);
+            delete t;
+            rt().graph_tables = nullptr;
+        });
+    }
+    return *static_cast<GraphDevTables*>(R.graph_tables);
+}
 int atlas_rt_trig_table(int op, const int32_t** d_table, const std::vector<int32_t>** h_table) {
-    static thread_local std::vector<int32_t> host[2];      // (per thread: a thread may own a runtime on a device of its own, runtime.hpp)
-    static thread_local int32_t* dev[2] = {nullptr, nullptr};
+    static std::vector<int32_t> host[2];
     const int k = op == ATLAS_OP_SIN ? 0 : op == ATLAS_OP_COS ? 1 : -1;
     if (k < 0) return fail(ATLAS_EINVAL, "trig_table: not Sin / Cos");
     std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+    std::lock_guard<std::mutex> hl(g_host_tables_mu);
+    int32_t** dev = graph_dev_tables().trig;
     if (host[k].empty()) {                                                    // SinTable / CosTable::materialize (neural_teleport/sin.rs:26-41)
         const size_t n = (size_t)1 << gr::TRIG_TABLE_VARS;
         const double scale = (double)((uint64_t)1 << (gr::MODEL_SCALE - gr::TRIG_DOWNSCALE_BITS));
@@ -306,19 +328,18 @@ int atlas_rt_trig_table(int op, const int32_t** d_table, const std::vector<int32
         HIP_TRY(hipMalloc(&dev[k], host[k].size() * 4));
         HIP_TRY(hipMemcpyAsync(dev[k], host[k].data(), host[k].size() * 4, hipMemcpyHostToDevice, rt().stream));
         HIP_TRY(hipStreamSynchronize(rt().stream));
-        static thread_local bool registered = false;
-        if (!registered) { registered = true; rt().at_shutdown.push_back([] { for (auto& d : dev) if (d) { (void)hipFree(d); d = nullptr; } registered = false; }); }
     }
     if (d_table) *d_table = dev[k];
     if (h_table) *h_table = &host[k];
     return ATLAS_OK;
 }
 int atlas_rt_activation_table(int op, const int32_t** d_table, const std::vector<int32_t>** h_table) {
-    static thread_local std::vector<int32_t> host[3];
-    static thread_local int32_t* dev[3] = {nullptr, nullptr, nullptr};
+    static std::vector<int32_t> host[3];
     const int k = op == ATLAS_OP_TANH ? 0 : op == ATLAS_OP_ERF ? 1 : op == ATLAS_OP_SIGMOID ? 2 : -1;
     if (k < 0) return fail(ATLAS_EINVAL, "activation_table: not a small-table activation");
     std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+    std::lock_guard<std::mutex> hl(g_host_tables_mu);
+    int32_t** dev = graph_dev_tables().act;
     if (host[k].empty()) {
         const size_t n = (size_t)1 << gr::ACTIVATION_TABLE_VARS;
         const double scale = (double)((uint64_t)1 << gr::MODEL_SCALE);
@@ -334,8 +355,6 @@ int atlas_rt_activation_table(int op, const int32_t** d_table, const std::vector
         HIP_TRY(hipMalloc(&dev[k], host[k].size() * 4));
         HIP_TRY(hipMemcpyAsync(dev[k], host[k].data(), host[k].size() * 4, hipMemcpyHostToDevice, rt().stream));
         HIP_TRY(hipStreamSynchronize(rt().stream));
-        static thread_local bool registered = false;
-        if (!registered) { registered = true; rt().at_shutdown.push_back([] { for (auto& d : dev) if (d) { (void)hipFree(d); d = nullptr; } registered = false; }); }
     }
     if (d_table) *d_table = dev[k];
     if (h_table) *h_table = &host[k];
@@ -343,9 +362,10 @@ int atlas_rt_activation_table(int op, const int32_t** d_table, const std::vector
 }
 
 int atlas_rt_exp_lut(const ExpLut** out) {
-    static thread_local ExpLut L;
-    static thread_local int32_t* dev = nullptr;
     std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+    GraphDevTables& GT = graph_dev_tables();
+    ExpLut& L = GT.exp_lut;                                  // (the sub-tables are a few hundred entries: a copy per runtime, with ITS device pointers)
+    int32_t*& dev = GT.exp;
     if (L.hi.empty()) {
         const double sf = (double)((uint64_t)1 << gr::MODEL_SCALE);
         const size_t needed = (size_t)std::ceil(sf * std::log(2.0 * sf)) + 2;                  // the flat LUT's cutoff exp(-i/S) S < 0.5
@@ -363,7 +383,6 @@ int atlas_rt_exp_lut(const ExpLut** out) {
         HIP_TRY(hipMemcpyAsync(dev + L.hi.size(), L.lo.data(), L.lo.size() * 4, hipMemcpyHostToDevice, rt().stream));
         HIP_TRY(hipStreamSynchronize(rt().stream));
         L.d_hi = dev; L.d_lo = dev + L.hi.size();
-        rt().at_shutdown.push_back([] { if (dev) { (void)hipFree(dev); dev = nullptr; L.d_hi = L.d_lo = nullptr; } });
     }
     *out = &L;
     return ATLAS_OK;

@@ -1530,7 +1530,9 @@ struct Prover : FlowSink {
     int prove_node(const Node& nd) {
         cur = nd.idx;
         mark(nullptr);
-        const int rc = prove_node_flow(nd);
+        rt().chan.long_mark();                                               // the node is the scope of its long-lived mail (channel.hpp)
+        int rc = prove_node_flow(nd);
+        if (!rc && !rt().chan.long_check()) rc = fail(ATLAS_ESTATE, "prove_graph: the long-lived mail ring wrapped inside one node");
         mark("(rest of the node)");
         return rc;
     }
@@ -1686,6 +1688,7 @@ static int prove_graph_impl(atlas_graph_t G, atlas_srs_t srs, atlas_shard_group_
     if (atlas_rt::Prof::on()) atlas_rt::Prof::get().reset();
     const bool gtrace = getenv("ATLAS_GRAPH_TRACE") != nullptr;             // per-operator wall clock of the node loop on stderr
     std::map<int, std::pair<double, size_t>> per_op;
+    struct LongScope { atlas_rt::Channel& C; bool was; explicit LongScope(atlas_rt::Channel& c) : C(c), was(c.long_scoped) { C.long_scoped = true; } ~LongScope() { C.long_scoped = was; } } long_scope(rt().chan);
     for (auto it = G->nodes.rbegin(); it != G->nodes.rend() && !rc; ++it) {
         const auto tn0 = gtrace ? now() : t2;
         rc = P.prove_node(it->second);
@@ -1696,7 +1699,9 @@ static int prove_graph_impl(atlas_graph_t G, atlas_srs_t srs, atlas_shard_group_
     if (atlas_rt::Prof::on()) { atlas_rt::Prof::get().dump(stderr, "node loop (iop)"); atlas_rt::Prof::get().reset(); }
     if (gtrace) for (auto& kv : per_op) fprintf(stderr, "[atlas graph] op %2d  x%-4zu %9.3f ms  (%.3f ms each)\n", kv.first, kv.second.second, kv.second.first, kv.second.first / kv.second.second);
     const auto t3 = now();
+    rt().chan.long_mark();                                                   // the opening reduction is a scope of its own
     if (!rc) rc = P.reduced_openings(nullptr);
+    if (!rc && !rt().chan.long_check()) rc = fail(ATLAS_ESTATE, "prove_graph: the long-lived mail ring wrapped inside the opening reduction");
     const auto t4 = now();
     if (atlas_rt::Prof::on()) { atlas_rt::Prof::get().dump(stderr, "prove_reduced_openings"); atlas_rt::Prof::get().reset(); }
     if (rc) return rc;

@@ -549,6 +549,8 @@ void release_arenas() {            // atlas_shutdown
     if (side_stream) { hipStreamDestroy(side_stream); side_stream = nullptr; }
     if (side_stream2) { hipStreamDestroy(side_stream2); side_stream2 = nullptr; }
     if (side_event) { hipEventDestroy(side_event); side_event = nullptr; }
+    delete static_cast<MsmState*>(rt().msm_ws);      // the state itself goes with the runtime it belongs to (atlas_shutdown / atlas_shutdown_thread)
+    rt().msm_ws = nullptr;
 }
 
 // Up to three pipelines side by side: the vectors long enough for the fixed-base table (when the SRS has one), the other

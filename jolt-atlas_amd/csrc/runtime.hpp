@@ -51,6 +51,7 @@ struct Runtime {
     std::vector<void (*)()> at_shutdown;   // release hooks of the translation units that keep device arenas
     struct DevPool* pool = nullptr;        // the caching allocator of this runtime (devpool.hpp): blocks are reused in the order of ITS streams
     void* msm_ws = nullptr;                // msm.hip's workspace (one per runtime: it lives on the runtime's device)
+    void* graph_tables = nullptr;          // graph_exec.hip's device copies of the trig / activation / exp tables (per runtime: they live on ITS device)
     Mutex mu;
 };
 // One Runtime per PROCESS by default (g_default: what every thread sees that never asked for its own), and one per THREAD for the threads
