@@ -151,7 +151,7 @@ struct Pipeline {
         tag0 = C.take_tags((max_rounds + 2) * (lanes.size() + 1));
         slot0 = C.take_slots(max_rounds);
         static const bool no_side = getenv("ATLAS_NO_LANE_STREAMS") != nullptr;
-        side = lanes.size() > 1 && !no_side;
+        side = lanes.size() > 1 && !no_side && !rt().no_lane_streams;
         if (side) {
             hipStream_t* st = side_streams();
             if (!st[0])

@@ -10,6 +10,7 @@
 // Host glue over the library's instance provers; the O(T) work is in their kernels.  Every scalar the reference appends
 // to the ProverOpeningAccumulator is appended here in the same order under the same OpeningId.
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 
 #include <algorithm>
 
@@ -1743,7 +1744,30 @@ extern "C" int atlas_prove_graph_sharded(atlas_graph_t G, atlas_srs_t srs, atlas
         (void)hipStreamSynchronize(rt().stream);
         (void)rt().chan.set_device_timeout(dev_wait * grp->world, rt().stream);
     }
+    // Do ranks share a device?  (The test box: N processes on ONE GPU.)  Every rank's lane streams, gates and resident launches then compete
+    // for the same hardware queues, and from three ranks on a lane's polling launch can sit in front of the launch it waits for — the 12-layer
+    // graph at world 4 on one GPU stalled until the channel's timeout with lane streams and takes 15 s without.  The ranks exchange their
+    // devices' PCI addresses; a rank whose device serves three or more of them keeps the lanes of its batches on the library stream for the call.
+    bool lanes_were = rt().no_lane_streams, shared_checked = false;
+    if (grp->world > 2 && rt().ready) {
+        int dom = 0, bus = 0, dev = 0;
+        (void)hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, rt().device);
+        (void)hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, rt().device);
+        (void)hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, rt().device);
+        char host[64] = {0};
+        (void)gethostname(host, sizeof(host) - 1);
+        uint64_t hh = 1469598103934665603ull;
+        for (const char* c = host; *c; c++) hh = (hh ^ (uint8_t)*c) * 1099511628211ull;
+        const uint64_t mine[2] = {((uint64_t)(uint32_t)dom << 32) | ((uint64_t)(uint32_t)bus << 16) | (uint32_t)dev, hh};
+        std::vector<uint64_t> all(2 * (size_t)grp->world);
+        if (!grp->allgather(mine, sizeof(mine), all.data())) return fail(ATLAS_ENODEV, "prove_graph_sharded: a rank did not answer (device addresses)");
+        int sharing = 0;
+        for (int r = 0; r < grp->world; r++) sharing += all[2 * r] == mine[0] && all[2 * r + 1] == mine[1];
+        shared_checked = true;
+        if (sharing >= 3) rt().no_lane_streams = true;
+    }
     int rc = prove_graph_impl(G, srs, grp, inputs, n_inputs, proof, cap, proof_len, final_transcript, timing);
+    if (shared_checked) rt().no_lane_streams = lanes_were;
     if (grp->world > 1 && rt().ready) {
         std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
         rt().chan.host_wait_s = host_wait;

@@ -47,6 +47,7 @@ struct Runtime {
     uint64_t* d_chal = nullptr;        // up to 64 rounds * 2
     atlas::Fe* d_finals = nullptr;     // 3 (+ scratch for reduced evals)
     void* h_pinned = nullptr;          // pinned staging for small D2H/H2D
+    bool no_lane_streams = false;      // the lanes of a pipelined batch stay on the library stream (set while several ranks' processes share THIS device: graph_prove.hip)
     int pending_async = 0;             // launches of shared_message_step calls whose results the driver has not waited for yet (batched.hip)
     std::vector<void (*)()> at_shutdown;   // release hooks of the translation units that keep device arenas
     struct DevPool* pool = nullptr;        // the caching allocator of this runtime (devpool.hpp): blocks are reused in the order of ITS streams

@@ -218,7 +218,7 @@ def test_sharded_elementwise_operator(tmp_path, world, n):
         assert f"SHARDED_EW_OK {r}" in o
 
 
-@pytest.mark.parametrize("world,name", [(2, "tiny2"), (4, "microgpt"), (2, "nanogpt_model"), (2, "gpt2")])
+@pytest.mark.parametrize("world,name", [(2, "tiny2"), (4, "microgpt"), (2, "nanogpt_model"), (2, "gpt2"), (4, "gpt2")])
 def test_sharded_prove_graph(tmp_path, world, name):
     """atlas_prove_graph_sharded (x2 / BASELINE config 4: the whole ONNXProof::prove over the GPUs of a node, one process per GPU): every rank
     traces the model and runs the IOP, the witness commitments are split by polynomial range and the opening's commitment groups by point
