@@ -481,6 +481,13 @@ int atlas_srs_free(atlas_srs_t s);
  * scalars whose points lie inside the table then needs ceil(255 / c) instead of 20 point additions per scalar;
  * outputs are unchanged (same group elements).  ATLAS_MSM_TAB=0 in the environment ignores the table. */
 int atlas_srs_precompute(atlas_srs_t s, size_t n_points, uint32_t window_bits);
+/* The same table over the powers [first_point, first_point + n_points) only (n_points = 0: to the end).  Rank r of a sharded proof commits
+ * the r-th point range of every long vector (atlas_prove_graph_sharded, atlas_hyperkzg_open_sharded: MSM by point range), so
+ * it needs — and with this call holds — 1 / world of the table: first_point = r * len / world, n_points = len / world.  An MSM whose
+ * points are not inside the range takes the variable-base path: the same group element, so the proof bytes do not depend on the range. */
+int atlas_srs_precompute_range(atlas_srs_t s, size_t first_point, size_t n_points, uint32_t window_bits);
+/* bytes of device memory the calling thread's runtime holds through the library's allocator: now, and at most since the last reset */
+int atlas_device_memory_stats(size_t *in_use_bytes, size_t *peak_bytes, int reset_peak);
 int atlas_srs_table_info(atlas_srs_t s, size_t *n_points, uint32_t *window_bits, uint32_t *levels);
 /* VariableBaseMSM::msm / msm_field_elements over bases[offset .. offset+n)
  * (joltworks/src/msm/mod.rs:27-38,184-190; replaces the arkworks Pippenger call).

@@ -96,6 +96,13 @@ def device_count():
     return lib.atlas_device_count()
 
 
+def device_memory(reset_peak=False):
+    """(bytes in use, peak bytes since the last reset) of the calling thread's runtime (atlas_device_memory_stats)"""
+    a, b = C.c_size_t(), C.c_size_t()
+    _check(lib.atlas_device_memory_stats(C.byref(a), C.byref(b), C.c_int(1 if reset_peak else 0)))
+    return a.value, b.value
+
+
 def set_timeouts(device_wait_s=0.0, host_wait_s=0.0, board_wait_s=0.0):
     """atlas_set_timeouts: how long a launch waits for a challenge / the host for mail / a rank for the board, in seconds (0 keeps a setting)"""
     lib.atlas_set_timeouts.argtypes = [C.c_double, C.c_double, C.c_double]
@@ -395,6 +402,11 @@ class SRS:
     def precompute(self, n_points=0, window_bits=0):
         """Fixed-base table 2^(c j) * g1_powers[i] for the first n_points powers (atlas_srs_precompute); setup-time work."""
         _check(lib.atlas_srs_precompute(self.h, C.c_size_t(n_points), C.c_uint32(window_bits)))
+        return self.table_info()
+
+    def precompute_range(self, first_point, n_points=0, window_bits=0):
+        """The fixed-base table over the powers [first_point, first_point + n_points) only (atlas_srs_precompute_range): a rank's share."""
+        _check(lib.atlas_srs_precompute_range(self.h, C.c_size_t(first_point), C.c_size_t(n_points), C.c_uint32(window_bits)))
         return self.table_info()
 
     def table_info(self):

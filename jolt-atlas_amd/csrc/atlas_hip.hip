@@ -199,6 +199,16 @@ int atlas_set_timeouts(double device_wait_s, double host_wait_s, double board_wa
     if (device_wait_s > 0) { HIP_TRY(hipStreamSynchronize(rt().stream)); HIP_TRY(rt().chan.set_device_timeout(device_wait_s, rt().stream)); }
     return ATLAS_OK;
 }
+// what the calling thread's runtime holds on its device through the library's allocator (devpool.hpp): bytes in use now and the peak since the
+// last reset — the figure a rank of a sharded proof reports (tests/test_gpu_sharded.py, tools/time_sharded.py)
+int atlas_device_memory_stats(size_t* in_use_bytes, size_t* peak_bytes, int reset_peak) {
+    atlas_rt::DevPool& P = atlas_rt::dev_pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    if (in_use_bytes) *in_use_bytes = P.in_use;
+    if (peak_bytes) *peak_bytes = P.peak;
+    if (reset_peak) P.peak = P.in_use;
+    return ATLAS_OK;
+}
 // diagnosis (ATLAS_DEV_STAMPS=1): write the device's and the host's stamps of the rounds since the last dump to `path` and reset them
 int atlas_rt_stamps_dump(const char* path) {
     NEED_INIT();

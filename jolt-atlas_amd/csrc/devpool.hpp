@@ -32,6 +32,11 @@ struct DevPool {
     size_t double_free = 0;
     size_t cross_stream = 0;                              // blocks passed over because they were freed under another stream
     size_t cached = 0;
+    // accounting (atlas_device_memory_stats): bytes handed out and not yet returned — pool blocks by their class size, blocks above POOL_MAX_BLOCK
+    // (`big`) by their own — and the highest value seen since the last reset: what a rank of a sharded proof holds on its device
+    size_t in_use = 0, peak = 0;
+    std::unordered_map<void*, size_t> big;
+    void account(ptrdiff_t d) { in_use = (size_t)((ptrdiff_t)in_use + d); if (in_use > peak) peak = in_use; }
     size_t n_real = 0;                                    // hipMalloc calls that reached the runtime (misses), and what they cost
     double real_ms = 0;
     // ATLAS_POOL_POISON=<byte>: no caching, and every block is filled with that byte before it is handed out (fresh
@@ -60,7 +65,11 @@ struct DevPool {
         return c;
     }
     hipError_t alloc(void** out, size_t bytes) {
-        if (off || bytes == 0 || bytes > POOL_MAX_BLOCK) return poisoned(out, bytes);
+        if (off || bytes == 0 || bytes > POOL_MAX_BLOCK) {
+            const hipError_t e = poisoned(out, bytes);
+            if (e == hipSuccess && bytes) { std::lock_guard<std::mutex> lk(mu); big[*out] = bytes; account((ptrdiff_t)bytes); }
+            return e;
+        }
         const uint32_t c = class_of(bytes);
         {
             std::lock_guard<std::mutex> lk(mu);
@@ -76,6 +85,7 @@ struct DevPool {
                     fl.erase(fl.begin() + (ptrdiff_t)k);
                     cached -= class_bytes(c);
                     live[p] = c;
+                    account((ptrdiff_t)class_bytes(c));
                     *out = p;
                     return hipSuccess;
                 }
@@ -96,6 +106,7 @@ struct DevPool {
         }
         std::lock_guard<std::mutex> lk(mu);
         live[p] = c;
+        account((ptrdiff_t)class_bytes(c));
         *out = p;
         return hipSuccess;
     }
@@ -113,9 +124,12 @@ struct DevPool {
                             return hipSuccess;
                         }
             }
+            auto bg = big.find(p);
+            if (bg != big.end()) { account(-(ptrdiff_t)bg->second); big.erase(bg); }
             if (it != live.end()) {
                 const uint32_t c = it->second;
                 live.erase(it);
+                account(-(ptrdiff_t)class_bytes(c));
                 if (cached + class_bytes(c) <= POOL_MAX_CACHED) {
                     if (free_lists.size() <= c) free_lists.resize(c + 1);
                     free_lists[c].push_back(FreeBlock{p, pool_tag_stream()});

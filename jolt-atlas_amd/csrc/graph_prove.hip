@@ -1658,11 +1658,21 @@ static int prove_graph_impl(atlas_graph_t G, atlas_srs_t srs, atlas_shard_group_
     if (int vrc = atlas_rt_validate_graph(*G)) return vrc;
     atlas_rt::HostSampler::Scope host_samples;                                // ATLAS_HOST_SAMPLE=<file>: backtraces of this thread every 50 us (diagnosis)
     auto now = [] { atlas_sync(); return std::chrono::steady_clock::now(); };
+    // ATLAS_MEM_TRACE=1: what this runtime holds on its device at the stage boundaries, and the peak inside each stage (devpool.hpp accounting)
+    static const bool mem_trace = getenv("ATLAS_MEM_TRACE") != nullptr;
+    auto mem_mark = [&](const char* what) {
+        if (!mem_trace) return;
+        atlas_rt::DevPool& DP = atlas_rt::dev_pool();
+        std::lock_guard<std::mutex> lk(DP.mu);
+        fprintf(stderr, "[atlas mem] %-28s in use %7.3f GB, peak since the last mark %7.3f GB, cached %7.3f GB\n", what, DP.in_use / 1073741824.0, DP.peak / 1073741824.0, DP.cached / 1073741824.0);
+        DP.peak = DP.in_use;
+    };
+    mem_mark("before the proof");
     const auto t0 = now();
     if (atlas_rt::Prof::on()) atlas_rt::Prof::get().reset();
     int rc = atlas_graph_trace(G, inputs, n_inputs);                          // pp.model().trace(inputs)
     if (rc) return rc;
-    const auto t1 = now();
+    mem_mark("trace"); const auto t1 = now();
     if (atlas_rt::Prof::on()) { atlas_rt::Prof::get().dump(stderr, "Model::trace"); atlas_rt::Prof::get().reset(); }
     Prover P(*G, srs);
     P.sh = sh;
@@ -1684,7 +1694,7 @@ static int prove_graph_impl(atlas_graph_t G, atlas_srs_t srs, atlas_shard_group_
     }
     rc = P.collect_committed();
     if (!rc) rc = P.commit_all();
-    const auto t2 = now();
+    mem_mark("witness commitments"); const auto t2 = now();
     if (!rc) rc = P.output_claim();
     if (atlas_rt::Prof::on()) atlas_rt::Prof::get().reset();
     const bool gtrace = getenv("ATLAS_GRAPH_TRACE") != nullptr;             // per-operator wall clock of the node loop on stderr
@@ -1699,11 +1709,11 @@ static int prove_graph_impl(atlas_graph_t G, atlas_srs_t srs, atlas_shard_group_
                         atlas_rt::dev_pool().n_real, atlas_rt::dev_pool().real_ms, atlas_rt::dev_pool().cross_stream);
     if (atlas_rt::Prof::on()) { atlas_rt::Prof::get().dump(stderr, "node loop (iop)"); atlas_rt::Prof::get().reset(); }
     if (gtrace) for (auto& kv : per_op) fprintf(stderr, "[atlas graph] op %2d  x%-4zu %9.3f ms  (%.3f ms each)\n", kv.first, kv.second.second, kv.second.first, kv.second.first / kv.second.second);
-    const auto t3 = now();
+    mem_mark("node loop (iop)"); const auto t3 = now();
     rt().chan.long_mark();                                                   // the opening reduction is a scope of its own
     if (!rc) rc = P.reduced_openings(nullptr);
     if (!rc && !rt().chan.long_check()) rc = fail(ATLAS_ESTATE, "prove_graph: the long-lived mail ring wrapped inside the opening reduction");
-    const auto t4 = now();
+    mem_mark("reduction + HyperKZG::open"); const auto t4 = now();
     if (atlas_rt::Prof::on()) { atlas_rt::Prof::get().dump(stderr, "prove_reduced_openings"); atlas_rt::Prof::get().reset(); }
     if (rc) return rc;
     std::vector<uint8_t> bytes;

@@ -379,7 +379,7 @@ int msm_tab_core(const atlas_srs* srs, size_t pt_off, const Fr* d_scalars, size_
         const size_t o = multi ? multi->offs[k] : 0, len = multi ? multi->lens[k] : n;
         for (size_t t0 = 0; t0 < len; t0 += TAB_TILE)
             h_tiles.push_back(TabTile{(uint32_t)(o + t0), (uint32_t)(o + (t0 + TAB_TILE < len ? t0 + TAB_TILE : len)),
-                                      (uint32_t)(k * bins_per_vec), (uint32_t)(pt_off - o)});
+                                      (uint32_t)(k * bins_per_vec), (uint32_t)(pt_off - srs->tab_off - o)});      // (table index = point index - tab_off)
     }
     const unsigned n_tiles = (unsigned)h_tiles.size();
 
@@ -505,7 +505,7 @@ int msm_tab_core(const atlas_srs* srs, size_t pt_off, const Fr* d_scalars, size_
 }
 
 // does the table cover points [pt_off, pt_off + n)?
-inline bool tab_covers(const atlas_srs* srs, size_t pt_off, size_t n) { return srs && srs->tab && pt_off + n <= srs->tab_len; }
+inline bool tab_covers(const atlas_srs* srs, size_t pt_off, size_t n) { return srs && srs->tab && pt_off >= srs->tab_off && pt_off + n <= srs->tab_off + srs->tab_len; }
 
 // scalars are Montgomery Fr already on the device
 int msm_device(const G1Affine* bases, const Fr* d_scalars, size_t n, atlas_g1_affine_t* out, const atlas_srs* srs = nullptr,
@@ -774,10 +774,13 @@ int atlas_srs_free(atlas_srs_t s) {
 // window_bits = 0 picks c from n_points (20 at 2^22).  One-time cost per prover key: ~c doublings per point and level.
 // MSMs over Fr scalars whose points lie inside the table use it (msm_tab_kernels.hip.h); results are the same group
 // elements, so every output stays bit-identical.  Calling it again replaces the table.
-int atlas_srs_precompute(atlas_srs_t srs, size_t n_points, uint32_t window_bits) {
+int atlas_srs_precompute(atlas_srs_t srs, size_t n_points, uint32_t window_bits) { return atlas_srs_precompute_range(srs, 0, n_points, window_bits); }
+// the table over the powers [first_point, first_point + n_points) only: what rank r of a sharded proof needs of it (its range of every long vector)
+int atlas_srs_precompute_range(atlas_srs_t srs, size_t first_point, size_t n_points, uint32_t window_bits) {
     NEED_INIT();
     if (!srs) return fail(ATLAS_EINVAL, "srs_precompute: null SRS");
-    if (n_points == 0 || n_points > srs->len) n_points = srs->len;
+    if (first_point >= srs->len) return fail(ATLAS_EINVAL, "srs_precompute_range: first point beyond the SRS");
+    if (n_points == 0 || first_point + n_points > srs->len) n_points = srs->len - first_point;
     uint32_t c = window_bits;
     if (c == 0) {
         uint32_t lg = 0;
@@ -790,11 +793,11 @@ int atlas_srs_precompute(atlas_srs_t srs, size_t n_points, uint32_t window_bits)
     const uint32_t levels = (255 + c - 1) / c;
     if ((size_t)levels * n_points >= ((size_t)1 << 31)) return fail(ATLAS_EINVAL, "srs_precompute: table beyond 2^31 points");
     std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
-    if (srs->tab) { hipStreamSynchronize(rt().stream); hipFree(srs->tab); srs->tab = nullptr; srs->tab_len = 0; srs->tab_c = srs->tab_levels = 0; }
+    if (srs->tab) { hipStreamSynchronize(rt().stream); hipFree(srs->tab); srs->tab = nullptr; srs->tab_len = srs->tab_off = 0; srs->tab_c = srs->tab_levels = 0; }
     G1Affine* tab = nullptr;
     hipError_t e = hipMalloc(&tab, (size_t)levels * n_points * sizeof(G1Affine));
     if (e != hipSuccess) return fail(ATLAS_ENOMEM, "hipMalloc(srs table)", e);
-    e = hipMemcpyAsync(tab, srs->d, n_points * sizeof(G1Affine), hipMemcpyDeviceToDevice, rt().stream);
+    e = hipMemcpyAsync(tab, srs->d + first_point, n_points * sizeof(G1Affine), hipMemcpyDeviceToDevice, rt().stream);
     for (uint32_t l = 1; l < levels && e == hipSuccess; l++) {
         k_tab_next_level<<<grid_for((n_points + TAB_INV_BATCH - 1) / TAB_INV_BATCH, 1 << 16), MSM_THREADS, 0, rt().stream>>>(
             tab + (size_t)(l - 1) * n_points, tab + (size_t)l * n_points, n_points, c);
@@ -802,7 +805,7 @@ int atlas_srs_precompute(atlas_srs_t srs, size_t n_points, uint32_t window_bits)
     }
     if (e == hipSuccess) e = hipStreamSynchronize(rt().stream);
     if (e != hipSuccess) { hipFree(tab); return fail(ATLAS_ENODEV, "srs_precompute", e); }
-    srs->tab = tab; srs->tab_len = n_points; srs->tab_c = c; srs->tab_levels = levels;
+    srs->tab = tab; srs->tab_len = n_points; srs->tab_off = first_point; srs->tab_c = c; srs->tab_levels = levels;
     return ATLAS_OK;
 }
 

@@ -41,6 +41,26 @@ def test_fixed_base_msm_matches_oracle(atlas, srs_ref, monkeypatch, wb, q, n):
     s.free()
 
 
+@pytest.mark.parametrize("wb,q", [(16, 1), (20, 2)])
+@pytest.mark.parametrize("first,count", [(512, 512), (1024, 1024), (0, 512), (37, 1000)])
+def test_table_over_a_point_range(atlas, srs_ref, monkeypatch, wb, q, first, count):
+    """atlas_srs_precompute_range: the table over the powers [first, first + count) only — a rank's share in a sharded proof.  MSMs whose
+    points lie inside the range go through it, the others take the variable-base path: every one equals the oracle's point."""
+    from oracle import orc
+    monkeypatch.setenv("ATLAS_MSM_TAB_Q", str(q))
+    s = atlas.SRS.upload(srs_ref)
+    info = s.precompute_range(first, count, wb)
+    assert info["n_points"] == count and info["window_bits"] == wb
+    sc = orc.random_fr(count, 4242 + first)
+    assert orc.g1_eq(s.msm(sc, offset=first), orc.msm(srs_ref[first:first + count], sc))                       # exactly the range
+    assert orc.g1_eq(s.msm(sc[:count // 2], offset=first + 5), orc.msm(srs_ref[first + 5:first + 5 + count // 2], sc[:count // 2]))   # inside it
+    n_out = min(300, len(srs_ref) - first - count + 100)
+    if first + count - 100 + n_out <= len(srs_ref):                                                              # straddling its end: no table
+        assert orc.g1_eq(s.msm(sc[:n_out], offset=first + count - 100), orc.msm(srs_ref[first + count - 100:first + count - 100 + n_out], sc[:n_out]))
+    assert orc.g1_eq(s.msm(sc[:200]), orc.msm(srs_ref[:200], sc[:200]))                                          # from 0: inside only when first == 0
+    s.free()
+
+
 @pytest.mark.parametrize("wb,q", [(16, 1), (20, 1), (16, 2)])
 def test_fixed_base_edge_scalars(atlas, srs_ref, monkeypatch, wb, q):
     """zero / one / r-1 / powers of two around the digit boundaries; all-equal scalars (every entry of a digit in one

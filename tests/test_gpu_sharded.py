@@ -245,10 +245,19 @@ def test_sharded_prove_graph(tmp_path, world, name):
         tau = orc.random_fr(1, gold["tau_seed"])[0]
         srs = A.SRS.generate(tau, 1 << nv)
         if nv >= 16:
-            srs.precompute()                               # the fixed-base table: the sharded MSMs index it by their point range
+            # the fixed-base table over THIS RANK's point range only (atlas_srs_precompute_range): 1 / world of it — the opening's three
+            # witness commitments (3 of the 4 MSM groups) lie inside, what does not takes the variable-base path: same bytes
+            part = (1 << nv) // world
+            srs.precompute_range(rank * part, part)
         G = GG.Graph(nodes, outputs)
         grp = sharded.ShardGroup(sys.argv[2], world, rank)
+        A.device_memory(reset_peak=True)
         proof, state, tm = G.prove(srs, inputs, group=grp)
+        in_use, peak = A.device_memory()
+        print("RANK_MEMORY", rank, "peak_GB", round(peak / 2 ** 30, 2), "in_use_GB", round(in_use / 2 ** 30, 2))
+        if {name!r} == "gpt2":                             # the whole table would be 12.9 GB on every rank
+            # (the 2^24 joint polynomial, the opening's 6 n Fr arena and the graph's witness are still whole on every rank: DESIGN 13)
+            assert peak / 2 ** 30 < 12.9 / world + 15.0, "per-rank device memory of the 12-layer proof: %.2f GB" % (peak / 2 ** 30)
         assert tm["n_committed"] == want["n_committed"]
         assert state.hex() == want["state"], "final transcript state differs from the one-GPU proof"
         assert hashlib.sha256(proof).hexdigest() == want["proof_sha256"], "proof bytes differ from the one-GPU proof"
@@ -270,6 +279,9 @@ def test_sharded_prove_graph(tmp_path, world, name):
     for r, (p, (o, e)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, e[-3000:]
         assert f"SHARDED_GRAPH_OK {r}" in o
+    for o, _ in outs:
+        for line in o.splitlines():
+            if line.startswith("RANK_MEMORY"): print(line)
 
 
 @pytest.mark.parametrize("world,name", [(2, "tiny2"), (2, "microgpt"), (2, "nanogpt_model")])
