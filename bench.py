@@ -683,9 +683,10 @@ def main():
                 nv_s = BG.max_vars(nodes_s)
                 tau_s = np.array([0x1234567, 0, 0, 0], dtype=np.uint64)
                 srs_s = A.SRS.generate(tau_s, 1 << nv_s)
-                if nv_s >= 16:
-                    srs_s.precompute()
+                if nv_s >= 16:                        # this rank's point range of the fixed-base table (atlas_srs_precompute_range): 1 / world of it per GPU
+                    srs_s.precompute_range(rank * ((1 << nv_s) // world), (1 << nv_s) // world)
                 Gs = GG.Graph(nodes_s, outs_s)
+                A.device_memory(reset_peak=True)
                 best_s, states_s, wall_s = None, set(), None
                 for rep in range(3):
                     barrier(); sync(); t0s = time.perf_counter()
@@ -698,7 +699,8 @@ def main():
                 all_st = grp.allgather(np.frombuffer(st_s, dtype=np.uint8))
                 assert all(bytes(x) == st_s for x in all_st), "ranks disagree on the whole proof's transcript"
                 entry = {"prove_graph_ms": wall_s * 1e3, "stage_ms": {k: best_s[k] for k in ("trace_ms", "commit_ms", "iop_ms", "reduction_ms", "hyperkzg_ms")},
-                         "nodes": best_s["n_nodes"], "committed_polys": best_s["n_committed"], "proof_bytes": len(pf_s), "max_num_vars": nv_s}
+                         "nodes": best_s["n_nodes"], "committed_polys": best_s["n_committed"], "proof_bytes": len(pf_s), "max_num_vars": nv_s,
+                         "rank0_peak_device_GB": A.device_memory()[1] / 2 ** 30, "fixed_base_table": "by point range: 1 / world per rank"}
                 if rank == 0:                         # ONNXProof::verify of the sharded proof
                     vk_s = A.HyperKZG.vk_from_trapdoor(tau_s, srs_s.download(0, 1)[0])
                     Vs = GG.Graph(nodes_s, outs_s)
