@@ -22,6 +22,13 @@ struct G1Xyzz9 {
     bool inf;
 };
 
+__device__ __forceinline__ G1Xyzz9 g1_inf_f9() {
+    G1Xyzz9 a;
+    a.x = f9_zero(); a.y = f9_zero(); a.zz = f9_zero(); a.zzz = f9_zero();
+    a.inf = true;
+    return a;
+}
+
 // 32 * a mod-free (value grows 32x): only for canonical inputs (a < q): result < 32 q < 2^259
 __device__ __forceinline__ F9 f9_x32(const F9& a) { return f9_shl5(a); }
 

@@ -55,6 +55,9 @@ struct atlas_instance {
     // on the calling thread; idempotent per round.  The driver makes these calls for every member on its own thread before it hands the
     // members to the workers, so that no worker ever touches the device (batched.hip).
     virtual int shared_message_step(size_t /*round*/) { return ATLAS_OK; }
+    // what the shared steps belong to (a pool: the same key for all its rows; default: the instance alone).  The driver calls the shared steps of ONE
+    // member per key — the one with the most rounds, which is in its stepping phase whenever any member of the key is.
+    virtual const void* shared_key() const { return this; }
     virtual int shared_ingest_step(const atlas_u128_t& /*r*/, size_t /*round*/) { return ATLAS_OK; }
     // does enqueue(round) launch nothing at all (host-only rounds: the driver then has nothing new for the runtime to retire)?
     virtual bool silent_round(size_t /*round*/) const { return false; }

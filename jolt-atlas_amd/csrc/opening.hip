@@ -22,6 +22,7 @@
 
 #include "../../include/atlas_hip.h"
 #include "host_poly.hpp"
+#include "host_threads.hpp"
 #include "instance.hpp"
 #include "runtime.hpp"
 #include "sc_consts.hpp"
@@ -253,12 +254,36 @@ struct DenseOpening : atlas_instance {
     }
 };
 
+// The address-phase message of a one-hot opening (opening_reduction.rs:583-633): e(0), e(2) of sum_k B(k) G[k] F[k >> unbound] in the round's variable.
+// G[k] = sum of eq(r_cycle, j) over the cycles j that read k has at most T nonzero entries out of K — GatherSmall's GatherRa: 16 of 2^14 — so the
+// sum runs over those (`nz`, built once) instead of the whole address space: the zero terms of the reference's loop add nothing, the field sums are
+// exact, and 14 rounds of K multiplications on the transcript's thread were 17 ms of the GPT-2-shaped reduction (r06x).
+inline void onehot_address_message(const std::vector<H::Fr>& B, const std::vector<H::Fr>& F, const std::vector<H::Fr>& G, std::vector<uint32_t>& nz, bool& have_nz,
+                                   size_t unbound, const H::Fr& claim, H::Fr* coeffs) {
+    if (!have_nz) {
+        for (size_t k = 0; k < G.size(); k++) if (!(G[k] == H::zero())) nz.push_back((uint32_t)k);
+        have_nz = true;
+    }
+    const size_t half = B.size() / 2;
+    H::Fr e0 = H::zero(), e2 = H::zero();
+    for (const uint32_t k : nz) {
+        const size_t kp = k & (half - 1);
+        const H::Fr gf = H::mul(G[k], F[k >> unbound]);
+        const H::Fr b0 = B[kp], b2 = H::add(B[kp + half], H::sub(B[kp + half], b0));
+        if (((k >> (unbound - 1)) & 1) == 0) { e0 = H::add(e0, H::mul(b0, gf)); e2 = H::sub(e2, H::mul(b2, gf)); }
+        else e2 = H::add(e2, H::mul(b2, H::add(gf, gf)));
+    }
+    const H::Fr ev[2] = {e0, e2};
+    H::unipoly_from_evals_and_hint(claim, ev, 2, coeffs);
+}
+
 // ---------------------------------------------------------------- OneHotPolynomialProverOpening
 struct OneHotOpening : atlas_instance {
     size_t log_K = 0, log_T = 0, round_next = 0;
     H::Fr eqa_inv_ = H::zero(); bool have_inv_ = false;
     const H::Fr& eqa_inv() { if (!have_inv_) { eqa_inv_ = H::inv(B[0]); have_inv_ = true; } return eqa_inv_; }   // B is fully bound
     std::vector<H::Fr> B, F, G;          // eq(r_address, .) bound HighToLow; expanding table; histogram
+    std::vector<uint32_t> nz; bool have_nz = false;   // the nonzero entries of G
     int32_t* d_idx = nullptr;
     Fr* d_H = nullptr;
     size_t H_len = 0;
@@ -271,20 +296,7 @@ struct OneHotOpening : atlas_instance {
         if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "onehot_opening: round out of order");
         coeffs.assign(3, H::zero());
         if (round < log_K) {                                         // opening_reduction.rs:583-633
-            const size_t unbound = log_K - round, K = (size_t)1 << log_K, half = B.size() / 2;
-            H::Fr e0 = H::zero(), e2 = H::zero();
-            for (size_t kp = 0; kp < half; kp++) {
-                const H::Fr b0 = B[kp], b2 = H::add(B[kp + half], H::sub(B[kp + half], b0));
-                H::Fr s0 = H::zero(), s2 = H::zero();
-                for (size_t k = kp; k < K; k += half) {
-                    const H::Fr gf = H::mul(G[k], F[k >> unbound]);
-                    if (((k >> (unbound - 1)) & 1) == 0) { s0 = H::add(s0, gf); s2 = H::sub(s2, gf); }
-                    else s2 = H::add(s2, H::add(gf, gf));
-                }
-                e0 = H::add(e0, H::mul(b0, s0)); e2 = H::add(e2, H::mul(b2, s2));
-            }
-            const H::Fr ev[2] = {e0, e2};
-            H::unipoly_from_evals_and_hint(claim, ev, 2, coeffs.data());
+            onehot_address_message(B, F, G, nz, have_nz, log_K - round, claim, coeffs.data());
             return ATLAS_OK;
         }
         H::Fr q0;                                                    // :634-676
@@ -450,6 +462,7 @@ struct OneHotRow : atlas_instance {
     H::Fr eqa_inv_ = H::zero(); bool have_inv_ = false;
     const H::Fr& eqa_inv() { if (!have_inv_) { eqa_inv_ = H::inv(B[0]); have_inv_ = true; } return eqa_inv_; }
     std::vector<H::Fr> B, F;
+    std::vector<uint32_t> nz; bool have_nz = false;   // the nonzero entries of the row's G
     ~OneHotRow() override { if (grp && --grp->refs == 0) delete grp; }
     size_t rounds() const override { return grp->log_K + grp->log_T; }
     size_t degree() const override { return 2; }
@@ -459,21 +472,7 @@ struct OneHotRow : atlas_instance {
         coeffs.assign(3, H::zero());
         const size_t log_K = grp->log_K;
         if (round < log_K) {
-            const std::vector<H::Fr>& G = grp->G[row];
-            const size_t unbound = log_K - round, K = (size_t)1 << log_K, half = B.size() / 2;
-            H::Fr e0 = H::zero(), e2 = H::zero();
-            for (size_t kp = 0; kp < half; kp++) {
-                const H::Fr b0 = B[kp], b2 = H::add(B[kp + half], H::sub(B[kp + half], b0));
-                H::Fr s0 = H::zero(), s2 = H::zero();
-                for (size_t k = kp; k < K; k += half) {
-                    const H::Fr gf = H::mul(G[k], F[k >> unbound]);
-                    if (((k >> (unbound - 1)) & 1) == 0) { s0 = H::add(s0, gf); s2 = H::sub(s2, gf); }
-                    else s2 = H::add(s2, H::add(gf, gf));
-                }
-                e0 = H::add(e0, H::mul(b0, s0)); e2 = H::add(e2, H::mul(b2, s2));
-            }
-            const H::Fr ev[2] = {e0, e2};
-            H::unipoly_from_evals_and_hint(claim, ev, 2, coeffs.data());
+            onehot_address_message(B, F, grp->G[row], nz, have_nz, log_K - round, claim, coeffs.data());
             return ATLAS_OK;
         }
         {
@@ -555,24 +554,35 @@ __global__ __launch_bounds__(OP_THREADS) void k_pool_chunk_rows(const uint64_t* 
     for (size_t j = (size_t)blockIdx.x * OP_THREADS + threadIdx.x; j < T; j += (size_t)gridDim.x * OP_THREADS)
         o[j] = (int32_t)(sh >= 64 ? 0 : ((lk[j] >> sh) & mask));
 }
-// G[r][k] = sum_{j : idx_r[j] = k} E_g(r)[j] as 64-bit sums of the eight 32-bit words of the (Montgomery) residues per bin, K <= 16
+// G[r][k] = sum_{j : idx_r[j] = k} E_g(r)[j] as 64-bit sums of the eight 32-bit words of the (Montgomery) residues per bin, K <= 16.
+// The LDS counters are kept in 32 copies, one per eight threads: with ONE copy the 256 threads of a workgroup met sixteen deep on each of the
+// 16 x 8 counters (8.7 ms for the 8292 rows of the GPT-2-shaped reduction, r06s).  Layout [copy][word][bin], a copy 144 counters apart, so that the
+// lanes of one instruction (one word, sixteen bins, eight copies) spread over the banks.  (Measured and dropped: bin-owner threads that pick
+// their entries out of the index stream without atomics — the scattered 32-byte loads of the matching lanes made it 5 x slower, r06t.)
+constexpr uint32_t HIST_COPIES = 32, HIST_STRIDE = 144;
 __global__ __launch_bounds__(OP_THREADS) void k_pool_hist(const int32_t* __restrict__ idx, const uint64_t* __restrict__ off, const uint32_t* __restrict__ Ts,
-                                                          const Fr* const* __restrict__ E, uint32_t K, unsigned long long* __restrict__ out /* [rows][K][8] */) {
-    __shared__ unsigned long long acc[16 * 8];
+                                                          const Fr* const* __restrict__ E, uint32_t K, unsigned long long* __restrict__ out /* [rows][16][8] */) {
+    __shared__ unsigned long long acc[HIST_COPIES * HIST_STRIDE];
     const size_t r = blockIdx.x;
-    for (uint32_t i = threadIdx.x; i < 16 * 8; i += OP_THREADS) acc[i] = 0;
+    for (uint32_t i = threadIdx.x; i < HIST_COPIES * HIST_STRIDE; i += OP_THREADS) acc[i] = 0;
     __syncthreads();
     const int32_t* ix = idx + off[r];
     const Fr* e = E[r];
     const uint32_t T = Ts[r];
+    unsigned long long* mine = acc + (threadIdx.x >> 3) * HIST_STRIDE;
     for (uint32_t j = threadIdx.x; j < T; j += OP_THREADS) {
         const Fr v = fe_load(e + j);
         const int32_t k = ix[j];
 #pragma unroll
-        for (int w = 0; w < 8; w++) atomicAdd(&acc[k * 8 + w], (unsigned long long)v.v[w]);
+        for (int w = 0; w < 8; w++) atomicAdd(&mine[w * 16 + k], (unsigned long long)v.v[w]);
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < K * 8; i += OP_THREADS) out[r * 16 * 8 + i] = acc[i];
+    for (uint32_t i = threadIdx.x; i < K * 8; i += OP_THREADS) {
+        const uint32_t k = i >> 3, w = i & 7u;
+        unsigned long long s = 0;
+        for (uint32_t c = 0; c < HIST_COPIES; c++) s += acc[c * HIST_STRIDE + w * 16 + k];
+        out[r * 16 * 8 + i] = s;
+    }
 }
 __global__ __launch_bounds__(OP_THREADS) void k_pool_gather(const PoolRowDev* __restrict__ rows) {
     const PoolRowDev R = rows[blockIdx.y];
@@ -758,12 +768,29 @@ struct OneHotPool {
         k_pool_fold<<<dim3(gx, (unsigned)n), OP_THREADS, 0, rt().stream>>>(d_desc, d_part);
         k_pool_reduce<<<(unsigned)n, 64, 0, rt().stream>>>(d_part, gx, d_q0);
         HIP_TRY(hipMemcpyAsync(h_q0, d_q0, n * sizeof(Fr), hipMemcpyDeviceToHost, rt().stream));
+        {   // gruen_poly_deg_2's division by eq(1), shared by the rows of a group: ONE inversion for all the groups of the round (Montgomery's trick),
+            // and under the device's fold — an inversion per group after the wait was 14 of the 20 ms this function took in the GPT-2-shaped reduction
+            std::vector<Group*> act;
+            for (auto& G : groups) if (cycle_of(G, R) >= 0) act.push_back(&G);
+            std::vector<H::Fr> val(act.size()), pre(act.size());
+            H::Fr run = H::one();
+            for (size_t q = 0; q < act.size(); q++) {
+                val[q] = H::mul(act[q]->st.scalar, act[q]->st.w_cur());
+                pre[q] = run;
+                if (!(val[q] == H::zero())) run = H::mul(run, val[q]);           // (a zero — r_cycle coordinate 0 — keeps inv(0) = 0 as H::inv does)
+            }
+            H::Fr inv = H::inv(run);
+            for (size_t q = act.size(); q-- > 0;) {
+                if (val[q] == H::zero()) { act[q]->inv_eq1 = H::zero(); }
+                else { act[q]->inv_eq1 = H::mul(inv, pre[q]); inv = H::mul(inv, val[q]); }
+                act[q]->inv_round = R;
+            }
+        }
         HIP_TRY(hipStreamSynchronize(rt().stream));
         n = 0;
         for (auto& G : groups) {
             if (cycle_of(G, R) < 0) continue;
             for (size_t r : G.rows) std::memcpy(&rows[r].q0, &h_q0[n++], sizeof(Fr));
-            G.inv_eq1 = H::inv(H::mul(G.st.scalar, G.st.w_cur())); G.inv_round = R;        // shared by the rows of the group (gruen_poly_deg_2's division)
         }
         folded.store(R, std::memory_order_release);
         return ATLAS_OK;
@@ -850,8 +877,8 @@ struct OneHotPoolRow : atlas_instance {
     int ingest(const atlas_u128_t& r, size_t round) override {      // :679-718
         if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "onehot_opening: round out of order");
         OneHotPool::Row& Rw = P->rows[row];
-        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode);
         if (round < P->log_K) {
+            const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode);
             const size_t half = Rw.B.size() / 2;
             for (size_t i = 0; i < half; i++) Rw.B[i] = H::add(Rw.B[i], H::mul(rf, H::sub(Rw.B[i + half], Rw.B[i])));
             Rw.B.resize(half);
@@ -860,13 +887,14 @@ struct OneHotPoolRow : atlas_instance {
             Rw.F.swap(nf);                                           // the gather H = F[idx] runs with the next round's fold (gather_pending)
         } else if (P->bound.load(std::memory_order_acquire) != round + P->row_off(Rw)) {
             std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
-            const int rc = P->bind_all(round + P->row_off(Rw), rf);
+            const int rc = P->bind_all(round + P->row_off(Rw), H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode));
             if (rc) return rc;
         }
         round_next++;
         return ATLAS_OK;
     }
     bool host_parallel() const override { return true; }
+    const void* shared_key() const override { return P; }
     // the pool's launches of a global round, on the caller's thread (the driver's): the rows' own calls then find them done
     int shared_message_step(size_t round) override {
         if (round != round_next || round >= rounds() || round < P->log_K) return ATLAS_OK;
@@ -892,7 +920,232 @@ struct OneHotPoolRow : atlas_instance {
     }
 };
 
+// ---------------------------------------------------------------- the dense members of a reduction, stepped together
+// A graph's reduction holds ~50 dense members beside its thousands of one-hot rows (the i32 quotient / remainder / auxiliary polynomials).  As
+// DenseOpening instances each of them brought its own clone, five allocations, two table launches and a synchronisation at construction, two
+// launches per message and one per bind: ~100 tiny kernels in a row per round and as many launches on the thread that runs the transcript —
+// a third of the GPT-2-shaped reduction's batched sumcheck (r06v).  DensePool keeps their coefficients (as Fr) and split-eq tables in one
+// allocation each and steps them with ONE fold / reduce / bind launch per global round, exactly like OneHotPool; the per-member host state is the
+// HighToLow split-eq scalar.  Member r takes part in global rounds [max_rounds - n_r, max_rounds) (front-loaded batching).
+struct DenseRowDev { Fr* P; const Fr *e_out, *e_in; uint32_t half, in_bits, slot, pad; };
+struct DenseImportJob { const void* src; Fr* dst; uint32_t len, is_i32; };
+__global__ __launch_bounds__(OP_THREADS) void k_dpool_import(const DenseImportJob* __restrict__ jobs, ScConsts K) {
+    const DenseImportJob J = jobs[blockIdx.y];
+    for (size_t j = (size_t)blockIdx.x * OP_THREADS + threadIdx.x; j < J.len; j += (size_t)gridDim.x * OP_THREADS)
+        fe_store(J.dst + j, J.is_i32 ? Src<int32_t>::get((const int32_t*)J.src, j, K) : fe_load((const Fr*)J.src + j));
+}
+__global__ __launch_bounds__(OP_THREADS) void k_dpool_fold(const DenseRowDev* __restrict__ rows, Fr* __restrict__ partials /* [rows][gridDim.x] */) {
+    const DenseRowDev R = rows[blockIdx.y];
+    Fr acc[1];
+    acc[0] = fe_zero();
+    const size_t mask = ((size_t)1 << R.in_bits) - 1;
+    for (size_t j = (size_t)blockIdx.x * OP_THREADS + threadIdx.x; j < R.half; j += (size_t)gridDim.x * OP_THREADS) {
+        const Fr w = fr_mul(fe_load(R.e_out + (j >> R.in_bits)), fe_load(R.e_in + (j & mask)));
+        acc[0] = fr_add(acc[0], fr_mul(w, fe_load(R.P + j)));
+    }
+    block_reduce_store<1>(acc, partials + (size_t)R.slot * gridDim.x);
+}
+__global__ __launch_bounds__(OP_THREADS) void k_dpool_bind(const DenseRowDev* __restrict__ rows, Fr r, int r_hi_only) {
+    const DenseRowDev R = rows[blockIdx.y];
+    for (size_t i = (size_t)blockIdx.x * OP_THREADS + threadIdx.x; i < R.half; i += (size_t)gridDim.x * OP_THREADS)
+        fe_store(R.P + i, bind_pair(fe_load(R.P + i), fe_load(R.P + i + R.half), r, r_hi_only != 0));
+}
+
+struct DensePool {
+    size_t max_rounds = 0, refs = 0;
+    struct Row { size_t n = 0, slot = 0; uint64_t off = 0; H::GseStateH st; Fr *d_ein = nullptr, *d_eout = nullptr; H::Fr fin; };
+    std::vector<Row> rows;
+    Fr *d_P = nullptr, *d_tabs = nullptr, *d_part = nullptr, *d_q0 = nullptr;
+    uint64_t* d_off = nullptr;
+    DenseRowDev *d_desc = nullptr, *h_desc = nullptr;      // h_desc: pinned staging, two regions of rows.size() descriptors (fold, bind)
+    Fr* h_q0 = nullptr;                                     // pinned
+    std::atomic<size_t> folded{(size_t)-1}, bound{(size_t)-1};   // written last by fold_all / bind_all (under rt().mu), read without the lock by the rows
+    bool have_finals = false;
+    static constexpr unsigned GX = 64;                      // workgroups along a member
+    ~DensePool() {
+        for (void* p : {(void*)d_P, (void*)d_tabs, (void*)d_part, (void*)d_q0, (void*)d_off, (void*)d_desc}) if (p) hipFree(p);
+        if (h_desc) (void)hipHostFree(h_desc);
+        if (h_q0) (void)hipHostFree(h_q0);
+    }
+    long local_round(const Row& r, size_t R) const { const long c = (long)R - (long)(max_rounds - r.n); return c >= 0 && c < (long)r.n ? c : -1; }
+    // the caller holds rt().mu.  wait = false: the sums are in h_q0 once the caller's thread has synchronised the stream (rt().pending_async)
+    int fold_all(size_t R, bool wait) {
+        if (folded.load(std::memory_order_acquire) == R) return ATLAS_OK;
+        size_t n = 0, max_half = 0;
+        for (auto& Rw : rows) {
+            const long c = local_round(Rw, R);
+            if (c < 0) continue;
+            const size_t half = ((size_t)1 << Rw.n) >> (c + 1);
+            h_desc[n] = DenseRowDev{d_P + Rw.off, Rw.d_ein + (((size_t)1 << Rw.st.in_top) - 1), Rw.d_eout + (((size_t)1 << Rw.st.out_top) - 1), (uint32_t)half, (uint32_t)Rw.st.out_top, (uint32_t)n, 0};
+            Rw.slot = n++;
+            max_half = half > max_half ? half : max_half;
+        }
+        if (n == 0) { folded.store(R, std::memory_order_release); return ATLAS_OK; }
+        const unsigned gx = grid_for(max_half, GX);
+        HIP_TRY(hipMemcpyAsync(d_desc, h_desc, n * sizeof(DenseRowDev), hipMemcpyHostToDevice, rt().stream));
+        k_dpool_fold<<<dim3(gx, (unsigned)n), OP_THREADS, 0, rt().stream>>>(d_desc, d_part);
+        k_pool_reduce<<<(unsigned)n, 64, 0, rt().stream>>>(d_part, gx, d_q0);
+        HIP_TRY(hipMemcpyAsync(h_q0, d_q0, n * sizeof(Fr), hipMemcpyDeviceToHost, rt().stream));
+        if (wait) HIP_TRY(hipStreamSynchronize(rt().stream));
+        else rt().pending_async++;
+        folded.store(R, std::memory_order_release);
+        return ATLAS_OK;
+    }
+    int bind_all(size_t R, const H::Fr& rf) {
+        if (bound.load(std::memory_order_acquire) == R) return ATLAS_OK;
+        size_t n = 0, max_half = 0;
+        DenseRowDev* hd = h_desc + rows.size();
+        for (auto& Rw : rows) {
+            const long c = local_round(Rw, R);
+            if (c < 0) continue;
+            const size_t half = ((size_t)1 << Rw.n) >> (c + 1);
+            hd[n++] = DenseRowDev{d_P + Rw.off, nullptr, nullptr, (uint32_t)half, 0, 0, 0};
+            max_half = half > max_half ? half : max_half;
+        }
+        if (n == 0) { bound.store(R, std::memory_order_release); return ATLAS_OK; }
+        HIP_TRY(hipMemcpyAsync(d_desc + rows.size(), hd, n * sizeof(DenseRowDev), hipMemcpyHostToDevice, rt().stream));
+        k_dpool_bind<<<dim3(grid_for(max_half, GX), (unsigned)n), OP_THREADS, 0, rt().stream>>>(d_desc + rows.size(), to_dev(rf), rt().challenge_mode == 0 ? 1 : 0);
+        hipError_t e = hipGetLastError();
+        bound.store(R, std::memory_order_release);
+        return e == hipSuccess ? ATLAS_OK : fail(ATLAS_ENODEV, "dense pool bind", e);
+    }
+    int fetch_finals() {
+        if (have_finals) return ATLAS_OK;
+        const size_t n = rows.size();
+        k_pool_heads<<<grid_for(n, 64), OP_THREADS, 0, rt().stream>>>(d_P, d_off, (uint32_t)n, d_q0);
+        std::vector<H::Fr> f(n);
+        HIP_TRY(hipMemcpyAsync(f.data(), d_q0, n * sizeof(Fr), hipMemcpyDeviceToHost, rt().stream));
+        HIP_TRY(hipStreamSynchronize(rt().stream));
+        for (size_t r = 0; r < n; r++) rows[r].fin = f[r];
+        have_finals = true;
+        return ATLAS_OK;
+    }
+};
+
+struct DensePoolRow : atlas_instance {
+    DensePool* P = nullptr;
+    size_t row = 0, round_next = 0;
+    ~DensePoolRow() override { if (P && --P->refs == 0) delete P; }
+    size_t rounds() const override { return P->rows[row].n; }
+    size_t degree() const override { return 2; }
+    size_t global_round(size_t round) const { return round + (P->max_rounds - P->rows[row].n); }
+    int message(size_t round, const H::Fr& claim, std::vector<H::Fr>& coeffs) override {
+        if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "dense_opening: round out of order");
+        const size_t R = global_round(round);
+        if (P->folded.load(std::memory_order_acquire) != R) {        // (a driver without shared steps: the first member to ask folds for all and waits)
+            std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+            const int rc = P->fold_all(R, true);
+            if (rc) return rc;
+        }
+        const DensePool::Row& Rw = P->rows[row];
+        H::Fr q0;
+        std::memcpy(&q0, &P->h_q0[Rw.slot], sizeof(q0));
+        coeffs.resize(3);
+        H::gruen_deg2(Rw.st.scalar, Rw.st.w_cur(), q0, claim, coeffs.data());
+        return ATLAS_OK;
+    }
+    int ingest(const atlas_u128_t& r, size_t round) override {
+        if (round != round_next || round >= rounds()) return fail(ATLAS_ESTATE, "dense_opening: round out of order");
+        const H::Fr rf = H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode);
+        const size_t R = global_round(round);
+        if (P->bound.load(std::memory_order_acquire) != R) {
+            std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+            const int rc = P->bind_all(R, rf);
+            if (rc) return rc;
+        }
+        P->rows[row].st.bind(rf);
+        round_next++;
+        return ATLAS_OK;
+    }
+    bool host_parallel() const override { return true; }
+    const void* shared_key() const override { return P; }
+    int shared_message_step(size_t round) override {
+        if (round != round_next || round >= rounds()) return ATLAS_OK;
+        const size_t R = global_round(round);
+        if (P->folded.load(std::memory_order_acquire) == R) return ATLAS_OK;
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+        return P->fold_all(R, false);
+    }
+    int shared_ingest_step(const atlas_u128_t& r, size_t round) override {
+        if (round != round_next || round >= rounds()) return ATLAS_OK;
+        const size_t R = global_round(round);
+        if (P->bound.load(std::memory_order_acquire) == R) return ATLAS_OK;
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+        return P->bind_all(R, H::challenge_to_fr(r.lo, r.hi, rt().challenge_mode));
+    }
+    int finals(std::vector<H::Fr>& out) override {
+        if (round_next != rounds()) return fail(ATLAS_ESTATE, "final_claims: rounds remaining");
+        std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+        const int rc = P->fetch_finals();
+        if (rc) return rc;
+        out.assign(1, P->rows[row].fin);
+        return ATLAS_OK;
+    }
+};
+
 }  // namespace
+
+// Dense opening instances stepped together (DensePool): polys[i] (Fr or i32, 2^ns[i] coefficients, ns[i] >= 1, not consumed: the pool works on an
+// Fr copy) opened at points[i]; batch_max_rounds: the round count of the BatchedSumcheck they will sit in.  Internal (reduced_openings.hip).
+int atlas_rt_dense_pool_new(const atlas_poly_t* polys, const atlas_fr_t* const* points, const size_t* ns, size_t count, size_t batch_max_rounds, atlas_instance_t* out) {
+    if (!polys || !points || !ns || !out || count == 0) return fail(ATLAS_EINVAL, "dense_pool_new");
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+    std::unique_ptr<DensePool> P(new DensePool());
+    P->max_rounds = batch_max_rounds;
+    P->rows.resize(count);
+    uint64_t total = 0;
+    size_t tab_total = 0, w_total = 0, max_len = 0;
+    for (size_t i = 0; i < count; i++) {
+        if (!polys[i] || !points[i] || ns[i] == 0 || ns[i] > 26 || ns[i] > batch_max_rounds || polys[i]->len != ((size_t)1 << ns[i])) return fail(ATLAS_EINVAL, "dense_pool_new: member");
+        DensePool::Row& R = P->rows[i];
+        R.n = ns[i]; R.off = total; total += polys[i]->len;
+        R.st.init(reinterpret_cast<const H::Fr*>(points[i]), ns[i]);
+        if (R.st.k_in > 13 || R.st.k_out > 13) return fail(ATLAS_EINVAL, "dense_pool_new: more than 26 variables");
+        tab_total += ((size_t)2 << R.st.k_in) + ((size_t)2 << R.st.k_out); w_total += ns[i];
+        max_len = polys[i]->len > max_len ? polys[i]->len : max_len;
+    }
+    Fr* d_w = nullptr; DenseImportJob* d_imp = nullptr; PoolEqJob* d_jobs = nullptr;
+    struct Tmp { std::vector<void*> v; ~Tmp() { for (void* p : v) if (p) hipFree(p); } } tmp;
+    auto tmalloc = [&](void** p, size_t bytes) { hipError_t e = hipMalloc(p, bytes); if (e == hipSuccess) tmp.v.push_back(*p); return e; };
+    HIP_TRY(hipMalloc(&P->d_P, total * sizeof(Fr)));
+    HIP_TRY(hipMalloc(&P->d_tabs, tab_total * sizeof(Fr)));
+    HIP_TRY(hipMalloc(&P->d_part, count * DensePool::GX * sizeof(Fr)));
+    HIP_TRY(hipMalloc(&P->d_q0, count * sizeof(Fr)));
+    HIP_TRY(hipMalloc(&P->d_off, count * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc(&P->d_desc, 2 * count * sizeof(DenseRowDev)));
+    HIP_TRY(hipHostMalloc(&P->h_desc, 2 * count * sizeof(DenseRowDev), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&P->h_q0, count * sizeof(Fr), hipHostMallocDefault));
+    HIP_TRY(tmalloc((void**)&d_w, w_total * sizeof(Fr)));
+    HIP_TRY(tmalloc((void**)&d_imp, count * sizeof(DenseImportJob)));
+    HIP_TRY(tmalloc((void**)&d_jobs, 2 * count * sizeof(PoolEqJob)));
+    std::vector<H::Fr> w_all; w_all.reserve(w_total);
+    std::vector<DenseImportJob> imp(count); std::vector<PoolEqJob> jobs(2 * count); std::vector<uint64_t> off(count);
+    size_t wo = 0, to = 0;
+    for (size_t i = 0; i < count; i++) {
+        DensePool::Row& R = P->rows[i];
+        w_all.insert(w_all.end(), R.st.w.begin(), R.st.w.end());
+        R.d_ein = P->d_tabs + to; to += (size_t)2 << R.st.k_in;
+        R.d_eout = P->d_tabs + to; to += (size_t)2 << R.st.k_out;
+        jobs[2 * i] = PoolEqJob{R.d_ein, d_w + wo + 1, (uint32_t)R.st.k_in, 0};            // the suffix tables of GseDevH::init
+        jobs[2 * i + 1] = PoolEqJob{R.d_eout, d_w + wo + 1 + R.st.k_in, (uint32_t)R.st.k_out, 0};
+        imp[i] = DenseImportJob{polys[i]->d, P->d_P + R.off, (uint32_t)polys[i]->len, polys[i]->is_i32 ? 1u : 0u};
+        off[i] = R.off;
+        wo += R.n;
+    }
+    HIP_TRY(hipMemcpyAsync(d_w, w_all.data(), w_all.size() * sizeof(Fr), hipMemcpyHostToDevice, rt().stream));
+    HIP_TRY(hipMemcpyAsync(d_imp, imp.data(), count * sizeof(DenseImportJob), hipMemcpyHostToDevice, rt().stream));
+    HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(PoolEqJob), hipMemcpyHostToDevice, rt().stream));
+    HIP_TRY(hipMemcpyAsync(P->d_off, off.data(), count * sizeof(uint64_t), hipMemcpyHostToDevice, rt().stream));
+    k_dpool_import<<<dim3(grid_for(max_len, DensePool::GX), (unsigned)count), OP_THREADS, 0, rt().stream>>>(d_imp, make_consts());
+    k_pool_eq_cached_rev<<<(unsigned)(2 * count), 1024, 0, rt().stream>>>(d_jobs);
+    HIP_TRY(hipStreamSynchronize(rt().stream));                    // (the staging vectors are pageable and leave scope)
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ATLAS_ENODEV, "dense_pool_new", e);
+    P->refs = count;
+    DensePool* raw = P.release();
+    for (size_t i = 0; i < count; i++) { DensePoolRow* I = new DensePoolRow(); I->P = raw; I->row = i; out[i] = I; }
+    return ATLAS_OK;
+}
 
 // One-hot opening instances over device-resident lookup indices, stepped together (OneHotPool).  rows[i]: the T = 2^log_T lookups, the
 // chunk's shift, the opening point (log_K address coordinates, then log_T cycle ones).  batch_max_rounds: the round count of the whole
@@ -958,9 +1211,14 @@ int atlas_rt_onehot_pool_new(const atlas_rt_pool_row* in, size_t n, size_t log_K
         P->groups[gi].rows.push_back(i);
         OneHotPool::Row& R = P->rows[i];
         R.group = gi; R.off = total; total += P->groups[gi].T;
-        R.B = H::eq_evals(reinterpret_cast<const H::Fr*>(in[i].point), log_K);     // EqAddressState::new
-        R.F = {H::one()};
     }
+    // the rows' host tables on the host threads (thousands of rows: EqAddressState::new here and the histogram sums below were ~10 ms on one)
+    atlas_host::HostThreads::get().parallel_for(n, [&](size_t lo, size_t hi, size_t) {
+        for (size_t i = lo; i < hi; i++) {
+            P->rows[i].B = H::eq_evals(reinterpret_cast<const H::Fr*>(in[i].point), log_K);     // EqAddressState::new
+            P->rows[i].F = {H::one()};
+        }
+    });
     const size_t NG = P->groups.size();
     // device state
     Fr *d_w = nullptr, *d_E = nullptr;
@@ -1033,17 +1291,19 @@ int atlas_rt_onehot_pool_new(const atlas_rt_pool_row* in, size_t n, size_t log_K
     std::vector<unsigned long long> hist(n * 16 * 8);
     HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, hist.size() * 8, hipMemcpyDeviceToHost, rt().stream));
     HIP_TRY(hipStreamSynchronize(rt().stream));
-    for (size_t i = 0; i < n; i++) {
-        OneHotPool::Row& R = P->rows[i];
-        R.G.resize(P->K);
-        for (size_t k = 0; k < P->K; k++) {
-            uint64_t acc[9];
-            for (int w = 0; w < 8; w++) acc[w] = hist[(i * 16 + k) * 8 + w];
-            acc[8] = 0;
-            R.G[k] = atlas_rt::sum_to_fr(acc, 32, 0);
+    atlas_host::HostThreads::get().parallel_for(n, [&](size_t lo, size_t hi, size_t) {
+        for (size_t i = lo; i < hi; i++) {
+            OneHotPool::Row& R = P->rows[i];
+            R.G.resize(P->K);
+            for (size_t k = 0; k < P->K; k++) {
+                uint64_t acc[9];
+                for (int w = 0; w < 8; w++) acc[w] = hist[(i * 16 + k) * 8 + w];
+                acc[8] = 0;
+                R.G[k] = atlas_rt::sum_to_fr(acc, 32, 0);
+            }
         }
-        if (d_idx_rows) d_idx_rows[i] = P->d_idx + R.off;
-    }
+    });
+    for (size_t i = 0; i < n && d_idx_rows; i++) d_idx_rows[i] = P->d_idx + P->rows[i].off;
     P->refs = n;
     OneHotPool* raw = P.release();
     for (size_t i = 0; i < n; i++) { OneHotPoolRow* I = new OneHotPoolRow(); I->P = raw; I->row = i; out[i] = I; }

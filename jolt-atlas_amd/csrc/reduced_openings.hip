@@ -27,6 +27,7 @@ int atlas_rt_onehot_pool_new(const atlas_rt_pool_row* in, size_t n, size_t log_K
 
 static thread_local double g_last_open_ms = 0;
 int atlas_rt_chunk_index_rows(const atlas_rt_pool_row* in, size_t n, size_t log_K, int32_t** d_buf, const int32_t** rows);      // opening.hip
+int atlas_rt_dense_pool_new(const atlas_poly_t* polys, const atlas_fr_t* const* points, const size_t* ns, size_t count, size_t batch_max_rounds, atlas_instance_t* out);   // opening.hip
 int atlas_rt_batched_set_shard(atlas_batched_t b, atlas_shard_group_t sh);                                                        // batched.hip
 int atlas_rt_batched_add_remote(atlas_batched_t b, size_t rounds, const atlas_fr_t* input_claim);
 double atlas_rt_last_hyperkzg_ms() { return g_last_open_ms; }
@@ -132,10 +133,29 @@ int atlas_rt_prove_reduced_openings(const atlas_opening_t* openings, size_t n_op
         O.k = host_rows.back().data();
     }
     openings = local.data();
+    // the dense members this rank steps, one pool for all of them (opening.hip DensePool; ATLAS_NO_DENSE_POOL=1: an instance each, as before)
+    if (!rc && getenv("ATLAS_NO_DENSE_POOL") == nullptr) {
+        size_t batch_rounds = 0;
+        for (size_t i = 0; i < n_open; i++) { const size_t nr = openings[i].kind ? openings[i].log_K + openings[i].log_T : openings[i].n; batch_rounds = nr > batch_rounds ? nr : batch_rounds; }
+        std::vector<atlas_poly_t> dp; std::vector<const atlas_fr_t*> dpt; std::vector<size_t> dn, where;
+        for (size_t i = 0; i < n_open; i++) {
+            const atlas_opening_t& O = openings[i];
+            if (O.kind != 0 || owner[i] != my_rank || !O.poly || !O.point || O.n == 0 || O.n > 26) continue;      // (constants and malformed members: the path below, with its checks)
+            size_t plen = 0;
+            if (atlas_poly_len(O.poly, &plen) || plen != ((size_t)1 << O.n)) continue;
+            dp.push_back(O.poly); dpt.push_back(O.point); dn.push_back(O.n); where.push_back(i);
+        }
+        if (dp.size() >= 2) {
+            std::vector<atlas_instance_t> di(dp.size(), nullptr);
+            { PROF("reduced: dense pool new"); rc = atlas_rt_dense_pool_new(dp.data(), dpt.data(), dn.data(), dp.size(), batch_rounds, di.data()); }
+            for (size_t q = 0; q < dp.size() && !rc; q++) { inst[where[q]] = di[q]; done[where[q]] = 1; }
+        }
+    }
     for (size_t i = 0; i < n_open && !rc; i++) {
         const atlas_opening_t& O = openings[i];
         if (owner[i] != my_rank) continue;                 // (another rank steps it; the members outside the pool all belong to rank 0)
         if (O.kind == 0) {
+            if (done[i]) continue;
             atlas_poly_t c = nullptr;
             if (!O.poly || (!O.point && O.n)) { rc = fail(ATLAS_EINVAL, "prove_reduced_openings: dense opening without polynomial/point"); break; }
             PROF("reduced: dense clone + new");
