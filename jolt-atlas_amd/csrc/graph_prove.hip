@@ -303,8 +303,18 @@ struct Prover : FlowSink {
     }
     int commit_all() {
         // every lookup family of the graph in ONE launch (its d chunk commitments are consecutive rows); the dense advice polynomials one by one
+        const bool trace = getenv("ATLAS_TRACE") != nullptr;
+        auto t_prev = std::chrono::steady_clock::now();
+        auto mark = [&](const char* what) {
+            if (!trace) return;
+            atlas_sync();
+            const auto t1 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[atlas trace] commit_witness_polynomials %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t_prev).count());
+            t_prev = t1;
+        };
         std::vector<atlas_lookup_family_t> fams;
         std::vector<gr::Committed*> first;                                    // first chunk of each family
+        std::vector<gr::Committed*> dense;
         for (auto& kv : G.wit) {
             auto& cs = kv.second.committed;
             for (size_t i = 0; i < cs.size();) {
@@ -316,13 +326,19 @@ struct Prover : FlowSink {
                     while (j < cs.size() && cs[j].kind == 1 && cs[j].d_lookups == cs[i].d_lookups) j++;
                     fams.push_back(atlas_lookup_family_t{cs[i].d_lookups, cs[i].log_T, cs[i].log_K});
                     first.push_back(&cs[i]);
-                } else {
-                    int rc = atlas_msm_poly(srs, 0, cs[i].dense, &cs[i].commitment);
-                    if (rc) return rc;
-                }
+                } else dense.push_back(&cs[i]);
                 i = j;
             }
         }
+        if (!dense.empty()) {                                                 // the dense advice polynomials: one batch (atlas_commit_batch: the i32 ones share a bucket pipeline)
+            std::vector<atlas_poly_t> dp(dense.size());
+            std::vector<atlas_g1_affine_t> dc(dense.size());
+            for (size_t q = 0; q < dense.size(); q++) dp[q] = dense[q]->dense;
+            int rc = atlas_commit_batch(srs, dp.data(), dp.size(), dc.data());
+            if (rc) return rc;
+            for (size_t q = 0; q < dense.size(); q++) dense[q]->commitment = dc[q];
+        }
+        mark("dense + wide one-hot members");
         if (!fams.empty()) {
             size_t total = 0;
             for (auto& f : fams) total += (f.log_K + 3) / 4;
@@ -364,6 +380,7 @@ struct Prover : FlowSink {
             size_t o = 0;
             for (size_t f = 0; f < fams.size(); f++) { const size_t d = (fams[f].log_K + 3) / 4; for (size_t q = 0; q < d; q++) first[f][q].commitment = pts[o++]; }
         }
+        mark("lookup families");
         for (auto& kv : committed) {                                          // transcript.append_serializable(commitment), BTreeMap order
             uint8_t b[64], rev[64];
             int rc = atlas_g1_to_bytes_uncompressed(&kv.second->commitment, b);
@@ -371,6 +388,7 @@ struct Prover : FlowSink {
             for (int i = 0; i < 64; i++) rev[i] = b[63 - i];
             H::tr_append_bytes(Tr, rev, 64);
         }
+        mark("transcript");
         return ATLAS_OK;
     }
 

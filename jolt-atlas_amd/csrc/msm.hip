@@ -661,6 +661,36 @@ int msm_small_device(const G1Affine* bases, const T* d_scalars, size_t n, atlas_
     }, out);
 }
 
+// K I32Scalars vectors (each against the prefix of the same SRS) through ONE bucket pipeline: the narrow-scalar plan of msm_small_device over the
+// concatenated scalars, one window shape from the largest magnitude of them all.  A graph commits ~50 dense advice polynomials (quotients,
+// remainders: i32) — one by one they were an abs-max pass, a synchronisation and a latency-bound pipeline each, 0.45 ms a polynomial (r06z).
+int msm_small_multi_i32(const G1Affine* bases, const int32_t* d_cat, size_t n_tot, size_t K, const size_t* lens, const size_t* offs, atlas_g1_affine_t* out) {
+    const H::G1Aff z{H::q_zero(), H::q_zero()};
+    if (n_tot == 0) { for (size_t k = 0; k < K; k++) to_out(z, out + k); return ATLAS_OK; }
+    int rc = ws.ensure(256);
+    if (rc) return rc;
+    unsigned long long* d_max = (unsigned long long*)ws.p;
+    HIP_TRY(hipMemsetAsync(d_max, 0, 8, rt().stream));
+    k_abs_max<int32_t><<<grid_for(n_tot, 1024), MSM_THREADS, 0, rt().stream>>>(d_cat, n_tot, d_max);
+    unsigned long long mx = 0;
+    HIP_TRY(hipMemcpyAsync(&mx, d_max, 8, hipMemcpyDeviceToHost, rt().stream));
+    HIP_TRY(hipStreamSynchronize(rt().stream));
+    if (mx == 0) { for (size_t k = 0; k < K; k++) to_out(z, out + k); return ATLAS_OK; }
+    size_t mx_len = 0;
+    for (size_t k = 0; k < K; k++) mx_len = lens[k] > mx_len ? lens[k] : mx_len;
+    const uint32_t bits = 64 - (uint32_t)__builtin_clzll(mx), total = bits + 2;       // (the top window stays below half after the incoming carry)
+    const uint32_t c0 = pick_shape(mx_len).c;
+    MsmShape S;
+    S.n_windows = (total + c0 - 1) / c0;
+    S.c = (total + S.n_windows - 1) / S.n_windows;
+    if (S.c < 2) S.c = 2;
+    S.bpw = 1u << (S.c - 1);
+    const MsmMulti M{K, lens, offs};
+    return msm_core(bases, n_tot, S, [&](int16_t* digits, hipStream_t st) {
+        k_msm_digits_small<int32_t><<<grid_for(n_tot), MSM_THREADS, 0, st>>>(d_cat, n_tot, S, digits);
+    }, out, &M);
+}
+
 }  // namespace
 
 // Transcript::append_point (blake2b.rs:166-187) on the host transcript
@@ -989,9 +1019,39 @@ int atlas_commit_lookup_chunks_multi(atlas_srs_t srs, const atlas_lookup_family_
         for (size_t i = 0; i < d; i++) rows.push_back(LookupChunkRow{fams[f].d_lookups, (uint32_t)T, (uint32_t)(log_k_chunk * (d - 1 - i))});
         maxT = T > maxT ? T : maxT;
     }
-    const size_t R = rows.size();
+    const size_t R_all = rows.size();
     std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     static const bool old_cut = getenv("ATLAS_COMMIT_OLD_CUT") != nullptr;      // A-B: one slice count for the whole launch
+    // chunk polynomials of a family that coincide with their left neighbour are not computed again (k_lookup_chunk_diff): alias[r] = the row whose
+    // commitment row r shares.  ATLAS_COMMIT_NO_ALIAS=1: every row on its own (A/B).
+    std::vector<uint32_t> alias(R_all);
+    for (size_t r = 0; r < R_all; r++) alias[r] = (uint32_t)r;
+    static const bool no_alias = getenv("ATLAS_COMMIT_NO_ALIAS") != nullptr;
+    if (!no_alias && !old_cut) {
+        std::vector<LookupFamilyDev> hf(n);
+        for (size_t f = 0; f < n; f++) hf[f] = LookupFamilyDev{fams[f].d_lookups, (uint32_t)((size_t)1 << fams[f].log_T), (uint32_t)((fams[f].log_K + log_k_chunk - 1) / log_k_chunk)};
+        DevBuf d_f, d_diff;
+        HIP_TRY(d_f.alloc(n * sizeof(LookupFamilyDev)));
+        HIP_TRY(d_diff.alloc(n * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpyAsync(d_f.p, hf.data(), n * sizeof(LookupFamilyDev), hipMemcpyHostToDevice, rt().stream));
+        k_lookup_chunk_diff<<<(unsigned)n, MSM_THREADS, 0, rt().stream>>>(d_f.as<LookupFamilyDev>(), (uint32_t)log_k_chunk, d_diff.as<uint32_t>());
+        std::vector<uint32_t> diff(n);
+        HIP_TRY(hipMemcpyAsync(diff.data(), d_diff.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, rt().stream));
+        HIP_TRY(hipStreamSynchronize(rt().stream));
+        size_t r0 = 0;
+        for (size_t f = 0; f < n; f++) {
+            const size_t d = hf[f].d;
+            for (size_t c = 1; c < d && d <= 32; c++) if (!((diff[f] >> (c - 1)) & 1u)) alias[r0 + c] = alias[r0 + c - 1];
+            r0 += d;
+        }
+    }
+    std::vector<uint32_t> slot(R_all, 0);                                       // row -> its place among the rows that are computed
+    {
+        std::vector<LookupChunkRow> uniq;
+        for (size_t r = 0; r < R_all; r++) if (alias[r] == r) { slot[r] = (uint32_t)uniq.size(); uniq.push_back(rows[r]); }
+        rows.swap(uniq);
+    }
+    const size_t R = rows.size();
     DevBuf d_rows, d_part, d_sum, d_slices, d_off;
     HIP_TRY(d_rows.alloc(R * sizeof(LookupChunkRow)));
     HIP_TRY(d_sum.alloc(R * sizeof(G1Xyzz)));
@@ -1029,7 +1089,7 @@ int atlas_commit_lookup_chunks_multi(atlas_srs_t srs, const atlas_lookup_family_
     HIP_TRY(hipStreamSynchronize(rt().stream));
     std::vector<H::G1Aff> aff(R);
     H::gx_batch_to_aff(res.data(), R, aff.data());
-    for (size_t r = 0; r < R; r++) to_out(aff[r], out + r);
+    for (size_t r = 0; r < R_all; r++) to_out(aff[slot[alias[r]]], out + r);
     return ATLAS_OK;
 }
 
@@ -1047,8 +1107,31 @@ int atlas_commit_batch(atlas_srs_t srs, const atlas_poly_t* polys, size_t n, atl
         if (!polys[i]->is_i32) { fr_idx.push_back(i); tot += polys[i]->len; }
     }
     std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
-    for (size_t i = 0; i < n; i++)
-        if (polys[i]->is_i32) { int rc = msm_small_device<int32_t>(srs->d, (const int32_t*)polys[i]->d, polys[i]->len, out + i); if (rc) return rc; }
+    {
+        std::vector<size_t> ii;
+        size_t itot = 0;
+        for (size_t i = 0; i < n; i++) if (polys[i]->is_i32) { ii.push_back(i); itot += polys[i]->len; }
+        static const bool one_by_one = getenv("ATLAS_COMMIT_I32_ONE_BY_ONE") != nullptr;       // A/B
+        if (ii.size() >= 2 && !one_by_one && itot < ((size_t)1 << 28)) {
+            DevBuf cat;
+            HIP_TRY(cat.alloc(itot * sizeof(int32_t)));
+            std::vector<size_t> il(ii.size()), io(ii.size());
+            size_t o = 0;
+            for (size_t j = 0; j < ii.size(); j++) {
+                const atlas_poly* P = polys[ii[j]];
+                il[j] = P->len; io[j] = o;
+                HIP_TRY(hipMemcpyAsync(cat.as<int32_t>() + o, P->d, P->len * sizeof(int32_t), hipMemcpyDeviceToDevice, rt().stream));
+                o += P->len;
+            }
+            std::vector<atlas_g1_affine_t> res(ii.size());
+            const int rc = msm_small_multi_i32(srs->d, cat.as<int32_t>(), itot, ii.size(), il.data(), io.data(), res.data());
+            (void)hipStreamSynchronize(rt().stream);
+            if (rc) return rc;
+            for (size_t j = 0; j < ii.size(); j++) out[ii[j]] = res[j];
+        } else {
+            for (size_t i : ii) { int rc = msm_small_device<int32_t>(srs->d, (const int32_t*)polys[i]->d, polys[i]->len, out + i); if (rc) return rc; }
+        }
+    }
     if (fr_idx.size() == 1) return msm_device(srs->d, (const Fr*)polys[fr_idx[0]]->d, polys[fr_idx[0]]->len, out + fr_idx[0], srs, 0);
     if (fr_idx.empty()) return ATLAS_OK;
     Fr* cat = nullptr;

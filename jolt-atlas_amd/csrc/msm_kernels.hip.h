@@ -740,6 +740,31 @@ __global__ __launch_bounds__(MSM_THREADS) void k_g1_sum_lookup_rows(const G1Affi
     if (threadIdx.x == 0) g1_store(out + (size_t)blockIdx.y * gridDim.x + blockIdx.x, sm[0]);
 }
 
+// Which consecutive chunk polynomials of a lookup family are THE SAME polynomial: bit c of diff[f] is set iff chunk c and chunk c + 1 (chunk c is
+// cut at shift = log_k_chunk (d - 1 - c)) differ at some cycle.  A 32-bit value sign-extended into a 64-bit lookup index has eight identical top
+// nibbles, and the nibbles above the operands' magnitude repeat the sign as well: 11 of the 16 chunk polynomials of a typical clamp / ReLU family
+// are one polynomial — one commitment, computed once (atlas_commit_lookup_chunks_multi).  One workgroup per family.
+struct LookupFamilyDev { const uint64_t* lookups; uint32_t T, d; };
+__global__ __launch_bounds__(MSM_THREADS) void k_lookup_chunk_diff(const LookupFamilyDev* __restrict__ fams, uint32_t log_k_chunk, uint32_t* __restrict__ diff) {
+    __shared__ uint32_t sm;
+    const LookupFamilyDev F = fams[blockIdx.x];
+    if (threadIdx.x == 0) sm = 0;
+    __syncthreads();
+    const uint64_t mask = ((uint64_t)1 << log_k_chunk) - 1;
+    uint32_t acc = 0;
+    for (uint32_t t = threadIdx.x; t < F.T; t += MSM_THREADS) {
+        const uint64_t v = F.lookups[t];
+        for (uint32_t c = 0; c + 1 < F.d; c++) {
+            const uint32_t s0 = log_k_chunk * (F.d - 1 - c), s1 = s0 - log_k_chunk;
+            const uint64_t a = s0 >= 64 ? 0 : ((v >> s0) & mask), b = (v >> s1) & mask;
+            acc |= (a != b ? 1u : 0u) << c;
+        }
+    }
+    if (acc) atomicOr(&sm, acc);
+    __syncthreads();
+    if (threadIdx.x == 0) diff[blockIdx.x] = sm;
+}
+
 // The same with the slices cut PER ROW (a graph's rows run from 2^6 to 2^20 cycles): a workgroup takes slice `slice` of `n_slices` of its row, a
 // thread ~32 points of it.  With one slice count for the whole launch (sized for the longest row) a row of 2^14 cycles was spread over 64
 // workgroups of ONE point per thread, each followed by the 8-level tree of full additions: the trees were the launch — 8823 rows x 64
