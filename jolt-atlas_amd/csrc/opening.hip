@@ -561,9 +561,13 @@ __global__ __launch_bounds__(OP_THREADS) void k_pool_chunk_rows(const uint64_t* 
 // their entries out of the index stream without atomics — the scattered 32-byte loads of the matching lanes made it 5 x slower, r06t.)
 constexpr uint32_t HIST_COPIES = 32, HIST_STRIDE = 144;
 __global__ __launch_bounds__(OP_THREADS) void k_pool_hist(const int32_t* __restrict__ idx, const uint64_t* __restrict__ off, const uint32_t* __restrict__ Ts,
-                                                          const Fr* const* __restrict__ E, uint32_t K, unsigned long long* __restrict__ out /* [rows][16][8] */) {
+                                                          const Fr* const* __restrict__ E, uint32_t K, uint32_t n_rows, unsigned long long* __restrict__ out /* [rows][16][8] */) {
     __shared__ unsigned long long acc[HIST_COPIES * HIST_STRIDE];
-    const size_t r = blockIdx.x;
+    // workgroups are dealt to the 8 XCDs round-robin, each with its own L2: row = xcd * ceil(rows / 8) + k keeps the rows of a group (consecutive, and
+    // all reading the group's eq table E) on ONE XCD, so that the table comes from HBM once instead of once per XCD
+    const size_t per = (gridDim.x + 7) / 8;
+    const size_t r = (size_t)(blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (r >= n_rows) return;
     for (uint32_t i = threadIdx.x; i < HIST_COPIES * HIST_STRIDE; i += OP_THREADS) acc[i] = 0;
     __syncthreads();
     const int32_t* ix = idx + off[r];
@@ -1287,7 +1291,7 @@ int atlas_rt_onehot_pool_new(const atlas_rt_pool_row* in, size_t n, size_t log_K
     HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(PoolEqJob), hipMemcpyHostToDevice, rt().stream));      // (jobs lives until the synchronisation below)
     k_pool_eq_cached_rev<<<(unsigned)(2 * NG), 1024, 0, rt().stream>>>(d_jobs);
     k_pool_eq_full<<<dim3((unsigned)max_hi_blocks, (unsigned)NG), 256, 0, rt().stream>>>(d_jobs + 2 * NG);
-    k_pool_hist<<<(unsigned)n, OP_THREADS, 0, rt().stream>>>(P->d_idx, P->d_off, d_Ts, d_Eptr, (uint32_t)P->K, d_hist);
+    k_pool_hist<<<(unsigned)(((n + 7) / 8) * 8), OP_THREADS, 0, rt().stream>>>(P->d_idx, P->d_off, d_Ts, d_Eptr, (uint32_t)P->K, (uint32_t)n, d_hist);
     std::vector<unsigned long long> hist(n * 16 * 8);
     HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, hist.size() * 8, hipMemcpyDeviceToHost, rt().stream));
     HIP_TRY(hipStreamSynchronize(rt().stream));
