@@ -151,6 +151,7 @@ int atlas_shutdown(void) {
     hipStreamSynchronize(rt().stream);
     for (auto f : rt().at_shutdown) f();
     rt().at_shutdown.clear();
+    if (rt().eval_stream) { hipStreamDestroy(rt().eval_stream); hipEventDestroy(rt().eval_event); hipFree(rt().d_eval_partials); rt().eval_stream = nullptr; rt().eval_event = nullptr; rt().d_eval_partials = nullptr; rt().eval_event_eq = nullptr; }
     hipFree(rt().d_partials); hipFree(rt().d_ctx); hipFree(rt().d_proof); hipFree(rt().d_chal); hipFree(rt().d_finals);
     hipHostFree(rt().h_pinned);
     rt().chan.release();

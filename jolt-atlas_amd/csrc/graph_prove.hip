@@ -446,6 +446,7 @@ struct Prover : FlowSink {
         Out O = out();
         int rc = ATLAS_OK;
         H::Fr lr[2];
+        bool have_lr = false;
         const int32_t* ops[2] = {G.tensor(nd.inputs[0]), G.tensor(nd.inputs[1])};
         if (T > 1) {
             atlas_poly_t p_acc = nullptr;
@@ -454,13 +455,24 @@ struct Prover : FlowSink {
             rc = pre.begin((const atlas_fr_t*)R.point.data(), log_T, {{W.cidx.as<uint64_t>(), (size_t)64}});
             if (!rc) rc = pre.prebuild_clamp(W.cidx.as<uint64_t>(), log_T, (const atlas_fr_t*)R.point.data());
             if (!rc) rc = atlas_poly_wrap_device_fr(W.acc_fr.p, T, &p_acc);
-            if (!rc) rc = pre.eq ? atlas_rt_evaluate_with_eq(&p_acc, 1, pre.eq, (atlas_fr_t*)&acc_claim) : atlas_poly_evaluate(p_acc, (const atlas_fr_t*)R.point.data(), log_T, (atlas_fr_t*)&acc_claim);
+            if (!rc && pre.eq) {
+                // the operands' openings at the same point ride the same pass (they are appended after the lookup's proofs, but depend on nothing drawn
+                // since: one evaluation and one wait per Add / Sub node instead of two — 136 nodes of the GPT-2-shaped graph)
+                atlas_poly_t p0 = nullptr, p1 = nullptr;
+                rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(ops[0]), T, &p0);
+                if (!rc) rc = atlas_poly_wrap_device_i32(const_cast<int32_t*>(ops[1]), T, &p1);
+                H::Fr ev[3];
+                if (!rc) { const atlas_poly_t ps[3] = {p_acc, p0, p1}; rc = atlas_rt_evaluate_with_eq(ps, 3, pre.eq, (atlas_fr_t*)ev); }
+                acc_claim = ev[0]; lr[0] = ev[1]; lr[1] = ev[2];
+                have_lr = !rc;
+                for (atlas_poly_t p : {p0, p1}) if (p) atlas_poly_free(p);
+            } else if (!rc) rc = atlas_poly_evaluate(p_acc, (const atlas_fr_t*)R.point.data(), log_T, (atlas_fr_t*)&acc_claim);
             if (p_acc) atlas_poly_free(p_acc);
             if (!rc) rc = pre.collect(false);
             if (!rc) rc = O.append_virtual(Tr, gr::node_exec(gr::virt(gr::VP_ClampAcc, nd.idx), nd.idx), R.point, acc_claim);       // append_raf_claims_prover
             if (!rc) rc = prove_clamp_lookup_flow(W.cidx.as<uint64_t>(), log_T, (const atlas_fr_t*)R.point.data(), acc_claim, R.claim, &t, O, nullptr, &pre);
         }
-        if (!rc) rc = eval_i32(ops, 2, T, R.point, lr);
+        if (!rc && !have_lr) rc = eval_i32(ops, 2, T, R.point, lr);
         if (!rc) rc = append_nodeio(nd, 0, R.point, lr[0]);
         if (!rc) rc = append_nodeio(nd, 1, R.point, lr[1]);
         return rc;

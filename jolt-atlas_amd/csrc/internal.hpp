@@ -32,6 +32,9 @@ int atlas_rt_identity_range_check_new(const uint64_t* lookup_indices, size_t log
 int atlas_rt_ps_set_gamma(atlas_instance_t inst, const atlas_fr_t* gamma);
 // MultilinearPolynomial::evaluate of <= 3 polynomials against a full eq table on the device (spliteq.hip); waits for the library stream
 int atlas_rt_evaluate_with_eq(const atlas_poly_t* polys, size_t count, atlas_poly_t eq_full, atlas_fr_t* out);
+int atlas_rt_eval_event_record(atlas_poly_t eq_full);      // spliteq.hip: the point of the library stream an evaluation against this eq table waits for
+void atlas_rt_eval_event_drop(atlas_poly_t eq_full);
+bool atlas_rt_eval_event_live(atlas_poly_t eq_full);
 // ReadRafProver over a table of at most 2^12 entries as a host-arithmetic instance (shout.hip): G = the device histogram (downloaded)
 int atlas_rt_shout_read_raf_host_new(atlas_poly_t G, const int32_t* table, size_t log_K, const atlas_fr_t* gamma, atlas_instance_t* out);
 // a BatchedSumcheck member over zero variables: no rounds, the given final claims (elementwise.hip)

@@ -198,6 +198,7 @@ struct NodePre {
     int begin(const atlas_fr_t* r, size_t log_T, std::initializer_list<std::pair<const uint64_t*, size_t>> lookups) {
         if (!on() || log_T == 0 || log_T > 16) return ATLAS_OK;
         int rc = atlas_eq_evals(r, log_T, nullptr, &eq);
+        if (!rc) rc = atlas_rt_eval_event_record(eq);              // the node's evaluation waits for the table, not for what follows it on the stream
         for (auto& lk : lookups) {
             if (rc) break;
             fams.push_back(Fam{lk.first, lk.second, nullptr, {}, false});
@@ -205,8 +206,11 @@ struct NodePre {
         }
         return rc;
     }
-    // after the caller has waited for the library stream (or wait = true)
+    // after the caller has waited for the library stream (or wait = true).  With the node's evaluation on its own stream (atlas_rt_eval_event_record)
+    // the caller's wait was NOT for the library stream: collect(false) then leaves the tables to G_for(), which waits when they are first asked for
+    // (the one-hot checks, a whole sumcheck later).
     int collect(bool wait) {
+        if (!wait && atlas_rt_eval_event_live(eq)) return ATLAS_OK;
         for (auto& F : fams) {
             if (F.have || !F.ticket) continue;
             int rc = atlas_rt_shout_ra_evals_finish(F.ticket, wait, F.G);
@@ -217,8 +221,20 @@ struct NodePre {
         return ATLAS_OK;
     }
     const std::vector<H::Fr>* G_for(const uint64_t* lookups, size_t log_K) const {
+        for (auto& F : fams) if (!F.have && F.ticket) { if (const_cast<NodePre*>(this)->collect_now()) return nullptr; break; }
         for (auto& F : fams) if (F.have && F.lookups == lookups && F.log_K == log_K) return &F.G;
         return nullptr;
+    }
+    int collect_now() {
+        bool wait = true;
+        for (auto& F : fams) {
+            if (F.have || !F.ticket) continue;
+            int rc = atlas_rt_shout_ra_evals_finish(F.ticket, wait, F.G);
+            if (rc) return rc;
+            wait = false;
+            F.have = true;
+        }
+        return ATLAS_OK;
     }
     // The node's prefix-suffix read-raf instances built AHEAD, behind the launches above and still before the node's first wait: their
     // constructors depend on r_node_output and the witness alone (u_evals = the shared eq table, the sign scan, phase 0's tables; gamma only
@@ -243,7 +259,7 @@ struct NodePre {
     ~NodePre() {
         for (atlas_instance_t i : {clamp, rc_inst, relu}) if (i) atlas_instance_free(i);      // (before the eq table they borrow)
         for (auto& F : fams) if (F.ticket) atlas_rt_shout_ra_evals_drop(F.ticket);
-        if (eq) atlas_poly_free(eq);
+        if (eq) { atlas_rt_eval_event_drop(eq); atlas_poly_free(eq); }
     }
     NodePre() = default;
     NodePre(const NodePre&) = delete;

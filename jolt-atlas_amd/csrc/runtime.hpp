@@ -48,6 +48,12 @@ struct Runtime {
     atlas::Fe* d_finals = nullptr;     // 3 (+ scratch for reduced evals)
     void* h_pinned = nullptr;          // pinned staging for small D2H/H2D
     bool no_lane_streams = false;      // the lanes of a pipelined batch stay on the library stream (set while several ranks' processes share THIS device: graph_prove.hip)
+    // atlas_rt_evaluate_with_eq on a stream of its own (spliteq.hip): the node's first wait is for ONE evaluation, not for everything NodePre put on the
+    // library stream behind the eq table.  eval_event: recorded right after the eq table whose device pointer is eval_event_eq.
+    hipStream_t eval_stream = nullptr;
+    hipEvent_t eval_event = nullptr;
+    const void* eval_event_eq = nullptr;
+    atlas::Fe* d_eval_partials = nullptr;
     int pending_async = 0;             // launches of shared_message_step calls whose results the driver has not waited for yet (batched.hip)
     std::vector<void (*)()> at_shutdown;   // release hooks of the translation units that keep device arenas
     struct DevPool* pool = nullptr;        // the caching allocator of this runtime (devpool.hpp): blocks are reused in the order of ITS streams

@@ -239,6 +239,30 @@ __global__ __launch_bounds__(SC_THREADS) void k_eval_with_eq(EvalEqArgs A, const
     block_reduce_store<3>(acc, partials);
 }
 }  // namespace
+// NodePre::begin calls this right after it has enqueued the node's eq table: the evaluation below then runs on a stream of its own behind THIS point of
+// the library stream — the operands are tensors / witness columns of the trace, complete long before — and the host waits for the evaluation alone,
+// while the lookup tables and prebuilt instances NodePre enqueues next (100-150 us of device work per lookup node, needed only when their proofs start)
+// run beside it.  Before, the wait was for all of it: 170 us per node, 343 nodes of the GPT-2-shaped graph (`sync atlas_rt_evaluate_with_eq`, r06m).
+// ATLAS_NO_SIDE_EVAL=1: everything on the library stream (A/B).
+int atlas_rt_eval_event_record(atlas_poly_t eq_full) {
+    static const bool off = getenv("ATLAS_NO_SIDE_EVAL") != nullptr;
+    if (off || !eq_full) return ATLAS_OK;
+    std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
+    if (rt().stream != rt().lib_stream || rt().no_lane_streams) return ATLAS_OK;          // (inside a lane, or ranks sharing the device: stay on one stream)
+    if (!rt().eval_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&rt().eval_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&rt().eval_event, hipEventDisableTiming));
+        HIP_TRY(hipMalloc(&rt().d_eval_partials, sizeof(Fr) * SC_MAX_BLOCKS * 3));
+    }
+    HIP_TRY(hipEventRecord(rt().eval_event, rt().stream));
+    rt().eval_event_eq = eq_full->d;
+    return ATLAS_OK;
+}
+void atlas_rt_eval_event_drop(atlas_poly_t eq_full) {
+    if (eq_full && rt().eval_event_eq == eq_full->d) rt().eval_event_eq = nullptr;
+}
+bool atlas_rt_eval_event_live(atlas_poly_t eq_full) { return eq_full && rt().eval_event_eq == eq_full->d; }
+
 int atlas_rt_evaluate_with_eq(const atlas_poly_t* polys, size_t count, atlas_poly_t eq_full, atlas_fr_t* out) {
     PROF("atlas_rt_evaluate_with_eq");
     NEED_INIT();
@@ -251,6 +275,15 @@ int atlas_rt_evaluate_with_eq(const atlas_poly_t* polys, size_t count, atlas_pol
     }
     std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
     const int grid = grid_for(eq_full->len);
+    if (rt().eval_event_eq == eq_full->d && rt().eval_stream && rt().stream == rt().lib_stream) {
+        Fr* slot = reinterpret_cast<Fr*>(static_cast<char*>(rt().h_pinned) + atlas_rt::PINNED_BYTES - 4 * sizeof(Fr));      // (the synchronous users of h_pinned start at 0)
+        HIP_TRY(hipStreamWaitEvent(rt().eval_stream, rt().eval_event, 0));
+        k_eval_with_eq<<<grid, SC_THREADS, 0, rt().eval_stream>>>(A, (const Fr*)eq_full->d, eq_full->len, rt().d_eval_partials, make_consts());
+        k_reduce1<<<1, SC_THREADS, 0, rt().eval_stream>>>(rt().d_eval_partials, grid, slot, 3);
+        HIP_TRY(hipStreamSynchronize(rt().eval_stream));
+        std::memcpy(out, slot, count * sizeof(Fr));
+        return ATLAS_OK;
+    }
     k_eval_with_eq<<<grid, SC_THREADS, 0, rt().stream>>>(A, (const Fr*)eq_full->d, eq_full->len, rt().d_partials, make_consts());
     k_reduce1<<<1, SC_THREADS, 0, rt().stream>>>(rt().d_partials, grid, (Fr*)rt().h_pinned, 3);
     HIP_TRY(hipStreamSynchronize(rt().stream));
