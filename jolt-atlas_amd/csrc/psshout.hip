@@ -286,7 +286,7 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_scale(const uint64_t* __restr
 // in, the word sums of its NQ suffix-weighted values per (phase, class).  The last workgroup turns the sums into residues and publishes
 // them with the minimum.  Sums of a phase are complete iff every lookup is pure there, i.e. for p < the published minimum.
 constexpr uint32_t PS_SIGN_PMAX = 7;
-struct PsSignOut { unsigned long long* acc /* [PMAX][2][NQ][8], zeroed */; uint32_t* min_lz /* = phases on entry */; uint32_t* counter; Fr* host_dst; Chunk* tag_chunk; uint32_t tag; };
+struct PsSignOut { unsigned long long* acc /* [PMAX][2][NQ][8], zeroed */; uint32_t* min_lz /* the COMPLEMENT of the minimum, as a maximum: zero on entry, so that one memset covers the whole scratch */; uint32_t* counter; Fr* host_dst; Chunk* tag_chunk; uint32_t tag; };
 template <int NQ>
 __global__ __launch_bounds__(RA_THREADS) void k_ps_sign_scan(const uint64_t* __restrict__ idx, const Fr* __restrict__ u0, size_t T, uint32_t N, uint32_t log_m,
                                                              uint32_t phases, uint32_t bound, PsSignOut O) {
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_sign_scan(const uint64_t* __r
     }
     __syncthreads();
     for (uint32_t w = threadIdx.x; w < n_words; w += RA_THREADS) if (sm[w]) atomicAdd(&O.acc[w], sm[w]);
-    if (threadIdx.x == 0) atomicMin(O.min_lz, s_min);
+    if (threadIdx.x == 0) atomicMax(O.min_lz, ~s_min);
     __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(RA_THREADS) void k_ps_sign_scan(const uint64_t* __r
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t mn = __hip_atomic_load(O.min_lz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t mn = ~__hip_atomic_load(O.min_lz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ch_store_sys(O.tag_chunk, ch_u32x4{n_vals, mn, 0u, O.tag});
     }
 }
@@ -715,7 +715,6 @@ struct PsLookup : atlas_instance {
         uint32_t* mn = reinterpret_cast<uint32_t*>(static_cast<char*>(sgn_scratch.p) + 7168);
         HIP_TRY(hipMemsetAsync(sgn_scratch.p, 0, 8192, rt().stream));
         const uint32_t ph = (uint32_t)phases;
-        HIP_TRY(hipMemsetAsync(mn, 0xFF, 4, rt().stream));                                // the minimum starts above any count
         atlas::Chunk* box = rt().chan.alloc_long(2 * n_vals + 4);
         const uint32_t tag = rt().chan.tag();
         size_t gb = (T + RA_THREADS - 1) / RA_THREADS; if (gb > 256) gb = 256;
