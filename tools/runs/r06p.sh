@@ -1,8 +1,8 @@
 #!/bin/bash
-# r06p: the capture at HEAD — bench line, rocprofv3 kernel stats of the same command, component / node / MSM / HyperKZG timings (capture_round.sh,
-# the suite having run at the same commit just before: r06p_pytest_gpu.txt), the device-idle table of a nanoGPT-shaped proof, the reduction's stage trace
+# r06p: the capture at HEAD — the whole GPU suite, bench line, rocprofv3 kernel stats of the same command, component / node / MSM / HyperKZG timings (capture_round.sh),
+# the device-idle table of a nanoGPT-shaped proof, the reduction's stage trace
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; O=$PWD/gpurun_out; R=$PWD; mkdir -p $O
-bash tools/capture_round.sh r06p skip-tests
+bash tools/capture_round.sh r06p
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace -d /tmp/prof_n -o r -- python $R/tools/time_graph.py nanogpt_model 2 2 > /tmp/prof_n.log 2>&1 )
 DB=$(find /tmp/prof_n -name "*.db" | head -1)
 python tools/rocprof_gaps.py $DB 480 60 > $O/r06p_nanogpt_gaps.txt 2>&1
