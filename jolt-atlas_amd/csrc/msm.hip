@@ -1281,7 +1281,20 @@ static int hyperkzg_open_impl(atlas_srs_t srs, atlas_poly_t poly, const atlas_u1
     Fr* polys = (Fr*)hk_arena.p; Fr* B = polys + 2 * n; Fr* h = B + n; Fr* scr = h + 3 * n;
     Fr* xincl = scr; Fr* blocktot = xincl + 3 * xs; Fr* G = blocktot + 3 * n_blocks; Fr* total = G + 3 * n_blocks;
     Fr* pw16 = total + 3; Fr* dq = pw16 + 3 * 257; Fr* evpart = dq + ell; Fr* evout = evpart + 3 * eval_blocks;
-    auto cleanup = [&]() {};
+    // The arenas of an opening of 2^22 points and more (this one: 6 n Fr — 3.2 GB at n = 2^24 —, the bucket pipelines' workspaces: 10 GB for the three
+    // witness vectors on one GPU) go back when it ends: kept, they sat under the NEXT proof's reduction, whose pools then came on top (per-rank peak of the
+    // sharded 12-layer proof 12-14 GB at world 4).  Smaller ones stay cached.  ATLAS_KEEP_ARENAS=1: as before (A/B).
+    auto cleanup = [&]() {
+        static const bool keep = getenv("ATLAS_KEEP_ARENAS") != nullptr;
+        if (keep) return;
+        bool any = false;
+        for (Workspace* wk : {&ws, &hk_arena, &ws_side, &ws_tab}) any = any || (wk->p && wk->cap >= ((size_t)1 << 30));
+        if (!any) return;
+        if (side_stream) { (void)hipStreamSynchronize(side_stream); (void)hipStreamSynchronize(side_stream2); }
+        (void)hipStreamSynchronize(rt().stream);
+        for (Workspace* wk : {&ws, &hk_arena, &ws_side, &ws_tab})
+            if (wk->p && wk->cap >= ((size_t)1 << 30)) { (void)hipFree(wk->p); wk->p = nullptr; wk->cap = 0; }
+    };
 
     HkTrace tr;
     // Phase 1: folds (LowToHigh, variable point[ell-i-1])

@@ -224,6 +224,11 @@ int atlas_rt_prove_reduced_openings(const atlas_opening_t* openings, size_t n_op
         }
     }
     rc = atlas_rlc_build(dense.data(), dense.size(), onehot.data(), onehot.size(), &joint);
+    // the members go BEFORE the opening allocates its arena (6 n Fr: 3.2 GB at n = 2^24): the pools' vectors (9 GB + the index rows on one GPU, 1 / world
+    // of the vectors per rank) and the opening's arena are then never resident together — the peak of the stage is the larger, not the sum
+    for (auto& i : inst) if (i) { atlas_instance_free(i); i = nullptr; }
+    if (b) { atlas_batched_free(b); b = nullptr; }
+    if (d_remote_idx) { std::lock_guard<atlas_rt::Mutex> lkg(atlas_rt::rt().mu); hipFree(d_remote_idx); d_remote_idx = nullptr; }
     mark("claims + joint polynomial");
     size_t jlen = 0;
     if (!rc) atlas_poly_len(joint, &jlen);

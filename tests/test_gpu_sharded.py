@@ -256,8 +256,8 @@ def test_sharded_prove_graph(tmp_path, world, name):
         in_use, peak = A.device_memory()
         print("RANK_MEMORY", rank, "peak_GB", round(peak / 2 ** 30, 2), "in_use_GB", round(in_use / 2 ** 30, 2))
         if {name!r} == "gpt2":                             # the whole table would be 12.9 GB on every rank
-            # (the 2^24 joint polynomial, the opening's 6 n Fr arena and the graph's witness are still whole on every rank: DESIGN 13)
-            assert peak / 2 ** 30 < 12.9 / world + 15.0, "per-rank device memory of the 12-layer proof: %.2f GB" % (peak / 2 ** 30)
+            # (the 2^24 joint polynomial, the opening's 6 n Fr arena and the graph's witness are still whole on every rank: DESIGN 13; measured 10.5-11.1 GB at world 4, 14.5-15.3 at world 2)
+            assert peak / 2 ** 30 < 12.9 / world + 10.0, "per-rank device memory of the 12-layer proof: %.2f GB" % (peak / 2 ** 30)
         assert tm["n_committed"] == want["n_committed"]
         assert state.hex() == want["state"], "final transcript state differs from the one-GPU proof"
         assert hashlib.sha256(proof).hexdigest() == want["proof_sha256"], "proof bytes differ from the one-GPU proof"
