@@ -538,8 +538,11 @@ struct OneHotRow : atlas_instance {
 // indices of the node witnesses (nonzero index = (lookup >> shift) & (K - 1)): no host rows, no uploads.
 // Rows of fewer rounds start later (front-loaded batching, sumcheck.rs:30-184): row r takes part in global rounds
 // [max_rounds - rounds(r), max_rounds).
+// H = F[idx] (T entries of K distinct values) is never materialised: the row's first cycle round folds and binds THROUGH the index row (4 bytes an
+// entry instead of 32, the F table in cache) and the bind writes the first H there is, T / 2 entries — half the pool's vectors (9 -> 4.5 GB for the
+// GPT-2-shaped reduction), no gather launch, and the round that moves the most bytes moves an eighth of them.
 struct PoolRowDev {
-    Fr* H; const int32_t* idx; const Fr* aux;        // aux: fold: unused; gather: the row's F table (K Fr)
+    Fr* H; const int32_t* idx; const Fr* aux;        // idx / aux: set in a row's FIRST cycle round only: its index row and its F table (K Fr)
     const Fr *e_out, *e_in;
     uint32_t half, in_bits, slot, T;
 };
@@ -588,10 +591,6 @@ __global__ __launch_bounds__(OP_THREADS) void k_pool_hist(const int32_t* __restr
         out[r * 16 * 8 + i] = s;
     }
 }
-__global__ __launch_bounds__(OP_THREADS) void k_pool_gather(const PoolRowDev* __restrict__ rows) {
-    const PoolRowDev R = rows[blockIdx.y];
-    for (size_t j = (size_t)blockIdx.x * OP_THREADS + threadIdx.x; j < R.T; j += (size_t)gridDim.x * OP_THREADS) fe_store(R.H + j, fe_load(R.aux + R.idx[j]));
-}
 __global__ __launch_bounds__(OP_THREADS) void k_pool_fold(const PoolRowDev* __restrict__ rows, Fr* __restrict__ partials /* [rows][POOL_GX] */) {
     const PoolRowDev R = rows[blockIdx.y];
     Fr acc[1];
@@ -599,7 +598,8 @@ __global__ __launch_bounds__(OP_THREADS) void k_pool_fold(const PoolRowDev* __re
     const size_t mask = ((size_t)1 << R.in_bits) - 1;
     for (size_t j = (size_t)blockIdx.x * OP_THREADS + threadIdx.x; j < R.half; j += (size_t)gridDim.x * OP_THREADS) {
         const Fr w = fr_mul(fe_load(R.e_out + (j >> R.in_bits)), fe_load(R.e_in + (j & mask)));
-        acc[0] = fr_add(acc[0], fr_mul(w, fe_load(R.H + j)));
+        const Fr h = R.idx ? fe_load(R.aux + R.idx[j]) : fe_load(R.H + j);      // a row's FIRST cycle round reads H = F[idx] through its index row (below)
+        acc[0] = fr_add(acc[0], fr_mul(w, h));
     }
     block_reduce_store<1>(acc, partials + (size_t)R.slot * gridDim.x);
 }
@@ -611,8 +611,11 @@ __global__ __launch_bounds__(64) void k_pool_reduce(const Fr* __restrict__ parti
 }
 __global__ __launch_bounds__(OP_THREADS) void k_pool_bind(const PoolRowDev* __restrict__ rows, Fr r, int r_hi_only) {
     const PoolRowDev R = rows[blockIdx.y];
-    for (size_t i = (size_t)blockIdx.x * OP_THREADS + threadIdx.x; i < R.half; i += (size_t)gridDim.x * OP_THREADS)
-        fe_store(R.H + i, bind_pair(fe_load(R.H + i), fe_load(R.H + i + R.half), r, r_hi_only != 0));
+    for (size_t i = (size_t)blockIdx.x * OP_THREADS + threadIdx.x; i < R.half; i += (size_t)gridDim.x * OP_THREADS) {
+        const Fr a = R.idx ? fe_load(R.aux + R.idx[i]) : fe_load(R.H + i);
+        const Fr b = R.idx ? fe_load(R.aux + R.idx[i + R.half]) : fe_load(R.H + i + R.half);
+        fe_store(R.H + i, bind_pair(a, b, r, r_hi_only != 0));
+    }
 }
 __global__ __launch_bounds__(OP_THREADS) void k_pool_heads(const Fr* __restrict__ H, const uint64_t* __restrict__ off, uint32_t n, Fr* __restrict__ out) {
     for (uint32_t r = blockIdx.x * OP_THREADS + threadIdx.x; r < n; r += gridDim.x * OP_THREADS) fe_store(out + r, fe_load(H + off[r]));
@@ -687,14 +690,14 @@ __global__ __launch_bounds__(256) void k_pool_eq_full(const PoolEqJob* __restric
 struct OneHotPool {
     size_t log_K = 0, K = 0, max_rounds = 0, refs = 0;
     struct Group { size_t log_T = 0, T = 0, off = 0; H::GseStateH st; Fr *d_ein = nullptr, *d_eout = nullptr; std::vector<size_t> rows; H::Fr inv_eq1; size_t inv_round = (size_t)-1; };
-    struct Row { size_t group = 0; uint64_t off = 0; std::vector<H::Fr> B, F, G; H::Fr eqa_inv, q0, fin; bool gathered = false; };
+    struct Row { size_t group = 0, fslot = 0; uint64_t off = 0; std::vector<H::Fr> B, F, G; H::Fr eqa_inv, q0, fin; bool gathered = false; };      // off: into d_idx (T a row); H lives at off / 2
     std::vector<Group> groups;
     std::vector<Row> rows;
     // device: the rows' index vectors and H vectors back to back, the groups' split-eq tables, scratch
     int32_t* d_idx = nullptr;
     Fr *d_H = nullptr, *d_tabs = nullptr, *d_part = nullptr, *d_q0 = nullptr, *d_F = nullptr;
-    uint64_t* d_off = nullptr;
-    PoolRowDev *d_desc = nullptr, *h_desc = nullptr;       // h_desc: pinned staging, three regions of rows.size() descriptors (fold, bind, gather)
+    uint64_t *d_off = nullptr, *d_hoff = nullptr;          // the rows' offsets into d_idx, and into d_H (half of them)
+    PoolRowDev *d_desc = nullptr, *h_desc = nullptr;       // h_desc: pinned staging, three regions of rows.size() descriptors (fold, bind, spare)
     Fr* h_q0 = nullptr;                                     // pinned
     // global rounds already folded / bound.  Written LAST by fold_all / bind_all (under rt().mu): a row that reads the current round here without
     // the lock (worker threads of a large batch, host_parallel) sees everything those calls wrote
@@ -704,7 +707,7 @@ struct OneHotPool {
     static bool pool_trace() { static const bool on = getenv("ATLAS_TRACE") != nullptr; return on; }
     ~OneHotPool() {
         if (pool_trace()) fprintf(stderr, "[atlas trace] onehot pool (%zu rows, %zu groups): gather %.3f ms, fold + reduce + copy %.3f ms, bind %.3f ms\n", rows.size(), groups.size(), t_gather, t_fold, t_bind);
-        for (void* p : {(void*)d_idx, (void*)d_H, (void*)d_tabs, (void*)d_part, (void*)d_q0, (void*)d_F, (void*)d_off, (void*)d_desc}) if (p) hipFree(p);
+        for (void* p : {(void*)d_idx, (void*)d_H, (void*)d_tabs, (void*)d_part, (void*)d_q0, (void*)d_F, (void*)d_off, (void*)d_hoff, (void*)d_desc}) if (p) hipFree(p);
         if (h_desc) (void)hipHostFree(h_desc);
         if (h_q0) (void)hipHostFree(h_q0);
     }
@@ -719,19 +722,18 @@ struct OneHotPool {
         E.in_bits = (uint32_t)G.st.out_top;
         return E;
     }
-    // the caller holds rt().mu.  H = F[idx] for the rows whose address phase ended in the round before R (their ingests have all run)
+    // the caller holds rt().mu.  The F tables of the rows whose address phase ended in the round before R (their ingests have all run) go to the device:
+    // the round's fold and bind read H = F[idx] through them (PoolRowDev)
     int gather_pending(size_t R) {
         std::vector<size_t> todo;
         for (auto& G : groups) if (cycle_of(G, R) == 0) for (size_t r : G.rows) if (!rows[r].gathered) todo.push_back(r);
         if (todo.empty()) return ATLAS_OK;
         std::vector<H::Fr> Fh(todo.size() * K), b0(todo.size());
-        PoolRowDev* hd = h_desc + 2 * rows.size();
         for (size_t q = 0; q < todo.size(); q++) {
             Row& Rw = rows[todo[q]];
-            const Group& G = groups[Rw.group];
             std::memcpy(&Fh[q * K], Rw.F.data(), K * sizeof(H::Fr));
             b0[q] = Rw.B[0];
-            hd[q] = PoolRowDev{d_H + Rw.off, d_idx + Rw.off, d_F + q * K, nullptr, nullptr, 0, 0, 0, (uint32_t)G.T};
+            Rw.fslot = q;                                                // the round's fold and bind read d_F + q K through the row's indices
             Rw.gathered = true; Rw.G.clear();
         }
         {   // eq(r_address, rho)^-1 of every row at once (Montgomery's trick: one inversion)
@@ -741,12 +743,8 @@ struct OneHotPool {
             H::Fr inv = H::inv(acc);
             for (size_t q = todo.size(); q-- > 0;) { rows[todo[q]].eqa_inv = H::mul(inv, pre[q]); inv = H::mul(inv, b0[q]); }
         }
-        size_t maxT = 0;
-        for (size_t r : todo) maxT = groups[rows[r].group].T > maxT ? groups[rows[r].group].T : maxT;
-        HIP_TRY(hipMemcpyAsync(d_F, Fh.data(), Fh.size() * sizeof(Fr), hipMemcpyHostToDevice, rt().stream));
-        HIP_TRY(hipMemcpyAsync(d_desc + 2 * rows.size(), hd, todo.size() * sizeof(PoolRowDev), hipMemcpyHostToDevice, rt().stream));
+        HIP_TRY(hipMemcpyAsync(d_F, Fh.data(), Fh.size() * sizeof(Fr), hipMemcpyHostToDevice, rt().stream));      // (behind the previous round's bind, the last reader of d_F)
         HIP_TRY(hipStreamSynchronize(rt().stream));                 // Fh leaves scope (pageable source)
-        k_pool_gather<<<dim3(grid_for(maxT, POOL_GX), (unsigned)todo.size()), OP_THREADS, 0, rt().stream>>>(d_desc + 2 * rows.size());
         return ATLAS_OK;
     }
     int fold_all(size_t R) {
@@ -763,7 +761,11 @@ struct OneHotPool {
             if (c < 0) continue;
             const size_t half = G.T >> (c + 1);
             const SplitEqView E = view(G);
-            for (size_t r : G.rows) { h_desc[n] = PoolRowDev{d_H + rows[r].off, nullptr, nullptr, E.e_out, E.e_in, (uint32_t)half, E.in_bits, (uint32_t)n, (uint32_t)G.T}; n++; }
+            for (size_t r : G.rows) {
+                const Row& Rw = rows[r];
+                h_desc[n] = PoolRowDev{d_H + Rw.off / 2, c == 0 ? d_idx + Rw.off : nullptr, c == 0 ? d_F + Rw.fslot * K : nullptr, E.e_out, E.e_in, (uint32_t)half, E.in_bits, (uint32_t)n, (uint32_t)G.T};
+                n++;
+            }
             max_half = half > max_half ? half : max_half;
         }
         if (n == 0) { folded.store(R, std::memory_order_release); return ATLAS_OK; }
@@ -808,7 +810,7 @@ struct OneHotPool {
             const long c = cycle_of(G, R);
             if (c < 0) continue;
             const size_t half = G.T >> (c + 1);
-            for (size_t r : G.rows) hd[n++] = PoolRowDev{d_H + rows[r].off, nullptr, nullptr, nullptr, nullptr, (uint32_t)half, 0, 0, (uint32_t)G.T};
+            for (size_t r : G.rows) { const Row& Rw = rows[r]; hd[n++] = PoolRowDev{d_H + Rw.off / 2, c == 0 ? d_idx + Rw.off : nullptr, c == 0 ? d_F + Rw.fslot * K : nullptr, nullptr, nullptr, (uint32_t)half, 0, 0, (uint32_t)G.T}; }
             max_half = half > max_half ? half : max_half;
             G.st.bind(rf);
         }
@@ -822,7 +824,7 @@ struct OneHotPool {
     int fetch_finals() {
         if (have_finals) return ATLAS_OK;
         const size_t n = rows.size();
-        k_pool_heads<<<grid_for(n, 64), OP_THREADS, 0, rt().stream>>>(d_H, d_off, (uint32_t)n, d_q0);
+        k_pool_heads<<<grid_for(n, 64), OP_THREADS, 0, rt().stream>>>(d_H, d_hoff, (uint32_t)n, d_q0);
         std::vector<H::Fr> f(n);
         HIP_TRY(hipMemcpyAsync(f.data(), d_q0, n * sizeof(Fr), hipMemcpyDeviceToHost, rt().stream));
         HIP_TRY(hipStreamSynchronize(rt().stream));
@@ -1232,7 +1234,8 @@ int atlas_rt_onehot_pool_new(const atlas_rt_pool_row* in, size_t n, size_t log_K
     size_t E_total = 0;
     for (auto& G : P->groups) E_total += G.T;
     HIP_TRY(hipMalloc(&P->d_idx, total * sizeof(int32_t)));
-    HIP_TRY(hipMalloc(&P->d_H, total * sizeof(Fr)));
+    HIP_TRY(hipMalloc(&P->d_H, (total / 2 + 1) * sizeof(Fr)));            // (the first H of a row is the bound one: T / 2 entries at off / 2; every T is a power of two >= 2)
+    HIP_TRY(hipMalloc(&P->d_hoff, n * sizeof(uint64_t)));
     HIP_TRY(hipMalloc(&P->d_tabs, tab_total * sizeof(Fr)));
     HIP_TRY(hipMalloc(&P->d_part, n * POOL_GX * sizeof(Fr)));
     HIP_TRY(hipMalloc(&P->d_q0, n * sizeof(Fr)));
@@ -1273,6 +1276,9 @@ int atlas_rt_onehot_pool_new(const atlas_rt_pool_row* in, size_t n, size_t log_K
     HIP_TRY(hipMemcpyAsync(d_shift, sh.data(), n * 4, hipMemcpyHostToDevice, rt().stream));
     HIP_TRY(hipMemcpyAsync(d_Ts, Ts.data(), n * 4, hipMemcpyHostToDevice, rt().stream));
     HIP_TRY(hipMemcpyAsync(P->d_off, off.data(), n * 8, hipMemcpyHostToDevice, rt().stream));
+    std::vector<uint64_t> hoff(n);
+    for (size_t i = 0; i < n; i++) hoff[i] = off[i] / 2;
+    HIP_TRY(hipMemcpyAsync(P->d_hoff, hoff.data(), n * 8, hipMemcpyHostToDevice, rt().stream));
     HIP_TRY(hipMemcpyAsync(d_Eptr, Eptr.data(), n * sizeof(void*), hipMemcpyHostToDevice, rt().stream));
     k_pool_chunk_rows<<<dim3(grid_for(maxT, POOL_GX), (unsigned)n), OP_THREADS, 0, rt().stream>>>(d_lk, d_shift, P->d_off, d_Ts, (uint32_t)(P->K - 1), P->d_idx);
     // the split-eq suffix tables (GseDevH::init) and D.merge() before any bind = EqPolynomial::evals(r_cycle) for the histogram: all groups at once
