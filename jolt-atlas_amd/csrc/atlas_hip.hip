@@ -31,6 +31,7 @@ namespace atlas_rt {
 Runtime g_default;
 thread_local Runtime* g_cur = nullptr;
 int g_thread_runtimes = 0;
+int g_device_runtimes[64] = {0};
 thread_local hipStream_t tl_lane_stream = nullptr;
 thread_local std::string t_err;       // atlas_last_error is per calling thread (commit is called from Rayon workers)
 int fail(int code, const char* what, hipError_t e) {
@@ -142,6 +143,7 @@ int atlas_init(int device_ordinal) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (sizeof(Fr) << SC_TAIL_LOG)));
     rt().device = device_ordinal;
     rt().ready = true;
+    if (device_ordinal >= 0 && device_ordinal < 64) __atomic_fetch_add(&atlas_rt::g_device_runtimes[device_ordinal], 1, __ATOMIC_SEQ_CST);
     return ATLAS_OK;
 }
 
@@ -157,6 +159,7 @@ int atlas_shutdown(void) {
     rt().chan.release();
     atlas_rt::dev_pool().release();
     hipStreamDestroy(rt().stream);
+    if (rt().device >= 0 && rt().device < 64) __atomic_fetch_sub(&atlas_rt::g_device_runtimes[rt().device], 1, __ATOMIC_SEQ_CST);
     rt().ready = false; rt().stream = nullptr; rt().lib_stream = nullptr; rt().d_partials = nullptr; rt().d_ctx = nullptr; rt().d_proof = nullptr;
     rt().d_chal = nullptr; rt().d_finals = nullptr; rt().h_pinned = nullptr;
     return ATLAS_OK;

@@ -153,7 +153,11 @@ struct Pipeline {
         tag0 = C.take_tags((max_rounds + 2) * (lanes.size() + 1));
         slot0 = C.take_slots(max_rounds);
         static const bool no_side = getenv("ATLAS_NO_LANE_STREAMS") != nullptr;
-        side = lanes.size() > 1 && !no_side && !rt().no_lane_streams;
+        // (several runtimes of ONE process on one device — threads that share a GPU, a test configuration — share the process's few hardware queues
+        // among twice the streams: the lanes stay on the library stream there, as they do for three and more ranks' processes on one device;
+        // the two-thread proof of tests/test_gpu_sharded.py stalled once in ~15 runs with lane streams)
+        const bool crowded = rt().device >= 0 && rt().device < 64 && __atomic_load_n(&atlas_rt::g_device_runtimes[rt().device], __ATOMIC_SEQ_CST) > 1;
+        side = lanes.size() > 1 && !no_side && !rt().no_lane_streams && !crowded;
         if (side) {
             hipStream_t* st = side_streams();
             if (!st[0])

@@ -1789,7 +1789,8 @@ extern "C" int atlas_prove_graph_sharded(atlas_graph_t G, atlas_srs_t srs, atlas
     // graph at world 4 on one GPU stalled until the channel's timeout with lane streams and takes 15 s without.  The ranks exchange their
     // devices' PCI addresses; a rank whose device serves three or more of them keeps the lanes of its batches on the library stream for the call.
     bool lanes_were = rt().no_lane_streams, shared_checked = false;
-    if (grp->world > 2 && rt().ready) {
+    const bool shared_was = rt().device_shared;
+    if (grp->world > 1 && rt().ready) {
         int dom = 0, bus = 0, dev = 0;
         (void)hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, rt().device);
         (void)hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, rt().device);
@@ -1805,9 +1806,10 @@ extern "C" int atlas_prove_graph_sharded(atlas_graph_t G, atlas_srs_t srs, atlas
         for (int r = 0; r < grp->world; r++) sharing += all[2 * r] == mine[0] && all[2 * r + 1] == mine[1];
         shared_checked = true;
         if (sharing >= 3) rt().no_lane_streams = true;
+        if (sharing >= 2) rt().device_shared = true;
     }
     int rc = prove_graph_impl(G, srs, grp, inputs, n_inputs, proof, cap, proof_len, final_transcript, timing);
-    if (shared_checked) rt().no_lane_streams = lanes_were;
+    if (shared_checked) { rt().no_lane_streams = lanes_were; rt().device_shared = shared_was; }
     if (grp->world > 1 && rt().ready) {
         std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
         rt().chan.host_wait_s = host_wait;

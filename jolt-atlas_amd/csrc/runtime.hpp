@@ -47,6 +47,7 @@ struct Runtime {
     uint64_t* d_chal = nullptr;        // up to 64 rounds * 2
     atlas::Fe* d_finals = nullptr;     // 3 (+ scratch for reduced evals)
     void* h_pinned = nullptr;          // pinned staging for small D2H/H2D
+    bool device_shared = false;        // other ranks' processes run on THIS device for the length of a sharded call (graph_prove.hip): no cross-stream event waits (spliteq.hip)
     bool no_lane_streams = false;      // the lanes of a pipelined batch stay on the library stream (set while several ranks' processes share THIS device: graph_prove.hip)
     // atlas_rt_evaluate_with_eq on a stream of its own (spliteq.hip): the node's first wait is for ONE evaluation, not for everything NodePre put on the
     // library stream behind the eq table.  eval_event: recorded right after the eq table whose device pointer is eval_event_eq.
@@ -67,6 +68,7 @@ struct Runtime {
 // runtime is also what the host-thread pool's workers of THAT thread see (host_threads.hpp hands the pointer over with every job).
 extern Runtime g_default;
 extern thread_local Runtime* g_cur;
+extern int g_device_runtimes[64];      // runtimes of THIS process that are up on device d: more than one (threads that share a GPU: tests) rules out the same
 extern int g_thread_runtimes;          // how many threads own a runtime right now: while none does, rt() is one load of a global and no TLS access
                                        // (a thread-local read in a shared library is a call: ~1 M of them per GPT-2-shaped proof were +0.8 %)
 inline Runtime& rt() {

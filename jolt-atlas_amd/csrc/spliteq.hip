@@ -248,7 +248,11 @@ int atlas_rt_eval_event_record(atlas_poly_t eq_full) {
     static const bool off = getenv("ATLAS_NO_SIDE_EVAL") != nullptr;
     if (off || !eq_full) return ATLAS_OK;
     std::lock_guard<atlas_rt::Mutex> lk(rt().mu);
-    if (rt().stream != rt().lib_stream || rt().no_lane_streams) return ATLAS_OK;          // (inside a lane, or ranks sharing the device: stay on one stream)
+    // Not while ANOTHER runtime drives this device (ranks of a sharded proof that share a GPU, threads of one process on one GPU: the test boxes): the
+    // evaluation's stream waits for an EVENT of the library stream, and with the other runtime's polling launches in the same hardware queues that is a
+    // cycle — its eq table behind their polling launch, their next launch behind the evaluation's barrier (seen: 1 run in 6 of the two-thread proof).
+    if (rt().stream != rt().lib_stream || rt().no_lane_streams || rt().device_shared) return ATLAS_OK;
+    if (rt().device >= 0 && rt().device < 64 && __atomic_load_n(&atlas_rt::g_device_runtimes[rt().device], __ATOMIC_SEQ_CST) > 1) return ATLAS_OK;
     if (!rt().eval_stream) {
         HIP_TRY(hipStreamCreateWithFlags(&rt().eval_stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&rt().eval_event, hipEventDisableTiming));
